@@ -1,0 +1,66 @@
+# Build recipe for the MI355X hot path of GSLAM.  gfx950 only.  `make` = everything buildable here.
+#   lib      gslam_amd/lib/libgslam_hip.so        C-ABI + HIP kernels (the product)
+#   oracle   oracle/liboracle.so                  CPU restatement (test infrastructure)
+#   ref      oracle/_ref/libgslam_ref*.so         the reference's own code, compiled from /root/reference
+#   plugins  gslam_amd/lib/libgslam_optimizer.so, libgslam_featuredetector.so + build/plugin_host
+#            (need the GSLAM headers at BUILD time only; the .so files travel to the GPU box)
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+ARCH      ?= gfx950
+REF       ?= /root/reference
+HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-unused-value -Iinclude
+CFLAGS    := -O3 -fPIC -std=c11 -ffp-contract=off -fopenmp -Wall -Wno-unknown-pragmas -Iinclude
+# the reference's own flags (CMakeLists.txt:9-11) for the reference shim
+REFFLAGS  := -O3 -DNDEBUG -std=c++11 -fPIC -fopenmp -w -I$(REF)
+
+CSRC      := $(wildcard gslam_amd/csrc/*.hip)
+COBJ      := $(patsubst gslam_amd/csrc/%.hip,build/obj/%.o,$(CSRC))
+OSRC      := $(wildcard oracle/*.c)
+LIBDIR    := gslam_amd/lib
+
+HAVE_REF  := $(wildcard $(REF)/GSLAM/core/GSLAM.h)
+
+.PHONY: all lib oracle ref plugins clean
+ifeq ($(HAVE_REF),)
+all: lib oracle
+else
+all: lib oracle ref plugins
+endif
+
+lib: $(LIBDIR)/libgslam_hip.so
+oracle: oracle/liboracle.so
+ref: oracle/_ref/libgslam_ref.so oracle/_ref/libgslam_ref_popcnt.so
+plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so build/plugin_host
+
+build/obj/%.o: gslam_amd/csrc/%.hip gslam_amd/csrc/common.h include/gslam_hip.h $(wildcard include/*.h gslam_amd/csrc/*.h)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libgslam_hip.so: $(COBJ)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(COBJ)
+
+oracle/liboracle.so: $(OSRC) $(wildcard include/*.h oracle/*.h)
+	gcc $(CFLAGS) -shared -o $@ $(OSRC) -lm
+
+oracle/_ref/libgslam_ref.so: oracle/ref_shim.cpp
+	@mkdir -p oracle/_ref
+	g++ $(REFFLAGS) -shared -o $@ $<
+
+oracle/_ref/libgslam_ref_popcnt.so: oracle/ref_shim.cpp
+	@mkdir -p oracle/_ref
+	g++ $(REFFLAGS) -mpopcnt -shared -o $@ $<
+
+PLUGFLAGS := -O2 -std=c++11 -fPIC -w -I$(REF) -Iinclude -Igslam_amd/plugin
+$(LIBDIR)/libgslam_optimizer.so: gslam_amd/plugin/optimizer_plugin.cpp include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
+	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
+
+$(LIBDIR)/libgslam_featuredetector.so: gslam_amd/plugin/featuredetector_plugin.cpp gslam_amd/plugin/FeatureDetector.h include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
+	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
+
+build/plugin_host: gslam_amd/plugin/plugin_host.cpp gslam_amd/plugin/FeatureDetector.h
+	@mkdir -p build
+	g++ $(PLUGFLAGS) -o $@ $< -lpthread -ldl
+
+clean:
+	rm -rf build $(LIBDIR)/*.so oracle/liboracle.so oracle/_ref

@@ -1,0 +1,275 @@
+// Brute-force 256-bit Hamming matcher for gfx950.
+//
+// Semantics (bit-exact with oracle/bf_oracle.c):
+//   distance  = GSLAM/core/Vocabulary.h:485-491 (hamming32: XOR + popcount over 4 x u64)
+//   selection = GSLAM/core/Vocabulary.h:1712-1725 (strict '<' => lowest train index wins ties)
+//
+// Mapping to CDNA4: this is popcount work, bound by VALU issue (8 v_xor_b32 + 8 accumulating
+// v_bcnt_u32_b32 per pair), not by HBM and not MFMA-shaped.  One wave owns 64*QPT query rows
+// held in VGPRs for the whole kernel; the train descriptor is wave-uniform, so it is fetched
+// with scalar loads (s_load_dwordx8 = one descriptor) and XOR-ed straight from SGPRs - no LDS,
+// no barrier.  Best/second-best are tracked on a packed key (dist << 16 | train_index) so
+// the first-minimum tie rule falls out of an unsigned min: v_lshl_or + v_med3_u32 + v_min_u32.
+#include "common.h"
+
+namespace {
+
+constexpr int kQPT = 2;            // query rows per lane
+constexpr int kWaveQueries = 64 * kQPT;
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+struct QueryRegs {
+  uint32_t w[8];
+};
+
+// key = dist << 16 | train index (train index is wave-uniform -> SGPR operand).
+__device__ __forceinline__ uint32_t make_key(uint32_t d, uint32_t j) {
+  uint32_t r;
+  asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(d), "s"(j));
+  return r;
+}
+
+__device__ __forceinline__ uint32_t dist256(const QueryRegs& q, const uint32_t (&t)[8]) {
+  // v_bcnt_u32_b32 D = popcount(S0) + S1: keep the accumulate form (the compiler otherwise
+  // splits the sum into 8 independent bcnt + 3 v_add3_u32).
+  uint32_t d;
+  {
+    uint32_t x = q.w[0] ^ t[0];
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+  }
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    uint32_t x = q.w[k] ^ t[k];
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+  }
+  return d;
+}
+
+// q_words / t_words: descriptor matrices as dwords (8 per row).  One wave per 64*QPT queries.
+__device__ __forceinline__ void bf_wave(const uint32_t* __restrict__ q_words, int nq,
+                                        const uint32_t* __restrict__ t_words, int nt, int out_rows,
+                                        int32_t* __restrict__ idx1, uint16_t* __restrict__ d1,
+                                        uint16_t* __restrict__ d2) {
+  const int lane = threadIdx.x;
+  const int q0 = blockIdx.x * kWaveQueries;
+  QueryRegs q[kQPT];
+#pragma unroll
+  for (int r = 0; r < kQPT; ++r) {
+    int qi = q0 + r * 64 + lane;
+    int qc = qi < nq ? qi : (nq > 0 ? nq - 1 : 0);
+    if (nq > 0) {
+      const uint4* p = reinterpret_cast<const uint4*>(q_words + (size_t)qc * 8);
+      uint4 a = p[0], b = p[1];
+      q[r].w[0] = a.x; q[r].w[1] = a.y; q[r].w[2] = a.z; q[r].w[3] = a.w;
+      q[r].w[4] = b.x; q[r].w[5] = b.y; q[r].w[6] = b.z; q[r].w[7] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[r].w[k] = 0;
+    }
+  }
+  uint32_t best[kQPT], second[kQPT];
+#pragma unroll
+  for (int r = 0; r < kQPT; ++r) best[r] = second[r] = 0xFFFFFFFFu;
+
+  int j = 0;
+  // Main loop: 4 train descriptors (32 SGPRs) per trip; t_words + j*8 is wave-uniform.
+  for (; j + 4 <= nt; j += 4) {
+    uint32_t t[4][8];
+    const uint32_t* tp = t_words + (size_t)j * 8;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[u][k] = tp[u * 8 + k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int r = 0; r < kQPT; ++r) {
+        uint32_t key = make_key(dist256(q[r], t[u]), (uint32_t)(j + u));
+        second[r] = umed3(key, best[r], second[r]);
+        best[r] = min(best[r], key);
+      }
+    }
+  }
+  for (; j < nt; ++j) {
+    uint32_t t[8];
+    const uint32_t* tp = t_words + (size_t)j * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = tp[k];
+#pragma unroll
+    for (int r = 0; r < kQPT; ++r) {
+      uint32_t key = make_key(dist256(q[r], t), (uint32_t)j);
+      second[r] = umed3(key, best[r], second[r]);
+      best[r] = min(best[r], key);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kQPT; ++r) {
+    int qi = q0 + r * 64 + lane;
+    if (qi < out_rows) {
+      bool valid = qi < nq;
+      uint32_t b = valid ? best[r] : 0xFFFFFFFFu, s = valid ? second[r] : 0xFFFFFFFFu;
+      idx1[qi] = (b == 0xFFFFFFFFu) ? -1 : (int32_t)(b & 0xFFFFu);
+      d1[qi] = (uint16_t)(b >> 16);
+      d2[qi] = (uint16_t)(s >> 16);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void bf_match_single_kernel(const uint32_t* __restrict__ q, int nq,
+                                                             const uint32_t* __restrict__ t, int nt,
+                                                             int32_t* __restrict__ idx1, uint16_t* __restrict__ d1,
+                                                             uint16_t* __restrict__ d2) {
+  bf_wave(q, nq, t, nt, nq, idx1, d1, d2);
+}
+
+__global__ __launch_bounds__(64) void bf_match_pairs_kernel(const uint32_t* __restrict__ desc,
+                                                            const int32_t* __restrict__ counts, int cap,
+                                                            const int32_t* __restrict__ pair_q,
+                                                            const int32_t* __restrict__ pair_t,
+                                                            int32_t* __restrict__ idx1, uint16_t* __restrict__ d1,
+                                                            uint16_t* __restrict__ d2) {
+  const int p = blockIdx.y;
+  const int fq = pair_q[p], ft = pair_t[p];
+  int nq = counts[fq], nt = counts[ft];
+  nq = nq < cap ? nq : cap;
+  nt = nt < cap ? nt : cap;
+  const size_t o = (size_t)p * cap;
+  bf_wave(desc + (size_t)fq * cap * 8, nq, desc + (size_t)ft * cap * 8, nt, cap, idx1 + o, d1 + o, d2 + o);
+}
+
+__global__ void match_mask_kernel(const int32_t* __restrict__ idx1, const uint16_t* __restrict__ d1,
+                                  const uint16_t* __restrict__ d2, int nq, const int32_t* __restrict__ back, int nt,
+                                  int max_dist, int ratio_num, int ratio_den, int cross_check,
+                                  uint8_t* __restrict__ keep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  int j = idx1[i];
+  bool ok = j >= 0 && (int)d1[i] <= max_dist;
+  if (ok && ratio_num > 0) ok = (int)d1[i] * ratio_den < ratio_num * (int)d2[i];
+  if (ok && cross_check) ok = j < nt && back[j] == i;
+  keep[i] = ok ? 1 : 0;
+}
+
+// VALU ceiling probe: 16 dependent-free xor+bcnt chains per lane, no memory traffic.
+__global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t* out, int iters, uint32_t seed) {
+  uint32_t q[8], t[8], acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    q[k] = seed * (k + 1) + threadIdx.x;
+    t[k] = seed ^ (0x9E3779B9u * (k + 3));
+  }
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint32_t x = q[k] ^ t[k];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[u]) : "v"(x));
+      }
+      // perturb the uniform operand so the compiler cannot hoist the chain
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+s"(t[k]));
+    }
+  }
+  if ((acc[0] + acc[1] + acc[2] + acc[3]) == 0xFFFFFFFFu) out[0] = 1;
+}
+
+}  // namespace
+
+extern "C" gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
+                                     int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535);
+  if (nq == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, q_dev && idx1_dev && d1_dev && d2_dev && (nt == 0 || t_dev));
+  GH_CHECK_ARG(ctx, ((uintptr_t)q_dev & 15) == 0 && ((uintptr_t)t_dev & 3) == 0);
+  dim3 grid(gh_div_up(nq, kWaveQueries));
+  GH_LAUNCH(ctx, "bf_match", bf_match_single_kernel, grid, dim3(64), 0, (const uint32_t*)q_dev, nq,
+            (const uint32_t*)t_dev, nt, idx1_dev, d1_dev, d2_dev);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx1,
+                                      uint16_t* d1, uint16_t* d2) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535);
+  if (nq == 0) return GH_OK;
+  size_t qb = (size_t)nq * 32, tb = (size_t)nt * 32;
+  size_t off_t = (qb + 255) & ~(size_t)255;
+  size_t off_i = off_t + ((tb + 255) & ~(size_t)255);
+  size_t off_d1 = off_i + (((size_t)nq * 4 + 255) & ~(size_t)255);
+  size_t off_d2 = off_d1 + (((size_t)nq * 2 + 255) & ~(size_t)255);
+  size_t total = off_d2 + (size_t)nq * 2;
+  void* base = nullptr;
+  GH_TRY(gh_scratch(ctx, total, &base));
+  uint8_t* b = (uint8_t*)base;
+  GH_HIP(ctx, hipMemcpyAsync(b, q, qb, hipMemcpyHostToDevice, ctx->stream));
+  if (tb) GH_HIP(ctx, hipMemcpyAsync(b + off_t, t, tb, hipMemcpyHostToDevice, ctx->stream));
+  GH_TRY(gh_bf_match_dev(ctx, b, nq, b + off_t, nt, (int32_t*)(b + off_i), (uint16_t*)(b + off_d1),
+                         (uint16_t*)(b + off_d2)));
+  GH_HIP(ctx, hipMemcpyAsync(idx1, b + off_i, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d1, b + off_d1, (size_t)nq * 2, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d2, b + off_d2, (size_t)nq * 2, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                           const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                           int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, cap >= 0 && cap <= 65535 && npairs >= 0);
+  if (npairs == 0 || cap == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, desc_dev && counts_dev && pair_q_dev && pair_t_dev && idx1_dev && d1_dev && d2_dev);
+  GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 15) == 0);
+  const int qblocks = gh_div_up(cap, kWaveQueries);
+  // grid.y is limited to 65535: chunk the pair list.
+  for (int p0 = 0; p0 < npairs; p0 += 65535) {
+    int np = npairs - p0 < 65535 ? npairs - p0 : 65535;
+    dim3 grid(qblocks, np);
+    size_t o = (size_t)p0 * cap;
+    GH_LAUNCH(ctx, "bf_match_pairs", bf_match_pairs_kernel, grid, dim3(64), 0, (const uint32_t*)desc_dev, counts_dev,
+              cap, pair_q_dev + p0, pair_t_dev + p0, idx1_dev + o, d1_dev + o, d2_dev + o);
+  }
+  return GH_OK;
+}
+
+extern "C" gh_status gh_match_mask_dev(gh_ctx* ctx, const int32_t* idx1_dev, const uint16_t* d1_dev,
+                                       const uint16_t* d2_dev, int nq, const int32_t* back_idx1_dev, int nt,
+                                       int max_dist, int ratio_num, int ratio_den, int cross_check,
+                                       uint8_t* keep_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0);
+  if (nq == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, idx1_dev && d1_dev && d2_dev && keep_dev && (!cross_check || back_idx1_dev));
+  GH_LAUNCH(ctx, "match_mask", match_mask_kernel, dim3(gh_div_up(nq, 256)), dim3(256), 0, idx1_dev, d1_dev, d2_dev,
+            nq, back_idx1_dev, nt, max_dist, ratio_num, ratio_den, cross_check, keep_dev);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bf_valu_probe(gh_ctx* ctx, double* pairs_per_s) {
+  if (!ctx || !pairs_per_s) return GH_ERR_ARG;
+  void* out = nullptr;
+  GH_TRY(gh_scratch(ctx, 256, &out));
+  const int iters = 4096, blocks = 256 * 16;
+  hipEvent_t e0, e1;
+  GH_HIP(ctx, hipEventCreate(&e0));
+  GH_HIP(ctx, hipEventCreate(&e1));
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t*)out, 16, 12345u);
+  GH_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t*)out, iters, 12345u);
+  GH_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  GH_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  GH_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  double pairs = (double)blocks * 256.0 * iters * 4.0;
+  *pairs_per_s = pairs / (ms * 1e-3);
+  return GH_OK;
+}

@@ -1,0 +1,74 @@
+// Internal shared definitions for libgslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gslam_hip.h"
+
+struct gh_prof_pending {
+  int slot;
+  hipEvent_t start, stop;
+};
+
+struct gh_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // profiling
+  bool prof_on = false;
+  std::vector<gh_prof_entry> prof_entries;
+  std::vector<gh_prof_pending> prof_pending;
+  std::vector<hipEvent_t> event_pool;
+  // scratch owned by the context (grown on demand)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  std::mutex mu;
+  int cu_count = 0;
+};
+
+gh_status gh_set_error(gh_ctx* ctx, gh_status st, const char* fmt, ...);
+gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out);
+int gh_prof_begin(gh_ctx* ctx, const char* name);  // returns pending index or -1
+void gh_prof_end(gh_ctx* ctx, int pending);
+
+#define GH_HIP(ctx, expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return gh_set_error((ctx), GH_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                          hipGetErrorString(_e), __FILE__, __LINE__);                      \
+  } while (0)
+
+#define GH_CHECK_ARG(ctx, cond)                                                            \
+  do {                                                                                     \
+    if (!(cond))                                                                           \
+      return gh_set_error((ctx), GH_ERR_ARG, "argument check failed: %s (%s:%d)", #cond,  \
+                          __FILE__, __LINE__);                                             \
+  } while (0)
+
+#define GH_TRY(expr)                 \
+  do {                               \
+    gh_status _s = (expr);           \
+    if (_s != GH_OK) return _s;      \
+  } while (0)
+
+// Launch a kernel on the ctx stream, timed under `name` when profiling is on.
+#define GH_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
+  do {                                                                                     \
+    int _p = gh_prof_begin((ctx), (name));                                                 \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);            \
+    gh_prof_end((ctx), _p);                                                                \
+    hipError_t _e = hipGetLastError();                                                     \
+    if (_e != hipSuccess)                                                                  \
+      return gh_set_error((ctx), GH_ERR_HIP, "launch %s failed: %s", (name),               \
+                          hipGetErrorString(_e));                                          \
+  } while (0)
+
+static inline int gh_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,60 @@
+"""Host-side mirror of the matcher half of the FeatureDetector plugin interface
+(gslam_amd/plugin/FeatureDetector.h), for tests and bench.py.  torch tensors are only the device
+buffers; all compute is libgslam_hip.so.
+
+Reference anchors: GSLAM/core/Vocabulary.h:485-491 (distance), :1712-1725 (first-minimum rule),
+GSLAM/core/Map.h:252-258 (match list = vector<pair<int,int>>).
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BFMatcher:
+    def __init__(self, ctx: hip.Context):
+        self.ctx = ctx
+
+    def match(self, q: torch.Tensor, t: torch.Tensor):
+        """q: nq x 32 u8 (cuda), t: nt x 32 u8 (cuda) -> idx1 int32, d1 u16, d2 u16 (as int16 views)."""
+        assert q.is_cuda and q.dtype == torch.uint8 and q.is_contiguous()
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+        nq, nt = q.shape[0], t.shape[0]
+        idx1 = torch.empty(nq, dtype=torch.int32, device=q.device)
+        d1 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        d2 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        self.ctx.check(hip.lib.gh_bf_match_dev(self.ctx.h, _p(q), nq, _p(t), nt, _p(idx1), _p(d1), _p(d2)))
+        return idx1, d1, d2
+
+    def match_pairs(self, desc: torch.Tensor, counts: torch.Tensor, pair_q: torch.Tensor, pair_t: torch.Tensor,
+                    out=None):
+        """desc: F x cap x 32 u8; counts: F int32; pair_q/pair_t: P int32 -> (P x cap) idx1, d1, d2."""
+        F, cap = desc.shape[0], desc.shape[1]
+        P = pair_q.shape[0]
+        if out is None:
+            idx1 = torch.empty((P, cap), dtype=torch.int32, device=desc.device)
+            d1 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
+            d2 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
+        else:
+            idx1, d1, d2 = out
+        self.ctx.check(hip.lib.gh_bf_match_pairs_dev(self.ctx.h, _p(desc), _p(counts), cap, _p(pair_q), _p(pair_t),
+                                                     P, _p(idx1), _p(d1), _p(d2)))
+        return idx1, d1, d2
+
+    def mask(self, idx1, d1, d2, back_idx1=None, nt=0, max_dist=50, ratio_num=0, ratio_den=1, cross_check=False):
+        nq = idx1.shape[0]
+        keep = torch.empty(nq, dtype=torch.uint8, device=idx1.device)
+        self.ctx.check(hip.lib.gh_match_mask_dev(self.ctx.h, _p(idx1), _p(d1), _p(d2), nq, _p(back_idx1), int(nt),
+                                                 int(max_dist), int(ratio_num), int(ratio_den),
+                                                 1 if cross_check else 0, _p(keep)))
+        return keep
+
+    def valu_probe(self):
+        r = C.c_double()
+        self.ctx.check(hip.lib.gh_bf_valu_probe(self.ctx.h, C.byref(r)))
+        return r.value

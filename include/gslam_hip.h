@@ -1,0 +1,222 @@
+/*
+ * gslam_hip.h — plain-C ABI of libgslam_hip.so: the MI355X (gfx950) hot path of GSLAM.
+ *
+ * This is the drop-in boundary underneath the GSLAM plugin shims (libgslam_optimizer.so,
+ * libgslam_featuredetector.so).  Everything here is `extern "C"`, plain pointers + sizes,
+ * POD structs, int status codes, no exceptions, no torch / C++ types.
+ *
+ * Reference interfaces each entry point stands in for (paths relative to the GSLAM tree):
+ *   gh_bf_*      GSLAM/core/Vocabulary.h:485-491  (DistanceFactory::hamming32: 4 x u64 XOR + popcount)
+ *                GSLAM/core/Vocabulary.h:1712-1725 (first strict minimum wins ties -> lowest index)
+ *                GSLAM/core/Map.h:252-258         (FrameConnection::getMatches vector<pair<int,int>>)
+ *   gh_orb_*     GSLAM/core/Map.h:122-195         (KeyPoint, 28-byte POD == gh_keypoint)
+ *                GSLAM/core/Map.h:309-321         (MapFrame::setKeyPoints(kps, N x 32 8UC1 GImage))
+ *                GSLAM/core/GImage.h:160-190,378-382 (dense row-major u8 image / descriptor matrix)
+ *   gh_ba_*      GSLAM/core/Optimizer.h:102-182   (BundleGraph, BundleEdge, KeyFrameEstimzation,
+ *                                                  MapPointEstimation, OptimzeConfig)
+ *                GSLAM/core/Optimizer.h:229       (Optimizer::optimize(BundleGraph&))
+ *                GSLAM/core/Optimizer.h:202-207   (Optimizer::optimizePnP)
+ *                GSLAM/core/SE3.h:100-103,257-287 (inverse / exp used by the pose update)
+ *
+ * Conventions
+ *   - `*_dev` pointers are DEVICE (HBM) addresses; everything else is host memory.
+ *   - Every call enqueues on the context's stream; `gh_ctx_sync` waits for it.  Host-buffer
+ *     convenience entry points (`*_host`) synchronise before returning.
+ *   - One gh_ctx per host thread; a ctx may be created on one thread and used on another
+ *     (GSLAM constructs optimizers on one thread and calls them on Messenger workers).
+ *   - No CPU fallback exists: every entry point fails with GH_ERR_HIP if the device is absent.
+ */
+#ifndef GSLAM_HIP_H_
+#define GSLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gh_ctx gh_ctx;
+
+typedef enum gh_status {
+  GH_OK = 0,
+  GH_ERR_ARG = 1,      /* bad argument (null pointer, negative size, capacity overflow) */
+  GH_ERR_HIP = 2,      /* a HIP runtime call failed; see gh_last_error */
+  GH_ERR_NOMEM = 3,    /* device or host allocation failed */
+  GH_ERR_NUMERIC = 4,  /* BA: reduced system not positive definite even at maximum damping */
+  GH_ERR_UNSUPPORTED = 5
+} gh_status;
+
+/* ------------------------------------------------------------------ context ---------- */
+int gh_abi_version(void); /* bumps when a struct in this header changes layout */
+gh_status gh_ctx_create(int device, gh_ctx** out);
+void gh_ctx_destroy(gh_ctx* ctx);
+const char* gh_last_error(const gh_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. the caller's current stream).  NULL is the legacy
+ * default stream (what torch's default stream is); gh_ctx_use_own_stream restores the private one. */
+gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream);
+gh_status gh_ctx_use_own_stream(gh_ctx* ctx);
+void* gh_ctx_stream(gh_ctx* ctx);
+gh_status gh_ctx_sync(gh_ctx* ctx);
+/* Device facts as the runtime reports them. */
+gh_status gh_device_info(gh_ctx* ctx, int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, int name_cap);
+
+/* Raw device memory helpers, so C/C++ hosts need no HIP headers. */
+gh_status gh_dev_alloc(gh_ctx* ctx, size_t bytes, void** out_dev);
+gh_status gh_dev_free(gh_ctx* ctx, void* dev);
+gh_status gh_dev_upload(gh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+gh_status gh_dev_download(gh_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+gh_status gh_dev_memset(gh_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* Live per-kernel timing with HIP events on the context's stream (bench.py's roofline). */
+typedef struct gh_prof_entry {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} gh_prof_entry;
+gh_status gh_prof_enable(gh_ctx* ctx, int on); /* on=1 also clears accumulated entries */
+/* Resolves pending events (synchronises), writes up to cap entries, returns count in *n. */
+gh_status gh_prof_collect(gh_ctx* ctx, gh_prof_entry* out, int cap, int* n);
+
+/* ------------------------------------------------------------------ BF matcher ------- */
+/* 256-bit descriptors, 32 bytes each, dense rows (GImage N x 32, 8UC1).
+ * For query i:  idx1[i] = argmin_j hamming(q_i, t_j), first minimum (lowest j) on ties;
+ *               d1[i]   = that distance; d2[i] = min over j != idx1[i] (65535 if nt < 2).
+ * nt == 0  ->  idx1 = -1, d1 = d2 = 65535.   nt <= 65535. */
+gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
+                          int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
+gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                           int32_t* idx1, uint16_t* d1, uint16_t* d2);
+
+/* Batched over frame pairs.  desc_dev: F frames x cap rows x 32 B; counts_dev[f] <= cap valid rows.
+ * Pair p matches frame pair_q[p] (queries) against frame pair_t[p] (train).
+ * Outputs are P x cap (rows >= counts[pair_q[p]] get idx1 = -1, d = 65535). */
+gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
+
+/* Match masks (integer only):  keep[i] = d1 <= max_dist  &&  d1 * ratio_den < ratio_num * d2
+ *                                        && (!cross_check || back_idx1[idx1[i]] == i).
+ * ratio_num <= 0 disables the ratio test.  back_idx1_dev may be NULL when cross_check == 0. */
+gh_status gh_match_mask_dev(gh_ctx* ctx, const int32_t* idx1_dev, const uint16_t* d1_dev,
+                            const uint16_t* d2_dev, int nq, const int32_t* back_idx1_dev, int nt,
+                            int max_dist, int ratio_num, int ratio_den, int cross_check,
+                            uint8_t* keep_dev);
+
+/* VALU ceiling probe: runs a register-resident xor+popcount chain and reports the measured
+ * rate in 256-bit pair-equivalents per second (16 VALU ops each). */
+gh_status gh_bf_valu_probe(gh_ctx* ctx, double* pairs_per_s);
+
+/* ------------------------------------------------------------------ ORB front end ---- */
+/* Layout-identical to GSLAM::KeyPoint (GSLAM/core/Map.h:122-195, sizeof == 28). */
+typedef struct gh_keypoint {
+  float x, y;     /* level-0 pixel coordinates */
+  float size;     /* 31 * scale^octave */
+  float angle;    /* degrees, [0,360), multiple of 12 (30 orientation bins) */
+  float response; /* FAST corner score */
+  int32_t octave;
+  int32_t class_id; /* -1 */
+} gh_keypoint;
+
+typedef struct gh_orb_params {
+  int32_t n_features;   /* K: total keypoint quota per frame (default 1000) */
+  int32_t n_levels;     /* pyramid levels, 1..8 (default 8); scale factor fixed at 1.2 */
+  int32_t ini_th_fast;  /* default 20 */
+  int32_t min_th_fast;  /* default 7 */
+} gh_orb_params;
+void gh_orb_default_params(gh_orb_params* p);
+
+typedef struct gh_orb_plan gh_orb_plan; /* owns pyramid + workspace for (w, h, batch) */
+gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
+                             const gh_orb_params* params, gh_orb_plan** out);
+void gh_orb_plan_destroy(gh_orb_plan* plan);
+/* Level geometry of the plan, for tests. */
+gh_status gh_orb_plan_level(const gh_orb_plan* plan, int level, int* w, int* h, int* quota);
+size_t gh_orb_plan_device_bytes(const gh_orb_plan* plan);
+
+/* Extract from `batch` gray u8 frames resident in HBM (frame f at gray_dev + f*frame_stride,
+ * rows `row_stride` bytes apart).  Outputs, each with capacity K = params.n_features per frame:
+ *   kps_dev  batch x K gh_keypoint, desc_dev batch x K x 32 B, counts_dev batch int32. */
+gh_status gh_orb_extract_dev(gh_orb_plan* plan, const uint8_t* gray_dev, int batch, size_t frame_stride,
+                             int row_stride, gh_keypoint* kps_dev, uint8_t* desc_dev, int32_t* counts_dev);
+/* Single host frame convenience (uploads, extracts, downloads, synchronises). */
+gh_status gh_orb_extract_host(gh_orb_plan* plan, const uint8_t* gray, int row_stride, gh_keypoint* kps,
+                              uint8_t* desc, int32_t* count);
+/* Fixed-point luma (B*1868 + G*9617 + R*4899 + 8192) >> 14 for 3- or 4-channel BGR(A) input. */
+gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
+                             int src_row_stride, uint8_t* gray_dev, int dst_row_stride);
+/* Debug/test access: copy pyramid level `level` of batch slot `slot` to host (w*h bytes, dense). */
+gh_status gh_orb_debug_level(gh_orb_plan* plan, int slot, int level, uint8_t* out_host);
+
+/* Deterministic synthetic frames (integer procedural texture, seed = base_seed + frame index);
+ * bit-identical to oracle/synth.c.  Test/bench input generator, resident in HBM. */
+gh_status gh_synth_frames_dev(gh_ctx* ctx, uint8_t* gray_dev, int width, int height, int row_stride,
+                              size_t frame_stride, int first_frame, int n_frames, uint32_t base_seed);
+
+/* ------------------------------------------------------------------ bundle adjustment - */
+/* DOF bits follow GSLAM::KeyFrameEstimzationDOF (GSLAM/core/Optimizer.h:70-84). */
+#define GH_KF_X 1
+#define GH_KF_Y 2
+#define GH_KF_Z 4
+#define GH_KF_RX 8
+#define GH_KF_RY 16
+#define GH_KF_RZ 32
+#define GH_KF_SE3 63
+
+typedef struct gh_ba_problem {
+  int32_t n_cams, n_points, n_obs;
+  /* T_wc (camera -> world) per keyframe: 7 doubles [qx,qy,qz,qw,tx,ty,tz]  (in/out) */
+  double* cam_pose;
+  const int32_t* cam_dof; /* GH_KF_* bitmask per camera; 0 = fixed */
+  double* point_xyz;      /* 3 doubles per point, world frame  (in/out) */
+  const uint8_t* point_free; /* 1 = optimise, 0 = fixed; NULL = all free */
+  const int32_t* obs_cam;
+  const int32_t* obs_point;
+  const double* obs_xy;   /* 2 doubles per observation: normalised (x,y) on the z=1 plane */
+  const double* obs_info; /* 4 doubles (row-major 2x2) per observation or NULL = identity */
+} gh_ba_problem;
+
+typedef struct gh_ba_options {
+  double huber_delta;        /* OptimzeConfig::projectErrorHuberThreshold; <= 0 disables */
+  int32_t max_iterations;    /* OptimzeConfig::maxIterations */
+  double initial_radius;     /* 1e4 */
+  double function_tolerance; /* 1e-6 */
+  double gradient_tolerance; /* 1e-10 */
+  double min_relative_decrease; /* 1e-3 */
+  int32_t verbose;
+  int32_t deterministic;     /* 1: ordered segmented Schur accumulation; 0: f64 atomics */
+} gh_ba_options;
+void gh_ba_default_options(gh_ba_options* o);
+
+#define GH_BA_MAX_TRACE 512
+typedef struct gh_ba_summary {
+  int32_t iterations;      /* LM iterations executed (accepted + rejected) */
+  int32_t accepted;
+  int32_t termination;     /* 0 max_iterations, 1 function_tolerance, 2 gradient_tolerance, 3 failure */
+  double initial_cost, final_cost;
+  double solve_ms_total;   /* time inside the dense reduced-camera solve */
+  double total_ms;
+  int32_t trace_len;
+  double trace_cost[GH_BA_MAX_TRACE];   /* candidate cost evaluated at each iteration */
+  double trace_radius[GH_BA_MAX_TRACE]; /* trust-region radius used at each iteration */
+  uint8_t trace_accepted[GH_BA_MAX_TRACE];
+} gh_ba_summary;
+
+/* Host-struct entry point (what the Optimizer plugin calls): uploads, runs LM on the GPU,
+ * writes cam_pose / point_xyz back in place. */
+gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* problem, const gh_ba_options* options,
+                      gh_ba_summary* summary);
+
+/* Pose-only (motion-only BA) on 3D-2D matches: pose = T_wc 7 doubles in/out;
+ * information_out (36 doubles, row-major 6x6 J^T J at the solution) may be NULL. */
+gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy, int n, double* pose,
+                    int dof, const gh_ba_options* options, double* information_out, gh_ba_summary* summary);
+
+/* Dense SPD solve used by the reduced camera system, exposed for tests and the C5 bench:
+ * A_dev is n x n column-major/symmetric (lower triangle read, overwritten by L), b_dev in, x out. */
+gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSLAM_HIP_H_ */

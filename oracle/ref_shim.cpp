@@ -1,0 +1,85 @@
+// ref_shim.cpp — thin C wrapper around the REFERENCE's own code, compiled from the sources where
+// they lie under /root/reference (never copied).  Output: oracle/_ref/libgslam_ref.so.
+// Used (a) to pin the oracle (tests + tools/gen_golden.py) and (b) as the "reference" CPU baseline
+// for BF matching.  Built with the reference's flags (-O3 -DNDEBUG, CMakeLists.txt:9-11); a second
+// build adds -mpopcnt (libgslam_ref_popcnt.so).
+#include <GSLAM/core/GSLAM.h>
+#include <GSLAM/core/Vocabulary.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstring>
+
+extern "C" {
+
+float ref_hamming32(const unsigned char* a, const unsigned char* b) {
+  return GSLAM::Vocabulary::DistanceFactory::hamming32(a, b);
+}
+
+// Brute-force loop written exactly like Vocabulary::transform's child scan
+// (GSLAM/core/Vocabulary.h:1712-1725): FLT_MAX start, strict '<'.
+void ref_bf_match(const unsigned char* q, int nq, const unsigned char* t, int nt, int32_t* idx1, float* d1,
+                  int threads) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int i = 0; i < nq; ++i) {
+    float best_d = std::numeric_limits<float>::max();
+    int best = -1;
+    for (int j = 0; j < nt; ++j) {
+      float d = GSLAM::Vocabulary::DistanceFactory::hamming32(q + (size_t)i * 32, t + (size_t)j * 32);
+      if (d < best_d) {
+        best_d = d;
+        best = j;
+      }
+    }
+    idx1[i] = best;
+    d1[i] = best_d;
+  }
+}
+
+// Lie-group helpers of the BA pose update (GSLAM/core/SE3.h, SO3.h).  Pose layout: tx ty tz qx qy qz qw.
+void ref_se3_exp(const double* xi6, double* pose7) {
+  GSLAM::Vector<double, 6> l;
+  for (int i = 0; i < 6; ++i) l[i] = xi6[i];
+  GSLAM::SE3 T = GSLAM::SE3::exp(l);
+  auto t = T.get_translation();
+  auto r = T.get_rotation();
+  pose7[0] = t.x; pose7[1] = t.y; pose7[2] = t.z;
+  pose7[3] = r.x; pose7[4] = r.y; pose7[5] = r.z; pose7[6] = r.w;
+}
+
+void ref_se3_log(const double* pose7, double* xi6) {
+  GSLAM::SE3 T(pose7[0], pose7[1], pose7[2], pose7[3], pose7[4], pose7[5], pose7[6]);
+  auto l = T.log();
+  for (int i = 0; i < 6; ++i) xi6[i] = l[i];
+}
+
+void ref_se3_mul(const double* a7, const double* b7, double* out7) {
+  GSLAM::SE3 A(a7[0], a7[1], a7[2], a7[3], a7[4], a7[5], a7[6]);
+  GSLAM::SE3 B(b7[0], b7[1], b7[2], b7[3], b7[4], b7[5], b7[6]);
+  GSLAM::SE3 C = A * B;
+  auto t = C.get_translation();
+  auto r = C.get_rotation();
+  out7[0] = t.x; out7[1] = t.y; out7[2] = t.z;
+  out7[3] = r.x; out7[4] = r.y; out7[5] = r.z; out7[6] = r.w;
+}
+
+void ref_se3_inverse(const double* a7, double* out7) {
+  GSLAM::SE3 A(a7[0], a7[1], a7[2], a7[3], a7[4], a7[5], a7[6]);
+  GSLAM::SE3 C = A.inverse();
+  auto t = C.get_translation();
+  auto r = C.get_rotation();
+  out7[0] = t.x; out7[1] = t.y; out7[2] = t.z;
+  out7[3] = r.x; out7[4] = r.y; out7[5] = r.z; out7[6] = r.w;
+}
+
+void ref_se3_apply(const double* a7, const double* p3, double* out3) {
+  GSLAM::SE3 A(a7[0], a7[1], a7[2], a7[3], a7[4], a7[5], a7[6]);
+  GSLAM::Point3d p(p3[0], p3[1], p3[2]);
+  GSLAM::Point3d o = A * p;
+  out3[0] = o.x; out3[1] = o.y; out3[2] = o.z;
+}
+
+int ref_sizeof_keypoint() { return (int)sizeof(GSLAM::KeyPoint); }
+int ref_sizeof_se3() { return (int)sizeof(GSLAM::SE3); }
+int ref_sizeof_sim3() { return (int)sizeof(GSLAM::SIM3); }
+}

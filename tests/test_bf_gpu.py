@@ -1,0 +1,143 @@
+"""GPU parity: gh_bf_* (HIP, through the C ABI) vs the CPU oracle — bit-exact indices and distances."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _u16(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+def _run(ctx, q, t):
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    m = BFMatcher(ctx)
+    dq = torch.from_numpy(q).cuda()
+    dt = torch.from_numpy(t).cuda() if t.shape[0] else torch.zeros((0, 32), dtype=torch.uint8, device="cuda")
+    idx1, d1, d2 = m.match(dq, dt)
+    torch.cuda.synchronize()
+    return idx1.cpu().numpy(), _u16(d1), _u16(d2)
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 5), (63, 64), (64, 3), (129, 130), (257, 301), (2000, 2000),
+                                   (1000, 4099)])
+def test_bf_parity_random(ctx, oracle, nq, nt):
+    q = oracle_lib.random_descriptors(nq, 100 + nq)
+    t = oracle_lib.random_descriptors(nt, 200 + nt)
+    got = _run(ctx, q, t)
+    exp = oracle.bf_match(q, t, threads=4)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+
+
+def test_bf_parity_correlated_and_ties(ctx, oracle):
+    base = oracle_lib.random_descriptors(2000, 7)
+    t, perm = oracle_lib.correlated_descriptors(base, 8)
+    t[100] = t[50]
+    t[1999] = t[0]
+    got = _run(ctx, base, t)
+    exp = oracle.bf_match(base, t, threads=4)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    # duplicate rows: the lower index must win
+    q = t[[100, 1999]]
+    idx1, d1, d2 = _run(ctx, q, t)
+    assert idx1.tolist() == [50, 0] and d1.tolist() == [0, 0] and d2.tolist() == [0, 0]
+
+
+def test_bf_golden_reference_vectors(ctx):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bf_reference.npz"))
+    idx1, d1, d2 = _run(ctx, g["q"], g["t"])
+    assert np.array_equal(idx1, g["idx1"])
+    assert np.array_equal(d1.astype(np.float32), g["d1"])
+
+
+def test_bf_empty_train_and_single(ctx):
+    q = oracle_lib.random_descriptors(5, 1)
+    idx1, d1, d2 = _run(ctx, q, np.zeros((0, 32), np.uint8))
+    assert (idx1 == -1).all() and (d1 == 65535).all() and (d2 == 65535).all()
+    idx1, d1, d2 = _run(ctx, q, q[:1])
+    assert (idx1 == 0).all() and d1[0] == 0 and (d2 == 65535).all()
+
+
+def test_bf_host_entry_point(ctx, oracle):
+    import ctypes as C
+    from gslam_amd import hip
+    q = oracle_lib.random_descriptors(300, 31)
+    t = oracle_lib.random_descriptors(500, 32)
+    idx1 = np.empty(300, np.int32)
+    d1 = np.empty(300, np.uint16)
+    d2 = np.empty(300, np.uint16)
+    ctx.check(hip.lib.gh_bf_match_host(ctx.h, q.ctypes.data_as(C.c_void_p), 300, t.ctypes.data_as(C.c_void_p), 500,
+                                       idx1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p),
+                                       d2.ctypes.data_as(C.c_void_p)))
+    e = oracle.bf_match(q, t)
+    assert np.array_equal(idx1, e[0]) and np.array_equal(d1, e[1]) and np.array_equal(d2, e[2])
+
+
+def test_bf_pairs_ragged_counts(ctx, oracle):
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    F, cap = 6, 300
+    counts = np.array([300, 0, 1, 129, 257, 64], np.int32)
+    desc = np.stack([oracle_lib.random_descriptors(cap, 900 + f) for f in range(F)])
+    pq = np.array([0, 1, 2, 3, 4, 5, 0, 3], np.int32)
+    pt = np.array([3, 0, 0, 4, 5, 1, 0, 2], np.int32)
+    m = BFMatcher(ctx)
+    idx1, d1, d2 = m.match_pairs(torch.from_numpy(desc).cuda(), torch.from_numpy(counts).cuda(),
+                                 torch.from_numpy(pq).cuda(), torch.from_numpy(pt).cuda())
+    torch.cuda.synchronize()
+    idx1, d1, d2 = idx1.cpu().numpy(), _u16(d1), _u16(d2)
+    for p in range(len(pq)):
+        nq, nt = counts[pq[p]], counts[pt[p]]
+        e = oracle.bf_match(desc[pq[p], :nq], desc[pt[p], :nt])
+        assert np.array_equal(idx1[p, :nq], e[0])
+        assert np.array_equal(d1[p, :nq], e[1])
+        assert np.array_equal(d2[p, :nq], e[2])
+        assert (idx1[p, nq:] == -1).all() and (d1[p, nq:] == 65535).all() and (d2[p, nq:] == 65535).all()
+
+
+def test_match_mask_parity(ctx, oracle):
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    base = oracle_lib.random_descriptors(1500, 17)
+    t, _ = oracle_lib.correlated_descriptors(base, 18)
+    m = BFMatcher(ctx)
+    dq, dt = torch.from_numpy(base).cuda(), torch.from_numpy(t).cuda()
+    f = m.match(dq, dt)
+    b = m.match(dt, dq)
+    keep = m.mask(f[0], f[1], f[2], back_idx1=b[0], nt=1500, max_dist=80, ratio_num=8, ratio_den=10,
+                  cross_check=True)
+    torch.cuda.synchronize()
+    fo = oracle.bf_match(base, t, threads=4)
+    bo = oracle.bf_match(t, base, threads=4)
+    ko = oracle.match_mask(fo[0], fo[1], fo[2], bo[0], 1500, 80, 8, 10, 1)
+    assert np.array_equal(keep.cpu().numpy(), ko)
+    assert 0 < ko.sum() < 1500
+
+
+def test_bf_full_size_property(ctx):
+    """C2 size (2000 x 2000 per pair, many pairs): size-independent properties instead of the oracle:
+    matching a set against a row-permutation of itself must return the inverse permutation with d1 = 0."""
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    F, cap = 8, 2000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    desc = torch.randint(0, 256, (F, cap, 32), dtype=torch.uint8, generator=g)
+    perm = torch.stack([torch.randperm(cap, generator=g) for _ in range(F)])
+    shuf = torch.stack([desc[f][perm[f]] for f in range(F)])
+    allf = torch.cat([desc, shuf]).cuda()
+    counts = torch.full((2 * F,), cap, dtype=torch.int32).cuda()
+    pq = torch.arange(F, dtype=torch.int32).cuda()
+    pt = (torch.arange(F, dtype=torch.int32) + F).cuda()
+    idx1, d1, d2 = BFMatcher(ctx).match_pairs(allf, counts, pq, pt)
+    torch.cuda.synchronize()
+    inv = torch.argsort(perm, dim=1).to(torch.int32)
+    assert torch.equal(idx1.cpu(), inv)
+    assert int(d1.cpu().abs().sum()) == 0
+    assert (d2.cpu().to(torch.int32) > 60).all()
