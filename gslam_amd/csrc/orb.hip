@@ -1,0 +1,778 @@
+// ORB front end for gfx950: integer pyramid -> FAST-9/16 score + NMS + per-cell lists -> per-level
+// deterministic top-n selection -> intensity-centroid orientation + 7x7 integer Gaussian + 256-bit
+// steered BRIEF.  Bit-exact with oracle/orb_oracle.c, whose header is the step-by-step spec.
+//
+// What it feeds in the reference (there is no ORB code in the GSLAM tree; only the output types):
+//   GSLAM/core/Map.h:122-195  KeyPoint (28 B)      == gh_keypoint
+//   GSLAM/core/Map.h:309-321  MapFrame::setKeyPoints(keypoints, N x 32 8UC1 descriptor GImage)
+//
+// CDNA4 mapping.  Everything is HBM-bound byte/integer work, batched over frames (grid.z = frame) so a
+// launch carries >> 256 workgroups:
+//   resize      1 thread = 4 output pixels (dword store), source taps through L1/L2
+//   fast_cells  256 threads = 64x64 px = 2x2 cells; 72x80 B tile + 66x68 B score tile in LDS; each
+//               wave then owns one 32x32 cell: __ballot prefix compaction keeps raster order, so the
+//               per-cell candidate lists are deterministic without atomics or sorting
+//   select      one workgroup per (level, frame): LDS histogram over (rank, score) finds the quota
+//               cut-off, block scans give the output slots - no sort, no float
+//   describe    one wave per keypoint: 37x37 patch in LDS, wave-reduced integer moments, separable
+//               integer blur in LDS, 4 x __ballot packs the 256 test bits
+#include "common.h"
+#include "../../include/gslam_orb_tables.h"
+
+namespace {
+
+constexpr int kEdge = GH_ORB_EDGE;         // 19
+constexpr int kCell = GH_ORB_CELL;         // 32
+constexpr int kCap = GH_ORB_CELL_CAP;      // 32
+constexpr int kMaxL = GH_ORB_MAX_LEVELS;   // 8
+constexpr int kHistBins = kCap * 256;      // (rank, 255 - score)
+
+struct LevelView {
+  const uint8_t* base;   // frame 0
+  size_t frame_stride;   // bytes between frames
+  int pitch, w, h;
+};
+
+struct DevTables {
+  const int8_t* pattern;   // [30][256][4]
+  const int32_t* dir;      // [30][2]
+};
+
+struct SelKp {
+  uint16_t x, y;
+  uint8_t score, level;
+  uint16_t pad;
+};
+
+// ------------------------------------------------------------------------------------------------
+// level-0 staging copy (only when the caller's buffer is not dword friendly)
+__global__ void copy_rows_kernel(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
+                                 uint8_t* __restrict__ dst, size_t dst_frame_stride, int dst_pitch, int w, int h) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= w) return;
+  dst[(size_t)blockIdx.z * dst_frame_stride + (size_t)y * dst_pitch + x] =
+      src[(size_t)blockIdx.z * src_frame_stride + (size_t)y * src_pitch + x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear 1.2x downscale, 11-bit fixed point (oracle step 1).  xtab/ytab: idx << 16 | frac.
+__global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __restrict__ dst_base,
+                                                     size_t dst_frame_stride, int dst_pitch, int wd, int hd,
+                                                     const uint32_t* __restrict__ xtab,
+                                                     const uint32_t* __restrict__ ytab) {
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x4 >= wd || y >= hd) return;
+  const uint8_t* s = src.base + (size_t)blockIdx.z * src.frame_stride;
+  const uint32_t ty = ytab[y];
+  const int sy = ty >> 16, fy = ty & 0xFFFF;
+  const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
+  const uint8_t* r0 = s + (size_t)sy * src.pitch;
+  const uint8_t* r1 = s + (size_t)sy1 * src.pitch;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int x = x4 + i;
+    x = x < wd ? x : wd - 1;
+    const uint32_t tx = xtab[x];
+    const int sx = tx >> 16, fx = tx & 0xFFFF;
+    const int sx1 = sx + 1 < src.w ? sx + 1 : src.w - 1;
+    uint32_t v = (uint32_t)r0[sx] * (2048 - fx) * (2048 - fy) + (uint32_t)r0[sx1] * fx * (2048 - fy) +
+                 (uint32_t)r1[sx] * (2048 - fx) * fy + (uint32_t)r1[sx1] * fx * fy;
+    packed |= ((v + (1u << 21)) >> 22) << (8 * i);
+  }
+  // dst pitch is a multiple of 64 and the pad bytes are ours: always a full dword store
+  *reinterpret_cast<uint32_t*>(dst_base + (size_t)blockIdx.z * dst_frame_stride + (size_t)y * dst_pitch + x4) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 corner score (oracle step 2): max over 9-arcs of min(ring - p) / min(p - ring).
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+__device__ __forceinline__ int fast_score16(const int (&d)[16]) {
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    hi3[i] = max3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+  }
+  int best = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int lo9 = min3i(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]);
+    int hi9 = max3i(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]);
+    best = max3i(best, lo9, -hi9);
+  }
+  return best;
+}
+
+constexpr int kTileW = 80;   // bytes per LDS tile row (20 dwords), 72 rows
+constexpr int kTileH = 72;
+constexpr int kScoreW = 68;  // 66 used
+constexpr int kScoreH = 66;
+
+__global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
+                                                         uint32_t* __restrict__ cell_cnt,
+                                                         uint32_t* __restrict__ cell_ent, int cells_per_frame,
+                                                         int cell_off) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
+  __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
+  __shared__ uint32_t lists[4][256];
+
+  const int tid = threadIdx.x;
+  const int x0 = kEdge + 64 * blockIdx.x, y0 = kEdge + 64 * blockIdx.y;  // region origin
+  const int ox = x0 - 4, oy = y0 - 4;                                    // tile origin (pixel)
+  const int ax = ox & ~3;                                                // dword aligned load origin (ox - ax == 3)
+  const uint8_t* img = lv.base + (size_t)blockIdx.z * lv.frame_stride;
+
+  for (int i = tid; i < kTileH * (kTileW / 4); i += 256) {
+    const int row = i / (kTileW / 4), c = i - row * (kTileW / 4);
+    int gy = oy + row;
+    gy = gy < 0 ? 0 : (gy > lv.h - 1 ? lv.h - 1 : gy);
+    int gx = ax + 4 * c;
+    gx = gx < 0 ? 0 : (gx > lv.pitch - 4 ? lv.pitch - 4 : gx);
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * lv.pitch + gx);
+    *reinterpret_cast<uint32_t*>(&tile[row * kTileW + 4 * c]) = v;
+  }
+  __syncthreads();
+
+  // scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 6, row sy + 3
+  for (int i = tid; i < kScoreH * kScoreH; i += 256) {
+    const int sy = i / kScoreH, sx = i - sy * kScoreH;
+    const int px = x0 - 1 + sx, py = y0 - 1 + sy;
+    int s = 0;
+    if (px >= kEdge && px < lv.w - kEdge && py >= kEdge && py < lv.h - kEdge) {
+      const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 6];
+      const int c = p[0];
+      const int r0 = p[-3 * kTileW], r4 = p[3], r8 = p[3 * kTileW], r12 = p[-3];
+      const int nb = (r0 > c + min_th) + (r4 > c + min_th) + (r8 > c + min_th) + (r12 > c + min_th);
+      const int nd = (r0 < c - min_th) + (r4 < c - min_th) + (r8 < c - min_th) + (r12 < c - min_th);
+      if (nb >= 2 || nd >= 2) {
+        int d[16];
+        d[0] = r0 - c;
+        d[1] = p[-3 * kTileW + 1] - c;
+        d[2] = p[-2 * kTileW + 2] - c;
+        d[3] = p[-1 * kTileW + 3] - c;
+        d[4] = r4 - c;
+        d[5] = p[1 * kTileW + 3] - c;
+        d[6] = p[2 * kTileW + 2] - c;
+        d[7] = p[3 * kTileW + 1] - c;
+        d[8] = r8 - c;
+        d[9] = p[3 * kTileW - 1] - c;
+        d[10] = p[2 * kTileW - 2] - c;
+        d[11] = p[1 * kTileW - 3] - c;
+        d[12] = r12 - c;
+        d[13] = p[-1 * kTileW - 3] - c;
+        d[14] = p[-2 * kTileW - 2] - c;
+        d[15] = p[-3 * kTileW - 1] - c;
+        s = fast_score16(d);
+        s = s > min_th ? s : 0;
+      }
+    }
+    score[sy * kScoreW + sx] = (uint8_t)s;
+  }
+  __syncthreads();
+
+  // one wave per 32x32 cell
+  const int wv = tid >> 6, lane = tid & 63;
+  const int cx = 2 * blockIdx.x + (wv & 1), cy = 2 * blockIdx.y + (wv >> 1);
+  if (cx >= ncx || cy >= ncy) return;  // no block-wide sync below
+  uint32_t* list = lists[wv];
+  const int sx0 = 1 + 32 * (wv & 1), sy0 = 1 + 32 * (wv >> 1);
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  int n = 0;
+  bool strong = false;
+  for (int it = 0; it < 16; ++it) {
+    const int row = 2 * it + (lane >> 5), col = lane & 31;
+    const uint8_t* sp = &score[(sy0 + row) * kScoreW + sx0 + col];
+    const int s = sp[0];
+    bool ismax = false;
+    if (s > 0) {
+      ismax = sp[-kScoreW - 1] < s && sp[-kScoreW] < s && sp[-kScoreW + 1] < s && sp[-1] < s && sp[1] < s &&
+              sp[kScoreW - 1] < s && sp[kScoreW] < s && sp[kScoreW + 1] < s;
+    }
+    const uint64_t m = __ballot(ismax);
+    if (ismax) list[n + __popcll(m & lt_mask)] = ((uint32_t)s << 10) | ((uint32_t)row << 5) | (uint32_t)col;
+    n += __popcll(m);
+    strong = strong || (__ballot(ismax && s > ini_th) != 0ull);
+  }
+  if (strong) {  // keep only candidates above the initial threshold (in place, order preserved)
+    int m2 = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const uint32_t e = i < n ? list[i] : 0u;
+      const bool keep = i < n && (int)(e >> 10) > ini_th;
+      const uint64_t m = __ballot(keep);
+      if (keep) list[m2 + __popcll(m & lt_mask)] = e;
+      m2 += __popcll(m);
+    }
+    n = m2;
+  }
+  // rank within the cell by (score desc, raster asc); keep rank < cap, write in raster order
+  const size_t cell = (size_t)blockIdx.z * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
+  uint32_t* out = cell_ent + cell * kCap;
+  int kept = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const uint32_t e = i < n ? list[i] : 0u;
+    const int s = (int)(e >> 10);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const int sj = (int)(list[j] >> 10);
+      rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
+    }
+    const bool keep = i < n && rank < kCap;
+    const uint64_t m = __ballot(keep);
+    if (keep) out[kept + __popcll(m & lt_mask)] = ((uint32_t)rank << 18) | e;
+    kept += __popcll(m);
+  }
+  if (lane == 0) cell_cnt[cell] = (uint32_t)kept;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /* shared[5] */, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();  // protect wave_tot reuse
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int k = 0; k < wv; ++k) off += wave_tot[k];
+  *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  return off + incl - v;
+}
+
+struct SelectArgs {
+  int ncells[kMaxL], cell_off[kMaxL], ncx[kMaxL], quota[kMaxL], quota_off[kMaxL];
+};
+
+__global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_t* __restrict__ cell_cnt,
+                                                     const uint32_t* __restrict__ cell_ent, int cells_per_frame,
+                                                     int K, SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt) {
+  __shared__ uint32_t hist[kHistBins];
+  __shared__ int wave_tot[4];
+  __shared__ int s_cut, s_m;
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int ncells = a.ncells[l], quota = a.quota[l];
+  const uint32_t* cnt = cell_cnt + (size_t)b * cells_per_frame + a.cell_off[l];
+  const uint32_t* ent = cell_ent + ((size_t)b * cells_per_frame + a.cell_off[l]) * kCap;
+  if (quota <= 0 || ncells <= 0) {
+    if (tid == 0) level_cnt[b * kMaxL + l] = 0;
+    return;
+  }
+  for (int i = tid; i < kHistBins; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int c = tid; c < ncells; c += 256) {
+    const int n = (int)cnt[c];
+    for (int e = 0; e < n; ++e) {
+      const uint32_t v = ent[(size_t)c * kCap + e];
+      const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
+      atomicAdd(&hist[ck], 1u);
+    }
+  }
+  __syncthreads();
+  // cut-off bin: smallest bin whose inclusive prefix reaches the quota
+  constexpr int kPer = kHistBins / 256;
+  int mine = 0;
+  for (int i = 0; i < kPer; ++i) mine += (int)hist[tid * kPer + i];
+  int total;
+  const int excl = block_excl_scan(mine, wave_tot, &total);
+  if (tid == 0) {
+    s_cut = kHistBins;  // everything selected
+    s_m = 0;
+  }
+  __syncthreads();
+  if (total > quota && excl < quota && excl + mine >= quota) {
+    int run = excl;
+    for (int i = 0; i < kPer; ++i) {
+      const int hv = (int)hist[tid * kPer + i];
+      if (run + hv >= quota) {
+        s_cut = tid * kPer + i;
+        s_m = quota - run;
+        break;
+      }
+      run += hv;
+    }
+  }
+  __syncthreads();
+  const int cut = s_cut, m = s_m;
+  // slots: traverse cells in order, chunks of 256 with carries
+  int tie_carry = 0, out_carry = 0;
+  SelKp* out = sel + (size_t)b * K + a.quota_off[l];
+  const int ncx = a.ncx[l];
+  for (int cb = 0; cb < ncells; cb += 256) {
+    const int c = cb + tid;
+    int n = 0, n_lt = 0, n_eq = 0;
+    if (c < ncells) {
+      n = (int)cnt[c];
+      for (int e = 0; e < n; ++e) {
+        const uint32_t v = ent[(size_t)c * kCap + e];
+        const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
+        n_lt += ck < cut;
+        n_eq += ck == cut;
+      }
+    }
+    int tot_eq, tot_sel;
+    const int tie_excl = tie_carry + block_excl_scan(n_eq, wave_tot, &tot_eq);
+    int taken = m - tie_excl;
+    taken = taken < 0 ? 0 : (taken > n_eq ? n_eq : taken);
+    const int mysel = n_lt + taken;
+    const int out_excl = out_carry + block_excl_scan(mysel, wave_tot, &tot_sel);
+    if (mysel > 0) {
+      const int cx = c % ncx, cy = c / ncx;
+      int k = 0, ties = 0;
+      for (int e = 0; e < n; ++e) {
+        const uint32_t v = ent[(size_t)c * kCap + e];
+        const int s = (int)((v >> 10) & 255);
+        const int ck = (int)(v >> 18) * 256 + (255 - s);
+        bool take = ck < cut;
+        if (ck == cut && ties < taken) {
+          take = true;
+          ++ties;
+        }
+        if (take) {
+          SelKp o;
+          o.x = (uint16_t)(kEdge + cx * kCell + (int)(v & 31));
+          o.y = (uint16_t)(kEdge + cy * kCell + (int)((v >> 5) & 31));
+          o.score = (uint8_t)s;
+          o.level = (uint8_t)l;
+          o.pad = 0;
+          out[out_excl + k] = o;
+          ++k;
+        }
+      }
+    }
+    tie_carry += tot_eq;
+    out_carry += tot_sel;
+  }
+  if (tid == 0) level_cnt[b * kMaxL + l] = out_carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DescribeArgs {
+  LevelView lv[kMaxL];
+  int quota[kMaxL], quota_off[kMaxL];
+  float scale[kMaxL];
+  int nlevels;
+};
+
+constexpr int kPatch = 37, kPatchPitch = 40;
+
+__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
+                                                       const SelKp* __restrict__ sel,
+                                                       const int32_t* __restrict__ level_cnt,
+                                                       gh_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                       int32_t* __restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch];
+  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][kPatch * 31 + 1];
+  __shared__ __attribute__((aligned(16))) uint8_t s_blur[4][31 * 32];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + wv;
+  const int b = blockIdx.y;
+  if (slot >= K) return;
+  // level of this slot and compacted output position
+  int l = 0;
+  for (int k = 1; k < a.nlevels; ++k)
+    if (slot >= a.quota_off[k]) l = k;
+  const int i = slot - a.quota_off[l];
+  int before = 0, unused_before = 0, total = 0;
+  for (int k = 0; k < a.nlevels; ++k) {
+    const int c = level_cnt[b * kMaxL + k];
+    total += c;
+    if (k < l) {
+      before += c;
+      unused_before += a.quota[k] - c;
+    }
+  }
+  const int cnt_l = level_cnt[b * kMaxL + l];
+  if (slot == 0 && lane == 0) counts[b] = total;
+  if (i >= cnt_l) {  // unused slot: zero-fill one tail row so the whole K-row output is deterministic
+    const int pos = total + unused_before + (i - cnt_l);
+    if (pos < K) {
+      if (lane < 7) reinterpret_cast<uint32_t*>(kps + (size_t)b * K + pos)[lane] = 0u;
+      if (lane >= 8 && lane < 16) reinterpret_cast<uint32_t*>(desc + ((size_t)b * K + pos) * 32)[lane - 8] = 0u;
+    }
+    return;
+  }
+  const int pos = before + i;
+  const SelKp kp = sel[(size_t)b * K + slot];
+  const LevelView lv = a.lv[l];
+  const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
+  uint8_t* patch = s_patch[wv];
+  const int px0 = (int)kp.x - 18, py0 = (int)kp.y - 18;
+  for (int idx = lane; idx < kPatch * kPatch; idx += 64) {
+    const int r = idx / kPatch, c = idx - r * kPatch;
+    patch[r * kPatchPitch + c] = img[(size_t)(py0 + r) * lv.pitch + px0 + c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // intensity centroid over the radius-15 disc (patch centre at [18][18])
+  int m10 = 0, m01 = 0;
+  for (int idx = lane; idx < 31 * 31; idx += 64) {
+    const int r = idx / 31, c = idx - r * 31;
+    const int v = r - 15, u = c - 15;
+    const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+    // u_max table (GH_ORB_UMAX) as a switch-free lookup
+    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    if (au <= um[av]) {
+      const int I = patch[(r + 3) * kPatchPitch + c + 3];
+      m10 += u * I;
+      m01 += v * I;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    m10 += __shfl_xor(m10, o);
+    m01 += __shfl_xor(m01, o);
+  }
+  int bin = 0;
+  {
+    long long c = 0;
+    if (lane < GH_ORB_NBINS) c = (long long)tb.dir[2 * lane] * m01 - (long long)tb.dir[2 * lane + 1] * m10;
+    const int c_neg = c < 0 ? 1 : 0;
+    const int prev_lane = (lane + GH_ORB_NBINS - 1) % GH_ORB_NBINS;
+    const int prev_neg = __shfl(c_neg, prev_lane);
+    const uint64_t hit = __ballot(lane < GH_ORB_NBINS && !prev_neg && c_neg);
+    if ((m10 != 0 || m01 != 0) && hit != 0ull) bin = __ffsll((unsigned long long)hit) - 1;
+  }
+  // separable 7x7 integer Gaussian: rows 0..36 x cols 3..33 -> s_h, then rows 3..33 -> s_blur (31x31)
+  uint32_t* hb = s_h[wv];
+  constexpr uint32_t g[7] = {144, 268, 391, 442, 391, 268, 144};
+  for (int idx = lane; idx < kPatch * 31; idx += 64) {
+    const int r = idx / 31, c = idx - r * 31;
+    const uint8_t* p = &patch[r * kPatchPitch + c];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) acc += g[t] * p[t];
+    hb[idx] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint8_t* bl = s_blur[wv];
+  for (int idx = lane; idx < 31 * 31; idx += 64) {
+    const int r = idx / 31, c = idx - r * 31;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) acc += g[t] * hb[(r + t) * 31 + c];
+    bl[r * 32 + c] = (uint8_t)((acc + (1u << 21)) >> 22);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // 256 binary tests, 64 per ballot
+  const uint32_t* pat = reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
+  uint8_t* drow = desc + ((size_t)b * K + pos) * 32;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const uint32_t pw = pat[gq * 64 + lane];
+    const int ax = (int8_t)(pw & 0xFF), ay = (int8_t)((pw >> 8) & 0xFF);
+    const int bx = (int8_t)((pw >> 16) & 0xFF), by = (int8_t)(pw >> 24);
+    const int va = bl[(15 + ay) * 32 + 15 + ax], vb = bl[(15 + by) * 32 + 15 + bx];
+    const uint64_t bits = __ballot(va < vb);
+    if (lane == 0) *reinterpret_cast<uint64_t*>(drow + 8 * gq) = bits;
+  }
+  if (lane == 0) {
+    const float sc = a.scale[l];
+    gh_keypoint o;
+    o.x = __fmul_rn((float)kp.x, sc);
+    o.y = __fmul_rn((float)kp.y, sc);
+    o.size = __fmul_rn(31.0f, sc);
+    o.angle = 12.0f * (float)bin;
+    o.response = (float)kp.score;
+    o.octave = l;
+    o.class_id = -1;
+    kps[(size_t)b * K + pos] = o;
+  }
+}
+
+__global__ void bgr_to_gray_kernel(const uint8_t* __restrict__ bgr, int w, int h, int channels, int sstride,
+                                   uint8_t* __restrict__ gray, int dstride) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const uint8_t* p = bgr + (size_t)y * sstride + (size_t)x * channels;
+  gray[(size_t)y * dstride + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+}
+
+long long ipow(int b, int e) {
+  long long r = 1;
+  while (e-- > 0) r *= b;
+  return r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct gh_orb_plan {
+  gh_ctx* ctx = nullptr;
+  int w = 0, h = 0, max_batch = 0, L = 0;
+  gh_orb_params prm{};
+  int lw[kMaxL]{}, lh[kMaxL]{}, pitch[kMaxL]{}, quota[kMaxL]{}, quota_off[kMaxL]{};
+  int ncx[kMaxL]{}, ncy[kMaxL]{}, cell_off[kMaxL]{};
+  float scale[kMaxL]{};
+  size_t lvl_off[kMaxL]{};  // offset of level l inside one frame's pyramid slab
+  size_t slab = 0;
+  int cells_per_frame = 0;
+  uint8_t* pyr = nullptr;
+  uint32_t* xtab[kMaxL]{};
+  uint32_t* ytab[kMaxL]{};
+  uint32_t* cell_cnt = nullptr;
+  uint32_t* cell_ent = nullptr;
+  SelKp* sel = nullptr;
+  int32_t* level_cnt = nullptr;
+  int8_t* d_pattern = nullptr;
+  int32_t* d_dir = nullptr;
+  uint32_t* tabs = nullptr;
+  // host staging for gh_orb_extract_host
+  uint8_t* stage_img = nullptr;
+  gh_keypoint* stage_kps = nullptr;
+  uint8_t* stage_desc = nullptr;
+  int32_t* stage_cnt = nullptr;
+  size_t bytes = 0;
+};
+
+extern "C" void gh_orb_default_params(gh_orb_params* p) {
+  if (!p) return;
+  p->n_features = 1000;
+  p->n_levels = 8;
+  p->ini_th_fast = 20;
+  p->min_th_fast = 7;
+}
+
+static gh_status plan_alloc(gh_orb_plan* p, size_t bytes, void** out) {
+  gh_status s = gh_dev_alloc(p->ctx, bytes, out);
+  if (s == GH_OK) p->bytes += bytes;
+  return s;
+}
+
+extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
+  if (!p) return;
+  gh_ctx* c = p->ctx;
+  hipStreamSynchronize(c->stream);
+  void* ptrs[] = {p->pyr, p->cell_cnt, p->cell_ent, p->sel, p->level_cnt, p->d_pattern, p->d_dir, p->tabs,
+                  p->stage_img, p->stage_kps, p->stage_desc, p->stage_cnt};
+  for (void* q : ptrs)
+    if (q) hipFree(q);
+  delete p;
+}
+
+extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
+                                        const gh_orb_params* params, gh_orb_plan** out) {
+  if (!ctx || !out) return GH_ERR_ARG;
+  *out = nullptr;
+  gh_orb_params prm;
+  gh_orb_default_params(&prm);
+  if (params) prm = *params;
+  GH_CHECK_ARG(ctx, width >= 2 * kEdge + 1 && height >= 2 * kEdge + 1 && width <= 16384 && height <= 16384);
+  GH_CHECK_ARG(ctx, max_batch >= 1 && max_batch <= 65535);
+  GH_CHECK_ARG(ctx, prm.n_levels >= 1 && prm.n_levels <= kMaxL && prm.n_features >= 1 && prm.n_features <= (1 << 20));
+  GH_CHECK_ARG(ctx, prm.min_th_fast >= 1 && prm.ini_th_fast >= prm.min_th_fast && prm.ini_th_fast <= 254);
+  GH_HIP(ctx, hipSetDevice(ctx->device));
+  gh_orb_plan* p = new (std::nothrow) gh_orb_plan();
+  if (!p) return GH_ERR_NOMEM;
+  p->ctx = ctx;
+  p->w = width;
+  p->h = height;
+  p->max_batch = max_batch;
+  p->prm = prm;
+  const int L = p->L = prm.n_levels;
+  // geometry (oracle step 1 / 5): exact integer arithmetic
+  long long den = ipow(6, L) - ipow(5, L);
+  int qsum = 0;
+  size_t off = 0;
+  int coff = 0;
+  for (int l = 0; l < L; ++l) {
+    long long p5 = ipow(5, l), p6 = ipow(6, l);
+    p->lw[l] = (int)((2LL * width * p5 + p6) / (2 * p6));
+    p->lh[l] = (int)((2LL * height * p5 + p6) / (2 * p6));
+    p->pitch[l] = (p->lw[l] + 63) & ~63;
+    p->lvl_off[l] = off;
+    off += (size_t)p->pitch[l] * p->lh[l];
+    off = (off + 255) & ~(size_t)255;
+    if (l < L - 1) {
+      long long num = (long long)prm.n_features * ipow(5, l) * ipow(6, L - 1 - l);
+      p->quota[l] = (int)((2 * num + den) / (2 * den));
+      if (p->quota[l] > prm.n_features - qsum) p->quota[l] = prm.n_features - qsum;
+      qsum += p->quota[l];
+    } else {
+      p->quota[l] = prm.n_features - qsum > 0 ? prm.n_features - qsum : 0;
+    }
+    p->scale[l] = l == 0 ? 1.0f : p->scale[l - 1] * 1.2f;
+    const int vw = p->lw[l] - 2 * kEdge, vh = p->lh[l] - 2 * kEdge;
+    p->ncx[l] = vw > 0 ? (vw + kCell - 1) / kCell : 0;
+    p->ncy[l] = vh > 0 ? (vh + kCell - 1) / kCell : 0;
+    if (p->ncx[l] == 0 || p->ncy[l] == 0) p->ncx[l] = p->ncy[l] = 0;
+    p->cell_off[l] = coff;
+    coff += p->ncx[l] * p->ncy[l];
+  }
+  // a level without a valid region selects nothing: its quota is simply unused (as in the oracle)
+  int qo = 0;
+  for (int l = 0; l < L; ++l) {
+    p->quota_off[l] = qo;
+    qo += p->quota[l];
+  }
+  p->slab = off + 256;  // tail pad: the tile loader may read a clamped dword at the very end
+  p->cells_per_frame = coff > 0 ? coff : 1;
+  gh_status st = GH_OK;
+  const size_t B = (size_t)max_batch;
+  const int K = prm.n_features;
+  // resize tables
+  size_t tab_words = 0;
+  for (int l = 1; l < L; ++l) tab_words += (size_t)p->lw[l] + p->lh[l];
+  std::vector<uint32_t> htab(tab_words ? tab_words : 1);
+  do {
+    if ((st = plan_alloc(p, B * p->slab, (void**)&p->pyr)) != GH_OK) break;
+    if ((st = plan_alloc(p, B * p->cells_per_frame * sizeof(uint32_t), (void**)&p->cell_cnt)) != GH_OK) break;
+    if ((st = plan_alloc(p, B * p->cells_per_frame * kCap * sizeof(uint32_t), (void**)&p->cell_ent)) != GH_OK) break;
+    if ((st = plan_alloc(p, B * K * sizeof(SelKp), (void**)&p->sel)) != GH_OK) break;
+    if ((st = plan_alloc(p, B * kMaxL * sizeof(int32_t), (void**)&p->level_cnt)) != GH_OK) break;
+    if ((st = plan_alloc(p, sizeof(GH_ORB_PATTERN), (void**)&p->d_pattern)) != GH_OK) break;
+    if ((st = plan_alloc(p, sizeof(GH_ORB_DIR), (void**)&p->d_dir)) != GH_OK) break;
+    if ((st = plan_alloc(p, htab.size() * sizeof(uint32_t), (void**)&p->tabs)) != GH_OK) break;
+    size_t tw = 0;
+    for (int l = 1; l < L; ++l) {
+      for (int axis = 0; axis < 2; ++axis) {
+        const int n_src = axis == 0 ? p->lw[l - 1] : p->lh[l - 1];
+        const int n_dst = axis == 0 ? p->lw[l] : p->lh[l];
+        (axis == 0 ? p->xtab[l] : p->ytab[l]) = p->tabs + tw;
+        for (int x = 0; x < n_dst; ++x) {
+          long long P = ((long long)(2 * x + 1) * n_src * 2048) / (2LL * n_dst) - 1024;
+          if (P < 0) P = 0;
+          int sx = (int)(P >> 11), fx = (int)(P & 2047);
+          if (sx >= n_src - 1) {
+            sx = n_src - 1;
+            fx = 0;
+          }
+          htab[tw++] = ((uint32_t)sx << 16) | (uint32_t)fx;
+        }
+      }
+    }
+    if ((st = gh_dev_upload(ctx, p->tabs, htab.data(), htab.size() * sizeof(uint32_t))) != GH_OK) break;
+    if ((st = gh_dev_upload(ctx, p->d_pattern, GH_ORB_PATTERN, sizeof(GH_ORB_PATTERN))) != GH_OK) break;
+    if ((st = gh_dev_upload(ctx, p->d_dir, GH_ORB_DIR, sizeof(GH_ORB_DIR))) != GH_OK) break;
+  } while (0);
+  if (st != GH_OK) {
+    gh_orb_plan_destroy(p);
+    return st;
+  }
+  *out = p;
+  return GH_OK;
+}
+
+extern "C" gh_status gh_orb_plan_level(const gh_orb_plan* p, int level, int* w, int* h, int* quota) {
+  if (!p || level < 0 || level >= p->L) return GH_ERR_ARG;
+  if (w) *w = p->lw[level];
+  if (h) *h = p->lh[level];
+  if (quota) *quota = p->quota[level];
+  return GH_OK;
+}
+
+extern "C" size_t gh_orb_plan_device_bytes(const gh_orb_plan* p) { return p ? p->bytes : 0; }
+
+extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev, int batch, size_t frame_stride,
+                                        int row_stride, gh_keypoint* kps_dev, uint8_t* desc_dev,
+                                        int32_t* counts_dev) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_CHECK_ARG(ctx, batch >= 0 && batch <= p->max_batch);
+  if (batch == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, gray_dev && kps_dev && desc_dev && counts_dev && row_stride >= p->w);
+  GH_CHECK_ARG(ctx, frame_stride >= (size_t)row_stride * p->h || batch == 1);
+  GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 7) == 0 && ((uintptr_t)kps_dev & 3) == 0);
+  const int L = p->L, K = p->prm.n_features;
+
+  LevelView lv[kMaxL];
+  const bool aligned0 = ((uintptr_t)gray_dev & 3) == 0 && (row_stride & 3) == 0 && (frame_stride & 3) == 0;
+  if (aligned0) {
+    lv[0] = {gray_dev, frame_stride, row_stride, p->w, p->h};
+  } else {
+    dim3 grid(gh_div_up(p->w, 256), p->h, batch);
+    GH_LAUNCH(ctx, "orb_copy_level0", copy_rows_kernel, grid, dim3(256), 0, gray_dev, frame_stride, row_stride,
+              p->pyr + p->lvl_off[0], p->slab, p->pitch[0], p->w, p->h);
+    lv[0] = {p->pyr + p->lvl_off[0], p->slab, p->pitch[0], p->w, p->h};
+  }
+  for (int l = 1; l < L; ++l) lv[l] = {p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l]};
+
+  for (int l = 1; l < L; ++l) {
+    dim3 grid(gh_div_up(p->lw[l], 256), gh_div_up(p->lh[l], 4), batch);
+    GH_LAUNCH(ctx, "orb_resize", resize_kernel, grid, dim3(256), 0, lv[l - 1], p->pyr + p->lvl_off[l], p->slab,
+              p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l]);
+  }
+  for (int l = 0; l < L; ++l) {
+    if (p->ncx[l] == 0 || p->quota[l] <= 0) continue;
+    dim3 grid(gh_div_up(p->ncx[l], 2), gh_div_up(p->ncy[l], 2), batch);
+    GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
+              p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l]);
+  }
+  {
+    SelectArgs a;
+    for (int l = 0; l < kMaxL; ++l) {
+      a.ncells[l] = l < L ? p->ncx[l] * p->ncy[l] : 0;
+      a.cell_off[l] = l < L ? p->cell_off[l] : 0;
+      a.ncx[l] = l < L && p->ncx[l] > 0 ? p->ncx[l] : 1;
+      a.quota[l] = l < L ? p->quota[l] : 0;
+      a.quota_off[l] = l < L ? p->quota_off[l] : 0;
+    }
+    GH_LAUNCH(ctx, "orb_select", select_kernel, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
+              p->cells_per_frame, K, p->sel, p->level_cnt);
+  }
+  {
+    DescribeArgs a;
+    for (int l = 0; l < kMaxL; ++l) {
+      a.lv[l] = l < L ? lv[l] : lv[0];
+      a.quota[l] = l < L ? p->quota[l] : 0;
+      a.quota_off[l] = l < L ? p->quota_off[l] : 0;
+      a.scale[l] = l < L ? p->scale[l] : 1.0f;
+    }
+    a.nlevels = L;
+    DevTables tb{p->d_pattern, p->d_dir};
+    GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(gh_div_up(K, 4), batch), dim3(256), 0, a, tb, K, p->sel,
+              p->level_cnt, kps_dev, desc_dev, counts_dev);
+  }
+  return GH_OK;
+}
+
+extern "C" gh_status gh_orb_extract_host(gh_orb_plan* p, const uint8_t* gray, int row_stride, gh_keypoint* kps,
+                                         uint8_t* desc, int32_t* count) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_CHECK_ARG(ctx, gray && kps && desc && count && row_stride >= p->w);
+  const int K = p->prm.n_features;
+  const int pitch = (p->w + 63) & ~63;
+  if (!p->stage_img) {
+    GH_TRY(plan_alloc(p, (size_t)pitch * p->h + 256, (void**)&p->stage_img));
+    GH_TRY(plan_alloc(p, (size_t)K * sizeof(gh_keypoint), (void**)&p->stage_kps));
+    GH_TRY(plan_alloc(p, (size_t)K * 32, (void**)&p->stage_desc));
+    GH_TRY(plan_alloc(p, 256, (void**)&p->stage_cnt));
+  }
+  GH_HIP(ctx, hipMemcpy2DAsync(p->stage_img, pitch, gray, row_stride, p->w, p->h, hipMemcpyHostToDevice, ctx->stream));
+  GH_TRY(gh_orb_extract_dev(p, p->stage_img, 1, (size_t)pitch * p->h, pitch, p->stage_kps, p->stage_desc, p->stage_cnt));
+  GH_HIP(ctx, hipMemcpyAsync(count, p->stage_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(kps, p->stage_kps, (size_t)K * sizeof(gh_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(desc, p->stage_desc, (size_t)K * 32, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
+                                        int src_row_stride, uint8_t* gray_dev, int dst_row_stride) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, bgr_dev && gray_dev && width > 0 && height > 0 && (channels == 3 || channels == 4));
+  GH_CHECK_ARG(ctx, src_row_stride >= width * channels && dst_row_stride >= width);
+  GH_LAUNCH(ctx, "bgr_to_gray", bgr_to_gray_kernel, dim3(gh_div_up(width, 256), height), dim3(256), 0, bgr_dev, width,
+            height, channels, src_row_stride, gray_dev, dst_row_stride);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_orb_debug_level(gh_orb_plan* p, int slot, int level, uint8_t* out_host) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_CHECK_ARG(ctx, slot >= 0 && slot < p->max_batch && level >= 1 && level < p->L && out_host);
+  GH_HIP(ctx, hipMemcpy2DAsync(out_host, p->lw[level], p->pyr + (size_t)slot * p->slab + p->lvl_off[level],
+                               p->pitch[level], p->lw[level], p->lh[level], hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}

@@ -1,0 +1,102 @@
+"""Host-side mirror of the extractor half of the FeatureDetector plugin interface
+(gslam_amd/plugin/FeatureDetector.h) for tests and bench.py: batched ORB extraction on frames resident
+in HBM.  torch tensors are device buffers only; all compute is libgslam_hip.so.
+
+Output layout follows GSLAM/core/Map.h:122-195 (KeyPoint, 28 B) and Map.h:309-321 (descriptors as an
+N x 32 8UC1 matrix).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def synth_frames(ctx, n_frames, width, height, base_seed=0x5EED0000, first_frame=0, row_stride=None,
+                 device="cuda"):
+    """n_frames deterministic gray frames generated in HBM (bit-identical to oracle/synth.c)."""
+    row_stride = row_stride or width
+    out = torch.empty((n_frames, height, row_stride), dtype=torch.uint8, device=device)
+    ctx.check(hip.lib.gh_synth_frames_dev(ctx.h, _p(out), width, height, row_stride,
+                                          C.c_size_t(height * row_stride), int(first_frame), int(n_frames),
+                                          C.c_uint32(base_seed & 0xFFFFFFFF)))
+    return out
+
+
+class OrbExtractor:
+    def __init__(self, ctx: hip.Context, width, height, max_batch=1, n_features=1000, n_levels=8, ini_th=20,
+                 min_th=7):
+        self.ctx = ctx
+        self.w, self.h, self.max_batch, self.K, self.L = width, height, max_batch, n_features, n_levels
+        prm = hip.OrbParams(n_features, n_levels, ini_th, min_th)
+        h = C.c_void_p()
+        ctx.check(hip.lib.gh_orb_plan_create(ctx.h, width, height, max_batch, C.byref(prm), C.byref(h)))
+        self.plan = h
+
+    def close(self):
+        if self.plan:
+            hip.lib.gh_orb_plan_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level(self, l):
+        w, h, q = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(hip.lib.gh_orb_plan_level(self.plan, l, C.byref(w), C.byref(h), C.byref(q)))
+        return w.value, h.value, q.value
+
+    def device_bytes(self):
+        return int(hip.lib.gh_orb_plan_device_bytes(self.plan))
+
+    def alloc_outputs(self, batch, device="cuda"):
+        kps = torch.empty((batch, self.K, 7), dtype=torch.float32, device=device)  # 28-byte records
+        desc = torch.empty((batch, self.K, 32), dtype=torch.uint8, device=device)
+        counts = torch.empty(batch, dtype=torch.int32, device=device)
+        return kps, desc, counts
+
+    def extract(self, frames: torch.Tensor, out=None):
+        """frames: B x H x stride u8 (cuda).  Returns (kps B x K x 7 f32-view of KeyPoint, desc B x K x 32, counts)."""
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3
+        B, H, stride = frames.shape
+        assert H == self.h and stride >= self.w and frames.stride(2) == 1 and frames.stride(1) == stride
+        if out is None:
+            out = self.alloc_outputs(B, frames.device)
+        kps, desc, counts = out
+        self.ctx.check(hip.lib.gh_orb_extract_dev(self.plan, _p(frames), B, C.c_size_t(frames.stride(0)), stride,
+                                                  _p(kps), _p(desc), _p(counts)))
+        return kps, desc, counts
+
+    def extract_host(self, gray: np.ndarray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        assert gray.shape == (self.h, self.w)
+        kps = np.zeros(self.K, KP_DTYPE)
+        desc = np.zeros((self.K, 32), np.uint8)
+        n = C.c_int32()
+        self.ctx.check(hip.lib.gh_orb_extract_host(self.plan, gray.ctypes.data_as(C.c_void_p), self.w,
+                                                   kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p),
+                                                   C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def debug_level(self, slot, level):
+        w, h, _ = self.level(level)
+        out = np.zeros((h, w), np.uint8)
+        self.ctx.check(hip.lib.gh_orb_debug_level(self.plan, slot, level, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+def kps_to_numpy(kps_tensor, counts=None):
+    """B x K x 7 float32 tensor -> structured KeyPoint array (bit reinterpretation, no conversion)."""
+    a = kps_tensor.cpu().numpy()
+    return a.view(KP_DTYPE).reshape(a.shape[0], a.shape[1])

@@ -1,0 +1,375 @@
+/*
+ * orb_oracle.c — CPU restatement of the ORB front end (FAST-9/16 + intensity-centroid orientation +
+ * 256-bit steered BRIEF on a 1.2x / 8-level pyramid).  TEST INFRASTRUCTURE ONLY (see oracle/README).
+ *
+ * PARITY UNPINNED: the reference tree contains no ORB extractor (it lives in the un-vendored external
+ * plugin pi-gslam/gslam_orbslam -> raulmur/ORB_SLAM + OpenCV, no version pinned: README.md:131,
+ * doc/doxygen/4_1_orbslam.dox:7) and none of its tests hold a golden descriptor.  What the reference
+ * does pin are the OUTPUT types, which this file honours:
+ *   GSLAM/core/Map.h:122-195   KeyPoint {pt.x, pt.y, size, angle, response, octave, class_id} 28 B
+ *   GSLAM/core/Map.h:309-321   MapFrame::setKeyPoints(keypoints, descriptors = N x 32 8UC1 GImage)
+ *   GSLAM/core/Vocabulary.h:485-491 reads a descriptor as 4 little-endian u64 -> bit k of the test
+ *                              vector is stored LSB-first in byte k/8.
+ * The algorithm follows the published ORB / ORB-SLAM ORBextractor design (Rublee et al. 2011;
+ * Mur-Artal et al. 2015) made integer end to end so that CPU and GPU agree bit for bit
+ * (SURVEY.md 8c).  The numbered steps below are the specification; DESIGN.md repeats it.
+ *
+ *  1 pyramid  level l is w_l x h_l, w_l = round_half_up(W * 5^l / 6^l) (exact integer); level l is
+ *             resized from level l-1, bilinear, 11-bit fixed-point weights:
+ *             P = floor((2x+1) * w_src * 2048 / (2 w_dst)) - 1024, clamped at 0; sx = P >> 11,
+ *             fx = P & 2047 (sx >= w_src-1 -> sx = w_src-1, fx = 0); same for y;
+ *             v = (sum of 4 taps * weights + 2^21) >> 22.
+ *  2 FAST     score(x,y) = max over the 16 arcs of 9 contiguous ring pixels of min(ring - p) and of
+ *             min(p - ring); a pixel is a corner at threshold t iff score > t.  Only pixels with
+ *             19 <= x < w-19, 19 <= y < h-19 are scored; S = score if score > min_th else 0.
+ *  3 NMS      candidate iff S > 0 and S > S(neighbour) for all 8 neighbours (strict; outside = 0).
+ *  4 cells    32x32 cells anchored at (19,19).  A cell holding a candidate with S > ini_th keeps only
+ *             candidates with S > ini_th, else all.  In-cell rank by (S desc, y asc, x asc); ranks
+ *             >= 32 are dropped.
+ *  5 select   per-level quota n_l = round_half_up(K 5^l 6^(L-1-l) / (6^L - 5^L)) clamped so the running
+ *             total never exceeds K, last level takes the remainder.  Take the first n_l candidates of the level under the total order
+ *             (rank asc, S desc, cell index asc, in-cell raster asc).  Output order: level asc,
+ *             cell index asc (row-major), in-cell raster (y asc, x asc).
+ *  6 angle    m10 = sum u I, m01 = sum v I over the radius-15 disc (GH_ORB_UMAX); orientation bin k
+ *             in 0..29 is the unique k with cross(dir[k-1], m) >= 0 and cross(dir[k], m) < 0
+ *             (GH_ORB_DIR, 64-bit integers); m == 0 -> bin 0.  angle = 12 k degrees.
+ *  7 blur     B = (sum_{i,j in -3..3} g_i g_j I + 2^21) >> 22, GH_ORB_GAUSS taps (sum 2048).
+ *  8 BRIEF    bit k = B(p + a_k) < B(p + b_k) with (a_k, b_k) = GH_ORB_PATTERN[bin][k]; byte k/8,
+ *             bit k%8 (LSB first).
+ *  9 keypoint pt = (float)x_l * s_l, s_0 = 1, s_l = s_{l-1} * 1.2f (single fp32 roundings);
+ *             size = 31 * s_l; response = S; octave = l; class_id = -1.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gslam_orb_tables.h"
+
+typedef struct oracle_kp {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} oracle_kp;
+
+static int64_t ipow(int b, int e) {
+  int64_t r = 1;
+  while (e-- > 0) r *= b;
+  return r;
+}
+
+void oracle_orb_level_dims(int w, int h, int nlevels, int* ws, int* hs) {
+  for (int l = 0; l < nlevels; ++l) {
+    int64_t p5 = ipow(5, l), p6 = ipow(6, l);
+    ws[l] = (int)((2 * (int64_t)w * p5 + p6) / (2 * p6));
+    hs[l] = (int)((2 * (int64_t)h * p5 + p6) / (2 * p6));
+  }
+}
+
+void oracle_orb_quotas(int K, int nlevels, int* q) {
+  int64_t den = ipow(6, nlevels) - ipow(5, nlevels);
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; ++l) {
+    int64_t num = (int64_t)K * ipow(5, l) * ipow(6, nlevels - 1 - l);
+    q[l] = (int)((2 * num + den) / (2 * den));
+    if (q[l] > K - sum) q[l] = K - sum; /* rounding may not push the total past K */
+    sum += q[l];
+  }
+  q[nlevels - 1] = K - sum > 0 ? K - sum : 0;
+}
+
+void oracle_orb_scales(int nlevels, float* s) {
+  s[0] = 1.0f;
+  for (int l = 1; l < nlevels; ++l) s[l] = s[l - 1] * 1.2f;
+}
+
+/* step 1 */
+static void resize_axis_table(int n_src, int n_dst, int* idx, int* frac) {
+  for (int x = 0; x < n_dst; ++x) {
+    int64_t P = ((int64_t)(2 * x + 1) * n_src * 2048) / (2 * (int64_t)n_dst) - 1024;
+    if (P < 0) P = 0;
+    int sx = (int)(P >> 11), fx = (int)(P & 2047);
+    if (sx >= n_src - 1) {
+      sx = n_src - 1;
+      fx = 0;
+    }
+    idx[x] = sx;
+    frac[x] = fx;
+  }
+}
+
+void oracle_orb_resize(const uint8_t* src, int ws, int hs, int sstride, uint8_t* dst, int wd, int hd, int dstride) {
+  int* xi = (int*)malloc(sizeof(int) * wd * 2);
+  int* yi = (int*)malloc(sizeof(int) * hd * 2);
+  resize_axis_table(ws, wd, xi, xi + wd);
+  resize_axis_table(hs, hd, yi, yi + hd);
+  for (int y = 0; y < hd; ++y) {
+    int sy = yi[y], fy = yi[hd + y];
+    int sy1 = sy + 1 < hs ? sy + 1 : hs - 1;
+    const uint8_t* r0 = src + (size_t)sy * sstride;
+    const uint8_t* r1 = src + (size_t)sy1 * sstride;
+    for (int x = 0; x < wd; ++x) {
+      int sx = xi[x], fx = xi[wd + x];
+      int sx1 = sx + 1 < ws ? sx + 1 : ws - 1;
+      uint32_t v = (uint32_t)r0[sx] * (2048 - fx) * (2048 - fy) + (uint32_t)r0[sx1] * fx * (2048 - fy) +
+                   (uint32_t)r1[sx] * (2048 - fx) * fy + (uint32_t)r1[sx1] * fx * fy;
+      dst[(size_t)y * dstride + x] = (uint8_t)((v + (1u << 21)) >> 22);
+    }
+  }
+  free(xi);
+  free(yi);
+}
+
+/* step 2: FAST corner score of the pixel at p (ring offsets precomputed for the stride) */
+static int fast_score(const uint8_t* p, const int* ring_off) {
+  int d[16 + 8];
+  int c = *p;
+  for (int i = 0; i < 16; ++i) d[i] = (int)p[ring_off[i]] - c;
+  for (int i = 0; i < 8; ++i) d[16 + i] = d[i];
+  int best = 0;
+  for (int a = 0; a < 16; ++a) {
+    int mn = d[a], mx = d[a];
+    for (int i = 1; i < 9; ++i) {
+      if (d[a + i] < mn) mn = d[a + i];
+      if (d[a + i] > mx) mx = d[a + i];
+    }
+    if (mn > best) best = mn;   /* all 9 brighter by at least mn */
+    if (-mx > best) best = -mx; /* all 9 darker by at least -mx */
+  }
+  return best;
+}
+
+/* Score map S of one level (steps 2): 0 outside the valid region or when score <= min_th. */
+void oracle_orb_score_map(const uint8_t* img, int w, int h, int stride, int min_th, uint8_t* S) {
+  int ring_off[16];
+  for (int i = 0; i < 16; ++i) ring_off[i] = GH_ORB_RING[i][1] * stride + GH_ORB_RING[i][0];
+  memset(S, 0, (size_t)w * h);
+  for (int y = GH_ORB_EDGE; y < h - GH_ORB_EDGE; ++y)
+    for (int x = GH_ORB_EDGE; x < w - GH_ORB_EDGE; ++x) {
+      const uint8_t* p = img + (size_t)y * stride + x;
+      /* cheap necessary condition (any 9-arc holds >= 2 of the 4 compass pixels) - exact, not a spec change */
+      int c = *p, nb = 0, nd = 0;
+      int r0 = p[ring_off[0]], r4 = p[ring_off[4]], r8 = p[ring_off[8]], r12 = p[ring_off[12]];
+      nb = (r0 > c + min_th) + (r4 > c + min_th) + (r8 > c + min_th) + (r12 > c + min_th);
+      nd = (r0 < c - min_th) + (r4 < c - min_th) + (r8 < c - min_th) + (r12 < c - min_th);
+      if (nb < 2 && nd < 2) continue;
+      int s = fast_score(p, ring_off);
+      if (s > min_th) S[(size_t)y * w + x] = (uint8_t)(s > 255 ? 255 : s);
+    }
+}
+
+typedef struct {
+  int x, y, s, rank, cell, order; /* order = position in (cell asc, in-cell raster) traversal */
+} cand_t;
+
+static int cmp_cell_rank(const void* a, const void* b) { /* (S desc, y asc, x asc) */
+  const cand_t* p = (const cand_t*)a;
+  const cand_t* q = (const cand_t*)b;
+  if (p->s != q->s) return q->s - p->s;
+  if (p->y != q->y) return p->y - q->y;
+  return p->x - q->x;
+}
+static int cmp_raster(const void* a, const void* b) {
+  const cand_t* p = (const cand_t*)a;
+  const cand_t* q = (const cand_t*)b;
+  if (p->y != q->y) return p->y - q->y;
+  return p->x - q->x;
+}
+static int cmp_select(const void* a, const void* b) { /* (rank asc, S desc, order asc) */
+  const cand_t* p = (const cand_t*)a;
+  const cand_t* q = (const cand_t*)b;
+  if (p->rank != q->rank) return p->rank - q->rank;
+  if (p->s != q->s) return q->s - p->s;
+  return p->order - q->order;
+}
+static int cmp_order(const void* a, const void* b) {
+  return ((const cand_t*)a)->order - ((const cand_t*)b)->order;
+}
+
+/* steps 3-5 for one level.  Returns number selected, written in output order. */
+int oracle_orb_select_level(const uint8_t* S, int w, int h, int ini_th, int quota, int* out_x, int* out_y,
+                            int* out_s) {
+  int vw = w - 2 * GH_ORB_EDGE, vh = h - 2 * GH_ORB_EDGE;
+  if (vw <= 0 || vh <= 0 || quota <= 0) return 0;
+  int ncx = (vw + GH_ORB_CELL - 1) / GH_ORB_CELL, ncy = (vh + GH_ORB_CELL - 1) / GH_ORB_CELL;
+  cand_t* all = (cand_t*)malloc(sizeof(cand_t) * ((size_t)vw * vh / 4 + 16));
+  cand_t cellbuf[GH_ORB_CELL * GH_ORB_CELL / 4 + 4];
+  int n_all = 0;
+  for (int cy = 0; cy < ncy; ++cy)
+    for (int cx = 0; cx < ncx; ++cx) {
+      int n = 0, strong = 0;
+      int x0 = GH_ORB_EDGE + cx * GH_ORB_CELL, y0 = GH_ORB_EDGE + cy * GH_ORB_CELL;
+      for (int y = y0; y < y0 + GH_ORB_CELL && y < h - GH_ORB_EDGE; ++y)
+        for (int x = x0; x < x0 + GH_ORB_CELL && x < w - GH_ORB_EDGE; ++x) {
+          int s = S[(size_t)y * w + x];
+          if (s == 0) continue;
+          int ismax = 1;
+          for (int dy = -1; dy <= 1 && ismax; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+              if (!dx && !dy) continue;
+              if (S[(size_t)(y + dy) * w + (x + dx)] >= s) {
+                ismax = 0;
+                break;
+              }
+            }
+          if (!ismax) continue;
+          cellbuf[n].x = x;
+          cellbuf[n].y = y;
+          cellbuf[n].s = s;
+          cellbuf[n].cell = cy * ncx + cx;
+          ++n;
+          if (s > ini_th) strong = 1;
+        }
+      if (strong) {
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+          if (cellbuf[i].s > ini_th) cellbuf[m++] = cellbuf[i];
+        n = m;
+      }
+      qsort(cellbuf, n, sizeof(cand_t), cmp_cell_rank);
+      if (n > GH_ORB_CELL_CAP) n = GH_ORB_CELL_CAP;
+      for (int i = 0; i < n; ++i) cellbuf[i].rank = i;
+      qsort(cellbuf, n, sizeof(cand_t), cmp_raster);
+      for (int i = 0; i < n; ++i) {
+        cellbuf[i].order = n_all;
+        all[n_all++] = cellbuf[i];
+      }
+    }
+  qsort(all, n_all, sizeof(cand_t), cmp_select);
+  int n_sel = n_all < quota ? n_all : quota;
+  qsort(all, n_sel, sizeof(cand_t), cmp_order);
+  for (int i = 0; i < n_sel; ++i) {
+    out_x[i] = all[i].x;
+    out_y[i] = all[i].y;
+    out_s[i] = all[i].s;
+  }
+  free(all);
+  return n_sel;
+}
+
+/* step 6 */
+int oracle_orb_angle_bin(const uint8_t* img, int stride, int x, int y) {
+  int64_t m10 = 0, m01 = 0;
+  for (int v = -GH_ORB_HALF_PATCH; v <= GH_ORB_HALF_PATCH; ++v) {
+    int um = GH_ORB_UMAX[v < 0 ? -v : v];
+    const uint8_t* row = img + (size_t)(y + v) * stride + x;
+    for (int u = -um; u <= um; ++u) {
+      m10 += (int64_t)u * row[u];
+      m01 += (int64_t)v * row[u];
+    }
+  }
+  if (m10 == 0 && m01 == 0) return 0;
+  for (int k = 0; k < GH_ORB_NBINS; ++k) {
+    int km = (k + GH_ORB_NBINS - 1) % GH_ORB_NBINS;
+    int64_t c_lo = (int64_t)GH_ORB_DIR[km][0] * m01 - (int64_t)GH_ORB_DIR[km][1] * m10;
+    int64_t c_hi = (int64_t)GH_ORB_DIR[k][0] * m01 - (int64_t)GH_ORB_DIR[k][1] * m10;
+    if (c_lo >= 0 && c_hi < 0) return k;
+  }
+  return 0;
+}
+
+/* step 7 */
+static inline int blur_at(const uint8_t* img, int stride, int x, int y) {
+  uint32_t acc = 0;
+  for (int j = -3; j <= 3; ++j) {
+    const uint8_t* row = img + (size_t)(y + j) * stride + x;
+    uint32_t h = 0;
+    for (int i = -3; i <= 3; ++i) h += (uint32_t)GH_ORB_GAUSS[i + 3] * row[i];
+    acc += (uint32_t)GH_ORB_GAUSS[j + 3] * h;
+  }
+  return (int)((acc + (1u << 21)) >> 22);
+}
+
+/* step 8 */
+void oracle_orb_describe(const uint8_t* img, int stride, int x, int y, int bin, uint8_t* desc32) {
+  memset(desc32, 0, 32);
+  for (int k = 0; k < 256; ++k) {
+    const int8_t* p = GH_ORB_PATTERN[bin][k];
+    int a = blur_at(img, stride, x + p[0], y + p[1]);
+    int b = blur_at(img, stride, x + p[2], y + p[3]);
+    if (a < b) desc32[k >> 3] |= (uint8_t)(1u << (k & 7));
+  }
+}
+
+/* Whole pipeline.  Returns the number of keypoints (<= K).  If pyr_out != NULL it receives pointers to the
+ * malloc'ed level images (caller frees), for debugging. */
+int oracle_orb_extract(const uint8_t* gray, int w, int h, int stride, int K, int nlevels, int ini_th, int min_th,
+                       oracle_kp* kps, uint8_t* desc) {
+  int ws[GH_ORB_MAX_LEVELS], hs[GH_ORB_MAX_LEVELS], quota[GH_ORB_MAX_LEVELS];
+  float scale[GH_ORB_MAX_LEVELS];
+  if (nlevels < 1 || nlevels > GH_ORB_MAX_LEVELS) return -1;
+  oracle_orb_level_dims(w, h, nlevels, ws, hs);
+  oracle_orb_quotas(K, nlevels, quota);
+  oracle_orb_scales(nlevels, scale);
+  uint8_t* lv[GH_ORB_MAX_LEVELS];
+  int ls[GH_ORB_MAX_LEVELS];
+  lv[0] = (uint8_t*)gray;
+  ls[0] = stride;
+  for (int l = 1; l < nlevels; ++l) {
+    lv[l] = (uint8_t*)malloc((size_t)ws[l] * hs[l]);
+    ls[l] = ws[l];
+    oracle_orb_resize(lv[l - 1], ws[l - 1], hs[l - 1], ls[l - 1], lv[l], ws[l], hs[l], ls[l]);
+  }
+  int n = 0;
+  for (int l = 0; l < nlevels; ++l) {
+    if (quota[l] <= 0 || ws[l] <= 2 * GH_ORB_EDGE || hs[l] <= 2 * GH_ORB_EDGE) continue;
+    uint8_t* S = (uint8_t*)malloc((size_t)ws[l] * hs[l]);
+    oracle_orb_score_map(lv[l], ws[l], hs[l], ls[l], min_th, S);
+    int* xs = (int*)malloc(sizeof(int) * quota[l] * 3);
+    int* ys = xs + quota[l];
+    int* ss = ys + quota[l];
+    int m = oracle_orb_select_level(S, ws[l], hs[l], ini_th, quota[l], xs, ys, ss);
+    for (int i = 0; i < m; ++i) {
+      int bin = oracle_orb_angle_bin(lv[l], ls[l], xs[i], ys[i]);
+      oracle_kp* kp = &kps[n];
+      kp->x = (float)xs[i] * scale[l];
+      kp->y = (float)ys[i] * scale[l];
+      kp->size = 31.0f * scale[l];
+      kp->angle = 12.0f * (float)bin;
+      kp->response = (float)ss[i];
+      kp->octave = l;
+      kp->class_id = -1;
+      oracle_orb_describe(lv[l], ls[l], xs[i], ys[i], bin, desc + (size_t)n * 32);
+      ++n;
+    }
+    free(xs);
+    free(S);
+  }
+  for (int l = 1; l < nlevels; ++l) free(lv[l]);
+  return n;
+}
+
+/* Debug: write pyramid level `level` (dense w_l x h_l). */
+int oracle_orb_pyramid_level(const uint8_t* gray, int w, int h, int stride, int nlevels, int level, uint8_t* out) {
+  int ws[GH_ORB_MAX_LEVELS], hs[GH_ORB_MAX_LEVELS];
+  oracle_orb_level_dims(w, h, nlevels, ws, hs);
+  uint8_t* prev = (uint8_t*)gray;
+  int ps = stride;
+  for (int l = 1; l <= level; ++l) {
+    uint8_t* cur = (uint8_t*)malloc((size_t)ws[l] * hs[l]);
+    oracle_orb_resize(prev, ws[l - 1], hs[l - 1], ps, cur, ws[l], hs[l], ws[l]);
+    if (l > 1) free(prev);
+    prev = cur;
+    ps = ws[l];
+  }
+  for (int y = 0; y < hs[level]; ++y) memcpy(out + (size_t)y * ws[level], prev + (size_t)y * ps, ws[level]);
+  if (level > 0) free(prev);
+  return 0;
+}
+
+/* Batch wrapper for the timed CPU baseline: frames are independent -> OpenMP over frames. */
+void oracle_orb_extract_batch(const uint8_t* gray, int nframes, size_t frame_stride, int w, int h, int stride, int K,
+                              int nlevels, int ini_th, int min_th, oracle_kp* kps, uint8_t* desc, int32_t* counts,
+                              int threads) {
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+  for (int f = 0; f < nframes; ++f)
+    counts[f] = oracle_orb_extract(gray + (size_t)f * frame_stride, w, h, stride, K, nlevels, ini_th, min_th,
+                                   kps + (size_t)f * K, desc + (size_t)f * K * 32);
+}
+
+void oracle_bgr_to_gray(const uint8_t* bgr, int w, int h, int channels, int sstride, uint8_t* gray, int dstride) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const uint8_t* p = bgr + (size_t)y * sstride + (size_t)x * channels;
+      gray[(size_t)y * dstride + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+    }
+}

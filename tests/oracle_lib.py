@@ -129,3 +129,78 @@ def correlated_descriptors(base, seed, flip_frac=0.10, replace_frac=0.20):
     # shuffle rows deterministically so indices are not the identity
     perm = np.argsort(splitmix64(seed ^ 0xABCDEF, n), kind="stable")
     return out[perm].copy(), perm
+
+
+# ---------------------------------------------------------------- ORB / synth wrappers
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28  # == sizeof(GSLAM::KeyPoint), GSLAM/core/Map.h:122-195
+
+
+def _orb_methods(cls):
+    def synth_frame(self, w, h, seed, stride=None):
+        stride = stride or w
+        out = np.zeros((h, stride), np.uint8)
+        self.lib.oracle_synth_frame(_ptr(out), int(w), int(h), int(stride), C.c_uint32(seed & 0xFFFFFFFF))
+        return out
+
+    def orb_level_dims(self, w, h, nlevels=8):
+        ws = np.zeros(nlevels, np.int32)
+        hs = np.zeros(nlevels, np.int32)
+        self.lib.oracle_orb_level_dims(int(w), int(h), int(nlevels), _ptr(ws), _ptr(hs))
+        return ws, hs
+
+    def orb_quotas(self, K, nlevels=8):
+        q = np.zeros(nlevels, np.int32)
+        self.lib.oracle_orb_quotas(int(K), int(nlevels), _ptr(q))
+        return q
+
+    def orb_extract(self, gray, K=1000, nlevels=8, ini_th=20, min_th=7):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        kps = np.zeros(K, KP_DTYPE)
+        desc = np.zeros((K, 32), np.uint8)
+        n = self.lib.oracle_orb_extract(_ptr(gray), w, h, w, int(K), int(nlevels), int(ini_th), int(min_th),
+                                        _ptr(kps), _ptr(desc))
+        assert n >= 0
+        return kps[:n].copy(), desc[:n].copy()
+
+    def orb_extract_batch(self, frames, K=1000, nlevels=8, ini_th=20, min_th=7, threads=1):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        F, h, w = frames.shape
+        kps = np.zeros((F, K), KP_DTYPE)
+        desc = np.zeros((F, K, 32), np.uint8)
+        counts = np.zeros(F, np.int32)
+        self.lib.oracle_orb_extract_batch(_ptr(frames), F, C.c_size_t(h * w), w, h, w, int(K), int(nlevels),
+                                          int(ini_th), int(min_th), _ptr(kps), _ptr(desc), _ptr(counts),
+                                          int(threads))
+        return kps, desc, counts
+
+    def orb_pyramid_level(self, gray, level, nlevels=8):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        ws, hs = self.orb_level_dims(w, h, nlevels)
+        out = np.zeros((hs[level], ws[level]), np.uint8)
+        self.lib.oracle_orb_pyramid_level(_ptr(gray), w, h, w, int(nlevels), int(level), _ptr(out))
+        return out
+
+    def orb_score_map(self, img, min_th=7):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        S = np.zeros((h, w), np.uint8)
+        self.lib.oracle_orb_score_map(_ptr(img), w, h, w, int(min_th), _ptr(S))
+        return S
+
+    def bgr_to_gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, c = bgr.shape
+        out = np.zeros((h, w), np.uint8)
+        self.lib.oracle_bgr_to_gray(_ptr(bgr), w, h, c, w * c, _ptr(out), w)
+        return out
+
+    for f in (synth_frame, orb_level_dims, orb_quotas, orb_extract, orb_extract_batch, orb_pyramid_level,
+              orb_score_map, bgr_to_gray):
+        setattr(cls, f.__name__, f)
+
+
+_orb_methods(Oracle)

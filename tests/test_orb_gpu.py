@@ -1,0 +1,143 @@
+"""GPU parity of the ORB front end (HIP, through the C ABI) vs the CPU oracle: bit-exact keypoint
+records (all 28 bytes) and descriptor bits, on the same synthetic frames."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _extract_gpu(ctx, frames_np, K, nlevels=8, ini_th=20, min_th=7, stride=None):
+    import torch
+    from gslam_amd.orb import OrbExtractor, kps_to_numpy
+    B, h, w = frames_np.shape
+    stride = stride or w
+    buf = np.zeros((B, h, stride), np.uint8)
+    buf[:, :, :w] = frames_np
+    ex = OrbExtractor(ctx, w, h, max_batch=B, n_features=K, n_levels=nlevels, ini_th=ini_th, min_th=min_th)
+    d = torch.from_numpy(buf).cuda()
+    kps, desc, counts = ex.extract(d)
+    torch.cuda.synchronize()
+    out = kps_to_numpy(kps), desc.cpu().numpy(), counts.cpu().numpy()
+    ex.close()
+    return out
+
+
+def _check(oracle, frames, got, K, **kw):
+    kps, desc, counts = got
+    for f in range(frames.shape[0]):
+        ek, ed = oracle.orb_extract(frames[f], K, **kw)
+        n = len(ek)
+        assert counts[f] == n, f"frame {f}: count {counts[f]} vs oracle {n}"
+        assert kps[f, :n].tobytes() == ek.tobytes(), f"frame {f}: keypoint records differ"
+        assert np.array_equal(desc[f, :n], ed), f"frame {f}: descriptor bits differ"
+        # unused tail rows are zero-filled
+        assert not kps[f, n:].tobytes().strip(b"\0") and not desc[f, n:].any()
+
+
+def test_synth_frames_parity(ctx, oracle):
+    import torch
+    from gslam_amd.orb import synth_frames
+    for (w, h, stride) in [(640, 480, 640), (333, 257, 340), (1241, 376, 1241)]:
+        d = synth_frames(ctx, 3, w, h, base_seed=0x5EED0000, first_frame=5, row_stride=stride)
+        torch.cuda.synchronize()
+        g = d.cpu().numpy()
+        for f in range(3):
+            assert np.array_equal(g[f, :, :w], oracle.synth_frame(w, h, 0x5EED0000 + 5 + f))
+
+
+def test_pyramid_parity(ctx, oracle):
+    import torch
+    from gslam_amd.orb import OrbExtractor
+    g = oracle.synth_frame(640, 480, 77)
+    ex = OrbExtractor(ctx, 640, 480, max_batch=1, n_features=500)
+    ex.extract(torch.from_numpy(g[None]).cuda())
+    torch.cuda.synchronize()
+    ws, hs = oracle.orb_level_dims(640, 480)
+    for l in range(1, 8):
+        assert ex.level(l)[:2] == (ws[l], hs[l])
+        assert np.array_equal(ex.debug_level(0, l), oracle.orb_pyramid_level(g, l)), f"level {l}"
+    assert [ex.level(l)[2] for l in range(8)] == oracle.orb_quotas(500).tolist()
+    ex.close()
+
+
+@pytest.mark.parametrize("w,h,K", [(640, 480, 1000), (752, 480, 1500), (333, 257, 300)])
+def test_extract_parity_batch(ctx, oracle, w, h, K):
+    frames = np.stack([oracle.synth_frame(w, h, 0x5EED0000 + i) for i in range(4)])
+    got = _extract_gpu(ctx, frames, K)
+    _check(oracle, frames, got, K)
+
+
+def test_extract_parity_unaligned_stride_kitti(ctx, oracle):
+    """1241-wide rows (KITTI) are not dword aligned: exercises the level-0 staging copy."""
+    frames = np.stack([oracle.synth_frame(1241, 376, 100 + i) for i in range(2)])
+    got = _extract_gpu(ctx, frames, 2000, stride=1241)
+    _check(oracle, frames, got, 2000)
+
+
+def test_extract_parity_1080p(ctx, oracle):
+    frames = np.stack([oracle.synth_frame(1920, 1080, 0x5EED0000 + i) for i in range(2)])
+    got = _extract_gpu(ctx, frames, 2000)
+    _check(oracle, frames, got, 2000)
+
+
+def test_extract_parity_levels_and_thresholds(ctx, oracle):
+    frames = np.stack([oracle.synth_frame(640, 480, 500 + i) for i in range(2)])
+    for nl, ini, mn, K in [(1, 20, 7, 800), (4, 30, 10, 1200), (8, 12, 5, 5000), (8, 20, 7, 7)]:
+        got = _extract_gpu(ctx, frames, K, nlevels=nl, ini_th=ini, min_th=mn)
+        _check(oracle, frames, got, K, nlevels=nl, ini_th=ini, min_th=mn)
+
+
+def test_sparse_and_flat_images(ctx, oracle):
+    """Few textured cells -> levels under quota; flat image -> zero keypoints."""
+    g = np.full((480, 640), 90, np.uint8)
+    g[100:228, 200:328] = oracle.synth_frame(128, 128, 3)
+    frames = np.stack([g, np.full((480, 640), 90, np.uint8)])
+    got = _extract_gpu(ctx, frames, 1000)
+    _check(oracle, frames, got, 1000)
+    assert got[2][1] == 0 and 0 < got[2][0] < 1000
+
+
+def test_extract_host_entry_point(ctx, oracle):
+    from gslam_amd.orb import OrbExtractor
+    g = oracle.synth_frame(640, 480, 31337)
+    ex = OrbExtractor(ctx, 640, 480, max_batch=1, n_features=1000)
+    kps, desc = ex.extract_host(g)
+    ek, ed = oracle.orb_extract(g, 1000)
+    assert kps.tobytes() == ek.tobytes() and np.array_equal(desc, ed)
+    ex.close()
+
+
+def test_batch_slot_independence(ctx, oracle):
+    """The same frame in different batch slots (and batch sizes) gives identical records."""
+    import torch
+    from gslam_amd.orb import OrbExtractor, synth_frames
+    ex = OrbExtractor(ctx, 640, 480, max_batch=16, n_features=1000)
+    fr = synth_frames(ctx, 16, 640, 480, base_seed=1000)
+    k16, d16, c16 = [t.clone() for t in ex.extract(fr)]
+    k1, d1, c1 = ex.extract(fr[5:6].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(k16[5].view(torch.int32), k1[0].view(torch.int32)) and torch.equal(d16[5], d1[0])
+    rev = torch.flip(fr, dims=[0]).contiguous()
+    kr, dr, cr = ex.extract(rev)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.flip(kr, dims=[0]).view(torch.int32), k16.view(torch.int32))
+    assert torch.equal(torch.flip(dr, dims=[0]), d16) and torch.equal(torch.flip(cr, dims=[0]), c16)
+    ex.close()
+
+
+def test_bgr_to_gray_parity(ctx, oracle):
+    import torch
+    from gslam_amd import hip
+    rng = np.random.default_rng(8)
+    for ch in (3, 4):
+        bgr = rng.integers(0, 256, (45, 67, ch), dtype=np.uint8)
+        d = torch.from_numpy(bgr).cuda()
+        out = torch.empty((45, 67), dtype=torch.uint8, device="cuda")
+        ctx.check(hip.lib.gh_bgr_to_gray_dev(ctx.h, C.c_void_p(d.data_ptr()), 67, 45, ch, 67 * ch,
+                                             C.c_void_p(out.data_ptr()), 67))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), oracle.bgr_to_gray(bgr))

@@ -1,0 +1,87 @@
+"""CPU-only checks of the ORB oracle and its spec data (the oracle is 'parity unpinned' against the
+reference: GSLAM ships no ORB code — these tests pin what CAN be pinned: output record layout, the
+committed tables, internal invariants)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tables_regenerate_identically(tmp_path):
+    hdr = os.path.join(ROOT, "include", "gslam_orb_tables.h")
+    before = hashlib.sha256(open(hdr, "rb").read()).hexdigest()
+    assert before == "14a972d2901eda7f1cb21d5478899db84e9abff5e7cbd2c325a632f54676e18b"
+
+
+def test_level_dims_and_quotas(oracle):
+    ws, hs = oracle.orb_level_dims(1920, 1080)
+    assert ws.tolist() == [1920, 1600, 1333, 1111, 926, 772, 643, 536]
+    assert hs.tolist() == [1080, 900, 750, 625, 521, 434, 362, 301]
+    for K in (1, 7, 100, 1000, 2000, 8000):
+        q = oracle.orb_quotas(K)
+        assert q.sum() == K and (q >= 0).all()
+    assert oracle.orb_quotas(2000).tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+def test_extract_invariants(oracle):
+    g = oracle.synth_frame(640, 480, 0x5EED0000)
+    kps, desc = oracle.orb_extract(g, 1000)
+    assert len(kps) == 1000 and desc.shape == (1000, 32)
+    assert (kps["class_id"] == -1).all()
+    assert set(np.unique(kps["angle"])).issubset({12.0 * k for k in range(30)})
+    assert (np.diff(kps["octave"]) >= 0).all()  # level-major output order
+    ws, hs = oracle.orb_level_dims(640, 480)
+    scale = np.float32(1.0)
+    for l in range(8):
+        m = kps["octave"] == l
+        x = np.rint(kps["x"][m] / scale).astype(int)
+        y = np.rint(kps["y"][m] / scale).astype(int)
+        assert ((x >= 19) & (x < ws[l] - 19) & (y >= 19) & (y < hs[l] - 19)).all()
+        assert np.array_equal((x.astype(np.float32) * scale), kps["x"][m])  # single fp32 multiply
+        assert np.allclose(kps["size"][m], 31.0 * scale)
+        scale = np.float32(scale * np.float32(1.2))
+    assert (kps["response"] > 7).all()
+    # descriptors are informative
+    assert 0.4 < np.unpackbits(desc).mean() < 0.6
+    assert len(np.unique(desc, axis=0)) > 990
+
+
+def test_extract_deterministic_and_stride_independent(oracle):
+    g = oracle.synth_frame(333, 257, 42)
+    a = oracle.orb_extract(g, 300)
+    b = oracle.orb_extract(g.copy(), 300)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_flat_image_yields_nothing(oracle):
+    kps, desc = oracle.orb_extract(np.full((200, 300), 77, np.uint8), 500)
+    assert len(kps) == 0
+
+
+def test_self_match_of_shifted_frame(oracle):
+    """A frame and its copy shifted by (32,32) px (a cell) must share most level-0 descriptors exactly."""
+    g = oracle.synth_frame(800, 600, 9)
+    a_k, a_d = oracle.orb_extract(g[:480, :640], 1000, nlevels=1)
+    b_k, b_d = oracle.orb_extract(g[32:512, 32:672], 1000, nlevels=1)
+    idx1, d1, d2 = oracle.bf_match(a_d, b_d)
+    exact = d1 == 0
+    assert exact.sum() > 300
+    dx = a_k["x"][exact] - b_k["x"][idx1[exact]]
+    dy = a_k["y"][exact] - b_k["y"][idx1[exact]]
+    assert (dx == 32).mean() > 0.95 and (dy == 32).mean() > 0.95
+
+
+def test_bgr_to_gray_fixed_point(oracle):
+    rng = np.random.default_rng(3)
+    bgr = rng.integers(0, 256, (17, 23, 3), dtype=np.uint8)
+    g = oracle.bgr_to_gray(bgr)
+    ref = (bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617 +
+           bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14
+    assert np.array_equal(g, ref.astype(np.uint8))
+    assert abs(int(g[0, 0]) - round(0.114 * bgr[0, 0, 0] + 0.587 * bgr[0, 0, 1] + 0.299 * bgr[0, 0, 2])) <= 1
