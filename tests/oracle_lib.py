@@ -204,3 +204,80 @@ def _orb_methods(cls):
 
 
 _orb_methods(Oracle)
+
+
+# ---------------------------------------------------------------- BA wrappers
+BA_MAX_TRACE = 512
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("huber_delta", C.c_double), ("max_iterations", C.c_int32), ("initial_radius", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("min_relative_decrease", C.c_double), ("verbose", C.c_int32), ("deterministic", C.c_int32)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("accepted", C.c_int32), ("termination", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms_total", C.c_double),
+                ("total_ms", C.c_double), ("trace_len", C.c_int32),
+                ("trace_cost", C.c_double * BA_MAX_TRACE), ("trace_radius", C.c_double * BA_MAX_TRACE),
+                ("trace_accepted", C.c_uint8 * BA_MAX_TRACE)]
+
+
+def ba_options(huber=0.01, max_iterations=50):
+    return BaOptions(huber, max_iterations, 1e4, 1e-6, 1e-10, 1e-3, 0, 0)
+
+
+def _ba_methods(cls):
+    def ba_solve(self, g, opts=None, threads=1):
+        """g: dict from gslam_amd.ba_synth.make_graph.  Returns (poses, points, summary)."""
+        opts = opts or ba_options()
+        poses = np.ascontiguousarray(g["cam_pose"], dtype=np.float64).copy()
+        pts = np.ascontiguousarray(g["point_xyz"], dtype=np.float64).copy()
+        dof = np.ascontiguousarray(g["cam_dof"], dtype=np.int32)
+        pfree = g.get("point_free")
+        info = g.get("obs_info")
+        s = BaSummary()
+        self.lib.oracle_ba_solve.restype = C.c_int
+        rc = self.lib.oracle_ba_solve(len(poses), len(pts), len(g["obs_cam"]), _ptr(poses), _ptr(dof), _ptr(pts),
+                                      _ptr(pfree), _ptr(np.ascontiguousarray(g["obs_cam"], dtype=np.int32)),
+                                      _ptr(np.ascontiguousarray(g["obs_point"], dtype=np.int32)),
+                                      _ptr(np.ascontiguousarray(g["obs_xy"], dtype=np.float64)), _ptr(info),
+                                      C.byref(opts), C.byref(s), int(threads))
+        return poses, pts, s, rc
+
+    def ba_cost(self, g, poses=None, pts=None, huber=0.01):
+        poses = np.ascontiguousarray(g["cam_pose"] if poses is None else poses, dtype=np.float64)
+        pts = np.ascontiguousarray(g["point_xyz"] if pts is None else pts, dtype=np.float64)
+        self.lib.oracle_ba_cost.restype = C.c_double
+        return self.lib.oracle_ba_cost(len(poses), len(pts), len(g["obs_cam"]), _ptr(poses), _ptr(pts),
+                                       _ptr(np.ascontiguousarray(g["obs_cam"], dtype=np.int32)),
+                                       _ptr(np.ascontiguousarray(g["obs_point"], dtype=np.int32)),
+                                       _ptr(np.ascontiguousarray(g["obs_xy"], dtype=np.float64)),
+                                       _ptr(g.get("obs_info")), C.c_double(huber))
+
+    def se3_exp(self, xi):
+        out = np.zeros(7)
+        self.lib.oracle_se3_exp(_ptr(np.ascontiguousarray(xi, dtype=np.float64)), _ptr(out))
+        return out
+
+    def se3_retract(self, pose, xi):
+        out = np.zeros(7)
+        self.lib.oracle_se3_retract(_ptr(np.ascontiguousarray(pose, dtype=np.float64)),
+                                    _ptr(np.ascontiguousarray(xi, dtype=np.float64)), _ptr(out))
+        return out
+
+    def potrf_solve(self, A, b, threads=1):
+        A = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+        b = np.ascontiguousarray(b, dtype=np.float64).copy()
+        self.lib.oracle_potrf.restype = C.c_int
+        info = self.lib.oracle_potrf(_ptr(A), A.shape[0], int(threads))
+        if info == 0:
+            self.lib.oracle_potrs(_ptr(A), A.shape[0], _ptr(b))
+        return np.tril(A), b, info
+
+    for f in (ba_solve, ba_cost, se3_exp, se3_retract, potrf_solve):
+        setattr(cls, f.__name__, f)
+
+
+_ba_methods(Oracle)
