@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X hot path of GSLAM (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
+
+One STEP = one pass of the ORB front end + brute-force matcher over one batch of synthetic frames
+already resident in HBM (BASELINE.json configs[1], "C2"): `--frames` 1920x1080 gray frames per GPU,
+2000 ORB keypoints each, 256-bit BF Hamming matching of every consecutive frame pair.  With N GPUs
+each rank owns `--frames` frames (weak scaling), descriptors and match records are exchanged with
+one RCCL all-gather each (north_star: "RCCL all-gather of descriptors/match pairs"), no other collective.
+
+Printed JSON line (rank 0): metric = extract+match Mkeypoints/s over the whole job, plus
+  roofline      the dominant kernel's algorithmic bytes / its HIP-event time vs 8 TB/s HBM
+  cpu_baseline  the CPU oracle ("port": no ORB implementation exists in the reference tree) timed on
+                this box's host cores on a bounded sample of the same workload
+  extra         BF Gpairs/s (against the measured VALU ceiling) and BA LM-iterations/s on C4
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK = 78.6e12   # FLOP/s dense f64 matrix
+
+
+def orb_bytes_per_frame(w, h, k):
+    """B_orb = 14.40 W H + 1021 K (8 levels, 1.2x)."""
+    return 14.40 * w * h + 1021.0 * k
+
+
+# SURVEY.md 8(d) split of the 14.40 W H + 1021 K figure by pipeline stage (bytes / frame)
+def stage_bytes(w, h, k):
+    return {
+        "orb_resize": (3.018 + 2.096) * w * h,      # pyramid reads + writes
+        "orb_fast_cells": 3.096 * w * h,            # FAST/NMS read of all levels
+        "orb_describe": 6.191 * w * h + 1021.0 * k,  # blur read+write (fused away here) + patch, kp, desc
+        "orb_select": 0.0,
+    }
+
+
+def host_cores():
+    """Usable host cores: affinity mask, further limited by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (C2: 1000)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--kpts", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="bounded CPU sample (frames)")
+    ap.add_argument("--ba-cams", type=int, default=500)
+    ap.add_argument("--ba-points", type=int, default=50000)
+    ap.add_argument("--ba-iters", type=int, default=12)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (gslam_amd has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gslam_amd import hip
+    from gslam_amd.matcher import BFMatcher
+    from gslam_amd.orb import OrbExtractor, synth_frames
+    from gslam_amd.sharding import exchange_features, exchange_matches, local_pairs
+
+    ctx = hip.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    F, W, H, K = a.frames, a.width, a.height, a.kpts
+    ex = OrbExtractor(ctx, W, H, max_batch=F, n_features=K)
+    matcher = BFMatcher(ctx)
+    # synthetic frames resident in HBM before the timed region; global frame index = rank * F + f
+    frames = synth_frames(ctx, F, W, H, base_seed=0x5EED0000, first_frame=rank * F, device=dev)
+    kps, desc, counts = ex.alloc_outputs(F, dev)
+    # gathered buffers (every GPU holds every frame's descriptors after the exchange)
+    g_desc = torch.empty((world * F, K, 32), dtype=torch.uint8, device=dev) if world > 1 else desc
+    g_counts = torch.empty(world * F, dtype=torch.int32, device=dev) if world > 1 else counts
+    pq, pt = local_pairs(rank, world, F, dev)
+    P = pq.shape[0]
+    m_idx = torch.empty((P, K), dtype=torch.int32, device=dev)
+    m_d1 = torch.empty((P, K), dtype=torch.int16, device=dev)
+    m_d2 = torch.empty((P, K), dtype=torch.int16, device=dev)
+    g_match = torch.empty((world, F, K), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        ex.extract(frames, (kps, desc, counts))
+        if world > 1:
+            exchange_features(desc, counts, g_desc, g_counts)
+        matcher.match_pairs(g_desc, g_counts, pq, pt, out=(m_idx, m_d1, m_d2))
+        if world > 1:
+            exchange_matches(m_idx, g_match, F)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ctx.prof_enable(True)  # HIP events on the launch stream, per kernel, over the timed region
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nk = counts.sum().to(torch.int64)
+        dist.all_reduce(nk)
+        total_kpts_step = int(nk.item())
+    else:
+        total_kpts_step = int(counts.sum().item())
+    n_pairs_step = int((g_counts[pq.long()].to(torch.int64) * g_counts[pt.long()].to(torch.int64)).sum().item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    log(f"timed region done: {elapsed:.3f}s for {a.steps} steps")
+    ms_per_step = elapsed * 1e3 / a.steps
+    value = total_kpts_step * a.steps / elapsed / 1e6
+    # ---- roofline of the dominant kernel (largest share of HIP-event time in the timed region)
+    sb = stage_bytes(W, H, K)
+    orb_k = {k: v for k, v in prof.items() if k.startswith("orb_")}
+    dom = max(orb_k, key=lambda k: orb_k[k]["total_ms"])
+    launches = prof[dom]["launches"]
+    avg_ms = prof[dom]["total_ms"] / launches
+    alg_bytes_per_launch = sb.get(dom, 0.0) * F * a.steps / launches
+    achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
+    orb_ms = sum(v["total_ms"] for v in orb_k.values())
+    pipeline = {"bound": "hbm", "what": "whole ORB pipeline vs B_orb = 14.40 W H + 1021 K",
+                "achieved": round(orb_bytes_per_frame(W, H, K) * F * a.steps / (orb_ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+    pipeline["frac"] = round(pipeline["achieved"] * 1e9 / HBM_PEAK, 4)
+    bf_ms = prof.get("bf_match_pairs", {}).get("total_ms", 0.0)
+    valu_ceiling = matcher.valu_probe()
+    bf = {"Gpairs_per_s": round(n_pairs_step * a.steps / (bf_ms * 1e-3) / 1e9, 1) if bf_ms else None,
+          "bound": "valu", "valu_ceiling_Gpairs_per_s": round(valu_ceiling / 1e9, 1),
+          "pairs_per_step": n_pairs_step}
+    if bf["Gpairs_per_s"]:
+        bf["frac"] = round(bf["Gpairs_per_s"] / bf["valu_ceiling_Gpairs_per_s"], 4)
+    kernels = {k: {"launches": v["launches"], "avg_ms": round(v["total_ms"] / v["launches"], 4)}
+               for k, v in prof.items()}
+
+    extra = {"bf_match": bf, "kernels": kernels, "roofline_pipeline": pipeline}
+    info = ctx.device_info()
+
+    # ---- BA (C4) on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve
+    if not a.no_ba:
+        from gslam_amd import ba
+        from gslam_amd.ba_synth import make_graph
+        log("BA leg: building graph")
+        g = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
+        log("BA leg: warm-up solve")
+        ba.solve(ctx, g, ba.default_options(max_iterations=2))  # warm-up (allocations, code load)
+        log("BA leg: timed solve")
+        ctx.prof_enable(True)
+        _, _, s, st = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))
+        bprof = ctx.prof_collect()
+        ctx.prof_enable(False)
+        n = 6 * a.ba_cams
+        solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * s.iterations
+        chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ("ba_potf2", "ba_trsm", "ba_syrk_panel",
+                                                                         "ba_syrk_trailing", "ba_trsv_fwd",
+                                                                         "ba_trsv_bwd"))
+        extra["ba"] = {"workload": f"C4: {a.ba_cams} cams, {a.ba_points} pts, {len(g['obs_cam'])} obs, Huber LM",
+                       "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
+                       "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
+                       "dense_solve": {"bound": "mfma", "n": n,
+                                       "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3) if chol_ms else None,
+                                       "peak_TFLOPs": FP64_MFMA_PEAK / 1e12},
+                       "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
+                                   for k, v in bprof.items()}}
+
+    # ---- CPU baseline on this box's host cores: bounded sample of the same workload (oracle = "port")
+    cpu = None
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib  # the checker, used here only as the timed CPU leg
+        oracle = oracle_lib.load()
+        cores = host_cores()
+        log(f"cpu baseline on {cores} cores (cpu_count={os.cpu_count()})")
+        S = max(2, min(a.cpu_frames, F))
+        host_frames = frames[:S, :, :W].contiguous().cpu().numpy()
+        t1 = time.perf_counter()
+        _, cdesc, ccnt = oracle.orb_extract_batch(host_frames, K, threads=cores)
+        t_ext = time.perf_counter() - t1
+        log(f"cpu extract done {t_ext:.2f}s")
+        t1 = time.perf_counter()
+        for f in range(S - 1):
+            oracle.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
+        t_match = time.perf_counter() - t1
+        # the sample has S frames and S-1 pairs; the GPU workload has F frames and F-1 pairs per rank
+        cpu_kpts = int(ccnt.sum())
+        cpu = {"value": round(cpu_kpts / (t_ext + t_match) / 1e6, 4), "unit": "Mkeypoints/s", "cores": cores,
+               "kind": "port",
+               "sample": f"{S} of the same {W}x{H} frames (K={K}) extracted + {S - 1} consecutive pairs matched, "
+                         f"OpenMP over {cores} threads: extract {t_ext:.2f}s, match {t_match:.2f}s",
+               "extract_Mkpts_per_s": round(cpu_kpts / t_ext / 1e6, 4),
+               "match_Gpairs_per_s": round(float((ccnt[:-1].astype(np.int64) * ccnt[1:]).sum()) / t_match / 1e9, 4)}
+        if oracle_lib.have_reference():
+            ref = oracle_lib.load_reference()
+            t1 = time.perf_counter()
+            nref = min(S - 1, 8)
+            for f in range(nref):
+                ref.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
+            t_ref = time.perf_counter() - t1
+            cpu["match_reference_kernel_Gpairs_per_s"] = round(
+                float((ccnt[:nref].astype(np.int64) * ccnt[1:nref + 1]).sum()) / t_ref / 1e9, 4)
+        log("cpu match done")
+        if not a.no_ba:
+            gsmall = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
+            t1 = time.perf_counter()
+            _, _, so, _ = oracle.ba_solve(gsmall, oracle_lib.ba_options(max_iterations=2), threads=cores)
+            t_ba = time.perf_counter() - t1
+            cpu["ba_iters_per_s"] = round(so.iterations / t_ba, 4)
+            cpu["ba_sample"] = f"2 LM iterations of the same C4 graph, {cores} threads"
+
+    line = {
+        "metric": "orb_extract_plus_bf_match_Mkeypoints_per_s", "value": round(value, 3), "unit": "Mkeypoints/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"C2: {F}x{W}x{H} frames per GPU, {K} ORB kpts each, BF Hamming consecutive-pair match",
+                   "frames_per_gpu": F, "width": W, "height": H, "kpts_per_frame": K,
+                   "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of descriptors + matches"
+                   if world > 1 else "single GPU",
+                   "device": info["name"], "cu_count": info["cu_count"]},
+        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

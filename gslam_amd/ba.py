@@ -1,0 +1,76 @@
+"""Host-side mirror of the Optimizer plugin (gslam_amd/plugin/optimizer_plugin.cpp) for tests and
+bench.py: bundle adjustment through gh_ba_solve.  numpy arrays in, numpy arrays out; the solver runs on
+the GPU (no CPU fallback).
+
+Mirrors GSLAM::Optimizer::optimize(BundleGraph&) (GSLAM/core/Optimizer.h:229): keyframes are T_wc as
+[qx qy qz qw tx ty tz] with UPDATE_KF_* dof bits, mappoints xyz (+ notFixed flag), observations are
+(pointId, frameId, normalised xy on the z = 1 plane, optional 2x2 information).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hip
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def default_options(**kw):
+    o = hip.BaOptions()
+    hip.lib.gh_ba_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def solve(ctx: hip.Context, graph: dict, options=None):
+    """graph: dict with cam_pose (Nc x 7), cam_dof (Nc), point_xyz (Np x 3), obs_cam, obs_point, obs_xy
+    (+ optional point_free, obs_info).  Returns (poses, points, summary, status)."""
+    options = options or default_options()
+    poses = np.ascontiguousarray(graph["cam_pose"], dtype=np.float64).copy()
+    pts = np.ascontiguousarray(graph["point_xyz"], dtype=np.float64).copy()
+    dof = np.ascontiguousarray(graph["cam_dof"], dtype=np.int32)
+    ocam = np.ascontiguousarray(graph["obs_cam"], dtype=np.int32)
+    opt = np.ascontiguousarray(graph["obs_point"], dtype=np.int32)
+    oxy = np.ascontiguousarray(graph["obs_xy"], dtype=np.float64)
+    pfree = graph.get("point_free")
+    pfree = np.ascontiguousarray(pfree, dtype=np.uint8) if pfree is not None else None
+    info = graph.get("obs_info")
+    info = np.ascontiguousarray(info, dtype=np.float64) if info is not None else None
+    pr = hip.BaProblem(len(poses), len(pts), len(ocam), _ptr(poses), _ptr(dof), _ptr(pts), _ptr(pfree), _ptr(ocam),
+                       _ptr(opt), _ptr(oxy), _ptr(info))
+    s = hip.BaSummary()
+    st = hip.lib.gh_ba_solve(ctx.h, C.byref(pr), C.byref(options), C.byref(s))
+    if st not in (0, 4):
+        ctx.check(st)
+    return poses, pts, s, st
+
+
+def pnp(ctx: hip.Context, points_xyz, obs_xy, pose, dof=63, options=None, want_information=False):
+    options = options or default_options()
+    X = np.ascontiguousarray(points_xyz, dtype=np.float64)
+    m = np.ascontiguousarray(obs_xy, dtype=np.float64)
+    p = np.ascontiguousarray(pose, dtype=np.float64).copy()
+    info = np.zeros(36) if want_information else None
+    s = hip.BaSummary()
+    st = hip.lib.gh_ba_pnp(ctx.h, _ptr(X), _ptr(m), len(X), _ptr(p), int(dof), C.byref(options), _ptr(info),
+                           C.byref(s))
+    if st not in (0, 4):
+        ctx.check(st)
+    return p, s, (info.reshape(6, 6) if want_information else None)
+
+
+def potrf_solve(ctx: hip.Context, A, b):
+    """Dense SPD solve on the GPU (lower Cholesky in place).  A: n x n (symmetric), b: n.  torch is plumbing."""
+    import torch
+    n = A.shape[0]
+    dA = torch.from_numpy(np.asfortranarray(A, dtype=np.float64).T.copy()).cuda()  # column-major bytes
+    db = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).cuda()
+    info = C.c_int()
+    ctx.check(hip.lib.gh_potrf_solve_dev(ctx.h, C.c_void_p(dA.data_ptr()), n, n, C.c_void_p(db.data_ptr()),
+                                         C.byref(info)))
+    ctx.sync()
+    L = np.tril(dA.cpu().numpy().T)
+    return L, db.cpu().numpy(), info.value

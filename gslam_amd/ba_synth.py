@@ -89,6 +89,8 @@ def make_graph(n_cams, n_points, n_obs_per_point=6, seed=1, noise=0.002, outlier
         poses[0] = poses_gt[0]
     dof = np.full(n_cams, KF_SE3, np.int32)
     dof[0] = 0  # first camera fixed (UPDATE_KF_NONE)
+    if n_cams > 1:
+        dof[1] = KF_SE3 & ~1  # second camera: local-x translation frozen -> fixes the monocular scale gauge
     return {
         "cam_pose": np.ascontiguousarray(poses), "cam_dof": dof, "point_xyz": np.ascontiguousarray(pts),
         "obs_cam": obs_cam, "obs_point": obs_point, "obs_xy": np.ascontiguousarray(xy),

@@ -1,0 +1,851 @@
+// Levenberg-Marquardt bundle adjustment inner loop on gfx950 (f64), behind gh_ba_solve / gh_ba_pnp.
+//
+// Drop-in for the solver behind GSLAM::Optimizer::optimize(BundleGraph&) (GSLAM/core/Optimizer.h:229,
+// problem container :102-172, config :174-182) and optimizePnP (:202-207).  Mirrors oracle/ba_oracle.c
+// operation for operation (same residual, Jacobians, Huber IRLS weight, damping, trust-region policy);
+// parity is tolerance based (f64 GPU vs f64 CPU, libm vs ocml sin/cos, summation order).
+//
+// Per LM iteration (all HBM/gather-bound except the dense solve):
+//   lin_points   1 thread / point over its CSR observation list   -> Hpp (3x3), g_p
+//   lin_cams     1 wave / camera over its CSR list, fixed shuffle tree -> Hcc (6x6), g_c   (deterministic)
+//   damp_points  (Hpp + D)^-1 closed form
+//   schur        S = Hcc + D - sum_p W Hpp^-1 W^T :  deterministic mode: 1 wave / camera row-block owns its
+//                rows of S and walks its observations in order (no atomics); fast mode: f64 atomics
+//   potrf/potrs  chol.hip (v_mfma_f64_16x16x4_f64 trailing updates)
+//   backsub      1 thread / point:  dp = Hpp^-1 (-g_p - sum W^T dc)
+//   update+eval  retract poses (guarded SE3::exp, GSLAM/core/SE3.h:257-287), candidate robust cost and the
+//                model decrease, fixed-order block reduction -> 2 doubles read back by the host loop.
+// Jacobians are recomputed where needed instead of being stored (80 B gathered beats 144 B of W traffic).
+#include <chrono>
+
+#include "common.h"
+
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev);
+gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work);
+
+namespace {
+
+constexpr double kMinDepth = 1e-9;
+
+struct Obs {
+  double r[2], w, s;
+  double Jc[12], Jp[6];
+};
+
+__device__ __forceinline__ void quat_rotate(const double* q, const double* p, double* o) {
+  double uvx = q[1] * p[2] - q[2] * p[1], uvy = q[2] * p[0] - q[0] * p[2], uvz = q[0] * p[1] - q[1] * p[0];
+  uvx += uvx; uvy += uvy; uvz += uvz;
+  o[0] = p[0] + q[3] * uvx + (q[1] * uvz - q[2] * uvy);
+  o[1] = p[1] + q[3] * uvy + (q[2] * uvx - q[0] * uvz);
+  o[2] = p[2] + q[3] * uvz + (q[0] * uvy - q[1] * uvx);
+}
+
+__device__ __forceinline__ void quat_mul(const double* a, const double* b, double* o) {
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+// T <- T * exp([v, w]) with guarded coefficients (the reference's SE3::exp is NaN at w == 0)
+__device__ void se3_retract(const double* pose, const double* xi, double* out) {
+  const double* v = xi;
+  const double* w = xi + 3;
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double th = sqrt(th2);
+  double imag, real, A, B;
+  if (th < 1e-5) {
+    const double th4 = th2 * th2;
+    imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+    real = 1.0 - th2 / 8.0 + th4 / 384.0;
+    A = 0.5 - th2 / 24.0 + th4 / 720.0;
+    B = 1.0 / 6.0 - th2 / 120.0 + th4 / 5040.0;
+  } else {
+    imag = sin(0.5 * th) / th;
+    real = cos(0.5 * th);
+    A = (1.0 - cos(th)) / th2;
+    B = (th - sin(th)) / (th2 * th);
+  }
+  double e[7];
+  e[0] = imag * w[0]; e[1] = imag * w[1]; e[2] = imag * w[2]; e[3] = real;
+  const double c1[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+  const double c2[3] = {w[1] * c1[2] - w[2] * c1[1], w[2] * c1[0] - w[0] * c1[2], w[0] * c1[1] - w[1] * c1[0]};
+  for (int i = 0; i < 3; ++i) e[4 + i] = v[i] + A * c1[i] + B * c2[i];
+  double q[4], t[3];
+  quat_mul(pose, e, q);
+  quat_rotate(pose, e + 4, t);
+  const double nrm = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) out[i] = q[i] * nrm;
+  for (int i = 0; i < 3; ++i) out[4 + i] = pose[4 + i] + t[i];
+}
+
+// residual / weight / Jacobians of one observation; false if the point is not in front of the camera
+template <bool WITH_J>
+__device__ __forceinline__ bool linearize(const double* pose, int dof, const double* X, int pfree, const double* m,
+                                          const double* info, double huber, Obs& o) {
+  const double qc[4] = {-pose[0], -pose[1], -pose[2], pose[3]};
+  const double d[3] = {X[0] - pose[4], X[1] - pose[5], X[2] - pose[6]};
+  double Xc[3];
+  quat_rotate(qc, d, Xc);
+  if (!(Xc[2] > kMinDepth)) return false;
+  const double iz = 1.0 / Xc[2];
+  const double u = Xc[0] * iz, v = Xc[1] * iz;
+  o.r[0] = u - m[0];
+  o.r[1] = v - m[1];
+  double L00 = 1, L01 = 0, L10 = 0, L11 = 1;
+  if (info) { L00 = info[0]; L01 = info[1]; L10 = info[2]; L11 = info[3]; }
+  const double s = o.r[0] * (L00 * o.r[0] + L01 * o.r[1]) + o.r[1] * (L10 * o.r[0] + L11 * o.r[1]);
+  double w = 1.0;
+  if (huber > 0 && s > huber * huber) w = huber / sqrt(s);
+  o.w = w;
+  o.s = s;
+  if (!WITH_J) return true;
+  const double P[6] = {iz, 0, -u * iz, 0, iz, -v * iz};
+  const double D[18] = {-1, 0, 0, 0, -Xc[2], Xc[1],
+                        0, -1, 0, Xc[2], 0, -Xc[0],
+                        0, 0, -1, -Xc[1], Xc[0], 0};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double acc = 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc += P[a * 3 + j] * D[j * 6 + k];
+      o.Jc[a * 6 + k] = ((dof >> k) & 1) ? acc : 0.0;
+    }
+  const double x = pose[0], y = pose[1], z = pose[2], qw = pose[3];
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - qw * z), 2 * (x * z + qw * y),
+                       2 * (x * y + qw * z), 1 - 2 * (x * x + z * z), 2 * (y * z - qw * x),
+                       2 * (x * z - qw * y), 2 * (y * z + qw * x), 1 - 2 * (x * x + y * y)};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double acc = 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc += P[a * 3 + j] * R[k * 3 + j];  // R^T[j][k] = R[k][j]
+      o.Jp[a * 3 + k] = pfree ? acc : 0.0;
+    }
+  return true;
+}
+
+__device__ __forceinline__ void weighted_info(const double* info, double w, double* L) {
+  L[0] = w; L[1] = 0; L[2] = 0; L[3] = w;
+  if (info) { L[0] = w * info[0]; L[1] = w * info[1]; L[2] = w * info[2]; L[3] = w * info[3]; }
+}
+
+struct Problem {
+  int nc, np, no;
+  const double* poses;   // nc x 7
+  const int32_t* dof;
+  const double* pts;     // np x 3
+  const uint8_t* pfree;  // may be null
+  const int32_t* ocam;
+  const int32_t* opt;
+  const double* oxy;
+  const double* oinfo;   // may be null
+  const int32_t* pstart; // CSR by point
+  const int32_t* plist;
+  const int32_t* cstart; // CSR by camera
+  const int32_t* clist;
+  double huber;
+};
+
+__device__ __forceinline__ bool lin_obs(const Problem& P, int k, Obs& o, bool with_j) {
+  const int ci = P.ocam[k], pi = P.opt[k];
+  const double* info = P.oinfo ? P.oinfo + 4 * k : nullptr;
+  const int pf = P.pfree ? P.pfree[pi] : 1;
+  if (with_j) return linearize<true>(P.poses + 7 * ci, P.dof[ci], P.pts + 3 * pi, pf, P.oxy + 2 * k, info, P.huber, o);
+  return linearize<false>(P.poses + 7 * ci, P.dof[ci], P.pts + 3 * pi, pf, P.oxy + 2 * k, info, P.huber, o);
+}
+
+// ---------------------------------------------------------------- linearisation
+__global__ __launch_bounds__(256) void lin_points_kernel(Problem P, double* __restrict__ Hpp, double* __restrict__ gp,
+                                                         unsigned long long* __restrict__ gmax_bits) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P.np) return;
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int q = P.pstart[p]; q < P.pstart[p + 1]; ++q) {
+    const int k = P.plist[q];
+    Obs o;
+    if (!lin_obs(P, k, o, true)) continue;
+    double L[4];
+    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, o.w, L);
+    const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
+    double LJp[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      LJp[j] = L[0] * o.Jp[j] + L[1] * o.Jp[3 + j];
+      LJp[3 + j] = L[2] * o.Jp[j] + L[3] * o.Jp[3 + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      g[a] += o.Jp[a] * Lr[0] + o.Jp[3 + a] * Lr[1];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) H[3 * a + b] += o.Jp[a] * LJp[b] + o.Jp[3 + a] * LJp[3 + b];
+    }
+  }
+  double gm = 0;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) Hpp[(size_t)9 * p + a] = H[a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gp[(size_t)3 * p + a] = g[a];
+    gm = fmax(gm, fabs(g[a]));
+  }
+  if (gm > 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(gm));
+}
+
+__global__ __launch_bounds__(256) void lin_cams_kernel(Problem P, double* __restrict__ Hcc, double* __restrict__ gc,
+                                                       unsigned long long* __restrict__ gmax_bits) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= P.nc) return;
+  double H[21], g[6];  // upper triangle, row-major packed
+#pragma unroll
+  for (int a = 0; a < 21; ++a) H[a] = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) g[a] = 0;
+  for (int q = P.cstart[c] + lane; q < P.cstart[c + 1]; q += 64) {
+    const int k = P.clist[q];
+    Obs o;
+    if (!lin_obs(P, k, o, true)) continue;
+    double L[4];
+    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, o.w, L);
+    const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
+    double LJc[12];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      LJc[j] = L[0] * o.Jc[j] + L[1] * o.Jc[6 + j];
+      LJc[6 + j] = L[2] * o.Jc[j] + L[3] * o.Jc[6 + j];
+    }
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      g[a] += o.Jc[a] * Lr[0] + o.Jc[6 + a] * Lr[1];
+#pragma unroll
+      for (int b = a; b < 6; ++b) H[t++] += o.Jc[a] * LJc[b] + o.Jc[6 + a] * LJc[6 + b];
+    }
+  }
+  // fixed-order butterfly: every lane ends with the same total, summed in the same order each run
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 21; ++a) H[a] += __shfl_xor(H[a], off);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) g[a] += __shfl_xor(g[a], off);
+  }
+  if (lane == 0) {
+    int t = 0;
+    double gm = 0;
+    for (int a = 0; a < 6; ++a) {
+      gc[(size_t)6 * c + a] = g[a];
+      gm = fmax(gm, fabs(g[a]));
+      for (int b = a; b < 6; ++b) {
+        Hcc[(size_t)36 * c + 6 * a + b] = H[t];
+        Hcc[(size_t)36 * c + 6 * b + a] = H[t];
+        ++t;
+      }
+    }
+    if (gm > 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(gm));
+  }
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void damp_points_kernel(int np, const double* __restrict__ Hpp, double radius,
+                                                          double* __restrict__ Hpi, int* __restrict__ bad) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= np) return;
+  double H[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) H[a] = Hpp[(size_t)9 * p + a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) H[4 * a] += clampd(H[4 * a], 1e-6, 1e32) / radius;
+  const double a = H[0], b = H[1], c = H[2], d = H[4], e = H[5], f = H[8];
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (!(det > 0)) {
+    atomicOr(bad, 1);
+    return;
+  }
+  const double id = 1.0 / det;
+  double* o = Hpi + (size_t)9 * p;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = o[1]; o[4] = (a * f - c * c) * id; o[5] = (b * c - a * e) * id;
+  o[6] = o[2]; o[7] = o[5]; o[8] = (a * d - b * b) * id;
+}
+
+// S diagonal blocks (+ damping) and rhs = -g_c.  S is n x n column-major, zeroed beforehand.
+__global__ __launch_bounds__(64) void schur_diag_kernel(int nc, const double* __restrict__ Hcc,
+                                                        const double* __restrict__ gc, double radius,
+                                                        double* __restrict__ S, int n, double* __restrict__ rhs) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (t < 36) {
+    const int a = t / 6, b = t - 6 * a;
+    double v = Hcc[(size_t)36 * c + t];
+    if (a == b) v += clampd(v, 1e-6, 1e32) / radius;
+    S[(size_t)(6 * c + b) * n + 6 * c + a] = v;
+  } else if (t < 42) {
+    rhs[6 * c + (t - 36)] = -gc[6 * c + (t - 36)];
+  }
+}
+
+// W_i = Jc^T L Jp (6x3), WH_i = W_i Hpp^-1
+__device__ __forceinline__ void make_W(const Obs& o, const double* L, double* W) {
+  double LJp[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    LJp[j] = L[0] * o.Jp[j] + L[1] * o.Jp[3 + j];
+    LJp[3 + j] = L[2] * o.Jp[j] + L[3] * o.Jp[3 + j];
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) W[3 * a + b] = o.Jc[a] * LJp[b] + o.Jc[6 + a] * LJp[3 + b];
+}
+
+__device__ __forceinline__ void mul_WH(const double* W, const double* Hi, double* WH) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) WH[3 * a + b] = W[3 * a] * Hi[b] + W[3 * a + 1] * Hi[3 + b] + W[3 * a + 2] * Hi[6 + b];
+}
+
+// Fast mode: one thread per observation i (in point-CSR order); all j of the same point; f64 atomics.
+__global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const double* __restrict__ Hpi,
+                                                           const double* __restrict__ gp, double* __restrict__ S,
+                                                           int n, double* __restrict__ rhs) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= P.no) return;
+  const int k = P.plist[q];
+  const int p = P.opt[k], ci = P.ocam[k];
+  Obs oi;
+  if (!lin_obs(P, k, oi, true)) return;
+  double L[4], Wi[18], WH[18];
+  weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, oi.w, L);
+  make_W(oi, L, Wi);
+  mul_WH(Wi, Hpi + (size_t)9 * p, WH);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double v = WH[3 * a] * gp[3 * p] + WH[3 * a + 1] * gp[3 * p + 1] + WH[3 * a + 2] * gp[3 * p + 2];
+    atomicAdd(&rhs[6 * ci + a], v);
+  }
+  for (int q2 = P.pstart[p]; q2 < P.pstart[p + 1]; ++q2) {
+    const int k2 = P.plist[q2];
+    const int cj = P.ocam[k2];
+    if (cj > ci) continue;  // only the lower triangle is stored; (j, i) covers the mirror block
+    Obs oj;
+    if (!lin_obs(P, k2, oj, true)) continue;
+    double L2[4], Wj[18];
+    weighted_info(P.oinfo ? P.oinfo + 4 * k2 : nullptr, oj.w, L2);
+    make_W(oj, L2, Wj);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        if (ci == cj && a < b) continue;
+        const double v = WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
+        atomicAdd(&S[(size_t)(6 * cj + b) * n + 6 * ci + a], -v);
+      }
+  }
+}
+
+// Deterministic mode: one wave owns camera row-block ci.  It walks the camera's observations in CSR
+// order; for observation i (point p) lane j handles the j-th observation of p.  Row-block ci of S and
+// rhs[6 ci ..] are touched by this wave only, in a fixed order -> bitwise reproducible.
+__global__ __launch_bounds__(64) void schur_rows_kernel(Problem P, const double* __restrict__ Hpi,
+                                                        const double* __restrict__ gp, double* __restrict__ S, int n,
+                                                        double* __restrict__ rhs) {
+  const int ci = blockIdx.x, lane = threadIdx.x;
+  double racc[6] = {0, 0, 0, 0, 0, 0};
+  for (int q = P.cstart[ci]; q < P.cstart[ci + 1]; ++q) {
+    const int k = P.clist[q];  // wave-uniform
+    const int p = P.opt[k];
+    Obs oi;
+    if (!lin_obs(P, k, oi, true)) continue;
+    double L[4], Wi[18], WH[18];
+    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, oi.w, L);
+    make_W(oi, L, Wi);
+    mul_WH(Wi, Hpi + (size_t)9 * p, WH);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+      racc[a] += WH[3 * a] * gp[3 * p] + WH[3 * a + 1] * gp[3 * p + 1] + WH[3 * a + 2] * gp[3 * p + 2];
+    const int pb = P.pstart[p], pn = P.pstart[p + 1] - pb;
+    for (int base = 0; base < pn; base += 64) {
+      const int j = base + lane;
+      bool act = j < pn;
+      int cj = -1;
+      Obs oj;
+      int k2 = 0;
+      if (act) {
+        k2 = P.plist[pb + j];
+        cj = P.ocam[k2];
+        act = cj <= ci && lin_obs(P, k2, oj, true);
+      }
+      // two observations of the same point in the same camera would collide: serialise those lanes
+      // (first lane of each distinct camera goes in round 0, the next in round 1, ...)
+      int round = 0;
+      if (act) {
+        for (int jj = base; jj < j; ++jj)
+          if (P.ocam[P.plist[pb + jj]] == cj) ++round;
+      }
+      int max_round = round;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) max_round = max(max_round, __shfl_xor(max_round, off));
+      double Wj[18];
+      if (act) {
+        double L2[4];
+        weighted_info(P.oinfo ? P.oinfo + 4 * k2 : nullptr, oj.w, L2);
+        make_W(oj, L2, Wj);
+      }
+      for (int rd = 0; rd <= max_round; ++rd) {
+        if (act && round == rd) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              if (ci == cj && a < b) continue;
+              const double v = WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
+              // plain read-modify-write: this wave is the only writer of row-block ci (device-scope f64
+              // atomics execute memory-side on the 8-XCD part and cost ~2 us each - measured 44 ms/iter)
+              double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
+              *dst = *dst - v;
+            }
+        }
+        // order this round's stores before the next round's loads of possibly the same block
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+    }
+  }
+  if (lane == 0)
+    for (int a = 0; a < 6; ++a) rhs[6 * ci + a] += racc[a];
+}
+
+__global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const double* __restrict__ Hpi,
+                                                             const double* __restrict__ gp,
+                                                             const double* __restrict__ dc, double* __restrict__ dp) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P.np) return;
+  double rhs[3] = {-gp[3 * p], -gp[3 * p + 1], -gp[3 * p + 2]};
+  for (int q = P.pstart[p]; q < P.pstart[p + 1]; ++q) {
+    const int k = P.plist[q], ci = P.ocam[k];
+    Obs o;
+    if (!lin_obs(P, k, o, true)) continue;
+    double L[4];
+    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, o.w, L);
+    double Jd[2] = {0, 0};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      Jd[0] += o.Jc[a] * dc[6 * ci + a];
+      Jd[1] += o.Jc[6 + a] * dc[6 * ci + a];
+    }
+    const double LJd[2] = {L[0] * Jd[0] + L[1] * Jd[1], L[2] * Jd[0] + L[3] * Jd[1]};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) rhs[b] -= o.Jp[b] * LJd[0] + o.Jp[3 + b] * LJd[1];
+  }
+  const double* Hi = Hpi + (size_t)9 * p;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) dp[3 * p + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+}
+
+__global__ __launch_bounds__(256) void update_state_kernel(int nc, int np, const double* __restrict__ poses,
+                                                           const int32_t* __restrict__ dof,
+                                                           const double* __restrict__ pts,
+                                                           const double* __restrict__ dc, const double* __restrict__ dp,
+                                                           double* __restrict__ poses_new, double* __restrict__ pts_new) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nc) {
+    if ((dof[i] & 63) == 0) {  // fixed keyframe: bitwise untouched
+      for (int a = 0; a < 7; ++a) poses_new[7 * i + a] = poses[7 * i + a];
+    } else {
+      se3_retract(poses + 7 * i, dc + 6 * i, poses_new + 7 * i);
+    }
+  }
+  if (i < np) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pts_new[3 * i + a] = pts[3 * i + a] + dp[3 * i + a];
+  }
+}
+
+// per-observation: robust cost at `Pn` state and (optionally) model decrease at the `P` linearisation.
+// Block partial sums in fixed order -> partial[2 * block + {0,1}].
+__global__ __launch_bounds__(256) void eval_kernel(Problem P, const double* __restrict__ poses_eval,
+                                                   const double* __restrict__ pts_eval, const double* __restrict__ dc,
+                                                   const double* __restrict__ dp, int with_model,
+                                                   double* __restrict__ partial) {
+  __shared__ double sc[256], sm[256];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  double cost = 0, model = 0;
+  if (k < P.no) {
+    const int ci = P.ocam[k], pi = P.opt[k];
+    const double* info = P.oinfo ? P.oinfo + 4 * k : nullptr;
+    Obs o;
+    if (linearize<false>(poses_eval + 7 * ci, 0, pts_eval + 3 * pi, 0, P.oxy + 2 * k, info, P.huber, o)) {
+      cost = (P.huber > 0 && o.s > P.huber * P.huber) ? 2.0 * P.huber * sqrt(o.s) - P.huber * P.huber : o.s;
+    }
+    if (with_model && lin_obs(P, k, o, true)) {
+      double L[4];
+      weighted_info(info, o.w, L);
+      double Jd[2] = {0, 0};
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        Jd[0] += o.Jc[a] * dc[6 * ci + a];
+        Jd[1] += o.Jc[6 + a] * dc[6 * ci + a];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        Jd[0] += o.Jp[a] * dp[3 * pi + a];
+        Jd[1] += o.Jp[3 + a] * dp[3 * pi + a];
+      }
+      const double LJd[2] = {L[0] * Jd[0] + L[1] * Jd[1], L[2] * Jd[0] + L[3] * Jd[1]};
+      const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
+      model = -(Jd[0] * Lr[0] + Jd[1] * Lr[1] + 0.5 * (Jd[0] * LJd[0] + Jd[1] * LJd[1]));
+    }
+  }
+  sc[threadIdx.x] = cost;
+  sm[threadIdx.x] = model;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (threadIdx.x < off) {
+      sc[threadIdx.x] += sc[threadIdx.x + off];
+      sm[threadIdx.x] += sm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = sc[0];
+    partial[2 * blockIdx.x + 1] = sm[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partial, int nblocks,
+                                                           double* __restrict__ out) {
+  __shared__ double sc[256], sm[256];
+  double c = 0, m = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    c += partial[2 * i];
+    m += partial[2 * i + 1];
+  }
+  sc[threadIdx.x] = c;
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (threadIdx.x < off) {
+      sc[threadIdx.x] += sc[threadIdx.x + off];
+      sm[threadIdx.x] += sm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = 0.5 * sc[0];
+    out[1] = sm[0];
+  }
+}
+
+struct DevBuf {
+  gh_ctx* ctx;
+  std::vector<void*> ptrs;
+  explicit DevBuf(gh_ctx* c) : ctx(c) {}
+  ~DevBuf() {
+    hipStreamSynchronize(ctx->stream);
+    for (void* p : ptrs) hipFree(p);
+  }
+  template <typename T>
+  gh_status alloc(T** out, size_t count) {
+    void* p = nullptr;
+    gh_status s = gh_dev_alloc(ctx, (count ? count : 1) * sizeof(T), &p);
+    if (s == GH_OK) {
+      ptrs.push_back(p);
+      *out = (T*)p;
+    }
+    return s;
+  }
+  template <typename T>
+  gh_status upload(T** out, const T* src, size_t count) {
+    GH_TRY(alloc(out, count));
+    if (count) GH_HIP(ctx, hipMemcpyAsync(*out, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return GH_OK;
+  }
+};
+
+void build_csr(const int32_t* key, int n_items, int n_keys, std::vector<int32_t>& start, std::vector<int32_t>& list) {
+  start.assign((size_t)n_keys + 1, 0);
+  list.resize((size_t)(n_items > 0 ? n_items : 1));
+  for (int k = 0; k < n_items; ++k) start[key[k] + 1]++;
+  for (int i = 0; i < n_keys; ++i) start[i + 1] += start[i];
+  std::vector<int32_t> fill(start.begin(), start.end() - 1);
+  for (int k = 0; k < n_items; ++k) list[fill[key[k]]++] = k;
+}
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" void gh_ba_default_options(gh_ba_options* o) {
+  if (!o) return;
+  o->huber_delta = 0.01;
+  o->max_iterations = 500;
+  o->initial_radius = 1e4;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->min_relative_decrease = 1e-3;
+  o->verbose = 0;
+  o->deterministic = 1;
+}
+
+extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_options* opt_in,
+                                 gh_ba_summary* sum_out) {
+  if (!ctx || !pr) return GH_ERR_ARG;
+  gh_ba_options opt;
+  gh_ba_default_options(&opt);
+  if (opt_in) opt = *opt_in;
+  gh_ba_summary local_sum;
+  gh_ba_summary* sum = sum_out ? sum_out : &local_sum;
+  memset(sum, 0, sizeof(*sum));
+  const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
+  GH_CHECK_ARG(ctx, nc >= 1 && np >= 0 && no >= 0 && nc <= (1 << 24));
+  GH_CHECK_ARG(ctx, pr->cam_pose && pr->cam_dof && (np == 0 || pr->point_xyz));
+  GH_CHECK_ARG(ctx, no == 0 || (pr->obs_cam && pr->obs_point && pr->obs_xy));
+  for (int k = 0; k < no; ++k)
+    GH_CHECK_ARG(ctx, pr->obs_cam[k] >= 0 && pr->obs_cam[k] < nc && pr->obs_point[k] >= 0 && pr->obs_point[k] < np);
+  GH_HIP(ctx, hipSetDevice(ctx->device));
+  const double t_begin = now_ms();
+  const int n = 6 * nc;
+  const int lda = n;
+
+  std::vector<int32_t> pstart, plist, cstart, clist;
+  build_csr(pr->obs_point, no, np, pstart, plist);
+  build_csr(pr->obs_cam, no, nc, cstart, clist);
+
+  DevBuf db(ctx);
+  double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
+  int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
+  uint8_t* d_pfree = nullptr;
+  GH_TRY(db.upload(&d_poses, pr->cam_pose, (size_t)nc * 7));
+  GH_TRY(db.upload(&d_pts, pr->point_xyz, (size_t)np * 3));
+  GH_TRY(db.alloc(&d_poses_new, (size_t)nc * 7));
+  GH_TRY(db.alloc(&d_pts_new, (size_t)np * 3));
+  GH_TRY(db.upload(&d_dof, pr->cam_dof, (size_t)nc));
+  if (pr->point_free) GH_TRY(db.upload(&d_pfree, pr->point_free, (size_t)np));
+  GH_TRY(db.upload(&d_ocam, pr->obs_cam, (size_t)no));
+  GH_TRY(db.upload(&d_opt, pr->obs_point, (size_t)no));
+  GH_TRY(db.upload(&d_oxy, pr->obs_xy, (size_t)no * 2));
+  if (pr->obs_info) GH_TRY(db.upload(&d_oinfo, pr->obs_info, (size_t)no * 4));
+  GH_TRY(db.upload(&d_pstart, (const int32_t*)pstart.data(), pstart.size()));
+  GH_TRY(db.upload(&d_plist, (const int32_t*)plist.data(), plist.size()));
+  GH_TRY(db.upload(&d_cstart, (const int32_t*)cstart.data(), cstart.size()));
+  GH_TRY(db.upload(&d_clist, (const int32_t*)clist.data(), clist.size()));
+  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work;
+  unsigned long long* d_gmax;
+  int *d_bad, *d_info;
+  const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
+  GH_TRY(db.alloc(&d_Hcc, (size_t)nc * 36));
+  GH_TRY(db.alloc(&d_gc, (size_t)n));
+  GH_TRY(db.alloc(&d_Hpp, (size_t)np * 9));
+  GH_TRY(db.alloc(&d_gp, (size_t)np * 3));
+  GH_TRY(db.alloc(&d_Hpi, (size_t)np * 9));
+  GH_TRY(db.alloc(&d_S, (size_t)n * lda));
+  GH_TRY(db.alloc(&d_dc, (size_t)n));
+  GH_TRY(db.alloc(&d_dp, (size_t)np * 3));
+  GH_TRY(db.alloc(&d_work, (size_t)n));
+  GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
+  GH_TRY(db.alloc(&d_out, 4));
+  GH_TRY(db.alloc(&d_gmax, 1));
+  GH_TRY(db.alloc(&d_bad, 1));
+  GH_TRY(db.alloc(&d_info, 1));
+
+  Problem P{nc, np, no, d_poses, d_dof, d_pts, d_pfree, d_ocam, d_opt, d_oxy, d_oinfo,
+            d_pstart, d_plist, d_cstart, d_clist, opt.huber_delta};
+
+  auto eval_cost = [&](const double* poses_eval, const double* pts_eval, int with_model, double* host2) -> gh_status {
+    GH_LAUNCH(ctx, "ba_eval", eval_kernel, dim3(eval_blocks), dim3(256), 0, P, poses_eval, pts_eval, d_dc, d_dp,
+              with_model, d_partial);
+    GH_LAUNCH(ctx, "ba_reduce", reduce_final_kernel, dim3(1), dim3(256), 0, d_partial, eval_blocks, d_out);
+    GH_HIP(ctx, hipMemcpyAsync(host2, d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GH_OK;
+  };
+
+  double h2[2];
+  GH_TRY(eval_cost(d_poses, d_pts, 0, h2));
+  double cost = h2[0];
+  sum->initial_cost = cost;
+  double radius = opt.initial_radius, decrease = 2.0;
+  bool need_lin = true;
+  int term = 0, it = 0;
+  for (it = 0; it < opt.max_iterations; ++it) {
+    if (need_lin) {
+      GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, sizeof(unsigned long long), ctx->stream));
+      if (np > 0)
+        GH_LAUNCH(ctx, "ba_lin_points", lin_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpp, d_gp,
+                  d_gmax);
+      GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_kernel, dim3(gh_div_up(nc, 4)), dim3(256), 0, P, d_Hcc, d_gc, d_gmax);
+      unsigned long long bits = 0;
+      GH_HIP(ctx, hipMemcpyAsync(&bits, d_gmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      double gmax;
+      memcpy(&gmax, &bits, sizeof(double));
+      if (gmax <= opt.gradient_tolerance) {
+        term = 2;
+        break;
+      }
+      need_lin = false;
+    }
+    GH_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+    if (np > 0)
+      GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
+                d_Hpi, d_bad);
+    {
+      int pend = gh_prof_begin(ctx, "ba_schur_zero");
+      hipError_t me = hipMemsetAsync(d_S, 0, (size_t)n * lda * sizeof(double), ctx->stream);
+      gh_prof_end(ctx, pend);
+      GH_HIP(ctx, me);
+    }
+    GH_LAUNCH(ctx, "ba_schur_diag", schur_diag_kernel, dim3(nc), dim3(64), 0, nc, d_Hcc, d_gc, radius, d_S, lda, d_dc);
+    if (no > 0) {
+      if (opt.deterministic)
+        GH_LAUNCH(ctx, "ba_schur_rows", schur_rows_kernel, dim3(nc), dim3(64), 0, P, d_Hpi, d_gp, d_S, lda, d_dc);
+      else
+        GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
+                  d_S, lda, d_dc);
+    }
+    const double t_solve0 = now_ms();
+    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info));
+    int flags[2] = {0, 0};
+    GH_HIP(ctx, hipMemcpyAsync(&flags[0], d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(&flags[1], d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool ok = flags[0] == 0 && flags[1] == 0;
+    double new_cost = cost, model = 0, rho = -1;
+    if (ok) {
+      GH_TRY(gh_potrs_dev_impl(ctx, d_S, n, lda, d_dc, d_work));
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      sum->solve_ms_total += now_ms() - t_solve0;
+      if (np > 0)
+        GH_LAUNCH(ctx, "ba_backsub", backsub_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpi, d_gp,
+                  d_dc, d_dp);
+      GH_LAUNCH(ctx, "ba_update", update_state_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, nc, np,
+                d_poses, d_dof, d_pts, d_dc, d_dp, d_poses_new, d_pts_new);
+      GH_TRY(eval_cost(d_poses_new, d_pts_new, 1, h2));
+      new_cost = h2[0];
+      model = h2[1];
+      rho = model > 0 ? (cost - new_cost) / model : -1;
+      if (!(new_cost == new_cost)) rho = -1;  // NaN guard
+    } else {
+      sum->solve_ms_total += now_ms() - t_solve0;
+    }
+    const bool acc = ok && rho > opt.min_relative_decrease;
+    if (sum->trace_len < GH_BA_MAX_TRACE) {
+      sum->trace_cost[sum->trace_len] = new_cost;
+      sum->trace_radius[sum->trace_len] = radius;
+      sum->trace_accepted[sum->trace_len] = (uint8_t)acc;
+      sum->trace_len++;
+    }
+    if (opt.verbose)
+      fprintf(stderr, "[gh_ba] it %3d cost %.9e -> %.9e model %.3e rho %.3f radius %.3e %s\n", it, cost, new_cost,
+              model, rho, radius, acc ? "accepted" : (ok ? "rejected" : "solve failed"));
+    if (acc) {
+      const double dcost = cost - new_cost;
+      std::swap(d_poses, d_poses_new);
+      std::swap(d_pts, d_pts_new);
+      P.poses = d_poses;
+      P.pts = d_pts;
+      const double t = 2.0 * rho - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      if (radius > 1e16) radius = 1e16;
+      decrease = 2.0;
+      sum->accepted++;
+      need_lin = true;
+      const double prev = cost;
+      cost = new_cost;
+      if (fabs(dcost) <= opt.function_tolerance * prev) {
+        term = 1;
+        ++it;
+        break;
+      }
+    } else {
+      radius = radius / decrease;
+      decrease *= 2.0;
+      if (radius < 1e-32) {
+        term = 3;
+        ++it;
+        break;
+      }
+    }
+  }
+  sum->iterations = it;
+  sum->termination = term;
+  sum->final_cost = cost;
+  GH_HIP(ctx, hipMemcpyAsync(pr->cam_pose, d_poses, (size_t)nc * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (np > 0)
+    GH_HIP(ctx, hipMemcpyAsync(pr->point_xyz, d_pts, (size_t)np * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sum->total_ms = now_ms() - t_begin;
+  return term == 3 ? GH_ERR_NUMERIC : GH_OK;
+}
+
+// Pose-only optimisation = the same solver on a 1-camera graph with every point fixed.
+extern "C" gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy, int n, double* pose,
+                               int dof, const gh_ba_options* options, double* information_out,
+                               gh_ba_summary* summary) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, n >= 0 && pose && (n == 0 || (points_xyz && obs_xy)));
+  std::vector<int32_t> ocam((size_t)(n > 0 ? n : 1), 0), opt((size_t)(n > 0 ? n : 1));
+  std::vector<uint8_t> pfree((size_t)(n > 0 ? n : 1), 0);
+  std::vector<double> pts(points_xyz, points_xyz + (size_t)3 * n);
+  for (int i = 0; i < n; ++i) opt[i] = i;
+  int32_t d = dof;
+  gh_ba_problem pr;
+  memset(&pr, 0, sizeof(pr));
+  pr.n_cams = 1;
+  pr.n_points = n;
+  pr.n_obs = n;
+  pr.cam_pose = pose;
+  pr.cam_dof = &d;
+  pr.point_xyz = pts.data();
+  pr.point_free = pfree.data();
+  pr.obs_cam = ocam.data();
+  pr.obs_point = opt.data();
+  pr.obs_xy = obs_xy;
+  gh_status st = gh_ba_solve(ctx, &pr, options, summary);
+  if (st != GH_OK && st != GH_ERR_NUMERIC) return st;
+  if (information_out) {
+    // J^T J at the solution (host, n is small): same residual model as the kernels
+    gh_ba_options o;
+    gh_ba_default_options(&o);
+    if (options) o = *options;
+    for (int i = 0; i < 36; ++i) information_out[i] = 0;
+    for (int k = 0; k < n; ++k) {
+      const double* q = pose;
+      const double* X = points_xyz + 3 * k;
+      const double dd[3] = {X[0] - q[4], X[1] - q[5], X[2] - q[6]};
+      const double qc[4] = {-q[0], -q[1], -q[2], q[3]};
+      double uvx = qc[1] * dd[2] - qc[2] * dd[1], uvy = qc[2] * dd[0] - qc[0] * dd[2], uvz = qc[0] * dd[1] - qc[1] * dd[0];
+      uvx += uvx; uvy += uvy; uvz += uvz;
+      const double Xc[3] = {dd[0] + qc[3] * uvx + (qc[1] * uvz - qc[2] * uvy),
+                            dd[1] + qc[3] * uvy + (qc[2] * uvx - qc[0] * uvz),
+                            dd[2] + qc[3] * uvz + (qc[0] * uvy - qc[1] * uvx)};
+      if (!(Xc[2] > 1e-9)) continue;
+      const double iz = 1.0 / Xc[2], u = Xc[0] * iz, v = Xc[1] * iz;
+      const double r0 = u - obs_xy[2 * k], r1 = v - obs_xy[2 * k + 1];
+      const double s = r0 * r0 + r1 * r1;
+      const double w = (o.huber_delta > 0 && s > o.huber_delta * o.huber_delta) ? o.huber_delta / sqrt(s) : 1.0;
+      const double Pm[6] = {iz, 0, -u * iz, 0, iz, -v * iz};
+      const double D[18] = {-1, 0, 0, 0, -Xc[2], Xc[1], 0, -1, 0, Xc[2], 0, -Xc[0], 0, 0, -1, -Xc[1], Xc[0], 0};
+      double J[12];
+      for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 6; ++c) {
+          double acc = 0;
+          for (int j = 0; j < 3; ++j) acc += Pm[a * 3 + j] * D[j * 6 + c];
+          J[a * 6 + c] = ((dof >> c) & 1) ? acc : 0.0;
+        }
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) information_out[6 * a + b] += w * (J[a] * J[b] + J[6 + a] * J[6 + b]);
+    }
+  }
+  return st;
+}

@@ -1,0 +1,344 @@
+// Dense SPD solve for the reduced camera system of bundle adjustment (f64, gfx950).
+//
+// Stands in for the linear solver inside the (absent) Ceres plugin behind
+// GSLAM::Optimizer::optimize (GSLAM/core/Optimizer.h:229); oracle: oracle_potrf / oracle_potrs.
+//
+// Two-level right-looking Cholesky of the lower triangle, column-major, in place:
+//   outer panels of 256 columns, inner steps of 64 columns
+//     potf2_64   one workgroup, block in LDS, 16-column register sub-steps
+//     trsm_64    one row per thread against L11 in LDS, 16-column register sub-blocks
+//     syrk_mfma  C -= P Q^T on v_mfma_f64_16x16x4_f64: 128x128 tile per workgroup (4 waves x 64x64),
+//                operands staged k-major in LDS with a 144-double pitch (conflict-free ds_read_b64),
+//                accumulators hold the TRANSPOSED tile so C is touched in 128-byte runs
+//   the rank-256 trailing update keeps C traffic (the HBM-bound part) at ~1/4 of a rank-64 update.
+// Solve: blocked forward / backward substitution, one launch per 64-block step.
+#include "common.h"
+
+namespace {
+
+constexpr int NBI = 64;    // inner block
+constexpr int NBO = 256;   // outer panel
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- potf2 on a 64x64 diagonal block
+// One workgroup, block in LDS, 16-column sub-steps (diag 16x16 left-looking with the row in
+// registers -> trsm of the rows below -> rank-16 update of the rest).  Missing rows/cols (kb < 64)
+// behave as identity.
+constexpr int NBS = 16;
+constexpr int LP = NBI + 1;  // LDS pitch (column-major: element (r, c) at c * LP + r)
+
+__global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int lda, int k0, int kb,
+                                                      int* __restrict__ info) {
+  __shared__ double As[NBI * LP];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  for (int idx = tid; idx < NBI * NBI; idx += 256) {
+    const int c = idx / NBI, r = idx - c * NBI;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < kb && c < kb && c <= r) v = A[(size_t)(k0 + c) * lda + k0 + r];
+    As[c * LP + r] = v;
+  }
+  __syncthreads();
+  for (int k = 0; k < NBI; k += NBS) {
+    // (a) 16x16 diagonal block: lanes 0..15 of wave 0, lane = row
+    if (tid < 64) {
+      const int i = tid & 15;
+      double li[NBS];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) {
+        double s = As[(k + j) * LP + k + i];
+#pragma unroll
+        for (int t = 0; t < j; ++t) s -= li[t] * __shfl(li[t], j, 16);  // L[i][t] * L[j][t]
+        const double d = __shfl(s, j, 16);
+        if (!(d > 0.0)) bad = true;
+        const double r = sqrt(d);
+        li[j] = (i == j) ? r : (i > j ? s / r : 0.0);
+      }
+      if (tid < NBS) {
+#pragma unroll
+        for (int j = 0; j < NBS; ++j) As[(k + j) * LP + k + i] = li[j];
+        if (bad) s_bad = 1;
+      }
+    }
+    __syncthreads();
+    // (b) rows below: x <- x * L11^-T, one row per thread
+    const int below = NBI - (k + NBS);
+    if (tid < below) {
+      const int r = k + NBS + tid;
+      double x[NBS];
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) {
+        double s = As[(k + j) * LP + r];
+#pragma unroll
+        for (int t = 0; t < j; ++t) s -= x[t] * As[(k + t) * LP + k + j];
+        x[j] = s / As[(k + j) * LP + k + j];
+      }
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) As[(k + j) * LP + r] = x[j];
+    }
+    __syncthreads();
+    // (c) rank-16 update of the trailing lower triangle
+    for (int idx = tid; idx < below * below; idx += 256) {
+      const int c = k + NBS + idx / below, r = k + NBS + idx % below;
+      if (r < c) continue;
+      double s = As[c * LP + r];
+#pragma unroll
+      for (int t = 0; t < NBS; ++t) s -= As[(k + t) * LP + r] * As[(k + t) * LP + c];
+      As[c * LP + r] = s;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && s_bad) atomicMax(info, k0 + 1);
+  for (int idx = tid; idx < NBI * NBI; idx += 256) {
+    const int c = idx / NBI, r = idx - c * NBI;
+    if (r < kb && c < kb && c <= r) A[(size_t)(k0 + c) * lda + k0 + r] = As[c * LP + r];
+  }
+}
+
+// ---------------------------------------------------------------- trsm: rows below the diagonal block
+// X <- X * L11^-T for rows [r0, n), columns [k0, k0+kb).  One thread per row, 16-column register
+// sub-blocks (keeps every unrolled body small).
+__global__ __launch_bounds__(256) void trsm_64_kernel(double* __restrict__ A, int lda, int n, int k0, int kb,
+                                                      int r0) {
+  __shared__ double Ls[NBI * LP];  // L11 (r, c) at c * LP + r
+  for (int idx = threadIdx.x; idx < NBI * NBI; idx += 256) {
+    const int c = idx / NBI, r = idx - c * NBI;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < kb && c < kb && c <= r) v = A[(size_t)(k0 + c) * lda + k0 + r];
+    Ls[c * LP + r] = v;
+  }
+  __syncthreads();
+  const int row = r0 + blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  double* arow = A + row;
+  for (int sb = 0; sb < NBI; sb += NBS) {
+    if (sb >= kb) break;
+    double x[NBS];
+#pragma unroll
+    for (int j = 0; j < NBS; ++j) x[j] = (sb + j < kb) ? arow[(size_t)(k0 + sb + j) * lda] : 0.0;
+    // contributions of the already solved columns (re-read from global: L1/L2 resident)
+    for (int t = 0; t < sb; ++t) {
+      const double xt = arow[(size_t)(k0 + t) * lda];
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) x[j] -= xt * Ls[t * LP + sb + j];
+    }
+#pragma unroll
+    for (int j = 0; j < NBS; ++j) {
+      double s = x[j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) s -= x[t] * Ls[(sb + t) * LP + sb + j];
+      x[j] = s / Ls[(sb + j) * LP + sb + j];
+    }
+#pragma unroll
+    for (int j = 0; j < NBS; ++j)
+      if (sb + j < kb) arow[(size_t)(k0 + sb + j) * lda] = x[j];
+  }
+}
+
+// ---------------------------------------------------------------- syrk on f64 MFMA
+// C[i][j] -= sum_k A[i][kc+k] * A[j][kc+k]   for j in [c_begin, c_end), i in [max(j, r_begin), n), lower part only.
+// grid.x enumerates 128x128 tiles (ti, tj) with ti >= tj over the region; K = kdim (multiple of 4, <= 256).
+constexpr int TM = 128, KC = 16, PITCH = 144;
+
+__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, int lda, int n, int r_begin,
+                                                        int c_begin, int c_end, int kc0, int kdim, int tiles_i,
+                                                        int tiles_j) {
+  __shared__ __attribute__((aligned(16))) double sP[KC * PITCH];  // rows i (C rows)   [k][i]
+  __shared__ __attribute__((aligned(16))) double sQ[KC * PITCH];  // rows j (C cols)   [k][j]
+  // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
+  const int tj = blockIdx.x % tiles_j, ti = blockIdx.x / tiles_j;
+  const int j0 = c_begin + tj * TM, i0 = r_begin + ti * TM;
+  if (i0 + TM <= j0) return;  // entirely in the strict upper triangle
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + 64 wr, cols j0 + 64 wc
+  double4_t acc[4][4];                  // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  // staging map: thread -> (k = tid / 16, 8 consecutive rows starting at (tid % 16) * 8)
+  const int sk = tid >> 4, sr = (tid & 15) * 8;
+  for (int kc = 0; kc < kdim; kc += KC) {
+    double p[8], q[8];
+    const int kk = kc + sk;
+    const size_t colP = (size_t)(kc0 + kk) * lda;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ri = i0 + sr + e, rj = j0 + sr + e;
+      p[e] = (kk < kdim && ri < n) ? A[colP + ri] : 0.0;
+      q[e] = (kk < kdim && rj < n && rj < c_end) ? A[colP + rj] : 0.0;
+    }
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sP[sk * PITCH + sr + e] = p[e];
+      sQ[sk * PITCH + sr + e] = q[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      double fa[4], fb[4];
+      const int krow = (4 * ks + (lane >> 4)) * PITCH;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = sQ[krow + 64 * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
+        fb[t] = sP[krow + 64 * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
+      }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[jt], fb[it], acc[jt][it], 0, 0, 0);
+    }
+  }
+  // C -= acc^T : lane holds, for tile (jt, it): j = jbase + (lane>>4) + 4r, i = ibase + (lane&15)
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = i0 + 64 * wr + 16 * it + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 64 * wc + 16 * jt + (lane >> 4) + 4 * r;
+        if (i < n && j < c_end && i >= j && i >= r_begin) {
+          double* c = &A[(size_t)j * lda + i];
+          *c -= acc[jt][it][r];
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------- blocked triangular solves
+// forward step k: y_k = L_kk^-1 b_k (every workgroup redundantly, wave 0), then b[rows below] -= L[rows, k-block] y_k
+// (b is read-only inside the k-block during this launch: the solved block goes to `w`)
+__global__ __launch_bounds__(256) void fwd_step_kernel(const double* __restrict__ A, int lda, int n, int k0, int kb,
+                                                       double* __restrict__ b, double* __restrict__ w) {
+  __shared__ double y[NBI];
+  __shared__ double Ls[NBI * (NBI + 1)];
+  for (int idx = threadIdx.x; idx < NBI * NBI; idx += 256) {
+    const int j = idx / NBI, t = idx - j * NBI;
+    double v = (j == t) ? 1.0 : 0.0;
+    if (j < kb && t < kb && t <= j) v = A[(size_t)(k0 + t) * lda + k0 + j];
+    Ls[t * (NBI + 1) + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int i = threadIdx.x;
+    double s = i < kb ? b[k0 + i] : 0.0;
+    // column-oriented forward substitution within one wave
+    for (int j = 0; j < NBI; ++j) {
+      const double yj = __shfl(s, j) / Ls[j * (NBI + 1) + j];
+      if (i == j) s = yj;
+      else if (i > j) s -= Ls[j * (NBI + 1) + i] * yj;
+    }
+    y[i] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < kb) w[k0 + threadIdx.x] = y[threadIdx.x];
+  const int row = k0 + kb + blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  double acc = b[row];
+  for (int t = 0; t < kb; ++t) acc -= A[(size_t)(k0 + t) * lda + row] * y[t];
+  b[row] = acc;
+}
+
+// backward step k: x_k = L_kk^-T y_k, then y[c] -= sum_r L[k0 + r][c] x_k[r] for all columns c < k0
+// (reads y from `w`, writes the solved block to b, updates w for the columns to the left)
+__global__ __launch_bounds__(256) void bwd_step_kernel(const double* __restrict__ A, int lda, int n, int k0, int kb,
+                                                       double* __restrict__ b, double* __restrict__ w) {
+  __shared__ double x[NBI];
+  __shared__ double Ls[NBI * (NBI + 1)];
+  for (int idx = threadIdx.x; idx < NBI * NBI; idx += 256) {
+    const int j = idx / NBI, t = idx - j * NBI;
+    double v = (j == t) ? 1.0 : 0.0;
+    if (j < kb && t < kb && t <= j) v = A[(size_t)(k0 + t) * lda + k0 + j];
+    Ls[t * (NBI + 1) + j] = v;  // Ls[t*65 + j] = L[j][t]
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int i = threadIdx.x;
+    double s = i < kb ? w[k0 + i] : 0.0;
+    // L^T x = y: process rows from the bottom; x_j = (y_j - sum_{i>j} L[i][j] x_i) / L[j][j]
+    for (int j = NBI - 1; j >= 0; --j) {
+      const double xj = __shfl(s, j) / Ls[j * (NBI + 1) + j];
+      if (i == j) s = xj;
+      else if (i < j) s -= Ls[i * (NBI + 1) + j] * xj;  // L[j][i]
+    }
+    x[i] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < kb) b[k0 + threadIdx.x] = x[threadIdx.x];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= k0) return;
+  double acc = w[c];
+  const double* col = A + (size_t)c * lda + k0;
+  for (int r = 0; r < kb; ++r) acc -= col[r] * x[r];
+  w[c] = acc;
+}
+
+}  // namespace
+
+// Factor (lower, in place) and optionally solve.  info_dev: device int (0 = ok, else first bad block column + 1).
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev) {
+  GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  for (int c0 = 0; c0 < n; c0 += NBO) {
+    const int pw = n - c0 < NBO ? n - c0 : NBO;  // panel width
+    for (int k = c0; k < c0 + pw; k += NBI) {
+      const int kb = c0 + pw - k < NBI ? c0 + pw - k : NBI;
+      GH_LAUNCH(ctx, "ba_potf2", potf2_64_kernel, dim3(1), dim3(256), 0, A, lda, k, kb, info_dev);
+      const int r0 = k + kb;
+      if (r0 < n) {
+        GH_LAUNCH(ctx, "ba_trsm", trsm_64_kernel, dim3(gh_div_up(n - r0, 256)), dim3(256), 0, A, lda, n, k, kb, r0);
+        // update the rest of this panel with the fresh 64 columns
+        const int cb = r0, ce = c0 + pw;
+        if (cb < ce) {
+          const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(n - cb, TM);
+          GH_LAUNCH(ctx, "ba_syrk_panel", syrk_mfma_kernel, dim3(tiles_i * tiles_j), dim3(256), 0, A, lda, n, cb, cb,
+                    ce, k, kb, tiles_i, tiles_j);
+        }
+      }
+    }
+    const int t0 = c0 + pw;
+    if (t0 < n) {
+      const int tiles = gh_div_up(n - t0, TM);
+      GH_LAUNCH(ctx, "ba_syrk_trailing", syrk_mfma_kernel, dim3(tiles * tiles), dim3(256), 0, A, lda, n, t0, t0, n,
+                c0, pw, tiles, tiles);
+    }
+  }
+  return GH_OK;
+}
+
+// work: n doubles of device scratch
+gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work) {
+  for (int k = 0; k < n; k += NBI) {
+    const int kb = n - k < NBI ? n - k : NBI;
+    const int rows = n - (k + kb);
+    GH_LAUNCH(ctx, "ba_trsv_fwd", fwd_step_kernel, dim3(rows > 0 ? gh_div_up(rows, 256) : 1), dim3(256), 0, L, lda, n,
+              k, kb, b, work);
+  }
+  const int last = ((n - 1) / NBI) * NBI;
+  for (int k = last; k >= 0; k -= NBI) {
+    const int kb = n - k < NBI ? n - k : NBI;
+    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step_kernel, dim3(k > 0 ? gh_div_up(k, 256) : 1), dim3(256), 0, L, lda, n, k, kb,
+              b, work);
+  }
+  return GH_OK;
+}
+
+extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
+  void* scratch = nullptr;
+  GH_TRY(gh_scratch(ctx, 256 + (size_t)n * sizeof(double), &scratch));
+  int* info_dev = (int*)scratch;
+  double* work = (double*)((char*)scratch + 256);
+  GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev));
+  GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (*info == 0 && b_dev) GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work));
+  return GH_OK;
+}

@@ -68,18 +68,32 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
   const uint32_t ty = ytab[y];
   const int sy = ty >> 16, fy = ty & 0xFFFF;
   const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
-  const uint8_t* r0 = s + (size_t)sy * src.pitch;
-  const uint8_t* r1 = s + (size_t)sy1 * src.pitch;
+  // The 4 outputs read source columns sx0 .. sx0+5 at most (scale 1.2): fetch the 12-byte aligned window
+  // of both rows with 3 dword loads each instead of 16 byte gathers; the x table (padded to a multiple
+  // of 4 entries, 16-byte aligned) comes in one dwordx4.
+  const uint4 tx4 = *reinterpret_cast<const uint4*>(xtab + x4);
+  const uint32_t txs[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
+  const int a0 = (int)(tx4.x >> 16) & ~3;
+  const int last_dw = (src.pitch >> 2) - 1;
+  const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s + (size_t)sy * src.pitch);
+  const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s + (size_t)sy1 * src.pitch);
+  const int d0 = a0 >> 2, d1 = min(d0 + 1, last_dw), d2 = min(d0 + 2, last_dw);
+  const uint32_t u0 = q0[d0], u1 = q0[d1], u2 = q0[d2];
+  const uint32_t v0 = q1[d0], v1 = q1[d1], v2 = q1[d2];
+  const uint64_t ulo = (uint64_t)u0 | ((uint64_t)u1 << 32), uhi = (uint64_t)u1 | ((uint64_t)u2 << 32);
+  const uint64_t vlo = (uint64_t)v0 | ((uint64_t)v1 << 32), vhi = (uint64_t)v1 | ((uint64_t)v2 << 32);
   uint32_t packed = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int x = x4 + i;
-    x = x < wd ? x : wd - 1;
-    const uint32_t tx = xtab[x];
+    const uint32_t tx = txs[i];
     const int sx = tx >> 16, fx = tx & 0xFFFF;
     const int sx1 = sx + 1 < src.w ? sx + 1 : src.w - 1;
-    uint32_t v = (uint32_t)r0[sx] * (2048 - fx) * (2048 - fy) + (uint32_t)r0[sx1] * fx * (2048 - fy) +
-                 (uint32_t)r1[sx] * (2048 - fx) * fy + (uint32_t)r1[sx1] * fx * fy;
+    const int o0 = sx - a0, o1 = sx1 - a0;  // 0..11
+    const uint32_t a00 = (uint32_t)((o0 < 4 ? ulo >> (8 * o0) : uhi >> (8 * (o0 - 4))) & 0xFF);
+    const uint32_t a01 = (uint32_t)((o1 < 4 ? ulo >> (8 * o1) : uhi >> (8 * (o1 - 4))) & 0xFF);
+    const uint32_t a10 = (uint32_t)((o0 < 4 ? vlo >> (8 * o0) : vhi >> (8 * (o0 - 4))) & 0xFF);
+    const uint32_t a11 = (uint32_t)((o1 < 4 ? vlo >> (8 * o1) : vhi >> (8 * (o1 - 4))) & 0xFF);
+    uint32_t v = a00 * (2048 - fx) * (2048 - fy) + a01 * fx * (2048 - fy) + a10 * (2048 - fx) * fy + a11 * fx * fy;
     packed |= ((v + (1u << 21)) >> 22) << (8 * i);
   }
   // dst pitch is a multiple of 64 and the pad bytes are ours: always a full dword store
@@ -120,8 +134,11 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
+  __shared__ uint16_t queue[kScoreH * kScoreH];
+  __shared__ int q_count;
 
   const int tid = threadIdx.x;
+  if (tid == 0) q_count = 0;
   const int x0 = kEdge + 64 * blockIdx.x, y0 = kEdge + 64 * blockIdx.y;  // region origin
   const int ox = x0 - 4, oy = y0 - 4;                                    // tile origin (pixel)
   const int ax = ox & ~3;                                                // dword aligned load origin (ox - ax == 3)
@@ -138,40 +155,65 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   }
   __syncthreads();
 
-  // scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 6, row sy + 3
-  for (int i = tid; i < kScoreH * kScoreH; i += 256) {
-    const int sy = i / kScoreH, sx = i - sy * kScoreH;
-    const int px = x0 - 1 + sx, py = y0 - 1 + sy;
-    int s = 0;
-    if (px >= kEdge && px < lv.w - kEdge && py >= kEdge && py < lv.h - kEdge) {
-      const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 6];
-      const int c = p[0];
-      const int r0 = p[-3 * kTileW], r4 = p[3], r8 = p[3 * kTileW], r12 = p[-3];
-      const int nb = (r0 > c + min_th) + (r4 > c + min_th) + (r8 > c + min_th) + (r12 > c + min_th);
-      const int nd = (r0 < c - min_th) + (r4 < c - min_th) + (r8 < c - min_th) + (r12 < c - min_th);
-      if (nb >= 2 || nd >= 2) {
-        int d[16];
-        d[0] = r0 - c;
-        d[1] = p[-3 * kTileW + 1] - c;
-        d[2] = p[-2 * kTileW + 2] - c;
-        d[3] = p[-1 * kTileW + 3] - c;
-        d[4] = r4 - c;
-        d[5] = p[1 * kTileW + 3] - c;
-        d[6] = p[2 * kTileW + 2] - c;
-        d[7] = p[3 * kTileW + 1] - c;
-        d[8] = r8 - c;
-        d[9] = p[3 * kTileW - 1] - c;
-        d[10] = p[2 * kTileW - 2] - c;
-        d[11] = p[1 * kTileW - 3] - c;
-        d[12] = r12 - c;
-        d[13] = p[-1 * kTileW - 3] - c;
-        d[14] = p[-2 * kTileW - 2] - c;
-        d[15] = p[-3 * kTileW - 1] - c;
-        s = fast_score16(d);
-        s = s > min_th ? s : 0;
+  // Scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 6, row sy + 3.
+  // Pass 1: cheap necessary condition on the 4 compass pixels (any 9-arc holds two ADJACENT compass
+  // pixels) for every pixel; survivors are appended to an LDS queue so that pass 2 (the ~100-op arc
+  // score) runs with all lanes busy instead of paying full price in every partially-hit wave.
+  // The queue order is irrelevant: results land in score[] by position.
+  for (int i0 = 0; i0 < kScoreH * kScoreH; i0 += 256) {
+    const int i = i0 + tid;
+    bool cand = false;
+    int sy = 0, sx = 0;
+    if (i < kScoreH * kScoreH) {
+      sy = i / kScoreH;
+      sx = i - sy * kScoreH;
+      const int px = x0 - 1 + sx, py = y0 - 1 + sy;
+      if (px >= kEdge && px < lv.w - kEdge && py >= kEdge && py < lv.h - kEdge) {
+        const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 6];
+        const int c = p[0];
+        const int r0 = p[-3 * kTileW], r4 = p[3], r8 = p[3 * kTileW], r12 = p[-3];
+        const int hi = c + min_th, lo = c - min_th;
+        const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
+        const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
+        cand = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (d0 && d4) || (d4 && d8) || (d8 && d12) ||
+               (d12 && d0);
       }
+      score[sy * kScoreW + sx] = 0;
     }
-    score[sy * kScoreW + sx] = (uint8_t)s;
+    const uint64_t m = __ballot(cand);
+    if (m != 0ull) {
+      int base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(&q_count, __popcll(m));
+      base = __shfl(base, 0);
+      if (cand) queue[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(sy * kScoreW + sx);
+    }
+  }
+  __syncthreads();
+  const int nq = q_count;
+  for (int i = tid; i < nq; i += 256) {
+    const int pos = queue[i];
+    const int sy = pos / kScoreW, sx = pos - sy * kScoreW;
+    const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 6];
+    const int c = p[0];
+    int d[16];
+    d[0] = p[-3 * kTileW] - c;
+    d[1] = p[-3 * kTileW + 1] - c;
+    d[2] = p[-2 * kTileW + 2] - c;
+    d[3] = p[-1 * kTileW + 3] - c;
+    d[4] = p[3] - c;
+    d[5] = p[1 * kTileW + 3] - c;
+    d[6] = p[2 * kTileW + 2] - c;
+    d[7] = p[3 * kTileW + 1] - c;
+    d[8] = p[3 * kTileW] - c;
+    d[9] = p[3 * kTileW - 1] - c;
+    d[10] = p[2 * kTileW - 2] - c;
+    d[11] = p[1 * kTileW - 3] - c;
+    d[12] = p[-3] - c;
+    d[13] = p[-1 * kTileW - 3] - c;
+    d[14] = p[-2 * kTileW - 2] - c;
+    d[15] = p[-3 * kTileW - 1] - c;
+    const int s = fast_score16(d);
+    if (s > min_th) score[pos] = (uint8_t)s;
   }
   __syncthreads();
 
@@ -364,7 +406,7 @@ struct DescribeArgs {
   int nlevels;
 };
 
-constexpr int kPatch = 37, kPatchPitch = 40;
+constexpr int kPatch = 37, kPatchPitch = 40;  // 10 dwords per row cover any 37-byte run
 
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
@@ -406,12 +448,16 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   const SelKp kp = sel[(size_t)b * K + slot];
   const LevelView lv = a.lv[l];
   const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
-  uint8_t* patch = s_patch[wv];
+  // 37x37 patch: each row is fetched as the 10 aligned dwords that cover it (the 37 bytes start at
+  // offset px0 & 3 of the window), so `patch` below points at the first wanted byte of row 0.
   const int px0 = (int)kp.x - 18, py0 = (int)kp.y - 18;
-  for (int idx = lane; idx < kPatch * kPatch; idx += 64) {
-    const int r = idx / kPatch, c = idx - r * kPatch;
-    patch[r * kPatchPitch + c] = img[(size_t)(py0 + r) * lv.pitch + px0 + c];
+  const int pa = px0 & ~3;
+  for (int idx = lane; idx < kPatch * 10; idx += 64) {
+    const int r = idx / 10, c = idx - r * 10;
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch + pa + 4 * c);
+    *reinterpret_cast<uint32_t*>(&s_patch[wv][r * kPatchPitch + 4 * c]) = v;
   }
+  const uint8_t* patch = s_patch[wv] + (px0 - pa);
   __builtin_amdgcn_wave_barrier();
   // intensity centroid over the radius-15 disc (patch centre at [18][18])
   int m10 = 0, m01 = 0;
@@ -621,7 +667,8 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   const int K = prm.n_features;
   // resize tables
   size_t tab_words = 0;
-  for (int l = 1; l < L; ++l) tab_words += (size_t)p->lw[l] + p->lh[l];
+  // every table starts 16-byte aligned and is padded (last entry replicated) to a multiple of 4 entries
+  for (int l = 1; l < L; ++l) tab_words += (((size_t)p->lw[l] + 3) & ~(size_t)3) + (((size_t)p->lh[l] + 3) & ~(size_t)3);
   std::vector<uint32_t> htab(tab_words ? tab_words : 1);
   do {
     if ((st = plan_alloc(p, B * p->slab, (void**)&p->pyr)) != GH_OK) break;
@@ -647,6 +694,10 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
             fx = 0;
           }
           htab[tw++] = ((uint32_t)sx << 16) | (uint32_t)fx;
+        }
+        while (tw & 3) {
+          htab[tw] = htab[tw - 1];
+          ++tw;
         }
       }
     }

@@ -1,0 +1,74 @@
+// FeatureDetector — plugin interface for the ORB front end + brute-force matcher.
+//
+// GSLAM 3.0.0 has NO such interface (the ORB extractor lives in the external gslam_orbslam plugin;
+// grep of /root/reference finds only LoopDetector, GSLAM/core/Map.h:381-395).  This header adds one in
+// the idiom of GSLAM/core/Optimizer.h:42-51,184-253: an abstract class with bool-returning virtuals
+// that default to "unsupported", a static create() that resolves `FeatureDetectorPlugin`
+// (default "libgslam_featuredetector") through GSLAM::Registry, and an unmangled factory symbol
+// `createFeatureDetectorInstance`.  Data types are GSLAM's own: GImage (8UC1 image / N x 32 descriptor
+// matrix, GSLAM/core/GImage.h), KeyPoint (GSLAM/core/Map.h:122-195), match list as
+// vector<pair<int,int>> (FrameConnection::getMatches, Map.h:252-258), inlier mask vector<uchar>
+// (as in GSLAM/core/Estimator.h:100-169).
+#ifndef GSLAM_AMD_FEATUREDETECTOR_H_
+#define GSLAM_AMD_FEATUREDETECTOR_H_
+
+#include <GSLAM/core/GSLAM.h>
+
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#define GSLAM_REGISTER_FEATUREDETECTOR(DET_CLASS)                                          \
+  extern "C" std::shared_ptr<GSLAM::FeatureDetector> createFeatureDetectorInstance() {     \
+    return std::shared_ptr<GSLAM::FeatureDetector>(new DET_CLASS());                       \
+  }
+
+namespace GSLAM {
+
+class FeatureDetector;
+typedef std::shared_ptr<FeatureDetector> (*funcCreateFeatureDetectorInstance)();
+
+struct FeatureDetectorConfig {
+  int nFeatures = 1000;   // ORB-SLAM nFeatures
+  int nLevels = 8;        // scale factor fixed at 1.2
+  int iniThFAST = 20;
+  int minThFAST = 7;
+  int matchMaxDistance = 100;   // Hamming threshold (ORB-SLAM TH_HIGH)
+  int matchRatioNum = 0, matchRatioDen = 1;  // ratio test d1 * den < num * d2; num <= 0 disables
+  bool matchCrossCheck = false;
+};
+
+class FeatureDetector {
+ public:
+  explicit FeatureDetector(FeatureDetectorConfig config = FeatureDetectorConfig()) : _config(config) {}
+  virtual ~FeatureDetector() {}
+
+  // gray (8UC1) or BGR/BGRA (8UC3/8UC4) image -> keypoints + N x 32 descriptors (8UC1)
+  virtual bool detectAndCompute(const GImage& image, std::vector<KeyPoint>& keypoints, GImage& descriptors) {
+    return false;
+  }
+  // brute-force Hamming matches (query idx, train idx) for the queries that pass the configured tests;
+  // mask (optional) has one entry per query row
+  virtual bool match(const GImage& queryDescriptors, const GImage& trainDescriptors,
+                     std::vector<std::pair<int, int> >& matches, std::vector<uchar>* mask = NULL) {
+    return false;
+  }
+
+  static std::shared_ptr<FeatureDetector> create(std::string pluginName = "") {
+    if (pluginName.empty()) pluginName = svar.GetString("FeatureDetectorPlugin", "libgslam_featuredetector");
+    std::shared_ptr<SharedLibrary> plugin = Registry::get(pluginName);
+    if (!plugin) return std::shared_ptr<FeatureDetector>();
+    funcCreateFeatureDetectorInstance f =
+        (funcCreateFeatureDetectorInstance)plugin->getSymbol("createFeatureDetectorInstance");
+    if (!f) return std::shared_ptr<FeatureDetector>();
+    return f();
+  }
+
+  FeatureDetectorConfig _config;
+};
+
+typedef std::shared_ptr<FeatureDetector> FeatureDetectorPtr;
+
+}  // namespace GSLAM
+#endif  // GSLAM_AMD_FEATUREDETECTOR_H_

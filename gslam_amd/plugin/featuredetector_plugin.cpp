@@ -1,0 +1,124 @@
+// libgslam_featuredetector.so — ORB extractor + brute-force Hamming matcher plugin on the MI355X.
+// Implements gslam_amd/plugin/FeatureDetector.h on top of the C ABI (gh_orb_*, gh_bf_*, gh_match_mask_dev).
+// Outputs use GSLAM's own containers: std::vector<GSLAM::KeyPoint> (GSLAM/core/Map.h:122-195, layout
+// identical to gh_keypoint) and an N x 32 8UC1 GImage (MapFrame::setKeyPoints, Map.h:311-312).
+#include "FeatureDetector.h"
+
+#include <cstring>
+#include <mutex>
+
+#include "gslam_hip.h"
+
+static_assert(sizeof(GSLAM::KeyPoint) == sizeof(gh_keypoint), "KeyPoint layout must match gh_keypoint");
+
+namespace {
+
+class FeatureDetectorHIP : public GSLAM::FeatureDetector {
+ public:
+  FeatureDetectorHIP() : ctx_(nullptr), plan_(nullptr), pw_(0), ph_(0), pk_(0), pl_(0) {}
+  ~FeatureDetectorHIP() override {
+    if (plan_) gh_orb_plan_destroy(plan_);
+    if (ctx_) gh_ctx_destroy(ctx_);
+  }
+
+  bool detectAndCompute(const GSLAM::GImage& image, std::vector<GSLAM::KeyPoint>& keypoints,
+                        GSLAM::GImage& descriptors) override {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (image.empty() || image.elemSize1() != 1 || !context()) return false;
+    const int w = image.cols, h = image.rows, ch = image.channels();
+    if (ch != 1 && ch != 3 && ch != 4) return false;
+    if (!plan_ || pw_ != w || ph_ != h || pk_ != _config.nFeatures || pl_ != _config.nLevels) {
+      if (plan_) gh_orb_plan_destroy(plan_);
+      plan_ = nullptr;
+      gh_orb_params p;
+      gh_orb_default_params(&p);
+      p.n_features = _config.nFeatures;
+      p.n_levels = _config.nLevels;
+      p.ini_th_fast = _config.iniThFAST;
+      p.min_th_fast = _config.minThFAST;
+      if (gh_orb_plan_create(ctx_, w, h, 1, &p, &plan_) != GH_OK) return fail("gh_orb_plan_create");
+      pw_ = w; ph_ = h; pk_ = _config.nFeatures; pl_ = _config.nLevels;
+    }
+    const int K = _config.nFeatures;
+    std::vector<gh_keypoint> kps((size_t)K);
+    std::vector<uint8_t> desc((size_t)K * 32);
+    int32_t n = 0;
+    if (ch == 1) {
+      if (gh_orb_extract_host(plan_, image.data, w, kps.data(), desc.data(), &n) != GH_OK)
+        return fail("gh_orb_extract_host");
+    } else {
+      // colour input (datasets deliver BGR/BGRA: GSLAM/plugins/datasets/IO.h:86-113): fixed-point luma on the GPU
+      void *d_bgr = nullptr, *d_gray = nullptr;
+      const size_t bgr_bytes = (size_t)w * h * ch, pitch = ((size_t)w + 63) & ~(size_t)63;
+      std::vector<uint8_t> gray((size_t)pitch * h);
+      bool ok = gh_dev_alloc(ctx_, bgr_bytes, &d_bgr) == GH_OK && gh_dev_alloc(ctx_, pitch * h, &d_gray) == GH_OK &&
+                gh_dev_upload(ctx_, d_bgr, image.data, bgr_bytes) == GH_OK &&
+                gh_bgr_to_gray_dev(ctx_, (const uint8_t*)d_bgr, w, h, ch, w * ch, (uint8_t*)d_gray, (int)pitch) == GH_OK &&
+                gh_dev_download(ctx_, gray.data(), d_gray, pitch * h) == GH_OK;
+      gh_dev_free(ctx_, d_bgr);
+      gh_dev_free(ctx_, d_gray);
+      if (!ok) return fail("bgr_to_gray");
+      if (gh_orb_extract_host(plan_, gray.data(), (int)pitch, kps.data(), desc.data(), &n) != GH_OK)
+        return fail("gh_orb_extract_host");
+    }
+    keypoints.resize((size_t)n);
+    if (n > 0) std::memcpy((void*)keypoints.data(), kps.data(), (size_t)n * sizeof(gh_keypoint));
+    descriptors = GSLAM::GImage(n, 32, GSLAM::GImageType<uchar>::Type, desc.data(), true);
+    return true;
+  }
+
+  bool match(const GSLAM::GImage& q, const GSLAM::GImage& t, std::vector<std::pair<int, int> >& matches,
+             std::vector<uchar>* mask = NULL) override {
+    std::lock_guard<std::mutex> lock(mu_);
+    matches.clear();
+    if (mask) mask->clear();
+    if (q.cols * q.elemSize() != 32 || (t.rows > 0 && t.cols * t.elemSize() != 32) || !context()) return false;
+    const int nq = q.rows, nt = t.rows;
+    if (nq == 0) return true;
+    if (nt > 65535) return false;
+    std::vector<int32_t> idx1((size_t)nq), back;
+    std::vector<uint16_t> d1((size_t)nq), d2((size_t)nq), bd1, bd2;
+    if (gh_bf_match_host(ctx_, q.data, nq, t.data, nt, idx1.data(), d1.data(), d2.data()) != GH_OK)
+      return fail("gh_bf_match_host");
+    if (_config.matchCrossCheck && nt > 0) {
+      back.resize((size_t)nt); bd1.resize((size_t)nt); bd2.resize((size_t)nt);
+      if (gh_bf_match_host(ctx_, t.data, nt, q.data, nq, back.data(), bd1.data(), bd2.data()) != GH_OK)
+        return fail("gh_bf_match_host(back)");
+    }
+    std::vector<uchar> keep((size_t)nq, 0);
+    for (int i = 0; i < nq; ++i) {  // same integer rules as gh_match_mask_dev (tiny, host side here)
+      const int j = idx1[i];
+      bool ok = j >= 0 && (int)d1[i] <= _config.matchMaxDistance;
+      if (ok && _config.matchRatioNum > 0) ok = (int)d1[i] * _config.matchRatioDen < _config.matchRatioNum * (int)d2[i];
+      if (ok && _config.matchCrossCheck) ok = j < nt && back[j] == i;
+      keep[i] = ok ? 1 : 0;
+      if (ok) matches.push_back(std::make_pair(i, j));
+    }
+    if (mask) mask->swap(keep);
+    return true;
+  }
+
+ private:
+  bool fail(const char* what) {
+    LOG(ERROR) << "FeatureDetectorHIP: " << what << " failed: " << (ctx_ ? gh_last_error(ctx_) : "no context");
+    return false;
+  }
+  bool context() {
+    if (!ctx_) {
+      const int dev = svar.GetInt("FeatureDetectorHIP.Device", 0);
+      if (gh_ctx_create(dev, &ctx_) != GH_OK) {
+        ctx_ = nullptr;
+        LOG(ERROR) << "FeatureDetectorHIP: no usable HIP device " << dev << " (there is no CPU fallback)";
+      }
+    }
+    return ctx_ != nullptr;
+  }
+  gh_ctx* ctx_;
+  gh_orb_plan* plan_;
+  int pw_, ph_, pk_, pl_;
+  std::mutex mu_;
+};
+
+}  // namespace
+
+GSLAM_REGISTER_FEATUREDETECTOR(FeatureDetectorHIP);

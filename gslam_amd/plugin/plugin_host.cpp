@@ -1,0 +1,157 @@
+// plugin_host — a minimal GSLAM host that exercises the drop-in boundary exactly as an application
+// plugin would: GSLAM::Optimizer::create() (GSLAM/core/Optimizer.h:234-248) and
+// GSLAM::FeatureDetector::create() resolve the plugins through GSLAM::Registry / dlopen, the host fills
+// GSLAM's own containers (BundleGraph, GImage, KeyPoint) and calls the virtuals.  Used by
+// tests/test_plugins_gpu.py; built here (needs the GSLAM headers), runs on the GPU box.
+//
+//   plugin_host ba   <plugin_dir> <graph.bin> <out.bin>
+//   plugin_host pnp  <plugin_dir> <pnp.bin> <out.bin>
+//   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
+#include <GSLAM/core/GSLAM.h>
+#include <GSLAM/core/Optimizer.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "FeatureDetector.h"
+
+using namespace GSLAM;
+
+template <typename T>
+static std::vector<T> read_vec(std::ifstream& f, size_t n) {
+  std::vector<T> v(n);
+  if (n) f.read((char*)v.data(), n * sizeof(T));
+  return v;
+}
+
+static int run_ba(const std::string& dir, const char* in, const char* out) {
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[6];  // nc, np, no, has_info, max_iterations, has_pfree
+  f.read((char*)hdr, sizeof(hdr));
+  double huber;
+  f.read((char*)&huber, 8);
+  const int nc = hdr[0], np = hdr[1], no = hdr[2];
+  std::vector<double> pose = read_vec<double>(f, (size_t)nc * 7);
+  std::vector<int32_t> dof = read_vec<int32_t>(f, nc);
+  std::vector<double> xyz = read_vec<double>(f, (size_t)np * 3);
+  std::vector<uint8_t> pfree = read_vec<uint8_t>(f, hdr[5] ? np : 0);
+  std::vector<int32_t> ocam = read_vec<int32_t>(f, no), opt = read_vec<int32_t>(f, no);
+  std::vector<double> oxy = read_vec<double>(f, (size_t)no * 2);
+  std::vector<double> info = read_vec<double>(f, hdr[3] ? (size_t)no * 4 : 0);
+
+  OptimizerPtr opt_ptr = Optimizer::create();
+  if (!opt_ptr) { std::cerr << "Optimizer::create() returned null\n"; return 2; }
+  opt_ptr->_config.projectErrorHuberThreshold = huber;
+  opt_ptr->_config.maxIterations = hdr[4];
+  BundleGraph g;
+  g.cameraDOF = UPDATE_CAMERA_NONE;
+  g.keyframes.resize(nc);
+  for (int i = 0; i < nc; ++i) {
+    const double* p = &pose[(size_t)i * 7];
+    g.keyframes[i].estimation = SIM3(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]), 1.0);
+    g.keyframes[i].dof = (KeyFrameEstimzationDOF)dof[i];
+  }
+  g.mappoints.resize(np);
+  for (int i = 0; i < np; ++i)
+    g.mappoints[i] = std::make_pair(Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), hdr[5] ? pfree[i] != 0 : true);
+  g.mappointObserves.resize(no);
+  for (int k = 0; k < no; ++k) {
+    BundleEdge e;
+    e.pointId = opt[k];
+    e.frameId = ocam[k];
+    e.measurement = Point3d(oxy[2 * k], oxy[2 * k + 1], 1.0);
+    e.information = hdr[3] ? &info[(size_t)k * 4] : NULL;
+    g.mappointObserves[k] = e;
+  }
+  const bool ok = opt_ptr->optimize(g);
+  std::ofstream o(out, std::ios::binary);
+  int32_t okv = ok ? 1 : 0;
+  o.write((char*)&okv, 4);
+  for (int i = 0; i < nc; ++i) {
+    const SIM3& T = g.keyframes[i].estimation;
+    SO3 r = T.get_rotation();
+    Point3d t = T.get_translation();
+    double p[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+    o.write((char*)p, sizeof(p));
+  }
+  for (int i = 0; i < np; ++i) {
+    double p[3] = {g.mappoints[i].first.x, g.mappoints[i].first.y, g.mappoints[i].first.z};
+    o.write((char*)p, sizeof(p));
+  }
+  // the other virtuals keep the interface's "unsupported" default
+  std::vector<std::pair<CameraAnchor, CameraAnchor> > m;
+  std::vector<IdepthEstimation> id;
+  SE3 rel;
+  std::cout << "optimize=" << ok << " optimizePose(unsupported)=" << opt_ptr->optimizePose(m, id, rel) << std::endl;
+  return ok ? 0 : 3;
+}
+
+static int run_pnp(const std::string& dir, const char* in, const char* out) {
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::ifstream f(in, std::ios::binary);
+  int32_t n;
+  f.read((char*)&n, 4);
+  std::vector<double> X = read_vec<double>(f, (size_t)n * 3), m = read_vec<double>(f, (size_t)n * 2),
+                      p = read_vec<double>(f, 7);
+  OptimizerPtr opt_ptr = Optimizer::create();
+  if (!opt_ptr) return 2;
+  std::vector<std::pair<Point3d, CameraAnchor> > matches(n);
+  for (int k = 0; k < n; ++k)
+    matches[k] = std::make_pair(Point3d(X[3 * k], X[3 * k + 1], X[3 * k + 2]), Point3d(m[2 * k], m[2 * k + 1], 1.0));
+  SE3 pose(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]));
+  double info[36];
+  const bool ok = opt_ptr->optimizePnP(matches, pose, UPDATE_KF_SE3, info);
+  std::ofstream o(out, std::ios::binary);
+  int32_t okv = ok ? 1 : 0;
+  o.write((char*)&okv, 4);
+  SO3 r = pose.get_rotation();
+  Point3d t = pose.get_translation();
+  double q[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+  o.write((char*)q, sizeof(q));
+  o.write((char*)info, sizeof(info));
+  return ok ? 0 : 3;
+}
+
+static int run_orb(const std::string& dir, int w, int h, int ch, const char* in, const char* out, int K) {
+  svar.GetString("FeatureDetectorPlugin", "") = dir + "/libgslam_featuredetector.so";
+  std::vector<uchar> img((size_t)w * h * ch);
+  std::ifstream f(in, std::ios::binary);
+  f.read((char*)img.data(), img.size());
+  FeatureDetectorPtr det = FeatureDetector::create();
+  if (!det) { std::cerr << "FeatureDetector::create() returned null\n"; return 2; }
+  det->_config.nFeatures = K;
+  GImage image(h, w, ch == 1 ? GImageType<uchar, 1>::Type : (ch == 3 ? GImageType<uchar, 3>::Type : GImageType<uchar, 4>::Type),
+               img.data(), false);
+  std::vector<KeyPoint> kps;
+  GImage desc;
+  const bool ok = det->detectAndCompute(image, kps, desc);
+  std::vector<std::pair<int, int> > matches;
+  std::vector<uchar> mask;
+  det->_config.matchCrossCheck = true;
+  const bool okm = ok && det->match(desc, desc, matches, &mask);
+  std::ofstream o(out, std::ios::binary);
+  int32_t hdr[4] = {ok ? 1 : 0, (int32_t)kps.size(), okm ? 1 : 0, (int32_t)matches.size()};
+  o.write((char*)hdr, sizeof(hdr));
+  if (!kps.empty()) {
+    o.write((char*)kps.data(), kps.size() * sizeof(KeyPoint));
+    o.write((char*)desc.data, (size_t)desc.rows * 32);
+    o.write((char*)matches.data(), matches.size() * sizeof(std::pair<int, int>));
+  }
+  std::cout << "detectAndCompute=" << ok << " keypoints=" << kps.size() << " match=" << okm << " matches="
+            << matches.size() << " desc=" << desc.rows << "x" << desc.cols << std::endl;
+  return ok && okm ? 0 : 3;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  const std::string mode = argv[1], dir = argv[2];
+  if (mode == "ba" && argc >= 5) return run_ba(dir, argv[3], argv[4]);
+  if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "orb" && argc >= 9)
+    return run_orb(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
+  return 1;
+}

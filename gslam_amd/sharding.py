@@ -1,0 +1,44 @@
+"""Multi-GPU sharding of the front end: frames are independent units, so rank r of a
+world of G owns the contiguous block of global frames [r F, (r+1) F).  There is exactly one exchange
+step on the data path: an RCCL all-gather of the fixed-capacity per-frame records (descriptors K x 32 B
++ count) so that every GPU holds every frame's descriptors, optionally followed by an all-gather of
+the match records.  Pure data movement: gathered buffers are byte-identical for every G.
+Bundle adjustment does not shard (one coupled dense system): replicas only.
+
+torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests) is plumbing here.
+"""
+import torch
+import torch.distributed as dist
+
+
+def local_pairs(rank: int, world: int, frames_per_rank: int, device="cpu"):
+    """Consecutive global frame pairs (g, g+1) owned by `rank`: g in [rank F, (rank+1) F), g+1 < world F.
+    Returned as indices into the gathered (world*F) frame axis."""
+    g0 = rank * frames_per_rank
+    g1 = min((rank + 1) * frames_per_rank, world * frames_per_rank - 1)
+    pq = torch.arange(g0, g1, dtype=torch.int32, device=device)
+    return pq, pq + 1
+
+
+def all_pairs_block(rank: int, world: int, n_frames_total: int, device="cpu"):
+    """Upper-triangle all-pairs (i < j) of the gathered frames, dealt round-robin to ranks."""
+    i, j = torch.triu_indices(n_frames_total, n_frames_total, offset=1)
+    sel = torch.arange(i.numel()) % world == rank
+    return i[sel].to(torch.int32).to(device), j[sel].to(torch.int32).to(device)
+
+
+def exchange_features(desc: torch.Tensor, counts: torch.Tensor, g_desc: torch.Tensor, g_counts: torch.Tensor):
+    """all-gather (F,K,32) u8 descriptors and (F,) counts into (G*F,K,32) / (G*F,)."""
+    dist.all_gather_into_tensor(g_desc.view(-1), desc.contiguous().view(-1))
+    dist.all_gather_into_tensor(g_counts, counts)
+
+
+def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
+    """all-gather per-rank (F,K) int32 match rows into (G,F,K); ranks with fewer than F pairs pad with -1."""
+    P, K = idx1.shape
+    if P < frames_per_rank:
+        pad = torch.full((frames_per_rank - P, K), -1, dtype=idx1.dtype, device=idx1.device)
+        send = torch.cat([idx1, pad])
+    else:
+        send = idx1
+    dist.all_gather_into_tensor(g_idx1.view(-1), send.contiguous().view(-1))

@@ -428,7 +428,10 @@ int oracle_ba_solve(int nc, int np, int no, double* poses, const int32_t* dof, d
         double Lr[2] = {L[0] * r[0] + L[1] * r[1], L[2] * r[0] + L[3] * r[1]};
         model -= Jd[0] * Lr[0] + Jd[1] * Lr[1] + 0.5 * (Jd[0] * LJd[0] + Jd[1] * LJd[1]);
       }
-      for (int ci = 0; ci < nc; ++ci) oracle_se3_retract(poses + 7 * ci, dc + 6 * ci, poses_new + 7 * ci);
+      for (int ci = 0; ci < nc; ++ci) {
+        if ((dof[ci] & 63) == 0) memcpy(poses_new + 7 * ci, poses + 7 * ci, 56); /* fixed: bitwise untouched */
+        else oracle_se3_retract(poses + 7 * ci, dc + 6 * ci, poses_new + 7 * ci);
+      }
       for (int i = 0; i < 3 * np; ++i) pts_new[i] = pts[i] + dp[i];
       new_cost = total_cost(&c, poses_new, pts_new);
       rho = model > 0 ? (cost - new_cost) / model : -1;

@@ -1,0 +1,109 @@
+"""Drop-in boundary on the GPU box: a real GSLAM host (build/plugin_host, compiled against the GSLAM
+headers in the authoring container) loads libgslam_optimizer.so / libgslam_featuredetector.so through
+GSLAM::Optimizer::create() / Registry / dlopen and drives them with GSLAM's own containers.  Results
+must equal the C-ABI path (bit-exact for ORB/BF, tolerance for BA)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from gslam_amd.ba_synth import make_graph
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "build", "plugin_host")
+LIBDIR = os.path.join(ROOT, "gslam_amd", "lib")
+
+
+def _need_host():
+    if not (os.path.exists(HOST) and os.path.exists(os.path.join(LIBDIR, "libgslam_optimizer.so"))):
+        pytest.fail("build/plugin_host or the plugin .so files are missing: run `make plugins` in the authoring "
+                    "container (they travel to the GPU box as built artefacts)")
+
+
+def _run(args):
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIBDIR + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([HOST] + [str(a) for a in args], capture_output=True, text=True, timeout=300, env=env)
+    return r
+
+
+def test_optimizer_plugin_optimize_matches_oracle(tmp_path, oracle):
+    _need_host()
+    g = make_graph(10, 200, n_obs_per_point=4, seed=21)
+    g["point_free"] = np.ones(200, np.uint8)
+    g["point_free"][:5] = 0
+    inp, out = tmp_path / "graph.bin", tmp_path / "out.bin"
+    nc, npt, no = len(g["cam_pose"]), len(g["point_xyz"]), len(g["obs_cam"])
+    with open(inp, "wb") as f:
+        f.write(np.array([nc, npt, no, 0, 30, 1], np.int32).tobytes())
+        f.write(struct.pack("d", 0.01))
+        for k, dt in (("cam_pose", np.float64), ("cam_dof", np.int32), ("point_xyz", np.float64),
+                      ("point_free", np.uint8), ("obs_cam", np.int32), ("obs_point", np.int32),
+                      ("obs_xy", np.float64)):
+            f.write(np.ascontiguousarray(g[k], dtype=dt).tobytes())
+    r = _run(["ba", LIBDIR, inp, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "optimize=1 optimizePose(unsupported)=0" in r.stdout
+    raw = open(out, "rb").read()
+    assert struct.unpack("i", raw[:4])[0] == 1
+    poses = np.frombuffer(raw, np.float64, nc * 7, 4).reshape(nc, 7)
+    pts = np.frombuffer(raw, np.float64, npt * 3, 4 + nc * 56).reshape(npt, 3)
+    po, xo, so, _ = oracle.ba_solve(g, oracle_lib.ba_options(max_iterations=30))
+    assert np.abs(poses - po).max() < 1e-7 and np.abs(pts - xo).max() < 1e-7
+    assert np.array_equal(pts[:5], g["point_xyz"][:5]) and np.array_equal(poses[0], g["cam_pose"][0])
+
+
+def test_optimizer_plugin_pnp(tmp_path, oracle):
+    _need_host()
+    g = make_graph(3, 150, n_obs_per_point=3, seed=11, noise=0.0, outlier_frac=0.0, perturb=False)
+    sel = g["obs_cam"] == 1
+    X = g["point_xyz_gt"][g["obs_point"][sel]]
+    m = g["obs_xy"][sel]
+    truth = g["cam_pose_gt"][1]
+    start = oracle.se3_retract(truth, np.array([0.05, -0.04, 0.03, 0.01, -0.02, 0.015]))
+    inp, out = tmp_path / "pnp.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("i", len(X)))
+        f.write(X.astype(np.float64).tobytes() + m.astype(np.float64).tobytes() + start.tobytes())
+    r = _run(["pnp", LIBDIR, inp, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    pose = np.frombuffer(raw, np.float64, 7, 4)
+    info = np.frombuffer(raw, np.float64, 36, 4 + 56).reshape(6, 6)
+    assert np.abs(pose - truth).max() < 1e-9
+    assert np.allclose(info, info.T) and np.all(np.linalg.eigvalsh(info) > 0)
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_featuredetector_plugin_matches_oracle(tmp_path, oracle, channels):
+    _need_host()
+    w, h, K = 640, 480, 800
+    gray = oracle.synth_frame(w, h, 4242)
+    if channels == 1:
+        img, expect_gray = gray, gray
+    else:
+        rng = np.random.default_rng(5)
+        img = np.stack([gray, np.roll(gray, 3, axis=1), rng.integers(0, 256, gray.shape, dtype=np.uint8)], axis=2)
+        expect_gray = oracle.bgr_to_gray(img)
+    inp, out = tmp_path / "img.raw", tmp_path / "out.bin"
+    img.tofile(inp)
+    r = _run(["orb", LIBDIR, w, h, channels, inp, out, K])
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    ok, n, okm, nm = struct.unpack("4i", raw[:16])
+    ek, ed = oracle.orb_extract(expect_gray, K)
+    assert ok == 1 and n == len(ek)
+    kps = np.frombuffer(raw, oracle_lib.KP_DTYPE, n, 16)
+    desc = np.frombuffer(raw, np.uint8, n * 32, 16 + n * 28).reshape(n, 32)
+    assert kps.tobytes() == ek.tobytes() and np.array_equal(desc, ed)
+    matches = np.frombuffer(raw, np.int32, nm * 2, 16 + n * 60).reshape(nm, 2)
+    # self-match with cross-check: every row matches itself unless an identical earlier row exists
+    e = oracle.bf_match(ed, ed)
+    keep = oracle.match_mask(e[0], e[1], e[2], e[0], n, 100, 0, 1, 1)
+    exp_matches = np.stack([np.nonzero(keep)[0], e[0][keep == 1]], axis=1).astype(np.int32)
+    assert okm == 1 and np.array_equal(matches, exp_matches)
