@@ -174,7 +174,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath)).get(dom, {})
+            # measured in a separate --pmc pass at rec["frames_per_launch"] frames; traffic scales with frames
+            traffic = int(rec["hbm_bytes_per_launch"] * F / rec["frames_per_launch"]) if rec else None
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

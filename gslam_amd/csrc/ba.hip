@@ -9,13 +9,14 @@
 //   lin_points   1 thread / point over its CSR observation list   -> Hpp (3x3), g_p
 //   lin_cams     1 wave / camera over its CSR list, fixed shuffle tree -> Hcc (6x6), g_c   (deterministic)
 //   damp_points  (Hpp + D)^-1 closed form
-//   schur        S = Hcc + D - sum_p W Hpp^-1 W^T :  deterministic mode: 1 wave / camera row-block owns its
-//                rows of S and walks its observations in order (no atomics); fast mode: f64 atomics
+//   schur        S = Hcc + D - sum_p W Hpp^-1 W^T :  deterministic mode: pair list sorted by destination 6x6
+//                block, 1 wave / block, fixed butterfly (no atomics); fast mode: f64 atomics
 //   potrf/potrs  chol.hip (v_mfma_f64_16x16x4_f64 trailing updates)
 //   backsub      1 thread / point:  dp = Hpp^-1 (-g_p - sum W^T dc)
 //   update+eval  retract poses (guarded SE3::exp, GSLAM/core/SE3.h:257-287), candidate robust cost and the
 //                model decrease, fixed-order block reduction -> 2 doubles read back by the host loop.
 // Jacobians are recomputed where needed instead of being stored (80 B gathered beats 144 B of W traffic).
+#include <algorithm>
 #include <chrono>
 
 #include "common.h"
@@ -351,75 +352,86 @@ __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const doub
   }
 }
 
-// Deterministic mode: one wave owns camera row-block ci.  It walks the camera's observations in CSR
-// order; for observation i (point p) lane j handles the j-th observation of p.  Row-block ci of S and
-// rhs[6 ci ..] are touched by this wave only, in a fixed order -> bitwise reproducible.
-__global__ __launch_bounds__(64) void schur_rows_kernel(Problem P, const double* __restrict__ Hpi,
-                                                        const double* __restrict__ gp, double* __restrict__ S, int n,
-                                                        double* __restrict__ rhs) {
-  const int ci = blockIdx.x, lane = threadIdx.x;
-  double racc[6] = {0, 0, 0, 0, 0, 0};
-  for (int q = P.cstart[ci]; q < P.cstart[ci + 1]; ++q) {
-    const int k = P.clist[q];  // wave-uniform
+// Deterministic mode: segmented reduction over a pair list sorted by destination block.
+// The host builds, once per solve (the structure is fixed across LM iterations), every contributing pair
+// of observations (k, k2) of a common point with cam(k) >= cam(k2), stably sorted by (cam(k), cam(k2)),
+// plus the list of distinct blocks.  One wave per block: lanes stride over the block's pairs, accumulate
+// W_i Hpp^-1 W_j^T in registers, and a fixed butterfly sums the 64 partials -> bitwise reproducible,
+// no atomics, and a camera with 20k observations is as parallel as one with 20.
+struct SchurBlocks {
+  const int32_t* pair_a;   // observation index k  (row camera)
+  const int32_t* pair_b;   // observation index k2 (column camera)
+  const int32_t* bstart;   // nblocks + 1
+  const int32_t* bci;
+  const int32_t* bcj;
+  int nblocks;
+};
+
+__global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlocks B, const double* __restrict__ Hpi,
+                                                           const double* __restrict__ gp, double* __restrict__ S,
+                                                           int n, double* __restrict__ rhs) {
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= B.nblocks) return;
+  const int ci = B.bci[blk], cj = B.bcj[blk];
+  double acc[36], racc[6];
+#pragma unroll
+  for (int t = 0; t < 36; ++t) acc[t] = 0;
+#pragma unroll
+  for (int t = 0; t < 6; ++t) racc[t] = 0;
+  for (int e = B.bstart[blk] + lane; e < B.bstart[blk + 1]; e += 64) {
+    const int k = B.pair_a[e], k2 = B.pair_b[e];
     const int p = P.opt[k];
     Obs oi;
     if (!lin_obs(P, k, oi, true)) continue;
-    double L[4], Wi[18], WH[18];
+    double L[4], Wi[18], WH[18], Wj[18];
     weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, oi.w, L);
     make_W(oi, L, Wi);
     mul_WH(Wi, Hpi + (size_t)9 * p, WH);
+    if (k2 == k) {
+#pragma unroll
+      for (int t = 0; t < 18; ++t) Wj[t] = Wi[t];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        racc[a] += WH[3 * a] * gp[3 * p] + WH[3 * a + 1] * gp[3 * p + 1] + WH[3 * a + 2] * gp[3 * p + 2];
+    } else {
+      Obs oj;
+      if (!lin_obs(P, k2, oj, true)) continue;
+      double L2[4];
+      weighted_info(P.oinfo ? P.oinfo + 4 * k2 : nullptr, oj.w, L2);
+      make_W(oj, L2, Wj);
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a)
-      racc[a] += WH[3 * a] * gp[3 * p] + WH[3 * a + 1] * gp[3 * p + 1] + WH[3 * a + 2] * gp[3 * p + 2];
-    const int pb = P.pstart[p], pn = P.pstart[p + 1] - pb;
-    for (int base = 0; base < pn; base += 64) {
-      const int j = base + lane;
-      bool act = j < pn;
-      int cj = -1;
-      Obs oj;
-      int k2 = 0;
-      if (act) {
-        k2 = P.plist[pb + j];
-        cj = P.ocam[k2];
-        act = cj <= ci && lin_obs(P, k2, oj, true);
-      }
-      // two observations of the same point in the same camera would collide: serialise those lanes
-      // (first lane of each distinct camera goes in round 0, the next in round 1, ...)
-      int round = 0;
-      if (act) {
-        for (int jj = base; jj < j; ++jj)
-          if (P.ocam[P.plist[pb + jj]] == cj) ++round;
-      }
-      int max_round = round;
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) max_round = max(max_round, __shfl_xor(max_round, off));
-      double Wj[18];
-      if (act) {
-        double L2[4];
-        weighted_info(P.oinfo ? P.oinfo + 4 * k2 : nullptr, oj.w, L2);
-        make_W(oj, L2, Wj);
-      }
-      for (int rd = 0; rd <= max_round; ++rd) {
-        if (act && round == rd) {
+      for (int b = 0; b < 6; ++b)
+        acc[6 * a + b] += WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
+  }
 #pragma unroll
-          for (int a = 0; a < 6; ++a)
+  for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-              if (ci == cj && a < b) continue;
-              const double v = WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
-              // plain read-modify-write: this wave is the only writer of row-block ci (device-scope f64
-              // atomics execute memory-side on the 8-XCD part and cost ~2 us each - measured 44 ms/iter)
-              double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
-              *dst = *dst - v;
-            }
-        }
-        // order this round's stores before the next round's loads of possibly the same block
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      }
+    for (int t = 0; t < 36; ++t) acc[t] += __shfl_xor(acc[t], off);
+  }
+  if (ci == cj) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) racc[t] += __shfl_xor(racc[t], off);
     }
   }
-  if (lane == 0)
-    for (int a = 0; a < 6; ++a) rhs[6 * ci + a] += racc[a];
+  // lane b owns column b of the 6x6 block (this wave is the block's only writer)
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    if (lane == b) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        if (ci == cj && a < b) continue;  // lower triangle only
+        double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
+        *dst = *dst - acc[6 * a + b];
+      }
+      if (ci == cj) rhs[6 * ci + b] += racc[b];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const double* __restrict__ Hpi,
@@ -621,6 +633,45 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   build_csr(pr->obs_point, no, np, pstart, plist);
   build_csr(pr->obs_cam, no, nc, cstart, clist);
 
+  // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant)
+  std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
+  if (opt.deterministic && no > 0) {
+    std::vector<std::pair<int32_t, int32_t>> tmp;  // (cj, local sequence) for one row camera
+    std::vector<int32_t> ta, tb;
+    for (int ci = 0; ci < nc; ++ci) {
+      tmp.clear();
+      ta.clear();
+      tb.clear();
+      for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
+        const int k = clist[q], p = pr->obs_point[k];
+        for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
+          const int k2 = plist[q2], cj = pr->obs_cam[k2];
+          if (cj > ci) continue;
+          tmp.emplace_back(cj, (int32_t)ta.size());
+          ta.push_back(k);
+          tb.push_back(k2);
+        }
+      }
+      std::stable_sort(tmp.begin(), tmp.end(),
+                       [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+                         return x.first < y.first;
+                       });
+      int last = -1;
+      for (const auto& t : tmp) {
+        if (t.first != last) {
+          bstart.push_back((int32_t)pair_a.size());
+          bci.push_back(ci);
+          bcj.push_back(t.first);
+          last = t.first;
+        }
+        pair_a.push_back(ta[t.second]);
+        pair_b.push_back(tb[t.second]);
+      }
+    }
+    bstart.push_back((int32_t)pair_a.size());
+  }
+  const int nblocks = (int)bci.size();
+
   DevBuf db(ctx);
   double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
   int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
@@ -639,6 +690,16 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.upload(&d_plist, (const int32_t*)plist.data(), plist.size()));
   GH_TRY(db.upload(&d_cstart, (const int32_t*)cstart.data(), cstart.size()));
   GH_TRY(db.upload(&d_clist, (const int32_t*)clist.data(), clist.size()));
+  SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nblocks};
+  if (nblocks > 0) {
+    int32_t *d_pa, *d_pb, *d_bs, *d_bci, *d_bcj;
+    GH_TRY(db.upload(&d_pa, (const int32_t*)pair_a.data(), pair_a.size()));
+    GH_TRY(db.upload(&d_pb, (const int32_t*)pair_b.data(), pair_b.size()));
+    GH_TRY(db.upload(&d_bs, (const int32_t*)bstart.data(), bstart.size()));
+    GH_TRY(db.upload(&d_bci, (const int32_t*)bci.data(), bci.size()));
+    GH_TRY(db.upload(&d_bcj, (const int32_t*)bcj.data(), bcj.size()));
+    SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, nblocks};
+  }
   double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work;
   unsigned long long* d_gmax;
   int *d_bad, *d_info;
@@ -708,7 +769,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_LAUNCH(ctx, "ba_schur_diag", schur_diag_kernel, dim3(nc), dim3(64), 0, nc, d_Hcc, d_gc, radius, d_S, lda, d_dc);
     if (no > 0) {
       if (opt.deterministic)
-        GH_LAUNCH(ctx, "ba_schur_rows", schur_rows_kernel, dim3(nc), dim3(64), 0, P, d_Hpi, d_gp, d_S, lda, d_dc);
+        GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, P, SB, d_Hpi,
+                  d_gp, d_S, lda, d_dc);
       else
         GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
                   d_S, lda, d_dc);

@@ -16,6 +16,8 @@
 //               cut-off, block scans give the output slots - no sort, no float
 //   describe    one wave per keypoint: 37x37 patch in LDS, wave-reduced integer moments, separable
 //               integer blur in LDS, 4 x __ballot packs the 256 test bits
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/gslam_orb_tables.h"
 
@@ -122,7 +124,7 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16]) {
   return best;
 }
 
-constexpr int kTileW = 80;   // bytes per LDS tile row (20 dwords), 72 rows
+constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligned window that covers x0-4 .. x0+67), 72 rows
 constexpr int kTileH = 72;
 constexpr int kScoreW = 68;  // 66 used
 constexpr int kScoreH = 66;
@@ -130,7 +132,7 @@ constexpr int kScoreH = 66;
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                         int cell_off) {
+                                                         int cell_off, int ablate) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
@@ -140,22 +142,23 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   const int tid = threadIdx.x;
   if (tid == 0) q_count = 0;
   const int x0 = kEdge + 64 * blockIdx.x, y0 = kEdge + 64 * blockIdx.y;  // region origin
-  const int ox = x0 - 4, oy = y0 - 4;                                    // tile origin (pixel)
-  const int ax = ox & ~3;                                                // dword aligned load origin (ox - ax == 3)
+  const int oy = y0 - 4;                       // tile origin row
+  const int ax = 64 * blockIdx.x;              // 16-byte aligned tile origin column: x0 - 4 == ax + 15
   const uint8_t* img = lv.base + (size_t)blockIdx.z * lv.frame_stride;
 
-  for (int i = tid; i < kTileH * (kTileW / 4); i += 256) {
-    const int row = i / (kTileW / 4), c = i - row * (kTileW / 4);
+  // 16 B per lane: rows of the level are 16-byte aligned (pitch % 16 == 0, checked by the launcher)
+  for (int i = tid; i < kTileH * (kTileW / 16); i += 256) {
+    const int row = i / (kTileW / 16), c = i - row * (kTileW / 16);
     int gy = oy + row;
     gy = gy < 0 ? 0 : (gy > lv.h - 1 ? lv.h - 1 : gy);
-    int gx = ax + 4 * c;
-    gx = gx < 0 ? 0 : (gx > lv.pitch - 4 ? lv.pitch - 4 : gx);
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * lv.pitch + gx);
-    *reinterpret_cast<uint32_t*>(&tile[row * kTileW + 4 * c]) = v;
+    int gx = ax + 16 * c;
+    gx = gx > lv.pitch - 16 ? lv.pitch - 16 : gx;
+    const uint4 v = *reinterpret_cast<const uint4*>(img + (size_t)gy * lv.pitch + gx);
+    *reinterpret_cast<uint4*>(&tile[row * kTileW + 16 * c]) = v;
   }
   __syncthreads();
 
-  // Scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 6, row sy + 3.
+  // Scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 18, row sy + 3.
   // Pass 1: cheap necessary condition on the 4 compass pixels (any 9-arc holds two ADJACENT compass
   // pixels) for every pixel; survivors are appended to an LDS queue so that pass 2 (the ~100-op arc
   // score) runs with all lanes busy instead of paying full price in every partially-hit wave.
@@ -163,13 +166,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   for (int i0 = 0; i0 < kScoreH * kScoreH; i0 += 256) {
     const int i = i0 + tid;
     bool cand = false;
+    if (ablate >= 2) {  // debug ablation (GH_ORB_ABLATE): no scoring at all
+      if (i < kScoreH * kScoreH) score[(i / kScoreH) * kScoreW + i % kScoreH] = 0;
+      continue;
+    }
     int sy = 0, sx = 0;
     if (i < kScoreH * kScoreH) {
       sy = i / kScoreH;
       sx = i - sy * kScoreH;
       const int px = x0 - 1 + sx, py = y0 - 1 + sy;
       if (px >= kEdge && px < lv.w - kEdge && py >= kEdge && py < lv.h - kEdge) {
-        const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 6];
+        const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 18];
         const int c = p[0];
         const int r0 = p[-3 * kTileW], r4 = p[3], r8 = p[3 * kTileW], r12 = p[-3];
         const int hi = c + min_th, lo = c - min_th;
@@ -189,11 +196,11 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     }
   }
   __syncthreads();
-  const int nq = q_count;
+  const int nq = ablate >= 1 ? 0 : q_count;
   for (int i = tid; i < nq; i += 256) {
     const int pos = queue[i];
     const int sy = pos / kScoreW, sx = pos - sy * kScoreW;
-    const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 6];
+    const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 18];
     const int c = p[0];
     int d[16];
     d[0] = p[-3 * kTileW] - c;
@@ -221,6 +228,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   const int wv = tid >> 6, lane = tid & 63;
   const int cx = 2 * blockIdx.x + (wv & 1), cy = 2 * blockIdx.y + (wv >> 1);
   if (cx >= ncx || cy >= ncy) return;  // no block-wide sync below
+  if (ablate >= 3) {
+    if (lane == 0) cell_cnt[(size_t)blockIdx.z * cells_per_frame + cell_off + (size_t)cy * ncx + cx] = 0;
+    return;
+  }
   uint32_t* list = lists[wv];
   const int sx0 = 1 + 32 * (wv & 1), sy0 = 1 + 32 * (wv >> 1);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -736,7 +747,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   const int L = p->L, K = p->prm.n_features;
 
   LevelView lv[kMaxL];
-  const bool aligned0 = ((uintptr_t)gray_dev & 3) == 0 && (row_stride & 3) == 0 && (frame_stride & 3) == 0;
+  const bool aligned0 = ((uintptr_t)gray_dev & 15) == 0 && (row_stride & 15) == 0 && (frame_stride & 15) == 0;
   if (aligned0) {
     lv[0] = {gray_dev, frame_stride, row_stride, p->w, p->h};
   } else {
@@ -752,11 +763,13 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     GH_LAUNCH(ctx, "orb_resize", resize_kernel, grid, dim3(256), 0, lv[l - 1], p->pyr + p->lvl_off[l], p->slab,
               p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l]);
   }
+  static const int ablate = getenv("GH_ORB_ABLATE") ? atoi(getenv("GH_ORB_ABLATE")) : 0;  // debug only
   for (int l = 0; l < L; ++l) {
     if (p->ncx[l] == 0 || p->quota[l] <= 0) continue;
     dim3 grid(gh_div_up(p->ncx[l], 2), gh_div_up(p->ncy[l], 2), batch);
     GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
-              p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l]);
+              p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
+              ablate);
   }
   {
     SelectArgs a;

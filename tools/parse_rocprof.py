@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (gpurun_out/prof_*) into the tracked summaries under profiles/.
+
+  python tools/parse_rocprof.py <round-tag> <frames-per-launch>
+    gpurun_out/prof_stats/**/_kernel_stats.csv      -> profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats)
+    gpurun_out/prof_fetch/**/_counter_collection.csv + prof_write/** -> profiles/pmc_traffic.json
+
+HBM traffic per launch follows MI355X_MICROARCH.md "HBM": separate --pmc passes for FETCH_SIZE and WRITE_SIZE
+(they do not fit one pass), both in KiB units; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
+(16 B/lane) coalesced read, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  WRITE_SIZE is uncalibrated
+per the guide and is reported as is.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "select_kernel": "orb_select",
+         "describe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "synth_kernel": "synth_frames",
+         "syrk_mfma_kernel": "ba_syrk", "potf2_64_kernel": "ba_potf2", "trsm_64_kernel": "ba_trsm",
+         "schur_blocks_kernel": "ba_schur_blocks", "lin_cams_kernel": "ba_lin_cams",
+         "lin_points_kernel": "ba_lin_points", "fwd_step_kernel": "ba_trsv_fwd", "bwd_step_kernel": "ba_trsv_bwd"}
+
+
+def short(name):
+    for k, v in NAMES.items():
+        if k in name:
+            return v
+    return None
+
+
+def counters(pattern, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for path in glob.glob(os.path.join(ROOT, "gpurun_out", pattern, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] != counter:
+                continue
+            s = short(row["Kernel_Name"])
+            if s:
+                acc[s][0] += float(row["Counter_Value"])
+                acc[s][1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
+                    f"--frames {frames} --no-cpu-baseline --ba-iters 6   (1x MI355X)\n")
+            csv.writer(f).writerows(rows)
+        print("wrote", f"profiles/{tag}_kernel_stats.csv")
+    fetch = counters("prof_fetch", "FETCH_SIZE")
+    write = counters("prof_write", "WRITE_SIZE")
+    traffic = {}
+    for k in sorted(set(fetch) | set(write)):
+        f_kib = fetch.get(k, (0.0, 0))[0]
+        w_kib = write.get(k, (0.0, 0))[0]
+        traffic[k] = {"frames_per_launch": frames, "launches_sampled": fetch.get(k, (0, 0))[1],
+                      "FETCH_SIZE_KiB_avg": round(f_kib, 1), "WRITE_SIZE_KiB_avg": round(w_kib, 1),
+                      "hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024),
+                      "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes"}
+    if traffic:
+        json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+        print("wrote profiles/pmc_traffic.json")
+        for k, v in traffic.items():
+            print("  %-18s fetch %.0f KiB  write %.0f KiB  -> %.1f MB/launch" %
+                  (k, v["FETCH_SIZE_KiB_avg"], v["WRITE_SIZE_KiB_avg"], v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
