@@ -46,6 +46,14 @@ struct SelKp {
   uint16_t pad;
 };
 
+// XCD-aware work mapping.  Workgroup b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2);
+// this hands every XCD one contiguous strip of the tile list so that spatial neighbours (tile halos,
+// overlapping keypoint patches) meet in the same L2.  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_strip_tile(int lin, int total) {
+  const int chunk = (total + 7) >> 3;
+  return (lin & 7) * chunk + (lin >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // level-0 staging copy (only when the caller's buffer is not dword friendly)
 __global__ void copy_rows_kernel(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
@@ -126,13 +134,14 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16]) {
 
 constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligned window that covers x0-4 .. x0+67), 72 rows
 constexpr int kTileH = 72;
-constexpr int kScoreW = 68;  // 66 used
-constexpr int kScoreH = 66;
+constexpr int kScoreH = 66;   // score window: 64x64 region + 1 px NMS halo
+constexpr int kScoreOff = 3;  // window col sx is stored at byte sx + 3 so that both cells of a row start dword aligned
+constexpr int kScoreW = 72;   // row pitch (bytes)
 
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                         int cell_off, int ablate) {
+                                                         int cell_off, int n_frames, int ablate) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
@@ -140,11 +149,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   __shared__ int q_count;
 
   const int tid = threadIdx.x;
+  const int nbx = (ncx + 1) >> 1, nby = (ncy + 1) >> 1;
+  const int tile_id = xcd_strip_tile(blockIdx.x, nbx * nby * n_frames);
+  if (tile_id >= nbx * nby * n_frames) return;
+  const int frame = tile_id / (nbx * nby);
+  const int trem = tile_id - frame * (nbx * nby);
+  const int bx = trem % nbx, by = trem / nbx;
   if (tid == 0) q_count = 0;
-  const int x0 = kEdge + 64 * blockIdx.x, y0 = kEdge + 64 * blockIdx.y;  // region origin
+  const int x0 = kEdge + 64 * bx, y0 = kEdge + 64 * by;  // region origin
   const int oy = y0 - 4;                       // tile origin row
-  const int ax = 64 * blockIdx.x;              // 16-byte aligned tile origin column: x0 - 4 == ax + 15
-  const uint8_t* img = lv.base + (size_t)blockIdx.z * lv.frame_stride;
+  const int ax = 64 * bx;                      // 16-byte aligned tile origin column: x0 - 4 == ax + 15
+  const uint8_t* img = lv.base + (size_t)frame * lv.frame_stride;
 
   // 16 B per lane: rows of the level are 16-byte aligned (pitch % 16 == 0, checked by the launcher)
   for (int i = tid; i < kTileH * (kTileW / 16); i += 256) {
@@ -163,43 +178,77 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   // pixels) for every pixel; survivors are appended to an LDS queue so that pass 2 (the ~100-op arc
   // score) runs with all lanes busy instead of paying full price in every partially-hit wave.
   // The queue order is irrelevant: results land in score[] by position.
-  for (int i0 = 0; i0 < kScoreH * kScoreH; i0 += 256) {
-    const int i = i0 + tid;
-    bool cand = false;
-    if (ablate >= 2) {  // debug ablation (GH_ORB_ABLATE): no scoring at all
-      if (i < kScoreH * kScoreH) score[(i / kScoreH) * kScoreW + i % kScoreH] = 0;
-      continue;
-    }
-    int sy = 0, sx = 0;
-    if (i < kScoreH * kScoreH) {
-      sy = i / kScoreH;
-      sx = i - sy * kScoreH;
-      const int px = x0 - 1 + sx, py = y0 - 1 + sy;
-      if (px >= kEdge && px < lv.w - kEdge && py >= kEdge && py < lv.h - kEdge) {
-        const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 18];
-        const int c = p[0];
-        const int r0 = p[-3 * kTileW], r4 = p[3], r8 = p[3 * kTileW], r12 = p[-3];
-        const int hi = c + min_th, lo = c - min_th;
-        const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
-        const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
-        cand = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (d0 && d4) || (d4 && d8) || (d8 && d12) ||
-               (d12 && d0);
+  // score tile cleared with dword stores
+  for (int i = tid; i < kScoreH * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0u;  // incl. pad cols
+  // One work item = one aligned tile dword = 4 horizontally adjacent pixels (tile cols 4m .. 4m+3, m = 4..21,
+  // i.e. window cols -2 .. 69), evaluated with packed 16-bit math: 5 LDS dword reads and ~56 VALU per 4 px.
+  // bright test: max over adjacent compass pairs of min(d_a, d_b) > t; dark: min over pairs of max < -t.
+  {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
+    constexpr int kRowDw = kTileW / 4, kItemsPerRow = 18;
+    const s16x2 T = {(short)min_th, (short)min_th};
+    const int sx_lo = max(0, kEdge - (x0 - 1)), sx_hi = min(kScoreH, lv.w - kEdge - (x0 - 1));
+    for (int i0 = 0; i0 < kScoreH * kItemsPerRow && ablate < 2; i0 += 256) {
+      const int item = i0 + tid;
+      uint32_t bits = 0;  // bit k: pixel k of the dword is a candidate
+      int sy = 0, m = 4;
+      if (item < kScoreH * kItemsPerRow) {
+        sy = item / kItemsPerRow;
+        m = item - sy * kItemsPerRow + 4;
+        const int trow = (sy + 3) * kRowDw;
+        const uint32_t wc = tile32[trow + m], wl = tile32[trow + m - 1], wr = tile32[trow + m + 1];
+        const uint32_t wu = tile32[trow - 3 * kRowDw + m], wd = tile32[trow + 3 * kRowDw + m];
+        const uint32_t left4 = __builtin_amdgcn_alignbyte(wc, wl, 1);   // cols 4m-3 .. 4m
+        const uint32_t right4 = __builtin_amdgcn_alignbyte(wr, wc, 3);  // cols 4m+3 .. 4m+6
+        uint32_t mask = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // bytes (2h, 2h+1) -> two zero-extended 16-bit lanes
+          const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u;
+          const s16x2 c = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wc, sel));
+          const s16x2 du = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wu, sel)) - c;
+          const s16x2 dd = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wd, sel)) - c;
+          const s16x2 dl = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, left4, sel)) - c;
+          const s16x2 dr = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, right4, sel)) - c;
+          const s16x2 bright = __builtin_elementwise_max(
+              __builtin_elementwise_max(__builtin_elementwise_min(du, dr), __builtin_elementwise_min(dr, dd)),
+              __builtin_elementwise_max(__builtin_elementwise_min(dd, dl), __builtin_elementwise_min(dl, du)));
+          const s16x2 dark = __builtin_elementwise_min(
+              __builtin_elementwise_min(__builtin_elementwise_max(du, dr), __builtin_elementwise_max(dr, dd)),
+              __builtin_elementwise_min(__builtin_elementwise_max(dd, dl), __builtin_elementwise_max(dl, du)));
+          // sign bits: (t - bright) < 0  <=>  bright > t ;  (dark + t) < 0  <=>  dark < -t
+          const uint32_t e = __builtin_bit_cast(uint32_t, T - bright) | __builtin_bit_cast(uint32_t, dark + T);
+          mask |= (((e >> 15) & 1u) | ((e >> 30) & 2u)) << (2 * h);
+        }
+        // keep only pixels inside the 66-wide window and the valid image region: window cols [sx_lo, sx_hi)
+        const int py = y0 - 1 + sy;
+        const int first = 4 * m - 18;  // window col of pixel 0 of this dword
+        uint32_t vm = 0xFu;
+        if (first < sx_lo) vm = (0xFu << min(sx_lo - first, 4)) & 0xFu;
+        if (first + 4 > sx_hi) vm &= 0xFu >> min(first + 4 - sx_hi, 4);
+        if (py >= kEdge && py < lv.h - kEdge) bits = mask & vm;
       }
-      score[sy * kScoreW + sx] = 0;
-    }
-    const uint64_t m = __ballot(cand);
-    if (m != 0ull) {
-      int base = 0;
-      if ((tid & 63) == 0) base = atomicAdd(&q_count, __popcll(m));
-      base = __shfl(base, 0);
-      if (cand) queue[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(sy * kScoreW + sx);
+      // one queue reservation per wave-trip: per-lane count (0..4) prefix-summed with three ballots
+      const int cnt = __popc(bits);
+      const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4);
+      if ((c0 | c1 | c2) != 0ull) {
+        const uint64_t ltm = (1ull << (tid & 63)) - 1ull;
+        int base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&q_count, __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2));
+        base = __shfl(base, 0) + __popcll(c0 & ltm) + 2 * __popcll(c1 & ltm) + 4 * __popcll(c2 & ltm);
+        const int pos0 = sy * kScoreW + kScoreOff + 4 * m - 18;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((bits >> k) & 1u) queue[base++] = (uint16_t)(pos0 + k);
+      }
     }
   }
   __syncthreads();
   const int nq = ablate >= 1 ? 0 : q_count;
   for (int i = tid; i < nq; i += 256) {
     const int pos = queue[i];
-    const int sy = pos / kScoreW, sx = pos - sy * kScoreW;
+    const int sy = pos / kScoreW, sx = pos - sy * kScoreW - kScoreOff;
     const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 18];
     const int c = p[0];
     int d[16];
@@ -226,30 +275,54 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
 
   // one wave per 32x32 cell
   const int wv = tid >> 6, lane = tid & 63;
-  const int cx = 2 * blockIdx.x + (wv & 1), cy = 2 * blockIdx.y + (wv >> 1);
+  const int cx = 2 * bx + (wv & 1), cy = 2 * by + (wv >> 1);
   if (cx >= ncx || cy >= ncy) return;  // no block-wide sync below
   if (ablate >= 3) {
-    if (lane == 0) cell_cnt[(size_t)blockIdx.z * cells_per_frame + cell_off + (size_t)cy * ncx + cx] = 0;
+    if (lane == 0) cell_cnt[(size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx] = 0;
     return;
   }
   uint32_t* list = lists[wv];
-  const int sx0 = 1 + 32 * (wv & 1), sy0 = 1 + 32 * (wv >> 1);
+  // 3x3 strict NMS over the cell.  Stage A scans the cell's score bytes as dwords (8 rows x 8 dwords per
+  // trip) and compacts the few non-zero pixels, in raster order, into list2; stage B tests only those
+  // against their 8 neighbours with every lane busy.  Ballot compaction keeps raster order in both stages.
+  const int sy0 = 1 + 32 * (wv >> 1);
+  const int col0 = kScoreOff + 1 + 32 * (wv & 1);  // byte column of the cell's first pixel: 4 or 36
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint16_t* list2 = queue + wv * 1024;  // the pass-1 queue is dead after pass 2: reuse it (row << 5 | col per entry)
+  int nz = 0;
+  for (int it = 0; it < 4; ++it) {
+    const int row = 8 * it + (lane >> 3), dw = lane & 7;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(&score[(sy0 + row) * kScoreW + col0 + 4 * dw]);
+    const uint32_t nzb = ((w & 0xFFu) ? 1u : 0u) | ((w & 0xFF00u) ? 2u : 0u) | ((w & 0xFF0000u) ? 4u : 0u) |
+                         ((w & 0xFF000000u) ? 8u : 0u);
+    const int cnt = __popc(nzb);
+    const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4);
+    if ((c0 | c1 | c2) == 0ull) continue;
+    int pos = nz + __popcll(c0 & lt_mask) + 2 * __popcll(c1 & lt_mask) + 4 * __popcll(c2 & lt_mask);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((nzb >> k) & 1u)
+        list2[pos++] = (uint16_t)((row << 5) | (4 * dw + k));
+    nz += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
+  }
   int n = 0;
   bool strong = false;
-  for (int it = 0; it < 16; ++it) {
-    const int row = 2 * it + (lane >> 5), col = lane & 31;
-    const uint8_t* sp = &score[(sy0 + row) * kScoreW + sx0 + col];
-    const int s = sp[0];
+  for (int base = 0; base < nz; base += 64) {
+    const int i = base + lane;
     bool ismax = false;
-    if (s > 0) {
-      ismax = sp[-kScoreW - 1] < s && sp[-kScoreW] < s && sp[-kScoreW + 1] < s && sp[-1] < s && sp[1] < s &&
-              sp[kScoreW - 1] < s && sp[kScoreW] < s && sp[kScoreW + 1] < s;
+    uint32_t e = 0;
+    if (i < nz) {
+      const uint32_t rc = list2[i];
+      const uint8_t* sp = &score[(sy0 + (int)(rc >> 5)) * kScoreW + col0 + (int)(rc & 31u)];
+      const int sv = sp[0];
+      e = ((uint32_t)sv << 10) | rc;
+      ismax = sp[-kScoreW - 1] < sv && sp[-kScoreW] < sv && sp[-kScoreW + 1] < sv && sp[-1] < sv && sp[1] < sv &&
+              sp[kScoreW - 1] < sv && sp[kScoreW] < sv && sp[kScoreW + 1] < sv;
     }
-    const uint64_t m = __ballot(ismax);
-    if (ismax) list[n + __popcll(m & lt_mask)] = ((uint32_t)s << 10) | ((uint32_t)row << 5) | (uint32_t)col;
-    n += __popcll(m);
-    strong = strong || (__ballot(ismax && s > ini_th) != 0ull);
+    const uint64_t bm = __ballot(ismax);
+    if (ismax) list[n + __popcll(bm & lt_mask)] = e;
+    n += __popcll(bm);
+    strong = strong || (__ballot(ismax && (int)(e >> 10) > ini_th) != 0ull);
   }
   if (strong) {  // keep only candidates above the initial threshold (in place, order preserved)
     int m2 = 0;
@@ -264,7 +337,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     n = m2;
   }
   // rank within the cell by (score desc, raster asc); keep rank < cap, write in raster order
-  const size_t cell = (size_t)blockIdx.z * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
+  const size_t cell = (size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
   uint32_t* out = cell_ent + cell * kCap;
   int kept = 0;
   for (int base = 0; base < n; base += 64) {
@@ -417,19 +490,24 @@ struct DescribeArgs {
   int nlevels;
 };
 
-constexpr int kPatch = 37, kPatchPitch = 40;  // 10 dwords per row cover any 37-byte run
+// 33x33 patch (radius 16): covers the radius-15 centroid disc and the 7x7 blur of the radius-13 test pattern.
+constexpr int kPatch = 33, kPatchPitch = 36;  // 9 dwords per row cover any 33-byte run
+constexpr int kBlur = 27, kBlurPitch = 28;     // blurred region: radius 13 (max |pattern coordinate|)
 
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
                                                        const int32_t* __restrict__ level_cnt,
                                                        gh_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                       int32_t* __restrict__ counts) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch];
-  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][kPatch * 31 + 1];
-  __shared__ __attribute__((aligned(16))) uint8_t s_blur[4][31 * 32];
+                                                       int32_t* __restrict__ counts, int n_frames) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch + 28];  // + slack for the 16-B row reads
+  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][(kPatch + 1) * kBlurPitch];     // 34 rows x 28 dwords
+  __shared__ __attribute__((aligned(16))) uint8_t s_blur[4][kBlur * kBlurPitch + 12];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + wv;
-  const int b = blockIdx.y;
+  const int blocks_per_frame = (K + 3) >> 2;
+  const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
+  if (gid >= blocks_per_frame * n_frames) return;
+  const int b = gid / blocks_per_frame;
+  const int slot = (gid - b * blocks_per_frame) * 4 + wv;
   if (slot >= K) return;
   // level of this slot and compacted output position
   int l = 0;
@@ -459,18 +537,18 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   const SelKp kp = sel[(size_t)b * K + slot];
   const LevelView lv = a.lv[l];
   const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
-  // 37x37 patch: each row is fetched as the 10 aligned dwords that cover it (the 37 bytes start at
+  // 33x33 patch: each row is fetched as the 9 aligned dwords that cover it (the 33 bytes start at
   // offset px0 & 3 of the window), so `patch` below points at the first wanted byte of row 0.
-  const int px0 = (int)kp.x - 18, py0 = (int)kp.y - 18;
+  const int px0 = (int)kp.x - 16, py0 = (int)kp.y - 16;
   const int pa = px0 & ~3;
-  for (int idx = lane; idx < kPatch * 10; idx += 64) {
-    const int r = idx / 10, c = idx - r * 10;
+  for (int idx = lane; idx < kPatch * 9; idx += 64) {
+    const int r = idx / 9, c = idx - r * 9;
     const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch + pa + 4 * c);
     *reinterpret_cast<uint32_t*>(&s_patch[wv][r * kPatchPitch + 4 * c]) = v;
   }
   const uint8_t* patch = s_patch[wv] + (px0 - pa);
   __builtin_amdgcn_wave_barrier();
-  // intensity centroid over the radius-15 disc (patch centre at [18][18])
+  // intensity centroid over the radius-15 disc (patch centre at [16][16])
   int m10 = 0, m01 = 0;
   for (int idx = lane; idx < 31 * 31; idx += 64) {
     const int r = idx / 31, c = idx - r * 31;
@@ -479,7 +557,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     // u_max table (GH_ORB_UMAX) as a switch-free lookup
     constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     if (au <= um[av]) {
-      const int I = patch[(r + 3) * kPatchPitch + c + 3];
+      const int I = patch[(r + 1) * kPatchPitch + c + 1];
       m10 += u * I;
       m01 += v * I;
     }
@@ -499,25 +577,56 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     const uint64_t hit = __ballot(lane < GH_ORB_NBINS && !prev_neg && c_neg);
     if ((m10 != 0 || m01 != 0) && hit != 0ull) bin = __ffsll((unsigned long long)hit) - 1;
   }
-  // separable 7x7 integer Gaussian: rows 0..36 x cols 3..33 -> s_h, then rows 3..33 -> s_blur (31x31)
+  // separable 7x7 integer Gaussian: patch rows 0..32 x blur cols 0..26 -> s_h, then blur rows 0..26 -> s_blur (27x27)
   uint32_t* hb = s_h[wv];
   constexpr uint32_t g[7] = {144, 268, 391, 442, 391, 268, 144};
-  for (int idx = lane; idx < kPatch * 31; idx += 64) {
-    const int r = idx / 31, c = idx - r * 31;
-    const uint8_t* p = &patch[r * kPatchPitch + c];
-    uint32_t acc = 0;
+  // Wide LDS accesses (the kernel is LDS-issue bound with byte reads): one work item = 4 adjacent outputs.
+  // h-pass: 4 dwords of the patch row -> 10 source bytes (v_alignbyte with the wave-uniform row offset)
+  //         -> 4 outputs stored as one 16-byte write;  v-pass: 10 dword reads down a column -> 4 outputs.
+  {
+    const uint32_t off = (uint32_t)(px0 - pa);  // 0..3, wave-uniform
+    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(s_patch[wv]);
+    for (int idx = lane; idx < kPatch * 7; idx += 64) {
+      const int r = idx / 7, gq = idx - r * 7;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
+      const uint32_t* q = p32 + r * (kPatchPitch / 4) + gq;
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off);  // source bytes 0..3 (patch col 4 gq + k)
+      const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, off);  // 4..7
+      const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, off);  // 8..11
+      uint32_t x[10];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) acc += g[t] * p[t];
-    hb[idx] = acc;
+      for (int k = 0; k < 4; ++k) {
+        x[k] = (w0 >> (8 * k)) & 0xFFu;
+        x[4 + k] = (w1 >> (8 * k)) & 0xFFu;
+      }
+      x[8] = w2 & 0xFFu;
+      x[9] = (w2 >> 8) & 0xFFu;
+      uint4 o;
+      uint32_t acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = 0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc[i] += g[t] * x[i + t];
+      }
+      o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
+      *reinterpret_cast<uint4*>(&hb[r * kBlurPitch + 4 * gq]) = o;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   uint8_t* bl = s_blur[wv];
-  for (int idx = lane; idx < 31 * 31; idx += 64) {
-    const int r = idx / 31, c = idx - r * 31;
-    uint32_t acc = 0;
+  for (int idx = lane; idx < kBlur * 7; idx += 64) {
+    const int rq = idx / kBlur, c = idx - rq * kBlur;  // outputs: blur rows 4 rq .. 4 rq + 3 of column c
+    uint32_t col[10];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) acc += g[t] * hb[(r + t) * 31 + c];
-    bl[r * 32 + c] = (uint8_t)((acc + (1u << 21)) >> 22);
+    for (int t = 0; t < 10; ++t) col[t] = hb[(4 * rq + t) * kBlurPitch + c];  // row 33 is slack (unused outputs)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) acc += g[t] * col[i + t];
+      if (4 * rq + i < kBlur) bl[(4 * rq + i) * kBlurPitch + c] = (uint8_t)((acc + (1u << 21)) >> 22);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   // 256 binary tests, 64 per ballot
@@ -528,7 +637,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     const uint32_t pw = pat[gq * 64 + lane];
     const int ax = (int8_t)(pw & 0xFF), ay = (int8_t)((pw >> 8) & 0xFF);
     const int bx = (int8_t)((pw >> 16) & 0xFF), by = (int8_t)(pw >> 24);
-    const int va = bl[(15 + ay) * 32 + 15 + ax], vb = bl[(15 + by) * 32 + 15 + bx];
+    const int va = bl[(13 + ay) * kBlurPitch + 13 + ax], vb = bl[(13 + by) * kBlurPitch + 13 + bx];
     const uint64_t bits = __ballot(va < vb);
     if (lane == 0) *reinterpret_cast<uint64_t*>(drow + 8 * gq) = bits;
   }
@@ -766,10 +875,12 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   static const int ablate = getenv("GH_ORB_ABLATE") ? atoi(getenv("GH_ORB_ABLATE")) : 0;  // debug only
   for (int l = 0; l < L; ++l) {
     if (p->ncx[l] == 0 || p->quota[l] <= 0) continue;
-    dim3 grid(gh_div_up(p->ncx[l], 2), gh_div_up(p->ncy[l], 2), batch);
+    const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
+    GH_CHECK_ARG(ctx, tiles < (1LL << 30));
+    dim3 grid(8 * gh_div_up(tiles, 8));
     GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
               p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-              ablate);
+              batch, ablate);
   }
   {
     SelectArgs a;
@@ -793,8 +904,10 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     }
     a.nlevels = L;
     DevTables tb{p->d_pattern, p->d_dir};
-    GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(gh_div_up(K, 4), batch), dim3(256), 0, a, tb, K, p->sel,
-              p->level_cnt, kps_dev, desc_dev, counts_dev);
+    const long long blocks = (long long)gh_div_up(K, 4) * batch;
+    GH_CHECK_ARG(ctx, blocks < (1LL << 30));
+    GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
+              p->level_cnt, kps_dev, desc_dev, counts_dev, batch);
   }
   return GH_OK;
 }
