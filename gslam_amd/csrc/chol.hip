@@ -143,15 +143,13 @@ __global__ __launch_bounds__(256) void trsm_64_kernel(double* __restrict__ A, in
 // grid.x enumerates 128x128 tiles (ti, tj) with ti >= tj over the region; K = kdim (multiple of 4, <= 256).
 constexpr int TM = 128, KC = 16, PITCH = 144;
 
-__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, int lda, int n, int r_begin,
-                                                        int c_begin, int c_end, int kc0, int kdim, int tiles_i,
-                                                        int tiles_j) {
-  __shared__ __attribute__((aligned(16))) double sP[KC * PITCH];  // rows i (C rows)   [k][i]
-  __shared__ __attribute__((aligned(16))) double sQ[KC * PITCH];  // rows j (C cols)   [k][j]
-  // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
-  const int tj = blockIdx.x % tiles_j, ti = blockIdx.x / tiles_j;
-  const int j0 = c_begin + tj * TM, i0 = r_begin + ti * TM;
-  if (i0 + TM <= j0) return;  // entirely in the strict upper triangle
+// INTERIOR = the whole 128x128 tile lies strictly below the diagonal and inside the matrix, and K is a
+// multiple of KC: no masks, so operand fetches are branch-free and the epilogue issues all loads of a
+// 16-element batch before the first store (a masked, per-element read-modify-write chain was measured
+// to cost 3x the MFMA time of the tile).
+template <bool INTERIOR>
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n, int r_begin, int c_end, int kc0,
+                                          int kdim, int i0, int j0, double* sP, double* sQ) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + 64 wr, cols j0 + 64 wc
   double4_t acc[4][4];                  // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
@@ -162,16 +160,38 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
 
   // staging map: thread -> (k = tid / 16, 8 consecutive rows starting at (tid % 16) * 8)
   const int sk = tid >> 4, sr = (tid & 15) * 8;
-  for (int kc = 0; kc < kdim; kc += KC) {
-    double p[8], q[8];
+  double p[8], q[8];
+  auto fetch = [&](int kc) {
     const int kk = kc + sk;
     const size_t colP = (size_t)(kc0 + kk) * lda;
+    if (INTERIOR) {
+      const double2* pp = reinterpret_cast<const double2*>(A + colP + i0 + sr);
+      const double2* qq = reinterpret_cast<const double2*>(A + colP + j0 + sr);
+      if ((((size_t)(A + colP + i0 + sr) | (size_t)(A + colP + j0 + sr)) & 15) == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ri = i0 + sr + e, rj = j0 + sr + e;
-      p[e] = (kk < kdim && ri < n) ? A[colP + ri] : 0.0;
-      q[e] = (kk < kdim && rj < n && rj < c_end) ? A[colP + rj] : 0.0;
+        for (int e = 0; e < 4; ++e) {
+          const double2 a2 = pp[e], b2 = qq[e];
+          p[2 * e] = a2.x; p[2 * e + 1] = a2.y;
+          q[2 * e] = b2.x; q[2 * e + 1] = b2.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          p[e] = A[colP + i0 + sr + e];
+          q[e] = A[colP + j0 + sr + e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ri = i0 + sr + e, rj = j0 + sr + e;
+        p[e] = (kk < kdim && ri < n) ? A[colP + ri] : 0.0;
+        q[e] = (kk < kdim && rj < n && rj < c_end) ? A[colP + rj] : 0.0;
+      }
     }
+  };
+  fetch(0);
+  for (int kc = 0; kc < kdim; kc += KC) {
     __syncthreads();  // previous chunk fully consumed
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -179,6 +199,8 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
       sQ[sk * PITCH + sr + e] = q[e];
     }
     __syncthreads();
+    // software pipeline: the next chunk's global loads are in flight while this chunk's 64 MFMAs issue
+    if (kc + KC < kdim) fetch(kc + KC);
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
       double fa[4], fb[4];
@@ -197,19 +219,44 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
   }
   // C -= acc^T : lane holds, for tile (jt, it): j = jbase + (lane>>4) + 4r, i = ibase + (lane&15)
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
+  for (int jt = 0; jt < 4; ++jt) {
+    double cv[4][4];
+    bool ok[4][4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int i = i0 + 64 * wr + 16 * it + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 64 * wc + 16 * jt + (lane >> 4) + 4 * r;
-        if (i < n && j < c_end && i >= j && i >= r_begin) {
-          double* c = &A[(size_t)j * lda + i];
-          *c -= acc[jt][it][r];
-        }
+        ok[it][r] = INTERIOR || (i < n && j < c_end && i >= j && i >= r_begin);
+        const size_t idx = ok[it][r] ? (size_t)j * lda + i : (size_t)j0 * lda + i0;  // clamped, always valid
+        cv[it][r] = A[idx];
       }
     }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = i0 + 64 * wr + 16 * it + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 64 * wc + 16 * jt + (lane >> 4) + 4 * r;
+        if (ok[it][r]) A[(size_t)j * lda + i] = cv[it][r] - acc[jt][it][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int lda, int n, int r_begin,
+                                                        int c_begin, int c_end, int kc0, int kdim, int tiles_i,
+                                                        int tiles_j) {
+  __shared__ __attribute__((aligned(16))) double sP[KC * PITCH];  // rows i (C rows)   [k][i]
+  __shared__ __attribute__((aligned(16))) double sQ[KC * PITCH];  // rows j (C cols)   [k][j]
+  // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
+  const int tj = blockIdx.x % tiles_j, ti = blockIdx.x / tiles_j;
+  const int j0 = c_begin + tj * TM, i0 = r_begin + ti * TM;
+  if (i0 + TM <= j0) return;  // entirely in the strict upper triangle
+  const bool interior = i0 + TM <= n && j0 + TM <= c_end && i0 >= j0 + TM && (kdim % KC) == 0;
+  if (interior) syrk_tile<true>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ);
+  else syrk_tile<false>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ);
 }
 
 // ---------------------------------------------------------------- blocked triangular solves

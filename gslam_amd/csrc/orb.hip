@@ -67,47 +67,63 @@ __global__ void copy_rows_kernel(const uint8_t* __restrict__ src, size_t src_fra
 
 // ------------------------------------------------------------------------------------------------
 // bilinear 1.2x downscale, 11-bit fixed point (oracle step 1).  xtab/ytab: idx << 16 | frac.
+constexpr int kResizeRows = 4;  // output rows per thread
+
 __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __restrict__ dst_base,
                                                      size_t dst_frame_stride, int dst_pitch, int wd, int hd,
                                                      const uint32_t* __restrict__ xtab,
                                                      const uint32_t* __restrict__ ytab) {
   const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x4 >= wd || y >= hd) return;
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kResizeRows;
+  if (x4 >= wd || y0 >= hd) return;
   const uint8_t* s = src.base + (size_t)blockIdx.z * src.frame_stride;
-  const uint32_t ty = ytab[y];
-  const int sy = ty >> 16, fy = ty & 0xFFFF;
-  const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
-  // The 4 outputs read source columns sx0 .. sx0+5 at most (scale 1.2): fetch the 12-byte aligned window
-  // of both rows with 3 dword loads each instead of 16 byte gathers; the x table (padded to a multiple
-  // of 4 entries, 16-byte aligned) comes in one dwordx4.
+  uint8_t* d = dst_base + (size_t)blockIdx.z * dst_frame_stride;
+  // The 4 outputs of a row read source columns sx0 .. sx0+5 (scale 1.2).  Per source row: 3 aligned dword
+  // loads -> an 8-byte window starting exactly at sx0 (2 x v_alignbyte) -> taps picked with v_perm_b32.
+  // The x table (padded to a multiple of 4 entries, 16-byte aligned) comes in one dwordx4 and is shared by
+  // the thread's 4 output rows.
   const uint4 tx4 = *reinterpret_cast<const uint4*>(xtab + x4);
   const uint32_t txs[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
-  const int a0 = (int)(tx4.x >> 16) & ~3;
+  const int sx0 = (int)(tx4.x >> 16);
+  const uint32_t al = (uint32_t)(sx0 & 3);
   const int last_dw = (src.pitch >> 2) - 1;
-  const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s + (size_t)sy * src.pitch);
-  const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s + (size_t)sy1 * src.pitch);
-  const int d0 = a0 >> 2, d1 = min(d0 + 1, last_dw), d2 = min(d0 + 2, last_dw);
-  const uint32_t u0 = q0[d0], u1 = q0[d1], u2 = q0[d2];
-  const uint32_t v0 = q1[d0], v1 = q1[d1], v2 = q1[d2];
-  const uint64_t ulo = (uint64_t)u0 | ((uint64_t)u1 << 32), uhi = (uint64_t)u1 | ((uint64_t)u2 << 32);
-  const uint64_t vlo = (uint64_t)v0 | ((uint64_t)v1 << 32), vhi = (uint64_t)v1 | ((uint64_t)v2 << 32);
-  uint32_t packed = 0;
+  const int d0 = sx0 >> 2, d1 = min(d0 + 1, last_dw), d2 = min(d0 + 2, last_dw);
+  uint32_t sel0[4], sel1[4], fxs[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const uint32_t tx = txs[i];
-    const int sx = tx >> 16, fx = tx & 0xFFFF;
+    const int sx = (int)(txs[i] >> 16);
     const int sx1 = sx + 1 < src.w ? sx + 1 : src.w - 1;
-    const int o0 = sx - a0, o1 = sx1 - a0;  // 0..11
-    const uint32_t a00 = (uint32_t)((o0 < 4 ? ulo >> (8 * o0) : uhi >> (8 * (o0 - 4))) & 0xFF);
-    const uint32_t a01 = (uint32_t)((o1 < 4 ? ulo >> (8 * o1) : uhi >> (8 * (o1 - 4))) & 0xFF);
-    const uint32_t a10 = (uint32_t)((o0 < 4 ? vlo >> (8 * o0) : vhi >> (8 * (o0 - 4))) & 0xFF);
-    const uint32_t a11 = (uint32_t)((o1 < 4 ? vlo >> (8 * o1) : vhi >> (8 * (o1 - 4))) & 0xFF);
-    uint32_t v = a00 * (2048 - fx) * (2048 - fy) + a01 * fx * (2048 - fy) + a10 * (2048 - fx) * fy + a11 * fx * fy;
-    packed |= ((v + (1u << 21)) >> 22) << (8 * i);
+    sel0[i] = 0x0c0c0c00u | (uint32_t)(sx - sx0);   // byte (sx - sx0) of the window into bits 7:0, rest zero
+    sel1[i] = 0x0c0c0c00u | (uint32_t)(sx1 - sx0);
+    fxs[i] = txs[i] & 0xFFFFu;
   }
-  // dst pitch is a multiple of 64 and the pad bytes are ours: always a full dword store
-  *reinterpret_cast<uint32_t*>(dst_base + (size_t)blockIdx.z * dst_frame_stride + (size_t)y * dst_pitch + x4) = packed;
+#pragma unroll
+  for (int rr = 0; rr < kResizeRows; ++rr) {
+    const int y = y0 + rr;
+    if (y >= hd) break;
+    const uint32_t ty = ytab[y];
+    const int sy = ty >> 16;
+    const uint32_t fy = ty & 0xFFFFu;
+    const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
+    const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s + (size_t)sy * src.pitch);
+    const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s + (size_t)sy1 * src.pitch);
+    const uint32_t u0 = q0[d0], u1 = q0[d1], u2 = q0[d2];
+    const uint32_t v0 = q1[d0], v1 = q1[d1], v2 = q1[d2];
+    const uint32_t ulo = __builtin_amdgcn_alignbyte(u1, u0, al), uhi = __builtin_amdgcn_alignbyte(u2, u1, al);
+    const uint32_t vlo = __builtin_amdgcn_alignbyte(v1, v0, al), vhi = __builtin_amdgcn_alignbyte(v2, v1, al);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t a00 = __builtin_amdgcn_perm(uhi, ulo, sel0[i]), a01 = __builtin_amdgcn_perm(uhi, ulo, sel1[i]);
+      const uint32_t a10 = __builtin_amdgcn_perm(vhi, vlo, sel0[i]), a11 = __builtin_amdgcn_perm(vhi, vlo, sel1[i]);
+      const uint32_t fx = fxs[i];
+      const uint32_t v = a00 * (2048 - fx) * (2048 - fy) + a01 * fx * (2048 - fy) + a10 * (2048 - fx) * fy +
+                         a11 * fx * fy;
+      packed |= ((v + (1u << 21)) >> 22) << (8 * i);
+    }
+    // dst pitch is a multiple of 64 and the pad bytes are ours: always a full dword store
+    *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = packed;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -868,7 +884,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   for (int l = 1; l < L; ++l) lv[l] = {p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l]};
 
   for (int l = 1; l < L; ++l) {
-    dim3 grid(gh_div_up(p->lw[l], 256), gh_div_up(p->lh[l], 4), batch);
+    dim3 grid(gh_div_up(p->lw[l], 256), gh_div_up(p->lh[l], 4 * kResizeRows), batch);
     GH_LAUNCH(ctx, "orb_resize", resize_kernel, grid, dim3(256), 0, lv[l - 1], p->pyr + p->lvl_off[l], p->slab,
               p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l]);
   }
