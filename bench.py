@@ -91,10 +91,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU (gslam_amd has no CPU fallback)"
+    # GSLAM_BENCH_DRYRUN_BACKEND=gloo: dry run of the multi-rank code path on a 1-GPU box (all ranks share GPU 0,
+    # collectives staged through the host).  Never used for reported numbers.
+    dry = os.environ.get("GSLAM_BENCH_DRYRUN_BACKEND")
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group(dry, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gslam_amd import hip
     from gslam_amd.matcher import BFMatcher
@@ -144,10 +152,11 @@ def main():
     prof = ctx.prof_collect()
     ctx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if dry else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nk = counts.sum().to(torch.int64)
+        nk = counts.sum().to(torch.int64).to(cdev)
         dist.all_reduce(nk)
         total_kpts_step = int(nk.item())
     else:

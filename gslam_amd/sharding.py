@@ -27,10 +27,21 @@ def all_pairs_block(rank: int, world: int, n_frames_total: int, device="cpu"):
     return i[sel].to(torch.int32).to(device), j[sel].to(torch.int32).to(device)
 
 
+def _all_gather_flat(out: torch.Tensor, inp: torch.Tensor):
+    """all_gather_into_tensor; device tensors over a CPU-only backend (gloo, used by the 1-GPU dry run of the
+    multi-rank code path) are staged through host memory."""
+    if out.is_cuda and dist.get_backend() == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
 def exchange_features(desc: torch.Tensor, counts: torch.Tensor, g_desc: torch.Tensor, g_counts: torch.Tensor):
     """all-gather (F,K,32) u8 descriptors and (F,) counts into (G*F,K,32) / (G*F,)."""
-    dist.all_gather_into_tensor(g_desc.view(-1), desc.contiguous().view(-1))
-    dist.all_gather_into_tensor(g_counts, counts)
+    _all_gather_flat(g_desc.view(-1), desc.contiguous().view(-1))
+    _all_gather_flat(g_counts, counts)
 
 
 def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
@@ -41,4 +52,4 @@ def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: 
         send = torch.cat([idx1, pad])
     else:
         send = idx1
-    dist.all_gather_into_tensor(g_idx1.view(-1), send.contiguous().view(-1))
+    _all_gather_flat(g_idx1.view(-1), send.contiguous().view(-1))
