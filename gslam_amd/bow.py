@@ -1,0 +1,62 @@
+"""Host-side mirror of the Vocabulary plugin (gslam_amd/plugin/vocabulary_plugin.cpp): GSLAM::Vocabulary's BoW
+transform on the GPU.  Mirrors Vocabulary::transform(features, bow, fv, levelsup) (GSLAM/core/Vocabulary.h:1558-1621).
+torch tensors are device buffers only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Vocabulary:
+    def __init__(self, ctx: hip.Context, voc: dict):
+        """voc: dict(k, L, weighting, scoring, nodes (structured childNum/weight), desc (nnodes x 32 u8))."""
+        self.ctx = ctx
+        self.k, self.L = int(voc["k"]), int(voc["L"])
+        nodes = np.ascontiguousarray(voc["nodes"])
+        desc = np.ascontiguousarray(voc["desc"], dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(hip.lib.gh_bow_vocab_create(ctx.h, self.k, self.L, int(voc["weighting"]), int(voc["scoring"]),
+                                              len(nodes), nodes.ctypes.data_as(C.c_void_p),
+                                              desc.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            hip.lib.gh_bow_vocab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, n_images, cap, device="cuda"):
+        z = lambda dt: torch.empty((n_images, cap), dtype=dt, device=device)
+        return (z(torch.int32), z(torch.float32), z(torch.int32), z(torch.int32), z(torch.float32),
+                torch.empty(n_images, dtype=torch.int32, device=device))
+
+    def transform(self, desc: torch.Tensor, counts=None, levelsup=2, out=None):
+        """desc: B x cap x 32 u8 (cuda) -> (word, weight, node, bow_word, bow_val, bow_n) device tensors."""
+        B, cap = desc.shape[0], desc.shape[1]
+        out = out or self.alloc(B, cap, desc.device)
+        self.ctx.check(hip.lib.gh_bow_transform_dev(self.h, _p(desc), _p(counts), cap, B, int(levelsup), *[_p(t) for t in out]))
+        return out
+
+    def transform_host(self, desc: np.ndarray, levelsup=2):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = desc.shape[0]
+        m = max(n, 1)
+        word, node, bw = np.zeros(m, np.uint32), np.zeros(m, np.uint32), np.zeros(m, np.uint32)
+        weight, bv = np.zeros(m, np.float32), np.zeros(m, np.float32)
+        nb = C.c_int32()
+        pv = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.ctx.check(hip.lib.gh_bow_transform_host(self.h, pv(desc), n, int(levelsup), pv(word), pv(weight), pv(node),
+                                                     pv(bw), pv(bv), C.byref(nb)))
+        return word[:n], weight[:n], node[:n], bw[:nb.value].copy(), bv[:nb.value].copy()

@@ -1,0 +1,267 @@
+// Bag-of-words transform of GSLAM::Vocabulary on gfx950 (the step right after extraction).
+//
+// Bit-exact with the reference's own code (oracle/bow_oracle.c is pinned to it through oracle/_ref):
+//   GSLAM/core/Vocabulary.h:1695-1736  per-feature greedy descent (children p*k+1 .. p*k+childNum, first strict
+//                                      minimum, leaf = childNum == 0, node id at level L - levelsup)
+//   GSLAM/core/Vocabulary.h:1558-1621  image transform (TF/TF_IDF accumulate, IDF/BINARY first weight, w <= 0 skipped)
+//   GSLAM/core/Vocabulary.h:386-408    L1 / L2 normalisation, float /= double
+//   GSLAM/core/Vocabulary.h:1843-1932  .gbow layout the vocabulary is created from
+//
+// CDNA4 mapping: words_kernel = one lane per descriptor, query in 8 VGPRs, children fetched as 2 x 16-byte loads
+// (the tree's top levels stay L2 resident; k*L ~ 40-60 popcount distances per descriptor make this gather-bound).
+// assemble_kernel = one workgroup per image: bitonic sort of the word ids in LDS, run-length -> value by repeated
+// float addition (exactly what std::map += does), then ONE lane accumulates the norm in the reference's order
+// (ascending word id, double) so the normalised floats are bit-identical.
+#include "common.h"
+
+namespace {
+
+struct Node {
+  uint32_t childNum;
+  float weight;
+};
+
+__device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__global__ __launch_bounds__(256) void bow_words_kernel(const Node* __restrict__ nodes,
+                                                        const uint4* __restrict__ ndesc, int k, int L,
+                                                        const uint4* __restrict__ desc,
+                                                        const int32_t* __restrict__ counts, int cap, int levelsup,
+                                                        uint32_t* __restrict__ word, float* __restrict__ weight,
+                                                        uint32_t* __restrict__ node) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = counts ? min(counts[img], cap) : cap;
+  if (i >= cap) return;
+  const size_t o = (size_t)img * cap + i;
+  if (i >= n) {
+    word[o] = 0xFFFFFFFFu;
+    weight[o] = 0.f;
+    node[o] = 0xFFFFFFFFu;
+    return;
+  }
+  const uint4 q0 = desc[2 * o], q1 = desc[2 * o + 1];
+  const int nid_level = L - levelsup;
+  uint32_t final_id = 0, nid = 0;
+  int level = 0;
+  uint32_t cn = nodes[0].childNum;
+  do {
+    ++level;
+    int best_d = 1 << 30;
+    uint32_t best = final_id;
+    const uint32_t first = final_id * (uint32_t)k + 1;
+    for (uint32_t c = 0; c < cn; ++c) {
+      const uint32_t id = first + c;
+      const int d = ham256(q0, q1, ndesc[2 * (size_t)id], ndesc[2 * (size_t)id + 1]);
+      if (d < best_d) {
+        best_d = d;
+        best = id;
+      }
+    }
+    final_id = best;
+    if (level == nid_level) nid = final_id;
+    cn = nodes[final_id].childNum;
+  } while (cn != 0);
+  word[o] = final_id;
+  weight[o] = nodes[final_id].weight;
+  node[o] = nid_level <= 0 ? 0u : nid;
+}
+
+// one workgroup per image; dynamic LDS: uint32 keys[P] + float vals[P]
+__global__ __launch_bounds__(256) void bow_assemble_kernel(const Node* __restrict__ nodes, int weighting, int scoring,
+                                                           const uint32_t* __restrict__ word,
+                                                           const float* __restrict__ weight, int cap, int P,
+                                                           uint32_t* __restrict__ bow_word,
+                                                           float* __restrict__ bow_val, int32_t* __restrict__ bow_n) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+  float* vals = reinterpret_cast<float*>(smem + (size_t)P * 4);
+  __shared__ int s_wave[4];
+  __shared__ int s_total;
+  __shared__ double s_norm;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)img * cap;
+  for (int i = tid; i < P; i += 256) keys[i] = (i < cap && weight[base + i] > 0.f) ? word[base + i] : 0xFFFFFFFFu;
+  __syncthreads();
+  // bitonic sort (ascending)
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint32_t a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // heads of runs -> output slot by block scan (P / 256 consecutive elements per thread)
+  const int per = P >> 8 ? P >> 8 : 1;
+  const int i0 = tid * per;
+  int heads = 0;
+  for (int e = 0; e < per; ++e) {
+    const int i = i0 + e;
+    if (i < P && keys[i] != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != keys[i])) ++heads;
+  }
+  // exclusive scan of `heads` over the block
+  int incl = heads;
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wv; ++w) off += s_wave[w];
+  if (tid == 255) s_total = off + incl;
+  int slot = off + incl - heads;
+  __syncthreads();
+  const int nb = s_total;
+  for (int e = 0; e < per; ++e) {
+    const int i = i0 + e;
+    if (i < P && keys[i] != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != keys[i])) {
+      const uint32_t id = keys[i];
+      int cnt = 1;
+      while (i + cnt < P && keys[i + cnt] == id) ++cnt;
+      const float w = nodes[id].weight;
+      float v = w;
+      if (weighting == 0 || weighting == 1)
+        for (int c = 1; c < cnt; ++c) v = __fadd_rn(v, w);  // std::map value += w, in feature order
+      bow_word[base + slot] = id;
+      vals[slot] = v;
+      ++slot;
+    }
+  }
+  __syncthreads();
+  const bool must = scoring != 5;
+  if (tid == 0) {
+    double norm = 0.0;
+    if ((weighting == 0 || weighting == 1) && nb > 0 && !must) {
+      norm = (double)nb;  // unnormalised TF: divide by the vector size
+    } else if (must) {
+      if (scoring == 1) {
+        for (int i = 0; i < nb; ++i) norm += (double)__fmul_rn(vals[i], vals[i]);
+        norm = sqrt(norm);
+      } else {
+        for (int i = 0; i < nb; ++i) norm += fabs((double)vals[i]);
+      }
+    }
+    s_norm = norm;
+    bow_n[img] = nb;
+  }
+  __syncthreads();
+  const double norm = s_norm;
+  for (int i = tid; i < nb; i += 256) {
+    float v = vals[i];
+    if (norm > 0.0) v = (float)((double)v / norm);
+    bow_val[base + i] = v;
+  }
+  for (int i = nb + tid; i < cap; i += 256) {  // deterministic tail
+    bow_word[base + i] = 0xFFFFFFFFu;
+    bow_val[base + i] = 0.f;
+  }
+}
+
+}  // namespace
+
+struct gh_bow_vocab {
+  gh_ctx* ctx;
+  int k, L, weighting, scoring;
+  uint32_t nnodes;
+  Node* d_nodes;
+  uint8_t* d_desc;
+};
+
+extern "C" gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
+                                         const void* nodes, const uint8_t* node_desc, gh_bow_vocab** out) {
+  if (!ctx || !out) return GH_ERR_ARG;
+  *out = nullptr;
+  GH_CHECK_ARG(ctx, k >= 2 && L >= 1 && nnodes >= 1 && nodes && node_desc);
+  GH_CHECK_ARG(ctx, weighting >= 0 && weighting <= 3 && scoring >= 0 && scoring <= 5);
+  const Node* hn = (const Node*)nodes;
+  for (uint32_t i = 0; i < nnodes; ++i)  // every child index must exist (the descent never checks bounds)
+    GH_CHECK_ARG(ctx, hn[i].childNum <= (uint32_t)k && (hn[i].childNum == 0 || (uint64_t)i * k + hn[i].childNum < nnodes));
+  gh_bow_vocab* v = new (std::nothrow) gh_bow_vocab();
+  if (!v) return GH_ERR_NOMEM;
+  *v = gh_bow_vocab{ctx, k, L, weighting, scoring, nnodes, nullptr, nullptr};
+  gh_status st = gh_dev_alloc(ctx, (size_t)nnodes * sizeof(Node), (void**)&v->d_nodes);
+  if (st == GH_OK) st = gh_dev_alloc(ctx, (size_t)nnodes * 32, (void**)&v->d_desc);
+  if (st == GH_OK) st = gh_dev_upload(ctx, v->d_nodes, nodes, (size_t)nnodes * sizeof(Node));
+  if (st == GH_OK) st = gh_dev_upload(ctx, v->d_desc, node_desc, (size_t)nnodes * 32);
+  if (st != GH_OK) {
+    if (v->d_nodes) hipFree(v->d_nodes);
+    if (v->d_desc) hipFree(v->d_desc);
+    delete v;
+    return st;
+  }
+  *out = v;
+  return GH_OK;
+}
+
+extern "C" void gh_bow_vocab_destroy(gh_bow_vocab* v) {
+  if (!v) return;
+  hipStreamSynchronize(v->ctx->stream);
+  hipFree(v->d_nodes);
+  hipFree(v->d_desc);
+  delete v;
+}
+
+extern "C" gh_status gh_bow_transform_dev(gh_bow_vocab* v, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                          int n_images, int levelsup, uint32_t* word_dev, float* weight_dev,
+                                          uint32_t* node_dev, uint32_t* bow_word_dev, float* bow_val_dev,
+                                          int32_t* bow_n_dev) {
+  if (!v) return GH_ERR_ARG;
+  gh_ctx* ctx = v->ctx;
+  GH_CHECK_ARG(ctx, cap >= 0 && cap <= 8192 && n_images >= 0 && n_images <= 65535);
+  if (cap == 0 || n_images == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, desc_dev && word_dev && weight_dev && node_dev && bow_word_dev && bow_val_dev && bow_n_dev);
+  GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 15) == 0);
+  GH_LAUNCH(ctx, "bow_words", bow_words_kernel, dim3(gh_div_up(cap, 256), n_images), dim3(256), 0, v->d_nodes,
+            (const uint4*)v->d_desc, v->k, v->L, (const uint4*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev,
+            node_dev);
+  int P = 256;
+  while (P < cap) P <<= 1;
+  GH_LAUNCH(ctx, "bow_assemble", bow_assemble_kernel, dim3(n_images), dim3(256), (size_t)P * 8, v->d_nodes, v->weighting,
+            v->scoring, word_dev, weight_dev, cap, P, bow_word_dev, bow_val_dev, bow_n_dev);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bow_transform_host(gh_bow_vocab* v, const uint8_t* desc, int n, int levelsup, uint32_t* word,
+                                           float* weight, uint32_t* node, uint32_t* bow_word, float* bow_val,
+                                           int32_t* bow_n) {
+  if (!v) return GH_ERR_ARG;
+  gh_ctx* ctx = v->ctx;
+  GH_CHECK_ARG(ctx, n >= 0 && n <= 8192 && bow_n);
+  *bow_n = 0;
+  if (n == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, desc && word && weight && node && bow_word && bow_val);
+  const size_t a = ((size_t)n * 32 + 255) & ~(size_t)255, b = ((size_t)n * 4 + 255) & ~(size_t)255;
+  void* s = nullptr;
+  GH_TRY(gh_scratch(ctx, a + 5 * b + 256, &s));
+  uint8_t* p = (uint8_t*)s;
+  uint8_t* d_desc = p;
+  uint32_t* d_word = (uint32_t*)(p + a);
+  float* d_weight = (float*)(p + a + b);
+  uint32_t* d_node = (uint32_t*)(p + a + 2 * b);
+  uint32_t* d_bw = (uint32_t*)(p + a + 3 * b);
+  float* d_bv = (float*)(p + a + 4 * b);
+  int32_t* d_n = (int32_t*)(p + a + 5 * b);
+  GH_HIP(ctx, hipMemcpyAsync(d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+  GH_TRY(gh_bow_transform_dev(v, d_desc, nullptr, n, 1, levelsup, d_word, d_weight, d_node, d_bw, d_bv, d_n));
+  GH_HIP(ctx, hipMemcpyAsync(word, d_word, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(weight, d_weight, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(node, d_node, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(bow_word, d_bw, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(bow_val, d_bv, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(bow_n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}

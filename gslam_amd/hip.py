@@ -98,6 +98,10 @@ SIGNATURES = {
     "gh_bgr_to_gray_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
     "gh_orb_debug_level": (C.c_int, [_vp, _i, _i, _vp]),
     "gh_synth_frames_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _sz, _i, _i, C.c_uint32]),
+    "gh_bow_vocab_create": (C.c_int, [_vp, _i, _i, _i, _i, C.c_uint32, _vp, _vp, C.POINTER(_vp)]),
+    "gh_bow_vocab_destroy": (None, [_vp]),
+    "gh_bow_transform_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gh_bow_transform_host": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     "gh_ba_default_options": (None, [C.POINTER(BaOptions)]),
     "gh_ba_solve": (C.c_int, [_vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "gh_ba_pnp": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, C.POINTER(BaOptions), _vp, C.POINTER(BaSummary)]),

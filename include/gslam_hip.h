@@ -153,6 +153,25 @@ gh_status gh_orb_debug_level(gh_orb_plan* plan, int slot, int level, uint8_t* ou
 gh_status gh_synth_frames_dev(gh_ctx* ctx, uint8_t* gray_dev, int width, int height, int row_stride,
                               size_t frame_stride, int first_frame, int n_frames, uint32_t base_seed);
 
+/* ------------------------------------------------------------------ BoW transform ---- */
+/* GSLAM::Vocabulary image -> BoW vector (GSLAM/core/Vocabulary.h:1558-1621, per-feature descent :1695-1736,
+ * normalisation :386-408), for 32-byte binary descriptors.  The vocabulary is given in the in-memory layout of the
+ * reference's .gbow file (:1843-1932): nodes = {uint32 childNum; float weight}[nnodes], node_desc = nnodes x 32 B,
+ * children of node p at p*k+1 .. p*k+childNum.  weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY;
+ * scoring: 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT (enum order of the reference). */
+typedef struct gh_bow_vocab gh_bow_vocab;
+gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
+                              const void* nodes, const uint8_t* node_desc, gh_bow_vocab** out);
+void gh_bow_vocab_destroy(gh_bow_vocab* vocab);
+/* Batched over images: desc_dev n_images x cap x 32 B, counts_dev (may be NULL = cap rows each).  Per feature:
+ * word id, word weight, node id at level L - levelsup (0xFFFFFFFF / 0 / 0xFFFFFFFF for rows >= count).  Per image:
+ * bow_word (ascending, 0xFFFFFFFF padded) / bow_val (normalised as the reference does) / bow_n.  cap <= 8192. */
+gh_status gh_bow_transform_dev(gh_bow_vocab* vocab, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                               int n_images, int levelsup, uint32_t* word_dev, float* weight_dev, uint32_t* node_dev,
+                               uint32_t* bow_word_dev, float* bow_val_dev, int32_t* bow_n_dev);
+gh_status gh_bow_transform_host(gh_bow_vocab* vocab, const uint8_t* desc, int n, int levelsup, uint32_t* word,
+                                float* weight, uint32_t* node, uint32_t* bow_word, float* bow_val, int32_t* bow_n);
+
 /* ------------------------------------------------------------------ bundle adjustment - */
 /* DOF bits follow GSLAM::KeyFrameEstimzationDOF (GSLAM/core/Optimizer.h:70-84). */
 #define GH_KF_X 1

@@ -1,0 +1,128 @@
+/*
+ * bow_oracle.c — CPU restatement of GSLAM::Vocabulary's BoW transform.  TEST INFRASTRUCTURE ONLY.
+ * PINNED: tests/test_bow_oracle.py compares this file, output for output, with the reference's own
+ * Vocabulary::load + transform compiled from /root/reference into oracle/_ref (ref_vocab_*), and with the committed
+ * golden vectors tests/golden/bow_reference.npz generated from it.
+ *
+ * Follows:
+ *   GSLAM/core/Vocabulary.h:1695-1736  transform(feature, word_id, weight, nid, levelsup): greedy descent from
+ *                                      the root; children of node p are p*k+1 .. p*k+childNum (:1716); strict '<'
+ *                                      keeps the FIRST minimum (:1719); stops at a node with childNum == 0;
+ *                                      nid = node reached at level L - levelsup (root if that level <= 0)
+ *   GSLAM/core/Vocabulary.h:485-491    distance = hamming32
+ *   GSLAM/core/Vocabulary.h:1558-1621  image transform: TF / TF_IDF accumulate v[id] += w in feature order
+ *                                      (float), IDF / BINARY keep the first w; words with w <= 0 are skipped;
+ *                                      without normalisation TF-type values are divided by the vector size
+ *   GSLAM/core/Vocabulary.h:386-408    normalize: L1 = sum |v| (double, ascending word id), L2 = sqrt(sum v^2);
+ *                                      v /= norm (float /= double)
+ *   GSLAM/core/Vocabulary.h:667-683    which scoring types normalise (all L1 except L2_NORM = L2, DOT_PRODUCT = none)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+int oracle_hamming32(const uint8_t* a, const uint8_t* b);
+
+typedef struct {
+  uint32_t childNum;
+  float weight;
+} bow_node;
+
+void oracle_bow_word(const bow_node* nodes, const uint8_t* ndesc, int k, int L, const uint8_t* f, int levelsup,
+                     uint32_t* word, float* weight, uint32_t* node) {
+  const int nid_level = L - levelsup;
+  uint32_t final_id = 0, nid = 0;
+  int level = 0;
+  do {
+    ++level;
+    int best_d = 1 << 30;
+    uint32_t best = final_id;
+    uint32_t id = final_id * (uint32_t)k + 1;
+    for (uint32_t end = id + nodes[final_id].childNum; id < end; ++id) {
+      int d = oracle_hamming32(f, ndesc + (size_t)id * 32);
+      if (d < best_d) {
+        best_d = d;
+        best = id;
+      }
+    }
+    final_id = best;
+    if (level == nid_level) nid = final_id;
+  } while (nodes[final_id].childNum != 0);
+  *word = final_id;
+  *weight = nodes[final_id].weight;
+  *node = nid_level <= 0 ? 0 : nid;
+}
+
+static int cmp_u32(const void* a, const void* b) {
+  uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1, 1 L2, 2 CHI2, 3 KL, 4 BHATT, 5 DOT.
+ * Outputs per feature (word, weight, node) and the BoW vector (ascending word id).  Returns the BoW length. */
+int oracle_bow_transform(const bow_node* nodes, const uint8_t* ndesc, int k, int L, int weighting, int scoring,
+                         const uint8_t* desc, int n, int levelsup, uint32_t* word, float* weight, uint32_t* node,
+                         uint32_t* bow_word, float* bow_val) {
+  for (int i = 0; i < n; ++i)
+    oracle_bow_word(nodes, ndesc, k, L, desc + (size_t)i * 32, levelsup, &word[i], &weight[i], &node[i]);
+  /* stable order by word id: features of one word keep their order (only counts matter: same weight) */
+  uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
+  int m = 0;
+  for (int i = 0; i < n; ++i)
+    if (weight[i] > 0) ids[m++] = word[i];
+  qsort(ids, m, sizeof(uint32_t), cmp_u32);
+  int nb = 0;
+  for (int i = 0; i < m;) {
+    int j = i;
+    while (j < m && ids[j] == ids[i]) ++j;
+    float w = nodes[ids[i]].weight, v = w;
+    if (weighting == 0 || weighting == 1)
+      for (int c = 1; c < j - i; ++c) v += w; /* addWeight: repeated float += in feature order */
+    bow_word[nb] = ids[i];
+    bow_val[nb] = v;
+    ++nb;
+    i = j;
+  }
+  free(ids);
+  const int must = scoring != 5;
+  if ((weighting == 0 || weighting == 1) && nb > 0 && !must) {
+    const double nd = (double)nb;
+    for (int i = 0; i < nb; ++i) bow_val[i] = (float)(bow_val[i] / nd);
+  }
+  if (must) {
+    double norm = 0.0;
+    if (scoring == 1) {
+      for (int i = 0; i < nb; ++i) norm += bow_val[i] * bow_val[i]; /* float * float, accumulated in double */
+      norm = sqrt(norm);
+    } else {
+      for (int i = 0; i < nb; ++i) norm += fabs(bow_val[i]);
+    }
+    if (norm > 0.0)
+      for (int i = 0; i < nb; ++i) bow_val[i] = (float)(bow_val[i] / norm);
+  }
+  return nb;
+}
+
+/* L1 score of two BoW vectors (Vocabulary.h:691-736): s = sum over common words of |vi - wi| - |vi| - |wi|; -s/2 */
+double oracle_bow_score_l1(const uint32_t* a_id, const float* a_v, int na, const uint32_t* b_id, const float* b_v,
+                           int nb) {
+  double score = 0;
+  int i = 0, j = 0;
+  while (i < na && j < nb) {
+    if (a_id[i] == b_id[j]) {
+      const float vi = a_v[i], wi = b_v[j];
+      /* the reference's unqualified fabs() on floats resolves to the float overload (C++ <cmath>): the three
+       * terms are combined in single precision, then accumulated in double (checked against oracle/_ref) */
+      const float term = fabsf(vi - wi) - fabsf(vi) - fabsf(wi);
+      score += term;
+      ++i;
+      ++j;
+    } else if (a_id[i] < b_id[j]) {
+      ++i;
+    } else {
+      ++j;
+    }
+  }
+  return -score / 2.0;
+}

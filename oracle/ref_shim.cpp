@@ -83,3 +83,83 @@ int ref_sizeof_keypoint() { return (int)sizeof(GSLAM::KeyPoint); }
 int ref_sizeof_se3() { return (int)sizeof(GSLAM::SE3); }
 int ref_sizeof_sim3() { return (int)sizeof(GSLAM::SIM3); }
 }
+
+// ---------------------------------------------------------------- Vocabulary
+// The reference's own BoW transform: GSLAM::Vocabulary::load(std::istream&) (Vocabulary.h:1891-1932) on an
+// in-memory .gbow image, then transform(features, bow, fv, levelsup) (:1558-1621).  Flat outputs:
+//   bow_ids/bow_vals (ascending word id, map order), fv pairs (node id, feature index) in map order.
+#include <sstream>
+
+extern "C" {
+
+void* ref_vocab_load(const unsigned char* gbow, size_t bytes) {
+  std::string buf((const char*)gbow, bytes);
+  std::istringstream is(buf, std::ios::binary);
+  GSLAM::Vocabulary* v = new GSLAM::Vocabulary();
+  if (!v->load(is)) {
+    delete v;
+    return nullptr;
+  }
+  return v;
+}
+
+void ref_vocab_free(void* v) { delete (GSLAM::Vocabulary*)v; }
+
+int ref_vocab_info(void* vp, int* k, int* L, int* nnodes) {
+  GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
+  *k = v->m_k;
+  *L = v->m_L;
+  *nnodes = (int)v->m_nodes.size();
+  return 0;
+}
+
+// returns number of BoW entries; fv_n receives the number of (node, feature) pairs
+int ref_vocab_transform(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* bow_ids, float* bow_vals,
+                        uint64_t* fv_nodes, uint32_t* fv_feat, int* fv_n) {
+  GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
+  GSLAM::TinyMat features(n, 32, GSLAM::GImageType<uchar>::Type, (uchar*)desc, false);
+  GSLAM::BowVector bow;
+  GSLAM::FeatureVector fv;
+  v->transform(features, bow, fv, levelsup);
+  int i = 0;
+  for (auto& kv : bow) {
+    bow_ids[i] = kv.first;
+    bow_vals[i] = kv.second;
+    ++i;
+  }
+  int j = 0;
+  for (auto& kv : fv)
+    for (unsigned f : kv.second) {
+      fv_nodes[j] = kv.first;
+      fv_feat[j] = f;
+      ++j;
+    }
+  *fv_n = j;
+  return i;
+}
+
+// per-feature word / weight / node (single-feature transform, Vocabulary.h:1695-1736)
+void ref_vocab_words(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* word, float* weight,
+                     uint64_t* node) {
+  GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
+  for (int i = 0; i < n; ++i) {
+    GSLAM::TinyMat f(1, 32, GSLAM::GImageType<uchar>::Type, (uchar*)desc + (size_t)i * 32, false);
+    GSLAM::WordId id;
+    GSLAM::WordValue w;
+    GSLAM::NodeId nid;
+    v->transform(f, id, w, &nid, levelsup);
+    word[i] = id;
+    weight[i] = w;
+    node[i] = nid;
+  }
+}
+
+double ref_vocab_score(void* vp, const uint64_t* a_ids, const float* a_vals, int na, const uint64_t* b_ids,
+                       const float* b_vals, int nb) {
+  GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
+  GSLAM::BowVector a, b;
+  for (int i = 0; i < na; ++i) a[a_ids[i]] = a_vals[i];
+  for (int i = 0; i < nb; ++i) b[b_ids[i]] = b_vals[i];
+  return v->m_scoring_object->score(a, b);
+}
+}

@@ -281,3 +281,82 @@ def _ba_methods(cls):
 
 
 _ba_methods(Oracle)
+
+
+# ---------------------------------------------------------------- BoW (Vocabulary transform) wrappers
+def _bow_methods(cls):
+    def bow_transform(self, voc, desc, levelsup=2):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = desc.shape[0]
+        word = np.zeros(n, np.uint32)
+        weight = np.zeros(n, np.float32)
+        node = np.zeros(n, np.uint32)
+        bw = np.zeros(max(n, 1), np.uint32)
+        bv = np.zeros(max(n, 1), np.float32)
+        nodes = np.ascontiguousarray(voc["nodes"])
+        nd = np.ascontiguousarray(voc["desc"])
+        nb = self.lib.oracle_bow_transform(_ptr(nodes), _ptr(nd), int(voc["k"]), int(voc["L"]), int(voc["weighting"]),
+                                           int(voc["scoring"]), _ptr(desc), n, int(levelsup), _ptr(word), _ptr(weight),
+                                           _ptr(node), _ptr(bw), _ptr(bv))
+        return word, weight, node, bw[:nb].copy(), bv[:nb].copy()
+
+    def bow_score_l1(self, a, b):
+        self.lib.oracle_bow_score_l1.restype = C.c_double
+        ai, av = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float32)
+        bi, bv = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float32)
+        return self.lib.oracle_bow_score_l1(_ptr(ai), _ptr(av), len(ai), _ptr(bi), _ptr(bv), len(bi))
+
+    cls.bow_transform = bow_transform
+    cls.bow_score_l1 = bow_score_l1
+
+
+_bow_methods(Oracle)
+
+
+class RefVocabulary:
+    """The reference's own GSLAM::Vocabulary loaded from an in-memory .gbow image (oracle/_ref)."""
+
+    def __init__(self, ref: Reference, gbow_bytes: bytes):
+        self.lib = ref.lib
+        self.lib.ref_vocab_load.restype = C.c_void_p
+        buf = np.frombuffer(gbow_bytes, np.uint8)
+        self.h = self.lib.ref_vocab_load(_ptr(buf), C.c_size_t(len(gbow_bytes)))
+        assert self.h, "reference Vocabulary::load rejected the image"
+        self.h = C.c_void_p(self.h)
+
+    def info(self):
+        k, L, n = C.c_int(), C.c_int(), C.c_int()
+        self.lib.ref_vocab_info(self.h, C.byref(k), C.byref(L), C.byref(n))
+        return k.value, L.value, n.value
+
+    def transform(self, desc, levelsup=2):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = desc.shape[0]
+        bi = np.zeros(max(n, 1), np.uint64)
+        bv = np.zeros(max(n, 1), np.float32)
+        fn = np.zeros(max(n, 1), np.uint64)
+        ff = np.zeros(max(n, 1), np.uint32)
+        fvn = C.c_int()
+        nb = self.lib.ref_vocab_transform(self.h, _ptr(desc), n, int(levelsup), _ptr(bi), _ptr(bv), _ptr(fn), _ptr(ff),
+                                          C.byref(fvn))
+        return bi[:nb].copy(), bv[:nb].copy(), fn[:fvn.value].copy(), ff[:fvn.value].copy()
+
+    def words(self, desc, levelsup=2):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = desc.shape[0]
+        w = np.zeros(n, np.uint64)
+        wt = np.zeros(n, np.float32)
+        nd = np.zeros(n, np.uint64)
+        self.lib.ref_vocab_words(self.h, _ptr(desc), n, int(levelsup), _ptr(w), _ptr(wt), _ptr(nd))
+        return w, wt, nd
+
+    def score(self, a, b):
+        self.lib.ref_vocab_score.restype = C.c_double
+        ai, av = np.ascontiguousarray(a[0], np.uint64), np.ascontiguousarray(a[1], np.float32)
+        bi, bv = np.ascontiguousarray(b[0], np.uint64), np.ascontiguousarray(b[1], np.float32)
+        return self.lib.ref_vocab_score(self.h, _ptr(ai), _ptr(av), len(ai), _ptr(bi), _ptr(bv), len(bi))
+
+    def close(self):
+        if self.h:
+            self.lib.ref_vocab_free(self.h)
+            self.h = None

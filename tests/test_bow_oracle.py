@@ -1,0 +1,63 @@
+"""BoW transform oracle PINNED to the reference: GSLAM::Vocabulary::load + transform compiled from
+/root/reference (oracle/_ref) live when available, and the committed golden vectors generated from it."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from gslam_amd import bow_synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "bow_reference.npz")
+
+
+def _fv_pairs(node, weight):
+    """FeatureVector in map order: (node id asc, feature index asc) for features with weight > 0."""
+    idx = np.nonzero(weight > 0)[0]
+    order = np.lexsort((idx, node[idx]))
+    return node[idx][order].astype(np.uint64), idx[order].astype(np.uint32)
+
+
+def test_golden_vectors_from_reference(oracle):
+    g = np.load(GOLD)
+    voc = bow_synth.make_vocabulary(k=int(g["k"]), L=int(g["L"]), seed=int(g["seed"]))
+    assert bow_synth.to_gbow_bytes(voc) == g["gbow"].tobytes()  # the generator is reproducible
+    word, weight, node, bw, bv = oracle.bow_transform(voc, g["desc"], levelsup=int(g["levelsup"]))
+    assert np.array_equal(word, g["word"]) and np.array_equal(weight, g["weight"]) and np.array_equal(node, g["node"])
+    assert np.array_equal(bw, g["bow_ids"]) and bv.tobytes() == g["bow_vals"].tobytes()  # bit-exact floats
+    fn, ff = _fv_pairs(node, weight)
+    assert np.array_equal(fn, g["fv_nodes"]) and np.array_equal(ff, g["fv_feat"])
+    assert abs(oracle.bow_score_l1((bw, bv), (g["bow2_ids"], g["bow2_vals"])) - float(g["score12"])) == 0.0
+
+
+@pytest.mark.skipif(not oracle_lib.have_reference(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("k,L,weighting,scoring,levelsup", [(10, 4, 0, 0, 2), (4, 3, 1, 1, 1), (10, 3, 2, 0, 0),
+                                                            (6, 4, 3, 5, 4), (10, 4, 0, 5, 7), (3, 5, 1, 2, 3)])
+def test_oracle_equals_reference_live(oracle, k, L, weighting, scoring, levelsup):
+    ref = oracle_lib.load_reference()
+    voc = bow_synth.make_vocabulary(k=k, L=L, seed=11 + k, weighting=weighting, scoring=scoring)
+    rv = oracle_lib.RefVocabulary(ref, bow_synth.to_gbow_bytes(voc))
+    assert rv.info() == (k, L, len(voc["nodes"]))
+    desc = np.concatenate([bow_synth.features_near_words(voc, 700, seed=5), oracle_lib.random_descriptors(300, 9)])
+    word, weight, node, bw, bv = oracle.bow_transform(voc, desc, levelsup=levelsup)
+    rw, rwt, rn = rv.words(desc, levelsup)
+    assert np.array_equal(word, rw) and np.array_equal(weight, rwt) and np.array_equal(node, rn)
+    bi, bvr, fn, ff = rv.transform(desc, levelsup)
+    assert np.array_equal(bw, bi) and bv.tobytes() == bvr.tobytes()
+    en, ef = _fv_pairs(node, weight)
+    assert np.array_equal(en, fn) and np.array_equal(ef, ff)
+    if scoring == 0:
+        desc2 = bow_synth.features_near_words(voc, 800, seed=6)
+        _, _, _, bw2, bv2 = oracle.bow_transform(voc, desc2, levelsup=levelsup)
+        assert oracle.bow_score_l1((bw, bv), (bw2, bv2)) == rv.score((bi, bvr), (bw2.astype(np.uint64), bv2))
+    rv.close()
+
+
+def test_stopped_words_and_empty_input(oracle):
+    voc = bow_synth.make_vocabulary(k=4, L=2, seed=3, stop_frac=0.5)
+    desc = bow_synth.features_near_words(voc, 200, seed=1)
+    word, weight, node, bw, bv = oracle.bow_transform(voc, desc)
+    assert (weight == 0).any() and not np.isin(word[weight == 0], bw).any()
+    assert abs(np.abs(bv).sum() - 1.0) < 1e-5
+    w0 = oracle.bow_transform(voc, np.zeros((0, 32), np.uint8))
+    assert len(w0[3]) == 0
