@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--kpts", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-bow", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48, help="bounded CPU sample (frames)")
     ap.add_argument("--ba-cams", type=int, default=500)
     ap.add_argument("--ba-points", type=int, default=50000)
@@ -236,6 +237,53 @@ def main():
                                        "peak_TFLOPs": FP64_MFMA_PEAK / 1e12},
                        "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
                                    for k, v in bprof.items()}}
+
+    # ---- BoW transform: the extracted descriptors of this step through GSLAM::Vocabulary-style
+    #      k=10 trees (L=4 / L=6, the two sizes the reference publishes: 615.5 / 723.7 us per image on an i7-6700)
+    if not a.no_bow:
+        from gslam_amd import bow_synth
+        from gslam_amd.bow import Vocabulary
+        extra["bow"] = {}
+        for Lv, pub in ((4, 615.5), (6, 723.7)):
+            log(f"BoW leg: L={Lv}")
+            voc = bow_synth.make_vocabulary(k=10, L=Lv, seed=1)
+            v = Vocabulary(ctx, voc)
+            nimg = min(F, 200)
+            outb = v.alloc(nimg, K, dev)
+            v.transform(desc[:nimg], counts[:nimg], 2, outb)
+            torch.cuda.synchronize()
+            ctx.prof_enable(True)
+            for _ in range(3):
+                v.transform(desc[:nimg], counts[:nimg], 2, outb)
+            bp = ctx.prof_collect()
+            ctx.prof_enable(False)
+            us_img = sum(x["total_ms"] for x in bp.values()) * 1e3 / (3 * nimg)
+            one = desc[0, :int(counts[0])].cpu().numpy()
+            v.transform_host(one, 2)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                v.transform_host(one, 2)
+            lat_us = (time.perf_counter() - t1) / 20 * 1e6
+            rec = {"us_per_image_batched": round(us_img, 2), "us_per_image_single_host_call": round(lat_us, 1),
+                   "descriptors_per_image": K, "published_us_per_image_i7_6700": pub,
+                   "nodes": len(voc["nodes"]), "words_image0": int(outb[5][0])}
+            if not a.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib
+                orc = oracle_lib.load()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    orc.bow_transform(voc, one, 2)
+                rec["cpu_oracle_us_per_image_1core"] = round((time.perf_counter() - t1) / 5 * 1e6, 1)
+                if oracle_lib.have_reference():
+                    rv = oracle_lib.RefVocabulary(oracle_lib.load_reference(), bow_synth.to_gbow_bytes(voc))
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        rv.transform(one, 2)
+                    rec["cpu_reference_us_per_image_1core"] = round((time.perf_counter() - t1) / 5 * 1e6, 1)
+                    rv.close()
+            extra["bow"][f"k10_L{Lv}"] = rec
+            v.close()
 
     # ---- CPU baseline on this box's host cores: bounded sample of the same workload (oracle = "port")
     cpu = None

@@ -7,6 +7,7 @@
 //   plugin_host ba   <plugin_dir> <graph.bin> <out.bin>
 //   plugin_host pnp  <plugin_dir> <pnp.bin> <out.bin>
 //   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
+//   plugin_host bow  <plugin_dir> <vocab.gbow> <desc.raw> <n> <levelsup> <out.bin>
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
 
@@ -15,6 +16,8 @@
 #include <fstream>
 #include <iostream>
 #include <vector>
+
+#include <GSLAM/core/Vocabulary.h>
 
 #include "FeatureDetector.h"
 
@@ -146,11 +149,48 @@ static int run_orb(const std::string& dir, int w, int h, int ch, const char* in,
   return ok && okm ? 0 : 3;
 }
 
+// Vocabulary: the plugin's subclass against the reference's own base-class transform, in the same process.
+static int run_bow(const std::string& dir, const char* gbow, const char* descf, int n, int levelsup, const char* out) {
+  typedef std::shared_ptr<Vocabulary> (*factory_t)(const char*);
+  std::shared_ptr<SharedLibrary> lib = Registry::get(dir + "/libgslam_vocabulary.so");
+  if (!lib) { std::cerr << "cannot load libgslam_vocabulary.so\n"; return 2; }
+  factory_t f = (factory_t)lib->getSymbol("createVocabularyInstance");
+  if (!f) return 2;
+  std::shared_ptr<Vocabulary> gpu = f(gbow);
+  Vocabulary cpu;
+  if (!gpu || !cpu.load(std::string(gbow))) { std::cerr << "vocabulary load failed\n"; return 2; }
+  std::vector<uchar> d((size_t)n * 32);
+  std::ifstream fi(descf, std::ios::binary);
+  fi.read((char*)d.data(), d.size());
+  TinyMat features(n, 32, GImageType<uchar>::Type, d.data(), false);
+  BowVector bg, bc;
+  FeatureVector fg, fc;
+  gpu->transform(features, bg, fg, levelsup);
+  cpu.transform(features, bc, fc, levelsup);
+  BowVector bg2, bc2;
+  gpu->transform(features, bg2);
+  cpu.transform(features, bc2);
+  const bool same = bg == bc && fg == fc && bg2 == bc2;
+  std::ofstream o(out, std::ios::binary);
+  int32_t hdr[4] = {same ? 1 : 0, (int32_t)bg.size(), (int32_t)fg.size(), (int32_t)bc.size()};
+  o.write((char*)hdr, sizeof(hdr));
+  for (auto& kv : bg) {
+    uint64_t id = kv.first;
+    float val = kv.second;
+    o.write((char*)&id, 8);
+    o.write((char*)&val, 4);
+  }
+  std::cout << "bow gpu==reference:" << same << " words=" << bg.size() << " nodes=" << fg.size()
+            << " score(self)=" << gpu->m_scoring_object->score(bg, bc) << std::endl;
+  return same ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
   if (mode == "ba" && argc >= 5) return run_ba(dir, argv[3], argv[4]);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "bow" && argc >= 8) return run_bow(dir, argv[3], argv[4], atoi(argv[5]), atoi(argv[6]), argv[7]);
   if (mode == "orb" && argc >= 9)
     return run_orb(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
   return 1;

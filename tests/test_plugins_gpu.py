@@ -107,3 +107,24 @@ def test_featuredetector_plugin_matches_oracle(tmp_path, oracle, channels):
     keep = oracle.match_mask(e[0], e[1], e[2], e[0], n, 100, 0, 1, 1)
     exp_matches = np.stack([np.nonzero(keep)[0], e[0][keep == 1]], axis=1).astype(np.int32)
     assert okm == 1 and np.array_equal(matches, exp_matches)
+
+
+def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle):
+    """libgslam_vocabulary.so (VocabularyHIP) vs GSLAM::Vocabulary itself, both inside the GSLAM host process:
+    BowVector and FeatureVector maps must compare equal (operator== on the std::maps, i.e. bit-exact floats)."""
+    _need_host()
+    from gslam_amd import bow_synth
+    voc = bow_synth.make_vocabulary(k=10, L=4, seed=5)
+    gb, df, out = tmp_path / "voc.gbow", tmp_path / "desc.raw", tmp_path / "out.bin"
+    open(gb, "wb").write(bow_synth.to_gbow_bytes(voc))
+    desc = bow_synth.features_near_words(voc, 1500, seed=8)
+    desc.tofile(df)
+    r = _run(["bow", LIBDIR, gb, df, 1500, 2, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bow gpu==reference:1" in r.stdout
+    raw = open(out, "rb").read()
+    same, nwords, nnodes, ncpu = struct.unpack("4i", raw[:16])
+    e = oracle.bow_transform(voc, desc, 2)
+    assert same == 1 and nwords == ncpu == len(e[3])
+    rec = np.frombuffer(raw, np.dtype([("id", "<u8"), ("v", "<f4")]), nwords, 16)
+    assert np.array_equal(rec["id"], e[3]) and rec["v"].tobytes() == e[4].tobytes()

@@ -13,6 +13,8 @@ for line in open(sys.argv[1]):
     print("bf", j["extra"]["bf_match"])
     for k, v in j["extra"]["kernels"].items():
         print("   %-20s %s" % (k, v))
+    if j["extra"].get("bow"):
+        print("bow", j["extra"]["bow"])
     ba = j["extra"].get("ba")
     if ba:
         print("ba", {k: v for k, v in ba.items() if k != "kernels"})
