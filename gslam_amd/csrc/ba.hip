@@ -21,8 +21,8 @@
 
 #include "common.h"
 
-gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev);
-gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work);
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows);
+gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work);
 
 namespace {
 
@@ -434,6 +434,16 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlock
   }
 }
 
+// rhs -> row n of S (rides through the factorisation, becomes y = L^-1 rhs), and back out into a vector
+__global__ void rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ S, int lda, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) S[(size_t)j * lda + n] = rhs[j];
+}
+__global__ void row_to_vec_kernel(const double* __restrict__ S, int lda, int n, double* __restrict__ y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) y[j] = S[(size_t)j * lda + n];
+}
+
 __global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const double* __restrict__ Hpi,
                                                              const double* __restrict__ gp,
                                                              const double* __restrict__ dc, double* __restrict__ dp) {
@@ -627,7 +637,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   const int n = 6 * nc;
-  const int lda = n;
+  const int lda = n + 1;  // one extra row carries the right-hand side through the factorisation
 
   std::vector<int32_t> pstart, plist, cstart, clist;
   build_csr(pr->obs_point, no, np, pstart, plist);
@@ -776,7 +786,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
                   d_S, lda, d_dc);
     }
     const double t_solve0 = now_ms();
-    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info));
+    GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
+    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1));
     int flags[2] = {0, 0};
     GH_HIP(ctx, hipMemcpyAsync(&flags[0], d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&flags[1], d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -784,7 +795,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     bool ok = flags[0] == 0 && flags[1] == 0;
     double new_cost = cost, model = 0, rho = -1;
     if (ok) {
-      GH_TRY(gh_potrs_dev_impl(ctx, d_S, n, lda, d_dc, d_work));
+      GH_LAUNCH(ctx, "ba_rhs_row", row_to_vec_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_S, lda, n, d_work);
+      GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work));
       GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
       sum->solve_ms_total += now_ms() - t_solve0;
       if (np > 0)
