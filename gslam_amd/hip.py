@@ -102,6 +102,10 @@ SIGNATURES = {
     "gh_bow_vocab_destroy": (None, [_vp]),
     "gh_bow_transform_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gh_bow_transform_host": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    "gh_undist_plan_create": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "gh_undist_plan_destroy": (None, [_vp]),
+    "gh_undistort_dev": (C.c_int, [_vp, _vp, _i, _i, _sz, _vp, _sz, _i]),
+    "gh_undistort_host": (C.c_int, [_vp, _vp, _i, _vp, _i]),
     "gh_ba_default_options": (None, [C.POINTER(BaOptions)]),
     "gh_ba_solve": (C.c_int, [_vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "gh_ba_pnp": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, C.POINTER(BaOptions), _vp, C.POINTER(BaSummary)]),

@@ -172,6 +172,19 @@ gh_status gh_bow_transform_dev(gh_bow_vocab* vocab, const uint8_t* desc_dev, con
 gh_status gh_bow_transform_host(gh_bow_vocab* vocab, const uint8_t* desc, int n, int levelsup, uint32_t* word,
                                 float* weight, uint32_t* node, uint32_t* bow_word, float* bow_val, int32_t* bow_n);
 
+/* ------------------------------------------------------------------ undistortion ----- */
+/* GSLAM::Undistorter::undistort / undistortFast (GSLAM/core/Undistorter.h:206-348) with the remap tables its
+ * prepareReMap builds on the host (:120-203): per output pixel remapX, remapFast, remapIdx[4], remapCoef[4].
+ * u8 images, 1 / 3 (/ 4 for `fast`) interleaved channels, dense rows.  Pixels the reference leaves unwritten are 0. */
+typedef struct gh_undist_plan gh_undist_plan;
+gh_status gh_undist_plan_create(gh_ctx* ctx, int w_in, int h_in, int w_out, int h_out, const float* remapX,
+                                const int32_t* remapFast, const int32_t* remapIdx, const float* remapCoef,
+                                gh_undist_plan** out);
+void gh_undist_plan_destroy(gh_undist_plan* plan);
+gh_status gh_undistort_dev(gh_undist_plan* plan, const uint8_t* img_dev, int channels, int batch,
+                           size_t in_frame_stride, uint8_t* out_dev, size_t out_frame_stride, int fast);
+gh_status gh_undistort_host(gh_undist_plan* plan, const uint8_t* img, int channels, uint8_t* out, int fast);
+
 /* ------------------------------------------------------------------ bundle adjustment - */
 /* DOF bits follow GSLAM::KeyFrameEstimzationDOF (GSLAM/core/Optimizer.h:70-84). */
 #define GH_KF_X 1

@@ -163,3 +163,50 @@ double ref_vocab_score(void* vp, const uint64_t* a_ids, const float* a_vals, int
   return v->m_scoring_object->score(a, b);
 }
 }
+
+// ---------------------------------------------------------------- Undistorter
+// The reference's own remap tables (UndistorterImpl::prepareReMap, GSLAM/core/Undistorter.h:120-203) and
+// its undistort / undistortFast loops (:206-348) for pinning oracle/undist_oracle.c and the golden vectors.
+#include <GSLAM/core/Undistorter.h>
+
+extern "C" {
+
+void* ref_undist_create(const double* pin, int n_in, const double* pout, int n_out) {
+  std::streambuf* old = std::cout.rdbuf(nullptr);  // prepareReMap prints the camera info
+  GSLAM::UndistorterImpl* u = new GSLAM::UndistorterImpl(GSLAM::Camera(std::vector<double>(pin, pin + n_in)),
+                                                         GSLAM::Camera(std::vector<double>(pout, pout + n_out)));
+  std::cout.rdbuf(old);
+  if (!u->valid) {
+    delete u;
+    return nullptr;
+  }
+  return u;
+}
+void ref_undist_free(void* u) { delete (GSLAM::UndistorterImpl*)u; }
+void ref_undist_dims(void* up, int* wi, int* hi, int* wo, int* ho) {
+  GSLAM::UndistorterImpl* u = (GSLAM::UndistorterImpl*)up;
+  *wi = u->camera_in.width(); *hi = u->camera_in.height();
+  *wo = u->camera_out.width(); *ho = u->camera_out.height();
+}
+void ref_undist_tables(void* up, float* remapX, float* remapY, int* remapFast, int* remapIdx, float* remapCoef) {
+  GSLAM::UndistorterImpl* u = (GSLAM::UndistorterImpl*)up;
+  size_t n = (size_t)u->camera_out.width() * u->camera_out.height();
+  memcpy(remapX, u->remapX, n * 4);
+  memcpy(remapY, u->remapY, n * 4);
+  memcpy(remapFast, u->remapFast, n * 4);
+  memcpy(remapIdx, u->remapIdx, n * 16);
+  memcpy(remapCoef, u->remapCoef, n * 16);
+}
+// out must be pre-filled by the caller (the reference leaves unmapped pixels untouched in several branches)
+int ref_undist_run(void* up, const unsigned char* img, int channels, int fast, unsigned char* out) {
+  GSLAM::UndistorterImpl* u = (GSLAM::UndistorterImpl*)up;
+  const int type = channels == 1 ? GSLAM::GImageType<uchar, 1>::Type
+                                 : (channels == 3 ? GSLAM::GImageType<uchar, 3>::Type : GSLAM::GImageType<uchar, 4>::Type);
+  GSLAM::GImage in(u->camera_in.height(), u->camera_in.width(), type, (uchar*)img, false);
+  GSLAM::GImage res;
+  bool ok = fast ? u->undistortFast(in, res) : u->undistort(in, res);
+  if (!ok) return 0;
+  memcpy(out, res.data, (size_t)res.total() * res.elemSize());
+  return 1;
+}
+}

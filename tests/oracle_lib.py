@@ -360,3 +360,64 @@ class RefVocabulary:
         if self.h:
             self.lib.ref_vocab_free(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- Undistorter wrappers
+def _undist_methods(cls):
+    def undistort(self, img, tables, fast=False):
+        """img: H_in x W_in [x C] u8; tables: dict(remapX, remapFast, remapIdx (n,4), remapCoef (n,4), w_out, h_out)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        n = tables["w_out"] * tables["h_out"]
+        out = np.zeros(n * ch, np.uint8)
+        written = np.zeros(n, np.uint8)
+        self.lib.oracle_undistort(_ptr(img), ch, int(tables["w_in"] * tables["h_in"]), n,
+                                  _ptr(np.ascontiguousarray(tables["remapX"], np.float32)),
+                                  _ptr(np.ascontiguousarray(tables["remapFast"], np.int32)),
+                                  _ptr(np.ascontiguousarray(tables["remapIdx"], np.int32)),
+                                  _ptr(np.ascontiguousarray(tables["remapCoef"], np.float32)), 1 if fast else 0,
+                                  _ptr(out), _ptr(written))
+        shape = (tables["h_out"], tables["w_out"]) if ch == 1 else (tables["h_out"], tables["w_out"], ch)
+        return out.reshape(shape), written.reshape(tables["h_out"], tables["w_out"]).astype(bool)
+
+    cls.undistort = undistort
+
+
+_undist_methods(Oracle)
+
+
+class RefUndistorter:
+    """The reference's own UndistorterImpl (oracle/_ref): tables from prepareReMap, undistort / undistortFast."""
+
+    def __init__(self, ref: Reference, cam_in, cam_out):
+        self.lib = ref.lib
+        self.lib.ref_undist_create.restype = C.c_void_p
+        a, b = np.asarray(cam_in, np.float64), np.asarray(cam_out, np.float64)
+        h = self.lib.ref_undist_create(_ptr(a), len(a), _ptr(b), len(b))
+        assert h, "reference Undistorter invalid"
+        self.h = C.c_void_p(h)
+        d = [C.c_int() for _ in range(4)]
+        self.lib.ref_undist_dims(self.h, *[C.byref(x) for x in d])
+        self.w_in, self.h_in, self.w_out, self.h_out = [x.value for x in d]
+
+    def tables(self):
+        n = self.w_out * self.h_out
+        t = {"remapX": np.zeros(n, np.float32), "remapY": np.zeros(n, np.float32), "remapFast": np.zeros(n, np.int32),
+             "remapIdx": np.zeros((n, 4), np.int32), "remapCoef": np.zeros((n, 4), np.float32)}
+        self.lib.ref_undist_tables(self.h, _ptr(t["remapX"]), _ptr(t["remapY"]), _ptr(t["remapFast"]),
+                                   _ptr(t["remapIdx"]), _ptr(t["remapCoef"]))
+        t.update(w_in=self.w_in, h_in=self.h_in, w_out=self.w_out, h_out=self.h_out)
+        return t
+
+    def run(self, img, fast=False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        out = np.zeros(self.w_out * self.h_out * ch, np.uint8)
+        ok = self.lib.ref_undist_run(self.h, _ptr(img), ch, 1 if fast else 0, _ptr(out))
+        assert ok
+        return out.reshape((self.h_out, self.w_out) if ch == 1 else (self.h_out, self.w_out, ch))
+
+    def close(self):
+        if self.h:
+            self.lib.ref_undist_free(self.h)
+            self.h = None
