@@ -61,9 +61,9 @@ $(LIBDIR)/libgslam_featuredetector.so: gslam_amd/plugin/featuredetector_plugin.c
 $(LIBDIR)/libgslam_vocabulary.so: gslam_amd/plugin/vocabulary_plugin.cpp include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
 	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
 
-build/plugin_host: gslam_amd/plugin/plugin_host.cpp gslam_amd/plugin/FeatureDetector.h
+build/plugin_host: gslam_amd/plugin/plugin_host.cpp gslam_amd/plugin/FeatureDetector.h gslam_amd/plugin/UndistorterHIP.h $(LIBDIR)/libgslam_hip.so
 	@mkdir -p build
-	g++ $(PLUGFLAGS) -o $@ $< -lpthread -ldl
+	g++ $(PLUGFLAGS) -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN/../gslam_amd/lib' -lpthread -ldl
 
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/liboracle.so oracle/_ref

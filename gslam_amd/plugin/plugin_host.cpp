@@ -8,6 +8,7 @@
 //   plugin_host pnp  <plugin_dir> <pnp.bin> <out.bin>
 //   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
 //   plugin_host bow  <plugin_dir> <vocab.gbow> <desc.raw> <n> <levelsup> <out.bin>
+//   plugin_host undist <plugin_dir> <channels> <image.raw>     (fixed OpenCV-model camera 320x240 -> pinhole)
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
 
@@ -20,6 +21,7 @@
 #include <GSLAM/core/Vocabulary.h>
 
 #include "FeatureDetector.h"
+#include "UndistorterHIP.h"
 
 using namespace GSLAM;
 
@@ -185,11 +187,50 @@ static int run_bow(const std::string& dir, const char* gbow, const char* descf, 
   return same ? 0 : 3;
 }
 
+// UndistorterHIP against GSLAM::Undistorter in the same process, on the pixels the reference defines.
+static int run_undist(int ch, const char* imgf) {
+  std::vector<double> pin = {320, 240, 260, 262, 161.5, 118.2, -0.31, 0.11, 0.001, -0.0007, -0.02};
+  std::vector<double> pout = {320, 240, 200, 200, 160, 120};
+  Camera cin(pin), cout_(pout);
+  UndistorterHIP gpu(cin, cout_);
+  std::streambuf* old = std::cout.rdbuf(nullptr);
+  Undistorter cpu(cin, cout_);
+  std::cout.rdbuf(old);
+  if (!gpu.valid() || !cpu.valid()) { std::cerr << "undistorter invalid\n"; return 2; }
+  std::vector<uchar> img((size_t)320 * 240 * ch);
+  std::ifstream f(imgf, std::ios::binary);
+  f.read((char*)img.data(), img.size());
+  GImage in(240, 320, ch == 1 ? GImageType<uchar, 1>::Type : GImageType<uchar, 3>::Type, img.data(), false);
+  UndistorterImpl tab(cin, cout_);  // tables, to know which pixels the reference defines
+  long bad = 0, checked = 0;
+  for (int fast = 0; fast < 2; ++fast) {
+    GImage a, b;
+    const bool oka = fast ? gpu.undistortFast(in, a) : gpu.undistort(in, a);
+    const bool okb = fast ? cpu.undistortFast(in, b) : cpu.undistort(in, b);
+    if (!oka || !okb) return 3;
+    const size_t n_in = (size_t)320 * 240;
+    for (int i = 0; i < 320 * 240; ++i) {
+      bool defined;
+      if (fast) defined = ch == 1 ? tab.remapFast[i] > 0 : tab.remapFast[i] >= 0;
+      else {
+        defined = ch == 1 ? true : tab.remapX[i] > 0;
+        for (int t = 0; t < 4; ++t) defined = defined && (size_t)tab.remapIdx[4 * i + t] < n_in;
+      }
+      if (!defined) continue;
+      ++checked;
+      for (int j = 0; j < ch; ++j) bad += a.data[(size_t)i * ch + j] != b.data[(size_t)i * ch + j];
+    }
+  }
+  std::cout << "undistort gpu==reference mismatches=" << bad << " checked=" << checked << std::endl;
+  return bad == 0 && checked > 100000 ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
   if (mode == "ba" && argc >= 5) return run_ba(dir, argv[3], argv[4]);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "undist" && argc >= 5) return run_undist(atoi(argv[3]), argv[4]);
   if (mode == "bow" && argc >= 8) return run_bow(dir, argv[3], argv[4], atoi(argv[5]), atoi(argv[6]), argv[7]);
   if (mode == "orb" && argc >= 9)
     return run_orb(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));

@@ -129,3 +129,16 @@ def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle):
     assert same == 1 and nwords == ncpu == len(e[3])
     rec = np.frombuffer(raw, np.dtype([("id", "<u8"), ("v", "<f4")]), nwords, 16)
     assert np.array_equal(rec["id"], e[3]) and rec["v"].tobytes() == e[4].tobytes()
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_undistorter_hip_equals_reference_class(tmp_path, channels):
+    """UndistorterHIP (gslam_amd/plugin/UndistorterHIP.h) vs GSLAM::Undistorter in the same GSLAM host process."""
+    _need_host()
+    rng = np.random.default_rng(channels)
+    img = rng.integers(0, 256, (240, 320, channels), dtype=np.uint8)
+    f = tmp_path / "img.raw"
+    img.tofile(f)
+    r = _run(["undist", LIBDIR, channels, f])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches=0" in r.stdout
