@@ -565,18 +565,41 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
   }
 }
 
+// Device buffers of one solve, bump-allocated from the context's grow-only arena (ctx->ba_arena); anything that does
+// not fit falls back to its own hipMalloc and is freed when the solve ends.
 struct DevBuf {
   gh_ctx* ctx;
   std::vector<void*> ptrs;
+  size_t used = 0;
   explicit DevBuf(gh_ctx* c) : ctx(c) {}
   ~DevBuf() {
     hipStreamSynchronize(ctx->stream);
     for (void* p : ptrs) hipFree(p);
   }
+  gh_status reserve(size_t bytes) {
+    if (bytes <= ctx->ba_arena_bytes) return GH_OK;
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ba_arena) GH_HIP(ctx, hipFree(ctx->ba_arena));
+    ctx->ba_arena = nullptr;
+    ctx->ba_arena_bytes = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    if (hipMalloc(&ctx->ba_arena, want) != hipSuccess) {
+      ctx->ba_arena = nullptr;
+      return GH_OK;  // every buffer will take the individual fallback path
+    }
+    ctx->ba_arena_bytes = want;
+    return GH_OK;
+  }
   template <typename T>
   gh_status alloc(T** out, size_t count) {
+    const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
+    if (ctx->ba_arena && used + bytes <= ctx->ba_arena_bytes) {
+      *out = (T*)((char*)ctx->ba_arena + used);
+      used += bytes;
+      return GH_OK;
+    }
     void* p = nullptr;
-    gh_status s = gh_dev_alloc(ctx, (count ? count : 1) * sizeof(T), &p);
+    gh_status s = gh_dev_alloc(ctx, bytes, &p);
     if (s == GH_OK) {
       ptrs.push_back(p);
       *out = (T*)p;
@@ -646,43 +669,53 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant)
   std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
   if (opt.deterministic && no > 0) {
-    std::vector<std::pair<int32_t, int32_t>> tmp;  // (cj, local sequence) for one row camera
-    std::vector<int32_t> ta, tb;
+    // counting sort per row camera: pairs grouped by column camera cj (ascending), generation order kept inside a group
+    std::vector<int32_t> cnt((size_t)nc, 0), off((size_t)nc, 0), touched;
     for (int ci = 0; ci < nc; ++ci) {
-      tmp.clear();
-      ta.clear();
-      tb.clear();
+      touched.clear();
+      for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
+        const int p = pr->obs_point[clist[q]];
+        for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
+          const int cj = pr->obs_cam[plist[q2]];
+          if (cj > ci) continue;
+          if (cnt[cj]++ == 0) touched.push_back(cj);
+        }
+      }
+      std::sort(touched.begin(), touched.end());
+      size_t run = pair_a.size();
+      for (int cj : touched) {
+        bstart.push_back((int32_t)run);
+        bci.push_back(ci);
+        bcj.push_back(cj);
+        off[cj] = (int32_t)run;
+        run += (size_t)cnt[cj];
+      }
+      pair_a.resize(run);
+      pair_b.resize(run);
       for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
         const int k = clist[q], p = pr->obs_point[k];
         for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
           const int k2 = plist[q2], cj = pr->obs_cam[k2];
           if (cj > ci) continue;
-          tmp.emplace_back(cj, (int32_t)ta.size());
-          ta.push_back(k);
-          tb.push_back(k2);
+          const int32_t pos = off[cj]++;
+          pair_a[pos] = k;
+          pair_b[pos] = k2;
         }
       }
-      std::stable_sort(tmp.begin(), tmp.end(),
-                       [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
-                         return x.first < y.first;
-                       });
-      int last = -1;
-      for (const auto& t : tmp) {
-        if (t.first != last) {
-          bstart.push_back((int32_t)pair_a.size());
-          bci.push_back(ci);
-          bcj.push_back(t.first);
-          last = t.first;
-        }
-        pair_a.push_back(ta[t.second]);
-        pair_b.push_back(tb[t.second]);
-      }
+      for (int cj : touched) cnt[cj] = 0;
     }
     bstart.push_back((int32_t)pair_a.size());
   }
   const int nblocks = (int)bci.size();
 
   DevBuf db(ctx);
+  {
+    const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
+    const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
+                             NP * 3 * 2 + N * (N + 1) + (NO / 256 + 2) * 2 + 8) +
+                        4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256;
+    GH_TRY(db.reserve(need));
+  }
   double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
   int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
   uint8_t* d_pfree = nullptr;

@@ -29,6 +29,9 @@ struct gh_ctx {
   // scratch owned by the context (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // grow-only arena reused by successive gh_ba_solve calls (local BA runs every keyframe: no malloc/free per call)
+  void* ba_arena = nullptr;
+  size_t ba_arena_bytes = 0;
   std::mutex mu;
   int cu_count = 0;
 };

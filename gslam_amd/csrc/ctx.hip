@@ -45,6 +45,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   }
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->ba_arena) hipFree(ctx->ba_arena);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
