@@ -142,6 +142,54 @@ __global__ __launch_bounds__(64) void bf_match_pairs_kernel(const uint32_t* __re
   bf_wave(desc + (size_t)fq * cap * 8, nq, desc + (size_t)ft * cap * 8, nt, cap, idx1 + o, d1 + o, d2 + o);
 }
 
+// Row-band restricted variant (stereo left-right matching, SURVEY.md 8e "C3"): train row j is a candidate of query
+// i only if |y_i - y_j| <= band_i with band_i = size_i * band_per_size (size = 31 * scale^octave, so the band grows
+// with the pyramid level as in ORB-SLAM's stereo matcher).  Same first-minimum / second-minimum rules.
+__global__ __launch_bounds__(64) void bf_match_band_pairs_kernel(const uint32_t* __restrict__ desc,
+                                                                 const gh_keypoint* __restrict__ kps,
+                                                                 const int32_t* __restrict__ counts, int cap,
+                                                                 const int32_t* __restrict__ pair_q,
+                                                                 const int32_t* __restrict__ pair_t,
+                                                                 float band_per_size, int32_t* __restrict__ idx1,
+                                                                 uint16_t* __restrict__ d1, uint16_t* __restrict__ d2) {
+  const int p = blockIdx.y;
+  const int fq = pair_q[p], ft = pair_t[p];
+  int nq = counts[fq], nt = counts[ft];
+  nq = nq < cap ? nq : cap;
+  nt = nt < cap ? nt : cap;
+  const int qi = blockIdx.x * 64 + threadIdx.x;
+  if (qi >= cap) return;
+  const size_t o = (size_t)p * cap + qi;
+  if (qi >= nq) {
+    idx1[o] = -1;
+    d1[o] = 65535;
+    d2[o] = 65535;
+    return;
+  }
+  const uint32_t* qw = desc + ((size_t)fq * cap + qi) * 8;
+  QueryRegs q;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q.w[k] = qw[k];
+  const gh_keypoint kq = kps[(size_t)fq * cap + qi];
+  const float yq = kq.y, band = __fmul_rn(kq.size, band_per_size);
+  uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+  const uint32_t* tw = desc + (size_t)ft * cap * 8;
+  const gh_keypoint* tk = kps + (size_t)ft * cap;
+  for (int j = 0; j < nt; ++j) {
+    uint32_t t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = tw[(size_t)j * 8 + k];
+    const float dy = fabsf(__fsub_rn(yq, tk[j].y));
+    uint32_t key = make_key(dist256(q, t), (uint32_t)j);
+    key = dy <= band ? key : 0xFFFFFFFFu;
+    second = umed3(key, best, second);
+    best = min(best, key);
+  }
+  idx1[o] = best == 0xFFFFFFFFu ? -1 : (int32_t)(best & 0xFFFFu);
+  d1[o] = (uint16_t)(best >> 16);
+  d2[o] = (uint16_t)(second >> 16);
+}
+
 __global__ void match_mask_kernel(const int32_t* __restrict__ idx1, const uint16_t* __restrict__ d1,
                                   const uint16_t* __restrict__ d2, int nq, const int32_t* __restrict__ back, int nt,
                                   int max_dist, int ratio_num, int ratio_den, int cross_check,
@@ -235,6 +283,24 @@ extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev,
     size_t o = (size_t)p0 * cap;
     GH_LAUNCH(ctx, "bf_match_pairs", bf_match_pairs_kernel, grid, dim3(64), 0, (const uint32_t*)desc_dev, counts_dev,
               cap, pair_q_dev + p0, pair_t_dev + p0, idx1_dev + o, d1_dev + o, d2_dev + o);
+  }
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bf_match_band_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const gh_keypoint* kps_dev,
+                                                const int32_t* counts_dev, int cap, const int32_t* pair_q_dev,
+                                                const int32_t* pair_t_dev, int npairs, float band_per_size,
+                                                int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_CHECK_ARG(ctx, cap >= 0 && cap <= 65535 && npairs >= 0 && band_per_size >= 0.f);
+  if (npairs == 0 || cap == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, desc_dev && kps_dev && counts_dev && pair_q_dev && pair_t_dev && idx1_dev && d1_dev && d2_dev);
+  for (int p0 = 0; p0 < npairs; p0 += 65535) {
+    const int np = npairs - p0 < 65535 ? npairs - p0 : 65535;
+    const size_t o = (size_t)p0 * cap;
+    GH_LAUNCH(ctx, "bf_match_band", bf_match_band_pairs_kernel, dim3(gh_div_up(cap, 64), np), dim3(64), 0,
+              (const uint32_t*)desc_dev, kps_dev, counts_dev, cap, pair_q_dev + p0, pair_t_dev + p0, band_per_size,
+              idx1_dev + o, d1_dev + o, d2_dev + o);
   }
   return GH_OK;
 }

@@ -46,6 +46,17 @@ class BFMatcher:
                                                      P, _p(idx1), _p(d1), _p(d2)))
         return idx1, d1, d2
 
+    def match_band_pairs(self, desc, kps, counts, pair_q, pair_t, band_per_size):
+        """Stereo variant: kps is the F x cap x 7 float32 view of the KeyPoint records parallel to desc."""
+        P, cap = pair_q.shape[0], desc.shape[1]
+        idx1 = torch.empty((P, cap), dtype=torch.int32, device=desc.device)
+        d1 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
+        d2 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
+        self.ctx.check(hip.lib.gh_bf_match_band_pairs_dev(self.ctx.h, _p(desc), _p(kps), _p(counts), cap, _p(pair_q),
+                                                          _p(pair_t), P, C.c_float(band_per_size), _p(idx1), _p(d1),
+                                                          _p(d2)))
+        return idx1, d1, d2
+
     def mask(self, idx1, d1, d2, back_idx1=None, nt=0, max_dist=50, ratio_num=0, ratio_den=1, cross_check=False):
         nq = idx1.shape[0]
         keep = torch.empty(nq, dtype=torch.uint8, device=idx1.device)

@@ -118,6 +118,14 @@ typedef struct gh_keypoint {
   int32_t class_id; /* -1 */
 } gh_keypoint;
 
+/* Row-band restricted variant for stereo left-right matching (BASELINE configs[2]): train row j is a
+ * candidate of query i only if |kps[i].y - kps[j].y| <= kps[i].size * band_per_size (single fp32 multiply).
+ * kps_dev: F x cap gh_keypoint records parallel to desc_dev.  Outputs as gh_bf_match_pairs_dev. */
+gh_status gh_bf_match_band_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const gh_keypoint* kps_dev,
+                                     const int32_t* counts_dev, int cap, const int32_t* pair_q_dev,
+                                     const int32_t* pair_t_dev, int npairs, float band_per_size,
+                                     int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
+
 typedef struct gh_orb_params {
   int32_t n_features;   /* K: total keypoint quota per frame (default 1000) */
   int32_t n_levels;     /* pyramid levels, 1..8 (default 8); scale factor fixed at 1.2 */

@@ -74,3 +74,30 @@ void oracle_match_mask(const int32_t* idx1, const uint16_t* d1, const uint16_t* 
     keep[i] = (uint8_t)(ok ? 1 : 0);
   }
 }
+
+/* Row-band restricted matcher (stereo): candidate j of query i iff |yq[i] - yt[j]| <= sizeq[i] * band_per_size
+ * (fp32, one multiply), otherwise as oracle_bf_match.  No reference counterpart: the band rule restates ORB-SLAM's
+ * stereo matcher (rows within +-2*scale) as SURVEY.md 8e prescribes ("same kernel + y-band mask"). */
+void oracle_bf_match_band(const uint8_t* q, const float* yq, const float* sizeq, int nq, const uint8_t* t,
+                          const float* yt, int nt, float band_per_size, int32_t* idx1, uint16_t* d1, uint16_t* d2) {
+  for (int i = 0; i < nq; ++i) {
+    int best_d = 1 << 30, best_j = -1, second_d = 1 << 30;
+    const float band = sizeq[i] * band_per_size;
+    for (int j = 0; j < nt; ++j) {
+      float dy = yq[i] - yt[j];
+      if (dy < 0) dy = -dy;
+      if (!(dy <= band)) continue;
+      int d = oracle_hamming32(q + (size_t)i * 32, t + (size_t)j * 32);
+      if (d < best_d) {
+        second_d = best_d;
+        best_d = d;
+        best_j = j;
+      } else if (d < second_d) {
+        second_d = d;
+      }
+    }
+    idx1[i] = best_j;
+    d1[i] = best_j >= 0 ? (uint16_t)best_d : 65535;
+    d2[i] = second_d < (1 << 30) ? (uint16_t)second_d : 65535;
+  }
+}

@@ -40,6 +40,18 @@ class Oracle:
             self.lib.oracle_bf_match_omp(_ptr(q), nq, _ptr(t), nt, _ptr(idx1), _ptr(d1), _ptr(d2), int(threads))
         return idx1, d1, d2
 
+    def bf_match_band(self, q, kq, t, kt, band_per_size):
+        """kq / kt: structured KeyPoint arrays parallel to q / t."""
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
+        nq, nt = q.shape[0], t.shape[0]
+        idx1, d1, d2 = np.empty(nq, np.int32), np.empty(nq, np.uint16), np.empty(nq, np.uint16)
+        yq, sq = np.ascontiguousarray(kq["y"]), np.ascontiguousarray(kq["size"])
+        yt = np.ascontiguousarray(kt["y"])
+        self.lib.oracle_bf_match_band(_ptr(q), _ptr(yq), _ptr(sq), nq, _ptr(t), _ptr(yt), nt, C.c_float(band_per_size),
+                                      _ptr(idx1), _ptr(d1), _ptr(d2))
+        return idx1, d1, d2
+
     def match_mask(self, idx1, d1, d2, back, nt, max_dist, ratio_num, ratio_den, cross_check):
         nq = idx1.shape[0]
         keep = np.empty(nq, np.uint8)
