@@ -157,7 +157,7 @@ constexpr int kScoreW = 72;   // row pitch (bytes)
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                         int cell_off, int n_frames, int ablate) {
+                                                         int cell_off, int n_frames) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     constexpr int kRowDw = kTileW / 4, kItemsPerRow = 18;
     const s16x2 T = {(short)min_th, (short)min_th};
     const int sx_lo = max(0, kEdge - (x0 - 1)), sx_hi = min(kScoreH, lv.w - kEdge - (x0 - 1));
-    for (int i0 = 0; i0 < kScoreH * kItemsPerRow && ablate < 2; i0 += 256) {
+    for (int i0 = 0; i0 < kScoreH * kItemsPerRow; i0 += 256) {
       const int item = i0 + tid;
       uint32_t bits = 0;  // bit k: pixel k of the dword is a candidate
       int sy = 0, m = 4;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     }
   }
   __syncthreads();
-  const int nq = ablate >= 1 ? 0 : q_count;
+  const int nq = q_count;
   for (int i = tid; i < nq; i += 256) {
     const int pos = queue[i];
     const int sy = pos / kScoreW, sx = pos - sy * kScoreW - kScoreOff;
@@ -293,10 +293,6 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   const int wv = tid >> 6, lane = tid & 63;
   const int cx = 2 * bx + (wv & 1), cy = 2 * by + (wv >> 1);
   if (cx >= ncx || cy >= ncy) return;  // no block-wide sync below
-  if (ablate >= 3) {
-    if (lane == 0) cell_cnt[(size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx] = 0;
-    return;
-  }
   uint32_t* list = lists[wv];
   // 3x3 strict NMS over the cell.  Stage A scans the cell's score bytes as dwords (8 rows x 8 dwords per
   // trip) and compacts the few non-zero pixels, in raster order, into list2; stage B tests only those
@@ -888,7 +884,6 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     GH_LAUNCH(ctx, "orb_resize", resize_kernel, grid, dim3(256), 0, lv[l - 1], p->pyr + p->lvl_off[l], p->slab,
               p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l]);
   }
-  static const int ablate = getenv("GH_ORB_ABLATE") ? atoi(getenv("GH_ORB_ABLATE")) : 0;  // debug only
   for (int l = 0; l < L; ++l) {
     if (p->ncx[l] == 0 || p->quota[l] <= 0) continue;
     const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
@@ -896,7 +891,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     dim3 grid(8 * gh_div_up(tiles, 8));
     GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
               p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-              batch, ablate);
+              batch);
   }
   {
     SelectArgs a;
