@@ -9,10 +9,15 @@
 //   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
 //   plugin_host bow  <plugin_dir> <vocab.gbow> <desc.raw> <n> <levelsup> <out.bin>
 //   plugin_host undist <plugin_dir> <channels> <image.raw>     (fixed OpenCV-model camera 320x240 -> pinhole)
+//   plugin_host app  <plugin_dir> <w> <h> <n_frames> <frames.raw> <out.bin> <K>   (launcher-style: loads the
+//                    `orbhip` application plugin exactly as GSLAM/gslam/main.cpp:18-45 does and feeds "dataset/frame")
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
 
+#include <chrono>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -225,11 +230,94 @@ static int run_undist(int ch, const char* imgf) {
   return bad == 0 && checked > 100000 ? 0 : 3;
 }
 
+// A minimal frame type that stores what MapFrame::setKeyPoints hands over (the gmap plugin's MapFrame does the same,
+// plugins/gmap/MapFrame.cpp:211-247).  Published as std::shared_ptr<MapFrame> (Messenger payloads are exact-typed).
+class HostFrame : public MapFrame {
+ public:
+  HostFrame(FrameID id, double t, const GImage& img) : MapFrame(id, t), img_(img) {}
+  std::string type() const override { return "HostFrame"; }
+  int cameraNum() const override { return 1; }
+  int imageChannels(int) const override { return IMAGE_GRAY; }
+  GImage getImage(int, int) override { return img_; }
+  int keyPointNum() const override { return (int)kps_.size(); }
+  bool setKeyPoints(const std::vector<KeyPoint>& k, const GImage& d) override {
+    kps_ = k;
+    desc_ = d.clone();
+    return true;
+  }
+  bool getKeyPoints(std::vector<KeyPoint>& k) const override {
+    k = kps_;
+    return true;
+  }
+  GImage getDescriptor(int idx) const override { return idx < 0 ? desc_ : desc_.row(idx); }
+
+ private:
+  GImage img_, desc_;
+  std::vector<KeyPoint> kps_;
+};
+
+static int run_app(const std::string& dir, int w, int h, int n, const char* framesf, const char* out, int K) {
+  svar.GetString("FeatureDetectorPlugin", "") = dir + "/libgslam_featuredetector.so";
+  svar.GetInt("orbhip.nFeatures", 1000) = K;
+  // --- what GSLAM/gslam/main.cpp does for every application name on its command line
+  Svar app = Registry::load(dir + "/libgslam_orbhip.so");
+  if (app.isUndefined()) { std::cerr << "cannot load libgslam_orbhip.so\n"; return 2; }
+  Svar run = app["gslam"]["apps"]["orbhip"];
+  if (!run.isFunction()) { std::cerr << "plugin has no run function\n"; return 2; }
+  Svar fsink = app["gslam"]["setGlobalLogSinks"], fmsg = app["gslam"]["setGlobalMessenger"];
+  if (fsink.isFunction()) fsink(getLogSinksGlobal());
+  if (fmsg.isFunction()) fmsg(messenger);
+  std::thread th([run]() { run(svar); });
+
+  // --- collect what the application publishes
+  std::mutex mu;
+  std::vector<FramePtr> got;
+  std::vector<int> nmatch;
+  Subscriber s1 = messenger.subscribe("orbhip/curframe", 0, [&](FramePtr fr) {
+    std::lock_guard<std::mutex> l(mu);
+    got.push_back(fr);
+  });
+  Subscriber s2 = messenger.subscribe("orbhip/matches", 0, [&](Svar m) {
+    std::lock_guard<std::mutex> l(mu);
+    nmatch.push_back(m["matches"].castAs<int>());
+  });
+  // wait until the application has subscribed, then play the frames like plugins/play does
+  Publisher pub = messenger.advertise<MapFrame>("dataset/frame", 0);
+  for (int i = 0; i < 200 && pub.getNumSubscribers() == 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+  if (pub.getNumSubscribers() == 0) { std::cerr << "orbhip never subscribed\n"; return 3; }
+  std::vector<uchar> raw((size_t)w * h * n);
+  std::ifstream f(framesf, std::ios::binary);
+  f.read((char*)raw.data(), raw.size());
+  for (int i = 0; i < n; ++i) {
+    GImage img(h, w, GImageType<uchar, 1>::Type, raw.data() + (size_t)i * w * h, true);
+    pub.publish(FramePtr(new HostFrame(i + 1, 0.05 * i, img)));
+  }
+  messenger.publish("messenger/stop", true);
+  th.join();
+  std::ofstream o(out, std::ios::binary);
+  int32_t hdr[2] = {(int32_t)got.size(), (int32_t)nmatch.size()};
+  o.write((char*)hdr, sizeof(hdr));
+  for (size_t i = 0; i < got.size(); ++i) {
+    std::vector<KeyPoint> kps = got[i]->getKeyPoints();
+    GImage d = got[i]->getDescriptor(-1);
+    int32_t rec[3] = {(int32_t)got[i]->id(), (int32_t)kps.size(), i < nmatch.size() ? nmatch[i] : -1};
+    o.write((char*)rec, sizeof(rec));
+    if (!kps.empty()) {
+      o.write((char*)kps.data(), kps.size() * sizeof(KeyPoint));
+      o.write((char*)d.data, (size_t)d.rows * 32);
+    }
+  }
+  std::cout << "app frames_out=" << got.size() << " match_msgs=" << nmatch.size() << std::endl;
+  return (int)got.size() == n ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
   if (mode == "ba" && argc >= 5) return run_ba(dir, argv[3], argv[4]);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "app" && argc >= 9)
+    return run_app(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
   if (mode == "undist" && argc >= 5) return run_undist(atoi(argv[3]), argv[4]);
   if (mode == "bow" && argc >= 8) return run_bow(dir, argv[3], argv[4], atoi(argv[5]), atoi(argv[6]), argv[7]);
   if (mode == "orb" && argc >= 9)

@@ -142,3 +142,44 @@ def test_undistorter_hip_equals_reference_class(tmp_path, channels):
     r = _run(["undist", LIBDIR, channels, f])
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches=0" in r.stdout
+
+
+def test_application_plugin_on_the_message_bus(tmp_path, oracle):
+    """BASELINE configs[0] plumbing: the `orbhip` application plugin is loaded the way GSLAM's launcher loads apps
+    (Registry::load -> gslam.apps.orbhip, shared Messenger), receives "dataset/frame", publishes "orbhip/curframe"
+    with keypoints + descriptors deposited through MapFrame::setKeyPoints.  Outputs equal the oracle bit for bit."""
+    _need_host()
+    if not os.path.exists(os.path.join(LIBDIR, "libgslam_orbhip.so")):
+        pytest.skip("libgslam_orbhip.so not built")
+    w, h, n, K = 640, 480, 5, 1000
+    frames = np.stack([oracle.synth_frame(w, h, 0x5EED0000 + i) for i in range(n)])
+    # make consecutive frames overlap so that matching is non-trivial: frame i = crop of a wider panorama
+    pano = np.concatenate([oracle.synth_frame(w, h, 77), oracle.synth_frame(w, h, 78)], axis=1)
+    frames = np.stack([pano[:, 32 * i:32 * i + w] for i in range(n)])
+    fin, out = tmp_path / "frames.raw", tmp_path / "out.bin"
+    frames.tofile(fin)
+    r = _run(["app", LIBDIR, w, h, n, fin, out, K])
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    n_out, n_msgs = struct.unpack("2i", raw[:8])
+    assert n_out == n and n_msgs == n
+    off = 8
+    prev = None
+    for i in range(n):
+        fid, nk, nm = struct.unpack("3i", raw[off:off + 12])
+        off += 12
+        ek, ed = oracle.orb_extract(frames[i], K)
+        assert fid == i + 1 and nk == len(ek)
+        kps = np.frombuffer(raw, oracle_lib.KP_DTYPE, nk, off)
+        off += nk * 28
+        desc = np.frombuffer(raw, np.uint8, nk * 32, off).reshape(nk, 32)
+        off += nk * 32
+        assert kps.tobytes() == ek.tobytes() and np.array_equal(desc, ed)
+        if prev is None:
+            assert nm == 0
+        else:
+            f = oracle.bf_match(ed, prev)
+            b = oracle.bf_match(prev, ed)
+            keep = oracle.match_mask(f[0], f[1], f[2], b[0], len(prev), 100, 0, 1, 1)
+            assert nm == int(keep.sum()) and nm > 100  # 32 px = one cell shift: many exact re-detections
+        prev = ed
