@@ -193,6 +193,20 @@ gh_status gh_undistort_dev(gh_undist_plan* plan, const uint8_t* img_dev, int cha
                            size_t in_frame_stride, uint8_t* out_dev, size_t out_frame_stride, int fast);
 gh_status gh_undistort_host(gh_undist_plan* plan, const uint8_t* img, int channels, uint8_t* out, int fast);
 
+/* ------------------------------------------------------------------ RANSAC estimation - */
+/* Robust model fitting with an inlier mask, behind GSLAM::Estimator::findHomography / findAffine2D / findFundamental /
+ * findAffine3D (GSLAM/core/Estimator.h:100-147; interface only in the reference).  model: 0 homography (src, dst:
+ * n x 2 doubles, model_out 9 row-major, h33 = 1), 1 affine 2D (model_out 6 = 2 x 3), 2 fundamental (dst^T F src = 0,
+ * model_out 9, Sampson error), 3 affine 3D (n x 3 doubles, model_out 12 = 3 x 4).  Deterministic: 2048 hypotheses drawn
+ * from `seed`; winner = most correspondences with squared error <= threshold^2, lowest hypothesis index on ties.
+ * model_out must hold 12 doubles; mask_out (n bytes, may be NULL) gets 1 for inliers; *inliers_out = 0 means no model. */
+#define GH_MODEL_HOMOGRAPHY 0
+#define GH_MODEL_AFFINE2D 1
+#define GH_MODEL_FUNDAMENTAL 2
+#define GH_MODEL_AFFINE3D 3
+gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* src, const double* dst, int n, double threshold,
+                             uint64_t seed, double* model_out, uint8_t* mask_out, int* inliers_out);
+
 /* ------------------------------------------------------------------ bundle adjustment - */
 /* DOF bits follow GSLAM::KeyFrameEstimzationDOF (GSLAM/core/Optimizer.h:70-84). */
 #define GH_KF_X 1

@@ -433,3 +433,21 @@ class RefUndistorter:
         if self.h:
             self.lib.ref_undist_free(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- RANSAC estimator wrappers
+def _ransac_methods(cls):
+    def ransac(self, model, src, dst, threshold, seed=1):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        dst = np.ascontiguousarray(dst, dtype=np.float64)
+        n = src.shape[0]
+        m = np.zeros(12)
+        mask = np.zeros(max(n, 1), np.uint8)
+        cnt = self.lib.oracle_ransac(int(model), _ptr(src), _ptr(dst), n, C.c_double(threshold), C.c_uint64(seed),
+                                     _ptr(m), _ptr(mask))
+        return m, mask[:n].copy(), cnt
+
+    cls.ransac = ransac
+
+
+_ransac_methods(Oracle)
