@@ -30,7 +30,7 @@ endif
 lib: $(LIBDIR)/libgslam_hip.so
 oracle: oracle/liboracle.so
 ref: oracle/_ref/libgslam_ref.so oracle/_ref/libgslam_ref_popcnt.so
-plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so build/plugin_host
+plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so build/plugin_host
 
 build/obj/%.o: gslam_amd/csrc/%.hip gslam_amd/csrc/common.h include/gslam_hip.h $(wildcard include/*.h gslam_amd/csrc/*.h)
 	@mkdir -p build/obj
@@ -59,6 +59,9 @@ $(LIBDIR)/libgslam_featuredetector.so: gslam_amd/plugin/featuredetector_plugin.c
 	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
 
 $(LIBDIR)/libgslam_vocabulary.so: gslam_amd/plugin/vocabulary_plugin.cpp include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
+	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
+
+$(LIBDIR)/libgslam_estimator.so: gslam_amd/plugin/estimator_plugin.cpp include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
 	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
 
 $(LIBDIR)/libgslam_orbhip.so: gslam_amd/plugin/orbhip_app.cpp gslam_amd/plugin/FeatureDetector.h

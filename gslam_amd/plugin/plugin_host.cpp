@@ -9,6 +9,7 @@
 //   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
 //   plugin_host bow  <plugin_dir> <vocab.gbow> <desc.raw> <n> <levelsup> <out.bin>
 //   plugin_host undist <plugin_dir> <channels> <image.raw>     (fixed OpenCV-model camera 320x240 -> pinhole)
+//   plugin_host est  <plugin_dir> <model 0|1|2> <n> <pts.raw (n x 4 doubles: src xy, dst xy)> <thr> <out.bin>
 //   plugin_host app  <plugin_dir> <w> <h> <n_frames> <frames.raw> <out.bin> <K>   (launcher-style: loads the
 //                    `orbhip` application plugin exactly as GSLAM/gslam/main.cpp:18-45 does and feeds "dataset/frame")
 #include <GSLAM/core/GSLAM.h>
@@ -24,6 +25,8 @@
 #include <vector>
 
 #include <GSLAM/core/Vocabulary.h>
+
+#include <GSLAM/core/Estimator.h>
 
 #include "FeatureDetector.h"
 #include "UndistorterHIP.h"
@@ -311,11 +314,52 @@ static int run_app(const std::string& dir, int w, int h, int n, const char* fram
   return (int)got.size() == n ? 0 : 3;
 }
 
+static int run_est(const std::string& dir, int model, int n, const char* ptsf, double thr, const char* out) {
+  svar.GetString("EstimatorPlugin", "") = dir + "/libgslam_estimator.so";
+  EstimatorPtr est = Estimator::create();
+  if (!est) { std::cerr << "Estimator::create() returned null\n"; return 2; }
+  std::vector<double> raw((size_t)n * 4);
+  std::ifstream f(ptsf, std::ios::binary);
+  f.read((char*)raw.data(), raw.size() * 8);
+  std::vector<Point2d> a(n), b(n);
+  for (int i = 0; i < n; ++i) {
+    a[i] = Point2d(raw[4 * i], raw[4 * i + 1]);
+    b[i] = Point2d(raw[4 * i + 2], raw[4 * i + 3]);
+  }
+  std::vector<uchar> mask;
+  double m[9] = {0};
+  bool ok = false;
+  if (model == 0) {
+    Homography2D H;
+    ok = est->findHomography(&H, a, b, H4_Point | RANSAC, thr, 0.99, &mask);
+    for (int i = 0; i < 9; ++i) m[i] = H.data()[i];
+  } else if (model == 1) {
+    Affine2D A;
+    ok = est->findAffine2D(&A, a, b, A3_Point | RANSAC, thr, 0.99, &mask);
+    for (int i = 0; i < 6; ++i) m[i] = A.data()[i];
+  } else {
+    Fundamental F;
+    ok = est->findFundamental(&F, a, b, F8_Point | RANSAC, thr, 0.99, &mask);
+    for (int i = 0; i < 9; ++i) m[i] = F.data()[i];
+  }
+  SE3 pose;
+  std::vector<Point3d> p3;
+  const bool unsupported = est->findPnP(&pose, p3, a) || est->findHomography(nullptr, a, b, H4_Point | NOSAMPLE, thr, 0.99, nullptr);
+  std::ofstream o(out, std::ios::binary);
+  int32_t hdr[2] = {ok ? 1 : 0, (int32_t)mask.size()};
+  o.write((char*)hdr, sizeof(hdr));
+  o.write((char*)m, sizeof(m));
+  if (!mask.empty()) o.write((char*)mask.data(), mask.size());
+  std::cout << "estimator " << est->type() << " ok=" << ok << " unsupported_paths=" << unsupported << std::endl;
+  return ok && !unsupported ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
   if (mode == "ba" && argc >= 5) return run_ba(dir, argv[3], argv[4]);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "est" && argc >= 8) return run_est(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);
   if (mode == "app" && argc >= 9)
     return run_app(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
   if (mode == "undist" && argc >= 5) return run_undist(atoi(argv[3]), argv[4]);

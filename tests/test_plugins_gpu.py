@@ -183,3 +183,27 @@ def test_application_plugin_on_the_message_bus(tmp_path, oracle):
             keep = oracle.match_mask(f[0], f[1], f[2], b[0], len(prev), 100, 0, 1, 1)
             assert nm == int(keep.sum()) and nm > 100  # 32 px = one cell shift: many exact re-detections
         prev = ed
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_estimator_plugin_through_estimator_create(tmp_path, oracle, model):
+    """GSLAM::Estimator::create() loads libgslam_estimator.so (createEstimatorInstance, Estimator.h:42-53,175-191);
+    findHomography / findAffine2D / findFundamental return the oracle's model and inlier mask bit for bit."""
+    _need_host()
+    if not os.path.exists(os.path.join(LIBDIR, "libgslam_estimator.so")):
+        pytest.skip("libgslam_estimator.so not built")
+    from test_ransac_oracle import _corr
+    n, thr = 900, 2.0 if model < 2 else 1.0
+    P, Q, inl, _ = _corr(model, n, 0.3, 40 + model, 0.3)
+    fin, out = tmp_path / "pts.raw", tmp_path / "out.bin"
+    np.ascontiguousarray(np.c_[P, Q], dtype=np.float64).tofile(fin)
+    r = _run(["est", LIBDIR, model, n, fin, thr, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "EstimatorHIP ok=1 unsupported_paths=0" in r.stdout
+    raw = open(out, "rb").read()
+    ok, nm = struct.unpack("2i", raw[:8])
+    m = np.frombuffer(raw, np.float64, 9, 8)
+    mask = np.frombuffer(raw, np.uint8, nm, 8 + 72)
+    em, emask, ecnt = oracle.ransac(model, P, Q, thr, seed=1)
+    ms = 6 if model == 1 else 9
+    assert ok == 1 and nm == n and np.array_equal(mask, emask) and m[:ms].tobytes() == em[:ms].tobytes()
