@@ -191,7 +191,9 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                "note": "HBM is the contractual bound (SURVEY.md 8d); SQ counters show this kernel VALU-issue bound "
+                        "(profiles/README.md), so frac understates how close the kernel is to ITS limit"}
     orb_ms = sum(v["total_ms"] for v in orb_k.values())
     pipeline = {"bound": "hbm", "what": "whole ORB pipeline vs B_orb = 14.40 W H + 1021 K",
                 "achieved": round(orb_bytes_per_frame(W, H, K) * F * a.steps / (orb_ms * 1e-3) / 1e9, 1),
