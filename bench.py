@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bow", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="bounded CPU sample (frames)")
+    ap.add_argument("--cpu-frames", type=int, default=1000, help="bounded CPU sample (frames; 1000 = the whole C2 step, ~10 s on 16 cores)")
     ap.add_argument("--ba-cams", type=int, default=500)
     ap.add_argument("--ba-points", type=int, default=50000)
     ap.add_argument("--ba-iters", type=int, default=12)

@@ -337,8 +337,11 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double* __restrict_
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
   GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
-  for (int c0 = 0; c0 < n; c0 += NBO) {
-    const int pw = n - c0 < NBO ? n - c0 : NBO;  // panel width
+  // outer panel width: 512 for large systems (halves the number of passes over the trailing matrix, whose C-tile
+  // read-modify-write is what keeps the rank-k update below the MFMA rate), 256 for small, latency-bound ones
+  const int nbo = n >= 16384 ? 2 * NBO : NBO;
+  for (int c0 = 0; c0 < n; c0 += nbo) {
+    const int pw = n - c0 < nbo ? n - c0 : nbo;  // panel width
     for (int k = c0; k < c0 + pw; k += NBI) {
       const int kb = c0 + pw - k < NBI ? c0 + pw - k : NBI;
       GH_LAUNCH(ctx, "ba_potf2", potf2_64_kernel, dim3(1), dim3(256), 0, A, lda, k, kb, info_dev);
