@@ -213,123 +213,146 @@ def main():
     info = ctx.device_info()
 
     # ---- BA (C4) on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve
-    if not a.no_ba:
-        from gslam_amd import ba
-        from gslam_amd.ba_synth import make_graph
-        log("BA leg: building graph")
-        g = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
-        log("BA leg: warm-up solve")
-        ba.solve(ctx, g, ba.default_options(max_iterations=2))  # warm-up (allocations, code load)
-        log("BA leg: timed solve")
-        _, _, s, st = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))  # timed without event overhead
-        ctx.prof_enable(True)
-        _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))  # same solve, per-kernel events
-        bprof = ctx.prof_collect()
-        ctx.prof_enable(False)
-        n = 6 * a.ba_cams
-        solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * s.iterations
-        chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ("ba_potf2", "ba_trsm", "ba_syrk_panel",
-                                                                         "ba_syrk_trailing", "ba_trsv_fwd",
-                                                                         "ba_trsv_bwd"))
-        extra["ba"] = {"workload": f"{'C5' if a.ba_cams >= 10000 else 'C4'}: {a.ba_cams} cams, {a.ba_points} pts, {len(g['obs_cam'])} obs, Huber LM",
-                       "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
-                       "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
-                       "dense_solve": {"bound": "mfma", "n": n,
-                                       "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3) if chol_ms else None,
-                                       "peak_TFLOPs": FP64_MFMA_PEAK / 1e12},
-                       "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
-                                   for k, v in bprof.items()}}
+    def _leg_ba():
+        if not a.no_ba:
+            from gslam_amd import ba
+            from gslam_amd.ba_synth import make_graph
+            log("BA leg: building graph")
+            g = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
+            log("BA leg: warm-up solve")
+            ba.solve(ctx, g, ba.default_options(max_iterations=2))  # warm-up (allocations, code load)
+            log("BA leg: timed solve")
+            _, _, s, st = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))  # timed without event overhead
+            ctx.prof_enable(True)
+            _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))  # same solve, per-kernel events
+            bprof = ctx.prof_collect()
+            ctx.prof_enable(False)
+            n = 6 * a.ba_cams
+            solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * s.iterations
+            chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ("ba_potf2", "ba_trsm", "ba_syrk_panel",
+                                                                             "ba_syrk_trailing", "ba_trsv_fwd",
+                                                                             "ba_trsv_bwd"))
+            extra["ba"] = {"workload": f"{'C5' if a.ba_cams >= 10000 else 'C4'}: {a.ba_cams} cams, {a.ba_points} pts, {len(g['obs_cam'])} obs, Huber LM",
+                           "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
+                           "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
+                           "dense_solve": {"bound": "mfma", "n": n,
+                                           "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3) if chol_ms else None,
+                                           "peak_TFLOPs": FP64_MFMA_PEAK / 1e12},
+                           "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
+                                       for k, v in bprof.items()}}
+
+    try:
+        _leg_ba()
+    except Exception as exc:  # an optional leg must never cost the headline line
+        extra.setdefault("errors", {})["ba"] = repr(exc)
+        log("ba leg failed: %r" % (exc,))
 
     # ---- BoW transform: the extracted descriptors of this step through GSLAM::Vocabulary-style
     #      k=10 trees (L=4 / L=6, the two sizes the reference publishes: 615.5 / 723.7 us per image on an i7-6700)
-    if not a.no_bow:
-        from gslam_amd import bow_synth
-        from gslam_amd.bow import Vocabulary
-        extra["bow"] = {}
-        for Lv, pub in ((4, 615.5), (6, 723.7)):
-            log(f"BoW leg: L={Lv}")
-            voc = bow_synth.make_vocabulary(k=10, L=Lv, seed=1)
-            v = Vocabulary(ctx, voc)
-            nimg = min(F, 200)
-            outb = v.alloc(nimg, K, dev)
-            v.transform(desc[:nimg], counts[:nimg], 2, outb)
-            torch.cuda.synchronize()
-            ctx.prof_enable(True)
-            for _ in range(3):
+    def _leg_bow():
+        if not a.no_bow:
+            from gslam_amd import bow_synth
+            from gslam_amd.bow import Vocabulary
+            extra["bow"] = {}
+            for Lv, pub in ((4, 615.5), (6, 723.7)):
+                log(f"BoW leg: L={Lv}")
+                voc = bow_synth.make_vocabulary(k=10, L=Lv, seed=1)
+                v = Vocabulary(ctx, voc)
+                nimg = min(F, 200)
+                outb = v.alloc(nimg, K, dev)
                 v.transform(desc[:nimg], counts[:nimg], 2, outb)
-            bp = ctx.prof_collect()
-            ctx.prof_enable(False)
-            us_img = sum(x["total_ms"] for x in bp.values()) * 1e3 / (3 * nimg)
-            one = desc[0, :int(counts[0])].cpu().numpy()
-            v.transform_host(one, 2)
-            t1 = time.perf_counter()
-            for _ in range(20):
+                torch.cuda.synchronize()
+                ctx.prof_enable(True)
+                for _ in range(3):
+                    v.transform(desc[:nimg], counts[:nimg], 2, outb)
+                bp = ctx.prof_collect()
+                ctx.prof_enable(False)
+                us_img = sum(x["total_ms"] for x in bp.values()) * 1e3 / (3 * nimg)
+                one = desc[0, :int(counts[0])].cpu().numpy()
                 v.transform_host(one, 2)
-            lat_us = (time.perf_counter() - t1) / 20 * 1e6
-            rec = {"us_per_image_batched": round(us_img, 2), "us_per_image_single_host_call": round(lat_us, 1),
-                   "descriptors_per_image": K, "published_us_per_image_i7_6700": pub,
-                   "nodes": len(voc["nodes"]), "words_image0": int(outb[5][0])}
-            if not a.no_cpu_baseline:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import oracle_lib
-                orc = oracle_lib.load()
                 t1 = time.perf_counter()
-                for _ in range(5):
-                    orc.bow_transform(voc, one, 2)
-                rec["cpu_oracle_us_per_image_1core"] = round((time.perf_counter() - t1) / 5 * 1e6, 1)
-                if oracle_lib.have_reference():
-                    rv = oracle_lib.RefVocabulary(oracle_lib.load_reference(), bow_synth.to_gbow_bytes(voc))
+                for _ in range(20):
+                    v.transform_host(one, 2)
+                lat_us = (time.perf_counter() - t1) / 20 * 1e6
+                rec = {"us_per_image_batched": round(us_img, 2), "us_per_image_single_host_call": round(lat_us, 1),
+                       "descriptors_per_image": K, "published_us_per_image_i7_6700": pub,
+                       "nodes": len(voc["nodes"]), "words_image0": int(outb[5][0])}
+                if not a.no_cpu_baseline:
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    import oracle_lib
+                    orc = oracle_lib.load()
                     t1 = time.perf_counter()
                     for _ in range(5):
-                        rv.transform(one, 2)
-                    rec["cpu_reference_us_per_image_1core"] = round((time.perf_counter() - t1) / 5 * 1e6, 1)
-                    rv.close()
-            extra["bow"][f"k10_L{Lv}"] = rec
-            v.close()
+                        orc.bow_transform(voc, one, 2)
+                    rec["cpu_oracle_us_per_image_1core"] = round((time.perf_counter() - t1) / 5 * 1e6, 1)
+                    if oracle_lib.have_reference():
+                        rv = oracle_lib.RefVocabulary(oracle_lib.load_reference(), bow_synth.to_gbow_bytes(voc))
+                        t1 = time.perf_counter()
+                        for _ in range(5):
+                            rv.transform(one, 2)
+                        rec["cpu_reference_us_per_image_1core"] = round((time.perf_counter() - t1) / 5 * 1e6, 1)
+                        rv.close()
+                extra["bow"][f"k10_L{Lv}"] = rec
+                v.close()
+
+    try:
+        _leg_bow()
+    except Exception as exc:  # an optional leg must never cost the headline line
+        extra.setdefault("errors", {})["bow"] = repr(exc)
+        log("bow leg failed: %r" % (exc,))
 
     # ---- CPU baseline on this box's host cores: bounded sample of the same workload (oracle = "port")
     cpu = None
-    if not a.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib  # the checker, used here only as the timed CPU leg
-        oracle = oracle_lib.load()
-        cores = host_cores()
-        log(f"cpu baseline on {cores} cores (cpu_count={os.cpu_count()})")
-        S = max(2, min(a.cpu_frames, F))
-        host_frames = frames[:S, :, :W].contiguous().cpu().numpy()
-        t1 = time.perf_counter()
-        _, cdesc, ccnt = oracle.orb_extract_batch(host_frames, K, threads=cores)
-        t_ext = time.perf_counter() - t1
-        log(f"cpu extract done {t_ext:.2f}s")
-        t1 = time.perf_counter()
-        for f in range(S - 1):
-            oracle.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
-        t_match = time.perf_counter() - t1
-        # the sample has S frames and S-1 pairs; the GPU workload has F frames and F-1 pairs per rank
-        cpu_kpts = int(ccnt.sum())
-        cpu = {"value": round(cpu_kpts / (t_ext + t_match) / 1e6, 4), "unit": "Mkeypoints/s", "cores": cores,
-               "kind": "port",
-               "sample": f"{S} of the same {W}x{H} frames (K={K}) extracted + {S - 1} consecutive pairs matched, "
-                         f"OpenMP over {cores} threads: extract {t_ext:.2f}s, match {t_match:.2f}s",
-               "extract_Mkpts_per_s": round(cpu_kpts / t_ext / 1e6, 4),
-               "match_Gpairs_per_s": round(float((ccnt[:-1].astype(np.int64) * ccnt[1:]).sum()) / t_match / 1e9, 4)}
-        if oracle_lib.have_reference():
-            ref = oracle_lib.load_reference()
+    def _leg_cpu():
+        nonlocal cpu
+        if not a.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib  # the checker, used here only as the timed CPU leg
+            oracle = oracle_lib.load()
+            cores = host_cores()
+            log(f"cpu baseline on {cores} cores (cpu_count={os.cpu_count()})")
+            S = max(2, min(a.cpu_frames, F))
+            host_frames = frames[:S, :, :W].contiguous().cpu().numpy()
             t1 = time.perf_counter()
-            nref = min(S - 1, 8)
-            for f in range(nref):
-                ref.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
-            t_ref = time.perf_counter() - t1
-            cpu["match_reference_kernel_Gpairs_per_s"] = round(
-                float((ccnt[:nref].astype(np.int64) * ccnt[1:nref + 1]).sum()) / t_ref / 1e9, 4)
-        log("cpu match done")
-        if not a.no_ba:
-            gsmall = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
+            _, cdesc, ccnt = oracle.orb_extract_batch(host_frames, K, threads=cores)
+            t_ext = time.perf_counter() - t1
+            log(f"cpu extract done {t_ext:.2f}s")
             t1 = time.perf_counter()
-            _, _, so, _ = oracle.ba_solve(gsmall, oracle_lib.ba_options(max_iterations=2), threads=cores)
-            t_ba = time.perf_counter() - t1
-            cpu["ba_iters_per_s"] = round(so.iterations / t_ba, 4)
-            cpu["ba_sample"] = f"2 LM iterations of the same C4 graph, {cores} threads"
+            for f in range(S - 1):
+                oracle.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
+            t_match = time.perf_counter() - t1
+            # the sample has S frames and S-1 pairs; the GPU workload has F frames and F-1 pairs per rank
+            cpu_kpts = int(ccnt.sum())
+            cpu = {"value": round(cpu_kpts / (t_ext + t_match) / 1e6, 4), "unit": "Mkeypoints/s", "cores": cores,
+                   "kind": "port",
+                   "sample": f"{S} of the same {W}x{H} frames (K={K}) extracted + {S - 1} consecutive pairs matched, "
+                             f"OpenMP over {cores} threads: extract {t_ext:.2f}s, match {t_match:.2f}s",
+                   "extract_Mkpts_per_s": round(cpu_kpts / t_ext / 1e6, 4),
+                   "match_Gpairs_per_s": round(float((ccnt[:-1].astype(np.int64) * ccnt[1:]).sum()) / t_match / 1e9, 4)}
+            if oracle_lib.have_reference():
+                ref = oracle_lib.load_reference()
+                t1 = time.perf_counter()
+                nref = min(S - 1, 8)
+                for f in range(nref):
+                    ref.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
+                t_ref = time.perf_counter() - t1
+                cpu["match_reference_kernel_Gpairs_per_s"] = round(
+                    float((ccnt[:nref].astype(np.int64) * ccnt[1:nref + 1]).sum()) / t_ref / 1e9, 4)
+            log("cpu match done")
+            if not a.no_ba:
+                from gslam_amd.ba_synth import make_graph
+                gsmall = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
+                t1 = time.perf_counter()
+                _, _, so, _ = oracle.ba_solve(gsmall, oracle_lib.ba_options(max_iterations=2), threads=cores)
+                t_ba = time.perf_counter() - t1
+                cpu["ba_iters_per_s"] = round(so.iterations / t_ba, 4)
+                cpu["ba_sample"] = f"2 LM iterations of the same C4 graph, {cores} threads"
+
+    try:
+        _leg_cpu()
+    except Exception as exc:
+        extra.setdefault("errors", {})["cpu_baseline"] = repr(exc)
+        log("cpu baseline leg failed: %r" % (exc,))
 
     line = {
         "metric": "orb_extract_plus_bf_match_Mkeypoints_per_s", "value": round(value, 3), "unit": "Mkeypoints/s",
