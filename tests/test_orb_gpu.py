@@ -84,6 +84,14 @@ def test_extract_parity_1080p(ctx, oracle):
     _check(oracle, frames, got, 2000)
 
 
+def test_extract_parity_4k(ctx, oracle):
+    """Upper end of the north-star range (3840x2160), K = 8000: > 7900 cells on level 0, quota 1737."""
+    frames = oracle.synth_frame(3840, 2160, 0x4B000000)[None]
+    got = _extract_gpu(ctx, frames, 8000)
+    _check(oracle, frames, got, 8000)
+    assert got[2][0] == 8000
+
+
 def test_extract_parity_levels_and_thresholds(ctx, oracle):
     frames = np.stack([oracle.synth_frame(640, 480, 500 + i) for i in range(2)])
     for nl, ini, mn, K in [(1, 20, 7, 800), (4, 30, 10, 1200), (8, 12, 5, 5000), (8, 20, 7, 7)]:
