@@ -209,6 +209,29 @@ def main():
     kernels = {k: {"launches": v["launches"], "avg_ms": round(v["total_ms"] / v["launches"], 4)}
                for k, v in prof.items()}
 
+    # all-pairs stress of the matcher: every frame pair (i < j) among the first 128 frames
+    try:
+        from gslam_amd.sharding import all_pairs_block
+        nf = min(F, 128)
+        ai, aj = all_pairs_block(0, 1, nf, dev)
+        o_idx = torch.empty((ai.shape[0], K), dtype=torch.int32, device=dev)
+        o_d1 = torch.empty((ai.shape[0], K), dtype=torch.int16, device=dev)
+        o_d2 = torch.empty_like(o_d1)
+        matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))
+        torch.cuda.synchronize()
+        ctx.prof_enable(True)
+        matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))
+        ap = ctx.prof_collect()
+        ctx.prof_enable(False)
+        npairs_all = int((counts[ai.long()].to(torch.int64) * counts[aj.long()].to(torch.int64)).sum().item())
+        ms_all = ap["bf_match_pairs"]["total_ms"]
+        bf["all_pairs"] = {"frames": nf, "frame_pairs": int(ai.shape[0]), "pairs": npairs_all,
+                           "Gpairs_per_s": round(npairs_all / (ms_all * 1e-3) / 1e9, 1),
+                           "frac": round(npairs_all / (ms_all * 1e-3) / valu_ceiling, 4)}
+        del o_idx, o_d1, o_d2
+    except Exception as exc:
+        bf["all_pairs"] = {"error": repr(exc)}
+
     extra = {"bf_match": bf, "kernels": kernels, "roofline_pipeline": pipeline}
     info = ctx.device_info()
 
