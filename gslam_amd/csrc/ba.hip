@@ -21,8 +21,9 @@
 
 #include "common.h"
 
-gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows);
-gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work);
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv);
+gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
+                                const double* dinv);
 
 namespace {
 
@@ -712,7 +713,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
-                             NP * 3 * 2 + N * (N + 1) + (NO / 256 + 2) * 2 + 8) +
+                             NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 + (NO / 256 + 2) * 2 + 8) +
                         4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256;
     GH_TRY(db.reserve(need));
   }
@@ -743,7 +744,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_TRY(db.upload(&d_bcj, (const int32_t*)bcj.data(), bcj.size()));
     SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, nblocks};
   }
-  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work;
+  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv;
   unsigned long long* d_gmax;
   int *d_bad, *d_info;
   const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
@@ -756,6 +757,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_dc, (size_t)n));
   GH_TRY(db.alloc(&d_dp, (size_t)np * 3));
   GH_TRY(db.alloc(&d_work, (size_t)n));
+  GH_TRY(db.alloc(&d_dinv, (size_t)gh_div_up(n, 64) * 4096));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
   GH_TRY(db.alloc(&d_out, 4));
   GH_TRY(db.alloc(&d_gmax, 1));
@@ -820,7 +822,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
     const double t_solve0 = now_ms();
     GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
-    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1));
+    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv));
     int flags[2] = {0, 0};
     GH_HIP(ctx, hipMemcpyAsync(&flags[0], d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&flags[1], d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -829,7 +831,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     double new_cost = cost, model = 0, rho = -1;
     if (ok) {
       GH_LAUNCH(ctx, "ba_rhs_row", row_to_vec_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_S, lda, n, d_work);
-      GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work));
+      GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv));
       GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
       sum->solve_ms_total += now_ms() - t_solve0;
       if (np > 0)

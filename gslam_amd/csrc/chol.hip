@@ -5,13 +5,15 @@
 //
 // Two-level right-looking Cholesky of the lower triangle, column-major, in place:
 //   outer panels of 256 columns, inner steps of 64 columns
-//     potf2_64   one workgroup, block in LDS, 16-column register sub-steps
-//     trsm_64    one row per thread against L11 in LDS, 16-column register sub-blocks
+//     potf2_inv  one workgroup, block in LDS, 16-column sub-steps; also emits M = L11^-1 (block-recursive inverse),
+//                reciprocal square roots by v_rsq_f64 + 2 Newton steps instead of sqrt + 64 dependent divisions
+//     trsm_inv   X = P M^T as a GEMM on MFMA (16 rows per wave): no sequential substitution on the critical path
 //     syrk_mfma  C -= P Q^T on v_mfma_f64_16x16x4_f64: 128x128 tile per workgroup (4 waves x 64x64),
 //                operands staged k-major in LDS with a 144-double pitch (conflict-free ds_read_b64),
 //                accumulators hold the TRANSPOSED tile so C is touched in 128-byte runs
 //   the rank-256 trailing update keeps C traffic (the HBM-bound part) at ~1/4 of a rank-64 update.
-// Solve: blocked forward / backward substitution, one launch per 64-block step.
+// Solve: the right-hand side rides through the factorisation as an extra row (forward substitution for free);
+// backward substitution = one launch per 64-block step: x_k = M_kk^T y_k, then a coalesced panel mat-vec.
 #include "common.h"
 
 namespace {
@@ -20,6 +22,19 @@ constexpr int NBI = 64;    // inner block
 constexpr int NBO = 256;   // outer panel
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// tools/chol_probe.hip defines GH_CHOL_PROBE to read cycle stamps out of the single-workgroup kernels
+#ifdef GH_CHOL_PROBE
+__device__ long long g_probe[64];
+#define CHOL_STAMP(i)                                                    \
+  do {                                                                   \
+    if (threadIdx.x == 0) g_probe[(i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define CHOL_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
 
 // ---------------------------------------------------------------- potf2 on a 64x64 diagonal block
 // One workgroup, block in LDS, 16-column sub-steps (diag 16x16 left-looking with the row in
@@ -137,6 +152,267 @@ __global__ __launch_bounds__(256) void trsm_64_kernel(double* __restrict__ A, in
 #pragma unroll
     for (int j = 0; j < NBS; ++j)
       if (sb + j < kb) arow[(size_t)(k0 + sb + j) * lda] = x[j];
+  }
+}
+
+// ---------------------------------------------------------------- potf2 + inverse of a 64x64 diagonal block
+// 1 / sqrt(d) to ~1 ulp: hardware estimate r0, then one fourth-order correction r0 (1 + e/2 + 3e^2/8 + 5e^3/16) with
+// e = 1 - d r0^2 -- a 5-instruction dependent chain (two Newton steps are 8); d > 0 is checked by the caller
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  const double r0 = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-(d * r0), r0, 1.0);
+  const double p = __builtin_fma(__builtin_fma(0.3125, e, 0.375), e, 0.5);
+  return __builtin_fma(r0 * e, p, r0);
+}
+
+// lane N of every 16-lane row, broadcast to the whole row (DPP row_newbcast, gfx90a+)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// value of lane `l` (wave-uniform index) broadcast through SGPRs
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// Right-looking elimination of a 16-column panel held one ROW per lane (lane = row index inside the 64-block,
+// s[c] = column k + c): factors the 16x16 diagonal block and solves the rows below it in the same pass.
+// Column J, once scaled, goes to its final place in LDS; the multiplier of the NEXT pivot column comes through
+// v_readlane (it is on the critical chain), the others are same-address LDS reads (broadcast), which have a
+// whole pivot step of slack -- 2 readlanes + ~8 LDS instructions per column instead of 30 readlanes.
+template <int J, int C>
+__device__ __forceinline__ void panel16_update(double (&s)[NBS], double l, const double* colJ) {
+  if constexpr (C < NBS) {
+    s[C] = __builtin_fma(-l, colJ[C], s[C]);  // A[i][k+C] -= L[i][k+J] L[k+C][k+J]
+    panel16_update<J, C + 1>(s, l, colJ);
+  }
+}
+template <int J>
+__device__ __forceinline__ void panel16_factor(double (&s)[NBS], double (&rinv)[NBS], double* As, int k, int lane,
+                                               bool& bad) {
+  if constexpr (J < NBS) {
+    const double d = readlane_f64(s[J], k + J);
+    if (!(d > 0.0)) bad = true;
+    const double rs = rsqrt_nr(d);
+    rinv[J] = rs;
+    const double l = (lane >= k + J) ? s[J] * rs : 0.0;  // the pivot lane holds d itself: d * rs = sqrt(d)
+    double* col = As + (k + J) * LP;
+    col[lane] = l;
+    if constexpr (J + 1 < NBS) s[J + 1] = __builtin_fma(-l, readlane_f64(l, k + J + 1), s[J + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    panel16_update<J, J + 2>(s, l, col + k);
+    panel16_factor<J + 1>(s, rinv, As, k, lane, bad);
+  }
+}
+
+// M = L^-1 of a 16x16 block, column `i` per lane (all four 16-lane rows redundantly): forward substitution on e_i,
+// right-looking, with the (lane-uniform) entries of L fetched by same-address LDS reads.  Lcol(t) -> &L[0][t].
+template <int T, int R>
+__device__ __forceinline__ void inv16_update(double (&acc)[NBS], double mt, const double* lcol) {
+  if constexpr (R < NBS) {
+    acc[R] = __builtin_fma(lcol[R], mt, acc[R]);  // acc[R] += L[R][T] M[T][i]
+    inv16_update<T, R + 1>(acc, mt, lcol);
+  }
+}
+template <int T>
+__device__ __forceinline__ void inv16(double (&acc)[NBS], double (&mi)[NBS], const double (&rinv)[NBS], const double* L16,
+                                      int i) {
+  if constexpr (T < NBS) {
+    mi[T] = ((T == i) ? 1.0 : -acc[T]) * rinv[T];  // acc[T] is still zero for T < i
+    inv16_update<T, T + 1>(acc, mi[T], L16 + T * LP);
+    inv16<T + 1>(acc, mi, rinv, L16, i);
+  }
+}
+
+// One 16x16 output tile of a small LDS-resident product on v_mfma_f64_16x16x4_f64:
+//   D[i][j] = sum_{t < 4 KS} a(i, t) * b(t, j);  lane supplies a(lane & 15, 4 ks + lane >> 4) and b(4 ks + lane >> 4, lane & 15),
+//   and receives D[(lane >> 4) + 4 r][lane & 15] in acc[r].
+template <int KS, typename FA, typename FB>
+__device__ __forceinline__ double4_t lds_mma(FA a, FB b, int lane) {
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(m, 4 * ks + q), b(4 * ks + q, m), acc, 0, 0, 0);
+  return acc;
+}
+
+struct Potf2Lds {
+  double As[NBI * LP];  // L  (r, c) at c * LP + r  (only the lower triangle is meaningful)
+  double Ms[NBI * LP];  // M = L^-1, same layout
+  double Ts[32 * 33];
+  double rinv[NBI];
+  int bad;
+};
+
+// Factor the 64x64 block held in sh.As (lower, in place) and build M = L^-1 in sh.Ms.  Called by all 256 threads;
+// sh.As must be complete (identity padding for missing rows/cols), sh.bad cleared, and a barrier passed.
+__device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
+  double* As = sh.As;
+  double* Ms = sh.Ms;
+  double* Ts = sh.Ts;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  for (int k = 0; k < NBI; k += NBS) {
+    // (a) 16-column panel: diagonal block + rows below in one right-looking pass, wave 0, lane = row
+    if (wv == 0) {
+      double s[NBS], ri[NBS];
+#pragma unroll
+      for (int c = 0; c < NBS; ++c) s[c] = As[(k + c) * LP + lane];
+      bool bad = false;
+      panel16_factor<0>(s, ri, As, k, lane, bad);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NBS; ++c) sh.rinv[k + c] = ri[c];
+      }
+      if (bad) sh.bad = 1;
+    }
+    __syncthreads();
+    CHOL_STAMP(2 + k / 8);
+    // (b) rank-16 update of the trailing lower triangle on MFMA: tiles (ti >= tj), round-robin over the waves
+    const int nb = (NBI - (k + NBS)) / NBS;
+    for (int t = wv; t < nb * (nb + 1) / 2; t += 4) {
+      const int ti = t < 1 ? 0 : (t < 3 ? 1 : 2), tj = t - ti * (ti + 1) / 2;  // nb <= 3
+      const int rb = k + NBS + 16 * ti, cb = k + NBS + 16 * tj;
+      const double4_t u = lds_mma<4>([&](int i, int tt) { return As[(k + tt) * LP + rb + i]; },
+                                     [&](int tt, int j) { return As[(k + tt) * LP + cb + j]; }, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) As[(cb + m) * LP + rb + q + 4 * r] -= u[r];
+    }
+    __syncthreads();
+    CHOL_STAMP(3 + k / 8);
+  }
+  // inverses of the four 16x16 diagonal blocks, one per wave (column m of M per lane)
+  {
+    const int b0 = 16 * wv;
+    double acc[NBS], ri[NBS], mi[NBS];
+#pragma unroll
+    for (int j = 0; j < NBS; ++j) {
+      acc[j] = 0.0;
+      ri[j] = sh.rinv[b0 + j];
+    }
+    inv16<0>(acc, mi, ri, As + b0 * LP + b0, m);
+    if (lane < NBS) {
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) Ms[(b0 + m) * LP + b0 + j] = mi[j];
+    }
+  }
+  __syncthreads();
+  CHOL_STAMP(10);
+  // block-recursive inverse: inv([A 0; C B]) = [A^-1 0; -B^-1 C A^-1  B^-1]
+  // level 32: two independent pairs of 16x16 blocks (waves 0 and 1)
+  if (wv < 2) {
+    const int b0 = 32 * wv;
+    const double4_t t1 = lds_mma<4>([&](int i, int t) { return As[(b0 + t) * LP + b0 + 16 + i]; },   // C[i][t]
+                                    [&](int t, int j) { return Ms[(b0 + j) * LP + b0 + t]; }, lane);  // A^-1[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(16 * wv + m) * 33 + q + 4 * r] = t1[r];
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const int b0 = 32 * wv;
+    const double4_t x = lds_mma<4>([&](int i, int t) { return Ms[(b0 + 16 + t) * LP + b0 + 16 + i]; },  // B^-1[i][t]
+                                   [&](int t, int j) { return Ts[(16 * wv + j) * 33 + t]; }, lane);      // T[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ms[(b0 + m) * LP + b0 + 16 + q + 4 * r] = -x[r];
+  }
+  __syncthreads();
+  // level 64: one 16x16 tile of the 32x32 products per wave
+  {
+    const int tr = 16 * (wv & 1), tc = 16 * (wv >> 1);
+    const double4_t t1 = lds_mma<8>([&](int i, int t) { return As[t * LP + 32 + tr + i]; },     // C[i][t]
+                                    [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
+    __syncthreads();
+    const double4_t x = lds_mma<8>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + tr + i]; },  // B^-1[i][t]
+                                   [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);      // T[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
+  }
+  __syncthreads();
+}
+
+// write the factor back to A (lower part of the kb x kb block) and M to Minv (column-major, pitch 64, upper part zero)
+__device__ __forceinline__ void potf2_store(const Potf2Lds& sh, double* __restrict__ A, int lda, int k0, int kb,
+                                            int* __restrict__ info, double* __restrict__ Minv) {
+  const int tid = threadIdx.x;
+  if (tid == 0 && sh.bad) atomicMax(info, k0 + 1);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = tid + 256 * e, c = idx / NBI, r = idx - c * NBI;
+    if (r < kb && c < kb && c <= r) A[(size_t)(k0 + c) * lda + k0 + r] = sh.As[c * LP + r];
+    Minv[idx] = (c <= r) ? sh.Ms[c * LP + r] : 0.0;
+  }
+}
+
+// Standalone diagonal-block kernel (first block of the matrix; later blocks are factored inside the syrk launch).
+__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int lda, int k0, int kb,
+                                                       int* __restrict__ info, double* __restrict__ Minv) {
+  __shared__ Potf2Lds sh;
+  const int tid = threadIdx.x;
+  CHOL_STAMP(0);
+  if (tid == 0) sh.bad = 0;
+  {
+    double v[16];  // all 16 loads in flight before the first LDS store (one memory round trip, not 16)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e, c = idx / NBI, r = idx - c * NBI;
+      v[e] = (r == c) ? 1.0 : 0.0;
+      if (r < kb && c < kb && c <= r) v[e] = A[(size_t)(k0 + c) * lda + k0 + r];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e, c = idx / NBI, r = idx - c * NBI;
+      sh.As[c * LP + r] = v[e];
+      sh.Ms[c * LP + r] = 0.0;
+    }
+  }
+  __syncthreads();
+  CHOL_STAMP(1);
+  potf2_inv_lds(sh);
+  CHOL_STAMP(20);
+  potf2_store(sh, A, lda, k0, kb, info, Minv);
+  CHOL_STAMP(21);
+}
+
+// ---------------------------------------------------------------- trsm as a GEMM with the inverted diagonal block
+// X = P M^T for rows [r0, nr), columns [k0, k0 + kb): D[j][i] = sum_k M[j][k] P[i][k] on v_mfma_f64_16x16x4_f64
+// (MFMA rows = j so the result is written in 128-byte runs along i).  One wave = 16 rows, all 64 columns.
+__global__ __launch_bounds__(256) void trsm_inv_kernel(double* __restrict__ A, int lda, int nr, int k0, int kb, int r0,
+                                                      const double* __restrict__ Minv) {
+  __shared__ double Ms[NBI * LP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int idx = tid; idx < NBI * NBI; idx += 256) Ms[(idx >> 6) * LP + (idx & 63)] = Minv[idx];
+  const int rbase = r0 + blockIdx.x * 64 + wv * 16;
+  const int row = rbase + (lane & 15), kq = lane >> 4;
+  const bool rok = row < nr;
+  double b[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int k = 4 * ks + kq;
+    b[ks] = (rok && k < kb) ? A[(size_t)(k0 + k) * lda + row] : 0.0;
+  }
+  __syncthreads();
+  if (rbase >= nr) return;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * (jt + 1); ++ks) {  // M[j][k] = 0 for k > j
+      const double a = Ms[(4 * ks + kq) * LP + 16 * jt + (lane & 15)];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * jt + kq + 4 * r;
+      if (rok && j < kb) A[(size_t)(k0 + j) * lda + row] = acc[r];
+    }
   }
 }
 
@@ -329,12 +605,60 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double* __restrict_
   w[c] = acc;
 }
 
+// backward step k with the inverted diagonal block: x_k = M_kk^T y_k (every workgroup redundantly), then
+// y[c] -= sum_r L[k0 + r][c] x_k[r] for the columns c < k0: one wave per column, lanes along r (512-byte coalesced
+// column segments), wave reduction.
+__global__ __launch_bounds__(256) void bwd_step_inv_kernel(const double* __restrict__ A, int lda, int k0, int kb,
+                                                          double* __restrict__ b, double* __restrict__ w,
+                                                          const double* __restrict__ Minv) {
+  __shared__ double Ms[NBI * LP];
+  __shared__ double part[4][NBI];
+  __shared__ double xs[NBI];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int idx = tid; idx < NBI * NBI; idx += 256) Ms[(idx >> 6) * LP + (idx & 63)] = Minv[idx];
+  __syncthreads();
+  {
+    // x[i] = sum_{j >= i} M[j][i] y[j]; wave wv covers j in [16 wv, 16 wv + 16)
+    double s = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * wv + jj;
+      if (j < kb) s += Ms[lane * LP + j] * w[k0 + j];
+    }
+    part[wv][lane] = s;
+  }
+  __syncthreads();
+  if (tid < 64) xs[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < kb) b[k0 + tid] = xs[tid];
+  const double xr = lane < kb ? xs[lane] : 0.0;
+  const int cbase = blockIdx.x * 64 + wv * 16;
+  double v[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = cbase + cc;
+    v[cc] = (c < k0 && lane < kb) ? A[(size_t)c * lda + k0 + lane] * xr : 0.0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) v[cc] += __shfl_xor(v[cc], off);
+  if (lane < 16) {
+    const int c = cbase + lane;
+    double tot = v[0];
+#pragma unroll
+    for (int cc = 1; cc < 16; ++cc) tot = (lane == cc) ? v[cc] : tot;
+    if (c < k0) w[c] -= tot;
+  }
+}
+
 }  // namespace
 
 // Factor (lower, in place) and optionally solve.  info_dev: device int (0 = ok, else first bad block column + 1).
 // `extra_rows` rows below the n x n matrix (lda >= n + extra_rows) ride along through trsm / syrk: with the
 // right-hand side stored as row n, the factorisation leaves y = L^-1 b there (forward substitution for free).
-gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows) {
+// `dinv`: ceil(n / 64) * 4096 doubles of device workspace that receives the inverted diagonal blocks.
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
   GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   // outer panel width: 512 for large systems (halves the number of passes over the trailing matrix, whose C-tile
@@ -344,10 +668,12 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
     const int pw = n - c0 < nbo ? n - c0 : nbo;  // panel width
     for (int k = c0; k < c0 + pw; k += NBI) {
       const int kb = c0 + pw - k < NBI ? c0 + pw - k : NBI;
-      GH_LAUNCH(ctx, "ba_potf2", potf2_64_kernel, dim3(1), dim3(256), 0, A, lda, k, kb, info_dev);
+      double* minv = dinv + (size_t)(k / NBI) * (NBI * NBI);
+      GH_LAUNCH(ctx, "ba_potf2", potf2_inv_kernel, dim3(1), dim3(256), 0, A, lda, k, kb, info_dev, minv);
       const int r0 = k + kb;
       if (r0 < nr) {
-        GH_LAUNCH(ctx, "ba_trsm", trsm_64_kernel, dim3(gh_div_up(nr - r0, 256)), dim3(256), 0, A, lda, nr, k, kb, r0);
+        GH_LAUNCH(ctx, "ba_trsm", trsm_inv_kernel, dim3(gh_div_up(nr - r0, 64)), dim3(256), 0, A, lda, nr, k, kb, r0,
+                  (const double*)minv);
         // update the rest of this panel with the fresh 64 columns
         const int cb = r0, ce = c0 + pw;
         if (cb < ce) {
@@ -368,43 +694,40 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
 }
 
 // backward substitution only: work (n doubles) holds y on entry, x is written to b
-gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work) {
+gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
+                                const double* dinv) {
   const int last = ((n - 1) / NBI) * NBI;
   for (int k = last; k >= 0; k -= NBI) {
     const int kb = n - k < NBI ? n - k : NBI;
-    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step_kernel, dim3(k > 0 ? gh_div_up(k, 256) : 1), dim3(256), 0, L, lda, n, k, kb,
-              b, work);
+    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step_inv_kernel, dim3(k > 0 ? gh_div_up(k, 64) : 1), dim3(256), 0, L, lda, k, kb,
+              b, work, dinv + (size_t)(k / NBI) * (NBI * NBI));
   }
   return GH_OK;
 }
 
 // work: n doubles of device scratch
-gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work) {
+gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work, const double* dinv) {
   for (int k = 0; k < n; k += NBI) {
     const int kb = n - k < NBI ? n - k : NBI;
     const int rows = n - (k + kb);
     GH_LAUNCH(ctx, "ba_trsv_fwd", fwd_step_kernel, dim3(rows > 0 ? gh_div_up(rows, 256) : 1), dim3(256), 0, L, lda, n,
               k, kb, b, work);
   }
-  const int last = ((n - 1) / NBI) * NBI;
-  for (int k = last; k >= 0; k -= NBI) {
-    const int kb = n - k < NBI ? n - k : NBI;
-    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step_kernel, dim3(k > 0 ? gh_div_up(k, 256) : 1), dim3(256), 0, L, lda, n, k, kb,
-              b, work);
-  }
-  return GH_OK;
+  return gh_potrs_bwd_dev_impl(ctx, L, n, lda, b, work, dinv);
 }
 
 extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info) {
   if (!ctx) return GH_ERR_ARG;
   GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
   void* scratch = nullptr;
-  GH_TRY(gh_scratch(ctx, 256 + (size_t)n * sizeof(double), &scratch));
+  const size_t nblk = (size_t)gh_div_up(n, NBI);
+  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI) * sizeof(double), &scratch));
   int* info_dev = (int*)scratch;
-  double* work = (double*)((char*)scratch + 256);
-  GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0));
+  double* dinv = (double*)((char*)scratch + 256);
+  double* work = dinv + nblk * NBI * NBI;
+  GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (*info == 0 && b_dev) GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work));
+  if (*info == 0 && b_dev) GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv));
   return GH_OK;
 }
