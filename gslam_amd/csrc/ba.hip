@@ -18,6 +18,7 @@
 // Jacobians are recomputed where needed instead of being stored (80 B gathered beats 144 B of W traffic).
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 #include "common.h"
 
@@ -624,6 +625,103 @@ void build_csr(const int32_t* key, int n_items, int n_keys, std::vector<int32_t>
   for (int k = 0; k < n_items; ++k) list[fill[key[k]]++] = k;
 }
 
+// Pair list of the deterministic Schur product: for every camera pair (ci >= cj) that shares a point, the list of
+// observation pairs (k of ci, k2 of cj) on a common point, grouped by destination block in (ci, cj) order with the
+// generation order kept inside a group.  Cameras are independent, so ranges of cameras (balanced by observation
+// count) are built by a few host threads and concatenated -- the result does not depend on the thread count.
+struct PairChunk {
+  std::vector<int32_t> pa, pb, bs, ci, cj;  // bs relative to the chunk
+};
+
+void build_pair_chunk(const gh_ba_problem* pr, int nc, int c_lo, int c_hi, const std::vector<int32_t>& pstart,
+                      const std::vector<int32_t>& plist, const std::vector<int32_t>& cstart,
+                      const std::vector<int32_t>& clist, PairChunk& out) {
+  std::vector<int32_t> cnt((size_t)nc, 0), off((size_t)nc, 0), touched;
+  for (int ci = c_lo; ci < c_hi; ++ci) {
+    touched.clear();
+    for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
+      const int p = pr->obs_point[clist[q]];
+      for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
+        const int cj = pr->obs_cam[plist[q2]];
+        if (cj > ci) continue;
+        if (cnt[cj]++ == 0) touched.push_back(cj);
+      }
+    }
+    std::sort(touched.begin(), touched.end());
+    size_t run = out.pa.size();
+    for (int cj : touched) {
+      out.bs.push_back((int32_t)run);
+      out.ci.push_back(ci);
+      out.cj.push_back(cj);
+      off[cj] = (int32_t)run;
+      run += (size_t)cnt[cj];
+    }
+    out.pa.resize(run);
+    out.pb.resize(run);
+    for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
+      const int k = clist[q], p = pr->obs_point[k];
+      for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
+        const int k2 = plist[q2], cj = pr->obs_cam[k2];
+        if (cj > ci) continue;
+        const int32_t pos = off[cj]++;
+        out.pa[pos] = k;
+        out.pb[pos] = k2;
+      }
+    }
+    for (int cj : touched) cnt[cj] = 0;
+  }
+}
+
+void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_t>& pstart,
+                       const std::vector<int32_t>& plist, const std::vector<int32_t>& cstart,
+                       const std::vector<int32_t>& clist, std::vector<int32_t>& pair_a, std::vector<int32_t>& pair_b,
+                       std::vector<int32_t>& bstart, std::vector<int32_t>& bci, std::vector<int32_t>& bcj) {
+  const int no = pr->n_obs;
+  int nthreads = no >= 20000 ? 8 : 1;
+  if (nthreads > nc) nthreads = nc;
+  std::vector<PairChunk> chunks((size_t)nthreads);
+  std::vector<int> bound((size_t)nthreads + 1, nc);
+  bound[0] = 0;
+  for (int t = 1, c = 0; t < nthreads; ++t) {  // camera ranges with ~equal observation counts
+    const long long target = (long long)no * t / nthreads;
+    while (c < nc && cstart[c] < target) ++c;
+    bound[t] = c;
+  }
+  if (nthreads == 1) {
+    build_pair_chunk(pr, nc, 0, nc, pstart, plist, cstart, clist, chunks[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t] { build_pair_chunk(pr, nc, bound[t], bound[t + 1], pstart, plist, cstart, clist, chunks[t]); });
+    for (auto& x : th) x.join();
+  }
+  size_t np_total = 0, nb_total = 0;
+  for (auto& c : chunks) {
+    np_total += c.pa.size();
+    nb_total += c.bs.size();
+  }
+  pair_a.resize(np_total);
+  pair_b.resize(np_total);
+  bstart.resize(nb_total + 1);
+  bci.resize(nb_total);
+  bcj.resize(nb_total);
+  size_t po = 0, bo = 0;
+  for (auto& c : chunks) {
+    if (!c.pa.empty()) {
+      memcpy(pair_a.data() + po, c.pa.data(), c.pa.size() * sizeof(int32_t));
+      memcpy(pair_b.data() + po, c.pb.data(), c.pb.size() * sizeof(int32_t));
+    }
+    for (size_t i = 0; i < c.bs.size(); ++i) {
+      bstart[bo + i] = (int32_t)(po + (size_t)c.bs[i]);
+      bci[bo + i] = c.ci[i];
+      bcj[bo + i] = c.cj[i];
+    }
+    po += c.pa.size();
+    bo += c.bs.size();
+  }
+  bstart[nb_total] = (int32_t)np_total;
+}
+
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -669,45 +767,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
 
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant)
   std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
-  if (opt.deterministic && no > 0) {
-    // counting sort per row camera: pairs grouped by column camera cj (ascending), generation order kept inside a group
-    std::vector<int32_t> cnt((size_t)nc, 0), off((size_t)nc, 0), touched;
-    for (int ci = 0; ci < nc; ++ci) {
-      touched.clear();
-      for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
-        const int p = pr->obs_point[clist[q]];
-        for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
-          const int cj = pr->obs_cam[plist[q2]];
-          if (cj > ci) continue;
-          if (cnt[cj]++ == 0) touched.push_back(cj);
-        }
-      }
-      std::sort(touched.begin(), touched.end());
-      size_t run = pair_a.size();
-      for (int cj : touched) {
-        bstart.push_back((int32_t)run);
-        bci.push_back(ci);
-        bcj.push_back(cj);
-        off[cj] = (int32_t)run;
-        run += (size_t)cnt[cj];
-      }
-      pair_a.resize(run);
-      pair_b.resize(run);
-      for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
-        const int k = clist[q], p = pr->obs_point[k];
-        for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
-          const int k2 = plist[q2], cj = pr->obs_cam[k2];
-          if (cj > ci) continue;
-          const int32_t pos = off[cj]++;
-          pair_a[pos] = k;
-          pair_b[pos] = k2;
-        }
-      }
-      for (int cj : touched) cnt[cj] = 0;
-    }
-    bstart.push_back((int32_t)pair_a.size());
-  }
+  if (opt.deterministic && no > 0) build_schur_pairs(pr, nc, pstart, plist, cstart, clist, pair_a, pair_b, bstart, bci, bcj);
   const int nblocks = (int)bci.size();
+  const double t_lists = now_ms();
 
   DevBuf db(ctx);
   {
@@ -778,6 +840,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
 
   double h2[2];
   GH_TRY(eval_cost(d_poses, d_pts, 0, h2));
+  if (opt.verbose)
+    fprintf(stderr, "[gh_ba] setup: index lists %.2f ms (%zu Schur pairs, %d blocks), upload + first cost %.2f ms\n",
+            t_lists - t_begin, pair_a.size(), nblocks, now_ms() - t_lists);
   double cost = h2[0];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;

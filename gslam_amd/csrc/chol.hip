@@ -36,124 +36,9 @@ __device__ long long g_probe[64];
   } while (0)
 #endif
 
-// ---------------------------------------------------------------- potf2 on a 64x64 diagonal block
-// One workgroup, block in LDS, 16-column sub-steps (diag 16x16 left-looking with the row in
-// registers -> trsm of the rows below -> rank-16 update of the rest).  Missing rows/cols (kb < 64)
-// behave as identity.
-constexpr int NBS = 16;
+// ---------------------------------------------------------------- constants of the 64x64 diagonal-block code
+constexpr int NBS = 16;      // sub-step width inside a 64-block
 constexpr int LP = NBI + 1;  // LDS pitch (column-major: element (r, c) at c * LP + r)
-
-__global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int lda, int k0, int kb,
-                                                      int* __restrict__ info) {
-  __shared__ double As[NBI * LP];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_bad = 0;
-  for (int idx = tid; idx < NBI * NBI; idx += 256) {
-    const int c = idx / NBI, r = idx - c * NBI;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < kb && c < kb && c <= r) v = A[(size_t)(k0 + c) * lda + k0 + r];
-    As[c * LP + r] = v;
-  }
-  __syncthreads();
-  for (int k = 0; k < NBI; k += NBS) {
-    // (a) 16x16 diagonal block: lanes 0..15 of wave 0, lane = row
-    if (tid < 64) {
-      const int i = tid & 15;
-      double li[NBS];
-      bool bad = false;
-#pragma unroll
-      for (int j = 0; j < NBS; ++j) {
-        double s = As[(k + j) * LP + k + i];
-#pragma unroll
-        for (int t = 0; t < j; ++t) s -= li[t] * __shfl(li[t], j, 16);  // L[i][t] * L[j][t]
-        const double d = __shfl(s, j, 16);
-        if (!(d > 0.0)) bad = true;
-        const double r = sqrt(d);
-        li[j] = (i == j) ? r : (i > j ? s / r : 0.0);
-      }
-      if (tid < NBS) {
-#pragma unroll
-        for (int j = 0; j < NBS; ++j) As[(k + j) * LP + k + i] = li[j];
-        if (bad) s_bad = 1;
-      }
-    }
-    __syncthreads();
-    // (b) rows below: x <- x * L11^-T, one row per thread
-    const int below = NBI - (k + NBS);
-    if (tid < below) {
-      const int r = k + NBS + tid;
-      double x[NBS];
-#pragma unroll
-      for (int j = 0; j < NBS; ++j) {
-        double s = As[(k + j) * LP + r];
-#pragma unroll
-        for (int t = 0; t < j; ++t) s -= x[t] * As[(k + t) * LP + k + j];
-        x[j] = s / As[(k + j) * LP + k + j];
-      }
-#pragma unroll
-      for (int j = 0; j < NBS; ++j) As[(k + j) * LP + r] = x[j];
-    }
-    __syncthreads();
-    // (c) rank-16 update of the trailing lower triangle
-    for (int idx = tid; idx < below * below; idx += 256) {
-      const int c = k + NBS + idx / below, r = k + NBS + idx % below;
-      if (r < c) continue;
-      double s = As[c * LP + r];
-#pragma unroll
-      for (int t = 0; t < NBS; ++t) s -= As[(k + t) * LP + r] * As[(k + t) * LP + c];
-      As[c * LP + r] = s;
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && s_bad) atomicMax(info, k0 + 1);
-  for (int idx = tid; idx < NBI * NBI; idx += 256) {
-    const int c = idx / NBI, r = idx - c * NBI;
-    if (r < kb && c < kb && c <= r) A[(size_t)(k0 + c) * lda + k0 + r] = As[c * LP + r];
-  }
-}
-
-// ---------------------------------------------------------------- trsm: rows below the diagonal block
-// X <- X * L11^-T for rows [r0, n), columns [k0, k0+kb).  One thread per row, 16-column register
-// sub-blocks (keeps every unrolled body small).
-__global__ __launch_bounds__(256) void trsm_64_kernel(double* __restrict__ A, int lda, int n, int k0, int kb,
-                                                      int r0) {
-  __shared__ double Ls[NBI * LP];  // L11 (r, c) at c * LP + r
-  for (int idx = threadIdx.x; idx < NBI * NBI; idx += 256) {
-    const int c = idx / NBI, r = idx - c * NBI;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < kb && c < kb && c <= r) v = A[(size_t)(k0 + c) * lda + k0 + r];
-    Ls[c * LP + r] = v;
-  }
-  __syncthreads();
-  const int row = r0 + blockIdx.x * 256 + threadIdx.x;
-  if (row >= n) return;
-  double* arow = A + row;
-  // 16-column register sub-blocks; already solved columns are re-read from global (L1/L2 resident).
-  // (Keeping all 64 entries in registers with a fully unrolled body makes the compiler hoist the 2016 LDS
-  // operands too: 3790 spilled VGPRs, measured 10x slower.)
-  for (int sb = 0; sb < NBI; sb += NBS) {
-    if (sb >= kb) break;
-    double x[NBS];
-#pragma unroll
-    for (int j = 0; j < NBS; ++j) x[j] = (sb + j < kb) ? arow[(size_t)(k0 + sb + j) * lda] : 0.0;
-    for (int t = 0; t < sb; ++t) {
-      const double xt = arow[(size_t)(k0 + t) * lda];
-#pragma unroll
-      for (int j = 0; j < NBS; ++j) x[j] -= xt * Ls[t * LP + sb + j];
-    }
-#pragma unroll
-    for (int j = 0; j < NBS; ++j) {
-      double s = x[j];
-#pragma unroll
-      for (int t = 0; t < j; ++t) s -= x[t] * Ls[(sb + t) * LP + sb + j];
-      x[j] = s / Ls[(sb + j) * LP + sb + j];
-    }
-#pragma unroll
-    for (int j = 0; j < NBS; ++j)
-      if (sb + j < kb) arow[(size_t)(k0 + sb + j) * lda] = x[j];
-  }
-}
 
 // ---------------------------------------------------------------- potf2 + inverse of a 64x64 diagonal block
 // 1 / sqrt(d) to ~1 ulp: hardware estimate r0, then one fourth-order correction r0 (1 + e/2 + 3e^2/8 + 5e^3/16) with
@@ -427,7 +312,7 @@ constexpr int TM = 128, KC = 16, PITCH = 144;
 // to cost 3x the MFMA time of the tile).
 template <bool INTERIOR>
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n, int r_begin, int c_end, int kc0,
-                                          int kdim, int i0, int j0, double* sP, double* sQ) {
+                                          int kdim, int i0, int j0, double* sP, double* sQ, int skip_end) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + 64 wr, cols j0 + 64 wc
   double4_t acc[4][4];                  // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
@@ -506,7 +391,8 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 64 * wc + 16 * jt + (lane >> 4) + 4 * r;
-        ok[it][r] = INTERIOR || (i < n && j < c_end && i >= j && i >= r_begin);
+        // (i, j) both below skip_end: the next diagonal block, owned by the potf2 workgroup of this launch
+        ok[it][r] = INTERIOR || (i < n && j < c_end && i >= j && i >= r_begin && !(i < skip_end && j < skip_end));
         const size_t idx = ok[it][r] ? (size_t)j * lda + i : (size_t)j0 * lda + i0;  // clamped, always valid
         cv[it][r] = A[idx];
       }
@@ -523,18 +409,98 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
   }
 }
 
+// The diagonal block that the NEXT panel step factors, done inside this launch by workgroup 0 (fuse_d >= 0):
+//   D = A[d.., d..] - P_d P_d^T  (the same rank-kdim update the tiles apply elsewhere; they skip this block),
+//   then potf2 + inverse.  This takes potf2 off the critical path: it overlaps the tiles of the update.
+__device__ __forceinline__ void potf2_fused(Potf2Lds& sh, double* __restrict__ A, int lda, int d, int kbn, int kc0, int kdim,
+                                            int* __restrict__ info, double* __restrict__ Minv) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+  if (tid == 0) sh.bad = 0;
+  // lower 16x16 tiles (ti >= tj) of the 64x64 block: 3, 3, 2, 2 per wave
+  const int t_i[4][3] = {{0, 1, 3}, {1, 2, 3}, {2, 3, 0}, {2, 3, 0}};
+  const int t_j[4][3] = {{0, 0, 3}, {1, 0, 2}, {1, 0, 0}, {2, 1, 0}};
+  const int nt = wv < 2 ? 3 : 2;
+  double4_t acc[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) acc[e] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double v[16];
+  auto fetch = [&](int ch) {  // 64 rows x 64 columns of the panel, coalesced along rows
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e, c = idx >> 6, r = idx & 63;
+      v[e] = (r < kbn && ch + c < kdim) ? A[(size_t)(kc0 + ch + c) * lda + d + r] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int ch = 0; ch < kdim; ch += NBI) {
+    __syncthreads();  // previous chunk consumed
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      sh.Ms[(idx >> 6) * LP + (idx & 63)] = v[e];
+    }
+    __syncthreads();
+    if (ch + NBI < kdim) fetch(ch + NBI);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if (e < nt) {
+        const int ib = 16 * t_i[wv][e], jb = 16 * t_j[wv][e];
+        // MFMA rows = j, columns = i: the result is stored / A is read in runs along i
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.Ms[(4 * ks + q) * LP + jb + m], sh.Ms[(4 * ks + q) * LP + ib + m],
+                                                        acc[e], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // staging buffer free
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    if (e < nt) {
+      const int i = 16 * t_i[wv][e] + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * t_j[wv][e] + q + 4 * r;
+        double val = (i == j) ? 1.0 : 0.0;  // identity padding of a partial block
+        if (i < kbn && j < kbn) val = A[(size_t)(d + j) * lda + d + i] - acc[e][r];
+        sh.As[j * LP + i] = val;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = tid + 256 * e;
+    sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
+  }
+  __syncthreads();
+  potf2_inv_lds(sh);
+  potf2_store(sh, A, lda, d, kbn, info, Minv);
+}
+
 __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int lda, int n, int r_begin,
                                                         int c_begin, int c_end, int kc0, int kdim, int tiles_i,
-                                                        int tiles_j) {
-  __shared__ __attribute__((aligned(16))) double sP[KC * PITCH];  // rows i (C rows)   [k][i]
-  __shared__ __attribute__((aligned(16))) double sQ[KC * PITCH];  // rows j (C cols)   [k][j]
+                                                        int tiles_j, int fuse_d, int fuse_kb, int* __restrict__ info,
+                                                        double* __restrict__ minv_next) {
+  __shared__ __attribute__((aligned(16))) Potf2Lds sh;  // the tile path uses its first 2 * KC * PITCH doubles
+  static_assert(sizeof(double) * 2 * KC * PITCH <= sizeof(double) * NBI * LP * 2, "operand staging must fit");
+  int bid = blockIdx.x;
+  if (fuse_d >= 0) {
+    if (bid == 0) {
+      potf2_fused(sh, A, lda, fuse_d, fuse_kb, kc0, kdim, info, minv_next);
+      return;
+    }
+    --bid;
+  }
+  double* sP = sh.As;              // rows i (C rows)   [k][i]
+  double* sQ = sh.As + KC * PITCH;  // rows j (C cols)   [k][j]
+  const int skip_end = fuse_d >= 0 ? fuse_d + fuse_kb : 0;  // rows past a partial block (the rhs row) stay with the tiles
   // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
-  const int tj = blockIdx.x % tiles_j, ti = blockIdx.x / tiles_j;
+  const int tj = bid % tiles_j, ti = bid / tiles_j;
   const int j0 = c_begin + tj * TM, i0 = r_begin + ti * TM;
   if (i0 + TM <= j0) return;  // entirely in the strict upper triangle
   const bool interior = i0 + TM <= n && j0 + TM <= c_end && i0 >= j0 + TM && (kdim % KC) == 0;
-  if (interior) syrk_tile<true>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ);
-  else syrk_tile<false>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ);
+  if (interior) syrk_tile<true>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
+  else syrk_tile<false>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
 }
 
 // ---------------------------------------------------------------- blocked triangular solves
@@ -569,40 +535,6 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double* __restrict_
   double acc = b[row];
   for (int t = 0; t < kb; ++t) acc -= A[(size_t)(k0 + t) * lda + row] * y[t];
   b[row] = acc;
-}
-
-// backward step k: x_k = L_kk^-T y_k, then y[c] -= sum_r L[k0 + r][c] x_k[r] for all columns c < k0
-// (reads y from `w`, writes the solved block to b, updates w for the columns to the left)
-__global__ __launch_bounds__(256) void bwd_step_kernel(const double* __restrict__ A, int lda, int n, int k0, int kb,
-                                                       double* __restrict__ b, double* __restrict__ w) {
-  __shared__ double x[NBI];
-  __shared__ double Ls[NBI * (NBI + 1)];
-  for (int idx = threadIdx.x; idx < NBI * NBI; idx += 256) {
-    const int j = idx / NBI, t = idx - j * NBI;
-    double v = (j == t) ? 1.0 : 0.0;
-    if (j < kb && t < kb && t <= j) v = A[(size_t)(k0 + t) * lda + k0 + j];
-    Ls[t * (NBI + 1) + j] = v;  // Ls[t*65 + j] = L[j][t]
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int i = threadIdx.x;
-    double s = i < kb ? w[k0 + i] : 0.0;
-    // L^T x = y: process rows from the bottom; x_j = (y_j - sum_{i>j} L[i][j] x_i) / L[j][j]
-    for (int j = NBI - 1; j >= 0; --j) {
-      const double xj = __shfl(s, j) / Ls[j * (NBI + 1) + j];
-      if (i == j) s = xj;
-      else if (i < j) s -= Ls[i * (NBI + 1) + j] * xj;  // L[j][i]
-    }
-    x[i] = s;
-  }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x < kb) b[k0 + threadIdx.x] = x[threadIdx.x];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= k0) return;
-  double acc = w[c];
-  const double* col = A + (size_t)c * lda + k0;
-  for (int r = 0; r < kb; ++r) acc -= col[r] * x[r];
-  w[c] = acc;
 }
 
 // backward step k with the inverted diagonal block: x_k = M_kk^T y_k (every workgroup redundantly), then
@@ -664,30 +596,34 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   // outer panel width: 512 for large systems (halves the number of passes over the trailing matrix, whose C-tile
   // read-modify-write is what keeps the rank-k update below the MFMA rate), 256 for small, latency-bound ones
   const int nbo = n >= 16384 ? 2 * NBO : NBO;
+  // The first diagonal block is factored by its own launch; every later one is factored by workgroup 0 of the
+  // rank-k update that precedes it (potf2_fused), so a panel step is two launches: trsm, then update + next potf2.
+  GH_LAUNCH(ctx, "ba_potf2", potf2_inv_kernel, dim3(1), dim3(256), 0, A, lda, 0, n < NBI ? n : NBI, info_dev, dinv);
   for (int c0 = 0; c0 < n; c0 += nbo) {
     const int pw = n - c0 < nbo ? n - c0 : nbo;  // panel width
     for (int k = c0; k < c0 + pw; k += NBI) {
       const int kb = c0 + pw - k < NBI ? c0 + pw - k : NBI;
       double* minv = dinv + (size_t)(k / NBI) * (NBI * NBI);
-      GH_LAUNCH(ctx, "ba_potf2", potf2_inv_kernel, dim3(1), dim3(256), 0, A, lda, k, kb, info_dev, minv);
       const int r0 = k + kb;
       if (r0 < nr) {
         GH_LAUNCH(ctx, "ba_trsm", trsm_inv_kernel, dim3(gh_div_up(nr - r0, 64)), dim3(256), 0, A, lda, nr, k, kb, r0,
                   (const double*)minv);
-        // update the rest of this panel with the fresh 64 columns
+        // update the rest of this panel with the fresh 64 columns (+ factor the next diagonal block)
         const int cb = r0, ce = c0 + pw;
         if (cb < ce) {
           const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(nr - cb, TM);
-          GH_LAUNCH(ctx, "ba_syrk_panel", syrk_mfma_kernel, dim3(tiles_i * tiles_j), dim3(256), 0, A, lda, nr, cb, cb,
-                    ce, k, kb, tiles_i, tiles_j);
+          const int kbn = ce - cb < NBI ? ce - cb : NBI;
+          GH_LAUNCH(ctx, "ba_syrk_panel", syrk_mfma_kernel, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, cb, cb,
+                    ce, k, kb, tiles_i, tiles_j, cb, kbn, info_dev, minv + NBI * NBI);
         }
       }
     }
     const int t0 = c0 + pw;
     if (t0 < n) {
       const int tiles_j = gh_div_up(n - t0, TM), tiles_i = gh_div_up(nr - t0, TM);
-      GH_LAUNCH(ctx, "ba_syrk_trailing", syrk_mfma_kernel, dim3(tiles_i * tiles_j), dim3(256), 0, A, lda, nr, t0, t0, n,
-                c0, pw, tiles_i, tiles_j);
+      const int kbn = n - t0 < NBI ? n - t0 : NBI;
+      GH_LAUNCH(ctx, "ba_syrk_trailing", syrk_mfma_kernel, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, t0, t0,
+                n, c0, pw, tiles_i, tiles_j, t0, kbn, info_dev, dinv + (size_t)(t0 / NBI) * (NBI * NBI));
     }
   }
   return GH_OK;
