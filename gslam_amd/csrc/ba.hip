@@ -199,36 +199,84 @@ __global__ __launch_bounds__(256) void lin_points_kernel(Problem P, double* __re
   if (gm > 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(gm));
 }
 
-__global__ __launch_bounds__(256) void lin_cams_kernel(Problem P, double* __restrict__ Hcc, double* __restrict__ gc,
-                                                       unsigned long long* __restrict__ gmax_bits) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= P.nc) return;
+// W_i = Jc^T L Jp (6x3), WH_i = W_i Hpp^-1
+__device__ __forceinline__ void make_W(const Obs& o, const double* L, double* W) {
+  double LJp[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    LJp[j] = L[0] * o.Jp[j] + L[1] * o.Jp[3 + j];
+    LJp[3 + j] = L[2] * o.Jp[j] + L[3] * o.Jp[3 + j];
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) W[3 * a + b] = o.Jc[a] * LJp[b] + o.Jc[6 + a] * LJp[3 + b];
+}
+
+__device__ __forceinline__ void mul_WH(const double* W, const double* Hi, double* WH) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) WH[3 * a + b] = W[3 * a] * Hi[b] + W[3 * a + 1] * Hi[3 + b] + W[3 * a + 2] * Hi[6 + b];
+}
+
+// Camera-side linearisation in chunks of at most kCamChunk observations (one workgroup per chunk, so a camera
+// that sees 20k points is as parallel as one that sees 20): each lane accumulates its share of Hcc (upper
+// triangle) / g_c, a fixed butterfly sums the lanes, the four wave totals are added in a fixed order and the
+// chunk total goes to `partial`; lin_cams_reduce_kernel adds a camera's chunks in order -> bitwise reproducible.
+// Also stores W_k = Jc^T L Jp of every observation (zero when the point is behind the camera): the Schur
+// product and the point back-substitution gather W instead of re-linearising.
+constexpr int kCamChunk = 1024;
+
+struct CamChunks {
+  const int32_t* cam;    // chunk -> camera
+  const int32_t* q0;     // chunk -> first position in clist
+  const int32_t* first;  // camera -> first chunk (nc + 1)
+  int nchunks;
+};
+
+__global__ __launch_bounds__(256) void lin_cams_kernel(Problem P, CamChunks C, double* __restrict__ partial,
+                                                       double* __restrict__ Wbuf) {
+  __shared__ double part[4][27];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = C.cam[blockIdx.x];
+  const int q_begin = C.q0[blockIdx.x];
+  const int q_end = min(q_begin + kCamChunk, P.cstart[c + 1]);
   double H[21], g[6];  // upper triangle, row-major packed
 #pragma unroll
   for (int a = 0; a < 21; ++a) H[a] = 0;
 #pragma unroll
   for (int a = 0; a < 6; ++a) g[a] = 0;
-  for (int q = P.cstart[c] + lane; q < P.cstart[c + 1]; q += 64) {
+  for (int q = q_begin + threadIdx.x; q < q_end; q += 256) {
     const int k = P.clist[q];
     Obs o;
-    if (!lin_obs(P, k, o, true)) continue;
-    double L[4];
-    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, o.w, L);
-    const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
-    double LJc[12];
+    double W[18];
+    const bool ok = lin_obs(P, k, o, true);
+    if (ok) {
+      double L[4];
+      weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, o.w, L);
+      make_W(o, L, W);
+      const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
+      double LJc[12];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      LJc[j] = L[0] * o.Jc[j] + L[1] * o.Jc[6 + j];
-      LJc[6 + j] = L[2] * o.Jc[j] + L[3] * o.Jc[6 + j];
+      for (int j = 0; j < 6; ++j) {
+        LJc[j] = L[0] * o.Jc[j] + L[1] * o.Jc[6 + j];
+        LJc[6 + j] = L[2] * o.Jc[j] + L[3] * o.Jc[6 + j];
+      }
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        g[a] += o.Jc[a] * Lr[0] + o.Jc[6 + a] * Lr[1];
+#pragma unroll
+        for (int b = a; b < 6; ++b) H[t++] += o.Jc[a] * LJc[b] + o.Jc[6 + a] * LJc[6 + b];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 18; ++t) W[t] = 0.0;
     }
-    int t = 0;
+    double2* dst = reinterpret_cast<double2*>(Wbuf + (size_t)18 * k);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      g[a] += o.Jc[a] * Lr[0] + o.Jc[6 + a] * Lr[1];
-#pragma unroll
-      for (int b = a; b < 6; ++b) H[t++] += o.Jc[a] * LJc[b] + o.Jc[6 + a] * LJc[6 + b];
-    }
+    for (int t = 0; t < 9; ++t) dst[t] = make_double2(W[2 * t], W[2 * t + 1]);
   }
   // fixed-order butterfly: every lane ends with the same total, summed in the same order each run
 #pragma unroll
@@ -239,18 +287,38 @@ __global__ __launch_bounds__(256) void lin_cams_kernel(Problem P, double* __rest
     for (int a = 0; a < 6; ++a) g[a] += __shfl_xor(g[a], off);
   }
   if (lane == 0) {
-    int t = 0;
-    double gm = 0;
-    for (int a = 0; a < 6; ++a) {
-      gc[(size_t)6 * c + a] = g[a];
-      gm = fmax(gm, fabs(g[a]));
-      for (int b = a; b < 6; ++b) {
-        Hcc[(size_t)36 * c + 6 * a + b] = H[t];
-        Hcc[(size_t)36 * c + 6 * b + a] = H[t];
-        ++t;
-      }
-    }
+#pragma unroll
+    for (int a = 0; a < 21; ++a) part[wv][a] = H[a];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) part[wv][21 + a] = g[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    partial[(size_t)27 * blockIdx.x + threadIdx.x] =
+        (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// 32 threads per camera: thread t < 27 adds element t of the camera's chunk totals in chunk order
+__global__ __launch_bounds__(256) void lin_cams_reduce_kernel(int nc, CamChunks C, const double* __restrict__ partial,
+                                                              double* __restrict__ Hcc, double* __restrict__ gc,
+                                                              unsigned long long* __restrict__ gmax_bits) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+  if (c >= nc || t >= 27) return;
+  double tot = 0;
+  for (int ch = C.first[c]; ch < C.first[c + 1]; ++ch) tot += partial[(size_t)27 * ch + t];
+  if (t >= 21) {
+    gc[(size_t)6 * c + (t - 21)] = tot;
+    const double gm = fabs(tot);
     if (gm > 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(gm));
+  } else {
+    int a = 0, rem = t;  // packed upper triangle index -> (a, b), b >= a
+    while (rem >= 6 - a) {
+      rem -= 6 - a;
+      ++a;
+    }
+    const int b = a + rem;
+    Hcc[(size_t)36 * c + 6 * a + b] = tot;
+    Hcc[(size_t)36 * c + 6 * b + a] = tot;
   }
 }
 
@@ -294,40 +362,27 @@ __global__ __launch_bounds__(64) void schur_diag_kernel(int nc, const double* __
   }
 }
 
-// W_i = Jc^T L Jp (6x3), WH_i = W_i Hpp^-1
-__device__ __forceinline__ void make_W(const Obs& o, const double* L, double* W) {
-  double LJp[6];
+__device__ __forceinline__ void load_W(const double* __restrict__ Wbuf, int k, double* W) {
+  const double2* src = reinterpret_cast<const double2*>(Wbuf + (size_t)18 * k);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    LJp[j] = L[0] * o.Jp[j] + L[1] * o.Jp[3 + j];
-    LJp[3 + j] = L[2] * o.Jp[j] + L[3] * o.Jp[3 + j];
+  for (int t = 0; t < 9; ++t) {
+    const double2 v = src[t];
+    W[2 * t] = v.x;
+    W[2 * t + 1] = v.y;
   }
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) W[3 * a + b] = o.Jc[a] * LJp[b] + o.Jc[6 + a] * LJp[3 + b];
-}
-
-__device__ __forceinline__ void mul_WH(const double* W, const double* Hi, double* WH) {
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) WH[3 * a + b] = W[3 * a] * Hi[b] + W[3 * a + 1] * Hi[3 + b] + W[3 * a + 2] * Hi[6 + b];
 }
 
 // Fast mode: one thread per observation i (in point-CSR order); all j of the same point; f64 atomics.
 __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const double* __restrict__ Hpi,
                                                            const double* __restrict__ gp, double* __restrict__ S,
-                                                           int n, double* __restrict__ rhs) {
+                                                           int n, double* __restrict__ rhs,
+                                                           const double* __restrict__ Wbuf) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= P.no) return;
   const int k = P.plist[q];
   const int p = P.opt[k], ci = P.ocam[k];
-  Obs oi;
-  if (!lin_obs(P, k, oi, true)) return;
-  double L[4], Wi[18], WH[18];
-  weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, oi.w, L);
-  make_W(oi, L, Wi);
+  double Wi[18], WH[18];
+  load_W(Wbuf, k, Wi);
   mul_WH(Wi, Hpi + (size_t)9 * p, WH);
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
@@ -338,11 +393,8 @@ __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const doub
     const int k2 = P.plist[q2];
     const int cj = P.ocam[k2];
     if (cj > ci) continue;  // only the lower triangle is stored; (j, i) covers the mirror block
-    Obs oj;
-    if (!lin_obs(P, k2, oj, true)) continue;
-    double L2[4], Wj[18];
-    weighted_info(P.oinfo ? P.oinfo + 4 * k2 : nullptr, oj.w, L2);
-    make_W(oj, L2, Wj);
+    double Wj[18];
+    load_W(Wbuf, k2, Wj);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -360,48 +412,46 @@ __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const doub
 // plus the list of distinct blocks.  One wave per block: lanes stride over the block's pairs, accumulate
 // W_i Hpp^-1 W_j^T in registers, and a fixed butterfly sums the 64 partials -> bitwise reproducible,
 // no atomics, and a camera with 20k observations is as parallel as one with 20.
+constexpr int kSchurSeg = 512;  // pairs per wave
+
 struct SchurBlocks {
   const int32_t* pair_a;   // observation index k  (row camera)
   const int32_t* pair_b;   // observation index k2 (column camera)
   const int32_t* bstart;   // nblocks + 1
   const int32_t* bci;
   const int32_t* bcj;
-  int nblocks;
+  const int32_t* seg_blk;    // segment -> block (a block is cut into segments of kSchurSeg pairs)
+  const int32_t* seg_first;  // block -> first segment (nblocks + 1)
+  int nblocks, nsegs;
 };
 
+// one wave per segment: partial[seg][0..35] = sum W_i Hpp^-1 W_j^T (row-major a, b), [36..41] = sum W_i Hpp^-1 g_p
 __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlocks B, const double* __restrict__ Hpi,
-                                                           const double* __restrict__ gp, double* __restrict__ S,
-                                                           int n, double* __restrict__ rhs) {
+                                                           const double* __restrict__ gp,
+                                                           const double* __restrict__ Wbuf,
+                                                           double* __restrict__ partial) {
   const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= B.nblocks) return;
-  const int ci = B.bci[blk], cj = B.bcj[blk];
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= B.nsegs) return;
+  const int blk = B.seg_blk[seg];
+  const int e_begin = B.bstart[blk] + (seg - B.seg_first[blk]) * kSchurSeg;
+  const int e_end = min(e_begin + kSchurSeg, B.bstart[blk + 1]);
   double acc[36], racc[6];
 #pragma unroll
   for (int t = 0; t < 36; ++t) acc[t] = 0;
 #pragma unroll
   for (int t = 0; t < 6; ++t) racc[t] = 0;
-  for (int e = B.bstart[blk] + lane; e < B.bstart[blk + 1]; e += 64) {
+  for (int e = e_begin + lane; e < e_end; e += 64) {
     const int k = B.pair_a[e], k2 = B.pair_b[e];
     const int p = P.opt[k];
-    Obs oi;
-    if (!lin_obs(P, k, oi, true)) continue;
-    double L[4], Wi[18], WH[18], Wj[18];
-    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, oi.w, L);
-    make_W(oi, L, Wi);
+    double Wi[18], WH[18], Wj[18];
+    load_W(Wbuf, k, Wi);
+    load_W(Wbuf, k2, Wj);  // zero for an observation behind its camera: the pair contributes nothing
     mul_WH(Wi, Hpi + (size_t)9 * p, WH);
     if (k2 == k) {
 #pragma unroll
-      for (int t = 0; t < 18; ++t) Wj[t] = Wi[t];
-#pragma unroll
       for (int a = 0; a < 6; ++a)
         racc[a] += WH[3 * a] * gp[3 * p] + WH[3 * a + 1] * gp[3 * p + 1] + WH[3 * a + 2] * gp[3 * p + 2];
-    } else {
-      Obs oj;
-      if (!lin_obs(P, k2, oj, true)) continue;
-      double L2[4];
-      weighted_info(P.oinfo ? P.oinfo + 4 * k2 : nullptr, oj.w, L2);
-      make_W(oj, L2, Wj);
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -413,26 +463,34 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlock
   for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
     for (int t = 0; t < 36; ++t) acc[t] += __shfl_xor(acc[t], off);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) racc[t] += __shfl_xor(racc[t], off);
   }
-  if (ci == cj) {
+  // every lane holds the totals: lane t stores element t
+  double mine = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+  for (int t = 0; t < 36; ++t) mine = (lane == t) ? acc[t] : mine;
 #pragma unroll
-      for (int t = 0; t < 6; ++t) racc[t] += __shfl_xor(racc[t], off);
-    }
-  }
-  // lane b owns column b of the 6x6 block (this wave is the block's only writer)
-#pragma unroll
-  for (int b = 0; b < 6; ++b) {
-    if (lane == b) {
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        if (ci == cj && a < b) continue;  // lower triangle only
-        double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
-        *dst = *dst - acc[6 * a + b];
-      }
-      if (ci == cj) rhs[6 * ci + b] += racc[b];
-    }
+  for (int t = 0; t < 6; ++t) mine = (lane == 36 + t) ? racc[t] : mine;
+  if (lane < 42) partial[(size_t)42 * seg + lane] = mine;
+}
+
+// 64 threads per block: thread t < 42 adds element t of the block's segment totals in segment order, then
+// S[block] -= total (this thread is the element's only writer), rhs += total for the diagonal blocks
+__global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const double* __restrict__ partial,
+                                                           double* __restrict__ S, int n, double* __restrict__ rhs) {
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), t = threadIdx.x & 63;
+  if (blk >= B.nblocks || t >= 42) return;
+  double tot = 0;
+  for (int sg = B.seg_first[blk]; sg < B.seg_first[blk + 1]; ++sg) tot += partial[(size_t)42 * sg + t];
+  const int ci = B.bci[blk], cj = B.bcj[blk];
+  if (t < 36) {
+    const int a = t / 6, b = t - 6 * a;
+    if (ci == cj && a < b) return;  // lower triangle only
+    double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
+    *dst = *dst - tot;
+  } else if (ci == cj) {
+    rhs[6 * ci + (t - 36)] += tot;
   }
 }
 
@@ -448,25 +506,22 @@ __global__ void row_to_vec_kernel(const double* __restrict__ S, int lda, int n, 
 
 __global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const double* __restrict__ Hpi,
                                                              const double* __restrict__ gp,
-                                                             const double* __restrict__ dc, double* __restrict__ dp) {
+                                                             const double* __restrict__ dc, double* __restrict__ dp,
+                                                             const double* __restrict__ Wbuf) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P.np) return;
   double rhs[3] = {-gp[3 * p], -gp[3 * p + 1], -gp[3 * p + 2]};
   for (int q = P.pstart[p]; q < P.pstart[p + 1]; ++q) {
     const int k = P.plist[q], ci = P.ocam[k];
-    Obs o;
-    if (!lin_obs(P, k, o, true)) continue;
-    double L[4];
-    weighted_info(P.oinfo ? P.oinfo + 4 * k : nullptr, o.w, L);
-    double Jd[2] = {0, 0};
+    double W[18];
+    load_W(Wbuf, k, W);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      Jd[0] += o.Jc[a] * dc[6 * ci + a];
-      Jd[1] += o.Jc[6 + a] * dc[6 * ci + a];
+    for (int b = 0; b < 3; ++b) {  // rhs -= W^T dc
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t += W[3 * a + b] * dc[6 * ci + a];
+      rhs[b] -= t;
     }
-    const double LJd[2] = {L[0] * Jd[0] + L[1] * Jd[1], L[2] * Jd[0] + L[3] * Jd[1]};
-#pragma unroll
-    for (int b = 0; b < 3; ++b) rhs[b] -= o.Jp[b] * LJd[0] + o.Jp[3 + b] * LJd[1];
   }
   const double* Hi = Hpi + (size_t)9 * p;
 #pragma unroll
@@ -775,8 +830,11 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
-                             NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 + (NO / 256 + 2) * 2 + 8) +
-                        4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256;
+                             NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
+                        4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256 +
+                        // chunk / segment tables and their partial sums (upper bounds)
+                        (NO / kCamChunk + NC + 2) * (27 * 8 + 2 * 4) + (NC + 2) * 4 +
+                        (pair_a.size() / kSchurSeg + bstart.size() + 2) * (42 * 8 + 4) + (bstart.size() + 2) * 4 + 16 * 256;
     GH_TRY(db.reserve(need));
   }
   double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
@@ -796,17 +854,43 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.upload(&d_plist, (const int32_t*)plist.data(), plist.size()));
   GH_TRY(db.upload(&d_cstart, (const int32_t*)cstart.data(), cstart.size()));
   GH_TRY(db.upload(&d_clist, (const int32_t*)clist.data(), clist.size()));
-  SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nblocks};
+  // camera chunks (lin_cams) and Schur segments: fixed-size work items, independent of how skewed the graph is
+  std::vector<int32_t> ch_cam, ch_q0, ch_first((size_t)nc + 1, 0), seg_blk, seg_first((size_t)nblocks + 1, 0);
+  for (int c = 0; c < nc; ++c) {
+    ch_first[c] = (int32_t)ch_cam.size();
+    for (int q = cstart[c]; q < cstart[c + 1]; q += kCamChunk) {
+      ch_cam.push_back(c);
+      ch_q0.push_back(q);
+    }
+  }
+  ch_first[nc] = (int32_t)ch_cam.size();
+  for (int b = 0; b < nblocks; ++b) {
+    seg_first[b] = (int32_t)seg_blk.size();
+    for (int e = bstart[b]; e < bstart[b + 1]; e += kSchurSeg) seg_blk.push_back(b);
+  }
+  seg_first[nblocks] = (int32_t)seg_blk.size();
+  const int nchunks = (int)ch_cam.size(), nsegs = (int)seg_blk.size();
+  CamChunks CC{nullptr, nullptr, nullptr, nchunks};
+  {
+    int32_t *d_cc, *d_cq, *d_cf;
+    GH_TRY(db.upload(&d_cc, (const int32_t*)ch_cam.data(), ch_cam.size()));
+    GH_TRY(db.upload(&d_cq, (const int32_t*)ch_q0.data(), ch_q0.size()));
+    GH_TRY(db.upload(&d_cf, (const int32_t*)ch_first.data(), ch_first.size()));
+    CC = CamChunks{d_cc, d_cq, d_cf, nchunks};
+  }
+  SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nblocks, nsegs};
   if (nblocks > 0) {
-    int32_t *d_pa, *d_pb, *d_bs, *d_bci, *d_bcj;
+    int32_t *d_pa, *d_pb, *d_bs, *d_bci, *d_bcj, *d_sb, *d_sf;
+    GH_TRY(db.upload(&d_sb, (const int32_t*)seg_blk.data(), seg_blk.size()));
+    GH_TRY(db.upload(&d_sf, (const int32_t*)seg_first.data(), seg_first.size()));
     GH_TRY(db.upload(&d_pa, (const int32_t*)pair_a.data(), pair_a.size()));
     GH_TRY(db.upload(&d_pb, (const int32_t*)pair_b.data(), pair_b.size()));
     GH_TRY(db.upload(&d_bs, (const int32_t*)bstart.data(), bstart.size()));
     GH_TRY(db.upload(&d_bci, (const int32_t*)bci.data(), bci.size()));
     GH_TRY(db.upload(&d_bcj, (const int32_t*)bcj.data(), bcj.size()));
-    SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, nblocks};
+    SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_sb, d_sf, nblocks, nsegs};
   }
-  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv;
+  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart;
   unsigned long long* d_gmax;
   int *d_bad, *d_info;
   const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
@@ -820,6 +904,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_dp, (size_t)np * 3));
   GH_TRY(db.alloc(&d_work, (size_t)n));
   GH_TRY(db.alloc(&d_dinv, (size_t)gh_div_up(n, 64) * 4096));
+  GH_TRY(db.alloc(&d_W, (size_t)no * 18));
+  GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
+  GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
   GH_TRY(db.alloc(&d_out, 4));
   GH_TRY(db.alloc(&d_gmax, 1));
@@ -854,7 +941,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       if (np > 0)
         GH_LAUNCH(ctx, "ba_lin_points", lin_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpp, d_gp,
                   d_gmax);
-      GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_kernel, dim3(gh_div_up(nc, 4)), dim3(256), 0, P, d_Hcc, d_gc, d_gmax);
+      if (nchunks > 0) GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_kernel, dim3(nchunks), dim3(256), 0, P, CC, d_cpart, d_W);
+      GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_reduce_kernel, dim3(gh_div_up(nc, 8)), dim3(256), 0, nc, CC,
+                (const double*)d_cpart, d_Hcc, d_gc, d_gmax);
       unsigned long long bits = 0;
       GH_HIP(ctx, hipMemcpyAsync(&bits, d_gmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
       GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -878,12 +967,15 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
     GH_LAUNCH(ctx, "ba_schur_diag", schur_diag_kernel, dim3(nc), dim3(64), 0, nc, d_Hcc, d_gc, radius, d_S, lda, d_dc);
     if (no > 0) {
-      if (opt.deterministic)
-        GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, P, SB, d_Hpi,
-                  d_gp, d_S, lda, d_dc);
-      else
+      if (opt.deterministic) {
+        GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(gh_div_up(nsegs, 4)), dim3(256), 0, P, SB, d_Hpi, d_gp,
+                  (const double*)d_W, d_spart);
+        GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, SB,
+                  (const double*)d_spart, d_S, lda, d_dc);
+      } else {
         GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
-                  d_S, lda, d_dc);
+                  d_S, lda, d_dc, (const double*)d_W);
+      }
     }
     const double t_solve0 = now_ms();
     GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
@@ -901,7 +993,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       sum->solve_ms_total += now_ms() - t_solve0;
       if (np > 0)
         GH_LAUNCH(ctx, "ba_backsub", backsub_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpi, d_gp,
-                  d_dc, d_dp);
+                  d_dc, d_dp, (const double*)d_W);
       GH_LAUNCH(ctx, "ba_update", update_state_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, nc, np,
                 d_poses, d_dof, d_pts, d_dc, d_dp, d_poses_new, d_pts_new);
       GH_TRY(eval_cost(d_poses_new, d_pts_new, 1, h2));

@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gslam_amd import hip, ba
 from gslam_amd.ba_synth import make_graph
 ctx = hip.Context(0)
