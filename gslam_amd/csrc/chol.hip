@@ -303,27 +303,33 @@ __global__ __launch_bounds__(256) void trsm_inv_kernel(double* __restrict__ A, i
 
 // ---------------------------------------------------------------- syrk on f64 MFMA
 // C[i][j] -= sum_k A[i][kc+k] * A[j][kc+k]   for j in [c_begin, c_end), i in [max(j, r_begin), n), lower part only.
-// grid.x enumerates 128x128 tiles (ti, tj) with ti >= tj over the region; K = kdim (multiple of 4, <= 256).
-constexpr int TM = 128, KC = 16, PITCH = 144;
+// grid.x enumerates TMT x TMT tiles (ti, tj) with ti >= tj over the region; K = kdim (multiple of 4).
+// TMT = 128 (4 waves x 64x64) for large trailing matrices (arithmetic intensity), TMT = 64 (4 waves x 32x32) when
+// the region has too few 128-tiles to fill 256 CUs: 4x the workgroups, 1/4 of the serial MFMA chain per wave.
+constexpr int TM = 128, KC = 16;
 
-// INTERIOR = the whole 128x128 tile lies strictly below the diagonal and inside the matrix, and K is a
+// INTERIOR = the whole tile lies strictly below the diagonal and inside the matrix, and K is a
 // multiple of KC: no masks, so operand fetches are branch-free and the epilogue issues all loads of a
 // 16-element batch before the first store (a masked, per-element read-modify-write chain was measured
 // to cost 3x the MFMA time of the tile).
-template <bool INTERIOR>
+template <bool INTERIOR, int TMT>
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n, int r_begin, int c_end, int kc0,
                                           int kdim, int i0, int j0, double* sP, double* sQ, int skip_end) {
+  constexpr int SUB = TMT / 2;      // wave sub-tile edge
+  constexpr int MT = SUB / 16;      // MFMA tiles per edge of the wave sub-tile
+  constexpr int RPT = TMT / 16;     // staged rows per thread
+  constexpr int PITCH = TMT + 16;   // k-major LDS pitch (conflict-free ds_read_b64)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + 64 wr, cols j0 + 64 wc
-  double4_t acc[4][4];                  // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
+  const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + SUB wr, cols j0 + SUB wc
+  double4_t acc[MT][MT];                // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < MT; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  // staging map: thread -> (k = tid / 16, 8 consecutive rows starting at (tid % 16) * 8)
-  const int sk = tid >> 4, sr = (tid & 15) * 8;
-  double p[8], q[8];
+  // staging map: thread -> (k = tid / 16, RPT consecutive rows starting at (tid % 16) * RPT)
+  const int sk = tid >> 4, sr = (tid & 15) * RPT;
+  double p[RPT], q[RPT];
   auto fetch = [&](int kc) {
     const int kk = kc + sk;
     const size_t colP = (size_t)(kc0 + kk) * lda;
@@ -332,21 +338,21 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
       const double2* qq = reinterpret_cast<const double2*>(A + colP + j0 + sr);
       if ((((size_t)(A + colP + i0 + sr) | (size_t)(A + colP + j0 + sr)) & 15) == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < RPT / 2; ++e) {
           const double2 a2 = pp[e], b2 = qq[e];
           p[2 * e] = a2.x; p[2 * e + 1] = a2.y;
           q[2 * e] = b2.x; q[2 * e + 1] = b2.y;
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < RPT; ++e) {
           p[e] = A[colP + i0 + sr + e];
           q[e] = A[colP + j0 + sr + e];
         }
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < RPT; ++e) {
         const int ri = i0 + sr + e, rj = j0 + sr + e;
         p[e] = (kk < kdim && ri < n) ? A[colP + ri] : 0.0;
         q[e] = (kk < kdim && rj < n && rj < c_end) ? A[colP + rj] : 0.0;
@@ -357,40 +363,40 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
   for (int kc = 0; kc < kdim; kc += KC) {
     __syncthreads();  // previous chunk fully consumed
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < RPT; ++e) {
       sP[sk * PITCH + sr + e] = p[e];
       sQ[sk * PITCH + sr + e] = q[e];
     }
     __syncthreads();
-    // software pipeline: the next chunk's global loads are in flight while this chunk's 64 MFMAs issue
+    // software pipeline: the next chunk's global loads are in flight while this chunk's MFMAs issue
     if (kc + KC < kdim) fetch(kc + KC);
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
-      double fa[4], fb[4];
+      double fa[MT], fb[MT];
       const int krow = (4 * ks + (lane >> 4)) * PITCH;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fa[t] = sQ[krow + 64 * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
-        fb[t] = sP[krow + 64 * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
+      for (int t = 0; t < MT; ++t) {
+        fa[t] = sQ[krow + SUB * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
+        fb[t] = sP[krow + SUB * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
       }
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < MT; ++jt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < MT; ++it)
           acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[jt], fb[it], acc[jt][it], 0, 0, 0);
     }
   }
   // C -= acc^T : lane holds, for tile (jt, it): j = jbase + (lane>>4) + 4r, i = ibase + (lane&15)
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    double cv[4][4];
-    bool ok[4][4];
+  for (int jt = 0; jt < MT; ++jt) {
+    double cv[MT][4];
+    bool ok[MT][4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = i0 + 64 * wr + 16 * it + (lane & 15);
+    for (int it = 0; it < MT; ++it) {
+      const int i = i0 + SUB * wr + 16 * it + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + 64 * wc + 16 * jt + (lane >> 4) + 4 * r;
+        const int j = j0 + SUB * wc + 16 * jt + (lane >> 4) + 4 * r;
         // (i, j) both below skip_end: the next diagonal block, owned by the potf2 workgroup of this launch
         ok[it][r] = INTERIOR || (i < n && j < c_end && i >= j && i >= r_begin && !(i < skip_end && j < skip_end));
         const size_t idx = ok[it][r] ? (size_t)j * lda + i : (size_t)j0 * lda + i0;  // clamped, always valid
@@ -398,11 +404,11 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
       }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = i0 + 64 * wr + 16 * it + (lane & 15);
+    for (int it = 0; it < MT; ++it) {
+      const int i = i0 + SUB * wr + 16 * it + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + 64 * wc + 16 * jt + (lane >> 4) + 4 * r;
+        const int j = j0 + SUB * wc + 16 * jt + (lane >> 4) + 4 * r;
         if (ok[it][r]) A[(size_t)j * lda + i] = cv[it][r] - acc[jt][it][r];
       }
     }
@@ -423,6 +429,17 @@ __device__ __forceinline__ void potf2_fused(Potf2Lds& sh, double* __restrict__ A
   double4_t acc[3];
 #pragma unroll
   for (int e = 0; e < 3; ++e) acc[e] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // the block's own entries are fetched up front, together with the first panel chunk (one memory round trip)
+  double dval[3][4];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int i = 16 * t_i[wv][e] + m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t_j[wv][e] + q + 4 * r;
+      dval[e][r] = (e < nt && i < kbn && j < kbn) ? A[(size_t)(d + j) * lda + d + i] : ((i == j) ? 1.0 : 0.0);
+    }
+  }
   double v[16];
   auto fetch = [&](int ch) {  // 64 rows x 64 columns of the panel, coalesced along rows
 #pragma unroll
@@ -461,9 +478,8 @@ __device__ __forceinline__ void potf2_fused(Potf2Lds& sh, double* __restrict__ A
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * t_j[wv][e] + q + 4 * r;
-        double val = (i == j) ? 1.0 : 0.0;  // identity padding of a partial block
-        if (i < kbn && j < kbn) val = A[(size_t)(d + j) * lda + d + i] - acc[e][r];
-        sh.As[j * LP + i] = val;
+        // outside a partial block acc is zero (masked panel rows) and dval is the identity padding
+        sh.As[j * LP + i] = dval[e][r] - acc[e][r];
       }
     }
   }
@@ -477,12 +493,13 @@ __device__ __forceinline__ void potf2_fused(Potf2Lds& sh, double* __restrict__ A
   potf2_store(sh, A, lda, d, kbn, info, Minv);
 }
 
+template <int TMT>
 __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ A, int lda, int n, int r_begin,
                                                         int c_begin, int c_end, int kc0, int kdim, int tiles_i,
                                                         int tiles_j, int fuse_d, int fuse_kb, int* __restrict__ info,
                                                         double* __restrict__ minv_next) {
-  __shared__ __attribute__((aligned(16))) Potf2Lds sh;  // the tile path uses its first 2 * KC * PITCH doubles
-  static_assert(sizeof(double) * 2 * KC * PITCH <= sizeof(double) * NBI * LP * 2, "operand staging must fit");
+  __shared__ __attribute__((aligned(16))) Potf2Lds sh;  // the tile path uses its first 2 * KC * (TMT + 16) doubles
+  static_assert(2 * KC * (TM + 16) <= 2 * NBI * LP, "operand staging must fit");
   int bid = blockIdx.x;
   if (fuse_d >= 0) {
     if (bid == 0) {
@@ -491,16 +508,16 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
     }
     --bid;
   }
-  double* sP = sh.As;              // rows i (C rows)   [k][i]
-  double* sQ = sh.As + KC * PITCH;  // rows j (C cols)   [k][j]
+  double* sP = sh.As;                      // rows i (C rows)   [k][i]
+  double* sQ = sh.As + KC * (TMT + 16);    // rows j (C cols)   [k][j]
   const int skip_end = fuse_d >= 0 ? fuse_d + fuse_kb : 0;  // rows past a partial block (the rhs row) stay with the tiles
   // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
   const int tj = bid % tiles_j, ti = bid / tiles_j;
-  const int j0 = c_begin + tj * TM, i0 = r_begin + ti * TM;
-  if (i0 + TM <= j0) return;  // entirely in the strict upper triangle
-  const bool interior = i0 + TM <= n && j0 + TM <= c_end && i0 >= j0 + TM && (kdim % KC) == 0;
-  if (interior) syrk_tile<true>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
-  else syrk_tile<false>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
+  const int j0 = c_begin + tj * TMT, i0 = r_begin + ti * TMT;
+  if (i0 + TMT <= j0) return;  // entirely in the strict upper triangle
+  const bool interior = i0 + TMT <= n && j0 + TMT <= c_end && i0 >= j0 + TMT && (kdim % KC) == 0;
+  if (interior) syrk_tile<true, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
+  else syrk_tile<false, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
 }
 
 // ---------------------------------------------------------------- blocked triangular solves
@@ -539,38 +556,43 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double* __restrict_
 
 // backward step k with the inverted diagonal block: x_k = M_kk^T y_k (every workgroup redundantly), then
 // y[c] -= sum_r L[k0 + r][c] x_k[r] for the columns c < k0: one wave per column, lanes along r (512-byte coalesced
-// column segments), wave reduction.
+// column segments), wave reduction.  Every global load of the step is issued before the first use: the kernel is
+// one memory round trip plus a few hundred cycles of arithmetic.
 __global__ __launch_bounds__(256) void bwd_step_inv_kernel(const double* __restrict__ A, int lda, int k0, int kb,
                                                           double* __restrict__ b, double* __restrict__ w,
                                                           const double* __restrict__ Minv) {
-  __shared__ double Ms[NBI * LP];
   __shared__ double part[4][NBI];
-  __shared__ double xs[NBI];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int idx = tid; idx < NBI * NBI; idx += 256) Ms[(idx >> 6) * LP + (idx & 63)] = Minv[idx];
-  __syncthreads();
-  {
-    // x[i] = sum_{j >= i} M[j][i] y[j]; wave wv covers j in [16 wv, 16 wv + 16)
-    double s = 0.0;
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = 16 * wv + jj;
-      if (j < kb) s += Ms[lane * LP + j] * w[k0 + j];
-    }
-    part[wv][lane] = s;
-  }
-  __syncthreads();
-  if (tid < 64) xs[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-  __syncthreads();
-  if (blockIdx.x == 0 && tid < kb) b[k0 + tid] = xs[tid];
-  const double xr = lane < kb ? xs[lane] : 0.0;
   const int cbase = blockIdx.x * 64 + wv * 16;
+  // M[16 wv + jj][lane], jj < 16: 128 contiguous bytes of column `lane` of M
+  double mreg[16];
+  {
+    const double2* src = reinterpret_cast<const double2*>(Minv + lane * NBI + 16 * wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 v2 = src[e];
+      mreg[2 * e] = v2.x;
+      mreg[2 * e + 1] = v2.y;
+    }
+  }
+  const double yv = lane < kb ? w[k0 + lane] : 0.0;
   double v[16];
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
     const int c = cbase + cc;
-    v[cc] = (c < k0 && lane < kb) ? A[(size_t)c * lda + k0 + lane] * xr : 0.0;
+    v[cc] = (c < k0 && lane < kb) ? A[(size_t)c * lda + k0 + lane] : 0.0;
   }
+  const double wold = (lane < 16 && cbase + lane < k0) ? w[cbase + lane] : 0.0;
+  // x[i] = sum_j M[j][i] y[j]; this wave covers j in [16 wv, 16 wv + 16)
+  double s = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) s += mreg[jj] * readlane_f64(yv, 16 * wv + jj);
+  part[wv][lane] = s;
+  __syncthreads();
+  const double xr = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);  // x[lane] (0 for lane >= kb)
+  if (blockIdx.x == 0 && wv == 0 && lane < kb) b[k0 + lane] = xr;
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) v[cc] *= xr;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(256) void bwd_step_inv_kernel(const double* __restr
     double tot = v[0];
 #pragma unroll
     for (int cc = 1; cc < 16; ++cc) tot = (lane == cc) ? v[cc] : tot;
-    if (c < k0) w[c] -= tot;
+    if (c < k0) w[c] = wold - tot;
   }
 }
 
@@ -599,6 +621,20 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   // The first diagonal block is factored by its own launch; every later one is factored by workgroup 0 of the
   // rank-k update that precedes it (potf2_fused), so a panel step is two launches: trsm, then update + next potf2.
   GH_LAUNCH(ctx, "ba_potf2", potf2_inv_kernel, dim3(1), dim3(256), 0, A, lda, 0, n < NBI ? n : NBI, info_dev, dinv);
+  // rank-kdim update of rows [cb, nr) x columns [cb, ce) + factorisation of the diagonal block at cb
+  auto update = [&](const char* name, int cb, int ce, int kc0, int kdim, int kbn, double* minv_next) -> gh_status {
+    const long long t128 = (long long)gh_div_up(nr - cb, TM) * gh_div_up(ce - cb, TM);
+    if (t128 >= 1024) {  // enough 128-tiles (the lower half of them does work) for 256 CUs x 2 workgroups
+      const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(nr - cb, TM);
+      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, cb, cb, ce, kc0,
+                kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
+    } else {
+      const int tiles_j = gh_div_up(ce - cb, TM / 2), tiles_i = gh_div_up(nr - cb, TM / 2);
+      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM / 2>, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, cb, cb, ce,
+                kc0, kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
+    }
+    return GH_OK;
+  };
   for (int c0 = 0; c0 < n; c0 += nbo) {
     const int pw = n - c0 < nbo ? n - c0 : nbo;  // panel width
     for (int k = c0; k < c0 + pw; k += NBI) {
@@ -610,21 +646,12 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
                   (const double*)minv);
         // update the rest of this panel with the fresh 64 columns (+ factor the next diagonal block)
         const int cb = r0, ce = c0 + pw;
-        if (cb < ce) {
-          const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(nr - cb, TM);
-          const int kbn = ce - cb < NBI ? ce - cb : NBI;
-          GH_LAUNCH(ctx, "ba_syrk_panel", syrk_mfma_kernel, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, cb, cb,
-                    ce, k, kb, tiles_i, tiles_j, cb, kbn, info_dev, minv + NBI * NBI);
-        }
+        if (cb < ce) GH_TRY(update("ba_syrk_panel", cb, ce, k, kb, ce - cb < NBI ? ce - cb : NBI, minv + NBI * NBI));
       }
     }
     const int t0 = c0 + pw;
-    if (t0 < n) {
-      const int tiles_j = gh_div_up(n - t0, TM), tiles_i = gh_div_up(nr - t0, TM);
-      const int kbn = n - t0 < NBI ? n - t0 : NBI;
-      GH_LAUNCH(ctx, "ba_syrk_trailing", syrk_mfma_kernel, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, t0, t0,
-                n, c0, pw, tiles_i, tiles_j, t0, kbn, info_dev, dinv + (size_t)(t0 / NBI) * (NBI * NBI));
-    }
+    if (t0 < n)
+      GH_TRY(update("ba_syrk_trailing", t0, n, c0, pw, n - t0 < NBI ? n - t0 : NBI, dinv + (size_t)(t0 / NBI) * (NBI * NBI)));
   }
   return GH_OK;
 }
