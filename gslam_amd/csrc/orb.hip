@@ -88,14 +88,18 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
   const uint32_t al = (uint32_t)(sx0 & 3);
   const int last_dw = (src.pitch >> 2) - 1;
   const int d0 = sx0 >> 2, d1 = min(d0 + 1, last_dw), d2 = min(d0 + 2, last_dw);
-  uint32_t sel0[4], sel1[4], fxs[4];
+  // Per output column: one v_perm selector that puts the two horizontal taps into the two 16-bit halves of a
+  // dword, and the weight pair {2048 - fx, fx}: the horizontal lerp of a source row is ONE v_dot2_u32_u16.
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  uint32_t selp[4];
+  u16x2 wx[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int sx = (int)(txs[i] >> 16);
     const int sx1 = sx + 1 < src.w ? sx + 1 : src.w - 1;
-    sel0[i] = 0x0c0c0c00u | (uint32_t)(sx - sx0);   // byte (sx - sx0) of the window into bits 7:0, rest zero
-    sel1[i] = 0x0c0c0c00u | (uint32_t)(sx1 - sx0);
-    fxs[i] = txs[i] & 0xFFFFu;
+    selp[i] = 0x0c000c00u | ((uint32_t)(sx1 - sx0) << 16) | (uint32_t)(sx - sx0);
+    const uint32_t fx = txs[i] & 0xFFFFu;
+    wx[i] = __builtin_bit_cast(u16x2, (fx << 16) | (2048u - fx));
   }
 #pragma unroll
   for (int rr = 0; rr < kResizeRows; ++rr) {
@@ -111,16 +115,19 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
     const uint32_t v0 = q1[d0], v1 = q1[d1], v2 = q1[d2];
     const uint32_t ulo = __builtin_amdgcn_alignbyte(u1, u0, al), uhi = __builtin_amdgcn_alignbyte(u2, u1, al);
     const uint32_t vlo = __builtin_amdgcn_alignbyte(v1, v0, al), vhi = __builtin_amdgcn_alignbyte(v2, v1, al);
-    uint32_t packed = 0;
+    // vertical weights x4: the 2^22 weight total becomes 2^24, so the rounded result is the TOP BYTE of the sum
+    // ((4 v + 2^23) >> 24 == (v + 2^21) >> 22, max 255 * 2^24 + 2^23 < 2^32) and packing is two v_perm + one or
+    const uint32_t wy0 = 4u * (2048u - fy), wy1 = 4u * fy;
+    uint32_t r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t a00 = __builtin_amdgcn_perm(uhi, ulo, sel0[i]), a01 = __builtin_amdgcn_perm(uhi, ulo, sel1[i]);
-      const uint32_t a10 = __builtin_amdgcn_perm(vhi, vlo, sel0[i]), a11 = __builtin_amdgcn_perm(vhi, vlo, sel1[i]);
-      const uint32_t fx = fxs[i];
-      const uint32_t v = a00 * (2048 - fx) * (2048 - fy) + a01 * fx * (2048 - fy) + a10 * (2048 - fx) * fy +
-                         a11 * fx * fy;
-      packed |= ((v + (1u << 21)) >> 22) << (8 * i);
+      const u16x2 pu = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(uhi, ulo, selp[i]));
+      const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(vhi, vlo, selp[i]));
+      const uint32_t h0 = __builtin_amdgcn_udot2(pu, wx[i], 0u, false);  // a00 (2048 - fx) + a01 fx  (< 2^20)
+      const uint32_t h1 = __builtin_amdgcn_udot2(pv, wx[i], 0u, false);
+      r[i] = __umul24(h0, wy0) + (__umul24(h1, wy1) + (1u << 23));
     }
+    const uint32_t packed = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0703u) << 16);
     // dst pitch is a multiple of 64 and the pad bytes are ours: always a full dword store
     *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = packed;
   }
