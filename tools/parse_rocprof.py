@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSV output (gpurun_out/prof_*) into the tracked summaries under profiles/.
 
-  python tools/parse_rocprof.py <round-tag> <frames-per-launch>
+  python tools/parse_rocprof.py <round-tag> <frames-per-launch> ["<profiled command>"]
     gpurun_out/prof_stats/**/_kernel_stats.csv      -> profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats)
     gpurun_out/prof_fetch/**/_counter_collection.csv + prof_write/** -> profiles/pmc_traffic.json
 
@@ -20,9 +20,10 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "select_kernel": "orb_select",
          "describe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "synth_kernel": "synth_frames",
-         "syrk_mfma_kernel": "ba_syrk", "potf2_64_kernel": "ba_potf2", "trsm_64_kernel": "ba_trsm",
-         "schur_blocks_kernel": "ba_schur_blocks", "lin_cams_kernel": "ba_lin_cams",
-         "lin_points_kernel": "ba_lin_points", "fwd_step_kernel": "ba_trsv_fwd", "bwd_step_kernel": "ba_trsv_bwd"}
+         "syrk_mfma_kernel": "ba_syrk", "potf2_inv_kernel": "ba_potf2", "trsm_inv_kernel": "ba_trsm",
+         "schur_blocks_kernel": "ba_schur_blocks", "schur_reduce_kernel": "ba_schur_reduce",
+         "lin_cams_kernel": "ba_lin_cams", "lin_cams_reduce_kernel": "ba_lin_cams_reduce",
+         "lin_points_kernel": "ba_lin_points", "fwd_step_kernel": "ba_trsv_fwd", "bwd_step_inv_kernel": "ba_trsv_bwd"}
 
 
 def short(name):
@@ -54,8 +55,8 @@ def main():
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-            f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 "
-                    f"--frames {frames} --no-cpu-baseline --ba-iters 6   (1x MI355X)\n")
+            cmd = sys.argv[3] if len(sys.argv) > 3 else f"python bench.py --frames {frames} --no-cpu-baseline"
+            f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}   (1x MI355X)\n")
             csv.writer(f).writerows(rows)
         print("wrote", f"profiles/{tag}_kernel_stats.csv")
     fetch = counters("prof_fetch", "FETCH_SIZE")
