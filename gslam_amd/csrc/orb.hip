@@ -565,19 +565,34 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   }
   const uint8_t* patch = s_patch[wv] + (px0 - pa);
   __builtin_amdgcn_wave_barrier();
-  // intensity centroid over the radius-15 disc (patch centre at [16][16])
+  // intensity centroid over the radius-15 disc (patch centre at [16][16]).  Lane = (disc row, half): 16 bytes of
+  // the row as 4 dwords (unaligned start: 5 dword reads + v_alignbyte), bytes outside |u| <= u_max(|v|) masked off,
+  // then two v_dot4_u32_u8 per dword: sum I and sum (u + 16) I  ->  m10 = sum (u + 16) I - 16 sum I, m01 = v sum I.
   int m10 = 0, m01 = 0;
-  for (int idx = lane; idx < 31 * 31; idx += 64) {
-    const int r = idx / 31, c = idx - r * 31;
-    const int v = r - 15, u = c - 15;
-    const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-    // u_max table (GH_ORB_UMAX) as a switch-free lookup
-    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    if (au <= um[av]) {
-      const int I = patch[(r + 1) * kPatchPitch + c + 1];
-      m10 += u * I;
-      m01 += v * I;
+  if (lane < 62) {
+    const int r = lane >> 1, h = lane & 1;
+    const int v = r - 15, av = v < 0 ? -v : v;
+    const int umax = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);  // GH_ORB_UMAX as nibbles
+    const uint32_t boff = (uint32_t)(px0 - pa) + 1u + 16u * (uint32_t)h;    // byte offset of u = -15 + 16 h in patch row r + 1
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (r + 1) * (kPatchPitch / 4) + (boff >> 2);
+    const uint32_t sh = boff & 3u;
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+    const uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                           __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+    // kept byte positions p (u = -15 + 16 h + p): h = 0: p >= 15 - umax;  h = 1: p <= umax - 1
+    const int lo = h ? 0 : 15 - umax, hi = h ? umax - 1 : 15;
+    uint32_t sI = 0, sW = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nlo = min(max(lo - 4 * j, 0), 4), nhi = min(max(4 * j + 3 - hi, 0), 4);
+      const uint32_t mask = (uint32_t)(0xFFFFFFFFull << (8 * nlo)) & (uint32_t)(0xFFFFFFFFull >> (8 * nhi));
+      const uint32_t I4 = w[j] & mask;
+      const uint32_t wgt = 0x04030201u + 0x04040404u * (uint32_t)j + 0x10101010u * (uint32_t)h;  // u + 16 per byte
+      sI = __builtin_amdgcn_udot4(I4, 0x01010101u, sI, false);
+      sW = __builtin_amdgcn_udot4(I4, wgt, sW, false);
     }
+    m10 = (int)sW - 16 * (int)sI;
+    m01 = v * (int)sI;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -610,21 +625,26 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
       const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off);  // source bytes 0..3 (patch col 4 gq + k)
       const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, off);  // 4..7
       const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, off);  // 8..11
-      uint32_t x[10];
+      // P[s] = {x[s], x[s+1]} as two 16-bit lanes (one v_perm each, straight from the 12-byte window); an output is
+      // 4 v_dot2_u32_u16 with the tap pairs (g0,g1) (g2,g3) (g4,g5) (g6,0) instead of 7 multiply-adds
+      typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+      u16x2 P[10];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        x[k] = (w0 >> (8 * k)) & 0xFFu;
-        x[4 + k] = (w1 >> (8 * k)) & 0xFFu;
+      for (int sft = 0; sft < 10; ++sft) {
+        // bytes sft, sft + 1 of {w0, w1, w2}: the perm sees 8 of the 12 bytes
+        const uint32_t lo_dw = sft < 7 ? w0 : w1, hi_dw = sft < 7 ? w1 : w2;
+        const uint32_t bsel = (uint32_t)(sft < 7 ? sft : sft - 4);
+        P[sft] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi_dw, lo_dw, 0x0c000c00u | ((bsel + 1u) << 16) | bsel));
       }
-      x[8] = w2 & 0xFFu;
-      x[9] = (w2 >> 8) & 0xFFu;
+      constexpr uint32_t g01 = 144u | (268u << 16), g23 = 391u | (442u << 16), g45 = 391u | (268u << 16), g6 = 144u;
       uint4 o;
       uint32_t acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[i] = 0;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) acc[i] += g[t] * x[i + t];
+        uint32_t t0 = __builtin_amdgcn_udot2(P[i], __builtin_bit_cast(u16x2, g01), 0u, false);
+        t0 = __builtin_amdgcn_udot2(P[i + 2], __builtin_bit_cast(u16x2, g23), t0, false);
+        t0 = __builtin_amdgcn_udot2(P[i + 4], __builtin_bit_cast(u16x2, g45), t0, false);
+        acc[i] = __builtin_amdgcn_udot2(P[i + 6], __builtin_bit_cast(u16x2, g6), t0, false);
       }
       o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
       *reinterpret_cast<uint4*>(&hb[r * kBlurPitch + 4 * gq]) = o;
@@ -632,18 +652,22 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   }
   __builtin_amdgcn_wave_barrier();
   uint8_t* bl = s_blur[wv];
+  // v-pass: one work item = 4 adjacent outputs of one blur row: 7 x 16-byte reads down the 4 columns, 28
+  // v_mad_u32_u24 (h sums < 2^20), weights x4 so that the rounded result is the top byte of the sum
+  // ((4 s + 2^23) >> 24 == (s + 2^21) >> 22; 4 * 2048 * 522240 + 2^23 < 2^32), one dword store.
   for (int idx = lane; idx < kBlur * 7; idx += 64) {
-    const int rq = idx / kBlur, c = idx - rq * kBlur;  // outputs: blur rows 4 rq .. 4 rq + 3 of column c
-    uint32_t col[10];
+    const int rb = idx / 7, cg = idx - rb * 7;
+    uint32_t acc[4] = {1u << 23, 1u << 23, 1u << 23, 1u << 23};
 #pragma unroll
-    for (int t = 0; t < 10; ++t) col[t] = hb[(4 * rq + t) * kBlurPitch + c];  // row 33 is slack (unused outputs)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t acc = 0;
-#pragma unroll
-      for (int t = 0; t < 7; ++t) acc += g[t] * col[i + t];
-      if (4 * rq + i < kBlur) bl[(4 * rq + i) * kBlurPitch + c] = (uint8_t)((acc + (1u << 21)) >> 22);
+    for (int t = 0; t < 7; ++t) {
+      const uint4 hv = *reinterpret_cast<const uint4*>(&hb[(rb + t) * kBlurPitch + 4 * cg]);
+      acc[0] += __umul24(4u * g[t], hv.x);
+      acc[1] += __umul24(4u * g[t], hv.y);
+      acc[2] += __umul24(4u * g[t], hv.z);
+      acc[3] += __umul24(4u * g[t], hv.w);
     }
+    *reinterpret_cast<uint32_t*>(&bl[rb * kBlurPitch + 4 * cg]) =
+        __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0703u) << 16);
   }
   __builtin_amdgcn_wave_barrier();
   // 256 binary tests, 64 per ballot
