@@ -212,8 +212,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     constexpr int kRowDw = kTileW / 4, kItemsPerRow = 18;
     const s16x2 T = {(short)min_th, (short)min_th};
     const int sx_lo = max(0, kEdge - (x0 - 1)), sx_hi = min(kScoreH, lv.w - kEdge - (x0 - 1));
-    for (int i0 = 0; i0 < kScoreH * kItemsPerRow; i0 += 256) {
-      const int item = i0 + tid;
+    constexpr int kTrips = (kScoreH * kItemsPerRow + 255) / 256;  // 5
+    static_assert(4 * kTrips <= 32 && kScoreW == 4 * kItemsPerRow, "candidate bits of all trips share one dword");
+    uint32_t allbits = 0;  // bit 4 t + k: pixel k of this thread's dword in trip t is a candidate
+#pragma unroll
+    for (int trip = 0; trip < kTrips; ++trip) {
+      const int item = 256 * trip + tid;
       uint32_t bits = 0;  // bit k: pixel k of the dword is a candidate
       int sy = 0, m = 4;
       if (item < kScoreH * kItemsPerRow) {
@@ -250,18 +254,28 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
         if (first + 4 > sx_hi) vm &= 0xFu >> min(first + 4 - sx_hi, 4);
         if (py >= kEdge && py < lv.h - kEdge) bits = mask & vm;
       }
-      // one queue reservation per wave-trip: per-lane count (0..4) prefix-summed with three ballots
-      const int cnt = __popc(bits);
-      const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4);
-      if ((c0 | c1 | c2) != 0ull) {
+      allbits |= bits << (4 * trip);
+    }
+    // ONE queue reservation per wave for all trips: per-lane count (0..20) prefix-summed with five ballots, then
+    // each lane unpacks its bits.  Score position of (item, k) = kScoreW sy + kScoreOff + 4 m - 18 + k with
+    // m = item - 18 sy + 4, which is 4 item + 1 + k: no division needed.
+    {
+      const int cnt = __popc(allbits);
+      const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4), c3 = __ballot(cnt & 8),
+                     c4 = __ballot(cnt & 16);
+      if ((c0 | c1 | c2 | c3 | c4) != 0ull) {
         const uint64_t ltm = (1ull << (tid & 63)) - 1ull;
         int base = 0;
-        if ((tid & 63) == 0) base = atomicAdd(&q_count, __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2));
-        base = __shfl(base, 0) + __popcll(c0 & ltm) + 2 * __popcll(c1 & ltm) + 4 * __popcll(c2 & ltm);
-        const int pos0 = sy * kScoreW + kScoreOff + 4 * m - 18;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((bits >> k) & 1u) queue[base++] = (uint16_t)(pos0 + k);
+        if ((tid & 63) == 0)
+          base = atomicAdd(&q_count, __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3) + 16 * __popcll(c4));
+        base = __shfl(base, 0) + __popcll(c0 & ltm) + 2 * __popcll(c1 & ltm) + 4 * __popcll(c2 & ltm) +
+               8 * __popcll(c3 & ltm) + 16 * __popcll(c4 & ltm);
+        const int p0 = 4 * tid + 1;
+        while (allbits) {
+          const int b = __ffs((int)allbits) - 1;
+          queue[base++] = (uint16_t)(p0 + ((b >> 2) << 10) + (b & 3));
+          allbits &= allbits - 1u;
+        }
       }
     }
   }
