@@ -313,28 +313,39 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   const int cx = 2 * bx + (wv & 1), cy = 2 * by + (wv >> 1);
   if (cx >= ncx || cy >= ncy) return;  // no block-wide sync below
   uint32_t* list = lists[wv];
-  // 3x3 strict NMS over the cell.  Stage A scans the cell's score bytes as dwords (8 rows x 8 dwords per
-  // trip) and compacts the few non-zero pixels, in raster order, into list2; stage B tests only those
-  // against their 8 neighbours with every lane busy.  Ballot compaction keeps raster order in both stages.
+  // 3x3 strict NMS over the cell.  Stage A compacts the few non-zero pixels of the cell, in raster order, into
+  // list2; stage B tests only those against their 8 neighbours with every lane busy.  Both keep raster order.
   const int sy0 = 1 + 32 * (wv >> 1);
   const int col0 = kScoreOff + 1 + 32 * (wv & 1);  // byte column of the cell's first pixel: 4 or 36
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   uint16_t* list2 = queue + wv * 1024;  // the pass-1 queue is dead after pass 2: reuse it (row << 5 | col per entry)
+  // Stage A: lane l scans 16 consecutive score bytes in raster order (cell row l >> 1, cols 16 (l & 1) ..), so lane
+  // order IS raster order and one wave prefix sum of the per-lane non-zero counts (0..16, five ballots) places
+  // every non-zero pixel; each lane then unpacks its own bits.
   int nz = 0;
-  for (int it = 0; it < 4; ++it) {
-    const int row = 8 * it + (lane >> 3), dw = lane & 7;
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(&score[(sy0 + row) * kScoreW + col0 + 4 * dw]);
-    const uint32_t nzb = ((w & 0xFFu) ? 1u : 0u) | ((w & 0xFF00u) ? 2u : 0u) | ((w & 0xFF0000u) ? 4u : 0u) |
-                         ((w & 0xFF000000u) ? 8u : 0u);
-    const int cnt = __popc(nzb);
-    const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4);
-    if ((c0 | c1 | c2) == 0ull) continue;
-    int pos = nz + __popcll(c0 & lt_mask) + 2 * __popcll(c1 & lt_mask) + 4 * __popcll(c2 & lt_mask);
+  {
+    const int row = lane >> 1, cb = 16 * (lane & 1);
+    const uint32_t* sp32 = reinterpret_cast<const uint32_t*>(&score[(sy0 + row) * kScoreW + col0 + cb]);
+    uint32_t nzb = 0;  // bit k: byte k of the 16 is non-zero
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if ((nzb >> k) & 1u)
-        list2[pos++] = (uint16_t)((row << 5) | (4 * dw + k));
-    nz += __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2);
+    for (int dwi = 0; dwi < 4; ++dwi) {
+      const uint32_t w = sp32[dwi];
+      // bit 7 of each byte <- byte != 0, then gather bits 7 / 15 / 23 / 31 into a nibble
+      const uint32_t t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+      nzb |= (((t >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * dwi);
+    }
+    const int cnt = __popc(nzb);
+    const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4), c3 = __ballot(cnt & 8),
+                   c4 = __ballot(cnt & 16);
+    int pos = __popcll(c0 & lt_mask) + 2 * __popcll(c1 & lt_mask) + 4 * __popcll(c2 & lt_mask) +
+              8 * __popcll(c3 & lt_mask) + 16 * __popcll(c4 & lt_mask);
+    nz = __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3) + 16 * __popcll(c4);
+    const uint32_t rc0 = (uint32_t)((row << 5) | cb);
+    while (nzb) {
+      const int k = __ffs((int)nzb) - 1;
+      list2[pos++] = (uint16_t)(rc0 + (uint32_t)k);
+      nzb &= nzb - 1u;
+    }
   }
   int n = 0;
   bool strong = false;
