@@ -194,6 +194,24 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                 "note": "HBM is the contractual bound (SURVEY.md 8d); SQ counters show this kernel VALU-issue bound "
                         "(profiles/README.md), so frac understates how close the kernel is to ITS limit"}
+    # VALU-issue view of the same kernel: wave-instructions issued per second (SQ_INSTS_VALU from a separate --pmc
+    # pass, profiles/sq_counters.json) against one VALU instruction per SIMD per 4 cycles
+    spath = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if os.path.exists(spath):
+        try:
+            rec = json.load(open(spath)).get(dom, {})
+            if rec:
+                insts = rec["SQ_INSTS_VALU_per_launch"] * F / rec["frames_per_launch"]
+                info0 = ctx.device_info()
+                peak_issue = info0["cu_count"] * 4 * 2.4e9 / 4.0
+                roofline["valu_issue"] = {"wave_insts_per_launch": int(insts),
+                                          "achieved_Ginst_per_s": round(insts / (avg_ms * 1e-3) / 1e9, 1),
+                                          "peak_Ginst_per_s": round(peak_issue / 1e9, 1),
+                                          "frac": round(insts / (avg_ms * 1e-3) / peak_issue, 3),
+                                          "note": "1 VALU wave-instruction / SIMD / 4 clk at 2.4 GHz; multi-pass "
+                                                  "instructions make the true ceiling lower"}
+        except Exception:
+            pass
     orb_ms = sum(v["total_ms"] for v in orb_k.values())
     pipeline = {"bound": "hbm", "what": "whole ORB pipeline vs B_orb = 14.40 W H + 1021 K",
                 "achieved": round(orb_bytes_per_frame(W, H, K) * F * a.steps / (orb_ms * 1e-3) / 1e9, 1),

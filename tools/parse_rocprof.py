@@ -4,6 +4,7 @@
   python tools/parse_rocprof.py <round-tag> <frames-per-launch> ["<profiled command>"]
     gpurun_out/prof_stats/**/_kernel_stats.csv      -> profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats)
     gpurun_out/prof_fetch/**/_counter_collection.csv + prof_write/** -> profiles/pmc_traffic.json
+    gpurun_out/prof_sq/**/_counter_collection.csv                    -> profiles/sq_counters.json
 
 HBM traffic per launch follows MI355X_MICROARCH.md "HBM": separate --pmc passes for FETCH_SIZE and WRITE_SIZE
 (they do not fit one pass), both in KiB units; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
@@ -69,6 +70,19 @@ def main():
                       "FETCH_SIZE_KiB_avg": round(f_kib, 1), "WRITE_SIZE_KiB_avg": round(w_kib, 1),
                       "hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024),
                       "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes"}
+    # instruction mix per launch (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES)
+    sq = {}
+    for cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES"):
+        for k, (avg, n) in counters("prof_sq", cname).items():
+            sq.setdefault(k, {"frames_per_launch": frames, "launches_sampled": n})[cname + "_per_launch"] = round(avg, 1)
+    if sq:
+        json.dump(sq, open(os.path.join(out_dir, "sq_counters.json"), "w"), indent=1)
+        print("wrote profiles/sq_counters.json")
+        for k, v in sq.items():
+            w = v.get("SQ_WAVES_per_launch", 0) or 1
+            print("  %-18s VALU/wave %.0f  SALU/wave %.0f  LDS/wave %.0f" %
+                  (k, v.get("SQ_INSTS_VALU_per_launch", 0) / w, v.get("SQ_INSTS_SALU_per_launch", 0) / w,
+                   v.get("SQ_INSTS_LDS_per_launch", 0) / w))
     if traffic:
         json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
         print("wrote profiles/pmc_traffic.json")
