@@ -138,21 +138,27 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-__device__ __forceinline__ int fast_score16(const int (&d)[16]) {
+// r[] = the 16 ring intensities, c = the centre.  min/max commute with the subtraction of c, so the arcs are
+// evaluated on the raw intensities (no 16 differences) and the running best takes two arcs per v_max3 / v_min3:
+//   score = max(0, max_i min(arc_i) - c, c - min_i max(arc_i))
+__device__ __forceinline__ int fast_score16(const int (&r)[16], int c) {
   int lo3[16], hi3[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    lo3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-    hi3[i] = max3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+    lo3[i] = min3i(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+    hi3[i] = max3i(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
   }
-  int best = 0;
+  int best_lo = 0, best_hi = 255;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int lo9 = min3i(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]);
-    int hi9 = max3i(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]);
-    best = max3i(best, lo9, -hi9);
+  for (int i = 0; i < 16; i += 2) {
+    const int lo9a = min3i(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]);
+    const int lo9b = min3i(lo3[i + 1], lo3[(i + 4) & 15], lo3[(i + 7) & 15]);
+    const int hi9a = max3i(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]);
+    const int hi9b = max3i(hi3[i + 1], hi3[(i + 4) & 15], hi3[(i + 7) & 15]);
+    best_lo = max3i(best_lo, lo9a, lo9b);
+    best_hi = min3i(best_hi, hi9a, hi9b);
   }
-  return best;
+  return max3i(0, best_lo - c, c - best_hi);
 }
 
 constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligned window that covers x0-4 .. x0+67), 72 rows
@@ -212,6 +218,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     constexpr int kRowDw = kTileW / 4, kItemsPerRow = 18;
     const s16x2 T = {(short)min_th, (short)min_th};
     const int sx_lo = max(0, kEdge - (x0 - 1)), sx_hi = min(kScoreH, lv.w - kEdge - (x0 - 1));
+    // tile-uniform: every window pixel lies in the valid region [kEdge, dim - kEdge) -> constant trim masks
+    const bool interior = sx_lo == 0 && sx_hi == kScoreH && y0 - 1 >= kEdge && y0 - 1 + kScoreH <= lv.h - kEdge;
     constexpr int kTrips = (kScoreH * kItemsPerRow + 255) / 256;  // 5
     static_assert(4 * kTrips <= 32 && kScoreW == 4 * kItemsPerRow, "candidate bits of all trips share one dword");
     uint32_t allbits = 0;  // bit 4 t + k: pixel k of this thread's dword in trip t is a candidate
@@ -247,12 +255,18 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
           mask |= (((e >> 15) & 1u) | ((e >> 30) & 2u)) << (2 * h);
         }
         // keep only pixels inside the 66-wide window and the valid image region: window cols [sx_lo, sx_hi)
-        const int py = y0 - 1 + sy;
-        const int first = 4 * m - 18;  // window col of pixel 0 of this dword
-        uint32_t vm = 0xFu;
-        if (first < sx_lo) vm = (0xFu << min(sx_lo - first, 4)) & 0xFu;
-        if (first + 4 > sx_hi) vm &= 0xFu >> min(first + 4 - sx_hi, 4);
-        if (py >= kEdge && py < lv.h - kEdge) bits = mask & vm;
+        if (interior) {
+          // whole window valid: only the dwords that stick out of it are trimmed (m = 4: window cols -2, -1; m = 21: 66 .. 69)
+          const uint32_t vm = m == 4 ? 0xCu : (m == 21 ? 0u : 0xFu);
+          bits = mask & vm;
+        } else {
+          const int py = y0 - 1 + sy;
+          const int first = 4 * m - 18;  // window col of pixel 0 of this dword
+          uint32_t vm = 0xFu;
+          if (first < sx_lo) vm = (0xFu << min(sx_lo - first, 4)) & 0xFu;
+          if (first + 4 > sx_hi) vm &= 0xFu >> min(first + 4 - sx_hi, 4);
+          if (py >= kEdge && py < lv.h - kEdge) bits = mask & vm;
+        }
       }
       allbits |= bits << (4 * trip);
     }
@@ -286,24 +300,24 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     const int sy = pos / kScoreW, sx = pos - sy * kScoreW - kScoreOff;
     const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 18];
     const int c = p[0];
-    int d[16];
-    d[0] = p[-3 * kTileW] - c;
-    d[1] = p[-3 * kTileW + 1] - c;
-    d[2] = p[-2 * kTileW + 2] - c;
-    d[3] = p[-1 * kTileW + 3] - c;
-    d[4] = p[3] - c;
-    d[5] = p[1 * kTileW + 3] - c;
-    d[6] = p[2 * kTileW + 2] - c;
-    d[7] = p[3 * kTileW + 1] - c;
-    d[8] = p[3 * kTileW] - c;
-    d[9] = p[3 * kTileW - 1] - c;
-    d[10] = p[2 * kTileW - 2] - c;
-    d[11] = p[1 * kTileW - 3] - c;
-    d[12] = p[-3] - c;
-    d[13] = p[-1 * kTileW - 3] - c;
-    d[14] = p[-2 * kTileW - 2] - c;
-    d[15] = p[-3 * kTileW - 1] - c;
-    const int s = fast_score16(d);
+    int r[16];
+    r[0] = p[-3 * kTileW];
+    r[1] = p[-3 * kTileW + 1];
+    r[2] = p[-2 * kTileW + 2];
+    r[3] = p[-1 * kTileW + 3];
+    r[4] = p[3];
+    r[5] = p[1 * kTileW + 3];
+    r[6] = p[2 * kTileW + 2];
+    r[7] = p[3 * kTileW + 1];
+    r[8] = p[3 * kTileW];
+    r[9] = p[3 * kTileW - 1];
+    r[10] = p[2 * kTileW - 2];
+    r[11] = p[1 * kTileW - 3];
+    r[12] = p[-3];
+    r[13] = p[-1 * kTileW - 3];
+    r[14] = p[-2 * kTileW - 2];
+    r[15] = p[-3 * kTileW - 1];
+    const int s = fast_score16(r, c);
     if (s > min_th) score[pos] = (uint8_t)s;
   }
   __syncthreads();
