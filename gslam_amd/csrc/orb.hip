@@ -67,69 +67,96 @@ __global__ void copy_rows_kernel(const uint8_t* __restrict__ src, size_t src_fra
 
 // ------------------------------------------------------------------------------------------------
 // bilinear 1.2x downscale, 11-bit fixed point (oracle step 1).  xtab/ytab: idx << 16 | frac.
+// The kernel is bound by the NUMBER of vector-memory instructions, not by bytes or VALU (measured: 3 dword loads
+// per source row -> one dwordx3 load gave -27 %), so a thread produces 8 x 4 outputs from ONE 16-byte load per
+// source row: the 8 outputs of a row read source columns sx0 .. sx0 + 10 (scale 1.2) and the window starts at the
+// dword that holds sx0.  Threads are numbered row-group-major over ceil(wd / 8) column groups so that waves stay
+// full on the narrow levels.
 constexpr int kResizeRows = 4;  // output rows per thread
+constexpr int kResizeCols = 8;  // output columns per thread
+
+struct __attribute__((packed, aligned(4))) ResizeWin { uint32_t a, b, c, d; };  // 16 bytes at 4-byte alignment
 
 __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __restrict__ dst_base,
                                                      size_t dst_frame_stride, int dst_pitch, int wd, int hd,
                                                      const uint32_t* __restrict__ xtab,
-                                                     const uint32_t* __restrict__ ytab) {
-  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kResizeRows;
-  if (x4 >= wd || y0 >= hd) return;
-  const uint8_t* s = src.base + (size_t)blockIdx.z * src.frame_stride;
-  uint8_t* d = dst_base + (size_t)blockIdx.z * dst_frame_stride;
-  // The 4 outputs of a row read source columns sx0 .. sx0+5 (scale 1.2).  Per source row: 3 aligned dword
-  // loads -> an 8-byte window starting exactly at sx0 (2 x v_alignbyte) -> taps picked with v_perm_b32.
-  // The x table (padded to a multiple of 4 entries, 16-byte aligned) comes in one dwordx4 and is shared by
-  // the thread's 4 output rows.
-  const uint4 tx4 = *reinterpret_cast<const uint4*>(xtab + x4);
-  const uint32_t txs[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
-  const int sx0 = (int)(tx4.x >> 16);
+                                                     const uint32_t* __restrict__ ytab, int groups_per_row,
+                                                     uint32_t groups_inv, int n_items, int tail_unsafe_frame) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= n_items) return;
+  const int rg = (int)__umulhi((uint32_t)item, groups_inv);  // item / groups_per_row (exact: checked on the host)
+  const int x8 = (item - rg * groups_per_row) * kResizeCols;
+  const int y0 = rg * kResizeRows;
+  const uint8_t* s = src.base + (size_t)blockIdx.y * src.frame_stride;
+  uint8_t* d = dst_base + (size_t)blockIdx.y * dst_frame_stride;
+  // x table: padded to a multiple of 8 entries (pads continue with sx + 1), 32-byte aligned per group
+  const uint4 txa = *reinterpret_cast<const uint4*>(xtab + x8), txb = *reinterpret_cast<const uint4*>(xtab + x8 + 4);
+  const uint32_t txs[8] = {txa.x, txa.y, txa.z, txa.w, txb.x, txb.y, txb.z, txb.w};
+  const int sx0 = (int)(txa.x >> 16);
   const uint32_t al = (uint32_t)(sx0 & 3);
-  const int last_dw = (src.pitch >> 2) - 1;
-  const int d0 = sx0 >> 2, d1 = min(d0 + 1, last_dw), d2 = min(d0 + 2, last_dw);
+  const int d0 = sx0 >> 2;
   // Per output column: one v_perm selector that puts the two horizontal taps into the two 16-bit halves of a
   // dword, and the weight pair {2048 - fx, fx}: the horizontal lerp of a source row is ONE v_dot2_u32_u16.
+  // Columns 0..3 take their taps from window bytes 0..7, columns 4..7 (offset >= 4) from bytes 4..11.
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  uint32_t selp[4];
-  u16x2 wx[4];
+  uint32_t selp[8];
+  u16x2 wx[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int sx = (int)(txs[i] >> 16);
-    const int sx1 = sx + 1 < src.w ? sx + 1 : src.w - 1;
-    selp[i] = 0x0c000c00u | ((uint32_t)(sx1 - sx0) << 16) | (uint32_t)(sx - sx0);
+    const int o = sx - sx0 - (i >= 4 ? 4 : 0);
+    const int o1 = max(min(sx + 1, src.w - 1), sx) - sx0 - (i >= 4 ? 4 : 0);  // == o for the clamped / pad entries
+    selp[i] = 0x0c000c00u | ((uint32_t)o1 << 16) | (uint32_t)o;
     const uint32_t fx = txs[i] & 0xFFFFu;
     wx[i] = __builtin_bit_cast(u16x2, (fx << 16) | (2048u - fx));
   }
+  const uint4 ty4 = *reinterpret_cast<const uint4*>(ytab + y0);  // y table padded to a multiple of 4 entries
+  const uint32_t tys[4] = {ty4.x, ty4.y, ty4.z, ty4.w};
+  // the 16-byte window may run up to 15 bytes past the end of a source row: harmless inside the buffer (next row,
+  // next frame, or the slab's tail pad), but the caller's level-0 buffer has no pad after its last row
+  const bool guard = (int)blockIdx.y == tail_unsafe_frame && 4 * d0 + 16 > src.pitch;
+  const int last_dw = (src.pitch >> 2) - 1;
 #pragma unroll
   for (int rr = 0; rr < kResizeRows; ++rr) {
     const int y = y0 + rr;
     if (y >= hd) break;
-    const uint32_t ty = ytab[y];
+    const uint32_t ty = tys[rr];
     const int sy = ty >> 16;
     const uint32_t fy = ty & 0xFFFFu;
     const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
     const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s + (size_t)sy * src.pitch);
     const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s + (size_t)sy1 * src.pitch);
-    const uint32_t u0 = q0[d0], u1 = q0[d1], u2 = q0[d2];
-    const uint32_t v0 = q1[d0], v1 = q1[d1], v2 = q1[d2];
-    const uint32_t ulo = __builtin_amdgcn_alignbyte(u1, u0, al), uhi = __builtin_amdgcn_alignbyte(u2, u1, al);
-    const uint32_t vlo = __builtin_amdgcn_alignbyte(v1, v0, al), vhi = __builtin_amdgcn_alignbyte(v2, v1, al);
+    ResizeWin u, v;
+    if (guard && sy1 == src.h - 1) {
+      u = ResizeWin{q0[d0], q0[min(d0 + 1, last_dw)], q0[min(d0 + 2, last_dw)], q0[min(d0 + 3, last_dw)]};
+      v = ResizeWin{q1[d0], q1[min(d0 + 1, last_dw)], q1[min(d0 + 2, last_dw)], q1[min(d0 + 3, last_dw)]};
+    } else {
+      u = *reinterpret_cast<const ResizeWin*>(q0 + d0);
+      v = *reinterpret_cast<const ResizeWin*>(q1 + d0);
+    }
+    // 12-byte windows that start exactly at sx0
+    const uint32_t uw[3] = {__builtin_amdgcn_alignbyte(u.b, u.a, al), __builtin_amdgcn_alignbyte(u.c, u.b, al),
+                            __builtin_amdgcn_alignbyte(u.d, u.c, al)};
+    const uint32_t vw[3] = {__builtin_amdgcn_alignbyte(v.b, v.a, al), __builtin_amdgcn_alignbyte(v.c, v.b, al),
+                            __builtin_amdgcn_alignbyte(v.d, v.c, al)};
     // vertical weights x4: the 2^22 weight total becomes 2^24, so the rounded result is the TOP BYTE of the sum
     // ((4 v + 2^23) >> 24 == (v + 2^21) >> 22, max 255 * 2^24 + 2^23 < 2^32) and packing is two v_perm + one or
     const uint32_t wy0 = 4u * (2048u - fy), wy1 = 4u * fy;
-    uint32_t r[4];
+    uint32_t r[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u16x2 pu = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(uhi, ulo, selp[i]));
-      const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(vhi, vlo, selp[i]));
+    for (int i = 0; i < 8; ++i) {
+      const int wsel = i >= 4 ? 1 : 0;
+      const u16x2 pu = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(uw[wsel + 1], uw[wsel], selp[i]));
+      const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(vw[wsel + 1], vw[wsel], selp[i]));
       const uint32_t h0 = __builtin_amdgcn_udot2(pu, wx[i], 0u, false);  // a00 (2048 - fx) + a01 fx  (< 2^20)
       const uint32_t h1 = __builtin_amdgcn_udot2(pv, wx[i], 0u, false);
       r[i] = __umul24(h0, wy0) + (__umul24(h1, wy1) + (1u << 23));
     }
-    const uint32_t packed = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0703u) << 16);
-    // dst pitch is a multiple of 64 and the pad bytes are ours: always a full dword store
-    *reinterpret_cast<uint32_t*>(d + (size_t)y * dst_pitch + x4) = packed;
+    uint2 packed;
+    packed.x = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0703u) << 16);
+    packed.y = __builtin_amdgcn_perm(r[5], r[4], 0x0c0c0703u) | (__builtin_amdgcn_perm(r[7], r[6], 0x0c0c0703u) << 16);
+    // dst pitch is a multiple of 64 and the pad bytes are ours: always a full 8-byte store
+    *reinterpret_cast<uint2*>(d + (size_t)y * dst_pitch + x8) = packed;
   }
 }
 
@@ -870,8 +897,9 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   const int K = prm.n_features;
   // resize tables
   size_t tab_words = 0;
-  // every table starts 16-byte aligned and is padded (last entry replicated) to a multiple of 4 entries
-  for (int l = 1; l < L; ++l) tab_words += (((size_t)p->lw[l] + 3) & ~(size_t)3) + (((size_t)p->lh[l] + 3) & ~(size_t)3);
+  // every table starts 32-byte aligned; x tables are padded to a multiple of 8 entries (pads continue with the next
+  // source column, fraction 0, so that the per-thread window bounds hold), y tables to a multiple of 4 (last replicated)
+  for (int l = 1; l < L; ++l) tab_words += (((size_t)p->lw[l] + 7) & ~(size_t)7) + (((size_t)p->lh[l] + 7) & ~(size_t)7);
   std::vector<uint32_t> htab(tab_words ? tab_words : 1);
   do {
     if ((st = plan_alloc(p, B * p->slab, (void**)&p->pyr)) != GH_OK) break;
@@ -898,11 +926,25 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
           }
           htab[tw++] = ((uint32_t)sx << 16) | (uint32_t)fx;
         }
-        while (tw & 3) {
-          htab[tw] = htab[tw - 1];
+        while (tw & 7) {  // keeps every table 32-byte aligned
+          htab[tw] = axis == 0 ? ((htab[tw - 1] >> 16) + 1u) << 16 : htab[tw - 1];
           ++tw;
         }
+        if (axis == 0) {
+          // window contract of resize_kernel: within a group of 8 columns, taps of columns 0..3 lie in window bytes
+          // 0..7 and taps of columns 4..7 in bytes 4..11 (true for the 1.2 scale; refuse anything else loudly)
+          const uint32_t* t = p->xtab[l] - p->tabs + htab.data();
+          for (size_t g = 0; g + 8 <= tw - (size_t)(p->xtab[l] - p->tabs); g += 8)
+            for (int i = 0; i < 8; ++i) {
+              const int o = (int)(t[g + i] >> 16) - (int)(t[g] >> 16) - (i >= 4 ? 4 : 0);
+              if (o < 0 || o + 1 > 7) st = GH_ERR_ARG;
+            }
+        }
       }
+    }
+    if (st != GH_OK) {
+      gh_set_error(ctx, st, "resize table violates the 8-column window contract (level size ratio is not ~1.2)");
+      break;
     }
     if ((st = gh_dev_upload(ctx, p->tabs, htab.data(), htab.size() * sizeof(uint32_t))) != GH_OK) break;
     if ((st = gh_dev_upload(ctx, p->d_pattern, GH_ORB_PATTERN, sizeof(GH_ORB_PATTERN))) != GH_OK) break;
@@ -951,9 +993,15 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   for (int l = 1; l < L; ++l) lv[l] = {p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l]};
 
   for (int l = 1; l < L; ++l) {
-    dim3 grid(gh_div_up(p->lw[l], 256), gh_div_up(p->lh[l], 4 * kResizeRows), batch);
-    GH_LAUNCH(ctx, "orb_resize", resize_kernel, grid, dim3(256), 0, lv[l - 1], p->pyr + p->lvl_off[l], p->slab,
-              p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l]);
+    const int gpr = gh_div_up(p->lw[l], kResizeCols), nrg = gh_div_up(p->lh[l], kResizeRows);
+    const int n_items = gpr * nrg;
+    const uint32_t inv = (uint32_t)((0x100000000ull + (uint64_t)gpr - 1) / (uint64_t)gpr);  // exact for item < 2^32 / gpr
+    GH_CHECK_ARG(ctx, (uint64_t)n_items * (uint64_t)gpr < 0x100000000ull);
+    // only the caller's own level-0 buffer can end right after its last row
+    const int unsafe_frame = (l == 1 && aligned0) ? batch - 1 : -1;
+    GH_LAUNCH(ctx, "orb_resize", resize_kernel, dim3(gh_div_up(n_items, 256), batch), dim3(256), 0, lv[l - 1],
+              p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l], gpr, inv,
+              n_items, unsafe_frame);
   }
   for (int l = 0; l < L; ++l) {
     if (p->ncx[l] == 0 || p->quota[l] <= 0) continue;
