@@ -576,6 +576,18 @@ struct DescribeArgs {
   int nlevels;
 };
 
+// Sum of one int per lane over the wave, returned in every lane: four DPP adds give each 16-lane row its row sum
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), the four row sums meet through v_readlane / SALU adds.
+// (A __shfl_xor butterfly is 6 x 2 ds_bpermute plus the index arithmetic.)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+
 // 33x33 patch (radius 16): covers the radius-15 centroid disc and the 7x7 blur of the radius-13 test pattern.
 constexpr int kPatch = 33, kPatchPitch = 36;  // 9 dwords per row cover any 33-byte run
 constexpr int kBlur = 27, kBlurPitch = 28;     // blurred region: radius 13 (max |pattern coordinate|)
@@ -627,10 +639,14 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   // offset px0 & 3 of the window), so `patch` below points at the first wanted byte of row 0.
   const int px0 = (int)kp.x - 16, py0 = (int)kp.y - 16;
   const int pa = px0 & ~3;
-  for (int idx = lane; idx < kPatch * 9; idx += 64) {
-    const int r = idx / 9, c = idx - r * 9;
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(py0 + r) * lv.pitch + pa + 4 * c);
-    *reinterpret_cast<uint32_t*>(&s_patch[wv][r * kPatchPitch + 4 * c]) = v;
+  // lane r < 33 fetches the whole 36-byte row r (dwordx4 + dwordx4 + dword: 3 vector-memory instructions per wave
+  // instead of 5 trips of address arithmetic + dword loads)
+  if (lane < kPatch) {
+    struct __attribute__((packed, aligned(4))) Row9 { uint32_t w[9]; };
+    const Row9 row = *reinterpret_cast<const Row9*>(img + (size_t)(py0 + lane) * lv.pitch + pa);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_patch[wv][lane * kPatchPitch]);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) dst[c] = row.w[c];
   }
   const uint8_t* patch = s_patch[wv] + (px0 - pa);
   __builtin_amdgcn_wave_barrier();
@@ -656,18 +672,15 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
       const int nlo = min(max(lo - 4 * j, 0), 4), nhi = min(max(4 * j + 3 - hi, 0), 4);
       const uint32_t mask = (uint32_t)(0xFFFFFFFFull << (8 * nlo)) & (uint32_t)(0xFFFFFFFFull >> (8 * nhi));
       const uint32_t I4 = w[j] & mask;
-      const uint32_t wgt = 0x04030201u + 0x04040404u * (uint32_t)j + 0x10101010u * (uint32_t)h;  // u + 16 per byte
+      const uint32_t wgt = 0x04030201u + 0x04040404u * (uint32_t)j + (h ? 0x10101010u : 0u);  // u + 16 per byte
       sI = __builtin_amdgcn_udot4(I4, 0x01010101u, sI, false);
       sW = __builtin_amdgcn_udot4(I4, wgt, sW, false);
     }
     m10 = (int)sW - 16 * (int)sI;
-    m01 = v * (int)sI;
+    m01 = __mul24(v, (int)sI);  // |v| <= 15, sI < 2^13
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    m10 += __shfl_xor(m10, o);
-    m01 += __shfl_xor(m01, o);
-  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
   int bin = 0;
   {
     long long c = 0;
