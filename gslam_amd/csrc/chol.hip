@@ -50,14 +50,6 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return __builtin_fma(r0 * e, p, r0);
 }
 
-// lane N of every 16-lane row, broadcast to the whole row (DPP row_newbcast, gfx90a+)
-template <int N>
-__device__ __forceinline__ double row_bcast(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
 // value of lane `l` (wave-uniform index) broadcast through SGPRs
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);

@@ -8,13 +8,13 @@
 //
 // CDNA4 mapping.  Everything is HBM-bound byte/integer work, batched over frames (grid.z = frame) so a
 // launch carries >> 256 workgroups:
-//   resize      1 thread = 4 output pixels (dword store), source taps through L1/L2
-//   fast_cells  256 threads = 64x64 px = 2x2 cells; 72x80 B tile + 66x68 B score tile in LDS; each
+//   resize      1 thread = 8 x 4 output pixels from one 16-byte load per source row
+//   fast_cells  256 threads = 64x64 px = 2x2 cells; 72x96 B tile + 66x72 B score tile in LDS; each
 //               wave then owns one 32x32 cell: __ballot prefix compaction keeps raster order, so the
 //               per-cell candidate lists are deterministic without atomics or sorting
 //   select      one workgroup per (level, frame): LDS histogram over (rank, score) finds the quota
 //               cut-off, block scans give the output slots - no sort, no float
-//   describe    one wave per keypoint: 37x37 patch in LDS, wave-reduced integer moments, separable
+//   describe    one wave per keypoint: 33x33 patch in LDS, wave-reduced integer moments, separable
 //               integer blur in LDS, 4 x __ballot packs the 256 test bits
 #include <stdlib.h>
 
@@ -635,8 +635,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   const SelKp kp = sel[(size_t)b * K + slot];
   const LevelView lv = a.lv[l];
   const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
-  // 33x33 patch: each row is fetched as the 9 aligned dwords that cover it (the 33 bytes start at
-  // offset px0 & 3 of the window), so `patch` below points at the first wanted byte of row 0.
+  // 33x33 patch: each row is fetched as the 9 aligned dwords that cover it; the 33 wanted bytes start at
+  // offset px0 & 3 (= px0 - pa) of the row in LDS.
   const int px0 = (int)kp.x - 16, py0 = (int)kp.y - 16;
   const int pa = px0 & ~3;
   // lane r < 33 fetches the whole 36-byte row r (dwordx4 + dwordx4 + dword: 3 vector-memory instructions per wave
@@ -648,7 +648,6 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
 #pragma unroll
     for (int c = 0; c < 9; ++c) dst[c] = row.w[c];
   }
-  const uint8_t* patch = s_patch[wv] + (px0 - pa);
   __builtin_amdgcn_wave_barrier();
   // intensity centroid over the radius-15 disc (patch centre at [16][16]).  Lane = (disc row, half): 16 bytes of
   // the row as 4 dwords (unaligned start: 5 dword reads + v_alignbyte), bytes outside |u| <= u_max(|v|) masked off,
