@@ -389,56 +389,86 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
       nzb &= nzb - 1u;
     }
   }
-  int n = 0;
-  bool strong = false;
-  for (int base = 0; base < nz; base += 64) {
-    const int i = base + lane;
+  const size_t cell = (size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
+  uint32_t* out = cell_ent + cell * kCap;
+  int kept = 0;
+  if (nz <= 64) {
+    // Common case (a cell holds ~25 scored pixels): one candidate per lane, everything stays in registers.  NMS
+    // test, then the strong-corner filter and the rank-in-cell are evaluated over the ballot masks with v_readlane
+    // broadcasts; lane order = raster order, so no list is written or re-read.
     bool ismax = false;
     uint32_t e = 0;
-    if (i < nz) {
-      const uint32_t rc = list2[i];
+    int sv = 0;
+    if (lane < nz) {
+      const uint32_t rc = list2[lane];
       const uint8_t* sp = &score[(sy0 + (int)(rc >> 5)) * kScoreW + col0 + (int)(rc & 31u)];
-      const int sv = sp[0];
+      sv = sp[0];
       e = ((uint32_t)sv << 10) | rc;
-      // branch-free: all 8 neighbour reads in flight at once, one comparison against their maximum
       const int n0 = sp[-kScoreW - 1], n1 = sp[-kScoreW], n2 = sp[-kScoreW + 1], n3 = sp[-1], n4 = sp[1],
                 n5 = sp[kScoreW - 1], n6 = sp[kScoreW], n7 = sp[kScoreW + 1];
       ismax = max3i(max3i(n0, n1, n2), max3i(n3, n4, n5), max(n6, n7)) < sv;
     }
-    const uint64_t bm = __ballot(ismax);
-    if (ismax) list[n + __popcll(bm & lt_mask)] = e;
-    n += __popcll(bm);
-    strong = strong || (__ballot(ismax && (int)(e >> 10) > ini_th) != 0ull);
-  }
-  if (strong) {  // keep only candidates above the initial threshold (in place, order preserved)
-    int m2 = 0;
+    const uint64_t strong_mask = __ballot(ismax && sv > ini_th);
+    const uint64_t cand = strong_mask != 0ull ? strong_mask : __ballot(ismax);  // a strong corner silences the weak ones
+    int rank = 0;
+    for (uint64_t mm = cand; mm != 0ull; mm &= mm - 1ull) {
+      const int j = __ffsll((unsigned long long)mm) - 1;
+      const int sj = __builtin_amdgcn_readlane(sv, j);
+      rank += (sj > sv || (sj == sv && j < lane)) ? 1 : 0;
+    }
+    const bool keep = ((cand >> lane) & 1ull) != 0ull && rank < kCap;
+    const uint64_t m = __ballot(keep);
+    if (keep) out[__popcll(m & lt_mask)] = ((uint32_t)rank << 18) | e;
+    kept = __popcll(m);
+  } else {
+    int n = 0;
+    bool strong = false;
+    for (int base = 0; base < nz; base += 64) {
+      const int i = base + lane;
+      bool ismax = false;
+      uint32_t e = 0;
+      if (i < nz) {
+        const uint32_t rc = list2[i];
+        const uint8_t* sp = &score[(sy0 + (int)(rc >> 5)) * kScoreW + col0 + (int)(rc & 31u)];
+        const int sv = sp[0];
+        e = ((uint32_t)sv << 10) | rc;
+        // branch-free: all 8 neighbour reads in flight at once, one comparison against their maximum
+        const int n0 = sp[-kScoreW - 1], n1 = sp[-kScoreW], n2 = sp[-kScoreW + 1], n3 = sp[-1], n4 = sp[1],
+                  n5 = sp[kScoreW - 1], n6 = sp[kScoreW], n7 = sp[kScoreW + 1];
+        ismax = max3i(max3i(n0, n1, n2), max3i(n3, n4, n5), max(n6, n7)) < sv;
+      }
+      const uint64_t bm = __ballot(ismax);
+      if (ismax) list[n + __popcll(bm & lt_mask)] = e;
+      n += __popcll(bm);
+      strong = strong || (__ballot(ismax && (int)(e >> 10) > ini_th) != 0ull);
+    }
+    if (strong) {  // keep only candidates above the initial threshold (in place, order preserved)
+      int m2 = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t e = i < n ? list[i] : 0u;
+        const bool keep = i < n && (int)(e >> 10) > ini_th;
+        const uint64_t m = __ballot(keep);
+        if (keep) list[m2 + __popcll(m & lt_mask)] = e;
+        m2 += __popcll(m);
+      }
+      n = m2;
+    }
+    // rank within the cell by (score desc, raster asc); keep rank < cap, write in raster order
     for (int base = 0; base < n; base += 64) {
       const int i = base + lane;
       const uint32_t e = i < n ? list[i] : 0u;
-      const bool keep = i < n && (int)(e >> 10) > ini_th;
+      const int s = (int)(e >> 10);
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const int sj = (int)(list[j] >> 10);
+        rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
+      }
+      const bool keep = i < n && rank < kCap;
       const uint64_t m = __ballot(keep);
-      if (keep) list[m2 + __popcll(m & lt_mask)] = e;
-      m2 += __popcll(m);
+      if (keep) out[kept + __popcll(m & lt_mask)] = ((uint32_t)rank << 18) | e;
+      kept += __popcll(m);
     }
-    n = m2;
-  }
-  // rank within the cell by (score desc, raster asc); keep rank < cap, write in raster order
-  const size_t cell = (size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
-  uint32_t* out = cell_ent + cell * kCap;
-  int kept = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const uint32_t e = i < n ? list[i] : 0u;
-    const int s = (int)(e >> 10);
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const int sj = (int)(list[j] >> 10);
-      rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
-    }
-    const bool keep = i < n && rank < kCap;
-    const uint64_t m = __ballot(keep);
-    if (keep) out[kept + __popcll(m & lt_mask)] = ((uint32_t)rank << 18) | e;
-    kept += __popcll(m);
   }
   if (lane == 0) cell_cnt[cell] = (uint32_t)kept;
 }
