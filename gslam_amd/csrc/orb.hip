@@ -492,6 +492,19 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /* shared[5]
   return off + incl - v;
 }
 
+// Visit the n (<= kCap) entries of one cell: the first 8 come from two 16-byte loads issued together (a cell holds
+// ~5 entries, so the per-entry dword loop cost one memory round trip PER ENTRY), the rest from memory.
+template <typename F>
+__device__ __forceinline__ void for_each_entry(const uint32_t* __restrict__ cell_entries, int n, F f) {
+  const uint4 a = reinterpret_cast<const uint4*>(cell_entries)[0];
+  const uint4 b = reinterpret_cast<const uint4*>(cell_entries)[1];
+  const uint32_t first[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (e < n) f(first[e]);
+  for (int e = 8; e < n; ++e) f(cell_entries[e]);
+}
+
 struct SelectArgs {
   int ncells[kMaxL], cell_off[kMaxL], ncx[kMaxL], quota[kMaxL], quota_off[kMaxL];
 };
@@ -514,11 +527,10 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
   __syncthreads();
   for (int c = tid; c < ncells; c += 256) {
     const int n = (int)cnt[c];
-    for (int e = 0; e < n; ++e) {
-      const uint32_t v = ent[(size_t)c * kCap + e];
+    for_each_entry(ent + (size_t)c * kCap, n, [&](uint32_t v) {
       const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
       atomicAdd(&hist[ck], 1u);
-    }
+    });
   }
   __syncthreads();
   // cut-off bin: smallest bin whose inclusive prefix reaches the quota
@@ -555,12 +567,11 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     int n = 0, n_lt = 0, n_eq = 0;
     if (c < ncells) {
       n = (int)cnt[c];
-      for (int e = 0; e < n; ++e) {
-        const uint32_t v = ent[(size_t)c * kCap + e];
+      for_each_entry(ent + (size_t)c * kCap, n, [&](uint32_t v) {
         const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
         n_lt += ck < cut;
         n_eq += ck == cut;
-      }
+      });
     }
     int tot_eq, tot_sel;
     const int tie_excl = tie_carry + block_excl_scan(n_eq, wave_tot, &tot_eq);
@@ -571,8 +582,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     if (mysel > 0) {
       const int cx = c % ncx, cy = c / ncx;
       int k = 0, ties = 0;
-      for (int e = 0; e < n; ++e) {
-        const uint32_t v = ent[(size_t)c * kCap + e];
+      for_each_entry(ent + (size_t)c * kCap, n, [&](uint32_t v) {
         const int s = (int)((v >> 10) & 255);
         const int ck = (int)(v >> 18) * 256 + (255 - s);
         bool take = ck < cut;
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
           out[out_excl + k] = o;
           ++k;
         }
-      }
+      });
     }
     tie_carry += tot_eq;
     out_carry += tot_sel;
