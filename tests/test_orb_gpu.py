@@ -149,3 +149,36 @@ def test_bgr_to_gray_parity(ctx, oracle):
                                              C.c_void_p(out.data_ptr()), 67))
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), oracle.bgr_to_gray(bgr))
+
+
+def test_extract_full_size_properties(ctx, oracle):
+    """BASELINE configs[1] geometry (1920x1080, K=2000) at a batch the oracle cannot cover in seconds: size-independent
+    properties instead -- batch-split invariance (one batch of 192 == three batches of 64, bitwise), record invariants,
+    and an oracle spot check on three frames spread over the batch."""
+    import torch
+    from gslam_amd.orb import OrbExtractor, kps_to_numpy, synth_frames
+    B, W, H, K = 192, 1920, 1080, 2000
+    ex = OrbExtractor(ctx, W, H, max_batch=B, n_features=K)
+    fr = synth_frames(ctx, B, W, H, base_seed=0x5EED0000)
+    k, d, c = [t.clone() for t in ex.extract(fr)]
+    for s in range(0, B, 64):
+        k2, d2, c2 = ex.extract(fr[s:s + 64])
+        torch.cuda.synchronize()
+        assert torch.equal(k2.view(torch.int32), k[s:s + 64].view(torch.int32))
+        assert torch.equal(d2, d[s:s + 64]) and torch.equal(c2, c[s:s + 64])
+    kp, dn, cn = kps_to_numpy(k), d.cpu().numpy(), c.cpu().numpy()
+    assert cn.min() > 0 and cn.max() <= K
+    for f in range(B):
+        n = int(cn[f])
+        rec = kp[f, :n]
+        assert rec["octave"].min() >= 0 and rec["octave"].max() <= 7
+        assert (np.diff(rec["octave"]) >= 0).all(), "keypoints are grouped by level"
+        assert rec["response"].min() > 7 and rec["response"].max() <= 255
+        assert (rec["x"] >= 19).all() and (rec["x"] < W - 19 + 1).all() and (rec["y"] >= 19).all() and (rec["y"] < H - 19 + 1).all()
+        assert set(np.unique(rec["angle"])) <= set(12.0 * np.arange(30))
+        assert not kp[f, n:].tobytes().strip(b"\0") and not dn[f, n:].any()
+    frames_np = fr[[0, 95, 191]].cpu().numpy()
+    for i, f in enumerate((0, 95, 191)):
+        ek, ed = oracle.orb_extract(frames_np[i], K)
+        assert cn[f] == len(ek) and kp[f, :len(ek)].tobytes() == ek.tobytes() and np.array_equal(dn[f, :len(ek)], ed)
+    ex.close()
