@@ -252,6 +252,10 @@ def main():
 
     extra = {"bf_match": bf, "kernels": kernels, "roofline_pipeline": pipeline}
     info = ctx.device_info()
+    if world > 1:
+        # the CPU baseline is reported at N = 1 only (contract), and the single-GPU side legs (BA, BoW) add nothing
+        # to a scaling line: the other ranks have already left
+        a.no_cpu_baseline = a.no_ba = a.no_bow = True
 
     # ---- BA (C4) on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve
     def _leg_ba():
