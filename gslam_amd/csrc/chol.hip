@@ -352,12 +352,17 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
     }
   };
   fetch(0);
-  for (int kc = 0; kc < kdim; kc += KC) {
-    __syncthreads();  // previous chunk fully consumed
+  // Double-buffered operand staging: chunk c goes to buffer c & 1, so one barrier per chunk is enough -- a wave
+  // reaches the barrier of chunk c + 1 only after its reads of chunk c, hence buffer c & 1 is free again when
+  // chunk c + 2 is stored.  (sP, sQ) of buffer b start at sP + b * 2 * KC * PITCH.
+  int buf = 0;
+  for (int kc = 0; kc < kdim; kc += KC, buf ^= 1) {
+    double* bP = sP + buf * (2 * KC * PITCH);
+    double* bQ = bP + KC * PITCH;
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
-      sP[sk * PITCH + sr + e] = p[e];
-      sQ[sk * PITCH + sr + e] = q[e];
+      bP[sk * PITCH + sr + e] = p[e];
+      bQ[sk * PITCH + sr + e] = q[e];
     }
     __syncthreads();
     // software pipeline: the next chunk's global loads are in flight while this chunk's MFMAs issue
@@ -368,8 +373,8 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
       const int krow = (4 * ks + (lane >> 4)) * PITCH;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        fa[t] = sQ[krow + SUB * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
-        fb[t] = sP[krow + SUB * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
+        fa[t] = bQ[krow + SUB * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
+        fb[t] = bP[krow + SUB * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
       }
 #pragma unroll
       for (int jt = 0; jt < MT; ++jt)
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
                                                         int tiles_j, int fuse_d, int fuse_kb, int* __restrict__ info,
                                                         double* __restrict__ minv_next) {
   __shared__ __attribute__((aligned(16))) Potf2Lds sh;  // the tile path uses its first 2 * KC * (TMT + 16) doubles
-  static_assert(2 * KC * (TM + 16) <= 2 * NBI * LP, "operand staging must fit");
+  static_assert(2 * 2 * KC * (TM + 16) * sizeof(double) <= sizeof(Potf2Lds), "double-buffered operand staging must fit");
   int bid = blockIdx.x;
   if (fuse_d >= 0) {
     if (bid == 0) {
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
     }
     --bid;
   }
-  double* sP = sh.As;                      // rows i (C rows)   [k][i]
+  double* sP = sh.As;                      // rows i (C rows)   [k][i]   (buffer 0; syrk_tile derives the rest)
   double* sQ = sh.As + KC * (TMT + 16);    // rows j (C cols)   [k][j]
   const int skip_end = fuse_d >= 0 ? fuse_d + fuse_kb : 0;  // rows past a partial block (the rhs row) stay with the tiles
   // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
