@@ -612,9 +612,10 @@ __global__ __launch_bounds__(256) void bwd_step_inv_kernel(const double* __restr
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
   GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
-  // outer panel width: 512 for large systems (halves the number of passes over the trailing matrix, whose C-tile
-  // read-modify-write is what keeps the rank-k update below the MFMA rate), 256 for small, latency-bound ones
-  const int nbo = n >= 16384 ? 2 * NBO : NBO;
+  // outer panel width: wider for large systems (each doubling halves the passes over the trailing matrix, whose C-tile
+  // read-modify-write is what keeps the rank-k update below the MFMA rate, at the price of more in-panel rank-64
+  // updates; measured at n = 60 000: 512 -> 58.0, 1024 -> 60.1 TFLOP/s), 256 for small, latency-bound ones
+  const int nbo = n >= 32768 ? 4 * NBO : (n >= 16384 ? 2 * NBO : NBO);
   // The first diagonal block is factored by its own launch; every later one is factored by workgroup 0 of the
   // rank-k update that precedes it (potf2_fused), so a panel step is two launches: trsm, then update + next potf2.
   GH_LAUNCH(ctx, "ba_potf2", potf2_inv_kernel, dim3(1), dim3(256), 0, A, lda, 0, n < NBI ? n : NBI, info_dev, dinv);
