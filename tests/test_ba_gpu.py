@@ -128,10 +128,10 @@ def test_pnp_recovers_pose(ctx, oracle):
     assert np.allclose(info, info.T) and np.all(np.linalg.eigvalsh(info) > 0)
 
 
-@pytest.mark.parametrize("n", [8192, 16500])
+@pytest.mark.parametrize("n", [8192, 16500, 33000])
 def test_potrf_solve_large_residual_property(ctx, n):
     """Full-size property instead of an oracle: ||A x - b|| / ||b|| <= 1e-10 for a well conditioned SPD
-    system; n = 16500 takes the 512-wide outer-panel path with ragged edge tiles."""
+    system; n = 16500 takes the 512-wide outer-panel path with ragged edge tiles, n = 33000 the 1024-wide one."""
     import ctypes as C
     import torch
     from gslam_amd import hip
@@ -148,6 +148,8 @@ def test_potrf_solve_large_residual_property(ctx, n):
     assert info.value == 0
     r = torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)
     assert float(r) <= 1e-10, float(r)
+    if n > 20000:
+        return  # the residual is the property; the O(n^3) reconstruction is checked at the smaller sizes
     # L L^T reproduces A on the lower triangle (column-major lower == row-major upper of the tensor)
     Lt = torch.triu(L)  # row-major view of the column-major lower factor is its transpose
     rec = Lt.T @ Lt
