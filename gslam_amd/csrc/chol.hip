@@ -508,10 +508,27 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
   double* sP = sh.As;                      // rows i (C rows)   [k][i]   (buffer 0; syrk_tile derives the rest)
   double* sQ = sh.As + KC * (TMT + 16);    // rows j (C cols)   [k][j]
   const int skip_end = fuse_d >= 0 ? fuse_d + fuse_kb : 0;  // rows past a partial block (the rhs row) stay with the tiles
-  // tile decode: column tile tj in [0, tiles_j), row tile ti in [0, tiles_i); skip tiles fully above the diagonal
-  const int tj = bid % tiles_j, ti = bid / tiles_j;
+  // Only the tiles that touch the lower part are enumerated (row-major: row ti holds min(ti + 1, tiles_j) tiles), and
+  // workgroup b runs on XCD b % 8 (own L2): every XCD gets a contiguous, equally long strip of that order, so the
+  // workgroups that share an L2 share the row panel P_i and neighbouring column panels.
+  const int tri = tiles_j * (tiles_j + 1) / 2, total = tri + (tiles_i - tiles_j) * tiles_j;
+  {
+    const int chunk = (total + 7) >> 3;
+    bid = (bid & 7) * chunk + (bid >> 3);
+    if (bid >= total) return;
+  }
+  int ti, tj;
+  if (bid < tri) {
+    ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > bid) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    tj = bid - ti * (ti + 1) / 2;
+  } else {
+    const int r = bid - tri;
+    ti = tiles_j + r / tiles_j;
+    tj = r - (ti - tiles_j) * tiles_j;
+  }
   const int j0 = c_begin + tj * TMT, i0 = r_begin + ti * TMT;
-  if (i0 + TMT <= j0) return;  // entirely in the strict upper triangle
   const bool interior = i0 + TMT <= n && j0 + TMT <= c_end && i0 >= j0 + TMT && (kdim % KC) == 0;
   if (interior) syrk_tile<true, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
   else syrk_tile<false, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
@@ -622,14 +639,16 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   // rank-kdim update of rows [cb, nr) x columns [cb, ce) + factorisation of the diagonal block at cb
   auto update = [&](const char* name, int cb, int ce, int kc0, int kdim, int kbn, double* minv_next) -> gh_status {
     const long long t128 = (long long)gh_div_up(nr - cb, TM) * gh_div_up(ce - cb, TM);
-    if (t128 >= 1024) {  // enough 128-tiles (the lower half of them does work) for 256 CUs x 2 workgroups
+    // grid = the lower tiles (see the decode in the kernel), rounded up to the 8 XCD strips, + the potf2 workgroup
+    auto lower_tiles = [](int ti, int tj) { return tj * (tj + 1) / 2 + (ti - tj) * tj; };
+    if (t128 >= 1024) {  // enough 128-tiles for 256 CUs x 2 workgroups
       const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(nr - cb, TM);
-      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, cb, cb, ce, kc0,
-                kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
+      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, dim3(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1), dim3(256), 0,
+                A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
     } else {
       const int tiles_j = gh_div_up(ce - cb, TM / 2), tiles_i = gh_div_up(nr - cb, TM / 2);
-      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM / 2>, dim3(tiles_i * tiles_j + 1), dim3(256), 0, A, lda, nr, cb, cb, ce,
-                kc0, kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
+      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM / 2>, dim3(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1), dim3(256),
+                0, A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
     }
     return GH_OK;
   };
