@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bow", action="store_true")
+    ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="bounded CPU sample (frames; 1000 = the whole C2 step, ~10 s on 16 cores)")
     ap.add_argument("--ba-cams", type=int, default=500)
     ap.add_argument("--ba-points", type=int, default=50000)
@@ -255,7 +256,50 @@ def main():
     if world > 1:
         # the CPU baseline is reported at N = 1 only (contract), and the single-GPU side legs (BA, BoW) add nothing
         # to a scaling line: the other ranks have already left
-        a.no_cpu_baseline = a.no_ba = a.no_bow = True
+        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = True
+
+    # ---- C3 (KITTI-like stereo 1241x376 x 2): extract both eyes, row-band left-right match, temporal match
+    def _leg_c3():
+        if a.no_c3:
+            return
+        Ws, Hs, S = 1241, 376, 500  # stereo frames in flight (one batch of 2 S eyes)
+        stride = 1244
+        ex3 = OrbExtractor(ctx, Ws, Hs, max_batch=2 * S, n_features=K)
+        eyes = synth_frames(ctx, 2 * S, Ws, Hs, base_seed=0xC3000000, row_stride=stride, device=dev)  # L0 R0 L1 R1 ...
+        o3 = ex3.alloc_outputs(2 * S, dev)
+        lq = torch.arange(0, 2 * S, 2, dtype=torch.int32, device=dev)          # L_t -> R_t
+        rq = lq + 1
+        tq, tt = lq[:-1].contiguous(), lq[1:].contiguous()                     # L_t -> L_{t+1}
+        band = 2.0 / 31.0
+
+        def step3():
+            ex3.extract(eyes, o3)
+            lr = matcher.match_band_pairs(o3[1], o3[0], o3[2], lq, rq, band)
+            tm = matcher.match_pairs(o3[1], o3[2], tq, tt)
+            return lr, tm
+
+        step3()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            step3()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        c3 = o3[2].to(torch.int64)
+        pairs = int((c3[lq.long()] * c3[rq.long()]).sum().item() + (c3[tq.long()] * c3[tt.long()]).sum().item())
+        extra["c3_stereo"] = {"workload": "C3: %d stereo frames 1241x376 x 2 eyes, K=%d per eye, band-limited L-R match "
+                                          "+ temporal L-L match" % (S, K),
+                              "stereo_frames_per_s": round(S / dt, 1),
+                              "Mkeypoints_per_s": round(int(c3.sum().item()) / dt / 1e6, 2),
+                              "candidate_Gpairs_per_s": round(pairs / dt / 1e9, 1), "ms_per_batch": round(dt * 1e3, 3)}
+        ex3.close()
+
+    try:
+        _leg_c3()
+    except Exception as exc:
+        extra.setdefault("errors", {})["c3"] = repr(exc)
+        log("c3 leg failed: %r" % (exc,))
 
     # ---- BA (C4) on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve
     def _leg_ba():
