@@ -427,6 +427,24 @@ def main():
                 t_ref = time.perf_counter() - t1
                 cpu["match_reference_kernel_Gpairs_per_s"] = round(
                     float((ccnt[:nref].astype(np.int64) * ccnt[1:nref + 1]).sum()) / t_ref / 1e9, 4)
+            # single-thread figures on a small sample (SURVEY.md 8d asks for 1 thread and all cores) + the CPU itself
+            S1 = min(S, 24)
+            t1 = time.perf_counter()
+            _, d1t, c1t = oracle.orb_extract_batch(host_frames[:S1], K, threads=1)
+            t_e1 = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            for f in range(min(S1 - 1, 6)):
+                oracle.bf_match(d1t[f, :c1t[f]], d1t[f + 1, :c1t[f + 1]], threads=1)
+            t_m1 = time.perf_counter() - t1
+            cpu["extract_Mkpts_per_s_1thread"] = round(int(c1t.sum()) / t_e1 / 1e6, 4)
+            cpu["match_Gpairs_per_s_1thread"] = round(
+                float((c1t[:min(S1 - 1, 6)].astype(np.int64) * c1t[1:min(S1 - 1, 6) + 1]).sum()) / t_m1 / 1e9, 4)
+            try:
+                model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")]
+                cpu["cpu_model"] = model[0] if model else "unknown"
+                cpu["logical_cpus"] = os.cpu_count()
+            except Exception:
+                pass
             log("cpu match done")
             if not a.no_ba:
                 from gslam_amd.ba_synth import make_graph
