@@ -253,17 +253,22 @@ extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, con
   size_t off_d1 = off_i + (((size_t)nq * 4 + 255) & ~(size_t)255);
   size_t off_d2 = off_d1 + (((size_t)nq * 2 + 255) & ~(size_t)255);
   size_t total = off_d2 + (size_t)nq * 2;
-  void* base = nullptr;
+  void *base = nullptr, *hbase = nullptr;
   GH_TRY(gh_scratch(ctx, total, &base));
-  uint8_t* b = (uint8_t*)base;
-  GH_HIP(ctx, hipMemcpyAsync(b, q, qb, hipMemcpyHostToDevice, ctx->stream));
-  if (tb) GH_HIP(ctx, hipMemcpyAsync(b + off_t, t, tb, hipMemcpyHostToDevice, ctx->stream));
+  GH_TRY(gh_pinned(ctx, total, &hbase));
+  uint8_t *b = (uint8_t*)base, *hb = (uint8_t*)hbase;
+  // one DMA up (q | t) and one down (idx1 | d1 | d2) through the context's pinned block: a pageable copy per array
+  // costs ~50 us each on this stack, the whole 2000 x 2000 match kernel ~5 us
+  memcpy(hb, q, qb);
+  if (tb) memcpy(hb + off_t, t, tb);
+  GH_HIP(ctx, hipMemcpyAsync(b, hb, off_t + tb, hipMemcpyHostToDevice, ctx->stream));
   GH_TRY(gh_bf_match_dev(ctx, b, nq, b + off_t, nt, (int32_t*)(b + off_i), (uint16_t*)(b + off_d1),
                          (uint16_t*)(b + off_d2)));
-  GH_HIP(ctx, hipMemcpyAsync(idx1, b + off_i, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d1, b + off_d1, (size_t)nq * 2, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d2, b + off_d2, (size_t)nq * 2, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(hb + off_i, b + off_i, total - off_i, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(idx1, hb + off_i, (size_t)nq * 4);
+  memcpy(d1, hb + off_d1, (size_t)nq * 2);
+  memcpy(d2, hb + off_d2, (size_t)nq * 2);
   return GH_OK;
 }
 

@@ -29,6 +29,9 @@ struct gh_ctx {
   // scratch owned by the context (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // pinned host staging for the small host-buffer entry points (one DMA each way instead of one per array)
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
   // grow-only arena reused by successive gh_ba_solve calls (local BA runs every keyframe: no malloc/free per call)
   void* ba_arena = nullptr;
   size_t ba_arena_bytes = 0;
@@ -38,6 +41,7 @@ struct gh_ctx {
 
 gh_status gh_set_error(gh_ctx* ctx, gh_status st, const char* fmt, ...);
 gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out);
+gh_status gh_pinned(gh_ctx* ctx, size_t bytes, void** out);  // grow-only pinned host block owned by the context
 int gh_prof_begin(gh_ctx* ctx, const char* name);  // returns pending index or -1
 void gh_prof_end(gh_ctx* ctx, int pending);
 

@@ -45,6 +45,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   }
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ba_arena) hipFree(ctx->ba_arena);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -138,6 +139,21 @@ gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
     ctx->scratch_bytes = want;
   }
   *out = ctx->scratch;
+  return GH_OK;
+}
+
+gh_status gh_pinned(gh_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->pinned_bytes) {
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a copy may still be reading the old block
+    if (ctx->pinned) GH_HIP(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) return gh_set_error(ctx, GH_ERR_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+    ctx->pinned_bytes = want;
+  }
+  *out = ctx->pinned;
   return GH_OK;
 }
 
