@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "gslam_hip.h"
 
@@ -18,6 +19,7 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
   FeatureDetectorHIP() : ctx_(nullptr), plan_(nullptr), pw_(0), ph_(0), pk_(0), pl_(0) {}
   ~FeatureDetectorHIP() override {
     if (plan_) gh_orb_plan_destroy(plan_);
+    free_device_buffers();
     if (ctx_) gh_ctx_destroy(ctx_);
   }
 
@@ -47,19 +49,35 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       if (gh_orb_extract_host(plan_, image.data, w, kps.data(), desc.data(), &n) != GH_OK)
         return fail("gh_orb_extract_host");
     } else {
-      // colour input (datasets deliver BGR/BGRA: GSLAM/plugins/datasets/IO.h:86-113): fixed-point luma on the GPU
-      void *d_bgr = nullptr, *d_gray = nullptr;
+      // colour input (datasets deliver BGR/BGRA: GSLAM/plugins/datasets/IO.h:86-113): fixed-point luma on the GPU, and
+      // the gray image never leaves the device: upload BGR -> luma -> extract -> one download of the result block.
+      // The device buffers live as long as the geometry does (no hipMalloc / hipFree per frame).
       const size_t bgr_bytes = (size_t)w * h * ch, pitch = ((size_t)w + 63) & ~(size_t)63;
-      std::vector<uint8_t> gray((size_t)pitch * h);
-      bool ok = gh_dev_alloc(ctx_, bgr_bytes, &d_bgr) == GH_OK && gh_dev_alloc(ctx_, pitch * h, &d_gray) == GH_OK &&
-                gh_dev_upload(ctx_, d_bgr, image.data, bgr_bytes) == GH_OK &&
-                gh_bgr_to_gray_dev(ctx_, (const uint8_t*)d_bgr, w, h, ch, w * ch, (uint8_t*)d_gray, (int)pitch) == GH_OK &&
-                gh_dev_download(ctx_, gray.data(), d_gray, pitch * h) == GH_OK;
-      gh_dev_free(ctx_, d_bgr);
-      gh_dev_free(ctx_, d_gray);
-      if (!ok) return fail("bgr_to_gray");
-      if (gh_orb_extract_host(plan_, gray.data(), (int)pitch, kps.data(), desc.data(), &n) != GH_OK)
-        return fail("gh_orb_extract_host");
+      const size_t off_kps = 256, off_desc = off_kps + (((size_t)K * sizeof(gh_keypoint) + 255) & ~(size_t)255);
+      const size_t out_bytes = off_desc + (size_t)K * 32;
+      if (bgr_cap_ < bgr_bytes || gray_cap_ < pitch * h + 256 || out_cap_ < out_bytes) {
+        free_device_buffers();
+        if (gh_dev_alloc(ctx_, bgr_bytes, &d_bgr_) != GH_OK || gh_dev_alloc(ctx_, pitch * h + 256, &d_gray_) != GH_OK ||
+            gh_dev_alloc(ctx_, out_bytes, &d_out_) != GH_OK) {
+          free_device_buffers();
+          return fail("gh_dev_alloc");
+        }
+        bgr_cap_ = bgr_bytes;
+        gray_cap_ = pitch * h + 256;
+        out_cap_ = out_bytes;
+      }
+      uint8_t* out = (uint8_t*)d_out_;
+      host_out_.resize(out_bytes);
+      const bool ok =
+          gh_dev_upload(ctx_, d_bgr_, image.data, bgr_bytes) == GH_OK &&
+          gh_bgr_to_gray_dev(ctx_, (const uint8_t*)d_bgr_, w, h, ch, w * ch, (uint8_t*)d_gray_, (int)pitch) == GH_OK &&
+          gh_orb_extract_dev(plan_, (const uint8_t*)d_gray_, 1, pitch * h, (int)pitch, (gh_keypoint*)(out + off_kps),
+                             out + off_desc, (int32_t*)out) == GH_OK &&
+          gh_dev_download(ctx_, host_out_.data(), d_out_, out_bytes) == GH_OK;
+      if (!ok) return fail("bgr -> gray -> extract");
+      std::memcpy(&n, host_out_.data(), sizeof(n));
+      std::memcpy(kps.data(), host_out_.data() + off_kps, (size_t)K * sizeof(gh_keypoint));
+      std::memcpy(desc.data(), host_out_.data() + off_desc, (size_t)K * 32);
     }
     keypoints.resize((size_t)n);
     if (n > 0) std::memcpy((void*)keypoints.data(), kps.data(), (size_t)n * sizeof(gh_keypoint));
@@ -99,6 +117,15 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
   }
 
  private:
+  void free_device_buffers() {
+    if (ctx_) {
+      if (d_bgr_) gh_dev_free(ctx_, d_bgr_);
+      if (d_gray_) gh_dev_free(ctx_, d_gray_);
+      if (d_out_) gh_dev_free(ctx_, d_out_);
+    }
+    d_bgr_ = d_gray_ = d_out_ = nullptr;
+    bgr_cap_ = gray_cap_ = out_cap_ = 0;
+  }
   bool fail(const char* what) {
     LOG(ERROR) << "FeatureDetectorHIP: " << what << " failed: " << (ctx_ ? gh_last_error(ctx_) : "no context");
     return false;
@@ -116,6 +143,9 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
   gh_ctx* ctx_;
   gh_orb_plan* plan_;
   int pw_, ph_, pk_, pl_;
+  void *d_bgr_ = nullptr, *d_gray_ = nullptr, *d_out_ = nullptr;  // colour path: BGR, luma, result block
+  size_t bgr_cap_ = 0, gray_cap_ = 0, out_cap_ = 0;
+  std::vector<uint8_t> host_out_;
   std::mutex mu_;
 };
 
