@@ -248,7 +248,7 @@ typedef struct gh_ba_summary {
   int32_t accepted;
   int32_t termination;     /* 0 max_iterations, 1 function_tolerance, 2 gradient_tolerance, 3 failure */
   double initial_cost, final_cost;
-  double solve_ms_total;   /* time inside the dense reduced-camera solve */
+  double solve_ms_total;   /* host time from the dense reduced-camera solve to the candidate cost (per-iteration sync) */
   double total_ms;
   int32_t trace_len;
   double trace_cost[GH_BA_MAX_TRACE];   /* candidate cost evaluated at each iteration */
