@@ -620,6 +620,84 @@ __global__ __launch_bounds__(256) void bwd_step_inv_kernel(const double* __restr
   }
 }
 
+// Two backward steps in one launch (blocks A = [kA0, kA0 + kbA) and B = the full block right before it): every
+// workgroup redundantly runs the short chain x_A = M_A^T y_A;  y_B -= L[A rows, B cols]^T x_A;  x_B = M_B^T y_B, then
+// applies both to its 64 columns c < kB0 as one 128-row panel mat-vec.  Halves the launches of the back-substitution,
+// whose steps are launch-latency bound (the arithmetic of a step is a few hundred cycles).
+__global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __restrict__ A, int lda, int kA0, int kbA,
+                                                           double* __restrict__ b, double* __restrict__ w,
+                                                           const double* __restrict__ MinvA,
+                                                           const double* __restrict__ MinvB) {
+  __shared__ double part[3][4][NBI];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kB0 = kA0 - NBI;
+  const int cbase = blockIdx.x * 64 + wv * 16;
+  double mA[16], mB[16], blk[16];
+  {
+    const double2* sa = reinterpret_cast<const double2*>(MinvA + lane * NBI + 16 * wv);
+    const double2* sb = reinterpret_cast<const double2*>(MinvB + lane * NBI + 16 * wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 a2 = sa[e], b2 = sb[e];
+      mA[2 * e] = a2.x; mA[2 * e + 1] = a2.y;
+      mB[2 * e] = b2.x; mB[2 * e + 1] = b2.y;
+    }
+    // L[kA0 + r][kB0 + lane] for r in [16 wv, 16 wv + 16): 128 contiguous bytes of column kB0 + lane
+    const double* col = A + (size_t)(kB0 + lane) * lda + kA0 + 16 * wv;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) blk[jj] = (16 * wv + jj < kbA) ? col[jj] : 0.0;
+  }
+  const double yA = lane < kbA ? w[kA0 + lane] : 0.0;
+  const double yB = w[kB0 + lane];
+  double vA[16], vB[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = cbase + cc;
+    const double* colp = A + (size_t)c * lda;
+    vB[cc] = c < kB0 ? colp[kB0 + lane] : 0.0;
+    vA[cc] = (c < kB0 && lane < kbA) ? colp[kA0 + lane] : 0.0;
+  }
+  const double wold = (lane < 16 && cbase + lane < kB0) ? w[cbase + lane] : 0.0;
+  // x_A
+  double s = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) s += mA[jj] * readlane_f64(yA, 16 * wv + jj);
+  part[0][wv][lane] = s;
+  __syncthreads();
+  const double xA = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+  // y_B' = y_B - L_AB^T x_A
+  s = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) s += blk[jj] * readlane_f64(xA, 16 * wv + jj);
+  part[1][wv][lane] = s;
+  __syncthreads();
+  const double yB2 = yB - ((part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]));
+  // x_B
+  s = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) s += mB[jj] * readlane_f64(yB2, 16 * wv + jj);
+  part[2][wv][lane] = s;
+  __syncthreads();
+  const double xB = (part[2][0][lane] + part[2][1][lane]) + (part[2][2][lane] + part[2][3][lane]);
+  if (blockIdx.x == 0 && wv == 0) {
+    if (lane < kbA) b[kA0 + lane] = xA;
+    b[kB0 + lane] = xB;
+  }
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) vA[cc] = vA[cc] * xA + vB[cc] * xB;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) vA[cc] += __shfl_xor(vA[cc], off);
+  if (lane < 16) {
+    const int c = cbase + lane;
+    double tot = vA[0];
+#pragma unroll
+    for (int cc = 1; cc < 16; ++cc) tot = (lane == cc) ? vA[cc] : tot;
+    if (c < kB0) w[c] = wold - tot;
+  }
+}
+
 }  // namespace
 
 // Factor (lower, in place) and optionally solve.  info_dev: device int (0 = ok, else first bad block column + 1).
@@ -677,10 +755,20 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv) {
   const int last = ((n - 1) / NBI) * NBI;
-  for (int k = last; k >= 0; k -= NBI) {
+  int k = last;
+  while (k >= 0) {
     const int kb = n - k < NBI ? n - k : NBI;
-    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step_inv_kernel, dim3(k > 0 ? gh_div_up(k, 64) : 1), dim3(256), 0, L, lda, k, kb,
-              b, work, dinv + (size_t)(k / NBI) * (NBI * NBI));
+    const double* minv = dinv + (size_t)(k / NBI) * (NBI * NBI);
+    if (k >= NBI) {  // this block and the (full) one before it in one launch
+      const int kB0 = k - NBI;
+      GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step2_inv_kernel, dim3(kB0 > 0 ? gh_div_up(kB0, 64) : 1), dim3(256), 0, L, lda, k,
+                kb, b, work, minv, minv - NBI * NBI);
+      k -= 2 * NBI;
+    } else {
+      GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_step_inv_kernel, dim3(k > 0 ? gh_div_up(k, 64) : 1), dim3(256), 0, L, lda, k, kb,
+                b, work, minv);
+      k -= NBI;
+    }
   }
   return GH_OK;
 }
