@@ -318,7 +318,7 @@ def main():
             ctx.prof_enable(False)
             n = 6 * a.ba_cams
             solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * s.iterations
-            chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ("ba_potf2", "ba_trsm", "ba_syrk_panel",
+            chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ("ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel",
                                                                              "ba_syrk_trailing", "ba_trsv_fwd",
                                                                              "ba_trsv_bwd"))
             extra["ba"] = {"workload": f"{'C5' if a.ba_cams >= 10000 else 'C4'}: {a.ba_cams} cams, {a.ba_points} pts, {len(g['obs_cam'])} obs, Huber LM",

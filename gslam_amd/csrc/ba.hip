@@ -22,7 +22,8 @@
 
 #include "common.h"
 
-gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv);
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
+                            double* xwork);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv);
 
@@ -830,7 +831,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
-                             NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
+                             NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 * 3 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
                         4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256 +
                         // chunk / segment tables and their partial sums (upper bounds)
                         (NO / kCamChunk + NC + 2) * (27 * 8 + 2 * 4) + (NC + 2) * 4 +
@@ -890,7 +891,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_TRY(db.upload(&d_bcj, (const int32_t*)bcj.data(), bcj.size()));
     SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_sb, d_sf, nblocks, nsegs};
   }
-  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart;
+  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart, *d_xwork;
   unsigned long long* d_gmax;
   int *d_bad, *d_info;
   const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
@@ -905,6 +906,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_work, (size_t)n));
   GH_TRY(db.alloc(&d_dinv, (size_t)gh_div_up(n, 64) * 4096));
   GH_TRY(db.alloc(&d_W, (size_t)no * 18));
+  GH_TRY(db.alloc(&d_xwork, (size_t)2 * 64 * (n + 1)));
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
   GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
@@ -982,7 +984,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host
     // synchronisation per iteration instead of three.
     GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
-    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv));
+    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork));
     int flags[2] = {0, 0};
     GH_HIP(ctx, hipMemcpyAsync(&flags[0], d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&flags[1], d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -261,9 +261,30 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
 // ---------------------------------------------------------------- trsm as a GEMM with the inverted diagonal block
 // X = P M^T for rows [r0, nr), columns [k0, k0 + kb): D[j][i] = sum_k M[j][k] P[i][k] on v_mfma_f64_16x16x4_f64
 // (MFMA rows = j so the result is written in 128-byte runs along i).  One wave = 16 rows, all 64 columns.
+// A deferred copy job: X of an earlier fused panel step (see panel_step_kernel) waits in a side buffer and is written
+// to its final place, columns [kcol, kcol + 64) x rows [row0, row0 + rows) of A, by spare workgroups of a later launch.
+struct XCopy {
+  const double* src;  // [64][ldx], column-major: src[kk * ldx + r]
+  int ldx, kcol, row0, rows;
+};
+
+__device__ __forceinline__ void xcopy_block(const XCopy& c, double* __restrict__ A, int lda, int blk) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = threadIdx.x + 256 * e, kk = idx >> 6, r = 64 * blk + (idx & 63);
+    if (r < c.rows) A[(size_t)(c.kcol + kk) * lda + c.row0 + r] = c.src[(size_t)kk * c.ldx + r];
+  }
+}
+
+__global__ __launch_bounds__(256) void xcopy_kernel(XCopy c, double* __restrict__ A, int lda) { xcopy_block(c, A, lda, blockIdx.x); }
+
 __global__ __launch_bounds__(256) void trsm_inv_kernel(double* __restrict__ A, int lda, int nr, int k0, int kb, int r0,
-                                                      const double* __restrict__ Minv) {
+                                                      const double* __restrict__ Minv, int n_trsm_blocks, XCopy cp) {
   __shared__ double Ms[NBI * LP];
+  if ((int)blockIdx.x >= n_trsm_blocks) {  // spare workgroups: deferred copy of an earlier step's X
+    xcopy_block(cp, A, lda, blockIdx.x - n_trsm_blocks);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int idx = tid; idx < NBI * NBI; idx += 256) Ms[(idx >> 6) * LP + (idx & 63)] = Minv[idx];
   const int rbase = r0 + blockIdx.x * 64 + wv * 16;
@@ -290,6 +311,26 @@ __global__ __launch_bounds__(256) void trsm_inv_kernel(double* __restrict__ A, i
       const int j = 16 * jt + kq + 4 * r;
       if (rok && j < kb) A[(size_t)(k0 + j) * lda + row] = acc[r];
     }
+  }
+}
+
+// 16 rows of X = P M^T (all 64 columns of a full step), straight into MFMA operand layout:
+//   x[ks] = X[rowbase + (lane & 15)][4 ks + (lane >> 4)]
+// Ms = M of the step in LDS (pitch LP).  Rows >= row_end read as zero.
+__device__ __forceinline__ void trsm_block16(const double* Ms, const double* __restrict__ A, int lda, int row_end, int kc0,
+                                             int rowbase, int lane, double (&x)[16]) {
+  const int row = rowbase + (lane & 15), kq = lane >> 4;
+  double pb[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) pb[ks] = row < row_end ? A[(size_t)(kc0 + 4 * ks + kq) * lda + row] : 0.0;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * (jt + 1); ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ms[(4 * ks + kq) * LP + 16 * jt + (lane & 15)], pb[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[4 * jt + r] = acc[r];  // column 16 jt + kq + 4 r = 4 (4 jt + r) + kq
   }
 }
 
@@ -534,6 +575,146 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
   else syrk_tile<false, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
 }
 
+// One WHOLE panel step of the small-matrix regime in a single launch (the step used to be trsm + update: at
+// n ~ 3000 a third of the factorisation time is in-stream launch dependency latency):
+//   workgroup 0      applies M_k to the 64 rows of the next diagonal block itself, updates the block, factors it and
+//                    emits M_{k+1} (the chain that bounds the step);
+//   tile workgroups  64x64 tiles of the rank-64 update; each wave turns the four 16-row operand blocks it needs into
+//                    X = P M_k^T on the fly (registers, MFMA operand layout) -- redundant across tiles, but hidden
+//                    behind workgroup 0.  P must stay raw while other tiles read it, so the tiles of column 0 write
+//                    their X rows to a side buffer;
+//   copy workgroups  move the PREVIOUS step's side buffer to its final place in A (nobody reads those columns now).
+__global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A, int lda, int nr, int cb, int ce, int kc0,
+                                                         int tiles_i, int tiles_j, int n_tile_blocks, int fuse_kb,
+                                                         int* __restrict__ info, const double* __restrict__ minv_cur,
+                                                         double* __restrict__ minv_next, double* __restrict__ Xw, int ldx,
+                                                         XCopy cp) {
+  __shared__ __attribute__((aligned(16))) Potf2Lds sh;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  if (bid > n_tile_blocks) {
+    xcopy_block(cp, A, lda, bid - n_tile_blocks - 1);
+    return;
+  }
+  // M_k -> LDS (both roles need it)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = tid + 256 * e;
+    sh.As[(idx >> 6) * LP + (idx & 63)] = minv_cur[idx];
+  }
+  if (bid == 0) {
+    // ---- next diagonal block: X_d = P_d M_k^T, D = A_dd - X_d X_d^T, potf2 + inverse
+    const int d = cb, kbn = fuse_kb;
+    if (tid == 0) sh.bad = 0;
+    const int t_i[4][3] = {{0, 1, 3}, {1, 2, 3}, {2, 3, 0}, {2, 3, 0}};
+    const int t_j[4][3] = {{0, 0, 3}, {1, 0, 2}, {1, 0, 0}, {2, 1, 0}};
+    const int nt = wv < 2 ? 3 : 2;
+    double dval[3][4];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int i = 16 * t_i[wv][e] + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * t_j[wv][e] + q + 4 * r;
+        dval[e][r] = (e < nt && i < kbn && j < kbn) ? A[(size_t)(d + j) * lda + d + i] : ((i == j) ? 1.0 : 0.0);
+      }
+    }
+    __syncthreads();  // M_k staged
+    double xd[16];
+    trsm_block16(sh.As, A, lda, d + kbn, kc0, d + 16 * wv, lane, xd);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) sh.Ms[(4 * ks + q) * LP + 16 * wv + m] = xd[ks];  // staged as [k][row]
+    __syncthreads();
+    double4_t acc[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      acc[e] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      if (e < nt) {
+        const int ib = 16 * t_i[wv][e], jb = 16 * t_j[wv][e];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.Ms[(4 * ks + q) * LP + jb + m], sh.Ms[(4 * ks + q) * LP + ib + m],
+                                                        acc[e], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // M_k (sh.As) and X_d (sh.Ms) consumed
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if (e < nt) {
+        const int i = 16 * t_i[wv][e] + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh.As[(16 * t_j[wv][e] + q + 4 * r) * LP + i] = dval[e][r] - acc[e][r];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
+    }
+    __syncthreads();
+    potf2_inv_lds(sh);
+    potf2_store(sh, A, lda, d, kbn, info, minv_next);
+    return;
+  }
+  // ---- tile workgroups: lower tiles only, equally long XCD strips (as in syrk_mfma_kernel)
+  --bid;
+  const int tri = tiles_j * (tiles_j + 1) / 2, total = tri + (tiles_i - tiles_j) * tiles_j;
+  {
+    const int chunk = (total + 7) >> 3;
+    bid = (bid & 7) * chunk + (bid >> 3);
+    if (bid >= total) return;  // whole workgroup: no barrier follows for it
+  }
+  int ti, tj;
+  if (bid < tri) {
+    ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > bid) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    tj = bid - ti * (ti + 1) / 2;
+  } else {
+    const int r = bid - tri;
+    ti = tiles_j + r / tiles_j;
+    tj = r - (ti - tiles_j) * tiles_j;
+  }
+  const int i0 = cb + 64 * ti, j0 = cb + 64 * tj;
+  const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + 32 wr, cols j0 + 32 wc
+  __syncthreads();  // M_k staged
+  double xi[2][16], xj[2][16];
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) {
+    trsm_block16(sh.As, A, lda, nr, kc0, i0 + 32 * wr + 16 * bb, lane, xi[bb]);
+    trsm_block16(sh.As, A, lda, nr, kc0, j0 + 32 * wc + 16 * bb, lane, xj[bb]);
+  }
+  if (tj == 0 && wc == 0) {  // this wave owns the X rows i0 + 32 wr .. + 31 of the side buffer
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int row = i0 + 32 * wr + 16 * bb + m;
+      if (row < nr) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) Xw[(size_t)(4 * ks + q) * ldx + (row - cb)] = xi[bb][ks];
+      }
+    }
+  }
+  // C[i][j] -= sum_k X_i[i][k] X_j[j][k]; MFMA rows = j, columns = i (128-byte runs along i)
+  const int skip_end = cb + fuse_kb;
+#pragma unroll
+  for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xj[ja][ks], xi[ib][ks], acc, 0, 0, 0);
+      const int i = i0 + 32 * wr + 16 * ib + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 32 * wc + 16 * ja + q + 4 * r;
+        if (i < nr && j < ce && i >= j && !(i < skip_end && j < skip_end)) {
+          double* dst = A + (size_t)j * lda + i;
+          *dst = *dst - acc[r];
+        }
+      }
+    }
+}
+
 // ---------------------------------------------------------------- blocked triangular solves
 // forward step k: y_k = L_kk^-1 b_k (every workgroup redundantly, wave 0), then b[rows below] -= L[rows, k-block] y_k
 // (b is read-only inside the k-block during this launch: the solved block goes to `w`)
@@ -704,7 +885,10 @@ __global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __rest
 // `extra_rows` rows below the n x n matrix (lda >= n + extra_rows) ride along through trsm / syrk: with the
 // right-hand side stored as row n, the factorisation leaves y = L^-1 b there (forward substitution for free).
 // `dinv`: ceil(n / 64) * 4096 doubles of device workspace that receives the inverted diagonal blocks.
-gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv) {
+// `xwork`: optional 2 * 64 * (n + extra_rows) doubles; when given, full panel steps of the small-matrix regime run as one
+// launch each (panel_step_kernel) with their X rows parked there until a later launch copies them home.
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
+                            double* xwork) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
   GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   // outer panel width: wider for large systems (each doubling halves the passes over the trailing matrix, whose C-tile
@@ -712,14 +896,15 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   // updates; measured at n = 60 000: 512 -> 58.0, 1024 -> 60.1 TFLOP/s), 256 for small, latency-bound ones
   const int nbo = n >= 32768 ? 4 * NBO : (n >= 16384 ? 2 * NBO : NBO);
   // The first diagonal block is factored by its own launch; every later one is factored by workgroup 0 of the
-  // rank-k update that precedes it (potf2_fused), so a panel step is two launches: trsm, then update + next potf2.
+  // rank-k update that precedes it (potf2_fused), so a panel step is two launches: trsm, then update + next potf2
+  // -- or one (panel_step_kernel) for full steps of small matrices.
   GH_LAUNCH(ctx, "ba_potf2", potf2_inv_kernel, dim3(1), dim3(256), 0, A, lda, 0, n < NBI ? n : NBI, info_dev, dinv);
+  auto lower_tiles = [](int ti, int tj) { return tj * (tj + 1) / 2 + (ti - tj) * tj; };
+  auto t128_of = [&](int cb, int ce) { return (long long)gh_div_up(nr - cb, TM) * gh_div_up(ce - cb, TM); };
   // rank-kdim update of rows [cb, nr) x columns [cb, ce) + factorisation of the diagonal block at cb
   auto update = [&](const char* name, int cb, int ce, int kc0, int kdim, int kbn, double* minv_next) -> gh_status {
-    const long long t128 = (long long)gh_div_up(nr - cb, TM) * gh_div_up(ce - cb, TM);
     // grid = the lower tiles (see the decode in the kernel), rounded up to the 8 XCD strips, + the potf2 workgroup
-    auto lower_tiles = [](int ti, int tj) { return tj * (tj + 1) / 2 + (ti - tj) * tj; };
-    if (t128 >= 1024) {  // enough 128-tiles for 256 CUs x 2 workgroups
+    if (t128_of(cb, ce) >= 1024) {  // enough 128-tiles for 256 CUs x 2 workgroups
       const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(nr - cb, TM);
       GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, dim3(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1), dim3(256), 0,
                 A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
@@ -730,19 +915,38 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
     }
     return GH_OK;
   };
+  XCopy pend{nullptr, nr, 0, 0, 0};  // X of the last fused step, not yet in place
+  int xsel = 0;
   for (int c0 = 0; c0 < n; c0 += nbo) {
     const int pw = n - c0 < nbo ? n - c0 : nbo;  // panel width
     for (int k = c0; k < c0 + pw; k += NBI) {
       const int kb = c0 + pw - k < NBI ? c0 + pw - k : NBI;
       double* minv = dinv + (size_t)(k / NBI) * (NBI * NBI);
       const int r0 = k + kb;
-      if (r0 < nr) {
-        GH_LAUNCH(ctx, "ba_trsm", trsm_inv_kernel, dim3(gh_div_up(nr - r0, 64)), dim3(256), 0, A, lda, nr, k, kb, r0,
-                  (const double*)minv);
+      if (r0 >= nr) continue;
+      const int cb = r0, ce = c0 + pw;
+      const int ncopy = pend.src ? gh_div_up(pend.rows, 64) : 0;
+      if (xwork && kb == NBI && cb < ce && t128_of(cb, ce) < 1024) {
+        const int tiles_j = gh_div_up(ce - cb, 64), tiles_i = gh_div_up(nr - cb, 64);
+        const int ntb = 8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8);
+        double* xw = xwork + (size_t)xsel * NBI * nr;
+        GH_LAUNCH(ctx, "ba_panel_step", panel_step_kernel, dim3(1 + ntb + ncopy), dim3(256), 0, A, lda, nr, cb, ce, k,
+                  tiles_i, tiles_j, ntb, ce - cb < NBI ? ce - cb : NBI, info_dev, (const double*)minv, minv + NBI * NBI, xw,
+                  nr, pend);
+        pend = XCopy{xw, nr, k, cb, nr - cb};
+        xsel ^= 1;
+      } else {
+        const int ntrsm = gh_div_up(nr - r0, 64);
+        GH_LAUNCH(ctx, "ba_trsm", trsm_inv_kernel, dim3(ntrsm + ncopy), dim3(256), 0, A, lda, nr, k, kb, r0,
+                  (const double*)minv, ntrsm, pend);
+        pend.src = nullptr;
         // update the rest of this panel with the fresh 64 columns (+ factor the next diagonal block)
-        const int cb = r0, ce = c0 + pw;
         if (cb < ce) GH_TRY(update("ba_syrk_panel", cb, ce, k, kb, ce - cb < NBI ? ce - cb : NBI, minv + NBI * NBI));
       }
+    }
+    if (pend.src) {  // cannot happen with the schedule above (a panel ends with an in-place step); kept as a guard
+      GH_LAUNCH(ctx, "ba_trsm", xcopy_kernel, dim3(gh_div_up(pend.rows, 64)), dim3(256), 0, pend, A, lda);
+      pend.src = nullptr;
     }
     const int t0 = c0 + pw;
     if (t0 < n)
@@ -789,11 +993,12 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
   void* scratch = nullptr;
   const size_t nblk = (size_t)gh_div_up(n, NBI);
-  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI) * sizeof(double), &scratch));
+  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI + 2 * (size_t)NBI * n) * sizeof(double), &scratch));
   int* info_dev = (int*)scratch;
   double* dinv = (double*)((char*)scratch + 256);
   double* work = dinv + nblk * NBI * NBI;
-  GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv));
+  double* xwork = work + n;
+  GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (*info == 0 && b_dev) GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv));
