@@ -926,8 +926,11 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       if (r0 >= nr) continue;
       const int cb = r0, ce = c0 + pw;
       const int ncopy = pend.src ? gh_div_up(pend.rows, 64) : 0;
-      if (xwork && kb == NBI && cb < ce && t128_of(cb, ce) < 1024) {
-        const int tiles_j = gh_div_up(ce - cb, 64), tiles_i = gh_div_up(nr - cb, 64);
+      // one-launch step only while its tiles fit one wave of workgroups: their on-the-fly trsm triples the tile work,
+      // which is free behind workgroup 0's chain but not once the tiles themselves bound the launch
+      // (measured at n = 60 000 with up to ~2000 tiles per step: 165 ms against 78 ms for trsm + update)
+      const int tiles_j = gh_div_up(ce - cb, 64), tiles_i = gh_div_up(nr - cb, 64);
+      if (xwork && kb == NBI && cb < ce && lower_tiles(tiles_i, tiles_j) <= 256) {
         const int ntb = 8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8);
         double* xw = xwork + (size_t)xsel * NBI * nr;
         GH_LAUNCH(ctx, "ba_panel_step", panel_step_kernel, dim3(1 + ntb + ncopy), dim3(256), 0, A, lda, nr, cb, ce, k,
