@@ -38,10 +38,44 @@ def _all_gather_flat(out: torch.Tensor, inp: torch.Tensor):
         dist.all_gather_into_tensor(out, inp)
 
 
+class _Pending:
+    """Handle of an all-gather in flight (see exchange_features_begin)."""
+
+    def __init__(self, works, finish):
+        self.works, self.finish = works, finish
+
+    def wait(self):
+        for w in self.works:
+            w.wait()  # nccl: the CURRENT STREAM waits (the host does not block); gloo: the host waits
+        for f in self.finish:
+            f()
+        self.works, self.finish = [], []
+
+
+def _all_gather_begin(out: torch.Tensor, inp: torch.Tensor):
+    if out.is_cuda and dist.get_backend() == "gloo":  # CPU-only backend: stage through host memory
+        o = torch.empty(out.shape, dtype=out.dtype)
+        w = dist.all_gather_into_tensor(o, inp.cpu(), async_op=True)
+        return w, (lambda: out.copy_(o))
+    return dist.all_gather_into_tensor(out, inp, async_op=True), None
+
+
+def exchange_features_begin(desc: torch.Tensor, counts: torch.Tensor, g_desc: torch.Tensor, g_counts: torch.Tensor):
+    """Start the all-gather of (F,K,32) u8 descriptors and (F,) counts into (G*F,K,32) / (G*F,).  With RCCL the
+    collective runs on its own stream (ordered after the work already queued on the current one), so kernels launched
+    before .wait() -- the matching of the rank's own frame pairs -- overlap the transfer over xGMI."""
+    works, finish = [], []
+    for o, i in ((g_desc.view(-1), desc.contiguous().view(-1)), (g_counts, counts)):
+        w, f = _all_gather_begin(o, i)
+        works.append(w)
+        if f is not None:
+            finish.append(f)
+    return _Pending(works, finish)
+
+
 def exchange_features(desc: torch.Tensor, counts: torch.Tensor, g_desc: torch.Tensor, g_counts: torch.Tensor):
-    """all-gather (F,K,32) u8 descriptors and (F,) counts into (G*F,K,32) / (G*F,)."""
-    _all_gather_flat(g_desc.view(-1), desc.contiguous().view(-1))
-    _all_gather_flat(g_counts, counts)
+    """all-gather (F,K,32) u8 descriptors and (F,) counts into (G*F,K,32) / (G*F,) (blocking form)."""
+    exchange_features_begin(desc, counts, g_desc, g_counts).wait()
 
 
 def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
