@@ -109,7 +109,7 @@ def main():
     from gslam_amd import hip
     from gslam_amd.matcher import BFMatcher
     from gslam_amd.orb import OrbExtractor, synth_frames
-    from gslam_amd.sharding import exchange_features_begin, exchange_matches, local_pairs
+    from gslam_amd.sharding import exchange_features_begin, exchange_matches_begin, local_pairs
 
     ctx = hip.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     F, W, H, K = a.frames, a.width, a.height, a.kpts
@@ -136,20 +136,29 @@ def main():
     out_local = (m_idx[:n_local], m_d1[:n_local], m_d2[:n_local])
     out_rest = (m_idx[n_local:], m_d1[n_local:], m_d2[n_local:])
 
+    match_gather = [None]  # all-gather of the previous step's match rows, still in flight during the next extraction
+
+    def finish_match_gather():
+        if match_gather[0] is not None:
+            match_gather[0].wait()
+            match_gather[0] = None
+
     def step():
         ex.extract(frames, (kps, desc, counts))
         if world > 1:
             pending = exchange_features_begin(desc, counts, g_desc, g_counts)
+            finish_match_gather()  # g_match of the previous step complete before anything of this step replaces it
             if n_local > 0:
                 matcher.match_pairs(desc, counts, lq, lt, out=out_local)
             pending.wait()
             if P > n_local:  # the boundary pair against the next rank's first frame
                 matcher.match_pairs(g_desc, g_counts, pq[n_local:], pt[n_local:], out=out_rest)
-            exchange_matches(m_idx, g_match, F)
+            match_gather[0] = exchange_matches_begin(m_idx, g_match, F)
         else:
             matcher.match_pairs(g_desc, g_counts, pq, pt, out=(m_idx, m_d1, m_d2))
 
     def barrier():
+        finish_match_gather()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -172,6 +181,7 @@ def main():
         ref = matcher.match_pairs(g_desc, g_counts, pq, pt)
         torch.cuda.synchronize()
         assert torch.equal(ref[0], m_idx) and torch.equal(ref[1], m_d1) and torch.equal(ref[2], m_d2), "overlap mismatch"
+        assert torch.equal(g_match[rank, :P], m_idx) and bool((g_match[rank, P:] == -1).all()), "match gather mismatch"
         log(f"rank {rank}: overlapped matching verified against the plain call ({P} pairs)")
     if world > 1:
         cdev = torch.device("cpu") if dry else dev

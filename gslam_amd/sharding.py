@@ -78,12 +78,21 @@ def exchange_features(desc: torch.Tensor, counts: torch.Tensor, g_desc: torch.Te
     exchange_features_begin(desc, counts, g_desc, g_counts).wait()
 
 
-def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
-    """all-gather per-rank (F,K) int32 match rows into (G,F,K); ranks with fewer than F pairs pad with -1."""
+def exchange_matches_begin(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
+    """Start the all-gather of per-rank (P,K) int32 match rows into (G,F,K); ranks with fewer than F pairs pad with -1.
+    The send buffer is a private copy, so the caller may overwrite idx1 (next step) while the transfer is in flight."""
     P, K = idx1.shape
     if P < frames_per_rank:
         pad = torch.full((frames_per_rank - P, K), -1, dtype=idx1.dtype, device=idx1.device)
         send = torch.cat([idx1, pad])
     else:
-        send = idx1
-    _all_gather_flat(g_idx1.view(-1), send.contiguous().view(-1))
+        send = idx1.clone()
+    w, f = _all_gather_begin(g_idx1.view(-1), send.contiguous().view(-1))
+    p = _Pending([w], [f] if f is not None else [])
+    p.keepalive = send
+    return p
+
+
+def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
+    """Blocking form of exchange_matches_begin."""
+    exchange_matches_begin(idx1, g_idx1, frames_per_rank).wait()
