@@ -24,7 +24,7 @@ def _free_port():
 
 def _worker(rank, world, port, F, K, out_dir):
     import oracle_lib
-    from gslam_amd.sharding import exchange_features, exchange_matches, local_pairs
+    from gslam_amd.sharding import exchange_features_begin, exchange_matches_begin, local_pairs
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,17 +38,27 @@ def _worker(rank, world, port, F, K, out_dir):
         counts[f] = n
     g_desc = torch.empty((world * F, K, 32), dtype=torch.uint8)
     g_counts = torch.empty(world * F, dtype=torch.int32)
-    exchange_features(desc, counts, g_desc, g_counts)
+    # the schedule bench.py uses: start the gather, match the purely local pairs from the LOCAL buffers while it is in
+    # flight, wait, then the boundary pair from the gathered buffers; the match rows travel asynchronously too
+    pending = exchange_features_begin(desc, counts, g_desc, g_counts)
     pq, pt = local_pairs(rank, world, F)
     oracle = oracle_lib.load()
     idx1 = torch.full((pq.numel(), K), -1, dtype=torch.int32)
-    for p in range(pq.numel()):
+    n_local = min(F - 1, pq.numel())
+    for p in range(n_local):
+        na, nb = int(counts[p]), int(counts[p + 1])
+        e = oracle.bf_match(desc[p, :na].numpy(), desc[p + 1, :nb].numpy())
+        idx1[p, :na] = torch.from_numpy(e[0])
+    pending.wait()
+    for p in range(n_local, pq.numel()):
         a, b = int(pq[p]), int(pt[p])
         na, nb = int(g_counts[a]), int(g_counts[b])
         e = oracle.bf_match(g_desc[a, :na].numpy(), g_desc[b, :nb].numpy())
         idx1[p, :na] = torch.from_numpy(e[0])
     g_idx = torch.empty((world, F, K), dtype=torch.int32)
-    exchange_matches(idx1, g_idx, F)
+    mg = exchange_matches_begin(idx1, g_idx, F)
+    idx1.fill_(-7)  # the send buffer is a private copy: the caller may reuse idx1 at once
+    mg.wait()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), g_desc=g_desc.numpy(), g_counts=g_counts.numpy(),
              g_idx=g_idx.numpy(), pq=pq.numpy())
     dist.destroy_process_group()
