@@ -64,7 +64,8 @@ def test_pyramid_parity(ctx, oracle):
     ex.close()
 
 
-@pytest.mark.parametrize("w,h,K", [(640, 480, 1000), (752, 480, 1500), (333, 257, 300)])
+@pytest.mark.parametrize("w,h,K", [(640, 480, 1000), (752, 480, 1500), (333, 257, 300), (1023, 577, 1200),
+                                   (517, 389, 500), (2047, 129, 400), (131, 1029, 400)])
 def test_extract_parity_batch(ctx, oracle, w, h, K):
     frames = np.stack([oracle.synth_frame(w, h, 0x5EED0000 + i) for i in range(4)])
     got = _extract_gpu(ctx, frames, K)
