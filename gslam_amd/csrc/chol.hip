@@ -947,7 +947,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
         if (cb < ce) GH_TRY(update("ba_syrk_panel", cb, ce, k, kb, ce - cb < NBI ? ce - cb : NBI, minv + NBI * NBI));
       }
     }
-    if (pend.src) {  // cannot happen with the schedule above (a panel ends with an in-place step); kept as a guard
+    if (pend.src) {  // the panel's last block had no rows below it (n a multiple of 64, no extra row): nobody copied yet
       GH_LAUNCH(ctx, "ba_trsm", xcopy_kernel, dim3(gh_div_up(pend.rows, 64)), dim3(256), 0, pend, A, lda);
       pend.src = nullptr;
     }

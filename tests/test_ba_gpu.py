@@ -92,7 +92,7 @@ def test_ba_deterministic_mode_is_bitwise_reproducible(ctx):
     assert [a[2].trace_cost[i] for i in range(a[2].trace_len)] == [b[2].trace_cost[i] for i in range(b[2].trace_len)]
 
 
-@pytest.mark.parametrize("n", [1, 6, 64, 70, 200, 300, 777, 1500])
+@pytest.mark.parametrize("n", [1, 6, 64, 70, 128, 200, 256, 257, 300, 320, 512, 777, 1024, 1500])
 def test_potrf_solve_vs_numpy(ctx, n):
     from gslam_amd import ba
     rng = np.random.default_rng(n)
