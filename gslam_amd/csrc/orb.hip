@@ -269,16 +269,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
           // bytes (2h, 2h+1) -> two zero-extended 16-bit lanes
           const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u;
           const s16x2 c = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wc, sel));
-          const s16x2 du = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wu, sel)) - c;
-          const s16x2 dd = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wd, sel)) - c;
-          const s16x2 dl = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, left4, sel)) - c;
-          const s16x2 dr = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, right4, sel)) - c;
+          const s16x2 pu = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wu, sel));
+          const s16x2 pd = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wd, sel));
+          const s16x2 pl = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, left4, sel));
+          const s16x2 pr = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, right4, sel));
           // every adjacent compass pair holds one vertical (up/down) and one horizontal (left/right) pixel, so
-          // "some adjacent pair both brighter" == max(up, down) > t && max(left, right) > t  (3 ops instead of 7)
-          const s16x2 bright = __builtin_elementwise_min(__builtin_elementwise_max(du, dd), __builtin_elementwise_max(dl, dr));
-          const s16x2 dark = __builtin_elementwise_max(__builtin_elementwise_min(du, dd), __builtin_elementwise_min(dl, dr));
-          // sign bits: (t - bright) < 0  <=>  bright > t ;  (dark + t) < 0  <=>  dark < -t
-          const uint32_t e = __builtin_bit_cast(uint32_t, T - bright) | __builtin_bit_cast(uint32_t, dark + T);
+          // "some adjacent pair both brighter than c + t" == min(max(up, down), max(left, right)) > c + t, evaluated on
+          // the raw intensities (min / max commute with subtracting c: no per-pixel differences); likewise for darker
+          const s16x2 bright = __builtin_elementwise_min(__builtin_elementwise_max(pu, pd), __builtin_elementwise_max(pl, pr));
+          const s16x2 dark = __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pl, pr));
+          // sign bits: (c + t) - bright < 0  <=>  bright > c + t ;  dark - (c - t) < 0  <=>  dark < c - t
+          const uint32_t e = __builtin_bit_cast(uint32_t, (c + T) - bright) | __builtin_bit_cast(uint32_t, dark - (c - T));
           mask |= (((e >> 15) & 1u) | ((e >> 30) & 2u)) << (2 * h);
         }
         // keep only pixels inside the 66-wide window and the valid image region: window cols [sx_lo, sx_hi)
