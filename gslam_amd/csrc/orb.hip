@@ -797,10 +797,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   uint8_t* drow = desc + ((size_t)b * K + pos) * 32;
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
-    const uint32_t pw = pat[gq * 64 + lane];
-    const int ax = (int8_t)(pw & 0xFF), ay = (int8_t)((pw >> 8) & 0xFF);
-    const int bx = (int8_t)((pw >> 16) & 0xFF), by = (int8_t)(pw >> 24);
-    const int va = bl[(13 + ay) * kBlurPitch + 13 + ax], vb = bl[(13 + by) * kBlurPitch + 13 + bx];
+    const uint32_t pw = pat[gq * 64 + lane];  // byte offsets of the two sample points in the blurred patch
+    const int va = bl[pw & 0xFFFFu], vb = bl[pw >> 16];
     const uint64_t bits = __ballot(va < vb);
     if (lane == 0) *reinterpret_cast<uint64_t*>(drow + 8 * gq) = bits;
   }
@@ -1003,7 +1001,20 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
       break;
     }
     if ((st = gh_dev_upload(ctx, p->tabs, htab.data(), htab.size() * sizeof(uint32_t))) != GH_OK) break;
-    if ((st = gh_dev_upload(ctx, p->d_pattern, GH_ORB_PATTERN, sizeof(GH_ORB_PATTERN))) != GH_OK) break;
+    {
+      // the device copy of the test pattern holds, per (bin, test), the two byte offsets into the 27 x 28 blurred patch
+      // ((13 + y) * kBlurPitch + 13 + x as two u16) instead of the four int8 coordinates: saves the sign extensions
+      // and address arithmetic of 256 tests per keypoint
+      static_assert(sizeof(GH_ORB_PATTERN) == 30 * 256 * 4, "pattern table layout");
+      std::vector<uint32_t> off(30 * 256);
+      for (int b = 0; b < 30; ++b)
+        for (int t = 0; t < 256; ++t) {
+          const int8_t* q = GH_ORB_PATTERN[b][t];
+          const uint32_t oa = (uint32_t)((13 + q[1]) * kBlurPitch + 13 + q[0]), ob = (uint32_t)((13 + q[3]) * kBlurPitch + 13 + q[2]);
+          off[b * 256 + t] = oa | (ob << 16);
+        }
+      if ((st = gh_dev_upload(ctx, p->d_pattern, off.data(), off.size() * sizeof(uint32_t))) != GH_OK) break;
+    }
     if ((st = gh_dev_upload(ctx, p->d_dir, GH_ORB_DIR, sizeof(GH_ORB_DIR))) != GH_OK) break;
   } while (0);
   if (st != GH_OK) {
