@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
         const uint32_t wu = tile32[trow - 3 * kRowDw + m], wd = tile32[trow + 3 * kRowDw + m];
         const uint32_t left4 = __builtin_amdgcn_alignbyte(wc, wl, 1);   // cols 4m-3 .. 4m
         const uint32_t right4 = __builtin_amdgcn_alignbyte(wr, wc, 3);  // cols 4m+3 .. 4m+6
-        uint32_t mask = 0;
+        uint32_t eh[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           // bytes (2h, 2h+1) -> two zero-extended 16-bit lanes
@@ -280,8 +280,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
           const s16x2 dark = __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pl, pr));
           // sign bits: (c + t) - bright < 0  <=>  bright > c + t ;  dark - (c - t) < 0  <=>  dark < c - t
           const uint32_t e = __builtin_bit_cast(uint32_t, (c + T) - bright) | __builtin_bit_cast(uint32_t, dark - (c - T));
-          mask |= (((e >> 15) & 1u) | ((e >> 30) & 2u)) << (2 * h);
+          eh[h] = e;
         }
+        // the four sign bits (bit 15 / 31 of eh[0], eh[1]) -> a nibble: high bytes picked by one v_perm, flags gathered
+        // by one v_dot4_u32_u8 with weights 1, 2, 4, 8
+        const uint32_t mask = __builtin_amdgcn_udot4((__builtin_amdgcn_perm(eh[1], eh[0], 0x07050301u) >> 7) & 0x01010101u,
+                                                     0x08040201u, 0u, false);
         // keep only pixels inside the 66-wide window and the valid image region: window cols [sx_lo, sx_hi)
         if (interior) {
           // whole window valid: only the dwords that stick out of it are trimmed (m = 4: window cols -2, -1; m = 21: 66 .. 69)
