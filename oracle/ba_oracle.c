@@ -475,3 +475,38 @@ double oracle_ba_cost(int nc, int np, int no, const double* poses, const double*
   ba_ctx c = {nc, np, no, NULL, NULL, ocam, opt, oxy, oinfo, huber};
   return total_cost(&c, poses, pts);
 }
+
+/* Exposes the per-observation linearisation to the tests (finite-difference Jacobian check, scipy cross-check). */
+int oracle_ba_obs_linearize(const double* pose, int dof, const double* X, int pfree, const double* m,
+                            const double* info, double huber, double* r, double* wgt, double* Jc, double* Jp,
+                            double* s_out) {
+  return obs_linearize(pose, dof, X, pfree, m, info, huber, r, wgt, Jc, Jp, s_out);
+}
+
+/* Pose-only (motion-only) BA behind GSLAM::Optimizer::optimizePnP (GSLAM/core/Optimizer.h:202-207): the same LM on a
+ * 1-camera graph whose points are all fixed; information_out (may be NULL) = J^T W J at the solution, row-major 6x6,
+ * W = Huber IRLS weight, columns masked by dof.  pose in/out [qx qy qz qw tx ty tz]. */
+int oracle_ba_pnp(const double* points_xyz, const double* obs_xy, int n, double* pose, int dof,
+                  const oracle_ba_options* opt, double* information_out, oracle_ba_summary* sum) {
+  int nn = n > 0 ? n : 1;
+  int32_t* ocam = (int32_t*)calloc((size_t)nn, sizeof(int32_t));
+  int32_t* opt_idx = (int32_t*)malloc((size_t)nn * sizeof(int32_t));
+  uint8_t* pfree = (uint8_t*)calloc((size_t)nn, 1);
+  double* pts = (double*)malloc((size_t)nn * 3 * 8);
+  memcpy(pts, points_xyz, (size_t)n * 3 * 8);
+  for (int i = 0; i < n; ++i) opt_idx[i] = i;
+  int32_t d = dof;
+  int rc = oracle_ba_solve(1, n, n, pose, &d, pts, pfree, ocam, opt_idx, obs_xy, NULL, opt, sum, 1);
+  if (information_out) {
+    memset(information_out, 0, 36 * 8);
+    for (int k = 0; k < n; ++k) {
+      double r[2], w, s, Jc[12], Jp[6];
+      if (!obs_linearize(pose, dof, points_xyz + 3 * k, 0, obs_xy + 2 * k, NULL, opt->huber_delta, r, &w, Jc, Jp, &s))
+        continue;
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) information_out[6 * a + b] += w * (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+    }
+  }
+  free(ocam); free(opt_idx); free(pfree); free(pts);
+  return rc;
+}

@@ -288,7 +288,19 @@ def _ba_methods(cls):
             self.lib.oracle_potrs(_ptr(A), A.shape[0], _ptr(b))
         return np.tril(A), b, info
 
-    for f in (ba_solve, ba_cost, se3_exp, se3_retract, potrf_solve):
+    def ba_pnp(self, points_xyz, obs_xy, pose, dof=63, opts=None, want_information=False):
+        """Motion-only BA (GSLAM::Optimizer::optimizePnP, Optimizer.h:202-207).  Returns (pose, summary, info, rc)."""
+        opts = opts or ba_options()
+        X = np.ascontiguousarray(points_xyz, dtype=np.float64)
+        m = np.ascontiguousarray(obs_xy, dtype=np.float64)
+        p = np.ascontiguousarray(pose, dtype=np.float64).copy()
+        info = np.zeros(36) if want_information else None
+        s = BaSummary()
+        self.lib.oracle_ba_pnp.restype = C.c_int
+        rc = self.lib.oracle_ba_pnp(_ptr(X), _ptr(m), len(X), _ptr(p), int(dof), C.byref(opts), _ptr(info), C.byref(s))
+        return p, s, (info.reshape(6, 6) if want_information else None), rc
+
+    for f in (ba_solve, ba_cost, se3_exp, se3_retract, potrf_solve, ba_pnp):
         setattr(cls, f.__name__, f)
 
 
