@@ -561,10 +561,13 @@ __global__ __launch_bounds__(256) void eval_kernel(Problem P, const double* __re
     const int ci = P.ocam[k], pi = P.opt[k];
     const double* info = P.oinfo ? P.oinfo + 4 * k : nullptr;
     Obs o;
-    if (linearize<false>(poses_eval + 7 * ci, 0, pts_eval + 3 * pi, 0, P.oxy + 2 * k, info, P.huber, o)) {
-      cost = (P.huber > 0 && o.s > P.huber * P.huber) ? 2.0 * P.huber * sqrt(o.s) - P.huber * P.huber : o.s;
-    }
-    if (with_model && lin_obs(P, k, o, true)) {
+    const bool in_front = linearize<false>(poses_eval + 7 * ci, 0, pts_eval + 3 * pi, 0, P.oxy + 2 * k, info, P.huber, o);
+    if (in_front) cost = (P.huber > 0 && o.s > P.huber * P.huber) ? 2.0 * P.huber * sqrt(o.s) - P.huber * P.huber : o.s;
+    const bool was_in_front = with_model && lin_obs(P, k, o, true);
+    // a candidate that moves a valid observation behind its camera would drop it from the sum and LOWER the cost:
+    // infinite cost instead, so the LM loop rejects the step (same rule in oracle/ba_oracle.c)
+    if (was_in_front && !in_front) cost = __builtin_inf();
+    if (was_in_front) {
       double L[4];
       weighted_info(info, o.w, L);
       double Jd[2] = {0, 0};
@@ -800,6 +803,7 @@ extern "C" void gh_ba_default_options(gh_ba_options* o) {
 extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_options* opt_in,
                                  gh_ba_summary* sum_out) {
   if (!ctx || !pr) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   gh_ba_options opt;
   gh_ba_default_options(&opt);
   if (opt_in) opt = *opt_in;
@@ -1060,6 +1064,7 @@ extern "C" gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const doub
                                int dof, const gh_ba_options* options, double* information_out,
                                gh_ba_summary* summary) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, n >= 0 && pose && (n == 0 || (points_xyz && obs_xy)));
   std::vector<int32_t> ocam((size_t)(n > 0 ? n : 1), 0), opt((size_t)(n > 0 ? n : 1));
   std::vector<uint8_t> pfree((size_t)(n > 0 ? n : 1), 0);

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t* out, int iter
 extern "C" gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
                                      int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535);
   if (nq == 0) return GH_OK;
   GH_CHECK_ARG(ctx, q_dev && idx1_dev && d1_dev && d2_dev && (nt == 0 || t_dev));
@@ -245,6 +246,7 @@ extern "C" gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, 
 extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx1,
                                       uint16_t* d1, uint16_t* d2) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535);
   if (nq == 0) return GH_OK;
   size_t qb = (size_t)nq * 32, tb = (size_t)nt * 32;
@@ -276,6 +278,7 @@ extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev,
                                            const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
                                            int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, cap >= 0 && cap <= 65535 && npairs >= 0);
   if (npairs == 0 || cap == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc_dev && counts_dev && pair_q_dev && pair_t_dev && idx1_dev && d1_dev && d2_dev);
@@ -297,6 +300,7 @@ extern "C" gh_status gh_bf_match_band_pairs_dev(gh_ctx* ctx, const uint8_t* desc
                                                 const int32_t* pair_t_dev, int npairs, float band_per_size,
                                                 int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, cap >= 0 && cap <= 65535 && npairs >= 0 && band_per_size >= 0.f);
   if (npairs == 0 || cap == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc_dev && kps_dev && counts_dev && pair_q_dev && pair_t_dev && idx1_dev && d1_dev && d2_dev);
@@ -315,6 +319,7 @@ extern "C" gh_status gh_match_mask_dev(gh_ctx* ctx, const int32_t* idx1_dev, con
                                        int max_dist, int ratio_num, int ratio_den, int cross_check,
                                        uint8_t* keep_dev) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0);
   if (nq == 0) return GH_OK;
   GH_CHECK_ARG(ctx, idx1_dev && d1_dev && d2_dev && keep_dev && (!cross_check || back_idx1_dev));
@@ -325,6 +330,7 @@ extern "C" gh_status gh_match_mask_dev(gh_ctx* ctx, const int32_t* idx1_dev, con
 
 extern "C" gh_status gh_bf_valu_probe(gh_ctx* ctx, double* pairs_per_s) {
   if (!ctx || !pairs_per_s) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   void* out = nullptr;
   GH_TRY(gh_scratch(ctx, 256, &out));
   const int iters = 4096, blocks = 256 * 16;

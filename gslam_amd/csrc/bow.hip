@@ -183,6 +183,7 @@ struct gh_bow_vocab {
 extern "C" gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
                                          const void* nodes, const uint8_t* node_desc, gh_bow_vocab** out) {
   if (!ctx || !out) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   *out = nullptr;
   GH_CHECK_ARG(ctx, k >= 2 && L >= 1 && nnodes >= 1 && nodes && node_desc);
   GH_CHECK_ARG(ctx, weighting >= 0 && weighting <= 3 && scoring >= 0 && scoring <= 5);
@@ -208,6 +209,7 @@ extern "C" gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weightin
 
 extern "C" void gh_bow_vocab_destroy(gh_bow_vocab* v) {
   if (!v) return;
+  GH_ENTER(v->ctx);
   hipStreamSynchronize(v->ctx->stream);
   hipFree(v->d_nodes);
   hipFree(v->d_desc);
@@ -220,7 +222,8 @@ extern "C" gh_status gh_bow_transform_dev(gh_bow_vocab* v, const uint8_t* desc_d
                                           int32_t* bow_n_dev) {
   if (!v) return GH_ERR_ARG;
   gh_ctx* ctx = v->ctx;
-  GH_CHECK_ARG(ctx, cap >= 0 && cap <= 8192 && n_images >= 0 && n_images <= 65535);
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, cap >= 0 && cap <= 16384 && n_images >= 0 && n_images <= 65535);
   if (cap == 0 || n_images == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc_dev && word_dev && weight_dev && node_dev && bow_word_dev && bow_val_dev && bow_n_dev);
   GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 15) == 0);
@@ -229,6 +232,11 @@ extern "C" gh_status gh_bow_transform_dev(gh_bow_vocab* v, const uint8_t* desc_d
             node_dev);
   int P = 256;
   while (P < cap) P <<= 1;
+  if ((size_t)P * 8 > 48 * 1024) {
+    // more than the default dynamic-LDS allowance: a gfx950 workgroup may take all 160 KB of its CU (P = 16384: 128 KB)
+    GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(bow_assemble_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+  }
   GH_LAUNCH(ctx, "bow_assemble", bow_assemble_kernel, dim3(n_images), dim3(256), (size_t)P * 8, v->d_nodes, v->weighting,
             v->scoring, word_dev, weight_dev, cap, P, bow_word_dev, bow_val_dev, bow_n_dev);
   return GH_OK;
@@ -239,7 +247,8 @@ extern "C" gh_status gh_bow_transform_host(gh_bow_vocab* v, const uint8_t* desc,
                                            int32_t* bow_n) {
   if (!v) return GH_ERR_ARG;
   gh_ctx* ctx = v->ctx;
-  GH_CHECK_ARG(ctx, n >= 0 && n <= 8192 && bow_n);
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, n >= 0 && n <= 16384 && bow_n);
   *bow_n = 0;
   if (n == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc && word && weight && node && bow_word && bow_val);

@@ -993,6 +993,7 @@ gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double
 
 extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
   void* scratch = nullptr;
   const size_t nblk = (size_t)gh_div_up(n, NBI);

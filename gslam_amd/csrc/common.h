@@ -35,9 +35,20 @@ struct gh_ctx {
   // grow-only arena reused by successive gh_ba_solve calls (local BA runs every keyframe: no malloc/free per call)
   void* ba_arena = nullptr;
   size_t ba_arena_bytes = 0;
-  std::mutex mu;
+  // every public entry point holds this for its whole call (GH_ENTER): a ctx shared by several Messenger worker threads
+  // serialises on it; recursive because gh_ba_pnp calls gh_ba_solve
+  std::recursive_mutex mu;
   int cu_count = 0;
 };
+
+// Entry guard of every public function that touches the device: serialises callers that share the context and makes the
+// context's GPU the calling thread's current device (a ctx may be created on one thread and used on another, and a
+// process may hold contexts for several GPUs; allocations, copies and launches below all go to the CURRENT device).
+struct gh_enter_guard {
+  std::lock_guard<std::recursive_mutex> lock;
+  explicit gh_enter_guard(gh_ctx* c) : lock(c->mu) { (void)hipSetDevice(c->device); }
+};
+#define GH_ENTER(ctx) gh_enter_guard _gh_enter_guard(ctx)
 
 gh_status gh_set_error(gh_ctx* ctx, gh_status st, const char* fmt, ...);
 gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out);

@@ -55,12 +55,14 @@ extern "C" const char* gh_last_error(const gh_ctx* ctx) { return ctx ? ctx->last
 
 extern "C" gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   ctx->stream = (hipStream_t)hip_stream;
   return GH_OK;
 }
 
 extern "C" gh_status gh_ctx_use_own_stream(gh_ctx* ctx) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   ctx->stream = ctx->own_stream;
   return GH_OK;
 }
@@ -69,6 +71,7 @@ extern "C" void* gh_ctx_stream(gh_ctx* ctx) { return ctx ? (void*)ctx->stream : 
 
 extern "C" gh_status gh_ctx_sync(gh_ctx* ctx) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return GH_OK;
 }
@@ -76,6 +79,7 @@ extern "C" gh_status gh_ctx_sync(gh_ctx* ctx) {
 extern "C" gh_status gh_device_info(gh_ctx* ctx, int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name,
                                     int name_cap) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   hipDeviceProp_t prop;
   GH_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
   if (cu_count) *cu_count = prop.multiProcessorCount;
@@ -89,6 +93,7 @@ extern "C" gh_status gh_device_info(gh_ctx* ctx, int* cu_count, int* clock_khz, 
 
 extern "C" gh_status gh_dev_alloc(gh_ctx* ctx, size_t bytes, void** out_dev) {
   if (!ctx || !out_dev) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_HIP(ctx, hipSetDevice(ctx->device));
   hipError_t e = hipMalloc(out_dev, bytes ? bytes : 1);
   if (e != hipSuccess) return gh_set_error(ctx, GH_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
@@ -97,12 +102,14 @@ extern "C" gh_status gh_dev_alloc(gh_ctx* ctx, size_t bytes, void** out_dev) {
 
 extern "C" gh_status gh_dev_free(gh_ctx* ctx, void* dev) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   if (dev) GH_HIP(ctx, hipFree(dev));
   return GH_OK;
 }
 
 extern "C" gh_status gh_dev_upload(gh_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   if (bytes == 0) return GH_OK;
   GH_CHECK_ARG(ctx, dst_dev && src_host);
   GH_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -112,6 +119,7 @@ extern "C" gh_status gh_dev_upload(gh_ctx* ctx, void* dst_dev, const void* src_h
 
 extern "C" gh_status gh_dev_download(gh_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   if (bytes == 0) return GH_OK;
   GH_CHECK_ARG(ctx, dst_host && src_dev);
   GH_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -121,6 +129,7 @@ extern "C" gh_status gh_dev_download(gh_ctx* ctx, void* dst_host, const void* sr
 
 extern "C" gh_status gh_dev_memset(gh_ctx* ctx, void* dst_dev, int value, size_t bytes) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   if (bytes == 0) return GH_OK;
   GH_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
   return GH_OK;
@@ -216,6 +225,7 @@ void gh_prof_end(gh_ctx* ctx, int pending) {
 
 extern "C" gh_status gh_prof_enable(gh_ctx* ctx, int on) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   resolve_pending(ctx);
   if (on) ctx->prof_entries.clear();
   ctx->prof_on = on != 0;
@@ -224,6 +234,7 @@ extern "C" gh_status gh_prof_enable(gh_ctx* ctx, int on) {
 
 extern "C" gh_status gh_prof_collect(gh_ctx* ctx, gh_prof_entry* out, int cap, int* n) {
   if (!ctx || !n) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   resolve_pending(ctx);
   int m = (int)ctx->prof_entries.size();
   if (m > cap) m = cap;

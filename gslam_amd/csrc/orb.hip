@@ -884,6 +884,7 @@ static gh_status plan_alloc(gh_orb_plan* p, size_t bytes, void** out) {
 extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   if (!p) return;
   gh_ctx* c = p->ctx;
+  GH_ENTER(c);
   hipStreamSynchronize(c->stream);
   void* ptrs[] = {p->pyr, p->cell_cnt, p->cell_ent, p->sel, p->level_cnt, p->d_pattern, p->d_dir, p->tabs,
                   p->stage_img, p->stage_out};
@@ -896,6 +897,7 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
 extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
                                         const gh_orb_params* params, gh_orb_plan** out) {
   if (!ctx || !out) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   *out = nullptr;
   gh_orb_params prm;
   gh_orb_default_params(&prm);
@@ -1044,6 +1046,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
                                         int32_t* counts_dev) {
   if (!p) return GH_ERR_ARG;
   gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, batch >= 0 && batch <= p->max_batch);
   if (batch == 0) return GH_OK;
   GH_CHECK_ARG(ctx, gray_dev && kps_dev && desc_dev && counts_dev && row_stride >= p->w);
@@ -1052,7 +1055,11 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   const int L = p->L, K = p->prm.n_features;
 
   LevelView lv[kMaxL];
-  const bool aligned0 = ((uintptr_t)gray_dev & 15) == 0 && (row_stride & 15) == 0 && (frame_stride & 15) == 0;
+  // zero-copy level 0 reads whole 16-byte windows of every padded row, the last row included, so it needs the full
+  // row_stride * h bytes of every frame to be readable; a single frame handed over with a smaller frame_stride (an ROI
+  // view whose allocation ends at (h-1) * row_stride + w) is staged through the plan's own level-0 slab instead
+  const bool aligned0 = ((uintptr_t)gray_dev & 15) == 0 && (row_stride & 15) == 0 && (frame_stride & 15) == 0 &&
+                        frame_stride >= (size_t)row_stride * p->h;
   if (aligned0) {
     lv[0] = {gray_dev, frame_stride, row_stride, p->w, p->h};
   } else {
@@ -1117,6 +1124,7 @@ extern "C" gh_status gh_orb_extract_host(gh_orb_plan* p, const uint8_t* gray, in
                                          uint8_t* desc, int32_t* count) {
   if (!p) return GH_ERR_ARG;
   gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, gray && kps && desc && count && row_stride >= p->w);
   const int K = p->prm.n_features;
   // result block: [count, pad to 256 B][K keypoints, padded to 256 B][K descriptors]
@@ -1140,7 +1148,8 @@ extern "C" gh_status gh_orb_extract_host(gh_orb_plan* p, const uint8_t* gray, in
       return gh_set_error(ctx, GH_ERR_NOMEM, "hipHostMalloc(%zu) for the result staging block failed", out_bytes);
     }
   }
-  GH_HIP(ctx, hipMemcpyAsync(p->stage_img, gray, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  // the caller's last row may end at its last pixel (ROI view): never read the padding behind it
+  GH_HIP(ctx, hipMemcpyAsync(p->stage_img, gray, (size_t)row_stride * (p->h - 1) + p->w, hipMemcpyHostToDevice, ctx->stream));
   GH_TRY(gh_orb_extract_dev(p, p->stage_img, 1, img_bytes, row_stride, reinterpret_cast<gh_keypoint*>(p->stage_out + off_kps),
                             p->stage_out + off_desc, reinterpret_cast<int32_t*>(p->stage_out)));
   GH_HIP(ctx, hipMemcpyAsync(p->stage_host, p->stage_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1154,6 +1163,7 @@ extern "C" gh_status gh_orb_extract_host(gh_orb_plan* p, const uint8_t* gray, in
 extern "C" gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
                                         int src_row_stride, uint8_t* gray_dev, int dst_row_stride) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, bgr_dev && gray_dev && width > 0 && height > 0 && (channels == 3 || channels == 4));
   GH_CHECK_ARG(ctx, src_row_stride >= width * channels && dst_row_stride >= width);
   GH_LAUNCH(ctx, "bgr_to_gray", bgr_to_gray_kernel, dim3(gh_div_up(width, 256), height), dim3(256), 0, bgr_dev, width,
@@ -1164,6 +1174,7 @@ extern "C" gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int
 extern "C" gh_status gh_orb_debug_level(gh_orb_plan* p, int slot, int level, uint8_t* out_host) {
   if (!p) return GH_ERR_ARG;
   gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, slot >= 0 && slot < p->max_batch && level >= 1 && level < p->L && out_host);
   GH_HIP(ctx, hipMemcpy2DAsync(out_host, p->lw[level], p->pyr + (size_t)slot * p->slab + p->lvl_off[level],
                                p->pitch[level], p->lw[level], p->lh[level], hipMemcpyDeviceToHost, ctx->stream));

@@ -313,6 +313,7 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
                                         double threshold, uint64_t seed, double* model_out, uint8_t* mask_out,
                                         int* inliers_out) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, model >= 0 && model <= 3 && src && dst && model_out && inliers_out && threshold >= 0);
   const int dim = model == kModelA3 ? 3 : 2;
   const int s = model == kModelH ? 4 : (model == kModelA2 ? 3 : (model == kModelF ? 8 : 4));

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ out, i
 extern "C" gh_status gh_synth_frames_dev(gh_ctx* ctx, uint8_t* gray_dev, int width, int height, int row_stride,
                                          size_t frame_stride, int first_frame, int n_frames, uint32_t base_seed) {
   if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, gray_dev && width > 0 && height > 0 && row_stride >= width && n_frames >= 0);
   if (n_frames == 0) return GH_OK;
   GH_CHECK_ARG(ctx, frame_stride >= (size_t)row_stride * height);

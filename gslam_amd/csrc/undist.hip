@@ -63,6 +63,7 @@ extern "C" gh_status gh_undist_plan_create(gh_ctx* ctx, int w_in, int h_in, int 
                                            const float* remapX, const int32_t* remapFast, const int32_t* remapIdx,
                                            const float* remapCoef, gh_undist_plan** out) {
   if (!ctx || !out) return GH_ERR_ARG;
+  GH_ENTER(ctx);
   *out = nullptr;
   GH_CHECK_ARG(ctx, w_in > 0 && h_in > 0 && w_out > 0 && h_out > 0 && remapX && remapFast && remapIdx && remapCoef);
   const size_t n = (size_t)w_out * h_out, n_in = (size_t)w_in * h_in;
@@ -100,6 +101,7 @@ extern "C" gh_status gh_undist_plan_create(gh_ctx* ctx, int w_in, int h_in, int 
 
 extern "C" void gh_undist_plan_destroy(gh_undist_plan* p) {
   if (!p) return;
+  GH_ENTER(p->ctx);
   hipStreamSynchronize(p->ctx->stream);
   hipFree(p->d_remapX);
   hipFree(p->d_fast);
@@ -112,6 +114,7 @@ extern "C" gh_status gh_undistort_dev(gh_undist_plan* p, const uint8_t* img_dev,
                                       size_t in_frame_stride, uint8_t* out_dev, size_t out_frame_stride, int fast) {
   if (!p) return GH_ERR_ARG;
   gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, img_dev && out_dev && batch >= 0 && batch <= 65535 && (channels == 1 || channels == 3 || channels == 4));
   GH_CHECK_ARG(ctx, fast || channels != 4);  // the reference's bilinear path is only defined for 1 and 3 channels
   if (batch == 0) return GH_OK;
@@ -133,6 +136,7 @@ extern "C" gh_status gh_undistort_dev(gh_undist_plan* p, const uint8_t* img_dev,
 extern "C" gh_status gh_undistort_host(gh_undist_plan* p, const uint8_t* img, int channels, uint8_t* out, int fast) {
   if (!p) return GH_ERR_ARG;
   gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, img && out && (channels == 1 || channels == 3 || channels == 4));
   const size_t nin = (size_t)p->w_in * p->h_in * channels, nout = (size_t)p->w_out * p->h_out * channels;
   void* s = nullptr;

@@ -16,7 +16,7 @@ namespace {
 
 class FeatureDetectorHIP : public GSLAM::FeatureDetector {
  public:
-  FeatureDetectorHIP() : ctx_(nullptr), plan_(nullptr), pw_(0), ph_(0), pk_(0), pl_(0) {}
+  FeatureDetectorHIP() : ctx_(nullptr), plan_(nullptr), pw_(0), ph_(0), pk_(0), pl_(0), pi_(0), pm_(0) {}
   ~FeatureDetectorHIP() override {
     if (plan_) gh_orb_plan_destroy(plan_);
     free_device_buffers();
@@ -29,7 +29,8 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
     if (image.empty() || image.elemSize1() != 1 || !context()) return false;
     const int w = image.cols, h = image.rows, ch = image.channels();
     if (ch != 1 && ch != 3 && ch != 4) return false;
-    if (!plan_ || pw_ != w || ph_ != h || pk_ != _config.nFeatures || pl_ != _config.nLevels) {
+    if (!plan_ || pw_ != w || ph_ != h || pk_ != _config.nFeatures || pl_ != _config.nLevels ||
+        pi_ != _config.iniThFAST || pm_ != _config.minThFAST) {
       if (plan_) gh_orb_plan_destroy(plan_);
       plan_ = nullptr;
       gh_orb_params p;
@@ -40,6 +41,7 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       p.min_th_fast = _config.minThFAST;
       if (gh_orb_plan_create(ctx_, w, h, 1, &p, &plan_) != GH_OK) return fail("gh_orb_plan_create");
       pw_ = w; ph_ = h; pk_ = _config.nFeatures; pl_ = _config.nLevels;
+      pi_ = _config.iniThFAST; pm_ = _config.minThFAST;
     }
     const int K = _config.nFeatures;
     std::vector<gh_keypoint> kps((size_t)K);
@@ -142,7 +144,7 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
   }
   gh_ctx* ctx_;
   gh_orb_plan* plan_;
-  int pw_, ph_, pk_, pl_;
+  int pw_, ph_, pk_, pl_, pi_, pm_;  // geometry + parameters the cached plan was built for
   void *d_bgr_ = nullptr, *d_gray_ = nullptr, *d_out_ = nullptr;  // colour path: BGR, luma, result block
   size_t bgr_cap_ = 0, gray_cap_ = 0, out_cap_ = 0;
   std::vector<uint8_t> host_out_;

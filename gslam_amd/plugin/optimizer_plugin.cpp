@@ -46,7 +46,12 @@ class OptimizerHIP : public GSLAM::Optimizer {
       const GSLAM::Point3d t = T.get_translation();
       double* p = &pose[i * 7];
       p[0] = r.x; p[1] = r.y; p[2] = r.z; p[3] = r.w; p[4] = t.x; p[5] = t.y; p[6] = t.z;
-      dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SE3;  // the scale bit is not optimised here
+      // SIM3 scale s > 0: X_c = T_wc^-1 X_w = R^T (X_w - t) / s (GSLAM/core/SIM3.h:120-131), and the pinhole residual
+      // X_c.xy / X_c.z does not depend on s -- the SE3 part (R, t) is the whole problem, s is a gauge that mappoint
+      // observations cannot see.  It is therefore neither optimised (UPDATE_KF_SCALE is ignored) nor changed: the
+      // keyframe gets (R', t', s) back.  s <= 0 flips the depth sign and is rejected.
+      if (!(T.get_scale() > 0)) return unsupported("keyframe with non-positive SIM3 scale");
+      dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SE3;
     }
     for (size_t i = 0; i < np; ++i) {
       xyz[3 * i] = graph.mappoints[i].first.x;
@@ -65,7 +70,11 @@ class OptimizerHIP : public GSLAM::Optimizer {
       }
       opt[k] = (int32_t)e.pointId;
       ocam[k] = (int32_t)e.frameId;
-      const double z = e.measurement.z != 0 ? e.measurement.z : 1.0;  // CameraAnchor on the z = 1 plane
+      const double z = e.measurement.z;  // CameraAnchor: pinhole measurements live on the z = 1 plane (:58-61,102-103)
+      if (!(z > 0)) {
+        LOG(ERROR) << "OptimizerHIP: observation " << k << " has measurement.z = " << z << " (pinhole anchors need z > 0)";
+        return false;
+      }
       oxy[2 * k] = e.measurement.x / z;
       oxy[2 * k + 1] = e.measurement.y / z;
       if (any_info) {
@@ -111,7 +120,11 @@ class OptimizerHIP : public GSLAM::Optimizer {
     std::vector<double> X(n * 3), m(n * 2);
     for (size_t k = 0; k < n; ++k) {
       X[3 * k] = matches[k].first.x; X[3 * k + 1] = matches[k].first.y; X[3 * k + 2] = matches[k].first.z;
-      const double z = matches[k].second.z != 0 ? matches[k].second.z : 1.0;
+      const double z = matches[k].second.z;
+      if (!(z > 0)) {
+        LOG(ERROR) << "OptimizerHIP: match " << k << " has anchor z = " << z << " (pinhole anchors need z > 0)";
+        return false;
+      }
       m[2 * k] = matches[k].second.x / z;
       m[2 * k + 1] = matches[k].second.y / z;
     }

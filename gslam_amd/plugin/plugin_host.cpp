@@ -40,7 +40,7 @@ static std::vector<T> read_vec(std::ifstream& f, size_t n) {
   return v;
 }
 
-static int run_ba(const std::string& dir, const char* in, const char* out) {
+static int run_ba(const std::string& dir, const char* in, const char* out, double kf_scale, int zero_z_obs) {
   svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
   std::ifstream f(in, std::ios::binary);
   int32_t hdr[6];  // nc, np, no, has_info, max_iterations, has_pfree
@@ -65,7 +65,7 @@ static int run_ba(const std::string& dir, const char* in, const char* out) {
   g.keyframes.resize(nc);
   for (int i = 0; i < nc; ++i) {
     const double* p = &pose[(size_t)i * 7];
-    g.keyframes[i].estimation = SIM3(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]), 1.0);
+    g.keyframes[i].estimation = SIM3(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]), kf_scale);
     g.keyframes[i].dof = (KeyFrameEstimzationDOF)dof[i];
   }
   g.mappoints.resize(np);
@@ -80,7 +80,29 @@ static int run_ba(const std::string& dir, const char* in, const char* out) {
     e.information = hdr[3] ? &info[(size_t)k * 4] : NULL;
     g.mappointObserves[k] = e;
   }
+  if (zero_z_obs >= 0 && zero_z_obs < no) g.mappointObserves[zero_z_obs].measurement.z = 0;  // a caller bug: must fail
   const bool ok = opt_ptr->optimize(g);
+  // sum of squared reprojection errors at the result through the reference's OWN SIM3 algebra (scale included):
+  // X_c = T_wc^-1 X_w  (GSLAM/core/SIM3.h:120-131)
+  double ssq = 0, min_scale = 1e300, max_scale = 0;
+  for (int k = 0; k < no; ++k) {
+    const BundleEdge& e = g.mappointObserves[k];
+    if (e.measurement.z == 0) continue;
+    // (SIM3::inv() itself does not compile in this snapshot -- it calls a non-existent SO3::inv(), SIM3.h:126-131 -- so
+    // the inverse of  X_w = R (s X_c) + t  (SIM3.h:120-123) is spelled out with the reference's SO3 operators)
+    const SIM3& T = g.keyframes[e.frameId].estimation;
+    const Point3d Xc = (T.get_rotation().inverse() * (g.mappoints[e.pointId].first - T.get_translation())) * (1.0 / T.get_scale());
+    const Point3d back = T * Xc;  // the reference's forward map must return the world point
+    if ((back - g.mappoints[e.pointId].first).norm() > 1e-9) { std::cerr << "SIM3 forward/inverse mismatch\n"; return 4; }
+    const double rx = Xc.x / Xc.z - e.measurement.x / e.measurement.z, ry = Xc.y / Xc.z - e.measurement.y / e.measurement.z;
+    ssq += rx * rx + ry * ry;
+  }
+  for (int i = 0; i < nc; ++i) {
+    min_scale = std::min(min_scale, g.keyframes[i].estimation.get_scale());
+    max_scale = std::max(max_scale, g.keyframes[i].estimation.get_scale());
+  }
+  std::cout.precision(17);
+  std::cout << "ref_sim3_ssq=" << ssq << " scale_min=" << min_scale << " scale_max=" << max_scale << std::endl;
   std::ofstream o(out, std::ios::binary);
   int32_t okv = ok ? 1 : 0;
   o.write((char*)&okv, 4);
@@ -357,7 +379,8 @@ static int run_est(const std::string& dir, int model, int n, const char* ptsf, d
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
-  if (mode == "ba" && argc >= 5) return run_ba(dir, argv[3], argv[4]);
+  if (mode == "ba" && argc >= 5)
+    return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
   if (mode == "est" && argc >= 8) return run_est(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);
   if (mode == "app" && argc >= 9)

@@ -68,6 +68,10 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     std::lock_guard<std::mutex> lock(mu_);
     const int n = features.rows;
     if (!voc_ || n <= 0 || features.cols * features.elemSize() != 32) return;
+    if (n > 16384) {  // one workgroup sorts an image's word ids in LDS: 16384 features is the library's limit
+      LOG(ERROR) << "VocabularyHIP: " << n << " features in one image exceed the limit of 16384; outputs left empty";
+      return;
+    }
     std::vector<uint32_t> word(n), node(n), bw(n);
     std::vector<float> weight(n), bv(n);
     int32_t nb = 0;

@@ -144,7 +144,11 @@ size_t gh_orb_plan_device_bytes(const gh_orb_plan* plan);
 
 /* Extract from `batch` gray u8 frames resident in HBM (frame f at gray_dev + f*frame_stride,
  * rows `row_stride` bytes apart).  Outputs, each with capacity K = params.n_features per frame:
- *   kps_dev  batch x K gh_keypoint, desc_dev batch x K x 32 B, counts_dev batch int32. */
+ *   kps_dev  batch x K gh_keypoint, desc_dev batch x K x 32 B, counts_dev batch int32.
+ * A 16-byte aligned buffer (pointer, row_stride, frame_stride) is read in place, in 16-byte windows over the whole
+ * row_stride x height extent of every frame: the padding of the rows must be allocated.  For a single frame whose
+ * allocation ends at (height-1) * row_stride + width (an ROI view) pass batch = 1 and frame_stride = 0: the frame
+ * is then copied row by row into the plan's own pyramid slab first. */
 gh_status gh_orb_extract_dev(gh_orb_plan* plan, const uint8_t* gray_dev, int batch, size_t frame_stride,
                              int row_stride, gh_keypoint* kps_dev, uint8_t* desc_dev, int32_t* counts_dev);
 /* Single host frame convenience (uploads, extracts, downloads, synchronises). */
@@ -173,7 +177,7 @@ gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scor
 void gh_bow_vocab_destroy(gh_bow_vocab* vocab);
 /* Batched over images: desc_dev n_images x cap x 32 B, counts_dev (may be NULL = cap rows each).  Per feature:
  * word id, word weight, node id at level L - levelsup (0xFFFFFFFF / 0 / 0xFFFFFFFF for rows >= count).  Per image:
- * bow_word (ascending, 0xFFFFFFFF padded) / bow_val (normalised as the reference does) / bow_n.  cap <= 8192. */
+ * bow_word (ascending, 0xFFFFFFFF padded) / bow_val (normalised as the reference does) / bow_n.  cap <= 16384. */
 gh_status gh_bow_transform_dev(gh_bow_vocab* vocab, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
                                int n_images, int levelsup, uint32_t* word_dev, float* weight_dev, uint32_t* node_dev,
                                uint32_t* bow_word_dev, float* bow_val_dev, int32_t* bow_n_dev);

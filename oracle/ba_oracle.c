@@ -25,6 +25,8 @@
  *   radius /= max(1/3, 1 - (2 rho - 1)^3), decrease_factor = 2; else radius /= decrease_factor,
  *   decrease_factor *= 2;  stop on |dcost| <= 1e-6 cost, max|g| <= 1e-10, or max iterations.
  *   Huber(delta) enters as the IRLS weight rho'(s) (Ceres' corrector with rho'' <= 0).
+ *   Observations with camera-frame depth <= 1e-9 contribute nothing (GSLAM/core/Camera.h:213-245 rejects z <= 0); a
+ *   candidate step that moves a previously valid observation behind its camera is rejected outright.
  */
 #include <math.h>
 #include <stdint.h>
@@ -434,6 +436,18 @@ int oracle_ba_solve(int nc, int np, int no, double* poses, const int32_t* dof, d
       }
       for (int i = 0; i < 3 * np; ++i) pts_new[i] = pts[i] + dp[i];
       new_cost = total_cost(&c, poses_new, pts_new);
+      /* An observation that was in front of its camera at the linearisation point and is not at the candidate would
+       * silently leave the sum and LOWER the cost: such a candidate is rejected (infinite cost) instead. */
+      for (int k = 0; k < no; ++k) {
+        double r[2], w, s;
+        const double* info = oinfo ? oinfo + 4 * k : NULL;
+        if (obs_linearize(poses + 7 * ocam[k], 0, pts + 3 * opt[k], 0, oxy + 2 * k, info, c.huber, r, &w, NULL, NULL, &s) &&
+            !obs_linearize(poses_new + 7 * ocam[k], 0, pts_new + 3 * opt[k], 0, oxy + 2 * k, info, c.huber, r, &w, NULL,
+                           NULL, &s)) {
+          new_cost = INFINITY;
+          break;
+        }
+      }
       rho = model > 0 ? (cost - new_cost) / model : -1;
     }
     int acc = ok && rho > opt_in->min_relative_decrease;

@@ -117,3 +117,19 @@ def test_information_matrix_scales_cost(oracle):
     c1 = oracle.ba_cost(g, huber=0.0)
     g["obs_info"] = np.tile(np.array([4.0, 0, 0, 4.0]), (len(g["obs_cam"]), 1))
     assert abs(oracle.ba_cost(g, huber=0.0) - 4 * c1) < 1e-12 * c1
+
+
+def behind_camera_graph():
+    """One fixed camera at the origin, one free point 1 cm in front of it whose Gauss-Newton step lands BEHIND the
+    camera: dropping the observation there would make the cost 0 and LM would accept a point behind the camera."""
+    return {"cam_pose": np.array([[0, 0, 0, 1.0, 0, 0, 0]]), "cam_dof": np.array([0], np.int32),
+            "point_xyz": np.array([[0.01, 0, 0.01]]), "obs_cam": np.array([0], np.int32),
+            "obs_point": np.array([0], np.int32), "obs_xy": np.array([[5.0, 0.0]])}
+
+
+def test_step_that_moves_a_point_behind_its_camera_is_rejected(oracle):
+    g = behind_camera_graph()
+    poses, pts, s, rc = oracle.ba_solve(g, oracle_lib.ba_options(huber=0.0, max_iterations=30))
+    assert rc == 0 and s.trace_accepted[0] == 0 and np.isinf(s.trace_cost[0])
+    assert pts[0, 2] > 1e-9 and s.final_cost < 1e-20 * s.initial_cost
+    assert abs(pts[0, 0] / pts[0, 2] - 5.0) < 1e-9

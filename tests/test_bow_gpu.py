@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("k,L,weighting,scoring,levelsup,n", [(10, 4, 0, 0, 2, 2000), (4, 3, 1, 1, 1, 777),
                                                               (10, 3, 2, 0, 0, 1000), (6, 4, 3, 5, 4, 300),
-                                                              (10, 4, 0, 5, 7, 1500), (3, 5, 1, 2, 3, 1)])
+                                                              (10, 4, 0, 5, 7, 1500), (3, 5, 1, 2, 3, 1),
+                                                              (10, 4, 0, 0, 2, 4097), (10, 4, 0, 0, 2, 8192),
+                                                              (10, 4, 1, 1, 1, 16384)])
 def test_bow_host_entry_parity(ctx, oracle, k, L, weighting, scoring, levelsup, n):
     from gslam_amd.bow import Vocabulary
     voc = bow_synth.make_vocabulary(k=k, L=L, seed=11 + k, weighting=weighting, scoring=scoring)

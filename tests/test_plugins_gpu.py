@@ -59,6 +59,48 @@ def test_optimizer_plugin_optimize_matches_oracle(tmp_path, oracle):
     assert np.array_equal(pts[:5], g["point_xyz"][:5]) and np.array_equal(poses[0], g["cam_pose"][0])
 
 
+def _write_graph(path, g, max_it, huber):
+    nc, npt, no = len(g["cam_pose"]), len(g["point_xyz"]), len(g["obs_cam"])
+    with open(path, "wb") as f:
+        f.write(np.array([nc, npt, no, 0, max_it, 0], np.int32).tobytes())
+        f.write(struct.pack("d", huber))
+        for k, dt in (("cam_pose", np.float64), ("cam_dof", np.int32), ("point_xyz", np.float64),
+                      ("obs_cam", np.int32), ("obs_point", np.int32), ("obs_xy", np.float64)):
+            f.write(np.ascontiguousarray(g[k], dtype=dt).tobytes())
+
+
+def test_optimizer_plugin_sim3_scale_and_bad_anchor(tmp_path, oracle):
+    """Keyframes are SIM3 (Optimizer.h:116-119).  The pinhole residual does not depend on the scale, so keyframes with
+    s = 2.5 must give the SAME (R, t, points) as s = 1, keep s, and the sum of squared reprojection errors evaluated
+    by the host through the reference's own SIM3 operators (scale included) must equal the oracle's cost at the
+    result.  A measurement with z = 0 is a caller bug: optimize() returns false instead of guessing z = 1."""
+    _need_host()
+    g = make_graph(8, 150, n_obs_per_point=4, seed=33)
+    inp = tmp_path / "graph.bin"
+    _write_graph(inp, g, 25, 0.0)
+    nc, npt = 8, 150
+    res = {}
+    for scale in (1.0, 2.5):
+        out = tmp_path / f"out_{scale}.bin"
+        r = _run(["ba", LIBDIR, inp, out, scale])
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        poses = np.frombuffer(raw, np.float64, nc * 7, 4).reshape(nc, 7)
+        pts = np.frombuffer(raw, np.float64, npt * 3, 4 + nc * 56).reshape(npt, 3)
+        kv = dict(tok.split("=") for line in r.stdout.splitlines() if line.startswith("ref_sim3_ssq") for tok in line.split())
+        assert float(kv["scale_min"]) == float(kv["scale_max"]) == scale
+        res[scale] = (poses, pts, float(kv["ref_sim3_ssq"]))
+    assert res[1.0][0].tobytes() == res[2.5][0].tobytes() and res[1.0][1].tobytes() == res[2.5][1].tobytes()
+    po, xo, so, _ = oracle.ba_solve(g, oracle_lib.ba_options(huber=0.0, max_iterations=25))
+    assert np.abs(res[2.5][0] - po).max() < 1e-7 and np.abs(res[2.5][1] - xo).max() < 1e-7
+    for scale in (1.0, 2.5):
+        assert abs(0.5 * res[scale][2] - so.final_cost) <= 1e-7 * so.final_cost
+    r = _run(["ba", LIBDIR, inp, tmp_path / "bad.bin", 1.0, 17])
+    assert r.returncode == 3 and "optimize=0" in r.stdout
+    r = _run(["ba", LIBDIR, inp, tmp_path / "bad2.bin", -1.0])
+    assert r.returncode == 3 and "optimize=0" in r.stdout
+
+
 def test_optimizer_plugin_pnp(tmp_path, oracle):
     _need_host()
     g = make_graph(3, 150, n_obs_per_point=3, seed=11, noise=0.0, outlier_frac=0.0, perturb=False)
