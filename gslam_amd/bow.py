@@ -60,3 +60,28 @@ class Vocabulary:
         self.ctx.check(hip.lib.gh_bow_transform_host(self.h, pv(desc), n, int(levelsup), pv(word), pv(weight), pv(node),
                                                      pv(bw), pv(bv), C.byref(nb)))
         return word[:n], weight[:n], node[:n], bw[:nb.value].copy(), bv[:nb.value].copy()
+
+
+def score(ctx: hip.Context, scoring: int, q, db):
+    """All-pairs GSLAM::Vocabulary::score on the GPU.  q / db: (bow_word, bow_val, bow_n) device tensors in the padded
+    layout Vocabulary.transform returns (n_q x cap_q, n_db x cap_db).  Returns an n_q x n_db float64 device tensor."""
+    qw, qv, qn = q
+    dw, dv, dn = db
+    out = torch.empty((qw.shape[0], dw.shape[0]), dtype=torch.float64, device=qw.device)
+    ctx.check(hip.lib.gh_bow_score_dev(ctx.h, int(scoring), _p(qw), _p(qv), _p(qn), qw.shape[0], qw.shape[1], _p(dw), _p(dv),
+                                       _p(dn), dw.shape[0], dw.shape[1], _p(out)))
+    return out
+
+
+def score_host(ctx: hip.Context, scoring: int, q, db_list):
+    """One query (ids, vals) against a list of host BowVectors [(ids, vals), ...] -> numpy float64 scores."""
+    qi, qv = np.ascontiguousarray(q[0], np.uint32), np.ascontiguousarray(q[1], np.float32)
+    off = np.zeros(len(db_list) + 1, np.int64)
+    off[1:] = np.cumsum([len(d[0]) for d in db_list])
+    di = np.ascontiguousarray(np.concatenate([np.asarray(d[0], np.uint32) for d in db_list]) if db_list else np.zeros(0, np.uint32))
+    dv = np.ascontiguousarray(np.concatenate([np.asarray(d[1], np.float32) for d in db_list]) if db_list else np.zeros(0, np.float32))
+    out = np.zeros(len(db_list), np.float64)
+    pv = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(hip.lib.gh_bow_score_host(ctx.h, int(scoring), pv(qi), pv(qv), len(qi), pv(di), pv(dv), pv(off), len(db_list),
+                                        pv(out)))
+    return out

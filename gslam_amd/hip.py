@@ -103,6 +103,8 @@ SIGNATURES = {
     "gh_bow_vocab_destroy": (None, [_vp]),
     "gh_bow_transform_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gh_bow_transform_host": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    "gh_bow_score_dev": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "gh_bow_score_host": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "gh_undist_plan_create": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "gh_undist_plan_destroy": (None, [_vp]),
     "gh_undistort_dev": (C.c_int, [_vp, _vp, _i, _i, _sz, _vp, _sz, _i]),

@@ -202,7 +202,34 @@ static int run_bow(const std::string& dir, const char* gbow, const char* descf, 
   BowVector bg2, bc2;
   gpu->transform(features, bg2);
   cpu.transform(features, bc2);
-  const bool same = bg == bc && fg == fc && bg2 == bc2;
+  bool same = bg == bc && fg == fc && bg2 == bc2;
+  // batched scoring (scoreVocabularyBatch) against the reference's own score() on a database of sub-images: windows
+  // of the same descriptor list, transformed by the reference itself
+  typedef bool (*score_t)(const Vocabulary*, const BowVector*, const BowVector* const*, int, double*);
+  score_t sb = (score_t)lib->getSymbol("scoreVocabularyBatch");
+  int score_bad = -1;
+  if (sb) {
+    std::vector<BowVector> db;
+    for (int w0 = 0; w0 + 50 <= n && db.size() < 40; w0 += n / 40 + 1) {
+      const int wn = std::min(n - w0, 50 + (int)db.size() * 17);
+      TinyMat sub(wn, 32, GImageType<uchar>::Type, d.data() + (size_t)w0 * 32, false);
+      BowVector v;
+      cpu.transform(sub, v);
+      db.push_back(v);
+    }
+    db.push_back(BowVector());  // an empty vector
+    std::vector<const BowVector*> ptr;
+    for (auto& v : db) ptr.push_back(&v);
+    std::vector<double> sc(db.size(), -1.0);
+    score_bad = sb(gpu.get(), &bc2, ptr.data(), (int)ptr.size(), sc.data()) ? 0 : (int)db.size();
+    for (size_t j = 0; j < db.size() && score_bad >= 0; ++j) {
+      const double e = cpu.m_scoring_object->score(bc2, db[j]);  // Vocabulary::score itself is declared but never defined
+      const bool kl = cpu.getScoringType() == Vocabulary::KL;
+      if (kl ? std::fabs(sc[j] - e) > 1e-6 * std::max(1.0, std::fabs(e)) : sc[j] != e) ++score_bad;
+    }
+    std::cout << "score batch: " << db.size() << " database vectors, mismatches=" << score_bad << std::endl;
+  }
+  same = same && score_bad == 0;
   std::ofstream o(out, std::ios::binary);
   int32_t hdr[4] = {same ? 1 : 0, (int32_t)bg.size(), (int32_t)fg.size(), (int32_t)bc.size()};
   o.write((char*)hdr, sizeof(hdr));

@@ -9,6 +9,12 @@
 //     extern "C" std::shared_ptr<GSLAM::Vocabulary> createVocabularyInstance(const char* gbow_file)
 // Results are bit-identical to the base class (tests/test_plugins_gpu.py); no GPU => falls back to nothing: the
 // methods leave the outputs empty and log an error.
+// Vocabulary::score is a non-virtual inline that this snapshot declares (:203-211) but never defines -- callers use
+// m_scoring_object->score -- and scoring ONE pair on a GPU would be pure latency, so the
+// batched form a loop detector needs is offered beside it:
+//     extern "C" bool scoreVocabularyBatch(const GSLAM::Vocabulary*, const BowVector* query,
+//                                          const BowVector* const* db, int n_db, double* scores)
+// = m_scoring_object->score(*query, *db[j]) for every j (GSLAM/core/Vocabulary.h:691-979) through gh_bow_score_host.
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Vocabulary.h>
 
@@ -39,6 +45,36 @@ class VocabularyHIP : public GSLAM::Vocabulary {
   void transform(const GSLAM::TinyMat& features, GSLAM::BowVector& v) const override {
     v.clear();
     run(features, 0, &v, nullptr);
+  }
+
+ public:
+  // scores[j] = m_scoring_object->score(query, *db[j]); ids above 2^32 - 2 cannot occur (node ids are 32-bit in .gbow)
+  bool scoreBatch(const GSLAM::BowVector& query, const GSLAM::BowVector* const* db, int n_db, double* scores) const {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (!ctx_ || n_db < 0 || (n_db > 0 && (!db || !scores))) return false;
+    std::vector<uint32_t> qi, di;
+    std::vector<float> qv, dv;
+    std::vector<int64_t> off((size_t)n_db + 1, 0);
+    qi.reserve(query.size());
+    qv.reserve(query.size());
+    for (GSLAM::BowVector::const_iterator it = query.begin(); it != query.end(); ++it) {
+      qi.push_back((uint32_t)it->first);
+      qv.push_back(it->second);
+    }
+    for (int j = 0; j < n_db; ++j) {
+      if (!db[j]) return false;
+      for (GSLAM::BowVector::const_iterator it = db[j]->begin(); it != db[j]->end(); ++it) {
+        di.push_back((uint32_t)it->first);
+        dv.push_back(it->second);
+      }
+      off[(size_t)j + 1] = (int64_t)di.size();
+    }
+    if (gh_bow_score_host(ctx_, (int)m_scoring, qi.data(), qv.data(), (int)qi.size(), di.data(), dv.data(), off.data(), n_db,
+                          scores) != GH_OK) {
+      LOG(ERROR) << "VocabularyHIP: " << gh_last_error(ctx_);
+      return false;
+    }
+    return true;
   }
 
  private:
@@ -93,6 +129,12 @@ class VocabularyHIP : public GSLAM::Vocabulary {
 };
 
 }  // namespace
+
+extern "C" bool scoreVocabularyBatch(const GSLAM::Vocabulary* voc, const GSLAM::BowVector* query,
+                                     const GSLAM::BowVector* const* db, int n_db, double* scores) {
+  const VocabularyHIP* v = dynamic_cast<const VocabularyHIP*>(voc);
+  return v && query && v->scoreBatch(*query, db, n_db, scores);
+}
 
 extern "C" std::shared_ptr<GSLAM::Vocabulary> createVocabularyInstance(const char* gbow_file) {
   std::shared_ptr<VocabularyHIP> v(new VocabularyHIP());

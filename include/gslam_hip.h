@@ -184,6 +184,21 @@ gh_status gh_bow_transform_dev(gh_bow_vocab* vocab, const uint8_t* desc_dev, con
 gh_status gh_bow_transform_host(gh_bow_vocab* vocab, const uint8_t* desc, int n, int levelsup, uint32_t* word,
                                 float* weight, uint32_t* node, uint32_t* bow_word, float* bow_val, int32_t* bow_n);
 
+/* Batched GSLAM::Vocabulary::score(a, b) = m_scoring_object->score(a, b) (GSLAM/core/Vocabulary.h:691-979, one class
+ * per ScoringType): every query BowVector against every database BowVector, scores_dev[q * n_db + j] = score(query q,
+ * database j) as the reference's double.  Vectors are in the padded layout gh_bow_transform_dev writes (word ids
+ * ascending, *_n valid entries of a row of capacity cap_*), so a block of images transformed on the GPU is scored with
+ * no host copy.  L1 / L2 / chi-square / Bhattacharyya / dot product are bit-identical to the reference (same float
+ * terms, same ascending-id double accumulation); KL goes through logf and matches to 1e-6 relative. */
+gh_status gh_bow_score_dev(gh_ctx* ctx, int scoring, const uint32_t* q_word_dev, const float* q_val_dev,
+                           const int32_t* q_n_dev, int n_q, int cap_q, const uint32_t* db_word_dev,
+                           const float* db_val_dev, const int32_t* db_n_dev, int n_db, int cap_db, double* scores_dev);
+/* One query against n_db host vectors in CSR form (db_off[n_db + 1] offsets into db_word / db_val): the loop-closure
+ * candidate scan of a detector that keeps std::map BowVectors on the host. */
+gh_status gh_bow_score_host(gh_ctx* ctx, int scoring, const uint32_t* q_word, const float* q_val, int q_n,
+                            const uint32_t* db_word, const float* db_val, const int64_t* db_off, int n_db,
+                            double* scores);
+
 /* ------------------------------------------------------------------ undistortion ----- */
 /* GSLAM::Undistorter::undistort / undistortFast (GSLAM/core/Undistorter.h:206-348) with the remap tables its
  * prepareReMap builds on the host (:120-203): per output pixel remapX, remapFast, remapIdx[4], remapCoef[4].

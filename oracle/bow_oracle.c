@@ -126,3 +126,57 @@ double oracle_bow_score_l1(const uint32_t* a_id, const float* a_v, int na, const
   }
   return -score / 2.0;
 }
+
+/* All six scoring classes of the reference (GSLAM/core/Vocabulary.h:691-979), selected by the ScoringType enum order
+ * (L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = 0..5); a = v1, b = v2, both ascending by word id.
+ * WordValue is float and the reference calls fabs / sqrt / log unqualified on floats, which C++ <cmath> resolves to the
+ * FLOAT overloads: every per-word term is formed in single precision and accumulated into a double, in ascending id
+ * order.  Checked bit for bit against oracle/_ref (tests/test_bow_oracle.py). */
+static const double BOW_LOG_EPS = -36.043653389117154; /* log(DBL_EPSILON), GeneralScoring::LOG_EPS (:631-634) */
+
+double oracle_bow_score(int scoring, const uint32_t* a_id, const float* a_v, int na, const uint32_t* b_id,
+                        const float* b_v, int nb) {
+  double score = 0;
+  int i = 0, j = 0;
+  if (scoring == 3) { /* KLScoring (:843-891): every word of v1 contributes */
+    while (i < na && j < nb) {
+      const float vi = a_v[i], wi = b_v[j];
+      if (a_id[i] == b_id[j]) {
+        if (vi != 0 && wi != 0) score += vi * logf(vi / wi);
+        ++i;
+        ++j;
+      } else if (a_id[i] < b_id[j]) {
+        score += vi * (logf(vi) - BOW_LOG_EPS);
+        ++i;
+      } else {
+        ++j; /* lower_bound(v1 id): no contribution */
+      }
+    }
+    for (; i < na; ++i)
+      if (a_v[i] != 0) score += a_v[i] * (logf(a_v[i]) - BOW_LOG_EPS);
+    return score;
+  }
+  while (i < na && j < nb) {
+    if (a_id[i] == b_id[j]) {
+      const float vi = a_v[i], wi = b_v[j];
+      switch (scoring) {
+        case 0: score += fabsf(vi - wi) - fabsf(vi) - fabsf(wi); break;         /* L1 (:691-736) */
+        case 1: case 5: score += vi * wi; break;                                /* L2 (:741-790), dot (:939-979) */
+        case 2: if (vi + wi != 0.0) score += vi * wi / (vi + wi); break;        /* chi square (:795-838) */
+        case 4: score += sqrtf(vi * wi); break;                                 /* Bhattacharyya (:896-934) */
+      }
+      ++i;
+      ++j;
+    } else if (a_id[i] < b_id[j]) {
+      ++i;
+    } else {
+      ++j;
+    }
+  }
+  switch (scoring) {
+    case 0: return -score / 2.0;
+    case 1: return score >= 1 ? 1.0 : 1.0 - sqrt(1.0 - score);
+    case 2: return 2. * score;
+    default: return score;
+  }
+}

@@ -330,8 +330,16 @@ def _bow_methods(cls):
         bi, bv = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float32)
         return self.lib.oracle_bow_score_l1(_ptr(ai), _ptr(av), len(ai), _ptr(bi), _ptr(bv), len(bi))
 
+    def bow_score(self, scoring, a, b):
+        """m_scoring_object->score(a, b) for ScoringType `scoring` (0..5); a, b = (ids ascending, float values)."""
+        self.lib.oracle_bow_score.restype = C.c_double
+        ai, av = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float32)
+        bi, bv = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float32)
+        return self.lib.oracle_bow_score(int(scoring), _ptr(ai), _ptr(av), len(ai), _ptr(bi), _ptr(bv), len(bi))
+
     cls.bow_transform = bow_transform
     cls.bow_score_l1 = bow_score_l1
+    cls.bow_score = bow_score
 
 
 _bow_methods(Oracle)

@@ -61,3 +61,69 @@ def test_bow_batched_ragged_and_large_tree(ctx, oracle):
         assert np.array_equal(bw[b, :bn[b]].view(np.uint32), e[3]) and bv[b, :bn[b]].tobytes() == e[4].tobytes()
         assert (bw[b, bn[b]:].view(np.uint32) == 0xFFFFFFFF).all() and not bv[b, bn[b]:].any()
     v.close()
+
+
+@pytest.mark.parametrize("scoring,weighting", [(0, 0), (1, 1), (2, 0), (3, 0), (4, 1), (5, 0)])
+def test_bow_score_batched_vs_oracle(ctx, oracle, scoring, weighting):
+    """GSLAM::Vocabulary::score for all six scoring classes (Vocabulary.h:691-979): every query against every database
+    vector straight from the transform's device output; ragged counts incl. empty vectors.  Bit-identical doubles for
+    L1 / L2 / chi-square / Bhattacharyya / dot; KL (logf) 1e-6 relative."""
+    import torch
+    from gslam_amd import bow
+    voc = bow_synth.make_vocabulary(k=10, L=3, seed=3, weighting=weighting, scoring=scoring)
+    v = bow.Vocabulary(ctx, voc)
+    B, cap = 12, 700
+    counts = np.array([700, 650, 0, 1, 699, 300, 700, 64, 65, 128, 500, 2], np.int32)
+    # descriptors drawn around a shared subset of words so that the vectors overlap substantially
+    desc = np.stack([bow_synth.features_near_words(voc, cap, seed=70 + (b % 4)) for b in range(B)])
+    rng = np.random.default_rng(4)
+    for b in range(B):
+        desc[b] = desc[b][rng.permutation(cap)]
+    out = v.transform(torch.from_numpy(desc).cuda(), torch.from_numpy(counts).cuda(), levelsup=1)
+    bw, bv, bn = out[3], out[4], out[5]
+    nq = 5
+    S = bow.score(ctx, scoring, (bw[:nq], bv[:nq], bn[:nq]), (bw, bv, bn))
+    torch.cuda.synchronize()
+    S = S.cpu().numpy()
+    hw, hv, hn = bw.cpu().numpy().view(np.uint32), bv.cpu().numpy(), bn.cpu().numpy()
+    vec = [(hw[b, :hn[b]], hv[b, :hn[b]]) for b in range(B)]
+    nonzero = 0
+    for q in range(nq):
+        for j in range(B):
+            e = oracle.bow_score(scoring, vec[q], vec[j])
+            if scoring == 3:
+                assert (np.isnan(e) and np.isnan(S[q, j])) or abs(S[q, j] - e) <= 1e-6 * max(1.0, abs(e)), (q, j)
+            else:
+                assert S[q, j] == e or (np.isnan(e) and np.isnan(S[q, j])), (scoring, q, j, S[q, j], e)
+            nonzero += e != 0
+    assert nonzero > nq * B // 2
+    # host entry point: one query against a list of host vectors
+    sh = bow.score_host(ctx, scoring, vec[0], vec)
+    assert np.array_equal(sh, S[0]) or scoring == 3
+    v.close()
+
+
+def test_bow_score_large_query_not_staged(ctx, oracle):
+    """cap_q above the LDS staging limit (16384 words) takes the global-memory search path."""
+    import torch
+    from gslam_amd import bow
+    rng = np.random.default_rng(9)
+    cap = 20000
+    ids_a = np.sort(rng.choice(200000, cap, replace=False)).astype(np.uint32)
+    ids_b = np.sort(rng.choice(200000, 15000, replace=False)).astype(np.uint32)
+    va = rng.random(cap).astype(np.float32) / cap
+    vb = rng.random(15000).astype(np.float32) / 15000
+    qw = torch.from_numpy(ids_a.view(np.int32)).cuda()[None]
+    qv = torch.from_numpy(va).cuda()[None]
+    dwn = np.full((2, cap), -1, np.int32)
+    dvn = np.zeros((2, cap), np.float32)
+    dwn[0, :15000] = ids_b.view(np.int32)
+    dvn[0, :15000] = vb
+    dwn[1] = ids_a.view(np.int32)
+    dvn[1] = va
+    S = bow.score(ctx, 0, (qw, qv, torch.tensor([cap], dtype=torch.int32).cuda()),
+                  (torch.from_numpy(dwn).cuda(), torch.from_numpy(dvn).cuda(), torch.tensor([15000, cap], dtype=torch.int32).cuda()))
+    torch.cuda.synchronize()
+    S = S.cpu().numpy()
+    assert S[0, 0] == oracle.bow_score(0, (ids_a, va), (ids_b, vb))
+    assert S[0, 1] == oracle.bow_score(0, (ids_a, va), (ids_a, va))

@@ -28,11 +28,18 @@ def test_golden_vectors_from_reference(oracle):
     fn, ff = _fv_pairs(node, weight)
     assert np.array_equal(fn, g["fv_nodes"]) and np.array_equal(ff, g["fv_feat"])
     assert abs(oracle.bow_score_l1((bw, bv), (g["bow2_ids"], g["bow2_vals"])) - float(g["score12"])) == 0.0
+    # all six scoring classes of the reference on the same descriptor pair (each vocabulary normalises its own way)
+    for sc in range(6):
+        v2 = dict(voc, scoring=sc)
+        a = oracle.bow_transform(v2, g["desc"], levelsup=int(g["levelsup"]))
+        b = oracle.bow_transform(v2, g["desc2"], levelsup=int(g["levelsup"]))
+        assert oracle.bow_score(sc, (a[3], a[4]), (b[3], b[4])) == float(g["scores_by_type"][sc]), sc
 
 
 @pytest.mark.skipif(not oracle_lib.have_reference(), reason="oracle/_ref not built (needs /root/reference)")
 @pytest.mark.parametrize("k,L,weighting,scoring,levelsup", [(10, 4, 0, 0, 2), (4, 3, 1, 1, 1), (10, 3, 2, 0, 0),
-                                                            (6, 4, 3, 5, 4), (10, 4, 0, 5, 7), (3, 5, 1, 2, 3)])
+                                                            (6, 4, 3, 5, 4), (10, 4, 0, 5, 7), (3, 5, 1, 2, 3),
+                                                            (8, 3, 0, 3, 1), (8, 3, 1, 4, 2)])
 def test_oracle_equals_reference_live(oracle, k, L, weighting, scoring, levelsup):
     ref = oracle_lib.load_reference()
     voc = bow_synth.make_vocabulary(k=k, L=L, seed=11 + k, weighting=weighting, scoring=scoring)
@@ -46,10 +53,14 @@ def test_oracle_equals_reference_live(oracle, k, L, weighting, scoring, levelsup
     assert np.array_equal(bw, bi) and bv.tobytes() == bvr.tobytes()
     en, ef = _fv_pairs(node, weight)
     assert np.array_equal(en, fn) and np.array_equal(ef, ff)
+    desc2 = bow_synth.features_near_words(voc, 800, seed=6)
+    _, _, _, bw2, bv2 = oracle.bow_transform(voc, desc2, levelsup=levelsup)
     if scoring == 0:
-        desc2 = bow_synth.features_near_words(voc, 800, seed=6)
-        _, _, _, bw2, bv2 = oracle.bow_transform(voc, desc2, levelsup=levelsup)
         assert oracle.bow_score_l1((bw, bv), (bw2, bv2)) == rv.score((bi, bvr), (bw2.astype(np.uint64), bv2))
+    # the vocabulary's own scoring object (chosen by `scoring` at load), both argument orders (KL is asymmetric)
+    assert oracle.bow_score(scoring, (bw, bv), (bw2, bv2)) == rv.score((bi, bvr), (bw2.astype(np.uint64), bv2))
+    assert oracle.bow_score(scoring, (bw2, bv2), (bw, bv)) == rv.score((bw2.astype(np.uint64), bv2), (bi, bvr))
+    assert oracle.bow_score(scoring, (bw, bv), (bw, bv)) == rv.score((bi, bvr), (bi, bvr))
     rv.close()
 
 

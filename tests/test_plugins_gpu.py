@@ -165,6 +165,7 @@ def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle):
     r = _run(["bow", LIBDIR, gb, df, 1500, 2, out])
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bow gpu==reference:1" in r.stdout
+    assert "database vectors, mismatches=0" in r.stdout  # scoreVocabularyBatch == the reference's own score()
     raw = open(out, "rb").read()
     same, nwords, nnodes, ncpu = struct.unpack("4i", raw[:16])
     e = oracle.bow_transform(voc, desc, 2)
