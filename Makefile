@@ -38,7 +38,7 @@ build/obj/%.o: gslam_amd/csrc/%.hip gslam_amd/csrc/common.h include/gslam_hip.h 
 
 $(LIBDIR)/libgslam_hip.so: $(COBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(COBJ) -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(COBJ) -lpthread -ldl -lrt
 
 oracle/liboracle.so: $(OSRC) $(wildcard include/*.h oracle/*.h)
 	gcc $(CFLAGS) -shared -o $@ $(OSRC) -lm

@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restri
           const float s = __fadd_rn(vi, wi);
           if (s != 0.f) term = __fdiv_rn(__fmul_rn(vi, wi), s); else found = false;
         }
-        if (SC == 4) term = __fsqrt_rn(__fmul_rn(vi, wi));
+        // correctly rounded float sqrt: a double sqrt rounded once more to float is exact for float inputs (53 >= 2 * 24 + 2);
+        // the float intrinsic maps to the 1-ulp hardware instruction
+        if (SC == 4) term = (float)__dsqrt_rn((double)__fmul_rn(vi, wi));
       }
       unsigned long long mask = __ballot(found);
       while (mask) {

@@ -1,0 +1,488 @@
+// Multi-GPU exchange step of the front end behind the C ABI: frames are sharded over the GPUs of one
+// node, one process per GPU; after extraction every rank needs every frame's records, and after matching every rank
+// may want every match row.  Both are all-gathers of fixed-size per-frame records -- pure data movement, so the
+// gathered buffers are bit-identical on every rank and for every world size.
+//
+// The reference has no transport at all (its Messenger is in-process: GSLAM/core/Messenger.h:455-468,687-715); this is
+// new work that a C++ host reaches through gh_comm_* with no Python and no torch in the process.
+//
+// Two transports behind one interface:
+//   RCCL   ncclAllGather on the communicator's own stream (xGMI).  librccl.so.1 is resolved with dlopen when the first
+//          communicator is created, so single-GPU users and hosts without RCCL never load it; a process that already
+//          holds RCCL (torch.distributed) shares that copy (same SONAME).
+//   IPC    same-node direct writes: every rank maps every peer's gathered buffer through HIP IPC and pushes its own
+//          slice into all of them with device-to-device copies (on a full xGMI mesh that drives all links at once);
+//          rendezvous, handle exchange and the barriers go through a POSIX shared-memory segment.  Works when several
+//          ranks share one GPU (RCCL refuses that: "Duplicate GPU detected"), which is how the 2-process test on a
+//          1-GPU box runs the real kernels.  Synchronous: gh_comm_wait blocks the host.
+//
+// Stream model: a gather issued by gh_allgather* is ordered AFTER everything already enqueued on the context's stream
+// (event), runs on the communicator's stream, and gh_comm_wait orders the context's stream after it -- so kernels
+// enqueued between the two calls overlap with the transfer.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <new>
+
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ RCCL entry points (dlopen) ----------
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) return;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(api.handle, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.handle, "ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd &&
+             api.GetErrorString;
+  });
+  return api;
+}
+
+// ------------------------------------------------------------------ IPC rendezvous segment ----------
+constexpr int kMaxWorld = 64;
+constexpr int kMaxBuffers = 16;
+
+struct ShmSegment {
+  std::atomic<uint32_t> magic;
+  std::atomic<int> arrived;          // sense-reversing barrier
+  std::atomic<int> generation;
+  std::atomic<int> attached;
+  std::atomic<int> failed;           // any rank that gives up sets this so the others stop waiting
+  hipIpcMemHandle_t handles[kMaxWorld];
+  uint64_t sizes[kMaxWorld];
+};
+
+struct IpcBuffer {
+  void* mine = nullptr;                 // world * bytes_per_rank, hipMalloc'ed here
+  void* peer[kMaxWorld] = {nullptr};    // peer[r] == r's `mine` mapped into this process (peer[rank] == mine)
+  size_t bytes_per_rank = 0;
+};
+
+}  // namespace
+
+struct gh_comm {
+  gh_ctx* ctx = nullptr;
+  int rank = 0, world = 1;
+  int transport = 0;  // 0 RCCL, 1 IPC
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  bool pending = false;
+  // RCCL
+  ncclComm_t nccl = nullptr;
+  std::vector<void*> plain_buffers;
+  // IPC
+  ShmSegment* shm = nullptr;
+  std::string shm_name;
+  int local_generation = 0;
+  std::vector<IpcBuffer> ipc_buffers;
+  double timeout_s = 60.0;
+};
+
+namespace {
+
+gh_status rccl_fail(gh_ctx* ctx, const char* what, ncclResult_t r) {
+  return gh_set_error(ctx, GH_ERR_HIP, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+}
+
+#define GH_NCCL(ctx, expr)                                 \
+  do {                                                     \
+    ncclResult_t _r = (expr);                              \
+    if (_r != ncclSuccess) return rccl_fail((ctx), #expr, _r); \
+  } while (0)
+
+// Host barrier over the ranks attached to the segment; false on timeout or when a peer has failed.
+bool shm_barrier(gh_comm* c) {
+  ShmSegment* s = c->shm;
+  const int gen = c->local_generation;
+  if (s->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
+    s->arrived.store(0, std::memory_order_relaxed);
+    s->generation.store(gen + 1, std::memory_order_release);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (s->generation.load(std::memory_order_acquire) == gen) {
+      if (s->failed.load(std::memory_order_relaxed)) return false;
+      if (++spins > 2000) {
+        sched_yield();
+        if ((spins & 1023) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+          s->failed.store(1, std::memory_order_relaxed);
+          return false;
+        }
+      }
+    }
+  }
+  c->local_generation = gen + 1;
+  return true;
+}
+
+gh_status comm_common_init(gh_ctx* ctx, gh_comm* c) {
+  GH_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  GH_HIP(ctx, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  GH_HIP(ctx, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  return GH_OK;
+}
+
+IpcBuffer* find_ipc_buffer(gh_comm* c, const void* gathered, size_t bytes_per_rank) {
+  for (auto& b : c->ipc_buffers)
+    if (b.mine == gathered && bytes_per_rank <= b.bytes_per_rank) return &b;
+  return nullptr;
+}
+
+// One gather of `bytes` per rank into `gathered` (world * stride bytes, rank r's slice at r * stride).
+gh_status gather_one(gh_comm* c, const void* send, void* gathered, size_t bytes, size_t stride) {
+  gh_ctx* ctx = c->ctx;
+  if (c->transport == 0) {
+    GH_CHECK_ARG(ctx, stride == bytes);  // ncclAllGather packs the slices back to back
+    GH_NCCL(ctx, rccl().AllGather(send, gathered, bytes, ncclUint8, c->nccl, c->stream));
+    return GH_OK;
+  }
+  IpcBuffer* b = find_ipc_buffer(c, gathered, stride);
+  if (!b) return gh_set_error(ctx, GH_ERR_ARG, "IPC transport: the gathered buffer must come from gh_comm_buffer");
+  for (int r = 0; r < c->world; ++r) {
+    const int p = (c->rank + r) % c->world;  // stagger the targets so the ranks do not all hit the same peer first
+    char* dst = (char*)b->peer[p] + (size_t)c->rank * stride;
+    if (dst == (const char*)send) continue;  // in-place slice of my own buffer
+    GH_HIP(ctx, hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return GH_OK;
+}
+
+gh_status begin_collective(gh_comm* c) {
+  gh_ctx* ctx = c->ctx;
+  if (c->pending) return gh_set_error(ctx, GH_ERR_ARG, "gh_comm_wait must be called before the next gather");
+  if (c->transport == 1) {
+    // peers still read their gathered buffers of the previous exchange through kernels on THEIR streams, and my send
+    // data is produced on mine: drain, then meet -- after the barrier every buffer may be overwritten
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!shm_barrier(c)) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a peer did not reach the barrier");
+  } else {
+    GH_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
+    GH_HIP(ctx, hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+  }
+  return GH_OK;
+}
+
+gh_status end_collective(gh_comm* c) {
+  GH_HIP(c->ctx, hipEventRecord(c->ev_done, c->stream));
+  c->pending = true;
+  return GH_OK;
+}
+
+}  // namespace
+
+extern "C" gh_status gh_comm_unique_id(uint8_t id_out[128]) {
+  if (!id_out) return GH_ERR_ARG;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!rccl().ok) return GH_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (rccl().GetUniqueId(&id) != ncclSuccess) return GH_ERR_HIP;
+  memcpy(id_out, &id, 128);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_comm_create_rccl(gh_ctx* ctx, int rank, int world, const uint8_t unique_id[128], gh_comm** out) {
+  if (!ctx || !out) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  *out = nullptr;
+  GH_CHECK_ARG(ctx, world >= 1 && rank >= 0 && rank < world && unique_id);
+  if (!rccl().ok) return gh_set_error(ctx, GH_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+  gh_comm* c = new (std::nothrow) gh_comm();
+  if (!c) return GH_ERR_NOMEM;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->transport = 0;
+  gh_status st = comm_common_init(ctx, c);
+  if (st == GH_OK) {
+    ncclUniqueId id;
+    memcpy(&id, unique_id, 128);
+    ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) st = rccl_fail(ctx, "ncclCommInitRank", r);
+  }
+  if (st != GH_OK) {
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return st;
+  }
+  *out = c;
+  return GH_OK;
+}
+
+extern "C" gh_status gh_comm_create_ipc(gh_ctx* ctx, int rank, int world, const char* rendezvous_name, gh_comm** out) {
+  if (!ctx || !out) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  *out = nullptr;
+  GH_CHECK_ARG(ctx, world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && rendezvous_name && rendezvous_name[0]);
+  gh_comm* c = new (std::nothrow) gh_comm();
+  if (!c) return GH_ERR_NOMEM;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->transport = 1;
+  c->shm_name = std::string(rendezvous_name[0] == '/' ? "" : "/") + rendezvous_name;
+  if (const char* t = getenv("GSLAM_HIP_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
+  gh_status st = comm_common_init(ctx, c);
+  int fd = -1;
+  if (st == GH_OK) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (rank == 0) {
+      shm_unlink(c->shm_name.c_str());  // a stale segment of a crashed run
+      fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd >= 0 && ftruncate(fd, sizeof(ShmSegment)) != 0) {
+        close(fd);
+        fd = -1;
+      }
+    } else {
+      while (fd < 0) {  // rank 0 may not have created it yet
+        fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+        struct stat sb;
+        if (fd >= 0 && (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmSegment))) {
+          close(fd);
+          fd = -1;
+        }
+        if (fd < 0) {
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) break;
+          usleep(1000);
+        }
+      }
+    }
+    if (fd < 0) st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: cannot open rendezvous segment %s", c->shm_name.c_str());
+  }
+  if (st == GH_OK) {
+    void* m = mmap(nullptr, sizeof(ShmSegment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+      st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: mmap of the rendezvous segment failed");
+    } else {
+      c->shm = (ShmSegment*)m;
+      if (rank == 0) {
+        c->shm->arrived.store(0);
+        c->shm->generation.store(0);
+        c->shm->attached.store(0);
+        c->shm->failed.store(0);
+        c->shm->magic.store(0x47534C4Du, std::memory_order_release);
+      } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c->shm->magic.load(std::memory_order_acquire) != 0x47534C4Du) {
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+            st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rank 0 never initialised the rendezvous segment");
+            break;
+          }
+          usleep(200);
+        }
+      }
+      if (st == GH_OK) {
+        c->shm->attached.fetch_add(1);
+        if (!shm_barrier(c)) st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rendezvous timed out (%d ranks expected)", world);
+      }
+    }
+  }
+  if (st != GH_OK) {
+    if (c->shm) munmap(c->shm, sizeof(ShmSegment));
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return st;
+  }
+  *out = c;
+  return GH_OK;
+}
+
+extern "C" void gh_comm_destroy(gh_comm* c) {
+  if (!c) return;
+  GH_ENTER(c->ctx);
+  hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->ctx->stream);
+  if (c->transport == 0) {
+    if (c->nccl) rccl().CommDestroy(c->nccl);
+    for (void* p : c->plain_buffers) hipFree(p);
+  } else {
+    // nobody may unmap a buffer a peer is still writing into
+    if (c->shm && !c->shm->failed.load()) shm_barrier(c);
+    for (auto& b : c->ipc_buffers) {
+      for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && b.peer[r]) hipIpcCloseMemHandle(b.peer[r]);
+    }
+    if (c->shm && !c->shm->failed.load()) shm_barrier(c);
+    for (auto& b : c->ipc_buffers) hipFree(b.mine);
+    if (c->shm) {
+      const int left = c->shm->attached.fetch_sub(1) - 1;
+      munmap(c->shm, sizeof(ShmSegment));
+      if (left == 0 || c->rank == 0) shm_unlink(c->shm_name.c_str());
+    }
+  }
+  hipEventDestroy(c->ev_ready);
+  hipEventDestroy(c->ev_done);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int gh_comm_rank(const gh_comm* c) { return c ? c->rank : -1; }
+extern "C" int gh_comm_world(const gh_comm* c) { return c ? c->world : 0; }
+
+// Collective: every rank calls it with the same size.  Returns a device buffer of world * bytes_per_rank bytes owned by
+// the communicator (freed by gh_comm_destroy); with the IPC transport every peer's copy is mapped into this process.
+extern "C" gh_status gh_comm_buffer(gh_comm* c, size_t bytes_per_rank, void** gathered_dev) {
+  if (!c || !gathered_dev) return GH_ERR_ARG;
+  gh_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
+  *gathered_dev = nullptr;
+  GH_CHECK_ARG(ctx, bytes_per_rank > 0);
+  const size_t total = bytes_per_rank * (size_t)c->world;
+  void* p = nullptr;
+  if (hipMalloc(&p, total) != hipSuccess) return gh_set_error(ctx, GH_ERR_NOMEM, "hipMalloc(%zu) for a gathered buffer", total);
+  if (c->transport == 0) {
+    c->plain_buffers.push_back(p);
+    *gathered_dev = p;
+    return GH_OK;
+  }
+  if ((int)c->ipc_buffers.size() >= kMaxBuffers) {
+    hipFree(p);
+    return gh_set_error(ctx, GH_ERR_ARG, "IPC transport: at most %d gathered buffers per communicator", kMaxBuffers);
+  }
+  IpcBuffer b;
+  b.mine = p;
+  b.bytes_per_rank = bytes_per_rank;
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    c->shm->failed.store(1);
+    hipFree(p);
+    return gh_set_error(ctx, GH_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+  }
+  c->shm->handles[c->rank] = h;
+  c->shm->sizes[c->rank] = total;
+  bool ok = shm_barrier(c);  // every handle is published
+  for (int r = 0; ok && r < c->world; ++r) {
+    if (r == c->rank) {
+      b.peer[r] = p;
+      continue;
+    }
+    if (c->shm->sizes[r] != total) {
+      ok = false;
+      gh_set_error(ctx, GH_ERR_ARG, "gh_comm_buffer: rank %d asked for %llu bytes, this rank for %zu", r,
+                   (unsigned long long)c->shm->sizes[r], total);
+      break;
+    }
+    e = hipIpcOpenMemHandle(&b.peer[r], c->shm->handles[r], hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      ok = false;
+      gh_set_error(ctx, GH_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+    }
+  }
+  if (!ok) c->shm->failed.store(1);
+  if (!shm_barrier(c) || !ok) {  // the handle slots may be reused only after everybody has opened them
+    if (ok) gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a peer failed while exchanging buffer handles");
+    return GH_ERR_HIP;
+  }
+  c->ipc_buffers.push_back(b);
+  *gathered_dev = p;
+  return GH_OK;
+}
+
+extern "C" gh_status gh_allgather(gh_comm* c, const void* send_dev, void* gathered_dev, size_t bytes_per_rank) {
+  if (!c) return GH_ERR_ARG;
+  gh_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, send_dev && gathered_dev && bytes_per_rank > 0);
+  GH_TRY(begin_collective(c));
+  GH_TRY(gather_one(c, send_dev, gathered_dev, bytes_per_rank, bytes_per_rank));
+  return end_collective(c);
+}
+
+// The exchange after extraction (SURVEY.md 8e record {n, KeyPoint[K], desc[K][32]} per frame, kept as the three arrays
+// gh_orb_extract_dev writes): this rank's `frames` frames into slot `rank` of the three gathered arrays.  kps may be
+// NULL on every rank when only descriptors are needed (consecutive-pair matching); the stereo band matcher needs them.
+extern "C" gh_status gh_allgather_features(gh_comm* c, int frames, int cap, const gh_keypoint* kps_dev,
+                                           const uint8_t* desc_dev, const int32_t* counts_dev, gh_keypoint* g_kps_dev,
+                                           uint8_t* g_desc_dev, int32_t* g_counts_dev) {
+  if (!c) return GH_ERR_ARG;
+  gh_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, frames > 0 && cap > 0 && desc_dev && counts_dev && g_desc_dev && g_counts_dev);
+  GH_CHECK_ARG(ctx, (kps_dev == nullptr) == (g_kps_dev == nullptr));
+  GH_TRY(begin_collective(c));
+  if (c->transport == 0) GH_NCCL(ctx, rccl().GroupStart());
+  gh_status st = gather_one(c, desc_dev, g_desc_dev, (size_t)frames * cap * 32, (size_t)frames * cap * 32);
+  if (st == GH_OK) st = gather_one(c, counts_dev, g_counts_dev, (size_t)frames * 4, (size_t)frames * 4);
+  if (st == GH_OK && kps_dev)
+    st = gather_one(c, kps_dev, g_kps_dev, (size_t)frames * cap * sizeof(gh_keypoint), (size_t)frames * cap * sizeof(gh_keypoint));
+  if (c->transport == 0) {
+    ncclResult_t r = rccl().GroupEnd();
+    if (st == GH_OK && r != ncclSuccess) st = rccl_fail(ctx, "ncclGroupEnd", r);
+  }
+  GH_TRY(st);
+  return end_collective(c);
+}
+
+// The exchange after matching: `rows` match rows (cap int32 train indices + optional cap u16 best / second distances).
+extern "C" gh_status gh_allgather_matches(gh_comm* c, int rows, int cap, const int32_t* idx1_dev, const uint16_t* d1_dev,
+                                          const uint16_t* d2_dev, int32_t* g_idx1_dev, uint16_t* g_d1_dev,
+                                          uint16_t* g_d2_dev) {
+  if (!c) return GH_ERR_ARG;
+  gh_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, rows > 0 && cap > 0 && idx1_dev && g_idx1_dev);
+  GH_CHECK_ARG(ctx, (d1_dev == nullptr) == (g_d1_dev == nullptr) && (d2_dev == nullptr) == (g_d2_dev == nullptr));
+  GH_TRY(begin_collective(c));
+  if (c->transport == 0) GH_NCCL(ctx, rccl().GroupStart());
+  gh_status st = gather_one(c, idx1_dev, g_idx1_dev, (size_t)rows * cap * 4, (size_t)rows * cap * 4);
+  if (st == GH_OK && d1_dev) st = gather_one(c, d1_dev, g_d1_dev, (size_t)rows * cap * 2, (size_t)rows * cap * 2);
+  if (st == GH_OK && d2_dev) st = gather_one(c, d2_dev, g_d2_dev, (size_t)rows * cap * 2, (size_t)rows * cap * 2);
+  if (c->transport == 0) {
+    ncclResult_t r = rccl().GroupEnd();
+    if (st == GH_OK && r != ncclSuccess) st = rccl_fail(ctx, "ncclGroupEnd", r);
+  }
+  GH_TRY(st);
+  return end_collective(c);
+}
+
+// Orders the context's stream after the gather in flight (RCCL: no host wait; IPC: blocks until every rank's slice has
+// landed in this rank's buffer).  A no-op when nothing is pending.
+extern "C" gh_status gh_comm_wait(gh_comm* c) {
+  if (!c) return GH_ERR_ARG;
+  gh_ctx* ctx = c->ctx;
+  GH_ENTER(ctx);
+  if (!c->pending) return GH_OK;
+  c->pending = false;
+  if (c->transport == 1) {
+    GH_HIP(ctx, hipStreamSynchronize(c->stream));  // my pushes have landed everywhere ...
+    if (!shm_barrier(c)) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a peer did not finish its pushes");
+    return GH_OK;  // ... and so have everybody else's
+  }
+  GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+  return GH_OK;
+}

@@ -99,6 +99,17 @@ SIGNATURES = {
     "gh_bgr_to_gray_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
     "gh_orb_debug_level": (C.c_int, [_vp, _i, _i, _vp]),
     "gh_synth_frames_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _sz, _i, _i, C.c_uint32]),
+    "gh_comm_unique_id": (C.c_int, [_vp]),
+    "gh_comm_create_rccl": (C.c_int, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "gh_comm_create_ipc": (C.c_int, [_vp, _i, _i, C.c_char_p, C.POINTER(_vp)]),
+    "gh_comm_destroy": (None, [_vp]),
+    "gh_comm_rank": (C.c_int, [_vp]),
+    "gh_comm_world": (C.c_int, [_vp]),
+    "gh_comm_buffer": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "gh_allgather": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "gh_allgather_features": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gh_allgather_matches": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gh_comm_wait": (C.c_int, [_vp]),
     "gh_bow_vocab_create": (C.c_int, [_vp, _i, _i, _i, _i, C.c_uint32, _vp, _vp, C.POINTER(_vp)]),
     "gh_bow_vocab_destroy": (None, [_vp]),
     "gh_bow_transform_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -96,3 +96,86 @@ def exchange_matches_begin(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_
 def exchange_matches(idx1: torch.Tensor, g_idx1: torch.Tensor, frames_per_rank: int):
     """Blocking form of exchange_matches_begin."""
     exchange_matches_begin(idx1, g_idx1, frames_per_rank).wait()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same exchange through the C ABI (include/gslam_hip.h, gh_comm_*): what a C++ host uses, and what bench.py / the
+# tests use from here on.  torch only supplies the views of the gathered buffers and (for RCCL) carries the 128-byte
+# unique id from rank 0 to the other ranks.
+import ctypes as _C
+
+from . import hip as _hip
+
+
+class _DeviceView:
+    """Zero-copy torch view of device memory owned by the communicator (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class Comm:
+    """gh_comm: RCCL all-gather over xGMI, or same-node HIP-IPC direct writes (several ranks may share a GPU)."""
+
+    def __init__(self, ctx, handle, rank, world, transport):
+        self.ctx, self.h, self.rank, self.world, self.transport = ctx, handle, rank, world, transport
+        self._keep = []
+
+    @classmethod
+    def rccl(cls, ctx, rank, world):
+        """Bootstrap: rank 0 creates the id, torch.distributed (any backend) broadcasts its 128 bytes."""
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (_C.c_uint8 * 128)()
+            st = _hip.lib.gh_comm_unique_id(buf)
+            if st != 0:
+                raise _hip.GslamHipError(f"gh_comm_unique_id failed with status {st} (librccl.so.1 not loadable?)")
+            uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        if world > 1:
+            dev = uid.cuda() if dist.get_backend() == "nccl" else uid
+            dist.broadcast(dev, src=0)
+            uid = dev.cpu()
+        raw = (_C.c_uint8 * 128)(*uid.tolist())
+        h = _C.c_void_p()
+        ctx.check(_hip.lib.gh_comm_create_rccl(ctx.h, rank, world, raw, _C.byref(h)))
+        return cls(ctx, h, rank, world, "rccl")
+
+    @classmethod
+    def ipc(cls, ctx, rank, world, name):
+        h = _C.c_void_p()
+        ctx.check(_hip.lib.gh_comm_create_ipc(ctx.h, rank, world, name.encode(), _C.byref(h)))
+        return cls(ctx, h, rank, world, "ipc")
+
+    def close(self):
+        if self.h:
+            self._keep = []
+            _hip.lib.gh_comm_destroy(self.h)
+            self.h = None
+
+    def buffer(self, per_rank_shape, dtype):
+        """Collective.  Gathered buffer of shape (world, *per_rank_shape) as a torch view."""
+        n = int(torch.tensor(per_rank_shape).prod().item()) * torch.empty(0, dtype=dtype).element_size()
+        p = _C.c_void_p()
+        self.ctx.check(_hip.lib.gh_comm_buffer(self.h, n, _C.byref(p)))
+        view = _DeviceView(p.value, n * self.world)
+        t = torch.as_tensor(view, device="cuda").view(dtype).view(self.world, *per_rank_shape)
+        assert t.data_ptr() == p.value
+        self._keep.append(view)
+        return t
+
+    def allgather_features(self, desc, counts, g_desc, g_counts, kps=None, g_kps=None):
+        F, K = desc.shape[0], desc.shape[1]
+        p = lambda t: _C.c_void_p(t.data_ptr()) if t is not None else None
+        self.ctx.check(_hip.lib.gh_allgather_features(self.h, F, K, p(kps), p(desc), p(counts), p(g_kps), p(g_desc), p(g_counts)))
+
+    def allgather_matches(self, idx1, g_idx1, d1=None, g_d1=None, d2=None, g_d2=None):
+        R, K = idx1.shape
+        p = lambda t: _C.c_void_p(t.data_ptr()) if t is not None else None
+        self.ctx.check(_hip.lib.gh_allgather_matches(self.h, R, K, p(idx1), p(d1), p(d2), p(g_idx1), p(g_d1), p(g_d2)))
+
+    def allgather(self, send, gathered):
+        self.ctx.check(_hip.lib.gh_allgather(self.h, _C.c_void_p(send.data_ptr()), _C.c_void_p(gathered.data_ptr()),
+                                             send.numel() * send.element_size()))
+
+    def wait(self):
+        self.ctx.check(_hip.lib.gh_comm_wait(self.h))

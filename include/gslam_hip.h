@@ -165,6 +165,38 @@ gh_status gh_orb_debug_level(gh_orb_plan* plan, int slot, int level, uint8_t* ou
 gh_status gh_synth_frames_dev(gh_ctx* ctx, uint8_t* gray_dev, int width, int height, int row_stride,
                               size_t frame_stride, int first_frame, int n_frames, uint32_t base_seed);
 
+/* ------------------------------------------------------------------ multi-GPU exchange */
+/* Frames shard over the GPUs of one node (one process per GPU); the only data-path exchange is an
+ * all-gather of the per-frame records after extraction and, optionally, of the match rows after matching.  The
+ * reference has no transport (GSLAM's Messenger is in-process, GSLAM/core/Messenger.h:455-468,687-715), so these entry
+ * points are what a multi-GPU C++ host adds; no Python / torch is involved.
+ *   RCCL transport: rank 0 calls gh_comm_unique_id and hands the 128 bytes to the other ranks by any out-of-band means
+ *     (file, socket, MPI, torch.distributed broadcast), then every rank calls gh_comm_create_rccl.  ncclAllGather over
+ *     xGMI on the communicator's own stream.
+ *   IPC transport (same node): every rank calls gh_comm_create_ipc with the same rendezvous name; peers' gathered
+ *     buffers are mapped through HIP IPC and each rank pushes its slice into all of them.  Also works when several ranks
+ *     share one GPU (RCCL refuses that).  gh_comm_wait blocks the host with this transport.
+ * A gather is ordered after the work already enqueued on the context's stream and runs beside it; gh_comm_wait orders
+ * the context's stream after the gather.  Gathered buffers must come from gh_comm_buffer (a collective call). */
+typedef struct gh_comm gh_comm;
+gh_status gh_comm_unique_id(uint8_t id_out[128]);
+gh_status gh_comm_create_rccl(gh_ctx* ctx, int rank, int world, const uint8_t unique_id[128], gh_comm** out);
+gh_status gh_comm_create_ipc(gh_ctx* ctx, int rank, int world, const char* rendezvous_name, gh_comm** out);
+void gh_comm_destroy(gh_comm* comm);
+int gh_comm_rank(const gh_comm* comm);
+int gh_comm_world(const gh_comm* comm);
+gh_status gh_comm_buffer(gh_comm* comm, size_t bytes_per_rank, void** gathered_dev); /* world x bytes_per_rank */
+gh_status gh_allgather(gh_comm* comm, const void* send_dev, void* gathered_dev, size_t bytes_per_rank);
+/* This rank's `frames` frames of gh_orb_extract_dev output into slot `rank` of the gathered arrays
+ * (world x frames x cap records).  kps_dev / g_kps_dev may both be NULL when only descriptors are needed. */
+gh_status gh_allgather_features(gh_comm* comm, int frames, int cap, const gh_keypoint* kps_dev, const uint8_t* desc_dev,
+                                const int32_t* counts_dev, gh_keypoint* g_kps_dev, uint8_t* g_desc_dev,
+                                int32_t* g_counts_dev);
+/* `rows` match rows of this rank (cap entries each) into slot `rank`; d1 / d2 (and their gathered arrays) may be NULL. */
+gh_status gh_allgather_matches(gh_comm* comm, int rows, int cap, const int32_t* idx1_dev, const uint16_t* d1_dev,
+                               const uint16_t* d2_dev, int32_t* g_idx1_dev, uint16_t* g_d1_dev, uint16_t* g_d2_dev);
+gh_status gh_comm_wait(gh_comm* comm);
+
 /* ------------------------------------------------------------------ BoW transform ---- */
 /* GSLAM::Vocabulary image -> BoW vector (GSLAM/core/Vocabulary.h:1558-1621, per-feature descent :1695-1736,
  * normalisation :386-408), for 32-byte binary descriptors.  The vocabulary is given in the in-memory layout of the
