@@ -67,8 +67,8 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (150 x ~20 ms = a 3 s timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (C2: 1000)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-bow", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 legs (10k cams / 1M points LM, n = 60000 dense solve)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="N > 1: exchange through torch.distributed instead of the C-ABI communicator (gh_comm_*)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="bounded CPU sample (frames; 1000 = the whole C2 step, ~10 s on 16 cores)")
     ap.add_argument("--ba-cams", type=int, default=500)
     ap.add_argument("--ba-points", type=int, default=50000)
@@ -118,15 +122,42 @@ def main():
     # synthetic frames resident in HBM before the timed region; global frame index = rank * F + f
     frames = synth_frames(ctx, F, W, H, base_seed=0x5EED0000, first_frame=rank * F, device=dev)
     kps, desc, counts = ex.alloc_outputs(F, dev)
+    # N > 1: the exchange goes through the C-ABI communicator (gh_comm_*: ncclAllGather on its own stream; what a C++
+    # host would call).  If RCCL cannot be brought up through it, fall back to torch.distributed's RCCL and say so.
+    comm, comm_note = None, None
+    if world > 1 and not a.torch_collectives:
+        from gslam_amd.sharding import Comm
+        try:
+            comm = Comm.ipc(ctx, rank, world, "gslam_bench_%s" % os.environ.get("MASTER_PORT", "0")) if dry else \
+                Comm.rccl(ctx, rank, world)
+            comm_note = "gh_comm (%s)" % comm.transport
+        except Exception as exc:  # noqa: BLE001
+            comm, comm_note = None, "torch.distributed (gh_comm failed: %r)" % (exc,)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device("cpu") if dry else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:  # some rank failed: everybody falls back together
+            comm.close()
+            comm, comm_note = None, "torch.distributed (gh_comm failed on another rank)"
+    elif world > 1:
+        comm_note = "torch.distributed"
     # gathered buffers (every GPU holds every frame's descriptors after the exchange)
-    g_desc = torch.empty((world * F, K, 32), dtype=torch.uint8, device=dev) if world > 1 else desc
-    g_counts = torch.empty(world * F, dtype=torch.int32, device=dev) if world > 1 else counts
+    if comm is not None:
+        g_desc_b = comm.buffer((F, K, 32), torch.uint8)
+        g_counts_b = comm.buffer((F,), torch.int32)
+        g_desc, g_counts = g_desc_b.view(world * F, K, 32), g_counts_b.view(world * F)
+    else:
+        g_desc = torch.empty((world * F, K, 32), dtype=torch.uint8, device=dev) if world > 1 else desc
+        g_counts = torch.empty(world * F, dtype=torch.int32, device=dev) if world > 1 else counts
     pq, pt = local_pairs(rank, world, F, dev)
     P = pq.shape[0]
-    m_idx = torch.empty((P, K), dtype=torch.int32, device=dev)
+    m_full = torch.full((F, K), -1, dtype=torch.int32, device=dev)  # F rows on every rank: the last global frame has no pair
+    m_idx = m_full[:P]
     m_d1 = torch.empty((P, K), dtype=torch.int16, device=dev)
     m_d2 = torch.empty((P, K), dtype=torch.int16, device=dev)
-    g_match = torch.empty((world, F, K), dtype=torch.int32, device=dev) if world > 1 else None
+    if comm is not None:
+        g_match = comm.buffer((F, K), torch.int32)
+    else:
+        g_match = torch.empty((world, F, K), dtype=torch.int32, device=dev) if world > 1 else None
 
     # Of this rank's consecutive pairs (g, g + 1) only the last one needs another rank's frame: the F - 1 purely local
     # pairs are matched straight from the local descriptors while the all-gather of the descriptors is in flight.
@@ -139,13 +170,24 @@ def main():
     match_gather = [None]  # all-gather of the previous step's match rows, still in flight during the next extraction
 
     def finish_match_gather():
-        if match_gather[0] is not None:
+        if comm is not None:
+            comm.wait()
+        elif match_gather[0] is not None:
             match_gather[0].wait()
             match_gather[0] = None
 
     def step():
         ex.extract(frames, (kps, desc, counts))
-        if world > 1:
+        if comm is not None:
+            comm.wait()  # the previous step's match gather (it ran behind this step's extraction)
+            comm.allgather_features(desc, counts, g_desc_b, g_counts_b)
+            if n_local > 0:
+                matcher.match_pairs(desc, counts, lq, lt, out=out_local)
+            comm.wait()
+            if P > n_local:  # the boundary pair against the next rank's first frame
+                matcher.match_pairs(g_desc, g_counts, pq[n_local:], pt[n_local:], out=out_rest)
+            comm.allgather_matches(m_full, g_match)
+        elif world > 1:
             pending = exchange_features_begin(desc, counts, g_desc, g_counts)
             finish_match_gather()  # g_match of the previous step complete before anything of this step replaces it
             if n_local > 0:
@@ -182,6 +224,7 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(ref[0], m_idx) and torch.equal(ref[1], m_d1) and torch.equal(ref[2], m_d2), "overlap mismatch"
         assert torch.equal(g_match[rank, :P], m_idx) and bool((g_match[rank, P:] == -1).all()), "match gather mismatch"
+        assert bool((g_counts > 0).all()), "feature gather incomplete"
         log(f"rank {rank}: overlapped matching verified against the plain call ({P} pairs)")
     if world > 1:
         cdev = torch.device("cpu") if dry else dev
@@ -195,7 +238,61 @@ def main():
         total_kpts_step = int(counts.sum().item())
     n_pairs_step = int((g_counts[pq.long()].to(torch.int64) * g_counts[pt.long()].to(torch.int64)).sum().item())
 
+    # ---- C3 at N > 1 (BASELINE configs[2]: per-frame stereo extract + match sharded over the GPUs, all-gather of the
+    #      records): every rank extracts its own S stereo frames, matches left-right inside the row band (needs keypoints)
+    #      and left(t) -> left(t+1); the pair that crosses the rank boundary is matched from the gathered records, for which
+    #      gh_allgather_features carries descriptors, counts AND keypoints.
+    c3_multi = None
+    if world > 1 and comm is not None and not a.no_c3:
+        try:
+            Ws, Hs, S = 1241, 376, 500
+            ex3 = OrbExtractor(ctx, Ws, Hs, max_batch=2 * S, n_features=K)
+            eyes = synth_frames(ctx, 2 * S, Ws, Hs, base_seed=0xC3000000, first_frame=rank * 2 * S, row_stride=1244, device=dev)
+            o3 = ex3.alloc_outputs(2 * S, dev)
+            gk3 = comm.buffer((2 * S, K, 7), torch.float32)
+            gd3 = comm.buffer((2 * S, K, 32), torch.uint8)
+            gc3 = comm.buffer((2 * S,), torch.int32)
+            lq3 = torch.arange(0, 2 * S, 2, dtype=torch.int32, device=dev)   # L_t -> R_t (local)
+            rq3 = lq3 + 1
+            tq3, tt3 = lq3[:-1].contiguous(), lq3[1:].contiguous()           # L_t -> L_{t+1} inside the rank
+            has_next = rank + 1 < world
+            bq = torch.tensor([rank * 2 * S + 2 * S - 2], dtype=torch.int32, device=dev)  # my last left eye ...
+            bt = torch.tensor([(rank + 1) * 2 * S], dtype=torch.int32, device=dev)        # ... -> the next rank's first
+
+            def step3():
+                ex3.extract(eyes, o3)
+                comm.allgather_features(o3[1], o3[2], gd3, gc3, o3[0], gk3)
+                matcher.match_band_pairs(o3[1], o3[0], o3[2], lq3, rq3, 2.0 / 31.0)
+                matcher.match_pairs(o3[1], o3[2], tq3, tt3)
+                comm.wait()
+                if has_next:
+                    matcher.match_pairs(gd3.view(world * 2 * S, K, 32), gc3.view(world * 2 * S), bq, bt)
+
+            step3()
+            barrier()
+            t1 = time.perf_counter()
+            reps3 = 3
+            for _ in range(reps3):
+                step3()
+            barrier()
+            dt3 = torch.tensor([(time.perf_counter() - t1) / reps3], dtype=torch.float64,
+                               device=torch.device("cpu") if dry else dev)
+            dist.all_reduce(dt3, op=dist.ReduceOp.MAX)
+            k3 = o3[2].sum().to(torch.int64).to(dt3.device)
+            dist.all_reduce(k3)
+            c3_multi = {"workload": "C3: %d stereo frames 1241x376 x 2 eyes per GPU, K=%d per eye; band-limited L-R match, "
+                                    "temporal L-L match incl. the pair across the rank boundary from gathered records "
+                                    "(descriptors + counts + keypoints all-gathered)" % (S, K),
+                        "stereo_frames_per_s": round(S * world / float(dt3.item()), 1),
+                        "Mkeypoints_per_s": round(int(k3.item()) / float(dt3.item()) / 1e6, 2),
+                        "ms_per_batch": round(float(dt3.item()) * 1e3, 3), "exchange": comm_note}
+            ex3.close()
+        except Exception as exc:  # noqa: BLE001  (an optional leg must never cost the headline line)
+            c3_multi = {"error": repr(exc)}
+
     if rank != 0:
+        if comm is not None:
+            comm.close()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -225,22 +322,31 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                 "note": "HBM is the contractual bound (SURVEY.md 8d); SQ counters show this kernel VALU-issue bound "
                         "(profiles/README.md), so frac understates how close the kernel is to ITS limit"}
-    # VALU-issue view of the same kernel: wave-instructions issued per second (SQ_INSTS_VALU from a separate --pmc
-    # pass, profiles/sq_counters.json) against one VALU instruction per SIMD per 4 cycles
+    # VALU-issue view of the same kernel.  The ceiling is MEASURED in this run (gh_valu_issue_probe: register-only chains of
+    # each instruction class, 8 waves / SIMD); the kernel's instruction count per launch comes from a separate
+    # rocprofv3 --pmc pass (SQ_INSTS_VALU, profiles/sq_counters.json) and is labelled as such.
+    probes = {}
+    try:
+        probes = ctx.valu_issue_probes()
+    except Exception as exc:  # noqa: BLE001
+        probes = {"error": repr(exc)}
     spath = os.path.join(ROOT, "profiles", "sq_counters.json")
-    if os.path.exists(spath):
+    if os.path.exists(spath) and "fast_cells mix" in probes:
         try:
             rec = json.load(open(spath)).get(dom, {})
             if rec:
                 insts = rec["SQ_INSTS_VALU_per_launch"] * F / rec["frames_per_launch"]
                 info0 = ctx.device_info()
-                peak_issue = info0["cu_count"] * 4 * 2.4e9 / 4.0
+                peak_issue = probes["fast_cells mix"]
+                simd_clk = info0["cu_count"] * 4 * info0["clock_khz"] * 1e3
                 roofline["valu_issue"] = {"wave_insts_per_launch": int(insts),
+                                          "wave_insts_source": "profiles/sq_counters.json (SQ_INSTS_VALU, separate --pmc pass)",
                                           "achieved_Ginst_per_s": round(insts / (avg_ms * 1e-3) / 1e9, 1),
                                           "peak_Ginst_per_s": round(peak_issue / 1e9, 1),
+                                          "peak_source": "measured in this run: perm / pk_max / pk_min / max3 / min3 / dot4 / "
+                                                         "alignbyte / add interleaved, 8 waves per SIMD",
                                           "frac": round(insts / (avg_ms * 1e-3) / peak_issue, 3),
-                                          "note": "1 VALU wave-instruction / SIMD / 4 clk at 2.4 GHz; multi-pass "
-                                                  "instructions make the true ceiling lower"}
+                                          "clk_per_wave_inst_at_reported_clock": round(simd_clk / peak_issue, 2)}
         except Exception:
             pass
     orb_ms = sum(v["total_ms"] for v in orb_k.values())
@@ -281,12 +387,15 @@ def main():
     except Exception as exc:
         bf["all_pairs"] = {"error": repr(exc)}
 
-    extra = {"bf_match": bf, "kernels": kernels, "roofline_pipeline": pipeline}
+    extra = {"bf_match": bf, "kernels": kernels, "roofline_pipeline": pipeline,
+             "valu_issue_probes_Ginst_per_s": {k: (round(v / 1e9, 1) if isinstance(v, float) else v) for k, v in probes.items()}}
+    if c3_multi is not None:
+        extra["c3_stereo"] = c3_multi
     info = ctx.device_info()
     if world > 1:
         # the CPU baseline is reported at N = 1 only (contract), and the single-GPU side legs (BA, BoW) add nothing
         # to a scaling line: the other ranks have already left
-        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = True
+        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = a.no_c5 = a.no_host_fed = True
 
     # ---- C3 (KITTI-like stereo 1241x376 x 2): extract both eyes, row-band left-right match, temporal match
     def _leg_c3():
@@ -331,40 +440,131 @@ def main():
         extra.setdefault("errors", {})["c3"] = repr(exc)
         log("c3 leg failed: %r" % (exc,))
 
-    # ---- BA (C4) on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve
-    def _leg_ba():
-        if not a.no_ba:
-            from gslam_amd import ba
-            from gslam_amd.ba_synth import make_graph
-            log("BA leg: building graph")
-            g = make_graph(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
-            log("BA leg: warm-up solve")
-            ba.solve(ctx, g, ba.default_options(max_iterations=2))  # warm-up (allocations, code load)
-            log("BA leg: timed solve")
-            _, _, s, st = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))  # timed without event overhead
-            ctx.prof_enable(True)
-            _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=a.ba_iters))  # same solve, per-kernel events
-            bprof = ctx.prof_collect()
-            ctx.prof_enable(False)
-            n = 6 * a.ba_cams
-            solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * s.iterations
-            chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ("ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel",
-                                                                             "ba_syrk_trailing", "ba_trsv_fwd",
-                                                                             "ba_trsv_bwd"))
-            extra["ba"] = {"workload": f"{'C5' if a.ba_cams >= 10000 else 'C4'}: {a.ba_cams} cams, {a.ba_points} pts, {len(g['obs_cam'])} obs, Huber LM",
-                           "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
-                           "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
-                           "dense_solve": {"bound": "mfma", "n": n,
-                                           "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3) if chol_ms else None,
-                                           "peak_TFLOPs": FP64_MFMA_PEAK / 1e12},
-                           "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
-                                       for k, v in bprof.items()}}
+    # ---- BA on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve.  C4 (500 cams / 50 k points /
+    #      300 k observations) and, by default at N = 1, C5 (10 k cams / 1 M points / 6 M observations: the n = 60000 dense
+    #      reduced-camera solve on MFMA f64), followed by a stand-alone n = 60000 solve whose residual is asserted.
+    CHOL = ("ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel", "ba_syrk_trailing", "ba_trsv_fwd", "ba_trsv_bwd",
+            "ba_chol_fused")
+
+    def ba_leg(cams, points, iters, separate_timed_run):
+        from gslam_amd import ba
+        from gslam_amd.ba_synth import make_graph
+        name = "C5" if cams >= 10000 else "C4"
+        log(f"BA leg {name}: building graph")
+        g = make_graph(cams, points, n_obs_per_point=6, seed=1)
+        log(f"BA leg {name}: warm-up solve")
+        ba.solve(ctx, g, ba.default_options(max_iterations=1 if cams >= 10000 else 2))  # allocations, code load
+        s = None
+        if separate_timed_run:  # small graphs: time without the event overhead, then repeat with per-kernel events
+            log(f"BA leg {name}: timed solve")
+            _, _, s, _ = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
+        ctx.prof_enable(True)
+        _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
+        bprof = ctx.prof_collect()
+        ctx.prof_enable(False)
+        s = s or sp
+        n = 6 * cams
+        solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * sp.iterations
+        chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CHOL)
+        launches = sum(v["launches"] for v in bprof.values())
+        return {"workload": f"{name}: {cams} cams, {points} pts, {len(g['obs_cam'])} obs, Huber LM",
+                "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
+                "ms_per_iteration": round(s.total_ms / max(1, s.iterations), 3),
+                "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
+                "launches_per_iteration": round(launches / max(1, sp.iterations), 1),
+                "hbm_floor": {"bytes_per_iteration": 640 * len(g["obs_cam"]) + 16 * n * n,
+                              "frac": round((640 * len(g["obs_cam"]) + 16 * n * n) / HBM_PEAK / (s.total_ms * 1e-3 / max(1, s.iterations)), 4)},
+                "dense_solve": {"bound": "mfma", "n": n,
+                                "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3) if chol_ms else None,
+                                "peak_TFLOPs": FP64_MFMA_PEAK / 1e12,
+                                "frac": round(solve_flops / (chol_ms * 1e-3) / FP64_MFMA_PEAK, 4) if chol_ms else None},
+                "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in bprof.items()}}
+
+    def dense_solve_check(n):
+        """gh_potrf_solve_dev on a well conditioned SPD system of the C5 size: TFLOP/s and ||A x - b|| / ||b|| <= 1e-10."""
+        import ctypes as C
+        gen = torch.Generator(device=dev).manual_seed(n)
+        M = torch.randn((n, 256), dtype=torch.float64, device=dev, generator=gen)
+        A = M @ M.T
+        A /= 256.0
+        A.diagonal().add_(4.0)
+        bvec = torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+        Lf, x = A.clone(), bvec.clone()
+        info = C.c_int()
+        ctx.prof_enable(True)
+        ctx.check(hip.lib.gh_potrf_solve_dev(ctx.h, C.c_void_p(Lf.data_ptr()), n, n, C.c_void_p(x.data_ptr()), C.byref(info)))
+        p = ctx.prof_collect()
+        ctx.prof_enable(False)
+        ms = sum(v["total_ms"] for k, v in p.items() if k in CHOL)
+        res = float(torch.linalg.norm(A @ x - bvec) / torch.linalg.norm(bvec))
+        assert info.value == 0 and res <= 1e-10, (info.value, res)
+        fl = n ** 3 / 3.0 + 2.0 * n * n
+        return {"n": n, "relative_residual": res, "ms": round(ms, 2), "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2),
+                "peak_TFLOPs": FP64_MFMA_PEAK / 1e12, "frac": round(fl / (ms * 1e-3) / FP64_MFMA_PEAK, 4),
+                "launches": sum(v["launches"] for v in p.values())}
 
     try:
-        _leg_ba()
+        if not a.no_ba:
+            extra["ba"] = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True)
     except Exception as exc:  # an optional leg must never cost the headline line
         extra.setdefault("errors", {})["ba"] = repr(exc)
         log("ba leg failed: %r" % (exc,))
+    try:
+        if not a.no_ba and not a.no_c5 and a.ba_cams < 10000:
+            extra["ba_c5"] = ba_leg(10000, 1000000, 3, False)
+            torch.cuda.empty_cache()
+            log("dense solve check n = 60000")
+            extra["ba_c5"]["dense_solve_check"] = dense_solve_check(60000)
+            torch.cuda.empty_cache()
+    except Exception as exc:  # noqa: BLE001
+        extra.setdefault("errors", {})["ba_c5"] = repr(exc)
+        log("c5 leg failed: %r" % (exc,))
+
+    # ---- PCIe-inclusive rate (SURVEY.md 8d defines the metric with H2D / D2H unless stated device-resident; `value` is
+    #      device-resident by contract, this is the same extraction fed from pinned host memory, double-buffered)
+    def _leg_host_fed():
+        Fh, CH = min(F, 200), 50
+        host = torch.empty((Fh, H, W), dtype=torch.uint8).pin_memory()
+        host.copy_(frames[:Fh, :, :W])
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        ctxs = [hip.Context(local_rank, stream=st.cuda_stream) for st in streams]
+        exs = [OrbExtractor(c, W, H, max_batch=CH, n_features=K) for c in ctxs]
+        bufs = [torch.empty((CH, H, W), dtype=torch.uint8, device=dev) for _ in streams]
+        outs = [e.alloc_outputs(CH, dev) for e in exs]
+        out_host = [torch.empty((Fh,) + tuple(t.shape[1:]), dtype=t.dtype).pin_memory() for t in outs[0]]
+
+        def run():
+            for i, c0 in enumerate(range(0, Fh, CH)):
+                k = i & 1
+                with torch.cuda.stream(streams[k]):
+                    bufs[k].copy_(host[c0:c0 + CH], non_blocking=True)
+                    exs[k].extract(bufs[k], outs[k])
+                    for hh, dd in zip(out_host, outs[k]):
+                        hh[c0:c0 + CH].copy_(dd, non_blocking=True)
+            torch.cuda.synchronize()
+
+        run()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            run()
+        dt = (time.perf_counter() - t1) / 3
+        kp = int(out_host[2].sum())
+        extra["host_fed"] = {"what": "same extraction, frames in pinned host memory -> H2D -> extract -> D2H of keypoints, "
+                                     "descriptors, counts; two streams, chunks of %d frames" % CH,
+                             "frames": Fh, "Mkeypoints_per_s": round(kp / dt / 1e6, 2),
+                             "h2d_GB_per_s": round(Fh * W * H / dt / 1e9, 1), "ms": round(dt * 1e3, 2)}
+        for e in exs:
+            e.close()
+        for c in ctxs:
+            c.close()
+
+    try:
+        if not a.no_host_fed:
+            _leg_host_fed()
+    except Exception as exc:  # noqa: BLE001
+        extra.setdefault("errors", {})["host_fed"] = repr(exc)
+        log("host-fed leg failed: %r" % (exc,))
 
     # ---- BoW transform (SURVEY.md 8 f1): the extracted descriptors of this step through GSLAM::Vocabulary-style
     #      k=10 trees (L=4 / L=6, the two sizes the reference publishes: 615.5 / 723.7 us per image on an i7-6700)
@@ -497,12 +697,14 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"C2: {F}x{W}x{H} frames per GPU, {K} ORB kpts each, BF Hamming consecutive-pair match",
                    "frames_per_gpu": F, "width": W, "height": H, "kpts_per_frame": K,
-                   "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of descriptors + matches"
+                   "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of descriptors + matches via {comm_note}"
                    if world > 1 else "single GPU",
                    "device": info["name"], "cu_count": info["cu_count"]},
         "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
     }
     print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "gh_bf_match_band_pairs_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, C.c_float, _vp, _vp, _vp]),
     "gh_match_mask_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "gh_bf_valu_probe": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "gh_valu_issue_probe": (C.c_int, [_vp, _i, C.POINTER(C.c_double), C.c_char_p, _i]),
     "gh_orb_default_params": (None, [C.POINTER(OrbParams)]),
     "gh_orb_plan_create": (C.c_int, [_vp, _i, _i, _i, C.POINTER(OrbParams), C.POINTER(_vp)]),
     "gh_orb_plan_destroy": (None, [_vp]),
@@ -183,6 +184,19 @@ class Context:
         name = C.create_string_buffer(128)
         self.check(lib.gh_device_info(self.h, C.byref(cu), C.byref(clk), C.byref(mem), name, 128))
         return {"cu_count": cu.value, "clock_khz": clk.value, "hbm_bytes": mem.value, "name": name.value.decode()}
+
+    def valu_issue_probes(self):
+        """{instruction class: measured wave-instructions / s over the whole device}."""
+        out = {}
+        op = 0
+        while True:
+            r = C.c_double()
+            name = C.create_string_buffer(32)
+            if lib.gh_valu_issue_probe(self.h, op, C.byref(r), name, 32) != GH_OK:
+                break
+            out[name.value.decode()] = r.value
+            op += 1
+        return out
 
     def prof_enable(self, on=True):
         self.check(lib.gh_prof_enable(self.h, 1 if on else 0))

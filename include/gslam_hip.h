@@ -107,6 +107,12 @@ gh_status gh_match_mask_dev(gh_ctx* ctx, const int32_t* idx1_dev, const uint16_t
  * rate in 256-bit pair-equivalents per second (16 VALU ops each). */
 gh_status gh_bf_valu_probe(gh_ctx* ctx, double* pairs_per_s);
 
+/* Issue-rate probes per VALU instruction class of the ORB / matcher inner loops (register-only chains, 8 waves per
+ * SIMD): wave-instructions per second over the whole device for op = 0, 1, ... ; GH_ERR_ARG past the last op.  name (may
+ * be NULL) receives the instruction class.  bench.py reports them as the MEASURED issue ceiling of the VALU-bound
+ * kernels instead of an assumed cycles-per-instruction figure. */
+gh_status gh_valu_issue_probe(gh_ctx* ctx, int op, double* wave_insts_per_s, char* name, int name_cap);
+
 /* ------------------------------------------------------------------ ORB front end ---- */
 /* Layout-identical to GSLAM::KeyPoint (GSLAM/core/Map.h:122-195, sizeof == 28). */
 typedef struct gh_keypoint {
