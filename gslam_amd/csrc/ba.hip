@@ -922,17 +922,33 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   Problem P{nc, np, no, d_poses, d_dof, d_pts, d_pfree, d_ocam, d_opt, d_oxy, d_oinfo,
             d_pstart, d_plist, d_cstart, d_clist, opt.huber_delta};
 
-  auto eval_cost = [&](const double* poses_eval, const double* pts_eval, int with_model, double* host2) -> gh_status {
+  // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
+  // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the
+  // middle of the launch chain, which left the GPU idle while the rest of the iteration was being enqueued.
+  struct Readback {
+    double cost, model;
+    unsigned long long gmax_bits;
+    int info, bad;
+  };
+  Readback* rb = nullptr;
+  {
+    void* pp = nullptr;
+    GH_TRY(gh_pinned(ctx, 256, &pp));
+    rb = (Readback*)pp;
+  }
+  auto eval_cost = [&](const double* poses_eval, const double* pts_eval, int with_model) -> gh_status {
     GH_LAUNCH(ctx, "ba_eval", eval_kernel, dim3(eval_blocks), dim3(256), 0, P, poses_eval, pts_eval, d_dc, d_dp,
               with_model, d_partial);
     GH_LAUNCH(ctx, "ba_reduce", reduce_final_kernel, dim3(1), dim3(256), 0, d_partial, eval_blocks, d_out);
-    GH_HIP(ctx, hipMemcpyAsync(host2, d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(&rb->cost, d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GH_OK;
   };
 
   double h2[2];
-  GH_TRY(eval_cost(d_poses, d_pts, 0, h2));
+  GH_TRY(eval_cost(d_poses, d_pts, 0));
+  h2[0] = rb->cost;
+  h2[1] = rb->model;
   if (opt.verbose)
     fprintf(stderr, "[gh_ba] setup: index lists %.2f ms (%zu Schur pairs, %d blocks), upload + first cost %.2f ms\n",
             t_lists - t_begin, pair_a.size(), nblocks, now_ms() - t_lists);
@@ -950,17 +966,12 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       if (nchunks > 0) GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_kernel, dim3(nchunks), dim3(256), 0, P, CC, d_cpart, d_W);
       GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_reduce_kernel, dim3(gh_div_up(nc, 8)), dim3(256), 0, nc, CC,
                 (const double*)d_cpart, d_Hcc, d_gc, d_gmax);
-      unsigned long long bits = 0;
-      GH_HIP(ctx, hipMemcpyAsync(&bits, d_gmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
-      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      double gmax;
-      memcpy(&gmax, &bits, sizeof(double));
-      if (gmax <= opt.gradient_tolerance) {
-        term = 2;
-        break;
-      }
-      need_lin = false;
+      // the gradient test is evaluated at the iteration's single synchronisation point below; if it fires, the step
+      // computed meanwhile is simply dropped (same decisions as testing here, one host round trip less)
+      GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     }
+    const bool fresh_lin = need_lin;
+    need_lin = false;
     GH_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
     if (np > 0)
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
@@ -989,9 +1000,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     // synchronisation per iteration instead of three.
     GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork));
-    int flags[2] = {0, 0};
-    GH_HIP(ctx, hipMemcpyAsync(&flags[0], d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    GH_HIP(ctx, hipMemcpyAsync(&flags[1], d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_LAUNCH(ctx, "ba_rhs_row", row_to_vec_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_S, lda, n, d_work);
     GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv));
     if (np > 0)
@@ -999,9 +1009,19 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
                 d_dp, (const double*)d_W);
     GH_LAUNCH(ctx, "ba_update", update_state_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, nc, np,
               d_poses, d_dof, d_pts, d_dc, d_dp, d_poses_new, d_pts_new);
-    GH_TRY(eval_cost(d_poses_new, d_pts_new, 1, h2));  // synchronises
+    GH_TRY(eval_cost(d_poses_new, d_pts_new, 1));  // the iteration's one synchronisation
+    h2[0] = rb->cost;
+    h2[1] = rb->model;
     sum->solve_ms_total += now_ms() - t_solve0;
-    const bool ok = flags[0] == 0 && flags[1] == 0;
+    if (fresh_lin) {
+      double gmax;
+      memcpy(&gmax, &rb->gmax_bits, sizeof(double));
+      if (gmax <= opt.gradient_tolerance) {
+        term = 2;
+        break;
+      }
+    }
+    const bool ok = rb->info == 0 && rb->bad == 0;
     double new_cost = cost, model = 0, rho = -1;
     if (ok) {
       new_cost = h2[0];
