@@ -894,6 +894,51 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   delete p;
 }
 
+// The device copy of the test pattern holds, per (bin, test), the two byte offsets into the 27 x 28 blurred patch
+// ((13 + y) * kBlurPitch + 13 + x as two u16) instead of the four int8 coordinates: saves the sign extensions and
+// address arithmetic of 256 tests per keypoint.  rot = [30][256][4] rotated coordinates, each within +-13.
+static gh_status upload_pattern(gh_orb_plan* p, const int8_t* rot) {
+  static_assert(sizeof(GH_ORB_PATTERN) == 30 * 256 * 4, "pattern table layout");
+  std::vector<uint32_t> off(30 * 256);
+  for (int b = 0; b < 30; ++b)
+    for (int t = 0; t < 256; ++t) {
+      const int8_t* q = rot + ((size_t)b * 256 + t) * 4;
+      const uint32_t oa = (uint32_t)((13 + q[1]) * kBlurPitch + 13 + q[0]), ob = (uint32_t)((13 + q[3]) * kBlurPitch + 13 + q[2]);
+      off[b * 256 + t] = oa | (ob << 16);
+    }
+  return gh_dev_upload(p->ctx, p->d_pattern, off.data(), off.size() * sizeof(uint32_t));
+}
+
+// Steered-BRIEF look-up table of a caller-supplied test pattern (Rublee et al. 2011, section 4.2): bin k rotates every
+// point by 12 k degrees, (x', y') = (round(x cos - y sin), round(x sin + y cos)), round half away from zero -- the rule
+// tools/gen_orb_tables.py used for the built-in pattern, so handing the built-in bin-0 pattern back reproduces it.
+extern "C" gh_status gh_orb_plan_set_pattern(gh_orb_plan* p, const int8_t* pattern) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, pattern != nullptr);
+  std::vector<int8_t> rot((size_t)30 * 256 * 4);
+  auto rnd = [](double v) { return (int)floor(fabs(v) + 0.5) * (v >= 0 ? 1 : -1); };
+  for (int k = 0; k < 30; ++k) {
+    const double th = (12.0 * k) * (3.14159265358979323846 / 180.0), c = cos(th), s = sin(th);
+    for (int t = 0; t < 256; ++t) {
+      const int8_t* q = pattern + 4 * t;
+      const int v[4] = {rnd(q[0] * c - q[1] * s), rnd(q[0] * s + q[1] * c), rnd(q[2] * c - q[3] * s), rnd(q[2] * s + q[3] * c)};
+      for (int e = 0; e < 4; ++e) {
+        if (v[e] < -13 || v[e] > 13)
+          return gh_set_error(ctx, GH_ERR_ARG,
+                              "test %d of the pattern leaves the +-13 px blurred patch when rotated by %d degrees "
+                              "(points must lie within radius 13.49 of the keypoint)", t, 12 * k);
+        rot[((size_t)k * 256 + t) * 4 + e] = (int8_t)v[e];
+      }
+      if (k == 0 && v[0] == v[2] && v[1] == v[3])
+        return gh_set_error(ctx, GH_ERR_ARG, "test %d of the pattern compares a point with itself", t);
+    }
+  }
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // extractions in flight still read the old table
+  return upload_pattern(p, rot.data());
+}
+
 extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
                                         const gh_orb_params* params, gh_orb_plan** out) {
   if (!ctx || !out) return GH_ERR_ARG;
@@ -1007,20 +1052,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
       break;
     }
     if ((st = gh_dev_upload(ctx, p->tabs, htab.data(), htab.size() * sizeof(uint32_t))) != GH_OK) break;
-    {
-      // the device copy of the test pattern holds, per (bin, test), the two byte offsets into the 27 x 28 blurred patch
-      // ((13 + y) * kBlurPitch + 13 + x as two u16) instead of the four int8 coordinates: saves the sign extensions
-      // and address arithmetic of 256 tests per keypoint
-      static_assert(sizeof(GH_ORB_PATTERN) == 30 * 256 * 4, "pattern table layout");
-      std::vector<uint32_t> off(30 * 256);
-      for (int b = 0; b < 30; ++b)
-        for (int t = 0; t < 256; ++t) {
-          const int8_t* q = GH_ORB_PATTERN[b][t];
-          const uint32_t oa = (uint32_t)((13 + q[1]) * kBlurPitch + 13 + q[0]), ob = (uint32_t)((13 + q[3]) * kBlurPitch + 13 + q[2]);
-          off[b * 256 + t] = oa | (ob << 16);
-        }
-      if ((st = gh_dev_upload(ctx, p->d_pattern, off.data(), off.size() * sizeof(uint32_t))) != GH_OK) break;
-    }
+    if ((st = upload_pattern(p, &GH_ORB_PATTERN[0][0][0])) != GH_OK) break;
     if ((st = gh_dev_upload(ctx, p->d_dir, GH_ORB_DIR, sizeof(GH_ORB_DIR))) != GH_OK) break;
   } while (0);
   if (st != GH_OK) {

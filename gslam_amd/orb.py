@@ -52,6 +52,11 @@ class OrbExtractor:
         except Exception:
             pass
 
+    def set_pattern(self, pattern):
+        """pattern: 256 x 4 int8 (ax, ay, bx, by), unrotated.  See gh_orb_plan_set_pattern."""
+        pat = np.ascontiguousarray(pattern, dtype=np.int8).reshape(256, 4)
+        self.ctx.check(hip.lib.gh_orb_plan_set_pattern(self.plan, pat.ctypes.data_as(C.c_void_p)))
+
     def level(self, l):
         w, h, q = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(hip.lib.gh_orb_plan_level(self.plan, l, C.byref(w), C.byref(h), C.byref(q)))

@@ -144,6 +144,12 @@ typedef struct gh_orb_plan gh_orb_plan; /* owns pyramid + workspace for (w, h, b
 gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
                              const gh_orb_params* params, gh_orb_plan** out);
 void gh_orb_plan_destroy(gh_orb_plan* plan);
+/* Replace the plan's BRIEF test pattern: 256 tests x (ax, ay, bx, by) int8, relative to the keypoint, unrotated.  The
+ * 30-bin steered look-up table is rebuilt from it (12-degree steps, round half away from zero).  Lets a deployer load
+ * the canonical ORB / ORB-SLAM `bit_pattern_31_` so that descriptors are compatible with existing ORB vocabularies; the
+ * built-in default is a seeded pattern of this repository (the canonical table is not available offline).  Every
+ * rotated point must stay inside the +-13 px blurred patch (radius <= 13.49), otherwise GH_ERR_ARG. */
+gh_status gh_orb_plan_set_pattern(gh_orb_plan* plan, const int8_t* pattern_256x4);
 /* Level geometry of the plan, for tests. */
 gh_status gh_orb_plan_level(const gh_orb_plan* plan, int level, int* w, int* h, int* quota);
 size_t gh_orb_plan_device_bytes(const gh_orb_plan* plan);

@@ -279,11 +279,38 @@ static inline int blur_at(const uint8_t* img, int stride, int x, int y) {
   return (int)((acc + (1u << 21)) >> 22);
 }
 
+/* Test pattern in use: the built-in table, or one installed by oracle_orb_set_pattern (the checker's counterpart of
+ * gh_orb_plan_set_pattern: same rotation rule as tools/gen_orb_tables.py -- round half away from zero).  Global state:
+ * tests install / reset it around single-threaded runs. */
+static int8_t g_custom_pattern[GH_ORB_NBINS][256][4];
+static int g_use_custom_pattern = 0;
+
+int oracle_orb_set_pattern(const int8_t* base /* 256 x 4, NULL = back to the built-in pattern */) {
+  if (!base) {
+    g_use_custom_pattern = 0;
+    return 0;
+  }
+  for (int k = 0; k < GH_ORB_NBINS; ++k) {
+    const double th = (12.0 * k) * (3.14159265358979323846 / 180.0), c = cos(th), s = sin(th);
+    for (int t = 0; t < 256; ++t) {
+      const int8_t* q = base + 4 * t;
+      const double v[4] = {q[0] * c - q[1] * s, q[0] * s + q[1] * c, q[2] * c - q[3] * s, q[2] * s + q[3] * c};
+      for (int e = 0; e < 4; ++e) {
+        const int r = (int)floor(fabs(v[e]) + 0.5) * (v[e] >= 0 ? 1 : -1);
+        if (r < -13 || r > 13) return -1;
+        g_custom_pattern[k][t][e] = (int8_t)r;
+      }
+    }
+  }
+  g_use_custom_pattern = 1;
+  return 0;
+}
+
 /* step 8 */
 void oracle_orb_describe(const uint8_t* img, int stride, int x, int y, int bin, uint8_t* desc32) {
   memset(desc32, 0, 32);
   for (int k = 0; k < 256; ++k) {
-    const int8_t* p = GH_ORB_PATTERN[bin][k];
+    const int8_t* p = g_use_custom_pattern ? g_custom_pattern[bin][k] : GH_ORB_PATTERN[bin][k];
     int a = blur_at(img, stride, x + p[0], y + p[1]);
     int b = blur_at(img, stride, x + p[2], y + p[3]);
     if (a < b) desc32[k >> 3] |= (uint8_t)(1u << (k & 7));

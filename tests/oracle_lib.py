@@ -167,6 +167,13 @@ def _orb_methods(cls):
         self.lib.oracle_orb_quotas(int(K), int(nlevels), _ptr(q))
         return q
 
+    def orb_set_pattern(self, pattern):
+        """Install a 256 x 4 int8 test pattern (None = built-in); returns False if a rotated point leaves the patch."""
+        if pattern is None:
+            return self.lib.oracle_orb_set_pattern(None) == 0
+        pat = np.ascontiguousarray(pattern, dtype=np.int8).reshape(256, 4)
+        return self.lib.oracle_orb_set_pattern(_ptr(pat)) == 0
+
     def orb_extract(self, gray, K=1000, nlevels=8, ini_th=20, min_th=7):
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         h, w = gray.shape
@@ -210,7 +217,7 @@ def _orb_methods(cls):
         self.lib.oracle_bgr_to_gray(_ptr(bgr), w, h, c, w * c, _ptr(out), w)
         return out
 
-    for f in (synth_frame, orb_level_dims, orb_quotas, orb_extract, orb_extract_batch, orb_pyramid_level,
+    for f in (synth_frame, orb_level_dims, orb_quotas, orb_set_pattern, orb_extract, orb_extract_batch, orb_pyramid_level,
               orb_score_map, bgr_to_gray):
         setattr(cls, f.__name__, f)
 

@@ -183,3 +183,45 @@ def test_extract_full_size_properties(ctx, oracle):
         ek, ed = oracle.orb_extract(frames_np[i], K)
         assert cn[f] == len(ek) and kp[f, :len(ek)].tobytes() == ek.tobytes() and np.array_equal(dn[f, :len(ek)], ed)
     ex.close()
+
+
+def test_runtime_pattern_injection(ctx, oracle):
+    """gh_orb_plan_set_pattern: (1) the built-in unrotated pattern reproduces the default bits, (2) a different pattern
+    matches the oracle with the same pattern installed, (3) a pattern that leaves the blurred patch is rejected."""
+    import os
+    import sys
+    import torch
+    from gslam_amd import hip
+    from gslam_amd.orb import OrbExtractor, kps_to_numpy, synth_frames
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_orb_tables as T
+    base = np.array(T.gen_pattern(), np.int8)
+    ex = OrbExtractor(ctx, 640, 480, max_batch=2, n_features=700)
+    frames = synth_frames(ctx, 2, 640, 480, base_seed=0x5EED0100)
+    k0, d0, c0 = [t.clone() for t in ex.extract(frames)]
+    ex.set_pattern(base)
+    k1, d1, c1 = ex.extract(frames)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and torch.equal(c0, c1) and torch.equal(k0, k1)
+    rng = np.random.default_rng(5)
+    pat = rng.integers(-9, 10, (256, 4)).astype(np.int8)
+    pat[pat[:, 0] == pat[:, 2], 2] += 1
+    ex.set_pattern(pat)
+    k2, d2, c2 = ex.extract(frames)
+    torch.cuda.synchronize()
+    assert oracle.orb_set_pattern(pat)
+    try:
+        host = frames.cpu().numpy()
+        for f in range(2):
+            ek, ed = oracle.orb_extract(host[f], 700)
+            n = int(c2[f])
+            assert n == len(ek) and kps_to_numpy(k2)[f, :n].tobytes() == ek.tobytes()
+            assert np.array_equal(d2[f, :n].cpu().numpy(), ed)
+    finally:
+        oracle.orb_set_pattern(None)
+    assert not torch.equal(d2, d0)
+    bad = pat.copy()
+    bad[3] = [13, 13, 0, 0]
+    with pytest.raises(hip.GslamHipError):
+        ex.set_pattern(bad)
+    ex.close()

@@ -85,3 +85,41 @@ def test_bgr_to_gray_fixed_point(oracle):
            bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14
     assert np.array_equal(g, ref.astype(np.uint8))
     assert abs(int(g[0, 0]) - round(0.114 * bgr[0, 0, 0] + 0.587 * bgr[0, 0, 1] + 0.299 * bgr[0, 0, 2])) <= 1
+
+
+def _builtin_base_pattern():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_orb_tables as T
+    return np.array(T.gen_pattern(), np.int8)
+
+
+def test_set_pattern_with_the_builtin_base_reproduces_the_builtin_table(oracle):
+    """gh_orb_plan_set_pattern / oracle_orb_set_pattern rebuild the 30-bin steered LUT at run time; feeding them the
+    unrotated built-in pattern must give today's descriptors bit for bit (same rotation + rounding rule as the generator
+    of include/gslam_orb_tables.h)."""
+    g = oracle.synth_frame(400, 300, 77)
+    a = oracle.orb_extract(g, 400)
+    assert oracle.orb_set_pattern(_builtin_base_pattern())
+    try:
+        b = oracle.orb_extract(g, 400)
+    finally:
+        oracle.orb_set_pattern(None)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_set_pattern_changes_descriptors_and_validates_range(oracle):
+    rng = np.random.default_rng(5)
+    pat = rng.integers(-9, 10, (256, 4)).astype(np.int8)
+    pat[pat[:, 0] == pat[:, 2], 2] += 1
+    g = oracle.synth_frame(400, 300, 78)
+    a = oracle.orb_extract(g, 300)
+    assert oracle.orb_set_pattern(pat)
+    try:
+        b = oracle.orb_extract(g, 300)
+    finally:
+        oracle.orb_set_pattern(None)
+    assert np.array_equal(a[0], b[0]) and not np.array_equal(a[1], b[1])  # same keypoints, different bits
+    bad = pat.copy()
+    bad[7] = [13, 13, 0, 0]  # radius 18.4: leaves the +-13 blurred patch at 45 degrees
+    assert not oracle.orb_set_pattern(bad)
+    oracle.orb_set_pattern(None)
