@@ -20,7 +20,7 @@ LIBDIR    := gslam_amd/lib
 
 HAVE_REF  := $(wildcard $(REF)/GSLAM/core/GSLAM.h)
 
-.PHONY: all lib oracle ref plugins clean
+.PHONY: all lib oracle ref plugins refapps clean
 ifeq ($(HAVE_REF),)
 all: lib oracle
 else
@@ -30,7 +30,7 @@ endif
 lib: $(LIBDIR)/libgslam_hip.so
 oracle: oracle/liboracle.so oracle/liboracle_fma.so
 ref: oracle/_ref/libgslam_ref.so oracle/_ref/libgslam_ref_popcnt.so
-plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so build/plugin_host
+plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so $(LIBDIR)/libgslamDB_synthplane.so build/plugin_host refapps
 
 build/obj/%.o: gslam_amd/csrc/%.hip gslam_amd/csrc/common.h include/gslam_hip.h $(wildcard include/*.h gslam_amd/csrc/*.h)
 	@mkdir -p build/obj
@@ -71,6 +71,24 @@ $(LIBDIR)/libgslam_estimator.so: gslam_amd/plugin/estimator_plugin.cpp include/g
 
 $(LIBDIR)/libgslam_orbhip.so: gslam_amd/plugin/orbhip_app.cpp gslam_amd/plugin/FeatureDetector.h
 	g++ $(PLUGFLAGS) -shared -o $@ $< -lpthread -ldl
+
+$(LIBDIR)/libgslamDB_synthplane.so: gslam_amd/plugin/dataset_synthplane.cpp include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
+	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
+
+# The reference's OWN launcher and two of its application plugins, compiled from the sources where they lie (no copy,
+# the reference's flags): `gslam` (GSLAM/gslam/main.cpp), `play` (plugins/play/main.cpp), `metric_time`
+# (evaluation/metric_time/main.cpp).  Test infrastructure: tests/test_launcher_gpu.py drives the orbhip application and
+# the synthplane dataset through them.  build/ is git-ignored and travels to the GPU box.
+refapps: build/ref/gslam build/ref/libgslam_play.so build/ref/libgslam_metric_time.so
+build/ref/gslam: $(REF)/GSLAM/gslam/main.cpp
+	@mkdir -p build/ref
+	g++ -O3 -DNDEBUG -std=c++11 -w -I$(REF) -I$(REF)/GSLAM/core -o $@ $< -lpthread -ldl
+build/ref/libgslam_play.so: $(REF)/GSLAM/plugins/play/main.cpp
+	@mkdir -p build/ref
+	g++ -O3 -DNDEBUG -std=c++11 -w -fPIC -shared -I$(REF) -o $@ $< -lpthread -ldl
+build/ref/libgslam_metric_time.so: $(REF)/GSLAM/evaluation/metric_time/main.cpp
+	@mkdir -p build/ref
+	g++ -O3 -DNDEBUG -std=c++11 -w -fPIC -shared -I$(REF) -o $@ $< -lpthread -ldl
 
 build/plugin_host: gslam_amd/plugin/plugin_host.cpp gslam_amd/plugin/FeatureDetector.h gslam_amd/plugin/UndistorterHIP.h $(LIBDIR)/libgslam_hip.so
 	@mkdir -p build

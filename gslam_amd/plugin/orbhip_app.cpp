@@ -1,23 +1,109 @@
 // libgslam_orbhip.so — a GSLAM *application* plugin (GSLAM_REGISTER_APPLICATION, GSLAM/core/GSLAM.h:26-33) that puts
-// the MI355X front end on GSLAM's own message bus, in the place the external ORBSLAM plugin occupies
+// the MI355X hot path on GSLAM's own message bus, in the place the external ORBSLAM plugin occupies
 // (doc/doxygen/4_1_orbslam.dox:10-29):
 //     in   "dataset/frame"     FramePtr  (what `gslam play` publishes, plugins/play/main.cpp:16,132)
+//          "dataset/status"    int       (5 = FINISHED, plugins/play/main.cpp:5-7)
 //     out  "orbhip/curframe"   FramePtr  (what qviz / metric_time / metric_traj subscribe to)
-//          "orbhip/matches"    Svar {id, keypoints, matches}
-// Per frame: gray image -> FeatureDetector::detectAndCompute -> MapFrame::setKeyPoints (Map.h:311-312) -> brute-force
-// match against the previous frame (cross-checked, Hamming <= matchMaxDistance) -> publish.
-// This is plumbing (SURVEY.md 8 f4 / BASELINE configs[0]): tracking, mapping and loop closing stay out of scope.
-//     gslam play orbhip -dataset X -FeatureDetectorPlugin /path/libgslam_featuredetector.so
+//          "orbhip/map"        MapPtr    (frames + map points after every windowed bundle adjustment)
+//          "orbhip/matches"    Svar {id, keypoints, matches, tracked}
+// Per frame (BASELINE configs[0] "C1": extract + match to previous + optimizePnP):
+//     gray image -> FeatureDetector::detectAndCompute -> MapFrame::setKeyPoints (Map.h:311-312)
+//     -> brute-force match against the previous frame (cross-checked, Hamming <= matchMaxDistance)
+//     -> Optimizer::optimizePnP on the matched (map point, CameraAnchor) pairs, start = previous pose (Optimizer.h:202-207)
+//     -> new keypoints get map points by intersecting their rays with the ground plane z = 0 (the `synthplane` dataset's
+//        scene; a monocular front end needs SOME initialisation and this one is exact for that scene)
+//     every `orbhip.ba_every` frames: Optimizer::optimize on the last `orbhip.ba_window` frames (Optimizer.h:229).
+// It is a minimal tracking front end, not a SLAM system: no relocalisation, no loop closing, no map management.
+//     gslam play -dataset seq.synthplane -autostart 1 orbhip metric_time -slam orbhip
+// `orbhip.log <file>` records every input and output of the three plugin calls so that tests can replay them through
+// the CPU checker.
 #include <GSLAM/core/GSLAM.h>
+#include <GSLAM/core/Optimizer.h>
+
+#include <atomic>
+#include <deque>
+#include <fstream>
+#include <map>
+#include <thread>
 
 #include "FeatureDetector.h"
 
 using namespace GSLAM;
 
+namespace {
+
+class OrbhipPoint : public MapPoint {
+ public:
+  OrbhipPoint(PointID id, const Point3d& p) : MapPoint(id, p) {}
+  std::string type() const override { return "OrbhipPoint"; }
+};
+
+class OrbhipMap : public Map {
+ public:
+  std::string type() const override { return "OrbhipMap"; }
+  bool insertMapPoint(const PointPtr& p) override { WriteMutex l(mu_); points_[p->id()] = p; return true; }
+  bool insertMapFrame(const FramePtr& f) override { WriteMutex l(mu_); frames_[f->id()] = f; return true; }
+  std::size_t frameNum() const override { ReadMutex l(mu_); return frames_.size(); }
+  std::size_t pointNum() const override { ReadMutex l(mu_); return points_.size(); }
+  FramePtr getFrame(const FrameID& id) const override {
+    ReadMutex l(mu_);
+    auto it = frames_.find(id);
+    return it == frames_.end() ? FramePtr() : it->second;
+  }
+  PointPtr getPoint(const PointID& id) const override {
+    ReadMutex l(mu_);
+    auto it = points_.find(id);
+    return it == points_.end() ? PointPtr() : it->second;
+  }
+  bool getFrames(FrameArray& frames) const override {
+    ReadMutex l(mu_);
+    for (auto& kv : frames_) frames.push_back(kv.second);
+    return true;
+  }
+  bool getPoints(PointArray& points) const override {
+    ReadMutex l(mu_);
+    for (auto& kv : points_) points.push_back(kv.second);
+    return true;
+  }
+
+ private:
+  mutable MutexRW mu_;
+  std::map<FrameID, FramePtr> frames_;
+  std::map<PointID, PointPtr> points_;
+};
+
+struct TrackedFrame {
+  FramePtr frame;
+  SE3 pose;                      // T_wc
+  std::vector<KeyPoint> kps;
+  std::vector<Point2d> anchors;  // camera.UnProject(kp.pt).xy (z = 1 plane)
+  std::vector<int64_t> pid;      // map point id per keypoint, -1 = none
+};
+
+template <typename T>
+void put(std::ofstream& o, const T& v) { o.write((const char*)&v, sizeof(T)); }
+void put_pose(std::ofstream& o, const SE3& T) {
+  const SO3 r = T.get_rotation();
+  const Point3d t = T.get_translation();
+  const double p[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+  o.write((const char*)p, sizeof(p));
+}
+
+}  // namespace
+
 int run_orbhip(Svar config) {
   svar = config;  // alias the host's registry, as every GSLAM application does
   const int n_features = config.arg<int>("orbhip.nFeatures", 1000, "ORB keypoints per frame");
   const int queue = config.arg<int>("orbhip.queue", 0, "subscriber queue (0 = handle in the publisher's thread)");
+  const int ba_every = config.arg<int>("orbhip.ba_every", 10, "windowed bundle adjustment every N frames (0 = never)");
+  const int ba_window = config.arg<int>("orbhip.ba_window", 10, "frames in the bundle-adjustment window");
+  const int min_track = config.arg<int>("orbhip.min_track", 30, "minimum 3D-2D matches for optimizePnP");
+  const bool track = config.arg<bool>("orbhip.track", true, "run optimizePnP / optimize (false: extract + match only)");
+  const bool stop_on_finish = config.arg<bool>("orbhip.stop_on_finish", false, "publish messenger/stop when the dataset ends");
+  const bool start_dataset = config.arg<bool>("orbhip.start_dataset", false,
+                                              "publish qviz/start (what the GUI's play button does) until the first frame "
+                                              "arrives, so that no frame is lost while the plugins load");
+  const std::string log_path = config.arg<std::string>("orbhip.log", "", "binary record of every plugin call (tests)");
   if (config.get("help", false)) return config.help();
 
   FeatureDetectorPtr det = FeatureDetector::create();
@@ -27,31 +113,217 @@ int run_orbhip(Svar config) {
   }
   det->_config.nFeatures = n_features;
   det->_config.matchCrossCheck = true;
+  OptimizerPtr opt;
+  if (track) {
+    opt = Optimizer::create();
+    if (!opt) LOG(WARNING) << "orbhip: no Optimizer plugin (svar OptimizerPlugin): tracking disabled";
+  }
+  if (opt) opt->_config.maxIterations = config.arg<int>("orbhip.max_iterations", 30, "LM iterations per call");
 
   Publisher pub_frame = messenger.advertise<MapFrame>("orbhip/curframe", 0);
+  Publisher pub_map = messenger.advertise<Map>("orbhip/map", 0);
   Publisher pub_match = messenger.advertise<Svar>("orbhip/matches", 0);
+  std::shared_ptr<OrbhipMap> map(new OrbhipMap());
+  std::map<int64_t, Point3d> points;  // map point id -> world position
+  std::deque<TrackedFrame> window;
   GImage last_desc;
+  int64_t next_pid = 1;
+  int n_frames = 0;
+  std::ofstream log;
+  if (!log_path.empty()) log.open(log_path.c_str(), std::ios::binary);
+
+  // ray of a keypoint through the plane z = 0
+  auto on_plane = [](const SE3& Twc, const Point2d& a, Point3d& X) {
+    const Point3d d = Twc.get_rotation() * Point3d(a.x, a.y, 1.0), c = Twc.get_translation();
+    if (!(fabs(d.z) > 1e-9)) return false;
+    const double lam = -c.z / d.z;
+    if (!(lam > 0)) return false;
+    X = c + d * lam;
+    return true;
+  };
 
   Subscriber sub = messenger.subscribe("dataset/frame", queue, [&](FramePtr fr) {
     if (!fr || !fr->cameraNum()) return;
     GImage img = fr->getImage(0, IMAGE_GRAY);
     if (img.empty()) img = fr->getImage(0);
-    std::vector<KeyPoint> kps;
+    TrackedFrame cur;
+    cur.frame = fr;
     GImage desc;
-    if (!det->detectAndCompute(img, kps, desc)) {
+    if (!det->detectAndCompute(img, cur.kps, desc)) {
       LOG(ERROR) << "orbhip: extraction failed on frame " << fr->id();
       return;
     }
-    fr->setKeyPoints(kps, desc);
+    fr->setKeyPoints(cur.kps, desc);
     std::vector<std::pair<int, int> > matches;
     if (!last_desc.empty() && desc.rows > 0) det->match(desc, last_desc, matches);
+    const Camera cam = fr->getCamera(0);
+    const int n = (int)cur.kps.size();
+    cur.anchors.resize(n);
+    cur.pid.assign(n, -1);
+    for (int i = 0; i < n; ++i) {
+      const Point3d a = cam.isValid() ? cam.UnProject(Point2d(cur.kps[i].pt.x, cur.kps[i].pt.y)) : Point3d(0, 0, 1);
+      cur.anchors[i] = Point2d(a.x / a.z, a.y / a.z);
+    }
+    if (log.is_open()) {
+      put(log, (int32_t)1);  // record type 1: frame
+      put(log, (int32_t)fr->id());
+      put(log, (int32_t)n);
+      if (n) log.write((const char*)cur.kps.data(), (std::streamsize)n * sizeof(KeyPoint));
+      if (n) log.write((const char*)desc.data, (std::streamsize)n * 32);
+      put(log, (int32_t)matches.size());
+      for (auto& m : matches) { put(log, (int32_t)m.first); put(log, (int32_t)m.second); }
+    }
+
+    int tracked = 0;
+    bool have_pose = false;
+    if (opt && cam.isValid()) {
+      if (window.empty()) {
+        cur.pose = fr->getPose();  // the gauge: the dataset's pose of the first frame
+        have_pose = true;
+      } else {
+        const TrackedFrame& prev = window.back();
+        std::vector<std::pair<Point3d, CameraAnchor> > m3d;
+        std::vector<std::pair<int, int64_t> > who;
+        for (auto& m : matches) {
+          const int64_t id = prev.pid[m.second];
+          if (id < 0) continue;
+          m3d.push_back(std::make_pair(points[id], CameraAnchor(cur.anchors[m.first].x, cur.anchors[m.first].y, 1.0)));
+          who.push_back(std::make_pair(m.first, id));
+        }
+        tracked = (int)m3d.size();
+        if (tracked >= min_track) {
+          SE3 pose = prev.pose;
+          const SE3 start = pose;
+          const bool ok = opt->optimizePnP(m3d, pose, UPDATE_KF_SE3, NULL);
+          if (log.is_open()) {
+            put(log, (int32_t)2);  // record type 2: optimizePnP call
+            put(log, (int32_t)fr->id());
+            put(log, (int32_t)tracked);
+            for (auto& p : m3d) {
+              const double r[5] = {p.first.x, p.first.y, p.first.z, p.second.x, p.second.y};
+              log.write((const char*)r, sizeof(r));
+            }
+            put_pose(log, start);
+            put_pose(log, pose);
+            put(log, (int32_t)(ok ? 1 : 0));
+          }
+          if (ok) {
+            cur.pose = pose;
+            have_pose = true;
+            for (auto& w : who) cur.pid[w.first] = w.second;
+          }
+        }
+      }
+      if (have_pose) {
+        fr->setPose(cur.pose);
+        for (int i = 0; i < n; ++i) {  // new map points for keypoints that are not tracked yet
+          if (cur.pid[i] >= 0) continue;
+          Point3d X;
+          if (!on_plane(cur.pose, cur.anchors[i], X)) continue;
+          cur.pid[i] = next_pid;
+          points[next_pid++] = X;
+        }
+        window.push_back(cur);
+        while ((int)window.size() > ba_window) window.pop_front();
+        map->insertMapFrame(fr);
+      } else {
+        window.clear();  // lost: start again from the next frame's dataset pose
+      }
+    }
     last_desc = desc.clone();
-    pub_match.publish(Svar({{"id", (int)fr->id()}, {"keypoints", (int)kps.size()}, {"matches", (int)matches.size()}}));
+    ++n_frames;
+
+    // windowed bundle adjustment over the frames in the window (first one fixed: the gauge)
+    if (opt && have_pose && ba_every > 0 && n_frames % ba_every == 0 && window.size() >= 3) {
+      BundleGraph g;
+      g.cameraDOF = UPDATE_CAMERA_NONE;
+      std::map<int64_t, int> count;
+      for (auto& f : window)
+        for (int64_t id : f.pid)
+          if (id >= 0) ++count[id];
+      std::map<int64_t, size_t> slot;
+      for (auto& kv : count)
+        if (kv.second >= 2) {
+          slot[kv.first] = g.mappoints.size();
+          g.mappoints.push_back(std::make_pair(points[kv.first], true));
+        }
+      for (size_t fi = 0; fi < window.size(); ++fi) {
+        KeyFrameEstimzation kf;
+        kf.estimation = SIM3(window[fi].pose, 1.0);
+        kf.dof = fi == 0 ? UPDATE_KF_NONE : UPDATE_KF_SE3;
+        g.keyframes.push_back(kf);
+        for (size_t i = 0; i < window[fi].pid.size(); ++i) {
+          auto it = slot.find(window[fi].pid[i]);
+          if (it == slot.end()) continue;
+          BundleEdge e;
+          e.pointId = it->second;
+          e.frameId = fi;
+          e.measurement = CameraAnchor(window[fi].anchors[i].x, window[fi].anchors[i].y, 1.0);
+          e.information = NULL;
+          g.mappointObserves.push_back(e);
+        }
+      }
+      if (log.is_open()) {
+        put(log, (int32_t)3);  // record type 3: optimize call (inputs)
+        put(log, (int32_t)fr->id());
+        put(log, (int32_t)g.keyframes.size());
+        put(log, (int32_t)g.mappoints.size());
+        put(log, (int32_t)g.mappointObserves.size());
+        for (auto& kf : g.keyframes) { put_pose(log, kf.estimation.get_se3()); put(log, (int32_t)kf.dof); }
+        for (auto& mp : g.mappoints) { const double p[3] = {mp.first.x, mp.first.y, mp.first.z}; log.write((const char*)p, sizeof(p)); }
+        for (auto& e : g.mappointObserves) {
+          put(log, (int32_t)e.frameId);
+          put(log, (int32_t)e.pointId);
+          const double m[2] = {e.measurement.x, e.measurement.y};
+          log.write((const char*)m, sizeof(m));
+        }
+      }
+      const bool ok = opt->optimize(g);
+      if (log.is_open()) {
+        put(log, (int32_t)(ok ? 1 : 0));
+        for (auto& kf : g.keyframes) put_pose(log, kf.estimation.get_se3());
+        for (auto& mp : g.mappoints) { const double p[3] = {mp.first.x, mp.first.y, mp.first.z}; log.write((const char*)p, sizeof(p)); }
+        log.flush();
+      }
+      if (ok) {
+        for (size_t fi = 0; fi < window.size(); ++fi) {
+          window[fi].pose = g.keyframes[fi].estimation.get_se3();
+          window[fi].frame->setPose(window[fi].pose);
+        }
+        for (auto& kv : slot) {
+          points[kv.first] = g.mappoints[kv.second].first;
+          map->insertMapPoint(PointPtr(new OrbhipPoint((PointID)kv.first, points[kv.first])));
+        }
+        pub_map.publish(std::static_pointer_cast<Map>(map));
+      }
+    }
+    pub_match.publish(Svar({{"id", (int)fr->id()}, {"keypoints", n}, {"matches", (int)matches.size()}, {"tracked", tracked}}));
     pub_frame.publish(fr);
   });
 
+  Subscriber sub_status = messenger.subscribe("dataset/status", 0, [&](int status) {
+    if (stop_on_finish && status == 5 && n_frames > 0) {  // FINISHED (plugins/play/main.cpp:5-7)
+      if (log.is_open()) log.flush();
+      messenger.publish("messenger/stop", true);
+    }
+  });
+
   LOG(INFO) << "orbhip ready.";
-  return Messenger::exec();
+  std::atomic<bool> exiting(false);
+  std::thread kick;
+  if (start_dataset)
+    kick = std::thread([&]() {
+      // `play` only reacts to qviz/start once its dataset is open (plugins/play/main.cpp:30-41); repeat until frames flow
+      for (int i = 0; i < 600 && !exiting && n_frames == 0; ++i) {
+        messenger.publish("qviz/start", true);
+        Rate::sleep(0.1);
+      }
+    });
+  const int rc = Messenger::exec();
+  exiting = true;
+  if (kick.joinable()) kick.join();
+  if (log.is_open()) log.close();
+  return rc;
 }
 
 GSLAM_REGISTER_APPLICATION(orbhip, run_orbhip);

@@ -1,0 +1,172 @@
+"""BASELINE configs[0] ("C1") for real: the reference's OWN launcher (`gslam`, GSLAM/gslam/main.cpp) with its own `play`
+and `metric_time` application plugins (GSLAM/plugins/play/main.cpp, GSLAM/evaluation/metric_time/main.cpp), all three
+compiled unchanged from /root/reference (Makefile target `refapps`), runs
+
+    gslam play orbhip metric_time -dataset seq.synthplane -slam orbhip ...
+
+The dataset plugin (libgslamDB_synthplane.so, GSLAM_REGISTER_DATASET) renders a 640x480 monocular sequence of a textured
+plane; the `orbhip` application extracts, matches to the previous frame, calls Optimizer::optimizePnP every frame and
+Optimizer::optimize on a sliding window, and publishes "orbhip/curframe" / "orbhip/map"; `metric_time` measures the
+per-frame latency between "dataset/frame" and "orbhip/curframe".  Everything the plugins computed is replayed through
+the CPU oracle: keypoints / descriptors / matches bit-exact, PnP poses and the BA window within tolerance, and the
+estimated trajectory must follow the dataset's ground truth."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "gslam_amd", "lib")
+REFDIR = os.path.join(ROOT, "build", "ref")
+W, H, K = 640, 480, 1000
+
+
+def _need():
+    for p in (os.path.join(REFDIR, "gslam"), os.path.join(REFDIR, "libgslam_play.so"),
+              os.path.join(REFDIR, "libgslam_metric_time.so"), os.path.join(LIBDIR, "libgslam_orbhip.so"),
+              os.path.join(LIBDIR, "libgslamDB_synthplane.so")):
+        if not os.path.exists(p):
+            pytest.skip(f"{p} missing: run `make plugins` in the authoring container (needs /root/reference at build time)")
+
+
+def _read_dump(path):
+    raw = open(path, "rb").read()
+    n, w, h = struct.unpack("3i", raw[:12])
+    rec = 4 + 8 + 56 + w * h
+    frames = {}
+    for i in range((len(raw) - 12) // rec):
+        o = 12 + i * rec
+        fid = struct.unpack("i", raw[o:o + 4])[0]
+        pose = np.frombuffer(raw, np.float64, 7, o + 12)
+        img = np.frombuffer(raw, np.uint8, w * h, o + 68).reshape(h, w)
+        frames[fid] = (pose, img)
+    return frames
+
+
+def _read_log(path):
+    raw = open(path, "rb").read()
+    o, out = 0, {"frames": [], "pnp": [], "ba": []}
+    rd = lambda fmt: struct.unpack_from(fmt, raw, o)
+    while o + 4 <= len(raw):
+        typ = rd("i")[0]
+        o += 4
+        if typ == 1:
+            fid, n = rd("2i")
+            o += 8
+            kps = np.frombuffer(raw, oracle_lib.KP_DTYPE, n, o).copy()
+            o += 28 * n
+            desc = np.frombuffer(raw, np.uint8, n * 32, o).reshape(n, 32).copy()
+            o += 32 * n
+            nm = rd("i")[0]
+            o += 4
+            m = np.frombuffer(raw, np.int32, 2 * nm, o).reshape(nm, 2).copy()
+            o += 8 * nm
+            out["frames"].append(dict(id=fid, kps=kps, desc=desc, matches=m))
+        elif typ == 2:
+            fid, n = rd("2i")
+            o += 8
+            xm = np.frombuffer(raw, np.float64, 5 * n, o).reshape(n, 5).copy()
+            o += 40 * n
+            start = np.frombuffer(raw, np.float64, 7, o).copy()
+            pose = np.frombuffer(raw, np.float64, 7, o + 56).copy()
+            o += 112
+            ok = rd("i")[0]
+            o += 4
+            out["pnp"].append(dict(id=fid, X=xm[:, :3], m=xm[:, 3:], start=start, pose=pose, ok=ok))
+        elif typ == 3:
+            fid, nc, npt, no = rd("4i")
+            o += 16
+            poses, dof = np.zeros((nc, 7)), np.zeros(nc, np.int32)
+            for c in range(nc):
+                poses[c] = np.frombuffer(raw, np.float64, 7, o)
+                dof[c] = struct.unpack_from("i", raw, o + 56)[0]
+                o += 60
+            pts = np.frombuffer(raw, np.float64, 3 * npt, o).reshape(npt, 3).copy()
+            o += 24 * npt
+            ocam, opt, oxy = np.zeros(no, np.int32), np.zeros(no, np.int32), np.zeros((no, 2))
+            for k in range(no):
+                ocam[k], opt[k] = struct.unpack_from("2i", raw, o)
+                oxy[k] = np.frombuffer(raw, np.float64, 2, o + 8)
+                o += 24
+            ok = rd("i")[0]
+            o += 4
+            rposes = np.frombuffer(raw, np.float64, 7 * nc, o).reshape(nc, 7).copy()
+            o += 56 * nc
+            rpts = np.frombuffer(raw, np.float64, 3 * npt, o).reshape(npt, 3).copy()
+            o += 24 * npt
+            out["ba"].append(dict(id=fid, graph={"cam_pose": poses, "cam_dof": dof, "point_xyz": pts, "obs_cam": ocam,
+                                                  "obs_point": opt, "obs_xy": oxy}, ok=ok, poses=rposes, pts=rpts))
+        else:
+            raise AssertionError(f"bad record type {typ} at {o}")
+    return out
+
+
+def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, oracle):
+    _need()
+    n_frames = 45
+    seq = tmp_path / "seq.synthplane"
+    seq.write_text(f"width {W}\nheight {H}\nframes {n_frames}\nfps 200\ntexture 2048\nseed 1592590336\n"
+                   f"dump {tmp_path / 'frames.bin'}\n")
+    cmd = [os.path.join(REFDIR, "gslam"), "play", "orbhip", "metric_time",
+           "-dataset", str(seq), "-slam", "orbhip", "-playspeed", "1",
+           "-orbhip.nFeatures", str(K), "-orbhip.log", str(tmp_path / "orbhip.bin"), "-orbhip.stop_on_finish", "1",
+           "-orbhip.start_dataset", "1", "-orbhip.ba_every", "10", "-orbhip.ba_window", "8",
+           "-FeatureDetectorPlugin", os.path.join(LIBDIR, "libgslam_featuredetector.so"),
+           "-OptimizerPlugin", os.path.join(LIBDIR, "libgslam_optimizer.so"),
+           "-GSLAM_LIBRARY_PATH", LIBDIR + ":" + REFDIR]
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIBDIR + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+    frames = _read_dump(tmp_path / "frames.bin")
+    log = _read_log(tmp_path / "orbhip.bin")
+    assert len(frames) == n_frames
+    assert [f["id"] for f in log["frames"]] == list(range(1, n_frames + 1)), "a frame was lost between play and orbhip"
+
+    # metric_time (the reference's evaluation plugin) saw every frame come back on "orbhip/curframe"
+    mt = [ln.split() for ln in open(tmp_path / "orbhip_metric_time.txt").read().splitlines()]
+    assert len(mt) == n_frames and all(0 < float(t) < 5.0 for _, t in mt)
+
+    # extraction + matching: bit-exact against the oracle on the frames the dataset delivered
+    prev = None
+    for f in log["frames"]:
+        ek, ed = oracle.orb_extract(frames[f["id"]][1], K)
+        assert len(ek) == len(f["kps"]) and f["kps"].tobytes() == ek.tobytes() and np.array_equal(f["desc"], ed)
+        if prev is not None:
+            fw = oracle.bf_match(ed, prev, threads=4)
+            bw = oracle.bf_match(prev, ed, threads=4)
+            keep = oracle.match_mask(fw[0], fw[1], fw[2], bw[0], len(prev), 50, 0, 1, 1).astype(bool)
+            exp = np.stack([np.nonzero(keep)[0], fw[0][keep]], axis=1).astype(np.int32)
+            assert np.array_equal(f["matches"], exp), f"matches of frame {f['id']}"
+        else:
+            assert len(f["matches"]) == 0
+        prev = ed
+
+    # optimizePnP on every frame but the first, replayed through the oracle
+    assert [p["id"] for p in log["pnp"]] == list(range(2, n_frames + 1))
+    for p in log["pnp"]:
+        assert p["ok"] == 1 and len(p["X"]) >= 100
+        po, so, _, rc = oracle.ba_pnp(p["X"], p["m"], p["start"], opts=oracle_lib.ba_options(huber=0.01, max_iterations=30))
+        assert rc == 0 and np.abs(po - p["pose"]).max() <= 1e-8, p["id"]
+
+    # windowed bundle adjustment, replayed through the oracle
+    assert len(log["ba"]) == n_frames // 10
+    for b in log["ba"]:
+        assert b["ok"] == 1 and len(b["graph"]["obs_cam"]) > 500
+        eo = oracle.ba_solve(b["graph"], oracle_lib.ba_options(huber=0.01, max_iterations=30), threads=4)
+        assert eo[3] == 0 and np.abs(eo[0] - b["poses"]).max() <= 1e-7 and np.abs(eo[1] - b["pts"]).max() <= 1e-7
+        assert np.array_equal(b["poses"][0], b["graph"]["cam_pose"][0])  # the window's first frame is the gauge
+
+    # the tracked trajectory follows the ground truth of the renderer (bilinear texture sampling + integer keypoints:
+    # a few millimetres at 2 m from the plane)
+    err = [np.linalg.norm(p["pose"][4:] - frames[p["id"]][0][4:]) for p in log["pnp"]]
+    assert max(err) < 0.02, max(err)
+    q_err = [1 - abs(np.dot(p["pose"][:4], frames[p["id"]][0][:4])) for p in log["pnp"]]
+    assert max(q_err) < 1e-4
