@@ -113,7 +113,14 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
     seq = tmp_path / "seq.synthplane"
     seq.write_text(f"width {W}\nheight {H}\nframes {n_frames}\nfps 200\ntexture 2048\nseed 1592590336\n"
                    f"dump {tmp_path / 'frames.bin'}\n")
-    cmd = [os.path.join(REFDIR, "gslam"), "play", "orbhip", "metric_time",
+    # Dataset::open -> Registry::load("gslamDB_synthplane") runs inside libgslam_play.so with THAT plugin's own svar
+    # instance, whose search path is ".", /usr/lib ... (GSLAM/core/Registry.h:178-232): an installed GSLAM finds dataset
+    # plugins in /usr/local/lib, here the plugin is linked into the working directory.
+    os.symlink(os.path.join(LIBDIR, "libgslamDB_synthplane.so"), tmp_path / "libgslamDB_synthplane.so")
+    # Application order: the launcher starts each application's thread as soon as its plugin is loaded and keeps writing
+    # svar["gslam"]["apps"] for the next one from the main thread (GSLAM/gslam/main.cpp:17-45) -- svar is not thread safe
+    # (Svar.h:783), so `play`, which touches svar for its whole life, goes last.
+    cmd = [os.path.join(REFDIR, "gslam"), "orbhip", "metric_time", "play",
            "-dataset", str(seq), "-slam", "orbhip", "-playspeed", "1",
            "-orbhip.nFeatures", str(K), "-orbhip.log", str(tmp_path / "orbhip.bin"), "-orbhip.stop_on_finish", "1",
            "-orbhip.start_dataset", "1", "-orbhip.ba_every", "10", "-orbhip.ba_window", "8",
@@ -142,19 +149,20 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
         if prev is not None:
             fw = oracle.bf_match(ed, prev, threads=4)
             bw = oracle.bf_match(prev, ed, threads=4)
-            keep = oracle.match_mask(fw[0], fw[1], fw[2], bw[0], len(prev), 50, 0, 1, 1).astype(bool)
+            keep = oracle.match_mask(fw[0], fw[1], fw[2], bw[0], len(prev), 100, 0, 1, 1).astype(bool)  # matchMaxDistance 100
             exp = np.stack([np.nonzero(keep)[0], fw[0][keep]], axis=1).astype(np.int32)
             assert np.array_equal(f["matches"], exp), f"matches of frame {f['id']}"
         else:
             assert len(f["matches"]) == 0
         prev = ed
 
-    # optimizePnP on every frame but the first, replayed through the oracle
-    assert [p["id"] for p in log["pnp"]] == list(range(2, n_frames + 1))
+    # optimizePnP twice on every frame but the first (robust fit, then refit on the inliers), replayed through the oracle
+    assert [p["id"] for p in log["pnp"]] == [i for i in range(2, n_frames + 1) for _ in (0, 1)]
     for p in log["pnp"]:
         assert p["ok"] == 1 and len(p["X"]) >= 100
         po, so, _, rc = oracle.ba_pnp(p["X"], p["m"], p["start"], opts=oracle_lib.ba_options(huber=0.01, max_iterations=30))
         assert rc == 0 and np.abs(po - p["pose"]).max() <= 1e-8, p["id"]
+    final = {p["id"]: p for p in log["pnp"]}  # the refit is the frame's pose
 
     # windowed bundle adjustment, replayed through the oracle
     assert len(log["ba"]) == n_frames // 10
@@ -162,11 +170,12 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
         assert b["ok"] == 1 and len(b["graph"]["obs_cam"]) > 500
         eo = oracle.ba_solve(b["graph"], oracle_lib.ba_options(huber=0.01, max_iterations=30), threads=4)
         assert eo[3] == 0 and np.abs(eo[0] - b["poses"]).max() <= 1e-7 and np.abs(eo[1] - b["pts"]).max() <= 1e-7
-        assert np.array_equal(b["poses"][0], b["graph"]["cam_pose"][0])  # the window's first frame is the gauge
+        assert np.array_equal(b["poses"][:2], b["graph"]["cam_pose"][:2])  # the window's two oldest frames are the gauge
 
-    # the tracked trajectory follows the ground truth of the renderer (bilinear texture sampling + integer keypoints:
-    # a few millimetres at 2 m from the plane)
-    err = [np.linalg.norm(p["pose"][4:] - frames[p["id"]][0][4:]) for p in log["pnp"]]
-    assert max(err) < 0.02, max(err)
-    q_err = [1 - abs(np.dot(p["pose"][:4], frames[p["id"]][0][:4])) for p in log["pnp"]]
+    # the tracked trajectory follows the renderer's ground truth: integer keypoints at pyramid scale localise a frame to
+    # ~1 mm at 2.2 m from the plane, and frame-to-frame re-anchoring lets that accumulate (measured: 12 mm at most
+    # over 45 frames; a scale-free window or unrejected outliers used to give 0.2 - 1 m)
+    err = [np.linalg.norm(p["pose"][4:] - frames[i][0][4:]) for i, p in final.items()]
+    assert max(err) < 0.03, max(err)
+    q_err = [1 - abs(np.dot(p["pose"][:4], frames[i][0][:4])) for i, p in final.items()]
     assert max(q_err) < 1e-4
