@@ -16,7 +16,7 @@
 
 namespace {
 
-enum { kModelH = 0, kModelA2 = 1, kModelF = 2, kModelA3 = 3 };
+enum { kModelH = 0, kModelA2 = 1, kModelF = 2, kModelA3 = 3, kModelE = 4, kModelSim3 = 5, kModelPlane = 6, kModelPnP = 7 };
 constexpr int kHyp = 2048;
 constexpr double kTiny = 1e-12;
 
@@ -27,8 +27,214 @@ __host__ __device__ inline uint64_t sm64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-__device__ inline int sample_size(int model) { return model == kModelH ? 4 : (model == kModelA2 ? 3 : (model == kModelF ? 8 : 4)); }
-__device__ inline int model_size(int model) { return model == kModelH ? 9 : (model == kModelA2 ? 6 : (model == kModelF ? 9 : 12)); }
+__host__ __device__ inline int sample_size(int model) {
+  switch (model) {
+    case kModelH: return 4;
+    case kModelA2: return 3;
+    case kModelF: case kModelE: return 8;
+    case kModelA3: return 4;
+    case kModelSim3: case kModelPlane: return 3;
+    default: return 6;  // PnP: 6-point DLT
+  }
+}
+__host__ __device__ inline int model_size(int model) {
+  switch (model) {
+    case kModelH: case kModelF: case kModelE: return 9;
+    case kModelA2: return 6;
+    case kModelSim3: return 8;
+    case kModelPlane: return 4;
+    default: return 12;  // A3 (3 x 4) and PnP ([R | t], world -> camera)
+  }
+}
+__host__ __device__ inline int dim_p(int model) { return (model == kModelA3 || model == kModelSim3 || model == kModelPlane || model == kModelPnP) ? 3 : 2; }
+__host__ __device__ inline int dim_q(int model) { return (model == kModelA3 || model == kModelSim3 || model == kModelPlane) ? 3 : 2; }
+
+// Cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (a is destroyed, v receives the eigenvectors as columns):
+// a fixed number of sweeps of the classical rotation, written with + - * / sqrt only, so that the device and the CPU
+// checker produce the same bits.
+template <int N>
+__host__ __device__ inline void jacobi_eig(double (*a)[N], double (*v)[N]) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep)
+    for (int p = 0; p < N - 1; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        const double apq = a[p][q];
+        if (!(fabs(apq) > 1e-300)) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < N; ++k) {  // A <- A J
+          const double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - sn * akq;
+          a[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < N; ++k) {  // A <- J^T A
+          const double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - sn * aqk;
+          a[q][k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double vkp = v[k][p], vkq = v[k][q];
+          v[k][p] = c * vkp - sn * vkq;
+          v[k][q] = sn * vkp + c * vkq;
+        }
+      }
+}
+
+// Horn's closed-form absolute orientation with scale (Horn 1987; GSLAM::Estimator::findSIM3, method S3_Horn) from three
+// point pairs: b ~ s R a + t.  out = [qx qy qz qw tx ty tz s] (GSLAM's SIM3 field order).
+__device__ inline bool solve_sim3(const double* p, const double* q, const int* idx, double* out) {
+  double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+  for (int j = 0; j < 3; ++j)
+    for (int e = 0; e < 3; ++e) {
+      ca[e] = ca[e] + p[3 * idx[j] + e];
+      cb[e] = cb[e] + q[3 * idx[j] + e];
+    }
+  for (int e = 0; e < 3; ++e) {
+    ca[e] = ca[e] / 3.0;
+    cb[e] = cb[e] / 3.0;
+  }
+  double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, na = 0.0, nb = 0.0;
+  for (int j = 0; j < 3; ++j) {
+    double a[3], b[3];
+    for (int e = 0; e < 3; ++e) {
+      a[e] = p[3 * idx[j] + e] - ca[e];
+      b[e] = q[3 * idx[j] + e] - cb[e];
+      na = na + a[e] * a[e];
+      nb = nb + b[e] * b[e];
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) S[r][c] = S[r][c] + a[r] * b[c];
+  }
+  if (!(na > kTiny) || !(nb > kTiny)) return false;
+  double N[4][4] = {{S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+                    {0, S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+                    {0, 0, -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+                    {0, 0, 0, -S[0][0] - S[1][1] + S[2][2]}};
+  for (int r = 1; r < 4; ++r)
+    for (int c = 0; c < r; ++c) N[r][c] = N[c][r];
+  double V[4][4];
+  jacobi_eig<4>(N, V);
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (N[k][k] > N[best][best]) best = k;
+  double qw = V[0][best], qx = V[1][best], qy = V[2][best], qz = V[3][best];
+  const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  if (!(qn > kTiny)) return false;
+  if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+  qw = qw / qn; qx = qx / qn; qy = qy / qn; qz = qz / qn;
+  const double sc = sqrt(nb / na);
+  const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                       2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                       2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+  out[0] = qx; out[1] = qy; out[2] = qz; out[3] = qw;
+  for (int r = 0; r < 3; ++r) out[4 + r] = cb[r] - sc * (R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]);
+  out[7] = sc;
+  return true;
+}
+
+// Plane through three points: out = [nx ny nz d], n unit, n . x + d = 0.
+__device__ inline bool solve_plane(const double* p, const int* idx, double* out) {
+  const double* p0 = p + 3 * idx[0];
+  const double* p1 = p + 3 * idx[1];
+  const double* p2 = p + 3 * idx[2];
+  const double u[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, v[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+  double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+  const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  if (!(len > kTiny)) return false;
+  for (int e = 0; e < 3; ++e) n[e] = n[e] / len;
+  out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+  out[3] = -(n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2]);
+  return true;
+}
+
+// Perspective-n-point from six 3D-2D pairs by the direct linear transform: 12 x 12 homogeneous system, nullspace by
+// elimination with full pivoting (as for F), scaled to |r3| = 1 with positive depth, rotation made orthonormal by
+// Gram-Schmidt on its rows.  out = [R (row-major 9) | t (3)], X_c = R X_w + t.  Coplanar object points are degenerate.
+__device__ inline bool solve_pnp_dlt(const double* p, const double* q, const int* idx, double* out) {
+  double a[12][12];
+  for (int j = 0; j < 6; ++j) {
+    const double X = p[3 * idx[j]], Y = p[3 * idx[j] + 1], Z = p[3 * idx[j] + 2], u = q[2 * idx[j]], v = q[2 * idx[j] + 1];
+    double* r0 = a[2 * j];
+    double* r1 = a[2 * j + 1];
+    r0[0] = X; r0[1] = Y; r0[2] = Z; r0[3] = 1; r0[4] = 0; r0[5] = 0; r0[6] = 0; r0[7] = 0;
+    r0[8] = -u * X; r0[9] = -u * Y; r0[10] = -u * Z; r0[11] = -u;
+    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = 0; r1[4] = X; r1[5] = Y; r1[6] = Z; r1[7] = 1;
+    r1[8] = -v * X; r1[9] = -v * Y; r1[10] = -v * Z; r1[11] = -v;
+  }
+  int perm[12];
+  for (int c = 0; c < 12; ++c) perm[c] = c;
+  for (int k = 0; k < 11; ++k) {
+    int pr = k, pc = k;
+    double best = -1.0;
+    for (int r = k; r < 12; ++r)
+      for (int c = k; c < 12; ++c) {
+        const double v = fabs(a[r][c]);
+        if (v > best) {
+          best = v;
+          pr = r;
+          pc = c;
+        }
+      }
+    if (!(best > kTiny)) return false;
+    if (pr != k)
+      for (int c = 0; c < 12; ++c) {
+        const double t = a[k][c];
+        a[k][c] = a[pr][c];
+        a[pr][c] = t;
+      }
+    if (pc != k) {
+      for (int r = 0; r < 12; ++r) {
+        const double t = a[r][k];
+        a[r][k] = a[r][pc];
+        a[r][pc] = t;
+      }
+      const int t = perm[k];
+      perm[k] = perm[pc];
+      perm[pc] = t;
+    }
+    const double inv = 1.0 / a[k][k];
+    for (int r = k + 1; r < 12; ++r) {
+      const double f = a[r][k] * inv;
+      for (int c = k; c < 12; ++c) a[r][c] = a[r][c] - f * a[k][c];
+    }
+  }
+  double z[12], P[12];
+  z[11] = 1.0;
+  for (int r = 10; r >= 0; --r) {
+    double sres = 0.0;
+    for (int c = r + 1; c < 12; ++c) sres = sres + a[r][c] * z[c];
+    z[r] = -sres / a[r][r];
+  }
+  for (int c = 0; c < 12; ++c) P[perm[c]] = z[c];
+  const double n3 = sqrt(P[8] * P[8] + P[9] * P[9] + P[10] * P[10]);
+  if (!(n3 > kTiny)) return false;
+  double lam = 1.0 / n3;
+  const double* X0 = p + 3 * idx[0];
+  if ((P[8] * X0[0] + P[9] * X0[1] + P[10] * X0[2] + P[11]) * lam < 0) lam = -lam;  // the sample lies in front of the camera
+  for (int c = 0; c < 12; ++c) P[c] = P[c] * lam;
+  double r1[3] = {P[0], P[1], P[2]}, r2[3] = {P[4], P[5], P[6]};
+  const double n1 = sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+  if (!(n1 > kTiny)) return false;
+  for (int e = 0; e < 3; ++e) r1[e] = r1[e] / n1;
+  const double d12 = r2[0] * r1[0] + r2[1] * r1[1] + r2[2] * r1[2];
+  for (int e = 0; e < 3; ++e) r2[e] = r2[e] - d12 * r1[e];
+  const double n2 = sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+  if (!(n2 > kTiny)) return false;
+  for (int e = 0; e < 3; ++e) r2[e] = r2[e] / n2;
+  const double r3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  if (!(r3[0] * P[8] + r3[1] * P[9] + r3[2] * P[10] > 0)) return false;  // a reflection, not a rotation
+  for (int e = 0; e < 3; ++e) {
+    out[e] = r1[e];
+    out[3 + e] = r2[e];
+    out[6 + e] = r3[e];
+  }
+  out[9] = P[3] / n1;  // each translation component carries the scale of its own row of the raw estimate
+  out[10] = P[7] / n2;
+  out[11] = P[11];
+  return true;
+}
 
 // Solve A x = b (n <= 8, nrhs <= 3) in place, partial pivoting (first maximum).  a: n x (n + nrhs) row-major, ld = 12.
 __device__ bool ge_solve(double (*a)[12], int n, int nrhs) {
@@ -125,7 +331,13 @@ __global__ __launch_bounds__(64) void ransac_solve_kernel(int model, const doubl
     if (ok)
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 4; ++c) out[4 * r + c] = a[c][4 + r];
-  } else {  // fundamental: 8 x 9 nullspace with full pivoting
+  } else if (model == kModelSim3) {
+    ok = solve_sim3(p, q, idx, out);
+  } else if (model == kModelPlane) {
+    ok = solve_plane(p, idx, out);
+  } else if (model == kModelPnP) {
+    ok = solve_pnp_dlt(p, q, idx, out);
+  } else {  // fundamental / essential: 8 x 9 nullspace with full pivoting
     for (int j = 0; j < 8; ++j) {
       const double x = (p[2 * idx[j]] - nm.m1x) * nm.s1, y = (p[2 * idx[j] + 1] - nm.m1y) * nm.s1;
       const double u = (q[2 * idx[j]] - nm.m2x) * nm.s2, v = (q[2 * idx[j] + 1] - nm.m2y) * nm.s2;
@@ -231,6 +443,34 @@ __device__ inline bool model_error(int model, const double* m, const double* p, 
     *err = e;
     return true;
   }
+  if (model == kModelSim3) {
+    const double qx = m[0], qy = m[1], qz = m[2], qw = m[3], sc = m[7];
+    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                         2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                         2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+    const double X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
+    double e = 0.0;
+    for (int r = 0; r < 3; ++r) {
+      const double d = (sc * (R[3 * r] * X + R[3 * r + 1] * Y + R[3 * r + 2] * Z) + m[4 + r]) - q[3 * i + r];
+      e = e + d * d;
+    }
+    *err = e;
+    return true;
+  }
+  if (model == kModelPlane) {
+    const double d = m[0] * p[3 * i] + m[1] * p[3 * i + 1] + m[2] * p[3 * i + 2] + m[3];
+    *err = d * d;
+    return true;
+  }
+  if (model == kModelPnP) {
+    const double X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
+    const double zc = m[6] * X + m[7] * Y + m[8] * Z + m[11];
+    if (!(zc > kTiny)) return false;
+    const double dx = (m[0] * X + m[1] * Y + m[2] * Z + m[9]) / zc - q[2 * i];
+    const double dy = (m[3] * X + m[4] * Y + m[5] * Z + m[10]) / zc - q[2 * i + 1];
+    *err = dx * dx + dy * dy;
+    return true;
+  }
   const double x = p[2 * i], y = p[2 * i + 1], u = q[2 * i], v = q[2 * i + 1];
   const double fx0 = m[0] * x + m[1] * y + m[2], fx1 = m[3] * x + m[4] * y + m[5], fx2 = m[6] * x + m[7] * y + m[8];
   const double ft0 = m[0] * u + m[3] * v + m[6], ft1 = m[1] * u + m[4] * v + m[7];
@@ -238,6 +478,42 @@ __device__ inline bool model_error(int model, const double* m, const double* p, 
   const double den = fx0 * fx0 + fx1 * fx1 + ft0 * ft0 + ft1 * ft1;
   if (!(den > 1e-300)) return false;
   *err = (num * num) / den;
+  return true;
+}
+
+// Projection of the winning 8-point estimate onto the essential manifold (two equal singular values, one zero):
+// E = U diag(s, s, 0) V^T with s = (s1 + s2) / 2, through the Jacobi eigen-decomposition of E^T E.  Host side, once.
+bool project_essential(double* E) {
+  double B[3][3], V[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + E[3 * k + r] * E[3 * k + c];
+      B[r][c] = acc;
+    }
+  jacobi_eig<3>(B, V);
+  int o[3] = {0, 1, 2};  // eigenvalues in descending order (stable selection)
+  for (int a = 0; a < 2; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (B[o[b]][o[b]] > B[o[a]][o[a]]) {
+        const int t = o[a];
+        o[a] = o[b];
+        o[b] = t;
+      }
+  const double l1 = B[o[0]][o[0]], l2 = B[o[1]][o[1]];
+  if (!(l2 > 1e-300)) return false;
+  const double s1 = sqrt(l1), s2 = sqrt(l2), sm = (s1 + s2) / 2.0;
+  double u[2][3];
+  for (int a = 0; a < 2; ++a) {
+    const double sv = a == 0 ? s1 : s2;
+    for (int r = 0; r < 3; ++r) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + E[3 * r + k] * V[k][o[a]];
+      u[a][r] = acc / sv;
+    }
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) E[3 * r + c] = sm * (u[0][r] * V[c][o[0]] + u[1][r] * V[c][o[1]]);
   return true;
 }
 
@@ -314,9 +590,9 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
                                         int* inliers_out) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
-  GH_CHECK_ARG(ctx, model >= 0 && model <= 3 && src && dst && model_out && inliers_out && threshold >= 0);
-  const int dim = model == kModelA3 ? 3 : 2;
-  const int s = model == kModelH ? 4 : (model == kModelA2 ? 3 : (model == kModelF ? 8 : 4));
+  GH_CHECK_ARG(ctx, model >= 0 && model <= 7 && src && dst && model_out && inliers_out && threshold >= 0);
+  const int dim = dim_p(model), dimq = dim_q(model);
+  const int s = sample_size(model);
   *inliers_out = 0;
   for (int k = 0; k < 12; ++k) model_out[k] = 0.0;
   if (mask_out)
@@ -324,7 +600,7 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
   if (n < s) return GH_OK;  // not enough correspondences: no model (inliers 0)
   GH_HIP(ctx, hipSetDevice(ctx->device));
   Norm nm = {0, 0, 1, 0, 0, 1};
-  if (model == kModelF) {  // Hartley normalisation, sequential sums in index order (the oracle does the same)
+  if (model == kModelF || model == kModelE) {  // Hartley normalisation, sequential sums in index order (the oracle does the same)
     double ax = 0, ay = 0, bx = 0, by = 0;
     for (int i = 0; i < n; ++i) {
       ax += src[2 * i]; ay += src[2 * i + 1];
@@ -342,7 +618,7 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
     nm.s1 = d1 > 0 ? 1.4142135623730951 / d1 : 1.0;
     nm.s2 = d2 > 0 ? 1.4142135623730951 / d2 : 1.0;
   }
-  const size_t pb = (((size_t)n * dim * 8) + 255) & ~(size_t)255;
+  const size_t pb = (((size_t)n * 3 * 8) + 255) & ~(size_t)255;  // sized for the wider of the two point sets
   const size_t off_q = pb, off_models = 2 * pb, off_valid = off_models + (size_t)kHyp * 12 * 8,
                off_counts = off_valid + kHyp * 4, off_best = off_counts + kHyp * 4, off_mout = off_best + 256,
                off_mask = off_mout + 256, total = off_mask + (((size_t)n + 255) & ~(size_t)255);
@@ -358,7 +634,7 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
   double* d_mout = (double*)(b + off_mout);
   uint8_t* d_mask = b + off_mask;
   GH_HIP(ctx, hipMemcpyAsync(d_p, src, (size_t)n * dim * 8, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_q, dst, (size_t)n * dim * 8, hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d_q, dst, (size_t)n * dimq * 8, hipMemcpyHostToDevice, ctx->stream));
   const double thr2 = threshold * threshold;
   GH_LAUNCH(ctx, "ransac_solve", ransac_solve_kernel, dim3(kHyp / 64), dim3(64), 0, model, d_p, d_q, n, seed, nm,
             d_models, d_valid);
@@ -377,5 +653,74 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
     return GH_OK;
   }
   *inliers_out = best[1];
+  if (model == kModelE && !project_essential(model_out)) {  // the mask stays that of the scored 8-point estimate
+    for (int k = 0; k < 12; ++k) model_out[k] = 0.0;
+    *inliers_out = 0;
+  }
+  return GH_OK;
+}
+
+namespace {
+
+// Midpoint triangulation of one correspondence per thread (GSLAM::Estimator::trianglate, Estimator.h:164-168): the point
+// of the REFERENCE frame closest to both rays, X_cur = R X_ref + t.  ok = 0 when the rays are parallel or the point lies
+// behind either camera.
+__global__ __launch_bounds__(256) void triangulate_kernel(const double* __restrict__ pose, int pose_stride,
+                                                          const double* __restrict__ dref, const double* __restrict__ dcur,
+                                                          int n, double* __restrict__ out, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double* T = pose + (size_t)i * pose_stride;  // [qx qy qz qw tx ty tz], ref -> cur
+  const double qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+  const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                       2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                       2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+  const double* d1 = dref + 3 * (size_t)i;
+  const double* b = dcur + 3 * (size_t)i;
+  double a[3];
+  for (int r = 0; r < 3; ++r) a[r] = R[3 * r] * d1[0] + R[3 * r + 1] * d1[1] + R[3 * r + 2] * d1[2];
+  const double aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+  const double ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  const double at = a[0] * T[4] + a[1] * T[5] + a[2] * T[6], bt = b[0] * T[4] + b[1] * T[5] + b[2] * T[6];
+  const double det = aa * bb - ab * ab;
+  bool good = det > 1e-12 * aa * bb;
+  double l1 = 0.0, l2 = 0.0;
+  if (good) {
+    l1 = (ab * bt - bb * at) / det;  // min |l1 a + t - l2 b|^2
+    l2 = (aa * bt - ab * at) / det;
+    good = l1 > 0.0 && l2 > 0.0;
+  }
+  double xr[3] = {0, 0, 0};
+  if (good) {
+    double mc[3];
+    for (int r = 0; r < 3; ++r) mc[r] = ((l1 * a[r] + T[4 + r]) + l2 * b[r]) / 2.0 - T[4 + r];  // midpoint - t, cur frame
+    for (int r = 0; r < 3; ++r) xr[r] = R[r] * mc[0] + R[3 + r] * mc[1] + R[6 + r] * mc[2];      // R^T (.)
+  }
+  for (int r = 0; r < 3; ++r) out[3 * (size_t)i + r] = xr[r];
+  ok[i] = good ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" gh_status gh_triangulate(gh_ctx* ctx, const double* ref2cur_pose, int pose_stride, const double* ref_dir,
+                                    const double* cur_dir, int n, double* ref_points, uint8_t* ok) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, n >= 0 && (pose_stride == 0 || pose_stride == 7));
+  if (n == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, ref2cur_pose && ref_dir && cur_dir && ref_points && ok);
+  const size_t np_ = pose_stride == 0 ? 1 : (size_t)n;
+  const size_t a = ((np_ * 56) + 255) & ~(size_t)255, b = (((size_t)n * 24) + 255) & ~(size_t)255;
+  void* base = nullptr;
+  GH_TRY(gh_scratch(ctx, a + 3 * b + (((size_t)n + 255) & ~(size_t)255), &base));
+  uint8_t* d = (uint8_t*)base;
+  GH_HIP(ctx, hipMemcpyAsync(d, ref2cur_pose, np_ * 56, hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d + a, ref_dir, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d + a + b, cur_dir, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+  GH_LAUNCH(ctx, "triangulate", triangulate_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)d, pose_stride,
+            (const double*)(d + a), (const double*)(d + a + b), n, (double*)(d + a + 2 * b), d + a + 3 * b);
+  GH_HIP(ctx, hipMemcpyAsync(ref_points, d + a + 2 * b, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(ok, d + a + 3 * b, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return GH_OK;
 }

@@ -7,7 +7,7 @@ import numpy as np
 
 from . import hip
 
-HOMOGRAPHY, AFFINE2D, FUNDAMENTAL, AFFINE3D = 0, 1, 2, 3
+HOMOGRAPHY, AFFINE2D, FUNDAMENTAL, AFFINE3D, ESSENTIAL, SIM3, PLANE, PNP = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def estimate(ctx: hip.Context, model, src, dst, threshold, seed=1):
@@ -21,3 +21,16 @@ def estimate(ctx: hip.Context, model, src, dst, threshold, seed=1):
     ctx.check(hip.lib.gh_ransac_estimate(ctx.h, int(model), pv(src), pv(dst), n, C.c_double(threshold), C.c_uint64(seed),
                                          pv(m), pv(mask), C.byref(cnt)))
     return m, mask[:n].copy(), cnt.value
+
+
+def triangulate(ctx: hip.Context, ref2cur_pose, ref_dir, cur_dir):
+    """Midpoint triangulation (GSLAM::Estimator::trianglate); ref2cur_pose: 7 doubles (one pose for all) or n x 7."""
+    T = np.ascontiguousarray(ref2cur_pose, dtype=np.float64)
+    d1 = np.ascontiguousarray(ref_dir, dtype=np.float64).reshape(-1, 3)
+    d2 = np.ascontiguousarray(cur_dir, dtype=np.float64).reshape(-1, 3)
+    n = d1.shape[0]
+    out = np.zeros((n, 3))
+    ok = np.zeros(max(n, 1), np.uint8)
+    pv = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(hip.lib.gh_triangulate(ctx.h, pv(T), 7 if T.ndim == 2 else 0, pv(d1), pv(d2), n, pv(out), pv(ok)))
+    return out, ok[:n].astype(bool)

@@ -58,16 +58,97 @@ class EstimatorHIP : public GSLAM::Estimator {
     if (A) for (int i = 0; i < 12; ++i) A->data()[i] = m[i];
     return true;
   }
-  bool findEssentialMatrix(GSLAM::Essential*, const std::vector<GSLAM::Point2d>&, const std::vector<GSLAM::Point2d>&,
-                           int, double, double, std::vector<uchar>*) const override { return false; }
-  bool findSIM3(GSLAM::SIM3*, const std::vector<GSLAM::Point3d>&, const std::vector<GSLAM::Point3d>&, int, double,
-                double, std::vector<uchar>*) const override { return false; }
-  bool findPlane(GSLAM::SE3*, const std::vector<GSLAM::Point3d>&, int, double, double,
-                 std::vector<uchar>*) const override { return false; }
-  bool findPnP(GSLAM::SE3*, const std::vector<GSLAM::Point3d>&, const std::vector<GSLAM::Point2d>&, int, double, double,
-               std::vector<uchar>*) const override { return false; }
-  bool trianglate(GSLAM::Point3d*, const GSLAM::SE3&, const GSLAM::Point3d&, const GSLAM::Point3d&) const override {
-    return false;
+  // points1 / points2 are normalised image coordinates (camera.UnProject), threshold in the same units
+  bool findEssentialMatrix(GSLAM::Essential* E, const std::vector<GSLAM::Point2d>& p1, const std::vector<GSLAM::Point2d>& p2,
+                           int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
+    double m[12];
+    if (!run(GH_MODEL_ESSENTIAL, p1, p2, method, threshold, m, mask)) return false;
+    if (E) for (int i = 0; i < 9; ++i) E->data()[i] = m[i];
+    return true;
+  }
+  // to ~ s R from + t (Horn's closed form inside RANSAC)
+  bool findSIM3(GSLAM::SIM3* S, const std::vector<GSLAM::Point3d>& from, const std::vector<GSLAM::Point3d>& to, int method,
+                double threshold, double confidence, std::vector<uchar>* mask) const override {
+    if (from.size() != to.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    double m[12];
+    if (!estimate(GH_MODEL_SIM3, (const double*)from.data(), (const double*)to.data(), (int)from.size(), threshold, m, mask))
+      return false;
+    if (S) *S = GSLAM::SIM3(GSLAM::SO3(m[0], m[1], m[2], m[3]), GSLAM::Point3d(m[4], m[5], m[6]), m[7]);
+    return true;
+  }
+  // plane pose: origin = the plane point closest to the world origin, z axis = the unit normal
+  bool findPlane(GSLAM::SE3* plane, const std::vector<GSLAM::Point3d>& points, int method, double threshold,
+                 double confidence, std::vector<uchar>* mask) const override {
+    if ((method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    double m[12];
+    if (!estimate(GH_MODEL_PLANE, (const double*)points.data(), (const double*)points.data(), (int)points.size(), threshold,
+                  m, mask))
+      return false;
+    if (plane) {
+      const double n[3] = {m[0], m[1], m[2]};
+      const double ref[3] = {fabs(n[0]) < 0.9 ? 1.0 : 0.0, fabs(n[0]) < 0.9 ? 0.0 : 1.0, 0.0};
+      double x[3] = {ref[1] * n[2] - ref[2] * n[1], ref[2] * n[0] - ref[0] * n[2], ref[0] * n[1] - ref[1] * n[0]};
+      const double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      for (int e = 0; e < 3; ++e) x[e] /= xn;
+      const double y[3] = {n[1] * x[2] - n[2] * x[1], n[2] * x[0] - n[0] * x[2], n[0] * x[1] - n[1] * x[0]};
+      double R[9] = {x[0], y[0], n[0], x[1], y[1], n[1], x[2], y[2], n[2]};
+      GSLAM::SO3 rot;
+      rot.fromMatrix(R);
+      *plane = GSLAM::SE3(rot, GSLAM::Point3d(-m[3] * n[0], -m[3] * n[1], -m[3] * n[2]));
+    }
+    return true;
+  }
+  // imagePoints are normalised (z = 1 plane); RANSAC over 6-point DLT hypotheses, then the motion-only bundle adjustment
+  // of the Optimizer path (gh_ba_pnp, Huber at the RANSAC threshold) on the inliers
+  bool findPnP(GSLAM::SE3* world2camera, const std::vector<GSLAM::Point3d>& obj, const std::vector<GSLAM::Point2d>& img,
+               int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
+    if (obj.size() != img.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    double m[12];
+    std::vector<uchar> local;
+    if (!estimate(GH_MODEL_PNP, (const double*)obj.data(), (const double*)img.data(), (int)obj.size(), threshold, m, &local))
+      return false;
+    std::vector<double> X, uv;
+    for (size_t i = 0; i < local.size(); ++i)
+      if (local[i]) {
+        X.push_back(obj[i].x); X.push_back(obj[i].y); X.push_back(obj[i].z);
+        uv.push_back(img[i].x); uv.push_back(img[i].y);
+      }
+    // [R | t] world -> camera  =>  T_wc = (R^T, -R^T t), the parametrisation gh_ba_pnp refines
+    GSLAM::SO3 rcw;
+    rcw.fromMatrix(m);
+    const GSLAM::SE3 Tcw(rcw, GSLAM::Point3d(m[9], m[10], m[11])), Twc = Tcw.inverse();
+    const GSLAM::SO3 r = Twc.get_rotation();
+    const GSLAM::Point3d t = Twc.get_translation();
+    double pose[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+    gh_ba_options o;
+    gh_ba_default_options(&o);
+    o.huber_delta = threshold;
+    o.max_iterations = 30;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (gh_ba_pnp(ctx_, X.data(), uv.data(), (int)(uv.size() / 2), pose, GH_KF_SE3, &o, NULL, NULL) != GH_OK) {
+        LOG(ERROR) << "EstimatorHIP: " << gh_last_error(ctx_);
+        return false;
+      }
+    }
+    if (world2camera)
+      *world2camera = GSLAM::SE3(GSLAM::SO3(pose[0], pose[1], pose[2], pose[3]), GSLAM::Point3d(pose[4], pose[5], pose[6])).inverse();
+    if (mask) mask->swap(local);
+    return true;
+  }
+  bool trianglate(GSLAM::Point3d* refPt, const GSLAM::SE3& ref2cur, const GSLAM::Point3d& refDirection,
+                  const GSLAM::Point3d& curDirection) const override {
+    if (!context()) return false;
+    const GSLAM::SO3 r = ref2cur.get_rotation();
+    const GSLAM::Point3d t = ref2cur.get_translation();
+    const double pose[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+    const double d1[3] = {refDirection.x, refDirection.y, refDirection.z}, d2[3] = {curDirection.x, curDirection.y, curDirection.z};
+    double X[3];
+    uint8_t ok = 0;
+    std::lock_guard<std::mutex> lock(mu_);
+    if (gh_triangulate(ctx_, pose, 0, d1, d2, 1, X, &ok) != GH_OK || !ok) return false;
+    if (refPt) *refPt = GSLAM::Point3d(X[0], X[1], X[2]);
+    return true;
   }
 
  private:

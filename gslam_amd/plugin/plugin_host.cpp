@@ -386,6 +386,10 @@ static int run_est(const std::string& dir, int model, int n, const char* ptsf, d
     Affine2D A;
     ok = est->findAffine2D(&A, a, b, A3_Point | RANSAC, thr, 0.99, &mask);
     for (int i = 0; i < 6; ++i) m[i] = A.data()[i];
+  } else if (model == 4) {
+    Essential E;
+    ok = est->findEssentialMatrix(&E, a, b, E5_Nister | RANSAC, thr, 0.99, &mask);
+    for (int i = 0; i < 9; ++i) m[i] = E.data()[i];
   } else {
     Fundamental F;
     ok = est->findFundamental(&F, a, b, F8_Point | RANSAC, thr, 0.99, &mask);
@@ -403,6 +407,65 @@ static int run_est(const std::string& dir, int model, int n, const char* ptsf, d
   return ok && !unsupported ? 0 : 3;
 }
 
+// findSIM3 (5) / findPlane (6) / findPnP (7) / trianglate (8) through Estimator::create(); input n x 6 doubles per row:
+// SIM3 (from xyz, to xyz), plane (xyz, unused), PnP (object xyz, normalised uv, unused), trianglate (ref dir, cur dir)
+// preceded, for mode 8, by the ref -> cur pose as 7 doubles.
+static int run_est3(const std::string& dir, int model, int n, const char* ptsf, double thr, const char* out) {
+  svar.GetString("EstimatorPlugin", "") = dir + "/libgslam_estimator.so";
+  EstimatorPtr est = Estimator::create();
+  if (!est) { std::cerr << "Estimator::create() returned null\n"; return 2; }
+  std::ifstream f(ptsf, std::ios::binary);
+  double pose7[7] = {0, 0, 0, 1, 0, 0, 0};
+  if (model == 8) f.read((char*)pose7, sizeof(pose7));
+  std::vector<double> raw((size_t)n * 6);
+  f.read((char*)raw.data(), raw.size() * 8);
+  std::vector<Point3d> a(n), b(n);
+  std::vector<Point2d> uv(n);
+  for (int i = 0; i < n; ++i) {
+    a[i] = Point3d(raw[6 * i], raw[6 * i + 1], raw[6 * i + 2]);
+    b[i] = Point3d(raw[6 * i + 3], raw[6 * i + 4], raw[6 * i + 5]);
+    uv[i] = Point2d(raw[6 * i + 3], raw[6 * i + 4]);
+  }
+  std::vector<uchar> mask;
+  std::vector<double> m;
+  bool ok = false;
+  if (model == 5) {
+    SIM3 S;
+    ok = est->findSIM3(&S, a, b, S3_Horn | RANSAC, thr, 0.99, &mask);
+    const SO3 r = S.get_rotation();
+    const Point3d t = S.get_translation();
+    m = {r.x, r.y, r.z, r.w, t.x, t.y, t.z, S.get_scale()};
+  } else if (model == 6) {
+    SE3 P;
+    ok = est->findPlane(&P, a, P3_Plane | RANSAC, thr, 0.99, &mask);
+    const SO3 r = P.get_rotation();
+    const Point3d t = P.get_translation(), z = r * Point3d(0, 0, 1);
+    m = {z.x, z.y, z.z, t.x, t.y, t.z};  // normal, point on the plane
+  } else if (model == 7) {
+    SE3 T;
+    ok = est->findPnP(&T, a, uv, P3_ITERATIVE | RANSAC, thr, 0.99, &mask);
+    const SO3 r = T.get_rotation();
+    const Point3d t = T.get_translation();
+    m = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+  } else {
+    const SE3 T(SO3(pose7[0], pose7[1], pose7[2], pose7[3]), Point3d(pose7[4], pose7[5], pose7[6]));
+    ok = true;
+    for (int i = 0; i < n; ++i) {
+      Point3d X(0, 0, 0);
+      const bool one = est->trianglate(&X, T, a[i], b[i]);
+      mask.push_back(one ? 1 : 0);
+      m.push_back(X.x); m.push_back(X.y); m.push_back(X.z);
+    }
+  }
+  std::ofstream o(out, std::ios::binary);
+  int32_t hdr[3] = {ok ? 1 : 0, (int32_t)mask.size(), (int32_t)m.size()};
+  o.write((char*)hdr, sizeof(hdr));
+  o.write((char*)m.data(), m.size() * 8);
+  if (!mask.empty()) o.write((char*)mask.data(), mask.size());
+  std::cout << "estimator3 " << est->type() << " model=" << model << " ok=" << ok << std::endl;
+  return ok ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
@@ -410,6 +473,7 @@ int main(int argc, char** argv) {
     return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
   if (mode == "est" && argc >= 8) return run_est(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);
+  if (mode == "est3" && argc >= 8) return run_est3(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);
   if (mode == "app" && argc >= 9)
     return run_app(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
   if (mode == "undist" && argc >= 5) return run_undist(atoi(argv[3]), argv[4]);

@@ -257,18 +257,38 @@ gh_status gh_undistort_dev(gh_undist_plan* plan, const uint8_t* img_dev, int cha
 gh_status gh_undistort_host(gh_undist_plan* plan, const uint8_t* img, int channels, uint8_t* out, int fast);
 
 /* ------------------------------------------------------------------ RANSAC estimation - */
-/* Robust model fitting with an inlier mask, behind GSLAM::Estimator::findHomography / findAffine2D / findFundamental /
- * findAffine3D (GSLAM/core/Estimator.h:100-147; interface only in the reference).  model: 0 homography (src, dst:
- * n x 2 doubles, model_out 9 row-major, h33 = 1), 1 affine 2D (model_out 6 = 2 x 3), 2 fundamental (dst^T F src = 0,
- * model_out 9, Sampson error), 3 affine 3D (n x 3 doubles, model_out 12 = 3 x 4).  Deterministic: 2048 hypotheses drawn
- * from `seed`; winner = most correspondences with squared error <= threshold^2, lowest hypothesis index on ties.
- * model_out must hold 12 doubles; mask_out (n bytes, may be NULL) gets 1 for inliers; *inliers_out = 0 means no model. */
+/* Robust model fitting with an inlier mask, behind GSLAM::Estimator (GSLAM/core/Estimator.h:100-169; interface only in
+ * the reference).  Deterministic: 2048 hypotheses drawn from `seed`; winner = most correspondences with squared error
+ * <= threshold^2, lowest hypothesis index on ties.  model_out must hold 12 doubles; mask_out (n bytes, may be NULL) gets
+ * 1 for inliers; *inliers_out = 0 means no model.
+ *   0 homography   findHomography      src, dst n x 2; model 9 row-major, h33 = 1; forward transfer error
+ *   1 affine 2D    findAffine2D        src, dst n x 2; model 6 = 2 x 3
+ *   2 fundamental  findFundamental     src, dst n x 2; dst^T F src = 0; model 9; Sampson error; rank not enforced
+ *   3 affine 3D    findAffine3D        src, dst n x 3; model 12 = 3 x 4
+ *   4 essential    findEssentialMatrix src, dst n x 2 NORMALISED image coordinates; hypotheses as (2), the winner is
+ *                                      projected onto the essential manifold (singular values s, s, 0); model 9
+ *   5 SIM3         findSIM3            src, dst n x 3; dst ~ s R src + t by Horn's closed form on 3 pairs;
+ *                                      model 8 = [qx qy qz qw tx ty tz s]
+ *   6 plane        findPlane           src n x 3 (dst ignored, pass src); model 4 = [nx ny nz d], n . x + d = 0, |n| = 1
+ *   7 PnP          findPnP             src n x 3 object points, dst n x 2 normalised image points; 6-point DLT
+ *                                      hypotheses (coplanar object points are degenerate); model 12 = [R row-major | t],
+ *                                      X_cam = R X + t.  Refine on the inliers with gh_ba_pnp. */
 #define GH_MODEL_HOMOGRAPHY 0
 #define GH_MODEL_AFFINE2D 1
 #define GH_MODEL_FUNDAMENTAL 2
 #define GH_MODEL_AFFINE3D 3
+#define GH_MODEL_ESSENTIAL 4
+#define GH_MODEL_SIM3 5
+#define GH_MODEL_PLANE 6
+#define GH_MODEL_PNP 7
 gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* src, const double* dst, int n, double threshold,
                              uint64_t seed, double* model_out, uint8_t* mask_out, int* inliers_out);
+/* Midpoint triangulation, one correspondence per thread (GSLAM::Estimator::trianglate, Estimator.h:164-168): the point of
+ * the REFERENCE frame closest to the two rays ref_dir and cur_dir (camera.UnProject of the two pixels), with
+ * X_cur = T_ref2cur X_ref, pose = [qx qy qz qw tx ty tz].  pose_stride = 7: one pose per correspondence; 0: one pose for
+ * all.  ok[i] = 0 when the rays are parallel or the point lies behind either camera. */
+gh_status gh_triangulate(gh_ctx* ctx, const double* ref2cur_pose, int pose_stride, const double* ref_dir,
+                         const double* cur_dir, int n, double* ref_points, uint8_t* ok);
 
 /* ------------------------------------------------------------------ bundle adjustment - */
 /* DOF bits follow GSLAM::KeyFrameEstimzationDOF (GSLAM/core/Optimizer.h:70-84). */

@@ -474,7 +474,15 @@ def _ransac_methods(cls):
                                      _ptr(m), _ptr(mask))
         return m, mask[:n].copy(), cnt
 
+    def triangulate(self, pose, d1, d2):
+        out = np.zeros(3)
+        ok = self.lib.oracle_triangulate(_ptr(np.ascontiguousarray(pose, dtype=np.float64)),
+                                         _ptr(np.ascontiguousarray(d1, dtype=np.float64)),
+                                         _ptr(np.ascontiguousarray(d2, dtype=np.float64)), _ptr(out))
+        return out, bool(ok)
+
     cls.ransac = ransac
+    cls.triangulate = triangulate
 
 
 _ransac_methods(Oracle)

@@ -250,3 +250,80 @@ def test_estimator_plugin_through_estimator_create(tmp_path, oracle, model):
     em, emask, ecnt = oracle.ransac(model, P, Q, thr, seed=1)
     ms = 6 if model == 1 else 9
     assert ok == 1 and nm == n and np.array_equal(mask, emask) and m[:ms].tobytes() == em[:ms].tobytes()
+
+
+@pytest.mark.parametrize("model", [4, 5, 6, 7, 8])
+def test_estimator_plugin_remaining_solvers(tmp_path, oracle, model):
+    """findEssentialMatrix / findSIM3 / findPlane / findPnP / trianglate through GSLAM::Estimator::create()
+    (GSLAM/core/Estimator.h:118-169): the plugin's answers equal the oracle's (RANSAC part bit for bit; findPnP's
+    motion-only refinement on the inliers to 1e-8)."""
+    _need_host()
+    from test_ransac_gpu import _cases
+    from test_ransac_oracle import _rot
+    fin, out = tmp_path / "pts.raw", tmp_path / "out.bin"
+    if model == 4:
+        P, Q, thr = _cases()[4]
+        n = len(P)
+        np.ascontiguousarray(np.c_[P, Q], dtype=np.float64).tofile(fin)
+        r = _run(["est", LIBDIR, 4, n, fin, thr, out])
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        ok, nm = struct.unpack("2i", raw[:8])
+        m = np.frombuffer(raw, np.float64, 9, 8)
+        mask = np.frombuffer(raw, np.uint8, nm, 8 + 72)
+        em, emask, _ = oracle.ransac(4, P, Q, thr, seed=1)
+        assert ok == 1 and np.array_equal(mask, emask) and m.tobytes() == em[:9].tobytes()
+        return
+    if model == 8:
+        from gslam_amd.ba_synth import _quat_from_R
+        rng = np.random.default_rng(3)
+        R, t = _rot([0.1, 1, 0.2], 0.2), np.array([-0.8, 0.02, 0.05])
+        pose = np.r_[_quat_from_R(R[None])[0], t]
+        X = np.c_[rng.uniform(-2, 2, (40, 2)), rng.uniform(3, 10, 40)]
+        X2 = X @ R.T + t
+        d1, d2 = X / X[:, 2:3], X2 / X2[:, 2:3]
+        d2[7] = R @ d1[7]
+        with open(fin, "wb") as f:
+            f.write(pose.tobytes() + np.ascontiguousarray(np.c_[d1, d2]).tobytes())
+        r = _run(["est3", LIBDIR, 8, 40, fin, 0.0, out])
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        ok, nm, nv = struct.unpack("3i", raw[:12])
+        pts = np.frombuffer(raw, np.float64, nv, 12).reshape(-1, 3)
+        mask = np.frombuffer(raw, np.uint8, nm, 12 + 8 * nv)
+        for i in range(40):
+            e, eok = oracle.triangulate(pose, d1[i], d2[i])
+            assert bool(mask[i]) == eok and (not eok or pts[i].tobytes() == e.tobytes())
+        assert mask.sum() == 39 and np.abs(pts[0] - X[0]).max() < 1e-9
+        return
+    P, Q, thr = _cases()[model]
+    n = len(P)
+    rows = np.zeros((n, 6))
+    rows[:, :3] = P
+    rows[:, 3:3 + Q.shape[1]] = Q
+    rows.tofile(fin)
+    r = _run(["est3", LIBDIR, model, n, fin, thr, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    ok, nm, nv = struct.unpack("3i", raw[:12])
+    m = np.frombuffer(raw, np.float64, nv, 12)
+    mask = np.frombuffer(raw, np.uint8, nm, 12 + 8 * nv)
+    em, emask, ecnt = oracle.ransac(model, P, Q, thr, seed=1)
+    assert ok == 1 and np.array_equal(mask, emask)
+    if model == 5:
+        assert m.tobytes() == em[:8].tobytes()
+    elif model == 6:
+        assert m[:3].tobytes() == em[:3].tobytes() and np.abs(m[3:6] + em[3] * em[:3]).max() < 1e-12
+    else:  # world -> camera pose after the refinement on the inliers
+        R = em[:9].reshape(3, 3)
+        from gslam_amd.ba_synth import _quat_from_R
+        start = np.r_[_quat_from_R(R.T[None])[0], -R.T @ em[9:12]]  # T_wc
+        inl = emask.astype(bool)
+        po, so, _, rc = oracle.ba_pnp(P[inl], Q[inl], start, opts=oracle_lib.ba_options(huber=thr, max_iterations=30))
+        from gslam_amd.ba_synth import quat_to_R
+        Rwc = quat_to_R(po[None, :4])[0]
+        qcw = _quat_from_R(Rwc.T[None])[0]
+        tcw = -Rwc.T @ po[4:]
+        got_q = m[:4] * np.sign(m[3]) if m[3] != 0 else m[:4]
+        exp_q = qcw * np.sign(qcw[3]) if qcw[3] != 0 else qcw
+        assert np.abs(got_q - exp_q).max() < 1e-8 and np.abs(m[4:7] - tcw).max() < 1e-8

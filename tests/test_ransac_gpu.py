@@ -28,3 +28,71 @@ def test_ransac_degenerate(ctx, oracle):
     assert cnt == 0 and not mask.any() and not m.any()
     m, mask, cnt = estimator.estimate(ctx, 2, np.zeros((5, 2)), np.zeros((5, 2)), 1.0)
     assert cnt == 0
+
+
+def _cases():
+    from test_ransac_oracle import _rot, _two_view
+    rng = np.random.default_rng(77)
+    n = 800
+    out = {}
+    p1, p2, _, _ = _two_view(n, 0.25, 31, 0.0005)
+    out[4] = (p1, p2, 0.002)
+    A = rng.uniform(-4, 4, (n, 3))
+    B = 1.7 * A @ _rot([1, 2, 3], 0.7).T + np.array([1.0, -2.0, 0.5]) + rng.normal(size=(n, 3)) * 0.002
+    bad = rng.random(n) < 0.3
+    B[bad] += rng.uniform(0.5, 2, (int(bad.sum()), 3))
+    out[5] = (A, B, 0.02)
+    nrm = np.array([0.2, -0.3, 0.93]); nrm /= np.linalg.norm(nrm)
+    P = rng.uniform(-5, 5, (n, 3))
+    P -= np.outer(P @ nrm + 1.5, nrm)
+    P += np.outer(rng.normal(size=n) * 0.002, nrm)
+    P[bad] += np.outer(rng.uniform(0.2, 2, int(bad.sum())), nrm)
+    out[6] = (P, P, 0.01)
+    X = np.c_[rng.uniform(-3, 3, (n, 2)), rng.uniform(-1, 1, n)]
+    Xc = X @ _rot([0.3, -1, 0.2], 0.4).T + np.array([0.2, -0.1, 6.0])
+    uv = Xc[:, :2] / Xc[:, 2:3] + rng.normal(size=(n, 2)) * 0.0003
+    uv[bad] += rng.uniform(0.03, 0.2, (int(bad.sum()), 2))
+    out[7] = (X, uv, 0.003)
+    return out
+
+
+@pytest.mark.parametrize("model", [4, 5, 6, 7])
+def test_ransac_new_models_bit_exact_vs_oracle(ctx, oracle, model):
+    """findEssentialMatrix / findSIM3 / findPlane / findPnP hypotheses (GSLAM/core/Estimator.h:118-161): model doubles and
+    inlier masks identical to the oracle's, bit for bit -- the solvers use + - * / sqrt only (Jacobi eigen-decomposition
+    for Horn's quaternion and the essential projection, full-pivot elimination for the DLT)."""
+    from gslam_amd import estimator
+    P, Q, thr = _cases()[model]
+    for seed in (1, 999):
+        em, emask, ecnt = oracle.ransac(model, P, Q, thr, seed=seed)
+        gm, gmask, gcnt = estimator.estimate(ctx, model, P, Q, thr, seed=seed)
+        assert gcnt == ecnt and np.array_equal(gmask, emask), (model, gcnt, ecnt)
+        assert gm.tobytes() == em.tobytes(), (model, gm, em)
+        assert ecnt > 400
+    m, mask, cnt = estimator.estimate(ctx, model, P[:2], Q[:2], thr)  # fewer points than the minimal sample
+    assert cnt == 0 and not m.any()
+
+
+def test_triangulate_bit_exact_vs_oracle(ctx, oracle):
+    from gslam_amd import estimator
+    from gslam_amd.ba_synth import _quat_from_R
+    from test_ransac_oracle import _rot
+    rng = np.random.default_rng(3)
+    R, t = _rot([0.1, 1, 0.2], 0.2), np.array([-0.8, 0.02, 0.05])
+    pose = np.r_[_quat_from_R(R[None])[0], t]
+    X = np.c_[rng.uniform(-2, 2, (300, 2)), rng.uniform(3, 10, 300)]
+    d1 = X / X[:, 2:3] + rng.normal(size=X.shape) * 1e-4
+    X2 = X @ R.T + t
+    d2 = X2 / X2[:, 2:3]
+    d2[::17] = d1[::17] @ R.T  # parallel rays
+    d1[5::23, 0] -= 3.0        # diverging rays
+    got, ok = estimator.triangulate(ctx, pose, d1, d2)
+    poses = np.tile(pose, (300, 1))
+    got2, ok2 = estimator.triangulate(ctx, poses, d1, d2)
+    assert got.tobytes() == got2.tobytes() and np.array_equal(ok, ok2)
+    n_ok = 0
+    for i in range(300):
+        e, eok = oracle.triangulate(pose, d1[i], d2[i])
+        assert eok == ok[i] and e.tobytes() == got[i].tobytes(), i
+        n_ok += eok
+    assert 200 < n_ok < 300

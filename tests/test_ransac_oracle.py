@@ -79,3 +79,93 @@ def test_deterministic_in_seed(oracle):
     c = oracle.ransac(0, P, Q, 2.0, seed=8)
     assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
     assert a[0].tobytes() != c[0].tobytes()
+
+
+# ---------------------------------------------------------------- essential / SIM3 / plane / PnP / triangulation
+def _rot(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def _two_view(n, outlier_frac, seed, noise):
+    """Normalised image coordinates of n points in two views; returns p1, p2, inlier flags, (R, t) with X2 = R X1 + t."""
+    rng = np.random.default_rng(seed)
+    X = np.c_[rng.uniform(-3, 3, (n, 2)), rng.uniform(4, 9, n)]
+    R, t = _rot([0.2, 1.0, 0.1], 0.12), np.array([0.6, 0.05, 0.1])
+    X2 = X @ R.T + t
+    p1 = X[:, :2] / X[:, 2:3]
+    p2 = X2[:, :2] / X2[:, 2:3] + rng.normal(size=(n, 2)) * noise
+    out = rng.random(n) < outlier_frac
+    p2[out] += rng.uniform(0.05, 0.3, (int(out.sum()), 2)) * rng.choice([-1, 1], (int(out.sum()), 2))
+    return p1, p2, ~out, (R, t)
+
+
+def test_essential_has_two_equal_singular_values_and_fits_the_geometry(oracle):
+    p1, p2, inl, (R, t) = _two_view(700, 0.25, 31, 0.0005)
+    m, mask, cnt = oracle.ransac(4, p1, p2, 0.002)
+    E = m[:9].reshape(3, 3)
+    sv = np.linalg.svd(E, compute_uv=False)
+    assert abs(sv[0] - sv[1]) <= 1e-9 * sv[0] and sv[2] <= 1e-9 * sv[0]
+    assert cnt >= 0.9 * inl.sum() and (mask.astype(bool) & ~inl).sum() <= 5
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Et = tx @ R
+    cosang = abs(np.sum(E * Et)) / (np.linalg.norm(E) * np.linalg.norm(Et))
+    assert cosang > 0.999  # the same matrix up to scale and sign
+
+
+def test_sim3_plane_pnp_recover_ground_truth(oracle):
+    rng = np.random.default_rng(7)
+    n = 500
+    # SIM3
+    A = rng.uniform(-4, 4, (n, 3))
+    R, t, s = _rot([1, 2, 3], 0.7), np.array([1.0, -2.0, 0.5]), 1.7
+    B = s * A @ R.T + t + rng.normal(size=(n, 3)) * 0.002
+    out = rng.random(n) < 0.3
+    B[out] += rng.uniform(0.5, 2, (int(out.sum()), 3))
+    m, mask, cnt = oracle.ransac(5, A, B, 0.02)
+    q = m[:4]
+    Rm = np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[3] * q[2]), 2 * (q[0] * q[2] + q[3] * q[1])],
+                   [2 * (q[0] * q[1] + q[3] * q[2]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[3] * q[0])],
+                   [2 * (q[0] * q[2] - q[3] * q[1]), 2 * (q[1] * q[2] + q[3] * q[0]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+    assert np.abs(Rm - R).max() < 5e-3 and abs(m[7] - s) < 5e-3 and np.abs(m[4:7] - t).max() < 2e-2
+    assert cnt >= 0.9 * (~out).sum() and (mask.astype(bool) & out).sum() <= 3
+    # plane
+    nrm = np.array([0.2, -0.3, 0.93]); nrm /= np.linalg.norm(nrm)
+    P = rng.uniform(-5, 5, (n, 3))
+    P -= np.outer(P @ nrm + 1.5, nrm)  # on the plane n . x + 1.5 = 0
+    P += np.outer(rng.normal(size=n) * 0.002, nrm)
+    off = rng.random(n) < 0.3
+    P[off] += np.outer(rng.uniform(0.2, 2, int(off.sum())) * rng.choice([-1, 1], int(off.sum())), nrm)
+    m, mask, cnt = oracle.ransac(6, P, P, 0.01)
+    sgn = np.sign(m[:3] @ nrm)
+    assert np.abs(sgn * m[:3] - nrm).max() < 2e-3 and abs(sgn * m[3] - 1.5) < 5e-3
+    assert cnt >= 0.95 * (~off).sum() and (mask.astype(bool) & off).sum() == 0
+    # PnP (non-planar object points)
+    X = np.c_[rng.uniform(-3, 3, (n, 2)), rng.uniform(-1, 1, n)]
+    Rc, tc = _rot([0.3, -1, 0.2], 0.4), np.array([0.2, -0.1, 6.0])
+    Xc = X @ Rc.T + tc
+    uv = Xc[:, :2] / Xc[:, 2:3] + rng.normal(size=(n, 2)) * 0.0003
+    bad = rng.random(n) < 0.3
+    uv[bad] += rng.uniform(0.03, 0.2, (int(bad.sum()), 2))
+    m, mask, cnt = oracle.ransac(7, X, uv, 0.003)
+    Rm = m[:9].reshape(3, 3)
+    assert np.abs(Rm @ Rm.T - np.eye(3)).max() < 1e-12 and np.linalg.det(Rm) > 0.999
+    assert np.abs(Rm - Rc).max() < 2e-2 and np.abs(m[9:12] - tc).max() < 0.1
+    assert cnt >= 0.8 * (~bad).sum() and (mask.astype(bool) & bad).sum() <= 3
+
+
+def test_triangulation_midpoint(oracle):
+    rng = np.random.default_rng(3)
+    R, t = _rot([0.1, 1, 0.2], 0.2), np.array([-0.8, 0.02, 0.05])
+    from gslam_amd.ba_synth import _quat_from_R
+    pose = np.r_[_quat_from_R(R[None])[0], t]
+    for _ in range(50):
+        X = np.r_[rng.uniform(-2, 2, 2), rng.uniform(3, 10)]
+        X2 = R @ X + t
+        got, ok = oracle.triangulate(pose, X / X[2], X2 / X2[2])
+        assert ok and np.abs(got - X).max() < 1e-9
+    _, ok = oracle.triangulate(pose, np.array([0, 0, 1.0]), R @ np.array([0, 0, 1.0]))  # parallel rays
+    assert not ok
+    _, ok = oracle.triangulate(pose, np.array([-0.5, 0, 1.0]), np.array([0.9, 0, 1.0]))  # diverging: behind a camera
+    assert not ok
