@@ -313,7 +313,8 @@ def test_estimator_plugin_remaining_solvers(tmp_path, oracle, model):
     if model == 5:
         assert m.tobytes() == em[:8].tobytes()
     elif model == 6:
-        assert m[:3].tobytes() == em[:3].tobytes() and np.abs(m[3:6] + em[3] * em[:3]).max() < 1e-12
+        # the normal comes back through SE3's quaternion (z axis of the plane pose): rounding of that round trip only
+        assert np.abs(m[:3] - em[:3]).max() < 1e-12 and np.abs(m[3:6] + em[3] * em[:3]).max() < 1e-12
     else:  # world -> camera pose after the refinement on the inliers
         R = em[:9].reshape(3, 3)
         from gslam_amd.ba_synth import _quat_from_R
