@@ -77,18 +77,11 @@ constexpr int kResizeCols = 8;  // output columns per thread
 
 struct __attribute__((packed, aligned(4))) ResizeWin { uint32_t a, b, c, d; };  // 16 bytes at 4-byte alignment
 
-__global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __restrict__ dst_base,
-                                                     size_t dst_frame_stride, int dst_pitch, int wd, int hd,
-                                                     const uint32_t* __restrict__ xtab,
-                                                     const uint32_t* __restrict__ ytab, int groups_per_row,
-                                                     uint32_t groups_inv, int n_items, int tail_unsafe_frame) {
-  const int item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= n_items) return;
-  const int rg = (int)__umulhi((uint32_t)item, groups_inv);  // item / groups_per_row (exact: checked on the host)
-  const int x8 = (item - rg * groups_per_row) * kResizeCols;
-  const int y0 = rg * kResizeRows;
-  const uint8_t* s = src.base + (size_t)blockIdx.y * src.frame_stride;
-  uint8_t* d = dst_base + (size_t)blockIdx.y * dst_frame_stride;
+// One work item: output columns x8 .. x8 + 7, output rows y0 .. y_end - 1 (at most kResizeRows of them) of one frame.
+// s / d: the frame's source level and destination level.  ytab may be read at any (unaligned) y0.
+__device__ __forceinline__ void resize_item(const LevelView& src, const uint8_t* __restrict__ s, uint8_t* __restrict__ d,
+                                            int dst_pitch, const uint32_t* __restrict__ xtab,
+                                            const uint32_t* __restrict__ ytab, int x8, int y0, int y_end, bool guard_frame) {
   // x table: padded to a multiple of 8 entries (pads continue with sx + 1), 32-byte aligned per group
   const uint4 txa = *reinterpret_cast<const uint4*>(xtab + x8), txb = *reinterpret_cast<const uint4*>(xtab + x8 + 4);
   const uint32_t txs[8] = {txa.x, txa.y, txa.z, txa.w, txb.x, txb.y, txb.z, txb.w};
@@ -110,17 +103,15 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
     const uint32_t fx = txs[i] & 0xFFFFu;
     wx[i] = __builtin_bit_cast(u16x2, (fx << 16) | (2048u - fx));
   }
-  const uint4 ty4 = *reinterpret_cast<const uint4*>(ytab + y0);  // y table padded to a multiple of 4 entries
-  const uint32_t tys[4] = {ty4.x, ty4.y, ty4.z, ty4.w};
   // the 16-byte window may run up to 15 bytes past the end of a source row: harmless inside the buffer (next row,
   // next frame, or the slab's tail pad), but the caller's level-0 buffer has no pad after its last row
-  const bool guard = (int)blockIdx.y == tail_unsafe_frame && 4 * d0 + 16 > src.pitch;
+  const bool guard = guard_frame && 4 * d0 + 16 > src.pitch;
   const int last_dw = (src.pitch >> 2) - 1;
 #pragma unroll
   for (int rr = 0; rr < kResizeRows; ++rr) {
     const int y = y0 + rr;
-    if (y >= hd) break;
-    const uint32_t ty = tys[rr];
+    if (y >= y_end) break;
+    const uint32_t ty = ytab[y];
     const int sy = ty >> 16;
     const uint32_t fy = ty & 0xFFFFu;
     const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
@@ -160,6 +151,33 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
   }
 }
 
+__global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __restrict__ dst_base,
+                                                     size_t dst_frame_stride, int dst_pitch, int wd, int hd,
+                                                     const uint32_t* __restrict__ xtab,
+                                                     const uint32_t* __restrict__ ytab, int groups_per_row,
+                                                     uint32_t groups_inv, int n_items, int tail_unsafe_frame) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= n_items) return;
+  const int rg = (int)__umulhi((uint32_t)item, groups_inv);  // item / groups_per_row (exact: checked on the host)
+  const int x8 = (item - rg * groups_per_row) * kResizeCols;
+  const int y0 = rg * kResizeRows;
+  resize_item(src, src.base + (size_t)blockIdx.y * src.frame_stride, dst_base + (size_t)blockIdx.y * dst_frame_stride, dst_pitch,
+              xtab, ytab, x8, y0, min(hd, y0 + kResizeRows), (int)blockIdx.y == tail_unsafe_frame);
+}
+
+// The next pyramid level produced from inside fast_cells (see there): which output 8-column groups / output rows of
+// level l + 1 the workgroups of tile column bx / tile row by own.
+struct NextLevel {
+  uint8_t* dst_base;       // level l + 1, frame 0; nullptr = nothing to produce
+  size_t dst_frame_stride;
+  int dst_pitch, hd;
+  const uint32_t* xtab;    // of level l + 1
+  const uint32_t* ytab;
+  const int32_t* gx0;      // [nbx + 1] first owned output group per tile column
+  const int32_t* gy0;      // [nby + 1] first owned output row per tile row
+  int tail_unsafe_frame;
+};
+
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 corner score (oracle step 2): max over 9-arcs of min(ring - p) / min(p - ring).
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -197,7 +215,7 @@ constexpr int kScoreW = 72;   // row pitch (bytes)
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                         int cell_off, int n_frames) {
+                                                         int cell_off, int n_frames, NextLevel nx) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
@@ -353,6 +371,25 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     if (s > min_th) score[pos] = (uint8_t)s;
   }
   __syncthreads();
+
+  // (placed after the last block-wide barrier: a wave that is done here goes straight on to its cell, nobody waits)
+  // The next pyramid level, fused: this workgroup resizes the part of level l + 1 whose source pixels it has just
+  // pulled through its L1 / the XCD's L2 for the tile (edge tiles also take the image border).  The pipeline is VALU-issue
+  // bound and a stand-alone resize pass is memory-instruction bound, so the bilinear arithmetic rides in this kernel's idle
+  // memory slots and the level is read from HBM once instead of twice.  Same arithmetic as resize_kernel (resize_item).
+  if (nx.dst_base != nullptr) {
+    const int g0 = nx.gx0[bx], ng = nx.gx0[bx + 1] - g0;
+    const int r0 = nx.gy0[by], r1 = nx.gy0[by + 1];
+    const int nq = (r1 - r0 + kResizeRows - 1) / kResizeRows;
+    const uint8_t* s = lv.base + (size_t)frame * lv.frame_stride;
+    uint8_t* d = nx.dst_base + (size_t)frame * nx.dst_frame_stride;
+    for (int item = tid; item < ng * nq; item += 256) {
+      const int q = item / ng, g = item - q * ng;
+      const int yy = r0 + kResizeRows * q;
+      resize_item(lv, s, d, nx.dst_pitch, nx.xtab, nx.ytab, 8 * (g0 + g), yy, min(r1, yy + kResizeRows),
+                  frame == nx.tail_unsafe_frame);
+    }
+  }
 
   // one wave per 32x32 cell
   const int wv = tid >> 6, lane = tid & 63;
@@ -854,6 +891,9 @@ struct gh_orb_plan {
   uint32_t* cell_ent = nullptr;
   SelKp* sel = nullptr;
   int32_t* level_cnt = nullptr;
+  const int32_t* own_gx[kMaxL] = {nullptr};  // fused pyramid: first owned output group / row per tile column / row of level l
+  const int32_t* own_gy[kMaxL] = {nullptr};
+  bool fuse_pyramid = true;  // GSLAM_HIP_ORB_FUSE_PYRAMID=0 keeps the stand-alone resize launches (A/B measurements)
   int8_t* d_pattern = nullptr;
   int32_t* d_dir = nullptr;
   uint32_t* tabs = nullptr;
@@ -959,6 +999,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   p->h = height;
   p->max_batch = max_batch;
   p->prm = prm;
+  if (const char* e = getenv("GSLAM_HIP_ORB_FUSE_PYRAMID")) p->fuse_pyramid = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
   long long den = ipow(6, L) - ipow(5, L);
@@ -1005,6 +1046,9 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   // every table starts 32-byte aligned; x tables are padded to a multiple of 8 entries (pads continue with the next
   // source column, fraction 0, so that the per-thread window bounds hold), y tables to a multiple of 4 (last replicated)
   for (int l = 1; l < L; ++l) tab_words += (((size_t)p->lw[l] + 7) & ~(size_t)7) + (((size_t)p->lh[l] + 7) & ~(size_t)7);
+  // + per source level l < L - 1: ownership of level l + 1 by the tile columns / rows of fast_cells(l), padded to 8 words
+  for (int l = 0; l + 1 < L; ++l)
+    tab_words += (((size_t)(p->ncx[l] + 1) / 2 + 1 + 7) & ~(size_t)7) + (((size_t)(p->ncy[l] + 1) / 2 + 1 + 7) & ~(size_t)7);
   std::vector<uint32_t> htab(tab_words ? tab_words : 1);
   do {
     if ((st = plan_alloc(p, B * p->slab, (void**)&p->pyr)) != GH_OK) break;
@@ -1050,6 +1094,35 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
     if (st != GH_OK) {
       gh_set_error(ctx, st, "resize table violates the 8-column window contract (level size ratio is not ~1.2)");
       break;
+    }
+    // ownership of level l + 1 inside fast_cells(l): tile column bx (level-l columns 64 bx .. 64 bx + 63 plus halo) owns
+    // the output 8-groups whose first source column lies in [64 bx, 64 bx + 64); tile row by (rows from 64 by + 15) the
+    // output rows whose source row lies in [64 by + 15, 64 by + 79); the first / last tile row and the last tile column
+    // also take what lies outside every tile.  Any partition is CORRECT (resize_item reads global memory); this one
+    // makes the reads hit the lines the tile load has just fetched.
+    for (int l = 0; l + 1 < L; ++l) {
+      const int nbx = (p->ncx[l] + 1) / 2, nby = (p->ncy[l] + 1) / 2;
+      const uint32_t* xt = htab.data() + (p->xtab[l + 1] - p->tabs);
+      const uint32_t* yt = htab.data() + (p->ytab[l + 1] - p->tabs);
+      const int ngroups = (p->lw[l + 1] + 7) / 8, hd = p->lh[l + 1];
+      p->own_gx[l] = reinterpret_cast<const int32_t*>(p->tabs + tw);
+      int g = 0;
+      for (int bx = 0; bx <= nbx; ++bx) {
+        if (bx == nbx) g = ngroups;
+        else
+          while (bx > 0 && g < ngroups && (int)(xt[8 * g] >> 16) < 64 * bx) ++g;
+        htab[tw++] = (uint32_t)g;
+      }
+      while (tw & 7) htab[tw++] = (uint32_t)ngroups;
+      p->own_gy[l] = reinterpret_cast<const int32_t*>(p->tabs + tw);
+      int y = 0;
+      for (int by = 0; by <= nby; ++by) {
+        if (by == nby) y = hd;
+        else
+          while (by > 0 && y < hd && (int)(yt[y] >> 16) < 64 * by + 15) ++y;
+        htab[tw++] = (uint32_t)y;
+      }
+      while (tw & 7) htab[tw++] = (uint32_t)hd;
     }
     if ((st = gh_dev_upload(ctx, p->tabs, htab.data(), htab.size() * sizeof(uint32_t))) != GH_OK) break;
     if ((st = upload_pattern(p, &GH_ORB_PATTERN[0][0][0])) != GH_OK) break;
@@ -1102,7 +1175,9 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   }
   for (int l = 1; l < L; ++l) lv[l] = {p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l]};
 
-  for (int l = 1; l < L; ++l) {
+  // Level l + 1 is produced inside fast_cells(l) (see the kernel); a level whose predecessor runs no FAST pass (no valid
+  // region or no quota) is produced by the stand-alone resize launch instead.
+  auto resize_standalone = [&](int l) -> gh_status {
     const int gpr = gh_div_up(p->lw[l], kResizeCols), nrg = gh_div_up(p->lh[l], kResizeRows);
     const int n_items = gpr * nrg;
     const uint32_t inv = (uint32_t)((0x100000000ull + (uint64_t)gpr - 1) / (uint64_t)gpr);  // exact for item < 2^32 / gpr
@@ -1112,15 +1187,25 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     GH_LAUNCH(ctx, "orb_resize", resize_kernel, dim3(gh_div_up(n_items, 256), batch), dim3(256), 0, lv[l - 1],
               p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l], gpr, inv,
               n_items, unsafe_frame);
-  }
+    return GH_OK;
+  };
   for (int l = 0; l < L; ++l) {
-    if (p->ncx[l] == 0 || p->quota[l] <= 0) continue;
+    const bool fast = p->ncx[l] != 0 && p->quota[l] > 0;
+    if (!fast) {
+      if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
+      continue;
+    }
+    NextLevel nx{nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, -1};
+    if (l + 1 < L && p->fuse_pyramid)
+      nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1], p->xtab[l + 1], p->ytab[l + 1],
+                     p->own_gx[l], p->own_gy[l], (l == 0 && aligned0) ? batch - 1 : -1};
     const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
     GH_CHECK_ARG(ctx, tiles < (1LL << 30));
     dim3 grid(8 * gh_div_up(tiles, 8));
     GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
               p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-              batch);
+              batch, nx);
+    if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
   }
   {
     SelectArgs a;
