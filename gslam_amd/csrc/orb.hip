@@ -28,6 +28,7 @@ constexpr int kCell = GH_ORB_CELL;         // 32
 constexpr int kCap = GH_ORB_CELL_CAP;      // 32
 constexpr int kMaxL = GH_ORB_MAX_LEVELS;   // 8
 constexpr int kHistBins = kCap * 256;      // (rank, 255 - score)
+constexpr int kCellRec = 8;                // dwords per compact cell record: count + the first 7 entries
 
 struct LevelView {
   const uint8_t* base;   // frame 0
@@ -432,7 +433,14 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     }
   }
   const size_t cell = (size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
-  uint32_t* out = cell_ent + cell * kCap;
+  // cell record: {count, entries 0..6} in one 32-byte line of cell_cnt (a cell holds ~5 entries: orb_select reads ONE
+  // 32-byte record per cell instead of a count plus a 128-byte slot); entries 7.. go to the cell's slot in cell_ent
+  uint32_t* rec = cell_cnt + cell * kCellRec;
+  uint32_t* ovf = cell_ent + cell * kCap;
+  auto put_entry = [&](int idx, uint32_t v) {
+    if (idx < kCellRec - 1) rec[1 + idx] = v;
+    else ovf[idx] = v;
+  };
   int kept = 0;
   if (nz <= 64) {
     // Common case (a cell holds ~25 scored pixels): one candidate per lane, everything stays in registers.  NMS
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     }
     const bool keep = ((cand >> lane) & 1ull) != 0ull && rank < kCap;
     const uint64_t m = __ballot(keep);
-    if (keep) out[__popcll(m & lt_mask)] = ((uint32_t)rank << 18) | e;
+    if (keep) put_entry(__popcll(m & lt_mask), ((uint32_t)rank << 18) | e);
     kept = __popcll(m);
   } else {
     int n = 0;
@@ -508,11 +516,11 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
       }
       const bool keep = i < n && rank < kCap;
       const uint64_t m = __ballot(keep);
-      if (keep) out[kept + __popcll(m & lt_mask)] = ((uint32_t)rank << 18) | e;
+      if (keep) put_entry(kept + __popcll(m & lt_mask), ((uint32_t)rank << 18) | e);
       kept += __popcll(m);
     }
   }
-  if (lane == 0) cell_cnt[cell] = (uint32_t)kept;
+  if (lane == 0) rec[0] = (uint32_t)kept;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,17 +542,19 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /* shared[5]
   return off + incl - v;
 }
 
-// Visit the n (<= kCap) entries of one cell: the first 8 come from two 16-byte loads issued together (a cell holds
-// ~5 entries, so the per-entry dword loop cost one memory round trip PER ENTRY), the rest from memory.
+// Visit the entries of one cell.  rec = the cell's 32-byte record {count, entries 0..6} (two 16-byte loads issued
+// together: one memory round trip for the common case), ovf = its 128-byte slot holding entries 7.. at their index.
 template <typename F>
-__device__ __forceinline__ void for_each_entry(const uint32_t* __restrict__ cell_entries, int n, F f) {
-  const uint4 a = reinterpret_cast<const uint4*>(cell_entries)[0];
-  const uint4 b = reinterpret_cast<const uint4*>(cell_entries)[1];
-  const uint32_t first[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+__device__ __forceinline__ int for_each_entry(const uint32_t* __restrict__ rec, const uint32_t* __restrict__ ovf, F f) {
+  const uint4 a = reinterpret_cast<const uint4*>(rec)[0];
+  const uint4 b = reinterpret_cast<const uint4*>(rec)[1];
+  const int n = (int)a.x;
+  const uint32_t first[kCellRec - 1] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
+  for (int e = 0; e < kCellRec - 1; ++e)
     if (e < n) f(first[e]);
-  for (int e = 8; e < n; ++e) f(cell_entries[e]);
+  for (int e = kCellRec - 1; e < n; ++e) f(ovf[e]);
+  return n;
 }
 
 struct SelectArgs {
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
   __shared__ int s_cut, s_m;
   const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int ncells = a.ncells[l], quota = a.quota[l];
-  const uint32_t* cnt = cell_cnt + (size_t)b * cells_per_frame + a.cell_off[l];
+  const uint32_t* rec = cell_cnt + ((size_t)b * cells_per_frame + a.cell_off[l]) * kCellRec;
   const uint32_t* ent = cell_ent + ((size_t)b * cells_per_frame + a.cell_off[l]) * kCap;
   if (quota <= 0 || ncells <= 0) {
     if (tid == 0) level_cnt[b * kMaxL + l] = 0;
@@ -568,8 +578,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
   for (int i = tid; i < kHistBins; i += 256) hist[i] = 0;
   __syncthreads();
   for (int c = tid; c < ncells; c += 256) {
-    const int n = (int)cnt[c];
-    for_each_entry(ent + (size_t)c * kCap, n, [&](uint32_t v) {
+    for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, [&](uint32_t v) {
       const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
       atomicAdd(&hist[ck], 1u);
     });
@@ -606,10 +615,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
   const int ncx = a.ncx[l];
   for (int cb = 0; cb < ncells; cb += 256) {
     const int c = cb + tid;
-    int n = 0, n_lt = 0, n_eq = 0;
+    int n_lt = 0, n_eq = 0;
     if (c < ncells) {
-      n = (int)cnt[c];
-      for_each_entry(ent + (size_t)c * kCap, n, [&](uint32_t v) {
+      for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, [&](uint32_t v) {
         const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
         n_lt += ck < cut;
         n_eq += ck == cut;
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     if (mysel > 0) {
       const int cx = c % ncx, cy = c / ncx;
       int k = 0, ties = 0;
-      for_each_entry(ent + (size_t)c * kCap, n, [&](uint32_t v) {
+      for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, [&](uint32_t v) {
         const int s = (int)((v >> 10) & 255);
         const int ck = (int)(v >> 18) * 256 + (255 - s);
         bool take = ck < cut;
@@ -1052,7 +1060,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   std::vector<uint32_t> htab(tab_words ? tab_words : 1);
   do {
     if ((st = plan_alloc(p, B * p->slab, (void**)&p->pyr)) != GH_OK) break;
-    if ((st = plan_alloc(p, B * p->cells_per_frame * sizeof(uint32_t), (void**)&p->cell_cnt)) != GH_OK) break;
+    if ((st = plan_alloc(p, B * p->cells_per_frame * kCellRec * sizeof(uint32_t), (void**)&p->cell_cnt)) != GH_OK) break;
     if ((st = plan_alloc(p, B * p->cells_per_frame * kCap * sizeof(uint32_t), (void**)&p->cell_ent)) != GH_OK) break;
     if ((st = plan_alloc(p, B * K * sizeof(SelKp), (void**)&p->sel)) != GH_OK) break;
     if ((st = plan_alloc(p, B * kMaxL * sizeof(int32_t), (void**)&p->level_cnt)) != GH_OK) break;
