@@ -303,6 +303,9 @@ def main():
     # ---- roofline of the dominant kernel (largest share of HIP-event time in the timed region)
     sb = stage_bytes(W, H, K)
     orb_k = {k: v for k, v in prof.items() if k.startswith("orb_")}
+    fused_pyramid = "orb_resize" not in orb_k
+    if fused_pyramid:  # level l + 1 is produced inside fast_cells(l): that kernel now carries both stages' bytes
+        sb["orb_fast_cells"] += sb["orb_resize"]
     dom = max(orb_k, key=lambda k: orb_k[k]["total_ms"])
     launches = prof[dom]["launches"]
     avg_ms = prof[dom]["total_ms"] / launches
@@ -320,6 +323,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                "stages": "FAST/NMS read of all levels (3.096 W H) + pyramid reads and writes (5.114 W H): the next level is "
+                          "resized inside this kernel" if fused_pyramid else "FAST/NMS read of all levels (3.096 W H)",
                 "note": "HBM is the contractual bound (SURVEY.md 8d); SQ counters show this kernel VALU-issue bound "
                         "(profiles/README.md), so frac understates how close the kernel is to ITS limit"}
     # VALU-issue view of the same kernel.  The ceiling is MEASURED in this run (gh_valu_issue_probe: register-only chains of
