@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 legs (10k cams / 1M points LM, n = 60000 dense solve)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-all-pairs-full", action="store_true", help="skip the 499 500-frame-pair all-pairs matching leg")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: exchange through torch.distributed instead of the C-ABI communicator (gh_comm_*)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="bounded CPU sample (frames; 1000 = the whole C2 step, ~10 s on 16 cores)")
@@ -389,6 +390,29 @@ def main():
                            "Gpairs_per_s": round(npairs_all / (ms_all * 1e-3) / 1e9, 1),
                            "frac": round(npairs_all / (ms_all * 1e-3) / valu_ceiling, 4)}
         del o_idx, o_d1, o_d2
+        # ... and the TRUE all-pairs configuration of BASELINE configs[1]: every frame pair (i < j) of the step's F frames
+        # (F = 1000: 499 500 frame pairs, 2.0e12 descriptor pairs; 8 GB of match records -- sized for the 288 GB of HBM)
+        if world == 1 and not a.no_all_pairs_full and F >= 256:
+            ai, aj = all_pairs_block(0, 1, F, dev)
+            o_idx = torch.empty((ai.shape[0], K), dtype=torch.int32, device=dev)
+            o_d1 = torch.empty((ai.shape[0], K), dtype=torch.int16, device=dev)
+            o_d2 = torch.empty_like(o_d1)
+            torch.cuda.synchronize()
+            ctx.prof_enable(True)
+            matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))
+            ap = ctx.prof_collect()
+            ctx.prof_enable(False)
+            c64 = counts.to(torch.int64)
+            npairs_full = int((c64.sum() ** 2 - (c64 * c64).sum()).item() // 2)
+            ms_full = ap["bf_match_pairs"]["total_ms"]
+            # size-independent check: a frame matched against itself is not in the list, so no query may be unmatched
+            assert bool((o_idx[:, 0] >= 0).all()), "all-pairs: unmatched query in a non-empty pair"
+            bf["all_pairs_full"] = {"frames": F, "frame_pairs": int(ai.shape[0]), "pairs": npairs_full,
+                                    "Gpairs_per_s": round(npairs_full / (ms_full * 1e-3) / 1e9, 1), "seconds": round(ms_full * 1e-3, 3),
+                                    "frac": round(npairs_full / (ms_full * 1e-3) / valu_ceiling, 4),
+                                    "match_record_GB": round(ai.shape[0] * K * 8 / 1e9, 2)}
+            del o_idx, o_d1, o_d2, ai, aj
+            torch.cuda.empty_cache()
     except Exception as exc:
         bf["all_pairs"] = {"error": repr(exc)}
 
@@ -400,7 +424,7 @@ def main():
     if world > 1:
         # the CPU baseline is reported at N = 1 only (contract), and the single-GPU side legs (BA, BoW) add nothing
         # to a scaling line: the other ranks have already left
-        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = a.no_c5 = a.no_host_fed = True
+        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = a.no_c5 = a.no_host_fed = a.no_all_pairs_full = True
 
     # ---- C3 (KITTI-like stereo 1241x376 x 2): extract both eyes, row-band left-right match, temporal match
     def _leg_c3():
