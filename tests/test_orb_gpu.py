@@ -225,3 +225,37 @@ def test_runtime_pattern_injection(ctx, oracle):
     with pytest.raises(hip.GslamHipError):
         ex.set_pattern(bad)
     ex.close()
+
+
+def test_roi_view_whose_allocation_ends_at_the_last_pixel(ctx, oracle):
+    """a single frame with row_stride > width whose buffer ends at (h-1) * stride + w (an ROI view of a larger
+    image) must not be read past its end.  Device path: frame_stride = 0 with batch = 1 stages the frame row by row; host
+    path: gh_orb_extract_host copies exactly (h-1) * stride + w bytes.  Results equal the oracle on the dense image."""
+    import ctypes as C
+    import torch
+    from gslam_amd import hip
+    from gslam_amd.orb import KP_DTYPE, OrbExtractor, kps_to_numpy
+    w, h, stride, K = 400, 300, 448, 500
+    img = oracle.synth_frame(w, h, 0x5EED0200)
+    ek, ed = oracle.orb_extract(img, K)
+    n_bytes = (h - 1) * stride + w
+    flat = np.zeros(n_bytes, np.uint8)
+    for y in range(h):
+        flat[y * stride:y * stride + w] = img[y]
+    ex = OrbExtractor(ctx, w, h, max_batch=1, n_features=K)
+    # device: the allocation is exactly n_bytes long (16-byte aligned pointer and stride, so the zero-copy path would apply)
+    dbuf = torch.from_numpy(flat).cuda()
+    kps, desc, counts = ex.alloc_outputs(1)
+    ctx.check(hip.lib.gh_orb_extract_dev(ex.plan, C.c_void_p(dbuf.data_ptr()), 1, C.c_size_t(0), stride,
+                                         C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), C.c_void_p(counts.data_ptr())))
+    torch.cuda.synchronize()
+    n = int(counts[0])
+    assert n == len(ek) and kps_to_numpy(kps)[0, :n].tobytes() == ek.tobytes() and np.array_equal(desc[0, :n].cpu().numpy(), ed)
+    # host: a buffer that really ends at the last pixel (guard page semantics are the OS's; here: exact-size numpy array)
+    hk = np.zeros(K, KP_DTYPE)
+    hd = np.zeros((K, 32), np.uint8)
+    hn = C.c_int32()
+    ctx.check(hip.lib.gh_orb_extract_host(ex.plan, flat.ctypes.data_as(C.c_void_p), stride, hk.ctypes.data_as(C.c_void_p),
+                                          hd.ctypes.data_as(C.c_void_p), C.byref(hn)))
+    assert hn.value == len(ek) and hk[:hn.value].tobytes() == ek.tobytes() and np.array_equal(hd[:hn.value], ed)
+    ex.close()
