@@ -77,9 +77,9 @@ $(LIBDIR)/libgslamDB_synthplane.so: gslam_amd/plugin/dataset_synthplane.cpp incl
 
 # The reference's OWN launcher and two of its application plugins, compiled from the sources where they lie (no copy,
 # the reference's flags): `gslam` (GSLAM/gslam/main.cpp), `play` (plugins/play/main.cpp), `metric_time`
-# (evaluation/metric_time/main.cpp).  Test infrastructure: tests/test_launcher_gpu.py drives the orbhip application and
+# (evaluation/metric_time/main.cpp), `metric_traj` (evaluation/metric_trajectory/main.cpp).  Test infrastructure: tests/test_launcher_gpu.py drives the orbhip application and
 # the synthplane dataset through them.  build/ is git-ignored and travels to the GPU box.
-refapps: build/ref/gslam build/ref/libgslam_play.so build/ref/libgslam_metric_time.so
+refapps: build/ref/gslam build/ref/libgslam_play.so build/ref/libgslam_metric_time.so build/ref/libgslam_metric_traj.so
 build/ref/gslam: $(REF)/GSLAM/gslam/main.cpp
 	@mkdir -p build/ref
 	g++ -O3 -DNDEBUG -std=c++11 -w -I$(REF) -I$(REF)/GSLAM/core -o $@ $< -lpthread -ldl
@@ -87,6 +87,9 @@ build/ref/libgslam_play.so: $(REF)/GSLAM/plugins/play/main.cpp
 	@mkdir -p build/ref
 	g++ -O3 -DNDEBUG -std=c++11 -w -fPIC -shared -I$(REF) -o $@ $< -lpthread -ldl
 build/ref/libgslam_metric_time.so: $(REF)/GSLAM/evaluation/metric_time/main.cpp
+	@mkdir -p build/ref
+	g++ -O3 -DNDEBUG -std=c++11 -w -fPIC -shared -I$(REF) -o $@ $< -lpthread -ldl
+build/ref/libgslam_metric_traj.so: $(REF)/GSLAM/evaluation/metric_trajectory/main.cpp
 	@mkdir -p build/ref
 	g++ -O3 -DNDEBUG -std=c++11 -w -fPIC -shared -I$(REF) -o $@ $< -lpthread -ldl
 

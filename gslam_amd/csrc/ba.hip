@@ -25,7 +25,7 @@
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
                             double* xwork);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
-                                const double* dinv);
+                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev);
 
 namespace {
 
@@ -495,14 +495,10 @@ __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const 
   }
 }
 
-// rhs -> row n of S (rides through the factorisation, becomes y = L^-1 rhs), and back out into a vector
+// rhs -> row n of S (rides through the factorisation, becomes y = L^-1 rhs; the back-substitution reads it there)
 __global__ void rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ S, int lda, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) S[(size_t)j * lda + n] = rhs[j];
-}
-__global__ void row_to_vec_kernel(const double* __restrict__ S, int lda, int n, double* __restrict__ y) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) y[j] = S[(size_t)j * lda + n];
 }
 
 __global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const double* __restrict__ Hpi,
@@ -895,7 +891,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_TRY(db.upload(&d_bcj, (const int32_t*)bcj.data(), bcj.size()));
     SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_sb, d_sf, nblocks, nsegs};
   }
-  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart, *d_xwork;
+  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart, *d_xwork, *d_xh;
   unsigned long long* d_gmax;
   int *d_bad, *d_info;
   const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
@@ -911,6 +907,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_dinv, (size_t)gh_div_up(n, 64) * 4096));
   GH_TRY(db.alloc(&d_W, (size_t)no * 18));
   GH_TRY(db.alloc(&d_xwork, (size_t)2 * 64 * (n + 1)));
+  GH_TRY(db.alloc(&d_xh, (size_t)gh_div_up(n, 64) * 64));
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
   GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
@@ -1000,10 +997,10 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     // synchronisation per iteration instead of three.
     GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork));
+    // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
+    GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info));
     GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    GH_LAUNCH(ctx, "ba_rhs_row", row_to_vec_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_S, lda, n, d_work);
-    GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv));
     if (np > 0)
       GH_LAUNCH(ctx, "ba_backsub", backsub_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpi, d_gp, d_dc,
                 d_dp, (const double*)d_W);

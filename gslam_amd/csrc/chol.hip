@@ -879,6 +879,108 @@ __global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __rest
   }
 }
 
+__global__ void gather_strided_kernel(const double* __restrict__ src, long long stride, int n, double* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(size_t)i * stride];
+}
+
+// ---------------------------------------------------------------- backward substitution as ONE launch (n <= kBwdChainMaxN)
+// The per-step launches above are bound by the launch chain (24 launches of ~13 us at n = 3000 for a few hundred cycles of
+// arithmetic each).  Here every 64-column block c has its own workgroup, all resident at once:
+//   workgroup c   keeps r_c = sum_{j > c} L[j-block, c-block]^T x_j as per-thread partial sums, consuming x_j in the order
+//                 j = nb-1 ... c+1 as the owners publish them (its tiles of L are prefetched one step ahead: they do not
+//                 depend on x), then x_c = M_c^T (y_c - r_c) and publishes x_c.
+// Hand-off = the data itself (MI355X_MICROARCH.md "handoff-1to1", cdna_hip_programming.md Guideline 16 form R2): `xh` is
+// filled with a NaN sentinel before the launch, each x value is ONE naturally aligned 8-byte agent-scope (sc1) store, the
+// consumer re-reads its 16 values with agent-scope relaxed loads until none is the sentinel.  No flag, no fence.
+// Workgroup c only waits for workgroups with a LOWER blockIdx (block 0 owns the last column block); every spin is bounded:
+// on expiry the workgroup raises `info`, publishes NaN so that nobody behind it waits, and the launch ends.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr unsigned long long kXSentinel = 0xFFF8BEEFFFF8BEEFull;  // a NaN no computation produces; two equal 32-bit halves
+constexpr int kBwdChainMaxN = 8192;                                // 128 workgroups; workgroup 0 streams <= 4 MB of L
+constexpr unsigned kBwdSpinLimit = 1u << 21;
+
+__global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict__ A, int lda, int n, int nb,
+                                                       const double* __restrict__ yv, long long ystride,
+                                                       const double* __restrict__ dinv, double* xh,
+                                                       double* __restrict__ x_out, int* __restrict__ info) {
+  __shared__ double part[2][4][NBI];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = nb - 1 - (int)blockIdx.x, c0 = c * NBI;
+  const int kb = n - c0 < NBI ? n - c0 : NBI;
+  // M_c[16 wv + jj][lane]: 128 contiguous bytes of column `lane` of M (as in bwd_step_inv_kernel)
+  double mreg[16];
+  {
+    const double2* src = reinterpret_cast<const double2*>(dinv + (size_t)c * (NBI * NBI) + lane * NBI + 16 * wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 v2 = src[e];
+      mreg[2 * e] = v2.x;
+      mreg[2 * e + 1] = v2.y;
+    }
+  }
+  const double yc = lane < kb ? yv[(size_t)(c0 + lane) * ystride] : 0.0;
+  // tile (j, c), this thread: column c0 + lane, rows j0 + 16 wv .. + 15 (128 contiguous bytes); rows >= n read as zero
+  const double* colp = A + (size_t)(c0 + (lane < kb ? lane : 0)) * lda;
+  auto fetch = [&](int j, double (&t)[16]) {
+    const int r0 = j * NBI + 16 * wv;
+    if (lane < kb && r0 + 16 <= n) {
+      const double2* src = reinterpret_cast<const double2*>(colp + r0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const double2 v2 = src[e];
+        t[2 * e] = v2.x;
+        t[2 * e + 1] = v2.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t[e] = (lane < kb && r0 + e < n) ? colp[r0 + e] : 0.0;
+    }
+  };
+  double acc = 0.0;
+  double cur[16], nxt[16];
+  bool expired = false;
+  if (c + 1 < nb) fetch(nb - 1, cur);
+  for (int j = nb - 1; j > c; --j) {
+    if (j - 1 > c) fetch(j - 1, nxt);
+    // x_j[16 wv + (lane & 15)], polled until it is there
+    const gu64* src = (const gu64*)(xh + (size_t)j * NBI + 16 * wv + (lane & 15));
+    unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 0; !__all(bits != kXSentinel);) {
+      if (++spins > kBwdSpinLimit) {
+        expired = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double xv = __longlong_as_double((long long)bits);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_fma(cur[t], readlane_f64(xv, t), acc);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
+  }
+  part[0][wv][lane] = acc;
+  __syncthreads();
+  const double r = yc - ((part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]));
+  // x_c[i] = sum_j M[j][i] r[j]; this wave covers j in [16 wv, 16 wv + 16)
+  double s = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) s = __builtin_fma(mreg[jj], readlane_f64(r, 16 * wv + jj), s);
+  part[1][wv][lane] = s;
+  __syncthreads();
+  if (wv == 0) {
+    double xr = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+    if (lane >= kb) xr = 0.0;
+    if (expired) xr = __longlong_as_double(0x7FF8000000000000ll);
+    unsigned long long pub = (unsigned long long)__double_as_longlong(xr);
+    if (pub == kXSentinel) pub = 0x7FF8000000000000ull;
+    __hip_atomic_store((gu64*)(xh + (size_t)c0 + lane), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < kb) x_out[c0 + lane] = xr;
+    if (expired && lane == 0) atomicMax(info, n + 1 + c);
+  }
+}
+
 }  // namespace
 
 // Factor (lower, in place) and optionally solve.  info_dev: device int (0 = ok, else first bad block column + 1).
@@ -958,9 +1060,22 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   return GH_OK;
 }
 
-// backward substitution only: work (n doubles) holds y on entry, x is written to b
+// backward substitution only: y[i] = yv[i * ystride] on entry, x is written to b.  `work`: n doubles (the launch-per-step
+// path keeps its running right-hand side there); `xh`: ceil(n / 64) * 64 doubles for the single-launch path (n <=
+// kBwdChainMaxN, GSLAM_HIP_BWD_CHAIN != 0) or nullptr; `info_dev` receives n + 1 + block if a hand-off wait expired.
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
-                                const double* dinv) {
+                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev) {
+  const char* env = getenv("GSLAM_HIP_BWD_CHAIN");  // "0" keeps the launch-per-step path (A/B measurements, tests)
+  const bool chain_ok = !(env && env[0] == '0');
+  if (xh && info_dev && chain_ok && n <= kBwdChainMaxN) {
+    const int nb = gh_div_up(n, NBI);
+    GH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)xh, (int)0xFFF8BEEFu, (size_t)nb * NBI * 2, ctx->stream));
+    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_chain_kernel, dim3(nb), dim3(256), 0, L, lda, n, nb, yv, ystride, dinv, xh, b,
+              info_dev);
+    return GH_OK;
+  }
+  if (yv != work || ystride != 1)
+    GH_LAUNCH(ctx, "ba_rhs_row", gather_strided_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, yv, ystride, n, work);
   const int last = ((n - 1) / NBI) * NBI;
   int k = last;
   while (k >= 0) {
@@ -981,14 +1096,15 @@ gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, do
 }
 
 // work: n doubles of device scratch
-gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work, const double* dinv) {
+gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work, const double* dinv,
+                            double* xh, int* info_dev) {
   for (int k = 0; k < n; k += NBI) {
     const int kb = n - k < NBI ? n - k : NBI;
     const int rows = n - (k + kb);
     GH_LAUNCH(ctx, "ba_trsv_fwd", fwd_step_kernel, dim3(rows > 0 ? gh_div_up(rows, 256) : 1), dim3(256), 0, L, lda, n,
               k, kb, b, work);
   }
-  return gh_potrs_bwd_dev_impl(ctx, L, n, lda, b, work, dinv);
+  return gh_potrs_bwd_dev_impl(ctx, L, n, lda, b, work, dinv, work, 1, xh, info_dev);
 }
 
 extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info) {
@@ -997,14 +1113,19 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
   void* scratch = nullptr;
   const size_t nblk = (size_t)gh_div_up(n, NBI);
-  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI + 2 * (size_t)NBI * n) * sizeof(double), &scratch));
+  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI + 2 * (size_t)NBI * n + nblk * NBI) * sizeof(double), &scratch));
   int* info_dev = (int*)scratch;
   double* dinv = (double*)((char*)scratch + 256);
   double* work = dinv + nblk * NBI * NBI;
   double* xwork = work + n;
+  double* xh = xwork + 2 * (size_t)NBI * n;
   GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (*info == 0 && b_dev) GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv));
+  if (*info == 0 && b_dev) {
+    GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv, xh, info_dev));
+    GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return GH_OK;
 }

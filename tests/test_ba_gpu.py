@@ -117,6 +117,26 @@ def test_potrf_solve_vs_numpy(ctx, n):
     assert np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b) * np.linalg.cond(A)
 
 
+@pytest.mark.parametrize("n", [64, 65, 130, 1000, 3000, 3001, 4097, 8192])
+def test_backsubstitution_single_launch_matches_the_stepwise_path(ctx, n, monkeypatch):
+    """The single-launch back-substitution (one resident workgroup per 64-column block, x handed from block to block
+    through agent-scope stores) against the launch-per-step one on the same factor: same sums in a different order."""
+    from gslam_amd import ba
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, 64))
+    A = M @ M.T / 64.0 + 2.0 * np.eye(n)
+    b = rng.standard_normal(n)
+    monkeypatch.setenv("GSLAM_HIP_BWD_CHAIN", "1")
+    L1, x1, info1 = ba.potrf_solve(ctx, A, b)
+    x1b = ba.potrf_solve(ctx, A, b)[1]
+    monkeypatch.setenv("GSLAM_HIP_BWD_CHAIN", "0")
+    L0, x0, info0 = ba.potrf_solve(ctx, A, b)
+    assert info0 == 0 and info1 == 0 and L0.tobytes() == L1.tobytes()
+    assert x1.tobytes() == x1b.tobytes()  # fixed summation order: reproducible run to run
+    assert np.abs(x1 - x0).max() <= 1e-13 * np.abs(x0).max()
+    assert np.linalg.norm(A @ x1 - b) <= 1e-12 * np.linalg.norm(b)
+
+
 def test_potrf_reports_not_positive_definite(ctx):
     from gslam_amd import ba
     A = np.eye(100)

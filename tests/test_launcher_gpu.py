@@ -29,7 +29,8 @@ W, H, K = 640, 480, 1000
 
 def _need():
     for p in (os.path.join(REFDIR, "gslam"), os.path.join(REFDIR, "libgslam_play.so"),
-              os.path.join(REFDIR, "libgslam_metric_time.so"), os.path.join(LIBDIR, "libgslam_orbhip.so"),
+              os.path.join(REFDIR, "libgslam_metric_time.so"), os.path.join(REFDIR, "libgslam_metric_traj.so"),
+              os.path.join(LIBDIR, "libgslam_orbhip.so"),
               os.path.join(LIBDIR, "libgslamDB_synthplane.so")):
         if not os.path.exists(p):
             pytest.skip(f"{p} missing: run `make plugins` in the authoring container (needs /root/reference at build time)")
@@ -120,7 +121,7 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
     # Application order: the launcher starts each application's thread as soon as its plugin is loaded and keeps writing
     # svar["gslam"]["apps"] for the next one from the main thread (GSLAM/gslam/main.cpp:17-45) -- svar is not thread safe
     # (Svar.h:783), so `play`, which touches svar for its whole life, goes last.
-    cmd = [os.path.join(REFDIR, "gslam"), "orbhip", "metric_time", "play",
+    cmd = [os.path.join(REFDIR, "gslam"), "orbhip", "metric_time", "metric_traj", "play",
            "-dataset", str(seq), "-slam", "orbhip", "-playspeed", "1",
            "-orbhip.nFeatures", str(K), "-orbhip.log", str(tmp_path / "orbhip.bin"), "-orbhip.stop_on_finish", "1",
            "-orbhip.start_dataset", "1", "-orbhip.ba_every", "10", "-orbhip.ba_window", "8",
@@ -132,7 +133,7 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
     # The reference launcher races on its global svar while applications start (see above); a crash in that window is the
     # launcher's, not the plugins': retry the run (observed: `play` listed first crashes every time, this order never).
     for attempt in range(3):
-        for f in ("frames.bin", "orbhip.bin", "orbhip_metric_time.txt"):
+        for f in ("frames.bin", "orbhip.bin", "orbhip_metric_time.txt", "orbhip_traj_vo.txt", "orbhip_traj_final.txt"):
             if (tmp_path / f).exists():
                 (tmp_path / f).unlink()
         r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
@@ -148,6 +149,13 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
     # metric_time (the reference's evaluation plugin) saw every frame come back on "orbhip/curframe"
     mt = [ln.split() for ln in open(tmp_path / "orbhip_metric_time.txt").read().splitlines()]
     assert len(mt) == n_frames and all(0 < float(t) < 5.0 for _, t in mt)
+
+    # metric_traj (the reference's trajectory evaluation plugin) consumed "orbhip/curframe" and "orbhip/map": one pose per
+    # frame as published, and the map's frames (those that went through bundle adjustment last) sorted by id
+    vo = np.loadtxt(tmp_path / "orbhip_traj_vo.txt")
+    assert vo.shape == (n_frames, 8) and np.all(np.diff(vo[:, 0]) > 0)
+    fin = np.loadtxt(tmp_path / "orbhip_traj_final.txt")
+    assert fin.shape == (n_frames, 8) and np.allclose(fin[:, 0], vo[:, 0])
 
     # extraction + matching: bit-exact against the oracle on the frames the dataset delivered
     prev = None
@@ -187,3 +195,12 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
     assert max(err) < 0.03, max(err)
     q_err = [1 - abs(np.dot(p["pose"][:4], frames[i][0][:4])) for i, p in final.items()]
     assert max(q_err) < 1e-4
+    # what metric_traj wrote is what the plugin calls produced: SE3 streams as "tx ty tz qx qy qz qw" (SE3.h operator<<);
+    # the published pose of a frame is its PnP refit -- or, on the frames that close a BA window, the window's result for
+    # its newest camera; the map's final pose of every frame additionally went through the later windows
+    published = {i: p["pose"] for i, p in final.items()}
+    for b in log["ba"]:
+        published[b["id"]] = b["poses"][-1]
+    for i, pose in published.items():  # the reference's Point3 / SO3 stream operators print 6 significant digits
+        assert np.abs(vo[i - 1, 1:4] - pose[4:]).max() < 5e-6 and np.abs(vo[i - 1, 4:] - pose[:4]).max() < 5e-6, i
+    assert np.abs(fin[:, 1:4] - np.array([frames[i + 1][0][4:] for i in range(n_frames)])).max() < 0.03
