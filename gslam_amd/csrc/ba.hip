@@ -23,7 +23,9 @@
 #include "common.h"
 
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
-                            double* xwork);
+                            double* xwork, unsigned* flow_state);
+size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
+std::mutex& gh_potrf_flow_mutex();
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev);
 
@@ -815,7 +817,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   const int n = 6 * nc;
-  const int lda = n + 1;  // one extra row carries the right-hand side through the factorisation
+  // one extra row carries the right-hand side through the factorisation; columns start on 128-byte lines
+  const int lda = (n + 1 + 15) & ~15;
 
   std::vector<int32_t> pstart, plist, cstart, clist;
   build_csr(pr->obs_point, no, np, pstart, plist);
@@ -908,6 +911,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_W, (size_t)no * 18));
   GH_TRY(db.alloc(&d_xwork, (size_t)2 * 64 * (n + 1)));
   GH_TRY(db.alloc(&d_xh, (size_t)gh_div_up(n, 64) * 64));
+  unsigned* d_flow = nullptr;  // state of the single-launch factorisation (null when the shape does not fit it)
+  if (const size_t words = gh_potrf_flow_words(ctx, n, 1)) GH_TRY(db.alloc(&d_flow, words));
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
   GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
@@ -992,11 +997,14 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       }
     }
     const double t_solve0 = now_ms();
+    // (one single-launch factorisation at a time per process, until this iteration's synchronisation: see chol.hip)
+    std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(), std::defer_lock);
+    if (d_flow) flow_lock.lock();
     // The whole candidate step is enqueued without waiting for the factorisation flags (the kernels have no
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host
     // synchronisation per iteration instead of three.
     GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
-    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork));
+    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
     GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info));
     GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1007,6 +1015,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_LAUNCH(ctx, "ba_update", update_state_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, nc, np,
               d_poses, d_dof, d_pts, d_dc, d_dp, d_poses_new, d_pts_new);
     GH_TRY(eval_cost(d_poses_new, d_pts_new, 1));  // the iteration's one synchronisation
+    if (flow_lock.owns_lock()) flow_lock.unlock();
     h2[0] = rb->cost;
     h2[1] = rb->model;
     sum->solve_ms_total += now_ms() - t_solve0;

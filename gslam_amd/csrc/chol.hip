@@ -22,6 +22,9 @@ constexpr int NBI = 64;    // inner block
 constexpr int NBO = 256;   // outer panel
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// global-address-space words for the agent-scope (sc1) accesses of the in-launch hand-offs
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
 
 // tools/chol_probe.hip defines GH_CHOL_PROBE to read cycle stamps out of the single-workgroup kernels
 #ifdef GH_CHOL_PROBE
@@ -30,9 +33,18 @@ __device__ long long g_probe[64];
   do {                                                                   \
     if (threadIdx.x == 0) g_probe[(i)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+// wall-clock stamps (100 MHz, common to all CUs) of diagonal workgroup j of potrf_flow_kernel: tools/flow_probe.hip
+__device__ long long g_flow_trace[128 * 8];
+#define FLOW_STAMP(j, e)                                                            \
+  do {                                                                              \
+    if (threadIdx.x == 0 && (j) < 128) g_flow_trace[(j) * 8 + (e)] = (long long)wall_clock64(); \
+  } while (0)
 #else
 #define CHOL_STAMP(i) \
   do {                \
+  } while (0)
+#define FLOW_STAMP(j, e) \
+  do {                   \
   } while (0)
 #endif
 
@@ -88,6 +100,11 @@ __device__ __forceinline__ void panel16_factor(double (&s)[NBS], double (&rinv)[
   }
 }
 
+// (Measured on the box, tools/lat_probe.hip + tools/chol_probe.hip: ONE wave issues a v_fma_f64 every ~7 cycles whether or
+// not it depends on the previous one, v_rsq_f64 takes 18, a v_readlane pair feeding a VALU operand 23-31.  The ~45
+// instructions of a pivot step therefore cost ~300 cycles however they are ordered: deferring the LDS-fed updates by one
+// or two steps so that nothing on the chain waits for LDS gave 310 cycles per pivot against 298.  The panel is bound by
+// the instruction count of the single wave that holds it.)
 // M = L^-1 of a 16x16 block, column `i` per lane (all four 16-lane rows redundantly): forward substitution on e_i,
 // right-looking, with the (lane-uniform) entries of L fetched by same-address LDS reads.  Lcol(t) -> &L[0][t].
 template <int T, int R>
@@ -879,6 +896,329 @@ __global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __rest
   }
 }
 
+// ---------------------------------------------------------------- single-launch dataflow factorisation (small n)
+// At n ~ 3000 the launch-per-step factorisation above is a chain of ~60 dependent launches whose workgroup 0 carries
+// the diagonal blocks; every launch boundary, and every trip of the diagonal block and its inverse through HBM, sits on
+// that chain.  Here the whole factorisation (with the right-hand-side row riding along) is ONE launch of resident
+// workgroups that hand tiles to each other through global memory while they run (MI355X_MICROARCH.md, "Persistent
+// kernels: hand-off price list"; protocol = cdna_hip_programming.md Guideline 16 form R1):
+//   64 x 64 tiles (i, j), i >= j.  A tile is LEFT-LOOKING: its owner keeps  -A[i,j] + sum_{k < j} L[i,k] L[j,k]^T  in MFMA
+//   accumulators for the whole launch (initialised with -A), adds column k as soon as the two operand tiles are
+//   published, and finally writes L[i,j] = (A[i,j] - sum) M_j^T exactly once.  Nothing is read-modify-written in memory, no two workgroups write the same
+//   tile, the summation order is fixed (k ascending): the result is reproducible bit for bit.
+//   diagonal workgroup j   owns (j, j-1) and (j, j): after column j-2 it waits for M_{j-1}, applies it to (j, j-1),
+//                          updates (j, j) with the result, factors it (potf2_inv_lds, as the launch path does) and
+//                          publishes M_j.  These 47 workgroups are the critical chain; everything they wait for except
+//                          M_{j-1} is ready a step earlier.
+//   worker workgroups      own up to FL_MAXT tiles (i, j0 .. j1) of one tile row, j1 <= i - 2.
+// The accumulators are held TRANSPOSED (MFMA rows = tile columns), which is at the same time the operand layout of the
+// X = P M^T product and of the later updates (trsm_block16 above): a tile never passes through LDS to change role.
+// Publishing = write-through (sc1) stores, every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE relaxed agent-scope
+// flag store; consuming = relaxed poll of that ONE word, then sc1 loads.  Every wait is bounded and watches a common
+// abort word: an expired wait raises `info`, sets the abort word and the launch runs out (with garbage) instead of hanging.
+constexpr int FL_MAXT = 6;                       // tiles per worker: 6 x 16 accumulator doubles per lane
+constexpr unsigned kFlowSpinLimit = 1u << 22;
+constexpr int kFlowLdsBytes = 3 * NBI * LP * (int)sizeof(double) + 10240;  // three tile buffers (or Potf2Lds) + extras
+
+struct FlowArgs {
+  double* A;
+  int lda, n, nr, nb, ntr;  // nb column blocks, ntr tile rows (ntr = nb, or nb + 1 when the extra row starts a tile row)
+  int n_groups;             // worker workgroups
+  double* dinv;
+  unsigned* tf;             // [ntr][nb]  tile (i, k) of L is final in A
+  unsigned* mf;             // [nb]       M_k is final in dinv
+  unsigned* abort_word;
+  int* info;
+};
+
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-uniform bounded wait for *flag != 0
+__device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& a, int code) {
+  unsigned spins = 0;
+  while (__hip_atomic_load((const gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    ++spins;
+    if (spins > kFlowSpinLimit ||
+        ((spins & 63u) == 0u && __hip_atomic_load((const gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+      if ((threadIdx.x & 63) == 0) {
+        __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(a.info, a.n + 1 + code);
+      }
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+// all stores of this workgroup are out -> one flag
+__device__ __forceinline__ void flow_publish(unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 64 x 64 tile (column-major, leading dimension ld, `rows` x `cols` valid, the rest reads as zero): thread = (row, 4
+// interleaved column sets) so that every wave instruction reads 512 contiguous bytes; LDS image [column][row], pitch LP
+__device__ __forceinline__ void flow_fetch(const double* src, size_t ld, int rows, int cols, double (&v)[16]) {
+  const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  // wave-uniform base + one 32-bit lane offset: the 16 loads share their address registers
+  const unsigned off = (unsigned)((size_t)cq * ld + row) * 8u;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const char* base = reinterpret_cast<const char*>(src + (size_t)(4 * e) * ld);
+    v[e] = (row < rows && cq + 4 * e < cols) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
+  }
+}
+__device__ __forceinline__ void flow_put(double* buf, const double (&v)[16]) {
+  const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) buf[(cq + 4 * e) * LP + row] = v[e];
+}
+// acc(ja)[r] += sum_k T[16 ja + (lane >> 4) + 4 r][k] * x[k-th operand]  with T staged in `buf`, for ja < ja_end
+__device__ __forceinline__ void flow_update(double4_t (&acc)[4], const double* buf, const double (&x)[16], int ja_end, int lane) {
+  const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja) {
+    if (ja < ja_end) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        acc[ja] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[(4 * ks + q) * LP + 16 * ja + m], x[ks], acc[ja], 0, 0, 0);
+    }
+  }
+}
+// x = P M^T for the wave's 16 rows, P = A - S = -acc; M staged in `mbuf`; result in operand layout (= accumulator layout)
+__device__ __forceinline__ void flow_trsm(const double* mbuf, const double4_t (&acc)[4], double (&x)[16], int lane) {
+  const int m = lane & 15, q = lane >> 4;
+  double pb[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) pb[ks] = -acc[ks >> 2][ks & 3];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * (jt + 1); ++ks)  // M[j][k] = 0 for k > j
+      t = __builtin_amdgcn_mfma_f64_16x16x4f64(mbuf[(4 * ks + q) * LP + 16 * jt + m], pb[ks], t, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[4 * jt + r] = t[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char flow_lds[];
+  double* buf0 = reinterpret_cast<double*>(flow_lds);
+  double* buf1 = buf0 + NBI * LP;
+  double* buf2 = buf1 + NBI * LP;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+  double* const A = a.A;
+  const size_t lda = (size_t)a.lda;
+  const int bid = blockIdx.x;
+  // operand-layout view of the wave's 16 rows of tile (ti, tj): element ks <-> (row 64 ti + 16 wv + m, column 64 tj + 4 ks + q)
+  // (the 16 accesses of a lane share one 32-bit offset from wave-uniform bases)
+  const unsigned lane_off = (unsigned)((size_t)q * lda + 16 * wv + m) * 8u;
+  auto elem = [&](int ti, int tj, int ks) {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(A + (size_t)(64 * tj + 4 * ks) * lda + 64 * ti) + lane_off);
+  };
+  auto row_of = [&](int ti) { return 64 * ti + 16 * wv + m; };
+  auto load_orig = [&](int ti, int tj, double (&v)[16]) {
+    const int row = row_of(ti);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) v[ks] = (row < a.nr && 64 * tj + 4 * ks + q < a.n) ? *elem(ti, tj, ks) : 0.0;
+  };
+  auto load_rows = [&](int ti, int tk, double (&v)[16]) {  // published tile (ti, tk): own 16 rows
+    const int row = row_of(ti);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) v[ks] = row < a.nr ? ld_sc1(elem(ti, tk, ks)) : 0.0;
+  };
+  auto store_rows = [&](int ti, int tj, const double (&v)[16]) {
+    const int row = row_of(ti);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (row < a.nr && 64 * tj + 4 * ks + q < a.n) st_sc1(elem(ti, tj, ks), v[ks]);
+  };
+  auto tile_rows = [&](int ti) { return a.nr - 64 * ti < 64 ? a.nr - 64 * ti : 64; };
+  auto tile_src = [&](int ti, int tk) { return A + (size_t)(64 * tk) * lda + 64 * ti; };
+
+  if (bid < a.ntr) {
+    // ------------------------------------------------------------ diagonal workgroup j
+    const int j = bid;
+    const bool has_diag = j < a.nb;
+    const int kb = has_diag ? (a.n - 64 * j < 64 ? a.n - 64 * j : 64) : 0;
+    double4_t accP[4], accD[4];
+    {  // only tiles this workgroup owns are ever read with plain loads
+      double v[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
+      if (j > 0) load_orig(j, j - 1, v);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) accP[ks >> 2][ks & 3] = -v[ks];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
+      if (has_diag) load_orig(j, j, v);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) accD[ks >> 2][ks & 3] = -v[ks];
+    }
+    const int ja_end = wv + 1;  // lower part of the diagonal tile: columns 16 ja .. <= rows 16 wv ..
+    FLOW_STAMP(j, 0);
+    if (j >= 2) {
+      double va[16], vb[16], xi[16];
+      for (int k = 0; k <= j - 2; ++k) {
+        flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j);
+        flow_fetch(tile_src(j - 1, k), lda, 64, 64, va);
+        flow_wait(a.tf + (size_t)j * a.nb + k, a, j);
+        flow_fetch(tile_src(j, k), lda, tile_rows(j), 64, vb);
+        __syncthreads();  // previous step's MFMA reads of buf0 / buf1 are done
+        flow_put(buf0, va);
+        flow_put(buf1, vb);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xi[ks] = buf1[(4 * ks + q) * LP + 16 * wv + m];
+        flow_update(accP, buf0, xi, 4, lane);
+        if (has_diag) flow_update(accD, buf1, xi, ja_end, lane);
+      }
+    }
+    FLOW_STAMP(j, 1);
+    Potf2Lds& sh = *reinterpret_cast<Potf2Lds*>(flow_lds);
+    static_assert(sizeof(Potf2Lds) + 64 * sizeof(double) <= (size_t)kFlowLdsBytes, "diagonal role must fit the LDS request");
+    double* ex = reinterpret_cast<double*>(flow_lds + sizeof(Potf2Lds));  // the extra (right-hand-side) row of the tile
+    if (j >= 1) {
+      double x[16];
+      {
+        double mv[16];
+        flow_wait(a.mf + (j - 1), a, j);
+        FLOW_STAMP(j, 2);
+        flow_fetch(a.dinv + (size_t)(j - 1) * (NBI * NBI), NBI, 64, 64, mv);
+        __syncthreads();
+        flow_put(buf2, mv);
+      }
+      __syncthreads();
+      FLOW_STAMP(j, 3);
+      flow_trsm(buf2, accP, x, lane);
+      store_rows(j, j - 1, x);
+      FLOW_STAMP(j, 4);
+      if (has_diag) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) buf0[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
+        __syncthreads();
+        flow_update(accD, buf0, x, ja_end, lane);
+      }
+      flow_publish(a.tf + (size_t)j * a.nb + (j - 1));  // (contains the barrier that frees buf0 / buf2)
+    }
+    if (!has_diag) return;
+    __syncthreads();
+    FLOW_STAMP(j, 5);
+    // D = A_jj - S into sh.As (lower part, identity padding); the tile's row past the block (the right-hand side) aside
+    if (tid == 0) sh.bad = 0;
+    {
+      const int row = 16 * wv + m;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {  // every (row, col) of the 64 x 64 block is written by exactly one lane
+        const int col = 4 * ks + q;
+        const double d = -accD[ks >> 2][ks & 3];  // meaningful for col <= row (the waves skip the upper tiles)
+        double v = (row == col) ? 1.0 : 0.0;
+        if (row < kb && col < kb) v = col <= row ? d : 0.0;
+        sh.As[col * LP + row] = v;
+        if (row == kb && col < kb) ex[col] = d;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int idx = tid + 256 * e;
+        sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
+      }
+    }
+    __syncthreads();
+    potf2_inv_lds(sh);
+    FLOW_STAMP(j, 6);
+    if (tid == 0 && sh.bad) atomicMax(a.info, 64 * j + 1);
+    double* Minv = a.dinv + (size_t)j * (NBI * NBI);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e, c = idx >> 6, r = idx & 63;
+      if (r < kb && c < kb && c <= r) A[(size_t)(64 * j + c) * lda + 64 * j + r] = sh.As[c * LP + r];
+      st_sc1(Minv + idx, (c <= r) ? sh.Ms[c * LP + r] : 0.0);
+    }
+    flow_publish(a.mf + j);
+    FLOW_STAMP(j, 7);
+    if (64 * j + kb < a.nr && kb < 64 && tid < kb) {  // y = e M^T for the right-hand-side row inside this tile
+      double y = 0.0;
+      for (int t = 0; t <= tid; ++t) y = __builtin_fma(ex[t], sh.Ms[t * LP + tid], y);
+      A[(size_t)(64 * j + tid) * lda + 64 * j + kb] = y;
+    }
+    return;
+  }
+  // -------------------------------------------------------------- worker: tiles (i, j0 .. j0 + T - 1), j0 + T - 1 <= i - 2
+  int g = bid - a.ntr, i = 2, j0 = 0, T = 0;
+  for (;; ++i) {
+    if (i >= a.ntr) return;
+    const int cols = i - 1, groups = (cols + FL_MAXT - 1) / FL_MAXT;
+    if (g < groups) {
+      const int base = cols / groups, rem = cols - base * groups;  // the first `rem` groups hold one tile more
+      j0 = g * base + (g < rem ? g : rem);
+      T = base + (g < rem ? 1 : 0);
+      break;
+    }
+    g -= groups;
+  }
+  double4_t acc[FL_MAXT][4];
+#pragma unroll
+  for (int t = 0; t < FL_MAXT; ++t) {
+    double v[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
+    if (t < T) load_orig(i, j0 + t, v);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc[t][ks >> 2][ks & 3] = -v[ks];
+  }
+  const int j1 = j0 + T - 1;
+  const int code = a.ntr + (bid - a.ntr);
+  for (int k = 0; k <= j1; ++k) {
+    double xi[16];
+    if (k >= j0) {
+      // own tile (i, k) has every column < k: finalise it, its X rows are this step's i-operand
+      {
+        double mv[16];
+        flow_wait(a.mf + k, a, code);
+        flow_fetch(a.dinv + (size_t)k * (NBI * NBI), NBI, 64, 64, mv);
+        __syncthreads();
+        flow_put(buf2, mv);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < FL_MAXT; ++t)
+        if (t == k - j0) flow_trsm(buf2, acc[t], xi, lane);
+      store_rows(i, k, xi);
+      flow_publish(a.tf + (size_t)i * a.nb + k);
+    } else {
+      flow_wait(a.tf + (size_t)i * a.nb + k, a, code);
+      load_rows(i, k, xi);
+    }
+    // the other tiles: (i, j) += L[i, k] L[j, k]^T for j > k; operand tile (j, k) staged through LDS (two buffers), the
+    // next one already in flight while the MFMAs of the current one run
+    const int t_begin = k + 1 - j0 > 0 ? k + 1 - j0 : 0;
+    double v[16];
+    if (t_begin < T) {
+      flow_wait(a.tf + (size_t)(j0 + t_begin) * a.nb + k, a, code);
+      flow_fetch(tile_src(j0 + t_begin, k), lda, 64, 64, v);
+    }
+#pragma unroll
+    for (int t = 0; t < FL_MAXT; ++t) {
+      if (t >= t_begin && t < T) {
+        double* buf = (t & 1) ? buf1 : buf0;
+        flow_put(buf, v);
+        __syncthreads();
+        if (t + 1 < T) {
+          flow_wait(a.tf + (size_t)(j0 + t + 1) * a.nb + k, a, code);
+          flow_fetch(tile_src(j0 + t + 1, k), lda, 64, 64, v);
+        }
+        flow_update(acc[t], buf, xi, 4, lane);
+      }
+    }
+    __syncthreads();  // both tile buffers free before the next step overwrites them
+  }
+}
+
 __global__ void gather_strided_kernel(const double* __restrict__ src, long long stride, int n, double* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[(size_t)i * stride];
@@ -895,7 +1235,6 @@ __global__ void gather_strided_kernel(const double* __restrict__ src, long long 
 // consumer re-reads its 16 values with agent-scope relaxed loads until none is the sentinel.  No flag, no fence.
 // Workgroup c only waits for workgroups with a LOWER blockIdx (block 0 owns the last column block); every spin is bounded:
 // on expiry the workgroup raises `info`, publishes NaN so that nobody behind it waits, and the launch ends.
-typedef __attribute__((address_space(1))) unsigned long long gu64;
 constexpr unsigned long long kXSentinel = 0xFFF8BEEFFFF8BEEFull;  // a NaN no computation produces; two equal 32-bit halves
 constexpr int kBwdChainMaxN = 8192;                                // 128 workgroups; workgroup 0 streams <= 4 MB of L
 constexpr unsigned kBwdSpinLimit = 1u << 21;
@@ -983,16 +1322,74 @@ __global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict
 
 }  // namespace
 
+// The dataflow launch needs every workgroup resident: one per CU (its LDS request admits no second one).  Returns the
+// number of worker workgroups, or -1 when the shape does not fit (then the launch-per-step path below is taken).
+static int flow_groups(const gh_ctx* ctx, int n, int extra_rows) {
+  if (extra_rows < 0 || extra_rows > 1 || n < 1) return -1;
+  const int nb = gh_div_up(n, NBI), ntr = gh_div_up(n + extra_rows, NBI);
+  int groups = 0;
+  for (int i = 2; i < ntr; ++i) groups += gh_div_up(i - 1, FL_MAXT);
+  const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  (void)nb;
+  return ntr + groups <= cus ? groups : -1;
+}
+
+// Two dataflow launches in flight on one GPU could each hold part of the CUs and wait for the rest for ever (until their
+// bounded waits expire): callers in this process take this lock from the launch to their next stream synchronisation.
+std::mutex& gh_potrf_flow_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+
+// u32 words of device state the dataflow launch needs (tile flags, block flags, abort word), 0 = shape not eligible
+size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows) {
+  if (flow_groups(ctx, n, extra_rows) < 0) return 0;
+  const size_t nb = (size_t)gh_div_up(n, NBI), ntr = (size_t)gh_div_up(n + extra_rows, NBI);
+  return ntr * nb + nb + 16;
+}
+
 // Factor (lower, in place) and optionally solve.  info_dev: device int (0 = ok, else first bad block column + 1).
 // `extra_rows` rows below the n x n matrix (lda >= n + extra_rows) ride along through trsm / syrk: with the
 // right-hand side stored as row n, the factorisation leaves y = L^-1 b there (forward substitution for free).
 // `dinv`: ceil(n / 64) * 4096 doubles of device workspace that receives the inverted diagonal blocks.
 // `xwork`: optional 2 * 64 * (n + extra_rows) doubles; when given, full panel steps of the small-matrix regime run as one
 // launch each (panel_step_kernel) with their X rows parked there until a later launch copies them home.
+// `flow_state`: optional gh_potrf_flow_words() u32 words; when given (and GSLAM_HIP_CHOL_FLOW != 0) the whole factorisation
+// is the single dataflow launch (potrf_flow_kernel).
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
-                            double* xwork) {
+                            double* xwork, unsigned* flow_state) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
   GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  {
+    const char* env = getenv("GSLAM_HIP_CHOL_FLOW");  // "0" keeps the launch-per-step path (A/B measurements, tests)
+    // tiles must not share 128-byte lines: a line is only ever touched with plain loads by the one workgroup that owns it
+    const bool aligned = lda % 16 == 0 && (reinterpret_cast<uintptr_t>(A) & 127u) == 0;
+    const int groups = flow_state && aligned && !(env && env[0] == '0') ? flow_groups(ctx, n, extra_rows) : -1;
+    if (groups >= 0) {
+      static bool lds_attr_set = false;  // per process: the attribute belongs to the loaded code object
+      if (!lds_attr_set) {
+        GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_flow_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kFlowLdsBytes));
+        lds_attr_set = true;
+      }
+      FlowArgs fa;
+      fa.A = A;
+      fa.lda = lda;
+      fa.n = n;
+      fa.nr = nr;
+      fa.nb = gh_div_up(n, NBI);
+      fa.ntr = gh_div_up(nr, NBI);
+      fa.n_groups = groups;
+      fa.dinv = dinv;
+      fa.tf = flow_state;
+      fa.mf = flow_state + (size_t)fa.ntr * fa.nb;
+      fa.abort_word = fa.mf + fa.nb;
+      fa.info = info_dev;
+      GH_HIP(ctx, hipMemsetAsync(flow_state, 0, ((size_t)fa.ntr * fa.nb + fa.nb + 16) * sizeof(unsigned), ctx->stream));
+      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(fa.ntr + groups), dim3(256), kFlowLdsBytes, fa);
+      return GH_OK;
+    }
+  }
   // outer panel width: wider for large systems (each doubling halves the passes over the trailing matrix, whose C-tile
   // read-modify-write is what keeps the rank-k update below the MFMA rate, at the price of more in-panel rank-64
   // updates; measured at n = 60 000: 512 -> 58.0, 1024 -> 60.1 TFLOP/s), 256 for small, latency-bound ones
@@ -1113,15 +1510,22 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
   void* scratch = nullptr;
   const size_t nblk = (size_t)gh_div_up(n, NBI);
-  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI + 2 * (size_t)NBI * n + nblk * NBI) * sizeof(double), &scratch));
+  const size_t flow_words = gh_potrf_flow_words(ctx, n, 0);
+  GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI + 2 * (size_t)NBI * n + nblk * NBI) * sizeof(double) +
+                             flow_words * sizeof(unsigned), &scratch));
   int* info_dev = (int*)scratch;
   double* dinv = (double*)((char*)scratch + 256);
   double* work = dinv + nblk * NBI * NBI;
   double* xwork = work + n;
   double* xh = xwork + 2 * (size_t)NBI * n;
-  GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork));
-  GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned* flow_state = flow_words ? (unsigned*)(xh + nblk * NBI) : nullptr;
+  {
+    std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(), std::defer_lock);
+    if (flow_state) flow_lock.lock();
+    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state));
+    GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (*info == 0 && b_dev) {
     GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv, xh, info_dev));
     GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

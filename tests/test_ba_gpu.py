@@ -137,6 +137,51 @@ def test_backsubstitution_single_launch_matches_the_stepwise_path(ctx, n, monkey
     assert np.linalg.norm(A @ x1 - b) <= 1e-12 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("n", [16, 64, 80, 128, 192, 256, 320, 1024, 2000, 3008, 3200])
+def test_single_launch_factorisation_matches_the_launch_per_step_path(ctx, n, monkeypatch):
+    """potrf_flow_kernel (one launch of resident workgroups handing tiles to each other, left-looking accumulation in
+    MFMA registers) against the launch-per-step factorisation: same factor to rounding, reproducible bit for bit."""
+    from gslam_amd import ba
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, 96))
+    A = M @ M.T / 96.0 + 2.0 * np.eye(n)
+    b = rng.standard_normal(n)
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "1")
+    L1, x1, info1 = ba.potrf_solve(ctx, A, b)
+    L1b = ba.potrf_solve(ctx, A, b)[0]
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "0")
+    L0, x0, info0 = ba.potrf_solve(ctx, A, b)
+    assert info0 == 0 and info1 == 0
+    assert L1.tobytes() == L1b.tobytes()
+    assert np.abs(L1 - L0).max() <= 1e-13 * np.abs(L0).max()
+    assert np.abs(L1 - np.linalg.cholesky(A)).max() <= 1e-12 * np.abs(L0).max()
+    assert np.linalg.norm(A @ x1 - b) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("cams", [3, 11, 32, 50, 64, 100])
+def test_ba_single_launch_factorisation_against_the_launch_path(ctx, cams, monkeypatch):
+    """The right-hand-side row rides through the factorisation: inside the last diagonal tile (6 * cams not a multiple of
+    64), or as a tile row of its own (cams = 32, 64: n = 192, 384)."""
+    from gslam_amd import ba
+    g = make_graph(cams, 40 * cams, n_obs_per_point=4, seed=cams)
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "1")
+    p1, x1, s1, _ = ba.solve(ctx, g, ba.default_options(max_iterations=8, deterministic=1))
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "0")
+    p0, x0, s0, _ = ba.solve(ctx, g, ba.default_options(max_iterations=8, deterministic=1))
+    assert s1.iterations == s0.iterations and s1.accepted == s0.accepted
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
+    assert np.abs(p1 - p0).max() <= 1e-8 and np.abs(x1 - x0).max() <= 1e-8  # eight LM iterations amplify the rounding
+
+
+def test_potrf_single_launch_reports_not_positive_definite(ctx, monkeypatch):
+    from gslam_amd import ba
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "1")
+    A = np.eye(320)
+    A[200, 200] = -1.0
+    _, _, info = ba.potrf_solve(ctx, A, np.ones(320))
+    assert info != 0
+
+
 def test_potrf_reports_not_positive_definite(ctx):
     from gslam_amd import ba
     A = np.eye(100)

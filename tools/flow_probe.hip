@@ -1,0 +1,70 @@
+// Wall-clock stamps of the diagonal workgroups of the single-launch factorisation (perf probe, not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -Iinclude tools/flow_probe.hip -o build/flow_probe -ldl -lrt
+// Prints, per diagonal block j (times in us): how long the block's accumulators were ready before M_{j-1} arrived (slack),
+// M fetch, X = P M^T, diagonal update + publish, potf2 + inverse, publishing M_j, and the step T_j - T_{j-1}.
+#define GH_CHOL_PROBE 1
+#include "../gslam_amd/csrc/chol.hip"
+#include "../gslam_amd/csrc/ctx.hip"
+
+#include <vector>
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 3000, lda = (n + 1 + 15) & ~15;
+  std::vector<double> A((size_t)n * lda, 0.0);
+  for (int c = 0; c < n; ++c) {
+    for (int r = c; r < n; ++r) A[(size_t)c * lda + r] = (r == c) ? 80.0 : 1.0 / (1 + r - c);
+    A[(size_t)c * lda + n] = 1.0 + 0.001 * c;  // right-hand-side row
+  }
+  gh_ctx* ctx = nullptr;
+  if (gh_ctx_create(0, &ctx) != GH_OK) return 1;
+  double *dA, *dM, *dX;
+  int* dinfo;
+  unsigned* dflow;
+  const size_t words = gh_potrf_flow_words(ctx, n, 1);
+  if (!words) { printf("shape not eligible\n"); return 1; }
+  hipMalloc(&dA, A.size() * 8);
+  hipMalloc(&dM, (size_t)((n + 63) / 64) * 4096 * 8);
+  hipMalloc(&dX, (size_t)2 * 64 * (n + 1) * 8);
+  hipMalloc(&dinfo, 4);
+  hipMalloc(&dflow, words * 4);
+  const int nb = (n + 63) / 64;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, ctx->stream);
+    if (gh_potrf_dev_impl(ctx, dA, n, lda, dinfo, 1, dM, dX, dflow) != GH_OK) { printf("launch failed: %s\n", ctx->last_error.c_str()); return 1; }
+    hipEventRecord(e1, ctx->stream);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    int info = -1;
+    hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
+    std::vector<long long> st(128 * 8);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_flow_trace), st.size() * 8);
+    printf("rep %d: n %d info %d  %.1f us (memset + launch)\n", rep, n, info, ms * 1e3);
+    if (rep < 2) continue;
+    auto us = [](long long d) { return d * 0.01; };
+    const long long t0 = st[0];
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    printf("  j   start  acc_done  slack   Mfetch   trsm   upd+pub  potf2  pubM   T_j      step\n");
+    for (int j = 0; j < nb; ++j) {
+      const long long* s = &st[j * 8];
+      const double step = j ? us(s[7] - st[(j - 1) * 8 + 7]) : us(s[7] - t0);
+      if (j >= 1) {
+        printf("%3d %7.1f %8.1f %7.1f %7.2f %7.2f %7.2f %7.2f %6.2f %8.1f %7.2f\n", j, us(s[0] - t0), us(s[1] - t0), us(s[2] - s[1]),
+               us(s[3] - s[2]), us(s[4] - s[3]), us(s[5] - s[4]), us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
+        if (j >= 2) { sum[0] += us(s[3] - s[2]); sum[1] += us(s[4] - s[3]); sum[2] += us(s[5] - s[4]); sum[3] += us(s[6] - s[5]); sum[4] += us(s[7] - s[6]); sum[5] += step; }
+      } else {
+        printf("%3d %7.1f %8.1f    -        -       -       -    %7.2f %6.2f %8.1f %7.2f\n", j, us(s[0] - t0), us(s[1] - t0), us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
+      }
+    }
+    const int cnt = nb - 2;
+    if (cnt > 0)
+      printf("mean over j >= 2: Mfetch %.2f trsm %.2f upd+pub %.2f potf2 %.2f pubM %.2f step %.2f us\n", sum[0] / cnt, sum[1] / cnt,
+             sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt);
+  }
+  return 0;
+}
