@@ -18,6 +18,8 @@
 // Jacobians are recomputed where needed instead of being stored (80 B gathered beats 144 B of W traffic).
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <thread>
 
 #include "common.h"
@@ -682,26 +684,124 @@ void build_csr(const int32_t* key, int n_items, int n_keys, std::vector<int32_t>
   for (int k = 0; k < n_items; ++k) list[fill[key[k]]++] = k;
 }
 
+// A few persistent host threads for the index lists below (spawning threads per solve cost more than the lists).
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool p;
+    return p;
+  }
+  int size() const { return (int)workers_.size() + 1; }
+  // runs f(t) for t in [0, n_tasks) on the pool threads and the caller; returns when all are done
+  template <typename F>
+  void run(int n_tasks, F&& f) {
+    if (n_tasks <= 1 || workers_.empty()) {
+      for (int t = 0; t < n_tasks; ++t) f(t);
+      return;
+    }
+    std::unique_lock<std::mutex> call(call_mu_);  // one parallel region at a time
+    std::function<void(int)> fn = f;
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      fn_ = &fn;
+      n_tasks_ = n_tasks;
+      next_ = 0;
+      pending_ = n_tasks;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = (int)(hw ? hw : 4) - 1;
+    if (n > 15) n = 15;
+    if (const char* e = getenv("GSLAM_HIP_HOST_THREADS")) n = atoi(e) - 1;
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  void work() {
+    for (;;) {
+      int t;
+      std::function<void(int)>* fn;
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (!fn_ || next_ >= n_tasks_) return;
+        t = next_++;
+        fn = fn_;
+      }
+      (*fn)(t);
+      std::lock_guard<std::mutex> l(mu_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_cv_;
+  std::function<void(int)>* fn_ = nullptr;
+  int n_tasks_ = 0, next_ = 0, pending_ = 0;
+  unsigned long long epoch_ = 0;
+  bool stop_ = false;
+};
+
 // Pair list of the deterministic Schur product: for every camera pair (ci >= cj) that shares a point, the list of
 // observation pairs (k of ci, k2 of cj) on a common point, grouped by destination block in (ci, cj) order with the
-// generation order kept inside a group.  Cameras are independent, so ranges of cameras (balanced by observation
-// count) are built by a few host threads and concatenated -- the result does not depend on the thread count.
+// generation order kept inside a group.  Cameras are independent: contiguous ranges of cameras (balanced by observation
+// count) are tasks for the host pool, each writes its pairs to a buffer of its own and, once every range knows where it
+// starts, copies them to their final place -- the result does not depend on the number of threads or ranges.
 struct PairChunk {
   std::vector<int32_t> pa, pb, bs, ci, cj;  // bs relative to the chunk
 };
 
+// pcam[q] = camera of the observation plist[q] (the inner loop then reads two contiguous arrays)
 void build_pair_chunk(const gh_ba_problem* pr, int nc, int c_lo, int c_hi, const std::vector<int32_t>& pstart,
-                      const std::vector<int32_t>& plist, const std::vector<int32_t>& cstart,
+                      const std::vector<int32_t>& plist, const std::vector<int32_t>& pcam, const std::vector<int32_t>& cstart,
                       const std::vector<int32_t>& clist, PairChunk& out) {
-  std::vector<int32_t> cnt((size_t)nc, 0), off((size_t)nc, 0), touched;
+  std::vector<int32_t> cnt((size_t)nc, 0), off((size_t)nc, 0), touched, tk, tk2, tc;
+  size_t total = 0;
+  for (int ci = c_lo; ci < c_hi; ++ci) total += (size_t)(cstart[ci + 1] - cstart[ci]);
+  out.pa.reserve(total * 4);
+  out.pb.reserve(total * 4);
   for (int ci = c_lo; ci < c_hi; ++ci) {
+    // pass A: the pairs of this camera in generation order (k ascending, then k2 ascending), counted per partner
     touched.clear();
+    tk.clear();
+    tk2.clear();
+    tc.clear();
     for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
-      const int p = pr->obs_point[clist[q]];
+      const int k = clist[q], p = pr->obs_point[k];
       for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
-        const int cj = pr->obs_cam[plist[q2]];
+        const int cj = pcam[q2];
         if (cj > ci) continue;
         if (cnt[cj]++ == 0) touched.push_back(cj);
+        tk.push_back(k);
+        tk2.push_back(plist[q2]);
+        tc.push_back(cj);
       }
     }
     std::sort(touched.begin(), touched.end());
@@ -715,15 +815,11 @@ void build_pair_chunk(const gh_ba_problem* pr, int nc, int c_lo, int c_hi, const
     }
     out.pa.resize(run);
     out.pb.resize(run);
-    for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
-      const int k = clist[q], p = pr->obs_point[k];
-      for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
-        const int k2 = plist[q2], cj = pr->obs_cam[k2];
-        if (cj > ci) continue;
-        const int32_t pos = off[cj]++;
-        out.pa[pos] = k;
-        out.pb[pos] = k2;
-      }
+    // pass B: stable scatter by partner camera (from the compact per-camera list: no second walk over the graph)
+    for (size_t e = 0; e < tk.size(); ++e) {
+      const int32_t pos = off[tc[e]]++;
+      out.pa[pos] = tk[e];
+      out.pb[pos] = tk2[e];
     }
     for (int cj : touched) cnt[cj] = 0;
   }
@@ -734,48 +830,43 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
                        const std::vector<int32_t>& clist, std::vector<int32_t>& pair_a, std::vector<int32_t>& pair_b,
                        std::vector<int32_t>& bstart, std::vector<int32_t>& bci, std::vector<int32_t>& bcj) {
   const int no = pr->n_obs;
-  int nthreads = no >= 20000 ? 8 : 1;
-  if (nthreads > nc) nthreads = nc;
-  std::vector<PairChunk> chunks((size_t)nthreads);
-  std::vector<int> bound((size_t)nthreads + 1, nc);
+  HostPool& pool = HostPool::get();
+  int nchunk = no >= 20000 ? 2 * pool.size() : 1;  // two ranges per thread: the pair count per observation varies
+  if (nchunk > nc) nchunk = nc;
+  std::vector<int32_t> pcam((size_t)(no > 0 ? no : 1));
+  for (int q = 0; q < no; ++q) pcam[q] = pr->obs_cam[plist[q]];
+  std::vector<PairChunk> chunks((size_t)nchunk);
+  std::vector<int> bound((size_t)nchunk + 1, nc);
   bound[0] = 0;
-  for (int t = 1, c = 0; t < nthreads; ++t) {  // camera ranges with ~equal observation counts
-    const long long target = (long long)no * t / nthreads;
+  for (int t = 1, c = 0; t < nchunk; ++t) {  // camera ranges with ~equal observation counts
+    const long long target = (long long)no * t / nchunk;
     while (c < nc && cstart[c] < target) ++c;
     bound[t] = c;
   }
-  if (nthreads == 1) {
-    build_pair_chunk(pr, nc, 0, nc, pstart, plist, cstart, clist, chunks[0]);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t)
-      th.emplace_back([&, t] { build_pair_chunk(pr, nc, bound[t], bound[t + 1], pstart, plist, cstart, clist, chunks[t]); });
-    for (auto& x : th) x.join();
+  pool.run(nchunk, [&](int t) { build_pair_chunk(pr, nc, bound[t], bound[t + 1], pstart, plist, pcam, cstart, clist, chunks[t]); });
+  std::vector<size_t> po((size_t)nchunk + 1, 0), bo((size_t)nchunk + 1, 0);
+  for (int t = 0; t < nchunk; ++t) {
+    po[t + 1] = po[t] + chunks[t].pa.size();
+    bo[t + 1] = bo[t] + chunks[t].bs.size();
   }
-  size_t np_total = 0, nb_total = 0;
-  for (auto& c : chunks) {
-    np_total += c.pa.size();
-    nb_total += c.bs.size();
-  }
+  const size_t np_total = po[nchunk], nb_total = bo[nchunk];
   pair_a.resize(np_total);
   pair_b.resize(np_total);
   bstart.resize(nb_total + 1);
   bci.resize(nb_total);
   bcj.resize(nb_total);
-  size_t po = 0, bo = 0;
-  for (auto& c : chunks) {
+  pool.run(nchunk, [&](int t) {
+    const PairChunk& c = chunks[t];
     if (!c.pa.empty()) {
-      memcpy(pair_a.data() + po, c.pa.data(), c.pa.size() * sizeof(int32_t));
-      memcpy(pair_b.data() + po, c.pb.data(), c.pb.size() * sizeof(int32_t));
+      memcpy(pair_a.data() + po[t], c.pa.data(), c.pa.size() * sizeof(int32_t));
+      memcpy(pair_b.data() + po[t], c.pb.data(), c.pb.size() * sizeof(int32_t));
     }
     for (size_t i = 0; i < c.bs.size(); ++i) {
-      bstart[bo + i] = (int32_t)(po + (size_t)c.bs[i]);
-      bci[bo + i] = c.ci[i];
-      bcj[bo + i] = c.cj[i];
+      bstart[bo[t] + i] = (int32_t)(po[t] + (size_t)c.bs[i]);
+      bci[bo[t] + i] = c.ci[i];
+      bcj[bo[t] + i] = c.cj[i];
     }
-    po += c.pa.size();
-    bo += c.bs.size();
-  }
+  });
   bstart[nb_total] = (int32_t)np_total;
 }
 
@@ -821,8 +912,10 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   const int lda = (n + 1 + 15) & ~15;
 
   std::vector<int32_t> pstart, plist, cstart, clist;
-  build_csr(pr->obs_point, no, np, pstart, plist);
-  build_csr(pr->obs_cam, no, nc, cstart, clist);
+  HostPool::get().run(2, [&](int t) {
+    if (t == 0) build_csr(pr->obs_point, no, np, pstart, plist);
+    else build_csr(pr->obs_cam, no, nc, cstart, clist);
+  });
 
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant)
   std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
