@@ -146,14 +146,16 @@ struct Potf2Lds {
 
 // Factor the 64x64 block held in sh.As (lower, in place) and build M = L^-1 in sh.Ms.  Called by all 256 threads;
 // sh.As must be complete (identity padding for missing rows/cols), sh.bad cleared, and a barrier passed.
-__device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
+// (two halves, so that a caller can slip other work -- a prefetch -- between the factorisation and the inversion)
+// `idle`: run once by the waves 1..3 while wave 0 is busy with the first 16 pivots
+template <typename F>
+__device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle) {
   double* As = sh.As;
-  double* Ms = sh.Ms;
-  double* Ts = sh.Ts;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   for (int k = 0; k < NBI; k += NBS) {
     // (a) 16-column panel: diagonal block + rows below in one right-looking pass, wave 0, lane = row
+    if (wv != 0 && k == 0) idle();
     if (wv == 0) {
       double s[NBS], ri[NBS];
 #pragma unroll
@@ -181,6 +183,14 @@ __device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
     __syncthreads();
     CHOL_STAMP(3 + k / 8);
   }
+}
+
+__device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
+  double* As = sh.As;
+  double* Ms = sh.Ms;
+  double* Ts = sh.Ts;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
   // inverses of the four 16x16 diagonal blocks, one per wave (column m of M per lane)
   {
     const int b0 = 16 * wv;
@@ -230,6 +240,11 @@ __device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
     for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
   }
   __syncthreads();
+}
+
+__device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
+  potf2_factor_lds(sh, [] {});
+  potf2_invert_lds(sh);
 }
 
 // write the factor back to A (lower part of the kb x kb block) and M to Minv (column-major, pitch 64, upper part zero)
@@ -927,6 +942,8 @@ struct FlowArgs {
   double* dinv;
   unsigned* tf;             // [ntr][nb]  tile (i, k) of L is final in A
   unsigned* mf;             // [nb]       M_k is final in dinv
+  unsigned* hf;             // [ntr]      the accumulators of tile row j are in `hand`
+  double* hand;             // [ntr][2][4096]
   unsigned* abort_word;
   int* info;
 };
@@ -937,10 +954,30 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 __device__ __forceinline__ void st_sc1(double* p, double v) {
   __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wave-uniform bounded wait for *flag != 0
-__device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& a, int code) {
+// 16-byte write-through store (8-byte sc1 stores are one fabric write each: publishing a 32 KB tile with them takes
+// ~1.6 us of issue time on the storing CU, MI355X_MICROARCH.md "stores of each flavour").  Inline asm: the compiler does
+// not count it in its vmcnt bookkeeping, which only makes its own waits stricter; every publication drains explicitly.
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_sc1_x2(double* p, double v0, double v1) {
+  const double2_t v = {v0, v1};
+  // s_nop: a store of more than 8 bytes reads its data registers a few cycles after issue; the compiler pads a VALU write
+  // to them behind its own stores (GCNHazardRecognizer, "VMEM store data hazard") but cannot see into inline asm --
+  // without the nops the v_mov that recycles the registers zeroed the upper half of the stored pair
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
+// Every publication is made of arrivals, one per storing wave of the publishing workgroup: the wave drains its own stores
+// and adds 1 to the word -- no workgroup barrier on the publishing side.  Consumers wait for the word to reach the number
+// of storing waves: 4, or 3 for what the chain workgroup publishes (its wave 0 never stores: it has to go straight into
+// the pivots of the next diagonal block while the other three, idle behind it, wait for their stores to be confirmed).
+constexpr unsigned kFlowArrivals = 4, kChainArrivals = 3;
+__device__ __forceinline__ void flow_arrive(unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-uniform bounded wait for *flag to reach `need` arrivals
+__device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& a, int code, unsigned need = kFlowArrivals) {
   unsigned spins = 0;
-  while (__hip_atomic_load((const gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+  while (__hip_atomic_load((const gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
     ++spins;
     if (spins > kFlowSpinLimit ||
         ((spins & 63u) == 0u && __hip_atomic_load((const gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -953,12 +990,6 @@ __device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& 
     __builtin_amdgcn_s_sleep(1);
   }
   asm volatile("" ::: "memory");
-}
-// all stores of this workgroup are out -> one flag
-__device__ __forceinline__ void flow_publish(unsigned* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // 64 x 64 tile (column-major, leading dimension ld, `rows` x `cols` valid, the rest reads as zero): thread = (row, 4
 // interleaved column sets) so that every wave instruction reads 512 contiguous bytes; LDS image [column][row], pitch LP
@@ -1041,17 +1072,17 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
   auto tile_rows = [&](int ti) { return a.nr - 64 * ti < 64 ? a.nr - 64 * ti : 64; };
   auto tile_src = [&](int ti, int tk) { return A + (size_t)(64 * tk) * lda + 64 * ti; };
 
-  if (bid < a.ntr) {
-    // ------------------------------------------------------------ diagonal workgroup j
-    const int j = bid;
+  const int n_acc = a.ntr > 2 ? a.ntr - 2 : 0;  // accumulator workgroups: tile rows 2 .. ntr - 1
+  double* const hand = a.hand;                  // [ntr][2][4096]: accumulators of (j, j-1) and (j, j), thread-major
+  if (bid >= 1 && bid <= n_acc) {
+    // ------------------------------------------------------------ accumulator workgroup of tile row j = bid + 1:
+    // -A + sum_{k <= j-2} for the tiles (j, j-1) and (j, j), then handed to the chain workgroup
+    const int j = bid + 1;
     const bool has_diag = j < a.nb;
-    const int kb = has_diag ? (a.n - 64 * j < 64 ? a.n - 64 * j : 64) : 0;
     double4_t accP[4], accD[4];
     {  // only tiles this workgroup owns are ever read with plain loads
       double v[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
-      if (j > 0) load_orig(j, j - 1, v);
+      load_orig(j, j - 1, v);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) accP[ks >> 2][ks & 3] = -v[ks];
 #pragma unroll
@@ -1061,95 +1092,201 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       for (int ks = 0; ks < 16; ++ks) accD[ks >> 2][ks & 3] = -v[ks];
     }
     const int ja_end = wv + 1;  // lower part of the diagonal tile: columns 16 ja .. <= rows 16 wv ..
-    FLOW_STAMP(j, 0);
-    if (j >= 2) {
-      double va[16], vb[16], xi[16];
-      for (int k = 0; k <= j - 2; ++k) {
-        flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j);
-        flow_fetch(tile_src(j - 1, k), lda, 64, 64, va);
-        flow_wait(a.tf + (size_t)j * a.nb + k, a, j);
-        flow_fetch(tile_src(j, k), lda, tile_rows(j), 64, vb);
-        __syncthreads();  // previous step's MFMA reads of buf0 / buf1 are done
-        flow_put(buf0, va);
-        flow_put(buf1, vb);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) xi[ks] = buf1[(4 * ks + q) * LP + 16 * wv + m];
-        flow_update(accP, buf0, xi, 4, lane);
-        if (has_diag) flow_update(accD, buf1, xi, ja_end, lane);
-      }
-    }
-    FLOW_STAMP(j, 1);
-    Potf2Lds& sh = *reinterpret_cast<Potf2Lds*>(flow_lds);
-    static_assert(sizeof(Potf2Lds) + 64 * sizeof(double) <= (size_t)kFlowLdsBytes, "diagonal role must fit the LDS request");
-    double* ex = reinterpret_cast<double*>(flow_lds + sizeof(Potf2Lds));  // the extra (right-hand-side) row of the tile
-    if (j >= 1) {
-      double x[16];
-      {
-        double mv[16];
-        flow_wait(a.mf + (j - 1), a, j);
-        FLOW_STAMP(j, 2);
-        flow_fetch(a.dinv + (size_t)(j - 1) * (NBI * NBI), NBI, 64, 64, mv);
-        __syncthreads();
-        flow_put(buf2, mv);
-      }
+    double va[16], vb[16], xi[16];
+    for (int k = 0; k <= j - 2; ++k) {
+      flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j, k == j - 2 ? kChainArrivals : kFlowArrivals);  // (j-1, j-2): the chain's
+      flow_fetch(tile_src(j - 1, k), lda, 64, 64, va);
+      flow_wait(a.tf + (size_t)j * a.nb + k, a, j);
+      flow_fetch(tile_src(j, k), lda, tile_rows(j), 64, vb);
+      __syncthreads();  // previous step's MFMA reads of buf0 / buf1 are done
+      flow_put(buf0, va);
+      flow_put(buf1, vb);
       __syncthreads();
-      FLOW_STAMP(j, 3);
-      flow_trsm(buf2, accP, x, lane);
-      store_rows(j, j - 1, x);
-      FLOW_STAMP(j, 4);
-      if (has_diag) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) buf0[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
+      for (int ks = 0; ks < 16; ++ks) xi[ks] = buf1[(4 * ks + q) * LP + 16 * wv + m];
+      flow_update(accP, buf0, xi, 4, lane);
+      if (has_diag) flow_update(accD, buf1, xi, ja_end, lane);
+    }
+    double* hp = hand + (size_t)j * 8192 + 2 * tid;  // element ks of thread tid at (ks >> 1) * 512 + 2 * tid + (ks & 1)
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 2) {
+      st_sc1_x2(hp + 256 * ks, accP[ks >> 2][ks & 3], accP[(ks + 1) >> 2][(ks + 1) & 3]);
+      if (has_diag) st_sc1_x2(hp + 4096 + 256 * ks, accD[ks >> 2][ks & 3], accD[(ks + 1) >> 2][(ks + 1) & 3]);
+    }
+    flow_arrive(a.hf + j);
+    return;
+  }
+  if (bid == 0) {
+    // ------------------------------------------------------------ the chain: every diagonal block, one after the other
+    // step j:  X = (j, j-1) M_{j-1}^T with M_{j-1} still in LDS from the step before;  (j, j) -= X X^T;  potf2 + inverse.
+    // What the step needs from outside -- the two accumulator tiles of row j -- is requested in the middle of the
+    // previous step's potf2 (they are ready by then) and lands while that potf2 finishes.
+    Potf2Lds& sh = *reinterpret_cast<Potf2Lds*>(flow_lds);
+    static_assert(sizeof(Potf2Lds) + 64 * sizeof(double) + NBI * LP * sizeof(double) <= (size_t)kFlowLdsBytes,
+                  "chain role: Potf2Lds + the extra row + one staging tile");
+    double* ex = reinterpret_cast<double*>(flow_lds + sizeof(Potf2Lds));  // the extra (right-hand-side) row of the tile
+    double* xs = ex + 64;                                                 // X staged as [k][row], pitch LP
+    const int ja_end = wv + 1;
+    double nP[16], nD[16];  // accumulators of the NEXT step, in flight
+    bool have_next = false;
+    auto request = [&](int jn) {  // jn >= 2: from the accumulator workgroup; jn < 2: the matrix itself
+      if (jn >= 2) {
+        const double* hp = hand + (size_t)jn * 8192 + 2 * tid;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          nP[ks] = ld_sc1(hp + 256 * (ks & ~1) + (ks & 1));
+          nD[ks] = ld_sc1(hp + 4096 + 256 * (ks & ~1) + (ks & 1));
+        }
+      } else {
+        double v[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) nP[ks] = 0.0;
+        if (jn == 1) {
+          load_orig(1, 0, v);
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) nP[ks] = -v[ks];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
+        if (jn < a.nb) load_orig(jn, jn, v);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) nD[ks] = -v[ks];
+      }
+    };
+    bool m_pending = false;  // M_{j-1} is stored but its flag is not up yet
+    for (int j = 0; j < a.ntr; ++j) {
+      const bool has_diag = j < a.nb;
+      const int kb = has_diag ? (a.n - 64 * j < 64 ? a.n - 64 * j : 64) : 0;
+      FLOW_STAMP(j, 0);
+      if (!have_next) {
+        if (j >= 2) flow_wait(a.hf + j, a, j);
+        request(j);
+      }
+      have_next = false;
+      double4_t accP[4], accD[4];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        accP[ks >> 2][ks & 3] = nP[ks];
+        accD[ks >> 2][ks & 3] = nD[ks];
+      }
+      FLOW_STAMP(j, 1);
+      if (j >= 1) {
+        double x[16];
+        FLOW_STAMP(j, 3);
+        flow_trsm(sh.Ms, accP, x, lane);  // M_{j-1}: lower part from potf2_invert_lds, zeros above
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xs[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
         __syncthreads();
-        flow_update(accD, buf0, x, ja_end, lane);
-      }
-      flow_publish(a.tf + (size_t)j * a.nb + (j - 1));  // (contains the barrier that frees buf0 / buf2)
-    }
-    if (!has_diag) return;
-    __syncthreads();
-    FLOW_STAMP(j, 5);
-    // D = A_jj - S into sh.As (lower part, identity padding); the tile's row past the block (the right-hand side) aside
-    if (tid == 0) sh.bad = 0;
-    {
-      const int row = 16 * wv + m;
+        FLOW_STAMP(j, 4);
+        if (wv != 0) {  // X rows to their place (waves 1..3), two rows per lane: 32 lanes x 16 bytes = a 512-byte column
+          const int t3 = tid - 64, rp = t3 & 31, row = 64 * j + 2 * rp;
+          double v0[11], v1[11];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {  // every (row, col) of the 64 x 64 block is written by exactly one lane
-        const int col = 4 * ks + q;
-        const double d = -accD[ks >> 2][ks & 3];  // meaningful for col <= row (the waves skip the upper tiles)
-        double v = (row == col) ? 1.0 : 0.0;
-        if (row < kb && col < kb) v = col <= row ? d : 0.0;
-        sh.As[col * LP + row] = v;
-        if (row == kb && col < kb) ex[col] = d;
-      }
+          for (int e = 0; e < 11; ++e) {  // 6 half-wave column slots, 64 columns: 11 rounds (the last one partial)
+            const int col = (t3 >> 5) + 6 * e;
+            v0[e] = col < 64 ? xs[col * LP + 2 * rp] : 0.0;
+            v1[e] = col < 64 ? xs[col * LP + 2 * rp + 1] : 0.0;
+          }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int idx = tid + 256 * e;
-        sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
+          for (int e = 0; e < 11; ++e) {
+            const int col = (t3 >> 5) + 6 * e;
+            double* dst = A + (size_t)(64 * (j - 1) + col) * lda + row;
+            if (col < 64) {
+              if (row + 1 < a.nr) st_sc1_x2(dst, v0[e], v1[e]);
+              else if (row < a.nr) st_sc1(dst, v0[e]);
+            }
+          }
+        }
+        if (has_diag) flow_update(accD, xs, x, ja_end, lane);
       }
-    }
-    __syncthreads();
-    potf2_inv_lds(sh);
-    FLOW_STAMP(j, 6);
-    if (tid == 0 && sh.bad) atomicMax(a.info, 64 * j + 1);
-    double* Minv = a.dinv + (size_t)j * (NBI * NBI);
+      if (!has_diag) {  // the right-hand-side-only tile row: nothing to factor
+        if (wv != 0) {
+          flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
+          if (m_pending) flow_arrive(a.mf + (j - 1));
+        }
+        m_pending = false;
+        break;
+      }
+      FLOW_STAMP(j, 5);
+      // D = A_jj - S into sh.As (lower part, identity padding); the tile's row past the block (the right-hand side) aside
+      if (tid == 0) sh.bad = 0;
+      {
+        const int row = 16 * wv + m;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = tid + 256 * e, c = idx >> 6, r = idx & 63;
-      if (r < kb && c < kb && c <= r) A[(size_t)(64 * j + c) * lda + 64 * j + r] = sh.As[c * LP + r];
-      st_sc1(Minv + idx, (c <= r) ? sh.Ms[c * LP + r] : 0.0);
+        for (int ks = 0; ks < 16; ++ks) {  // every (row, col) of the 64 x 64 block is written by exactly one lane
+          const int col = 4 * ks + q;
+          const double d = -accD[ks >> 2][ks & 3];  // meaningful for col <= row (the waves skip the upper tiles)
+          double v = (row == col) ? 1.0 : 0.0;
+          if (row < kb && col < kb) v = col <= row ? d : 0.0;
+          sh.As[col * LP + row] = v;
+          if (row == kb && col < kb) ex[col] = d;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int idx = tid + 256 * e;
+          sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
+        }
+      }
+      __syncthreads();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
+      // The X rows of this step and M_{j-1} / L_{j-1,j-1} of the last one: the waves 1..3, which stored them, confirm their
+      // stores and arrive while they would otherwise idle behind wave 0's first pivots.
+      const bool m_was_pending = m_pending;
+      potf2_factor_lds(sh, [&] {
+        if (j >= 1) {
+          flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
+          if (m_was_pending) flow_arrive(a.mf + (j - 1));
+        }
+      });
+      m_pending = false;
+      // the next step's accumulators: ask for them now if their owner is done (it normally is), else after the inversion
+      if (j + 1 < a.ntr) {
+        const bool ready = j + 1 < 2 || __hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kFlowArrivals;
+        if (ready) {
+          asm volatile("" ::: "memory");
+          request(j + 1);
+          have_next = true;
+        }
+      }
+      potf2_invert_lds(sh);
+      FLOW_STAMP(j, 6);
+      if (tid == 0 && sh.bad) atomicMax(a.info, 64 * j + 1);
+      double* Minv = a.dinv + (size_t)j * (NBI * NBI);
+      if (wv != 0) {  // M_j and L_jj leave through the waves 1..3: every LDS read first, then the stores
+        const int t3 = tid - 64;
+        double m0[11], m1[11], l0[11], l1[11];
+#pragma unroll
+        for (int e = 0; e < 11; ++e) {  // 2048 row pairs over 192 lanes
+          const int idx = t3 + 192 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
+          m0[e] = sh.Ms[c * LP + r];
+          m1[e] = sh.Ms[c * LP + r + 1];
+          l0[e] = sh.As[c * LP + r];
+          l1[e] = sh.As[c * LP + r + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 11; ++e) {
+          const int idx = t3 + 192 * e, c = idx >> 5, r = 2 * (idx & 31);
+          if (idx < 2048) {
+            st_sc1_x2(Minv + c * NBI + r, (c <= r) ? m0[e] : 0.0, (c <= r + 1) ? m1[e] : 0.0);
+            // L_jj: nobody reads it inside this launch (plain stores)
+            double* dst = A + (size_t)(64 * j + c) * lda + 64 * j + r;
+            if (c < kb && c <= r && r < kb) dst[0] = l0[e];
+            if (c < kb && c <= r + 1 && r + 1 < kb) dst[1] = l1[e];
+          }
+        }
+      }
+      m_pending = true;
+      if (64 * j + kb < a.nr && kb < 64 && tid < kb) {  // y = e M^T for the right-hand-side row inside this tile
+        double y = 0.0;
+        for (int t = 0; t <= tid; ++t) y = __builtin_fma(ex[t], sh.Ms[t * LP + tid], y);
+        A[(size_t)(64 * j + tid) * lda + 64 * j + kb] = y;
+      }
+      FLOW_STAMP(j, 7);
     }
-    flow_publish(a.mf + j);
-    FLOW_STAMP(j, 7);
-    if (64 * j + kb < a.nr && kb < 64 && tid < kb) {  // y = e M^T for the right-hand-side row inside this tile
-      double y = 0.0;
-      for (int t = 0; t <= tid; ++t) y = __builtin_fma(ex[t], sh.Ms[t * LP + tid], y);
-      A[(size_t)(64 * j + tid) * lda + 64 * j + kb] = y;
-    }
+    if (m_pending && wv != 0) flow_arrive(a.mf + (a.nb - 1));
     return;
   }
   // -------------------------------------------------------------- worker: tiles (i, j0 .. j0 + T - 1), j0 + T - 1 <= i - 2
-  int g = bid - a.ntr, i = 2, j0 = 0, T = 0;
+  int g = bid - 1 - n_acc, i = 2, j0 = 0, T = 0;
   for (;; ++i) {
     if (i >= a.ntr) return;
     const int cols = i - 1, groups = (cols + FL_MAXT - 1) / FL_MAXT;
@@ -1172,14 +1309,14 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     for (int ks = 0; ks < 16; ++ks) acc[t][ks >> 2][ks & 3] = -v[ks];
   }
   const int j1 = j0 + T - 1;
-  const int code = a.ntr + (bid - a.ntr);
+  const int code = bid;
   for (int k = 0; k <= j1; ++k) {
     double xi[16];
     if (k >= j0) {
       // own tile (i, k) has every column < k: finalise it, its X rows are this step's i-operand
       {
         double mv[16];
-        flow_wait(a.mf + k, a, code);
+        flow_wait(a.mf + k, a, code, kChainArrivals);
         flow_fetch(a.dinv + (size_t)k * (NBI * NBI), NBI, 64, 64, mv);
         __syncthreads();
         flow_put(buf2, mv);
@@ -1189,7 +1326,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       for (int t = 0; t < FL_MAXT; ++t)
         if (t == k - j0) flow_trsm(buf2, acc[t], xi, lane);
       store_rows(i, k, xi);
-      flow_publish(a.tf + (size_t)i * a.nb + k);
+      flow_arrive(a.tf + (size_t)i * a.nb + k);
     } else {
       flow_wait(a.tf + (size_t)i * a.nb + k, a, code);
       load_rows(i, k, xi);
@@ -1199,7 +1336,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     const int t_begin = k + 1 - j0 > 0 ? k + 1 - j0 : 0;
     double v[16];
     if (t_begin < T) {
-      flow_wait(a.tf + (size_t)(j0 + t_begin) * a.nb + k, a, code);
+      flow_wait(a.tf + (size_t)(j0 + t_begin) * a.nb + k, a, code, j0 + t_begin == k + 1 ? kChainArrivals : kFlowArrivals);
       flow_fetch(tile_src(j0 + t_begin, k), lda, 64, 64, v);
     }
 #pragma unroll
@@ -1209,7 +1346,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         flow_put(buf, v);
         __syncthreads();
         if (t + 1 < T) {
-          flow_wait(a.tf + (size_t)(j0 + t + 1) * a.nb + k, a, code);
+          flow_wait(a.tf + (size_t)(j0 + t + 1) * a.nb + k, a, code, j0 + t + 1 == k + 1 ? kChainArrivals : kFlowArrivals);
           flow_fetch(tile_src(j0 + t + 1, k), lda, 64, 64, v);
         }
         flow_update(acc[t], buf, xi, 4, lane);
@@ -1331,7 +1468,7 @@ static int flow_groups(const gh_ctx* ctx, int n, int extra_rows) {
   for (int i = 2; i < ntr; ++i) groups += gh_div_up(i - 1, FL_MAXT);
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
   (void)nb;
-  return ntr + groups <= cus ? groups : -1;
+  return 1 + (ntr > 2 ? ntr - 2 : 0) + groups <= cus ? groups : -1;  // chain + accumulator workgroups + workers
 }
 
 // Two dataflow launches in flight on one GPU could each hold part of the CUs and wait for the rest for ever (until their
@@ -1341,11 +1478,13 @@ std::mutex& gh_potrf_flow_mutex() {
   return mu;
 }
 
+static size_t flow_flag_words(size_t nb, size_t ntr) { return (ntr * nb + nb + ntr + 16 + 31) & ~(size_t)31; }
+
 // u32 words of device state the dataflow launch needs (tile flags, block flags, abort word), 0 = shape not eligible
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows) {
   if (flow_groups(ctx, n, extra_rows) < 0) return 0;
   const size_t nb = (size_t)gh_div_up(n, NBI), ntr = (size_t)gh_div_up(n + extra_rows, NBI);
-  return ntr * nb + nb + 16;
+  return flow_flag_words(nb, ntr) + ntr * 8192 * 2;  // flags, then the hand-over tiles (doubles)
 }
 
 // Factor (lower, in place) and optionally solve.  info_dev: device int (0 = ok, else first bad block column + 1).
@@ -1383,10 +1522,14 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       fa.dinv = dinv;
       fa.tf = flow_state;
       fa.mf = flow_state + (size_t)fa.ntr * fa.nb;
-      fa.abort_word = fa.mf + fa.nb;
+      fa.hf = fa.mf + fa.nb;
+      fa.abort_word = fa.hf + fa.ntr;
+      const size_t flag_words = flow_flag_words((size_t)fa.nb, (size_t)fa.ntr);
+      fa.hand = reinterpret_cast<double*>(flow_state + flag_words);
       fa.info = info_dev;
-      GH_HIP(ctx, hipMemsetAsync(flow_state, 0, ((size_t)fa.ntr * fa.nb + fa.nb + 16) * sizeof(unsigned), ctx->stream));
-      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(fa.ntr + groups), dim3(256), kFlowLdsBytes, fa);
+      GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
+      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 2 ? fa.ntr - 2 : 0) + groups), dim3(256),
+                kFlowLdsBytes, fa);
       return GH_OK;
     }
   }

@@ -48,22 +48,22 @@ int main(int argc, char** argv) {
     if (rep < 2) continue;
     auto us = [](long long d) { return d * 0.01; };
     const long long t0 = st[0];
+    printf("  j    wait   trsm    upd+pub  potf2  stores   T_j      step   (us; wait = for the row's accumulators)\n");
     double sum[6] = {0, 0, 0, 0, 0, 0};
-    printf("  j   start  acc_done  slack   Mfetch   trsm   upd+pub  potf2  pubM   T_j      step\n");
     for (int j = 0; j < nb; ++j) {
       const long long* s = &st[j * 8];
       const double step = j ? us(s[7] - st[(j - 1) * 8 + 7]) : us(s[7] - t0);
       if (j >= 1) {
-        printf("%3d %7.1f %8.1f %7.1f %7.2f %7.2f %7.2f %7.2f %6.2f %8.1f %7.2f\n", j, us(s[0] - t0), us(s[1] - t0), us(s[2] - s[1]),
-               us(s[3] - s[2]), us(s[4] - s[3]), us(s[5] - s[4]), us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
-        if (j >= 2) { sum[0] += us(s[3] - s[2]); sum[1] += us(s[4] - s[3]); sum[2] += us(s[5] - s[4]); sum[3] += us(s[6] - s[5]); sum[4] += us(s[7] - s[6]); sum[5] += step; }
+        printf("%3d %7.2f %7.2f %7.2f %7.2f %6.2f %8.1f %7.2f\n", j, us(s[1] - s[0]), us(s[4] - s[3]), us(s[5] - s[4]),
+               us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
+        if (j >= 2) { sum[0] += us(s[1] - s[0]); sum[1] += us(s[4] - s[3]); sum[2] += us(s[5] - s[4]); sum[3] += us(s[6] - s[5]); sum[4] += us(s[7] - s[6]); sum[5] += step; }
       } else {
-        printf("%3d %7.1f %8.1f    -        -       -       -    %7.2f %6.2f %8.1f %7.2f\n", j, us(s[0] - t0), us(s[1] - t0), us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
+        printf("%3d %7.2f    -       -    %7.2f %6.2f %8.1f %7.2f\n", j, us(s[1] - s[0]), us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
       }
     }
     const int cnt = nb - 2;
     if (cnt > 0)
-      printf("mean over j >= 2: Mfetch %.2f trsm %.2f upd+pub %.2f potf2 %.2f pubM %.2f step %.2f us\n", sum[0] / cnt, sum[1] / cnt,
+      printf("mean over j >= 2: wait %.2f trsm %.2f upd+pub %.2f potf2 %.2f stores %.2f step %.2f us\n", sum[0] / cnt, sum[1] / cnt,
              sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt);
   }
   return 0;
