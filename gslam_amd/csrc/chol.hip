@@ -801,6 +801,9 @@ __global__ __launch_bounds__(256) void bwd_step_inv_kernel(const double* __restr
       mreg[2 * e] = v2.x;
       mreg[2 * e + 1] = v2.y;
     }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj)  // only the lower triangle of a dinv block is defined
+      if (lane > 16 * wv + jj) mreg[jj] = 0.0;
   }
   const double yv = lane < kb ? w[k0 + lane] : 0.0;
   double v[16];
@@ -855,6 +858,9 @@ __global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __rest
       mA[2 * e] = a2.x; mA[2 * e + 1] = a2.y;
       mB[2 * e] = b2.x; mB[2 * e + 1] = b2.y;
     }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj)  // only the lower triangle of a dinv block is defined
+      if (lane > 16 * wv + jj) mA[jj] = mB[jj] = 0.0;
     // L[kA0 + r][kB0 + lane] for r in [16 wv, 16 wv + 16): 128 contiguous bytes of column kB0 + lane
     const double* col = A + (size_t)(kB0 + lane) * lda + kA0 + 16 * wv;
 #pragma unroll
@@ -939,6 +945,7 @@ struct FlowArgs {
   double* A;
   int lda, n, nr, nb, ntr;  // nb column blocks, ntr tile rows (ntr = nb, or nb + 1 when the extra row starts a tile row)
   int n_groups;             // worker workgroups
+  int store_diag;           // write the diagonal blocks of L too (nobody inside the launch reads them)
   double* dinv;
   unsigned* tf;             // [ntr][nb]  tile (i, k) of L is final in A
   unsigned* mf;             // [nb]       M_k is final in dinv
@@ -1001,6 +1008,16 @@ __device__ __forceinline__ void flow_fetch(const double* src, size_t ld, int row
   for (int e = 0; e < 16; ++e) {
     const char* base = reinterpret_cast<const char*>(src + (size_t)(4 * e) * ld);
     v[e] = (row < rows && cq + 4 * e < cols) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
+  }
+}
+// M_k from dinv (pitch 64): only its lower triangle is ever stored by the dataflow launch; the rest reads as zero
+__device__ __forceinline__ void flow_fetch_lower(const double* src, double (&v)[16]) {
+  const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  const unsigned off = (unsigned)(cq * NBI + row) * 8u;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const char* base = reinterpret_cast<const char*>(src + (size_t)(4 * e) * NBI);
+    v[e] = (cq + 4 * e <= row) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
   }
 }
 __device__ __forceinline__ void flow_put(double* buf, const double (&v)[16]) {
@@ -1072,12 +1089,14 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
   auto tile_rows = [&](int ti) { return a.nr - 64 * ti < 64 ? a.nr - 64 * ti : 64; };
   auto tile_src = [&](int ti, int tk) { return A + (size_t)(64 * tk) * lda + 64 * ti; };
 
-  const int n_acc = a.ntr > 2 ? a.ntr - 2 : 0;  // accumulator workgroups: tile rows 2 .. ntr - 1
+  const int n_acc = a.ntr > 1 ? a.ntr - 1 : 0;  // accumulator workgroups: tile rows 1 .. ntr - 1
   double* const hand = a.hand;                  // [ntr][2][4096]: accumulators of (j, j-1) and (j, j), thread-major
   if (bid >= 1 && bid <= n_acc) {
-    // ------------------------------------------------------------ accumulator workgroup of tile row j = bid + 1:
-    // -A + sum_{k <= j-2} for the tiles (j, j-1) and (j, j), then handed to the chain workgroup
-    const int j = bid + 1;
+    // ------------------------------------------------------------ accumulator workgroup of tile row j = bid:
+    // -A + sum_{k <= j-2} for the tiles (j, j-1) and (j, j), handed to the chain workgroup; then, with M_{j-1}, the
+    // same X = (j, j-1) M_{j-1}^T the chain computes for itself, written to its place in L: the chain workgroup, whose
+    // path to memory is on the critical chain (a CU drains write-through stores at ~20 GB/s), stores nothing but M_j
+    const int j = bid;
     const bool has_diag = j < a.nb;
     double4_t accP[4], accD[4];
     {  // only tiles this workgroup owns are ever read with plain loads
@@ -1114,6 +1133,17 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       if (has_diag) st_sc1_x2(hp + 4096 + 256 * ks, accD[ks >> 2][ks & 3], accD[(ks + 1) >> 2][(ks + 1) & 3]);
     }
     flow_arrive(a.hf + j);
+    {
+      double mv[16], x[16];
+      flow_wait(a.mf + (j - 1), a, j, kChainArrivals);
+      flow_fetch_lower(a.dinv + (size_t)(j - 1) * (NBI * NBI), mv);
+      __syncthreads();
+      flow_put(buf2, mv);
+      __syncthreads();
+      flow_trsm(buf2, accP, x, lane);
+      store_rows(j, j - 1, x);
+      flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
+    }
     return;
   }
   if (bid == 0) {
@@ -1129,8 +1159,8 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     const int ja_end = wv + 1;
     double nP[16], nD[16];  // accumulators of the NEXT step, in flight
     bool have_next = false;
-    auto request = [&](int jn) {  // jn >= 2: from the accumulator workgroup; jn < 2: the matrix itself
-      if (jn >= 2) {
+    auto request = [&](int jn) {  // jn >= 1: from the accumulator workgroup; block 0: the matrix itself
+      if (jn >= 1) {
         const double* hp = hand + (size_t)jn * 8192 + 2 * tid;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -1139,18 +1169,12 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         }
       } else {
         double v[16];
+        load_orig(0, 0, v);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) nP[ks] = 0.0;
-        if (jn == 1) {
-          load_orig(1, 0, v);
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) nP[ks] = -v[ks];
+        for (int ks = 0; ks < 16; ++ks) {
+          nP[ks] = 0.0;
+          nD[ks] = -v[ks];
         }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
-        if (jn < a.nb) load_orig(jn, jn, v);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) nD[ks] = -v[ks];
       }
     };
     bool m_pending = false;  // M_{j-1} is stored but its flag is not up yet
@@ -1159,7 +1183,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       const int kb = has_diag ? (a.n - 64 * j < 64 ? a.n - 64 * j : 64) : 0;
       FLOW_STAMP(j, 0);
       if (!have_next) {
-        if (j >= 2) flow_wait(a.hf + j, a, j);
+        if (j >= 1) flow_wait(a.hf + j, a, j);
         request(j);
       }
       have_next = false;
@@ -1170,7 +1194,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         accD[ks >> 2][ks & 3] = nD[ks];
       }
       FLOW_STAMP(j, 1);
-      if (j >= 1) {
+      if (j >= 1 && has_diag) {
         double x[16];
         FLOW_STAMP(j, 3);
         flow_trsm(sh.Ms, accP, x, lane);  // M_{j-1}: lower part from potf2_invert_lds, zeros above
@@ -1178,32 +1202,10 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         for (int ks = 0; ks < 16; ++ks) xs[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
         __syncthreads();
         FLOW_STAMP(j, 4);
-        if (wv != 0) {  // X rows to their place (waves 1..3), two rows per lane: 32 lanes x 16 bytes = a 512-byte column
-          const int t3 = tid - 64, rp = t3 & 31, row = 64 * j + 2 * rp;
-          double v0[11], v1[11];
-#pragma unroll
-          for (int e = 0; e < 11; ++e) {  // 6 half-wave column slots, 64 columns: 11 rounds (the last one partial)
-            const int col = (t3 >> 5) + 6 * e;
-            v0[e] = col < 64 ? xs[col * LP + 2 * rp] : 0.0;
-            v1[e] = col < 64 ? xs[col * LP + 2 * rp + 1] : 0.0;
-          }
-#pragma unroll
-          for (int e = 0; e < 11; ++e) {
-            const int col = (t3 >> 5) + 6 * e;
-            double* dst = A + (size_t)(64 * (j - 1) + col) * lda + row;
-            if (col < 64) {
-              if (row + 1 < a.nr) st_sc1_x2(dst, v0[e], v1[e]);
-              else if (row < a.nr) st_sc1(dst, v0[e]);
-            }
-          }
-        }
-        if (has_diag) flow_update(accD, xs, x, ja_end, lane);
+        flow_update(accD, xs, x, ja_end, lane);
       }
-      if (!has_diag) {  // the right-hand-side-only tile row: nothing to factor
-        if (wv != 0) {
-          flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
-          if (m_pending) flow_arrive(a.mf + (j - 1));
-        }
+      if (!has_diag) {  // the right-hand-side-only tile row: nothing to factor (its accumulator workgroup writes X)
+        if (wv != 0 && m_pending) flow_arrive(a.mf + (j - 1));
         m_pending = false;
         break;
       }
@@ -1228,19 +1230,16 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         }
       }
       __syncthreads();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
-      // The X rows of this step and M_{j-1} / L_{j-1,j-1} of the last one: the waves 1..3, which stored them, confirm their
-      // stores and arrive while they would otherwise idle behind wave 0's first pivots.
+      // M_{j-1} (and L_{j-1,j-1}) of the last step: the waves 1..3, which stored them, confirm their stores and arrive
+      // while they would otherwise idle behind wave 0's first pivots.
       const bool m_was_pending = m_pending;
       potf2_factor_lds(sh, [&] {
-        if (j >= 1) {
-          flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
-          if (m_was_pending) flow_arrive(a.mf + (j - 1));
-        }
+        if (m_was_pending) flow_arrive(a.mf + (j - 1));
       });
       m_pending = false;
       // the next step's accumulators: ask for them now if their owner is done (it normally is), else after the inversion
       if (j + 1 < a.ntr) {
-        const bool ready = j + 1 < 2 || __hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kFlowArrivals;
+        const bool ready = __hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kFlowArrivals;
         if (ready) {
           asm volatile("" ::: "memory");
           request(j + 1);
@@ -1251,26 +1250,35 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       FLOW_STAMP(j, 6);
       if (tid == 0 && sh.bad) atomicMax(a.info, 64 * j + 1);
       double* Minv = a.dinv + (size_t)j * (NBI * NBI);
-      if (wv != 0) {  // M_j and L_jj leave through the waves 1..3: every LDS read first, then the stores
+      if (wv != 0) {  // M_j (lower triangle only) and, if asked for, L_jj leave through the waves 1..3
         const int t3 = tid - 64;
-        double m0[11], m1[11], l0[11], l1[11];
+        double m0[11], m1[11];
 #pragma unroll
-        for (int e = 0; e < 11; ++e) {  // 2048 row pairs over 192 lanes
+        for (int e = 0; e < 11; ++e) {  // 2048 row pairs over 192 lanes; every LDS read first, then the stores
           const int idx = t3 + 192 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
           m0[e] = sh.Ms[c * LP + r];
           m1[e] = sh.Ms[c * LP + r + 1];
-          l0[e] = sh.As[c * LP + r];
-          l1[e] = sh.As[c * LP + r + 1];
         }
 #pragma unroll
         for (int e = 0; e < 11; ++e) {
           const int idx = t3 + 192 * e, c = idx >> 5, r = 2 * (idx & 31);
-          if (idx < 2048) {
-            st_sc1_x2(Minv + c * NBI + r, (c <= r) ? m0[e] : 0.0, (c <= r + 1) ? m1[e] : 0.0);
-            // L_jj: nobody reads it inside this launch (plain stores)
-            double* dst = A + (size_t)(64 * j + c) * lda + 64 * j + r;
-            if (c < kb && c <= r && r < kb) dst[0] = l0[e];
-            if (c < kb && c <= r + 1 && r + 1 < kb) dst[1] = l1[e];
+          if (idx < 2048 && c <= r + 1) st_sc1_x2(Minv + c * NBI + r, (c <= r) ? m0[e] : 0.0, m1[e]);
+        }
+        if (a.store_diag) {  // nobody reads L_jj inside this launch (plain stores)
+#pragma unroll
+          for (int e = 0; e < 11; ++e) {
+            const int idx = t3 + 192 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
+            m0[e] = sh.As[c * LP + r];
+            m1[e] = sh.As[c * LP + r + 1];
+          }
+#pragma unroll
+          for (int e = 0; e < 11; ++e) {
+            const int idx = t3 + 192 * e, c = idx >> 5, r = 2 * (idx & 31);
+            if (idx < 2048) {
+              double* dst = A + (size_t)(64 * j + c) * lda + 64 * j + r;
+              if (c < kb && c <= r && r < kb) dst[0] = m0[e];
+              if (c < kb && c <= r + 1 && r + 1 < kb) dst[1] = m1[e];
+            }
           }
         }
       }
@@ -1317,7 +1325,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       {
         double mv[16];
         flow_wait(a.mf + k, a, code, kChainArrivals);
-        flow_fetch(a.dinv + (size_t)k * (NBI * NBI), NBI, 64, 64, mv);
+        flow_fetch_lower(a.dinv + (size_t)k * (NBI * NBI), mv);
         __syncthreads();
         flow_put(buf2, mv);
       }
@@ -1394,6 +1402,9 @@ __global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict
       mreg[2 * e] = v2.x;
       mreg[2 * e + 1] = v2.y;
     }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj)  // only the lower triangle of a dinv block is defined
+      if (lane > 16 * wv + jj) mreg[jj] = 0.0;
   }
   const double yc = lane < kb ? yv[(size_t)(c0 + lane) * ystride] : 0.0;
   // tile (j, c), this thread: column c0 + lane, rows j0 + 16 wv .. + 15 (128 contiguous bytes); rows >= n read as zero
@@ -1468,7 +1479,7 @@ static int flow_groups(const gh_ctx* ctx, int n, int extra_rows) {
   for (int i = 2; i < ntr; ++i) groups += gh_div_up(i - 1, FL_MAXT);
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
   (void)nb;
-  return 1 + (ntr > 2 ? ntr - 2 : 0) + groups <= cus ? groups : -1;  // chain + accumulator workgroups + workers
+  return 1 + (ntr > 1 ? ntr - 1 : 0) + groups <= cus ? groups : -1;  // chain + accumulator workgroups + workers
 }
 
 // Two dataflow launches in flight on one GPU could each hold part of the CUs and wait for the rest for ever (until their
@@ -1494,9 +1505,11 @@ size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows) {
 // `xwork`: optional 2 * 64 * (n + extra_rows) doubles; when given, full panel steps of the small-matrix regime run as one
 // launch each (panel_step_kernel) with their X rows parked there until a later launch copies them home.
 // `flow_state`: optional gh_potrf_flow_words() u32 words; when given (and GSLAM_HIP_CHOL_FLOW != 0) the whole factorisation
-// is the single dataflow launch (potrf_flow_kernel).
+// is the single dataflow launch (potrf_flow_kernel); `store_diag` = false lets it leave the diagonal blocks of L unwritten
+// (a caller that only solves never reads them: the triangular solves use `dinv`).
+// `dinv`: only the lower triangle of each block is defined -- every reader masks the rest.
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
-                            double* xwork, unsigned* flow_state) {
+                            double* xwork, unsigned* flow_state, bool store_diag) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
   GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   {
@@ -1519,6 +1532,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       fa.nb = gh_div_up(n, NBI);
       fa.ntr = gh_div_up(nr, NBI);
       fa.n_groups = groups;
+      fa.store_diag = store_diag ? 1 : 0;
       fa.dinv = dinv;
       fa.tf = flow_state;
       fa.mf = flow_state + (size_t)fa.ntr * fa.nb;
@@ -1528,7 +1542,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       fa.hand = reinterpret_cast<double*>(flow_state + flag_words);
       fa.info = info_dev;
       GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
-      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 2 ? fa.ntr - 2 : 0) + groups), dim3(256),
+      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 1 ? fa.ntr - 1 : 0) + groups), dim3(256),
                 kFlowLdsBytes, fa);
       return GH_OK;
     }
@@ -1665,7 +1679,7 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   {
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(), std::defer_lock);
     if (flow_state) flow_lock.lock();
-    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state));
+    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state, true));
     GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
