@@ -472,7 +472,7 @@ def main():
     # ---- BA on this GPU, outside the timed region: LM iterations / s inside gh_ba_solve.  C4 (500 cams / 50 k points /
     #      300 k observations) and, by default at N = 1, C5 (10 k cams / 1 M points / 6 M observations: the n = 60000 dense
     #      reduced-camera solve on MFMA f64), followed by a stand-alone n = 60000 solve whose residual is asserted.
-    CHOL = ("ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel", "ba_syrk_trailing", "ba_trsv_fwd", "ba_trsv_bwd",
+    CHOL = ("ba_potrf_flow", "ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel", "ba_syrk_trailing", "ba_trsv_fwd", "ba_trsv_bwd",
             "ba_chol_fused")
 
     def ba_leg(cams, points, iters, separate_timed_run):

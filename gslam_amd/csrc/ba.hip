@@ -684,6 +684,11 @@ void build_csr(const int32_t* key, int n_items, int n_keys, std::vector<int32_t>
   for (int k = 0; k < n_items; ++k) list[fill[key[k]]++] = k;
 }
 
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
 // A few persistent host threads for the index lists below (spawning threads per solve cost more than the lists).
 class HostPool {
  public:
@@ -830,6 +835,8 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
                        const std::vector<int32_t>& clist, std::vector<int32_t>& pair_a, std::vector<int32_t>& pair_b,
                        std::vector<int32_t>& bstart, std::vector<int32_t>& bci, std::vector<int32_t>& bcj) {
   const int no = pr->n_obs;
+  const bool timing = getenv("GSLAM_HIP_BA_TIMING") != nullptr;
+  const double t0 = now_ms();
   HostPool& pool = HostPool::get();
   int nchunk = no >= 20000 ? 2 * pool.size() : 1;  // two ranges per thread: the pair count per observation varies
   if (nchunk > nc) nchunk = nc;
@@ -843,7 +850,9 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
     while (c < nc && cstart[c] < target) ++c;
     bound[t] = c;
   }
+  const double t1 = now_ms();
   pool.run(nchunk, [&](int t) { build_pair_chunk(pr, nc, bound[t], bound[t + 1], pstart, plist, pcam, cstart, clist, chunks[t]); });
+  const double t2 = now_ms();
   std::vector<size_t> po((size_t)nchunk + 1, 0), bo((size_t)nchunk + 1, 0);
   for (int t = 0; t < nchunk; ++t) {
     po[t + 1] = po[t] + chunks[t].pa.size();
@@ -855,6 +864,7 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
   bstart.resize(nb_total + 1);
   bci.resize(nb_total);
   bcj.resize(nb_total);
+  const double t3 = now_ms();
   pool.run(nchunk, [&](int t) {
     const PairChunk& c = chunks[t];
     if (!c.pa.empty()) {
@@ -868,11 +878,9 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
     }
   });
   bstart[nb_total] = (int32_t)np_total;
-}
-
-double now_ms() {
-  using namespace std::chrono;
-  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+  if (timing)
+    fprintf(stderr, "[gh_ba] pair lists: pcam %.2f, %d ranges on %d threads %.2f, allocate %.2f, gather %.2f ms\n", t1 - t0, nchunk,
+            pool.size(), t2 - t1, t3 - t2, now_ms() - t3);
 }
 
 }  // namespace
@@ -916,6 +924,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     if (t == 0) build_csr(pr->obs_point, no, np, pstart, plist);
     else build_csr(pr->obs_cam, no, nc, cstart, clist);
   });
+  const double t_csr = now_ms();
 
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant)
   std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
@@ -1041,12 +1050,13 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   };
 
   double h2[2];
+  const double t_upload = now_ms();
   GH_TRY(eval_cost(d_poses, d_pts, 0));
   h2[0] = rb->cost;
   h2[1] = rb->model;
   if (opt.verbose)
-    fprintf(stderr, "[gh_ba] setup: index lists %.2f ms (%zu Schur pairs, %d blocks), upload + first cost %.2f ms\n",
-            t_lists - t_begin, pair_a.size(), nblocks, now_ms() - t_lists);
+    fprintf(stderr, "[gh_ba] setup: index lists %.2f ms (csr %.2f; %zu Schur pairs, %d blocks), upload %.2f ms, first cost %.2f ms\n",
+            t_lists - t_begin, t_csr - t_begin, pair_a.size(), nblocks, t_upload - t_lists, now_ms() - t_upload);
   double cost = h2[0];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;
