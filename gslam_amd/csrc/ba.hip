@@ -1130,6 +1130,17 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
         break;
       }
     }
+    if (rb->info > n && (d_flow || d_xh)) {
+      // A bounded wait inside one of the single-launch kernels expired (chol.hip: the launch could not get all its
+      // workgroups resident, e.g. another process holds part of the GPU).  Nothing was decided yet: repeat this iteration
+      // on the launch-per-step path and stay on it for the rest of the solve.
+      if (opt.verbose) fprintf(stderr, "[gh_ba] it %3d: single-launch solve timed out (info %d), repeating on the launch path\n", it, rb->info);
+      d_flow = nullptr;
+      d_xh = nullptr;
+      if (fresh_lin) need_lin = true;  // (cheap, and keeps the gradient read-back of this iteration in place)
+      --it;
+      continue;
+    }
     const bool ok = rb->info == 0 && rb->bad == 0;
     double new_cost = cost, model = 0, rho = -1;
     if (ok) {

@@ -953,6 +953,7 @@ struct FlowArgs {
   double* hand;             // [ntr][2][4096]
   unsigned* abort_word;
   int* info;
+  unsigned spin_limit;      // polls before a wait gives up (kFlowSpinLimit; tests shrink it to exercise the way out)
 };
 
 __device__ __forceinline__ double ld_sc1(const double* p) {
@@ -986,7 +987,7 @@ __device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& 
   unsigned spins = 0;
   while (__hip_atomic_load((const gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
     ++spins;
-    if (spins > kFlowSpinLimit ||
+    if (spins > a.spin_limit ||
         ((spins & 63u) == 0u && __hip_atomic_load((const gu32*)a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
       if ((threadIdx.x & 63) == 0) {
         __hip_atomic_store((gu32*)a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1387,7 +1388,8 @@ constexpr unsigned kBwdSpinLimit = 1u << 21;
 __global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict__ A, int lda, int n, int nb,
                                                        const double* __restrict__ yv, long long ystride,
                                                        const double* __restrict__ dinv, double* xh,
-                                                       double* __restrict__ x_out, int* __restrict__ info) {
+                                                       double* __restrict__ x_out, int* __restrict__ info,
+                                                       unsigned spin_limit) {
   __shared__ double part[2][4][NBI];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = nb - 1 - (int)blockIdx.x, c0 = c * NBI;
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict
     const gu64* src = (const gu64*)(xh + (size_t)j * NBI + 16 * wv + (lane & 15));
     unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned spins = 0; !__all(bits != kXSentinel);) {
-      if (++spins > kBwdSpinLimit) {
+      if (++spins > spin_limit) {
         expired = true;
         break;
       }
@@ -1541,6 +1543,8 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       const size_t flag_words = flow_flag_words((size_t)fa.nb, (size_t)fa.ntr);
       fa.hand = reinterpret_cast<double*>(flow_state + flag_words);
       fa.info = info_dev;
+      fa.spin_limit = kFlowSpinLimit;
+      if (const char* e = getenv("GSLAM_HIP_FLOW_SPIN_LIMIT")) fa.spin_limit = (unsigned)strtoul(e, nullptr, 10);
       GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
       GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 1 ? fa.ntr - 1 : 0) + groups), dim3(256),
                 kFlowLdsBytes, fa);
@@ -1624,8 +1628,10 @@ gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, do
   if (xh && info_dev && chain_ok && n <= kBwdChainMaxN) {
     const int nb = gh_div_up(n, NBI);
     GH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)xh, (int)0xFFF8BEEFu, (size_t)nb * NBI * 2, ctx->stream));
+    unsigned spin_limit = kBwdSpinLimit;
+    if (const char* e = getenv("GSLAM_HIP_FLOW_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
     GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_chain_kernel, dim3(nb), dim3(256), 0, L, lda, n, nb, yv, ystride, dinv, xh, b,
-              info_dev);
+              info_dev, spin_limit);
     return GH_OK;
   }
   if (yv != work || ystride != 1)

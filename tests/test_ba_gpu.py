@@ -173,6 +173,29 @@ def test_ba_single_launch_factorisation_against_the_launch_path(ctx, cams, monke
     assert np.abs(p1 - p0).max() <= 1e-8 and np.abs(x1 - x0).max() <= 1e-8  # eight LM iterations amplify the rounding
 
 
+def test_single_launch_kernels_give_up_instead_of_hanging(ctx, monkeypatch):
+    """Every wait inside the single-launch factorisation / back-substitution is bounded.  With the bound shrunk to one poll
+    the waits expire: the stand-alone solve reports it (info > n), and gh_ba_solve repeats the iteration on the
+    launch-per-step path -- same iterates as with the single-launch kernels switched off."""
+    from gslam_amd import ba
+    n = 640
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((n, 96))
+    A = M @ M.T / 96.0 + 2.0 * np.eye(n)
+    g = make_graph(100, 4000, n_obs_per_point=4, seed=9)
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "0")
+    monkeypatch.setenv("GSLAM_HIP_BWD_CHAIN", "0")
+    p0, x0, s0, _ = ba.solve(ctx, g, ba.default_options(max_iterations=6, deterministic=1))
+    monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "1")
+    monkeypatch.setenv("GSLAM_HIP_BWD_CHAIN", "1")
+    monkeypatch.setenv("GSLAM_HIP_FLOW_SPIN_LIMIT", "1")
+    _, _, info = ba.potrf_solve(ctx, A, rng.standard_normal(n))
+    assert info > n
+    p1, x1, s1, _ = ba.solve(ctx, g, ba.default_options(max_iterations=6, deterministic=1))
+    assert s1.iterations == s0.iterations and s1.accepted == s0.accepted
+    assert p1.tobytes() == p0.tobytes() and x1.tobytes() == x0.tobytes()
+
+
 def test_potrf_single_launch_reports_not_positive_definite(ctx, monkeypatch):
     from gslam_amd import ba
     monkeypatch.setenv("GSLAM_HIP_CHOL_FLOW", "1")
