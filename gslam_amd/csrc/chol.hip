@@ -26,6 +26,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() (and the s_barrier builtin) make the compiler drain
+// EVERY counter first, s_waitcnt vmcnt(0) included, so a barrier in a kernel that keeps global stores or prefetch loads in
+// flight stalls until they have landed.  Inline asm is opaque to that pass.  Only between LDS producers and consumers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // tools/chol_probe.hip defines GH_CHOL_PROBE to read cycle stamps out of the single-workgroup kernels
 #ifdef GH_CHOL_PROBE
 __device__ long long g_probe[64];
@@ -35,9 +40,13 @@ __device__ long long g_probe[64];
   } while (0)
 // wall-clock stamps (100 MHz, common to all CUs) of diagonal workgroup j of potrf_flow_kernel: tools/flow_probe.hip
 __device__ long long g_flow_trace[128 * 8];
+__device__ long long g_flow_cycles[128 * 8];  // shader-clock counter at the same points: cycles / wall time = the clock
 #define FLOW_STAMP(j, e)                                                            \
   do {                                                                              \
-    if (threadIdx.x == 0 && (j) < 128) g_flow_trace[(j) * 8 + (e)] = (long long)wall_clock64(); \
+    if (threadIdx.x == 0 && (j) < 128) {                                            \
+      g_flow_trace[(j) * 8 + (e)] = (long long)wall_clock64();                      \
+      g_flow_cycles[(j) * 8 + (e)] = (long long)__builtin_readcyclecounter();       \
+    }                                                                               \
   } while (0)
 #else
 #define CHOL_STAMP(i) \
@@ -168,7 +177,7 @@ __device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle) {
       }
       if (bad) sh.bad = 1;
     }
-    __syncthreads();
+    lds_barrier();
     CHOL_STAMP(2 + k / 8);
     // (b) rank-16 update of the trailing lower triangle on MFMA: tiles (ti >= tj), round-robin over the waves
     const int nb = (NBI - (k + NBS)) / NBS;
@@ -180,7 +189,7 @@ __device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) As[(cb + m) * LP + rb + q + 4 * r] -= u[r];
     }
-    __syncthreads();
+    lds_barrier();
     CHOL_STAMP(3 + k / 8);
   }
 }
@@ -206,7 +215,7 @@ __device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
       for (int j = 0; j < NBS; ++j) Ms[(b0 + m) * LP + b0 + j] = mi[j];
     }
   }
-  __syncthreads();
+  lds_barrier();
   CHOL_STAMP(10);
   // block-recursive inverse: inv([A 0; C B]) = [A^-1 0; -B^-1 C A^-1  B^-1]
   // level 32: two independent pairs of 16x16 blocks (waves 0 and 1)
@@ -217,7 +226,7 @@ __device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ts[(16 * wv + m) * 33 + q + 4 * r] = t1[r];
   }
-  __syncthreads();
+  lds_barrier();
   if (wv < 2) {
     const int b0 = 32 * wv;
     const double4_t x = lds_mma<4>([&](int i, int t) { return Ms[(b0 + 16 + t) * LP + b0 + 16 + i]; },  // B^-1[i][t]
@@ -225,7 +234,7 @@ __device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ms[(b0 + m) * LP + b0 + 16 + q + 4 * r] = -x[r];
   }
-  __syncthreads();
+  lds_barrier();
   // level 64: one 16x16 tile of the 32x32 products per wave
   {
     const int tr = 16 * (wv & 1), tc = 16 * (wv >> 1);
@@ -233,13 +242,13 @@ __device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
                                     [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
-    __syncthreads();
+    lds_barrier();
     const double4_t x = lds_mma<8>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + tr + i]; },  // B^-1[i][t]
                                    [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);      // T[t][j]
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
@@ -975,8 +984,8 @@ __device__ __forceinline__ void st_sc1_x2(double* p, double v0, double v1) {
 }
 // Every publication is made of arrivals, one per storing wave of the publishing workgroup: the wave drains its own stores
 // and adds 1 to the word -- no workgroup barrier on the publishing side.  Consumers wait for the word to reach the number
-// of storing waves: 4, or 3 for what the chain workgroup publishes (its wave 0 never stores: it has to go straight into
-// the pivots of the next diagonal block while the other three, idle behind it, wait for their stores to be confirmed).
+// of storing waves: 4 for a tile of L, 3 for an M block (the chain workgroup's wave 0 never stores: it has to go straight
+// into the pivots of the next diagonal block while the other three, idle behind it, wait for their stores to be confirmed).
 constexpr unsigned kFlowArrivals = 4, kChainArrivals = 3;
 __device__ __forceinline__ void flow_arrive(unsigned* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     const int ja_end = wv + 1;  // lower part of the diagonal tile: columns 16 ja .. <= rows 16 wv ..
     double va[16], vb[16], xi[16];
     for (int k = 0; k <= j - 2; ++k) {
-      flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j, k == j - 2 ? kChainArrivals : kFlowArrivals);  // (j-1, j-2): the chain's
+      flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j);
       flow_fetch(tile_src(j - 1, k), lda, 64, 64, va);
       flow_wait(a.tf + (size_t)j * a.nb + k, a, j);
       flow_fetch(tile_src(j, k), lda, tile_rows(j), 64, vb);
@@ -1201,7 +1210,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         flow_trsm(sh.Ms, accP, x, lane);  // M_{j-1}: lower part from potf2_invert_lds, zeros above
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) xs[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
-        __syncthreads();
+        lds_barrier();
         FLOW_STAMP(j, 4);
         flow_update(accD, xs, x, ja_end, lane);
       }
@@ -1230,7 +1239,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
           sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
         }
       }
-      __syncthreads();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
+      lds_barrier();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
       // M_{j-1} (and L_{j-1,j-1}) of the last step: the waves 1..3, which stored them, confirm their stores and arrive
       // while they would otherwise idle behind wave 0's first pivots.
       const bool m_was_pending = m_pending;
@@ -1345,7 +1354,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     const int t_begin = k + 1 - j0 > 0 ? k + 1 - j0 : 0;
     double v[16];
     if (t_begin < T) {
-      flow_wait(a.tf + (size_t)(j0 + t_begin) * a.nb + k, a, code, j0 + t_begin == k + 1 ? kChainArrivals : kFlowArrivals);
+      flow_wait(a.tf + (size_t)(j0 + t_begin) * a.nb + k, a, code);
       flow_fetch(tile_src(j0 + t_begin, k), lda, 64, 64, v);
     }
 #pragma unroll
@@ -1355,7 +1364,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         flow_put(buf, v);
         __syncthreads();
         if (t + 1 < T) {
-          flow_wait(a.tf + (size_t)(j0 + t + 1) * a.nb + k, a, code, j0 + t + 1 == k + 1 ? kChainArrivals : kFlowArrivals);
+          flow_wait(a.tf + (size_t)(j0 + t + 1) * a.nb + k, a, code);
           flow_fetch(tile_src(j0 + t + 1, k), lda, 64, 64, v);
         }
         flow_update(acc[t], buf, xi, 4, lane);

@@ -44,6 +44,12 @@ int main(int argc, char** argv) {
     hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
     std::vector<long long> st(128 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_flow_trace), st.size() * 8);
+    std::vector<long long> cy(128 * 8);
+    hipMemcpyFromSymbol(cy.data(), HIP_SYMBOL(g_flow_cycles), cy.size() * 8);
+    if (rep == 2 && nb > 10)
+      printf("shader clock during potf2 of block 10: %.0f MHz; over blocks 2..%d: %.0f MHz\n",
+             (cy[10 * 8 + 6] - cy[10 * 8 + 5]) / ((st[10 * 8 + 6] - st[10 * 8 + 5]) * 0.01),
+             nb - 1, (cy[(nb - 1) * 8 + 7] - cy[2 * 8 + 0]) / ((st[(nb - 1) * 8 + 7] - st[2 * 8 + 0]) * 0.01));
     printf("rep %d: n %d info %d  %.1f us (memset + launch)\n", rep, n, info, ms * 1e3);
     if (rep < 2) continue;
     auto us = [](long long d) { return d * 0.01; };
