@@ -350,7 +350,11 @@ gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy,
                     int dof, const gh_ba_options* options, double* information_out, gh_ba_summary* summary);
 
 /* Dense SPD solve used by the reduced camera system, exposed for tests and the C5 bench:
- * A_dev is n x n column-major/symmetric (lower triangle read, overwritten by L), b_dev in, x out. */
+ * A_dev is n x n column-major/symmetric (lower triangle read, overwritten by L), b_dev in, x out.
+ * *info: 0 = ok; 1 .. n = the matrix is not positive definite (first bad 64-column block, 1-based first column);
+ * > n = a single-launch kernel (n <= ~3300 with lda % 16 == 0: factorisation; n <= 8192: back-substitution) could not
+ * get all its workgroups resident in bounded time -- rebuild A and retry with GSLAM_HIP_CHOL_FLOW=0 / GSLAM_HIP_BWD_CHAIN=0
+ * in the environment (gh_ba_solve does this by itself). */
 gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info);
 
 #ifdef __cplusplus
