@@ -1529,11 +1529,12 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
     const bool aligned = lda % 16 == 0 && (reinterpret_cast<uintptr_t>(A) & 127u) == 0;
     const int groups = flow_state && aligned && !(env && env[0] == '0') ? flow_groups(ctx, n, extra_rows) : -1;
     if (groups >= 0) {
-      static bool lds_attr_set = false;  // per process: the attribute belongs to the loaded code object
-      if (!lds_attr_set) {
+      static bool lds_attr_set[64] = {};  // per device: the attribute belongs to the code object loaded there
+      const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+      if (!lds_attr_set[dev] || ctx->device != dev) {
         GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_flow_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kFlowLdsBytes));
-        lds_attr_set = true;
+        lds_attr_set[dev] = true;
       }
       FlowArgs fa;
       fa.A = A;
