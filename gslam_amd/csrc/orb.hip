@@ -542,6 +542,21 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /* shared[5]
   return off + incl - v;
 }
 
+// Entries 7 .. n-1 of a cell, from its 128-byte slot: entry 7 alone, then four per 16-byte load -- a dense cell costs
+// 1 + (n - 8) / 4 dependent memory round trips per pass instead of n - 7 (the slowest thread of a workgroup sets its pace).
+template <typename F>
+__device__ __forceinline__ void for_each_overflow(const uint32_t* __restrict__ ovf, int n, F f) {
+  static_assert(kCellRec - 1 == 7 && kCap % 4 == 0, "entry 8 starts the 16-byte groups");
+  if (n > 7) f(ovf[7]);
+  for (int e = 8; e < n; e += 4) {
+    const uint4 w = *reinterpret_cast<const uint4*>(ovf + e);
+    f(w.x);
+    if (e + 1 < n) f(w.y);
+    if (e + 2 < n) f(w.z);
+    if (e + 3 < n) f(w.w);
+  }
+}
+
 // Visit the entries of one cell.  rec = the cell's 32-byte record {count, entries 0..6} (two 16-byte loads issued
 // together: one memory round trip for the common case), ovf = its 128-byte slot holding entries 7.. at their index.
 template <typename F>
@@ -553,7 +568,19 @@ __device__ __forceinline__ int for_each_entry(const uint32_t* __restrict__ rec, 
 #pragma unroll
   for (int e = 0; e < kCellRec - 1; ++e)
     if (e < n) f(first[e]);
-  for (int e = kCellRec - 1; e < n; ++e) f(ovf[e]);
+  for_each_overflow(ovf, n, f);
+  return n;
+}
+
+// The same on a record that is already in registers
+template <typename F>
+__device__ __forceinline__ int for_each_entry_reg(const uint4& a, const uint4& b, const uint32_t* __restrict__ ovf, F f) {
+  const int n = (int)a.x;
+  const uint32_t first[kCellRec - 1] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < kCellRec - 1; ++e)
+    if (e < n) f(first[e]);
+  for_each_overflow(ovf, n, f);
   return n;
 }
 
@@ -561,10 +588,18 @@ struct SelectArgs {
   int ncells[kMaxL], cell_off[kMaxL], ncx[kMaxL], quota[kMaxL], quota_off[kMaxL];
 };
 
+// CACHED (levels of at most kSelCached * 256 cells): every thread fetches the records of ALL its cells up front -- one
+// memory round trip with up to kSelCached loads in flight -- and the three passes below (histogram, counts, output) read
+// them from registers.  Streaming them three times made the kernel a chain of ~24 dependent round trips per thread at
+// 1080p (the workgroup does little else: it was latency, not bandwidth).
+constexpr int kSelCached = 8;
+template <bool CACHED>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_t* __restrict__ cell_cnt,
                                                      const uint32_t* __restrict__ cell_ent, int cells_per_frame,
                                                      int K, SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt) {
-  __shared__ uint32_t hist[kHistBins];
+  // bin k lives at k + (k >> 5): a thread's 32 consecutive bins (tid * 32 + i) then fall into different banks for
+  // different threads (unpadded, all 64 lanes of a wave hit bank i)
+  __shared__ uint32_t hist[kHistBins + kHistBins / 32];
   __shared__ int wave_tot[4];
   __shared__ int s_cut, s_m;
   const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -575,19 +610,40 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     if (tid == 0) level_cnt[b * kMaxL + l] = 0;
     return;
   }
-  for (int i = tid; i < kHistBins; i += 256) hist[i] = 0;
+  uint4 ra[kSelCached], rb[kSelCached];
+  if (CACHED) {
+#pragma unroll
+    for (int ci = 0; ci < kSelCached; ++ci) {
+      const int c = ci * 256 + tid;
+      ra[ci] = make_uint4(0u, 0u, 0u, 0u);
+      rb[ci] = make_uint4(0u, 0u, 0u, 0u);
+      if (c < ncells) {
+        ra[ci] = reinterpret_cast<const uint4*>(rec + (size_t)c * kCellRec)[0];
+        rb[ci] = reinterpret_cast<const uint4*>(rec + (size_t)c * kCellRec)[1];
+      }
+    }
+  }
+  for (int i = tid; i < kHistBins + kHistBins / 32; i += 256) hist[i] = 0;
   __syncthreads();
-  for (int c = tid; c < ncells; c += 256) {
-    for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, [&](uint32_t v) {
-      const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
-      atomicAdd(&hist[ck], 1u);
-    });
+  auto hist_add = [&](uint32_t v) {
+    const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
+    atomicAdd(&hist[ck + (ck >> 5)], 1u);
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int ci = 0; ci < kSelCached; ++ci) {  // compile-time indices: the records stay in registers
+      const int c = ci * 256 + tid;
+      if (c < ncells) for_each_entry_reg(ra[ci], rb[ci], ent + (size_t)c * kCap, hist_add);
+    }
+  } else {
+    for (int c = tid; c < ncells; c += 256) for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, hist_add);
   }
   __syncthreads();
   // cut-off bin: smallest bin whose inclusive prefix reaches the quota
   constexpr int kPer = kHistBins / 256;
   int mine = 0;
-  for (int i = 0; i < kPer; ++i) mine += (int)hist[tid * kPer + i];
+  static_assert(kPer == 32, "the padding below assumes 32 bins per thread");
+  for (int i = 0; i < kPer; ++i) mine += (int)hist[tid * (kPer + 1) + i];
   int total;
   const int excl = block_excl_scan(mine, wave_tot, &total);
   if (tid == 0) {
@@ -598,7 +654,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
   if (total > quota && excl < quota && excl + mine >= quota) {
     int run = excl;
     for (int i = 0; i < kPer; ++i) {
-      const int hv = (int)hist[tid * kPer + i];
+      const int hv = (int)hist[tid * (kPer + 1) + i];
       if (run + hv >= quota) {
         s_cut = tid * kPer + i;
         s_m = quota - run;
@@ -613,11 +669,11 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
   int tie_carry = 0, out_carry = 0;
   SelKp* out = sel + (size_t)b * K + a.quota_off[l];
   const int ncx = a.ncx[l];
-  for (int cb = 0; cb < ncells; cb += 256) {
-    const int c = cb + tid;
+  // one chunk of 256 cells: cell c of this thread, its entries visited through `each(f)`
+  auto chunk = [&](int c, auto each) {
     int n_lt = 0, n_eq = 0;
     if (c < ncells) {
-      for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, [&](uint32_t v) {
+      each([&](uint32_t v) {
         const int ck = (int)(v >> 18) * 256 + (255 - (int)((v >> 10) & 255));
         n_lt += ck < cut;
         n_eq += ck == cut;
@@ -632,7 +688,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     if (mysel > 0) {
       const int cx = c % ncx, cy = c / ncx;
       int k = 0, ties = 0;
-      for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, [&](uint32_t v) {
+      each([&](uint32_t v) {
         const int s = (int)((v >> 10) & 255);
         const int ck = (int)(v >> 18) * 256 + (255 - s);
         bool take = ck < cut;
@@ -654,6 +710,20 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     }
     tie_carry += tot_eq;
     out_carry += tot_sel;
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int ci = 0; ci < kSelCached; ++ci) {
+      if (ci * 256 < ncells) {  // (uniform: the block scans inside are reached by every thread or by none)
+        const int c = ci * 256 + tid;
+        chunk(c, [&](auto f) { for_each_entry_reg(ra[ci], rb[ci], ent + (size_t)c * kCap, f); });
+      }
+    }
+  } else {
+    for (int cb = 0; cb < ncells; cb += 256) {
+      const int c = cb + tid;
+      chunk(c, [&](auto f) { for_each_entry(rec + (size_t)c * kCellRec, ent + (size_t)c * kCap, f); });
+    }
   }
   if (tid == 0) level_cnt[b * kMaxL + l] = out_carry;
 }
@@ -1224,8 +1294,18 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
       a.quota[l] = l < L ? p->quota[l] : 0;
       a.quota_off[l] = l < L ? p->quota_off[l] : 0;
     }
-    GH_LAUNCH(ctx, "orb_select", select_kernel, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
-              p->cells_per_frame, K, p->sel, p->level_cnt);
+    int max_cells = 0;
+    for (int l = 0; l < L; ++l) max_cells = a.ncells[l] > max_cells ? a.ncells[l] : max_cells;
+    static const bool no_cache = [] {
+      const char* e = getenv("GSLAM_HIP_ORB_SELECT_CACHED");  // "0": stream the records (A/B measurements)
+      return e && e[0] == '0';
+    }();
+    if (max_cells <= kSelCached * 256 && !no_cache)
+      GH_LAUNCH(ctx, "orb_select", select_kernel<true>, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
+                p->cells_per_frame, K, p->sel, p->level_cnt);
+    else
+      GH_LAUNCH(ctx, "orb_select", select_kernel<false>, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
+                p->cells_per_frame, K, p->sel, p->level_cnt);
   }
   {
     DescribeArgs a;
