@@ -367,6 +367,42 @@ __global__ __launch_bounds__(64) void schur_diag_kernel(int nc, const double* __
   }
 }
 
+// The same plus the clearing of S, in one pass over what a factorisation reads: for column c the rows from the top of
+// its 64 x 64 diagonal tile down to the right-hand-side row n (pitch lda), i.e. the lower block triangle with whole
+// diagonal tiles -- half the bytes of a memset of the full square, and two launches less.  Element (r, c) of a camera's
+// diagonal 6 x 6 block gets H_cc (+ damping), row n gets rhs = -g_c (it rides through the factorisation), the rest zero.
+__global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
+                                                         const double* __restrict__ gc, double radius,
+                                                         double* __restrict__ S, double* __restrict__ rhs) {
+  // one workgroup = 2048 rows of one column (8 per thread: four 16-byte stores), starting at the column's diagonal tile
+  const int c = blockIdx.y, r0 = (c >> 6) << 6;
+  const int rb = r0 + blockIdx.x * 2048;
+  if (rb > n) return;
+  const int cam = c / 6, b = c - 6 * cam;
+  double* col = S + (size_t)c * lda;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = rb + 512 * e + 2 * threadIdx.x;  // r even, lda even: a 16-byte aligned pair inside the column
+    if (r > n) break;
+    double v[2] = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rr = r + u;
+      if (rr == n) {
+        v[u] = -gc[c];
+        rhs[c] = v[u];
+      } else if (rr < n && rr / 6 == cam) {
+        const int a = rr - 6 * cam;
+        double h = Hcc[(size_t)36 * cam + 6 * a + b];
+        if (a == b) h += clampd(h, 1e-6, 1e32) / radius;
+        v[u] = h;
+      }
+    }
+    if (r + 1 < lda) *reinterpret_cast<double2*>(col + r) = make_double2(v[0], v[1]);
+    else col[r] = v[0];
+  }
+}
+
 __device__ __forceinline__ void load_W(const double* __restrict__ Wbuf, int k, double* W) {
   const double2* src = reinterpret_cast<const double2*>(Wbuf + (size_t)18 * k);
 #pragma unroll
@@ -482,8 +518,10 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlock
 
 // 64 threads per block: thread t < 42 adds element t of the block's segment totals in segment order, then
 // S[block] -= total (this thread is the element's only writer), rhs += total for the diagonal blocks
+// (the right-hand side is also kept as row `rhs_row` of S, where the factorisation picks it up)
 __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const double* __restrict__ partial,
-                                                           double* __restrict__ S, int n, double* __restrict__ rhs) {
+                                                           double* __restrict__ S, int n, double* __restrict__ rhs,
+                                                           int rhs_row) {
   const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), t = threadIdx.x & 63;
   if (blk >= B.nblocks || t >= 42) return;
   double tot = 0;
@@ -495,7 +533,9 @@ __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const 
     double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
     *dst = *dst - tot;
   } else if (ci == cj) {
-    rhs[6 * ci + (t - 36)] += tot;
+    const double v = rhs[6 * ci + (t - 36)] + tot;
+    rhs[6 * ci + (t - 36)] = v;
+    S[(size_t)(6 * ci + (t - 36)) * n + rhs_row] = v;
   }
 }
 
@@ -505,12 +545,28 @@ __global__ void rhs_to_row_kernel(const double* __restrict__ rhs, double* __rest
   if (j < n) S[(size_t)j * lda + n] = rhs[j];
 }
 
-__global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const double* __restrict__ Hpi,
+// back-substitution for the points and the candidate state in one launch: thread i handles point i and camera i; it also
+// clears the two flag words the NEXT iteration accumulates into (their read-back copies are already queued ahead of it)
+__global__ __launch_bounds__(256) void backsub_update_kernel(Problem P, const double* __restrict__ Hpi,
                                                              const double* __restrict__ gp,
                                                              const double* __restrict__ dc, double* __restrict__ dp,
-                                                             const double* __restrict__ Wbuf) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= P.np) return;
+                                                             const double* __restrict__ Wbuf,
+                                                             double* __restrict__ poses_new, double* __restrict__ pts_new,
+                                                             int* __restrict__ bad, unsigned long long* __restrict__ gmax) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    *bad = 0;
+    *gmax = 0ull;
+  }
+  if (i < P.nc) {
+    if ((P.dof[i] & 63) == 0) {  // fixed keyframe: bitwise untouched
+      for (int a = 0; a < 7; ++a) poses_new[7 * i + a] = P.poses[7 * i + a];
+    } else {
+      se3_retract(P.poses + 7 * i, dc + 6 * i, poses_new + 7 * i);
+    }
+  }
+  if (i >= P.np) return;
+  const int p = i;
   double rhs[3] = {-gp[3 * p], -gp[3 * p + 1], -gp[3 * p + 2]};
   for (int q = P.pstart[p]; q < P.pstart[p + 1]; ++q) {
     const int k = P.plist[q], ci = P.ocam[k];
@@ -526,25 +582,10 @@ __global__ __launch_bounds__(256) void backsub_points_kernel(Problem P, const do
   }
   const double* Hi = Hpi + (size_t)9 * p;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) dp[3 * p + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
-}
-
-__global__ __launch_bounds__(256) void update_state_kernel(int nc, int np, const double* __restrict__ poses,
-                                                           const int32_t* __restrict__ dof,
-                                                           const double* __restrict__ pts,
-                                                           const double* __restrict__ dc, const double* __restrict__ dp,
-                                                           double* __restrict__ poses_new, double* __restrict__ pts_new) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nc) {
-    if ((dof[i] & 63) == 0) {  // fixed keyframe: bitwise untouched
-      for (int a = 0; a < 7; ++a) poses_new[7 * i + a] = poses[7 * i + a];
-    } else {
-      se3_retract(poses + 7 * i, dc + 6 * i, poses_new + 7 * i);
-    }
-  }
-  if (i < np) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) pts_new[3 * i + a] = pts[3 * i + a] + dp[3 * i + a];
+  for (int a = 0; a < 3; ++a) {
+    const double d = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+    dp[3 * p + a] = d;
+    pts_new[3 * p + a] = P.pts[3 * p + a] + d;
   }
 }
 
@@ -1049,6 +1090,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     return GH_OK;
   };
 
+  GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, sizeof(unsigned long long), ctx->stream));
+  GH_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
   double h2[2];
   const double t_upload = now_ms();
   GH_TRY(eval_cost(d_poses, d_pts, 0));
@@ -1063,8 +1106,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   bool need_lin = true;
   int term = 0, it = 0;
   for (it = 0; it < opt.max_iterations; ++it) {
-    if (need_lin) {
-      GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, sizeof(unsigned long long), ctx->stream));
+    if (need_lin) {  // (d_gmax and d_bad are zero here: cleared before the loop and by every backsub_update launch)
       if (np > 0)
         GH_LAUNCH(ctx, "ba_lin_points", lin_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpp, d_gp,
                   d_gmax);
@@ -1077,23 +1119,26 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
     const bool fresh_lin = need_lin;
     need_lin = false;
-    GH_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
     if (np > 0)
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
                 d_Hpi, d_bad);
-    {
+    const bool slim_init = d_flow != nullptr && n < 65536;  // the single-launch factorisation reads the lower tiles only
+    if (slim_init) {
+      GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc, d_gc,
+                radius, d_S, d_dc);
+    } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
       hipError_t me = hipMemsetAsync(d_S, 0, (size_t)n * lda * sizeof(double), ctx->stream);
       gh_prof_end(ctx, pend);
       GH_HIP(ctx, me);
+      GH_LAUNCH(ctx, "ba_schur_diag", schur_diag_kernel, dim3(nc), dim3(64), 0, nc, d_Hcc, d_gc, radius, d_S, lda, d_dc);
     }
-    GH_LAUNCH(ctx, "ba_schur_diag", schur_diag_kernel, dim3(nc), dim3(64), 0, nc, d_Hcc, d_gc, radius, d_S, lda, d_dc);
     if (no > 0) {
       if (opt.deterministic) {
         GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(gh_div_up(nsegs, 4)), dim3(256), 0, P, SB, d_Hpi, d_gp,
                   (const double*)d_W, d_spart);
         GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, SB,
-                  (const double*)d_spart, d_S, lda, d_dc);
+                  (const double*)d_spart, d_S, lda, d_dc, n);
       } else {
         GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
                   d_S, lda, d_dc, (const double*)d_W);
@@ -1106,17 +1151,16 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     // The whole candidate step is enqueued without waiting for the factorisation flags (the kernels have no
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host
     // synchronisation per iteration instead of three.
-    GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
+    // rhs -> row n of S: already there when schur_init_kernel + schur_reduce_kernel wrote it
+    if (!(slim_init && opt.deterministic))
+      GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
     GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info));
     GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (np > 0)
-      GH_LAUNCH(ctx, "ba_backsub", backsub_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpi, d_gp, d_dc,
-                d_dp, (const double*)d_W);
-    GH_LAUNCH(ctx, "ba_update", update_state_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, nc, np,
-              d_poses, d_dof, d_pts, d_dc, d_dp, d_poses_new, d_pts_new);
+    GH_LAUNCH(ctx, "ba_backsub", backsub_update_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, P, d_Hpi,
+              d_gp, d_dc, d_dp, (const double*)d_W, d_poses_new, d_pts_new, d_bad, d_gmax);
     GH_TRY(eval_cost(d_poses_new, d_pts_new, 1));  // the iteration's one synchronisation
     if (flow_lock.owns_lock()) flow_lock.unlock();
     h2[0] = rb->cost;
