@@ -516,6 +516,206 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlock
   if (lane < 42) partial[(size_t)42 * seg + lane] = mine;
 }
 
+// block-wide exclusive scan of one int per thread (256 threads); returns the exclusive prefix, *total = the sum
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /* shared[4] */, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();  // protect wave_tot reuse
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int k = 0; k < wv; ++k) off += wave_tot[k];
+  *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  return off + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The pair list of the deterministic Schur product, built on the GPU (large graphs: on the host it was the largest part of
+// the per-solve setup, 1.6 ms on 16 threads + 8 MB of upload at C4).  Same lists as build_schur_pairs below, element for
+// element (tests compare them):
+//   generation order = cameras ascending, the camera's observations k ascending, the point's observations k2 ascending,
+//   a pair is kept if cam(k2) <= cam(k);  then a STABLE sort by cam(k2) inside each camera  ->  blocks (ci, cj) ascending
+//   with the generation order kept inside a block.
+// count -> exclusive scan -> emit -> one workgroup per camera sorts its pairs in LDS (bitonic on (cj << 32 | position):
+// the position makes it stable) and marks block starts -> scan over cameras -> block tables -> scan -> segment tables.
+constexpr int kPairSortMaxCams = 15360;  // one LDS cursor per partner camera (60 KB); more cameras -> host path
+
+__global__ __launch_bounds__(256) void pair_count_kernel(int no, const int32_t* __restrict__ clist,
+                                                         const int32_t* __restrict__ ocam, const int32_t* __restrict__ opt,
+                                                         const int32_t* __restrict__ pstart,
+                                                         const int32_t* __restrict__ plist, int32_t* __restrict__ cnt) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= no) return;
+  const int k = clist[q], ci = ocam[k], p = opt[k];
+  int c = 0;
+  for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) c += ocam[plist[q2]] <= ci ? 1 : 0;
+  cnt[q] = c;
+}
+
+// exclusive scan of n ints, 1024 per workgroup: out[i] = sum of in[< i] within the workgroup's chunk, sums[blk] = chunk total
+__global__ __launch_bounds__(256) void scan_chunks_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out,
+                                                          int32_t* __restrict__ sums) {
+  __shared__ int wave_tot[4];
+  const int base = blockIdx.x * 1024 + 4 * threadIdx.x;
+  int v[4], t = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] = base + e < n ? in[base + e] : 0;
+    t += v[e];
+  }
+  int total;
+  int run = block_excl_scan(t, wave_tot, &total);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (base + e < n) out[base + e] = run;
+    run += v[e];
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+// one workgroup: sums[0 .. m) -> exclusive prefix in place, grand total to sums[m] and *total_out
+__global__ __launch_bounds__(256) void scan_sums_kernel(int32_t* __restrict__ sums, int m, int32_t* __restrict__ total_out) {
+  __shared__ int wave_tot[4];
+  int carry = 0;
+  for (int b0 = 0; b0 < m; b0 += 256) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < m ? sums[i] : 0;
+    int total;
+    const int ex = block_excl_scan(v, wave_tot, &total);
+    if (i < m) sums[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[m] = carry;
+    if (total_out) *total_out = carry;
+  }
+}
+__global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ out, int n, const int32_t* __restrict__ sums,
+                                                       int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] += sums[i >> 10];
+  if (i == 0) out[n] = sums[m];  // out has n + 1 entries: the total closes it
+}
+
+__global__ __launch_bounds__(256) void pair_emit_kernel(int no, const int32_t* __restrict__ clist,
+                                                        const int32_t* __restrict__ ocam, const int32_t* __restrict__ opt,
+                                                        const int32_t* __restrict__ pstart,
+                                                        const int32_t* __restrict__ plist, const int32_t* __restrict__ goff,
+                                                        int32_t* __restrict__ gen_k, int32_t* __restrict__ gen_k2,
+                                                        int32_t* __restrict__ gen_cj) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= no) return;
+  const int k = clist[q], ci = ocam[k], p = opt[k];
+  int o = goff[q];
+  for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
+    const int k2 = plist[q2], cj = ocam[k2];
+    if (cj > ci) continue;
+    gen_k[o] = k;
+    gen_k2[o] = k2;
+    gen_cj[o] = cj;
+    ++o;
+  }
+}
+
+// one workgroup per camera: STABLE counting sort of its pairs by partner camera (cj <= ci: at most ci + 1 bins in LDS),
+// sorted pairs to their final place, block starts and partner cameras of its blocks into the scratch arrays (indexed
+// from the camera's first pair), block count to blk_cnt.  Any number of pairs per camera.
+//   histogram (LDS atomics: only counts, order-free) -> exclusive scan of the bins = where each block starts ->
+//   placement in generation order, 256 pairs at a time: rank among the equal keys of the chunk by a plain count over the
+//   chunk (same-address LDS reads), the last of them moves the bin's cursor on.
+__global__ __launch_bounds__(256) void pair_sort_kernel(const int32_t* __restrict__ cstart, const int32_t* __restrict__ goff,
+                                                        const int32_t* __restrict__ gen_k,
+                                                        const int32_t* __restrict__ gen_k2,
+                                                        const int32_t* __restrict__ gen_cj, int32_t* __restrict__ pair_a,
+                                                        int32_t* __restrict__ pair_b, int32_t* __restrict__ tmp_start,
+                                                        int32_t* __restrict__ tmp_cj, int32_t* __restrict__ blk_cnt) {
+  extern __shared__ __attribute__((aligned(16))) int bins[];  // ci + 1 cursors
+  __shared__ int wave_tot[4];
+  __shared__ __attribute__((aligned(16))) int chunk_cj[256];
+  const int ci = blockIdx.x, tid = threadIdx.x, nbins = ci + 1;
+  const int begin = goff[cstart[ci]], end = goff[cstart[ci + 1]], m = end - begin;
+  for (int i = tid; i < nbins; i += 256) bins[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) atomicAdd(&bins[gen_cj[begin + i]], 1);
+  __syncthreads();
+  // exclusive scan of the counts (bin -> first position) and of the non-empty flags (bin -> local block number)
+  int carry = 0, bcarry = 0;
+  for (int b0 = 0; b0 < nbins; b0 += 256) {
+    const int bi = b0 + tid;
+    const int c = bi < nbins ? bins[bi] : 0;
+    int total, btotal;
+    const int ex = block_excl_scan(c, wave_tot, &total);
+    const int bex = block_excl_scan(c > 0 ? 1 : 0, wave_tot, &btotal);
+    if (bi < nbins) {
+      bins[bi] = carry + ex;
+      if (c > 0) {
+        tmp_start[begin + bcarry + bex] = begin + carry + ex;
+        tmp_cj[begin + bcarry + bex] = bi;
+      }
+    }
+    carry += total;
+    bcarry += btotal;
+    __syncthreads();
+  }
+  if (tid == 0) blk_cnt[ci] = bcarry;
+  for (int c0 = 0; c0 < m; c0 += 256) {
+    const int i = c0 + tid, n_here = m - c0 < 256 ? m - c0 : 256;
+    const int cj = i < m ? gen_cj[begin + i] : -1;
+    chunk_cj[tid] = cj;
+    __syncthreads();
+    int before = 0, all = 0;
+    (void)n_here;  // the tail of the last chunk holds -1, which matches no key of a valid lane
+    const int4* c4 = reinterpret_cast<const int4*>(chunk_cj);
+#pragma unroll 4
+    for (int t4 = 0; t4 < 64; ++t4) {  // four keys per (same-address) 16-byte LDS read
+      const int4 w = c4[t4];
+      const int s0 = w.x == cj, s1 = w.y == cj, s2 = w.z == cj, s3 = w.w == cj;
+      all += (s0 + s1) + (s2 + s3);
+      const int t = 4 * t4;
+      before += (t < tid ? s0 : 0) + (t + 1 < tid ? s1 : 0) + (t + 2 < tid ? s2 : 0) + (t + 3 < tid ? s3 : 0);
+    }
+    if (i < m) {
+      const int dst = begin + bins[cj] + before;
+      pair_a[dst] = gen_k[begin + i];
+      pair_b[dst] = gen_k2[begin + i];
+    }
+    __syncthreads();  // every cursor of this chunk has been read
+    if (i < m && before == all - 1) bins[cj] += all;
+    __syncthreads();
+  }
+}
+
+// block tables from the per-camera scratch: blk_off = exclusive scan of blk_cnt (nc + 1 entries)
+__global__ __launch_bounds__(256) void pair_blocks_kernel(const int32_t* __restrict__ cstart, const int32_t* __restrict__ goff,
+                                                          const int32_t* __restrict__ blk_off,
+                                                          const int32_t* __restrict__ tmp_start,
+                                                          const int32_t* __restrict__ tmp_cj, int nc,
+                                                          int32_t* __restrict__ bstart, int32_t* __restrict__ bci,
+                                                          int32_t* __restrict__ bcj, int32_t* __restrict__ seg_cnt) {
+  const int ci = blockIdx.x;
+  const int begin = goff[cstart[ci]], end = goff[cstart[ci + 1]];
+  const int b0 = blk_off[ci], nb = blk_off[ci + 1] - b0;
+  for (int lb = threadIdx.x; lb < nb; lb += 256) {
+    const int st = tmp_start[begin + lb], nx = lb + 1 < nb ? tmp_start[begin + lb + 1] : end;
+    bstart[b0 + lb] = st;
+    bci[b0 + lb] = ci;
+    bcj[b0 + lb] = tmp_cj[begin + lb];
+    seg_cnt[b0 + lb] = (nx - st + kSchurSeg - 1) / kSchurSeg;
+  }
+  if (ci == nc - 1 && threadIdx.x == 0) bstart[blk_off[nc]] = end;  // = number of pairs
+}
+__global__ __launch_bounds__(256) void pair_segments_kernel(int nblocks, const int32_t* __restrict__ seg_first,
+                                                            int32_t* __restrict__ seg_blk) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nblocks) return;
+  for (int sg = seg_first[b]; sg < seg_first[b + 1]; ++sg) seg_blk[sg] = b;
+}
+
 // 64 threads per block: thread t < 42 adds element t of the block's segment totals in segment order, then
 // S[block] -= total (this thread is the element's only writer), rhs += total for the diagonal blocks
 // (the right-hand side is also kept as row `rhs_row` of S, where the factorisation picks it up)
@@ -924,6 +1124,74 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
             pool.size(), t2 - t1, t3 - t2, now_ms() - t3);
 }
 
+// Device build of the pair lists (kernels above).  `pairs_ub` >= the number of pairs.  On return SB points at the device
+// tables, *counts = {pairs, blocks, segments, 0} is a pinned host block that is valid after the NEXT stream
+// synchronisation (the caller's first cost evaluation): nothing here waits.
+gh_status build_schur_pairs_device(gh_ctx* ctx, DevBuf& db, int nc, int no, size_t pairs_ub, size_t blocks_ub,
+                                   const int32_t* d_ocam, const int32_t* d_opt, const int32_t* d_pstart,
+                                   const int32_t* d_plist, const int32_t* d_cstart, const int32_t* d_clist,
+                                   SchurBlocks* SB, int32_t* counts_pinned) {
+  const size_t segs_ub = pairs_ub / kSchurSeg + blocks_ub + 2;
+  int32_t *d_goff, *d_sums, *d_gen_k, *d_gen_k2, *d_gen_cj, *d_pa, *d_pb, *d_tmp_start, *d_tmp_cj, *d_blk_off, *d_bs, *d_bci,
+      *d_bcj, *d_seg_first, *d_seg_blk, *d_sums2, *d_counts;
+  const int chunks = gh_div_up(no, 1024), bchunks = gh_div_up((long long)blocks_ub + 1, 1024);
+  GH_TRY(db.alloc(&d_goff, (size_t)no + 1));
+  GH_TRY(db.alloc(&d_sums, (size_t)chunks + 1));
+  GH_TRY(db.alloc(&d_gen_k, pairs_ub));
+  GH_TRY(db.alloc(&d_gen_k2, pairs_ub));
+  GH_TRY(db.alloc(&d_gen_cj, pairs_ub));
+  GH_TRY(db.alloc(&d_pa, pairs_ub));
+  GH_TRY(db.alloc(&d_pb, pairs_ub));
+  GH_TRY(db.alloc(&d_tmp_start, pairs_ub));
+  GH_TRY(db.alloc(&d_tmp_cj, pairs_ub));
+  GH_TRY(db.alloc(&d_blk_off, (size_t)nc + 2));
+  GH_TRY(db.alloc(&d_bs, blocks_ub + 1));
+  GH_TRY(db.alloc(&d_bci, blocks_ub + 1));
+  GH_TRY(db.alloc(&d_bcj, blocks_ub + 1));
+  GH_TRY(db.alloc(&d_seg_first, blocks_ub + 2));
+  GH_TRY(db.alloc(&d_seg_blk, segs_ub));
+  GH_TRY(db.alloc(&d_sums2, (size_t)bchunks + 1));
+  GH_TRY(db.alloc(&d_counts, 4));
+  GH_HIP(ctx, hipMemsetAsync(d_counts, 0, 4 * sizeof(int32_t), ctx->stream));
+  GH_HIP(ctx, hipMemsetAsync(d_seg_first, 0, (blocks_ub + 2) * sizeof(int32_t), ctx->stream));  // counts beyond nblocks: 0
+  const dim3 T(256);
+  // pairs per observation (camera-major order), exclusive scan -> goff (no + 1 entries), total -> counts[0]
+  GH_LAUNCH(ctx, "ba_pl_count", pair_count_kernel, dim3(gh_div_up(no, 256)), T, 0, no, d_clist, d_ocam, d_opt, d_pstart,
+            d_plist, d_goff);
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_chunks_kernel, dim3(chunks), T, 0, (const int32_t*)d_goff, no, d_goff, d_sums);
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_sums_kernel, dim3(1), T, 0, d_sums, chunks, d_counts + 0);
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_add_kernel, dim3(gh_div_up(no, 256)), T, 0, d_goff, no, (const int32_t*)d_sums, chunks);
+  GH_LAUNCH(ctx, "ba_pl_emit", pair_emit_kernel, dim3(gh_div_up(no, 256)), T, 0, no, d_clist, d_ocam, d_opt, d_pstart,
+            d_plist, (const int32_t*)d_goff, d_gen_k, d_gen_k2, d_gen_cj);
+  static bool lds_attr[64] = {};
+  const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+  if (!lds_attr[dev]) {
+    GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pair_sort_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kPairSortMaxCams * 4));
+    lds_attr[dev] = true;
+  }
+  GH_LAUNCH(ctx, "ba_pl_sort", pair_sort_kernel, dim3(nc), T, (size_t)nc * sizeof(int), d_cstart, (const int32_t*)d_goff,
+            (const int32_t*)d_gen_k, (const int32_t*)d_gen_k2, (const int32_t*)d_gen_cj, d_pa, d_pb, d_tmp_start, d_tmp_cj,
+            d_blk_off);
+  // blocks: exclusive scan of the per-camera block counts (in place, nc + 1 entries), total -> counts[1]
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_sums_kernel, dim3(1), T, 0, d_blk_off, nc, d_counts + 1);
+  GH_LAUNCH(ctx, "ba_pl_blocks", pair_blocks_kernel, dim3(nc), T, 0, d_cstart, (const int32_t*)d_goff,
+            (const int32_t*)d_blk_off, (const int32_t*)d_tmp_start, (const int32_t*)d_tmp_cj, nc, d_bs, d_bci, d_bcj,
+            d_seg_first);
+  // segments: exclusive scan of the per-block segment counts over blocks_ub entries (the tail beyond nblocks is zero)
+  // -> seg_first (nblocks + 1 meaningful entries), total -> counts[2]
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_chunks_kernel, dim3(bchunks), T, 0, (const int32_t*)d_seg_first, (int)blocks_ub + 1,
+            d_seg_first, d_sums2);
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_sums_kernel, dim3(1), T, 0, d_sums2, bchunks, d_counts + 2);
+  GH_LAUNCH(ctx, "ba_pl_scan", scan_add_kernel, dim3(gh_div_up((long long)blocks_ub + 1, 256)), T, 0, d_seg_first,
+            (int)blocks_ub + 1, (const int32_t*)d_sums2, bchunks);
+  GH_LAUNCH(ctx, "ba_pl_segs", pair_segments_kernel, dim3(gh_div_up((long long)blocks_ub, 256)), T, 0, (int)blocks_ub,
+            (const int32_t*)d_seg_first, d_seg_blk);
+  GH_HIP(ctx, hipMemcpyAsync(counts_pinned, d_counts, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  *SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_seg_blk, d_seg_first, 0, 0};
+  return GH_OK;
+}
+
 }  // namespace
 
 extern "C" void gh_ba_default_options(gh_ba_options* o) {
@@ -967,21 +1235,53 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   });
   const double t_csr = now_ms();
 
-  // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant)
+  // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant).  Large
+  // graphs build it on the GPU (build_schur_pairs_device); GSLAM_HIP_BA_PAIRS=host keeps the host build, =check runs both
+  // and compares them element for element (tests).
   std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
-  if (opt.deterministic && no > 0) build_schur_pairs(pr, nc, pstart, plist, cstart, clist, pair_a, pair_b, bstart, bci, bcj);
-  const int nblocks = (int)bci.size();
+  const char* pairs_env = getenv("GSLAM_HIP_BA_PAIRS");
+  const bool want_pairs = opt.deterministic && no > 0;
+  const bool pairs_check = want_pairs && pairs_env && pairs_env[0] == 'c';
+  bool device_pairs = want_pairs && (no >= 20000 || pairs_check) && !(pairs_env && pairs_env[0] == 'h');
+  size_t pairs_ub = 0, blocks_ub = 0;
+  if (device_pairs) {
+    for (int p = 0; p < np; ++p) pairs_ub += (size_t)(pstart[p + 1] - pstart[p]) * (size_t)(pstart[p + 1] - pstart[p]);
+    blocks_ub = std::min(pairs_ub, (size_t)nc * ((size_t)nc + 1) / 2);
+    if (pairs_ub > (size_t)1 << 30 || nc > kPairSortMaxCams) device_pairs = false;  // 32-bit offsets, LDS cursors
+  }
+  if (want_pairs && (!device_pairs || pairs_check))
+    build_schur_pairs(pr, nc, pstart, plist, cstart, clist, pair_a, pair_b, bstart, bci, bcj);
+  int nblocks = (int)bci.size();
   const double t_lists = now_ms();
 
+  // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
+  // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the middle
+  // of the launch chain, which left the GPU idle while the rest of the iteration was being enqueued.
+  struct Readback {
+    double cost, model;
+    unsigned long long gmax_bits;
+    int info, bad;
+    int32_t pair_counts[4];  // device-built pair lists: pairs, blocks, segments, (unused)
+  };
+  Readback* rb = nullptr;
+  {
+    void* pp = nullptr;
+    GH_TRY(gh_pinned(ctx, 256, &pp));
+    rb = (Readback*)pp;
+  }
   DevBuf db(ctx);
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
                              NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 * 3 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
                         4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256 +
+                        // device-built pair lists: 7 arrays of pairs_ub ints, block / segment tables, scan scratch
+                        4 * (pairs_ub * 7 + blocks_ub * 5 + pairs_ub / kSchurSeg + NO + NO / 1024 + blocks_ub / 1024 + NC + 64) +
+                        (device_pairs ? 24 * 256 : 0) +
                         // chunk / segment tables and their partial sums (upper bounds)
                         (NO / kCamChunk + NC + 2) * (27 * 8 + 2 * 4) + (NC + 2) * 4 +
-                        (pair_a.size() / kSchurSeg + bstart.size() + 2) * (42 * 8 + 4) + (bstart.size() + 2) * 4 + 16 * 256;
+                        (std::max(pair_a.size(), pairs_ub) / kSchurSeg + std::max(bstart.size(), blocks_ub) + 2) * (42 * 8 + 4) +
+                        (bstart.size() + 2) * 4 + 16 * 256;
     GH_TRY(db.reserve(need));
   }
   double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
@@ -1016,7 +1316,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     for (int e = bstart[b]; e < bstart[b + 1]; e += kSchurSeg) seg_blk.push_back(b);
   }
   seg_first[nblocks] = (int32_t)seg_blk.size();
-  const int nchunks = (int)ch_cam.size(), nsegs = (int)seg_blk.size();
+  const int nchunks = (int)ch_cam.size();
+  int nsegs = (int)seg_blk.size();
   CamChunks CC{nullptr, nullptr, nullptr, nchunks};
   {
     int32_t *d_cc, *d_cq, *d_cf;
@@ -1026,7 +1327,19 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     CC = CamChunks{d_cc, d_cq, d_cf, nchunks};
   }
   SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nblocks, nsegs};
-  if (nblocks > 0) {
+  SchurBlocks SB_host = SB;  // (check mode: the host-built tables beside the device-built ones)
+  if (device_pairs) {
+    const double tq0 = now_ms();
+    GH_TRY(build_schur_pairs_device(ctx, db, nc, no, pairs_ub, blocks_ub, d_ocam, d_opt, d_pstart, d_plist, d_cstart, d_clist,
+                                    &SB, rb->pair_counts));
+    if (getenv("GSLAM_HIP_BA_TIMING")) {
+      const double tq1 = now_ms();
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      fprintf(stderr, "[gh_ba] device pair lists: enqueue %.2f ms, then %.2f ms until the stream is idle (ub %zu pairs, %zu blocks)\n",
+              tq1 - tq0, now_ms() - tq1, pairs_ub, blocks_ub);
+    }
+  }
+  if (nblocks > 0 && (!device_pairs || pairs_check)) {
     int32_t *d_pa, *d_pb, *d_bs, *d_bci, *d_bcj, *d_sb, *d_sf;
     GH_TRY(db.upload(&d_sb, (const int32_t*)seg_blk.data(), seg_blk.size()));
     GH_TRY(db.upload(&d_sf, (const int32_t*)seg_first.data(), seg_first.size()));
@@ -1035,7 +1348,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_TRY(db.upload(&d_bs, (const int32_t*)bstart.data(), bstart.size()));
     GH_TRY(db.upload(&d_bci, (const int32_t*)bci.data(), bci.size()));
     GH_TRY(db.upload(&d_bcj, (const int32_t*)bcj.data(), bcj.size()));
-    SB = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_sb, d_sf, nblocks, nsegs};
+    SB_host = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_sb, d_sf, nblocks, nsegs};
+    if (!device_pairs) SB = SB_host;
   }
   double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart, *d_xwork, *d_xh;
   unsigned long long* d_gmax;
@@ -1057,7 +1371,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   unsigned* d_flow = nullptr;  // state of the single-launch factorisation (null when the shape does not fit it)
   if (const size_t words = gh_potrf_flow_words(ctx, n, 1)) GH_TRY(db.alloc(&d_flow, words));
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
-  GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
+  d_spart = nullptr;
+  if (!device_pairs) GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
   GH_TRY(db.alloc(&d_out, 4));
   GH_TRY(db.alloc(&d_gmax, 1));
@@ -1067,20 +1382,6 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   Problem P{nc, np, no, d_poses, d_dof, d_pts, d_pfree, d_ocam, d_opt, d_oxy, d_oinfo,
             d_pstart, d_plist, d_cstart, d_clist, opt.huber_delta};
 
-  // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
-  // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the
-  // middle of the launch chain, which left the GPU idle while the rest of the iteration was being enqueued.
-  struct Readback {
-    double cost, model;
-    unsigned long long gmax_bits;
-    int info, bad;
-  };
-  Readback* rb = nullptr;
-  {
-    void* pp = nullptr;
-    GH_TRY(gh_pinned(ctx, 256, &pp));
-    rb = (Readback*)pp;
-  }
   auto eval_cost = [&](const double* poses_eval, const double* pts_eval, int with_model) -> gh_status {
     GH_LAUNCH(ctx, "ba_eval", eval_kernel, dim3(eval_blocks), dim3(256), 0, P, poses_eval, pts_eval, d_dc, d_dp,
               with_model, d_partial);
@@ -1097,9 +1398,43 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(eval_cost(d_poses, d_pts, 0));
   h2[0] = rb->cost;
   h2[1] = rb->model;
+  if (device_pairs) {  // the lists were built behind the uploads; their sizes came back with the first cost
+    {
+      if (pairs_check) {
+        auto same = [&](const int32_t* dev, const std::vector<int32_t>& host, size_t count, const char* what) -> gh_status {
+          std::vector<int32_t> got(count);
+          GH_HIP(ctx, hipMemcpy(got.data(), dev, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+          for (size_t i = 0; i < count; ++i)
+            if (got[i] != host[i])
+              return gh_set_error(ctx, GH_ERR_NUMERIC, "device-built %s differs from the host list at %zu: %d vs %d", what, i,
+                                  got[i], host[i]);
+          return GH_OK;
+        };
+        if (rb->pair_counts[0] != (int)pair_a.size() || rb->pair_counts[1] != (int)bci.size() || rb->pair_counts[2] != nsegs)
+          return gh_set_error(ctx, GH_ERR_NUMERIC, "device-built pair lists: %d pairs / %d blocks / %d segments, host %zu / %zu / %d",
+                              rb->pair_counts[0], rb->pair_counts[1], rb->pair_counts[2], pair_a.size(), bci.size(), nsegs);
+        GH_TRY(same(SB.pair_a, pair_a, pair_a.size(), "pair_a"));
+        GH_TRY(same(SB.pair_b, pair_b, pair_b.size(), "pair_b"));
+        GH_TRY(same(SB.bstart, bstart, bstart.size(), "bstart"));
+        GH_TRY(same(SB.bci, bci, bci.size(), "bci"));
+        GH_TRY(same(SB.bcj, bcj, bcj.size(), "bcj"));
+        std::vector<int32_t> sf((size_t)nblocks + 1), sb((size_t)nsegs);
+        GH_HIP(ctx, hipMemcpy(sf.data(), SB_host.seg_first, sf.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        GH_HIP(ctx, hipMemcpy(sb.data(), SB_host.seg_blk, sb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        GH_TRY(same(SB.seg_first, sf, sf.size(), "seg_first"));
+        GH_TRY(same(SB.seg_blk, sb, sb.size(), "seg_blk"));
+      }
+      nblocks = rb->pair_counts[1];
+      nsegs = rb->pair_counts[2];
+      SB.nblocks = nblocks;
+      SB.nsegs = nsegs;
+    }
+    GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
+  }
   if (opt.verbose)
     fprintf(stderr, "[gh_ba] setup: index lists %.2f ms (csr %.2f; %zu Schur pairs, %d blocks), upload %.2f ms, first cost %.2f ms\n",
-            t_lists - t_begin, t_csr - t_begin, pair_a.size(), nblocks, t_upload - t_lists, now_ms() - t_upload);
+            t_lists - t_begin, t_csr - t_begin, device_pairs ? (size_t)rb->pair_counts[0] : pair_a.size(), nblocks,
+            t_upload - t_lists, now_ms() - t_upload);
   double cost = h2[0];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;

@@ -173,6 +173,24 @@ def test_ba_single_launch_factorisation_against_the_launch_path(ctx, cams, monke
     assert np.abs(p1 - p0).max() <= 1e-8 and np.abs(x1 - x0).max() <= 1e-8  # eight LM iterations amplify the rounding
 
 
+@pytest.mark.parametrize("cams,points,per_point", [(12, 300, 5), (60, 6000, 6), (500, 50000, 6), (40, 3000, 12)])
+def test_schur_pair_lists_built_on_the_gpu_equal_the_host_lists(ctx, cams, points, per_point, monkeypatch):
+    """GSLAM_HIP_BA_PAIRS=check builds the deterministic Schur pair lists both ways and compares every table (pairs,
+    block starts, block cameras, segment tables) element for element inside gh_ba_solve; the iterates must then equal the
+    host-list run bit for bit."""
+    from gslam_amd import ba
+    g = make_graph(cams, points, n_obs_per_point=per_point, seed=cams + per_point)
+    monkeypatch.setenv("GSLAM_HIP_BA_PAIRS", "host")
+    p0, x0, s0, st0 = ba.solve(ctx, g, ba.default_options(max_iterations=4, deterministic=1))
+    monkeypatch.setenv("GSLAM_HIP_BA_PAIRS", "check")
+    p1, x1, s1, st1 = ba.solve(ctx, g, ba.default_options(max_iterations=4, deterministic=1))
+    assert st0 == 0 and st1 == 0
+    assert p1.tobytes() == p0.tobytes() and x1.tobytes() == x0.tobytes()
+    monkeypatch.setenv("GSLAM_HIP_BA_PAIRS", "device")
+    p2, x2, s2, st2 = ba.solve(ctx, g, ba.default_options(max_iterations=4, deterministic=1))
+    assert st2 == 0 and p2.tobytes() == p0.tobytes() and x2.tobytes() == x0.tobytes()
+
+
 def test_single_launch_kernels_give_up_instead_of_hanging(ctx, monkeypatch):
     """Every wait inside the single-launch factorisation / back-substitution is bounded.  With the bound shrunk to one poll
     the waits expire: the stand-alone solve reports it (info > n), and gh_ba_solve repeats the iteration on the

@@ -48,5 +48,5 @@ for v in variants:
     ctx.prof_enable(False)
     tot = sum(x["total_ms"] for x in p.values())
     print("   kernels ms/iteration:", {k: (x["launches"], round(x["total_ms"] / sp.iterations, 4)) for k, x in
-                                        sorted(p.items(), key=lambda kv: -kv[1]["total_ms"]) if x["total_ms"] > 0.05},
+                                        sorted(p.items(), key=lambda kv: -kv[1]["total_ms"]) if x["total_ms"] > 0.01},
           "sum", round(tot / sp.iterations, 3), "launches/it", round(sum(x["launches"] for x in p.values()) / sp.iterations, 1))
