@@ -48,9 +48,20 @@ __device__ long long g_flow_cycles[128 * 8];  // shader-clock counter at the sam
       g_flow_cycles[(j) * 8 + (e)] = (long long)__builtin_readcyclecounter();       \
     }                                                                               \
   } while (0)
+// the dependency loop around the chain, per diagonal block j (wall clock): 0 M_j stores issued, 1 M_j published,
+// 2 the worker of tile (j+2, j) has seen it, 3 has published its tile, 4 the accumulator workgroup of row j+2 has seen both
+// tiles of column j, 5 has added them, 6 has handed its accumulators over
+__device__ long long g_flow_loop[128 * 8];
+#define FLOW_LOOP_STAMP(j, e, cond)                                                                       \
+  do {                                                                                                    \
+    if ((cond) && (j) >= 0 && (j) < 128) g_flow_loop[(j) * 8 + (e)] = (long long)wall_clock64();          \
+  } while (0)
 #else
 #define CHOL_STAMP(i) \
   do {                \
+  } while (0)
+#define FLOW_LOOP_STAMP(j, e, cond) \
+  do {                              \
   } while (0)
 #define FLOW_STAMP(j, e) \
   do {                   \
@@ -1126,6 +1137,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j);
       flow_fetch(tile_src(j - 1, k), lda, 64, 64, va);
       flow_wait(a.tf + (size_t)j * a.nb + k, a, j);
+      FLOW_LOOP_STAMP(k, 4, tid == 0 && k == j - 2);
       flow_fetch(tile_src(j, k), lda, tile_rows(j), 64, vb);
       __syncthreads();  // previous step's MFMA reads of buf0 / buf1 are done
       flow_put(buf0, va);
@@ -1135,6 +1147,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       for (int ks = 0; ks < 16; ++ks) xi[ks] = buf1[(4 * ks + q) * LP + 16 * wv + m];
       flow_update(accP, buf0, xi, 4, lane);
       if (has_diag) flow_update(accD, buf1, xi, ja_end, lane);
+      FLOW_LOOP_STAMP(k, 5, tid == 192 && k == j - 2);  // wave 3 has the most MFMAs
     }
     double* hp = hand + (size_t)j * 8192 + 2 * tid;  // element ks of thread tid at (ks >> 1) * 512 + 2 * tid + (ks & 1)
 #pragma unroll
@@ -1143,6 +1156,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       if (has_diag) st_sc1_x2(hp + 4096 + 256 * ks, accD[ks >> 2][ks & 3], accD[(ks + 1) >> 2][(ks + 1) & 3]);
     }
     flow_arrive(a.hf + j);
+    FLOW_LOOP_STAMP(j - 2, 6, tid == 0);
     {
       double mv[16], x[16];
       flow_wait(a.mf + (j - 1), a, j, kChainArrivals);
@@ -1210,6 +1224,14 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         flow_trsm(sh.Ms, accP, x, lane);  // M_{j-1}: lower part from potf2_invert_lds, zeros above
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) xs[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
+        // M_{j-1} left this CU ~2.5 us ago (the stores were issued before this step's X): the waves that stored it confirm
+        // and publish it here -- behind the next potf2's first pivots it was 3.5 us later, and that delay sits on the
+        // dependency loop (publish -> worker tile -> row accumulators -> this chain) that bounds the step
+        if (wv != 0 && m_pending) {
+          flow_arrive(a.mf + (j - 1));
+          FLOW_LOOP_STAMP(j - 1, 1, tid == 64);
+        }
+        m_pending = false;
         lds_barrier();
         FLOW_STAMP(j, 4);
         flow_update(accD, xs, x, ja_end, lane);
@@ -1240,13 +1262,9 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         }
       }
       lds_barrier();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
-      // M_{j-1} (and L_{j-1,j-1}) of the last step: the waves 1..3, which stored them, confirm their stores and arrive
-      // while they would otherwise idle behind wave 0's first pivots.
-      const bool m_was_pending = m_pending;
-      potf2_factor_lds(sh, [&] {
-        if (m_was_pending) flow_arrive(a.mf + (j - 1));
-      });
-      m_pending = false;
+      FLOW_STAMP(j, 2);
+      potf2_factor_lds(sh, [] {});
+      FLOW_LOOP_STAMP(j, 7, tid == 0);
       // the next step's accumulators: ask for them now if their owner is done (it normally is), else after the inversion
       if (j + 1 < a.ntr) {
         const bool ready = __hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kFlowArrivals;
@@ -1293,6 +1311,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         }
       }
       m_pending = true;
+      FLOW_LOOP_STAMP(j, 0, tid == 64);
       if (64 * j + kb < a.nr && kb < 64 && tid < kb) {  // y = e M^T for the right-hand-side row inside this tile
         double y = 0.0;
         for (int t = 0; t <= tid; ++t) y = __builtin_fma(ex[t], sh.Ms[t * LP + tid], y);
@@ -1335,6 +1354,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       {
         double mv[16];
         flow_wait(a.mf + k, a, code, kChainArrivals);
+        FLOW_LOOP_STAMP(k, 2, tid == 0 && i == k + 2);
         flow_fetch_lower(a.dinv + (size_t)k * (NBI * NBI), mv);
         __syncthreads();
         flow_put(buf2, mv);
@@ -1345,6 +1365,7 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         if (t == k - j0) flow_trsm(buf2, acc[t], xi, lane);
       store_rows(i, k, xi);
       flow_arrive(a.tf + (size_t)i * a.nb + k);
+      FLOW_LOOP_STAMP(k, 3, tid == 0 && i == k + 2);
     } else {
       flow_wait(a.tf + (size_t)i * a.nb + k, a, code);
       load_rows(i, k, xi);

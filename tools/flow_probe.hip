@@ -67,6 +67,34 @@ int main(int argc, char** argv) {
         printf("%3d %7.2f    -       -    %7.2f %6.2f %8.1f %7.2f\n", j, us(s[1] - s[0]), us(s[6] - s[5]), us(s[7] - s[6]), us(s[7] - t0), step);
       }
     }
+    {  // the dependency loop: M_j published -> worker tile (j+2, j) -> accumulators of row j+2 -> chain step j+2
+      std::vector<long long> lp(128 * 8);
+      hipMemcpyFromSymbol(lp.data(), HIP_SYMBOL(g_flow_loop), lp.size() * 8);
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int cntl = 0;
+      for (int j = 4; j + 2 < nb; ++j) {
+        const long long* l = &lp[j * 8];
+        const long long tj = st[j * 8 + 6];  // end of potf2 of block j
+        acc[0] += us(l[0] - tj); acc[1] += us(l[1] - tj); acc[2] += us(l[2] - tj); acc[3] += us(l[3] - tj);
+        acc[4] += us(l[4] - tj); acc[5] += us(l[5] - tj); acc[6] += us(l[6] - tj);
+        acc[7] += us(st[(j + 2) * 8 + 1] - tj);
+        ++cntl;
+      }
+      if (cntl) {
+        double dw = 0, fa = 0, iv = 0;
+        for (int j = 4; j + 2 < nb; ++j) {
+          dw += us(st[j * 8 + 2] - st[j * 8 + 5]);
+          fa += us(lp[j * 8 + 7] - st[j * 8 + 2]);
+          iv += us(st[j * 8 + 6] - lp[j * 8 + 7]);
+        }
+        printf("inside the potf2 phase, mean us: D to LDS + barrier %.2f, 64 pivots + rank-16 updates %.2f, prefetch + inverse %.2f\n",
+               dw / cntl, fa / cntl, iv / cntl);
+      }
+      if (cntl)
+        printf("loop, mean us after the end of potf2(j): M stores issued %.2f, M published %.2f, worker saw it %.2f, tile (j+2, j) "
+               "published %.2f, row j+2 saw its column-j tiles %.2f, added them %.2f, handed over %.2f, chain has them %.2f\n",
+               acc[0] / cntl, acc[1] / cntl, acc[2] / cntl, acc[3] / cntl, acc[4] / cntl, acc[5] / cntl, acc[6] / cntl, acc[7] / cntl);
+    }
     const int cnt = nb - 2;
     if (cnt > 0)
       printf("mean over j >= 2: wait %.2f trsm %.2f upd+pub %.2f potf2 %.2f stores %.2f step %.2f us\n", sum[0] / cnt, sum[1] / cnt,
