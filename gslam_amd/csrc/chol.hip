@@ -38,6 +38,13 @@ __device__ long long g_probe[64];
   do {                                                                   \
     if (threadIdx.x == 0) g_probe[(i)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+#define CHAIN_STAMP(i)                                                   \
+  do {                                                                   \
+    if (threadIdx.x == 0) {                                              \
+      g_probe[(i)] = (long long)wall_clock64();                          \
+      if ((i) > 20) g_probe[(i) + 20] += g_probe[(i)] - g_probe[(i) - 1]; \
+    }                                                                    \
+  } while (0)
 // wall-clock stamps (100 MHz, common to all CUs) of diagonal workgroup j of potrf_flow_kernel: tools/flow_probe.hip
 __device__ long long g_flow_trace[128 * 8];
 __device__ long long g_flow_cycles[128 * 8];  // shader-clock counter at the same points: cycles / wall time = the clock
@@ -65,6 +72,9 @@ __device__ long long g_flow_loop[128 * 8];
   } while (0)
 #define FLOW_STAMP(j, e) \
   do {                   \
+  } while (0)
+#define CHAIN_STAMP(i) \
+  do {                 \
   } while (0)
 #endif
 
@@ -162,16 +172,21 @@ struct Potf2Lds {
   double Ts[32 * 33];
   double rinv[NBI];
   int bad;
+  int pivots_done, next_ready;  // potf2_chain_lds: wave 0 is through its last pivot / what the side wave found out meanwhile
 };
 
 // Factor the 64x64 block held in sh.As (lower, in place) and build M = L^-1 in sh.Ms.  Called by all 256 threads;
 // sh.As must be complete (identity padding for missing rows/cols), sh.bad cleared, and a barrier passed.
 // (two halves, so that a caller can slip other work -- a prefetch -- between the factorisation and the inversion)
 // `idle`: run once by the waves 1..3 while wave 0 is busy with the first 16 pivots
-template <typename F>
-__device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle) {
+// NW = waves of the calling workgroup (4 or 8): the pivots and the inversions belong to the waves 0..3, the MFMA tiles of
+// the trailing updates are dealt over all of them, every wave passes every barrier
+// (`tid`: the caller's thread index; the dataflow kernel passes an opaque copy per phase so that the address arithmetic of
+// one phase is not kept alive in registers -- or scratch -- through all the others)
+template <int NW = 4, typename F>
+__device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle, int tid = threadIdx.x) {
   double* As = sh.As;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63, wv = NW == 4 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
   for (int k = 0; k < NBI; k += NBS) {
     // (a) 16-column panel: diagonal block + rows below in one right-looking pass, wave 0, lane = row
@@ -192,7 +207,7 @@ __device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle) {
     CHOL_STAMP(2 + k / 8);
     // (b) rank-16 update of the trailing lower triangle on MFMA: tiles (ti >= tj), round-robin over the waves
     const int nb = (NBI - (k + NBS)) / NBS;
-    for (int t = wv; t < nb * (nb + 1) / 2; t += 4) {
+    for (int t = wv; t < nb * (nb + 1) / 2; t += NW) {
       const int ti = t < 1 ? 0 : (t < 3 ? 1 : 2), tj = t - ti * (ti + 1) / 2;  // nb <= 3
       const int rb = k + NBS + 16 * ti, cb = k + NBS + 16 * tj;
       const double4_t u = lds_mma<4>([&](int i, int tt) { return As[(k + tt) * LP + rb + i]; },
@@ -205,14 +220,15 @@ __device__ __forceinline__ void potf2_factor_lds(Potf2Lds& sh, F&& idle) {
   }
 }
 
-__device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
+template <int NW = 4>
+__device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh, int tid = threadIdx.x) {
   double* As = sh.As;
   double* Ms = sh.Ms;
   double* Ts = sh.Ts;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63, wv = NW == 4 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
   // inverses of the four 16x16 diagonal blocks, one per wave (column m of M per lane)
-  {
+  if (NW == 4 || wv < 4) {
     const int b0 = 16 * wv;
     double acc[NBS], ri[NBS], mi[NBS];
 #pragma unroll
@@ -248,16 +264,21 @@ __device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
   lds_barrier();
   // level 64: one 16x16 tile of the 32x32 products per wave
   {
-    const int tr = 16 * (wv & 1), tc = 16 * (wv >> 1);
-    const double4_t t1 = lds_mma<8>([&](int i, int t) { return As[t * LP + 32 + tr + i]; },     // C[i][t]
-                                    [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
+    const bool on = NW == 4 || wv < 4;
+    const int tr = 16 * (wv & 1), tc = 16 * ((wv >> 1) & 1);
+    if (on) {
+      const double4_t t1 = lds_mma<8>([&](int i, int t) { return As[t * LP + 32 + tr + i]; },     // C[i][t]
+                                      [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
+      for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
+    }
     lds_barrier();
-    const double4_t x = lds_mma<8>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + tr + i]; },  // B^-1[i][t]
-                                   [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);      // T[t][j]
+    if (on) {
+      const double4_t x = lds_mma<8>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + tr + i]; },  // B^-1[i][t]
+                                     [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);      // T[t][j]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
+      for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
+    }
   }
   lds_barrier();
 }
@@ -265,6 +286,138 @@ __device__ __forceinline__ void potf2_invert_lds(Potf2Lds& sh) {
 __device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
   potf2_factor_lds(sh, [] {});
   potf2_invert_lds(sh);
+}
+
+// potf2 + inverse for the chain workgroup of the dataflow launch (8 waves): the same arithmetic as potf2_factor_lds +
+// potf2_invert_lds, but the inversion no longer waits for the last pivot.  Column panel b of L is final as soon as its 16
+// pivots are done, so while wave 0 holds the pivots of panel b + 1 (the other waves would idle), wave 1 inverts the 16x16
+// diagonal block b and wave 2 builds the off-diagonal block of the first 32x32 inverse; what is left behind the last
+// pivot is: inverse of diagonal block 3 (with the products that do not need it alongside), one 16x16 product, one
+// 32x32 product -- ~1.7 us instead of ~3.9.  Waves 1, 2, 3, 5, 6, 7 do the side work: wave 4 shares its SIMD with wave 0.
+// `T2`: 16 x 17 doubles of scratch.
+// `side()` is run by the waves 1..7 during the last 16 pivots, behind their own work (they may watch sh.pivots_done),
+// `after_pivots()` by all waves right behind those pivots.
+template <typename FS, typename F>
+__device__ __forceinline__ void potf2_chain_lds(Potf2Lds& sh, double* T2, int tid, FS&& side, F&& after_pivots) {
+  double* As = sh.As;
+  double* Ms = sh.Ms;
+  double* Ts = sh.Ts;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, q = lane >> 4;
+  auto panel = [&](int k) {  // wave 0, lane = row
+    double s[NBS], ri[NBS];
+#pragma unroll
+    for (int c = 0; c < NBS; ++c) s[c] = As[(k + c) * LP + lane];
+    bool bad = false;
+    panel16_factor<0>(s, ri, As, k, lane, bad);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < NBS; ++c) sh.rinv[k + c] = ri[c];
+    }
+    if (bad) sh.bad = 1;
+  };
+  auto trailing = [&](int k) {  // rank-16 update of the trailing lower triangle: 16x16 tiles (ti >= tj) over the waves
+    const int nb = (NBI - (k + NBS)) / NBS;
+    for (int t = wv; t < nb * (nb + 1) / 2; t += 8) {
+      const int ti = t < 1 ? 0 : (t < 3 ? 1 : 2), tj = t - ti * (ti + 1) / 2;
+      const int rb = k + NBS + 16 * ti, cb = k + NBS + 16 * tj;
+      const double4_t u = lds_mma<4>([&](int i, int tt) { return As[(k + tt) * LP + rb + i]; },
+                                     [&](int tt, int j) { return As[(k + tt) * LP + cb + j]; }, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) As[(cb + m) * LP + rb + q + 4 * r] -= u[r];
+    }
+  };
+  auto inv_diag = [&](int b0) {  // one wave: column m of M per lane (all four 16-lane rows redundantly)
+    double acc[NBS], ri[NBS], mi[NBS];
+#pragma unroll
+    for (int j = 0; j < NBS; ++j) {
+      acc[j] = 0.0;
+      ri[j] = sh.rinv[b0 + j];
+    }
+    inv16<0>(acc, mi, ri, As + b0 * LP + b0, m);
+    if (lane < NBS) {
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) Ms[(b0 + m) * LP + b0 + j] = mi[j];
+    }
+  };
+  // inv([A 0; C B]) = [A^-1 0; -B^-1 C A^-1  B^-1] for the 32x32 block at b0: T = C A^-1 (into `t`, pitch tp), then -B^-1 T
+  auto pair_t = [&](int b0, double* t, int tp) {
+    const double4_t t1 = lds_mma<4>([&](int i, int tt) { return As[(b0 + tt) * LP + b0 + 16 + i]; },   // C[i][t]
+                                    [&](int tt, int j) { return Ms[(b0 + j) * LP + b0 + tt]; }, lane);  // A^-1[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[m * tp + q + 4 * r] = t1[r];
+  };
+  auto pair_x = [&](int b0, const double* t, int tp) {
+    const double4_t x = lds_mma<4>([&](int i, int tt) { return Ms[(b0 + 16 + tt) * LP + b0 + 16 + i]; },  // B^-1[i][t]
+                                   [&](int tt, int j) { return t[j * tp + tt]; }, lane);                   // T[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ms[(b0 + m) * LP + b0 + 16 + q + 4 * r] = -x[r];
+  };
+  // the 64-level products, one 16x16 tile (tr, tc) per wave
+  auto tile_of = [&](int& tr, int& tc) {  // waves 2, 3, 5, 6 (and 1, 2, 3, 5 with `shift`): tiles 0..3
+    const int t = wv == 2 ? 0 : (wv == 3 ? 1 : (wv == 5 ? 2 : 3));
+    tr = 16 * (t & 1);
+    tc = 16 * (t >> 1);
+  };
+  CHAIN_STAMP(20);
+  if (wv == 0) panel(0);
+  lds_barrier();
+  CHAIN_STAMP(21);
+  trailing(0);
+  lds_barrier();
+  CHAIN_STAMP(22);
+  if (wv == 0) panel(16);
+  else if (wv == 1) inv_diag(0);
+  lds_barrier();
+  CHAIN_STAMP(23);
+  trailing(16);
+  lds_barrier();
+  CHAIN_STAMP(24);
+  if (wv == 0) panel(32);
+  else if (wv == 1) inv_diag(16);
+  else if (wv == 2) pair_t(0, Ts, 33);
+  lds_barrier();
+  CHAIN_STAMP(25);
+  trailing(32);
+  lds_barrier();
+  CHAIN_STAMP(26);
+  if (wv == 0) {
+    panel(48);
+    if (lane == 0) *(volatile int*)&sh.pivots_done = 1;
+  } else {
+    if (wv == 1) inv_diag(32);
+    else if (wv == 2) pair_x(0, Ts, 33);
+    side();
+  }
+  lds_barrier();
+  CHAIN_STAMP(27);
+  after_pivots();
+  CHAIN_STAMP(28);
+  if (wv == 1) inv_diag(48);
+  else if (wv == 7) pair_t(32, T2, 17);
+  else if (wv == 2 || wv == 3 || wv == 5 || wv == 6) {
+    int tr, tc;
+    tile_of(tr, tc);
+    const double4_t t1 = lds_mma<8>([&](int i, int t) { return As[t * LP + 32 + tr + i]; },     // C[i][t]
+                                    [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
+  }
+  lds_barrier();
+  CHAIN_STAMP(29);
+  if (wv == 1) pair_x(32, T2, 17);
+  lds_barrier();
+  CHAIN_STAMP(30);
+  if (wv == 2 || wv == 3 || wv == 5 || wv == 6) {
+    int tr, tc;
+    tile_of(tr, tc);
+    const double4_t x = lds_mma<8>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + tr + i]; },  // B^-1[i][t]
+                                   [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);      // T[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
+  }
+  lds_barrier();
+  CHAIN_STAMP(31);
 }
 
 // write the factor back to A (lower part of the kb x kb block) and M to Minv (column-major, pitch 64, upper part zero)
@@ -957,9 +1110,9 @@ __global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __rest
 // Publishing = write-through (sc1) stores, every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE relaxed agent-scope
 // flag store; consuming = relaxed poll of that ONE word, then sc1 loads.  Every wait is bounded and watches a common
 // abort word: an expired wait raises `info`, sets the abort word and the launch runs out (with garbage) instead of hanging.
-constexpr int FL_MAXT = 6;                       // tiles per worker: 6 x 16 accumulator doubles per lane
+constexpr int FL_MAXT = 6;                       // tiles per worker: 3 per half of the workgroup, 16 accumulator doubles per lane each
 constexpr unsigned kFlowSpinLimit = 1u << 22;
-constexpr int kFlowLdsBytes = 3 * NBI * LP * (int)sizeof(double) + 10240;  // three tile buffers (or Potf2Lds) + extras
+constexpr int kFlowLdsBytes = 4 * NBI * LP * (int)sizeof(double) + 1024;  // four tile buffers (or Potf2Lds + extras)
 
 struct FlowArgs {
   double* A;
@@ -995,9 +1148,10 @@ __device__ __forceinline__ void st_sc1_x2(double* p, double v0, double v1) {
 }
 // Every publication is made of arrivals, one per storing wave of the publishing workgroup: the wave drains its own stores
 // and adds 1 to the word -- no workgroup barrier on the publishing side.  Consumers wait for the word to reach the number
-// of storing waves: 4 for a tile of L, 3 for an M block (the chain workgroup's wave 0 never stores: it has to go straight
-// into the pivots of the next diagonal block while the other three, idle behind it, wait for their stores to be confirmed).
-constexpr unsigned kFlowArrivals = 4, kChainArrivals = 3;
+// of storing waves: 4 for a tile of L (one half of a workgroup writes it), 8 for a row's accumulators, 7 for an M block
+// (the chain workgroup's wave 0 never stores: it has to go straight into the pivots of the next diagonal block while the
+// others, idle behind it, wait for their stores to be confirmed).
+constexpr unsigned kFlowArrivals = 4, kChainArrivals = 7, kHandArrivals = 8;
 __device__ __forceinline__ void flow_arrive(unsigned* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1019,10 +1173,14 @@ __device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& 
   }
   asm volatile("" ::: "memory");
 }
-// 64 x 64 tile (column-major, leading dimension ld, `rows` x `cols` valid, the rest reads as zero): thread = (row, 4
-// interleaved column sets) so that every wave instruction reads 512 contiguous bytes; LDS image [column][row], pitch LP
+// The workgroups of the dataflow launch are 512 threads: two HALVES of four waves that do the tile work of a role side by
+// side (one wave per SIMD sustains one f64 MFMA per ~120 cycles, two reach the pipe's 64: tools/lat_probe.hip).  Inside a
+// half, wave `rg` holds rows 16 rg .. 16 rg + 15 of a tile; `lt` numbers the 256 threads of the half.
+// 64 x 64 tile (column-major, leading dimension ld, `rows` x `cols` valid, the rest reads as zero) fetched by ONE half:
+// thread = (row, 4 interleaved column sets) so that every wave instruction reads 512 contiguous bytes; LDS image
+// [column][row], pitch LP
 __device__ __forceinline__ void flow_fetch(const double* src, size_t ld, int rows, int cols, double (&v)[16]) {
-  const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  const int lt = threadIdx.x & 255, row = lt & 63, cq = lt >> 6;
   // wave-uniform base + one 32-bit lane offset: the 16 loads share their address registers
   const unsigned off = (unsigned)((size_t)cq * ld + row) * 8u;
 #pragma unroll
@@ -1031,20 +1189,26 @@ __device__ __forceinline__ void flow_fetch(const double* src, size_t ld, int row
     v[e] = (row < rows && cq + 4 * e < cols) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
   }
 }
-// M_k from dinv (pitch 64): only its lower triangle is ever stored by the dataflow launch; the rest reads as zero
-__device__ __forceinline__ void flow_fetch_lower(const double* src, double (&v)[16]) {
+__device__ __forceinline__ void flow_put(double* buf, const double (&v)[16]) {
+  const int lt = threadIdx.x & 255, row = lt & 63, cq = lt >> 6;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) buf[(cq + 4 * e) * LP + row] = v[e];
+}
+// M_k from dinv (pitch 64) by the WHOLE workgroup (8 interleaved column sets): only its lower triangle is ever stored by
+// the dataflow launch; the rest reads as zero
+__device__ __forceinline__ void flow_fetch_lower(const double* src, double (&v)[8]) {
   const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
   const unsigned off = (unsigned)(cq * NBI + row) * 8u;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const char* base = reinterpret_cast<const char*>(src + (size_t)(4 * e) * NBI);
-    v[e] = (cq + 4 * e <= row) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
+  for (int e = 0; e < 8; ++e) {
+    const char* base = reinterpret_cast<const char*>(src + (size_t)(8 * e) * NBI);
+    v[e] = (cq + 8 * e <= row) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
   }
 }
-__device__ __forceinline__ void flow_put(double* buf, const double (&v)[16]) {
+__device__ __forceinline__ void flow_put_lower(double* buf, const double (&v)[8]) {
   const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) buf[(cq + 4 * e) * LP + row] = v[e];
+  for (int e = 0; e < 8; ++e) buf[(cq + 8 * e) * LP + row] = v[e];
 }
 // acc(ja)[r] += sum_k T[16 ja + (lane >> 4) + 4 r][k] * x[k-th operand]  with T staged in `buf`, for ja < ja_end
 __device__ __forceinline__ void flow_update(double4_t (&acc)[4], const double* buf, const double (&x)[16], int ja_end, int lane) {
@@ -1058,39 +1222,48 @@ __device__ __forceinline__ void flow_update(double4_t (&acc)[4], const double* b
     }
   }
 }
-// x = P M^T for the wave's 16 rows, P = A - S = -acc; M staged in `mbuf`; result in operand layout (= accumulator layout)
-__device__ __forceinline__ void flow_trsm(const double* mbuf, const double4_t (&acc)[4], double (&x)[16], int lane) {
+// 16 columns (block jt) of x = P M^T for the wave's 16 rows, P in operand layout; M staged in `mbuf`
+template <int JT>
+__device__ __forceinline__ double4_t flow_trsm_block(const double* mbuf, const double (&pb)[16], int lane) {
   const int m = lane & 15, q = lane >> 4;
+  double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 4 * (JT + 1); ++ks)  // M[j][k] = 0 for k > j
+    t = __builtin_amdgcn_mfma_f64_16x16x4f64(mbuf[(4 * ks + q) * LP + 16 * JT + m], pb[ks], t, 0, 0, 0);
+  return t;
+}
+// x = P M^T for the wave's 16 rows, P = A - S = -acc; result in operand layout (= accumulator layout)
+__device__ __forceinline__ void flow_trsm(const double* mbuf, const double4_t (&acc)[4], double (&x)[16], int lane) {
   double pb[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) pb[ks] = -acc[ks >> 2][ks & 3];
+  const double4_t t0 = flow_trsm_block<0>(mbuf, pb, lane), t1 = flow_trsm_block<1>(mbuf, pb, lane);
+  const double4_t t2 = flow_trsm_block<2>(mbuf, pb, lane), t3 = flow_trsm_block<3>(mbuf, pb, lane);
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 4 * (jt + 1); ++ks)  // M[j][k] = 0 for k > j
-      t = __builtin_amdgcn_mfma_f64_16x16x4f64(mbuf[(4 * ks + q) * LP + 16 * jt + m], pb[ks], t, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[4 * jt + r] = t[r];
+  for (int r = 0; r < 4; ++r) {
+    x[r] = t0[r];
+    x[4 + r] = t1[r];
+    x[8 + r] = t2[r];
+    x[12 + r] = t3[r];
   }
 }
 
-__global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
+__global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char flow_lds[];
-  double* buf0 = reinterpret_cast<double*>(flow_lds);
-  double* buf1 = buf0 + NBI * LP;
-  double* buf2 = buf1 + NBI * LP;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+  auto tb = [&](int b) { return reinterpret_cast<double*>(flow_lds) + (size_t)b * (NBI * LP); };  // four tile buffers
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler knows it: scalar branches
+  const int half = wv >> 2, rg = wv & 3, lt = tid & 255;
   double* const A = a.A;
   const size_t lda = (size_t)a.lda;
   const int bid = blockIdx.x;
-  // operand-layout view of the wave's 16 rows of tile (ti, tj): element ks <-> (row 64 ti + 16 wv + m, column 64 tj + 4 ks + q)
+  // operand-layout view of the wave's 16 rows of tile (ti, tj): element ks <-> (row 64 ti + 16 rg + m, column 64 tj + 4 ks + q)
   // (the 16 accesses of a lane share one 32-bit offset from wave-uniform bases)
-  const unsigned lane_off = (unsigned)((size_t)q * lda + 16 * wv + m) * 8u;
+  const unsigned lane_off = (unsigned)((size_t)q * lda + 16 * rg + m) * 8u;
   auto elem = [&](int ti, int tj, int ks) {
     return reinterpret_cast<double*>(reinterpret_cast<char*>(A + (size_t)(64 * tj + 4 * ks) * lda + 64 * ti) + lane_off);
   };
-  auto row_of = [&](int ti) { return 64 * ti + 16 * wv + m; };
+  auto row_of = [&](int ti) { return 64 * ti + 16 * rg + m; };
   auto load_orig = [&](int ti, int tj, double (&v)[16]) {
     const int row = row_of(ti);
 #pragma unroll
@@ -1114,59 +1287,63 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
   double* const hand = a.hand;                  // [ntr][2][4096]: accumulators of (j, j-1) and (j, j), thread-major
   if (bid >= 1 && bid <= n_acc) {
     // ------------------------------------------------------------ accumulator workgroup of tile row j = bid:
-    // -A + sum_{k <= j-2} for the tiles (j, j-1) and (j, j), handed to the chain workgroup; then, with M_{j-1}, the
-    // same X = (j, j-1) M_{j-1}^T the chain computes for itself, written to its place in L: the chain workgroup, whose
-    // path to memory is on the critical chain (a CU drains write-through stores at ~20 GB/s), stores nothing but M_j
+    // -A + sum_{k <= j-2} for the tiles (j, j-1) [half 0] and (j, j) [half 1], handed to the chain workgroup; then, with
+    // M_{j-1}, the same X = (j, j-1) M_{j-1}^T the chain computes for itself, written to its place in L: the chain
+    // workgroup, whose path to memory is on the critical chain (a CU drains write-through stores at ~20 GB/s), stores
+    // nothing but M_j
     const int j = bid;
     const bool has_diag = j < a.nb;
-    double4_t accP[4], accD[4];
+    const bool busy = half == 0 || has_diag;
+    double4_t acc[4];
     {  // only tiles this workgroup owns are ever read with plain loads
       double v[16];
-      load_orig(j, j - 1, v);
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) accP[ks >> 2][ks & 3] = -v[ks];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
-      if (has_diag) load_orig(j, j, v);
+      if (half == 0) load_orig(j, j - 1, v);
+      else if (has_diag) load_orig(j, j, v);
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) accD[ks >> 2][ks & 3] = -v[ks];
+      for (int ks = 0; ks < 16; ++ks) acc[ks >> 2][ks & 3] = -v[ks];
     }
-    const int ja_end = wv + 1;  // lower part of the diagonal tile: columns 16 ja .. <= rows 16 wv ..
-    double va[16], vb[16], xi[16];
+    // half 0 stages L[j-1, k] (its accumulators are the full tile), half 1 stages L[j, k] (lower part of the diagonal
+    // tile: columns 16 ja .. <= rows 16 rg ..); the rows of L[j, k] are the other operand of both
+    const int ja_end = half == 0 ? 4 : rg + 1;
+    const int ti = half == 0 ? j - 1 : j;
+    double* const own = tb(half);
+    double v[16], xi[16];
     for (int k = 0; k <= j - 2; ++k) {
-      flow_wait(a.tf + (size_t)(j - 1) * a.nb + k, a, j);
-      flow_fetch(tile_src(j - 1, k), lda, 64, 64, va);
-      flow_wait(a.tf + (size_t)j * a.nb + k, a, j);
-      FLOW_LOOP_STAMP(k, 4, tid == 0 && k == j - 2);
-      flow_fetch(tile_src(j, k), lda, tile_rows(j), 64, vb);
-      __syncthreads();  // previous step's MFMA reads of buf0 / buf1 are done
-      flow_put(buf0, va);
-      flow_put(buf1, vb);
+      flow_wait(a.tf + (size_t)ti * a.nb + k, a, j);
+      FLOW_LOOP_STAMP(k, 4, tid == 256 && k == j - 2);
+      flow_fetch(tile_src(ti, k), lda, tile_rows(ti), 64, v);
+      __syncthreads();  // previous step's MFMA reads of the two buffers are done
+      flow_put(own, v);
       __syncthreads();
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) xi[ks] = buf1[(4 * ks + q) * LP + 16 * wv + m];
-      flow_update(accP, buf0, xi, 4, lane);
-      if (has_diag) flow_update(accD, buf1, xi, ja_end, lane);
-      FLOW_LOOP_STAMP(k, 5, tid == 192 && k == j - 2);  // wave 3 has the most MFMAs
+      for (int ks = 0; ks < 16; ++ks) xi[ks] = tb(1)[(4 * ks + q) * LP + 16 * rg + m];
+      if (busy) flow_update(acc, own, xi, ja_end, lane);
+      FLOW_LOOP_STAMP(k, 5, tid == 192 && k == j - 2);
     }
-    double* hp = hand + (size_t)j * 8192 + 2 * tid;  // element ks of thread tid at (ks >> 1) * 512 + 2 * tid + (ks & 1)
+    double* hp = hand + (size_t)j * 8192 + 4096 * half + 2 * lt;  // element ks of thread lt at (ks >> 1) * 512 + 2 lt + (ks & 1)
+    if (busy) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ks += 2) {
-      st_sc1_x2(hp + 256 * ks, accP[ks >> 2][ks & 3], accP[(ks + 1) >> 2][(ks + 1) & 3]);
-      if (has_diag) st_sc1_x2(hp + 4096 + 256 * ks, accD[ks >> 2][ks & 3], accD[(ks + 1) >> 2][(ks + 1) & 3]);
+      for (int ks = 0; ks < 16; ks += 2) st_sc1_x2(hp + 256 * ks, acc[ks >> 2][ks & 3], acc[(ks + 1) >> 2][(ks + 1) & 3]);
     }
     flow_arrive(a.hf + j);
     FLOW_LOOP_STAMP(j - 2, 6, tid == 0);
     {
-      double mv[16], x[16];
-      flow_wait(a.mf + (j - 1), a, j, kChainArrivals);
+      double mv[8];
+      // ONE wave polls (every M block has ~45 workgroups waiting for it, and their polls queue in the same L2 channel as
+      // the chain's arrivals), the others wait at the barrier
+      if (wv == 0) flow_wait(a.mf + (j - 1), a, j, kChainArrivals);
+      lds_barrier();
       flow_fetch_lower(a.dinv + (size_t)(j - 1) * (NBI * NBI), mv);
+      flow_put_lower(tb(2), mv);  // a buffer the loop above never used
       __syncthreads();
-      flow_put(buf2, mv);
-      __syncthreads();
-      flow_trsm(buf2, accP, x, lane);
-      store_rows(j, j - 1, x);
-      flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
+      if (half == 0) {
+        double x[16];
+        flow_trsm(tb(2), acc, x, lane);
+        store_rows(j, j - 1, x);
+        flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
+      }
     }
     return;
   }
@@ -1174,57 +1351,87 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     // ------------------------------------------------------------ the chain: every diagonal block, one after the other
     // step j:  X = (j, j-1) M_{j-1}^T with M_{j-1} still in LDS from the step before;  (j, j) -= X X^T;  potf2 + inverse.
     // What the step needs from outside -- the two accumulator tiles of row j -- is requested in the middle of the
-    // previous step's potf2 (they are ready by then) and lands while that potf2 finishes.
+    // previous step's potf2 (they are ready by then) and lands while that potf2 finishes.  The two halves share the MFMA
+    // phases: column blocks {0, 3} / {1, 2} of X (20 MFMAs a wave), and the 16-column blocks {0, 1} / {2, 3} of the
+    // diagonal tile, whose accumulators each half holds only its part of.
     Potf2Lds& sh = *reinterpret_cast<Potf2Lds*>(flow_lds);
     static_assert(sizeof(Potf2Lds) + 64 * sizeof(double) + NBI * LP * sizeof(double) <= (size_t)kFlowLdsBytes,
                   "chain role: Potf2Lds + the extra row + one staging tile");
     double* ex = reinterpret_cast<double*>(flow_lds + sizeof(Potf2Lds));  // the extra (right-hand-side) row of the tile
     double* xs = ex + 64;                                                 // X staged as [k][row], pitch LP
-    const int ja_end = wv + 1;
-    double nP[16], nD[16];  // accumulators of the NEXT step, in flight
+    double nP[16], nD[8];  // accumulators of the NEXT step, in flight
     bool have_next = false;
-    auto request = [&](int jn) {  // jn >= 1: from the accumulator workgroup; block 0: the matrix itself
-      if (jn >= 1) {
-        const double* hp = hand + (size_t)jn * 8192 + 2 * tid;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          nP[ks] = ld_sc1(hp + 256 * (ks & ~1) + (ks & 1));
-          nD[ks] = ld_sc1(hp + 4096 + 256 * (ks & ~1) + (ks & 1));
-        }
-      } else {
-        double v[16];
-        load_orig(0, 0, v);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          nP[ks] = 0.0;
-          nD[ks] = -v[ks];
-        }
-      }
-    };
+    // the ten 16x16 tiles (row block, column block) of the lower part of the diagonal tile, dealt over the waves so that every
+    // SIMD (waves s and s + 4) has 3 or 2 of them: {(0,0),(3,3) | (3,0)}, {(1,0),(1,1) | (3,1)}, {(2,0) | (2,1)}, {(2,2) | (3,2)}
+    const int dr0 = wv == 0 ? 0 : (wv == 1 ? 1 : (wv == 2 || wv == 3 || wv == 6 ? 2 : 3));
+    const int dc0 = wv == 5 || wv == 6 ? 1 : (wv == 3 || wv == 7 ? 2 : 0);
+    const int dr1 = wv == 0 ? 3 : (wv == 1 ? 1 : -1), dc1 = wv == 0 ? 3 : 1;
+    {  // the upper part of the image is never written again except with zeros (potf2 masks it)
+      double* z = reinterpret_cast<double*>(flow_lds);
+      for (int e = tid; e < NBI * LP; e += 512) z[e] = 0.0;
+      lds_barrier();
+    }
     bool m_pending = false;  // M_{j-1} is stored but its flag is not up yet
+    const int tid_all = tid;
     for (int j = 0; j < a.ntr; ++j) {
       const bool has_diag = j < a.nb;
       const int kb = has_diag ? (a.n - 64 * j < 64 ? a.n - 64 * j : 64) : 0;
+      // an opaque copy of the thread index per phase: what a phase derives from it (LDS offsets, lane predicates) dies with
+      // the phase instead of being hoisted out of the loop -- hoisted, they overflowed the 256 registers a wave of a
+      // 512-thread workgroup has and were reloaded from scratch on the chain
+      int tid = tid_all;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, m = lane & 15, q = lane >> 4, lt = tid & 255;
+      auto request = [&](int jn) {  // jn >= 1: from the accumulator workgroup; block 0: the matrix itself
+        if (jn >= 1) {
+          const double* hp = hand + (size_t)jn * 8192 + 2 * lt;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) nP[ks] = ld_sc1(hp + 256 * (ks & ~1) + (ks & 1));
+          const double* hd = hand + (size_t)jn * 8192 + 4096 + 2 * lane;  // the diagonal tile's accumulators, thread-major
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            nD[r] = ld_sc1(hd + (2 * dc0 + (r >> 1)) * 512 + 128 * dr0 + (r & 1));
+            nD[4 + r] = dr1 >= 0 ? ld_sc1(hd + (2 * dc1 + (r >> 1)) * 512 + 128 * dr1 + (r & 1)) : 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) nP[ks] = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row0 = 16 * dr0 + m, col0 = 16 * dc0 + 4 * r + q, row1 = 16 * dr1 + m, col1 = 16 * dc1 + 4 * r + q;
+            nD[r] = (row0 < a.nr && col0 < a.n) ? -A[(size_t)col0 * lda + row0] : 0.0;
+            nD[4 + r] = (dr1 >= 0 && row1 < a.nr && col1 < a.n) ? -A[(size_t)col1 * lda + row1] : 0.0;
+          }
+        }
+      };
       FLOW_STAMP(j, 0);
       if (!have_next) {
-        if (j >= 1) flow_wait(a.hf + j, a, j);
+        if (j >= 1) flow_wait(a.hf + j, a, j, kHandArrivals);
         request(j);
       }
       have_next = false;
-      double4_t accP[4], accD[4];
+      double pb[16];
+      double4_t accD[2];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        accP[ks >> 2][ks & 3] = nP[ks];
-        accD[ks >> 2][ks & 3] = nD[ks];
-      }
+      for (int ks = 0; ks < 16; ++ks) pb[ks] = -nP[ks];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) accD[e >> 2][e & 3] = nD[e];
       FLOW_STAMP(j, 1);
       if (j >= 1 && has_diag) {
-        double x[16];
         FLOW_STAMP(j, 3);
-        flow_trsm(sh.Ms, accP, x, lane);  // M_{j-1}: lower part from potf2_invert_lds, zeros above
+        // M_{j-1}: lower part from potf2_invert_lds, zeros above
+        auto stage = [&](int jt, const double4_t& t) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) xs[(4 * ks + q) * LP + 16 * wv + m] = x[ks];
-        // M_{j-1} left this CU ~2.5 us ago (the stores were issued before this step's X): the waves that stored it confirm
+          for (int r = 0; r < 4; ++r) xs[(4 * (4 * jt + r) + q) * LP + 16 * rg + m] = t[r];
+        };
+        if (half == 0) {
+          stage(0, flow_trsm_block<0>(sh.Ms, pb, lane));
+          stage(3, flow_trsm_block<3>(sh.Ms, pb, lane));
+        } else {
+          stage(1, flow_trsm_block<1>(sh.Ms, pb, lane));
+          stage(2, flow_trsm_block<2>(sh.Ms, pb, lane));
+        }
+        // M_{j-1} left this CU ~2 us ago (the stores were issued before this step's X): the waves that stored it confirm
         // and publish it here -- behind the next potf2's first pivots it was 3.5 us later, and that delay sits on the
         // dependency loop (publish -> worker tile -> row accumulators -> this chain) that bounds the step
         if (wv != 0 && m_pending) {
@@ -1234,7 +1441,20 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
         m_pending = false;
         lds_barrier();
         FLOW_STAMP(j, 4);
-        flow_update(accD, xs, x, ja_end, lane);
+        {
+          double x0[16], x1[16];
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            x0[ks] = xs[(4 * ks + q) * LP + 16 * dr0 + m];
+            x1[ks] = dr1 >= 0 ? xs[(4 * ks + q) * LP + 16 * dr1 + m] : 0.0;
+          }
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {  // (two independent accumulation chains side by side)
+            accD[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[(4 * ks + q) * LP + 16 * dc0 + m], x0[ks], accD[0], 0, 0, 0);
+            if (dr1 >= 0)
+              accD[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[(4 * ks + q) * LP + 16 * dc1 + m], x1[ks], accD[1], 0, 0, 0);
+          }
+        }
       }
       if (!has_diag) {  // the right-hand-side-only tile row: nothing to factor (its accumulator workgroup writes X)
         if (wv != 0 && m_pending) flow_arrive(a.mf + (j - 1));
@@ -1245,63 +1465,93 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
       // D = A_jj - S into sh.As (lower part, identity padding); the tile's row past the block (the right-hand side) aside
       if (tid == 0) sh.bad = 0;
       {
-        const int row = 16 * wv + m;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {  // every (row, col) of the 64 x 64 block is written by exactly one lane
-          const int col = 4 * ks + q;
-          const double d = -accD[ks >> 2][ks & 3];  // meaningful for col <= row (the waves skip the upper tiles)
-          double v = (row == col) ? 1.0 : 0.0;
-          if (row < kb && col < kb) v = col <= row ? d : 0.0;
-          sh.As[col * LP + row] = v;
-          if (row == kb && col < kb) ex[col] = d;
+        for (int e = 0; e < 8; ++e) {  // every (row, col) of the lower 16x16 tiles is written by exactly one lane
+          const int dr = e < 4 ? dr0 : dr1, dc = e < 4 ? dc0 : dc1;
+          if (dr >= 0) {
+            const int row = 16 * dr + m, col = 16 * dc + 4 * (e & 3) + q;
+            const double d = -accD[e >> 2][e & 3];
+            double v = (row == col) ? 1.0 : 0.0;
+            if (row < kb && col < kb) v = col <= row ? d : 0.0;
+            sh.As[col * LP + row] = v;
+            if (row == kb && col < kb) ex[col] = d;
+          }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int idx = tid + 256 * e;
+        for (int e = 0; e < 8; ++e) {
+          const int idx = tid + 512 * e;
           sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
         }
       }
       lds_barrier();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
       FLOW_STAMP(j, 2);
-      potf2_factor_lds(sh, [] {});
-      FLOW_LOOP_STAMP(j, 7, tid == 0);
-      // the next step's accumulators: ask for them now if their owner is done (it normally is), else after the inversion
-      if (j + 1 < a.ntr) {
-        const bool ready = __hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kFlowArrivals;
-        if (ready) {
-          asm volatile("" ::: "memory");
-          request(j + 1);
-          have_next = true;
-        }
+      int tid_f = tid_all;
+      asm volatile("" : "+v"(tid_f));
+      if (tid == 0) {
+        sh.pivots_done = 0;
+        sh.next_ready = 0;
       }
-      potf2_invert_lds(sh);
+      // The next step's accumulators: their owner is normally done before this block's last pivots.  Wave 5, idle by then,
+      // watches the owner's word; the other idle waves watch wave 5 (in LDS) and ask for their part of the two tiles while
+      // wave 0 is still in its pivots -- 512 threads x 24 loads keep the CU's memory pipe busy for ~1.5 us, which used to
+      // sit between the last pivot and the inversion.  Whoever has not asked by the end of the pivots (wave 0 always) does
+      // so then; if the owner is late, everybody asks at the top of the next step.
+      bool requested = false;
+      potf2_chain_lds(
+          sh, xs, tid_f,
+          [&] {
+            if (j + 1 >= a.ntr) return;
+            for (;;) {
+              if (wv == 5) {
+                if (__hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHandArrivals)
+                  *(volatile int*)&sh.next_ready = 1;
+              }
+              if (*(volatile int*)&sh.next_ready) break;
+              if (*(volatile int*)&sh.pivots_done) break;
+              if (wv == 4) __builtin_amdgcn_s_sleep(8);  // shares its SIMD with wave 0
+              else __builtin_amdgcn_s_sleep(2);
+            }
+            if (*(volatile int*)&sh.next_ready) {
+              asm volatile("" ::: "memory");
+              request(j + 1);
+              requested = true;
+            }
+          },
+          [&] {
+            FLOW_LOOP_STAMP(j, 7, tid_f == 0);
+            if (*(volatile int*)&sh.next_ready) {
+              if (!requested) request(j + 1);
+              have_next = true;
+            }
+          });
       FLOW_STAMP(j, 6);
       if (tid == 0 && sh.bad) atomicMax(a.info, 64 * j + 1);
       double* Minv = a.dinv + (size_t)j * (NBI * NBI);
-      if (wv != 0) {  // M_j (lower triangle only) and, if asked for, L_jj leave through the waves 1..3
-        const int t3 = tid - 64;
-        double m0[11], m1[11];
+      if (wv != 0) {  // M_j (lower triangle only) and, if asked for, L_jj leave through the waves 1..7
+        int t7 = tid_all - 64;
+        asm volatile("" : "+v"(t7));
+        double m0[5], m1[5];
 #pragma unroll
-        for (int e = 0; e < 11; ++e) {  // 2048 row pairs over 192 lanes; every LDS read first, then the stores
-          const int idx = t3 + 192 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
+        for (int e = 0; e < 5; ++e) {  // 2048 row pairs over 448 lanes; every LDS read first, then the stores
+          const int idx = t7 + 448 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
           m0[e] = sh.Ms[c * LP + r];
           m1[e] = sh.Ms[c * LP + r + 1];
         }
 #pragma unroll
-        for (int e = 0; e < 11; ++e) {
-          const int idx = t3 + 192 * e, c = idx >> 5, r = 2 * (idx & 31);
+        for (int e = 0; e < 5; ++e) {
+          const int idx = t7 + 448 * e, c = idx >> 5, r = 2 * (idx & 31);
           if (idx < 2048 && c <= r + 1) st_sc1_x2(Minv + c * NBI + r, (c <= r) ? m0[e] : 0.0, m1[e]);
         }
         if (a.store_diag) {  // nobody reads L_jj inside this launch (plain stores)
 #pragma unroll
-          for (int e = 0; e < 11; ++e) {
-            const int idx = t3 + 192 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
+          for (int e = 0; e < 5; ++e) {
+            const int idx = t7 + 448 * e, c = (idx >> 5) & 63, r = 2 * (idx & 31);
             m0[e] = sh.As[c * LP + r];
             m1[e] = sh.As[c * LP + r + 1];
           }
 #pragma unroll
-          for (int e = 0; e < 11; ++e) {
-            const int idx = t3 + 192 * e, c = idx >> 5, r = 2 * (idx & 31);
+          for (int e = 0; e < 5; ++e) {
+            const int idx = t7 + 448 * e, c = idx >> 5, r = 2 * (idx & 31);
             if (idx < 2048) {
               double* dst = A + (size_t)(64 * j + c) * lda + 64 * j + r;
               if (c < kb && c <= r && r < kb) dst[0] = m0[e];
@@ -1322,7 +1572,8 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     if (m_pending && wv != 0) flow_arrive(a.mf + (a.nb - 1));
     return;
   }
-  // -------------------------------------------------------------- worker: tiles (i, j0 .. j0 + T - 1), j0 + T - 1 <= i - 2
+  // -------------------------------------------------------------- worker: tiles (i, j0 .. j0 + T - 1), j0 + T - 1 <= i - 2;
+  // tile t belongs to half (t & 1): the halves run their tiles of a column side by side
   int g = bid - 1 - n_acc, i = 2, j0 = 0, T = 0;
   for (;; ++i) {
     if (i >= a.ntr) return;
@@ -1335,63 +1586,85 @@ __global__ __launch_bounds__(256) void potrf_flow_kernel(FlowArgs a) {
     }
     g -= groups;
   }
-  double4_t acc[FL_MAXT][4];
+  constexpr int FL_HALF = FL_MAXT / 2;
+  double4_t acc[FL_HALF][4];
 #pragma unroll
-  for (int t = 0; t < FL_MAXT; ++t) {
+  for (int u = 0; u < FL_HALF; ++u) {
     double v[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) v[ks] = 0.0;
-    if (t < T) load_orig(i, j0 + t, v);
+    if (2 * u + half < T) load_orig(i, j0 + 2 * u + half, v);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc[t][ks >> 2][ks & 3] = -v[ks];
+    for (int ks = 0; ks < 16; ++ks) acc[u][ks >> 2][ks & 3] = -v[ks];
   }
   const int j1 = j0 + T - 1;
   const int code = bid;
   for (int k = 0; k <= j1; ++k) {
     double xi[16];
     if (k >= j0) {
-      // own tile (i, k) has every column < k: finalise it, its X rows are this step's i-operand
+      // own tile (i, k) has every column < k: its half finalises it, and the X rows are this step's i-operand for both
+      const int tk = k - j0;
+      const bool mine = (tk & 1) == half, more = tk + 1 < T;
       {
-        double mv[16];
-        flow_wait(a.mf + k, a, code, kChainArrivals);
+        double mv[8];
+        if (wv == 0) flow_wait(a.mf + k, a, code, kChainArrivals);  // one poller per workgroup
+        lds_barrier();
         FLOW_LOOP_STAMP(k, 2, tid == 0 && i == k + 2);
         flow_fetch_lower(a.dinv + (size_t)k * (NBI * NBI), mv);
-        __syncthreads();
-        flow_put(buf2, mv);
+        flow_put_lower(tb(0), mv);  // every buffer is free: the barrier at the end of the previous step
       }
-      __syncthreads();
+      lds_barrier();
+      if (mine) {
 #pragma unroll
-      for (int t = 0; t < FL_MAXT; ++t)
-        if (t == k - j0) flow_trsm(buf2, acc[t], xi, lane);
-      store_rows(i, k, xi);
-      flow_arrive(a.tf + (size_t)i * a.nb + k);
-      FLOW_LOOP_STAMP(k, 3, tid == 0 && i == k + 2);
+        for (int u = 0; u < FL_HALF; ++u)
+          if (u == (tk >> 1)) flow_trsm(tb(0), acc[u], xi, lane);
+        store_rows(i, k, xi);
+        if (more) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) tb(1)[ks * 256 + lt] = xi[ks];
+        }
+      }
+      if (more) {
+        lds_barrier();
+        if (!mine) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) xi[ks] = tb(1)[ks * 256 + lt];
+        }
+        lds_barrier();  // tb(1) is a tile buffer again
+      }
+      if (mine) {
+        flow_arrive(a.tf + (size_t)i * a.nb + k);
+        FLOW_LOOP_STAMP(k, 3, lt == 0 && i == k + 2);
+      }
     } else {
       flow_wait(a.tf + (size_t)i * a.nb + k, a, code);
       load_rows(i, k, xi);
     }
-    // the other tiles: (i, j) += L[i, k] L[j, k]^T for j > k; operand tile (j, k) staged through LDS (two buffers), the
-    // next one already in flight while the MFMAs of the current one run
+    // the other tiles: (i, j) += L[i, k] L[j, k]^T for j > k; operand tile (j, k) staged through LDS (two buffers per
+    // half), the next one already in flight while the MFMAs of the current one run
     const int t_begin = k + 1 - j0 > 0 ? k + 1 - j0 : 0;
+    const int t_first = t_begin + ((half - t_begin) & 1);  // this half's first tile of the step
     double v[16];
-    if (t_begin < T) {
-      flow_wait(a.tf + (size_t)(j0 + t_begin) * a.nb + k, a, code);
-      flow_fetch(tile_src(j0 + t_begin, k), lda, 64, 64, v);
+    if (t_first < T) {
+      flow_wait(a.tf + (size_t)(j0 + t_first) * a.nb + k, a, code);
+      flow_fetch(tile_src(j0 + t_first, k), lda, 64, 64, v);
     }
 #pragma unroll
-    for (int t = 0; t < FL_MAXT; ++t) {
-      if (t >= t_begin && t < T) {
-        double* buf = (t & 1) ? buf1 : buf0;
-        flow_put(buf, v);
-        __syncthreads();
-        if (t + 1 < T) {
-          flow_wait(a.tf + (size_t)(j0 + t + 1) * a.nb + k, a, code);
-          flow_fetch(tile_src(j0 + t + 1, k), lda, 64, 64, v);
+    for (int u = 0; u < FL_HALF; ++u) {
+      if (2 * u + 1 >= t_begin && 2 * u < T) {  // (the same for both halves: they pass the barriers together)
+        const int t = 2 * u + half;
+        const bool act = t >= t_begin && t < T;
+        double* buf = tb(2 * half + (u & 1));
+        if (act) flow_put(buf, v);
+        lds_barrier();
+        if (act && t + 2 < T) {
+          flow_wait(a.tf + (size_t)(j0 + t + 2) * a.nb + k, a, code);
+          flow_fetch(tile_src(j0 + t + 2, k), lda, 64, 64, v);
         }
-        flow_update(acc[t], buf, xi, 4, lane);
+        if (act) flow_update(acc[u], buf, xi, 4, lane);
       }
     }
-    __syncthreads();  // both tile buffers free before the next step overwrites them
+    lds_barrier();  // every tile buffer free before the next step overwrites them
   }
 }
 
@@ -1577,7 +1850,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       fa.spin_limit = kFlowSpinLimit;
       if (const char* e = getenv("GSLAM_HIP_FLOW_SPIN_LIMIT")) fa.spin_limit = (unsigned)strtoul(e, nullptr, 10);
       GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
-      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 1 ? fa.ntr - 1 : 0) + groups), dim3(256),
+      GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 1 ? fa.ntr - 1 : 0) + groups), dim3(512),
                 kFlowLdsBytes, fa);
       return GH_OK;
     }

@@ -80,6 +80,17 @@ int main(int argc, char** argv) {
         acc[7] += us(st[(j + 2) * 8 + 1] - tj);
         ++cntl;
       }
+      {
+        std::vector<long long> pr(64);
+        hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_probe), pr.size() * 8);
+        static const char* nm[] = {"panel 0", "update", "panel 1 | inv 0", "update", "panel 2 | inv 1, T", "update",
+                                   "panel 3 | inv 2, X, poll", "request", "inv 3 | T', T64", "X32", "X64"};
+        printf("potf2 phases, mean over the blocks (us):");
+        for (int e = 0; e < 11; ++e) printf("  %s %.2f", nm[e], pr[41 + e] * 0.01 / nb);
+        printf("\n");
+        long long zero[64] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero, sizeof(zero));
+      }
       if (cntl) {
         double dw = 0, fa = 0, iv = 0;
         for (int j = 4; j + 2 < nb; ++j) {
