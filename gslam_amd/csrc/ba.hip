@@ -1228,11 +1228,63 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   // one extra row carries the right-hand side through the factorisation; columns start on 128-byte lines
   const int lda = (n + 1 + 15) & ~15;
 
+  // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
+  // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the middle
+  // of the launch chain, which left the GPU idle while the rest of the iteration was being enqueued.
+  struct Readback {
+    double cost, model;
+    unsigned long long gmax_bits;
+    int info, bad;
+    int32_t pair_counts[4];  // device-built pair lists: pairs, blocks, segments, (unused)
+  };
+  Readback* rb = nullptr;
+  {
+    void* pp = nullptr;
+    GH_TRY(gh_pinned(ctx, 256, &pp));
+    rb = (Readback*)pp;
+  }
+  DevBuf db(ctx);
+  double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
+  int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
+  uint8_t* d_pfree = nullptr;
+  // The caller's arrays (8.9 MB at C4, pageable: ~0.85 ms of staged copies) go up on a pool thread WHILE the host builds
+  // its index lists -- when the arena of an earlier solve is there to take them (a first solve, or one that has to grow
+  // the arena, uploads after the lists as before).
+  auto raw_arrays = [&](bool copy) -> gh_status {
+    auto put = [&](auto** out, auto* src, size_t count) -> gh_status {
+      GH_TRY(db.alloc(out, count));
+      if (copy && count)
+        GH_HIP(ctx, hipMemcpyAsync(*out, src, count * sizeof(**out), hipMemcpyHostToDevice, ctx->stream));
+      return GH_OK;
+    };
+    GH_TRY(put(&d_poses, pr->cam_pose, (size_t)nc * 7));
+    GH_TRY(put(&d_pts, pr->point_xyz, (size_t)np * 3));
+    GH_TRY(db.alloc(&d_poses_new, (size_t)nc * 7));
+    GH_TRY(db.alloc(&d_pts_new, (size_t)np * 3));
+    GH_TRY(put(&d_dof, pr->cam_dof, (size_t)nc));
+    if (pr->point_free) GH_TRY(put(&d_pfree, pr->point_free, (size_t)np));
+    GH_TRY(put(&d_ocam, pr->obs_cam, (size_t)no));
+    GH_TRY(put(&d_opt, pr->obs_point, (size_t)no));
+    GH_TRY(put(&d_oxy, pr->obs_xy, (size_t)no * 2));
+    if (pr->obs_info) GH_TRY(put(&d_oinfo, pr->obs_info, (size_t)no * 4));
+    return GH_OK;
+  };
+  const size_t raw_bytes = 8 * ((size_t)nc * 7 * 2 + (size_t)np * 3 * 2 + (size_t)no * 2 + (pr->obs_info ? (size_t)no * 4 : 0)) +
+                           4 * ((size_t)nc + 2 * (size_t)no) + (size_t)np + 16 * 256;
+  const char* early_env = getenv("GSLAM_HIP_BA_EARLY_UPLOAD");  // "0": upload after the lists (A/B measurements)
+  bool early = ctx->ba_arena != nullptr && raw_bytes <= ctx->ba_arena_bytes && !(early_env && early_env[0] == '0');
+  gh_status early_status = GH_OK;
+
   std::vector<int32_t> pstart, plist, cstart, clist;
-  HostPool::get().run(2, [&](int t) {
+  HostPool::get().run(early ? 3 : 2, [&](int t) {
     if (t == 0) build_csr(pr->obs_point, no, np, pstart, plist);
-    else build_csr(pr->obs_cam, no, nc, cstart, clist);
+    else if (t == 1) build_csr(pr->obs_cam, no, nc, cstart, clist);
+    else {
+      (void)hipSetDevice(ctx->device);  // the current device is a per-thread setting
+      early_status = raw_arrays(true);
+    }
   });
+  GH_TRY(early_status);
   const double t_csr = now_ms();
 
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant).  Large
@@ -1254,22 +1306,6 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   int nblocks = (int)bci.size();
   const double t_lists = now_ms();
 
-  // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
-  // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the middle
-  // of the launch chain, which left the GPU idle while the rest of the iteration was being enqueued.
-  struct Readback {
-    double cost, model;
-    unsigned long long gmax_bits;
-    int info, bad;
-    int32_t pair_counts[4];  // device-built pair lists: pairs, blocks, segments, (unused)
-  };
-  Readback* rb = nullptr;
-  {
-    void* pp = nullptr;
-    GH_TRY(gh_pinned(ctx, 256, &pp));
-    rb = (Readback*)pp;
-  }
-  DevBuf db(ctx);
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
@@ -1282,21 +1318,13 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
                         (NO / kCamChunk + NC + 2) * (27 * 8 + 2 * 4) + (NC + 2) * 4 +
                         (std::max(pair_a.size(), pairs_ub) / kSchurSeg + std::max(bstart.size(), blocks_ub) + 2) * (42 * 8 + 4) +
                         (bstart.size() + 2) * 4 + 16 * 256;
+    if (early && need > ctx->ba_arena_bytes) {  // the arena has to grow: what went up early goes up again
+      early = false;
+      db.used = 0;
+    }
     GH_TRY(db.reserve(need));
   }
-  double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
-  int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
-  uint8_t* d_pfree = nullptr;
-  GH_TRY(db.upload(&d_poses, pr->cam_pose, (size_t)nc * 7));
-  GH_TRY(db.upload(&d_pts, pr->point_xyz, (size_t)np * 3));
-  GH_TRY(db.alloc(&d_poses_new, (size_t)nc * 7));
-  GH_TRY(db.alloc(&d_pts_new, (size_t)np * 3));
-  GH_TRY(db.upload(&d_dof, pr->cam_dof, (size_t)nc));
-  if (pr->point_free) GH_TRY(db.upload(&d_pfree, pr->point_free, (size_t)np));
-  GH_TRY(db.upload(&d_ocam, pr->obs_cam, (size_t)no));
-  GH_TRY(db.upload(&d_opt, pr->obs_point, (size_t)no));
-  GH_TRY(db.upload(&d_oxy, pr->obs_xy, (size_t)no * 2));
-  if (pr->obs_info) GH_TRY(db.upload(&d_oinfo, pr->obs_info, (size_t)no * 4));
+  if (!early) GH_TRY(raw_arrays(true));
   GH_TRY(db.upload(&d_pstart, (const int32_t*)pstart.data(), pstart.size()));
   GH_TRY(db.upload(&d_plist, (const int32_t*)plist.data(), plist.size()));
   GH_TRY(db.upload(&d_cstart, (const int32_t*)cstart.data(), cstart.size()));

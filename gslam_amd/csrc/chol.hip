@@ -38,6 +38,12 @@ __device__ long long g_probe[64];
   do {                                                                   \
     if (threadIdx.x == 0) g_probe[(i)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+#define CHAIN_SINCE(i, from)                                                           \
+  do {                                                                                 \
+    long long now_ = (long long)wall_clock64();                                        \
+    asm volatile("" : "+s"(now_)::"memory");                                           \
+    if ((threadIdx.x & 63) == 0) g_probe[(i)] += now_ - g_probe[(from)];               \
+  } while (0)
 #define CHAIN_STAMP(i)                                                   \
   do {                                                                   \
     if (threadIdx.x == 0) {                                              \
@@ -76,6 +82,17 @@ __device__ long long g_flow_loop[128 * 8];
 #define CHAIN_STAMP(i) \
   do {                 \
   } while (0)
+#define CHAIN_SINCE(i, from) \
+  do {                       \
+  } while (0)
+#endif
+
+// timing experiments on the dataflow launch (tools/flow_whatif.py, make lib WHATIF=1): a mask of phases to skip
+#ifdef GH_FLOW_WHATIF
+__device__ unsigned g_flow_whatif;
+#define FLOW_SKIP(w, bit) (((w) & (bit)) != 0u)
+#else
+#define FLOW_SKIP(w, bit) false
 #endif
 
 // ---------------------------------------------------------------- constants of the 64x64 diagonal-block code
@@ -111,23 +128,36 @@ __device__ __forceinline__ void panel16_update(double (&s)[NBS], double l, const
     panel16_update<J, C + 1>(s, l, colJ);
   }
 }
-template <int J>
+// PUB (k >= 1 only): the wave also leaves 1/sqrt(d) in row 0 of the column -- a slot of the upper triangle, which nobody
+// reads as part of the matrix -- and, after every pivot, the number of finished columns in `*progress` (LDS executes a
+// wave's instructions in order, so whoever sees the count sees the column): another wave can follow the panel
+// (potf2_chain_lds)
+template <int J, bool PUB = false>
 __device__ __forceinline__ void panel16_factor(double (&s)[NBS], double (&rinv)[NBS], double* As, int k, int lane,
-                                               bool& bad) {
+                                               bool& bad, int* progress) {
   if constexpr (J < NBS) {
     const double d = readlane_f64(s[J], k + J);
     if (!(d > 0.0)) bad = true;
     const double rs = rsqrt_nr(d);
     rinv[J] = rs;
-    const double l = (lane >= k + J) ? s[J] * rs : 0.0;  // the pivot lane holds d itself: d * rs = sqrt(d)
+    double l = (lane >= k + J) ? s[J] * rs : 0.0;  // the pivot lane holds d itself: d * rs = sqrt(d)
     double* col = As + (k + J) * LP;
-    col[lane] = l;
+    if constexpr (PUB) col[lane] = lane == 0 ? rs : l;
+    else col[lane] = l;
     if constexpr (J + 1 < NBS) s[J + 1] = __builtin_fma(-l, readlane_f64(l, k + J + 1), s[J + 1]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (PUB) {
+      if (lane == 0) __hip_atomic_store(progress, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     panel16_update<J, J + 2>(s, l, col + k);
-    panel16_factor<J + 1>(s, rinv, As, k, lane, bad);
+    panel16_factor<J + 1, PUB>(s, rinv, As, k, lane, bad, progress);
   }
+}
+template <int J>
+__device__ __forceinline__ void panel16_factor(double (&s)[NBS], double (&rinv)[NBS], double* As, int k, int lane,
+                                               bool& bad) {
+  panel16_factor<J, false>(s, rinv, As, k, lane, bad, reinterpret_cast<int*>(As));
 }
 
 // (Measured on the box, tools/lat_probe.hip + tools/chol_probe.hip: ONE wave issues a v_fma_f64 every ~7 cycles whether or
@@ -154,6 +184,36 @@ __device__ __forceinline__ void inv16(double (&acc)[NBS], double (&mi)[NBS], con
   }
 }
 
+// the same with a small register footprint (a wave of a 512-thread workgroup has 256 registers): 1/sqrt(d) read when it
+// is needed, every entry of M stored as soon as it exists (column i of the block at `mcol`, by the lanes `store`)
+template <int T>
+__device__ __forceinline__ void inv16_lean(double (&acc)[NBS], const double* rinv_lds, const double* L16, double* mcol, int i,
+                                           bool store) {
+  if constexpr (T < NBS) {
+    const double mt = ((T == i) ? 1.0 : -acc[T]) * rinv_lds[T];
+    if (store) mcol[T] = mt;
+    inv16_update<T, T + 1>(acc, mt, L16 + T * LP);
+    inv16_lean<T + 1>(acc, rinv_lds, L16, mcol, i, store);
+  }
+}
+// the same, following a panel that is still being factored by another wave (panel16_factor<.., PUB>), four columns at a
+// time (the LDS reads of a group go out together; the last group is the cheapest: 6 of the 120 updates)
+template <int T>
+__device__ __forceinline__ void inv16_chase(double (&acc)[NBS], const double* L16, const double* rs_row, int* progress,
+                                            double* mcol, int i, bool store) {
+  if constexpr (T < NBS) {
+    if constexpr (T % 4 == 0) {
+      while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < T + 4) {
+      }
+      asm volatile("" ::: "memory");
+    }
+    const double mt = ((T == i) ? 1.0 : -acc[T]) * rs_row[T * LP];
+    if (store) mcol[T] = mt;
+    inv16_update<T, T + 1>(acc, mt, L16 + T * LP);
+    inv16_chase<T + 1>(acc, L16, rs_row, progress, mcol, i, store);
+  }
+}
+
 // One 16x16 output tile of a small LDS-resident product on v_mfma_f64_16x16x4_f64:
 //   D[i][j] = sum_{t < 4 KS} a(i, t) * b(t, j);  lane supplies a(lane & 15, 4 ks + lane >> 4) and b(4 ks + lane >> 4, lane & 15),
 //   and receives D[(lane >> 4) + 4 r][lane & 15] in acc[r].
@@ -172,7 +232,9 @@ struct Potf2Lds {
   double Ts[32 * 33];
   double rinv[NBI];
   int bad;
-  int pivots_done, next_ready;  // potf2_chain_lds: wave 0 is through its last pivot / what the side wave found out meanwhile
+  // potf2_chain_lds: wave 0 is through its last pivot / what the side wave found out meanwhile / columns of the last
+  // panel that are final / the off-diagonal block of the first 32x32 inverse is in place
+  int pivots_done, next_ready, progress, x10_done;
 };
 
 // Factor the 64x64 block held in sh.As (lower, in place) and build M = L^-1 in sh.Ms.  Called by all 256 threads;
@@ -288,17 +350,20 @@ __device__ __forceinline__ void potf2_inv_lds(Potf2Lds& sh) {
   potf2_invert_lds(sh);
 }
 
-// potf2 + inverse for the chain workgroup of the dataflow launch (8 waves): the same arithmetic as potf2_factor_lds +
-// potf2_invert_lds, but the inversion no longer waits for the last pivot.  Column panel b of L is final as soon as its 16
-// pivots are done, so while wave 0 holds the pivots of panel b + 1 (the other waves would idle), wave 1 inverts the 16x16
-// diagonal block b and wave 2 builds the off-diagonal block of the first 32x32 inverse; what is left behind the last
-// pivot is: inverse of diagonal block 3 (with the products that do not need it alongside), one 16x16 product, one
-// 32x32 product -- ~1.7 us instead of ~3.9.  Waves 1, 2, 3, 5, 6, 7 do the side work: wave 4 shares its SIMD with wave 0.
-// `T2`: 16 x 17 doubles of scratch.
-// `side()` is run by the waves 1..7 during the last 16 pivots, behind their own work (they may watch sh.pivots_done),
-// `after_pivots()` by all waves right behind those pivots.
+// potf2 + inverse for the chain workgroup of the dataflow launch (8 waves): the arithmetic of potf2_factor_lds +
+// potf2_invert_lds, but the inversion does not wait for the last pivot.  Column panel b of L is final as soon as its 16
+// pivots are done, so while wave 0 holds the pivots of the next panel (the other waves would idle), other waves invert the
+// 16x16 diagonal blocks and build the products that need nothing newer; during the LAST panel wave 1 follows wave 0 column
+// by column (inv16_chase), so the inverse of the last diagonal block is complete ~one inversion step after the last pivot.
+// Behind the pivots there are two rounds of one 16x16x16 product left (the lower half of the big off-diagonal block is
+// taken as -M33 (T_low - T' T_up) instead of -(X32 T_up + M33 T_low): it does not wait for X32):  ~0.6 us instead of ~3.9.
+// `T2`: 16 x 17 doubles of scratch.  `side()` is run by the waves 1..7 during the last 16 pivots, behind their own work
+// (they may watch sh.pivots_done), and by wave 0 behind its last pivot; `after_pivots()` by all waves behind the barrier
+// that ends the pivots.  tid 0 must have cleared
+// sh.pivots_done / next_ready / progress / x10_done (a barrier is passed before they are used).
 template <typename FS, typename F>
-__device__ __forceinline__ void potf2_chain_lds(Potf2Lds& sh, double* T2, int tid, FS&& side, F&& after_pivots) {
+__device__ __forceinline__ void potf2_chain_lds(Potf2Lds& sh, double* T2, int tid, FS&& side, F&& after_pivots,
+                                                unsigned whatif = 0u) {
   double* As = sh.As;
   double* Ms = sh.Ms;
   double* Ts = sh.Ts;
@@ -328,17 +393,10 @@ __device__ __forceinline__ void potf2_chain_lds(Potf2Lds& sh, double* T2, int ti
     }
   };
   auto inv_diag = [&](int b0) {  // one wave: column m of M per lane (all four 16-lane rows redundantly)
-    double acc[NBS], ri[NBS], mi[NBS];
+    double acc[NBS];
 #pragma unroll
-    for (int j = 0; j < NBS; ++j) {
-      acc[j] = 0.0;
-      ri[j] = sh.rinv[b0 + j];
-    }
-    inv16<0>(acc, mi, ri, As + b0 * LP + b0, m);
-    if (lane < NBS) {
-#pragma unroll
-      for (int j = 0; j < NBS; ++j) Ms[(b0 + m) * LP + b0 + j] = mi[j];
-    }
+    for (int j = 0; j < NBS; ++j) acc[j] = 0.0;
+    inv16_lean<0>(acc, sh.rinv + b0, As + b0 * LP + b0, Ms + (b0 + m) * LP + b0, m, lane < NBS);
   };
   // inv([A 0; C B]) = [A^-1 0; -B^-1 C A^-1  B^-1] for the 32x32 block at b0: T = C A^-1 (into `t`, pitch tp), then -B^-1 T
   auto pair_t = [&](int b0, double* t, int tp) {
@@ -353,71 +411,110 @@ __device__ __forceinline__ void potf2_chain_lds(Potf2Lds& sh, double* T2, int ti
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ms[(b0 + m) * LP + b0 + 16 + q + 4 * r] = -x[r];
   };
-  // the 64-level products, one 16x16 tile (tr, tc) per wave
-  auto tile_of = [&](int& tr, int& tc) {  // waves 2, 3, 5, 6 (and 1, 2, 3, 5 with `shift`): tiles 0..3
-    const int t = wv == 2 ? 0 : (wv == 3 ? 1 : (wv == 5 ? 2 : 3));
-    tr = 16 * (t & 1);
-    tc = 16 * (t >> 1);
+  // 64 level, T = C A^-1 with C = L[32.., 0..31], A^-1 = the first 32x32 inverse: 16x16 tile (tr, tc) into Ts
+  auto t64 = [&](int tr, int tc) {
+    const double4_t t1 = lds_mma<8>([&](int i, int t) { return As[t * LP + 32 + tr + i]; },     // C[i][t]
+                                    [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
   };
   CHAIN_STAMP(20);
   if (wv == 0) panel(0);
   lds_barrier();
   CHAIN_STAMP(21);
-  trailing(0);
+  if (!FLOW_SKIP(whatif, 128u)) trailing(0);
   lds_barrier();
   CHAIN_STAMP(22);
   if (wv == 0) panel(16);
-  else if (wv == 1) inv_diag(0);
+  else if (wv == 1 && !FLOW_SKIP(whatif, 64u)) inv_diag(0);
   lds_barrier();
   CHAIN_STAMP(23);
-  trailing(16);
+  if (!FLOW_SKIP(whatif, 128u)) trailing(16);
   lds_barrier();
   CHAIN_STAMP(24);
   if (wv == 0) panel(32);
-  else if (wv == 1) inv_diag(16);
-  else if (wv == 2) pair_t(0, Ts, 33);
+  else if (wv == 1 && !FLOW_SKIP(whatif, 64u)) inv_diag(16);
+  else if (wv == 2 && !FLOW_SKIP(whatif, 64u)) pair_t(0, Ts, 33);
   lds_barrier();
   CHAIN_STAMP(25);
-  trailing(32);
+  if (!FLOW_SKIP(whatif, 128u)) trailing(32);
   lds_barrier();
   CHAIN_STAMP(26);
   if (wv == 0) {
-    panel(48);
+    double s[NBS], ri[NBS];
+#pragma unroll
+    for (int c = 0; c < NBS; ++c) s[c] = As[(48 + c) * LP + lane];
+    bool bad = false;
+    panel16_factor<0, true>(s, ri, As, 48, lane, bad, &sh.progress);
+    if (bad) sh.bad = 1;
     if (lane == 0) *(volatile int*)&sh.pivots_done = 1;
+    CHAIN_SINCE(56, 26);
+    side();  // (does not wait any more: wave 0 asks for its part before it joins the others at the barrier)
   } else {
-    if (wv == 1) inv_diag(32);
-    else if (wv == 2) pair_x(0, Ts, 33);
+    if (FLOW_SKIP(whatif, 1u) && wv == 1) {
+    } else if (FLOW_SKIP(whatif, 256u) && (wv == 2 || wv == 3 || wv == 6 || wv == 7)) {
+    } else if (wv == 1) {  // the last diagonal block, column by column behind wave 0
+      double acc[NBS];
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) acc[j] = 0.0;
+      inv16_chase<0>(acc, As + 48 * LP + 48, As + 48 * LP, &sh.progress, Ms + (48 + m) * LP + 48, m, lane < NBS);
+      CHAIN_SINCE(57, 26);
+    } else if (wv == 3) {
+      inv_diag(32);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // M22 is in LDS before this wave reads it back
+      pair_t(32, T2, 17);
+      CHAIN_SINCE(58, 26);
+    } else if (wv == 2 || wv == 6 || wv == 7) {  // (not wave 4: it shares its SIMD with wave 0)
+      if (wv == 2) {
+        pair_x(0, Ts, 33);
+        asm volatile("" ::: "memory");
+        if (lane == 0) *(volatile int*)&sh.x10_done = 1;
+      }
+      while (__hip_atomic_load(&sh.x10_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      if (wv == 2) {
+        t64(0, 0);
+        t64(16, 0);
+      } else {
+        t64(wv == 6 ? 0 : 16, 16);
+      }
+      if (wv == 2) CHAIN_SINCE(59, 26);
+      if (wv == 7) CHAIN_SINCE(60, 26);
+    }
     side();
+    if (wv == 5) CHAIN_SINCE(61, 26);
+    if (wv == 6) CHAIN_SINCE(62, 26);
   }
   lds_barrier();
   CHAIN_STAMP(27);
   after_pivots();
   CHAIN_STAMP(28);
-  if (wv == 1) inv_diag(48);
-  else if (wv == 7) pair_t(32, T2, 17);
-  else if (wv == 2 || wv == 3 || wv == 5 || wv == 6) {
-    int tr, tc;
-    tile_of(tr, tc);
-    const double4_t t1 = lds_mma<8>([&](int i, int t) { return As[t * LP + 32 + tr + i]; },     // C[i][t]
-                                    [&](int t, int j) { return Ms[(tc + j) * LP + t]; }, lane);  // A^-1[t][j]
+  if (FLOW_SKIP(whatif, 4u)) return;
+  if (wv == 1) pair_x(32, T2, 17);
+  else if (wv == 2 || wv == 3) {  // upper half of the big off-diagonal block: -M22 T_up
+    const int tc = wv == 2 ? 0 : 16;
+    const double4_t x = lds_mma<4>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + i]; },
+                                   [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + tr + q + 4 * r] = t1[r];
+    for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + q + 4 * r] = -x[r];
+  } else if (wv == 6 || wv == 7) {  // W = T_low - T' T_up, in place
+    const int tc = wv == 6 ? 0 : 16;
+    const double4_t w = lds_mma<4>([&](int i, int t) { return T2[t * 17 + i]; },
+                                   [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(tc + m) * 33 + 16 + q + 4 * r] -= w[r];
   }
   lds_barrier();
   CHAIN_STAMP(29);
-  if (wv == 1) pair_x(32, T2, 17);
-  lds_barrier();
-  CHAIN_STAMP(30);
-  if (wv == 2 || wv == 3 || wv == 5 || wv == 6) {
-    int tr, tc;
-    tile_of(tr, tc);
-    const double4_t x = lds_mma<8>([&](int i, int t) { return Ms[(32 + t) * LP + 32 + tr + i]; },  // B^-1[i][t]
-                                   [&](int t, int j) { return Ts[(tc + j) * 33 + t]; }, lane);      // T[t][j]
+  if (wv == 6 || wv == 7) {  // lower half: -M33 W
+    const int tc = wv == 6 ? 0 : 16;
+    const double4_t x = lds_mma<4>([&](int i, int t) { return Ms[(48 + t) * LP + 48 + i]; },
+                                   [&](int t, int j) { return Ts[(tc + j) * 33 + 16 + t]; }, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 32 + tr + q + 4 * r] = -x[r];  // lower-left quadrant: read by nobody above
+    for (int r = 0; r < 4; ++r) Ms[(tc + m) * LP + 48 + q + 4 * r] = -x[r];
   }
   lds_barrier();
-  CHAIN_STAMP(31);
+  CHAIN_STAMP(30);
 }
 
 // write the factor back to A (lower part of the kb x kb block) and M to Minv (column-major, pitch 64, upper part zero)
@@ -1129,29 +1226,42 @@ struct FlowArgs {
   unsigned spin_limit;      // polls before a wait gives up (kFlowSpinLimit; tests shrink it to exercise the way out)
 };
 
-__device__ __forceinline__ double ld_sc1(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+// Every hand-off access is a BUFFER instruction: address = descriptor base (4 SGPRs) + a 32-bit per-lane offset (one VGPR,
+// the same for all 16 accesses of a tile) + a wave-uniform 32-bit offset (an SGPR, scalar arithmetic).  With global_load
+// the compiler forms a 64-bit VGPR address per access and hoists their lane-invariant parts out of the loops: 64+
+// registers of addresses, which a wave of a 512-thread workgroup (256 registers) does not have.  `sc1` = agent scope
+// (aux bit 4), the same cache behaviour as the global_load/global_store ... sc1 the protocol is described with.
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
 }
-__device__ __forceinline__ void st_sc1(double* p, double v) {
-  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ double bld_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const uint2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxSc1);
+  return __hiloint2double((int)w.y, (int)w.x);
+}
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {  // owner's plain load
+  const uint2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __hiloint2double((int)w.y, (int)w.x);
+}
+__device__ __forceinline__ void bst_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+  const uint2_t w = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+  __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, kAuxSc1);
 }
 // 16-byte write-through store (8-byte sc1 stores are one fabric write each: publishing a 32 KB tile with them takes
-// ~1.6 us of issue time on the storing CU, MI355X_MICROARCH.md "stores of each flavour").  Inline asm: the compiler does
-// not count it in its vmcnt bookkeeping, which only makes its own waits stricter; every publication drains explicitly.
-typedef double double2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void st_sc1_x2(double* p, double v0, double v1) {
-  const double2_t v = {v0, v1};
-  // s_nop: a store of more than 8 bytes reads its data registers a few cycles after issue; the compiler pads a VALU write
-  // to them behind its own stores (GCNHazardRecognizer, "VMEM store data hazard") but cannot see into inline asm --
-  // without the nops the v_mov that recycles the registers zeroed the upper half of the stored pair
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+// ~1.6 us of issue time on the storing CU, MI355X_MICROARCH.md "stores of each flavour")
+__device__ __forceinline__ void bst_sc1_x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v0, double v1) {
+  const uint4_t w = {(unsigned)__double2loint(v0), (unsigned)__double2hiint(v0), (unsigned)__double2loint(v1),
+                     (unsigned)__double2hiint(v1)};
+  __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, kAuxSc1);
 }
 // Every publication is made of arrivals, one per storing wave of the publishing workgroup: the wave drains its own stores
 // and adds 1 to the word -- no workgroup barrier on the publishing side.  Consumers wait for the word to reach the number
-// of storing waves: 4 for a tile of L (one half of a workgroup writes it), 8 for a row's accumulators, 7 for an M block
+// of waves of the publishing workgroup: 8 for a tile of L and for a row's accumulators, 7 for an M block
 // (the chain workgroup's wave 0 never stores: it has to go straight into the pivots of the next diagonal block while the
 // others, idle behind it, wait for their stores to be confirmed).
-constexpr unsigned kFlowArrivals = 4, kChainArrivals = 7, kHandArrivals = 8;
+constexpr unsigned kFlowArrivals = 8, kChainArrivals = 7, kHandArrivals = 8;
 __device__ __forceinline__ void flow_arrive(unsigned* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1179,15 +1289,13 @@ __device__ __forceinline__ void flow_wait(const unsigned* flag, const FlowArgs& 
 // 64 x 64 tile (column-major, leading dimension ld, `rows` x `cols` valid, the rest reads as zero) fetched by ONE half:
 // thread = (row, 4 interleaved column sets) so that every wave instruction reads 512 contiguous bytes; LDS image
 // [column][row], pitch LP
-__device__ __forceinline__ void flow_fetch(const double* src, size_t ld, int rows, int cols, double (&v)[16]) {
+__device__ __forceinline__ void flow_fetch(__amdgpu_buffer_rsrc_t rA, unsigned tile_off /* doubles */, unsigned ld, int rows,
+                                           int cols, double (&v)[16]) {
   const int lt = threadIdx.x & 255, row = lt & 63, cq = lt >> 6;
-  // wave-uniform base + one 32-bit lane offset: the 16 loads share their address registers
-  const unsigned off = (unsigned)((size_t)cq * ld + row) * 8u;
+  const unsigned voff = ((unsigned)cq * ld + row) * 8u;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const char* base = reinterpret_cast<const char*>(src + (size_t)(4 * e) * ld);
-    v[e] = (row < rows && cq + 4 * e < cols) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
-  }
+  for (int e = 0; e < 16; ++e)
+    v[e] = (row < rows && cq + 4 * e < cols) ? bld_sc1(rA, voff, (tile_off + (unsigned)(4 * e) * ld) * 8u) : 0.0;
 }
 __device__ __forceinline__ void flow_put(double* buf, const double (&v)[16]) {
   const int lt = threadIdx.x & 255, row = lt & 63, cq = lt >> 6;
@@ -1196,14 +1304,12 @@ __device__ __forceinline__ void flow_put(double* buf, const double (&v)[16]) {
 }
 // M_k from dinv (pitch 64) by the WHOLE workgroup (8 interleaved column sets): only its lower triangle is ever stored by
 // the dataflow launch; the rest reads as zero
-__device__ __forceinline__ void flow_fetch_lower(const double* src, double (&v)[8]) {
+__device__ __forceinline__ void flow_fetch_lower(__amdgpu_buffer_rsrc_t rM, int k, double (&v)[8]) {
   const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
-  const unsigned off = (unsigned)(cq * NBI + row) * 8u;
+  const unsigned voff = (unsigned)(cq * NBI + row) * 8u;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const char* base = reinterpret_cast<const char*>(src + (size_t)(8 * e) * NBI);
-    v[e] = (cq + 8 * e <= row) ? ld_sc1(reinterpret_cast<const double*>(base + off)) : 0.0;
-  }
+  for (int e = 0; e < 8; ++e)
+    v[e] = (cq + 8 * e <= row) ? bld_sc1(rM, voff, (unsigned)(k * (NBI * NBI) + 8 * e * NBI) * 8u) : 0.0;
 }
 __device__ __forceinline__ void flow_put_lower(double* buf, const double (&v)[8]) {
   const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
@@ -1219,32 +1325,38 @@ __device__ __forceinline__ void flow_update(double4_t (&acc)[4], const double* b
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
         acc[ja] = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[(4 * ks + q) * LP + 16 * ja + m], x[ks], acc[ja], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of the next 16 columns behind these MFMAs: registers are short
     }
   }
 }
-// 16 columns (block jt) of x = P M^T for the wave's 16 rows, P in operand layout; M staged in `mbuf`
+// 16 columns (block JT) of -x = S M^T for the wave's 16 rows, S = -P the accumulators (operand layout = accumulator
+// layout: element ks is acc[ks >> 2][ks & 3]); M staged in `mbuf`.  The caller negates.
 template <int JT>
-__device__ __forceinline__ double4_t flow_trsm_block(const double* mbuf, const double (&pb)[16], int lane) {
+__device__ __forceinline__ double4_t flow_trsm_block(const double* mbuf, const double4_t (&acc)[4], int lane) {
   const int m = lane & 15, q = lane >> 4;
   double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int ks = 0; ks < 4 * (JT + 1); ++ks)  // M[j][k] = 0 for k > j
-    t = __builtin_amdgcn_mfma_f64_16x16x4f64(mbuf[(4 * ks + q) * LP + 16 * JT + m], pb[ks], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f64_16x16x4f64(mbuf[(4 * ks + q) * LP + 16 * JT + m], acc[ks >> 2][ks & 3], t, 0, 0, 0);
   return t;
 }
 // x = P M^T for the wave's 16 rows, P = A - S = -acc; result in operand layout (= accumulator layout)
 __device__ __forceinline__ void flow_trsm(const double* mbuf, const double4_t (&acc)[4], double (&x)[16], int lane) {
-  double pb[16];
+  {
+    const double4_t t0 = flow_trsm_block<0>(mbuf, acc, lane), t1 = flow_trsm_block<1>(mbuf, acc, lane);
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) pb[ks] = -acc[ks >> 2][ks & 3];
-  const double4_t t0 = flow_trsm_block<0>(mbuf, pb, lane), t1 = flow_trsm_block<1>(mbuf, pb, lane);
-  const double4_t t2 = flow_trsm_block<2>(mbuf, pb, lane), t3 = flow_trsm_block<3>(mbuf, pb, lane);
+    for (int r = 0; r < 4; ++r) {
+      x[r] = -t0[r];
+      x[4 + r] = -t1[r];
+    }
+  }
+  {
+    const double4_t t2 = flow_trsm_block<2>(mbuf, acc, lane), t3 = flow_trsm_block<3>(mbuf, acc, lane);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    x[r] = t0[r];
-    x[4 + r] = t1[r];
-    x[8 + r] = t2[r];
-    x[12 + r] = t3[r];
+    for (int r = 0; r < 4; ++r) {
+      x[8 + r] = -t2[r];
+      x[12 + r] = -t3[r];
+    }
   }
 }
 
@@ -1257,31 +1369,34 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
   double* const A = a.A;
   const size_t lda = (size_t)a.lda;
   const int bid = blockIdx.x;
-  // operand-layout view of the wave's 16 rows of tile (ti, tj): element ks <-> (row 64 ti + 16 rg + m, column 64 tj + 4 ks + q)
-  // (the 16 accesses of a lane share one 32-bit offset from wave-uniform bases)
-  const unsigned lane_off = (unsigned)((size_t)q * lda + 16 * rg + m) * 8u;
-  auto elem = [&](int ti, int tj, int ks) {
-    return reinterpret_cast<double*>(reinterpret_cast<char*>(A + (size_t)(64 * tj + 4 * ks) * lda + 64 * ti) + lane_off);
-  };
+  const unsigned ldu = (unsigned)a.lda;
+  const __amdgpu_buffer_rsrc_t rA = flow_rsrc(A, (size_t)a.lda * a.n * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rM = flow_rsrc(a.dinv, (size_t)a.nb * NBI * NBI * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rH = flow_rsrc(a.hand, (size_t)a.ntr * 8192 * 2 * sizeof(double));
+  // operand-layout view of the wave's 16 rows of tile (ti, tj): element ks <-> (row 64 ti + 16 rg + m, column 64 tj + 4 ks + q):
+  // the lane's offset is the same for all tiles and all ks, the rest is wave-uniform
+  const unsigned lane_off = ((unsigned)q * ldu + 16 * rg + m) * 8u;
+  auto elem_off = [&](int ti, int tj, int ks) { return ((unsigned)(64 * tj + 4 * ks) * ldu + 64 * ti) * 8u; };
   auto row_of = [&](int ti) { return 64 * ti + 16 * rg + m; };
   auto load_orig = [&](int ti, int tj, double (&v)[16]) {
     const int row = row_of(ti);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) v[ks] = (row < a.nr && 64 * tj + 4 * ks + q < a.n) ? *elem(ti, tj, ks) : 0.0;
+    for (int ks = 0; ks < 16; ++ks)
+      v[ks] = (row < a.nr && 64 * tj + 4 * ks + q < a.n) ? bld(rA, lane_off, elem_off(ti, tj, ks)) : 0.0;
   };
   auto load_rows = [&](int ti, int tk, double (&v)[16]) {  // published tile (ti, tk): own 16 rows
     const int row = row_of(ti);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) v[ks] = row < a.nr ? ld_sc1(elem(ti, tk, ks)) : 0.0;
+    for (int ks = 0; ks < 16; ++ks) v[ks] = row < a.nr ? bld_sc1(rA, lane_off, elem_off(ti, tk, ks)) : 0.0;
   };
   auto store_rows = [&](int ti, int tj, const double (&v)[16]) {
     const int row = row_of(ti);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      if (row < a.nr && 64 * tj + 4 * ks + q < a.n) st_sc1(elem(ti, tj, ks), v[ks]);
+      if (row < a.nr && 64 * tj + 4 * ks + q < a.n) bst_sc1(rA, lane_off, elem_off(ti, tj, ks), v[ks]);
   };
   auto tile_rows = [&](int ti) { return a.nr - 64 * ti < 64 ? a.nr - 64 * ti : 64; };
-  auto tile_src = [&](int ti, int tk) { return A + (size_t)(64 * tk) * lda + 64 * ti; };
+  auto tile_src = [&](int ti, int tk) { return (unsigned)(64 * tk) * ldu + 64 * ti; };  // offset of the tile in doubles
 
   const int n_acc = a.ntr > 1 ? a.ntr - 1 : 0;  // accumulator workgroups: tile rows 1 .. ntr - 1
   double* const hand = a.hand;                  // [ntr][2][4096]: accumulators of (j, j-1) and (j, j), thread-major
@@ -1313,19 +1428,25 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
     for (int k = 0; k <= j - 2; ++k) {
       flow_wait(a.tf + (size_t)ti * a.nb + k, a, j);
       FLOW_LOOP_STAMP(k, 4, tid == 256 && k == j - 2);
-      flow_fetch(tile_src(ti, k), lda, tile_rows(ti), 64, v);
+      flow_fetch(rA, tile_src(ti, k), ldu, tile_rows(ti), 64, v);
       __syncthreads();  // previous step's MFMA reads of the two buffers are done
       flow_put(own, v);
       __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) xi[ks] = tb(1)[(4 * ks + q) * LP + 16 * rg + m];
+#ifdef GH_FLOW_WHATIF
+      if (busy && !FLOW_SKIP(g_flow_whatif, 0x400u)) flow_update(acc, own, xi, ja_end, lane);
+#else
       if (busy) flow_update(acc, own, xi, ja_end, lane);
+#endif
       FLOW_LOOP_STAMP(k, 5, tid == 192 && k == j - 2);
     }
-    double* hp = hand + (size_t)j * 8192 + 4096 * half + 2 * lt;  // element ks of thread lt at (ks >> 1) * 512 + 2 lt + (ks & 1)
+    // element ks of thread lt at (ks >> 1) * 512 + 2 lt + (ks & 1) of [j][half][4096]
     if (busy) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ks += 2) st_sc1_x2(hp + 256 * ks, acc[ks >> 2][ks & 3], acc[(ks + 1) >> 2][(ks + 1) & 3]);
+      for (int ks = 0; ks < 16; ks += 2)
+        bst_sc1_x2(rH, (unsigned)(2 * lt) * 8u, (unsigned)(j * 8192 + 4096 * half + 256 * ks) * 8u, acc[ks >> 2][ks & 3],
+                   acc[(ks + 1) >> 2][(ks + 1) & 3]);
     }
     flow_arrive(a.hf + j);
     FLOW_LOOP_STAMP(j - 2, 6, tid == 0);
@@ -1335,15 +1456,15 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
       // the chain's arrivals), the others wait at the barrier
       if (wv == 0) flow_wait(a.mf + (j - 1), a, j, kChainArrivals);
       lds_barrier();
-      flow_fetch_lower(a.dinv + (size_t)(j - 1) * (NBI * NBI), mv);
+      flow_fetch_lower(rM, j - 1, mv);
       flow_put_lower(tb(2), mv);  // a buffer the loop above never used
       __syncthreads();
       if (half == 0) {
         double x[16];
         flow_trsm(tb(2), acc, x, lane);
         store_rows(j, j - 1, x);
-        flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));
       }
+      flow_arrive(a.tf + (size_t)j * a.nb + (j - 1));  // (every tile word counts 8 waves)
     }
     return;
   }
@@ -1367,11 +1488,16 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
     const int dc0 = wv == 5 || wv == 6 ? 1 : (wv == 3 || wv == 7 ? 2 : 0);
     const int dr1 = wv == 0 ? 3 : (wv == 1 ? 1 : -1), dc1 = wv == 0 ? 3 : 1;
     {  // the upper part of the image is never written again except with zeros (potf2 masks it)
-      double* z = reinterpret_cast<double*>(flow_lds);
-      for (int e = tid; e < NBI * LP; e += 512) z[e] = 0.0;
+      double* z = reinterpret_cast<double*>(flow_lds);  // As, then Ms: the inversion writes every lower block of M anew
+      for (int e = tid; e < 2 * NBI * LP; e += 512) z[e] = 0.0;
       lds_barrier();
     }
     bool m_pending = false;  // M_{j-1} is stored but its flag is not up yet
+#ifdef GH_FLOW_WHATIF
+    const unsigned whatif = g_flow_whatif;
+#else
+    const unsigned whatif = 0u;
+#endif
     const int tid_all = tid;
     for (int j = 0; j < a.ntr; ++j) {
       const bool has_diag = j < a.nb;
@@ -1384,14 +1510,17 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
       const int lane = tid & 63, m = lane & 15, q = lane >> 4, lt = tid & 255;
       auto request = [&](int jn) {  // jn >= 1: from the accumulator workgroup; block 0: the matrix itself
         if (jn >= 1) {
-          const double* hp = hand + (size_t)jn * 8192 + 2 * lt;
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) nP[ks] = ld_sc1(hp + 256 * (ks & ~1) + (ks & 1));
-          const double* hd = hand + (size_t)jn * 8192 + 4096 + 2 * lane;  // the diagonal tile's accumulators, thread-major
+          for (int ks = 0; ks < 16; ++ks)
+            nP[ks] = bld_sc1(rH, (unsigned)(2 * lt) * 8u, (unsigned)(jn * 8192 + 256 * (ks & ~1) + (ks & 1)) * 8u);
+          // the diagonal tile's accumulators, thread-major: lane `lane` of row block dr
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            nD[r] = ld_sc1(hd + (2 * dc0 + (r >> 1)) * 512 + 128 * dr0 + (r & 1));
-            nD[4 + r] = dr1 >= 0 ? ld_sc1(hd + (2 * dc1 + (r >> 1)) * 512 + 128 * dr1 + (r & 1)) : 0.0;
+            nD[r] = bld_sc1(rH, (unsigned)(2 * lane) * 8u,
+                            (unsigned)(jn * 8192 + 4096 + (2 * dc0 + (r >> 1)) * 512 + 128 * dr0 + (r & 1)) * 8u);
+            nD[4 + r] = dr1 >= 0 ? bld_sc1(rH, (unsigned)(2 * lane) * 8u,
+                                           (unsigned)(jn * 8192 + 4096 + (2 * dc1 + (r >> 1)) * 512 + 128 * dr1 + (r & 1)) * 8u)
+                                 : 0.0;
           }
         } else {
 #pragma unroll
@@ -1410,10 +1539,9 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
         request(j);
       }
       have_next = false;
-      double pb[16];
-      double4_t accD[2];
+      double4_t accP[4], accD[2];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) pb[ks] = -nP[ks];
+      for (int ks = 0; ks < 16; ++ks) accP[ks >> 2][ks & 3] = nP[ks];
 #pragma unroll
       for (int e = 0; e < 8; ++e) accD[e >> 2][e & 3] = nD[e];
       FLOW_STAMP(j, 1);
@@ -1422,14 +1550,15 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
         // M_{j-1}: lower part from potf2_invert_lds, zeros above
         auto stage = [&](int jt, const double4_t& t) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xs[(4 * (4 * jt + r) + q) * LP + 16 * rg + m] = t[r];
+          for (int r = 0; r < 4; ++r) xs[(4 * (4 * jt + r) + q) * LP + 16 * rg + m] = -t[r];
         };
-        if (half == 0) {
-          stage(0, flow_trsm_block<0>(sh.Ms, pb, lane));
-          stage(3, flow_trsm_block<3>(sh.Ms, pb, lane));
+        if (FLOW_SKIP(whatif, 32u)) {
+        } else if (half == 0) {
+          stage(0, flow_trsm_block<0>(sh.Ms, accP, lane));
+          stage(3, flow_trsm_block<3>(sh.Ms, accP, lane));
         } else {
-          stage(1, flow_trsm_block<1>(sh.Ms, pb, lane));
-          stage(2, flow_trsm_block<2>(sh.Ms, pb, lane));
+          stage(1, flow_trsm_block<1>(sh.Ms, accP, lane));
+          stage(2, flow_trsm_block<2>(sh.Ms, accP, lane));
         }
         // M_{j-1} left this CU ~2 us ago (the stores were issued before this step's X): the waves that stored it confirm
         // and publish it here -- behind the next potf2's first pivots it was 3.5 us later, and that delay sits on the
@@ -1441,7 +1570,7 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
         m_pending = false;
         lds_barrier();
         FLOW_STAMP(j, 4);
-        {
+        if (!FLOW_SKIP(whatif, 16u)) {
           double x0[16], x1[16];
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks) {
@@ -1477,19 +1606,16 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
             if (row == kb && col < kb) ex[col] = d;
           }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int idx = tid + 512 * e;
-          sh.Ms[(idx >> 6) * LP + (idx & 63)] = 0.0;
-        }
       }
-      lds_barrier();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms ... which the loop above just zeroed)
+      lds_barrier();  // (also: every wave is done with xs and with M_{j-1} in sh.Ms, which the inversion overwrites)
       FLOW_STAMP(j, 2);
       int tid_f = tid_all;
       asm volatile("" : "+v"(tid_f));
       if (tid == 0) {
         sh.pivots_done = 0;
         sh.next_ready = 0;
+        sh.progress = 0;
+        sh.x10_done = 0;
       }
       // The next step's accumulators: their owner is normally done before this block's last pivots.  Wave 5, idle by then,
       // watches the owner's word; the other idle waves watch wave 5 (in LDS) and ask for their part of the two tiles while
@@ -1500,7 +1626,7 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
       potf2_chain_lds(
           sh, xs, tid_f,
           [&] {
-            if (j + 1 >= a.ntr) return;
+            if (j + 1 >= a.ntr || FLOW_SKIP(whatif, 2u)) return;
             for (;;) {
               if (wv == 5) {
                 if (__hip_atomic_load((const gu32*)(a.hf + j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHandArrivals)
@@ -1523,11 +1649,12 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
               if (!requested) request(j + 1);
               have_next = true;
             }
-          });
+          },
+          whatif);
       FLOW_STAMP(j, 6);
       if (tid == 0 && sh.bad) atomicMax(a.info, 64 * j + 1);
       double* Minv = a.dinv + (size_t)j * (NBI * NBI);
-      if (wv != 0) {  // M_j (lower triangle only) and, if asked for, L_jj leave through the waves 1..7
+      if (wv != 0 && !FLOW_SKIP(whatif, 8u)) {  // M_j (lower triangle only) and, if asked for, L_jj leave through the waves 1..7
         int t7 = tid_all - 64;
         asm volatile("" : "+v"(t7));
         double m0[5], m1[5];
@@ -1540,7 +1667,8 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
 #pragma unroll
         for (int e = 0; e < 5; ++e) {
           const int idx = t7 + 448 * e, c = idx >> 5, r = 2 * (idx & 31);
-          if (idx < 2048 && c <= r + 1) st_sc1_x2(Minv + c * NBI + r, (c <= r) ? m0[e] : 0.0, m1[e]);
+          if (idx < 2048 && c <= r + 1)
+            bst_sc1_x2(rM, (unsigned)(c * NBI + r) * 8u, (unsigned)(j * (NBI * NBI)) * 8u, (c <= r) ? m0[e] : 0.0, m1[e]);
         }
         if (a.store_diag) {  // nobody reads L_jj inside this launch (plain stores)
 #pragma unroll
@@ -1599,55 +1727,33 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
   }
   const int j1 = j0 + T - 1;
   const int code = bid;
-  for (int k = 0; k <= j1; ++k) {
-    double xi[16];
-    if (k >= j0) {
-      // own tile (i, k) has every column < k: its half finalises it, and the X rows are this step's i-operand for both
-      const int tk = k - j0;
-      const bool mine = (tk & 1) == half, more = tk + 1 < T;
-      {
-        double mv[8];
-        if (wv == 0) flow_wait(a.mf + k, a, code, kChainArrivals);  // one poller per workgroup
-        lds_barrier();
-        FLOW_LOOP_STAMP(k, 2, tid == 0 && i == k + 2);
-        flow_fetch_lower(a.dinv + (size_t)k * (NBI * NBI), mv);
-        flow_put_lower(tb(0), mv);  // every buffer is free: the barrier at the end of the previous step
-      }
-      lds_barrier();
-      if (mine) {
-#pragma unroll
-        for (int u = 0; u < FL_HALF; ++u)
-          if (u == (tk >> 1)) flow_trsm(tb(0), acc[u], xi, lane);
-        store_rows(i, k, xi);
-        if (more) {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) tb(1)[ks * 256 + lt] = xi[ks];
-        }
-      }
-      if (more) {
-        lds_barrier();
-        if (!mine) {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) xi[ks] = tb(1)[ks * 256 + lt];
-        }
-        lds_barrier();  // tb(1) is a tile buffer again
-      }
-      if (mine) {
-        flow_arrive(a.tf + (size_t)i * a.nb + k);
-        FLOW_LOOP_STAMP(k, 3, lt == 0 && i == k + 2);
-      }
-    } else {
-      flow_wait(a.tf + (size_t)i * a.nb + k, a, code);
-      load_rows(i, k, xi);
-    }
-    // the other tiles: (i, j) += L[i, k] L[j, k]^T for j > k; operand tile (j, k) staged through LDS (two buffers per
-    // half), the next one already in flight while the MFMAs of the current one run
+#ifdef GH_FLOW_WHATIF
+  const unsigned whatif_w = g_flow_whatif;
+#else
+  const unsigned whatif_w = 0u;
+#endif
+  auto first_tile = [&](int kk) {  // this half's first tile of column kk
+    const int tb0 = kk + 1 - j0 > 0 ? kk + 1 - j0 : 0;
+    return tb0 + ((half - tb0) & 1);
+  };
+  auto peek = [&](const unsigned* flag) { return __hip_atomic_load((const gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  double v[16];
+  // (i, j) += L[i, k] L[j, k]^T for the tiles j > k: operand tile (j, k) staged through LDS (two buffers per half), the
+  // next one already in flight while the MFMAs of the current one run; `ahead()` runs before this half's last MFMAs
+  auto update_tiles = [&](int k, const double (&xi)[16], bool have_v, auto&& ahead) {
     const int t_begin = k + 1 - j0 > 0 ? k + 1 - j0 : 0;
-    const int t_first = t_begin + ((half - t_begin) & 1);  // this half's first tile of the step
-    double v[16];
-    if (t_first < T) {
+    const int t_first = first_tile(k);
+    // the words of this half's later tiles of the column are asked for here and looked at when their turn comes (a wave
+    // that polls in front of every fetch waits for a round trip to L2, ~0.7 us, each time -- with the MFMAs behind it)
+    unsigned seen[FL_HALF];
+#pragma unroll
+    for (int u = 0; u < FL_HALF; ++u) {
+      const int t = 2 * u + half;
+      seen[u] = (t > t_first && t < T) ? peek(a.tf + (size_t)(j0 + t) * a.nb + k) : 0u;
+    }
+    if (t_first < T && !have_v) {
       flow_wait(a.tf + (size_t)(j0 + t_first) * a.nb + k, a, code);
-      flow_fetch(tile_src(j0 + t_first, k), lda, 64, 64, v);
+      flow_fetch(rA, tile_src(j0 + t_first, k), ldu, 64, 64, v);
     }
 #pragma unroll
     for (int u = 0; u < FL_HALF; ++u) {
@@ -1655,16 +1761,135 @@ __global__ __launch_bounds__(512) void potrf_flow_kernel(FlowArgs a) {
         const int t = 2 * u + half;
         const bool act = t >= t_begin && t < T;
         double* buf = tb(2 * half + (u & 1));
-        if (act) flow_put(buf, v);
+        if (act && !FLOW_SKIP(whatif_w, 0x800u)) flow_put(buf, v);
         lds_barrier();
         if (act && t + 2 < T) {
-          flow_wait(a.tf + (size_t)(j0 + t + 2) * a.nb + k, a, code);
-          flow_fetch(tile_src(j0 + t + 2, k), lda, 64, 64, v);
+          if (u + 1 < FL_HALF && seen[u + 1 < FL_HALF ? u + 1 : 0] < kFlowArrivals)
+            flow_wait(a.tf + (size_t)(j0 + t + 2) * a.nb + k, a, code);
+          asm volatile("" ::: "memory");
+          flow_fetch(rA, tile_src(j0 + t + 2, k), ldu, 64, 64, v);
+        } else if (act) {
+          ahead();
         }
-        if (act) flow_update(acc[u], buf, xi, 4, lane);
+        if (act && !FLOW_SKIP(whatif_w, 0x200u)) flow_update(acc[u], buf, xi, 4, lane);
       }
     }
     lds_barrier();  // every tile buffer free before the next step overwrites them
+  };
+  // Columns k < j0 are pure update steps: L[i, k] and the operand tiles come from other workgroups, and a worker that is
+  // the bottleneck of the launch finds column k + 1 published while it is still busy with column k.  It then asks for its
+  // rows of L[i, k + 1] and for the first operand tile of column k + 1 BEFORE the last MFMAs of column k (their flags are
+  // read at the top of the step and looked at later: no wave ever waits for that answer), instead of paying both round
+  // trips (~2.5 us of the ~16 us a six-tile column took) at the top of the next step.
+  {
+    double xi[16], xn[16];
+    bool have_x = false, have_v = false;
+    for (int k = 0; k < j0; ++k) {
+#ifdef GH_CHOL_PROBE
+      if (tid == 0 && i == a.ntr - 1 && j1 == i - 2) {  // the last worker of the last row: time per pure update column
+        const long long now_ = (long long)wall_clock64();
+        if (k > 0) g_probe[10] += now_ - g_probe[11];
+        g_probe[11] = now_;
+        g_probe[12] = k;
+        g_probe[13] = T;
+      }
+#endif
+      const bool want = k + 1 < j0;
+      const int tn_first = want ? first_tile(k + 1) : T;
+      const unsigned seen_x = want ? peek(a.tf + (size_t)i * a.nb + k + 1) : 0u;
+      const unsigned seen_v = tn_first < T ? peek(a.tf + (size_t)(j0 + tn_first) * a.nb + k + 1) : 0u;
+      if (have_x) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xi[ks] = xn[ks];
+      } else {
+        flow_wait(a.tf + (size_t)i * a.nb + k, a, code);
+        load_rows(i, k, xi);
+      }
+#ifdef GH_CHOL_PROBE
+      if (tid == 0 && i == a.ntr - 1 && j1 == i - 2) {
+        g_probe[14] = (long long)wall_clock64();
+        g_probe[16] += have_x ? 1 : 0;
+        g_probe[17] += have_v ? 1 : 0;
+      }
+#endif
+      const bool had_v = have_v;
+      have_x = have_v = false;
+      update_tiles(k, xi, had_v, [&] {  // the next column's loads go out ahead of this column's last MFMAs
+        asm volatile("" ::: "memory");
+        if (seen_x >= kFlowArrivals) {
+          load_rows(i, k + 1, xn);
+          have_x = true;
+        }
+        if (seen_v >= kFlowArrivals) {
+          flow_fetch(rA, tile_src(j0 + tn_first, k + 1), ldu, 64, 64, v);
+          have_v = true;
+        }
+      });
+#ifdef GH_CHOL_PROBE
+      if (tid == 0 && i == a.ntr - 1 && j1 == i - 2) g_probe[15] += (long long)wall_clock64() - g_probe[14];
+#endif
+    }
+  }
+  for (int k = j0; k <= j1; ++k) {
+    // own tile (i, k) has every column < k: its half finalises it, and the X rows are this step's i-operand for both
+    double xi[16];
+    const int tk = k - j0;
+    const bool mine = (tk & 1) == half, more = tk + 1 < T;
+    {
+      double mv[8];
+      if (wv == 0) flow_wait(a.mf + k, a, code, kChainArrivals);  // one poller per workgroup
+      lds_barrier();
+      FLOW_LOOP_STAMP(k, 2, tid == 0 && i == k + 2);
+      flow_fetch_lower(rM, k, mv);
+      flow_put_lower(tb(0), mv);  // every buffer is free: the barrier at the end of the previous step
+    }
+    // X = P M^T by BOTH halves (column blocks {0, 3} / {1, 2}: 20 MFMAs a wave, two waves per SIMD -- the owner half alone
+    // took 40 at the single-wave rate, and this product sits on the dependency loop around the chain): the owner's
+    // accumulators go to the other half through LDS, every wave stores the 8 elements per lane it computed, and the
+    // rows come back to everybody through LDS as this step's i-operand
+    double4_t P[4];
+    if (mine) {
+#pragma unroll
+      for (int u = 0; u < FL_HALF; ++u)
+        if (u == (tk >> 1)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) P[c] = acc[u][c];
+        }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) tb(1)[ks * 256 + lt] = P[ks >> 2][ks & 3];
+    }
+    lds_barrier();
+    if (!mine) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) P[ks >> 2][ks & 3] = tb(1)[ks * 256 + lt];
+    }
+    {
+      const int row = row_of(i);
+      auto emit = [&](int jt, const double4_t& t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ks = 4 * jt + r;
+          if (row < a.nr && 64 * k + 4 * ks + q < a.n) bst_sc1(rA, lane_off, elem_off(i, k, ks), -t[r]);
+          if (more) tb(2)[(4 * ks + q) * LP + 16 * rg + m] = -t[r];
+        }
+      };
+      if (half == 0) {
+        emit(0, flow_trsm_block<0>(tb(0), P, lane));
+        emit(3, flow_trsm_block<3>(tb(0), P, lane));
+      } else {
+        emit(1, flow_trsm_block<1>(tb(0), P, lane));
+        emit(2, flow_trsm_block<2>(tb(0), P, lane));
+      }
+    }
+    if (more) {
+      lds_barrier();
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) xi[ks] = tb(2)[(4 * ks + q) * LP + 16 * rg + m];
+      lds_barrier();  // tb(2) is a tile buffer again
+    }
+    flow_arrive(a.tf + (size_t)i * a.nb + k);
+    FLOW_LOOP_STAMP(k, 3, tid == 0 && i == k + 2);
+    update_tiles(k, xi, false, [] {});
   }
 }
 
@@ -1849,6 +2074,13 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       fa.info = info_dev;
       fa.spin_limit = kFlowSpinLimit;
       if (const char* e = getenv("GSLAM_HIP_FLOW_SPIN_LIMIT")) fa.spin_limit = (unsigned)strtoul(e, nullptr, 10);
+#ifdef GH_FLOW_WHATIF
+      {
+        const char* w = getenv("GSLAM_HIP_FLOW_WHATIF");
+        const unsigned mask = w ? (unsigned)strtoul(w, nullptr, 0) : 0u;
+        GH_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_flow_whatif), &mask, sizeof(mask)));
+      }
+#endif
       GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
       GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 1 ? fa.ntr - 1 : 0) + groups), dim3(512),
                 kFlowLdsBytes, fa);

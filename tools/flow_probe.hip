@@ -84,10 +84,14 @@ int main(int argc, char** argv) {
         std::vector<long long> pr(64);
         hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_probe), pr.size() * 8);
         static const char* nm[] = {"panel 0", "update", "panel 1 | inv 0", "update", "panel 2 | inv 1, T", "update",
-                                   "panel 3 | inv 2, X, poll", "request", "inv 3 | T', T64", "X32", "X64"};
+                                   "panel 3 | inv 2, 3, X, T64, poll", "request", "X32, X64 up, W", "X64 low"};
         printf("potf2 phases, mean over the blocks (us):");
-        for (int e = 0; e < 11; ++e) printf("  %s %.2f", nm[e], pr[41 + e] * 0.01 / nb);
-        printf("\n");
+        for (int e = 0; e < 10; ++e) printf("  %s %.2f", nm[e], pr[41 + e] * 0.01 / nb / 3);
+        printf("\n   within the last-panel phase, us after its start: wave 0 pivots done %.2f, wave 1 inverse done %.2f, wave 3 %.2f, wave 2 %.2f, wave 7 %.2f, wave 5 after side %.2f, wave 6 after side %.2f\n",
+               pr[56] * 0.01 / nb / 3, pr[57] * 0.01 / nb / 3, pr[58] * 0.01 / nb / 3, pr[59] * 0.01 / nb / 3, pr[60] * 0.01 / nb / 3, pr[61] * 0.01 / nb / 3, pr[62] * 0.01 / nb / 3);
+        if (pr[12] > 0)
+          printf("   the last worker of the last row (%lld tiles): %.2f us per pure update column (mean over %lld columns), %.2f us of them between having its rows of L[i,k] and the end of the column; next column's rows prefetched %.0f%%, first tile %.0f%%\n", pr[13],
+                 pr[10] * 0.01 / 3 / pr[12], pr[12], pr[15] * 0.01 / 3 / (pr[12] + 1), pr[16] * 100.0 / 3 / (pr[12] + 1), pr[17] * 100.0 / 3 / (pr[12] + 1));
         long long zero[64] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero, sizeof(zero));
       }
