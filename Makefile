@@ -10,7 +10,7 @@ ARCH      ?= gfx950
 REF       ?= /root/reference
 HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -Iinclude
 ifdef WHATIF
-HIPFLAGS  += -DGH_FLOW_WHATIF  # timing experiments only (tools/flow_whatif.py)
+HIPFLAGS  += -DGH_FLOW_WHATIF $(WHATIF_FLAGS)  # timing experiments only (tools/flow_whatif.py)
 endif
 CFLAGS    := -O3 -fPIC -std=c11 -ffp-contract=off -fopenmp -Wall -Wno-unknown-pragmas -Iinclude
 # the reference's own flags (CMakeLists.txt:9-11) for the reference shim

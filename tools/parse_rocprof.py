@@ -35,9 +35,14 @@ def short(name):
     return None
 
 
+def newest(paths):
+    """gpurun merges every call's files into gpurun_out/: only the latest collection counts."""
+    return sorted(paths, key=os.path.getmtime)[-1:]
+
+
 def counters(pattern, counter):
     acc = defaultdict(lambda: [0.0, 0])
-    for path in glob.glob(os.path.join(ROOT, "gpurun_out", pattern, "**", "*_counter_collection.csv"), recursive=True):
+    for path in newest(glob.glob(os.path.join(ROOT, "gpurun_out", pattern, "**", "*_counter_collection.csv"), recursive=True)):
         for row in csv.DictReader(open(path)):
             if row["Counter_Name"] != counter:
                 continue
@@ -53,7 +58,7 @@ def main():
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    stats = newest(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True))
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
