@@ -628,7 +628,33 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(int no, const int32_t* _
 //   histogram (LDS atomics: only counts, order-free) -> exclusive scan of the bins = where each block starts ->
 //   placement in generation order, 256 pairs at a time: rank among the equal keys of the chunk by a plain count over the
 //   chunk (same-address LDS reads), the last of them moves the bin's cursor on.
+// ranges of kPairSortRange pairs per camera (exclusive scan over the cameras, nc + 1 entries): one workgroup sorts one range
+constexpr int kPairSortRange = 4096;
+__global__ __launch_bounds__(256) void pair_ranges_kernel(const int32_t* __restrict__ cstart, const int32_t* __restrict__ goff, int nc,
+                                                          int32_t* __restrict__ range_off) {
+  __shared__ int wave_tot[4];
+  int carry = 0;
+  for (int c0 = 0; c0 < nc; c0 += 256) {
+    const int ci = c0 + threadIdx.x;
+    int v = 0;
+    if (ci < nc) {
+      const int m = goff[cstart[ci + 1]] - goff[cstart[ci]];
+      v = m > 0 ? (m + kPairSortRange - 1) / kPairSortRange : 1;  // (an empty camera still writes its block count)
+    }
+    int total;
+    const int ex = block_excl_scan(v, wave_tot, &total);
+    if (ci < nc) range_off[ci] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) range_off[nc] = carry;
+}
+// Stable counting sort of the pairs of camera ci by their second camera.  A workgroup takes ONE range of kPairSortRange
+// pairs (a graph has cameras with tens of thousands of pairs: with a workgroup per camera the launch lasted as long as
+// the biggest of them, 0.63 ms at C4 for 0.04 ms of work per CU): it counts the camera's keys (all of them: the bin
+// starts), then the keys in front of its range (added to the starts: its cursors), then ranks its own pairs chunk by chunk.
 __global__ __launch_bounds__(256) void pair_sort_kernel(const int32_t* __restrict__ cstart, const int32_t* __restrict__ goff,
+                                                        const int32_t* __restrict__ range_off, int nc,
                                                         const int32_t* __restrict__ gen_k,
                                                         const int32_t* __restrict__ gen_k2,
                                                         const int32_t* __restrict__ gen_cj, int32_t* __restrict__ pair_a,
@@ -637,8 +663,17 @@ __global__ __launch_bounds__(256) void pair_sort_kernel(const int32_t* __restric
   extern __shared__ __attribute__((aligned(16))) int bins[];  // ci + 1 cursors
   __shared__ int wave_tot[4];
   __shared__ __attribute__((aligned(16))) int chunk_cj[256];
-  const int ci = blockIdx.x, tid = threadIdx.x, nbins = ci + 1;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= range_off[nc]) return;
+  int lo = 0, hi = nc - 1;  // the camera whose ranges hold this workgroup: last ci with range_off[ci] <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (range_off[mid] <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const int ci = lo, nbins = ci + 1, range = (int)blockIdx.x - range_off[ci];
   const int begin = goff[cstart[ci]], end = goff[cstart[ci + 1]], m = end - begin;
+  const int r0 = range * kPairSortRange, r1 = r0 + kPairSortRange < m ? r0 + kPairSortRange : m;
   for (int i = tid; i < nbins; i += 256) bins[i] = 0;
   __syncthreads();
   for (int i = tid; i < m; i += 256) atomicAdd(&bins[gen_cj[begin + i]], 1);
@@ -653,7 +688,7 @@ __global__ __launch_bounds__(256) void pair_sort_kernel(const int32_t* __restric
     const int bex = block_excl_scan(c > 0 ? 1 : 0, wave_tot, &btotal);
     if (bi < nbins) {
       bins[bi] = carry + ex;
-      if (c > 0) {
+      if (c > 0 && range == 0) {
         tmp_start[begin + bcarry + bex] = begin + carry + ex;
         tmp_cj[begin + bcarry + bex] = bi;
       }
@@ -662,10 +697,12 @@ __global__ __launch_bounds__(256) void pair_sort_kernel(const int32_t* __restric
     bcarry += btotal;
     __syncthreads();
   }
-  if (tid == 0) blk_cnt[ci] = bcarry;
-  for (int c0 = 0; c0 < m; c0 += 256) {
-    const int i = c0 + tid, n_here = m - c0 < 256 ? m - c0 : 256;
-    const int cj = i < m ? gen_cj[begin + i] : -1;
+  if (tid == 0 && range == 0) blk_cnt[ci] = bcarry;
+  for (int i = tid; i < r0; i += 256) atomicAdd(&bins[gen_cj[begin + i]], 1);  // the keys in front of this range
+  __syncthreads();
+  for (int c0 = r0; c0 < r1; c0 += 256) {
+    const int i = c0 + tid, n_here = r1 - c0 < 256 ? r1 - c0 : 256;
+    const int cj = i < r1 ? gen_cj[begin + i] : -1;
     chunk_cj[tid] = cj;
     __syncthreads();
     int before = 0, all = 0;
@@ -679,13 +716,13 @@ __global__ __launch_bounds__(256) void pair_sort_kernel(const int32_t* __restric
       const int t = 4 * t4;
       before += (t < tid ? s0 : 0) + (t + 1 < tid ? s1 : 0) + (t + 2 < tid ? s2 : 0) + (t + 3 < tid ? s3 : 0);
     }
-    if (i < m) {
+    if (i < r1) {
       const int dst = begin + bins[cj] + before;
       pair_a[dst] = gen_k[begin + i];
       pair_b[dst] = gen_k2[begin + i];
     }
     __syncthreads();  // every cursor of this chunk has been read
-    if (i < m && before == all - 1) bins[cj] += all;
+    if (i < r1 && before == all - 1) bins[cj] += all;
     __syncthreads();
   }
 }
@@ -1145,6 +1182,8 @@ gh_status build_schur_pairs_device(gh_ctx* ctx, DevBuf& db, int nc, int no, size
   GH_TRY(db.alloc(&d_tmp_start, pairs_ub));
   GH_TRY(db.alloc(&d_tmp_cj, pairs_ub));
   GH_TRY(db.alloc(&d_blk_off, (size_t)nc + 2));
+  int32_t* d_range_off;
+  GH_TRY(db.alloc(&d_range_off, (size_t)nc + 2));
   GH_TRY(db.alloc(&d_bs, blocks_ub + 1));
   GH_TRY(db.alloc(&d_bci, blocks_ub + 1));
   GH_TRY(db.alloc(&d_bcj, blocks_ub + 1));
@@ -1170,8 +1209,10 @@ gh_status build_schur_pairs_device(gh_ctx* ctx, DevBuf& db, int nc, int no, size
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kPairSortMaxCams * 4));
     lds_attr[dev] = true;
   }
-  GH_LAUNCH(ctx, "ba_pl_sort", pair_sort_kernel, dim3(nc), T, (size_t)nc * sizeof(int), d_cstart, (const int32_t*)d_goff,
-            (const int32_t*)d_gen_k, (const int32_t*)d_gen_k2, (const int32_t*)d_gen_cj, d_pa, d_pb, d_tmp_start, d_tmp_cj,
+  GH_LAUNCH(ctx, "ba_pl_scan", pair_ranges_kernel, dim3(1), T, 0, d_cstart, (const int32_t*)d_goff, nc, d_range_off);
+  // (the grid is an upper bound on the number of ranges: the workgroups beyond the device's count return at once)
+  GH_LAUNCH(ctx, "ba_pl_sort", pair_sort_kernel, dim3((unsigned)(pairs_ub / kPairSortRange + (size_t)nc)), T,
+            (size_t)nc * sizeof(int), d_cstart, (const int32_t*)d_goff, (const int32_t*)d_range_off, nc, (const int32_t*)d_gen_k, (const int32_t*)d_gen_k2, (const int32_t*)d_gen_cj, d_pa, d_pb, d_tmp_start, d_tmp_cj,
             d_blk_off);
   // blocks: exclusive scan of the per-camera block counts (in place, nc + 1 entries), total -> counts[1]
   GH_LAUNCH(ctx, "ba_pl_scan", scan_sums_kernel, dim3(1), T, 0, d_blk_off, nc, d_counts + 1);
@@ -1312,8 +1353,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
                              NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 * 3 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
                         4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256 +
                         // device-built pair lists: 7 arrays of pairs_ub ints, block / segment tables, scan scratch
-                        4 * (pairs_ub * 7 + blocks_ub * 5 + pairs_ub / kSchurSeg + NO + NO / 1024 + blocks_ub / 1024 + NC + 64) +
-                        (device_pairs ? 24 * 256 : 0) +
+                        4 * (pairs_ub * 7 + blocks_ub * 5 + pairs_ub / kSchurSeg + NO + NO / 1024 + blocks_ub / 1024 + 2 * NC + 128) +
+                        (device_pairs ? 26 * 256 : 0) +
                         // chunk / segment tables and their partial sums (upper bounds)
                         (NO / kCamChunk + NC + 2) * (27 * 8 + 2 * 4) + (NC + 2) * 4 +
                         (std::max(pair_a.size(), pairs_ub) / kSchurSeg + std::max(bstart.size(), blocks_ub) + 2) * (42 * 8 + 4) +
@@ -1325,10 +1366,12 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_TRY(db.reserve(need));
   }
   if (!early) GH_TRY(raw_arrays(true));
+  const double t_u0 = now_ms();
   GH_TRY(db.upload(&d_pstart, (const int32_t*)pstart.data(), pstart.size()));
   GH_TRY(db.upload(&d_plist, (const int32_t*)plist.data(), plist.size()));
   GH_TRY(db.upload(&d_cstart, (const int32_t*)cstart.data(), cstart.size()));
   GH_TRY(db.upload(&d_clist, (const int32_t*)clist.data(), clist.size()));
+  const double t_u1 = now_ms();
   // camera chunks (lin_cams) and Schur segments: fixed-size work items, independent of how skewed the graph is
   std::vector<int32_t> ch_cam, ch_q0, ch_first((size_t)nc + 1, 0), seg_blk, seg_first((size_t)nblocks + 1, 0);
   for (int c = 0; c < nc; ++c) {
@@ -1354,6 +1397,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     GH_TRY(db.upload(&d_cf, (const int32_t*)ch_first.data(), ch_first.size()));
     CC = CamChunks{d_cc, d_cq, d_cf, nchunks};
   }
+  const double t_u2 = now_ms();
   SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nblocks, nsegs};
   SchurBlocks SB_host = SB;  // (check mode: the host-built tables beside the device-built ones)
   if (device_pairs) {
@@ -1379,6 +1423,10 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     SB_host = SchurBlocks{d_pa, d_pb, d_bs, d_bci, d_bcj, d_sb, d_sf, nblocks, nsegs};
     if (!device_pairs) SB = SB_host;
   }
+  const double t_u3 = now_ms();
+  if (getenv("GSLAM_HIP_BA_TIMING"))
+    fprintf(stderr, "[gh_ba] upload phase: reserve %.2f, index lists up %.2f, chunk tables %.2f, pair lists %.2f ms\n", t_u0 - t_lists,
+            t_u1 - t_u0, t_u2 - t_u1, t_u3 - t_u2);
   double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart, *d_xwork, *d_xh;
   unsigned long long* d_gmax;
   int *d_bad, *d_info;
