@@ -17,6 +17,7 @@
 //                model decrease, fixed-order block reduction -> 2 doubles read back by the host loop.
 // Jacobians are recomputed where needed instead of being stored (80 B gathered beats 144 B of W traffic).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -962,6 +963,54 @@ void build_csr(const int32_t* key, int n_items, int n_keys, std::vector<int32_t>
   for (int k = 0; k < n_items; ++k) list[fill[key[k]]++] = k;
 }
 
+// The same lists by T cooperating tasks (all T must be running at the same time: they meet at two spin barriers).  Task t
+// counts the keys of its slice of the items, the key ranges are prefixed in parallel (start[] and, per task, the first
+// position of each key for that task's slice), then every task fills its slice in item order: stable, element for element
+// what build_csr gives.
+struct CsrShared {
+  std::vector<int32_t> counts;  // [T][n_keys]
+  std::vector<long long> range_sum;
+  std::atomic<int> arrived[2];
+  void reset(int T, int n_keys) {
+    counts.assign((size_t)T * n_keys, 0);
+    range_sum.assign((size_t)T, 0);
+    arrived[0] = arrived[1] = 0;
+  }
+};
+void build_csr_task(const int32_t* key, int n_items, int n_keys, std::vector<int32_t>& start, std::vector<int32_t>& list, int T,
+                    int t, CsrShared& sh) {
+  auto barrier = [&](int which) {
+    sh.arrived[which].fetch_add(1, std::memory_order_acq_rel);
+    while (sh.arrived[which].load(std::memory_order_acquire) < T) std::this_thread::yield();
+  };
+  const int i0 = (int)((long long)n_items * t / T), i1 = (int)((long long)n_items * (t + 1) / T);
+  int32_t* mine = sh.counts.data() + (size_t)t * n_keys;
+  for (int k = i0; k < i1; ++k) mine[key[k]]++;
+  barrier(0);
+  const int k0 = (int)((long long)n_keys * t / T), k1 = (int)((long long)n_keys * (t + 1) / T);
+  long long sum = 0;
+  for (int kk = k0; kk < k1; ++kk)
+    for (int tt = 0; tt < T; ++tt) sum += sh.counts[(size_t)tt * n_keys + kk];
+  sh.range_sum[t] = sum;
+  barrier(1);
+  long long pos = 0;
+  for (int tt = 0; tt < t; ++tt) pos += sh.range_sum[tt];
+  for (int kk = k0; kk < k1; ++kk) {
+    start[kk] = (int32_t)pos;
+    for (int tt = 0; tt < T; ++tt) {
+      int32_t& c = sh.counts[(size_t)tt * n_keys + kk];
+      const int32_t n = c;
+      c = (int32_t)pos;  // the slot now holds task tt's first position for this key
+      pos += n;
+    }
+  }
+  if (t == T - 1) start[n_keys] = (int32_t)pos;
+  // every task's offsets must be final before anybody fills: a third meeting, on the first counter (it only grows)
+  sh.arrived[0].fetch_add(1, std::memory_order_acq_rel);
+  while (sh.arrived[0].load(std::memory_order_acquire) < 2 * T) std::this_thread::yield();
+  for (int k = i0; k < i1; ++k) list[mine[key[k]]++] = k;
+}
+
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -1317,14 +1366,37 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   gh_status early_status = GH_OK;
 
   std::vector<int32_t> pstart, plist, cstart, clist;
-  HostPool::get().run(early ? 3 : 2, [&](int t) {
-    if (t == 0) build_csr(pr->obs_point, no, np, pstart, plist);
-    else if (t == 1) build_csr(pr->obs_cam, no, nc, cstart, clist);
-    else {
+  {
+    // index lists by point and by camera: each by a team of pool tasks when the pool has a thread for every task of the
+    // region (the teams meet at spin barriers), else one task per list
+    HostPool& pool = HostPool::get();
+    const int Tp = 6, Tc = 3, extra = early ? 1 : 0;
+    const bool teams = no >= 20000 && pool.size() >= Tp + Tc + extra;
+    auto upload_task = [&] {
       (void)hipSetDevice(ctx->device);  // the current device is a per-thread setting
       early_status = raw_arrays(true);
+    };
+    if (teams) {
+      CsrShared shp, shc;
+      shp.reset(Tp, np);
+      shc.reset(Tc, nc);
+      pstart.assign((size_t)np + 1, 0);
+      cstart.assign((size_t)nc + 1, 0);
+      plist.resize((size_t)(no > 0 ? no : 1));
+      clist.resize((size_t)(no > 0 ? no : 1));
+      pool.run(Tp + Tc + extra, [&](int t) {
+        if (t < Tp) build_csr_task(pr->obs_point, no, np, pstart, plist, Tp, t, shp);
+        else if (t < Tp + Tc) build_csr_task(pr->obs_cam, no, nc, cstart, clist, Tc, t - Tp, shc);
+        else upload_task();
+      });
+    } else {
+      pool.run(2 + extra, [&](int t) {
+        if (t == 0) build_csr(pr->obs_point, no, np, pstart, plist);
+        else if (t == 1) build_csr(pr->obs_cam, no, nc, cstart, clist);
+        else upload_task();
+      });
     }
-  });
+  }
   GH_TRY(early_status);
   const double t_csr = now_ms();
 
