@@ -1327,54 +1327,89 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     int info, bad;
     int32_t pair_counts[4];  // device-built pair lists: pairs, blocks, segments, (unused)
   };
+  // The caller's arrays (8.9 MB at C4, pageable: 0.85-1.2 ms of staged copies when the driver does it) go up WHILE the host
+  // builds its index lists -- when the arena of an earlier solve is there to take them (a first solve, or one that has to
+  // grow the arena, uploads after the lists as before).  With enough pool threads the staging is ours: the arrays lie back
+  // to back on the device, four tasks copy a quarter of that image each into pinned memory and send it with one
+  // asynchronous copy.
+  const size_t raw_bytes = 8 * ((size_t)nc * 7 * 2 + (size_t)np * 3 * 2 + (size_t)no * 2 + (pr->obs_info ? (size_t)no * 4 : 0)) +
+                           4 * ((size_t)nc + 2 * (size_t)no) + (size_t)np + 16 * 256;
+  const char* early_env = getenv("GSLAM_HIP_BA_EARLY_UPLOAD");  // "0": upload after the lists (A/B measurements)
+  bool early = ctx->ba_arena != nullptr && raw_bytes <= ctx->ba_arena_bytes && !(early_env && early_env[0] == '0');
+  constexpr size_t kStageOffset = 4096;  // the read-back block sits in front of the staging area
   Readback* rb = nullptr;
+  char* stage = nullptr;
   {
     void* pp = nullptr;
-    GH_TRY(gh_pinned(ctx, 256, &pp));
+    GH_TRY(gh_pinned(ctx, early ? kStageOffset + raw_bytes : 256, &pp));
     rb = (Readback*)pp;
+    stage = (char*)pp + kStageOffset;
   }
   DevBuf db(ctx);
   double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
   int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
   uint8_t* d_pfree = nullptr;
-  // The caller's arrays (8.9 MB at C4, pageable: ~0.85 ms of staged copies) go up on a pool thread WHILE the host builds
-  // its index lists -- when the arena of an earlier solve is there to take them (a first solve, or one that has to grow
-  // the arena, uploads after the lists as before).
-  auto raw_arrays = [&](bool copy) -> gh_status {
+  struct RawPiece {
+    char* dst;
+    const char* src;
+    size_t bytes;
+  };
+  std::vector<RawPiece> raw_pieces;
+  auto raw_arrays = [&](bool copy) -> gh_status {  // copy = false: allocate and note the pieces only
+    raw_pieces.clear();
     auto put = [&](auto** out, auto* src, size_t count) -> gh_status {
       GH_TRY(db.alloc(out, count));
+      if (count) raw_pieces.push_back(RawPiece{(char*)*out, (const char*)src, count * sizeof(**out)});
       if (copy && count)
         GH_HIP(ctx, hipMemcpyAsync(*out, src, count * sizeof(**out), hipMemcpyHostToDevice, ctx->stream));
       return GH_OK;
     };
     GH_TRY(put(&d_poses, pr->cam_pose, (size_t)nc * 7));
     GH_TRY(put(&d_pts, pr->point_xyz, (size_t)np * 3));
-    GH_TRY(db.alloc(&d_poses_new, (size_t)nc * 7));
-    GH_TRY(db.alloc(&d_pts_new, (size_t)np * 3));
     GH_TRY(put(&d_dof, pr->cam_dof, (size_t)nc));
     if (pr->point_free) GH_TRY(put(&d_pfree, pr->point_free, (size_t)np));
     GH_TRY(put(&d_ocam, pr->obs_cam, (size_t)no));
     GH_TRY(put(&d_opt, pr->obs_point, (size_t)no));
     GH_TRY(put(&d_oxy, pr->obs_xy, (size_t)no * 2));
     if (pr->obs_info) GH_TRY(put(&d_oinfo, pr->obs_info, (size_t)no * 4));
+    GH_TRY(db.alloc(&d_poses_new, (size_t)nc * 7));
+    GH_TRY(db.alloc(&d_pts_new, (size_t)np * 3));
     return GH_OK;
   };
-  const size_t raw_bytes = 8 * ((size_t)nc * 7 * 2 + (size_t)np * 3 * 2 + (size_t)no * 2 + (pr->obs_info ? (size_t)no * 4 : 0)) +
-                           4 * ((size_t)nc + 2 * (size_t)no) + (size_t)np + 16 * 256;
-  const char* early_env = getenv("GSLAM_HIP_BA_EARLY_UPLOAD");  // "0": upload after the lists (A/B measurements)
-  bool early = ctx->ba_arena != nullptr && raw_bytes <= ctx->ba_arena_bytes && !(early_env && early_env[0] == '0');
   gh_status early_status = GH_OK;
+  // part u of U of the device image of the arrays: pageable -> pinned, then one asynchronous copy
+  auto stage_part = [&](int u, int U) -> gh_status {
+    char* base = raw_pieces.front().dst;
+    const size_t total = (size_t)(raw_pieces.back().dst - base) + raw_pieces.back().bytes;
+    const size_t b0 = (total * u / U) & ~(size_t)255, b1 = u + 1 == U ? total : (total * (u + 1) / U) & ~(size_t)255;
+    for (const RawPiece& pc : raw_pieces) {
+      const size_t p0 = (size_t)(pc.dst - base), p1 = p0 + pc.bytes;
+      const size_t lo = std::max(p0, b0), hi = std::min(p1, b1);
+      if (lo < hi) memcpy(stage + lo, pc.src + (lo - p0), hi - lo);
+    }
+    if (b1 > b0) GH_HIP(ctx, hipMemcpyAsync(base + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, ctx->stream));
+    return GH_OK;
+  };
 
   std::vector<int32_t> pstart, plist, cstart, clist;
   {
     // index lists by point and by camera: each by a team of pool tasks when the pool has a thread for every task of the
     // region (the teams meet at spin barriers), else one task per list
     HostPool& pool = HostPool::get();
-    const int Tp = 6, Tc = 3, extra = early ? 1 : 0;
-    const bool teams = no >= 20000 && pool.size() >= Tp + Tc + extra;
-    auto upload_task = [&] {
+    constexpr int Tp = 6, Tc = 3, U = 4;
+    const bool teams = no >= 20000 && pool.size() >= Tp + Tc + (early ? U : 0);
+    gh_status part_status[U] = {GH_OK, GH_OK, GH_OK, GH_OK};
+    if (early && teams) {
+      GH_TRY(raw_arrays(false));
+      early = !raw_pieces.empty() && raw_pieces.front().dst >= (char*)ctx->ba_arena &&
+              raw_pieces.back().dst + raw_pieces.back().bytes <= (char*)ctx->ba_arena + ctx->ba_arena_bytes;
+      if (!early) db.used = 0;  // (cannot happen with an arena that holds raw_bytes; the plain path allocates again)
+    }
+    const int extra = early ? (teams ? U : 1) : 0;
+    auto upload_task = [&](int u) {
       (void)hipSetDevice(ctx->device);  // the current device is a per-thread setting
-      early_status = raw_arrays(true);
+      if (teams) part_status[u] = stage_part(u, U);
+      else early_status = raw_arrays(true);
     };
     if (teams) {
       CsrShared shp, shc;
@@ -1387,13 +1422,14 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       pool.run(Tp + Tc + extra, [&](int t) {
         if (t < Tp) build_csr_task(pr->obs_point, no, np, pstart, plist, Tp, t, shp);
         else if (t < Tp + Tc) build_csr_task(pr->obs_cam, no, nc, cstart, clist, Tc, t - Tp, shc);
-        else upload_task();
+        else upload_task(t - Tp - Tc);
       });
+      for (int u = 0; u < U; ++u) GH_TRY(part_status[u]);
     } else {
       pool.run(2 + extra, [&](int t) {
         if (t == 0) build_csr(pr->obs_point, no, np, pstart, plist);
         else if (t == 1) build_csr(pr->obs_cam, no, nc, cstart, clist);
-        else upload_task();
+        else upload_task(0);
       });
     }
   }
