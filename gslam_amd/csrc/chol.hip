@@ -1195,18 +1195,23 @@ __global__ __launch_bounds__(256) void bwd_step2_inv_kernel(const double* __rest
 // kernels: hand-off price list"; protocol = cdna_hip_programming.md Guideline 16 form R1):
 //   64 x 64 tiles (i, j), i >= j.  A tile is LEFT-LOOKING: its owner keeps  -A[i,j] + sum_{k < j} L[i,k] L[j,k]^T  in MFMA
 //   accumulators for the whole launch (initialised with -A), adds column k as soon as the two operand tiles are
-//   published, and finally writes L[i,j] = (A[i,j] - sum) M_j^T exactly once.  Nothing is read-modify-written in memory, no two workgroups write the same
-//   tile, the summation order is fixed (k ascending): the result is reproducible bit for bit.
-//   diagonal workgroup j   owns (j, j-1) and (j, j): after column j-2 it waits for M_{j-1}, applies it to (j, j-1),
-//                          updates (j, j) with the result, factors it (potf2_inv_lds, as the launch path does) and
-//                          publishes M_j.  These 47 workgroups are the critical chain; everything they wait for except
-//                          M_{j-1} is ready a step earlier.
-//   worker workgroups      own up to FL_MAXT tiles (i, j0 .. j1) of one tile row, j1 <= i - 2.
+//   published, and finally writes L[i,j] = (A[i,j] - sum) M_j^T exactly once.  Nothing is read-modify-written in memory,
+//   no two workgroups write the same tile, the summation order is fixed (k ascending): the result is reproducible bit for
+//   bit.
+//   workgroups are 512 threads, two HALVES of four waves that share the MFMA phases of a role (one wave per SIMD
+//   sustains one f64 MFMA per ~120 cycles, two reach the pipe's 64).  Three roles:
+//   chain workgroup (0)    every diagonal block in turn: X = (j, j-1) M_{j-1}^T, (j, j) -= X X^T, potf2 + inverse
+//                          (potf2_chain_lds: the inversion pipelined behind the pivots), publishes M_j.  It is handed the
+//                          accumulators of (j, j-1) and (j, j) through `hand` and stores nothing but M_j.
+//   accumulator workgroup  of tile row j (1 .. ntr-1): (j, j-1) [half 0] and (j, j) [half 1] up to column j-2, handed to
+//                          the chain; then, with M_{j-1}, writes L[j, j-1].
+//   worker workgroups      own up to FL_MAXT tiles (i, j0 .. j1) of one tile row, j1 <= i - 2; tile t belongs to half t & 1.
 // The accumulators are held TRANSPOSED (MFMA rows = tile columns), which is at the same time the operand layout of the
 // X = P M^T product and of the later updates (trsm_block16 above): a tile never passes through LDS to change role.
-// Publishing = write-through (sc1) stores, every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE relaxed agent-scope
-// flag store; consuming = relaxed poll of that ONE word, then sc1 loads.  Every wait is bounded and watches a common
-// abort word: an expired wait raises `info`, sets the abort word and the launch runs out (with garbage) instead of hanging.
+// Publishing = write-through (sc1) stores, every wave of the publishing workgroup drains (s_waitcnt vmcnt(0)) and adds 1
+// to the tile's word; consuming = relaxed poll of that ONE word until all waves have arrived, then sc1 loads.  Every wait
+// is bounded and watches a common abort word: an expired wait raises `info`, sets the abort word and the launch runs out
+// (with garbage) instead of hanging.
 constexpr int FL_MAXT = 6;                       // tiles per worker: 3 per half of the workgroup, 16 accumulator doubles per lane each
 constexpr unsigned kFlowSpinLimit = 1u << 22;
 constexpr int kFlowLdsBytes = 4 * NBI * LP * (int)sizeof(double) + 1024;  // four tile buffers (or Potf2Lds + extras)
