@@ -1434,6 +1434,14 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
   }
   GH_TRY(early_status);
+  if (const char* pe = getenv("GSLAM_HIP_BA_PAIRS"); pe && pe[0] == 'c') {  // check mode: the team-built lists against the serial ones
+    std::vector<int32_t> s0, l0, s1, l1;
+    build_csr(pr->obs_point, no, np, s0, l0);
+    build_csr(pr->obs_cam, no, nc, s1, l1);
+    if (s0 != pstart || s1 != cstart || !std::equal(plist.begin(), plist.begin() + no, l0.begin()) ||
+        !std::equal(clist.begin(), clist.begin() + no, l1.begin()))
+      return gh_set_error(ctx, GH_ERR_NUMERIC, "index lists built by the pool teams differ from the serial lists");
+  }
   const double t_csr = now_ms();
 
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant).  Large

@@ -176,8 +176,8 @@ def test_ba_single_launch_factorisation_against_the_launch_path(ctx, cams, monke
 @pytest.mark.parametrize("cams,points,per_point", [(12, 300, 5), (60, 6000, 6), (500, 50000, 6), (40, 3000, 12)])
 def test_schur_pair_lists_built_on_the_gpu_equal_the_host_lists(ctx, cams, points, per_point, monkeypatch):
     """GSLAM_HIP_BA_PAIRS=check builds the deterministic Schur pair lists both ways and compares every table (pairs,
-    block starts, block cameras, segment tables) element for element inside gh_ba_solve; the iterates must then equal the
-    host-list run bit for bit."""
+    block starts, block cameras, segment tables) element for element inside gh_ba_solve -- and the index lists built by
+    the pool teams against the serial ones; the iterates must then equal the host-list run bit for bit."""
     from gslam_amd import ba
     g = make_graph(cams, points, n_obs_per_point=per_point, seed=cams + per_point)
     monkeypatch.setenv("GSLAM_HIP_BA_PAIRS", "host")
