@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const doub
 // plus the list of distinct blocks.  One wave per block: lanes stride over the block's pairs, accumulate
 // W_i Hpp^-1 W_j^T in registers, and a fixed butterfly sums the 64 partials -> bitwise reproducible,
 // no atomics, and a camera with 20k observations is as parallel as one with 20.
-constexpr int kSchurSeg = 512;  // pairs per wave
+constexpr int kSchurSeg = 256;  // pairs per wave
 
 struct SchurBlocks {
   const int32_t* pair_a;   // observation index k  (row camera)
@@ -473,7 +473,10 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlock
                                                            const double* __restrict__ Wbuf,
                                                            double* __restrict__ partial) {
   const int lane = threadIdx.x & 63;
-  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the grid is a multiple of 8 workgroups; workgroup L runs on XCD L % 8: every XCD takes one contiguous eighth of the
+  // segments, so that the blocks of one row camera (consecutive in the list) gather its W rows through one L2
+  const int wg = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int seg = wg * 4 + (threadIdx.x >> 6);
   if (seg >= B.nsegs) return;
   const int blk = B.seg_blk[seg];
   const int e_begin = B.bstart[blk] + (seg - B.seg_first[blk]) * kSchurSeg;
@@ -1662,7 +1665,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
     if (no > 0) {
       if (opt.deterministic) {
-        GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(gh_div_up(nsegs, 4)), dim3(256), 0, P, SB, d_Hpi, d_gp,
+        GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(8 * gh_div_up(nsegs, 32)), dim3(256), 0, P, SB, d_Hpi, d_gp,
                   (const double*)d_W, d_spart);
         GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, SB,
                   (const double*)d_spart, d_S, lda, d_dc, n);
