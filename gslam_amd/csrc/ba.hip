@@ -169,9 +169,9 @@ __device__ __forceinline__ bool lin_obs(const Problem& P, int k, Obs& o, bool wi
 }
 
 // ---------------------------------------------------------------- linearisation
-__global__ __launch_bounds__(256) void lin_points_kernel(Problem P, double* __restrict__ Hpp, double* __restrict__ gp,
-                                                         unsigned long long* __restrict__ gmax_bits) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void lin_points_block(const Problem& P, double* __restrict__ Hpp, double* __restrict__ gp,
+                                                 unsigned long long* __restrict__ gmax_bits, int bid) {
+  const int p = bid * 256 + threadIdx.x;
   if (p >= P.np) return;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (int q = P.pstart[p]; q < P.pstart[p + 1]; ++q) {
@@ -241,12 +241,12 @@ struct CamChunks {
   int nchunks;
 };
 
-__global__ __launch_bounds__(256) void lin_cams_kernel(Problem P, CamChunks C, double* __restrict__ partial,
-                                                       double* __restrict__ Wbuf) {
+__device__ __forceinline__ void lin_cams_block(const Problem& P, const CamChunks& C, double* __restrict__ partial,
+                                               double* __restrict__ Wbuf, int bid) {
   __shared__ double part[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = C.cam[blockIdx.x];
-  const int q_begin = C.q0[blockIdx.x];
+  const int c = C.cam[bid];
+  const int q_begin = C.q0[bid];
   const int q_end = min(q_begin + kCamChunk, P.cstart[c + 1]);
   double H[21], g[6];  // upper triangle, row-major packed
 #pragma unroll
@@ -300,8 +300,18 @@ __global__ __launch_bounds__(256) void lin_cams_kernel(Problem P, CamChunks C, d
   }
   __syncthreads();
   if (threadIdx.x < 27)
-    partial[(size_t)27 * blockIdx.x + threadIdx.x] =
+    partial[(size_t)27 * bid + threadIdx.x] =
         (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ONE launch for both linearisations: the first `nchunks` workgroups take the camera chunks (the long ones: dispatched first),
+// the rest a block of 256 points each.  The two do not depend on each other, and 196 point workgroups alone do not fill
+// 256 CUs: as its own launch the point side cost 24 us per iteration plus a launch gap, here it runs beside the chunks.
+__global__ __launch_bounds__(256) void lin_kernel(Problem P, CamChunks C, double* __restrict__ partial,
+                                                  double* __restrict__ Wbuf, double* __restrict__ Hpp,
+                                                  double* __restrict__ gp, unsigned long long* __restrict__ gmax_bits) {
+  if ((int)blockIdx.x < C.nchunks) lin_cams_block(P, C, partial, Wbuf, (int)blockIdx.x);
+  else lin_points_block(P, Hpp, gp, gmax_bits, (int)blockIdx.x - C.nchunks);
 }
 
 // 32 threads per camera: thread t < 27 adds element t of the camera's chunk totals in chunk order
@@ -1637,10 +1647,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   int term = 0, it = 0;
   for (it = 0; it < opt.max_iterations; ++it) {
     if (need_lin) {  // (d_gmax and d_bad are zero here: cleared before the loop and by every backsub_update launch)
-      if (np > 0)
-        GH_LAUNCH(ctx, "ba_lin_points", lin_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, P, d_Hpp, d_gp,
+      if (np > 0 || nchunks > 0)
+        GH_LAUNCH(ctx, "ba_lin", lin_kernel, dim3(nchunks + gh_div_up(np, 256)), dim3(256), 0, P, CC, d_cpart, d_W, d_Hpp, d_gp,
                   d_gmax);
-      if (nchunks > 0) GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_kernel, dim3(nchunks), dim3(256), 0, P, CC, d_cpart, d_W);
       GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_reduce_kernel, dim3(gh_div_up(nc, 8)), dim3(256), 0, nc, CC,
                 (const double*)d_cpart, d_Hcc, d_gc, d_gmax);
       // the gradient test is evaluated at the iteration's single synchronisation point below; if it fires, the step

@@ -23,8 +23,8 @@ NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "
          "describe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "synth_kernel": "synth_frames",
          "syrk_mfma_kernel": "ba_syrk", "panel_step_kernel": "ba_panel_step", "potf2_inv_kernel": "ba_potf2", "trsm_inv_kernel": "ba_trsm",
          "schur_blocks_kernel": "ba_schur_blocks", "schur_reduce_kernel": "ba_schur_reduce",
-         "lin_cams_kernel": "ba_lin_cams", "lin_cams_reduce_kernel": "ba_lin_cams_reduce",
-         "lin_points_kernel": "ba_lin_points", "fwd_step_kernel": "ba_trsv_fwd", "bwd_step_inv_kernel": "ba_trsv_bwd",
+         "lin_kernel": "ba_lin", "lin_cams_reduce_kernel": "ba_lin_cams_reduce",
+         "fwd_step_kernel": "ba_trsv_fwd", "bwd_step_inv_kernel": "ba_trsv_bwd",
          "potrf_flow_kernel": "ba_potrf_flow", "bwd_chain_kernel": "ba_trsv_bwd (single launch)"}
 
 
