@@ -315,10 +315,10 @@ __global__ __launch_bounds__(256) void lin_kernel(Problem P, CamChunks C, double
 }
 
 // 32 threads per camera: thread t < 27 adds element t of the camera's chunk totals in chunk order
-__global__ __launch_bounds__(256) void lin_cams_reduce_kernel(int nc, CamChunks C, const double* __restrict__ partial,
-                                                              double* __restrict__ Hcc, double* __restrict__ gc,
-                                                              unsigned long long* __restrict__ gmax_bits) {
-  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+__device__ __forceinline__ void lin_cams_reduce_block(int nc, const CamChunks& C, const double* __restrict__ partial,
+                                                      double* __restrict__ Hcc, double* __restrict__ gc,
+                                                      unsigned long long* __restrict__ gmax_bits, int bid) {
+  const int c = bid * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
   if (c >= nc || t >= 27) return;
   double tot = 0;
   for (int ch = C.first[c]; ch < C.first[c + 1]; ++ch) tot += partial[(size_t)27 * ch + t];
@@ -340,9 +340,9 @@ __global__ __launch_bounds__(256) void lin_cams_reduce_kernel(int nc, CamChunks 
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(256) void damp_points_kernel(int np, const double* __restrict__ Hpp, double radius,
-                                                          double* __restrict__ Hpi, int* __restrict__ bad) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void damp_points_block(int np, const double* __restrict__ Hpp, double radius,
+                                                  double* __restrict__ Hpi, int* __restrict__ bad, int bid) {
+  const int p = bid * 256 + threadIdx.x;
   if (p >= np) return;
   double H[9];
 #pragma unroll
@@ -361,6 +361,21 @@ __global__ __launch_bounds__(256) void damp_points_kernel(int np, const double* 
   o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
   o[3] = o[1]; o[4] = (a * f - c * c) * id; o[5] = (b * c - a * e) * id;
   o[6] = o[2]; o[7] = o[5]; o[8] = (a * d - b * b) * id;
+}
+
+__global__ __launch_bounds__(256) void damp_points_kernel(int np, const double* __restrict__ Hpp, double radius,
+                                                          double* __restrict__ Hpi, int* __restrict__ bad) {
+  damp_points_block(np, Hpp, radius, Hpi, bad, (int)blockIdx.x);
+}
+// after a fresh linearisation: the camera-side reduction (first `nrb` workgroups) and the point-side damping + inversion
+// side by side -- neither reads what the other writes, and each alone leaves most of the CUs idle
+__global__ __launch_bounds__(256) void lin_reduce_damp_kernel(int nc, CamChunks C, const double* __restrict__ partial,
+                                                              double* __restrict__ Hcc, double* __restrict__ gc,
+                                                              unsigned long long* __restrict__ gmax_bits, int nrb, int np,
+                                                              const double* __restrict__ Hpp, double radius,
+                                                              double* __restrict__ Hpi, int* __restrict__ bad) {
+  if ((int)blockIdx.x < nrb) lin_cams_reduce_block(nc, C, partial, Hcc, gc, gmax_bits, (int)blockIdx.x);
+  else damp_points_block(np, Hpp, radius, Hpi, bad, (int)blockIdx.x - nrb);
 }
 
 // S diagonal blocks (+ damping) and rhs = -g_c.  S is n x n column-major, zeroed beforehand.
@@ -382,12 +397,12 @@ __global__ __launch_bounds__(64) void schur_diag_kernel(int nc, const double* __
 // its 64 x 64 diagonal tile down to the right-hand-side row n (pitch lda), i.e. the lower block triangle with whole
 // diagonal tiles -- half the bytes of a memset of the full square, and two launches less.  Element (r, c) of a camera's
 // diagonal 6 x 6 block gets H_cc (+ damping), row n gets rhs = -g_c (it rides through the factorisation), the rest zero.
-__global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
-                                                         const double* __restrict__ gc, double radius,
-                                                         double* __restrict__ S, double* __restrict__ rhs) {
+__device__ __forceinline__ void schur_init_block(int n, int lda, const double* __restrict__ Hcc,
+                                                 const double* __restrict__ gc, double radius, double* __restrict__ S,
+                                                 double* __restrict__ rhs, int bx, int by) {
   // one workgroup = 2048 rows of one column (8 per thread: four 16-byte stores), starting at the column's diagonal tile
-  const int c = blockIdx.y, r0 = (c >> 6) << 6;
-  const int rb = r0 + blockIdx.x * 2048;
+  const int c = by, r0 = (c >> 6) << 6;
+  const int rb = r0 + bx * 2048;
   if (rb > n) return;
   const int cam = c / 6, b = c - 6 * cam;
   double* col = S + (size_t)c * lda;
@@ -412,6 +427,12 @@ __global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const d
     if (r + 1 < lda) *reinterpret_cast<double2*>(col + r) = make_double2(v[0], v[1]);
     else col[r] = v[0];
   }
+}
+
+__global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
+                                                         const double* __restrict__ gc, double radius,
+                                                         double* __restrict__ S, double* __restrict__ rhs) {
+  schur_init_block(n, lda, Hcc, gc, radius, S, rhs, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 __device__ __forceinline__ void load_W(const double* __restrict__ Wbuf, int k, double* W) {
@@ -478,14 +499,13 @@ struct SchurBlocks {
 };
 
 // one wave per segment: partial[seg][0..35] = sum W_i Hpp^-1 W_j^T (row-major a, b), [36..41] = sum W_i Hpp^-1 g_p
-__global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlocks B, const double* __restrict__ Hpi,
-                                                           const double* __restrict__ gp,
-                                                           const double* __restrict__ Wbuf,
-                                                           double* __restrict__ partial) {
+__device__ __forceinline__ void schur_blocks_block(const Problem& P, const SchurBlocks& B, const double* __restrict__ Hpi,
+                                                   const double* __restrict__ gp, const double* __restrict__ Wbuf,
+                                                   double* __restrict__ partial, unsigned bid, unsigned nbid) {
   const int lane = threadIdx.x & 63;
-  // the grid is a multiple of 8 workgroups; workgroup L runs on XCD L % 8: every XCD takes one contiguous eighth of the
+  // `nbid` (a multiple of 8) workgroups take the segments; workgroup L runs on XCD L % 8: every XCD takes one contiguous eighth of the
   // segments, so that the blocks of one row camera (consecutive in the list) gather its W rows through one L2
-  const int wg = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int wg = (int)(bid & 7u) * (int)(nbid >> 3) + (int)(bid >> 3);
   const int seg = wg * 4 + (threadIdx.x >> 6);
   if (seg >= B.nsegs) return;
   const int blk = B.seg_blk[seg];
@@ -528,6 +548,30 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlock
 #pragma unroll
   for (int t = 0; t < 6; ++t) mine = (lane == 36 + t) ? racc[t] : mine;
   if (lane < 42) partial[(size_t)42 * seg + lane] = mine;
+}
+
+__global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlocks B, const double* __restrict__ Hpi,
+                                                           const double* __restrict__ gp,
+                                                           const double* __restrict__ Wbuf,
+                                                           double* __restrict__ partial) {
+  schur_blocks_block(P, B, Hpi, gp, Wbuf, partial, blockIdx.x, gridDim.x);
+}
+// The segment sums (first `nsb` workgroups, a multiple of 8) and the seeding of S with the damped camera blocks + the
+// right-hand side row, in ONE launch: the sums only write `partial`, the seed only S; schur_reduce_kernel, which joins them,
+// comes behind both either way.  `gx` = workgroups per column of the seed.
+__global__ __launch_bounds__(256) void schur_blocks_init_kernel(Problem P, SchurBlocks B, const double* __restrict__ Hpi,
+                                                                const double* __restrict__ gp,
+                                                                const double* __restrict__ Wbuf,
+                                                                double* __restrict__ partial, unsigned nsb, int n, int lda,
+                                                                const double* __restrict__ Hcc,
+                                                                const double* __restrict__ gc, double radius,
+                                                                double* __restrict__ S, double* __restrict__ rhs, int gx) {
+  if (blockIdx.x < nsb) {
+    schur_blocks_block(P, B, Hpi, gp, Wbuf, partial, blockIdx.x, nsb);
+  } else {
+    const int b = (int)(blockIdx.x - nsb);
+    schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
+  }
 }
 
 // block-wide exclusive scan of one int per thread (256 threads); returns the exclusive prefix, *total = the sum
@@ -1650,21 +1694,27 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       if (np > 0 || nchunks > 0)
         GH_LAUNCH(ctx, "ba_lin", lin_kernel, dim3(nchunks + gh_div_up(np, 256)), dim3(256), 0, P, CC, d_cpart, d_W, d_Hpp, d_gp,
                   d_gmax);
-      GH_LAUNCH(ctx, "ba_lin_cams", lin_cams_reduce_kernel, dim3(gh_div_up(nc, 8)), dim3(256), 0, nc, CC,
-                (const double*)d_cpart, d_Hcc, d_gc, d_gmax);
-      // the gradient test is evaluated at the iteration's single synchronisation point below; if it fires, the step
-      // computed meanwhile is simply dropped (same decisions as testing here, one host round trip less)
-      GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      // (the camera-side reduction shares its launch with the point-side damping below)
     }
     const bool fresh_lin = need_lin;
     need_lin = false;
-    if (np > 0)
+    if (fresh_lin) {
+      const int nrb = gh_div_up(nc, 8);
+      GH_LAUNCH(ctx, "ba_damp_points", lin_reduce_damp_kernel, dim3(nrb + gh_div_up(np, 256)), dim3(256), 0, nc, CC,
+                (const double*)d_cpart, d_Hcc, d_gc, d_gmax, nrb, np, (const double*)d_Hpp, radius, d_Hpi, d_bad);
+      // the gradient test is evaluated at the iteration's single synchronisation point below; if it fires, the step
+      // computed meanwhile is simply dropped (same decisions as testing here, one host round trip less)
+      GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    } else if (np > 0) {
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
                 d_Hpi, d_bad);
+    }
     const bool slim_init = d_flow != nullptr && n < 65536;  // the single-launch factorisation reads the lower tiles only
+    const bool fused_seed = slim_init && no > 0 && opt.deterministic;  // then the seed rides with the segment sums below
     if (slim_init) {
-      GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc, d_gc,
-                radius, d_S, d_dc);
+      if (!fused_seed)
+        GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc,
+                  d_gc, radius, d_S, d_dc);
     } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
       hipError_t me = hipMemsetAsync(d_S, 0, (size_t)n * lda * sizeof(double), ctx->stream);
@@ -1674,8 +1724,16 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
     if (no > 0) {
       if (opt.deterministic) {
-        GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(8 * gh_div_up(nsegs, 32)), dim3(256), 0, P, SB, d_Hpi, d_gp,
-                  (const double*)d_W, d_spart);
+        const unsigned nsb = 8u * (unsigned)gh_div_up(nsegs, 32);
+        if (fused_seed) {
+          const int gx = gh_div_up(n + 1, 2048);
+          GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_init_kernel, dim3(nsb + (unsigned)gx * (unsigned)n), dim3(256), 0, P,
+                    SB, d_Hpi, d_gp, (const double*)d_W, d_spart, nsb, n, lda, (const double*)d_Hcc, (const double*)d_gc,
+                    radius, d_S, d_dc, gx);
+        } else {
+          GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(nsb), dim3(256), 0, P, SB, d_Hpi, d_gp,
+                    (const double*)d_W, d_spart);
+        }
         GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, SB,
                   (const double*)d_spart, d_S, lda, d_dc, n);
       } else {
