@@ -26,11 +26,13 @@
 #include "common.h"
 
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
-                            double* xwork, unsigned* flow_state, bool store_diag);
+                            double* xwork, unsigned* flow_state, bool store_diag, bool state_ready);
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
+size_t gh_potrf_flow_flag_words(int n, int extra_rows);
 std::mutex& gh_potrf_flow_mutex();
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
-                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev);
+                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
+                                bool xh_ready);
 
 namespace {
 
@@ -814,9 +816,25 @@ __global__ __launch_bounds__(256) void pair_segments_kernel(int nblocks, const i
 // 64 threads per block: thread t < 42 adds element t of the block's segment totals in segment order, then
 // S[block] -= total (this thread is the element's only writer), rhs += total for the diagonal blocks
 // (the right-hand side is also kept as row `rhs_row` of S, where the factorisation picks it up)
+// what the two single-launch kernels behind the Schur product need cleared / filled before they start: done by the tail
+// workgroups of schur_reduce_kernel instead of three memset nodes in the stream
+struct SolveState {
+  unsigned* flow_flags;  // zero
+  unsigned n_flow;
+  unsigned* xh_words;    // the sentinel of bwd_chain_kernel in every 32-bit word
+  unsigned n_xh;
+  int* info;             // zero
+};
 __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const double* __restrict__ partial,
                                                            double* __restrict__ S, int n, double* __restrict__ rhs,
-                                                           int rhs_row) {
+                                                           int rhs_row, int n_reduce_blocks, SolveState st) {
+  if ((int)blockIdx.x >= n_reduce_blocks) {
+    const unsigned i = ((unsigned)blockIdx.x - (unsigned)n_reduce_blocks) * 256u + threadIdx.x;
+    if (i < st.n_flow) st.flow_flags[i] = 0u;
+    if (i < st.n_xh) st.xh_words[i] = 0xFFF8BEEFu;
+    if (i == 0 && st.info) *st.info = 0;
+    return;
+  }
   const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), t = threadIdx.x & 63;
   if (blk >= B.nblocks || t >= 42) return;
   double tot = 0;
@@ -1711,6 +1729,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     }
     const bool slim_init = d_flow != nullptr && n < 65536;  // the single-launch factorisation reads the lower tiles only
     const bool fused_seed = slim_init && no > 0 && opt.deterministic;  // then the seed rides with the segment sums below
+    bool solve_state_ready = false;  // set when schur_reduce_kernel has cleared what the single-launch solve kernels need
     if (slim_init) {
       if (!fused_seed)
         GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc,
@@ -1734,8 +1753,22 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(nsb), dim3(256), 0, P, SB, d_Hpi, d_gp,
                     (const double*)d_W, d_spart);
         }
-        GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, SB,
-                  (const double*)d_spart, d_S, lda, d_dc, n);
+        {
+          const int nred = gh_div_up(nblocks, 4);
+          SolveState st{nullptr, 0u, nullptr, 0u, d_info};
+          if (d_flow) {
+            st.flow_flags = d_flow;
+            st.n_flow = (unsigned)gh_potrf_flow_flag_words(n, 1);
+          }
+          if (d_xh) {
+            st.xh_words = reinterpret_cast<unsigned*>(d_xh);
+            st.n_xh = (unsigned)gh_div_up(n, 64) * 64u * 2u;
+          }
+          const unsigned words = st.n_flow > st.n_xh ? st.n_flow : st.n_xh;
+          GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(nred + gh_div_up((int)(words ? words : 1u), 256)),
+                    dim3(256), 0, SB, (const double*)d_spart, d_S, lda, d_dc, n, nred, st);
+          solve_state_ready = true;
+        }
       } else {
         GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
                   d_S, lda, d_dc, (const double*)d_W);
@@ -1751,9 +1784,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     // rhs -> row n of S: already there when schur_init_kernel + schur_reduce_kernel wrote it
     if (!(slim_init && opt.deterministic))
       GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
-    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false));
+    GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
-    GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info));
+    GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info, solve_state_ready));
     GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_LAUNCH(ctx, "ba_backsub", backsub_update_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, P, d_Hpi,

@@ -2025,6 +2025,10 @@ std::mutex& gh_potrf_flow_mutex() {
 }
 
 static size_t flow_flag_words(size_t nb, size_t ntr) { return (ntr * nb + nb + ntr + 16 + 31) & ~(size_t)31; }
+// u32 words at the start of the dataflow state that have to be ZERO when the launch starts (flags, abort word)
+size_t gh_potrf_flow_flag_words(int n, int extra_rows) {
+  return flow_flag_words((size_t)gh_div_up(n, NBI), (size_t)gh_div_up(n + extra_rows, NBI));
+}
 
 // u32 words of device state the dataflow launch needs (tile flags, block flags, abort word), 0 = shape not eligible
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows) {
@@ -2043,10 +2047,12 @@ size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows) {
 // is the single dataflow launch (potrf_flow_kernel); `store_diag` = false lets it leave the diagonal blocks of L unwritten
 // (a caller that only solves never reads them: the triangular solves use `dinv`).
 // `dinv`: only the lower triangle of each block is defined -- every reader masks the rest.
+// `state_ready`: the caller's previous kernel has already cleared `info_dev` and the flag words of `flow_state`
+// (gh_potrf_flow_flag_words): two memset nodes less in front of the launch.
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
-                            double* xwork, unsigned* flow_state, bool store_diag) {
+                            double* xwork, unsigned* flow_state, bool store_diag, bool state_ready) {
   const int nr = n + extra_rows;  // row bound of every panel / trailing operation
-  GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  if (!state_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   {
     const char* env = getenv("GSLAM_HIP_CHOL_FLOW");  // "0" keeps the launch-per-step path (A/B measurements, tests)
     // tiles must not share 128-byte lines: a line is only ever touched with plain loads by the one workgroup that owns it
@@ -2086,7 +2092,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
         GH_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_flow_whatif), &mask, sizeof(mask)));
       }
 #endif
-      GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
+      if (!state_ready) GH_HIP(ctx, hipMemsetAsync(flow_state, 0, flag_words * sizeof(unsigned), ctx->stream));
       GH_LAUNCH(ctx, "ba_potrf_flow", potrf_flow_kernel, dim3(1 + (fa.ntr > 1 ? fa.ntr - 1 : 0) + groups), dim3(512),
                 kFlowLdsBytes, fa);
       return GH_OK;
@@ -2162,13 +2168,16 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
 // backward substitution only: y[i] = yv[i * ystride] on entry, x is written to b.  `work`: n doubles (the launch-per-step
 // path keeps its running right-hand side there); `xh`: ceil(n / 64) * 64 doubles for the single-launch path (n <=
 // kBwdChainMaxN, GSLAM_HIP_BWD_CHAIN != 0) or nullptr; `info_dev` receives n + 1 + block if a hand-off wait expired.
+// `xh_ready`: the caller has already filled `xh` with the sentinel (every 32-bit word 0xFFF8BEEF).
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
-                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev) {
+                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
+                                bool xh_ready) {
   const char* env = getenv("GSLAM_HIP_BWD_CHAIN");  // "0" keeps the launch-per-step path (A/B measurements, tests)
   const bool chain_ok = !(env && env[0] == '0');
   if (xh && info_dev && chain_ok && n <= kBwdChainMaxN) {
     const int nb = gh_div_up(n, NBI);
-    GH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)xh, (int)0xFFF8BEEFu, (size_t)nb * NBI * 2, ctx->stream));
+    if (!xh_ready)
+      GH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)xh, (int)0xFFF8BEEFu, (size_t)nb * NBI * 2, ctx->stream));
     unsigned spin_limit = kBwdSpinLimit;
     if (const char* e = getenv("GSLAM_HIP_FLOW_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
     GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_chain_kernel, dim3(nb), dim3(256), 0, L, lda, n, nb, yv, ystride, dinv, xh, b,
@@ -2205,7 +2214,7 @@ gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double
     GH_LAUNCH(ctx, "ba_trsv_fwd", fwd_step_kernel, dim3(rows > 0 ? gh_div_up(rows, 256) : 1), dim3(256), 0, L, lda, n,
               k, kb, b, work);
   }
-  return gh_potrs_bwd_dev_impl(ctx, L, n, lda, b, work, dinv, work, 1, xh, info_dev);
+  return gh_potrs_bwd_dev_impl(ctx, L, n, lda, b, work, dinv, work, 1, xh, info_dev, false);
 }
 
 extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info) {
@@ -2226,7 +2235,7 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   {
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(), std::defer_lock);
     if (flow_state) flow_lock.lock();
-    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state, true));
+    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state, true, false));
     GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
