@@ -1707,6 +1707,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   double radius = opt.initial_radius, decrease = 2.0;
   bool need_lin = true;
   int term = 0, it = 0;
+  const double t_loop = now_ms();
   for (it = 0; it < opt.max_iterations; ++it) {
     if (need_lin) {  // (d_gmax and d_bad are zero here: cleared before the loop and by every backsub_update launch)
       if (np > 0 || nchunks > 0)
@@ -1865,11 +1866,15 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   sum->iterations = it;
   sum->termination = term;
   sum->final_cost = cost;
+  const double t_loop_end = now_ms();
   GH_HIP(ctx, hipMemcpyAsync(pr->cam_pose, d_poses, (size_t)nc * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (np > 0)
     GH_HIP(ctx, hipMemcpyAsync(pr->point_xyz, d_pts, (size_t)np * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   sum->total_ms = now_ms() - t_begin;
+  if (getenv("GSLAM_HIP_BA_TIMING"))
+    fprintf(stderr, "[gh_ba] whole solve %.2f ms: lists + early upload %.2f, to the first cost %.2f, first cost %.2f, iterations %.2f, result download %.2f\n",
+            sum->total_ms, t_lists - t_begin, t_upload - t_lists, t_loop - t_upload, t_loop_end - t_loop, now_ms() - t_loop_end);
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;
 }
 
