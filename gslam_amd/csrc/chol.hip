@@ -100,13 +100,16 @@ constexpr int NBS = 16;      // sub-step width inside a 64-block
 constexpr int LP = NBI + 1;  // LDS pitch (column-major: element (r, c) at c * LP + r)
 
 // ---------------------------------------------------------------- potf2 + inverse of a 64x64 diagonal block
-// 1 / sqrt(d) to ~1 ulp: hardware estimate r0, then one fourth-order correction r0 (1 + e/2 + 3e^2/8 + 5e^3/16) with
-// e = 1 - d r0^2 -- a 5-instruction dependent chain (two Newton steps are 8); d > 0 is checked by the caller
+// 1 / sqrt(d) to ~1 ulp: hardware estimate r0 (v_rsq_f64: relative error <= ~2^-24), then ONE correction
+// r0 (1 + e/2 + 3 e^2 / 8) with e = 1 - d r0^2: the next term, 5 e^3 / 16 <= 2^-70, is far below an ulp.  Written with
+// q = e / 2 so that every constant is an inline operand (0.5, 1.0): r0 + r0 (q + 1.5 q^2), 1.5 q = q + q / 2 -- a 0.375
+// costs two v_mov per call to build, on the one wave that holds the pivots.  d > 0 is checked by the caller
 __device__ __forceinline__ double rsqrt_nr(double d) {
   const double r0 = __builtin_amdgcn_rsq(d);
   const double e = __builtin_fma(-(d * r0), r0, 1.0);
-  const double p = __builtin_fma(__builtin_fma(0.3125, e, 0.375), e, 0.5);
-  return __builtin_fma(r0 * e, p, r0);
+  const double q = e * 0.5;
+  const double b = __builtin_fma(__builtin_fma(q, 0.5, q), q, q);
+  return __builtin_fma(r0, b, r0);
 }
 
 // value of lane `l` (wave-uniform index) broadcast through SGPRs
