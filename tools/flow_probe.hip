@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipEventRecord(e0, ctx->stream);
-    if (gh_potrf_dev_impl(ctx, dA, n, lda, dinfo, 1, dM, dX, dflow, false) != GH_OK) { printf("launch failed: %s\n", ctx->last_error.c_str()); return 1; }
+    if (gh_potrf_dev_impl(ctx, dA, n, lda, dinfo, 1, dM, dX, dflow, false, false) != GH_OK) { printf("launch failed: %s\n", ctx->last_error.c_str()); return 1; }
     hipEventRecord(e1, ctx->stream);
     hipDeviceSynchronize();
     float ms = 0;
