@@ -30,6 +30,25 @@ constexpr int kMaxL = GH_ORB_MAX_LEVELS;   // 8
 constexpr int kHistBins = kCap * 256;      // (rank, 255 - score)
 constexpr int kCellRec = 8;                // dwords per compact cell record: count + the first 7 entries
 
+// Test-only branch census (gh_orb_plan_debug_counters): which rarely taken paths an extraction went through.
+enum {
+  kDbgCells = 0,         // cells processed by fast_cells
+  kDbgDenseCells,        // cells with more than 64 scored pixels (the list-based branch)
+  kDbgOverflowCells,     // cells that wrote entries 7.. to their overflow slot
+  kDbgCapCells,          // cells that kept exactly kCap entries
+  kDbgRankDropped,       // cells with more than kCap candidates: ranks >= kCap dropped
+  kDbgStrongSilenced,    // cells where a strong corner removed weaker candidates
+  kDbgMaxQueue,          // longest pass-1 queue of a tile
+  kDbgMaxNz,             // most scored pixels in one cell
+  kDbgSelCut,            // (level, frame) selections where the quota cut something off
+  kDbgSelTieSplit,       // ... and the cut-off bin was taken only in part
+  kDbgSelOverflowCells,  // cells whose overflow entries orb_select visited (output pass)
+  kDbgSelStreamed,       // select launches of the streaming (non-cached) variant
+  kDbgUnusedSlots,       // zero-filled output rows
+  kDbgStarvedLevels,     // (level, frame) selections with fewer candidates than quota
+  kDbgCount = 16
+};
+
 struct LevelView {
   const uint8_t* base;   // frame 0
   size_t frame_stride;   // bytes between frames
@@ -216,7 +235,8 @@ constexpr int kScoreW = 72;   // row pitch (bytes)
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                         int cell_off, int n_frames, NextLevel nx) {
+                                                         int cell_off, int n_frames, NextLevel nx,
+                                                         uint32_t* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
@@ -470,6 +490,13 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     const uint64_t m = __ballot(keep);
     if (keep) put_entry(__popcll(m & lt_mask), ((uint32_t)rank << 18) | e);
     kept = __popcll(m);
+    if (dbg != nullptr) {  // test-only branch census (gh_orb_plan_debug_counters)
+      const uint64_t all_max = __ballot(ismax);
+      if (lane == 0) {
+        if (__popcll(cand) > kCap) atomicAdd(&dbg[kDbgRankDropped], 1u);
+        if (strong_mask != 0ull && strong_mask != all_max) atomicAdd(&dbg[kDbgStrongSilenced], 1u);
+      }
+    }
   } else {
     int n = 0;
     bool strong = false;
@@ -502,7 +529,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
         if (keep) list[m2 + __popcll(m & lt_mask)] = e;
         m2 += __popcll(m);
       }
+      if (dbg != nullptr && lane == 0 && m2 != n) atomicAdd(&dbg[kDbgStrongSilenced], 1u);
       n = m2;
+    }
+    if (dbg != nullptr && lane == 0) {
+      atomicAdd(&dbg[kDbgDenseCells], 1u);
+      if (n > kCap) atomicAdd(&dbg[kDbgRankDropped], 1u);
     }
     // rank within the cell by (score desc, raster asc); keep rank < cap, write in raster order
     for (int base = 0; base < n; base += 64) {
@@ -521,6 +553,13 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     }
   }
   if (lane == 0) rec[0] = (uint32_t)kept;
+  if (dbg != nullptr && lane == 0) {
+    atomicAdd(&dbg[kDbgCells], 1u);
+    if (kept > kCellRec - 1) atomicAdd(&dbg[kDbgOverflowCells], 1u);
+    if (kept == kCap) atomicAdd(&dbg[kDbgCapCells], 1u);
+    atomicMax(&dbg[kDbgMaxQueue], (uint32_t)nq);
+    atomicMax(&dbg[kDbgMaxNz], (uint32_t)nz);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,7 +635,8 @@ constexpr int kSelCached = 8;
 template <bool CACHED>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_t* __restrict__ cell_cnt,
                                                      const uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                     int K, SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt) {
+                                                     int K, SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt,
+                                                     uint32_t* __restrict__ dbg) {
   // bin k lives at k + (k >> 5): a thread's 32 consecutive bins (tid * 32 + i) then fall into different banks for
   // different threads (unpadded, all 64 lanes of a wave hit bank i)
   __shared__ uint32_t hist[kHistBins + kHistBins / 32];
@@ -658,6 +698,10 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
       if (run + hv >= quota) {
         s_cut = tid * kPer + i;
         s_m = quota - run;
+        if (dbg != nullptr) {
+          atomicAdd(&dbg[kDbgSelCut], 1u);
+          if (quota - run < hv) atomicAdd(&dbg[kDbgSelTieSplit], 1u);
+        }
         break;
       }
       run += hv;
@@ -688,6 +732,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     if (mysel > 0) {
       const int cx = c % ncx, cy = c / ncx;
       int k = 0, ties = 0;
+      if (dbg != nullptr && n_lt + n_eq > kCellRec - 1) atomicAdd(&dbg[kDbgSelOverflowCells], 1u);
       each([&](uint32_t v) {
         const int s = (int)((v >> 10) & 255);
         const int ck = (int)(v >> 18) * 256 + (255 - s);
@@ -726,6 +771,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_
     }
   }
   if (tid == 0) level_cnt[b * kMaxL + l] = out_carry;
+  if (dbg != nullptr && tid == 0 && out_carry < quota) atomicAdd(&dbg[kDbgStarvedLevels], 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,7 +802,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
                                                        const SelKp* __restrict__ sel,
                                                        const int32_t* __restrict__ level_cnt,
                                                        gh_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                       int32_t* __restrict__ counts, int n_frames) {
+                                                       int32_t* __restrict__ counts, int n_frames,
+                                                       uint32_t* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch + 28];  // + slack for the 16-B row reads
   __shared__ __attribute__((aligned(16))) uint32_t s_h[4][(kPatch + 1) * kBlurPitch];     // 34 rows x 28 dwords
   __shared__ __attribute__((aligned(16))) uint8_t s_blur[4][kBlur * kBlurPitch + 12];
@@ -785,6 +832,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   if (slot == 0 && lane == 0) counts[b] = total;
   if (i >= cnt_l) {  // unused slot: zero-fill one tail row so the whole K-row output is deterministic
     const int pos = total + unused_before + (i - cnt_l);
+    if (dbg != nullptr && lane == 0) atomicAdd(&dbg[kDbgUnusedSlots], 1u);
     if (pos < K) {
       if (lane < 7) reinterpret_cast<uint32_t*>(kps + (size_t)b * K + pos)[lane] = 0u;
       if (lane >= 8 && lane < 16) reinterpret_cast<uint32_t*>(desc + ((size_t)b * K + pos) * 32)[lane - 8] = 0u;
@@ -975,6 +1023,8 @@ struct gh_orb_plan {
   int8_t* d_pattern = nullptr;
   int32_t* d_dir = nullptr;
   uint32_t* tabs = nullptr;
+  uint32_t* dbg = nullptr;  // kDbgCount counters, allocated by gh_orb_plan_debug_counters(enable)
+  bool dbg_on = false;
   // host staging for gh_orb_extract_host
   // single-frame host entry point: device staging (image; count | keypoints | descriptors in ONE block so that the
   // results come back in one copy) and a pinned host mirror of the result block
@@ -1005,7 +1055,7 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   GH_ENTER(c);
   hipStreamSynchronize(c->stream);
   void* ptrs[] = {p->pyr, p->cell_cnt, p->cell_ent, p->sel, p->level_cnt, p->d_pattern, p->d_dir, p->tabs,
-                  p->stage_img, p->stage_out};
+                  p->stage_img, p->stage_out, p->dbg};
   for (void* q : ptrs)
     if (q) hipFree(q);
   if (p->stage_host) hipHostFree(p->stage_host);
@@ -1252,6 +1302,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     lv[0] = {p->pyr + p->lvl_off[0], p->slab, p->pitch[0], p->w, p->h};
   }
   for (int l = 1; l < L; ++l) lv[l] = {p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l]};
+  uint32_t* dbg = p->dbg_on ? p->dbg : nullptr;
 
   // Level l + 1 is produced inside fast_cells(l) (see the kernel); a level whose predecessor runs no FAST pass (no valid
   // region or no quota) is produced by the stand-alone resize launch instead.
@@ -1282,7 +1333,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     dim3 grid(8 * gh_div_up(tiles, 8));
     GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
               p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-              batch, nx);
+              batch, nx, dbg);
     if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
   }
   {
@@ -1302,10 +1353,12 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     }();
     if (max_cells <= kSelCached * 256 && !no_cache)
       GH_LAUNCH(ctx, "orb_select", select_kernel<true>, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
-                p->cells_per_frame, K, p->sel, p->level_cnt);
-    else
+                p->cells_per_frame, K, p->sel, p->level_cnt, dbg);
+    else {
       GH_LAUNCH(ctx, "orb_select", select_kernel<false>, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
-                p->cells_per_frame, K, p->sel, p->level_cnt);
+                p->cells_per_frame, K, p->sel, p->level_cnt, dbg);
+      if (dbg) GH_HIP(ctx, hipMemsetAsync(dbg + kDbgSelStreamed, 1, 1, ctx->stream));
+    }
   }
   {
     DescribeArgs a;
@@ -1320,7 +1373,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     const long long blocks = (long long)gh_div_up(K, 4) * batch;
     GH_CHECK_ARG(ctx, blocks < (1LL << 30));
     GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
-              p->level_cnt, kps_dev, desc_dev, counts_dev, batch);
+              p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
   }
   return GH_OK;
 }
@@ -1373,6 +1426,23 @@ extern "C" gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int
   GH_CHECK_ARG(ctx, src_row_stride >= width * channels && dst_row_stride >= width);
   GH_LAUNCH(ctx, "bgr_to_gray", bgr_to_gray_kernel, dim3(gh_div_up(width, 256), height), dim3(256), 0, bgr_dev, width,
             height, channels, src_row_stride, gray_dev, dst_row_stride);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_orb_plan_debug_counters(gh_orb_plan* p, int enable, uint32_t* out16) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
+  if (!p->dbg) {
+    GH_TRY(plan_alloc(p, kDbgCount * sizeof(uint32_t), (void**)&p->dbg));
+    GH_HIP(ctx, hipMemsetAsync(p->dbg, 0, kDbgCount * sizeof(uint32_t), ctx->stream));
+  }
+  if (out16) {  // read and clear
+    GH_HIP(ctx, hipMemcpyAsync(out16, p->dbg, kDbgCount * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GH_HIP(ctx, hipMemsetAsync(p->dbg, 0, kDbgCount * sizeof(uint32_t), ctx->stream));
+  }
+  p->dbg_on = enable != 0;
   return GH_OK;
 }
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gh_orb_extract_dev": (C.c_int, [_vp, _vp, _i, _sz, _i, _vp, _vp, _vp]),
     "gh_orb_extract_host": (C.c_int, [_vp, _vp, _i, _vp, _vp, C.POINTER(C.c_int32)]),
     "gh_bgr_to_gray_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "gh_orb_plan_debug_counters": (C.c_int, [_vp, _i, _vp]),
     "gh_orb_debug_level": (C.c_int, [_vp, _i, _i, _vp]),
     "gh_synth_frames_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _sz, _i, _i, C.c_uint32]),
     "gh_comm_unique_id": (C.c_int, [_vp]),

@@ -94,6 +94,17 @@ class OrbExtractor:
                                                    C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    DBG_NAMES = ("cells", "dense_cells", "overflow_cells", "cap_cells", "rank_dropped", "strong_silenced",
+                 "max_queue", "max_nz", "sel_cut", "sel_tie_split", "sel_overflow_cells", "sel_streamed",
+                 "unused_slots", "starved_levels")
+
+    def debug_counters(self, enable=True, read=True):
+        """Branch census of the extractions since the last read (gh_orb_plan_debug_counters)."""
+        out = np.zeros(16, np.uint32)
+        self.ctx.check(hip.lib.gh_orb_plan_debug_counters(self.plan, 1 if enable else 0,
+                                                          out.ctypes.data_as(C.c_void_p) if read else None))
+        return dict(zip(self.DBG_NAMES, out.tolist()))
+
     def debug_level(self, slot, level):
         w, h, _ = self.level(level)
         out = np.zeros((h, w), np.uint8)

@@ -169,6 +169,15 @@ gh_status gh_orb_extract_host(gh_orb_plan* plan, const uint8_t* gray, int row_st
 /* Fixed-point luma (B*1868 + G*9617 + R*4899 + 8192) >> 14 for 3- or 4-channel BGR(A) input. */
 gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
                              int src_row_stride, uint8_t* gray_dev, int dst_row_stride);
+/* Test-only branch census.  enable != 0 makes the following extractions of this plan count how often the rarely taken
+ * paths run; out16 (may be NULL) receives and clears the 16 counters accumulated so far:
+ *   [0] cells processed  [1] cells with > 64 scored pixels (list branch)  [2] cells that wrote overflow entries (8th..)
+ *   [3] cells at the 32-entry cap  [4] cells with > 32 candidates (ranks dropped)  [5] cells where a strong corner
+ *   silenced weaker ones  [6] longest pass-1 queue  [7] most scored pixels in a cell  [8] level selections cut by the
+ *   quota  [9] ... with the cut-off bin split among ties  [10] cells whose overflow entries the selection read
+ *   [11] streaming selection variant used  [12] zero-filled output rows  [13] level selections below quota.
+ * tests/test_orb_adversarial_gpu.py uses it to prove that its inputs reach those branches. */
+gh_status gh_orb_plan_debug_counters(gh_orb_plan* plan, int enable, uint32_t* out16);
 /* Debug/test access: copy pyramid level `level` of batch slot `slot` to host (w*h bytes, dense). */
 gh_status gh_orb_debug_level(gh_orb_plan* plan, int slot, int level, uint8_t* out_host);
 

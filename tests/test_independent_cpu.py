@@ -364,3 +364,54 @@ def test_selected_keypoints_are_strict_local_maxima_of_the_naive_score(oracle):
     for c in set(zip(cx.tolist(), cy.tolist())):
         r = kps["response"][(cx == c[0]) & (cy == c[1])]
         assert (r > 20).all() or (r <= 20).all()
+
+
+def _naive_select_level0(img, K, ini_th=20, min_th=7):
+    """Spec steps 2-5 for a one-level pyramid, written from the numbered specification in plain Python (no code shared
+    with oracle/orb_oracle.c or the kernels): naive FAST-9 score, strict 3x3 NMS, 32x32 cells anchored at (19, 19)
+    with the strong-corner rule, in-cell rank by (S desc, y, x) capped at 32, quota K under the order
+    (rank, S desc, cell, raster), output in (cell, raster) order.  Returns [(x, y, S)]."""
+    h, w = img.shape
+    full = np.zeros((h, w), np.int32)
+    full[3:h - 3, 3:w - 3] = np.minimum(_naive_fast9_count(img), 255)
+    S = np.zeros((h, w), np.int32)
+    S[19:h - 19, 19:w - 19] = full[19:h - 19, 19:w - 19]
+    S[S <= min_th] = 0
+    ncx = (w - 38 + 31) // 32
+    cells = {}
+    for y in range(19, h - 19):
+        for x in range(19, w - 19):
+            s = S[y, x]
+            if s == 0:
+                continue
+            nb = S[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if nb.max() < s:
+                cells.setdefault(((y - 19) // 32) * ncx + (x - 19) // 32, []).append((int(s), y, x))
+    ranked = []
+    for c, lst in cells.items():
+        if any(s > ini_th for s, _, _ in lst):
+            lst = [e for e in lst if e[0] > ini_th]
+        lst.sort(key=lambda e: (-e[0], e[1], e[2]))
+        ranked += [(r, -s, c, y, x) for r, (s, y, x) in enumerate(lst[:32])]
+    ranked.sort()
+    take = ranked[:K]
+    take.sort(key=lambda e: (e[2], e[3], e[4]))
+    return [(x, y, -ns) for _, ns, _, y, x in take]
+
+
+@pytest.mark.parametrize("name", ["noise", "binary_noise", "low_contrast", "dots8", "checker2", "checker5", "mixed",
+                                  "step_edges", "sparse_binary"])
+def test_selection_against_naive_restatement_on_adversarial_images(oracle, name):
+    """Saturated cells, the 32-entry cap, quota cuts through tied scores: the oracle's one-level selection (positions,
+    responses AND output order) equals the plain-Python restatement of spec steps 2-5."""
+    from orb_images import CLASSES
+    img = CLASSES[name](150, 131, 5)
+    n_total = 0
+    for K, ini in ((40, 20), (700, 20), (6000, 35)):
+        kps, _ = oracle.orb_extract(img, K, nlevels=1, ini_th=ini, min_th=7)
+        want = _naive_select_level0(img, K, ini_th=ini)
+        got = [(int(k["x"]), int(k["y"]), int(k["response"])) for k in kps]
+        assert got == want, (name, K, len(got), len(want))
+        n_total += len(got)
+    assert n_total > 0 or name == "checker2"  # a 2-px checkerboard has no 9-arc at level 0: both sides agree on "nothing"
