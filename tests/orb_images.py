@@ -73,7 +73,8 @@ def few_corners(w, h, n, seed):
     rng = np.random.default_rng(seed)
     img = np.full((h, w), 60, np.uint8)
     for _ in range(n):
-        x, y = int(rng.integers(25, w - 30)), int(rng.integers(25, h - 30))
+        x = int(rng.integers(min(25, w // 2), max(w - 30, w // 2 + 1)))
+        y = int(rng.integers(min(25, h // 2), max(h - 30, h // 2 + 1)))
         img[y:y + 5, x:x + 5] = 200
     return img
 
