@@ -44,9 +44,23 @@ struct gh_ctx {
 // Entry guard of every public function that touches the device: serialises callers that share the context and makes the
 // context's GPU the calling thread's current device (a ctx may be created on one thread and used on another, and a
 // process may hold contexts for several GPUs; allocations, copies and launches below all go to the CURRENT device).
+// The caller's current device is restored on exit: a host process that also drives another GPU through HIP / torch must
+// not find its thread switched to ours after a gh_* call.
+struct gh_device_guard {
+  int prev = -1;
+  explicit gh_device_guard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) (void)hipSetDevice(device);
+    else prev = -1;  // nothing to restore
+  }
+  ~gh_device_guard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 struct gh_enter_guard {
   std::lock_guard<std::recursive_mutex> lock;
-  explicit gh_enter_guard(gh_ctx* c) : lock(c->mu) { (void)hipSetDevice(c->device); }
+  gh_device_guard dev;
+  explicit gh_enter_guard(gh_ctx* c) : lock(c->mu), dev(c->device) {}
 };
 #define GH_ENTER(ctx) gh_enter_guard _gh_enter_guard(ctx)
 

@@ -135,6 +135,21 @@ extern "C" gh_status gh_dev_memset(gh_ctx* ctx, void* dst_dev, int value, size_t
   return GH_OK;
 }
 
+extern "C" gh_status gh_host_alloc_pinned(gh_ctx* ctx, size_t bytes, void** out_host) {
+  if (!ctx || !out_host) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  hipError_t e = hipHostMalloc(out_host, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return gh_set_error(ctx, GH_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return GH_OK;
+}
+
+extern "C" gh_status gh_host_free_pinned(gh_ctx* ctx, void* host) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  if (host) GH_HIP(ctx, hipHostFree(host));
+  return GH_OK;
+}
+
 gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->scratch_bytes) {
     // The stream may still be using the old block: drain before replacing it.

@@ -984,11 +984,12 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
 }
 
 __global__ void bgr_to_gray_kernel(const uint8_t* __restrict__ bgr, int w, int h, int channels, int sstride,
-                                   uint8_t* __restrict__ gray, int dstride) {
+                                   size_t src_frame_stride, uint8_t* __restrict__ gray, int dstride, size_t dst_frame_stride) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= w || y >= h) return;
-  const uint8_t* p = bgr + (size_t)y * sstride + (size_t)x * channels;
-  gray[(size_t)y * dstride + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+  const uint8_t* p = bgr + (size_t)blockIdx.z * src_frame_stride + (size_t)y * sstride + (size_t)x * channels;
+  gray[(size_t)blockIdx.z * dst_frame_stride + (size_t)y * dstride + x] =
+      (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
 }
 
 long long ipow(int b, int e) {
@@ -1425,7 +1426,19 @@ extern "C" gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int
   GH_CHECK_ARG(ctx, bgr_dev && gray_dev && width > 0 && height > 0 && (channels == 3 || channels == 4));
   GH_CHECK_ARG(ctx, src_row_stride >= width * channels && dst_row_stride >= width);
   GH_LAUNCH(ctx, "bgr_to_gray", bgr_to_gray_kernel, dim3(gh_div_up(width, 256), height), dim3(256), 0, bgr_dev, width,
-            height, channels, src_row_stride, gray_dev, dst_row_stride);
+            height, channels, src_row_stride, (size_t)0, gray_dev, dst_row_stride, (size_t)0);
+  return GH_OK;
+}
+
+extern "C" gh_status gh_bgr_to_gray_batch_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
+                                              int src_row_stride, size_t src_frame_stride, int n_frames, uint8_t* gray_dev,
+                                              int dst_row_stride, size_t dst_frame_stride) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, bgr_dev && gray_dev && width > 0 && height > 0 && height <= 65535 && (channels == 3 || channels == 4));
+  GH_CHECK_ARG(ctx, src_row_stride >= width * channels && dst_row_stride >= width && n_frames >= 1 && n_frames <= 65535);
+  GH_LAUNCH(ctx, "bgr_to_gray", bgr_to_gray_kernel, dim3(gh_div_up(width, 256), height, n_frames), dim3(256), 0, bgr_dev,
+            width, height, channels, src_row_stride, src_frame_stride, gray_dev, dst_row_stride, dst_frame_stride);
   return GH_OK;
 }
 

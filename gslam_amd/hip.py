@@ -39,6 +39,11 @@ class OrbParams(C.Structure):
                 ("min_th_fast", C.c_int32)]
 
 
+class OrbStreamResult(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("offsets", C.POINTER(C.c_int32)), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("gpu_ms", C.c_float)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -99,6 +104,15 @@ SIGNATURES = {
     "gh_orb_extract_dev": (C.c_int, [_vp, _vp, _i, _sz, _i, _vp, _vp, _vp]),
     "gh_orb_extract_host": (C.c_int, [_vp, _vp, _i, _vp, _vp, C.POINTER(C.c_int32)]),
     "gh_bgr_to_gray_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "gh_bgr_to_gray_batch_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _sz, _i, _vp, _i, _sz]),
+    "gh_orb_stream_create": (C.c_int, [_vp, _i, _i, _i, _i, _sz, _i, _i, C.POINTER(OrbParams), C.POINTER(_vp)]),
+    "gh_orb_stream_destroy": (None, [_vp]),
+    "gh_orb_stream_staging": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "gh_orb_stream_submit": (C.c_int, [_vp, _vp, _i, C.POINTER(C.c_int64)]),
+    "gh_orb_stream_poll": (C.c_int, [_vp, C.c_int64, C.POINTER(_i)]),
+    "gh_orb_stream_collect": (C.c_int, [_vp, C.c_int64, C.POINTER(OrbStreamResult)]),
+    "gh_host_alloc_pinned": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "gh_host_free_pinned": (C.c_int, [_vp, _vp]),
     "gh_orb_plan_debug_counters": (C.c_int, [_vp, _i, _vp]),
     "gh_orb_debug_level": (C.c_int, [_vp, _i, _i, _vp]),
     "gh_synth_frames_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _sz, _i, _i, C.c_uint32]),

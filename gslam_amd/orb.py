@@ -116,3 +116,70 @@ def kps_to_numpy(kps_tensor, counts=None):
     """B x K x 7 float32 tensor -> structured KeyPoint array (bit reinterpretation, no conversion)."""
     a = kps_tensor.cpu().numpy()
     return a.view(KP_DTYPE).reshape(a.shape[0], a.shape[1])
+
+
+class OrbStream:
+    """gh_orb_stream_*: host-fed extraction (frames in host memory -> packed records in host memory) on three HIP streams.
+    No torch involved.  Mirrors the C ABI one to one; numpy views of the pinned blocks are handed out."""
+
+    def __init__(self, ctx: hip.Context, width, height, chunk_frames, depth=3, channels=1, row_stride=None,
+                 frame_stride=None, n_features=1000, n_levels=8, ini_th=20, min_th=7):
+        self.ctx = ctx
+        self.w, self.h, self.ch = width, height, channels
+        self.row_stride = row_stride or width * channels
+        self.frame_stride = frame_stride or self.row_stride * height
+        self.chunk, self.depth, self.K = chunk_frames, depth, n_features
+        prm = hip.OrbParams(n_features, n_levels, ini_th, min_th)
+        h = C.c_void_p()
+        ctx.check(hip.lib.gh_orb_stream_create(ctx.h, width, height, channels, self.row_stride,
+                                               C.c_size_t(self.frame_stride), chunk_frames, depth, C.byref(prm),
+                                               C.byref(h)))
+        self.s = h
+
+    def close(self):
+        if self.s:
+            hip.lib.gh_orb_stream_destroy(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def staging(self):
+        """numpy view (chunk x frame_stride bytes) of the pinned staging block the next submit will use."""
+        p = C.c_void_p()
+        self.ctx.check(hip.lib.gh_orb_stream_staging(self.s, C.byref(p)))
+        buf = (C.c_uint8 * (self.chunk * self.frame_stride)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.chunk, self.frame_stride)
+
+    def submit(self, frames=None, n_frames=None):
+        """frames: None (the staging block was filled) or a C-contiguous uint8 array laid out as the stream expects."""
+        t = C.c_int64()
+        if frames is None:
+            self.ctx.check(hip.lib.gh_orb_stream_submit(self.s, None, int(n_frames), C.byref(t)))
+        else:
+            assert frames.dtype == np.uint8 and frames.flags.c_contiguous
+            n = int(n_frames if n_frames is not None else frames.shape[0])
+            self.ctx.check(hip.lib.gh_orb_stream_submit(self.s, frames.ctypes.data_as(C.c_void_p), n, C.byref(t)))
+        return t.value
+
+    def poll(self, ticket):
+        r = C.c_int()
+        self.ctx.check(hip.lib.gh_orb_stream_poll(self.s, C.c_int64(ticket), C.byref(r)))
+        return bool(r.value)
+
+    def collect(self, ticket, copy=True):
+        """-> (offsets int32[n + 1], kps KP_DTYPE[total], desc uint8[total, 32], gpu_ms)."""
+        r = hip.OrbStreamResult()
+        self.ctx.check(hip.lib.gh_orb_stream_collect(self.s, C.c_int64(ticket), C.byref(r)))
+        n = r.n_frames
+        off = np.ctypeslib.as_array(r.offsets, shape=(n + 1,))
+        total = int(off[n])
+        kps = np.frombuffer((C.c_uint8 * (total * 28)).from_address(r.kps), KP_DTYPE) if total else np.zeros(0, KP_DTYPE)
+        desc = (np.frombuffer((C.c_uint8 * (total * 32)).from_address(r.desc), np.uint8).reshape(total, 32) if total
+                else np.zeros((0, 32), np.uint8))
+        if copy:
+            off, kps, desc = off.copy(), kps.copy(), desc.copy()
+        return off, kps, desc, float(r.gpu_ms)

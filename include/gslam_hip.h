@@ -169,6 +169,48 @@ gh_status gh_orb_extract_host(gh_orb_plan* plan, const uint8_t* gray, int row_st
 /* Fixed-point luma (B*1868 + G*9617 + R*4899 + 8192) >> 14 for 3- or 4-channel BGR(A) input. */
 gh_status gh_bgr_to_gray_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
                              int src_row_stride, uint8_t* gray_dev, int dst_row_stride);
+/* The same for n_frames frames laid out src_frame_stride / dst_frame_stride bytes apart (one launch). */
+gh_status gh_bgr_to_gray_batch_dev(gh_ctx* ctx, const uint8_t* bgr_dev, int width, int height, int channels,
+                                   int src_row_stride, size_t src_frame_stride, int n_frames, uint8_t* gray_dev,
+                                   int dst_row_stride, size_t dst_frame_stride);
+
+/* ---- Host-fed streaming extraction: frames arrive in HOST memory, results are wanted in HOST memory -------------------
+ * What a GSLAM process sees: a dataset / camera thread hands over frames one by one (GSLAM/plugins/play/main.cpp:99-155)
+ * and MapFrame::setKeyPoints wants std::vector<KeyPoint> + an N x 32 descriptor matrix on the host (GSLAM/core/Map.h:
+ * 309-321).  A ring of `depth` slots of up to `chunk_frames` frames each; per submit ONE flat host-to-device DMA, the
+ * extraction, and a pack kernel that writes per-frame offsets + only the valid records straight into pinned host memory --
+ * on three HIP streams chained by events, so the copies of neighbouring chunks run under the kernels of this one.  No
+ * torch, no Python: this is the entry a C++ host uses.  Frame layout is fixed per stream: `channels` interleaved u8
+ * (1 gray, 3 BGR, 4 BGRA: luma as gh_bgr_to_gray_dev), rows row_stride bytes apart, frames frame_stride bytes apart.
+ *   gh_orb_stream_staging  pinned staging block (chunk_frames x frame_stride bytes) of the slot the NEXT submit uses: a
+ *                          producer that decodes / captures straight into it saves the host copy (submit with NULL).
+ *   gh_orb_stream_submit   frames_host = NULL (the staging block) or the caller's own buffer (pinned: DMA in place;
+ *                          pageable: the runtime stages it and the call returns when that is done).  Returns at once
+ *                          otherwise; blocks only while the slot's previous ticket (ticket - depth) is still running.
+ *                          The results of ticket t are overwritten by ticket t + depth: collect before that.
+ *   gh_orb_stream_collect  waits for the ticket; *out points into the slot's pinned result block (valid until the slot
+ *                          is reused): frame f owns records offsets[f] .. offsets[f + 1] - 1 of kps / desc.
+ *                          Thread-safe against a concurrent submit (producer / consumer threads).
+ *   gh_orb_stream_poll     *ready = 1 when collect would not block. */
+typedef struct gh_orb_stream gh_orb_stream;
+typedef struct gh_orb_stream_result {
+  int32_t n_frames;
+  const int32_t* offsets;   /* n_frames + 1 */
+  const gh_keypoint* kps;   /* offsets[n_frames] records, frame after frame */
+  const uint8_t* desc;      /* offsets[n_frames] x 32 B */
+  float gpu_ms;             /* first byte on the link -> last result byte in host memory, for this ticket */
+} gh_orb_stream_result;
+gh_status gh_orb_stream_create(gh_ctx* ctx, int width, int height, int channels, int row_stride, size_t frame_stride,
+                               int chunk_frames, int depth, const gh_orb_params* params, gh_orb_stream** out);
+void gh_orb_stream_destroy(gh_orb_stream* stream);
+gh_status gh_orb_stream_staging(gh_orb_stream* stream, uint8_t** host_pinned);
+gh_status gh_orb_stream_submit(gh_orb_stream* stream, const uint8_t* frames_host, int n_frames, int64_t* ticket);
+gh_status gh_orb_stream_poll(gh_orb_stream* stream, int64_t ticket, int* ready);
+gh_status gh_orb_stream_collect(gh_orb_stream* stream, int64_t ticket, gh_orb_stream_result* out);
+/* Pinned (page-locked, DMA-able) host memory for callers without HIP headers. */
+gh_status gh_host_alloc_pinned(gh_ctx* ctx, size_t bytes, void** out_host);
+gh_status gh_host_free_pinned(gh_ctx* ctx, void* host);
+
 /* Test-only branch census.  enable != 0 makes the following extractions of this plan count how often the rarely taken
  * paths run; out16 (may be NULL) receives and clears the 16 counters accumulated so far:
  *   [0] cells processed  [1] cells with > 64 scored pixels (list branch)  [2] cells that wrote overflow entries (8th..)
