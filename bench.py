@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 legs (10k cams / 1M points LM, n = 60000 dense solve)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-range", action="store_true", help="skip the 640x480 / 3840x2160 extraction legs")
     ap.add_argument("--no-all-pairs-full", action="store_true", help="skip the 499 500-frame-pair all-pairs matching leg")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: exchange through torch.distributed instead of the C-ABI communicator (gh_comm_*)")
@@ -424,7 +425,7 @@ def main():
     if world > 1:
         # the CPU baseline is reported at N = 1 only (contract), and the single-GPU side legs (BA, BoW) add nothing
         # to a scaling line: the other ranks have already left
-        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = a.no_c5 = a.no_host_fed = a.no_all_pairs_full = True
+        a.no_cpu_baseline = a.no_ba = a.no_bow = a.no_c3 = a.no_c5 = a.no_host_fed = a.no_all_pairs_full = a.no_range = True
 
     # ---- C3 (KITTI-like stereo 1241x376 x 2): extract both eyes, row-band left-right match, temporal match
     def _leg_c3():
@@ -475,7 +476,7 @@ def main():
     CHOL = ("ba_potrf_flow", "ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel", "ba_syrk_trailing", "ba_trsv_fwd", "ba_trsv_bwd",
             "ba_chol_fused")
 
-    def ba_leg(cams, points, iters, separate_timed_run):
+    def ba_leg(cams, points, iters, separate_timed_run, prof_iters=None):
         from gslam_amd import ba
         from gslam_amd.ba_synth import make_graph
         name = "C5" if cams >= 10000 else "C4"
@@ -488,7 +489,7 @@ def main():
             log(f"BA leg {name}: timed solve")
             _, _, s, _ = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
         ctx.prof_enable(True)
-        _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
+        _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=prof_iters or iters))
         bprof = ctx.prof_collect()
         ctx.prof_enable(False)
         s = s or sp
@@ -540,7 +541,7 @@ def main():
         log("ba leg failed: %r" % (exc,))
     try:
         if not a.no_ba and not a.no_c5 and a.ba_cams < 10000:
-            extra["ba_c5"] = ba_leg(10000, 1000000, 3, False)
+            extra["ba_c5"] = ba_leg(10000, 1000000, 5, True, prof_iters=2)
             torch.cuda.empty_cache()
             log("dense solve check n = 60000")
             extra["ba_c5"]["dense_solve_check"] = dense_solve_check(60000)
@@ -552,41 +553,134 @@ def main():
     # ---- PCIe-inclusive rate (SURVEY.md 8d defines the metric with H2D / D2H unless stated device-resident; `value` is
     #      device-resident by contract, this is the same extraction fed from pinned host memory, double-buffered)
     def _leg_host_fed():
-        Fh, CH = min(F, 200), 50
-        host = torch.empty((Fh, H, W), dtype=torch.uint8).pin_memory()
-        host.copy_(frames[:Fh, :, :W])
-        torch.cuda.synchronize()
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        ctxs = [hip.Context(local_rank, stream=st.cuda_stream) for st in streams]
-        exs = [OrbExtractor(c, W, H, max_batch=CH, n_features=K) for c in ctxs]
-        bufs = [torch.empty((CH, H, W), dtype=torch.uint8, device=dev) for _ in streams]
-        outs = [e.alloc_outputs(CH, dev) for e in exs]
-        out_host = [torch.empty((Fh,) + tuple(t.shape[1:]), dtype=t.dtype).pin_memory() for t in outs[0]]
-
-        def run():
-            for i, c0 in enumerate(range(0, Fh, CH)):
-                k = i & 1
-                with torch.cuda.stream(streams[k]):
-                    bufs[k].copy_(host[c0:c0 + CH], non_blocking=True)
-                    exs[k].extract(bufs[k], outs[k])
-                    for hh, dd in zip(out_host, outs[k]):
-                        hh[c0:c0 + CH].copy_(dd, non_blocking=True)
+        """gh_orb_stream_* (C ABI, no torch): a ring of pinned slots, three HIP streams (H2D DMA / extraction / pack kernel
+        writing exact-size results into pinned host memory).  Frames start in pinned HOST memory, results end there."""
+        import ctypes as C
+        from gslam_amd.orb import OrbStream
+        Fh, CH, depth = min(F, 400), 25, 3
+        hp = C.c_void_p()
+        ctx.check(hip.lib.gh_host_alloc_pinned(ctx.h, C.c_size_t(Fh * W * H), C.byref(hp)))
+        try:
+            src = frames[:Fh, :, :W].contiguous()
             torch.cuda.synchronize()
+            ctx.check(hip.lib.gh_dev_download(ctx.h, hp, C.c_void_p(src.data_ptr()), C.c_size_t(Fh * W * H)))
+            del src
+            host = np.frombuffer((C.c_uint8 * (Fh * W * H)).from_address(hp.value), np.uint8).reshape(Fh, W * H)
+            st = OrbStream(ctx, W, H, CH, depth, n_features=K)
 
-        run()
-        t1 = time.perf_counter()
-        for _ in range(3):
+            def run():
+                tickets, total = [], 0
+                for c0 in range(0, Fh - CH + 1, CH):
+                    tickets.append(st.submit(host[c0:c0 + CH]))
+                    if len(tickets) >= depth:
+                        total += int(st.collect(tickets.pop(0), copy=False)[0][-1])
+                for t in tickets:
+                    total += int(st.collect(t, copy=False)[0][-1])
+                return total
+
             run()
-        dt = (time.perf_counter() - t1) / 3
-        kp = int(out_host[2].sum())
-        extra["host_fed"] = {"what": "same extraction, frames in pinned host memory -> H2D -> extract -> D2H of keypoints, "
-                                     "descriptors, counts; two streams, chunks of %d frames" % CH,
-                             "frames": Fh, "Mkeypoints_per_s": round(kp / dt / 1e6, 2),
-                             "h2d_GB_per_s": round(Fh * W * H / dt / 1e9, 1), "ms": round(dt * 1e3, 2)}
-        for e in exs:
-            e.close()
-        for c in ctxs:
-            c.close()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                kp = run()
+            dt = (time.perf_counter() - t1) / 3
+            nf = (Fh // CH) * CH
+            extra["host_fed"] = {"what": "gh_orb_stream_* (C ABI): frames in pinned host memory -> one H2D DMA per chunk -> "
+                                         "extraction -> pack kernel writes offsets + only the valid records into pinned "
+                                         "host memory; 3 HIP streams, ring of %d slots x %d frames" % (depth, CH),
+                                 "frames": nf, "Mkeypoints_per_s": round(kp / dt / 1e6, 2),
+                                 "h2d_GB_per_s": round(nf * W * H / dt / 1e9, 1), "ms": round(dt * 1e3, 2),
+                                 "us_per_frame": round(dt / nf * 1e6, 1),
+                                 "link_probe": "profiles/pcie_probe_r03.txt: 57 GB/s H2D, 57 GB/s D2H, 48 GB/s each way at once"}
+            st.close()
+        finally:
+            hip.lib.gh_host_free_pinned(ctx.h, hp)
+
+    # ---- latency of the deployed per-frame path (GSLAM/plugins/play/main.cpp:99-155 hands frames over one at a time;
+    #      evaluation/metric_time/main.cpp:4-34 measures exactly this).  (a) C ABI: one frame through gh_orb_stream
+    #      (chunk 1, nothing else in flight), host clock around submit + collect; (b) through the GSLAM plugins in a C++
+    #      host process (build/plugin_host lat): detectAndCompute + match + optimizePnP per frame, p50 / p99.
+    def _leg_latency():
+        import subprocess
+        from gslam_amd.orb import OrbStream
+        lat = {}
+        for (w, h, k, tag) in ((640, 480, 1000, "c1_640x480_k1000"), (W, H, K, "c2_%dx%d_k%d" % (W, H, K))):
+            fr = frames[0, :h, :w].contiguous().cpu().numpy().reshape(-1) if (w <= W and h <= H) else None
+            if fr is None:
+                continue
+            st = OrbStream(ctx, w, h, 1, 1, n_features=k)
+            buf = st.staging()
+            host_ms, gpu_ms = [], []
+            for i in range(260):
+                t1 = time.perf_counter()
+                buf[0, : w * h] = fr
+                off, _, _, g = st.collect(st.submit(None, 1), copy=False)
+                host_ms.append((time.perf_counter() - t1) * 1e3)
+                gpu_ms.append(g)
+            n_kp = int(off[-1])  # (off is a view of the stream's pinned block: read it before the stream goes away)
+            st.close()
+            host_ms, gpu_ms = np.sort(host_ms[60:]), np.sort(gpu_ms[60:])
+            lat[tag] = {"extract_host_p50_ms": round(float(host_ms[len(host_ms) // 2]), 3),
+                        "extract_host_p99_ms": round(float(host_ms[int(len(host_ms) * 0.99)]), 3),
+                        "extract_link_to_link_p50_ms": round(float(gpu_ms[len(gpu_ms) // 2]), 3),
+                        "keypoints": n_kp,
+                        "what": "gh_orb_stream chunk 1: memcpy into pinned staging + H2D + extraction + packed D2H"}
+        hostbin = os.path.join(ROOT, "build", "plugin_host")
+        libdir = os.path.join(ROOT, "gslam_amd", "lib")
+        if os.path.exists(hostbin) and os.path.exists(os.path.join(libdir, "libgslam_featuredetector.so")):
+            env = dict(os.environ)
+            env["LD_LIBRARY_PATH"] = libdir + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+            for (w, h, k, tag) in ((640, 480, 1000, "c1_640x480_k1000"), (W, H, K, "c2_%dx%d_k%d" % (W, H, K))):
+                if w > W or h > H:
+                    continue
+                raw = os.path.join("/tmp", "gslam_bench_lat_%d.raw" % os.getpid())
+                frames[:8, :h, :w].contiguous().cpu().numpy().tofile(raw)
+                try:
+                    r = subprocess.run([hostbin, "lat", libdir, str(w), str(h), "8", raw, str(k), "200"], capture_output=True,
+                                       text=True, timeout=300, env=env)
+                    kv = dict(tok.split("=", 1) for ln in r.stdout.splitlines() if ln.startswith("lat ")
+                              for tok in ln.split()[1:])
+                    if r.returncode == 0 and kv:
+                        lat.setdefault(tag, {})["plugins"] = {
+                            "what": "C++ GSLAM host (build/plugin_host): FeatureDetector::detectAndCompute + match against the "
+                                    "previous frame + Optimizer::optimizePnP (300 points) per frame, 200 frames",
+                            **{kk: round(float(kv[kk]), 3) for kk in kv if kk.endswith("_ms")},
+                            "async_submit_collect_frames_per_s": round(float(kv.get("async_frames_per_s", 0.0)), 1)}
+                    else:
+                        lat.setdefault(tag, {})["plugins"] = {"error": (r.stdout + r.stderr)[-300:]}
+                finally:
+                    if os.path.exists(raw):
+                        os.remove(raw)
+        else:
+            lat["plugins"] = "build/plugin_host missing (built only where the GSLAM headers are)"
+        extra["latency"] = lat
+
+    # ---- the ends of north_star's frame range (SURVEY.md 8d byte figures): 640x480 K=1000 (5.44 MB / frame) and
+    #      3840x2160 K=2000 / K=8000 (121.5 MB / frame at K=2000), frames resident in HBM, extraction only
+    def _leg_range():
+        out = {}
+        for (w, h, k, nfr) in ((640, 480, 1000, 2000), (3840, 2160, 2000, 100), (3840, 2160, 8000, 100)):
+            exr = OrbExtractor(ctx, w, h, max_batch=nfr, n_features=k)
+            fr = synth_frames(ctx, nfr, w, h, base_seed=0x5EED0000, device=dev)
+            o = exr.alloc_outputs(nfr, dev)
+            exr.extract(fr, o)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                exr.extract(fr, o)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            kp = int(o[2].sum().item())
+            bpf = orb_bytes_per_frame(w, h, k)
+            out["%dx%d_k%d" % (w, h, k)] = {"frames": nfr, "Mkeypoints_per_s": round(kp / dt / 1e6, 2),
+                                            "frames_per_s": round(nfr / dt, 1), "us_per_frame": round(dt / nfr * 1e6, 2),
+                                            "algorithmic_MB_per_frame": round(bpf / 1e6, 2),
+                                            "achieved_GB_per_s": round(bpf * nfr / dt / 1e9, 1),
+                                            "hbm_frac": round(bpf * nfr / dt / HBM_PEAK, 4), "keypoints_per_frame": kp // nfr}
+            exr.close()
+            del fr, o
+            torch.cuda.empty_cache()
+        extra["orb_range"] = out
 
     try:
         if not a.no_host_fed:
@@ -594,6 +688,14 @@ def main():
     except Exception as exc:  # noqa: BLE001
         extra.setdefault("errors", {})["host_fed"] = repr(exc)
         log("host-fed leg failed: %r" % (exc,))
+    for leg_name, leg_fn, skip in (("latency", _leg_latency, a.no_host_fed), ("orb_range", _leg_range, a.no_range)):
+        try:
+            if not skip:
+                log("leg %s" % leg_name)
+                leg_fn()
+        except Exception as exc:  # noqa: BLE001
+            extra.setdefault("errors", {})[leg_name] = repr(exc)
+            log("%s leg failed: %r" % (leg_name, exc))
 
     # ---- BoW transform: the extracted descriptors of this step through GSLAM::Vocabulary-style
     #      k=10 trees (L=4 / L=6, the two sizes the reference publishes: 615.5 / 723.7 us per image on an i7-6700)
@@ -729,7 +831,14 @@ def main():
                    "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of descriptors + matches via {comm_note}"
                    if world > 1 else "single GPU",
                    "device": info["name"], "cu_count": info["cu_count"]},
-        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        "roofline": roofline, "cpu_baseline": cpu,
+        # BASELINE.json's metric names three rates: the other two at top level as well (details under extra)
+        "bf_match_all_pairs_Gpairs_per_s": (bf.get("all_pairs_full") or bf.get("all_pairs") or {}).get("Gpairs_per_s"),
+        "bf_match_consecutive_Gpairs_per_s": bf.get("Gpairs_per_s"),
+        "ba_c4_lm_iters_per_s": (extra.get("ba") or {}).get("iters_per_s"),
+        "ba_c5_lm_iters_per_s": (extra.get("ba_c5") or {}).get("iters_per_s"),
+        "host_fed_Mkeypoints_per_s": (extra.get("host_fed") or {}).get("Mkeypoints_per_s"),
+        "extra": extra,
     }
     print(json.dumps(line))
     if comm is not None:

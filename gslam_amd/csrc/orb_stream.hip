@@ -134,8 +134,16 @@ extern "C" gh_status gh_orb_stream_create(gh_ctx* ctx, int width, int height, in
   s->off_desc = s->off_kps + ((C * K * sizeof(gh_keypoint) + 255) & ~(size_t)255);
   s->out_bytes = s->off_desc + C * K * 32;
   s->slots.resize((size_t)depth);
-  bool ok = hipStreamCreateWithFlags(&s->s_h2d, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking) == hipSuccess;
+  // The two copy streams are HIGH priority: the runtime multiplexes the streams of a process onto a few hardware queues
+  // (4 by default) PER PRIORITY LEVEL, and two streams that land on one queue execute in submission order -- in a process
+  // that already owns several streams (measured inside bench.py: torch + the other legs) the upload of chunk i + 1 then
+  // queued behind the kernels of chunk i and the pipeline ran at copy + compute (32 GB/s) instead of max(copy, compute)
+  // (52 GB/s).  A priority of their own gives the copies queues of their own, and it is also the right order: a late
+  // copy stalls the whole ring, a late kernel does not.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  bool ok = hipStreamCreateWithPriority(&s->s_h2d, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&s->s_d2h, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   for (Slot& sl : s->slots) {
     if (!ok) break;
     ok = hipHostMalloc((void**)&sl.h_in, C * frame_stride, hipHostMallocDefault) == hipSuccess &&

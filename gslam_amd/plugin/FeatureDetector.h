@@ -55,6 +55,24 @@ class FeatureDetector {
     return false;
   }
 
+  // A burst of same-sized images in one call (keyframe burst, stereo pair, offline sequence): the base class loops over
+  // detectAndCompute, an accelerated plugin pipelines uploads, extraction and downloads.
+  virtual bool detectAndComputeBatch(const std::vector<GImage>& images, std::vector<std::vector<KeyPoint> >& keypoints,
+                                     std::vector<GImage>& descriptors) {
+    keypoints.resize(images.size());
+    descriptors.resize(images.size());
+    for (size_t i = 0; i < images.size(); ++i)
+      if (!detectAndCompute(images[i], keypoints[i], descriptors[i])) return false;
+    return true;
+  }
+  // Asynchronous pair for a caller that receives frames one at a time (GSLAM/plugins/play/main.cpp:99-155 publishes a
+  // FramePtr per frame): submit() returns a ticket at once (< 0: unsupported / failed) while the image is still on its
+  // way to the device, collect() blocks until that frame's records are on the host.  At most asyncDepth() tickets may be
+  // outstanding; tickets are collected in any order.
+  virtual long submit(const GImage& image) { return -1; }
+  virtual bool collect(long ticket, std::vector<KeyPoint>& keypoints, GImage& descriptors) { return false; }
+  virtual int asyncDepth() const { return 0; }
+
   static std::shared_ptr<FeatureDetector> create(std::string pluginName = "") {
     if (pluginName.empty()) pluginName = svar.GetString("FeatureDetectorPlugin", "libgslam_featuredetector");
     std::shared_ptr<SharedLibrary> plugin = Registry::get(pluginName);

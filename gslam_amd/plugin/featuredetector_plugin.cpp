@@ -4,6 +4,7 @@
 // identical to gh_keypoint) and an N x 32 8UC1 GImage (MapFrame::setKeyPoints, Map.h:311-312).
 #include "FeatureDetector.h"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -18,6 +19,8 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
  public:
   FeatureDetectorHIP() : ctx_(nullptr), plan_(nullptr), pw_(0), ph_(0), pk_(0), pl_(0), pi_(0), pm_(0) {}
   ~FeatureDetectorHIP() override {
+    if (batch_.s) gh_orb_stream_destroy(batch_.s);
+    if (async_.s) gh_orb_stream_destroy(async_.s);
     if (plan_) gh_orb_plan_destroy(plan_);
     free_device_buffers();
     if (ctx_) gh_ctx_destroy(ctx_);
@@ -87,6 +90,75 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
     return true;
   }
 
+  // ---- batch + asynchronous entries: gh_orb_stream_* (pinned ring, three HIP streams, exact-size results) -----------
+  bool detectAndComputeBatch(const std::vector<GSLAM::GImage>& images, std::vector<std::vector<GSLAM::KeyPoint> >& keypoints,
+                             std::vector<GSLAM::GImage>& descriptors) override {
+    std::lock_guard<std::mutex> lock(mu_);
+    const size_t n = images.size();
+    keypoints.assign(n, std::vector<GSLAM::KeyPoint>());
+    descriptors.assign(n, GSLAM::GImage());
+    if (n == 0) return true;
+    if (!context()) return false;
+    for (size_t i = 0; i < n; ++i)
+      if (images[i].empty() || images[i].elemSize1() != 1 || images[i].cols != images[0].cols || images[i].rows != images[0].rows ||
+          images[i].channels() != images[0].channels())
+        return false;  // a burst is same-sized by contract
+    const int chunk = (int)std::min<size_t>(n, (size_t)svar.GetInt("FeatureDetectorHIP.BatchChunk", 16));
+    if (!ensure_stream(batch_, images[0], chunk, 3)) return false;
+    const size_t fbytes = batch_.frame_bytes;
+    std::vector<std::pair<int64_t, size_t> > inflight;  // (ticket, first image)
+    auto drain_one = [&]() -> bool {
+      gh_orb_stream_result r;
+      if (gh_orb_stream_collect(batch_.s, inflight.front().first, &r) != GH_OK) return fail("gh_orb_stream_collect");
+      const size_t base = inflight.front().second;
+      inflight.erase(inflight.begin());
+      for (int f = 0; f < r.n_frames; ++f) unpack(r, f, keypoints[base + f], descriptors[base + f]);
+      return true;
+    };
+    for (size_t i0 = 0; i0 < n; i0 += (size_t)chunk) {
+      if (inflight.size() == 3 && !drain_one()) return false;
+      const int m = (int)std::min<size_t>((size_t)chunk, n - i0);
+      uint8_t* stage = nullptr;
+      if (gh_orb_stream_staging(batch_.s, &stage) != GH_OK) return fail("gh_orb_stream_staging");
+      for (int f = 0; f < m; ++f) std::memcpy(stage + (size_t)f * fbytes, images[i0 + f].data, fbytes);
+      int64_t t = -1;
+      if (gh_orb_stream_submit(batch_.s, nullptr, m, &t) != GH_OK) return fail("gh_orb_stream_submit");
+      inflight.push_back(std::make_pair(t, i0));
+    }
+    while (!inflight.empty())
+      if (!drain_one()) return false;
+    return true;
+  }
+
+  long submit(const GSLAM::GImage& image) override {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (image.empty() || image.elemSize1() != 1 || !context()) return -1;
+    if (!ensure_stream(async_, image, 1, kAsyncDepth)) return -1;
+    int64_t t = -1;
+    // the image is read by the DMA (pinned memory) or staged by the runtime (pageable) before submit returns control of
+    // it only in the second case, so copy it into the slot's pinned block: the caller may free the GImage at once
+    uint8_t* stage = nullptr;
+    if (gh_orb_stream_staging(async_.s, &stage) != GH_OK) { fail("gh_orb_stream_staging"); return -1; }
+    std::memcpy(stage, image.data, async_.frame_bytes);
+    if (gh_orb_stream_submit(async_.s, nullptr, 1, &t) != GH_OK) { fail("gh_orb_stream_submit"); return -1; }
+    return (long)t;
+  }
+
+  bool collect(long ticket, std::vector<GSLAM::KeyPoint>& keypoints, GSLAM::GImage& descriptors) override {
+    gh_orb_stream* s;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      s = async_.s;
+    }
+    if (!s) return false;
+    gh_orb_stream_result r;
+    if (gh_orb_stream_collect(s, (int64_t)ticket, &r) != GH_OK) return fail("gh_orb_stream_collect");  // blocks WITHOUT mu_
+    unpack(r, 0, keypoints, descriptors);
+    return true;
+  }
+
+  int asyncDepth() const override { return kAsyncDepth; }
+
   bool match(const GSLAM::GImage& q, const GSLAM::GImage& t, std::vector<std::pair<int, int> >& matches,
              std::vector<uchar>* mask = NULL) override {
     std::lock_guard<std::mutex> lock(mu_);
@@ -119,6 +191,42 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
   }
 
  private:
+  enum { kAsyncDepth = 8 };
+  struct StreamSlot {
+    gh_orb_stream* s = nullptr;
+    int w = 0, h = 0, ch = 0, chunk = 0, k = 0, l = 0, ini = 0, mn = 0;
+    size_t frame_bytes = 0;
+  };
+  StreamSlot batch_, async_;
+  bool ensure_stream(StreamSlot& ss, const GSLAM::GImage& img, int chunk, int depth) {
+    const int w = img.cols, h = img.rows, ch = img.channels();
+    if (ch != 1 && ch != 3 && ch != 4) return false;
+    if (ss.s && ss.w == w && ss.h == h && ss.ch == ch && ss.chunk >= chunk && ss.k == _config.nFeatures && ss.l == _config.nLevels &&
+        ss.ini == _config.iniThFAST && ss.mn == _config.minThFAST)
+      return true;
+    if (ss.s) gh_orb_stream_destroy(ss.s);
+    ss.s = nullptr;
+    gh_orb_params p;
+    gh_orb_default_params(&p);
+    p.n_features = _config.nFeatures;
+    p.n_levels = _config.nLevels;
+    p.ini_th_fast = _config.iniThFAST;
+    p.min_th_fast = _config.minThFAST;
+    const size_t fbytes = (size_t)w * h * ch;
+    if (gh_orb_stream_create(ctx_, w, h, ch, w * ch, fbytes, chunk, depth, &p, &ss.s) != GH_OK) {
+      ss.s = nullptr;
+      return fail("gh_orb_stream_create");
+    }
+    ss.w = w; ss.h = h; ss.ch = ch; ss.chunk = chunk; ss.k = p.n_features; ss.l = p.n_levels; ss.ini = p.ini_th_fast; ss.mn = p.min_th_fast;
+    ss.frame_bytes = fbytes;
+    return true;
+  }
+  static void unpack(const gh_orb_stream_result& r, int f, std::vector<GSLAM::KeyPoint>& kps, GSLAM::GImage& desc) {
+    const int o = r.offsets[f], n = r.offsets[f + 1] - o;
+    kps.resize((size_t)n);
+    if (n > 0) std::memcpy((void*)kps.data(), r.kps + o, (size_t)n * sizeof(gh_keypoint));
+    desc = GSLAM::GImage(n, 32, GSLAM::GImageType<uchar>::Type, const_cast<uchar*>(r.desc) + (size_t)o * 32, true);
+  }
   void free_device_buffers() {
     if (ctx_) {
       if (d_bgr_) gh_dev_free(ctx_, d_bgr_);

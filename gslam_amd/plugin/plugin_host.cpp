@@ -7,6 +7,10 @@
 //   plugin_host ba   <plugin_dir> <graph.bin> <out.bin>
 //   plugin_host pnp  <plugin_dir> <pnp.bin> <out.bin>
 //   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
+//   plugin_host orbbatch <plugin_dir> <w> <h> <channels> <n> <frames.raw> <out.bin> <K>   (detectAndComputeBatch and the
+//                    asynchronous submit / collect pair against per-frame detectAndCompute, all three written out)
+//   plugin_host lat  <plugin_dir> <w> <h> <n> <frames.raw> <K> <iterations>   (single-frame latency of
+//                    detectAndCompute, match, optimizePnP through the plugins: p50 / p99; async frames per second)
 //   plugin_host bow  <plugin_dir> <vocab.gbow> <desc.raw> <n> <levelsup> <out.bin>
 //   plugin_host undist <plugin_dir> <channels> <image.raw>     (fixed OpenCV-model camera 320x240 -> pinhole)
 //   plugin_host est  <plugin_dir> <model 0|1|2> <n> <pts.raw (n x 4 doubles: src xy, dst xy)> <thr> <out.bin>
@@ -15,6 +19,7 @@
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <mutex>
@@ -179,6 +184,143 @@ static int run_orb(const std::string& dir, int w, int h, int ch, const char* in,
   std::cout << "detectAndCompute=" << ok << " keypoints=" << kps.size() << " match=" << okm << " matches="
             << matches.size() << " desc=" << desc.rows << "x" << desc.cols << std::endl;
   return ok && okm ? 0 : 3;
+}
+
+static int gimage_type(int ch) {
+  return ch == 1 ? GImageType<uchar, 1>::Type : (ch == 3 ? GImageType<uchar, 3>::Type : GImageType<uchar, 4>::Type);
+}
+
+static void write_frame_records(std::ofstream& o, const std::vector<std::vector<KeyPoint> >& kps, const std::vector<GImage>& desc) {
+  for (size_t i = 0; i < kps.size(); ++i) {
+    int32_t n = (int32_t)kps[i].size();
+    o.write((char*)&n, 4);
+    if (n) {
+      o.write((char*)kps[i].data(), (size_t)n * sizeof(KeyPoint));
+      o.write((char*)desc[i].data, (size_t)n * 32);
+    }
+  }
+}
+
+// Batch and asynchronous entries of the FeatureDetector interface: three result sets (per-frame, batch, async) for the
+// same frames; the test compares each with the oracle.
+static int run_orb_batch(const std::string& dir, int w, int h, int ch, int n, const char* in, const char* out, int K) {
+  svar.GetString("FeatureDetectorPlugin", "") = dir + "/libgslam_featuredetector.so";
+  svar.GetInt("FeatureDetectorHIP.BatchChunk", 16) = 5;  // several chunks + a partial one for small n
+  std::vector<uchar> raw((size_t)w * h * ch * n);
+  std::ifstream f(in, std::ios::binary);
+  f.read((char*)raw.data(), raw.size());
+  FeatureDetectorPtr det = FeatureDetector::create();
+  if (!det) { std::cerr << "FeatureDetector::create() returned null\n"; return 2; }
+  det->_config.nFeatures = K;
+  std::vector<GImage> images;
+  for (int i = 0; i < n; ++i) images.push_back(GImage(h, w, gimage_type(ch), raw.data() + (size_t)i * w * h * ch, false));
+  std::vector<std::vector<KeyPoint> > k1(n), k2, k3(n);
+  std::vector<GImage> d1(n), d2, d3(n);
+  bool ok = true;
+  for (int i = 0; i < n; ++i) ok = ok && det->detectAndCompute(images[i], k1[i], d1[i]);
+  const bool okb = det->detectAndComputeBatch(images, k2, d2);
+  // async: keep asyncDepth() tickets in flight, collect the oldest
+  bool oka = det->asyncDepth() > 0;
+  std::vector<long> tickets;
+  size_t done = 0;
+  for (int i = 0; i < n && oka; ++i) {
+    if ((int)(tickets.size() - done) == det->asyncDepth()) {
+      oka = det->collect(tickets[done], k3[done], d3[done]);
+      ++done;
+    }
+    const long t = det->submit(images[i]);
+    oka = oka && t >= 0;
+    tickets.push_back(t);
+  }
+  for (; done < tickets.size() && oka; ++done) oka = det->collect(tickets[done], k3[done], d3[done]);
+  std::ofstream o(out, std::ios::binary);
+  int32_t hdr[4] = {ok ? 1 : 0, okb ? 1 : 0, oka ? 1 : 0, n};
+  o.write((char*)hdr, sizeof(hdr));
+  write_frame_records(o, k1, d1);
+  if (okb) write_frame_records(o, k2, d2);
+  if (oka) write_frame_records(o, k3, d3);
+  std::cout << "orbbatch single=" << ok << " batch=" << okb << " async=" << oka << " depth=" << det->asyncDepth() << std::endl;
+  return ok && okb && oka ? 0 : 3;
+}
+
+static void pct(std::vector<double>& v, double* p50, double* p99) {
+  std::sort(v.begin(), v.end());
+  *p50 = v[v.size() / 2];
+  *p99 = v[std::min(v.size() - 1, (size_t)(v.size() * 0.99))];
+}
+
+// What one tracking step costs a GSLAM application that calls the plugins frame by frame: detectAndCompute on the new
+// frame, match against the previous one, optimizePnP on 3D-2D correspondences (GSLAM/plugins/play/main.cpp:99-155 feeds
+// frames one at a time; evaluation/metric_time/main.cpp:4-34 measures exactly this per-frame time).
+static int run_lat(const std::string& dir, int w, int h, int n, const char* in, int K, int iters) {
+  svar.GetString("FeatureDetectorPlugin", "") = dir + "/libgslam_featuredetector.so";
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::vector<uchar> raw((size_t)w * h * n);
+  std::ifstream f(in, std::ios::binary);
+  f.read((char*)raw.data(), raw.size());
+  FeatureDetectorPtr det = FeatureDetector::create();
+  OptimizerPtr opt = Optimizer::create();
+  if (!det || !opt) { std::cerr << "plugin create() returned null\n"; return 2; }
+  det->_config.nFeatures = K;
+  // a PnP problem of the size tracking sees: 300 points in front of the camera, exact projections, perturbed start
+  std::vector<std::pair<Point3d, CameraAnchor> > m3d;
+  unsigned long long rs = 88172645463325252ull;
+  auto rnd = [&rs]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (double)(rs >> 11) / 9007199254740992.0; };
+  const SE3 truth(SO3::exp(Point3d(0.02, -0.03, 0.01)), Point3d(0.1, -0.05, 0.2));
+  for (int k = 0; k < 300; ++k) {
+    const Point3d X(4 * rnd() - 2, 3 * rnd() - 1.5, 4 + 4 * rnd());
+    const Point3d c = truth.inverse() * X;
+    m3d.push_back(std::make_pair(X, Point3d(c.x / c.z, c.y / c.z, 1.0)));
+  }
+  std::vector<double> t_det, t_match, t_pnp, t_all;
+  std::vector<KeyPoint> kps, prev_kps;
+  GImage desc, prev_desc;
+  typedef std::chrono::steady_clock clk;
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  bool ok = true;
+  for (int it = 0; it < iters + 20 && ok; ++it) {
+    GImage img(h, w, GImageType<uchar, 1>::Type, raw.data() + (size_t)(it % n) * w * h, false);
+    const clk::time_point t0 = clk::now();
+    ok = det->detectAndCompute(img, kps, desc);
+    const clk::time_point t1 = clk::now();
+    std::vector<std::pair<int, int> > matches;
+    if (ok && !prev_desc.empty()) ok = det->match(desc, prev_desc, matches);
+    const clk::time_point t2 = clk::now();
+    SE3 pose;
+    ok = ok && opt->optimizePnP(m3d, pose);
+    const clk::time_point t3 = clk::now();
+    if (it >= 20) {
+      t_det.push_back(ms(t0, t1));
+      t_match.push_back(ms(t1, t2));
+      t_pnp.push_back(ms(t2, t3));
+      t_all.push_back(ms(t0, t3));
+    }
+    prev_desc = desc;
+  }
+  if (!ok) { std::cerr << "a plugin call failed\n"; return 3; }
+  // asynchronous throughput: asyncDepth() frames in flight, frame by frame
+  double async_fps = 0;
+  if (det->asyncDepth() > 0) {
+    std::vector<long> tickets;
+    size_t done = 0;
+    const int total = iters;
+    const clk::time_point a0 = clk::now();
+    for (int it = 0; it < total; ++it) {
+      GImage img(h, w, GImageType<uchar, 1>::Type, raw.data() + (size_t)(it % n) * w * h, false);
+      if ((int)(tickets.size() - done) == det->asyncDepth()) det->collect(tickets[done++], kps, desc);
+      tickets.push_back(det->submit(img));
+    }
+    for (; done < tickets.size(); ++done) det->collect(tickets[done], kps, desc);
+    async_fps = total / (ms(a0, clk::now()) * 1e-3);
+  }
+  double a, b;
+  std::cout << "lat w=" << w << " h=" << h << " K=" << K << " iters=" << iters << " keypoints=" << kps.size();
+  pct(t_det, &a, &b);   std::cout << " detect_p50_ms=" << a << " detect_p99_ms=" << b;
+  pct(t_match, &a, &b); std::cout << " match_p50_ms=" << a << " match_p99_ms=" << b;
+  pct(t_pnp, &a, &b);   std::cout << " pnp_p50_ms=" << a << " pnp_p99_ms=" << b;
+  pct(t_all, &a, &b);   std::cout << " step_p50_ms=" << a << " step_p99_ms=" << b;
+  std::cout << " async_frames_per_s=" << async_fps << std::endl;
+  return 0;
 }
 
 // Vocabulary: the plugin's subclass against the reference's own base-class transform, in the same process.
@@ -478,6 +620,9 @@ int main(int argc, char** argv) {
     return run_app(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
   if (mode == "undist" && argc >= 5) return run_undist(atoi(argv[3]), argv[4]);
   if (mode == "bow" && argc >= 8) return run_bow(dir, argv[3], argv[4], atoi(argv[5]), atoi(argv[6]), argv[7]);
+  if (mode == "orbbatch" && argc >= 10)
+    return run_orb_batch(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7], argv[8], atoi(argv[9]));
+  if (mode == "lat" && argc >= 9) return run_lat(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], atoi(argv[7]), atoi(argv[8]));
   if (mode == "orb" && argc >= 9)
     return run_orb(dir, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argv[6], argv[7], atoi(argv[8]));
   return 1;

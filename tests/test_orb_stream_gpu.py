@@ -163,3 +163,48 @@ def test_stream_matches_resident_path_at_1080p(ctx, oracle):
             assert np.array_equal(d[off[f]:off[f + 1]], d_np[base + f, :c])
     st.close()
     ex.close()
+
+
+def test_featuredetector_batch_and_async_entries(tmp_path, oracle):
+    """FeatureDetector::detectAndComputeBatch and the asynchronous submit / collect pair (gslam_amd/plugin/FeatureDetector.h)
+    inside a real GSLAM host process: per-frame, batch and async results of the same 13 frames all equal the oracle."""
+    import os
+    import struct
+    import subprocess
+    import oracle_lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host, libdir = os.path.join(root, "build", "plugin_host"), os.path.join(root, "gslam_amd", "lib")
+    if not (os.path.exists(host) and os.path.exists(os.path.join(libdir, "libgslam_featuredetector.so"))):
+        pytest.skip("build/plugin_host or libgslam_featuredetector.so missing (run `make plugins` where the GSLAM headers are)")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = libdir + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for ch in (1, 3):
+        w, h, K, n = 320, 240, 600, 13
+        gray = [oracle.synth_frame(w, h, 300 + i) if i % 3 else CLASSES["noise"](w, h, i) for i in range(n)]
+        if ch == 1:
+            imgs, expect_gray = np.stack(gray), gray
+        else:
+            rng = np.random.default_rng(1)
+            imgs = np.stack([np.stack([g // 2 + rng.integers(0, 100, g.shape, dtype=np.uint8) for _ in range(3)], axis=-1)
+                             for g in gray]).astype(np.uint8)
+            expect_gray = [oracle.bgr_to_gray(im) for im in imgs]
+        inp, out = tmp_path / f"frames{ch}.raw", tmp_path / f"out{ch}.bin"
+        imgs.tofile(inp)
+        r = subprocess.run([host, "orbbatch", libdir, str(w), str(h), str(ch), str(n), str(inp), str(out), str(K)],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        ok, okb, oka, nn = struct.unpack("4i", raw[:16])
+        assert (ok, okb, oka, nn) == (1, 1, 1, n)
+        pos = 16
+        for which in ("single", "batch", "async"):
+            for f in range(n):
+                ek, ed = oracle.orb_extract(expect_gray[f], K)
+                (m,) = struct.unpack("i", raw[pos:pos + 4])
+                pos += 4
+                assert m == len(ek), (which, f, m, len(ek))
+                assert raw[pos:pos + 28 * m] == ek.tobytes(), (which, f)
+                pos += 28 * m
+                assert raw[pos:pos + 32 * m] == ed.tobytes(), (which, f)
+                pos += 32 * m
+        assert pos == len(raw)
