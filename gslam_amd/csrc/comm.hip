@@ -156,6 +156,113 @@ gh_status comm_common_init(gh_ctx* ctx, gh_comm* c) {
   return GH_OK;
 }
 
+constexpr uint32_t kShmMagic = 0x47534C4Du;
+
+ShmSegment* map_segment(int fd) {
+  void* m = mmap(nullptr, sizeof(ShmSegment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  return m == MAP_FAILED ? nullptr : (ShmSegment*)m;
+}
+
+// Rendezvous on the named segment.  The name is chosen by the launcher and may be the name of a segment a crashed run
+// left behind (bench.py derives it from MASTER_PORT), and ranks start in any order, so a rank >= 1 can find the OLD
+// segment before rank 0 has replaced it.  Rules that make this safe:
+//   rank 0   poisons whatever segment exists under the name (magic = 0, failed = 1: ranks parked in it leave), unlinks
+//            it, creates a fresh one (O_EXCL) and publishes the magic last;
+//   rank r   attaches only to a segment that looks unused (magic set, generation 0, nobody failed, fewer than `world`
+//            ranks attached); whenever the segment it sits in turns out to be dead -- poisoned, or replaced under the
+//            name (different inode) -- it lets go and opens the name again, until the overall timeout.
+gh_status ipc_rendezvous(gh_ctx* ctx, gh_comm* c) {
+  const char* name = c->shm_name.c_str();
+  const auto t0 = std::chrono::steady_clock::now();
+  auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s; };
+  if (c->rank == 0) {
+    int old = shm_open(name, O_RDWR, 0600);
+    if (old >= 0) {
+      struct stat sb;
+      if (fstat(old, &sb) == 0 && (size_t)sb.st_size >= sizeof(ShmSegment)) {
+        if (ShmSegment* stale = map_segment(old)) {
+          stale->magic.store(0, std::memory_order_release);
+          stale->failed.store(1, std::memory_order_release);
+          munmap(stale, sizeof(ShmSegment));
+        }
+      }
+      close(old);
+    }
+    shm_unlink(name);
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(ShmSegment)) != 0) {
+      if (fd >= 0) close(fd);
+      return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: cannot create rendezvous segment %s", name);
+    }
+    c->shm = map_segment(fd);
+    close(fd);
+    if (!c->shm) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: mmap of the rendezvous segment failed");
+    c->shm->arrived.store(0);
+    c->shm->generation.store(0);
+    c->shm->attached.store(1);
+    c->shm->failed.store(0);
+    c->shm->magic.store(kShmMagic, std::memory_order_release);
+    c->local_generation = 0;
+    if (!shm_barrier(c)) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rendezvous timed out (%d ranks expected)", c->world);
+    return GH_OK;
+  }
+  while (!expired()) {
+    int fd = shm_open(name, O_RDWR, 0600);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmSegment)) {  // not created / not sized yet
+      if (fd >= 0) close(fd);
+      usleep(1000);
+      continue;
+    }
+    const ino_t ino = sb.st_ino;
+    ShmSegment* seg = map_segment(fd);
+    close(fd);
+    if (!seg) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: mmap of the rendezvous segment failed");
+    // still the segment the name points to?
+    auto replaced = [&] {
+      int f2 = shm_open(name, O_RDWR, 0600);
+      if (f2 < 0) return true;  // unlinked: rank 0 is between unlink and create, or the run is over
+      struct stat s2;
+      const bool differs = fstat(f2, &s2) != 0 || s2.st_ino != ino;
+      close(f2);
+      return differs;
+    };
+    bool usable = false;
+    for (int spin = 0; !expired(); ++spin) {
+      if (seg->magic.load(std::memory_order_acquire) == kShmMagic) {
+        usable = seg->failed.load() == 0 && seg->generation.load() == 0 && seg->attached.load() < c->world;
+        break;  // initialised: usable, or a leftover of an earlier run
+      }
+      if (seg->failed.load() != 0 || ((spin & 63) == 63 && replaced())) break;  // poisoned or superseded
+      usleep(200);
+    }
+    if (usable) {
+      c->shm = seg;
+      c->local_generation = 0;
+      seg->attached.fetch_add(1);
+      if (shm_barrier(c)) return GH_OK;
+      c->shm = nullptr;
+      // the barrier failed: a real peer failure of THIS run, or rank 0 has just poisoned a stale segment we were parked in
+      const bool stale = seg->magic.load(std::memory_order_acquire) != kShmMagic || replaced();
+      munmap(seg, sizeof(ShmSegment));
+      if (!stale) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rendezvous timed out (%d ranks expected)", c->world);
+      continue;
+    }
+    munmap(seg, sizeof(ShmSegment));
+    usleep(2000);  // stale segment: wait for rank 0 to replace it
+  }
+  return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: no live rendezvous segment %s within %.0f s (is rank 0 running?)", name,
+                      c->timeout_s);
+}
+
+void comm_common_free(gh_comm* c) {
+  if (c->ev_ready) hipEventDestroy(c->ev_ready);
+  if (c->ev_done) hipEventDestroy(c->ev_done);
+  if (c->stream) hipStreamDestroy(c->stream);
+  c->ev_ready = c->ev_done = nullptr;
+  c->stream = nullptr;
+}
+
 IpcBuffer* find_ipc_buffer(gh_comm* c, const void* gathered, size_t bytes_per_rank) {
   for (auto& b : c->ipc_buffers)
     if (b.mine == gathered && bytes_per_rank <= b.bytes_per_rank) return &b;
@@ -219,7 +326,11 @@ extern "C" gh_status gh_comm_create_rccl(gh_ctx* ctx, int rank, int world, const
   GH_ENTER(ctx);
   *out = nullptr;
   GH_CHECK_ARG(ctx, world >= 1 && rank >= 0 && rank < world && unique_id);
-  if (!rccl().ok) return gh_set_error(ctx, GH_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+  if (!rccl().ok) {
+    const char* why = dlerror();
+    return gh_set_error(ctx, GH_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded or lacks a required symbol: %s",
+                        why ? why : "(no loader message)");
+  }
   gh_comm* c = new (std::nothrow) gh_comm();
   if (!c) return GH_ERR_NOMEM;
   c->ctx = ctx;
@@ -234,7 +345,7 @@ extern "C" gh_status gh_comm_create_rccl(gh_ctx* ctx, int rank, int world, const
     if (r != ncclSuccess) st = rccl_fail(ctx, "ncclCommInitRank", r);
   }
   if (st != GH_OK) {
-    if (c->stream) hipStreamDestroy(c->stream);
+    comm_common_free(c);
     delete c;
     return st;
   }
@@ -256,64 +367,10 @@ extern "C" gh_status gh_comm_create_ipc(gh_ctx* ctx, int rank, int world, const 
   c->shm_name = std::string(rendezvous_name[0] == '/' ? "" : "/") + rendezvous_name;
   if (const char* t = getenv("GSLAM_HIP_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
   gh_status st = comm_common_init(ctx, c);
-  int fd = -1;
-  if (st == GH_OK) {
-    const auto t0 = std::chrono::steady_clock::now();
-    if (rank == 0) {
-      shm_unlink(c->shm_name.c_str());  // a stale segment of a crashed run
-      fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-      if (fd >= 0 && ftruncate(fd, sizeof(ShmSegment)) != 0) {
-        close(fd);
-        fd = -1;
-      }
-    } else {
-      while (fd < 0) {  // rank 0 may not have created it yet
-        fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
-        struct stat sb;
-        if (fd >= 0 && (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmSegment))) {
-          close(fd);
-          fd = -1;
-        }
-        if (fd < 0) {
-          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) break;
-          usleep(1000);
-        }
-      }
-    }
-    if (fd < 0) st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: cannot open rendezvous segment %s", c->shm_name.c_str());
-  }
-  if (st == GH_OK) {
-    void* m = mmap(nullptr, sizeof(ShmSegment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) {
-      st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: mmap of the rendezvous segment failed");
-    } else {
-      c->shm = (ShmSegment*)m;
-      if (rank == 0) {
-        c->shm->arrived.store(0);
-        c->shm->generation.store(0);
-        c->shm->attached.store(0);
-        c->shm->failed.store(0);
-        c->shm->magic.store(0x47534C4Du, std::memory_order_release);
-      } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (c->shm->magic.load(std::memory_order_acquire) != 0x47534C4Du) {
-          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
-            st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rank 0 never initialised the rendezvous segment");
-            break;
-          }
-          usleep(200);
-        }
-      }
-      if (st == GH_OK) {
-        c->shm->attached.fetch_add(1);
-        if (!shm_barrier(c)) st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rendezvous timed out (%d ranks expected)", world);
-      }
-    }
-  }
+  if (st == GH_OK) st = ipc_rendezvous(ctx, c);
   if (st != GH_OK) {
     if (c->shm) munmap(c->shm, sizeof(ShmSegment));
-    if (c->stream) hipStreamDestroy(c->stream);
+    comm_common_free(c);
     delete c;
     return st;
   }
@@ -406,6 +463,9 @@ extern "C" gh_status gh_comm_buffer(gh_comm* c, size_t bytes_per_rank, void** ga
   if (!ok) c->shm->failed.store(1);
   if (!shm_barrier(c) || !ok) {  // the handle slots may be reused only after everybody has opened them
     if (ok) gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a peer failed while exchanging buffer handles");
+    for (int r = 0; r < c->world; ++r)
+      if (r != c->rank && b.peer[r]) hipIpcCloseMemHandle(b.peer[r]);
+    hipFree(p);
     return GH_ERR_HIP;
   }
   c->ipc_buffers.push_back(b);

@@ -130,3 +130,42 @@ def test_rccl_transport_world_one(tmp_path):
     stream, stream ordering through gh_comm_wait).  N > 1 needs N GPUs: the driver's scaling run."""
     (r0,) = _spawn(1, 3, 500, 640, 376, "rccl", tmp_path)
     assert (r0["g_counts"] > 0).all() and r0["g_desc"].any() and (r0["g_idx"][:2] >= 0).any()
+
+
+def test_ipc_rendezvous_survives_a_stale_segment_and_late_rank0(tmp_path):
+    """a crashed run leaves /dev/shm/<name> behind with its magic set and its barrier generation advanced; a rank
+    >= 1 that starts before rank 0 finds it.  It must neither attach to it (its barriers would fall through) nor give up:
+    rank 0 poisons + replaces the segment and the late rendezvous completes; results equal the clean run."""
+    import struct
+    import time
+    F, K, W, H = 2, 300, 640, 376
+    name = "gslam_comm_stale_%d" % os.getpid()
+    # ShmSegment starts with magic (u32), arrived, generation, attached, failed (i32 each); the rest is handle space
+    stale = struct.pack("<Iiiii", 0x47534C4D, 0, 7, 2, 0) + b"\0" * (1 << 16)
+    with open("/dev/shm/" + name, "wb") as f:
+        f.write(stale)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GSLAM_HIP_COMM_TIMEOUT_S="60")
+
+    def start(r):
+        return subprocess.Popen([sys.executable, str(script), str(r), "2", str(F), str(K), str(W), str(H), name,
+                                 str(tmp_path / f"rank{r}_{name}.npz")], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.STDOUT, text=True)
+    p1 = start(1)
+    time.sleep(6.0)  # rank 1 is well inside its rendezvous loop, looking at the stale segment
+    assert p1.poll() is None, p1.communicate()[0][-2000:]
+    p0 = start(0)
+    outs = []
+    for p in (p0, p1):
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            p0.kill(); p1.kill()
+            raise
+    assert p0.returncode == 0 and p1.returncode == 0, outs[0][-2000:] + outs[1][-2000:]
+    r0, r1 = (np.load(tmp_path / f"rank{r}_{name}.npz") for r in range(2))
+    for k in ("g_desc", "g_counts", "g_kps", "g_idx"):
+        assert r0[k].tobytes() == r1[k].tobytes(), k
+    assert (r0["g_counts"] > 0).all()
+    assert not os.path.exists("/dev/shm/" + name)  # the last rank out unlinks it
