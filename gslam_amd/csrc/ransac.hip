@@ -585,15 +585,53 @@ __global__ __launch_bounds__(256) void ransac_mask_kernel(int model, const doubl
 
 }  // namespace
 
+// The adaptive stopping rule of sequential RANSAC (Fischler & Bolles; the rule behind a `confidence` argument): walking the
+// hypotheses in index order, after every strict improvement of the best inlier count c the number of hypotheses needed is
+// N = ceil(log(1 - confidence) / log(1 - (c / n)^s)), and the walk stops once h + 1 >= N.  All kHyp hypotheses are scored
+// in parallel anyway; the rule only decides WHICH prefix of them a sequential run would have looked at, so the result is
+// the one a CPU implementation with the same draws returns.  Evaluated on the host with libm (the oracle makes the same
+// calls), never on the device.  confidence outside (0, 1): every hypothesis counts.
+static int adaptive_prefix_best(const int* counts, int n, int s, double confidence, int* best_count, int* used) {
+  int best_h = -1, best_c = -1, limit = kHyp;
+  const bool adaptive = confidence > 0.0 && confidence < 1.0;
+  int h = 0;
+  for (; h < limit; ++h) {
+    if (counts[h] > best_c) {
+      best_c = counts[h];
+      best_h = h;
+      if (adaptive && best_c > 0) {
+        const double pg = pow((double)best_c / (double)n, (double)s);
+        int need = kHyp;
+        if (pg >= 1.0) need = h + 1;
+        else if (pg > 0.0) {
+          const double v = ceil(log(1.0 - confidence) / log(1.0 - pg));
+          need = v < 1.0 ? 1 : (v > (double)kHyp ? kHyp : (int)v);
+        }
+        if (need < limit) limit = need < h + 1 ? h + 1 : need;
+      }
+    }
+  }
+  *best_count = best_c < 0 ? 0 : best_c;
+  *used = h;
+  return best_c < 0 ? -1 : best_h;
+}
+
 extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* src, const double* dst, int n,
                                         double threshold, uint64_t seed, double* model_out, uint8_t* mask_out,
                                         int* inliers_out) {
+  return gh_ransac_estimate_conf(ctx, model, src, dst, n, threshold, 1.0, seed, model_out, mask_out, inliers_out, nullptr);
+}
+
+extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const double* src, const double* dst, int n,
+                                             double threshold, double confidence, uint64_t seed, double* model_out,
+                                             uint8_t* mask_out, int* inliers_out, int* hypotheses_used_out) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, model >= 0 && model <= 7 && src && dst && model_out && inliers_out && threshold >= 0);
   const int dim = dim_p(model), dimq = dim_q(model);
   const int s = sample_size(model);
   *inliers_out = 0;
+  if (hypotheses_used_out) *hypotheses_used_out = 0;
   for (int k = 0; k < 12; ++k) model_out[k] = 0.0;
   if (mask_out)
     for (int i = 0; i < n; ++i) mask_out[i] = 0;
@@ -640,10 +678,23 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
             d_models, d_valid);
   GH_LAUNCH(ctx, "ransac_score", ransac_score_kernel, dim3(kHyp), dim3(256), 0, model, d_p, d_q, n, thr2, d_models,
             d_valid, d_counts);
-  GH_LAUNCH(ctx, "ransac_best", ransac_best_kernel, dim3(1), dim3(256), 0, d_counts, d_best);
+  int best[2] = {-1, 0};
+  if (confidence > 0.0 && confidence < 1.0) {
+    // the prefix rule needs the counts on the host: 8 KB back, the choice (two ints) forth
+    std::vector<int> h_counts(kHyp);
+    GH_HIP(ctx, hipMemcpyAsync(h_counts.data(), d_counts, kHyp * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int used = 0;
+    best[0] = adaptive_prefix_best(h_counts.data(), n, s, confidence, &best[1], &used);
+    if (hypotheses_used_out) *hypotheses_used_out = used;
+    GH_HIP(ctx, hipMemcpyAsync(d_best, best, 8, hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `best` is a stack buffer
+  } else {
+    GH_LAUNCH(ctx, "ransac_best", ransac_best_kernel, dim3(1), dim3(256), 0, d_counts, d_best);
+    if (hypotheses_used_out) *hypotheses_used_out = kHyp;
+  }
   GH_LAUNCH(ctx, "ransac_mask", ransac_mask_kernel, dim3(gh_div_up(n > 12 ? n : 12, 256)), dim3(256), 0, model, d_p, d_q,
             n, thr2, d_models, d_best, d_mask, d_mout);
-  int best[2] = {-1, 0};
   GH_HIP(ctx, hipMemcpyAsync(best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(model_out, d_mout, 12 * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (mask_out) GH_HIP(ctx, hipMemcpyAsync(mask_out, d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -29,14 +29,14 @@ class EstimatorHIP : public GSLAM::Estimator {
                       const std::vector<GSLAM::Point2d>& dst, int method, double threshold, double confidence,
                       std::vector<uchar>* mask) const override {
     double m[12];
-    if (!run(GH_MODEL_HOMOGRAPHY, src, dst, method, threshold, m, mask)) return false;
+    if (!run(GH_MODEL_HOMOGRAPHY, src, dst, method, threshold, confidence, m, mask)) return false;
     if (H) for (int i = 0; i < 9; ++i) H->data()[i] = m[i];
     return true;
   }
   bool findAffine2D(GSLAM::Affine2D* A, const std::vector<GSLAM::Point2d>& src, const std::vector<GSLAM::Point2d>& dst,
                     int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
     double m[12];
-    if (!run(GH_MODEL_AFFINE2D, src, dst, method, threshold, m, mask)) return false;
+    if (!run(GH_MODEL_AFFINE2D, src, dst, method, threshold, confidence, m, mask)) return false;
     if (A) for (int i = 0; i < 6; ++i) A->data()[i] = m[i];
     return true;
   }
@@ -44,7 +44,7 @@ class EstimatorHIP : public GSLAM::Estimator {
                        const std::vector<GSLAM::Point2d>& p2, int method, double threshold, double confidence,
                        std::vector<uchar>* mask) const override {
     double m[12];
-    if (!run(GH_MODEL_FUNDAMENTAL, p1, p2, method, threshold, m, mask)) return false;
+    if (!run(GH_MODEL_FUNDAMENTAL, p1, p2, method, threshold, confidence, m, mask)) return false;
     if (F) for (int i = 0; i < 9; ++i) F->data()[i] = m[i];
     return true;
   }
@@ -52,7 +52,7 @@ class EstimatorHIP : public GSLAM::Estimator {
                     int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
     if (src.size() != dst.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
     double m[12];
-    if (!estimate(GH_MODEL_AFFINE3D, (const double*)src.data(), (const double*)dst.data(), (int)src.size(), threshold, m,
+    if (!estimate(GH_MODEL_AFFINE3D, (const double*)src.data(), (const double*)dst.data(), (int)src.size(), threshold, confidence, m,
                   mask))
       return false;
     if (A) for (int i = 0; i < 12; ++i) A->data()[i] = m[i];
@@ -62,7 +62,7 @@ class EstimatorHIP : public GSLAM::Estimator {
   bool findEssentialMatrix(GSLAM::Essential* E, const std::vector<GSLAM::Point2d>& p1, const std::vector<GSLAM::Point2d>& p2,
                            int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
     double m[12];
-    if (!run(GH_MODEL_ESSENTIAL, p1, p2, method, threshold, m, mask)) return false;
+    if (!run(GH_MODEL_ESSENTIAL, p1, p2, method, threshold, confidence, m, mask)) return false;
     if (E) for (int i = 0; i < 9; ++i) E->data()[i] = m[i];
     return true;
   }
@@ -71,7 +71,7 @@ class EstimatorHIP : public GSLAM::Estimator {
                 double threshold, double confidence, std::vector<uchar>* mask) const override {
     if (from.size() != to.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
     double m[12];
-    if (!estimate(GH_MODEL_SIM3, (const double*)from.data(), (const double*)to.data(), (int)from.size(), threshold, m, mask))
+    if (!estimate(GH_MODEL_SIM3, (const double*)from.data(), (const double*)to.data(), (int)from.size(), threshold, confidence, m, mask))
       return false;
     if (S) *S = GSLAM::SIM3(GSLAM::SO3(m[0], m[1], m[2], m[3]), GSLAM::Point3d(m[4], m[5], m[6]), m[7]);
     return true;
@@ -81,7 +81,7 @@ class EstimatorHIP : public GSLAM::Estimator {
                  double confidence, std::vector<uchar>* mask) const override {
     if ((method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
     double m[12];
-    if (!estimate(GH_MODEL_PLANE, (const double*)points.data(), (const double*)points.data(), (int)points.size(), threshold,
+    if (!estimate(GH_MODEL_PLANE, (const double*)points.data(), (const double*)points.data(), (int)points.size(), threshold, confidence,
                   m, mask))
       return false;
     if (plane) {
@@ -105,7 +105,7 @@ class EstimatorHIP : public GSLAM::Estimator {
     if (obj.size() != img.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
     double m[12];
     std::vector<uchar> local;
-    if (!estimate(GH_MODEL_PNP, (const double*)obj.data(), (const double*)img.data(), (int)obj.size(), threshold, m, &local))
+    if (!estimate(GH_MODEL_PNP, (const double*)obj.data(), (const double*)img.data(), (int)obj.size(), threshold, confidence, m, &local))
       return false;
     std::vector<double> X, uv;
     for (size_t i = 0; i < local.size(); ++i)
@@ -126,7 +126,10 @@ class EstimatorHIP : public GSLAM::Estimator {
     o.max_iterations = 30;
     {
       std::lock_guard<std::mutex> lock(mu_);
-      if (gh_ba_pnp(ctx_, X.data(), uv.data(), (int)(uv.size() / 2), pose, GH_KF_SE3, &o, NULL, NULL) != GH_OK) {
+      // GH_ERR_NUMERIC = LM stopped on trust-region underflow with a VALID pose (the DLT start was already at the optimum
+      // and no step could lower the cost): gh_ba_pnp passes it through, and so does this caller
+      const gh_status st = gh_ba_pnp(ctx_, X.data(), uv.data(), (int)(uv.size() / 2), pose, GH_KF_SE3, &o, NULL, NULL);
+      if (st != GH_OK && st != GH_ERR_NUMERIC) {
         LOG(ERROR) << "EstimatorHIP: " << gh_last_error(ctx_);
         return false;
       }
@@ -154,17 +157,19 @@ class EstimatorHIP : public GSLAM::Estimator {
  private:
   static_assert(sizeof(GSLAM::Point2d) == 16 && sizeof(GSLAM::Point3d) == 24, "point arrays are passed as packed doubles");
   bool run(int model, const std::vector<GSLAM::Point2d>& a, const std::vector<GSLAM::Point2d>& b, int method,
-           double threshold, double* m, std::vector<uchar>* mask) const {
+           double threshold, double confidence, double* m, std::vector<uchar>* mask) const {
     if (a.size() != b.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
-    return estimate(model, (const double*)a.data(), (const double*)b.data(), (int)a.size(), threshold, m, mask);
+    return estimate(model, (const double*)a.data(), (const double*)b.data(), (int)a.size(), threshold, confidence, m, mask);
   }
-  bool estimate(int model, const double* a, const double* b, int n, double threshold, double* m,
+  // `confidence` is honoured as a sequential RANSAC would (gh_ransac_estimate_conf): the hypotheses are scored in parallel,
+  // the winner is the best of the prefix the adaptive stopping rule would have examined
+  bool estimate(int model, const double* a, const double* b, int n, double threshold, double confidence, double* m,
                 std::vector<uchar>* mask) const {
     std::lock_guard<std::mutex> lock(mu_);
     std::vector<uchar> local((size_t)(n > 0 ? n : 1));
     int inliers = 0;
     const uint64_t seed = (uint64_t)svar.GetInt("EstimatorHIP.Seed", 1);
-    if (gh_ransac_estimate(ctx_, model, a, b, n, threshold, seed, m, local.data(), &inliers) != GH_OK) {
+    if (gh_ransac_estimate_conf(ctx_, model, a, b, n, threshold, confidence, seed, m, local.data(), &inliers, NULL) != GH_OK) {
       LOG(ERROR) << "EstimatorHIP: " << gh_last_error(ctx_);
       return false;
     }

@@ -309,7 +309,8 @@ gh_status gh_undistort_host(gh_undist_plan* plan, const uint8_t* img, int channe
 
 /* ------------------------------------------------------------------ RANSAC estimation - */
 /* Robust model fitting with an inlier mask, behind GSLAM::Estimator (GSLAM/core/Estimator.h:100-169; interface only in
- * the reference).  Deterministic: 2048 hypotheses drawn from `seed`; winner = most correspondences with squared error
+ * the reference).  Deterministic: 2048 hypotheses drawn from `seed` (gh_ransac_estimate_conf: the prefix of them that
+ * the requested confidence asks for); winner = most correspondences with squared error
  * <= threshold^2, lowest hypothesis index on ties.  model_out must hold 12 doubles; mask_out (n bytes, may be NULL) gets
  * 1 for inliers; *inliers_out = 0 means no model.
  *   0 homography   findHomography      src, dst n x 2; model 9 row-major, h33 = 1; forward transfer error
@@ -334,6 +335,14 @@ gh_status gh_undistort_host(gh_undist_plan* plan, const uint8_t* img, int channe
 #define GH_MODEL_PNP 7
 gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* src, const double* dst, int n, double threshold,
                              uint64_t seed, double* model_out, uint8_t* mask_out, int* inliers_out);
+/* The same with GSLAM::Estimator's `confidence` argument honoured (Estimator.h:100-169 pass threshold AND confidence):
+ * the winner is the best among the hypotheses a SEQUENTIAL adaptive RANSAC with the same draws would have examined -- in
+ * index order, after every strict improvement of the best inlier count c the needed number of hypotheses becomes
+ * ceil(log(1 - confidence) / log(1 - (c / n)^s)) (s = sample size of the model), and the walk ends when it is reached.
+ * *hypotheses_used_out (may be NULL) reports that number.  confidence <= 0 or >= 1: all 2048 (== gh_ransac_estimate). */
+gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const double* src, const double* dst, int n, double threshold,
+                                  double confidence, uint64_t seed, double* model_out, uint8_t* mask_out,
+                                  int* inliers_out, int* hypotheses_used_out);
 /* Midpoint triangulation, one correspondence per thread (GSLAM::Estimator::trianglate, Estimator.h:164-168): the point of
  * the REFERENCE frame closest to the two rays ref_dir and cur_dir (camera.UnProject of the two pixels), with
  * X_cur = T_ref2cur X_ref, pose = [qx qy qz qw tx ty tz].  pose_stride = 7: one pose per correspondence; 0: one pose for

@@ -453,9 +453,20 @@ static int model_err(int model, const double* m, const double* p, const double* 
   return 1;
 }
 
+int oracle_ransac_conf(int model, const double* p, const double* q, int n, double threshold, double confidence,
+                       uint64_t seed, double* model_out, uint8_t* mask, int* used_out);
+
 /* returns the inlier count of the winning hypothesis (0 = no model) */
 int oracle_ransac(int model, const double* p, const double* q, int n, double threshold, uint64_t seed, double* model_out,
                   uint8_t* mask) {
+  return oracle_ransac_conf(model, p, q, n, threshold, 1.0, seed, model_out, mask, 0);
+}
+
+/* GSLAM::Estimator's confidence argument (Estimator.h:100-169): plain sequential RANSAC with the textbook adaptive
+ * stopping rule -- after a strict improvement of the best inlier count c, N = ceil(log(1 - conf) / log(1 - (c/n)^s));
+ * stop when h + 1 >= N.  confidence outside (0, 1): all R_HYP hypotheses. */
+int oracle_ransac_conf(int model, const double* p, const double* q, int n, double threshold, double confidence,
+                       uint64_t seed, double* model_out, uint8_t* mask, int* used_out) {
   static const int S_OF[8] = {4, 3, 8, 4, 8, 3, 3, 6}, M_OF[8] = {9, 6, 9, 12, 9, 8, 4, 12};
   const int s = S_OF[model], ms = M_OF[model];
   memset(model_out, 0, 12 * sizeof(double));
@@ -480,9 +491,11 @@ int oracle_ransac(int model, const double* p, const double* q, int n, double thr
     nm.s2 = d2 > 0 ? 1.4142135623730951 / d2 : 1.0;
   }
   const double thr2 = threshold * threshold;
-  int best_h = -1, best_c = -1;
+  int best_h = -1, best_c = -1, limit = R_HYP, h = 0;
+  const int adaptive = confidence > 0.0 && confidence < 1.0;
   double best_m[12];
-  for (int h = 0; h < R_HYP; ++h) {
+  if (used_out) *used_out = 0;
+  for (; h < limit; ++h) {
     int idx[8];
     uint64_t st = sm64(seed ^ ((uint64_t)h * 0xD1B54A32D192ED03ull));
     for (int j = 0; j < s; ++j)
@@ -507,8 +520,19 @@ int oracle_ransac(int model, const double* p, const double* q, int n, double thr
       best_c = cnt;
       best_h = h;
       memcpy(best_m, m, sizeof(m));
+      if (adaptive && best_c > 0) {
+        double pg = pow((double)best_c / (double)n, (double)s);
+        int need = R_HYP;
+        if (pg >= 1.0) need = h + 1;
+        else if (pg > 0.0) {
+          double v = ceil(log(1.0 - confidence) / log(1.0 - pg));
+          need = v < 1.0 ? 1 : (v > (double)R_HYP ? R_HYP : (int)v);
+        }
+        if (need < limit) limit = need < h + 1 ? h + 1 : need;
+      }
     }
   }
+  if (used_out) *used_out = h;
   if (best_h < 0) return 0;
   for (int k = 0; k < ms; ++k) model_out[k] = best_m[k];
   if (model == 4 && !project_essential(model_out)) { /* the mask stays that of the scored 8-point estimate */

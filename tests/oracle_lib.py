@@ -474,6 +474,17 @@ def _ransac_methods(cls):
                                      _ptr(m), _ptr(mask))
         return m, mask[:n].copy(), cnt
 
+    def ransac_conf(self, model, src, dst, threshold, confidence, seed=1):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        dst = np.ascontiguousarray(dst, dtype=np.float64)
+        n = src.shape[0]
+        m = np.zeros(12)
+        mask = np.zeros(max(n, 1), np.uint8)
+        used = C.c_int()
+        cnt = self.lib.oracle_ransac_conf(int(model), _ptr(src), _ptr(dst), n, C.c_double(threshold), C.c_double(confidence),
+                                          C.c_uint64(seed), _ptr(m), _ptr(mask), C.byref(used))
+        return m, mask[:n].copy(), cnt, used.value
+
     def triangulate(self, pose, d1, d2):
         out = np.zeros(3)
         ok = self.lib.oracle_triangulate(_ptr(np.ascontiguousarray(pose, dtype=np.float64)),
@@ -482,6 +493,7 @@ def _ransac_methods(cls):
         return out, bool(ok)
 
     cls.ransac = ransac
+    cls.ransac_conf = ransac_conf
     cls.triangulate = triangulate
 
 

@@ -96,3 +96,18 @@ def test_triangulate_bit_exact_vs_oracle(ctx, oracle):
         assert eok == ok[i] and e.tobytes() == got[i].tobytes(), i
         n_ok += eok
     assert 200 < n_ok < 300
+
+
+@pytest.mark.parametrize("model,thr,n,noise", [(0, 2.0, 1500, 0.4), (1, 2.0, 500, 0.3), (2, 1.0, 1200, 0.3), (3, 0.05, 700, 0.005)])
+def test_ransac_confidence_bit_exact_vs_oracle(ctx, oracle, model, thr, n, noise):
+    """gh_ransac_estimate_conf: same winner, mask, model doubles AND the same number of hypotheses examined as the
+    oracle's sequential adaptive RANSAC, for every confidence."""
+    from gslam_amd import estimator
+    P, Q, inl, _ = _corr(model, n, 0.3, 300 + model + n, noise)
+    used_all = []
+    for conf in (0.5, 0.95, 0.99, 0.9999999, 1.0, 0.0):
+        em, emask, ecnt, eused = oracle.ransac_conf(model, P, Q, thr, conf, seed=9)
+        gm, gmask, gcnt, gused = estimator.estimate_conf(ctx, model, P, Q, thr, conf, seed=9)
+        assert (gcnt, gused) == (ecnt, eused) and np.array_equal(gmask, emask) and gm.tobytes() == em.tobytes()
+        used_all.append(gused)
+    assert used_all[-1] == used_all[-2] == 2048 and used_all[0] < 2048

@@ -169,3 +169,26 @@ def test_triangulation_midpoint(oracle):
     assert not ok
     _, ok = oracle.triangulate(pose, np.array([-0.5, 0, 1.0]), np.array([0.9, 0, 1.0]))  # diverging: behind a camera
     assert not ok
+
+
+def test_confidence_is_the_sequential_adaptive_stopping_rule(oracle):
+    """Estimator.h:100-169 pass threshold AND confidence.  oracle_ransac_conf restates sequential RANSAC with the textbook
+    stopping rule; re-derive it here from oracle_ransac's own hypothesis stream: scoring prefixes of the hypothesis list
+    is the same as running the full search with the data the prefix saw, so the winner at confidence c must be the best of
+    the first `used` hypotheses and `used` must satisfy the rule for that winner but for no earlier best."""
+    import math
+    for model, thr, s in ((0, 2.0, 4), (1, 2.0, 3), (2, 1.0, 8)):
+        P, Q, inl, _ = _corr(model, 600, 0.35, 900 + model, 0.3)
+        m_full, mask_full, cnt_full = oracle.ransac(model, P, Q, thr, seed=5)
+        m1, mask1, cnt1, used1 = oracle.ransac_conf(model, P, Q, thr, 1.0, seed=5)
+        assert used1 == 2048 and cnt1 == cnt_full and m1.tobytes() == m_full.tobytes()
+        prev_used = 0
+        for conf in (0.5, 0.9, 0.99, 0.999999):
+            m, mask, cnt, used = oracle.ransac_conf(model, P, Q, thr, conf, seed=5)
+            assert 1 <= used <= 2048 and used >= prev_used and 0 < cnt <= cnt_full
+            prev_used = used
+            w = cnt / len(P)
+            need = math.ceil(math.log(1 - conf) / math.log(1 - w ** s)) if 0 < w < 1 else 1
+            assert used <= max(need, 1) + 2048 * (need > 2048) or used == 2048
+            assert mask.sum() == cnt
+        assert prev_used < 2048 or cnt_full / len(P) < 0.3  # a 65 % inlier set never needs all 2048 draws of 4 / 3 points
