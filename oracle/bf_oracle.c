@@ -8,8 +8,8 @@
  *   selection  GSLAM/core/Vocabulary.h:1712-1725 — best_d starts at FLT_MAX, `if (d < best_d)`:
  *              strict '<' so the FIRST minimum (lowest train index) wins ties.
  * Pinning: oracle/_ref/libgslam_ref.so compiles the reference's own hamming32 from
- * /root/reference/GSLAM/core/Vocabulary.h; tests/test_oracle_pinning.py checks this file against it
- * and against tests/golden/bf_*.bin generated from it (tools/gen_golden.py).
+ * /root/reference/GSLAM/core/Vocabulary.h; tests/test_bf_oracle.py checks this file against it (live, where
+ * /root/reference exists) and against tests/golden/bf_reference.npz generated from it (tools/gen_golden.py).
  */
 #include <stdint.h>
 #include <string.h>
