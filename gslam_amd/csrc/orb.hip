@@ -95,63 +95,70 @@ __global__ void copy_rows_kernel(const uint8_t* __restrict__ src, size_t src_fra
 constexpr int kResizeRows = 4;  // output rows per thread
 constexpr int kResizeCols = 8;  // output columns per thread
 
-struct __attribute__((packed, aligned(4))) ResizeWin { uint32_t a, b, c, d; };  // 16 bytes at 4-byte alignment
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at 4-byte alignment: ONE dwordx4 load
+
+// a * b + c on the 24-bit multiplier (the compiler turns __umul24(a, b) + __umul24(c, d) + k into two multiplies and a
+// three-input add: one instruction more per output pixel)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// Per output column of a level, precomputed at plan creation (it depends on the column only): the v_perm selector that
+// puts the column's two horizontal taps into the 16-bit halves of a dword, relative to the 16-byte window of its
+// 8-column group, and the weight pair {2048 - fx, fx} -- the horizontal lerp of a source row is then ONE v_perm and ONE
+// v_dot2_u32_u16 per output pixel with no per-item set-up arithmetic (it was ~7 VALU per column per item).
+struct ResizeTabs {
+  const uint32_t* xtab;  // idx << 16 | frac per output column, padded to 8 (only the group's first entry is read)
+  const uint32_t* xsel;  // perm selector per output column
+  const uint32_t* xwgt;  // fx << 16 | (2048 - fx)
+  const uint32_t* ytab;  // idx << 16 | frac per output row
+};
 
 // One work item: output columns x8 .. x8 + 7, output rows y0 .. y_end - 1 (at most kResizeRows of them) of one frame.
-// s / d: the frame's source level and destination level.  ytab may be read at any (unaligned) y0.
+// s / d: the frame's source level and destination level (uniform per workgroup: all addressing is a scalar base plus a
+// 32-bit lane offset).  ytab may be read at any (unaligned) y0.
 __device__ __forceinline__ void resize_item(const LevelView& src, const uint8_t* __restrict__ s, uint8_t* __restrict__ d,
-                                            int dst_pitch, const uint32_t* __restrict__ xtab,
-                                            const uint32_t* __restrict__ ytab, int x8, int y0, int y_end, bool guard_frame) {
-  // x table: padded to a multiple of 8 entries (pads continue with sx + 1), 32-byte aligned per group
-  const uint4 txa = *reinterpret_cast<const uint4*>(xtab + x8), txb = *reinterpret_cast<const uint4*>(xtab + x8 + 4);
-  const uint32_t txs[8] = {txa.x, txa.y, txa.z, txa.w, txb.x, txb.y, txb.z, txb.w};
-  const int sx0 = (int)(txa.x >> 16);
-  const uint32_t al = (uint32_t)(sx0 & 3);
-  const int d0 = sx0 >> 2;
-  // Per output column: one v_perm selector that puts the two horizontal taps into the two 16-bit halves of a
-  // dword, and the weight pair {2048 - fx, fx}: the horizontal lerp of a source row is ONE v_dot2_u32_u16.
-  // Columns 0..3 take their taps from window bytes 0..7, columns 4..7 (offset >= 4) from bytes 4..11.
+                                            int dst_pitch, const ResizeTabs& tb, int x8, int y0, int y_end, bool guard_frame) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  uint32_t selp[8];
-  u16x2 wx[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int sx = (int)(txs[i] >> 16);
-    const int o = sx - sx0 - (i >= 4 ? 4 : 0);
-    const int o1 = max(min(sx + 1, src.w - 1), sx) - sx0 - (i >= 4 ? 4 : 0);  // == o for the clamped / pad entries
-    selp[i] = 0x0c000c00u | ((uint32_t)o1 << 16) | (uint32_t)o;
-    const uint32_t fx = txs[i] & 0xFFFFu;
-    wx[i] = __builtin_bit_cast(u16x2, (fx << 16) | (2048u - fx));
-  }
+  const int sx0 = (int)(tb.xtab[x8] >> 16);
+  const uint32_t al = (uint32_t)(sx0 & 3);
+  const uint32_t d0 = (uint32_t)sx0 & ~3u;  // byte offset of the dword that holds sx0
+  const uint4 sa = *reinterpret_cast<const uint4*>(tb.xsel + x8), sb = *reinterpret_cast<const uint4*>(tb.xsel + x8 + 4);
+  const uint4 wa = *reinterpret_cast<const uint4*>(tb.xwgt + x8), wb = *reinterpret_cast<const uint4*>(tb.xwgt + x8 + 4);
+  const uint32_t selp[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+  const uint32_t wx[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
   // the 16-byte window may run up to 15 bytes past the end of a source row: harmless inside the buffer (next row,
   // next frame, or the slab's tail pad), but the caller's level-0 buffer has no pad after its last row
-  const bool guard = guard_frame && 4 * d0 + 16 > src.pitch;
-  const int last_dw = (src.pitch >> 2) - 1;
+  const bool guard = guard_frame && (int)d0 + 16 > src.pitch;
+  const uint32_t last_dw = (uint32_t)src.pitch - 4u;
+  const uint32_t pitch = (uint32_t)src.pitch;
 #pragma unroll
   for (int rr = 0; rr < kResizeRows; ++rr) {
     const int y = y0 + rr;
     if (y >= y_end) break;
-    const uint32_t ty = ytab[y];
-    const int sy = ty >> 16;
+    const uint32_t ty = tb.ytab[y];
+    const uint32_t sy = ty >> 16;
     const uint32_t fy = ty & 0xFFFFu;
-    const int sy1 = sy + 1 < src.h ? sy + 1 : src.h - 1;
-    const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s + (size_t)sy * src.pitch);
-    const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s + (size_t)sy1 * src.pitch);
-    ResizeWin u, v;
-    if (guard && sy1 == src.h - 1) {
-      u = ResizeWin{q0[d0], q0[min(d0 + 1, last_dw)], q0[min(d0 + 2, last_dw)], q0[min(d0 + 3, last_dw)]};
-      v = ResizeWin{q1[d0], q1[min(d0 + 1, last_dw)], q1[min(d0 + 2, last_dw)], q1[min(d0 + 3, last_dw)]};
+    const uint32_t sy1 = sy + 1 < (uint32_t)src.h ? sy + 1 : (uint32_t)src.h - 1;
+    const uint32_t o0 = sy * pitch, o1 = sy1 * pitch;  // 32-bit offsets inside the frame (a level is < 4 GiB)
+    u32x4_a4 u, v;
+    if (guard && sy1 == (uint32_t)src.h - 1) {
+      auto ld = [&](uint32_t row, uint32_t k) { return *reinterpret_cast<const uint32_t*>(s + row + min(d0 + 4u * k, last_dw)); };
+      u = u32x4_a4{ld(o0, 0), ld(o0, 1), ld(o0, 2), ld(o0, 3)};
+      v = u32x4_a4{ld(o1, 0), ld(o1, 1), ld(o1, 2), ld(o1, 3)};
     } else {
-      u = *reinterpret_cast<const ResizeWin*>(q0 + d0);
-      v = *reinterpret_cast<const ResizeWin*>(q1 + d0);
+      u = *reinterpret_cast<const u32x4_a4*>(s + (o0 + d0));
+      v = *reinterpret_cast<const u32x4_a4*>(s + (o1 + d0));
     }
     // 12-byte windows that start exactly at sx0
-    const uint32_t uw[3] = {__builtin_amdgcn_alignbyte(u.b, u.a, al), __builtin_amdgcn_alignbyte(u.c, u.b, al),
-                            __builtin_amdgcn_alignbyte(u.d, u.c, al)};
-    const uint32_t vw[3] = {__builtin_amdgcn_alignbyte(v.b, v.a, al), __builtin_amdgcn_alignbyte(v.c, v.b, al),
-                            __builtin_amdgcn_alignbyte(v.d, v.c, al)};
+    const uint32_t uw[3] = {__builtin_amdgcn_alignbyte(u.y, u.x, al), __builtin_amdgcn_alignbyte(u.z, u.y, al),
+                            __builtin_amdgcn_alignbyte(u.w, u.z, al)};
+    const uint32_t vw[3] = {__builtin_amdgcn_alignbyte(v.y, v.x, al), __builtin_amdgcn_alignbyte(v.z, v.y, al),
+                            __builtin_amdgcn_alignbyte(v.w, v.z, al)};
     // vertical weights x4: the 2^22 weight total becomes 2^24, so the rounded result is the TOP BYTE of the sum
-    // ((4 v + 2^23) >> 24 == (v + 2^21) >> 22, max 255 * 2^24 + 2^23 < 2^32) and packing is two v_perm + one or
+    // ((4 v + 2^23) >> 24 == (v + 2^21) >> 22, max 255 * 2^24 + 2^23 < 2^32): two v_mad_u32_u24 per pixel
     const uint32_t wy0 = 4u * (2048u - fy), wy1 = 4u * fy;
     uint32_t r[8];
 #pragma unroll
@@ -159,22 +166,23 @@ __device__ __forceinline__ void resize_item(const LevelView& src, const uint8_t*
       const int wsel = i >= 4 ? 1 : 0;
       const u16x2 pu = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(uw[wsel + 1], uw[wsel], selp[i]));
       const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(vw[wsel + 1], vw[wsel], selp[i]));
-      const uint32_t h0 = __builtin_amdgcn_udot2(pu, wx[i], 0u, false);  // a00 (2048 - fx) + a01 fx  (< 2^20)
-      const uint32_t h1 = __builtin_amdgcn_udot2(pv, wx[i], 0u, false);
-      r[i] = __umul24(h0, wy0) + (__umul24(h1, wy1) + (1u << 23));
+      const u16x2 w2 = __builtin_bit_cast(u16x2, wx[i]);
+      const uint32_t h0 = __builtin_amdgcn_udot2(pu, w2, 0u, false);  // a00 (2048 - fx) + a01 fx  (< 2^20)
+      const uint32_t h1 = __builtin_amdgcn_udot2(pv, w2, 0u, false);
+      r[i] = mad_u24(h0, wy0, mad_u24(h1, wy1, 1u << 23));
     }
+    // top bytes of r[0..7] -> 8 output bytes: one v_perm per pixel pair, one v_perm per dword
     uint2 packed;
-    packed.x = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0703u) << 16);
-    packed.y = __builtin_amdgcn_perm(r[5], r[4], 0x0c0c0703u) | (__builtin_amdgcn_perm(r[7], r[6], 0x0c0c0703u) << 16);
+    packed.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0703u), __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0703u), 0x05040100u);
+    packed.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[7], r[6], 0x0c0c0703u), __builtin_amdgcn_perm(r[5], r[4], 0x0c0c0703u), 0x05040100u);
     // dst pitch is a multiple of 64 and the pad bytes are ours: always a full 8-byte store
-    *reinterpret_cast<uint2*>(d + (size_t)y * dst_pitch + x8) = packed;
+    *reinterpret_cast<uint2*>(d + ((uint32_t)y * (uint32_t)dst_pitch + (uint32_t)x8)) = packed;
   }
 }
 
 __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __restrict__ dst_base,
                                                      size_t dst_frame_stride, int dst_pitch, int wd, int hd,
-                                                     const uint32_t* __restrict__ xtab,
-                                                     const uint32_t* __restrict__ ytab, int groups_per_row,
+                                                     ResizeTabs tb, int groups_per_row,
                                                      uint32_t groups_inv, int n_items, int tail_unsafe_frame) {
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= n_items) return;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void resize_kernel(LevelView src, uint8_t* __r
   const int x8 = (item - rg * groups_per_row) * kResizeCols;
   const int y0 = rg * kResizeRows;
   resize_item(src, src.base + (size_t)blockIdx.y * src.frame_stride, dst_base + (size_t)blockIdx.y * dst_frame_stride, dst_pitch,
-              xtab, ytab, x8, y0, min(hd, y0 + kResizeRows), (int)blockIdx.y == tail_unsafe_frame);
+              tb, x8, y0, min(hd, y0 + kResizeRows), (int)blockIdx.y == tail_unsafe_frame);
 }
 
 // The next pyramid level produced from inside fast_cells (see there): which output 8-column groups / output rows of
@@ -191,12 +199,24 @@ struct NextLevel {
   uint8_t* dst_base;       // level l + 1, frame 0; nullptr = nothing to produce
   size_t dst_frame_stride;
   int dst_pitch, hd;
-  const uint32_t* xtab;    // of level l + 1
-  const uint32_t* ytab;
+  ResizeTabs tb;           // of level l + 1
   const int32_t* gx0;      // [nbx + 1] first owned output group per tile column
   const int32_t* gy0;      // [nby + 1] first owned output row per tile row
   int tail_unsafe_frame;
 };
+
+// Inclusive prefix sum of one int per lane over the wave: four DPP row shifts scan each 16-lane row, two row broadcasts
+// (lane 15 -> next row on rows 1 / 3, lane 31 -> rows 2 / 3) carry the row totals: 6 VALU (five ballots and their
+// masked popcounts were ~30).  Every lane of the wave must be active.
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 corner score (oracle step 2): max over 9-arcs of min(ring - p) / min(p - ring).
@@ -341,20 +361,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
       }
       allbits |= bits << (4 * trip);
     }
-    // ONE queue reservation per wave for all trips: per-lane count (0..20) prefix-summed with five ballots, then
+    // ONE queue reservation per wave for all trips: per-lane count (0..20), wave prefix sum (DPP scan), then
     // each lane unpacks its bits.  Score position of (item, k) = kScoreW sy + kScoreOff + 4 m - 18 + k with
     // m = item - 18 sy + 4, which is 4 item + 1 + k: no division needed.
     {
       const int cnt = __popc(allbits);
-      const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4), c3 = __ballot(cnt & 8),
-                     c4 = __ballot(cnt & 16);
-      if ((c0 | c1 | c2 | c3 | c4) != 0ull) {
-        const uint64_t ltm = (1ull << (tid & 63)) - 1ull;
+      const int incl = wave_incl_scan_i32(cnt);
+      const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+      if (wave_total != 0) {
         int base = 0;
-        if ((tid & 63) == 0)
-          base = atomicAdd(&q_count, __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3) + 16 * __popcll(c4));
-        base = __shfl(base, 0) + __popcll(c0 & ltm) + 2 * __popcll(c1 & ltm) + 4 * __popcll(c2 & ltm) +
-               8 * __popcll(c3 & ltm) + 16 * __popcll(c4 & ltm);
+        if ((tid & 63) == 0) base = atomicAdd(&q_count, wave_total);
+        base = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
         const int p0 = 4 * tid + 1;
         while (allbits) {
           const int b = __ffs((int)allbits) - 1;
@@ -404,11 +421,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     const int nq = (r1 - r0 + kResizeRows - 1) / kResizeRows;
     const uint8_t* s = lv.base + (size_t)frame * lv.frame_stride;
     uint8_t* d = nx.dst_base + (size_t)frame * nx.dst_frame_stride;
-    for (int item = tid; item < ng * nq; item += 256) {
-      const int q = item / ng, g = item - q * ng;
-      const int yy = r0 + kResizeRows * q;
-      resize_item(lv, s, d, nx.dst_pitch, nx.xtab, nx.ytab, 8 * (g0 + g), yy, min(r1, yy + kResizeRows),
-                  frame == nx.tail_unsafe_frame);
+    // lane -> (group g = tid & 7, row quad q = tid >> 3): a tile owns 6-7 groups x ~14 row quads, so one pass of 8 x 32
+    // slots covers it with shifts and masks only (edge tiles that also take the image border loop over further blocks)
+    for (int gb = 0; gb < ng; gb += 8) {
+      const int g = gb + (tid & 7);
+      for (int q = tid >> 3; q < nq; q += 32) {
+        const int yy = r0 + kResizeRows * q;
+        if (g < ng)
+          resize_item(lv, s, d, nx.dst_pitch, nx.tb, 8 * (g0 + g), yy, min(r1, yy + kResizeRows), frame == nx.tail_unsafe_frame);
+      }
     }
   }
 
@@ -440,11 +461,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
       nzb |= __builtin_amdgcn_udot4(f, 0x08040201u, 0u, false) << (4 * dwi);
     }
     const int cnt = __popc(nzb);
-    const uint64_t c0 = __ballot(cnt & 1), c1 = __ballot(cnt & 2), c2 = __ballot(cnt & 4), c3 = __ballot(cnt & 8),
-                   c4 = __ballot(cnt & 16);
-    int pos = __popcll(c0 & lt_mask) + 2 * __popcll(c1 & lt_mask) + 4 * __popcll(c2 & lt_mask) +
-              8 * __popcll(c3 & lt_mask) + 16 * __popcll(c4 & lt_mask);
-    nz = __popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3) + 16 * __popcll(c4);
+    const int incl = wave_incl_scan_i32(cnt);
+    int pos = incl - cnt;
+    nz = __builtin_amdgcn_readlane(incl, 63);
     const uint32_t rc0 = (uint32_t)((row << 5) | cb);
     while (nzb) {
       const int k = __ffs((int)nzb) - 1;
@@ -1014,6 +1033,8 @@ struct gh_orb_plan {
   uint8_t* pyr = nullptr;
   uint32_t* xtab[kMaxL]{};
   uint32_t* ytab[kMaxL]{};
+  uint32_t* xsel[kMaxL]{};  // per output column: perm selector / weight pair of the horizontal lerp (ResizeTabs)
+  uint32_t* xwgt[kMaxL]{};
   uint32_t* cell_cnt = nullptr;
   uint32_t* cell_ent = nullptr;
   SelKp* sel = nullptr;
@@ -1174,7 +1195,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   size_t tab_words = 0;
   // every table starts 32-byte aligned; x tables are padded to a multiple of 8 entries (pads continue with the next
   // source column, fraction 0, so that the per-thread window bounds hold), y tables to a multiple of 4 (last replicated)
-  for (int l = 1; l < L; ++l) tab_words += (((size_t)p->lw[l] + 7) & ~(size_t)7) + (((size_t)p->lh[l] + 7) & ~(size_t)7);
+  for (int l = 1; l < L; ++l) tab_words += 3 * (((size_t)p->lw[l] + 7) & ~(size_t)7) + (((size_t)p->lh[l] + 7) & ~(size_t)7);
   // + per source level l < L - 1: ownership of level l + 1 by the tile columns / rows of fast_cells(l), padded to 8 words
   for (int l = 0; l + 1 < L; ++l)
     tab_words += (((size_t)(p->ncx[l] + 1) / 2 + 1 + 7) & ~(size_t)7) + (((size_t)(p->ncy[l] + 1) / 2 + 1 + 7) & ~(size_t)7);
@@ -1211,12 +1232,27 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
         if (axis == 0) {
           // window contract of resize_kernel: within a group of 8 columns, taps of columns 0..3 lie in window bytes
           // 0..7 and taps of columns 4..7 in bytes 4..11 (true for the 1.2 scale; refuse anything else loudly)
-          const uint32_t* t = p->xtab[l] - p->tabs + htab.data();
-          for (size_t g = 0; g + 8 <= tw - (size_t)(p->xtab[l] - p->tabs); g += 8)
+          const size_t x0 = (size_t)(p->xtab[l] - p->tabs), nx_pad = tw - x0;
+          const uint32_t* t = htab.data() + x0;
+          for (size_t g = 0; g + 8 <= nx_pad; g += 8)
             for (int i = 0; i < 8; ++i) {
               const int o = (int)(t[g + i] >> 16) - (int)(t[g] >> 16) - (i >= 4 ? 4 : 0);
               if (o < 0 || o + 1 > 7) st = GH_ERR_ARG;
             }
+          // the per-column selector / weight tables derived from it (ResizeTabs)
+          p->xsel[l] = p->tabs + tw;
+          p->xwgt[l] = p->tabs + tw + nx_pad;
+          for (size_t c = 0; c < nx_pad; ++c) {
+            const int sx = (int)(t[c] >> 16), sx0 = (int)(t[c & ~(size_t)7] >> 16), hi = (c & 7) >= 4 ? 4 : 0;
+            const int o = sx - sx0 - hi;
+            int sx1 = sx + 1 < n_src ? sx + 1 : n_src - 1;
+            if (sx1 < sx) sx1 = sx;  // pad entries past the last source column
+            const int o1 = sx1 - sx0 - hi;
+            const uint32_t fx = t[c] & 0xFFFFu;
+            htab[tw + c] = 0x0c000c00u | ((uint32_t)(o1 & 7) << 16) | (uint32_t)(o & 7);
+            htab[tw + nx_pad + c] = (fx << 16) | (2048u - fx);
+          }
+          tw += 2 * nx_pad;
         }
       }
     }
@@ -1315,8 +1351,8 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     // only the caller's own level-0 buffer can end right after its last row
     const int unsafe_frame = (l == 1 && aligned0) ? batch - 1 : -1;
     GH_LAUNCH(ctx, "orb_resize", resize_kernel, dim3(gh_div_up(n_items, 256), batch), dim3(256), 0, lv[l - 1],
-              p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l], p->xtab[l], p->ytab[l], gpr, inv,
-              n_items, unsafe_frame);
+              p->pyr + p->lvl_off[l], p->slab, p->pitch[l], p->lw[l], p->lh[l],
+              ResizeTabs{p->xtab[l], p->xsel[l], p->xwgt[l], p->ytab[l]}, gpr, inv, n_items, unsafe_frame);
     return GH_OK;
   };
   for (int l = 0; l < L; ++l) {
@@ -1325,9 +1361,10 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
       if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
       continue;
     }
-    NextLevel nx{nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, -1};
+    NextLevel nx{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
     if (l + 1 < L && p->fuse_pyramid)
-      nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1], p->xtab[l + 1], p->ytab[l + 1],
+      nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1],
+                     ResizeTabs{p->xtab[l + 1], p->xsel[l + 1], p->xwgt[l + 1], p->ytab[l + 1]},
                      p->own_gx[l], p->own_gy[l], (l == 0 && aligned0) ? batch - 1 : -1};
     const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
     GH_CHECK_ARG(ctx, tiles < (1LL << 30));
