@@ -48,6 +48,56 @@ def solve(ctx: hip.Context, graph: dict, options=None):
     return poses, pts, s, st
 
 
+class Graph:
+    """gh_ba_graph_*: the problem stays in HBM between solves (index lists, pair lists, tables, arrays)."""
+
+    def __init__(self, ctx: hip.Context, graph: dict, options=None):
+        self.ctx = ctx
+        options = options or default_options()
+        a = {k: np.ascontiguousarray(graph[k], dtype=dt) for k, dt in (("cam_pose", np.float64), ("point_xyz", np.float64),
+             ("cam_dof", np.int32), ("obs_cam", np.int32), ("obs_point", np.int32), ("obs_xy", np.float64))}
+        pfree = graph.get("point_free")
+        pfree = np.ascontiguousarray(pfree, dtype=np.uint8) if pfree is not None else None
+        info = graph.get("obs_info")
+        info = np.ascontiguousarray(info, dtype=np.float64) if info is not None else None
+        self.nc, self.np_ = len(a["cam_pose"]), len(a["point_xyz"])
+        pr = hip.BaProblem(self.nc, self.np_, len(a["obs_cam"]), _ptr(a["cam_pose"]), _ptr(a["cam_dof"]), _ptr(a["point_xyz"]),
+                           _ptr(pfree), _ptr(a["obs_cam"]), _ptr(a["obs_point"]), _ptr(a["obs_xy"]), _ptr(info))
+        h = C.c_void_p()
+        ctx.check(hip.lib.gh_ba_graph_create(ctx.h, C.byref(pr), C.byref(options), C.byref(h)))
+        self.g = h
+
+    def close(self):
+        if self.g:
+            hip.lib.gh_ba_graph_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, cam_pose=None, point_xyz=None, obs_xy=None, obs_info=None, cam_dof=None, point_free=None):
+        c = lambda a, dt: np.ascontiguousarray(a, dtype=dt) if a is not None else None
+        arrs = [c(cam_pose, np.float64), c(point_xyz, np.float64), c(obs_xy, np.float64), c(obs_info, np.float64),
+                c(cam_dof, np.int32), c(point_free, np.uint8)]
+        self.ctx.check(hip.lib.gh_ba_graph_update(self.g, *[_ptr(a) for a in arrs]))
+
+    def solve(self, options=None):
+        options = options or default_options()
+        s = hip.BaSummary()
+        st = hip.lib.gh_ba_graph_solve(self.g, C.byref(options), C.byref(s))
+        if st not in (0, 4):
+            self.ctx.check(st)
+        return s, st
+
+    def read(self):
+        poses, pts = np.zeros((self.nc, 7)), np.zeros((self.np_, 3))
+        self.ctx.check(hip.lib.gh_ba_graph_read(self.g, _ptr(poses), _ptr(pts)))
+        return poses, pts
+
+
 def pnp(ctx: hip.Context, points_xyz, obs_xy, pose, dof=63, options=None, want_information=False):
     options = options or default_options()
     X = np.ascontiguousarray(points_xyz, dtype=np.float64)

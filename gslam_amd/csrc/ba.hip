@@ -982,34 +982,39 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
 
 // Device buffers of one solve, bump-allocated from the context's grow-only arena (ctx->ba_arena); anything that does
 // not fit falls back to its own hipMalloc and is freed when the solve ends.
+// Sub-allocator over ONE device arena: the context's grow-only arena (one-shot gh_ba_solve calls reuse it from solve to
+// solve) or an arena owned by a gh_ba_graph (resident across solves, untouched by other solves on the context).
 struct DevBuf {
   gh_ctx* ctx;
+  void** arena;         // -> ctx->ba_arena or the graph's own
+  size_t* arena_bytes;
   std::vector<void*> ptrs;
   size_t used = 0;
-  explicit DevBuf(gh_ctx* c) : ctx(c) {}
+  explicit DevBuf(gh_ctx* c) : ctx(c), arena(&c->ba_arena), arena_bytes(&c->ba_arena_bytes) {}
+  DevBuf(gh_ctx* c, void** a, size_t* ab) : ctx(c), arena(a), arena_bytes(ab) {}
   ~DevBuf() {
     hipStreamSynchronize(ctx->stream);
     for (void* p : ptrs) hipFree(p);
   }
   gh_status reserve(size_t bytes) {
-    if (bytes <= ctx->ba_arena_bytes) return GH_OK;
+    if (bytes <= *arena_bytes) return GH_OK;
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->ba_arena) GH_HIP(ctx, hipFree(ctx->ba_arena));
-    ctx->ba_arena = nullptr;
-    ctx->ba_arena_bytes = 0;
+    if (*arena) GH_HIP(ctx, hipFree(*arena));
+    *arena = nullptr;
+    *arena_bytes = 0;
     const size_t want = bytes + bytes / 8 + (1 << 20);
-    if (hipMalloc(&ctx->ba_arena, want) != hipSuccess) {
-      ctx->ba_arena = nullptr;
+    if (hipMalloc(arena, want) != hipSuccess) {
+      *arena = nullptr;
       return GH_OK;  // every buffer will take the individual fallback path
     }
-    ctx->ba_arena_bytes = want;
+    *arena_bytes = want;
     return GH_OK;
   }
   template <typename T>
   gh_status alloc(T** out, size_t count) {
     const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
-    if (ctx->ba_arena && used + bytes <= ctx->ba_arena_bytes) {
-      *out = (T*)((char*)ctx->ba_arena + used);
+    if (*arena && used + bytes <= *arena_bytes) {
+      *out = (T*)((char*)*arena + used);
       used += bytes;
       return GH_OK;
     }
@@ -1371,22 +1376,64 @@ extern "C" void gh_ba_default_options(gh_ba_options* o) {
   o->deterministic = 1;
 }
 
-extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_options* opt_in,
-                                 gh_ba_summary* sum_out) {
-  if (!ctx || !pr) return GH_ERR_ARG;
-  GH_ENTER(ctx);
+namespace {
+
+// Everything a solve keeps on the device.  A one-shot gh_ba_solve builds one on the stack over the context's arena; a
+// gh_ba_graph owns one (and its arena) so that the index lists, pair lists, chunk tables and all arrays stay in HBM
+// between the windowed solves of a SLAM back end (GSLAM/core/Optimizer.h:229 is called every few keyframes on a graph
+// whose topology changes far less often than its values).
+struct BaSession {
+  bool ready = false;
+  void* arena = nullptr;  // graph-owned arena (unused by one-shot solves)
+  size_t arena_bytes = 0;
+  DevBuf* db = nullptr;
+  int nc = 0, np = 0, no = 0, deterministic = 0;
+  bool has_info = false, has_pfree = false;
+  double *d_poses = nullptr, *d_pts = nullptr, *d_poses_new = nullptr, *d_pts_new = nullptr, *d_oxy = nullptr, *d_oinfo = nullptr;
+  int32_t *d_dof = nullptr, *d_ocam = nullptr, *d_opt = nullptr, *d_pstart = nullptr, *d_plist = nullptr, *d_cstart = nullptr,
+          *d_clist = nullptr;
+  uint8_t* d_pfree = nullptr;
+  CamChunks CC{nullptr, nullptr, nullptr, 0};
+  SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  int nchunks = 0, nsegs = 0, nblocks = 0;
+  bool device_pairs = false;
+  double *d_Hcc = nullptr, *d_gc = nullptr, *d_Hpp = nullptr, *d_gp = nullptr, *d_Hpi = nullptr, *d_S = nullptr, *d_dc = nullptr,
+         *d_dp = nullptr, *d_partial = nullptr, *d_out = nullptr, *d_work = nullptr, *d_dinv = nullptr, *d_W = nullptr,
+         *d_cpart = nullptr, *d_spart = nullptr, *d_xwork = nullptr, *d_xh = nullptr;
+  unsigned long long* d_gmax = nullptr;
+  int *d_bad = nullptr, *d_info = nullptr;
+  unsigned* d_flow = nullptr;
+  size_t n_pairs = 0;
+  ~BaSession() {
+    delete db;
+    if (arena) hipFree(arena);
+  }
+};
+
+// pr == nullptr (graph sessions only): the values already on the device are solved as they are.  download: write the
+// result back into pr->cam_pose / pr->point_xyz.
+gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out,
+                 bool download) {
   gh_ba_options opt;
   gh_ba_default_options(&opt);
   if (opt_in) opt = *opt_in;
   gh_ba_summary local_sum;
   gh_ba_summary* sum = sum_out ? sum_out : &local_sum;
   memset(sum, 0, sizeof(*sum));
-  const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
+  GH_CHECK_ARG(ctx, pr != nullptr || S.ready);
+  const int nc = pr ? pr->n_cams : S.nc, np = pr ? pr->n_points : S.np, no = pr ? pr->n_obs : S.no;
   GH_CHECK_ARG(ctx, nc >= 1 && np >= 0 && no >= 0 && nc <= (1 << 24));
-  GH_CHECK_ARG(ctx, pr->cam_pose && pr->cam_dof && (np == 0 || pr->point_xyz));
-  GH_CHECK_ARG(ctx, no == 0 || (pr->obs_cam && pr->obs_point && pr->obs_xy));
-  for (int k = 0; k < no; ++k)
-    GH_CHECK_ARG(ctx, pr->obs_cam[k] >= 0 && pr->obs_cam[k] < nc && pr->obs_point[k] >= 0 && pr->obs_point[k] < np);
+  if (pr) {
+    GH_CHECK_ARG(ctx, pr->cam_pose && pr->cam_dof && (np == 0 || pr->point_xyz));
+    GH_CHECK_ARG(ctx, no == 0 || (pr->obs_cam && pr->obs_point && pr->obs_xy));
+  }
+  if (S.ready) {  // a resident graph: same topology by contract, checked as far as the sizes go
+    GH_CHECK_ARG(ctx, nc == S.nc && np == S.np && no == S.no && (opt.deterministic != 0) == (S.deterministic != 0));
+    GH_CHECK_ARG(ctx, !pr || ((pr->obs_info != nullptr) == S.has_info && (pr->point_free != nullptr) == S.has_pfree));
+  } else {
+    for (int k = 0; k < no; ++k)
+      GH_CHECK_ARG(ctx, pr->obs_cam[k] >= 0 && pr->obs_cam[k] < nc && pr->obs_point[k] >= 0 && pr->obs_point[k] < np);
+  }
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   const int n = 6 * nc;
@@ -1407,10 +1454,12 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   // grow the arena, uploads after the lists as before).  With enough pool threads the staging is ours: the arrays lie back
   // to back on the device, four tasks copy a quarter of that image each into pinned memory and send it with one
   // asynchronous copy.
-  const size_t raw_bytes = 8 * ((size_t)nc * 7 * 2 + (size_t)np * 3 * 2 + (size_t)no * 2 + (pr->obs_info ? (size_t)no * 4 : 0)) +
+  const bool with_info = pr ? pr->obs_info != nullptr : S.has_info;
+  const size_t raw_bytes = 8 * ((size_t)nc * 7 * 2 + (size_t)np * 3 * 2 + (size_t)no * 2 + (with_info ? (size_t)no * 4 : 0)) +
                            4 * ((size_t)nc + 2 * (size_t)no) + (size_t)np + 16 * 256;
   const char* early_env = getenv("GSLAM_HIP_BA_EARLY_UPLOAD");  // "0": upload after the lists (A/B measurements)
-  bool early = ctx->ba_arena != nullptr && raw_bytes <= ctx->ba_arena_bytes && !(early_env && early_env[0] == '0');
+  DevBuf& db = *S.db;
+  bool early = !S.ready && *db.arena != nullptr && raw_bytes <= *db.arena_bytes && !(early_env && early_env[0] == '0');
   constexpr size_t kStageOffset = 4096;  // the read-back block sits in front of the staging area
   Readback* rb = nullptr;
   char* stage = nullptr;
@@ -1420,10 +1469,28 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     rb = (Readback*)pp;
     stage = (char*)pp + kStageOffset;
   }
-  DevBuf db(ctx);
-  double *d_poses, *d_pts, *d_poses_new, *d_pts_new, *d_oxy, *d_oinfo = nullptr;
-  int32_t *d_dof, *d_ocam, *d_opt, *d_pstart, *d_plist, *d_cstart, *d_clist;
-  uint8_t* d_pfree = nullptr;
+  double *&d_poses = S.d_poses, *&d_pts = S.d_pts, *&d_poses_new = S.d_poses_new, *&d_pts_new = S.d_pts_new, *&d_oxy = S.d_oxy,
+         *&d_oinfo = S.d_oinfo;
+  int32_t *&d_dof = S.d_dof, *&d_ocam = S.d_ocam, *&d_opt = S.d_opt, *&d_pstart = S.d_pstart, *&d_plist = S.d_plist,
+          *&d_cstart = S.d_cstart, *&d_clist = S.d_clist;
+  uint8_t*& d_pfree = S.d_pfree;
+  CamChunks& CC = S.CC;
+  SchurBlocks& SB = S.SB;
+  int &nchunks = S.nchunks, &nsegs = S.nsegs, &nblocks = S.nblocks;
+  bool& device_pairs = S.device_pairs;
+  double *&d_Hcc = S.d_Hcc, *&d_gc = S.d_gc, *&d_Hpp = S.d_Hpp, *&d_gp = S.d_gp, *&d_Hpi = S.d_Hpi, *&d_S = S.d_S, *&d_dc = S.d_dc,
+         *&d_dp = S.d_dp, *&d_partial = S.d_partial, *&d_out = S.d_out, *&d_work = S.d_work, *&d_dinv = S.d_dinv, *&d_W = S.d_W,
+         *&d_cpart = S.d_cpart, *&d_spart = S.d_spart, *&d_xwork = S.d_xwork, *&d_xh = S.d_xh;
+  unsigned long long*& d_gmax = S.d_gmax;
+  int *&d_bad = S.d_bad, *&d_info = S.d_info;
+  unsigned*& d_flow = S.d_flow;
+  const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
+  // (first run only, kept for the verbose / check paths below)
+  std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
+  bool pairs_check = false;
+  SchurBlocks SB_host = SB;
+  double t_csr = t_begin, t_lists = t_begin;
+  if (!S.ready) {  // ================================================================ set-up (once per topology)
   struct RawPiece {
     char* dst;
     const char* src;
@@ -1476,8 +1543,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     gh_status part_status[U] = {GH_OK, GH_OK, GH_OK, GH_OK};
     if (early && teams) {
       GH_TRY(raw_arrays(false));
-      early = !raw_pieces.empty() && raw_pieces.front().dst >= (char*)ctx->ba_arena &&
-              raw_pieces.back().dst + raw_pieces.back().bytes <= (char*)ctx->ba_arena + ctx->ba_arena_bytes;
+      early = !raw_pieces.empty() && raw_pieces.front().dst >= (char*)*db.arena &&
+              raw_pieces.back().dst + raw_pieces.back().bytes <= (char*)*db.arena + *db.arena_bytes;
       if (!early) db.used = 0;  // (cannot happen with an arena that holds raw_bytes; the plain path allocates again)
     }
     const int extra = early ? (teams ? U : 1) : 0;
@@ -1517,16 +1584,15 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
         !std::equal(clist.begin(), clist.begin() + no, l1.begin()))
       return gh_set_error(ctx, GH_ERR_NUMERIC, "index lists built by the pool teams differ from the serial lists");
   }
-  const double t_csr = now_ms();
+  t_csr = now_ms();
 
   // deterministic Schur: pair list sorted by destination block (built once; structure is iteration-invariant).  Large
   // graphs build it on the GPU (build_schur_pairs_device); GSLAM_HIP_BA_PAIRS=host keeps the host build, =check runs both
   // and compares them element for element (tests).
-  std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
   const char* pairs_env = getenv("GSLAM_HIP_BA_PAIRS");
   const bool want_pairs = opt.deterministic && no > 0;
-  const bool pairs_check = want_pairs && pairs_env && pairs_env[0] == 'c';
-  bool device_pairs = want_pairs && (no >= 20000 || pairs_check) && !(pairs_env && pairs_env[0] == 'h');
+  pairs_check = want_pairs && pairs_env && pairs_env[0] == 'c';
+  device_pairs = want_pairs && (no >= 20000 || pairs_check) && !(pairs_env && pairs_env[0] == 'h');
   size_t pairs_ub = 0, blocks_ub = 0;
   if (device_pairs) {
     for (int p = 0; p < np; ++p) pairs_ub += (size_t)(pstart[p + 1] - pstart[p]) * (size_t)(pstart[p + 1] - pstart[p]);
@@ -1535,8 +1601,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   }
   if (want_pairs && (!device_pairs || pairs_check))
     build_schur_pairs(pr, nc, pstart, plist, cstart, clist, pair_a, pair_b, bstart, bci, bcj);
-  int nblocks = (int)bci.size();
-  const double t_lists = now_ms();
+  nblocks = (int)bci.size();
+  t_lists = now_ms();
 
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
@@ -1550,7 +1616,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
                         (NO / kCamChunk + NC + 2) * (27 * 8 + 2 * 4) + (NC + 2) * 4 +
                         (std::max(pair_a.size(), pairs_ub) / kSchurSeg + std::max(bstart.size(), blocks_ub) + 2) * (42 * 8 + 4) +
                         (bstart.size() + 2) * 4 + 16 * 256;
-    if (early && need > ctx->ba_arena_bytes) {  // the arena has to grow: what went up early goes up again
+    if (early && need > *db.arena_bytes) {  // the arena has to grow: what went up early goes up again
       early = false;
       db.used = 0;
     }
@@ -1578,9 +1644,9 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     for (int e = bstart[b]; e < bstart[b + 1]; e += kSchurSeg) seg_blk.push_back(b);
   }
   seg_first[nblocks] = (int32_t)seg_blk.size();
-  const int nchunks = (int)ch_cam.size();
-  int nsegs = (int)seg_blk.size();
-  CamChunks CC{nullptr, nullptr, nullptr, nchunks};
+  nchunks = (int)ch_cam.size();
+  nsegs = (int)seg_blk.size();
+  CC = CamChunks{nullptr, nullptr, nullptr, nchunks};
   {
     int32_t *d_cc, *d_cq, *d_cf;
     GH_TRY(db.upload(&d_cc, (const int32_t*)ch_cam.data(), ch_cam.size()));
@@ -1589,8 +1655,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
     CC = CamChunks{d_cc, d_cq, d_cf, nchunks};
   }
   const double t_u2 = now_ms();
-  SchurBlocks SB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nblocks, nsegs};
-  SchurBlocks SB_host = SB;  // (check mode: the host-built tables beside the device-built ones)
+  SB = SchurBlocks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nblocks, nsegs};
+  SB_host = SB;  // (check mode: the host-built tables beside the device-built ones)
   if (device_pairs) {
     const double tq0 = now_ms();
     GH_TRY(build_schur_pairs_device(ctx, db, nc, no, pairs_ub, blocks_ub, d_ocam, d_opt, d_pstart, d_plist, d_cstart, d_clist,
@@ -1618,10 +1684,6 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   if (getenv("GSLAM_HIP_BA_TIMING"))
     fprintf(stderr, "[gh_ba] upload phase: reserve %.2f, index lists up %.2f, chunk tables %.2f, pair lists %.2f ms\n", t_u0 - t_lists,
             t_u1 - t_u0, t_u2 - t_u1, t_u3 - t_u2);
-  double *d_Hcc, *d_gc, *d_Hpp, *d_gp, *d_Hpi, *d_S, *d_dc, *d_dp, *d_partial, *d_out, *d_work, *d_dinv, *d_W, *d_cpart, *d_spart, *d_xwork, *d_xh;
-  unsigned long long* d_gmax;
-  int *d_bad, *d_info;
-  const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
   GH_TRY(db.alloc(&d_Hcc, (size_t)nc * 36));
   GH_TRY(db.alloc(&d_gc, (size_t)n));
   GH_TRY(db.alloc(&d_Hpp, (size_t)np * 9));
@@ -1635,7 +1697,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_W, (size_t)no * 18));
   GH_TRY(db.alloc(&d_xwork, (size_t)2 * 64 * (n + 1)));
   GH_TRY(db.alloc(&d_xh, (size_t)gh_div_up(n, 64) * 64));
-  unsigned* d_flow = nullptr;  // state of the single-launch factorisation (null when the shape does not fit it)
+  d_flow = nullptr;  // state of the single-launch factorisation (null when the shape does not fit it)
   if (const size_t words = gh_potrf_flow_words(ctx, n, 1)) GH_TRY(db.alloc(&d_flow, words));
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
   d_spart = nullptr;
@@ -1645,6 +1707,24 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(db.alloc(&d_gmax, 1));
   GH_TRY(db.alloc(&d_bad, 1));
   GH_TRY(db.alloc(&d_info, 1));
+  S.nc = nc;
+  S.np = np;
+  S.no = no;
+  S.deterministic = opt.deterministic;
+  S.has_info = pr->obs_info != nullptr;
+  S.has_pfree = pr->point_free != nullptr;
+  } else if (pr) {  // ============================================================== resident graph: new values only
+    auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
+      if (bytes) GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return GH_OK;
+    };
+    GH_TRY(up(d_poses, pr->cam_pose, (size_t)nc * 7 * 8));
+    GH_TRY(up(d_pts, pr->point_xyz, (size_t)np * 3 * 8));
+    GH_TRY(up(d_dof, pr->cam_dof, (size_t)nc * 4));
+    if (pr->point_free) GH_TRY(up(d_pfree, pr->point_free, (size_t)np));
+    GH_TRY(up(d_oxy, pr->obs_xy, (size_t)no * 16));
+    if (pr->obs_info) GH_TRY(up(d_oinfo, pr->obs_info, (size_t)no * 32));
+  }
 
   Problem P{nc, np, no, d_poses, d_dof, d_pts, d_pfree, d_ocam, d_opt, d_oxy, d_oinfo,
             d_pstart, d_plist, d_cstart, d_clist, opt.huber_delta};
@@ -1665,7 +1745,7 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   GH_TRY(eval_cost(d_poses, d_pts, 0));
   h2[0] = rb->cost;
   h2[1] = rb->model;
-  if (device_pairs) {  // the lists were built behind the uploads; their sizes came back with the first cost
+  if (device_pairs && !S.ready) {  // the lists were built behind the uploads; their sizes came back with the first cost
     {
       if (pairs_check) {
         auto same = [&](const int32_t* dev, const std::vector<int32_t>& host, size_t count, const char* what) -> gh_status {
@@ -1697,11 +1777,15 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
       SB.nsegs = nsegs;
     }
     GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
+    S.n_pairs = (size_t)rb->pair_counts[0];
+  } else if (!S.ready) {
+    S.n_pairs = pair_a.size();
   }
   if (opt.verbose)
-    fprintf(stderr, "[gh_ba] setup: index lists %.2f ms (csr %.2f; %zu Schur pairs, %d blocks), upload %.2f ms, first cost %.2f ms\n",
-            t_lists - t_begin, t_csr - t_begin, device_pairs ? (size_t)rb->pair_counts[0] : pair_a.size(), nblocks,
-            t_upload - t_lists, now_ms() - t_upload);
+    fprintf(stderr, "[gh_ba] %s: index lists %.2f ms (csr %.2f; %zu Schur pairs, %d blocks), upload %.2f ms, first cost %.2f ms\n",
+            S.ready ? "resident graph" : "setup", t_lists - t_begin, t_csr - t_begin, S.n_pairs, nblocks, t_upload - t_lists,
+            now_ms() - t_upload);
+  S.ready = true;
   double cost = h2[0];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;
@@ -1867,15 +1951,108 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   sum->termination = term;
   sum->final_cost = cost;
   const double t_loop_end = now_ms();
-  GH_HIP(ctx, hipMemcpyAsync(pr->cam_pose, d_poses, (size_t)nc * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (np > 0)
-    GH_HIP(ctx, hipMemcpyAsync(pr->point_xyz, d_pts, (size_t)np * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (download && pr) {
+    GH_HIP(ctx, hipMemcpyAsync(pr->cam_pose, d_poses, (size_t)nc * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (np > 0)
+      GH_HIP(ctx, hipMemcpyAsync(pr->point_xyz, d_pts, (size_t)np * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   sum->total_ms = now_ms() - t_begin;
   if (getenv("GSLAM_HIP_BA_TIMING"))
     fprintf(stderr, "[gh_ba] whole solve %.2f ms: lists + early upload %.2f, to the first cost %.2f, first cost %.2f, iterations %.2f, result download %.2f\n",
             sum->total_ms, t_lists - t_begin, t_upload - t_lists, t_loop - t_upload, t_loop_end - t_loop, now_ms() - t_loop_end);
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;
+}
+
+}  // namespace
+
+extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
+  if (!ctx || !pr) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  BaSession S;
+  S.db = new (std::nothrow) DevBuf(ctx);
+  if (!S.db) return GH_ERR_NOMEM;
+  return ba_run(ctx, S, pr, opt_in, sum_out, true);
+}
+
+// ---------------------------------------------------------------- device-resident graph across solves
+struct gh_ba_graph {
+  gh_ctx* ctx = nullptr;
+  BaSession S;
+};
+
+extern "C" gh_status gh_ba_graph_create(gh_ctx* ctx, const gh_ba_problem* problem, const gh_ba_options* options,
+                                        gh_ba_graph** out) {
+  if (!ctx || !problem || !out) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  *out = nullptr;
+  gh_ba_graph* g = new (std::nothrow) gh_ba_graph();
+  if (!g) return GH_ERR_NOMEM;
+  g->ctx = ctx;
+  g->S.db = new (std::nothrow) DevBuf(ctx, &g->S.arena, &g->S.arena_bytes);
+  if (!g->S.db) {
+    delete g;
+    return GH_ERR_NOMEM;
+  }
+  gh_ba_options o;
+  gh_ba_default_options(&o);
+  if (options) o = *options;
+  o.max_iterations = 0;  // set-up only: lists, tables, uploads, the initial cost
+  gh_ba_summary sum;
+  gh_ba_problem pr = *problem;
+  const gh_status st = ba_run(ctx, g->S, &pr, &o, &sum, false);
+  if (st != GH_OK) {
+    delete g;
+    return st;
+  }
+  *out = g;
+  return GH_OK;
+}
+
+extern "C" void gh_ba_graph_destroy(gh_ba_graph* g) {
+  if (!g) return;
+  GH_ENTER(g->ctx);
+  hipStreamSynchronize(g->ctx->stream);
+  delete g;
+}
+
+extern "C" gh_status gh_ba_graph_update(gh_ba_graph* g, const double* cam_pose, const double* point_xyz, const double* obs_xy,
+                                        const double* obs_info, const int32_t* cam_dof, const uint8_t* point_free) {
+  if (!g) return GH_ERR_ARG;
+  gh_ctx* ctx = g->ctx;
+  GH_ENTER(ctx);
+  BaSession& S = g->S;
+  GH_CHECK_ARG(ctx, S.ready && (obs_info == nullptr || S.has_info) && (point_free == nullptr || S.has_pfree));
+  auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
+    if (src && bytes) GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GH_OK;
+  };
+  GH_TRY(up(S.d_poses, cam_pose, (size_t)S.nc * 56));
+  GH_TRY(up(S.d_pts, point_xyz, (size_t)S.np * 24));
+  GH_TRY(up(S.d_oxy, obs_xy, (size_t)S.no * 16));
+  GH_TRY(up(S.d_oinfo, obs_info, (size_t)S.no * 32));
+  GH_TRY(up(S.d_dof, cam_dof, (size_t)S.nc * 4));
+  GH_TRY(up(S.d_pfree, point_free, (size_t)S.np));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays may be pageable and freed on return
+  return GH_OK;
+}
+
+extern "C" gh_status gh_ba_graph_solve(gh_ba_graph* g, const gh_ba_options* options, gh_ba_summary* summary) {
+  if (!g) return GH_ERR_ARG;
+  GH_ENTER(g->ctx);
+  return ba_run(g->ctx, g->S, nullptr, options, summary, false);
+}
+
+extern "C" gh_status gh_ba_graph_read(gh_ba_graph* g, double* cam_pose, double* point_xyz) {
+  if (!g) return GH_ERR_ARG;
+  gh_ctx* ctx = g->ctx;
+  GH_ENTER(ctx);
+  if (cam_pose)
+    GH_HIP(ctx, hipMemcpyAsync(cam_pose, g->S.d_poses, (size_t)g->S.nc * 56, hipMemcpyDeviceToHost, ctx->stream));
+  if (point_xyz && g->S.np > 0)
+    GH_HIP(ctx, hipMemcpyAsync(point_xyz, g->S.d_pts, (size_t)g->S.np * 24, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
 }
 
 // Pose-only optimisation = the same solver on a 1-camera graph with every point fixed.

@@ -143,6 +143,11 @@ SIGNATURES = {
     "gh_triangulate": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "gh_ba_default_options": (None, [C.POINTER(BaOptions)]),
     "gh_ba_solve": (C.c_int, [_vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
+    "gh_ba_graph_create": (C.c_int, [_vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(_vp)]),
+    "gh_ba_graph_destroy": (None, [_vp]),
+    "gh_ba_graph_update": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gh_ba_graph_solve": (C.c_int, [_vp, C.POINTER(BaOptions), C.POINTER(BaSummary)]),
+    "gh_ba_graph_read": (C.c_int, [_vp, _vp, _vp]),
     "gh_ba_pnp": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, C.POINTER(BaOptions), _vp, C.POINTER(BaSummary)]),
     "gh_potrf_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, C.POINTER(_i)]),
 }

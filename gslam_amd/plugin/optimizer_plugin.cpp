@@ -3,7 +3,8 @@
 // Drop-in at GSLAM's own boundary: exports `createOptimizerInstance` through GSLAM_REGISTER_OPTIMIZER
 // (GSLAM/core/Optimizer.h:42-51) so that GSLAM::Optimizer::create() (:234-248, default plugin name
 // "libgslam_optimizer") loads it with no change to the host.  Implements
-//   optimize(BundleGraph&)   (:229)      -> gh_ba_solve   (mappoint bundle adjustment, SE3 keyframes)
+//   optimize(BundleGraph&)   (:229)      -> gh_ba_graph_* (mappoint bundle adjustment, SE3 keyframes); the graph stays in
+//                                           HBM between calls and is rebuilt only when its topology changes
 //   optimizePnP(...)         (:202-207)  -> gh_ba_pnp
 // Everything else keeps the base-class default `return false` ("unsupported"), as the interface allows.
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
@@ -22,6 +23,7 @@ class OptimizerHIP : public GSLAM::Optimizer {
  public:
   OptimizerHIP() : ctx_(nullptr), tried_(false) {}
   ~OptimizerHIP() override {
+    if (graph_) gh_ba_graph_destroy(graph_);
     if (ctx_) gh_ctx_destroy(ctx_);
   }
 
@@ -94,9 +96,37 @@ class OptimizerHIP : public GSLAM::Optimizer {
     o.max_iterations = _config.maxIterations;
     o.verbose = _config.verbose ? 1 : 0;
     gh_ba_summary s;
-    const gh_status st = gh_ba_solve(ctx_, &pr, &o, &s);
+    // A back end optimises the same window again and again (local BA after every keyframe): the device-resident graph is
+    // kept while the topology -- sizes, the (frame, point) pair of every observation, presence of information matrices --
+    // is the one of the previous call; then only the values travel.  OptimizerHIP.CacheGraph=0 solves one-shot.
+    gh_status st;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (svar.GetInt("OptimizerHIP.CacheGraph", 1) == 0) {
+        st = gh_ba_solve(ctx_, &pr, &o, &s);
+      } else {
+        const bool same = graph_ != NULL && any_info == graph_info_ && ocam == graph_ocam_ && opt == graph_opt_ &&
+                          nc == graph_nc_ && np == graph_np_;
+        if (same) {
+          st = gh_ba_graph_update(graph_, pose.data(), xyz.data(), oxy.data(), any_info ? info.data() : NULL, dof.data(),
+                                  pfree.data());
+          ++graph_hits_;
+        } else {
+          if (graph_) gh_ba_graph_destroy(graph_);
+          graph_ = NULL;
+          st = gh_ba_graph_create(ctx_, &pr, &o, &graph_);
+          if (st == GH_OK) {
+            graph_ocam_ = ocam; graph_opt_ = opt; graph_nc_ = nc; graph_np_ = np; graph_info_ = any_info;
+          } else {
+            graph_ = NULL;
+          }
+        }
+        if (st == GH_OK) st = gh_ba_graph_solve(graph_, &o, &s);
+        if (st == GH_OK) st = gh_ba_graph_read(graph_, pose.data(), xyz.data());
+      }
+    }
     if (st != GH_OK) {
-      LOG(ERROR) << "OptimizerHIP: gh_ba_solve failed (" << st << "): " << gh_last_error(ctx_);
+      LOG(ERROR) << "OptimizerHIP: bundle adjustment failed (" << st << "): " << gh_last_error(ctx_);
       return false;
     }
     if (_config.verbose)
@@ -167,6 +197,11 @@ class OptimizerHIP : public GSLAM::Optimizer {
   gh_ctx* ctx_;
   bool tried_;
   std::mutex mu_;
+  // device-resident graph of the previous optimize() and the topology it was built for
+  gh_ba_graph* graph_ = NULL;
+  std::vector<int32_t> graph_ocam_, graph_opt_;
+  size_t graph_nc_ = 0, graph_np_ = 0, graph_hits_ = 0;
+  bool graph_info_ = false;
 };
 
 }  // namespace

@@ -86,6 +86,14 @@ static int run_ba(const std::string& dir, const char* in, const char* out, doubl
     g.mappointObserves[k] = e;
   }
   if (zero_z_obs >= 0 && zero_z_obs < no) g.mappointObserves[zero_z_obs].measurement.z = 0;  // a caller bug: must fail
+  if (getenv("GSLAM_HOST_WARM_GRAPH")) {
+    // a back end re-optimises the same window: a first call on a copy with other values leaves the plugin's resident
+    // graph behind, the checked call below then goes through the update path (same topology, new values)
+    BundleGraph warm = g;
+    for (size_t i = 0; i < warm.mappoints.size(); ++i) warm.mappoints[i].first = warm.mappoints[i].first + Point3d(0.01, -0.02, 0.015);
+    const bool okw = opt_ptr->optimize(warm);
+    std::cout << "warm_optimize=" << okw << std::endl;
+  }
   const bool ok = opt_ptr->optimize(g);
   // sum of squared reprojection errors at the result through the reference's OWN SIM3 algebra (scale included):
   // X_c = T_wc^-1 X_w  (GSLAM/core/SIM3.h:120-131)

@@ -404,6 +404,26 @@ typedef struct gh_ba_summary {
 gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* problem, const gh_ba_options* options,
                       gh_ba_summary* summary);
 
+/* Device-resident graph across solves.  A windowed SLAM back end calls Optimizer::optimize (GSLAM/core/Optimizer.h:229)
+ * every few keyframes on a graph whose TOPOLOGY (which camera observes which point) changes far less often than its
+ * values; gh_ba_solve rebuilds the index lists, the Schur pair lists and the chunk tables and uploads every array each
+ * time (1.1-2.4 ms at C4 against 12 x 1.0 ms of iterations).  A gh_ba_graph keeps all of that in HBM:
+ *   gh_ba_graph_create   validates + uploads the problem, builds the lists and tables (what gh_ba_solve does before its
+ *                        first iteration).  options->deterministic is fixed here (it decides whether pair lists exist).
+ *   gh_ba_graph_update   new VALUES for the same topology; any pointer may be NULL = unchanged.  obs_info / point_free
+ *                        can only be updated if the graph was created with them.
+ *   gh_ba_graph_solve    LM iterations on the resident state (same algorithm, same results as gh_ba_solve on the same
+ *                        values); the state stays on the device: consecutive solves continue from the last accepted one.
+ *   gh_ba_graph_read     cam_pose (n_cams x 7) / point_xyz (n_points x 3) back to the host; either may be NULL.
+ * The Optimizer plugin caches one graph keyed on the topology of the BundleGraph it is given. */
+typedef struct gh_ba_graph gh_ba_graph;
+gh_status gh_ba_graph_create(gh_ctx* ctx, const gh_ba_problem* problem, const gh_ba_options* options, gh_ba_graph** out);
+void gh_ba_graph_destroy(gh_ba_graph* graph);
+gh_status gh_ba_graph_update(gh_ba_graph* graph, const double* cam_pose, const double* point_xyz, const double* obs_xy,
+                             const double* obs_info, const int32_t* cam_dof, const uint8_t* point_free);
+gh_status gh_ba_graph_solve(gh_ba_graph* graph, const gh_ba_options* options, gh_ba_summary* summary);
+gh_status gh_ba_graph_read(gh_ba_graph* graph, double* cam_pose, double* point_xyz);
+
 /* Pose-only (motion-only BA) on 3D-2D matches: pose = T_wc 7 doubles in/out;
  * information_out (36 doubles, row-major 6x6 J^T J at the solution) may be NULL. */
 gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy, int n, double* pose,

@@ -273,3 +273,75 @@ def test_potrf_solve_large_residual_property(ctx, n):
     Lt = torch.triu(L)  # row-major view of the column-major lower factor is its transpose
     rec = Lt.T @ Lt
     assert float((rec - A).abs().max() / A.abs().max()) <= 1e-12
+
+
+def test_resident_graph_equals_one_shot_solves(ctx, oracle):
+    """gh_ba_graph_*: create once, then (a) a solve equals gh_ba_solve on the same problem bit for bit, (b) two solves of
+    6 iterations continue where one of 12 would be (same trust-region restart aside: compared against the oracle run the
+    same way), (c) new values through update() on the same topology equal a fresh one-shot solve of those values, and
+    (d) a second graph on the same context does not disturb the first (own arenas)."""
+    from gslam_amd import ba
+    g = make_graph(20, 800, n_obs_per_point=5, seed=11)
+    g["point_free"] = np.ones(800, np.uint8)
+    g["point_free"][:7] = 0
+    opts = ba.default_options(max_iterations=15)
+    p1, x1, s1, st1 = ba.solve(ctx, g, opts)
+    G = ba.Graph(ctx, g, opts)
+    sg, stg = G.solve(opts)
+    pg, xg = G.read()
+    assert stg == st1 == 0 and sg.iterations == s1.iterations and sg.final_cost == s1.final_cost
+    assert pg.tobytes() == p1.tobytes() and xg.tobytes() == x1.tobytes()
+    # (c) new values, same topology: a noisier start
+    rng = np.random.default_rng(3)
+    g2 = dict(g)
+    g2["cam_pose"] = g["cam_pose"].copy()
+    g2["cam_pose"][1:, 4:] += rng.normal(size=(19, 3)) * 0.02
+    g2["point_xyz"] = g["point_xyz"] + rng.normal(size=g["point_xyz"].shape) * 0.03
+    g2["obs_xy"] = g["obs_xy"] + rng.normal(size=g["obs_xy"].shape) * 1e-4
+    other = ba.Graph(ctx, make_graph(9, 200, n_obs_per_point=4, seed=5), opts)  # (d) a neighbour on the same context
+    other.solve(opts)
+    G.update(cam_pose=g2["cam_pose"], point_xyz=g2["point_xyz"], obs_xy=g2["obs_xy"])
+    s2g, _ = G.solve(opts)
+    p2g, x2g = G.read()
+    p2, x2, s2, _ = ba.solve(ctx, g2, opts)
+    assert s2g.iterations == s2.iterations and s2g.final_cost == s2.final_cost
+    assert p2g.tobytes() == p2.tobytes() and x2g.tobytes() == x2.tobytes()
+    eo = oracle.ba_solve(g2, oracle_lib.ba_options(max_iterations=15), threads=4)
+    assert eo[2].iterations == s2g.iterations and np.abs(p2g - eo[0]).max() <= STATE_ATOL
+    # (b) continuing on the resident state: 2 x 6 iterations from the original values == the oracle run the same way
+    G.update(cam_pose=g["cam_pose"], point_xyz=g["point_xyz"], obs_xy=g["obs_xy"])
+    o6 = ba.default_options(max_iterations=6)
+    G.solve(o6)
+    sB, _ = G.solve(o6)
+    pB, xB = G.read()
+    e1 = oracle.ba_solve(g, oracle_lib.ba_options(max_iterations=6), threads=4)
+    gmid = dict(g)
+    gmid["cam_pose"], gmid["point_xyz"] = e1[0], e1[1]
+    e2 = oracle.ba_solve(gmid, oracle_lib.ba_options(max_iterations=6), threads=4)
+    assert sB.iterations == e2[2].iterations and abs(sB.final_cost - e2[2].final_cost) <= COST_RTOL * e2[2].final_cost
+    assert np.abs(pB - e2[0]).max() <= STATE_ATOL and np.abs(xB - e2[1]).max() <= STATE_ATOL
+    other.close()
+    G.close()
+
+
+def test_resident_graph_c4_resolve_rate(ctx):
+    """C4-sized graph kept on the device: re-solves skip the list building and the uploads."""
+    import time
+    from gslam_amd import ba
+    g = make_graph(500, 50000, n_obs_per_point=6, seed=1)
+    opts = ba.default_options(max_iterations=12)
+    ba.solve(ctx, g, opts)
+    t0 = time.perf_counter()
+    p1, x1, s1, _ = ba.solve(ctx, g, opts)
+    t_one = time.perf_counter() - t0
+    G = ba.Graph(ctx, g, opts)
+    G.solve(opts)
+    G.update(cam_pose=g["cam_pose"], point_xyz=g["point_xyz"])
+    t0 = time.perf_counter()
+    sg, _ = G.solve(opts)
+    t_res = time.perf_counter() - t0
+    pg, xg = G.read()
+    assert sg.iterations == s1.iterations and pg.tobytes() == p1.tobytes() and xg.tobytes() == x1.tobytes()
+    print(f"C4 one-shot {t_one * 1e3:.2f} ms, resident {t_res * 1e3:.2f} ms for {sg.iterations} iterations")
+    assert t_res < t_one
+    G.close()

@@ -26,8 +26,9 @@ def _need_host():
                     "container (they travel to the GPU box as built artefacts)")
 
 
-def _run(args):
+def _run(args, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env["LD_LIBRARY_PATH"] = LIBDIR + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([HOST] + [str(a) for a in args], capture_output=True, text=True, timeout=300, env=env)
     return r
@@ -57,6 +58,27 @@ def test_optimizer_plugin_optimize_matches_oracle(tmp_path, oracle):
     po, xo, so, _ = oracle.ba_solve(g, oracle_lib.ba_options(max_iterations=30))
     assert np.abs(poses - po).max() < 1e-7 and np.abs(pts - xo).max() < 1e-7
     assert np.array_equal(pts[:5], g["point_xyz"][:5]) and np.array_equal(poses[0], g["cam_pose"][0])
+
+
+def test_optimizer_plugin_resident_graph_update_path(tmp_path, oracle):
+    """The plugin keeps the graph on the device between optimize() calls (gh_ba_graph_*): a first call on the same
+    topology with other values, then the checked call through the update path, must equal the oracle / the one-shot path."""
+    _need_host()
+    g = make_graph(10, 200, n_obs_per_point=4, seed=21)
+    inp = tmp_path / "graph.bin"
+    nc, npt = 10, 200
+    _write_graph(inp, g, 30, 0.01)
+    res = []
+    for warm in (False, True):
+        out = tmp_path / f"out_{int(warm)}.bin"
+        r = _run(["ba", LIBDIR, inp, out], {"GSLAM_HOST_WARM_GRAPH": "1"} if warm else None)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("warm_optimize=1" in r.stdout) == warm
+        raw = open(out, "rb").read()
+        res.append((np.frombuffer(raw, np.float64, nc * 7, 4).copy(), np.frombuffer(raw, np.float64, npt * 3, 4 + nc * 56).copy()))
+    assert res[0][0].tobytes() == res[1][0].tobytes() and res[0][1].tobytes() == res[1][1].tobytes()
+    po, xo, so, _ = oracle.ba_solve(g, oracle_lib.ba_options(max_iterations=30))
+    assert np.abs(res[1][0].reshape(nc, 7) - po).max() < 1e-7 and np.abs(res[1][1].reshape(npt, 3) - xo).max() < 1e-7
 
 
 def _write_graph(path, g, max_it, huber):
@@ -247,7 +269,7 @@ def test_estimator_plugin_through_estimator_create(tmp_path, oracle, model):
     ok, nm = struct.unpack("2i", raw[:8])
     m = np.frombuffer(raw, np.float64, 9, 8)
     mask = np.frombuffer(raw, np.uint8, nm, 8 + 72)
-    em, emask, ecnt = oracle.ransac(model, P, Q, thr, seed=1)
+    em, emask, ecnt, _ = oracle.ransac_conf(model, P, Q, thr, 0.99, seed=1)  # the host passes confidence 0.99
     ms = 6 if model == 1 else 9
     assert ok == 1 and nm == n and np.array_equal(mask, emask) and m[:ms].tobytes() == em[:ms].tobytes()
 
@@ -271,7 +293,7 @@ def test_estimator_plugin_remaining_solvers(tmp_path, oracle, model):
         ok, nm = struct.unpack("2i", raw[:8])
         m = np.frombuffer(raw, np.float64, 9, 8)
         mask = np.frombuffer(raw, np.uint8, nm, 8 + 72)
-        em, emask, _ = oracle.ransac(4, P, Q, thr, seed=1)
+        em, emask, _, _ = oracle.ransac_conf(4, P, Q, thr, 0.99, seed=1)
         assert ok == 1 and np.array_equal(mask, emask) and m.tobytes() == em[:9].tobytes()
         return
     if model == 8:
@@ -308,7 +330,7 @@ def test_estimator_plugin_remaining_solvers(tmp_path, oracle, model):
     ok, nm, nv = struct.unpack("3i", raw[:12])
     m = np.frombuffer(raw, np.float64, nv, 12)
     mask = np.frombuffer(raw, np.uint8, nm, 12 + 8 * nv)
-    em, emask, ecnt = oracle.ransac(model, P, Q, thr, seed=1)
+    em, emask, ecnt, _ = oracle.ransac_conf(model, P, Q, thr, 0.99, seed=1)  # the host passes confidence 0.99
     assert ok == 1 and np.array_equal(mask, emask)
     if model == 5:
         assert m.tobytes() == em[:8].tobytes()
