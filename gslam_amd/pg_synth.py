@@ -1,0 +1,86 @@
+"""Synthetic pose graphs for tests / bench: a camera trajectory (SIM3 keyframes T_wc) on a loop, odometry edges between
+neighbours, loop-closure edges across the loop, optional GPS priors.  Measurements follow GSLAM/core/Optimizer.h:127-148:
+SE3Edge / SIM3Edge measurement = S_first^-1 * S_second, GPSEdge measurement = SE3 of the frame."""
+import numpy as np
+
+
+def _qmul(a, b):
+    return np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2],
+                     a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+
+
+def _qrot(q, p):
+    u = 2.0 * np.cross(q[:3], p)
+    return p + q[3] * u + np.cross(q[:3], u)
+
+
+def sim3_mul(a, b):
+    return np.concatenate([_qmul(a[:4], b[:4]), a[4:7] + _qrot(a[:4], a[7] * b[4:7]), [a[7] * b[7]]])
+
+
+def sim3_inv(a):
+    qc = np.array([-a[0], -a[1], -a[2], a[3]])
+    return np.concatenate([qc, -(1.0 / a[7]) * _qrot(qc, a[4:7]), [1.0 / a[7]]])
+
+
+def _quat_from_rotvec(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.array([0.5 * w[0], 0.5 * w[1], 0.5 * w[2], 1.0])
+    return np.concatenate([np.sin(0.5 * th) * w / th, [np.cos(0.5 * th)]])
+
+
+def make_pose_graph(n_frames=40, n_loops=8, kind="sim3", seed=1, noise=0.0, perturb=0.05, scale_drift=0.0, gps_every=0,
+                    with_info=False):
+    """Returns (truth n x 8, start n x 8, dof n, problem dict for oracle_lib.pg_edges / gslam_amd.posegraph)."""
+    rng = np.random.default_rng(seed)
+    truth = np.zeros((n_frames, 8))
+    for i in range(n_frames):
+        a = 2 * np.pi * i / n_frames
+        pos = np.array([6 * np.cos(a), 6 * np.sin(a), 0.5 * np.sin(3 * a)])
+        q = _quat_from_rotvec(np.array([0.1 * np.sin(a), 0.15 * np.cos(2 * a), a + np.pi / 2]))
+        truth[i] = np.concatenate([q, pos, [1.0 if kind != "sim3" else np.exp(scale_drift * np.sin(a))]])
+
+    def rel(i, j):
+        m = sim3_mul(sim3_inv(truth[i]), truth[j])
+        if noise > 0:
+            d = rng.normal(size=7) * noise
+            m = sim3_mul(m, np.concatenate([_quat_from_rotvec(d[3:6]), d[:3], [np.exp(d[6] if kind == "sim3" else 0.0)]]))
+        return m
+
+    pairs = [(i, i + 1) for i in range(n_frames - 1)]
+    for k in range(n_loops):
+        i = int(rng.integers(0, n_frames // 3))
+        pairs.append((i, n_frames - 1 - int(rng.integers(0, n_frames // 3))))
+    pairs.append((n_frames - 1, 0))
+    first = np.array([p[0] for p in pairs], np.int32)
+    second = np.array([p[1] for p in pairs], np.int32)
+    meas = np.stack([rel(i, j) for i, j in pairs])
+    problem = {}
+
+    def spd(dim):
+        a = rng.normal(size=(dim, dim)) * 0.2
+        return (np.eye(dim) * (1.0 + rng.random()) + a @ a.T).reshape(-1)
+
+    if kind == "sim3":
+        problem["sim3"] = (first, second, meas, np.stack([spd(7) for _ in pairs]) if with_info else None)
+    else:
+        problem["se3"] = (first, second, meas[:, :7].copy(), np.stack([spd(6) for _ in pairs]) if with_info else None)
+    if kind == "mixed":  # half of the loop closures as SIM3 edges on top
+        h = len(pairs) // 2
+        problem["sim3"] = (first[h:], second[h:], meas[h:], None)
+    if gps_every:
+        fr = np.arange(0, n_frames, gps_every, dtype=np.int32)
+        gm = truth[fr, :7].copy()
+        if noise > 0:
+            gm[:, 4:7] += rng.normal(size=(len(fr), 3)) * noise
+        problem["gps"] = (fr, gm, np.stack([spd(6) for _ in fr]) if with_info else None)
+    start = truth.copy()
+    for i in range(1, n_frames):
+        d = rng.normal(size=7) * perturb
+        if kind != "sim3":
+            d[6] = 0.0
+        start[i] = sim3_mul(truth[i], np.concatenate([_quat_from_rotvec(d[3:6]), d[:3], [np.exp(d[6])]]))
+    dof = np.full(n_frames, 127 if kind in ("sim3", "mixed") else 63, np.int32)
+    dof[0] = 0  # gauge
+    return truth, start, dof, problem

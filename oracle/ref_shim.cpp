@@ -79,6 +79,31 @@ void ref_se3_apply(const double* a7, const double* p3, double* out3) {
   out3[0] = o.x; out3[1] = o.y; out3[2] = o.z;
 }
 
+// SIM3 algebra of the pose-graph / alignment oracle (GSLAM/core/SIM3.h:114-270).  Layout: qx qy qz qw tx ty tz s.
+static GSLAM::SIM3 sim3_from(const double* s8) {
+  return GSLAM::SIM3(GSLAM::SO3(s8[0], s8[1], s8[2], s8[3]), GSLAM::Point3d(s8[4], s8[5], s8[6]), s8[7]);
+}
+static void sim3_to(const GSLAM::SIM3& S, double* o8) {
+  auto r = S.get_rotation();
+  auto t = S.get_translation();
+  o8[0] = r.x; o8[1] = r.y; o8[2] = r.z; o8[3] = r.w;
+  o8[4] = t.x; o8[5] = t.y; o8[6] = t.z; o8[7] = S.get_scale();
+}
+void ref_sim3_exp(const double* mu7, double* out8) {
+  GSLAM::Vector<double, 7> m;
+  for (int i = 0; i < 7; ++i) m[i] = mu7[i];
+  sim3_to(GSLAM::SIM3::exp(m), out8);
+}
+void ref_sim3_log(const double* s8, double* mu7) {
+  auto l = sim3_from(s8).log();
+  for (int i = 0; i < 7; ++i) mu7[i] = l[i];
+}
+void ref_sim3_mul(const double* a8, const double* b8, double* out8) { sim3_to(sim3_from(a8) * sim3_from(b8), out8); }
+void ref_sim3_apply(const double* a8, const double* p3, double* out3) {
+  GSLAM::Point3d o = sim3_from(a8) * GSLAM::Point3d(p3[0], p3[1], p3[2]);
+  out3[0] = o.x; out3[1] = o.y; out3[2] = o.z;
+}
+
 int ref_sizeof_keypoint() { return (int)sizeof(GSLAM::KeyPoint); }
 int ref_sizeof_se3() { return (int)sizeof(GSLAM::SE3); }
 int ref_sizeof_sim3() { return (int)sizeof(GSLAM::SIM3); }

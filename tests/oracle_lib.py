@@ -99,6 +99,19 @@ class Reference:
     def se3_apply(self, a, p):
         return self._se3("ref_se3_apply", a, p, out_n=3)
 
+    # SIM3 (GSLAM/core/SIM3.h), layout qx qy qz qw tx ty tz s
+    def sim3_exp(self, mu):
+        return self._se3("ref_sim3_exp", mu, out_n=8)
+
+    def sim3_log(self, s):
+        return self._se3("ref_sim3_log", s, out_n=7)
+
+    def sim3_mul(self, a, b):
+        return self._se3("ref_sim3_mul", a, b, out_n=8)
+
+    def sim3_apply(self, a, p):
+        return self._se3("ref_sim3_apply", a, p, out_n=3)
+
 
 def load():
     return Oracle()
@@ -498,3 +511,107 @@ def _ransac_methods(cls):
 
 
 _ransac_methods(Oracle)
+
+
+# ---------------------------------------------------------------- pose graph / alignment (oracle/pg_oracle.c)
+def pg_edges(problem):
+    """Flatten {se3: (first, second, meas n x 7, info n x 36 | None), sim3: (.., meas n x 8, info n x 49 | None),
+    gps: (frame, meas n x 7, info n x 36 | None)} into the oracle's parallel arrays (type, i, j, meas 8, info 49 | None)."""
+    et, ei, ej, meas, infos = [], [], [], [], []
+    any_info = any(problem.get(k) is not None and problem[k][-1] is not None for k in ("se3", "sim3", "gps"))
+
+    def add(t, i, j, m, info, dim):
+        m8 = np.ones(8)
+        m8[:len(m)] = m
+        et.append(t); ei.append(i); ej.append(j); meas.append(m8)
+        if any_info:
+            L = np.zeros((7, 7))
+            L[:dim, :dim] = np.eye(dim) if info is None else np.asarray(info, np.float64).reshape(dim, dim)
+            infos.append(L.reshape(-1))
+
+    for key, t, dim in (("se3", 0, 6), ("sim3", 1, 7)):
+        if problem.get(key) is not None:
+            f, s, m, inf = problem[key]
+            for k in range(len(f)):
+                add(t, int(f[k]), int(s[k]), m[k], None if inf is None else inf[k], dim)
+    if problem.get("gps") is not None:
+        f, m, inf = problem["gps"]
+        for k in range(len(f)):
+            add(2, int(f[k]), -1, m[k], None if inf is None else inf[k], 6)
+    return (np.array(et, np.int32), np.array(ei, np.int32), np.array(ej, np.int32),
+            np.ascontiguousarray(np.array(meas, np.float64).reshape(-1, 8)),
+            np.ascontiguousarray(np.array(infos, np.float64)) if any_info else None)
+
+
+def _pg_methods(cls):
+    def sim3_exp(self, mu):
+        out = np.zeros(8)
+        self.lib.oracle_sim3_exp(_ptr(np.ascontiguousarray(mu, dtype=np.float64)), _ptr(out))
+        return out
+
+    def sim3_log(self, s):
+        out = np.zeros(7)
+        self.lib.oracle_sim3_log(_ptr(np.ascontiguousarray(s, dtype=np.float64)), _ptr(out))
+        return out
+
+    def sim3_mul(self, a, b):
+        out = np.zeros(8)
+        self.lib.oracle_sim3_mul(_ptr(np.ascontiguousarray(a, dtype=np.float64)), _ptr(np.ascontiguousarray(b, dtype=np.float64)),
+                                 _ptr(out))
+        return out
+
+    def sim3_inv(self, a):
+        out = np.zeros(8)
+        self.lib.oracle_sim3_inv(_ptr(np.ascontiguousarray(a, dtype=np.float64)), _ptr(out))
+        return out
+
+    def sim3_retract(self, s, delta):
+        out = np.zeros(8)
+        self.lib.oracle_sim3_retract(_ptr(np.ascontiguousarray(s, dtype=np.float64)),
+                                     _ptr(np.ascontiguousarray(delta, dtype=np.float64)), _ptr(out))
+        return out
+
+    def se3_log(self, pose):
+        out = np.zeros(6)
+        self.lib.oracle_se3_log(_ptr(np.ascontiguousarray(pose, dtype=np.float64)), _ptr(out))
+        return out
+
+    def pg_solve(self, frames, dof, problem, opts=None, threads=1):
+        """-> (frames n x 8, summary, status)."""
+        opts = opts or ba_options()
+        S = np.ascontiguousarray(frames, dtype=np.float64).copy()
+        d = np.ascontiguousarray(dof, dtype=np.int32)
+        et, ei, ej, meas, info = pg_edges(problem)
+        sm = BaSummary()
+        st = self.lib.oracle_pg_solve(len(S), _ptr(S), _ptr(d), len(et), _ptr(et), _ptr(ei), _ptr(ej), _ptr(meas),
+                                      _ptr(info) if info is not None else None, C.byref(opts), C.byref(sm), int(threads))
+        return S, sm, st
+
+    def pg_cost(self, frames, problem):
+        S = np.ascontiguousarray(frames, dtype=np.float64)
+        et, ei, ej, meas, info = pg_edges(problem)
+        self.lib.oracle_pg_cost.restype = C.c_double
+        return self.lib.oracle_pg_cost(len(S), _ptr(S), len(et), _ptr(et), _ptr(ei), _ptr(ej), _ptr(meas),
+                                       _ptr(info) if info is not None else None)
+
+    def pg_edge_residual(self, etype, si, sj, meas):
+        r = np.zeros(7)
+        m8 = np.ones(8)
+        m8[:len(meas)] = meas
+        dim = self.lib.oracle_pg_edge_residual(int(etype), _ptr(np.ascontiguousarray(si, dtype=np.float64)),
+                                               _ptr(np.ascontiguousarray(sj, dtype=np.float64)), _ptr(m8), _ptr(r))
+        return r[:dim]
+
+    def align_sim3(self, src, dst, dof=127):
+        """-> (ok, sim3 8, information 7 x 7, sum of squared residuals)."""
+        a = np.ascontiguousarray(src, dtype=np.float64)
+        b = np.ascontiguousarray(dst, dtype=np.float64)
+        out, info, ssq = np.zeros(8), np.zeros(49), C.c_double()
+        ok = self.lib.oracle_align_sim3(_ptr(a), _ptr(b), len(a), int(dof), _ptr(out), _ptr(info), C.byref(ssq))
+        return bool(ok), out, info.reshape(7, 7), ssq.value
+
+    for f in (sim3_exp, sim3_log, sim3_mul, sim3_inv, sim3_retract, se3_log, pg_solve, pg_cost, pg_edge_residual, align_sim3):
+        setattr(cls, f.__name__, f)
+
+
+_pg_methods(Oracle)

@@ -5,6 +5,7 @@ Run in the authoring container only (needs /root/reference); the outputs are com
   bf_reference.npz   q, t, idx1, d1 (float, as hamming32 returns), dmat — from
                      GSLAM::Vocabulary::DistanceFactory::hamming32 + the first-min scan.
   se3_reference.npz  exp/log/mul/inverse/apply samples of GSLAM::SE3 for pinning the BA pose algebra.
+  sim3_reference.npz exp/log/mul/apply samples of GSLAM::SIM3 for pinning the pose-graph / alignment algebra.
   bow_reference.npz  a synthetic .gbow image (k = 10, L = 3) loaded by the reference's own Vocabulary::load; word / node
                      ids, weights, BowVector, FeatureVector of Vocabulary::transform on 500 descriptors, a second
                      BowVector and the reference's score() between the two; plus all six scoring types on that pair.
@@ -47,6 +48,16 @@ def main():
     app = np.stack([ref.se3_apply(poses[i], pts[i]) for i in range(64)])
     np.savez_compressed(os.path.join(out, "se3_reference.npz"), xi=xi, poses=poses, logs=logs, muls=muls,
                         invs=invs, pts=pts, app=app)
+    # ---- SIM3 algebra of the pose-graph / alignment oracle: the reference's own exp / log / operator* / apply
+    mu = rng.normal(size=(64, 7)) * np.array([3, 3, 3, 0.6, 0.6, 0.6, 0.5])
+    mu[0, 3:6] *= 1e-4   # small rotation
+    mu[1, 6] = 0.02      # small (not tiny) log-scale; the reference loses digits below ~1e-6 ((s - 1) / sigma)
+    mu[2, 3:6] *= 4.0    # large rotation
+    sims = np.stack([ref.sim3_exp(m) for m in mu])
+    slogs = np.stack([ref.sim3_log(q) for q in sims])
+    smuls = np.stack([ref.sim3_mul(sims[i], sims[(i + 1) % 64]) for i in range(64)])
+    sapp = np.stack([ref.sim3_apply(sims[i], pts[i]) for i in range(64)])
+    np.savez_compressed(os.path.join(out, "sim3_reference.npz"), mu=mu, sims=sims, logs=slogs, muls=smuls, pts=pts, app=sapp)
     # ---- BoW: the reference's own Vocabulary::load / transform / score on a synthetic vocabulary image
     from gslam_amd import bow_synth
     k, L, seed, levelsup = 10, 3, 7, 1
