@@ -29,7 +29,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
                             double* xwork, unsigned* flow_state, bool store_diag, bool state_ready);
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
 size_t gh_potrf_flow_flag_words(int n, int extra_rows);
-std::mutex& gh_potrf_flow_mutex();
+std::mutex& gh_potrf_flow_mutex(int device);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
                                 bool xh_ready);
@@ -1861,7 +1861,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     }
     const double t_solve0 = now_ms();
     // (one single-launch factorisation at a time per process, until this iteration's synchronisation: see chol.hip)
-    std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(), std::defer_lock);
+    std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
     if (d_flow) flow_lock.lock();
     // The whole candidate step is enqueued without waiting for the factorisation flags (the kernels have no
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host

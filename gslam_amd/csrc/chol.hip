@@ -2022,9 +2022,12 @@ static int flow_groups(const gh_ctx* ctx, int n, int extra_rows) {
 
 // Two dataflow launches in flight on one GPU could each hold part of the CUs and wait for the rest for ever (until their
 // bounded waits expire): callers in this process take this lock from the launch to their next stream synchronisation.
-std::mutex& gh_potrf_flow_mutex() {
-  static std::mutex mu;
-  return mu;
+// The hazard is per device: solves on different GPUs of one process do not serialise on each other.  (Across PROCESSES
+// that share a GPU nothing protects; there the bounded waits expire, info > n comes back and the caller stays on the
+// launch-per-step path for the rest of its solve: gh_ba_solve.)
+std::mutex& gh_potrf_flow_mutex(int device) {
+  static std::mutex mu[64];
+  return mu[(unsigned)device & 63u];
 }
 
 static size_t flow_flag_words(size_t nb, size_t ntr) { return (ntr * nb + nb + ntr + 16 + 31) & ~(size_t)31; }
@@ -2236,7 +2239,7 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   double* xh = xwork + 2 * (size_t)NBI * n;
   unsigned* flow_state = flow_words ? (unsigned*)(xh + nblk * NBI) : nullptr;
   {
-    std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(), std::defer_lock);
+    std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
     if (flow_state) flow_lock.lock();
     GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state, true, false));
     GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

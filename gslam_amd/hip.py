@@ -55,6 +55,15 @@ class BaProblem(C.Structure):
                 ("obs_xy", C.c_void_p), ("obs_info", C.c_void_p)]
 
 
+class PgProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("frame_sim3", C.c_void_p), ("frame_dof", C.c_void_p),
+                ("n_se3", C.c_int32), ("se3_first", C.c_void_p), ("se3_second", C.c_void_p), ("se3_meas", C.c_void_p),
+                ("se3_info", C.c_void_p),
+                ("n_sim3", C.c_int32), ("sim3_first", C.c_void_p), ("sim3_second", C.c_void_p), ("sim3_meas", C.c_void_p),
+                ("sim3_info", C.c_void_p),
+                ("n_gps", C.c_int32), ("gps_frame", C.c_void_p), ("gps_meas", C.c_void_p), ("gps_info", C.c_void_p)]
+
+
 class BaOptions(C.Structure):
     _fields_ = [("huber_delta", C.c_double), ("max_iterations", C.c_int32), ("initial_radius", C.c_double),
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
@@ -149,6 +158,8 @@ SIGNATURES = {
     "gh_ba_graph_solve": (C.c_int, [_vp, C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "gh_ba_graph_read": (C.c_int, [_vp, _vp, _vp]),
     "gh_ba_pnp": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, C.POINTER(BaOptions), _vp, C.POINTER(BaSummary)]),
+    "gh_pg_solve": (C.c_int, [_vp, C.POINTER(PgProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
+    "gh_align_sim3": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "gh_potrf_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, C.POINTER(_i)]),
 }
 

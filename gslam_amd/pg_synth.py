@@ -32,7 +32,7 @@ def _quat_from_rotvec(w):
 
 def make_pose_graph(n_frames=40, n_loops=8, kind="sim3", seed=1, noise=0.0, perturb=0.05, scale_drift=0.0, gps_every=0,
                     with_info=False):
-    """Returns (truth n x 8, start n x 8, dof n, problem dict for oracle_lib.pg_edges / gslam_amd.posegraph)."""
+    """Returns (truth n x 8, start n x 8, dof n, problem dict in the layout gslam_amd.posegraph.solve takes)."""
     rng = np.random.default_rng(seed)
     truth = np.zeros((n_frames, 8))
     for i in range(n_frames):

@@ -359,6 +359,8 @@ gh_status gh_triangulate(gh_ctx* ctx, const double* ref2cur_pose, int pose_strid
 #define GH_KF_RY 16
 #define GH_KF_RZ 32
 #define GH_KF_SE3 63
+#define GH_KF_SCALE 64 /* UPDATE_KF_SCALE: only the pose-graph solver and gh_align_sim3 have a scale to update */
+#define GH_KF_SIM3 127
 
 typedef struct gh_ba_problem {
   int32_t n_cams, n_points, n_obs;
@@ -428,6 +430,41 @@ gh_status gh_ba_graph_read(gh_ba_graph* graph, double* cam_pose, double* point_x
  * information_out (36 doubles, row-major 6x6 J^T J at the solution) may be NULL. */
 gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy, int n, double* pose,
                     int dof, const gh_ba_options* options, double* information_out, gh_ba_summary* summary);
+
+/* ---- Pose graph: Optimizer::optimize(BundleGraph&) with se3Graph / sim3Graph / gpsGraph edges ---------------------------
+ * Data contract GSLAM/core/Optimizer.h:127-148,162-167: SE3Edge {firstId, secondId, measurement SE3_12 := SE3_1^-1 SE3_2,
+ * information 6x6}, SIM3Edge {.., SIM3_12 := SIM3_1^-1 SIM3_2, 7x7}, GPSEdge {frameId, SE3_gps := SE3_frame, 6x6};
+ * keyframes are SIM3 T_wc with KeyFrameEstimzationDOF masks incl. UPDATE_KF_SCALE.  The reference ships no solver; the
+ * specification is the header of oracle/pg_oracle.c: residual = log(M^-1 * S_first^-1 * S_second) (SE3 edges on the (R, t)
+ * part, GPS edges log(M^-1 * T_frame)), cost 1/2 sum r^T Lambda r, update S <- S * SIM3::exp(delta) restricted to the dof
+ * mask, central-difference Jacobians, Levenberg-Marquardt on the dense normal equations with the trust-region strategy of
+ * gh_ba_solve (options / summary are shared; huber_delta and deterministic are not used: the assembly is always
+ * deterministic).  Arrays: frame_sim3 n_frames x 8 [qx qy qz qw tx ty tz s] (in/out); *_meas n x 7 (SE3, GPS:
+ * [qx qy qz qw tx ty tz]) or n x 8 (SIM3); *_info row-major 6x6 / 7x7 per edge, NULL = identity. */
+typedef struct gh_pg_problem {
+  int32_t n_frames;
+  double* frame_sim3;
+  const int32_t* frame_dof; /* GH_KF_* bits; 0 = fixed (at least one frame should be: the gauge) */
+  int32_t n_se3;
+  const int32_t *se3_first, *se3_second;
+  const double *se3_meas, *se3_info;
+  int32_t n_sim3;
+  const int32_t *sim3_first, *sim3_second;
+  const double *sim3_meas, *sim3_info;
+  int32_t n_gps;
+  const int32_t* gps_frame;
+  const double *gps_meas, *gps_info;
+} gh_pg_problem;
+gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* problem, const gh_ba_options* options, gh_ba_summary* summary);
+
+/* 3-D alignment dst_k ~ s R src_k + t over n correspondences (n x 3 doubles each), Horn's closed form: what
+ * Optimizer::optimizeICP (3D-3D correspondences, Optimizer.h:210-217) and Optimizer::fitSim3 (translations of two
+ * synchronised trajectories, :220-225) compute.  dof & GH_KF_SCALE decides whether s is estimated (else s = 1).
+ * sim3_out 8 doubles [qx qy qz qw tx ty tz s]; information_out (49 doubles, may be NULL) = J^T J of the residuals
+ * dst - S exp(delta) src at the solution, rows / columns of masked dof zero; ssq_out (may be NULL) = sum of squared
+ * residuals; *ok_out = 0 for fewer than 3 or degenerate (coincident) correspondences. */
+gh_status gh_align_sim3(gh_ctx* ctx, const double* src, const double* dst, int n, int dof, double* sim3_out,
+                        double* information_out, double* ssq_out, int* ok_out);
 
 /* Dense SPD solve used by the reduced camera system, exposed for tests and the C5 bench:
  * A_dev is n x n column-major/symmetric (lower triangle read, overwritten by L), b_dev in, x out.
