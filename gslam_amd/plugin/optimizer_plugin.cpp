@@ -5,13 +5,20 @@
 // "libgslam_optimizer") loads it with no change to the host.  Implements
 //   optimize(BundleGraph&)   (:229)      -> gh_ba_graph_* (mappoint bundle adjustment, SE3 keyframes); the graph stays in
 //                                           HBM between calls and is rebuilt only when its topology changes
+//                                        -> gh_pg_solve   when the graph holds se3Graph / sim3Graph / gpsGraph edges and no
+//                                           point observations (pose-graph optimisation, SIM3 keyframes, UPDATE_KF_SCALE)
 //   optimizePnP(...)         (:202-207)  -> gh_ba_pnp
-// Everything else keeps the base-class default `return false` ("unsupported"), as the interface allows.
+//   optimizePose(...)        (:193-199)  -> gh_ba_pnp on the points of the first frame (anchor / idepth)
+//   optimizeICP(...)         (:210-217)  -> gh_align_sim3 (3D-3D correspondences)
+//   fitSim3(...)             (:220-225)  -> gh_align_sim3 (translations of two synchronised trajectories)
+// Still `return false` ("unsupported", as the interface allows): inverse-depth vertices, camera self-calibration, sphere
+// projection, pose-graph edges mixed with point observations in one graph, magin().
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
 
 #include <cstdint>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -31,8 +38,10 @@ class OptimizerHIP : public GSLAM::Optimizer {
     // supported sub-problem: xyz map points observed by SE3/SIM3 keyframes, pinhole anchors
     if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
     if (!graph.invDepths.empty() || !graph.invDepthObserves.empty()) return unsupported("inverse-depth points");
-    if (!graph.se3Graph.empty() || !graph.sim3Graph.empty() || !graph.gpsGraph.empty())
-      return unsupported("pose-graph / GPS edges");
+    if (!graph.se3Graph.empty() || !graph.sim3Graph.empty() || !graph.gpsGraph.empty()) {
+      if (!graph.mappointObserves.empty()) return unsupported("pose-graph edges mixed with point observations");
+      return optimizePoseGraph(graph);
+    }
     if (graph.cameraDOF != GSLAM::UPDATE_CAMERA_NONE && graph.camera.isValid())
       return unsupported("camera self-calibration");
     if (graph.keyframes.empty()) return false;
@@ -142,6 +151,133 @@ class OptimizerHIP : public GSLAM::Optimizer {
     return true;
   }
 
+  // Pose graph (loop closing / GPS fusion): keyframes are SIM3 T_wc, edges as Optimizer.h:127-148 defines them.
+  bool optimizePoseGraph(GSLAM::BundleGraph& graph) {
+    if (graph.keyframes.empty() || !context()) return false;
+    const size_t nf = graph.keyframes.size();
+    std::vector<double> frames(nf * 8);
+    std::vector<int32_t> dof(nf);
+    for (size_t i = 0; i < nf; ++i) {
+      const GSLAM::SIM3& T = graph.keyframes[i].estimation;
+      if (!(T.get_scale() > 0)) return unsupported("keyframe with non-positive SIM3 scale");
+      put_sim3(T, &frames[i * 8]);
+      dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SIM3;
+    }
+    std::vector<int32_t> f1, s1, f2, s2, fg;
+    std::vector<double> m1, m2, mg, i1, i2, ig;
+    bool any1 = false, any2 = false, anyg = false;
+    for (size_t k = 0; k < graph.se3Graph.size(); ++k) any1 = any1 || graph.se3Graph[k].information != NULL;
+    for (size_t k = 0; k < graph.sim3Graph.size(); ++k) any2 = any2 || graph.sim3Graph[k].information != NULL;
+    for (size_t k = 0; k < graph.gpsGraph.size(); ++k) anyg = anyg || graph.gpsGraph[k].information != NULL;
+    auto put_info = [](std::vector<double>& dst, const double* inf, int dim) {
+      for (int a = 0; a < dim; ++a)
+        for (int b = 0; b < dim; ++b) dst.push_back(inf ? inf[dim * a + b] : (a == b ? 1.0 : 0.0));
+    };
+    for (size_t k = 0; k < graph.se3Graph.size(); ++k) {
+      const GSLAM::SE3Edge& e = graph.se3Graph[k];
+      if (e.firstId >= nf || e.secondId >= nf || e.firstId == e.secondId) return bad_edge("se3Graph", k);
+      f1.push_back((int32_t)e.firstId); s1.push_back((int32_t)e.secondId);
+      double m[8];
+      put_sim3(GSLAM::SIM3(e.measurement, 1.0), m);
+      m1.insert(m1.end(), m, m + 7);
+      if (any1) put_info(i1, e.information, 6);
+    }
+    for (size_t k = 0; k < graph.sim3Graph.size(); ++k) {
+      const GSLAM::SIM3Edge& e = graph.sim3Graph[k];
+      if (e.firstId >= nf || e.secondId >= nf || e.firstId == e.secondId || !(e.measurement.get_scale() > 0))
+        return bad_edge("sim3Graph", k);
+      f2.push_back((int32_t)e.firstId); s2.push_back((int32_t)e.secondId);
+      double m[8];
+      put_sim3(e.measurement, m);
+      m2.insert(m2.end(), m, m + 8);
+      if (any2) put_info(i2, e.information, 7);
+    }
+    for (size_t k = 0; k < graph.gpsGraph.size(); ++k) {
+      const GSLAM::GPSEdge& e = graph.gpsGraph[k];
+      if (e.frameId >= nf) return bad_edge("gpsGraph", k);
+      fg.push_back((int32_t)e.frameId);
+      double m[8];
+      put_sim3(GSLAM::SIM3(e.measurement, 1.0), m);
+      mg.insert(mg.end(), m, m + 7);
+      if (anyg) put_info(ig, e.information, 6);
+    }
+    gh_pg_problem pr;
+    std::memset(&pr, 0, sizeof(pr));
+    pr.n_frames = (int32_t)nf; pr.frame_sim3 = frames.data(); pr.frame_dof = dof.data();
+    pr.n_se3 = (int32_t)f1.size(); pr.se3_first = f1.data(); pr.se3_second = s1.data(); pr.se3_meas = m1.data();
+    pr.se3_info = any1 ? i1.data() : NULL;
+    pr.n_sim3 = (int32_t)f2.size(); pr.sim3_first = f2.data(); pr.sim3_second = s2.data(); pr.sim3_meas = m2.data();
+    pr.sim3_info = any2 ? i2.data() : NULL;
+    pr.n_gps = (int32_t)fg.size(); pr.gps_frame = fg.data(); pr.gps_meas = mg.data(); pr.gps_info = anyg ? ig.data() : NULL;
+    gh_ba_options o;
+    gh_ba_default_options(&o);
+    o.max_iterations = _config.maxIterations;
+    o.verbose = _config.verbose ? 1 : 0;
+    gh_ba_summary s;
+    gh_status st;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      st = gh_pg_solve(ctx_, &pr, &o, &s);
+    }
+    if (st != GH_OK) {
+      LOG(ERROR) << "OptimizerHIP: pose-graph optimisation failed (" << st << "): " << gh_last_error(ctx_);
+      return false;
+    }
+    if (_config.verbose)
+      LOG(INFO) << "OptimizerHIP: pose graph, " << s.iterations << " LM iterations, cost " << s.initial_cost << " -> "
+                << s.final_cost << " in " << s.total_ms << " ms";
+    for (size_t i = 0; i < nf; ++i) {
+      const double* p = &frames[i * 8];
+      graph.keyframes[i].estimation = GSLAM::SIM3(GSLAM::SO3(p[0], p[1], p[2], p[3]), GSLAM::Point3d(p[4], p[5], p[6]), p[7]);
+    }
+    return true;
+  }
+
+  // TRACKING with known depth in the first frame (Optimizer.h:193-199): the point of match k lives at anchor1 / idepth in
+  // frame 1, its projection into frame 2 is matched against anchor2; relativePose = T_12 (P_1 = T_12 P_2, :131-134) is the
+  // camera-to-"world" pose of camera 2 with frame 1 as the world, i.e. a PnP problem.  Matches whose inverse depth is
+  // not positive (unknown) are left out; the depth estimates themselves are not updated.
+  bool optimizePose(std::vector<std::pair<GSLAM::CameraAnchor, GSLAM::CameraAnchor> >& matches,
+                    std::vector<GSLAM::IdepthEstimation>& firstIDepth, GSLAM::SE3& relativePose,
+                    GSLAM::KeyFrameEstimzationDOF dof = GSLAM::UPDATE_KF_SE3, double* information = NULL) override {
+    if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
+    if (matches.size() != firstIDepth.size() || !context()) return false;
+    std::vector<std::pair<GSLAM::Point3d, GSLAM::CameraAnchor> > m3d;
+    for (size_t k = 0; k < matches.size(); ++k) {
+      const double rho = firstIDepth[k].x, z1 = matches[k].first.z;
+      if (!(rho > 0) || !(z1 > 0)) continue;
+      const double d = 1.0 / (rho * z1);  // the anchor is on the z = 1 plane after division by its z
+      m3d.push_back(std::make_pair(GSLAM::Point3d(matches[k].first.x * d, matches[k].first.y * d, 1.0 / rho), matches[k].second));
+    }
+    if (m3d.size() < 3) return false;
+    return optimizePnP(m3d, relativePose, dof, information);
+  }
+
+  // 3D-3D correspondences (first, second): pose maps the FIRST point set onto the SECOND, second ~ pose * first, in closed
+  // form (Horn).  dof & UPDATE_KF_SCALE decides whether the scale is estimated.  information: 7 x 7 row-major.
+  bool optimizeICP(const std::vector<std::pair<GSLAM::Point3d, GSLAM::Point3d> >& matches, GSLAM::SIM3& pose,
+                   GSLAM::KeyFrameEstimzationDOF dof = GSLAM::UPDATE_KF_SE3, double* information = NULL) override {
+    std::vector<double> a, b;
+    for (size_t k = 0; k < matches.size(); ++k) {
+      a.push_back(matches[k].first.x); a.push_back(matches[k].first.y); a.push_back(matches[k].first.z);
+      b.push_back(matches[k].second.x); b.push_back(matches[k].second.y); b.push_back(matches[k].second.z);
+    }
+    return align(a, b, pose, dof, information);
+  }
+
+  // Two synchronised trajectories (pairs of poses of the same instants): the similarity that maps the translations of the
+  // first trajectory onto those of the second (what an evaluation / map-merging step needs; scale with UPDATE_KF_SIM3).
+  bool fitSim3(const std::vector<std::pair<GSLAM::SE3, GSLAM::SE3> >& matches, GSLAM::SIM3& sim3,
+               GSLAM::KeyFrameEstimzationDOF dof = GSLAM::UPDATE_KF_SIM3, double* information = NULL) override {
+    std::vector<double> a, b;
+    for (size_t k = 0; k < matches.size(); ++k) {
+      const GSLAM::Point3d p = matches[k].first.get_translation(), q = matches[k].second.get_translation();
+      a.push_back(p.x); a.push_back(p.y); a.push_back(p.z);
+      b.push_back(q.x); b.push_back(q.y); b.push_back(q.z);
+    }
+    return align(a, b, sim3, dof, information);
+  }
+
   bool optimizePnP(const std::vector<std::pair<GSLAM::Point3d, GSLAM::CameraAnchor> >& matches, GSLAM::SE3& pose,
                    GSLAM::KeyFrameEstimzationDOF dof = GSLAM::UPDATE_KF_SE3, double* information = NULL) override {
     if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
@@ -176,6 +312,33 @@ class OptimizerHIP : public GSLAM::Optimizer {
   }
 
  private:
+  static void put_sim3(const GSLAM::SIM3& T, double* p) {
+    const GSLAM::SO3 r = T.get_rotation();
+    const GSLAM::Point3d t = T.get_translation();
+    p[0] = r.x; p[1] = r.y; p[2] = r.z; p[3] = r.w; p[4] = t.x; p[5] = t.y; p[6] = t.z; p[7] = T.get_scale();
+  }
+  bool bad_edge(const char* list, size_t k) {
+    LOG(ERROR) << "OptimizerHIP: " << list << "[" << k << "] references a missing keyframe, connects a keyframe with itself or "
+               << "carries a non-positive scale";
+    return false;
+  }
+  bool align(const std::vector<double>& a, const std::vector<double>& b, GSLAM::SIM3& out, int dof, double* information) {
+    if (a.size() < 9 || !context()) return false;
+    double S[8], ssq = 0;
+    int ok = 0;
+    gh_status st;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      st = gh_align_sim3(ctx_, a.data(), b.data(), (int)(a.size() / 3), dof & GH_KF_SIM3, S, information, &ssq, &ok);
+    }
+    if (st != GH_OK) {
+      LOG(ERROR) << "OptimizerHIP: gh_align_sim3 failed (" << st << "): " << gh_last_error(ctx_);
+      return false;
+    }
+    if (!ok) return false;  // degenerate correspondences
+    out = GSLAM::SIM3(GSLAM::SO3(S[0], S[1], S[2], S[3]), GSLAM::Point3d(S[4], S[5], S[6]), S[7]);
+    return true;
+  }
   bool unsupported(const char* what) {
     LOG(WARNING) << "OptimizerHIP: " << what << " is not supported by the HIP optimizer";
     return false;

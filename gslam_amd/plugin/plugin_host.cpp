@@ -6,6 +6,8 @@
 //
 //   plugin_host ba   <plugin_dir> <graph.bin> <out.bin>
 //   plugin_host pnp  <plugin_dir> <pnp.bin> <out.bin>
+//   plugin_host pg   <plugin_dir> <posegraph.bin> <out.bin>    (optimize() on se3Graph / sim3Graph / gpsGraph edges)
+//   plugin_host align <plugin_dir> <align.bin> <out.bin>       (optimizeICP, fitSim3, optimizePose)
 //   plugin_host orb  <plugin_dir> <w> <h> <channels> <image.raw> <out.bin> <K>
 //   plugin_host orbbatch <plugin_dir> <w> <h> <channels> <n> <frames.raw> <out.bin> <K>   (detectAndComputeBatch and the
 //                    asynchronous submit / collect pair against per-frame detectAndCompute, all three written out)
@@ -134,8 +136,130 @@ static int run_ba(const std::string& dir, const char* in, const char* out, doubl
   std::vector<std::pair<CameraAnchor, CameraAnchor> > m;
   std::vector<IdepthEstimation> id;
   SE3 rel;
-  std::cout << "optimize=" << ok << " optimizePose(unsupported)=" << opt_ptr->optimizePose(m, id, rel) << std::endl;
+  std::cout << "optimize=" << ok << " optimizePose(unsupported)=" << opt_ptr->optimizePose(m, id, rel) << std::endl;  // (no matches)
   return ok ? 0 : 3;
+}
+
+// Pose graph through Optimizer::optimize: keyframes + se3Graph / sim3Graph / gpsGraph (Optimizer.h:127-148).
+// File: int32 {nf, n_se3, n_sim3, n_gps, has_info, max_iterations}; frames nf x 8 [qx qy qz qw tx ty tz s]; dof nf;
+// se3: first, second, meas n x 7 [, info n x 36]; sim3: first, second, meas n x 8 [, info n x 49]; gps: frame, meas n x 7 [, info].
+static int run_pg(const std::string& dir, const char* in, const char* out) {
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[6];
+  f.read((char*)hdr, sizeof(hdr));
+  const int nf = hdr[0], n1 = hdr[1], n2 = hdr[2], ng = hdr[3];
+  const bool has_info = hdr[4] != 0;
+  std::vector<double> fr = read_vec<double>(f, (size_t)nf * 8);
+  std::vector<int32_t> dof = read_vec<int32_t>(f, nf);
+  std::vector<int32_t> f1 = read_vec<int32_t>(f, n1), s1 = read_vec<int32_t>(f, n1);
+  std::vector<double> m1 = read_vec<double>(f, (size_t)n1 * 7), i1 = read_vec<double>(f, has_info ? (size_t)n1 * 36 : 0);
+  std::vector<int32_t> f2 = read_vec<int32_t>(f, n2), s2 = read_vec<int32_t>(f, n2);
+  std::vector<double> m2 = read_vec<double>(f, (size_t)n2 * 8), i2 = read_vec<double>(f, has_info ? (size_t)n2 * 49 : 0);
+  std::vector<int32_t> fg = read_vec<int32_t>(f, ng);
+  std::vector<double> mg = read_vec<double>(f, (size_t)ng * 7), ig = read_vec<double>(f, has_info ? (size_t)ng * 36 : 0);
+  OptimizerPtr opt_ptr = Optimizer::create();
+  if (!opt_ptr) { std::cerr << "Optimizer::create() returned null\n"; return 2; }
+  opt_ptr->_config.maxIterations = hdr[5];
+  BundleGraph g;
+  g.cameraDOF = UPDATE_CAMERA_NONE;
+  g.keyframes.resize(nf);
+  for (int i = 0; i < nf; ++i) {
+    const double* p = &fr[(size_t)i * 8];
+    g.keyframes[i].estimation = SIM3(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]), p[7]);
+    g.keyframes[i].dof = (KeyFrameEstimzationDOF)dof[i];
+  }
+  for (int k = 0; k < n1; ++k) {
+    SE3Edge e;
+    e.firstId = f1[k]; e.secondId = s1[k];
+    const double* m = &m1[(size_t)k * 7];
+    e.measurement = SE3(SO3(m[0], m[1], m[2], m[3]), Point3d(m[4], m[5], m[6]));
+    e.information = has_info ? &i1[(size_t)k * 36] : NULL;
+    g.se3Graph.push_back(e);
+  }
+  for (int k = 0; k < n2; ++k) {
+    SIM3Edge e;
+    e.firstId = f2[k]; e.secondId = s2[k];
+    const double* m = &m2[(size_t)k * 8];
+    e.measurement = SIM3(SO3(m[0], m[1], m[2], m[3]), Point3d(m[4], m[5], m[6]), m[7]);
+    e.information = has_info ? &i2[(size_t)k * 49] : NULL;
+    g.sim3Graph.push_back(e);
+  }
+  for (int k = 0; k < ng; ++k) {
+    GPSEdge e;
+    e.frameId = fg[k];
+    const double* m = &mg[(size_t)k * 7];
+    e.measurement = SE3(SO3(m[0], m[1], m[2], m[3]), Point3d(m[4], m[5], m[6]));
+    e.information = has_info ? &ig[(size_t)k * 36] : NULL;
+    g.gpsGraph.push_back(e);
+  }
+  const bool ok = opt_ptr->optimize(g);
+  std::ofstream o(out, std::ios::binary);
+  int32_t okv = ok ? 1 : 0;
+  o.write((char*)&okv, 4);
+  for (int i = 0; i < nf; ++i) {
+    const SIM3& T = g.keyframes[i].estimation;
+    SO3 r = T.get_rotation();
+    Point3d t = T.get_translation();
+    double p[8] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z, T.get_scale()};
+    o.write((char*)p, sizeof(p));
+  }
+  std::cout << "pose_graph_optimize=" << ok << std::endl;
+  return ok ? 0 : 3;
+}
+
+// optimizeICP + fitSim3 + optimizePose in one go.  File: int32 {n, dof}; src n x 3; dst n x 3; then the tracking problem:
+// int32 m; anchors1 m x 3; anchors2 m x 3; idepth m x 2; start pose 7 [qx qy qz qw tx ty tz].
+static int run_align(const std::string& dir, const char* in, const char* out) {
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[2];
+  f.read((char*)hdr, sizeof(hdr));
+  const int n = hdr[0];
+  std::vector<double> a = read_vec<double>(f, (size_t)n * 3), b = read_vec<double>(f, (size_t)n * 3);
+  int32_t m;
+  f.read((char*)&m, 4);
+  std::vector<double> a1 = read_vec<double>(f, (size_t)m * 3), a2 = read_vec<double>(f, (size_t)m * 3), idp = read_vec<double>(f, (size_t)m * 2),
+                      p0 = read_vec<double>(f, 7);
+  OptimizerPtr opt_ptr = Optimizer::create();
+  if (!opt_ptr) return 2;
+  std::vector<std::pair<Point3d, Point3d> > pts(n);
+  std::vector<std::pair<SE3, SE3> > traj(n);
+  for (int k = 0; k < n; ++k) {
+    pts[k] = std::make_pair(Point3d(a[3 * k], a[3 * k + 1], a[3 * k + 2]), Point3d(b[3 * k], b[3 * k + 1], b[3 * k + 2]));
+    // rotations of the trajectory poses are irrelevant to fitSim3: give them something non-trivial
+    traj[k] = std::make_pair(SE3(SO3::exp(Point3d(0.1 * k, 0.2, -0.1)), pts[k].first), SE3(SO3::exp(Point3d(0.3, -0.1 * k, 0.2)), pts[k].second));
+  }
+  SIM3 S1, S2;
+  double info1[49], info2[49];
+  const bool ok1 = opt_ptr->optimizeICP(pts, S1, (KeyFrameEstimzationDOF)hdr[1], info1);
+  const bool ok2 = opt_ptr->fitSim3(traj, S2, (KeyFrameEstimzationDOF)hdr[1], info2);
+  std::vector<std::pair<CameraAnchor, CameraAnchor> > mm(m);
+  std::vector<IdepthEstimation> idv(m);
+  for (int k = 0; k < m; ++k) {
+    mm[k] = std::make_pair(Point3d(a1[3 * k], a1[3 * k + 1], a1[3 * k + 2]), Point3d(a2[3 * k], a2[3 * k + 1], a2[3 * k + 2]));
+    idv[k] = IdepthEstimation(idp[2 * k], idp[2 * k + 1]);
+  }
+  SE3 rel(SO3(p0[0], p0[1], p0[2], p0[3]), Point3d(p0[4], p0[5], p0[6]));
+  double info3[36];
+  const bool ok3 = opt_ptr->optimizePose(mm, idv, rel, UPDATE_KF_SE3, info3);
+  std::ofstream o(out, std::ios::binary);
+  int32_t oks[3] = {ok1 ? 1 : 0, ok2 ? 1 : 0, ok3 ? 1 : 0};
+  o.write((char*)oks, sizeof(oks));
+  auto w8 = [&o](const SIM3& T) {
+    SO3 r = T.get_rotation();
+    Point3d t = T.get_translation();
+    double p[8] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z, T.get_scale()};
+    o.write((char*)p, sizeof(p));
+  };
+  w8(S1);
+  o.write((char*)info1, sizeof(info1));
+  w8(S2);
+  o.write((char*)info2, sizeof(info2));
+  w8(SIM3(rel, 1.0));
+  o.write((char*)info3, sizeof(info3));
+  std::cout << "optimizeICP=" << ok1 << " fitSim3=" << ok2 << " optimizePose=" << ok3 << std::endl;
+  return ok1 && ok2 && ok3 ? 0 : 3;
 }
 
 static int run_pnp(const std::string& dir, const char* in, const char* out) {
@@ -622,6 +746,8 @@ int main(int argc, char** argv) {
   if (mode == "ba" && argc >= 5)
     return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "pg" && argc >= 5) return run_pg(dir, argv[3], argv[4]);
+  if (mode == "align" && argc >= 5) return run_align(dir, argv[3], argv[4]);
   if (mode == "est" && argc >= 8) return run_est(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);
   if (mode == "est3" && argc >= 8) return run_est3(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);
   if (mode == "app" && argc >= 9)

@@ -73,3 +73,93 @@ def test_alignment_parity(ctx, oracle):
     assert not ok and S.tolist() == [0, 0, 0, 1, 0, 0, 0, 1]
     ok, _, _, _ = posegraph.align_sim3(ctx, np.zeros((2, 3)), np.ones((2, 3)))
     assert not ok
+
+
+# ------------------------------------------------------------------------------------------------------------
+# through the Optimizer plugin inside a real GSLAM host process (GSLAM's own BundleGraph / SE3Edge / SIM3Edge / GPSEdge)
+import os
+import struct
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "build", "plugin_host")
+LIBDIR = os.path.join(ROOT, "gslam_amd", "lib")
+
+
+def _host(args):
+    if not (os.path.exists(HOST) and os.path.exists(os.path.join(LIBDIR, "libgslam_optimizer.so"))):
+        pytest.skip("build/plugin_host or libgslam_optimizer.so missing (run `make plugins` where the GSLAM headers are)")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIBDIR + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    return subprocess.run([HOST] + [str(a) for a in args], capture_output=True, text=True, timeout=300, env=env)
+
+
+@pytest.mark.parametrize("kind,gps,info", [("mixed", 6, True), ("se3", 0, False)])
+def test_optimizer_plugin_pose_graph(tmp_path, oracle, kind, gps, info):
+    truth, start, dof, prob = make_pose_graph(30, 6, kind=kind, seed=13, noise=0.02, perturb=0.05, scale_drift=0.1,
+                                              gps_every=gps, with_info=info)
+    inp, out = tmp_path / "pg.bin", tmp_path / "out.bin"
+    se3 = prob.get("se3") or (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 7)), None)
+    sim3 = prob.get("sim3") or (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 8)), None)
+    gp = prob.get("gps") or (np.zeros(0, np.int32), np.zeros((0, 7)), None)
+    with open(inp, "wb") as f:
+        f.write(np.array([len(start), len(se3[0]), len(sim3[0]), len(gp[0]), 1 if info else 0, 40], np.int32).tobytes())
+        f.write(start.astype(np.float64).tobytes() + dof.astype(np.int32).tobytes())
+        for first, second, meas, inf, dim in ((se3[0], se3[1], se3[2], se3[3], 6), (sim3[0], sim3[1], sim3[2], sim3[3], 7)):
+            f.write(np.asarray(first, np.int32).tobytes() + np.asarray(second, np.int32).tobytes() + np.asarray(meas, np.float64).tobytes())
+            if info:
+                f.write((np.asarray(inf, np.float64) if inf is not None else np.tile(np.eye(dim).reshape(-1), (len(first), 1))).tobytes())
+        f.write(np.asarray(gp[0], np.int32).tobytes() + np.asarray(gp[1], np.float64).tobytes())
+        if info:
+            f.write((np.asarray(gp[2], np.float64) if gp[2] is not None else np.tile(np.eye(6).reshape(-1), (len(gp[0]), 1))).tobytes())
+    r = _host(["pg", LIBDIR, inp, out])
+    assert r.returncode == 0 and "pose_graph_optimize=1" in r.stdout, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    S = np.frombuffer(raw, np.float64, len(start) * 8, 4).reshape(-1, 8)
+    if info:  # edge lists without their own information get the identity in the file: tell the oracle the same
+        prob = dict(prob)
+        for key, dim in (("se3", 6), ("sim3", 7)):
+            if prob.get(key) is not None and prob[key][3] is None:
+                prob[key] = prob[key][:3] + (np.tile(np.eye(dim).reshape(-1), (len(prob[key][0]), 1)),)
+    So, so, sto = oracle.pg_solve(start, dof, prob, oracle_lib.ba_options(max_iterations=40), threads=4)
+    assert sto == 0 and np.abs(S - So).max() <= 1e-7
+    assert oracle.pg_cost(S, prob) <= 1.0000001 * so.final_cost
+
+
+def test_optimizer_plugin_icp_fitsim3_optimizepose(tmp_path, oracle):
+    from gslam_amd.pg_synth import _qrot
+    rng = np.random.default_rng(21)
+    n = 400
+    src = rng.normal(size=(n, 3)) * 3
+    S = oracle.sim3_exp(np.array([1.0, 2.0, -0.5, 0.2, -0.6, 0.4, 0.25]))
+    dst = np.stack([_qrot(S[:4], S[7] * p) + S[4:7] for p in src]) + rng.normal(size=(n, 3)) * 0.01
+    # tracking problem: points in frame 1 at depth 1 / rho, camera 2 at T_12 (P_1 = T_12 P_2)
+    m = 250
+    X1 = np.c_[rng.uniform(-2, 2, (m, 2)), rng.uniform(3, 8, m)]
+    T12 = oracle.se3_retract(np.array([0, 0, 0, 1.0, 0, 0, 0]), np.array([0.3, -0.1, 0.2, 0.05, -0.04, 0.03]))
+    qc = np.array([-T12[0], -T12[1], -T12[2], T12[3]])
+    X2 = np.stack([_qrot(qc, p - T12[4:7]) for p in X1])
+    a1 = np.c_[X1[:, :2] / X1[:, 2:3], np.ones(m)]
+    a2 = np.c_[X2[:, :2] / X2[:, 2:3], np.ones(m)] * 2.0   # anchors need not be normalised to z = 1
+    idp = np.c_[1.0 / X1[:, 2], np.full(m, 0.1)]
+    idp[::17, 0] = -1.0                                     # unknown depth: left out
+    start = oracle.se3_retract(T12, np.array([0.04, -0.03, 0.02, 0.01, 0.015, -0.01]))
+    inp, out = tmp_path / "align.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(np.array([n, 127], np.int32).tobytes() + src.tobytes() + dst.tobytes())
+        f.write(np.array([m], np.int32).tobytes() + a1.tobytes() + a2.tobytes() + idp.tobytes() + start.tobytes())
+    r = _host(["align", LIBDIR, inp, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    assert struct.unpack("3i", raw[:12]) == (1, 1, 1)
+    v = np.frombuffer(raw, np.float64, offset=12)
+    S1, I1, S2, I2, P3, I3 = v[:8], v[8:57].reshape(7, 7), v[57:65], v[65:114].reshape(7, 7), v[114:122], v[122:158].reshape(6, 6)
+    ok, So, Io, _ = oracle.align_sim3(src, dst, 127)
+    assert ok and np.abs(S1 - So).max() < 1e-11 and np.abs(S2 - So).max() < 1e-11
+    assert np.abs(I1 - Io).max() <= 1e-10 * np.abs(Io).max() and np.abs(I2 - Io).max() <= 1e-10 * np.abs(Io).max()
+    assert np.abs(S1 - S).max() < 5e-3
+    sign = np.sign(P3[:4] @ T12[:4])
+    assert np.abs(P3[:4] * sign - T12[:4]).max() < 1e-8 and np.abs(P3[4:7] - T12[4:7]).max() < 1e-7 and P3[7] == 1.0
+    keep = idp[:, 0] > 0
+    po, _, io, _ = oracle.ba_pnp(X1[keep], a2[keep, :2] / a2[keep, 2:3], start, want_information=True)
+    assert np.abs(P3[:7] - po).max() < 1e-8 and np.abs(I3 - io).max() <= 1e-7 * np.abs(io).max()
