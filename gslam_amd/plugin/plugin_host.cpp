@@ -477,6 +477,25 @@ static int run_bow(const std::string& dir, const char* gbow, const char* descf, 
   gpu->transform(features, bg2);
   cpu.transform(features, bc2);
   bool same = bg == bc && fg == fc && bg2 == bc2;
+  // the std::vector<TinyMat> overload (one feature per element) and the single-feature transform -> WordId, against the
+  // base class on the same features (Vocabulary.h:183,200)
+  {
+    std::vector<TinyMat> list;
+    for (int i = 0; i < n; ++i) list.push_back(TinyMat(1, 32, GImageType<uchar>::Type, d.data() + (size_t)i * 32, false));
+    BowVector bgl, bcl;
+    FeatureVector fgl, fcl;
+    gpu->transform(list, bgl, fgl, levelsup);
+    cpu.transform(list, bcl, fcl, levelsup);
+    int word_bad = 0;
+    for (int i = 0; i < std::min(n, 200); ++i)
+      if (gpu->transform(list[i]) != cpu.transform(list[i])) ++word_bad;
+    typedef int (*fail_t)(const Vocabulary*);
+    fail_t fc_ = (fail_t)lib->getSymbol("vocabularyFailureCount");
+    const int fails = fc_ ? fc_(gpu.get()) : -2;
+    std::cout << "list overload equal=" << (bgl == bcl && fgl == fcl && bgl == bg) << " single-feature word mismatches=" << word_bad
+              << " failures=" << fails << std::endl;
+    same = same && bgl == bcl && fgl == fcl && word_bad == 0 && fails == 0;
+  }
   // batched scoring (scoreVocabularyBatch) against the reference's own score() on a database of sub-images: windows
   // of the same descriptor list, transformed by the reference itself
   typedef bool (*score_t)(const Vocabulary*, const BowVector*, const BowVector* const*, int, double*);

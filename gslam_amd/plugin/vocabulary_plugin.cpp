@@ -7,8 +7,13 @@
 //     transform(const TinyMat& features, BowVector&)                                (:1437-1497)
 // to gh_bow_transform_host.  Factory (same idiom as createOptimizerInstance):
 //     extern "C" std::shared_ptr<GSLAM::Vocabulary> createVocabularyInstance(const char* gbow_file)
-// Results are bit-identical to the base class (tests/test_plugins_gpu.py); no GPU => falls back to nothing: the
-// methods leave the outputs empty and log an error.
+// as well as the std::vector<TinyMat> overload (:183, one feature per element) and the single-feature
+// transform(const TinyMat&) -> WordId (:200).  Images of more than 16384 features are descended on the GPU in chunks and
+// merged on the host exactly as the reference accumulates them (:1572-1618).
+// Results are bit-identical to the base class (tests/test_plugins_gpu.py).  There is no CPU fallback: when a transform
+// cannot run (no device, library error) the outputs stay empty, an error is logged AND the failure is counted --
+// the reference's transform cannot fail, so a caller that wants to notice asks
+//     extern "C" int vocabularyFailureCount(const GSLAM::Vocabulary*)
 // Vocabulary::score is a non-virtual inline that this snapshot declares (:203-211) but never defines -- callers use
 // m_scoring_object->score -- and scoring ONE pair on a GPU would be pure latency, so the
 // batched form a loop detector needs is offered beside it:
@@ -18,6 +23,9 @@
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Vocabulary.h>
 
+#include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -46,6 +54,41 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     v.clear();
     run(features, 0, &v, nullptr);
   }
+
+  // one feature per element (GSLAM/core/Vocabulary.h:183,1625-1690: the same accumulation as the matrix form)
+  void transform(const std::vector<GSLAM::TinyMat>& features, GSLAM::BowVector& v, GSLAM::FeatureVector& fv,
+                 int levelsup = 0) const override {
+    v.clear();
+    fv.clear();
+    if (features.empty()) return;
+    std::vector<uchar> packed(features.size() * 32);
+    for (size_t i = 0; i < features.size(); ++i) {
+      if (features[i].rows < 1 || features[i].cols * features[i].elemSize() != 32) {
+        failed("a feature of the list is not one 32-byte descriptor row");
+        return;
+      }
+      std::memcpy(&packed[i * 32], features[i].data, 32);
+    }
+    GSLAM::TinyMat all((int)features.size(), 32, GSLAM::GImageType<uchar>::Type, packed.data(), false);
+    run(all, levelsup, &v, &fv);
+  }
+
+  // a single feature -> its word (GSLAM/core/Vocabulary.h:200,1421-1433)
+  GSLAM::WordId transform(const GSLAM::TinyMat& feature) const override {
+    if (empty() || feature.rows < 1 || feature.cols * feature.elemSize() != 32) return 0;
+    std::lock_guard<std::mutex> lock(mu_);
+    if (!voc_) return 0;
+    uint32_t word = 0, node = 0, bw = 0;
+    float weight = 0, bv = 0;
+    int32_t nb = 0;
+    if (gh_bow_transform_host(voc_, feature.data, 1, 0, &word, &weight, &node, &bw, &bv, &nb) != GH_OK) {
+      failed(gh_last_error(ctx_));
+      return 0;
+    }
+    return (GSLAM::WordId)word;
+  }
+
+  int failures() const { return failures_; }
 
  public:
   // scores[j] = m_scoring_object->score(query, *db[j]); ids above 2^32 - 2 cannot occur (node ids are 32-bit in .gbow)
@@ -100,24 +143,47 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     return true;
   }
 
+  void failed(const char* why) const {
+    ++failures_;
+    LOG(ERROR) << "VocabularyHIP: transform failed, outputs left empty: " << why;
+  }
+
   void run(const GSLAM::TinyMat& features, int levelsup, GSLAM::BowVector* v, GSLAM::FeatureVector* fv) const {
     std::lock_guard<std::mutex> lock(mu_);
     const int n = features.rows;
-    if (!voc_ || n <= 0 || features.cols * features.elemSize() != 32) return;
-    if (n > 16384) {  // one workgroup sorts an image's word ids in LDS: 16384 features is the library's limit
-      LOG(ERROR) << "VocabularyHIP: " << n << " features in one image exceed the limit of 16384; outputs left empty";
-      return;
-    }
-    std::vector<uint32_t> word(n), node(n), bw(n);
-    std::vector<float> weight(n), bv(n);
+    if (n <= 0) return;
+    if (!voc_) return failed("no device vocabulary (load failed or no GPU)");
+    if (features.cols * features.elemSize() != 32) return failed("descriptors are not 32 bytes wide");
+    constexpr int kMax = 16384;  // one workgroup sorts an image's word ids in LDS: the library's limit per call
+    std::vector<uint32_t> word(n), node(n), bw(std::min(n, kMax));
+    std::vector<float> weight(n), bv(std::min(n, kMax));
     int32_t nb = 0;
-    if (gh_bow_transform_host(voc_, features.data, n, levelsup, word.data(), weight.data(), node.data(), bw.data(),
-                              bv.data(), &nb) != GH_OK) {
-      LOG(ERROR) << "VocabularyHIP: " << gh_last_error(ctx_);
-      return;
+    for (int c0 = 0; c0 < n; c0 += kMax) {
+      const int m = std::min(kMax, n - c0);
+      if (gh_bow_transform_host(voc_, features.data + (size_t)c0 * 32, m, levelsup, word.data() + c0, weight.data() + c0,
+                                node.data() + c0, bw.data(), bv.data(), &nb) != GH_OK)
+        return failed(gh_last_error(ctx_));
     }
-    GSLAM::BowVector::iterator hint = v->end();
-    for (int i = 0; i < nb; ++i) hint = v->insert(hint, GSLAM::BowVector::value_type(bw[i], bv[i]));  // ascending ids
+    if (n <= kMax) {
+      GSLAM::BowVector::iterator hint = v->end();
+      for (int i = 0; i < nb; ++i) hint = v->insert(hint, GSLAM::BowVector::value_type(bw[i], bv[i]));  // ascending ids
+    } else {
+      // more than one chunk: the per-feature words / weights came from the GPU, the image-level accumulation is the
+      // reference's own sequence (Vocabulary.h:1572-1618): addWeight / addIfNotExist in feature order, / size, normalize
+      LNorm norm;  // (members of the base class)
+      const bool must = m_scoring_object->mustNormalize(norm);
+      const bool tf = m_weighting == TF || m_weighting == TF_IDF;
+      for (int i = 0; i < n; ++i) {
+        if (!(weight[i] > 0)) continue;
+        if (tf) addWeight(*v, word[i], weight[i]);
+        else addIfNotExist(*v, word[i], weight[i]);
+      }
+      if (tf && !v->empty() && !must) {
+        const double nd = v->size();
+        for (GSLAM::BowVector::iterator it = v->begin(); it != v->end(); ++it) it->second /= nd;
+      }
+      if (must) normalize(*v, norm);
+    }
     if (fv)
       for (int i = 0; i < n; ++i)
         if (weight[i] > 0) (*fv)[node[i]].push_back((unsigned int)i);  // feature order == the reference's order
@@ -126,6 +192,7 @@ class VocabularyHIP : public GSLAM::Vocabulary {
   gh_ctx* ctx_;
   gh_bow_vocab* voc_;
   mutable std::mutex mu_;
+  mutable std::atomic<int> failures_{0};
 };
 
 }  // namespace
@@ -134,6 +201,11 @@ extern "C" bool scoreVocabularyBatch(const GSLAM::Vocabulary* voc, const GSLAM::
                                      const GSLAM::BowVector* const* db, int n_db, double* scores) {
   const VocabularyHIP* v = dynamic_cast<const VocabularyHIP*>(voc);
   return v && query && v->scoreBatch(*query, db, n_db, scores);
+}
+
+extern "C" int vocabularyFailureCount(const GSLAM::Vocabulary* voc) {
+  const VocabularyHIP* v = dynamic_cast<const VocabularyHIP*>(voc);
+  return v ? v->failures() : -1;
 }
 
 extern "C" std::shared_ptr<GSLAM::Vocabulary> createVocabularyInstance(const char* gbow_file) {

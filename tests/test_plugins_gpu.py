@@ -196,6 +196,24 @@ def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle):
     assert np.array_equal(rec["id"], e[3]) and rec["v"].tobytes() == e[4].tobytes()
 
 
+def test_vocabulary_plugin_overloads_and_large_images(tmp_path, oracle):
+    """The std::vector<TinyMat> overload, the single-feature transform -> WordId and an image of 40 000 features (more than
+    the 16384 one library call sorts: chunked descent + the reference's own accumulation) equal the base class; the failure
+    counter stays 0."""
+    _need_host()
+    from gslam_amd import bow_synth
+    voc = bow_synth.make_vocabulary(k=10, L=3, seed=9)
+    gb = tmp_path / "voc.gbow"
+    open(gb, "wb").write(bow_synth.to_gbow_bytes(voc))
+    for n in (700, 40000):
+        df, out = tmp_path / f"desc{n}.raw", tmp_path / f"out{n}.bin"
+        desc = np.concatenate([bow_synth.features_near_words(voc, n - n // 5, seed=n), oracle_lib.random_descriptors(n // 5, 0xAB + n)])
+        desc.tofile(df)
+        r = _run(["bow", LIBDIR, gb, df, n, 1, out])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "bow gpu==reference:1" in r.stdout and "list overload equal=1 single-feature word mismatches=0 failures=0" in r.stdout
+
+
 @pytest.mark.parametrize("channels", [1, 3])
 def test_undistorter_hip_equals_reference_class(tmp_path, channels):
     """UndistorterHIP (gslam_amd/plugin/UndistorterHIP.h) vs GSLAM::Undistorter in the same GSLAM host process."""
