@@ -33,7 +33,7 @@ endif
 lib: $(LIBDIR)/libgslam_hip.so
 oracle: oracle/liboracle.so oracle/liboracle_fma.so
 ref: oracle/_ref/libgslam_ref.so oracle/_ref/libgslam_ref_popcnt.so
-plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so $(LIBDIR)/libgslamDB_synthplane.so build/plugin_host refapps
+plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so $(LIBDIR)/libgslamDB_synthplane.so $(LIBDIR)/libgslamDB_tumrgbd.so $(LIBDIR)/libgslamDB_kitti.so build/plugin_host build/gmap_check refapps
 
 build/obj/%.o: gslam_amd/csrc/%.hip gslam_amd/csrc/common.h include/gslam_hip.h $(wildcard include/*.h gslam_amd/csrc/*.h)
 	@mkdir -p build/obj
@@ -78,11 +78,31 @@ $(LIBDIR)/libgslam_orbhip.so: gslam_amd/plugin/orbhip_app.cpp gslam_amd/plugin/F
 $(LIBDIR)/libgslamDB_synthplane.so: gslam_amd/plugin/dataset_synthplane.cpp include/gslam_hip.h $(LIBDIR)/libgslam_hip.so
 	g++ $(PLUGFLAGS) -shared -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN' -lpthread -ldl
 
+# TUM-RGBD reader on the stb path (the reference's own reader needs OpenCV); host I/O only, no libgslam_hip
+$(LIBDIR)/libgslamDB_tumrgbd.so: gslam_amd/plugin/dataset_tumrgbd.cpp
+	@mkdir -p $(LIBDIR)
+	g++ $(PLUGFLAGS) -I$(REF)/GSLAM/core -shared -o $@ $< -lpthread -ldl
+
+# KITTI odometry reader on the stb path (the reference's own reader cannot open anything in this snapshot: see the file)
+$(LIBDIR)/libgslamDB_kitti.so: gslam_amd/plugin/dataset_kitti.cpp
+	@mkdir -p $(LIBDIR)
+	g++ $(PLUGFLAGS) -I$(REF)/GSLAM/core -shared -o $@ $< -lpthread -ldl
+
+# test harness: loads a .gmap with the reference's OWN MapHash (GSLAM/plugins/gmap, compiled from where it lies) and
+# prints what it holds
+build/gmap_check: gslam_amd/plugin/gmap_check.cpp $(wildcard $(REF)/GSLAM/plugins/gmap/Map*.cpp)
+	@mkdir -p build
+	g++ -O2 -std=c++11 -w -I$(REF) -I$(REF)/GSLAM/plugins/gmap -o $@ $< $(REF)/GSLAM/plugins/gmap/MapHash.cpp $(REF)/GSLAM/plugins/gmap/MapFrame.cpp $(REF)/GSLAM/plugins/gmap/MapPoint.cpp -lpthread -ldl
+
 # The reference's OWN launcher and two of its application plugins, compiled from the sources where they lie (no copy,
 # the reference's flags): `gslam` (GSLAM/gslam/main.cpp), `play` (plugins/play/main.cpp), `metric_time`
 # (evaluation/metric_time/main.cpp), `metric_traj` (evaluation/metric_trajectory/main.cpp).  Test infrastructure: tests/test_launcher_gpu.py drives the orbhip application and
 # the synthplane dataset through them.  build/ is git-ignored and travels to the GPU box.
-refapps: build/ref/gslam build/ref/libgslam_play.so build/ref/libgslam_metric_time.so build/ref/libgslam_metric_traj.so
+refapps: build/ref/gslam build/ref/libgslam_play.so build/ref/libgslam_metric_time.so build/ref/libgslam_metric_traj.so build/ref/libgslam_gmap.so
+# the reference's own gmap application plugin
+build/ref/libgslam_gmap.so: $(wildcard $(REF)/GSLAM/plugins/gmap/*.cpp)
+	@mkdir -p build/ref
+	g++ -O3 -DNDEBUG -std=c++11 -w -fPIC -shared -I$(REF) -I$(REF)/GSLAM/plugins/gmap -o $@ $^ -lpthread -ldl
 build/ref/gslam: $(REF)/GSLAM/gslam/main.cpp
 	@mkdir -p build/ref
 	g++ -O3 -DNDEBUG -std=c++11 -w -I$(REF) -I$(REF)/GSLAM/core -o $@ $< -lpthread -ldl

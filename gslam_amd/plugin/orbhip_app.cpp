@@ -66,10 +66,108 @@ class OrbhipMap : public Map {
     return true;
   }
 
+  // what the front end knows about a frame beyond the frame object itself: keypoints, descriptors and which map point
+  // each keypoint observes (dataset frame classes such as the reference's FrameMono keep none of it)
+  void setFeatures(FrameID id, const std::vector<KeyPoint>& kps, const GImage& desc,
+                   const std::vector<std::pair<PointID, size_t> >& obs) {
+    WriteMutex l(mu_);
+    FrameData& d = features_[id];
+    d.kps = kps;
+    d.desc = desc.clone();
+    d.obs = obs;
+  }
+
+  // The reference's map file (`.gmap`: "Hash" / "binary", GSLAM/plugins/gmap/MapHash.cpp:278-360 writes it, :363-445 reads
+  // it): so that `gslam orbhip gmap play ... -map orbhip/map -out map.gmap` (the reference's own gmap application calls
+  // Map::save on whatever map is published, plugins/gmap/main.cpp:11-13) leaves a file GSLAM's MapHash::load, its gmap
+  // viewer and its evaluation tools read.  Field order and raw-struct encoding are the reference's OutStream
+  // (:207-236: every value as its in-memory bytes, vectors as size_t count + elements, GImage as cols rows flags + data,
+  // strings as size_t length + bytes).  Unlike the reference (which writes empty images there) the descriptors are kept.
+  bool save(std::string path) const override {
+    if (path.empty() || path.find(".gmap") == std::string::npos) return false;
+    std::ofstream ofs(path.c_str(), std::ios::out | std::ios::binary);
+    if (!ofs.is_open()) return false;
+    ReadMutex l(mu_);
+    auto raw = [&ofs](const void* p, size_t n) { ofs.write((const char*)p, (std::streamsize)n); };
+    auto put_image = [&](const GImage& im) {
+      const int hdr[3] = {im.cols, im.rows, im.flags};
+      raw(hdr, sizeof(hdr));
+      if (!im.empty()) raw(im.data, (size_t)im.total() * im.elemSize());
+    };
+    auto put_doubles = [&](const std::vector<double>& v) {
+      const size_t n = v.size();
+      raw(&n, sizeof(n));
+      if (n) raw(v.data(), n * sizeof(double));
+    };
+    ofs << "Hash" << std::endl << "binary" << std::endl;
+    const size_t nf = frames_.size(), np = points_.size();
+    raw(&nf, sizeof(nf));
+    raw(&np, sizeof(np));
+    for (auto& kv : points_) {
+      const PointPtr& pt = kv.second;
+      const PointID id = pt->id();
+      const Point3d pos = pt->getPose(), nrm = pt->getNormal();
+      const ColorType col = pt->getColor();
+      const FrameID ref = pt->refKeyframeID();
+      raw(&id, sizeof(id));
+      raw(&pos, sizeof(pos));
+      raw(&nrm, sizeof(nrm));
+      raw(&col, sizeof(col));
+      raw(&ref, sizeof(ref));
+      put_image(GImage());
+    }
+    for (auto& kv : frames_) {
+      const FramePtr& fr = kv.second;
+      auto fit = features_.find(kv.first);
+      static const FrameData none;
+      const FrameData& fd = fit == features_.end() ? none : fit->second;
+      const FrameID id = fr->id();
+      const double stamp = fr->timestamp();
+      const SIM3 pose = fr->getPoseScale();
+      raw(&id, sizeof(id));
+      raw(&stamp, sizeof(stamp));
+      raw(&pose, sizeof(pose));
+      put_image(GImage());  // the image itself stays with the dataset
+      const std::string img_file;
+      const size_t slen = img_file.size();
+      raw(&slen, sizeof(slen));
+      const int channels = fr->imageChannels(0);
+      raw(&channels, sizeof(channels));
+      put_doubles(fr->getCamera(0).getParameters());
+      put_doubles(std::vector<double>());  // no GPS
+      put_image(fd.desc);
+      const size_t nk = fd.kps.size();
+      raw(&nk, sizeof(nk));
+      if (nk) raw(fd.kps.data(), nk * sizeof(KeyPoint));
+      raw(&nk, sizeof(nk));  // one colour per keypoint (MapHash::load asserts the sizes agree)
+      for (size_t i = 0; i < nk; ++i) {
+        const ColorType white(255, 255, 255);
+        raw(&white, sizeof(white));
+      }
+      // only observations of points that are in the map (a point enters it with its first bundle adjustment)
+      std::vector<std::pair<PointID, size_t> > obs;
+      for (size_t i = 0; i < fd.obs.size(); ++i)
+        if (points_.count(fd.obs[i].first)) obs.push_back(fd.obs[i]);
+      const size_t no = obs.size();
+      raw(&no, sizeof(no));
+      for (size_t i = 0; i < no; ++i) raw(&obs[i], sizeof(obs[i]));
+      const size_t zero = 0;
+      raw(&zero, sizeof(zero));  // children
+      raw(&zero, sizeof(zero));  // parents
+    }
+    return ofs.good();
+  }
+
  private:
+  struct FrameData {
+    std::vector<KeyPoint> kps;
+    GImage desc;
+    std::vector<std::pair<PointID, size_t> > obs;
+  };
   mutable MutexRW mu_;
   std::map<FrameID, FramePtr> frames_;
   std::map<PointID, PointPtr> points_;
+  std::map<FrameID, FrameData> features_;
 };
 
 struct TrackedFrame {
@@ -119,6 +217,11 @@ int run_orbhip(Svar config) {
     opt = Optimizer::create();
     if (!opt) LOG(WARNING) << "orbhip: no Optimizer plugin (svar OptimizerPlugin): tracking disabled";
   }
+  // `.gmap` file (the reference's map format, OrbhipMap::save) rewritten after every bundle adjustment.  The reference's
+  // own gmap application would do the same for any published map (plugins/gmap/main.cpp:11-13: Map::save on the "map"
+  // topic), but in this snapshot loading it next to `play` makes play's "qviz/open" / frame callbacks fire two and three
+  // times (reproduced with reference plugins only), so the application saves its map itself.
+  const std::string save_map = config.arg<std::string>("orbhip.save_map", "", "write the map as a .gmap file after every BA");
   if (opt) opt->_config.maxIterations = config.arg<int>("orbhip.max_iterations", 30, "LM iterations per call");
 
   Publisher pub_frame = messenger.advertise<MapFrame>("orbhip/curframe", 0);
@@ -250,6 +353,12 @@ int run_orbhip(Svar config) {
         window.push_back(cur);
         while ((int)window.size() > ba_window) window.pop_front();
         map->insertMapFrame(fr);
+        {
+          std::vector<std::pair<PointID, size_t> > obs;
+          for (int i = 0; i < n; ++i)
+            if (cur.pid[i] >= 0) obs.push_back(std::make_pair((PointID)cur.pid[i], (size_t)i));
+          map->setFeatures(fr->id(), cur.kps, desc, obs);
+        }
       } else {
         window.clear();  // lost: start again from the next frame's dataset pose
       }
@@ -319,6 +428,7 @@ int run_orbhip(Svar config) {
           map->insertMapPoint(PointPtr(new OrbhipPoint((PointID)kv.first, points[kv.first])));
         }
         pub_map.publish(std::static_pointer_cast<Map>(map));
+        if (!save_map.empty() && !map->save(save_map)) LOG(ERROR) << "orbhip: cannot write " << save_map;
       }
     }
     pub_match.publish(Svar({{"id", (int)fr->id()}, {"keypoints", n}, {"matches", (int)matches.size()}, {"tracked", tracked}}));
