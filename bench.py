@@ -318,8 +318,9 @@ def main():
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath)).get(dom, {})
-            # measured in a separate --pmc pass at rec["frames_per_launch"] frames; traffic scales with frames
-            traffic = int(rec["hbm_bytes_per_launch"] * F / rec["frames_per_launch"]) if rec else None
+            # measured in a separate --pmc pass at rec["frames_per_launch"] frames of the same geometry: a file collected at
+            # another frame count is refused rather than rescaled (the launch shape would differ)
+            traffic = int(rec["hbm_bytes_per_launch"]) if rec and int(rec.get("frames_per_launch", 0)) == F else None
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -341,8 +342,8 @@ def main():
     if os.path.exists(spath) and "fast_cells mix" in probes:
         try:
             rec = json.load(open(spath)).get(dom, {})
-            if rec:
-                insts = rec["SQ_INSTS_VALU_per_launch"] * F / rec["frames_per_launch"]
+            if rec and int(rec.get("frames_per_launch", 0)) == F:
+                insts = rec["SQ_INSTS_VALU_per_launch"]
                 info0 = ctx.device_info()
                 peak_issue = probes["fast_cells mix"]
                 simd_clk = info0["cu_count"] * 4 * info0["clock_khz"] * 1e3

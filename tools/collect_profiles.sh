@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind profiles/ on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh
-# then, back in the authoring container:  python tools/parse_rocprof.py r02 1000 "<stats command>"
+# then, back in the authoring container:  python tools/parse_rocprof.py r03 1000 "<stats command>"
 # Counter passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not share a pass).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -40,17 +40,32 @@ def newest(paths):
     return sorted(paths, key=os.path.getmtime)[-1:]
 
 
+# Kernels launched on ONE shape per step: dispatches of any other grid (e.g. the all-pairs stress launches of the matcher,
+# 8x the work of a step launch) are left out instead of being averaged in.  orb_fast_cells is launched once per pyramid
+# level (8 shapes per step): its per-launch figure is the average over all of them, like its duration.
+SINGLE_SHAPE = {"bf_match_pairs", "orb_select", "orb_describe"}
+
+
 def counters(pattern, counter):
-    acc = defaultdict(lambda: [0.0, 0])
+    rows_by = defaultdict(list)
     for path in newest(glob.glob(os.path.join(ROOT, "gpurun_out", pattern, "**", "*_counter_collection.csv"), recursive=True)):
         for row in csv.DictReader(open(path)):
             if row["Counter_Name"] != counter:
                 continue
             s = short(row["Kernel_Name"])
             if s:
-                acc[s][0] += float(row["Counter_Value"])
-                acc[s][1] += 1
-    return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+                rows_by[s].append((row.get("Grid_Size", "?"), float(row["Counter_Value"])))
+    out = {}
+    for k, rows in rows_by.items():
+        grid = None
+        if k in SINGLE_SHAPE:
+            cnt = defaultdict(int)
+            for g, _ in rows:
+                cnt[g] += 1
+            grid = max(cnt, key=lambda g: cnt[g])
+            rows = [r for r in rows if r[0] == grid]
+        out[k] = (sum(v for _, v in rows) / len(rows), len(rows), grid)
+    return out
 
 
 def main():
@@ -70,17 +85,18 @@ def main():
     write = counters("prof_write", "WRITE_SIZE")
     traffic = {}
     for k in sorted(set(fetch) | set(write)):
-        f_kib = fetch.get(k, (0.0, 0))[0]
-        w_kib = write.get(k, (0.0, 0))[0]
-        traffic[k] = {"frames_per_launch": frames, "launches_sampled": fetch.get(k, (0, 0))[1],
+        f_kib = fetch.get(k, (0.0, 0, None))[0]
+        w_kib = write.get(k, (0.0, 0, None))[0]
+        traffic[k] = {"frames_per_launch": frames, "launches_sampled": fetch.get(k, (0, 0, None))[1],
+                      "grid_size": fetch.get(k, (0, 0, None))[2],
                       "FETCH_SIZE_KiB_avg": round(f_kib, 1), "WRITE_SIZE_KiB_avg": round(w_kib, 1),
                       "hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024),
                       "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes"}
     # instruction mix per launch (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES)
     sq = {}
     for cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES"):
-        for k, (avg, n) in counters("prof_sq", cname).items():
-            sq.setdefault(k, {"frames_per_launch": frames, "launches_sampled": n})[cname + "_per_launch"] = round(avg, 1)
+        for k, (avg, n, grid) in counters("prof_sq", cname).items():
+            sq.setdefault(k, {"frames_per_launch": frames, "launches_sampled": n, "grid_size": grid})[cname + "_per_launch"] = round(avg, 1)
     if sq:
         json.dump(sq, open(os.path.join(out_dir, "sq_counters.json"), "w"), indent=1)
         print("wrote profiles/sq_counters.json")
