@@ -98,6 +98,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's own account of the topology it found (rings / trees over xGMI, transports per peer) goes to a file per
+        # rank: the evidence to read after the first real N > 1 run.  GSLAM_BENCH_NCCL_LOG=0 switches it off.
+        if os.environ.get("GSLAM_BENCH_NCCL_LOG", "1") != "0" and not os.environ.get("GSLAM_BENCH_DRYRUN_BACKEND"):
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(ROOT, "gpurun_out", "rccl_n%d_rank%s.log" % (world, os.environ.get("RANK", "0"))))
     assert torch.cuda.is_available(), "bench.py needs a GPU (gslam_amd has no CPU fallback)"
     # GSLAM_BENCH_DRYRUN_BACKEND=gloo: dry run of the multi-rank code path on a 1-GPU box (all ranks share GPU 0,
     # collectives staged through the host).  Never used for reported numbers.
@@ -239,6 +246,69 @@ def main():
     else:
         total_kpts_step = int(counts.sum().item())
     n_pairs_step = int((g_counts[pq.long()].to(torch.int64) * g_counts[pt.long()].to(torch.int64)).sum().item())
+
+    # ---- all-pairs matching sharded over the ranks (BASELINE configs[1] read literally, at N > 1): every rank holds
+    #      every frame's descriptors after the gather; the frame pairs (i < j) of the first `nf` global frames are dealt
+    #      round-robin (sharding.all_pairs_block), no further exchange.  Also the cross-check quantities of
+    #      tests/test_bench_multirank_gpu.py: hashes of the gathered buffers and an order-independent checksum of the
+    #      all-pairs result, equal for every world size that covers the same global frames.
+    verify = None
+    all_pairs_multi = None
+    if world > 1 or os.environ.get("GSLAM_BENCH_VERIFY"):
+        import hashlib
+        from gslam_amd.sharding import all_pairs_block
+        finish_match_gather()
+        torch.cuda.synchronize()
+        nf = min(world * F, 128)
+        ai, aj = all_pairs_block(rank, world, nf, dev)
+        o_idx = torch.empty((max(1, ai.shape[0]), K), dtype=torch.int32, device=dev)
+        o_d1 = torch.empty((max(1, ai.shape[0]), K), dtype=torch.int16, device=dev)
+        o_d2 = torch.empty_like(o_d1)
+        if ai.shape[0] > 0:
+            matcher.match_pairs(g_desc, g_counts, ai, aj, out=(o_idx, o_d1, o_d2))
+        barrier()
+        t1 = time.perf_counter()
+        if ai.shape[0] > 0:
+            matcher.match_pairs(g_desc, g_counts, ai, aj, out=(o_idx, o_d1, o_d2))
+        barrier()
+        dt_ap = time.perf_counter() - t1
+        w = (ai.to(torch.int64) * nf + aj.to(torch.int64) + 1)[:, None]
+        chk = ((o_idx[:ai.shape[0]].to(torch.int64) + 2) * w % 1000003).sum() + (o_d1[:ai.shape[0]].to(torch.int64) & 0xFFFF).sum()
+        npair = (g_counts[ai.long()].to(torch.int64) * g_counts[aj.long()].to(torch.int64)).sum()
+        red = torch.stack([chk, npair]).to(torch.int64)
+        if world > 1:
+            cdev = torch.device("cpu") if dry else dev
+            red = red.to(cdev)
+            dist.all_reduce(red)
+            tt = torch.tensor([dt_ap], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ap = float(tt.item())
+        all_pairs_multi = {"frames": nf, "frame_pairs": nf * (nf - 1) // 2, "pairs": int(red[1].item()),
+                           "Gpairs_per_s": round(int(red[1].item()) / dt_ap / 1e9, 1), "ms": round(dt_ap * 1e3, 3),
+                           "how": "frame pairs dealt round-robin over %d rank(s), each on its copy of the gathered descriptors" % world}
+        # every rank's id through the transport in use: the gathered buffer must read 0 .. world - 1 on every rank (the first
+        # thing to look at the day this runs on N GPUs: a rank missing here means the exchange did not span the job)
+        ranks_seen = [0]
+        if world > 1:
+            me = torch.tensor([rank], dtype=torch.int32, device=dev)
+            if comm is not None:
+                g_rank = comm.buffer((1,), torch.int32)
+                comm.allgather(me, g_rank)
+                comm.wait()
+                torch.cuda.synchronize()
+                ranks_seen = g_rank.view(-1).cpu().tolist()
+            else:
+                gl = [torch.zeros(1, dtype=torch.int32, device=torch.device("cpu") if dry else dev) for _ in range(world)]
+                dist.all_gather(gl, me.to(gl[0].device))
+                ranks_seen = [int(t.item()) for t in gl]
+            assert ranks_seen == list(range(world)), "exchange did not reach every rank: %r" % (ranks_seen,)
+        if rank == 0:
+            gm = g_match if g_match is not None else m_full
+            verify = {"features_sha256": hashlib.sha256(g_desc.cpu().numpy().tobytes() + g_counts.cpu().numpy().tobytes()).hexdigest(),
+                      "matches_sha256": hashlib.sha256(gm.reshape(-1, K).cpu().numpy().tobytes()).hexdigest(),
+                      "all_pairs_checksum": int(red[0].item()), "global_frames": world * F, "ranks_seen": ranks_seen,
+                      "transport": comm_note or "none (single GPU)"}
+        del o_idx, o_d1, o_d2
 
     # ---- C3 at N > 1 (BASELINE configs[2]: per-frame stereo extract + match sharded over the GPUs, all-gather of the
     #      records): every rank extracts its own S stereo frames, matches left-right inside the row band (needs keypoints)
@@ -422,6 +492,10 @@ def main():
              "valu_issue_probes_Ginst_per_s": {k: (round(v / 1e9, 1) if isinstance(v, float) else v) for k, v in probes.items()}}
     if c3_multi is not None:
         extra["c3_stereo"] = c3_multi
+    if all_pairs_multi is not None:
+        extra["all_pairs_sharded"] = all_pairs_multi
+    if verify is not None:
+        extra["verify"] = verify
     info = ctx.device_info()
     if world > 1:
         # the CPU baseline is reported at N = 1 only (contract), and the single-GPU side legs (BA, BoW) add nothing
