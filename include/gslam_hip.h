@@ -95,6 +95,14 @@ gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int3
                                 const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
                                 int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
 
+/* The same contract through an exact integer MFMA formulation (an experiment reported BESIDE the popcount kernel, which
+ * stays the contract path): hamming = |a| + |b| - 2 |a & b| with |a & b| as a dot product of the descriptors expanded to
+ * one byte per bit on v_mfma_i32_16x16x64_i8; three VALU instructions per pair instead of nineteen.  Results are
+ * bit-identical to gh_bf_match_pairs_dev. */
+gh_status gh_bf_match_pairs_mfma_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                     const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                     int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
+
 /* Match masks (integer only):  keep[i] = d1 <= max_dist  &&  d1 * ratio_den < ratio_num * d2
  *                                        && (!cross_check || back_idx1[idx1[i]] == i).
  * ratio_num <= 0 disables the ratio test.  back_idx1_dev may be NULL when cross_check == 0. */

@@ -141,3 +141,41 @@ def test_bf_full_size_property(ctx):
     assert torch.equal(idx1.cpu(), inv)
     assert int(d1.cpu().abs().sum()) == 0
     assert (d2.cpu().to(torch.int32) > 60).all()
+
+
+def test_mfma_formulation_is_bit_identical_to_the_popcount_kernel(ctx, oracle):
+    """gh_bf_match_pairs_mfma_dev (hamming = |a| + |b| - 2 |a & b| on v_mfma_i32_16x16x64_i8) against the popcount kernel
+    and the oracle: idx1, d1, d2 for every row, incl. ragged counts (0, 1, 2, 17, cap), correlated descriptors with forced
+    ties (lowest index must win), all-zero / all-one descriptors and capacities that are not multiples of 16."""
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    m = BFMatcher(ctx)
+    for cap, counts in ((300, [300, 0, 1, 2, 17, 299, 300, 64]), (2000, [2000, 1999, 1234, 2000]), (37, [37, 5, 16, 33])):
+        F = len(counts)
+        desc = np.zeros((F, cap, 32), np.uint8)
+        base = oracle_lib.random_descriptors(cap, 0xBEEF + cap)
+        for f, n in enumerate(counts):
+            d, _ = oracle_lib.correlated_descriptors(base, 77 + f)
+            desc[f, :n] = d[:n]
+        desc[0, 3] = desc[0, 1]      # exact duplicates: the first must win
+        desc[0, 5] = 0
+        desc[0, 6] = 255
+        if cap > 40:
+            desc[3, 40] = desc[0, 10]
+            desc[3, 7] = desc[0, 10]
+        pq = np.array([(i, j) for i in range(F) for j in range(F)], np.int32)
+        dd = torch.from_numpy(desc).cuda()
+        cc = torch.tensor(counts, dtype=torch.int32, device="cuda")
+        q, t = torch.from_numpy(pq[:, 0].copy()).cuda(), torch.from_numpy(pq[:, 1].copy()).cuda()
+        a = m.match_pairs(dd, cc, q, t)
+        b = m.match_pairs(dd, cc, q, t, mfma=True)
+        torch.cuda.synchronize()
+        for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
+            assert torch.equal(x, y), (cap, name, (x != y).nonzero()[:5].tolist())
+        # and against the oracle for a few pairs
+        for p in (0, 1, F + 2, len(pq) - 1):
+            i, j = pq[p]
+            e = oracle.bf_match(desc[i, :counts[i]], desc[j, :counts[j]])
+            n = counts[i]
+            assert np.array_equal(b[0][p, :n].cpu().numpy(), e[0]) and np.array_equal(b[1][p, :n].cpu().numpy().view(np.uint16), e[1])
+            assert np.array_equal(b[2][p, :n].cpu().numpy().view(np.uint16), e[2])
