@@ -461,6 +461,29 @@ def main():
         bf["all_pairs"] = {"frames": nf, "frame_pairs": int(ai.shape[0]), "pairs": npairs_all,
                            "Gpairs_per_s": round(npairs_all / (ms_all * 1e-3) / 1e9, 1),
                            "frac": round(npairs_all / (ms_all * 1e-3) / valu_ceiling, 4)}
+        # the same pairs through the exact integer MFMA formulation (bf_match_mfma.hip): reported BESIDE the popcount
+        # kernel, which stays the contract path; the two results must be identical
+        try:
+            m_idx, m_d1, m_d2 = torch.empty_like(o_idx), torch.empty_like(o_d1), torch.empty_like(o_d2)
+            matcher.match_pairs(desc, counts, ai, aj, out=(m_idx, m_d1, m_d2), mfma=True)
+            torch.cuda.synchronize()
+            ctx.prof_enable(True)
+            matcher.match_pairs(desc, counts, ai, aj, out=(m_idx, m_d1, m_d2), mfma=True)
+            apm = ctx.prof_collect()
+            ctx.prof_enable(False)
+            ms_m = apm["bf_match_pairs_mfma"]["total_ms"]
+            mfma_ops = npairs_all * 512  # algorithmic: 256 multiply-adds per descriptor pair
+            bf["all_pairs_mfma"] = {
+                "Gpairs_per_s": round(npairs_all / (ms_m * 1e-3) / 1e9, 1), "ms": round(ms_m, 3),
+                "identical_to_popcount": bool(torch.equal(m_idx, o_idx) and torch.equal(m_d1, o_d1) and torch.equal(m_d2, o_d2)),
+                "roofline": {"bound": "mfma", "unit": "TOP/s", "peak": 5033.0,
+                             "peak_source": "v_mfma_i32_16x16x64_i8 at 16 clocks per SIMD (tools/mfma_probe.hip, profiles/mfma_probe_r03.txt)",
+                             "achieved": round(mfma_ops / (ms_m * 1e-3) / 1e12, 1),
+                             "frac": round(mfma_ops / (ms_m * 1e-3) / 1e12 / 5033.0, 4)},
+                "what": "v_mfma_i32_16x16x64_i8, key = 4096 (hamming - |a| + 256) + tile straight from the accumulator, v_med3 + v_min per pair"}
+            del m_idx, m_d1, m_d2
+        except Exception as exc:
+            bf["all_pairs_mfma"] = {"error": repr(exc)}
         del o_idx, o_d1, o_d2
         # ... and the TRUE all-pairs configuration of BASELINE configs[1]: every frame pair (i < j) of the step's F frames
         # (F = 1000: 499 500 frame pairs, 2.0e12 descriptor pairs; 8 GB of match records -- sized for the 288 GB of HBM)
@@ -926,6 +949,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         # BASELINE.json's metric names three rates: the other two at top level as well (details under extra)
         "bf_match_all_pairs_Gpairs_per_s": (bf.get("all_pairs_full") or bf.get("all_pairs") or {}).get("Gpairs_per_s"),
+        "bf_match_all_pairs_mfma_Gpairs_per_s": (bf.get("all_pairs_mfma") or {}).get("Gpairs_per_s"),
         "bf_match_consecutive_Gpairs_per_s": bf.get("Gpairs_per_s"),
         "ba_c4_lm_iters_per_s": (extra.get("ba") or {}).get("iters_per_s"),
         "ba_c5_lm_iters_per_s": (extra.get("ba_c5") or {}).get("iters_per_s"),
