@@ -14,11 +14,24 @@
 //          slice into all of them with device-to-device copies (on a full xGMI mesh that drives all links at once);
 //          rendezvous, handle exchange and the barriers go through a POSIX shared-memory segment.  Works when several
 //          ranks share one GPU (RCCL refuses that: "Duplicate GPU detected"), which is how the 2-process test on a
-//          1-GPU box runs the real kernels.  Synchronous: gh_comm_wait blocks the host.
+//          1-GPU box runs the real kernels.  Asynchronous like the RCCL path: no host thread waits for a GPU or for a
+//          peer during an exchange.  The ordering between the ranks' streams goes through two rows of flags in the
+//          rendezvous segment (host memory, registered with HIP in every process, so every GPU reads and writes it
+//          coherently):
+//              ready[r] = k   written by a one-thread kernel on r's CONTEXT stream when exchange k is issued: everything
+//                             r enqueued before has run -- its send data exists and its gathered buffers are no longer
+//                             being read, so peers may overwrite them;
+//              done[r]  = k   written on r's COMMUNICATOR stream after its pushes of exchange k: r's slice has landed in
+//                             every peer.
+//          r's communicator stream starts with a kernel that polls ready[*] >= k, then pushes; gh_comm_wait enqueues a
+//          kernel on the context stream that polls done[*] >= k.  Every poll is bounded (GSLAM_HIP_COMM_TIMEOUT_S):
+//          a rank that gives up sets `failed`, which every other poll and the next gh_comm_* call on any rank sees
+//          (gh_comm_status).  GSLAM_HIP_IPC_SYNC=1 selects the older protocol (host barriers around the pushes), kept
+//          for diagnosis.
 //
-// Stream model: a gather issued by gh_allgather* is ordered AFTER everything already enqueued on the context's stream
-// (event), runs on the communicator's stream, and gh_comm_wait orders the context's stream after it -- so kernels
-// enqueued between the two calls overlap with the transfer.
+// Stream model (both transports): a gather issued by gh_allgather* is ordered AFTER everything already enqueued on the
+// context's stream, runs on the communicator's stream, and gh_comm_wait orders the context's stream after it -- so
+// kernels enqueued between the two calls overlap with the transfer and the host never blocks.
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
@@ -75,15 +88,49 @@ RcclApi& rccl() {
 constexpr int kMaxWorld = 64;
 constexpr int kMaxBuffers = 16;
 
+struct alignas(64) FlagLine {
+  uint32_t v;
+  uint32_t pad[15];
+};
+
 struct ShmSegment {
   std::atomic<uint32_t> magic;
   std::atomic<int> arrived;          // sense-reversing barrier
   std::atomic<int> generation;
   std::atomic<int> attached;
-  std::atomic<int> failed;           // any rank that gives up sets this so the others stop waiting
+  std::atomic<int> failed;           // any rank (host or a polling kernel) that gives up sets this so the others stop waiting
   hipIpcMemHandle_t handles[kMaxWorld];
   uint64_t sizes[kMaxWorld];
+  FlagLine ready[kMaxWorld];         // exchange number up to which rank r's buffers may be overwritten / its send data exists
+  FlagLine done[kMaxWorld];          // exchange number up to which rank r's pushes have landed everywhere
 };
+static_assert(sizeof(std::atomic<int>) == sizeof(int), "the polling kernels read `failed` as a plain int");
+
+// one thread: everything enqueued before on this stream is complete -> publish exchange number k
+__global__ void comm_flag_set_kernel(uint32_t* flag, uint32_t k) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope: the default of the builtin)
+  __hip_atomic_store(flag, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// lane r < world polls flags[r] >= k (wrap-safe); bounded by `timeout_ticks` of the 100 MHz wall clock and by `failed`
+__global__ void comm_flag_wait_kernel(const FlagLine* flags, int world, uint32_t k, unsigned long long timeout_ticks, int* failed) {
+  const int r = threadIdx.x;
+  if (r < world) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while ((int32_t)(__hip_atomic_load(&flags[r].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
+      if ((++spins & 63u) == 0) {
+        if (__hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        if (wall_clock64() - t0 > timeout_ticks) {
+          __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
 
 struct IpcBuffer {
   void* mine = nullptr;                 // world * bytes_per_rank, hipMalloc'ed here
@@ -109,6 +156,10 @@ struct gh_comm {
   int local_generation = 0;
   std::vector<IpcBuffer> ipc_buffers;
   double timeout_s = 60.0;
+  bool ipc_sync = false;           // GSLAM_HIP_IPC_SYNC=1: host barriers instead of the flag kernels
+  ShmSegment* shm_dev = nullptr;   // the segment as the GPU sees it (hipHostRegister)
+  bool shm_registered = false;
+  uint32_t round = 0;              // number of the exchange in flight / last issued
 };
 
 namespace {
@@ -201,6 +252,7 @@ gh_status ipc_rendezvous(gh_ctx* ctx, gh_comm* c) {
     c->shm->generation.store(0);
     c->shm->attached.store(1);
     c->shm->failed.store(0);
+    for (int r = 0; r < kMaxWorld; ++r) c->shm->ready[r].v = c->shm->done[r].v = 0;
     c->shm->magic.store(kShmMagic, std::memory_order_release);
     c->local_generation = 0;
     if (!shm_barrier(c)) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: rendezvous timed out (%d ranks expected)", c->world);
@@ -291,11 +343,21 @@ gh_status gather_one(gh_comm* c, const void* send, void* gathered, size_t bytes,
 gh_status begin_collective(gh_comm* c) {
   gh_ctx* ctx = c->ctx;
   if (c->pending) return gh_set_error(ctx, GH_ERR_ARG, "gh_comm_wait must be called before the next gather");
-  if (c->transport == 1) {
+  if (c->transport == 1 && c->ipc_sync) {
     // peers still read their gathered buffers of the previous exchange through kernels on THEIR streams, and my send
     // data is produced on mine: drain, then meet -- after the barrier every buffer may be overwritten
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!shm_barrier(c)) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a peer did not reach the barrier");
+  } else if (c->transport == 1) {
+    if (c->shm->failed.load(std::memory_order_relaxed))
+      return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a rank gave up waiting in an earlier exchange (timeout %.0f s)", c->timeout_s);
+    const uint32_t k = ++c->round;
+    // ready[rank] = k once everything before this call has run on my context stream ...
+    hipLaunchKernelGGL(comm_flag_set_kernel, dim3(1), dim3(1), 0, ctx->stream, &c->shm_dev->ready[c->rank].v, k);
+    // ... and my communicator stream pushes when EVERY rank (me included: my send data) has got there
+    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(64), 0, c->stream, c->shm_dev->ready, c->world, k,
+                       (unsigned long long)(c->timeout_s * 1e8), (int*)&c->shm_dev->failed);
+    GH_HIP(ctx, hipGetLastError());
   } else {
     GH_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
     GH_HIP(ctx, hipStreamWaitEvent(c->stream, c->ev_ready, 0));
@@ -304,7 +366,12 @@ gh_status begin_collective(gh_comm* c) {
 }
 
 gh_status end_collective(gh_comm* c) {
-  GH_HIP(c->ctx, hipEventRecord(c->ev_done, c->stream));
+  if (c->transport == 1 && !c->ipc_sync) {
+    hipLaunchKernelGGL(comm_flag_set_kernel, dim3(1), dim3(1), 0, c->stream, &c->shm_dev->done[c->rank].v, c->round);
+    GH_HIP(c->ctx, hipGetLastError());
+  } else {
+    GH_HIP(c->ctx, hipEventRecord(c->ev_done, c->stream));
+  }
   c->pending = true;
   return GH_OK;
 }
@@ -366,9 +433,23 @@ extern "C" gh_status gh_comm_create_ipc(gh_ctx* ctx, int rank, int world, const 
   c->transport = 1;
   c->shm_name = std::string(rendezvous_name[0] == '/' ? "" : "/") + rendezvous_name;
   if (const char* t = getenv("GSLAM_HIP_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
+  if (const char* e = getenv("GSLAM_HIP_IPC_SYNC")) c->ipc_sync = atoi(e) != 0;
   gh_status st = comm_common_init(ctx, c);
   if (st == GH_OK) st = ipc_rendezvous(ctx, c);
+  if (st == GH_OK && !c->ipc_sync) {
+    // the GPU's view of the segment (pinned + mapped: device loads / stores go straight to host memory)
+    hipError_t e = hipHostRegister(c->shm, sizeof(ShmSegment), hipHostRegisterMapped);
+    if (e == hipSuccess) {
+      c->shm_registered = true;
+      e = hipHostGetDevicePointer((void**)&c->shm_dev, c->shm, 0);
+    }
+    if (e != hipSuccess) {
+      c->shm->failed.store(1);
+      st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: cannot map the rendezvous segment into the GPU: %s", hipGetErrorString(e));
+    }
+  }
   if (st != GH_OK) {
+    if (c->shm_registered) hipHostUnregister(c->shm);
     if (c->shm) munmap(c->shm, sizeof(ShmSegment));
     comm_common_free(c);
     delete c;
@@ -395,6 +476,7 @@ extern "C" void gh_comm_destroy(gh_comm* c) {
     }
     if (c->shm && !c->shm->failed.load()) shm_barrier(c);
     for (auto& b : c->ipc_buffers) hipFree(b.mine);
+    if (c->shm_registered) hipHostUnregister(c->shm);
     if (c->shm) {
       const int left = c->shm->attached.fetch_sub(1) - 1;
       munmap(c->shm, sizeof(ShmSegment));
@@ -405,6 +487,15 @@ extern "C" void gh_comm_destroy(gh_comm* c) {
   hipEventDestroy(c->ev_done);
   hipStreamDestroy(c->stream);
   delete c;
+}
+
+// GH_OK, or the error of an exchange that a rank abandoned (a bounded poll ran out): the asynchronous IPC transport
+// cannot report that from gh_comm_wait, which does not wait.  Cheap (one host load); call it after a stream sync.
+extern "C" gh_status gh_comm_status(gh_comm* c) {
+  if (!c) return GH_ERR_ARG;
+  if (c->transport == 1 && c->shm && c->shm->failed.load(std::memory_order_relaxed))
+    return gh_set_error(c->ctx, GH_ERR_HIP, "IPC transport: a rank gave up waiting for its peers (timeout %.0f s)", c->timeout_s);
+  return GH_OK;
 }
 
 extern "C" int gh_comm_rank(const gh_comm* c) { return c ? c->rank : -1; }
@@ -530,18 +621,25 @@ extern "C" gh_status gh_allgather_matches(gh_comm* c, int rows, int cap, const i
   return end_collective(c);
 }
 
-// Orders the context's stream after the gather in flight (RCCL: no host wait; IPC: blocks until every rank's slice has
-// landed in this rank's buffer).  A no-op when nothing is pending.
+// Orders the context's stream after the gather in flight; the host does not wait (with GSLAM_HIP_IPC_SYNC=1 the IPC
+// transport blocks until every rank's slice has landed).  A no-op when nothing is pending.
 extern "C" gh_status gh_comm_wait(gh_comm* c) {
   if (!c) return GH_ERR_ARG;
   gh_ctx* ctx = c->ctx;
   GH_ENTER(ctx);
   if (!c->pending) return GH_OK;
   c->pending = false;
-  if (c->transport == 1) {
+  if (c->transport == 1 && c->ipc_sync) {
     GH_HIP(ctx, hipStreamSynchronize(c->stream));  // my pushes have landed everywhere ...
     if (!shm_barrier(c)) return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a peer did not finish its pushes");
     return GH_OK;  // ... and so have everybody else's
+  }
+  if (c->transport == 1) {
+    // the context stream goes on when every rank's pushes of this exchange have landed (mine included)
+    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, c->shm_dev->done, c->world, c->round,
+                       (unsigned long long)(c->timeout_s * 1e8), (int*)&c->shm_dev->failed);
+    GH_HIP(ctx, hipGetLastError());
+    return GH_OK;
   }
   GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
   return GH_OK;

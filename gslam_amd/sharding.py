@@ -178,4 +178,9 @@ class Comm:
                                              send.numel() * send.element_size()))
 
     def wait(self):
+        """Orders the context's stream after the gather in flight; the host does not wait (both transports)."""
         self.ctx.check(_hip.lib.gh_comm_wait(self.h))
+
+    def status(self):
+        """Raises once any rank has abandoned an exchange (bounded polls of the IPC transport); call after a sync."""
+        self.ctx.check(_hip.lib.gh_comm_status(self.h))

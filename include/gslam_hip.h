@@ -246,9 +246,12 @@ gh_status gh_synth_frames_dev(gh_ctx* ctx, uint8_t* gray_dev, int width, int hei
  *     xGMI on the communicator's own stream.
  *   IPC transport (same node): every rank calls gh_comm_create_ipc with the same rendezvous name; peers' gathered
  *     buffers are mapped through HIP IPC and each rank pushes its slice into all of them.  Also works when several ranks
- *     share one GPU (RCCL refuses that).  gh_comm_wait blocks the host with this transport.
+ *     share one GPU (RCCL refuses that).  Asynchronous like RCCL: the ranks' streams order themselves through flags in
+ *     the rendezvous segment that bounded one-wave kernels set and poll; no host thread waits during an exchange.
  * A gather is ordered after the work already enqueued on the context's stream and runs beside it; gh_comm_wait orders
- * the context's stream after the gather.  Gathered buffers must come from gh_comm_buffer (a collective call). */
+ * the context's stream after the gather and returns at once.  A rank that gave up waiting for a peer (timeout
+ * GSLAM_HIP_COMM_TIMEOUT_S, default 60) shows in gh_comm_status and in the next gh_allgather* call of every rank.
+ * Gathered buffers must come from gh_comm_buffer (a collective call). */
 typedef struct gh_comm gh_comm;
 gh_status gh_comm_unique_id(uint8_t id_out[128]);
 gh_status gh_comm_create_rccl(gh_ctx* ctx, int rank, int world, const uint8_t unique_id[128], gh_comm** out);
@@ -267,6 +270,7 @@ gh_status gh_allgather_features(gh_comm* comm, int frames, int cap, const gh_key
 gh_status gh_allgather_matches(gh_comm* comm, int rows, int cap, const int32_t* idx1_dev, const uint16_t* d1_dev,
                                const uint16_t* d2_dev, int32_t* g_idx1_dev, uint16_t* g_d1_dev, uint16_t* g_d2_dev);
 gh_status gh_comm_wait(gh_comm* comm);
+gh_status gh_comm_status(gh_comm* comm); /* GH_OK, or GH_ERR_HIP once any rank abandoned an exchange */
 
 /* ------------------------------------------------------------------ BoW transform ---- */
 /* GSLAM::Vocabulary image -> BoW vector (GSLAM/core/Vocabulary.h:1558-1621, per-feature descent :1695-1736,
