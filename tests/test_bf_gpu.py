@@ -179,3 +179,26 @@ def test_mfma_formulation_is_bit_identical_to_the_popcount_kernel(ctx, oracle):
             n = counts[i]
             assert np.array_equal(b[0][p, :n].cpu().numpy(), e[0]) and np.array_equal(b[1][p, :n].cpu().numpy().view(np.uint16), e[1])
             assert np.array_equal(b[2][p, :n].cpu().numpy().view(np.uint16), e[2])
+
+
+def test_mfma_persistent_workgroups_walk_many_pairs(ctx):
+    """More frame pairs than workgroup columns (the workgroups loop over pairs and reuse their LDS stages, with inactive
+    waves and empty frames in between): every row equals the popcount kernel's."""
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    m = BFMatcher(ctx)
+    F, cap = 48, 150
+    g = torch.Generator(device="cuda").manual_seed(11)
+    desc = torch.randint(0, 256, (F, cap, 32), dtype=torch.uint8, device="cuda", generator=g)
+    desc[:, 1::2] &= desc[:, 0::2][:, : desc[:, 1::2].shape[1]]  # correlated rows: small distances and ties
+    counts = torch.randint(0, cap + 1, (F,), dtype=torch.int32, device="cuda", generator=g)
+    counts[3] = 0
+    counts[4] = cap
+    q = torch.arange(F, dtype=torch.int32, device="cuda").repeat_interleave(F)
+    t = torch.arange(F, dtype=torch.int32, device="cuda").repeat(F)
+    assert q.shape[0] > 4 * 256  # more pairs than persistent workgroup columns
+    a = m.match_pairs(desc, counts, q, t)
+    b = m.match_pairs(desc, counts, q, t, mfma=True)
+    torch.cuda.synchronize()
+    for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
+        assert torch.equal(x, y), (name, (x != y).nonzero()[:5].tolist())
