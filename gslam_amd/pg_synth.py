@@ -84,3 +84,70 @@ def make_pose_graph(n_frames=40, n_loops=8, kind="sim3", seed=1, noise=0.0, pert
     dof = np.full(n_frames, 127 if kind in ("sim3", "mixed") else 63, np.int32)
     dof[0] = 0  # gauge
     return truth, start, dof, problem
+
+
+def make_landmark_graph(n_frames=8, n_xyz=30, n_idp=30, kind="se3", seed=1, noise=0.0, perturb=0.03, point_perturb=0.05,
+                        obs_per_point=4, pose_edges=False, with_info=False, observe_host=True, outliers=0.0):
+    """A general BundleGraph (GSLAM/core/Optimizer.h:150-172): keyframes on the loop of make_pose_graph looking up at a
+    cloud of landmarks, `n_xyz` of them as world points, `n_idp` as inverse-depth points anchored in a host keyframe;
+    pinhole observations m = (x / z, y / z) in the observing camera; optionally the odometry / loop edges on top.
+    Returns (truth frames, start frames, dof, problem) with problem = the pose-edge dict of make_pose_graph plus
+      "xyz": (points n x 3 START values, free mask), "idp": (host, anchor n x 3, rho START values, free mask),
+      "obs": (kind, point, frame, xy n x 2, info n x 4 | None), "truth_xyz", "truth_rho"."""
+    rng = np.random.default_rng(seed)
+    truth, start, dof, problem = make_pose_graph(n_frames, n_loops=2, kind="sim3" if kind == "sim3" else "se3", seed=seed,
+                                                 noise=noise, perturb=perturb)
+    if not pose_edges:
+        problem = {}
+    if kind != "sim3":
+        truth[:, 7] = 1.0
+        start[:, 7] = 1.0
+
+    def cam_coords(S, X):
+        qc = np.array([-S[0], -S[1], -S[2], S[3]])
+        return _qrot(qc, X - S[4:7]) / S[7]
+
+    def sample_point():
+        return np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), rng.uniform(5, 11)])
+
+    okind, opoint, oframe, oxy = [], [], [], []
+    xyz = np.zeros((n_xyz, 3))
+    for p in range(n_xyz):
+        xyz[p] = sample_point()
+        frames = rng.choice(n_frames, size=min(obs_per_point, n_frames), replace=False)
+        for j in frames:
+            Xc = cam_coords(truth[j], xyz[p])
+            assert Xc[2] > 0.5
+            okind.append(0); opoint.append(p); oframe.append(int(j)); oxy.append(Xc[:2] / Xc[2])
+    host = np.zeros(n_idp, np.int32)
+    anchor = np.zeros((n_idp, 3))
+    rho = np.zeros(n_idp)
+    for p in range(n_idp):
+        X = sample_point()
+        frames = rng.choice(n_frames, size=min(obs_per_point, n_frames), replace=False)
+        host[p] = int(frames[0])
+        Xh = cam_coords(truth[host[p]], X)
+        anchor[p] = [Xh[0] / Xh[2], Xh[1] / Xh[2], 1.0]
+        rho[p] = 1.0 / Xh[2]
+        for j in (frames if observe_host else frames[1:]):
+            Xc = cam_coords(truth[j], X)
+            okind.append(1); opoint.append(p); oframe.append(int(j)); oxy.append(Xc[:2] / Xc[2])
+    oxy = np.array(oxy)
+    if noise > 0:
+        oxy = oxy + rng.normal(size=oxy.shape) * noise
+    if outliers > 0:
+        bad = rng.random(len(oxy)) < outliers
+        oxy[bad] += rng.normal(size=(int(bad.sum()), 2)) * 0.2
+    info = None
+    if with_info:
+        a = rng.normal(size=(len(oxy), 2, 2)) * 0.2
+        info = (np.eye(2)[None] * (1.0 + rng.random((len(oxy), 1, 1))) + a @ a.transpose(0, 2, 1)).reshape(-1, 4)
+    problem["xyz"] = (xyz + rng.normal(size=xyz.shape) * point_perturb, np.ones(n_xyz, np.uint8))
+    problem["idp"] = (host, anchor, rho * np.exp(rng.normal(size=n_idp) * point_perturb), np.ones(n_idp, np.uint8))
+    problem["obs"] = (np.array(okind, np.int32), np.array(opoint, np.int32), np.array(oframe, np.int32), oxy, info)
+    problem["truth_xyz"], problem["truth_rho"] = xyz, rho
+    dof = np.full(n_frames, 127 if kind == "sim3" else 63, np.int32)
+    dof[0] = 0  # gauge: the first keyframe is fixed ...
+    if n_frames > 1 and not pose_edges:
+        dof[1] &= ~1  # ... and one translation component of the second (the scale of a monocular reconstruction)
+    return truth, start, dof, problem

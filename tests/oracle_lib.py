@@ -615,3 +615,74 @@ def _pg_methods(cls):
 
 
 _pg_methods(Oracle)
+
+
+# ---------------------------------------------------------------- general BundleGraph (graph_oracle.c)
+class GraphProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("frames", _vp), ("dof", _vp), ("n_edges", C.c_int32), ("etype", _vp), ("ei", _vp),
+                ("ej", _vp), ("meas", _vp), ("info", _vp), ("n_xyz", C.c_int32), ("xyz", _vp), ("xyz_free", _vp),
+                ("n_idp", C.c_int32), ("idp_host", _vp), ("idp_anchor", _vp), ("idp_rho", _vp), ("idp_free", _vp),
+                ("n_obs", C.c_int32), ("obs_kind", _vp), ("obs_point", _vp), ("obs_frame", _vp), ("obs_xy", _vp),
+                ("obs_info", _vp), ("huber", C.c_double)]
+
+
+def graph_arrays(frames, dof, problem):
+    """Contiguous copies of everything a general-graph solve touches (gslam_amd.pg_synth.make_landmark_graph layout)."""
+    a = {"frames": np.ascontiguousarray(frames, dtype=np.float64).copy(), "dof": np.ascontiguousarray(dof, dtype=np.int32)}
+    if any(problem.get(k) is not None for k in ("se3", "sim3", "gps")):
+        a["et"], a["ei"], a["ej"], a["meas"], a["info"] = pg_edges(problem)
+    else:
+        a["et"] = a["ei"] = a["ej"] = np.zeros(0, np.int32)
+        a["meas"], a["info"] = np.zeros((0, 8)), None
+    xyz, xfree = problem.get("xyz") or (np.zeros((0, 3)), np.zeros(0, np.uint8))
+    host, anchor, rho, ifree = problem.get("idp") or (np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros(0), np.zeros(0, np.uint8))
+    kind, point, frame, xy, oinfo = problem.get("obs") or (np.zeros(0, np.int32),) * 3 + (np.zeros((0, 2)), None)
+    a["xyz"] = np.ascontiguousarray(xyz, dtype=np.float64).copy()
+    a["xfree"] = np.ascontiguousarray(xfree, dtype=np.uint8)
+    a["host"] = np.ascontiguousarray(host, dtype=np.int32)
+    a["anchor"] = np.ascontiguousarray(anchor, dtype=np.float64)
+    a["rho"] = np.ascontiguousarray(rho, dtype=np.float64).copy()
+    a["ifree"] = np.ascontiguousarray(ifree, dtype=np.uint8)
+    a["kind"], a["point"], a["frame"] = (np.ascontiguousarray(v, dtype=np.int32) for v in (kind, point, frame))
+    a["xy"] = np.ascontiguousarray(xy, dtype=np.float64)
+    a["oinfo"] = None if oinfo is None else np.ascontiguousarray(oinfo, dtype=np.float64)
+    return a
+
+
+def _graph_methods(cls):
+    def _problem(self, a, huber):
+        return GraphProblem(len(a["frames"]), _ptr(a["frames"]), _ptr(a["dof"]), len(a["et"]), _ptr(a["et"]), _ptr(a["ei"]),
+                            _ptr(a["ej"]), _ptr(a["meas"]), _ptr(a["info"]), len(a["xyz"]), _ptr(a["xyz"]), _ptr(a["xfree"]),
+                            len(a["rho"]), _ptr(a["host"]), _ptr(a["anchor"]), _ptr(a["rho"]), _ptr(a["ifree"]), len(a["kind"]),
+                            _ptr(a["kind"]), _ptr(a["point"]), _ptr(a["frame"]), _ptr(a["xy"]), _ptr(a["oinfo"]), float(huber))
+
+    def graph_solve(self, frames, dof, problem, opts=None, threads=1):
+        """-> (frames, xyz, rho, summary, status).  opts.huber_delta is the projection Huber threshold."""
+        opts = opts or ba_options()
+        a = graph_arrays(frames, dof, problem)
+        gp = _problem(self, a, opts.huber_delta)
+        sm = BaSummary()
+        st = self.lib.oracle_graph_solve(C.byref(gp), C.byref(opts), C.byref(sm), int(threads))
+        return a["frames"], a["xyz"], a["rho"], sm, st
+
+    def graph_cost(self, frames, dof, problem, huber=0.01):
+        a = graph_arrays(frames, dof, problem)
+        gp = _problem(self, a, huber)
+        self.lib.oracle_graph_cost.restype = C.c_double
+        return self.lib.oracle_graph_cost(C.byref(gp))
+
+    def graph_obs(self, kind, Sj, dof_j, Sh, dof_h, same_host, lm, lm_free, anchor, m, info=None, huber=0.0):
+        """-> (ok, r 2, w, s, Jj 2 x 7, Jh 2 x 7, Jp 2 x 3)."""
+        r, Jj, Jh, Jp = np.zeros(2), np.zeros(14), np.zeros(14), np.zeros(6)
+        w, s = C.c_double(), C.c_double()
+        f = lambda v: _ptr(np.ascontiguousarray(v, dtype=np.float64)) if v is not None else None
+        ok = self.lib.oracle_graph_obs(int(kind), f(Sj), int(dof_j), f(Sh), int(dof_h), int(same_host), f(lm), int(lm_free),
+                                       f(anchor if anchor is not None else np.zeros(3)), f(m), f(info), C.c_double(huber), _ptr(r),
+                                       C.byref(w), C.byref(s), _ptr(Jj), _ptr(Jh), _ptr(Jp))
+        return bool(ok), r, w.value, s.value, Jj.reshape(2, 7), Jh.reshape(2, 7), Jp.reshape(2, 3)
+
+    for f in (graph_solve, graph_cost, graph_obs):
+        setattr(cls, f.__name__, f)
+
+
+_graph_methods(Oracle)
