@@ -421,28 +421,24 @@ struct DevArena {  // a handful of hipMalloc'ed buffers freed together
   }
 };
 
-}  // namespace
+// Host side of the pose-graph part of a problem: the three edge lists flattened (order: SE3, SIM3, GPS -- the oracle's)
+// and the assembly lists of pg_assemble_kernel.
+struct PoseHost {
+  int ne = 0, n_pairs = 0;
+  bool any_info = false;
+  std::vector<int32_t> etype, ei, ej, vstart, vlist, pstart, plist, prow, pcol;
+  std::vector<double> meas, info;
+  gh_status build(gh_ctx* ctx, const gh_pg_problem* pr);
+};
 
-extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
-  if (!ctx || !pr) return GH_ERR_ARG;
-  GH_ENTER(ctx);
-  gh_ba_options opt;
-  gh_ba_default_options(&opt);
-  if (opt_in) opt = *opt_in;
-  gh_ba_summary local;
-  gh_ba_summary* sum = sum_out ? sum_out : &local;
-  memset(sum, 0, sizeof(*sum));
-  const int nf = pr->n_frames, ne = pr->n_se3 + pr->n_sim3 + pr->n_gps;
-  GH_CHECK_ARG(ctx, nf >= 1 && nf <= (1 << 20) && pr->frame_sim3 && pr->frame_dof && pr->n_se3 >= 0 && pr->n_sim3 >= 0 && pr->n_gps >= 0);
-  GH_CHECK_ARG(ctx, pr->n_se3 == 0 || (pr->se3_first && pr->se3_second && pr->se3_meas));
-  GH_CHECK_ARG(ctx, pr->n_sim3 == 0 || (pr->sim3_first && pr->sim3_second && pr->sim3_meas));
-  GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
-  for (int f = 0; f < nf; ++f) GH_CHECK_ARG(ctx, pr->frame_sim3[8 * (size_t)f + 7] > 0);
-  const double t_begin = now_ms_pg();
-  // ---- flatten the three edge lists (order: SE3, SIM3, GPS -- the oracle's) and build the assembly lists
-  std::vector<int32_t> etype((size_t)(ne > 0 ? ne : 1)), ei(etype.size()), ej(etype.size());
-  std::vector<double> meas((size_t)8 * etype.size(), 1.0), info;
-  const bool any_info = pr->se3_info || pr->sim3_info || pr->gps_info;
+gh_status PoseHost::build(gh_ctx* ctx, const gh_pg_problem* pr) {
+  const int nf = pr->n_frames;
+  ne = pr->n_se3 + pr->n_sim3 + pr->n_gps;
+  etype.assign((size_t)(ne > 0 ? ne : 1), 0);
+  ei.assign(etype.size(), 0);
+  ej.assign(etype.size(), 0);
+  meas.assign((size_t)8 * etype.size(), 1.0);
+  any_info = pr->se3_info || pr->sim3_info || pr->gps_info;
   if (any_info) info.assign((size_t)49 * etype.size(), 0.0);
   int e = 0;
   auto put = [&](int type, int i, int j, const double* m, int mlen, const double* inf, int dim) -> bool {
@@ -468,7 +464,7 @@ extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_opt
   for (int k = 0; k < pr->n_gps; ++k)
     GH_CHECK_ARG(ctx, put(2, pr->gps_frame[k], -1, pr->gps_meas + 7 * (size_t)k, 7,
                           pr->gps_info ? pr->gps_info + 36 * (size_t)k : nullptr, 6));
-  std::vector<int32_t> vstart((size_t)nf + 1, 0), vlist;
+  vstart.assign((size_t)nf + 1, 0);
   for (int k = 0; k < ne; ++k) {
     vstart[ei[k] + 1]++;
     if (ej[k] >= 0) vstart[ej[k] + 1]++;
@@ -491,7 +487,7 @@ extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_opt
     keyed.push_back({(long long)rf * nf + cf, (k << 1) | (ej[k] == rf ? 0 : 1)});
   }
   std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-  std::vector<int32_t> pstart(1, 0), plist, prow, pcol;
+  pstart.assign(1, 0);
   for (size_t k = 0; k < keyed.size(); ++k) {
     if (k == 0 || keyed[k].first != keyed[k - 1].first) {
       if (k) pstart.push_back((int32_t)plist.size());
@@ -501,10 +497,38 @@ extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_opt
     plist.push_back(keyed[k].second);
   }
   pstart.push_back((int32_t)plist.size());
-  const int n_pairs = (int)prow.size();
+  n_pairs = (int)prow.size();
   if (plist.empty()) plist.push_back(0);
   if (prow.empty()) { prow.push_back(0); pcol.push_back(0); }
 
+  return GH_OK;
+}
+
+}  // namespace
+
+extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
+  if (!ctx || !pr) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  gh_ba_options opt;
+  gh_ba_default_options(&opt);
+  if (opt_in) opt = *opt_in;
+  gh_ba_summary local;
+  gh_ba_summary* sum = sum_out ? sum_out : &local;
+  memset(sum, 0, sizeof(*sum));
+  const int nf = pr->n_frames, ne = pr->n_se3 + pr->n_sim3 + pr->n_gps;
+  GH_CHECK_ARG(ctx, nf >= 1 && nf <= (1 << 20) && pr->frame_sim3 && pr->frame_dof && pr->n_se3 >= 0 && pr->n_sim3 >= 0 && pr->n_gps >= 0);
+  GH_CHECK_ARG(ctx, pr->n_se3 == 0 || (pr->se3_first && pr->se3_second && pr->se3_meas));
+  GH_CHECK_ARG(ctx, pr->n_sim3 == 0 || (pr->sim3_first && pr->sim3_second && pr->sim3_meas));
+  GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
+  for (int f = 0; f < nf; ++f) GH_CHECK_ARG(ctx, pr->frame_sim3[8 * (size_t)f + 7] > 0);
+  const double t_begin = now_ms_pg();
+  PoseHost PH;
+  GH_TRY(PH.build(ctx, pr));
+  std::vector<int32_t>&etype = PH.etype, &ei = PH.ei, &ej = PH.ej, &vstart = PH.vstart, &vlist = PH.vlist, &pstart = PH.pstart,
+                      &plist = PH.plist, &prow = PH.prow, &pcol = PH.pcol;
+  std::vector<double>&meas = PH.meas, &info = PH.info;
+  const bool any_info = PH.any_info;
+  const int n_pairs = PH.n_pairs;
   const int n = 7 * nf;
   const int lda = (n + 15) & ~15;
   DevArena A;
@@ -638,6 +662,689 @@ extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_opt
   sum->termination = term;
   sum->final_cost = cost;
   GH_HIP(ctx, hipMemcpyAsync(pr->frame_sim3, d_S, (size_t)nf * 64, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sum->total_ms = now_ms_pg() - t_begin;
+  return term == 3 ? GH_ERR_NUMERIC : GH_OK;
+}
+
+// ---------------------------------------------------------------- general BundleGraph: landmarks on top of the pose graph
+// gh_graph_solve: SIM3 keyframes + pose-graph edges + XYZ and inverse-depth landmarks with pinhole observations in ONE
+// graph (GSLAM/core/Optimizer.h:150-172) -- what the specialised bundle adjustment of ba.hip (SE3 cameras, XYZ points
+// only) does not cover: inverse-depth points, keyframe scale, pose-graph edges mixed with observations.  Specification =
+// header of oracle/graph_oracle.c.  Same LM loop as gh_pg_solve; the landmarks (3 x 3 / 1 x 1 blocks) are eliminated by a
+// Schur complement into the dense keyframe system:
+//   gr_obs_lin     one thread per observation: residual, Huber weight, analytic Jacobians w.r.t. the observing keyframe,
+//                  the host keyframe (inverse depth) and the landmark -> record; J^T L J / J^T L r added to the keyframe
+//                  blocks of H, to g and to the landmark's H_pp / g_p with f64 atomics (the sums are short; their order,
+//                  hence the last bits, varies from run to run -- the parity tests carry that in their tolerance)
+//   gr_lm_prepare  one thread per landmark: (H_pp + D)^-1 in closed form
+//   gr_schur       one thread per (observation, keyframe) slot a: U_a = W_a (H_pp + D)^-1; rhs += U_a g_p; for every slot b
+//                  of the same landmark with frame(b) <= frame(a): block(frame a, frame b) -= U_a W_b^T
+//   gr_backsub     one thread per landmark: d_p = -(H_pp + D)^-1 (g_p + sum W^T d_f)
+//   gr_model / gr_cost / gr_reduce   per-item terms and a fixed-order two-level sum
+namespace {
+
+constexpr double kMinDepthG = 1e-9;
+constexpr int kObsRec = 40;  // r(2) L(4) Jj(14) Jh(14) Jp(6)
+
+struct GrLandmarks {
+  int n_xyz, n_idp, n_obs;
+  const uint8_t* xyz_free;
+  const int32_t* idp_host;
+  const double* idp_anchor;
+  const uint8_t* idp_free;
+  const int32_t *obs_kind, *obs_point, *obs_frame;
+  const double* obs_xy;
+  const double* obs_info;  // may be null
+  const int32_t *lstart, *llist;  // observations by landmark (XYZ points first, then inverse-depth points)
+  double huber;
+};
+
+__device__ inline void q_matrix(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// residual r, quadratic form s = r^T Lambda r, Huber weight; optionally the Jacobians.  false: not in front of the camera
+template <bool WITH_J>
+__device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, bool same_host,
+                                 const double* lm, bool lm_free, const double* anchor, const double* m, const double* info,
+                                 double huber, double* r, double* wgt, double* s_out, double* Jj, double* Jh, double* Jp) {
+  double Z[3], Y[3], Ra[3] = {0, 0, 0}, dth[3] = {0, 0, 0};
+  if (kind == 0) {
+    for (int e = 0; e < 3; ++e) Z[e] = lm[e] - Sj[4 + e];
+  } else {
+    q_rot(Sh, anchor, Ra);
+    for (int e = 0; e < 3; ++e) {
+      dth[e] = Sh[4 + e] - Sj[4 + e];
+      Z[e] = Sh[7] * Ra[e] + lm[0] * dth[e];
+    }
+  }
+  const double qc[4] = {-Sj[0], -Sj[1], -Sj[2], Sj[3]};
+  q_rot(qc, Z, Y);
+  if (!(Y[2] > kMinDepthG)) return false;
+  const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
+  r[0] = u - m[0];
+  r[1] = v - m[1];
+  double L00 = 1, L01 = 0, L10 = 0, L11 = 1;
+  if (info) { L00 = info[0]; L01 = info[1]; L10 = info[2]; L11 = info[3]; }
+  const double s = r[0] * (L00 * r[0] + L01 * r[1]) + r[1] * (L10 * r[0] + L11 * r[1]);
+  double w = 1.0;
+  if (huber > 0 && s > huber * huber) w = huber / sqrt(s);
+  *wgt = w;
+  *s_out = s;
+  if (!WITH_J) return true;
+  for (int k = 0; k < 14; ++k) Jj[k] = Jh[k] = 0.0;
+  for (int k = 0; k < 6; ++k) Jp[k] = 0.0;
+  if (kind == 1 && same_host) return true;
+  const double P[6] = {iz, 0, -u * iz, 0, iz, -v * iz};
+  const double c = kind == 0 ? 1.0 : lm[0];
+  const double Dj[21] = {-c * Sj[7], 0, 0, 0, -Y[2], Y[1], 0,
+                         0, -c * Sj[7], 0, Y[2], 0, -Y[0], 0,
+                         0, 0, -c * Sj[7], -Y[1], Y[0], 0, 0};
+  for (int a = 0; a < 2; ++a)
+    for (int k = 0; k < 7; ++k) {
+      double acc = 0;
+      for (int e = 0; e < 3; ++e) acc += P[3 * a + e] * Dj[7 * e + k];
+      Jj[7 * a + k] = ((dof_j >> k) & 1) ? acc : 0.0;
+    }
+  double Rj[9];
+  q_matrix(Sj, Rj);
+  if (kind == 0) {
+    for (int a = 0; a < 2; ++a)
+      for (int k = 0; k < 3; ++k) {
+        double acc = 0;
+        for (int e = 0; e < 3; ++e) acc += P[3 * a + e] * Rj[3 * k + e];
+        Jp[3 * a + k] = lm_free ? acc : 0.0;
+      }
+    return true;
+  }
+  double Rh[9], M[9];
+  q_matrix(Sh, Rh);
+  for (int e = 0; e < 3; ++e)
+    for (int f = 0; f < 3; ++f) {
+      double acc = 0;
+      for (int k = 0; k < 3; ++k) acc += Rj[3 * k + e] * Rh[3 * k + f];
+      M[3 * e + f] = acc;
+    }
+  const double nax[9] = {0, anchor[2], -anchor[1], -anchor[2], 0, anchor[0], anchor[1], -anchor[0], 0};
+  double Dh[21];
+  for (int e = 0; e < 3; ++e) {
+    for (int k = 0; k < 3; ++k) {
+      Dh[7 * e + k] = lm[0] * Sh[7] * M[3 * e + k];
+      double acc = 0;
+      for (int f = 0; f < 3; ++f) acc += M[3 * e + f] * nax[3 * f + k];
+      Dh[7 * e + 3 + k] = Sh[7] * acc;
+    }
+    Dh[7 * e + 6] = Sh[7] * (M[3 * e] * anchor[0] + M[3 * e + 1] * anchor[1] + M[3 * e + 2] * anchor[2]);
+  }
+  for (int a = 0; a < 2; ++a)
+    for (int k = 0; k < 7; ++k) {
+      double acc = 0;
+      for (int e = 0; e < 3; ++e) acc += P[3 * a + e] * Dh[7 * e + k];
+      Jh[7 * a + k] = ((dof_h >> k) & 1) ? acc : 0.0;
+    }
+  double dr[3];
+  q_rot(qc, dth, dr);
+  for (int a = 0; a < 2; ++a) Jp[3 * a] = lm_free ? P[3 * a] * dr[0] + P[3 * a + 1] * dr[1] + P[3 * a + 2] * dr[2] : 0.0;
+  return true;
+}
+
+// frames / landmark of observation k; returns its kind
+struct ObsRef {
+  int kind, p, fj, fh, lm, dp;  // fh = -1 unless an inverse-depth point seen from another keyframe than its host
+  bool same_host, lm_free;
+};
+__device__ inline ObsRef obs_ref(const GrLandmarks& G, int k) {
+  ObsRef o;
+  o.kind = G.obs_kind[k];
+  o.p = G.obs_point[k];
+  o.fj = G.obs_frame[k];
+  const int h = o.kind == 1 ? G.idp_host[o.p] : o.fj;
+  o.same_host = o.kind == 1 && h == o.fj;
+  o.fh = (o.kind == 1 && h != o.fj) ? h : -1;
+  o.lm = o.kind == 0 ? o.p : G.n_xyz + o.p;
+  o.lm_free = o.kind == 0 ? (G.xyz_free ? G.xyz_free[o.p] != 0 : true) : (G.idp_free ? G.idp_free[o.p] != 0 : true);
+  o.dp = o.lm_free ? (o.kind == 0 ? 3 : 1) : 0;
+  return o;
+}
+
+template <bool WITH_J>
+__device__ inline bool obs_eval(const GrLandmarks& G, const int32_t* dof, int k, const ObsRef& o, const double* S, const double* xyz,
+                                const double* rho, double* r, double* w, double* s, double* Jj, double* Jh, double* Jp) {
+  double Sj[8], Sh[8], lm[3] = {0, 0, 0}, anchor[3] = {0, 0, 0}, info[4];
+  const int h = o.kind == 1 ? G.idp_host[o.p] : o.fj;
+  for (int e = 0; e < 8; ++e) {
+    Sj[e] = S[8 * (size_t)o.fj + e];
+    Sh[e] = S[8 * (size_t)h + e];
+  }
+  if (o.kind == 0) {
+    for (int e = 0; e < 3; ++e) lm[e] = xyz[3 * (size_t)o.p + e];
+  } else {
+    lm[0] = rho[o.p];
+    for (int e = 0; e < 3; ++e) anchor[e] = G.idp_anchor[3 * (size_t)o.p + e];
+  }
+  if (G.obs_info)
+    for (int e = 0; e < 4; ++e) info[e] = G.obs_info[4 * (size_t)k + e];
+  const double m[2] = {G.obs_xy[2 * (size_t)k], G.obs_xy[2 * (size_t)k + 1]};
+  return graph_obs<WITH_J>(o.kind, Sj, dof[o.fj], Sh, dof[h], o.same_host, lm, o.lm_free, anchor, m, G.obs_info ? info : nullptr,
+                           G.huber, r, w, s, Jj, Jh, Jp);
+}
+
+__global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const int32_t* __restrict__ dof, const double* __restrict__ S,
+                                                         const double* __restrict__ xyz, const double* __restrict__ rho,
+                                                         double* __restrict__ orec, uint8_t* __restrict__ valid, double* __restrict__ H,
+                                                         int lda, double* __restrict__ g, double* __restrict__ Hpp,
+                                                         double* __restrict__ gp) {
+  const int k = blockIdx.x * 128 + threadIdx.x;
+  if (k >= G.n_obs) return;
+  const ObsRef o = obs_ref(G, k);
+  double r[2], w, s, Jj[14], Jh[14], Jp[6];
+  const bool ok = obs_eval<true>(G, dof, k, o, S, xyz, rho, r, &w, &s, Jj, Jh, Jp);
+  valid[k] = ok ? 1 : 0;
+  double* R = orec + (size_t)kObsRec * k;
+  if (!ok) {
+    for (int e = 0; e < kObsRec; ++e) R[e] = 0.0;
+    return;
+  }
+  double L[4] = {w, 0, 0, w};
+  if (G.obs_info)
+    for (int e = 0; e < 4; ++e) L[e] = w * G.obs_info[4 * (size_t)k + e];
+  R[0] = r[0]; R[1] = r[1];
+  for (int e = 0; e < 4; ++e) R[2 + e] = L[e];
+  for (int e = 0; e < 14; ++e) { R[6 + e] = Jj[e]; R[20 + e] = Jh[e]; }
+  for (int e = 0; e < 6; ++e) R[34 + e] = Jp[e];
+  const double Lr[2] = {L[0] * r[0] + L[1] * r[1], L[2] * r[0] + L[3] * r[1]};
+  const double* Jf[2] = {Jj, Jh};
+  const int ff[2] = {o.fj, o.fh};
+  for (int x = 0; x < 2; ++x) {
+    if (ff[x] < 0) continue;
+    for (int p = 0; p < 7; ++p) {
+      const double gv = Jf[x][p] * Lr[0] + Jf[x][7 + p] * Lr[1];
+      if (gv != 0.0) atomicAdd(&g[7 * ff[x] + p], gv);
+    }
+    for (int y = 0; y < 2; ++y) {
+      if (ff[y] < 0 || ff[y] > ff[x]) continue;  // lower triangle of blocks: row frame >= column frame
+      for (int q = 0; q < 7; ++q) {
+        const double LJ0 = L[0] * Jf[y][q] + L[1] * Jf[y][7 + q], LJ1 = L[2] * Jf[y][q] + L[3] * Jf[y][7 + q];
+        for (int p = 0; p < 7; ++p) {
+          const double hv = Jf[x][p] * LJ0 + Jf[x][7 + p] * LJ1;
+          if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[y] + q) * lda + 7 * ff[x] + p], hv);
+        }
+      }
+    }
+  }
+  for (int a = 0; a < o.dp; ++a) {
+    atomicAdd(&gp[3 * (size_t)o.lm + a], Jp[a] * Lr[0] + Jp[3 + a] * Lr[1]);
+    for (int b = 0; b < o.dp; ++b) {
+      const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
+      atomicAdd(&Hpp[9 * (size_t)o.lm + 3 * a + b], Jp[a] * LJ0 + Jp[3 + a] * LJ1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gr_gmax_kernel(const double* __restrict__ g, int n, const double* __restrict__ gp, int m,
+                                                      unsigned long long* __restrict__ gmax_bits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double v = 0;
+  if (i < n) v = fabs(g[i]);
+  else if (i < n + m) v = fabs(gp[i - n]);
+  if (v > 0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(v));
+}
+
+// (H_pp + D)^-1 per landmark; lmdim = 0 for a landmark that is fixed or has no valid observation
+__global__ __launch_bounds__(256) void gr_lm_prepare_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ Hpp,
+                                                            double radius, double* __restrict__ Hinv, int32_t* __restrict__ lmdim) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= G.n_xyz + G.n_idp) return;
+  int dp = 0;
+  for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
+    const int k = G.llist[q];
+    if (valid[k]) {
+      const ObsRef o = obs_ref(G, k);
+      dp = o.dp > dp ? o.dp : dp;
+    }
+  }
+  lmdim[p] = dp;
+  double Hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (dp) {
+    double Hp[9];
+    for (int e = 0; e < 9; ++e) Hp[e] = Hpp[9 * (size_t)p + e];
+    for (int a = 0; a < dp; ++a) {
+      const double v = Hp[4 * a];
+      Hp[4 * a] += (v < 1e-6 ? 1e-6 : (v > 1e32 ? 1e32 : v)) / radius;
+    }
+    if (dp == 1) {
+      Hi[0] = 1.0 / Hp[0];
+    } else {
+      const double a = Hp[0], b = Hp[1], c = Hp[2], d = Hp[4], e = Hp[5], f = Hp[8];
+      const double A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
+      const double id = 1.0 / (a * A + b * B + c * C);
+      Hi[0] = A * id; Hi[1] = B * id; Hi[2] = C * id;
+      Hi[3] = B * id; Hi[4] = (a * f - c * c) * id; Hi[5] = (b * c - a * e) * id;
+      Hi[6] = C * id; Hi[7] = Hi[5]; Hi[8] = (a * d - b * b) * id;
+    }
+  }
+  for (int e = 0; e < 9; ++e) Hinv[9 * (size_t)p + e] = Hi[e];
+}
+
+// W = J_f^T L J_p (7 x 3, columns >= dp zero) of slot x (0: observing keyframe, 1: host) of a recorded observation
+__device__ inline void slot_W(const double* R, int x, int dp, double* W) {
+  const double* L = R + 2;
+  const double* Jf = R + (x == 0 ? 6 : 20);
+  const double* Jp = R + 34;
+  for (int b = 0; b < 3; ++b) {
+    const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
+    for (int r7 = 0; r7 < 7; ++r7) W[3 * r7 + b] = b < dp ? Jf[r7] * LJ0 + Jf[7 + r7] * LJ1 : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+                                                       const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
+                                                       const double* __restrict__ gp, double* __restrict__ Hd, int lda,
+                                                       double* __restrict__ d) {
+  const int sa = blockIdx.x * 128 + threadIdx.x;
+  const int ka = sa >> 1, x = sa & 1;
+  if (ka >= G.n_obs || !valid[ka]) return;
+  const ObsRef oa = obs_ref(G, ka);
+  const int fa = x == 0 ? oa.fj : oa.fh;
+  if (fa < 0) return;
+  const int dp = lmdim[oa.lm];
+  if (!dp) return;
+  double Wa[21], Ua[21], Hi[9];
+  slot_W(orec + (size_t)kObsRec * ka, x, dp, Wa);
+  for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)oa.lm + e];
+  for (int r7 = 0; r7 < 7; ++r7)
+    for (int b = 0; b < 3; ++b) Ua[3 * r7 + b] = Wa[3 * r7] * Hi[b] + Wa[3 * r7 + 1] * Hi[3 + b] + Wa[3 * r7 + 2] * Hi[6 + b];
+  const double g0 = gp[3 * (size_t)oa.lm], g1 = gp[3 * (size_t)oa.lm + 1], g2 = gp[3 * (size_t)oa.lm + 2];
+  for (int r7 = 0; r7 < 7; ++r7) {
+    const double v = Ua[3 * r7] * g0 + Ua[3 * r7 + 1] * g1 + Ua[3 * r7 + 2] * g2;
+    if (v != 0.0) atomicAdd(&d[7 * fa + r7], v);
+  }
+  for (int q = G.lstart[oa.lm]; q < G.lstart[oa.lm + 1]; ++q) {
+    const int kb = G.llist[q];
+    if (!valid[kb]) continue;
+    const ObsRef ob = obs_ref(G, kb);
+    for (int y = 0; y < 2; ++y) {
+      const int fb = y == 0 ? ob.fj : ob.fh;
+      if (fb < 0 || fb > fa) continue;  // lower triangle of blocks; equal frames: the whole block, from both orders
+      double Wb[21];
+      slot_W(orec + (size_t)kObsRec * kb, y, dp, Wb);
+      for (int c7 = 0; c7 < 7; ++c7)
+        for (int r7 = 0; r7 < 7; ++r7) {
+          const double v = Ua[3 * r7] * Wb[3 * c7] + Ua[3 * r7 + 1] * Wb[3 * c7 + 1] + Ua[3 * r7 + 2] * Wb[3 * c7 + 2];
+          if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + 7 * fa + r7], -v);
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gr_backsub_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+                                                         const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
+                                                         const double* __restrict__ gp, const double* __restrict__ d,
+                                                         double* __restrict__ dlm) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= G.n_xyz + G.n_idp) return;
+  const int dp = lmdim[p];
+  double out[3] = {0, 0, 0};
+  if (dp) {
+    double t[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
+    for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
+      const int k = G.llist[q];
+      if (!valid[k]) continue;
+      const ObsRef o = obs_ref(G, k);
+      const double* R = orec + (size_t)kObsRec * k;
+      const double* L = R + 2;
+      const double* Jp = R + 34;
+      for (int x = 0; x < 2; ++x) {
+        const int f = x == 0 ? o.fj : o.fh;
+        if (f < 0) continue;
+        const double* Jf = R + (x == 0 ? 6 : 20);
+        double Jd0 = 0, Jd1 = 0;
+        for (int c = 0; c < 7; ++c) {
+          Jd0 += Jf[c] * d[7 * f + c];
+          Jd1 += Jf[7 + c] * d[7 * f + c];
+        }
+        const double LJd0 = L[0] * Jd0 + L[1] * Jd1, LJd1 = L[2] * Jd0 + L[3] * Jd1;
+        for (int b = 0; b < o.dp; ++b) t[b] += Jp[b] * LJd0 + Jp[3 + b] * LJd1;
+      }
+    }
+    const double* Hi = Hinv + 9 * (size_t)p;
+    for (int a = 0; a < dp; ++a) out[a] = -(Hi[3 * a] * t[0] + Hi[3 * a + 1] * t[1] + Hi[3 * a + 2] * t[2]);
+  }
+  for (int a = 0; a < 3; ++a) dlm[3 * (size_t)p + a] = out[a];
+}
+
+// model-decrease terms: items [0, n_edges) pose edges (from the pg_edge record), then the observations
+__global__ __launch_bounds__(256) void gr_model_kernel(PgGraph P, GrLandmarks G, const double* __restrict__ erec, const uint8_t* __restrict__ valid,
+                                                       const double* __restrict__ orec, const double* __restrict__ d,
+                                                       const double* __restrict__ dlm, double* __restrict__ term) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < P.n_edges) {
+    const double* R = erec + (size_t)kEdgeRec * i;
+    const int fi = P.ei[i], fj = P.ej[i];
+    double lin = 0, quad = 0;
+    for (int p = 0; p < 7; ++p) {
+      const double dip = d[7 * fi + p], djp = fj >= 0 ? d[7 * fj + p] : 0.0;
+      lin += R[147 + p] * dip + (fj >= 0 ? R[154 + p] * djp : 0.0);
+      for (int q = 0; q < 7; ++q) {
+        const double diq = d[7 * fi + q];
+        quad += dip * R[7 * p + q] * diq;
+        if (fj >= 0) quad += djp * R[49 + 7 * p + q] * d[7 * fj + q] + 2.0 * djp * R[98 + 7 * p + q] * diq;
+      }
+    }
+    term[i] = -(lin + 0.5 * quad);
+    return;
+  }
+  const int k = i - P.n_edges;
+  if (k >= G.n_obs) return;
+  double out = 0;
+  if (valid[k]) {
+    const ObsRef o = obs_ref(G, k);
+    const double* R = orec + (size_t)kObsRec * k;
+    const double* L = R + 2;
+    double Jd0 = 0, Jd1 = 0;
+    for (int q = 0; q < 7; ++q) {
+      Jd0 += R[6 + q] * d[7 * o.fj + q];
+      Jd1 += R[13 + q] * d[7 * o.fj + q];
+      if (o.fh >= 0) {
+        Jd0 += R[20 + q] * d[7 * o.fh + q];
+        Jd1 += R[27 + q] * d[7 * o.fh + q];
+      }
+    }
+    for (int b = 0; b < o.dp; ++b) {
+      Jd0 += R[34 + b] * dlm[3 * (size_t)o.lm + b];
+      Jd1 += R[37 + b] * dlm[3 * (size_t)o.lm + b];
+    }
+    const double LJd0 = L[0] * Jd0 + L[1] * Jd1, LJd1 = L[2] * Jd0 + L[3] * Jd1;
+    const double Lr0 = L[0] * R[0] + L[1] * R[1], Lr1 = L[2] * R[0] + L[3] * R[1];
+    out = -((Jd0 * Lr0 + Jd1 * Lr1) + 0.5 * (Jd0 * LJd0 + Jd1 * LJd1));
+  }
+  term[i] = out;
+}
+
+__global__ __launch_bounds__(256) void gr_update_kernel(int n_xyz, int n_idp, const double* __restrict__ xyz, const double* __restrict__ rho,
+                                                        const double* __restrict__ dlm, double* __restrict__ xyz_new,
+                                                        double* __restrict__ rho_new) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < n_xyz) {
+    for (int a = 0; a < 3; ++a) xyz_new[3 * (size_t)p + a] = xyz[3 * (size_t)p + a] + dlm[3 * (size_t)p + a];
+  } else if (p < n_xyz + n_idp) {
+    const double v = rho[p - n_xyz] + dlm[3 * (size_t)p];
+    rho_new[p - n_xyz] = v > 1e-9 ? v : 1e-9;
+  }
+}
+
+// robust cost of every observation at a candidate (1/2 rho(s)); an observation that was valid at the linearisation point
+// (was_valid) and is not any more makes the candidate infinitely bad
+__global__ __launch_bounds__(128) void gr_cost_kernel(GrLandmarks G, const int32_t* __restrict__ dof, const double* __restrict__ S,
+                                                      const double* __restrict__ xyz, const double* __restrict__ rho,
+                                                      const uint8_t* __restrict__ was_valid, double* __restrict__ cost_o) {
+  const int k = blockIdx.x * 128 + threadIdx.x;
+  if (k >= G.n_obs) return;
+  const ObsRef o = obs_ref(G, k);
+  double r[2], w, s;
+  double c = 0;
+  if (obs_eval<false>(G, dof, k, o, S, xyz, rho, r, &w, &s, nullptr, nullptr, nullptr)) {
+    c = 0.5 * ((G.huber > 0 && s > G.huber * G.huber) ? 2.0 * G.huber * sqrt(s) - G.huber * G.huber : s);
+  } else if (was_valid && was_valid[k]) {
+    c = INFINITY;
+  }
+  cost_o[k] = c;
+}
+
+// fixed-order sum: each block adds 1024 consecutive values (thread t: 4 in order, then a fixed tree), one partial per block
+__global__ __launch_bounds__(256) void gr_reduce_kernel(const double* __restrict__ v, int n, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  double s = 0;
+  for (int e = 0; e < 4; ++e)
+    if (base + e < n) s += v[base + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+}  // namespace
+
+extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
+  if (!ctx || !gpr) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  gh_pg_problem* pr = &gpr->pg;
+  gh_ba_options opt;
+  gh_ba_default_options(&opt);
+  if (opt_in) opt = *opt_in;
+  gh_ba_summary local;
+  gh_ba_summary* sum = sum_out ? sum_out : &local;
+  memset(sum, 0, sizeof(*sum));
+  const int nf = pr->n_frames, nx = gpr->n_xyz, ni = gpr->n_idp, no = gpr->n_obs, nlm = nx + ni;
+  GH_CHECK_ARG(ctx, nf >= 1 && nf <= (1 << 20) && pr->frame_sim3 && pr->frame_dof && pr->n_se3 >= 0 && pr->n_sim3 >= 0 && pr->n_gps >= 0);
+  GH_CHECK_ARG(ctx, pr->n_se3 == 0 || (pr->se3_first && pr->se3_second && pr->se3_meas));
+  GH_CHECK_ARG(ctx, pr->n_sim3 == 0 || (pr->sim3_first && pr->sim3_second && pr->sim3_meas));
+  GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
+  GH_CHECK_ARG(ctx, nx >= 0 && ni >= 0 && no >= 0 && (nx == 0 || gpr->xyz) && (ni == 0 || (gpr->idp_host && gpr->idp_anchor && gpr->idp_rho)));
+  GH_CHECK_ARG(ctx, no == 0 || (gpr->obs_kind && gpr->obs_point && gpr->obs_frame && gpr->obs_xy));
+  for (int f = 0; f < nf; ++f) GH_CHECK_ARG(ctx, pr->frame_sim3[8 * (size_t)f + 7] > 0);
+  for (int p = 0; p < ni; ++p) GH_CHECK_ARG(ctx, gpr->idp_host[p] >= 0 && gpr->idp_host[p] < nf && gpr->idp_rho[p] > 0);
+  const double t_begin = now_ms_pg();
+  PoseHost PH;
+  GH_TRY(PH.build(ctx, pr));
+  const int ne = PH.ne;
+  // observations grouped by landmark (XYZ points first), in observation order
+  std::vector<int32_t> lstart((size_t)nlm + 2, 0), llist((size_t)(no ? no : 1), 0);
+  for (int k = 0; k < no; ++k) {
+    const int kind = gpr->obs_kind[k], p = gpr->obs_point[k], f = gpr->obs_frame[k];
+    GH_CHECK_ARG(ctx, (kind == 0 || kind == 1) && p >= 0 && p < (kind == 0 ? nx : ni) && f >= 0 && f < nf);
+    lstart[(kind == 0 ? p : nx + p) + 1]++;
+  }
+  for (int p = 0; p < nlm; ++p) lstart[p + 1] += lstart[p];
+  {
+    std::vector<int32_t> fill(lstart.begin(), lstart.end() - 1);
+    for (int k = 0; k < no; ++k) llist[fill[gpr->obs_kind[k] == 0 ? gpr->obs_point[k] : nx + gpr->obs_point[k]]++] = k;
+  }
+  const int n = 7 * nf;
+  const int lda = (n + 15) & ~15;
+  const int n_items = ne + no, n_part = gh_div_up(std::max(n_items, std::max(no, 1)), 1024);
+  DevArena A;
+  double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H, *d_Hd, *d_g, *d_d, *d_out;
+  double *d_xyz, *d_xyz_new, *d_rho, *d_rho_new, *d_anchor, *d_oxy, *d_oinfo = nullptr, *d_orec, *d_Hpp, *d_gp, *d_Hinv, *d_dlm, *d_term,
+      *d_part;
+  int32_t *d_dof, *d_etype, *d_ei, *d_ej, *d_vstart, *d_vlist, *d_pstart, *d_plist, *d_prow, *d_pcol, *d_host, *d_okind, *d_opoint,
+      *d_oframe, *d_lstart, *d_llist, *d_lmdim;
+  uint8_t *d_xfree = nullptr, *d_ifree = nullptr, *d_valid;
+  unsigned long long* d_gmax;
+  const size_t nlm1 = (size_t)std::max(nlm, 1), no1 = (size_t)std::max(no, 1);
+  bool ok = A.alloc(&d_S, (size_t)nf * 8) && A.alloc(&d_Snew, (size_t)nf * 8) && A.alloc(&d_meas, PH.meas.size()) &&
+            (!PH.any_info || A.alloc(&d_info, PH.info.size())) && A.alloc(&d_rec, (size_t)kEdgeRec * PH.etype.size()) &&
+            A.alloc(&d_cost_e, PH.etype.size()) && A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda) &&
+            A.alloc(&d_g, (size_t)n) && A.alloc(&d_d, (size_t)n) && A.alloc(&d_out, 4) && A.alloc(&d_dof, (size_t)nf) &&
+            A.alloc(&d_etype, PH.etype.size()) && A.alloc(&d_ei, PH.etype.size()) && A.alloc(&d_ej, PH.etype.size()) &&
+            A.alloc(&d_vstart, PH.vstart.size()) && A.alloc(&d_vlist, PH.vlist.size()) && A.alloc(&d_pstart, PH.pstart.size()) &&
+            A.alloc(&d_plist, PH.plist.size()) && A.alloc(&d_prow, PH.prow.size()) && A.alloc(&d_pcol, PH.pcol.size()) &&
+            A.alloc(&d_gmax, 1) && A.alloc(&d_xyz, (size_t)std::max(nx, 1) * 3) && A.alloc(&d_xyz_new, (size_t)std::max(nx, 1) * 3) &&
+            A.alloc(&d_rho, (size_t)std::max(ni, 1)) && A.alloc(&d_rho_new, (size_t)std::max(ni, 1)) &&
+            A.alloc(&d_anchor, (size_t)std::max(ni, 1) * 3) && A.alloc(&d_host, (size_t)std::max(ni, 1)) && A.alloc(&d_oxy, no1 * 2) &&
+            (!gpr->obs_info || A.alloc(&d_oinfo, no1 * 4)) && A.alloc(&d_orec, no1 * kObsRec) && A.alloc(&d_Hpp, nlm1 * 9) &&
+            A.alloc(&d_gp, nlm1 * 3) && A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) &&
+            A.alloc(&d_term, (size_t)std::max(n_items, 1)) && A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_okind, no1) &&
+            A.alloc(&d_opoint, no1) && A.alloc(&d_oframe, no1) && A.alloc(&d_lstart, lstart.size()) && A.alloc(&d_llist, llist.size()) &&
+            A.alloc(&d_lmdim, nlm1) && A.alloc(&d_valid, no1) && (!gpr->xyz_free || A.alloc(&d_xfree, (size_t)std::max(nx, 1))) &&
+            (!gpr->idp_free || A.alloc(&d_ifree, (size_t)std::max(ni, 1)));
+  if (!ok) return gh_set_error(ctx, GH_ERR_NOMEM, "gh_graph_solve: device allocation failed (dense keyframe system: %d x %d doubles)", n, lda);
+  auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
+    if (bytes) GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GH_OK;
+  };
+  GH_TRY(up(d_S, pr->frame_sim3, (size_t)nf * 64));
+  GH_TRY(up(d_dof, pr->frame_dof, (size_t)nf * 4));
+  GH_TRY(up(d_meas, PH.meas.data(), PH.meas.size() * 8));
+  if (PH.any_info) GH_TRY(up(d_info, PH.info.data(), PH.info.size() * 8));
+  GH_TRY(up(d_etype, PH.etype.data(), PH.etype.size() * 4));
+  GH_TRY(up(d_ei, PH.ei.data(), PH.ei.size() * 4));
+  GH_TRY(up(d_ej, PH.ej.data(), PH.ej.size() * 4));
+  GH_TRY(up(d_vstart, PH.vstart.data(), PH.vstart.size() * 4));
+  GH_TRY(up(d_vlist, PH.vlist.data(), PH.vlist.size() * 4));
+  GH_TRY(up(d_pstart, PH.pstart.data(), PH.pstart.size() * 4));
+  GH_TRY(up(d_plist, PH.plist.data(), PH.plist.size() * 4));
+  GH_TRY(up(d_prow, PH.prow.data(), PH.prow.size() * 4));
+  GH_TRY(up(d_pcol, PH.pcol.data(), PH.pcol.size() * 4));
+  GH_TRY(up(d_xyz, gpr->xyz, (size_t)nx * 24));
+  GH_TRY(up(d_rho, gpr->idp_rho, (size_t)ni * 8));
+  GH_TRY(up(d_anchor, gpr->idp_anchor, (size_t)ni * 24));
+  GH_TRY(up(d_host, gpr->idp_host, (size_t)ni * 4));
+  GH_TRY(up(d_oxy, gpr->obs_xy, (size_t)no * 16));
+  if (gpr->obs_info) GH_TRY(up(d_oinfo, gpr->obs_info, (size_t)no * 32));
+  GH_TRY(up(d_okind, gpr->obs_kind, (size_t)no * 4));
+  GH_TRY(up(d_opoint, gpr->obs_point, (size_t)no * 4));
+  GH_TRY(up(d_oframe, gpr->obs_frame, (size_t)no * 4));
+  GH_TRY(up(d_lstart, lstart.data(), lstart.size() * 4));
+  GH_TRY(up(d_llist, llist.data(), llist.size() * 4));
+  if (gpr->xyz_free) GH_TRY(up(d_xfree, gpr->xyz_free, (size_t)nx));
+  if (gpr->idp_free) GH_TRY(up(d_ifree, gpr->idp_free, (size_t)ni));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
+  PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, PH.n_pairs};
+  GrLandmarks LM{nx, ni, no, d_xfree, d_host, d_anchor, d_ifree, d_okind, d_opoint, d_oframe, d_oxy, d_oinfo, d_lstart, d_llist,
+                 opt.huber_delta};
+  const int eb = gh_div_up(ne > 0 ? ne : 1, 64), ob = gh_div_up(no > 0 ? no : 1, 128);
+  double host4[4];
+  // sum of v[0..count) into d_out[slot]: fixed order (1024 per block, then the partials one after the other)
+  auto reduce_to = [&](const double* v, int count, int slot) -> gh_status {
+    const int nb = gh_div_up(count > 0 ? count : 1, 1024);
+    GH_LAUNCH(ctx, "gr_reduce", gr_reduce_kernel, dim3(nb), dim3(256), 0, v, count, d_part);
+    GH_LAUNCH(ctx, "pg_sum", pg_sum_kernel, dim3(1), dim3(64), 0, (const double*)d_part, nb, d_out, slot);
+    return GH_OK;
+  };
+  // d_out[0] = cost of the pose edges, d_out[2] = cost of the observations at (S, xyz, rho)
+  auto enqueue_cost = [&](const double* S_dev, const double* xyz_dev, const double* rho_dev, const uint8_t* was_valid) -> gh_status {
+    if (ne > 0) GH_LAUNCH(ctx, "pg_cost", pg_cost_kernel, dim3(eb), dim3(64), 0, G, S_dev, d_cost_e);
+    GH_TRY(reduce_to(d_cost_e, ne, 0));
+    if (no > 0) GH_LAUNCH(ctx, "gr_cost", gr_cost_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, S_dev, xyz_dev, rho_dev, was_valid, d_term);
+    GH_TRY(reduce_to(d_term, no, 2));
+    return GH_OK;
+  };
+  GH_TRY(enqueue_cost(d_S, d_xyz, d_rho, nullptr));
+  GH_HIP(ctx, hipMemcpyAsync(host4, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double cost = host4[0] + host4[2];
+  sum->initial_cost = cost;
+  double radius = opt.initial_radius, decrease = 2.0;
+  bool need_lin = true;
+  int term = 0, it = 0;
+  for (it = 0; it < opt.max_iterations; ++it) {
+    if (need_lin) {
+      GH_HIP(ctx, hipMemsetAsync(d_H, 0, (size_t)n * lda * sizeof(double), ctx->stream));
+      GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
+      GH_HIP(ctx, hipMemsetAsync(d_Hpp, 0, nlm1 * 72, ctx->stream));
+      GH_HIP(ctx, hipMemsetAsync(d_gp, 0, nlm1 * 24, ctx->stream));
+      if (ne > 0) GH_LAUNCH(ctx, "pg_edge", pg_edge_kernel, dim3(eb), dim3(64), 0, G, (const double*)d_S, d_rec, d_cost_e);
+      // stores the pose-edge sums into every diagonal block, every edge pair block and g (zeros where there is no edge)
+      GH_LAUNCH(ctx, "pg_assemble", pg_assemble_kernel, dim3(nf + PH.n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, d_H, lda,
+                d_g, d_gmax);
+      if (no > 0)
+        GH_LAUNCH(ctx, "gr_obs_lin", gr_obs_lin_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, (const double*)d_S,
+                  (const double*)d_xyz, (const double*)d_rho, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp);
+      GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
+      GH_LAUNCH(ctx, "gr_gmax", gr_gmax_kernel, dim3(gh_div_up(n + 3 * nlm, 256)), dim3(256), 0, (const double*)d_g, n,
+                (const double*)d_gp, 3 * nlm, d_gmax);
+      unsigned long long gb = 0;
+      GH_HIP(ctx, hipMemcpyAsync(&gb, d_gmax, 8, hipMemcpyDeviceToHost, ctx->stream));
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      double gmax;
+      memcpy(&gmax, &gb, 8);
+      if (gmax <= opt.gradient_tolerance) {
+        term = 2;
+        break;
+      }
+      need_lin = false;
+    }
+    GH_LAUNCH(ctx, "pg_damp", pg_damp_kernel, dim3(gh_div_up((long long)n * lda, 256)), dim3(256), 0, (const double*)d_H, d_Hd,
+              n, lda, (const double*)d_g, d_d, radius);
+    if (nlm > 0) {
+      GH_LAUNCH(ctx, "gr_lm_prepare", gr_lm_prepare_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
+                (const double*)d_Hpp, radius, d_Hinv, d_lmdim);
+      if (no > 0)
+        GH_LAUNCH(ctx, "gr_schur", gr_schur_kernel, dim3(gh_div_up(2 * no, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
+                  (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_gp, d_Hd, lda, d_d);
+    }
+    int info = 0;
+    const double t_s0 = now_ms_pg();
+    GH_TRY(gh_potrf_solve_dev(ctx, d_Hd, n, lda, d_d, &info));
+    sum->solve_ms_total += now_ms_pg() - t_s0;
+    const bool okf = info == 0;
+    double new_cost = cost, model = 0, rho = -1;
+    if (okf) {
+      if (nlm > 0)
+        GH_LAUNCH(ctx, "gr_backsub", gr_backsub_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
+                  (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_gp, (const double*)d_d, d_dlm);
+      if (n_items > 0)
+        GH_LAUNCH(ctx, "gr_model", gr_model_kernel, dim3(gh_div_up(n_items, 256)), dim3(256), 0, G, LM, (const double*)d_rec,
+                  (const uint8_t*)d_valid, (const double*)d_orec, (const double*)d_d, (const double*)d_dlm, d_term);
+      GH_TRY(reduce_to(d_term, n_items, 1));
+      GH_LAUNCH(ctx, "pg_update", pg_update_kernel, dim3(gh_div_up(nf, 256)), dim3(256), 0, nf, (const int32_t*)d_dof,
+                (const double*)d_S, (const double*)d_d, d_Snew);
+      if (nlm > 0)
+        GH_LAUNCH(ctx, "gr_update", gr_update_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, nx, ni, (const double*)d_xyz,
+                  (const double*)d_rho, (const double*)d_dlm, d_xyz_new, d_rho_new);
+      GH_TRY(enqueue_cost(d_Snew, d_xyz_new, d_rho_new, d_valid));
+      GH_HIP(ctx, hipMemcpyAsync(host4, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      new_cost = host4[0] + host4[2];
+      model = host4[1];
+      rho = model > 0 ? (cost - new_cost) / model : -1;
+      if (!(new_cost == new_cost)) rho = -1;
+    }
+    const bool acc = okf && rho > opt.min_relative_decrease;
+    if (sum->trace_len < GH_BA_MAX_TRACE) {
+      sum->trace_cost[sum->trace_len] = new_cost;
+      sum->trace_radius[sum->trace_len] = radius;
+      sum->trace_accepted[sum->trace_len] = (uint8_t)acc;
+      sum->trace_len++;
+    }
+    if (opt.verbose)
+      fprintf(stderr, "[gh_graph] it %3d cost %.9e -> %.9e model %.3e rho %.3f radius %.3e %s\n", it, cost, new_cost, model, rho,
+              radius, acc ? "accepted" : (okf ? "rejected" : "solve failed"));
+    if (acc) {
+      const double dcost = cost - new_cost;
+      std::swap(d_S, d_Snew);
+      std::swap(d_xyz, d_xyz_new);
+      std::swap(d_rho, d_rho_new);
+      const double t = 2.0 * rho - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      if (radius > 1e16) radius = 1e16;
+      decrease = 2.0;
+      sum->accepted++;
+      need_lin = true;
+      const double prev = cost;
+      cost = new_cost;
+      if (fabs(dcost) <= opt.function_tolerance * prev) {
+        term = 1;
+        ++it;
+        break;
+      }
+    } else {
+      radius = radius / decrease;
+      decrease *= 2.0;
+      if (radius < 1e-32) {
+        term = 3;
+        ++it;
+        break;
+      }
+    }
+  }
+  sum->iterations = it;
+  sum->termination = term;
+  sum->final_cost = cost;
+  GH_HIP(ctx, hipMemcpyAsync(pr->frame_sim3, d_S, (size_t)nf * 64, hipMemcpyDeviceToHost, ctx->stream));
+  if (nx) GH_HIP(ctx, hipMemcpyAsync(gpr->xyz, d_xyz, (size_t)nx * 24, hipMemcpyDeviceToHost, ctx->stream));
+  if (ni) GH_HIP(ctx, hipMemcpyAsync(gpr->idp_rho, d_rho, (size_t)ni * 8, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   sum->total_ms = now_ms_pg() - t_begin;
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;

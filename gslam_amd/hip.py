@@ -64,6 +64,13 @@ class PgProblem(C.Structure):
                 ("n_gps", C.c_int32), ("gps_frame", C.c_void_p), ("gps_meas", C.c_void_p), ("gps_info", C.c_void_p)]
 
 
+class GraphProblem(C.Structure):
+    _fields_ = [("pg", PgProblem), ("n_xyz", C.c_int32), ("xyz", C.c_void_p), ("xyz_free", C.c_void_p),
+                ("n_idp", C.c_int32), ("idp_host", C.c_void_p), ("idp_anchor", C.c_void_p), ("idp_rho", C.c_void_p),
+                ("idp_free", C.c_void_p), ("n_obs", C.c_int32), ("obs_kind", C.c_void_p), ("obs_point", C.c_void_p),
+                ("obs_frame", C.c_void_p), ("obs_xy", C.c_void_p), ("obs_info", C.c_void_p)]
+
+
 class BaOptions(C.Structure):
     _fields_ = [("huber_delta", C.c_double), ("max_iterations", C.c_int32), ("initial_radius", C.c_double),
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
@@ -161,6 +168,7 @@ SIGNATURES = {
     "gh_ba_graph_read": (C.c_int, [_vp, _vp, _vp]),
     "gh_ba_pnp": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, C.POINTER(BaOptions), _vp, C.POINTER(BaSummary)]),
     "gh_pg_solve": (C.c_int, [_vp, C.POINTER(PgProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
+    "gh_graph_solve": (C.c_int, [_vp, C.POINTER(GraphProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "gh_align_sim3": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "gh_potrf_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, C.POINTER(_i)]),
 }

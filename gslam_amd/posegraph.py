@@ -13,14 +13,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def solve(ctx: hip.Context, frames, dof, problem: dict, options=None):
-    """problem: {"se3": (first, second, meas n x 7, info n x 36 | None), "sim3": (first, second, meas n x 8, info n x 49 |
-    None), "gps": (frame, meas n x 7, info n x 36 | None)} (any subset).  -> (frames n x 8, summary, status)."""
-    options = options or default_options()
-    S = np.ascontiguousarray(frames, dtype=np.float64).copy()
-    d = np.ascontiguousarray(dof, dtype=np.int32)
-    keep = [S, d]
-    pr = hip.PgProblem()
+def _fill_pose_part(pr, S, d, problem, keep):
     pr.n_frames, pr.frame_sim3, pr.frame_dof = len(S), _p(S), _p(d)
     for key in ("se3", "sim3"):
         if problem.get(key) is not None:
@@ -38,11 +31,54 @@ def solve(ctx: hip.Context, frames, dof, problem: dict, options=None):
         inf = np.ascontiguousarray(inf, dtype=np.float64) if inf is not None else None
         keep += [f, m, inf]
         pr.n_gps, pr.gps_frame, pr.gps_meas, pr.gps_info = len(f), _p(f), _p(m), _p(inf)
+
+
+def solve(ctx: hip.Context, frames, dof, problem: dict, options=None):
+    """problem: {"se3": (first, second, meas n x 7, info n x 36 | None), "sim3": (first, second, meas n x 8, info n x 49 |
+    None), "gps": (frame, meas n x 7, info n x 36 | None)} (any subset).  -> (frames n x 8, summary, status)."""
+    options = options or default_options()
+    S = np.ascontiguousarray(frames, dtype=np.float64).copy()
+    d = np.ascontiguousarray(dof, dtype=np.int32)
+    keep = [S, d]
+    pr = hip.PgProblem()
+    _fill_pose_part(pr, S, d, problem, keep)
     sm = hip.BaSummary()
     st = hip.lib.gh_pg_solve(ctx.h, C.byref(pr), C.byref(options), C.byref(sm))
     if st not in (0, 4):
         ctx.check(st)
     return S, sm, st
+
+
+def solve_graph(ctx: hip.Context, frames, dof, problem: dict, options=None):
+    """The general BundleGraph (gh_graph_solve): the pose-edge keys of solve() plus
+      "xyz": (points n x 3, free mask | None), "idp": (host, anchor n x 3, rho, free mask | None),
+      "obs": (kind, point, frame, xy n x 2, info n x 4 | None)            (gslam_amd.pg_synth.make_landmark_graph).
+    options.huber_delta = the projection Huber threshold.  -> (frames, xyz, rho, summary, status)."""
+    options = options or default_options()
+    S = np.ascontiguousarray(frames, dtype=np.float64).copy()
+    d = np.ascontiguousarray(dof, dtype=np.int32)
+    keep = [S, d]
+    gp = hip.GraphProblem()
+    _fill_pose_part(gp.pg, S, d, problem, keep)
+    xyz, xfree = problem.get("xyz") or (np.zeros((0, 3)), None)
+    host, anchor, rho, ifree = problem.get("idp") or (np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros(0), None)
+    kind, point, frame, xy, oinfo = problem.get("obs") or (np.zeros(0, np.int32),) * 3 + (np.zeros((0, 2)), None)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).copy()
+    rho = np.ascontiguousarray(rho, dtype=np.float64).copy()
+    u8 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.uint8)
+    i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+    f64 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float64)
+    xfree, ifree, host, anchor = u8(xfree), u8(ifree), i32(host), f64(anchor)
+    kind, point, frame, xy, oinfo = i32(kind), i32(point), i32(frame), f64(xy), f64(oinfo)
+    keep += [xyz, rho, xfree, ifree, host, anchor, kind, point, frame, xy, oinfo]
+    gp.n_xyz, gp.xyz, gp.xyz_free = len(xyz), _p(xyz), _p(xfree)
+    gp.n_idp, gp.idp_host, gp.idp_anchor, gp.idp_rho, gp.idp_free = len(rho), _p(host), _p(anchor), _p(rho), _p(ifree)
+    gp.n_obs, gp.obs_kind, gp.obs_point, gp.obs_frame, gp.obs_xy, gp.obs_info = len(kind), _p(kind), _p(point), _p(frame), _p(xy), _p(oinfo)
+    sm = hip.BaSummary()
+    st = hip.lib.gh_graph_solve(ctx.h, C.byref(gp), C.byref(options), C.byref(sm))
+    if st not in (0, 4):
+        ctx.check(st)
+    return S, xyz, rho, sm, st
 
 
 def align_sim3(ctx: hip.Context, src, dst, dof=127):

@@ -469,6 +469,33 @@ typedef struct gh_pg_problem {
 } gh_pg_problem;
 gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* problem, const gh_ba_options* options, gh_ba_summary* summary);
 
+/* The GENERAL BundleGraph of Optimizer::optimize (GSLAM/core/Optimizer.h:150-172,229): the keyframes and pose-graph edges
+ * of gh_pg_problem PLUS landmarks -- XYZ map points (mappoints, :113-114,155) and inverse-depth points (invDepths,
+ * :106-111,152-153: host keyframe, anchor in the host camera, idepth) -- with their pinhole observations (BundleEdge,
+ * :121-125,160-161).  This is the path for what gh_ba_solve (SE3 cameras + XYZ points only, the fast path) does not take:
+ * inverse-depth points, keyframes with a free scale, pose-graph edges mixed with observations.  The reference holds no
+ * implementation: specification and cross-checks in oracle/graph_oracle.c (parity unpinned).  options->huber_delta is
+ * OptimzeConfig::projectErrorHuberThreshold (0 = no robust kernel).  Landmarks are eliminated by a Schur complement, the
+ * keyframe system (7 n_frames square) is dense.  In/out: pg.frame_sim3, xyz, idp_rho.
+ *   xyz n_xyz x 3 world points, xyz_free NULL = all free;  idp_host / idp_anchor (n x 3, pinhole anchors (x, y, 1)) /
+ *   idp_rho > 0 / idp_free;  obs_kind 0 = XYZ point, 1 = inverse-depth point; obs_point indexes the respective array;
+ *   obs_xy n_obs x 2 normalised image coordinates; obs_info n_obs x 4 row-major 2x2 or NULL. */
+typedef struct gh_graph_problem {
+  gh_pg_problem pg;
+  int32_t n_xyz;
+  double* xyz;
+  const uint8_t* xyz_free;
+  int32_t n_idp;
+  const int32_t* idp_host;
+  const double* idp_anchor;
+  double* idp_rho;
+  const uint8_t* idp_free;
+  int32_t n_obs;
+  const int32_t *obs_kind, *obs_point, *obs_frame;
+  const double *obs_xy, *obs_info;
+} gh_graph_problem;
+gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* problem, const gh_ba_options* options, gh_ba_summary* summary);
+
 /* 3-D alignment dst_k ~ s R src_k + t over n correspondences (n x 3 doubles each), Horn's closed form: what
  * Optimizer::optimizeICP (3D-3D correspondences, Optimizer.h:210-217) and Optimizer::fitSim3 (translations of two
  * synchronised trajectories, :220-225) compute.  dof & GH_KF_SCALE decides whether s is estimated (else s = 1).

@@ -1,0 +1,95 @@
+"""GPU parity of gh_graph_solve (general BundleGraph: SIM3 keyframes, pose edges, XYZ and inverse-depth landmarks) against
+oracle/graph_oracle.c through the C ABI.  f64 on both sides; the GPU assembles with atomics (summation order varies), so
+traces agree to ~1e-9 relative, not bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from gslam_amd.pg_synth import make_landmark_graph, make_pose_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(huber, iters=40):
+    from gslam_amd.ba import default_options
+    o = default_options()
+    o.huber_delta = huber
+    o.max_iterations = iters
+    return o
+
+
+def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-7):
+    from gslam_amd import posegraph
+    oo = oracle_lib.ba_options(huber=huber, max_iterations=iters)
+    S0, x0, r0, so, st0 = oracle.graph_solve(start, dof, problem, oo)
+    S1, x1, r1, sg, st1 = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, iters))
+    assert st0 == 0 and st1 == 0
+    assert np.isclose(sg.initial_cost, so.initial_cost, rtol=1e-12)
+    assert sg.iterations == so.iterations and sg.trace_len == so.trace_len
+    assert list(sg.trace_accepted[:sg.trace_len]) == list(so.trace_accepted[:so.trace_len])
+    assert np.allclose(np.array(sg.trace_cost[:sg.trace_len]), np.array(so.trace_cost[:so.trace_len]), rtol=rtol, atol=1e-15)
+    assert np.isclose(sg.final_cost, so.final_cost, rtol=rtol, atol=1e-15)
+    assert np.allclose(S1, S0, atol=1e-7) and np.allclose(x1, x0, atol=1e-6) and np.allclose(r1, r0, rtol=1e-6, atol=1e-9)
+    return so, sg
+
+
+@pytest.mark.parametrize("kind,n_xyz,n_idp,pose_edges,with_info,huber", [
+    ("se3", 200, 0, False, False, 0.01),      # plain BA through the general path
+    ("se3", 0, 200, False, False, 0.01),      # inverse-depth points only
+    ("se3", 150, 150, False, True, 0.02),     # both kinds, 2x2 informations
+    ("sim3", 120, 120, True, False, 0.01),    # free keyframe scales + pose-graph edges mixed with observations
+    ("se3", 100, 100, True, True, 0.0),       # no robust kernel
+])
+def test_graph_solve_matches_the_oracle(ctx, oracle, kind, n_xyz, n_idp, pose_edges, with_info, huber):
+    truth, start, dof, problem = make_landmark_graph(n_frames=12, n_xyz=n_xyz, n_idp=n_idp, kind=kind, seed=21, noise=2e-3,
+                                                     pose_edges=pose_edges, with_info=with_info, outliers=0.05, obs_per_point=5)
+    so, sg = _compare(ctx, oracle, start, dof, problem, huber)
+    assert so.final_cost < (0.2 if huber > 0 else 0.5) * so.initial_cost and so.iterations >= 3  # (outliers stay in the sum without a kernel)
+
+
+def test_graph_solve_without_landmarks_is_the_pose_graph_solver(ctx, oracle):
+    from gslam_amd import posegraph
+    truth, start, dof, problem = make_pose_graph(n_frames=30, n_loops=5, kind="sim3", seed=4, noise=0.01, scale_drift=0.1)
+    S1, s1, st1 = posegraph.solve(ctx, start, dof, problem, _opts(0.0, 30))
+    S2, _, _, s2, st2 = posegraph.solve_graph(ctx, start, dof, problem, _opts(0.0, 30))
+    assert st1 == st2 == 0 and s1.iterations == s2.iterations
+    assert np.allclose(np.array(s1.trace_cost[:s1.trace_len]), np.array(s2.trace_cost[:s2.trace_len]), rtol=1e-9)
+    assert np.allclose(S1, S2, atol=1e-9)
+
+
+def test_graph_solve_fixed_landmarks_points_behind_and_host_observations(ctx, oracle):
+    truth, start, dof, problem = make_landmark_graph(n_frames=9, n_xyz=60, n_idp=60, kind="se3", seed=8, noise=1e-3, obs_per_point=4)
+    xyz, xfree = problem["xyz"]
+    host, anchor, rho, ifree = problem["idp"]
+    xfree = xfree.copy(); xfree[::3] = 0
+    ifree = ifree.copy(); ifree[1::4] = 0
+    xyz = xyz.copy()
+    # one point behind every camera that sees it (dropped observations), one nearly at infinity
+    xyz[1] = [0.0, 0.0, -50.0]
+    rho = rho.copy(); rho[2] = 1e-7
+    prob = dict(problem, xyz=(xyz, xfree), idp=(host, anchor, rho, ifree))
+    so, sg = _compare(ctx, oracle, start, dof, prob, 0.01, rtol=1e-6)
+    from gslam_amd import posegraph
+    S1, x1, r1, _, _ = posegraph.solve_graph(ctx, start, dof, prob, _opts(0.01))
+    assert np.array_equal(x1[::3], xyz[::3]) and np.array_equal(r1[1::4], rho[1::4])
+    assert not np.array_equal(x1[2], xyz[2])
+
+
+def test_graph_solve_larger_window(ctx, oracle):
+    """60 keyframes (n = 420: above the single-block regime of the dense solver), 3000 landmarks, 15 000 observations."""
+    truth, start, dof, problem = make_landmark_graph(n_frames=60, n_xyz=1500, n_idp=1500, kind="se3", seed=31, noise=1e-3,
+                                                     obs_per_point=5, outliers=0.03)
+    so, sg = _compare(ctx, oracle, start, dof, problem, 0.01, iters=15, rtol=1e-6)
+    assert so.final_cost < 0.2 * so.initial_cost  # (3 % outliers keep their Huber cost)
+
+
+def test_graph_solve_rejects_bad_arguments(ctx):
+    from gslam_amd import hip, posegraph
+    truth, start, dof, problem = make_landmark_graph(n_frames=4, n_xyz=5, n_idp=5, seed=1)
+    kind, point, frame, xy, info = problem["obs"]
+    bad = dict(problem, obs=(kind, point + 100, frame, xy, info))
+    with pytest.raises(hip.GslamHipError):
+        posegraph.solve_graph(ctx, start, dof, bad)
+    host, anchor, rho, free = problem["idp"]
+    with pytest.raises(hip.GslamHipError):
+        posegraph.solve_graph(ctx, start, dof, dict(problem, idp=(host, anchor, -rho, free)))
