@@ -11,8 +11,10 @@
 //   optimizePose(...)        (:193-199)  -> gh_ba_pnp on the points of the first frame (anchor / idepth)
 //   optimizeICP(...)         (:210-217)  -> gh_align_sim3 (3D-3D correspondences)
 //   fitSim3(...)             (:220-225)  -> gh_align_sim3 (translations of two synchronised trajectories)
-// Still `return false` ("unsupported", as the interface allows): inverse-depth vertices, camera self-calibration, sphere
-// projection, pose-graph edges mixed with point observations in one graph, magin().
+//                                        -> gh_graph_solve when the graph holds inverse-depth points (invDepths /
+//                                           invDepthObserves, :106-111,152-153,160) or pose-graph edges TOGETHER with
+//                                           point observations: the general solver (SIM3 keyframes, both landmark kinds)
+// Still `return false` ("unsupported", as the interface allows): camera self-calibration, sphere projection, magin().
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
@@ -37,13 +39,12 @@ class OptimizerHIP : public GSLAM::Optimizer {
   bool optimize(GSLAM::BundleGraph& graph) override {
     // supported sub-problem: xyz map points observed by SE3/SIM3 keyframes, pinhole anchors
     if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
-    if (!graph.invDepths.empty() || !graph.invDepthObserves.empty()) return unsupported("inverse-depth points");
-    if (!graph.se3Graph.empty() || !graph.sim3Graph.empty() || !graph.gpsGraph.empty()) {
-      if (!graph.mappointObserves.empty()) return unsupported("pose-graph edges mixed with point observations");
-      return optimizePoseGraph(graph);
-    }
     if (graph.cameraDOF != GSLAM::UPDATE_CAMERA_NONE && graph.camera.isValid())
       return unsupported("camera self-calibration");
+    const bool pose_edges = !graph.se3Graph.empty() || !graph.sim3Graph.empty() || !graph.gpsGraph.empty();
+    if (!graph.invDepths.empty() || !graph.invDepthObserves.empty() || (pose_edges && !graph.mappointObserves.empty()))
+      return optimizeGeneral(graph);
+    if (pose_edges) return optimizePoseGraph(graph);
     if (graph.keyframes.empty()) return false;
     if (!context()) return false;
 
@@ -151,6 +152,60 @@ class OptimizerHIP : public GSLAM::Optimizer {
     return true;
   }
 
+  // the three pose-graph edge lists of a BundleGraph flattened for gh_pg_problem (the vectors own the storage)
+  struct PoseEdges {
+    std::vector<int32_t> f1, s1, f2, s2, fg;
+    std::vector<double> m1, m2, mg, i1, i2, ig;
+  };
+  bool fill_pose_part(GSLAM::BundleGraph& graph, std::vector<double>& frames, std::vector<int32_t>& dof, PoseEdges& E,
+                      gh_pg_problem& pr) {
+    const size_t nf = graph.keyframes.size();
+    bool any1 = false, any2 = false, anyg = false;
+    for (size_t k = 0; k < graph.se3Graph.size(); ++k) any1 = any1 || graph.se3Graph[k].information != NULL;
+    for (size_t k = 0; k < graph.sim3Graph.size(); ++k) any2 = any2 || graph.sim3Graph[k].information != NULL;
+    for (size_t k = 0; k < graph.gpsGraph.size(); ++k) anyg = anyg || graph.gpsGraph[k].information != NULL;
+    auto put_info = [](std::vector<double>& dst, const double* inf, int dim) {
+      for (int a = 0; a < dim; ++a)
+        for (int b = 0; b < dim; ++b) dst.push_back(inf ? inf[dim * a + b] : (a == b ? 1.0 : 0.0));
+    };
+    for (size_t k = 0; k < graph.se3Graph.size(); ++k) {
+      const GSLAM::SE3Edge& e = graph.se3Graph[k];
+      if (e.firstId >= nf || e.secondId >= nf || e.firstId == e.secondId) return bad_edge("se3Graph", k);
+      E.f1.push_back((int32_t)e.firstId); E.s1.push_back((int32_t)e.secondId);
+      double m[8];
+      put_sim3(GSLAM::SIM3(e.measurement, 1.0), m);
+      E.m1.insert(E.m1.end(), m, m + 7);
+      if (any1) put_info(E.i1, e.information, 6);
+    }
+    for (size_t k = 0; k < graph.sim3Graph.size(); ++k) {
+      const GSLAM::SIM3Edge& e = graph.sim3Graph[k];
+      if (e.firstId >= nf || e.secondId >= nf || e.firstId == e.secondId || !(e.measurement.get_scale() > 0))
+        return bad_edge("sim3Graph", k);
+      E.f2.push_back((int32_t)e.firstId); E.s2.push_back((int32_t)e.secondId);
+      double m[8];
+      put_sim3(e.measurement, m);
+      E.m2.insert(E.m2.end(), m, m + 8);
+      if (any2) put_info(E.i2, e.information, 7);
+    }
+    for (size_t k = 0; k < graph.gpsGraph.size(); ++k) {
+      const GSLAM::GPSEdge& e = graph.gpsGraph[k];
+      if (e.frameId >= nf) return bad_edge("gpsGraph", k);
+      E.fg.push_back((int32_t)e.frameId);
+      double m[8];
+      put_sim3(GSLAM::SIM3(e.measurement, 1.0), m);
+      E.mg.insert(E.mg.end(), m, m + 7);
+      if (anyg) put_info(E.ig, e.information, 6);
+    }
+    std::memset(&pr, 0, sizeof(pr));
+    pr.n_frames = (int32_t)nf; pr.frame_sim3 = frames.data(); pr.frame_dof = dof.data();
+    pr.n_se3 = (int32_t)E.f1.size(); pr.se3_first = E.f1.data(); pr.se3_second = E.s1.data(); pr.se3_meas = E.m1.data();
+    pr.se3_info = any1 ? E.i1.data() : NULL;
+    pr.n_sim3 = (int32_t)E.f2.size(); pr.sim3_first = E.f2.data(); pr.sim3_second = E.s2.data(); pr.sim3_meas = E.m2.data();
+    pr.sim3_info = any2 ? E.i2.data() : NULL;
+    pr.n_gps = (int32_t)E.fg.size(); pr.gps_frame = E.fg.data(); pr.gps_meas = E.mg.data(); pr.gps_info = anyg ? E.ig.data() : NULL;
+    return true;
+  }
+
   // Pose graph (loop closing / GPS fusion): keyframes are SIM3 T_wc, edges as Optimizer.h:127-148 defines them.
   bool optimizePoseGraph(GSLAM::BundleGraph& graph) {
     if (graph.keyframes.empty() || !context()) return false;
@@ -163,52 +218,9 @@ class OptimizerHIP : public GSLAM::Optimizer {
       put_sim3(T, &frames[i * 8]);
       dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SIM3;
     }
-    std::vector<int32_t> f1, s1, f2, s2, fg;
-    std::vector<double> m1, m2, mg, i1, i2, ig;
-    bool any1 = false, any2 = false, anyg = false;
-    for (size_t k = 0; k < graph.se3Graph.size(); ++k) any1 = any1 || graph.se3Graph[k].information != NULL;
-    for (size_t k = 0; k < graph.sim3Graph.size(); ++k) any2 = any2 || graph.sim3Graph[k].information != NULL;
-    for (size_t k = 0; k < graph.gpsGraph.size(); ++k) anyg = anyg || graph.gpsGraph[k].information != NULL;
-    auto put_info = [](std::vector<double>& dst, const double* inf, int dim) {
-      for (int a = 0; a < dim; ++a)
-        for (int b = 0; b < dim; ++b) dst.push_back(inf ? inf[dim * a + b] : (a == b ? 1.0 : 0.0));
-    };
-    for (size_t k = 0; k < graph.se3Graph.size(); ++k) {
-      const GSLAM::SE3Edge& e = graph.se3Graph[k];
-      if (e.firstId >= nf || e.secondId >= nf || e.firstId == e.secondId) return bad_edge("se3Graph", k);
-      f1.push_back((int32_t)e.firstId); s1.push_back((int32_t)e.secondId);
-      double m[8];
-      put_sim3(GSLAM::SIM3(e.measurement, 1.0), m);
-      m1.insert(m1.end(), m, m + 7);
-      if (any1) put_info(i1, e.information, 6);
-    }
-    for (size_t k = 0; k < graph.sim3Graph.size(); ++k) {
-      const GSLAM::SIM3Edge& e = graph.sim3Graph[k];
-      if (e.firstId >= nf || e.secondId >= nf || e.firstId == e.secondId || !(e.measurement.get_scale() > 0))
-        return bad_edge("sim3Graph", k);
-      f2.push_back((int32_t)e.firstId); s2.push_back((int32_t)e.secondId);
-      double m[8];
-      put_sim3(e.measurement, m);
-      m2.insert(m2.end(), m, m + 8);
-      if (any2) put_info(i2, e.information, 7);
-    }
-    for (size_t k = 0; k < graph.gpsGraph.size(); ++k) {
-      const GSLAM::GPSEdge& e = graph.gpsGraph[k];
-      if (e.frameId >= nf) return bad_edge("gpsGraph", k);
-      fg.push_back((int32_t)e.frameId);
-      double m[8];
-      put_sim3(GSLAM::SIM3(e.measurement, 1.0), m);
-      mg.insert(mg.end(), m, m + 7);
-      if (anyg) put_info(ig, e.information, 6);
-    }
+    PoseEdges E;
     gh_pg_problem pr;
-    std::memset(&pr, 0, sizeof(pr));
-    pr.n_frames = (int32_t)nf; pr.frame_sim3 = frames.data(); pr.frame_dof = dof.data();
-    pr.n_se3 = (int32_t)f1.size(); pr.se3_first = f1.data(); pr.se3_second = s1.data(); pr.se3_meas = m1.data();
-    pr.se3_info = any1 ? i1.data() : NULL;
-    pr.n_sim3 = (int32_t)f2.size(); pr.sim3_first = f2.data(); pr.sim3_second = s2.data(); pr.sim3_meas = m2.data();
-    pr.sim3_info = any2 ? i2.data() : NULL;
-    pr.n_gps = (int32_t)fg.size(); pr.gps_frame = fg.data(); pr.gps_meas = mg.data(); pr.gps_info = anyg ? ig.data() : NULL;
+    if (!fill_pose_part(graph, frames, dof, E, pr)) return false;
     gh_ba_options o;
     gh_ba_default_options(&o);
     o.max_iterations = _config.maxIterations;
@@ -230,6 +242,99 @@ class OptimizerHIP : public GSLAM::Optimizer {
       const double* p = &frames[i * 8];
       graph.keyframes[i].estimation = GSLAM::SIM3(GSLAM::SO3(p[0], p[1], p[2], p[3]), GSLAM::Point3d(p[4], p[5], p[6]), p[7]);
     }
+    return true;
+  }
+
+  // The general BundleGraph: SIM3 keyframes, pose-graph edges, XYZ map points and inverse-depth points together
+  // (gh_graph_solve; specification in oracle/graph_oracle.c).  An inverse-depth point lives at anchor / idepth in the camera
+  // of its host keyframe (InvDepthEstimation::frameId), the anchor taken on the z = 1 plane; UPDATE_ID_IDEPTH frees the
+  // inverse depth, sigma is carried through untouched.
+  bool optimizeGeneral(GSLAM::BundleGraph& graph) {
+    if (graph.keyframes.empty() || !context()) return false;
+    const size_t nf = graph.keyframes.size(), np = graph.mappoints.size(), ni = graph.invDepths.size();
+    std::vector<double> frames(nf * 8);
+    std::vector<int32_t> dof(nf);
+    for (size_t i = 0; i < nf; ++i) {
+      const GSLAM::SIM3& T = graph.keyframes[i].estimation;
+      if (!(T.get_scale() > 0)) return unsupported("keyframe with non-positive SIM3 scale");
+      put_sim3(T, &frames[i * 8]);
+      dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SIM3;
+    }
+    PoseEdges E;
+    gh_graph_problem gp;
+    std::memset(&gp, 0, sizeof(gp));
+    if (!fill_pose_part(graph, frames, dof, E, gp.pg)) return false;
+    std::vector<double> xyz(np * 3), anchor(ni * 3), rho(ni), oxy, oinfo;
+    std::vector<uint8_t> xfree(np), ifree(ni);
+    std::vector<int32_t> host(ni), okind, opoint, oframe;
+    for (size_t i = 0; i < np; ++i) {
+      xyz[3 * i] = graph.mappoints[i].first.x;
+      xyz[3 * i + 1] = graph.mappoints[i].first.y;
+      xyz[3 * i + 2] = graph.mappoints[i].first.z;
+      xfree[i] = graph.mappoints[i].second ? 1 : 0;
+    }
+    for (size_t i = 0; i < ni; ++i) {
+      const GSLAM::InvDepthEstimation& v = graph.invDepths[i];
+      if (v.frameId >= nf || !(v.anchor.z > 0) || !(v.estimation.x > 0)) {
+        LOG(ERROR) << "OptimizerHIP: inverse-depth point " << i << " needs a valid host keyframe, anchor.z > 0 and idepth > 0";
+        return false;
+      }
+      host[i] = (int32_t)v.frameId;
+      anchor[3 * i] = v.anchor.x / v.anchor.z;
+      anchor[3 * i + 1] = v.anchor.y / v.anchor.z;
+      anchor[3 * i + 2] = 1.0;
+      rho[i] = v.estimation.x;
+      ifree[i] = (v.dof & GSLAM::UPDATE_ID_IDEPTH) ? 1 : 0;
+    }
+    bool any_info = false;
+    for (size_t k = 0; k < graph.mappointObserves.size(); ++k) any_info = any_info || graph.mappointObserves[k].information != NULL;
+    for (size_t k = 0; k < graph.invDepthObserves.size(); ++k) any_info = any_info || graph.invDepthObserves[k].information != NULL;
+    for (int kind = 0; kind < 2; ++kind) {
+      const std::vector<GSLAM::BundleEdge>& obs = kind == 0 ? graph.mappointObserves : graph.invDepthObserves;
+      for (size_t k = 0; k < obs.size(); ++k) {
+        const GSLAM::BundleEdge& e = obs[k];
+        if (e.pointId >= (kind == 0 ? np : ni) || e.frameId >= nf || !(e.measurement.z > 0)) {
+          LOG(ERROR) << "OptimizerHIP: " << (kind == 0 ? "mappoint" : "inverse-depth") << " observation " << k
+                     << " references a missing vertex or has measurement.z <= 0";
+          return false;
+        }
+        okind.push_back(kind);
+        opoint.push_back((int32_t)e.pointId);
+        oframe.push_back((int32_t)e.frameId);
+        oxy.push_back(e.measurement.x / e.measurement.z);
+        oxy.push_back(e.measurement.y / e.measurement.z);
+        if (any_info)
+          for (int a = 0; a < 4; ++a) oinfo.push_back(e.information ? e.information[a] : ((a == 0 || a == 3) ? 1.0 : 0.0));
+      }
+    }
+    gp.n_xyz = (int32_t)np; gp.xyz = xyz.data(); gp.xyz_free = xfree.data();
+    gp.n_idp = (int32_t)ni; gp.idp_host = host.data(); gp.idp_anchor = anchor.data(); gp.idp_rho = rho.data(); gp.idp_free = ifree.data();
+    gp.n_obs = (int32_t)okind.size(); gp.obs_kind = okind.data(); gp.obs_point = opoint.data(); gp.obs_frame = oframe.data();
+    gp.obs_xy = oxy.data(); gp.obs_info = any_info ? oinfo.data() : NULL;
+    gh_ba_options o;
+    gh_ba_default_options(&o);
+    o.huber_delta = _config.projectErrorHuberThreshold;
+    o.max_iterations = _config.maxIterations;
+    o.verbose = _config.verbose ? 1 : 0;
+    gh_ba_summary s;
+    gh_status st;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      st = gh_graph_solve(ctx_, &gp, &o, &s);
+    }
+    if (st != GH_OK) {
+      LOG(ERROR) << "OptimizerHIP: graph optimisation failed (" << st << "): " << gh_last_error(ctx_);
+      return false;
+    }
+    if (_config.verbose)
+      LOG(INFO) << "OptimizerHIP: general graph, " << s.iterations << " LM iterations, cost " << s.initial_cost << " -> "
+                << s.final_cost << " in " << s.total_ms << " ms";
+    for (size_t i = 0; i < nf; ++i) {
+      const double* p = &frames[i * 8];
+      graph.keyframes[i].estimation = GSLAM::SIM3(GSLAM::SO3(p[0], p[1], p[2], p[3]), GSLAM::Point3d(p[4], p[5], p[6]), p[7]);
+    }
+    for (size_t i = 0; i < np; ++i) graph.mappoints[i].first = GSLAM::Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    for (size_t i = 0; i < ni; ++i) graph.invDepths[i].estimation.x = rho[i];
     return true;
   }
 

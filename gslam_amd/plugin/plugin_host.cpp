@@ -193,6 +193,45 @@ static int run_pg(const std::string& dir, const char* in, const char* out) {
     e.information = has_info ? &ig[(size_t)k * 36] : NULL;
     g.gpsGraph.push_back(e);
   }
+  // optional landmark section (the general BundleGraph): int32 {n_xyz, n_idp, n_obs_xyz, n_obs_idp, has_obs_info}, double
+  // huber; xyz n x 3, free n (u8); idp: host n (i32), anchor n x 3, [idepth, sigma] n x 2, dof n (i32); then for each of the
+  // two observation lists: point (i32), frame (i32), measurement n x 3, information n x 4 (if has_obs_info)
+  int32_t lh[5] = {0, 0, 0, 0, 0};
+  std::vector<double> oinf_xyz, oinf_idp;
+  if (f.read((char*)lh, sizeof(lh))) {
+    double huber = 0;
+    f.read((char*)&huber, 8);
+    opt_ptr->_config.projectErrorHuberThreshold = huber;
+    std::vector<double> xyz = read_vec<double>(f, (size_t)lh[0] * 3);
+    std::vector<uint8_t> xfree = read_vec<uint8_t>(f, lh[0]);
+    std::vector<int32_t> host = read_vec<int32_t>(f, lh[1]);
+    std::vector<double> anchor = read_vec<double>(f, (size_t)lh[1] * 3), est = read_vec<double>(f, (size_t)lh[1] * 2);
+    std::vector<int32_t> idof = read_vec<int32_t>(f, lh[1]);
+    for (int i = 0; i < lh[0]; ++i)
+      g.mappoints.push_back(std::make_pair(Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), xfree[i] != 0));
+    for (int i = 0; i < lh[1]; ++i) {
+      InvDepthEstimation v;
+      v.frameId = host[i];
+      v.anchor = Point3d(anchor[3 * i], anchor[3 * i + 1], anchor[3 * i + 2]);
+      v.estimation = Point2d(est[2 * i], est[2 * i + 1]);
+      v.dof = (InvDepthEstimationDOF)idof[i];
+      g.invDepths.push_back(v);
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      const int n = lh[2 + kind];
+      std::vector<int32_t> pt = read_vec<int32_t>(f, n), fr2 = read_vec<int32_t>(f, n);
+      std::vector<double> ms = read_vec<double>(f, (size_t)n * 3);
+      std::vector<double>& inf = kind == 0 ? oinf_xyz : oinf_idp;
+      inf = read_vec<double>(f, lh[4] ? (size_t)n * 4 : 0);
+      for (int k = 0; k < n; ++k) {
+        BundleEdge e;
+        e.pointId = pt[k]; e.frameId = fr2[k];
+        e.measurement = Point3d(ms[3 * k], ms[3 * k + 1], ms[3 * k + 2]);
+        e.information = lh[4] ? &inf[(size_t)k * 4] : NULL;
+        (kind == 0 ? g.mappointObserves : g.invDepthObserves).push_back(e);
+      }
+    }
+  }
   const bool ok = opt_ptr->optimize(g);
   std::ofstream o(out, std::ios::binary);
   int32_t okv = ok ? 1 : 0;
@@ -202,6 +241,14 @@ static int run_pg(const std::string& dir, const char* in, const char* out) {
     SO3 r = T.get_rotation();
     Point3d t = T.get_translation();
     double p[8] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z, T.get_scale()};
+    o.write((char*)p, sizeof(p));
+  }
+  for (size_t i = 0; i < g.mappoints.size(); ++i) {
+    double p[3] = {g.mappoints[i].first.x, g.mappoints[i].first.y, g.mappoints[i].first.z};
+    o.write((char*)p, sizeof(p));
+  }
+  for (size_t i = 0; i < g.invDepths.size(); ++i) {
+    double p[2] = {g.invDepths[i].estimation.x, g.invDepths[i].estimation.y};
     o.write((char*)p, sizeof(p));
   }
   std::cout << "pose_graph_optimize=" << ok << std::endl;

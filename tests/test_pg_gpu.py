@@ -163,3 +163,58 @@ def test_optimizer_plugin_icp_fitsim3_optimizepose(tmp_path, oracle):
     keep = idp[:, 0] > 0
     po, _, io, _ = oracle.ba_pnp(X1[keep], a2[keep, :2] / a2[keep, 2:3], start, want_information=True)
     assert np.abs(P3[:7] - po).max() < 1e-8 and np.abs(I3 - io).max() <= 1e-7 * np.abs(io).max()
+
+
+@pytest.mark.parametrize("kind,pose_edges,info", [("se3", False, False), ("sim3", True, True)])
+def test_optimizer_plugin_general_graph_inverse_depth_and_mixed(tmp_path, oracle, kind, pose_edges, info):
+    """Optimizer::optimize on a BundleGraph with invDepths / invDepthObserves, mappoints and (second case) sim3 pose edges
+    in the same graph, through the GSLAM plugin (C++ host): keyframes, map points and inverse depths equal the oracle's;
+    sigma and fixed vertices come back untouched; anchors / measurements not on the z = 1 plane are normalised."""
+    from gslam_amd.pg_synth import make_landmark_graph
+    truth, start, dof, prob = make_landmark_graph(n_frames=10, n_xyz=80, n_idp=80, kind=kind, seed=17, noise=2e-3,
+                                                  pose_edges=pose_edges, with_info=info, outliers=0.05, obs_per_point=4)
+    xyz, xfree = prob["xyz"]
+    host, anchor, rho, ifree = prob["idp"]
+    okind, opoint, oframe, oxy, oinfo = prob["obs"]
+    xfree = xfree.copy(); xfree[::7] = 0
+    ifree = ifree.copy(); ifree[::5] = 0
+    prob = dict(prob, xyz=(xyz, xfree), idp=(host, anchor, rho, ifree))
+    huber = 0.01
+    inp, out = tmp_path / "graph.bin", tmp_path / "out.bin"
+    se3 = prob.get("se3") or (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 7)), None)
+    sim3 = prob.get("sim3") or (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 8)), None)
+    rng = np.random.default_rng(1)
+    with open(inp, "wb") as f:
+        f.write(np.array([len(start), len(se3[0]), len(sim3[0]), 0, 0, 40], np.int32).tobytes())
+        f.write(start.astype(np.float64).tobytes() + dof.astype(np.int32).tobytes())
+        for first, second, meas in ((se3[0], se3[1], se3[2]), (sim3[0], sim3[1], sim3[2])):
+            f.write(np.asarray(first, np.int32).tobytes() + np.asarray(second, np.int32).tobytes() + np.asarray(meas, np.float64).tobytes())
+        mx, mi = okind == 0, okind == 1
+        f.write(np.array([len(xyz), len(rho), int(mx.sum()), int(mi.sum()), 1 if info else 0], np.int32).tobytes())
+        f.write(np.float64(huber).tobytes())
+        f.write(xyz.astype(np.float64).tobytes() + xfree.astype(np.uint8).tobytes())
+        zs = rng.uniform(0.5, 2.0, len(rho))  # anchors off the z = 1 plane: the plugin normalises them
+        f.write(host.astype(np.int32).tobytes() + (anchor * zs[:, None]).astype(np.float64).tobytes())
+        f.write(np.c_[rho, np.full(len(rho), 0.123)].astype(np.float64).tobytes())
+        f.write(np.where(ifree != 0, 3, 2).astype(np.int32).tobytes())  # UPDATE_ID_IDEPTHSIGMA / UPDATE_ID_SIGMA only
+        for m in (mx, mi):
+            zm = rng.uniform(0.5, 2.0, int(m.sum()))
+            f.write(opoint[m].astype(np.int32).tobytes() + oframe[m].astype(np.int32).tobytes())
+            f.write((np.c_[oxy[m], np.ones(int(m.sum()))] * zm[:, None]).astype(np.float64).tobytes())
+            if info:
+                f.write(oinfo[m].astype(np.float64).tobytes())
+    r = _host(["pg", LIBDIR, inp, out])
+    assert r.returncode == 0 and "pose_graph_optimize=1" in r.stdout, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    nf, nx, ni = len(start), len(xyz), len(rho)
+    S = np.frombuffer(raw, np.float64, nf * 8, 4).reshape(-1, 8)
+    X = np.frombuffer(raw, np.float64, nx * 3, 4 + nf * 64).reshape(-1, 3)
+    E = np.frombuffer(raw, np.float64, ni * 2, 4 + nf * 64 + nx * 24).reshape(-1, 2)
+    # the plugin lists mappoint observations first, then the inverse-depth ones: same order for the oracle
+    order = np.concatenate([np.nonzero(mx)[0], np.nonzero(mi)[0]])
+    prob_o = dict(prob, obs=(okind[order], opoint[order], oframe[order], oxy[order], None if oinfo is None or not info else oinfo[order]))
+    So, xo, ro, so, sto = oracle.graph_solve(start, dof, prob_o, oracle_lib.ba_options(huber=huber, max_iterations=40), threads=4)
+    assert sto == 0 and so.final_cost < 0.3 * so.initial_cost
+    assert np.abs(S - So).max() <= 1e-6 and np.abs(X - xo).max() <= 1e-5 and np.allclose(E[:, 0], ro, rtol=1e-5)
+    assert np.array_equal(E[:, 1], np.full(ni, 0.123))
+    assert np.array_equal(X[::7], xyz[::7]) and np.array_equal(E[::5, 0], rho[::5]) and not np.array_equal(E[1::5, 0], rho[1::5])
