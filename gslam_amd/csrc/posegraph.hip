@@ -698,6 +698,7 @@ struct GrLandmarks {
   const double* obs_info;  // may be null
   const int32_t *lstart, *llist;  // observations by landmark (XYZ points first, then inverse-depth points)
   double huber;
+  int projection;             // 0 pinhole (obs_xy n x 2), 1 sphere (obs_xy n x 3 unit bearings)
 };
 
 __device__ inline void q_matrix(const double* q, double* R) {
@@ -707,11 +708,30 @@ __device__ inline void q_matrix(const double* q, double* R) {
   R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
+// tangent plane of a unit bearing: e1 = normalise(b x k), e2 = b x e1, k = the axis b is least aligned with
+__device__ inline void tangent_basis(const double* b, double* e1, double* e2) {
+  const double ax = fabs(b[0]), ay = fabs(b[1]), az = fabs(b[2]);
+  double k[3] = {0, 0, 0};
+  if (ax <= ay && ax <= az) k[0] = 1;
+  else if (ay <= az) k[1] = 1;
+  else k[2] = 1;
+  e1[0] = b[1] * k[2] - b[2] * k[1];
+  e1[1] = b[2] * k[0] - b[0] * k[2];
+  e1[2] = b[0] * k[1] - b[1] * k[0];
+  const double n = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  for (int e = 0; e < 3; ++e) e1[e] *= n;
+  e2[0] = b[1] * e1[2] - b[2] * e1[1];
+  e2[1] = b[2] * e1[0] - b[0] * e1[2];
+  e2[2] = b[0] * e1[1] - b[1] * e1[0];
+}
+
 // residual r, quadratic form s = r^T Lambda r, Huber weight; optionally the Jacobians.  false: not in front of the camera
+// (pinhole) / on the opposite hemisphere (sphere)
 template <bool WITH_J>
 __device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, bool same_host,
                                  const double* lm, bool lm_free, const double* anchor, const double* m, const double* info,
-                                 double huber, double* r, double* wgt, double* s_out, double* Jj, double* Jh, double* Jp) {
+                                 double huber, double* r, double* wgt, double* s_out, double* Jj, double* Jh, double* Jp,
+                                 int projection) {
   double Z[3], Y[3], Ra[3] = {0, 0, 0}, dth[3] = {0, 0, 0};
   if (kind == 0) {
     for (int e = 0; e < 3; ++e) Z[e] = lm[e] - Sj[4 + e];
@@ -724,10 +744,27 @@ __device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const do
   }
   const double qc[4] = {-Sj[0], -Sj[1], -Sj[2], Sj[3]};
   q_rot(qc, Z, Y);
-  if (!(Y[2] > kMinDepthG)) return false;
-  const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
-  r[0] = u - m[0];
-  r[1] = v - m[1];
+  double P[6];
+  if (projection == 0) {
+    if (!(Y[2] > kMinDepthG)) return false;
+    const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
+    r[0] = u - m[0];
+    r[1] = v - m[1];
+    P[0] = iz; P[1] = 0; P[2] = -u * iz; P[3] = 0; P[4] = iz; P[5] = -v * iz;
+  } else {
+    const double nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
+    if (!(nY > kMinDepthG)) return false;
+    const double in = 1.0 / nY, y[3] = {Y[0] * in, Y[1] * in, Y[2] * in};
+    if (!(y[0] * m[0] + y[1] * m[1] + y[2] * m[2] > 0)) return false;
+    double e1[3], e2[3];
+    tangent_basis(m, e1, e2);
+    r[0] = e1[0] * y[0] + e1[1] * y[1] + e1[2] * y[2];
+    r[1] = e2[0] * y[0] + e2[1] * y[1] + e2[2] * y[2];
+    for (int e = 0; e < 3; ++e) {  // E (I - y y^T) / |Y|
+      P[e] = (e1[e] - r[0] * y[e]) * in;
+      P[3 + e] = (e2[e] - r[1] * y[e]) * in;
+    }
+  }
   double L00 = 1, L01 = 0, L10 = 0, L11 = 1;
   if (info) { L00 = info[0]; L01 = info[1]; L10 = info[2]; L11 = info[3]; }
   const double s = r[0] * (L00 * r[0] + L01 * r[1]) + r[1] * (L10 * r[0] + L11 * r[1]);
@@ -739,7 +776,6 @@ __device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const do
   for (int k = 0; k < 14; ++k) Jj[k] = Jh[k] = 0.0;
   for (int k = 0; k < 6; ++k) Jp[k] = 0.0;
   if (kind == 1 && same_host) return true;
-  const double P[6] = {iz, 0, -u * iz, 0, iz, -v * iz};
   const double c = kind == 0 ? 1.0 : lm[0];
   const double Dj[21] = {-c * Sj[7], 0, 0, 0, -Y[2], Y[1], 0,
                          0, -c * Sj[7], 0, Y[2], 0, -Y[0], 0,
@@ -828,9 +864,10 @@ __device__ inline bool obs_eval(const GrLandmarks& G, const int32_t* dof, int k,
   }
   if (G.obs_info)
     for (int e = 0; e < 4; ++e) info[e] = G.obs_info[4 * (size_t)k + e];
-  const double m[2] = {G.obs_xy[2 * (size_t)k], G.obs_xy[2 * (size_t)k + 1]};
+  const int ms = G.projection ? 3 : 2;
+  const double m[3] = {G.obs_xy[ms * (size_t)k], G.obs_xy[ms * (size_t)k + 1], G.projection ? G.obs_xy[ms * (size_t)k + 2] : 1.0};
   return graph_obs<WITH_J>(o.kind, Sj, dof[o.fj], Sh, dof[h], o.same_host, lm, o.lm_free, anchor, m, G.obs_info ? info : nullptr,
-                           G.huber, r, w, s, Jj, Jh, Jp);
+                           G.huber, r, w, s, Jj, Jh, Jp, G.projection);
 }
 
 __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const int32_t* __restrict__ dof, const double* __restrict__ S,
@@ -1129,7 +1166,10 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GH_CHECK_ARG(ctx, pr->n_sim3 == 0 || (pr->sim3_first && pr->sim3_second && pr->sim3_meas));
   GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
   GH_CHECK_ARG(ctx, nx >= 0 && ni >= 0 && no >= 0 && (nx == 0 || gpr->xyz) && (ni == 0 || (gpr->idp_host && gpr->idp_anchor && gpr->idp_rho)));
-  GH_CHECK_ARG(ctx, no == 0 || (gpr->obs_kind && gpr->obs_point && gpr->obs_frame && gpr->obs_xy));
+  GH_CHECK_ARG(ctx, gpr->projection == 0 || gpr->projection == 1);
+  const double* obs_meas = gpr->projection ? gpr->obs_bearing : gpr->obs_xy;
+  const int ms = gpr->projection ? 3 : 2;
+  GH_CHECK_ARG(ctx, no == 0 || (gpr->obs_kind && gpr->obs_point && gpr->obs_frame && obs_meas));
   for (int f = 0; f < nf; ++f) GH_CHECK_ARG(ctx, pr->frame_sim3[8 * (size_t)f + 7] > 0);
   for (int p = 0; p < ni; ++p) GH_CHECK_ARG(ctx, gpr->idp_host[p] >= 0 && gpr->idp_host[p] < nf && gpr->idp_rho[p] > 0);
   const double t_begin = now_ms_pg();
@@ -1169,7 +1209,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
             A.alloc(&d_plist, PH.plist.size()) && A.alloc(&d_prow, PH.prow.size()) && A.alloc(&d_pcol, PH.pcol.size()) &&
             A.alloc(&d_gmax, 1) && A.alloc(&d_xyz, (size_t)std::max(nx, 1) * 3) && A.alloc(&d_xyz_new, (size_t)std::max(nx, 1) * 3) &&
             A.alloc(&d_rho, (size_t)std::max(ni, 1)) && A.alloc(&d_rho_new, (size_t)std::max(ni, 1)) &&
-            A.alloc(&d_anchor, (size_t)std::max(ni, 1) * 3) && A.alloc(&d_host, (size_t)std::max(ni, 1)) && A.alloc(&d_oxy, no1 * 2) &&
+            A.alloc(&d_anchor, (size_t)std::max(ni, 1) * 3) && A.alloc(&d_host, (size_t)std::max(ni, 1)) && A.alloc(&d_oxy, no1 * 3) &&
             (!gpr->obs_info || A.alloc(&d_oinfo, no1 * 4)) && A.alloc(&d_orec, no1 * kObsRec) && A.alloc(&d_Hpp, nlm1 * 9) &&
             A.alloc(&d_gp, nlm1 * 3) && A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) &&
             A.alloc(&d_term, (size_t)std::max(n_items, 1)) && A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_okind, no1) &&
@@ -1198,7 +1238,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GH_TRY(up(d_rho, gpr->idp_rho, (size_t)ni * 8));
   GH_TRY(up(d_anchor, gpr->idp_anchor, (size_t)ni * 24));
   GH_TRY(up(d_host, gpr->idp_host, (size_t)ni * 4));
-  GH_TRY(up(d_oxy, gpr->obs_xy, (size_t)no * 16));
+  GH_TRY(up(d_oxy, obs_meas, (size_t)no * ms * 8));
   if (gpr->obs_info) GH_TRY(up(d_oinfo, gpr->obs_info, (size_t)no * 32));
   GH_TRY(up(d_okind, gpr->obs_kind, (size_t)no * 4));
   GH_TRY(up(d_opoint, gpr->obs_point, (size_t)no * 4));
@@ -1212,7 +1252,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
   PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, PH.n_pairs};
   GrLandmarks LM{nx, ni, no, d_xfree, d_host, d_anchor, d_ifree, d_okind, d_opoint, d_oframe, d_oxy, d_oinfo, d_lstart, d_llist,
-                 opt.huber_delta};
+                 opt.huber_delta, gpr->projection};
   const int eb = gh_div_up(ne > 0 ? ne : 1, 64), ob = gh_div_up(no > 0 ? no : 1, 128);
   double host4[4];
   // sum of v[0..count) into d_out[slot]: fixed order (1024 per block, then the partials one after the other)

@@ -87,13 +87,17 @@ def make_pose_graph(n_frames=40, n_loops=8, kind="sim3", seed=1, noise=0.0, pert
 
 
 def make_landmark_graph(n_frames=8, n_xyz=30, n_idp=30, kind="se3", seed=1, noise=0.0, perturb=0.03, point_perturb=0.05,
-                        obs_per_point=4, pose_edges=False, with_info=False, observe_host=True, outliers=0.0):
+                        obs_per_point=4, pose_edges=False, with_info=False, observe_host=True, outliers=0.0,
+                        projection="pinhole"):
     """A general BundleGraph (GSLAM/core/Optimizer.h:150-172): keyframes on the loop of make_pose_graph looking up at a
     cloud of landmarks, `n_xyz` of them as world points, `n_idp` as inverse-depth points anchored in a host keyframe;
     pinhole observations m = (x / z, y / z) in the observing camera; optionally the odometry / loop edges on top.
     Returns (truth frames, start frames, dof, problem) with problem = the pose-edge dict of make_pose_graph plus
       "xyz": (points n x 3 START values, free mask), "idp": (host, anchor n x 3, rho START values, free mask),
-      "obs": (kind, point, frame, xy n x 2, info n x 4 | None), "truth_xyz", "truth_rho"."""
+      "obs": (kind, point, frame, xy n x 2, info n x 4 | None), "truth_xyz", "truth_rho".
+    projection="sphere" (PROJECTION_SPHERE): anchors and measurements are unit bearings (xy becomes n x 3), rho an inverse
+    range, and "projection": "sphere" is set in the problem."""
+    sphere = projection == "sphere"
     rng = np.random.default_rng(seed)
     truth, start, dof, problem = make_pose_graph(n_frames, n_loops=2, kind="sim3" if kind == "sim3" else "se3", seed=seed,
                                                  noise=noise, perturb=perturb)
@@ -118,7 +122,7 @@ def make_landmark_graph(n_frames=8, n_xyz=30, n_idp=30, kind="se3", seed=1, nois
         for j in frames:
             Xc = cam_coords(truth[j], xyz[p])
             assert Xc[2] > 0.5
-            okind.append(0); opoint.append(p); oframe.append(int(j)); oxy.append(Xc[:2] / Xc[2])
+            okind.append(0); opoint.append(p); oframe.append(int(j)); oxy.append(Xc / np.linalg.norm(Xc) if sphere else Xc[:2] / Xc[2])
     host = np.zeros(n_idp, np.int32)
     anchor = np.zeros((n_idp, 3))
     rho = np.zeros(n_idp)
@@ -127,17 +131,20 @@ def make_landmark_graph(n_frames=8, n_xyz=30, n_idp=30, kind="se3", seed=1, nois
         frames = rng.choice(n_frames, size=min(obs_per_point, n_frames), replace=False)
         host[p] = int(frames[0])
         Xh = cam_coords(truth[host[p]], X)
-        anchor[p] = [Xh[0] / Xh[2], Xh[1] / Xh[2], 1.0]
-        rho[p] = 1.0 / Xh[2]
+        anchor[p] = Xh / np.linalg.norm(Xh) if sphere else [Xh[0] / Xh[2], Xh[1] / Xh[2], 1.0]
+        rho[p] = 1.0 / (np.linalg.norm(Xh) if sphere else Xh[2])
         for j in (frames if observe_host else frames[1:]):
             Xc = cam_coords(truth[j], X)
-            okind.append(1); opoint.append(p); oframe.append(int(j)); oxy.append(Xc[:2] / Xc[2])
+            okind.append(1); opoint.append(p); oframe.append(int(j)); oxy.append(Xc / np.linalg.norm(Xc) if sphere else Xc[:2] / Xc[2])
     oxy = np.array(oxy)
     if noise > 0:
         oxy = oxy + rng.normal(size=oxy.shape) * noise
     if outliers > 0:
         bad = rng.random(len(oxy)) < outliers
-        oxy[bad] += rng.normal(size=(int(bad.sum()), 2)) * 0.2
+        oxy[bad] += rng.normal(size=(int(bad.sum()), oxy.shape[1])) * 0.2
+    if sphere:
+        oxy /= np.linalg.norm(oxy, axis=1, keepdims=True)
+        problem["projection"] = "sphere"
     info = None
     if with_info:
         a = rng.normal(size=(len(oxy), 2, 2)) * 0.2

@@ -14,11 +14,14 @@
 //                                        -> gh_graph_solve when the graph holds inverse-depth points (invDepths /
 //                                           invDepthObserves, :106-111,152-153,160) or pose-graph edges TOGETHER with
 //                                           point observations: the general solver (SIM3 keyframes, both landmark kinds)
-// Still `return false` ("unsupported", as the interface allows): camera self-calibration, sphere projection, magin().
+//                                           and every graph with observations under PROJECTION_SPHERE
+// Still `return false` ("unsupported", as the interface allows): camera self-calibration, magin(); optimizePnP /
+// optimizePose under the sphere projection.
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -37,13 +40,14 @@ class OptimizerHIP : public GSLAM::Optimizer {
   }
 
   bool optimize(GSLAM::BundleGraph& graph) override {
-    // supported sub-problem: xyz map points observed by SE3/SIM3 keyframes, pinhole anchors
-    if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
     if (graph.cameraDOF != GSLAM::UPDATE_CAMERA_NONE && graph.camera.isValid())
       return unsupported("camera self-calibration");
     const bool pose_edges = !graph.se3Graph.empty() || !graph.sim3Graph.empty() || !graph.gpsGraph.empty();
-    if (!graph.invDepths.empty() || !graph.invDepthObserves.empty() || (pose_edges && !graph.mappointObserves.empty()))
-      return optimizeGeneral(graph);
+    const bool sphere = _config.cameraProjectionType == GSLAM::PROJECTION_SPHERE;
+    const bool observations = !graph.mappointObserves.empty() || !graph.invDepthObserves.empty();
+    if (!graph.invDepths.empty() || !graph.invDepthObserves.empty() || (pose_edges && !graph.mappointObserves.empty()) ||
+        (sphere && observations))
+      return optimizeGeneral(graph);  // the fast path below is pinhole bundle adjustment over XYZ points only
     if (pose_edges) return optimizePoseGraph(graph);
     if (graph.keyframes.empty()) return false;
     if (!context()) return false;
@@ -248,8 +252,10 @@ class OptimizerHIP : public GSLAM::Optimizer {
   // The general BundleGraph: SIM3 keyframes, pose-graph edges, XYZ map points and inverse-depth points together
   // (gh_graph_solve; specification in oracle/graph_oracle.c).  An inverse-depth point lives at anchor / idepth in the camera
   // of its host keyframe (InvDepthEstimation::frameId), the anchor taken on the z = 1 plane; UPDATE_ID_IDEPTH frees the
-  // inverse depth, sigma is carried through untouched.
+  // inverse depth, sigma is carried through untouched.  PROJECTION_SPHERE: anchors and measurements are bearings (normalised
+  // to unit length here), the inverse depth is an inverse range, the residual lives in the tangent plane of the measurement.
   bool optimizeGeneral(GSLAM::BundleGraph& graph) {
+    const bool sphere = _config.cameraProjectionType == GSLAM::PROJECTION_SPHERE;
     if (graph.keyframes.empty() || !context()) return false;
     const size_t nf = graph.keyframes.size(), np = graph.mappoints.size(), ni = graph.invDepths.size();
     std::vector<double> frames(nf * 8);
@@ -275,14 +281,15 @@ class OptimizerHIP : public GSLAM::Optimizer {
     }
     for (size_t i = 0; i < ni; ++i) {
       const GSLAM::InvDepthEstimation& v = graph.invDepths[i];
-      if (v.frameId >= nf || !(v.anchor.z > 0) || !(v.estimation.x > 0)) {
-        LOG(ERROR) << "OptimizerHIP: inverse-depth point " << i << " needs a valid host keyframe, anchor.z > 0 and idepth > 0";
+      const double an = sphere ? std::sqrt(v.anchor.x * v.anchor.x + v.anchor.y * v.anchor.y + v.anchor.z * v.anchor.z) : v.anchor.z;
+      if (v.frameId >= nf || !(an > 0) || !(v.estimation.x > 0)) {
+        LOG(ERROR) << "OptimizerHIP: inverse-depth point " << i << " needs a valid host keyframe, a usable anchor and idepth > 0";
         return false;
       }
       host[i] = (int32_t)v.frameId;
-      anchor[3 * i] = v.anchor.x / v.anchor.z;
-      anchor[3 * i + 1] = v.anchor.y / v.anchor.z;
-      anchor[3 * i + 2] = 1.0;
+      anchor[3 * i] = v.anchor.x / an;
+      anchor[3 * i + 1] = v.anchor.y / an;
+      anchor[3 * i + 2] = v.anchor.z / an;
       rho[i] = v.estimation.x;
       ifree[i] = (v.dof & GSLAM::UPDATE_ID_IDEPTH) ? 1 : 0;
     }
@@ -293,16 +300,19 @@ class OptimizerHIP : public GSLAM::Optimizer {
       const std::vector<GSLAM::BundleEdge>& obs = kind == 0 ? graph.mappointObserves : graph.invDepthObserves;
       for (size_t k = 0; k < obs.size(); ++k) {
         const GSLAM::BundleEdge& e = obs[k];
-        if (e.pointId >= (kind == 0 ? np : ni) || e.frameId >= nf || !(e.measurement.z > 0)) {
+        const GSLAM::Point3d& m = e.measurement;
+        const double mn = sphere ? std::sqrt(m.x * m.x + m.y * m.y + m.z * m.z) : m.z;
+        if (e.pointId >= (kind == 0 ? np : ni) || e.frameId >= nf || !(mn > 0)) {
           LOG(ERROR) << "OptimizerHIP: " << (kind == 0 ? "mappoint" : "inverse-depth") << " observation " << k
-                     << " references a missing vertex or has measurement.z <= 0";
+                     << " references a missing vertex or has an unusable measurement";
           return false;
         }
         okind.push_back(kind);
         opoint.push_back((int32_t)e.pointId);
         oframe.push_back((int32_t)e.frameId);
-        oxy.push_back(e.measurement.x / e.measurement.z);
-        oxy.push_back(e.measurement.y / e.measurement.z);
+        oxy.push_back(m.x / mn);
+        oxy.push_back(m.y / mn);
+        if (sphere) oxy.push_back(m.z / mn);
         if (any_info)
           for (int a = 0; a < 4; ++a) oinfo.push_back(e.information ? e.information[a] : ((a == 0 || a == 3) ? 1.0 : 0.0));
       }
@@ -310,7 +320,9 @@ class OptimizerHIP : public GSLAM::Optimizer {
     gp.n_xyz = (int32_t)np; gp.xyz = xyz.data(); gp.xyz_free = xfree.data();
     gp.n_idp = (int32_t)ni; gp.idp_host = host.data(); gp.idp_anchor = anchor.data(); gp.idp_rho = rho.data(); gp.idp_free = ifree.data();
     gp.n_obs = (int32_t)okind.size(); gp.obs_kind = okind.data(); gp.obs_point = opoint.data(); gp.obs_frame = oframe.data();
-    gp.obs_xy = oxy.data(); gp.obs_info = any_info ? oinfo.data() : NULL;
+    gp.obs_info = any_info ? oinfo.data() : NULL;
+    gp.projection = sphere ? 1 : 0;
+    (sphere ? gp.obs_bearing : gp.obs_xy) = oxy.data();
     gh_ba_options o;
     gh_ba_default_options(&o);
     o.huber_delta = _config.projectErrorHuberThreshold;

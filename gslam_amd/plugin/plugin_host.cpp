@@ -193,15 +193,16 @@ static int run_pg(const std::string& dir, const char* in, const char* out) {
     e.information = has_info ? &ig[(size_t)k * 36] : NULL;
     g.gpsGraph.push_back(e);
   }
-  // optional landmark section (the general BundleGraph): int32 {n_xyz, n_idp, n_obs_xyz, n_obs_idp, has_obs_info}, double
+  // optional landmark section (the general BundleGraph): int32 {n_xyz, n_idp, n_obs_xyz, n_obs_idp, has_obs_info, sphere}, double
   // huber; xyz n x 3, free n (u8); idp: host n (i32), anchor n x 3, [idepth, sigma] n x 2, dof n (i32); then for each of the
   // two observation lists: point (i32), frame (i32), measurement n x 3, information n x 4 (if has_obs_info)
-  int32_t lh[5] = {0, 0, 0, 0, 0};
+  int32_t lh[6] = {0, 0, 0, 0, 0, 0};
   std::vector<double> oinf_xyz, oinf_idp;
   if (f.read((char*)lh, sizeof(lh))) {
     double huber = 0;
     f.read((char*)&huber, 8);
     opt_ptr->_config.projectErrorHuberThreshold = huber;
+    if (lh[5]) opt_ptr->_config.cameraProjectionType = PROJECTION_SPHERE;
     std::vector<double> xyz = read_vec<double>(f, (size_t)lh[0] * 3);
     std::vector<uint8_t> xfree = read_vec<uint8_t>(f, lh[0]);
     std::vector<int32_t> host = read_vec<int32_t>(f, lh[1]);

@@ -73,7 +73,9 @@ def solve_graph(ctx: hip.Context, frames, dof, problem: dict, options=None):
     keep += [xyz, rho, xfree, ifree, host, anchor, kind, point, frame, xy, oinfo]
     gp.n_xyz, gp.xyz, gp.xyz_free = len(xyz), _p(xyz), _p(xfree)
     gp.n_idp, gp.idp_host, gp.idp_anchor, gp.idp_rho, gp.idp_free = len(rho), _p(host), _p(anchor), _p(rho), _p(ifree)
-    gp.n_obs, gp.obs_kind, gp.obs_point, gp.obs_frame, gp.obs_xy, gp.obs_info = len(kind), _p(kind), _p(point), _p(frame), _p(xy), _p(oinfo)
+    sphere = problem.get("projection") == "sphere"  # then `xy` is n x 3 unit bearings
+    gp.n_obs, gp.obs_kind, gp.obs_point, gp.obs_frame, gp.obs_info = len(kind), _p(kind), _p(point), _p(frame), _p(oinfo)
+    gp.projection, gp.obs_xy, gp.obs_bearing = (1, None, _p(xy)) if sphere else (0, _p(xy), None)
     sm = hip.BaSummary()
     st = hip.lib.gh_graph_solve(ctx.h, C.byref(gp), C.byref(options), C.byref(sm))
     if st not in (0, 4):

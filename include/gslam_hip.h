@@ -479,7 +479,9 @@ gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* problem, const gh_ba_options* 
  * keyframe system (7 n_frames square) is dense.  In/out: pg.frame_sim3, xyz, idp_rho.
  *   xyz n_xyz x 3 world points, xyz_free NULL = all free;  idp_host / idp_anchor (n x 3, pinhole anchors (x, y, 1)) /
  *   idp_rho > 0 / idp_free;  obs_kind 0 = XYZ point, 1 = inverse-depth point; obs_point indexes the respective array;
- *   obs_xy n_obs x 2 normalised image coordinates; obs_info n_obs x 4 row-major 2x2 or NULL. */
+ *   obs_xy n_obs x 2 normalised image coordinates; obs_info n_obs x 4 row-major 2x2 or NULL.
+ * Sphere projection: the residual is the predicted bearing in the tangent plane of the measured one (2-vector, same
+ * information / Huber), dropped on the opposite hemisphere. */
 typedef struct gh_graph_problem {
   gh_pg_problem pg;
   int32_t n_xyz;
@@ -493,6 +495,8 @@ typedef struct gh_graph_problem {
   int32_t n_obs;
   const int32_t *obs_kind, *obs_point, *obs_frame;
   const double *obs_xy, *obs_info;
+  int32_t projection;        /* 0 = PROJECTION_PINHOLE (obs_xy), 1 = PROJECTION_SPHERE (obs_bearing; Optimizer.h:58-61,175) */
+  const double* obs_bearing; /* n_obs x 3 unit bearings, sphere only: anchors are unit bearings too, idepth = 1 / range */
 } gh_graph_problem;
 gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* problem, const gh_ba_options* options, gh_ba_summary* summary);
 

@@ -26,6 +26,12 @@
  *                  weight w = 1 or h / sqrt(s) fixed at the linearisation point (ba_oracle.c's convention)
  *                  An observation of an inverse-depth point in its own host frame is constant (a_xy / a_z - m): it adds
  *                  to the cost and has no Jacobian.
+ *   sphere         CameraProjectionType PROJECTION_SPHERE ("||x,y,z|| = 1", Optimizer.h:58-61): anchors and measurements
+ *                  are unit bearings b; the inverse depth is an inverse RANGE (X_c(h) = a / rho, |a| = 1).  Residual = the
+ *                  predicted bearing y = Y / |Y| in the tangent plane of the measured one: r = (e1 . y, e2 . y) with
+ *                  e1 = normalise(b x k), e2 = b x e1, k = the coordinate axis b is least aligned with (ties: x, then y);
+ *                  dropped while y . b <= 0 (opposite hemisphere).  Same information / Huber; the projection Jacobian
+ *                  becomes P = E (I - y y^T) / |Y|, everything else is unchanged.
  *   Jacobians      analytic, first order in the right-multiplicative delta (R' = R (I + [w]x), t' = t + s R v,
  *                  s' = s (1 + sigma)), P = (1 / Y_z) [1 0 -u; 0 1 -v]:
  *                    dY/dv_j = -c s_j I   (c = 1 for XYZ, rho for inverse depth),  dY/dw_j = [Y]x,  dY/dsigma_j = 0
@@ -83,6 +89,8 @@ typedef struct {
   const double* obs_xy;     /* n_obs x 2 */
   const double* obs_info;   /* n_obs x 4 or NULL */
   double huber;
+  int32_t projection;         /* 0 pinhole (obs_xy), 1 sphere (obs_bearing) */
+  const double* obs_bearing;  /* n_obs x 3 unit vectors, sphere only */
 } graph_problem;
 
 /* pg_oracle.c / ba_oracle.c */
@@ -115,9 +123,26 @@ static void q_matrix(const double* q, double* R) { /* row-major */
 /* One observation.  kind 0: lm = X (3); kind 1: lm[0] = rho, host frame Sh, anchor a.  Returns 0 when the landmark is
  * not in front of the camera.  Jj / Jh: 2 x 7 (row-major), Jp: 2 x 3 (inverse depth: column 0).  same_host: the
  * observing frame IS the host (constant residual). */
+static void tangent_basis(const double* b, double* e1, double* e2) {
+  const double ax = fabs(b[0]), ay = fabs(b[1]), az = fabs(b[2]);
+  double k[3] = {0, 0, 0};
+  if (ax <= ay && ax <= az) k[0] = 1;
+  else if (ay <= az) k[1] = 1;
+  else k[2] = 1;
+  e1[0] = b[1] * k[2] - b[2] * k[1];
+  e1[1] = b[2] * k[0] - b[0] * k[2];
+  e1[2] = b[0] * k[1] - b[1] * k[0];
+  const double n = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  for (int e = 0; e < 3; ++e) e1[e] *= n;
+  e2[0] = b[1] * e1[2] - b[2] * e1[1];
+  e2[1] = b[2] * e1[0] - b[0] * e1[2];
+  e2[2] = b[0] * e1[1] - b[1] * e1[0];
+}
+
+/* projection 0: m = (m_x, m_y) on the z = 1 plane; 1: m = unit bearing (3) */
 int oracle_graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, int same_host, const double* lm,
                      int lm_free, const double* anchor, const double* m, const double* info, double huber, double* r,
-                     double* wgt, double* s_out, double* Jj, double* Jh, double* Jp) {
+                     double* wgt, double* s_out, double* Jj, double* Jh, double* Jp, int projection) {
   double Z[3], Y[3], Ra[3] = {0, 0, 0}, dth[3] = {0, 0, 0};
   if (kind == 0) {
     for (int e = 0; e < 3; ++e) Z[e] = lm[e] - Sj[4 + e];
@@ -129,10 +154,27 @@ int oracle_graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, in
     }
   }
   q_rot_inv(Sj, Z, Y);
-  if (!(Y[2] > G_MIN_DEPTH)) return 0;
-  const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
-  r[0] = u - m[0];
-  r[1] = v - m[1];
+  double P[6];
+  if (projection == 0) {
+    if (!(Y[2] > G_MIN_DEPTH)) return 0;
+    const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
+    r[0] = u - m[0];
+    r[1] = v - m[1];
+    P[0] = iz; P[1] = 0; P[2] = -u * iz; P[3] = 0; P[4] = iz; P[5] = -v * iz;
+  } else {
+    const double nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
+    if (!(nY > G_MIN_DEPTH)) return 0;
+    const double in = 1.0 / nY, y[3] = {Y[0] * in, Y[1] * in, Y[2] * in};
+    if (!(y[0] * m[0] + y[1] * m[1] + y[2] * m[2] > 0)) return 0;
+    double e1[3], e2[3];
+    tangent_basis(m, e1, e2);
+    r[0] = e1[0] * y[0] + e1[1] * y[1] + e1[2] * y[2];
+    r[1] = e2[0] * y[0] + e2[1] * y[1] + e2[2] * y[2];
+    for (int e = 0; e < 3; ++e) {  /* E (I - y y^T) / |Y| */
+      P[e] = (e1[e] - r[0] * y[e]) * in;
+      P[3 + e] = (e2[e] - r[1] * y[e]) * in;
+    }
+  }
   double L00 = 1, L01 = 0, L10 = 0, L11 = 1;
   if (info) { L00 = info[0]; L01 = info[1]; L10 = info[2]; L11 = info[3]; }
   const double s = r[0] * (L00 * r[0] + L01 * r[1]) + r[1] * (L10 * r[0] + L11 * r[1]);
@@ -145,7 +187,6 @@ int oracle_graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, in
   memset(Jh, 0, 14 * 8);
   memset(Jp, 0, 6 * 8);
   if (kind == 1 && same_host) return 1;
-  const double P[6] = {iz, 0, -u * iz, 0, iz, -v * iz};
   const double c = kind == 0 ? 1.0 : lm[0];
   /* dY / d delta_j = [ -c s_j I | [Y]x | 0 ] */
   const double Dj[21] = {-c * Sj[7], 0, 0, 0, -Y[2], Y[1], 0,
@@ -224,8 +265,9 @@ static int obs_eval(const graph_problem* g, int k, const double* frames, const d
   double w = 1, s = 0, r[2] = {0, 0};
   double Jj[14], Jh[14], Jp[6];
   const int ok = oracle_graph_obs(kind, frames + 8 * (size_t)j, g->dof[j], frames + 8 * (size_t)h, g->dof[h], h == j, lm, lm_free,
-                                  kind == 1 ? g->idp_anchor + 3 * (size_t)p : NULL, g->obs_xy + 2 * (size_t)k, info, g->huber, r,
-                                  &w, &s, with_j ? Jj : NULL, with_j ? Jh : NULL, with_j ? Jp : NULL);
+                                  kind == 1 ? g->idp_anchor + 3 * (size_t)p : NULL,
+                                  g->projection ? g->obs_bearing + 3 * (size_t)k : g->obs_xy + 2 * (size_t)k, info, g->huber, r,
+                                  &w, &s, with_j ? Jj : NULL, with_j ? Jh : NULL, with_j ? Jp : NULL, g->projection);
   if (s_out) *s_out = s;
   if (!o) return ok;
   memset(o, 0, sizeof(*o));

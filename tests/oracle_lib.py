@@ -623,7 +623,7 @@ class GraphProblem(C.Structure):
                 ("ej", _vp), ("meas", _vp), ("info", _vp), ("n_xyz", C.c_int32), ("xyz", _vp), ("xyz_free", _vp),
                 ("n_idp", C.c_int32), ("idp_host", _vp), ("idp_anchor", _vp), ("idp_rho", _vp), ("idp_free", _vp),
                 ("n_obs", C.c_int32), ("obs_kind", _vp), ("obs_point", _vp), ("obs_frame", _vp), ("obs_xy", _vp),
-                ("obs_info", _vp), ("huber", C.c_double)]
+                ("obs_info", _vp), ("huber", C.c_double), ("projection", C.c_int32), ("obs_bearing", _vp)]
 
 
 def graph_arrays(frames, dof, problem):
@@ -646,6 +646,7 @@ def graph_arrays(frames, dof, problem):
     a["kind"], a["point"], a["frame"] = (np.ascontiguousarray(v, dtype=np.int32) for v in (kind, point, frame))
     a["xy"] = np.ascontiguousarray(xy, dtype=np.float64)
     a["oinfo"] = None if oinfo is None else np.ascontiguousarray(oinfo, dtype=np.float64)
+    a["sphere"] = 1 if problem.get("projection") == "sphere" else 0  # then `xy` holds n x 3 unit bearings
     return a
 
 
@@ -654,7 +655,8 @@ def _graph_methods(cls):
         return GraphProblem(len(a["frames"]), _ptr(a["frames"]), _ptr(a["dof"]), len(a["et"]), _ptr(a["et"]), _ptr(a["ei"]),
                             _ptr(a["ej"]), _ptr(a["meas"]), _ptr(a["info"]), len(a["xyz"]), _ptr(a["xyz"]), _ptr(a["xfree"]),
                             len(a["rho"]), _ptr(a["host"]), _ptr(a["anchor"]), _ptr(a["rho"]), _ptr(a["ifree"]), len(a["kind"]),
-                            _ptr(a["kind"]), _ptr(a["point"]), _ptr(a["frame"]), _ptr(a["xy"]), _ptr(a["oinfo"]), float(huber))
+                            _ptr(a["kind"]), _ptr(a["point"]), _ptr(a["frame"]), None if a["sphere"] else _ptr(a["xy"]), _ptr(a["oinfo"]),
+                            float(huber), a["sphere"], _ptr(a["xy"]) if a["sphere"] else None)
 
     def graph_solve(self, frames, dof, problem, opts=None, threads=1):
         """-> (frames, xyz, rho, summary, status).  opts.huber_delta is the projection Huber threshold."""
@@ -671,14 +673,14 @@ def _graph_methods(cls):
         self.lib.oracle_graph_cost.restype = C.c_double
         return self.lib.oracle_graph_cost(C.byref(gp))
 
-    def graph_obs(self, kind, Sj, dof_j, Sh, dof_h, same_host, lm, lm_free, anchor, m, info=None, huber=0.0):
+    def graph_obs(self, kind, Sj, dof_j, Sh, dof_h, same_host, lm, lm_free, anchor, m, info=None, huber=0.0, projection=0):
         """-> (ok, r 2, w, s, Jj 2 x 7, Jh 2 x 7, Jp 2 x 3)."""
         r, Jj, Jh, Jp = np.zeros(2), np.zeros(14), np.zeros(14), np.zeros(6)
         w, s = C.c_double(), C.c_double()
         f = lambda v: _ptr(np.ascontiguousarray(v, dtype=np.float64)) if v is not None else None
         ok = self.lib.oracle_graph_obs(int(kind), f(Sj), int(dof_j), f(Sh), int(dof_h), int(same_host), f(lm), int(lm_free),
                                        f(anchor if anchor is not None else np.zeros(3)), f(m), f(info), C.c_double(huber), _ptr(r),
-                                       C.byref(w), C.byref(s), _ptr(Jj), _ptr(Jh), _ptr(Jp))
+                                       C.byref(w), C.byref(s), _ptr(Jj), _ptr(Jh), _ptr(Jp), int(projection))
         return bool(ok), r, w.value, s.value, Jj.reshape(2, 7), Jh.reshape(2, 7), Jp.reshape(2, 3)
 
     for f in (graph_solve, graph_cost, graph_obs):

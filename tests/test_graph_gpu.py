@@ -93,3 +93,13 @@ def test_graph_solve_rejects_bad_arguments(ctx):
     host, anchor, rho, free = problem["idp"]
     with pytest.raises(hip.GslamHipError):
         posegraph.solve_graph(ctx, start, dof, dict(problem, idp=(host, anchor, -rho, free)))
+
+
+@pytest.mark.parametrize("n_xyz,n_idp,pose_edges", [(150, 150, False), (80, 80, True)])
+def test_graph_solve_sphere_projection(ctx, oracle, n_xyz, n_idp, pose_edges):
+    """PROJECTION_SPHERE: unit-bearing anchors / measurements, tangent-plane residual."""
+    truth, start, dof, problem = make_landmark_graph(n_frames=10, n_xyz=n_xyz, n_idp=n_idp, kind="se3", seed=33, noise=2e-3,
+                                                     pose_edges=pose_edges, with_info=True, outliers=0.05, obs_per_point=5,
+                                                     projection="sphere")
+    so, sg = _compare(ctx, oracle, start, dof, problem, 0.01)
+    assert so.final_cost < 0.3 * so.initial_cost

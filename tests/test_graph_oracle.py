@@ -180,3 +180,69 @@ def test_inverse_depth_recovers_the_truth_and_respects_fixed_landmarks(oracle):
     free = free.copy(); free[:10] = 0
     S, xyz, rho2, sm, st = oracle.graph_solve(start, dof, dict(problem, idp=(host, anchor, rho0, free)), opts)
     assert np.array_equal(rho2[:10], rho0[:10]) and not np.array_equal(rho2[10:], rho0[10:])
+
+
+def _bearing_residual_py(Sj, Sh, kind, lm, anchor, b):
+    """Independent restatement of the sphere residual: tangent-plane coordinates of the predicted bearing."""
+    if kind == 0:
+        Xw = np.asarray(lm, float)
+    else:
+        Xw = Sh[7] * _qrot(Sh[:4], np.asarray(anchor) / lm[0]) + Sh[4:7]
+    qc = np.array([-Sj[0], -Sj[1], -Sj[2], Sj[3]])
+    Xc = _qrot(qc, Xw - Sj[4:7]) / Sj[7]
+    y = Xc / np.linalg.norm(Xc)
+    k = np.zeros(3); k[int(np.argmin(np.abs(b)))] = 1.0
+    e1 = np.cross(b, k); e1 /= np.linalg.norm(e1)
+    e2 = np.cross(b, e1)
+    return np.array([e1 @ y, e2 @ y]), float(y @ b)
+
+
+def test_sphere_projection_residual_and_jacobians(oracle):
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        kind = trial & 1
+        mk = lambda: np.concatenate([_quat_from_rotvec(rng.normal(size=3) * 0.5), rng.normal(size=3), [np.exp(rng.normal() * 0.3)]])
+        Sj, Sh = mk(), mk()
+        Xc = rng.normal(size=3) * 3  # any direction: a panoramic camera sees behind itself too
+        if kind == 0:
+            lm, anchor = Sj[7] * _qrot(Sj[:4], Xc) + Sj[4:7], None
+        else:
+            a = rng.normal(size=3); a /= np.linalg.norm(a)
+            lm = np.array([rng.uniform(0.1, 0.5)])
+            Xw = Sh[7] * _qrot(Sh[:4], a / lm[0]) + Sh[4:7]
+            Sj[4:7] = Xw - Sj[7] * _qrot(Sj[:4], Xc)
+            anchor = a
+        b = Xc / np.linalg.norm(Xc) + rng.normal(size=3) * 0.05
+        b /= np.linalg.norm(b)
+        ok, r, w, s, Jj, Jh, Jp = oracle.graph_obs(kind, Sj, 127, Sh, 127, False, lm, True, anchor, b, None, 0.0, projection=1)
+        r_py, dot = _bearing_residual_py(Sj, Sh, kind, lm, anchor, b)
+        assert ok and dot > 0 and np.allclose(r, r_py, rtol=1e-10, atol=1e-12)
+        h = 1e-6
+        for which, J in ((0, Jj), (1, Jh)):
+            if kind == 0 and which == 1:
+                continue
+            for k in range(7):
+                d = np.zeros(7); d[k] = h
+                ap = (_retract(oracle, Sj, d), Sh) if which == 0 else (Sj, _retract(oracle, Sh, d))
+                am = (_retract(oracle, Sj, -d), Sh) if which == 0 else (Sj, _retract(oracle, Sh, -d))
+                fd = (_bearing_residual_py(*ap, kind, lm, anchor, b)[0] - _bearing_residual_py(*am, kind, lm, anchor, b)[0]) / (2 * h)
+                assert np.allclose(J[:, k], fd, rtol=2e-6, atol=2e-8), (trial, which, k)
+        for k in range(3 if kind == 0 else 1):
+            d = np.zeros(len(lm)); d[k] = h
+            fd = (_bearing_residual_py(Sj, Sh, kind, lm + d, anchor, b)[0] - _bearing_residual_py(Sj, Sh, kind, lm - d, anchor, b)[0]) / (2 * h)
+            assert np.allclose(Jp[:, k], fd, rtol=2e-6, atol=2e-8)
+    # opposite hemisphere: dropped
+    S = np.concatenate([_quat_from_rotvec(np.array([0.1, 0.2, 0.3])), [1.0, 2.0, 3.0], [1.0]])
+    X = S[4:7] + _qrot(S[:4], np.array([0.0, 0.0, 2.0]))
+    assert not oracle.graph_obs(0, S, 127, S, 127, False, X, True, None, np.array([0.0, 0.0, -1.0]), None, 0.0, projection=1)[0]
+
+
+def test_sphere_graph_converges_to_the_truth(oracle):
+    truth, start, dof, problem = make_landmark_graph(n_frames=8, n_xyz=40, n_idp=40, kind="se3", seed=6, noise=0.0, obs_per_point=5,
+                                                     projection="sphere")
+    opts = oracle_lib.ba_options(huber=0.0, max_iterations=60)
+    opts.function_tolerance = 1e-16
+    S, xyz, rho, sm, st = oracle.graph_solve(start, dof, problem, opts)
+    assert st == 0 and sm.final_cost < 1e-15 and sm.initial_cost > 1e-4
+    ratio = rho / problem["truth_rho"]
+    assert np.allclose(ratio, ratio[0], rtol=1e-5)  # the truth up to the gauge the fixed dof leave

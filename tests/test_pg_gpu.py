@@ -165,14 +165,16 @@ def test_optimizer_plugin_icp_fitsim3_optimizepose(tmp_path, oracle):
     assert np.abs(P3[:7] - po).max() < 1e-8 and np.abs(I3 - io).max() <= 1e-7 * np.abs(io).max()
 
 
-@pytest.mark.parametrize("kind,pose_edges,info", [("se3", False, False), ("sim3", True, True)])
-def test_optimizer_plugin_general_graph_inverse_depth_and_mixed(tmp_path, oracle, kind, pose_edges, info):
+@pytest.mark.parametrize("kind,pose_edges,info,sphere", [("se3", False, False, False), ("sim3", True, True, False),
+                                                         ("se3", False, True, True)])
+def test_optimizer_plugin_general_graph_inverse_depth_and_mixed(tmp_path, oracle, kind, pose_edges, info, sphere):
     """Optimizer::optimize on a BundleGraph with invDepths / invDepthObserves, mappoints and (second case) sim3 pose edges
     in the same graph, through the GSLAM plugin (C++ host): keyframes, map points and inverse depths equal the oracle's;
     sigma and fixed vertices come back untouched; anchors / measurements not on the z = 1 plane are normalised."""
     from gslam_amd.pg_synth import make_landmark_graph
     truth, start, dof, prob = make_landmark_graph(n_frames=10, n_xyz=80, n_idp=80, kind=kind, seed=17, noise=2e-3,
-                                                  pose_edges=pose_edges, with_info=info, outliers=0.05, obs_per_point=4)
+                                                  pose_edges=pose_edges, with_info=info, outliers=0.05, obs_per_point=4,
+                                                  projection="sphere" if sphere else "pinhole")
     xyz, xfree = prob["xyz"]
     host, anchor, rho, ifree = prob["idp"]
     okind, opoint, oframe, oxy, oinfo = prob["obs"]
@@ -190,7 +192,7 @@ def test_optimizer_plugin_general_graph_inverse_depth_and_mixed(tmp_path, oracle
         for first, second, meas in ((se3[0], se3[1], se3[2]), (sim3[0], sim3[1], sim3[2])):
             f.write(np.asarray(first, np.int32).tobytes() + np.asarray(second, np.int32).tobytes() + np.asarray(meas, np.float64).tobytes())
         mx, mi = okind == 0, okind == 1
-        f.write(np.array([len(xyz), len(rho), int(mx.sum()), int(mi.sum()), 1 if info else 0], np.int32).tobytes())
+        f.write(np.array([len(xyz), len(rho), int(mx.sum()), int(mi.sum()), 1 if info else 0, 1 if sphere else 0], np.int32).tobytes())
         f.write(np.float64(huber).tobytes())
         f.write(xyz.astype(np.float64).tobytes() + xfree.astype(np.uint8).tobytes())
         zs = rng.uniform(0.5, 2.0, len(rho))  # anchors off the z = 1 plane: the plugin normalises them
@@ -200,7 +202,8 @@ def test_optimizer_plugin_general_graph_inverse_depth_and_mixed(tmp_path, oracle
         for m in (mx, mi):
             zm = rng.uniform(0.5, 2.0, int(m.sum()))
             f.write(opoint[m].astype(np.int32).tobytes() + oframe[m].astype(np.int32).tobytes())
-            f.write((np.c_[oxy[m], np.ones(int(m.sum()))] * zm[:, None]).astype(np.float64).tobytes())
+            m3 = oxy[m] if sphere else np.c_[oxy[m], np.ones(int(m.sum()))]  # (scaled: the plugin normalises bearings / anchors)
+            f.write((m3 * zm[:, None]).astype(np.float64).tobytes())
             if info:
                 f.write(oinfo[m].astype(np.float64).tobytes())
     r = _host(["pg", LIBDIR, inp, out])
