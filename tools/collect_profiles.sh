@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-ba --no-bow --no-c3 --no-c5 --no-host-fed --no-all-pairs-full"
+LIGHT="--steps 2 --warmup 1 --no-cpu-baseline --no-ba --no-bow --no-c3 --no-c5 --no-host-fed --no-all-pairs-full --no-range"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c3 --no-c5 --no-host-fed --no-all-pairs-full > $O/prof_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- python $R/bench.py $LIGHT > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- python $R/bench.py $LIGHT > $O/prof_write.log 2>&1
