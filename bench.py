@@ -803,7 +803,49 @@ def main():
     except Exception as exc:  # noqa: BLE001
         extra.setdefault("errors", {})["host_fed"] = repr(exc)
         log("host-fed leg failed: %r" % (exc,))
-    for leg_name, leg_fn, skip in (("latency", _leg_latency, a.no_host_fed), ("orb_range", _leg_range, a.no_range)):
+    # ---- the rest of the Optimizer boundary (round 3): pose-graph optimisation (gh_pg_solve) and the general BundleGraph
+    #      with inverse-depth + XYZ landmarks and pose edges in one graph (gh_graph_solve).  LM iterations per second with
+    #      the per-kernel HIP-event breakdown; parity of both is in tests/test_pg_gpu.py / test_graph_gpu.py.
+    def _leg_graph():
+        import numpy as np
+        from gslam_amd import posegraph
+        from gslam_amd.ba import default_options
+        from gslam_amd.pg_synth import make_landmark_graph, make_pose_graph
+        out = {}
+        truth, start, dof, prob = make_pose_graph(400, 60, kind="sim3", seed=3, noise=0.01, perturb=0.05, scale_drift=0.1)
+        o = default_options()
+        o.max_iterations = 30
+        posegraph.solve(ctx, start, dof, prob, o)
+        ctx.prof_enable(True)
+        t1 = time.perf_counter()
+        S, sm, st = posegraph.solve(ctx, start, dof, prob, o)
+        dt = time.perf_counter() - t1
+        pk = ctx.prof_collect()
+        ctx.prof_enable(False)
+        out["pose_graph"] = {"workload": "400 SIM3 keyframes, 460 sim3 edges (n = 2800 dense)", "iterations": sm.iterations,
+                             "iters_per_s": round(sm.iterations / dt, 1), "total_ms": round(dt * 1e3, 2), "status": int(st),
+                             "cost": [sm.initial_cost, sm.final_cost],
+                             "kernels_ms": {k: round(v["total_ms"], 3) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
+        truth, start, dof, prob = make_landmark_graph(n_frames=120, n_xyz=6000, n_idp=6000, kind="sim3", seed=5, noise=1e-3,
+                                                      pose_edges=True, obs_per_point=5, outliers=0.02)
+        o = default_options()
+        o.huber_delta = 0.01
+        o.max_iterations = 15
+        posegraph.solve_graph(ctx, start, dof, prob, o)
+        ctx.prof_enable(True)
+        t1 = time.perf_counter()
+        S, xyz, rho, sm, st = posegraph.solve_graph(ctx, start, dof, prob, o)
+        dt = time.perf_counter() - t1
+        pk = ctx.prof_collect()
+        ctx.prof_enable(False)
+        out["general_graph"] = {"workload": "120 SIM3 keyframes + 123 pose edges + 6000 XYZ + 6000 inverse-depth landmarks, 60 000 observations",
+                                "iterations": sm.iterations, "iters_per_s": round(sm.iterations / dt, 1), "total_ms": round(dt * 1e3, 2),
+                                "status": int(st), "cost": [sm.initial_cost, sm.final_cost],
+                                "kernels_ms": {k: round(v["total_ms"], 3) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}
+        extra["graph_solvers"] = out
+
+    for leg_name, leg_fn, skip in (("latency", _leg_latency, a.no_host_fed), ("orb_range", _leg_range, a.no_range),
+                                   ("graph_solvers", _leg_graph, a.no_ba)):
         try:
             if not skip:
                 log("leg %s" % leg_name)

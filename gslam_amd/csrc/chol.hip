@@ -2223,13 +2223,24 @@ gh_status gh_potrs_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double
   return gh_potrs_bwd_dev_impl(ctx, L, n, lda, b, work, dinv, work, 1, xh, info_dev, false);
 }
 
+namespace {
+__global__ void solve_rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ A, int lda, int n) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) A[(size_t)j * lda + n] = rhs[j];
+}
+}  // namespace
+
+// When the caller's leading dimension leaves room for one more row (lda > n) the right-hand side rides through the
+// factorisation as row n (L y = b comes out of the same launches, as in the bundle adjustment) and only the backward
+// substitution is left; the padding rows n .. lda - 1 of A are scratch in that case.
 extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, A_dev && n > 0 && lda >= n && info);
+  const int extra = (b_dev && lda > n) ? 1 : 0;
   void* scratch = nullptr;
   const size_t nblk = (size_t)gh_div_up(n, NBI);
-  const size_t flow_words = gh_potrf_flow_words(ctx, n, 0);
+  const size_t flow_words = gh_potrf_flow_words(ctx, n, extra);
   GH_TRY(gh_scratch(ctx, 256 + ((size_t)n + nblk * NBI * NBI + 2 * (size_t)NBI * n + nblk * NBI) * sizeof(double) +
                              flow_words * sizeof(unsigned), &scratch));
   int* info_dev = (int*)scratch;
@@ -2241,11 +2252,14 @@ extern "C" gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   {
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
     if (flow_state) flow_lock.lock();
-    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, 0, dinv, xwork, flow_state, true, false));
+    if (extra)
+      GH_LAUNCH(ctx, "ba_rhs_row", solve_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
+    GH_TRY(gh_potrf_dev_impl(ctx, A_dev, n, lda, info_dev, extra, dinv, xwork, flow_state, true, false));
+    if (extra) GH_TRY(gh_potrs_bwd_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv, A_dev + n, lda, xh, info_dev, false));
     GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  if (*info == 0 && b_dev) {
+  if (*info == 0 && b_dev && !extra) {
     GH_TRY(gh_potrs_dev_impl(ctx, A_dev, n, lda, b_dev, work, dinv, xh, info_dev));
     GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));

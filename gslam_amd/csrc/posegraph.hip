@@ -15,7 +15,8 @@
 //   solve        the dense SPD solver of the bundle adjustment (gh_potrf_solve_dev: MFMA f64, single-launch dataflow
 //                factorisation for n <= ~3300).  Dense on purpose: 7 n_frames squared doubles is 1.6 GB at 2000 keyframes
 //                and 157 GB at 20 000 -- the 288 GB of HBM hold what a CPU back end needs a sparse factorisation for
-//   pg_model / pg_update / pg_cost   fixed-order reductions, one launch each
+//   gr_model / pg_update / pg_cost   per-edge terms + fixed-order reductions (shared with the general graph solver below,
+//                which gh_pg_solve is the landmark-free case of)
 #include <math.h>
 
 #include <algorithm>
@@ -366,17 +367,6 @@ __global__ __launch_bounds__(256) void pg_damp_kernel(const double* __restrict__
   if (idx < (size_t)n) d[idx] = -g[idx];
 }
 
-// model decrease term of one edge: -( (J d)^T L r + 1/2 (J d)^T L (J d) ) needs L: recomputed as in the edge kernel would
-// cost the information again; instead  model = -(g^T d + 1/2 d^T H d)  with the UNDAMPED H, row by row (fixed order)
-__global__ __launch_bounds__(256) void pg_model_rows_kernel(const double* __restrict__ H, int n, int lda, const double* __restrict__ g,
-                                                            const double* __restrict__ d, double* __restrict__ row_term) {
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= n) return;
-  double hd = 0;
-  for (int b = 0; b < n; ++b) hd += (b <= a ? H[(size_t)b * lda + a] : H[(size_t)a * lda + b]) * d[b];  // symmetric read of the lower triangle
-  row_term[a] = -d[a] * (g[a] + 0.5 * hd);
-}
-
 __global__ __launch_bounds__(256) void pg_update_kernel(int n_frames, const int32_t* __restrict__ dof, const double* __restrict__ S,
                                                         const double* __restrict__ d, double* __restrict__ Snew) {
   const int f = blockIdx.x * 256 + threadIdx.x;
@@ -505,167 +495,6 @@ gh_status PoseHost::build(gh_ctx* ctx, const gh_pg_problem* pr) {
 }
 
 }  // namespace
-
-extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
-  if (!ctx || !pr) return GH_ERR_ARG;
-  GH_ENTER(ctx);
-  gh_ba_options opt;
-  gh_ba_default_options(&opt);
-  if (opt_in) opt = *opt_in;
-  gh_ba_summary local;
-  gh_ba_summary* sum = sum_out ? sum_out : &local;
-  memset(sum, 0, sizeof(*sum));
-  const int nf = pr->n_frames, ne = pr->n_se3 + pr->n_sim3 + pr->n_gps;
-  GH_CHECK_ARG(ctx, nf >= 1 && nf <= (1 << 20) && pr->frame_sim3 && pr->frame_dof && pr->n_se3 >= 0 && pr->n_sim3 >= 0 && pr->n_gps >= 0);
-  GH_CHECK_ARG(ctx, pr->n_se3 == 0 || (pr->se3_first && pr->se3_second && pr->se3_meas));
-  GH_CHECK_ARG(ctx, pr->n_sim3 == 0 || (pr->sim3_first && pr->sim3_second && pr->sim3_meas));
-  GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
-  for (int f = 0; f < nf; ++f) GH_CHECK_ARG(ctx, pr->frame_sim3[8 * (size_t)f + 7] > 0);
-  const double t_begin = now_ms_pg();
-  PoseHost PH;
-  GH_TRY(PH.build(ctx, pr));
-  std::vector<int32_t>&etype = PH.etype, &ei = PH.ei, &ej = PH.ej, &vstart = PH.vstart, &vlist = PH.vlist, &pstart = PH.pstart,
-                      &plist = PH.plist, &prow = PH.prow, &pcol = PH.pcol;
-  std::vector<double>&meas = PH.meas, &info = PH.info;
-  const bool any_info = PH.any_info;
-  const int n_pairs = PH.n_pairs;
-  const int n = 7 * nf;
-  const int lda = (n + 15) & ~15;
-  DevArena A;
-  double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H, *d_Hd, *d_g, *d_d, *d_rows, *d_out;
-  int32_t *d_dof, *d_etype, *d_ei, *d_ej, *d_vstart, *d_vlist, *d_pstart, *d_plist, *d_prow, *d_pcol;
-  unsigned long long* d_gmax;
-  bool ok = A.alloc(&d_S, (size_t)nf * 8) && A.alloc(&d_Snew, (size_t)nf * 8) && A.alloc(&d_meas, meas.size()) &&
-            (!any_info || A.alloc(&d_info, info.size())) && A.alloc(&d_rec, (size_t)kEdgeRec * etype.size()) &&
-            A.alloc(&d_cost_e, etype.size()) && A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda) &&
-            A.alloc(&d_g, (size_t)n) && A.alloc(&d_d, (size_t)n) && A.alloc(&d_rows, (size_t)n) && A.alloc(&d_out, 4) &&
-            A.alloc(&d_dof, (size_t)nf) && A.alloc(&d_etype, etype.size()) && A.alloc(&d_ei, etype.size()) &&
-            A.alloc(&d_ej, etype.size()) && A.alloc(&d_vstart, vstart.size()) && A.alloc(&d_vlist, vlist.size()) &&
-            A.alloc(&d_pstart, pstart.size()) && A.alloc(&d_plist, plist.size()) && A.alloc(&d_prow, prow.size()) &&
-            A.alloc(&d_pcol, pcol.size()) && A.alloc(&d_gmax, 1);
-  if (!ok) return gh_set_error(ctx, GH_ERR_NOMEM, "gh_pg_solve: device allocation failed (dense normal equations: %d x %d doubles)", n, lda);
-  auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
-    GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return GH_OK;
-  };
-  GH_TRY(up(d_S, pr->frame_sim3, (size_t)nf * 64));
-  GH_TRY(up(d_dof, pr->frame_dof, (size_t)nf * 4));
-  GH_TRY(up(d_meas, meas.data(), meas.size() * 8));
-  if (any_info) GH_TRY(up(d_info, info.data(), info.size() * 8));
-  GH_TRY(up(d_etype, etype.data(), etype.size() * 4));
-  GH_TRY(up(d_ei, ei.data(), ei.size() * 4));
-  GH_TRY(up(d_ej, ej.data(), ej.size() * 4));
-  GH_TRY(up(d_vstart, vstart.data(), vstart.size() * 4));
-  GH_TRY(up(d_vlist, vlist.data(), vlist.size() * 4));
-  GH_TRY(up(d_pstart, pstart.data(), pstart.size() * 4));
-  GH_TRY(up(d_plist, plist.data(), plist.size() * 4));
-  GH_TRY(up(d_prow, prow.data(), prow.size() * 4));
-  GH_TRY(up(d_pcol, pcol.data(), pcol.size() * 4));
-  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors above go out of use only at the end, but be explicit
-
-  PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
-  PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, n_pairs};
-  const int eb = gh_div_up(ne > 0 ? ne : 1, 64);
-  double host4[4];
-  auto total_cost = [&](const double* S_dev, double* out) -> gh_status {
-    if (ne > 0) GH_LAUNCH(ctx, "pg_cost", pg_cost_kernel, dim3(eb), dim3(64), 0, G, S_dev, d_cost_e);
-    GH_LAUNCH(ctx, "pg_sum", pg_sum_kernel, dim3(1), dim3(64), 0, (const double*)d_cost_e, ne, d_out, 0);
-    GH_HIP(ctx, hipMemcpyAsync(host4, d_out, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *out = host4[0];
-    return GH_OK;
-  };
-  double cost = 0;
-  GH_TRY(total_cost(d_S, &cost));
-  sum->initial_cost = cost;
-  double radius = opt.initial_radius, decrease = 2.0;
-  bool need_lin = true;
-  int term = 0, it = 0;
-  for (it = 0; it < opt.max_iterations; ++it) {
-    if (need_lin) {
-      GH_HIP(ctx, hipMemsetAsync(d_H, 0, (size_t)n * lda * sizeof(double), ctx->stream));
-      GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
-      if (ne > 0) GH_LAUNCH(ctx, "pg_edge", pg_edge_kernel, dim3(eb), dim3(64), 0, G, (const double*)d_S, d_rec, d_cost_e);
-      GH_LAUNCH(ctx, "pg_assemble", pg_assemble_kernel, dim3(nf + n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, d_H, lda,
-                d_g, d_gmax);
-      unsigned long long gb = 0;
-      GH_HIP(ctx, hipMemcpyAsync(&gb, d_gmax, 8, hipMemcpyDeviceToHost, ctx->stream));
-      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      double gmax;
-      memcpy(&gmax, &gb, 8);
-      if (gmax <= opt.gradient_tolerance) {
-        term = 2;
-        break;
-      }
-      need_lin = false;
-    }
-    GH_LAUNCH(ctx, "pg_damp", pg_damp_kernel, dim3(gh_div_up((long long)n * lda, 256)), dim3(256), 0, (const double*)d_H, d_Hd,
-              n, lda, (const double*)d_g, d_d, radius);
-    int info = 0;
-    const double t_s0 = now_ms_pg();
-    GH_TRY(gh_potrf_solve_dev(ctx, d_Hd, n, lda, d_d, &info));
-    sum->solve_ms_total += now_ms_pg() - t_s0;
-    const bool okf = info == 0;
-    double new_cost = cost, model = 0, rho = -1;
-    if (okf) {
-      GH_LAUNCH(ctx, "pg_model", pg_model_rows_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)d_H, n, lda,
-                (const double*)d_g, (const double*)d_d, d_rows);
-      GH_LAUNCH(ctx, "pg_sum", pg_sum_kernel, dim3(1), dim3(64), 0, (const double*)d_rows, n, d_out, 1);
-      GH_LAUNCH(ctx, "pg_update", pg_update_kernel, dim3(gh_div_up(nf, 256)), dim3(256), 0, nf, (const int32_t*)d_dof,
-                (const double*)d_S, (const double*)d_d, d_Snew);
-      if (ne > 0) GH_LAUNCH(ctx, "pg_cost", pg_cost_kernel, dim3(eb), dim3(64), 0, G, (const double*)d_Snew, d_cost_e);
-      GH_LAUNCH(ctx, "pg_sum", pg_sum_kernel, dim3(1), dim3(64), 0, (const double*)d_cost_e, ne, d_out, 0);
-      GH_HIP(ctx, hipMemcpyAsync(host4, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
-      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      new_cost = host4[0];
-      model = host4[1];
-      rho = model > 0 ? (cost - new_cost) / model : -1;
-      if (!(new_cost == new_cost)) rho = -1;
-    }
-    const bool acc = okf && rho > opt.min_relative_decrease;
-    if (sum->trace_len < GH_BA_MAX_TRACE) {
-      sum->trace_cost[sum->trace_len] = new_cost;
-      sum->trace_radius[sum->trace_len] = radius;
-      sum->trace_accepted[sum->trace_len] = (uint8_t)acc;
-      sum->trace_len++;
-    }
-    if (opt.verbose)
-      fprintf(stderr, "[gh_pg] it %3d cost %.9e -> %.9e model %.3e rho %.3f radius %.3e %s\n", it, cost, new_cost, model, rho, radius,
-              acc ? "accepted" : (okf ? "rejected" : "solve failed"));
-    if (acc) {
-      const double dcost = cost - new_cost;
-      std::swap(d_S, d_Snew);
-      const double t = 2.0 * rho - 1.0;
-      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-      if (radius > 1e16) radius = 1e16;
-      decrease = 2.0;
-      sum->accepted++;
-      need_lin = true;
-      const double prev = cost;
-      cost = new_cost;
-      if (fabs(dcost) <= opt.function_tolerance * prev) {
-        term = 1;
-        ++it;
-        break;
-      }
-    } else {
-      radius = radius / decrease;
-      decrease *= 2.0;
-      if (radius < 1e-32) {
-        term = 3;
-        ++it;
-        break;
-      }
-    }
-  }
-  sum->iterations = it;
-  sum->termination = term;
-  sum->final_cost = cost;
-  GH_HIP(ctx, hipMemcpyAsync(pr->frame_sim3, d_S, (size_t)nf * 64, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  sum->total_ms = now_ms_pg() - t_begin;
-  return term == 3 ? GH_ERR_NUMERIC : GH_OK;
-}
 
 // ---------------------------------------------------------------- general BundleGraph: landmarks on top of the pose graph
 // gh_graph_solve: SIM3 keyframes + pose-graph edges + XYZ and inverse-depth landmarks with pinhole observations in ONE
@@ -1189,7 +1018,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
     for (int k = 0; k < no; ++k) llist[fill[gpr->obs_kind[k] == 0 ? gpr->obs_point[k] : nx + gpr->obs_point[k]]++] = k;
   }
   const int n = 7 * nf;
-  const int lda = (n + 15) & ~15;
+  const int lda = (n + 1 + 15) & ~15;  // one spare row: the right-hand side rides through the factorisation (gh_potrf_solve_dev)
   const int n_items = ne + no, n_part = gh_div_up(std::max(n_items, std::max(no, 1)), 1024);
   DevArena A;
   double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H, *d_Hd, *d_g, *d_d, *d_out;
@@ -1388,6 +1217,20 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   sum->total_ms = now_ms_pg() - t_begin;
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;
+}
+
+// The pose graph alone is the general graph without landmarks (no atomics are involved then: the assembly is the
+// deterministic pg_assemble, the sums are fixed-order -- bitwise reproducible from run to run).
+extern "C" gh_status gh_pg_solve(gh_ctx* ctx, gh_pg_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
+  if (!ctx || !pr) return GH_ERR_ARG;
+  gh_graph_problem g;
+  memset(&g, 0, sizeof(g));
+  g.pg = *pr;
+  gh_ba_options opt;
+  gh_ba_default_options(&opt);
+  if (opt_in) opt = *opt_in;
+  opt.huber_delta = 0.0;  // (the projection Huber threshold has no meaning without observations)
+  return gh_graph_solve(ctx, &g, &opt, sum_out);
 }
 
 // ---------------------------------------------------------------- 3-D alignment

@@ -515,6 +515,8 @@ gh_status gh_align_sim3(gh_ctx* ctx, const double* src, const double* dst, int n
  * > n = a single-launch kernel (n <= ~3300 with lda % 16 == 0: factorisation; n <= 8192: back-substitution) could not
  * get all its workgroups resident in bounded time -- rebuild A and retry with GSLAM_HIP_CHOL_FLOW=0 / GSLAM_HIP_BWD_CHAIN=0
  * in the environment (gh_ba_solve does this by itself). */
+/* With lda > n the right-hand side rides through the factorisation as row n of A (one launch less per solve, as in the
+ * bundle adjustment): the padding rows n .. lda - 1 are scratch then. */
 gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info);
 
 #ifdef __cplusplus
