@@ -198,85 +198,90 @@ __device__ inline void load_info(const PgGraph& G, int e, int dim, double* L) {
   for (int a = 0; a < dim; ++a) L[7 * a + a] = 1.0;
 }
 
+// 16 lanes per edge (4 edges per 64-thread block): lanes 0..13 each take ONE Jacobian column (endpoint = lane / 7,
+// component = lane % 7: two retractions + two SIM3 logs), lane 14 the residual itself; the products are then dealt over the
+// 16 lanes.  Every sum keeps the loop order of the oracle, so the record is bit-identical to a one-thread-per-edge evaluation
+// -- 14 times less latency, which is what a few hundred edges are bound by.
 __global__ __launch_bounds__(64) void pg_edge_kernel(PgGraph G, const double* __restrict__ S, double* __restrict__ rec,
                                                      double* __restrict__ cost_e) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= G.n_edges) return;
-  const int type = G.etype[e], i = G.ei[e], j = G.ej[e];
-  double Si[8], Sj[8], meas[8], r[7], L[49], Ji[49], Jj[49];
-  for (int k = 0; k < 8; ++k) {
-    Si[k] = S[8 * (size_t)i + k];
-    Sj[k] = j >= 0 ? S[8 * (size_t)j + k] : Si[k];
-    meas[k] = G.meas[8 * (size_t)e + k];
-  }
-  const int dim = edge_residual(type, Si, Sj, meas, r);
-  load_info(G, e, dim, L);
-  for (int k = 0; k < 49; ++k) Ji[k] = Jj[k] = 0.0;
-  const int dof_i = G.dof[i], dof_j = j >= 0 ? G.dof[j] : 0;
-  for (int which = 0; which < 2; ++which) {
-    if (which == 1 && j < 0) break;
-    const int dof = which == 0 ? dof_i : dof_j;
-    double* J = which == 0 ? Ji : Jj;
-    for (int k = 0; k < 7; ++k) {
-      if (!((dof >> k) & 1)) continue;
-      double dp[7] = {0, 0, 0, 0, 0, 0, 0}, Sp[8], Sm[8], rp[7], rm[7];
-      dp[k] = kFdStep;
-      sim3_retract(which == 0 ? Si : Sj, dp, Sp);
-      dp[k] = -kFdStep;
-      sim3_retract(which == 0 ? Si : Sj, dp, Sm);
-      edge_residual(type, which == 0 ? Sp : Si, which == 0 ? Sj : Sp, meas, rp);
-      edge_residual(type, which == 0 ? Sm : Si, which == 0 ? Sj : Sm, meas, rm);
-      for (int a = 0; a < dim; ++a) J[7 * a + k] = (rp[a] - rm[a]) / (2.0 * kFdStep);
+  __shared__ double sJ[4][2][49], sL[4][49], sLr[4][7], sLJ[4][2][49];
+  const int slot = threadIdx.x >> 4, t = threadIdx.x & 15;
+  const int e = blockIdx.x * 4 + slot;
+  const bool live = e < G.n_edges;
+  int type = 0, i = 0, j = -1, dim = 0;
+  double Si[8], Sj[8], meas[8];
+  if (live) {
+    type = G.etype[e];
+    i = G.ei[e];
+    j = G.ej[e];
+    for (int k = 0; k < 8; ++k) {
+      Si[k] = S[8 * (size_t)i + k];
+      Sj[k] = j >= 0 ? S[8 * (size_t)j + k] : Si[k];
+      meas[k] = G.meas[8 * (size_t)e + k];
     }
-  }
-  double* o = rec + (size_t)kEdgeRec * e;
-  double Lr[7], q = 0;
-  for (int a = 0; a < 7; ++a) Lr[a] = 0.0;
-  for (int a = 0; a < dim; ++a) {
-    double s = 0;
-    for (int b = 0; b < dim; ++b) s += L[7 * a + b] * r[b];
-    Lr[a] = s;
-    q += r[a] * s;
-  }
-  cost_e[e] = 0.5 * q;
-  // L J (dim x 7) for both endpoints, then the three blocks and the two gradient pieces -- same loop order as the oracle
-  double LJi[49], LJj[49];
-  for (int a = 0; a < 7; ++a)
-    for (int k = 0; k < 7; ++k) {
-      double si = 0, sj = 0;
-      if (a < dim)
-        for (int b = 0; b < dim; ++b) {
-          si += L[7 * a + b] * Ji[7 * b + k];
-          sj += L[7 * a + b] * Jj[7 * b + k];
-        }
-      LJi[7 * a + k] = si;
-      LJj[7 * a + k] = sj;
-    }
-  for (int p = 0; p < 7; ++p) {
-    double gi = 0, gj = 0;
-    for (int a = 0; a < dim; ++a) {
-      gi += Ji[7 * a + p] * Lr[a];
-      gj += Jj[7 * a + p] * Lr[a];
-    }
-    o[147 + p] = gi;
-    o[154 + p] = gj;
-    for (int q2 = 0; q2 < 7; ++q2) {
-      double hii = 0, hjj = 0, hji = 0;
-      for (int a = 0; a < dim; ++a) {
-        hii += Ji[7 * a + p] * LJi[7 * a + q2];
-        hjj += Jj[7 * a + p] * LJj[7 * a + q2];
-        hji += Jj[7 * a + p] * LJi[7 * a + q2];
+    dim = type == 1 ? 7 : 6;
+    if (t < 14) {
+      const int which = t / 7, k = t - 7 * which;
+      const int dof = which == 0 ? G.dof[i] : (j >= 0 ? G.dof[j] : 0);
+      double col[7] = {0, 0, 0, 0, 0, 0, 0};
+      if ((which == 0 || j >= 0) && ((dof >> k) & 1)) {
+        double dp[7] = {0, 0, 0, 0, 0, 0, 0}, Sp[8], Sm[8], rp[7], rm[7];
+        dp[k] = kFdStep;
+        sim3_retract(which == 0 ? Si : Sj, dp, Sp);
+        dp[k] = -kFdStep;
+        sim3_retract(which == 0 ? Si : Sj, dp, Sm);
+        edge_residual(type, which == 0 ? Sp : Si, which == 0 ? Sj : Sp, meas, rp);
+        edge_residual(type, which == 0 ? Sm : Si, which == 0 ? Sj : Sm, meas, rm);
+        for (int a = 0; a < dim; ++a) col[a] = (rp[a] - rm[a]) / (2.0 * kFdStep);
       }
-      o[7 * p + q2] = hii;        // A_ii[p][q]
-      o[49 + 7 * p + q2] = hjj;   // A_jj[p][q]
-      o[98 + 7 * p + q2] = hji;   // A_ji[p][q]: row index in frame j, column index in frame i
+      for (int a = 0; a < 7; ++a) sJ[slot][which][7 * a + k] = col[a];
+    } else if (t == 14) {
+      double r[7], L[49], q = 0;
+      edge_residual(type, Si, Sj, meas, r);
+      load_info(G, e, dim, L);
+      for (int k = 0; k < 49; ++k) sL[slot][k] = L[k];
+      for (int a = 0; a < 7; ++a) {
+        double s = 0;
+        if (a < dim) {
+          for (int b = 0; b < dim; ++b) s += L[7 * a + b] * r[b];
+          q += r[a] * s;
+        }
+        sLr[slot][a] = s;
+      }
+      cost_e[e] = 0.5 * q;
     }
   }
-  for (int k = 0; k < 49; ++k) {
-    o[161 + k] = Ji[k];
-    o[210 + k] = Jj[k];
+  __syncthreads();
+  // L J (dim x 7) for both endpoints: 98 entries over the 16 lanes
+  if (live)
+    for (int idx = t; idx < 98; idx += 16) {
+      const int which = idx / 49, ak = idx - 49 * which, a = ak / 7, k = ak - 7 * a;
+      double s = 0;
+      if (a < dim)
+        for (int b = 0; b < dim; ++b) s += sL[slot][7 * a + b] * sJ[slot][which][7 * b + k];
+      sLJ[slot][which][ak] = s;
+    }
+  __syncthreads();
+  if (!live) return;
+  double* o = rec + (size_t)kEdgeRec * e;
+  const double(*J)[49] = sJ[slot];
+  const double(*LJ)[49] = sLJ[slot];
+  // the three 7 x 7 blocks (147 entries), the two gradient pieces (14), the Jacobians (98) and L r (7)
+  for (int idx = t; idx < 147; idx += 16) {
+    const int blk = idx / 49, pq = idx - 49 * blk, p = pq / 7, q2 = pq - 7 * p;
+    double h = 0;
+    for (int a = 0; a < dim; ++a)
+      h += blk == 0 ? J[0][7 * a + p] * LJ[0][7 * a + q2] : blk == 1 ? J[1][7 * a + p] * LJ[1][7 * a + q2] : J[1][7 * a + p] * LJ[0][7 * a + q2];
+    o[49 * blk + 7 * p + q2] = h;  // A_ii, A_jj, A_ji (row index in frame j, column index in frame i)
   }
-  for (int a = 0; a < 7; ++a) o[259 + a] = Lr[a];
+  if (t < 14) {
+    const int which = t / 7, p = t - 7 * which;
+    double g = 0;
+    for (int a = 0; a < dim; ++a) g += J[which][7 * a + p] * sLr[slot][a];
+    o[147 + 7 * which + p] = g;
+  }
+  for (int idx = t; idx < 98; idx += 16) o[161 + idx] = idx < 49 ? J[0][idx] : J[1][idx - 49];
+  if (t < 7) o[259 + t] = sLr[slot][t];
 }
 
 // residual-only pass at a candidate state
@@ -761,19 +766,34 @@ __global__ __launch_bounds__(256) void gr_gmax_kernel(const double* __restrict__
 }
 
 // (H_pp + D)^-1 per landmark; lmdim = 0 for a landmark that is fixed or has no valid observation
+// Also, for an inverse-depth landmark: every observation from another keyframe has a slot in the HOST keyframe; those
+// are summed into one (Wh = sum of their W, a 7-vector since the landmark is a scalar) represented by the first of them
+// (hrep), so that the Schur product sees one host slot per landmark instead of one per observation.
 __global__ __launch_bounds__(256) void gr_lm_prepare_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ Hpp,
-                                                            double radius, double* __restrict__ Hinv, int32_t* __restrict__ lmdim) {
+                                                            const double* __restrict__ orec, double radius, double* __restrict__ Hinv,
+                                                            int32_t* __restrict__ lmdim, double* __restrict__ Wh,
+                                                            int32_t* __restrict__ hrep) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= G.n_xyz + G.n_idp) return;
-  int dp = 0;
+  int dp = 0, rep = -1;
+  double wh[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
     const int k = G.llist[q];
     if (valid[k]) {
       const ObsRef o = obs_ref(G, k);
       dp = o.dp > dp ? o.dp : dp;
+      if (o.fh >= 0 && o.dp == 1) {
+        if (rep < 0) rep = k;
+        const double* R = orec + (size_t)kObsRec * k;
+        const double* L = R + 2;
+        const double LJ0 = L[0] * R[34] + L[1] * R[37], LJ1 = L[2] * R[34] + L[3] * R[37];
+        for (int r7 = 0; r7 < 7; ++r7) wh[r7] += R[20 + r7] * LJ0 + R[27 + r7] * LJ1;
+      }
     }
   }
   lmdim[p] = dp;
+  hrep[p] = rep;
+  for (int r7 = 0; r7 < 7; ++r7) Wh[7 * (size_t)p + r7] = wh[r7];
   double Hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (dp) {
     double Hp[9];
@@ -809,6 +829,7 @@ __device__ inline void slot_W(const double* R, int x, int dp, double* W) {
 
 __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
                                                        const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
+                                                       const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
                                                        const double* __restrict__ gp, double* __restrict__ Hd, int lda,
                                                        double* __restrict__ d) {
   const int sa = blockIdx.x * 128 + threadIdx.x;
@@ -819,8 +840,17 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
   if (fa < 0) return;
   const int dp = lmdim[oa.lm];
   if (!dp) return;
+  const int rep = hrep[oa.lm];
+  if (x == 1 && ka != rep) return;  // the landmark's host slots are one slot, carried by their first observation
   double Wa[21], Ua[21], Hi[9];
-  slot_W(orec + (size_t)kObsRec * ka, x, dp, Wa);
+  if (x == 1) {
+    for (int r7 = 0; r7 < 7; ++r7) {
+      Wa[3 * r7] = Wh[7 * (size_t)oa.lm + r7];
+      Wa[3 * r7 + 1] = Wa[3 * r7 + 2] = 0.0;
+    }
+  } else {
+    slot_W(orec + (size_t)kObsRec * ka, x, dp, Wa);
+  }
   for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)oa.lm + e];
   for (int r7 = 0; r7 < 7; ++r7)
     for (int b = 0; b < 3; ++b) Ua[3 * r7 + b] = Wa[3 * r7] * Hi[b] + Wa[3 * r7 + 1] * Hi[3 + b] + Wa[3 * r7 + 2] * Hi[6 + b];
@@ -835,9 +865,16 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
     const ObsRef ob = obs_ref(G, kb);
     for (int y = 0; y < 2; ++y) {
       const int fb = y == 0 ? ob.fj : ob.fh;
-      if (fb < 0 || fb > fa) continue;  // lower triangle of blocks; equal frames: the whole block, from both orders
+      if (fb < 0 || fb > fa || (y == 1 && kb != rep)) continue;  // lower triangle of blocks; equal frames: the whole block, from both orders
       double Wb[21];
-      slot_W(orec + (size_t)kObsRec * kb, y, dp, Wb);
+      if (y == 1) {
+        for (int c7 = 0; c7 < 7; ++c7) {
+          Wb[3 * c7] = Wh[7 * (size_t)oa.lm + c7];
+          Wb[3 * c7 + 1] = Wb[3 * c7 + 2] = 0.0;
+        }
+      } else {
+        slot_W(orec + (size_t)kObsRec * kb, y, dp, Wb);
+      }
       for (int c7 = 0; c7 < 7; ++c7)
         for (int r7 = 0; r7 < 7; ++r7) {
           const double v = Ua[3 * r7] * Wb[3 * c7] + Ua[3 * r7 + 1] * Wb[3 * c7 + 1] + Ua[3 * r7 + 2] * Wb[3 * c7 + 2];
@@ -1023,9 +1060,9 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   DevArena A;
   double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H, *d_Hd, *d_g, *d_d, *d_out;
   double *d_xyz, *d_xyz_new, *d_rho, *d_rho_new, *d_anchor, *d_oxy, *d_oinfo = nullptr, *d_orec, *d_Hpp, *d_gp, *d_Hinv, *d_dlm, *d_term,
-      *d_part;
+      *d_part, *d_Wh;
   int32_t *d_dof, *d_etype, *d_ei, *d_ej, *d_vstart, *d_vlist, *d_pstart, *d_plist, *d_prow, *d_pcol, *d_host, *d_okind, *d_opoint,
-      *d_oframe, *d_lstart, *d_llist, *d_lmdim;
+      *d_oframe, *d_lstart, *d_llist, *d_lmdim, *d_hrep;
   uint8_t *d_xfree = nullptr, *d_ifree = nullptr, *d_valid;
   unsigned long long* d_gmax;
   const size_t nlm1 = (size_t)std::max(nlm, 1), no1 = (size_t)std::max(no, 1);
@@ -1043,7 +1080,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
             A.alloc(&d_gp, nlm1 * 3) && A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) &&
             A.alloc(&d_term, (size_t)std::max(n_items, 1)) && A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_okind, no1) &&
             A.alloc(&d_opoint, no1) && A.alloc(&d_oframe, no1) && A.alloc(&d_lstart, lstart.size()) && A.alloc(&d_llist, llist.size()) &&
-            A.alloc(&d_lmdim, nlm1) && A.alloc(&d_valid, no1) && (!gpr->xyz_free || A.alloc(&d_xfree, (size_t)std::max(nx, 1))) &&
+            A.alloc(&d_lmdim, nlm1) && A.alloc(&d_hrep, nlm1) && A.alloc(&d_Wh, nlm1 * 7) && A.alloc(&d_valid, no1) && (!gpr->xyz_free || A.alloc(&d_xfree, (size_t)std::max(nx, 1))) &&
             (!gpr->idp_free || A.alloc(&d_ifree, (size_t)std::max(ni, 1)));
   if (!ok) return gh_set_error(ctx, GH_ERR_NOMEM, "gh_graph_solve: device allocation failed (dense keyframe system: %d x %d doubles)", n, lda);
   auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
@@ -1082,7 +1119,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, PH.n_pairs};
   GrLandmarks LM{nx, ni, no, d_xfree, d_host, d_anchor, d_ifree, d_okind, d_opoint, d_oframe, d_oxy, d_oinfo, d_lstart, d_llist,
                  opt.huber_delta, gpr->projection};
-  const int eb = gh_div_up(ne > 0 ? ne : 1, 64), ob = gh_div_up(no > 0 ? no : 1, 128);
+  const int eb = gh_div_up(ne > 0 ? ne : 1, 64), eb4 = gh_div_up(ne > 0 ? ne : 1, 4), ob = gh_div_up(no > 0 ? no : 1, 128);
   double host4[4];
   // sum of v[0..count) into d_out[slot]: fixed order (1024 per block, then the partials one after the other)
   auto reduce_to = [&](const double* v, int count, int slot) -> gh_status {
@@ -1113,7 +1150,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_Hpp, 0, nlm1 * 72, ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_gp, 0, nlm1 * 24, ctx->stream));
-      if (ne > 0) GH_LAUNCH(ctx, "pg_edge", pg_edge_kernel, dim3(eb), dim3(64), 0, G, (const double*)d_S, d_rec, d_cost_e);
+      if (ne > 0) GH_LAUNCH(ctx, "pg_edge", pg_edge_kernel, dim3(eb4), dim3(64), 0, G, (const double*)d_S, d_rec, d_cost_e);
       // stores the pose-edge sums into every diagonal block, every edge pair block and g (zeros where there is no edge)
       GH_LAUNCH(ctx, "pg_assemble", pg_assemble_kernel, dim3(nf + PH.n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, d_H, lda,
                 d_g, d_gmax);
@@ -1138,10 +1175,11 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
               n, lda, (const double*)d_g, d_d, radius);
     if (nlm > 0) {
       GH_LAUNCH(ctx, "gr_lm_prepare", gr_lm_prepare_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
-                (const double*)d_Hpp, radius, d_Hinv, d_lmdim);
+                (const double*)d_Hpp, (const double*)d_orec, radius, d_Hinv, d_lmdim, d_Wh, d_hrep);
       if (no > 0)
         GH_LAUNCH(ctx, "gr_schur", gr_schur_kernel, dim3(gh_div_up(2 * no, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
-                  (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_gp, d_Hd, lda, d_d);
+                  (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
+                  (const double*)d_gp, d_Hd, lda, d_d);
     }
     int info = 0;
     const double t_s0 = now_ms_pg();
