@@ -15,15 +15,17 @@ def _p(t):
 
 class Vocabulary:
     def __init__(self, ctx: hip.Context, voc: dict):
-        """voc: dict(k, L, weighting, scoring, nodes (structured childNum/weight), desc (nnodes x 32 u8))."""
+        """voc: dict(k, L, weighting, scoring, nodes (structured childNum/weight), desc (nnodes x W u8, W a multiple of 8:
+        32-byte ORB / BRIEF words, 64-byte long binary descriptors ...))."""
         self.ctx = ctx
         self.k, self.L = int(voc["k"]), int(voc["L"])
         nodes = np.ascontiguousarray(voc["nodes"])
         desc = np.ascontiguousarray(voc["desc"], dtype=np.uint8)
+        self.desc_bytes = int(desc.shape[1])
         h = C.c_void_p()
-        ctx.check(hip.lib.gh_bow_vocab_create(ctx.h, self.k, self.L, int(voc["weighting"]), int(voc["scoring"]),
-                                              len(nodes), nodes.ctypes.data_as(C.c_void_p),
-                                              desc.ctypes.data_as(C.c_void_p), C.byref(h)))
+        ctx.check(hip.lib.gh_bow_vocab_create_bytes(ctx.h, self.k, self.L, int(voc["weighting"]), int(voc["scoring"]),
+                                                    len(nodes), nodes.ctypes.data_as(C.c_void_p),
+                                                    desc.ctypes.data_as(C.c_void_p), self.desc_bytes, C.byref(h)))
         self.h = h
 
     def close(self):
@@ -43,14 +45,14 @@ class Vocabulary:
                 torch.empty(n_images, dtype=torch.int32, device=device))
 
     def transform(self, desc: torch.Tensor, counts=None, levelsup=2, out=None):
-        """desc: B x cap x 32 u8 (cuda) -> (word, weight, node, bow_word, bow_val, bow_n) device tensors."""
+        """desc: B x cap x desc_bytes u8 (cuda) -> (word, weight, node, bow_word, bow_val, bow_n) device tensors."""
         B, cap = desc.shape[0], desc.shape[1]
         out = out or self.alloc(B, cap, desc.device)
         self.ctx.check(hip.lib.gh_bow_transform_dev(self.h, _p(desc), _p(counts), cap, B, int(levelsup), *[_p(t) for t in out]))
         return out
 
     def transform_host(self, desc: np.ndarray, levelsup=2):
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, self.desc_bytes)
         n = desc.shape[0]
         m = max(n, 1)
         word, node, bw = np.zeros(m, np.uint32), np.zeros(m, np.uint32), np.zeros(m, np.uint32)

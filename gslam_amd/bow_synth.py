@@ -14,13 +14,13 @@ TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
 L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = 0, 1, 2, 3, 4, 5
 
 
-def make_vocabulary(k=10, L=4, seed=1, weighting=TF_IDF, scoring=L1_NORM, ragged=True, stop_frac=0.02):
+def make_vocabulary(k=10, L=4, seed=1, weighting=TF_IDF, scoring=L1_NORM, ragged=True, stop_frac=0.02, desc_bytes=32):
     rng = np.random.default_rng(seed)
     nnodes = (k ** (L + 1) - 1) // (k - 1)
-    desc = np.zeros((nnodes, 32), np.uint8)
+    desc = np.zeros((nnodes, desc_bytes), np.uint8)  # any multiple of 8 bytes (Vocabulary.h:560-568)
     child_num = np.zeros(nnodes, np.uint32)
     weight = np.zeros(nnodes, np.float32)
-    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc[0] = rng.integers(0, 256, desc_bytes, dtype=np.uint8)
     level_start = 0
     for lvl in range(L):
         n_lvl = k ** lvl
@@ -33,8 +33,8 @@ def make_vocabulary(k=10, L=4, seed=1, weighting=TF_IDF, scoring=L1_NORM, ragged
         nflip = max(8, 48 >> lvl)
         kids = parents[:, None] * k + 1 + np.arange(k)[None, :]
         base = np.repeat(desc[parents], k, axis=0)
-        flips = np.zeros((n_lvl * k, 256), np.uint8)
-        cols = rng.integers(0, 256, (n_lvl * k, nflip))
+        flips = np.zeros((n_lvl * k, 8 * desc_bytes), np.uint8)
+        cols = rng.integers(0, 8 * desc_bytes, (n_lvl * k, nflip))
         np.put_along_axis(flips, cols, 1, axis=1)
         desc[kids.reshape(-1)] = base ^ np.packbits(flips, axis=1, bitorder="little")
         level_start += n_lvl
@@ -50,7 +50,7 @@ def make_vocabulary(k=10, L=4, seed=1, weighting=TF_IDF, scoring=L1_NORM, ragged
 
 def to_gbow_bytes(v):
     hdr = struct.pack("<QBI", MAGIC, 0, len(v["nodes"]))
-    hdr += struct.pack("<7i", v["k"], v["L"], v["scoring"], v["weighting"], 32, 1, 0)
+    hdr += struct.pack("<7i", v["k"], v["L"], v["scoring"], v["weighting"], v["desc"].shape[1], 1, 0)
     return hdr + v["nodes"].tobytes() + v["desc"].tobytes()
 
 
@@ -59,7 +59,7 @@ def features_near_words(v, n, seed=2, flip_bits=10):
     rng = np.random.default_rng(seed)
     ids = rng.integers(len(v["nodes"]) // 2, len(v["nodes"]), n)
     d = v["desc"][ids].copy()
-    flips = np.zeros((n, 256), np.uint8)
-    cols = rng.integers(0, 256, (n, flip_bits))
+    flips = np.zeros((n, 8 * d.shape[1]), np.uint8)
+    cols = rng.integers(0, 8 * d.shape[1], (n, flip_bits))
     np.put_along_axis(flips, cols, 1, axis=1)
     return d ^ np.packbits(flips, axis=1, bitorder="little")

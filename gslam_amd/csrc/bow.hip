@@ -21,14 +21,12 @@ struct Node {
   float weight;
 };
 
-__device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
-  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
-         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-}
-
-__global__ __launch_bounds__(256) void bow_words_kernel(const Node* __restrict__ nodes,
-                                                        const uint4* __restrict__ ndesc, int k, int L,
-                                                        const uint4* __restrict__ desc,
+// Descriptors are binary strings of 8 W8 bytes (GSLAM/core/Vocabulary.h:560-568: 32 -> hamming32, 64 -> hamming64, any
+// other multiple of 8 -> hamming8x; all three are the popcount of the xor, 64 bits at a time).  W8 = 4 / 8 keep the query
+// in registers; W8 = 0 is the run-time-length version (query re-read from memory for every child).
+template <int W8>
+__global__ __launch_bounds__(256) void bow_words_kernel(const Node* __restrict__ nodes, const uint2* __restrict__ ndesc, int k,
+                                                        int L, int w8_rt, const uint2* __restrict__ desc,
                                                         const int32_t* __restrict__ counts, int cap, int levelsup,
                                                         uint32_t* __restrict__ word, float* __restrict__ weight,
                                                         uint32_t* __restrict__ node) {
@@ -43,7 +41,12 @@ __global__ __launch_bounds__(256) void bow_words_kernel(const Node* __restrict__
     node[o] = 0xFFFFFFFFu;
     return;
   }
-  const uint4 q0 = desc[2 * o], q1 = desc[2 * o + 1];
+  const int w8 = W8 ? W8 : w8_rt;
+  uint2 q[W8 ? W8 : 1];
+  if (W8) {
+#pragma unroll
+    for (int w = 0; w < W8; ++w) q[w] = desc[(size_t)W8 * o + w];
+  }
   const int nid_level = L - levelsup;
   uint32_t final_id = 0, nid = 0;
   int level = 0;
@@ -55,7 +58,19 @@ __global__ __launch_bounds__(256) void bow_words_kernel(const Node* __restrict__
     const uint32_t first = final_id * (uint32_t)k + 1;
     for (uint32_t c = 0; c < cn; ++c) {
       const uint32_t id = first + c;
-      const int d = ham256(q0, q1, ndesc[2 * (size_t)id], ndesc[2 * (size_t)id + 1]);
+      int d = 0;
+      if (W8) {
+#pragma unroll
+        for (int w = 0; w < W8; ++w) {
+          const uint2 t = ndesc[(size_t)W8 * id + w];
+          d += __popc(q[w].x ^ t.x) + __popc(q[w].y ^ t.y);
+        }
+      } else {
+        for (int w = 0; w < w8; ++w) {
+          const uint2 t = ndesc[(size_t)w8 * id + w], f = desc[(size_t)w8 * o + w];
+          d += __popc(f.x ^ t.x) + __popc(f.y ^ t.y);
+        }
+      }
       if (d < best_d) {
         best_d = d;
         best = id;
@@ -178,25 +193,32 @@ struct gh_bow_vocab {
   uint32_t nnodes;
   Node* d_nodes;
   uint8_t* d_desc;
+  int desc_bytes;  // a multiple of 8 (32 for ORB / BRIEF, 64 for the long binary descriptors)
 };
 
 extern "C" gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
                                          const void* nodes, const uint8_t* node_desc, gh_bow_vocab** out) {
+  return gh_bow_vocab_create_bytes(ctx, k, L, weighting, scoring, nnodes, nodes, node_desc, 32, out);
+}
+
+extern "C" gh_status gh_bow_vocab_create_bytes(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
+                                               const void* nodes, const uint8_t* node_desc, int desc_bytes, gh_bow_vocab** out) {
   if (!ctx || !out) return GH_ERR_ARG;
   GH_ENTER(ctx);
   *out = nullptr;
   GH_CHECK_ARG(ctx, k >= 2 && L >= 1 && nnodes >= 1 && nodes && node_desc);
+  GH_CHECK_ARG(ctx, desc_bytes >= 8 && desc_bytes <= 1024 && desc_bytes % 8 == 0);
   GH_CHECK_ARG(ctx, weighting >= 0 && weighting <= 3 && scoring >= 0 && scoring <= 5);
   const Node* hn = (const Node*)nodes;
   for (uint32_t i = 0; i < nnodes; ++i)  // every child index must exist (the descent never checks bounds)
     GH_CHECK_ARG(ctx, hn[i].childNum <= (uint32_t)k && (hn[i].childNum == 0 || (uint64_t)i * k + hn[i].childNum < nnodes));
   gh_bow_vocab* v = new (std::nothrow) gh_bow_vocab();
   if (!v) return GH_ERR_NOMEM;
-  *v = gh_bow_vocab{ctx, k, L, weighting, scoring, nnodes, nullptr, nullptr};
+  *v = gh_bow_vocab{ctx, k, L, weighting, scoring, nnodes, nullptr, nullptr, desc_bytes};
   gh_status st = gh_dev_alloc(ctx, (size_t)nnodes * sizeof(Node), (void**)&v->d_nodes);
-  if (st == GH_OK) st = gh_dev_alloc(ctx, (size_t)nnodes * 32, (void**)&v->d_desc);
+  if (st == GH_OK) st = gh_dev_alloc(ctx, (size_t)nnodes * desc_bytes, (void**)&v->d_desc);
   if (st == GH_OK) st = gh_dev_upload(ctx, v->d_nodes, nodes, (size_t)nnodes * sizeof(Node));
-  if (st == GH_OK) st = gh_dev_upload(ctx, v->d_desc, node_desc, (size_t)nnodes * 32);
+  if (st == GH_OK) st = gh_dev_upload(ctx, v->d_desc, node_desc, (size_t)nnodes * desc_bytes);
   if (st != GH_OK) {
     if (v->d_nodes) hipFree(v->d_nodes);
     if (v->d_desc) hipFree(v->d_desc);
@@ -226,10 +248,18 @@ extern "C" gh_status gh_bow_transform_dev(gh_bow_vocab* v, const uint8_t* desc_d
   GH_CHECK_ARG(ctx, cap >= 0 && cap <= 16384 && n_images >= 0 && n_images <= 65535);
   if (cap == 0 || n_images == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc_dev && word_dev && weight_dev && node_dev && bow_word_dev && bow_val_dev && bow_n_dev);
-  GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 15) == 0);
-  GH_LAUNCH(ctx, "bow_words", bow_words_kernel, dim3(gh_div_up(cap, 256), n_images), dim3(256), 0, v->d_nodes,
-            (const uint4*)v->d_desc, v->k, v->L, (const uint4*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev,
-            node_dev);
+  GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 7) == 0);
+  const int w8 = v->desc_bytes / 8;
+  const dim3 wgrid(gh_div_up(cap, 256), n_images);
+  if (w8 == 4)
+    GH_LAUNCH(ctx, "bow_words", bow_words_kernel<4>, wgrid, dim3(256), 0, v->d_nodes, (const uint2*)v->d_desc, v->k, v->L, w8,
+              (const uint2*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev, node_dev);
+  else if (w8 == 8)
+    GH_LAUNCH(ctx, "bow_words", bow_words_kernel<8>, wgrid, dim3(256), 0, v->d_nodes, (const uint2*)v->d_desc, v->k, v->L, w8,
+              (const uint2*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev, node_dev);
+  else
+    GH_LAUNCH(ctx, "bow_words", bow_words_kernel<0>, wgrid, dim3(256), 0, v->d_nodes, (const uint2*)v->d_desc, v->k, v->L, w8,
+              (const uint2*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev, node_dev);
   int P = 256;
   while (P < cap) P <<= 1;
   if ((size_t)P * 8 > 48 * 1024) {
@@ -252,7 +282,7 @@ extern "C" gh_status gh_bow_transform_host(gh_bow_vocab* v, const uint8_t* desc,
   *bow_n = 0;
   if (n == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc && word && weight && node && bow_word && bow_val);
-  const size_t a = ((size_t)n * 32 + 255) & ~(size_t)255, b = ((size_t)n * 4 + 255) & ~(size_t)255;
+  const size_t a = ((size_t)n * v->desc_bytes + 255) & ~(size_t)255, b = ((size_t)n * 4 + 255) & ~(size_t)255;
   void* s = nullptr;
   GH_TRY(gh_scratch(ctx, a + 5 * b + 256, &s));
   uint8_t* p = (uint8_t*)s;
@@ -263,7 +293,7 @@ extern "C" gh_status gh_bow_transform_host(gh_bow_vocab* v, const uint8_t* desc,
   uint32_t* d_bw = (uint32_t*)(p + a + 3 * b);
   float* d_bv = (float*)(p + a + 4 * b);
   int32_t* d_n = (int32_t*)(p + a + 5 * b);
-  GH_HIP(ctx, hipMemcpyAsync(d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d_desc, desc, (size_t)n * v->desc_bytes, hipMemcpyHostToDevice, ctx->stream));
   GH_TRY(gh_bow_transform_dev(v, d_desc, nullptr, n, 1, levelsup, d_word, d_weight, d_node, d_bw, d_bv, d_n));
   GH_HIP(ctx, hipMemcpyAsync(word, d_word, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(weight, d_weight, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));

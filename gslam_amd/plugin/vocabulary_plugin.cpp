@@ -5,7 +5,9 @@
 // class (load/save, node tables, scoring object) and only moves
 //     transform(const TinyMat& features, BowVector&, FeatureVector&, int levelsup)   (:1558-1621)
 //     transform(const TinyMat& features, BowVector&)                                (:1437-1497)
-// to gh_bow_transform_host.  Factory (same idiom as createOptimizerInstance):
+// to gh_bow_transform_host.  Binary vocabularies of any width the reference's DistanceFactory accepts (:560-568: 32 bytes ->
+// hamming32, 64 -> hamming64, other multiples of 8 -> hamming8x) are taken; float (L2) vocabularies are refused at load.
+// Factory (same idiom as createOptimizerInstance):
 //     extern "C" std::shared_ptr<GSLAM::Vocabulary> createVocabularyInstance(const char* gbow_file)
 // as well as the std::vector<TinyMat> overload (:183, one feature per element) and the single-feature
 // transform(const TinyMat&) -> WordId (:200).  Images of more than 16384 features are descended on the GPU in chunks and
@@ -61,21 +63,21 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     v.clear();
     fv.clear();
     if (features.empty()) return;
-    std::vector<uchar> packed(features.size() * 32);
+    std::vector<uchar> packed(features.size() * (size_t)width_);
     for (size_t i = 0; i < features.size(); ++i) {
-      if (features[i].rows < 1 || features[i].cols * features[i].elemSize() != 32) {
-        failed("a feature of the list is not one 32-byte descriptor row");
+      if (features[i].rows < 1 || (int)(features[i].cols * features[i].elemSize()) != width_) {
+        failed("a feature of the list is not one descriptor row of the vocabulary's width");
         return;
       }
-      std::memcpy(&packed[i * 32], features[i].data, 32);
+      std::memcpy(&packed[i * width_], features[i].data, width_);
     }
-    GSLAM::TinyMat all((int)features.size(), 32, GSLAM::GImageType<uchar>::Type, packed.data(), false);
+    GSLAM::TinyMat all((int)features.size(), width_, GSLAM::GImageType<uchar>::Type, packed.data(), false);
     run(all, levelsup, &v, &fv);
   }
 
   // a single feature -> its word (GSLAM/core/Vocabulary.h:200,1421-1433)
   GSLAM::WordId transform(const GSLAM::TinyMat& feature) const override {
-    if (empty() || feature.rows < 1 || feature.cols * feature.elemSize() != 32) return 0;
+    if (empty() || feature.rows < 1 || (int)(feature.cols * feature.elemSize()) != width_) return 0;
     std::lock_guard<std::mutex> lock(mu_);
     if (!voc_) return 0;
     uint32_t word = 0, node = 0, bw = 0;
@@ -123,8 +125,9 @@ class VocabularyHIP : public GSLAM::Vocabulary {
  private:
   bool upload() {
     std::lock_guard<std::mutex> lock(mu_);
-    if (m_nodes.empty() || m_nodeDescriptors.cols * m_nodeDescriptors.elemSize() != 32) {
-      LOG(ERROR) << "VocabularyHIP: only 32-byte binary descriptors are supported";
+    width_ = (int)(m_nodeDescriptors.cols * m_nodeDescriptors.elemSize());
+    if (m_nodes.empty() || m_nodeDescriptors.type() != GSLAM::GImageType<uchar>::Type || width_ < 8 || width_ % 8 != 0) {
+      LOG(ERROR) << "VocabularyHIP: only binary descriptors of a multiple of 8 bytes are supported (float vocabularies are not)";
       return false;
     }
     if (!ctx_ && gh_ctx_create(svar.GetInt("VocabularyHIP.Device", 0), &ctx_) != GH_OK) {
@@ -135,8 +138,8 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     if (voc_) gh_bow_vocab_destroy(voc_);
     voc_ = nullptr;
     static_assert(sizeof(Node) == 8, "Vocabulary::Node layout");
-    if (gh_bow_vocab_create(ctx_, m_k, m_L, (int)m_weighting, (int)m_scoring, (uint32_t)m_nodes.size(), m_nodes.data(),
-                            m_nodeDescriptors.data, &voc_) != GH_OK) {
+    if (gh_bow_vocab_create_bytes(ctx_, m_k, m_L, (int)m_weighting, (int)m_scoring, (uint32_t)m_nodes.size(), m_nodes.data(),
+                                  m_nodeDescriptors.data, width_, &voc_) != GH_OK) {
       LOG(ERROR) << "VocabularyHIP: " << gh_last_error(ctx_);
       return false;
     }
@@ -153,14 +156,14 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     const int n = features.rows;
     if (n <= 0) return;
     if (!voc_) return failed("no device vocabulary (load failed or no GPU)");
-    if (features.cols * features.elemSize() != 32) return failed("descriptors are not 32 bytes wide");
+    if ((int)(features.cols * features.elemSize()) != width_) return failed("descriptors do not have the vocabulary's width");
     constexpr int kMax = 16384;  // one workgroup sorts an image's word ids in LDS: the library's limit per call
     std::vector<uint32_t> word(n), node(n), bw(std::min(n, kMax));
     std::vector<float> weight(n), bv(std::min(n, kMax));
     int32_t nb = 0;
     for (int c0 = 0; c0 < n; c0 += kMax) {
       const int m = std::min(kMax, n - c0);
-      if (gh_bow_transform_host(voc_, features.data + (size_t)c0 * 32, m, levelsup, word.data() + c0, weight.data() + c0,
+      if (gh_bow_transform_host(voc_, features.data + (size_t)c0 * width_, m, levelsup, word.data() + c0, weight.data() + c0,
                                 node.data() + c0, bw.data(), bv.data(), &nb) != GH_OK)
         return failed(gh_last_error(ctx_));
     }
@@ -191,6 +194,7 @@ class VocabularyHIP : public GSLAM::Vocabulary {
 
   gh_ctx* ctx_;
   gh_bow_vocab* voc_;
+  int width_ = 32;  // descriptor bytes
   mutable std::mutex mu_;
   mutable std::atomic<int> failures_{0};
 };

@@ -281,6 +281,10 @@ gh_status gh_comm_status(gh_comm* comm); /* GH_OK, or GH_ERR_HIP once any rank a
 typedef struct gh_bow_vocab gh_bow_vocab;
 gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
                               const void* nodes, const uint8_t* node_desc, gh_bow_vocab** out);
+/* Binary descriptors of any multiple of 8 bytes (Vocabulary.h:560-568: 32 -> hamming32, 64 -> hamming64, others ->
+ * hamming8x); gh_bow_vocab_create is desc_bytes = 32.  The transforms take descriptors of the vocabulary's width. */
+gh_status gh_bow_vocab_create_bytes(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
+                                    const void* nodes, const uint8_t* node_desc, int desc_bytes, gh_bow_vocab** out);
 void gh_bow_vocab_destroy(gh_bow_vocab* vocab);
 /* Batched over images: desc_dev n_images x cap x 32 B, counts_dev (may be NULL = cap rows each).  Per feature:
  * word id, word weight, node id at level L - levelsup (0xFFFFFFFF / 0 / 0xFFFFFFFF for rows >= count).  Per image:

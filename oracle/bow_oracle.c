@@ -29,8 +29,29 @@ typedef struct {
   float weight;
 } bow_node;
 
+/* Vocabulary.h:493-513: hamming64 / hamming8x = popcount of the xor over the descriptor, 64 bits at a time */
+static int hamming_bytes(const uint8_t* a, const uint8_t* b, int bytes) {
+  int d = 0;
+  for (int w = 0; w < bytes / 8; ++w) {
+    uint64_t x, y;
+    memcpy(&x, a + 8 * w, 8);
+    memcpy(&y, b + 8 * w, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+void oracle_bow_word_bytes(const bow_node* nodes, const uint8_t* ndesc, int k, int L, const uint8_t* f, int levelsup,
+                           uint32_t* word, float* weight, uint32_t* node, int desc_bytes);
+
 void oracle_bow_word(const bow_node* nodes, const uint8_t* ndesc, int k, int L, const uint8_t* f, int levelsup,
                      uint32_t* word, float* weight, uint32_t* node) {
+  oracle_bow_word_bytes(nodes, ndesc, k, L, f, levelsup, word, weight, node, 32);
+}
+
+/* desc_bytes: any multiple of 8 (DistanceFactory::create, Vocabulary.h:560-568) */
+void oracle_bow_word_bytes(const bow_node* nodes, const uint8_t* ndesc, int k, int L, const uint8_t* f, int levelsup,
+                           uint32_t* word, float* weight, uint32_t* node, int desc_bytes) {
   const int nid_level = L - levelsup;
   uint32_t final_id = 0, nid = 0;
   int level = 0;
@@ -40,7 +61,7 @@ void oracle_bow_word(const bow_node* nodes, const uint8_t* ndesc, int k, int L, 
     uint32_t best = final_id;
     uint32_t id = final_id * (uint32_t)k + 1;
     for (uint32_t end = id + nodes[final_id].childNum; id < end; ++id) {
-      int d = oracle_hamming32(f, ndesc + (size_t)id * 32);
+      int d = desc_bytes == 32 ? oracle_hamming32(f, ndesc + (size_t)id * 32) : hamming_bytes(f, ndesc + (size_t)id * desc_bytes, desc_bytes);
       if (d < best_d) {
         best_d = d;
         best = id;
@@ -61,11 +82,22 @@ static int cmp_u32(const void* a, const void* b) {
 
 /* weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1, 1 L2, 2 CHI2, 3 KL, 4 BHATT, 5 DOT.
  * Outputs per feature (word, weight, node) and the BoW vector (ascending word id).  Returns the BoW length. */
+int oracle_bow_transform_bytes(const bow_node* nodes, const uint8_t* ndesc, int k, int L, int weighting, int scoring,
+                               const uint8_t* desc, int n, int levelsup, uint32_t* word, float* weight, uint32_t* node,
+                               uint32_t* bow_word, float* bow_val, int desc_bytes);
+
 int oracle_bow_transform(const bow_node* nodes, const uint8_t* ndesc, int k, int L, int weighting, int scoring,
                          const uint8_t* desc, int n, int levelsup, uint32_t* word, float* weight, uint32_t* node,
                          uint32_t* bow_word, float* bow_val) {
+  return oracle_bow_transform_bytes(nodes, ndesc, k, L, weighting, scoring, desc, n, levelsup, word, weight, node, bow_word,
+                                    bow_val, 32);
+}
+
+int oracle_bow_transform_bytes(const bow_node* nodes, const uint8_t* ndesc, int k, int L, int weighting, int scoring,
+                               const uint8_t* desc, int n, int levelsup, uint32_t* word, float* weight, uint32_t* node,
+                               uint32_t* bow_word, float* bow_val, int desc_bytes) {
   for (int i = 0; i < n; ++i)
-    oracle_bow_word(nodes, ndesc, k, L, desc + (size_t)i * 32, levelsup, &word[i], &weight[i], &node[i]);
+    oracle_bow_word_bytes(nodes, ndesc, k, L, desc + (size_t)i * desc_bytes, levelsup, &word[i], &weight[i], &node[i], desc_bytes);
   /* stable order by word id: features of one word keep their order (only counts matter: same weight) */
   uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
   int m = 0;

@@ -139,10 +139,17 @@ int ref_vocab_info(void* vp, int* k, int* L, int* nnodes) {
 }
 
 // returns number of BoW entries; fv_n receives the number of (node, feature) pairs
+int ref_vocab_transform_bytes(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* bow_ids, float* bow_vals,
+                              uint64_t* fv_nodes, uint32_t* fv_feat, int* fv_n, int desc_bytes);
 int ref_vocab_transform(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* bow_ids, float* bow_vals,
                         uint64_t* fv_nodes, uint32_t* fv_feat, int* fv_n) {
+  return ref_vocab_transform_bytes(vp, desc, n, levelsup, bow_ids, bow_vals, fv_nodes, fv_feat, fv_n, 32);
+}
+// descriptors of desc_bytes bytes (the reference picks hamming32 / hamming64 / hamming8x by the column count)
+int ref_vocab_transform_bytes(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* bow_ids, float* bow_vals,
+                              uint64_t* fv_nodes, uint32_t* fv_feat, int* fv_n, int desc_bytes) {
   GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
-  GSLAM::TinyMat features(n, 32, GSLAM::GImageType<uchar>::Type, (uchar*)desc, false);
+  GSLAM::TinyMat features(n, desc_bytes, GSLAM::GImageType<uchar>::Type, (uchar*)desc, false);
   GSLAM::BowVector bow;
   GSLAM::FeatureVector fv;
   v->transform(features, bow, fv, levelsup);
@@ -164,11 +171,17 @@ int ref_vocab_transform(void* vp, const unsigned char* desc, int n, int levelsup
 }
 
 // per-feature word / weight / node (single-feature transform, Vocabulary.h:1695-1736)
+void ref_vocab_words_bytes(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* word, float* weight,
+                           uint64_t* node, int desc_bytes);
 void ref_vocab_words(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* word, float* weight,
                      uint64_t* node) {
+  ref_vocab_words_bytes(vp, desc, n, levelsup, word, weight, node, 32);
+}
+void ref_vocab_words_bytes(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* word, float* weight,
+                           uint64_t* node, int desc_bytes) {
   GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
   for (int i = 0; i < n; ++i) {
-    GSLAM::TinyMat f(1, 32, GSLAM::GImageType<uchar>::Type, (uchar*)desc + (size_t)i * 32, false);
+    GSLAM::TinyMat f(1, desc_bytes, GSLAM::GImageType<uchar>::Type, (uchar*)desc + (size_t)i * desc_bytes, false);
     GSLAM::WordId id;
     GSLAM::WordValue w;
     GSLAM::NodeId nid;

@@ -330,7 +330,8 @@ _ba_methods(Oracle)
 # ---------------------------------------------------------------- BoW (Vocabulary transform) wrappers
 def _bow_methods(cls):
     def bow_transform(self, voc, desc, levelsup=2):
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        width = voc["desc"].shape[1]
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, width)
         n = desc.shape[0]
         word = np.zeros(n, np.uint32)
         weight = np.zeros(n, np.float32)
@@ -339,9 +340,9 @@ def _bow_methods(cls):
         bv = np.zeros(max(n, 1), np.float32)
         nodes = np.ascontiguousarray(voc["nodes"])
         nd = np.ascontiguousarray(voc["desc"])
-        nb = self.lib.oracle_bow_transform(_ptr(nodes), _ptr(nd), int(voc["k"]), int(voc["L"]), int(voc["weighting"]),
-                                           int(voc["scoring"]), _ptr(desc), n, int(levelsup), _ptr(word), _ptr(weight),
-                                           _ptr(node), _ptr(bw), _ptr(bv))
+        nb = self.lib.oracle_bow_transform_bytes(_ptr(nodes), _ptr(nd), int(voc["k"]), int(voc["L"]), int(voc["weighting"]),
+                                                 int(voc["scoring"]), _ptr(desc), n, int(levelsup), _ptr(word), _ptr(weight),
+                                                 _ptr(node), _ptr(bw), _ptr(bv), int(width))
         return word, weight, node, bw[:nb].copy(), bv[:nb].copy()
 
     def bow_score_l1(self, a, b):
@@ -381,25 +382,25 @@ class RefVocabulary:
         self.lib.ref_vocab_info(self.h, C.byref(k), C.byref(L), C.byref(n))
         return k.value, L.value, n.value
 
-    def transform(self, desc, levelsup=2):
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    def transform(self, desc, levelsup=2, desc_bytes=32):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, desc_bytes)
         n = desc.shape[0]
         bi = np.zeros(max(n, 1), np.uint64)
         bv = np.zeros(max(n, 1), np.float32)
         fn = np.zeros(max(n, 1), np.uint64)
         ff = np.zeros(max(n, 1), np.uint32)
         fvn = C.c_int()
-        nb = self.lib.ref_vocab_transform(self.h, _ptr(desc), n, int(levelsup), _ptr(bi), _ptr(bv), _ptr(fn), _ptr(ff),
-                                          C.byref(fvn))
+        nb = self.lib.ref_vocab_transform_bytes(self.h, _ptr(desc), n, int(levelsup), _ptr(bi), _ptr(bv), _ptr(fn), _ptr(ff),
+                                                C.byref(fvn), int(desc_bytes))
         return bi[:nb].copy(), bv[:nb].copy(), fn[:fvn.value].copy(), ff[:fvn.value].copy()
 
-    def words(self, desc, levelsup=2):
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    def words(self, desc, levelsup=2, desc_bytes=32):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, desc_bytes)
         n = desc.shape[0]
         w = np.zeros(n, np.uint64)
         wt = np.zeros(n, np.float32)
         nd = np.zeros(n, np.uint64)
-        self.lib.ref_vocab_words(self.h, _ptr(desc), n, int(levelsup), _ptr(w), _ptr(wt), _ptr(nd))
+        self.lib.ref_vocab_words_bytes(self.h, _ptr(desc), n, int(levelsup), _ptr(w), _ptr(wt), _ptr(nd), int(desc_bytes))
         return w, wt, nd
 
     def score(self, a, b):

@@ -127,3 +127,41 @@ def test_bow_score_large_query_not_staged(ctx, oracle):
     S = S.cpu().numpy()
     assert S[0, 0] == oracle.bow_score(0, (ids_a, va), (ids_b, vb))
     assert S[0, 1] == oracle.bow_score(0, (ids_a, va), (ids_a, va))
+
+
+@pytest.mark.parametrize("desc_bytes,k,L,weighting,scoring,levelsup,n", [(64, 10, 4, 0, 0, 2, 2000), (64, 6, 3, 1, 1, 1, 333),
+                                                                         (40, 8, 3, 0, 0, 0, 1000), (8, 4, 3, 2, 5, 1, 100),
+                                                                         (128, 5, 3, 3, 0, 2, 500)])
+def test_bow_wide_binary_descriptors(ctx, oracle, desc_bytes, k, L, weighting, scoring, levelsup, n):
+    """64-byte (hamming64) and other 8 n-byte (hamming8x) vocabularies, host entry and batched device entry: bit-identical
+    to the oracle, which is pinned to the reference for these widths (tests/test_bow_oracle.py)."""
+    import torch
+    from gslam_amd.bow import Vocabulary
+    voc = bow_synth.make_vocabulary(k=k, L=L, seed=3 + desc_bytes, weighting=weighting, scoring=scoring, desc_bytes=desc_bytes)
+    rng = np.random.default_rng(desc_bytes)
+    desc = np.concatenate([bow_synth.features_near_words(voc, n - n // 4, seed=5, flip_bits=min(10, desc_bytes)),
+                           rng.integers(0, 256, (n // 4, desc_bytes), dtype=np.uint8)])
+    v = Vocabulary(ctx, voc)
+    got = v.transform_host(desc, levelsup)
+    exp = oracle.bow_transform(voc, desc, levelsup)
+    assert np.array_equal(got[0], exp[0]) and got[1].tobytes() == exp[1].tobytes() and np.array_equal(got[2], exp[2])
+    assert np.array_equal(got[3], exp[3]) and got[4].tobytes() == exp[4].tobytes()
+    out = v.transform(torch.from_numpy(np.stack([desc, desc[::-1].copy()])).cuda(), None, levelsup=levelsup)
+    torch.cuda.synchronize()
+    e2 = oracle.bow_transform(voc, desc[::-1].copy(), levelsup)
+    assert np.array_equal(out[0][1].cpu().numpy().view(np.uint32), e2[0]) and int(out[5][1]) == len(e2[3])
+    assert out[4][1, :len(e2[3])].cpu().numpy().tobytes() == e2[4].tobytes()
+    v.close()
+
+
+def test_bow_wide_golden_reference_vectors(ctx):
+    """Directly against the reference's outputs for 64- and 40-byte descriptors (tests/golden/bow_reference_wide.npz)."""
+    from gslam_amd.bow import Vocabulary
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_reference_wide.npz"))
+    for w in (64, 40):
+        voc = bow_synth.make_vocabulary(k=int(g[f"k{w}"]), L=int(g[f"L{w}"]), seed=int(g[f"seed{w}"]), desc_bytes=w)
+        v = Vocabulary(ctx, voc)
+        word, weight, node, bw, bv = v.transform_host(g[f"desc{w}"], int(g[f"levelsup{w}"]))
+        assert np.array_equal(word, g[f"word{w}"]) and weight.tobytes() == g[f"weight{w}"].tobytes()
+        assert np.array_equal(node, g[f"node{w}"]) and np.array_equal(bw, g[f"bow_ids{w}"]) and bv.tobytes() == g[f"bow_vals{w}"].tobytes()
+        v.close()

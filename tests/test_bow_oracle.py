@@ -72,3 +72,36 @@ def test_stopped_words_and_empty_input(oracle):
     assert abs(np.abs(bv).sum() - 1.0) < 1e-5
     w0 = oracle.bow_transform(voc, np.zeros((0, 32), np.uint8))
     assert len(w0[3]) == 0
+
+
+@pytest.mark.skipif(not oracle_lib.have_reference(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("desc_bytes,k,L,weighting,scoring,levelsup", [(64, 10, 3, 0, 0, 1), (64, 6, 4, 1, 1, 2), (40, 8, 3, 0, 0, 0),
+                                                                       (8, 4, 3, 2, 5, 1), (128, 5, 3, 3, 0, 2)])
+def test_wide_binary_descriptors_equal_the_reference_live(oracle, desc_bytes, k, L, weighting, scoring, levelsup):
+    """64-byte descriptors take the reference's hamming64, other multiples of 8 its hamming8x (Vocabulary.h:493-513,560-568)."""
+    ref = oracle_lib.load_reference()
+    voc = bow_synth.make_vocabulary(k=k, L=L, seed=3 + desc_bytes, weighting=weighting, scoring=scoring, desc_bytes=desc_bytes)
+    rv = oracle_lib.RefVocabulary(ref, bow_synth.to_gbow_bytes(voc))
+    assert rv.info() == (k, L, len(voc["nodes"]))
+    rng = np.random.default_rng(desc_bytes)
+    desc = np.concatenate([bow_synth.features_near_words(voc, 500, seed=5, flip_bits=min(10, desc_bytes)),
+                           rng.integers(0, 256, (200, desc_bytes), dtype=np.uint8)])
+    word, weight, node, bw, bv = oracle.bow_transform(voc, desc, levelsup=levelsup)
+    rw, rwt, rn = rv.words(desc, levelsup, desc_bytes=desc_bytes)
+    assert np.array_equal(word, rw) and np.array_equal(weight, rwt) and np.array_equal(node, rn)
+    bi, bvr, fn, ff = rv.transform(desc, levelsup, desc_bytes=desc_bytes)
+    assert np.array_equal(bw, bi) and bv.tobytes() == bvr.tobytes()
+    en, ef = _fv_pairs(node, weight)
+    assert np.array_equal(en, fn) and np.array_equal(ef, ff)
+    assert len(np.unique(word)) > 20
+    rv.close()
+
+
+def test_wide_descriptor_golden_vectors(oracle):
+    """The same pinned on fixtures that travel to the GPU box (tools/gen_golden.py, from oracle/_ref)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_reference_wide.npz"))
+    for w in (64, 40):
+        voc = bow_synth.make_vocabulary(k=int(g[f"k{w}"]), L=int(g[f"L{w}"]), seed=int(g[f"seed{w}"]), desc_bytes=w)
+        word, weight, node, bw, bv = oracle.bow_transform(voc, g[f"desc{w}"], levelsup=int(g[f"levelsup{w}"]))
+        assert np.array_equal(word, g[f"word{w}"]) and np.array_equal(node, g[f"node{w}"])
+        assert np.array_equal(bw, g[f"bow_ids{w}"]) and bv.tobytes() == g[f"bow_vals{w}"].tobytes()

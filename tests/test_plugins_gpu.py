@@ -174,12 +174,13 @@ def test_featuredetector_plugin_matches_oracle(tmp_path, oracle, channels):
     assert okm == 1 and np.array_equal(matches, exp_matches)
 
 
-def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle):
+@pytest.mark.parametrize("desc_bytes", [32, 64, 40])
+def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle, desc_bytes):
     """libgslam_vocabulary.so (VocabularyHIP) vs GSLAM::Vocabulary itself, both inside the GSLAM host process:
     BowVector and FeatureVector maps must compare equal (operator== on the std::maps, i.e. bit-exact floats)."""
     _need_host()
     from gslam_amd import bow_synth
-    voc = bow_synth.make_vocabulary(k=10, L=4, seed=5)
+    voc = bow_synth.make_vocabulary(k=10, L=4, seed=5, desc_bytes=desc_bytes)  # hamming32 / hamming64 / hamming8x
     gb, df, out = tmp_path / "voc.gbow", tmp_path / "desc.raw", tmp_path / "out.bin"
     open(gb, "wb").write(bow_synth.to_gbow_bytes(voc))
     desc = bow_synth.features_near_words(voc, 1500, seed=8)

@@ -9,6 +9,7 @@ Run in the authoring container only (needs /root/reference); the outputs are com
   bow_reference.npz  a synthetic .gbow image (k = 10, L = 3) loaded by the reference's own Vocabulary::load; word / node
                      ids, weights, BowVector, FeatureVector of Vocabulary::transform on 500 descriptors, a second
                      BowVector and the reference's score() between the two; plus all six scoring types on that pair.
+  bow_reference_wide.npz  the same for a 64-byte (hamming64) and a 40-byte (hamming8x) vocabulary (`gen_golden.py wide`).
   undist_reference.npz  remap tables of the reference's UndistorterImpl::prepareReMap (OpenCV model, 128x96 -> 112x84)
                      and its undistort / undistortFast outputs on seeded 1- and 3-channel images.
 """
@@ -23,8 +24,29 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib  # noqa: E402
 
 
+def wide_bow(ref, out):
+    """bow_reference_wide.npz: 64-byte (hamming64) and 40-byte (hamming8x) vocabularies through the reference."""
+    from gslam_amd import bow_synth
+    rec = {}
+    for w, k, L, seed, levelsup in ((64, 9, 3, 41, 1), (40, 7, 3, 42, 2)):
+        voc = bow_synth.make_vocabulary(k=k, L=L, seed=seed, desc_bytes=w)
+        rv = oracle_lib.RefVocabulary(ref, bow_synth.to_gbow_bytes(voc))
+        rng = np.random.default_rng(seed)
+        desc = np.concatenate([bow_synth.features_near_words(voc, 300, seed=seed + 1), rng.integers(0, 256, (100, w), dtype=np.uint8)])
+        word, weight, node = rv.words(desc, levelsup, desc_bytes=w)
+        bi, bv, fn, ff = rv.transform(desc, levelsup, desc_bytes=w)
+        rv.close()
+        rec.update({f"k{w}": k, f"L{w}": L, f"seed{w}": seed, f"levelsup{w}": levelsup, f"desc{w}": desc,
+                    f"word{w}": word.astype(np.uint32), f"weight{w}": weight, f"node{w}": node.astype(np.uint32),
+                    f"bow_ids{w}": bi.astype(np.uint32), f"bow_vals{w}": bv})
+    np.savez_compressed(os.path.join(out, "bow_reference_wide.npz"), **rec)
+    print("bow_reference_wide.npz written")
+
+
 def main():
     ref = oracle_lib.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        return wide_bow(ref, os.path.join(ROOT, "tests", "golden"))
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
 
@@ -103,6 +125,7 @@ def main():
             rec[f"out{ch}_{fast}"] = ru.run(img, fast=bool(fast))
     ru.close()
     np.savez_compressed(os.path.join(out, "undist_reference.npz"), **rec)
+    wide_bow(ref, out)
     print("golden vectors written to", out)
 
 
