@@ -20,12 +20,18 @@ class Vocabulary:
         self.ctx = ctx
         self.k, self.L = int(voc["k"]), int(voc["L"])
         nodes = np.ascontiguousarray(voc["nodes"])
-        desc = np.ascontiguousarray(voc["desc"], dtype=np.uint8)
-        self.desc_bytes = int(desc.shape[1])
+        self.is_float = voc["desc"].dtype == np.float32  # float (L2) vocabulary: desc nnodes x dims float32, dims % 8 == 0
+        desc = np.ascontiguousarray(voc["desc"], dtype=np.float32 if self.is_float else np.uint8)
+        self.desc_bytes = int(desc.shape[1]) * (4 if self.is_float else 1)
         h = C.c_void_p()
-        ctx.check(hip.lib.gh_bow_vocab_create_bytes(ctx.h, self.k, self.L, int(voc["weighting"]), int(voc["scoring"]),
-                                                    len(nodes), nodes.ctypes.data_as(C.c_void_p),
-                                                    desc.ctypes.data_as(C.c_void_p), self.desc_bytes, C.byref(h)))
+        if self.is_float:
+            ctx.check(hip.lib.gh_bow_vocab_create_f32(ctx.h, self.k, self.L, int(voc["weighting"]), int(voc["scoring"]), len(nodes),
+                                                      nodes.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p),
+                                                      int(desc.shape[1]), C.byref(h)))
+        else:
+            ctx.check(hip.lib.gh_bow_vocab_create_bytes(ctx.h, self.k, self.L, int(voc["weighting"]), int(voc["scoring"]),
+                                                        len(nodes), nodes.ctypes.data_as(C.c_void_p),
+                                                        desc.ctypes.data_as(C.c_void_p), self.desc_bytes, C.byref(h)))
         self.h = h
 
     def close(self):
@@ -52,7 +58,10 @@ class Vocabulary:
         return out
 
     def transform_host(self, desc: np.ndarray, levelsup=2):
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, self.desc_bytes)
+        if self.is_float:
+            desc = np.ascontiguousarray(desc, dtype=np.float32).reshape(-1, self.desc_bytes // 4)
+        else:
+            desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, self.desc_bytes)
         n = desc.shape[0]
         m = max(n, 1)
         word, node, bw = np.zeros(m, np.uint32), np.zeros(m, np.uint32), np.zeros(m, np.uint32)

@@ -50,8 +50,42 @@ def make_vocabulary(k=10, L=4, seed=1, weighting=TF_IDF, scoring=L1_NORM, ragged
 
 def to_gbow_bytes(v):
     hdr = struct.pack("<QBI", MAGIC, 0, len(v["nodes"]))
-    hdr += struct.pack("<7i", v["k"], v["L"], v["scoring"], v["weighting"], v["desc"].shape[1], 1, 0)
+    is_float = v["desc"].dtype == np.float32  # GElementType_32F = 5, GElementType_8U = 0 (GSLAM/core/GImage.h:60-69)
+    hdr += struct.pack("<7i", v["k"], v["L"], v["scoring"], v["weighting"], v["desc"].shape[1], 1, 5 if is_float else 0)
     return hdr + v["nodes"].tobytes() + v["desc"].tobytes()
+
+
+def make_float_vocabulary(k=8, L=3, dims=64, seed=1, weighting=TF_IDF, scoring=L1_NORM, stop_frac=0.02):
+    """A float (L2) vocabulary in the style of SIFT / SURF trees: every node's descriptor is its parent's plus noise that
+    shrinks with the level.  desc: nnodes x dims float32 (dims a multiple of 8)."""
+    rng = np.random.default_rng(seed)
+    nnodes = (k ** (L + 1) - 1) // (k - 1)
+    desc = np.zeros((nnodes, dims), np.float32)
+    child_num = np.zeros(nnodes, np.uint32)
+    weight = np.zeros(nnodes, np.float32)
+    desc[0] = rng.normal(size=dims).astype(np.float32)
+    level_start = 0
+    for lvl in range(L):
+        n_lvl = k ** lvl
+        parents = np.arange(level_start, level_start + n_lvl)
+        child_num[parents] = k
+        kids = parents[:, None] * k + 1 + np.arange(k)[None, :]
+        base = np.repeat(desc[parents], k, axis=0)
+        desc[kids.reshape(-1)] = base + (rng.normal(size=base.shape) * (1.0 / (1 << lvl))).astype(np.float32)
+        level_start += n_lvl
+    leaves = child_num == 0
+    weight[leaves] = rng.uniform(0.5, 9.0, int(leaves.sum())).astype(np.float32)
+    weight[leaves & (rng.random(nnodes) < stop_frac)] = 0.0
+    nodes = np.zeros(nnodes, dtype=[("childNum", "<u4"), ("weight", "<f4")])
+    nodes["childNum"] = child_num
+    nodes["weight"] = weight
+    return {"k": k, "L": L, "weighting": weighting, "scoring": scoring, "nodes": nodes, "desc": desc}
+
+
+def float_features_near_words(v, n, seed=2, sigma=0.05):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(len(v["nodes"]) // 2, len(v["nodes"]), n)
+    return (v["desc"][ids] + rng.normal(size=(n, v["desc"].shape[1])) * sigma).astype(np.float32)
 
 
 def features_near_words(v, n, seed=2, flip_bits=10):

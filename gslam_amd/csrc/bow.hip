@@ -85,6 +85,59 @@ __global__ __launch_bounds__(256) void bow_words_kernel(const Node* __restrict__
   node[o] = nid_level <= 0 ? 0u : nid;
 }
 
+// Float descriptors (SIFT / SURF style vocabularies): the reference's l2generic (Vocabulary.h:550-560) -- squared L2,
+// float accumulation in index order, one multiply and one add per component (this file is compiled with
+// -ffp-contract=off: no fused multiply-add) -- which is what DistanceFactory::create selects for every dimension that is a
+// multiple of 8 whatever ISA the host was built for (:569-578).  Start value FLT_MAX, first strict minimum (:1712-1725).
+__global__ __launch_bounds__(256) void bow_words_f32_kernel(const Node* __restrict__ nodes, const float* __restrict__ ndesc, int k,
+                                                            int L, int dims, const float* __restrict__ desc,
+                                                            const int32_t* __restrict__ counts, int cap, int levelsup,
+                                                            uint32_t* __restrict__ word, float* __restrict__ weight,
+                                                            uint32_t* __restrict__ node) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = counts ? min(counts[img], cap) : cap;
+  if (i >= cap) return;
+  const size_t o = (size_t)img * cap + i;
+  if (i >= n) {
+    word[o] = 0xFFFFFFFFu;
+    weight[o] = 0.f;
+    node[o] = 0xFFFFFFFFu;
+    return;
+  }
+  const float* q = desc + o * (size_t)dims;
+  const int nid_level = L - levelsup;
+  uint32_t final_id = 0, nid = 0;
+  int level = 0;
+  uint32_t cn = nodes[0].childNum;
+  do {
+    ++level;
+    float best_d = 3.402823466e+38f;
+    uint32_t best = final_id;
+    const uint32_t first = final_id * (uint32_t)k + 1;
+    for (uint32_t c = 0; c < cn; ++c) {
+      const uint32_t id = first + c;
+      const float* t = ndesc + (size_t)id * dims;
+      float sqd = 0.f;
+      for (int e = 0; e < dims; ++e) {
+        const float tmp = q[e] - t[e];
+        sqd += tmp * tmp;
+      }
+      if (sqd < best_d) {
+        best_d = sqd;
+        best = id;
+      }
+    }
+    if (best == final_id) break;  // no child compared below FLT_MAX (NaN / inf input): the reference would not terminate
+    final_id = best;
+    if (level == nid_level) nid = final_id;
+    cn = nodes[final_id].childNum;
+  } while (cn != 0);
+  word[o] = final_id;
+  weight[o] = nodes[final_id].weight;
+  node[o] = nid_level <= 0 ? 0u : nid;
+}
+
 // one workgroup per image; dynamic LDS: uint32 keys[P] + float vals[P]
 __global__ __launch_bounds__(256) void bow_assemble_kernel(const Node* __restrict__ nodes, int weighting, int scoring,
                                                            const uint32_t* __restrict__ word,
@@ -193,12 +246,25 @@ struct gh_bow_vocab {
   uint32_t nnodes;
   Node* d_nodes;
   uint8_t* d_desc;
-  int desc_bytes;  // a multiple of 8 (32 for ORB / BRIEF, 64 for the long binary descriptors)
+  int desc_bytes;  // a multiple of 8 (32 for ORB / BRIEF, 64 for the long binary descriptors); 4 * dims for float
+  int is_float;    // descriptors are `desc_bytes / 4` floats compared with the squared L2 distance
 };
 
 extern "C" gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
                                          const void* nodes, const uint8_t* node_desc, gh_bow_vocab** out) {
   return gh_bow_vocab_create_bytes(ctx, k, L, weighting, scoring, nnodes, nodes, node_desc, 32, out);
+}
+
+extern "C" gh_status gh_bow_vocab_create_f32(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
+                                             const void* nodes, const float* node_desc, int dims, gh_bow_vocab** out) {
+  if (!ctx || !out) return GH_ERR_ARG;
+  {
+    GH_ENTER(ctx);
+    GH_CHECK_ARG(ctx, dims >= 8 && dims <= 4096 && dims % 8 == 0);
+  }
+  const gh_status st = gh_bow_vocab_create_bytes(ctx, k, L, weighting, scoring, nnodes, nodes, (const uint8_t*)node_desc, 4 * dims, out);
+  if (st == GH_OK) (*out)->is_float = 1;
+  return st;
 }
 
 extern "C" gh_status gh_bow_vocab_create_bytes(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
@@ -207,14 +273,14 @@ extern "C" gh_status gh_bow_vocab_create_bytes(gh_ctx* ctx, int k, int L, int we
   GH_ENTER(ctx);
   *out = nullptr;
   GH_CHECK_ARG(ctx, k >= 2 && L >= 1 && nnodes >= 1 && nodes && node_desc);
-  GH_CHECK_ARG(ctx, desc_bytes >= 8 && desc_bytes <= 1024 && desc_bytes % 8 == 0);
+  GH_CHECK_ARG(ctx, desc_bytes >= 8 && desc_bytes <= 16384 && desc_bytes % 8 == 0);
   GH_CHECK_ARG(ctx, weighting >= 0 && weighting <= 3 && scoring >= 0 && scoring <= 5);
   const Node* hn = (const Node*)nodes;
   for (uint32_t i = 0; i < nnodes; ++i)  // every child index must exist (the descent never checks bounds)
     GH_CHECK_ARG(ctx, hn[i].childNum <= (uint32_t)k && (hn[i].childNum == 0 || (uint64_t)i * k + hn[i].childNum < nnodes));
   gh_bow_vocab* v = new (std::nothrow) gh_bow_vocab();
   if (!v) return GH_ERR_NOMEM;
-  *v = gh_bow_vocab{ctx, k, L, weighting, scoring, nnodes, nullptr, nullptr, desc_bytes};
+  *v = gh_bow_vocab{ctx, k, L, weighting, scoring, nnodes, nullptr, nullptr, desc_bytes, 0};
   gh_status st = gh_dev_alloc(ctx, (size_t)nnodes * sizeof(Node), (void**)&v->d_nodes);
   if (st == GH_OK) st = gh_dev_alloc(ctx, (size_t)nnodes * desc_bytes, (void**)&v->d_desc);
   if (st == GH_OK) st = gh_dev_upload(ctx, v->d_nodes, nodes, (size_t)nnodes * sizeof(Node));
@@ -251,7 +317,10 @@ extern "C" gh_status gh_bow_transform_dev(gh_bow_vocab* v, const uint8_t* desc_d
   GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 7) == 0);
   const int w8 = v->desc_bytes / 8;
   const dim3 wgrid(gh_div_up(cap, 256), n_images);
-  if (w8 == 4)
+  if (v->is_float)
+    GH_LAUNCH(ctx, "bow_words", bow_words_f32_kernel, wgrid, dim3(256), 0, v->d_nodes, (const float*)v->d_desc, v->k, v->L,
+              v->desc_bytes / 4, (const float*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev, node_dev);
+  else if (w8 == 4)
     GH_LAUNCH(ctx, "bow_words", bow_words_kernel<4>, wgrid, dim3(256), 0, v->d_nodes, (const uint2*)v->d_desc, v->k, v->L, w8,
               (const uint2*)desc_dev, counts_dev, cap, levelsup, word_dev, weight_dev, node_dev);
   else if (w8 == 8)

@@ -148,6 +148,7 @@ SIGNATURES = {
     "gh_comm_status": (C.c_int, [_vp]),
     "gh_bow_vocab_create": (C.c_int, [_vp, _i, _i, _i, _i, C.c_uint32, _vp, _vp, C.POINTER(_vp)]),
     "gh_bow_vocab_create_bytes": (C.c_int, [_vp, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _i, C.POINTER(_vp)]),
+    "gh_bow_vocab_create_f32": (C.c_int, [_vp, _i, _i, _i, _i, C.c_uint32, _vp, _vp, _i, C.POINTER(_vp)]),
     "gh_bow_vocab_destroy": (None, [_vp]),
     "gh_bow_transform_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gh_bow_transform_host": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),

@@ -514,10 +514,11 @@ static int run_bow(const std::string& dir, const char* gbow, const char* descf, 
   Vocabulary cpu;
   if (!gpu || !cpu.load(std::string(gbow))) { std::cerr << "vocabulary load failed\n"; return 2; }
   const int W = (int)(cpu.m_nodeDescriptors.cols * cpu.m_nodeDescriptors.elemSize());  // descriptor bytes of this vocabulary
+  const bool is_f32 = cpu.m_nodeDescriptors.type() == GImageType<float>::Type;
   std::vector<uchar> d((size_t)n * W);
   std::ifstream fi(descf, std::ios::binary);
   fi.read((char*)d.data(), d.size());
-  TinyMat features(n, W, GImageType<uchar>::Type, d.data(), false);
+  TinyMat features(n, is_f32 ? W / 4 : W, is_f32 ? (int)GImageType<float>::Type : (int)GImageType<uchar>::Type, d.data(), false);
   BowVector bg, bc;
   FeatureVector fg, fc;
   gpu->transform(features, bg, fg, levelsup);
@@ -530,7 +531,7 @@ static int run_bow(const std::string& dir, const char* gbow, const char* descf, 
   // base class on the same features (Vocabulary.h:183,200)
   {
     std::vector<TinyMat> list;
-    for (int i = 0; i < n; ++i) list.push_back(TinyMat(1, W, GImageType<uchar>::Type, d.data() + (size_t)i * W, false));
+    for (int i = 0; i < n; ++i) list.push_back(TinyMat(1, is_f32 ? W / 4 : W, is_f32 ? (int)GImageType<float>::Type : (int)GImageType<uchar>::Type, d.data() + (size_t)i * W, false));
     BowVector bgl, bcl;
     FeatureVector fgl, fcl;
     gpu->transform(list, bgl, fgl, levelsup);
@@ -554,7 +555,7 @@ static int run_bow(const std::string& dir, const char* gbow, const char* descf, 
     std::vector<BowVector> db;
     for (int w0 = 0; w0 + 50 <= n && db.size() < 40; w0 += n / 40 + 1) {
       const int wn = std::min(n - w0, 50 + (int)db.size() * 17);
-      TinyMat sub(wn, W, GImageType<uchar>::Type, d.data() + (size_t)w0 * W, false);
+      TinyMat sub(wn, is_f32 ? W / 4 : W, is_f32 ? (int)GImageType<float>::Type : (int)GImageType<uchar>::Type, d.data() + (size_t)w0 * W, false);
       BowVector v;
       cpu.transform(sub, v);
       db.push_back(v);

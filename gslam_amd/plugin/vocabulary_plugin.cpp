@@ -6,7 +6,8 @@
 //     transform(const TinyMat& features, BowVector&, FeatureVector&, int levelsup)   (:1558-1621)
 //     transform(const TinyMat& features, BowVector&)                                (:1437-1497)
 // to gh_bow_transform_host.  Binary vocabularies of any width the reference's DistanceFactory accepts (:560-568: 32 bytes ->
-// hamming32, 64 -> hamming64, other multiples of 8 -> hamming8x) are taken; float (L2) vocabularies are refused at load.
+// hamming32, 64 -> hamming64, other multiples of 8 -> hamming8x) are taken, and float vocabularies whose dimension is a
+// multiple of 8 (:569-578: l2generic whatever ISA the host was built for); other float dimensions are refused at load.
 // Factory (same idiom as createOptimizerInstance):
 //     extern "C" std::shared_ptr<GSLAM::Vocabulary> createVocabularyInstance(const char* gbow_file)
 // as well as the std::vector<TinyMat> overload (:183, one feature per element) and the single-feature
@@ -71,7 +72,8 @@ class VocabularyHIP : public GSLAM::Vocabulary {
       }
       std::memcpy(&packed[i * width_], features[i].data, width_);
     }
-    GSLAM::TinyMat all((int)features.size(), width_, GSLAM::GImageType<uchar>::Type, packed.data(), false);
+    GSLAM::TinyMat all((int)features.size(), float_ ? width_ / 4 : width_,
+                       float_ ? (int)GSLAM::GImageType<float>::Type : (int)GSLAM::GImageType<uchar>::Type, packed.data(), false);
     run(all, levelsup, &v, &fv);
   }
 
@@ -126,8 +128,10 @@ class VocabularyHIP : public GSLAM::Vocabulary {
   bool upload() {
     std::lock_guard<std::mutex> lock(mu_);
     width_ = (int)(m_nodeDescriptors.cols * m_nodeDescriptors.elemSize());
-    if (m_nodes.empty() || m_nodeDescriptors.type() != GSLAM::GImageType<uchar>::Type || width_ < 8 || width_ % 8 != 0) {
-      LOG(ERROR) << "VocabularyHIP: only binary descriptors of a multiple of 8 bytes are supported (float vocabularies are not)";
+    float_ = m_nodeDescriptors.type() == GSLAM::GImageType<float>::Type;
+    const bool binary = m_nodeDescriptors.type() == GSLAM::GImageType<uchar>::Type;
+    if (m_nodes.empty() || (!binary && !float_) || width_ < 8 || (binary && width_ % 8 != 0) || (float_ && m_nodeDescriptors.cols % 8 != 0)) {
+      LOG(ERROR) << "VocabularyHIP: binary descriptors of a multiple of 8 bytes or float descriptors of a multiple of 8 dimensions only";
       return false;
     }
     if (!ctx_ && gh_ctx_create(svar.GetInt("VocabularyHIP.Device", 0), &ctx_) != GH_OK) {
@@ -138,8 +142,12 @@ class VocabularyHIP : public GSLAM::Vocabulary {
     if (voc_) gh_bow_vocab_destroy(voc_);
     voc_ = nullptr;
     static_assert(sizeof(Node) == 8, "Vocabulary::Node layout");
-    if (gh_bow_vocab_create_bytes(ctx_, m_k, m_L, (int)m_weighting, (int)m_scoring, (uint32_t)m_nodes.size(), m_nodes.data(),
-                                  m_nodeDescriptors.data, width_, &voc_) != GH_OK) {
+    const gh_status st =
+        float_ ? gh_bow_vocab_create_f32(ctx_, m_k, m_L, (int)m_weighting, (int)m_scoring, (uint32_t)m_nodes.size(), m_nodes.data(),
+                                         (const float*)m_nodeDescriptors.data, m_nodeDescriptors.cols, &voc_)
+               : gh_bow_vocab_create_bytes(ctx_, m_k, m_L, (int)m_weighting, (int)m_scoring, (uint32_t)m_nodes.size(), m_nodes.data(),
+                                           m_nodeDescriptors.data, width_, &voc_);
+    if (st != GH_OK) {
       LOG(ERROR) << "VocabularyHIP: " << gh_last_error(ctx_);
       return false;
     }
@@ -195,6 +203,7 @@ class VocabularyHIP : public GSLAM::Vocabulary {
   gh_ctx* ctx_;
   gh_bow_vocab* voc_;
   int width_ = 32;  // descriptor bytes
+  bool float_ = false;
   mutable std::mutex mu_;
   mutable std::atomic<int> failures_{0};
 };

@@ -285,6 +285,11 @@ gh_status gh_bow_vocab_create(gh_ctx* ctx, int k, int L, int weighting, int scor
  * hamming8x); gh_bow_vocab_create is desc_bytes = 32.  The transforms take descriptors of the vocabulary's width. */
 gh_status gh_bow_vocab_create_bytes(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes,
                                     const void* nodes, const uint8_t* node_desc, int desc_bytes, gh_bow_vocab** out);
+/* Float vocabularies (SIFT / SURF style): node_desc n_nodes x dims floats, dims a multiple of 8 -- the dimensions for which
+ * the reference's DistanceFactory picks l2generic whatever ISA it was built for (Vocabulary.h:550-560,569-578): squared L2,
+ * float accumulation in index order, no fused multiply-add.  The transforms then take descriptors of dims floats. */
+gh_status gh_bow_vocab_create_f32(gh_ctx* ctx, int k, int L, int weighting, int scoring, uint32_t nnodes, const void* nodes,
+                                  const float* node_desc, int dims, gh_bow_vocab** out);
 void gh_bow_vocab_destroy(gh_bow_vocab* vocab);
 /* Batched over images: desc_dev n_images x cap x 32 B, counts_dev (may be NULL = cap rows each).  Per feature:
  * word id, word weight, node id at level L - levelsup (0xFFFFFFFF / 0 / 0xFFFFFFFF for rows >= count).  Per image:

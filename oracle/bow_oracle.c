@@ -49,6 +49,43 @@ void oracle_bow_word(const bow_node* nodes, const uint8_t* ndesc, int k, int L, 
   oracle_bow_word_bytes(nodes, ndesc, k, L, f, levelsup, word, weight, node, 32);
 }
 
+/* Vocabulary.h:550-560 l2generic: squared L2, float accumulation in index order (no FMA: built with -ffp-contract=off) */
+static float l2_f32(const float* a, const float* b, int dims) {
+  float sqd = 0.f;
+  for (int i = 0; i < dims; ++i) {
+    const float tmp = a[i] - b[i];
+    sqd += tmp * tmp;
+  }
+  return sqd;
+}
+
+/* float vocabulary: same descent with l2generic, FLT_MAX start, first strict minimum (Vocabulary.h:1712-1725) */
+void oracle_bow_word_f32(const bow_node* nodes, const float* ndesc, int k, int L, const float* f, int levelsup, uint32_t* word,
+                         float* weight, uint32_t* node, int dims) {
+  const int nid_level = L - levelsup;
+  uint32_t final_id = 0, nid = 0;
+  int level = 0;
+  do {
+    ++level;
+    float best_d = 3.402823466e+38f;
+    uint32_t best = final_id;
+    uint32_t id = final_id * (uint32_t)k + 1;
+    for (uint32_t end = id + nodes[final_id].childNum; id < end; ++id) {
+      const float d = l2_f32(f, ndesc + (size_t)id * dims, dims);
+      if (d < best_d) {
+        best_d = d;
+        best = id;
+      }
+    }
+    if (best == final_id) break;
+    final_id = best;
+    if (level == nid_level) nid = final_id;
+  } while (nodes[final_id].childNum != 0);
+  *word = final_id;
+  *weight = nodes[final_id].weight;
+  *node = nid_level <= 0 ? 0 : nid;
+}
+
 /* desc_bytes: any multiple of 8 (DistanceFactory::create, Vocabulary.h:560-568) */
 void oracle_bow_word_bytes(const bow_node* nodes, const uint8_t* ndesc, int k, int L, const uint8_t* f, int levelsup,
                            uint32_t* word, float* weight, uint32_t* node, int desc_bytes) {
@@ -96,8 +133,14 @@ int oracle_bow_transform(const bow_node* nodes, const uint8_t* ndesc, int k, int
 int oracle_bow_transform_bytes(const bow_node* nodes, const uint8_t* ndesc, int k, int L, int weighting, int scoring,
                                const uint8_t* desc, int n, int levelsup, uint32_t* word, float* weight, uint32_t* node,
                                uint32_t* bow_word, float* bow_val, int desc_bytes) {
-  for (int i = 0; i < n; ++i)
-    oracle_bow_word_bytes(nodes, ndesc, k, L, desc + (size_t)i * desc_bytes, levelsup, &word[i], &weight[i], &node[i], desc_bytes);
+  /* desc_bytes < 0: float descriptors of -desc_bytes / 4 dimensions */
+  for (int i = 0; i < n; ++i) {
+    if (desc_bytes < 0)
+      oracle_bow_word_f32(nodes, (const float*)ndesc, k, L, (const float*)(desc + (size_t)i * (size_t)(-desc_bytes)), levelsup,
+                          &word[i], &weight[i], &node[i], -desc_bytes / 4);
+    else
+      oracle_bow_word_bytes(nodes, ndesc, k, L, desc + (size_t)i * desc_bytes, levelsup, &word[i], &weight[i], &node[i], desc_bytes);
+  }
   /* stable order by word id: features of one word keep their order (only counts matter: same weight) */
   uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
   int m = 0;

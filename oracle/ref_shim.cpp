@@ -145,6 +145,32 @@ int ref_vocab_transform(void* vp, const unsigned char* desc, int n, int levelsup
                         uint64_t* fv_nodes, uint32_t* fv_feat, int* fv_n) {
   return ref_vocab_transform_bytes(vp, desc, n, levelsup, bow_ids, bow_vals, fv_nodes, fv_feat, fv_n, 32);
 }
+// float descriptors of `dims` dimensions through the reference (l2generic for dims % 8 == 0)
+int ref_vocab_transform_f32(void* vp, const float* desc, int n, int dims, int levelsup, uint64_t* bow_ids, float* bow_vals,
+                            uint64_t* word, float* weight, uint64_t* node) {
+  GSLAM::Vocabulary* v = (GSLAM::Vocabulary*)vp;
+  GSLAM::TinyMat features(n, dims, GSLAM::GImageType<float>::Type, (uchar*)desc, false);
+  GSLAM::BowVector bow;
+  GSLAM::FeatureVector fv;
+  v->transform(features, bow, fv, levelsup);
+  int i = 0;
+  for (auto& kv : bow) {
+    bow_ids[i] = kv.first;
+    bow_vals[i] = kv.second;
+    ++i;
+  }
+  for (int f = 0; f < n; ++f) {
+    GSLAM::TinyMat one(1, dims, GSLAM::GImageType<float>::Type, (uchar*)(desc + (size_t)f * dims), false);
+    GSLAM::WordId id;
+    GSLAM::WordValue w;
+    GSLAM::NodeId nid;
+    v->transform(one, id, w, &nid, levelsup);
+    word[f] = id;
+    weight[f] = w;
+    node[f] = nid;
+  }
+  return i;
+}
 // descriptors of desc_bytes bytes (the reference picks hamming32 / hamming64 / hamming8x by the column count)
 int ref_vocab_transform_bytes(void* vp, const unsigned char* desc, int n, int levelsup, uint64_t* bow_ids, float* bow_vals,
                               uint64_t* fv_nodes, uint32_t* fv_feat, int* fv_n, int desc_bytes) {

@@ -331,7 +331,11 @@ _ba_methods(Oracle)
 def _bow_methods(cls):
     def bow_transform(self, voc, desc, levelsup=2):
         width = voc["desc"].shape[1]
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, width)
+        if voc["desc"].dtype == np.float32:  # float (L2) vocabulary: the oracle takes a negative byte width
+            desc = np.ascontiguousarray(desc, dtype=np.float32).reshape(-1, width)
+            width = -4 * width
+        else:
+            desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, width)
         n = desc.shape[0]
         word = np.zeros(n, np.uint32)
         weight = np.zeros(n, np.float32)
@@ -393,6 +397,15 @@ class RefVocabulary:
         nb = self.lib.ref_vocab_transform_bytes(self.h, _ptr(desc), n, int(levelsup), _ptr(bi), _ptr(bv), _ptr(fn), _ptr(ff),
                                                 C.byref(fvn), int(desc_bytes))
         return bi[:nb].copy(), bv[:nb].copy(), fn[:fvn.value].copy(), ff[:fvn.value].copy()
+
+    def transform_f32(self, desc, levelsup=2):
+        """Float descriptors n x dims through the reference -> (bow ids, bow vals, word, weight, node)."""
+        desc = np.ascontiguousarray(desc, dtype=np.float32)
+        n, dims = desc.shape
+        bi, bv = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.float32)
+        w, wt, nd = np.zeros(n, np.uint64), np.zeros(n, np.float32), np.zeros(n, np.uint64)
+        nb = self.lib.ref_vocab_transform_f32(self.h, _ptr(desc), n, dims, int(levelsup), _ptr(bi), _ptr(bv), _ptr(w), _ptr(wt), _ptr(nd))
+        return bi[:nb].copy(), bv[:nb].copy(), w, wt, nd
 
     def words(self, desc, levelsup=2, desc_bytes=32):
         desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, desc_bytes)

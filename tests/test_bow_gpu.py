@@ -165,3 +165,27 @@ def test_bow_wide_golden_reference_vectors(ctx):
         assert np.array_equal(word, g[f"word{w}"]) and weight.tobytes() == g[f"weight{w}"].tobytes()
         assert np.array_equal(node, g[f"node{w}"]) and np.array_equal(bw, g[f"bow_ids{w}"]) and bv.tobytes() == g[f"bow_vals{w}"].tobytes()
         v.close()
+
+
+@pytest.mark.parametrize("dims,k,L,weighting,scoring,levelsup,n", [(64, 8, 3, 0, 0, 1, 2000), (128, 6, 3, 1, 1, 2, 700), (8, 5, 4, 0, 5, 0, 300)])
+def test_bow_float_vocabulary(ctx, oracle, dims, k, L, weighting, scoring, levelsup, n):
+    """Float (L2) vocabularies: squared L2 accumulated in float in index order without FMA, as the reference's l2generic --
+    words, nodes, weights and BoW floats bit-identical to the oracle (pinned to the reference for these in
+    tests/test_bow_oracle.py); then directly against the reference's golden outputs."""
+    from gslam_amd.bow import Vocabulary
+    voc = bow_synth.make_float_vocabulary(k=k, L=L, dims=dims, seed=dims, weighting=weighting, scoring=scoring)
+    rng = np.random.default_rng(dims)
+    desc = np.concatenate([bow_synth.float_features_near_words(voc, n - n // 4, seed=5), rng.normal(size=(n // 4, dims)).astype(np.float32) * 2])
+    v = Vocabulary(ctx, voc)
+    got = v.transform_host(desc, levelsup)
+    exp = oracle.bow_transform(voc, desc, levelsup)
+    assert np.array_equal(got[0], exp[0]) and got[1].tobytes() == exp[1].tobytes() and np.array_equal(got[2], exp[2])
+    assert np.array_equal(got[3], exp[3]) and got[4].tobytes() == exp[4].tobytes()
+    v.close()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_reference_wide.npz"))
+    voc = bow_synth.make_float_vocabulary(k=int(g["kf"]), L=int(g["Lf"]), dims=int(g["dimsf"]), seed=int(g["seedf"]))
+    v = Vocabulary(ctx, voc)
+    word, weight, node, bw, bv = v.transform_host(g["descf"], int(g["levelsupf"]))
+    assert np.array_equal(word, g["wordf"]) and weight.tobytes() == g["weightf"].tobytes() and np.array_equal(node, g["nodef"])
+    assert np.array_equal(bw, g["bow_idsf"]) and bv.tobytes() == g["bow_valsf"].tobytes()
+    v.close()

@@ -105,3 +105,29 @@ def test_wide_descriptor_golden_vectors(oracle):
         word, weight, node, bw, bv = oracle.bow_transform(voc, g[f"desc{w}"], levelsup=int(g[f"levelsup{w}"]))
         assert np.array_equal(word, g[f"word{w}"]) and np.array_equal(node, g[f"node{w}"])
         assert np.array_equal(bw, g[f"bow_ids{w}"]) and bv.tobytes() == g[f"bow_vals{w}"].tobytes()
+
+
+@pytest.mark.skipif(not oracle_lib.have_reference(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("dims,k,L,weighting,scoring,levelsup", [(64, 8, 3, 0, 0, 1), (128, 6, 3, 1, 1, 2), (8, 5, 4, 0, 5, 0), (24, 4, 3, 2, 0, 1)])
+def test_float_vocabulary_equals_the_reference_live(oracle, dims, k, L, weighting, scoring, levelsup):
+    """Float (L2) vocabularies: the reference's l2generic (Vocabulary.h:550-560) through oracle/_ref, bit for bit."""
+    ref = oracle_lib.load_reference()
+    voc = bow_synth.make_float_vocabulary(k=k, L=L, dims=dims, seed=dims, weighting=weighting, scoring=scoring)
+    rv = oracle_lib.RefVocabulary(ref, bow_synth.to_gbow_bytes(voc))
+    assert rv.info() == (k, L, len(voc["nodes"]))
+    rng = np.random.default_rng(dims)
+    desc = np.concatenate([bow_synth.float_features_near_words(voc, 500, seed=5), rng.normal(size=(200, dims)).astype(np.float32) * 2])
+    word, weight, node, bw, bv = oracle.bow_transform(voc, desc, levelsup=levelsup)
+    bi, bvr, rw, rwt, rn = rv.transform_f32(desc, levelsup)
+    assert np.array_equal(word, rw) and np.array_equal(weight, rwt) and np.array_equal(node, rn)
+    assert np.array_equal(bw, bi) and bv.tobytes() == bvr.tobytes()
+    assert len(np.unique(word)) > 20
+    rv.close()
+
+
+def test_float_vocabulary_golden_vectors(oracle):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_reference_wide.npz"))
+    voc = bow_synth.make_float_vocabulary(k=int(g["kf"]), L=int(g["Lf"]), dims=int(g["dimsf"]), seed=int(g["seedf"]))
+    word, weight, node, bw, bv = oracle.bow_transform(voc, g["descf"], levelsup=int(g["levelsupf"]))
+    assert np.array_equal(word, g["wordf"]) and np.array_equal(node, g["nodef"])
+    assert np.array_equal(bw, g["bow_idsf"]) and bv.tobytes() == g["bow_valsf"].tobytes()

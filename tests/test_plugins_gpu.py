@@ -174,16 +174,20 @@ def test_featuredetector_plugin_matches_oracle(tmp_path, oracle, channels):
     assert okm == 1 and np.array_equal(matches, exp_matches)
 
 
-@pytest.mark.parametrize("desc_bytes", [32, 64, 40])
+@pytest.mark.parametrize("desc_bytes", [32, 64, 40, -64])
 def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle, desc_bytes):
     """libgslam_vocabulary.so (VocabularyHIP) vs GSLAM::Vocabulary itself, both inside the GSLAM host process:
     BowVector and FeatureVector maps must compare equal (operator== on the std::maps, i.e. bit-exact floats)."""
     _need_host()
     from gslam_amd import bow_synth
-    voc = bow_synth.make_vocabulary(k=10, L=4, seed=5, desc_bytes=desc_bytes)  # hamming32 / hamming64 / hamming8x
+    if desc_bytes < 0:  # a float (L2) vocabulary of -desc_bytes dimensions: l2generic
+        voc = bow_synth.make_float_vocabulary(k=8, L=3, dims=-desc_bytes, seed=5)
+        desc = bow_synth.float_features_near_words(voc, 1500, seed=8)
+    else:
+        voc = bow_synth.make_vocabulary(k=10, L=4, seed=5, desc_bytes=desc_bytes)  # hamming32 / hamming64 / hamming8x
+        desc = bow_synth.features_near_words(voc, 1500, seed=8)
     gb, df, out = tmp_path / "voc.gbow", tmp_path / "desc.raw", tmp_path / "out.bin"
     open(gb, "wb").write(bow_synth.to_gbow_bytes(voc))
-    desc = bow_synth.features_near_words(voc, 1500, seed=8)
     desc.tofile(df)
     r = _run(["bow", LIBDIR, gb, df, 1500, 2, out])
     assert r.returncode == 0, r.stdout + r.stderr

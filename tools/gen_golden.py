@@ -39,6 +39,16 @@ def wide_bow(ref, out):
         rec.update({f"k{w}": k, f"L{w}": L, f"seed{w}": seed, f"levelsup{w}": levelsup, f"desc{w}": desc,
                     f"word{w}": word.astype(np.uint32), f"weight{w}": weight, f"node{w}": node.astype(np.uint32),
                     f"bow_ids{w}": bi.astype(np.uint32), f"bow_vals{w}": bv})
+    # a float (L2) vocabulary: l2generic
+    k, L, dims, seed, levelsup = 7, 3, 64, 43, 1
+    voc = bow_synth.make_float_vocabulary(k=k, L=L, dims=dims, seed=seed)
+    rv = oracle_lib.RefVocabulary(ref, bow_synth.to_gbow_bytes(voc))
+    rng = np.random.default_rng(seed)
+    desc = np.concatenate([bow_synth.float_features_near_words(voc, 300, seed=seed + 1), rng.normal(size=(100, dims)).astype(np.float32) * 2])
+    bi, bv, word, weight, node = rv.transform_f32(desc, levelsup)
+    rv.close()
+    rec.update(dict(kf=k, Lf=L, dimsf=dims, seedf=seed, levelsupf=levelsup, descf=desc, wordf=word.astype(np.uint32), weightf=weight,
+                    nodef=node.astype(np.uint32), bow_idsf=bi.astype(np.uint32), bow_valsf=bv))
     np.savez_compressed(os.path.join(out, "bow_reference_wide.npz"), **rec)
     print("bow_reference_wide.npz written")
 
