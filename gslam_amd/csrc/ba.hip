@@ -30,6 +30,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
 size_t gh_potrf_flow_flag_words(int n, int extra_rows);
 std::mutex& gh_potrf_flow_mutex(int device);
+gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
                                 bool xh_ready);
@@ -1553,7 +1554,26 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       if (teams) part_status[u] = stage_part(u, U);
       else early_status = raw_arrays(true);
     };
-    if (teams) {
+    // Large graphs: the two lists come from a stable radix sort on the GPU (csr_sort.hip) while the pool stages the raw
+    // arrays -- the host teams need ~60 ms for the 6 M observations of C5.  GSLAM_HIP_BA_CSR=host keeps the host lists.
+    const char* csr_env = getenv("GSLAM_HIP_BA_CSR");
+    const bool gpu_csr = no >= (1 << 20) && !(csr_env && csr_env[0] == 'h');
+    if (gpu_csr) {
+      pstart.assign((size_t)np + 1, 0);
+      cstart.assign((size_t)nc + 1, 0);
+      plist.resize((size_t)no);
+      clist.resize((size_t)no);
+      gh_status csr_status[2] = {GH_OK, GH_OK};
+      pool.run(2 + extra, [&](int t) {  // (the two sorts share the stream; their pageable host copies overlap)
+        (void)hipSetDevice(ctx->device);
+        if (t == 0) csr_status[0] = gh_csr_build_dev(ctx, pr->obs_point, no, np, pstart.data(), plist.data());
+        else if (t == 1) csr_status[1] = gh_csr_build_dev(ctx, pr->obs_cam, no, nc, cstart.data(), clist.data());
+        else upload_task(t - 2);
+      });
+      GH_TRY(csr_status[0]);
+      GH_TRY(csr_status[1]);
+      for (int u = 0; u < U; ++u) GH_TRY(part_status[u]);
+    } else if (teams) {
       CsrShared shp, shc;
       shp.reset(Tp, np);
       shc.reset(Tc, nc);

@@ -650,23 +650,27 @@ constexpr int TM = 128, KC = 16;
 // multiple of KC: no masks, so operand fetches are branch-free and the epilogue issues all loads of a
 // 16-element batch before the first store (a masked, per-element read-modify-write chain was measured
 // to cost 3x the MFMA time of the tile).
-template <bool INTERIOR, int TMT>
+// WAVES = 4: the wave sub-tile is (TMT / 2) x (TMT / 2); WAVES = 8 (TMT = 128): 64 rows x 32 columns per wave, so that two
+// workgroups per CU put FOUR waves on every SIMD -- an f64 MFMA stream needs that many to keep the matrix core busy
+// (tools/clock_probe.hip: 8 accumulators per wave reach 50 TFLOP/s with two waves per SIMD and 88 with four).
+template <bool INTERIOR, int TMT, int WAVES = 4>
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n, int r_begin, int c_end, int kc0,
                                           int kdim, int i0, int j0, double* sP, double* sQ, int skip_end) {
-  constexpr int SUB = TMT / 2;      // wave sub-tile edge
-  constexpr int MT = SUB / 16;      // MFMA tiles per edge of the wave sub-tile
-  constexpr int RPT = TMT / 16;     // staged rows per thread
+  constexpr int WC = WAVES / 2;                  // wave grid: 2 row halves x WC column parts
+  constexpr int SUBI = TMT / 2, SUBJ = TMT / WC; // wave sub-tile: rows (i) x columns (j)
+  constexpr int MTI = SUBI / 16, MTJ = SUBJ / 16;  // MFMA tiles per edge of the wave sub-tile
+  constexpr int RPT = KC * TMT / (64 * WAVES);   // staged rows per thread
   constexpr int PITCH = TMT + 16;   // k-major LDS pitch (conflict-free ds_read_b64)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;  // wave sub-tile: rows i0 + SUB wr, cols j0 + SUB wc
-  double4_t acc[MT][MT];                // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
+  const int wr = wv / WC, wc = wv % WC;  // wave sub-tile: rows i0 + SUBI wr, cols j0 + SUBJ wc
+  double4_t acc[MTJ][MTI];               // acc[jt][it]: transposed tile (MFMA rows = j, cols = i)
 #pragma unroll
-  for (int a = 0; a < MT; ++a)
+  for (int a = 0; a < MTJ; ++a)
 #pragma unroll
-    for (int b = 0; b < MT; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < MTI; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  // staging map: thread -> (k = tid / 16, RPT consecutive rows starting at (tid % 16) * RPT)
-  const int sk = tid >> 4, sr = (tid & 15) * RPT;
+  // staging map: thread -> (k = tid / (TMT / RPT), RPT consecutive rows starting at (tid % (TMT / RPT)) * RPT)
+  const int sk = tid / (TMT / RPT), sr = (tid % (TMT / RPT)) * RPT;
   double p[RPT], q[RPT];
   auto fetch = [&](int kc) {
     const int kk = kc + sk;
@@ -713,33 +717,34 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
     __syncthreads();
     // software pipeline: the next chunk's global loads are in flight while this chunk's MFMAs issue
     if (kc + KC < kdim) fetch(kc + KC);
+    // (Fetching the fragments of step ks + 1 ahead of the MFMAs of step ks was measured slower with eight waves: 1164 ms
+    // against 1154 ms for the n = 60 000 factorisation; four waves per SIMD hide the LDS latency by themselves.)
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
-      double fa[MT], fb[MT];
+      double fa[MTJ], fb[MTI];
       const int krow = (4 * ks + (lane >> 4)) * PITCH;
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        fa[t] = bQ[krow + SUB * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
-        fb[t] = bP[krow + SUB * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
-      }
+      for (int t = 0; t < MTJ; ++t) fa[t] = bQ[krow + SUBJ * wc + 16 * t + (lane & 15)];  // MFMA A operand: rows = j
 #pragma unroll
-      for (int jt = 0; jt < MT; ++jt)
+      for (int t = 0; t < MTI; ++t) fb[t] = bP[krow + SUBI * wr + 16 * t + (lane & 15)];  // MFMA B operand: cols = i
 #pragma unroll
-        for (int it = 0; it < MT; ++it)
+      for (int jt = 0; jt < MTJ; ++jt)
+#pragma unroll
+        for (int it = 0; it < MTI; ++it)
           acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[jt], fb[it], acc[jt][it], 0, 0, 0);
     }
   }
   // C -= acc^T : lane holds, for tile (jt, it): j = jbase + (lane>>4) + 4r, i = ibase + (lane&15)
 #pragma unroll
-  for (int jt = 0; jt < MT; ++jt) {
-    double cv[MT][4];
-    bool ok[MT][4];
+  for (int jt = 0; jt < MTJ; ++jt) {
+    double cv[MTI][4];
+    bool ok[MTI][4];
 #pragma unroll
-    for (int it = 0; it < MT; ++it) {
-      const int i = i0 + SUB * wr + 16 * it + (lane & 15);
+    for (int it = 0; it < MTI; ++it) {
+      const int i = i0 + SUBI * wr + 16 * it + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + SUB * wc + 16 * jt + (lane >> 4) + 4 * r;
+        const int j = j0 + SUBJ * wc + 16 * jt + (lane >> 4) + 4 * r;
         // (i, j) both below skip_end: the next diagonal block, owned by the potf2 workgroup of this launch
         ok[it][r] = INTERIOR || (i < n && j < c_end && i >= j && i >= r_begin && !(i < skip_end && j < skip_end));
         const size_t idx = ok[it][r] ? (size_t)j * lda + i : (size_t)j0 * lda + i0;  // clamped, always valid
@@ -747,11 +752,11 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
       }
     }
 #pragma unroll
-    for (int it = 0; it < MT; ++it) {
-      const int i = i0 + SUB * wr + 16 * it + (lane & 15);
+    for (int it = 0; it < MTI; ++it) {
+      const int i = i0 + SUBI * wr + 16 * it + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + SUB * wc + 16 * jt + (lane >> 4) + 4 * r;
+        const int j = j0 + SUBJ * wc + 16 * jt + (lane >> 4) + 4 * r;
         if (ok[it][r]) A[(size_t)j * lda + i] = cv[it][r] - acc[jt][it][r];
       }
     }
@@ -878,6 +883,51 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(double* __restrict__ 
   const bool interior = i0 + TMT <= n && j0 + TMT <= c_end && i0 >= j0 + TMT && (kdim % KC) == 0;
   if (interior) syrk_tile<true, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
   else syrk_tile<false, TMT>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
+}
+
+// The same update with EIGHT waves per 128 x 128 tile (64 x 32 per wave): two workgroups per CU = four waves per SIMD.
+template <int TMT>
+__global__ __launch_bounds__(512, 4) void syrk_mfma8_kernel(double* __restrict__ A, int lda, int n, int r_begin,
+                                                        int c_begin, int c_end, int kc0, int kdim, int tiles_i,
+                                                        int tiles_j, int fuse_d, int fuse_kb, int* __restrict__ info,
+                                                        double* __restrict__ minv_next) {
+  __shared__ __attribute__((aligned(16))) Potf2Lds sh;  // the tile path uses its first 2 * KC * (TMT + 16) doubles
+  static_assert(2 * 2 * KC * (TM + 16) * sizeof(double) <= sizeof(Potf2Lds), "double-buffered operand staging must fit");
+  int bid = blockIdx.x;
+  if (fuse_d >= 0) {
+    if (bid == 0) {
+      if (threadIdx.x < 256) potf2_fused(sh, A, lda, fuse_d, fuse_kb, kc0, kdim, info, minv_next);  // (written for four waves)
+      return;
+    }
+    --bid;
+  }
+  double* sP = sh.As;                      // rows i (C rows)   [k][i]   (buffer 0; syrk_tile derives the rest)
+  double* sQ = sh.As + KC * (TMT + 16);    // rows j (C cols)   [k][j]
+  const int skip_end = fuse_d >= 0 ? fuse_d + fuse_kb : 0;  // rows past a partial block (the rhs row) stay with the tiles
+  // Only the tiles that touch the lower part are enumerated (row-major: row ti holds min(ti + 1, tiles_j) tiles), and
+  // workgroup b runs on XCD b % 8 (own L2): every XCD gets a contiguous, equally long strip of that order, so the
+  // workgroups that share an L2 share the row panel P_i and neighbouring column panels.
+  const int tri = tiles_j * (tiles_j + 1) / 2, total = tri + (tiles_i - tiles_j) * tiles_j;
+  {
+    const int chunk = (total + 7) >> 3;
+    bid = (bid & 7) * chunk + (bid >> 3);
+    if (bid >= total) return;
+  }
+  int ti, tj;
+  if (bid < tri) {
+    ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > bid) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    tj = bid - ti * (ti + 1) / 2;
+  } else {
+    const int r = bid - tri;
+    ti = tiles_j + r / tiles_j;
+    tj = r - (ti - tiles_j) * tiles_j;
+  }
+  const int j0 = c_begin + tj * TMT, i0 = r_begin + ti * TMT;
+  const bool interior = i0 + TMT <= n && j0 + TMT <= c_end && i0 >= j0 + TMT && (kdim % KC) == 0;
+  if (interior) syrk_tile<true, TMT, 8>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
+  else syrk_tile<false, TMT, 8>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
 }
 
 // One WHOLE panel step of the small-matrix regime in a single launch (the step used to be trsm + update: at
@@ -1906,7 +1956,7 @@ __global__ void gather_strided_kernel(const double* __restrict__ src, long long 
   if (i < n) dst[i] = src[(size_t)i * stride];
 }
 
-// ---------------------------------------------------------------- backward substitution as ONE launch (n <= kBwdChainMaxN)
+// ---------------------------------------------------------------- backward substitution as ONE launch per kBwdChainMaxN columns
 // The per-step launches above are bound by the launch chain (24 launches of ~13 us at n = 3000 for a few hundred cycles of
 // arithmetic each).  Here every 64-column block c has its own workgroup, all resident at once:
 //   workgroup c   keeps r_c = sum_{j > c} L[j-block, c-block]^T x_j as per-thread partial sums, consuming x_j in the order
@@ -1921,14 +1971,16 @@ constexpr unsigned long long kXSentinel = 0xFFF8BEEFFFF8BEEFull;  // a NaN no co
 constexpr int kBwdChainMaxN = 8192;                                // 128 workgroups; workgroup 0 streams <= 4 MB of L
 constexpr unsigned kBwdSpinLimit = 1u << 21;
 
-__global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict__ A, int lda, int n, int nb,
+// `first`: column blocks nb - 1 .. nb - first were finished by earlier launches (their x is final in `xh`): larger systems
+// run as a sequence of launches of at most kBwdChainMaxN / 64 workgroups, each of which must be resident as a whole.
+__global__ __launch_bounds__(256) void bwd_chain_kernel(const double* __restrict__ A, int lda, int n, int nb, int first,
                                                        const double* __restrict__ yv, long long ystride,
                                                        const double* __restrict__ dinv, double* xh,
                                                        double* __restrict__ x_out, int* __restrict__ info,
                                                        unsigned spin_limit) {
   __shared__ double part[2][4][NBI];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int c = nb - 1 - (int)blockIdx.x, c0 = c * NBI;
+  const int c = nb - 1 - first - (int)blockIdx.x, c0 = c * NBI;
   const int kb = n - c0 < NBI ? n - c0 : NBI;
   // M_c[16 wv + jj][lane]: 128 contiguous bytes of column `lane` of M (as in bwd_step_inv_kernel)
   double mreg[16];
@@ -2115,12 +2167,24 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   auto lower_tiles = [](int ti, int tj) { return tj * (tj + 1) / 2 + (ti - tj) * tj; };
   auto t128_of = [&](int cb, int ce) { return (long long)gh_div_up(nr - cb, TM) * gh_div_up(ce - cb, TM); };
   // rank-kdim update of rows [cb, nr) x columns [cb, ce) + factorisation of the diagonal block at cb
+  // The eight-wave tile is worth 4.5 % on the reduced camera system of C5 (1175 -> 1124 ms per LM iteration, same box) and
+  // nothing on a dense random matrix of the same size (1154 ms for either tile shape, and for every other variant tried):
+  // fully dense operands run into the board's power limit at ~62.5 TFLOP/s, the Schur complement's many zero blocks do not.
+  // (Tried and dropped: look-ahead -- the bulk of a trailing update on a low-priority side stream while the next panel is
+  // factored on this one.  Bit-identical, but the two streams' kernels do not overlap on this part: 1155 ms against
+  // 1152 ms for the n = 60 000 factorisation, tools/c5_solve_probe.py.)
+  const int syrk8 = [] { const char* e = getenv("GSLAM_HIP_SYRK8"); return e ? atoi(e) : 1; }();
   auto update = [&](const char* name, int cb, int ce, int kc0, int kdim, int kbn, double* minv_next) -> gh_status {
     // grid = the lower tiles (see the decode in the kernel), rounded up to the 8 XCD strips, + the potf2 workgroup
     if (t128_of(cb, ce) >= 1024) {  // enough 128-tiles for 256 CUs x 2 workgroups
       const int tiles_j = gh_div_up(ce - cb, TM), tiles_i = gh_div_up(nr - cb, TM);
-      GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, dim3(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1), dim3(256), 0,
-                A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb, kbn, info_dev, minv_next);
+      const dim3 grid(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1);
+      if (syrk8)  // eight waves per tile: four waves per SIMD keep the f64 matrix core busier (GSLAM_HIP_SYRK8=0: four)
+        GH_LAUNCH(ctx, name, syrk_mfma8_kernel<TM>, grid, dim3(512), 0, A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb,
+                  kbn, info_dev, minv_next);
+      else
+        GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, grid, dim3(256), 0, A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb, kbn,
+                  info_dev, minv_next);
     } else {
       const int tiles_j = gh_div_up(ce - cb, TM / 2), tiles_i = gh_div_up(nr - cb, TM / 2);
       GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM / 2>, dim3(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1), dim3(256),
@@ -2180,14 +2244,19 @@ gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, do
                                 bool xh_ready) {
   const char* env = getenv("GSLAM_HIP_BWD_CHAIN");  // "0" keeps the launch-per-step path (A/B measurements, tests)
   const bool chain_ok = !(env && env[0] == '0');
-  if (xh && info_dev && chain_ok && n <= kBwdChainMaxN) {
+  if (xh && info_dev && chain_ok) {
     const int nb = gh_div_up(n, NBI);
     if (!xh_ready)
       GH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)xh, (int)0xFFF8BEEFu, (size_t)nb * NBI * 2, ctx->stream));
     unsigned spin_limit = kBwdSpinLimit;
     if (const char* e = getenv("GSLAM_HIP_FLOW_SPIN_LIMIT")) spin_limit = (unsigned)strtoul(e, nullptr, 10);
-    GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_chain_kernel, dim3(nb), dim3(256), 0, L, lda, n, nb, yv, ystride, dinv, xh, b,
-              info_dev, spin_limit);
+    // segments of at most 128 column blocks from the bottom right up: a workgroup only ever waits for workgroups of its own
+    // launch with a lower index, everything older is final (n = 60 000: 8 launches instead of 938)
+    for (int first = 0; first < nb; first += kBwdChainMaxN / NBI) {
+      const int cnt = nb - first < kBwdChainMaxN / NBI ? nb - first : kBwdChainMaxN / NBI;
+      GH_LAUNCH(ctx, "ba_trsv_bwd", bwd_chain_kernel, dim3(cnt), dim3(256), 0, L, lda, n, nb, first, yv, ystride, dinv, xh, b,
+                info_dev, spin_limit);
+    }
     return GH_OK;
   }
   if (yv != work || ystride != 1)

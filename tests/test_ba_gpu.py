@@ -117,7 +117,7 @@ def test_potrf_solve_vs_numpy(ctx, n):
     assert np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b) * np.linalg.cond(A)
 
 
-@pytest.mark.parametrize("n", [64, 65, 130, 1000, 3000, 3001, 4097, 8192])
+@pytest.mark.parametrize("n", [64, 65, 130, 1000, 3000, 3001, 4097, 8192, 8256, 12300, 16500])
 def test_backsubstitution_single_launch_matches_the_stepwise_path(ctx, n, monkeypatch):
     """The single-launch back-substitution (one resident workgroup per 64-column block, x handed from block to block
     through agent-scope stores) against the launch-per-step one on the same factor: same sums in a different order."""
@@ -345,3 +345,48 @@ def test_resident_graph_c4_resolve_rate(ctx):
     print(f"C4 one-shot {t_one * 1e3:.2f} ms, resident {t_res * 1e3:.2f} ms for {sg.iterations} iterations")
     assert t_res < t_one
     G.close()
+
+
+@pytest.mark.parametrize("n,pad", [(20000, 0), (33000, 8)])
+def test_blocked_cholesky_eight_wave_tiles_are_bit_identical(ctx, n, pad, monkeypatch):
+    """Large systems: the trailing updates run with eight waves per 128 x 128 tile (four waves per SIMD).  Same sums per
+    element: the factor and the solution must be the bits of the four-wave kernel's, and solve the system.
+    pad > 0: the right-hand side rides as an extra row."""
+    import ctypes as C
+    import torch
+    from gslam_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(n)
+    M = torch.randn((n, 96), dtype=torch.float64, device="cuda", generator=g)
+    lda = n + pad
+    A = torch.zeros((n, lda), dtype=torch.float64, device="cuda")  # column-major n x n in an lda-row buffer = row-major (n, lda)
+    A[:, :n] = M @ M.T / 96.0
+    A[:, :n].diagonal().add_(2.0)
+    b = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GSLAM_HIP_SYRK8", mode)
+        a, x = A.clone(), b.clone()
+        info = C.c_int()
+        ctx.check(hip.lib.gh_potrf_solve_dev(ctx.h, C.c_void_p(a.data_ptr()), n, lda, C.c_void_p(x.data_ptr()), C.byref(info)))
+        ctx.sync()
+        assert info.value == 0
+        out[mode] = (torch.triu(a[:, :n]), x)  # (the buffer is the transpose: L^T sits in the upper triangle of the view)
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
+    r = A[:, :n] @ out["1"][1] - b
+    assert float(r.norm() / b.norm()) < 1e-11
+
+
+def test_index_lists_from_the_gpu_sort_equal_the_host_lists(ctx, monkeypatch):
+    """Graphs of a million observations and more build their point / camera index lists with a stable radix sort on the
+    GPU (csr_sort.hip): element for element the host lists (GSLAM_HIP_BA_PAIRS=check compares them inside the solve), and
+    the solve is bit-identical to one on host-built lists."""
+    from gslam_amd import ba
+    g = make_graph(1500, 180000, n_obs_per_point=6, seed=5)
+    assert len(g["obs_cam"]) >= 1 << 20
+    monkeypatch.setenv("GSLAM_HIP_BA_PAIRS", "check")
+    p1, x1, s1, st1 = ba.solve(ctx, g, ba.default_options(max_iterations=2, deterministic=1))
+    monkeypatch.delenv("GSLAM_HIP_BA_PAIRS")
+    monkeypatch.setenv("GSLAM_HIP_BA_CSR", "host")
+    p0, x0, s0, st0 = ba.solve(ctx, g, ba.default_options(max_iterations=2, deterministic=1))
+    assert st1 == 0 and st0 == 0 and s1.iterations == s0.iterations
+    assert p1.tobytes() == p0.tobytes() and x1.tobytes() == x0.tobytes()
