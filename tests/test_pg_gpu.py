@@ -57,6 +57,13 @@ def test_pose_graph_larger_essential_graph(ctx, oracle):
     _compare(ctx, oracle, truth, start, dof, prob, max_it=12)
 
 
+def test_pose_graph_beyond_the_single_launch_solver(ctx, oracle):
+    """700 keyframes: n = 4900 unknowns, past the dataflow factorisation (n <= ~3300): the blocked path with the right-hand
+    side riding as the extra row and the segmented back-substitution."""
+    truth, start, dof, prob = make_pose_graph(700, 80, kind="sim3", seed=12, noise=0.01, perturb=0.03, scale_drift=0.1)
+    _compare(ctx, oracle, truth, start, dof, prob, max_it=6)
+
+
 def test_alignment_parity(ctx, oracle):
     from gslam_amd import posegraph
     from gslam_amd.pg_synth import _qrot
