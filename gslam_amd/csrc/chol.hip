@@ -2194,8 +2194,14 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   };
   XCopy pend{nullptr, nr, 0, 0, 0};  // X of the last fused step, not yet in place
   int xsel = 0;
+  // In-panel updates two blocks at a time (large systems): after block k only the NEXT 64 columns get its rank-64 update
+  // (a narrow strip, so that block k + 64 can be factored and solved), the rest of the panel then takes blocks k and k + 64
+  // together as ONE rank-128 update.  The panel's columns are read and written half as often: these updates are bound by
+  // exactly that traffic (C5: 822 launches, 3.2 TB/s, 60 ms per factorisation).  GSLAM_HIP_CHOL_PAIR=0 switches it off.
+  const bool pair_blocks = [] { const char* e = getenv("GSLAM_HIP_CHOL_PAIR"); return !(e && e[0] == '0'); }() && n >= 16384;
   for (int c0 = 0; c0 < n; c0 += nbo) {
     const int pw = n - c0 < nbo ? n - c0 : nbo;  // panel width
+    int deferred_k = -1;  // first block of a pair whose update of the columns past the pair is still owed
     for (int k = c0; k < c0 + pw; k += NBI) {
       const int kb = c0 + pw - k < NBI ? c0 + pw - k : NBI;
       double* minv = dinv + (size_t)(k / NBI) * (NBI * NBI);
@@ -2203,6 +2209,15 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       if (r0 >= nr) continue;
       const int cb = r0, ce = c0 + pw;
       const int ncopy = pend.src ? gh_div_up(pend.rows, 64) : 0;
+      if (deferred_k >= 0) {  // second block of a pair: its trsm, then both blocks' update of the rest of the panel
+        const int ntrsm = gh_div_up(nr - r0, 64);
+        GH_LAUNCH(ctx, "ba_trsm", trsm_inv_kernel, dim3(ntrsm + ncopy), dim3(256), 0, A, lda, nr, k, kb, r0,
+                  (const double*)minv, ntrsm, pend);
+        pend.src = nullptr;
+        if (cb < ce) GH_TRY(update("ba_syrk_panel", cb, ce, deferred_k, 2 * NBI, ce - cb < NBI ? ce - cb : NBI, minv + NBI * NBI));
+        deferred_k = -1;
+        continue;
+      }
       // one-launch step only while its tiles fit one wave of workgroups: their on-the-fly trsm triples the tile work,
       // which is free behind workgroup 0's chain but not once the tiles themselves bound the launch
       // (measured at n = 60 000 with up to ~2000 tiles per step: 165 ms against 78 ms for trsm + update)
@@ -2220,8 +2235,18 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
         GH_LAUNCH(ctx, "ba_trsm", trsm_inv_kernel, dim3(ntrsm + ncopy), dim3(256), 0, A, lda, nr, k, kb, r0,
                   (const double*)minv, ntrsm, pend);
         pend.src = nullptr;
-        // update the rest of this panel with the fresh 64 columns (+ factor the next diagonal block)
-        if (cb < ce) GH_TRY(update("ba_syrk_panel", cb, ce, k, kb, ce - cb < NBI ? ce - cb : NBI, minv + NBI * NBI));
+        // pair with the next block when it is a full one of this panel, has columns behind it, and is itself on this path
+        const int cb2 = cb + NBI;
+        const bool pair = pair_blocks && kb == NBI && cb2 < ce &&
+                          !(xwork && lower_tiles(gh_div_up(nr - cb2, 64), gh_div_up(ce - cb2, 64)) <= 256);
+        if (pair) {
+          // the next block's 64 columns only (+ its factorisation); the rest waits for the pair's rank-128 update
+          GH_TRY(update("ba_syrk_panel", cb, cb2, k, kb, NBI, minv + NBI * NBI));
+          deferred_k = k;
+        } else if (cb < ce) {
+          // update the rest of this panel with the fresh 64 columns (+ factor the next diagonal block)
+          GH_TRY(update("ba_syrk_panel", cb, ce, k, kb, ce - cb < NBI ? ce - cb : NBI, minv + NBI * NBI));
+        }
       }
     }
     if (pend.src) {  // the panel's last block had no rows below it (n a multiple of 64, no extra row): nobody copied yet
