@@ -46,6 +46,7 @@ enum {
   kDbgSelStreamed,       // select launches of the streaming (non-cached) variant
   kDbgUnusedSlots,       // zero-filled output rows
   kDbgStarvedLevels,     // (level, frame) selections with fewer candidates than quota
+  kDbgWeakCells,         // cells with candidates but no corner above the initial threshold (a two-phase detector's second pass)
   kDbgCount = 16
 };
 
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
       if (lane == 0) {
         if (__popcll(cand) > kCap) atomicAdd(&dbg[kDbgRankDropped], 1u);
         if (strong_mask != 0ull && strong_mask != all_max) atomicAdd(&dbg[kDbgStrongSilenced], 1u);
+        if (strong_mask == 0ull && all_max != 0ull) atomicAdd(&dbg[kDbgWeakCells], 1u);
       }
     }
   } else {
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
       n = m2;
     }
     if (dbg != nullptr && lane == 0) {
+      if (!strong && n > 0) atomicAdd(&dbg[kDbgWeakCells], 1u);
       atomicAdd(&dbg[kDbgDenseCells], 1u);
       if (n > kCap) atomicAdd(&dbg[kDbgRankDropped], 1u);
     }

@@ -96,7 +96,7 @@ class OrbExtractor:
 
     DBG_NAMES = ("cells", "dense_cells", "overflow_cells", "cap_cells", "rank_dropped", "strong_silenced",
                  "max_queue", "max_nz", "sel_cut", "sel_tie_split", "sel_overflow_cells", "sel_streamed",
-                 "unused_slots", "starved_levels")
+                 "unused_slots", "starved_levels", "weak_cells")
 
     def debug_counters(self, enable=True, read=True):
         """Branch census of the extractions since the last read (gh_orb_plan_debug_counters)."""

@@ -21,3 +21,13 @@ for min_th in (7, 20):
     print("min_th", min_th, {k: round(v["total_ms"] / v["launches"], 4) for k, v in p.items() if k.startswith("orb_")},
           "kpts", int(out[2].sum()))
     ex.close()
+
+# census on the bench texture: how many cells hold candidates but no corner above the initial threshold?
+ex = OrbExtractor(ctx, W, H, max_batch=8, n_features=K)
+ex.debug_counters(enable=True)
+ex.extract(frames[:8])
+torch.cuda.synchronize()
+c = ex.debug_counters(enable=False)
+print("bench texture, 8 frames:", {k: c[k] for k in ("cells", "weak_cells", "strong_silenced", "dense_cells")},
+      "weak share %.3f" % (c["weak_cells"] / max(1, c["cells"])))
+ex.close()
