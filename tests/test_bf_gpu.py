@@ -202,3 +202,33 @@ def test_mfma_persistent_workgroups_walk_many_pairs(ctx):
     torch.cuda.synchronize()
     for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
         assert torch.equal(x, y), (name, (x != y).nonzero()[:5].tolist())
+
+
+def test_mfma_matcher_fuzz_against_the_popcount_kernel(ctx):
+    """Random capacities (incl. non-multiples of 16 / 64 / 512), ragged counts with zeros and ones, correlated rows, random
+    pair lists with repeats and self-pairs: the MFMA formulation must return the popcount kernel's rows bit for bit."""
+    import torch
+    from hypothesis import given, settings, strategies as st
+    from gslam_amd.matcher import BFMatcher
+    m = BFMatcher(ctx)
+
+    @settings(max_examples=60, deadline=None)
+    @given(cap=st.integers(1, 700), frames=st.integers(1, 6), npairs=st.integers(1, 12), seed=st.integers(0, 2 ** 31 - 1),
+           corr=st.booleans())
+    def run(cap, frames, npairs, seed, corr):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        desc = torch.randint(0, 256, (frames, cap, 32), dtype=torch.uint8, device="cuda", generator=g)
+        if corr and cap > 1:  # few distinct rows: many exact ties
+            desc = desc[:, torch.randint(0, max(1, cap // 8), (cap,), device="cuda", generator=g)]
+            desc = desc.contiguous()
+        counts = torch.randint(0, cap + 1, (frames,), dtype=torch.int32, device="cuda", generator=g)
+        counts[torch.randint(0, frames, (1,), device="cuda", generator=g)] = cap
+        q = torch.randint(0, frames, (npairs,), dtype=torch.int32, device="cuda", generator=g)
+        t = torch.randint(0, frames, (npairs,), dtype=torch.int32, device="cuda", generator=g)
+        a = m.match_pairs(desc, counts, q, t)
+        b = m.match_pairs(desc, counts, q, t, mfma=True)
+        torch.cuda.synchronize()
+        for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
+            assert torch.equal(x, y), (cap, frames, npairs, seed, name, (x != y).nonzero()[:4].tolist())
+
+    run()

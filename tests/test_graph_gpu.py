@@ -103,3 +103,22 @@ def test_graph_solve_sphere_projection(ctx, oracle, n_xyz, n_idp, pose_edges):
                                                      projection="sphere")
     so, sg = _compare(ctx, oracle, start, dof, problem, 0.01)
     assert so.final_cost < 0.3 * so.initial_cost
+
+
+def test_graph_solve_fuzz_small_graphs(ctx, oracle):
+    """Random small graphs (keyframe kind, landmark mix, pose edges, informations, Huber on / off, sphere): the GPU trace equals
+    the oracle's."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None)
+    @given(nf=st.integers(3, 9), n_xyz=st.integers(0, 25), n_idp=st.integers(0, 25), sim3=st.booleans(), pose_edges=st.booleans(),
+           info=st.booleans(), huber=st.sampled_from([0.0, 0.01]), sphere=st.booleans(), seed=st.integers(0, 10 ** 6))
+    def run(nf, n_xyz, n_idp, sim3, pose_edges, info, huber, sphere, seed):
+        if n_xyz + n_idp == 0 and not pose_edges:
+            n_xyz = 5
+        truth, start, dof, problem = make_landmark_graph(n_frames=nf, n_xyz=n_xyz, n_idp=n_idp, kind="sim3" if sim3 else "se3",
+                                                         seed=seed, noise=1e-3, pose_edges=pose_edges, with_info=info,
+                                                         obs_per_point=min(4, nf), projection="sphere" if sphere else "pinhole")
+        _compare(ctx, oracle, start, dof, problem, huber, iters=12, rtol=1e-6)
+
+    run()
