@@ -23,6 +23,7 @@
 #include <new>
 #include <vector>
 
+#include "bsparse.h"
 #include "common.h"
 
 namespace {
@@ -353,6 +354,46 @@ __global__ __launch_bounds__(64) void pg_assemble_kernel(PgGraph G, PgLists Ls, 
   }
   const int rf = Ls.prow[pr], cf = Ls.pcol[pr];
   H[(size_t)(7 * cf + q) * lda + 7 * rf + p] = s;  // lower triangle (row frame > column frame)
+}
+
+// The same sums stored into the block-sparse layout of bsparse.h: block b (frames first, then pairs) goes to
+// V[off[b] + p * sp[b] + q * sq[b]] (sp / sq swap when the elimination order puts the pair's row frame first).
+struct BsDest {
+  const int64_t* off;
+  const int32_t *sp, *sq;
+};
+__global__ __launch_bounds__(64) void pg_assemble_bs_kernel(PgGraph G, PgLists Ls, const double* __restrict__ rec,
+                                                            double* __restrict__ V, BsDest D, double* __restrict__ g) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b < G.n_frames) {
+    if (t < 49) {
+      const int p = t / 7, q = t - 7 * p;
+      double s = 0;
+      for (int k = Ls.vstart[b]; k < Ls.vstart[b + 1]; ++k) {
+        const int v = Ls.vlist[k];
+        s += rec[(size_t)kEdgeRec * (v >> 1) + ((v & 1) ? 49 : 0) + 7 * p + q];
+      }
+      V[D.off[b] + p * D.sp[b] + q * D.sq[b]] = s;
+    } else if (t < 56) {
+      const int p = t - 49;
+      double s = 0;
+      for (int k = Ls.vstart[b]; k < Ls.vstart[b + 1]; ++k) {
+        const int v = Ls.vlist[k];
+        s += rec[(size_t)kEdgeRec * (v >> 1) + ((v & 1) ? 154 : 147) + p];
+      }
+      g[7 * b + p] = s;
+    }
+    return;
+  }
+  const int pr = b - G.n_frames;
+  if (pr >= Ls.n_pairs || t >= 49) return;
+  const int p = t / 7, q = t - 7 * p;
+  double s = 0;
+  for (int k = Ls.pstart[pr]; k < Ls.pstart[pr + 1]; ++k) {
+    const int v = Ls.plist[k];
+    s += rec[(size_t)kEdgeRec * (v >> 1) + 98 + ((v & 1) ? 7 * q + p : 7 * p + q)];
+  }
+  V[D.off[b] + p * D.sp[b] + q * D.sq[b]] = s;
 }
 
 // Hd = H (lower blocks incl. the diagonal) + clamp(H_kk, 1e-6, 1e32) / radius on the diagonal; d = -g
@@ -1056,9 +1097,47 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   }
   const int n = 7 * nf;
   const int lda = (n + 1 + 15) & ~15;  // one spare row: the right-hand side rides through the factorisation (gh_potrf_solve_dev)
+  // A large pose graph (no landmarks) is solved block-sparse: bsparse.h.  GSLAM_HIP_PG_SPARSE_MIN = keyframes from which
+  // it is used (0: always; default 384 -- below it the dense system is a single-launch factorisation and bitwise
+  // reproducible), GSLAM_HIP_PG_ROOT = keyframes kept for the dense root.
+  int sparse_min = 384, root_min = 128;
+  if (const char* e = getenv("GSLAM_HIP_PG_SPARSE_MIN")) sparse_min = atoi(e);
+  if (const char* e = getenv("GSLAM_HIP_PG_ROOT")) root_min = std::max(1, atoi(e));
+  const bool sparse = nlm == 0 && nf >= sparse_min && sparse_min >= 0;
+  BsSolver BS;
+  std::vector<int64_t> bs_off;
+  std::vector<int32_t> bs_sp, bs_sq;
+  if (sparse) {
+    BS.P.build(nf, PH.n_pairs, PH.prow.data(), PH.pcol.data(), root_min, 64);
+    GH_TRY(BS.init(ctx));
+    const size_t nb = (size_t)nf + PH.n_pairs;
+    bs_off.resize(nb);
+    bs_sp.resize(nb);
+    bs_sq.resize(nb);
+    for (int f = 0; f < nf; ++f) {
+      size_t o = 0;
+      int cs = 7;
+      GH_CHECK_ARG(ctx, BS.block_addr(BS.P.pos[f], BS.P.pos[f], &o, &cs));
+      bs_off[f] = (int64_t)o;
+      bs_sp[f] = 1;
+      bs_sq[f] = cs;
+    }
+    for (int k = 0; k < PH.n_pairs; ++k) {
+      const int pa = BS.P.pos[PH.prow[k]], pb = BS.P.pos[PH.pcol[k]];
+      size_t o = 0;
+      int cs = 7;
+      GH_CHECK_ARG(ctx, BS.block_addr(std::max(pa, pb), std::min(pa, pb), &o, &cs));
+      bs_off[nf + k] = (int64_t)o;
+      bs_sp[nf + k] = pa > pb ? 1 : cs;  // p indexes the pair's ROW frame: the block's row when that frame comes later in the order
+      bs_sq[nf + k] = pa > pb ? cs : 1;
+    }
+    if (opt.verbose)
+      fprintf(stderr, "[gh_graph] block-sparse: %d keyframes -> %d sparse columns in %d rounds, %d blocks, root %d\n", nf, BS.P.ns,
+              BS.P.n_rounds, BS.P.n_slots, BS.P.nr);
+  }
   const int n_items = ne + no, n_part = gh_div_up(std::max(n_items, std::max(no, 1)), 1024);
   DevArena A;
-  double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H, *d_Hd, *d_g, *d_d, *d_out;
+  double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H = nullptr, *d_Hd = nullptr, *d_g, *d_d, *d_out;
   double *d_xyz, *d_xyz_new, *d_rho, *d_rho_new, *d_anchor, *d_oxy, *d_oinfo = nullptr, *d_orec, *d_Hpp, *d_gp, *d_Hinv, *d_dlm, *d_term,
       *d_part, *d_Wh;
   int32_t *d_dof, *d_etype, *d_ei, *d_ej, *d_vstart, *d_vlist, *d_pstart, *d_plist, *d_prow, *d_pcol, *d_host, *d_okind, *d_opoint,
@@ -1068,7 +1147,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   const size_t nlm1 = (size_t)std::max(nlm, 1), no1 = (size_t)std::max(no, 1);
   bool ok = A.alloc(&d_S, (size_t)nf * 8) && A.alloc(&d_Snew, (size_t)nf * 8) && A.alloc(&d_meas, PH.meas.size()) &&
             (!PH.any_info || A.alloc(&d_info, PH.info.size())) && A.alloc(&d_rec, (size_t)kEdgeRec * PH.etype.size()) &&
-            A.alloc(&d_cost_e, PH.etype.size()) && A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda) &&
+            A.alloc(&d_cost_e, PH.etype.size()) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda))) &&
             A.alloc(&d_g, (size_t)n) && A.alloc(&d_d, (size_t)n) && A.alloc(&d_out, 4) && A.alloc(&d_dof, (size_t)nf) &&
             A.alloc(&d_etype, PH.etype.size()) && A.alloc(&d_ei, PH.etype.size()) && A.alloc(&d_ej, PH.etype.size()) &&
             A.alloc(&d_vstart, PH.vstart.size()) && A.alloc(&d_vlist, PH.vlist.size()) && A.alloc(&d_pstart, PH.pstart.size()) &&
@@ -1113,6 +1192,15 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GH_TRY(up(d_llist, llist.data(), llist.size() * 4));
   if (gpr->xyz_free) GH_TRY(up(d_xfree, gpr->xyz_free, (size_t)nx));
   if (gpr->idp_free) GH_TRY(up(d_ifree, gpr->idp_free, (size_t)ni));
+  int64_t* d_bs_off = nullptr;
+  int32_t *d_bs_sp = nullptr, *d_bs_sq = nullptr;
+  if (sparse) {
+    if (!(A.alloc(&d_bs_off, bs_off.size()) && A.alloc(&d_bs_sp, bs_sp.size()) && A.alloc(&d_bs_sq, bs_sq.size())))
+      return gh_set_error(ctx, GH_ERR_NOMEM, "gh_graph_solve: device allocation failed");
+    GH_TRY(up(d_bs_off, bs_off.data(), bs_off.size() * 8));
+    GH_TRY(up(d_bs_sp, bs_sp.data(), bs_sp.size() * 4));
+    GH_TRY(up(d_bs_sq, bs_sq.data(), bs_sq.size() * 4));
+  }
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
   PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
@@ -1146,14 +1234,19 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   int term = 0, it = 0;
   for (it = 0; it < opt.max_iterations; ++it) {
     if (need_lin) {
-      GH_HIP(ctx, hipMemsetAsync(d_H, 0, (size_t)n * lda * sizeof(double), ctx->stream));
+      if (sparse) GH_HIP(ctx, hipMemsetAsync(BS.d_H, 0, BS.n_vals * sizeof(double), ctx->stream));
+      else GH_HIP(ctx, hipMemsetAsync(d_H, 0, (size_t)n * lda * sizeof(double), ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_Hpp, 0, nlm1 * 72, ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_gp, 0, nlm1 * 24, ctx->stream));
       if (ne > 0) GH_LAUNCH(ctx, "pg_edge", pg_edge_kernel, dim3(eb4), dim3(64), 0, G, (const double*)d_S, d_rec, d_cost_e);
       // stores the pose-edge sums into every diagonal block, every edge pair block and g (zeros where there is no edge)
-      GH_LAUNCH(ctx, "pg_assemble", pg_assemble_kernel, dim3(nf + PH.n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, d_H, lda,
-                d_g, d_gmax);
+      if (sparse)
+        GH_LAUNCH(ctx, "pg_assemble_bs", pg_assemble_bs_kernel, dim3(nf + PH.n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, BS.d_H,
+                  BsDest{d_bs_off, d_bs_sp, d_bs_sq}, d_g);
+      else
+        GH_LAUNCH(ctx, "pg_assemble", pg_assemble_kernel, dim3(nf + PH.n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, d_H, lda,
+                  d_g, d_gmax);
       if (no > 0)
         GH_LAUNCH(ctx, "gr_obs_lin", gr_obs_lin_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, (const double*)d_S,
                   (const double*)d_xyz, (const double*)d_rho, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp);
@@ -1171,8 +1264,9 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       }
       need_lin = false;
     }
-    GH_LAUNCH(ctx, "pg_damp", pg_damp_kernel, dim3(gh_div_up((long long)n * lda, 256)), dim3(256), 0, (const double*)d_H, d_Hd,
-              n, lda, (const double*)d_g, d_d, radius);
+    if (!sparse)
+      GH_LAUNCH(ctx, "pg_damp", pg_damp_kernel, dim3(gh_div_up((long long)n * lda, 256)), dim3(256), 0, (const double*)d_H, d_Hd,
+                n, lda, (const double*)d_g, d_d, radius);
     if (nlm > 0) {
       GH_LAUNCH(ctx, "gr_lm_prepare", gr_lm_prepare_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                 (const double*)d_Hpp, (const double*)d_orec, radius, d_Hinv, d_lmdim, d_Wh, d_hrep);
@@ -1183,7 +1277,8 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
     }
     int info = 0;
     const double t_s0 = now_ms_pg();
-    GH_TRY(gh_potrf_solve_dev(ctx, d_Hd, n, lda, d_d, &info));
+    if (sparse) GH_TRY(BS.factor_solve(ctx, radius, d_g, d_d, &info));
+    else GH_TRY(gh_potrf_solve_dev(ctx, d_Hd, n, lda, d_d, &info));
     sum->solve_ms_total += now_ms_pg() - t_s0;
     const bool okf = info == 0;
     double new_cost = cost, model = 0, rho = -1;

@@ -90,3 +90,40 @@ def align_sim3(ctx: hip.Context, src, dst, dof=127):
     out, info, ssq, ok = np.zeros(8), np.zeros(49), C.c_double(), C.c_int()
     ctx.check(hip.lib.gh_align_sim3(ctx.h, _p(a), _p(b), len(a), int(dof), _p(out), _p(info), C.byref(ssq), C.byref(ok)))
     return bool(ok.value), out, info.reshape(7, 7), ssq.value
+
+
+def bs_symbolic(n_frames, prow, pcol, root_min=128, max_rounds=64):
+    """gh_bs_symbolic (host only): the elimination order of the block-sparse pose-graph solver.
+    -> dict(pos, ns, nr, round_ptr, colptr, rows, pair_products)."""
+    prow = np.ascontiguousarray(prow, dtype=np.int32)
+    pcol = np.ascontiguousarray(pcol, dtype=np.int32)
+    counts = np.zeros(5, np.int64)
+    pos = np.zeros(n_frames, np.int32)
+    st = hip.lib.gh_bs_symbolic(n_frames, len(prow), _p(prow), _p(pcol), root_min, max_rounds, _p(pos), _p(counts), None, 0, None,
+                                None, 0)
+    if st:
+        raise RuntimeError("gh_bs_symbolic failed: %d" % st)
+    ns, nr, n_rounds, n_slots = (int(v) for v in counts[:4])
+    round_ptr = np.zeros(n_rounds + 1, np.int32)
+    colptr = np.zeros(ns + 1, np.int32)
+    rows = np.zeros(max(n_slots, 1), np.int32)
+    st = hip.lib.gh_bs_symbolic(n_frames, len(prow), _p(prow), _p(pcol), root_min, max_rounds, _p(pos), _p(counts), _p(round_ptr),
+                                len(round_ptr), _p(colptr), _p(rows), len(rows))
+    if st:
+        raise RuntimeError("gh_bs_symbolic failed: %d" % st)
+    return dict(pos=pos, ns=ns, nr=nr, round_ptr=round_ptr, colptr=colptr, rows=rows[:n_slots], pair_products=int(counts[4]))
+
+
+def bs_solve(ctx: hip.Context, prow, pcol, diag, off, g, radius=1e30, root_min=128, max_rounds=64):
+    """gh_bs_solve_host: (H + clamp(diag) / radius) x = -g with H given by 7 x 7 blocks (column-major).  -> (x, info)."""
+    prow = np.ascontiguousarray(prow, dtype=np.int32)
+    pcol = np.ascontiguousarray(pcol, dtype=np.int32)
+    diag = np.ascontiguousarray(diag, dtype=np.float64)
+    off = np.ascontiguousarray(off, dtype=np.float64)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    nf = len(diag)
+    x = np.zeros(7 * nf)
+    info = C.c_int(0)
+    ctx.check(hip.lib.gh_bs_solve_host(ctx.h, nf, len(prow), _p(prow), _p(pcol), _p(diag), _p(off), _p(g), float(radius), root_min,
+                                       max_rounds, _p(x), C.byref(info)))
+    return x, info.value

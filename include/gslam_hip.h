@@ -528,6 +528,25 @@ gh_status gh_align_sim3(gh_ctx* ctx, const double* src, const double* dst, int n
  * bundle adjustment): the padding rows n .. lda - 1 are scratch then. */
 gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info);
 
+/* Block-sparse Cholesky with a dense root: the linear solver gh_pg_solve uses for LARGE pose graphs
+ * (GSLAM/core/Optimizer.h:127-148,162-167 -- se3Graph / sim3Graph / gpsGraph over thousands of keyframes; the system has
+ * one 7 x 7 block per keyframe and one per edge).  Exposed for tests and tools:
+ * gh_bs_symbolic (host only, no GPU): the elimination order of the keyframe graph given its distinct frame pairs --
+ *   rounds of independent low-degree keyframes (cyclic reduction on an odometry chain), the rest is the dense root.
+ *   counts_out[5] = {sparse columns, root keyframes, rounds, below-diagonal blocks incl. fill, 7 x 7 block products};
+ *   pos_out[n_frames] frame -> position; round_ptr_out[rounds + 1]; colptr_out[sparse columns + 1]; rows_out = row
+ *   positions of the blocks of each sparse column, ascending (any of the arrays may be NULL).
+ * gh_bs_solve_host: (H + clamp(diag H, 1e-6, 1e32) / radius) x = -g for a symmetric positive definite H given by its
+ *   diagonal blocks diag[n_frames][49] and off-diagonal blocks off[n_pairs][49] (block (row frame prow[k], column frame
+ *   pcol[k]), both column-major); g, x_out[7 n_frames].  *info: 0 ok, > 0 a non-positive pivot.
+ * root_min: keyframes kept for the dense root at least; max_rounds: bound on the elimination rounds. */
+gh_status gh_bs_symbolic(int n_frames, int n_pairs, const int32_t* prow, const int32_t* pcol, int root_min, int max_rounds,
+                         int32_t* pos_out, int64_t* counts_out, int32_t* round_ptr_out, int round_cap, int32_t* colptr_out,
+                         int32_t* rows_out, int rows_cap);
+gh_status gh_bs_solve_host(gh_ctx* ctx, int n_frames, int n_pairs, const int32_t* prow, const int32_t* pcol, const double* diag,
+                           const double* off, const double* g, double radius, int root_min, int max_rounds, double* x_out,
+                           int* info);
+
 #ifdef __cplusplus
 }
 #endif

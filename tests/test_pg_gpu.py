@@ -51,17 +51,69 @@ def test_pose_graph_noise_free_recovers_truth_and_respects_dof_masks(ctx, oracle
     _compare(ctx, oracle, truth, start, dof2, prob, max_it=30)
 
 
-def test_pose_graph_larger_essential_graph(ctx, oracle):
+def test_pose_graph_larger_essential_graph(ctx, oracle, monkeypatch):
     """400 keyframes, 460 SIM3 edges: n = 2800 unknowns, the dataflow factorisation path of the dense solver."""
+    monkeypatch.setenv("GSLAM_HIP_PG_SPARSE_MIN", "1000000")
     truth, start, dof, prob = make_pose_graph(400, 60, kind="sim3", seed=11, noise=0.01, perturb=0.03, scale_drift=0.1)
     _compare(ctx, oracle, truth, start, dof, prob, max_it=12)
 
 
-def test_pose_graph_beyond_the_single_launch_solver(ctx, oracle):
+def test_pose_graph_beyond_the_single_launch_solver(ctx, oracle, monkeypatch):
     """700 keyframes: n = 4900 unknowns, past the dataflow factorisation (n <= ~3300): the blocked path with the right-hand
     side riding as the extra row and the segmented back-substitution."""
+    monkeypatch.setenv("GSLAM_HIP_PG_SPARSE_MIN", "1000000")
     truth, start, dof, prob = make_pose_graph(700, 80, kind="sim3", seed=12, noise=0.01, perturb=0.03, scale_drift=0.1)
     _compare(ctx, oracle, truth, start, dof, prob, max_it=6)
+
+
+def _ran(ctx, fn, name):
+    ctx.prof_enable(True)
+    try:
+        out = fn()
+        names = set(ctx.prof_collect().keys())
+    finally:
+        ctx.prof_enable(False)
+    return out, name in names
+
+
+@pytest.mark.parametrize("nf,loops,kind,gps,info,root", [(40, 8, "sim3", 0, True, 4), (60, 10, "mixed", 6, False, 8),
+                                                         (300, 40, "sim3", 0, False, 24), (520, 60, "se3", 50, True, 128)])
+def test_pose_graph_block_sparse_parity(ctx, oracle, monkeypatch, nf, loops, kind, gps, info, root):
+    """The same bars through the block-sparse solver (rounds of independent keyframes + dense root, bsparse.hip), forced on
+    at sizes the dense oracle finishes in seconds."""
+    monkeypatch.setenv("GSLAM_HIP_PG_SPARSE_MIN", "0")
+    monkeypatch.setenv("GSLAM_HIP_PG_ROOT", str(root))
+    truth, start, dof, prob = make_pose_graph(nf, loops, kind=kind, seed=21, noise=0.01, perturb=0.04, scale_drift=0.1,
+                                              gps_every=gps, with_info=info)
+    _, used = _ran(ctx, lambda: _compare(ctx, oracle, truth, start, dof, prob, max_it=5 if nf > 100 else 40), "bs_factor_cols")
+    assert used
+
+
+def test_pose_graph_block_sparse_matches_the_dense_path(ctx, monkeypatch):
+    from gslam_amd import ba, posegraph
+    truth, start, dof, prob = make_pose_graph(1500, 200, kind="sim3", seed=5, noise=0.01, perturb=0.03, scale_drift=0.1)
+    monkeypatch.setenv("GSLAM_HIP_PG_SPARSE_MIN", "1000000")
+    Sd, sd, std_ = posegraph.solve(ctx, start, dof, prob, ba.default_options(max_iterations=8))
+    monkeypatch.setenv("GSLAM_HIP_PG_SPARSE_MIN", "0")
+    (Ss, ss, sts), used = _ran(ctx, lambda: posegraph.solve(ctx, start, dof, prob, ba.default_options(max_iterations=8)), "bs_update")
+    assert used and std_ == sts == 0
+    assert (ss.iterations, ss.accepted, ss.trace_len) == (sd.iterations, sd.accepted, sd.trace_len)
+    for i in range(sd.trace_len):
+        assert ss.trace_accepted[i] == sd.trace_accepted[i]
+        assert abs(ss.trace_cost[i] - sd.trace_cost[i]) <= 1e-9 * sd.trace_cost[i] + 1e-20
+    assert np.abs(Ss - Sd).max() <= 1e-7
+    print("n = 10500: dense %.1f ms, block-sparse %.1f ms per solve call" % (sd.total_ms, ss.total_ms))
+
+
+def test_pose_graph_of_6000_keyframes_recovers_the_truth(ctx):
+    """A loop-closing sized essential graph (42 000 unknowns; the dense system would be 14 GB): block-sparse by default."""
+    from gslam_amd import ba, posegraph
+    truth, start, dof, prob = make_pose_graph(6000, 700, kind="sim3", seed=9, perturb=0.02, scale_drift=0.1)
+    (S, sm, st), used = _ran(ctx, lambda: posegraph.solve(ctx, start, dof, prob, ba.default_options(max_iterations=30)), "bs_factor_cols")
+    assert used and st == 0 and sm.final_cost < 1e-10 * sm.initial_cost
+    sign = np.sign((S[:, :4] * truth[:, :4]).sum(axis=1))[:, None]
+    assert np.abs(S[:, :4] * sign - truth[:, :4]).max() < 1e-5 and np.abs(S[:, 4:] - truth[:, 4:]).max() < 1e-4
+    print("6000 keyframes: %d iterations in %.1f ms (%.2f ms in the linear solves)" % (sm.iterations, sm.total_ms, sm.solve_ms_total))
 
 
 def test_alignment_parity(ctx, oracle):
