@@ -17,6 +17,7 @@ struct BsPattern {  // host-side symbolic factorisation
   std::vector<int32_t> colptr;     // ns + 1: the below-diagonal blocks (slots) of sparse column c are colptr[c] .. colptr[c + 1]
   std::vector<int32_t> rows;       // n_slots: row POSITION of each slot, ascending within a column
   std::vector<int32_t> slot_col;   // n_slots: the column a slot belongs to
+  std::vector<int32_t> rowptr, rowlist;  // by row position (sparse and root): the slots in that row, ascending column
   long long pair_products = 0;     // 7 x 7 block products of the numeric factorisation (work estimate)
   void build(int n_frames, int n_pairs, const int32_t* prow, const int32_t* pcol, int root_min, int max_rounds);
   // slot of row position r in sparse column c (-1: structurally zero)
@@ -31,6 +32,12 @@ struct BsSolver {
   int nr7 = 0, ldr = 0;
   size_t off_slots = 0, off_root = 0, n_vals = 0;
   int32_t *d_colptr = nullptr, *d_rows = nullptr, *d_slot_col = nullptr, *d_pos = nullptr, *d_flag = nullptr;
+  int32_t *d_rowptr = nullptr, *d_rowlist = nullptr;
+  // update lists: destinations of round r are upd_round[r] .. upd_round[r + 1]; destination d takes the products of the
+  // slot pairs d_upd_src[d_upd_ptr[d] .. d_upd_ptr[d + 1]) in that order
+  std::vector<int32_t> upd_round;
+  int64_t* d_upd_off = nullptr;
+  int32_t *d_upd_cs = nullptr, *d_upd_ptr = nullptr, *d_upd_src = nullptr;
   double *d_H = nullptr, *d_W = nullptr;  // assembled values / damped working copy that becomes the factor
   double *d_Ld = nullptr, *d_y = nullptr, *d_b = nullptr;
   std::vector<void*> owned;

@@ -1,19 +1,18 @@
 // Block-sparse Cholesky with a dense root (see bsparse.h).  gfx950 only.
 //
-// Numeric factorisation, one round = two launches:
+// Numeric factorisation, one round = two launches, no atomics anywhere:
 //   bs_factor_cols   one workgroup per column c of the round: every thread factorises the 7 x 7 diagonal block in registers
-//                    (84 flops -- cheaper than sharing it), thread t takes row t % 7 of slot t / 7:  L_rc = H_rc L_cc^-T
-//                    (a 7-step substitution), and carries the forward substitution of the right-hand side along:
-//                    y_c = L_cc^-1 b_c,  b_r -= L_rc y_c  (f64 atomics: columns of one round share rows)
-//   bs_update        one workgroup per slot (c, c'): for every slot (c, r) below it, block(r, c') -= L_rc L_c'c^T, 49 lanes
-//                    one element each, f64 atomics into the destination column's slot (binary search in its sorted row
-//                    list), its diagonal block, or the dense root.  Rounds are independent sets, so a round only writes
-//                    into LATER rounds and the root.
+//                    (84 flops -- cheaper than sharing it) and thread t takes row t % 7 of slot t / 7:  L_rc = H_rc L_cc^-T
+//                    (a 7-step substitution).  Lanes 0..7 carry the forward substitution along:
+//                    y_c = L_cc^-1 (b_c - sum_k L_ck y_k), a GATHER over the blocks of row c (all in earlier rounds).
+//   bs_update        one wave per DESTINATION block touched by the round: block(r, c') -= sum L_rc L_c'c^T over the round's
+//                    columns c that hold both rows, in column order, from a list the host built with the symbolic
+//                    factorisation (one entry per 7 x 7 product) -- one writer per block, a fixed order of the sums.
+//                    Rounds are independent sets, so a round only writes into LATER rounds and the root.
 // Then the root (dense lower triangle, right-hand side in its spare row) goes through gh_potrf_solve_dev, and the rounds
 // are walked backwards:
-//   bs_back          8 lanes per column: x_c = L_cc^-T (y_c - sum_r L_rc^T x_r), a gather (no atomics).
-// The sums that meet in one block come from different columns in scheduling order: the factor is reproducible to
-// rounding, not bit for bit (the dense path, used below GSLAM_HIP_PG_SPARSE_MIN keyframes, is).
+//   bs_back          8 lanes per column: x_c = L_cc^-T (y_c - sum_r L_rc^T x_r), a gather.
+// Every sum has a fixed order: the factor and the solution are bitwise reproducible from run to run.
 #include "bsparse.h"
 
 #include <algorithm>
@@ -105,6 +104,14 @@ void BsPattern::build(int n_frames, int n_pairs, const int32_t* prow, const int3
     }
     std::sort(r, r + sv.size());
   }
+  rowptr.assign((size_t)nf + 1, 0);
+  for (int g = 0; g < n_slots; ++g) rowptr[rows[g] + 1]++;
+  for (int r = 0; r < nf; ++r) rowptr[r + 1] += rowptr[r];
+  rowlist.assign((size_t)std::max(n_slots, 1), 0);
+  {
+    std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+    for (int g = 0; g < n_slots; ++g) rowlist[fill[rows[g]]++] = g;  // ascending slot = ascending column
+  }
 }
 
 int BsPattern::find(int c, int r) const {
@@ -144,19 +151,35 @@ __device__ inline bool chol7(const double* __restrict__ D, double* L) {
   return ok;
 }
 
-__global__ __launch_bounds__(64) void bs_factor_cols_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rows,
+__global__ __launch_bounds__(64) void bs_factor_cols_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ rowlist, const int32_t* __restrict__ slot_col,
                                                             double* __restrict__ V, size_t off_slots, double* __restrict__ Ld,
-                                                            double* __restrict__ y, double* __restrict__ b, int c0,
+                                                            double* __restrict__ y, const double* __restrict__ b, int c0,
                                                             int32_t* __restrict__ flag) {
   const int c = c0 + blockIdx.x;
-  double L[28], yc[7];
+  double L[28];
   const bool ok = chol7(V + 49 * (size_t)c, L);
+  if (threadIdx.x < 8) {  // forward substitution of the right-hand side (lane 7 shadows lane 6)
+    const int k = threadIdx.x < 7 ? threadIdx.x : 6;
+    double t = b[7 * (size_t)c + k];
+    for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {  // blocks (c, earlier column), ascending column
+      const int g = rowlist[e];
+      const double* Bk = V + off_slots + 49 * (size_t)g + k;
+      const double* yk = y + 7 * (size_t)slot_col[g];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    double v = b[7 * (size_t)c + k];
+      for (int j = 0; j < 7; ++j) t -= Bk[7 * j] * yk[j];
+    }
 #pragma unroll
-    for (int j = 0; j < k; ++j) v -= L[tri(k, j)] * yc[j];
-    yc[k] = v / L[tri(k, k)];
+    for (int j = 0; j < 7; ++j) {
+      const double yj = __shfl(t / L[tri(j, j)], j, 8);
+      double lkj = 0;
+#pragma unroll
+      for (int kk = j + 1; kk < 7; ++kk)
+        if (k == kk) lkj = L[tri(kk, j)];
+      if (k > j) t -= lkj * yj;
+      else if (k == j) t = yj;
+    }
+    if (threadIdx.x < 7) y[7 * (size_t)c + k] = t;
   }
   if (threadIdx.x == 0) {
     if (!ok) atomicCAS(flag, 0, c + 1);
@@ -164,14 +187,12 @@ __global__ __launch_bounds__(64) void bs_factor_cols_kernel(const int32_t* __res
     for (int j = 0; j < 7; ++j)
 #pragma unroll
       for (int i = 0; i < 7; ++i) Ld[49 * (size_t)c + 7 * j + i] = i >= j ? L[tri(i, j)] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) y[7 * (size_t)c + k] = yc[k];
   }
   const int g0 = colptr[c], m = colptr[c + 1] - g0;
   for (int i = threadIdx.x; i < 7 * m; i += 64) {
     const int s = i / 7, p = i - 7 * s;
     double* Bk = V + off_slots + 49 * (size_t)(g0 + s);
-    double x[7], dot = 0;
+    double x[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       double v = Bk[7 * k + p];
@@ -180,54 +201,51 @@ __global__ __launch_bounds__(64) void bs_factor_cols_kernel(const int32_t* __res
       x[k] = v / L[tri(k, k)];
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      Bk[7 * k + p] = x[k];
-      dot += x[k] * yc[k];
-    }
-    atomicAdd(&b[7 * (size_t)rows[g0 + s] + p], -dot);
+    for (int k = 0; k < 7; ++k) Bk[7 * k + p] = x[k];
   }
 }
 
-__global__ __launch_bounds__(256) void bs_update_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rows,
-                                                        const int32_t* __restrict__ slot_col, double* __restrict__ V,
-                                                        size_t off_slots, size_t off_root, int ns, int ldr, int g_first) {
-  const int g = g_first + blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane >= 49) return;  // (no barrier below)
-  const int c = slot_col[g], gc1 = colptr[c + 1];
-  const int cp = rows[g];  // destination column (a position)
+// destination d of the round: V[dst_off[d] + p + |cs| q] -= sum over its sources (g1, g) of (L_g1 L_g^T)(p, q); cs < 0 marks a
+// diagonal block of the root (lower triangle only)
+__global__ __launch_bounds__(256) void bs_update_kernel(const int64_t* __restrict__ dst_off, const int32_t* __restrict__ dst_cs,
+                                                        const int32_t* __restrict__ src_ptr, const int2* __restrict__ src,
+                                                        double* __restrict__ V, size_t off_slots, int d0, int d1) {
+  const int d = d0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (d >= d1 || lane >= 49) return;
   const int p = lane % 7, q = lane / 7;
-  double b2[7];
+  double acc = 0;
+  for (int e = src_ptr[d]; e < src_ptr[d + 1]; ++e) {
+    const int2 sg = src[e];
+    const double* B1 = V + off_slots + 49 * (size_t)sg.x + p;
+    const double* B2 = V + off_slots + 49 * (size_t)sg.y + q;
 #pragma unroll
-  for (int k = 0; k < 7; ++k) b2[k] = V[off_slots + 49 * (size_t)g + 7 * k + q];
-  int d0 = 0, d1 = 0;
-  if (cp < ns) {
-    d0 = colptr[cp];
-    d1 = colptr[cp + 1];
+    for (int k = 0; k < 7; ++k) acc += B1[7 * k] * B2[7 * k];
   }
-  for (int g1 = g + wave; g1 < gc1; g1 += 4) {
-    const int r = rows[g1];
-    const double* B1 = V + off_slots + 49 * (size_t)g1 + p;
-    double v = 0;
+  int cs = dst_cs[d];
+  if (cs < 0) {
+    cs = -cs;
+    if (p < q) return;
+  }
+  V[dst_off[d] + p + (size_t)cs * q] -= acc;
+}
+
+// right-hand side of the root: b_r -= sum over the blocks of row r (all in sparse columns) of L_rk y_k
+__global__ __launch_bounds__(256) void bs_root_rhs_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowlist,
+                                                          const int32_t* __restrict__ slot_col, const double* __restrict__ V,
+                                                          size_t off_slots, const double* __restrict__ y, double* __restrict__ b,
+                                                          int ns, int nf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 7 * (nf - ns)) return;
+  const int r = ns + i / 7, k = i % 7;
+  double t = b[7 * (size_t)r + k];
+  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+    const int g = rowlist[e];
+    const double* Bk = V + off_slots + 49 * (size_t)g + k;
+    const double* yk = y + 7 * (size_t)slot_col[g];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) v += B1[7 * k] * b2[k];
-    double* dst;
-    if (cp >= ns) {
-      if (r == cp && p < q) continue;  // the root keeps its lower triangle only
-      dst = V + off_root + (size_t)(7 * (cp - ns) + q) * ldr + 7 * (r - ns) + p;
-    } else if (r == cp) {
-      dst = V + 49 * (size_t)cp + 7 * q + p;
-    } else {
-      int lo = d0, hi = d1;  // first slot of column cp whose row is >= r: it IS r (fill property)
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (rows[mid] < r) lo = mid + 1;
-        else hi = mid;
-      }
-      dst = V + off_slots + 49 * (size_t)lo + 7 * q + p;
-    }
-    atomicAdd(dst, -v);
+    for (int j = 0; j < 7; ++j) t -= Bk[7 * j] * yk[j];
   }
+  b[7 * (size_t)r + k] = t;
 }
 
 __global__ __launch_bounds__(64) void bs_back_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rows,
@@ -300,6 +318,52 @@ gh_status BsSolver::init(gh_ctx* ctx) {
   if (!ok)
     return gh_set_error(ctx, GH_ERR_NOMEM, "block-sparse solver: device allocation failed (%d sparse columns, %d slots, root %d)", P.ns,
                         P.n_slots, nr7);
+  // update lists: per round, the 7 x 7 products grouped by destination block (stable: column order within a destination)
+  std::vector<int64_t> upd_off;
+  std::vector<int32_t> upd_cs, upd_ptr(1, 0), upd_src;
+  upd_round.assign(1, 0);
+  {
+    struct Entry {
+      uint64_t key;
+      int32_t g1, g;
+    };
+    std::vector<Entry> ent;
+    for (int r = 0; r < P.n_rounds; ++r) {
+      ent.clear();
+      for (int c = P.round_ptr[r]; c < P.round_ptr[r + 1]; ++c)
+        for (int g = P.colptr[c]; g < P.colptr[c + 1]; ++g)
+          for (int g1 = g; g1 < P.colptr[c + 1]; ++g1) ent.push_back({(uint64_t)P.rows[g] * (uint64_t)P.nf + (uint64_t)P.rows[g1], g1, g});
+      std::stable_sort(ent.begin(), ent.end(), [](const Entry& a, const Entry& b) { return a.key < b.key; });
+      for (size_t k = 0; k < ent.size(); ++k) {
+        if (k == 0 || ent[k].key != ent[k - 1].key) {
+          if (!upd_off.empty()) upd_ptr.push_back((int32_t)(upd_src.size() / 2));
+          const int cp = (int)(ent[k].key / (uint64_t)P.nf), rr = (int)(ent[k].key % (uint64_t)P.nf);
+          size_t o = 0;
+          int cs = 7;
+          if (!block_addr(rr, cp, &o, &cs)) return gh_set_error(ctx, GH_ERR_ARG, "block-sparse solver: fill block (%d, %d) missing", rr, cp);
+          upd_off.push_back((int64_t)o);
+          upd_cs.push_back(cp >= P.ns && rr == cp ? -cs : cs);
+        }
+        upd_src.push_back(ent[k].g1);
+        upd_src.push_back(ent[k].g);
+      }
+      upd_round.push_back((int32_t)upd_off.size());
+    }
+    upd_ptr.push_back((int32_t)(upd_src.size() / 2));
+    if (upd_off.empty()) upd_ptr.assign(2, 0);
+  }
+  if (!(alloc((void**)&d_rowptr, P.rowptr.size() * 4) && alloc((void**)&d_rowlist, P.rowlist.size() * 4) &&
+        alloc((void**)&d_upd_off, upd_off.size() * 8) && alloc((void**)&d_upd_cs, upd_cs.size() * 4) &&
+        alloc((void**)&d_upd_ptr, upd_ptr.size() * 4) && alloc((void**)&d_upd_src, upd_src.size() * 4)))
+    return gh_set_error(ctx, GH_ERR_NOMEM, "block-sparse solver: device allocation failed (update lists: %zu products)", upd_src.size() / 2);
+  GH_HIP(ctx, hipMemcpyAsync(d_rowptr, P.rowptr.data(), P.rowptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(d_rowlist, P.rowlist.data(), P.rowlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!upd_off.empty()) {
+    GH_HIP(ctx, hipMemcpyAsync(d_upd_off, upd_off.data(), upd_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(d_upd_cs, upd_cs.data(), upd_cs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(d_upd_src, upd_src.data(), upd_src.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  GH_HIP(ctx, hipMemcpyAsync(d_upd_ptr, upd_ptr.data(), upd_ptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(d_colptr, P.colptr.data(), P.colptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(d_rows, P.rows.data(), P.rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(d_slot_col, P.slot_col.data(), P.slot_col.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -334,15 +398,18 @@ gh_status BsSolver::factor_solve(gh_ctx* ctx, double radius, const double* g_dev
   GH_LAUNCH(ctx, "bs_prepare", bs_prepare_kernel, dim3(gh_div_up(7 * P.nf, 256)), dim3(256), 0, (const int32_t*)d_pos, P.nf, P.ns, d_W,
             off_root, ldr, radius, g_dev, d_b);
   for (int r = 0; r < P.n_rounds; ++r) {
-    const int c0 = P.round_ptr[r], c1 = P.round_ptr[r + 1], g0 = P.colptr[c0], g1 = P.colptr[c1];
-    GH_LAUNCH(ctx, "bs_factor_cols", bs_factor_cols_kernel, dim3(c1 - c0), dim3(64), 0, (const int32_t*)d_colptr, (const int32_t*)d_rows,
-              d_W, off_slots, d_Ld, d_y, d_b, c0, d_flag);
-    if (g1 > g0)
-      GH_LAUNCH(ctx, "bs_update", bs_update_kernel, dim3(g1 - g0), dim3(256), 0, (const int32_t*)d_colptr, (const int32_t*)d_rows,
-                (const int32_t*)d_slot_col, d_W, off_slots, off_root, P.ns, ldr, g0);
+    const int c0 = P.round_ptr[r], c1 = P.round_ptr[r + 1], u0 = upd_round[r], u1 = upd_round[r + 1];
+    GH_LAUNCH(ctx, "bs_factor_cols", bs_factor_cols_kernel, dim3(c1 - c0), dim3(64), 0, (const int32_t*)d_colptr, (const int32_t*)d_rowptr,
+              (const int32_t*)d_rowlist, (const int32_t*)d_slot_col, d_W, off_slots, d_Ld, d_y, (const double*)d_b, c0, d_flag);
+    if (u1 > u0)
+      GH_LAUNCH(ctx, "bs_update", bs_update_kernel, dim3(gh_div_up(u1 - u0, 4)), dim3(256), 0, (const int64_t*)d_upd_off,
+                (const int32_t*)d_upd_cs, (const int32_t*)d_upd_ptr, (const int2*)d_upd_src, d_W, off_slots, u0, u1);
   }
   if (P.nr > 0) {
     int dinfo = 0;
+    if (P.ns > 0)
+      GH_LAUNCH(ctx, "bs_root_rhs", bs_root_rhs_kernel, dim3(gh_div_up(nr7, 256)), dim3(256), 0, (const int32_t*)d_rowptr,
+                (const int32_t*)d_rowlist, (const int32_t*)d_slot_col, (const double*)d_W, off_slots, (const double*)d_y, d_b, P.ns, P.nf);
     GH_TRY(gh_potrf_solve_dev(ctx, d_W + off_root, nr7, ldr, d_b + (size_t)7 * P.ns, &dinfo));
     if (dinfo) {
       *info = P.nf + dinfo;

@@ -124,6 +124,8 @@ def test_numeric_factorisation_against_numpy(nf, loops, root_min):
     x, info = posegraph.bs_solve(ctx, prow, pcol, to_colmajor(diag), to_colmajor(off), g, radius=radius, root_min=root_min)
     assert info == 0
     assert np.max(np.abs(x - ref)) <= 1e-9 * np.max(np.abs(ref))
+    x2, _ = posegraph.bs_solve(ctx, prow, pcol, to_colmajor(diag), to_colmajor(off), g, radius=radius, root_min=root_min)
+    assert x2.tobytes() == x.tobytes()  # no atomics: bitwise reproducible
 
 
 @pytest.mark.gpu
