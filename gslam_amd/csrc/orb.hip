@@ -658,13 +658,13 @@ template <bool CACHED>
 __global__ __launch_bounds__(256) void select_kernel(SelectArgs a, const uint32_t* __restrict__ cell_cnt,
                                                      const uint32_t* __restrict__ cell_ent, int cells_per_frame,
                                                      int K, SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt,
-                                                     uint32_t* __restrict__ dbg) {
+                                                     uint32_t* __restrict__ dbg, int level0) {
   // bin k lives at k + (k >> 5): a thread's 32 consecutive bins (tid * 32 + i) then fall into different banks for
   // different threads (unpadded, all 64 lanes of a wave hit bank i)
   __shared__ uint32_t hist[kHistBins + kHistBins / 32];
   __shared__ int wave_tot[4];
   __shared__ int s_cut, s_m;
-  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int l = level0 + blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int ncells = a.ncells[l], quota = a.quota[l];
   const uint32_t* rec = cell_cnt + ((size_t)b * cells_per_frame + a.cell_off[l]) * kCellRec;
   const uint32_t* ent = cell_ent + ((size_t)b * cells_per_frame + a.cell_off[l]) * kCap;
@@ -1053,6 +1053,9 @@ struct gh_orb_plan {
   // host staging for gh_orb_extract_host
   // single-frame host entry point: device staging (image; count | keypoints | descriptors in ONE block so that the
   // results come back in one copy) and a pinned host mirror of the result block
+  // batched calls: select(level l) runs on a side stream beside fast_cells(l + 1 ..) (gh_orb_extract_dev)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_level[kMaxL]{}, ev_join = nullptr;
   uint8_t* stage_img = nullptr;
   uint8_t* stage_out = nullptr;
   uint8_t* stage_host = nullptr;  // hipHostMalloc
@@ -1084,6 +1087,13 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   for (void* q : ptrs)
     if (q) hipFree(q);
   if (p->stage_host) hipHostFree(p->stage_host);
+  if (p->side) {
+    hipStreamSynchronize(p->side);
+    hipStreamDestroy(p->side);
+  }
+  for (hipEvent_t e : p->ev_level)
+    if (e) hipEventDestroy(e);
+  if (p->ev_join) hipEventDestroy(p->ev_join);
   delete p;
 }
 
@@ -1358,49 +1368,87 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
               ResizeTabs{p->xtab[l], p->xsel[l], p->xwgt[l], p->ytab[l]}, gpr, inv, n_items, unsafe_frame);
     return GH_OK;
   };
+  SelectArgs sa;
+  for (int l = 0; l < kMaxL; ++l) {
+    sa.ncells[l] = l < L ? p->ncx[l] * p->ncy[l] : 0;
+    sa.cell_off[l] = l < L ? p->cell_off[l] : 0;
+    sa.ncx[l] = l < L && p->ncx[l] > 0 ? p->ncx[l] : 1;
+    sa.quota[l] = l < L ? p->quota[l] : 0;
+    sa.quota_off[l] = l < L ? p->quota_off[l] : 0;
+  }
+  int max_cells = 0;
+  for (int l = 0; l < L; ++l) max_cells = sa.ncells[l] > max_cells ? sa.ncells[l] : max_cells;
+  static const bool no_cache = [] {
+    const char* e = getenv("GSLAM_HIP_ORB_SELECT_CACHED");  // "0": stream the records (A/B measurements)
+    return e && e[0] == '0';
+  }();
+  const bool cached = max_cells <= kSelCached * 256 && !no_cache;
+  auto launch_select = [&](int l0, int nl) -> gh_status {
+    if (cached)
+      GH_LAUNCH(ctx, "orb_select", select_kernel<true>, dim3(nl, batch), dim3(256), 0, sa, p->cell_cnt, p->cell_ent,
+                p->cells_per_frame, K, p->sel, p->level_cnt, dbg, l0);
+    else
+      GH_LAUNCH(ctx, "orb_select", select_kernel<false>, dim3(nl, batch), dim3(256), 0, sa, p->cell_cnt, p->cell_ent,
+                p->cells_per_frame, K, p->sel, p->level_cnt, dbg, l0);
+    return GH_OK;
+  };
+  // select(l) needs fast_cells(l) only, and it is a latency-bound kernel (histogram + three passes over the cell
+  // records): in a batched call it runs on a side stream beside the VALU-bound fast_cells of the levels that follow,
+  // instead of as one launch behind the last level.  A single frame keeps the one launch (8 more launches and 9 event
+  // operations would cost more than the overlap gives).  GSLAM_HIP_ORB_SELECT_OVERLAP=0 / 1 forces either.
+  static const int overlap_env = [] {
+    const char* e = getenv("GSLAM_HIP_ORB_SELECT_OVERLAP");
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  bool overlap = overlap_env < 0 ? batch >= 16 : overlap_env == 1;
+  if (overlap && !p->side) {
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
+      p->side = nullptr;
+      overlap = false;
+    } else {
+      bool ok = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
+      for (int l = 0; l < kMaxL && ok; ++l) ok = hipEventCreateWithFlags(&p->ev_level[l], hipEventDisableTiming) == hipSuccess;
+      if (!ok) return gh_set_error(ctx, GH_ERR_HIP, "gh_orb_extract_dev: event creation failed");
+    }
+  }
+  struct StreamSwap {  // GH_LAUNCH launches (and profiles) on ctx->stream
+    gh_ctx* c;
+    hipStream_t keep;
+    StreamSwap(gh_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = keep; }
+  };
   for (int l = 0; l < L; ++l) {
     const bool fast = p->ncx[l] != 0 && p->quota[l] > 0;
     if (!fast) {
       if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
-      continue;
+    } else {
+      NextLevel nx{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
+      if (l + 1 < L && p->fuse_pyramid)
+        nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1],
+                       ResizeTabs{p->xtab[l + 1], p->xsel[l + 1], p->xwgt[l + 1], p->ytab[l + 1]},
+                       p->own_gx[l], p->own_gy[l], (l == 0 && aligned0) ? batch - 1 : -1};
+      const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
+      GH_CHECK_ARG(ctx, tiles < (1LL << 30));
+      dim3 grid(8 * gh_div_up(tiles, 8));
+      GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
+                p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
+                batch, nx, dbg);
+      if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
     }
-    NextLevel nx{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
-    if (l + 1 < L && p->fuse_pyramid)
-      nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1],
-                     ResizeTabs{p->xtab[l + 1], p->xsel[l + 1], p->xwgt[l + 1], p->ytab[l + 1]},
-                     p->own_gx[l], p->own_gy[l], (l == 0 && aligned0) ? batch - 1 : -1};
-    const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
-    GH_CHECK_ARG(ctx, tiles < (1LL << 30));
-    dim3 grid(8 * gh_div_up(tiles, 8));
-    GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
-              p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-              batch, nx, dbg);
-    if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
-  }
-  {
-    SelectArgs a;
-    for (int l = 0; l < kMaxL; ++l) {
-      a.ncells[l] = l < L ? p->ncx[l] * p->ncy[l] : 0;
-      a.cell_off[l] = l < L ? p->cell_off[l] : 0;
-      a.ncx[l] = l < L && p->ncx[l] > 0 ? p->ncx[l] : 1;
-      a.quota[l] = l < L ? p->quota[l] : 0;
-      a.quota_off[l] = l < L ? p->quota_off[l] : 0;
-    }
-    int max_cells = 0;
-    for (int l = 0; l < L; ++l) max_cells = a.ncells[l] > max_cells ? a.ncells[l] : max_cells;
-    static const bool no_cache = [] {
-      const char* e = getenv("GSLAM_HIP_ORB_SELECT_CACHED");  // "0": stream the records (A/B measurements)
-      return e && e[0] == '0';
-    }();
-    if (max_cells <= kSelCached * 256 && !no_cache)
-      GH_LAUNCH(ctx, "orb_select", select_kernel<true>, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
-                p->cells_per_frame, K, p->sel, p->level_cnt, dbg);
-    else {
-      GH_LAUNCH(ctx, "orb_select", select_kernel<false>, dim3(L, batch), dim3(256), 0, a, p->cell_cnt, p->cell_ent,
-                p->cells_per_frame, K, p->sel, p->level_cnt, dbg);
-      if (dbg) GH_HIP(ctx, hipMemsetAsync(dbg + kDbgSelStreamed, 1, 1, ctx->stream));
+    if (overlap) {  // (a level without a FAST pass still gets its level_cnt = 0 from select)
+      GH_HIP(ctx, hipEventRecord(p->ev_level[l], ctx->stream));
+      GH_HIP(ctx, hipStreamWaitEvent(p->side, p->ev_level[l], 0));
+      StreamSwap sw(ctx, p->side);
+      GH_TRY(launch_select(l, 1));
     }
   }
+  if (overlap) {
+    GH_HIP(ctx, hipEventRecord(p->ev_join, p->side));
+    GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->ev_join, 0));
+  } else {
+    GH_TRY(launch_select(0, L));
+  }
+  if (!cached && dbg) GH_HIP(ctx, hipMemsetAsync(dbg + kDbgSelStreamed, 1, 1, ctx->stream));
   {
     DescribeArgs a;
     for (int l = 0; l < kMaxL; ++l) {
