@@ -399,7 +399,8 @@ def main():
                 "stages": "FAST/NMS read of all levels (3.096 W H) + pyramid reads and writes (5.114 W H): the next level is "
                           "resized inside this kernel" if fused_pyramid else "FAST/NMS read of all levels (3.096 W H)",
                 "note": "HBM is the contractual bound (SURVEY.md 8d); SQ counters show this kernel VALU-issue bound "
-                        "(profiles/README.md), so frac understates how close the kernel is to ITS limit"}
+                        "(profiles/README.md), so frac understates how close the kernel is to ITS limit; its launches "
+                        "share the GPU with orb_select on a side stream (1.60 ms alone, GSLAM_HIP_ORB_SELECT_OVERLAP=0)"}
     # VALU-issue view of the same kernel.  The ceiling is MEASURED in this run (gh_valu_issue_probe: register-only chains of
     # each instruction class, 8 waves / SIMD); the kernel's instruction count per launch comes from a separate
     # rocprofv3 --pmc pass (SQ_INSTS_VALU, profiles/sq_counters.json) and is labelled as such.
