@@ -138,3 +138,72 @@ def test_numeric_factorisation_reports_a_bad_pivot():
     diag[7] = -np.eye(7)
     x, info = posegraph.bs_solve(ctx, prow, pcol, to_colmajor(diag), to_colmajor(off), np.ones(7 * nf), radius=1e30, root_min=4)
     assert info != 0
+
+
+def _random_graph(rng, nf, density):
+    pairs = set()
+    for a in range(nf):
+        for b in range(a):
+            if rng.random() < density:
+                pairs.add((a, b))
+    if not pairs:
+        pairs.add((nf - 1, 0))
+    pairs = sorted(pairs)
+    return np.array([p[0] for p in pairs], np.int32), np.array([p[1] for p in pairs], np.int32)
+
+
+def test_symbolic_fuzz_random_graphs():
+    """Arbitrary keyframe graphs (trees, dense clusters, disconnected parts): positions are a permutation, rounds are
+    independent sets, and the predicted pattern contains the exact fill of the elimination order."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(2, 36), st.floats(0.02, 0.6), st.integers(1, 12), st.integers(0, 2**31 - 1))
+    def run(nf, density, root_min, seed):
+        rng = np.random.default_rng(seed)
+        prow, pcol = _random_graph(rng, nf, density)
+        sym = posegraph.bs_symbolic(nf, prow, pcol, root_min=root_min)
+        pos, ns = sym["pos"], sym["ns"]
+        assert sorted(pos.tolist()) == list(range(nf))
+        assert sym["nr"] >= min(root_min, nf)
+        colptr, rows, rp = sym["colptr"], sym["rows"], sym["round_ptr"]
+        # exact symbolic elimination of the permuted graph (boolean): every fill block below the diagonal of a sparse
+        # column must be in the pattern, and nothing else may be
+        A = np.zeros((nf, nf), bool)
+        A[pos[prow], pos[pcol]] = True
+        A |= A.T
+        for c in range(ns):
+            nb = np.nonzero(A[c + 1:, c])[0] + c + 1
+            assert rows[colptr[c]:colptr[c + 1]].tolist() == nb.tolist()
+            A[np.ix_(nb, nb)] = True
+            np.fill_diagonal(A, False)
+        rnd = np.full(nf, len(rp))
+        for r in range(len(rp) - 1):
+            rnd[rp[r]:rp[r + 1]] = r
+        for c in range(ns):
+            assert np.all(rnd[rows[colptr[c]:colptr[c + 1]]] > rnd[c])
+
+    run()
+
+
+@pytest.mark.gpu
+def test_numeric_fuzz_random_graphs():
+    from hypothesis import given, settings, strategies as st
+    from gslam_amd import hip
+    ctx = hip.Context()
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(2, 60), st.floats(0.02, 0.5), st.integers(1, 16), st.integers(0, 2**31 - 1))
+    def run(nf, density, root_min, seed):
+        rng = np.random.default_rng(seed)
+        prow, pcol = _random_graph(rng, nf, density)
+        diag, off = spd_blocks(nf, prow, pcol, seed % 1000)
+        H = dense_of(nf, prow, pcol, diag, off)
+        g = rng.standard_normal(7 * nf)
+        radius = 10.0 ** rng.uniform(0, 6)
+        ref = np.linalg.solve(H + np.diag(np.clip(np.diag(H), 1e-6, 1e32) / radius), -g)
+        x, info = posegraph.bs_solve(ctx, prow, pcol, to_colmajor(diag), to_colmajor(off), g, radius=radius, root_min=root_min)
+        assert info == 0
+        assert np.max(np.abs(x - ref)) <= 1e-8 * max(np.max(np.abs(ref)), 1e-30)
+
+    run()
