@@ -1394,13 +1394,13 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   };
   // select(l) needs fast_cells(l) only, and it is a latency-bound kernel (histogram + three passes over the cell
   // records): in a batched call it runs on a side stream beside the VALU-bound fast_cells of the levels that follow,
-  // instead of as one launch behind the last level.  A single frame keeps the one launch (8 more launches and 9 event
-  // operations would cost more than the overlap gives).  GSLAM_HIP_ORB_SELECT_OVERLAP=0 / 1 forces either.
+  // instead of as one launch behind the last level.  Small calls (below 16 Mpixel) keep the one launch (8 more launches and
+  // 9 event operations would cost more than the overlap gives).  GSLAM_HIP_ORB_SELECT_OVERLAP=0 / 1 forces either.
   static const int overlap_env = [] {
     const char* e = getenv("GSLAM_HIP_ORB_SELECT_OVERLAP");
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
-  bool overlap = overlap_env < 0 ? batch >= 16 : overlap_env == 1;
+  bool overlap = overlap_env < 0 ? (long long)batch * p->w * p->h >= (16LL << 20) : overlap_env == 1;  // >= 8 frames of 1080p
   if (overlap && !p->side) {
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
       p->side = nullptr;
