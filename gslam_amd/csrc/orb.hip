@@ -1053,6 +1053,16 @@ struct gh_orb_plan {
   // host staging for gh_orb_extract_host
   // single-frame host entry point: device staging (image; count | keypoints | descriptors in ONE block so that the
   // results come back in one copy) and a pinned host mirror of the result block
+  // small calls are launch-bound (11 launches for a 640x480 frame whose kernels take a few microseconds each): the launch
+  // sequence of a call is captured once per argument set and replayed as ONE hipGraph launch (gh_orb_extract_dev)
+  struct CallGraph {
+    const void *gray, *kps, *desc, *counts;
+    int batch, row_stride;
+    size_t frame_stride;
+    hipGraphExec_t exec;
+  };
+  std::vector<CallGraph> graphs;
+  bool graphs_off = false, capturing = false;
   // batched calls: select(level l) runs on a side stream beside fast_cells(l + 1 ..) (gh_orb_extract_dev)
   hipStream_t side = nullptr;
   hipEvent_t ev_level[kMaxL]{}, ev_join = nullptr;
@@ -1087,6 +1097,7 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   for (void* q : ptrs)
     if (q) hipFree(q);
   if (p->stage_host) hipHostFree(p->stage_host);
+  for (auto& g : p->graphs) hipGraphExecDestroy(g.exec);
   if (p->side) {
     hipStreamSynchronize(p->side);
     hipStreamDestroy(p->side);
@@ -1324,6 +1335,9 @@ extern "C" gh_status gh_orb_plan_level(const gh_orb_plan* p, int level, int* w, 
 
 extern "C" size_t gh_orb_plan_device_bytes(const gh_orb_plan* p) { return p ? p->bytes : 0; }
 
+static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch, size_t frame_stride, int row_stride,
+                             gh_keypoint* kps_dev, uint8_t* desc_dev, int32_t* counts_dev);
+
 extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev, int batch, size_t frame_stride,
                                         int row_stride, gh_keypoint* kps_dev, uint8_t* desc_dev,
                                         int32_t* counts_dev) {
@@ -1335,6 +1349,52 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   GH_CHECK_ARG(ctx, gray_dev && kps_dev && desc_dev && counts_dev && row_stride >= p->w);
   GH_CHECK_ARG(ctx, frame_stride >= (size_t)row_stride * p->h || batch == 1);
   GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 7) == 0 && ((uintptr_t)kps_dev & 3) == 0);
+  // GSLAM_HIP_ORB_GRAPH=0: always launch kernel by kernel (A/B measurements)
+  static const bool graph_env = [] {
+    const char* e = getenv("GSLAM_HIP_ORB_GRAPH");
+    return !(e && e[0] == '0');
+  }();
+  const bool small = (long long)batch * p->w * p->h <= (4LL << 20);  // up to two 1080p frames: launch-bound
+  if (!(graph_env && small && !p->graphs_off && !ctx->prof_on && !p->dbg_on && ctx->stream != nullptr))
+    return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
+  for (const auto& g : p->graphs)
+    if (g.gray == gray_dev && g.kps == kps_dev && g.desc == desc_dev && g.counts == counts_dev && g.batch == batch &&
+        g.row_stride == row_stride && g.frame_stride == frame_stride) {
+      GH_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
+      return GH_OK;
+    }
+  // first call with these arguments: capture the launch sequence (nothing executes during the capture), then replay it
+  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    p->graphs_off = true;  // (a stream that cannot be captured, e.g. the legacy default stream)
+    return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
+  }
+  p->capturing = true;
+  const gh_status st = orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
+  p->capturing = false;
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (st != GH_OK || ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (graph) hipGraphDestroy(graph);
+    p->graphs_off = true;
+    if (st != GH_OK) return st;
+    return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
+  }
+  hipGraphDestroy(graph);
+  if (p->graphs.size() >= 8) {  // a ring of staging slots has a handful of argument sets; anything beyond that is churn
+    hipGraphExecDestroy(p->graphs.front().exec);
+    p->graphs.erase(p->graphs.begin());
+  }
+  p->graphs.push_back({gray_dev, kps_dev, desc_dev, counts_dev, batch, row_stride, frame_stride, exec});
+  GH_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+  return GH_OK;
+}
+
+static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch, size_t frame_stride, int row_stride,
+                             gh_keypoint* kps_dev, uint8_t* desc_dev, int32_t* counts_dev) {
+  gh_ctx* ctx = p->ctx;
   const int L = p->L, K = p->prm.n_features;
 
   LevelView lv[kMaxL];
@@ -1401,6 +1461,7 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   bool overlap = overlap_env < 0 ? (long long)batch * p->w * p->h >= (16LL << 20) : overlap_env == 1;  // >= 8 frames of 1080p
+  if (p->capturing) overlap = false;  // (a captured call is a small one: one select launch)
   if (overlap && !p->side) {
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
       p->side = nullptr;
