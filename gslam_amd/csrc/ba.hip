@@ -2075,6 +2075,252 @@ extern "C" gh_status gh_ba_graph_read(gh_ba_graph* g, double* cam_pose, double* 
   return GH_OK;
 }
 
+// ---------------------------------------------------------------- pose-only LM in ONE launch
+// optimizePnP / optimizePose are called once per frame by a tracking front end (GSLAM/core/Optimizer.h:193-207): one
+// camera, a few hundred fixed points, ~10 LM iterations.  Through gh_ba_solve that is ~10 x (6 launches + a host round
+// trip) plus the list building of a general graph: 0.5 ms of pure latency.  Here the whole LM loop runs inside one
+// workgroup -- linearisation, the 6 x 6 damped solve, candidate cost, accept / reject, trust-region update -- with
+// fixed-shape block reductions, and the host sees one upload, one launch and one download.  Same algorithm, same
+// policy constants and the same per-observation arithmetic (linearize<>, se3_retract) as the general path and
+// oracle/ba_oracle.c; only the order of the sums over the observations differs (within the parity tolerance).
+namespace {
+
+struct PnpResult {
+  gh_ba_summary sum;
+  double pose[7];
+  double info[36];
+};
+
+// v[0..N) summed over the 256 threads of the block in a fixed order; the totals land in tot[0..N) (valid after return)
+template <int N>
+__device__ inline void pnp_block_sum(double* v, double (*red)[36], double* tot) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double x = v[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    if (lane == 0) red[wv][i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) tot[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pnp_lm_kernel(const double* __restrict__ X, const double* __restrict__ M, int n,
+                                                     const double* __restrict__ pose_in, int dof, gh_ba_options opt,
+                                                     int want_info, PnpResult* __restrict__ out) {
+  __shared__ double s_pose[7], s_dc[6], s_red[4][36], s_tot[36];
+  __shared__ double s_cost, s_radius, s_decrease;
+  __shared__ int s_ctl[4];  // [0] stop, [1] solve ok, [2] need_lin
+  const int tid = threadIdx.x;
+  const double huber = opt.huber_delta;
+  if (tid < 7) s_pose[tid] = pose_in[tid];
+  __syncthreads();
+  auto rho_of = [&](double s) { return (huber > 0 && s > huber * huber) ? 2.0 * huber * sqrt(s) - huber * huber : s; };
+  // robust cost at `pose` (sum of rho, not yet halved); with `old`: infinite if an observation valid at `old` is lost
+  auto cost_pass = [&](const double* pose, const double* old) {
+    double c = 0;
+    for (int k = tid; k < n; k += 256) {
+      Obs o;
+      const bool in_front = linearize<false>(pose, 0, X + 3 * k, 0, M + 2 * k, nullptr, huber, o);
+      double ck = in_front ? rho_of(o.s) : 0.0;
+      if (old != nullptr && !in_front && linearize<false>(old, 0, X + 3 * k, 0, M + 2 * k, nullptr, huber, o)) ck = __builtin_inf();
+      c += ck;
+    }
+    return c;
+  };
+  double v[36];
+  v[0] = cost_pass(s_pose, nullptr);
+  pnp_block_sum<1>(v, s_red, s_tot);
+  if (tid == 0) {
+    s_cost = 0.5 * s_tot[0];
+    s_radius = opt.initial_radius;
+    s_decrease = 2.0;
+    s_ctl[0] = 0;
+    s_ctl[2] = 1;
+    out->sum.initial_cost = s_cost;
+    out->sum.trace_len = 0;
+    out->sum.accepted = 0;
+  }
+  __syncthreads();
+  double H[21], g[6];  // lower triangle of J^T L J (row a >= column b at a (a + 1) / 2 + b) and J^T L r: thread 0 keeps them
+  int it = 0, term = 0;
+  for (it = 0; it < opt.max_iterations; ++it) {
+    if (s_ctl[2]) {
+      for (int i = 0; i < 27; ++i) v[i] = 0;
+      for (int k = tid; k < n; k += 256) {
+        Obs o;
+        if (!linearize<true>(s_pose, dof, X + 3 * k, 0, M + 2 * k, nullptr, huber, o)) continue;
+        double L[4];
+        weighted_info(nullptr, o.w, L);
+        const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
+        double LJ[12];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          LJ[j] = L[0] * o.Jc[j] + L[1] * o.Jc[6 + j];
+          LJ[6 + j] = L[2] * o.Jc[j] + L[3] * o.Jc[6 + j];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          v[21 + a] += o.Jc[a] * Lr[0] + o.Jc[6 + a] * Lr[1];
+#pragma unroll
+          for (int b = 0; b <= a; ++b) v[a * (a + 1) / 2 + b] += o.Jc[a] * LJ[b] + o.Jc[6 + a] * LJ[6 + b];
+        }
+      }
+      pnp_block_sum<27>(v, s_red, s_tot);
+      if (tid == 0) {
+        double gmax = 0;
+        for (int i = 0; i < 21; ++i) H[i] = s_tot[i];
+        for (int a = 0; a < 6; ++a) {
+          g[a] = s_tot[21 + a];
+          gmax = fmax(gmax, fabs(g[a]));
+        }
+        if (gmax <= opt.gradient_tolerance) s_ctl[0] = 2;  // termination 2, nothing recorded for this iteration
+        s_ctl[2] = 0;
+      }
+      __syncthreads();
+      if (s_ctl[0] == 2) {
+        term = 2;
+        break;
+      }
+    }
+    if (tid == 0) {  // damped 6 x 6 system, Cholesky, dc = -(H + D)^-1 g
+      const double radius = s_radius;
+      double Lc[21];
+      bool ok = true;
+      for (int j = 0; j < 6 && ok; ++j) {
+        const double hjj = H[j * (j + 1) / 2 + j];
+        double d = hjj + (hjj < 1e-6 ? 1e-6 : (hjj > 1e32 ? 1e32 : hjj)) / radius;
+        for (int k = 0; k < j; ++k) d -= Lc[j * (j + 1) / 2 + k] * Lc[j * (j + 1) / 2 + k];
+        if (!(d > 0.0)) {
+          ok = false;
+          break;
+        }
+        const double ljj = sqrt(d);
+        Lc[j * (j + 1) / 2 + j] = ljj;
+        for (int i = j + 1; i < 6; ++i) {
+          double x = H[i * (i + 1) / 2 + j];
+          for (int k = 0; k < j; ++k) x -= Lc[i * (i + 1) / 2 + k] * Lc[j * (j + 1) / 2 + k];
+          Lc[i * (i + 1) / 2 + j] = x / ljj;
+        }
+      }
+      if (ok) {
+        double y[6];
+        for (int i = 0; i < 6; ++i) {
+          double x = -g[i];
+          for (int k = 0; k < i; ++k) x -= Lc[i * (i + 1) / 2 + k] * y[k];
+          y[i] = x / Lc[i * (i + 1) / 2 + i];
+        }
+        for (int i = 5; i >= 0; --i) {
+          double x = y[i];
+          for (int k = i + 1; k < 6; ++k) x -= Lc[k * (k + 1) / 2 + i] * y[k];
+          y[i] = x / Lc[i * (i + 1) / 2 + i];
+        }
+        for (int i = 0; i < 6; ++i) s_dc[i] = y[i];
+      }
+      s_ctl[1] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = s_ctl[1] != 0;
+    double pnew[7];
+    if (ok) {
+      double dc[6];
+      for (int a = 0; a < 6; ++a) dc[a] = s_dc[a];
+      if ((dof & 63) == 0) {
+        for (int i = 0; i < 7; ++i) pnew[i] = s_pose[i];
+      } else {
+        double cur[7];
+        for (int i = 0; i < 7; ++i) cur[i] = s_pose[i];
+        se3_retract(cur, dc, pnew);
+      }
+      double model = 0;
+      for (int k = tid; k < n; k += 256) {
+        Obs o;
+        if (!linearize<true>(s_pose, dof, X + 3 * k, 0, M + 2 * k, nullptr, huber, o)) continue;
+        double L[4];
+        weighted_info(nullptr, o.w, L);
+        double Jd[2] = {0, 0};
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          Jd[0] += o.Jc[a] * dc[a];
+          Jd[1] += o.Jc[6 + a] * dc[a];
+        }
+        const double LJd[2] = {L[0] * Jd[0] + L[1] * Jd[1], L[2] * Jd[0] + L[3] * Jd[1]};
+        const double Lr[2] = {L[0] * o.r[0] + L[1] * o.r[1], L[2] * o.r[0] + L[3] * o.r[1]};
+        model -= Jd[0] * Lr[0] + Jd[1] * Lr[1] + 0.5 * (Jd[0] * LJd[0] + Jd[1] * LJd[1]);
+      }
+      v[0] = cost_pass(pnew, s_pose);
+      v[1] = model;
+      pnp_block_sum<2>(v, s_red, s_tot);
+    }
+    if (tid == 0) {
+      const double cost = s_cost, radius = s_radius;
+      double new_cost = cost, model = 0, rho = -1;
+      if (ok) {
+        new_cost = 0.5 * s_tot[0];
+        model = s_tot[1];
+        rho = model > 0 ? (cost - new_cost) / model : -1;
+        if (!(new_cost == new_cost)) rho = -1;
+      }
+      const bool acc = ok && rho > opt.min_relative_decrease;
+      const int tl = out->sum.trace_len;
+      if (tl < GH_BA_MAX_TRACE) {
+        out->sum.trace_cost[tl] = new_cost;
+        out->sum.trace_radius[tl] = radius;
+        out->sum.trace_accepted[tl] = (uint8_t)acc;
+        out->sum.trace_len = tl + 1;
+      }
+      if (acc) {
+        const double dcost = cost - new_cost;
+        for (int i = 0; i < 7; ++i) s_pose[i] = pnew[i];
+        const double t = 2.0 * rho - 1.0;
+        double r2 = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        if (r2 > 1e16) r2 = 1e16;
+        s_radius = r2;
+        s_decrease = 2.0;
+        out->sum.accepted = out->sum.accepted + 1;
+        s_ctl[2] = 1;
+        s_cost = new_cost;
+        if (fabs(dcost) <= opt.function_tolerance * cost) s_ctl[0] = 1;
+      } else {
+        s_radius = radius / s_decrease;
+        s_decrease = s_decrease * 2.0;
+        if (s_radius < 1e-32) s_ctl[0] = 3;
+      }
+    }
+    __syncthreads();
+    if (s_ctl[0] != 0) {
+      term = s_ctl[0];
+      ++it;
+      break;
+    }
+  }
+  if (want_info) {  // J^T W J at the solution (columns masked by dof), W = the Huber IRLS weight
+    for (int i = 0; i < 36; ++i) v[i] = 0;
+    for (int k = tid; k < n; k += 256) {
+      Obs o;
+      if (!linearize<true>(s_pose, dof, X + 3 * k, 0, M + 2 * k, nullptr, huber, o)) continue;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) v[6 * a + b] += o.w * (o.Jc[a] * o.Jc[b] + o.Jc[6 + a] * o.Jc[6 + b]);
+    }
+    pnp_block_sum<36>(v, s_red, s_tot);
+    if (tid < 36) out->info[tid] = s_tot[tid];
+  }
+  if (tid == 0) {
+    out->sum.iterations = it;
+    out->sum.termination = term;
+    out->sum.final_cost = s_cost;
+    out->sum.solve_ms_total = 0;
+    out->sum.total_ms = 0;
+    for (int i = 0; i < 7; ++i) out->pose[i] = s_pose[i];
+  }
+}
+
+}  // namespace
+
 // Pose-only optimisation = the same solver on a 1-camera graph with every point fixed.
 extern "C" gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy, int n, double* pose,
                                int dof, const gh_ba_options* options, double* information_out,
@@ -2082,6 +2328,42 @@ extern "C" gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const doub
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, n >= 0 && pose && (n == 0 || (points_xyz && obs_xy)));
+  {
+    gh_ba_options o;
+    gh_ba_default_options(&o);
+    if (options) o = *options;
+    const char* pe = getenv("GSLAM_HIP_PNP_KERNEL");  // "0": through the general solver (A/B measurements, tests of both)
+    const bool kernel_env = !(pe && pe[0] == '0');
+    if (kernel_env && !o.verbose && n <= 65536) {
+      // one pinned block up ([points | observations | pose]), one launch, one pinned block down
+      const double t0 = now_ms();
+      const size_t in_doubles = (size_t)5 * n + 7, in_bytes = (in_doubles * 8 + 255) & ~(size_t)255;
+      char *hp = nullptr, *dp = nullptr;
+      GH_TRY(gh_pinned(ctx, in_bytes + sizeof(PnpResult), (void**)&hp));
+      GH_TRY(gh_scratch(ctx, in_bytes + sizeof(PnpResult), (void**)&dp));
+      double* hin = reinterpret_cast<double*>(hp);
+      if (n) {
+        memcpy(hin, points_xyz, (size_t)3 * n * 8);
+        memcpy(hin + (size_t)3 * n, obs_xy, (size_t)2 * n * 8);
+      }
+      memcpy(hin + (size_t)5 * n, pose, 56);
+      GH_HIP(ctx, hipMemcpyAsync(dp, hp, in_doubles * 8, hipMemcpyHostToDevice, ctx->stream));
+      const double* din = reinterpret_cast<const double*>(dp);
+      PnpResult* dres = reinterpret_cast<PnpResult*>(dp + in_bytes);
+      GH_LAUNCH(ctx, "ba_pnp_lm", pnp_lm_kernel, dim3(1), dim3(256), 0, din, din + (size_t)3 * n, n, din + (size_t)5 * n, dof, o,
+                information_out ? 1 : 0, dres);
+      PnpResult* hres = reinterpret_cast<PnpResult*>(hp + in_bytes);
+      GH_HIP(ctx, hipMemcpyAsync(hres, dres, sizeof(PnpResult), hipMemcpyDeviceToHost, ctx->stream));
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      memcpy(pose, hres->pose, 56);
+      if (information_out) memcpy(information_out, hres->info, 36 * 8);
+      if (summary) {
+        *summary = hres->sum;
+        summary->total_ms = now_ms() - t0;
+      }
+      return hres->sum.termination == 3 ? GH_ERR_NUMERIC : GH_OK;
+    }
+  }
   std::vector<int32_t> ocam((size_t)(n > 0 ? n : 1), 0), opt((size_t)(n > 0 ? n : 1));
   std::vector<uint8_t> pfree((size_t)(n > 0 ? n : 1), 0);
   std::vector<double> pts(points_xyz, points_xyz + (size_t)3 * n);

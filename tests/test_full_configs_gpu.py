@@ -117,8 +117,12 @@ def _pnp_case(oracle, seed, n_pts, noise, outlier_every):
 @pytest.mark.parametrize("seed,n_pts,noise,outlier_every,huber,dof",
                          [(41, 200, 0.002, 7, 0.01, 63), (42, 1000, 0.002, 5, 0.01, 63), (43, 60, 0.004, 0, 0.0, 63),
                           (44, 300, 0.002, 9, 0.01, 0b111000), (45, 300, 0.002, 9, 0.01, 0b000111)])
-def test_pnp_parity_noisy_huber(ctx, oracle, seed, n_pts, noise, outlier_every, huber, dof):
+@pytest.mark.parametrize("path", ["one_launch", "general_solver"])
+def test_pnp_parity_noisy_huber(ctx, oracle, monkeypatch, path, seed, n_pts, noise, outlier_every, huber, dof):
+    """Both implementations behind gh_ba_pnp: the single-launch LM kernel (default) and the general solver on a
+    1-camera graph (GSLAM_HIP_PNP_KERNEL=0)."""
     from gslam_amd import ba
+    monkeypatch.setenv("GSLAM_HIP_PNP_KERNEL", "1" if path == "one_launch" else "0")
     X, m, start = _pnp_case(oracle, seed, n_pts, noise, outlier_every)
     po, so, io, rc = oracle.ba_pnp(X, m, start, dof=dof, opts=oracle_lib.ba_options(huber=huber, max_iterations=50),
                                    want_information=True)
@@ -136,3 +140,27 @@ def test_pnp_parity_noisy_huber(ctx, oracle, seed, n_pts, noise, outlier_every, 
     assert so.final_cost < so.initial_cost
     if dof == 0b111000:  # rotation only: translation bitwise untouched
         assert np.array_equal(pg[4:], start[4:])
+    used = "ba_pnp_lm" in _kernels_of(ctx, lambda: ba.pnp(ctx, X, m, start, dof=dof, options=ba.default_options(huber_delta=huber, max_iterations=3)))
+    assert used == (path == "one_launch")
+
+
+def _kernels_of(ctx, fn):
+    ctx.prof_enable(True)
+    try:
+        fn()
+        return set(ctx.prof_collect().keys())
+    finally:
+        ctx.prof_enable(False)
+
+
+def test_pnp_degenerate_inputs(ctx, oracle):
+    """No observation, every point behind the camera, and fewer points than unknowns: same answers as the oracle."""
+    from gslam_amd import ba
+    start = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for X, m in ((np.zeros((0, 3)), np.zeros((0, 2))), (np.array([[0.1, 0.2, -3.0], [0.0, 0.1, -2.0]]), np.zeros((2, 2))),
+                 (np.array([[0.1, 0.2, 3.0], [-0.3, 0.1, 2.0]]), np.array([[0.05, 0.06], [-0.14, 0.06]]))):
+        po, so, io, rc = oracle.ba_pnp(X, m, start, dof=63, opts=oracle_lib.ba_options(huber=0.01, max_iterations=20), want_information=True)
+        pg, sg, ig = ba.pnp(ctx, X, m, start, dof=63, options=ba.default_options(huber_delta=0.01, max_iterations=20), want_information=True)
+        assert (sg.iterations, sg.accepted, sg.termination, sg.trace_len) == (so.iterations, so.accepted, so.termination, so.trace_len)
+        assert np.abs(pg - po).max() <= 1e-8 and np.abs(ig - io).max() <= 1e-9 * max(np.abs(io).max(), 1e-300)
+        assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost + 1e-20
