@@ -127,6 +127,68 @@ __global__ __launch_bounds__(64) void bf_match_single_kernel(const uint32_t* __r
   bf_wave(q, nq, t, nt, nq, idx1, d1, d2);
 }
 
+// One frame pair alone (the per-frame call of a tracking front end) leaves the machine empty with one wave per 64 * kQPT
+// queries: the kernel is then a latency chain of nt x kQPT distance evaluations per wave (~100 us at 1000 x 1000).  Here a
+// workgroup takes 64 queries and its S waves split the TRAIN rows; the partial (best, second) keys meet in LDS.  The
+// keys carry the global train index, so the merged minimum / second minimum are the ones of the single sweep, bit for bit.
+__global__ __launch_bounds__(1024) void bf_match_split_kernel(const uint32_t* __restrict__ q_words, int nq,
+                                                              const uint32_t* __restrict__ t_words, int nt, int chunk,
+                                                              int32_t* __restrict__ idx1, uint16_t* __restrict__ d1,
+                                                              uint16_t* __restrict__ d2) {
+  __shared__ uint32_t sb[16][64], ss[16][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), S = blockDim.x >> 6;
+  const int qi = blockIdx.x * 64 + lane;
+  const int qc = qi < nq ? qi : nq - 1;
+  QueryRegs q;
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(q_words + (size_t)qc * 8);
+    const uint4 a = p[0], b = p[1];
+    q.w[0] = a.x; q.w[1] = a.y; q.w[2] = a.z; q.w[3] = a.w;
+    q.w[4] = b.x; q.w[5] = b.y; q.w[6] = b.z; q.w[7] = b.w;
+  }
+  uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+  int j = w * chunk;
+  const int j1 = min(nt, j + chunk);
+  for (; j + 4 <= j1; j += 4) {
+    uint32_t t[4][8];
+    const uint32_t* tp = t_words + (size_t)j * 8;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[u][k] = tp[u * 8 + k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t key = make_key(dist256(q, t[u]), (uint32_t)(j + u));
+      second = umed3(key, best, second);
+      best = min(best, key);
+    }
+  }
+  for (; j < j1; ++j) {
+    uint32_t t[8];
+    const uint32_t* tp = t_words + (size_t)j * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = tp[k];
+    const uint32_t key = make_key(dist256(q, t), (uint32_t)j);
+    second = umed3(key, best, second);
+    best = min(best, key);
+  }
+  sb[w][lane] = best;
+  ss[w][lane] = second;
+  __syncthreads();
+  if (w != 0 || qi >= nq) return;
+  for (int s2 = 1; s2 < S; ++s2) {
+    const uint32_t kb = sb[s2][lane], ks = ss[s2][lane];
+    second = umed3(kb, best, second);
+    best = min(best, kb);
+    second = umed3(ks, best, second);
+    best = min(best, ks);
+  }
+  idx1[qi] = (best == 0xFFFFFFFFu) ? -1 : (int32_t)(best & 0xFFFFu);
+  d1[qi] = (uint16_t)(best >> 16);
+  d2[qi] = (uint16_t)(second >> 16);
+}
+
 __global__ __launch_bounds__(64) void bf_match_pairs_kernel(const uint32_t* __restrict__ desc,
                                                             const int32_t* __restrict__ counts, int cap,
                                                             const int32_t* __restrict__ pair_q,
@@ -237,6 +299,18 @@ extern "C" gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, 
   if (nq == 0) return GH_OK;
   GH_CHECK_ARG(ctx, q_dev && idx1_dev && d1_dev && d2_dev && (nt == 0 || t_dev));
   GH_CHECK_ARG(ctx, ((uintptr_t)q_dev & 15) == 0 && ((uintptr_t)t_dev & 3) == 0);
+  // few queries: split the train rows over the waves of a workgroup (latency); many: one wave per 64 * kQPT queries
+  static const bool split_env = [] {
+    const char* e = getenv("GSLAM_HIP_BF_SPLIT");  // "0": always the one-wave sweep (A/B measurements)
+    return !(e && e[0] == '0');
+  }();
+  const int S = nt / 64 < 1 ? 1 : (nt / 64 > 16 ? 16 : nt / 64);
+  if (split_env && S > 1 && (long long)gh_div_up(nq, 64) * S <= 4096) {
+    const int chunk = (gh_div_up(nt, S) + 3) & ~3;
+    GH_LAUNCH(ctx, "bf_match_split", bf_match_split_kernel, dim3(gh_div_up(nq, 64)), dim3(64 * S), 0, (const uint32_t*)q_dev, nq,
+              (const uint32_t*)t_dev, nt, chunk, idx1_dev, d1_dev, d2_dev);
+    return GH_OK;
+  }
   dim3 grid(gh_div_up(nq, kWaveQueries));
   GH_LAUNCH(ctx, "bf_match", bf_match_single_kernel, grid, dim3(64), 0, (const uint32_t*)q_dev, nq,
             (const uint32_t*)t_dev, nt, idx1_dev, d1_dev, d2_dev);
