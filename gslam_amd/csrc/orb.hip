@@ -253,11 +253,11 @@ constexpr int kScoreH = 66;   // score window: 64x64 region + 1 px NMS halo
 constexpr int kScoreOff = 3;  // window col sx is stored at byte sx + 3 so that both cells of a row start dword aligned
 constexpr int kScoreW = 72;   // row pitch (bytes)
 
-__global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
-                                                         uint32_t* __restrict__ cell_cnt,
-                                                         uint32_t* __restrict__ cell_ent, int cells_per_frame,
-                                                         int cell_off, int n_frames, NextLevel nx,
-                                                         uint32_t* __restrict__ dbg) {
+// One 64 x 64 tile (2 x 2 cells) of one level of one frame, by one 256-thread workgroup; tile_id in [0, nbx nby n_frames).
+__device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, int ncy, int min_th, int ini_th,
+                                                uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_ent,
+                                                int cells_per_frame, int cell_off, int n_frames, const NextLevel& nx,
+                                                uint32_t* __restrict__ dbg, int tile_id) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
   __shared__ uint32_t lists[4][256];
@@ -266,8 +266,6 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
 
   const int tid = threadIdx.x;
   const int nbx = (ncx + 1) >> 1, nby = (ncy + 1) >> 1;
-  const int tile_id = xcd_strip_tile(blockIdx.x, nbx * nby * n_frames);
-  if (tile_id >= nbx * nby * n_frames) return;
   const int frame = tile_id / (nbx * nby);
   const int trem = tile_id - frame * (nbx * nby);
   const int bx = trem % nbx, by = trem / nbx;
@@ -582,6 +580,37 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
     atomicMax(&dbg[kDbgMaxQueue], (uint32_t)nq);
     atomicMax(&dbg[kDbgMaxNz], (uint32_t)nz);
   }
+}
+
+__global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
+                                                         uint32_t* __restrict__ cell_cnt,
+                                                         uint32_t* __restrict__ cell_ent, int cells_per_frame,
+                                                         int cell_off, int n_frames, NextLevel nx,
+                                                         uint32_t* __restrict__ dbg) {
+  const int total = ((ncx + 1) >> 1) * ((ncy + 1) >> 1) * n_frames;
+  const int tile_id = xcd_strip_tile(blockIdx.x, total);
+  if (tile_id >= total) return;
+  fast_cells_tile(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
+}
+
+// Every level in ONE launch, over a pyramid that exists already (stand-alone resize launches): what a small call wants --
+// with the next level fused into fast_cells(l) the eight levels are eight DEPENDENT launches of ~14 us of latency each,
+// whatever the image size; here the dependent chain is seven small resize launches and one FAST launch.
+struct AllLevels {
+  LevelView lv[kMaxL];
+  int ncx[kMaxL], ncy[kMaxL], cell_off[kMaxL], tile_start[kMaxL + 1];
+  int n_levels;
+};
+__global__ __launch_bounds__(256) void fast_cells_all_kernel(AllLevels A, int min_th, int ini_th,
+                                                             uint32_t* __restrict__ cell_cnt,
+                                                             uint32_t* __restrict__ cell_ent, int cells_per_frame,
+                                                             int n_frames, uint32_t* __restrict__ dbg) {
+  int l = 0;
+  for (int k = 1; k < A.n_levels; ++k)
+    if ((int)blockIdx.x >= A.tile_start[k]) l = k;
+  const NextLevel none{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
+  fast_cells_tile(A.lv[l], A.ncx[l], A.ncy[l], min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, A.cell_off[l], n_frames, none,
+                  dbg, (int)blockIdx.x - A.tile_start[l]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1478,7 +1507,32 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     StreamSwap(gh_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
     ~StreamSwap() { c->stream = keep; }
   };
-  for (int l = 0; l < L; ++l) {
+  // small calls: pyramid first, then every level in one FAST launch (GSLAM_HIP_ORB_ALL_LEVELS=0: A/B measurements)
+  static const bool all_env = [] {
+    const char* e = getenv("GSLAM_HIP_ORB_ALL_LEVELS");
+    return !(e && e[0] == '0');
+  }();
+  const bool all_levels = all_env && (long long)batch * p->w * p->h <= (4LL << 20);
+  if (all_levels) {
+    for (int l = 1; l < L; ++l) GH_TRY(resize_standalone(l));
+    AllLevels A;
+    A.n_levels = L;
+    int tiles = 0;
+    for (int l = 0; l < kMaxL; ++l) {
+      A.tile_start[l] = tiles;
+      A.lv[l] = lv[l < L ? l : 0];
+      A.ncx[l] = l < L ? p->ncx[l] : 0;
+      A.ncy[l] = l < L ? p->ncy[l] : 0;
+      A.cell_off[l] = l < L ? p->cell_off[l] : 0;
+      if (l < L && p->ncx[l] != 0 && p->quota[l] > 0) tiles += gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
+    }
+    A.tile_start[kMaxL] = tiles;
+    if (tiles > 0)
+      GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_all_kernel, dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast, p->prm.ini_th_fast,
+                p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg);
+    overlap = false;
+  }
+  for (int l = 0; l < L && !all_levels; ++l) {
     const bool fast = p->ncx[l] != 0 && p->quota[l] > 0;
     if (!fast) {
       if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
