@@ -865,8 +865,43 @@ def main():
                                 "kernels_ms": {k: round(v["total_ms"], 3) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}
         extra["graph_solvers"] = out
 
+    # ---- the other per-frame host entry points (pageable memory in and out, median wall time per call): RANSAC with inlier
+    #      masks (Estimator boundary), triangulation, 3-D alignment (optimizeICP / fitSim3)
+    def _leg_host_calls():
+        from gslam_amd import estimator, posegraph
+        rng = np.random.default_rng(5)
+        n = 1000
+
+        def med_us(fn, reps=30):
+            for _ in range(3):
+                fn()
+            ts = []
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t1)
+            return round(sorted(ts)[len(ts) // 2] * 1e6, 1)
+        src = rng.uniform(-1, 1, (n, 2))
+        ph = np.c_[src, np.ones(n)] @ np.array([[1.0, 0.02, 0.1], [-0.03, 0.98, -0.05], [0.01, -0.02, 1.0]]).T
+        dst = ph[:, :2] / ph[:, 2:] + rng.normal(0, 1e-3, (n, 2))
+        dst[::7] += rng.uniform(-0.3, 0.3, (len(dst[::7]), 2))
+        T = np.array([0, 0, 0, 1, 0.3, 0.0, 0.02])
+        X = rng.uniform(-1, 1, (n, 3)) + np.array([0, 0, 4.0])
+        d1 = X / np.linalg.norm(X, axis=1, keepdims=True)
+        d2 = (X + T[4:]) / np.linalg.norm(X + T[4:], axis=1, keepdims=True)
+        pa = rng.uniform(-2, 2, (n, 3))
+        pb = 1.3 * pa[:, [1, 2, 0]] + np.array([0.5, -0.2, 1.0]) + rng.normal(0, 1e-3, (n, 3))
+        extra["host_calls"] = {
+            "what": "median wall time of one call, %d correspondences, pageable host arrays in and out (one pinned DMA each way "
+                    "inside)" % n,
+            "ransac_homography_us": med_us(lambda: estimator.estimate(ctx, estimator.HOMOGRAPHY, src, dst, 5e-3)),
+            "ransac_homography_confidence_0p99_us": med_us(lambda: estimator.estimate_conf(ctx, estimator.HOMOGRAPHY, src, dst, 5e-3, 0.99)),
+            "ransac_fundamental_us": med_us(lambda: estimator.estimate(ctx, estimator.FUNDAMENTAL, src, dst, 5e-3)),
+            "triangulate_us": med_us(lambda: estimator.triangulate(ctx, T, d1, d2)),
+            "align_sim3_with_information_us": med_us(lambda: posegraph.align_sim3(ctx, pa, pb))}
+
     for leg_name, leg_fn, skip in (("latency", _leg_latency, a.no_host_fed), ("orb_range", _leg_range, a.no_range),
-                                   ("graph_solvers", _leg_graph, a.no_ba)):
+                                   ("graph_solvers", _leg_graph, a.no_ba), ("host_calls", _leg_host_calls, a.no_host_fed)):
         try:
             if not skip:
                 log("leg %s" % leg_name)

@@ -352,9 +352,11 @@ extern "C" gh_status gh_bow_transform_host(gh_bow_vocab* v, const uint8_t* desc,
   if (n == 0) return GH_OK;
   GH_CHECK_ARG(ctx, desc && word && weight && node && bow_word && bow_val);
   const size_t a = ((size_t)n * v->desc_bytes + 255) & ~(size_t)255, b = ((size_t)n * 4 + 255) & ~(size_t)255;
-  void* s = nullptr;
-  GH_TRY(gh_scratch(ctx, a + 5 * b + 256, &s));
-  uint8_t* p = (uint8_t*)s;
+  const size_t total = a + 5 * b + 256;
+  void *s = nullptr, *hs = nullptr;
+  GH_TRY(gh_scratch(ctx, total, &s));
+  GH_TRY(gh_pinned(ctx, total, &hs));
+  uint8_t *p = (uint8_t*)s, *hp = (uint8_t*)hs;
   uint8_t* d_desc = p;
   uint32_t* d_word = (uint32_t*)(p + a);
   float* d_weight = (float*)(p + a + b);
@@ -362,14 +364,20 @@ extern "C" gh_status gh_bow_transform_host(gh_bow_vocab* v, const uint8_t* desc,
   uint32_t* d_bw = (uint32_t*)(p + a + 3 * b);
   float* d_bv = (float*)(p + a + 4 * b);
   int32_t* d_n = (int32_t*)(p + a + 5 * b);
-  GH_HIP(ctx, hipMemcpyAsync(d_desc, desc, (size_t)n * v->desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  // one DMA up (descriptors) and one down (word | weight | node | bow_word | bow_val | bow_n) through the context's pinned
+  // block, as gh_bf_match_host does: a per-frame caller (Vocabulary::transform of one image) paid seven pageable copies
+  // of ~30-50 us each for two kernels of ~20 us
+  memcpy(hp, desc, (size_t)n * v->desc_bytes);
+  GH_HIP(ctx, hipMemcpyAsync(d_desc, hp, (size_t)n * v->desc_bytes, hipMemcpyHostToDevice, ctx->stream));
   GH_TRY(gh_bow_transform_dev(v, d_desc, nullptr, n, 1, levelsup, d_word, d_weight, d_node, d_bw, d_bv, d_n));
-  GH_HIP(ctx, hipMemcpyAsync(word, d_word, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(weight, d_weight, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(node, d_node, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(bow_word, d_bw, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(bow_val, d_bv, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(bow_n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(hp + a, p + a, 5 * b + 4, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t nb = (size_t)n * 4;
+  memcpy(word, hp + a, nb);
+  memcpy(weight, hp + a + b, nb);
+  memcpy(node, hp + a + 2 * b, nb);
+  memcpy(bow_word, hp + a + 3 * b, nb);
+  memcpy(bow_val, hp + a + 4 * b, nb);
+  memcpy(bow_n, hp + a + 5 * b, 4);
   return GH_OK;
 }

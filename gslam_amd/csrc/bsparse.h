@@ -9,6 +9,7 @@
 // place in a dense lower-triangular matrix and goes through the blocked MFMA Cholesky of chol.hip.
 #pragma once
 #include "common.h"
+#include "graph_arena.h"
 
 struct BsPattern {  // host-side symbolic factorisation
   int nf = 0, ns = 0, nr = 0, n_rounds = 0, n_slots = 0;
@@ -40,9 +41,16 @@ struct BsSolver {
   int32_t *d_upd_cs = nullptr, *d_upd_ptr = nullptr, *d_upd_src = nullptr;
   double *d_H = nullptr, *d_W = nullptr;  // assembled values / damped working copy that becomes the factor
   double *d_Ld = nullptr, *d_y = nullptr, *d_b = nullptr;
-  std::vector<void*> owned;
-  ~BsSolver();
-  gh_status init(gh_ctx* ctx);  // after P.build: device copies and buffers
+  // host images of the update lists (kept until the uploads noted by note_uploads() have been flushed)
+  std::vector<int64_t> h_upd_off;
+  std::vector<int32_t> h_upd_cs, h_upd_ptr, h_upd_src;
+  int32_t* h_flag = nullptr;  // pinned word the pivot flag of a factorisation is read back into (nullptr: a local)
+  // After P.build, in this order: prepare_host (sizes and update lists), alloc_dev (once with the arena measuring, once for
+  // real), note_uploads + A.flush() + clear_values; the arena owns the device memory.
+  gh_status prepare_host(gh_ctx* ctx);
+  bool alloc_dev(GraphArena& A);
+  void note_uploads(GraphArena& A);
+  gh_status clear_values(gh_ctx* ctx);
   // offset (in doubles from d_H / d_W) and strides of the block (row frame position pr, column frame position pc), pr >= pc:
   // element (a, b) of the block is at off + a + cs * b
   bool block_addr(int pr, int pc, size_t* off, int* cs) const;

@@ -295,32 +295,19 @@ __global__ __launch_bounds__(256) void bs_unpermute_kernel(const int32_t* __rest
 }  // namespace
 
 // ---------------------------------------------------------------- solver object
-BsSolver::~BsSolver() {
-  for (void* p : owned) (void)hipFree(p);
-}
-
-gh_status BsSolver::init(gh_ctx* ctx) {
+gh_status BsSolver::prepare_host(gh_ctx* ctx) {
   nr7 = 7 * P.nr;
   ldr = (nr7 + 1 + 15) & ~15;
   off_slots = (size_t)49 * P.ns;
   off_root = (off_slots + (size_t)49 * P.n_slots + 15) & ~(size_t)15;
   n_vals = off_root + (size_t)nr7 * ldr + 16;
-  auto alloc = [&](void** out, size_t bytes) -> bool {
-    if (hipMalloc(out, bytes ? bytes : 8) != hipSuccess) return false;
-    owned.push_back(*out);
-    return true;
-  };
-  const size_t nf7 = (size_t)7 * P.nf;
-  const bool ok = alloc((void**)&d_colptr, P.colptr.size() * 4) && alloc((void**)&d_rows, P.rows.size() * 4) &&
-                  alloc((void**)&d_slot_col, P.slot_col.size() * 4) && alloc((void**)&d_pos, P.pos.size() * 4) &&
-                  alloc((void**)&d_flag, 8) && alloc((void**)&d_H, n_vals * 8) && alloc((void**)&d_W, n_vals * 8) &&
-                  alloc((void**)&d_Ld, (size_t)49 * std::max(P.ns, 1) * 8) && alloc((void**)&d_y, nf7 * 8) && alloc((void**)&d_b, (nf7 + 16) * 8);
-  if (!ok)
-    return gh_set_error(ctx, GH_ERR_NOMEM, "block-sparse solver: device allocation failed (%d sparse columns, %d slots, root %d)", P.ns,
-                        P.n_slots, nr7);
   // update lists: per round, the 7 x 7 products grouped by destination block (stable: column order within a destination)
-  std::vector<int64_t> upd_off;
-  std::vector<int32_t> upd_cs, upd_ptr(1, 0), upd_src;
+  std::vector<int64_t>& upd_off = h_upd_off;
+  std::vector<int32_t>&upd_cs = h_upd_cs, &upd_ptr = h_upd_ptr, &upd_src = h_upd_src;
+  upd_off.clear();
+  upd_cs.clear();
+  upd_src.clear();
+  upd_ptr.assign(1, 0);
   upd_round.assign(1, 0);
   {
     struct Entry {
@@ -352,24 +339,34 @@ gh_status BsSolver::init(gh_ctx* ctx) {
     upd_ptr.push_back((int32_t)(upd_src.size() / 2));
     if (upd_off.empty()) upd_ptr.assign(2, 0);
   }
-  if (!(alloc((void**)&d_rowptr, P.rowptr.size() * 4) && alloc((void**)&d_rowlist, P.rowlist.size() * 4) &&
-        alloc((void**)&d_upd_off, upd_off.size() * 8) && alloc((void**)&d_upd_cs, upd_cs.size() * 4) &&
-        alloc((void**)&d_upd_ptr, upd_ptr.size() * 4) && alloc((void**)&d_upd_src, upd_src.size() * 4)))
-    return gh_set_error(ctx, GH_ERR_NOMEM, "block-sparse solver: device allocation failed (update lists: %zu products)", upd_src.size() / 2);
-  GH_HIP(ctx, hipMemcpyAsync(d_rowptr, P.rowptr.data(), P.rowptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_rowlist, P.rowlist.data(), P.rowlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (!upd_off.empty()) {
-    GH_HIP(ctx, hipMemcpyAsync(d_upd_off, upd_off.data(), upd_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    GH_HIP(ctx, hipMemcpyAsync(d_upd_cs, upd_cs.data(), upd_cs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    GH_HIP(ctx, hipMemcpyAsync(d_upd_src, upd_src.data(), upd_src.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  }
-  GH_HIP(ctx, hipMemcpyAsync(d_upd_ptr, upd_ptr.data(), upd_ptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_colptr, P.colptr.data(), P.colptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_rows, P.rows.data(), P.rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_slot_col, P.slot_col.data(), P.slot_col.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_pos, P.pos.data(), P.pos.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  return GH_OK;
+}
+
+// the uploaded lists first and in the order of note_uploads(): they form one run of the arena and travel in one DMA
+bool BsSolver::alloc_dev(GraphArena& A) {
+  const size_t nf7 = (size_t)7 * P.nf;
+  return A.alloc(&d_rowptr, P.rowptr.size()) && A.alloc(&d_rowlist, P.rowlist.size()) && A.alloc(&d_upd_off, h_upd_off.size()) &&
+         A.alloc(&d_upd_cs, h_upd_cs.size()) && A.alloc(&d_upd_src, h_upd_src.size()) && A.alloc(&d_upd_ptr, h_upd_ptr.size()) &&
+         A.alloc(&d_colptr, P.colptr.size()) && A.alloc(&d_rows, P.rows.size()) && A.alloc(&d_slot_col, P.slot_col.size()) &&
+         A.alloc(&d_pos, P.pos.size()) && A.alloc(&d_flag, 2) && A.alloc(&d_Ld, (size_t)49 * std::max(P.ns, 1)) && A.alloc(&d_y, nf7) &&
+         A.alloc(&d_b, nf7 + 16) && A.alloc(&d_H, n_vals) && A.alloc(&d_W, n_vals);
+}
+
+void BsSolver::note_uploads(GraphArena& A) {
+  A.upload(d_rowptr, P.rowptr.data(), P.rowptr.size() * 4);
+  A.upload(d_rowlist, P.rowlist.data(), P.rowlist.size() * 4);
+  A.upload(d_upd_off, h_upd_off.data(), h_upd_off.size() * 8);
+  A.upload(d_upd_cs, h_upd_cs.data(), h_upd_cs.size() * 4);
+  A.upload(d_upd_src, h_upd_src.data(), h_upd_src.size() * 4);
+  A.upload(d_upd_ptr, h_upd_ptr.data(), h_upd_ptr.size() * 4);
+  A.upload(d_colptr, P.colptr.data(), P.colptr.size() * 4);
+  A.upload(d_rows, P.rows.data(), P.rows.size() * 4);
+  A.upload(d_slot_col, P.slot_col.data(), P.slot_col.size() * 4);
+  A.upload(d_pos, P.pos.data(), P.pos.size() * 4);
+}
+
+gh_status BsSolver::clear_values(gh_ctx* ctx) {
   GH_HIP(ctx, hipMemsetAsync(d_H, 0, n_vals * 8, ctx->stream));
-  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return GH_OK;
 }
 
@@ -424,9 +421,10 @@ gh_status BsSolver::factor_solve(gh_ctx* ctx, double radius, const double* g_dev
   GH_LAUNCH(ctx, "bs_unpermute", bs_unpermute_kernel, dim3(gh_div_up(7 * P.nf, 256)), dim3(256), 0, (const int32_t*)d_pos, P.nf,
             (const double*)d_b, x_dev);
   int32_t flag = 0;
-  GH_HIP(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t* hf = h_flag ? h_flag : &flag;  // (pinned when the caller has a read-back block: a plain DMA, no staging)
+  GH_HIP(ctx, hipMemcpyAsync(hf, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *info = flag;
+  *info = *hf;
   return GH_OK;
 }
 
@@ -463,7 +461,18 @@ extern "C" gh_status gh_bs_solve_host(gh_ctx* ctx, int n_frames, int n_pairs, co
   GH_CHECK_ARG(ctx, n_frames >= 1 && n_pairs >= 0 && diag && g && x_out && info && radius > 0 && (n_pairs == 0 || (prow && pcol && off)));
   BsSolver S;
   S.P.build(n_frames, n_pairs, prow, pcol, root_min, max_rounds);
-  GH_TRY(S.init(ctx));
+  GH_TRY(S.prepare_host(ctx));
+  GraphArena A(ctx);
+  double *d_g = nullptr, *d_x = nullptr;
+  auto alloc_all = [&]() { return S.alloc_dev(A) && A.alloc(&d_g, (size_t)7 * n_frames) && A.alloc(&d_x, (size_t)7 * n_frames); };
+  alloc_all();  // measuring pass
+  GH_TRY(A.reserve());
+  if (!alloc_all())
+    return gh_set_error(ctx, GH_ERR_NOMEM, "block-sparse solver: device allocation failed (%d sparse columns, %d slots, root %d)",
+                        S.P.ns, S.P.n_slots, S.nr7);
+  S.note_uploads(A);
+  GH_TRY(A.flush());
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the staging block is free again)
   std::vector<double> vals(S.n_vals, 0.0);
   for (int f = 0; f < n_frames; ++f) {
     size_t o;
@@ -485,11 +494,6 @@ extern "C" gh_status gh_bs_solve_host(gh_ctx* ctx, int n_frames, int n_pairs, co
         vals[pa > pb ? o + a + (size_t)cs * b : o + b + (size_t)cs * a] += v;
       }
   }
-  double *d_g = nullptr, *d_x = nullptr;
-  GH_HIP(ctx, hipMalloc((void**)&d_g, (size_t)7 * n_frames * 8));
-  S.owned.push_back(d_g);
-  GH_HIP(ctx, hipMalloc((void**)&d_x, (size_t)7 * n_frames * 8));
-  S.owned.push_back(d_x);
   GH_HIP(ctx, hipMemcpyAsync(S.d_H, vals.data(), S.n_vals * 8, hipMemcpyHostToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(d_g, g, (size_t)7 * n_frames * 8, hipMemcpyHostToDevice, ctx->stream));
   GH_TRY(S.factor_solve(ctx, radius, d_g, d_x, info));

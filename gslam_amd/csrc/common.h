@@ -35,6 +35,9 @@ struct gh_ctx {
   // grow-only arena reused by successive gh_ba_solve calls (local BA runs every keyframe: no malloc/free per call)
   void* ba_arena = nullptr;
   size_t ba_arena_bytes = 0;
+  // grow-only arena of the graph solvers (gh_graph_solve / gh_pg_solve, graph_arena.h): one hipMalloc per context, not ~70 per solve
+  void* pg_arena = nullptr;
+  size_t pg_arena_bytes = 0;
   // every public entry point holds this for its whole call (GH_ENTER): a ctx shared by several Messenger worker threads
   // serialises on it; recursive because gh_ba_pnp calls gh_ba_solve
   std::recursive_mutex mu;

@@ -47,6 +47,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ba_arena) hipFree(ctx->ba_arena);
+  if (ctx->pg_arena) hipFree(ctx->pg_arena);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -442,21 +442,6 @@ double now_ms_pg() {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-struct DevArena {  // a handful of hipMalloc'ed buffers freed together
-  std::vector<void*> ptrs;
-  ~DevArena() {
-    for (void* p : ptrs) (void)hipFree(p);
-  }
-  template <typename T>
-  bool alloc(T** out, size_t count) {
-    void* p = nullptr;
-    if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) return false;
-    ptrs.push_back(p);
-    *out = (T*)p;
-    return true;
-  }
-};
-
 // Host side of the pose-graph part of a problem: the three edge lists flattened (order: SE3, SIM3, GPS -- the oracle's)
 // and the assembly lists of pg_assemble_kernel.
 struct PoseHost {
@@ -1109,7 +1094,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   std::vector<int32_t> bs_sp, bs_sq;
   if (sparse) {
     BS.P.build(nf, PH.n_pairs, PH.prow.data(), PH.pcol.data(), root_min, 64);
-    GH_TRY(BS.init(ctx));
+    GH_TRY(BS.prepare_host(ctx));
     const size_t nb = (size_t)nf + PH.n_pairs;
     bs_off.resize(nb);
     bs_sp.resize(nb);
@@ -1136,7 +1121,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
               BS.P.n_rounds, BS.P.n_slots, BS.P.nr);
   }
   const int n_items = ne + no, n_part = gh_div_up(std::max(n_items, std::max(no, 1)), 1024);
-  DevArena A;
+  GraphArena A(ctx);
   double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H = nullptr, *d_Hd = nullptr, *d_g, *d_d, *d_out;
   double *d_xyz, *d_xyz_new, *d_rho, *d_rho_new, *d_anchor, *d_oxy, *d_oinfo = nullptr, *d_orec, *d_Hpp, *d_gp, *d_Hinv, *d_dlm, *d_term,
       *d_part, *d_Wh;
@@ -1144,71 +1129,93 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       *d_oframe, *d_lstart, *d_llist, *d_lmdim, *d_hrep;
   uint8_t *d_xfree = nullptr, *d_ifree = nullptr, *d_valid;
   unsigned long long* d_gmax;
-  const size_t nlm1 = (size_t)std::max(nlm, 1), no1 = (size_t)std::max(no, 1);
-  bool ok = A.alloc(&d_S, (size_t)nf * 8) && A.alloc(&d_Snew, (size_t)nf * 8) && A.alloc(&d_meas, PH.meas.size()) &&
-            (!PH.any_info || A.alloc(&d_info, PH.info.size())) && A.alloc(&d_rec, (size_t)kEdgeRec * PH.etype.size()) &&
-            A.alloc(&d_cost_e, PH.etype.size()) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda))) &&
-            A.alloc(&d_g, (size_t)n) && A.alloc(&d_d, (size_t)n) && A.alloc(&d_out, 4) && A.alloc(&d_dof, (size_t)nf) &&
-            A.alloc(&d_etype, PH.etype.size()) && A.alloc(&d_ei, PH.etype.size()) && A.alloc(&d_ej, PH.etype.size()) &&
-            A.alloc(&d_vstart, PH.vstart.size()) && A.alloc(&d_vlist, PH.vlist.size()) && A.alloc(&d_pstart, PH.pstart.size()) &&
-            A.alloc(&d_plist, PH.plist.size()) && A.alloc(&d_prow, PH.prow.size()) && A.alloc(&d_pcol, PH.pcol.size()) &&
-            A.alloc(&d_gmax, 1) && A.alloc(&d_xyz, (size_t)std::max(nx, 1) * 3) && A.alloc(&d_xyz_new, (size_t)std::max(nx, 1) * 3) &&
-            A.alloc(&d_rho, (size_t)std::max(ni, 1)) && A.alloc(&d_rho_new, (size_t)std::max(ni, 1)) &&
-            A.alloc(&d_anchor, (size_t)std::max(ni, 1) * 3) && A.alloc(&d_host, (size_t)std::max(ni, 1)) && A.alloc(&d_oxy, no1 * 3) &&
-            (!gpr->obs_info || A.alloc(&d_oinfo, no1 * 4)) && A.alloc(&d_orec, no1 * kObsRec) && A.alloc(&d_Hpp, nlm1 * 9) &&
-            A.alloc(&d_gp, nlm1 * 3) && A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) &&
-            A.alloc(&d_term, (size_t)std::max(n_items, 1)) && A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_okind, no1) &&
-            A.alloc(&d_opoint, no1) && A.alloc(&d_oframe, no1) && A.alloc(&d_lstart, lstart.size()) && A.alloc(&d_llist, llist.size()) &&
-            A.alloc(&d_lmdim, nlm1) && A.alloc(&d_hrep, nlm1) && A.alloc(&d_Wh, nlm1 * 7) && A.alloc(&d_valid, no1) && (!gpr->xyz_free || A.alloc(&d_xfree, (size_t)std::max(nx, 1))) &&
-            (!gpr->idp_free || A.alloc(&d_ifree, (size_t)std::max(ni, 1)));
-  if (!ok) return gh_set_error(ctx, GH_ERR_NOMEM, "gh_graph_solve: device allocation failed (dense keyframe system: %d x %d doubles)", n, lda);
-  auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
-    if (bytes) GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return GH_OK;
-  };
-  GH_TRY(up(d_S, pr->frame_sim3, (size_t)nf * 64));
-  GH_TRY(up(d_dof, pr->frame_dof, (size_t)nf * 4));
-  GH_TRY(up(d_meas, PH.meas.data(), PH.meas.size() * 8));
-  if (PH.any_info) GH_TRY(up(d_info, PH.info.data(), PH.info.size() * 8));
-  GH_TRY(up(d_etype, PH.etype.data(), PH.etype.size() * 4));
-  GH_TRY(up(d_ei, PH.ei.data(), PH.ei.size() * 4));
-  GH_TRY(up(d_ej, PH.ej.data(), PH.ej.size() * 4));
-  GH_TRY(up(d_vstart, PH.vstart.data(), PH.vstart.size() * 4));
-  GH_TRY(up(d_vlist, PH.vlist.data(), PH.vlist.size() * 4));
-  GH_TRY(up(d_pstart, PH.pstart.data(), PH.pstart.size() * 4));
-  GH_TRY(up(d_plist, PH.plist.data(), PH.plist.size() * 4));
-  GH_TRY(up(d_prow, PH.prow.data(), PH.prow.size() * 4));
-  GH_TRY(up(d_pcol, PH.pcol.data(), PH.pcol.size() * 4));
-  GH_TRY(up(d_xyz, gpr->xyz, (size_t)nx * 24));
-  GH_TRY(up(d_rho, gpr->idp_rho, (size_t)ni * 8));
-  GH_TRY(up(d_anchor, gpr->idp_anchor, (size_t)ni * 24));
-  GH_TRY(up(d_host, gpr->idp_host, (size_t)ni * 4));
-  GH_TRY(up(d_oxy, obs_meas, (size_t)no * ms * 8));
-  if (gpr->obs_info) GH_TRY(up(d_oinfo, gpr->obs_info, (size_t)no * 32));
-  GH_TRY(up(d_okind, gpr->obs_kind, (size_t)no * 4));
-  GH_TRY(up(d_opoint, gpr->obs_point, (size_t)no * 4));
-  GH_TRY(up(d_oframe, gpr->obs_frame, (size_t)no * 4));
-  GH_TRY(up(d_lstart, lstart.data(), lstart.size() * 4));
-  GH_TRY(up(d_llist, llist.data(), llist.size() * 4));
-  if (gpr->xyz_free) GH_TRY(up(d_xfree, gpr->xyz_free, (size_t)nx));
-  if (gpr->idp_free) GH_TRY(up(d_ifree, gpr->idp_free, (size_t)ni));
   int64_t* d_bs_off = nullptr;
   int32_t *d_bs_sp = nullptr, *d_bs_sq = nullptr;
+  const size_t nlm1 = (size_t)std::max(nlm, 1), no1 = (size_t)std::max(no, 1), nx1 = (size_t)std::max(nx, 1), ni1 = (size_t)std::max(ni, 1);
+  // Run twice (graph_arena.h): once measuring, once for real.  The uploaded arrays come first, in the order of the uploads
+  // below, so that they form one run of the arena and travel in one DMA; then the lists of the block-sparse solver (the
+  // same way), then the work arrays.
+  auto alloc_all = [&]() -> bool {
+    return A.alloc(&d_S, (size_t)nf * 8) && A.alloc(&d_dof, (size_t)nf) && A.alloc(&d_meas, PH.meas.size()) &&
+           (!PH.any_info || A.alloc(&d_info, PH.info.size())) && A.alloc(&d_etype, PH.etype.size()) && A.alloc(&d_ei, PH.etype.size()) &&
+           A.alloc(&d_ej, PH.etype.size()) && A.alloc(&d_vstart, PH.vstart.size()) && A.alloc(&d_vlist, PH.vlist.size()) &&
+           A.alloc(&d_pstart, PH.pstart.size()) && A.alloc(&d_plist, PH.plist.size()) && A.alloc(&d_prow, PH.prow.size()) &&
+           A.alloc(&d_pcol, PH.pcol.size()) && A.alloc(&d_xyz, nx1 * 3) && A.alloc(&d_rho, ni1) && A.alloc(&d_anchor, ni1 * 3) &&
+           A.alloc(&d_host, ni1) && A.alloc(&d_oxy, no1 * 3) && (!gpr->obs_info || A.alloc(&d_oinfo, no1 * 4)) && A.alloc(&d_okind, no1) &&
+           A.alloc(&d_opoint, no1) && A.alloc(&d_oframe, no1) && A.alloc(&d_lstart, lstart.size()) && A.alloc(&d_llist, llist.size()) &&
+           (!gpr->xyz_free || A.alloc(&d_xfree, nx1)) && (!gpr->idp_free || A.alloc(&d_ifree, ni1)) &&
+           (!sparse || (A.alloc(&d_bs_off, bs_off.size()) && A.alloc(&d_bs_sp, bs_sp.size()) && A.alloc(&d_bs_sq, bs_sq.size()) &&
+                        BS.alloc_dev(A))) &&
+           // work arrays
+           A.alloc(&d_Snew, (size_t)nf * 8) && A.alloc(&d_rec, (size_t)kEdgeRec * PH.etype.size()) && A.alloc(&d_cost_e, PH.etype.size()) &&
+           A.alloc(&d_g, (size_t)n) && A.alloc(&d_d, (size_t)n) && A.alloc(&d_out, 4) && A.alloc(&d_gmax, 1) && A.alloc(&d_xyz_new, nx1 * 3) &&
+           A.alloc(&d_rho_new, ni1) && A.alloc(&d_orec, no1 * kObsRec) && A.alloc(&d_Hpp, nlm1 * 9) && A.alloc(&d_gp, nlm1 * 3) &&
+           A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) && A.alloc(&d_term, (size_t)std::max(n_items, 1)) &&
+           A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_lmdim, nlm1) && A.alloc(&d_hrep, nlm1) && A.alloc(&d_Wh, nlm1 * 7) &&
+           A.alloc(&d_valid, no1) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda)));
+  };
+  alloc_all();  // measuring pass
+  GH_TRY(A.reserve());
+  if (!alloc_all())
+    return gh_set_error(ctx, GH_ERR_NOMEM, "gh_graph_solve: device allocation failed (dense keyframe system: %d x %d doubles)", n, lda);
+  A.upload(d_S, pr->frame_sim3, (size_t)nf * 64);
+  A.upload(d_dof, pr->frame_dof, (size_t)nf * 4);
+  A.upload(d_meas, PH.meas.data(), PH.meas.size() * 8);
+  if (PH.any_info) A.upload(d_info, PH.info.data(), PH.info.size() * 8);
+  A.upload(d_etype, PH.etype.data(), PH.etype.size() * 4);
+  A.upload(d_ei, PH.ei.data(), PH.ei.size() * 4);
+  A.upload(d_ej, PH.ej.data(), PH.ej.size() * 4);
+  A.upload(d_vstart, PH.vstart.data(), PH.vstart.size() * 4);
+  A.upload(d_vlist, PH.vlist.data(), PH.vlist.size() * 4);
+  A.upload(d_pstart, PH.pstart.data(), PH.pstart.size() * 4);
+  A.upload(d_plist, PH.plist.data(), PH.plist.size() * 4);
+  A.upload(d_prow, PH.prow.data(), PH.prow.size() * 4);
+  A.upload(d_pcol, PH.pcol.data(), PH.pcol.size() * 4);
+  A.upload(d_xyz, gpr->xyz, (size_t)nx * 24);
+  A.upload(d_rho, gpr->idp_rho, (size_t)ni * 8);
+  A.upload(d_anchor, gpr->idp_anchor, (size_t)ni * 24);
+  A.upload(d_host, gpr->idp_host, (size_t)ni * 4);
+  A.upload(d_oxy, obs_meas, (size_t)no * ms * 8);
+  if (gpr->obs_info) A.upload(d_oinfo, gpr->obs_info, (size_t)no * 32);
+  A.upload(d_okind, gpr->obs_kind, (size_t)no * 4);
+  A.upload(d_opoint, gpr->obs_point, (size_t)no * 4);
+  A.upload(d_oframe, gpr->obs_frame, (size_t)no * 4);
+  A.upload(d_lstart, lstart.data(), lstart.size() * 4);
+  A.upload(d_llist, llist.data(), llist.size() * 4);
+  if (gpr->xyz_free) A.upload(d_xfree, gpr->xyz_free, (size_t)nx);
+  if (gpr->idp_free) A.upload(d_ifree, gpr->idp_free, (size_t)ni);
   if (sparse) {
-    if (!(A.alloc(&d_bs_off, bs_off.size()) && A.alloc(&d_bs_sp, bs_sp.size()) && A.alloc(&d_bs_sq, bs_sq.size())))
-      return gh_set_error(ctx, GH_ERR_NOMEM, "gh_graph_solve: device allocation failed");
-    GH_TRY(up(d_bs_off, bs_off.data(), bs_off.size() * 8));
-    GH_TRY(up(d_bs_sp, bs_sp.data(), bs_sp.size() * 4));
-    GH_TRY(up(d_bs_sq, bs_sq.data(), bs_sq.size() * 4));
+    A.upload(d_bs_off, bs_off.data(), bs_off.size() * 8);
+    A.upload(d_bs_sp, bs_sp.data(), bs_sp.size() * 4);
+    A.upload(d_bs_sq, bs_sq.data(), bs_sq.size() * 4);
+    BS.note_uploads(A);
   }
+  GH_TRY(A.flush());
+  if (sparse) GH_TRY(BS.clear_values(ctx));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // Everything the host reads back inside the loop lands in the context's pinned block (free again after the
+  // synchronisation above; nothing below asks for it): plain DMAs, no staged copies into pageable memory.
+  struct Readback {
+    double out4[4];
+    unsigned long long gmax_bits;
+    int info;
+    int32_t bs_flag;
+  };
+  Readback* rb = nullptr;
+  {
+    void* hp = nullptr;
+    GH_TRY(gh_pinned(ctx, sizeof(Readback), &hp));
+    rb = static_cast<Readback*>(hp);
+    memset(rb, 0, sizeof(*rb));
+  }
+  if (sparse) BS.h_flag = &rb->bs_flag;
+  double* host4 = rb->out4;
 
   PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
   PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, PH.n_pairs};
   GrLandmarks LM{nx, ni, no, d_xfree, d_host, d_anchor, d_ifree, d_okind, d_opoint, d_oframe, d_oxy, d_oinfo, d_lstart, d_llist,
                  opt.huber_delta, gpr->projection};
   const int eb = gh_div_up(ne > 0 ? ne : 1, 64), eb4 = gh_div_up(ne > 0 ? ne : 1, 4), ob = gh_div_up(no > 0 ? no : 1, 128);
-  double host4[4];
   // sum of v[0..count) into d_out[slot]: fixed order (1024 per block, then the partials one after the other)
   auto reduce_to = [&](const double* v, int count, int slot) -> gh_status {
     const int nb = gh_div_up(count > 0 ? count : 1, 1024);
@@ -1253,11 +1260,10 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_LAUNCH(ctx, "gr_gmax", gr_gmax_kernel, dim3(gh_div_up(n + 3 * nlm, 256)), dim3(256), 0, (const double*)d_g, n,
                 (const double*)d_gp, 3 * nlm, d_gmax);
-      unsigned long long gb = 0;
-      GH_HIP(ctx, hipMemcpyAsync(&gb, d_gmax, 8, hipMemcpyDeviceToHost, ctx->stream));
+      GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, 8, hipMemcpyDeviceToHost, ctx->stream));
       GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
       double gmax;
-      memcpy(&gmax, &gb, 8);
+      memcpy(&gmax, &rb->gmax_bits, 8);
       if (gmax <= opt.gradient_tolerance) {
         term = 2;
         break;
@@ -1277,8 +1283,13 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
     }
     int info = 0;
     const double t_s0 = now_ms_pg();
-    if (sparse) GH_TRY(BS.factor_solve(ctx, radius, d_g, d_d, &info));
-    else GH_TRY(gh_potrf_solve_dev(ctx, d_Hd, n, lda, d_d, &info));
+    if (sparse) {
+      GH_TRY(BS.factor_solve(ctx, radius, d_g, d_d, &info));
+    } else {
+      rb->info = 0;
+      GH_TRY(gh_potrf_solve_dev(ctx, d_Hd, n, lda, d_d, &rb->info));
+      info = rb->info;
+    }
     sum->solve_ms_total += now_ms_pg() - t_s0;
     const bool okf = info == 0;
     double new_cost = cost, model = 0, rho = -1;
@@ -1344,10 +1355,20 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   sum->iterations = it;
   sum->termination = term;
   sum->final_cost = cost;
-  GH_HIP(ctx, hipMemcpyAsync(pr->frame_sim3, d_S, (size_t)nf * 64, hipMemcpyDeviceToHost, ctx->stream));
-  if (nx) GH_HIP(ctx, hipMemcpyAsync(gpr->xyz, d_xyz, (size_t)nx * 24, hipMemcpyDeviceToHost, ctx->stream));
-  if (ni) GH_HIP(ctx, hipMemcpyAsync(gpr->idp_rho, d_rho, (size_t)ni * 8, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  {  // results: through the pinned block too (the read-back words are not needed any more)
+    const size_t bS = (size_t)nf * 64, bX = (size_t)nx * 24, bR = (size_t)ni * 8;
+    const size_t oX = (bS + 255) & ~(size_t)255, oR = oX + ((bX + 255) & ~(size_t)255);
+    void* hp = nullptr;
+    GH_TRY(gh_pinned(ctx, oR + bR + 256, &hp));
+    char* h = static_cast<char*>(hp);
+    GH_HIP(ctx, hipMemcpyAsync(h, d_S, bS, hipMemcpyDeviceToHost, ctx->stream));
+    if (nx) GH_HIP(ctx, hipMemcpyAsync(h + oX, d_xyz, bX, hipMemcpyDeviceToHost, ctx->stream));
+    if (ni) GH_HIP(ctx, hipMemcpyAsync(h + oR, d_rho, bR, hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(pr->frame_sim3, h, bS);
+    if (nx) memcpy(gpr->xyz, h + oX, bX);
+    if (ni) memcpy(gpr->idp_rho, h + oR, bR);
+  }
   sum->total_ms = now_ms_pg() - t_begin;
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;
 }
@@ -1526,17 +1547,20 @@ extern "C" gh_status gh_align_sim3(gh_ctx* ctx, const double* src, const double*
   if (n < 3) return GH_OK;
   const int nb = gh_div_up(n, 256);
   const size_t pts = (((size_t)n * 24) + 255) & ~(size_t)255, part = (((size_t)nb * 50 * 8) + 255) & ~(size_t)255;
-  void* base = nullptr;
+  void *base = nullptr, *hbase = nullptr;
   GH_TRY(gh_scratch(ctx, 2 * pts + part + 256, &base));
+  GH_TRY(gh_pinned(ctx, 2 * pts + part + 256, &hbase));  // host mirror of the layout: every copy is one DMA from / to pinned memory
   double* d_src = (double*)base;
   double* d_dst = (double*)((char*)base + pts);
   double* d_part = (double*)((char*)base + 2 * pts);
   double* d_S = (double*)((char*)base + 2 * pts + part);
-  GH_HIP(ctx, hipMemcpyAsync(d_src, src, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_dst, dst, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+  char* hb = (char*)hbase;
+  double* hp = (double*)(hb + 2 * pts);
+  memcpy(hb, src, (size_t)n * 24);
+  memcpy(hb + pts, dst, (size_t)n * 24);
+  GH_HIP(ctx, hipMemcpyAsync(d_src, hb, pts + (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
   GH_LAUNCH(ctx, "align_sums", align_sums_kernel, dim3(nb), dim3(256), 0, (const double*)d_src, (const double*)d_dst, n, d_part);
-  std::vector<double> hp((size_t)nb * 50);
-  GH_HIP(ctx, hipMemcpyAsync(hp.data(), d_part, (size_t)nb * 17 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(hp, d_part, (size_t)nb * 17 * 8, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double sums[17];
   for (int q = 0; q < 17; ++q) {
@@ -1550,10 +1574,11 @@ extern "C" gh_status gh_align_sim3(gh_ctx* ctx, const double* src, const double*
   }
   *ok_out = 1;
   if (information_out || ssq_out) {
-    GH_HIP(ctx, hipMemcpyAsync(d_S, sim3_out, 64, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(hb + 2 * pts + part, sim3_out, 64);
+    GH_HIP(ctx, hipMemcpyAsync(d_S, hb + 2 * pts + part, 64, hipMemcpyHostToDevice, ctx->stream));
     GH_LAUNCH(ctx, "align_info", align_info_kernel, dim3(nb), dim3(256), 0, (const double*)d_src, (const double*)d_dst, n,
               (const double*)d_S, dof, d_part);
-    GH_HIP(ctx, hipMemcpyAsync(hp.data(), d_part, (size_t)nb * 50 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(hp, d_part, (size_t)nb * 50 * 8, hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int q = 0; q < 50; ++q) {
       double s = 0;

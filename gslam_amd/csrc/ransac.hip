@@ -660,9 +660,10 @@ extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const doubl
   const size_t off_q = pb, off_models = 2 * pb, off_valid = off_models + (size_t)kHyp * 12 * 8,
                off_counts = off_valid + kHyp * 4, off_best = off_counts + kHyp * 4, off_mout = off_best + 256,
                off_mask = off_mout + 256, total = off_mask + (((size_t)n + 255) & ~(size_t)255);
-  void* base = nullptr;
+  void *base = nullptr, *hbase = nullptr;
   GH_TRY(gh_scratch(ctx, total, &base));
-  uint8_t* b = (uint8_t*)base;
+  GH_TRY(gh_pinned(ctx, total, &hbase));  // host mirror of the same layout: one DMA per direction and phase
+  uint8_t *b = (uint8_t*)base, *hb = (uint8_t*)hbase;
   double* d_p = (double*)b;
   double* d_q = (double*)(b + off_q);
   double* d_models = (double*)(b + off_models);
@@ -671,8 +672,11 @@ extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const doubl
   int* d_best = (int*)(b + off_best);
   double* d_mout = (double*)(b + off_mout);
   uint8_t* d_mask = b + off_mask;
-  GH_HIP(ctx, hipMemcpyAsync(d_p, src, (size_t)n * dim * 8, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d_q, dst, (size_t)n * dimq * 8, hipMemcpyHostToDevice, ctx->stream));
+  // (a per-frame caller -- Estimator::findFundamental / findHomography / findPnPRansac -- paid two pageable uploads and
+  // three to five pageable downloads of ~30-50 us each around ~100 us of kernels)
+  memcpy(hb, src, (size_t)n * dim * 8);
+  memcpy(hb + off_q, dst, (size_t)n * dimq * 8);
+  GH_HIP(ctx, hipMemcpyAsync(b, hb, off_q + (size_t)n * dimq * 8, hipMemcpyHostToDevice, ctx->stream));
   const double thr2 = threshold * threshold;
   GH_LAUNCH(ctx, "ransac_solve", ransac_solve_kernel, dim3(kHyp / 64), dim3(64), 0, model, d_p, d_q, n, seed, nm,
             d_models, d_valid);
@@ -681,24 +685,28 @@ extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const doubl
   int best[2] = {-1, 0};
   if (confidence > 0.0 && confidence < 1.0) {
     // the prefix rule needs the counts on the host: 8 KB back, the choice (two ints) forth
-    std::vector<int> h_counts(kHyp);
-    GH_HIP(ctx, hipMemcpyAsync(h_counts.data(), d_counts, kHyp * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    const int* h_counts = (const int*)(hb + off_counts);
+    GH_HIP(ctx, hipMemcpyAsync(hb + off_counts, d_counts, kHyp * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int used = 0;
-    best[0] = adaptive_prefix_best(h_counts.data(), n, s, confidence, &best[1], &used);
+    best[0] = adaptive_prefix_best(h_counts, n, s, confidence, &best[1], &used);
     if (hypotheses_used_out) *hypotheses_used_out = used;
-    GH_HIP(ctx, hipMemcpyAsync(d_best, best, 8, hipMemcpyHostToDevice, ctx->stream));
-    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `best` is a stack buffer
+    // sent from the pinned mirror; the download below into the same words is ordered behind it by the stream
+    memcpy(hb + off_best, best, 8);
+    GH_HIP(ctx, hipMemcpyAsync(d_best, hb + off_best, 8, hipMemcpyHostToDevice, ctx->stream));
   } else {
     GH_LAUNCH(ctx, "ransac_best", ransac_best_kernel, dim3(1), dim3(256), 0, d_counts, d_best);
     if (hypotheses_used_out) *hypotheses_used_out = kHyp;
   }
   GH_LAUNCH(ctx, "ransac_mask", ransac_mask_kernel, dim3(gh_div_up(n > 12 ? n : 12, 256)), dim3(256), 0, model, d_p, d_q,
             n, thr2, d_models, d_best, d_mask, d_mout);
-  GH_HIP(ctx, hipMemcpyAsync(best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(model_out, d_mout, 12 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (mask_out) GH_HIP(ctx, hipMemcpyAsync(mask_out, d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  // best | model | mask lie back to back: one download
+  GH_HIP(ctx, hipMemcpyAsync(hb + off_best, d_best, (off_mask - off_best) + (mask_out ? (size_t)n : 0), hipMemcpyDeviceToHost,
+                             ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(best, hb + off_best, 8);
+  memcpy(model_out, hb + off_mout, 12 * 8);
+  if (mask_out) memcpy(mask_out, hb + off_mask, (size_t)n);
   if (best[0] < 0) {
     for (int k = 0; k < 12; ++k) model_out[k] = 0.0;
     return GH_OK;
@@ -762,16 +770,21 @@ extern "C" gh_status gh_triangulate(gh_ctx* ctx, const double* ref2cur_pose, int
   GH_CHECK_ARG(ctx, ref2cur_pose && ref_dir && cur_dir && ref_points && ok);
   const size_t np_ = pose_stride == 0 ? 1 : (size_t)n;
   const size_t a = ((np_ * 56) + 255) & ~(size_t)255, b = (((size_t)n * 24) + 255) & ~(size_t)255;
-  void* base = nullptr;
-  GH_TRY(gh_scratch(ctx, a + 3 * b + (((size_t)n + 255) & ~(size_t)255), &base));
-  uint8_t* d = (uint8_t*)base;
-  GH_HIP(ctx, hipMemcpyAsync(d, ref2cur_pose, np_ * 56, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d + a, ref_dir, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(d + a + b, cur_dir, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+  void *base = nullptr, *hbase = nullptr;
+  const size_t total = a + 3 * b + (((size_t)n + 255) & ~(size_t)255);
+  GH_TRY(gh_scratch(ctx, total, &base));
+  GH_TRY(gh_pinned(ctx, total, &hbase));
+  uint8_t *d = (uint8_t*)base, *hd = (uint8_t*)hbase;
+  // [pose | ref_dir | cur_dir] up and [points | ok] down: one DMA each way through the pinned mirror of the layout
+  memcpy(hd, ref2cur_pose, np_ * 56);
+  memcpy(hd + a, ref_dir, (size_t)n * 24);
+  memcpy(hd + a + b, cur_dir, (size_t)n * 24);
+  GH_HIP(ctx, hipMemcpyAsync(d, hd, a + b + (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
   GH_LAUNCH(ctx, "triangulate", triangulate_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)d, pose_stride,
             (const double*)(d + a), (const double*)(d + a + b), n, (double*)(d + a + 2 * b), d + a + 3 * b);
-  GH_HIP(ctx, hipMemcpyAsync(ref_points, d + a + 2 * b, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
-  GH_HIP(ctx, hipMemcpyAsync(ok, d + a + 3 * b, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(hd + a + 2 * b, d + a + 2 * b, b + (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(ref_points, hd + a + 2 * b, (size_t)n * 24);
+  memcpy(ok, hd + a + 3 * b, (size_t)n);
   return GH_OK;
 }

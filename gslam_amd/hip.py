@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgslam_hip.so")
+# GSLAM_HIP_LIB: another build of the same library (A/B measurements of two builds on one box: tools/host_call_probe.py)
+LIB_PATH = os.environ.get("GSLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libgslam_hip.so")
 
 
 class GslamHipError(RuntimeError):

@@ -98,6 +98,31 @@ def test_pose_graph_dense_and_block_sparse_paths_agree(ctx, monkeypatch, nf, loo
     print("%s: dense %.1f ms, block-sparse %.1f ms per solve call" % (what, sd.total_ms, ss.total_ms))
 
 
+def test_graph_arena_bit_identical_to_one_allocation_per_array(ctx, monkeypatch):
+    """graph_arena.h: the arrays of a solve bump-allocated from the context's grow-only arena and the uploads sent as one
+    staged DMA must not change a bit against one hipMalloc / one copy per array (GSLAM_HIP_PG_ARENA=0) -- on the dense and
+    the block-sparse path, on an arena that has to grow, one that is reused with the previous solve's contents in it, and
+    one that is larger than the solve (a small graph after a large one)."""
+    from gslam_amd import ba, posegraph
+    graphs = [make_pose_graph(nf, loops, kind=kind, seed=31 + nf, noise=0.01, perturb=0.04, scale_drift=0.1, gps_every=gps,
+                              with_info=info)
+              for nf, loops, kind, gps, info in ((60, 10, "mixed", 6, True), (500, 70, "sim3", 0, False), (90, 12, "se3", 0, False))]
+
+    def run_all():
+        out = []
+        for truth, start, dof, prob in graphs:
+            S, sm, st = posegraph.solve(ctx, start, dof, prob, ba.default_options(max_iterations=6))
+            assert st == 0
+            out.append((S.tobytes(), list(sm.trace_cost[:sm.trace_len]), sm.iterations))
+        return out
+
+    monkeypatch.setenv("GSLAM_HIP_PG_ARENA", "0")
+    ref = run_all()
+    monkeypatch.setenv("GSLAM_HIP_PG_ARENA", "1")
+    assert run_all() == ref  # arena grows twice, then serves a smaller graph
+    assert run_all() == ref  # arena reused as it is
+
+
 def test_pose_graph_of_6000_keyframes_recovers_the_truth(ctx):
     """A loop-closing sized essential graph (42 000 unknowns; the dense system would be 14 GB): block-sparse by default."""
     from gslam_amd import ba, posegraph
