@@ -247,6 +247,42 @@ __device__ __forceinline__ int fast_score16(const int (&r)[16], int c) {
   return max3i(0, best_lo - c, c - best_hi);
 }
 
+// The same score with BOTH polarities in one register: v = r | (255 - r) << 16, two 16-bit lanes whose bit patterns are
+// fp16 DENORMALS (0 .. 255 -> exponent field 0), which order exactly as the integers do; the kernels run with fp16
+// denormals preserved (amdhsa_float_denorm_mode_16_64 = 3).  min over an arc of the high lane is 255 - max over the arc of
+// r, so ONE gfx950 v_pk_minimum3_f16 does the work of a v_min3_u32 and a v_max3_u32, and the running best of both
+// polarities is a maximum: 16 packs + 16 + 16 + 8 three-input packed ops + 5 instead of 32 + 32 + 16 + 3 (bit-identical:
+// every value is an exact small integer, no rounding anywhere).
+__device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int fast_score16_pk(const int (&r)[16], int c) {
+  uint32_t v[16], m3[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    // r - 65536 r + 255 * 65536 = r | (255 - r) << 16
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(v[i]) : "v"(r[i]), "v"(-65535), "v"(255 << 16));
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m3[i] = pk_min3_f16(v[i], v[(i + 1) & 15], v[(i + 2) & 15]);
+  uint32_t best = 0u;  // low lane: max(0, max_i min(arc_i)); high lane: 255 - min(255, min_i max(arc_i))
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const uint32_t a = pk_min3_f16(m3[i], m3[(i + 3) & 15], m3[(i + 6) & 15]);
+    const uint32_t b = pk_min3_f16(m3[i + 1], m3[(i + 4) & 15], m3[(i + 7) & 15]);
+    best = pk_max3_f16(best, a, b);
+  }
+  const int best_lo = (int)(best & 0xFFFFu), hi_c = (int)(best >> 16);
+  return max3i(0, best_lo - c, c - 255 + hi_c);
+}
+
 constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligned window that covers x0-4 .. x0+67), 72 rows
 constexpr int kTileH = 72;
 constexpr int kScoreH = 66;   // score window: 64x64 region + 1 px NMS halo
@@ -254,6 +290,8 @@ constexpr int kScoreOff = 3;  // window col sx is stored at byte sx + 3 so that 
 constexpr int kScoreW = 72;   // row pitch (bytes)
 
 // One 64 x 64 tile (2 x 2 cells) of one level of one frame, by one 256-thread workgroup; tile_id in [0, nbx nby n_frames).
+// PK: arc scores through fast_score16_pk (GSLAM_HIP_ORB_PKSCORE, decided per plan).
+template <bool PK>
 __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, int ncy, int min_th, int ini_th,
                                                 uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_ent,
                                                 int cells_per_frame, int cell_off, int n_frames, const NextLevel& nx,
@@ -404,7 +442,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     r[13] = p[-1 * kTileW - 3];
     r[14] = p[-2 * kTileW - 2];
     r[15] = p[-3 * kTileW - 1];
-    const int s = fast_score16(r, c);
+    const int s = PK ? fast_score16_pk(r, c) : fast_score16(r, c);
     if (s > min_th) score[pos] = (uint8_t)s;
   }
   __syncthreads();
@@ -582,6 +620,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   }
 }
 
+template <bool PK>
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
@@ -590,7 +629,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   const int total = ((ncx + 1) >> 1) * ((ncy + 1) >> 1) * n_frames;
   const int tile_id = xcd_strip_tile(blockIdx.x, total);
   if (tile_id >= total) return;
-  fast_cells_tile(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
+  fast_cells_tile<PK>(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
 }
 
 // Every level in ONE launch, over a pyramid that exists already (stand-alone resize launches): what a small call wants --
@@ -601,6 +640,7 @@ struct AllLevels {
   int ncx[kMaxL], ncy[kMaxL], cell_off[kMaxL], tile_start[kMaxL + 1];
   int n_levels;
 };
+template <bool PK>
 __global__ __launch_bounds__(256) void fast_cells_all_kernel(AllLevels A, int min_th, int ini_th,
                                                              uint32_t* __restrict__ cell_cnt,
                                                              uint32_t* __restrict__ cell_ent, int cells_per_frame,
@@ -609,8 +649,8 @@ __global__ __launch_bounds__(256) void fast_cells_all_kernel(AllLevels A, int mi
   for (int k = 1; k < A.n_levels; ++k)
     if ((int)blockIdx.x >= A.tile_start[k]) l = k;
   const NextLevel none{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
-  fast_cells_tile(A.lv[l], A.ncx[l], A.ncy[l], min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, A.cell_off[l], n_frames, none,
-                  dbg, (int)blockIdx.x - A.tile_start[l]);
+  fast_cells_tile<PK>(A.lv[l], A.ncx[l], A.ncy[l], min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, A.cell_off[l], n_frames, none,
+                      dbg, (int)blockIdx.x - A.tile_start[l]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1074,6 +1114,7 @@ struct gh_orb_plan {
   const int32_t* own_gx[kMaxL] = {nullptr};  // fused pyramid: first owned output group / row per tile column / row of level l
   const int32_t* own_gy[kMaxL] = {nullptr};
   bool fuse_pyramid = true;  // GSLAM_HIP_ORB_FUSE_PYRAMID=0 keeps the stand-alone resize launches (A/B measurements)
+  bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
   int8_t* d_pattern = nullptr;
   int32_t* d_dir = nullptr;
   uint32_t* tabs = nullptr;
@@ -1203,6 +1244,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   p->max_batch = max_batch;
   p->prm = prm;
   if (const char* e = getenv("GSLAM_HIP_ORB_FUSE_PYRAMID")) p->fuse_pyramid = atoi(e) != 0;
+  if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
   long long den = ipow(6, L) - ipow(5, L);
@@ -1527,9 +1569,14 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       if (l < L && p->ncx[l] != 0 && p->quota[l] > 0) tiles += gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
     }
     A.tile_start[kMaxL] = tiles;
-    if (tiles > 0)
-      GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_all_kernel, dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast, p->prm.ini_th_fast,
-                p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg);
+    if (tiles > 0) {
+      if (p->pk_score)
+        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_all_kernel<true>, dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast,
+                  p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg);
+      else
+        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_all_kernel<false>, dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast,
+                  p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg);
+    }
     overlap = false;
   }
   for (int l = 0; l < L && !all_levels; ++l) {
@@ -1545,9 +1592,14 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
       GH_CHECK_ARG(ctx, tiles < (1LL << 30));
       dim3 grid(8 * gh_div_up(tiles, 8));
-      GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
-                p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-                batch, nx, dbg);
+      if (p->pk_score)
+        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel<true>, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
+                  p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
+                  batch, nx, dbg);
+      else
+        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel<false>, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
+                  p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
+                  batch, nx, dbg);
       if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
     }
     if (overlap) {  // (a level without a FAST pass still gets its level_cnt = 0 from select)
