@@ -586,7 +586,10 @@ def main():
         s = None
         if separate_timed_run:  # small graphs: time without the event overhead, then repeat with per-kernel events
             log(f"BA leg {name}: timed solve")
-            _, _, s, _ = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
+            for _ in range(1 if cams >= 10000 else 3):  # C4: best of 3, like the resident-graph figure below (the per-solve host work varies from run to run)
+                _, _, s1, _ = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
+                if s is None or s1.total_ms < s.total_ms:
+                    s = s1
         ctx.prof_enable(True)
         _, _, sp, _ = ba.solve(ctx, g, ba.default_options(max_iterations=prof_iters or iters))
         bprof = ctx.prof_collect()
@@ -817,12 +820,20 @@ def main():
         o = default_options()
         o.max_iterations = 30
         posegraph.solve(ctx, start, dof, prob, o)
-        ctx.prof_enable(True)
-        t1 = time.perf_counter()
-        S, sm, st = posegraph.solve(ctx, start, dof, prob, o)
-        dt = time.perf_counter() - t1
-        pk = ctx.prof_collect()
-        ctx.prof_enable(False)
+
+        def timed(fn, reps=5):
+            """median wall time of fn() without the per-kernel events, then one profiled call for the kernel breakdown"""
+            ts = []
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                r = fn()
+                ts.append(time.perf_counter() - t1)
+            ctx.prof_enable(True)
+            fn()
+            pk_ = ctx.prof_collect()
+            ctx.prof_enable(False)
+            return r, sorted(ts)[len(ts) // 2], pk_
+        (S, sm, st), dt, pk = timed(lambda: posegraph.solve(ctx, start, dof, prob, o))
         out["pose_graph"] = {"workload": "400 SIM3 keyframes, 460 sim3 edges (n = 2800; block-sparse + dense root of 128 keyframes)",
                              "iterations": sm.iterations,
                              "iters_per_s": round(sm.iterations / dt, 1), "total_ms": round(dt * 1e3, 2), "status": int(st),
@@ -833,12 +844,7 @@ def main():
         o = default_options()
         o.max_iterations = 15
         posegraph.solve(ctx, start, dof, prob, o)
-        ctx.prof_enable(True)
-        t1 = time.perf_counter()
-        S, sm, st = posegraph.solve(ctx, start, dof, prob, o)
-        dt = time.perf_counter() - t1
-        pk = ctx.prof_collect()
-        ctx.prof_enable(False)
+        (S, sm, st), dt, pk = timed(lambda: posegraph.solve(ctx, start, dof, prob, o))
         sym = posegraph.bs_symbolic(5000, np.maximum(prob["sim3"][0], prob["sim3"][1]), np.minimum(prob["sim3"][0], prob["sim3"][1]))
         out["pose_graph_large"] = {"workload": "5000 SIM3 keyframes, 5600 sim3 edges (n = 35 000)", "iterations": sm.iterations,
                                    "iters_per_s": round(sm.iterations / dt, 1), "total_ms": round(dt * 1e3, 2), "status": int(st),
@@ -853,12 +859,7 @@ def main():
         o.huber_delta = 0.01
         o.max_iterations = 15
         posegraph.solve_graph(ctx, start, dof, prob, o)
-        ctx.prof_enable(True)
-        t1 = time.perf_counter()
-        S, xyz, rho, sm, st = posegraph.solve_graph(ctx, start, dof, prob, o)
-        dt = time.perf_counter() - t1
-        pk = ctx.prof_collect()
-        ctx.prof_enable(False)
+        (S, xyz, rho, sm, st), dt, pk = timed(lambda: posegraph.solve_graph(ctx, start, dof, prob, o))
         out["general_graph"] = {"workload": "120 SIM3 keyframes + 123 pose edges + 6000 XYZ + 6000 inverse-depth landmarks, 60 000 observations",
                                 "iterations": sm.iterations, "iters_per_s": round(sm.iterations / dt, 1), "total_ms": round(dt * 1e3, 2),
                                 "status": int(st), "cost": [sm.initial_cost, sm.final_cost],
