@@ -90,6 +90,20 @@ PROBE(mix_xor_bcnt, "v_xor_b32 %0, %1, %0\n v_bcnt_u32_b32 %0, %2, %0")
 PROBE(mix_fma_perm, "v_fma_f32 %0, %1, %2, %0\n v_perm_b32 %0, %1, %0, %2")
 PROBE(mix_xor_xor_bcnt, "v_xor_b32 %0, %1, %0\n v_xor_b32 %0, %2, %0\n v_bcnt_u32_b32 %0, %2, %0")
 
+// gfx950 additions and the classes the packed fp16 arc score of orb_fast_cells uses (round 3, end)
+PROBE(pk_minimum3_f16, "v_pk_minimum3_f16 %0, %1, %2, %0")
+PROBE(pk_maximum3_f16, "v_pk_maximum3_f16 %0, %1, %2, %0")
+PROBE(minimum3_f32, "v_minimum3_f32 %0, %1, %2, %0")
+PROBE(pk_min_f16, "v_pk_min_f16 %0, %1, %0")
+PROBE(pk_min_u16, "v_pk_min_u16 %0, %1, %0")
+PROBE(pk_mad_u16, "v_pk_mad_u16 %0, %1, %2, %0")
+PROBE(mad_i32_i24, "v_mad_i32_i24 %0, %1, %2, %0")
+PROBE(bitop3_b32, "v_bitop3_b32 %0, %1, %2, %0 bitop3:0x96")
+PROBE(mix_pkmin3_perm, "v_pk_minimum3_f16 %0, %1, %2, %0\n v_perm_b32 %0, %1, %0, %2")
+PROBE(mix_pkmin3_pkmax_i16, "v_pk_minimum3_f16 %0, %1, %2, %0\n v_pk_max_i16 %0, %1, %0")
+PROBE(mix_pkmin3_fma_f32, "v_pk_minimum3_f16 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0")
+PROBE(mix_pkmin3_xor, "v_pk_minimum3_f16 %0, %1, %2, %0\n v_xor_b32 %0, %1, %0")
+
 struct P { const char* name; void (*fn)(uint32_t*, int, uint32_t); int per; };
 #define E(NAME, PER) {#NAME, k_##NAME, PER}
 
@@ -110,7 +124,9 @@ int main() {
                       E(mul_u32_u24, 1), E(mad_u32_u24, 1), E(mul_lo_u32, 1), E(max_u16, 1), E(sub_u16, 1), E(pk_max_i16, 1),
                       E(pk_add_u16, 1), E(pk_sub_i16, 1), E(pk_add_f16, 1), E(pk_max_f16, 1), E(pk_fma_f16, 1), E(max_f16, 1),
                       E(sdwa_max_u16_b0, 1), E(sdwa_add_u32_b1, 1), E(sdwa_max_f32, 1), E(dpp_add_u32, 1), E(readlane_pair, 2),
-                      E(mix_xor_bcnt, 2), E(mix_fma_perm, 2), E(mix_xor_xor_bcnt, 3)};
+                      E(mix_xor_bcnt, 2), E(mix_fma_perm, 2), E(mix_xor_xor_bcnt, 3), E(pk_minimum3_f16, 1), E(pk_maximum3_f16, 1),
+                      E(minimum3_f32, 1), E(pk_min_f16, 1), E(pk_min_u16, 1), E(pk_mad_u16, 1), E(mad_i32_i24, 1), E(bitop3_b32, 1),
+                      E(mix_pkmin3_perm, 2), E(mix_pkmin3_pkmax_i16, 2), E(mix_pkmin3_fma_f32, 2), E(mix_pkmin3_xor, 2)};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
