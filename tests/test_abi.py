@@ -80,3 +80,22 @@ def test_product_never_imports_oracle():
                     if re.search(r"oracle_lib|liboracle|#include\s+\"[^\"]*oracle/|import oracle|from oracle", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_library_override_for_ab_measurements(tmp_path):
+    """GSLAM_HIP_LIB points the ctypes mirror at another build of the same library (tools/host_call_probe.py measures two
+    builds on one box that way); a path that does not exist fails loudly, like a missing library."""
+    import shutil
+    import subprocess
+    import sys
+    from gslam_amd import hip
+    other = tmp_path / "libgslam_hip_other.so"
+    shutil.copy(os.path.join(ROOT, "gslam_amd", "lib", "libgslam_hip.so"), other)
+    code = "from gslam_amd import hip; print(hip.LIB_PATH, hip.lib.gh_abi_version())"
+    env = dict(os.environ, GSLAM_HIP_LIB=str(other), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and r.stdout.split() == [str(other), "1"], r.stderr[-400:]
+    env["GSLAM_HIP_LIB"] = str(tmp_path / "missing.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert r.returncode != 0 and "ImportError" in r.stderr
+    assert hip.LIB_PATH.endswith(os.path.join("gslam_amd", "lib", "libgslam_hip.so"))
