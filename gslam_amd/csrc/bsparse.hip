@@ -77,18 +77,27 @@ void BsPattern::build(int n_frames, int n_pairs, const int32_t* prow, const int3
       pair_products += (long long)sv.size() * (sv.size() + 1) / 2;
       for (int32_t u : sv) {  // u loses v and gains the rest of v's neighbourhood: one merge of two ascending lists
         const std::vector<int32_t>& au = adj[u];
-        merged.clear();
-        size_t a = 0, b = 0;
-        while (a < au.size() || b < sv.size()) {
-          int32_t w;
-          if (b >= sv.size() || (a < au.size() && au[a] < sv[b])) w = au[a++];
-          else if (a >= au.size() || sv[b] < au[a]) w = sv[b++];
-          else {
-            w = au[a++];
-            ++b;
-          }
-          if (w != u && w != v) merged.push_back(w);
+        const size_t na = au.size(), nb = sv.size();
+        merged.resize(na + nb);
+        const int32_t *pa = au.data(), *pb = sv.data();
+        int32_t* out = merged.data();
+        size_t a = 0, b = 0, n = 0;
+        while (a < na && b < nb) {  // branch-light: both cursors advance on equal elements, u and v are dropped by not counting them
+          const int32_t x = pa[a], y = pb[b], w = x < y ? x : y;
+          a += x <= y;
+          b += y <= x;
+          out[n] = w;
+          n += (w != u) & (w != v);
         }
+        for (; a < na; ++a) {
+          out[n] = pa[a];
+          n += (pa[a] != u) & (pa[a] != v);
+        }
+        for (; b < nb; ++b) {
+          out[n] = pb[b];
+          n += (pb[b] != u) & (pb[b] != v);
+        }
+        merged.resize(n);
         adj[u].swap(merged);
       }
     }
