@@ -199,3 +199,19 @@ def test_adversarial_through_featuredetector_plugin(tmp_path, oracle, name):
     keep = oracle.match_mask(e[0], e[1], e[2], e[0], n, 100, 0, 1, 1)
     exp = np.stack([np.nonzero(keep)[0], e[0][keep == 1]], axis=1).astype(np.int32)
     assert np.array_equal(np.frombuffer(raw, np.int32, nm * 2, 16 + n * 60).reshape(nm, 2), exp)
+
+
+def test_arc_score_paths_agree_bit_for_bit(ctx, monkeypatch):
+    """orb_fast_cells computes the FAST arc score on packed fp16 denormals (v_pk_minimum3_f16 / v_pk_maximum3_f16, the
+    default) or with 32-bit v_min3 / v_max3 (GSLAM_HIP_ORB_PKSCORE=0, read when the plan is created): the two must give
+    identical records on inputs that saturate, clip at 0 / 255 and tie (the default path is the one every other test in
+    this file holds against the oracle)."""
+    names = ("noise", "binary_noise", "checker1", "checker2", "step_edges", "low_contrast", "mixed")
+    for name in names:
+        frames = np.stack([CLASSES[name](320, 240, 99 + i) for i in range(2)])
+        monkeypatch.setenv("GSLAM_HIP_ORB_PKSCORE", "1")
+        (k1, d1, c1), _ = _extract_gpu(ctx, frames, 800, census=False)
+        monkeypatch.setenv("GSLAM_HIP_ORB_PKSCORE", "0")
+        (k0, d0, c0), _ = _extract_gpu(ctx, frames, 800, census=False)
+        assert np.array_equal(c0, c1) and k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1), name
+    monkeypatch.delenv("GSLAM_HIP_ORB_PKSCORE")
