@@ -11,7 +11,8 @@ REF       ?= /root/reference
 # (-ffp-contract=off: the float vocabulary distance and the LM arithmetic must round like the oracle's.  Never add
 #  -fgpu-flush-denormals-to-zero / -ffast-math: orb_fast_cells compares bytes held as fp16 DENORMALS with
 #  v_pk_minimum3_f16 / v_pk_maximum3_f16 and relies on the default float mode that preserves them --
-#  tests/test_orb_adversarial_gpu.py::test_arc_score_paths_agree_bit_for_bit would catch it.)
+#  tests/test_build_float_mode.py (no GPU needed) and tests/test_orb_adversarial_gpu.py::test_arc_score_paths_agree_bit_for_bit
+#  would catch it.)
 HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -Iinclude
 ifdef WHATIF
 HIPFLAGS  += -DGH_FLOW_WHATIF $(WHATIF_FLAGS)  # timing experiments only (tools/flow_whatif.py)
