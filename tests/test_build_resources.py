@@ -1,0 +1,75 @@
+"""Build check (no GPU): register / scratch budgets of the hot kernels in the shipped libgslam_hip.so, read from the code
+objects' metadata.  The kernels are tuned against these numbers (occupancy of the VALU-bound ORB
+kernels, 256-register budget of the single-launch factorisation, no spills to scratch anywhere on the hot path); a
+compiler or flag change that breaks one of them should fail here, on the CPU, before it shows up as a slower bench."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from test_build_float_mode import LIB, LLVM, _code_objects
+
+# kernel-name fragment -> (max VGPRs + AGPRs, max bytes of scratch per work-item)
+BUDGET = {
+    "fast_cells_kernel": (72, 0),        # >= 6 waves per SIMD beside 24.5 KB of LDS per workgroup
+    "fast_cells_all_kernel": (72, 0),
+    "describe_kernel": (48, 0),
+    "select_kernel": (128, 0),
+    "resize_kernel": (64, 0),
+    "bf_match_pairs_kernel": (64, 0),    # 8 waves per SIMD
+    "bf_match_split_kernel": (64, 0),
+    "bf_match_pairs_mfma_kernel": (256, 0),
+    "potrf_flow_kernel": (256, 0),       # 512-thread workgroups: two waves per SIMD, everything in registers
+    "bwd_chain_kernel": (128, 0),
+    "syrk_mfma_kernel": (256, 0),
+    # eight waves per 128 x 128 tile, four waves per SIMD: 128 registers; the potf2 + inverse of the next diagonal block that
+    # ONE workgroup of the launch runs (potf2_fused, written for 256 registers) spills a few values there -- the MFMA loops of
+    # the tiles hold everything in registers (no scratch instruction between the loop labels of the ISA)
+    "syrk_mfma8_kernel": (128, 64),
+    "lin_kernel": (192, 0),
+    "schur_blocks_kernel": (256, 0),
+    "bow_words_kernel": (64, 0),
+    "pack_results_kernel": (32, 0),
+}
+
+
+def _kernels():
+    rows = {}
+    for i, co in enumerate(_code_objects(LIB)):
+        p = "/tmp/gslam_build_res_%d_%d.elf" % (os.getpid(), i)
+        with open(p, "wb") as f:
+            f.write(co)
+        try:
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", p], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.remove(p)
+        cur = {}
+        for line in notes.splitlines():
+            m = re.match(r"\s+(?:- )?\.(\w+):\s+(\S+)\s*$", line)
+            if not m:
+                continue
+            k, v = m.groups()
+            if k == "agpr_count" and "name" in cur:  # first key of the next kernel's record
+                rows[cur["name"]] = cur
+                cur = {}
+            if k in ("name", "vgpr_count", "agpr_count", "vgpr_spill_count", "private_segment_fixed_size"):
+                cur[k] = v
+        if "name" in cur:
+            rows[cur["name"]] = cur
+    return rows
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="needs the ROCm llvm-readelf")
+def test_hot_kernels_stay_within_their_register_and_scratch_budgets():
+    assert os.path.exists(LIB), "build the library first (make lib)"
+    rows = _kernels()
+    assert len(rows) >= 60
+    for frag, (max_regs, max_scratch) in BUDGET.items():
+        hits = [r for n, r in rows.items() if re.search(r"\d+%s[A-Z]" % frag, n)]  # the mangled name holds <length><identifier>
+        assert hits, "kernel %s not found in the library" % frag
+        for r in hits:
+            regs = int(r["vgpr_count"]) + int(r.get("agpr_count", 0))
+            assert regs <= max_regs, "%s: %d registers (budget %d)" % (r["name"], regs, max_regs)
+            assert int(r["vgpr_spill_count"]) == 0 or max_scratch > 0, "%s spills vector registers" % r["name"]
+            assert int(r["private_segment_fixed_size"]) <= max_scratch, "%s: %s bytes of scratch" % (r["name"], r["private_segment_fixed_size"])
