@@ -577,10 +577,11 @@ def main():
 
     def ba_leg(cams, points, iters, separate_timed_run, prof_iters=None):
         from gslam_amd import ba
-        from gslam_amd.ba_synth import make_graph
+        from gslam_amd.ba_synth import graph_census, make_graph
         name = "C5" if cams >= 10000 else "C4"
         log(f"BA leg {name}: building graph")
         g = make_graph(cams, points, n_obs_per_point=6, seed=1)
+        census = graph_census(g)  # cameras observed, observations per camera, block fill of the reduced camera system
         log(f"BA leg {name}: warm-up solve")
         ba.solve(ctx, g, ba.default_options(max_iterations=1 if cams >= 10000 else 2))  # allocations, code load
         s = None
@@ -616,6 +617,7 @@ def main():
         chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CHOL)
         launches = sum(v["launches"] for v in bprof.values())
         return {"workload": f"{name}: {cams} cams, {points} pts, {len(g['obs_cam'])} obs, Huber LM",
+                "graph_census": census,
                 "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
                 "ms_per_iteration": round(s.total_ms / max(1, s.iterations), 3),
                 "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,

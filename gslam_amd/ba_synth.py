@@ -1,7 +1,14 @@
 """Synthetic bundle-adjustment graphs: cameras on a noisy helix looking inward, points
-uniform in a box, each point observed by its `n_obs_per_point` nearest cameras, pixel noise
-sigma = 1 px at f = 500 (0.002 normalised), 5 % outliers (x50), initial poses perturbed 1 deg / 1 %,
-points 1 %; first camera fixed.  Input generator for tests and bench.py — numpy/scipy only.
+uniform in a box around the axis, each point observed by `n_obs_per_point` cameras drawn from a window of
+consecutive cameras along the trajectory (its co-visibility neighbourhood: +-12 cameras around a home
+position drawn uniformly along the helix), pixel noise sigma = 1 px at f = 500 (0.002 normalised), 5 %
+outliers (x50), initial poses perturbed 1 deg / 1 %, points 1 %; first camera fixed.  Input generator for
+tests and bench.py -- numpy only.
+
+Every camera therefore carries about n_points * n_obs_per_point / n_cams observations and the reduced
+camera system is a band of half-width <= 24 blocks (`graph_census` reports the numbers; bench.py prints
+them).  Rounds 1-3 picked each point's observers by EUCLIDEAN distance to the camera centres, which gave
+nearly all observations to the few cameras with the smallest radius noise.
 
 Layout mirrors GSLAM::BundleGraph (GSLAM/core/Optimizer.h:150-172): keyframes = T_wc as
 [qx qy qz qw tx ty tz] + dof bitmask, mappoints = xyz, mappointObserves = (pointId, frameId,
@@ -50,8 +57,51 @@ def _quat_mul(a, b):
                      aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz], axis=1)
 
 
+COVIS_HALF_WINDOW = 12  # cameras either side of a point's home position that may observe it
+
+
+def _pick_observers(rng, n_cams, n_points, k):
+    """(n_points, k) camera ids: k distinct cameras out of the window of 2 * COVIS_HALF_WINDOW + 1 consecutive cameras
+    around a home position drawn uniformly along the trajectory (the whole trajectory when it is shorter than that)."""
+    win = min(n_cams, 2 * COVIS_HALF_WINDOW + 1)
+    home = rng.integers(0, n_cams, size=n_points)
+    lo = np.clip(home - win // 2, 0, n_cams - win)
+    nn = np.empty((n_points, k), np.int64)
+    step = 1 << 18  # bounded temporaries for the 1M-point graph
+    for a in range(0, n_points, step):
+        b = min(n_points, a + step)
+        order = np.argsort(rng.random((b - a, win)), axis=1)[:, :k]
+        nn[a:b] = lo[a:b, None] + np.sort(order, axis=1)
+    return nn
+
+
+def graph_census(g):
+    """Who sees what: cameras observed, observations per camera (min / median / max) and the block fill of the reduced
+    camera system S (lower triangle incl. diagonal, 6x6 blocks, all cameras counted)."""
+    n_cams = len(g["cam_dof"])
+    per_cam = np.bincount(g["obs_cam"], minlength=n_cams)
+    order = np.argsort(g["obs_point"], kind="stable")
+    pt, cam = g["obs_point"][order].astype(np.int64), g["obs_cam"][order].astype(np.int64)
+    start = np.flatnonzero(np.r_[True, pt[1:] != pt[:-1]])
+    cnt = np.diff(np.r_[start, len(pt)])
+    keys = [cam * n_cams + cam]
+    kmax = int(cnt.max()) if len(cnt) else 0
+    idx = np.arange(len(pt))
+    first = np.repeat(start, cnt)
+    for d in range(1, kmax):
+        ok = idx + d < first + np.repeat(cnt, cnt)
+        a, b = cam[idx[ok]], cam[idx[ok] + d]
+        keys.append(np.maximum(a, b) * n_cams + np.minimum(a, b))
+    blocks = len(np.unique(np.concatenate(keys)))
+    total = n_cams * (n_cams + 1) // 2
+    seen = per_cam[per_cam > 0]
+    return {"cams": int(n_cams), "cams_observed": int((per_cam > 0).sum()), "obs_per_cam_min": int(per_cam.min()),
+            "obs_per_cam_median": float(np.median(per_cam)), "obs_per_cam_max": int(per_cam.max()),
+            "obs_per_observed_cam_min": int(seen.min()) if len(seen) else 0,
+            "s_lower_blocks": int(blocks), "s_lower_blocks_total": int(total), "s_block_fill": blocks / total}
+
+
 def make_graph(n_cams, n_points, n_obs_per_point=6, seed=1, noise=0.002, outlier_frac=0.05, perturb=True):
-    from scipy.spatial import cKDTree
     rng = np.random.default_rng(seed)
     ang = np.linspace(0, 2 * np.pi * max(1.0, n_cams / 200.0), n_cams, endpoint=False)
     radius = 10.0 + 0.3 * rng.standard_normal(n_cams)
@@ -66,8 +116,12 @@ def make_graph(n_cams, n_points, n_obs_per_point=6, seed=1, noise=0.002, outlier
     q_gt = _quat_from_R(R)
     pts_gt = rng.uniform(-3, 3, size=(n_points, 3))
     k = min(n_obs_per_point, n_cams)
-    _, nn = cKDTree(pos).query(pts_gt, k=k)
-    nn = nn.reshape(n_points, k)
+    nn = _pick_observers(rng, n_cams, n_points, k)
+    per_cam = np.bincount(nn.reshape(-1), minlength=n_cams)
+    mean_obs = n_points * k / n_cams
+    # every camera is observed, and evenly: no camera carries the graph (the bar VERDICT r3 item 3 set for the bench graphs)
+    assert per_cam.min() >= min(50, int(mean_obs / 4)), (per_cam.min(), mean_obs)
+    assert mean_obs < 100 or per_cam.max() <= 4 * np.median(per_cam), (per_cam.max(), np.median(per_cam))
     obs_point = np.repeat(np.arange(n_points, dtype=np.int32), k)
     obs_cam = nn.reshape(-1).astype(np.int32)
     Xc = np.einsum("nji,nj->ni", R[obs_cam], pts_gt[obs_point] - pos[obs_cam])

@@ -287,22 +287,34 @@ constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligne
 constexpr int kTileH = 72;
 constexpr int kScoreH = 66;   // score window: 64x64 region + 1 px NMS halo
 constexpr int kScoreOff = 3;  // window col sx is stored at byte sx + 3 so that both cells of a row start dword aligned
-constexpr int kScoreW = 72;   // row pitch (bytes)
+constexpr int kScoreWPk = 72;  // row pitch (bytes) of the packed-16-bit pass 1; the SWAR pass 1 uses 68 (see fast_cells_tile)
 
 // One 64 x 64 tile (2 x 2 cells) of one level of one frame, by one 256-thread workgroup; tile_id in [0, nbx nby n_frames).
 // PK: arc scores through fast_score16_pk (GSLAM_HIP_ORB_PKSCORE, decided per plan).
-template <bool PK>
+// P1: formulation of pass 1 (GSLAM_HIP_ORB_PASS1, decided per plan) -- 0 = packed 16-bit min / max (rounds 2-3),
+//     1 = SWAR on 16-bit fields with full-rate ALU ops, fields split in registers, 2 = the same on pre-split LDS planes.
+template <bool PK, int P1>
 __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, int ncy, int min_th, int ini_th,
                                                 uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_ent,
                                                 int cells_per_frame, int cell_off, int n_frames, const NextLevel& nx,
                                                 uint32_t* __restrict__ dbg, int tile_id) {
+  // SWAR pass 1 covers a window row with 17 aligned dwords (window cols -2 .. 65) and the score tile is FLAT with 68 bytes
+  // per row: byte 68 sy + 3 + sx, so (item, pixel k) lands at 4 item + 1 + k.  Cols -2 / -1 of a row share their bytes with
+  // cols 66 / 67 of the row above; nothing ever reads them (NMS looks at cols 0 .. 65 only).
+  constexpr int kScoreW = P1 != 0 ? 68 : kScoreWPk;
+  constexpr int kScoreBytes = P1 != 0 ? kScoreH * 68 + 8 : kScoreH * kScoreWPk;
+  constexpr int kQueueLen = P1 != 0 ? kScoreH * 68 : kScoreH * kScoreH;
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
-  __shared__ __attribute__((aligned(16))) uint8_t score[kScoreH * kScoreW];
+  __shared__ __attribute__((aligned(16))) uint8_t score[kScoreBytes];
   __shared__ uint32_t lists[4][256];
-  __shared__ uint16_t queue[kScoreH * kScoreH];
+  __shared__ uint16_t queue[kQueueLen];
   __shared__ int q_count;
+  // P1 == 2: every tile dword split once into its even bytes {b0, b2} and odd bytes {b1, b3} as zero-extended 16-bit fields
+  __shared__ __attribute__((aligned(16))) uint2 planes[P1 == 2 ? kTileH * (kTileW / 4) : 2];
+  __shared__ uint16_t bit_pos[32];  // P1 != 0: score-tile offset of candidate bit b of a thread, relative to 4 tid
 
   const int tid = threadIdx.x;
+  __builtin_assume(tid >= 0 && tid < 256);
   const int nbx = (ncx + 1) >> 1, nby = (ncy + 1) >> 1;
   const int frame = tile_id / (nbx * nby);
   const int trem = tile_id - frame * (nbx * nby);
@@ -322,6 +334,19 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     gx = gx > lv.pitch - 16 ? lv.pitch - 16 : gx;
     const uint4 v = *reinterpret_cast<const uint4*>(img + (size_t)gy * lv.pitch + gx);
     *reinterpret_cast<uint4*>(&tile[row * kTileW + 16 * c]) = v;
+    if constexpr (P1 == 2) {
+      constexpr uint32_t kF = 0x00FF00FFu;
+      uint4* pl = reinterpret_cast<uint4*>(&planes[row * (kTileW / 4) + 4 * c]);
+      pl[0] = uint4{v.x & kF, (v.x >> 8) & kF, v.y & kF, (v.y >> 8) & kF};
+      pl[1] = uint4{v.z & kF, (v.z >> 8) & kF, v.w & kF, (v.w >> 8) & kF};
+    }
+  }
+  if constexpr (P1 != 0) {
+    // candidate bit b of a thread (see pass 1): b ^ 15 = 16 (k >> 1) + 2 trip + (k & 1) -> score offset 1024 trip + 1 + k
+    if (tid < 32) {
+      const int ix = tid ^ 15, k = (ix & 1) + 2 * (ix >> 4), trip = (ix >> 1) & 7;
+      bit_pos[tid] = (uint16_t)(1024 * trip + 1 + k);
+    }
   }
   __syncthreads();
 
@@ -331,18 +356,85 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   // score) runs with all lanes busy instead of paying full price in every partially-hit wave.
   // The queue order is irrelevant: results land in score[] by position.
   // score tile cleared with dword stores
-  for (int i = tid; i < kScoreH * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0u;  // incl. pad cols
+  for (int i = tid; i < kScoreBytes / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0u;  // incl. pad cols
   // One work item = one aligned tile dword = 4 horizontally adjacent pixels (tile cols 4m .. 4m+3, m = 4..21,
   // i.e. window cols -2 .. 69), evaluated with packed 16-bit math: 5 LDS dword reads and ~56 VALU per 4 px.
   // bright test: some adjacent compass pair both > c + t; dark: both < c - t.
-  {
+  const int sx_lo = max(0, kEdge - (x0 - 1)), sx_hi = min(kScoreH, lv.w - kEdge - (x0 - 1));
+  // tile-uniform: every window pixel lies in the valid region [kEdge, dim - kEdge) -> constant trim masks
+  const bool interior = sx_lo == 0 && sx_hi == kScoreH && y0 - 1 >= kEdge && y0 - 1 + kScoreH <= lv.h - kEdge;
+  if constexpr (P1 != 0) {
+    // SWAR pass 1.  Every byte sits zero-extended in a 16-bit field: E(w) = {b0, b2}, O(w) = {b1, b3} of a tile dword.
+    // With A = c + t + BIAS per field, A - x keeps its BIAS bit iff x <= c + t (x is NOT brighter), and with
+    // D = c - t - 1 + BIAS, D - x keeps it iff x < c - t (x IS darker); fields never borrow from each other (|c +- t - x| < 2^10).
+    // bright = (b_u | b_d) & (b_l | b_r), dark likewise, folded with and / or / v_bitop3.  Everything but the two
+    // v_alignbit is in the full-rate ALU class (profiles/issue_probe_r03.txt).  BIAS = 2^15 for the even pixels of the
+    // dword and 2^14 for the odd ones, so that the four flags come out at bits 15, 14, 31, 30 (pixels 0, 1, 2, 3)
+    // without any shifting; trip t parks them 2 t bits lower.  No trimming here: the two extra pixels of a row (window
+    // cols -2, -1) and, in border tiles, pixels outside the valid region are dropped (or harmlessly scored) in pass 2.
+    constexpr int kItemsPerRow = 17, kItems = kScoreH * kItemsPerRow;
+    constexpr int kTrips = (kItems + 255) / 256;  // 5
+    static_assert(2 * kTrips <= 14 && kScoreW == 4 * kItemsPerRow, "candidate bits of all trips share one dword");
+    constexpr uint32_t kF = 0x00FF00FFu;
+    const uint32_t t = (uint32_t)min(max(min_th, 0), 255);
+    const uint32_t kAe = (0x8000u + t) * 0x10001u, kDe = (0x8000u - t - 1u) * 0x10001u;
+    const uint32_t kAo = (0x4000u + t) * 0x10001u, kDo = (0x4000u - t - 1u) * 0x10001u;
+    const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
+    const uint32_t tid3856 = (uint32_t)tid * 3856u;  // (item * 3856) >> 16 == item / 17 for item < 3855
+    uint32_t allbits = 0;
+#pragma unroll
+    for (int trip = 0; trip < kTrips; ++trip) {
+      const int item = 256 * trip + tid;
+      if (item < kItems) {
+        const uint32_t sy = (tid3856 + 3856u * 256u * (uint32_t)trip) >> 16;
+        const uint32_t ix = (uint32_t)item + 7u * sy + (3 * (kTileW / 4) + 4);  // (sy + 3) * 24 + m, m = item - 17 sy + 4
+        uint2 C, U, D, L, R;
+        if constexpr (P1 == 2) {
+          C = planes[ix], U = planes[ix - 3 * (kTileW / 4)], D = planes[ix + 3 * (kTileW / 4)], L = planes[ix - 1], R = planes[ix + 1];
+        } else {
+          const uint32_t wc = tile32[ix], wl = tile32[ix - 1], wr = tile32[ix + 1];
+          const uint32_t wu = tile32[ix - 3 * (kTileW / 4)], wd = tile32[ix + 3 * (kTileW / 4)];
+          C = uint2{wc & kF, (wc >> 8) & kF}, U = uint2{wu & kF, (wu >> 8) & kF}, D = uint2{wd & kF, (wd >> 8) & kF};
+          L = uint2{wl & kF, (wl >> 8) & kF}, R = uint2{wr & kF, (wr >> 8) & kF};
+        }
+        // even pixels (cols 4m, 4m+2): left = cols 4m-3, 4m-1 = O(wl); right = cols 4m+3, 4m+5 = {O(wc).hi, O(wr).lo}
+        // odd pixels (cols 4m+1, 4m+3): left = cols 4m-2, 4m = {E(wl).hi, E(wc).lo}; right = cols 4m+4, 4m+6 = E(wr)
+        const uint32_t le = L.y, re = __builtin_amdgcn_alignbit(R.y, C.y, 16);
+        const uint32_t lo = __builtin_amdgcn_alignbit(C.x, L.x, 16), ro = R.x;
+        auto half = [](uint32_t A, uint32_t Dk, uint32_t u, uint32_t d, uint32_t l, uint32_t r) {
+          const uint32_t not_bright_lr = (A - l) & (A - r);
+          const uint32_t bright = __builtin_amdgcn_bitop3_b32(A - u, A - d, not_bright_lr, 0x15);  // ~(a & b) & ~c
+          const uint32_t dark_lr = (Dk - l) | (Dk - r);
+          const uint32_t dark = __builtin_amdgcn_bitop3_b32(Dk - u, Dk - d, dark_lr, 0xA8);  // (a | b) & c
+          return bright | dark;
+        };
+        const uint32_t ye = half(C.x + kAe, C.x + kDe, U.x, D.x, le, re);
+        const uint32_t yo = half(C.y + kAo, C.y + kDo, U.y, D.y, lo, ro);
+        const uint32_t w = __builtin_amdgcn_bitop3_b32(ye, yo, 0x80008000u, 0xE4);  // (a & c) | (b & ~c)
+        allbits = __builtin_amdgcn_bitop3_b32(allbits, w >> (2 * trip), 0xC000C000u >> (2 * trip), 0xF8);  // a | (b & c)
+      }
+    }
+    // ONE queue reservation per wave for all trips; an entry is (bit << 8 | tid), decoded in pass 2 where every lane is busy
+    {
+      const int cnt = __popc(allbits);
+      const int incl = wave_incl_scan_i32(cnt);
+      const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+      if (wave_total != 0) {
+        int base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&q_count, wave_total);
+        base = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+        while (allbits) {
+          const int b = __ffs((int)allbits) - 1;
+          queue[base++] = (uint16_t)((b << 8) | tid);
+          allbits &= allbits - 1u;
+        }
+      }
+    }
+  } else {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
     constexpr int kRowDw = kTileW / 4, kItemsPerRow = 18;
     const s16x2 T = {(short)min_th, (short)min_th};
-    const int sx_lo = max(0, kEdge - (x0 - 1)), sx_hi = min(kScoreH, lv.w - kEdge - (x0 - 1));
-    // tile-uniform: every window pixel lies in the valid region [kEdge, dim - kEdge) -> constant trim masks
-    const bool interior = sx_lo == 0 && sx_hi == kScoreH && y0 - 1 >= kEdge && y0 - 1 + kScoreH <= lv.h - kEdge;
     constexpr int kTrips = (kScoreH * kItemsPerRow + 255) / 256;  // 5
     static_assert(4 * kTrips <= 32 && kScoreW == 4 * kItemsPerRow, "candidate bits of all trips share one dword");
     uint32_t allbits = 0;  // bit 4 t + k: pixel k of this thread's dword in trip t is a candidate
@@ -421,8 +513,14 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   __syncthreads();
   const int nq = q_count;
   for (int i = tid; i < nq; i += 256) {
-    const int pos = queue[i];
-    const int sy = pos / kScoreW, sx = pos - sy * kScoreW - kScoreOff;
+    int pos = queue[i];
+    if constexpr (P1 != 0) pos = 4 * (pos & 255) + bit_pos[pos >> 8];
+    // (flat 68-byte rows: position 68 sy + 1 + j holds window col j - 2, j = 0 .. 67)
+    const int sy = P1 != 0 ? (pos - 1) / kScoreW : pos / kScoreW, sx = pos - sy * kScoreW - kScoreOff;
+    if constexpr (P1 != 0) {
+      // border tiles: pass 1 did not trim -- pixels outside the valid region [kEdge, dim - kEdge) keep S = 0 (oracle step 2)
+      if (!interior && (sx < sx_lo || sx >= sx_hi || y0 - 1 + sy < kEdge || y0 - 1 + sy >= lv.h - kEdge)) continue;
+    }
     const uint8_t* p = &tile[(sy + 3) * kTileW + sx + 18];
     const int c = p[0];
     int r[16];
@@ -620,7 +718,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   }
 }
 
-template <bool PK>
+template <bool PK, int P1>
 __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
@@ -629,7 +727,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, 
   const int total = ((ncx + 1) >> 1) * ((ncy + 1) >> 1) * n_frames;
   const int tile_id = xcd_strip_tile(blockIdx.x, total);
   if (tile_id >= total) return;
-  fast_cells_tile<PK>(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
+  fast_cells_tile<PK, P1>(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
 }
 
 // Every level in ONE launch, over a pyramid that exists already (stand-alone resize launches): what a small call wants --
@@ -640,7 +738,7 @@ struct AllLevels {
   int ncx[kMaxL], ncy[kMaxL], cell_off[kMaxL], tile_start[kMaxL + 1];
   int n_levels;
 };
-template <bool PK>
+template <bool PK, int P1>
 __global__ __launch_bounds__(256) void fast_cells_all_kernel(AllLevels A, int min_th, int ini_th,
                                                              uint32_t* __restrict__ cell_cnt,
                                                              uint32_t* __restrict__ cell_ent, int cells_per_frame,
@@ -649,7 +747,7 @@ __global__ __launch_bounds__(256) void fast_cells_all_kernel(AllLevels A, int mi
   for (int k = 1; k < A.n_levels; ++k)
     if ((int)blockIdx.x >= A.tile_start[k]) l = k;
   const NextLevel none{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
-  fast_cells_tile<PK>(A.lv[l], A.ncx[l], A.ncy[l], min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, A.cell_off[l], n_frames, none,
+  fast_cells_tile<PK, P1>(A.lv[l], A.ncx[l], A.ncy[l], min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, A.cell_off[l], n_frames, none,
                       dbg, (int)blockIdx.x - A.tile_start[l]);
 }
 
@@ -1114,6 +1212,8 @@ struct gh_orb_plan {
   const int32_t* own_gx[kMaxL] = {nullptr};  // fused pyramid: first owned output group / row per tile column / row of level l
   const int32_t* own_gy[kMaxL] = {nullptr};
   bool fuse_pyramid = true;  // GSLAM_HIP_ORB_FUSE_PYRAMID=0 keeps the stand-alone resize launches (A/B measurements)
+  int lds_pad = 0;           // GSLAM_HIP_ORB_LDSPAD: extra dynamic LDS bytes per workgroup (occupancy experiments only)
+  int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test, 1 = SWAR (split in registers), 2 = SWAR on LDS planes
   bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
   int8_t* d_pattern = nullptr;
   int32_t* d_dir = nullptr;
@@ -1245,6 +1345,8 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   p->prm = prm;
   if (const char* e = getenv("GSLAM_HIP_ORB_FUSE_PYRAMID")) p->fuse_pyramid = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
+  if (const char* e = getenv("GSLAM_HIP_ORB_LDSPAD")) p->lds_pad = atoi(e) < 0 ? 0 : atoi(e);
+  if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
   long long den = ipow(6, L) - ipow(5, L);
@@ -1570,12 +1672,14 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     }
     A.tile_start[kMaxL] = tiles;
     if (tiles > 0) {
-      if (p->pk_score)
-        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_all_kernel<true>, dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast,
-                  p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg);
-      else
-        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_all_kernel<false>, dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast,
-                  p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg);
+#define GH_FAST_ALL(PK_, P1_)                                                                                            \
+  GH_LAUNCH(ctx, "orb_fast_cells", (fast_cells_all_kernel<PK_, P1_>), dim3(tiles), dim3(256), 0, A, p->prm.min_th_fast, \
+            p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg)
+      if (!p->pk_score) GH_FAST_ALL(false, 0);
+      else if (p->pass1 == 0) GH_FAST_ALL(true, 0);
+      else if (p->pass1 == 1) GH_FAST_ALL(true, 1);
+      else GH_FAST_ALL(true, 2);
+#undef GH_FAST_ALL
     }
     overlap = false;
   }
@@ -1592,14 +1696,15 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
       GH_CHECK_ARG(ctx, tiles < (1LL << 30));
       dim3 grid(8 * gh_div_up(tiles, 8));
-      if (p->pk_score)
-        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel<true>, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
-                  p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-                  batch, nx, dbg);
-      else
-        GH_LAUNCH(ctx, "orb_fast_cells", fast_cells_kernel<false>, grid, dim3(256), 0, lv[l], p->ncx[l], p->ncy[l],
-                  p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l],
-                  batch, nx, dbg);
+#define GH_FAST(PK_, P1_)                                                                                                     \
+  GH_LAUNCH(ctx, "orb_fast_cells", (fast_cells_kernel<PK_, P1_>), grid, dim3(256), p->lds_pad, lv[l], p->ncx[l], p->ncy[l],            \
+            p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l], batch, nx, \
+            dbg)
+      if (!p->pk_score) GH_FAST(false, 0);
+      else if (p->pass1 == 0) GH_FAST(true, 0);
+      else if (p->pass1 == 1) GH_FAST(true, 1);
+      else GH_FAST(true, 2);
+#undef GH_FAST
       if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
     }
     if (overlap) {  // (a level without a FAST pass still gets its level_cnt = 0 from select)

@@ -136,10 +136,11 @@ def test_step_that_moves_a_point_behind_its_camera_is_rejected(oracle):
 
 
 def test_full_c4_state_sensitivity_to_rounding(oracle):
-    """Why the GPU-vs-oracle state bar at full C4 is 1e-5 and not the 1e-8 of the small graphs: the oracle compiled with
-    FMA contraction (oracle/liboracle_fma.so, same source) against itself.  Costs agree to 1e-12 at every iteration and
-    the accept/reject sequence is identical, yet the final poses differ by ~1e-6: the robust cost is flat along weakly
-    determined directions, so rounding alone moves the state that far.  (Measured: 1.1e-6 pose, 1.0e-7 points.)"""
+    """How far rounding alone moves the C4 solution: the oracle compiled with FMA contraction (oracle/liboracle_fma.so, same
+    source) against itself.  Costs agree to 1e-12 at every iteration, the accept/reject sequence is identical and the final
+    states agree to ~1e-11 (measured 1.6e-12 .. 1.2e-11 in pose over seeds 1-3) -- which is why the GPU-vs-oracle state bar
+    at full C4 is the 1e-8 of the small graphs (tests/test_full_configs_gpu.py::STATE_ATOL_FULL).  On the generator of
+    rounds 1-3 (303 of 500 cameras unobserved) the same experiment gave 1.1e-6."""
     import os
     fma = oracle_lib.Oracle(os.path.join(oracle_lib.ROOT, "oracle", "liboracle_fma.so"))
     g = make_graph(500, 50000, n_obs_per_point=6, seed=1)
@@ -151,5 +152,13 @@ def test_full_c4_state_sensitivity_to_rounding(oracle):
         assert sa.trace_accepted[i] == sb.trace_accepted[i]
         assert abs(sa.trace_cost[i] - sb.trace_cost[i]) <= 1e-12 * sa.trace_cost[i]
     d_pose, d_pts = np.abs(a[0] - b[0]).max(), np.abs(a[1] - b[1]).max()
-    assert d_pose <= 1e-5 and d_pts <= 1e-5
-    assert d_pose > 1e-8, "if this ever holds, tighten STATE_ATOL_FULL in tests/test_full_configs_gpu.py"
+    assert d_pose <= 1e-9 and d_pts <= 1e-9
+
+
+def test_bench_graphs_are_well_posed():
+    """every camera of the C4 graph sees points, evenly, and the reduced camera system is a band."""
+    from gslam_amd.ba_synth import graph_census
+    c = graph_census(make_graph(500, 50000, n_obs_per_point=6, seed=1))
+    assert c["cams_observed"] == 500 and c["obs_per_cam_min"] >= 50
+    assert c["obs_per_cam_max"] <= 4 * c["obs_per_cam_median"]
+    assert 0.05 < c["s_block_fill"] < 0.15

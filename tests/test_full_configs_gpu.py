@@ -2,8 +2,7 @@
   C2  all-pairs BF on a 50-frame 1920x1080 subset (1225 frame pairs, K = 2000) vs the oracle, bit-exact, on
       descriptors extracted by the HIP path from frames the oracle extracts identically;
   C4  full size (500 cams / 50 k points / 300 k observations, Huber), seeds 1-3: LM iteration count, accept/reject
-      sequence, per-iteration cost 1e-9 vs the oracle; final state 1e-5 (see STATE_ATOL_FULL: the problem's own
-      rounding sensitivity at this size is 1e-6, shown on the oracle alone);
+      sequence, per-iteration cost 1e-9 vs the oracle; final state 1e-8 (STATE_ATOL_FULL);
   C5/10  1000 cams / 100 k points / 600 k observations (n = 6000 reduced system), same bars;
   PnP motion-only BA with noisy matches + outliers + Huber vs oracle_ba_pnp (Optimizer.h:202-207).
 The n = 60000 dense-solve residual (C5 full size) lives in test_ba_gpu.py::test_potrf_solve_large_residual_property."""
@@ -17,13 +16,12 @@ from gslam_amd.ba_synth import make_graph
 
 pytestmark = pytest.mark.gpu
 
-# Full-size bars.  Cost per iteration, accept/reject sequence and iteration counts keep the C4/10 bars (1e-9, identical).
-# The final STATE and the trust-region radius cannot: at 500 cameras / 50 k points the robust cost is flat to 1e-15
-# along weakly determined directions, so two correct evaluations of the same algorithm that differ only in rounding end
-# 1e-6 apart in pose -- the oracle compiled with and without FMA contraction differs from ITSELF by 1.1e-6 in pose and
-# 2e-8 in radius at identical costs (tests/test_ba_oracle.py::test_full_c4_state_sensitivity_to_rounding, CPU).
-STATE_ATOL_FULL = 1e-5
-RADIUS_RTOL_FULL = 1e-6
+# Full-size bars = the bars of the small graphs (cost 1e-9, state 1e-8, identical accept / reject sequence).
+# Rounds 1-3 had to loosen the state to 1e-5 because their generator left 300 of 500 cameras unobserved;
+# on the co-visibility-window graphs of gslam_amd/ba_synth.py the oracle compiled with and without FMA contraction differs
+# from itself by 1e-11 in pose (tests/test_ba_oracle.py::test_full_c4_state_sensitivity_to_rounding, CPU).
+STATE_ATOL_FULL = 1e-8
+RADIUS_RTOL_FULL = 1e-9
 THREADS = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 COST_RTOL = 1e-9
 STATE_ATOL = 1e-8
