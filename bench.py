@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-range", action="store_true", help="skip the 640x480 / 3840x2160 extraction legs")
     ap.add_argument("--no-all-pairs-full", action="store_true", help="skip the 499 500-frame-pair all-pairs matching leg")
+    ap.add_argument("--match-overlap", action="store_true",
+                    help="N = 1: run the timed steps with the matcher on a side stream under the next step's extraction (measured "
+                         "either way in extra.bf_match.overlap: it hides 0.03 of 0.70 ms -- the two kernels compete for the same CUs)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: exchange through torch.distributed instead of the C-ABI communicator (gh_comm_*)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="bounded CPU sample (frames; 1000 = the whole C2 step, ~10 s on 16 cores)")
@@ -185,7 +188,35 @@ def main():
             match_gather[0].wait()
             match_gather[0] = None
 
+    # N = 1: the matcher of step i runs on a side stream (its own gh_ctx) while step i + 1 extracts into the other of two
+    # output sets -- what a front end that streams frame batches does; with the MFMA formulation the matrix pipe does the
+    # matching while the VALU does FAST.  Events order (extraction i -> match i) and (match i -> extraction i + 2).
+    overlap = world == 1 and a.match_overlap
+    bufs = [(kps, desc, counts)]
+    step_no = [0]
+    if world == 1:
+        bufs.append(ex.alloc_outputs(F, dev))
+        side = torch.cuda.Stream(device=dev)
+        ctx_side = hip.Context(local_rank, stream=side.cuda_stream)
+        matcher_side = BFMatcher(ctx_side)
+        ev_extracted = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_matched = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def step_overlapped():
+        i = step_no[0] & 1
+        step_no[0] += 1
+        main = torch.cuda.current_stream()
+        main.wait_event(ev_matched[i])  # the match that last read this output set has finished
+        ex.extract(frames, bufs[i])
+        ev_extracted[i].record(main)
+        side.wait_event(ev_extracted[i])
+        matcher_side.match_pairs(bufs[i][1], bufs[i][2], pq, pt, out=(m_idx, m_d1, m_d2))
+        ev_matched[i].record(side)
+
     def step():
+        if overlap:
+            return step_overlapped()
+        step_no[0] += 1
         ex.extract(frames, (kps, desc, counts))
         if comm is not None:
             comm.wait()  # the previous step's match gather (it ran behind this step's extraction)
@@ -219,6 +250,8 @@ def main():
         step()
     barrier()
     ctx.prof_enable(True)  # HIP events on the launch stream, per kernel, over the timed region
+    if overlap:
+        ctx_side.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -226,6 +259,45 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.prof_collect()
     ctx.prof_enable(False)
+    if overlap:
+        prof.update(ctx_side.prof_collect())
+        ctx_side.prof_enable(False)
+    last_out = bufs[(step_no[0] - 1) & 1] if overlap else bufs[0]  # the output set of the last timed step (in-run parity)
+    match_overlap = None
+    if world == 1:
+        # what a side stream would hide: the same steps with the matcher on the launch stream after the extraction and with
+        # the matcher of step i on a side stream under the extraction of step i + 1
+        def timed(fn, n):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            return (time.perf_counter() - t1) * 1e3 / n
+
+        def step_serial():
+            ex.extract(frames, bufs[0])
+            matcher.match_pairs(bufs[0][1], bufs[0][2], pq, pt, out=(m_idx, m_d1, m_d2))
+
+        def step_extract_only():
+            ex.extract(frames, bufs[0])
+
+        def step_match_only():
+            matcher.match_pairs(bufs[0][1], bufs[0][2], pq, pt, out=(m_idx, m_d1, m_d2))
+
+        n_ab = max(4, min(20, a.steps))
+        step_serial()
+        ms_serial, ms_ext, ms_match = timed(step_serial, n_ab), timed(step_extract_only, n_ab), timed(step_match_only, n_ab)
+        step_no[0] = 0
+        step_overlapped()
+        ms_over = timed(step_overlapped, 2 * (n_ab // 2))
+        step_no[0] = 0
+        match_overlap = {"serial_ms_per_step": round(ms_serial, 3), "overlapped_ms_per_step": round(ms_over, 3),
+                         "extract_alone_ms": round(ms_ext, 3), "match_alone_ms": round(ms_match, 3),
+                         "hidden_ms": round(ms_serial - ms_over, 3), "steps_each": n_ab,
+                         "how": "matcher of step i on a side stream (second gh_ctx) under the extraction of step i + 1, two output sets"}
+        step_serial()  # leave set 0 and the match rows as one complete step (in-run parity reads them)
+        last_out = bufs[0]
     if world > 1 and os.environ.get("GSLAM_BENCH_VERIFY"):
         # debug aid for the dry run: the overlapped schedule must give exactly what one plain call over the gathered
         # buffers gives
@@ -433,13 +505,20 @@ def main():
                 "achieved": round(orb_bytes_per_frame(W, H, K) * F * a.steps / (orb_ms * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
     pipeline["frac"] = round(pipeline["achieved"] * 1e9 / HBM_PEAK, 4)
-    bf_ms = prof.get("bf_match_pairs", {}).get("total_ms", 0.0)
+    MFMA_I8_PEAK_TOPS = 5033.0  # v_mfma_i32_16x16x64_i8 at 16 clocks per SIMD (tools/mfma_probe.hip, profiles/mfma_probe_r03.txt)
+    bf_kernel = "bf_match_pairs_mfma" if "bf_match_pairs_mfma" in prof else "bf_match_pairs"
+    bf_ms = prof.get(bf_kernel, {}).get("total_ms", 0.0)
     valu_ceiling = matcher.valu_probe()
     bf = {"Gpairs_per_s": round(n_pairs_step * a.steps / (bf_ms * 1e-3) / 1e9, 1) if bf_ms else None,
-          "bound": "valu", "valu_ceiling_Gpairs_per_s": round(valu_ceiling / 1e9, 1),
-          "pairs_per_step": n_pairs_step}
+          "kernel": bf_kernel, "ms_per_step": round(bf_ms / a.steps, 4),
+          "bound": "mfma" if bf_kernel.endswith("mfma") else "valu", "valu_ceiling_Gpairs_per_s": round(valu_ceiling / 1e9, 1),
+          "pairs_per_step": n_pairs_step, "schedule": "side stream under the next extraction" if overlap else "launch stream",
+          "overlap": match_overlap}
     if bf["Gpairs_per_s"]:
-        bf["frac"] = round(bf["Gpairs_per_s"] / bf["valu_ceiling_Gpairs_per_s"], 4)
+        # popcount kernel: against the measured xor + bcnt issue ceiling; MFMA kernel: 512 integer ops per descriptor pair
+        # against the i8 MFMA peak (while it shares the chip with the next step's extraction)
+        bf["frac"] = round(bf["Gpairs_per_s"] * 512e9 / (MFMA_I8_PEAK_TOPS * 1e12), 4) if bf_kernel.endswith("mfma") else \
+            round(bf["Gpairs_per_s"] / bf["valu_ceiling_Gpairs_per_s"], 4)
     kernels = {k: {"launches": v["launches"], "avg_ms": round(v["total_ms"] / v["launches"], 4)}
                for k, v in prof.items()}
 
@@ -451,10 +530,10 @@ def main():
         o_idx = torch.empty((ai.shape[0], K), dtype=torch.int32, device=dev)
         o_d1 = torch.empty((ai.shape[0], K), dtype=torch.int16, device=dev)
         o_d2 = torch.empty_like(o_d1)
-        matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))
+        matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2), mfma=False)
         torch.cuda.synchronize()
         ctx.prof_enable(True)
-        matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))
+        matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2), mfma=False)  # the popcount kernel (north_star's formulation)
         ap = ctx.prof_collect()
         ctx.prof_enable(False)
         npairs_all = int((counts[ai.long()].to(torch.int64) * counts[aj.long()].to(torch.int64)).sum().item())
@@ -465,24 +544,24 @@ def main():
         # the same pairs through the exact integer MFMA formulation (bf_match_mfma.hip): reported BESIDE the popcount
         # kernel, which stays the contract path; the two results must be identical
         try:
-            m_idx, m_d1, m_d2 = torch.empty_like(o_idx), torch.empty_like(o_d1), torch.empty_like(o_d2)
-            matcher.match_pairs(desc, counts, ai, aj, out=(m_idx, m_d1, m_d2), mfma=True)
+            q_idx, q_d1, q_d2 = torch.empty_like(o_idx), torch.empty_like(o_d1), torch.empty_like(o_d2)
+            matcher.match_pairs(desc, counts, ai, aj, out=(q_idx, q_d1, q_d2), mfma=True)
             torch.cuda.synchronize()
             ctx.prof_enable(True)
-            matcher.match_pairs(desc, counts, ai, aj, out=(m_idx, m_d1, m_d2), mfma=True)
+            matcher.match_pairs(desc, counts, ai, aj, out=(q_idx, q_d1, q_d2), mfma=True)
             apm = ctx.prof_collect()
             ctx.prof_enable(False)
             ms_m = apm["bf_match_pairs_mfma"]["total_ms"]
             mfma_ops = npairs_all * 512  # algorithmic: 256 multiply-adds per descriptor pair
             bf["all_pairs_mfma"] = {
                 "Gpairs_per_s": round(npairs_all / (ms_m * 1e-3) / 1e9, 1), "ms": round(ms_m, 3),
-                "identical_to_popcount": bool(torch.equal(m_idx, o_idx) and torch.equal(m_d1, o_d1) and torch.equal(m_d2, o_d2)),
-                "roofline": {"bound": "mfma", "unit": "TOP/s", "peak": 5033.0,
+                "identical_to_popcount": bool(torch.equal(q_idx, o_idx) and torch.equal(q_d1, o_d1) and torch.equal(q_d2, o_d2)),
+                "roofline": {"bound": "mfma", "unit": "TOP/s", "peak": MFMA_I8_PEAK_TOPS,
                              "peak_source": "v_mfma_i32_16x16x64_i8 at 16 clocks per SIMD (tools/mfma_probe.hip, profiles/mfma_probe_r03.txt)",
                              "achieved": round(mfma_ops / (ms_m * 1e-3) / 1e12, 1),
-                             "frac": round(mfma_ops / (ms_m * 1e-3) / 1e12 / 5033.0, 4)},
+                             "frac": round(mfma_ops / (ms_m * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4)},
                 "what": "v_mfma_i32_16x16x64_i8, key = 4096 (hamming - |a| + 256) + tile straight from the accumulator, v_med3 + v_min per pair"}
-            del m_idx, m_d1, m_d2
+            del q_idx, q_d1, q_d2
         except Exception as exc:
             bf["all_pairs_mfma"] = {"error": repr(exc)}
         del o_idx, o_d1, o_d2
@@ -495,20 +574,38 @@ def main():
             o_d2 = torch.empty_like(o_d1)
             torch.cuda.synchronize()
             ctx.prof_enable(True)
-            matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))
+            matcher.match_pairs(desc, counts, ai, aj, out=(o_idx, o_d1, o_d2))  # the product entry: dispatches to the MFMA kernel
             ap = ctx.prof_collect()
             ctx.prof_enable(False)
             c64 = counts.to(torch.int64)
             npairs_full = int((c64.sum() ** 2 - (c64 * c64).sum()).item() // 2)
-            ms_full = ap["bf_match_pairs"]["total_ms"]
+            k_full = "bf_match_pairs_mfma" if "bf_match_pairs_mfma" in ap else "bf_match_pairs"
+            ms_full = ap[k_full]["total_ms"]
             # size-independent check: a frame matched against itself is not in the list, so no query may be unmatched
             assert bool((o_idx[:, 0] >= 0).all()), "all-pairs: unmatched query in a non-empty pair"
-            bf["all_pairs_full"] = {"frames": F, "frame_pairs": int(ai.shape[0]), "pairs": npairs_full,
+            bf["all_pairs_full"] = {"frames": F, "frame_pairs": int(ai.shape[0]), "pairs": npairs_full, "kernel": k_full,
                                     "Gpairs_per_s": round(npairs_full / (ms_full * 1e-3) / 1e9, 1), "seconds": round(ms_full * 1e-3, 3),
-                                    "frac": round(npairs_full / (ms_full * 1e-3) / valu_ceiling, 4),
+                                    "frac": round(npairs_full * 512 / (ms_full * 1e-3) / (MFMA_I8_PEAK_TOPS * 1e12), 4)
+                                    if k_full.endswith("mfma") else round(npairs_full / (ms_full * 1e-3) / valu_ceiling, 4),
                                     "match_record_GB": round(ai.shape[0] * K * 8 / 1e9, 2)}
+            # the whole result again through the popcount kernel: every one of the 499 500 x K records must be identical
+            p_idx, p_d1, p_d2 = torch.empty_like(o_idx), torch.empty_like(o_d1), torch.empty_like(o_d2)
+            ctx.prof_enable(True)
+            matcher.match_pairs(desc, counts, ai, aj, out=(p_idx, p_d1, p_d2), mfma=False)
+            app = ctx.prof_collect()
+            ctx.prof_enable(False)
+            same = bool(torch.equal(p_idx, o_idx) and torch.equal(p_d1, o_d1) and torch.equal(p_d2, o_d2))
+            ms_pop = app["bf_match_pairs"]["total_ms"]
+            bf["all_pairs_full"]["popcount_kernel"] = {"seconds": round(ms_pop * 1e-3, 3),
+                                                       "Gpairs_per_s": round(npairs_full / (ms_pop * 1e-3) / 1e9, 1),
+                                                       "frac_of_valu_ceiling": round(npairs_full / (ms_pop * 1e-3) / valu_ceiling, 4)}
+            bf["all_pairs_full"]["identical_to_popcount"] = same
+            assert same, "all-pairs: the MFMA matcher and the popcount matcher disagree"
+            del p_idx, p_d1, p_d2
             del o_idx, o_d1, o_d2, ai, aj
             torch.cuda.empty_cache()
+    except AssertionError:
+        raise  # the two matcher formulations disagree: no bench line
     except Exception as exc:
         bf["all_pairs"] = {"error": repr(exc)}
 
@@ -556,15 +653,37 @@ def main():
         dt = (time.perf_counter() - t1) / reps
         c3 = o3[2].to(torch.int64)
         pairs = int((c3[lq.long()] * c3[rq.long()]).sum().item() + (c3[tq.long()] * c3[tt.long()]).sum().item())
+        c3_parity = None
+        if not a.no_cpu_baseline:
+            # in-run parity of the band matcher: the first stereo pair of the timed batch against the oracle
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib  # the checker
+            from gslam_amd.orb import kps_to_numpy
+            orc = oracle_lib.load()
+            lr, _tm = step3()
+            torch.cuda.synchronize()
+            ek, ed, ec = orc.orb_extract_batch(eyes[:2, :, :Ws].contiguous().cpu().numpy(), K, threads=2)
+            nl, nr = int(ec[0]), int(ec[1])
+            e = orc.bf_match_band(ed[0, :nl], ek[0, :nl], ed[1, :nr], ek[1, :nr], band)
+            ok = bool(np.array_equal(o3[2][:2].cpu().numpy(), ec)) and kps_to_numpy(o3[0][:2]).tobytes() == ek.tobytes() and \
+                bool(np.array_equal(lr[0][0, :nl].cpu().numpy(), e[0])) and \
+                bool(np.array_equal(lr[1][0, :nl].cpu().numpy().view(np.uint16), e[1])) and \
+                bool(np.array_equal(lr[2][0, :nl].cpu().numpy().view(np.uint16), e[2]))
+            c3_parity = {"stereo_pairs": 1, "left_keypoints": nl, "band_match_rows_equal": ok}
+            if not ok:
+                raise AssertionError("in-run parity failed: C3 band matcher")
         extra["c3_stereo"] = {"workload": "C3: %d stereo frames 1241x376 x 2 eyes, K=%d per eye, band-limited L-R match "
                                           "+ temporal L-L match" % (S, K),
                               "stereo_frames_per_s": round(S / dt, 1),
                               "Mkeypoints_per_s": round(int(c3.sum().item()) / dt / 1e6, 2),
-                              "candidate_Gpairs_per_s": round(pairs / dt / 1e9, 1), "ms_per_batch": round(dt * 1e3, 3)}
+                              "candidate_Gpairs_per_s": round(pairs / dt / 1e9, 1), "ms_per_batch": round(dt * 1e3, 3),
+                              "parity_in_run": c3_parity}
         ex3.close()
 
     try:
         _leg_c3()
+    except AssertionError:
+        raise
     except Exception as exc:
         extra.setdefault("errors", {})["c3"] = repr(exc)
         log("c3 leg failed: %r" % (exc,))
@@ -793,6 +912,17 @@ def main():
             dt = (time.perf_counter() - t1) / reps
             kp = int(o[2].sum().item())
             bpf = orb_bytes_per_frame(w, h, k)
+            if not a.no_cpu_baseline and k <= 2000:
+                # in-run parity at the ends of the frame range: the first frame of the timed batch against the oracle
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib  # the checker
+                from gslam_amd.orb import kps_to_numpy
+                ek, ed, ec = oracle_lib.load().orb_extract_batch(fr[:1, :, :w].contiguous().cpu().numpy(), k, threads=1)
+                ok = int(o[2][0].item()) == int(ec[0]) and kps_to_numpy(o[0][:1]).tobytes() == ek.tobytes() and \
+                    bool(np.array_equal(o[1][:1].cpu().numpy(), ed))
+                extra.setdefault("parity_in_run_range", {})["%dx%d_k%d" % (w, h, k)] = {"frames": 1, "keypoints": int(ec[0]), "equal": bool(ok)}
+                if not ok:
+                    raise AssertionError("in-run parity failed at %dx%d" % (w, h))
             out["%dx%d_k%d" % (w, h, k)] = {"frames": nfr, "Mkeypoints_per_s": round(kp / dt / 1e6, 2),
                                             "frames_per_s": round(nfr / dt, 1), "us_per_frame": round(dt / nfr * 1e6, 2),
                                             "algorithmic_MB_per_frame": round(bpf / 1e6, 2),
@@ -909,6 +1039,8 @@ def main():
             if not skip:
                 log("leg %s" % leg_name)
                 leg_fn()
+        except AssertionError:
+            raise  # in-run parity
         except Exception as exc:  # noqa: BLE001
             extra.setdefault("errors", {})[leg_name] = repr(exc)
             log("%s leg failed: %r" % (leg_name, exc))
@@ -980,13 +1112,36 @@ def main():
             S = max(2, min(a.cpu_frames, F))
             host_frames = frames[:S, :, :W].contiguous().cpu().numpy()
             t1 = time.perf_counter()
-            _, cdesc, ccnt = oracle.orb_extract_batch(host_frames, K, threads=cores)
+            ckps, cdesc, ccnt = oracle.orb_extract_batch(host_frames, K, threads=cores)
             t_ext = time.perf_counter() - t1
             log(f"cpu extract done {t_ext:.2f}s")
             t1 = time.perf_counter()
+            cmatch = []
             for f in range(S - 1):
-                oracle.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores)
+                cmatch.append(oracle.bf_match(cdesc[f, :ccnt[f]], cdesc[f + 1, :ccnt[f + 1]], threads=cores))
             t_match = time.perf_counter() - t1
+            # In-run parity ("bit-exact vs oracle on all frames (consecutive)"): what the oracle has
+            # just computed for the timing IS the expected output of the last timed GPU step -- keypoint records, descriptor
+            # bits, counts and the match rows of every consecutive pair.  A mismatch fails the run.
+            from gslam_amd.orb import kps_to_numpy
+            torch.cuda.synchronize()
+            g_kps, g_desc_h, g_cnt = kps_to_numpy(last_out[0][:S]), last_out[1][:S].cpu().numpy(), last_out[2][:S].cpu().numpy()
+            par = {"frames": S, "counts_equal": bool(np.array_equal(g_cnt, ccnt)),
+                   "keypoints_equal": g_kps.tobytes() == ckps.tobytes(), "descriptors_equal": bool(np.array_equal(g_desc_h, cdesc))}
+            gi, g1, g2 = m_idx[:S - 1].cpu().numpy(), m_d1[:S - 1].cpu().numpy().view(np.uint16), m_d2[:S - 1].cpu().numpy().view(np.uint16)
+            rows_ok = True
+            for f in range(S - 1):
+                n = int(ccnt[f])
+                e = cmatch[f]
+                rows_ok = rows_ok and np.array_equal(gi[f, :n], e[0]) and np.array_equal(g1[f, :n], e[1]) and \
+                    np.array_equal(g2[f, :n], e[2]) and bool((gi[f, n:] == -1).all())
+            par["match_pairs"] = S - 1
+            par["match_rows_equal"] = bool(rows_ok)
+            par["matcher_kernel"] = bf.get("kernel")
+            extra["parity_in_run"] = par
+            if not (par["counts_equal"] and par["keypoints_equal"] and par["descriptors_equal"] and par["match_rows_equal"]):
+                raise AssertionError("in-run parity failed: %r" % (par,))
+            del cmatch
             # the sample has S frames and S-1 pairs; the GPU workload has F frames and F-1 pairs per rank
             cpu_kpts = int(ccnt.sum())
             cpu = {"value": round(cpu_kpts / (t_ext + t_match) / 1e6, 4), "unit": "Mkeypoints/s", "cores": cores,
@@ -1034,6 +1189,8 @@ def main():
 
     try:
         _leg_cpu()
+    except AssertionError:
+        raise  # in-run parity: the GPU step and the oracle disagree -- no bench line
     except Exception as exc:
         extra.setdefault("errors", {})["cpu_baseline"] = repr(exc)
         log("cpu baseline leg failed: %r" % (exc,))
@@ -1047,7 +1204,7 @@ def main():
                    "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of descriptors + matches via {comm_note}"
                    if world > 1 else "single GPU",
                    "device": info["name"], "cu_count": info["cu_count"]},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "parity_in_run": extra.get("parity_in_run"),
         # BASELINE.json's metric names three rates: the other two at top level as well (details under extra)
         "bf_match_all_pairs_Gpairs_per_s": (bf.get("all_pairs_full") or bf.get("all_pairs") or {}).get("Gpairs_per_s"),
         "bf_match_all_pairs_mfma_Gpairs_per_s": (bf.get("all_pairs_mfma") or {}).get("Gpairs_per_s"),

@@ -10,6 +10,8 @@
 // with scalar loads (s_load_dwordx8 = one descriptor) and XOR-ed straight from SGPRs - no LDS,
 // no barrier.  Best/second-best are tracked on a packed key (dist << 16 | train_index) so
 // the first-minimum tie rule falls out of an unsigned min: v_lshl_or + v_med3_u32 + v_min_u32.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -348,9 +350,9 @@ extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, con
   return GH_OK;
 }
 
-extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
-                                           const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
-                                           int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+extern "C" gh_status gh_bf_match_pairs_popc_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                                const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                                int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, cap >= 0 && cap <= 65535 && npairs >= 0);
@@ -367,6 +369,27 @@ extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev,
               cap, pair_q_dev + p0, pair_t_dev + p0, idx1_dev + o, d1_dev + o, d2_dev + o);
   }
   return GH_OK;
+}
+
+// The batched entry the plugins and bench.py call.  Both kernels return the same bits (tests/test_bf_gpu.py,
+// __graft_entry__.smoke): the popcount kernel is the contract formulation of north_star and serves small batches; a batch
+// with enough pair work to fill the chip goes through the exact MFMA formulation (bf_match_mfma.hip), 2.8x faster and on
+// the otherwise idle matrix pipe.  GSLAM_HIP_BF_MFMA = 0 / 1 forces one or the other (A/B measurements).
+extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                           const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                           int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  static const int force = [] {
+    const char* e = getenv("GSLAM_HIP_BF_MFMA");
+    return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1;
+  }();
+  // a workgroup of the MFMA kernel takes 512 queries of one frame pair and expands the whole train set for them: it pays
+  // from a few hundred rows per frame and enough frame pairs to occupy the CUs
+  const bool big = cap >= 512 && cap <= 65535 && (long long)npairs * cap * cap >= (1LL << 27);
+  const bool mfma = force >= 0 ? force == 1 : big;
+  if (mfma && ((uintptr_t)desc_dev & 7) == 0)
+    return gh_bf_match_pairs_mfma_dev(ctx, desc_dev, counts_dev, cap, pair_q_dev, pair_t_dev, npairs, idx1_dev, d1_dev, d2_dev);
+  return gh_bf_match_pairs_popc_dev(ctx, desc_dev, counts_dev, cap, pair_q_dev, pair_t_dev, npairs, idx1_dev, d1_dev, d2_dev);
 }
 
 extern "C" gh_status gh_bf_match_band_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const gh_keypoint* kps_dev,

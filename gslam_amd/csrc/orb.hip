@@ -283,6 +283,9 @@ __device__ __forceinline__ int fast_score16_pk(const int (&r)[16], int c) {
   return max3i(0, best_lo - c, c - 255 + hi_c);
 }
 
+#ifndef GH_FAST_WAVES
+#define GH_FAST_WAVES 8
+#endif
 constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligned window that covers x0-4 .. x0+67), 72 rows
 constexpr int kTileH = 72;
 constexpr int kScoreH = 66;   // score window: 64x64 region + 1 px NMS halo
@@ -292,7 +295,8 @@ constexpr int kScoreWPk = 72;  // row pitch (bytes) of the packed-16-bit pass 1;
 // One 64 x 64 tile (2 x 2 cells) of one level of one frame, by one 256-thread workgroup; tile_id in [0, nbx nby n_frames).
 // PK: arc scores through fast_score16_pk (GSLAM_HIP_ORB_PKSCORE, decided per plan).
 // P1: formulation of pass 1 (GSLAM_HIP_ORB_PASS1, decided per plan) -- 0 = packed 16-bit min / max (rounds 2-3),
-//     1 = SWAR on 16-bit fields with full-rate ALU ops, fields split in registers, 2 = the same on pre-split LDS planes.
+//     1 = SWAR on 16-bit fields (full-rate and / or / sub / v_bitop3), fields split in registers.  (A variant that read the
+//     fields pre-split from LDS planes lost 22 %: 38 KB of LDS leave 4 workgroups per CU; profiles/orb_pass1_ab_r04.txt.)
 template <bool PK, int P1>
 __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, int ncy, int min_th, int ini_th,
                                                 uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_ent,
@@ -306,11 +310,13 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   constexpr int kQueueLen = P1 != 0 ? kScoreH * 68 : kScoreH * kScoreH;
   __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
   __shared__ __attribute__((aligned(16))) uint8_t score[kScoreBytes];
-  __shared__ uint32_t lists[4][256];
+  // the dense-cell lists of the NMS stage live in the image tile, which is dead after pass 2 (P1 != 0: 20.4 KB of LDS per
+  // workgroup -> 7-8 workgroups per CU instead of 6; the kernel is latency sensitive: profiles/orb_pass1_ab_r04.txt)
+  __shared__ uint32_t lists_own[P1 == 0 ? 4 * 256 : 1];
+  uint32_t(*lists)[256] = reinterpret_cast<uint32_t(*)[256]>(P1 == 0 ? reinterpret_cast<uint8_t*>(lists_own) : tile);
+  static_assert(sizeof(tile) >= 4 * 256 * sizeof(uint32_t), "four 1 KB lists fit the tile");
   __shared__ uint16_t queue[kQueueLen];
   __shared__ int q_count;
-  // P1 == 2: every tile dword split once into its even bytes {b0, b2} and odd bytes {b1, b3} as zero-extended 16-bit fields
-  __shared__ __attribute__((aligned(16))) uint2 planes[P1 == 2 ? kTileH * (kTileW / 4) : 2];
   __shared__ uint16_t bit_pos[32];  // P1 != 0: score-tile offset of candidate bit b of a thread, relative to 4 tid
 
   const int tid = threadIdx.x;
@@ -334,12 +340,6 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     gx = gx > lv.pitch - 16 ? lv.pitch - 16 : gx;
     const uint4 v = *reinterpret_cast<const uint4*>(img + (size_t)gy * lv.pitch + gx);
     *reinterpret_cast<uint4*>(&tile[row * kTileW + 16 * c]) = v;
-    if constexpr (P1 == 2) {
-      constexpr uint32_t kF = 0x00FF00FFu;
-      uint4* pl = reinterpret_cast<uint4*>(&planes[row * (kTileW / 4) + 4 * c]);
-      pl[0] = uint4{v.x & kF, (v.x >> 8) & kF, v.y & kF, (v.y >> 8) & kF};
-      pl[1] = uint4{v.z & kF, (v.z >> 8) & kF, v.w & kF, (v.w >> 8) & kF};
-    }
   }
   if constexpr (P1 != 0) {
     // candidate bit b of a thread (see pass 1): b ^ 15 = 16 (k >> 1) + 2 trip + (k & 1) -> score offset 1024 trip + 1 + k
@@ -367,8 +367,8 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     // SWAR pass 1.  Every byte sits zero-extended in a 16-bit field: E(w) = {b0, b2}, O(w) = {b1, b3} of a tile dword.
     // With A = c + t + BIAS per field, A - x keeps its BIAS bit iff x <= c + t (x is NOT brighter), and with
     // D = c - t - 1 + BIAS, D - x keeps it iff x < c - t (x IS darker); fields never borrow from each other (|c +- t - x| < 2^10).
-    // bright = (b_u | b_d) & (b_l | b_r), dark likewise, folded with and / or / v_bitop3.  Everything but the two
-    // v_alignbit is in the full-rate ALU class (profiles/issue_probe_r03.txt).  BIAS = 2^15 for the even pixels of the
+    // bright = (b_u | b_d) & (b_l | b_r), dark likewise, folded with and / or / v_bitop3: 4 px per instruction instead of 2,
+    // and the compare / fold instructions are in the full-rate ALU class (profiles/issue_probe_r03.txt).  BIAS = 2^15 for the even pixels of the
     // dword and 2^14 for the odd ones, so that the four flags come out at bits 15, 14, 31, 30 (pixels 0, 1, 2, 3)
     // without any shifting; trip t parks them 2 t bits lower.  No trimming here: the two extra pixels of a row (window
     // cols -2, -1) and, in border tiles, pixels outside the valid region are dropped (or harmlessly scored) in pass 2.
@@ -388,19 +388,17 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
       if (item < kItems) {
         const uint32_t sy = (tid3856 + 3856u * 256u * (uint32_t)trip) >> 16;
         const uint32_t ix = (uint32_t)item + 7u * sy + (3 * (kTileW / 4) + 4);  // (sy + 3) * 24 + m, m = item - 17 sy + 4
-        uint2 C, U, D, L, R;
-        if constexpr (P1 == 2) {
-          C = planes[ix], U = planes[ix - 3 * (kTileW / 4)], D = planes[ix + 3 * (kTileW / 4)], L = planes[ix - 1], R = planes[ix + 1];
-        } else {
-          const uint32_t wc = tile32[ix], wl = tile32[ix - 1], wr = tile32[ix + 1];
-          const uint32_t wu = tile32[ix - 3 * (kTileW / 4)], wd = tile32[ix + 3 * (kTileW / 4)];
-          C = uint2{wc & kF, (wc >> 8) & kF}, U = uint2{wu & kF, (wu >> 8) & kF}, D = uint2{wd & kF, (wd >> 8) & kF};
-          L = uint2{wl & kF, (wl >> 8) & kF}, R = uint2{wr & kF, (wr >> 8) & kF};
-        }
-        // even pixels (cols 4m, 4m+2): left = cols 4m-3, 4m-1 = O(wl); right = cols 4m+3, 4m+5 = {O(wc).hi, O(wr).lo}
-        // odd pixels (cols 4m+1, 4m+3): left = cols 4m-2, 4m = {E(wl).hi, E(wc).lo}; right = cols 4m+4, 4m+6 = E(wr)
-        const uint32_t le = L.y, re = __builtin_amdgcn_alignbit(R.y, C.y, 16);
-        const uint32_t lo = __builtin_amdgcn_alignbit(C.x, L.x, 16), ro = R.x;
+        const uint32_t wc = tile32[ix], wl = tile32[ix - 1], wr = tile32[ix + 1];
+        const uint32_t wu = tile32[ix - 3 * (kTileW / 4)], wd = tile32[ix + 3 * (kTileW / 4)];
+        // E(w) by one v_and, O(w) by one v_perm (bytes 1, 3 -> the two fields)
+        constexpr uint32_t kOdd = 0x0c030c01u;
+        const uint2 C{wc & kF, __builtin_amdgcn_perm(0u, wc, kOdd)}, U{wu & kF, __builtin_amdgcn_perm(0u, wu, kOdd)},
+            D{wd & kF, __builtin_amdgcn_perm(0u, wd, kOdd)};
+        // even pixels (cols 4m, 4m+2): left = cols 4m-3, 4m-1 = O(wl); right = cols 4m+3, 4m+5 = {wc.b3, wr.b1}
+        // odd pixels (cols 4m+1, 4m+3): left = cols 4m-2, 4m = {wl.b2, wc.b0}; right = cols 4m+4, 4m+6 = E(wr)
+        // (v_perm_b32 D, S0, S1: selector bytes 0-3 address S1, 4-7 address S0, 0x0c = zero)
+        const uint32_t le = __builtin_amdgcn_perm(0u, wl, kOdd), re = __builtin_amdgcn_perm(wr, wc, 0x0c050c03u);
+        const uint32_t lo = __builtin_amdgcn_perm(wc, wl, 0x0c040c02u), ro = wr & kF;
         auto half = [](uint32_t A, uint32_t Dk, uint32_t u, uint32_t d, uint32_t l, uint32_t r) {
           const uint32_t not_bright_lr = (A - l) & (A - r);
           const uint32_t bright = __builtin_amdgcn_bitop3_b32(A - u, A - d, not_bright_lr, 0x15);  // ~(a & b) & ~c
@@ -718,8 +716,9 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   }
 }
 
+// (SWAR variant: 8 waves per SIMD -- at most 64 VGPRs -- and 20.4 KB of LDS let 8 workgroups share a CU)
 template <bool PK, int P1>
-__global__ __launch_bounds__(256) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
+__global__ __launch_bounds__(256, P1 != 0 ? GH_FAST_WAVES : 1) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
                                                          int cell_off, int n_frames, NextLevel nx,
@@ -1213,7 +1212,7 @@ struct gh_orb_plan {
   const int32_t* own_gy[kMaxL] = {nullptr};
   bool fuse_pyramid = true;  // GSLAM_HIP_ORB_FUSE_PYRAMID=0 keeps the stand-alone resize launches (A/B measurements)
   int lds_pad = 0;           // GSLAM_HIP_ORB_LDSPAD: extra dynamic LDS bytes per workgroup (occupancy experiments only)
-  int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test, 1 = SWAR (split in registers), 2 = SWAR on LDS planes
+  int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test (rounds 2-3), 1 = SWAR on 16-bit fields
   bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
   int8_t* d_pattern = nullptr;
   int32_t* d_dir = nullptr;
@@ -1346,7 +1345,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   if (const char* e = getenv("GSLAM_HIP_ORB_FUSE_PYRAMID")) p->fuse_pyramid = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_LDSPAD")) p->lds_pad = atoi(e) < 0 ? 0 : atoi(e);
-  if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+  if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
   long long den = ipow(6, L) - ipow(5, L);
@@ -1677,8 +1676,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
             p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, batch, dbg)
       if (!p->pk_score) GH_FAST_ALL(false, 0);
       else if (p->pass1 == 0) GH_FAST_ALL(true, 0);
-      else if (p->pass1 == 1) GH_FAST_ALL(true, 1);
-      else GH_FAST_ALL(true, 2);
+      else GH_FAST_ALL(true, 1);
 #undef GH_FAST_ALL
     }
     overlap = false;
@@ -1702,8 +1700,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
             dbg)
       if (!p->pk_score) GH_FAST(false, 0);
       else if (p->pass1 == 0) GH_FAST(true, 0);
-      else if (p->pass1 == 1) GH_FAST(true, 1);
-      else GH_FAST(true, 2);
+      else GH_FAST(true, 1);
 #undef GH_FAST
       if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
     }

@@ -109,6 +109,7 @@ SIGNATURES = {
     "gh_bf_match_dev": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_host": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_pairs_dev": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "gh_bf_match_pairs_popc_dev": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_pairs_mfma_dev": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_band_pairs_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, C.c_float, _vp, _vp, _vp]),
     "gh_match_mask_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

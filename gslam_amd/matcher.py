@@ -32,9 +32,10 @@ class BFMatcher:
         return idx1, d1, d2
 
     def match_pairs(self, desc: torch.Tensor, counts: torch.Tensor, pair_q: torch.Tensor, pair_t: torch.Tensor,
-                    out=None, mfma=False):
+                    out=None, mfma=None):
         """desc: F x cap x 32 u8; counts: F int32; pair_q/pair_t: P int32 -> (P x cap) idx1, d1, d2.
-        mfma=True: the exact integer MFMA formulation (gh_bf_match_pairs_mfma_dev), same results."""
+        mfma=None: gh_bf_match_pairs_dev (dispatches on the amount of pair work); True: the exact integer MFMA formulation
+        (gh_bf_match_pairs_mfma_dev); False: the popcount kernel (gh_bf_match_pairs_popc_dev).  Same results all three."""
         F, cap = desc.shape[0], desc.shape[1]
         P = pair_q.shape[0]
         if out is None:
@@ -43,7 +44,8 @@ class BFMatcher:
             d2 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
         else:
             idx1, d1, d2 = out
-        fn = hip.lib.gh_bf_match_pairs_mfma_dev if mfma else hip.lib.gh_bf_match_pairs_dev
+        fn = hip.lib.gh_bf_match_pairs_dev if mfma is None else (
+            hip.lib.gh_bf_match_pairs_mfma_dev if mfma else hip.lib.gh_bf_match_pairs_popc_dev)
         self.ctx.check(fn(self.ctx.h, _p(desc), _p(counts), cap, _p(pair_q), _p(pair_t), P, _p(idx1), _p(d1), _p(d2)))
         return idx1, d1, d2
 

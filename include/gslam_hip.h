@@ -90,15 +90,22 @@ gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t*
 
 /* Batched over frame pairs.  desc_dev: F frames x cap rows x 32 B; counts_dev[f] <= cap valid rows.
  * Pair p matches frame pair_q[p] (queries) against frame pair_t[p] (train).
- * Outputs are P x cap (rows >= counts[pair_q[p]] get idx1 = -1, d = 65535). */
+ * Outputs are P x cap (rows >= counts[pair_q[p]] get idx1 = -1, d = 65535).
+ * Dispatches on the amount of pair work: small batches run the popcount kernel (gh_bf_match_pairs_popc_dev), batches
+ * that fill the chip the exact MFMA formulation (gh_bf_match_pairs_mfma_dev); the results are bit-identical. */
 gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
                                 const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
                                 int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
 
-/* The same contract through an exact integer MFMA formulation (an experiment reported BESIDE the popcount kernel, which
- * stays the contract path): hamming = |a| + |b| - 2 |a & b| with |a & b| as a dot product of the descriptors expanded to
- * one byte per bit on v_mfma_i32_16x16x64_i8; three VALU instructions per pair instead of nineteen.  Results are
- * bit-identical to gh_bf_match_pairs_dev. */
+/* The popcount formulation, always (north_star's contract kernel: v_xor + v_bcnt, GSLAM/core/Vocabulary.h:485-491 as
+ * written; the kernel bench.py prices against the VALU issue ceiling). */
+gh_status gh_bf_match_pairs_popc_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
+                                     const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                     int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
+
+/* The same contract through an exact integer MFMA formulation, always: hamming = |a| + |b| - 2 |a & b| with |a & b| as a
+ * dot product of the descriptors expanded to one byte per bit on v_mfma_i32_16x16x64_i8; three VALU instructions per
+ * pair instead of nineteen.  Results are bit-identical to gh_bf_match_pairs_popc_dev. */
 gh_status gh_bf_match_pairs_mfma_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap,
                                      const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
                                      int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);

@@ -167,7 +167,7 @@ def test_mfma_formulation_is_bit_identical_to_the_popcount_kernel(ctx, oracle):
         dd = torch.from_numpy(desc).cuda()
         cc = torch.tensor(counts, dtype=torch.int32, device="cuda")
         q, t = torch.from_numpy(pq[:, 0].copy()).cuda(), torch.from_numpy(pq[:, 1].copy()).cuda()
-        a = m.match_pairs(dd, cc, q, t)
+        a = m.match_pairs(dd, cc, q, t, mfma=False)
         b = m.match_pairs(dd, cc, q, t, mfma=True)
         torch.cuda.synchronize()
         for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
@@ -197,7 +197,7 @@ def test_mfma_persistent_workgroups_walk_many_pairs(ctx):
     q = torch.arange(F, dtype=torch.int32, device="cuda").repeat_interleave(F)
     t = torch.arange(F, dtype=torch.int32, device="cuda").repeat(F)
     assert q.shape[0] > 4 * 256  # more pairs than persistent workgroup columns
-    a = m.match_pairs(desc, counts, q, t)
+    a = m.match_pairs(desc, counts, q, t, mfma=False)
     b = m.match_pairs(desc, counts, q, t, mfma=True)
     torch.cuda.synchronize()
     for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
@@ -225,10 +225,34 @@ def test_mfma_matcher_fuzz_against_the_popcount_kernel(ctx):
         counts[torch.randint(0, frames, (1,), device="cuda", generator=g)] = cap
         q = torch.randint(0, frames, (npairs,), dtype=torch.int32, device="cuda", generator=g)
         t = torch.randint(0, frames, (npairs,), dtype=torch.int32, device="cuda", generator=g)
-        a = m.match_pairs(desc, counts, q, t)
+        a = m.match_pairs(desc, counts, q, t, mfma=False)
         b = m.match_pairs(desc, counts, q, t, mfma=True)
         torch.cuda.synchronize()
         for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
             assert torch.equal(x, y), (cap, frames, npairs, seed, name, (x != y).nonzero()[:4].tolist())
 
     run()
+
+
+def test_pairs_entry_dispatches_on_pair_work_and_both_routes_agree(ctx):
+    """gh_bf_match_pairs_dev (what the plugins and bench.py call): a small batch runs the popcount kernel, a batch with
+    enough pair work the MFMA kernel (seen in the per-kernel profile); either way the rows equal the popcount entry's."""
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    m = BFMatcher(ctx)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for F, cap, want in ((4, 300, "bf_match_pairs"), (40, 2000, "bf_match_pairs_mfma")):
+        desc = torch.randint(0, 256, (F, cap, 32), dtype=torch.uint8, device="cuda", generator=g)
+        desc[:, 1::2] &= desc[:, 0::2]
+        counts = torch.randint(cap // 2, cap + 1, (F,), dtype=torch.int32, device="cuda", generator=g)
+        q = torch.arange(F - 1, dtype=torch.int32, device="cuda")
+        t = q + 1
+        ctx.prof_enable(True)
+        a = m.match_pairs(desc, counts, q, t)
+        used = ctx.prof_collect()
+        ctx.prof_enable(False)
+        assert want in used and len([k for k in used if k.startswith("bf_match")]) == 1, used.keys()
+        b = m.match_pairs(desc, counts, q, t, mfma=False)
+        torch.cuda.synchronize()
+        for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
+            assert torch.equal(x, y), (F, cap, name)

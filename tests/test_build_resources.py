@@ -12,7 +12,7 @@ from test_build_float_mode import LIB, LLVM, _code_objects
 
 # kernel-name fragment -> (max VGPRs + AGPRs, max bytes of scratch per work-item)
 BUDGET = {
-    "fast_cells_kernel": (72, 0),        # >= 6 waves per SIMD beside 24.5 KB of LDS per workgroup
+    "fast_cells_kernel": (72, 0),        # packed-16-bit variant: >= 6 waves per SIMD beside 24.5 KB of LDS per workgroup
     "fast_cells_all_kernel": (72, 0),
     "describe_kernel": (48, 0),
     "select_kernel": (128, 0),
@@ -53,7 +53,7 @@ def _kernels():
             if k == "agpr_count" and "name" in cur:  # first key of the next kernel's record
                 rows[cur["name"]] = cur
                 cur = {}
-            if k in ("name", "vgpr_count", "agpr_count", "vgpr_spill_count", "private_segment_fixed_size"):
+            if k in ("name", "vgpr_count", "agpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
                 cur[k] = v
         if "name" in cur:
             rows[cur["name"]] = cur
@@ -73,3 +73,17 @@ def test_hot_kernels_stay_within_their_register_and_scratch_budgets():
             assert regs <= max_regs, "%s: %d registers (budget %d)" % (r["name"], regs, max_regs)
             assert int(r["vgpr_spill_count"]) == 0 or max_scratch > 0, "%s spills vector registers" % r["name"]
             assert int(r["private_segment_fixed_size"]) <= max_scratch, "%s: %s bytes of scratch" % (r["name"], r["private_segment_fixed_size"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="needs the ROCm llvm-readelf")
+def test_swar_fast_cells_fits_eight_workgroups_per_cu():
+    """The shipped orb_fast_cells (SWAR pass 1, fast_cells_kernel<true, 1>) is latency sensitive: 6 -> 7 -> 8 workgroups per
+    CU measured 5.26 -> 4.82 -> 4.33 ms per 8 launches (profiles/orb_pass1_ab_r04.txt).  Eight 256-thread workgroups need
+    at most 64 VGPRs (8 waves per SIMD) and 160 KB / 8 = 20480 bytes of LDS each."""
+    rows = _kernels()
+    hits = [r for n, r in rows.items() if "fast_cells_kernelILb1ELi1E" in n]
+    assert len(hits) == 1, [n for n in rows if "fast_cells" in n]
+    r = hits[0]
+    assert int(r["vgpr_count"]) + int(r.get("agpr_count", 0)) <= 64, r
+    assert int(r["group_segment_fixed_size"]) <= 20480, r
+    assert int(r["vgpr_spill_count"]) == 0 and int(r["private_segment_fixed_size"]) == 0, r
