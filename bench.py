@@ -242,6 +242,8 @@ def main():
     def barrier():
         finish_match_gather()
         torch.cuda.synchronize()
+        if comm is not None:
+            comm.status()  # the asynchronous IPC transport reports an abandoned exchange only here (raises)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

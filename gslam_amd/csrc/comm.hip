@@ -365,6 +365,14 @@ gh_status begin_collective(gh_comm* c) {
   return GH_OK;
 }
 
+// A rank that has announced an exchange (ready[rank] = k) and then fails locally (a buffer that is not a communicator
+// buffer, a stride mismatch) will never publish done[rank] = k: without this its peers would sit out the whole timeout.
+// The communicator is poisoned at once -- every poll stops, every later call on every rank reports it.
+gh_status abandon_collective(gh_comm* c, gh_status st) {
+  if (c->transport == 1 && !c->ipc_sync && c->shm) c->shm->failed.store(1, std::memory_order_relaxed);
+  return st;
+}
+
 gh_status end_collective(gh_comm* c) {
   if (c->transport == 1 && !c->ipc_sync) {
     hipLaunchKernelGGL(comm_flag_set_kernel, dim3(1), dim3(1), 0, c->stream, &c->shm_dev->done[c->rank].v, c->round);
@@ -570,7 +578,8 @@ extern "C" gh_status gh_allgather(gh_comm* c, const void* send_dev, void* gather
   GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, send_dev && gathered_dev && bytes_per_rank > 0);
   GH_TRY(begin_collective(c));
-  GH_TRY(gather_one(c, send_dev, gathered_dev, bytes_per_rank, bytes_per_rank));
+  const gh_status st = gather_one(c, send_dev, gathered_dev, bytes_per_rank, bytes_per_rank);
+  if (st != GH_OK) return abandon_collective(c, st);
   return end_collective(c);
 }
 
@@ -595,7 +604,7 @@ extern "C" gh_status gh_allgather_features(gh_comm* c, int frames, int cap, cons
     ncclResult_t r = rccl().GroupEnd();
     if (st == GH_OK && r != ncclSuccess) st = rccl_fail(ctx, "ncclGroupEnd", r);
   }
-  GH_TRY(st);
+  if (st != GH_OK) return abandon_collective(c, st);
   return end_collective(c);
 }
 
@@ -617,7 +626,7 @@ extern "C" gh_status gh_allgather_matches(gh_comm* c, int rows, int cap, const i
     ncclResult_t r = rccl().GroupEnd();
     if (st == GH_OK && r != ncclSuccess) st = rccl_fail(ctx, "ncclGroupEnd", r);
   }
-  GH_TRY(st);
+  if (st != GH_OK) return abandon_collective(c, st);
   return end_collective(c);
 }
 
@@ -639,6 +648,12 @@ extern "C" gh_status gh_comm_wait(gh_comm* c) {
     hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, c->shm_dev->done, c->world, c->round,
                        (unsigned long long)(c->timeout_s * 1e8), (int*)&c->shm_dev->failed);
     GH_HIP(ctx, hipGetLastError());
+    // This call does not wait, so a peer that goes missing in THIS exchange shows only once the poll above has run out:
+    // in gh_comm_status (call it after the next stream synchronisation -- bench.py and gslam_amd/sharding.py do) and in
+    // every later gh_comm_* call, this one included: an exchange that was abandoned earlier is reported here
+    if (c->shm->failed.load(std::memory_order_relaxed))
+      return gh_set_error(ctx, GH_ERR_HIP, "IPC transport: a rank gave up waiting in an earlier exchange (timeout %.0f s): "
+                                           "the gathered buffers are incomplete", c->timeout_s);
     return GH_OK;
   }
   GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));

@@ -47,6 +47,7 @@ enum {
   kDbgUnusedSlots,       // zero-filled output rows
   kDbgStarvedLevels,     // (level, frame) selections with fewer candidates than quota
   kDbgWeakCells,         // cells with candidates but no corner above the initial threshold (a two-phase detector's second pass)
+  kDbgResizePasses,      // wave-level passes through the fused resize body (one per wave with at least one item, per item block)
   kDbgCount = 16
 };
 
@@ -560,6 +561,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
       const int g = gb + (tid & 7);
       for (int q = tid >> 3; q < nq; q += 32) {
         const int yy = r0 + kResizeRows * q;
+        if (dbg != nullptr && __ffsll((unsigned long long)__ballot(true)) - 1 == (tid & 63)) atomicAdd(&dbg[kDbgResizePasses], 1u);
         if (g < ng)
           resize_item(lv, s, d, nx.dst_pitch, nx.tb, 8 * (g0 + g), yy, min(r1, yy + kResizeRows), frame == nx.tail_unsafe_frame);
       }
@@ -994,7 +996,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
                                                        uint32_t* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch + 28];  // + slack for the 16-B row reads
   __shared__ __attribute__((aligned(16))) uint32_t s_h[4][(kPatch + 1) * kBlurPitch];     // 34 rows x 28 dwords
-  __shared__ __attribute__((aligned(16))) uint8_t s_blur[4][kBlur * kBlurPitch + 12];
+  // The blurred patch REPLACES the raw one (last read by the h-pass, a wave barrier before the v-pass writes): 20.2 KB of
+  // LDS per workgroup = 8 workgroups per CU instead of 6 (GSLAM_HIP_ORB_DESC_LDSPAD=3000 restores 6 for A/B runs)
+  static_assert(sizeof(s_patch[0]) >= kBlur * kBlurPitch + 12, "the blurred patch fits where the raw patch was");
+  static_assert(sizeof(s_patch) + sizeof(s_h) <= 20480, "8 workgroups per CU");
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blocks_per_frame = (K + 3) >> 2;
   const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
@@ -1128,7 +1133,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     }
   }
   __builtin_amdgcn_wave_barrier();
-  uint8_t* bl = s_blur[wv];
+  uint8_t* bl = s_patch[wv];
   // v-pass: one work item = 4 adjacent outputs of one blur row: 7 x 16-byte reads down the 4 columns, 28
   // v_mad_u32_u24 (h sums < 2^20), weights x4 so that the rounded result is the top byte of the sum
   // ((4 s + 2^23) >> 24 == (s + 2^21) >> 22; 4 * 2048 * 522240 + 2^23 < 2^32), one dword store.
@@ -1211,6 +1216,10 @@ struct gh_orb_plan {
   const int32_t* own_gx[kMaxL] = {nullptr};  // fused pyramid: first owned output group / row per tile column / row of level l
   const int32_t* own_gy[kMaxL] = {nullptr};
   bool fuse_pyramid = true;  // GSLAM_HIP_ORB_FUSE_PYRAMID=0 keeps the stand-alone resize launches (A/B measurements)
+  bool pyramid_ahead = false;  // GSLAM_HIP_ORB_FUSE_PYRAMID=2: the stand-alone resize chain runs AHEAD on its own stream, beside the FAST passes
+  hipStream_t pyr_stream = nullptr;
+  hipEvent_t ev_pyr[kMaxL]{}, ev_pyr_start = nullptr;
+  int desc_lds_pad = 0;      // GSLAM_HIP_ORB_DESC_LDSPAD: the same for orb_describe
   int lds_pad = 0;           // GSLAM_HIP_ORB_LDSPAD: extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test (rounds 2-3), 1 = SWAR on 16-bit fields
   bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
@@ -1229,8 +1238,16 @@ struct gh_orb_plan {
     int batch, row_stride;
     size_t frame_stride;
     hipGraphExec_t exec;
+    hipEvent_t done;  // recorded behind every launch of `exec`: an evicted graph is destroyed only once this has passed
   };
-  std::vector<CallGraph> graphs;
+  // A ring of staging slots (gh_orb_stream: depth <= 16) or a caller that reuses its buffers has a handful of argument
+  // sets.  A caller that hands in fresh pointers every call (extract() without out=) never hits: after kGraphGiveUp
+  // misses that outnumber the hits four to one the plan stops capturing and launches kernel by kernel (a miss costs a
+  // capture + an instantiation on top of the launches it saves).
+  static constexpr int kGraphRing = 16, kGraphGiveUp = 8;
+  std::vector<CallGraph> graphs, retired;
+  long long graph_hits = 0, graph_misses = 0;
+  hipStream_t cap_stream = nullptr;  // the capture runs on a stream of the plan, never on the caller's (another host thread may be enqueuing there)
   bool graphs_off = false, capturing = false;
   // batched calls: select(level l) runs on a side stream beside fast_cells(l + 1 ..) (gh_orb_extract_dev)
   hipStream_t side = nullptr;
@@ -1266,7 +1283,20 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   for (void* q : ptrs)
     if (q) hipFree(q);
   if (p->stage_host) hipHostFree(p->stage_host);
-  for (auto& g : p->graphs) hipGraphExecDestroy(g.exec);
+  for (auto* v : {&p->graphs, &p->retired})
+    for (auto& g : *v) {
+      hipEventSynchronize(g.done);  // (the caller may have moved the context to another stream since the last launch)
+      hipGraphExecDestroy(g.exec);
+      hipEventDestroy(g.done);
+    }
+  if (p->cap_stream) hipStreamDestroy(p->cap_stream);
+  if (p->pyr_stream) {
+    hipStreamSynchronize(p->pyr_stream);
+    hipStreamDestroy(p->pyr_stream);
+  }
+  for (hipEvent_t e : p->ev_pyr)
+    if (e) hipEventDestroy(e);
+  if (p->ev_pyr_start) hipEventDestroy(p->ev_pyr_start);
   if (p->side) {
     hipStreamSynchronize(p->side);
     hipStreamDestroy(p->side);
@@ -1342,9 +1372,13 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   p->h = height;
   p->max_batch = max_batch;
   p->prm = prm;
-  if (const char* e = getenv("GSLAM_HIP_ORB_FUSE_PYRAMID")) p->fuse_pyramid = atoi(e) != 0;
+  if (const char* e = getenv("GSLAM_HIP_ORB_FUSE_PYRAMID")) {
+    p->fuse_pyramid = atoi(e) == 1;
+    p->pyramid_ahead = atoi(e) == 2;
+  }
   if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_LDSPAD")) p->lds_pad = atoi(e) < 0 ? 0 : atoi(e);
+  if (const char* e = getenv("GSLAM_HIP_ORB_DESC_LDSPAD")) p->desc_lds_pad = atoi(e) < 0 ? 0 : atoi(e);
   if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
@@ -1529,38 +1563,70 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   const bool small = (long long)batch * p->w * p->h <= (4LL << 20);  // up to two 1080p frames: launch-bound
   if (!(graph_env && small && !p->graphs_off && !ctx->prof_on && !p->dbg_on && ctx->stream != nullptr))
     return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
-  for (const auto& g : p->graphs)
+  for (auto& g : p->graphs)
     if (g.gray == gray_dev && g.kps == kps_dev && g.desc == desc_dev && g.counts == counts_dev && g.batch == batch &&
         g.row_stride == row_stride && g.frame_stride == frame_stride) {
+      ++p->graph_hits;
       GH_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
+      GH_HIP(ctx, hipEventRecord(g.done, ctx->stream));
       return GH_OK;
     }
-  // first call with these arguments: capture the launch sequence (nothing executes during the capture), then replay it
-  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-    (void)hipGetLastError();
-    p->graphs_off = true;  // (a stream that cannot be captured, e.g. the legacy default stream)
+  // retired graphs whose last launch has completed can go now
+  for (size_t k = 0; k < p->retired.size();) {
+    if (hipEventQuery(p->retired[k].done) == hipSuccess) {
+      hipGraphExecDestroy(p->retired[k].exec);
+      hipEventDestroy(p->retired[k].done);
+      p->retired.erase(p->retired.begin() + (long)k);
+    } else {
+      (void)hipGetLastError();
+      ++k;
+    }
+  }
+  ++p->graph_misses;
+  if (p->graph_misses >= gh_orb_plan::kGraphGiveUp && p->graph_misses > 4 * p->graph_hits) {
+    p->graphs_off = true;  // the caller's argument sets do not repeat: capturing costs more than it saves
     return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
   }
+  // first call with these arguments: capture the launch sequence on the plan's own stream (nothing executes during the
+  // capture, and nobody else can enqueue there), then replay it on the caller's
+  if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    p->cap_stream = nullptr;
+    p->graphs_off = true;
+    return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
+  }
+  if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    p->graphs_off = true;
+    return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
+  }
+  hipStream_t const user_stream = ctx->stream;
+  ctx->stream = p->cap_stream;
   p->capturing = true;
   const gh_status st = orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
   p->capturing = false;
+  ctx->stream = user_stream;
   hipGraph_t graph = nullptr;
-  const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
+  const hipError_t ee = hipStreamEndCapture(p->cap_stream, &graph);
   hipGraphExec_t exec = nullptr;
-  if (st != GH_OK || ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+  hipEvent_t done = nullptr;
+  if (st != GH_OK || ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess ||
+      hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
+    if (exec) hipGraphExecDestroy(exec);
     if (graph) hipGraphDestroy(graph);
     p->graphs_off = true;
     if (st != GH_OK) return st;
     return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
   }
   hipGraphDestroy(graph);
-  if (p->graphs.size() >= 8) {  // a ring of staging slots has a handful of argument sets; anything beyond that is churn
-    hipGraphExecDestroy(p->graphs.front().exec);
+  if ((int)p->graphs.size() >= gh_orb_plan::kGraphRing) {  // the oldest set goes; its exec may still be queued on the stream
+    p->retired.push_back(p->graphs.front());
     p->graphs.erase(p->graphs.begin());
   }
-  p->graphs.push_back({gray_dev, kps_dev, desc_dev, counts_dev, batch, row_stride, frame_stride, exec});
+  p->graphs.push_back({gray_dev, kps_dev, desc_dev, counts_dev, batch, row_stride, frame_stride, exec, done});
   GH_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+  GH_HIP(ctx, hipEventRecord(done, ctx->stream));
   return GH_OK;
 }
 
@@ -1681,9 +1747,42 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     }
     overlap = false;
   }
+  // pyramid ahead: levels 1 .. L-1 by the stand-alone resize kernel on a stream of their own, each FAST pass waits for its
+  // level only -- the memory-instruction-bound resize chain shares the CUs with the VALU-bound FAST passes of earlier levels
+  bool ahead = p->pyramid_ahead && !all_levels && !p->capturing && L > 1;
+  if (ahead && !p->pyr_stream) {
+    bool ok = hipStreamCreateWithFlags(&p->pyr_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->ev_pyr_start, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l < kMaxL && ok; ++l) ok = hipEventCreateWithFlags(&p->ev_pyr[l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      ahead = false;
+    }
+  }
+  if (ahead) {
+    GH_HIP(ctx, hipEventRecord(p->ev_pyr_start, ctx->stream));  // level 0 (the caller's frames, or the staging copy) is ready
+    GH_HIP(ctx, hipStreamWaitEvent(p->pyr_stream, p->ev_pyr_start, 0));
+    StreamSwap sw(ctx, p->pyr_stream);
+    for (int l = 1; l < L; ++l) {
+      GH_TRY(resize_standalone(l));
+      GH_HIP(ctx, hipEventRecord(p->ev_pyr[l], p->pyr_stream));
+    }
+  }
   for (int l = 0; l < L && !all_levels; ++l) {
     const bool fast = p->ncx[l] != 0 && p->quota[l] > 0;
-    if (!fast) {
+    if (ahead) {
+      if (l > 0) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->ev_pyr[l], 0));
+      if (fast) {
+        const NextLevel none{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
+        const NextLevel& nx = none;
+        const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
+        GH_CHECK_ARG(ctx, tiles < (1LL << 30));
+        dim3 grid(8 * gh_div_up(tiles, 8));
+        if (!p->pk_score) GH_LAUNCH(ctx, "orb_fast_cells", (fast_cells_kernel<false, 0>), grid, dim3(256), p->lds_pad, lv[l], p->ncx[l], p->ncy[l], p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l], batch, nx, dbg);
+        else if (p->pass1 == 0) GH_LAUNCH(ctx, "orb_fast_cells", (fast_cells_kernel<true, 0>), grid, dim3(256), p->lds_pad, lv[l], p->ncx[l], p->ncy[l], p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l], batch, nx, dbg);
+        else GH_LAUNCH(ctx, "orb_fast_cells", (fast_cells_kernel<true, 1>), grid, dim3(256), p->lds_pad, lv[l], p->ncx[l], p->ncy[l], p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l], batch, nx, dbg);
+      }
+    } else if (!fast) {
       if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
     } else {
       NextLevel nx{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
@@ -1730,7 +1829,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     DevTables tb{p->d_pattern, p->d_dir};
     const long long blocks = (long long)gh_div_up(K, 4) * batch;
     GH_CHECK_ARG(ctx, blocks < (1LL << 30));
-    GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
+    GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K, p->sel,
               p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
   }
   return GH_OK;

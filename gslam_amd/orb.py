@@ -72,7 +72,9 @@ class OrbExtractor:
         return kps, desc, counts
 
     def extract(self, frames: torch.Tensor, out=None):
-        """frames: B x H x stride u8 (cuda).  Returns (kps B x K x 7 f32-view of KeyPoint, desc B x K x 32, counts)."""
+        """frames: B x H x stride u8 (cuda).  Returns (kps B x K x 7 f32-view of KeyPoint, desc B x K x 32, counts).
+        Small calls (up to two 1080p frames) replay a captured launch graph when the SAME frames / out buffers come back
+        (pass out= and reuse it); with fresh buffers every call the plan stops capturing after a few misses."""
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3
         B, H, stride = frames.shape
         assert H == self.h and stride >= self.w and frames.stride(2) == 1 and frames.stride(1) == stride
@@ -96,7 +98,7 @@ class OrbExtractor:
 
     DBG_NAMES = ("cells", "dense_cells", "overflow_cells", "cap_cells", "rank_dropped", "strong_silenced",
                  "max_queue", "max_nz", "sel_cut", "sel_tie_split", "sel_overflow_cells", "sel_streamed",
-                 "unused_slots", "starved_levels", "weak_cells")
+                 "unused_slots", "starved_levels", "weak_cells", "resize_passes")
 
     def debug_counters(self, enable=True, read=True):
         """Branch census of the extractions since the last read (gh_orb_plan_debug_counters)."""

@@ -259,3 +259,34 @@ def test_roi_view_whose_allocation_ends_at_the_last_pixel(ctx, oracle):
                                           hd.ctypes.data_as(C.c_void_p), C.byref(hn)))
     assert hn.value == len(ek) and hk[:hn.value].tobytes() == ek.tobytes() and np.array_equal(hd[:hn.value], ed)
     ex.close()
+
+
+def test_small_call_graph_cache_survives_fresh_and_rotating_buffers(ctx):
+    """The hipGraph replay of small calls (gh_orb_extract_dev): (a) more rotating output sets than the cache holds -- evicted
+    graphs are retired, not destroyed under a queued launch; (b) fresh output buffers every call -- the plan gives up
+    capturing; the records stay identical throughout."""
+    import torch
+    from gslam_amd.orb import OrbExtractor, synth_frames
+    for fresh_first in (False, True):
+        ex = OrbExtractor(ctx, 320, 240, max_batch=1, n_features=300)
+        fr = synth_frames(ctx, 1, 320, 240, base_seed=0x5EED0000)
+        def same(out, ref):  # (KeyPoint.class_id = -1 reads as a NaN through the float32 view: compare the bits)
+            return all(torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                                   b.view(torch.int32) if b.dtype == torch.float32 else b) for a, b in zip(out, ref))
+
+        ref = [t.clone() for t in ex.extract(fr)]
+        torch.cuda.synchronize()
+        assert int(ref[2][0]) > 100
+        if fresh_first:
+            for it in range(24):  # fresh buffers every call
+                out = ex.extract(fr)
+                torch.cuda.synchronize()
+                assert same(out, ref), it
+        sets = [ex.alloc_outputs(1) for _ in range(20)]  # more than the 16-entry ring
+        for rnd in range(3):
+            for o in sets:
+                ex.extract(fr, o)
+            torch.cuda.synchronize()
+            for o in sets:
+                assert same(o, ref), (fresh_first, rnd)
+        ex.close()
