@@ -7,7 +7,8 @@
 One STEP = one pass of the ORB front end + brute-force matcher over one batch of synthetic frames
 already resident in HBM (BASELINE.json configs[1], "C2"): `--frames` 1920x1080 gray frames per GPU,
 2000 ORB keypoints each, 256-bit BF Hamming matching of every consecutive frame pair.  With N GPUs
-each rank owns `--frames` frames (weak scaling), descriptors and match records are exchanged with
+each rank owns `--frames` frames (weak scaling; `--scaling strong` splits them over the ranks instead: BASELINE's "1000
+frames at 1/2/4/8 GPUs"), descriptors and match records are exchanged with
 one RCCL all-gather each (north_star: "RCCL all-gather of descriptors/match pairs"), no other collective.
 
 Printed JSON line (rank 0): metric = extract+match Mkeypoints/s over the whole job, plus
@@ -69,7 +70,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150, help="timed steps (150 x ~20 ms = a 3 s timed region)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (C2: 1000)")
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (C2: 1000); with --scaling strong: frames of the whole job")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns --frames frames (the driver's scaling bench); strong: the --frames frames of BASELINE "
+                         "configs[1] are split over the ranks (1000 / N each), everything else unchanged")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--kpts", type=int, default=2000)
@@ -128,7 +132,9 @@ def main():
     from gslam_amd.sharding import exchange_features_begin, exchange_matches_begin, local_pairs
 
     ctx = hip.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    F, W, H, K = a.frames, a.width, a.height, a.kpts
+    if a.scaling == "strong":
+        assert a.frames % world == 0 and a.frames // world >= 2, "--scaling strong: --frames must be a multiple of the rank count (>= 2 per rank)"
+    F, W, H, K = (a.frames // world if a.scaling == "strong" else a.frames), a.width, a.height, a.kpts
     ex = OrbExtractor(ctx, W, H, max_batch=F, n_features=K)
     matcher = BFMatcher(ctx)
     # synthetic frames resident in HBM before the timed region; global frame index = rank * F + f
@@ -1200,8 +1206,9 @@ def main():
     line = {
         "metric": "orb_extract_plus_bf_match_Mkeypoints_per_s", "value": round(value, 3), "unit": "Mkeypoints/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"C2: {F}x{W}x{H} frames per GPU, {K} ORB kpts each, BF Hamming consecutive-pair match",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"C2: {F}x{W}x{H} frames per GPU" + (f" ({a.frames} in the job, split over the ranks)" if a.scaling == "strong" else "")
+                               + f", {K} ORB kpts each, BF Hamming consecutive-pair match",
                    "frames_per_gpu": F, "width": W, "height": H, "kpts_per_frame": K,
                    "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of descriptors + matches via {comm_note}"
                    if world > 1 else "single GPU",

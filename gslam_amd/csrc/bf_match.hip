@@ -291,16 +291,76 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t* out, int iter
   if ((acc[0] + acc[1] + acc[2] + acc[3]) == 0xFFFFFFFFu) out[0] = 1;
 }
 
+// Train sets beyond 65535 rows (a frame against a local map): the 16-bit index field of the search key holds one CHUNK;
+// chunks are matched one after the other and folded into the running (best, index, second best) with the same strict '<':
+// an equal distance in a later chunk never displaces the earlier index (GSLAM/core/Vocabulary.h:1712-1725) and becomes the
+// second best, exactly as in one sweep over all rows.
+__global__ void bf_merge_chunk_kernel(int nq, int32_t* __restrict__ idx1, uint16_t* __restrict__ d1, uint16_t* __restrict__ d2,
+                                      const int32_t* __restrict__ cidx, const uint16_t* __restrict__ cd1,
+                                      const uint16_t* __restrict__ cd2, int base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq || cidx[i] < 0) return;
+  const unsigned b1 = d1[i], b2 = d2[i], c1 = cd1[i], c2 = cd2[i];
+  const bool had = idx1[i] >= 0;
+  if (!had || c1 < b1) {
+    idx1[i] = base + cidx[i];
+    d1[i] = (uint16_t)c1;
+    d2[i] = (uint16_t)(!had ? c2 : (b1 < c2 ? b1 : c2));
+  } else {
+    d2[i] = (uint16_t)(c1 < b2 ? c1 : b2);
+  }
+}
+
 }  // namespace
+
+static gh_status bf_match_chunk(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int32_t* idx1_dev,
+                                uint16_t* d1_dev, uint16_t* d2_dev);
+
+// bytes of device memory bf_match_any wants for a train set of nt rows (0 up to 65535 rows)
+static size_t bf_chunk_tmp_bytes(int nq, int nt) {
+  return nt <= 65535 ? 0 : ((((size_t)nq * 4) + 255) & ~(size_t)255) + 2 * ((((size_t)nq * 2) + 255) & ~(size_t)255);
+}
+static gh_status bf_match_any(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int32_t* idx1_dev,
+                              uint16_t* d1_dev, uint16_t* d2_dev, void* tmp);
 
 extern "C" gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
                                      int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
-  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535);
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0);
   if (nq == 0) return GH_OK;
   GH_CHECK_ARG(ctx, q_dev && idx1_dev && d1_dev && d2_dev && (nt == 0 || t_dev));
   GH_CHECK_ARG(ctx, ((uintptr_t)q_dev & 15) == 0 && ((uintptr_t)t_dev & 3) == 0);
+  void* tmp = nullptr;
+  if (nt > 65535) GH_TRY(gh_scratch(ctx, bf_chunk_tmp_bytes(nq, nt), &tmp));
+  return bf_match_any(ctx, q_dev, nq, t_dev, nt, idx1_dev, d1_dev, d2_dev, tmp);
+}
+
+static gh_status bf_match_any(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int32_t* idx1_dev,
+                              uint16_t* d1_dev, uint16_t* d2_dev, void* tmp) {
+  if (nt <= 65535) return bf_match_chunk(ctx, q_dev, nq, t_dev, nt, idx1_dev, d1_dev, d2_dev);
+  // chunks of 65532 rows (a multiple of 4: the split kernel's row quads), results of chunk 0 straight into the outputs
+  constexpr int kChunk = 65532;
+  const size_t ib = (((size_t)nq * 4) + 255) & ~(size_t)255, db = (((size_t)nq * 2) + 255) & ~(size_t)255;
+  int32_t* cidx = (int32_t*)tmp;
+  uint16_t* cd1 = (uint16_t*)((uint8_t*)tmp + ib);
+  uint16_t* cd2 = (uint16_t*)((uint8_t*)tmp + ib + db);
+  for (int base = 0; base < nt; base += kChunk) {
+    const int n = nt - base < kChunk ? nt - base : kChunk;
+    const uint8_t* tc = t_dev + (size_t)base * 32;
+    if (base == 0) {
+      GH_TRY(bf_match_chunk(ctx, q_dev, nq, tc, n, idx1_dev, d1_dev, d2_dev));
+    } else {
+      GH_TRY(bf_match_chunk(ctx, q_dev, nq, tc, n, cidx, cd1, cd2));
+      GH_LAUNCH(ctx, "bf_merge_chunk", bf_merge_chunk_kernel, dim3(gh_div_up(nq, 256)), dim3(256), 0, nq, idx1_dev, d1_dev, d2_dev,
+                cidx, cd1, cd2, base);
+    }
+  }
+  return GH_OK;
+}
+
+static gh_status bf_match_chunk(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int32_t* idx1_dev,
+                                uint16_t* d1_dev, uint16_t* d2_dev) {
   // few queries: split the train rows over the waves of a workgroup (latency); many: one wave per 64 * kQPT queries
   static const bool split_env = [] {
     const char* e = getenv("GSLAM_HIP_BF_SPLIT");  // "0": always the one-wave sweep (A/B measurements)
@@ -323,7 +383,7 @@ extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, con
                                       uint16_t* d1, uint16_t* d2) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
-  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535);
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0);
   if (nq == 0) return GH_OK;
   size_t qb = (size_t)nq * 32, tb = (size_t)nt * 32;
   size_t off_t = (qb + 255) & ~(size_t)255;
@@ -331,8 +391,10 @@ extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, con
   size_t off_d1 = off_i + (((size_t)nq * 4 + 255) & ~(size_t)255);
   size_t off_d2 = off_d1 + (((size_t)nq * 2 + 255) & ~(size_t)255);
   size_t total = off_d2 + (size_t)nq * 2;
+  const size_t off_tmp = (total + 255) & ~(size_t)255;  // chunk results of a train set beyond 65535 rows (device side only)
+  const size_t dev_total = off_tmp + bf_chunk_tmp_bytes(nq, nt);
   void *base = nullptr, *hbase = nullptr;
-  GH_TRY(gh_scratch(ctx, total, &base));
+  GH_TRY(gh_scratch(ctx, dev_total, &base));
   GH_TRY(gh_pinned(ctx, total, &hbase));
   uint8_t *b = (uint8_t*)base, *hb = (uint8_t*)hbase;
   // one DMA up (q | t) and one down (idx1 | d1 | d2) through the context's pinned block: a pageable copy per array
@@ -340,8 +402,8 @@ extern "C" gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, con
   memcpy(hb, q, qb);
   if (tb) memcpy(hb + off_t, t, tb);
   GH_HIP(ctx, hipMemcpyAsync(b, hb, off_t + tb, hipMemcpyHostToDevice, ctx->stream));
-  GH_TRY(gh_bf_match_dev(ctx, b, nq, b + off_t, nt, (int32_t*)(b + off_i), (uint16_t*)(b + off_d1),
-                         (uint16_t*)(b + off_d2)));
+  GH_TRY(bf_match_any(ctx, b, nq, b + off_t, nt, (int32_t*)(b + off_i), (uint16_t*)(b + off_d1), (uint16_t*)(b + off_d2),
+                      b + off_tmp));
   GH_HIP(ctx, hipMemcpyAsync(hb + off_i, b + off_i, total - off_i, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(idx1, hb + off_i, (size_t)nq * 4);

@@ -58,8 +58,9 @@ struct LevelView {
 };
 
 struct DevTables {
-  const int8_t* pattern;   // [30][256][4]
-  const int32_t* dir;      // [30][2]
+  const int8_t* pattern;        // table mode: [30][256] offset pairs (upload_pattern)
+  const int32_t* dir;           // [30][2]
+  const int8_t* base_pattern;   // continuous steering: the unrotated tests [256][4] int8
 };
 
 struct SelKp {
@@ -984,22 +985,72 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
          __builtin_amdgcn_readlane(v, 48);
 }
 
-// 33x33 patch (radius 16): covers the radius-15 centroid disc and the 7x7 blur of the radius-13 test pattern.
-constexpr int kPatch = 33, kPatchPitch = 36;  // 9 dwords per row cover any 33-byte run
-constexpr int kBlur = 27, kBlurPitch = 28;     // blurred region: radius 13 (max |pattern coordinate|)
+// Patch geometry of orb_describe for a test pattern of radius BR (blurred region = (2 BR + 1)^2, raw patch 3 px wider for
+// the 7x7 Gaussian): BR = 13 is the 30-bin table mode (33 x 33 patch: also covers the radius-15 centroid disc), BR = 19 the
+// continuous-steering mode, whose rotated points reach radius 19 (45 x 45 patch).
+template <int BR>
+struct DescGeom {
+  static constexpr int kC = BR + 3;                         // patch radius
+  static constexpr int kPatch = 2 * kC + 1;                  // 33 / 45
+  static constexpr int kPatchPitch = (kPatch + 6) & ~3;      // 36 / 48: whole dwords that cover any kPatch-byte run
+  static constexpr int kRowDw = kPatchPitch / 4;
+  static constexpr int kBlur = 2 * BR + 1;                   // 27 / 39
+  static constexpr int kBlurPitch = (kBlur + 3) & ~3;        // 28 / 40
+  static constexpr int kGroups = kBlurPitch / 4;             // 4-column groups per blur row
+};
+constexpr int kBlurPitch = DescGeom<13>::kBlurPitch;  // (the table mode's pitch: upload_pattern bakes it into the offsets)
 
+// Continuous steering (gh_orb_plan_set_steering, oracle/orb_oracle.c steps 6' and 8'): the orientation is the fp32
+// polynomial arctangent OpenCV's fastAtan2 uses (ORB-SLAM's IC_Angle calls it), and every test point is rotated by it.
+// Plain fp32 + - * / in a fixed order, no contraction, so that the CPU checker reproduces every bit.
+__host__ __device__ inline float orb_fast_atan2_deg(float y, float x) {
+  const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;  // 0.99978784, -0.32580840, 0.15557865, -0.044326555 x (float)(180 / pi)
+  const float eps = 2.2204460492503131e-16f;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a;
+  if (ax >= ay) {
+    const float c = ay / (ax + eps), c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    const float c = ax / (ay + eps), c2 = c * c;
+    a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0.0f) a = 180.0f - a;
+  if (y < 0.0f) a = 360.0f - a;
+  return a;
+}
+// cos / sin of an angle in degrees, [0, 360]: nearest quadrant k, remainder r in [-45, 45] degrees, Taylor polynomials
+__host__ __device__ inline void orb_sincos_deg(float a, float* cs, float* sn) {
+  const int k = (int)(a / 90.0f + 0.5f);
+  const float r = (a - 90.0f * (float)k) * 0.017453292f, r2 = r * r;
+  const float s = r * (1.0f + r2 * (-0.16666667f + r2 * (0.0083333338f + r2 * -0.00019841270f)));
+  const float c = 1.0f + r2 * (-0.5f + r2 * (0.041666668f + r2 * (-0.0013888889f + r2 * 0.000024801588f)));
+  switch (k & 3) {
+    case 0: *cs = c; *sn = s; break;
+    case 1: *cs = -s; *sn = c; break;
+    case 2: *cs = -c; *sn = -s; break;
+    default: *cs = s; *sn = -c; break;
+  }
+}
+__host__ __device__ inline int orb_reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+template <int BR, bool STEER>
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
                                                        const int32_t* __restrict__ level_cnt,
                                                        gh_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                        int32_t* __restrict__ counts, int n_frames,
                                                        uint32_t* __restrict__ dbg) {
+  typedef DescGeom<BR> G;
+  constexpr int kC = G::kC, kPatch = G::kPatch, kPatchPitch = G::kPatchPitch, kRowDw = G::kRowDw, kBlur = G::kBlur,
+                kBlurPitch = G::kBlurPitch, kGroups = G::kGroups;
+  static_assert(kPatch <= 64 && kC >= 16, "one lane per patch row; the radius-15 centroid disc lies inside the patch");
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch + 28];  // + slack for the 16-B row reads
-  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][(kPatch + 1) * kBlurPitch];     // 34 rows x 28 dwords
+  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][(kPatch + 1) * kBlurPitch];
   // The blurred patch REPLACES the raw one (last read by the h-pass, a wave barrier before the v-pass writes): 20.2 KB of
-  // LDS per workgroup = 8 workgroups per CU instead of 6 (GSLAM_HIP_ORB_DESC_LDSPAD=3000 restores 6 for A/B runs)
+  // LDS per workgroup in the table mode = 8 workgroups per CU instead of 6 (GSLAM_HIP_ORB_DESC_LDSPAD=3000 restores 6 for A/B runs)
   static_assert(sizeof(s_patch[0]) >= kBlur * kBlurPitch + 12, "the blurred patch fits where the raw patch was");
-  static_assert(sizeof(s_patch) + sizeof(s_h) <= 20480, "8 workgroups per CU");
+  static_assert(BR != 13 || sizeof(s_patch) + sizeof(s_h) <= 20480, "8 workgroups per CU");
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blocks_per_frame = (K + 3) >> 2;
   const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
@@ -1036,21 +1087,33 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   const SelKp kp = sel[(size_t)b * K + slot];
   const LevelView lv = a.lv[l];
   const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
-  // 33x33 patch: each row is fetched as the 9 aligned dwords that cover it; the 33 wanted bytes start at
+  // kPatch x kPatch patch: each row is fetched as the kRowDw aligned dwords that cover it; the wanted bytes start at
   // offset px0 & 3 (= px0 - pa) of the row in LDS.
-  const int px0 = (int)kp.x - 16, py0 = (int)kp.y - 16;
+  const int px0 = (int)kp.x - kC, py0 = (int)kp.y - kC;
   const int pa = px0 & ~3;
-  // lane r < 33 fetches the whole 36-byte row r (dwordx4 + dwordx4 + dword: 3 vector-memory instructions per wave
-  // instead of 5 trips of address arithmetic + dword loads)
+  // lane r < kPatch fetches the whole row r (dwordx4 loads + a tail: 3 vector-memory instructions per wave instead of
+  // trips of address arithmetic + dword loads).  The table mode's patch (radius 16) never leaves the image (keypoints keep
+  // 19 px from the border); the radius-22 patch of the continuous mode can: such keypoints gather their patch byte by
+  // byte with BORDER_REFLECT_101 coordinates (what ORB-SLAM's padded pyramid holds there).
+  const bool inside = !STEER || (pa >= 0 && pa + kPatchPitch <= lv.pitch && px0 + kPatch <= lv.w && py0 >= 0 && py0 + kPatch <= lv.h);
   if (lane < kPatch) {
-    struct __attribute__((packed, aligned(4))) Row9 { uint32_t w[9]; };
-    const Row9 row = *reinterpret_cast<const Row9*>(img + (size_t)(py0 + lane) * lv.pitch + pa);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_patch[wv][lane * kPatchPitch]);
+    if (inside) {
+      struct __attribute__((packed, aligned(4))) RowN { uint32_t w[kRowDw]; };
+      const RowN row = *reinterpret_cast<const RowN*>(img + (size_t)(py0 + lane) * lv.pitch + pa);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) dst[c] = row.w[c];
+      for (int c = 0; c < kRowDw; ++c) dst[c] = row.w[c];
+    } else {
+      const uint8_t* rp = img + (size_t)orb_reflect101(py0 + lane, lv.h) * lv.pitch;
+      for (int c = 0; c < kRowDw; ++c) {
+        uint32_t w = 0;
+        for (int e = 0; e < 4; ++e) w |= (uint32_t)rp[orb_reflect101(pa + 4 * c + e, lv.w)] << (8 * e);
+        dst[c] = w;
+      }
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  // intensity centroid over the radius-15 disc (patch centre at [16][16]).  Lane = (disc row, half): 16 bytes of
+  // intensity centroid over the radius-15 disc (patch centre at [kC][kC]).  Lane = (disc row, half): 16 bytes of
   // the row as 4 dwords (unaligned start: 5 dword reads + v_alignbyte), bytes outside |u| <= u_max(|v|) masked off,
   // then two v_dot4_u32_u8 per dword: sum I and sum (u + 16) I  ->  m10 = sum (u + 16) I - 16 sum I, m01 = v sum I.
   int m10 = 0, m01 = 0;
@@ -1058,8 +1121,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     const int r = lane >> 1, h = lane & 1;
     const int v = r - 15, av = v < 0 ? -v : v;
     const int umax = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);  // GH_ORB_UMAX as nibbles
-    const uint32_t boff = (uint32_t)(px0 - pa) + 1u + 16u * (uint32_t)h;    // byte offset of u = -15 + 16 h in patch row r + 1
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (r + 1) * (kPatchPitch / 4) + (boff >> 2);
+    const uint32_t boff = (uint32_t)(px0 - pa) + (uint32_t)(kC - 15) + 16u * (uint32_t)h;  // byte offset of u = -15 + 16 h in patch row r + kC - 15
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (r + kC - 15) * kRowDw + (boff >> 2);
     const uint32_t sh = boff & 3u;
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
     const uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
@@ -1082,7 +1145,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   m10 = wave_sum_i32(m10);
   m01 = wave_sum_i32(m01);
   int bin = 0;
-  {
+  float angle = 0.0f;
+  if constexpr (STEER) {
+    angle = orb_fast_atan2_deg((float)m01, (float)m10);  // |m| < 2^24: the conversions are exact
+  } else {
     long long c = 0;
     if (lane < GH_ORB_NBINS) c = (long long)tb.dir[2 * lane] * m01 - (long long)tb.dir[2 * lane + 1] * m10;
     const int c_neg = c < 0 ? 1 : 0;
@@ -1090,19 +1156,20 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     const int prev_neg = __shfl(c_neg, prev_lane);
     const uint64_t hit = __ballot(lane < GH_ORB_NBINS && !prev_neg && c_neg);
     if ((m10 != 0 || m01 != 0) && hit != 0ull) bin = __ffsll((unsigned long long)hit) - 1;
+    angle = 12.0f * (float)bin;
   }
-  // separable 7x7 integer Gaussian: patch rows 0..32 x blur cols 0..26 -> s_h, then blur rows 0..26 -> s_blur (27x27)
+  // separable 7x7 integer Gaussian: patch rows 0..kPatch-1 x blur cols -> s_h, then blur rows -> the blurred patch
   uint32_t* hb = s_h[wv];
   constexpr uint32_t g[7] = {144, 268, 391, 442, 391, 268, 144};
   // Wide LDS accesses (the kernel is LDS-issue bound with byte reads): one work item = 4 adjacent outputs.
   // h-pass: 4 dwords of the patch row -> 10 source bytes (v_alignbyte with the wave-uniform row offset)
-  //         -> 4 outputs stored as one 16-byte write;  v-pass: 10 dword reads down a column -> 4 outputs.
+  //         -> 4 outputs stored as one 16-byte write;  v-pass: 7 x 16-byte reads down the 4 columns -> 4 outputs.
   {
     const uint32_t off = (uint32_t)(px0 - pa);  // 0..3, wave-uniform
     const uint32_t* p32 = reinterpret_cast<const uint32_t*>(s_patch[wv]);
-    for (int idx = lane; idx < kPatch * 7; idx += 64) {
-      const int r = idx / 7, gq = idx - r * 7;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
-      const uint32_t* q = p32 + r * (kPatchPitch / 4) + gq;
+    for (int idx = lane; idx < kPatch * kGroups; idx += 64) {
+      const int r = idx / kGroups, gq = idx - r * kGroups;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
+      const uint32_t* q = p32 + r * kRowDw + gq;
       const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
       const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off);  // source bytes 0..3 (patch col 4 gq + k)
       const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, off);  // 4..7
@@ -1137,8 +1204,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   // v-pass: one work item = 4 adjacent outputs of one blur row: 7 x 16-byte reads down the 4 columns, 28
   // v_mad_u32_u24 (h sums < 2^20), weights x4 so that the rounded result is the top byte of the sum
   // ((4 s + 2^23) >> 24 == (s + 2^21) >> 22; 4 * 2048 * 522240 + 2^23 < 2^32), one dword store.
-  for (int idx = lane; idx < kBlur * 7; idx += 64) {
-    const int rb = idx / 7, cg = idx - rb * 7;
+  for (int idx = lane; idx < kBlur * kGroups; idx += 64) {
+    const int rb = idx / kGroups, cg = idx - rb * kGroups;
     uint32_t acc[4] = {1u << 23, 1u << 23, 1u << 23, 1u << 23};
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
@@ -1153,12 +1220,27 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   }
   __builtin_amdgcn_wave_barrier();
   // 256 binary tests, 64 per ballot
-  const uint32_t* pat = reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
   uint8_t* drow = desc + ((size_t)b * K + pos) * 32;
+  float cs = 1.0f, sn = 0.0f;
+  if constexpr (STEER) orb_sincos_deg(angle, &cs, &sn);
+  const uint32_t* pat = STEER ? reinterpret_cast<const uint32_t*>(tb.base_pattern)
+                              : reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
-    const uint32_t pw = pat[gq * 64 + lane];  // byte offsets of the two sample points in the blurred patch
-    const int va = bl[pw & 0xFFFFu], vb = bl[pw >> 16];
+    const uint32_t pw = pat[gq * 64 + lane];
+    int va, vb;
+    if constexpr (STEER) {
+      // pw = the unrotated test (ax, ay, bx, by) as four int8; (x', y') = (rint(x cos - y sin), rint(x sin + y cos)), ties to even
+      const float ax = (float)(int)(int8_t)(pw & 0xFFu), ay = (float)(int)(int8_t)((pw >> 8) & 0xFFu);
+      const float bx = (float)(int)(int8_t)((pw >> 16) & 0xFFu), by = (float)(int)(int8_t)(pw >> 24);
+      const int rax = (int)rintf(ax * cs - ay * sn), ray = (int)rintf(ax * sn + ay * cs);
+      const int rbx = (int)rintf(bx * cs - by * sn), rby = (int)rintf(bx * sn + by * cs);
+      va = bl[(BR + ray) * kBlurPitch + BR + rax];
+      vb = bl[(BR + rby) * kBlurPitch + BR + rbx];
+    } else {
+      va = bl[pw & 0xFFFFu];  // byte offsets of the two sample points in the blurred patch
+      vb = bl[pw >> 16];
+    }
     const uint64_t bits = __ballot(va < vb);
     if (lane == 0) *reinterpret_cast<uint64_t*>(drow + 8 * gq) = bits;
   }
@@ -1168,7 +1250,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     o.x = __fmul_rn((float)kp.x, sc);
     o.y = __fmul_rn((float)kp.y, sc);
     o.size = __fmul_rn(31.0f, sc);
-    o.angle = 12.0f * (float)bin;
+    o.angle = angle;
     o.response = (float)kp.score;
     o.octave = l;
     o.class_id = -1;
@@ -1224,6 +1306,10 @@ struct gh_orb_plan {
   int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test (rounds 2-3), 1 = SWAR on 16-bit fields
   bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
   int8_t* d_pattern = nullptr;
+  int8_t* d_base_pattern = nullptr;  // the unrotated tests, 256 x 4 int8 (continuous steering)
+  int8_t base_pattern[256 * 4] = {};
+  bool base_pattern_fits_table = true;  // every 12-degree rotation stays within +-13 (the 30-bin table exists)
+  int steer = 0;                     // gh_orb_plan_set_steering: 0 = 30 orientation bins, 1 = continuous (fastAtan2 + per-keypoint rotation)
   int32_t* d_dir = nullptr;
   uint32_t* tabs = nullptr;
   uint32_t* dbg = nullptr;  // kDbgCount counters, allocated by gh_orb_plan_debug_counters(enable)
@@ -1278,7 +1364,7 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   gh_ctx* c = p->ctx;
   GH_ENTER(c);
   hipStreamSynchronize(c->stream);
-  void* ptrs[] = {p->pyr, p->cell_cnt, p->cell_ent, p->sel, p->level_cnt, p->d_pattern, p->d_dir, p->tabs,
+  void* ptrs[] = {p->pyr, p->cell_cnt, p->cell_ent, p->sel, p->level_cnt, p->d_pattern, p->d_base_pattern, p->d_dir, p->tabs,
                   p->stage_img, p->stage_out, p->dbg};
   for (void* q : ptrs)
     if (q) hipFree(q);
@@ -1332,24 +1418,73 @@ extern "C" gh_status gh_orb_plan_set_pattern(gh_orb_plan* p, const int8_t* patte
   GH_CHECK_ARG(ctx, pattern != nullptr);
   std::vector<int8_t> rot((size_t)30 * 256 * 4);
   auto rnd = [](double v) { return (int)floor(fabs(v) + 0.5) * (v >= 0 ? 1 : -1); };
+  bool fits_table = true;
+  int bad_t = -1, bad_k = 0;
+  for (int t = 0; t < 256; ++t) {
+    const int8_t* q = pattern + 4 * t;
+    if (q[0] == q[2] && q[1] == q[3]) return gh_set_error(ctx, GH_ERR_ARG, "test %d of the pattern compares a point with itself", t);
+    // continuous steering rotates by any angle: a point of radius r reaches rint(r) on an axis -- the blurred patch of that mode is +-19 px
+    for (int e = 0; e < 4; e += 2)
+      if ((int)q[e] * q[e] + (int)q[e + 1] * q[e + 1] > 379)  // 19.49^2 = 379.9
+        return gh_set_error(ctx, GH_ERR_ARG, "test %d of the pattern has a point beyond radius 19.49 of the keypoint", t);
+  }
   for (int k = 0; k < 30; ++k) {
     const double th = (12.0 * k) * (3.14159265358979323846 / 180.0), c = cos(th), s = sin(th);
     for (int t = 0; t < 256; ++t) {
       const int8_t* q = pattern + 4 * t;
       const int v[4] = {rnd(q[0] * c - q[1] * s), rnd(q[0] * s + q[1] * c), rnd(q[2] * c - q[3] * s), rnd(q[2] * s + q[3] * c)};
       for (int e = 0; e < 4; ++e) {
-        if (v[e] < -13 || v[e] > 13)
-          return gh_set_error(ctx, GH_ERR_ARG,
-                              "test %d of the pattern leaves the +-13 px blurred patch when rotated by %d degrees "
-                              "(points must lie within radius 13.49 of the keypoint)", t, 12 * k);
-        rot[((size_t)k * 256 + t) * 4 + e] = (int8_t)v[e];
+        if (v[e] < -13 || v[e] > 13) {
+          if (fits_table) {
+            bad_t = t;
+            bad_k = k;
+          }
+          fits_table = false;
+        }
+        rot[((size_t)k * 256 + t) * 4 + e] = (int8_t)(v[e] < -13 ? -13 : (v[e] > 13 ? 13 : v[e]));
       }
-      if (k == 0 && v[0] == v[2] && v[1] == v[3])
-        return gh_set_error(ctx, GH_ERR_ARG, "test %d of the pattern compares a point with itself", t);
     }
   }
+  // The 30-bin table mode blurs +-13 px only: a pattern with points beyond radius 13.49 (the canonical ORB bit_pattern_31_
+  // has (-13, -13)) is accepted for continuous steering alone.
+  if (!fits_table && p->steer == 0)
+    return gh_set_error(ctx, GH_ERR_ARG,
+                        "test %d of the pattern leaves the +-13 px blurred patch when rotated by %d degrees (points must lie within "
+                        "radius 13.49 of the keypoint for the 30-bin table; gh_orb_plan_set_steering(plan, 1) first takes radius 19.49)",
+                        bad_t, 12 * bad_k);
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // extractions in flight still read the old table
+  memcpy(p->base_pattern, pattern, sizeof(p->base_pattern));
+  p->base_pattern_fits_table = fits_table;
+  GH_TRY(gh_dev_upload(ctx, p->d_base_pattern, p->base_pattern, sizeof(p->base_pattern)));
   return upload_pattern(p, rot.data());
+}
+
+// Orientation / steering mode of the plan (oracle/orb_oracle.c steps 6 and 8 vs 6' and 8').
+//   0  30 orientation bins of 12 degrees, precomputed rotated pattern per bin (the default; integer end to end)
+//   1  continuous: angle = the fp32 polynomial arctangent of OpenCV's fastAtan2 (what ORB-SLAM's IC_Angle calls) on the same
+//      integer moments, every test point rotated by it and rounded to the nearest pixel (ties to even, cvRound) -- the
+//      steering of OpenCV / ORB-SLAM's computeOrbDescriptor, so that with the canonical test pattern installed
+//      (gh_orb_plan_set_pattern) the descriptors are those an ORB vocabulary was trained on, up to the image arithmetic
+//      (integer pyramid and blur here, float there).  KeyPoint.angle is the continuous angle.
+extern "C" gh_status gh_orb_plan_set_steering(gh_orb_plan* p, int mode) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, mode == 0 || mode == 1);
+  if (mode == 0 && !p->base_pattern_fits_table)
+    return gh_set_error(ctx, GH_ERR_ARG, "the installed test pattern has points beyond radius 13.49: it only works with continuous steering");
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  p->steer = mode;
+  // (graphs captured for the other mode hold the other kernel)
+  for (auto* v : {&p->graphs, &p->retired})
+    for (auto& g : *v) {
+      hipEventSynchronize(g.done);
+      hipGraphExecDestroy(g.exec);
+      hipEventDestroy(g.done);
+    }
+  p->graphs.clear();
+  p->retired.clear();
+  return GH_OK;
 }
 
 extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
@@ -1437,6 +1572,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
     if ((st = plan_alloc(p, B * K * sizeof(SelKp), (void**)&p->sel)) != GH_OK) break;
     if ((st = plan_alloc(p, B * kMaxL * sizeof(int32_t), (void**)&p->level_cnt)) != GH_OK) break;
     if ((st = plan_alloc(p, sizeof(GH_ORB_PATTERN), (void**)&p->d_pattern)) != GH_OK) break;
+    if ((st = plan_alloc(p, 256 * 4, (void**)&p->d_base_pattern)) != GH_OK) break;
     if ((st = plan_alloc(p, sizeof(GH_ORB_DIR), (void**)&p->d_dir)) != GH_OK) break;
     if ((st = plan_alloc(p, htab.size() * sizeof(uint32_t), (void**)&p->tabs)) != GH_OK) break;
     size_t tw = 0;
@@ -1521,6 +1657,8 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
     }
     if ((st = gh_dev_upload(ctx, p->tabs, htab.data(), htab.size() * sizeof(uint32_t))) != GH_OK) break;
     if ((st = upload_pattern(p, &GH_ORB_PATTERN[0][0][0])) != GH_OK) break;
+    memcpy(p->base_pattern, &GH_ORB_PATTERN[0][0][0], sizeof(p->base_pattern));  // bin 0 = the unrotated tests
+    if ((st = gh_dev_upload(ctx, p->d_base_pattern, p->base_pattern, sizeof(p->base_pattern))) != GH_OK) break;
     if ((st = gh_dev_upload(ctx, p->d_dir, GH_ORB_DIR, sizeof(GH_ORB_DIR))) != GH_OK) break;
   } while (0);
   if (st != GH_OK) {
@@ -1826,11 +1964,15 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       a.scale[l] = l < L ? p->scale[l] : 1.0f;
     }
     a.nlevels = L;
-    DevTables tb{p->d_pattern, p->d_dir};
+    DevTables tb{p->d_pattern, p->d_dir, p->d_base_pattern};
     const long long blocks = (long long)gh_div_up(K, 4) * batch;
     GH_CHECK_ARG(ctx, blocks < (1LL << 30));
-    GH_LAUNCH(ctx, "orb_describe", describe_kernel, dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K, p->sel,
-              p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
+    if (p->steer == 0)
+      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<13, false>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
+                p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
+    else
+      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<19, true>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
+                p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
   }
   return GH_OK;
 }

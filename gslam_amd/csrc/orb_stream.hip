@@ -272,3 +272,7 @@ extern "C" gh_status gh_orb_stream_collect(gh_orb_stream* s, int64_t ticket, gh_
   out->gpu_ms = ms;
   return GH_OK;
 }
+
+// The extraction plan behind the stream, for the per-plan settings (gh_orb_plan_set_pattern / gh_orb_plan_set_steering): call
+// them while no ticket is outstanding.  The stream owns the plan.
+extern "C" gh_orb_plan* gh_orb_stream_plan(gh_orb_stream* stream) { return stream ? stream->plan : nullptr; }

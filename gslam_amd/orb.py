@@ -57,6 +57,11 @@ class OrbExtractor:
         pat = np.ascontiguousarray(pattern, dtype=np.int8).reshape(256, 4)
         self.ctx.check(hip.lib.gh_orb_plan_set_pattern(self.plan, pat.ctypes.data_as(C.c_void_p)))
 
+    def set_steering(self, mode):
+        """0: 30 orientation bins (default); 1: continuous (fastAtan2 angle, per-keypoint pattern rotation).  See
+        gh_orb_plan_set_steering."""
+        self.ctx.check(hip.lib.gh_orb_plan_set_steering(self.plan, int(mode)))
+
     def level(self, l):
         w, h, q = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(hip.lib.gh_orb_plan_level(self.plan, l, C.byref(w), C.byref(h), C.byref(q)))

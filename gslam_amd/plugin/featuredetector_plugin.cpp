@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <fstream>
 #include <mutex>
 #include <vector>
 
@@ -43,6 +44,7 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       p.ini_th_fast = _config.iniThFAST;
       p.min_th_fast = _config.minThFAST;
       if (gh_orb_plan_create(ctx_, w, h, 1, &p, &plan_) != GH_OK) return fail("gh_orb_plan_create");
+      if (!configure(plan_)) return false;
       pw_ = w; ph_ = h; pk_ = _config.nFeatures; pl_ = _config.nLevels;
       pi_ = _config.iniThFAST; pm_ = _config.minThFAST;
     }
@@ -217,8 +219,34 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       ss.s = nullptr;
       return fail("gh_orb_stream_create");
     }
+    if (!configure(gh_orb_stream_plan(ss.s))) return false;
     ss.w = w; ss.h = h; ss.ch = ch; ss.chunk = chunk; ss.k = p.n_features; ss.l = p.n_levels; ss.ini = p.ini_th_fast; ss.mn = p.min_th_fast;
     ss.frame_bytes = fbytes;
+    return true;
+  }
+  // svar FeatureDetectorHIP.Steering = 1: continuous orientation + per-keypoint pattern rotation (OpenCV / ORB-SLAM steering,
+  // gh_orb_plan_set_steering); svar FeatureDetectorHIP.Pattern = <text file of 1024 integers>: the 256 x 4 test pattern
+  // (e.g. the canonical bit_pattern_31_ copied from OpenCV's orb.cpp, which needs Steering = 1: it reaches radius 18.4)
+  bool configure(gh_orb_plan* plan) {
+    if (!plan) return false;
+    const int steer = svar.GetInt("FeatureDetectorHIP.Steering", 0);
+    if (steer != 0 && gh_orb_plan_set_steering(plan, 1) != GH_OK) return fail("gh_orb_plan_set_steering");
+    const std::string pf = svar.GetString("FeatureDetectorHIP.Pattern", "");
+    if (!pf.empty()) {
+      std::ifstream in(pf.c_str());
+      std::vector<int8_t> pat;
+      int v;
+      char c;
+      while (in) {
+        if (in >> v) pat.push_back((int8_t)v);
+        else if (!in.eof()) { in.clear(); in >> c; }  // separators: commas, braces, comments' punctuation
+      }
+      if (pat.size() != 1024) {
+        LOG(ERROR) << "FeatureDetectorHIP: " << pf << " holds " << pat.size() << " integers, a test pattern has 1024";
+        return false;
+      }
+      if (gh_orb_plan_set_pattern(plan, pat.data()) != GH_OK) return fail("gh_orb_plan_set_pattern");
+    }
     return true;
   }
   static void unpack(const gh_orb_stream_result& r, int f, std::vector<GSLAM::KeyPoint>& kps, GSLAM::GImage& desc) {

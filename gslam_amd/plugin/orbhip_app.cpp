@@ -13,7 +13,17 @@
 //     -> new keypoints get map points by intersecting their rays with the ground plane z = 0 (the `synthplane` dataset's
 //        scene; a monocular front end needs SOME initialisation and this one is exact for that scene)
 //     every `orbhip.ba_every` frames: Optimizer::optimize on the last `orbhip.ba_window` frames (Optimizer.h:229).
-// It is a minimal tracking front end, not a SLAM system: no relocalisation, no loop closing, no map management.
+// With `orbhip.vocabulary <file.gbow>` (GSLAM's own vocabulary format, core/Vocabulary.h:1843-1932) the application also
+// does the place-recognition half of the ORBSLAM plugin's front end on the GPU:
+//     descriptors -> Vocabulary::transform (libgslam_vocabulary: gh_bow_transform_host) -> BowVector + FeatureVector, kept in
+//        an OrbhipFrame (MapFrame::getBoWVector / getFeatureVector, Map.h:322-325) that is what gets published and mapped,
+//     OrbhipLoopDetector (LoopDetector, Map.h:382-395): every frame is inserted, candidates = the frames at least
+//        `orbhip.loop_gap` frames old, scored in ONE batched call (scoreVocabularyBatch -> gh_bow_score_host), best first,
+//     a candidate above `orbhip.loop_score` is brute-force matched; matches whose two features lie in the same vocabulary
+//        node (the FeatureVector test of ORB-SLAM's SearchByBoW) are kept, and with at least `orbhip.loop_matches` of them
+//        a FrameConnection (Map.h:246-262) is added to both frames and {id, candidate, score, matches} goes out on "orbhip/loop".
+//     Consecutive tracked frames are linked by FrameConnections too (matches + child-to-parent SE3).
+// It is a minimal tracking front end, not a SLAM system: no relocalisation, no loop CORRECTION, no map management.
 //     gslam play -dataset seq.synthplane -autostart 1 orbhip metric_time -slam orbhip
 // `orbhip.log <file>` records every input and output of the three plugin calls so that tests can replay them through
 // the CPU checker.
@@ -26,11 +36,140 @@
 #include <map>
 #include <thread>
 
+#include <GSLAM/core/Vocabulary.h>
+
 #include "FeatureDetector.h"
 
 using namespace GSLAM;
 
 namespace {
+
+// FrameConnection (Map.h:246-262) with storage: the matches of a frame pair and, when known, the child-to-parent motion.
+class OrbhipConnection : public FrameConnection {
+ public:
+  std::string type() const override { return "OrbhipConnection"; }
+  int matchesNum() override { return (int)matches_.size(); }
+  bool getMatches(std::vector<std::pair<int, int> >& m) override { m = matches_; return true; }
+  bool getChild2Parent(SE3& T) override { if (has_pose_) T = c2p_; return has_pose_; }
+  bool getChild2Parent(SIM3& S) override { if (has_pose_) S = SIM3(c2p_, 1.0); return has_pose_; }
+  bool setMatches(std::vector<std::pair<int, int> >& m) override { matches_ = m; return true; }
+  bool setChild2Parent(SE3& T) override { c2p_ = T; has_pose_ = true; return true; }
+  bool setChild2Parent(SIM3& S) override { c2p_ = S.get_se3(); has_pose_ = true; return true; }
+
+ private:
+  std::vector<std::pair<int, int> > matches_;
+  SE3 c2p_;
+  bool has_pose_ = false;
+};
+
+// The frame the application publishes and maps when a vocabulary is configured: the dataset's frame (image, camera) plus
+// what the front end computed -- keypoints, descriptors, BoW / feature vectors, connections.
+class OrbhipFrame : public MapFrame {
+ public:
+  explicit OrbhipFrame(const FramePtr& src) : MapFrame(src->id(), src->timestamp()), src_(src) { setPose(src->getPoseScale()); }
+  std::string type() const override { return "OrbhipFrame"; }
+  int cameraNum() const override { return src_->cameraNum(); }
+  SE3 getCameraPose(int idx = 0) const override { return src_->getCameraPose(idx); }
+  int imageChannels(int idx = 0) const override { return src_->imageChannels(idx); }
+  Camera getCamera(int idx = 0) override { return src_->getCamera(idx); }
+  GImage getImage(int idx = 0, int mask = IMAGE_UNDEFINED) override { return src_->getImage(idx, mask); }
+  int keyPointNum() const override { ReadMutex l(mu_); return (int)kps_.size(); }
+  bool setKeyPoints(const std::vector<KeyPoint>& k, const GImage& d) override {
+    WriteMutex l(mu_);
+    kps_ = k;
+    desc_ = d.clone();
+    return true;
+  }
+  bool getKeyPoints(std::vector<KeyPoint>& k) const override { ReadMutex l(mu_); k = kps_; return true; }
+  bool getKeyPoint(int idx, KeyPoint& pt) const override {
+    ReadMutex l(mu_);
+    if (idx < 0 || idx >= (int)kps_.size()) return false;
+    pt = kps_[idx];
+    return true;
+  }
+  bool getKeyPoint(int idx, Point2f& pt) const override {
+    ReadMutex l(mu_);
+    if (idx < 0 || idx >= (int)kps_.size()) return false;
+    pt = kps_[idx].pt;
+    return true;
+  }
+  GImage getDescriptor(int idx = -1) const override {
+    ReadMutex l(mu_);
+    if (idx < 0) return desc_;
+    return idx < desc_.rows ? desc_.row(idx) : GImage();
+  }
+  bool getBoWVector(BowVector& v) const override { ReadMutex l(mu_); v = bow_; return !bow_.empty(); }
+  bool getFeatureVector(FeatureVector& v) const override { ReadMutex l(mu_); v = feat_; return !feat_.empty(); }
+  void setBoW(const BowVector& b, const FeatureVector& f) { WriteMutex l(mu_); bow_ = b; feat_ = f; }
+  FrameConnectionPtr getParent(FrameID id) const override { ReadMutex l(mu_); auto it = parents_.find(id); return it == parents_.end() ? FrameConnectionPtr() : it->second; }
+  FrameConnectionPtr getChild(FrameID id) const override { ReadMutex l(mu_); auto it = children_.find(id); return it == children_.end() ? FrameConnectionPtr() : it->second; }
+  bool getParents(FrameConnectionMap& p) const override { ReadMutex l(mu_); p = parents_; return true; }
+  bool getChildren(FrameConnectionMap& c) const override { ReadMutex l(mu_); c = children_; return true; }
+  bool addParent(FrameID id, const FrameConnectionPtr& c) override { WriteMutex l(mu_); parents_[id] = c; return true; }
+  bool addChildren(FrameID id, const FrameConnectionPtr& c) override { WriteMutex l(mu_); children_[id] = c; return true; }
+  bool eraseParent(FrameID id) override { WriteMutex l(mu_); return parents_.erase(id) > 0; }
+  bool eraseChild(FrameID id) override { WriteMutex l(mu_); return children_.erase(id) > 0; }
+  bool clearParents() override { WriteMutex l(mu_); parents_.clear(); return true; }
+  bool clearChildren() override { WriteMutex l(mu_); children_.clear(); return true; }
+
+ private:
+  FramePtr src_;
+  mutable MutexRW mu_;
+  std::vector<KeyPoint> kps_;
+  GImage desc_;
+  BowVector bow_;
+  FeatureVector feat_;
+  FrameConnectionMap parents_, children_;
+};
+
+// LoopDetector (Map.h:382-395) on BoW vectors: all candidates older than `gap` frames are scored in one batched GPU call.
+class OrbhipLoopDetector : public LoopDetector {
+ public:
+  typedef bool (*score_fn)(const Vocabulary*, const BowVector*, const BowVector* const*, int, double*);
+  OrbhipLoopDetector(const std::shared_ptr<Vocabulary>& voc, score_fn score, int gap, double min_score)
+      : voc_(voc), score_(score), gap_(gap), min_score_(min_score) {}
+  std::string type() const override { return "OrbhipLoopDetector"; }
+  bool insertMapFrame(const FramePtr& f) override {
+    BowVector v;
+    if (!f || !f->getBoWVector(v)) return false;
+    entries_.push_back(std::make_pair(f->id(), v));
+    return true;
+  }
+  bool eraseMapFrame(const FrameID& id) override {
+    for (size_t i = 0; i < entries_.size(); ++i)
+      if (entries_[i].first == id) {
+        entries_.erase(entries_.begin() + (long)i);
+        return true;
+      }
+    return false;
+  }
+  bool obtainCandidates(const FramePtr& f, LoopCandidates& out) override {
+    out.clear();
+    BowVector q;
+    if (!f || !f->getBoWVector(q) || !score_) return false;
+    std::vector<const BowVector*> db;
+    std::vector<FrameID> ids;
+    for (auto& e : entries_)
+      if (e.first + (FrameID)gap_ <= f->id()) {  // old enough not to be a neighbour of the query
+        db.push_back(&e.second);
+        ids.push_back(e.first);
+      }
+    if (db.empty()) return true;
+    std::vector<double> sc(db.size(), 0.0);
+    if (!score_(voc_.get(), &q, db.data(), (int)db.size(), sc.data())) return false;
+    for (size_t i = 0; i < db.size(); ++i)
+      if (sc[i] >= min_score_) out.push_back(LoopCandidate(ids[i], sc[i]));
+    std::stable_sort(out.begin(), out.end(), [](const LoopCandidate& a, const LoopCandidate& b) { return a.score > b.score; });
+    return true;
+  }
+
+ private:
+  std::shared_ptr<Vocabulary> voc_;
+  score_fn score_;
+  int gap_;
+  double min_score_;
+  std::vector<std::pair<FrameID, BowVector> > entries_;
+};
 
 class OrbhipPoint : public MapPoint {
  public:
@@ -203,6 +342,11 @@ int run_orbhip(Svar config) {
                                               "publish qviz/start (what the GUI's play button does) until the first frame "
                                               "arrives, so that no frame is lost while the plugins load");
   const std::string log_path = config.arg<std::string>("orbhip.log", "", "binary record of every plugin call (tests)");
+  const std::string voc_path = config.arg<std::string>("orbhip.vocabulary", "", ".gbow vocabulary: BoW vectors per frame, loop candidates");
+  const int loop_gap = config.arg<int>("orbhip.loop_gap", 20, "frames between a query and its oldest-allowed loop candidate");
+  const double loop_score = config.arg<double>("orbhip.loop_score", 0.05, "minimum BoW score of a loop candidate");
+  const int loop_matches = config.arg<int>("orbhip.loop_matches", 40, "node-consistent matches that make a loop connection");
+  const int levels_up = config.arg<int>("orbhip.levels_up", 4, "FeatureVector level (levels up from the leaves)");
   if (config.get("help", false)) return config.help();
 
   FeatureDetectorPtr det = FeatureDetector::create();
@@ -224,6 +368,23 @@ int run_orbhip(Svar config) {
   const std::string save_map = config.arg<std::string>("orbhip.save_map", "", "write the map as a .gmap file after every BA");
   if (opt) opt->_config.maxIterations = config.arg<int>("orbhip.max_iterations", 30, "LM iterations per call");
 
+  // vocabulary plugin (libgslam_vocabulary.so: the subclass of GSLAM::Vocabulary whose transforms and batched scoring run on the GPU)
+  std::shared_ptr<Vocabulary> voc;
+  std::shared_ptr<OrbhipLoopDetector> loops;
+  if (!voc_path.empty()) {
+    typedef std::shared_ptr<Vocabulary> (*factory_t)(const char*);
+    SharedLibraryPtr lib = Registry::get(svar.GetString("VocabularyPlugin", "libgslam_vocabulary"));
+    factory_t f = lib ? (factory_t)lib->getSymbol("createVocabularyInstance") : NULL;
+    OrbhipLoopDetector::score_fn sf = lib ? (OrbhipLoopDetector::score_fn)lib->getSymbol("scoreVocabularyBatch") : NULL;
+    if (f) voc = f(voc_path.c_str());
+    if (!voc || !sf) {
+      LOG(ERROR) << "orbhip: cannot load vocabulary " << voc_path << " through the Vocabulary plugin (svar VocabularyPlugin)";
+      return -1;
+    }
+    loops.reset(new OrbhipLoopDetector(voc, sf, loop_gap, loop_score));
+  }
+  std::map<FrameID, std::shared_ptr<OrbhipFrame> > bow_frames;  // frames by id (loop candidates are looked up here)
+  Publisher pub_loop = messenger.advertise<Svar>("orbhip/loop", 0);
   Publisher pub_frame = messenger.advertise<MapFrame>("orbhip/curframe", 0);
   Publisher pub_map = messenger.advertise<Map>("orbhip/map", 0);
   Publisher pub_match = messenger.advertise<Svar>("orbhip/matches", 0);
@@ -248,6 +409,11 @@ int run_orbhip(Svar config) {
 
   Subscriber sub = messenger.subscribe("dataset/frame", queue, [&](FramePtr fr) {
     if (!fr || !fr->cameraNum()) return;
+    std::shared_ptr<OrbhipFrame> of;
+    if (voc) {  // the frame that is published and mapped carries the BoW data: the dataset's frame classes cannot
+      of.reset(new OrbhipFrame(fr));
+      fr = of;
+    }
     GImage img = fr->getImage(0, IMAGE_GRAY);
     if (img.empty()) img = fr->getImage(0);
     TrackedFrame cur;
@@ -260,6 +426,66 @@ int run_orbhip(Svar config) {
     fr->setKeyPoints(cur.kps, desc);
     std::vector<std::pair<int, int> > matches;
     if (!last_desc.empty() && desc.rows > 0) det->match(desc, last_desc, matches);
+    if (of && desc.rows > 0) {
+      BowVector bow;
+      FeatureVector feat;
+      voc->transform(desc, bow, feat, levels_up);
+      of->setBoW(bow, feat);
+      if (log.is_open()) {
+        put(log, (int32_t)4);  // record type 4: BoW vector + feature vector of the frame
+        put(log, (int32_t)fr->id());
+        put(log, (int32_t)bow.size());
+        for (auto& kv : bow) { put(log, (uint32_t)kv.first); put(log, (float)kv.second); }
+        put(log, (int32_t)feat.size());
+        for (auto& kv : feat) {
+          put(log, (uint32_t)kv.first);
+          put(log, (int32_t)kv.second.size());
+          for (unsigned int i : kv.second) put(log, (uint32_t)i);
+        }
+      }
+      // loop candidates: one batched scoring call over every frame that is old enough, then the best one is verified
+      LoopCandidates cands;
+      loops->obtainCandidates(fr, cands);
+      if (log.is_open()) {
+        put(log, (int32_t)5);  // record type 5: loop candidates (best first) and the verified connection, if any
+        put(log, (int32_t)fr->id());
+        put(log, (int32_t)cands.size());
+        for (auto& c : cands) { put(log, (int32_t)c.frameId); put(log, (double)c.score); }
+      }
+      int32_t loop_to = -1;
+      std::vector<std::pair<int, int> > lm;
+      if (!cands.empty()) {
+        std::shared_ptr<OrbhipFrame> old = bow_frames[cands[0].frameId];
+        std::vector<std::pair<int, int> > raw;
+        if (old && det->match(desc, old->getDescriptor(), raw)) {
+          // the FeatureVector test of ORB-SLAM's SearchByBoW: both features descend to the same node `levels_up` above the leaves
+          FeatureVector fo;
+          old->getFeatureVector(fo);
+          std::vector<uint32_t> node_q((size_t)desc.rows, 0u), node_t((size_t)old->keyPointNum(), 0u);
+          for (auto& kv : feat)
+            for (unsigned int i : kv.second) node_q[i] = (uint32_t)kv.first + 1u;
+          for (auto& kv : fo)
+            for (unsigned int i : kv.second) node_t[i] = (uint32_t)kv.first + 1u;
+          for (auto& m : raw)
+            if (node_q[m.first] != 0u && node_q[m.first] == node_t[m.second]) lm.push_back(m);
+          if ((int)lm.size() >= loop_matches) {
+            loop_to = (int32_t)old->id();
+            FrameConnectionPtr c(new OrbhipConnection());
+            c->setMatches(lm);
+            of->addParent(old->id(), c);
+            old->addChildren(of->id(), c);
+            pub_loop.publish(Svar({{"id", (int)fr->id()}, {"candidate", (int)old->id()}, {"score", cands[0].score}, {"matches", (int)lm.size()}}));
+          }
+        }
+      }
+      if (log.is_open()) {
+        put(log, loop_to);
+        put(log, (int32_t)lm.size());
+        for (auto& m : lm) { put(log, (int32_t)m.first); put(log, (int32_t)m.second); }
+      }
+      loops->insertMapFrame(fr);
+      bow_frames[fr->id()] = of;
+    }
     const Camera cam = fr->getCamera(0);
     const int n = (int)cur.kps.size();
     cur.anchors.resize(n);
@@ -349,6 +575,17 @@ int run_orbhip(Svar config) {
           if (!on_plane(cur.pose, cur.anchors[i], X)) continue;
           cur.pid[i] = next_pid;
           points[next_pid++] = X;
+        }
+        if (of && !window.empty()) {  // FrameConnection child (this frame) -> parent (the previous tracked frame)
+          std::shared_ptr<OrbhipFrame> pf = std::dynamic_pointer_cast<OrbhipFrame>(window.back().frame);
+          if (pf) {
+            FrameConnectionPtr c(new OrbhipConnection());
+            c->setMatches(matches);
+            SE3 c2p = window.back().pose.inverse() * cur.pose;
+            c->setChild2Parent(c2p);
+            of->addParent(pf->id(), c);
+            pf->addChildren(of->id(), c);
+          }
         }
         window.push_back(cur);
         while ((int)window.size() > ba_window) window.pop_front();

@@ -82,7 +82,9 @@ gh_status gh_prof_collect(gh_ctx* ctx, gh_prof_entry* out, int cap, int* n);
 /* 256-bit descriptors, 32 bytes each, dense rows (GImage N x 32, 8UC1).
  * For query i:  idx1[i] = argmin_j hamming(q_i, t_j), first minimum (lowest j) on ties;
  *               d1[i]   = that distance; d2[i] = min over j != idx1[i] (65535 if nt < 2).
- * nt == 0  ->  idx1 = -1, d1 = d2 = 65535.   nt <= 65535. */
+ * nt == 0  ->  idx1 = -1, d1 = d2 = 65535.   Any nt: train sets beyond 65535 rows (a frame against a local map) are swept
+ * in chunks and folded with the same strict '<', so the result is the one of a single sweep.  (The batched pair entries
+ * below keep cap <= 65535: their rows are frames.) */
 gh_status gh_bf_match_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
                           int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
 gh_status gh_bf_match_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
@@ -133,7 +135,7 @@ gh_status gh_valu_issue_probe(gh_ctx* ctx, int op, double* wave_insts_per_s, cha
 typedef struct gh_keypoint {
   float x, y;     /* level-0 pixel coordinates */
   float size;     /* 31 * scale^octave */
-  float angle;    /* degrees, [0,360), multiple of 12 (30 orientation bins) */
+  float angle;    /* degrees, [0,360]: a multiple of 12 (30 orientation bins), or continuous (gh_orb_plan_set_steering) */
   float response; /* FAST corner score */
   int32_t octave;
   int32_t class_id; /* -1 */
@@ -161,10 +163,20 @@ gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int max_batch,
 void gh_orb_plan_destroy(gh_orb_plan* plan);
 /* Replace the plan's BRIEF test pattern: 256 tests x (ax, ay, bx, by) int8, relative to the keypoint, unrotated.  The
  * 30-bin steered look-up table is rebuilt from it (12-degree steps, round half away from zero).  Lets a deployer load
- * the canonical ORB / ORB-SLAM `bit_pattern_31_` so that descriptors are compatible with existing ORB vocabularies; the
- * built-in default is a seeded pattern of this repository (the canonical table is not available offline).  Every
- * rotated point must stay inside the +-13 px blurred patch (radius <= 13.49), otherwise GH_ERR_ARG. */
+ * the canonical ORB / ORB-SLAM `bit_pattern_31_` (after gh_orb_plan_set_steering(plan, 1): it has points of radius 18.4) so
+ * that descriptors are compatible with existing ORB vocabularies; the built-in default is a seeded pattern of this
+ * repository (the canonical table is not available offline).  In the 30-bin mode every rotated point must stay inside the
+ * +-13 px blurred patch (radius <= 13.49), in the continuous mode inside radius 19.49; otherwise GH_ERR_ARG. */
 gh_status gh_orb_plan_set_pattern(gh_orb_plan* plan, const int8_t* pattern_256x4);
+/* Orientation / steering mode.  0 (default): 30 orientation bins of 12 degrees with a precomputed rotated pattern per
+ * bin, KeyPoint.angle a multiple of 12.  1: continuous -- angle = the fp32 polynomial arctangent of OpenCV's fastAtan2
+ * (what ORB-SLAM's IC_Angle calls) on the same integer moments, every test point rotated by that angle and rounded to the
+ * nearest pixel (ties to even, as cvRound): the steering of OpenCV / ORB-SLAM's computeOrbDescriptor.  In this mode
+ * gh_orb_plan_set_pattern takes points up to radius 19.49 (the canonical ORB `bit_pattern_31_` reaches (-13, -13)), the
+ * 7x7 blur reads up to 22 px from the keypoint and pixels beyond the image border are mirrored (BORDER_REFLECT_101, what
+ * ORB-SLAM's padded pyramid holds there).  With the canonical pattern installed the descriptors are the ones ORB
+ * vocabularies were trained on up to the image arithmetic (integer pyramid / FAST score / blur here, float there). */
+gh_status gh_orb_plan_set_steering(gh_orb_plan* plan, int mode);
 /* Level geometry of the plan, for tests. */
 gh_status gh_orb_plan_level(const gh_orb_plan* plan, int level, int* w, int* h, int* quota);
 size_t gh_orb_plan_device_bytes(const gh_orb_plan* plan);
@@ -218,6 +230,9 @@ typedef struct gh_orb_stream_result {
 gh_status gh_orb_stream_create(gh_ctx* ctx, int width, int height, int channels, int row_stride, size_t frame_stride,
                                int chunk_frames, int depth, const gh_orb_params* params, gh_orb_stream** out);
 void gh_orb_stream_destroy(gh_orb_stream* stream);
+/* The extraction plan behind the stream (owned by it), for gh_orb_plan_set_pattern / gh_orb_plan_set_steering: call them
+ * while no ticket is outstanding. */
+gh_orb_plan* gh_orb_stream_plan(gh_orb_stream* stream);
 gh_status gh_orb_stream_staging(gh_orb_stream* stream, uint8_t** host_pinned);
 gh_status gh_orb_stream_submit(gh_orb_stream* stream, const uint8_t* frames_host, int n_frames, int64_t* ticket);
 gh_status gh_orb_stream_poll(gh_orb_stream* stream, int64_t ticket, int* ready);

@@ -38,6 +38,18 @@
  *             bit k%8 (LSB first).
  *  9 keypoint pt = (float)x_l * s_l, s_0 = 1, s_l = s_{l-1} * 1.2f (single fp32 roundings);
  *             size = 31 * s_l; response = S; octave = l; class_id = -1.
+ *
+ * Continuous steering (oracle_orb_set_steer(1) <-> gh_orb_plan_set_steering(plan, 1)) replaces steps 6 and 8 by what
+ * OpenCV / ORB-SLAM do there (ORBextractor.cc IC_Angle + computeOrbDescriptor; neither is in the reference tree, see above):
+ *  6' angle   a = fastAtan2((float)m01, (float)m10) in degrees -- OpenCV's fp32 polynomial: with ax = |x|, ay = |y|,
+ *             c = min / (max + (float)DBL_EPSILON), a = (((p7 c^2 + p5) c^2 + p3) c^2 + p1) c (or 90 - that when ay > ax),
+ *             a = 180 - a if x < 0, a = 360 - a if y < 0; p1, p3, p5, p7 = 57.283627f, -18.667446f, 8.9140005f, -2.5397246f.
+ *             Every operation a single fp32 rounding, no contraction.  KeyPoint.angle = a.
+ *  8' BRIEF   (cos, sin)(a): k = (int)(a / 90 + 0.5), r = (a - 90 k) * 0.017453292f, Taylor polynomials of degree 7 / 8 in r
+ *             (fp32, Horner, coefficients below), quadrant fixed up by k & 3.  Test point (x, y) of the UNROTATED pattern ->
+ *             (x', y') = (rintf(x cos - y sin), rintf(x sin + y cos)) (ties to even = cvRound);
+ *             bit k = B(p + a'_k) < B(p + b'_k).  B is the blur of step 7 over the level with BORDER_REFLECT_101
+ *             coordinates (index -i -> i, n - 1 + i -> n - 1 - i): points reach 19 px, the blur 22, the border is 19 away.
  */
 #include <math.h>
 #include <stdint.h>
@@ -279,17 +291,84 @@ static inline int blur_at(const uint8_t* img, int stride, int x, int y) {
   return (int)((acc + (1u << 21)) >> 22);
 }
 
+/* ---- continuous steering (steps 6' and 8') */
+static int g_steer = 0;
+void oracle_orb_set_steer(int mode) { g_steer = mode != 0; }
+
+float oracle_orb_fast_atan2_deg(float y, float x) {
+  const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
+  const float eps = 2.2204460492503131e-16f;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a;
+  if (ax >= ay) {
+    const float c = ay / (ax + eps), c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    const float c = ax / (ay + eps), c2 = c * c;
+    a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0.0f) a = 180.0f - a;
+  if (y < 0.0f) a = 360.0f - a;
+  return a;
+}
+
+void oracle_orb_sincos_deg(float a, float* cs, float* sn) {
+  const int k = (int)(a / 90.0f + 0.5f);
+  const float r = (a - 90.0f * (float)k) * 0.017453292f, r2 = r * r;
+  const float s = r * (1.0f + r2 * (-0.16666667f + r2 * (0.0083333338f + r2 * -0.00019841270f)));
+  const float c = 1.0f + r2 * (-0.5f + r2 * (0.041666668f + r2 * (-0.0013888889f + r2 * 0.000024801588f)));
+  switch (k & 3) {
+    case 0: *cs = c; *sn = s; break;
+    case 1: *cs = -s; *sn = c; break;
+    case 2: *cs = -c; *sn = -s; break;
+    default: *cs = s; *sn = -c; break;
+  }
+}
+
+static inline int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+static inline int blur_at_reflect(const uint8_t* img, int w, int h, int stride, int x, int y) {
+  uint32_t acc = 0;
+  for (int j = -3; j <= 3; ++j) {
+    const uint8_t* row = img + (size_t)reflect101(y + j, h) * stride;
+    uint32_t hs = 0;
+    for (int i = -3; i <= 3; ++i) hs += (uint32_t)GH_ORB_GAUSS[i + 3] * row[reflect101(x + i, w)];
+    acc += (uint32_t)GH_ORB_GAUSS[j + 3] * hs;
+  }
+  return (int)((acc + (1u << 21)) >> 22);
+}
+
+float oracle_orb_angle_deg(const uint8_t* img, int stride, int x, int y) {
+  int64_t m10 = 0, m01 = 0;
+  for (int v = -GH_ORB_HALF_PATCH; v <= GH_ORB_HALF_PATCH; ++v) {
+    int um = GH_ORB_UMAX[v < 0 ? -v : v];
+    const uint8_t* row = img + (size_t)(y + v) * stride + x;
+    for (int u = -um; u <= um; ++u) {
+      m10 += (int64_t)u * row[u];
+      m01 += (int64_t)v * row[u];
+    }
+  }
+  return oracle_orb_fast_atan2_deg((float)m01, (float)m10);
+}
+
 /* Test pattern in use: the built-in table, or one installed by oracle_orb_set_pattern (the checker's counterpart of
  * gh_orb_plan_set_pattern: same rotation rule as tools/gen_orb_tables.py -- round half away from zero).  Global state:
  * tests install / reset it around single-threaded runs. */
 static int8_t g_custom_pattern[GH_ORB_NBINS][256][4];
+static int8_t g_custom_base[256][4];
 static int g_use_custom_pattern = 0;
 
+/* Returns -1 when the pattern cannot be used in the current steering mode: a point beyond radius 19.49, or (30-bin mode)
+ * a rotated coordinate beyond +-13. */
 int oracle_orb_set_pattern(const int8_t* base /* 256 x 4, NULL = back to the built-in pattern */) {
   if (!base) {
     g_use_custom_pattern = 0;
     return 0;
   }
+  for (int t = 0; t < 256; ++t)
+    for (int e = 0; e < 4; e += 2)
+      if ((int)base[4 * t + e] * base[4 * t + e] + (int)base[4 * t + e + 1] * base[4 * t + e + 1] > 379) return -1;
+  int fits = 1;
   for (int k = 0; k < GH_ORB_NBINS; ++k) {
     const double th = (12.0 * k) * (3.14159265358979323846 / 180.0), c = cos(th), s = sin(th);
     for (int t = 0; t < 256; ++t) {
@@ -297,13 +376,31 @@ int oracle_orb_set_pattern(const int8_t* base /* 256 x 4, NULL = back to the bui
       const double v[4] = {q[0] * c - q[1] * s, q[0] * s + q[1] * c, q[2] * c - q[3] * s, q[2] * s + q[3] * c};
       for (int e = 0; e < 4; ++e) {
         const int r = (int)floor(fabs(v[e]) + 0.5) * (v[e] >= 0 ? 1 : -1);
-        if (r < -13 || r > 13) return -1;
-        g_custom_pattern[k][t][e] = (int8_t)r;
+        if (r < -13 || r > 13) fits = 0;
+        g_custom_pattern[k][t][e] = (int8_t)(r < -13 ? -13 : (r > 13 ? 13 : r));
       }
     }
   }
+  if (!fits && !g_steer) return -1;
+  memcpy(g_custom_base, base, sizeof(g_custom_base));
   g_use_custom_pattern = 1;
   return 0;
+}
+
+/* step 8' */
+void oracle_orb_describe_steer(const uint8_t* img, int w, int h, int stride, int x, int y, float angle, uint8_t* desc32) {
+  float cs, sn;
+  oracle_orb_sincos_deg(angle, &cs, &sn);
+  memset(desc32, 0, 32);
+  for (int k = 0; k < 256; ++k) {
+    const int8_t* p = g_use_custom_pattern ? g_custom_base[k] : GH_ORB_PATTERN[0][k];
+    const float ax = (float)p[0], ay = (float)p[1], bx = (float)p[2], by = (float)p[3];
+    const int rax = (int)rintf(ax * cs - ay * sn), ray = (int)rintf(ax * sn + ay * cs);
+    const int rbx = (int)rintf(bx * cs - by * sn), rby = (int)rintf(bx * sn + by * cs);
+    const int a = blur_at_reflect(img, w, h, stride, x + rax, y + ray);
+    const int b = blur_at_reflect(img, w, h, stride, x + rbx, y + rby);
+    if (a < b) desc32[k >> 3] |= (uint8_t)(1u << (k & 7));
+  }
 }
 
 /* step 8 */
@@ -346,16 +443,21 @@ int oracle_orb_extract(const uint8_t* gray, int w, int h, int stride, int K, int
     int* ss = ys + quota[l];
     int m = oracle_orb_select_level(S, ws[l], hs[l], ini_th, quota[l], xs, ys, ss);
     for (int i = 0; i < m; ++i) {
-      int bin = oracle_orb_angle_bin(lv[l], ls[l], xs[i], ys[i]);
       oracle_kp* kp = &kps[n];
       kp->x = (float)xs[i] * scale[l];
       kp->y = (float)ys[i] * scale[l];
       kp->size = 31.0f * scale[l];
-      kp->angle = 12.0f * (float)bin;
       kp->response = (float)ss[i];
       kp->octave = l;
       kp->class_id = -1;
-      oracle_orb_describe(lv[l], ls[l], xs[i], ys[i], bin, desc + (size_t)n * 32);
+      if (g_steer) {
+        kp->angle = oracle_orb_angle_deg(lv[l], ls[l], xs[i], ys[i]);
+        oracle_orb_describe_steer(lv[l], ws[l], hs[l], ls[l], xs[i], ys[i], kp->angle, desc + (size_t)n * 32);
+      } else {
+        int bin = oracle_orb_angle_bin(lv[l], ls[l], xs[i], ys[i]);
+        kp->angle = 12.0f * (float)bin;
+        oracle_orb_describe(lv[l], ls[l], xs[i], ys[i], bin, desc + (size_t)n * 32);
+      }
       ++n;
     }
     free(xs);

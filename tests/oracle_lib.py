@@ -187,6 +187,19 @@ def _orb_methods(cls):
         pat = np.ascontiguousarray(pattern, dtype=np.int8).reshape(256, 4)
         return self.lib.oracle_orb_set_pattern(_ptr(pat)) == 0
 
+    def orb_set_steer(self, mode):
+        """0: 30 orientation bins; 1: continuous steering (oracle/orb_oracle.c steps 6' and 8').  Global: reset after use."""
+        self.lib.oracle_orb_set_steer(int(mode))
+
+    def orb_fast_atan2_deg(self, y, x):
+        self.lib.oracle_orb_fast_atan2_deg.restype = C.c_float
+        return float(self.lib.oracle_orb_fast_atan2_deg(C.c_float(y), C.c_float(x)))
+
+    def orb_sincos_deg(self, a):
+        cs, sn = C.c_float(), C.c_float()
+        self.lib.oracle_orb_sincos_deg(C.c_float(a), C.byref(cs), C.byref(sn))
+        return cs.value, sn.value
+
     def orb_extract(self, gray, K=1000, nlevels=8, ini_th=20, min_th=7):
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         h, w = gray.shape
@@ -230,7 +243,7 @@ def _orb_methods(cls):
         self.lib.oracle_bgr_to_gray(_ptr(bgr), w, h, c, w * c, _ptr(out), w)
         return out
 
-    for f in (synth_frame, orb_level_dims, orb_quotas, orb_set_pattern, orb_extract, orb_extract_batch, orb_pyramid_level,
+    for f in (synth_frame, orb_level_dims, orb_quotas, orb_set_pattern, orb_set_steer, orb_fast_atan2_deg, orb_sincos_deg, orb_extract, orb_extract_batch, orb_pyramid_level,
               orb_score_map, bgr_to_gray):
         setattr(cls, f.__name__, f)
 

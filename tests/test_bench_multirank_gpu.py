@@ -57,3 +57,25 @@ def test_two_rank_bench_equals_single_rank(tmp_path):
     ap2, ap1 = two["extra"]["all_pairs_sharded"], one["extra"]["all_pairs_sharded"]
     assert ap2["frame_pairs"] == ap1["frame_pairs"] == 66 and ap2["pairs"] == ap1["pairs"] > 0
     assert "c3_stereo" in two["extra"] and "error" not in two["extra"]["c3_stereo"]  # the C3 leg ran on both ranks
+
+
+def test_strong_scaling_mode_splits_the_same_frames(tmp_path):
+    """`--scaling strong --frames 12` on two ranks works on the SAME 12 global frames as one rank with --frames 12: identical
+    gathered descriptors and match rows, the line says "strong"."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GSLAM_BENCH_DRYRUN_BACKEND="gloo", GSLAM_BENCH_VERIFY="1",
+               GSLAM_HIP_COMM_TIMEOUT_S="120")
+    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "12", "--scaling", "strong"] + FLAGS
+    r2 = subprocess.run(cmd2, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
+    two = _line(r2.stdout)
+    env1 = dict(env)
+    env1.pop("GSLAM_BENCH_DRYRUN_BACKEND")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "12", "--scaling", "strong"] + FLAGS,
+                        cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env1)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    one = _line(r1.stdout)
+    assert two["scaling"] == one["scaling"] == "strong" and two["config"]["frames_per_gpu"] == 6 and one["config"]["frames_per_gpu"] == 12
+    v2, v1 = two["extra"]["verify"], one["extra"]["verify"]
+    assert v2["global_frames"] == v1["global_frames"] == 12
+    assert v2["features_sha256"] == v1["features_sha256"] and v2["matches_sha256"] == v1["matches_sha256"]

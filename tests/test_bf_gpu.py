@@ -256,3 +256,31 @@ def test_pairs_entry_dispatches_on_pair_work_and_both_routes_agree(ctx):
         torch.cuda.synchronize()
         for x, y, name in zip(a, b, ("idx1", "d1", "d2")):
             assert torch.equal(x, y), (F, cap, name)
+
+
+def test_train_set_beyond_65535_rows(ctx, oracle):
+    """A frame against a local map: nt = 150 000 (three chunks of the 16-bit index field).  Exact duplicates of the best row
+    planted in later chunks must not displace the first one and must show up as the second-best distance; a strictly better
+    row in the last chunk must win.  Device and host entries, vs the oracle."""
+    import torch
+    from gslam_amd import hip
+    from gslam_amd.matcher import BFMatcher
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    nq, nt = 300, 150000
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    t[1000] = q[0]; t[70000] = q[0]; t[140000] = q[0]        # three exact copies: index 1000 wins, d2 = 0
+    t[66000] = q[1]; t[66000, 0] ^= 1; t[149999] = q[1]       # distance 1 in chunk 1, distance 0 in the last row: the last row wins, d2 = 1
+    t[65531] = q[2]; t[65532] = q[2]                          # duplicates across the chunk boundary (65532 rows per chunk)
+    e = oracle.bf_match(q, t, threads=8)
+    assert e[0][0] == 1000 and e[2][0] == 0 and e[0][1] == 149999 and e[2][1] == 1 and e[0][2] == 65531
+    m = BFMatcher(ctx)
+    idx1, d1, d2 = m.match(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(idx1.cpu().numpy(), e[0])
+    assert np.array_equal(d1.cpu().numpy().view(np.uint16), e[1]) and np.array_equal(d2.cpu().numpy().view(np.uint16), e[2])
+    hi, h1, h2 = np.empty(nq, np.int32), np.empty(nq, np.uint16), np.empty(nq, np.uint16)
+    ctx.check(hip.lib.gh_bf_match_host(ctx.h, q.ctypes.data_as(C.c_void_p), nq, t.ctypes.data_as(C.c_void_p), nt,
+                                       hi.ctypes.data_as(C.c_void_p), h1.ctypes.data_as(C.c_void_p), h2.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(hi, e[0]) and np.array_equal(h1, e[1]) and np.array_equal(h2, e[2])

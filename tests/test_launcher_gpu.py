@@ -103,6 +103,33 @@ def _read_log(path):
             o += 24 * npt
             out["ba"].append(dict(id=fid, graph={"cam_pose": poses, "cam_dof": dof, "point_xyz": pts, "obs_cam": ocam,
                                                   "obs_point": opt, "obs_xy": oxy}, ok=ok, poses=rposes, pts=rpts))
+        elif typ == 4:
+            fid, nb = rd("2i")
+            o += 8
+            bw = np.frombuffer(raw, np.dtype([("id", "<u4"), ("v", "<f4")]), nb, o).copy()
+            o += 8 * nb
+            nf = rd("i")[0]
+            o += 4
+            feat = {}
+            for _ in range(nf):
+                node, cnt = struct.unpack_from("Ii", raw, o)
+                o += 8
+                feat[node] = np.frombuffer(raw, np.uint32, cnt, o).copy()
+                o += 4 * cnt
+            out.setdefault("bow", []).append(dict(id=fid, ids=bw["id"], vals=bw["v"], feat=feat))
+        elif typ == 5:
+            fid, nc = rd("2i")
+            o += 8
+            cands = []
+            for _ in range(nc):
+                cid, sc = struct.unpack_from("=id", raw, o)
+                o += 12
+                cands.append((cid, sc))
+            loop_to, nm = rd("2i")
+            o += 8
+            m = np.frombuffer(raw, np.int32, 2 * nm, o).reshape(nm, 2).copy()
+            o += 8 * nm
+            out.setdefault("loops", []).append(dict(id=fid, cands=cands, loop_to=loop_to, matches=m))
         else:
             raise AssertionError(f"bad record type {typ} at {o}")
     return out
@@ -204,3 +231,88 @@ def test_reference_launcher_runs_orbhip_on_the_synthetic_sequence(tmp_path, orac
     for i, pose in published.items():  # the reference's Point3 / SO3 stream operators print 6 significant digits
         assert np.abs(vo[i - 1, 1:4] - pose[4:]).max() < 5e-6 and np.abs(vo[i - 1, 4:] - pose[:4]).max() < 5e-6, i
     assert np.abs(fin[:, 1:4] - np.array([frames[i + 1][0][4:] for i in range(n_frames)])).max() < 0.03
+
+
+def test_launcher_bow_vectors_loop_candidates_and_connections(tmp_path, oracle):
+    """`-orbhip.vocabulary voc.gbow`: every frame's BoW / feature vector through the Vocabulary plugin (libgslam_vocabulary,
+    GPU transform) equals the oracle's on the logged descriptors; the loop candidates are the batched GPU scores of the
+    frames at least `loop_gap` older, best first, equal to the oracle's scores; the orbit closes after 45 frames, so the last
+    frames must find the first ones and verify them with node-consistent matches (a FrameConnection, "orbhip/loop")."""
+    _need()
+    from gslam_amd import bow_synth
+    voc_lib = os.path.join(LIBDIR, "libgslam_vocabulary.so")
+    if not os.path.exists(voc_lib):
+        pytest.skip("libgslam_vocabulary.so missing")
+    n_frames, gap, levels_up = 45, 20, 2
+    voc = bow_synth.make_vocabulary(k=10, L=4, seed=3)
+    (tmp_path / "voc.gbow").write_bytes(bow_synth.to_gbow_bytes(voc))
+    seq = tmp_path / "seq.synthplane"
+    seq.write_text(f"width {W}\nheight {H}\nframes {n_frames}\nfps 200\ntexture 2048\nseed 1592590336\n")
+    os.symlink(os.path.join(LIBDIR, "libgslamDB_synthplane.so"), tmp_path / "libgslamDB_synthplane.so")
+    cmd = [os.path.join(REFDIR, "gslam"), "orbhip", "metric_time", "play",
+           "-dataset", str(seq), "-slam", "orbhip", "-playspeed", "1",
+           "-orbhip.nFeatures", str(K), "-orbhip.log", str(tmp_path / "orbhip.bin"), "-orbhip.stop_on_finish", "1",
+           "-orbhip.start_dataset", "1", "-orbhip.ba_every", "0",
+           "-orbhip.vocabulary", str(tmp_path / "voc.gbow"), "-orbhip.loop_gap", str(gap), "-orbhip.levels_up", str(levels_up),
+           "-orbhip.loop_score", "0.0", "-orbhip.loop_matches", "30",
+           "-VocabularyPlugin", voc_lib,
+           "-FeatureDetectorPlugin", os.path.join(LIBDIR, "libgslam_featuredetector.so"),
+           "-OptimizerPlugin", os.path.join(LIBDIR, "libgslam_optimizer.so"),
+           "-GSLAM_LIBRARY_PATH", LIBDIR + ":" + REFDIR]
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIBDIR + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for attempt in range(3):
+        for f in ("orbhip.bin", "orbhip_metric_time.txt"):
+            if (tmp_path / f).exists():
+                (tmp_path / f).unlink()
+        r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+        if r.returncode == 0 or r.returncode > 0:
+            break
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log = _read_log(tmp_path / "orbhip.bin")
+    assert [f["id"] for f in log["frames"]] == list(range(1, n_frames + 1))
+    assert [b["id"] for b in log["bow"]] == list(range(1, n_frames + 1)) == [lp["id"] for lp in log["loops"]]
+    # metric_time saw the wrapped frames come back on "orbhip/curframe"
+    assert len(open(tmp_path / "orbhip_metric_time.txt").read().splitlines()) == n_frames
+    vecs = {}
+    for f, b in zip(log["frames"], log["bow"]):
+        word, weight, node, bw, bv = oracle.bow_transform(voc, f["desc"], levels_up)
+        assert np.array_equal(b["ids"], bw) and np.array_equal(b["vals"], bv), f["id"]
+        exp_feat = {}
+        for i, nd in enumerate(node):
+            if weight[i] > 0:  # a stop word (weight 0) enters neither vector (GSLAM/core/Vocabulary.h:1600-1612)
+                exp_feat.setdefault(int(nd), []).append(i)
+        assert sorted(b["feat"]) == sorted(exp_feat) and all(np.array_equal(b["feat"][k], np.array(v, np.uint32)) for k, v in exp_feat.items()), f["id"]
+        vecs[f["id"]] = (bw, bv)
+    descs = {f["id"]: f["desc"] for f in log["frames"]}
+    nodes = {}
+    for f in log["frames"]:
+        word, weight, node, _, _ = oracle.bow_transform(voc, f["desc"], levels_up)
+        nodes[f["id"]] = np.where(weight > 0, node.astype(np.int64), -1)  # a stop word is in no feature vector
+    found = 0
+    for lp in log["loops"]:
+        old = [i for i in range(1, n_frames + 1) if i + gap <= lp["id"]]
+        assert sorted(c[0] for c in lp["cands"]) == old
+        sc = [c[1] for c in lp["cands"]]
+        assert sc == sorted(sc, reverse=True)
+        for cid, s in lp["cands"]:
+            e = oracle.bow_score(int(voc["scoring"]), vecs[lp["id"]], vecs[cid])
+            assert abs(s - e) <= 1e-6 * max(1.0, abs(e)), (lp["id"], cid, s, e)
+        if not lp["cands"]:
+            assert lp["loop_to"] == -1 and len(lp["matches"]) == 0
+            continue
+        # verification of the best candidate: cross-checked brute-force matches whose two features share their vocabulary node
+        best = lp["cands"][0][0]
+        q, t = descs[lp["id"]], descs[best]
+        fw, bw_ = oracle.bf_match(q, t, threads=4), oracle.bf_match(t, q, threads=4)
+        keep = oracle.match_mask(fw[0], fw[1], fw[2], bw_[0], len(t), 100, 0, 1, 1).astype(bool)
+        qi = np.nonzero(keep)[0]
+        ti = fw[0][keep]
+        same = (nodes[lp["id"]][qi] >= 0) & (nodes[lp["id"]][qi] == nodes[best][ti])
+        exp = np.stack([qi[same], ti[same]], axis=1).astype(np.int32)
+        assert np.array_equal(lp["matches"], exp), lp["id"]
+        assert lp["loop_to"] == (best if len(exp) >= 30 else -1), (lp["id"], len(exp))
+        found += int(lp["loop_to"] >= 0)
+    # (the procedural texture repeats, so the BoW scores of this sequence barely separate the frames: what is checked above
+    #  is the machinery -- transform, batched scoring, ordering, node-consistent verification -- not place recognition)
+    assert len([lp for lp in log["loops"] if lp["cands"]]) == n_frames - gap

@@ -290,3 +290,86 @@ def test_small_call_graph_cache_survives_fresh_and_rotating_buffers(ctx):
             for o in sets:
                 assert same(o, ref), (fresh_first, rnd)
         ex.close()
+
+
+def _steer_pattern():
+    from test_orb_oracle import _canonical_like_pattern
+    return _canonical_like_pattern()
+
+
+@pytest.mark.parametrize("w,h,K,B,pattern", [(640, 480, 1000, 2, False), (640, 480, 1000, 2, True), (1920, 1080, 2000, 2, True),
+                                              (161, 123, 200, 3, True), (1241, 376, 1500, 2, False)])
+def test_continuous_steering_parity(ctx, oracle, w, h, K, B, pattern):
+    """gh_orb_plan_set_steering(plan, 1): fastAtan2 orientation + per-keypoint rotation of the test pattern (the
+    OpenCV / ORB-SLAM steering), all 28 bytes of every keypoint and all 256 bits of every descriptor against the oracle's
+    steps 6' / 8' -- with the built-in pattern and with one that has the reach of the canonical ORB table (radius 18.4);
+    keypoints 19..24 px from the border read mirrored pixels."""
+    import torch
+    from gslam_amd.orb import OrbExtractor, kps_to_numpy, synth_frames
+    ex = OrbExtractor(ctx, w, h, max_batch=B, n_features=K)
+    ex.set_steering(1)
+    pat = _steer_pattern() if pattern else None
+    if pat is not None:
+        ex.set_pattern(pat)
+    frames = synth_frames(ctx, B, w, h, base_seed=0x5EED0300 + w)
+    kps, desc, counts = ex.extract(frames)
+    torch.cuda.synchronize()
+    host = frames.cpu().numpy()[:, :, :w]
+    oracle.orb_set_steer(1)
+    try:
+        assert pat is None or oracle.orb_set_pattern(pat)
+        near = 0
+        for f in range(B):
+            ek, ed = oracle.orb_extract(host[f], K)
+            n = int(counts[f])
+            assert n == len(ek)
+            assert kps_to_numpy(kps)[f, :n].tobytes() == ek.tobytes(), f"frame {f}: keypoint records differ"
+            assert np.array_equal(desc[f, :n].cpu().numpy(), ed), f"frame {f}: descriptor bits differ"
+            lv0 = ek[ek["octave"] == 0]
+            near += int(((lv0["x"] < 22) | (lv0["y"] < 22) | (lv0["x"] > w - 23) | (lv0["y"] > h - 23)).sum())
+            assert len(np.unique(ek["angle"])) > 50  # continuous, not 30 bins
+        assert near > 0, "no keypoint exercised the mirrored border"
+    finally:
+        oracle.orb_set_pattern(None)
+        oracle.orb_set_steer(0)
+    ex.close()
+
+
+def test_steering_mode_rules_and_vocabulary_round_trip(ctx, oracle):
+    """(a) the 30-bin mode refuses a pattern of radius 18 and the continuous mode takes it; going back to bins with it
+    installed is refused; switching modes changes descriptors and angles, not keypoint positions; (b) the steered
+    descriptors go through the GPU vocabulary (gh_bow_transform_dev) to the same BoW vector as the oracle's transform."""
+    import torch
+    from gslam_amd import bow_synth, hip
+    from gslam_amd.bow import Vocabulary
+    from gslam_amd.orb import OrbExtractor, kps_to_numpy, synth_frames
+    pat = _steer_pattern()
+    ex = OrbExtractor(ctx, 640, 480, max_batch=1, n_features=800)
+    frames = synth_frames(ctx, 1, 640, 480, base_seed=0x5EED0400)
+    out = ex.alloc_outputs(1)
+    k0, d0, c0 = [t.clone() for t in ex.extract(frames, out)]
+    with pytest.raises(hip.GslamHipError):
+        ex.set_pattern(pat)
+    ex.set_steering(1)
+    ex.set_pattern(pat)
+    with pytest.raises(hip.GslamHipError):
+        ex.set_steering(0)
+    k1, d1, c1 = ex.extract(frames, out)  # the same buffers: a graph captured for the other mode must not be replayed
+    torch.cuda.synchronize()
+    a0, a1 = kps_to_numpy(k0)[0], kps_to_numpy(k1)[0]
+    assert torch.equal(c0, c1)
+    for f in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(a0[f], a1[f])
+    assert not np.array_equal(a0["angle"], a1["angle"]) and not torch.equal(d0, d1)
+    d = (a1["angle"] - a0["angle"] + 180.0) % 360.0 - 180.0
+    assert np.abs(d).max() <= 12.5  # the bin is the 12-degree sector that holds the continuous angle
+    voc = bow_synth.make_vocabulary(k=10, L=4, seed=2)
+    v = Vocabulary(ctx, voc)
+    n = int(c1[0])
+    word, weight, node, bw, bv, bn = v.transform(d1, c1, 3)
+    torch.cuda.synchronize()
+    ew, ewt, en, ebw, ebv = oracle.bow_transform(voc, d1[0, :n].cpu().numpy(), 3)
+    assert np.array_equal(word[0, :n].cpu().numpy().astype(np.uint32), ew) and np.array_equal(node[0, :n].cpu().numpy().astype(np.uint32), en)
+    m = int(bn[0])
+    assert m == len(ebw) and np.array_equal(bw[0, :m].cpu().numpy().astype(np.uint32), ebw) and np.array_equal(bv[0, :m].cpu().numpy(), ebv)
+    ex.close()

@@ -123,3 +123,89 @@ def test_set_pattern_changes_descriptors_and_validates_range(oracle):
     bad[7] = [13, 13, 0, 0]  # radius 18.4: leaves the +-13 blurred patch at 45 degrees
     assert not oracle.orb_set_pattern(bad)
     oracle.orb_set_pattern(None)
+
+
+def _canonical_like_pattern(seed=5):
+    """A test pattern with the reach of the canonical ORB bit_pattern_31_ (points up to (-13, -13), radius 18.4): the real
+    table is not available offline."""
+    rng = np.random.default_rng(seed)
+    pat = rng.integers(-13, 14, (256, 4)).astype(np.int8)
+    pat[0] = (-13, -13, 13, 13)
+    pat[1] = (12, -13, -13, 12)
+    same = (pat[:, 0] == pat[:, 2]) & (pat[:, 1] == pat[:, 3])
+    pat[same, 2] = -pat[same, 2] - 1
+    return pat
+
+
+def test_continuous_steering_pieces_against_independent_float64(oracle):
+    """Steps 6' and 8' of the oracle against plain numpy float64: the fp32 polynomial arctangent stays within 0.02 degrees of
+    atan2 (OpenCV documents 0.3), the Taylor (cos, sin) within 6e-7 of the exact values, quadrant handling included."""
+    rng = np.random.default_rng(3)
+    for _ in range(4000):
+        x, y = (float(v) for v in rng.integers(-2_000_000, 2_000_001, 2))
+        a = oracle.orb_fast_atan2_deg(y, x)
+        e = np.degrees(np.arctan2(y, x)) % 360.0
+        assert min(abs(a - e), 360.0 - abs(a - e)) < 0.02, (x, y, a, e)
+    assert oracle.orb_fast_atan2_deg(0.0, 0.0) == 0.0 and oracle.orb_fast_atan2_deg(0.0, -5.0) == 180.0
+    assert oracle.orb_fast_atan2_deg(7.0, 0.0) == 90.0 and oracle.orb_fast_atan2_deg(-7.0, 0.0) == 270.0
+    for a in list(np.linspace(0, 360, 1441)) + [44.999, 45.0, 45.001, 134.9999, 315.0, 359.99997]:
+        cs, sn = oracle.orb_sincos_deg(np.float32(a))
+        ea = np.radians(float(np.float32(a)))
+        assert abs(cs - np.cos(ea)) < 6e-7 and abs(sn - np.sin(ea)) < 6e-7, a
+
+
+def test_continuous_steering_extraction_against_a_python_restatement(oracle):
+    """The whole steered describe step restated in numpy from the spec text (reflected blur, rotated tests, rint) on the
+    oracle's own keypoints: same angles, same 256 bits.  Also: the 30-bin mode refuses a pattern of radius 18, the continuous
+    mode takes it, and the keypoints (positions, scores) do not depend on the mode."""
+    pat = _canonical_like_pattern()
+    g = oracle.synth_frame(200, 160, 77)
+    base_k, base_d = oracle.orb_extract(g, 120, nlevels=3)
+    assert not oracle.orb_set_pattern(pat)          # 30-bin table: points beyond radius 13.49 are refused
+    oracle.orb_set_steer(1)
+    try:
+        assert oracle.orb_set_pattern(pat)
+        kps, desc = oracle.orb_extract(g, 120, nlevels=3)
+    finally:
+        oracle.orb_set_pattern(None)
+        oracle.orb_set_steer(0)
+    assert len(kps) == len(base_k)
+    for f in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(kps[f], base_k[f])
+    assert not set(np.unique(kps["angle"])).issubset({12.0 * k for k in range(30)})
+    gauss = np.array([144, 268, 391, 442, 391, 268, 144], np.int64)
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    lv = [g] + [oracle.orb_pyramid_level(g, l, 3) for l in (1, 2)]
+    scale = [np.float32(1.0), np.float32(1.2), np.float32(np.float32(1.2) * np.float32(1.2))]
+
+    def refl(i, n):
+        return -i if i < 0 else (2 * n - 2 - i if i >= n else i)
+
+    def blur(img, x, y):
+        h, w = img.shape
+        acc = 0
+        for j in range(-3, 4):
+            row = img[refl(y + j, h)]
+            acc += int(gauss[j + 3]) * sum(int(gauss[i + 3]) * int(row[refl(x + i, w)]) for i in range(-3, 4))
+        return (acc + (1 << 21)) >> 22
+
+    near_border = 0
+    for k, d in list(zip(kps, desc))[::7]:
+        img = lv[k["octave"]]
+        x, y = int(round(float(k["x"]) / float(scale[k["octave"]]))), int(round(float(k["y"]) / float(scale[k["octave"]])))
+        m10 = sum(u * int(img[y + v, x + u]) for v in range(-15, 16) for u in range(-umax[abs(v)], umax[abs(v)] + 1))
+        m01 = sum(v * int(img[y + v, x + u]) for v in range(-15, 16) for u in range(-umax[abs(v)], umax[abs(v)] + 1))
+        ang = np.float32(oracle.orb_fast_atan2_deg(float(m01), float(m10)))
+        assert ang == k["angle"]
+        assert abs(float(ang) - np.degrees(np.arctan2(m01, m10)) % 360.0) < 0.02 or (m10 == 0 and m01 == 0)
+        cs, sn = (np.float32(v) for v in oracle.orb_sincos_deg(ang))
+        bits = np.zeros(256, np.uint8)
+        for t in range(256):
+            ax, ay, bx, by = (np.float32(v) for v in pat[t])
+            ra = (int(np.rint(ax * cs - ay * sn)), int(np.rint(ax * sn + ay * cs)))
+            rb = (int(np.rint(bx * cs - by * sn)), int(np.rint(bx * sn + by * cs)))
+            bits[t] = blur(img, x + ra[0], y + ra[1]) < blur(img, x + rb[0], y + rb[1])
+        assert np.array_equal(np.packbits(bits, bitorder="little"), d)
+        h, w = img.shape
+        near_border += int(min(x, y, w - 1 - x, h - 1 - y) < 22)
+    assert near_border > 0  # some of the checked keypoints read mirrored pixels
