@@ -84,23 +84,27 @@ __host__ __device__ inline void jacobi_eig(double (*a)[N], double (*v)[N]) {
 
 // Horn's closed-form absolute orientation with scale (Horn 1987; GSLAM::Estimator::findSIM3, method S3_Horn) from three
 // point pairs: b ~ s R a + t.  out = [qx qy qz qw tx ty tz s] (GSLAM's SIM3 field order).
-__device__ inline bool solve_sim3(const double* p, const double* q, const int* idx, double* out) {
+// (m pairs: the three of a RANSAC sample through idx, or all n in index order with idx = nullptr -- the NOSAMPLE fit)
+__host__ __device__ inline bool solve_sim3(const double* p, const double* q, const int* idx, double* out, int m = 3) {
   double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < m; ++j) {
+    const int ij = idx ? idx[j] : j;
     for (int e = 0; e < 3; ++e) {
-      ca[e] = ca[e] + p[3 * idx[j] + e];
-      cb[e] = cb[e] + q[3 * idx[j] + e];
+      ca[e] = ca[e] + p[3 * ij + e];
+      cb[e] = cb[e] + q[3 * ij + e];
     }
+  }
   for (int e = 0; e < 3; ++e) {
-    ca[e] = ca[e] / 3.0;
-    cb[e] = cb[e] / 3.0;
+    ca[e] = ca[e] / (double)m;
+    cb[e] = cb[e] / (double)m;
   }
   double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, na = 0.0, nb = 0.0;
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < m; ++j) {
+    const int ij = idx ? idx[j] : j;
     double a[3], b[3];
     for (int e = 0; e < 3; ++e) {
-      a[e] = p[3 * idx[j] + e] - ca[e];
-      b[e] = q[3 * idx[j] + e] - cb[e];
+      a[e] = p[3 * ij + e] - ca[e];
+      b[e] = q[3 * ij + e] - cb[e];
       na = na + a[e] * a[e];
       nb = nb + b[e] * b[e];
     }
@@ -152,6 +156,7 @@ __device__ inline bool solve_plane(const double* p, const int* idx, double* out)
 // Perspective-n-point from six 3D-2D pairs by the direct linear transform: 12 x 12 homogeneous system, nullspace by
 // elimination with full pivoting (as for F), scaled to |r3| = 1 with positive depth, rotation made orthonormal by
 // Gram-Schmidt on its rows.  out = [R (row-major 9) | t (3)], X_c = R X_w + t.  Coplanar object points are degenerate.
+__host__ __device__ inline bool pnp_from_projection(double* P, const double* X0, double* out);
 __device__ inline bool solve_pnp_dlt(const double* p, const double* q, const int* idx, double* out) {
   double a[12][12];
   for (int j = 0; j < 6; ++j) {
@@ -208,10 +213,15 @@ __device__ inline bool solve_pnp_dlt(const double* p, const double* q, const int
     z[r] = -sres / a[r][r];
   }
   for (int c = 0; c < 12; ++c) P[perm[c]] = z[c];
+  return pnp_from_projection(P, p + 3 * idx[0], out);
+}
+
+// [R | t] from a 3 x 4 projection known up to scale: scaled to |r3| = 1 with X0 in front of the camera, rotation made
+// orthonormal by Gram-Schmidt on its rows.
+__host__ __device__ inline bool pnp_from_projection(double* P, const double* X0, double* out) {
   const double n3 = sqrt(P[8] * P[8] + P[9] * P[9] + P[10] * P[10]);
   if (!(n3 > kTiny)) return false;
   double lam = 1.0 / n3;
-  const double* X0 = p + 3 * idx[0];
   if ((P[8] * X0[0] + P[9] * X0[1] + P[10] * X0[2] + P[11]) * lam < 0) lam = -lam;  // the sample lies in front of the camera
   for (int c = 0; c < 12; ++c) P[c] = P[c] * lam;
   double r1[3] = {P[0], P[1], P[2]}, r2[3] = {P[4], P[5], P[6]};
@@ -237,7 +247,7 @@ __device__ inline bool solve_pnp_dlt(const double* p, const double* q, const int
 }
 
 // Solve A x = b (n <= 8, nrhs <= 3) in place, partial pivoting (first maximum).  a: n x (n + nrhs) row-major, ld = 12.
-__device__ bool ge_solve(double (*a)[12], int n, int nrhs) {
+__host__ __device__ inline bool ge_solve(double (*a)[12], int n, int nrhs) {
   for (int k = 0; k < n; ++k) {
     int piv = k;
     double best = fabs(a[k][k]);
@@ -583,6 +593,175 @@ __global__ __launch_bounds__(256) void ransac_mask_kernel(int model, const doubl
   }
 }
 
+// LMedS score of a hypothesis: the element of rank n / 2 (ascending, 0-based) of its squared errors; a correspondence whose
+// error is undefined counts as +inf.  Squared errors are non-negative doubles, whose bit patterns order as the values do:
+// an exact radix select, 8 bits per pass, one workgroup per hypothesis (the errors are recomputed in every pass: ~50 flops each).
+__global__ __launch_bounds__(256) void ransac_median_kernel(int model, const double* __restrict__ p,
+                                                            const double* __restrict__ q, int n,
+                                                            const double* __restrict__ models,
+                                                            const int* __restrict__ valid,
+                                                            unsigned long long* __restrict__ med) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned s_rank;
+  const int h = blockIdx.x, tid = threadIdx.x;
+  if (!valid[h]) {
+    if (tid == 0) med[h] = ~0ull;
+    return;
+  }
+  double m[12];
+  const int ms = model_size(model);
+  for (int k = 0; k < ms; ++k) m[k] = models[(size_t)h * 12 + k];
+  unsigned long long prefix = 0ull;
+  unsigned rank = (unsigned)(n / 2);
+  for (int pass = 7; pass >= 0; --pass) {
+    hist[tid] = 0u;
+    __syncthreads();
+    const unsigned long long hi_mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+    for (int i = tid; i < n; i += 256) {
+      double e;
+      const unsigned long long b = (model_error(model, m, p, q, i, &e) && e == e) ? (unsigned long long)__double_as_longlong(e)
+                                                                                 : 0x7FF0000000000000ull;
+      if ((b & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(b >> (8 * pass)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned acc = 0u;
+      int d = 0;
+      for (; d < 255; ++d) {
+        if (acc + hist[d] > rank) break;
+        acc += hist[d];
+      }
+      s_prefix = prefix | ((unsigned long long)d << (8 * pass));
+      s_rank = rank - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    rank = s_rank;
+    __syncthreads();
+  }
+  if (tid == 0) med[h] = prefix;
+}
+
+// NOSAMPLE (GSLAM/core/Estimator.h:89): the model from ALL correspondences, no hypotheses -- the algebraic least-squares
+// counterpart of each minimal solver, sums taken sequentially in index order (host side: n x a few dozen flops; the oracle
+// adds in the same order).  H, A2, A3: normal equations of the minimal solver's rows, Gaussian elimination.  F / E, PnP:
+// eigenvector of the smallest eigenvalue of A^T A (cyclic Jacobi), then the minimal solver's own post-processing.  SIM3:
+// Horn's closed form over all pairs.  Plane: normal = eigenvector of the smallest eigenvalue of the covariance.
+template <int N>
+static int smallest_eig_vector(double (*A)[N], double* vec) {
+  double V[N][N];
+  jacobi_eig<N>(A, V);
+  int best = 0;
+  for (int k = 1; k < N; ++k)
+    if (A[k][k] < A[best][best]) best = k;
+  for (int k = 0; k < N; ++k) vec[k] = V[k][best];
+  return best;
+}
+
+static bool fit_all(int model, const double* p, const double* q, int n, const Norm& nm, double* out) {
+  for (int k = 0; k < 12; ++k) out[k] = 0.0;
+  if (model == kModelH || model == kModelA2 || model == kModelA3) {
+    const int nu = model == kModelH ? 8 : (model == kModelA2 ? 3 : 4), nr = model == kModelH ? 1 : (model == kModelA2 ? 2 : 3);
+    double N[8][12];
+    for (int r = 0; r < 8; ++r)
+      for (int c = 0; c < 12; ++c) N[r][c] = 0.0;
+    auto add_row = [&](const double* r) {
+      for (int a = 0; a < nu; ++a)
+        for (int b = 0; b < nu + nr; ++b) N[a][b] = N[a][b] + r[a] * r[b];
+    };
+    for (int i = 0; i < n; ++i) {
+      if (model == kModelH) {
+        const double x = p[2 * i], y = p[2 * i + 1], u = q[2 * i], v = q[2 * i + 1];
+        const double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, u}, r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, v};
+        add_row(r0);
+        add_row(r1);
+      } else if (model == kModelA2) {
+        const double r[5] = {p[2 * i], p[2 * i + 1], 1, q[2 * i], q[2 * i + 1]};
+        add_row(r);
+      } else {
+        const double r[7] = {p[3 * i], p[3 * i + 1], p[3 * i + 2], 1, q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+        add_row(r);
+      }
+    }
+    if (!ge_solve(N, nu, nr)) return false;
+    if (model == kModelH) {
+      for (int k = 0; k < 8; ++k) out[k] = N[k][8];
+      out[8] = 1.0;
+    } else if (model == kModelA2) {
+      for (int k = 0; k < 3; ++k) {
+        out[k] = N[k][3];
+        out[3 + k] = N[k][4];
+      }
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) out[4 * r + c] = N[c][4 + r];
+    }
+    return true;
+  }
+  if (model == kModelSim3) return solve_sim3(p, q, nullptr, out, n);
+  if (model == kModelPlane) {
+    double c[3] = {0, 0, 0}, C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, nv[3];
+    for (int i = 0; i < n; ++i)
+      for (int e = 0; e < 3; ++e) c[e] = c[e] + p[3 * i + e];
+    for (int e = 0; e < 3; ++e) c[e] = c[e] / (double)n;
+    for (int i = 0; i < n; ++i) {
+      const double d[3] = {p[3 * i] - c[0], p[3 * i + 1] - c[1], p[3 * i + 2] - c[2]};
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) C[a][b] = C[a][b] + d[a] * d[b];
+    }
+    smallest_eig_vector<3>(C, nv);
+    const double len = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    if (!(len > kTiny)) return false;
+    for (int e = 0; e < 3; ++e) out[e] = nv[e] / len;
+    out[3] = -(out[0] * c[0] + out[1] * c[1] + out[2] * c[2]);
+    return true;
+  }
+  if (model == kModelPnP) {
+    double A[12][12];
+    for (int r = 0; r < 12; ++r)
+      for (int c = 0; c < 12; ++c) A[r][c] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2], u = q[2 * i], v = q[2 * i + 1];
+      const double r0[12] = {X, Y, Z, 1, 0, 0, 0, 0, -u * X, -u * Y, -u * Z, -u}, r1[12] = {0, 0, 0, 0, X, Y, Z, 1, -v * X, -v * Y, -v * Z, -v};
+      for (int a = 0; a < 12; ++a)
+        for (int b = 0; b < 12; ++b) A[a][b] = A[a][b] + (r0[a] * r0[b] + r1[a] * r1[b]);
+    }
+    double P[12];
+    smallest_eig_vector<12>(A, P);
+    return pnp_from_projection(P, p, out);
+  }
+  // fundamental / essential
+  double A[9][9];
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) A[r][c] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = (p[2 * i] - nm.m1x) * nm.s1, y = (p[2 * i + 1] - nm.m1y) * nm.s1;
+    const double u = (q[2 * i] - nm.m2x) * nm.s2, v = (q[2 * i + 1] - nm.m2y) * nm.s2;
+    const double r[9] = {u * x, u * y, u, v * x, v * y, v, x, y, 1};
+    for (int a = 0; a < 9; ++a)
+      for (int b = 0; b < 9; ++b) A[a][b] = A[a][b] + r[a] * r[b];
+  }
+  double fh[9];
+  smallest_eig_vector<9>(A, fh);
+  const double T1[9] = {nm.s1, 0, -nm.s1 * nm.m1x, 0, nm.s1, -nm.s1 * nm.m1y, 0, 0, 1};
+  const double T2[9] = {nm.s2, 0, -nm.s2 * nm.m2x, 0, nm.s2, -nm.s2 * nm.m2y, 0, 0, 1};
+  double tmp[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + fh[3 * r + k] * T1[3 * k + c];
+      tmp[3 * r + c] = acc;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + T2[3 * k + r] * tmp[3 * k + c];
+      out[3 * r + c] = acc;
+    }
+  return true;
+}
+
 }  // namespace
 
 // The adaptive stopping rule of sequential RANSAC (Fischler & Bolles; the rule behind a `confidence` argument): walking the
@@ -625,9 +804,17 @@ extern "C" gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* sr
 extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const double* src, const double* dst, int n,
                                              double threshold, double confidence, uint64_t seed, double* model_out,
                                              uint8_t* mask_out, int* inliers_out, int* hypotheses_used_out) {
+  return gh_ransac_estimate_ex(ctx, model, src, dst, n, threshold, confidence, seed, GH_SAMPLE_RANSAC, model_out, mask_out,
+                               inliers_out, hypotheses_used_out);
+}
+
+extern "C" gh_status gh_ransac_estimate_ex(gh_ctx* ctx, int model, const double* src, const double* dst, int n,
+                                           double threshold, double confidence, uint64_t seed, int sampling, double* model_out,
+                                           uint8_t* mask_out, int* inliers_out, int* hypotheses_used_out) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);
   GH_CHECK_ARG(ctx, model >= 0 && model <= 7 && src && dst && model_out && inliers_out && threshold >= 0);
+  GH_CHECK_ARG(ctx, sampling == GH_SAMPLE_RANSAC || sampling == GH_SAMPLE_LMEDS || sampling == GH_SAMPLE_NONE);
   const int dim = dim_p(model), dimq = dim_q(model);
   const int s = sample_size(model);
   *inliers_out = 0;
@@ -657,8 +844,9 @@ extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const doubl
     nm.s2 = d2 > 0 ? 1.4142135623730951 / d2 : 1.0;
   }
   const size_t pb = (((size_t)n * 3 * 8) + 255) & ~(size_t)255;  // sized for the wider of the two point sets
+  // (the counts slot holds 8 bytes per hypothesis: LMedS stores its medians there as 64-bit keys)
   const size_t off_q = pb, off_models = 2 * pb, off_valid = off_models + (size_t)kHyp * 12 * 8,
-               off_counts = off_valid + kHyp * 4, off_best = off_counts + kHyp * 4, off_mout = off_best + 256,
+               off_counts = off_valid + kHyp * 4, off_best = off_counts + kHyp * 8, off_mout = off_best + 256,
                off_mask = off_mout + 256, total = off_mask + (((size_t)n + 255) & ~(size_t)255);
   void *base = nullptr, *hbase = nullptr;
   GH_TRY(gh_scratch(ctx, total, &base));
@@ -677,13 +865,53 @@ extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const doubl
   memcpy(hb, src, (size_t)n * dim * 8);
   memcpy(hb + off_q, dst, (size_t)n * dimq * 8);
   GH_HIP(ctx, hipMemcpyAsync(b, hb, off_q + (size_t)n * dimq * 8, hipMemcpyHostToDevice, ctx->stream));
-  const double thr2 = threshold * threshold;
-  GH_LAUNCH(ctx, "ransac_solve", ransac_solve_kernel, dim3(kHyp / 64), dim3(64), 0, model, d_p, d_q, n, seed, nm,
-            d_models, d_valid);
-  GH_LAUNCH(ctx, "ransac_score", ransac_score_kernel, dim3(kHyp), dim3(256), 0, model, d_p, d_q, n, thr2, d_models,
-            d_valid, d_counts);
+  double thr2 = threshold * threshold;
   int best[2] = {-1, 0};
-  if (confidence > 0.0 && confidence < 1.0) {
+  if (sampling == GH_SAMPLE_NONE) {
+    // the all-point fit is hypothesis 0; the device evaluates it against every correspondence (mask + inlier count)
+    double m[12];
+    const bool ok = fit_all(model, src, dst, n, nm, m);
+    if (hypotheses_used_out) *hypotheses_used_out = ok ? 1 : 0;
+    if (!ok) return GH_OK;
+    memcpy(hb + off_models, m, sizeof(m));
+    best[0] = 0;
+    memcpy(hb + off_best, best, 8);
+    GH_HIP(ctx, hipMemcpyAsync(d_models, hb + off_models, sizeof(m), hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(d_best, hb + off_best, 8, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    GH_LAUNCH(ctx, "ransac_solve", ransac_solve_kernel, dim3(kHyp / 64), dim3(64), 0, model, d_p, d_q, n, seed, nm,
+              d_models, d_valid);
+  }
+  if (sampling == GH_SAMPLE_LMEDS) {
+    // least median of squares (Rousseeuw; OpenCV's LMEDS): the hypothesis with the smallest median squared error wins
+    // (lowest index on ties); inlier radius = max(threshold, 2.5 * 1.4826 * (1 + 5 / (n - s)) * sqrt(median))
+    unsigned long long* d_med = (unsigned long long*)d_counts;
+    GH_LAUNCH(ctx, "ransac_median", ransac_median_kernel, dim3(kHyp), dim3(256), 0, model, d_p, d_q, n, d_models, d_valid, d_med);
+    const unsigned long long* h_med = (const unsigned long long*)(hb + off_counts);
+    GH_HIP(ctx, hipMemcpyAsync(hb + off_counts, d_med, kHyp * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long bm = ~0ull;
+    for (int h = 0; h < kHyp; ++h)
+      if (h_med[h] < bm) {
+        bm = h_med[h];
+        best[0] = h;
+      }
+    if (hypotheses_used_out) *hypotheses_used_out = kHyp;
+    if (best[0] < 0 || bm >= 0x7FF0000000000000ull) return GH_OK;  // no hypothesis explains half of the correspondences
+    double med;
+    memcpy(&med, &bm, 8);
+    const double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / (double)(n - s > 0 ? n - s : 1)) * sqrt(med);
+    const double radius = sigma > threshold ? sigma : threshold;
+    thr2 = radius * radius;
+    memcpy(hb + off_best, best, 8);
+    GH_HIP(ctx, hipMemcpyAsync(d_best, hb + off_best, 8, hipMemcpyHostToDevice, ctx->stream));
+  } else if (sampling == GH_SAMPLE_RANSAC) {
+    GH_LAUNCH(ctx, "ransac_score", ransac_score_kernel, dim3(kHyp), dim3(256), 0, model, d_p, d_q, n, thr2, d_models,
+              d_valid, d_counts);
+  }
+  if (sampling != GH_SAMPLE_RANSAC) {
+    // (the winner is known on the host already)
+  } else if (confidence > 0.0 && confidence < 1.0) {
     // the prefix rule needs the counts on the host: 8 KB back, the choice (two ints) forth
     const int* h_counts = (const int*)(hb + off_counts);
     GH_HIP(ctx, hipMemcpyAsync(hb + off_counts, d_counts, kHyp * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -701,15 +929,20 @@ extern "C" gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const doubl
   GH_LAUNCH(ctx, "ransac_mask", ransac_mask_kernel, dim3(gh_div_up(n > 12 ? n : 12, 256)), dim3(256), 0, model, d_p, d_q,
             n, thr2, d_models, d_best, d_mask, d_mout);
   // best | model | mask lie back to back: one download
-  GH_HIP(ctx, hipMemcpyAsync(hb + off_best, d_best, (off_mask - off_best) + (mask_out ? (size_t)n : 0), hipMemcpyDeviceToHost,
-                             ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(hb + off_best, d_best, (off_mask - off_best) + ((mask_out || sampling != GH_SAMPLE_RANSAC) ? (size_t)n : 0),
+                             hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(best, hb + off_best, 8);
+  if (sampling == GH_SAMPLE_RANSAC) memcpy(best, hb + off_best, 8);
   memcpy(model_out, hb + off_mout, 12 * 8);
   if (mask_out) memcpy(mask_out, hb + off_mask, (size_t)n);
   if (best[0] < 0) {
     for (int k = 0; k < 12; ++k) model_out[k] = 0.0;
     return GH_OK;
+  }
+  if (sampling != GH_SAMPLE_RANSAC) {  // the inlier count of the chosen model is the population of its mask
+    best[1] = 0;
+    const uint8_t* hm = hb + off_mask;
+    for (int i = 0; i < n; ++i) best[1] += hm[i] ? 1 : 0;
   }
   *inliers_out = best[1];
   if (model == kModelE && !project_essential(model_out)) {  // the mask stays that of the scored 8-point estimate

@@ -8,6 +8,21 @@ import numpy as np
 from . import hip
 
 HOMOGRAPHY, AFFINE2D, FUNDAMENTAL, AFFINE3D, ESSENTIAL, SIM3, PLANE, PNP = 0, 1, 2, 3, 4, 5, 6, 7
+RANSAC, LMEDS, NOSAMPLE = 0, 1, 2  # GSLAM::EstimatorMethod sampling flags (Estimator.h:86-89) as gh_ransac_estimate_ex takes them
+
+
+def estimate_ex(ctx: hip.Context, model, src, dst, threshold, sampling, confidence=1.0, seed=1):
+    """gh_ransac_estimate_ex -> (model, mask, inliers, hypotheses_used)."""
+    src = np.ascontiguousarray(src, dtype=np.float64)
+    dst = np.ascontiguousarray(dst, dtype=np.float64)
+    n = src.shape[0]
+    m = np.zeros(12)
+    mask = np.zeros(max(n, 1), np.uint8)
+    cnt, used = C.c_int(), C.c_int()
+    pv = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(hip.lib.gh_ransac_estimate_ex(ctx.h, int(model), pv(src), pv(dst), n, C.c_double(threshold), C.c_double(confidence),
+                                            C.c_uint64(seed), int(sampling), pv(m), pv(mask), C.byref(cnt), C.byref(used)))
+    return m, mask[:n].copy(), cnt.value, used.value
 
 
 def estimate_conf(ctx: hip.Context, model, src, dst, threshold, confidence, seed=1):

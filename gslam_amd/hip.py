@@ -165,6 +165,8 @@ SIGNATURES = {
     "gh_ransac_estimate": (C.c_int, [_vp, _i, _vp, _vp, _i, C.c_double, C.c_uint64, _vp, _vp, C.POINTER(_i)]),
     "gh_ransac_estimate_conf": (C.c_int, [_vp, _i, _vp, _vp, _i, C.c_double, C.c_double, C.c_uint64, _vp, _vp, C.POINTER(_i),
                                           C.POINTER(_i)]),
+    "gh_ransac_estimate_ex": (C.c_int, [_vp, _i, _vp, _vp, _i, C.c_double, C.c_double, C.c_uint64, _i, _vp, _vp, C.POINTER(_i),
+                                          C.POINTER(_i)]),
     "gh_triangulate": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "gh_ba_default_options": (None, [C.POINTER(BaOptions)]),
     "gh_ba_solve": (C.c_int, [_vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),

@@ -1,12 +1,16 @@
 // libgslam_estimator.so — GSLAM::Estimator plugin (GSLAM/core/Estimator.h:92-191) on the MI355X.
 // Exports `createEstimatorInstance` through the reference's own USE_ESTIMATOR_PLUGIN macro (:42-53), so
 // GSLAM::Estimator::create() (default plugin name "libgslam_estimator", svar EstimatorPlugin) loads it unchanged.
-// RANSAC with inlier masks for findHomography / findAffine2D / findFundamental / findAffine3D -> gh_ransac_estimate.
-// The other pure virtuals (findEssentialMatrix, findSIM3, findPlane, findPnP, trianglate) and the NOSAMPLE mode return
-// false ("unsupported"), as callers of the interface must already expect from the bool result.
-// Note on `method`: in the reference's EstimatorMethod enum the model ids follow MODEL_METHOD = 0xFF, i.e. they are
-// 0x100..0x111 and collide with the sampling bits (LMEDS = 1 << 8); the interface's own defaults are `X & RANSAC` = 0.
-// The only sampling flag that can be told apart is NOSAMPLE (2 << 8), so every other value means RANSAC here.
+// All nine pure virtuals are implemented: findHomography / findAffine2D / findFundamental / findEssentialMatrix / findSIM3 /
+// findAffine3D / findPlane / findPnP -> gh_ransac_estimate_ex (inlier masks, `confidence` honoured), trianglate -> gh_triangulate.
+// Sampling (`method & SAMPLE_METHOD`, Estimator.h:86-89):
+//   RANSAC    the default.
+//   NOSAMPLE  (2 << 8) the least-squares model of all correspondences, mask by `threshold`.
+//   LMEDS     (1 << 8) least median of squares.  In the reference's enum the model ids follow MODEL_METHOD = 0xFF, i.e. they are
+//             0x100..0x111 and collide with this bit (F8_Point == LMEDS == 0x100; the interface's own defaults are
+//             `X & RANSAC` = 0), so a caller cannot flag it next to a model id.  It is taken when `method` is exactly LMEDS in a
+//             function whose model is not F8_Point (every one but findFundamental), or for every call with svar
+//             `EstimatorHIP.Sampling` = "LMEDS" ("NOSAMPLE" / "RANSAC" force those).
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Estimator.h>
 
@@ -50,10 +54,10 @@ class EstimatorHIP : public GSLAM::Estimator {
   }
   bool findAffine3D(GSLAM::Affine3D* A, const std::vector<GSLAM::Point3d>& src, const std::vector<GSLAM::Point3d>& dst,
                     int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
-    if (src.size() != dst.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    if (src.size() != dst.size() || !context()) return false;
     double m[12];
     if (!estimate(GH_MODEL_AFFINE3D, (const double*)src.data(), (const double*)dst.data(), (int)src.size(), threshold, confidence, m,
-                  mask))
+                  mask, method))
       return false;
     if (A) for (int i = 0; i < 12; ++i) A->data()[i] = m[i];
     return true;
@@ -69,9 +73,10 @@ class EstimatorHIP : public GSLAM::Estimator {
   // to ~ s R from + t (Horn's closed form inside RANSAC)
   bool findSIM3(GSLAM::SIM3* S, const std::vector<GSLAM::Point3d>& from, const std::vector<GSLAM::Point3d>& to, int method,
                 double threshold, double confidence, std::vector<uchar>* mask) const override {
-    if (from.size() != to.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    if (from.size() != to.size() || !context()) return false;
     double m[12];
-    if (!estimate(GH_MODEL_SIM3, (const double*)from.data(), (const double*)to.data(), (int)from.size(), threshold, confidence, m, mask))
+    if (!estimate(GH_MODEL_SIM3, (const double*)from.data(), (const double*)to.data(), (int)from.size(), threshold, confidence, m, mask,
+                  method))
       return false;
     if (S) *S = GSLAM::SIM3(GSLAM::SO3(m[0], m[1], m[2], m[3]), GSLAM::Point3d(m[4], m[5], m[6]), m[7]);
     return true;
@@ -79,10 +84,10 @@ class EstimatorHIP : public GSLAM::Estimator {
   // plane pose: origin = the plane point closest to the world origin, z axis = the unit normal
   bool findPlane(GSLAM::SE3* plane, const std::vector<GSLAM::Point3d>& points, int method, double threshold,
                  double confidence, std::vector<uchar>* mask) const override {
-    if ((method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    if (!context()) return false;
     double m[12];
     if (!estimate(GH_MODEL_PLANE, (const double*)points.data(), (const double*)points.data(), (int)points.size(), threshold, confidence,
-                  m, mask))
+                  m, mask, method))
       return false;
     if (plane) {
       const double n[3] = {m[0], m[1], m[2]};
@@ -102,10 +107,11 @@ class EstimatorHIP : public GSLAM::Estimator {
   // of the Optimizer path (gh_ba_pnp, Huber at the RANSAC threshold) on the inliers
   bool findPnP(GSLAM::SE3* world2camera, const std::vector<GSLAM::Point3d>& obj, const std::vector<GSLAM::Point2d>& img,
                int method, double threshold, double confidence, std::vector<uchar>* mask) const override {
-    if (obj.size() != img.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
+    if (obj.size() != img.size() || !context()) return false;
     double m[12];
     std::vector<uchar> local;
-    if (!estimate(GH_MODEL_PNP, (const double*)obj.data(), (const double*)img.data(), (int)obj.size(), threshold, confidence, m, &local))
+    if (!estimate(GH_MODEL_PNP, (const double*)obj.data(), (const double*)img.data(), (int)obj.size(), threshold, confidence, m, &local,
+                  method))
       return false;
     std::vector<double> X, uv;
     for (size_t i = 0; i < local.size(); ++i)
@@ -158,18 +164,28 @@ class EstimatorHIP : public GSLAM::Estimator {
   static_assert(sizeof(GSLAM::Point2d) == 16 && sizeof(GSLAM::Point3d) == 24, "point arrays are passed as packed doubles");
   bool run(int model, const std::vector<GSLAM::Point2d>& a, const std::vector<GSLAM::Point2d>& b, int method,
            double threshold, double confidence, double* m, std::vector<uchar>* mask) const {
-    if (a.size() != b.size() || (method & GSLAM::NOSAMPLE) != 0 || !context()) return false;
-    return estimate(model, (const double*)a.data(), (const double*)b.data(), (int)a.size(), threshold, confidence, m, mask);
+    if (a.size() != b.size() || !context()) return false;
+    return estimate(model, (const double*)a.data(), (const double*)b.data(), (int)a.size(), threshold, confidence, m, mask, method);
   }
   // `confidence` is honoured as a sequential RANSAC would (gh_ransac_estimate_conf): the hypotheses are scored in parallel,
   // the winner is the best of the prefix the adaptive stopping rule would have examined
+  static int sampling_of(int model, int method) {
+    const std::string forced = svar.GetString("EstimatorHIP.Sampling", "");
+    if (forced == "LMEDS") return GH_SAMPLE_LMEDS;
+    if (forced == "NOSAMPLE") return GH_SAMPLE_NONE;
+    if (forced == "RANSAC") return GH_SAMPLE_RANSAC;
+    if ((method & GSLAM::NOSAMPLE) != 0) return GH_SAMPLE_NONE;
+    if (method == GSLAM::LMEDS && model != GH_MODEL_FUNDAMENTAL) return GH_SAMPLE_LMEDS;  // (== F8_Point: see the header)
+    return GH_SAMPLE_RANSAC;
+  }
   bool estimate(int model, const double* a, const double* b, int n, double threshold, double confidence, double* m,
-                std::vector<uchar>* mask) const {
+                std::vector<uchar>* mask, int method = 0) const {
     std::lock_guard<std::mutex> lock(mu_);
     std::vector<uchar> local((size_t)(n > 0 ? n : 1));
     int inliers = 0;
     const uint64_t seed = (uint64_t)svar.GetInt("EstimatorHIP.Seed", 1);
-    if (gh_ransac_estimate_conf(ctx_, model, a, b, n, threshold, confidence, seed, m, local.data(), &inliers, NULL) != GH_OK) {
+    if (gh_ransac_estimate_ex(ctx_, model, a, b, n, threshold, confidence, seed, sampling_of(model, method), m, local.data(), &inliers,
+                              NULL) != GH_OK) {
       LOG(ERROR) << "EstimatorHIP: " << gh_last_error(ctx_);
       return false;
     }

@@ -740,12 +740,33 @@ static int run_est(const std::string& dir, int model, int n, const char* ptsf, d
   }
   SE3 pose;
   std::vector<Point3d> p3;
-  const bool unsupported = est->findPnP(&pose, p3, a) || est->findHomography(nullptr, a, b, H4_Point | NOSAMPLE, thr, 0.99, nullptr);
+  const bool unsupported = est->findPnP(&pose, p3, a);  // mismatched sizes: the one call that must refuse
+  // the sampling flags of EstimatorMethod (Estimator.h:86-89): NOSAMPLE (2 << 8, distinguishable next to a model id) and LMEDS
+  // (1 << 8 == F8_Point: passed bare; not meaningful for findFundamental, which reads it as F8_Point + RANSAC)
+  auto call = [&](int method, double* mm, std::vector<uchar>* mk) {
+    for (int i = 0; i < 9; ++i) mm[i] = 0;
+    if (model == 0) { Homography2D H; const bool r = est->findHomography(&H, a, b, method, thr, 0.99, mk); for (int i = 0; i < 9; ++i) mm[i] = H.data()[i]; return r; }
+    if (model == 1) { Affine2D A; const bool r = est->findAffine2D(&A, a, b, method, thr, 0.99, mk); for (int i = 0; i < 6; ++i) mm[i] = A.data()[i]; return r; }
+    if (model == 4) { Essential E; const bool r = est->findEssentialMatrix(&E, a, b, method, thr, 0.99, mk); for (int i = 0; i < 9; ++i) mm[i] = E.data()[i]; return r; }
+    Fundamental F; const bool r = est->findFundamental(&F, a, b, method, thr, 0.99, mk); for (int i = 0; i < 9; ++i) mm[i] = F.data()[i]; return r;
+  };
+  double m_nos[9], m_lmeds[9];
+  std::vector<uchar> mask_nos, mask_lmeds;
+  const int model_id[5] = {H4_Point, A3_Point, F8_Point, 0, E5_Nister};
+  const bool ok_nos = call(model_id[model] | NOSAMPLE, m_nos, &mask_nos);
+  const bool ok_lmeds = model == 2 ? false : call(LMEDS, m_lmeds, &mask_lmeds);
   std::ofstream o(out, std::ios::binary);
   int32_t hdr[2] = {ok ? 1 : 0, (int32_t)mask.size()};
   o.write((char*)hdr, sizeof(hdr));
   o.write((char*)m, sizeof(m));
   if (!mask.empty()) o.write((char*)mask.data(), mask.size());
+  for (int v = 0; v < 2; ++v) {
+    const int32_t h2[2] = {(v == 0 ? ok_nos : ok_lmeds) ? 1 : 0, (int32_t)(v == 0 ? mask_nos : mask_lmeds).size()};
+    o.write((char*)h2, sizeof(h2));
+    o.write((char*)(v == 0 ? m_nos : m_lmeds), 72);
+    const std::vector<uchar>& mk = v == 0 ? mask_nos : mask_lmeds;
+    if (!mk.empty()) o.write((char*)mk.data(), mk.size());
+  }
   std::cout << "estimator " << est->type() << " ok=" << ok << " unsupported_paths=" << unsupported << std::endl;
   return ok && !unsupported ? 0 : 3;
 }

@@ -386,6 +386,22 @@ gh_status gh_ransac_estimate(gh_ctx* ctx, int model, const double* src, const do
 gh_status gh_ransac_estimate_conf(gh_ctx* ctx, int model, const double* src, const double* dst, int n, double threshold,
                                   double confidence, uint64_t seed, double* model_out, uint8_t* mask_out,
                                   int* inliers_out, int* hypotheses_used_out);
+/* The same with GSLAM::EstimatorMethod's sampling flag (Estimator.h:86-89):
+ *   GH_SAMPLE_RANSAC  as gh_ransac_estimate_conf.
+ *   GH_SAMPLE_LMEDS   least median of squares over the same 2048 hypotheses: the winner has the smallest MEDIAN squared error
+ *                     (the element of rank n / 2, ascending; lowest hypothesis index on ties), `confidence` is not used; the
+ *                     mask holds the correspondences within max(threshold, 2.5 * 1.4826 * (1 + 5 / (n - s)) * sqrt(median))
+ *                     (Rousseeuw's robust standard deviation, the rule of OpenCV's LMEDS); no model when even the best
+ *                     median is undefined.
+ *   GH_SAMPLE_NONE    NOSAMPLE: no hypotheses -- the algebraic least-squares model of ALL correspondences (normal equations of
+ *                     the minimal solver's rows for H / affine, smallest eigenvector of A^T A for F / E / PnP, Horn over all
+ *                     pairs for SIM3, principal plane); mask / inliers by `threshold`; *hypotheses_used_out = 1. */
+#define GH_SAMPLE_RANSAC 0
+#define GH_SAMPLE_LMEDS 1
+#define GH_SAMPLE_NONE 2
+gh_status gh_ransac_estimate_ex(gh_ctx* ctx, int model, const double* src, const double* dst, int n, double threshold,
+                                double confidence, uint64_t seed, int sampling, double* model_out, uint8_t* mask_out,
+                                int* inliers_out, int* hypotheses_used_out);
 /* Midpoint triangulation, one correspondence per thread (GSLAM::Estimator::trianglate, Estimator.h:164-168): the point of
  * the REFERENCE frame closest to the two rays ref_dir and cur_dir (camera.UnProject of the two pixels), with
  * X_cur = T_ref2cur X_ref, pose = [qx qy qz qw tx ty tz].  pose_stride = 7: one pose per correspondence; 0: one pose for

@@ -29,6 +29,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define R_HYP 2048
@@ -108,6 +109,8 @@ static void jacobi4(double a[4][4], double v[4][4]);
       }
 static void jacobi3(double a[3][3], double v[3][3]) { JACOBI_BODY(3) }
 static void jacobi4(double a[4][4], double v[4][4]) { JACOBI_BODY(4) }
+static void jacobi9(double a[9][9], double v[9][9]) { JACOBI_BODY(9) }
+static void jacobi12(double a[12][12], double v[12][12]) { JACOBI_BODY(12) }
 
 static void quat_R(double qx, double qy, double qz, double qw, double* R) {
   R[0] = 1 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qw * qz); R[2] = 2 * (qx * qz + qw * qy);
@@ -115,23 +118,26 @@ static void quat_R(double qx, double qy, double qz, double qw, double* R) {
   R[6] = 2 * (qx * qz - qw * qy); R[7] = 2 * (qy * qz + qw * qx); R[8] = 1 - 2 * (qx * qx + qy * qy);
 }
 
-static int solve_sim3(const double* p, const double* q, const int* idx, double* out) {
+/* m pairs: the three of a sample through idx, or all n in index order with idx = NULL (NOSAMPLE) */
+static int solve_sim3_m(const double* p, const double* q, const int* idx, double* out, int m);
+static int solve_sim3(const double* p, const double* q, const int* idx, double* out) { return solve_sim3_m(p, q, idx, out, 3); }
+static int solve_sim3_m(const double* p, const double* q, const int* idxp, double* out, int m) {
   double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < m; ++j)
     for (int e = 0; e < 3; ++e) {
-      ca[e] = ca[e] + p[3 * idx[j] + e];
-      cb[e] = cb[e] + q[3 * idx[j] + e];
+      ca[e] = ca[e] + p[3 * (idxp ? idxp[j] : j) + e];
+      cb[e] = cb[e] + q[3 * (idxp ? idxp[j] : j) + e];
     }
   for (int e = 0; e < 3; ++e) {
-    ca[e] = ca[e] / 3.0;
-    cb[e] = cb[e] / 3.0;
+    ca[e] = ca[e] / (double)m;
+    cb[e] = cb[e] / (double)m;
   }
   double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, na = 0.0, nb = 0.0;
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < m; ++j) {
     double a[3], b[3];
     for (int e = 0; e < 3; ++e) {
-      a[e] = p[3 * idx[j] + e] - ca[e];
-      b[e] = q[3 * idx[j] + e] - cb[e];
+      a[e] = p[3 * (idxp ? idxp[j] : j) + e] - ca[e];
+      b[e] = q[3 * (idxp ? idxp[j] : j) + e] - cb[e];
       na = na + a[e] * a[e];
       nb = nb + b[e] * b[e];
     }
@@ -175,6 +181,7 @@ static int solve_plane(const double* p, const int* idx, double* out) {
   return 1;
 }
 
+static int pnp_from_projection(double* P, const double* X0, double* out);
 static int solve_pnp_dlt(const double* p, const double* q, const int* idx, double* out) {
   double a[12][12];
   for (int j = 0; j < 6; ++j) {
@@ -227,10 +234,13 @@ static int solve_pnp_dlt(const double* p, const double* q, const int* idx, doubl
     z[r] = -s / a[r][r];
   }
   for (int c = 0; c < 12; ++c) P[perm[c]] = z[c];
+  return pnp_from_projection(P, p + 3 * idx[0], out);
+}
+
+static int pnp_from_projection(double* P, const double* X0, double* out) {
   double n3 = sqrt(P[8] * P[8] + P[9] * P[9] + P[10] * P[10]);
   if (!(n3 > R_TINY)) return 0;
   double lam = 1.0 / n3;
-  const double* X0 = p + 3 * idx[0];
   if ((P[8] * X0[0] + P[9] * X0[1] + P[10] * X0[2] + P[11]) * lam < 0) lam = -lam;
   for (int c = 0; c < 12; ++c) P[c] = P[c] * lam;
   double r1[3] = {P[0], P[1], P[2]}, r2[3] = {P[4], P[5], P[6]};
@@ -546,6 +556,221 @@ int oracle_ransac_conf(int model, const double* p, const double* q, int n, doubl
       mask[i] = (uint8_t)((model_err(model, best_m, p, q, i, &e) && e <= thr2) ? 1 : 0);
     }
   return best_c;
+}
+
+/* ---- sampling modes of GSLAM::EstimatorMethod (Estimator.h:86-89) beside RANSAC: LMEDS and NOSAMPLE -- the restatement
+ * gh_ransac_estimate_ex is checked against.  sampling: 0 RANSAC (= oracle_ransac_conf), 1 LMEDS, 2 NOSAMPLE. */
+static int cmp_double(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+static void hartley(int model, const double* p, const double* q, int n, norm_t* nm) {
+  nm->m1x = nm->m1y = nm->m2x = nm->m2y = 0;
+  nm->s1 = nm->s2 = 1;
+  if (model != 2 && model != 4) return;
+  double ax = 0, ay = 0, bx = 0, by = 0;
+  for (int i = 0; i < n; ++i) {
+    ax += p[2 * i]; ay += p[2 * i + 1];
+    bx += q[2 * i]; by += q[2 * i + 1];
+  }
+  nm->m1x = ax / n; nm->m1y = ay / n; nm->m2x = bx / n; nm->m2y = by / n;
+  double d1 = 0, d2 = 0;
+  for (int i = 0; i < n; ++i) {
+    double x = p[2 * i] - nm->m1x, y = p[2 * i + 1] - nm->m1y, u = q[2 * i] - nm->m2x, v = q[2 * i + 1] - nm->m2y;
+    d1 += sqrt(x * x + y * y);
+    d2 += sqrt(u * u + v * v);
+  }
+  d1 /= n; d2 /= n;
+  nm->s1 = d1 > 0 ? 1.4142135623730951 / d1 : 1.0;
+  nm->s2 = d2 > 0 ? 1.4142135623730951 / d2 : 1.0;
+}
+
+/* NOSAMPLE: the algebraic least-squares model of all correspondences, sums in index order */
+static int fit_all(int model, const double* p, const double* q, int n, const norm_t* nm, double* out) {
+  memset(out, 0, 12 * sizeof(double));
+  if (model == 0 || model == 1 || model == 3) {
+    int nu = model == 0 ? 8 : (model == 1 ? 3 : 4), nr = model == 0 ? 1 : (model == 1 ? 2 : 3);
+    double N[8][12];
+    memset(N, 0, sizeof(N));
+    for (int i = 0; i < n; ++i) {
+      double rows[2][9];
+      int nrows = 1;
+      if (model == 0) {
+        double x = p[2 * i], y = p[2 * i + 1], u = q[2 * i], v = q[2 * i + 1];
+        double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, u}, r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, v};
+        memcpy(rows[0], r0, sizeof(r0));
+        memcpy(rows[1], r1, sizeof(r1));
+        nrows = 2;
+      } else if (model == 1) {
+        double r[9] = {p[2 * i], p[2 * i + 1], 1, q[2 * i], q[2 * i + 1], 0, 0, 0, 0};
+        memcpy(rows[0], r, sizeof(r));
+      } else {
+        double r[9] = {p[3 * i], p[3 * i + 1], p[3 * i + 2], 1, q[3 * i], q[3 * i + 1], q[3 * i + 2], 0, 0};
+        memcpy(rows[0], r, sizeof(r));
+      }
+      for (int k = 0; k < nrows; ++k)
+        for (int a = 0; a < nu; ++a)
+          for (int b = 0; b < nu + nr; ++b) N[a][b] = N[a][b] + rows[k][a] * rows[k][b];
+    }
+    if (!ge(N, nu, nr)) return 0;
+    if (model == 0) {
+      for (int k = 0; k < 8; ++k) out[k] = N[k][8];
+      out[8] = 1.0;
+    } else if (model == 1) {
+      for (int k = 0; k < 3; ++k) {
+        out[k] = N[k][3];
+        out[3 + k] = N[k][4];
+      }
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) out[4 * r + c] = N[c][4 + r];
+    }
+    return 1;
+  }
+  if (model == 5) return solve_sim3_m(p, q, 0, out, n);
+  if (model == 6) {
+    double c[3] = {0, 0, 0}, C[3][3], V[3][3];
+    memset(C, 0, sizeof(C));
+    for (int i = 0; i < n; ++i)
+      for (int e = 0; e < 3; ++e) c[e] = c[e] + p[3 * i + e];
+    for (int e = 0; e < 3; ++e) c[e] = c[e] / (double)n;
+    for (int i = 0; i < n; ++i) {
+      double d[3] = {p[3 * i] - c[0], p[3 * i + 1] - c[1], p[3 * i + 2] - c[2]};
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) C[a][b] = C[a][b] + d[a] * d[b];
+    }
+    jacobi3(C, V);
+    int best = 0;
+    for (int k = 1; k < 3; ++k)
+      if (C[k][k] < C[best][best]) best = k;
+    double nv[3] = {V[0][best], V[1][best], V[2][best]};
+    double len = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    if (!(len > R_TINY)) return 0;
+    for (int e = 0; e < 3; ++e) out[e] = nv[e] / len;
+    out[3] = -(out[0] * c[0] + out[1] * c[1] + out[2] * c[2]);
+    return 1;
+  }
+  if (model == 7) {
+    double A[12][12], V[12][12];
+    memset(A, 0, sizeof(A));
+    for (int i = 0; i < n; ++i) {
+      double X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2], u = q[2 * i], v = q[2 * i + 1];
+      double r0[12] = {X, Y, Z, 1, 0, 0, 0, 0, -u * X, -u * Y, -u * Z, -u}, r1[12] = {0, 0, 0, 0, X, Y, Z, 1, -v * X, -v * Y, -v * Z, -v};
+      for (int a = 0; a < 12; ++a)
+        for (int b = 0; b < 12; ++b) A[a][b] = A[a][b] + (r0[a] * r0[b] + r1[a] * r1[b]);
+    }
+    jacobi12(A, V);
+    int best = 0;
+    for (int k = 1; k < 12; ++k)
+      if (A[k][k] < A[best][best]) best = k;
+    double P[12];
+    for (int k = 0; k < 12; ++k) P[k] = V[k][best];
+    return pnp_from_projection(P, p, out);
+  }
+  double A[9][9], V[9][9];
+  memset(A, 0, sizeof(A));
+  for (int i = 0; i < n; ++i) {
+    double x = (p[2 * i] - nm->m1x) * nm->s1, y = (p[2 * i + 1] - nm->m1y) * nm->s1;
+    double u = (q[2 * i] - nm->m2x) * nm->s2, v = (q[2 * i + 1] - nm->m2y) * nm->s2;
+    double r[9] = {u * x, u * y, u, v * x, v * y, v, x, y, 1};
+    for (int a = 0; a < 9; ++a)
+      for (int b = 0; b < 9; ++b) A[a][b] = A[a][b] + r[a] * r[b];
+  }
+  jacobi9(A, V);
+  int best = 0;
+  for (int k = 1; k < 9; ++k)
+    if (A[k][k] < A[best][best]) best = k;
+  double fh[9];
+  for (int k = 0; k < 9; ++k) fh[k] = V[k][best];
+  double T1[9] = {nm->s1, 0, -nm->s1 * nm->m1x, 0, nm->s1, -nm->s1 * nm->m1y, 0, 0, 1};
+  double T2[9] = {nm->s2, 0, -nm->s2 * nm->m2x, 0, nm->s2, -nm->s2 * nm->m2y, 0, 0, 1};
+  double tmp[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + fh[3 * r + k] * T1[3 * k + c];
+      tmp[3 * r + c] = acc;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc = acc + T2[3 * k + r] * tmp[3 * k + c];
+      out[3 * r + c] = acc;
+    }
+  return 1;
+}
+
+/* returns the inlier count (0 = no model) */
+int oracle_estimate_ex(int model, const double* p, const double* q, int n, double threshold, double confidence,
+                       uint64_t seed, int sampling, double* model_out, uint8_t* mask, int* used_out) {
+  static const int S_OF[8] = {4, 3, 8, 4, 8, 3, 3, 6}, M_OF[8] = {9, 6, 9, 12, 9, 8, 4, 12};
+  if (sampling == 0) return oracle_ransac_conf(model, p, q, n, threshold, confidence, seed, model_out, mask, used_out);
+  const int s = S_OF[model], ms = M_OF[model];
+  memset(model_out, 0, 12 * sizeof(double));
+  if (mask) memset(mask, 0, (size_t)(n > 0 ? n : 0));
+  if (used_out) *used_out = 0;
+  if (n < s) return 0;
+  norm_t nm;
+  hartley(model, p, q, n, &nm);
+  double best_m[12], thr2 = threshold * threshold;
+  memset(best_m, 0, sizeof(best_m));
+  if (sampling == 2) {
+    if (!fit_all(model, p, q, n, &nm, best_m)) return 0;
+    if (used_out) *used_out = 1;
+  } else {
+    double best_med = INFINITY;
+    int best_h = -1;
+    double* errs = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int h = 0; h < R_HYP; ++h) {
+      int idx[8];
+      uint64_t st = sm64(seed ^ ((uint64_t)h * 0xD1B54A32D192ED03ull));
+      for (int j = 0; j < s; ++j)
+        for (;;) {
+          st = sm64(st);
+          int c = (int)(st % (uint64_t)n), dup = 0;
+          for (int t = 0; t < j; ++t) dup |= idx[t] == c;
+          if (!dup) {
+            idx[j] = c;
+            break;
+          }
+        }
+      double m[12];
+      memset(m, 0, sizeof(m));
+      if (!solve_model(model, p, q, idx, &nm, m)) continue;
+      for (int i = 0; i < n; ++i) {
+        double e;
+        errs[i] = (model_err(model, m, p, q, i, &e) && e == e) ? e : INFINITY;
+      }
+      qsort(errs, (size_t)n, sizeof(double), cmp_double);
+      double med = errs[n / 2];
+      if (med < best_med) { /* strict: the lowest index wins ties */
+        best_med = med;
+        best_h = h;
+        memcpy(best_m, m, sizeof(m));
+      }
+    }
+    free(errs);
+    if (used_out) *used_out = R_HYP;
+    if (best_h < 0 || !(best_med < INFINITY)) return 0;
+    double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / (double)(n - s > 0 ? n - s : 1)) * sqrt(best_med);
+    double radius = sigma > threshold ? sigma : threshold;
+    thr2 = radius * radius;
+  }
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    double e;
+    int in = (model_err(model, best_m, p, q, i, &e) && e <= thr2) ? 1 : 0;
+    if (mask) mask[i] = (uint8_t)in;
+    cnt += in;
+  }
+  for (int k = 0; k < ms; ++k) model_out[k] = best_m[k];
+  if (model == 4 && !project_essential(model_out)) {
+    memset(model_out, 0, 12 * sizeof(double));
+    if (mask) memset(mask, 0, (size_t)n);
+    return 0;
+  }
+  return cnt;
 }
 
 /* Midpoint triangulation (GSLAM::Estimator::trianglate, Estimator.h:164-168): the point of the reference frame closest

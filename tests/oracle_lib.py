@@ -525,6 +525,17 @@ def _ransac_methods(cls):
                                           C.c_uint64(seed), _ptr(m), _ptr(mask), C.byref(used))
         return m, mask[:n].copy(), cnt, used.value
 
+    def estimate_ex(self, model, src, dst, threshold, sampling, confidence=1.0, seed=1):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        dst = np.ascontiguousarray(dst, dtype=np.float64)
+        n = src.shape[0]
+        m = np.zeros(12)
+        mask = np.zeros(max(n, 1), np.uint8)
+        used = C.c_int()
+        cnt = self.lib.oracle_estimate_ex(int(model), _ptr(src), _ptr(dst), n, C.c_double(threshold), C.c_double(confidence),
+                                          C.c_uint64(seed), int(sampling), _ptr(m), _ptr(mask), C.byref(used))
+        return m, mask[:n].copy(), cnt, used.value
+
     def triangulate(self, pose, d1, d2):
         out = np.zeros(3)
         ok = self.lib.oracle_triangulate(_ptr(np.ascontiguousarray(pose, dtype=np.float64)),
@@ -534,6 +545,7 @@ def _ransac_methods(cls):
 
     cls.ransac = ransac
     cls.ransac_conf = ransac_conf
+    cls.estimate_ex = estimate_ex
     cls.triangulate = triangulate
 
 

@@ -295,6 +295,18 @@ def test_estimator_plugin_through_estimator_create(tmp_path, oracle, model):
     em, emask, ecnt, _ = oracle.ransac_conf(model, P, Q, thr, 0.99, seed=1)  # the host passes confidence 0.99
     ms = 6 if model == 1 else 9
     assert ok == 1 and nm == n and np.array_equal(mask, emask) and m[:ms].tobytes() == em[:ms].tobytes()
+    # the sampling flags of EstimatorMethod (Estimator.h:86-89) through the same virtuals: `X | NOSAMPLE`, bare `LMEDS`
+    o = 8 + 72 + nm
+    for sampling in (2, 1):
+        ok2, nm2 = struct.unpack_from("2i", raw, o)
+        m2 = np.frombuffer(raw, np.float64, 9, o + 8)
+        mask2 = np.frombuffer(raw, np.uint8, nm2, o + 80)
+        o += 80 + nm2
+        if sampling == 1 and model == 2:  # LMEDS == F8_Point: findFundamental cannot be asked for it through `method`
+            assert ok2 == 0
+            continue
+        xm, xmask, xcnt, _ = oracle.estimate_ex(model, P, Q, thr, sampling, confidence=0.99, seed=1)
+        assert ok2 == 1 and nm2 == n and np.array_equal(mask2, xmask) and m2[:ms].tobytes() == xm[:ms].tobytes(), sampling
 
 
 @pytest.mark.parametrize("model", [4, 5, 6, 7, 8])

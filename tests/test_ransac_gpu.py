@@ -111,3 +111,28 @@ def test_ransac_confidence_bit_exact_vs_oracle(ctx, oracle, model, thr, n, noise
         assert (gcnt, gused) == (ecnt, eused) and np.array_equal(gmask, emask) and gm.tobytes() == em.tobytes()
         used_all.append(gused)
     assert used_all[-1] == used_all[-2] == 2048 and used_all[0] < 2048
+
+
+@pytest.mark.parametrize("sampling", [1, 2])
+def test_lmeds_and_nosample_bit_exact_vs_oracle(ctx, oracle, sampling):
+    """gh_ransac_estimate_ex with GSLAM::EstimatorMethod's LMEDS / NOSAMPLE flags (Estimator.h:86-89), all eight models:
+    model doubles, inlier masks and counts identical to the oracle's.  LMedS: the exact radix-select median per hypothesis
+    on the GPU vs qsort on the CPU; NOSAMPLE: the sums run in index order on both sides."""
+    from gslam_amd import estimator
+    from test_ransac_oracle import _all_model_cases
+    for model, P, Q, thr, inl in _all_model_cases():
+        for t in ((0.0, thr) if sampling == 1 else (thr,)):
+            em, emask, ecnt, eused = oracle.estimate_ex(model, P, Q, t, sampling, seed=3)
+            gm, gmask, gcnt, gused = estimator.estimate_ex(ctx, model, P, Q, t, sampling, seed=3)
+            assert (gcnt, gused) == (ecnt, eused) and np.array_equal(gmask, emask), (model, t, gcnt, ecnt)
+            assert gm.tobytes() == em.tobytes(), (model, gm, em)
+            assert ecnt > 100
+    # odd / even counts and undefined errors in the median (a homography that sends points to infinity), tiny inputs
+    rng = np.random.default_rng(9)
+    for n in (9, 10, 257, 1000):
+        P, Q, _, _ = _corr(0, n, 0.3, 500 + n, 0.3)
+        em, emask, ecnt, _ = oracle.estimate_ex(0, P, Q, 0.5, sampling, seed=11)
+        gm, gmask, gcnt, _ = estimator.estimate_ex(ctx, 0, P, Q, 0.5, sampling, seed=11)
+        assert gcnt == ecnt and np.array_equal(gmask, emask) and gm.tobytes() == em.tobytes(), n
+    m, mask, cnt, used = estimator.estimate_ex(ctx, 0, np.zeros((3, 2)), np.zeros((3, 2)), 1.0, sampling)
+    assert cnt == 0 and not m.any()

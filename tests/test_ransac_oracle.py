@@ -192,3 +192,81 @@ def test_confidence_is_the_sequential_adaptive_stopping_rule(oracle):
             assert used >= min(max(need, 1), 2048)  # the walk never stops before the rule holds for its winner
             assert mask.sum() == cnt
         assert prev_used < 2048 or cnt_full / len(P) < 0.3  # a 65 % inlier set never needs all 2048 draws of 4 / 3 points
+
+
+# ---------------------------------------------------------------- LMEDS and NOSAMPLE (GSLAM/core/Estimator.h:86-89)
+def _all_model_cases():
+    """(model, src, dst, threshold, inlier flags) for the eight models, 25-30 % outliers."""
+    out = []
+    for model, thr, noise in ((0, 2.0, 0.3), (1, 2.0, 0.3), (3, 0.05, 0.005), (2, 1.0, 0.2)):
+        P, Q, inl, _ = _corr(model, 600, 0.28, 40 + model, noise)
+        out.append((model, P, Q, thr, inl))
+    p1, p2, inl, _ = _two_view(600, 0.25, 33, 0.0005)
+    out.append((4, p1, p2, 0.002, inl))
+    rng = np.random.default_rng(17)
+    n = 600
+    bad = rng.random(n) < 0.3
+    A = rng.uniform(-4, 4, (n, 3))
+    B = 1.7 * A @ _rot([1, 2, 3], 0.7).T + np.array([1.0, -2.0, 0.5]) + rng.normal(size=(n, 3)) * 0.002
+    B[bad] += rng.uniform(0.5, 2, (int(bad.sum()), 3))
+    out.append((5, A, B, 0.02, ~bad))
+    nrm = np.array([0.2, -0.3, 0.93]); nrm /= np.linalg.norm(nrm)
+    P = rng.uniform(-5, 5, (n, 3))
+    P -= np.outer(P @ nrm + 1.5, nrm)
+    P += np.outer(rng.normal(size=n) * 0.002, nrm)
+    P[bad] += np.outer(rng.uniform(0.2, 2, int(bad.sum())) * rng.choice([-1, 1], int(bad.sum())), nrm)
+    out.append((6, P, P, 0.01, ~bad))
+    X = np.c_[rng.uniform(-3, 3, (n, 2)), rng.uniform(-1, 1, n)]
+    Xc = X @ _rot([0.3, -1, 0.2], 0.4).T + np.array([0.2, -0.1, 6.0])
+    uv = Xc[:, :2] / Xc[:, 2:3] + rng.normal(size=(n, 2)) * 0.0003
+    uv[bad] += rng.uniform(0.03, 0.2, (int(bad.sum()), 2))
+    out.append((7, X, uv, 0.003, ~bad))
+    return out
+
+
+def test_lmeds_needs_no_threshold_and_finds_the_inliers(oracle):
+    """Least median of squares: with under half of the correspondences wrong, the hypothesis of smallest median error is a
+    clean one and the robust sigma rule separates the two populations -- with threshold 0 (none given)."""
+    for model, P, Q, thr, inl in _all_model_cases():
+        m, mask, cnt, used = oracle.estimate_ex(model, P, Q, 0.0, 1)
+        assert used == 2048 and cnt == mask.sum()
+        assert cnt >= 0.85 * inl.sum(), (model, cnt, inl.sum())
+        assert (mask.astype(bool) & ~inl).sum() <= 0.03 * len(inl), model
+        # a threshold above the robust sigma widens the mask and never shrinks it
+        m2, mask2, cnt2, _ = oracle.estimate_ex(model, P, Q, 10 * thr, 1)
+        assert m2.tobytes() == m.tobytes() and cnt2 >= cnt and not (mask.astype(bool) & ~mask2.astype(bool)).any()
+    # more than half outliers: the median is an outlier error, LMedS is not the tool (RANSAC still is)
+    P, Q, inl, _ = _corr(0, 600, 0.6, 5, 0.3)
+    _, mask, cnt, _ = oracle.estimate_ex(0, P, Q, 0.0, 1)
+    _, rmask, rcnt = oracle.ransac(0, P, Q, 2.0)
+    assert rcnt >= 0.9 * inl.sum()
+
+
+def test_nosample_is_the_least_squares_fit_of_all_points(oracle):
+    """NOSAMPLE on clean data (noise, no outliers) recovers the generating model at least as well as a minimal sample; on the
+    exact minimal number of points it reproduces the minimal solver's model; outliers pull it away (that is what it is)."""
+    clean = []
+    for model, thr, noise in ((0, 2.0, 0.3), (1, 2.0, 0.3), (3, 0.05, 0.005)):
+        P, Q, inl, truth = _corr(model, 400, 0.0, 70 + model, noise)
+        m, mask, cnt, used = oracle.estimate_ex(model, P, Q, thr, 2)
+        assert used == 1 and cnt == mask.sum() and cnt >= 0.99 * len(P)
+        assert np.allclose(m[:len(truth)], truth, rtol=2e-3, atol=0.15), model
+        rm, _, _ = oracle.ransac(model, P, Q, thr)
+        assert np.abs(m[:len(truth)] - truth).max() <= np.abs(rm[:len(truth)] - truth).max() + 1e-12
+        clean.append((model, P, Q, thr))
+    for model, P, Q, thr, inl in _all_model_cases():
+        Pi, Qi = P[inl], Q[inl]
+        m, mask, cnt, used = oracle.estimate_ex(model, Pi, Qi, thr, 2)
+        assert used == 1 and cnt >= 0.9 * len(Pi), (model, cnt, len(Pi))
+        mo, masko, cnto, _ = oracle.estimate_ex(model, P, Q, thr, 2)  # with the outliers in: a worse fit
+        assert cnto < cnt
+    # exactly the minimal sample: the same model as the minimal solver up to rounding (H: 4 pairs)
+    rng = np.random.default_rng(1)
+    P = rng.uniform(0, 100, (4, 2))
+    H = np.array([[1.05, 0.02, 3.0], [-0.03, 0.97, -2.0], [1e-4, 2e-4, 1.0]])
+    ph = np.c_[P, np.ones(4)] @ H.T
+    Q = ph[:, :2] / ph[:, 2:3]
+    m, mask, cnt, _ = oracle.estimate_ex(0, P, Q, 1e-6, 2)
+    assert cnt == 4 and np.allclose(m[:9], H.reshape(-1), atol=1e-7)
+    m, _, cnt, used = oracle.estimate_ex(0, P[:3], Q[:3], 1.0, 2)  # fewer points than unknowns: no model
+    assert cnt == 0 and used == 0 and not m.any()
