@@ -15,8 +15,8 @@
 //                                           invDepthObserves, :106-111,152-153,160) or pose-graph edges TOGETHER with
 //                                           point observations: the general solver (SIM3 keyframes, both landmark kinds)
 //                                           and every graph with observations under PROJECTION_SPHERE
-// Still `return false` ("unsupported", as the interface allows): camera self-calibration, magin(); optimizePnP /
-// optimizePose under the sphere projection.
+// Still `return false` ("unsupported", as the interface allows): camera self-calibration, magin().
+// (optimizePnP / optimizePose under PROJECTION_SPHERE go through the general graph solver: optimizePnPSphere.)
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
 #include <GSLAM/core/Optimizer.h>
@@ -357,14 +357,23 @@ class OptimizerHIP : public GSLAM::Optimizer {
   bool optimizePose(std::vector<std::pair<GSLAM::CameraAnchor, GSLAM::CameraAnchor> >& matches,
                     std::vector<GSLAM::IdepthEstimation>& firstIDepth, GSLAM::SE3& relativePose,
                     GSLAM::KeyFrameEstimzationDOF dof = GSLAM::UPDATE_KF_SE3, double* information = NULL) override {
-    if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
     if (matches.size() != firstIDepth.size() || !context()) return false;
+    const bool sphere = _config.cameraProjectionType == GSLAM::PROJECTION_SPHERE;
     std::vector<std::pair<GSLAM::Point3d, GSLAM::CameraAnchor> > m3d;
     for (size_t k = 0; k < matches.size(); ++k) {
-      const double rho = firstIDepth[k].x, z1 = matches[k].first.z;
+      const GSLAM::CameraAnchor& a = matches[k].first;
+      const double rho = firstIDepth[k].x;
+      if (sphere) {  // the anchor is a bearing, the inverse depth an inverse RANGE (Optimizer.h:58-61,102-103)
+        const double an = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+        if (!(rho > 0) || !(an > 0)) continue;
+        const double d = 1.0 / (rho * an);
+        m3d.push_back(std::make_pair(GSLAM::Point3d(a.x * d, a.y * d, a.z * d), matches[k].second));
+        continue;
+      }
+      const double z1 = a.z;
       if (!(rho > 0) || !(z1 > 0)) continue;
       const double d = 1.0 / (rho * z1);  // the anchor is on the z = 1 plane after division by its z
-      m3d.push_back(std::make_pair(GSLAM::Point3d(matches[k].first.x * d, matches[k].first.y * d, 1.0 / rho), matches[k].second));
+      m3d.push_back(std::make_pair(GSLAM::Point3d(a.x * d, a.y * d, 1.0 / rho), matches[k].second));
     }
     if (m3d.size() < 3) return false;
     return optimizePnP(m3d, relativePose, dof, information);
@@ -397,8 +406,8 @@ class OptimizerHIP : public GSLAM::Optimizer {
 
   bool optimizePnP(const std::vector<std::pair<GSLAM::Point3d, GSLAM::CameraAnchor> >& matches, GSLAM::SE3& pose,
                    GSLAM::KeyFrameEstimzationDOF dof = GSLAM::UPDATE_KF_SE3, double* information = NULL) override {
-    if (_config.cameraProjectionType != GSLAM::PROJECTION_PINHOLE) return unsupported("sphere projection");
     if (matches.empty() || !context()) return false;
+    if (_config.cameraProjectionType == GSLAM::PROJECTION_SPHERE) return optimizePnPSphere(matches, pose, dof, information);
     const size_t n = matches.size();
     std::vector<double> X(n * 3), m(n * 2);
     for (size_t k = 0; k < n; ++k) {
@@ -429,6 +438,89 @@ class OptimizerHIP : public GSLAM::Optimizer {
   }
 
  private:
+  // optimizePnP under PROJECTION_SPHERE (Optimizer.h:58-61,174-176,202-207): the measurements are bearings, the residual of
+  // a match is the predicted bearing in the tangent plane of the measured one.  That is the observation model of the general
+  // graph solver (gh_graph_solve, projection = 1), so the problem goes there as ONE free keyframe observing n fixed map
+  // points.  information (6 x 6, row-major, [t r] order of the dof bits): sum of J^T J of the tangent-plane residuals at the
+  // solution w.r.t. the right-multiplicative update T_wc <- T_wc exp(delta), by central differences on the host (n x 12
+  // evaluations of a 3-vector), rows / columns of masked dof zero.
+  bool optimizePnPSphere(const std::vector<std::pair<GSLAM::Point3d, GSLAM::CameraAnchor> >& matches, GSLAM::SE3& pose,
+                         GSLAM::KeyFrameEstimzationDOF dof, double* information) {
+    const size_t n = matches.size();
+    std::vector<double> xyz(n * 3), bearing(n * 3);
+    std::vector<uint8_t> xfree(n, 0);
+    std::vector<int32_t> okind(n, 0), opoint(n), oframe(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+      const GSLAM::Point3d& m = matches[k].second;
+      const double mn = std::sqrt(m.x * m.x + m.y * m.y + m.z * m.z);
+      if (!(mn > 0)) {
+        LOG(ERROR) << "OptimizerHIP: match " << k << " has a zero bearing";
+        return false;
+      }
+      xyz[3 * k] = matches[k].first.x; xyz[3 * k + 1] = matches[k].first.y; xyz[3 * k + 2] = matches[k].first.z;
+      bearing[3 * k] = m.x / mn; bearing[3 * k + 1] = m.y / mn; bearing[3 * k + 2] = m.z / mn;
+      opoint[k] = (int32_t)k;
+    }
+    double frame[8];
+    put_sim3(GSLAM::SIM3(pose, 1.0), frame);
+    int32_t fdof = (int32_t)dof & GH_KF_SE3;
+    gh_graph_problem gp;
+    std::memset(&gp, 0, sizeof(gp));
+    gp.pg.n_frames = 1;
+    gp.pg.frame_sim3 = frame;
+    gp.pg.frame_dof = &fdof;
+    gp.n_xyz = (int32_t)n; gp.xyz = xyz.data(); gp.xyz_free = xfree.data();
+    gp.n_obs = (int32_t)n; gp.obs_kind = okind.data(); gp.obs_point = opoint.data(); gp.obs_frame = oframe.data();
+    gp.projection = 1;
+    gp.obs_bearing = bearing.data();
+    gh_ba_options o;
+    gh_ba_default_options(&o);
+    o.huber_delta = _config.projectErrorHuberThreshold;
+    o.max_iterations = _config.maxIterations;
+    gh_ba_summary s;
+    gh_status st;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      st = gh_graph_solve(ctx_, &gp, &o, &s);
+    }
+    if (st != GH_OK && st != GH_ERR_NUMERIC) {  // (GH_ERR_NUMERIC: the start was the optimum already, the pose is valid)
+      LOG(ERROR) << "OptimizerHIP: sphere PnP failed (" << st << "): " << gh_last_error(ctx_);
+      return false;
+    }
+    pose = GSLAM::SE3(GSLAM::SO3(frame[0], frame[1], frame[2], frame[3]), GSLAM::Point3d(frame[4], frame[5], frame[6]));
+    if (information) {
+      for (int i = 0; i < 36; ++i) information[i] = 0.0;
+      const double h = 1e-6;
+      for (size_t k = 0; k < n; ++k) {
+        const GSLAM::Point3d X = matches[k].first, b(bearing[3 * k], bearing[3 * k + 1], bearing[3 * k + 2]);
+        // an orthonormal basis of the tangent plane at b (J^T J does not depend on which)
+        GSLAM::Point3d e1 = std::fabs(b.x) < 0.9 ? GSLAM::Point3d(1, 0, 0) : GSLAM::Point3d(0, 1, 0);
+        e1 = e1 - b * (e1.x * b.x + e1.y * b.y + e1.z * b.z);
+        e1 = e1 / std::sqrt(e1.x * e1.x + e1.y * e1.y + e1.z * e1.z);
+        const GSLAM::Point3d e2(b.y * e1.z - b.z * e1.y, b.z * e1.x - b.x * e1.z, b.x * e1.y - b.y * e1.x);
+        double J[2][6];
+        for (int c = 0; c < 6; ++c) {
+          double r[2][2];
+          for (int sgn = 0; sgn < 2; ++sgn) {
+            GSLAM::Vector<double, 6> d;
+            for (int e = 0; e < 6; ++e) d[e] = 0.0;
+            d[c] = sgn == 0 ? h : -h;
+            const GSLAM::Point3d Xc = (pose * GSLAM::SE3::exp(d)).inverse() * X;
+            const double xn = std::sqrt(Xc.x * Xc.x + Xc.y * Xc.y + Xc.z * Xc.z);
+            const GSLAM::Point3d u = Xc / xn;
+            r[sgn][0] = e1.x * u.x + e1.y * u.y + e1.z * u.z;
+            r[sgn][1] = e2.x * u.x + e2.y * u.y + e2.z * u.z;
+          }
+          J[0][c] = (((int)dof >> c) & 1) ? (r[0][0] - r[1][0]) / (2 * h) : 0.0;
+          J[1][c] = (((int)dof >> c) & 1) ? (r[0][1] - r[1][1]) / (2 * h) : 0.0;
+        }
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 6; ++c) information[6 * a + c] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
+      }
+    }
+    return true;
+  }
+
   static void put_sim3(const GSLAM::SIM3& T, double* p) {
     const GSLAM::SO3 r = T.get_rotation();
     const GSLAM::Point3d t = T.get_translation();

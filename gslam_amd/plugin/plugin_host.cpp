@@ -310,18 +310,22 @@ static int run_align(const std::string& dir, const char* in, const char* out) {
   return ok1 && ok2 && ok3 ? 0 : 3;
 }
 
-static int run_pnp(const std::string& dir, const char* in, const char* out) {
+// sphere != 0: the measurements are 3-vectors (bearings, any length) and the optimiser runs under PROJECTION_SPHERE
+static int run_pnp(const std::string& dir, const char* in, const char* out, int sphere = 0) {
   svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
   std::ifstream f(in, std::ios::binary);
   int32_t n;
   f.read((char*)&n, 4);
-  std::vector<double> X = read_vec<double>(f, (size_t)n * 3), m = read_vec<double>(f, (size_t)n * 2),
+  const int md = sphere ? 3 : 2;
+  std::vector<double> X = read_vec<double>(f, (size_t)n * 3), m = read_vec<double>(f, (size_t)n * md),
                       p = read_vec<double>(f, 7);
   OptimizerPtr opt_ptr = Optimizer::create();
   if (!opt_ptr) return 2;
+  if (sphere) opt_ptr->_config.cameraProjectionType = PROJECTION_SPHERE;
   std::vector<std::pair<Point3d, CameraAnchor> > matches(n);
   for (int k = 0; k < n; ++k)
-    matches[k] = std::make_pair(Point3d(X[3 * k], X[3 * k + 1], X[3 * k + 2]), Point3d(m[2 * k], m[2 * k + 1], 1.0));
+    matches[k] = std::make_pair(Point3d(X[3 * k], X[3 * k + 1], X[3 * k + 2]),
+                                sphere ? Point3d(m[3 * k], m[3 * k + 1], m[3 * k + 2]) : Point3d(m[2 * k], m[2 * k + 1], 1.0));
   SE3 pose(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]));
   double info[36];
   const bool ok = opt_ptr->optimizePnP(matches, pose, UPDATE_KF_SE3, info);
@@ -835,7 +839,7 @@ int main(int argc, char** argv) {
   const std::string mode = argv[1], dir = argv[2];
   if (mode == "ba" && argc >= 5)
     return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
-  if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4]);
+  if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4], argc >= 6 ? atoi(argv[5]) : 0);
   if (mode == "pg" && argc >= 5) return run_pg(dir, argv[3], argv[4]);
   if (mode == "align" && argc >= 5) return run_align(dir, argv[3], argv[4]);
   if (mode == "est" && argc >= 8) return run_est(dir, atoi(argv[3]), atoi(argv[4]), argv[5], atof(argv[6]), argv[7]);

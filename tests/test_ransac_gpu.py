@@ -126,7 +126,12 @@ def test_lmeds_and_nosample_bit_exact_vs_oracle(ctx, oracle, sampling):
             gm, gmask, gcnt, gused = estimator.estimate_ex(ctx, model, P, Q, t, sampling, seed=3)
             assert (gcnt, gused) == (ecnt, eused) and np.array_equal(gmask, emask), (model, t, gcnt, ecnt)
             assert gm.tobytes() == em.tobytes(), (model, gm, em)
-            assert ecnt > 100
+            assert ecnt > 100 or sampling == 2  # (least squares over 28 % outliers may fit nobody within the threshold)
+        if sampling == 2:  # ... and on the inliers alone it fits nearly all of them
+            em, emask, ecnt, _ = oracle.estimate_ex(model, P[inl], Q[inl], thr, 2)
+            gm, gmask, gcnt, _ = estimator.estimate_ex(ctx, model, P[inl], Q[inl], thr, 2)
+            assert gcnt == ecnt and np.array_equal(gmask, emask) and gm.tobytes() == em.tobytes(), model
+            assert ecnt >= 0.9 * inl.sum()
     # odd / even counts and undefined errors in the median (a homography that sends points to infinity), tiny inputs
     rng = np.random.default_rng(9)
     for n in (9, 10, 257, 1000):
