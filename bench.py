@@ -86,8 +86,10 @@ def parse():
     ap.add_argument("--no-range", action="store_true", help="skip the 640x480 / 3840x2160 extraction legs")
     ap.add_argument("--no-all-pairs-full", action="store_true", help="skip the 499 500-frame-pair all-pairs matching leg")
     ap.add_argument("--match-overlap", action="store_true",
-                    help="N = 1: run the timed steps with the matcher on a side stream under the next step's extraction (measured "
-                         "either way in extra.bf_match.overlap: it hides 0.03 of 0.70 ms -- the two kernels compete for the same CUs)")
+                    help="N = 1: run the timed steps with the matcher on a side stream under the next step's extraction and report the "
+                         "A/B against the serial schedule in extra.bf_match.overlap (measured: it hides 0.01-0.05 of 0.70 ms -- the two "
+                         "kernels compete for the same CUs: profiles/BENCH_r04_n1.json).  Off by default: the extra stream would also "
+                         "take a hardware queue away from the host-fed leg's copy streams")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: exchange through torch.distributed instead of the C-ABI communicator (gh_comm_*)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="bounded CPU sample (frames; 1000 = the whole C2 step, ~10 s on 16 cores)")
@@ -200,7 +202,7 @@ def main():
     overlap = world == 1 and a.match_overlap
     bufs = [(kps, desc, counts)]
     step_no = [0]
-    if world == 1:
+    if overlap:
         bufs.append(ex.alloc_outputs(F, dev))
         side = torch.cuda.Stream(device=dev)
         ctx_side = hip.Context(local_rank, stream=side.cuda_stream)
@@ -272,7 +274,7 @@ def main():
         ctx_side.prof_enable(False)
     last_out = bufs[(step_no[0] - 1) & 1] if overlap else bufs[0]  # the output set of the last timed step (in-run parity)
     match_overlap = None
-    if world == 1:
+    if overlap:
         # what a side stream would hide: the same steps with the matcher on the launch stream after the extraction and with
         # the matcher of step i on a side stream under the extraction of step i + 1
         def timed(fn, n):
@@ -496,16 +498,20 @@ def main():
             if rec and int(rec.get("frames_per_launch", 0)) == F:
                 insts = rec["SQ_INSTS_VALU_per_launch"]
                 info0 = ctx.device_info()
-                peak_issue = probes["fast_cells mix"]
+                half = probes["fast_cells mix"]  # perm / pk_max / pk_min / max3 / min3 / dot4 / alignbyte: the 4.2-clock class
+                full = max(v for k, v in probes.items() if isinstance(v, float))  # the fastest probed class (and / or / sub / fp32: ~2.5 clocks)
                 simd_clk = info0["cu_count"] * 4 * info0["clock_khz"] * 1e3
+                ach = insts / (avg_ms * 1e-3)
                 roofline["valu_issue"] = {"wave_insts_per_launch": int(insts),
                                           "wave_insts_source": "profiles/sq_counters.json (SQ_INSTS_VALU, separate --pmc pass)",
-                                          "achieved_Ginst_per_s": round(insts / (avg_ms * 1e-3) / 1e9, 1),
-                                          "peak_Ginst_per_s": round(peak_issue / 1e9, 1),
-                                          "peak_source": "measured in this run: perm / pk_max / pk_min / max3 / min3 / dot4 / "
-                                                         "alignbyte / add interleaved, 8 waves per SIMD",
-                                          "frac": round(insts / (avg_ms * 1e-3) / peak_issue, 3),
-                                          "clk_per_wave_inst_at_reported_clock": round(simd_clk / peak_issue, 2)}
+                                          "achieved_Ginst_per_s": round(ach / 1e9, 1),
+                                          "half_rate_class_ceiling_Ginst_per_s": round(half / 1e9, 1),
+                                          "full_rate_class_ceiling_Ginst_per_s": round(full / 1e9, 1),
+                                          "ceilings_source": "measured in this run (gh_valu_issue_probe, register-only chains, 8 waves per SIMD)",
+                                          "clk_per_wave_inst_at_reported_clock": round(simd_clk / ach, 2),
+                                          "note": "since round 4 the kernel mixes both classes (SWAR pass 1 is and / or / sub / v_bitop3): the "
+                                                  "achieved rate lies between the two ceilings; SQ counters put the VALU pipe at ~92 % "
+                                                  "(profiles/orb_pass1_counters_r04.txt)"}
         except Exception:
             pass
     orb_ms = sum(v["total_ms"] for v in orb_k.values())

@@ -502,10 +502,12 @@ class OptimizerHIP : public GSLAM::Optimizer {
         for (int c = 0; c < 6; ++c) {
           double r[2][2];
           for (int sgn = 0; sgn < 2; ++sgn) {
-            GSLAM::Vector<double, 6> d;
-            for (int e = 0; e < 6; ++e) d[e] = 0.0;
-            d[c] = sgn == 0 ? h : -h;
-            const GSLAM::Point3d Xc = (pose * GSLAM::SE3::exp(d)).inverse() * X;
+            // exp(delta) for a delta along one axis: a pure translation (c < 3) or a pure rotation (the reference's SE3::exp
+            // divides by the rotation angle, which is zero for the former)
+            GSLAM::Point3d axis(0, 0, 0);
+            (c % 3 == 0 ? axis.x : (c % 3 == 1 ? axis.y : axis.z)) = sgn == 0 ? h : -h;
+            const GSLAM::SE3 step = c < 3 ? GSLAM::SE3(GSLAM::SO3(), axis) : GSLAM::SE3(GSLAM::SO3::exp(axis), GSLAM::Point3d(0, 0, 0));
+            const GSLAM::Point3d Xc = (pose * step).inverse() * X;
             const double xn = std::sqrt(Xc.x * Xc.x + Xc.y * Xc.y + Xc.z * Xc.z);
             const GSLAM::Point3d u = Xc / xn;
             r[sgn][0] = e1.x * u.x + e1.y * u.y + e1.z * u.z;

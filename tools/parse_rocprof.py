@@ -20,7 +20,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "select_kernel": "orb_select",
-         "describe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "synth_kernel": "synth_frames",
+         "describe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "bf_match_pairs_mfma_kernel": "bf_match_pairs_mfma", "synth_kernel": "synth_frames",
          "syrk_mfma_kernel": "ba_syrk", "panel_step_kernel": "ba_panel_step", "potf2_inv_kernel": "ba_potf2", "trsm_inv_kernel": "ba_trsm",
          "schur_blocks_kernel": "ba_schur_blocks", "schur_reduce_kernel": "ba_schur_reduce",
          "lin_kernel": "ba_lin", "lin_cams_reduce_kernel": "ba_lin_cams_reduce",
@@ -43,7 +43,7 @@ def newest(paths):
 # Kernels launched on ONE shape per step: dispatches of any other grid (e.g. the all-pairs stress launches of the matcher,
 # 8x the work of a step launch) are left out instead of being averaged in.  orb_fast_cells is launched once per pyramid
 # level (8 shapes per step): its per-launch figure is the average over all of them, like its duration.
-SINGLE_SHAPE = {"bf_match_pairs", "orb_select", "orb_describe"}
+SINGLE_SHAPE = {"bf_match_pairs", "bf_match_pairs_mfma", "orb_select", "orb_describe"}
 
 
 def counters(pattern, counter):
