@@ -383,3 +383,44 @@ def test_blocked_cholesky_eight_wave_tiles_are_bit_identical(ctx, n, pad, monkey
     L0 = torch.triu(a[:, :n])
     assert info.value == 0 and float((L0 - out["1"][0]).abs().max()) <= 1e-12 * float(L0.abs().max())
     assert float((x - out["1"][1]).abs().max()) <= 1e-11 * float(x.abs().max())
+
+
+@pytest.mark.parametrize("n", [8256, 8300, 16421])
+def test_rhs_row_path_at_large_n_matches_the_plain_paths(ctx, n, monkeypatch):
+    """gh_potrf_solve_dev with lda > n carries the right-hand side through the factorisation as row n of A (include/gslam_hip.h:
+    the padding rows are scratch then).  Beyond n = 8192 the backward pass runs in segments, from n = 16384 the panels take
+    blocks in pairs (rank-128 updates), n % 64 != 0 leaves a partial last block: each of these against the same call with
+    GSLAM_HIP_CHOL_PAIR=0 / GSLAM_HIP_BWD_CHAIN=0 and against lda == n (forward + backward substitution after the
+    factorisation), plus the residual property."""
+    import ctypes as C
+    import torch
+    from gslam_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(n)
+    M = torch.randn((n, 192), dtype=torch.float64, device="cuda", generator=g)
+    A = M @ M.T
+    A /= 192.0
+    A.diagonal().add_(3.0)
+    b = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    lda = (n + 1 + 15) // 16 * 16
+
+    def solve(with_row):
+        ld = lda if with_row else n
+        buf = torch.zeros((n, ld), dtype=torch.float64, device="cuda")  # column-major n x n inside ld-row columns
+        buf[:, :n] = A  # symmetric: column j of the column-major matrix = row j of the tensor
+        x = b.clone()
+        info = C.c_int()
+        ctx.check(hip.lib.gh_potrf_solve_dev(ctx.h, C.c_void_p(buf.data_ptr()), n, ld, C.c_void_p(x.data_ptr()), C.byref(info)))
+        ctx.sync()
+        assert info.value == 0
+        return x, buf[:, :n].clone()
+
+    x_row, L_row = solve(True)
+    assert float(torch.linalg.norm(A @ x_row - b) / torch.linalg.norm(b)) <= 1e-11
+    x_plain, L_plain = solve(False)
+    assert float((torch.triu(L_row) - torch.triu(L_plain)).abs().max()) == 0.0  # the factor does not depend on who carries b
+    assert float((x_row - x_plain).abs().max() / x_plain.abs().max()) <= 1e-12
+    monkeypatch.setenv("GSLAM_HIP_CHOL_PAIR", "0")
+    monkeypatch.setenv("GSLAM_HIP_BWD_CHAIN", "0")
+    x_ref, L_ref = solve(True)
+    assert float((torch.triu(L_row) - torch.triu(L_ref)).abs().max() / torch.triu(L_ref).abs().max()) <= 1e-12
+    assert float((x_row - x_ref).abs().max() / x_ref.abs().max()) <= 1e-12
