@@ -55,6 +55,21 @@ class FeatureDetector {
     return false;
   }
 
+  // Many frame pairs in one call (a keyframe against its covisible keyframes, loop candidates, an offline all-pairs pass):
+  // descriptors[f] is the N_f x 32 matrix of frame f, pairs[p] = (query frame, train frame); matches[p] as match() returns
+  // them for that pair, under the same configured tests.  The base class loops over match(); an accelerated plugin runs all
+  // pairs as one batch.
+  virtual bool matchBatch(const std::vector<GImage>& descriptors, const std::vector<std::pair<int, int> >& pairs,
+                          std::vector<std::vector<std::pair<int, int> > >& matches) {
+    matches.assign(pairs.size(), std::vector<std::pair<int, int> >());
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      if (pairs[p].first < 0 || pairs[p].second < 0 || pairs[p].first >= (int)descriptors.size() || pairs[p].second >= (int)descriptors.size())
+        return false;
+      if (!match(descriptors[pairs[p].first], descriptors[pairs[p].second], matches[p])) return false;
+    }
+    return true;
+  }
+
   // A burst of same-sized images in one call (keyframe burst, stereo pair, offline sequence): the base class loops over
   // detectAndCompute, an accelerated plugin pipelines uploads, extraction and downloads.
   virtual bool detectAndComputeBatch(const std::vector<GImage>& images, std::vector<std::vector<KeyPoint> >& keypoints,

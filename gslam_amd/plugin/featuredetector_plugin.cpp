@@ -169,7 +169,6 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
     if (q.cols * q.elemSize() != 32 || (t.rows > 0 && t.cols * t.elemSize() != 32) || !context()) return false;
     const int nq = q.rows, nt = t.rows;
     if (nq == 0) return true;
-    if (nt > 65535) return false;
     std::vector<int32_t> idx1((size_t)nq), back;
     std::vector<uint16_t> d1((size_t)nq), d2((size_t)nq), bd1, bd2;
     if (gh_bf_match_host(ctx_, q.data, nq, t.data, nt, idx1.data(), d1.data(), d2.data()) != GH_OK)
@@ -189,6 +188,80 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       if (ok) matches.push_back(std::make_pair(i, j));
     }
     if (mask) mask->swap(keep);
+    return true;
+  }
+
+  // All pairs as ONE batched device call: the descriptor matrices go up once as F x cap x 32 (cap = the largest frame), the
+  // forward rows -- and, with cross-checking, the backward rows of the swapped pairs -- come from gh_bf_match_pairs_dev
+  // (which runs the exact MFMA kernel once the batch is large), the configured tests from gh_match_mask_dev.
+  bool matchBatch(const std::vector<GSLAM::GImage>& descriptors, const std::vector<std::pair<int, int> >& pairs,
+                  std::vector<std::vector<std::pair<int, int> > >& matches) override {
+    std::lock_guard<std::mutex> lock(mu_);
+    matches.assign(pairs.size(), std::vector<std::pair<int, int> >());
+    if (pairs.empty()) return true;
+    if (!context()) return false;
+    const int F = (int)descriptors.size(), P = (int)pairs.size();
+    int cap = 1;
+    for (const GSLAM::GImage& d : descriptors) {
+      if (d.rows > 0 && d.cols * d.elemSize() != 32) return false;
+      cap = std::max(cap, d.rows);
+    }
+    if (cap > 65535) return false;  // (frames, not maps: the batched entry keeps 16-bit train indices)
+    cap = (cap + 15) & ~15;
+    const bool cross = _config.matchCrossCheck;
+    const int NP = cross ? 2 * P : P;
+    std::vector<int32_t> counts((size_t)F), pq((size_t)NP), pt((size_t)NP);
+    for (int f = 0; f < F; ++f) counts[f] = descriptors[f].rows;
+    for (int p = 0; p < P; ++p) {
+      if (pairs[p].first < 0 || pairs[p].second < 0 || pairs[p].first >= F || pairs[p].second >= F) return false;
+      pq[p] = pairs[p].first;
+      pt[p] = pairs[p].second;
+      if (cross) {
+        pq[P + p] = pairs[p].second;
+        pt[P + p] = pairs[p].first;
+      }
+    }
+    const size_t desc_b = (size_t)F * cap * 32, cnt_b = ((size_t)F * 4 + 255) & ~(size_t)255, pair_b = ((size_t)NP * 4 + 255) & ~(size_t)255,
+                 idx_b = (size_t)NP * cap * 4, d_b = (size_t)NP * cap * 2, keep_b = ((size_t)P * cap + 255) & ~(size_t)255;
+    const size_t total = desc_b + cnt_b + 2 * pair_b + idx_b + 2 * d_b + keep_b;
+    void* dev = nullptr;
+    if (gh_dev_alloc(ctx_, total, &dev) != GH_OK) return fail("gh_dev_alloc");
+    uint8_t* b = (uint8_t*)dev;
+    uint8_t* d_desc = b;
+    int32_t* d_cnt = (int32_t*)(b + desc_b);
+    int32_t* d_pq = (int32_t*)(b + desc_b + cnt_b);
+    int32_t* d_pt = (int32_t*)(b + desc_b + cnt_b + pair_b);
+    int32_t* d_idx = (int32_t*)(b + desc_b + cnt_b + 2 * pair_b);
+    uint16_t* d_d1 = (uint16_t*)((uint8_t*)d_idx + idx_b);
+    uint16_t* d_d2 = (uint16_t*)((uint8_t*)d_d1 + d_b);
+    uint8_t* d_keep = (uint8_t*)d_d2 + d_b;
+    bool ok = true;
+    {
+      std::vector<uint8_t> host(desc_b, 0);
+      for (int f = 0; f < F; ++f)
+        if (descriptors[f].rows > 0) std::memcpy(&host[(size_t)f * cap * 32], descriptors[f].data, (size_t)descriptors[f].rows * 32);
+      ok = gh_dev_upload(ctx_, d_desc, host.data(), desc_b) == GH_OK && gh_dev_upload(ctx_, d_cnt, counts.data(), (size_t)F * 4) == GH_OK &&
+           gh_dev_upload(ctx_, d_pq, pq.data(), (size_t)NP * 4) == GH_OK && gh_dev_upload(ctx_, d_pt, pt.data(), (size_t)NP * 4) == GH_OK;
+    }
+    ok = ok && gh_bf_match_pairs_dev(ctx_, d_desc, d_cnt, cap, d_pq, d_pt, NP, d_idx, d_d1, d_d2) == GH_OK;
+    for (int p = 0; p < P && ok; ++p) {
+      const int nq = counts[pq[p]], nt = counts[pt[p]];
+      if (nq == 0) continue;
+      ok = gh_match_mask_dev(ctx_, d_idx + (size_t)p * cap, d_d1 + (size_t)p * cap, d_d2 + (size_t)p * cap, nq,
+                             cross ? d_idx + (size_t)(P + p) * cap : NULL, nt, _config.matchMaxDistance, _config.matchRatioNum,
+                             _config.matchRatioDen, cross ? 1 : 0, d_keep + (size_t)p * cap) == GH_OK;
+    }
+    std::vector<int32_t> idx((size_t)P * cap);
+    std::vector<uint8_t> keep((size_t)P * cap);
+    ok = ok && gh_dev_download(ctx_, idx.data(), d_idx, (size_t)P * cap * 4) == GH_OK &&
+         gh_dev_download(ctx_, keep.data(), d_keep, (size_t)P * cap) == GH_OK;
+    gh_dev_free(ctx_, dev);
+    if (!ok) return fail("matchBatch");
+    for (int p = 0; p < P; ++p) {
+      const int nq = counts[pq[p]];
+      for (int i = 0; i < nq; ++i)
+        if (keep[(size_t)p * cap + i]) matches[p].push_back(std::make_pair(i, (int)idx[(size_t)p * cap + i]));
+    }
     return true;
   }
 

@@ -423,8 +423,27 @@ static int run_orb_batch(const std::string& dir, int w, int h, int ch, int n, co
   write_frame_records(o, k1, d1);
   if (okb) write_frame_records(o, k2, d2);
   if (oka) write_frame_records(o, k3, d3);
-  std::cout << "orbbatch single=" << ok << " batch=" << okb << " async=" << oka << " depth=" << det->asyncDepth() << std::endl;
-  return ok && okb && oka ? 0 : 3;
+  // matchBatch: every ordered pair of the frames in ONE call (with and without cross-checking) against match() pair by pair
+  bool okm = ok;
+  size_t n_matches = 0;
+  for (int cc = 0; cc < 2 && okm; ++cc) {
+    det->_config.matchCrossCheck = cc != 0;
+    std::vector<std::pair<int, int> > pairs;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        if (i != j) pairs.push_back(std::make_pair(i, j));
+    std::vector<std::vector<std::pair<int, int> > > mb;
+    okm = det->matchBatch(d1, pairs, mb) && mb.size() == pairs.size();
+    for (size_t p = 0; p < pairs.size() && okm; ++p) {
+      std::vector<std::pair<int, int> > m1;
+      okm = det->match(d1[pairs[p].first], d1[pairs[p].second], m1) && m1 == mb[p];
+      n_matches += m1.size();
+    }
+  }
+  det->_config.matchCrossCheck = false;
+  std::cout << "orbbatch single=" << ok << " batch=" << okb << " async=" << oka << " depth=" << det->asyncDepth()
+            << " matchBatch=" << okm << " (" << n_matches << " matches)" << std::endl;
+  return ok && okb && oka && okm ? 0 : 3;
 }
 
 static void pct(std::vector<double>& v, double* p50, double* p99) {

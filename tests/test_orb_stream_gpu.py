@@ -193,6 +193,7 @@ def test_featuredetector_batch_and_async_entries(tmp_path, oracle):
         r = subprocess.run([host, "orbbatch", libdir, str(w), str(h), str(ch), str(n), str(inp), str(out), str(K)],
                            capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
+        assert "matchBatch=1" in r.stdout  # FeatureDetector::matchBatch (all ordered frame pairs, one device batch) == match() per pair
         raw = open(out, "rb").read()
         ok, okb, oka, nn = struct.unpack("4i", raw[:16])
         assert (ok, okb, oka, nn) == (1, 1, 1, n)
