@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "orb_quadtree.h"
 #include "../../include/gslam_orb_tables.h"
 
 namespace {
@@ -51,22 +52,10 @@ enum {
   kDbgCount = 16
 };
 
-struct LevelView {
-  const uint8_t* base;   // frame 0
-  size_t frame_stride;   // bytes between frames
-  int pitch, w, h;
-};
-
 struct DevTables {
   const int8_t* pattern;        // table mode: [30][256] offset pairs (upload_pattern)
   const int32_t* dir;           // [30][2]
   const int8_t* base_pattern;   // continuous steering: the unrotated tests [256][4] int8
-};
-
-struct SelKp {
-  uint16_t x, y;
-  uint8_t score, level;
-  uint16_t pad;
 };
 
 // XCD-aware work mapping.  Workgroup b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2);
@@ -1309,6 +1298,8 @@ struct gh_orb_plan {
   int8_t* d_base_pattern = nullptr;  // the unrotated tests, 256 x 4 int8 (continuous steering)
   int8_t base_pattern[256 * 4] = {};
   bool base_pattern_fits_table = true;  // every 12-degree rotation stays within +-13 (the 30-bin table exists)
+  int distribution = 0;              // gh_orb_plan_set_distribution: 0 = 32 x 32 cells + rank order, 1 = ORB-SLAM's cells + quadtree
+  gh_qt_plan* qt = nullptr;          // buffers of mode 1 (orb_quadtree.hip)
   int steer = 0;                     // gh_orb_plan_set_steering: 0 = 30 orientation bins, 1 = continuous (fastAtan2 + per-keypoint rotation)
   int32_t* d_dir = nullptr;
   uint32_t* tabs = nullptr;
@@ -1369,6 +1360,7 @@ extern "C" void gh_orb_plan_destroy(gh_orb_plan* p) {
   for (void* q : ptrs)
     if (q) hipFree(q);
   if (p->stage_host) hipHostFree(p->stage_host);
+  gh_qt_destroy(p->qt);
   for (auto* v : {&p->graphs, &p->retired})
     for (auto& g : *v) {
       hipEventSynchronize(g.done);  // (the caller may have moved the context to another stream since the last launch)
@@ -1484,6 +1476,19 @@ extern "C" gh_status gh_orb_plan_set_steering(gh_orb_plan* p, int mode) {
     }
   p->graphs.clear();
   p->retired.clear();
+  return GH_OK;
+}
+
+extern "C" gh_status gh_orb_plan_set_distribution(gh_orb_plan* p, int mode) {
+  if (!p) return GH_ERR_ARG;
+  gh_ctx* ctx = p->ctx;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, mode == 0 || mode == 1);
+  if (mode == 1 && !p->qt) {
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GH_TRY(gh_qt_create(ctx, p->L, p->lw, p->lh, p->quota, p->max_batch, &p->qt, &p->bytes));
+  }
+  p->distribution = mode;
   return GH_OK;
 }
 
@@ -1699,6 +1704,13 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
     return !(e && e[0] == '0');
   }();
   const bool small = (long long)batch * p->w * p->h <= (4LL << 20);  // up to two 1080p frames: launch-bound
+  if (p->distribution != 0) {
+    // quadtree mode: the candidate lists have a budget, and a list that overflowed is an error of THIS call -- it waits for
+    // its own kernels (the mode is the compatibility path, not the throughput path)
+    GH_TRY(orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev));
+    GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return gh_qt_check(ctx, p->qt);
+  }
   if (!(graph_env && small && !p->graphs_off && !ctx->prof_on && !p->dbg_on && ctx->stream != nullptr))
     return orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev);
   for (auto& g : p->graphs)
@@ -1837,7 +1849,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   bool overlap = overlap_env < 0 ? (long long)batch * p->w * p->h >= (16LL << 20) : overlap_env == 1;  // >= 8 frames of 1080p
-  if (p->capturing) overlap = false;  // (a captured call is a small one: one select launch)
+  if (p->capturing || p->distribution != 0) overlap = false;  // (a captured call is a small one: one select launch)
   if (overlap && !p->side) {
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
       p->side = nullptr;
@@ -1859,8 +1871,15 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     const char* e = getenv("GSLAM_HIP_ORB_ALL_LEVELS");
     return !(e && e[0] == '0');
   }();
-  const bool all_levels = all_env && (long long)batch * p->w * p->h <= (4LL << 20);
-  if (all_levels) {
+  const bool quadtree = p->distribution != 0;
+  const bool all_levels = (all_env && (long long)batch * p->w * p->h <= (4LL << 20)) || quadtree;
+  if (quadtree) {
+    // ORB-SLAM's distribution (oracle steps 4', 5'): the whole pyramid first, then cells + tree of orb_quadtree.hip leave sel /
+    // level_cnt as orb_select would
+    for (int l = 1; l < L; ++l) GH_TRY(resize_standalone(l));
+    GH_TRY(gh_qt_enqueue(ctx, p->qt, lv, batch, p->prm.min_th_fast, p->prm.ini_th_fast, p->quota_off, K, p->sel, p->level_cnt));
+    overlap = false;
+  } else if (all_levels) {
     for (int l = 1; l < L; ++l) GH_TRY(resize_standalone(l));
     AllLevels A;
     A.n_levels = L;
@@ -1951,7 +1970,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
   if (overlap) {
     GH_HIP(ctx, hipEventRecord(p->ev_join, p->side));
     GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->ev_join, 0));
-  } else {
+  } else if (!quadtree) {
     GH_TRY(launch_select(0, L));
   }
   if (!cached && dbg) GH_HIP(ctx, hipMemsetAsync(dbg + kDbgSelStreamed, 1, 1, ctx->stream));

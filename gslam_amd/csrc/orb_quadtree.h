@@ -1,0 +1,30 @@
+// Internal interface between orb.hip and orb_quadtree.hip (the ORB-SLAM style keypoint distribution,
+// gh_orb_plan_set_distribution(plan, 1); specification: oracle/orb_oracle.c steps 4' and 5').
+#pragma once
+#include "common.h"
+
+struct LevelView {
+  const uint8_t* base;   // frame 0
+  size_t frame_stride;   // bytes between frames
+  int pitch, w, h;
+};
+
+// one selected keypoint of a level, in level coordinates (select / quadtree -> describe)
+struct SelKp {
+  uint16_t x, y;
+  uint8_t score, level;
+  uint16_t pad;
+};
+
+struct gh_qt_plan;
+
+// Buffers of the quadtree mode for `max_batch` frames of the given pyramid.  *bytes += device bytes allocated.
+gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, const int* quota, int max_batch,
+                       gh_qt_plan** out, size_t* bytes);
+void gh_qt_destroy(gh_qt_plan* q);
+// Steps 4' and 5' for levels 0 .. n_levels-1 of `batch` frames on ctx->stream: sel[b * K + quota_off[l] + i], level_cnt[b * 8 + l]
+// exactly as orb_select leaves them.
+gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int batch, int min_th, int ini_th,
+                        const int* quota_off, int K, SelKp* sel, int32_t* level_cnt);
+// After the stream has drained: GH_ERR_RANGE-style failure if a candidate list overflowed its buffer (never silent).
+gh_status gh_qt_check(gh_ctx* ctx, gh_qt_plan* q);

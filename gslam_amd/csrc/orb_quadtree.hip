@@ -1,0 +1,557 @@
+// ORB-SLAM style keypoint distribution for the ORB front end (gh_orb_plan_set_distribution(plan, 1)): FAST per ~30 x 30
+// cell with the cell's own threshold fallback and non-maximum suppression, then ORBextractor's DistributeOctTree per
+// (frame, level).  Bit-exact with oracle/orb_oracle.c steps 4' and 5', which are the specification (ORB-SLAM's extractor
+// is not part of the reference tree: README.md:131, doc/doxygen/4_1_orbslam.dox:7; the outputs feed the same
+// GSLAM/core/Map.h:122-195 KeyPoint rows as the default mode).
+//
+// CDNA4 mapping.
+//   slam_cells     one workgroup per cell: (cell + 6)^2 bytes in LDS, FAST-9/16 score per pixel, 8-neighbour suppression
+//                  inside the cell, candidates appended to the (frame, level) key list (order is irrelevant: every later
+//                  step is a function of the key SET)
+//   slam_quadtree  one 1024-lane workgroup per (frame, level).  ORB-SLAM's list of nodes becomes a level-synchronous
+//                  table in LDS: a pass = one sweep over the keys counting the four children of every node being split
+//                  (LDS atomics), one block scan that renumbers the table, one sweep that moves the keys.  The "largest
+//                  nodes first until N" stage is a bitonic sort of the candidates + a scan of their gains, so the whole
+//                  tree costs ~2 sweeps per generation instead of a pointer chase.
+#include "orb_quadtree.h"
+
+#include <math.h>
+
+#include <new>
+
+#include "../../include/gslam_orb_tables.h"
+
+namespace {
+
+constexpr int kEdge = GH_ORB_EDGE;
+constexpr int kMaxL = GH_ORB_MAX_LEVELS;
+constexpr int kBorder = kEdge - 3;      // ORB-SLAM's minBorder: the key coordinates of the tree start here
+constexpr int kQtNodes = 2048;          // table capacity: quota + 3 and 4 * roots must fit
+constexpr int kQtThreads = 1024;
+constexpr int kCellMax = 59;            // wCell = ceil(W' / floor(W' / 30)) < 60
+constexpr int kCellPitch = 68;          // (kCellMax + 6) bytes per tile row, padded
+constexpr int kCellList = 30 * 30;      // suppressed maxima of a cell: at most ceil(59 / 2)^2
+
+struct QtLevel {
+  int w, h, quota, quota_off, n_ini;
+  float hx;
+  int ncols, nrows, wc, hc;
+  uint32_t cap;       // key slots of this level per frame
+  size_t key_off;     // first slot of this level inside a frame's block
+};
+
+struct QtArgs {
+  QtLevel lv[kMaxL];
+};
+
+// the radius-3 ring in circular order (== GH_ORB_RING, checked in gh_qt_create)
+struct Ring16 { int dx[16], dy[16]; };
+constexpr Ring16 kRing = {{0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}, {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3}};
+
+// FAST-9/16 score of oracle step 2 at q (tile pitch `pitch`): the largest t such that 9 contiguous ring pixels are all
+// brighter than centre + t - 1 or all darker than centre - t + 1, as max over the 16 arcs of min / -max of the differences.
+__device__ __forceinline__ int fast_score_px(const uint8_t* q, int pitch, int min_th) {
+  const int c = q[0];
+  int d[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[i] = (int)q[kRing.dy[i] * pitch + kRing.dx[i]] - c;
+  // necessary condition (every 9-arc holds at least two of the four compass points): exact, skips most pixels
+  const int nb = (d[0] > min_th) + (d[4] > min_th) + (d[8] > min_th) + (d[12] > min_th);
+  const int nd = (d[0] < -min_th) + (d[4] < -min_th) + (d[8] < -min_th) + (d[12] < -min_th);
+  if (nb < 2 && nd < 2) return 0;
+  int best = 0;
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    int mn = d[a], mx = d[a];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+      mn = min(mn, d[(a + i) & 15]);
+      mx = max(mx, d[(a + i) & 15]);
+    }
+    best = max(best, max(mn, -mx));
+  }
+  return best;
+}
+
+// step 4': one workgroup per cell
+__global__ __launch_bounds__(256) void slam_cells_kernel(LevelView lv, int ncols, int wc, int hc, int min_th, int ini_th,
+                                                         uint32_t* __restrict__ keys, size_t keys_per_frame,
+                                                         uint32_t cap, uint32_t* __restrict__ key_cnt, int level,
+                                                         uint32_t* __restrict__ flags) {
+  __shared__ uint8_t s_img[(kCellMax + 6) * kCellPitch];
+  __shared__ uint8_t s_S[kCellMax * 60];
+  __shared__ uint32_t s_list[kCellList];
+  __shared__ int s_n, s_strong, s_kept, s_base;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int ci = (int)blockIdx.x / ncols, cj = (int)blockIdx.x - ci * ncols;
+  const int x0 = kEdge + cj * wc, y0 = kEdge + ci * hc;
+  const int x1 = min(x0 + wc, lv.w - kEdge), y1 = min(y0 + hc, lv.h - kEdge);
+  const int cw = x1 - x0, ch = y1 - y0;
+  if (cw <= 0 || ch <= 0) return;
+  const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
+  const int tw = cw + 6;
+  for (int idx = tid; idx < (ch + 6) * tw; idx += 256) {
+    const int r = idx / tw, c = idx - r * tw;
+    s_img[r * kCellPitch + c] = img[(size_t)(y0 - 3 + r) * lv.pitch + (x0 - 3 + c)];
+  }
+  if (tid == 0) {
+    s_n = 0;
+    s_strong = 0;
+    s_kept = 0;
+  }
+  __syncthreads();
+  for (int p = tid; p < cw * ch; p += 256) {
+    const int y = p / cw, x = p - y * cw;
+    const int s = fast_score_px(&s_img[(y + 3) * kCellPitch + x + 3], kCellPitch, min_th);
+    s_S[y * 60 + x] = (uint8_t)(s > min_th ? min(s, 255) : 0);
+  }
+  __syncthreads();
+  for (int p = tid; p < cw * ch; p += 256) {
+    const int y = p / cw, x = p - y * cw;
+    const int s = s_S[y * 60 + x];
+    if (s == 0) continue;
+    bool ismax = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = x + dx, yy = y + dy;
+        if ((dx == 0 && dy == 0) || xx < 0 || xx >= cw || yy < 0 || yy >= ch) continue;
+        if ((int)s_S[yy * 60 + xx] >= s) ismax = false;
+      }
+    if (!ismax) continue;
+    s_list[atomicAdd(&s_n, 1)] = ((uint32_t)s << 24) | ((uint32_t)(y0 + y) << 12) | (uint32_t)(x0 + x);
+    if (s > ini_th) s_strong = 1;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const bool strong = s_strong != 0;
+  for (int e = tid; e < n; e += 256)
+    if (!strong || (int)(s_list[e] >> 24) > ini_th) atomicAdd(&s_kept, 1);
+  __syncthreads();
+  if (s_kept == 0) return;
+  if (tid == 0) s_base = (int)atomicAdd(&key_cnt[b * kMaxL + level], (uint32_t)s_kept);
+  __syncthreads();
+  uint32_t* out = keys + (size_t)b * keys_per_frame;
+  for (int e = tid; e < n; e += 256) {
+    const uint32_t v = s_list[e];
+    if (strong && (int)(v >> 24) <= ini_th) continue;
+    const uint32_t slot = (uint32_t)s_base + (uint32_t)atomicAdd(&s_n, 1) - (uint32_t)n;  // (s_n keeps counting past n)
+    if (slot < cap) out[slot] = v;
+    else atomicOr(flags, 1u);  // reported by gh_qt_check: never a silent drop
+  }
+}
+
+// ---- step 5'
+// exclusive scan of one int per thread over the 1024-lane workgroup
+__device__ __forceinline__ int block_scan_1024(int v, int* wave_tot /* shared[16] */, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kQtThreads / 64; ++k) {
+    const int t = wave_tot[k];
+    if (k < wv) off += t;
+    tot += t;
+  }
+  *total = tot;
+  return off + incl - v;
+}
+
+// ascending bitonic sort of kQtNodes values in LDS (every thread of the workgroup calls it)
+template <typename T>
+__device__ __forceinline__ void bitonic_sort_nodes(T* a) {
+  for (int k = 2; k <= kQtNodes; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      const int t = threadIdx.x;                     // pair index: kQtNodes / 2 pairs
+      const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
+      const int p = i | j;
+      const bool up = (i & k) == 0;
+      const T x = a[i], y = a[p];
+      if ((x > y) == up) {
+        a[i] = y;
+        a[p] = x;
+      }
+    }
+  __syncthreads();
+}
+
+struct QtShared {
+  uint32_t box_x[2][kQtNodes];   // x0 | x1 << 16 (region coordinates)
+  uint32_t box_y[2][kQtNodes];
+  uint32_t cnt[2][kQtNodes];     // keys of the node
+  uint8_t fresh[2][kQtNodes];    // created by the last pass
+  uint32_t ccnt[kQtNodes][4];    // keys of the four children of a node being split
+  uint16_t cbase[kQtNodes];      // id of the node (or of its first child) in the next table
+  uint8_t split[kQtNodes];
+  unsigned long long sortbuf[kQtNodes];
+  int wave_tot[16];
+  int cut;
+};
+static_assert(sizeof(QtShared) <= 120 * 1024, "one workgroup per CU: 160 KB of LDS");
+
+__device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, uint32_t key) {
+  const int x0 = (int)(bx & 0xFFFFu), x1 = (int)(bx >> 16), y0 = (int)(by & 0xFFFFu), y1 = (int)(by >> 16);
+  const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
+  const int kx = (int)(key & 0xFFFu) - kBorder, ky = (int)((key >> 12) & 0xFFFu) - kBorder;
+  return (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
+}
+
+__global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, const uint32_t* __restrict__ keys,
+                                                                   uint16_t* __restrict__ knode, size_t keys_per_frame,
+                                                                   const uint32_t* __restrict__ key_cnt, int K,
+                                                                   SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t qt_lds[];
+  QtShared& sh = *reinterpret_cast<QtShared*>(qt_lds);
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const QtLevel L = a.lv[l];
+  const int N = L.quota;
+  const uint32_t m = min(key_cnt[b * kMaxL + l], L.cap);
+  if (N <= 0 || m == 0 || L.cap == 0) {
+    if (tid == 0) level_cnt[b * kMaxL + l] = 0;
+    return;
+  }
+  const uint32_t* kk = keys + (size_t)b * keys_per_frame + L.key_off;
+  uint16_t* kn = knode + (size_t)b * keys_per_frame + L.key_off;
+  const int H2 = L.h - 2 * kBorder;
+  int cur = 0, n_tab = L.n_ini;
+  // roots
+  for (int n = tid; n < kQtNodes; n += kQtThreads) {
+    if (n < L.n_ini) {
+      const int x0 = (int)__fmul_rn(L.hx, (float)n), x1 = (int)__fmul_rn(L.hx, (float)(n + 1));
+      sh.box_x[0][n] = (uint32_t)x0 | ((uint32_t)x1 << 16);
+      sh.box_y[0][n] = (uint32_t)H2 << 16;
+    }
+    sh.cnt[0][n] = 0;
+    sh.fresh[0][n] = 0;
+  }
+  __syncthreads();
+  for (uint32_t k = tid; k < m; k += kQtThreads) {
+    const int kx = (int)(kk[k] & 0xFFFu) - kBorder;
+    int r = (int)__fdiv_rn((float)kx, L.hx);
+    r = min(r, L.n_ini - 1);
+    kn[k] = (uint16_t)r;
+    atomicAdd(&sh.cnt[0][r], 1u);
+  }
+  __syncthreads();
+  int n_nodes = 0;
+  {
+    int mine = 0;
+    for (int n = tid; n < n_tab; n += kQtThreads) mine += sh.cnt[0][n] > 0;
+    block_scan_1024(mine, sh.wave_tot, &n_nodes);
+  }
+  // one pass: the children of every node with split[] set have been counted into ccnt; builds the next table and moves the keys.
+  // Returns the new node count; *made = children holding more than one key.
+  auto rebuild = [&](int* made) -> int {
+    const int nx = cur ^ 1;
+    // thread t owns table rows 2 t and 2 t + 1 (table order = scan order)
+    int c[2] = {0, 0}, e = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = 2 * tid + u;
+      if (n < n_tab) {
+        if (sh.split[n]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            c[u] += sh.ccnt[n][q] > 0;
+            e += sh.ccnt[n][q] > 1;
+          }
+        } else {
+          c[u] = sh.cnt[cur][n] > 0;
+        }
+      }
+    }
+    int total, made_total;
+    const int base = block_scan_1024(c[0] + c[1], sh.wave_tot, &total);
+    block_scan_1024(e, sh.wave_tot, &made_total);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = 2 * tid + u;
+      if (n >= n_tab) continue;
+      int id = base + (u ? c[0] : 0);
+      sh.cbase[n] = (uint16_t)id;
+      const uint32_t bx = sh.box_x[cur][n], by = sh.box_y[cur][n];
+      if (sh.split[n]) {
+        const uint32_t x0 = bx & 0xFFFFu, x1 = bx >> 16, y0 = by & 0xFFFFu, y1 = by >> 16;
+        const uint32_t xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t cc = sh.ccnt[n][q];
+          if (cc == 0) continue;
+          sh.box_x[nx][id] = (q & 1) ? (xm | (x1 << 16)) : (x0 | (xm << 16));
+          sh.box_y[nx][id] = (q & 2) ? (ym | (y1 << 16)) : (y0 | (ym << 16));
+          sh.cnt[nx][id] = cc;
+          sh.fresh[nx][id] = 1;
+          ++id;
+        }
+      } else if (sh.cnt[cur][n] > 0) {
+        sh.box_x[nx][id] = bx;
+        sh.box_y[nx][id] = by;
+        sh.cnt[nx][id] = sh.cnt[cur][n];
+        sh.fresh[nx][id] = 0;
+      }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < m; k += kQtThreads) {
+      const int n = kn[k];
+      int id = sh.cbase[n];
+      if (sh.split[n]) {
+        const int q = qt_quadrant(sh.box_x[cur][n], sh.box_y[cur][n], kk[k]);
+        for (int qq = 0; qq < q; ++qq) id += sh.ccnt[n][qq] > 0;
+      }
+      kn[k] = (uint16_t)id;
+    }
+    __syncthreads();
+    cur = nx;
+    n_tab = total;
+    *made = made_total;
+    return total;
+  };
+  // counts the children of the nodes with split[] set
+  auto count_children = [&]() {
+    for (int n = tid; n < n_tab; n += kQtThreads)
+      if (sh.split[n]) sh.ccnt[n][0] = sh.ccnt[n][1] = sh.ccnt[n][2] = sh.ccnt[n][3] = 0;
+    __syncthreads();
+    for (uint32_t k = tid; k < m; k += kQtThreads) {
+      const int n = kn[k];
+      if (sh.split[n]) atomicAdd(&sh.ccnt[n][qt_quadrant(sh.box_x[cur][n], sh.box_y[cur][n], kk[k])], 1u);
+    }
+    __syncthreads();
+  };
+
+  bool finish = false;
+  while (!finish) {
+    // (A) every node that holds more than one key is split
+    const int before = n_nodes;
+    for (int n = tid; n < n_tab; n += kQtThreads) sh.split[n] = sh.cnt[cur][n] > 1;
+    __syncthreads();
+    count_children();
+    int made;
+    n_nodes = rebuild(&made);
+    if (n_nodes >= N || n_nodes == before) {
+      finish = true;
+    } else if (n_nodes + 3 * made > N) {
+      // (B) the nodes of the last pass, largest first, one by one until N is reached
+      while (!finish) {
+        const int before_b = n_nodes;
+        for (int n = tid; n < kQtNodes; n += kQtThreads) {
+          const bool cand = n < n_tab && sh.fresh[cur][n] && sh.cnt[cur][n] > 1;
+          if (n < n_tab) sh.split[n] = cand;
+          const uint32_t bx = sh.box_x[cur][n < n_tab ? n : 0], by = sh.box_y[cur][n < n_tab ? n : 0];
+          sh.sortbuf[n] = cand ? ((unsigned long long)(0x3FFFFFu - sh.cnt[cur][n]) << 35) | ((unsigned long long)(by & 0xFFFu) << 23) |
+                                     ((unsigned long long)(bx & 0xFFFu) << 11) | (unsigned long long)n
+                               : ~0ull;
+        }
+        if (tid == 0) sh.cut = kQtNodes;
+        __syncthreads();
+        count_children();
+        bitonic_sort_nodes(sh.sortbuf);
+        // gains in expansion order; the first position where the node count reaches N ends the pass
+        int g[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned long long v = sh.sortbuf[2 * tid + u];
+          if (v != ~0ull) {
+            const int n = (int)(v & 0x7FFu);
+            g[u] = (sh.ccnt[n][0] > 0) + (sh.ccnt[n][1] > 0) + (sh.ccnt[n][2] > 0) + (sh.ccnt[n][3] > 0) - 1;
+          }
+        }
+        int tot;
+        const int excl = block_scan_1024(g[0] + g[1], sh.wave_tot, &tot);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (sh.sortbuf[2 * tid + u] != ~0ull && n_nodes + excl + g[0] + (u ? g[1] : 0) >= N) atomicMin(&sh.cut, 2 * tid + u);
+        __syncthreads();
+        const int cut = sh.cut;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned long long v = sh.sortbuf[2 * tid + u];
+          if (v != ~0ull && 2 * tid + u > cut) sh.split[(int)(v & 0x7FFu)] = 0;
+        }
+        __syncthreads();
+        n_nodes = rebuild(&made);
+        if (n_nodes >= N || n_nodes == before_b) finish = true;
+      }
+    }
+  }
+  // the best key of every node: (S desc, y asc, x asc) = max of S | ~(y, x)
+  uint32_t* best = &sh.ccnt[0][0];
+  for (int n = tid; n < kQtNodes; n += kQtThreads) best[n] = 0;
+  __syncthreads();
+  for (uint32_t k = tid; k < m; k += kQtThreads) {
+    const uint32_t v = kk[k];
+    atomicMax(&best[kn[k]], (v & 0xFF000000u) | (0xFFFFFFu - (v & 0xFFFFFFu)));
+  }
+  __syncthreads();
+  // the tree may hold up to 3 nodes more than N: keep the N best, then (y, x) order
+  uint32_t* srt = reinterpret_cast<uint32_t*>(sh.sortbuf);
+  for (int n = tid; n < kQtNodes; n += kQtThreads) srt[n] = ~best[n];  // ascending ~ = descending (S, ~yx); empty slots last
+  bitonic_sort_nodes(srt);
+  const int keep = min(n_tab, N);
+  {
+    uint32_t v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * tid + u;
+      const uint32_t w = ~srt[i];  // S << 24 | ~yx
+      v[u] = i < keep ? ((0xFFFFFFu - (w & 0xFFFFFFu)) << 8) | (w >> 24) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    srt[2 * tid] = v[0];
+    srt[2 * tid + 1] = v[1];
+  }
+  bitonic_sort_nodes(srt);
+  SelKp* out = sel + (size_t)b * K + L.quota_off;
+  for (int i = tid; i < keep; i += kQtThreads) {
+    const uint32_t v = srt[i];
+    SelKp o;
+    o.x = (uint16_t)((v >> 8) & 0xFFFu);
+    o.y = (uint16_t)(v >> 20);
+    o.score = (uint8_t)(v & 0xFFu);
+    o.level = (uint8_t)l;
+    o.pad = 0;
+    out[i] = o;
+  }
+  if (tid == 0) level_cnt[b * kMaxL + l] = keep;
+}
+
+}  // namespace
+
+struct gh_qt_plan {
+  int L = 0, max_batch = 0;
+  QtArgs args{};
+  size_t keys_per_frame = 0;
+  uint32_t* keys = nullptr;
+  uint16_t* knode = nullptr;
+  uint32_t* key_cnt = nullptr;  // [max_batch][8], then the overflow flag word
+  bool attr_set = false;
+};
+
+void gh_qt_destroy(gh_qt_plan* q) {
+  if (!q) return;
+  if (q->keys) (void)hipFree(q->keys);
+  if (q->knode) (void)hipFree(q->knode);
+  if (q->key_cnt) (void)hipFree(q->key_cnt);
+  delete q;
+}
+
+gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, const int* quota, int max_batch,
+                       gh_qt_plan** out, size_t* bytes) {
+  *out = nullptr;
+  for (int i = 0; i < 16; ++i)
+    if (kRing.dx[i] != GH_ORB_RING[i][0] || kRing.dy[i] != GH_ORB_RING[i][1])
+      return gh_set_error(ctx, GH_ERR_UNSUPPORTED, "orb_quadtree.hip: ring table differs from gslam_orb_tables.h");
+  gh_qt_plan* q = new (std::nothrow) gh_qt_plan();
+  if (!q) return GH_ERR_NOMEM;
+  q->L = n_levels;
+  q->max_batch = max_batch;
+  // key slots: the exact bound (suppressed maxima of a cell are pairwise non-adjacent) while it fits the budget, a share
+  // of the budget otherwise -- an overflowing list is an error of the call (gh_qt_check), never a silent truncation
+  size_t worst[kMaxL] = {}, worst_total = 0;
+  int qo = 0;
+  for (int l = 0; l < kMaxL; ++l) {
+    QtLevel& v = q->args.lv[l];
+    v = QtLevel{};
+    if (l >= n_levels) continue;
+    v.w = lw[l];
+    v.h = lh[l];
+    v.quota = quota[l];
+    v.quota_off = qo;
+    qo += quota[l];
+    if (v.w <= 2 * kEdge || v.h <= 2 * kEdge || v.quota <= 0) {
+      v.quota = 0;
+      continue;
+    }
+    if (v.w > 4096 || v.h > 4096 || v.quota + 3 > kQtNodes) {
+      gh_qt_destroy(q);
+      return gh_set_error(ctx, GH_ERR_ARG,
+                          "quadtree distribution: level %d is %d x %d with quota %d (limits: 4096 x 4096, quota <= %d)", l,
+                          v.w, v.h, v.quota, kQtNodes - 3);
+    }
+    const int W2 = v.w - 2 * kBorder, H2 = v.h - 2 * kBorder;
+    v.ncols = W2 / 30 > 1 ? W2 / 30 : 1;
+    v.nrows = H2 / 30 > 1 ? H2 / 30 : 1;
+    v.wc = (W2 + v.ncols - 1) / v.ncols;
+    v.hc = (H2 + v.nrows - 1) / v.nrows;
+    v.n_ini = (int)roundf((float)W2 / (float)H2);
+    if (v.n_ini < 1) v.n_ini = 1;
+    v.hx = (float)W2 / (float)v.n_ini;
+    if (4 * v.n_ini > kQtNodes || v.wc > kCellMax || v.hc > kCellMax) {
+      gh_qt_destroy(q);
+      return gh_set_error(ctx, GH_ERR_ARG, "quadtree distribution: level %d (%d x %d) has an unsupported aspect ratio", l, v.w, v.h);
+    }
+    worst[l] = (size_t)v.ncols * v.nrows * ((v.wc + 1) / 2) * ((v.hc + 1) / 2);
+    worst_total += worst[l];
+  }
+  const size_t budget = ((size_t)4 << 30) / 6 / (size_t)max_batch;  // 4 GB for keys (4 B) + node ids (2 B) of all frames
+  size_t off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    QtLevel& v = q->args.lv[l];
+    size_t cap = worst[l];
+    if (worst_total > budget) cap = (size_t)((double)worst[l] * (double)budget / (double)worst_total);
+    if (cap >= ((size_t)1 << 22)) cap = ((size_t)1 << 22) - 1;  // the sort key of stage (B) carries the count in 22 bits
+    v.cap = (uint32_t)cap;
+    v.key_off = off;
+    off += (cap + 63) & ~(size_t)63;
+  }
+  q->keys_per_frame = off ? off : 64;
+  const size_t B = (size_t)max_batch;
+  gh_status st;
+  if ((st = gh_dev_alloc(ctx, B * q->keys_per_frame * 4, (void**)&q->keys)) != GH_OK ||
+      (st = gh_dev_alloc(ctx, B * q->keys_per_frame * 2, (void**)&q->knode)) != GH_OK ||
+      (st = gh_dev_alloc(ctx, (B * kMaxL + 1) * 4, (void**)&q->key_cnt)) != GH_OK) {
+    gh_qt_destroy(q);
+    return st;
+  }
+  if (hipMemset(q->key_cnt, 0, (B * kMaxL + 1) * 4) != hipSuccess) {
+    gh_qt_destroy(q);
+    return gh_set_error(ctx, GH_ERR_HIP, "gh_qt_create: hipMemset failed");
+  }
+  if (bytes) *bytes += B * q->keys_per_frame * 6 + (B * kMaxL + 1) * 4;
+  *out = q;
+  return GH_OK;
+}
+
+gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int batch, int min_th, int ini_th,
+                        const int* quota_off, int K, SelKp* sel, int32_t* level_cnt) {
+  GH_CHECK_ARG(ctx, q && batch >= 1 && batch <= q->max_batch);
+  for (int l = 0; l < q->L; ++l) GH_CHECK_ARG(ctx, q->args.lv[l].quota == 0 || q->args.lv[l].quota_off == quota_off[l]);
+  if (!q->attr_set) {
+    GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(slam_quadtree_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(QtShared)));
+    q->attr_set = true;
+  }
+  GH_HIP(ctx, hipMemsetAsync(q->key_cnt, 0, ((size_t)batch * kMaxL) * 4, ctx->stream));
+  uint32_t* flags = q->key_cnt + (size_t)q->max_batch * kMaxL;
+  for (int l = 0; l < q->L; ++l) {
+    const QtLevel& v = q->args.lv[l];
+    if (v.quota <= 0) continue;
+    GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_kernel, dim3(v.ncols * v.nrows, batch), dim3(256), 0, lv[l], v.ncols, v.wc,
+              v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
+  }
+  GH_LAUNCH(ctx, "orb_slam_quadtree", slam_quadtree_kernel, dim3(q->L, batch), dim3(kQtThreads), sizeof(QtShared), q->args,
+            q->keys, q->knode, q->keys_per_frame, q->key_cnt, K, sel, level_cnt);
+  return GH_OK;
+}
+
+gh_status gh_qt_check(gh_ctx* ctx, gh_qt_plan* q) {
+  uint32_t f = 0;
+  uint32_t* flags = q->key_cnt + (size_t)q->max_batch * kMaxL;
+  GH_HIP(ctx, hipMemcpy(&f, flags, 4, hipMemcpyDeviceToHost));
+  if (f != 0) {
+    (void)hipMemset(flags, 0, 4);
+    return gh_set_error(ctx, GH_ERR_NOMEM,
+                        "quadtree distribution: a candidate list overflowed its buffer (more FAST maxima than the plan's "
+                        "key budget holds for this batch size; use a smaller max_batch)");
+  }
+  return GH_OK;
+}

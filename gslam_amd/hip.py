@@ -120,6 +120,7 @@ SIGNATURES = {
     "gh_orb_plan_destroy": (None, [_vp]),
     "gh_orb_plan_set_pattern": (C.c_int, [_vp, _vp]),
     "gh_orb_plan_set_steering": (C.c_int, [_vp, _i]),
+    "gh_orb_plan_set_distribution": (C.c_int, [_vp, _i]),
     "gh_orb_stream_plan": (_vp, [_vp]),
     "gh_orb_plan_level": (C.c_int, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "gh_orb_plan_device_bytes": (_sz, [_vp]),

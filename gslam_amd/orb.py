@@ -62,6 +62,10 @@ class OrbExtractor:
         gh_orb_plan_set_steering."""
         self.ctx.check(hip.lib.gh_orb_plan_set_steering(self.plan, int(mode)))
 
+    def set_distribution(self, mode):
+        """0: 32 x 32 cells + rank order (default); 1: ORB-SLAM's cells + quadtree.  See gh_orb_plan_set_distribution."""
+        self.ctx.check(hip.lib.gh_orb_plan_set_distribution(self.plan, int(mode)))
+
     def level(self, l):
         w, h, q = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(hip.lib.gh_orb_plan_level(self.plan, l, C.byref(w), C.byref(h), C.byref(q)))

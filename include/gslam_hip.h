@@ -177,6 +177,18 @@ gh_status gh_orb_plan_set_pattern(gh_orb_plan* plan, const int8_t* pattern_256x4
  * ORB-SLAM's padded pyramid holds there).  With the canonical pattern installed the descriptors are the ones ORB
  * vocabularies were trained on up to the image arithmetic (integer pyramid / FAST score / blur here, float there). */
 gh_status gh_orb_plan_set_steering(gh_orb_plan* plan, int mode);
+/* Keypoint distribution.  0 (default): 32 x 32 cells, in-cell rank, per-level quota by rank order (oracle steps 3-5; the
+ * throughput path).  1: what ORB-SLAM's ORBextractor does (ComputeKeyPointsOctTree + DistributeOctTree) -- FAST per ~30 x 30
+ * cell (W' = w - 32: nCols = W' / 30, wCell = ceil(W' / nCols)) with non-maximum suppression INSIDE the cell and the
+ * cell's own fall-back from ini_th_fast to min_th_fast, every surviving corner a candidate (no per-cell cap), then per
+ * (frame, level) the quadtree: nodes split into four until there are n_l of them (largest first in the last stage), the
+ * strongest corner of each node kept.  Specification: oracle/orb_oracle.c steps 4' and 5' (bit-exact; ties that ORB-SLAM
+ * leaves to heap addresses are fixed there).  Output rows per level are in (y, x) order.  Limits: levels up to 4096 x 4096,
+ * per-level quota <= 2045.  A call in this mode waits for its kernels; a frame with more FAST maxima than the plan's
+ * candidate budget (exact worst case while that fits 4 GB over max_batch frames) fails with GH_ERR_NOMEM, never silently.
+ * Together with gh_orb_plan_set_steering(plan, 1) and the canonical pattern this is the ORB-SLAM extraction up to the image
+ * arithmetic (integer pyramid and blur here, float resize there; KeyPoint.response = FAST score, OpenCV's is score - 1). */
+gh_status gh_orb_plan_set_distribution(gh_orb_plan* plan, int mode);
 /* Level geometry of the plan, for tests. */
 gh_status gh_orb_plan_level(const gh_orb_plan* plan, int level, int* w, int* h, int* quota);
 size_t gh_orb_plan_device_bytes(const gh_orb_plan* plan);

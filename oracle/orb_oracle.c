@@ -39,6 +39,32 @@
  *  9 keypoint pt = (float)x_l * s_l, s_0 = 1, s_l = s_{l-1} * 1.2f (single fp32 roundings);
  *             size = 31 * s_l; response = S; octave = l; class_id = -1.
  *
+ * Quadtree distribution (oracle_orb_set_distribution(1) <-> gh_orb_plan_set_distribution(plan, 1)) replaces steps 3-5 by what
+ * ORB-SLAM's ORBextractor does there (ComputeKeyPointsOctTree + DistributeOctTree + ExtractorNode::DivideNode; not in the
+ * reference tree, restated from the published algorithm; "border" below = EDGE_THRESHOLD - 3 = 16):
+ *  4' cells   W' = w - 32, H' = h - 32; nCols = max(1, W' / 30), nRows = max(1, H' / 30) (integer division),
+ *             wCell = ceil(W' / nCols), hCell = ceil(H' / nRows).  ORB-SLAM runs OpenCV FAST on the window of cell (i, j) that
+ *             starts at (16 + j wCell, 16 + i hCell) and is wCell + 6 x hCell + 6 (clipped at w - 16, h - 16); FAST leaves a 3 px
+ *             border, so cell (i, j) DETECTS in [19 + j wCell, min(19 + (j + 1) wCell, w - 19)) x (same in y): the cells tile
+ *             the scored region of step 2.  A pixel is a candidate of its cell at threshold t iff S > t and S > S(neighbour)
+ *             for the neighbours that lie INSIDE the cell's detection region (OpenCV's non-maximum suppression never sees
+ *             the others).  t = ini_th; a cell without a candidate at ini_th is searched again at min_th.  No per-cell cap.
+ *  5' tree    per level, keys (x - 16, y - 16) in the region W' x H', N = n_l (the quota of step 5):
+ *             nIni = max(1, round(W' / H')) (fp32 division, half away from zero), hX = (float)W' / nIni (fp32); root i spans
+ *             x in [(int)(hX i), (int)(hX (i + 1))) x [0, H'); a key joins root min((int)(kx / hX), nIni - 1).  Empty roots
+ *             are dropped.  DivideNode: halfX = ceil((x1 - x0) / 2), halfY = ceil((y1 - y0) / 2), the four children are
+ *             [x0, x0 + halfX) / [x0 + halfX, x1) x [y0, y0 + halfY) / [y0 + halfY, y1); a key goes left iff
+ *             kx < x0 + halfX, up iff ky < y0 + halfY; empty children are dropped.
+ *             Loop: (A) split EVERY node that holds more than one key; let n = nodes, e = children of this pass holding
+ *             more than one key.  If n >= N or n did not change: stop.  If n + 3 e > N: (B) take the nodes created by the
+ *             last pass that hold more than one key in the order (keys desc, y0 asc, x0 asc) [ORB-SLAM: std::sort of
+ *             (size, pointer) pairs walked from the back -- its tie order is the heap's; this one is fixed] and split them
+ *             one by one until n >= N; if the list is exhausted and n changed, repeat (B) with the children just made;
+ *             stop when n >= N or a whole pass leaves n unchanged.  Otherwise (A) again.
+ *             Each node yields its key of greatest S (ties: smaller y, then smaller x).  The tree can end with up to 3 nodes more
+ *             than N (ORB-SLAM keeps them all; the output here has n_l rows per level): the n_l best by (S desc, y asc, x asc)
+ *             are kept.  Output order: level asc, then y asc, x asc.
+ *
  * Continuous steering (oracle_orb_set_steer(1) <-> gh_orb_plan_set_steering(plan, 1)) replaces steps 6 and 8 by what
  * OpenCV / ORB-SLAM do there (ORBextractor.cc IC_Angle + computeOrbDescriptor; neither is in the reference tree, see above):
  *  6' angle   a = fastAtan2((float)m01, (float)m10) in degrees -- OpenCV's fp32 polynomial: with ax = |x|, ay = |y|,
@@ -258,6 +284,248 @@ int oracle_orb_select_level(const uint8_t* S, int w, int h, int ini_th, int quot
   return n_sel;
 }
 
+/* ---- quadtree distribution (steps 4' and 5') */
+static int g_distribution = 0;
+void oracle_orb_set_distribution(int mode) { g_distribution = mode != 0; }
+
+void oracle_orb_slam_grid(int w, int h, int* ncols, int* nrows, int* wcell, int* hcell) {
+  const int W2 = w - 32, H2 = h - 32;
+  *ncols = W2 / 30 > 1 ? W2 / 30 : 1;
+  *nrows = H2 / 30 > 1 ? H2 / 30 : 1;
+  *wcell = (W2 + *ncols - 1) / *ncols;
+  *hcell = (H2 + *nrows - 1) / *nrows;
+}
+
+/* step 4': candidates of one level in (cell row-major, in-cell raster) order; returns their number */
+int oracle_orb_slam_candidates(const uint8_t* S, int w, int h, int ini_th, int* cx, int* cy, int* cs) {
+  int ncols, nrows, wc, hc, n = 0;
+  if (w <= 2 * GH_ORB_EDGE || h <= 2 * GH_ORB_EDGE) return 0;
+  oracle_orb_slam_grid(w, h, &ncols, &nrows, &wc, &hc);
+  for (int i = 0; i < nrows; ++i)
+    for (int j = 0; j < ncols; ++j) {
+      const int x0 = GH_ORB_EDGE + j * wc, y0 = GH_ORB_EDGE + i * hc;
+      const int x1 = x0 + wc < w - GH_ORB_EDGE ? x0 + wc : w - GH_ORB_EDGE;
+      const int y1 = y0 + hc < h - GH_ORB_EDGE ? y0 + hc : h - GH_ORB_EDGE;
+      const int first = n;
+      int strong = 0;
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+          const int s = S[(size_t)y * w + x];
+          if (s == 0) continue;
+          int ismax = 1;
+          for (int dy = -1; dy <= 1 && ismax; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+              const int xx = x + dx, yy = y + dy;
+              if ((!dx && !dy) || xx < x0 || xx >= x1 || yy < y0 || yy >= y1) continue;
+              if (S[(size_t)yy * w + xx] >= s) {
+                ismax = 0;
+                break;
+              }
+            }
+          if (!ismax) continue;
+          cx[n] = x;
+          cy[n] = y;
+          cs[n] = s;
+          ++n;
+          if (s > ini_th) strong = 1;
+        }
+      if (strong) {
+        int m = first;
+        for (int k = first; k < n; ++k)
+          if (cs[k] > ini_th) {
+            cx[m] = cx[k];
+            cy[m] = cy[k];
+            cs[m] = cs[k];
+            ++m;
+          }
+        n = m;
+      }
+    }
+  return n;
+}
+
+typedef struct qt_node {
+  int x0, y0, x1, y1; /* [x0, x1) x [y0, y1) in region coordinates */
+  int* keys;          /* indices into the candidate arrays, in arrival order */
+  int n;
+  struct qt_node *prev, *next;
+} qt_node;
+
+typedef struct {
+  qt_node *head, *tail;
+  int size;
+} qt_list;
+
+static qt_node* qt_new(int x0, int y0, int x1, int y1, int cap) {
+  qt_node* q = (qt_node*)calloc(1, sizeof(qt_node));
+  q->x0 = x0; q->y0 = y0; q->x1 = x1; q->y1 = y1;
+  q->keys = (int*)malloc(sizeof(int) * (cap > 0 ? cap : 1));
+  return q;
+}
+static void qt_push_front(qt_list* L, qt_node* q) {
+  q->prev = NULL;
+  q->next = L->head;
+  if (L->head) L->head->prev = q; else L->tail = q;
+  L->head = q;
+  ++L->size;
+}
+static void qt_push_back(qt_list* L, qt_node* q) {
+  q->next = NULL;
+  q->prev = L->tail;
+  if (L->tail) L->tail->next = q; else L->head = q;
+  L->tail = q;
+  ++L->size;
+}
+static void qt_erase(qt_list* L, qt_node* q) {
+  if (q->prev) q->prev->next = q->next; else L->head = q->next;
+  if (q->next) q->next->prev = q->prev; else L->tail = q->prev;
+  --L->size;
+  free(q->keys);
+  free(q);
+}
+/* DivideNode; children with keys go to the front of the list, those with more than one key also into `made` */
+static void qt_divide(qt_list* L, qt_node* q, const int* kx, const int* ky, qt_node** made, int* n_made) {
+  const int hx = (q->x1 - q->x0 + 1) / 2, hy = (q->y1 - q->y0 + 1) / 2; /* ceil of the half extent */
+  const int xm = q->x0 + hx, ym = q->y0 + hy;
+  qt_node* c[4] = {qt_new(q->x0, q->y0, xm, ym, q->n), qt_new(xm, q->y0, q->x1, ym, q->n), qt_new(q->x0, ym, xm, q->y1, q->n),
+                   qt_new(xm, ym, q->x1, q->y1, q->n)};
+  for (int k = 0; k < q->n; ++k) {
+    const int id = q->keys[k];
+    qt_node* t = kx[id] < xm ? (ky[id] < ym ? c[0] : c[2]) : (ky[id] < ym ? c[1] : c[3]);
+    t->keys[t->n++] = id;
+  }
+  for (int e = 0; e < 4; ++e) {
+    if (c[e]->n > 0) {
+      qt_push_front(L, c[e]);
+      if (c[e]->n > 1) made[(*n_made)++] = c[e];
+    } else {
+      free(c[e]->keys);
+      free(c[e]);
+    }
+  }
+}
+static int qt_cmp_expand(const void* a, const void* b) { /* (keys desc, y0 asc, x0 asc) */
+  const qt_node* p = *(qt_node* const*)a;
+  const qt_node* q = *(qt_node* const*)b;
+  if (p->n != q->n) return q->n - p->n;
+  if (p->y0 != q->y0) return p->y0 - q->y0;
+  return p->x0 - q->x0;
+}
+typedef struct { int x, y, s; } qt_win;
+static int qt_cmp_best(const void* a, const void* b) { /* (S desc, y asc, x asc) */
+  const qt_win* p = (const qt_win*)a;
+  const qt_win* q = (const qt_win*)b;
+  if (p->s != q->s) return q->s - p->s;
+  if (p->y != q->y) return p->y - q->y;
+  return p->x - q->x;
+}
+static int qt_cmp_yx(const void* a, const void* b) {
+  const qt_win* p = (const qt_win*)a;
+  const qt_win* q = (const qt_win*)b;
+  if (p->y != q->y) return p->y - q->y;
+  return p->x - q->x;
+}
+
+/* step 5' for one level: candidates (level coordinates) -> at most N keypoints in (y, x) order.  Returns their number. */
+int oracle_orb_quadtree(const int* cx, const int* cy, const int* cs, int n, int w, int h, int N, int* out_x, int* out_y,
+                        int* out_s) {
+  if (n <= 0 || N <= 0) return 0;
+  const int W2 = w - 32, H2 = h - 32;
+  int* kx = (int*)malloc(sizeof(int) * n * 2);
+  int* ky = kx + n;
+  for (int k = 0; k < n; ++k) {
+    kx[k] = cx[k] - 16;
+    ky[k] = cy[k] - 16;
+  }
+  int n_ini = (int)roundf((float)W2 / (float)H2);
+  if (n_ini < 1) n_ini = 1;
+  const float hX = (float)W2 / (float)n_ini;
+  qt_list L = {NULL, NULL, 0};
+  qt_node** roots = (qt_node**)malloc(sizeof(qt_node*) * n_ini);
+  for (int i = 0; i < n_ini; ++i) {
+    roots[i] = qt_new((int)(hX * (float)i), 0, (int)(hX * (float)(i + 1)), H2, n);
+    qt_push_back(&L, roots[i]);
+  }
+  for (int k = 0; k < n; ++k) {
+    int r = (int)((float)kx[k] / hX);
+    if (r > n_ini - 1) r = n_ini - 1;
+    roots[r]->keys[roots[r]->n++] = k;
+  }
+  for (int i = 0; i < n_ini; ++i)
+    if (roots[i]->n == 0) qt_erase(&L, roots[i]);
+  free(roots);
+  qt_node** made = (qt_node**)malloc(sizeof(qt_node*) * ((size_t)4 * n + 16));
+  qt_node** prev = (qt_node**)malloc(sizeof(qt_node*) * ((size_t)4 * n + 16));
+  int finish = 0;
+  while (!finish) {
+    const int prev_size = L.size;
+    int n_made = 0;
+    for (qt_node* q = L.head; q;) { /* (A): children go to the FRONT, so this walk meets only nodes of earlier passes */
+      qt_node* nx = q->next;
+      if (q->n > 1) {
+        qt_divide(&L, q, kx, ky, made, &n_made);
+        qt_erase(&L, q);
+      }
+      q = nx;
+    }
+    if (L.size >= N || L.size == prev_size) {
+      finish = 1;
+    } else if (L.size + 3 * n_made > N) {
+      while (!finish) {
+        const int before = L.size;
+        const int n_prev = n_made;
+        memcpy(prev, made, sizeof(qt_node*) * n_prev);
+        n_made = 0;
+        qsort(prev, n_prev, sizeof(qt_node*), qt_cmp_expand);
+        for (int j = 0; j < n_prev; ++j) {
+          qt_divide(&L, prev[j], kx, ky, made, &n_made);
+          qt_erase(&L, prev[j]);
+          if (L.size >= N) break;
+        }
+        if (L.size >= N || L.size == before) finish = 1;
+      }
+    }
+  }
+  qt_win* win = (qt_win*)malloc(sizeof(qt_win) * (L.size > 0 ? L.size : 1));
+  int m = 0;
+  for (qt_node* q = L.head; q; q = q->next) {
+    qt_win b = {0, 0, -1};
+    for (int k = 0; k < q->n; ++k) {
+      const qt_win c = {cx[q->keys[k]], cy[q->keys[k]], cs[q->keys[k]]};
+      if (b.s < 0 || qt_cmp_best(&c, &b) < 0) b = c;
+    }
+    win[m++] = b;
+  }
+  while (L.head) qt_erase(&L, L.head);
+  qsort(win, m, sizeof(qt_win), qt_cmp_best);
+  if (m > N) m = N;
+  qsort(win, m, sizeof(qt_win), qt_cmp_yx);
+  for (int i = 0; i < m; ++i) {
+    out_x[i] = win[i].x;
+    out_y[i] = win[i].y;
+    out_s[i] = win[i].s;
+  }
+  free(win);
+  free(made);
+  free(prev);
+  free(kx);
+  return m;
+}
+
+/* steps 4' + 5' for one level */
+int oracle_orb_select_level_quadtree(const uint8_t* S, int w, int h, int ini_th, int quota, int* out_x, int* out_y,
+                                     int* out_s) {
+  if (w <= 2 * GH_ORB_EDGE || h <= 2 * GH_ORB_EDGE || quota <= 0) return 0;
+  const size_t cap = (size_t)w * h / 2 + 64;
+  int* cx = (int*)malloc(sizeof(int) * cap * 3);
+  int* cy = cx + cap;
+  int* cs = cy + cap;
+  const int n = oracle_orb_slam_candidates(S, w, h, ini_th, cx, cy, cs);
+  const int m = oracle_orb_quadtree(cx, cy, cs, n, w, h, quota, out_x, out_y, out_s);
+  free(cx);
+  return m;
+}
+
 /* step 6 */
 int oracle_orb_angle_bin(const uint8_t* img, int stride, int x, int y) {
   int64_t m10 = 0, m01 = 0;
@@ -441,7 +709,8 @@ int oracle_orb_extract(const uint8_t* gray, int w, int h, int stride, int K, int
     int* xs = (int*)malloc(sizeof(int) * quota[l] * 3);
     int* ys = xs + quota[l];
     int* ss = ys + quota[l];
-    int m = oracle_orb_select_level(S, ws[l], hs[l], ini_th, quota[l], xs, ys, ss);
+    int m = g_distribution ? oracle_orb_select_level_quadtree(S, ws[l], hs[l], ini_th, quota[l], xs, ys, ss)
+                           : oracle_orb_select_level(S, ws[l], hs[l], ini_th, quota[l], xs, ys, ss);
     for (int i = 0; i < m; ++i) {
       oracle_kp* kp = &kps[n];
       kp->x = (float)xs[i] * scale[l];

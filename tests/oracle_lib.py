@@ -191,6 +191,37 @@ def _orb_methods(cls):
         """0: 30 orientation bins; 1: continuous steering (oracle/orb_oracle.c steps 6' and 8').  Global: reset after use."""
         self.lib.oracle_orb_set_steer(int(mode))
 
+    def orb_set_distribution(self, mode):
+        """0: 32 x 32 cells + rank order (steps 3-5); 1: ORB-SLAM's cells + quadtree (steps 4', 5').  Global: reset after use."""
+        self.lib.oracle_orb_set_distribution(int(mode))
+
+    def orb_score_map(self, img, min_th=7):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        S = np.zeros((h, w), np.uint8)
+        self.lib.oracle_orb_score_map(_ptr(img), w, h, w, int(min_th), _ptr(S))
+        return S
+
+    def orb_slam_grid(self, w, h):
+        v = [C.c_int() for _ in range(4)]
+        self.lib.oracle_orb_slam_grid(int(w), int(h), *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)  # ncols, nrows, wcell, hcell
+
+    def orb_slam_candidates(self, S, ini_th=20):
+        S = np.ascontiguousarray(S, dtype=np.uint8)
+        h, w = S.shape
+        cap = w * h // 2 + 64
+        cx, cy, cs = (np.zeros(cap, np.int32) for _ in range(3))
+        n = self.lib.oracle_orb_slam_candidates(_ptr(S), w, h, int(ini_th), _ptr(cx), _ptr(cy), _ptr(cs))
+        return cx[:n].copy(), cy[:n].copy(), cs[:n].copy()
+
+    def orb_quadtree(self, cx, cy, cs, w, h, N):
+        cx, cy, cs = (np.ascontiguousarray(a, dtype=np.int32) for a in (cx, cy, cs))
+        ox, oy, os_ = (np.zeros(max(N, 1), np.int32) for _ in range(3))
+        m = self.lib.oracle_orb_quadtree(_ptr(cx), _ptr(cy), _ptr(cs), len(cx), int(w), int(h), int(N), _ptr(ox), _ptr(oy),
+                                         _ptr(os_))
+        return ox[:m].copy(), oy[:m].copy(), os_[:m].copy()
+
     def orb_fast_atan2_deg(self, y, x):
         self.lib.oracle_orb_fast_atan2_deg.restype = C.c_float
         return float(self.lib.oracle_orb_fast_atan2_deg(C.c_float(y), C.c_float(x)))
@@ -243,7 +274,7 @@ def _orb_methods(cls):
         self.lib.oracle_bgr_to_gray(_ptr(bgr), w, h, c, w * c, _ptr(out), w)
         return out
 
-    for f in (synth_frame, orb_level_dims, orb_quotas, orb_set_pattern, orb_set_steer, orb_fast_atan2_deg, orb_sincos_deg, orb_extract, orb_extract_batch, orb_pyramid_level,
+    for f in (synth_frame, orb_level_dims, orb_quotas, orb_set_pattern, orb_set_steer, orb_set_distribution, orb_score_map, orb_slam_grid, orb_slam_candidates, orb_quadtree, orb_fast_atan2_deg, orb_sincos_deg, orb_extract, orb_extract_batch, orb_pyramid_level,
               orb_score_map, bgr_to_gray):
         setattr(cls, f.__name__, f)
 

@@ -373,3 +373,94 @@ def test_steering_mode_rules_and_vocabulary_round_trip(ctx, oracle):
     m = int(bn[0])
     assert m == len(ebw) and np.array_equal(bw[0, :m].cpu().numpy().astype(np.uint32), ebw) and np.array_equal(bv[0, :m].cpu().numpy(), ebv)
     ex.close()
+
+
+# ---------------------------------------------------------------- quadtree distribution (gh_orb_plan_set_distribution)
+def _quadtree_case(ctx, oracle, host, K, steer, **kw):
+    import torch
+    from gslam_amd.orb import OrbExtractor, kps_to_numpy
+    B, h, w = host.shape
+    ex = OrbExtractor(ctx, w, h, max_batch=B, n_features=K, **kw)
+    ex.set_distribution(1)
+    if steer:
+        ex.set_steering(1)
+    frames = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    kps, desc, counts = ex.extract(frames)
+    torch.cuda.synchronize()
+    kps, desc, counts = kps_to_numpy(kps), desc.cpu().numpy(), counts.cpu().numpy()
+    okw = {}
+    if "n_levels" in kw:
+        okw["nlevels"] = kw["n_levels"]
+    if "ini_th" in kw:
+        okw["ini_th"], okw["min_th"] = kw["ini_th"], kw["min_th"]
+    oracle.orb_set_distribution(1)
+    oracle.orb_set_steer(1 if steer else 0)
+    try:
+        for f in range(B):
+            ek, ed = oracle.orb_extract(host[f], K, **okw)
+            n = len(ek)
+            assert counts[f] == n, f"frame {f}: count {counts[f]} vs oracle {n}"
+            assert kps[f, :n].tobytes() == ek.tobytes(), f"frame {f}: keypoint records differ"
+            assert np.array_equal(desc[f, :n], ed), f"frame {f}: descriptor bits differ"
+            assert not kps[f, n:].tobytes().strip(b"\0") and not desc[f, n:].any()
+    finally:
+        oracle.orb_set_distribution(0)
+        oracle.orb_set_steer(0)
+    # back to the default mode on the same plan: the default results
+    ex.set_distribution(0)
+    ex.set_steering(0)
+    k0, d0, c0 = ex.extract(frames)
+    torch.cuda.synchronize()
+    ek, ed = oracle.orb_extract(host[0], K, **okw)
+    assert int(c0[0]) == len(ek) and kps_to_numpy(k0)[0, :len(ek)].tobytes() == ek.tobytes()
+    ex.close()
+    return counts
+
+
+@pytest.mark.parametrize("w,h,K,B,steer", [(640, 480, 1000, 3, False), (640, 480, 2000, 2, True), (752, 480, 1500, 2, True),
+                                           (333, 257, 300, 3, False), (161, 123, 200, 2, True), (1241, 376, 2000, 2, True),
+                                           (150, 420, 400, 2, False), (1920, 1080, 2000, 2, True)])
+def test_quadtree_distribution_parity(ctx, oracle, w, h, K, B, steer):
+    """gh_orb_plan_set_distribution(plan, 1): ORB-SLAM's per-cell FAST + DistributeOctTree (oracle steps 4', 5'), all 28
+    bytes of every keypoint and every descriptor bit against the oracle -- VGA, KITTI's aspect ratio (4 roots), a portrait
+    frame (one root), 1080p, with and without continuous steering."""
+    from gslam_amd.orb import synth_frames
+    host = synth_frames(ctx, B, w, h, base_seed=0x5EED0400 + w).cpu().numpy()[:, :, :w]
+    counts = _quadtree_case(ctx, oracle, host, K, steer)
+    assert (counts > 0).all()
+
+
+def test_quadtree_distribution_dense_candidates_and_small_quotas(ctx, oracle):
+    """Noise frames: ~1 candidate per 12 pixels, deep trees, stage (B) of the tree repeated; K from 8 (quotas of 1-2 per
+    level, the first pass already overshoots them) to 6000; other level counts and thresholds."""
+    rng = np.random.default_rng(77)
+    host = rng.integers(0, 256, (2, 300, 420), dtype=np.uint8)
+    for K in (8, 60, 1000, 6000):
+        _quadtree_case(ctx, oracle, host, K, False)
+    _quadtree_case(ctx, oracle, host, 700, True, n_levels=3)
+    _quadtree_case(ctx, oracle, host, 700, False, n_levels=5, ini_th=40, min_th=15)
+    flat = np.full((1, 200, 320), 90, np.uint8)
+    flat[0, 100, 160] = 255  # a single corner-like blob
+    c = _quadtree_case(ctx, oracle, flat, 100, False)
+    assert c[0] <= 8
+
+
+def test_quadtree_distribution_limits_and_host_entry(ctx, oracle):
+    """quota > 2045 per level is refused loudly; the single-frame host entry point honours the mode."""
+    from gslam_amd import hip
+    from gslam_amd.orb import OrbExtractor
+    ex = OrbExtractor(ctx, 640, 480, max_batch=1, n_features=12000)
+    with pytest.raises(hip.GslamHipError):
+        ex.set_distribution(1)
+    ex.close()
+    ex = OrbExtractor(ctx, 640, 480, max_batch=1, n_features=800)
+    ex.set_distribution(1)
+    img = oracle.synth_frame(640, 480, 1234)
+    kps, desc = ex.extract_host(img)
+    oracle.orb_set_distribution(1)
+    try:
+        ek, ed = oracle.orb_extract(img, 800)
+    finally:
+        oracle.orb_set_distribution(0)
+    assert kps.tobytes() == ek.tobytes() and np.array_equal(desc, ed)
+    ex.close()

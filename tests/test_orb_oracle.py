@@ -209,3 +209,126 @@ def test_continuous_steering_extraction_against_a_python_restatement(oracle):
         h, w = img.shape
         near_border += int(min(x, y, w - 1 - x, h - 1 - y) < 22)
     assert near_border > 0  # some of the checked keypoints read mirrored pixels
+
+
+# ---------------------------------------------------------------- quadtree distribution (oracle steps 4' and 5')
+def _slam_candidates_py(S, ini_th):
+    """Step 4' with array operations only (independent of the C loops): per-cell non-maximum suppression + threshold."""
+    h, w = S.shape
+    W2, H2 = w - 32, h - 32
+    ncols, nrows = max(1, W2 // 30), max(1, H2 // 30)
+    wc, hc = -(-W2 // ncols), -(-H2 // nrows)
+    out = []
+    for i in range(nrows):
+        for j in range(ncols):
+            x0, y0 = 19 + j * wc, 19 + i * hc
+            x1, y1 = min(x0 + wc, w - 19), min(y0 + hc, h - 19)
+            if x1 <= x0 or y1 <= y0:
+                continue
+            c = S[y0:y1, x0:x1].astype(np.int32)
+            p = np.pad(c, 1)  # neighbours outside the cell's detection region count as 0
+            nb = np.stack([p[1 + dy:1 + dy + c.shape[0], 1 + dx:1 + dx + c.shape[1]]
+                           for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dy, dx) != (0, 0)]).max(axis=0)
+            mx = (c > 0) & (c > nb)
+            if (mx & (c > ini_th)).any():
+                mx &= c > ini_th
+            ys, xs = np.nonzero(mx)
+            out += [(x0 + x, y0 + y, int(c[y, x])) for y, x in zip(ys, xs)]
+    return out
+
+
+def _quadtree_py(cands, w, h, N):
+    """Step 5' as a level-synchronous set computation (no list, no pointers): a node is (x0, y0, x1, y1) -> [keys]."""
+    W2, H2 = w - 32, h - 32
+    f32 = np.float32
+    n_ini = max(1, int(np.floor(float(f32(W2) / f32(H2)) + 0.5)))
+    hX = f32(W2) / f32(n_ini)
+    nodes = {}
+    for (x, y, s) in cands:
+        r = min(int(f32(x - 16) / hX), n_ini - 1)
+        box = (int(hX * f32(r)), 0, int(hX * f32(r + 1)), H2)
+        nodes.setdefault(box, []).append((x, y, s))
+
+    def split(box, keys):
+        x0, y0, x1, y1 = box
+        xm, ym = x0 + (x1 - x0 + 1) // 2, y0 + (y1 - y0 + 1) // 2
+        ch = {}
+        for k in keys:
+            left, up = k[0] - 16 < xm, k[1] - 16 < ym
+            b = (x0 if left else xm, y0 if up else ym, xm if left else x1, ym if up else y1)
+            ch.setdefault(b, []).append(k)
+        return ch
+
+    fresh = set(nodes)  # nodes created by the last pass
+    while True:
+        before = len(nodes)
+        new = {}
+        for box in [b for b in nodes if len(nodes[b]) > 1]:
+            new.update(split(box, nodes.pop(box)))
+        nodes.update(new)
+        fresh = {b for b in new if len(new[b]) > 1}
+        if len(nodes) >= N or len(nodes) == before:
+            break
+        if len(nodes) + 3 * len(fresh) > N:
+            done = False
+            while not done:
+                before = len(nodes)
+                order = sorted(fresh, key=lambda b: (-len(nodes[b]), b[1], b[0]))
+                fresh = set()
+                for b in order:
+                    ch = split(b, nodes.pop(b))
+                    nodes.update(ch)
+                    fresh |= {c for c in ch if len(ch[c]) > 1}
+                    if len(nodes) >= N:
+                        break
+                done = len(nodes) >= N or len(nodes) == before
+            break
+    win = [min(v, key=lambda k: (-k[2], k[1], k[0])) for v in nodes.values()]
+    win = sorted(win, key=lambda k: (-k[2], k[1], k[0]))[:N]
+    return sorted(win, key=lambda k: (k[1], k[0]))
+
+
+def test_quadtree_distribution_against_an_independent_python_restatement(oracle):
+    rng = np.random.default_rng(11)
+    cases = [(oracle.synth_frame(640, 480, 3), 20, 7), (oracle.synth_frame(333, 257, 9), 20, 7),
+             (rng.integers(0, 256, (200, 310), dtype=np.uint8), 60, 30),   # noise: dense candidates, deep trees
+             (oracle.synth_frame(150, 420, 4), 20, 7)]                        # portrait: round(W'/H') = 0 -> one root
+    for img, ini, mn in cases:
+        h, w = img.shape
+        S = oracle.orb_score_map(img, mn)
+        cx, cy, cs = oracle.orb_slam_candidates(S, ini)
+        assert sorted(zip(cx.tolist(), cy.tolist(), cs.tolist())) == sorted(_slam_candidates_py(S, ini))
+        assert len(cx) > 50
+        cands = list(zip(cx.tolist(), cy.tolist(), cs.tolist()))
+        for N in (1, 2, 5, 17, 64, 200, 433, len(cands), len(cands) + 10):
+            ox, oy, os_ = oracle.orb_quadtree(cx, cy, cs, w, h, N)
+            assert list(zip(ox.tolist(), oy.tolist(), os_.tolist())) == _quadtree_py(cands, w, h, N), (w, h, N)
+            assert len(ox) <= N
+            if N >= len(cands):
+                assert len(ox) == len(cands)  # enough room: every candidate ends alone in a node
+
+
+def test_quadtree_distribution_spreads_the_keypoints(oracle):
+    """What the mode is for: keypoints cover the image instead of piling up on the strongest texture."""
+    img = oracle.synth_frame(640, 480, 21).copy()
+    img[:, :320] = (img[:, :320].astype(np.int32) * 0.25 + 96).astype(np.uint8)  # left half: low contrast
+    k0, _ = oracle.orb_extract(img, K=500)
+    oracle.orb_set_distribution(1)
+    try:
+        k1, d1 = oracle.orb_extract(img, K=500)
+        k1b, d1b = oracle.orb_extract(img, K=500)
+    finally:
+        oracle.orb_set_distribution(0)
+    assert np.array_equal(k1.view(np.uint8), k1b.view(np.uint8)) and np.array_equal(d1, d1b)
+    assert 0 < len(k1) <= 500
+
+    def occupied(k):  # 80-px blocks of level-0 coordinates holding at least one level-0 keypoint
+        m = k["octave"] == 0
+        return len({(int(x) // 80, int(y) // 80) for x, y in zip(k["x"][m], k["y"][m])})
+    assert occupied(k1) >= occupied(k0)
+    q = oracle.orb_quotas(500)
+    for l in range(8):
+        assert (k1["octave"] == l).sum() <= q[l]
+        m = k1["octave"] == l
+        yx = np.stack([k1["y"][m], k1["x"][m]], 1)
+        assert (np.lexsort((yx[:, 1], yx[:, 0])) == np.arange(len(yx))).all()  # (y, x) order inside a level
