@@ -946,6 +946,50 @@ def main():
             del fr, o
             torch.cuda.empty_cache()
         extra["orb_range"] = out
+        # the ORB-SLAM compatible mode (gh_orb_plan_set_distribution + gh_orb_plan_set_steering): per-cell FAST, quadtree,
+        # continuous steering.  A compatibility path (each call waits for its kernels), reported beside the default mode.
+        slam = {}
+        for (w, h, k, nfr) in ((640, 480, 1000, 500), (1920, 1080, 2000, 100)):
+            exr = OrbExtractor(ctx, w, h, max_batch=nfr, n_features=k)
+            exr.set_distribution(1)
+            exr.set_steering(1)
+            fr = synth_frames(ctx, nfr, w, h, base_seed=0x5EED0000, device=dev)
+            o = exr.alloc_outputs(nfr, dev)
+            exr.extract(fr, o)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                exr.extract(fr, o)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            kp = int(o[2].sum().item())
+            rec = {"frames": nfr, "Mkeypoints_per_s": round(kp / dt / 1e6, 2), "frames_per_s": round(nfr / dt, 1),
+                   "us_per_frame": round(dt / nfr * 1e6, 2), "keypoints_per_frame": kp // nfr,
+                   "plan_device_MB": round(exr.device_bytes() / 1e6, 1)}
+            if not a.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib  # the checker
+                from gslam_amd.orb import kps_to_numpy
+                orc = oracle_lib.load()
+                orc.orb_set_distribution(1)
+                orc.orb_set_steer(1)
+                try:
+                    ek, ed = orc.orb_extract(fr[0, :, :w].contiguous().cpu().numpy(), k)
+                finally:
+                    orc.orb_set_distribution(0)
+                    orc.orb_set_steer(0)
+                n0 = int(o[2][0].item())
+                ok = n0 == len(ek) and kps_to_numpy(o[0][:1])[0, :n0].tobytes() == ek.tobytes() and \
+                    bool(np.array_equal(o[1][0, :n0].cpu().numpy(), ed))
+                rec["parity_in_run"] = {"frames": 1, "keypoints": len(ek), "equal": bool(ok)}
+                if not ok:
+                    raise AssertionError("in-run parity of the quadtree mode failed at %dx%d" % (w, h))
+            slam["%dx%d_k%d" % (w, h, k)] = rec
+            exr.close()
+            del fr, o
+            torch.cuda.empty_cache()
+        extra["orb_slam_mode"] = slam
 
     try:
         if not a.no_host_fed:

@@ -304,6 +304,9 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
     if (!plan) return false;
     const int steer = svar.GetInt("FeatureDetectorHIP.Steering", 0);
     if (steer != 0 && gh_orb_plan_set_steering(plan, 1) != GH_OK) return fail("gh_orb_plan_set_steering");
+    // svar FeatureDetectorHIP.Distribution = 1: ORB-SLAM's per-cell FAST + quadtree (gh_orb_plan_set_distribution)
+    if (svar.GetInt("FeatureDetectorHIP.Distribution", 0) != 0 && gh_orb_plan_set_distribution(plan, 1) != GH_OK)
+      return fail("gh_orb_plan_set_distribution");
     const std::string pf = svar.GetString("FeatureDetectorHIP.Pattern", "");
     if (!pf.empty()) {
       std::ifstream in(pf.c_str());

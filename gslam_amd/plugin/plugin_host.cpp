@@ -28,6 +28,7 @@
 #include <thread>
 #include <cstdlib>
 #include <fstream>
+#include <sstream>
 #include <iostream>
 #include <vector>
 
@@ -856,6 +857,15 @@ static int run_est3(const std::string& dir, int model, int n, const char* ptsf, 
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   const std::string mode = argv[1], dir = argv[2];
+  // integer svar options for the plugins under test: GSLAM_HOST_SVAR="FeatureDetectorHIP.Steering=1;FeatureDetectorHIP.Distribution=1"
+  if (const char* e = getenv("GSLAM_HOST_SVAR")) {
+    std::stringstream ss(e);
+    std::string kv;
+    while (std::getline(ss, kv, ';')) {
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos) svar.GetInt(kv.substr(0, eq), 0) = atoi(kv.c_str() + eq + 1);
+    }
+  }
   if (mode == "ba" && argc >= 5)
     return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4], argc >= 6 ? atoi(argv[5]) : 0);

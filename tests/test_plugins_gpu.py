@@ -229,6 +229,34 @@ def test_featuredetector_plugin_matches_oracle(tmp_path, oracle, channels):
     assert okm == 1 and np.array_equal(matches, exp_matches)
 
 
+def test_featuredetector_plugin_orbslam_mode(tmp_path, oracle):
+    """svar FeatureDetectorHIP.Distribution = 1 + FeatureDetectorHIP.Steering = 1: ORB-SLAM's cell / quadtree distribution
+    and continuous steering behind FeatureDetector::detectAndCompute, against the oracle's steps 4', 5', 6', 8'."""
+    _need_host()
+    w, h, K = 752, 480, 1200
+    gray = oracle.synth_frame(w, h, 777)
+    inp, out = tmp_path / "img.raw", tmp_path / "out.bin"
+    gray.tofile(inp)
+    r = _run(["orb", LIBDIR, w, h, 1, inp, out, K],
+             {"GSLAM_HOST_SVAR": "FeatureDetectorHIP.Steering=1;FeatureDetectorHIP.Distribution=1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    ok, n, okm, nm = struct.unpack("4i", raw[:16])
+    oracle.orb_set_distribution(1)
+    oracle.orb_set_steer(1)
+    try:
+        ek, ed = oracle.orb_extract(gray, K)
+    finally:
+        oracle.orb_set_distribution(0)
+        oracle.orb_set_steer(0)
+    e0, _ = oracle.orb_extract(gray, K)
+    assert ok == 1 and n == len(ek)
+    kps = np.frombuffer(raw, oracle_lib.KP_DTYPE, n, 16)
+    desc = np.frombuffer(raw, np.uint8, n * 32, 16 + n * 28).reshape(n, 32)
+    assert kps.tobytes() == ek.tobytes() and np.array_equal(desc, ed)
+    assert kps.tobytes() != e0[:n].tobytes()  # (the options did reach the plugin)
+
+
 @pytest.mark.parametrize("desc_bytes", [32, 64, 40, -64])
 def test_vocabulary_plugin_equals_reference_base_class(tmp_path, oracle, desc_bytes):
     """libgslam_vocabulary.so (VocabularyHIP) vs GSLAM::Vocabulary itself, both inside the GSLAM host process:
