@@ -126,7 +126,7 @@ build/ref/libgslam_metric_traj.so: $(REF)/GSLAM/evaluation/metric_trajectory/mai
 
 build/plugin_host: gslam_amd/plugin/plugin_host.cpp gslam_amd/plugin/FeatureDetector.h gslam_amd/plugin/UndistorterHIP.h $(LIBDIR)/libgslam_hip.so
 	@mkdir -p build
-	g++ $(PLUGFLAGS) -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN/../gslam_amd/lib' -lpthread -ldl
+	g++ $(PLUGFLAGS) -rdynamic -o $@ $< -L$(LIBDIR) -lgslam_hip -Wl,-rpath,'$$ORIGIN/../gslam_amd/lib' -lpthread -ldl
 
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/liboracle.so oracle/liboracle_fma.so oracle/_ref
