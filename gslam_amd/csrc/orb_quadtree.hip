@@ -59,15 +59,24 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* q, int pitch, int mi
   const int nb = (d[0] > min_th) + (d[4] > min_th) + (d[8] > min_th) + (d[12] > min_th);
   const int nd = (d[0] < -min_th) + (d[4] < -min_th) + (d[8] < -min_th) + (d[12] < -min_th);
   if (nb < 2 && nd < 2) return 0;
+  // min / max over every window of 9 by doubling: windows of 2, 4, 8, then one more element (4 x 16 ops instead of 8 x 16)
+  int lo[16], hi[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo[i] = min(d[i], d[(i + 1) & 15]);
+    hi[i] = max(d[i], d[(i + 1) & 15]);
+  }
+  int lo4[16], hi4[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo4[i] = min(lo[i], lo[(i + 2) & 15]);
+    hi4[i] = max(hi[i], hi[(i + 2) & 15]);
+  }
   int best = 0;
 #pragma unroll
-  for (int a = 0; a < 16; ++a) {
-    int mn = d[a], mx = d[a];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) {
-      mn = min(mn, d[(a + i) & 15]);
-      mx = max(mx, d[(a + i) & 15]);
-    }
+  for (int i = 0; i < 16; ++i) {
+    const int mn = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const int mx = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
     best = max(best, max(mn, -mx));
   }
   return best;
