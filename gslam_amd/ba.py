@@ -124,3 +124,20 @@ def potrf_solve(ctx: hip.Context, A, b):
     ctx.sync()
     L = np.tril(dA.cpu().numpy().T)
     return L, db.cpu().numpy(), info.value
+
+
+def band_solve(ctx: hip.Context, A, b, half_bandwidth):
+    """Band SPD solve by block cyclic reduction (gh_band_solve_dev).  A: n x n symmetric with A[r][c] = 0 for
+    |r - c| > half_bandwidth; b: n.  Returns (x, info)."""
+    import torch
+    n = A.shape[0]
+    lda = (n + 1 + 15) // 16 * 16
+    buf = np.zeros((n, lda))  # row c of `buf` = column c of the column-major device matrix
+    buf[:, :n] = np.tril(np.asarray(A, dtype=np.float64)).T
+    dA = torch.from_numpy(buf).cuda()
+    db = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).cuda()
+    info = C.c_int()
+    ctx.check(hip.lib.gh_band_solve_dev(ctx.h, C.c_void_p(dA.data_ptr()), n, lda, int(half_bandwidth),
+                                        C.c_void_p(db.data_ptr()), C.byref(info)))
+    ctx.sync()
+    return db.cpu().numpy(), info.value

@@ -30,6 +30,12 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
 size_t gh_potrf_flow_flag_words(int n, int extra_rows);
 std::mutex& gh_potrf_flow_mutex(int device);
+// chol_cr.hip: band solver (block cyclic reduction)
+int gh_cr_tiles(int n, int hbw);
+size_t gh_cr_dinv_doubles(int n, int T);
+size_t gh_cr_panel_doubles(int n, int T);
+gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, double* dinv, double* W, double* x_dev,
+                               int* info_dev, bool info_ready);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
@@ -1405,6 +1411,9 @@ struct BaSession {
   int *d_bad = nullptr, *d_info = nullptr;
   unsigned* d_flow = nullptr;
   size_t n_pairs = 0;
+  // band solver (chol_cr.hip): tiles per superblock (0 = the dense factorisation), its inverted diagonal tiles and panels
+  int cr_T = 0, cam_span = 0;
+  double *d_cr_dinv = nullptr, *d_cr_W = nullptr;
   ~BaSession() {
     delete db;
     if (arena) hipFree(arena);
@@ -1485,6 +1494,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   unsigned long long*& d_gmax = S.d_gmax;
   int *&d_bad = S.d_bad, *&d_info = S.d_info;
   unsigned*& d_flow = S.d_flow;
+  int& cr_T = S.cr_T;
+  double *&d_cr_dinv = S.d_cr_dinv, *&d_cr_W = S.d_cr_W;
   const int eval_blocks = gh_div_up(no > 0 ? no : 1, 256);
   // (first run only, kept for the verbose / check paths below)
   std::vector<int32_t> pair_a, pair_b, bstart, bci, bcj;
@@ -1719,6 +1730,33 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   GH_TRY(db.alloc(&d_xh, (size_t)gh_div_up(n, 64) * 64));
   d_flow = nullptr;  // state of the single-launch factorisation (null when the shape does not fit it)
   if (const size_t words = gh_potrf_flow_words(ctx, n, 1)) GH_TRY(db.alloc(&d_flow, words));
+  {
+    // The reduced camera system couples two cameras only if they see a common point: with every point seen from cameras
+    // at most `span` indices apart (a trajectory), S is a band of half-width 6 span + 5 and the band solver applies.
+    int span = 0;
+    {
+      std::vector<int32_t> lo((size_t)np, INT32_MAX), hi((size_t)np, -1);
+      for (int k = 0; k < no; ++k) {
+        const int p = pr->obs_point[k], c = pr->obs_cam[k];
+        if (c < lo[p]) lo[p] = c;
+        if (c > hi[p]) hi[p] = c;
+      }
+      for (int p = 0; p < np; ++p)
+        if (hi[p] >= 0 && hi[p] - lo[p] > span) span = hi[p] - lo[p];
+    }
+    S.cam_span = span;
+    int want = ctx->ba_solver;
+    if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
+    cr_T = want == 1 || n >= 65536 ? 0 : gh_cr_tiles(n, 6 * span + 5);
+    d_cr_dinv = d_cr_W = nullptr;
+    if (cr_T) {
+      GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n, cr_T)));
+      GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n, cr_T)));
+    }
+    if (opt.verbose)
+      fprintf(stderr, "[gh_ba] cameras of a point at most %d indices apart: half-bandwidth %d of n = %d -> %s\n", span,
+              6 * span + 5, n, cr_T ? "band solver (block cyclic reduction)" : "dense factorisation");
+  }
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
   d_spart = nullptr;
   if (!device_pairs) GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
@@ -1832,7 +1870,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
                 d_Hpi, d_bad);
     }
-    const bool slim_init = d_flow != nullptr && n < 65536;  // the single-launch factorisation reads the lower tiles only
+    const bool slim_init = (d_flow != nullptr || cr_T != 0) && n < 65536;  // both solvers read the lower tiles only
     const bool fused_seed = slim_init && no > 0 && opt.deterministic;  // then the seed rides with the segment sums below
     bool solve_state_ready = false;  // set when schur_reduce_kernel has cleared what the single-launch solve kernels need
     if (slim_init) {
@@ -1882,16 +1920,20 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const double t_solve0 = now_ms();
     // (one single-launch factorisation at a time per process, until this iteration's synchronisation: see chol.hip)
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
-    if (d_flow) flow_lock.lock();
+    if (d_flow && !cr_T) flow_lock.lock();
     // The whole candidate step is enqueued without waiting for the factorisation flags (the kernels have no
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host
     // synchronisation per iteration instead of three.
     // rhs -> row n of S: already there when schur_init_kernel + schur_reduce_kernel wrote it
     if (!(slim_init && opt.deterministic))
       GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
+    if (cr_T) {
+      GH_TRY(gh_cr_solve_dev_impl(ctx, d_S, n, lda, cr_T, d_cr_dinv, d_cr_W, d_dc, d_info, solve_state_ready));
+    } else {
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
     GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info, solve_state_ready));
+    }
     GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GH_LAUNCH(ctx, "ba_backsub", backsub_update_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, P, d_Hpi,

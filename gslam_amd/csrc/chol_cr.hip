@@ -1,0 +1,843 @@
+// Banded SPD solve by block cyclic reduction (f64, gfx950): the linear solver of bundle adjustment when the reduced
+// camera system is a BAND -- cameras along a trajectory that only share points with their neighbours, the normal case of
+// visual odometry / windowed SLAM -- instead of the dense factorisation of chol.hip.
+//
+// Stands in for the SPARSE_SCHUR solve inside the (absent) Ceres plugin behind GSLAM::Optimizer::optimize
+// (GSLAM/core/Optimizer.h:229); the result equals the dense Cholesky solve up to rounding (it IS a Cholesky factorisation,
+// of the symmetrically permuted matrix), restated independently in tests/test_cr_solver.py.
+//
+// Why: the dense single-launch factorisation (ba_potrf_flow) is a chain of n sequential pivots -- 47 diagonal blocks of
+// 16 us at n = 3000, 85 % of its wave-cycles idle -- whether or not the tiles off the band are zero.  A band of half-width
+// h <= m is block TRIDIAGONAL in superblocks of m = 64 T columns (T = 1..3), and eliminating every other superblock is
+// independent work: level r (stride s = 2^r) removes the superblocks i = s (mod 2 s) at once,
+//     L_i = chol(D_i),   W_u = B(i,u)^T L_i^-T,  W_d = B(d,i) L_i^-T          (u = i - s, d = i + s)
+//     D_u -= W_u W_u^T,  D_d -= W_d W_d^T,  B(d,u) -= W_d W_u^T  (fill: lands in the zero part of the dense lower triangle)
+// and the survivors are again block tridiagonal with stride 2 s.  ceil(log2 N) levels + one last block: the chain is
+// (levels + 1) m pivots -- 960 instead of 3000 at C4 -- and every level is three launches without any in-launch hand-off:
+//     ba_cr_factor   one workgroup per eliminated superblock: potf2 + inverse of its T diagonal tiles (chol_potf2.h),
+//                    X = P M^T and the trailing tiles on MFMA, everything of the superblock through LDS / L2
+//     ba_cr_panels   W = P L_i^-T by 16-row strips (4 waves = the four 16-column blocks of a tile, the strip in LDS, the
+//                    tiles of L_i and M straight from L2 in MFMA operand layout); the right-hand side (row n of A, as in
+//                    chol.hip) is one more strip: y_i = b_i L_i^-T
+//     ba_cr_update   one workgroup per 64 x 64 tile of D_u / D_d / B(d,u): rank-m update from the W panels (both sources of
+//                    a diagonal block in one task: fixed summation order, no atomics); b_j -= y_i W^T for the rhs
+// then backwards, one launch per level:  x_i = (y_i - x_u W_u - x_d W_d) L_i^-1   (ba_cr_back).
+// Storage: A is the dense column-major lower triangle chol.hip uses (n x n, lda > n, rhs in row n); L_i overwrites D_i, the
+// W panels go to a workspace (2 N m^2 doubles), the inverted diagonal tiles to `dinv` (N T tiles).
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int NBI = 64;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#include "chol_potf2.h"
+
+// tools/cr_stamp_probe.hip defines GH_CR_PROBE: wall-clock stamps (100 MHz) of workgroup 0 of the level-0 launches
+#ifdef GH_CR_PROBE
+__device__ long long g_cr_stamp[64];
+#define CR_STAMP(slot)                                                                              \
+  do {                                                                                              \
+    if (a.s == 1 && blockIdx.x == 0 && threadIdx.x == 0) g_cr_stamp[(slot)] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define CR_STAMP(slot) \
+  do {                 \
+  } while (0)
+#endif
+
+constexpr int kCrXP = 80;  // LDS pitch of the operand tiles of the MFMA phases (see cr_factor_kernel)
+
+struct CrArgs {
+  double* A;     // n x n lower triangle + rhs row n, column-major
+  int lda, n;
+  int N;         // superblocks of m = 64 T columns
+  int s;         // stride of this level: eliminated i = first + e * 2 s, neighbours i -+ s
+  int first, count;
+  double* dinv;  // N * T tiles of 4096 doubles: M = L^-1 of every diagonal tile (column-major, pitch 64, upper part zero)
+  double* W;     // [N][2][m * m]: W(i, side)[rho][c] at c * m + rho   (side 0 = u, 1 = d)
+  double* G;     // [N][2][m * m]: G(i, side) = W(i, side) L_i^-1, same layout: the backward pass is x_i = yh_i - x_u G_u - x_d G_d
+  double* W3;    // [N][m * m]: L_i^-T (the panel of P = identity), same layout
+  double* yh;    // [N * m]: yh_i = y_i L_i^-1
+  double* x;     // n
+  int* info;
+};
+
+// compile-time loop: f(std::integral_constant<int, K>) for K = 0 .. N - 1 (a runtime loop around the potf2 code is not
+// unrolled by the compiler, and the accumulator arrays it indexes would then live in scratch)
+template <int K, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
+
+// Guarded element of A WITHOUT a branch.  A lane-conditional global load -- and equally a select between a loaded value and
+// a constant, which the code generator turns back into a branch around the load -- compiles to "skip if exec is empty; load;
+// s_waitcnt vmcnt(0)": every load of a prefetch block waits for the one before it (22 us for the 48 operand loads of a panel
+// strip).  So: the address is clamped into the matrix, the load is unconditional, and the value is kept or zeroed by an
+// integer AND on its bits (never NaN, whatever the clamped address held).
+__device__ __forceinline__ double keep_if(double v, bool ok) {
+  return __longlong_as_double(__double_as_longlong(v) & (ok ? ~0ll : 0ll));
+}
+__device__ __forceinline__ double ld_guard(const double* __restrict__ A, size_t lda, int row, int col, int row_lim, int col_lim) {
+  const int rc = row < row_lim ? row : row_lim - 1, cc = col < col_lim ? col : col_lim - 1;
+  return keep_if(A[(size_t)cc * lda + rc], row < row_lim && col < col_lim);
+}
+
+// D[i][j] += sum_t a(i, t) b(t, j) on v_mfma_f64_16x16x4_f64: the lane supplies a(m, 4 ks + q) and b(4 ks + q, m) and holds
+// D[q + 4 r][m] in acc[r]  (m = lane & 15, q = lane >> 4), as lds_mma in chol_potf2.h.
+__device__ __forceinline__ double4_t mma(double a, double b, double4_t acc) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ factor
+// One workgroup (8 waves) per eliminated superblock.  Every tile of the superblock is read ONCE, at the start, into MFMA
+// accumulators (negated: -A + sum X X^T, lane = [row 16 rg + m][col 16 cb + q + 4 r], the 16 rows of a lane group are 128
+// contiguous bytes of A); per diagonal tile k the accumulators of column k go to LDS, potf2 + inverse run there
+// (potf2_chain_lds: the inversion hides behind the pivots), X = P M^T and the trailing tiles are MFMA work out of LDS, and
+// L / M leave with fire-and-forget stores: no global load sits between two diagonal tiles.
+// Wave (rg, hf): rows 16 rg .. of a tile, column blocks 2 hf, 2 hf + 1.
+template <int T>
+__global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cr_lds[];
+  Potf2Lds& sh = *reinterpret_cast<Potf2Lds*>(cr_lds);
+  constexpr size_t kShBytes = (sizeof(Potf2Lds) + 15) & ~(size_t)15;
+  double* const T2 = reinterpret_cast<double*>(cr_lds + kShBytes);  // 16 x 17 doubles of scratch for the inversion
+  // tile j = 1 .. T - 1 of the current column: element (row, t) at t * XP + row.  Pitch 80: the four k-rows (q) of an MFMA
+  // operand read start 32 banks apart, so a half-wave touches every bank once (pitch 65 is a two-way conflict)
+  constexpr int XP = kCrXP;
+  auto xs = [&](int j) {
+    return reinterpret_cast<double*>(cr_lds + kShBytes + 16 * 17 * sizeof(double)) + (size_t)(j - 1) * (NBI * XP);
+  };
+  constexpr int m_ = NBI * T;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), rg = wv & 3, hf = wv >> 2;
+  const int i = a.first + (int)blockIdx.x * 2 * a.s;
+  const int i0 = i * m_, n = a.n;
+  const size_t lda = (size_t)a.lda;
+  double* const A = a.A;
+  CR_STAMP(0);
+  // neg[tile (ii, jj)][cbi]: -(A - sum) of the lower tiles, ii >= jj; tile (0, 0) first: the first potf2 only waits for it,
+  // the other tiles land while it runs
+  double4_t neg[T * (T + 1) / 2][2];
+#pragma unroll
+  for (int ii = 0; ii < T; ++ii) {
+#pragma unroll
+    for (int jj = 0; jj <= ii; ++jj) {
+#pragma unroll
+      for (int cbi = 0; cbi < 2; ++cbi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + NBI * ii + 16 * rg + m, col = i0 + NBI * jj + 16 * (2 * hf + cbi) + q + 4 * r;
+          double v = ld_guard(A, lda, row, col, n, n);
+          if (ii == jj) v = keep_if(v, col <= row) + ((row == col && row >= n) ? 1.0 : 0.0);  // lower part; identity padding past n
+          neg[ii * (ii + 1) / 2 + jj][cbi][r] = -v;
+        }
+      }
+    }
+  }
+  for (int e = tid; e < NBI * LP; e += 512) sh.Ms[e] = 0.0;  // the inversion only ever writes the lower blocks
+  static_for<0, T>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int c0 = i0 + NBI * k;
+    const int kb = n - c0 < NBI ? (n - c0 > 0 ? n - c0 : 0) : NBI;
+    double* const Minv = a.dinv + (size_t)(i * T + k) * (NBI * NBI);
+    lds_barrier();  // the previous step's products are done with the tile buffers
+    if (tid == 0) {
+      sh.bad = 0;
+      sh.pivots_done = 0;
+      sh.next_ready = 0;
+      sh.progress = 0;
+      sh.x10_done = 0;
+    }
+#pragma unroll
+    for (int cbi = 0; cbi < 2; ++cbi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rg + m, col = 16 * (2 * hf + cbi) + q + 4 * r;
+        sh.As[col * LP + row] = col <= row ? -neg[k * (k + 1) / 2 + k][cbi][r] : 0.0;
+      }
+    }
+    lds_barrier();
+    CR_STAMP(1 + 4 * k);
+    potf2_chain_lds(sh, T2, tid, [] {}, [] {});
+    CR_STAMP(2 + 4 * k);
+    if (tid == 0 && sh.bad) atomicMax(a.info, c0 + 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = tid + 512 * e, c = idx >> 6, r = idx & 63;
+      if (r < kb && c < kb && c <= r) A[(size_t)(c0 + c) * lda + c0 + r] = sh.As[c * LP + r];
+      Minv[idx] = (c <= r) ? sh.Ms[c * LP + r] : 0.0;
+    }
+    CR_STAMP(3 + 4 * k);
+    if constexpr (k + 1 < T) {
+      // the tiles below, out of their accumulators (for k = 0 their loads had the whole potf2 to land)
+#pragma unroll
+      for (int cbi = 0; cbi < 2; ++cbi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rg + m, col = 16 * (2 * hf + cbi) + q + 4 * r;
+#pragma unroll
+          for (int j = k + 1; j < T; ++j) xs(j)[col * XP + row] = -neg[j * (j + 1) / 2 + k][cbi][r];
+        }
+      }
+      lds_barrier();
+      // X(j, k) = P M^T: one read of P feeds both column blocks of the wave, the chains of different tiles interleave
+      double4_t xa[T > 1 ? T - 1 : 1][2];
+#pragma unroll
+      for (int j = k + 1; j < T; ++j) xa[j - 1][0] = xa[j - 1][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks < 4 * (2 * hf + 2)) {  // M[c][t] = 0 for t > c
+          const double m0 = sh.Ms[(4 * ks + q) * LP + 16 * (2 * hf) + m], m1 = sh.Ms[(4 * ks + q) * LP + 16 * (2 * hf + 1) + m];
+#pragma unroll
+          for (int j = k + 1; j < T; ++j) {
+            const double b = xs(j)[(4 * ks + q) * XP + 16 * rg + m];
+            if (ks < 4 * (2 * hf + 1)) xa[j - 1][0] = mma(m0, b, xa[j - 1][0]);
+            xa[j - 1][1] = mma(m1, b, xa[j - 1][1]);
+          }
+        }
+      }
+      lds_barrier();  // every wave is done reading P
+#pragma unroll
+      for (int j = k + 1; j < T; ++j) {
+        const int r0 = i0 + NBI * j;
+#pragma unroll
+        for (int cbi = 0; cbi < 2; ++cbi) {
+          const int cb = 2 * hf + cbi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = 16 * cb + q + 4 * r, row = 16 * rg + m;
+            xs(j)[col * XP + row] = xa[j - 1][cbi][r];
+            if (r0 + row < n && col < kb) A[(size_t)(c0 + col) * lda + r0 + row] = xa[j - 1][cbi][r];
+          }
+        }
+      }
+      lds_barrier();
+      CR_STAMP(4 + 4 * k);
+      // trailing tiles (ii, jj), k < jj <= ii < T:  -C += X_ii X_jj^T; per k-step one read of every operand block
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        double av[T][2], bv[T];
+#pragma unroll
+        for (int j = k + 1; j < T; ++j) {
+          bv[j] = xs(j)[(4 * ks + q) * XP + 16 * rg + m];
+          av[j][0] = xs(j)[(4 * ks + q) * XP + 16 * (2 * hf) + m];
+          av[j][1] = xs(j)[(4 * ks + q) * XP + 16 * (2 * hf + 1) + m];
+        }
+#pragma unroll
+        for (int jj = k + 1; jj < T; ++jj) {
+#pragma unroll
+          for (int ii = jj; ii < T; ++ii) {
+#pragma unroll
+            for (int cbi = 0; cbi < 2; ++cbi) {
+              if (ii == jj && 2 * hf + cbi > rg) continue;  // strictly upper 16 x 16 blocks of a diagonal tile
+              neg[ii * (ii + 1) / 2 + jj][cbi] = mma(av[jj][cbi], bv[ii], neg[ii * (ii + 1) / 2 + jj][cbi]);
+            }
+          }
+        }
+      }
+    }
+  });
+  CR_STAMP(15);
+}
+
+// ------------------------------------------------------------------------------------------------ panels
+// One workgroup (4 waves) per 16-row strip of a panel of an eliminated superblock i: W = P L_i^-T, column tile by column
+// tile:  W_c = (P_c - sum_{c' < c} W_c' L(c, c')^T) M_cc^T.  Wave w owns the 16-column block w of every tile.  Every tile of
+// L_i / M the wave will multiply with is asked for at the START, in MFMA operand layout (the 16 rows of a lane group are
+// contiguous), together with the strip itself: one memory round trip, then only LDS and MFMA phases.  The strip lives in LDS
+// as [column t][row j] (pitch 17): Pl holds P / P', Xl the finished W.
+// task: 0 .. 4T-1 strips of side u (P = B(i, u)^T), 4T .. 8T-1 side d (P = B(d, i)), 8T = the right-hand side,
+// 8T+1 .. 12T strips of P = identity: W3 = L_i^-T, what turns the backward pass into plain products (cr_update_kernel).
+template <int T>
+__global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int ntask) {
+  constexpr int m_ = NBI * T, PW = 17;
+  __shared__ double Pl[m_ * PW], Xl[m_ * PW];
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // every task of an eliminated superblock on ONE XCD (block b runs on XCD b % 8, each with its own L2): the six operand
+  // tiles come over the fabric once per XCD instead of once per workgroup (placement only affects speed)
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int e = xcd + 8 * (slot / ntask), task = task0 + slot % ntask;
+  if (e >= a.count) return;
+  // (a.s == 0: every eliminated superblock of every level, i = 1 .. N - 1 -- only the identity strips are run that way)
+  const int i = a.s == 0 ? 1 + e : a.first + e * 2 * a.s, i0 = i * m_, n = a.n;
+  const size_t lda = (size_t)a.lda;
+  const double* const A = a.A;
+  const int side = task > 8 * T ? 3 : (task == 8 * T ? 2 : (task >= 4 * T ? 1 : 0));
+  const int strip = side == 3 ? task - 8 * T - 1 : task - 4 * T * (side == 1 ? 1 : (side == 2 ? 2 : 0));
+  const int nb = side == 0 ? i - a.s : i + a.s;
+  if (side < 2 && (nb < 0 || nb >= a.N)) return;
+  const int nb0 = nb * m_ + 16 * strip;  // first row of the strip (side u / d)
+  CR_STAMP(16);
+  // ---- the strip of P: asked for first (it is needed first), into registers; LDS behind the operand requests below
+  constexpr int kStripIt = 16 * m_ / 256;
+  double pv[kStripIt];
+#pragma unroll
+  for (int it = 0; it < kStripIt; ++it) {
+    // (one branch-free load per element whatever the side: see ld_guard)
+    const int idx = tid + 256 * it;
+    const int j = side == 0 ? idx / m_ : (idx & 15), t = side == 0 ? idx - (idx / m_) * m_ : (idx >> 4);
+    const int row = side == 0 ? i0 + t : (side == 1 ? nb0 + j : (side == 2 ? n : 0));
+    const int col = side == 0 ? nb0 + j : (side == 3 ? 0 : i0 + t);
+    const double v = ld_guard(A, lda, row, col, side == 2 ? n + 1 : n, n);
+    pv[it] = keep_if(v, side < 2 || (side == 2 && j == 0)) + ((side == 3 && t == 16 * strip + j) ? 1.0 : 0.0);
+  }
+  // ---- operands of every product of this wave
+  double mreg[T][16], lreg[T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1][16];
+#pragma unroll
+  for (int c = 0; c < T; ++c) {
+    const double* Minv = a.dinv + (size_t)(i * T + c) * (NBI * NBI);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) mreg[c][ks] = Minv[(4 * ks + q) * NBI + 16 * w + m];  // (stored zeros above the diagonal)
+#pragma unroll
+    for (int cp = 0; cp < c; ++cp) {
+      const int lrow = i0 + NBI * c + 16 * w + m;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int lcol = i0 + NBI * cp + 4 * ks + q;
+        lreg[c * (c - 1) / 2 + cp][ks] = -ld_guard(A, lda, lrow, lcol, n, n);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kStripIt; ++it) {
+    const int idx = tid + 256 * it;
+    const int j = side == 0 ? idx / m_ : (idx & 15), t = side == 0 ? idx - (idx / m_) * m_ : (idx >> 4);
+    Pl[t * PW + j] = pv[it];
+  }
+  lds_barrier();
+  CR_STAMP(17);
+#pragma unroll
+  for (int c = 0; c < T; ++c) {
+    if (c > 0) {
+      // P'_c = P_c - sum_{c' < c} W_c' L(c, c')^T : lane holds [row m][col 64 c + 16 w + q + 4 r]; two accumulation chains
+      double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc0[r] = Pl[(NBI * c + 16 * w + q + 4 * r) * PW + m];
+#pragma unroll
+      for (int cp = 0; cp < c; ++cp) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+          acc0 = mma(lreg[c * (c - 1) / 2 + cp][ks], Xl[(NBI * cp + 4 * ks + q) * PW + m], acc0);
+          acc1 = mma(lreg[c * (c - 1) / 2 + cp][ks + 1], Xl[(NBI * cp + 4 * (ks + 1) + q) * PW + m], acc1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pl[(NBI * c + 16 * w + q + 4 * r) * PW + m] = acc0[r] + acc1[r];
+      lds_barrier();
+    }
+    // W_c = P'_c M_cc^T
+    double4_t x0 = (double4_t){0.0, 0.0, 0.0, 0.0}, x1 = x0;
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 2) {
+      if (ks < 4 * (w + 1)) {
+        x0 = mma(mreg[c][ks], Pl[(NBI * c + 4 * ks + q) * PW + m], x0);
+        x1 = mma(mreg[c][ks + 1], Pl[(NBI * c + 4 * (ks + 1) + q) * PW + m], x1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xl[(NBI * c + 16 * w + q + 4 * r) * PW + m] = x0[r] + x1[r];
+    lds_barrier();
+  }
+  CR_STAMP(18);
+  // ---- out
+  if (side != 2) {
+    double* Wo = (side == 3 ? a.W3 + (size_t)i * ((size_t)m_ * m_) : a.W + ((size_t)i * 2 + side) * ((size_t)m_ * m_)) + 16 * strip;
+#pragma unroll
+    for (int it = 0; it < 16 * m_ / 256; ++it) {
+      const int idx = tid + 256 * it, j = idx & 15, t = idx >> 4;
+      Wo[(size_t)t * m_ + j] = Xl[t * PW + j];
+    }
+  } else {
+    for (int t = tid; t < m_; t += 256)
+      if (i0 + t < n) a.A[(size_t)(i0 + t) * lda + n] = Xl[t * PW];
+  }
+  CR_STAMP(19);
+}
+
+// ------------------------------------------------------------------------------------------------ update
+// Products of the panels the previous launch wrote; one 16 x 16 block of a 64 x 64 output tile per WAVE, operands read
+// straight from L2 in MFMA layout (no LDS, no barrier): every task of a group runs on ONE XCD (block b -> XCD b % 8), so a
+// panel crosses the fabric once per XCD and the 16-fold re-reads of its rows hit that XCD's L2.
+// mode 0, group = survivor j = 2 s q:  tiles 0 .. T(T+1)/2 - 1  the lower tiles of D_j (sources: W_d of j - s, W_u of j + s),
+//   then T T tiles of the fill block B(j + 2 s, j) (source j + s: W_d W_u^T), then the right-hand side of j (m / 16 workgroups).
+// mode 1, group = eliminated i = 1 + group of ANY level (off the critical path: cr_solve_t runs it once, on a side stream,
+//   under the factorisation of the last block): 2 T T tiles of
+//   G(i, side) = W(i, side) L_i^-1 = W W3^T (W3 = L_i^-T is upper triangular: only the K-tiles >= the column tile count), then
+//   yh_i = y_i L_i^-1.
+// A workgroup = one quadrant (32 x 32) of a tile, or the vector task of the group.
+template <int T>
+__global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int ngroups) {
+  constexpr int m_ = NBI * T, ND = T * (T + 1) / 2, NV = m_ / 16, NTS = 4 * (ND + T * T) + NV, NTE = 4 * (2 * T * T) + NV;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = a.n;
+  const size_t lda = (size_t)a.lda;
+  const size_t mm = (size_t)m_ * m_;
+  const bool elim_task = mode != 0;
+  const int ntask = elim_task ? NTE : NTS;
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int grp = xcd + 8 * (slot / ntask), task = slot % ntask;
+  if (grp >= ngroups) return;
+  // ---- the vector tasks: out[c] (+)= -+ sum_t y[t] W[c][t], 16 columns per workgroup (a whole panel through one CU takes
+  // ~25 us); thread = (column tid & 15, the t with t % 16 == tid >> 4): every wave instruction reads four 128-byte rows
+  if (task >= ntask - NV) {
+    __shared__ double red[16][17];
+    const int c = 16 * (task - (ntask - NV)) + (tid & 15), tg = tid >> 4;
+    const int j = grp * 2 * a.s;             // survivor
+    const int i = elim_task ? 1 + grp : 0;   // eliminated (mode 1 runs over the superblocks of every level)
+    double sum = 0.0;
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      int src;
+      const double* Wp;
+      if (elim_task) {
+        if (sd == 1) continue;
+        src = i;
+        Wp = a.W3 + (size_t)i * mm;
+      } else {
+        src = sd == 0 ? j - a.s : j + a.s;
+        if (src < 0 || src >= a.N) continue;
+        Wp = a.W + ((size_t)src * 2 + (sd == 0 ? 1 : 0)) * mm;  // j is the d-neighbour of j - s, the u-neighbour of j + s
+      }
+      const int s0 = src * m_;
+      double yv[m_ / 16], wv[m_ / 16];
+#pragma unroll
+      for (int k = 0; k < m_ / 16; ++k) {
+        const int t = tg + 16 * k;
+        yv[k] = ld_guard(a.A, lda, n, s0 + t, n + 1, n);
+        wv[k] = Wp[(size_t)t * m_ + c];
+      }
+#pragma unroll
+      for (int k = 0; k < m_ / 16; ++k) sum = __builtin_fma(yv[k], wv[k], sum);
+    }
+    red[tg][tid & 15] = sum;
+    __syncthreads();
+    if (tid < 16) {
+      double tot = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tot += red[g][tid];
+      if (elim_task) a.yh[(size_t)i * m_ + c] = tot;
+      else if (j * m_ + c < n) a.A[(size_t)(j * m_ + c) * lda + n] -= tot;
+    }
+    return;
+  }
+  // ---- tile tasks
+  const int tile = task >> 2, quad = task & 3;
+  const int rb = 2 * (quad & 1) + (w & 1), cb = 2 * (quad >> 1) + (w >> 1);  // this wave's 16 x 16 block of the tile
+  int ta, tb, tt_lo = 0, nsrc = 0, row0, col0;
+  bool diag = false;
+  const double *R0 = nullptr, *R1 = nullptr, *C0 = nullptr, *C1 = nullptr;  // panel of the row / column operand per source
+  double* out;      // element (row, col) of the output tile at out[col * ldo + row]
+  size_t ldo;
+  if (elim_task) {
+    const int i = 1 + grp, si = i & -i;  // eliminated at the level of stride si
+    const int side = tile / (T * T), f = tile - side * (T * T);
+    const int nb = side == 0 ? i - si : i + si;
+    if (nb < 0 || nb >= a.N) return;
+    ta = f / T;
+    tb = f - ta * T;
+    tt_lo = tb;
+    nsrc = 1;
+    R0 = a.W + ((size_t)i * 2 + side) * mm;
+    C0 = a.W3 + (size_t)i * mm;
+    out = a.G + ((size_t)i * 2 + side) * mm + (size_t)(NBI * tb) * m_ + NBI * ta;
+    ldo = m_;
+    row0 = col0 = 0;  // (no bounds: the panels are padded with zeros)
+  } else {
+    const int j = grp * 2 * a.s;
+    const int src_lo = j - a.s, src_hi = j + a.s;  // eliminated neighbours of j (each may be absent)
+    const bool has_lo = src_lo >= 0, has_hi = src_hi < a.N;
+    int row_blk;
+    if (tile < ND) {
+      ta = tile < 1 ? 0 : (tile < 3 ? 1 : 2);
+      tb = tile - ta * (ta + 1) / 2;
+      row_blk = j;
+      if (has_lo) {
+        R0 = C0 = a.W + ((size_t)src_lo * 2 + 1) * mm;
+        nsrc = 1;
+      }
+      if (has_hi) {
+        (nsrc ? R1 : R0) = a.W + ((size_t)src_hi * 2 + 0) * mm;
+        (nsrc ? C1 : C0) = a.W + ((size_t)src_hi * 2 + 0) * mm;
+        ++nsrc;
+      }
+      diag = ta == tb;
+    } else {
+      const int f = tile - ND;
+      ta = f / T;
+      tb = f - ta * T;
+      row_blk = j + 2 * a.s;
+      if (row_blk >= a.N) return;
+      nsrc = 1;
+      R0 = a.W + ((size_t)src_hi * 2 + 1) * mm;  // W_d of j + s: rows of j + 2 s
+      C0 = a.W + ((size_t)src_hi * 2 + 0) * mm;  // W_u of j + s: rows of j
+    }
+    if (nsrc == 0) return;
+    row0 = row_blk * m_ + NBI * ta;
+    col0 = j * m_ + NBI * tb;
+    if (row0 >= n || col0 >= n) return;
+    out = a.A + (size_t)col0 * lda + row0;
+    ldo = lda;
+  }
+  if (diag && cb > rb) return;  // strictly upper block of a diagonal tile
+  const int rlim = elim_task ? NBI : n - row0, clim = elim_task ? NBI : n - col0;  // valid rows / columns of the output tile
+  CR_STAMP(24);
+  double4_t acc0, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * rb + m, col = 16 * cb + q + 4 * r;
+    double v = 0.0;
+    if (!elim_task) v = ld_guard(out, ldo, row, col, rlim, clim);  // (uniform branch)
+    acc0[r] = -keep_if(v, !(diag && col > row));
+  }
+  CR_STAMP(25);
+  // the phases (source, K-tile) of this task are the contiguous range [tt_lo, nsrc T); the operands of phase p + 1 are
+  // asked for before the MFMAs of phase p (two register sets, ping-pong)
+  const int p_hi = nsrc * T;
+  auto fetch = [&](int ph, double (&av)[16], double (&bv)[16]) {
+    const int sd = ph >= T ? 1 : 0, tt = ph - sd * T;
+    const double* Rp = (sd == 0 ? R0 : R1) + (size_t)(NBI * tt + q) * m_ + NBI * ta + 16 * rb + m;
+    const double* Cp = (sd == 0 ? C0 : C1) + (size_t)(NBI * tt + q) * m_ + NBI * tb + 16 * cb + m;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      av[ks] = Cp[(size_t)(4 * ks) * m_];
+      bv[ks] = Rp[(size_t)(4 * ks) * m_];
+    }
+  };
+  auto product = [&](const double (&av)[16], const double (&bv)[16]) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 2) {
+      acc0 = mma(av[ks], bv[ks], acc0);
+      acc1 = mma(av[ks + 1], bv[ks + 1], acc1);
+    }
+  };
+  {
+    double a0[16], b0[16], a1[16], b1[16];
+    int ph = tt_lo;
+    fetch(ph, a0, b0);
+    while (true) {
+      if (ph + 1 < p_hi) fetch(ph + 1, a1, b1);
+      product(a0, b0);
+      if (++ph >= p_hi) break;
+      if (ph + 1 < p_hi) fetch(ph + 1, a0, b0);
+      product(a1, b1);
+      if (++ph >= p_hi) break;
+    }
+  }
+  CR_STAMP(26);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * rb + m, col = 16 * cb + q + 4 * r;
+    const double v = acc0[r] + acc1[r];
+    if (row < rlim && col < clim && (!diag || col <= row)) out[(size_t)col * ldo + row] = elim_task ? v : -v;
+  }
+  CR_STAMP(27);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Sum over the wave, valid in lane 63: four DPP row shifts + two row broadcasts (three VALU each for a double), as
+// wave_incl_scan_i32 in orb.hip.  Every lane of the wave must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum63(double v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31
+  return v;
+}
+
+// Levels: x_i = yh_i - x_u G_u - x_d G_d.  16 columns of a superblock per workgroup (49 KB of G: a workgroup that streams
+// a whole superblock's panels -- 590 KB -- through one CU takes ~25 us), a wave per 4 columns, lanes along the column.
+template <int T>
+__global__ __launch_bounds__(256) void cr_back_kernel(CrArgs a) {
+  constexpr int m_ = NBI * T, NG = m_ / 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int e = xcd + 8 * (slot / NG), g = slot % NG;
+  if (e >= a.count) return;
+  const int i = a.first + e * 2 * a.s, i0 = i * m_, n = a.n;
+  const size_t mm = (size_t)m_ * m_;
+  const int u = i - a.s, d = i + a.s;
+  const bool has_u = u >= 0, has_d = d < a.N;
+  CR_STAMP(32);
+  double xu[T], xd[T];
+#pragma unroll
+  for (int rr = 0; rr < T; ++rr) {
+    const int rho = lane + 64 * rr;
+    const int iu = has_u ? u * m_ + rho : 0, id = has_d ? d * m_ + rho : 0;
+    xu[rr] = keep_if(a.x[iu < n ? iu : n - 1], has_u && iu < n);
+    xd[rr] = keep_if(a.x[id < n ? id : n - 1], has_d && id < n);
+  }
+  const double* Gu = a.G + ((size_t)i * 2 + 0) * mm;
+  const double* Gd = a.G + ((size_t)i * 2 + 1) * mm;
+  double part[4];
+#pragma unroll
+  for (int cj = 0; cj < 4; ++cj) {
+    const int c = 16 * g + 4 * wv + cj;
+    double sum = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < T; ++rr) {
+      const int rho = lane + 64 * rr;
+      // (a missing neighbour's panel was never written: its bits are dropped, not multiplied by zero)
+      sum = __builtin_fma(xu[rr], keep_if(Gu[(size_t)c * m_ + rho], has_u), sum);
+      sum = __builtin_fma(xd[rr], keep_if(Gd[(size_t)c * m_ + rho], has_d), sum);
+    }
+    part[cj] = sum;
+  }
+  CR_STAMP(33);
+#pragma unroll
+  for (int cj = 0; cj < 4; ++cj) {
+    const int c = 16 * g + 4 * wv + cj;
+    const double sum = wave_sum63(part[cj]);
+    if (lane == 63 && i0 + c < n) a.x[i0 + c] = a.yh[(size_t)i * m_ + c] - sum;
+  }
+  CR_STAMP(36);
+}
+
+// The last block (no neighbours): x = y L^-1 by one workgroup, a wave per column, lanes along it; the columns of L / M the
+// triangular solve needs are asked for before anything else.
+__device__ __forceinline__ double wave_sum(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wave_sum63(v)), 63),
+                          __builtin_amdgcn_readlane(__double2loint(wave_sum63(v)), 63));
+}
+template <int T>
+__global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
+  constexpr int m_ = NBI * T;
+  __shared__ double xu[m_], xd[m_], tv[m_], zv[m_];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = a.first + (int)blockIdx.x * 2 * a.s, i0 = i * m_, n = a.n;
+  const size_t lda = (size_t)a.lda;
+  const size_t mm = (size_t)m_ * m_;
+  const int u = i - a.s, d = i + a.s;
+  const bool has_u = u >= 0, has_d = d < a.N;
+  // columns wv + 16 cj of every tile: M_kk[lane][c] and L(kp, k)[lane][c]
+  double mreg[T][4], lreg[T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1][4];
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    const double* Minv = a.dinv + (size_t)(i * T + k) * (NBI * NBI);
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const int c = wv + 16 * cj;
+      mreg[k][cj] = Minv[c * NBI + lane];  // zero above the diagonal
+#pragma unroll
+      for (int kp = k + 1; kp < T; ++kp) {
+        const int row = i0 + NBI * kp + lane, col = i0 + NBI * k + c;
+        lreg[kp * (kp - 1) / 2 + k][cj] = ld_guard(a.A, lda, row, col, n, n);
+      }
+    }
+  }
+  if (tid < m_) {
+    xu[tid] = (has_u && u * m_ + tid < n) ? a.x[u * m_ + tid] : 0.0;
+    xd[tid] = (has_d && d * m_ + tid < n) ? a.x[d * m_ + tid] : 0.0;
+    tv[tid] = i0 + tid < n ? a.A[(size_t)(i0 + tid) * lda + n] : 0.0;
+  }
+  __syncthreads();
+  if (has_u || has_d) {
+    const double* Wu = a.W + ((size_t)i * 2 + 0) * mm;
+    const double* Wd = a.W + ((size_t)i * 2 + 1) * mm;
+    double part[m_ / 16];
+#pragma unroll
+    for (int ci = 0; ci < m_ / 16; ++ci) {
+      const int c = wv + 16 * ci;
+      double sum = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < T; ++rr) {
+        const int rho = lane + 64 * rr;
+        if (has_u) sum = __builtin_fma(xu[rho], Wu[(size_t)c * m_ + rho], sum);
+        if (has_d) sum = __builtin_fma(xd[rho], Wd[(size_t)c * m_ + rho], sum);
+      }
+      part[ci] = sum;
+    }
+#pragma unroll
+    for (int ci = 0; ci < m_ / 16; ++ci) {
+      const double sum = wave_sum(part[ci]);
+      if (lane == 0) tv[wv + 16 * ci] -= sum;
+    }
+    __syncthreads();
+  }
+  // z L_i = t, tile by tile from the last:  z_k = (t_k - sum_{k' > k} z_k' L(k', k)) M_kk
+#pragma unroll
+  for (int k = T - 1; k >= 0; --k) {
+    if (k < T - 1) {
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        double sum = 0.0;
+#pragma unroll
+        for (int kp = k + 1; kp < T; ++kp) sum = __builtin_fma(zv[NBI * kp + lane], lreg[kp * (kp - 1) / 2 + k][cj], sum);
+        sum = wave_sum(sum);
+        if (lane == 0) tv[NBI * k + wv + 16 * cj] -= sum;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const double sum = wave_sum(tv[NBI * k + lane] * mreg[k][cj]);
+      if (lane == 0) zv[NBI * k + wv + 16 * cj] = sum;
+    }
+    __syncthreads();
+  }
+  if (tid < m_ && i0 + tid < n) a.x[i0 + tid] = zv[tid];
+}
+
+// a launch on `stream` through the context's profiler (GH_LAUNCH times on ctx->stream)
+#define CR_LAUNCH_ON(stream_, ...)          \
+  do {                                      \
+    hipStream_t keep_ = ctx->stream;        \
+    ctx->stream = (stream_);                \
+    gh_status st_ = [&]() -> gh_status {    \
+      GH_LAUNCH(ctx, __VA_ARGS__);          \
+      return GH_OK;                         \
+    }();                                    \
+    ctx->stream = keep_;                    \
+    if (st_ != GH_OK) return st_;           \
+  } while (0)
+
+template <int T>
+gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, double* W, double* x, int* info_dev) {
+  constexpr int m_ = NBI * T;
+  const int N = gh_div_up(n, m_);
+  const size_t mm = (size_t)m_ * m_;
+  const size_t factor_lds = ((sizeof(Potf2Lds) + 15) & ~(size_t)15) + 16 * 17 * sizeof(double) + (size_t)(T - 1) * NBI * kCrXP * sizeof(double);
+  {
+    static bool attr_set[64] = {};
+    const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (!attr_set[dev]) {
+      GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cr_factor_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)factor_lds));
+      attr_set[dev] = true;
+    }
+  }
+  // Off the critical path, on a side stream, in two launches behind the last level's panels (they overlap the factorisation
+  // of the last block): W3 = L_i^-T of every eliminated superblock, then G = W W3^T and yh -- only the backward pass reads
+  // them.  One event each way: every marker on the main stream costs its dependent launch chain ~7 us.
+  if (!ctx->cr_side && hipStreamCreateWithFlags(&ctx->cr_side, hipStreamNonBlocking) != hipSuccess)
+    return gh_set_error(ctx, GH_ERR_HIP, "band solver: side stream");
+  while ((int)ctx->cr_events.size() < 2) {
+    hipEvent_t ev;
+    GH_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->cr_events.push_back(ev);
+  }
+  hipStream_t side = ctx->cr_side;
+  // workspace: W [2 N m^2], G [2 N m^2], W3 [N m^2], yh [N m]
+  CrArgs a{A, lda, n, N, 1, 0, 0, dinv, W, W + 2 * (size_t)N * mm, W + 4 * (size_t)N * mm, W + 5 * (size_t)N * mm, x, info_dev};
+  constexpr int NTS = 4 * (T * (T + 1) / 2 + T * T) + m_ / 16, NTE = 4 * (2 * T * T) + m_ / 16;
+  for (int s = 1; s < N; s *= 2) {
+    a.s = s;
+    a.first = s;
+    a.count = (N - s + 2 * s - 1) / (2 * s);
+    const int g8 = 8 * gh_div_up(a.count, 8);  // groups of eight eliminated superblocks, one per XCD
+    GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(a.count), dim3(512), factor_lds, a);
+    GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(g8 * (8 * T + 1)), dim3(256), 0, a, 0, 8 * T + 1);
+    if (2 * s >= N) {  // the last level: everything the side work reads is (or will be, in stream order) complete here
+      GH_HIP(ctx, hipEventRecord(ctx->cr_events[0], ctx->stream));
+      GH_HIP(ctx, hipStreamWaitEvent(side, ctx->cr_events[0], 0));
+      CrArgs b = a;
+      b.s = 0;
+      b.first = 1;
+      b.count = N - 1;
+      const int ge = 8 * gh_div_up(N - 1, 8);
+      CR_LAUNCH_ON(side, "ba_cr_inverse", cr_panels_kernel<T>, dim3(ge * 4 * T), dim3(256), 0, b, 8 * T + 1, 4 * T);
+      CR_LAUNCH_ON(side, "ba_cr_backprep", cr_update_kernel<T>, dim3(ge * NTE), dim3(256), 0, b, 1, N - 1);
+      GH_HIP(ctx, hipEventRecord(ctx->cr_events[1], side));
+    }
+    const int nsurv = gh_div_up(N, 2 * s);
+    GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(8 * gh_div_up(nsurv, 8) * NTS), dim3(256), 0, a, 0, nsurv);
+  }
+  // the last block: block 0 with no neighbours (stride >= N)
+  int s_top = 1;
+  while (s_top < N) s_top *= 2;
+  a.s = s_top;
+  a.first = 0;
+  a.count = 1;
+  GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(1), dim3(512), factor_lds, a);
+  GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(8), dim3(256), 0, a, 8 * T, 1);  // y_0 (one task, XCD 0)
+  GH_LAUNCH(ctx, "ba_cr_back", cr_back_last_kernel<T>, dim3(1), dim3(1024), 0, a);
+  if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
+  for (int s = s_top / 2; s >= 1; s /= 2) {
+    a.s = s;
+    a.first = s;
+    a.count = (N - s + 2 * s - 1) / (2 * s);
+    GH_LAUNCH(ctx, "ba_cr_back", cr_back_kernel<T>, dim3(8 * gh_div_up(a.count, 8) * (m_ / 16)), dim3(256), 0, a);
+  }
+  return GH_OK;
+}
+
+}  // namespace
+
+// Tiles per superblock for a half-bandwidth of `hbw` scalars (A[r][c] = 0 for r - c > hbw), 0 = the band is too wide for
+// this solver (or the matrix too small to gain from it): the caller stays on the dense factorisation.
+int gh_cr_tiles(int n, int hbw) {
+  if (hbw < 0 || n < 1) return 0;
+  const int T = hbw <= NBI ? 1 : (hbw <= 2 * NBI ? 2 : (hbw <= 3 * NBI ? 3 : 0));
+  if (T == 0) return 0;
+  if (gh_div_up(n, NBI * T) < 4) return 0;
+  return T;
+}
+size_t gh_cr_dinv_doubles(int n, int T) { return (size_t)gh_div_up(n, NBI * T) * T * (NBI * NBI); }
+// workspace of the panels: W and G (two sides each), W3, yh
+size_t gh_cr_panel_doubles(int n, int T) {
+  const size_t N = (size_t)gh_div_up(n, NBI * T), m = (size_t)NBI * T;
+  return N * (5 * m * m + m);
+}
+
+// Solve A x = b for a band matrix: A n x n column-major lower triangle (overwritten), b in row n of A (lda > n), T from
+// gh_cr_tiles; everything outside the band must be ZERO in the lower triangle (the fill lands there).  x_dev: n doubles.
+// *info_dev: 0 or the first column + 1 of a diagonal tile that is not positive definite.  Asynchronous on the ctx stream.
+gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, double* dinv, double* W, double* x_dev,
+                               int* info_dev, bool info_ready) {
+  if (!info_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  switch (T) {
+    case 1: return cr_solve_t<1>(ctx, A, n, lda, dinv, W, x_dev, info_dev);
+    case 2: return cr_solve_t<2>(ctx, A, n, lda, dinv, W, x_dev, info_dev);
+    case 3: return cr_solve_t<3>(ctx, A, n, lda, dinv, W, x_dev, info_dev);
+    default: return gh_set_error(ctx, GH_ERR_ARG, "gh_cr_solve: %d tiles per superblock", T);
+  }
+}
+
+namespace {
+__global__ void cr_rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ A, int lda, int n) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) A[(size_t)j * lda + n] = rhs[j];
+}
+}  // namespace
+
+extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half_bandwidth, double* b_dev,
+                                       int* info) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, A_dev && b_dev && info && n > 0 && lda > n && half_bandwidth >= 0);
+  const int T = gh_cr_tiles(n, half_bandwidth);
+  if (T == 0)
+    return gh_set_error(ctx, GH_ERR_ARG, "gh_band_solve_dev: half-bandwidth %d of n = %d does not fit (<= %d, >= 4 superblocks)",
+                        half_bandwidth, n, 3 * NBI);
+  void* scratch = nullptr;
+  const size_t nd = gh_cr_dinv_doubles(n, T), nw = gh_cr_panel_doubles(n, T);
+  GH_TRY(gh_scratch(ctx, 256 + (nd + nw + (size_t)n) * sizeof(double), &scratch));
+  int* info_dev = (int*)scratch;
+  double* dinv = (double*)((char*)scratch + 256);
+  double* W = dinv + nd;
+  double* x = W + nw;
+  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
+  GH_TRY(gh_cr_solve_dev_impl(ctx, A_dev, n, lda, T, dinv, W, x, info_dev, false));
+  GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}

@@ -42,6 +42,11 @@ struct gh_ctx {
   // serialises on it; recursive because gh_ba_pnp calls gh_ba_solve
   std::recursive_mutex mu;
   int cu_count = 0;
+  // linear solver of gh_ba_solve's reduced camera system (gh_ctx_set_ba_solver): 0 auto, 1 dense, 2 band (cyclic reduction)
+  int ba_solver = 0;
+  // band solver (chol_cr.hip): side stream for the work off its critical path, and the events that order the two
+  hipStream_t cr_side = nullptr;
+  std::vector<hipEvent_t> cr_events;
 };
 
 // Entry guard of every public function that touches the device: serialises callers that share the context and makes the

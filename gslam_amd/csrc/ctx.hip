@@ -48,11 +48,21 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ba_arena) hipFree(ctx->ba_arena);
   if (ctx->pg_arena) hipFree(ctx->pg_arena);
+  for (auto e : ctx->cr_events) hipEventDestroy(e);
+  if (ctx->cr_side) hipStreamDestroy(ctx->cr_side);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
 extern "C" const char* gh_last_error(const gh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+extern "C" gh_status gh_ctx_set_ba_solver(gh_ctx* ctx, int solver) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, solver >= 0 && solver <= 2);
+  ctx->ba_solver = solver;
+  return GH_OK;
+}
 
 extern "C" gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream) {
   if (!ctx) return GH_ERR_ARG;

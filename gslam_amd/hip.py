@@ -104,6 +104,7 @@ SIGNATURES = {
     "gh_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
     "gh_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "gh_dev_memset": (C.c_int, [_vp, _vp, _i, _sz]),
+    "gh_ctx_set_ba_solver": (C.c_int, [_vp, _i]),
     "gh_prof_enable": (C.c_int, [_vp, _i]),
     "gh_prof_collect": (C.c_int, [_vp, C.POINTER(ProfEntry), _i, C.POINTER(_i)]),
     "gh_bf_match_dev": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -181,6 +182,7 @@ SIGNATURES = {
     "gh_graph_solve": (C.c_int, [_vp, C.POINTER(GraphProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "gh_align_sim3": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "gh_potrf_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, C.POINTER(_i)]),
+    "gh_band_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i)]),
     "gh_bs_symbolic": (C.c_int, [_i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "gh_bs_solve_host": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp, C.POINTER(_i)]),
 }
@@ -254,6 +256,11 @@ class Context:
             out[name.value.decode()] = r.value
             op += 1
         return out
+
+    def set_ba_solver(self, solver):
+        """0 / "auto", 1 / "dense", 2 / "band": linear solver of the reduced camera system (gh_ctx_set_ba_solver)."""
+        code = {"auto": 0, "dense": 1, "band": 2}.get(solver, solver)
+        self.check(lib.gh_ctx_set_ba_solver(self.h, int(code)))
 
     def prof_enable(self, on=True):
         self.check(lib.gh_prof_enable(self.h, 1 if on else 0))

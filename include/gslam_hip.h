@@ -55,6 +55,15 @@ const char* gh_last_error(const gh_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. the caller's current stream).  NULL is the legacy
  * default stream (what torch's default stream is); gh_ctx_use_own_stream restores the private one. */
 gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream);
+/* Linear solver of the reduced camera system in gh_ba_solve / gh_ba_graph_solve: GH_BA_SOLVER_AUTO (default) takes the
+ * band solver (block cyclic reduction, chol_cr.hip) when every point is seen from cameras at most 32 indices apart and
+ * the system has at least four superblocks, else the dense MFMA factorisation; _DENSE forces the dense path (what
+ * BASELINE's C5 names); _BAND asks for the band solver and falls back to dense when the graph is not a band.
+ * The environment variable GSLAM_HIP_BA_SOLVER=dense|band|auto overrides it (A/B measurements). */
+#define GH_BA_SOLVER_AUTO 0
+#define GH_BA_SOLVER_DENSE 1
+#define GH_BA_SOLVER_BAND 2
+gh_status gh_ctx_set_ba_solver(gh_ctx* ctx, int solver);
 gh_status gh_ctx_use_own_stream(gh_ctx* ctx);
 void* gh_ctx_stream(gh_ctx* ctx);
 gh_status gh_ctx_sync(gh_ctx* ctx);
@@ -577,6 +586,15 @@ gh_status gh_align_sim3(gh_ctx* ctx, const double* src, const double* dst, int n
 /* With lda > n the right-hand side rides through the factorisation as row n of A (one launch less per solve, as in the
  * bundle adjustment): the padding rows n .. lda - 1 are scratch then. */
 gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double* b_dev, int* info);
+
+/* The same solve for a BAND matrix by block cyclic reduction (gslam_amd/csrc/chol_cr.hip): what gh_ba_solve uses for the
+ * reduced camera system when the cameras only share points with their neighbours along the trajectory (the SPARSE_SCHUR
+ * case of the Ceres solve behind GSLAM/core/Optimizer.h:229).  A_dev n x n column-major, lower triangle read and
+ * overwritten, A[r][c] = 0 (stored zeros) for r - c > half_bandwidth; lda > n (row n is scratch for the right-hand side);
+ * b_dev in, x out.  half_bandwidth <= 192 and n >= 4 superblocks of 64 * ceil(half_bandwidth / 64) columns, else
+ * GH_ERR_ARG.  The result equals gh_potrf_solve_dev's up to rounding (a Cholesky factorisation of the odd-even permuted
+ * matrix).  *info: 0 = ok, else first column + 1 of a diagonal tile that is not positive definite. */
+gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half_bandwidth, double* b_dev, int* info);
 
 /* Block-sparse Cholesky with a dense root: the linear solver gh_pg_solve uses for LARGE pose graphs
  * (GSLAM/core/Optimizer.h:127-148,162-167 -- se3Graph / sim3Graph / gpsGraph over thousands of keyframes; the system has

@@ -1,0 +1,161 @@
+"""Band SPD solve by block cyclic reduction (gslam_amd/csrc/chol_cr.hip).
+
+CPU part: an independent numpy restatement of the elimination schedule the kernels follow (levels of stride 2^r, the
+two neighbours of an eliminated superblock, the fill block, the backward pass) checked against numpy's dense solve --
+it pins the ALGORITHM without a GPU.  GPU part: gh_band_solve_dev against numpy on band matrices of every tile count,
+ragged last superblocks, and against the dense gh_potrf_solve_dev path.
+Reference anchor: the linear solve inside Optimizer::optimize (GSLAM/core/Optimizer.h:229; Ceres SPARSE_SCHUR restated).
+"""
+import numpy as np
+import pytest
+
+
+def make_band(n, hb, seed=0, cond_boost=1.0):
+    rng = np.random.default_rng(seed)
+    A = np.zeros((n, n))
+    for i in range(n):
+        lo = max(0, i - hb)
+        A[i, lo:i + 1] = rng.standard_normal(i - lo + 1)
+    A = np.tril(A)
+    A = A + A.T
+    A += np.eye(n) * (np.abs(A).sum(1).max() * cond_boost + 1.0)
+    return A
+
+
+def cr_solve_restated(S, b, m):
+    """Block cyclic reduction on superblocks of m columns (half-bandwidth of S <= m), as chol_cr.hip schedules it."""
+    n = S.shape[0]
+    N = -(-n // m)
+    A = np.tril(S).copy()
+    rhs = b.copy()
+    blk = lambda k: slice(k * m, min((k + 1) * m, n))
+    W, L, levels = {}, {}, []
+    s = 1
+    while s < N:
+        elim = list(range(s, N, 2 * s))
+        levels.append((s, elim))
+        for i in elim:
+            D = A[blk(i), blk(i)]
+            L[i] = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
+        for i in elim:
+            u, d = i - s, i + s
+            if u >= 0:
+                W[(i, 0)] = np.linalg.solve(L[i], A[blk(i), blk(u)]).T      # B(i,u)^T L^-T
+            if d < N:
+                W[(i, 1)] = np.linalg.solve(L[i], A[blk(d), blk(i)].T).T    # B(d,i) L^-T
+            rhs[blk(i)] = np.linalg.solve(L[i], rhs[blk(i)])
+        for i in elim:
+            u, d = i - s, i + s
+            y = rhs[blk(i)]
+            if u >= 0:
+                A[blk(u), blk(u)] -= np.tril(W[(i, 0)] @ W[(i, 0)].T)
+                rhs[blk(u)] -= W[(i, 0)] @ y
+            if d < N:
+                A[blk(d), blk(d)] -= np.tril(W[(i, 1)] @ W[(i, 1)].T)
+                rhs[blk(d)] -= W[(i, 1)] @ y
+            if u >= 0 and d < N:
+                A[blk(d), blk(u)] -= W[(i, 1)] @ W[(i, 0)].T
+        s *= 2
+    D = A[blk(0), blk(0)]
+    L0 = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
+    x = np.zeros(n)
+    x[blk(0)] = np.linalg.solve(L0.T, np.linalg.solve(L0, rhs[blk(0)]))
+    for s, elim in reversed(levels):
+        for i in elim:
+            t = rhs[blk(i)].copy()
+            if i - s >= 0:
+                t -= W[(i, 0)].T @ x[blk(i - s)]
+            if i + s < N:
+                t -= W[(i, 1)].T @ x[blk(i + s)]
+            x[blk(i)] = np.linalg.solve(L[i].T, t)
+    return x
+
+
+@pytest.mark.parametrize("n,hb,m", [(3000, 149, 192), (1000, 60, 64), (777, 100, 128), (500, 191, 192), (200, 63, 64),
+                                    (1345, 128, 128)])
+def test_schedule_restated_matches_dense(n, hb, m):
+    S = make_band(n, hb, seed=n)
+    b = np.random.default_rng(1).standard_normal(n)
+    x = cr_solve_restated(S, b, m)
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-13 * np.abs(xr).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    from gslam_amd import hip
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return hip.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hb", [(3000, 149), (3000, 191), (1024, 64), (1000, 40), (777, 100), (1345, 128), (260, 17),
+                                  (3005, 150), (768, 192), (6000, 149)])
+def test_band_solve_vs_numpy(ctx, n, hb):
+    from gslam_amd import ba
+    S = make_band(n, hb, seed=n + hb)
+    b = np.random.default_rng(2).standard_normal(n)
+    x, info = ba.band_solve(ctx, S, b, hb)
+    assert info == 0
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-12 * np.abs(xr).max()
+    # and it is the factorisation the restatement describes: same numbers to rounding
+    m = 64 * (-(-hb // 64))
+    xs = cr_solve_restated(S, b, m)
+    assert np.abs(x - xs).max() <= 1e-12 * np.abs(xr).max()
+
+
+@pytest.mark.gpu
+def test_band_solve_ill_conditioned_residual(ctx):
+    """A weakly dominant band (condition ~1e6): the residual, not the error, is the bar."""
+    from gslam_amd import ba
+    n, hb = 3000, 149
+    rng = np.random.default_rng(5)
+    G = np.zeros((n, n))
+    for i in range(n):
+        lo = max(0, i - hb // 2)
+        G[i, lo:i + 1] = rng.standard_normal(i - lo + 1)
+    S = G @ G.T + 1e-3 * np.eye(n)   # half-bandwidth hb - 1 at most, SPD
+    assert np.abs(np.tril(S, -hb - 1)).max() == 0.0
+    b = rng.standard_normal(n)
+    x, info = ba.band_solve(ctx, S, b, hb)
+    assert info == 0
+    r = S @ x - b
+    xr = np.linalg.solve(S, b)
+    rr = S @ xr - b
+    assert np.linalg.norm(r) <= 10 * max(np.linalg.norm(rr), 1e-13 * np.linalg.norm(b))
+
+
+@pytest.mark.gpu
+def test_band_solve_equals_dense_path(ctx):
+    from gslam_amd import ba
+    n, hb = 3000, 149
+    S = make_band(n, hb, seed=9)
+    b = np.random.default_rng(3).standard_normal(n)
+    x, info = ba.band_solve(ctx, S, b, hb)
+    _, xd, infod = ba.potrf_solve(ctx, S, b)
+    assert info == 0 and infod == 0
+    assert np.abs(x - xd).max() <= 1e-12 * np.abs(xd).max()
+
+
+@pytest.mark.gpu
+def test_band_solve_not_positive_definite(ctx):
+    from gslam_amd import ba
+    n, hb = 1000, 60
+    S = make_band(n, hb, seed=4)
+    S[500, 500] = -1.0
+    _, info = ba.band_solve(ctx, S, np.ones(n), hb)
+    assert 1 <= info <= n
+
+
+@pytest.mark.gpu
+def test_band_solve_refuses_wide_band(ctx):
+    from gslam_amd import ba, hip
+    S = make_band(1000, 10, seed=1)
+    with pytest.raises(hip.GslamHipError):
+        ba.band_solve(ctx, S, np.ones(1000), 200)      # beyond three tiles
+    with pytest.raises(hip.GslamHipError):
+        ba.band_solve(ctx, S[:100, :100], np.ones(100), 60)   # fewer than four superblocks
