@@ -708,12 +708,23 @@ def main():
     CHOL = ("ba_potrf_flow", "ba_potf2", "ba_trsm", "ba_panel_step", "ba_syrk_panel", "ba_syrk_trailing", "ba_trsv_fwd", "ba_trsv_bwd",
             "ba_chol_fused")
 
-    def ba_leg(cams, points, iters, separate_timed_run, prof_iters=None):
+    CR = ("ba_cr_factor", "ba_cr_panels", "ba_cr_update", "ba_cr_back", "ba_cr_inverse", "ba_cr_backprep")
+
+    def ba_leg(cams, points, iters, separate_timed_run, prof_iters=None, solver="auto", graph=None):
+        """solver: "auto" (band solver -- block cyclic reduction, chol_cr.hip -- when the graph is a trajectory band, what a
+        deployment runs), "dense" (the MFMA factorisation BASELINE's C5 names) or "band"."""
         from gslam_amd import ba
         from gslam_amd.ba_synth import graph_census, make_graph
         name = "C5" if cams >= 10000 else "C4"
+        ctx.set_ba_solver(solver)
+        try:
+            return _ba_leg(ba, graph_census, make_graph, name, cams, points, iters, separate_timed_run, prof_iters, graph)
+        finally:
+            ctx.set_ba_solver("auto")
+
+    def _ba_leg(ba, graph_census, make_graph, name, cams, points, iters, separate_timed_run, prof_iters, graph):
         log(f"BA leg {name}: building graph")
-        g = make_graph(cams, points, n_obs_per_point=6, seed=1)
+        g = graph or make_graph(cams, points, n_obs_per_point=6, seed=1)
         census = graph_census(g)  # cameras observed, observations per camera, block fill of the reduced camera system
         log(f"BA leg {name}: warm-up solve")
         ba.solve(ctx, g, ba.default_options(max_iterations=1 if cams >= 10000 else 2))  # allocations, code load
@@ -748,9 +759,16 @@ def main():
         n = 6 * cams
         solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * sp.iterations
         chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CHOL)
+        cr_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CR)
         launches = sum(v["launches"] for v in bprof.values())
+        used, tiles, span = ctx.last_ba_solver()
         return {"workload": f"{name}: {cams} cams, {points} pts, {len(g['obs_cam'])} obs, Huber LM",
                 "graph_census": census,
+                "linear_solver": {"used": used, "camera_span": span, "half_bandwidth": 6 * span + 5,
+                                  "superblock_columns": 64 * tiles if tiles else None,
+                                  "solver_kernel_ms_per_iteration": round((cr_ms if used == "band" else chol_ms) / max(1, sp.iterations), 4),
+                                  "what": "band: block cyclic reduction over superblocks of the reduced camera system "
+                                          "(gslam_amd/csrc/chol_cr.hip); dense: the MFMA f64 factorisation (chol.hip)"},
                 "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
                 "ms_per_iteration": round(s.total_ms / max(1, s.iterations), 3),
                 "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
@@ -758,10 +776,10 @@ def main():
                 "launches_per_iteration": round(launches / max(1, sp.iterations), 1),
                 "hbm_floor": {"bytes_per_iteration": 640 * len(g["obs_cam"]) + 16 * n * n,
                               "frac": round((640 * len(g["obs_cam"]) + 16 * n * n) / HBM_PEAK / (s.total_ms * 1e-3 / max(1, s.iterations)), 4)},
-                "dense_solve": {"bound": "mfma", "n": n,
-                                "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3) if chol_ms else None,
-                                "peak_TFLOPs": FP64_MFMA_PEAK / 1e12,
-                                "frac": round(solve_flops / (chol_ms * 1e-3) / FP64_MFMA_PEAK, 4) if chol_ms else None},
+                "dense_solve": ({"bound": "mfma", "n": n,
+                                 "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3),
+                                 "peak_TFLOPs": FP64_MFMA_PEAK / 1e12,
+                                 "frac": round(solve_flops / (chol_ms * 1e-3) / FP64_MFMA_PEAK, 4)} if chol_ms else None),
                 "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in bprof.items()}}
 
     def dense_solve_check(n):
@@ -789,13 +807,31 @@ def main():
 
     try:
         if not a.no_ba:
-            extra["ba"] = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True)
+            from gslam_amd.ba_synth import make_graph as _mk
+            g4 = _mk(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1)
+            extra["ba"] = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True, graph=g4)  # auto: the band solver on this graph
+            dn = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True, solver="dense", graph=g4)
+            assert dn["iterations"] == extra["ba"]["iterations"] and abs(dn["final_cost"] - extra["ba"]["final_cost"]) <= 1e-9 * abs(dn["final_cost"]), \
+                "the two linear solvers led the LM loop to different results"
+            extra["ba"]["dense_solver"] = {k: dn[k] for k in ("iters_per_s", "ms_per_iteration", "resolve_iters_per_s", "launches_per_iteration",
+                                                               "dense_solve", "linear_solver", "final_cost", "kernels")}
     except Exception as exc:  # an optional leg must never cost the headline line
         extra.setdefault("errors", {})["ba"] = repr(exc)
         log("ba leg failed: %r" % (exc,))
     try:
         if not a.no_ba and not a.no_c5 and a.ba_cams < 10000:
-            extra["ba_c5"] = ba_leg(10000, 1000000, 5, True, prof_iters=2)
+            from gslam_amd.ba_synth import make_graph as _mk
+            g5 = _mk(10000, 1000000, n_obs_per_point=6, seed=1)
+            # BASELINE configs[4] names the DENSE Schur-complement solve on MFMA: that is this leg's contract figure
+            extra["ba_c5"] = ba_leg(10000, 1000000, 5, True, prof_iters=2, solver="dense", graph=g5)
+            torch.cuda.empty_cache()
+            # the same graph through the band solver (what gh_ba_solve picks by itself on a trajectory graph)
+            bd = ba_leg(10000, 1000000, 5, True, prof_iters=2, solver="auto", graph=g5)
+            assert bd["iterations"] == extra["ba_c5"]["iterations"] and \
+                abs(bd["final_cost"] - extra["ba_c5"]["final_cost"]) <= 1e-9 * abs(bd["final_cost"]), "C5: the two linear solvers disagree"
+            extra["ba_c5"]["band_solver"] = {k: bd[k] for k in ("iters_per_s", "ms_per_iteration", "launches_per_iteration", "linear_solver",
+                                                               "final_cost", "kernels")}
+            del g5
             torch.cuda.empty_cache()
             log("dense solve check n = 60000")
             extra["ba_c5"]["dense_solve_check"] = dense_solve_check(60000)
@@ -1269,7 +1305,10 @@ def main():
         "bf_match_all_pairs_mfma_Gpairs_per_s": (bf.get("all_pairs_mfma") or {}).get("Gpairs_per_s"),
         "bf_match_consecutive_Gpairs_per_s": bf.get("Gpairs_per_s"),
         "ba_c4_lm_iters_per_s": (extra.get("ba") or {}).get("iters_per_s"),
-        "ba_c5_lm_iters_per_s": (extra.get("ba_c5") or {}).get("iters_per_s"),
+        "ba_c4_linear_solver": ((extra.get("ba") or {}).get("linear_solver") or {}).get("used"),
+        "ba_c4_dense_solver_lm_iters_per_s": ((extra.get("ba") or {}).get("dense_solver") or {}).get("iters_per_s"),
+        "ba_c5_lm_iters_per_s": (extra.get("ba_c5") or {}).get("iters_per_s"),  # dense MFMA solve: BASELINE configs[4]
+        "ba_c5_band_solver_lm_iters_per_s": ((extra.get("ba_c5") or {}).get("band_solver") or {}).get("iters_per_s"),
         "ba_c4_resident_graph_lm_iters_per_s": (extra.get("ba") or {}).get("resolve_iters_per_s"),
         "host_fed_Mkeypoints_per_s": (extra.get("host_fed") or {}).get("Mkeypoints_per_s"),
         "extra": extra,

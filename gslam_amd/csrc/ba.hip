@@ -1844,6 +1844,9 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
             S.ready ? "resident graph" : "setup", t_lists - t_begin, t_csr - t_begin, S.n_pairs, nblocks, t_upload - t_lists,
             now_ms() - t_upload);
   S.ready = true;
+  ctx->ba_last_solver = cr_T ? 2 : 1;
+  ctx->ba_last_band_tiles = cr_T;
+  ctx->ba_last_cam_span = S.cam_span;
   double cost = h2[0];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;

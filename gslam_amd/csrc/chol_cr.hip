@@ -95,6 +95,24 @@ __device__ __forceinline__ double4_t mma(double a, double b, double4_t acc) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
 }
 
+// Sum over the wave, valid in lane 63: four DPP row shifts + two row broadcasts (three VALU each for a double), as
+// wave_incl_scan_i32 in orb.hip.  Every lane of the wave must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum63(double v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------ factor
 // One workgroup (8 waves) per eliminated superblock.  Every tile of the superblock is read ONCE, at the start, into MFMA
 // accumulators (negated: -A + sum X X^T, lane = [row 16 rg + m][col 16 cb + q + 4 r], the 16 rows of a lane group are 128
@@ -122,26 +140,43 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
   const size_t lda = (size_t)a.lda;
   double* const A = a.A;
   CR_STAMP(0);
-  // neg[tile (ii, jj)][cbi]: -(A - sum) of the lower tiles, ii >= jj; tile (0, 0) first: the first potf2 only waits for it,
-  // the other tiles land while it runs
+  // neg[tile (ii, jj)][cbi]: -(A - sum) of the lower tiles, ii >= jj.  Tile (0, 0) is asked for alone and goes to LDS as
+  // soon as it is there; the other tiles are asked for behind that and land while the first potf2 runs (one wait for all 48
+  // loads of a lane -- 196 KB through one CU -- was 7.5 us in front of the first pivot).
   double4_t neg[T * (T + 1) / 2][2];
+  auto load_tile = [&](int ii, int jj) {
 #pragma unroll
-  for (int ii = 0; ii < T; ++ii) {
+    for (int cbi = 0; cbi < 2; ++cbi) {
 #pragma unroll
-    for (int jj = 0; jj <= ii; ++jj) {
-#pragma unroll
-      for (int cbi = 0; cbi < 2; ++cbi) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i0 + NBI * ii + 16 * rg + m, col = i0 + NBI * jj + 16 * (2 * hf + cbi) + q + 4 * r;
-          double v = ld_guard(A, lda, row, col, n, n);
-          if (ii == jj) v = keep_if(v, col <= row) + ((row == col && row >= n) ? 1.0 : 0.0);  // lower part; identity padding past n
-          neg[ii * (ii + 1) / 2 + jj][cbi][r] = -v;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + NBI * ii + 16 * rg + m, col = i0 + NBI * jj + 16 * (2 * hf + cbi) + q + 4 * r;
+        double v = ld_guard(A, lda, row, col, n, n);
+        if (ii == jj) v = keep_if(v, col <= row) + ((row == col && row >= n) ? 1.0 : 0.0);  // lower part; identity padding past n
+        neg[ii * (ii + 1) / 2 + jj][cbi][r] = -v;
       }
     }
-  }
+  };
+  load_tile(0, 0);
+  // The LAST block (no neighbours, a.count == 1 at first == 0) also solves its right-hand side here, both ways: two launches
+  // of ~10 us less at the end of the chain.  tvec = b (row n of A), yv = b L^-T tile by tile behind each potf2.
+  const bool last = a.first == 0;
+  double* const tvec = reinterpret_cast<double*>(cr_lds + kShBytes + 16 * 17 * sizeof(double)) + (size_t)(T - 1) * (NBI * XP);
+  double* const yv = tvec + m_;
+  if (last && tid < m_) tvec[tid] = ld_guard(A, lda, n, i0 + tid, n + 1, n);
   for (int e = tid; e < NBI * LP; e += 512) sh.Ms[e] = 0.0;  // the inversion only ever writes the lower blocks
+#pragma unroll
+  for (int cbi = 0; cbi < 2; ++cbi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rg + m, col = 16 * (2 * hf + cbi) + q + 4 * r;
+      sh.As[col * LP + row] = col <= row ? -neg[0][cbi][r] : 0.0;
+    }
+  }
+  asm volatile("" ::: "memory");  // (keeps the requests below behind the LDS writes above: they must not be waited for here)
+  // column 0 now (wanted right behind the first potf2), the trailing tiles behind that potf2 (wanted after the X tiles):
+  // all of them in flight through the potf2 would not fit the 256 registers of a wave of this workgroup
+#pragma unroll
+  for (int ii = 1; ii < T; ++ii) load_tile(ii, 0);
   static_for<0, T>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int c0 = i0 + NBI * k;
@@ -155,12 +190,14 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
       sh.progress = 0;
       sh.x10_done = 0;
     }
+    if constexpr (k > 0) {  // (tile (0, 0) went to LDS in the prologue)
 #pragma unroll
-    for (int cbi = 0; cbi < 2; ++cbi) {
+      for (int cbi = 0; cbi < 2; ++cbi) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * rg + m, col = 16 * (2 * hf + cbi) + q + 4 * r;
-        sh.As[col * LP + row] = col <= row ? -neg[k * (k + 1) / 2 + k][cbi][r] : 0.0;
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rg + m, col = 16 * (2 * hf + cbi) + q + 4 * r;
+          sh.As[col * LP + row] = col <= row ? -neg[k * (k + 1) / 2 + k][cbi][r] : 0.0;
+        }
       }
     }
     lds_barrier();
@@ -174,7 +211,29 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
       if (r < kb && c < kb && c <= r) A[(size_t)(c0 + c) * lda + c0 + r] = sh.As[c * LP + r];
       Minv[idx] = (c <= r) ? sh.Ms[c * LP + r] : 0.0;
     }
+    if (last) {  // y_k = t_k M_kk^T: thread = (column c, the t with t / 8 == wave), partial sums through Ts
+      const int c = tid & 63;
+      double part = 0.0;
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8) part = __builtin_fma(sh.Ms[(8 * wv + t8) * LP + c], tvec[NBI * k + 8 * wv + t8], part);
+      sh.Ts[wv * 64 + c] = part;
+      lds_barrier();
+      if (tid < 64) {
+        double y = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) y += sh.Ts[g * 64 + tid];
+        yv[NBI * k + tid] = y;
+      }
+      lds_barrier();
+    }
     CR_STAMP(3 + 4 * k);
+    if constexpr (k == 0) {
+#pragma unroll
+      for (int ii = 1; ii < T; ++ii) {
+#pragma unroll
+        for (int jj = 1; jj <= ii; ++jj) load_tile(ii, jj);
+      }
+    }
     if constexpr (k + 1 < T) {
       // the tiles below, out of their accumulators (for k = 0 their loads had the whole potf2 to land)
 #pragma unroll
@@ -219,6 +278,27 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
         }
       }
       lds_barrier();
+      if (last) {  // t_j -= y_k L(j, k)^T for the tiles below: thread = (row r, the c with c / 8 == wave)
+        const int r = tid & 63;
+#pragma unroll
+        for (int j = k + 1; j < T; ++j) {
+          double part = 0.0;
+#pragma unroll
+          for (int c8 = 0; c8 < 8; ++c8) part = __builtin_fma(xs(j)[(8 * wv + c8) * XP + r], yv[NBI * k + 8 * wv + c8], part);
+          sh.Ts[(j - k - 1) * 512 + wv * 64 + r] = part;
+        }
+        lds_barrier();
+        if (tid < 64) {
+#pragma unroll
+          for (int j = k + 1; j < T; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sum += sh.Ts[(j - k - 1) * 512 + g * 64 + tid];
+            tvec[NBI * j + tid] -= sum;
+          }
+        }
+        lds_barrier();
+      }
       CR_STAMP(4 + 4 * k);
       // trailing tiles (ii, jj), k < jj <= ii < T:  -C += X_ii X_jj^T; per k-step one read of every operand block
 #pragma unroll
@@ -244,6 +324,50 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
       }
     }
   });
+  if (last) {
+    // x = y L^-1, tile by tile from the last: x_k = (y_k - sum_{j > k} x_j L(j, k)) M_kk.  In LDS at this point: M of the last
+    // tile (Ms), L(j, j - 1) in xs(j); the other tiles come back from L2 (this CU stored them a moment ago).  A wave per
+    // column, lanes along it (wave_sum63); x overwrites yv.
+    static_assert((T - 1) * 512 * sizeof(double) <= sizeof(sh.Ts) || T <= 2, "Ts holds the partial sums of T - 1 tiles");
+    double* const xv = yv;
+    auto reload = [&](double* dst, int pitch, const double* src, size_t ld, bool guard, int r0, int c0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = tid + 512 * e, c = idx >> 6, r = idx & 63;
+        dst[c * pitch + r] = guard ? ld_guard(src, ld, r0 + r, c0 + c, n, n) : src[(size_t)c * ld + r];
+      }
+    };
+    for (int k = T - 1; k >= 0; --k) {
+      lds_barrier();
+      if (k < T - 1) reload(sh.Ms, LP, a.dinv + (size_t)(i * T + k) * (NBI * NBI), NBI, false, 0, 0);
+      for (int j = k + 2; j < T; ++j) {  // (T = 3: only L(2, 0)) through As, one tile at a time
+        reload(sh.As, LP, A, lda, true, i0 + NBI * j, i0 + NBI * k);
+        lds_barrier();
+        for (int c = wv; c < NBI; c += 8) {
+          const double sum = wave_sum63(xv[NBI * j + lane] * sh.As[c * LP + lane]);
+          if (lane == 63) yv[NBI * k + c] -= sum;
+        }
+        lds_barrier();
+      }
+      lds_barrier();
+      if (k + 1 < T) {
+        for (int c = wv; c < NBI; c += 8) {
+          const double sum = wave_sum63(xv[NBI * (k + 1) + lane] * xs(k + 1)[c * XP + lane]);
+          if (lane == 63) yv[NBI * k + c] -= sum;
+        }
+        lds_barrier();
+      }
+      double xk[8];
+#pragma unroll
+      for (int cj = 0; cj < 8; ++cj) xk[cj] = wave_sum63(yv[NBI * k + lane] * sh.Ms[(wv + 8 * cj) * LP + lane]);  // M[r][c], zero above the diagonal
+      lds_barrier();  // every wave has read y_k
+#pragma unroll
+      for (int cj = 0; cj < 8; ++cj)
+        if (lane == 63) xv[NBI * k + wv + 8 * cj] = xk[cj];
+    }
+    lds_barrier();
+    if (tid < m_ && i0 + tid < n) a.x[i0 + tid] = xv[tid];
+  }
   CR_STAMP(15);
 }
 
@@ -543,24 +667,6 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Sum over the wave, valid in lane 63: four DPP row shifts + two row broadcasts (three VALU each for a double), as
-// wave_incl_scan_i32 in orb.hip.  Every lane of the wave must be active.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum63(double v) {
-  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31
-  return v;
-}
-
 // Levels: x_i = yh_i - x_u G_u - x_d G_d.  16 columns of a superblock per workgroup (49 KB of G: a workgroup that streams
 // a whole superblock's panels -- 590 KB -- through one CU takes ~25 us), a wave per 4 columns, lanes along the column.
 template <int T>
@@ -714,7 +820,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   constexpr int m_ = NBI * T;
   const int N = gh_div_up(n, m_);
   const size_t mm = (size_t)m_ * m_;
-  const size_t factor_lds = ((sizeof(Potf2Lds) + 15) & ~(size_t)15) + 16 * 17 * sizeof(double) + (size_t)(T - 1) * NBI * kCrXP * sizeof(double);
+  const size_t factor_lds = ((sizeof(Potf2Lds) + 15) & ~(size_t)15) + 16 * 17 * sizeof(double) + (size_t)(T - 1) * NBI * kCrXP * sizeof(double) + 2 * m_ * sizeof(double);
   {
     static bool attr_set[64] = {};
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
@@ -766,9 +872,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   a.s = s_top;
   a.first = 0;
   a.count = 1;
-  GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(1), dim3(512), factor_lds, a);
-  GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(8), dim3(256), 0, a, 8 * T, 1);  // y_0 (one task, XCD 0)
-  GH_LAUNCH(ctx, "ba_cr_back", cr_back_last_kernel<T>, dim3(1), dim3(1024), 0, a);
+  GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(1), dim3(512), factor_lds, a);  // (also solves: x_0 is final)
   if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
   for (int s = s_top / 2; s >= 1; s /= 2) {
     a.s = s;

@@ -44,6 +44,8 @@ struct gh_ctx {
   int cu_count = 0;
   // linear solver of gh_ba_solve's reduced camera system (gh_ctx_set_ba_solver): 0 auto, 1 dense, 2 band (cyclic reduction)
   int ba_solver = 0;
+  int ba_last_solver = 0;  // what the last gh_ba_solve / gh_ba_graph_solve used: 1 dense, 2 band (T tiles in ba_last_band_tiles)
+  int ba_last_band_tiles = 0, ba_last_cam_span = 0;
   // band solver (chol_cr.hip): side stream for the work off its critical path, and the events that order the two
   hipStream_t cr_side = nullptr;
   std::vector<hipEvent_t> cr_events;

@@ -64,6 +64,14 @@ extern "C" gh_status gh_ctx_set_ba_solver(gh_ctx* ctx, int solver) {
   return GH_OK;
 }
 
+extern "C" int gh_ctx_last_ba_solver(gh_ctx* ctx, int* band_tiles, int* cam_span) {
+  if (!ctx) return 0;
+  GH_ENTER(ctx);
+  if (band_tiles) *band_tiles = ctx->ba_last_band_tiles;
+  if (cam_span) *cam_span = ctx->ba_last_cam_span;
+  return ctx->ba_last_solver;
+}
+
 extern "C" gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);

@@ -105,6 +105,7 @@ SIGNATURES = {
     "gh_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "gh_dev_memset": (C.c_int, [_vp, _vp, _i, _sz]),
     "gh_ctx_set_ba_solver": (C.c_int, [_vp, _i]),
+    "gh_ctx_last_ba_solver": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "gh_prof_enable": (C.c_int, [_vp, _i]),
     "gh_prof_collect": (C.c_int, [_vp, C.POINTER(ProfEntry), _i, C.POINTER(_i)]),
     "gh_bf_match_dev": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -261,6 +262,12 @@ class Context:
         """0 / "auto", 1 / "dense", 2 / "band": linear solver of the reduced camera system (gh_ctx_set_ba_solver)."""
         code = {"auto": 0, "dense": 1, "band": 2}.get(solver, solver)
         self.check(lib.gh_ctx_set_ba_solver(self.h, int(code)))
+
+    def last_ba_solver(self):
+        """("dense" | "band" | None, tiles per superblock, camera span) of the last BA solve on this context."""
+        t, sp = C.c_int(), C.c_int()
+        code = lib.gh_ctx_last_ba_solver(self.h, C.byref(t), C.byref(sp))
+        return {0: None, 1: "dense", 2: "band"}[code], t.value, sp.value
 
     def prof_enable(self, on=True):
         self.check(lib.gh_prof_enable(self.h, 1 if on else 0))

@@ -64,6 +64,11 @@ gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream);
 #define GH_BA_SOLVER_DENSE 1
 #define GH_BA_SOLVER_BAND 2
 gh_status gh_ctx_set_ba_solver(gh_ctx* ctx, int solver);
+/* What the last gh_ba_solve / gh_ba_graph_solve on this context used: GH_BA_SOLVER_DENSE or _BAND (0 before the first
+ * solve); *band_tiles = 64-column tiles per superblock of the band solver (0 for dense), *cam_span = the largest distance
+ * in camera indices between two observers of one point (the half-bandwidth of the reduced system is 6 * span + 5).
+ * Either pointer may be NULL. */
+int gh_ctx_last_ba_solver(gh_ctx* ctx, int* band_tiles, int* cam_span);
 gh_status gh_ctx_use_own_stream(gh_ctx* ctx);
 void* gh_ctx_stream(gh_ctx* ctx);
 gh_status gh_ctx_sync(gh_ctx* ctx);

@@ -159,3 +159,52 @@ def test_band_solve_refuses_wide_band(ctx):
         ba.band_solve(ctx, S, np.ones(1000), 200)      # beyond three tiles
     with pytest.raises(hip.GslamHipError):
         ba.band_solve(ctx, S[:100, :100], np.ones(100), 60)   # fewer than four superblocks
+
+
+# ------------------------------------------------------------------------------------------------- inside the LM loop
+def _solve_with(ctx, g, solver, iters=30):
+    from gslam_amd import ba
+    ctx.set_ba_solver(solver)
+    try:
+        poses, pts, s, st = ba.solve(ctx, g, ba.default_options(max_iterations=iters))
+        used = ctx.last_ba_solver()
+    finally:
+        ctx.set_ba_solver("auto")
+    return poses, pts, s, used
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cams,points", [(160, 8000), (500, 50000)])
+def test_ba_band_and_dense_solvers_agree(ctx, cams, points):
+    """Same graph through both linear solvers: identical LM decisions, costs to 1e-10, states to 1e-9 (C4 at full size
+    included).  The graphs of ba_synth are trajectories: every point is seen from cameras at most 24 indices apart."""
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(cams, points, n_obs_per_point=6, seed=2)
+    pd, xd, sd, used_d = _solve_with(ctx, g, "dense")
+    pb, xb, sb, used_b = _solve_with(ctx, g, "band")
+    assert used_d[0] == "dense" and used_b[0] == "band" and used_b[1] == 3 and used_b[2] <= 32
+    assert sd.iterations == sb.iterations and sd.trace_len == sb.trace_len
+    n = sd.trace_len
+    assert list(sd.trace_accepted[:n]) == list(sb.trace_accepted[:n])
+    cd, cb = np.array(sd.trace_cost[:n]), np.array(sb.trace_cost[:n])
+    assert np.abs(cd - cb).max() <= 1e-10 * np.abs(cd).max()
+    assert np.abs(pd - pb).max() <= 1e-9 and np.abs(xd - xb).max() <= 1e-9
+    # auto picks the band solver on this graph
+    _, _, _, used_a = _solve_with(ctx, g, "auto", iters=1)
+    assert used_a[0] == "band"
+
+
+@pytest.mark.gpu
+def test_ba_wide_graph_stays_dense(ctx):
+    """Observers drawn from the whole trajectory (a loop closure between far cameras is enough): not a band -> dense path,
+    also when the band solver is asked for."""
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(160, 8000, n_obs_per_point=6, seed=3)
+    oc = np.array(g["obs_cam"]).copy()
+    op = np.array(g["obs_point"])
+    k = int(np.flatnonzero(op == op[0])[0])
+    oc[k] = 159 if oc[k] < 80 else 0     # one observation from the other end of the trajectory
+    g2 = dict(g)
+    g2["obs_cam"] = oc
+    _, _, s, used = _solve_with(ctx, g2, "band", iters=3)
+    assert used[0] == "dense" and used[2] > 32 and s.iterations >= 1
