@@ -507,6 +507,22 @@ struct SchurBlocks {
   int nblocks, nsegs;
 };
 
+// one step of the reduce-scatter butterfly of schur_blocks_block: K values per lane -> ceil(K / 2); lanes with bit M clear
+// keep the lower half (and send the upper), the others the upper half (zero padded)
+template <int K, int M>
+__device__ __forceinline__ void schur_scatter_step(double (&v)[42], int lane, int& elem, int& mylen) {
+  constexpr int H = (K + 1) / 2;
+  const bool up = (lane & M) != 0;
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const double lo = v[j], hi = H + j < K ? v[H + j] : 0.0;
+    const double recv = __shfl_xor(up ? lo : hi, M);
+    v[j] = (up ? hi : lo) + recv;
+  }
+  elem += up ? H : 0;
+  mylen = up ? (mylen > H ? mylen - H : 0) : (mylen < H ? mylen : H);
+}
+
 // one wave per segment: partial[seg][0..35] = sum W_i Hpp^-1 W_j^T (row-major a, b), [36..41] = sum W_i Hpp^-1 g_p
 __device__ __forceinline__ void schur_blocks_block(const Problem& P, const SchurBlocks& B, const double* __restrict__ Hpi,
                                                    const double* __restrict__ gp, const double* __restrict__ Wbuf,
@@ -543,20 +559,23 @@ __device__ __forceinline__ void schur_blocks_block(const Problem& P, const Schur
       for (int b = 0; b < 6; ++b)
         acc[6 * a + b] += WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
   }
+  // Reduce-scatter butterfly over the wave: at every step a lane keeps one half of its values and trades the other half
+  // with its partner, so the 42 sums cost 21 + 11 + 6 + 3 + 2 + 1 = 44 exchanges instead of 42 x 6, and every lane ends up
+  // with (at most) ONE element's total: element 21 b5 + 11 b4 + 6 b3 + 3 b2 + 2 b1 + b0 of its lane number's bits.
+  // Fixed order of additions: deterministic, like the butterfly it replaces.
+  double v[42];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
+  for (int t = 0; t < 36; ++t) v[t] = acc[t];
 #pragma unroll
-    for (int t = 0; t < 36; ++t) acc[t] += __shfl_xor(acc[t], off);
-#pragma unroll
-    for (int t = 0; t < 6; ++t) racc[t] += __shfl_xor(racc[t], off);
-  }
-  // every lane holds the totals: lane t stores element t
-  double mine = 0;
-#pragma unroll
-  for (int t = 0; t < 36; ++t) mine = (lane == t) ? acc[t] : mine;
-#pragma unroll
-  for (int t = 0; t < 6; ++t) mine = (lane == 36 + t) ? racc[t] : mine;
-  if (lane < 42) partial[(size_t)42 * seg + lane] = mine;
+  for (int t = 0; t < 6; ++t) v[36 + t] = racc[t];
+  int elem = 0, mylen = 42;
+  schur_scatter_step<42, 32>(v, lane, elem, mylen);
+  schur_scatter_step<21, 16>(v, lane, elem, mylen);
+  schur_scatter_step<11, 8>(v, lane, elem, mylen);
+  schur_scatter_step<6, 4>(v, lane, elem, mylen);
+  schur_scatter_step<3, 2>(v, lane, elem, mylen);
+  schur_scatter_step<2, 1>(v, lane, elem, mylen);
+  if (mylen > 0) partial[(size_t)42 * seg + elem] = v[0];
 }
 
 __global__ __launch_bounds__(256) void schur_blocks_kernel(Problem P, SchurBlocks B, const double* __restrict__ Hpi,
@@ -1911,7 +1930,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
             st.n_xh = (unsigned)gh_div_up(n, 64) * 64u * 2u;
           }
           const unsigned words = st.n_flow > st.n_xh ? st.n_flow : st.n_xh;
-          GH_LAUNCH(ctx, "ba_schur_blocks", schur_reduce_kernel, dim3(nred + gh_div_up((int)(words ? words : 1u), 256)),
+          GH_LAUNCH(ctx, "ba_schur_reduce", schur_reduce_kernel, dim3(nred + gh_div_up((int)(words ? words : 1u), 256)),
                     dim3(256), 0, SB, (const double*)d_spart, d_S, lda, d_dc, n, nred, st);
           solve_state_ready = true;
         }
