@@ -564,6 +564,10 @@ class OptimizerHIP : public GSLAM::Optimizer {
       if (gh_ctx_create(dev, &ctx_) != GH_OK) {
         ctx_ = nullptr;
         LOG(ERROR) << "OptimizerHIP: no usable HIP device " << dev << " (there is no CPU fallback)";
+      } else {
+        // linear solver of the reduced camera system: "auto" (band solver on trajectory graphs, else dense), "dense", "band"
+        const std::string solver = svar.GetString("OptimizerHIP.Solver", "auto");
+        gh_ctx_set_ba_solver(ctx_, solver == "dense" ? GH_BA_SOLVER_DENSE : (solver == "band" ? GH_BA_SOLVER_BAND : GH_BA_SOLVER_AUTO));
       }
     }
     return ctx_ != nullptr;
