@@ -1489,14 +1489,16 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   const char* early_env = getenv("GSLAM_HIP_BA_EARLY_UPLOAD");  // "0": upload after the lists (A/B measurements)
   DevBuf& db = *S.db;
   bool early = !S.ready && *db.arena != nullptr && raw_bytes <= *db.arena_bytes && !(early_env && early_env[0] == '0');
-  constexpr size_t kStageOffset = 4096;  // the read-back block sits in front of the staging area
-  Readback* rb = nullptr;
+  Readback* rb = nullptr;  // (a pinned block of its own: nothing the staging below or a later gh_pinned does can move it)
   char* stage = nullptr;
   {
     void* pp = nullptr;
-    GH_TRY(gh_pinned(ctx, early ? kStageOffset + raw_bytes : 256, &pp));
+    GH_TRY(gh_readback_block(ctx, sizeof(Readback), &pp));
     rb = (Readback*)pp;
-    stage = (char*)pp + kStageOffset;
+    if (early) {
+      GH_TRY(gh_pinned(ctx, raw_bytes, &pp));
+      stage = (char*)pp;
+    }
   }
   double *&d_poses = S.d_poses, *&d_pts = S.d_pts, *&d_poses_new = S.d_poses_new, *&d_pts_new = S.d_pts_new, *&d_oxy = S.d_oxy,
          *&d_oinfo = S.d_oinfo;

@@ -32,6 +32,9 @@ struct gh_ctx {
   // pinned host staging for the small host-buffer entry points (one DMA each way instead of one per array)
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // small pinned block of its own for what the solvers read back inside their loops (gh_readback_block): it never moves,
+  // whatever gh_pinned is asked for meanwhile
+  void* rb_pinned = nullptr;
   // grow-only arena reused by successive gh_ba_solve calls (local BA runs every keyframe: no malloc/free per call)
   void* ba_arena = nullptr;
   size_t ba_arena_bytes = 0;
@@ -77,6 +80,7 @@ struct gh_enter_guard {
 gh_status gh_set_error(gh_ctx* ctx, gh_status st, const char* fmt, ...);
 gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out);
 gh_status gh_pinned(gh_ctx* ctx, size_t bytes, void** out);  // grow-only pinned host block owned by the context
+gh_status gh_readback_block(gh_ctx* ctx, size_t bytes, void** out);  // <= 4096 bytes of pinned host memory that never move
 int gh_prof_begin(gh_ctx* ctx, const char* name);  // returns pending index or -1
 void gh_prof_end(gh_ctx* ctx, int pending);
 

@@ -46,6 +46,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->rb_pinned) hipHostFree(ctx->rb_pinned);
   if (ctx->ba_arena) hipFree(ctx->ba_arena);
   if (ctx->pg_arena) hipFree(ctx->pg_arena);
   for (auto e : ctx->cr_events) hipEventDestroy(e);
@@ -182,6 +183,43 @@ gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
     ctx->scratch_bytes = want;
   }
   *out = ctx->scratch;
+  return GH_OK;
+}
+
+gh_status gh_readback_block(gh_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > 4096) return gh_set_error(ctx, GH_ERR_ARG, "gh_readback_block: %zu bytes", bytes);
+  if (!ctx->rb_pinned) {
+    hipError_t e = hipHostMalloc(&ctx->rb_pinned, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      ctx->rb_pinned = nullptr;
+      return gh_set_error(ctx, GH_ERR_NOMEM, "hipHostMalloc(4096): %s", hipGetErrorString(e));
+    }
+  }
+  *out = ctx->rb_pinned;
+  return GH_OK;
+}
+
+// Give back what the context has grown for past calls: scratch, pinned staging and the two solver arenas (a single large
+// loop closure or graph would otherwise pin its high-water mark -- up to 64 MB of host memory and tens of MB of HBM -- for
+// the life of the context).  Everything is re-grown on demand; device-resident graphs (gh_ba_graph) own their memory and
+// are not touched.
+extern "C" gh_status gh_ctx_trim(gh_ctx* ctx) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->cr_side) GH_HIP(ctx, hipStreamSynchronize(ctx->cr_side));
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  ctx->pinned = nullptr;
+  ctx->pinned_bytes = 0;
+  if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
+  ctx->ba_arena = nullptr;
+  ctx->ba_arena_bytes = 0;
+  if (ctx->pg_arena) (void)hipFree(ctx->pg_arena);
+  ctx->pg_arena = nullptr;
+  ctx->pg_arena_bytes = 0;
   return GH_OK;
 }
 

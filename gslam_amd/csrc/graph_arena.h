@@ -20,6 +20,7 @@
 
 struct GraphArena {
   static constexpr size_t kBigBytes = (size_t)32 << 20;
+  static constexpr size_t kStageCap = (size_t)8 << 20;  // most pinned host memory one flush() may ask the context for
   gh_ctx* ctx;
   bool measuring = true, enabled = true;
   size_t used = 0, want = 0;
@@ -123,7 +124,8 @@ struct GraphArena {
       void* hp = nullptr;
       // (a graph with millions of observations uploads hundreds of MB: not worth pinning that much host memory for,
       // and its set-up time is not what its caller waits for)
-      if (stage_bytes && stage_bytes <= kBigBytes * 2 && gh_pinned(ctx, stage_bytes, &hp) == GH_OK) stage = static_cast<char*>(hp);
+      // (and the pinned block is grow-only: more than kStageCap is sent piece by piece straight from the caller's memory)
+      if (stage_bytes && stage_bytes <= kStageCap && gh_pinned(ctx, stage_bytes, &hp) == GH_OK) stage = static_cast<char*>(hp);
     }
     while (i < pieces.size()) {
       size_t j = i + 1;

@@ -1204,7 +1204,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   Readback* rb = nullptr;
   {
     void* hp = nullptr;
-    GH_TRY(gh_pinned(ctx, sizeof(Readback), &hp));
+    GH_TRY(gh_readback_block(ctx, sizeof(Readback), &hp));  // (its own block: later gh_pinned requests cannot move it)
     rb = static_cast<Readback*>(hp);
     memset(rb, 0, sizeof(*rb));
   }

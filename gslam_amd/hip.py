@@ -104,6 +104,7 @@ SIGNATURES = {
     "gh_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
     "gh_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "gh_dev_memset": (C.c_int, [_vp, _vp, _i, _sz]),
+    "gh_ctx_trim": (C.c_int, [_vp]),
     "gh_ctx_set_ba_solver": (C.c_int, [_vp, _i]),
     "gh_ctx_last_ba_solver": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "gh_prof_enable": (C.c_int, [_vp, _i]),
@@ -257,6 +258,10 @@ class Context:
             out[name.value.decode()] = r.value
             op += 1
         return out
+
+    def trim(self):
+        """gh_ctx_trim: give back scratch, pinned staging and the solver arenas (re-grown on demand)."""
+        self.check(lib.gh_ctx_trim(self.h))
 
     def set_ba_solver(self, solver):
         """0 / "auto", 1 / "dense", 2 / "band": linear solver of the reduced camera system (gh_ctx_set_ba_solver)."""

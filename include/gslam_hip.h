@@ -55,6 +55,10 @@ const char* gh_last_error(const gh_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. the caller's current stream).  NULL is the legacy
  * default stream (what torch's default stream is); gh_ctx_use_own_stream restores the private one. */
 gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream);
+/* Frees what the context has grown for past calls (device scratch, pinned staging, the arenas of gh_ba_solve and of the
+ * graph solvers): a single large graph would otherwise pin its high-water mark for the life of the context.  Waits for the
+ * context's stream; everything is re-grown on demand; gh_ba_graph objects own their memory and are not touched. */
+gh_status gh_ctx_trim(gh_ctx* ctx);
 /* Linear solver of the reduced camera system in gh_ba_solve / gh_ba_graph_solve: GH_BA_SOLVER_AUTO (default) takes the
  * band solver (block cyclic reduction, chol_cr.hip) when every point is seen from cameras at most 32 indices apart and
  * the system has at least four superblocks, else the dense MFMA factorisation; _DENSE forces the dense path (what

@@ -208,3 +208,22 @@ def test_ba_wide_graph_stays_dense(ctx):
     g2["obs_cam"] = oc
     _, _, s, used = _solve_with(ctx, g2, "band", iters=3)
     assert used[0] == "dense" and used[2] > 32 and s.iterations >= 1
+
+
+@pytest.mark.gpu
+def test_ctx_trim_regrows(ctx):
+    """gh_ctx_trim gives the context's grown buffers back; the next solves re-grow them and return the same numbers."""
+    from gslam_amd import ba
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(160, 8000, n_obs_per_point=6, seed=5)
+    p0, x0, s0, _ = ba.solve(ctx, g, ba.default_options(max_iterations=10))
+    ctx.trim()
+    p1, x1, s1, _ = ba.solve(ctx, g, ba.default_options(max_iterations=10))
+    assert s0.iterations == s1.iterations and s0.final_cost == s1.final_cost
+    assert np.array_equal(p0, p1) and np.array_equal(x0, x1)
+    S = make_band(1000, 60, seed=8)
+    b = np.ones(1000)
+    xa, _ = ba.band_solve(ctx, S, b, 60)
+    ctx.trim()
+    xb, _ = ba.band_solve(ctx, S, b, 60)
+    assert np.array_equal(xa, xb)
