@@ -831,6 +831,10 @@ def main():
                 abs(bd["final_cost"] - extra["ba_c5"]["final_cost"]) <= 1e-9 * abs(bd["final_cost"]), "C5: the two linear solvers disagree"
             extra["ba_c5"]["band_solver"] = {k: bd[k] for k in ("iters_per_s", "ms_per_iteration", "launches_per_iteration", "linear_solver",
                                                                "final_cost", "kernels")}
+            # 5 iterations are mostly set-up (index lists + 200 MB of upload) at this solver's speed: the rate of a run to convergence
+            bl = ba_leg(10000, 1000000, 40, True, prof_iters=2, solver="auto", graph=g5)
+            extra["ba_c5"]["band_solver"]["to_convergence"] = {k: bl[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
+                                                                                    "initial_cost", "final_cost")}
             del g5
             torch.cuda.empty_cache()
             log("dense solve check n = 60000")

@@ -438,10 +438,44 @@ __device__ __forceinline__ void schur_init_block(int n, int lda, const double* _
   }
 }
 
+// The same for the BAND solver (chol_cr.hip), which only ever touches, in column c of superblock J = c / m: the band rows
+// (from the top of the column's diagonal tile to the end of superblock J + 1) and the fill blocks B(J + 2 s, J) of the
+// levels s at which J survives (J % 2 s == 0): ~ (2 + log2 N) m rows instead of n - c -- at C5 0.9 GB of zeros per LM
+// iteration instead of 14.4 GB.  One workgroup per column.
+__device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, const double* __restrict__ Hcc,
+                                                      const double* __restrict__ gc, double radius, double* __restrict__ S,
+                                                      double* __restrict__ rhs, int c) {
+  const int cam = c / 6, b = c - 6 * cam;
+  double* col = S + (size_t)c * lda;
+  const int J = c / m, N = (n + m - 1) / m;
+  const int r0 = (c >> 6) << 6, r1 = min(n, (J + 2) * m);
+  for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
+    double v = 0.0;
+    if (r / 6 == cam) {
+      const int a = r - 6 * cam;
+      double h = Hcc[(size_t)36 * cam + 6 * a + b];
+      if (a == b) h += clampd(h, 1e-6, 1e32) / radius;
+      v = h;
+    }
+    col[r] = v;
+  }
+  for (int s = 1; J + 2 * s < N; s *= 2) {
+    if (J % (2 * s) != 0) break;  // (J survives level s only if it survived every level before)
+    const int f0 = (J + 2 * s) * m, f1 = min(n, f0 + m);
+    for (int r = f0 + (int)threadIdx.x; r < f1; r += 256) col[r] = 0.0;
+  }
+  if (threadIdx.x == 0) {
+    const double v = -gc[c];
+    col[n] = v;
+    rhs[c] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
                                                          const double* __restrict__ gc, double radius,
-                                                         double* __restrict__ S, double* __restrict__ rhs) {
-  schur_init_block(n, lda, Hcc, gc, radius, S, rhs, (int)blockIdx.x, (int)blockIdx.y);
+                                                         double* __restrict__ S, double* __restrict__ rhs, int band_m) {
+  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, (int)blockIdx.y);  // (gridDim.x == 1)
+  else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 __device__ __forceinline__ void load_W(const double* __restrict__ Wbuf, int k, double* W) {
@@ -593,12 +627,14 @@ __global__ __launch_bounds__(256) void schur_blocks_init_kernel(Problem P, Schur
                                                                 double* __restrict__ partial, unsigned nsb, int n, int lda,
                                                                 const double* __restrict__ Hcc,
                                                                 const double* __restrict__ gc, double radius,
-                                                                double* __restrict__ S, double* __restrict__ rhs, int gx) {
+                                                                double* __restrict__ S, double* __restrict__ rhs, int gx,
+                                                                int band_m) {
   if (blockIdx.x < nsb) {
     schur_blocks_block(P, B, Hpi, gp, Wbuf, partial, blockIdx.x, nsb);
   } else {
     const int b = (int)(blockIdx.x - nsb);
-    schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
+    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b);  // (gx == 1)
+    else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
   }
 }
 
@@ -1899,8 +1935,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     bool solve_state_ready = false;  // set when schur_reduce_kernel has cleared what the single-launch solve kernels need
     if (slim_init) {
       if (!fused_seed)
-        GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc,
-                  d_gc, radius, d_S, d_dc);
+        GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(cr_T ? 1 : gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc,
+                  d_gc, radius, d_S, d_dc, 64 * cr_T);
     } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
       hipError_t me = hipMemsetAsync(d_S, 0, (size_t)n * lda * sizeof(double), ctx->stream);
@@ -1912,10 +1948,10 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       if (opt.deterministic) {
         const unsigned nsb = 8u * (unsigned)gh_div_up(nsegs, 32);
         if (fused_seed) {
-          const int gx = gh_div_up(n + 1, 2048);
+          const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);  // (the band solver's seed: one workgroup per column)
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_init_kernel, dim3(nsb + (unsigned)gx * (unsigned)n), dim3(256), 0, P,
                     SB, d_Hpi, d_gp, (const double*)d_W, d_spart, nsb, n, lda, (const double*)d_Hcc, (const double*)d_gc,
-                    radius, d_S, d_dc, gx);
+                    radius, d_S, d_dc, gx, 64 * cr_T);
         } else {
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(nsb), dim3(256), 0, P, SB, d_Hpi, d_gp,
                     (const double*)d_W, d_spart);
