@@ -1496,8 +1496,18 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     GH_CHECK_ARG(ctx, nc == S.nc && np == S.np && no == S.no && (opt.deterministic != 0) == (S.deterministic != 0));
     GH_CHECK_ARG(ctx, !pr || ((pr->obs_info != nullptr) == S.has_info && (pr->point_free != nullptr) == S.has_pfree));
   } else {
-    for (int k = 0; k < no; ++k)
-      GH_CHECK_ARG(ctx, pr->obs_cam[k] >= 0 && pr->obs_cam[k] < nc && pr->obs_point[k] >= 0 && pr->obs_point[k] < np);
+    // (the same pass finds how far apart, in camera indices, the observers of one point are: a band -> the band solver)
+    std::vector<int32_t> cam_lo((size_t)np, INT32_MAX), cam_hi((size_t)np, -1);
+    for (int k = 0; k < no; ++k) {
+      const int32_t c = pr->obs_cam[k], p = pr->obs_point[k];
+      GH_CHECK_ARG(ctx, c >= 0 && c < nc && p >= 0 && p < np);
+      if (c < cam_lo[p]) cam_lo[p] = c;
+      if (c > cam_hi[p]) cam_hi[p] = c;
+    }
+    int span = 0;
+    for (int p = 0; p < np; ++p)
+      if (cam_hi[p] >= 0 && cam_hi[p] - cam_lo[p] > span) span = cam_hi[p] - cam_lo[p];
+    S.cam_span = span;
   }
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
@@ -1790,18 +1800,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   {
     // The reduced camera system couples two cameras only if they see a common point: with every point seen from cameras
     // at most `span` indices apart (a trajectory), S is a band of half-width 6 span + 5 and the band solver applies.
-    int span = 0;
-    {
-      std::vector<int32_t> lo((size_t)np, INT32_MAX), hi((size_t)np, -1);
-      for (int k = 0; k < no; ++k) {
-        const int p = pr->obs_point[k], c = pr->obs_cam[k];
-        if (c < lo[p]) lo[p] = c;
-        if (c > hi[p]) hi[p] = c;
-      }
-      for (int p = 0; p < np; ++p)
-        if (hi[p] >= 0 && hi[p] - lo[p] > span) span = hi[p] - lo[p];
-    }
-    S.cam_span = span;
+    const int span = S.cam_span;  // (found with the argument check)
     int want = ctx->ba_solver;
     if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
     cr_T = want == 1 || n >= 65536 ? 0 : gh_cr_tiles(n, 6 * span + 5);

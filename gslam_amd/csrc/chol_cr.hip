@@ -507,9 +507,14 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
   const size_t mm = (size_t)m_ * m_;
   const bool elim_task = mode != 0;
   const int ntask = elim_task ? NTE : NTS;
+  // groups -> XCDs: eight groups share the eight XCDs one each; FEWER groups (the upper levels) spread each group's tasks
+  // over 8 / G XCDs instead of crowding 60-70 workgroups onto the 32 CUs of one (the panels then cross the fabric 8 / G
+  // times: nothing at those sizes)
+  const int G = ngroups >= 8 ? 8 : (ngroups > 4 ? 8 : (ngroups > 2 ? 4 : (ngroups > 1 ? 2 : 1))), kx = 8 / G;
+  const int per = (ntask + kx - 1) / kx;  // slots per XCD and group
   const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-  const int grp = xcd + 8 * (slot / ntask), task = slot % ntask;
-  if (grp >= ngroups) return;
+  const int grp = xcd / kx + G * (slot / per), task = (slot % per) * kx + xcd % kx;
+  if (grp >= ngroups || task >= ntask) return;
   // ---- the vector tasks: out[c] (+)= -+ sum_t y[t] W[c][t], 16 columns per workgroup (a whole panel through one CU takes
   // ~25 us); thread = (column tid & 15, the t with t % 16 == tid >> 4): every wave instruction reads four 128-byte rows
   if (task >= ntask - NV) {
@@ -844,6 +849,10 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   // workspace: W [2 N m^2], G [2 N m^2], W3 [N m^2], yh [N m]
   CrArgs a{A, lda, n, N, 1, 0, 0, dinv, W, W + 2 * (size_t)N * mm, W + 4 * (size_t)N * mm, W + 5 * (size_t)N * mm, x, info_dev};
   constexpr int NTS = 4 * (T * (T + 1) / 2 + T * T) + m_ / 16, NTE = 4 * (2 * T * T) + m_ / 16;
+  auto update_grid = [](int ngroups, int ntask) {  // the mapping of cr_update_kernel
+    const int G = ngroups > 4 ? 8 : (ngroups > 2 ? 4 : (ngroups > 1 ? 2 : 1)), kx = 8 / G;
+    return 8 * gh_div_up(ntask, kx) * gh_div_up(ngroups, G);
+  };
   for (int s = 1; s < N; s *= 2) {
     a.s = s;
     a.first = s;
@@ -860,11 +869,11 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
       b.count = N - 1;
       const int ge = 8 * gh_div_up(N - 1, 8);
       CR_LAUNCH_ON(side, "ba_cr_inverse", cr_panels_kernel<T>, dim3(ge * 4 * T), dim3(256), 0, b, 8 * T + 1, 4 * T);
-      CR_LAUNCH_ON(side, "ba_cr_backprep", cr_update_kernel<T>, dim3(ge * NTE), dim3(256), 0, b, 1, N - 1);
+      CR_LAUNCH_ON(side, "ba_cr_backprep", cr_update_kernel<T>, dim3(update_grid(N - 1, NTE)), dim3(256), 0, b, 1, N - 1);
       GH_HIP(ctx, hipEventRecord(ctx->cr_events[1], side));
     }
     const int nsurv = gh_div_up(N, 2 * s);
-    GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(8 * gh_div_up(nsurv, 8) * NTS), dim3(256), 0, a, 0, nsurv);
+    GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(update_grid(nsurv, NTS)), dim3(256), 0, a, 0, nsurv);
   }
   // the last block: block 0 with no neighbours (stride >= N)
   int s_top = 1;
