@@ -141,3 +141,29 @@ def band_solve(ctx: hip.Context, A, b, half_bandwidth):
                                         C.c_void_p(db.data_ptr()), C.byref(info)))
     ctx.sync()
     return db.cpu().numpy(), info.value
+
+
+def marginalize(ctx: hip.Context, graph: dict, huber=0.01, min_shared=1):
+    """gh_ba_marginalize (Optimizer::magin): the SE3 edges of the pose graph a bundle graph marginalises to.
+    Returns (first, second, shared, info n x 6 x 6)."""
+    poses = np.ascontiguousarray(graph["cam_pose"], dtype=np.float64)
+    pts = np.ascontiguousarray(graph["point_xyz"], dtype=np.float64)
+    dof = np.ascontiguousarray(graph["cam_dof"], dtype=np.int32)
+    ocam = np.ascontiguousarray(graph["obs_cam"], dtype=np.int32)
+    opt = np.ascontiguousarray(graph["obs_point"], dtype=np.int32)
+    oxy = np.ascontiguousarray(graph["obs_xy"], dtype=np.float64)
+    pfree = graph.get("point_free")
+    pfree = np.ascontiguousarray(pfree, dtype=np.uint8) if pfree is not None else None
+    info = graph.get("obs_info")
+    info = np.ascontiguousarray(info, dtype=np.float64) if info is not None else None
+    pr = hip.BaProblem(len(poses), len(pts), len(ocam), _ptr(poses), _ptr(dof), _ptr(pts), _ptr(pfree), _ptr(ocam),
+                       _ptr(opt), _ptr(oxy), _ptr(info))
+    n = C.c_int32()
+    ctx.check(hip.lib.gh_ba_marginalize(ctx.h, C.byref(pr), float(huber), int(min_shared), 0, None, None, None, None, C.byref(n)))
+    ne = n.value
+    first, second, shared = (np.zeros(ne, np.int32) for _ in range(3))
+    lam = np.zeros((ne, 6, 6))
+    if ne:
+        ctx.check(hip.lib.gh_ba_marginalize(ctx.h, C.byref(pr), float(huber), int(min_shared), ne, _ptr(first), _ptr(second),
+                                            _ptr(shared), _ptr(lam), C.byref(n)))
+    return first, second, shared, lam

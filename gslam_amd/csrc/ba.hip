@@ -2520,3 +2520,221 @@ extern "C" gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const doub
   }
   return st;
 }
+
+
+// ---------------------------------------------------------------- Optimizer::magin: bundle graph -> pose graph
+// GSLAM/core/Optimizer.h:230-232 ("Convert bundle graph to pose graph") has no implementation in the reference; the
+// specification is the header of oracle_ba_marginalize (oracle/ba_oracle.c): for every pair of cameras (i < j) that share
+// at least `min_shared` points, one SE3 edge whose information is that of camera j's pose RELATIVE to camera i held fixed,
+// from the two-view problem over the shared points at the current estimate,
+//     Lambda_ij = sum_p  A_jp - B_jp V_p^-1 B_jp^T,   A = Jc^T L Jc,  B = Jc^T L Jp  (observation of p in j),
+//                                                     V_p = Jp^T L Jp of BOTH observations of p  (fixed point: A alone)
+// in the perturbation T_j <- T_j exp(delta) the pose-graph residual log(M^-1 T_i^-1 T_j) is linear in.  The host lists the
+// (first, second) observation pairs per camera pair (sorted, stable); one wave per camera pair sums its terms with the
+// reduce-scatter butterfly of the Schur product: fixed order, deterministic.
+namespace {
+template <int K, int M>
+__device__ __forceinline__ void scatter_step36(double (&v)[36], int lane, int& elem, int& mylen) {
+  constexpr int H = (K + 1) / 2;
+  const bool up = (lane & M) != 0;
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const double lo = v[j], hi = H + j < K ? v[H + j] : 0.0;
+    const double recv = __shfl_xor(up ? lo : hi, M);
+    v[j] = (up ? hi : lo) + recv;
+  }
+  elem += up ? H : 0;
+  mylen = up ? (mylen > H ? mylen - H : 0) : (mylen < H ? mylen : H);
+}
+
+__global__ __launch_bounds__(256) void marginalize_pairs_kernel(int nblocks, const double* __restrict__ poses,
+                                                                const double* __restrict__ pts, const uint8_t* __restrict__ pfree,
+                                                                const int32_t* __restrict__ opt, const double* __restrict__ oxy,
+                                                                const double* __restrict__ oinfo, double huber,
+                                                                const int32_t* __restrict__ bstart, const int32_t* __restrict__ bi,
+                                                                const int32_t* __restrict__ bj, const int32_t* __restrict__ e_first,
+                                                                const int32_t* __restrict__ e_second, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nblocks) return;
+  const int ci = bi[blk], cj = bj[blk];
+  double acc[36];
+#pragma unroll
+  for (int t = 0; t < 36; ++t) acc[t] = 0.0;
+  for (int e = bstart[blk] + lane; e < bstart[blk + 1]; e += 64) {
+    const int k1 = e_first[e], k2 = e_second[e];  // the observations of the shared point in camera i and in camera j
+    const int p = opt[k2];
+    const int pf = pfree ? pfree[p] : 1;
+    Obs o1, o2;
+    const bool f1 = linearize<true>(poses + 7 * ci, GH_KF_SE3, pts + 3 * p, pf, oxy + 2 * k1, oinfo ? oinfo + 4 * k1 : nullptr, huber, o1);
+    const bool f2 = linearize<true>(poses + 7 * cj, GH_KF_SE3, pts + 3 * p, pf, oxy + 2 * k2, oinfo ? oinfo + 4 * k2 : nullptr, huber, o2);
+    if (!f1 || !f2) continue;  // behind one of the two cameras: no constraint
+    double L1[4], L2[4];
+    weighted_info(oinfo ? oinfo + 4 * k1 : nullptr, o1.w, L1);
+    weighted_info(oinfo ? oinfo + 4 * k2 : nullptr, o2.w, L2);
+    // LJc (2 x 6), LJp (2 x 3) of the observation in camera j
+    double LJc[12], LJp2[6], LJp1[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      LJc[c] = L2[0] * o2.Jc[c] + L2[1] * o2.Jc[6 + c];
+      LJc[6 + c] = L2[2] * o2.Jc[c] + L2[3] * o2.Jc[6 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      LJp2[c] = L2[0] * o2.Jp[c] + L2[1] * o2.Jp[3 + c];
+      LJp2[3 + c] = L2[2] * o2.Jp[c] + L2[3] * o2.Jp[3 + c];
+      LJp1[c] = L1[0] * o1.Jp[c] + L1[1] * o1.Jp[3 + c];
+      LJp1[3 + c] = L1[2] * o1.Jp[c] + L1[3] * o1.Jp[3 + c];
+    }
+    double A[36], B[18], V[9];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) A[6 * a + b] = o2.Jc[a] * LJc[b] + o2.Jc[6 + a] * LJc[6 + b];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) B[3 * a + b] = o2.Jc[a] * LJp2[b] + o2.Jc[6 + a] * LJp2[3 + b];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        V[3 * a + b] = (o2.Jp[a] * LJp2[b] + o2.Jp[3 + a] * LJp2[3 + b]) + (o1.Jp[a] * LJp1[b] + o1.Jp[3 + a] * LJp1[3 + b]);
+    // V^-1 by the adjugate (V symmetric positive definite for a point two cameras constrain)
+    const double c00 = V[4] * V[8] - V[5] * V[7], c01 = V[5] * V[6] - V[3] * V[8], c02 = V[3] * V[7] - V[4] * V[6];
+    const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
+    if (pf && det > 0.0) {
+      const double id = 1.0 / det;
+      const double Vi[9] = {c00 * id, (V[2] * V[7] - V[1] * V[8]) * id, (V[1] * V[5] - V[2] * V[4]) * id,
+                            c01 * id, (V[0] * V[8] - V[2] * V[6]) * id, (V[2] * V[3] - V[0] * V[5]) * id,
+                            c02 * id, (V[1] * V[6] - V[0] * V[7]) * id, (V[0] * V[4] - V[1] * V[3]) * id};
+      double BV[18];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) BV[3 * a + b] = B[3 * a] * Vi[b] + B[3 * a + 1] * Vi[3 + b] + B[3 * a + 2] * Vi[6 + b];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) A[6 * a + b] -= BV[3 * a] * B[3 * b] + BV[3 * a + 1] * B[3 * b + 1] + BV[3 * a + 2] * B[3 * b + 2];
+    }
+#pragma unroll
+    for (int t = 0; t < 36; ++t) acc[t] += A[t];
+  }
+  int elem = 0, mylen = 36;
+  scatter_step36<36, 32>(acc, lane, elem, mylen);
+  scatter_step36<18, 16>(acc, lane, elem, mylen);
+  scatter_step36<9, 8>(acc, lane, elem, mylen);
+  scatter_step36<5, 4>(acc, lane, elem, mylen);
+  scatter_step36<3, 2>(acc, lane, elem, mylen);
+  scatter_step36<2, 1>(acc, lane, elem, mylen);
+  if (mylen > 0) out[(size_t)36 * blk + elem] = acc[0];
+}
+}  // namespace
+
+extern "C" gh_status gh_ba_marginalize(gh_ctx* ctx, const gh_ba_problem* pr, double huber_delta, int32_t min_shared,
+                                       int32_t max_edges, int32_t* edge_first, int32_t* edge_second, int32_t* edge_shared,
+                                       double* edge_info, int32_t* n_edges) {
+  if (!ctx || !pr || !n_edges) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
+  GH_CHECK_ARG(ctx, nc >= 1 && np >= 0 && no >= 0 && max_edges >= 0 && min_shared >= 1);
+  GH_CHECK_ARG(ctx, pr->cam_pose && (np == 0 || pr->point_xyz) && (no == 0 || (pr->obs_cam && pr->obs_point && pr->obs_xy)));
+  GH_CHECK_ARG(ctx, max_edges == 0 || (edge_first && edge_second && edge_info));
+  for (int k = 0; k < no; ++k)
+    GH_CHECK_ARG(ctx, pr->obs_cam[k] >= 0 && pr->obs_cam[k] < nc && pr->obs_point[k] >= 0 && pr->obs_point[k] < np);
+  // observations by point (original order inside a point)
+  std::vector<int32_t> pstart((size_t)np + 1, 0), plist((size_t)no);
+  for (int k = 0; k < no; ++k) ++pstart[pr->obs_point[k] + 1];
+  for (int p = 0; p < np; ++p) pstart[p + 1] += pstart[p];
+  {
+    std::vector<int32_t> cur(pstart.begin(), pstart.end() - 1);
+    for (int k = 0; k < no; ++k) plist[cur[pr->obs_point[k]]++] = k;
+  }
+  // the pairs of observations of one point in two different cameras, keyed by (lower camera, higher camera)
+  struct Entry {
+    int64_t key;
+    int32_t k_first, k_second;
+  };
+  std::vector<Entry> ent;
+  for (int p = 0; p < np; ++p)
+    for (int a = pstart[p]; a < pstart[p + 1]; ++a)
+      for (int b = a + 1; b < pstart[p + 1]; ++b) {
+        const int ka = plist[a], kb = plist[b], ca = pr->obs_cam[ka], cb = pr->obs_cam[kb];
+        if (ca == cb) continue;
+        const int k1 = ca < cb ? ka : kb, k2 = ca < cb ? kb : ka;
+        ent.push_back(Entry{(int64_t)std::min(ca, cb) * nc + std::max(ca, cb), k1, k2});
+      }
+  std::stable_sort(ent.begin(), ent.end(), [](const Entry& x, const Entry& y) { return x.key < y.key; });
+  std::vector<int32_t> bstart, bi, bj, e1, e2;
+  for (size_t b0 = 0; b0 < ent.size();) {
+    size_t b1 = b0;
+    while (b1 < ent.size() && ent[b1].key == ent[b0].key) ++b1;
+    if ((int64_t)(b1 - b0) >= min_shared) {
+      bstart.push_back((int32_t)e1.size());
+      bi.push_back((int32_t)(ent[b0].key / nc));
+      bj.push_back((int32_t)(ent[b0].key % nc));
+      for (size_t e = b0; e < b1; ++e) {
+        e1.push_back(ent[e].k_first);
+        e2.push_back(ent[e].k_second);
+      }
+    }
+    b0 = b1;
+  }
+  const int nblocks = (int)bi.size();
+  bstart.push_back((int32_t)e1.size());
+  *n_edges = nblocks;
+  if (nblocks == 0 || max_edges == 0) return GH_OK;
+  if (nblocks > max_edges)
+    return gh_set_error(ctx, GH_ERR_ARG, "gh_ba_marginalize: %d camera pairs share >= %d points, room for %d", nblocks, min_shared, max_edges);
+  // device image: one scratch block
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const bool has_info = pr->obs_info != nullptr, has_free = pr->point_free != nullptr;
+  const size_t b_pose = pad((size_t)nc * 56), b_pts = pad((size_t)np * 24), b_free = pad(has_free ? (size_t)np : 0),
+               b_opt = pad((size_t)no * 4), b_xy = pad((size_t)no * 16), b_inf = pad(has_info ? (size_t)no * 32 : 0),
+               b_bs = pad(bstart.size() * 4), b_b = pad((size_t)nblocks * 4), b_e = pad(e1.size() * 4),
+               b_out = pad((size_t)nblocks * 288);
+  void* base = nullptr;
+  GH_TRY(gh_scratch(ctx, b_pose + b_pts + b_free + b_opt + b_xy + b_inf + b_bs + 2 * b_b + 2 * b_e + b_out, &base));
+  char* c = static_cast<char*>(base);
+  auto take = [&](size_t b) { char* r = c; c += b; return r; };
+  double* d_pose = (double*)take(b_pose);
+  double* d_pts = (double*)take(b_pts);
+  uint8_t* d_free = (uint8_t*)take(b_free);
+  int32_t* d_opt = (int32_t*)take(b_opt);
+  double* d_xy = (double*)take(b_xy);
+  double* d_inf = (double*)take(b_inf);
+  int32_t* d_bs = (int32_t*)take(b_bs);
+  int32_t* d_bi = (int32_t*)take(b_b);
+  int32_t* d_bj = (int32_t*)take(b_b);
+  int32_t* d_e1 = (int32_t*)take(b_e);
+  int32_t* d_e2 = (int32_t*)take(b_e);
+  double* d_out = (double*)take(b_out);
+  auto up = [&](void* dst, const void* src, size_t bytes) -> gh_status {
+    if (bytes) GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GH_OK;
+  };
+  GH_TRY(up(d_pose, pr->cam_pose, (size_t)nc * 56));
+  GH_TRY(up(d_pts, pr->point_xyz, (size_t)np * 24));
+  if (has_free) GH_TRY(up(d_free, pr->point_free, (size_t)np));
+  GH_TRY(up(d_opt, pr->obs_point, (size_t)no * 4));
+  GH_TRY(up(d_xy, pr->obs_xy, (size_t)no * 16));
+  if (has_info) GH_TRY(up(d_inf, pr->obs_info, (size_t)no * 32));
+  GH_TRY(up(d_bs, bstart.data(), bstart.size() * 4));
+  GH_TRY(up(d_bi, bi.data(), (size_t)nblocks * 4));
+  GH_TRY(up(d_bj, bj.data(), (size_t)nblocks * 4));
+  GH_TRY(up(d_e1, e1.data(), e1.size() * 4));
+  GH_TRY(up(d_e2, e2.data(), e2.size() * 4));
+  GH_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)nblocks * 288, ctx->stream));
+  GH_LAUNCH(ctx, "ba_marginalize", marginalize_pairs_kernel, dim3(gh_div_up(nblocks, 4)), dim3(256), 0, nblocks,
+            (const double*)d_pose, (const double*)d_pts, has_free ? (const uint8_t*)d_free : nullptr, (const int32_t*)d_opt,
+            (const double*)d_xy, has_info ? (const double*)d_inf : nullptr, huber_delta, (const int32_t*)d_bs,
+            (const int32_t*)d_bi, (const int32_t*)d_bj, (const int32_t*)d_e1, (const int32_t*)d_e2, d_out);
+  GH_HIP(ctx, hipMemcpyAsync(edge_info, d_out, (size_t)nblocks * 288, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the uploads above read the caller's and this function's host arrays)
+  for (int b = 0; b < nblocks; ++b) {
+    edge_first[b] = bi[b];
+    edge_second[b] = bj[b];
+    if (edge_shared) edge_shared[b] = bstart[b + 1] - bstart[b];
+  }
+  return GH_OK;
+}

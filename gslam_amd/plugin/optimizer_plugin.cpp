@@ -15,7 +15,7 @@
 //                                           invDepthObserves, :106-111,152-153,160) or pose-graph edges TOGETHER with
 //                                           point observations: the general solver (SIM3 keyframes, both landmark kinds)
 //                                           and every graph with observations under PROJECTION_SPHERE
-// Still `return false` ("unsupported", as the interface allows): camera self-calibration, magin().
+// Still `return false` ("unsupported", as the interface allows): camera self-calibration.
 // (optimizePnP / optimizePose under PROJECTION_SPHERE go through the general graph solver: optimizePnPSphere.)
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
@@ -52,58 +52,14 @@ class OptimizerHIP : public GSLAM::Optimizer {
     if (graph.keyframes.empty()) return false;
     if (!context()) return false;
 
-    const size_t nc = graph.keyframes.size(), np = graph.mappoints.size(), no = graph.mappointObserves.size();
-    std::vector<double> pose(nc * 7), xyz(np * 3), oxy(no * 2), info;
-    std::vector<int32_t> dof(nc), ocam(no), opt(no);
-    std::vector<uint8_t> pfree(np);
-    for (size_t i = 0; i < nc; ++i) {
-      const GSLAM::SIM3& T = graph.keyframes[i].estimation;  // T_wc, camera -> world
-      const GSLAM::SO3 r = T.get_rotation();
-      const GSLAM::Point3d t = T.get_translation();
-      double* p = &pose[i * 7];
-      p[0] = r.x; p[1] = r.y; p[2] = r.z; p[3] = r.w; p[4] = t.x; p[5] = t.y; p[6] = t.z;
-      // SIM3 scale s > 0: X_c = T_wc^-1 X_w = R^T (X_w - t) / s (GSLAM/core/SIM3.h:120-131), and the pinhole residual
-      // X_c.xy / X_c.z does not depend on s -- the SE3 part (R, t) is the whole problem, s is a gauge that mappoint
-      // observations cannot see.  It is therefore neither optimised (UPDATE_KF_SCALE is ignored) nor changed: the
-      // keyframe gets (R', t', s) back.  s <= 0 flips the depth sign and is rejected.
-      if (!(T.get_scale() > 0)) return unsupported("keyframe with non-positive SIM3 scale");
-      dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SE3;
-    }
-    for (size_t i = 0; i < np; ++i) {
-      xyz[3 * i] = graph.mappoints[i].first.x;
-      xyz[3 * i + 1] = graph.mappoints[i].first.y;
-      xyz[3 * i + 2] = graph.mappoints[i].first.z;
-      pfree[i] = graph.mappoints[i].second ? 1 : 0;
-    }
-    bool any_info = false;
-    for (size_t k = 0; k < no; ++k) any_info = any_info || graph.mappointObserves[k].information != NULL;
-    if (any_info) info.resize(no * 4);
-    for (size_t k = 0; k < no; ++k) {
-      const GSLAM::BundleEdge& e = graph.mappointObserves[k];
-      if (e.pointId >= np || e.frameId >= nc) {
-        LOG(ERROR) << "OptimizerHIP: observation " << k << " references a missing vertex";
-        return false;
-      }
-      opt[k] = (int32_t)e.pointId;
-      ocam[k] = (int32_t)e.frameId;
-      const double z = e.measurement.z;  // CameraAnchor: pinhole measurements live on the z = 1 plane (:58-61,102-103)
-      if (!(z > 0)) {
-        LOG(ERROR) << "OptimizerHIP: observation " << k << " has measurement.z = " << z << " (pinhole anchors need z > 0)";
-        return false;
-      }
-      oxy[2 * k] = e.measurement.x / z;
-      oxy[2 * k + 1] = e.measurement.y / z;
-      if (any_info) {
-        double* L = &info[4 * k];
-        if (e.information) { L[0] = e.information[0]; L[1] = e.information[1]; L[2] = e.information[2]; L[3] = e.information[3]; }
-        else { L[0] = 1; L[1] = 0; L[2] = 0; L[3] = 1; }
-      }
-    }
-    gh_ba_problem pr;
-    pr.n_cams = (int32_t)nc; pr.n_points = (int32_t)np; pr.n_obs = (int32_t)no;
-    pr.cam_pose = pose.data(); pr.cam_dof = dof.data(); pr.point_xyz = xyz.data(); pr.point_free = pfree.data();
-    pr.obs_cam = ocam.data(); pr.obs_point = opt.data(); pr.obs_xy = oxy.data();
-    pr.obs_info = any_info ? info.data() : NULL;
+    BaArrays A;
+    if (!to_problem(graph, A)) return false;
+    const size_t nc = A.nc, np = A.np;
+    std::vector<double>&pose = A.pose, &xyz = A.xyz, &oxy = A.oxy, &info = A.info;
+    std::vector<int32_t>&dof = A.dof, &ocam = A.ocam, &opt = A.opt;
+    std::vector<uint8_t>& pfree = A.pfree;
+    const bool any_info = A.any_info;
+    gh_ba_problem& pr = A.pr;
     gh_ba_options o;
     gh_ba_default_options(&o);
     o.huber_delta = _config.projectErrorHuberThreshold;
@@ -153,6 +109,118 @@ class OptimizerHIP : public GSLAM::Optimizer {
     }
     for (size_t i = 0; i < np; ++i)
       graph.mappoints[i].first = GSLAM::Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return true;
+  }
+
+  // A pinhole bundle graph over XYZ points flattened for gh_ba_problem (the vectors own the storage)
+  struct BaArrays {
+    size_t nc = 0, np = 0, no = 0;
+    std::vector<double> pose, xyz, oxy, info;
+    std::vector<int32_t> dof, ocam, opt;
+    std::vector<uint8_t> pfree;
+    bool any_info = false;
+    gh_ba_problem pr;
+  };
+  bool to_problem(GSLAM::BundleGraph& graph, BaArrays& A) {
+    const size_t nc = graph.keyframes.size(), np = graph.mappoints.size(), no = graph.mappointObserves.size();
+    A.nc = nc; A.np = np; A.no = no;
+    A.pose.assign(nc * 7, 0.0); A.xyz.assign(np * 3, 0.0); A.oxy.assign(no * 2, 0.0); A.info.clear();
+    A.dof.assign(nc, 0); A.ocam.assign(no, 0); A.opt.assign(no, 0); A.pfree.assign(np, 0);
+    std::vector<double>&pose = A.pose, &xyz = A.xyz, &oxy = A.oxy, &info = A.info;
+    std::vector<int32_t>&dof = A.dof, &ocam = A.ocam, &opt = A.opt;
+    std::vector<uint8_t>& pfree = A.pfree;
+    for (size_t i = 0; i < nc; ++i) {
+      const GSLAM::SIM3& T = graph.keyframes[i].estimation;  // T_wc, camera -> world
+      const GSLAM::SO3 r = T.get_rotation();
+      const GSLAM::Point3d t = T.get_translation();
+      double* p = &pose[i * 7];
+      p[0] = r.x; p[1] = r.y; p[2] = r.z; p[3] = r.w; p[4] = t.x; p[5] = t.y; p[6] = t.z;
+      // SIM3 scale s > 0: X_c = T_wc^-1 X_w = R^T (X_w - t) / s (GSLAM/core/SIM3.h:120-131), and the pinhole residual
+      // X_c.xy / X_c.z does not depend on s -- the SE3 part (R, t) is the whole problem, s is a gauge that mappoint
+      // observations cannot see.  It is therefore neither optimised (UPDATE_KF_SCALE is ignored) nor changed: the
+      // keyframe gets (R', t', s) back.  s <= 0 flips the depth sign and is rejected.
+      if (!(T.get_scale() > 0)) return unsupported("keyframe with non-positive SIM3 scale");
+      dof[i] = (int32_t)graph.keyframes[i].dof & GH_KF_SE3;
+    }
+    for (size_t i = 0; i < np; ++i) {
+      xyz[3 * i] = graph.mappoints[i].first.x;
+      xyz[3 * i + 1] = graph.mappoints[i].first.y;
+      xyz[3 * i + 2] = graph.mappoints[i].first.z;
+      pfree[i] = graph.mappoints[i].second ? 1 : 0;
+    }
+    bool any_info = false;
+    for (size_t k = 0; k < no; ++k) any_info = any_info || graph.mappointObserves[k].information != NULL;
+    A.any_info = any_info;
+    if (any_info) info.resize(no * 4);
+    for (size_t k = 0; k < no; ++k) {
+      const GSLAM::BundleEdge& e = graph.mappointObserves[k];
+      if (e.pointId >= np || e.frameId >= nc) {
+        LOG(ERROR) << "OptimizerHIP: observation " << k << " references a missing vertex";
+        return false;
+      }
+      opt[k] = (int32_t)e.pointId;
+      ocam[k] = (int32_t)e.frameId;
+      const double z = e.measurement.z;  // CameraAnchor: pinhole measurements live on the z = 1 plane (:58-61,102-103)
+      if (!(z > 0)) {
+        LOG(ERROR) << "OptimizerHIP: observation " << k << " has measurement.z = " << z << " (pinhole anchors need z > 0)";
+        return false;
+      }
+      oxy[2 * k] = e.measurement.x / z;
+      oxy[2 * k + 1] = e.measurement.y / z;
+      if (any_info) {
+        double* L = &info[4 * k];
+        if (e.information) { L[0] = e.information[0]; L[1] = e.information[1]; L[2] = e.information[2]; L[3] = e.information[3]; }
+        else { L[0] = 1; L[1] = 0; L[2] = 0; L[3] = 1; }
+      }
+    }
+    gh_ba_problem& pr = A.pr;
+    pr.n_cams = (int32_t)nc; pr.n_points = (int32_t)np; pr.n_obs = (int32_t)no;
+    pr.cam_pose = pose.data(); pr.cam_dof = dof.data(); pr.point_xyz = xyz.data(); pr.point_free = pfree.data();
+    pr.obs_cam = ocam.data(); pr.obs_point = opt.data(); pr.obs_xy = oxy.data();
+    pr.obs_info = any_info ? info.data() : NULL;
+    return true;
+  }
+
+  // "Convert bundle graph to pose graph" (GSLAM/core/Optimizer.h:230-232; the reference declares it and nothing else, so
+  // the semantics are ours: gh_ba_marginalize / oracle_ba_marginalize).  Every pair of keyframes that shares at least
+  // OptimizerHIP.MaginMinShared (default 15) map points becomes an SE3Edge {first < second, T_first^-1 T_second of the current
+  // estimates, information = the two-view Schur complement over the shared points}; the map-point observations are
+  // removed from the graph (they are what the edges stand for), keyframes and map points stay.  The information blocks the
+  // edges point to are owned by this optimizer and live until its next magin() or its destruction.  Pinhole XYZ-point
+  // graphs only (the fast path of optimize()).
+  bool magin(GSLAM::BundleGraph& graph) override {
+    if (_config.cameraProjectionType == GSLAM::PROJECTION_SPHERE) return unsupported("magin under PROJECTION_SPHERE");
+    if (!graph.invDepths.empty() || !graph.invDepthObserves.empty()) return unsupported("magin of inverse-depth points");
+    if (graph.keyframes.empty() || graph.mappointObserves.empty()) return false;
+    if (!context()) return false;
+    BaArrays A;
+    if (!to_problem(graph, A)) return false;
+    const int min_shared = svar.GetInt("OptimizerHIP.MaginMinShared", 15);
+    std::lock_guard<std::mutex> lock(mu_);
+    int32_t n = 0;
+    gh_status st = gh_ba_marginalize(ctx_, &A.pr, _config.projectErrorHuberThreshold, min_shared, 0, NULL, NULL, NULL, NULL, &n);
+    std::vector<int32_t> first((size_t)n), second((size_t)n);
+    magin_info_.assign((size_t)n * 36, 0.0);
+    if (st == GH_OK && n > 0)
+      st = gh_ba_marginalize(ctx_, &A.pr, _config.projectErrorHuberThreshold, min_shared, n, first.data(), second.data(), NULL,
+                             magin_info_.data(), &n);
+    if (st != GH_OK) {
+      LOG(ERROR) << "OptimizerHIP: magin failed (" << st << "): " << gh_last_error(ctx_);
+      return false;
+    }
+    graph.se3Graph.reserve(graph.se3Graph.size() + (size_t)n);
+    for (int32_t e = 0; e < n; ++e) {
+      GSLAM::SE3Edge edge;
+      edge.firstId = (GSLAM::FrameID)first[e];
+      edge.secondId = (GSLAM::FrameID)second[e];
+      const GSLAM::SIM3 &Ti = graph.keyframes[first[e]].estimation, &Tj = graph.keyframes[second[e]].estimation;
+      const GSLAM::SE3 Ei(Ti.get_rotation(), Ti.get_translation()), Ej(Tj.get_rotation(), Tj.get_translation());
+      edge.measurement = Ei.inverse() * Ej;
+      edge.information = &magin_info_[(size_t)e * 36];
+      graph.se3Graph.push_back(edge);
+    }
+    graph.mappointObserves.clear();
+    if (_config.verbose) LOG(INFO) << "OptimizerHIP: magin: " << n << " SE3 edges from " << A.no << " observations";
     return true;
   }
 
@@ -580,6 +648,7 @@ class OptimizerHIP : public GSLAM::Optimizer {
   std::vector<int32_t> graph_ocam_, graph_opt_;
   size_t graph_nc_ = 0, graph_np_ = 0, graph_hits_ = 0;
   bool graph_info_ = false;
+  std::vector<double> magin_info_;  // 6 x 6 information blocks the edges of the last magin() point to
 };
 
 }  // namespace

@@ -48,6 +48,88 @@ static std::vector<T> read_vec(std::ifstream& f, size_t n) {
   return v;
 }
 
+// Optimizer::magin through the plugin: same input file as run_ba; out = int32 ok, int32 n_edges, then per edge
+// int32 first, int32 second, 7 doubles measurement [qx qy qz qw tx ty tz], 36 doubles information; then the converted
+// graph (keyframes + SE3 edges, no observations) goes back through optimize() -- the pose-graph path of the same plugin.
+static int run_magin(const std::string& dir, const char* in, const char* out) {
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[6];
+  f.read((char*)hdr, sizeof(hdr));
+  double huber;
+  f.read((char*)&huber, 8);
+  const int nc = hdr[0], np = hdr[1], no = hdr[2];
+  std::vector<double> pose = read_vec<double>(f, (size_t)nc * 7);
+  std::vector<int32_t> dof = read_vec<int32_t>(f, nc);
+  std::vector<double> xyz = read_vec<double>(f, (size_t)np * 3);
+  std::vector<uint8_t> pfree = read_vec<uint8_t>(f, hdr[5] ? np : 0);
+  std::vector<int32_t> ocam = read_vec<int32_t>(f, no), opt = read_vec<int32_t>(f, no);
+  std::vector<double> oxy = read_vec<double>(f, (size_t)no * 2);
+  std::vector<double> info = read_vec<double>(f, hdr[3] ? (size_t)no * 4 : 0);
+  OptimizerPtr opt_ptr = Optimizer::create();
+  if (!opt_ptr) { std::cerr << "Optimizer::create() returned null\n"; return 2; }
+  opt_ptr->_config.projectErrorHuberThreshold = huber;
+  opt_ptr->_config.maxIterations = hdr[4];
+  BundleGraph g;
+  g.cameraDOF = UPDATE_CAMERA_NONE;
+  g.keyframes.resize(nc);
+  for (int i = 0; i < nc; ++i) {
+    const double* p = &pose[(size_t)i * 7];
+    g.keyframes[i].estimation = SIM3(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]), 1.0);
+    g.keyframes[i].dof = (KeyFrameEstimzationDOF)dof[i];
+  }
+  g.mappoints.resize(np);
+  for (int i = 0; i < np; ++i)
+    g.mappoints[i] = std::make_pair(Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), hdr[5] ? pfree[i] != 0 : true);
+  g.mappointObserves.resize(no);
+  for (int k = 0; k < no; ++k) {
+    BundleEdge e;
+    e.pointId = opt[k];
+    e.frameId = ocam[k];
+    e.measurement = Point3d(oxy[2 * k], oxy[2 * k + 1], 1.0);
+    e.information = hdr[3] ? &info[(size_t)k * 4] : NULL;
+    g.mappointObserves[k] = e;
+  }
+  const bool ok = opt_ptr->magin(g);
+  std::cout << "magin=" << ok << " edges=" << g.se3Graph.size() << " observations_left=" << g.mappointObserves.size() << std::endl;
+  std::ofstream o(out, std::ios::binary);
+  int32_t okv = ok ? 1 : 0, ne = (int32_t)g.se3Graph.size();
+  o.write((char*)&okv, 4);
+  o.write((char*)&ne, 4);
+  for (size_t k = 0; k < g.se3Graph.size(); ++k) {
+    const SE3Edge& e = g.se3Graph[k];
+    int32_t ij[2] = {(int32_t)e.firstId, (int32_t)e.secondId};
+    o.write((char*)ij, 8);
+    const SO3 r = e.measurement.get_rotation();
+    const Point3d t = e.measurement.get_translation();
+    double m[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+    o.write((char*)m, sizeof(m));
+    o.write((char*)e.information, 36 * sizeof(double));
+  }
+  if (ok) {
+    // the result is a pose graph the same plugin solves: start from perturbed keyframes, the first one fixed
+    BundleGraph pg = g;
+    for (size_t i = 1; i < pg.keyframes.size(); ++i) {
+      SIM3& T = pg.keyframes[i].estimation;
+      T = SIM3(T.get_rotation(), T.get_translation() + Point3d(0.01 * (i % 3), -0.01 * (i % 2), 0.005), 1.0);
+    }
+    pg.keyframes[0].dof = UPDATE_KF_NONE;
+    const bool okp = opt_ptr->optimize(pg);
+    double worst = 0;
+    for (size_t k = 0; k < pg.se3Graph.size(); ++k) {
+      const SE3Edge& e = pg.se3Graph[k];
+      const SIM3 &Ti = pg.keyframes[e.firstId].estimation, &Tj = pg.keyframes[e.secondId].estimation;
+      const SE3 rel = SE3(Ti.get_rotation(), Ti.get_translation()).inverse() * SE3(Tj.get_rotation(), Tj.get_translation());
+      const SE3 err = e.measurement.inverse() * rel;
+      const SO3 q = err.get_rotation();
+      worst = std::max(worst, std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z));
+    }
+    std::cout.precision(6);
+    std::cout << "posegraph_optimize=" << okp << " worst_rotation_residual=" << worst << std::endl;
+  }
+  return 0;
+}
+
 static int run_ba(const std::string& dir, const char* in, const char* out, double kf_scale, int zero_z_obs) {
   svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
   std::ifstream f(in, std::ios::binary);
@@ -868,6 +950,7 @@ int main(int argc, char** argv) {
   }
   if (mode == "ba" && argc >= 5)
     return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
+  if (mode == "magin" && argc >= 5) return run_magin(dir, argv[3], argv[4]);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4], argc >= 6 ? atoi(argv[5]) : 0);
   if (mode == "pg" && argc >= 5) return run_pg(dir, argv[3], argv[4]);
   if (mode == "align" && argc >= 5) return run_align(dir, argv[3], argv[4]);

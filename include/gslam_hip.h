@@ -520,6 +520,18 @@ gh_status gh_ba_graph_read(gh_ba_graph* graph, double* cam_pose, double* point_x
 gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy, int n, double* pose,
                     int dof, const gh_ba_options* options, double* information_out, gh_ba_summary* summary);
 
+/* Optimizer::magin (GSLAM/core/Optimizer.h:230-232, "Convert bundle graph to pose graph"; the reference ships the
+ * declaration only): one SE3 edge per pair of cameras (first < second) that share at least min_shared points, with the 6x6
+ * information (row-major, [v, w] order of SE3::exp) of the second camera's pose relative to the first held fixed -- the
+ * Schur complement of the two-view problem over the shared points at the current estimate, Huber-weighted like
+ * gh_ba_solve (specification: oracle_ba_marginalize in oracle/ba_oracle.c).  The measurement of the edge is
+ * T_first^-1 T_second of the current poses (the caller forms it).  Edges come sorted by (first, second); *n_edges is
+ * always the number found; with max_edges == 0 nothing else is written (size query), with 0 < max_edges < *n_edges the
+ * call fails.  edge_shared (may be NULL) = shared points per edge. */
+gh_status gh_ba_marginalize(gh_ctx* ctx, const gh_ba_problem* problem, double huber_delta, int32_t min_shared,
+                            int32_t max_edges, int32_t* edge_first, int32_t* edge_second, int32_t* edge_shared,
+                            double* edge_info, int32_t* n_edges);
+
 /* ---- Pose graph: Optimizer::optimize(BundleGraph&) with se3Graph / sim3Graph / gpsGraph edges ---------------------------
  * Data contract GSLAM/core/Optimizer.h:127-148,162-167: SE3Edge {firstId, secondId, measurement SE3_12 := SE3_1^-1 SE3_2,
  * information 6x6}, SIM3Edge {.., SIM3_12 := SIM3_1^-1 SIM3_2, 7x7}, GPSEdge {frameId, SE3_gps := SE3_frame, 6x6};

@@ -524,3 +524,122 @@ int oracle_ba_pnp(const double* points_xyz, const double* obs_xy, int n, double*
   free(ocam); free(opt_idx); free(pfree); free(pts);
   return rc;
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Optimizer::magin (GSLAM/core/Optimizer.h:230-232: "Convert bundle graph to pose graph").  The reference declares it and
+ * nothing else -- no implementation, no caller, no test -- so this is the specification (parity unpinned):
+ *   for every pair of cameras first < second that share at least min_shared points (a point counts once per pair of its
+ *   observations in the two cameras), one SE3 edge {first, second, T_first^-1 T_second, Lambda};
+ *   Lambda (6 x 6, [v, w] order of SE3::exp, row-major) = the information of the second camera's pose, in the perturbation
+ *   T <- T exp(delta), relative to the first camera held fixed, from the two-view problem over the shared points at the
+ *   current estimate:   Lambda = sum_p  A - B V^-1 B^T   with, for the observation of p in `second`,
+ *       A = Jc^T L Jc,  B = Jc^T L Jp,  and  V = Jp^T L Jp summed over BOTH observations of p   (L = Huber weight x information);
+ *   a fixed point (or a singular V) contributes A alone; a point behind either camera contributes nothing.
+ * Edges sorted by (first, second).  Returns the number of edges (all of them, also beyond max_edges: then only the first
+ * max_edges are written). */
+typedef struct { int64_t key; int32_t k1, k2, seq; } marg_entry;
+static int marg_cmp(const void* a, const void* b) {
+  const marg_entry* x = (const marg_entry*)a;
+  const marg_entry* y = (const marg_entry*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+int oracle_ba_marginalize(int nc, int np, int no, const double* poses, const double* pts, const uint8_t* pfree,
+                          const int32_t* ocam, const int32_t* opt, const double* oxy, const double* oinfo, double huber,
+                          int min_shared, int max_edges, int32_t* edge_first, int32_t* edge_second, int32_t* edge_shared,
+                          double* edge_info) {
+  int32_t* pstart = (int32_t*)calloc((size_t)np + 1, sizeof(int32_t));
+  int32_t* plist = (int32_t*)malloc((size_t)(no > 0 ? no : 1) * sizeof(int32_t));
+  int32_t* cur = (int32_t*)malloc((size_t)(np > 0 ? np : 1) * sizeof(int32_t));
+  for (int k = 0; k < no; ++k) ++pstart[opt[k] + 1];
+  for (int p = 0; p < np; ++p) pstart[p + 1] += pstart[p];
+  for (int p = 0; p < np; ++p) cur[p] = pstart[p];
+  for (int k = 0; k < no; ++k) plist[cur[opt[k]]++] = k;
+  size_t cap = 0;
+  for (int p = 0; p < np; ++p) {
+    const size_t d = (size_t)(pstart[p + 1] - pstart[p]);
+    cap += d * (d - (d > 0)) / 2;
+  }
+  marg_entry* ent = (marg_entry*)malloc((cap > 0 ? cap : 1) * sizeof(marg_entry));
+  size_t ne = 0;
+  for (int p = 0; p < np; ++p)
+    for (int a = pstart[p]; a < pstart[p + 1]; ++a)
+      for (int b = a + 1; b < pstart[p + 1]; ++b) {
+        const int ka = plist[a], kb = plist[b], ca = ocam[ka], cb = ocam[kb];
+        if (ca == cb) continue;
+        ent[ne].key = (int64_t)(ca < cb ? ca : cb) * nc + (ca < cb ? cb : ca);
+        ent[ne].k1 = ca < cb ? ka : kb;
+        ent[ne].k2 = ca < cb ? kb : ka;
+        ent[ne].seq = (int32_t)ne;
+        ++ne;
+      }
+  qsort(ent, ne, sizeof(marg_entry), marg_cmp);
+  int n_edges = 0;
+  for (size_t b0 = 0; b0 < ne;) {
+    size_t b1 = b0;
+    while (b1 < ne && ent[b1].key == ent[b0].key) ++b1;
+    if ((int64_t)(b1 - b0) >= min_shared) {
+      const int ci = (int)(ent[b0].key / nc), cj = (int)(ent[b0].key % nc);
+      if (n_edges < max_edges) {
+        double Lam[36];
+        for (int t = 0; t < 36; ++t) Lam[t] = 0;
+        for (size_t e = b0; e < b1; ++e) {
+          const int k1 = ent[e].k1, k2 = ent[e].k2, p = opt[k2];
+          const int pf = pfree ? pfree[p] : 1;
+          double r1[2], w1, Jc1[12], Jp1[6], s1, r2[2], w2, Jc2[12], Jp2[6], s2;
+          if (!obs_linearize(poses + 7 * ci, 63, pts + 3 * p, pf, oxy + 2 * k1, oinfo ? oinfo + 4 * k1 : NULL, huber, r1, &w1, Jc1, Jp1, &s1)) continue;
+          if (!obs_linearize(poses + 7 * cj, 63, pts + 3 * p, pf, oxy + 2 * k2, oinfo ? oinfo + 4 * k2 : NULL, huber, r2, &w2, Jc2, Jp2, &s2)) continue;
+          double L1[4] = {w1, 0, 0, w1}, L2[4] = {w2, 0, 0, w2};
+          if (oinfo) {
+            for (int t = 0; t < 4; ++t) { L1[t] = w1 * oinfo[4 * k1 + t]; L2[t] = w2 * oinfo[4 * k2 + t]; }
+          }
+          double LJc[12], LJp2[6], LJp1[6];
+          for (int c = 0; c < 6; ++c) {
+            LJc[c] = L2[0] * Jc2[c] + L2[1] * Jc2[6 + c];
+            LJc[6 + c] = L2[2] * Jc2[c] + L2[3] * Jc2[6 + c];
+          }
+          for (int c = 0; c < 3; ++c) {
+            LJp2[c] = L2[0] * Jp2[c] + L2[1] * Jp2[3 + c];
+            LJp2[3 + c] = L2[2] * Jp2[c] + L2[3] * Jp2[3 + c];
+            LJp1[c] = L1[0] * Jp1[c] + L1[1] * Jp1[3 + c];
+            LJp1[3 + c] = L1[2] * Jp1[c] + L1[3] * Jp1[3 + c];
+          }
+          double A[36], B[18], V[9];
+          for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) A[6 * a + b] = Jc2[a] * LJc[b] + Jc2[6 + a] * LJc[6 + b];
+            for (int b = 0; b < 3; ++b) B[3 * a + b] = Jc2[a] * LJp2[b] + Jc2[6 + a] * LJp2[3 + b];
+          }
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+              V[3 * a + b] = (Jp2[a] * LJp2[b] + Jp2[3 + a] * LJp2[3 + b]) + (Jp1[a] * LJp1[b] + Jp1[3 + a] * LJp1[3 + b]);
+          const double c00 = V[4] * V[8] - V[5] * V[7], c01 = V[5] * V[6] - V[3] * V[8], c02 = V[3] * V[7] - V[4] * V[6];
+          const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
+          if (pf && det > 0.0) {
+            const double id = 1.0 / det;
+            const double Vi[9] = {c00 * id, (V[2] * V[7] - V[1] * V[8]) * id, (V[1] * V[5] - V[2] * V[4]) * id,
+                                  c01 * id, (V[0] * V[8] - V[2] * V[6]) * id, (V[2] * V[3] - V[0] * V[5]) * id,
+                                  c02 * id, (V[1] * V[6] - V[0] * V[7]) * id, (V[0] * V[4] - V[1] * V[3]) * id};
+            double BV[18];
+            for (int a = 0; a < 6; ++a)
+              for (int b = 0; b < 3; ++b) BV[3 * a + b] = B[3 * a] * Vi[b] + B[3 * a + 1] * Vi[3 + b] + B[3 * a + 2] * Vi[6 + b];
+            for (int a = 0; a < 6; ++a)
+              for (int b = 0; b < 6; ++b) A[6 * a + b] -= BV[3 * a] * B[3 * b] + BV[3 * a + 1] * B[3 * b + 1] + BV[3 * a + 2] * B[3 * b + 2];
+          }
+          for (int t = 0; t < 36; ++t) Lam[t] += A[t];
+        }
+        edge_first[n_edges] = ci;
+        edge_second[n_edges] = cj;
+        if (edge_shared) edge_shared[n_edges] = (int32_t)(b1 - b0);
+        for (int t = 0; t < 36; ++t) edge_info[36 * (size_t)n_edges + t] = Lam[t];
+      }
+      ++n_edges;
+    }
+    b0 = b1;
+  }
+  free(ent);
+  free(cur);
+  free(plist);
+  free(pstart);
+  return n_edges;
+}

@@ -332,6 +332,27 @@ def _ba_methods(cls):
                                        _ptr(np.ascontiguousarray(g["obs_xy"], dtype=np.float64)),
                                        _ptr(g.get("obs_info")), C.c_double(huber))
 
+    def ba_marginalize(self, g, huber=0.01, min_shared=1):
+        """oracle_ba_marginalize (the specification of Optimizer::magin) -> (first, second, shared, info n x 6 x 6)."""
+        poses = np.ascontiguousarray(g["cam_pose"], dtype=np.float64)
+        pts = np.ascontiguousarray(g["point_xyz"], dtype=np.float64)
+        ocam = np.ascontiguousarray(g["obs_cam"], dtype=np.int32)
+        opt = np.ascontiguousarray(g["obs_point"], dtype=np.int32)
+        oxy = np.ascontiguousarray(g["obs_xy"], dtype=np.float64)
+        pfree = g.get("point_free")
+        pfree = np.ascontiguousarray(pfree, dtype=np.uint8) if pfree is not None else None
+        info = g.get("obs_info")
+        info = np.ascontiguousarray(info, dtype=np.float64) if info is not None else None
+        self.lib.oracle_ba_marginalize.restype = C.c_int
+        args = (len(poses), len(pts), len(ocam), _ptr(poses), _ptr(pts), _ptr(pfree), _ptr(ocam), _ptr(opt), _ptr(oxy),
+                _ptr(info), C.c_double(huber), int(min_shared))
+        ne = self.lib.oracle_ba_marginalize(*args, 0, None, None, None, None)
+        first, second, shared = (np.zeros(ne, np.int32) for _ in range(3))
+        lam = np.zeros((ne, 6, 6))
+        if ne:
+            self.lib.oracle_ba_marginalize(*args, ne, _ptr(first), _ptr(second), _ptr(shared), _ptr(lam))
+        return first, second, shared, lam
+
     def se3_exp(self, xi):
         out = np.zeros(7)
         self.lib.oracle_se3_exp(_ptr(np.ascontiguousarray(xi, dtype=np.float64)), _ptr(out))
@@ -364,7 +385,7 @@ def _ba_methods(cls):
         rc = self.lib.oracle_ba_pnp(_ptr(X), _ptr(m), len(X), _ptr(p), int(dof), C.byref(opts), _ptr(info), C.byref(s))
         return p, s, (info.reshape(6, 6) if want_information else None), rc
 
-    for f in (ba_solve, ba_cost, se3_exp, se3_retract, potrf_solve, ba_pnp):
+    for f in (ba_solve, ba_cost, ba_marginalize, se3_exp, se3_retract, potrf_solve, ba_pnp):
         setattr(cls, f.__name__, f)
 
 

@@ -60,6 +60,49 @@ def test_optimizer_plugin_optimize_matches_oracle(tmp_path, oracle):
     assert np.array_equal(pts[:5], g["point_xyz"][:5]) and np.array_equal(poses[0], g["cam_pose"][0])
 
 
+def test_optimizer_plugin_magin(tmp_path, oracle):
+    """Optimizer::magin (GSLAM/core/Optimizer.h:230-232) through Optimizer::create(): the SE3 edges equal the oracle's
+    (oracle_ba_marginalize, default OptimizerHIP.MaginMinShared = 15), their measurements are T_first^-1 T_second by the
+    reference's own SE3 algebra, the observations are gone, and the converted graph runs through optimize() again."""
+    _need_host()
+    g = make_graph(24, 1500, n_obs_per_point=5, seed=23)
+    inp, out = tmp_path / "graph.bin", tmp_path / "out.bin"
+    nc, npt, no = len(g["cam_pose"]), len(g["point_xyz"]), len(g["obs_cam"])
+    with open(inp, "wb") as f:
+        f.write(np.array([nc, npt, no, 0, 30, 0], np.int32).tobytes())
+        f.write(struct.pack("d", 0.01))
+        for k, dt in (("cam_pose", np.float64), ("cam_dof", np.int32), ("point_xyz", np.float64),
+                      ("obs_cam", np.int32), ("obs_point", np.int32), ("obs_xy", np.float64)):
+            f.write(np.ascontiguousarray(g[k], dtype=dt).tobytes())
+    r = _run(["magin", LIBDIR, inp, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "magin=1" in r.stdout and "observations_left=0" in r.stdout and "posegraph_optimize=1" in r.stdout, r.stdout
+    worst = float(r.stdout.split("worst_rotation_residual=")[1].split()[0])
+    assert worst < 1e-5, r.stdout
+    raw = open(out, "rb").read()
+    ok, ne = struct.unpack("ii", raw[:8])
+    fo, so, no_, lamo = oracle.ba_marginalize(g, huber=0.01, min_shared=15)
+    assert ok == 1 and ne == len(fo) > 20
+    rec = np.dtype([("ij", np.int32, 2), ("m", np.float64, 7), ("info", np.float64, 36)])
+    ed = np.frombuffer(raw, rec, ne, 8)
+    assert np.array_equal(ed["ij"][:, 0], fo) and np.array_equal(ed["ij"][:, 1], so)
+    scale = np.abs(lamo).reshape(ne, -1).max(axis=1)[:, None]
+    assert (np.abs(ed["info"] - lamo.reshape(ne, 36)) <= 1e-11 * scale).all()
+    poses = np.asarray(g["cam_pose"], dtype=np.float64)
+    for e in range(0, ne, 7):   # T_i^-1 T_j
+        i, j = fo[e], so[e]
+        qi, ti, qj, tj = poses[i, :4], poses[i, 4:], poses[j, :4], poses[j, 4:]
+        qic = np.array([-qi[0], -qi[1], -qi[2], qi[3]])
+        def qmul(a, b):
+            return np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
+                             a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+        q = qmul(qic, qj)
+        t = qmul(qmul(qic, np.array([*(tj - ti), 0.0])), qi)[:3]
+        m = ed["m"][e]
+        sgn = np.sign(np.dot(m[:4], q))
+        assert np.abs(m[:4] * sgn - q).max() < 1e-12 and np.abs(m[4:] - t).max() < 1e-11
+
+
 def test_optimizer_plugin_resident_graph_update_path(tmp_path, oracle):
     """The plugin keeps the graph on the device between optimize() calls (gh_ba_graph_*): a first call on the same
     topology with other values, then the checked call through the update path, must equal the oracle / the one-shot path."""
