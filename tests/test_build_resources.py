@@ -30,6 +30,12 @@ BUDGET = {
     "syrk_mfma8_kernel": (128, 64),
     "lin_kernel": (192, 0),
     "schur_blocks_kernel": (256, 0),
+    # band solver (chol_cr.hip): the factor kernel is a 512-thread workgroup (256 registers per wave: its tiles are loaded in
+    # two stages for exactly that), the update kernel must keep two workgroups per CU, nothing may touch scratch
+    "cr_factor_kernel": (256, 0),
+    "cr_update_kernel": (256, 0),
+    "cr_back_kernel": (96, 0),
+    "marginalize_pairs_kernel": (512, 0),   # (not hot: one wave per camera pair, 36 + 60 doubles live; no scratch)
     "bow_words_kernel": (64, 0),
     "pack_results_kernel": (32, 0),
 }
