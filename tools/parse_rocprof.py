@@ -25,7 +25,10 @@ NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "
          "schur_blocks_kernel": "ba_schur_blocks", "schur_reduce_kernel": "ba_schur_reduce",
          "lin_kernel": "ba_lin", "lin_cams_reduce_kernel": "ba_lin_cams_reduce",
          "fwd_step_kernel": "ba_trsv_fwd", "bwd_step_inv_kernel": "ba_trsv_bwd",
-         "potrf_flow_kernel": "ba_potrf_flow", "bwd_chain_kernel": "ba_trsv_bwd (single launch)"}
+         "potrf_flow_kernel": "ba_potrf_flow", "bwd_chain_kernel": "ba_trsv_bwd (single launch)",
+         "cr_factor_kernel": "ba_cr_factor", "cr_panels_kernel": "ba_cr_panels (+ ba_cr_inverse)",
+         "cr_update_kernel": "ba_cr_update (+ ba_cr_backprep)", "cr_back_kernel": "ba_cr_back",
+         "schur_blocks_init_kernel": "ba_schur_blocks (+ seed of S)"}
 
 
 def short(name):
