@@ -575,8 +575,13 @@ __device__ __forceinline__ void schur_blocks_block(const Problem& P, const Schur
   for (int t = 0; t < 36; ++t) acc[t] = 0;
 #pragma unroll
   for (int t = 0; t < 6; ++t) racc[t] = 0;
-  for (int e = e_begin + lane; e < e_end; e += 64) {
-    const int k = B.pair_a[e], k2 = B.pair_b[e];
+  // (the pair indices of the NEXT trip are asked for before this trip's blocks: one level less in the chain of dependent
+  //  loads index -> point / W blocks -> point block that bounds this kernel at two waves per SIMD)
+  int e = e_begin + lane;
+  int k = e < e_end ? B.pair_a[e] : -1, k2 = e < e_end ? B.pair_b[e] : -1;
+  for (; k >= 0; e += 64) {
+    const int en = e + 64;
+    const int kn = en < e_end ? B.pair_a[en] : -1, k2n = en < e_end ? B.pair_b[en] : -1;
     const int p = P.opt[k];
     double Wi[18], WH[18], Wj[18];
     load_W(Wbuf, k, Wi);
@@ -592,6 +597,8 @@ __device__ __forceinline__ void schur_blocks_block(const Problem& P, const Schur
 #pragma unroll
       for (int b = 0; b < 6; ++b)
         acc[6 * a + b] += WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
+    k = kn;
+    k2 = k2n;
   }
   // Reduce-scatter butterfly over the wave: at every step a lane keeps one half of its values and trades the other half
   // with its partner, so the 42 sums cost 21 + 11 + 6 + 3 + 2 + 1 = 44 exchanges instead of 42 x 6, and every lane ends up
