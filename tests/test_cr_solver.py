@@ -227,3 +227,33 @@ def test_ctx_trim_regrows(ctx):
     ctx.trim()
     xb, _ = ba.band_solve(ctx, S, b, 60)
     assert np.array_equal(xa, xb)
+
+
+@pytest.mark.gpu
+def test_ba_band_solver_with_masked_dofs_fixed_points_and_information(ctx):
+    """The band path sees the same S as the dense one whatever the graph carries: fixed and partly fixed cameras inside the
+    trajectory, fixed points, per-observation information matrices."""
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(200, 10000, n_obs_per_point=6, seed=11)
+    rng = np.random.default_rng(11)
+    dof = np.array(g["cam_dof"], dtype=np.int32).copy()
+    dof[50] = 0          # fixed in the middle of the band
+    dof[51] = 7          # translation only
+    dof[120] = 56        # rotation only
+    g["cam_dof"] = dof
+    pf = np.ones(len(g["point_xyz"]), np.uint8)
+    pf[rng.choice(len(pf), 300, replace=False)] = 0
+    g["point_free"] = pf
+    M = rng.standard_normal((len(g["obs_cam"]), 2, 2)) * 0.2
+    g["obs_info"] = np.ascontiguousarray((M @ M.transpose(0, 2, 1) + np.eye(2)).reshape(-1, 4))
+    pd, xd, sd, used_d = _solve_with(ctx, g, "dense", iters=25)
+    pb, xb, sb, used_b = _solve_with(ctx, g, "band", iters=25)
+    assert used_d[0] == "dense" and used_b[0] == "band"
+    assert sd.iterations == sb.iterations
+    n = sd.trace_len
+    assert list(sd.trace_accepted[:n]) == list(sb.trace_accepted[:n])
+    cd, cb = np.array(sd.trace_cost[:n]), np.array(sb.trace_cost[:n])
+    assert np.abs(cd - cb).max() <= 1e-9 * np.abs(cd).max()
+    assert np.abs(pd - pb).max() <= 1e-8 and np.abs(xd - xb).max() <= 1e-8
+    assert np.array_equal(pb[50], np.asarray(g["cam_pose"])[50])            # the fixed camera did not move
+    assert np.array_equal(xb[pf == 0], np.asarray(g["point_xyz"])[pf == 0])
