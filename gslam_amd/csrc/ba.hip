@@ -934,9 +934,14 @@ __global__ __launch_bounds__(256) void backsub_update_kernel(Problem P, const do
                                                              const double* __restrict__ dc, double* __restrict__ dp,
                                                              const double* __restrict__ Wbuf,
                                                              double* __restrict__ poses_new, double* __restrict__ pts_new,
-                                                             int* __restrict__ bad, unsigned long long* __restrict__ gmax) {
+                                                             int* __restrict__ bad, unsigned long long* __restrict__ gmax,
+                                                             unsigned long long* __restrict__ keep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {
+    if (keep) {  // (what the iteration's publication sends to the host: see reduce_publish_kernel)
+      keep[0] = *gmax;
+      keep[1] = (unsigned long long)(unsigned)*bad;
+    }
     *bad = 0;
     *gmax = 0ull;
   }
@@ -1046,6 +1051,47 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
   if (threadIdx.x == 0) {
     out[0] = 0.5 * sc[0];
     out[1] = sm[0];
+  }
+}
+
+// The same reduction, and everything the host decides an LM iteration on -- candidate cost, model decrease, gradient
+// maximum, damping and factorisation flags -- written STRAIGHT into pinned host memory, the stamp last (system-scope
+// release): the host polls the stamp instead of waiting for four small device-to-host copies and the stream (each copy is
+// a launch of its own on the stream: ~6 us apiece, and the stream may then go on with the next linearisation at once).
+struct HostVerdict {
+  double cost, model;
+  unsigned long long gmax_bits;
+  int info, bad;
+  int32_t pair_counts[4];
+  volatile unsigned stamp;
+};
+__global__ __launch_bounds__(256) void reduce_publish_kernel(const double* __restrict__ partial, int nblocks,
+                                                             const unsigned long long* __restrict__ keep,
+                                                             const int* __restrict__ info, HostVerdict* host, unsigned stamp) {
+  __shared__ double sc[256], sm[256];
+  double c = 0, m = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    c += partial[2 * i];
+    m += partial[2 * i + 1];
+  }
+  sc[threadIdx.x] = c;
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (threadIdx.x < off) {
+      sc[threadIdx.x] += sc[threadIdx.x + off];
+      sm[threadIdx.x] += sm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    host->cost = 0.5 * sc[0];
+    host->model = sm[0];
+    host->gmax_bits = keep[0];
+    host->bad = (int)keep[1];
+    host->info = *info;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<unsigned*>(&host->stamp), stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1469,6 +1515,9 @@ struct BaSession {
   double *d_Hcc = nullptr, *d_gc = nullptr, *d_Hpp = nullptr, *d_gp = nullptr, *d_Hpi = nullptr, *d_S = nullptr, *d_dc = nullptr,
          *d_dp = nullptr, *d_partial = nullptr, *d_out = nullptr, *d_work = nullptr, *d_dinv = nullptr, *d_W = nullptr,
          *d_cpart = nullptr, *d_spart = nullptr, *d_xwork = nullptr, *d_xh = nullptr;
+  // second set of the linearisation's outputs: the candidate state is linearised speculatively while the host decides
+  double *d_W2 = nullptr, *d_Hpp2 = nullptr, *d_gp2 = nullptr, *d_cpart2 = nullptr;
+  unsigned long long* d_keep = nullptr;  // {gradient maximum, damping flag} of the iteration, saved by backsub_update before it clears them
   unsigned long long* d_gmax = nullptr;
   int *d_bad = nullptr, *d_info = nullptr;
   unsigned* d_flow = nullptr;
@@ -1525,12 +1574,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
   // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the middle
   // of the launch chain, which left the GPU idle while the rest of the iteration was being enqueued.
-  struct Readback {
-    double cost, model;
-    unsigned long long gmax_bits;
-    int info, bad;
-    int32_t pair_counts[4];  // device-built pair lists: pairs, blocks, segments, (unused)
-  };
+  typedef HostVerdict Readback;  // cost, model, gmax_bits, info, bad, pair_counts[4] (device-built pair lists: pairs, blocks, segments), stamp
   // The caller's arrays (8.9 MB at C4, pageable: 0.85-1.2 ms of staged copies when the driver does it) go up WHILE the host
   // builds its index lists -- when the arena of an earlier solve is there to take them (a first solve, or one that has to
   // grow the arena, uploads after the lists as before).  With enough pool threads the staging is ours: the arrays lie back
@@ -1565,6 +1609,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   double *&d_Hcc = S.d_Hcc, *&d_gc = S.d_gc, *&d_Hpp = S.d_Hpp, *&d_gp = S.d_gp, *&d_Hpi = S.d_Hpi, *&d_S = S.d_S, *&d_dc = S.d_dc,
          *&d_dp = S.d_dp, *&d_partial = S.d_partial, *&d_out = S.d_out, *&d_work = S.d_work, *&d_dinv = S.d_dinv, *&d_W = S.d_W,
          *&d_cpart = S.d_cpart, *&d_spart = S.d_spart, *&d_xwork = S.d_xwork, *&d_xh = S.d_xh;
+  double *&d_W2 = S.d_W2, *&d_Hpp2 = S.d_Hpp2, *&d_gp2 = S.d_gp2, *&d_cpart2 = S.d_cpart2;
   unsigned long long*& d_gmax = S.d_gmax;
   int *&d_bad = S.d_bad, *&d_info = S.d_info;
   unsigned*& d_flow = S.d_flow;
@@ -1821,6 +1866,11 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
               6 * span + 5, n, cr_T ? "band solver (block cyclic reduction)" : "dense factorisation");
   }
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
+  GH_TRY(db.alloc(&d_cpart2, (size_t)nchunks * 27));
+  GH_TRY(db.alloc(&d_W2, (size_t)no * 18));
+  GH_TRY(db.alloc(&d_Hpp2, (size_t)np * 9));
+  GH_TRY(db.alloc(&d_gp2, (size_t)np * 3));
+  GH_TRY(db.alloc(&S.d_keep, 2));
   d_spart = nullptr;
   if (!device_pairs) GH_TRY(db.alloc(&d_spart, (size_t)nsegs * 42));
   GH_TRY(db.alloc(&d_partial, (size_t)eval_blocks * 2));
@@ -1915,23 +1965,39 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   double radius = opt.initial_radius, decrease = 2.0;
   bool need_lin = true;
   int term = 0, it = 0;
+  // Speculative linearisation: behind the candidate cost's read-back the stream goes on to linearise the CANDIDATE state
+  // into the second buffer set while the host waits for that cost (an event, not the stream) and decides -- the ~30 us of
+  // host turnaround per iteration are then GPU work the next iteration needs anyway if the step is accepted (most are; a
+  // rejected step's speculation is dropped).  Same kernel, same inputs: the LM trace is bit-identical.
+  const bool speculate = [] { const char* e = getenv("GSLAM_HIP_BA_SPECULATE"); return !(e && e[0] == '0'); }() && (np > 0 || nchunks > 0);
+  bool spec_ready = false;  // the second buffer set holds the linearisation of what is now the current state
+  unsigned stamp = 0;
+  rb->stamp = 0;  // (nothing is in flight: the first cost above ended with a stream synchronisation)
   const double t_loop = now_ms();
   for (it = 0; it < opt.max_iterations; ++it) {
     if (need_lin) {  // (d_gmax and d_bad are zero here: cleared before the loop and by every backsub_update launch)
-      if (np > 0 || nchunks > 0)
+      if (spec_ready) {
+        std::swap(d_W, d_W2);
+        std::swap(d_Hpp, d_Hpp2);
+        std::swap(d_gp, d_gp2);
+        std::swap(d_cpart, d_cpart2);
+      } else if (np > 0 || nchunks > 0) {
         GH_LAUNCH(ctx, "ba_lin", lin_kernel, dim3(nchunks + gh_div_up(np, 256)), dim3(256), 0, P, CC, d_cpart, d_W, d_Hpp, d_gp,
                   d_gmax);
+      }
       // (the camera-side reduction shares its launch with the point-side damping below)
     }
+    spec_ready = false;
     const bool fresh_lin = need_lin;
     need_lin = false;
+    const bool publish = speculate && it + 1 < opt.max_iterations;  // this iteration's verdict goes to the host by reduce_publish_kernel
     if (fresh_lin) {
       const int nrb = gh_div_up(nc, 8);
       GH_LAUNCH(ctx, "ba_damp_points", lin_reduce_damp_kernel, dim3(nrb + gh_div_up(np, 256)), dim3(256), 0, nc, CC,
                 (const double*)d_cpart, d_Hcc, d_gc, d_gmax, nrb, np, (const double*)d_Hpp, radius, d_Hpi, d_bad);
       // the gradient test is evaluated at the iteration's single synchronisation point below; if it fires, the step
       // computed meanwhile is simply dropped (same decisions as testing here, one host round trip less)
-      GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      if (!publish) GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     } else if (np > 0) {
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
                 d_Hpi, d_bad);
@@ -2000,11 +2066,42 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
     GH_TRY(gh_potrs_bwd_dev_impl(ctx, d_S, n, lda, d_dc, d_work, d_dinv, d_S + n, lda, d_xh, d_info, solve_state_ready));
     }
-    GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (!publish) {
+      GH_HIP(ctx, hipMemcpyAsync(&rb->info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
     GH_LAUNCH(ctx, "ba_backsub", backsub_update_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, P, d_Hpi,
-              d_gp, d_dc, d_dp, (const double*)d_W, d_poses_new, d_pts_new, d_bad, d_gmax);
-    GH_TRY(eval_cost(d_poses_new, d_pts_new, 1));  // the iteration's one synchronisation
+              d_gp, d_dc, d_dp, (const double*)d_W, d_poses_new, d_pts_new, d_bad, d_gmax, publish ? S.d_keep : nullptr);
+    bool spec_launched = false;
+    if (publish) {
+      const unsigned want = ++stamp;
+      GH_LAUNCH(ctx, "ba_eval", eval_kernel, dim3(eval_blocks), dim3(256), 0, P, (const double*)d_poses_new,
+                (const double*)d_pts_new, d_dc, d_dp, 1, d_partial);
+      GH_LAUNCH(ctx, "ba_reduce", reduce_publish_kernel, dim3(1), dim3(256), 0, (const double*)d_partial, eval_blocks,
+                (const unsigned long long*)S.d_keep, (const int*)d_info, rb, want);
+      Problem Pn = P;
+      Pn.poses = d_poses_new;
+      Pn.pts = d_pts_new;
+      GH_LAUNCH(ctx, "ba_lin", lin_kernel, dim3(nchunks + gh_div_up(np, 256)), dim3(256), 0, Pn, CC, d_cpart2, d_W2, d_Hpp2,
+                d_gp2, d_gmax);  // (d_gmax was cleared by backsub_update above: exactly what a linearisation at the top would find)
+      spec_launched = true;
+      // the iteration's one synchronisation: the verdict's stamp in pinned memory (bounded: a fault in a kernel must not hang us)
+      {
+        const double t_spin = now_ms();
+        unsigned spins = 0;
+        while (rb->stamp != want) {
+          if ((++spins & 0xFFFu) == 0u && now_ms() - t_spin > 10000.0) break;
+          __builtin_ia32_pause();
+        }
+        if (rb->stamp != want) {
+          GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          if (rb->stamp != want) return gh_set_error(ctx, GH_ERR_HIP, "gh_ba_solve: the iteration's verdict never reached the host");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+    } else {
+      GH_TRY(eval_cost(d_poses_new, d_pts_new, 1));  // the iteration's one synchronisation
+    }
     if (flow_lock.owns_lock()) flow_lock.unlock();
     h2[0] = rb->cost;
     h2[1] = rb->model;
@@ -2025,6 +2122,9 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       d_flow = nullptr;
       d_xh = nullptr;
       if (fresh_lin) need_lin = true;  // (cheap, and keeps the gradient read-back of this iteration in place)
+      if (spec_launched) {  // the speculation wrote the gradient maximum the repeated linearisation accumulates into
+        GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, sizeof(unsigned long long), ctx->stream));
+      }
       --it;
       continue;
     }
@@ -2058,6 +2158,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       decrease = 2.0;
       sum->accepted++;
       need_lin = true;
+      spec_ready = spec_launched;
       const double prev = cost;
       cost = new_cost;
       if (fabs(dcost) <= opt.function_tolerance * prev) {

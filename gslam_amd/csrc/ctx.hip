@@ -50,6 +50,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   if (ctx->ba_arena) hipFree(ctx->ba_arena);
   if (ctx->pg_arena) hipFree(ctx->pg_arena);
   for (auto e : ctx->cr_events) hipEventDestroy(e);
+  if (ctx->ba_event) hipEventDestroy(ctx->ba_event);
   if (ctx->cr_side) hipStreamDestroy(ctx->cr_side);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
