@@ -190,7 +190,8 @@ gh_status gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
 gh_status gh_readback_block(gh_ctx* ctx, size_t bytes, void** out) {
   if (bytes > 4096) return gh_set_error(ctx, GH_ERR_ARG, "gh_readback_block: %zu bytes", bytes);
   if (!ctx->rb_pinned) {
-    hipError_t e = hipHostMalloc(&ctx->rb_pinned, 4096, hipHostMallocDefault);
+    // coherent (fine-grained) by request: gh_ba_solve polls this block while the kernel that writes it is still in the stream
+    hipError_t e = hipHostMalloc(&ctx->rb_pinned, 4096, hipHostMallocCoherent);
     if (e != hipSuccess) {
       ctx->rb_pinned = nullptr;
       return gh_set_error(ctx, GH_ERR_NOMEM, "hipHostMalloc(4096): %s", hipGetErrorString(e));
