@@ -762,11 +762,23 @@ def main():
         cr_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CR)
         launches = sum(v["launches"] for v in bprof.values())
         used, tiles, span = ctx.last_ba_solver()
+        band_flops = None
+        if used == "band":
+            # executed flops of the block cyclic reduction, per solve: per eliminated superblock (two neighbours) m^3 / 3 (potrf)
+            # + 2 m^3 (the two panels) + 2 m^3 + 2 m^3 (two rank-m updates, one fill block) + off the critical path ~2.4 m^3
+            # (L^-T, the two G products); all f64 MFMA work except the potf2 pivots
+            m_sb = 64 * tiles
+            band_flops = (-(-n // m_sb) - 1) * (1.0 / 3 + 6 + 2.4) * m_sb ** 3
         return {"workload": f"{name}: {cams} cams, {points} pts, {len(g['obs_cam'])} obs, Huber LM",
                 "graph_census": census,
                 "linear_solver": {"used": used, "camera_span": span, "half_bandwidth": 6 * span + 5,
                                   "superblock_columns": 64 * tiles if tiles else None,
                                   "solver_kernel_ms_per_iteration": round((cr_ms if used == "band" else chol_ms) / max(1, sp.iterations), 4),
+                                  "band_executed_GFLOP_per_solve": round(band_flops / 1e9, 3) if band_flops else None,
+                                  "band_achieved_TFLOPs": round(band_flops * sp.iterations / (cr_ms * 1e-3) / 1e12, 3) if band_flops and cr_ms else None,
+                                  "dense_GFLOP_per_solve": round((n ** 3 / 3.0 + 2.0 * n * n) / 1e9, 3),
+                                  "note": "the band solver wins by doing ~1/10 (C4) to ~1/25000 (C5) of the dense factorisation's flops, "
+                                          "not by running them faster: it is bound by launch / pivot-chain latency, not by the f64 MFMA rate",
                                   "what": "band: block cyclic reduction over superblocks of the reduced camera system "
                                           "(gslam_amd/csrc/chol_cr.hip); dense: the MFMA f64 factorisation (chol.hip)"},
                 "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
