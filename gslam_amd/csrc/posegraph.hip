@@ -1237,7 +1237,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   double cost = host4[0] + host4[2];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;
-  bool need_lin = true;
+  bool need_lin = true, fresh_gmax = false;
   int term = 0, it = 0;
   for (it = 0; it < opt.max_iterations; ++it) {
     if (need_lin) {
@@ -1260,14 +1260,10 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_LAUNCH(ctx, "gr_gmax", gr_gmax_kernel, dim3(gh_div_up(n + 3 * nlm, 256)), dim3(256), 0, (const double*)d_g, n,
                 (const double*)d_gp, 3 * nlm, d_gmax);
+      // (read behind the solve below, which synchronises anyway: if the gradient test fires, the step computed meanwhile is
+      //  simply dropped -- same decisions, one host round trip less per iteration)
       GH_HIP(ctx, hipMemcpyAsync(&rb->gmax_bits, d_gmax, 8, hipMemcpyDeviceToHost, ctx->stream));
-      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      double gmax;
-      memcpy(&gmax, &rb->gmax_bits, 8);
-      if (gmax <= opt.gradient_tolerance) {
-        term = 2;
-        break;
-      }
+      fresh_gmax = true;
       need_lin = false;
     }
     if (!sparse)
@@ -1291,6 +1287,15 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       info = rb->info;
     }
     sum->solve_ms_total += now_ms_pg() - t_s0;
+    if (fresh_gmax) {  // (both solve paths end with a stream synchronisation: the gradient maximum is on the host)
+      fresh_gmax = false;
+      double gmax;
+      memcpy(&gmax, &rb->gmax_bits, 8);
+      if (gmax <= opt.gradient_tolerance) {
+        term = 2;
+        break;
+      }
+    }
     const bool okf = info == 0;
     double new_cost = cost, model = 0, rho = -1;
     if (okf) {
