@@ -158,3 +158,30 @@ def make_landmark_graph(n_frames=8, n_xyz=30, n_idp=30, kind="se3", seed=1, nois
     if n_frames > 1 and not pose_edges:
         dof[1] &= ~1  # ... and one translation component of the second (the scale of a monocular reconstruction)
     return truth, start, dof, problem
+
+
+def opencv_project(cam, x, y):
+    """GSLAM's OpenCV camera model on normalised coordinates (GSLAM/core/Camera.h:386-407; pinhole = zero distortion):
+    cam = (fx, fy, cx, cy, k1, k2, p1, p2, k3) -> pixel (U, V).  numpy restatement used by the generators and tests."""
+    fx, fy, cx, cy, k1, k2, p1, p2, k3 = cam
+    r2 = x * x + y * y
+    rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    xd = x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+    yd = y * rad + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+    return cx + fx * xd, cy + fy * yd
+
+
+def with_camera(problem, cam_true, cam_start, free_mask, pixel_noise=0.0, seed=0):
+    """BundleGraph::camera + cameraDOF (GSLAM/core/Optimizer.h:86-100,169-171): the normalised observations of a
+    make_landmark_graph problem become PIXELS of `cam_true`; the solve starts from `cam_start` and estimates the parameters
+    whose bit is set in free_mask (bit i = parameter i of fx fy cx cy k1 k2 p1 p2 k3).  Information blocks (if any) are kept
+    as they are (now in pixel units)."""
+    kind, point, frame, xy, info = problem["obs"]
+    U, V = opencv_project(np.asarray(cam_true, float), xy[:, 0], xy[:, 1])
+    px = np.stack([U, V], axis=1)
+    if pixel_noise > 0:
+        px = px + np.random.default_rng(seed).normal(size=px.shape) * pixel_noise
+    out = dict(problem)
+    out["obs"] = (kind, point, frame, px, info)
+    out["intrinsics"] = (np.asarray(cam_start, float).copy(), int(free_mask))
+    return out

@@ -38,6 +38,18 @@
  *                    dY/dX = R_j^T;   dY/drho = R_j^T (t_h - t_j)
  *                    dY/dv_h = rho s_h R_j^T R_h,  dY/dw_h = -s_h R_j^T R_h [a]x,  dY/dsigma_h = s_h R_j^T R_h a
  *                  pose-graph edges: central differences as in pg_oracle.c
+ *   intrinsics     BundleGraph::camera + cameraDOF (Optimizer.h:86-100,169-171: "Invalid camera indicates idea camera"):
+ *                  with a camera c = (fx, fy, cx, cy, k1, k2, p1, p2, k3) the measurements are PIXELS and the residual is
+ *                  r = Project_c(Y) - m with GSLAM's OpenCV model (GSLAM/core/Camera.h:386-407; the pinhole model :213-227
+ *                  is k = p = 0):  x = Y_x / Y_z, y = Y_y / Y_z, r2 = x^2 + y^2, rad = 1 + k1 r2 + k2 r2^2 + k3 r2^3,
+ *                    X1 = x rad + 2 p1 x y + p2 (r2 + 2 x^2),  Y1 = y rad + 2 p2 x y + p1 (r2 + 2 y^2),
+ *                    U = cx + fx X1,  V = cy + fy Y1.
+ *                  The parameters whose bit is set in intrinsics_free (bit i = parameter i of c; CameraEstimationDOF maps
+ *                  FOCAL -> fx fy, CENTER -> cx cy, K1 K2 P1 P2 K3) are unknowns of the SAME Levenberg-Marquardt problem:
+ *                  additive update, analytic Jacobian d(U, V)/dc, same damping rule, a 9-row block behind the keyframe
+ *                  unknowns of the reduced system (the landmarks' Schur complement couples it to every keyframe).  The
+ *                  projection Jacobian becomes P <- [d(U, V)/d(x, y)] P; Huber threshold and information are in pixels.
+ *                  Pinhole projection only.
  *   solver         Levenberg-Marquardt, trust-region policy of ba_oracle.c / pg_oracle.c (damping clamp(H_kk, 1e-6, 1e32)
  *                  / radius on EVERY diagonal entry, keyframes and landmarks), landmarks eliminated by a Schur
  *                  complement (3x3 / 1x1 blocks), dense reduced system over the 7 n_frames keyframe unknowns, model
@@ -91,6 +103,8 @@ typedef struct {
   double huber;
   int32_t projection;         /* 0 pinhole (obs_xy), 1 sphere (obs_bearing) */
   const double* obs_bearing;  /* n_obs x 3 unit vectors, sphere only */
+  double* intrinsics;         /* 9: fx fy cx cy k1 k2 p1 p2 k3, in / out; NULL = ideal camera (obs_xy on the z = 1 plane) */
+  int32_t intrinsics_free;    /* bit i: parameter i is estimated */
 } graph_problem;
 
 /* pg_oracle.c / ba_oracle.c */
@@ -139,10 +153,53 @@ static void tangent_basis(const double* b, double* e1, double* e2) {
   e2[2] = b[0] * e1[1] - b[1] * e1[0];
 }
 
+/* pixel coordinates of the normalised point (x, y) under c = fx fy cx cy k1 k2 p1 p2 k3 (GSLAM/core/Camera.h:396-406),
+ * A = d(U, V)/d(x, y) row-major 2 x 2, Jc = d(U, V)/dc row-major 2 x 9 */
+void oracle_cam_project(const double* c, double x, double y, double* UV, double* A, double* Jc) {
+  const double fx = c[0], fy = c[1], k1 = c[4], k2 = c[5], p1 = c[6], p2 = c[7], k3 = c[8];
+  const double x2 = x * x, y2 = y * y, r2 = x2 + y2, r4 = r2 * r2, r6 = r2 * r4, xy2 = x * y * 2.0;
+  const double rad = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+  const double X1 = x * rad + xy2 * p1 + p2 * (r2 + 2.0 * x2);
+  const double Y1 = y * rad + xy2 * p2 + p1 * (r2 + 2.0 * y2);
+  UV[0] = c[2] + fx * X1;
+  UV[1] = c[3] + fy * Y1;
+  if (A) {
+    const double radp = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4; /* d rad / d r2 */
+    A[0] = fx * (rad + 2.0 * x2 * radp + 2.0 * p1 * y + 6.0 * p2 * x);
+    A[1] = fx * (2.0 * x * y * radp + 2.0 * p1 * x + 2.0 * p2 * y);
+    A[2] = fy * (2.0 * x * y * radp + 2.0 * p2 * y + 2.0 * p1 * x);
+    A[3] = fy * (rad + 2.0 * y2 * radp + 2.0 * p2 * x + 6.0 * p1 * y);
+  }
+  if (Jc) {
+    memset(Jc, 0, 18 * 8);
+    Jc[0] = X1;            Jc[9 + 1] = Y1;
+    Jc[2] = 1.0;           Jc[9 + 3] = 1.0;
+    Jc[4] = fx * x * r2;   Jc[9 + 4] = fy * y * r2;
+    Jc[5] = fx * x * r4;   Jc[9 + 5] = fy * y * r4;
+    Jc[6] = fx * xy2;      Jc[9 + 6] = fy * (r2 + 2.0 * y2);
+    Jc[7] = fx * (r2 + 2.0 * x2); Jc[9 + 7] = fy * xy2;
+    Jc[8] = fx * x * r6;   Jc[9 + 8] = fy * y * r6;
+  }
+}
+
+int oracle_graph_obs_cam(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, int same_host, const double* lm,
+                         int lm_free, const double* anchor, const double* m, const double* info, double huber, double* r,
+                         double* wgt, double* s_out, double* Jj, double* Jh, double* Jp, int projection, const double* cam,
+                         int cam_free, double* Jc);
+
 /* projection 0: m = (m_x, m_y) on the z = 1 plane; 1: m = unit bearing (3) */
 int oracle_graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, int same_host, const double* lm,
                      int lm_free, const double* anchor, const double* m, const double* info, double huber, double* r,
                      double* wgt, double* s_out, double* Jj, double* Jh, double* Jp, int projection) {
+  return oracle_graph_obs_cam(kind, Sj, dof_j, Sh, dof_h, same_host, lm, lm_free, anchor, m, info, huber, r, wgt, s_out, Jj, Jh, Jp,
+                              projection, NULL, 0, NULL);
+}
+
+/* cam != NULL (pinhole projection only): m in pixels, Jc = dr/dc (2 x 9, columns of fixed parameters zero) */
+int oracle_graph_obs_cam(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, int same_host, const double* lm,
+                         int lm_free, const double* anchor, const double* m, const double* info, double huber, double* r,
+                         double* wgt, double* s_out, double* Jj, double* Jh, double* Jp, int projection, const double* cam,
+                         int cam_free, double* Jc) {
   double Z[3], Y[3], Ra[3] = {0, 0, 0}, dth[3] = {0, 0, 0};
   if (kind == 0) {
     for (int e = 0; e < 3; ++e) Z[e] = lm[e] - Sj[4 + e];
@@ -158,9 +215,24 @@ int oracle_graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, in
   if (projection == 0) {
     if (!(Y[2] > G_MIN_DEPTH)) return 0;
     const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
-    r[0] = u - m[0];
-    r[1] = v - m[1];
     P[0] = iz; P[1] = 0; P[2] = -u * iz; P[3] = 0; P[4] = iz; P[5] = -v * iz;
+    if (cam) {
+      double UV[2], A[4], Jcf[18];
+      oracle_cam_project(cam, u, v, UV, A, Jcf);
+      r[0] = UV[0] - m[0];
+      r[1] = UV[1] - m[1];
+      const double P0[6] = {P[0], P[1], P[2], P[3], P[4], P[5]};
+      for (int e = 0; e < 3; ++e) {
+        P[e] = A[0] * P0[e] + A[1] * P0[3 + e];
+        P[3 + e] = A[2] * P0[e] + A[3] * P0[3 + e];
+      }
+      if (Jc)
+        for (int a = 0; a < 2; ++a)
+          for (int k = 0; k < 9; ++k) Jc[9 * a + k] = ((cam_free >> k) & 1) ? Jcf[9 * a + k] : 0.0;
+    } else {
+      r[0] = u - m[0];
+      r[1] = v - m[1];
+    }
   } else {
     const double nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
     if (!(nY > G_MIN_DEPTH)) return 0;
@@ -252,22 +324,39 @@ static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v >
 typedef struct {
   double r[2], w, L[4];
   int valid, fj, fh, lm, dp; /* dp = landmark dimension: 3 / 1 / 0 (fixed) */
-  double Jj[14], Jh[14], Jp[6];
+  double Jj[14], Jh[14], Jp[6], Jc[18];
 } obs_rec;
 
-static int obs_eval(const graph_problem* g, int k, const double* frames, const double* xyz, const double* rho, obs_rec* o,
-                    int with_j, double* s_out) {
+/* the (at most three) blocks of the reduced system an observation touches: observing keyframe, host keyframe (inverse-depth
+ * point seen from another keyframe), intrinsics; J row-major 2 x width */
+typedef struct {
+  int ns, base[3], width[3];
+  const double* J[3];
+} obs_slots;
+static obs_slots slots_of(const obs_rec* o, int nf, int with_cam) {
+  obs_slots t;
+  t.ns = 0;
+  t.base[t.ns] = 7 * o->fj; t.width[t.ns] = 7; t.J[t.ns] = o->Jj; t.ns++;
+  if (o->fh >= 0) { t.base[t.ns] = 7 * o->fh; t.width[t.ns] = 7; t.J[t.ns] = o->Jh; t.ns++; }
+  if (with_cam) { t.base[t.ns] = 7 * nf; t.width[t.ns] = 9; t.J[t.ns] = o->Jc; t.ns++; }
+  return t;
+}
+
+static int obs_eval(const graph_problem* g, int k, const double* frames, const double* xyz, const double* rho, const double* cam,
+                    obs_rec* o, int with_j, double* s_out) {
   const int kind = g->obs_kind[k], p = g->obs_point[k], j = g->obs_frame[k];
   const int h = kind == 1 ? g->idp_host[p] : j;
   const double* info = g->obs_info ? g->obs_info + 4 * (size_t)k : NULL;
   const int lm_free = kind == 0 ? (g->xyz_free ? g->xyz_free[p] : 1) : (g->idp_free ? g->idp_free[p] : 1);
   const double* lm = kind == 0 ? xyz + 3 * (size_t)p : rho + p;
   double w = 1, s = 0, r[2] = {0, 0};
-  double Jj[14], Jh[14], Jp[6];
-  const int ok = oracle_graph_obs(kind, frames + 8 * (size_t)j, g->dof[j], frames + 8 * (size_t)h, g->dof[h], h == j, lm, lm_free,
+  double Jj[14], Jh[14], Jp[6], Jc[18];
+  memset(Jc, 0, sizeof(Jc));
+  const int ok = oracle_graph_obs_cam(kind, frames + 8 * (size_t)j, g->dof[j], frames + 8 * (size_t)h, g->dof[h], h == j, lm, lm_free,
                                   kind == 1 ? g->idp_anchor + 3 * (size_t)p : NULL,
                                   g->projection ? g->obs_bearing + 3 * (size_t)k : g->obs_xy + 2 * (size_t)k, info, g->huber, r,
-                                  &w, &s, with_j ? Jj : NULL, with_j ? Jh : NULL, with_j ? Jp : NULL, g->projection);
+                                  &w, &s, with_j ? Jj : NULL, with_j ? Jh : NULL, with_j ? Jp : NULL, g->projection, cam,
+                                  g->intrinsics_free, with_j ? Jc : NULL);
   if (s_out) *s_out = s;
   if (!o) return ok;
   memset(o, 0, sizeof(*o));
@@ -284,6 +373,7 @@ static int obs_eval(const graph_problem* g, int k, const double* frames, const d
     memcpy(o->Jj, Jj, sizeof(Jj));
     memcpy(o->Jh, Jh, sizeof(Jh));
     memcpy(o->Jp, Jp, sizeof(Jp));
+    memcpy(o->Jc, Jc, sizeof(Jc));
   }
   return 1;
 }
@@ -310,7 +400,7 @@ double oracle_graph_cost(const graph_problem* g) {
   double c = 0;
   for (int k = 0; k < g->n_obs; ++k) {
     double s;
-    if (obs_eval(g, k, g->frames, g->xyz, g->idp_rho, NULL, 0, &s)) c += rho_huber(s, g->huber);
+    if (obs_eval(g, k, g->frames, g->xyz, g->idp_rho, g->intrinsics, NULL, 0, &s)) c += rho_huber(s, g->huber);
   }
   return 0.5 * c + pose_edge_cost(g, g->frames);
 }
@@ -347,7 +437,10 @@ static void inv_sym(const double* H, int dp, double* Hi) {
 }
 
 int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum, int threads) {
-  const int nf = g->n_frames, n = 7 * nf, nlm = g->n_xyz + g->n_idp, no = g->n_obs, ne = g->n_edges;
+  const int with_cam = g->intrinsics != NULL;
+  if (with_cam && g->projection != 0) return 2;
+  const int nf = g->n_frames, n = 7 * nf + (with_cam ? 9 : 0), nlm = g->n_xyz + g->n_idp, no = g->n_obs, ne = g->n_edges;
+  double cam_new[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double* H = (double*)calloc((size_t)n * n, 8);   /* keyframe block of the normal equations, column-major */
   double* Hd = (double*)malloc((size_t)n * n * 8);
   double* gf = (double*)malloc((size_t)n * 8);
@@ -444,19 +537,18 @@ int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum,
       /* observations */
       for (int k = 0; k < no; ++k) {
         obs_rec* o = rec + k;
-        if (!obs_eval(g, k, g->frames, g->xyz, g->idp_rho, o, 1, NULL)) continue;
+        if (!obs_eval(g, k, g->frames, g->xyz, g->idp_rho, g->intrinsics, o, 1, NULL)) continue;
         const double Lr[2] = {o->L[0] * o->r[0] + o->L[1] * o->r[1], o->L[2] * o->r[0] + o->L[3] * o->r[1]};
-        const double* Jf[2] = {o->Jj, o->Jh};
-        const int ff[2] = {o->fj, o->fh};
-        for (int x = 0; x < 2; ++x) {
-          if (ff[x] < 0) continue;
-          for (int p = 0; p < 7; ++p) gf[7 * ff[x] + p] += Jf[x][p] * Lr[0] + Jf[x][7 + p] * Lr[1];
-          for (int y = 0; y < 2; ++y) {
-            if (ff[y] < 0) continue;
-            for (int p = 0; p < 7; ++p)
-              for (int q = 0; q < 7; ++q) {
-                const double LJ0 = o->L[0] * Jf[y][q] + o->L[1] * Jf[y][7 + q], LJ1 = o->L[2] * Jf[y][q] + o->L[3] * Jf[y][7 + q];
-                H[(size_t)(7 * ff[y] + q) * n + 7 * ff[x] + p] += Jf[x][p] * LJ0 + Jf[x][7 + p] * LJ1;
+        const obs_slots T = slots_of(o, nf, with_cam);
+        for (int x = 0; x < T.ns; ++x) {
+          const int wx = T.width[x];
+          for (int p = 0; p < wx; ++p) gf[T.base[x] + p] += T.J[x][p] * Lr[0] + T.J[x][wx + p] * Lr[1];
+          for (int y = 0; y < T.ns; ++y) {
+            const int wy = T.width[y];
+            for (int p = 0; p < wx; ++p)
+              for (int q = 0; q < wy; ++q) {
+                const double LJ0 = o->L[0] * T.J[y][q] + o->L[1] * T.J[y][wy + q], LJ1 = o->L[2] * T.J[y][q] + o->L[3] * T.J[y][wy + q];
+                H[(size_t)(T.base[y] + q) * n + T.base[x] + p] += T.J[x][p] * LJ0 + T.J[x][wx + p] * LJ1;
               }
           }
         }
@@ -494,35 +586,33 @@ int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum,
       for (int qa = lstart[p]; qa < lstart[p + 1]; ++qa) {
         const obs_rec* oa = rec + llist[qa];
         if (!oa->valid) continue;
-        const double* Ja[2] = {oa->Jj, oa->Jh};
-        const int fa[2] = {oa->fj, oa->fh};
-        for (int x = 0; x < 2; ++x) {
-          if (fa[x] < 0) continue;
-          double Wa[21], Ua[21];
-          for (int r7 = 0; r7 < 7; ++r7)
+        const obs_slots Ta = slots_of(oa, nf, with_cam);
+        for (int x = 0; x < Ta.ns; ++x) {
+          const int wa = Ta.width[x];
+          double Wa[27], Ua[27];
+          for (int r7 = 0; r7 < wa; ++r7)
             for (int b = 0; b < 3; ++b) {
               const double LJ0 = oa->L[0] * oa->Jp[b] + oa->L[1] * oa->Jp[3 + b], LJ1 = oa->L[2] * oa->Jp[b] + oa->L[3] * oa->Jp[3 + b];
-              Wa[3 * r7 + b] = b < dp ? Ja[x][r7] * LJ0 + Ja[x][7 + r7] * LJ1 : 0.0;
+              Wa[3 * r7 + b] = b < dp ? Ta.J[x][r7] * LJ0 + Ta.J[x][wa + r7] * LJ1 : 0.0;
             }
-          for (int r7 = 0; r7 < 7; ++r7)
+          for (int r7 = 0; r7 < wa; ++r7)
             for (int b = 0; b < 3; ++b) Ua[3 * r7 + b] = Wa[3 * r7] * Hi[b] + Wa[3 * r7 + 1] * Hi[3 + b] + Wa[3 * r7 + 2] * Hi[6 + b];
-          for (int r7 = 0; r7 < 7; ++r7)
-            d[7 * fa[x] + r7] += Ua[3 * r7] * gp[3 * (size_t)p] + Ua[3 * r7 + 1] * gp[3 * (size_t)p + 1] + Ua[3 * r7 + 2] * gp[3 * (size_t)p + 2];
+          for (int r7 = 0; r7 < wa; ++r7)
+            d[Ta.base[x] + r7] += Ua[3 * r7] * gp[3 * (size_t)p] + Ua[3 * r7 + 1] * gp[3 * (size_t)p + 1] + Ua[3 * r7 + 2] * gp[3 * (size_t)p + 2];
           for (int qb = lstart[p]; qb < lstart[p + 1]; ++qb) {
             const obs_rec* ob = rec + llist[qb];
             if (!ob->valid) continue;
-            const double* Jb[2] = {ob->Jj, ob->Jh};
-            const int fb[2] = {ob->fj, ob->fh};
-            for (int y = 0; y < 2; ++y) {
-              if (fb[y] < 0) continue;
-              for (int c7 = 0; c7 < 7; ++c7) {
+            const obs_slots Tb = slots_of(ob, nf, with_cam);
+            for (int y = 0; y < Tb.ns; ++y) {
+              const int wb = Tb.width[y];
+              for (int c7 = 0; c7 < wb; ++c7) {
                 double Wb[3];
                 for (int b = 0; b < 3; ++b) {
                   const double LJ0 = ob->L[0] * ob->Jp[b] + ob->L[1] * ob->Jp[3 + b], LJ1 = ob->L[2] * ob->Jp[b] + ob->L[3] * ob->Jp[3 + b];
-                  Wb[b] = b < dp ? Jb[y][c7] * LJ0 + Jb[y][7 + c7] * LJ1 : 0.0;
+                  Wb[b] = b < dp ? Tb.J[y][c7] * LJ0 + Tb.J[y][wb + c7] * LJ1 : 0.0;
                 }
-                for (int r7 = 0; r7 < 7; ++r7)
-                  Hd[(size_t)(7 * fb[y] + c7) * n + 7 * fa[x] + r7] -= Ua[3 * r7] * Wb[0] + Ua[3 * r7 + 1] * Wb[1] + Ua[3 * r7 + 2] * Wb[2];
+                for (int r7 = 0; r7 < wa; ++r7)
+                  Hd[(size_t)(Tb.base[y] + c7) * n + Ta.base[x] + r7] -= Ua[3 * r7] * Wb[0] + Ua[3 * r7 + 1] * Wb[1] + Ua[3 * r7 + 2] * Wb[2];
               }
             }
           }
@@ -542,14 +632,13 @@ int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum,
           const obs_rec* o = rec + llist[q];
           if (!o->valid) continue;
           if (o->dp > dp) dp = o->dp;
-          const double* Jf[2] = {o->Jj, o->Jh};
-          const int ff[2] = {o->fj, o->fh};
-          for (int x = 0; x < 2; ++x) {
-            if (ff[x] < 0) continue;
+          const obs_slots T = slots_of(o, nf, with_cam);
+          for (int x = 0; x < T.ns; ++x) {
+            const int wx = T.width[x];
             double Jd[2] = {0, 0};
-            for (int k = 0; k < 7; ++k) {
-              Jd[0] += Jf[x][k] * d[7 * ff[x] + k];
-              Jd[1] += Jf[x][7 + k] * d[7 * ff[x] + k];
+            for (int k = 0; k < wx; ++k) {
+              Jd[0] += T.J[x][k] * d[T.base[x] + k];
+              Jd[1] += T.J[x][wx + k] * d[T.base[x] + k];
             }
             const double LJd[2] = {o->L[0] * Jd[0] + o->L[1] * Jd[1], o->L[2] * Jd[0] + o->L[3] * Jd[1]};
             for (int b = 0; b < o->dp; ++b) t[b] += o->Jp[b] * LJd[0] + o->Jp[3 + b] * LJd[1];
@@ -587,6 +676,11 @@ int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum,
             Jd[1] += o->Jh[7 + q] * d[7 * o->fh + q];
           }
         }
+        if (with_cam)
+          for (int q = 0; q < 9; ++q) {
+            Jd[0] += o->Jc[q] * d[7 * nf + q];
+            Jd[1] += o->Jc[9 + q] * d[7 * nf + q];
+          }
         for (int b = 0; b < o->dp; ++b) {
           Jd[0] += o->Jp[b] * dlm[3 * (size_t)o->lm + b];
           Jd[1] += o->Jp[3 + b] * dlm[3 * (size_t)o->lm + b];
@@ -603,10 +697,12 @@ int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum,
       for (int p = 0; p < g->n_xyz; ++p)
         for (int a = 0; a < 3; ++a) xyz_new[3 * (size_t)p + a] = g->xyz[3 * (size_t)p + a] + dlm[3 * (size_t)p + a];
       for (int p = 0; p < g->n_idp; ++p) rho_new[p] = fmax(g->idp_rho[p] + dlm[3 * (size_t)(g->n_xyz + p)], 1e-9);
+      if (with_cam)
+        for (int q = 0; q < 9; ++q) cam_new[q] = g->intrinsics[q] + (((g->intrinsics_free >> q) & 1) ? d[7 * nf + q] : 0.0);
       double c = 0;
       for (int k = 0; k < no; ++k) {
         double s;
-        if (obs_eval(g, k, Snew, xyz_new, rho_new, NULL, 0, &s)) c += rho_huber(s, g->huber);
+        if (obs_eval(g, k, Snew, xyz_new, rho_new, with_cam ? cam_new : NULL, NULL, 0, &s)) c += rho_huber(s, g->huber);
         else if (rec[k].valid) { c = INFINITY; break; }
       }
       new_cost = 0.5 * c + pose_edge_cost(g, Snew);
@@ -625,6 +721,7 @@ int oracle_graph_solve(graph_problem* g, const pg_options* opt, pg_summary* sum,
       memcpy(g->frames, Snew, (size_t)nf * 64);
       if (g->n_xyz) memcpy(g->xyz, xyz_new, (size_t)g->n_xyz * 24);
       if (g->n_idp) memcpy(g->idp_rho, rho_new, (size_t)g->n_idp * 8);
+      if (with_cam) memcpy(g->intrinsics, cam_new, sizeof(cam_new));
       const double t = 2.0 * rho - 1.0;
       radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
       if (radius > 1e16) radius = 1e16;

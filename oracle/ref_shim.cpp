@@ -274,3 +274,19 @@ int ref_undist_run(void* up, const unsigned char* img, int channels, int fast, u
   return 1;
 }
 }
+
+// ---------------------------------------------------------------- Camera::Project (self-calibration, Optimizer.h:169-171)
+// The reference's camera models evaluated on camera-frame points (GSLAM/core/Camera.h:213-227 pinhole, :386-407 OpenCV):
+// pins oracle_cam_project (graph_oracle.c) and the golden vectors tests/golden/camera_reference.npz.
+extern "C" {
+int ref_camera_project(const double* params, int n_params, const double* xyz, int n, double* uv) {
+  GSLAM::Camera cam(std::vector<double>(params, params + n_params));
+  if (!cam.isValid()) return 0;
+  for (int i = 0; i < n; ++i) {
+    const GSLAM::Point2d p = cam.Project(GSLAM::Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    uv[2 * i] = p.x;
+    uv[2 * i + 1] = p.y;
+  }
+  return 1;
+}
+}

@@ -112,6 +112,13 @@ class Reference:
     def sim3_apply(self, a, p):
         return self._se3("ref_sim3_apply", a, p, out_n=3)
 
+    def camera_project(self, params, xyz, uv_out):
+        """GSLAM::Camera(params).Project on n x 3 camera-frame points -> uv_out n x 2 (in place); False: invalid camera."""
+        a = np.ascontiguousarray(params, dtype=np.float64)
+        x = np.ascontiguousarray(xyz, dtype=np.float64)
+        assert uv_out.flags.c_contiguous and uv_out.shape == (len(x), 2)
+        return bool(self.lib.ref_camera_project(_ptr(a), len(a), _ptr(x), len(x), _ptr(uv_out)))
+
 
 def load():
     return Oracle()
@@ -714,7 +721,8 @@ class GraphProblem(C.Structure):
                 ("ej", _vp), ("meas", _vp), ("info", _vp), ("n_xyz", C.c_int32), ("xyz", _vp), ("xyz_free", _vp),
                 ("n_idp", C.c_int32), ("idp_host", _vp), ("idp_anchor", _vp), ("idp_rho", _vp), ("idp_free", _vp),
                 ("n_obs", C.c_int32), ("obs_kind", _vp), ("obs_point", _vp), ("obs_frame", _vp), ("obs_xy", _vp),
-                ("obs_info", _vp), ("huber", C.c_double), ("projection", C.c_int32), ("obs_bearing", _vp)]
+                ("obs_info", _vp), ("huber", C.c_double), ("projection", C.c_int32), ("obs_bearing", _vp),
+                ("intrinsics", _vp), ("intrinsics_free", C.c_int32)]
 
 
 def graph_arrays(frames, dof, problem):
@@ -738,6 +746,10 @@ def graph_arrays(frames, dof, problem):
     a["xy"] = np.ascontiguousarray(xy, dtype=np.float64)
     a["oinfo"] = None if oinfo is None else np.ascontiguousarray(oinfo, dtype=np.float64)
     a["sphere"] = 1 if problem.get("projection") == "sphere" else 0  # then `xy` holds n x 3 unit bearings
+    # "intrinsics": (fx fy cx cy k1 k2 p1 p2 k3, free-parameter bit mask): `xy` holds pixels then
+    cam = problem.get("intrinsics")
+    a["cam"] = None if cam is None else np.ascontiguousarray(cam[0], dtype=np.float64).copy()
+    a["cam_free"] = 0 if cam is None else int(cam[1])
     return a
 
 
@@ -747,7 +759,8 @@ def _graph_methods(cls):
                             _ptr(a["ej"]), _ptr(a["meas"]), _ptr(a["info"]), len(a["xyz"]), _ptr(a["xyz"]), _ptr(a["xfree"]),
                             len(a["rho"]), _ptr(a["host"]), _ptr(a["anchor"]), _ptr(a["rho"]), _ptr(a["ifree"]), len(a["kind"]),
                             _ptr(a["kind"]), _ptr(a["point"]), _ptr(a["frame"]), None if a["sphere"] else _ptr(a["xy"]), _ptr(a["oinfo"]),
-                            float(huber), a["sphere"], _ptr(a["xy"]) if a["sphere"] else None)
+                            float(huber), a["sphere"], _ptr(a["xy"]) if a["sphere"] else None,
+                            None if a["cam"] is None else _ptr(a["cam"]), a["cam_free"])
 
     def graph_solve(self, frames, dof, problem, opts=None, threads=1):
         """-> (frames, xyz, rho, summary, status).  opts.huber_delta is the projection Huber threshold."""
@@ -757,6 +770,22 @@ def _graph_methods(cls):
         sm = BaSummary()
         st = self.lib.oracle_graph_solve(C.byref(gp), C.byref(opts), C.byref(sm), int(threads))
         return a["frames"], a["xyz"], a["rho"], sm, st
+
+    def graph_solve_cam(self, frames, dof, problem, opts=None, threads=1):
+        """The same with problem["intrinsics"]: -> (frames, xyz, rho, intrinsics 9, summary, status)."""
+        opts = opts or ba_options()
+        a = graph_arrays(frames, dof, problem)
+        gp = _problem(self, a, opts.huber_delta)
+        sm = BaSummary()
+        st = self.lib.oracle_graph_solve(C.byref(gp), C.byref(opts), C.byref(sm), int(threads))
+        return a["frames"], a["xyz"], a["rho"], a["cam"], sm, st
+
+    def cam_project(self, cam, x, y):
+        """-> (UV 2, A = d(U, V)/d(x, y) 2 x 2, Jc = d(U, V)/dc 2 x 9)."""
+        UV, A, Jc = np.zeros(2), np.zeros(4), np.zeros(18)
+        self.lib.oracle_cam_project(_ptr(np.ascontiguousarray(cam, dtype=np.float64)), C.c_double(x), C.c_double(y), _ptr(UV), _ptr(A),
+                                    _ptr(Jc))
+        return UV, A.reshape(2, 2), Jc.reshape(2, 9)
 
     def graph_cost(self, frames, dof, problem, huber=0.01):
         a = graph_arrays(frames, dof, problem)
@@ -774,7 +803,7 @@ def _graph_methods(cls):
                                        C.byref(w), C.byref(s), _ptr(Jj), _ptr(Jh), _ptr(Jp), int(projection))
         return bool(ok), r, w.value, s.value, Jj.reshape(2, 7), Jh.reshape(2, 7), Jp.reshape(2, 3)
 
-    for f in (graph_solve, graph_cost, graph_obs):
+    for f in (graph_solve, graph_solve_cam, cam_project, graph_cost, graph_obs):
         setattr(cls, f.__name__, f)
 
 

@@ -1,0 +1,171 @@
+"""Camera self-calibration in the general-BundleGraph oracle (BundleGraph::camera + cameraDOF, GSLAM/core/Optimizer.h:86-100,
+169-171; camera model GSLAM/core/Camera.h:386-407).  The reference holds no implementation: the oracle's projection is
+checked against the compiled reference camera where oracle/_ref exists, its Jacobians against finite differences, and the
+solve against scipy.optimize.least_squares on an independent numpy restatement of the residuals."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from gslam_amd.pg_synth import make_landmark_graph, opencv_project, with_camera, _qrot
+
+CAM = np.array([520.0, 515.0, 318.0, 242.0, -0.28, 0.09, 1.2e-3, -8e-4, -0.01])
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return oracle_lib.Oracle()
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "camera_reference.npz")
+
+
+def test_projection_is_the_references_camera_project(oracle):
+    """Pinned: oracle_cam_project == GSLAM::Camera::Project (golden vectors from the compiled reference, and live where
+    oracle/_ref exists)."""
+    g = np.load(GOLD)
+    for i, c in enumerate(g["cams"]):
+        xyz = g["xyz"]
+        got = np.array([oracle.cam_project(c[2:], X[0] / X[2], X[1] / X[2])[0] for X in xyz])
+        assert np.allclose(got, g["uv"][i], rtol=1e-13, atol=1e-10)
+        if oracle_lib.have_reference():
+            live = np.zeros((len(xyz), 2))
+            params = c[:6] if not c[6:].any() else c
+            assert oracle_lib.load_reference().camera_project(params, xyz, live) and np.array_equal(live, g["uv"][i])
+
+
+def test_projection_matches_the_numpy_restatement_and_finite_differences(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        cam = CAM * (1.0 + rng.normal(size=9) * 0.05)
+        x, y = rng.uniform(-0.6, 0.6, size=2)
+        UV, A, Jc = oracle.cam_project(cam, x, y)
+        assert np.allclose(UV, opencv_project(cam, x, y), rtol=1e-13, atol=1e-10)
+        h = 1e-6
+        fd_A = np.stack([(np.array(opencv_project(cam, x + h, y)) - np.array(opencv_project(cam, x - h, y))) / (2 * h),
+                         (np.array(opencv_project(cam, x, y + h)) - np.array(opencv_project(cam, x, y - h))) / (2 * h)], axis=1)
+        assert np.allclose(A, fd_A, rtol=1e-6, atol=1e-5)
+        for k in range(9):
+            e = np.zeros(9)
+            e[k] = 1e-6 * max(1.0, abs(cam[k]))
+            fd = (np.array(opencv_project(cam + e, x, y)) - np.array(opencv_project(cam - e, x, y))) / (2 * e[k])
+            assert np.allclose(Jc[:, k], fd, rtol=1e-6, atol=1e-6), k
+
+
+def _pixel_residual_py(Sj, Sh, kind, lm, anchor, cam, m):
+    if kind == 0:
+        Xw = np.asarray(lm, float)
+    else:
+        Xw = Sh[7] * _qrot(Sh[:4], np.asarray(anchor) / lm[0]) + Sh[4:7]
+    qc = np.array([-Sj[0], -Sj[1], -Sj[2], Sj[3]])
+    Xc = _qrot(qc, Xw - Sj[4:7]) / Sj[7]
+    U, V = opencv_project(cam, Xc[0] / Xc[2], Xc[1] / Xc[2])
+    return np.array([U - m[0], V - m[1]])
+
+
+def _scipy_minimum(oracle, start, dof, problem):
+    from scipy.optimize import least_squares
+    nf = len(start)
+    xyz0, _ = problem["xyz"]
+    host, anchor, rho0, _ = problem["idp"]
+    kind, point, frame, px, info = problem["obs"]
+    cam0, free = problem["intrinsics"]
+    cols = [(f, k) for f in range(nf) for k in range(7) if (dof[f] >> k) & 1]
+    ccols = [k for k in range(9) if (free >> k) & 1]
+    cscale = np.array([max(1.0, abs(cam0[k])) for k in ccols])
+
+    def unpack(x):
+        d = np.zeros((nf, 7))
+        for c, (f, k) in enumerate(cols):
+            d[f, k] = x[c]
+        S = np.stack([oracle.sim3_retract(start[f], d[f]) if d[f].any() else start[f] for f in range(nf)])
+        o = len(cols)
+        xyz = xyz0 + x[o:o + xyz0.size].reshape(-1, 3)
+        rho = rho0 + x[o + xyz0.size:o + xyz0.size + rho0.size]
+        cam = cam0.copy()
+        cam[ccols] += x[o + xyz0.size + rho0.size:] * cscale
+        return S, xyz, rho, cam
+
+    def res(x):
+        S, xyz, rho, cam = unpack(x)
+        out = []
+        for k in range(len(kind)):
+            j, p = frame[k], point[k]
+            if kind[k] == 0:
+                out.append(_pixel_residual_py(S[j], S[j], 0, xyz[p], None, cam, px[k]))
+            else:
+                out.append(_pixel_residual_py(S[j], S[host[p]], 1, rho[p:p + 1], anchor[p], cam, px[k]))
+        return np.concatenate(out)
+
+    x0 = np.zeros(len(cols) + xyz0.size + rho0.size + len(ccols))
+    sol = least_squares(res, x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=300)
+    return 0.5 * float(sol.fun @ sol.fun), unpack(sol.x)
+
+
+def _problem(seed, free, noise=0.0, start_scale=None, n_frames=8, n_xyz=40, n_idp=12):
+    truth, start, dof, problem = make_landmark_graph(n_frames=n_frames, n_xyz=n_xyz, n_idp=n_idp, kind="se3", seed=seed, noise=0.0,
+                                                     perturb=0.02, point_perturb=0.03, obs_per_point=5)
+    cam_start = CAM.copy()
+    if start_scale is not None:
+        for k in range(9):
+            if (free >> k) & 1:
+                cam_start[k] = CAM[k] * start_scale[k] if abs(CAM[k]) > 1 else CAM[k] + start_scale[k] - 1.0
+    return truth, start, dof, with_camera(problem, CAM, cam_start, free, pixel_noise=noise, seed=seed)
+
+
+def test_fixed_intrinsics_equal_the_normalised_problem_through_a_pinhole_camera(oracle):
+    """A pinhole camera with nothing to estimate is a change of units: same minimiser as the normalised problem."""
+    truth, start, dof, base = make_landmark_graph(n_frames=6, n_xyz=20, n_idp=10, kind="se3", seed=4, noise=1e-3)
+    cam = np.array([400.0, 400.0, 320.0, 240.0, 0, 0, 0, 0, 0])
+    prob = with_camera(base, cam, cam, 0)
+    opts = oracle_lib.ba_options(huber=0.0, max_iterations=60)
+    opts.function_tolerance = 1e-12
+    S0, xyz0, rho0, sm0, st0 = oracle.graph_solve(start, dof, base, opts)
+    S1, xyz1, rho1, cam1, sm1, st1 = oracle.graph_solve_cam(start, dof, prob, opts)
+    assert st0 == 0 and st1 == 0 and np.array_equal(cam1, cam)
+    assert np.isclose(sm1.final_cost, sm0.final_cost * 400.0 ** 2, rtol=1e-6)
+    assert np.allclose(S0, S1, atol=1e-6) and np.allclose(xyz0, xyz1, atol=1e-5) and np.allclose(rho0, rho1, atol=1e-6)
+
+
+@pytest.mark.parametrize("free", [0b000000011, 0b000001111, 0b100111111, 0b111111111])
+def test_noise_free_calibration_recovers_the_camera(oracle, free):
+    scale = np.array([1.06, 0.95, 1.03, 0.97, 1.05, 0.97, 1.001, 0.999, 1.01])
+    truth, start, dof, prob = _problem(7, free, start_scale=scale)
+    opts = oracle_lib.ba_options(huber=0.0, max_iterations=200)
+    opts.function_tolerance = 1e-16
+    S, xyz, rho, cam, sm, st = oracle.graph_solve_cam(start, dof, prob, opts)
+    # (st 1 = the trust region ran dry at a zero-residual minimum: no relative decrease is left to accept)
+    assert st in (0, 1) and sm.final_cost < 1e-12 * max(sm.initial_cost, 1.0), (sm.initial_cost, sm.final_cost)
+    fixed = [k for k in range(9) if not (free >> k) & 1]
+    assert np.array_equal(cam[fixed], prob["intrinsics"][0][fixed])
+    assert np.allclose(cam[:4], CAM[:4], rtol=1e-5) and np.allclose(cam[4:], CAM[4:], atol=1e-5), cam - CAM
+
+
+def test_calibration_reaches_scipys_minimum(oracle):
+    free = 0b000111111
+    scale = np.array([1.04, 0.97, 1.02, 0.98, 1.03, 0.98, 1, 1, 1])
+    truth, start, dof, prob = _problem(11, free, noise=0.3, start_scale=scale, n_frames=6, n_xyz=24, n_idp=8)
+    opts = oracle_lib.ba_options(huber=0.0, max_iterations=200)
+    opts.function_tolerance = 1e-13
+    S, xyz, rho, cam, sm, st = oracle.graph_solve_cam(start, dof, prob, opts)
+    assert st in (0, 1)
+    ref_cost, (S2, xyz2, rho2, cam2) = _scipy_minimum(oracle, start, dof, prob)
+    assert np.isclose(sm.final_cost, ref_cost, rtol=1e-5), (sm.final_cost, ref_cost)
+    assert np.allclose(cam[:4], cam2[:4], rtol=2e-3) and np.allclose(cam[4:6], cam2[4:6], atol=2e-2)
+
+
+def test_huber_and_information_in_pixels(oracle):
+    truth, start, dof, base = make_landmark_graph(n_frames=6, n_xyz=30, n_idp=10, kind="se3", seed=9, outliers=0.1, with_info=True)
+    prob = with_camera(base, CAM, CAM * np.array([1.03, 0.98, 1, 1, 1, 1, 1, 1, 1]), 0b11, pixel_noise=0.2, seed=3)
+    opts = oracle_lib.ba_options(huber=2.0, max_iterations=80)
+    S, xyz, rho, cam, sm, st = oracle.graph_solve_cam(start, dof, prob, opts)
+    assert st == 0 and sm.final_cost < sm.initial_cost and np.allclose(cam[:2], CAM[:2], rtol=0.03)
+    done = dict(prob, xyz=(xyz, prob["xyz"][1]), idp=(prob["idp"][0], prob["idp"][1], rho, prob["idp"][3]), intrinsics=(cam, 0b11))
+    assert np.isclose(oracle.graph_cost(S, dof, done, 2.0), sm.final_cost, rtol=1e-12)
+
+
+def test_sphere_projection_with_a_camera_is_refused(oracle):
+    truth, start, dof, base = make_landmark_graph(n_frames=4, n_xyz=8, n_idp=0, projection="sphere")
+    base["intrinsics"] = (CAM.copy(), 3)
+    assert oracle.graph_solve_cam(start, dof, base)[-1] == 2

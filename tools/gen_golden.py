@@ -12,6 +12,8 @@ Run in the authoring container only (needs /root/reference); the outputs are com
   bow_reference_wide.npz  the same for a 64-byte (hamming64) and a 40-byte (hamming8x) vocabulary (`gen_golden.py wide`).
   undist_reference.npz  remap tables of the reference's UndistorterImpl::prepareReMap (OpenCV model, 128x96 -> 112x84)
                      and its undistort / undistortFast outputs on seeded 1- and 3-channel images.
+  camera_reference.npz  GSLAM::Camera::Project of a pinhole and two OpenCV cameras on seeded camera-frame points
+                     (`gen_golden.py camera`): pins the projection the self-calibrating graph solve differentiates.
 """
 import os
 import sys
@@ -53,10 +55,28 @@ def wide_bow(ref, out):
     print("bow_reference_wide.npz written")
 
 
+def camera_golden(ref, out):
+    """camera_reference.npz: the reference's Camera::Project (GSLAM/core/Camera.h:213-227,386-407)."""
+    rng = np.random.default_rng(20260925)
+    cams = np.array([[640, 480, 520.0, 515.0, 318.0, 242.0, 0, 0, 0, 0, 0],
+                     [640, 480, 520.0, 515.0, 318.0, 242.0, -0.28, 0.09, 1.2e-3, -8e-4, -0.01],
+                     [1920, 1080, 1400.0, 1395.0, 955.0, 545.0, 0.12, -0.3, -2e-3, 1.5e-3, 0.2]])
+    xyz = np.stack([rng.uniform(-3, 3, 400), rng.uniform(-3, 3, 400), rng.uniform(2, 9, 400)], axis=1)
+    xyz[:40, 2] = 1.0  # (the reference short-cuts z == 1)
+    uv = np.zeros((len(cams), len(xyz), 2))
+    for i, c in enumerate(cams):
+        params = c[:6] if not c[6:].any() else c  # 6 parameters = CameraPinhole, 11 = CameraOpenCV
+        assert ref.camera_project(params, xyz, uv[i])
+    np.savez_compressed(os.path.join(out, "camera_reference.npz"), cams=cams, xyz=xyz, uv=uv)
+    print("camera_reference.npz written")
+
+
 def main():
     ref = oracle_lib.load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         return wide_bow(ref, os.path.join(ROOT, "tests", "golden"))
+    if len(sys.argv) > 1 and sys.argv[1] == "camera":
+        return camera_golden(ref, os.path.join(ROOT, "tests", "golden"))
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
 
@@ -136,6 +156,7 @@ def main():
     ru.close()
     np.savez_compressed(os.path.join(out, "undist_reference.npz"), **rec)
     wide_bow(ref, out)
+    camera_golden(ref, out)
     print("golden vectors written to", out)
 
 
