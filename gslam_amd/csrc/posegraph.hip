@@ -545,7 +545,8 @@ gh_status PoseHost::build(gh_ctx* ctx, const gh_pg_problem* pr) {
 namespace {
 
 constexpr double kMinDepthG = 1e-9;
-constexpr int kObsRec = 40;  // r(2) L(4) Jj(14) Jh(14) Jp(6)
+constexpr int kObsRec = 40;     // r(2) L(4) Jj(14) Jh(14) Jp(6)
+constexpr int kObsRecCam = 58;  // ... + Jc(18): the record of a graph with a camera (GrLandmarks::rec is one of the two)
 
 struct GrLandmarks {
   int n_xyz, n_idp, n_obs;
@@ -559,7 +560,40 @@ struct GrLandmarks {
   const int32_t *lstart, *llist;  // observations by landmark (XYZ points first, then inverse-depth points)
   double huber;
   int projection;             // 0 pinhole (obs_xy n x 2), 1 sphere (obs_xy n x 3 unit bearings)
+  // BundleGraph::camera + cameraDOF (Optimizer.h:86-100,169-171): with_cam = the observations are pixels of the camera
+  // c = fx fy cx cy k1 k2 p1 p2 k3 (the current / candidate value is a kernel argument), cam_free = which of the nine are
+  // unknowns; they sit behind the keyframes in the reduced system: rows 7 n_frames .. 7 n_frames + 8
+  int with_cam, cam_free, n_frames, rec;
 };
+
+// pixel coordinates of the normalised point (x, y), A = d(U, V)/d(x, y), Jc = d(U, V)/dc (2 x 9): GSLAM's OpenCV camera
+// model (GSLAM/core/Camera.h:396-406; the pinhole model is k = p = 0), same operation order as oracle_cam_project
+__device__ inline void cam_project(const double* c, double x, double y, double* UV, double* A, double* Jc) {
+  const double fx = c[0], fy = c[1], k1 = c[4], k2 = c[5], p1 = c[6], p2 = c[7], k3 = c[8];
+  const double x2 = x * x, y2 = y * y, r2 = x2 + y2, r4 = r2 * r2, r6 = r2 * r4, xy2 = x * y * 2.0;
+  const double rad = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+  const double X1 = x * rad + xy2 * p1 + p2 * (r2 + 2.0 * x2);
+  const double Y1 = y * rad + xy2 * p2 + p1 * (r2 + 2.0 * y2);
+  UV[0] = c[2] + fx * X1;
+  UV[1] = c[3] + fy * Y1;
+  if (A) {
+    const double radp = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+    A[0] = fx * (rad + 2.0 * x2 * radp + 2.0 * p1 * y + 6.0 * p2 * x);
+    A[1] = fx * (2.0 * x * y * radp + 2.0 * p1 * x + 2.0 * p2 * y);
+    A[2] = fy * (2.0 * x * y * radp + 2.0 * p2 * y + 2.0 * p1 * x);
+    A[3] = fy * (rad + 2.0 * y2 * radp + 2.0 * p2 * x + 6.0 * p1 * y);
+  }
+  if (Jc) {
+    for (int e = 0; e < 18; ++e) Jc[e] = 0.0;
+    Jc[0] = X1;                   Jc[9 + 1] = Y1;
+    Jc[2] = 1.0;                  Jc[9 + 3] = 1.0;
+    Jc[4] = fx * x * r2;          Jc[9 + 4] = fy * y * r2;
+    Jc[5] = fx * x * r4;          Jc[9 + 5] = fy * y * r4;
+    Jc[6] = fx * xy2;             Jc[9 + 6] = fy * (r2 + 2.0 * y2);
+    Jc[7] = fx * (r2 + 2.0 * x2); Jc[9 + 7] = fy * xy2;
+    Jc[8] = fx * x * r6;          Jc[9 + 8] = fy * y * r6;
+  }
+}
 
 __device__ inline void q_matrix(const double* q, double* R) {
   const double x = q[0], y = q[1], z = q[2], w = q[3];
@@ -591,7 +625,7 @@ template <bool WITH_J>
 __device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const double* Sh, int dof_h, bool same_host,
                                  const double* lm, bool lm_free, const double* anchor, const double* m, const double* info,
                                  double huber, double* r, double* wgt, double* s_out, double* Jj, double* Jh, double* Jp,
-                                 int projection) {
+                                 int projection, const double* cam = nullptr, int cam_free = 0, double* Jc = nullptr) {
   double Z[3], Y[3], Ra[3] = {0, 0, 0}, dth[3] = {0, 0, 0};
   if (kind == 0) {
     for (int e = 0; e < 3; ++e) Z[e] = lm[e] - Sj[4 + e];
@@ -608,9 +642,25 @@ __device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const do
   if (projection == 0) {
     if (!(Y[2] > kMinDepthG)) return false;
     const double iz = 1.0 / Y[2], u = Y[0] * iz, v = Y[1] * iz;
-    r[0] = u - m[0];
-    r[1] = v - m[1];
     P[0] = iz; P[1] = 0; P[2] = -u * iz; P[3] = 0; P[4] = iz; P[5] = -v * iz;
+    if (cam) {
+      double UV[2], A[4], Jcf[18];
+      cam_project(cam, u, v, UV, WITH_J ? A : nullptr, WITH_J ? Jcf : nullptr);
+      r[0] = UV[0] - m[0];
+      r[1] = UV[1] - m[1];
+      if (WITH_J) {
+        const double P0[6] = {P[0], P[1], P[2], P[3], P[4], P[5]};
+        for (int e = 0; e < 3; ++e) {
+          P[e] = A[0] * P0[e] + A[1] * P0[3 + e];
+          P[3 + e] = A[2] * P0[e] + A[3] * P0[3 + e];
+        }
+        for (int a = 0; a < 2; ++a)
+          for (int k = 0; k < 9; ++k) Jc[9 * a + k] = ((cam_free >> k) & 1) ? Jcf[9 * a + k] : 0.0;
+      }
+    } else {
+      r[0] = u - m[0];
+      r[1] = v - m[1];
+    }
   } else {
     const double nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
     if (!(nY > kMinDepthG)) return false;
@@ -709,7 +759,8 @@ __device__ inline ObsRef obs_ref(const GrLandmarks& G, int k) {
 
 template <bool WITH_J>
 __device__ inline bool obs_eval(const GrLandmarks& G, const int32_t* dof, int k, const ObsRef& o, const double* S, const double* xyz,
-                                const double* rho, double* r, double* w, double* s, double* Jj, double* Jh, double* Jp) {
+                                const double* rho, double* r, double* w, double* s, double* Jj, double* Jh, double* Jp,
+                                const double* cam_dev = nullptr, double* Jc = nullptr) {
   double Sj[8], Sh[8], lm[3] = {0, 0, 0}, anchor[3] = {0, 0, 0}, info[4];
   const int h = o.kind == 1 ? G.idp_host[o.p] : o.fj;
   for (int e = 0; e < 8; ++e) {
@@ -726,58 +777,102 @@ __device__ inline bool obs_eval(const GrLandmarks& G, const int32_t* dof, int k,
     for (int e = 0; e < 4; ++e) info[e] = G.obs_info[4 * (size_t)k + e];
   const int ms = G.projection ? 3 : 2;
   const double m[3] = {G.obs_xy[ms * (size_t)k], G.obs_xy[ms * (size_t)k + 1], G.projection ? G.obs_xy[ms * (size_t)k + 2] : 1.0};
+  double cam[9];
+  if (G.with_cam)
+    for (int e = 0; e < 9; ++e) cam[e] = cam_dev[e];
   return graph_obs<WITH_J>(o.kind, Sj, dof[o.fj], Sh, dof[h], o.same_host, lm, o.lm_free, anchor, m, G.obs_info ? info : nullptr,
-                           G.huber, r, w, s, Jj, Jh, Jp, G.projection);
+                           G.huber, r, w, s, Jj, Jh, Jp, G.projection, G.with_cam ? cam : nullptr, G.cam_free, Jc);
+}
+
+// sum of one double per lane over the wave (every lane must take part), returned in every lane
+__device__ inline double wave_add_f64(double v) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
 }
 
 __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const int32_t* __restrict__ dof, const double* __restrict__ S,
                                                          const double* __restrict__ xyz, const double* __restrict__ rho,
-                                                         double* __restrict__ orec, uint8_t* __restrict__ valid, double* __restrict__ H,
+                                                         const double* __restrict__ cam, double* __restrict__ orec,
+                                                         uint8_t* __restrict__ valid, double* __restrict__ H,
                                                          int lda, double* __restrict__ g, double* __restrict__ Hpp,
                                                          double* __restrict__ gp) {
   const int k = blockIdx.x * 128 + threadIdx.x;
-  if (k >= G.n_obs) return;
-  const ObsRef o = obs_ref(G, k);
-  double r[2], w, s, Jj[14], Jh[14], Jp[6];
-  const bool ok = obs_eval<true>(G, dof, k, o, S, xyz, rho, r, &w, &s, Jj, Jh, Jp);
-  valid[k] = ok ? 1 : 0;
-  double* R = orec + (size_t)kObsRec * k;
-  if (!ok) {
-    for (int e = 0; e < kObsRec; ++e) R[e] = 0.0;
-    return;
-  }
-  double L[4] = {w, 0, 0, w};
-  if (G.obs_info)
-    for (int e = 0; e < 4; ++e) L[e] = w * G.obs_info[4 * (size_t)k + e];
-  R[0] = r[0]; R[1] = r[1];
-  for (int e = 0; e < 4; ++e) R[2 + e] = L[e];
-  for (int e = 0; e < 14; ++e) { R[6 + e] = Jj[e]; R[20 + e] = Jh[e]; }
-  for (int e = 0; e < 6; ++e) R[34 + e] = Jp[e];
-  const double Lr[2] = {L[0] * r[0] + L[1] * r[1], L[2] * r[0] + L[3] * r[1]};
-  const double* Jf[2] = {Jj, Jh};
-  const int ff[2] = {o.fj, o.fh};
-  for (int x = 0; x < 2; ++x) {
-    if (ff[x] < 0) continue;
-    for (int p = 0; p < 7; ++p) {
-      const double gv = Jf[x][p] * Lr[0] + Jf[x][7 + p] * Lr[1];
-      if (gv != 0.0) atomicAdd(&g[7 * ff[x] + p], gv);
-    }
-    for (int y = 0; y < 2; ++y) {
-      if (ff[y] < 0 || ff[y] > ff[x]) continue;  // lower triangle of blocks: row frame >= column frame
-      for (int q = 0; q < 7; ++q) {
-        const double LJ0 = L[0] * Jf[y][q] + L[1] * Jf[y][7 + q], LJ1 = L[2] * Jf[y][q] + L[3] * Jf[y][7 + q];
+  const bool in_range = k < G.n_obs;
+  if (!in_range && !G.with_cam) return;  // (with a camera every lane stays for the wave sums of the intrinsics block)
+  double r[2] = {0, 0}, w = 0, s = 0, Jj[14], Jh[14], Jp[6], Jc[18], L[4] = {0, 0, 0, 0}, Lr[2] = {0, 0};
+  for (int e = 0; e < 18; ++e) Jc[e] = 0.0;
+  bool ok = false;
+  ObsRef o;
+  if (in_range) {
+    o = obs_ref(G, k);
+    ok = obs_eval<true>(G, dof, k, o, S, xyz, rho, r, &w, &s, Jj, Jh, Jp, cam, Jc);
+    valid[k] = ok ? 1 : 0;
+    double* R = orec + (size_t)G.rec * k;
+    if (!ok) {
+      for (int e = 0; e < G.rec; ++e) R[e] = 0.0;
+      for (int e = 0; e < 18; ++e) Jc[e] = 0.0;
+    } else {
+      L[0] = L[3] = w;
+      if (G.obs_info)
+        for (int e = 0; e < 4; ++e) L[e] = w * G.obs_info[4 * (size_t)k + e];
+      R[0] = r[0]; R[1] = r[1];
+      for (int e = 0; e < 4; ++e) R[2 + e] = L[e];
+      for (int e = 0; e < 14; ++e) { R[6 + e] = Jj[e]; R[20 + e] = Jh[e]; }
+      for (int e = 0; e < 6; ++e) R[34 + e] = Jp[e];
+      if (G.with_cam)
+        for (int e = 0; e < 18; ++e) R[40 + e] = Jc[e];
+      Lr[0] = L[0] * r[0] + L[1] * r[1];
+      Lr[1] = L[2] * r[0] + L[3] * r[1];
+      const double* Jf[2] = {Jj, Jh};
+      const int ff[2] = {o.fj, o.fh};
+      for (int x = 0; x < 2; ++x) {
+        if (ff[x] < 0) continue;
         for (int p = 0; p < 7; ++p) {
-          const double hv = Jf[x][p] * LJ0 + Jf[x][7 + p] * LJ1;
-          if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[y] + q) * lda + 7 * ff[x] + p], hv);
+          const double gv = Jf[x][p] * Lr[0] + Jf[x][7 + p] * Lr[1];
+          if (gv != 0.0) atomicAdd(&g[7 * ff[x] + p], gv);
+        }
+        for (int y = 0; y < 2; ++y) {
+          if (ff[y] < 0 || ff[y] > ff[x]) continue;  // lower triangle of blocks: row frame >= column frame
+          for (int q = 0; q < 7; ++q) {
+            const double LJ0 = L[0] * Jf[y][q] + L[1] * Jf[y][7 + q], LJ1 = L[2] * Jf[y][q] + L[3] * Jf[y][7 + q];
+            for (int p = 0; p < 7; ++p) {
+              const double hv = Jf[x][p] * LJ0 + Jf[x][7 + p] * LJ1;
+              if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[y] + q) * lda + 7 * ff[x] + p], hv);
+            }
+          }
+        }
+        if (G.with_cam) {  // intrinsics rows x this keyframe's columns (the intrinsics block comes last: always the lower triangle)
+          for (int q = 0; q < 7; ++q) {
+            const double LJ0 = L[0] * Jf[x][q] + L[1] * Jf[x][7 + q], LJ1 = L[2] * Jf[x][q] + L[3] * Jf[x][7 + q];
+            for (int p = 0; p < 9; ++p) {
+              const double hv = Jc[p] * LJ0 + Jc[9 + p] * LJ1;
+              if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[x] + q) * lda + 7 * G.n_frames + p], hv);
+            }
+          }
+        }
+      }
+      for (int a = 0; a < o.dp; ++a) {
+        atomicAdd(&gp[3 * (size_t)o.lm + a], Jp[a] * Lr[0] + Jp[3 + a] * Lr[1]);
+        for (int b = 0; b < o.dp; ++b) {
+          const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
+          atomicAdd(&Hpp[9 * (size_t)o.lm + 3 * a + b], Jp[a] * LJ0 + Jp[3 + a] * LJ1);
         }
       }
     }
   }
-  for (int a = 0; a < o.dp; ++a) {
-    atomicAdd(&gp[3 * (size_t)o.lm + a], Jp[a] * Lr[0] + Jp[3 + a] * Lr[1]);
-    for (int b = 0; b < o.dp; ++b) {
-      const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
-      atomicAdd(&Hpp[9 * (size_t)o.lm + 3 * a + b], Jp[a] * LJ0 + Jp[3 + a] * LJ1);
+  if (!G.with_cam) return;
+  // intrinsics block: every observation adds to the same 9 + 45 words -> summed over the wave first, one atomic per wave
+  const int cb = 7 * G.n_frames;
+  const bool lead = (threadIdx.x & 63) == 0;
+  for (int p = 0; p < 9; ++p) {
+    if (!((G.cam_free >> p) & 1)) continue;
+    const double gv = wave_add_f64(Jc[p] * Lr[0] + Jc[9 + p] * Lr[1]);
+    if (lead && gv != 0.0) atomicAdd(&g[cb + p], gv);
+    for (int q = 0; q <= p; ++q) {
+      if (!((G.cam_free >> q) & 1)) continue;
+      const double LJ0 = L[0] * Jc[q] + L[1] * Jc[9 + q], LJ1 = L[2] * Jc[q] + L[3] * Jc[9 + q];
+      const double hv = wave_add_f64(Jc[p] * LJ0 + Jc[9 + p] * LJ1);
+      if (lead && hv != 0.0) atomicAdd(&H[(size_t)(cb + q) * lda + cb + p], hv);
     }
   }
 }
@@ -798,11 +893,15 @@ __global__ __launch_bounds__(256) void gr_gmax_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void gr_lm_prepare_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ Hpp,
                                                             const double* __restrict__ orec, double radius, double* __restrict__ Hinv,
                                                             int32_t* __restrict__ lmdim, double* __restrict__ Wh,
-                                                            int32_t* __restrict__ hrep) {
+                                                            int32_t* __restrict__ hrep, double* __restrict__ Wc) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= G.n_xyz + G.n_idp) return;
   int dp = 0, rep = -1;
   double wh[7] = {0, 0, 0, 0, 0, 0, 0};
+  // with a camera: the landmark's coupling to the intrinsics, W_c = sum over its observations of J_c^T L J_p (9 x 3) --
+  // one slot per landmark in the Schur product (gr_schur_cam_kernel)
+  double wc[27];
+  for (int e = 0; e < 27; ++e) wc[e] = 0.0;
   for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
     const int k = G.llist[q];
     if (valid[k]) {
@@ -810,13 +909,23 @@ __global__ __launch_bounds__(256) void gr_lm_prepare_kernel(GrLandmarks G, const
       dp = o.dp > dp ? o.dp : dp;
       if (o.fh >= 0 && o.dp == 1) {
         if (rep < 0) rep = k;
-        const double* R = orec + (size_t)kObsRec * k;
+        const double* R = orec + (size_t)G.rec * k;
         const double* L = R + 2;
         const double LJ0 = L[0] * R[34] + L[1] * R[37], LJ1 = L[2] * R[34] + L[3] * R[37];
         for (int r7 = 0; r7 < 7; ++r7) wh[r7] += R[20 + r7] * LJ0 + R[27 + r7] * LJ1;
       }
+      if (G.with_cam && o.dp > 0) {
+        const double* R = orec + (size_t)G.rec * k;
+        const double* L = R + 2;
+        for (int b = 0; b < o.dp; ++b) {
+          const double LJ0 = L[0] * R[34 + b] + L[1] * R[37 + b], LJ1 = L[2] * R[34 + b] + L[3] * R[37 + b];
+          for (int r9 = 0; r9 < 9; ++r9) wc[3 * r9 + b] += R[40 + r9] * LJ0 + R[49 + r9] * LJ1;
+        }
+      }
     }
   }
+  if (G.with_cam)
+    for (int e = 0; e < 27; ++e) Wc[27 * (size_t)p + e] = wc[e];
   lmdim[p] = dp;
   hrep[p] = rep;
   for (int r7 = 0; r7 < 7; ++r7) Wh[7 * (size_t)p + r7] = wh[r7];
@@ -875,7 +984,7 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
       Wa[3 * r7 + 1] = Wa[3 * r7 + 2] = 0.0;
     }
   } else {
-    slot_W(orec + (size_t)kObsRec * ka, x, dp, Wa);
+    slot_W(orec + (size_t)G.rec * ka, x, dp, Wa);
   }
   for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)oa.lm + e];
   for (int r7 = 0; r7 < 7; ++r7)
@@ -899,13 +1008,73 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
           Wb[3 * c7 + 1] = Wb[3 * c7 + 2] = 0.0;
         }
       } else {
-        slot_W(orec + (size_t)kObsRec * kb, y, dp, Wb);
+        slot_W(orec + (size_t)G.rec * kb, y, dp, Wb);
       }
       for (int c7 = 0; c7 < 7; ++c7)
         for (int r7 = 0; r7 < 7; ++r7) {
           const double v = Ua[3 * r7] * Wb[3 * c7] + Ua[3 * r7 + 1] * Wb[3 * c7 + 1] + Ua[3 * r7 + 2] * Wb[3 * c7 + 2];
           if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + 7 * fa + r7], -v);
         }
+    }
+  }
+}
+
+// The intrinsics' slot of the Schur product, one thread per landmark: U_c = W_c (H_pp + D)^-1 (9 x 3); rhs_c += U_c g_p;
+// block(c, c) -= U_c W_c^T; block(c, f) -= U_c W_f^T for every keyframe slot f of the landmark (the intrinsics rows are the
+// last rows: always the lower triangle).  The (c, c) and rhs sums meet in the same words for every landmark: wave sums first.
+__global__ __launch_bounds__(128) void gr_schur_cam_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+                                                           const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
+                                                           const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
+                                                           const double* __restrict__ Wc, const double* __restrict__ gp,
+                                                           double* __restrict__ Hd, int lda, double* __restrict__ d) {
+  const int p = blockIdx.x * 128 + threadIdx.x;
+  const int nlm = G.n_xyz + G.n_idp;
+  const int dp = p < nlm ? lmdim[p] : 0;
+  double W[27], U[27];
+  for (int e = 0; e < 27; ++e) W[e] = U[e] = 0.0;
+  double g0 = 0, g1 = 0, g2 = 0;
+  const int cb = 7 * G.n_frames;
+  if (dp) {
+    double Hi[9];
+    for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)p + e];
+    for (int e = 0; e < 27; ++e) W[e] = Wc[27 * (size_t)p + e];
+    for (int r9 = 0; r9 < 9; ++r9)
+      for (int b = 0; b < 3; ++b) U[3 * r9 + b] = W[3 * r9] * Hi[b] + W[3 * r9 + 1] * Hi[3 + b] + W[3 * r9 + 2] * Hi[6 + b];
+    g0 = gp[3 * (size_t)p]; g1 = gp[3 * (size_t)p + 1]; g2 = gp[3 * (size_t)p + 2];
+    const int rep = hrep[p];
+    for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
+      const int kb = G.llist[q];
+      if (!valid[kb]) continue;
+      const ObsRef ob = obs_ref(G, kb);
+      for (int y = 0; y < 2; ++y) {
+        const int fb = y == 0 ? ob.fj : ob.fh;
+        if (fb < 0 || (y == 1 && kb != rep)) continue;
+        double Wb[21];
+        if (y == 1) {
+          for (int c7 = 0; c7 < 7; ++c7) {
+            Wb[3 * c7] = Wh[7 * (size_t)p + c7];
+            Wb[3 * c7 + 1] = Wb[3 * c7 + 2] = 0.0;
+          }
+        } else {
+          slot_W(orec + (size_t)G.rec * kb, y, dp, Wb);
+        }
+        for (int c7 = 0; c7 < 7; ++c7)
+          for (int r9 = 0; r9 < 9; ++r9) {
+            const double v = U[3 * r9] * Wb[3 * c7] + U[3 * r9 + 1] * Wb[3 * c7 + 1] + U[3 * r9 + 2] * Wb[3 * c7 + 2];
+            if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + cb + r9], -v);
+          }
+      }
+    }
+  }
+  const bool lead = (threadIdx.x & 63) == 0;
+  for (int r9 = 0; r9 < 9; ++r9) {
+    if (!((G.cam_free >> r9) & 1)) continue;
+    const double v = wave_add_f64(U[3 * r9] * g0 + U[3 * r9 + 1] * g1 + U[3 * r9 + 2] * g2);
+    if (lead && v != 0.0) atomicAdd(&d[cb + r9], v);
+    for (int c9 = 0; c9 <= r9; ++c9) {
+      if (!((G.cam_free >> c9) & 1)) continue;
+      const double h = wave_add_f64(U[3 * r9] * W[3 * c9] + U[3 * r9 + 1] * W[3 * c9 + 1] + U[3 * r9 + 2] * W[3 * c9 + 2]);
+      if (lead && h != 0.0) atomicAdd(&Hd[(size_t)(cb + c9) * lda + cb + r9], -h);
     }
   }
 }
@@ -924,7 +1093,7 @@ __global__ __launch_bounds__(256) void gr_backsub_kernel(GrLandmarks G, const ui
       const int k = G.llist[q];
       if (!valid[k]) continue;
       const ObsRef o = obs_ref(G, k);
-      const double* R = orec + (size_t)kObsRec * k;
+      const double* R = orec + (size_t)G.rec * k;
       const double* L = R + 2;
       const double* Jp = R + 34;
       for (int x = 0; x < 2; ++x) {
@@ -935,6 +1104,15 @@ __global__ __launch_bounds__(256) void gr_backsub_kernel(GrLandmarks G, const ui
         for (int c = 0; c < 7; ++c) {
           Jd0 += Jf[c] * d[7 * f + c];
           Jd1 += Jf[7 + c] * d[7 * f + c];
+        }
+        const double LJd0 = L[0] * Jd0 + L[1] * Jd1, LJd1 = L[2] * Jd0 + L[3] * Jd1;
+        for (int b = 0; b < o.dp; ++b) t[b] += Jp[b] * LJd0 + Jp[3 + b] * LJd1;
+      }
+      if (G.with_cam) {
+        double Jd0 = 0, Jd1 = 0;
+        for (int c = 0; c < 9; ++c) {
+          Jd0 += R[40 + c] * d[7 * G.n_frames + c];
+          Jd1 += R[49 + c] * d[7 * G.n_frames + c];
         }
         const double LJd0 = L[0] * Jd0 + L[1] * Jd1, LJd1 = L[2] * Jd0 + L[3] * Jd1;
         for (int b = 0; b < o.dp; ++b) t[b] += Jp[b] * LJd0 + Jp[3 + b] * LJd1;
@@ -972,7 +1150,7 @@ __global__ __launch_bounds__(256) void gr_model_kernel(PgGraph P, GrLandmarks G,
   double out = 0;
   if (valid[k]) {
     const ObsRef o = obs_ref(G, k);
-    const double* R = orec + (size_t)kObsRec * k;
+    const double* R = orec + (size_t)G.rec * k;
     const double* L = R + 2;
     double Jd0 = 0, Jd1 = 0;
     for (int q = 0; q < 7; ++q) {
@@ -983,6 +1161,11 @@ __global__ __launch_bounds__(256) void gr_model_kernel(PgGraph P, GrLandmarks G,
         Jd1 += R[27 + q] * d[7 * o.fh + q];
       }
     }
+    if (G.with_cam)
+      for (int q = 0; q < 9; ++q) {
+        Jd0 += R[40 + q] * d[7 * G.n_frames + q];
+        Jd1 += R[49 + q] * d[7 * G.n_frames + q];
+      }
     for (int b = 0; b < o.dp; ++b) {
       Jd0 += R[34 + b] * dlm[3 * (size_t)o.lm + b];
       Jd1 += R[37 + b] * dlm[3 * (size_t)o.lm + b];
@@ -996,8 +1179,10 @@ __global__ __launch_bounds__(256) void gr_model_kernel(PgGraph P, GrLandmarks G,
 
 __global__ __launch_bounds__(256) void gr_update_kernel(int n_xyz, int n_idp, const double* __restrict__ xyz, const double* __restrict__ rho,
                                                         const double* __restrict__ dlm, double* __restrict__ xyz_new,
-                                                        double* __restrict__ rho_new) {
+                                                        double* __restrict__ rho_new, const double* __restrict__ cam,
+                                                        const double* __restrict__ d_cam, int cam_free, double* __restrict__ cam_new) {
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (cam != nullptr && p < 9) cam_new[p] = cam[p] + (((cam_free >> p) & 1) ? d_cam[p] : 0.0);  // (d_cam = the step's intrinsics rows)
   if (p < n_xyz) {
     for (int a = 0; a < 3; ++a) xyz_new[3 * (size_t)p + a] = xyz[3 * (size_t)p + a] + dlm[3 * (size_t)p + a];
   } else if (p < n_xyz + n_idp) {
@@ -1010,13 +1195,14 @@ __global__ __launch_bounds__(256) void gr_update_kernel(int n_xyz, int n_idp, co
 // (was_valid) and is not any more makes the candidate infinitely bad
 __global__ __launch_bounds__(128) void gr_cost_kernel(GrLandmarks G, const int32_t* __restrict__ dof, const double* __restrict__ S,
                                                       const double* __restrict__ xyz, const double* __restrict__ rho,
-                                                      const uint8_t* __restrict__ was_valid, double* __restrict__ cost_o) {
+                                                      const double* __restrict__ cam, const uint8_t* __restrict__ was_valid,
+                                                      double* __restrict__ cost_o) {
   const int k = blockIdx.x * 128 + threadIdx.x;
   if (k >= G.n_obs) return;
   const ObsRef o = obs_ref(G, k);
   double r[2], w, s;
   double c = 0;
-  if (obs_eval<false>(G, dof, k, o, S, xyz, rho, r, &w, &s, nullptr, nullptr, nullptr)) {
+  if (obs_eval<false>(G, dof, k, o, S, xyz, rho, r, &w, &s, nullptr, nullptr, nullptr, cam)) {
     c = 0.5 * ((G.huber > 0 && s > G.huber * G.huber) ? 2.0 * G.huber * sqrt(s) - G.huber * G.huber : s);
   } else if (was_valid && was_valid[k]) {
     c = INFINITY;
@@ -1059,6 +1245,12 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
   GH_CHECK_ARG(ctx, nx >= 0 && ni >= 0 && no >= 0 && (nx == 0 || gpr->xyz) && (ni == 0 || (gpr->idp_host && gpr->idp_anchor && gpr->idp_rho)));
   GH_CHECK_ARG(ctx, gpr->projection == 0 || gpr->projection == 1);
+  // camera self-calibration (BundleGraph::camera + cameraDOF): pixels through the camera model, pinhole projection only
+  const bool with_cam = gpr->intrinsics != nullptr && no > 0;
+  if (gpr->intrinsics) {
+    if (gpr->projection != 0) return gh_set_error(ctx, GH_ERR_ARG, "gh_graph_solve: intrinsics need the pinhole projection");
+    GH_CHECK_ARG(ctx, gpr->intrinsics[0] != 0.0 && gpr->intrinsics[1] != 0.0 && (gpr->intrinsics_free & ~0x1FF) == 0);
+  }
   const double* obs_meas = gpr->projection ? gpr->obs_bearing : gpr->obs_xy;
   const int ms = gpr->projection ? 3 : 2;
   GH_CHECK_ARG(ctx, no == 0 || (gpr->obs_kind && gpr->obs_point && gpr->obs_frame && obs_meas));
@@ -1080,7 +1272,8 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
     std::vector<int32_t> fill(lstart.begin(), lstart.end() - 1);
     for (int k = 0; k < no; ++k) llist[fill[gpr->obs_kind[k] == 0 ? gpr->obs_point[k] : nx + gpr->obs_point[k]]++] = k;
   }
-  const int n = 7 * nf;
+  const int n = 7 * nf + (with_cam ? 9 : 0);  // the intrinsics follow the keyframes
+  const int rec = with_cam ? kObsRecCam : kObsRec;
   const int lda = (n + 1 + 15) & ~15;  // one spare row: the right-hand side rides through the factorisation (gh_potrf_solve_dev)
   // A large pose graph (no landmarks) is solved block-sparse: bsparse.h.  GSLAM_HIP_PG_SPARSE_MIN = keyframes from which
   // it is used (0: always; default 384 -- below it the dense system is a single-launch factorisation and bitwise
@@ -1124,7 +1317,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GraphArena A(ctx);
   double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H = nullptr, *d_Hd = nullptr, *d_g, *d_d, *d_out;
   double *d_xyz, *d_xyz_new, *d_rho, *d_rho_new, *d_anchor, *d_oxy, *d_oinfo = nullptr, *d_orec, *d_Hpp, *d_gp, *d_Hinv, *d_dlm, *d_term,
-      *d_part, *d_Wh;
+      *d_part, *d_Wh, *d_cam = nullptr, *d_cam_new = nullptr, *d_Wc = nullptr;
   int32_t *d_dof, *d_etype, *d_ei, *d_ej, *d_vstart, *d_vlist, *d_pstart, *d_plist, *d_prow, *d_pcol, *d_host, *d_okind, *d_opoint,
       *d_oframe, *d_lstart, *d_llist, *d_lmdim, *d_hrep;
   uint8_t *d_xfree = nullptr, *d_ifree = nullptr, *d_valid;
@@ -1144,15 +1337,16 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
            A.alloc(&d_host, ni1) && A.alloc(&d_oxy, no1 * 3) && (!gpr->obs_info || A.alloc(&d_oinfo, no1 * 4)) && A.alloc(&d_okind, no1) &&
            A.alloc(&d_opoint, no1) && A.alloc(&d_oframe, no1) && A.alloc(&d_lstart, lstart.size()) && A.alloc(&d_llist, llist.size()) &&
            (!gpr->xyz_free || A.alloc(&d_xfree, nx1)) && (!gpr->idp_free || A.alloc(&d_ifree, ni1)) &&
+           (!with_cam || A.alloc(&d_cam, 9)) &&
            (!sparse || (A.alloc(&d_bs_off, bs_off.size()) && A.alloc(&d_bs_sp, bs_sp.size()) && A.alloc(&d_bs_sq, bs_sq.size()) &&
                         BS.alloc_dev(A))) &&
            // work arrays
            A.alloc(&d_Snew, (size_t)nf * 8) && A.alloc(&d_rec, (size_t)kEdgeRec * PH.etype.size()) && A.alloc(&d_cost_e, PH.etype.size()) &&
            A.alloc(&d_g, (size_t)n) && A.alloc(&d_d, (size_t)n) && A.alloc(&d_out, 4) && A.alloc(&d_gmax, 1) && A.alloc(&d_xyz_new, nx1 * 3) &&
-           A.alloc(&d_rho_new, ni1) && A.alloc(&d_orec, no1 * kObsRec) && A.alloc(&d_Hpp, nlm1 * 9) && A.alloc(&d_gp, nlm1 * 3) &&
+           A.alloc(&d_rho_new, ni1) && A.alloc(&d_orec, no1 * rec) && A.alloc(&d_Hpp, nlm1 * 9) && A.alloc(&d_gp, nlm1 * 3) &&
            A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) && A.alloc(&d_term, (size_t)std::max(n_items, 1)) &&
            A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_lmdim, nlm1) && A.alloc(&d_hrep, nlm1) && A.alloc(&d_Wh, nlm1 * 7) &&
-           A.alloc(&d_valid, no1) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda)));
+           A.alloc(&d_valid, no1) && (!with_cam || (A.alloc(&d_cam_new, 9) && A.alloc(&d_Wc, nlm1 * 27))) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda)));
   };
   alloc_all();  // measuring pass
   GH_TRY(A.reserve());
@@ -1184,6 +1378,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   A.upload(d_llist, llist.data(), llist.size() * 4);
   if (gpr->xyz_free) A.upload(d_xfree, gpr->xyz_free, (size_t)nx);
   if (gpr->idp_free) A.upload(d_ifree, gpr->idp_free, (size_t)ni);
+  if (with_cam) A.upload(d_cam, gpr->intrinsics, 72);
   if (sparse) {
     A.upload(d_bs_off, bs_off.data(), bs_off.size() * 8);
     A.upload(d_bs_sp, bs_sp.data(), bs_sp.size() * 4);
@@ -1214,7 +1409,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
   PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, PH.n_pairs};
   GrLandmarks LM{nx, ni, no, d_xfree, d_host, d_anchor, d_ifree, d_okind, d_opoint, d_oframe, d_oxy, d_oinfo, d_lstart, d_llist,
-                 opt.huber_delta, gpr->projection};
+                 opt.huber_delta, gpr->projection, with_cam ? 1 : 0, with_cam ? gpr->intrinsics_free : 0, nf, rec};
   const int eb = gh_div_up(ne > 0 ? ne : 1, 64), eb4 = gh_div_up(ne > 0 ? ne : 1, 4), ob = gh_div_up(no > 0 ? no : 1, 128);
   // sum of v[0..count) into d_out[slot]: fixed order (1024 per block, then the partials one after the other)
   auto reduce_to = [&](const double* v, int count, int slot) -> gh_status {
@@ -1224,14 +1419,15 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
     return GH_OK;
   };
   // d_out[0] = cost of the pose edges, d_out[2] = cost of the observations at (S, xyz, rho)
-  auto enqueue_cost = [&](const double* S_dev, const double* xyz_dev, const double* rho_dev, const uint8_t* was_valid) -> gh_status {
+  auto enqueue_cost = [&](const double* S_dev, const double* xyz_dev, const double* rho_dev, const double* cam_dev,
+                          const uint8_t* was_valid) -> gh_status {
     if (ne > 0) GH_LAUNCH(ctx, "pg_cost", pg_cost_kernel, dim3(eb), dim3(64), 0, G, S_dev, d_cost_e);
     GH_TRY(reduce_to(d_cost_e, ne, 0));
-    if (no > 0) GH_LAUNCH(ctx, "gr_cost", gr_cost_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, S_dev, xyz_dev, rho_dev, was_valid, d_term);
+    if (no > 0) GH_LAUNCH(ctx, "gr_cost", gr_cost_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, S_dev, xyz_dev, rho_dev, cam_dev, was_valid, d_term);
     GH_TRY(reduce_to(d_term, no, 2));
     return GH_OK;
   };
-  GH_TRY(enqueue_cost(d_S, d_xyz, d_rho, nullptr));
+  GH_TRY(enqueue_cost(d_S, d_xyz, d_rho, d_cam, nullptr));
   GH_HIP(ctx, hipMemcpyAsync(host4, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double cost = host4[0] + host4[2];
@@ -1254,9 +1450,10 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       else
         GH_LAUNCH(ctx, "pg_assemble", pg_assemble_kernel, dim3(nf + PH.n_pairs), dim3(64), 0, G, Ls, (const double*)d_rec, d_H, lda,
                   d_g, d_gmax);
+      if (with_cam) GH_HIP(ctx, hipMemsetAsync(d_g + 7 * nf, 0, 72, ctx->stream));  // (pg_assemble stores the keyframe rows only)
       if (no > 0)
         GH_LAUNCH(ctx, "gr_obs_lin", gr_obs_lin_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, (const double*)d_S,
-                  (const double*)d_xyz, (const double*)d_rho, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp);
+                  (const double*)d_xyz, (const double*)d_rho, (const double*)d_cam, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp);
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_LAUNCH(ctx, "gr_gmax", gr_gmax_kernel, dim3(gh_div_up(n + 3 * nlm, 256)), dim3(256), 0, (const double*)d_g, n,
                 (const double*)d_gp, 3 * nlm, d_gmax);
@@ -1271,11 +1468,15 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
                 n, lda, (const double*)d_g, d_d, radius);
     if (nlm > 0) {
       GH_LAUNCH(ctx, "gr_lm_prepare", gr_lm_prepare_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
-                (const double*)d_Hpp, (const double*)d_orec, radius, d_Hinv, d_lmdim, d_Wh, d_hrep);
+                (const double*)d_Hpp, (const double*)d_orec, radius, d_Hinv, d_lmdim, d_Wh, d_hrep, d_Wc);
       if (no > 0)
         GH_LAUNCH(ctx, "gr_schur", gr_schur_kernel, dim3(gh_div_up(2 * no, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
                   (const double*)d_gp, d_Hd, lda, d_d);
+      if (with_cam)
+        GH_LAUNCH(ctx, "gr_schur_cam", gr_schur_cam_kernel, dim3(gh_div_up(nlm, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
+                  (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
+                  (const double*)d_Wc, (const double*)d_gp, d_Hd, lda, d_d);
     }
     int info = 0;
     const double t_s0 = now_ms_pg();
@@ -1310,8 +1511,9 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
                 (const double*)d_S, (const double*)d_d, d_Snew);
       if (nlm > 0)
         GH_LAUNCH(ctx, "gr_update", gr_update_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, nx, ni, (const double*)d_xyz,
-                  (const double*)d_rho, (const double*)d_dlm, d_xyz_new, d_rho_new);
-      GH_TRY(enqueue_cost(d_Snew, d_xyz_new, d_rho_new, d_valid));
+                  (const double*)d_rho, (const double*)d_dlm, d_xyz_new, d_rho_new, (const double*)d_cam,
+                  (const double*)(d_d + 7 * nf), with_cam ? gpr->intrinsics_free : 0, d_cam_new);
+      GH_TRY(enqueue_cost(d_Snew, d_xyz_new, d_rho_new, d_cam_new, d_valid));
       GH_HIP(ctx, hipMemcpyAsync(host4, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
       GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
       new_cost = host4[0] + host4[2];
@@ -1334,6 +1536,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       std::swap(d_S, d_Snew);
       std::swap(d_xyz, d_xyz_new);
       std::swap(d_rho, d_rho_new);
+      std::swap(d_cam, d_cam_new);
       const double t = 2.0 * rho - 1.0;
       radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
       if (radius > 1e16) radius = 1e16;
@@ -1362,17 +1565,19 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   sum->final_cost = cost;
   {  // results: through the pinned block too (the read-back words are not needed any more)
     const size_t bS = (size_t)nf * 64, bX = (size_t)nx * 24, bR = (size_t)ni * 8;
-    const size_t oX = (bS + 255) & ~(size_t)255, oR = oX + ((bX + 255) & ~(size_t)255);
+    const size_t oX = (bS + 255) & ~(size_t)255, oR = oX + ((bX + 255) & ~(size_t)255), oC = oR + ((bR + 255) & ~(size_t)255);
     void* hp = nullptr;
-    GH_TRY(gh_pinned(ctx, oR + bR + 256, &hp));
+    GH_TRY(gh_pinned(ctx, oC + 72 + 256, &hp));
     char* h = static_cast<char*>(hp);
     GH_HIP(ctx, hipMemcpyAsync(h, d_S, bS, hipMemcpyDeviceToHost, ctx->stream));
     if (nx) GH_HIP(ctx, hipMemcpyAsync(h + oX, d_xyz, bX, hipMemcpyDeviceToHost, ctx->stream));
     if (ni) GH_HIP(ctx, hipMemcpyAsync(h + oR, d_rho, bR, hipMemcpyDeviceToHost, ctx->stream));
+    if (with_cam) GH_HIP(ctx, hipMemcpyAsync(h + oC, d_cam, 72, hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(pr->frame_sim3, h, bS);
     if (nx) memcpy(gpr->xyz, h + oX, bX);
     if (ni) memcpy(gpr->idp_rho, h + oR, bR);
+    if (with_cam) memcpy(gpr->intrinsics, h + oC, 72);
   }
   sum->total_ms = now_ms_pg() - t_begin;
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;

@@ -70,7 +70,7 @@ class GraphProblem(C.Structure):
                 ("n_idp", C.c_int32), ("idp_host", C.c_void_p), ("idp_anchor", C.c_void_p), ("idp_rho", C.c_void_p),
                 ("idp_free", C.c_void_p), ("n_obs", C.c_int32), ("obs_kind", C.c_void_p), ("obs_point", C.c_void_p),
                 ("obs_frame", C.c_void_p), ("obs_xy", C.c_void_p), ("obs_info", C.c_void_p), ("projection", C.c_int32),
-                ("obs_bearing", C.c_void_p)]
+                ("obs_bearing", C.c_void_p), ("intrinsics", C.c_void_p), ("intrinsics_free", C.c_int32)]
 
 
 class BaOptions(C.Structure):

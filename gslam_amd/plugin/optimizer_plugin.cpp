@@ -15,7 +15,8 @@
 //                                           invDepthObserves, :106-111,152-153,160) or pose-graph edges TOGETHER with
 //                                           point observations: the general solver (SIM3 keyframes, both landmark kinds)
 //                                           and every graph with observations under PROJECTION_SPHERE
-// Still `return false` ("unsupported", as the interface allows): camera self-calibration.
+// Camera self-calibration (BundleGraph::camera + cameraDOF) of PinHole / OpenCV cameras goes through the general graph solve;
+// still `return false` ("unsupported", as the interface allows): self-calibration of other camera models or under PROJECTION_SPHERE.
 // (optimizePnP / optimizePose under PROJECTION_SPHERE go through the general graph solver: optimizePnPSphere.)
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
@@ -40,8 +41,13 @@ class OptimizerHIP : public GSLAM::Optimizer {
   }
 
   bool optimize(GSLAM::BundleGraph& graph) override {
-    if (graph.cameraDOF != GSLAM::UPDATE_CAMERA_NONE && graph.camera.isValid())
-      return unsupported("camera self-calibration");
+    // Self-calibration (BundleGraph::camera + cameraDOF): the intrinsics join the unknowns of the general graph solve.
+    if (graph.cameraDOF != GSLAM::UPDATE_CAMERA_NONE && graph.camera.isValid()) {
+      if (_config.cameraProjectionType == GSLAM::PROJECTION_SPHERE) return unsupported("camera self-calibration under PROJECTION_SPHERE");
+      const std::string type = graph.camera.CameraType();
+      if (type != "PinHole" && type != "OpenCV") return unsupported("camera self-calibration of a camera that is neither PinHole nor OpenCV");
+      if (calibrationMask(graph) != 0) return optimizeGeneral(graph);
+    }
     const bool pose_edges = !graph.se3Graph.empty() || !graph.sim3Graph.empty() || !graph.gpsGraph.empty();
     const bool sphere = _config.cameraProjectionType == GSLAM::PROJECTION_SPHERE;
     const bool observations = !graph.mappointObserves.empty() || !graph.invDepthObserves.empty();
@@ -322,8 +328,39 @@ class OptimizerHIP : public GSLAM::Optimizer {
   // of its host keyframe (InvDepthEstimation::frameId), the anchor taken on the z = 1 plane; UPDATE_ID_IDEPTH frees the
   // inverse depth, sigma is carried through untouched.  PROJECTION_SPHERE: anchors and measurements are bearings (normalised
   // to unit length here), the inverse depth is an inverse range, the residual lives in the tangent plane of the measurement.
+  // CameraEstimationDOF (Optimizer.h:86-100) -> the free-parameter mask of gh_graph_problem::intrinsics (fx fy cx cy k1 k2 p1 p2 k3);
+  // a PinHole camera has no distortion parameters to free
+  static int calibrationMask(const GSLAM::BundleGraph& graph) {
+    if (graph.cameraDOF == GSLAM::UPDATE_CAMERA_NONE || !graph.camera.isValid()) return 0;
+    const int d = (int)graph.cameraDOF;
+    int m = 0;
+    if (d & GSLAM::UPDATE_CAMERA_FOCAL) m |= 3;
+    if (d & GSLAM::UPDATE_CAMERA_CENTER) m |= 12;
+    if (d & GSLAM::UPDATE_CAMERA_K1) m |= 1 << 4;
+    if (d & GSLAM::UPDATE_CAMERA_K2) m |= 1 << 5;
+    if (d & GSLAM::UPDATE_CAMERA_P1) m |= 1 << 6;
+    if (d & GSLAM::UPDATE_CAMERA_P2) m |= 1 << 7;
+    if (d & GSLAM::UPDATE_CAMERA_K3) m |= 1 << 8;
+    if (graph.camera.CameraType() == "PinHole") m &= 15;
+    return m;
+  }
+
+  // With a camera to calibrate (calibrationMask != 0): the measurements stay what they are everywhere else in GSLAM --
+  // CameraAnchors, i.e. camera.UnProject(pixel) of the camera the graph carries -- and are taken back to pixels through that
+  // camera's own Project; the solve then minimises the PIXEL error over keyframes, landmarks and the freed intrinsics
+  // (gh_graph_problem::intrinsics), and graph.camera is replaced by the estimate.  projectErrorHuberThreshold and the 2x2
+  // informations are given on the z = 1 plane: scaled by the focal lengths (threshold x sqrt(fx fy), information(a, b) /
+  // (f_a f_b)).  Anchors of inverse-depth points keep the normalised value the initial camera gave them.
   bool optimizeGeneral(GSLAM::BundleGraph& graph) {
     const bool sphere = _config.cameraProjectionType == GSLAM::PROJECTION_SPHERE;
+    const int calib = sphere ? 0 : calibrationMask(graph);
+    double cam[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<double> cam_params;
+    if (calib) {
+      cam_params = graph.camera.getParameters();  // PinHole: w h fx fy cx cy; OpenCV: + k1 k2 p1 p2 k3
+      if (cam_params.size() != 6 && cam_params.size() != 11) return unsupported("camera with an unexpected parameter list");
+      for (size_t k = 2; k < cam_params.size(); ++k) cam[k - 2] = cam_params[k];
+    }
     if (graph.keyframes.empty() || !context()) return false;
     const size_t nf = graph.keyframes.size(), np = graph.mappoints.size(), ni = graph.invDepths.size();
     std::vector<double> frames(nf * 8);
@@ -378,11 +415,20 @@ class OptimizerHIP : public GSLAM::Optimizer {
         okind.push_back(kind);
         opoint.push_back((int32_t)e.pointId);
         oframe.push_back((int32_t)e.frameId);
-        oxy.push_back(m.x / mn);
-        oxy.push_back(m.y / mn);
-        if (sphere) oxy.push_back(m.z / mn);
+        if (calib) {
+          const GSLAM::Point2d px = graph.camera.Project(GSLAM::Point3d(m.x / mn, m.y / mn, 1.0));
+          oxy.push_back(px.x);
+          oxy.push_back(px.y);
+        } else {
+          oxy.push_back(m.x / mn);
+          oxy.push_back(m.y / mn);
+          if (sphere) oxy.push_back(m.z / mn);
+        }
         if (any_info)
-          for (int a = 0; a < 4; ++a) oinfo.push_back(e.information ? e.information[a] : ((a == 0 || a == 3) ? 1.0 : 0.0));
+          for (int a = 0; a < 4; ++a) {
+            const double v = e.information ? e.information[a] : ((a == 0 || a == 3) ? 1.0 : 0.0);
+            oinfo.push_back(calib ? v / (cam[a >> 1] * cam[a & 1]) : v);
+          }
       }
     }
     gp.n_xyz = (int32_t)np; gp.xyz = xyz.data(); gp.xyz_free = xfree.data();
@@ -391,9 +437,13 @@ class OptimizerHIP : public GSLAM::Optimizer {
     gp.obs_info = any_info ? oinfo.data() : NULL;
     gp.projection = sphere ? 1 : 0;
     (sphere ? gp.obs_bearing : gp.obs_xy) = oxy.data();
+    if (calib) {
+      gp.intrinsics = cam;
+      gp.intrinsics_free = calib;
+    }
     gh_ba_options o;
     gh_ba_default_options(&o);
-    o.huber_delta = _config.projectErrorHuberThreshold;
+    o.huber_delta = _config.projectErrorHuberThreshold * (calib ? std::sqrt(std::fabs(cam[0] * cam[1])) : 1.0);
     o.max_iterations = _config.maxIterations;
     o.verbose = _config.verbose ? 1 : 0;
     gh_ba_summary s;
@@ -415,6 +465,11 @@ class OptimizerHIP : public GSLAM::Optimizer {
     }
     for (size_t i = 0; i < np; ++i) graph.mappoints[i].first = GSLAM::Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     for (size_t i = 0; i < ni; ++i) graph.invDepths[i].estimation.x = rho[i];
+    if (calib) {
+      for (size_t k = 2; k < cam_params.size(); ++k) cam_params[k] = cam[k - 2];
+      graph.camera = GSLAM::Camera(cam_params);
+      if (_config.verbose) LOG(INFO) << "OptimizerHIP: calibrated camera " << graph.camera.info();
+    }
     return true;
   }
 

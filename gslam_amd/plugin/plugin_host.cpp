@@ -51,6 +51,76 @@ static std::vector<T> read_vec(std::ifstream& f, size_t n) {
 // Optimizer::magin through the plugin: same input file as run_ba; out = int32 ok, int32 n_edges, then per edge
 // int32 first, int32 second, 7 doubles measurement [qx qy qz qw tx ty tz], 36 doubles information; then the converted
 // graph (keyframes + SE3 edges, no observations) goes back through optimize() -- the pose-graph path of the same plugin.
+// Self-calibrating bundle adjustment through Optimizer::optimize (BundleGraph::camera + cameraDOF, Optimizer.h:86-100,
+// 169-171).  The host does what a GSLAM front end does: pixels -> CameraAnchors with the camera it believes in
+// (camera.UnProject), the graph carries that camera and the parameters to free.  File: int32 {nc, np, no, camera dof,
+// max iterations, n camera parameters}, double huber (on the z = 1 plane), camera parameters (w h fx fy cx cy [k1 k2 p1 p2 k3]),
+// poses nc x 7, keyframe dof nc, points np x 3, observation frame / point no each, pixels no x 2.
+static int run_calib(const std::string& dir, const char* in, const char* out) {
+  svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[6];
+  f.read((char*)hdr, sizeof(hdr));
+  double huber;
+  f.read((char*)&huber, 8);
+  const int nc = hdr[0], np = hdr[1], no = hdr[2];
+  std::vector<double> cam = read_vec<double>(f, hdr[5]);
+  std::vector<double> pose = read_vec<double>(f, (size_t)nc * 7);
+  std::vector<int32_t> dof = read_vec<int32_t>(f, nc);
+  std::vector<double> xyz = read_vec<double>(f, (size_t)np * 3);
+  std::vector<int32_t> ocam = read_vec<int32_t>(f, no), opt = read_vec<int32_t>(f, no);
+  std::vector<double> px = read_vec<double>(f, (size_t)no * 2);
+  OptimizerPtr opt_ptr = Optimizer::create();
+  if (!opt_ptr) { std::cerr << "Optimizer::create() returned null\n"; return 2; }
+  opt_ptr->_config.projectErrorHuberThreshold = huber;
+  opt_ptr->_config.maxIterations = hdr[4];
+  BundleGraph g;
+  g.camera = Camera(cam);
+  g.cameraDOF = (CameraEstimationDOF)hdr[3];
+  g.keyframes.resize(nc);
+  for (int i = 0; i < nc; ++i) {
+    const double* p = &pose[(size_t)i * 7];
+    g.keyframes[i].estimation = SIM3(SO3(p[0], p[1], p[2], p[3]), Point3d(p[4], p[5], p[6]), 1.0);
+    g.keyframes[i].dof = (KeyFrameEstimzationDOF)dof[i];
+  }
+  g.mappoints.resize(np);
+  for (int i = 0; i < np; ++i) g.mappoints[i] = std::make_pair(Point3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), true);
+  g.mappointObserves.resize(no);
+  double worst_roundtrip = 0;
+  for (int k = 0; k < no; ++k) {
+    BundleEdge e;
+    e.pointId = opt[k];
+    e.frameId = ocam[k];
+    e.measurement = g.camera.UnProject(Point2d(px[2 * k], px[2 * k + 1]));
+    const Point2d back = g.camera.Project(e.measurement);
+    worst_roundtrip = std::max(worst_roundtrip, std::max(std::fabs(back.x - px[2 * k]), std::fabs(back.y - px[2 * k + 1])));
+    e.information = NULL;
+    g.mappointObserves[k] = e;
+  }
+  const bool ok = opt_ptr->optimize(g);
+  const std::vector<double> res = g.camera.getParameters();
+  std::cout.precision(9);
+  std::cout << "calib=" << ok << " camera=" << g.camera.info() << " unproject_project_roundtrip_px=" << worst_roundtrip << std::endl;
+  std::ofstream o(out, std::ios::binary);
+  int32_t okv = ok ? 1 : 0, n = (int32_t)res.size();
+  o.write((char*)&okv, 4);
+  o.write((char*)&n, 4);
+  o.write((char*)res.data(), res.size() * 8);
+  o.write((char*)&worst_roundtrip, 8);
+  for (int i = 0; i < nc; ++i) {
+    const SIM3& T = g.keyframes[i].estimation;
+    const SO3 r = T.get_rotation();
+    const Point3d t = T.get_translation();
+    double m[7] = {r.x, r.y, r.z, r.w, t.x, t.y, t.z};
+    o.write((char*)m, sizeof(m));
+  }
+  for (int i = 0; i < np; ++i) {
+    double m[3] = {g.mappoints[i].first.x, g.mappoints[i].first.y, g.mappoints[i].first.z};
+    o.write((char*)m, sizeof(m));
+  }
+  return ok ? 0 : 3;
+}
+
 static int run_magin(const std::string& dir, const char* in, const char* out) {
   svar.GetString("OptimizerPlugin", "") = dir + "/libgslam_optimizer.so";
   std::ifstream f(in, std::ios::binary);
@@ -951,6 +1021,7 @@ int main(int argc, char** argv) {
   if (mode == "ba" && argc >= 5)
     return run_ba(dir, argv[3], argv[4], argc >= 6 ? atof(argv[5]) : 1.0, argc >= 7 ? atoi(argv[6]) : -1);
   if (mode == "magin" && argc >= 5) return run_magin(dir, argv[3], argv[4]);
+  if (mode == "calib" && argc >= 5) return run_calib(dir, argv[3], argv[4]);
   if (mode == "pnp" && argc >= 5) return run_pnp(dir, argv[3], argv[4], argc >= 6 ? atoi(argv[5]) : 0);
   if (mode == "pg" && argc >= 5) return run_pg(dir, argv[3], argv[4]);
   if (mode == "align" && argc >= 5) return run_align(dir, argv[3], argv[4]);

@@ -53,7 +53,9 @@ def solve_graph(ctx: hip.Context, frames, dof, problem: dict, options=None):
     """The general BundleGraph (gh_graph_solve): the pose-edge keys of solve() plus
       "xyz": (points n x 3, free mask | None), "idp": (host, anchor n x 3, rho, free mask | None),
       "obs": (kind, point, frame, xy n x 2, info n x 4 | None)            (gslam_amd.pg_synth.make_landmark_graph).
-    options.huber_delta = the projection Huber threshold.  -> (frames, xyz, rho, summary, status)."""
+      "intrinsics": (fx fy cx cy k1 k2 p1 p2 k3, free-parameter bit mask) -- camera self-calibration: `xy` are pixels then
+    options.huber_delta = the projection Huber threshold.  -> (frames, xyz, rho, summary, status), or with "intrinsics"
+    (frames, xyz, rho, intrinsics, summary, status)."""
     options = options or default_options()
     S = np.ascontiguousarray(frames, dtype=np.float64).copy()
     d = np.ascontiguousarray(dof, dtype=np.int32)
@@ -76,11 +78,16 @@ def solve_graph(ctx: hip.Context, frames, dof, problem: dict, options=None):
     sphere = problem.get("projection") == "sphere"  # then `xy` is n x 3 unit bearings
     gp.n_obs, gp.obs_kind, gp.obs_point, gp.obs_frame, gp.obs_info = len(kind), _p(kind), _p(point), _p(frame), _p(oinfo)
     gp.projection, gp.obs_xy, gp.obs_bearing = (1, None, _p(xy)) if sphere else (0, _p(xy), None)
+    cam = None
+    if problem.get("intrinsics") is not None:
+        cam = np.ascontiguousarray(problem["intrinsics"][0], dtype=np.float64).copy()
+        keep.append(cam)
+        gp.intrinsics, gp.intrinsics_free = _p(cam), int(problem["intrinsics"][1])
     sm = hip.BaSummary()
     st = hip.lib.gh_graph_solve(ctx.h, C.byref(gp), C.byref(options), C.byref(sm))
     if st not in (0, 4):
         ctx.check(st)
-    return S, xyz, rho, sm, st
+    return (S, xyz, rho, sm, st) if cam is None else (S, xyz, rho, cam, sm, st)
 
 
 def align_sim3(ctx: hip.Context, src, dst, dof=127):

@@ -586,6 +586,15 @@ typedef struct gh_graph_problem {
   const double *obs_xy, *obs_info;
   int32_t projection;        /* 0 = PROJECTION_PINHOLE (obs_xy), 1 = PROJECTION_SPHERE (obs_bearing; Optimizer.h:58-61,175) */
   const double* obs_bearing; /* n_obs x 3 unit bearings, sphere only: anchors are unit bearings too, idepth = 1 / range */
+  /* Camera self-calibration -- BundleGraph::camera + cameraDOF (Optimizer.h:86-100,169-171: "Invalid camera indicates idea
+   * camera").  intrinsics = fx fy cx cy k1 k2 p1 p2 k3 of GSLAM's OpenCV camera model (GSLAM/core/Camera.h:386-407; a
+   * pinhole camera :213-227 has k = p = 0), in / out; NULL = ideal camera.  With intrinsics, obs_xy are PIXELS, the residual
+   * is Project(Y) - obs_xy (Huber threshold and obs_info in pixel units), and the parameters whose bit is set in
+   * intrinsics_free (bit i = parameter i; CameraEstimationDOF: FOCAL -> bits 0-1, CENTER -> 2-3, K1 4, K2 5, P1 6, P2 7,
+   * K3 8) are unknowns of the same Levenberg-Marquardt problem (a 9-row block behind the keyframes in the reduced system).
+   * Anchors of inverse-depth points stay normalised.  Pinhole projection only (GH_ERR_ARG with projection = 1). */
+  double* intrinsics;
+  int32_t intrinsics_free;
 } gh_graph_problem;
 gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* problem, const gh_ba_options* options, gh_ba_summary* summary);
 

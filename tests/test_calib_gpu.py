@@ -1,0 +1,108 @@
+"""GPU parity of camera self-calibration in gh_graph_solve (BundleGraph::camera + cameraDOF, GSLAM/core/Optimizer.h:86-100,
+169-171) against oracle/graph_oracle.c through the C ABI: same LM trace, same intrinsics, same state.  The projection model
+itself is pinned to the reference's Camera::Project in tests/test_calib_oracle.py."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from gslam_amd.pg_synth import make_landmark_graph, with_camera
+from lm_trace import assert_same_trace
+
+pytestmark = pytest.mark.gpu
+
+CAM = np.array([520.0, 515.0, 318.0, 242.0, -0.28, 0.09, 1.2e-3, -8e-4, -0.01])
+
+
+def _opts(huber, iters):
+    from gslam_amd.ba import default_options
+    o = default_options()
+    o.huber_delta = huber
+    o.max_iterations = iters
+    return o
+
+
+def _start_cam(free, rel=0.04):
+    c = CAM.copy()
+    sgn = np.array([1, -1, 1, -1, 1, -1, 1, -1, 1.0])
+    for k in range(9):
+        if (free >> k) & 1:
+            c[k] = CAM[k] * (1 + rel * sgn[k]) if k < 4 else CAM[k] + 0.02 * sgn[k] * (0.05 if k in (6, 7) else 1.0)
+    return c
+
+
+def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-6):
+    from gslam_amd import posegraph
+    oo = oracle_lib.ba_options(huber=huber, max_iterations=iters)
+    S0, x0, r0, c0, so, st0 = oracle.graph_solve_cam(start, dof, prob, oo)
+    S1, x1, r1, c1, sg, st1 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, iters))
+    assert st0 == 0 and st1 == 0
+    if assert_same_trace(sg, so, rtol):  # (decisions in the settled tail may differ: lm_trace.py)
+        assert np.allclose(c1[:4], c0[:4], rtol=1e-7) and np.allclose(c1[4:], c0[4:], atol=1e-7), (c1 - c0)
+        assert np.allclose(S1, S0, atol=1e-6) and np.allclose(x1, x0, atol=1e-5) and np.allclose(r1, r0, rtol=1e-5, atol=1e-8)
+    else:
+        assert np.allclose(c1[:4], c0[:4], rtol=1e-3) and np.allclose(c1[4:], c0[4:], atol=1e-2), (c1 - c0)
+    return so, sg, c1
+
+
+@pytest.mark.parametrize("free,n_xyz,n_idp,with_info,huber", [
+    (0b000000011, 300, 0, False, 2.0),      # focal only
+    (0b000001111, 200, 100, False, 2.0),    # pinhole, both landmark kinds
+    (0b000111111, 300, 100, True, 3.0),     # + k1 k2, 2x2 informations
+    (0b111111111, 400, 0, False, 0.0),      # everything, no robust kernel
+    (0, 150, 150, False, 2.0),              # a fixed camera: pixels, nothing to estimate
+])
+def test_calibration_matches_the_oracle(ctx, oracle, free, n_xyz, n_idp, with_info, huber):
+    truth, start, dof, base = make_landmark_graph(n_frames=12, n_xyz=n_xyz, n_idp=n_idp, kind="se3", seed=33, noise=0.0,
+                                                  with_info=with_info, outliers=0.03 if huber > 0 else 0.0, obs_per_point=6)
+    prob = with_camera(base, CAM, _start_cam(free), free, pixel_noise=0.3, seed=5)
+    # (all nine free: rejected steps far from the minimum amplify the summation-order differences to ~1e-6 relative)
+    so, sg, cam = _compare(ctx, oracle, start, dof, prob, huber, rtol=1e-4 if free == 0x1FF else 1e-6)
+    assert so.final_cost < 0.2 * so.initial_cost
+    fixed = [k for k in range(9) if not (free >> k) & 1]
+    assert np.array_equal(cam[fixed], prob["intrinsics"][0][fixed])
+    if free & 3 and free != 0x1FF:  # (all nine free on 60 iterations of noisy data: parity only, the focal / distortion valley is long)
+        assert np.allclose(cam[:2], CAM[:2], rtol=0.01)
+
+
+def test_noise_free_calibration_recovers_the_camera_on_the_gpu(ctx):
+    from gslam_amd import posegraph
+    free = 0b100111111
+    truth, start, dof, base = make_landmark_graph(n_frames=10, n_xyz=200, n_idp=40, kind="se3", seed=12, noise=0.0, perturb=0.02,
+                                                  point_perturb=0.03, obs_per_point=6)
+    prob = with_camera(base, CAM, _start_cam(free), free)
+    o = _opts(0.0, 100)
+    o.function_tolerance = 1e-16
+    S, xyz, rho, cam, sm, st = posegraph.solve_graph(ctx, start, dof, prob, o)
+    assert st in (0, 4) and sm.final_cost < 1e-12 * sm.initial_cost
+    assert np.allclose(cam[:4], CAM[:4], rtol=1e-6) and np.allclose(cam[4:], CAM[4:], atol=1e-6), cam - CAM
+
+
+def test_calibration_with_pose_edges_and_free_scales(ctx, oracle):
+    truth, start, dof, base = make_landmark_graph(n_frames=10, n_xyz=120, n_idp=120, kind="sim3", seed=3, noise=0.0, pose_edges=True,
+                                                  obs_per_point=5)
+    free = 0b000001111
+    prob = with_camera(base, CAM, _start_cam(free, 0.02), free, pixel_noise=0.2, seed=2)
+    _compare(ctx, oracle, start, dof, prob, 2.0)
+
+
+def test_larger_window(ctx, oracle):
+    """60 keyframes, 3000 landmarks, 18 000 observations: the wave-summed intrinsics block under real contention."""
+    truth, start, dof, base = make_landmark_graph(n_frames=60, n_xyz=2500, n_idp=500, kind="se3", seed=41, noise=0.0, obs_per_point=6)
+    free = 0b000011111
+    prob = with_camera(base, CAM, _start_cam(free, 0.03), free, pixel_noise=0.3, seed=8)
+    so, sg, cam = _compare(ctx, oracle, start, dof, prob, 2.0, iters=25, rtol=1e-5)
+    assert np.allclose(cam[:4], CAM[:4], rtol=5e-3)
+
+
+def test_refusals(ctx):
+    from gslam_amd import posegraph
+    truth, start, dof, base = make_landmark_graph(n_frames=4, n_xyz=10, n_idp=0, projection="sphere")
+    base["intrinsics"] = (CAM.copy(), 3)
+    with pytest.raises(Exception):
+        posegraph.solve_graph(ctx, start, dof, base)
+    truth, start, dof, base = make_landmark_graph(n_frames=4, n_xyz=10, n_idp=0)
+    bad = CAM.copy(); bad[0] = 0.0
+    with pytest.raises(Exception):
+        posegraph.solve_graph(ctx, start, dof, with_camera(base, CAM, bad, 3))
+    with pytest.raises(Exception):
+        posegraph.solve_graph(ctx, start, dof, with_camera(base, CAM, CAM, 1 << 9))

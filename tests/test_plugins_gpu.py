@@ -103,6 +103,63 @@ def test_optimizer_plugin_magin(tmp_path, oracle):
         assert np.abs(m[:4] * sgn - q).max() < 1e-12 and np.abs(m[4:] - t).max() < 1e-11
 
 
+@pytest.mark.parametrize("model,dof_flags", [("OpenCV", 1 | 2 | 4 | 8), ("PinHole", 1 | 2 | 4 | 64)])
+def test_optimizer_plugin_self_calibration(tmp_path, ctx, model, dof_flags):
+    """BundleGraph::camera + cameraDOF (GSLAM/core/Optimizer.h:86-100,169-171) through Optimizer::create(): the host turns
+    pixels into CameraAnchors with the reference's own Camera::UnProject of a WRONG camera, optimize() must hand back the
+    camera the pixels were made with (0.1 px of noise) -- and the same camera gh_graph_solve finds on the pixels directly.
+    A PinHole camera ignores the distortion flags."""
+    _need_host()
+    from gslam_amd import posegraph
+    from gslam_amd.ba import default_options
+    from gslam_amd.pg_synth import make_landmark_graph, with_camera
+    truth, start, dof, base = make_landmark_graph(n_frames=10, n_xyz=300, n_idp=0, kind="se3", seed=17, noise=0.0, perturb=0.02,
+                                                  point_perturb=0.03, obs_per_point=6)
+    cam_true = np.array([260.0, 258.0, 318.0, 242.0, -0.05, 0.01, 8e-4, -5e-4, 0.0])  # (a wide lens: the scene fills 640 x 480)
+    cam_start = cam_true * np.array([1.04, 0.97, 1.02, 0.98, 0.9, 1.2, 1, 1, 1])
+    if model == "PinHole":
+        cam_true[4:] = 0.0
+        cam_start[4:] = 0.0
+    free = 0b001111 if model == "PinHole" else 0b111111
+    prob = with_camera(base, cam_true, cam_start, free, pixel_noise=0.1, seed=4)  # (noise: the solve ends on the function tolerance)
+    kind, point, frame, px, _ = prob["obs"]
+    inside = (px[:, 0] >= 0) & (px[:, 0] < 640) & (px[:, 1] >= 0) & (px[:, 1] < 480)  # (what a 640 x 480 sensor sees)
+    kind, point, frame, px = kind[inside], point[inside], frame[inside], px[inside]
+    prob["obs"] = (kind, point, frame, px, None)
+    assert inside.sum() > 800
+    params = np.concatenate([[640.0, 480.0], cam_start[:4] if model == "PinHole" else cam_start])
+    inp, out = tmp_path / "calib.bin", tmp_path / "out.bin"
+    nc, npt, no = len(start), len(prob["xyz"][0]), len(kind)
+    with open(inp, "wb") as f:
+        f.write(np.array([nc, npt, no, dof_flags, 100, len(params)], np.int32).tobytes())
+        f.write(struct.pack("d", 0.0))
+        f.write(params.tobytes())
+        f.write(np.ascontiguousarray(start[:, :7]).tobytes())
+        f.write(np.ascontiguousarray(dof, np.int32).tobytes())
+        f.write(np.ascontiguousarray(prob["xyz"][0]).tobytes())
+        f.write(np.ascontiguousarray(frame, np.int32).tobytes())
+        f.write(np.ascontiguousarray(point, np.int32).tobytes())
+        f.write(np.ascontiguousarray(px).tobytes())
+    r = _run(["calib", LIBDIR, inp, out])
+    assert r.returncode == 0 and "calib=1" in r.stdout, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    ok, n = struct.unpack("ii", raw[:8])
+    got = np.frombuffer(raw, np.float64, n, 8)
+    roundtrip = struct.unpack("d", raw[8 + 8 * n:16 + 8 * n])[0]
+    assert ok == 1 and n == len(params) and np.array_equal(got[:2], [640.0, 480.0]) and roundtrip < 0.05
+    cam = np.zeros(9)
+    cam[:n - 2] = got[2:]
+    # the anchors carry the error of the reference's 5-step UnProject (measured above, in pixels): recovery to that level
+    assert np.allclose(cam[:4], cam_true[:4], rtol=4e-3, atol=20 * roundtrip), (cam, cam_true)
+    assert np.allclose(cam[4:6], cam_true[4:6], atol=1e-2) and np.array_equal(cam[6:], cam_start[6:])
+    o = default_options()
+    o.huber_delta, o.max_iterations = 0.0, 100
+    S, xyz, rho, cam_abi, sm, st = posegraph.solve_graph(ctx, start, dof, prob, o)
+    assert st in (0, 4) and np.allclose(cam[:4], cam_abi[:4], rtol=2e-3, atol=20 * roundtrip) and np.allclose(cam[4:6], cam_abi[4:6], atol=5e-3)
+    poses = np.frombuffer(raw, np.float64, nc * 7, 16 + 8 * n).reshape(nc, 7)
+    assert np.allclose(poses, S[:, :7], atol=2e-3)
+
+
 def test_optimizer_plugin_resident_graph_update_path(tmp_path, oracle):
     """The plugin keeps the graph on the device between optimize() calls (gh_ba_graph_*): a first call on the same
     topology with other values, then the checked call through the update path, must equal the oracle / the one-shot path."""
