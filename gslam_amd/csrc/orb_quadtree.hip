@@ -5,9 +5,13 @@
 // GSLAM/core/Map.h:122-195 KeyPoint rows as the default mode).
 //
 // CDNA4 mapping.
-//   slam_cells     one workgroup per cell: (cell + 6)^2 bytes in LDS, FAST-9/16 score per pixel, 8-neighbour suppression
-//                  inside the cell, candidates appended to the (frame, level) key list (order is irrelevant: every later
-//                  step is a function of the key SET)
+//   slam_cells     one WAVE per cell (cells up to 32 x 32: every level but the smallest ones; four cells per workgroup, no
+//                  block-wide barrier): tile + 3-px ring in LDS by dword loads, compass test on every pixel (exact necessary
+//                  condition), the ~11 % survivors compacted by ballots, the 16-arc score only on those with every lane
+//                  busy, 8-neighbour suppression inside the cell on a zero-bordered score plane, candidates appended to the
+//                  (frame, level) key list (order is irrelevant: every later step is a function of the key SET).  Larger
+//                  cells (a level narrower than 2 x 30 px is ONE column of cells up to 59 px wide) take the plain
+//                  one-workgroup-per-cell kernel.
 //   slam_quadtree  one 1024-lane workgroup per (frame, level).  ORB-SLAM's list of nodes becomes a level-synchronous
 //                  table in LDS: a pass = one sweep over the keys counting the four children of every node being split
 //                  (LDS atomics), one block scan that renumbers the table, one sweep that moves the keys.  The "largest
@@ -82,7 +86,161 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* q, int pitch, int mi
   return best;
 }
 
-// step 4': one workgroup per cell
+// The two halves of fast_score_px for the wave-per-cell kernel: the compass test, and the arc score of a survivor.
+__device__ __forceinline__ bool fast_compass_px(const uint8_t* q, int pitch, int min_th) {
+  const int c = q[0];
+  const int d0 = (int)q[-3 * pitch] - c, d4 = (int)q[3] - c, d8 = (int)q[3 * pitch] - c, d12 = (int)q[-3] - c;
+  const int nb = (d0 > min_th) + (d4 > min_th) + (d8 > min_th) + (d12 > min_th);
+  const int nd = (d0 < -min_th) + (d4 < -min_th) + (d8 < -min_th) + (d12 < -min_th);
+  return nb >= 2 || nd >= 2;
+}
+__device__ __forceinline__ int fast_arc_score_px(const uint8_t* q, int pitch) {
+  const int c = q[0];
+  int d[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[i] = (int)q[kRing.dy[i] * pitch + kRing.dx[i]] - c;
+  int lo[16], hi[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo[i] = min(d[i], d[(i + 1) & 15]);
+    hi[i] = max(d[i], d[(i + 1) & 15]);
+  }
+  int lo4[16], hi4[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo4[i] = min(lo[i], lo[(i + 2) & 15]);
+    hi4[i] = max(hi[i], hi[(i + 2) & 15]);
+  }
+  int best = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int mn = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const int mx = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+    best = max(best, max(mn, -mx));
+  }
+  return best;
+}
+
+// step 4', cells up to kWcMax x kWcMax: one wave per cell, four cells per workgroup (independent: no block-wide barrier)
+constexpr int kWcMax = 32;
+constexpr int kWRowDw = 11;                    // dwords per tile row: (3 bytes of alignment + 32 + 6 + 3) / 4
+constexpr int kWImgPitch = 4 * kWRowDw;        // 44
+constexpr int kWSPitch = 36;                   // score plane (kWcMax + 2)^2 with a zero border, padded rows
+struct WaveCellLds {
+  uint32_t img[(kWcMax + 6) * kWRowDw];        // 1672 B
+  uint32_t S[(kWcMax + 2) * kWSPitch / 4];     // 1224 B
+  uint16_t queue[kWcMax * kWcMax];             // compass survivors, (y << 5) | x: 2048 B
+  uint32_t list[(kWcMax / 2) * (kWcMax / 2)];  // suppressed maxima: at most 16 x 16
+};
+static_assert(sizeof(WaveCellLds) * 4 <= 24 * 1024, "six workgroups per CU");
+
+__global__ __launch_bounds__(256) void slam_cells_wave_kernel(LevelView lv, int ncols, int ncells, int wc, int hc, int min_th,
+                                                              int ini_th, uint32_t* __restrict__ keys, size_t keys_per_frame,
+                                                              uint32_t cap, uint32_t* __restrict__ key_cnt, int level,
+                                                              uint32_t* __restrict__ flags) {
+  __shared__ WaveCellLds sh[4];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.y;
+  const int cell = (int)blockIdx.x * 4 + wv;
+  if (cell >= ncells) return;  // (wave-uniform)
+  WaveCellLds& L = sh[wv];
+  const int ci = cell / ncols, cj = cell - ci * ncols;
+  const int x0 = kEdge + cj * wc, y0 = kEdge + ci * hc;
+  const int x1 = min(x0 + wc, lv.w - kEdge), y1 = min(y0 + hc, lv.h - kEdge);
+  const int cw = x1 - x0, ch = y1 - y0;
+  if (cw <= 0 || ch <= 0) return;
+  const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
+  // tile rows y0 - 3 .. y1 + 2 as the aligned dwords that cover columns x0 - 3 .. x1 + 2 (the level's pitch is a multiple of
+  // 4 and rows are padded to it: checked at the launch); pixel (r, c) of the tile is byte r * 44 + al + c
+  const int xa = (x0 - 3) & ~3, al = (x0 - 3) & 3;
+  const int ndw = (al + cw + 6 + 3) >> 2, nrow = ch + 6;
+  for (int idx = lane; idx < nrow * kWRowDw; idx += 64) {
+    const int r = idx / kWRowDw, d = idx - r * kWRowDw;
+    if (d < ndw) L.img[idx] = *reinterpret_cast<const uint32_t*>(img + (size_t)(y0 - 3 + r) * lv.pitch + xa + 4 * d);
+  }
+  for (int idx = lane; idx < (int)(sizeof(L.S) / 4); idx += 64) L.S[idx] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  const uint8_t* I = reinterpret_cast<const uint8_t*>(L.img) + 3 * kWImgPitch + al + 3;  // pixel (0, 0) of the cell
+  uint8_t* S = reinterpret_cast<uint8_t*>(L.S) + kWSPitch + 1;                            // score of cell pixel (0, 0)
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // compass test on every pixel, survivors queued
+  const int npx = cw * ch;
+  const uint32_t inv = (65536u + (uint32_t)cw - 1u) / (uint32_t)cw;  // p / cw == (p * inv) >> 16 for p < 1024, cw <= 32
+  int nq = 0;
+  for (int base = 0; base < npx; base += 64) {
+    const int p = base + lane;
+    bool pass = false;
+    uint32_t yx = 0;
+    if (p < npx) {
+      const int y = (int)(((uint32_t)p * inv) >> 16), x = p - y * cw;
+      yx = (uint32_t)((y << 5) | x);
+      pass = fast_compass_px(I + y * kWImgPitch + x, kWImgPitch, min_th);
+    }
+    const uint64_t m = __ballot(pass);
+    if (pass) L.queue[nq + __popcll(m & lt_mask)] = (uint16_t)yx;
+    nq += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // arc score of the survivors
+  for (int base = 0; base < nq; base += 64) {
+    const int i = base + lane;
+    if (i < nq) {
+      const int yx = L.queue[i], y = yx >> 5, x = yx & 31;
+      const int s = fast_arc_score_px(I + y * kWImgPitch + x, kWImgPitch);
+      S[y * kWSPitch + x] = (uint8_t)(s > min_th ? min(s, 255) : 0);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // 8-neighbour suppression inside the cell (the border of the score plane is zero: pixels outside the cell do not compete)
+  int n = 0;
+  bool strong = false;
+  for (int base = 0; base < nq; base += 64) {
+    const int i = base + lane;
+    bool ismax = false;
+    uint32_t key = 0;
+    int s = 0;
+    if (i < nq) {
+      const int yx = L.queue[i], y = yx >> 5, x = yx & 31;
+      const uint8_t* sp = S + y * kWSPitch + x;
+      s = sp[0];
+      if (s != 0) {
+        const int n0 = sp[-kWSPitch - 1], n1 = sp[-kWSPitch], n2 = sp[-kWSPitch + 1], n3 = sp[-1], n4 = sp[1],
+                  n5 = sp[kWSPitch - 1], n6 = sp[kWSPitch], n7 = sp[kWSPitch + 1];
+        ismax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7))) < s;
+        key = ((uint32_t)s << 24) | ((uint32_t)(y0 + y) << 12) | (uint32_t)(x0 + x);
+      }
+    }
+    const uint64_t m = __ballot(ismax);
+    if (ismax) L.list[n + __popcll(m & lt_mask)] = key;
+    n += __popcll(m);
+    strong = strong || __ballot(ismax && s > ini_th) != 0ull;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // a strong corner silences the weak ones of the cell
+  int kept = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int e = base + lane;
+    kept += __popcll(__ballot(e < n && (!strong || (int)(L.list[e] >> 24) > ini_th)));
+  }
+  if (kept == 0) return;
+  uint32_t slot0 = 0;
+  if (lane == 0) slot0 = atomicAdd(&key_cnt[b * kMaxL + level], (uint32_t)kept);
+  slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+  uint32_t* out = keys + (size_t)b * keys_per_frame;
+  for (int base = 0; base < n; base += 64) {
+    const int e = base + lane;
+    const uint32_t v = e < n ? L.list[e] : 0u;
+    const bool keep = e < n && (!strong || (int)(v >> 24) > ini_th);
+    const uint64_t m = __ballot(keep);
+    if (keep) {
+      const uint32_t slot = slot0 + (uint32_t)__popcll(m & lt_mask);
+      if (slot < cap) out[slot] = v;
+      else atomicOr(flags, 1u);  // reported by gh_qt_check: never a silent drop
+    }
+    slot0 += (uint32_t)__popcll(m);
+  }
+}
+
+// step 4', any cell size: one workgroup per cell
 __global__ __launch_bounds__(256) void slam_cells_kernel(LevelView lv, int ncols, int wc, int hc, int min_th, int ini_th,
                                                          uint32_t* __restrict__ keys, size_t keys_per_frame,
                                                          uint32_t cap, uint32_t* __restrict__ key_cnt, int level,
@@ -544,8 +702,14 @@ gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int bat
   for (int l = 0; l < q->L; ++l) {
     const QtLevel& v = q->args.lv[l];
     if (v.quota <= 0) continue;
-    GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_kernel, dim3(v.ncols * v.nrows, batch), dim3(256), 0, lv[l], v.ncols, v.wc,
-              v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
+    static const bool wave_cells = getenv("GSLAM_HIP_QT_WAVE_CELLS") == nullptr || atoi(getenv("GSLAM_HIP_QT_WAVE_CELLS")) != 0;  // (A/B switch)
+    if (wave_cells && v.wc <= kWcMax && v.hc <= kWcMax && (lv[l].pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(lv[l].base) & 3) == 0 &&
+        (lv[l].frame_stride & 3) == 0)
+      GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_wave_kernel, dim3(gh_div_up(v.ncols * v.nrows, 4), batch), dim3(256), 0, lv[l], v.ncols,
+                v.ncols * v.nrows, v.wc, v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
+    else
+      GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_kernel, dim3(v.ncols * v.nrows, batch), dim3(256), 0, lv[l], v.ncols, v.wc,
+                v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
   }
   GH_LAUNCH(ctx, "orb_slam_quadtree", slam_quadtree_kernel, dim3(q->L, batch), dim3(kQtThreads), sizeof(QtShared), q->args,
             q->keys, q->knode, q->keys_per_frame, q->key_cnt, K, sel, level_cnt);
