@@ -127,14 +127,15 @@ constexpr int kWRowDw = 11;                    // dwords per tile row: (3 bytes 
 constexpr int kWImgPitch = 4 * kWRowDw;        // 44
 constexpr int kWSPitch = 36;                   // score plane (kWcMax + 2)^2 with a zero border, padded rows
 struct WaveCellLds {
-  uint32_t img[(kWcMax + 6) * kWRowDw];        // 1672 B
+  uint32_t img[(kWcMax + 6) * kWRowDw];        // 1672 B; dead after the arc scores: the list of suppressed maxima (at most
+                                               // 16 x 16 words) takes its place
   uint32_t S[(kWcMax + 2) * kWSPitch / 4];     // 1224 B
   uint16_t queue[kWcMax * kWcMax];             // compass survivors, (y << 5) | x: 2048 B
-  uint32_t list[(kWcMax / 2) * (kWcMax / 2)];  // suppressed maxima: at most 16 x 16
 };
-static_assert(sizeof(WaveCellLds) * 4 <= 24 * 1024, "six workgroups per CU");
+static_assert(sizeof(WaveCellLds) * 4 <= 20 * 1024, "eight workgroups per CU");
+static_assert((kWcMax / 2) * (kWcMax / 2) <= (kWcMax + 6) * kWRowDw, "the maxima fit where the tile was");
 
-__global__ __launch_bounds__(256) void slam_cells_wave_kernel(LevelView lv, int ncols, int ncells, int wc, int hc, int min_th,
+__global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, int ncols, int ncells, int wc, int hc, int min_th,
                                                               int ini_th, uint32_t* __restrict__ keys, size_t keys_per_frame,
                                                               uint32_t cap, uint32_t* __restrict__ key_cnt, int level,
                                                               uint32_t* __restrict__ flags) {
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void slam_cells_wave_kernel(LevelView lv, int 
   const int cell = (int)blockIdx.x * 4 + wv;
   if (cell >= ncells) return;  // (wave-uniform)
   WaveCellLds& L = sh[wv];
+  uint32_t* list = L.img;
   const int ci = cell / ncols, cj = cell - ci * ncols;
   const int x0 = kEdge + cj * wc, y0 = kEdge + ci * hc;
   const int x1 = min(x0 + wc, lv.w - kEdge), y1 = min(y0 + hc, lv.h - kEdge);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void slam_cells_wave_kernel(LevelView lv, int 
       }
     }
     const uint64_t m = __ballot(ismax);
-    if (ismax) L.list[n + __popcll(m & lt_mask)] = key;
+    if (ismax) list[n + __popcll(m & lt_mask)] = key;
     n += __popcll(m);
     strong = strong || __ballot(ismax && s > ini_th) != 0ull;
   }
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void slam_cells_wave_kernel(LevelView lv, int 
   int kept = 0;
   for (int base = 0; base < n; base += 64) {
     const int e = base + lane;
-    kept += __popcll(__ballot(e < n && (!strong || (int)(L.list[e] >> 24) > ini_th)));
+    kept += __popcll(__ballot(e < n && (!strong || (int)(list[e] >> 24) > ini_th)));
   }
   if (kept == 0) return;
   uint32_t slot0 = 0;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void slam_cells_wave_kernel(LevelView lv, int 
   uint32_t* out = keys + (size_t)b * keys_per_frame;
   for (int base = 0; base < n; base += 64) {
     const int e = base + lane;
-    const uint32_t v = e < n ? L.list[e] : 0u;
+    const uint32_t v = e < n ? list[e] : 0u;
     const bool keep = e < n && (!strong || (int)(v >> 24) > ini_th);
     const uint64_t m = __ballot(keep);
     if (keep) {

@@ -36,6 +36,8 @@ BUDGET = {
     "cr_update_kernel": (256, 0),
     "cr_back_kernel": (96, 0),
     "marginalize_pairs_kernel": (512, 0),   # (not hot: one wave per camera pair, 36 + 60 doubles live; no scratch)
+    "slam_cells_wave_kernel": (80, 0),      # quadtree mode: one wave per cell, six workgroups (24 waves) per CU beside 23.9 KB of LDS
+    "gr_schur_cam_kernel": (256, 0),        # self-calibration's Schur slot (one thread per landmark, 27 + 27 doubles live)
     "bow_words_kernel": (64, 0),
     "pack_results_kernel": (32, 0),
 }
