@@ -835,7 +835,8 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
           if (ff[y] < 0 || ff[y] > ff[x]) continue;  // lower triangle of blocks: row frame >= column frame
           for (int q = 0; q < 7; ++q) {
             const double LJ0 = L[0] * Jf[y][q] + L[1] * Jf[y][7 + q], LJ1 = L[2] * Jf[y][q] + L[3] * Jf[y][7 + q];
-            for (int p = 0; p < 7; ++p) {
+            // (a diagonal block is symmetric and the solver reads the lower triangle only: rows p >= q there)
+            for (int p = ff[y] == ff[x] ? q : 0; p < 7; ++p) {
               const double hv = Jf[x][p] * LJ0 + Jf[x][7 + p] * LJ1;
               if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[y] + q) * lda + 7 * ff[x] + p], hv);
             }
@@ -1010,8 +1011,10 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
       } else {
         slot_W(orec + (size_t)G.rec * kb, y, dp, Wb);
       }
+      // (equal frames: the two orders (a, b) and (b, a) are transposes of each other, so their lower triangles add up to the
+      //  lower triangle of the symmetric sum -- the solver reads nothing else)
       for (int c7 = 0; c7 < 7; ++c7)
-        for (int r7 = 0; r7 < 7; ++r7) {
+        for (int r7 = fb == fa ? c7 : 0; r7 < 7; ++r7) {
           const double v = Ua[3 * r7] * Wb[3 * c7] + Ua[3 * r7 + 1] * Wb[3 * c7 + 1] + Ua[3 * r7 + 2] * Wb[3 * c7 + 2];
           if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + 7 * fa + r7], -v);
         }
@@ -1019,33 +1022,31 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
   }
 }
 
-// The intrinsics' slot of the Schur product, one thread per landmark: U_c = W_c (H_pp + D)^-1 (9 x 3); rhs_c += U_c g_p;
-// block(c, c) -= U_c W_c^T; block(c, f) -= U_c W_f^T for every keyframe slot f of the landmark (the intrinsics rows are the
-// last rows: always the lower triangle).  The (c, c) and rhs sums meet in the same words for every landmark: wave sums first.
+// The intrinsics' slot of the Schur product, one thread per observation: U_c = W_c (H_pp + D)^-1 (9 x 3) of the observation's
+// landmark; block(c, f) -= U_c W_f^T for the observation's keyframe slots (the intrinsics rows are the last rows: always the
+// lower triangle); the landmark's FIRST valid observation also carries rhs_c += U_c g_p and block(c, c) -= U_c W_c^T, which
+// meet in the same words for every landmark: wave sums first, one atomic per wave.
 __global__ __launch_bounds__(128) void gr_schur_cam_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
                                                            const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
                                                            const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
                                                            const double* __restrict__ Wc, const double* __restrict__ gp,
                                                            double* __restrict__ Hd, int lda, double* __restrict__ d) {
-  const int p = blockIdx.x * 128 + threadIdx.x;
-  const int nlm = G.n_xyz + G.n_idp;
-  const int dp = p < nlm ? lmdim[p] : 0;
+  const int kb = blockIdx.x * 128 + threadIdx.x;
   double W[27], U[27];
   for (int e = 0; e < 27; ++e) W[e] = U[e] = 0.0;
   double g0 = 0, g1 = 0, g2 = 0;
   const int cb = 7 * G.n_frames;
-  if (dp) {
-    double Hi[9];
-    for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)p + e];
-    for (int e = 0; e < 27; ++e) W[e] = Wc[27 * (size_t)p + e];
-    for (int r9 = 0; r9 < 9; ++r9)
-      for (int b = 0; b < 3; ++b) U[3 * r9 + b] = W[3 * r9] * Hi[b] + W[3 * r9 + 1] * Hi[3 + b] + W[3 * r9 + 2] * Hi[6 + b];
-    g0 = gp[3 * (size_t)p]; g1 = gp[3 * (size_t)p + 1]; g2 = gp[3 * (size_t)p + 2];
-    const int rep = hrep[p];
-    for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
-      const int kb = G.llist[q];
-      if (!valid[kb]) continue;
-      const ObsRef ob = obs_ref(G, kb);
+  bool first = false;
+  if (kb < G.n_obs && valid[kb]) {
+    const ObsRef ob = obs_ref(G, kb);
+    const int p = ob.lm, dp = lmdim[p];
+    if (dp) {
+      double Hi[9];
+      for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)p + e];
+      for (int e = 0; e < 27; ++e) W[e] = Wc[27 * (size_t)p + e];
+      for (int r9 = 0; r9 < 9; ++r9)
+        for (int b = 0; b < 3; ++b) U[3 * r9 + b] = W[3 * r9] * Hi[b] + W[3 * r9 + 1] * Hi[3 + b] + W[3 * r9 + 2] * Hi[6 + b];
+      const int rep = hrep[p];
       for (int y = 0; y < 2; ++y) {
         const int fb = y == 0 ? ob.fj : ob.fh;
         if (fb < 0 || (y == 1 && kb != rep)) continue;
@@ -1064,8 +1065,16 @@ __global__ __launch_bounds__(128) void gr_schur_cam_kernel(GrLandmarks G, const 
             if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + cb + r9], -v);
           }
       }
+      int q = G.lstart[p];
+      while (!valid[G.llist[q]]) ++q;  // (kb itself is valid: the scan ends at or before it)
+      first = G.llist[q] == kb;
+      if (first) {
+        g0 = gp[3 * (size_t)p]; g1 = gp[3 * (size_t)p + 1]; g2 = gp[3 * (size_t)p + 2];
+      }
     }
   }
+  if (!first)
+    for (int e = 0; e < 27; ++e) U[e] = 0.0;  // (only the landmark's first observation adds its (c, c) block and rhs)
   const bool lead = (threadIdx.x & 63) == 0;
   for (int r9 = 0; r9 < 9; ++r9) {
     if (!((G.cam_free >> r9) & 1)) continue;
@@ -1474,7 +1483,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
                   (const double*)d_gp, d_Hd, lda, d_d);
       if (with_cam)
-        GH_LAUNCH(ctx, "gr_schur_cam", gr_schur_cam_kernel, dim3(gh_div_up(nlm, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
+        GH_LAUNCH(ctx, "gr_schur_cam", gr_schur_cam_kernel, dim3(gh_div_up(no, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
                   (const double*)d_Wc, (const double*)d_gp, d_Hd, lda, d_d);
     }
