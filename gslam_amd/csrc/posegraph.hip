@@ -823,35 +823,7 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
         for (int e = 0; e < 18; ++e) R[40 + e] = Jc[e];
       Lr[0] = L[0] * r[0] + L[1] * r[1];
       Lr[1] = L[2] * r[0] + L[3] * r[1];
-      const double* Jf[2] = {Jj, Jh};
-      const int ff[2] = {o.fj, o.fh};
-      for (int x = 0; x < 2; ++x) {
-        if (ff[x] < 0) continue;
-        for (int p = 0; p < 7; ++p) {
-          const double gv = Jf[x][p] * Lr[0] + Jf[x][7 + p] * Lr[1];
-          if (gv != 0.0) atomicAdd(&g[7 * ff[x] + p], gv);
-        }
-        for (int y = 0; y < 2; ++y) {
-          if (ff[y] < 0 || ff[y] > ff[x]) continue;  // lower triangle of blocks: row frame >= column frame
-          for (int q = 0; q < 7; ++q) {
-            const double LJ0 = L[0] * Jf[y][q] + L[1] * Jf[y][7 + q], LJ1 = L[2] * Jf[y][q] + L[3] * Jf[y][7 + q];
-            // (a diagonal block is symmetric and the solver reads the lower triangle only: rows p >= q there)
-            for (int p = ff[y] == ff[x] ? q : 0; p < 7; ++p) {
-              const double hv = Jf[x][p] * LJ0 + Jf[x][7 + p] * LJ1;
-              if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[y] + q) * lda + 7 * ff[x] + p], hv);
-            }
-          }
-        }
-        if (G.with_cam) {  // intrinsics rows x this keyframe's columns (the intrinsics block comes last: always the lower triangle)
-          for (int q = 0; q < 7; ++q) {
-            const double LJ0 = L[0] * Jf[x][q] + L[1] * Jf[x][7 + q], LJ1 = L[2] * Jf[x][q] + L[3] * Jf[x][7 + q];
-            for (int p = 0; p < 9; ++p) {
-              const double hv = Jc[p] * LJ0 + Jc[9 + p] * LJ1;
-              if (hv != 0.0) atomicAdd(&H[(size_t)(7 * ff[x] + q) * lda + 7 * G.n_frames + p], hv);
-            }
-          }
-        }
-      }
+      // (the keyframe rows of g and H are summed from the records by gr_frame_rows_kernel, seven consecutive words at a time)
       for (int a = 0; a < o.dp; ++a) {
         atomicAdd(&gp[3 * (size_t)o.lm + a], Jp[a] * Lr[0] + Jp[3 + a] * Lr[1]);
         for (int b = 0; b < o.dp; ++b) {
@@ -874,6 +846,57 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
       const double LJ0 = L[0] * Jc[q] + L[1] * Jc[9 + q], LJ1 = L[2] * Jc[q] + L[3] * Jc[9 + q];
       const double hv = wave_add_f64(Jc[p] * LJ0 + Jc[9 + p] * LJ1);
       if (lead && hv != 0.0) atomicAdd(&H[(size_t)(cb + q) * lda + cb + p], hv);
+    }
+  }
+}
+
+// Keyframe part of the normal equations from the observation records, EIGHT lanes per (observation, keyframe slot x), lane r
+// = row r of the slot's blocks: g(f_x) += J_x^T L r, block(f_x, f_y) += J_x^T L J_y for the observation's slots with f_y <= f_x
+// (lower triangle of blocks; inside a diagonal block rows r >= q: the solver reads nothing else), and with a camera the
+// intrinsics rows x this keyframe's columns (the intrinsics block comes last: always the lower triangle).  Seven (nine)
+// consecutive words per atomic instruction and slot: see gr_schur_kernel.
+__global__ __launch_bounds__(256) void gr_frame_rows_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+                                                            double* __restrict__ H, int lda, double* __restrict__ g) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int sa = t >> 3, r = t & 7;
+  const int k = sa >> 1, x = sa & 1;
+  if (k >= G.n_obs || !valid[k]) return;
+  const ObsRef o = obs_ref(G, k);
+  const int fx = x == 0 ? o.fj : o.fh;
+  if (fx < 0) return;
+  const double* R = orec + (size_t)G.rec * k;
+  const double L0 = R[2], L1 = R[3], L2 = R[4], L3 = R[5];
+  const double* Jx = R + (x == 0 ? 6 : 20);
+  if (r < 7) {
+    const double j0 = Jx[r], j1 = Jx[7 + r];
+    const double gv = j0 * (L0 * R[0] + L1 * R[1]) + j1 * (L2 * R[0] + L3 * R[1]);
+    if (gv != 0.0) atomicAdd(&g[7 * fx + r], gv);
+    for (int y = 0; y < 2; ++y) {
+      const int fy = y == 0 ? o.fj : o.fh;
+      if (fy < 0 || fy > fx) continue;
+      const double* Jy = R + (y == 0 ? 6 : 20);
+      double* col = H + (size_t)(7 * fy) * lda + 7 * fx + r;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const double LJ0 = L0 * Jy[q] + L1 * Jy[7 + q], LJ1 = L2 * Jy[q] + L3 * Jy[7 + q];
+        const double hv = j0 * LJ0 + j1 * LJ1;
+        if (hv != 0.0 && (fy != fx || r >= q)) atomicAdd(col + (size_t)q * lda, hv);
+      }
+    }
+  }
+  if (G.with_cam) {  // rows 0..7 of the intrinsics block by the eight lanes, row 8 by lane 0 again
+    const double* Jc = R + 40;
+    const double c0 = Jc[r], c1 = Jc[9 + r];
+    double* col = H + (size_t)(7 * fx) * lda + 7 * G.n_frames;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const double LJ0 = L0 * Jx[q] + L1 * Jx[7 + q], LJ1 = L2 * Jx[q] + L3 * Jx[7 + q];
+      const double hv = c0 * LJ0 + c1 * LJ1;
+      if (hv != 0.0) atomicAdd(col + (size_t)q * lda + r, hv);
+      if (r == 0) {
+        const double h8 = Jc[8] * LJ0 + Jc[17] * LJ1;
+        if (h8 != 0.0) atomicAdd(col + (size_t)q * lda + 8, h8);
+      }
     }
   }
 }
@@ -963,14 +986,32 @@ __device__ inline void slot_W(const double* R, int x, int dp, double* W) {
   }
 }
 
-__global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+// Row r7 of W = J_f^T L J_p (columns >= dp zero) of slot x of a recorded observation, straight from the record
+__device__ __forceinline__ void slot_W_row(const double* R, int x, int dp, int r7, double* w) {
+  const double* L = R + 2;
+  const double* Jf = R + (x == 0 ? 6 : 20);
+  const double* Jp = R + 34;
+  const double j0 = Jf[r7], j1 = Jf[7 + r7];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
+    w[b] = b < dp ? j0 * LJ0 + j1 * LJ1 : 0.0;
+  }
+}
+
+// EIGHT lanes per (observation, keyframe) slot a, lane r < 7 = row r of U_a = W_a (H_pp + D)^-1: an atomic instruction then
+// adds seven CONSECUTIVE words of a block column per slot.  f64 atomics resolve at the memory side and are bound by 64-byte
+// sector requests, not by lanes (tools/atomic_probe.hip: 23.6 G lane-atomics/s scattered, 160 G/s in runs of seven), so the
+// 7 x 7 block of a slot pair costs 7 requests instead of 49.  No local arrays: everything is read from the records by index.
+__global__ __launch_bounds__(256) void gr_schur_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
                                                        const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
                                                        const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
                                                        const double* __restrict__ gp, double* __restrict__ Hd, int lda,
                                                        double* __restrict__ d) {
-  const int sa = blockIdx.x * 128 + threadIdx.x;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int sa = t >> 3, r = t & 7;
   const int ka = sa >> 1, x = sa & 1;
-  if (ka >= G.n_obs || !valid[ka]) return;
+  if (r == 7 || ka >= G.n_obs || !valid[ka]) return;
   const ObsRef oa = obs_ref(G, ka);
   const int fa = x == 0 ? oa.fj : oa.fh;
   if (fa < 0) return;
@@ -978,22 +1019,19 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
   if (!dp) return;
   const int rep = hrep[oa.lm];
   if (x == 1 && ka != rep) return;  // the landmark's host slots are one slot, carried by their first observation
-  double Wa[21], Ua[21], Hi[9];
+  double wa[3], ua[3];
   if (x == 1) {
-    for (int r7 = 0; r7 < 7; ++r7) {
-      Wa[3 * r7] = Wh[7 * (size_t)oa.lm + r7];
-      Wa[3 * r7 + 1] = Wa[3 * r7 + 2] = 0.0;
-    }
+    wa[0] = Wh[7 * (size_t)oa.lm + r];
+    wa[1] = wa[2] = 0.0;
   } else {
-    slot_W(orec + (size_t)G.rec * ka, x, dp, Wa);
+    slot_W_row(orec + (size_t)G.rec * ka, x, dp, r, wa);
   }
-  for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)oa.lm + e];
-  for (int r7 = 0; r7 < 7; ++r7)
-    for (int b = 0; b < 3; ++b) Ua[3 * r7 + b] = Wa[3 * r7] * Hi[b] + Wa[3 * r7 + 1] * Hi[3 + b] + Wa[3 * r7 + 2] * Hi[6 + b];
-  const double g0 = gp[3 * (size_t)oa.lm], g1 = gp[3 * (size_t)oa.lm + 1], g2 = gp[3 * (size_t)oa.lm + 2];
-  for (int r7 = 0; r7 < 7; ++r7) {
-    const double v = Ua[3 * r7] * g0 + Ua[3 * r7 + 1] * g1 + Ua[3 * r7 + 2] * g2;
-    if (v != 0.0) atomicAdd(&d[7 * fa + r7], v);
+  const double* Hi = Hinv + 9 * (size_t)oa.lm;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) ua[b] = wa[0] * Hi[b] + wa[1] * Hi[3 + b] + wa[2] * Hi[6 + b];
+  {
+    const double v = ua[0] * gp[3 * (size_t)oa.lm] + ua[1] * gp[3 * (size_t)oa.lm + 1] + ua[2] * gp[3 * (size_t)oa.lm + 2];
+    if (v != 0.0) atomicAdd(&d[7 * fa + r], v);
   }
   for (int q = G.lstart[oa.lm]; q < G.lstart[oa.lm + 1]; ++q) {
     const int kb = G.llist[q];
@@ -1001,85 +1039,102 @@ __global__ __launch_bounds__(128) void gr_schur_kernel(GrLandmarks G, const uint
     const ObsRef ob = obs_ref(G, kb);
     for (int y = 0; y < 2; ++y) {
       const int fb = y == 0 ? ob.fj : ob.fh;
-      if (fb < 0 || fb > fa || (y == 1 && kb != rep)) continue;  // lower triangle of blocks; equal frames: the whole block, from both orders
-      double Wb[21];
-      if (y == 1) {
-        for (int c7 = 0; c7 < 7; ++c7) {
-          Wb[3 * c7] = Wh[7 * (size_t)oa.lm + c7];
-          Wb[3 * c7 + 1] = Wb[3 * c7 + 2] = 0.0;
-        }
-      } else {
-        slot_W(orec + (size_t)G.rec * kb, y, dp, Wb);
-      }
+      if (fb < 0 || fb > fa || (y == 1 && kb != rep)) continue;  // lower triangle of blocks
       // (equal frames: the two orders (a, b) and (b, a) are transposes of each other, so their lower triangles add up to the
       //  lower triangle of the symmetric sum -- the solver reads nothing else)
-      for (int c7 = 0; c7 < 7; ++c7)
-        for (int r7 = fb == fa ? c7 : 0; r7 < 7; ++r7) {
-          const double v = Ua[3 * r7] * Wb[3 * c7] + Ua[3 * r7 + 1] * Wb[3 * c7 + 1] + Ua[3 * r7 + 2] * Wb[3 * c7 + 2];
-          if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + 7 * fa + r7], -v);
+      const double* Rb = orec + (size_t)G.rec * kb;
+      double* col = Hd + (size_t)(7 * fb) * lda + 7 * fa + r;
+#pragma unroll
+      for (int c7 = 0; c7 < 7; ++c7) {
+        double wb[3];
+        if (y == 1) {
+          wb[0] = Wh[7 * (size_t)oa.lm + c7];
+          wb[1] = wb[2] = 0.0;
+        } else {
+          slot_W_row(Rb, 0, dp, c7, wb);
         }
+        const double v = ua[0] * wb[0] + ua[1] * wb[1] + ua[2] * wb[2];
+        if (v != 0.0 && (fb != fa || r >= c7)) atomicAdd(col + (size_t)c7 * lda, -v);
+      }
     }
   }
 }
 
-// The intrinsics' slot of the Schur product, one thread per observation: U_c = W_c (H_pp + D)^-1 (9 x 3) of the observation's
-// landmark; block(c, f) -= U_c W_f^T for the observation's keyframe slots (the intrinsics rows are the last rows: always the
-// lower triangle); the landmark's FIRST valid observation also carries rhs_c += U_c g_p and block(c, c) -= U_c W_c^T, which
-// meet in the same words for every landmark: wave sums first, one atomic per wave.
-__global__ __launch_bounds__(128) void gr_schur_cam_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+// The intrinsics' slot of the Schur product, SIXTEEN lanes per observation, lane r < 9 = row r of U_c = W_c (H_pp + D)^-1
+// (9 x 3) of the observation's landmark: block(c, f) -= U_c W_f^T for the observation's keyframe slots (the intrinsics rows are
+// the last rows: always the lower triangle), nine consecutive words per slot and atomic instruction (see gr_schur_kernel).
+__global__ __launch_bounds__(256) void gr_schur_cam_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
                                                            const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
                                                            const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
-                                                           const double* __restrict__ Wc, const double* __restrict__ gp,
-                                                           double* __restrict__ Hd, int lda, double* __restrict__ d) {
-  const int kb = blockIdx.x * 128 + threadIdx.x;
-  double W[27], U[27];
-  for (int e = 0; e < 27; ++e) W[e] = U[e] = 0.0;
-  double g0 = 0, g1 = 0, g2 = 0;
+                                                           const double* __restrict__ Wc, double* __restrict__ Hd, int lda) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int kb = t >> 4, r = t & 15;
+  double ua[3];
   const int cb = 7 * G.n_frames;
-  bool first = false;
-  if (kb < G.n_obs && valid[kb]) {
+  if (kb < G.n_obs && r < 9 && valid[kb]) {
     const ObsRef ob = obs_ref(G, kb);
     const int p = ob.lm, dp = lmdim[p];
     if (dp) {
-      double Hi[9];
-      for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)p + e];
-      for (int e = 0; e < 27; ++e) W[e] = Wc[27 * (size_t)p + e];
-      for (int r9 = 0; r9 < 9; ++r9)
-        for (int b = 0; b < 3; ++b) U[3 * r9 + b] = W[3 * r9] * Hi[b] + W[3 * r9 + 1] * Hi[3 + b] + W[3 * r9 + 2] * Hi[6 + b];
+      const double* Hi = Hinv + 9 * (size_t)p;
+      const double* Wp = Wc + 27 * (size_t)p;
+      const double w0 = Wp[3 * r], w1 = Wp[3 * r + 1], w2 = Wp[3 * r + 2];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) ua[b] = w0 * Hi[b] + w1 * Hi[3 + b] + w2 * Hi[6 + b];
       const int rep = hrep[p];
       for (int y = 0; y < 2; ++y) {
         const int fb = y == 0 ? ob.fj : ob.fh;
         if (fb < 0 || (y == 1 && kb != rep)) continue;
-        double Wb[21];
-        if (y == 1) {
-          for (int c7 = 0; c7 < 7; ++c7) {
-            Wb[3 * c7] = Wh[7 * (size_t)p + c7];
-            Wb[3 * c7 + 1] = Wb[3 * c7 + 2] = 0.0;
+        const double* Rb = orec + (size_t)G.rec * kb;
+        double* col = Hd + (size_t)(7 * fb) * lda + cb + r;
+#pragma unroll
+        for (int c7 = 0; c7 < 7; ++c7) {
+          double wb[3];
+          if (y == 1) {
+            wb[0] = Wh[7 * (size_t)p + c7];
+            wb[1] = wb[2] = 0.0;
+          } else {
+            slot_W_row(Rb, 0, dp, c7, wb);
           }
-        } else {
-          slot_W(orec + (size_t)G.rec * kb, y, dp, Wb);
+          const double v = ua[0] * wb[0] + ua[1] * wb[1] + ua[2] * wb[2];
+          if (v != 0.0) atomicAdd(col + (size_t)c7 * lda, -v);
         }
-        for (int c7 = 0; c7 < 7; ++c7)
-          for (int r9 = 0; r9 < 9; ++r9) {
-            const double v = U[3 * r9] * Wb[3 * c7] + U[3 * r9 + 1] * Wb[3 * c7 + 1] + U[3 * r9 + 2] * Wb[3 * c7 + 2];
-            if (v != 0.0) atomicAdd(&Hd[(size_t)(7 * fb + c7) * lda + cb + r9], -v);
-          }
-      }
-      int q = G.lstart[p];
-      while (!valid[G.llist[q]]) ++q;  // (kb itself is valid: the scan ends at or before it)
-      first = G.llist[q] == kb;
-      if (first) {
-        g0 = gp[3 * (size_t)p]; g1 = gp[3 * (size_t)p + 1]; g2 = gp[3 * (size_t)p + 2];
       }
     }
   }
-  if (!first)
-    for (int e = 0; e < 27; ++e) U[e] = 0.0;  // (only the landmark's first observation adds its (c, c) block and rhs)
+}
+
+// ... and the landmark's own part, one thread per landmark: rhs_c += U_c g_p, block(c, c) -= U_c W_c^T.  Every landmark adds to
+// the same 9 + 45 words: summed over the wave first, one atomic per wave and word (188 waves for 12 000 landmarks; issued
+// from the per-observation kernel above, the same-address atomics of 15 000 waves took 0.9 ms).
+__global__ __launch_bounds__(128) void gr_schur_cam_cc_kernel(GrLandmarks G, const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
+                                                              const double* __restrict__ Wc, const double* __restrict__ gp,
+                                                              double* __restrict__ Hd, int lda, double* __restrict__ d) {
+  const int p = blockIdx.x * 128 + threadIdx.x;
+  const int nlm = G.n_xyz + G.n_idp;
+  double W[27], U[27];
+#pragma unroll
+  for (int e = 0; e < 27; ++e) W[e] = U[e] = 0.0;
+  double g0 = 0, g1 = 0, g2 = 0;
+  if (p < nlm && lmdim[p] != 0) {
+    double Hi[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Hi[e] = Hinv[9 * (size_t)p + e];
+#pragma unroll
+    for (int e = 0; e < 27; ++e) W[e] = Wc[27 * (size_t)p + e];
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) U[3 * r9 + b] = W[3 * r9] * Hi[b] + W[3 * r9 + 1] * Hi[3 + b] + W[3 * r9 + 2] * Hi[6 + b];
+    g0 = gp[3 * (size_t)p]; g1 = gp[3 * (size_t)p + 1]; g2 = gp[3 * (size_t)p + 2];
+  }
+  const int cb = 7 * G.n_frames;
   const bool lead = (threadIdx.x & 63) == 0;
+#pragma unroll
   for (int r9 = 0; r9 < 9; ++r9) {
     if (!((G.cam_free >> r9) & 1)) continue;
     const double v = wave_add_f64(U[3 * r9] * g0 + U[3 * r9 + 1] * g1 + U[3 * r9 + 2] * g2);
     if (lead && v != 0.0) atomicAdd(&d[cb + r9], v);
+#pragma unroll
     for (int c9 = 0; c9 <= r9; ++c9) {
       if (!((G.cam_free >> c9) & 1)) continue;
       const double h = wave_add_f64(U[3 * r9] * W[3 * c9] + U[3 * r9 + 1] * W[3 * c9 + 1] + U[3 * r9 + 2] * W[3 * c9 + 2]);
@@ -1463,6 +1518,9 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       if (no > 0)
         GH_LAUNCH(ctx, "gr_obs_lin", gr_obs_lin_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, (const double*)d_S,
                   (const double*)d_xyz, (const double*)d_rho, (const double*)d_cam, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp);
+      if (no > 0)
+        GH_LAUNCH(ctx, "gr_frame_rows", gr_frame_rows_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
+                  (const double*)d_orec, d_H, lda, d_g);
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_LAUNCH(ctx, "gr_gmax", gr_gmax_kernel, dim3(gh_div_up(n + 3 * nlm, 256)), dim3(256), 0, (const double*)d_g, n,
                 (const double*)d_gp, 3 * nlm, d_gmax);
@@ -1479,13 +1537,16 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       GH_LAUNCH(ctx, "gr_lm_prepare", gr_lm_prepare_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                 (const double*)d_Hpp, (const double*)d_orec, radius, d_Hinv, d_lmdim, d_Wh, d_hrep, d_Wc);
       if (no > 0)
-        GH_LAUNCH(ctx, "gr_schur", gr_schur_kernel, dim3(gh_div_up(2 * no, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
+        GH_LAUNCH(ctx, "gr_schur", gr_schur_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
                   (const double*)d_gp, d_Hd, lda, d_d);
       if (with_cam)
-        GH_LAUNCH(ctx, "gr_schur_cam", gr_schur_cam_kernel, dim3(gh_div_up(no, 128)), dim3(128), 0, LM, (const uint8_t*)d_valid,
+        GH_LAUNCH(ctx, "gr_schur_cam", gr_schur_cam_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
-                  (const double*)d_Wc, (const double*)d_gp, d_Hd, lda, d_d);
+                  (const double*)d_Wc, d_Hd, lda);
+      if (with_cam)
+        GH_LAUNCH(ctx, "gr_schur_cam_cc", gr_schur_cam_cc_kernel, dim3(gh_div_up(nlm, 128)), dim3(128), 0, LM, (const double*)d_Hinv,
+                  (const int32_t*)d_lmdim, (const double*)d_Wc, (const double*)d_gp, d_Hd, lda, d_d);
     }
     int info = 0;
     const double t_s0 = now_ms_pg();
