@@ -1307,6 +1307,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   GH_CHECK_ARG(ctx, pr->n_se3 == 0 || (pr->se3_first && pr->se3_second && pr->se3_meas));
   GH_CHECK_ARG(ctx, pr->n_sim3 == 0 || (pr->sim3_first && pr->sim3_second && pr->sim3_meas));
   GH_CHECK_ARG(ctx, pr->n_gps == 0 || (pr->gps_frame && pr->gps_meas));
+  GH_CHECK_ARG(ctx, no <= (1 << 26));  // (sixteen lanes per observation in the Schur kernels: 32-bit thread indices)
   GH_CHECK_ARG(ctx, nx >= 0 && ni >= 0 && no >= 0 && (nx == 0 || gpr->xyz) && (ni == 0 || (gpr->idp_host && gpr->idp_anchor && gpr->idp_rho)));
   GH_CHECK_ARG(ctx, gpr->projection == 0 || gpr->projection == 1);
   // camera self-calibration (BundleGraph::camera + cameraDOF): pixels through the camera model, pinhole projection only
