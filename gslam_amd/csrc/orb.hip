@@ -1149,6 +1149,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   }
   // separable 7x7 integer Gaussian: patch rows 0..kPatch-1 x blur cols -> s_h, then blur rows -> the blurred patch
   uint32_t* hb = s_h[wv];
+  constexpr int kRowsPerTrip = 64 / kGroups;
+  const int lrow = lane / kGroups, lgrp = lane - lrow * kGroups;
   constexpr uint32_t g[7] = {144, 268, 391, 442, 391, 268, 144};
   // Wide LDS accesses (the kernel is LDS-issue bound with byte reads): one work item = 4 adjacent outputs.
   // h-pass: 4 dwords of the patch row -> 10 source bytes (v_alignbyte with the wave-uniform row offset)
@@ -1156,8 +1158,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   {
     const uint32_t off = (uint32_t)(px0 - pa);  // 0..3, wave-uniform
     const uint32_t* p32 = reinterpret_cast<const uint32_t*>(s_patch[wv]);
-    for (int idx = lane; idx < kPatch * kGroups; idx += 64) {
-      const int r = idx / kGroups, gq = idx - r * kGroups;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
+    // lane -> (row of the trip, 4-column group), fixed for the whole kernel: kRowsPerTrip rows x kGroups groups per trip (63 / 60
+    // of the 64 lanes; same trip counts as a flat index, without a division by 7 / 10 in every trip)
+    for (int r = lrow; r < kPatch && lane < kRowsPerTrip * kGroups; r += kRowsPerTrip) {
+      const int gq = lgrp;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
       const uint32_t* q = p32 + r * kRowDw + gq;
       const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
       const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off);  // source bytes 0..3 (patch col 4 gq + k)
@@ -1193,8 +1197,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   // v-pass: one work item = 4 adjacent outputs of one blur row: 7 x 16-byte reads down the 4 columns, 28
   // v_mad_u32_u24 (h sums < 2^20), weights x4 so that the rounded result is the top byte of the sum
   // ((4 s + 2^23) >> 24 == (s + 2^21) >> 22; 4 * 2048 * 522240 + 2^23 < 2^32), one dword store.
-  for (int idx = lane; idx < kBlur * kGroups; idx += 64) {
-    const int rb = idx / kGroups, cg = idx - rb * kGroups;
+  for (int rb = lrow; rb < kBlur && lane < kRowsPerTrip * kGroups; rb += kRowsPerTrip) {
+    const int cg = lgrp;
     uint32_t acc[4] = {1u << 23, 1u << 23, 1u << 23, 1u << 23};
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
