@@ -106,3 +106,27 @@ def test_refusals(ctx):
         posegraph.solve_graph(ctx, start, dof, with_camera(base, CAM, bad, 3))
     with pytest.raises(Exception):
         posegraph.solve_graph(ctx, start, dof, with_camera(base, CAM, CAM, 1 << 9))
+
+
+def test_calibration_fuzz_small_graphs(ctx, oracle):
+    """Small windows with every combination of freed parameters, landmark mixes, informations and Huber on / off (fixed
+    examples: a tolerance-based comparison): the GPU trace equals the oracle's up to the settled tail."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=20, deadline=None, derandomize=True)
+    @given(nf=st.integers(4, 9), n_xyz=st.integers(12, 40), n_idp=st.integers(0, 15), free=st.integers(0, 511), info=st.booleans(),
+           huber=st.sampled_from([0.0, 2.0]), seed=st.integers(0, 10 ** 6))
+    def run(nf, n_xyz, n_idp, free, info, huber, seed):
+        truth, start, dof, base = make_landmark_graph(n_frames=nf, n_xyz=n_xyz, n_idp=n_idp, kind="se3", seed=seed, noise=0.0,
+                                                      with_info=info, obs_per_point=min(5, nf))
+        prob = with_camera(base, CAM, _start_cam(free, 0.02), free, pixel_noise=0.2, seed=seed + 1)
+        from gslam_amd import posegraph
+        oo = oracle_lib.ba_options(huber=huber, max_iterations=15)
+        S0, x0, r0, c0, so, st0 = oracle.graph_solve_cam(start, dof, prob, oo)
+        S1, x1, r1, c1, sg, st1 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, 15))
+        assert st0 == st1 == 0
+        assert_same_trace(sg, so, rtol=1e-4)  # (few observations per unknown: ill-conditioned steps amplify the summation order)
+        fixed = [k for k in range(9) if not (free >> k) & 1]
+        assert np.array_equal(c1[fixed], prob["intrinsics"][0][fixed])
+
+    run()
