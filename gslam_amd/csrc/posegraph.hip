@@ -546,6 +546,7 @@ namespace {
 
 constexpr double kMinDepthG = 1e-9;
 constexpr int kObsRec = 40;     // r(2) L(4) Jj(14) Jh(14) Jp(6)
+constexpr int kCamPart = 54;    // per wave of gr_obs_lin: g_c (9) and the lower triangle of block(c, c) (45), row by row
 constexpr int kObsRecCam = 58;  // ... + Jc(18): the record of a graph with a camera (GrLandmarks::rec is one of the two)
 
 struct GrLandmarks {
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
                                                          const double* __restrict__ cam, double* __restrict__ orec,
                                                          uint8_t* __restrict__ valid, double* __restrict__ H,
                                                          int lda, double* __restrict__ g, double* __restrict__ Hpp,
-                                                         double* __restrict__ gp) {
+                                                         double* __restrict__ gp, double* __restrict__ cam_part) {
   const int k = blockIdx.x * 128 + threadIdx.x;
   const bool in_range = k < G.n_obs;
   if (!in_range && !G.with_cam) return;  // (with a camera every lane stays for the wave sums of the intrinsics block)
@@ -834,20 +835,52 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
     }
   }
   if (!G.with_cam) return;
-  // intrinsics block: every observation adds to the same 9 + 45 words -> summed over the wave first, one atomic per wave
-  const int cb = 7 * G.n_frames;
+  // intrinsics block: every observation adds to the same 9 + 45 words -> summed over the wave, the wave's 54 sums stored (no
+  // atomics: from ~1000 waves the same-address atomics took twice as long as the rest of the kernel); gr_cam_fold_kernel adds
+  // the partial sums up in wave order
   const bool lead = (threadIdx.x & 63) == 0;
+  double* part = cam_part + (size_t)kCamPart * (blockIdx.x * 2 + (threadIdx.x >> 6));
+  int slot = 0;
+#pragma unroll
   for (int p = 0; p < 9; ++p) {
-    if (!((G.cam_free >> p) & 1)) continue;
-    const double gv = wave_add_f64(Jc[p] * Lr[0] + Jc[9 + p] * Lr[1]);
-    if (lead && gv != 0.0) atomicAdd(&g[cb + p], gv);
+    const double gv = wave_add_f64(Jc[p] * Lr[0] + Jc[9 + p] * Lr[1]);  // (columns of fixed parameters are zero in the record)
+    if (lead) part[slot] = gv;
+    ++slot;
+#pragma unroll
     for (int q = 0; q <= p; ++q) {
-      if (!((G.cam_free >> q) & 1)) continue;
       const double LJ0 = L[0] * Jc[q] + L[1] * Jc[9 + q], LJ1 = L[2] * Jc[q] + L[3] * Jc[9 + q];
       const double hv = wave_add_f64(Jc[p] * LJ0 + Jc[9 + p] * LJ1);
-      if (lead && hv != 0.0) atomicAdd(&H[(size_t)(cb + q) * lda + cb + p], hv);
+      if (lead) part[slot] = hv;
+      ++slot;
     }
   }
+}
+
+// g_c += sum of the waves' partial sums, block(c, c) += likewise: 16 threads per word, each over every 16th wave, then the 16
+// partial sums of a word in order (a fixed order: reproducible)
+__global__ __launch_bounds__(1024) void gr_cam_fold_kernel(const double* __restrict__ cam_part, int n_waves, int n_frames,
+                                                           double* __restrict__ H, int lda, double* __restrict__ g) {
+  __shared__ double sh[16][kCamPart];
+  const int t = threadIdx.x;
+  if (t < 16 * kCamPart) {
+    const int j = t / kCamPart, w = t - j * kCamPart;
+    double s = 0;
+    for (int k = j; k < n_waves; k += 16) s += cam_part[(size_t)kCamPart * k + w];
+    sh[j][w] = s;
+  }
+  __syncthreads();
+  if (t >= kCamPart) return;
+  double s = 0;
+  for (int j = 0; j < 16; ++j) s += sh[j][t];
+  // word t: the rows p = 0..8 one after the other, g_p first, then the columns q = 0..p of row p
+  int p = 0, base = 0;
+  while (base + p + 2 <= t) {
+    base += p + 2;
+    ++p;
+  }
+  const int cb = 7 * n_frames, q = t - base - 1;
+  if (q < 0) g[cb + p] += s;
+  else H[(size_t)(cb + q) * lda + cb + p] += s;
 }
 
 // Keyframe part of the normal equations from the observation records, EIGHT lanes per (observation, keyframe slot x), lane r
@@ -1378,11 +1411,12 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       fprintf(stderr, "[gh_graph] block-sparse: %d keyframes -> %d sparse columns in %d rounds, %d blocks, root %d\n", nf, BS.P.ns,
               BS.P.n_rounds, BS.P.n_slots, BS.P.nr);
   }
+  const int ob_alloc = gh_div_up(no > 0 ? no : 1, 128);  // workgroups of gr_obs_lin (two waves each)
   const int n_items = ne + no, n_part = gh_div_up(std::max(n_items, std::max(no, 1)), 1024);
   GraphArena A(ctx);
   double *d_S, *d_Snew, *d_meas, *d_info = nullptr, *d_rec, *d_cost_e, *d_H = nullptr, *d_Hd = nullptr, *d_g, *d_d, *d_out;
   double *d_xyz, *d_xyz_new, *d_rho, *d_rho_new, *d_anchor, *d_oxy, *d_oinfo = nullptr, *d_orec, *d_Hpp, *d_gp, *d_Hinv, *d_dlm, *d_term,
-      *d_part, *d_Wh, *d_cam = nullptr, *d_cam_new = nullptr, *d_Wc = nullptr;
+      *d_part, *d_Wh, *d_cam = nullptr, *d_cam_new = nullptr, *d_Wc = nullptr, *d_cam_part = nullptr;
   int32_t *d_dof, *d_etype, *d_ei, *d_ej, *d_vstart, *d_vlist, *d_pstart, *d_plist, *d_prow, *d_pcol, *d_host, *d_okind, *d_opoint,
       *d_oframe, *d_lstart, *d_llist, *d_lmdim, *d_hrep;
   uint8_t *d_xfree = nullptr, *d_ifree = nullptr, *d_valid;
@@ -1411,7 +1445,7 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
            A.alloc(&d_rho_new, ni1) && A.alloc(&d_orec, no1 * rec) && A.alloc(&d_Hpp, nlm1 * 9) && A.alloc(&d_gp, nlm1 * 3) &&
            A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) && A.alloc(&d_term, (size_t)std::max(n_items, 1)) &&
            A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_lmdim, nlm1) && A.alloc(&d_hrep, nlm1) && A.alloc(&d_Wh, nlm1 * 7) &&
-           A.alloc(&d_valid, no1) && (!with_cam || (A.alloc(&d_cam_new, 9) && A.alloc(&d_Wc, nlm1 * 27))) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda)));
+           A.alloc(&d_valid, no1) && (!with_cam || (A.alloc(&d_cam_new, 9) && A.alloc(&d_Wc, nlm1 * 27) && A.alloc(&d_cam_part, (size_t)kCamPart * 2 * ob_alloc))) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda)));
   };
   alloc_all();  // measuring pass
   GH_TRY(A.reserve());
@@ -1518,7 +1552,9 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       if (with_cam) GH_HIP(ctx, hipMemsetAsync(d_g + 7 * nf, 0, 72, ctx->stream));  // (pg_assemble stores the keyframe rows only)
       if (no > 0)
         GH_LAUNCH(ctx, "gr_obs_lin", gr_obs_lin_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, (const double*)d_S,
-                  (const double*)d_xyz, (const double*)d_rho, (const double*)d_cam, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp);
+                  (const double*)d_xyz, (const double*)d_rho, (const double*)d_cam, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp, d_cam_part);
+      if (with_cam)
+        GH_LAUNCH(ctx, "gr_cam_fold", gr_cam_fold_kernel, dim3(1), dim3(1024), 0, (const double*)d_cam_part, 2 * ob, nf, d_H, lda, d_g);
       if (no > 0)
         GH_LAUNCH(ctx, "gr_frame_rows", gr_frame_rows_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, d_H, lda, d_g);
