@@ -16,7 +16,9 @@
 //                                           point observations: the general solver (SIM3 keyframes, both landmark kinds)
 //                                           and every graph with observations under PROJECTION_SPHERE
 // Camera self-calibration (BundleGraph::camera + cameraDOF) of PinHole / OpenCV cameras goes through the general graph solve;
-// still `return false` ("unsupported", as the interface allows): self-calibration of other camera models or under PROJECTION_SPHERE.
+// still `return false` ("unsupported", as the interface allows): self-calibration of other camera models (CameraEstimationDOF names
+// no flag for the ATAN model's parameter, and the reference's CameraATAN::Project disagrees with itself between its SSE and scalar
+// paths off the z = 1 plane: Camera.h:291-294 vs :327-331) or under PROJECTION_SPHERE.
 // (optimizePnP / optimizePose under PROJECTION_SPHERE go through the general graph solver: optimizePnPSphere.)
 // Host code only; all arithmetic runs in libgslam_hip.so (no CPU fallback: no GPU => returns false).
 #include <GSLAM/core/GSLAM.h>
