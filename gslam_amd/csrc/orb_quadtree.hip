@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, i
   const int xa = (x0 - 3) & ~3, al = (x0 - 3) & 3;
   const int ndw = (al + cw + 6 + 3) >> 2, nrow = ch + 6;
   for (int idx = lane; idx < nrow * kWRowDw; idx += 64) {
-    const int r = idx / kWRowDw, d = idx - r * kWRowDw;
+    // idx / 11 on the 24-bit multiplier (full rate; a division by a constant costs a quarter-rate v_mul_hi_u32): exact for
+    // idx < 418 since 5958 / 65536 - 1 / 11 = 2.8e-6
+    const int r = (int)(__umul24((uint32_t)idx, 5958u) >> 16), d = idx - r * kWRowDw;
     if (d < ndw) L.img[idx] = *reinterpret_cast<const uint32_t*>(img + (size_t)(y0 - 3 + r) * lv.pitch + xa + 4 * d);
   }
   for (int idx = lane; idx < (int)(sizeof(L.S) / 4); idx += 64) L.S[idx] = 0u;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, i
     bool pass = false;
     uint32_t yx = 0;
     if (p < npx) {
-      const int y = (int)(((uint32_t)p * inv) >> 16), x = p - y * cw;
+      const int y = (int)(__umul24((uint32_t)p, inv) >> 16), x = p - (int)__umul24((uint32_t)y, (uint32_t)cw);
       yx = (uint32_t)((y << 5) | x);
       pass = fast_compass_px(I + y * kWImgPitch + x, kWImgPitch, min_th);
     }
