@@ -197,7 +197,19 @@ struct NextLevel {
   const int32_t* gx0;      // [nbx + 1] first owned output group per tile column
   const int32_t* gy0;      // [nby + 1] first owned output row per tile row
   int tail_unsafe_frame;
+  // tile id -> (frame, tile row, tile column) without integer divisions: q = __umulhi(n, inv) == n / d for every tile id of
+  // the launch (checked on the host: magic_div); 0 = divide (the one-launch-for-all-levels path of small calls)
+  uint32_t tiles_inv = 0, nbx_inv = 0;
 };
+
+// inv with __umulhi(n, inv) == n / d for every n <= n_max, or 0 when no such 32-bit constant is guaranteed
+inline uint32_t magic_div(uint32_t d, uint32_t n_max) {
+  if (d == 0) return 0;
+  if (d == 1) return 0;  // (n * 2^32 does not fit: let the kernel divide)
+  const uint64_t inv = ((1ull << 32) + d - 1) / d;   // ceil(2^32 / d)
+  const uint64_t excess = inv * d - (1ull << 32);    // < d
+  return (inv < (1ull << 32) && (uint64_t)n_max * excess < (1ull << 32)) ? (uint32_t)inv : 0u;
+}
 
 // Inclusive prefix sum of one int per lane over the wave: four DPP row shifts scan each 16-lane row, two row broadcasts
 // (lane 15 -> next row on rows 1 / 3, lane 31 -> rows 2 / 3) carry the row totals: 6 VALU (five ballots and their
@@ -315,9 +327,18 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   const int tid = threadIdx.x;
   __builtin_assume(tid >= 0 && tid < 256);
   const int nbx = (ncx + 1) >> 1, nby = (ncy + 1) >> 1;
-  const int frame = tile_id / (nbx * nby);
-  const int trem = tile_id - frame * (nbx * nby);
-  const int bx = trem % nbx, by = trem / nbx;
+  int frame, trem, bx, by;
+  if (nx.tiles_inv != 0u && nx.nbx_inv != 0u) {  // (two integer divisions were ~40 VALU per wave: 4 % of the kernel)
+    frame = (int)__umulhi((uint32_t)tile_id, nx.tiles_inv);
+    trem = tile_id - frame * (nbx * nby);
+    by = (int)__umulhi((uint32_t)trem, nx.nbx_inv);
+    bx = trem - by * nbx;
+  } else {
+    frame = tile_id / (nbx * nby);
+    trem = tile_id - frame * (nbx * nby);
+    bx = trem % nbx;
+    by = trem / nbx;
+  }
   if (tid == 0) q_count = 0;
   const int x0 = kEdge + 64 * bx, y0 = kEdge + 64 * by;  // region origin
   const int oy = y0 - 4;                       // tile origin row
@@ -1956,6 +1977,11 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
       GH_CHECK_ARG(ctx, tiles < (1LL << 30));
       dim3 grid(8 * gh_div_up(tiles, 8));
+      {
+        const uint32_t nbx = (uint32_t)gh_div_up(p->ncx[l], 2), tpf = nbx * (uint32_t)gh_div_up(p->ncy[l], 2);
+        nx.tiles_inv = magic_div(tpf, (uint32_t)tiles);
+        nx.nbx_inv = magic_div(nbx, tpf);
+      }
 #define GH_FAST(PK_, P1_)                                                                                                     \
   GH_LAUNCH(ctx, "orb_fast_cells", (fast_cells_kernel<PK_, P1_>), grid, dim3(256), p->lds_pad, lv[l], p->ncx[l], p->ncy[l],            \
             p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame, p->cell_off[l], batch, nx, \
