@@ -170,7 +170,7 @@ __device__ __forceinline__ void resize_item(const LevelView& src, const uint8_t*
     packed.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0703u), __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0703u), 0x05040100u);
     packed.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[7], r[6], 0x0c0c0703u), __builtin_amdgcn_perm(r[5], r[4], 0x0c0c0703u), 0x05040100u);
     // dst pitch is a multiple of 64 and the pad bytes are ours: always a full 8-byte store
-    *reinterpret_cast<uint2*>(d + ((uint32_t)y * (uint32_t)dst_pitch + (uint32_t)x8)) = packed;
+    *reinterpret_cast<uint2*>(d + (__umul24((uint32_t)y, (uint32_t)dst_pitch) + (uint32_t)x8)) = packed;
   }
 }
 
@@ -347,12 +347,16 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
 
   // 16 B per lane: rows of the level are 16-byte aligned (pitch % 16 == 0, checked by the launcher)
   for (int i = tid; i < kTileH * (kTileW / 16); i += 256) {
-    const int row = i / (kTileW / 16), c = i - row * (kTileW / 16);
+    // i / 6 on the full-rate 24-bit multiplier: exact for i < 420 since 10923 / 65536 - 1 / 6 = 5e-6 (a division by a
+    // constant costs a quarter-rate v_mul_hi)
+    static_assert(kTileW / 16 == 6 && kTileH * (kTileW / 16) <= 4096, "the constant below divides by 6");
+    const int row = (int)(__umul24((uint32_t)i, 10923u) >> 16), c = i - row * (kTileW / 16);
     int gy = oy + row;
     gy = gy < 0 ? 0 : (gy > lv.h - 1 ? lv.h - 1 : gy);
     int gx = ax + 16 * c;
     gx = gx > lv.pitch - 16 ? lv.pitch - 16 : gx;
-    const uint4 v = *reinterpret_cast<const uint4*>(img + (size_t)gy * lv.pitch + gx);
+    // (rows and pitch are < 2^24, a level is < 4 GiB: 32-bit offset, full-rate multiply instead of a 64-bit v_mad_i64_i32)
+    const uint4 v = *reinterpret_cast<const uint4*>(img + (__umul24((uint32_t)gy, (uint32_t)lv.pitch) + (uint32_t)gx));
     *reinterpret_cast<uint4*>(&tile[row * kTileW + 16 * c]) = v;
   }
   if constexpr (P1 != 0) {
@@ -390,7 +394,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     constexpr int kTrips = (kItems + 255) / 256;  // 5
     static_assert(2 * kTrips <= 14 && kScoreW == 4 * kItemsPerRow, "candidate bits of all trips share one dword");
     constexpr uint32_t kF = 0x00FF00FFu;
-    const uint32_t t = (uint32_t)min(max(min_th, 0), 255);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(min_th, 0), 255));  // (scalar: the constants below are s_mul)
     const uint32_t kAe = (0x8000u + t) * 0x10001u, kDe = (0x8000u - t - 1u) * 0x10001u;
     const uint32_t kAo = (0x4000u + t) * 0x10001u, kDo = (0x4000u - t - 1u) * 0x10001u;
     const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
@@ -528,7 +532,16 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     int pos = queue[i];
     if constexpr (P1 != 0) pos = 4 * (pos & 255) + bit_pos[pos >> 8];
     // (flat 68-byte rows: position 68 sy + 1 + j holds window col j - 2, j = 0 .. 67)
-    const int sy = P1 != 0 ? (pos - 1) / kScoreW : pos / kScoreW, sx = pos - sy * kScoreW - kScoreOff;
+    // P1: n / 68 on the full-rate 24-bit multiplier (exact for n < 68 * 72: 15421 / 2^20 - 1 / 68 = 7.6e-7; a signed division by
+    // a constant is a quarter-rate v_mul_hi_i32 and three fix-up instructions)
+    int sy;
+    if constexpr (P1 != 0) {
+      static_assert(kScoreW == 68, "the constant below divides by 68");
+      sy = (int)(__umul24((uint32_t)(pos - 1), 15421u) >> 20);
+    } else {
+      sy = pos / kScoreW;
+    }
+    const int sx = pos - sy * kScoreW - kScoreOff;
     if constexpr (P1 != 0) {
       // border tiles: pass 1 did not trim -- pixels outside the valid region [kEdge, dim - kEdge) keep S = 0 (oracle step 2)
       if (!interior && (sx < sx_lo || sx >= sx_hi || y0 - 1 + sy < kEdge || y0 - 1 + sy >= lv.h - kEdge)) continue;
@@ -619,7 +632,8 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
       nzb &= nzb - 1u;
     }
   }
-  const size_t cell = (size_t)frame * cells_per_frame + cell_off + (size_t)cy * ncx + cx;
+  // (cy * ncx + cx < 2^24: the per-wave part on the 24-bit multiplier, the per-frame part is scalar)
+  const size_t cell = (size_t)frame * cells_per_frame + cell_off + (size_t)(__umul24((uint32_t)cy, (uint32_t)ncx) + (uint32_t)cx);
   // cell record: {count, entries 0..6} in one 32-byte line of cell_cnt (a cell holds ~5 entries: orb_select reads ONE
   // 32-byte record per cell instead of a count plus a 128-byte slot); entries 7.. go to the cell's slot in cell_ent
   uint32_t* rec = cell_cnt + cell * kCellRec;
@@ -1067,8 +1081,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   const int blocks_per_frame = (K + 3) >> 2;
   const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
   if (gid >= blocks_per_frame * n_frames) return;
-  const int b = gid / blocks_per_frame;
-  const int slot = (gid - b * blocks_per_frame) * 4 + wv;
+  // frame and slot are the same for the whole wave: through v_readfirstlane so that everything derived from them (level,
+  // output position, every base address) is scalar arithmetic instead of quarter-rate 64-bit VALU multiplies
+  const int b = __builtin_amdgcn_readfirstlane(gid / blocks_per_frame);
+  const int slot = __builtin_amdgcn_readfirstlane((gid - b * blocks_per_frame) * 4 + wv);
   if (slot >= K) return;
   // level of this slot and compacted output position
   int l = 0;
@@ -1112,7 +1128,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_patch[wv][lane * kPatchPitch]);
     if (inside) {
       struct __attribute__((packed, aligned(4))) RowN { uint32_t w[kRowDw]; };
-      const RowN row = *reinterpret_cast<const RowN*>(img + (size_t)(py0 + lane) * lv.pitch + pa);
+      // (rows and pitch are < 2^24 and a level is < 4 GiB: a 32-bit offset on the full-rate 24-bit multiplier)
+      const RowN row = *reinterpret_cast<const RowN*>(img + (__umul24((uint32_t)(py0 + lane), (uint32_t)lv.pitch) + (uint32_t)pa));
 #pragma unroll
       for (int c = 0; c < kRowDw; ++c) dst[c] = row.w[c];
     } else {
