@@ -803,7 +803,17 @@ def _graph_methods(cls):
                                        C.byref(w), C.byref(s), _ptr(Jj), _ptr(Jh), _ptr(Jp), int(projection))
         return bool(ok), r, w.value, s.value, Jj.reshape(2, 7), Jh.reshape(2, 7), Jp.reshape(2, 3)
 
-    for f in (graph_solve, graph_solve_cam, cam_project, graph_cost, graph_obs):
+    def graph_obs_cam(self, kind, Sj, dof_j, Sh, dof_h, same_host, lm, lm_free, anchor, m, cam, cam_free, info=None, huber=0.0):
+        """Observation through a camera (pixels): -> (ok, r 2, w, s, Jj 2 x 7, Jh 2 x 7, Jp 2 x 3, Jc 2 x 9)."""
+        r, Jj, Jh, Jp, Jc = np.zeros(2), np.zeros(14), np.zeros(14), np.zeros(6), np.zeros(18)
+        w, s = C.c_double(), C.c_double()
+        f = lambda v: _ptr(np.ascontiguousarray(v, dtype=np.float64)) if v is not None else None
+        ok = self.lib.oracle_graph_obs_cam(int(kind), f(Sj), int(dof_j), f(Sh), int(dof_h), int(same_host), f(lm), int(lm_free),
+                                           f(anchor if anchor is not None else np.zeros(3)), f(m), f(info), C.c_double(huber), _ptr(r),
+                                           C.byref(w), C.byref(s), _ptr(Jj), _ptr(Jh), _ptr(Jp), 0, f(cam), int(cam_free), _ptr(Jc))
+        return bool(ok), r, w.value, s.value, Jj.reshape(2, 7), Jh.reshape(2, 7), Jp.reshape(2, 3), Jc.reshape(2, 9)
+
+    for f in (graph_solve, graph_solve_cam, cam_project, graph_cost, graph_obs, graph_obs_cam):
         setattr(cls, f.__name__, f)
 
 

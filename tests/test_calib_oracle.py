@@ -169,3 +169,46 @@ def test_sphere_projection_with_a_camera_is_refused(oracle):
     truth, start, dof, base = make_landmark_graph(n_frames=4, n_xyz=8, n_idp=0, projection="sphere")
     base["intrinsics"] = (CAM.copy(), 3)
     assert oracle.graph_solve_cam(start, dof, base)[-1] == 2
+
+
+def test_pixel_observation_jacobians_against_finite_differences(oracle):
+    """Every Jacobian of a pixel observation (keyframe, host keyframe, landmark, intrinsics) against central differences of
+    the independent numpy residual; fixed dofs / parameters give zero columns."""
+    from gslam_amd.pg_synth import _quat_from_rotvec
+    rng = np.random.default_rng(8)
+    for trial in range(30):
+        kind = trial & 1
+        mk = lambda: np.concatenate([_quat_from_rotvec(rng.normal(size=3) * 0.3), rng.normal(size=3), [np.exp(rng.normal() * 0.2)]])
+        Sj, Sh = mk(), mk()
+        cam = CAM * (1.0 + rng.normal(size=9) * 0.03)
+        free = 0x1FF if trial % 4 else 0b010010011
+        dof_j, dof_h = (127, 127) if trial % 5 else (0b1011011, 0b0110110)
+        if kind == 0:
+            Xc = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2.5, 6)])
+            lm = Sj[7] * _qrot(Sj[:4], Xc) + Sj[4:7]
+            anchor = None
+        else:
+            anchor = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), 1.0])
+            lm = np.array([rng.uniform(0.15, 0.5)])
+            Xw = Sh[7] * _qrot(Sh[:4], anchor / lm[0]) + Sh[4:7]
+            Sj[4:7] = Xw - Sj[7] * _qrot(Sj[:4], np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2.5, 6)]))
+        m = np.array([rng.uniform(100, 500), rng.uniform(100, 400)])
+        ok, r, w, s, Jj, Jh, Jp, Jc = oracle.graph_obs_cam(kind, Sj, dof_j, Sh, dof_h, False, lm, True, anchor, m, cam, free)
+        assert ok and np.allclose(r, _pixel_residual_py(Sj, Sh, kind, lm, anchor, cam, m), rtol=1e-11, atol=1e-9)
+        res = lambda Sj_, Sh_, lm_, cam_: _pixel_residual_py(Sj_, Sh_, kind, lm_, anchor, cam_, m)
+        h = 1e-6
+        for k in range(7):
+            d = np.zeros(7); d[k] = h
+            fd = (res(oracle.sim3_retract(Sj, d), Sh, lm, cam) - res(oracle.sim3_retract(Sj, -d), Sh, lm, cam)) / (2 * h)
+            assert np.allclose(Jj[:, k], fd if (dof_j >> k) & 1 else 0.0, rtol=2e-5, atol=2e-4), ("Jj", trial, k)
+            if kind == 1:
+                fd = (res(Sj, oracle.sim3_retract(Sh, d), lm, cam) - res(Sj, oracle.sim3_retract(Sh, -d), lm, cam)) / (2 * h)
+                assert np.allclose(Jh[:, k], fd if (dof_h >> k) & 1 else 0.0, rtol=2e-5, atol=2e-4), ("Jh", trial, k)
+        for k in range(len(lm)):
+            e = np.zeros(len(lm)); e[k] = 1e-6
+            fd = (res(Sj, Sh, lm + e, cam) - res(Sj, Sh, lm - e, cam)) / 2e-6
+            assert np.allclose(Jp[:, k], fd, rtol=2e-5, atol=2e-4), ("Jp", trial, k)
+        for k in range(9):
+            e = np.zeros(9); e[k] = 1e-6 * max(1.0, abs(cam[k]))
+            fd = (res(Sj, Sh, lm, cam + e) - res(Sj, Sh, lm, cam - e)) / (2 * e[k])
+            assert np.allclose(Jc[:, k], fd if (free >> k) & 1 else 0.0, rtol=2e-5, atol=2e-4), ("Jc", trial, k)
