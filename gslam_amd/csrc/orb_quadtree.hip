@@ -20,6 +20,8 @@
 #include "orb_quadtree.h"
 
 #include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
 
 #include <new>
 
