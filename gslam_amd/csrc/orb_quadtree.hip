@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, i
     // idx / 11 on the 24-bit multiplier (full rate; a division by a constant costs a quarter-rate v_mul_hi_u32): exact for
     // idx < 418 since 5958 / 65536 - 1 / 11 = 2.8e-6
     const int r = (int)(__umul24((uint32_t)idx, 5958u) >> 16), d = idx - r * kWRowDw;
-    if (d < ndw) L.img[idx] = *reinterpret_cast<const uint32_t*>(img + (size_t)(y0 - 3 + r) * lv.pitch + xa + 4 * d);
+    // (rows and pitch are < 2^24, a level is < 4 GiB: 32-bit offset on the full-rate 24-bit multiplier)
+    if (d < ndw) L.img[idx] = *reinterpret_cast<const uint32_t*>(img + (__umul24((uint32_t)(y0 - 3 + r), (uint32_t)lv.pitch) + (uint32_t)(xa + 4 * d)));
   }
   for (int idx = lane; idx < (int)(sizeof(L.S) / 4); idx += 64) L.S[idx] = 0u;
   __builtin_amdgcn_wave_barrier();

@@ -18,7 +18,7 @@ BUDGET = {
     "fast_cells_kernelILb1ELi1E": 0,     # the shipped FAST / NMS / pyramid kernel
     "describe_kernelILi13ELb0E": 0,      # table-mode descriptors
     "resize_kernel": 0,
-    "slam_cells_wave_kernel": 1,         # quadtree mode: the 64-bit row address of the tile load
+    "slam_cells_wave_kernel": 0,         # quadtree mode
 }
 
 
