@@ -1308,6 +1308,9 @@ long long ipow(int b, int e) {
 
 }  // namespace
 
+// (host only) the multiplier the FAST launch uses instead of an integer division: see magic_div
+extern "C" uint32_t gh_magic_div(uint32_t d, uint32_t n_max) { return magic_div(d, n_max); }
+
 // ------------------------------------------------------------------------------------------------
 struct gh_orb_plan {
   gh_ctx* ctx = nullptr;

@@ -105,6 +105,7 @@ SIGNATURES = {
     "gh_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "gh_dev_memset": (C.c_int, [_vp, _vp, _i, _sz]),
     "gh_ctx_trim": (C.c_int, [_vp]),
+    "gh_magic_div": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "gh_ctx_set_ba_solver": (C.c_int, [_vp, _i]),
     "gh_ctx_last_ba_solver": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "gh_prof_enable": (C.c_int, [_vp, _i]),

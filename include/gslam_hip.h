@@ -148,6 +148,11 @@ gh_status gh_bf_valu_probe(gh_ctx* ctx, double* pairs_per_s);
  * kernels instead of an assumed cycles-per-instruction figure. */
 gh_status gh_valu_issue_probe(gh_ctx* ctx, int op, double* wave_insts_per_s, char* name, int name_cap);
 
+/* Host only (no GPU needed): the 32-bit multiplier m with (n * m) >> 32 == n / d for EVERY n <= n_max, or 0 when no such
+ * constant is guaranteed (the kernels then divide).  orb_fast_cells turns its tile id into (frame, tile row, tile column)
+ * with two of these instead of two integer divisions per wave; exported so that the guarantee can be tested exhaustively. */
+uint32_t gh_magic_div(uint32_t d, uint32_t n_max);
+
 /* ------------------------------------------------------------------ ORB front end ---- */
 /* Layout-identical to GSLAM::KeyPoint (GSLAM/core/Map.h:122-195, sizeof == 28). */
 typedef struct gh_keypoint {
