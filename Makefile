@@ -41,7 +41,7 @@ ref: oracle/_ref/libgslam_ref.so oracle/_ref/libgslam_ref_popcnt.so
 plugins: $(LIBDIR)/libgslam_optimizer.so $(LIBDIR)/libgslam_featuredetector.so $(LIBDIR)/libgslam_vocabulary.so $(LIBDIR)/libgslam_orbhip.so $(LIBDIR)/libgslam_estimator.so $(LIBDIR)/libgslamDB_synthplane.so $(LIBDIR)/libgslamDB_tumrgbd.so $(LIBDIR)/libgslamDB_kitti.so build/plugin_host build/gmap_check refapps
 
 # the MFMA matcher reads its accumulators with the VALU right away: keep them in VGPRs (no v_accvgpr_read per pair)
-build/obj/bf_match_mfma.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
+build/obj/bf_match_mfma.o build/obj/orb.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
 
 build/obj/%.o: gslam_amd/csrc/%.hip gslam_amd/csrc/common.h include/gslam_hip.h $(wildcard include/*.h gslam_amd/csrc/*.h)
 	@mkdir -p build/obj

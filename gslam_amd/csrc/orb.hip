@@ -1060,7 +1060,36 @@ __host__ __device__ inline void orb_sincos_deg(float a, float* cs, float* sn) {
 }
 __host__ __device__ inline int orb_reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-template <int BR, bool STEER>
+// The h-pass of the 7x7 blur as a banded matrix product on the (otherwise idle) matrix cores -- describe_kernel<13, false, true>.
+// B operand of v_mfma_f32_16x16x32_f16 for the horizontal taps: B[k][n] = g[k - n] (0 <= k - n <= 6), the same for both
+// 16-column blocks because each block has its own K window (patch columns 16 nb .. 16 nb + 31).  Lane l supplies column
+// n = l & 15, k = 8 (l >> 4) + e, e = 0..7 as eight f16 (the taps 144 / 268 / 391 / 442 are exact in f16).
+struct BlurBTable { uint32_t w[64][4]; };
+constexpr uint32_t f16_bits_of_int(int v) {  // 0 <= v < 2048: exact
+  if (v == 0) return 0u;
+  int e = 0;
+  while ((v >> (e + 1)) != 0) ++e;
+  return (uint32_t)(((e + 15) << 10) | ((v << (10 - e)) & 0x3FF));
+}
+constexpr BlurBTable make_blur_b() {
+  BlurBTable t{};
+  const int g[7] = {144, 268, 391, 442, 391, 268, 144};
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < 8; ++e) {
+      const int d = 8 * (l >> 4) + e - (l & 15);
+      const uint32_t h = (d >= 0 && d <= 6) ? f16_bits_of_int(g[d]) : 0u;
+      t.w[l][e >> 1] |= h << (16 * (e & 1));
+    }
+  return t;
+}
+__device__ const BlurBTable kBlurB = make_blur_b();
+
+// Layout of the blurred patch the MFMA variant leaves in LDS: column-major, one 32-byte line per blur column, row r at byte
+// 8 (r / 7) + r % 7 of the line (each lane of the v-pass owns 7 consecutive rows of one column and stores them as one
+// 8-byte write).  upload_pattern bakes either layout into the per-bin offset table.
+__host__ __device__ constexpr int blur_offset_mfma(int row, int col) { return col * 32 + 8 * (row / 7) + row % 7; }
+
+template <int BR, bool STEER, bool MF = false>
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
                                                        const int32_t* __restrict__ level_cnt,
@@ -1071,9 +1100,12 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   constexpr int kC = G::kC, kPatch = G::kPatch, kPatchPitch = G::kPatchPitch, kRowDw = G::kRowDw, kBlur = G::kBlur,
                 kBlurPitch = G::kBlurPitch, kGroups = G::kGroups;
   static_assert(kPatch <= 64 && kC >= 16, "one lane per patch row; the radius-15 centroid disc lies inside the patch");
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatch * kPatchPitch + 28];  // + slack for the 16-B row reads
-  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][(kPatch + 1) * kBlurPitch];
-  // The blurred patch REPLACES the raw one (last read by the h-pass, a wave barrier before the v-pass writes): 20.2 KB of
+  static_assert(!MF || (BR == 13 && !STEER), "the MFMA blur is written for the 33 x 33 patch of the table mode");
+  // MF: four more (uninitialised) rows below the patch -- the row map of the MFMA h-pass runs to row 36 with constant offsets
+  constexpr int kPatchRows = MF ? kPatch + 4 : kPatch;
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatchRows * kPatchPitch + 28];  // + slack for the 16-B row reads
+  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][MF ? 256 : (kPatch + 1) * kBlurPitch];  // MF: the blurred patch (1 KB)
+  // VALU variant: the blurred patch REPLACES the raw one (last read by the h-pass, a wave barrier before the v-pass writes): 20.2 KB of
   // LDS per workgroup in the table mode = 8 workgroups per CU instead of 6 (GSLAM_HIP_ORB_DESC_LDSPAD=3000 restores 6 for A/B runs)
   static_assert(sizeof(s_patch[0]) >= kBlur * kBlurPitch + 12, "the blurred patch fits where the raw patch was");
   static_assert(BR != 13 || sizeof(s_patch) + sizeof(s_h) <= 20480, "8 workgroups per CU");
@@ -1130,8 +1162,15 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
       struct __attribute__((packed, aligned(4))) RowN { uint32_t w[kRowDw]; };
       // (rows and pitch are < 2^24 and a level is < 4 GiB: a 32-bit offset on the full-rate 24-bit multiplier)
       const RowN row = *reinterpret_cast<const RowN*>(img + (__umul24((uint32_t)(py0 + lane), (uint32_t)lv.pitch) + (uint32_t)pa));
+      if constexpr (MF) {
+        // the MFMA operands are read as whole dwords: shift the row so that patch column 0 is byte 0 of its LDS row
+        const uint32_t sh = (uint32_t)(px0 - pa);
 #pragma unroll
-      for (int c = 0; c < kRowDw; ++c) dst[c] = row.w[c];
+        for (int c = 0; c < kRowDw; ++c) dst[c] = __builtin_amdgcn_alignbyte(c + 1 < kRowDw ? row.w[c + 1] : 0u, row.w[c], sh);
+      } else {
+#pragma unroll
+        for (int c = 0; c < kRowDw; ++c) dst[c] = row.w[c];
+      }
     } else {
       const uint8_t* rp = img + (size_t)orb_reflect101(py0 + lane, lv.h) * lv.pitch;
       for (int c = 0; c < kRowDw; ++c) {
@@ -1150,7 +1189,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     const int r = lane >> 1, h = lane & 1;
     const int v = r - 15, av = v < 0 ? -v : v;
     const int umax = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);  // GH_ORB_UMAX as nibbles
-    const uint32_t boff = (uint32_t)(px0 - pa) + (uint32_t)(kC - 15) + 16u * (uint32_t)h;  // byte offset of u = -15 + 16 h in patch row r + kC - 15
+    const uint32_t boff = (MF ? 0u : (uint32_t)(px0 - pa)) + (uint32_t)(kC - 15) + 16u * (uint32_t)h;  // byte offset of u = -15 + 16 h in patch row r + kC - 15
     const uint32_t* q = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (r + kC - 15) * kRowDw + (boff >> 2);
     const uint32_t sh = boff & 3u;
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
@@ -1187,80 +1226,145 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     if ((m10 != 0 || m01 != 0) && hit != 0ull) bin = __ffsll((unsigned long long)hit) - 1;
     angle = 12.0f * (float)bin;
   }
-  // separable 7x7 integer Gaussian: patch rows 0..kPatch-1 x blur cols -> s_h, then blur rows -> the blurred patch
-  uint32_t* hb = s_h[wv];
-  constexpr int kRowsPerTrip = 64 / kGroups;
-  const int lrow = lane / kGroups, lgrp = lane - lrow * kGroups;
-  constexpr uint32_t g[7] = {144, 268, 391, 442, 391, 268, 144};
-  // Wide LDS accesses (the kernel is LDS-issue bound with byte reads): one work item = 4 adjacent outputs.
-  // h-pass: 4 dwords of the patch row -> 10 source bytes (v_alignbyte with the wave-uniform row offset)
-  //         -> 4 outputs stored as one 16-byte write;  v-pass: 7 x 16-byte reads down the 4 columns -> 4 outputs.
-  {
-    const uint32_t off = (uint32_t)(px0 - pa);  // 0..3, wave-uniform
-    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(s_patch[wv]);
-    // lane -> (row of the trip, 4-column group), fixed for the whole kernel: kRowsPerTrip rows x kGroups groups per trip (63 / 60
-    // of the 64 lanes; same trip counts as a flat index, without a division by 7 / 10 in every trip)
-    for (int r = lrow; r < kPatch && lane < kRowsPerTrip * kGroups; r += kRowsPerTrip) {
-      const int gq = lgrp;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
-      const uint32_t* q = p32 + r * kRowDw + gq;
-      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-      const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off);  // source bytes 0..3 (patch col 4 gq + k)
-      const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, off);  // 4..7
-      const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, off);  // 8..11
-      // P[s] = {x[s], x[s+1]} as two 16-bit lanes (one v_perm each, straight from the 12-byte window); an output is
-      // 4 v_dot2_u32_u16 with the tap pairs (g0,g1) (g2,g3) (g4,g5) (g6,0) instead of 7 multiply-adds
-      typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-      u16x2 P[10];
+  // the four test words of this lane, requested before the blur so that their latency (an L2 hit each) hides under it instead
+  // of forming a chain of four load -> test -> store round trips behind it
+  const uint32_t* pat = STEER ? reinterpret_cast<const uint32_t*>(tb.base_pattern)
+                              : reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
+  const uint32_t pws[4] = {pat[lane], pat[64 + lane], pat[128 + lane], pat[192 + lane]};
+  uint8_t* bl = MF ? reinterpret_cast<uint8_t*>(s_h[wv]) : s_patch[wv];
+  if constexpr (MF) {
+    // Separable 7x7 integer Gaussian, horizontal pass on the matrix cores, vertical pass out of the accumulators.
+    //   h-pass   D[m][n] = sum_k A[m][k] B[k][n]:  A[m][k] = f16(1024 + P[row(m)][16 nb + k]) (a byte OR 0x6400 is that f16,
+    //            exact), B = the banded tap matrix kBlurB, C = 0.  The byte bias adds 1024 * 2048: D = 2^21 + H with H < 2^19,
+    //            a float in [2^21, 2^22) whose ulp is 1/4 -- its bits are 0x4A000000 | (H << 2): THE LOW 24 BITS ARE THE INTEGER
+    //            4 H (every partial sum is an integer below 2^24, so the f32 accumulation is exact in any order).
+    //   rows     D row m = 4 q + j of M-block mb is patch row 7 q + 4 mb + j: lane group q = lane >> 4 ends up holding the 16
+    //            consecutive rows 7 q .. 7 q + 15 of its blur column n = lane & 15 -- all the vertical pass needs for the 7
+    //            blur rows 7 q .. 7 q + 6.  (Rows 33 .. 36 are uninitialised LDS: finite after the OR, and only feed outputs
+    //            nobody reads.)
+    //   v-pass   7 x 7 v_mad_u32_u24 straight on the accumulator bits (the 24-bit multiplier reads exactly 4 H): the rounded
+    //            result is the top byte of sum 4 H g + 2^23, as in the VALU variant.
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int n16 = lane & 15, q4 = lane >> 4;
+    const uint4 bw = *reinterpret_cast<const uint4*>(kBlurB.w[lane]);
+    const f16x8 bfrag = __builtin_bit_cast(f16x8, bw);
+    // A: patch row 7 ((lane & 15) >> 2) + (lane & 3) + 4 mb, bytes 16 nb + 8 (lane >> 4) .. + 7
+    const uint32_t* arow = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (7 * (n16 >> 2) + (lane & 3)) * kRowDw + 2 * q4;
+    const uint32_t k64 = 0x64646464u;
+    uint32_t hs[2][16];
 #pragma unroll
-      for (int sft = 0; sft < 10; ++sft) {
-        // bytes sft, sft + 1 of {w0, w1, w2}: the perm sees 8 of the 12 bytes
-        const uint32_t lo_dw = sft < 7 ? w0 : w1, hi_dw = sft < 7 ? w1 : w2;
-        const uint32_t bsel = (uint32_t)(sft < 7 ? sft : sft - 4);
-        P[sft] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi_dw, lo_dw, 0x0c000c00u | ((bsel + 1u) << 16) | bsel));
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const uint32_t d0 = arow[4 * mb * kRowDw + 4 * nb], d1 = arow[4 * mb * kRowDw + 4 * nb + 1];
+        uint4 af;
+        af.x = __builtin_amdgcn_perm(k64, d0, 0x04010400u);  // {1024 + p0, 1024 + p1}
+        af.y = __builtin_amdgcn_perm(k64, d0, 0x04030402u);
+        af.z = __builtin_amdgcn_perm(k64, d1, 0x04010400u);
+        af.w = __builtin_amdgcn_perm(k64, d1, 0x04030402u);
+        const f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f};  // (an inline constant: no accumulator set-up)
+        const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af), bfrag, c0, 0, 0, 0);
+        // (__float_as_uint of an rvalue: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index)
+        hs[nb][4 * mb + 0] = __float_as_uint(dd[0]);
+        hs[nb][4 * mb + 1] = __float_as_uint(dd[1]);
+        hs[nb][4 * mb + 2] = __float_as_uint(dd[2]);
+        hs[nb][4 * mb + 3] = __float_as_uint(dd[3]);
       }
-      constexpr uint32_t g01 = 144u | (268u << 16), g23 = 391u | (442u << 16), g45 = 391u | (268u << 16), g6 = 144u;
-      uint4 o;
-      uint32_t acc[4];
+    // The 49 multiply-adds of a column block are ONE asm statement that opens with its own wait states: the compiler's hazard
+    // recogniser does not look inside asm statements, and a VALU read of an MFMA result needs up to 18 of them (an asm
+    // v_mad_u32_u24 per term read the accumulators while the matrix core was still writing them; written with __umul24 the
+    // compiler emits v_mul_u32_u24 pairs + v_add3_u32 instead -- 136 instructions for these 98).  (The factor 4 of the VALU
+    // variant's weights is in the accumulator bits.)
+    const uint32_t gw0 = 144u, gw1 = 268u, gw2 = 391u, gw3 = 442u, c23 = 1u << 23;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t t0 = __builtin_amdgcn_udot2(P[i], __builtin_bit_cast(u16x2, g01), 0u, false);
-        t0 = __builtin_amdgcn_udot2(P[i + 2], __builtin_bit_cast(u16x2, g23), t0, false);
-        t0 = __builtin_amdgcn_udot2(P[i + 4], __builtin_bit_cast(u16x2, g45), t0, false);
-        acc[i] = __builtin_amdgcn_udot2(P[i + 6], __builtin_bit_cast(u16x2, g6), t0, false);
+    for (int nb = 0; nb < 2; ++nb) {
+      uint32_t o[8];
+      asm volatile("s_nop 15\n\ts_nop 2\n\tv_mad_u32_u24 %0, %7, %20, %24\n\tv_mad_u32_u24 %0, %8, %21, %0\n\tv_mad_u32_u24 %0, %9, %22, %0\n\tv_mad_u32_u24 %0, %10, %23, %0\n\tv_mad_u32_u24 %0, %11, %22, %0\n\tv_mad_u32_u24 %0, %12, %21, %0\n\tv_mad_u32_u24 %0, %13, %20, %0\n\tv_mad_u32_u24 %1, %8, %20, %24\n\tv_mad_u32_u24 %1, %9, %21, %1\n\tv_mad_u32_u24 %1, %10, %22, %1\n\tv_mad_u32_u24 %1, %11, %23, %1\n\tv_mad_u32_u24 %1, %12, %22, %1\n\tv_mad_u32_u24 %1, %13, %21, %1\n\tv_mad_u32_u24 %1, %14, %20, %1\n\tv_mad_u32_u24 %2, %9, %20, %24\n\tv_mad_u32_u24 %2, %10, %21, %2\n\tv_mad_u32_u24 %2, %11, %22, %2\n\tv_mad_u32_u24 %2, %12, %23, %2\n\tv_mad_u32_u24 %2, %13, %22, %2\n\tv_mad_u32_u24 %2, %14, %21, %2\n\tv_mad_u32_u24 %2, %15, %20, %2\n\tv_mad_u32_u24 %3, %10, %20, %24\n\tv_mad_u32_u24 %3, %11, %21, %3\n\tv_mad_u32_u24 %3, %12, %22, %3\n\tv_mad_u32_u24 %3, %13, %23, %3\n\tv_mad_u32_u24 %3, %14, %22, %3\n\tv_mad_u32_u24 %3, %15, %21, %3\n\tv_mad_u32_u24 %3, %16, %20, %3\n\tv_mad_u32_u24 %4, %11, %20, %24\n\tv_mad_u32_u24 %4, %12, %21, %4\n\tv_mad_u32_u24 %4, %13, %22, %4\n\tv_mad_u32_u24 %4, %14, %23, %4\n\tv_mad_u32_u24 %4, %15, %22, %4\n\tv_mad_u32_u24 %4, %16, %21, %4\n\tv_mad_u32_u24 %4, %17, %20, %4\n\tv_mad_u32_u24 %5, %12, %20, %24\n\tv_mad_u32_u24 %5, %13, %21, %5\n\tv_mad_u32_u24 %5, %14, %22, %5\n\tv_mad_u32_u24 %5, %15, %23, %5\n\tv_mad_u32_u24 %5, %16, %22, %5\n\tv_mad_u32_u24 %5, %17, %21, %5\n\tv_mad_u32_u24 %5, %18, %20, %5\n\tv_mad_u32_u24 %6, %13, %20, %24\n\tv_mad_u32_u24 %6, %14, %21, %6\n\tv_mad_u32_u24 %6, %15, %22, %6\n\tv_mad_u32_u24 %6, %16, %23, %6\n\tv_mad_u32_u24 %6, %17, %22, %6\n\tv_mad_u32_u24 %6, %18, %21, %6\n\tv_mad_u32_u24 %6, %19, %20, %6"
+                   : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
+                   : "v"(hs[nb][0]), "v"(hs[nb][1]), "v"(hs[nb][2]), "v"(hs[nb][3]), "v"(hs[nb][4]), "v"(hs[nb][5]), "v"(hs[nb][6]),
+                     "v"(hs[nb][7]), "v"(hs[nb][8]), "v"(hs[nb][9]), "v"(hs[nb][10]), "v"(hs[nb][11]), "v"(hs[nb][12]),
+                     "v"(gw0), "v"(gw1), "v"(gw2), "v"(gw3), "s"(c23));
+      o[7] = 0u;
+      uint2 pk;
+      pk.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0703u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
+      pk.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[7], o[6], 0x0c0c0703u), __builtin_amdgcn_perm(o[5], o[4], 0x0c0c0703u), 0x05040100u);
+      // blur column 16 nb + n16 (columns 27 .. 31 are scratch lines of the 1 KB buffer), rows 7 q4 .. 7 q4 + 6
+      *reinterpret_cast<uint2*>(bl + (16 * nb + n16) * 32 + 8 * q4) = pk;
+    }
+  } else {
+    // separable 7x7 integer Gaussian: patch rows 0..kPatch-1 x blur cols -> s_h, then blur rows -> the blurred patch
+    uint32_t* hb = s_h[wv];
+    constexpr int kRowsPerTrip = 64 / kGroups;
+    const int lrow = lane / kGroups, lgrp = lane - lrow * kGroups;
+    constexpr uint32_t g[7] = {144, 268, 391, 442, 391, 268, 144};
+    // Wide LDS accesses (the kernel is LDS-issue bound with byte reads): one work item = 4 adjacent outputs.
+    // h-pass: 4 dwords of the patch row -> 10 source bytes (v_alignbyte with the wave-uniform row offset)
+    //         -> 4 outputs stored as one 16-byte write;  v-pass: 7 x 16-byte reads down the 4 columns -> 4 outputs.
+    {
+      const uint32_t off = (uint32_t)(px0 - pa);  // 0..3, wave-uniform
+      const uint32_t* p32 = reinterpret_cast<const uint32_t*>(s_patch[wv]);
+      // lane -> (row of the trip, 4-column group), fixed for the whole kernel: kRowsPerTrip rows x kGroups groups per trip (63 / 60
+      // of the 64 lanes; same trip counts as a flat index, without a division by 7 / 10 in every trip)
+      for (int r = lrow; r < kPatch && lane < kRowsPerTrip * kGroups; r += kRowsPerTrip) {
+        const int gq = lgrp;  // outputs: blur cols 4 gq .. 4 gq + 3 of patch row r
+        const uint32_t* q = p32 + r * kRowDw + gq;
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off);  // source bytes 0..3 (patch col 4 gq + k)
+        const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, off);  // 4..7
+        const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, off);  // 8..11
+        // P[s] = {x[s], x[s+1]} as two 16-bit lanes (one v_perm each, straight from the 12-byte window); an output is
+        // 4 v_dot2_u32_u16 with the tap pairs (g0,g1) (g2,g3) (g4,g5) (g6,0) instead of 7 multiply-adds
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        u16x2 P[10];
+  #pragma unroll
+        for (int sft = 0; sft < 10; ++sft) {
+          // bytes sft, sft + 1 of {w0, w1, w2}: the perm sees 8 of the 12 bytes
+          const uint32_t lo_dw = sft < 7 ? w0 : w1, hi_dw = sft < 7 ? w1 : w2;
+          const uint32_t bsel = (uint32_t)(sft < 7 ? sft : sft - 4);
+          P[sft] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi_dw, lo_dw, 0x0c000c00u | ((bsel + 1u) << 16) | bsel));
+        }
+        constexpr uint32_t g01 = 144u | (268u << 16), g23 = 391u | (442u << 16), g45 = 391u | (268u << 16), g6 = 144u;
+        uint4 o;
+        uint32_t acc[4];
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint32_t t0 = __builtin_amdgcn_udot2(P[i], __builtin_bit_cast(u16x2, g01), 0u, false);
+          t0 = __builtin_amdgcn_udot2(P[i + 2], __builtin_bit_cast(u16x2, g23), t0, false);
+          t0 = __builtin_amdgcn_udot2(P[i + 4], __builtin_bit_cast(u16x2, g45), t0, false);
+          acc[i] = __builtin_amdgcn_udot2(P[i + 6], __builtin_bit_cast(u16x2, g6), t0, false);
+        }
+        o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
+        *reinterpret_cast<uint4*>(&hb[r * kBlurPitch + 4 * gq]) = o;
       }
-      o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
-      *reinterpret_cast<uint4*>(&hb[r * kBlurPitch + 4 * gq]) = o;
     }
-  }
-  __builtin_amdgcn_wave_barrier();
-  uint8_t* bl = s_patch[wv];
-  // v-pass: one work item = 4 adjacent outputs of one blur row: 7 x 16-byte reads down the 4 columns, 28
-  // v_mad_u32_u24 (h sums < 2^20), weights x4 so that the rounded result is the top byte of the sum
-  // ((4 s + 2^23) >> 24 == (s + 2^21) >> 22; 4 * 2048 * 522240 + 2^23 < 2^32), one dword store.
-  for (int rb = lrow; rb < kBlur && lane < kRowsPerTrip * kGroups; rb += kRowsPerTrip) {
-    const int cg = lgrp;
-    uint32_t acc[4] = {1u << 23, 1u << 23, 1u << 23, 1u << 23};
-#pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      const uint4 hv = *reinterpret_cast<const uint4*>(&hb[(rb + t) * kBlurPitch + 4 * cg]);
-      acc[0] += __umul24(4u * g[t], hv.x);
-      acc[1] += __umul24(4u * g[t], hv.y);
-      acc[2] += __umul24(4u * g[t], hv.z);
-      acc[3] += __umul24(4u * g[t], hv.w);
+    __builtin_amdgcn_wave_barrier();
+    // v-pass: one work item = 4 adjacent outputs of one blur row: 7 x 16-byte reads down the 4 columns, 28
+    // v_mad_u32_u24 (h sums < 2^20), weights x4 so that the rounded result is the top byte of the sum
+    // ((4 s + 2^23) >> 24 == (s + 2^21) >> 22; 4 * 2048 * 522240 + 2^23 < 2^32), one dword store.
+    for (int rb = lrow; rb < kBlur && lane < kRowsPerTrip * kGroups; rb += kRowsPerTrip) {
+      const int cg = lgrp;
+      uint32_t acc[4] = {1u << 23, 1u << 23, 1u << 23, 1u << 23};
+  #pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const uint4 hv = *reinterpret_cast<const uint4*>(&hb[(rb + t) * kBlurPitch + 4 * cg]);
+        acc[0] += __umul24(4u * g[t], hv.x);
+        acc[1] += __umul24(4u * g[t], hv.y);
+        acc[2] += __umul24(4u * g[t], hv.z);
+        acc[3] += __umul24(4u * g[t], hv.w);
+      }
+      *reinterpret_cast<uint32_t*>(&bl[rb * kBlurPitch + 4 * cg]) =
+          __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0703u) << 16);
     }
-    *reinterpret_cast<uint32_t*>(&bl[rb * kBlurPitch + 4 * cg]) =
-        __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0703u) << 16);
   }
   __builtin_amdgcn_wave_barrier();
   // 256 binary tests, 64 per ballot
   uint8_t* drow = desc + ((size_t)b * K + pos) * 32;
   float cs = 1.0f, sn = 0.0f;
   if constexpr (STEER) orb_sincos_deg(angle, &cs, &sn);
-  const uint32_t* pat = STEER ? reinterpret_cast<const uint32_t*>(tb.base_pattern)
-                              : reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
-    const uint32_t pw = pat[gq * 64 + lane];
+    const uint32_t pw = pws[gq];
     int va, vb;
     if constexpr (STEER) {
       // pw = the unrotated test (ax, ay, bx, by) as four int8; (x', y') = (rint(x cos - y sin), rint(x sin + y cos)), ties to even
@@ -1338,6 +1442,7 @@ struct gh_orb_plan {
   hipStream_t pyr_stream = nullptr;
   hipEvent_t ev_pyr[kMaxL]{}, ev_pyr_start = nullptr;
   int desc_lds_pad = 0;      // GSLAM_HIP_ORB_DESC_LDSPAD: the same for orb_describe
+  bool desc_mfma = true;     // GSLAM_HIP_ORB_DESC_MFMA=0: the 7x7 blur of orb_describe on the VALU (rounds 1-4) instead of the h-pass on MFMA
   int lds_pad = 0;           // GSLAM_HIP_ORB_LDSPAD: extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test (rounds 2-3), 1 = SWAR on 16-bit fields
   bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
@@ -1441,7 +1546,8 @@ static gh_status upload_pattern(gh_orb_plan* p, const int8_t* rot) {
   for (int b = 0; b < 30; ++b)
     for (int t = 0; t < 256; ++t) {
       const int8_t* q = rot + ((size_t)b * 256 + t) * 4;
-      const uint32_t oa = (uint32_t)((13 + q[1]) * kBlurPitch + 13 + q[0]), ob = (uint32_t)((13 + q[3]) * kBlurPitch + 13 + q[2]);
+      const uint32_t oa = p->desc_mfma ? (uint32_t)blur_offset_mfma(13 + q[1], 13 + q[0]) : (uint32_t)((13 + q[1]) * kBlurPitch + 13 + q[0]);
+      const uint32_t ob = p->desc_mfma ? (uint32_t)blur_offset_mfma(13 + q[3], 13 + q[2]) : (uint32_t)((13 + q[3]) * kBlurPitch + 13 + q[2]);
       off[b * 256 + t] = oa | (ob << 16);
     }
   return gh_dev_upload(p->ctx, p->d_pattern, off.data(), off.size() * sizeof(uint32_t));
@@ -1566,6 +1672,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_LDSPAD")) p->lds_pad = atoi(e) < 0 ? 0 : atoi(e);
   if (const char* e = getenv("GSLAM_HIP_ORB_DESC_LDSPAD")) p->desc_lds_pad = atoi(e) < 0 ? 0 : atoi(e);
+  if (const char* e = getenv("GSLAM_HIP_ORB_DESC_MFMA")) p->desc_mfma = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
@@ -2038,11 +2145,14 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     DevTables tb{p->d_pattern, p->d_dir, p->d_base_pattern};
     const long long blocks = (long long)gh_div_up(K, 4) * batch;
     GH_CHECK_ARG(ctx, blocks < (1LL << 30));
-    if (p->steer == 0)
-      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<13, false>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
+    if (p->steer == 0 && p->desc_mfma)
+      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<13, false, true>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
+                p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
+    else if (p->steer == 0)
+      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<13, false, false>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
                 p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
     else
-      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<19, true>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
+      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<19, true, false>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
                 p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
   }
   return GH_OK;
