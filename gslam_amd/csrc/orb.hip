@@ -1089,6 +1089,127 @@ __device__ const BlurBTable kBlurB = make_blur_b();
 // 8-byte write).  upload_pattern bakes either layout into the per-bin offset table.
 __host__ __device__ constexpr int blur_offset_mfma(int row, int col) { return col * 32 + 8 * (row / 7) + row % 7; }
 
+// Intensity-centroid moments of a patch in LDS (oracle step 6): rows of kRowDw dwords, patch column 0 at byte xoff of a row,
+// patch centre at [kC][kC].  Returns the wave sums in every lane.
+template <int kC, int kRowDw>
+__device__ __forceinline__ void desc_moments(const uint8_t* patch, uint32_t xoff, int lane, int* m10_out, int* m01_out) {
+  // intensity centroid over the radius-15 disc (patch centre at [kC][kC]).  Lane = (disc row, half): 16 bytes of
+  // the row as 4 dwords (unaligned start: 5 dword reads + v_alignbyte), bytes outside |u| <= u_max(|v|) masked off,
+  // then two v_dot4_u32_u8 per dword: sum I and sum (u + 16) I  ->  m10 = sum (u + 16) I - 16 sum I, m01 = v sum I.
+  int m10 = 0, m01 = 0;
+  if (lane < 62) {
+    const int r = lane >> 1, h = lane & 1;
+    const int v = r - 15, av = v < 0 ? -v : v;
+    const int umax = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);  // GH_ORB_UMAX as nibbles
+    const uint32_t boff = xoff + (uint32_t)(kC - 15) + 16u * (uint32_t)h;  // byte offset of u = -15 + 16 h in patch row r + kC - 15
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(patch) + (r + kC - 15) * kRowDw + (boff >> 2);
+    const uint32_t sh = boff & 3u;
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+    const uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                           __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+    // kept byte positions p (u = -15 + 16 h + p): h = 0: p >= 15 - umax;  h = 1: p <= umax - 1
+    const int lo = h ? 0 : 15 - umax, hi = h ? umax - 1 : 15;
+    uint32_t sI = 0, sW = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nlo = min(max(lo - 4 * j, 0), 4), nhi = min(max(4 * j + 3 - hi, 0), 4);
+      const uint32_t mask = (uint32_t)(0xFFFFFFFFull << (8 * nlo)) & (uint32_t)(0xFFFFFFFFull >> (8 * nhi));
+      const uint32_t I4 = w[j] & mask;
+      const uint32_t wgt = 0x04030201u + 0x04040404u * (uint32_t)j + (h ? 0x10101010u : 0u);  // u + 16 per byte
+      sI = __builtin_amdgcn_udot4(I4, 0x01010101u, sI, false);
+      sW = __builtin_amdgcn_udot4(I4, wgt, sW, false);
+    }
+    m10 = (int)sW - 16 * (int)sI;
+    m01 = __mul24(v, (int)sI);  // |v| <= 15, sI < 2^13
+  }
+  *m10_out = wave_sum_i32(m10);
+  *m01_out = wave_sum_i32(m01);
+}
+
+// Orientation bin of the 30-bin table mode from the moments: the first bin whose direction has the centroid to its right
+// while the previous one has it to its left (integer cross products, oracle step 6).
+__device__ __forceinline__ int desc_bin(int dir_x, int dir_y, int m10, int m01, int lane);
+__device__ __forceinline__ int desc_bin(const int32_t* __restrict__ dir, int m10, int m01, int lane) {
+  return desc_bin(lane < GH_ORB_NBINS ? dir[2 * lane] : 0, lane < GH_ORB_NBINS ? dir[2 * lane + 1] : 0, m10, m01, lane);
+}
+// (dir_x, dir_y) = this lane's direction (lanes >= GH_ORB_NBINS: anything)
+__device__ __forceinline__ int desc_bin(int dir_x, int dir_y, int m10, int m01, int lane) {
+  long long c = 0;
+  if (lane < GH_ORB_NBINS) c = (long long)dir_x * m01 - (long long)dir_y * m10;
+  const int c_neg = c < 0 ? 1 : 0;
+  const int prev_lane = (lane + GH_ORB_NBINS - 1) % GH_ORB_NBINS;
+  const int prev_neg = __shfl(c_neg, prev_lane);
+  const uint64_t hit = __ballot(lane < GH_ORB_NBINS && !prev_neg && c_neg);
+  int bin = 0;
+  if ((m10 != 0 || m01 != 0) && hit != 0ull) bin = __ffsll((unsigned long long)hit) - 1;
+  return bin;
+}
+
+// The 7x7 blur of a 33 x 33 patch (+ 4 scratch rows) in LDS, rows of 9 dwords with patch column 0 at byte 0, into the
+// column-major 1 KB blurred patch bl (blur_offset_mfma) -- orb_describe's MFMA formulation.
+__device__ __forceinline__ uint4 desc_blur_b(int lane) { return *reinterpret_cast<const uint4*>(kBlurB.w[lane]); }
+__device__ __forceinline__ void desc_blur_mfma(const uint8_t* patch, uint8_t* bl, int lane, const uint4 bw) {
+  constexpr int kRowDw = 9;
+  // Separable 7x7 integer Gaussian, horizontal pass on the matrix cores, vertical pass out of the accumulators.
+  //   h-pass   D[m][n] = sum_k A[m][k] B[k][n]:  A[m][k] = f16(1024 + P[row(m)][16 nb + k]) (a byte OR 0x6400 is that f16,
+  //            exact), B = the banded tap matrix kBlurB, C = 0.  The byte bias adds 1024 * 2048: D = 2^21 + H with H < 2^19,
+  //            a float in [2^21, 2^22) whose ulp is 1/4 -- its bits are 0x4A000000 | (H << 2): THE LOW 24 BITS ARE THE INTEGER
+  //            4 H (every partial sum is an integer below 2^24, so the f32 accumulation is exact in any order).
+  //   rows     D row m = 4 q + j of M-block mb is patch row 7 q + 4 mb + j: lane group q = lane >> 4 ends up holding the 16
+  //            consecutive rows 7 q .. 7 q + 15 of its blur column n = lane & 15 -- all the vertical pass needs for the 7
+  //            blur rows 7 q .. 7 q + 6.  (Rows 33 .. 36 are uninitialised LDS: finite after the OR, and only feed outputs
+  //            nobody reads.)
+  //   v-pass   7 x 7 v_mad_u32_u24 straight on the accumulator bits (the 24-bit multiplier reads exactly 4 H): the rounded
+  //            result is the top byte of sum 4 H g + 2^23, as in the VALU variant.
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int n16 = lane & 15, q4 = lane >> 4;
+  const f16x8 bfrag = __builtin_bit_cast(f16x8, bw);
+  // A: patch row 7 ((lane & 15) >> 2) + (lane & 3) + 4 mb, bytes 16 nb + 8 (lane >> 4) .. + 7
+  const uint32_t* arow = reinterpret_cast<const uint32_t*>(patch) + (7 * (n16 >> 2) + (lane & 3)) * kRowDw + 2 * q4;
+  const uint32_t k64 = 0x64646464u;
+  uint32_t hs[2][16];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const uint32_t d0 = arow[4 * mb * kRowDw + 4 * nb], d1 = arow[4 * mb * kRowDw + 4 * nb + 1];
+      uint4 af;
+      af.x = __builtin_amdgcn_perm(k64, d0, 0x04010400u);  // {1024 + p0, 1024 + p1}
+      af.y = __builtin_amdgcn_perm(k64, d0, 0x04030402u);
+      af.z = __builtin_amdgcn_perm(k64, d1, 0x04010400u);
+      af.w = __builtin_amdgcn_perm(k64, d1, 0x04030402u);
+      const f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f};  // (an inline constant: no accumulator set-up)
+      const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af), bfrag, c0, 0, 0, 0);
+      // (__float_as_uint of an rvalue: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index)
+      hs[nb][4 * mb + 0] = __float_as_uint(dd[0]);
+      hs[nb][4 * mb + 1] = __float_as_uint(dd[1]);
+      hs[nb][4 * mb + 2] = __float_as_uint(dd[2]);
+      hs[nb][4 * mb + 3] = __float_as_uint(dd[3]);
+    }
+  // The 49 multiply-adds of a column block are ONE asm statement that opens with its own wait states: the compiler's hazard
+  // recogniser does not look inside asm statements, and a VALU read of an MFMA result needs up to 18 of them (an asm
+  // v_mad_u32_u24 per term read the accumulators while the matrix core was still writing them; written with __umul24 the
+  // compiler emits v_mul_u32_u24 pairs + v_add3_u32 instead -- 136 instructions for these 98).  (The factor 4 of the VALU
+  // variant's weights is in the accumulator bits.)
+  const uint32_t gw0 = 144u, gw1 = 268u, gw2 = 391u, gw3 = 442u, c23 = 1u << 23;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    uint32_t o[8];
+    asm volatile("s_nop 15\n\ts_nop 2\n\tv_mad_u32_u24 %0, %7, %20, %24\n\tv_mad_u32_u24 %0, %8, %21, %0\n\tv_mad_u32_u24 %0, %9, %22, %0\n\tv_mad_u32_u24 %0, %10, %23, %0\n\tv_mad_u32_u24 %0, %11, %22, %0\n\tv_mad_u32_u24 %0, %12, %21, %0\n\tv_mad_u32_u24 %0, %13, %20, %0\n\tv_mad_u32_u24 %1, %8, %20, %24\n\tv_mad_u32_u24 %1, %9, %21, %1\n\tv_mad_u32_u24 %1, %10, %22, %1\n\tv_mad_u32_u24 %1, %11, %23, %1\n\tv_mad_u32_u24 %1, %12, %22, %1\n\tv_mad_u32_u24 %1, %13, %21, %1\n\tv_mad_u32_u24 %1, %14, %20, %1\n\tv_mad_u32_u24 %2, %9, %20, %24\n\tv_mad_u32_u24 %2, %10, %21, %2\n\tv_mad_u32_u24 %2, %11, %22, %2\n\tv_mad_u32_u24 %2, %12, %23, %2\n\tv_mad_u32_u24 %2, %13, %22, %2\n\tv_mad_u32_u24 %2, %14, %21, %2\n\tv_mad_u32_u24 %2, %15, %20, %2\n\tv_mad_u32_u24 %3, %10, %20, %24\n\tv_mad_u32_u24 %3, %11, %21, %3\n\tv_mad_u32_u24 %3, %12, %22, %3\n\tv_mad_u32_u24 %3, %13, %23, %3\n\tv_mad_u32_u24 %3, %14, %22, %3\n\tv_mad_u32_u24 %3, %15, %21, %3\n\tv_mad_u32_u24 %3, %16, %20, %3\n\tv_mad_u32_u24 %4, %11, %20, %24\n\tv_mad_u32_u24 %4, %12, %21, %4\n\tv_mad_u32_u24 %4, %13, %22, %4\n\tv_mad_u32_u24 %4, %14, %23, %4\n\tv_mad_u32_u24 %4, %15, %22, %4\n\tv_mad_u32_u24 %4, %16, %21, %4\n\tv_mad_u32_u24 %4, %17, %20, %4\n\tv_mad_u32_u24 %5, %12, %20, %24\n\tv_mad_u32_u24 %5, %13, %21, %5\n\tv_mad_u32_u24 %5, %14, %22, %5\n\tv_mad_u32_u24 %5, %15, %23, %5\n\tv_mad_u32_u24 %5, %16, %22, %5\n\tv_mad_u32_u24 %5, %17, %21, %5\n\tv_mad_u32_u24 %5, %18, %20, %5\n\tv_mad_u32_u24 %6, %13, %20, %24\n\tv_mad_u32_u24 %6, %14, %21, %6\n\tv_mad_u32_u24 %6, %15, %22, %6\n\tv_mad_u32_u24 %6, %16, %23, %6\n\tv_mad_u32_u24 %6, %17, %22, %6\n\tv_mad_u32_u24 %6, %18, %21, %6\n\tv_mad_u32_u24 %6, %19, %20, %6"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
+                 : "v"(hs[nb][0]), "v"(hs[nb][1]), "v"(hs[nb][2]), "v"(hs[nb][3]), "v"(hs[nb][4]), "v"(hs[nb][5]), "v"(hs[nb][6]),
+                   "v"(hs[nb][7]), "v"(hs[nb][8]), "v"(hs[nb][9]), "v"(hs[nb][10]), "v"(hs[nb][11]), "v"(hs[nb][12]),
+                   "v"(gw0), "v"(gw1), "v"(gw2), "v"(gw3), "s"(c23));
+    o[7] = 0u;
+    uint2 pk;
+    pk.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0703u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
+    pk.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[7], o[6], 0x0c0c0703u), __builtin_amdgcn_perm(o[5], o[4], 0x0c0c0703u), 0x05040100u);
+    // blur column 16 nb + n16 (columns 27 .. 31 are scratch lines of the 1 KB buffer), rows 7 q4 .. 7 q4 + 6
+    *reinterpret_cast<uint2*>(bl + (16 * nb + n16) * 32 + 8 * q4) = pk;
+  }
+}
+
 template <int BR, bool STEER, bool MF = false>
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
@@ -1181,49 +1302,14 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
     }
   }
   __builtin_amdgcn_wave_barrier();
-  // intensity centroid over the radius-15 disc (patch centre at [kC][kC]).  Lane = (disc row, half): 16 bytes of
-  // the row as 4 dwords (unaligned start: 5 dword reads + v_alignbyte), bytes outside |u| <= u_max(|v|) masked off,
-  // then two v_dot4_u32_u8 per dword: sum I and sum (u + 16) I  ->  m10 = sum (u + 16) I - 16 sum I, m01 = v sum I.
-  int m10 = 0, m01 = 0;
-  if (lane < 62) {
-    const int r = lane >> 1, h = lane & 1;
-    const int v = r - 15, av = v < 0 ? -v : v;
-    const int umax = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);  // GH_ORB_UMAX as nibbles
-    const uint32_t boff = (MF ? 0u : (uint32_t)(px0 - pa)) + (uint32_t)(kC - 15) + 16u * (uint32_t)h;  // byte offset of u = -15 + 16 h in patch row r + kC - 15
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (r + kC - 15) * kRowDw + (boff >> 2);
-    const uint32_t sh = boff & 3u;
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-    const uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                           __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-    // kept byte positions p (u = -15 + 16 h + p): h = 0: p >= 15 - umax;  h = 1: p <= umax - 1
-    const int lo = h ? 0 : 15 - umax, hi = h ? umax - 1 : 15;
-    uint32_t sI = 0, sW = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nlo = min(max(lo - 4 * j, 0), 4), nhi = min(max(4 * j + 3 - hi, 0), 4);
-      const uint32_t mask = (uint32_t)(0xFFFFFFFFull << (8 * nlo)) & (uint32_t)(0xFFFFFFFFull >> (8 * nhi));
-      const uint32_t I4 = w[j] & mask;
-      const uint32_t wgt = 0x04030201u + 0x04040404u * (uint32_t)j + (h ? 0x10101010u : 0u);  // u + 16 per byte
-      sI = __builtin_amdgcn_udot4(I4, 0x01010101u, sI, false);
-      sW = __builtin_amdgcn_udot4(I4, wgt, sW, false);
-    }
-    m10 = (int)sW - 16 * (int)sI;
-    m01 = __mul24(v, (int)sI);  // |v| <= 15, sI < 2^13
-  }
-  m10 = wave_sum_i32(m10);
-  m01 = wave_sum_i32(m01);
+  int m10, m01;
+  desc_moments<kC, kRowDw>(s_patch[wv], MF ? 0u : (uint32_t)(px0 - pa), lane, &m10, &m01);
   int bin = 0;
   float angle = 0.0f;
   if constexpr (STEER) {
     angle = orb_fast_atan2_deg((float)m01, (float)m10);  // |m| < 2^24: the conversions are exact
   } else {
-    long long c = 0;
-    if (lane < GH_ORB_NBINS) c = (long long)tb.dir[2 * lane] * m01 - (long long)tb.dir[2 * lane + 1] * m10;
-    const int c_neg = c < 0 ? 1 : 0;
-    const int prev_lane = (lane + GH_ORB_NBINS - 1) % GH_ORB_NBINS;
-    const int prev_neg = __shfl(c_neg, prev_lane);
-    const uint64_t hit = __ballot(lane < GH_ORB_NBINS && !prev_neg && c_neg);
-    if ((m10 != 0 || m01 != 0) && hit != 0ull) bin = __ffsll((unsigned long long)hit) - 1;
+    bin = desc_bin(tb.dir, m10, m01, lane);
     angle = 12.0f * (float)bin;
   }
   // the four test words of this lane, requested before the blur so that their latency (an L2 hit each) hides under it instead
@@ -1233,65 +1319,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   const uint32_t pws[4] = {pat[lane], pat[64 + lane], pat[128 + lane], pat[192 + lane]};
   uint8_t* bl = MF ? reinterpret_cast<uint8_t*>(s_h[wv]) : s_patch[wv];
   if constexpr (MF) {
-    // Separable 7x7 integer Gaussian, horizontal pass on the matrix cores, vertical pass out of the accumulators.
-    //   h-pass   D[m][n] = sum_k A[m][k] B[k][n]:  A[m][k] = f16(1024 + P[row(m)][16 nb + k]) (a byte OR 0x6400 is that f16,
-    //            exact), B = the banded tap matrix kBlurB, C = 0.  The byte bias adds 1024 * 2048: D = 2^21 + H with H < 2^19,
-    //            a float in [2^21, 2^22) whose ulp is 1/4 -- its bits are 0x4A000000 | (H << 2): THE LOW 24 BITS ARE THE INTEGER
-    //            4 H (every partial sum is an integer below 2^24, so the f32 accumulation is exact in any order).
-    //   rows     D row m = 4 q + j of M-block mb is patch row 7 q + 4 mb + j: lane group q = lane >> 4 ends up holding the 16
-    //            consecutive rows 7 q .. 7 q + 15 of its blur column n = lane & 15 -- all the vertical pass needs for the 7
-    //            blur rows 7 q .. 7 q + 6.  (Rows 33 .. 36 are uninitialised LDS: finite after the OR, and only feed outputs
-    //            nobody reads.)
-    //   v-pass   7 x 7 v_mad_u32_u24 straight on the accumulator bits (the 24-bit multiplier reads exactly 4 H): the rounded
-    //            result is the top byte of sum 4 H g + 2^23, as in the VALU variant.
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int n16 = lane & 15, q4 = lane >> 4;
-    const uint4 bw = *reinterpret_cast<const uint4*>(kBlurB.w[lane]);
-    const f16x8 bfrag = __builtin_bit_cast(f16x8, bw);
-    // A: patch row 7 ((lane & 15) >> 2) + (lane & 3) + 4 mb, bytes 16 nb + 8 (lane >> 4) .. + 7
-    const uint32_t* arow = reinterpret_cast<const uint32_t*>(s_patch[wv]) + (7 * (n16 >> 2) + (lane & 3)) * kRowDw + 2 * q4;
-    const uint32_t k64 = 0x64646464u;
-    uint32_t hs[2][16];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const uint32_t d0 = arow[4 * mb * kRowDw + 4 * nb], d1 = arow[4 * mb * kRowDw + 4 * nb + 1];
-        uint4 af;
-        af.x = __builtin_amdgcn_perm(k64, d0, 0x04010400u);  // {1024 + p0, 1024 + p1}
-        af.y = __builtin_amdgcn_perm(k64, d0, 0x04030402u);
-        af.z = __builtin_amdgcn_perm(k64, d1, 0x04010400u);
-        af.w = __builtin_amdgcn_perm(k64, d1, 0x04030402u);
-        const f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f};  // (an inline constant: no accumulator set-up)
-        const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af), bfrag, c0, 0, 0, 0);
-        // (__float_as_uint of an rvalue: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index)
-        hs[nb][4 * mb + 0] = __float_as_uint(dd[0]);
-        hs[nb][4 * mb + 1] = __float_as_uint(dd[1]);
-        hs[nb][4 * mb + 2] = __float_as_uint(dd[2]);
-        hs[nb][4 * mb + 3] = __float_as_uint(dd[3]);
-      }
-    // The 49 multiply-adds of a column block are ONE asm statement that opens with its own wait states: the compiler's hazard
-    // recogniser does not look inside asm statements, and a VALU read of an MFMA result needs up to 18 of them (an asm
-    // v_mad_u32_u24 per term read the accumulators while the matrix core was still writing them; written with __umul24 the
-    // compiler emits v_mul_u32_u24 pairs + v_add3_u32 instead -- 136 instructions for these 98).  (The factor 4 of the VALU
-    // variant's weights is in the accumulator bits.)
-    const uint32_t gw0 = 144u, gw1 = 268u, gw2 = 391u, gw3 = 442u, c23 = 1u << 23;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      uint32_t o[8];
-      asm volatile("s_nop 15\n\ts_nop 2\n\tv_mad_u32_u24 %0, %7, %20, %24\n\tv_mad_u32_u24 %0, %8, %21, %0\n\tv_mad_u32_u24 %0, %9, %22, %0\n\tv_mad_u32_u24 %0, %10, %23, %0\n\tv_mad_u32_u24 %0, %11, %22, %0\n\tv_mad_u32_u24 %0, %12, %21, %0\n\tv_mad_u32_u24 %0, %13, %20, %0\n\tv_mad_u32_u24 %1, %8, %20, %24\n\tv_mad_u32_u24 %1, %9, %21, %1\n\tv_mad_u32_u24 %1, %10, %22, %1\n\tv_mad_u32_u24 %1, %11, %23, %1\n\tv_mad_u32_u24 %1, %12, %22, %1\n\tv_mad_u32_u24 %1, %13, %21, %1\n\tv_mad_u32_u24 %1, %14, %20, %1\n\tv_mad_u32_u24 %2, %9, %20, %24\n\tv_mad_u32_u24 %2, %10, %21, %2\n\tv_mad_u32_u24 %2, %11, %22, %2\n\tv_mad_u32_u24 %2, %12, %23, %2\n\tv_mad_u32_u24 %2, %13, %22, %2\n\tv_mad_u32_u24 %2, %14, %21, %2\n\tv_mad_u32_u24 %2, %15, %20, %2\n\tv_mad_u32_u24 %3, %10, %20, %24\n\tv_mad_u32_u24 %3, %11, %21, %3\n\tv_mad_u32_u24 %3, %12, %22, %3\n\tv_mad_u32_u24 %3, %13, %23, %3\n\tv_mad_u32_u24 %3, %14, %22, %3\n\tv_mad_u32_u24 %3, %15, %21, %3\n\tv_mad_u32_u24 %3, %16, %20, %3\n\tv_mad_u32_u24 %4, %11, %20, %24\n\tv_mad_u32_u24 %4, %12, %21, %4\n\tv_mad_u32_u24 %4, %13, %22, %4\n\tv_mad_u32_u24 %4, %14, %23, %4\n\tv_mad_u32_u24 %4, %15, %22, %4\n\tv_mad_u32_u24 %4, %16, %21, %4\n\tv_mad_u32_u24 %4, %17, %20, %4\n\tv_mad_u32_u24 %5, %12, %20, %24\n\tv_mad_u32_u24 %5, %13, %21, %5\n\tv_mad_u32_u24 %5, %14, %22, %5\n\tv_mad_u32_u24 %5, %15, %23, %5\n\tv_mad_u32_u24 %5, %16, %22, %5\n\tv_mad_u32_u24 %5, %17, %21, %5\n\tv_mad_u32_u24 %5, %18, %20, %5\n\tv_mad_u32_u24 %6, %13, %20, %24\n\tv_mad_u32_u24 %6, %14, %21, %6\n\tv_mad_u32_u24 %6, %15, %22, %6\n\tv_mad_u32_u24 %6, %16, %23, %6\n\tv_mad_u32_u24 %6, %17, %22, %6\n\tv_mad_u32_u24 %6, %18, %21, %6\n\tv_mad_u32_u24 %6, %19, %20, %6"
-                   : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
-                   : "v"(hs[nb][0]), "v"(hs[nb][1]), "v"(hs[nb][2]), "v"(hs[nb][3]), "v"(hs[nb][4]), "v"(hs[nb][5]), "v"(hs[nb][6]),
-                     "v"(hs[nb][7]), "v"(hs[nb][8]), "v"(hs[nb][9]), "v"(hs[nb][10]), "v"(hs[nb][11]), "v"(hs[nb][12]),
-                     "v"(gw0), "v"(gw1), "v"(gw2), "v"(gw3), "s"(c23));
-      o[7] = 0u;
-      uint2 pk;
-      pk.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0703u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
-      pk.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[7], o[6], 0x0c0c0703u), __builtin_amdgcn_perm(o[5], o[4], 0x0c0c0703u), 0x05040100u);
-      // blur column 16 nb + n16 (columns 27 .. 31 are scratch lines of the 1 KB buffer), rows 7 q4 .. 7 q4 + 6
-      *reinterpret_cast<uint2*>(bl + (16 * nb + n16) * 32 + 8 * q4) = pk;
-    }
+    desc_blur_mfma(s_patch[wv], bl, lane, desc_blur_b(lane));
   } else {
     // separable 7x7 integer Gaussian: patch rows 0..kPatch-1 x blur cols -> s_h, then blur rows -> the blurred patch
     uint32_t* hb = s_h[wv];
@@ -1395,6 +1423,167 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   }
 }
 
+// orb_describe of the default mode (30-bin table steering, blur on MFMA) as a SOFTWARE PIPELINE over the keypoints of a wave.
+// describe_kernel is one keypoint per wave and is bound by the latency of its dependent chain (selection record -> patch rows
+// from HBM -> compute) at the hardware's 8 waves per SIMD; here a wave owns kDescPipe slots (slot0 + 4 j) and, while it
+// computes keypoint j, the patch rows of keypoint j + 1 are already in flight into registers and the selection record of
+// keypoint j + 2 into scalar registers.  Same arithmetic, same outputs (desc_moments / desc_bin / desc_blur_mfma).
+constexpr int kDescPipe = 8;
+
+__global__ __launch_bounds__(256) void describe_pipe_kernel(DescribeArgs a, DevTables tb, int K, const SelKp* __restrict__ sel,
+                                                            const int32_t* __restrict__ level_cnt,
+                                                            gh_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                            int32_t* __restrict__ counts, int n_frames,
+                                                            uint32_t* __restrict__ dbg) {
+  typedef DescGeom<13> G;
+  constexpr int kC = G::kC, kPatch = G::kPatch, kPatchPitch = G::kPatchPitch, kRowDw = G::kRowDw;
+  static_assert(kRowDw == 9 && kPatch == 33, "desc_blur_mfma's patch geometry");
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][(kPatch + 4) * kPatchPitch + 28];
+  __shared__ __attribute__((aligned(16))) uint32_t s_blur[4][256];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blocks_per_frame = (K + 4 * kDescPipe - 1) / (4 * kDescPipe);
+  const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
+  if (gid >= blocks_per_frame * n_frames) return;
+  const int b = __builtin_amdgcn_readfirstlane(gid / blocks_per_frame);
+  const int slot0 = __builtin_amdgcn_readfirstlane((gid - b * blocks_per_frame) * (4 * kDescPipe) + wv);
+  if (slot0 >= K) return;
+  // per-frame level counts, once per wave (scalar loads)
+  int cnt[kMaxL], total = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxL; ++k) {
+    cnt[k] = k < a.nlevels ? level_cnt[b * kMaxL + k] : 0;
+    total += cnt[k];
+  }
+  if (slot0 == 0 && lane == 0) counts[b] = total;
+
+  // what a slot is: 0 = beyond K, 1 = unused slot of its level (zero-fill output row pos), 2 = keypoint (output row pos)
+  struct SlotInfo { int kind, pos, l; };
+  auto slot_info = [&](int slot) {
+    SlotInfo si{0, 0, 0};
+    if (slot >= K) return si;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxL; ++k)
+      if (k < a.nlevels && slot >= a.quota_off[k]) l = k;
+    int before = 0, unused_before = 0, cnt_l = 0, qoff = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxL; ++k) {
+      if (k < l) {
+        before += cnt[k];
+        unused_before += a.quota[k] - cnt[k];
+      }
+      if (k == l) {
+        cnt_l = cnt[k];
+        qoff = a.quota_off[k];
+      }
+    }
+    const int i = slot - qoff;
+    si.l = l;
+    if (i >= cnt_l) {
+      si.kind = 1;
+      si.pos = total + unused_before + (i - cnt_l);
+    } else {
+      si.kind = 2;
+      si.pos = before + i;
+    }
+    return si;
+  };
+  // selection record of a slot as one 8-byte scalar load: x | y << 16, score | level << 8
+  // (through the CONSTANT address space: the records were written by an earlier launch, and only such a load is emitted as
+  //  s_load inside the loop -- a global load of a uniform address behind this kernel's own stores stays a vector load, whose
+  //  in-order vmcnt would make its consumer wait for the prefetched patch rows as well)
+  typedef const __attribute__((address_space(4))) uint64_t* sel_cptr;
+  const sel_cptr sel_c = (sel_cptr)(reinterpret_cast<const uint64_t*>(sel) + (size_t)b * K);
+  auto load_sel = [&](int slot) {
+    const uint64_t v = sel_c[slot];
+    return uint2{(uint32_t)v, (uint32_t)(v >> 32)};
+  };
+  // the 9 dwords that cover patch row `lane` of keypoint (x, y) of level l (lanes >= 33: nothing)
+  struct __attribute__((packed, aligned(4))) RowN { uint32_t w[kRowDw]; };
+  // UNCONDITIONAL, every lane (lanes >= 33 fetch row 32 again; a slot without a keypoint fetches the top-left patch of level
+  // 0, which every frame has): a branch around the loads would put them in a block of their own, the compiler's s_waitcnt
+  // insertion would merge the paths with and without them conservatively, and the waits for the test words behind them
+  // (vmcnt counts in order) would then wait for the prefetched rows too
+  auto issue_patch = [&](bool valid, const SlotInfo& si, uint2 raw, RowN& row) {
+    const LevelView lv = a.lv[valid ? si.l : 0];
+    const uint32_t xy = valid ? raw.x : (uint32_t)(kC | (kC << 16));
+    const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
+    const int px0 = (int)(xy & 0xFFFFu) - kC, py0 = (int)(xy >> 16) - kC;
+    const int pa = px0 & ~3;
+    row = *reinterpret_cast<const RowN*>(img + (__umul24((uint32_t)(py0 + min(lane, kPatch - 1)), (uint32_t)lv.pitch) + (uint32_t)pa));
+  };
+
+  SlotInfo si0 = slot_info(slot0), si1 = slot_info(slot0 + 4);
+  uint2 raw0 = si0.kind == 2 ? load_sel(slot0) : uint2{0u, 0u};
+  uint2 raw1 = si1.kind == 2 ? load_sel(slot0 + 4) : uint2{0u, 0u};
+  RowN row{};
+  issue_patch(si0.kind == 2, si0, raw0, row);
+  uint8_t* patch = s_patch[wv];
+  uint8_t* bl = reinterpret_cast<uint8_t*>(s_blur[wv]);
+  // loop invariants held in registers: no vector load inside the loop may sit between the prefetch and its consumer
+  const uint4 bw = desc_blur_b(lane);
+  const int dir_x = lane < GH_ORB_NBINS ? tb.dir[2 * lane] : 0, dir_y = lane < GH_ORB_NBINS ? tb.dir[2 * lane + 1] : 0;
+  for (int j = 0; j < kDescPipe && si0.kind != 0; ++j) {
+    // patch rows of keypoint j: registers -> LDS, shifted so that patch column 0 is byte 0 of its row
+    if (si0.kind == 2 && lane < kPatch) {
+      const uint32_t sh = ((raw0.x & 0xFFFFu) - (uint32_t)kC) & 3u;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(patch + lane * kPatchPitch);
+#pragma unroll
+      for (int c = 0; c < kRowDw; ++c) dst[c] = __builtin_amdgcn_alignbyte(c + 1 < kRowDw ? row.w[c + 1] : 0u, row.w[c], sh);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // keypoint j + 2: its selection record (a scalar load)
+    const int slot2 = slot0 + 4 * (j + 2);
+    const SlotInfo si2 = j + 2 < kDescPipe ? slot_info(slot2) : SlotInfo{0, 0, 0};
+    const uint2 raw2 = si2.kind == 2 ? load_sel(slot2) : uint2{0u, 0u};
+
+    if (si0.kind == 1) {  // unused slot: zero-fill one tail row so the whole K-row output is deterministic
+      issue_patch(j + 1 < kDescPipe && si1.kind == 2, si1, raw1, row);
+      if (dbg != nullptr && lane == 0) atomicAdd(&dbg[kDbgUnusedSlots], 1u);
+      if (si0.pos < K) {
+        if (lane < 7) reinterpret_cast<uint32_t*>(kps + (size_t)b * K + si0.pos)[lane] = 0u;
+        if (lane >= 8 && lane < 16) reinterpret_cast<uint32_t*>(desc + ((size_t)b * K + si0.pos) * 32)[lane - 8] = 0u;
+      }
+    } else {
+      int m10, m01;
+      desc_moments<kC, kRowDw>(patch, 0u, lane, &m10, &m01);
+      const int bin = desc_bin(dir_x, dir_y, m10, m01, lane);
+      const uint32_t* pat = reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
+      const uint32_t pws[4] = {pat[lane], pat[64 + lane], pat[128 + lane], pat[192 + lane]};
+      // keypoint j + 1: its patch rows go in flight now, BEHIND the test words (vmcnt counts in order: the tests below wait for
+      // the words with three loads still outstanding) and ahead of the blur, the tests and the stores
+      issue_patch(j + 1 < kDescPipe && si1.kind == 2, si1, raw1, row);
+      desc_blur_mfma(patch, bl, lane, bw);
+      __builtin_amdgcn_wave_barrier();
+      uint8_t* drow = desc + ((size_t)b * K + si0.pos) * 32;
+      // all four ballots first, the stores behind them: a (conditional) store between two waits for test words would make the
+      // later wait count it as possibly absent and reach into the prefetched rows
+      uint64_t bits[4];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int va = bl[pws[gq] & 0xFFFFu], vb = bl[pws[gq] >> 16];
+        bits[gq] = __ballot(va < vb);
+      }
+      if (lane == 0) {
+        reinterpret_cast<uint4*>(drow)[0] = uint4{(uint32_t)bits[0], (uint32_t)(bits[0] >> 32), (uint32_t)bits[1], (uint32_t)(bits[1] >> 32)};
+        reinterpret_cast<uint4*>(drow)[1] = uint4{(uint32_t)bits[2], (uint32_t)(bits[2] >> 32), (uint32_t)bits[3], (uint32_t)(bits[3] >> 32)};
+        const float sc = a.scale[si0.l];
+        gh_keypoint o;
+        o.x = __fmul_rn((float)(raw0.x & 0xFFFFu), sc);
+        o.y = __fmul_rn((float)(raw0.x >> 16), sc);
+        o.size = __fmul_rn(31.0f, sc);
+        o.angle = 12.0f * (float)bin;
+        o.response = (float)(raw0.y & 0xFFu);
+        o.octave = si0.l;
+        o.class_id = -1;
+        kps[(size_t)b * K + si0.pos] = o;
+      }
+    }
+    si0 = si1; raw0 = raw1;
+    si1 = si2; raw1 = raw2;
+  }
+}
+
 __global__ void bgr_to_gray_kernel(const uint8_t* __restrict__ bgr, int w, int h, int channels, int sstride,
                                    size_t src_frame_stride, uint8_t* __restrict__ gray, int dstride, size_t dst_frame_stride) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -1442,7 +1631,7 @@ struct gh_orb_plan {
   hipStream_t pyr_stream = nullptr;
   hipEvent_t ev_pyr[kMaxL]{}, ev_pyr_start = nullptr;
   int desc_lds_pad = 0;      // GSLAM_HIP_ORB_DESC_LDSPAD: the same for orb_describe
-  bool desc_mfma = true;     // GSLAM_HIP_ORB_DESC_MFMA=0: the 7x7 blur of orb_describe on the VALU (rounds 1-4) instead of the h-pass on MFMA
+  int desc_mfma = 2;         // GSLAM_HIP_ORB_DESC_MFMA: 0 = the 7x7 blur of orb_describe on the VALU (rounds 1-4), 1 = h-pass on MFMA, one keypoint per wave, 2 = MFMA + software pipeline over 8 keypoints per wave
   int lds_pad = 0;           // GSLAM_HIP_ORB_LDSPAD: extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int pass1 = 1;             // GSLAM_HIP_ORB_PASS1: 0 = packed 16-bit compass test (rounds 2-3), 1 = SWAR on 16-bit fields
   bool pk_score = true;      // GSLAM_HIP_ORB_PKSCORE=0: arc scores with v_min3 / v_max3_u32 instead of packed fp16 minimum3 / maximum3
@@ -1672,7 +1861,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_LDSPAD")) p->lds_pad = atoi(e) < 0 ? 0 : atoi(e);
   if (const char* e = getenv("GSLAM_HIP_ORB_DESC_LDSPAD")) p->desc_lds_pad = atoi(e) < 0 ? 0 : atoi(e);
-  if (const char* e = getenv("GSLAM_HIP_ORB_DESC_MFMA")) p->desc_mfma = atoi(e) != 0;
+  if (const char* e = getenv("GSLAM_HIP_ORB_DESC_MFMA")) p->desc_mfma = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
   // geometry (oracle step 1 / 5): exact integer arithmetic
@@ -2145,7 +2334,11 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     DevTables tb{p->d_pattern, p->d_dir, p->d_base_pattern};
     const long long blocks = (long long)gh_div_up(K, 4) * batch;
     GH_CHECK_ARG(ctx, blocks < (1LL << 30));
-    if (p->steer == 0 && p->desc_mfma)
+    if (p->steer == 0 && p->desc_mfma == 2) {
+      const long long pblocks = (long long)gh_div_up(K, 4 * kDescPipe) * batch;
+      GH_LAUNCH(ctx, "orb_describe", describe_pipe_kernel, dim3(8 * gh_div_up(pblocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
+                p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
+    } else if (p->steer == 0 && p->desc_mfma)
       GH_LAUNCH(ctx, "orb_describe", (describe_kernel<13, false, true>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
                 p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
     else if (p->steer == 0)
