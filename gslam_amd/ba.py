@@ -143,6 +143,23 @@ def band_solve(ctx: hip.Context, A, b, half_bandwidth):
     return db.cpu().numpy(), info.value
 
 
+def arrow_solve(ctx: hip.Context, A, b, n_band, half_bandwidth):
+    """Arrowhead SPD solve (gh_arrow_solve_dev): the first n_band unknowns of A (n x n symmetric) form a band of
+    half_bandwidth, the others are a dense border; b: n.  Returns (x, info)."""
+    import torch
+    n = A.shape[0]
+    lda = (n + 1 + 15) // 16 * 16
+    buf = np.zeros((n, lda))  # row c of `buf` = column c of the column-major device matrix
+    buf[:, :n] = np.tril(np.asarray(A, dtype=np.float64)).T
+    dA = torch.from_numpy(buf).cuda()
+    db = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).cuda()
+    info = C.c_int()
+    ctx.check(hip.lib.gh_arrow_solve_dev(ctx.h, C.c_void_p(dA.data_ptr()), n, lda, int(n_band), int(half_bandwidth),
+                                         C.c_void_p(db.data_ptr()), C.byref(info)))
+    ctx.sync()
+    return db.cpu().numpy(), info.value
+
+
 def marginalize(ctx: hip.Context, graph: dict, huber=0.01, min_shared=1):
     """gh_ba_marginalize (Optimizer::magin): the SE3 edges of the pose graph a bundle graph marginalises to.
     Returns (first, second, shared, info n x 6 x 6)."""

@@ -28,6 +28,13 @@
 
 #include <type_traits>
 
+// chol.hip: the dense factorisation / back-substitution (the arrowhead solver hands them superblock 0 + the border)
+gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
+                            double* xwork, unsigned* flow_state, bool store_diag, bool state_ready);
+gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
+                                const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
+                                bool xh_ready);
+
 namespace {
 
 constexpr int NBI = 64;
@@ -64,6 +71,9 @@ struct CrArgs {
   double* yh;    // [N * m]: yh_i = y_i L_i^-1
   double* x;     // n
   int* info;
+  // Arrowhead systems (band + dense border, cr_arrow_solve_t below): `nbr` border rows a.n .. a.n + nbr - 1 lie under the band
+  // and the right-hand side is row rr = a.n + nbr (band-only systems: nbr = 0, rr = n -- the layout of rounds 1-4)
+  int rr = 0, nbr = 0;
 };
 
 // compile-time loop: f(std::integral_constant<int, K>) for K = 0 .. N - 1 (a runtime loop around the potf2 code is not
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
   const bool last = a.first == 0;
   double* const tvec = reinterpret_cast<double*>(cr_lds + kShBytes + 16 * 17 * sizeof(double)) + (size_t)(T - 1) * (NBI * XP);
   double* const yv = tvec + m_;
-  if (last && tid < m_) tvec[tid] = ld_guard(A, lda, n, i0 + tid, n + 1, n);
+  if (last && tid < m_) tvec[tid] = ld_guard(A, lda, a.rr, i0 + tid, a.rr + 1, n);
   for (int e = tid; e < NBI * LP; e += 512) sh.Ms[e] = 0.0;  // the inversion only ever writes the lower blocks
 #pragma unroll
   for (int cbi = 0; cbi < 2; ++cbi) {
@@ -394,8 +404,9 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int
   const int i = a.s == 0 ? 1 + e : a.first + e * 2 * a.s, i0 = i * m_, n = a.n;
   const size_t lda = (size_t)a.lda;
   const double* const A = a.A;
-  const int side = task > 8 * T ? 3 : (task == 8 * T ? 2 : (task >= 4 * T ? 1 : 0));
-  const int strip = side == 3 ? task - 8 * T - 1 : task - 4 * T * (side == 1 ? 1 : (side == 2 ? 2 : 0));
+  // (tasks from 12 T + 1: side 4 = a 16-row strip of the BORDER rows a.n .. a.n + nbr - 1 of an arrowhead system: Y_i = E_i L_i^-T in place)
+  const int side = task > 12 * T ? 4 : (task > 8 * T ? 3 : (task == 8 * T ? 2 : (task >= 4 * T ? 1 : 0)));
+  const int strip = side == 4 ? task - 12 * T - 1 : (side == 3 ? task - 8 * T - 1 : task - 4 * T * (side == 1 ? 1 : (side == 2 ? 2 : 0)));
   const int nb = side == 0 ? i - a.s : i + a.s;
   if (side < 2 && (nb < 0 || nb >= a.N)) return;
   const int nb0 = nb * m_ + 16 * strip;  // first row of the strip (side u / d)
@@ -408,10 +419,10 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int
     // (one branch-free load per element whatever the side: see ld_guard)
     const int idx = tid + 256 * it;
     const int j = side == 0 ? idx / m_ : (idx & 15), t = side == 0 ? idx - (idx / m_) * m_ : (idx >> 4);
-    const int row = side == 0 ? i0 + t : (side == 1 ? nb0 + j : (side == 2 ? n : 0));
+    const int row = side == 0 ? i0 + t : (side == 1 ? nb0 + j : (side == 2 ? a.rr : (side == 4 ? n + 16 * strip + j : 0)));
     const int col = side == 0 ? nb0 + j : (side == 3 ? 0 : i0 + t);
-    const double v = ld_guard(A, lda, row, col, side == 2 ? n + 1 : n, n);
-    pv[it] = keep_if(v, side < 2 || (side == 2 && j == 0)) + ((side == 3 && t == 16 * strip + j) ? 1.0 : 0.0);
+    const double v = ld_guard(A, lda, row, col, side == 2 ? a.rr + 1 : (side == 4 ? n + a.nbr : n), n);
+    pv[it] = keep_if(v, side < 2 || (side == 2 && j == 0) || side == 4) + ((side == 3 && t == 16 * strip + j) ? 1.0 : 0.0);
   }
   // ---- operands of every product of this wave
   double mreg[T][16], lreg[T * (T - 1) / 2 > 0 ? T * (T - 1) / 2 : 1][16];
@@ -472,7 +483,13 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int
   }
   CR_STAMP(18);
   // ---- out
-  if (side != 2) {
+  if (side == 4) {
+#pragma unroll
+    for (int it = 0; it < 16 * m_ / 256; ++it) {
+      const int idx = tid + 256 * it, j = idx & 15, t = idx >> 4;
+      if (i0 + t < n && 16 * strip + j < a.nbr) a.A[(size_t)(i0 + t) * lda + n + 16 * strip + j] = Xl[t * PW + j];
+    }
+  } else if (side != 2) {
     double* Wo = (side == 3 ? a.W3 + (size_t)i * ((size_t)m_ * m_) : a.W + ((size_t)i * 2 + side) * ((size_t)m_ * m_)) + 16 * strip;
 #pragma unroll
     for (int it = 0; it < 16 * m_ / 256; ++it) {
@@ -481,7 +498,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int
     }
   } else {
     for (int t = tid; t < m_; t += 256)
-      if (i0 + t < n) a.A[(size_t)(i0 + t) * lda + n] = Xl[t * PW];
+      if (i0 + t < n) a.A[(size_t)(i0 + t) * lda + a.rr] = Xl[t * PW];
   }
   CR_STAMP(19);
 }
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
 #pragma unroll
       for (int k = 0; k < m_ / 16; ++k) {
         const int t = tg + 16 * k;
-        yv[k] = ld_guard(a.A, lda, n, s0 + t, n + 1, n);
+        yv[k] = ld_guard(a.A, lda, a.rr, s0 + t, a.rr + 1, n);
         wv[k] = Wp[(size_t)t * m_ + c];
       }
 #pragma unroll
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
 #pragma unroll
       for (int g = 0; g < 16; ++g) tot += red[g][tid];
       if (elim_task) a.yh[(size_t)i * m_ + c] = tot;
-      else if (j * m_ + c < n) a.A[(size_t)(j * m_ + c) * lda + n] -= tot;
+      else if (j * m_ + c < n) a.A[(size_t)(j * m_ + c) * lda + a.rr] -= tot;
     }
     return;
   }
@@ -757,7 +774,7 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
   if (tid < m_) {
     xu[tid] = (has_u && u * m_ + tid < n) ? a.x[u * m_ + tid] : 0.0;
     xd[tid] = (has_d && d * m_ + tid < n) ? a.x[d * m_ + tid] : 0.0;
-    tv[tid] = i0 + tid < n ? a.A[(size_t)(i0 + tid) * lda + n] : 0.0;
+    tv[tid] = i0 + tid < n ? a.A[(size_t)(i0 + tid) * lda + a.rr] : 0.0;
   }
   __syncthreads();
   if (has_u || has_d) {
@@ -807,6 +824,206 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
   if (tid < m_ && i0 + tid < n) a.x[i0 + tid] = zv[tid];
 }
 
+// ------------------------------------------------------------------------------------------------ arrowhead: the border
+// A reduced camera system whose cameras follow a trajectory EXCEPT for a few long-range points (loop closures) is a band plus a
+// dense border once the cameras those points tie to far-away ones are numbered last (ba.hip: arrow ordering):
+//     [ B   E^T ] [x_b]   [g_b]        B: band, n x n (a.n)         rows 0 .. n - 1
+//     [ E   C   ] [x_c] = [g_c]        E: nbr x n, C: nbr x nbr     rows n .. n + nbr - 1;  right-hand side: row rr = n + nbr
+// Block cyclic reduction runs on B exactly as above, with E and the right-hand side riding along as EXTRA ROWS of every
+// eliminated superblock i:  Y_i = E_i L_i^-T (cr_panels_kernel, side 4), E_u -= Y_i W_u^T, E_d -= Y_i W_d^T
+// (cr_border_update_kernel) -- what the band solver does to its one right-hand-side row, for nbr rows.  When only superblock 0
+// is left, C has to lose sum_i Y_i Y_i^T over every eliminated i (cr_border_syrk_kernel: the rank-(n - m) update of the corner,
+// right-hand-side row included, in K chunks whose partial tiles are summed in a fixed order), and what remains is the DENSE
+// system of superblock 0 and the border, (m + nbr)^2, solved by chol.hip's dense path.  Backwards the border only adds
+// - x_c Y_i to the right-hand side of superblock i:  yh_i -= (x_c Y_i) L_i^-1, then cr_back_kernel as before.
+// It is a Cholesky factorisation of the symmetrically permuted matrix: same result as the dense solve to rounding
+// (tests/test_cr_solver.py: restated in numpy; gh_arrow_solve_dev against numpy and the dense path).
+constexpr int kBorderChunk = 16;  // superblocks of columns per K chunk of the corner update
+
+// level s, survivor j = grp 2 s:  E_j -= Y_{j-s} W_d(j-s)^T + Y_{j+s} W_u(j+s)^T.  Workgroup = 64 border rows x 64 columns of j,
+// wave = a 32 x 32 block (2 x 2 MFMA blocks), operands straight from L2 in MFMA layout.  D'[out column][out row]: the lane
+// holds out column q + 4 r, out row m -- 16 consecutive rows of A per register, a 128-byte run.
+template <int T>
+__global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt) {
+  constexpr int m_ = NBI * T;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w & 1, wc = w >> 1;
+  const int per = nrt * T;
+  const int grp = (int)blockIdx.x / per, rem = (int)blockIdx.x - grp * per, rt = rem / T, tb = rem - rt * T;
+  const int j = grp * 2 * a.s, n = a.n;
+  if (j >= a.N) return;
+  const size_t lda = (size_t)a.lda, mm = (size_t)m_ * m_;
+  const double* const A = a.A;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int row_b = 64 * rt + 32 * wr;  // border row of this wave's block
+  const int col_b = 64 * tb + 32 * wc;  // column within superblock j
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    const int src = sd == 0 ? j - a.s : j + a.s;
+    if (src < 0 || src >= a.N) continue;
+    const double* Wp = a.W + ((size_t)src * 2 + (sd == 0 ? 1 : 0)) * mm;  // j is the d-neighbour of j - s, the u-neighbour of j + s
+    const int s0 = src * m_;
+    for (int ks = 0; ks < m_ / 4; ks += 4) {
+      double av[4][2], bv[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 4 * (ks + u) + q;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) av[u][cb] = Wp[(size_t)k * m_ + col_b + 16 * cb + m];  // (panels are zero-padded)
+        const int kc = s0 + k < n ? s0 + k : n - 1;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int r = row_b + 16 * rb + m;
+          bv[u][rb] = keep_if(A[(size_t)kc * lda + n + (r < a.nbr ? r : a.nbr - 1)], r < a.nbr && s0 + k < n);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = mma(av[u][cb], bv[u][rb], acc[cb][rb]);
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = j * m_ + col_b + 16 * cb + q + 4 * r, row = row_b + 16 * rb + m;
+        if (col < n && row < a.nbr) a.A[(size_t)col * lda + n + row] -= acc[cb][rb][r];
+      }
+}
+
+// The corner: partial[chunk][tile] = sum over the chunk's columns k of Yx[rows of the tile][k] Yx[cols of the tile][k], Yx = rows
+// n .. rr of A (the border rows and the right-hand side), k from m (superblock 0 stays) to n.  Tiles of 64 x 64 over the lower
+// triangle of the (nbr + 1) x nbr corner, four waves = 2 x 2 blocks of 32 x 32.
+template <int T>
+__global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int ntile_rows, int ntiles, double* __restrict__ part) {
+  constexpr int m_ = NBI * T;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w & 1, wc = w >> 1;
+  const int chunk = (int)blockIdx.x / ntiles, tile = (int)blockIdx.x - chunk * ntiles;
+  // tile -> (ta >= tb) of the lower triangle, row-major: ta (ta + 1) / 2 + tb
+  int ta = 0;
+  while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
+  const int tb = tile - ta * (ta + 1) / 2;
+  (void)ntile_rows;
+  const int n = a.n, next = a.nbr + 1;
+  const size_t lda = (size_t)a.lda;
+  const double* const A = a.A;
+  const int k0 = m_ + chunk * (kBorderChunk * m_), k1 = k0 + kBorderChunk * m_ < n ? k0 + kBorderChunk * m_ : n;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  int ro[2], co[2];  // extra-row index of this lane for the two row / column blocks, clamped into the matrix
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = 64 * ta + 32 * wr + 16 * b + m, c = 64 * tb + 32 * wc + 16 * b + m;
+    ro[b] = n + (r < next ? r : next - 1);
+    co[b] = n + (c < next ? c : next - 1);
+  }
+  for (int k = k0; k < k1; k += 16) {
+    double av[4][2], bv[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k + 4 * u + q, kc = kk < k1 ? kk : k1 - 1;
+      const bool ok = kk < k1;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        av[u][b] = keep_if(A[(size_t)kc * lda + co[b]], ok);
+        bv[u][b] = A[(size_t)kc * lda + ro[b]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = mma(av[u][cb], bv[u][rb], acc[cb][rb]);
+  }
+  double* out = part + ((size_t)chunk * ntiles + tile) * 4096;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(32 * wc + 16 * cb + q + 4 * r) * 64 + 32 * wr + 16 * rb + m] = acc[cb][rb][r];
+}
+
+// corner -= the chunks' partial tiles, summed in chunk order (fixed: results do not depend on the launch's scheduling)
+template <int T>
+__global__ __launch_bounds__(256) void cr_border_syrk_reduce_kernel(CrArgs a, int ntiles, int nchunks, const double* __restrict__ part) {
+  const int tile = (int)blockIdx.x;
+  int ta = 0;
+  while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
+  const int tb = tile - ta * (ta + 1) / 2;
+  const int n = a.n, next = a.nbr + 1;
+  const size_t lda = (size_t)a.lda;
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int c = e >> 6, r = e & 63;
+    const int row = 64 * ta + r, col = 64 * tb + c;
+    if (row >= next || col >= a.nbr || col > row) continue;
+    double sum = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) sum += part[((size_t)ch * ntiles + tile) * 4096 + e];
+    a.A[(size_t)(n + col) * lda + n + row] -= sum;
+  }
+}
+
+// The dense system that is left: superblock 0 (reduced, not factored) and the border, with the right-hand side as row qn.
+// M is qn x qn column-major with pitch ldq; element (r, c), r >= c.
+template <int T>
+__global__ void cr_border_gather_kernel(CrArgs a, double* __restrict__ M, int ldq) {
+  constexpr int m_ = NBI * T;
+  const int c = (int)blockIdx.x, qn = m_ + a.nbr, n = a.n;
+  const size_t lda = (size_t)a.lda;
+  const size_t src_col = c < m_ ? (size_t)c : (size_t)(n + c - m_);
+  for (int r = c + (int)threadIdx.x; r <= qn; r += (int)blockDim.x) {
+    const size_t src_row = r < m_ ? (size_t)r : (r < qn ? (size_t)(n + r - m_) : (size_t)a.rr);
+    M[(size_t)c * ldq + r] = a.A[src_col * lda + src_row];
+  }
+}
+
+// x_0 and x_c out of the dense solution; t[k] = sum_r x_c[r] Y[r][k] for the columns k >= m of the band (one wave per column)
+template <int T>
+__global__ __launch_bounds__(256) void cr_border_back_kernel(CrArgs a, const double* __restrict__ xq, double* __restrict__ tvec) {
+  constexpr int m_ = NBI * T;
+  const int n = a.n, lane = threadIdx.x & 63;
+  const int k = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // k < n: a column of the band; n <= k < n + nbr: a border unknown
+  if (k >= n + a.nbr) return;
+  if (k < m_ || k >= n) {  // superblock 0 and the border: x is final
+    if (lane == 0) a.x[k] = xq[k < m_ ? k : m_ + k - n];
+    return;
+  }
+  const double* col = a.A + (size_t)k * a.lda + n;
+  double sum = 0.0;
+  for (int r = lane; r < a.nbr; r += 64) sum = __builtin_fma(xq[m_ + r], col[r], sum);
+  sum = wave_sum63(sum);
+  if (lane == 63) tvec[k] = sum;
+}
+// yh_i -= t_i L_i^-1 for every eliminated superblock i >= 1 (L_i^-1[c][c'] = W3_i at c m + c')
+template <int T>
+__global__ __launch_bounds__(256) void cr_border_yh_kernel(CrArgs a, const double* __restrict__ tvec) {
+  constexpr int m_ = NBI * T;
+  __shared__ double ts[m_];
+  const int i = 1 + (int)blockIdx.x, n = a.n;
+  for (int c = threadIdx.x; c < m_; c += 256) ts[c] = i * m_ + c < n ? tvec[i * m_ + c] : 0.0;
+  __syncthreads();
+  const double* W3 = a.W3 + (size_t)i * ((size_t)m_ * m_);
+  for (int cp = threadIdx.x; cp < m_; cp += 256) {
+    double sum = 0.0;
+    for (int c = 0; c < m_; ++c) sum = __builtin_fma(ts[c], W3[(size_t)c * m_ + cp], sum);  // (the zeros of the triangle are stored)
+    a.yh[(size_t)i * m_ + cp] -= sum;
+  }
+}
+
 // a launch on `stream` through the context's profiler (GH_LAUNCH times on ctx->stream)
 #define CR_LAUNCH_ON(stream_, ...)          \
   do {                                      \
@@ -820,8 +1037,10 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
     if (st_ != GH_OK) return st_;           \
   } while (0)
 
+// nbr > 0: an arrowhead system (see above) -- A holds n + nbr unknowns, bws the border workspace (gh_arrow_ws_doubles).
 template <int T>
-gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, double* W, double* x, int* info_dev) {
+gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, double* W, double* x, int* info_dev, int nbr = 0,
+                     double* bws = nullptr) {
   constexpr int m_ = NBI * T;
   const int N = gh_div_up(n, m_);
   const size_t mm = (size_t)m_ * m_;
@@ -848,6 +1067,9 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   hipStream_t side = ctx->cr_side;
   // workspace: W [2 N m^2], G [2 N m^2], W3 [N m^2], yh [N m]
   CrArgs a{A, lda, n, N, 1, 0, 0, dinv, W, W + 2 * (size_t)N * mm, W + 4 * (size_t)N * mm, W + 5 * (size_t)N * mm, x, info_dev};
+  a.nbr = nbr;
+  a.rr = n + nbr;
+  const int nbs = gh_div_up(nbr, 16), nrt = gh_div_up(nbr, 64);  // 16-row strips / 64-row tiles of the border
   constexpr int NTS = 4 * (T * (T + 1) / 2 + T * T) + m_ / 16, NTE = 4 * (2 * T * T) + m_ / 16;
   auto update_grid = [](int ngroups, int ntask) {  // the mapping of cr_update_kernel
     const int G = ngroups > 4 ? 8 : (ngroups > 2 ? 4 : (ngroups > 1 ? 2 : 1)), kx = 8 / G;
@@ -860,6 +1082,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     const int g8 = 8 * gh_div_up(a.count, 8);  // groups of eight eliminated superblocks, one per XCD
     GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(a.count), dim3(512), factor_lds, a);
     GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(g8 * (8 * T + 1)), dim3(256), 0, a, 0, 8 * T + 1);
+    if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_panels", cr_panels_kernel<T>, dim3(g8 * nbs), dim3(256), 0, a, 12 * T + 1, nbs);
     if (2 * s >= N) {  // the last level: everything the side work reads is (or will be, in stream order) complete here
       GH_HIP(ctx, hipEventRecord(ctx->cr_events[0], ctx->stream));
       GH_HIP(ctx, hipStreamWaitEvent(side, ctx->cr_events[0], 0));
@@ -874,6 +1097,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     }
     const int nsurv = gh_div_up(N, 2 * s);
     GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(update_grid(nsurv, NTS)), dim3(256), 0, a, 0, nsurv);
+    if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_update", cr_border_update_kernel<T>, dim3(nsurv * nrt * T), dim3(256), 0, a, nrt);
   }
   // the last block: block 0 with no neighbours (stride >= N)
   int s_top = 1;
@@ -881,8 +1105,34 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   a.s = s_top;
   a.first = 0;
   a.count = 1;
+  if (nbr > 0) {
+    // superblock 0 is not factored on its own: it joins the border in the dense system that is left
+    const int qn = m_ + nbr, ldq = (qn + 1 + 15) & ~15;
+    const int ntr = gh_div_up(nbr + 1, 64), ntiles = ntr * (ntr + 1) / 2;
+    const int nchunks = n > m_ ? gh_div_up(n - m_, kBorderChunk * m_) : 0;
+    double* part = bws;
+    double* Mq = part + (size_t)nchunks * ntiles * 4096;
+    double* dinv_q = Mq + (size_t)ldq * qn;
+    double* xwork_q = dinv_q + (size_t)gh_div_up(qn, NBI) * (NBI * NBI);
+    double* work_q = xwork_q + (size_t)2 * 64 * (qn + 1);
+    double* xq = work_q + (((size_t)qn + 15) & ~(size_t)15);
+    double* xh_q = xq + (((size_t)qn + 15) & ~(size_t)15);
+    double* tvec = xh_q + (size_t)gh_div_up(qn, NBI) * NBI;
+    if (nchunks > 0) {
+      GH_LAUNCH(ctx, "ba_cr_border_syrk", cr_border_syrk_kernel<T>, dim3(nchunks * ntiles), dim3(256), 0, a, ntr, ntiles, part);
+      GH_LAUNCH(ctx, "ba_cr_border_reduce", cr_border_syrk_reduce_kernel<T>, dim3(ntiles), dim3(256), 0, a, ntiles, nchunks,
+                (const double*)part);
+    }
+    GH_LAUNCH(ctx, "ba_cr_border_gather", cr_border_gather_kernel<T>, dim3(qn), dim3(256), 0, a, Mq, ldq);
+    GH_TRY(gh_potrf_dev_impl(ctx, Mq, qn, ldq, info_dev, 1, dinv_q, xwork_q, nullptr, false, true));
+    GH_TRY(gh_potrs_bwd_dev_impl(ctx, Mq, qn, ldq, xq, work_q, dinv_q, Mq + qn, ldq, xh_q, info_dev, false));
+    if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
+    GH_LAUNCH(ctx, "ba_cr_border_back", cr_border_back_kernel<T>, dim3(gh_div_up(n + nbr, 4)), dim3(256), 0, a, (const double*)xq, tvec);
+    if (N > 1) GH_LAUNCH(ctx, "ba_cr_border_yh", cr_border_yh_kernel<T>, dim3(N - 1), dim3(256), 0, a, (const double*)tvec);
+  } else {
   GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(1), dim3(512), factor_lds, a);  // (also solves: x_0 is final)
   if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
+  }
   for (int s = s_top / 2; s >= 1; s /= 2) {
     a.s = s;
     a.first = s;
@@ -893,6 +1143,17 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
 }
 
 }  // namespace
+
+// border workspace of an arrowhead solve (doubles): the corner update's partial tiles, the dense system of superblock 0 + border
+// and what chol.hip's dense path needs for it, the backward pass's t vector
+size_t gh_arrow_ws_doubles(int n_band, int T, int nbr) {
+  const size_t m = (size_t)NBI * T, qn = m + (size_t)nbr, ldq = (qn + 1 + 15) & ~(size_t)15;
+  const size_t ntr = ((size_t)nbr + 1 + 63) / 64, ntiles = ntr * (ntr + 1) / 2;
+  const size_t nchunks = (size_t)n_band > m ? ((size_t)n_band - m + kBorderChunk * m - 1) / (kBorderChunk * m) : 0;
+  const size_t qb = (qn + NBI - 1) / NBI;
+  return nchunks * ntiles * 4096 + ldq * qn + qb * (NBI * NBI) + 2 * 64 * (qn + 1) + 2 * ((qn + 15) & ~(size_t)15) + qb * NBI +
+         (size_t)n_band + 64;
+}
 
 // Tiles per superblock for a half-bandwidth of `hbw` scalars (A[r][c] = 0 for r - c > hbw), 0 = the band is too wide for
 // this solver (or the matrix too small to gain from it): the caller stays on the dense factorisation.
@@ -924,6 +1185,19 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
   }
 }
 
+// Arrowhead solve: A holds n_band + nbr unknowns (band first, border last) and the right-hand side in row n_band + nbr; the
+// lower triangle of the band part must be zero outside the band, the border rows are dense.  x_dev: n_band + nbr doubles.
+gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
+                                  double* x_dev, int* info_dev, bool info_ready) {
+  if (!info_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
+  switch (T) {
+    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws);
+    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws);
+    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws);
+    default: return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve: %d tiles per superblock", T);
+  }
+}
+
 namespace {
 __global__ void cr_rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ A, int lda, int n) {
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -949,6 +1223,33 @@ extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int ld
   double* x = W + nw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
   GH_TRY(gh_cr_solve_dev_impl(ctx, A_dev, n, lda, T, dinv, W, x, info_dev, false));
+  GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}
+
+// Arrowhead SPD solve (test / tool entry, like gh_band_solve_dev): A_dev n x n column-major lower triangle (lda > n, overwritten),
+// the first n_band unknowns form a band of `half_bandwidth`, the last n - n_band are the dense border.
+extern "C" gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth, double* b_dev,
+                                        int* info) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, A_dev && b_dev && info && n > 0 && lda > n && half_bandwidth >= 0 && n_band > 0 && n_band < n);
+  const int T = gh_cr_tiles(n_band, half_bandwidth), nbr = n - n_band;
+  if (T == 0)
+    return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve_dev: half-bandwidth %d of n_band = %d does not fit (<= %d, >= 4 superblocks)",
+                        half_bandwidth, n_band, 3 * NBI);
+  void* scratch = nullptr;
+  const size_t nd = gh_cr_dinv_doubles(n_band, T), nw = gh_cr_panel_doubles(n_band, T), nbw = gh_arrow_ws_doubles(n_band, T, nbr);
+  GH_TRY(gh_scratch(ctx, 256 + (nd + nw + nbw + (size_t)n) * sizeof(double), &scratch));
+  int* info_dev = (int*)scratch;
+  double* dinv = (double*)((char*)scratch + 256);
+  double* W = dinv + nd;
+  double* bws = W + nw;
+  double* x = bws + nbw;
+  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -187,6 +187,7 @@ SIGNATURES = {
     "gh_ba_marginalize": (C.c_int, [_vp, _vp, C.c_double, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     "gh_potrf_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "gh_band_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i)]),
+    "gh_arrow_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i)]),
     "gh_bs_symbolic": (C.c_int, [_i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "gh_bs_solve_host": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp, C.POINTER(_i)]),
 }

@@ -631,6 +631,16 @@ gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double*
  * matrix).  *info: 0 = ok, else first column + 1 of a diagonal tile that is not positive definite. */
 gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half_bandwidth, double* b_dev, int* info);
 
+/* ... and for an ARROWHEAD matrix, a band with a dense border: the reduced camera system of a trajectory with a few loop
+ * closures once the cameras that long-range points tie to far-away ones are numbered last (what gh_ba_solve does by itself:
+ * gh_ba_options.solver / the arrow ordering of gslam_amd/csrc/ba.hip; the graphs global BA exists for,
+ * GSLAM/core/Optimizer.h:127-148,229).  The first n_band unknowns form the band (A[r][c] = 0 for r - c > half_bandwidth,
+ * r < n_band), rows n_band .. n - 1 are dense.  Block cyclic reduction on the band with the border rows riding along as extra
+ * rows of every eliminated superblock, then the dense system of the first superblock + the border through the dense
+ * factorisation.  Same limits on the band as gh_band_solve_dev; the result equals gh_potrf_solve_dev's up to rounding. */
+gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth, double* b_dev,
+                             int* info);
+
 /* Block-sparse Cholesky with a dense root: the linear solver gh_pg_solve uses for LARGE pose graphs
  * (GSLAM/core/Optimizer.h:127-148,162-167 -- se3Graph / sim3Graph / gpsGraph over thousands of keyframes; the system has
  * one 7 x 7 block per keyframe and one per edge).  Exposed for tests and tools:

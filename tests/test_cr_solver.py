@@ -81,6 +81,103 @@ def test_schedule_restated_matches_dense(n, hb, m):
     assert np.abs(x - xr).max() <= 1e-13 * np.abs(xr).max()
 
 
+def make_arrow(n_band, hb, nbr, seed=0, fill=1.0):
+    """SPD arrowhead: a band of n_band unknowns + nbr dense border rows (fill = fraction of non-zero border columns)."""
+    rng = np.random.default_rng(seed)
+    n = n_band + nbr
+    A = np.zeros((n, n))
+    for i in range(n_band):
+        lo = max(0, i - hb)
+        A[i, lo:i + 1] = rng.standard_normal(i - lo + 1)
+    E = rng.standard_normal((nbr, n_band))
+    if fill < 1.0:
+        E *= rng.random((nbr, n_band)) < fill
+    A[n_band:, :n_band] = E
+    A[n_band:, n_band:] = np.tril(rng.standard_normal((nbr, nbr)))
+    A = np.tril(A)
+    A = A + A.T
+    A += np.eye(n) * (np.abs(A).sum(1).max() + 1.0)
+    return A
+
+
+def arrow_solve_restated(S, b, n_band, m):
+    """The schedule of chol_cr.hip's arrowhead mode: block cyclic reduction on the band with the border rows E and the
+    right-hand side riding along as extra rows (Y_i = E_i L_i^-T, E_u -= Y_i W_u^T, E_d -= Y_i W_d^T), the corner update
+    C -= sum_i Y_i Y_i^T over every eliminated superblock, the dense solve of superblock 0 + border, and the backward pass
+    with - x_c Y_i added to the right-hand side of superblock i."""
+    n = S.shape[0]
+    nbr = n - n_band
+    N = -(-n_band // m)
+    A = np.tril(S).copy()
+    rhs = b.copy()
+    blk = lambda k: slice(k * m, min((k + 1) * m, n_band))
+    bord = slice(n_band, n)
+    W, L, Y, levels = {}, {}, {}, []
+    s = 1
+    while s < N:
+        elim = list(range(s, N, 2 * s))
+        levels.append((s, elim))
+        for i in elim:
+            D = A[blk(i), blk(i)]
+            L[i] = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
+            u, d = i - s, i + s
+            if u >= 0:
+                W[(i, 0)] = np.linalg.solve(L[i], A[blk(i), blk(u)]).T
+            if d < N:
+                W[(i, 1)] = np.linalg.solve(L[i], A[blk(d), blk(i)].T).T
+            rhs[blk(i)] = np.linalg.solve(L[i], rhs[blk(i)])
+            Y[i] = np.linalg.solve(L[i], A[bord, blk(i)].T).T            # E_i L_i^-T  (nbr x m)
+            A[bord, blk(i)] = Y[i]
+        for i in elim:
+            u, d = i - s, i + s
+            y = rhs[blk(i)]
+            if u >= 0:
+                A[blk(u), blk(u)] -= np.tril(W[(i, 0)] @ W[(i, 0)].T)
+                rhs[blk(u)] -= W[(i, 0)] @ y
+                A[bord, blk(u)] -= Y[i] @ W[(i, 0)].T
+            if d < N:
+                A[blk(d), blk(d)] -= np.tril(W[(i, 1)] @ W[(i, 1)].T)
+                rhs[blk(d)] -= W[(i, 1)] @ y
+                A[bord, blk(d)] -= Y[i] @ W[(i, 1)].T
+            if u >= 0 and d < N:
+                A[blk(d), blk(u)] -= W[(i, 1)] @ W[(i, 0)].T
+        s *= 2
+    # corner: every eliminated superblock at once (columns m .. n_band of the border rows now hold the Y_i)
+    Yall = A[bord, m:n_band]
+    C = A[bord, bord] - np.tril(Yall @ Yall.T)
+    gc = rhs[bord] - Yall @ rhs[m:n_band]
+    # dense system of superblock 0 + border
+    q = m + nbr
+    M = np.zeros((q, q))
+    M[:m, :m] = A[blk(0), blk(0)]
+    M[m:, :m] = A[bord, blk(0)]
+    M[m:, m:] = C
+    M = np.tril(M) + np.tril(M, -1).T
+    xq = np.linalg.solve(M, np.concatenate([rhs[blk(0)], gc]))
+    x = np.zeros(n)
+    x[blk(0)] = xq[:m]
+    x[bord] = xq[m:]
+    for s, elim in reversed(levels):
+        for i in elim:
+            t = rhs[blk(i)] - Y[i].T @ x[bord]
+            if i - s >= 0:
+                t -= W[(i, 0)].T @ x[blk(i - s)]
+            if i + s < N:
+                t -= W[(i, 1)].T @ x[blk(i + s)]
+            x[blk(i)] = np.linalg.solve(L[i].T, t)
+    return x
+
+
+@pytest.mark.parametrize("n_band,hb,m,nbr", [(3000, 149, 192, 90), (1000, 60, 64, 7), (777, 100, 128, 130), (520, 191, 192, 64),
+                                             (1345, 128, 128, 1)])
+def test_arrow_schedule_restated_matches_dense(n_band, hb, m, nbr):
+    S = make_arrow(n_band, hb, nbr, seed=n_band + nbr)
+    b = np.random.default_rng(1).standard_normal(n_band + nbr)
+    x = arrow_solve_restated(S, b, n_band, m)
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-13 * np.abs(xr).max()
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -106,6 +203,38 @@ def test_band_solve_vs_numpy(ctx, n, hb):
     m = 64 * (-(-hb // 64))
     xs = cr_solve_restated(S, b, m)
     assert np.abs(x - xs).max() <= 1e-12 * np.abs(xr).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_band,hb,nbr,fill", [(3000, 149, 90, 1.0), (3000, 191, 360, 0.05), (1024, 64, 7, 1.0), (1000, 40, 1, 1.0),
+                                                (777, 100, 130, 0.3), (1345, 128, 65, 1.0), (260, 17, 300, 1.0),
+                                                (3005, 150, 17, 1.0), (768, 192, 64, 1.0), (6000, 149, 128, 0.02)])
+def test_arrow_solve_vs_numpy(ctx, n_band, hb, nbr, fill):
+    """gh_arrow_solve_dev (band + dense border) against numpy and against the restated schedule: every tile count, ragged
+    last superblocks, borders from one row to wider than the band part's superblock, sparse and dense border rows."""
+    from gslam_amd import ba
+    S = make_arrow(n_band, hb, nbr, seed=n_band + hb + nbr, fill=fill)
+    b = np.random.default_rng(2).standard_normal(n_band + nbr)
+    x, info = ba.arrow_solve(ctx, S, b, n_band, hb)
+    assert info == 0
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-12 * np.abs(xr).max()
+    m = 64 * (-(-hb // 64))
+    xs = arrow_solve_restated(S, b, n_band, m)
+    assert np.abs(x - xs).max() <= 1e-12 * np.abs(xr).max()
+
+
+@pytest.mark.gpu
+def test_arrow_solve_is_reproducible_and_equals_dense_path(ctx):
+    from gslam_amd import ba
+    S = make_arrow(3000, 149, 200, seed=11, fill=0.1)
+    b = np.random.default_rng(3).standard_normal(3200)
+    x1, info1 = ba.arrow_solve(ctx, S, b, 3000, 149)
+    x2, info2 = ba.arrow_solve(ctx, S, b, 3000, 149)
+    _, xd, infod = ba.potrf_solve(ctx, S, b)
+    assert info1 == 0 and info2 == 0 and infod == 0
+    assert x1.tobytes() == x2.tobytes(), "fixed summation order: two runs agree bit for bit"
+    assert np.abs(x1 - xd).max() <= 1e-12 * np.abs(xd).max()
 
 
 @pytest.mark.gpu
