@@ -36,6 +36,9 @@ size_t gh_cr_dinv_doubles(int n, int T);
 size_t gh_cr_panel_doubles(int n, int T);
 gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, double* dinv, double* W, double* x_dev,
                                int* info_dev, bool info_ready);
+size_t gh_arrow_ws_doubles(int n_band, int T, int nbr);
+gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
+                                  double* x_dev, int* info_dev, bool info_ready);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
@@ -442,11 +445,34 @@ __device__ __forceinline__ void schur_init_block(int n, int lda, const double* _
 // (from the top of the column's diagonal tile to the end of superblock J + 1) and the fill blocks B(J + 2 s, J) of the
 // levels s at which J survives (J % 2 s == 0): ~ (2 + log2 N) m rows instead of n - c -- at C5 0.9 GB of zeros per LM
 // iteration instead of 14.4 GB.  One workgroup per column.
+// ARROWHEAD systems (nband < n: the last n - nband unknowns are the dense border of chol_cr.hip's arrowhead mode): a band column
+// also clears its border rows nband .. n - 1, a border column its whole lower part.
 __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, const double* __restrict__ Hcc,
                                                       const double* __restrict__ gc, double radius, double* __restrict__ S,
-                                                      double* __restrict__ rhs, int c) {
+                                                      double* __restrict__ rhs, int c, int nband) {
   const int cam = c / 6, b = c - 6 * cam;
   double* col = S + (size_t)c * lda;
+  if (c >= nband) {  // a border column: dense from its 64-row tile down
+    for (int r = ((c >> 6) << 6) + (int)threadIdx.x; r < n; r += 256) {
+      double v = 0.0;
+      if (r / 6 == cam) {
+        const int a = r - 6 * cam;
+        double h = Hcc[(size_t)36 * cam + 6 * a + b];
+        if (a == b) h += clampd(h, 1e-6, 1e32) / radius;
+        v = h;
+      }
+      col[r] = v;
+    }
+    if (threadIdx.x == 0) {
+      const double v = -gc[c];
+      col[n] = v;
+      rhs[c] = v;
+    }
+    return;
+  }
+  for (int r = nband + (int)threadIdx.x; r < n; r += 256) col[r] = 0.0;  // (nothing when there is no border)
+  const int n_full = n;
+  n = nband;
   const int J = c / m, N = (n + m - 1) / m;
   const int r0 = (c >> 6) << 6, r1 = min(n, (J + 2) * m);
   for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
@@ -466,15 +492,15 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
   }
   if (threadIdx.x == 0) {
     const double v = -gc[c];
-    col[n] = v;
+    col[n_full] = v;
     rhs[c] = v;
   }
 }
 
 __global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
                                                          const double* __restrict__ gc, double radius,
-                                                         double* __restrict__ S, double* __restrict__ rhs, int band_m) {
-  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, (int)blockIdx.y);  // (gridDim.x == 1)
+                                                         double* __restrict__ S, double* __restrict__ rhs, int band_m, int nband) {
+  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, (int)blockIdx.y, nband);  // (gridDim.x == 1)
   else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -635,12 +661,12 @@ __global__ __launch_bounds__(256) void schur_blocks_init_kernel(Problem P, Schur
                                                                 const double* __restrict__ Hcc,
                                                                 const double* __restrict__ gc, double radius,
                                                                 double* __restrict__ S, double* __restrict__ rhs, int gx,
-                                                                int band_m) {
+                                                                int band_m, int nband) {
   if (blockIdx.x < nsb) {
     schur_blocks_block(P, B, Hpi, gp, Wbuf, partial, blockIdx.x, nsb);
   } else {
     const int b = (int)(blockIdx.x - nsb);
-    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b);  // (gx == 1)
+    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband);  // (gx == 1)
     else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
   }
 }
@@ -1498,6 +1524,12 @@ namespace {
 // between the windowed solves of a SLAM back end (GSLAM/core/Optimizer.h:229 is called every few keyframes on a graph
 // whose topology changes far less often than its values).
 struct BaSession {
+  // Arrow ordering (loop closures): cameras are renumbered so that the ones long-range points tie to far-away cameras come
+  // last -- the reduced camera system is then a band + a dense border (chol_cr.hip, arrowhead mode).  perm[new] = old camera
+  // (empty = the caller's order); everything on the device is in the new order, the entry points translate.
+  std::vector<int32_t> perm;
+  int n_border = 0;  // cameras of the border
+  double* d_arrow_ws = nullptr;
   bool ready = false;
   void* arena = nullptr;  // graph-owned arena (unused by one-shot solves)
   size_t arena_bytes = 0;
@@ -1554,9 +1586,11 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   } else {
     // (the same pass finds how far apart, in camera indices, the observers of one point are: a band -> the band solver)
     std::vector<int32_t> cam_lo((size_t)np, INT32_MAX), cam_hi((size_t)np, -1);
+    const int nc_band = nc - S.n_border;  // (arrow ordering: the border cameras are the last ones and do not count)
     for (int k = 0; k < no; ++k) {
       const int32_t c = pr->obs_cam[k], p = pr->obs_point[k];
       GH_CHECK_ARG(ctx, c >= 0 && c < nc && p >= 0 && p < np);
+      if (c >= nc_band) continue;
       if (c < cam_lo[p]) cam_lo[p] = c;
       if (c > cam_hi[p]) cam_hi[p] = c;
     }
@@ -1568,6 +1602,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   const int n = 6 * nc;
+  const int n_band = 6 * (nc - S.n_border);  // (== n unless the cameras are in arrow order)
   // one extra row carries the right-hand side through the factorisation; columns start on 128-byte lines
   const int lda = (n + 1 + 15) & ~15;
 
@@ -1855,15 +1890,18 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const int span = S.cam_span;  // (found with the argument check)
     int want = ctx->ba_solver;
     if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
-    cr_T = want == 1 || n >= 65536 ? 0 : gh_cr_tiles(n, 6 * span + 5);
-    d_cr_dinv = d_cr_W = nullptr;
+    cr_T = want == 1 || n >= 65536 ? 0 : gh_cr_tiles(n_band, 6 * span + 5);
+    d_cr_dinv = d_cr_W = S.d_arrow_ws = nullptr;
     if (cr_T) {
-      GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n, cr_T)));
-      GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n, cr_T)));
+      GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n_band, cr_T)));
+      GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n_band, cr_T)));
+      if (n_band < n) GH_TRY(db.alloc(&S.d_arrow_ws, gh_arrow_ws_doubles(n_band, cr_T, n - n_band)));
     }
     if (opt.verbose)
-      fprintf(stderr, "[gh_ba] cameras of a point at most %d indices apart: half-bandwidth %d of n = %d -> %s\n", span,
-              6 * span + 5, n, cr_T ? "band solver (block cyclic reduction)" : "dense factorisation");
+      fprintf(stderr, "[gh_ba] band cameras of a point at most %d indices apart, %d border cameras: half-bandwidth %d of n = %d -> %s\n",
+              span, S.n_border, 6 * span + 5, n_band,
+              cr_T ? (n_band < n ? "arrowhead solver (block cyclic reduction + dense border)" : "band solver (block cyclic reduction)")
+                   : "dense factorisation");
   }
   GH_TRY(db.alloc(&d_cpart, (size_t)nchunks * 27));
   GH_TRY(db.alloc(&d_cpart2, (size_t)nchunks * 27));
@@ -1957,7 +1995,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
             S.ready ? "resident graph" : "setup", t_lists - t_begin, t_csr - t_begin, S.n_pairs, nblocks, t_upload - t_lists,
             now_ms() - t_upload);
   S.ready = true;
-  ctx->ba_last_solver = cr_T ? 2 : 1;
+  ctx->ba_last_solver = cr_T ? (n_band < n ? 3 : 2) : 1;
   ctx->ba_last_band_tiles = cr_T;
   ctx->ba_last_cam_span = S.cam_span;
   double cost = h2[0];
@@ -2008,7 +2046,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     if (slim_init) {
       if (!fused_seed)
         GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(cr_T ? 1 : gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc,
-                  d_gc, radius, d_S, d_dc, 64 * cr_T);
+                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band);
     } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
       hipError_t me = hipMemsetAsync(d_S, 0, (size_t)n * lda * sizeof(double), ctx->stream);
@@ -2023,7 +2061,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
           const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);  // (the band solver's seed: one workgroup per column)
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_init_kernel, dim3(nsb + (unsigned)gx * (unsigned)n), dim3(256), 0, P,
                     SB, d_Hpi, d_gp, (const double*)d_W, d_spart, nsb, n, lda, (const double*)d_Hcc, (const double*)d_gc,
-                    radius, d_S, d_dc, gx, 64 * cr_T);
+                    radius, d_S, d_dc, gx, 64 * cr_T, n_band);
         } else {
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(nsb), dim3(256), 0, P, SB, d_Hpi, d_gp,
                     (const double*)d_W, d_spart);
@@ -2059,7 +2097,10 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     // rhs -> row n of S: already there when schur_init_kernel + schur_reduce_kernel wrote it
     if (!(slim_init && opt.deterministic))
       GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
-    if (cr_T) {
+    if (cr_T && n_band < n) {
+      GH_TRY(gh_arrow_solve_dev_impl(ctx, d_S, n_band, n - n_band, lda, cr_T, d_cr_dinv, d_cr_W, S.d_arrow_ws, d_dc, d_info,
+                                     solve_state_ready));
+    } else if (cr_T) {
       GH_TRY(gh_cr_solve_dev_impl(ctx, d_S, n, lda, cr_T, d_cr_dinv, d_cr_W, d_dc, d_info, solve_state_ready));
     } else {
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
@@ -2193,6 +2234,101 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;
 }
 
+// ---------------------------------------------------------------- arrow ordering (loop closures)
+// The band solver needs every point's observers within kBandSpan camera indices of each other; ONE point seen from both
+// ends of a loop used to send the whole graph to the dense factorisation (C5: 163 -> 0.89 LM iterations per second).  Here the
+// few cameras such points tie to far-away ones are moved to the END of the camera order: for every long-range point the
+// window of kBandSpan + 1 camera indices that holds most of its observers stays in the band, its other observers join the
+// border.  What is left is a band (the band cameras are renumbered compactly: spans only shrink) + a dense border, the shape of
+// chol_cr.hip's arrowhead solve -- what Ceres' SPARSE_SCHUR ordering achieves behind GSLAM/core/Optimizer.h:229, restated for
+// trajectories.  Returns the number of border cameras (0: leave the caller's order -- already a band, too many border cameras,
+// or too few band cameras) and perm[new] = old.
+constexpr int kBandSpan = 31;         // gh_cr_tiles: 6 * 31 + 5 = 191 <= 3 * 64
+constexpr int kMaxBorderCams = 1024;  // 6144 border rows: beyond that the dense corner dominates
+int ba_arrow_order(const gh_ba_problem* pr, std::vector<int32_t>& perm) {
+  perm.clear();
+  const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
+  if (nc < 4 * 32 + 1 || np <= 0 || no <= 0 || 6 * (long long)nc >= 65536) return 0;
+  std::vector<int32_t> lo((size_t)np, INT32_MAX), hi((size_t)np, -1);
+  for (int k = 0; k < no; ++k) {
+    const int32_t c = pr->obs_cam[k], p = pr->obs_point[k];
+    if (c < 0 || c >= nc || p < 0 || p >= np) return 0;  // (ba_run reports the bad index)
+    if (c < lo[p]) lo[p] = c;
+    if (c > hi[p]) hi[p] = c;
+  }
+  // the long-range points and their observers
+  std::vector<int32_t> slot((size_t)np, -1);
+  int nlong = 0;
+  for (int p = 0; p < np; ++p)
+    if (hi[p] >= 0 && hi[p] - lo[p] > kBandSpan) slot[p] = nlong++;
+  if (nlong == 0) return 0;
+  std::vector<std::vector<int32_t>> seen((size_t)nlong);
+  for (int k = 0; k < no; ++k) {
+    const int32_t sl = slot[pr->obs_point[k]];
+    if (sl >= 0) seen[sl].push_back(pr->obs_cam[k]);
+  }
+  std::vector<uint8_t> border((size_t)nc, 0);
+  for (auto& v : seen) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    // cameras already in the border do not constrain the window
+    size_t best_a = 0, best_cnt = 0;
+    for (size_t a = 0, b = 0; a < v.size(); ++a) {
+      if (border[v[a]]) continue;
+      if (b < a) b = a;
+      while (b + 1 < v.size() && v[b + 1] - v[a] <= kBandSpan) ++b;
+      size_t cnt = 0;
+      for (size_t t = a; t <= b; ++t) cnt += border[v[t]] ? 0 : 1;
+      if (cnt > best_cnt) {
+        best_cnt = cnt;
+        best_a = a;
+      }
+    }
+    for (size_t t = 0; t < v.size(); ++t)
+      if (v[t] < v[best_a] || v[t] - v[best_a] > kBandSpan) border[v[t]] = 1;
+  }
+  int nb = 0;
+  for (int c = 0; c < nc; ++c) nb += border[c];
+  if (nb == 0 || nb > kMaxBorderCams || 6 * (nc - nb) < 4 * 64) return 0;
+  perm.resize((size_t)nc);
+  int w = 0;
+  for (int c = 0; c < nc; ++c)
+    if (!border[c]) perm[w++] = c;
+  for (int c = 0; c < nc; ++c)
+    if (border[c]) perm[w++] = c;
+  return nb;
+}
+
+// The caller's problem in arrow order: cam_pose / cam_dof / obs_cam are re-indexed copies, everything else is shared.
+struct ArrowProblem {
+  gh_ba_problem pr;
+  std::vector<double> pose;
+  std::vector<int32_t> dof, ocam;
+  void build(const gh_ba_problem* src, const std::vector<int32_t>& perm) {
+    pr = *src;
+    const int nc = src->n_cams, no = src->n_obs;
+    pose.resize((size_t)nc * 7);
+    dof.resize((size_t)nc);
+    std::vector<int32_t> inv((size_t)nc);
+    for (int c = 0; c < nc; ++c) {
+      inv[perm[c]] = c;
+      memcpy(&pose[(size_t)c * 7], src->cam_pose + (size_t)perm[c] * 7, 7 * sizeof(double));
+      dof[c] = src->cam_dof[perm[c]];
+    }
+    ocam.resize((size_t)no);
+    for (int k = 0; k < no; ++k) ocam[k] = inv[src->obs_cam[k]];
+    pr.cam_pose = pose.data();
+    pr.cam_dof = dof.data();
+    pr.obs_cam = ocam.data();
+  }
+};
+bool ba_arrow_wanted(const gh_ctx* ctx) {
+  int want = ctx->ba_solver;
+  if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
+  if (const char* e = getenv("GSLAM_HIP_BA_ARROW")) if (e[0] == '0') return false;  // A/B measurements: loop closures -> dense, as in rounds 1-4
+  return want != 1;
+}
+
 }  // namespace
 
 extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_options* opt_in, gh_ba_summary* sum_out) {
@@ -2201,7 +2337,14 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   BaSession S;
   S.db = new (std::nothrow) DevBuf(ctx);
   if (!S.db) return GH_ERR_NOMEM;
-  return ba_run(ctx, S, pr, opt_in, sum_out, true);
+  if (pr->n_cams > 0 && pr->cam_pose && pr->cam_dof && pr->obs_cam && pr->obs_point && ba_arrow_wanted(ctx))
+    S.n_border = ba_arrow_order(pr, S.perm);
+  if (S.n_border == 0) return ba_run(ctx, S, pr, opt_in, sum_out, true);
+  ArrowProblem ap;
+  ap.build(pr, S.perm);
+  const gh_status st = ba_run(ctx, S, &ap.pr, opt_in, sum_out, true);
+  for (int c = 0; c < pr->n_cams; ++c) memcpy(pr->cam_pose + (size_t)S.perm[c] * 7, &ap.pose[(size_t)c * 7], 7 * sizeof(double));
+  return st;
 }
 
 // ---------------------------------------------------------------- device-resident graph across solves
@@ -2229,6 +2372,13 @@ extern "C" gh_status gh_ba_graph_create(gh_ctx* ctx, const gh_ba_problem* proble
   o.max_iterations = 0;  // set-up only: lists, tables, uploads, the initial cost
   gh_ba_summary sum;
   gh_ba_problem pr = *problem;
+  ArrowProblem ap;
+  if (pr.n_cams > 0 && pr.cam_pose && pr.cam_dof && pr.obs_cam && pr.obs_point && ba_arrow_wanted(ctx))
+    g->S.n_border = ba_arrow_order(&pr, g->S.perm);
+  if (g->S.n_border > 0) {
+    ap.build(problem, g->S.perm);
+    pr = ap.pr;
+  }
   const gh_status st = ba_run(ctx, g->S, &pr, &o, &sum, false);
   if (st != GH_OK) {
     delete g;
@@ -2256,6 +2406,20 @@ extern "C" gh_status gh_ba_graph_update(gh_ba_graph* g, const double* cam_pose, 
     if (src && bytes) GH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return GH_OK;
   };
+  std::vector<double> pose_p;
+  std::vector<int32_t> dof_p;
+  if (!S.perm.empty()) {  // arrow order on the device: translate the caller's per-camera arrays
+    if (cam_pose) {
+      pose_p.resize((size_t)S.nc * 7);
+      for (int c = 0; c < S.nc; ++c) memcpy(&pose_p[(size_t)c * 7], cam_pose + (size_t)S.perm[c] * 7, 56);
+      cam_pose = pose_p.data();
+    }
+    if (cam_dof) {
+      dof_p.resize((size_t)S.nc);
+      for (int c = 0; c < S.nc; ++c) dof_p[c] = cam_dof[S.perm[c]];
+      cam_dof = dof_p.data();
+    }
+  }
   GH_TRY(up(S.d_poses, cam_pose, (size_t)S.nc * 56));
   GH_TRY(up(S.d_pts, point_xyz, (size_t)S.np * 24));
   GH_TRY(up(S.d_oxy, obs_xy, (size_t)S.no * 16));
@@ -2276,11 +2440,19 @@ extern "C" gh_status gh_ba_graph_read(gh_ba_graph* g, double* cam_pose, double* 
   if (!g) return GH_ERR_ARG;
   gh_ctx* ctx = g->ctx;
   GH_ENTER(ctx);
+  std::vector<double> pose_p;
+  double* pose_dst = cam_pose;
+  if (cam_pose && !g->S.perm.empty()) {
+    pose_p.resize((size_t)g->S.nc * 7);
+    pose_dst = pose_p.data();
+  }
   if (cam_pose)
-    GH_HIP(ctx, hipMemcpyAsync(cam_pose, g->S.d_poses, (size_t)g->S.nc * 56, hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(ctx, hipMemcpyAsync(pose_dst, g->S.d_poses, (size_t)g->S.nc * 56, hipMemcpyDeviceToHost, ctx->stream));
   if (point_xyz && g->S.np > 0)
     GH_HIP(ctx, hipMemcpyAsync(point_xyz, g->S.d_pts, (size_t)g->S.np * 24, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (cam_pose && !g->S.perm.empty())
+    for (int c = 0; c < g->S.nc; ++c) memcpy(cam_pose + (size_t)g->S.perm[c] * 7, &pose_p[(size_t)c * 7], 56);
   return GH_OK;
 }
 

@@ -272,10 +272,10 @@ class Context:
         self.check(lib.gh_ctx_set_ba_solver(self.h, int(code)))
 
     def last_ba_solver(self):
-        """("dense" | "band" | None, tiles per superblock, camera span) of the last BA solve on this context."""
+        """("dense" | "band" | "arrow" | None, tiles per superblock, camera span of the band part) of the last BA solve on this context."""
         t, sp = C.c_int(), C.c_int()
         code = lib.gh_ctx_last_ba_solver(self.h, C.byref(t), C.byref(sp))
-        return {0: None, 1: "dense", 2: "band"}[code], t.value, sp.value
+        return {0: None, 1: "dense", 2: "band", 3: "arrow"}[code], t.value, sp.value
 
     def prof_enable(self, on=True):
         self.check(lib.gh_prof_enable(self.h, 1 if on else 0))

@@ -60,17 +60,22 @@ gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream);
  * context's stream; everything is re-grown on demand; gh_ba_graph objects own their memory and are not touched. */
 gh_status gh_ctx_trim(gh_ctx* ctx);
 /* Linear solver of the reduced camera system in gh_ba_solve / gh_ba_graph_solve: GH_BA_SOLVER_AUTO (default) takes the
- * band solver (block cyclic reduction, chol_cr.hip) when every point is seen from cameras at most 32 indices apart and
- * the system has at least four superblocks, else the dense MFMA factorisation; _DENSE forces the dense path (what
- * BASELINE's C5 names); _BAND asks for the band solver and falls back to dense when the graph is not a band.
+ * band solver (block cyclic reduction, chol_cr.hip) when every point is seen from cameras at most 31 indices apart, the
+ * system has at least four superblocks of 64 * ceil((6 span + 5) / 64) columns and fewer than 65536 unknowns, else the
+ * dense MFMA factorisation; _DENSE forces the dense path (what BASELINE's C5 names); _BAND asks for the band solver and
+ * falls back to dense when the graph is not a band.  LOOP CLOSURES: under _AUTO / _BAND the cameras that long-range points
+ * tie to far-away cameras (at most 1024 of them) are numbered last inside the solver, and the system is solved as a band +
+ * dense border (GH_BA_SOLVER_ARROW in gh_ctx_last_ba_solver; gh_arrow_solve_dev) instead of falling to the dense path.
  * The environment variable GSLAM_HIP_BA_SOLVER=dense|band|auto overrides it (A/B measurements). */
 #define GH_BA_SOLVER_AUTO 0
 #define GH_BA_SOLVER_DENSE 1
 #define GH_BA_SOLVER_BAND 2
+#define GH_BA_SOLVER_ARROW 3 /* reported only: band + dense border */
 gh_status gh_ctx_set_ba_solver(gh_ctx* ctx, int solver);
 /* What the last gh_ba_solve / gh_ba_graph_solve on this context used: GH_BA_SOLVER_DENSE or _BAND (0 before the first
  * solve); *band_tiles = 64-column tiles per superblock of the band solver (0 for dense), *cam_span = the largest distance
- * in camera indices between two observers of one point (the half-bandwidth of the reduced system is 6 * span + 5).
+ * in camera indices between two observers of one point -- border cameras of the arrow ordering left out -- (the
+ * half-bandwidth of the band part is 6 * span + 5).
  * Either pointer may be NULL. */
 int gh_ctx_last_ba_solver(gh_ctx* ctx, int* band_tiles, int* cam_span);
 gh_status gh_ctx_use_own_stream(gh_ctx* ctx);

@@ -323,10 +323,19 @@ def test_ba_band_and_dense_solvers_agree(ctx, cams, points):
     assert used_a[0] == "band"
 
 
+def _same_lm_run(sd, sb, pd, pb, xd, xb):
+    assert sd.iterations == sb.iterations and sd.trace_len == sb.trace_len
+    n = sd.trace_len
+    assert list(sd.trace_accepted[:n]) == list(sb.trace_accepted[:n])
+    cd, cb = np.array(sd.trace_cost[:n]), np.array(sb.trace_cost[:n])
+    assert np.abs(cd - cb).max() <= 1e-10 * np.abs(cd).max()
+    assert np.abs(pd - pb).max() <= 1e-9 and np.abs(xd - xb).max() <= 1e-9
+
+
 @pytest.mark.gpu
-def test_ba_wide_graph_stays_dense(ctx):
-    """Observers drawn from the whole trajectory (a loop closure between far cameras is enough): not a band -> dense path,
-    also when the band solver is asked for."""
+def test_ba_one_loop_closure_takes_the_arrow_solver(ctx):
+    """ONE observation from the other end of the trajectory used to send the whole graph to the dense factorisation (rounds
+    1-4); now the camera it ties in joins the border of an arrowhead system.  Same LM run as the dense solver's."""
     from gslam_amd.ba_synth import make_graph
     g = make_graph(160, 8000, n_obs_per_point=6, seed=3)
     oc = np.array(g["obs_cam"]).copy()
@@ -335,8 +344,70 @@ def test_ba_wide_graph_stays_dense(ctx):
     oc[k] = 159 if oc[k] < 80 else 0     # one observation from the other end of the trajectory
     g2 = dict(g)
     g2["obs_cam"] = oc
+    pa, xa, sa, used = _solve_with(ctx, g2, "auto")
+    assert used[0] == "arrow" and used[1] == 3 and used[2] <= 31 and sa.iterations >= 1
+    pd, xd, sd, used_d = _solve_with(ctx, g2, "dense")
+    assert used_d[0] == "dense"
+    _same_lm_run(sd, sa, pd, pa, xd, xa)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cams,points,closures,span", [(160, 8000, 5, 80), (300, 20000, 12, None), (500, 50000, 20, None)])
+def test_ba_arrow_and_dense_solvers_agree(ctx, cams, points, closures, span):
+    """Trajectories with loop-closure points (ba_synth.make_graph(loop_closures=...)) through the dense factorisation and through
+    the arrowhead solver (band + border, arrow ordering of the cameras inside gh_ba_solve): identical LM decisions, costs to
+    1e-10, states to 1e-9 in the CALLER's camera order (C4 + 20 closures at full size included)."""
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(cams, points, n_obs_per_point=6, seed=2, loop_closures=closures, closure_span=span)
+    pd, xd, sd, used_d = _solve_with(ctx, g, "dense")
+    pa, xa, sa, used_a = _solve_with(ctx, g, "auto")
+    assert used_d[0] == "dense" and used_a[0] == "arrow" and used_a[2] <= 31
+    _same_lm_run(sd, sa, pd, pa, xd, xa)
+    # the loop closures matter: without them the run is a different one
+    g0 = make_graph(cams, points, n_obs_per_point=6, seed=2)
+    _, _, s0, used_0 = _solve_with(ctx, g0, "auto")
+    assert used_0[0] == "band" and s0.final_cost != sa.final_cost
+
+
+@pytest.mark.gpu
+def test_ba_arrow_graph_session_round_trip(ctx):
+    """The device-resident graph API keeps its cameras in arrow order inside: create / update / solve / read give the one-shot
+    solve's result in the caller's camera order."""
+    from gslam_amd import ba
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(200, 10000, n_obs_per_point=6, seed=4, loop_closures=6)
+    p1, x1, s1, _ = ba.solve(ctx, g, ba.default_options(max_iterations=15))
+    assert ctx.last_ba_solver()[0] == "arrow"
+    gr = ba.Graph(ctx, g, ba.default_options(max_iterations=15))
+    try:
+        s2, _ = gr.solve(ba.default_options(max_iterations=15))
+        assert ctx.last_ba_solver()[0] == "arrow"
+        p2, x2 = gr.read()
+        assert s2.iterations == s1.iterations and abs(s2.final_cost - s1.final_cost) <= 1e-12 * s1.final_cost
+        assert np.abs(p2 - p1).max() <= 1e-10 and np.abs(x2 - x1).max() <= 1e-10
+        # a second solve from re-uploaded initial values (caller's order) reproduces it
+        gr.update(cam_pose=g["cam_pose"], point_xyz=g["point_xyz"])
+        s3, _ = gr.solve(ba.default_options(max_iterations=15))
+        p3, x3 = gr.read()
+        assert s3.iterations == s1.iterations and np.abs(p3 - p1).max() <= 1e-10 and np.abs(x3 - x1).max() <= 1e-10
+    finally:
+        gr.close()
+
+
+@pytest.mark.gpu
+def test_ba_wide_graph_stays_dense(ctx):
+    """Observers drawn from the WHOLE trajectory for every point: the band that is left would be too short -> dense path, also
+    when the band solver is asked for."""
+    from gslam_amd.ba_synth import make_graph
+    g = make_graph(160, 8000, n_obs_per_point=6, seed=3)
+    rng = np.random.default_rng(0)
+    oc = np.array(g["obs_cam"]).reshape(-1, 6).copy()
+    for p in range(0, oc.shape[0], 2):
+        oc[p] = np.sort(rng.choice(160, 6, replace=False))
+    g2 = dict(g)
+    g2["obs_cam"] = oc.reshape(-1).astype(np.int32)
     _, _, s, used = _solve_with(ctx, g2, "band", iters=3)
-    assert used[0] == "dense" and used[2] > 32 and s.iterations >= 1
+    assert used[0] == "dense" and used[2] > 31 and s.iterations >= 1
 
 
 @pytest.mark.gpu
