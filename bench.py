@@ -709,6 +709,9 @@ def main():
             "ba_chol_fused")
 
     CR = ("ba_cr_factor", "ba_cr_panels", "ba_cr_update", "ba_cr_back", "ba_cr_inverse", "ba_cr_backprep")
+    # the arrowhead solver (band + dense border: loop closures) adds the border's kernels and the dense corner
+    ARROW = CR + ("ba_cr_border_panels", "ba_cr_border_update", "ba_cr_border_syrk", "ba_cr_border_reduce", "ba_cr_border_gather",
+                  "ba_cr_border_back", "ba_cr_border_yh") + CHOL
 
     def ba_leg(cams, points, iters, separate_timed_run, prof_iters=None, solver="auto", graph=None):
         """solver: "auto" (band solver -- block cyclic reduction, chol_cr.hip -- when the graph is a trajectory band, what a
@@ -760,10 +763,11 @@ def main():
         solve_flops = (n ** 3 / 3.0 + 2.0 * n * n) * sp.iterations
         chol_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CHOL)
         cr_ms = sum(v["total_ms"] for k, v in bprof.items() if k in CR)
+        arrow_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ARROW)
         launches = sum(v["launches"] for v in bprof.values())
         used, tiles, span = ctx.last_ba_solver()
         band_flops = None
-        if used == "band":
+        if used == "band" and cr_ms:
             # executed flops of the block cyclic reduction, per solve: per eliminated superblock (two neighbours) m^3 / 3 (potrf)
             # + 2 m^3 (the two panels) + 2 m^3 + 2 m^3 (two rank-m updates, one fill block) + off the critical path ~2.4 m^3
             # (L^-T, the two G products); all f64 MFMA work except the potf2 pivots
@@ -773,7 +777,7 @@ def main():
                 "graph_census": census,
                 "linear_solver": {"used": used, "camera_span": span, "half_bandwidth": 6 * span + 5,
                                   "superblock_columns": 64 * tiles if tiles else None,
-                                  "solver_kernel_ms_per_iteration": round((cr_ms if used == "band" else chol_ms) / max(1, sp.iterations), 4),
+                                  "solver_kernel_ms_per_iteration": round((cr_ms if used == "band" else (arrow_ms if used == "arrow" else chol_ms)) / max(1, sp.iterations), 4),
                                   "band_executed_GFLOP_per_solve": round(band_flops / 1e9, 3) if band_flops else None,
                                   "band_achieved_TFLOPs": round(band_flops * sp.iterations / (cr_ms * 1e-3) / 1e12, 3) if band_flops and cr_ms else None,
                                   "dense_GFLOP_per_solve": round((n ** 3 / 3.0 + 2.0 * n * n) / 1e9, 3),
@@ -781,7 +785,9 @@ def main():
                                            "not by running them faster: it is bound by launch / pivot-chain latency, not by the f64 MFMA rate"
                                            % ((n ** 3 / 3.0 + 2.0 * n * n) / band_flops)) if band_flops else None,
                                   "what": "band: block cyclic reduction over superblocks of the reduced camera system "
-                                          "(gslam_amd/csrc/chol_cr.hip); dense: the MFMA f64 factorisation (chol.hip)"},
+                                          "(gslam_amd/csrc/chol_cr.hip); arrow: the same with the cameras that loop-closure points tie "
+                                          "to far-away ones as a dense border (camera_span = the band part's); dense: the MFMA f64 "
+                                          "factorisation (chol.hip)"},
                 "iters_per_s": round(s.iterations / (s.total_ms * 1e-3), 2), "iterations": s.iterations,
                 "ms_per_iteration": round(s.total_ms / max(1, s.iterations), 3),
                 "total_ms": round(s.total_ms, 2), "initial_cost": s.initial_cost, "final_cost": s.final_cost,
@@ -794,6 +800,17 @@ def main():
                                  "peak_TFLOPs": FP64_MFMA_PEAK / 1e12,
                                  "frac": round(solve_flops / (chol_ms * 1e-3) / FP64_MFMA_PEAK, 4)} if chol_ms else None),
                 "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in bprof.items()}}
+
+    def ctx_border_cams(g):
+        """how many cameras the arrow ordering of gh_ba_solve moves to the border (restated: per long-range point the observers
+        outside the 32-camera window that holds most of them)"""
+        border = set()
+        oc, op = np.asarray(g["obs_cam"]), np.asarray(g["obs_point"])
+        for p in g.get("closure_points", []):
+            v = np.unique(oc[op == p])
+            best = max(range(len(v)), key=lambda a: (sum(1 for t in v[a:] if t - v[a] <= 31 and t not in border), -a))
+            border.update(int(t) for t in v if t < v[best] or t - v[best] > 31)
+        return len(border)
 
     def dense_solve_check(n):
         """gh_potrf_solve_dev on a well conditioned SPD system of the C5 size: TFLOP/s and ||A x - b|| / ||b|| <= 1e-10."""
@@ -828,6 +845,24 @@ def main():
                 "the two linear solvers led the LM loop to different results"
             extra["ba"]["dense_solver"] = {k: dn[k] for k in ("iters_per_s", "ms_per_iteration", "resolve_iters_per_s", "launches_per_iteration",
                                                                "dense_solve", "linear_solver", "final_cost", "kernels")}
+            # the same trajectory with loop-closure points (the band is exact by construction without them): ONE such
+            # point used to send the graph to the dense solver; now the cameras it ties in form the border of an arrowhead system
+            if a.ba_cams >= 200:
+                nlc = 20
+                g4c = _mk(a.ba_cams, a.ba_points, n_obs_per_point=6, seed=1, loop_closures=nlc)
+                lc = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True, graph=g4c)
+                ld = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True, solver="dense", graph=g4c)
+                assert lc["iterations"] == ld["iterations"] and abs(lc["final_cost"] - ld["final_cost"]) <= 1e-9 * abs(ld["final_cost"]), \
+                    "loop closures: the arrowhead and the dense solver led the LM loop to different results"
+                keys = ("iters_per_s", "ms_per_iteration", "resolve_iters_per_s", "launches_per_iteration", "linear_solver", "iterations", "final_cost")
+                extra["ba"]["loop_closure"] = {"closure_points": nlc, "closure_span_cams": a.ba_cams // 2,
+                                               "border_cams": int(ctx_border_cams(g4c)),
+                                               **{k: lc[k] for k in keys}, "kernels": lc["kernels"],
+                                               "dense_solver": {k: ld[k] for k in keys},
+                                               "what": "make_graph(loop_closures=20): 20 points seen from two ends of the trajectory; "
+                                                       "gh_ba_solve orders their far observers last (arrow ordering) and solves band + "
+                                                       "border; dense_solver = the same graph through the dense factorisation (what rounds "
+                                                       "1-4 fell back to); same LM run asserted"}
     except Exception as exc:  # an optional leg must never cost the headline line
         extra.setdefault("errors", {})["ba"] = repr(exc)
         log("ba leg failed: %r" % (exc,))
@@ -849,6 +884,25 @@ def main():
             extra["ba_c5"]["band_solver"]["to_convergence"] = {k: bl[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
                                                                                     "initial_cost", "final_cost")}
             del g5
+            torch.cuda.empty_cache()
+            # C5 + 50 loop-closure points 5000 cameras apart: rounds 1-4 solved this dense (0.89 LM it/s), now band + border
+            g5c = _mk(10000, 1000000, n_obs_per_point=6, seed=1, loop_closures=50, closure_span=5000)
+            lc5 = ba_leg(10000, 1000000, 5, True, prof_iters=2, solver="auto", graph=g5c)
+            ld5 = ba_leg(10000, 1000000, 2, False, prof_iters=2, solver="dense", graph=g5c)
+            lc5_2 = ba_leg(10000, 1000000, 2, False, prof_iters=2, solver="auto", graph=g5c)
+            assert lc5_2["iterations"] == ld5["iterations"] and abs(lc5_2["final_cost"] - ld5["final_cost"]) <= 1e-9 * abs(ld5["final_cost"]), \
+                "C5 + loop closures: the arrowhead and the dense solver disagree"
+            ll5 = ba_leg(10000, 1000000, 40, True, prof_iters=2, solver="auto", graph=g5c)
+            keys5 = ("iters_per_s", "ms_per_iteration", "launches_per_iteration", "linear_solver", "iterations", "final_cost")
+            extra["ba_c5"]["loop_closure"] = {"closure_points": 50, "closure_span_cams": 5000, "border_cams": int(ctx_border_cams(g5c)),
+                                              **{k: lc5[k] for k in keys5}, "kernels": lc5["kernels"],
+                                              "to_convergence": {k: ll5[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
+                                                                                     "initial_cost", "final_cost")},
+                                              "dense_solver_2_iterations": {k: ld5[k] for k in ("iters_per_s", "ms_per_iteration", "iterations", "final_cost")},
+                                              "what": "make_graph(loop_closures=50, closure_span=5000); arrowhead solver (band + border); the "
+                                                      "dense solver on the same graph for 2 iterations as the parity check and the rate rounds "
+                                                      "1-4 had on such a graph"}
+            del g5c
             torch.cuda.empty_cache()
             log("dense solve check n = 60000")
             extra["ba_c5"]["dense_solve_check"] = dense_solve_check(60000)
@@ -1347,6 +1401,8 @@ def main():
         "ba_c5_lm_iters_per_s": (extra.get("ba_c5") or {}).get("iters_per_s"),  # dense MFMA solve: BASELINE configs[4]
         "ba_c5_band_solver_lm_iters_per_s": ((extra.get("ba_c5") or {}).get("band_solver") or {}).get("iters_per_s"),
         "ba_c4_resident_graph_lm_iters_per_s": (extra.get("ba") or {}).get("resolve_iters_per_s"),
+        "ba_c4_loop_closure_lm_iters_per_s": ((extra.get("ba") or {}).get("loop_closure") or {}).get("iters_per_s"),
+        "ba_c5_loop_closure_lm_iters_per_s": ((extra.get("ba_c5") or {}).get("loop_closure") or {}).get("iters_per_s"),
         "host_fed_Mkeypoints_per_s": (extra.get("host_fed") or {}).get("Mkeypoints_per_s"),
         "extra": extra,
     }

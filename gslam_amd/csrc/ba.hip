@@ -36,7 +36,7 @@ size_t gh_cr_dinv_doubles(int n, int T);
 size_t gh_cr_panel_doubles(int n, int T);
 gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, double* dinv, double* W, double* x_dev,
                                int* info_dev, bool info_ready);
-size_t gh_arrow_ws_doubles(int n_band, int T, int nbr);
+size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr);
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
                                   double* x_dev, int* info_dev, bool info_ready);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
@@ -1895,7 +1895,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     if (cr_T) {
       GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n_band, cr_T)));
       GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n_band, cr_T)));
-      if (n_band < n) GH_TRY(db.alloc(&S.d_arrow_ws, gh_arrow_ws_doubles(n_band, cr_T, n - n_band)));
+      if (n_band < n) GH_TRY(db.alloc(&S.d_arrow_ws, gh_arrow_ws_doubles(ctx, n_band, cr_T, n - n_band)));
     }
     if (opt.verbose)
       fprintf(stderr, "[gh_ba] band cameras of a point at most %d indices apart, %d border cameras: half-bandwidth %d of n = %d -> %s\n",
@@ -2090,7 +2090,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const double t_solve0 = now_ms();
     // (one single-launch factorisation at a time per process, until this iteration's synchronisation: see chol.hip)
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
-    if (d_flow && !cr_T) flow_lock.lock();
+    if ((d_flow && !cr_T) || (cr_T && n_band < n)) flow_lock.lock();  // (arrowhead: its dense corner may run as the single-launch factorisation)
     // The whole candidate step is enqueued without waiting for the factorisation flags (the kernels have no
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host
     // synchronisation per iteration instead of three.

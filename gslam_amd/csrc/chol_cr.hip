@@ -34,6 +34,9 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
                                 bool xh_ready);
+size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
+size_t gh_potrf_flow_flag_words(int n, int extra_rows);
+std::mutex& gh_potrf_flow_mutex(int device);
 
 namespace {
 
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
 // task: 0 .. 4T-1 strips of side u (P = B(i, u)^T), 4T .. 8T-1 side d (P = B(d, i)), 8T = the right-hand side,
 // 8T+1 .. 12T strips of P = identity: W3 = L_i^-T, what turns the backward pass into plain products (cr_update_kernel).
 template <int T>
-__global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int ntask) {
+__global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, int ntask) {
   constexpr int m_ = NBI * T, PW = 17;
   __shared__ double Pl[m_ * PW], Xl[m_ * PW];
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
@@ -398,15 +401,17 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int task0, int
   // every task of an eliminated superblock on ONE XCD (block b runs on XCD b % 8, each with its own L2): the six operand
   // tiles come over the fabric once per XCD instead of once per workgroup (placement only affects speed)
   const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-  const int e = xcd + 8 * (slot / ntask), task = task0 + slot % ntask;
+  const int e = xcd + 8 * (slot / ntask), task = slot % ntask;
   if (e >= a.count) return;
   // (a.s == 0: every eliminated superblock of every level, i = 1 .. N - 1 -- only the identity strips are run that way)
   const int i = a.s == 0 ? 1 + e : a.first + e * 2 * a.s, i0 = i * m_, n = a.n;
   const size_t lda = (size_t)a.lda;
   const double* const A = a.A;
-  // (tasks from 12 T + 1: side 4 = a 16-row strip of the BORDER rows a.n .. a.n + nbr - 1 of an arrowhead system: Y_i = E_i L_i^-T in place)
-  const int side = task > 12 * T ? 4 : (task > 8 * T ? 3 : (task == 8 * T ? 2 : (task >= 4 * T ? 1 : 0)));
-  const int strip = side == 4 ? task - 12 * T - 1 : (side == 3 ? task - 8 * T - 1 : task - 4 * T * (side == 1 ? 1 : (side == 2 ? 2 : 0)));
+  // forward launches: tasks 0 .. 4T-1 side u, 4T .. 8T-1 side d, 8T the right-hand side, from 8T + 1 side 4 = a 16-row strip of
+  // the BORDER rows a.n .. a.n + nbr - 1 of an arrowhead system (Y_i = E_i L_i^-T in place); inverse launches: 4T strips of
+  // the identity (side 3)
+  const int side = inverse ? 3 : (task > 8 * T ? 4 : (task == 8 * T ? 2 : (task >= 4 * T ? 1 : 0)));
+  const int strip = side == 4 ? task - 8 * T - 1 : (side == 3 ? task : task - 4 * T * (side == 1 ? 1 : (side == 2 ? 2 : 0)));
   const int nb = side == 0 ? i - a.s : i + a.s;
   if (side < 2 && (nb < 0 || nb >= a.N)) return;
   const int nb0 = nb * m_ + 16 * strip;  // first row of the strip (side u / d)
@@ -838,73 +843,74 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
 // - x_c Y_i to the right-hand side of superblock i:  yh_i -= (x_c Y_i) L_i^-1, then cr_back_kernel as before.
 // It is a Cholesky factorisation of the symmetrically permuted matrix: same result as the dense solve to rounding
 // (tests/test_cr_solver.py: restated in numpy; gh_arrow_solve_dev against numpy and the dense path).
-constexpr int kBorderChunk = 16;  // superblocks of columns per K chunk of the corner update
+// K chunks of the corner update: columns per chunk (a multiple of 16) and their number -- at most 16 superblocks per chunk, and
+// enough chunks that tiles x chunks fill the chip when the corner has few tiles (C4 + 20 loop closures: 21 tiles)
+struct BorderChunks { int kc, n; };
+inline BorderChunks border_chunks(int n_band, int m, int nbr) {
+  const int K = n_band > m ? n_band - m : 0;
+  if (K == 0) return BorderChunks{16, 0};
+  const int ntr = (nbr + 1 + 63) / 64, ntiles = ntr * (ntr + 1) / 2;
+  int want = (K + 16 * m - 1) / (16 * m);
+  const int fill = (1024 + ntiles - 1) / ntiles;
+  if (fill > want) want = fill < 64 ? fill : 64;
+  if (want > (K + 63) / 64) want = (K + 63) / 64;
+  const int kc = (((K + want - 1) / want) + 15) & ~15;
+  return BorderChunks{kc, (K + kc - 1) / kc};
+}
 
-// level s, survivor j = grp 2 s:  E_j -= Y_{j-s} W_d(j-s)^T + Y_{j+s} W_u(j+s)^T.  Workgroup = 64 border rows x 64 columns of j,
-// wave = a 32 x 32 block (2 x 2 MFMA blocks), operands straight from L2 in MFMA layout.  D'[out column][out row]: the lane
-// holds out column q + 4 r, out row m -- 16 consecutive rows of A per register, a 128-byte run.
+// level s, survivor j = grp 2 s:  E_j -= Y_{j-s} W_d(j-s)^T + Y_{j+s} W_u(j+s)^T.  Workgroup = 64 border rows x 16 columns of j,
+// wave = one 16 x 16 block, operands straight from L2 in MFMA layout with ALL k-steps of a source in flight at once (the launch
+// is a chain of L2 round trips: two per wave this way; 32 x 32 blocks with 16 k-steps in flight took 35 us per level at C4).
+// D'[out column][out row]: the lane holds out column q + 4 r, out row m -- 16 consecutive rows of A per register, a 128-byte run.
 template <int T>
 __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt) {
-  constexpr int m_ = NBI * T;
+  constexpr int m_ = NBI * T, KS = m_ / 4;
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w & 1, wc = w >> 1;
-  const int per = nrt * T;
-  const int grp = (int)blockIdx.x / per, rem = (int)blockIdx.x - grp * per, rt = rem / T, tb = rem - rt * T;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = nrt * T * 4;
+  const int grp = (int)blockIdx.x / per, rem = (int)blockIdx.x - grp * per, rt = rem / (T * 4), cq = rem - rt * (T * 4);
   const int j = grp * 2 * a.s, n = a.n;
   if (j >= a.N) return;
   const size_t lda = (size_t)a.lda, mm = (size_t)m_ * m_;
   const double* const A = a.A;
-  double4_t acc[2][2];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const int row_b = 64 * rt + 32 * wr;  // border row of this wave's block
-  const int col_b = 64 * tb + 32 * wc;  // column within superblock j
+  const int row_b = 64 * rt + 16 * w;  // border row of this wave's block
+  const int col_b = 16 * cq;           // column within superblock j
+  if (row_b >= a.nbr) return;
+  const int r = row_b + m;
+  const size_t roff = (size_t)n + (size_t)(r < a.nbr ? r : a.nbr - 1);
+  double4_t acc0 = (double4_t){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
     const int src = sd == 0 ? j - a.s : j + a.s;
     if (src < 0 || src >= a.N) continue;
-    const double* Wp = a.W + ((size_t)src * 2 + (sd == 0 ? 1 : 0)) * mm;  // j is the d-neighbour of j - s, the u-neighbour of j + s
+    const double* Wp = a.W + ((size_t)src * 2 + (sd == 0 ? 1 : 0)) * mm + col_b + m;  // j is the d-neighbour of j - s, the u-neighbour of j + s
     const int s0 = src * m_;
-    for (int ks = 0; ks < m_ / 4; ks += 4) {
-      double av[4][2], bv[4][2];
+    double av[KS], bv[KS];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = 4 * (ks + u) + q;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + q;
+      av[ks] = Wp[(size_t)k * m_];  // (panels are zero-padded)
+      const int kc = s0 + k < n ? s0 + k : n - 1;
+      bv[ks] = keep_if(A[(size_t)kc * lda + roff], r < a.nbr && s0 + k < n);
+    }
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) av[u][cb] = Wp[(size_t)k * m_ + col_b + 16 * cb + m];  // (panels are zero-padded)
-        const int kc = s0 + k < n ? s0 + k : n - 1;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          const int r = row_b + 16 * rb + m;
-          bv[u][rb] = keep_if(A[(size_t)kc * lda + n + (r < a.nbr ? r : a.nbr - 1)], r < a.nbr && s0 + k < n);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = mma(av[u][cb], bv[u][rb], acc[cb][rb]);
+    for (int ks = 0; ks < KS; ks += 2) {
+      acc0 = mma(av[ks], bv[ks], acc0);
+      acc1 = mma(av[ks + 1], bv[ks + 1], acc1);
     }
   }
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = j * m_ + col_b + 16 * cb + q + 4 * r, row = row_b + 16 * rb + m;
-        if (col < n && row < a.nbr) a.A[(size_t)col * lda + n + row] -= acc[cb][rb][r];
-      }
+  for (int rr = 0; rr < 4; ++rr) {
+    const int col = j * m_ + col_b + q + 4 * rr;
+    if (col < n && r < a.nbr) a.A[(size_t)col * lda + n + r] -= acc0[rr] + acc1[rr];
+  }
 }
 
 // The corner: partial[chunk][tile] = sum over the chunk's columns k of Yx[rows of the tile][k] Yx[cols of the tile][k], Yx = rows
 // n .. rr of A (the border rows and the right-hand side), k from m (superblock 0 stays) to n.  Tiles of 64 x 64 over the lower
 // triangle of the (nbr + 1) x nbr corner, four waves = 2 x 2 blocks of 32 x 32.
 template <int T>
-__global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int ntile_rows, int ntiles, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int kcols, int ntiles, double* __restrict__ part) {
   constexpr int m_ = NBI * T;
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w & 1, wc = w >> 1;
@@ -913,11 +919,10 @@ __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int ntile
   int ta = 0;
   while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
   const int tb = tile - ta * (ta + 1) / 2;
-  (void)ntile_rows;
   const int n = a.n, next = a.nbr + 1;
   const size_t lda = (size_t)a.lda;
   const double* const A = a.A;
-  const int k0 = m_ + chunk * (kBorderChunk * m_), k1 = k0 + kBorderChunk * m_ < n ? k0 + kBorderChunk * m_ : n;
+  const int k0 = m_ + chunk * kcols, k1 = k0 + kcols < n ? k0 + kcols : n;
   double4_t acc[2][2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -961,28 +966,44 @@ __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int ntile
 // corner -= the chunks' partial tiles, summed in chunk order (fixed: results do not depend on the launch's scheduling)
 template <int T>
 __global__ __launch_bounds__(256) void cr_border_syrk_reduce_kernel(CrArgs a, int ntiles, int nchunks, const double* __restrict__ part) {
-  const int tile = (int)blockIdx.x;
+  const int tile = (int)blockIdx.x >> 4;  // 16 workgroups per tile, one element per thread
   int ta = 0;
   while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
   const int tb = tile - ta * (ta + 1) / 2;
   const int n = a.n, next = a.nbr + 1;
   const size_t lda = (size_t)a.lda;
-  for (int e = threadIdx.x; e < 4096; e += 256) {
-    const int c = e >> 6, r = e & 63;
-    const int row = 64 * ta + r, col = 64 * tb + c;
-    if (row >= next || col >= a.nbr || col > row) continue;
-    double sum = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch) sum += part[((size_t)ch * ntiles + tile) * 4096 + e];
-    a.A[(size_t)(n + col) * lda + n + row] -= sum;
+  const int e = (((int)blockIdx.x & 15) << 8) + (int)threadIdx.x;
+  const int c = e >> 6, r = e & 63;
+  const int row = 64 * ta + r, col = 64 * tb + c;
+  if (row >= next || col >= a.nbr || col > row) return;
+  const double* p = part + (size_t)tile * 4096 + e;
+  const size_t stride = (size_t)ntiles * 4096;
+  double sum = 0.0;
+  int ch = 0;
+  for (; ch + 8 <= nchunks; ch += 8) {  // eight loads in flight, added in chunk order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(ch + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
   }
+  for (; ch < nchunks; ++ch) sum += p[(size_t)ch * stride];
+  a.A[(size_t)(n + col) * lda + n + row] -= sum;
 }
 
 // The dense system that is left: superblock 0 (reduced, not factored) and the border, with the right-hand side as row qn.
 // M is qn x qn column-major with pitch ldq; element (r, c), r >= c.
 template <int T>
-__global__ void cr_border_gather_kernel(CrArgs a, double* __restrict__ M, int ldq) {
+__global__ void cr_border_gather_kernel(CrArgs a, double* __restrict__ M, int ldq, unsigned* __restrict__ flow_flags, unsigned n_flow,
+                                        unsigned* __restrict__ xh_words, unsigned n_xh) {
   constexpr int m_ = NBI * T;
   const int c = (int)blockIdx.x, qn = m_ + a.nbr, n = a.n;
+  if (c >= qn) {  // the workgroups behind the columns clear what the single-launch solve kernels need (as ba.hip's schur_reduce does)
+    const unsigned i0 = (unsigned)(c - qn) * blockDim.x + threadIdx.x, step = (gridDim.x - (unsigned)qn) * blockDim.x;
+    for (unsigned i = i0; i < n_flow; i += step) flow_flags[i] = 0u;
+    for (unsigned i = i0; i < n_xh; i += step) xh_words[i] = 0xFFF8BEEFu;
+    return;
+  }
   const size_t lda = (size_t)a.lda;
   const size_t src_col = c < m_ ? (size_t)c : (size_t)(n + c - m_);
   for (int r = c + (int)threadIdx.x; r <= qn; r += (int)blockDim.x) {
@@ -1081,8 +1102,8 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     a.count = (N - s + 2 * s - 1) / (2 * s);
     const int g8 = 8 * gh_div_up(a.count, 8);  // groups of eight eliminated superblocks, one per XCD
     GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(a.count), dim3(512), factor_lds, a);
-    GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(g8 * (8 * T + 1)), dim3(256), 0, a, 0, 8 * T + 1);
-    if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_panels", cr_panels_kernel<T>, dim3(g8 * nbs), dim3(256), 0, a, 12 * T + 1, nbs);
+    // (the border strips of an arrowhead system ride in the same launch: they need nothing but L_i either)
+    GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(g8 * (8 * T + 1 + nbs)), dim3(256), 0, a, 0, 8 * T + 1 + nbs);
     if (2 * s >= N) {  // the last level: everything the side work reads is (or will be, in stream order) complete here
       GH_HIP(ctx, hipEventRecord(ctx->cr_events[0], ctx->stream));
       GH_HIP(ctx, hipStreamWaitEvent(side, ctx->cr_events[0], 0));
@@ -1091,13 +1112,13 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
       b.first = 1;
       b.count = N - 1;
       const int ge = 8 * gh_div_up(N - 1, 8);
-      CR_LAUNCH_ON(side, "ba_cr_inverse", cr_panels_kernel<T>, dim3(ge * 4 * T), dim3(256), 0, b, 8 * T + 1, 4 * T);
+      CR_LAUNCH_ON(side, "ba_cr_inverse", cr_panels_kernel<T>, dim3(ge * 4 * T), dim3(256), 0, b, 1, 4 * T);
       CR_LAUNCH_ON(side, "ba_cr_backprep", cr_update_kernel<T>, dim3(update_grid(N - 1, NTE)), dim3(256), 0, b, 1, N - 1);
       GH_HIP(ctx, hipEventRecord(ctx->cr_events[1], side));
     }
     const int nsurv = gh_div_up(N, 2 * s);
     GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(update_grid(nsurv, NTS)), dim3(256), 0, a, 0, nsurv);
-    if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_update", cr_border_update_kernel<T>, dim3(nsurv * nrt * T), dim3(256), 0, a, nrt);
+    if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_update", cr_border_update_kernel<T>, dim3(nsurv * nrt * T * 4), dim3(256), 0, a, nrt);
   }
   // the last block: block 0 with no neighbours (stride >= N)
   int s_top = 1;
@@ -1109,7 +1130,8 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     // superblock 0 is not factored on its own: it joins the border in the dense system that is left
     const int qn = m_ + nbr, ldq = (qn + 1 + 15) & ~15;
     const int ntr = gh_div_up(nbr + 1, 64), ntiles = ntr * (ntr + 1) / 2;
-    const int nchunks = n > m_ ? gh_div_up(n - m_, kBorderChunk * m_) : 0;
+    const BorderChunks bc = border_chunks(n, m_, nbr);
+    const int nchunks = bc.n;
     double* part = bws;
     double* Mq = part + (size_t)nchunks * ntiles * 4096;
     double* dinv_q = Mq + (size_t)ldq * qn;
@@ -1118,14 +1140,20 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     double* xq = work_q + (((size_t)qn + 15) & ~(size_t)15);
     double* xh_q = xq + (((size_t)qn + 15) & ~(size_t)15);
     double* tvec = xh_q + (size_t)gh_div_up(qn, NBI) * NBI;
+    // the corner through the single-launch factorisation when its shape fits (the caller holds gh_potrf_flow_mutex)
+    const size_t flow_words = gh_potrf_flow_words(ctx, qn, 1);
+    unsigned* flow_q = flow_words ? reinterpret_cast<unsigned*>(tvec + (((size_t)n + 15) & ~(size_t)15)) : nullptr;
+    const unsigned n_flow = flow_words ? (unsigned)gh_potrf_flow_flag_words(qn, 1) : 0u;
+    const unsigned n_xh = (unsigned)gh_div_up(qn, NBI) * NBI * 2u;
     if (nchunks > 0) {
-      GH_LAUNCH(ctx, "ba_cr_border_syrk", cr_border_syrk_kernel<T>, dim3(nchunks * ntiles), dim3(256), 0, a, ntr, ntiles, part);
-      GH_LAUNCH(ctx, "ba_cr_border_reduce", cr_border_syrk_reduce_kernel<T>, dim3(ntiles), dim3(256), 0, a, ntiles, nchunks,
+      GH_LAUNCH(ctx, "ba_cr_border_syrk", cr_border_syrk_kernel<T>, dim3(nchunks * ntiles), dim3(256), 0, a, bc.kc, ntiles, part);
+      GH_LAUNCH(ctx, "ba_cr_border_reduce", cr_border_syrk_reduce_kernel<T>, dim3(16 * ntiles), dim3(256), 0, a, ntiles, nchunks,
                 (const double*)part);
     }
-    GH_LAUNCH(ctx, "ba_cr_border_gather", cr_border_gather_kernel<T>, dim3(qn), dim3(256), 0, a, Mq, ldq);
-    GH_TRY(gh_potrf_dev_impl(ctx, Mq, qn, ldq, info_dev, 1, dinv_q, xwork_q, nullptr, false, true));
-    GH_TRY(gh_potrs_bwd_dev_impl(ctx, Mq, qn, ldq, xq, work_q, dinv_q, Mq + qn, ldq, xh_q, info_dev, false));
+    GH_LAUNCH(ctx, "ba_cr_border_gather", cr_border_gather_kernel<T>, dim3(qn + 8), dim3(256), 0, a, Mq, ldq, flow_q, n_flow,
+              reinterpret_cast<unsigned*>(xh_q), n_xh);
+    GH_TRY(gh_potrf_dev_impl(ctx, Mq, qn, ldq, info_dev, 1, dinv_q, xwork_q, flow_q, false, true));
+    GH_TRY(gh_potrs_bwd_dev_impl(ctx, Mq, qn, ldq, xq, work_q, dinv_q, Mq + qn, ldq, xh_q, info_dev, true));
     if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
     GH_LAUNCH(ctx, "ba_cr_border_back", cr_border_back_kernel<T>, dim3(gh_div_up(n + nbr, 4)), dim3(256), 0, a, (const double*)xq, tvec);
     if (N > 1) GH_LAUNCH(ctx, "ba_cr_border_yh", cr_border_yh_kernel<T>, dim3(N - 1), dim3(256), 0, a, (const double*)tvec);
@@ -1146,13 +1174,13 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
 
 // border workspace of an arrowhead solve (doubles): the corner update's partial tiles, the dense system of superblock 0 + border
 // and what chol.hip's dense path needs for it, the backward pass's t vector
-size_t gh_arrow_ws_doubles(int n_band, int T, int nbr) {
+size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr) {
   const size_t m = (size_t)NBI * T, qn = m + (size_t)nbr, ldq = (qn + 1 + 15) & ~(size_t)15;
   const size_t ntr = ((size_t)nbr + 1 + 63) / 64, ntiles = ntr * (ntr + 1) / 2;
-  const size_t nchunks = (size_t)n_band > m ? ((size_t)n_band - m + kBorderChunk * m - 1) / (kBorderChunk * m) : 0;
+  const size_t nchunks = (size_t)border_chunks(n_band, (int)m, nbr).n;
   const size_t qb = (qn + NBI - 1) / NBI;
   return nchunks * ntiles * 4096 + ldq * qn + qb * (NBI * NBI) + 2 * 64 * (qn + 1) + 2 * ((qn + 15) & ~(size_t)15) + qb * NBI +
-         (size_t)n_band + 64;
+         (((size_t)n_band + 15) & ~(size_t)15) + gh_potrf_flow_words(ctx, (int)qn, 1) / 2 + 64;
 }
 
 // Tiles per superblock for a half-bandwidth of `hbw` scalars (A[r][c] = 0 for r - c > hbw), 0 = the band is too wide for
@@ -1241,7 +1269,8 @@ extern "C" gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
     return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve_dev: half-bandwidth %d of n_band = %d does not fit (<= %d, >= 4 superblocks)",
                         half_bandwidth, n_band, 3 * NBI);
   void* scratch = nullptr;
-  const size_t nd = gh_cr_dinv_doubles(n_band, T), nw = gh_cr_panel_doubles(n_band, T), nbw = gh_arrow_ws_doubles(n_band, T, nbr);
+  const size_t nd = gh_cr_dinv_doubles(n_band, T), nw = gh_cr_panel_doubles(n_band, T), nbw = gh_arrow_ws_doubles(ctx, n_band, T, nbr);
+  std::lock_guard<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device));  // (the dense corner may run as the single-launch factorisation)
   GH_TRY(gh_scratch(ctx, 256 + (nd + nw + nbw + (size_t)n) * sizeof(double), &scratch));
   int* info_dev = (int*)scratch;
   double* dinv = (double*)((char*)scratch + 256);
