@@ -1157,9 +1157,24 @@ def main():
         o.max_iterations = 15
         posegraph.solve_graph(ctx, start, dof, prob, o)
         (S, xyz, rho, sm, st), dt, pk = timed(lambda: posegraph.solve_graph(ctx, start, dof, prob, o))
+        # run-to-run reproducibility of the default mode (pre-rounded accumulation of the landmark part), asserted in the run
+        S2, xyz2, rho2, sm2, st2 = posegraph.solve_graph(ctx, start, dof, prob, o)
+        repro = S2.tobytes() == S.tobytes() and xyz2.tobytes() == xyz.tobytes() and \
+            list(sm2.trace_cost[:sm2.trace_len]) == list(sm.trace_cost[:sm.trace_len])
+        assert repro, "gh_graph_solve (deterministic = 1) differs between two runs"
+        oa = default_options()
+        oa.huber_delta, oa.max_iterations, oa.deterministic = 0.01, 15, 0  # plain f64 atomics: rounds 3-4, not reproducible
+        posegraph.solve_graph(ctx, start, dof, prob, oa)
+        (Sa, xa, ra, sma, sta), dta, pka = timed(lambda: posegraph.solve_graph(ctx, start, dof, prob, oa))
         out["general_graph"] = {"workload": "120 SIM3 keyframes + 123 pose edges + 6000 XYZ + 6000 inverse-depth landmarks, 60 000 observations",
                                 "iterations": sm.iterations, "iters_per_s": round(sm.iterations / dt, 1), "total_ms": round(dt * 1e3, 2),
                                 "status": int(st), "cost": [sm.initial_cost, sm.final_cost],
+                                "assembly": "reproducible (gh_ba_options.deterministic = 1, default): every atomic contribution pre-rounded "
+                                            "against two constants so that the sums are exact, hence order-independent",
+                                "bit_identical_across_two_runs": bool(repro),
+                                "atomics_mode": {"iterations": sma.iterations, "iters_per_s": round(sma.iterations / dta, 1),
+                                                 "final_cost": sma.final_cost,
+                                                 "what": "deterministic = 0: plain f64 atomics (the assembly of rounds 3-4)"},
                                 "kernels_ms": {k: round(v["total_ms"], 3) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}
         # camera self-calibration (BundleGraph::camera + cameraDOF): the same kind of window in pixels of an OpenCV camera whose
         # focal lengths, centre and k1 k2 start 3 % off and are unknowns of the solve (a 9-row block behind the keyframes)

@@ -739,6 +739,66 @@ __device__ inline bool graph_obs(int kind, const double* Sj, int dof_j, const do
   return true;
 }
 
+// REPRODUCIBLE ACCUMULATION (gh_ba_options.deterministic, the default).  The landmark part of the normal equations is summed
+// with f64 atomics, whose order changes from run to run -- and with it the last bits of H, the step, and now and then an LM
+// decision taken within rounding of a threshold.  Floating-point addition is exact, hence order-independent,
+// when every summand is a multiple of a common quantum q and every partial sum stays below 2^52 q.  So each contribution v is
+// split against two constants,  h = (v + M1) - M1,  l = ((v - h) + M2) - M2  (M = 1.5 * 2^E: the classic pre-rounding of
+// reproducible summation), and h / l are added -- with the same atomics -- into two ZEROED accumulators shaped like the target;
+// a fold kernel adds hi + lo to the target afterwards.  With |v| <= B and at most 2^K contributions per word,
+// E1 = log2 B + K + 1 keeps 51 - K bits of the largest contributions in h, and l (quantum 2^(E1 - 104 + K)) the next 51 - K:
+// what is dropped is below 2^(2K - 103) B -- beyond double precision for the K <= 20 of any real graph.  B comes from
+// gr_obs_lin_kernel (an atomicMax of a per-observation bound: order-independent by itself): every later contribution is an
+// entry of J^T L J, J^T L r or of a Schur product W V^-1 W^T <= the same landmark's J^T L J (the per-landmark Hessian is
+// positive semi-definite), with 2^8 of head room.  Twice the atomics of the plain mode, bit-identical results run to run.
+struct DetAcc {
+  double* hi;   // matrix-shaped accumulators (null: plain atomics straight into the target)
+  double* lo;
+  double* vhi;  // vector-shaped ones (right-hand side)
+  double* vlo;
+  const unsigned long long* bound_bits;  // bits of B (a non-negative double)
+  int K;
+};
+struct DetConst { double M1, M2; };
+__device__ inline DetConst det_consts(const DetAcc& A) {
+  DetConst c{0.0, 0.0};
+  if (A.hi == nullptr) return c;
+  const double B = __longlong_as_double((long long)*A.bound_bits);
+  int e = B > 0.0 ? ilogb(B) + 1 : -900;   // |v| <= B < 2^e
+  e += 8;                                  // head room
+  if (e < -900) e = -900;
+  if (e > 900) e = 900;
+  const int E1 = e + A.K + 1, E2 = E1 - 53 + A.K + 1;
+  c.M1 = ldexp(1.5, E1);
+  c.M2 = ldexp(1.5, E2);
+  return c;
+}
+// target[off] += v: plain atomic, or the two pre-rounded parts into the accumulators
+__device__ __forceinline__ void acc_add(double* target, double* hi, double* lo, size_t off, double v, const DetConst& c) {
+  if (hi == nullptr) {
+    atomicAdd(target + off, v);
+  } else {
+    const double h = (v + c.M1) - c.M1;
+    const double l = ((v - h) + c.M2) - c.M2;
+    if (h != 0.0) atomicAdd(hi + off, h);
+    if (l != 0.0) atomicAdd(lo + off, l);
+  }
+}
+// target += hi + lo (matrix: n columns of lda; vector: nv words), one fixed expression per word
+__global__ __launch_bounds__(256) void gr_det_fold_kernel(double* __restrict__ M, const double* __restrict__ hi, const double* __restrict__ lo,
+                                                          int n, int lda, double* __restrict__ v, const double* __restrict__ vhi,
+                                                          const double* __restrict__ vlo, int nv) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)n * lda;
+  if (i < total) {
+    const double a = hi[i] + lo[i];
+    if (a != 0.0) M[i] += a;
+  } else if (i - total < (size_t)nv) {
+    const size_t k = i - total;
+    const double a = vhi[k] + vlo[k];
+    if (a != 0.0) v[k] += a;
+  }
+}
+
 // frames / landmark of observation k; returns its kind
 struct ObsRef {
   int kind, p, fj, fh, lm, dp;  // fh = -1 unless an inverse-depth point seen from another keyframe than its host
@@ -796,7 +856,8 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
                                                          const double* __restrict__ cam, double* __restrict__ orec,
                                                          uint8_t* __restrict__ valid, double* __restrict__ H,
                                                          int lda, double* __restrict__ g, double* __restrict__ Hpp,
-                                                         double* __restrict__ gp, double* __restrict__ cam_part) {
+                                                         double* __restrict__ gp, double* __restrict__ cam_part,
+                                                         unsigned long long* __restrict__ bound_bits) {
   const int k = blockIdx.x * 128 + threadIdx.x;
   const bool in_range = k < G.n_obs;
   if (!in_range && !G.with_cam) return;  // (with a camera every lane stays for the wave sums of the intrinsics block)
@@ -824,8 +885,21 @@ __global__ __launch_bounds__(128) void gr_obs_lin_kernel(GrLandmarks G, const in
         for (int e = 0; e < 18; ++e) R[40 + e] = Jc[e];
       Lr[0] = L[0] * r[0] + L[1] * r[1];
       Lr[1] = L[2] * r[0] + L[3] * r[1];
+      if (bound_bits != nullptr) {
+        // reproducible mode: the bound B of every contribution this observation will make (see DetAcc), and the landmark sums
+        // are left to gr_lm_sum_kernel (one thread per landmark, its observations in list order)
+        double jm = 0.0, lm = 0.0;
+        for (int e = 0; e < 14; ++e) jm = fmax(jm, fmax(fabs(Jj[e]), fabs(Jh[e])));
+        for (int e = 0; e < 6; ++e) jm = fmax(jm, fabs(Jp[e]));
+        if (G.with_cam)
+          for (int e = 0; e < 18; ++e) jm = fmax(jm, fabs(Jc[e]));
+        for (int e = 0; e < 4; ++e) lm = fmax(lm, fabs(L[e]));
+        const double mx = fmax(jm, fmax(fabs(r[0]), fabs(r[1])));
+        const double B = 16.0 * lm * mx * mx;
+        if (B > 0.0 && B < 1e300) atomicMax(bound_bits, (unsigned long long)__double_as_longlong(B));
+      }
       // (the keyframe rows of g and H are summed from the records by gr_frame_rows_kernel, seven consecutive words at a time)
-      for (int a = 0; a < o.dp; ++a) {
+      for (int a = 0; bound_bits == nullptr && a < o.dp; ++a) {
         atomicAdd(&gp[3 * (size_t)o.lm + a], Jp[a] * Lr[0] + Jp[3 + a] * Lr[1]);
         for (int b = 0; b < o.dp; ++b) {
           const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
@@ -883,17 +957,44 @@ __global__ __launch_bounds__(1024) void gr_cam_fold_kernel(const double* __restr
   else H[(size_t)(cb + q) * lda + cb + p] += s;
 }
 
+// Reproducible mode: H_pp and g_p of a landmark from the records of its observations, in list order, by one thread.
+__global__ __launch_bounds__(256) void gr_lm_sum_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
+                                                        double* __restrict__ Hpp, double* __restrict__ gp) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= G.n_xyz + G.n_idp) return;
+  double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+  for (int q = G.lstart[p]; q < G.lstart[p + 1]; ++q) {
+    const int k = G.llist[q];
+    if (!valid[k]) continue;
+    const ObsRef o = obs_ref(G, k);
+    const double* R = orec + (size_t)G.rec * k;
+    const double* L = R + 2;
+    const double* Jp = R + 34;
+    const double Lr0 = L[0] * R[0] + L[1] * R[1], Lr1 = L[2] * R[0] + L[3] * R[1];
+    for (int a = 0; a < o.dp; ++a) {
+      gv[a] += Jp[a] * Lr0 + Jp[3 + a] * Lr1;
+      for (int b = 0; b < o.dp; ++b) {
+        const double LJ0 = L[0] * Jp[b] + L[1] * Jp[3 + b], LJ1 = L[2] * Jp[b] + L[3] * Jp[3 + b];
+        h[3 * a + b] += Jp[a] * LJ0 + Jp[3 + a] * LJ1;
+      }
+    }
+  }
+  for (int e = 0; e < 9; ++e) Hpp[9 * (size_t)p + e] = h[e];
+  for (int e = 0; e < 3; ++e) gp[3 * (size_t)p + e] = gv[e];
+}
+
 // Keyframe part of the normal equations from the observation records, EIGHT lanes per (observation, keyframe slot x), lane r
 // = row r of the slot's blocks: g(f_x) += J_x^T L r, block(f_x, f_y) += J_x^T L J_y for the observation's slots with f_y <= f_x
 // (lower triangle of blocks; inside a diagonal block rows r >= q: the solver reads nothing else), and with a camera the
 // intrinsics rows x this keyframe's columns (the intrinsics block comes last: always the lower triangle).  Seven (nine)
 // consecutive words per atomic instruction and slot: see gr_schur_kernel.
 __global__ __launch_bounds__(256) void gr_frame_rows_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
-                                                            double* __restrict__ H, int lda, double* __restrict__ g) {
+                                                            double* __restrict__ H, int lda, double* __restrict__ g, DetAcc DA) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int sa = t >> 3, r = t & 7;
   const int k = sa >> 1, x = sa & 1;
   if (k >= G.n_obs || !valid[k]) return;
+  const DetConst dc = det_consts(DA);
   const ObsRef o = obs_ref(G, k);
   const int fx = x == 0 ? o.fj : o.fh;
   if (fx < 0) return;
@@ -903,32 +1004,32 @@ __global__ __launch_bounds__(256) void gr_frame_rows_kernel(GrLandmarks G, const
   if (r < 7) {
     const double j0 = Jx[r], j1 = Jx[7 + r];
     const double gv = j0 * (L0 * R[0] + L1 * R[1]) + j1 * (L2 * R[0] + L3 * R[1]);
-    if (gv != 0.0) atomicAdd(&g[7 * fx + r], gv);
+    if (gv != 0.0) acc_add(g, DA.vhi, DA.vlo, (size_t)(7 * fx + r), gv, dc);
     for (int y = 0; y < 2; ++y) {
       const int fy = y == 0 ? o.fj : o.fh;
       if (fy < 0 || fy > fx) continue;
       const double* Jy = R + (y == 0 ? 6 : 20);
-      double* col = H + (size_t)(7 * fy) * lda + 7 * fx + r;
+      const size_t col = (size_t)(7 * fy) * lda + 7 * fx + r;
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         const double LJ0 = L0 * Jy[q] + L1 * Jy[7 + q], LJ1 = L2 * Jy[q] + L3 * Jy[7 + q];
         const double hv = j0 * LJ0 + j1 * LJ1;
-        if (hv != 0.0 && (fy != fx || r >= q)) atomicAdd(col + (size_t)q * lda, hv);
+        if (hv != 0.0 && (fy != fx || r >= q)) acc_add(H, DA.hi, DA.lo, col + (size_t)q * lda, hv, dc);
       }
     }
   }
   if (G.with_cam) {  // rows 0..7 of the intrinsics block by the eight lanes, row 8 by lane 0 again
     const double* Jc = R + 40;
     const double c0 = Jc[r], c1 = Jc[9 + r];
-    double* col = H + (size_t)(7 * fx) * lda + 7 * G.n_frames;
+    const size_t col = (size_t)(7 * fx) * lda + 7 * G.n_frames;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       const double LJ0 = L0 * Jx[q] + L1 * Jx[7 + q], LJ1 = L2 * Jx[q] + L3 * Jx[7 + q];
       const double hv = c0 * LJ0 + c1 * LJ1;
-      if (hv != 0.0) atomicAdd(col + (size_t)q * lda + r, hv);
+      if (hv != 0.0) acc_add(H, DA.hi, DA.lo, col + (size_t)q * lda + r, hv, dc);
       if (r == 0) {
         const double h8 = Jc[8] * LJ0 + Jc[17] * LJ1;
-        if (h8 != 0.0) atomicAdd(col + (size_t)q * lda + 8, h8);
+        if (h8 != 0.0) acc_add(H, DA.hi, DA.lo, col + (size_t)q * lda + 8, h8, dc);
       }
     }
   }
@@ -1040,11 +1141,12 @@ __global__ __launch_bounds__(256) void gr_schur_kernel(GrLandmarks G, const uint
                                                        const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
                                                        const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
                                                        const double* __restrict__ gp, double* __restrict__ Hd, int lda,
-                                                       double* __restrict__ d) {
+                                                       double* __restrict__ d, DetAcc DA) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int sa = t >> 3, r = t & 7;
   const int ka = sa >> 1, x = sa & 1;
   if (r == 7 || ka >= G.n_obs || !valid[ka]) return;
+  const DetConst dc = det_consts(DA);
   const ObsRef oa = obs_ref(G, ka);
   const int fa = x == 0 ? oa.fj : oa.fh;
   if (fa < 0) return;
@@ -1064,7 +1166,7 @@ __global__ __launch_bounds__(256) void gr_schur_kernel(GrLandmarks G, const uint
   for (int b = 0; b < 3; ++b) ua[b] = wa[0] * Hi[b] + wa[1] * Hi[3 + b] + wa[2] * Hi[6 + b];
   {
     const double v = ua[0] * gp[3 * (size_t)oa.lm] + ua[1] * gp[3 * (size_t)oa.lm + 1] + ua[2] * gp[3 * (size_t)oa.lm + 2];
-    if (v != 0.0) atomicAdd(&d[7 * fa + r], v);
+    if (v != 0.0) acc_add(d, DA.vhi, DA.vlo, (size_t)(7 * fa + r), v, dc);
   }
   for (int q = G.lstart[oa.lm]; q < G.lstart[oa.lm + 1]; ++q) {
     const int kb = G.llist[q];
@@ -1076,7 +1178,7 @@ __global__ __launch_bounds__(256) void gr_schur_kernel(GrLandmarks G, const uint
       // (equal frames: the two orders (a, b) and (b, a) are transposes of each other, so their lower triangles add up to the
       //  lower triangle of the symmetric sum -- the solver reads nothing else)
       const double* Rb = orec + (size_t)G.rec * kb;
-      double* col = Hd + (size_t)(7 * fb) * lda + 7 * fa + r;
+      const size_t col = (size_t)(7 * fb) * lda + 7 * fa + r;
 #pragma unroll
       for (int c7 = 0; c7 < 7; ++c7) {
         double wb[3];
@@ -1087,7 +1189,7 @@ __global__ __launch_bounds__(256) void gr_schur_kernel(GrLandmarks G, const uint
           slot_W_row(Rb, 0, dp, c7, wb);
         }
         const double v = ua[0] * wb[0] + ua[1] * wb[1] + ua[2] * wb[2];
-        if (v != 0.0 && (fb != fa || r >= c7)) atomicAdd(col + (size_t)c7 * lda, -v);
+        if (v != 0.0 && (fb != fa || r >= c7)) acc_add(Hd, DA.hi, DA.lo, col + (size_t)c7 * lda, -v, dc);
       }
     }
   }
@@ -1099,10 +1201,11 @@ __global__ __launch_bounds__(256) void gr_schur_kernel(GrLandmarks G, const uint
 __global__ __launch_bounds__(256) void gr_schur_cam_kernel(GrLandmarks G, const uint8_t* __restrict__ valid, const double* __restrict__ orec,
                                                            const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
                                                            const double* __restrict__ Wh, const int32_t* __restrict__ hrep,
-                                                           const double* __restrict__ Wc, double* __restrict__ Hd, int lda) {
+                                                           const double* __restrict__ Wc, double* __restrict__ Hd, int lda, DetAcc DA) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int kb = t >> 4, r = t & 15;
   double ua[3];
+  const DetConst dc = det_consts(DA);
   const int cb = 7 * G.n_frames;
   if (kb < G.n_obs && r < 9 && valid[kb]) {
     const ObsRef ob = obs_ref(G, kb);
@@ -1118,7 +1221,7 @@ __global__ __launch_bounds__(256) void gr_schur_cam_kernel(GrLandmarks G, const 
         const int fb = y == 0 ? ob.fj : ob.fh;
         if (fb < 0 || (y == 1 && kb != rep)) continue;
         const double* Rb = orec + (size_t)G.rec * kb;
-        double* col = Hd + (size_t)(7 * fb) * lda + cb + r;
+        const size_t col = (size_t)(7 * fb) * lda + cb + r;
 #pragma unroll
         for (int c7 = 0; c7 < 7; ++c7) {
           double wb[3];
@@ -1129,7 +1232,7 @@ __global__ __launch_bounds__(256) void gr_schur_cam_kernel(GrLandmarks G, const 
             slot_W_row(Rb, 0, dp, c7, wb);
           }
           const double v = ua[0] * wb[0] + ua[1] * wb[1] + ua[2] * wb[2];
-          if (v != 0.0) atomicAdd(col + (size_t)c7 * lda, -v);
+          if (v != 0.0) acc_add(Hd, DA.hi, DA.lo, col + (size_t)c7 * lda, -v, dc);
         }
       }
     }
@@ -1141,9 +1244,10 @@ __global__ __launch_bounds__(256) void gr_schur_cam_kernel(GrLandmarks G, const 
 // from the per-observation kernel above, the same-address atomics of 15 000 waves took 0.9 ms).
 __global__ __launch_bounds__(128) void gr_schur_cam_cc_kernel(GrLandmarks G, const double* __restrict__ Hinv, const int32_t* __restrict__ lmdim,
                                                               const double* __restrict__ Wc, const double* __restrict__ gp,
-                                                              double* __restrict__ Hd, int lda, double* __restrict__ d) {
+                                                              double* __restrict__ Hd, int lda, double* __restrict__ d, DetAcc DA) {
   const int p = blockIdx.x * 128 + threadIdx.x;
   const int nlm = G.n_xyz + G.n_idp;
+  const DetConst dc = det_consts(DA);
   double W[27], U[27];
 #pragma unroll
   for (int e = 0; e < 27; ++e) W[e] = U[e] = 0.0;
@@ -1166,12 +1270,12 @@ __global__ __launch_bounds__(128) void gr_schur_cam_cc_kernel(GrLandmarks G, con
   for (int r9 = 0; r9 < 9; ++r9) {
     if (!((G.cam_free >> r9) & 1)) continue;
     const double v = wave_add_f64(U[3 * r9] * g0 + U[3 * r9 + 1] * g1 + U[3 * r9 + 2] * g2);
-    if (lead && v != 0.0) atomicAdd(&d[cb + r9], v);
+    if (lead && v != 0.0) acc_add(d, DA.vhi, DA.vlo, (size_t)(cb + r9), v, dc);
 #pragma unroll
     for (int c9 = 0; c9 <= r9; ++c9) {
       if (!((G.cam_free >> c9) & 1)) continue;
       const double h = wave_add_f64(U[3 * r9] * W[3 * c9] + U[3 * r9 + 1] * W[3 * c9 + 1] + U[3 * r9 + 2] * W[3 * c9 + 2]);
-      if (lead && h != 0.0) atomicAdd(&Hd[(size_t)(cb + c9) * lda + cb + r9], -h);
+      if (lead && h != 0.0) acc_add(Hd, DA.hi, DA.lo, (size_t)(cb + c9) * lda + cb + r9, -h, dc);
     }
   }
 }
@@ -1421,6 +1525,10 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       *d_oframe, *d_lstart, *d_llist, *d_lmdim, *d_hrep;
   uint8_t *d_xfree = nullptr, *d_ifree = nullptr, *d_valid;
   unsigned long long* d_gmax;
+  // reproducible accumulation of the landmark part (DetAcc): two matrix-shaped and two vector-shaped accumulators, the bound
+  const bool det = opt.deterministic != 0 && !sparse && no > 0;
+  double *d_acc_hi = nullptr, *d_acc_lo = nullptr, *d_vacc = nullptr;
+  unsigned long long* d_bound = nullptr;
   int64_t* d_bs_off = nullptr;
   int32_t *d_bs_sp = nullptr, *d_bs_sq = nullptr;
   const size_t nlm1 = (size_t)std::max(nlm, 1), no1 = (size_t)std::max(no, 1), nx1 = (size_t)std::max(nx, 1), ni1 = (size_t)std::max(ni, 1);
@@ -1445,7 +1553,8 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
            A.alloc(&d_rho_new, ni1) && A.alloc(&d_orec, no1 * rec) && A.alloc(&d_Hpp, nlm1 * 9) && A.alloc(&d_gp, nlm1 * 3) &&
            A.alloc(&d_Hinv, nlm1 * 9) && A.alloc(&d_dlm, nlm1 * 3) && A.alloc(&d_term, (size_t)std::max(n_items, 1)) &&
            A.alloc(&d_part, (size_t)n_part) && A.alloc(&d_lmdim, nlm1) && A.alloc(&d_hrep, nlm1) && A.alloc(&d_Wh, nlm1 * 7) &&
-           A.alloc(&d_valid, no1) && (!with_cam || (A.alloc(&d_cam_new, 9) && A.alloc(&d_Wc, nlm1 * 27) && A.alloc(&d_cam_part, (size_t)kCamPart * 2 * ob_alloc))) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda)));
+           A.alloc(&d_valid, no1) && (!with_cam || (A.alloc(&d_cam_new, 9) && A.alloc(&d_Wc, nlm1 * 27) && A.alloc(&d_cam_part, (size_t)kCamPart * 2 * ob_alloc))) && (sparse || (A.alloc(&d_H, (size_t)n * lda) && A.alloc(&d_Hd, (size_t)n * lda))) &&
+           (!det || (A.alloc(&d_acc_hi, (size_t)n * lda) && A.alloc(&d_acc_lo, (size_t)n * lda) && A.alloc(&d_vacc, (size_t)2 * n) && A.alloc(&d_bound, 1)));
   };
   alloc_all();  // measuring pass
   GH_TRY(A.reserve());
@@ -1505,6 +1614,28 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
   if (sparse) BS.h_flag = &rb->bs_flag;
   double* host4 = rb->out4;
 
+  DetAcc DA{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (det) {
+    // contributions to one word: a keyframe's diagonal block takes one per observation slot in gr_frame_rows and one per slot
+    // pair of a landmark in gr_schur (<= slots x the landmark's slots in that keyframe, usually 1); the intrinsics block one per
+    // wave of landmarks.  K = ceil(log2(4 x the busiest keyframe's slots + waves + 16))
+    std::vector<int> slots((size_t)nf, 0);
+    for (int k = 0; k < no; ++k) {
+      const int fj = gpr->obs_frame[k];
+      if (fj >= 0 && fj < nf) ++slots[fj];
+      if (gpr->obs_kind[k] == 1) {
+        const int p = gpr->obs_point[k];
+        const int h = (p >= 0 && p < ni) ? gpr->idp_host[p] : -1;
+        if (h >= 0 && h < nf && h != fj) ++slots[h];
+      }
+    }
+    long long most = 16;
+    for (int f = 0; f < nf; ++f) most = std::max<long long>(most, slots[f]);
+    most = 4 * most + nlm / 64 + 16;
+    int K = 0;
+    while ((1ll << K) < most) ++K;
+    DA = DetAcc{d_acc_hi, d_acc_lo, d_vacc, d_vacc + n, d_bound, K};
+  }
   PgGraph G{nf, ne, d_dof, d_etype, d_ei, d_ej, d_meas, d_info};
   PgLists Ls{d_vstart, d_vlist, d_pstart, d_plist, d_prow, d_pcol, PH.n_pairs};
   GrLandmarks LM{nx, ni, no, d_xfree, d_host, d_anchor, d_ifree, d_okind, d_opoint, d_oframe, d_oxy, d_oinfo, d_lstart, d_llist,
@@ -1541,6 +1672,12 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_Hpp, 0, nlm1 * 72, ctx->stream));
       GH_HIP(ctx, hipMemsetAsync(d_gp, 0, nlm1 * 24, ctx->stream));
+      if (det) {
+        GH_HIP(ctx, hipMemsetAsync(d_acc_hi, 0, (size_t)n * lda * sizeof(double), ctx->stream));
+        GH_HIP(ctx, hipMemsetAsync(d_acc_lo, 0, (size_t)n * lda * sizeof(double), ctx->stream));
+        GH_HIP(ctx, hipMemsetAsync(d_vacc, 0, (size_t)2 * n * sizeof(double), ctx->stream));
+        GH_HIP(ctx, hipMemsetAsync(d_bound, 0, 8, ctx->stream));
+      }
       if (ne > 0) GH_LAUNCH(ctx, "pg_edge", pg_edge_kernel, dim3(eb4), dim3(64), 0, G, (const double*)d_S, d_rec, d_cost_e);
       // stores the pose-edge sums into every diagonal block, every edge pair block and g (zeros where there is no edge)
       if (sparse)
@@ -1552,12 +1689,20 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       if (with_cam) GH_HIP(ctx, hipMemsetAsync(d_g + 7 * nf, 0, 72, ctx->stream));  // (pg_assemble stores the keyframe rows only)
       if (no > 0)
         GH_LAUNCH(ctx, "gr_obs_lin", gr_obs_lin_kernel, dim3(ob), dim3(128), 0, LM, (const int32_t*)d_dof, (const double*)d_S,
-                  (const double*)d_xyz, (const double*)d_rho, (const double*)d_cam, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp, d_cam_part);
+                  (const double*)d_xyz, (const double*)d_rho, (const double*)d_cam, d_orec, d_valid, d_H, lda, d_g, d_Hpp, d_gp, d_cam_part,
+                  d_bound);
+      if (det && nlm > 0)
+        GH_LAUNCH(ctx, "gr_lm_sum", gr_lm_sum_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
+                  (const double*)d_orec, d_Hpp, d_gp);
       if (with_cam)
         GH_LAUNCH(ctx, "gr_cam_fold", gr_cam_fold_kernel, dim3(1), dim3(1024), 0, (const double*)d_cam_part, 2 * ob, nf, d_H, lda, d_g);
       if (no > 0)
         GH_LAUNCH(ctx, "gr_frame_rows", gr_frame_rows_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
-                  (const double*)d_orec, d_H, lda, d_g);
+                  (const double*)d_orec, d_H, lda, d_g, DA);
+      if (det) {  // H += hi + lo, g likewise; the accumulators are cleared again for the Schur products of the iterations
+        GH_LAUNCH(ctx, "gr_det_fold", gr_det_fold_kernel, dim3(gh_div_up((long long)n * lda + n, 256)), dim3(256), 0, d_H,
+                  (const double*)d_acc_hi, (const double*)d_acc_lo, n, lda, d_g, (const double*)d_vacc, (const double*)(d_vacc + n), n);
+      }
       GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, 8, ctx->stream));
       GH_LAUNCH(ctx, "gr_gmax", gr_gmax_kernel, dim3(gh_div_up(n + 3 * nlm, 256)), dim3(256), 0, (const double*)d_g, n,
                 (const double*)d_gp, 3 * nlm, d_gmax);
@@ -1571,19 +1716,27 @@ extern "C" gh_status gh_graph_solve(gh_ctx* ctx, gh_graph_problem* gpr, const gh
       GH_LAUNCH(ctx, "pg_damp", pg_damp_kernel, dim3(gh_div_up((long long)n * lda, 256)), dim3(256), 0, (const double*)d_H, d_Hd,
                 n, lda, (const double*)d_g, d_d, radius);
     if (nlm > 0) {
+      if (det) {
+        GH_HIP(ctx, hipMemsetAsync(d_acc_hi, 0, (size_t)n * lda * sizeof(double), ctx->stream));
+        GH_HIP(ctx, hipMemsetAsync(d_acc_lo, 0, (size_t)n * lda * sizeof(double), ctx->stream));
+        GH_HIP(ctx, hipMemsetAsync(d_vacc, 0, (size_t)2 * n * sizeof(double), ctx->stream));
+      }
       GH_LAUNCH(ctx, "gr_lm_prepare", gr_lm_prepare_kernel, dim3(gh_div_up(nlm, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                 (const double*)d_Hpp, (const double*)d_orec, radius, d_Hinv, d_lmdim, d_Wh, d_hrep, d_Wc);
       if (no > 0)
         GH_LAUNCH(ctx, "gr_schur", gr_schur_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
-                  (const double*)d_gp, d_Hd, lda, d_d);
+                  (const double*)d_gp, d_Hd, lda, d_d, DA);
       if (with_cam)
         GH_LAUNCH(ctx, "gr_schur_cam", gr_schur_cam_kernel, dim3(gh_div_up(16 * no, 256)), dim3(256), 0, LM, (const uint8_t*)d_valid,
                   (const double*)d_orec, (const double*)d_Hinv, (const int32_t*)d_lmdim, (const double*)d_Wh, (const int32_t*)d_hrep,
-                  (const double*)d_Wc, d_Hd, lda);
+                  (const double*)d_Wc, d_Hd, lda, DA);
       if (with_cam)
         GH_LAUNCH(ctx, "gr_schur_cam_cc", gr_schur_cam_cc_kernel, dim3(gh_div_up(nlm, 128)), dim3(128), 0, LM, (const double*)d_Hinv,
-                  (const int32_t*)d_lmdim, (const double*)d_Wc, (const double*)d_gp, d_Hd, lda, d_d);
+                  (const int32_t*)d_lmdim, (const double*)d_Wc, (const double*)d_gp, d_Hd, lda, d_d, DA);
+      if (det)
+        GH_LAUNCH(ctx, "gr_det_fold", gr_det_fold_kernel, dim3(gh_div_up((long long)n * lda + n, 256)), dim3(256), 0, d_Hd,
+                  (const double*)d_acc_hi, (const double*)d_acc_lo, n, lda, d_d, (const double*)d_vacc, (const double*)(d_vacc + n), n);
     }
     int info = 0;
     const double t_s0 = now_ms_pg();

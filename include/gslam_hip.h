@@ -482,7 +482,9 @@ typedef struct gh_ba_options {
   double gradient_tolerance; /* 1e-10 */
   double min_relative_decrease; /* 1e-3 */
   int32_t verbose;
-  int32_t deterministic;     /* 1: ordered segmented Schur accumulation; 0: f64 atomics */
+  int32_t deterministic;     /* 1 (default): reproducible sums -- gh_ba_solve: ordered segmented Schur accumulation; gh_graph_solve:
+                                the landmark part pre-rounded so that its atomics add exactly (bit-identical from run to run);
+                                0: plain f64 atomics (faster assembly, last bits vary between runs) */
 } gh_ba_options;
 void gh_ba_default_options(gh_ba_options* o);
 

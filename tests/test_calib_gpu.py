@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib
 from gslam_amd.pg_synth import make_landmark_graph, with_camera
-from lm_trace import assert_same_trace
+from lm_trace import assert_identical_trace, assert_same_trace
 
 pytestmark = pytest.mark.gpu
 
@@ -30,17 +30,19 @@ def _start_cam(free, rel=0.04):
     return c
 
 
-def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-6):
+def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-9):
+    """whole LM trace: same decisions, costs to rtol; the GPU run twice is bit-identical (reproducible accumulation)"""
     from gslam_amd import posegraph
     oo = oracle_lib.ba_options(huber=huber, max_iterations=iters)
     S0, x0, r0, c0, so, st0 = oracle.graph_solve_cam(start, dof, prob, oo)
     S1, x1, r1, c1, sg, st1 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, iters))
     assert st0 == 0 and st1 == 0
-    if assert_same_trace(sg, so, rtol):  # (decisions in the settled tail may differ: lm_trace.py)
-        assert np.allclose(c1[:4], c0[:4], rtol=1e-7) and np.allclose(c1[4:], c0[4:], atol=1e-7), (c1 - c0)
-        assert np.allclose(S1, S0, atol=1e-6) and np.allclose(x1, x0, atol=1e-5) and np.allclose(r1, r0, rtol=1e-5, atol=1e-8)
-    else:
-        assert np.allclose(c1[:4], c0[:4], rtol=1e-3) and np.allclose(c1[4:], c0[4:], atol=1e-2), (c1 - c0)
+    assert_identical_trace(sg, so, rtol)
+    assert np.allclose(c1[:4], c0[:4], rtol=1e-7) and np.allclose(c1[4:], c0[4:], atol=1e-7), (c1 - c0)
+    assert np.allclose(S1, S0, atol=1e-6) and np.allclose(x1, x0, atol=1e-5) and np.allclose(r1, r0, rtol=1e-5, atol=1e-8)
+    S2, x2, r2, c2, sg2, st2 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, iters))
+    assert st2 == 0 and S2.tobytes() == S1.tobytes() and x2.tobytes() == x1.tobytes() and c2.tobytes() == c1.tobytes()
+    assert list(sg2.trace_cost[:sg2.trace_len]) == list(sg.trace_cost[:sg.trace_len]), "self-calibration is not reproducible run to run"
     return so, sg, c1
 
 
@@ -56,7 +58,9 @@ def test_calibration_matches_the_oracle(ctx, oracle, free, n_xyz, n_idp, with_in
                                                   with_info=with_info, outliers=0.03 if huber > 0 else 0.0, obs_per_point=6)
     prob = with_camera(base, CAM, _start_cam(free), free, pixel_noise=0.3, seed=5)
     # (all nine free: rejected steps far from the minimum amplify the summation-order differences to ~1e-6 relative)
-    so, sg, cam = _compare(ctx, oracle, start, dof, prob, huber, rtol=1e-4 if free == 0x1FF else 1e-6)
+    # (all nine free and no robust kernel: the cost of a REJECTED trial step far from the minimum, where the damped system is
+    #  ill-conditioned, differs by 2e-6 relative between the two summation orders -- decisions and accepted costs do not)
+    so, sg, cam = _compare(ctx, oracle, start, dof, prob, huber, rtol=1e-4 if free == 0x1FF else 1e-9)
     assert so.final_cost < 0.2 * so.initial_cost
     fixed = [k for k in range(9) if not (free >> k) & 1]
     assert np.array_equal(cam[fixed], prob["intrinsics"][0][fixed])
@@ -90,7 +94,7 @@ def test_larger_window(ctx, oracle):
     truth, start, dof, base = make_landmark_graph(n_frames=60, n_xyz=2500, n_idp=500, kind="se3", seed=41, noise=0.0, obs_per_point=6)
     free = 0b000011111
     prob = with_camera(base, CAM, _start_cam(free, 0.03), free, pixel_noise=0.3, seed=8)
-    so, sg, cam = _compare(ctx, oracle, start, dof, prob, 2.0, iters=25, rtol=1e-5)
+    so, sg, cam = _compare(ctx, oracle, start, dof, prob, 2.0, iters=25)
     assert np.allclose(cam[:4], CAM[:4], rtol=5e-3)
 
 
@@ -125,7 +129,7 @@ def test_calibration_fuzz_small_graphs(ctx, oracle):
         S0, x0, r0, c0, so, st0 = oracle.graph_solve_cam(start, dof, prob, oo)
         S1, x1, r1, c1, sg, st1 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, 15))
         assert st0 == st1 == 0
-        assert_same_trace(sg, so, rtol=1e-4)  # (few observations per unknown: ill-conditioned steps amplify the summation order)
+        assert_identical_trace(sg, so, rtol=1e-9)
         fixed = [k for k in range(9) if not (free >> k) & 1]
         assert np.array_equal(c1[fixed], prob["intrinsics"][0][fixed])
 

@@ -1,12 +1,13 @@
 """GPU parity of gh_graph_solve (general BundleGraph: SIM3 keyframes, pose edges, XYZ and inverse-depth landmarks) against
-oracle/graph_oracle.c through the C ABI.  f64 on both sides; the GPU assembles with atomics (summation order varies), so
-traces agree to ~1e-9 relative, not bit for bit."""
+oracle/graph_oracle.c through the C ABI.  f64 on both sides; the GPU's sums are REPRODUCIBLE (pre-rounded accumulation,
+gh_ba_options.deterministic = 1, the default) but in another order than the oracle's: identical LM decisions, every cost of
+the trace to 1e-9 relative, bit-identical from one GPU run to the next."""
 import numpy as np
 import pytest
 
 import oracle_lib
 from gslam_amd.pg_synth import make_landmark_graph, make_pose_graph
-from lm_trace import assert_same_trace
+from lm_trace import assert_identical_trace, assert_same_trace
 
 pytestmark = pytest.mark.gpu
 
@@ -19,19 +20,18 @@ def _opts(huber, iters=40):
     return o
 
 
-def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-7, settled_tail=False):
-    """settled_tail: decisions taken after the cost has settled may differ (lm_trace.assert_same_trace); otherwise the traces
-    must be identical."""
+def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-9, state_atol=1e-7):
+    """The whole LM trace: same length, same decisions, every cost to rtol; and the GPU run twice is bit-identical."""
     from gslam_amd import posegraph
     oo = oracle_lib.ba_options(huber=huber, max_iterations=iters)
     S0, x0, r0, so, st0 = oracle.graph_solve(start, dof, problem, oo)
     S1, x1, r1, sg, st1 = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, iters))
     assert st0 == 0 and st1 == 0
-    identical = assert_same_trace(sg, so, rtol)
-    assert identical or settled_tail, (list(sg.trace_accepted[:sg.trace_len]), list(so.trace_accepted[:so.trace_len]))
-    if identical:
-        assert sg.iterations == so.iterations
-        assert np.allclose(S1, S0, atol=1e-7) and np.allclose(x1, x0, atol=1e-6) and np.allclose(r1, r0, rtol=1e-6, atol=1e-9)
+    assert_identical_trace(sg, so, rtol)
+    assert np.allclose(S1, S0, atol=state_atol) and np.allclose(x1, x0, atol=10 * state_atol) and np.allclose(r1, r0, rtol=1e-6, atol=1e-9)
+    S2, x2, r2, sg2, st2 = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, iters))
+    assert st2 == 0 and S2.tobytes() == S1.tobytes() and x2.tobytes() == x1.tobytes() and r2.tobytes() == r1.tobytes()
+    assert list(sg2.trace_cost[:sg2.trace_len]) == list(sg.trace_cost[:sg.trace_len]), "gh_graph_solve is not reproducible run to run"
     return so, sg
 
 
@@ -70,7 +70,7 @@ def test_graph_solve_fixed_landmarks_points_behind_and_host_observations(ctx, or
     xyz[1] = [0.0, 0.0, -50.0]
     rho = rho.copy(); rho[2] = 1e-7
     prob = dict(problem, xyz=(xyz, xfree), idp=(host, anchor, rho, ifree))
-    so, sg = _compare(ctx, oracle, start, dof, prob, 0.01, rtol=1e-6)
+    so, sg = _compare(ctx, oracle, start, dof, prob, 0.01)
     from gslam_amd import posegraph
     S1, x1, r1, _, _ = posegraph.solve_graph(ctx, start, dof, prob, _opts(0.01))
     assert np.array_equal(x1[::3], xyz[::3]) and np.array_equal(r1[1::4], rho[1::4])
@@ -81,7 +81,7 @@ def test_graph_solve_larger_window(ctx, oracle):
     """60 keyframes (n = 420: above the single-block regime of the dense solver), 3000 landmarks, 15 000 observations."""
     truth, start, dof, problem = make_landmark_graph(n_frames=60, n_xyz=1500, n_idp=1500, kind="se3", seed=31, noise=1e-3,
                                                      obs_per_point=5, outliers=0.03)
-    so, sg = _compare(ctx, oracle, start, dof, problem, 0.01, iters=15, rtol=1e-6)
+    so, sg = _compare(ctx, oracle, start, dof, problem, 0.01, iters=15)
     assert so.final_cost < 0.2 * so.initial_cost  # (3 % outliers keep their Huber cost)
 
 
@@ -107,12 +107,51 @@ def test_graph_solve_sphere_projection(ctx, oracle, n_xyz, n_idp, pose_edges):
     assert so.final_cost < 0.3 * so.initial_cost
 
 
+def test_graph_solve_atomics_mode_still_agrees(ctx, oracle):
+    """deterministic = 0 keeps the plain f64 atomics of rounds 3-4 (the faster assembly): same run up to the settled tail."""
+    from gslam_amd import posegraph
+    truth, start, dof, problem = make_landmark_graph(n_frames=12, n_xyz=150, n_idp=150, kind="se3", seed=21, noise=2e-3,
+                                                     with_info=True, outliers=0.05, obs_per_point=5)
+    oo = oracle_lib.ba_options(huber=0.02, max_iterations=40)
+    S0, x0, r0, so, st0 = oracle.graph_solve(start, dof, problem, oo)
+    o = _opts(0.02, 40)
+    o.deterministic = 0
+    S1, x1, r1, sg, st1 = posegraph.solve_graph(ctx, start, dof, problem, o)
+    assert st0 == 0 and st1 == 0
+    assert_same_trace(sg, so, 1e-7)
+
+
+def test_graph_solve_random_graphs_are_reproducible(ctx):
+    """RANDOM small graphs (a fresh draw every run): two GPU solves of the same problem agree bit for bit -- states and every cost
+    of the trace (the property the pre-rounded accumulation exists for; no tolerance involved, so no example can be flaky)."""
+    from gslam_amd import posegraph
+    rng = np.random.default_rng()
+    for _ in range(12):
+        nf = int(rng.integers(3, 10))
+        n_xyz, n_idp = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        if n_xyz + n_idp == 0:
+            n_xyz = 5
+        sphere = bool(rng.integers(0, 2))
+        truth, start, dof, problem = make_landmark_graph(n_frames=nf, n_xyz=n_xyz, n_idp=n_idp, kind="sim3" if rng.integers(0, 2) else "se3",
+                                                         seed=int(rng.integers(0, 10 ** 6)), noise=1e-3, pose_edges=bool(rng.integers(0, 2)),
+                                                         with_info=bool(rng.integers(0, 2)), obs_per_point=min(4, nf),
+                                                         projection="sphere" if sphere else "pinhole")
+        huber = float(rng.choice([0.0, 0.01]))
+        a = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, 12))
+        b = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, 12))
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
+        assert list(a[3].trace_cost[:a[3].trace_len]) == list(b[3].trace_cost[:b[3].trace_len])
+        assert list(a[3].trace_accepted[:a[3].trace_len]) == list(b[3].trace_accepted[:b[3].trace_len])
+
+
 def test_graph_solve_fuzz_small_graphs(ctx, oracle):
     """Random small graphs (keyframe kind, landmark mix, pose edges, informations, Huber on / off, sphere): the GPU trace equals
-    the oracle's."""
+    the oracle's -- whole trace, identical decisions, costs to 1e-9."""
     from hypothesis import given, settings, strategies as st
 
-    # derandomize: a tolerance-based comparison -- the examples the driver runs are the ones that were run here
+    # derandomize: the oracle sums in another order than the GPU, and on a near-singular toy graph a cost can land within rounding
+    # of an LM threshold -- the examples the driver runs are the ones that were run here (the GPU itself is reproducible: the
+    # random draw is in test_graph_solve_random_graphs_are_reproducible)
     @settings(max_examples=25, deadline=None, derandomize=True)
     @given(nf=st.integers(3, 9), n_xyz=st.integers(0, 25), n_idp=st.integers(0, 25), sim3=st.booleans(), pose_edges=st.booleans(),
            info=st.booleans(), huber=st.sampled_from([0.0, 0.01]), sphere=st.booleans(), seed=st.integers(0, 10 ** 6))
@@ -122,6 +161,6 @@ def test_graph_solve_fuzz_small_graphs(ctx, oracle):
         truth, start, dof, problem = make_landmark_graph(n_frames=nf, n_xyz=n_xyz, n_idp=n_idp, kind="sim3" if sim3 else "se3",
                                                          seed=seed, noise=1e-3, pose_edges=pose_edges, with_info=info,
                                                          obs_per_point=min(4, nf), projection="sphere" if sphere else "pinhole")
-        _compare(ctx, oracle, start, dof, problem, huber, iters=12, rtol=1e-6, settled_tail=True)
+        _compare(ctx, oracle, start, dof, problem, huber, iters=12)
 
     run()
