@@ -53,7 +53,6 @@ struct gh_ctx {
   hipStream_t cr_side = nullptr;
   std::vector<hipEvent_t> cr_events;
   // gh_ba_solve: marks the candidate cost's read-back (the host waits for it, not for the stream: see ba.hip)
-  hipEvent_t ba_event = nullptr;
 };
 
 // Entry guard of every public function that touches the device: serialises callers that share the context and makes the

@@ -13,7 +13,9 @@ gh_status gh_set_error(gh_ctx* ctx, gh_status st, const char* fmt, ...) {
   return st;
 }
 
-extern "C" int gh_abi_version(void) { return 1; }
+// 2 (round 5): gh_graph_problem grew intrinsics / intrinsics_free (round 4), gh_ctx_last_ba_solver reports GH_BA_SOLVER_ARROW,
+//               gh_arrow_solve_dev, gh_bf_match*_bytes; a host built against version 1 must be rebuilt
+extern "C" int gh_abi_version(void) { return 2; }
 
 extern "C" gh_status gh_ctx_create(int device, gh_ctx** out) {
   if (!out) return GH_ERR_ARG;
@@ -50,7 +52,6 @@ extern "C" void gh_ctx_destroy(gh_ctx* ctx) {
   if (ctx->ba_arena) hipFree(ctx->ba_arena);
   if (ctx->pg_arena) hipFree(ctx->pg_arena);
   for (auto e : ctx->cr_events) hipEventDestroy(e);
-  if (ctx->ba_event) hipEventDestroy(ctx->ba_event);
   if (ctx->cr_side) hipStreamDestroy(ctx->cr_side);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;

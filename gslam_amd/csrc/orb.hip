@@ -2039,6 +2039,8 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   GH_CHECK_ARG(ctx, batch >= 0 && batch <= p->max_batch);
   if (batch == 0) return GH_OK;
   GH_CHECK_ARG(ctx, gray_dev && kps_dev && desc_dev && counts_dev && row_stride >= p->w && row_stride < (1 << 24));  // (24-bit row offsets)
+  // (32-bit byte offsets inside a level: a view into a very wide buffer -- an ROI -- can pass the test above and still wrap)
+  GH_CHECK_ARG(ctx, (uint64_t)row_stride * (uint64_t)p->h < (1ull << 32));
   GH_CHECK_ARG(ctx, frame_stride >= (size_t)row_stride * p->h || batch == 1);
   GH_CHECK_ARG(ctx, ((uintptr_t)desc_dev & 7) == 0 && ((uintptr_t)kps_dev & 3) == 0);
   // GSLAM_HIP_ORB_GRAPH=0: always launch kernel by kernel (A/B measurements)

@@ -872,7 +872,10 @@ extern "C" gh_status gh_ransac_estimate_ex(gh_ctx* ctx, int model, const double*
     double m[12];
     const bool ok = fit_all(model, src, dst, n, nm, m);
     if (hypotheses_used_out) *hypotheses_used_out = ok ? 1 : 0;
-    if (!ok) return GH_OK;
+    if (!ok) {  // degenerate fit: outputs stay zero (cleared at entry); the upload from the pinned block must not outlive the call
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return GH_OK;
+    }
     memcpy(hb + off_models, m, sizeof(m));
     best[0] = 0;
     memcpy(hb + off_best, best, 8);

@@ -211,6 +211,12 @@ def bind(strict=True):
 
 MISSING = bind(strict=False)
 
+# the struct layouts mirrored above are those of ABI version 2 (include/gslam_hip.h: GH_ABI_VERSION): a library built from
+# another header version must not be driven through them
+ABI_VERSION = 2
+if "gh_abi_version" not in MISSING and lib.gh_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} reports ABI version {lib.gh_abi_version()}, this mirror was written for {ABI_VERSION}: rebuild (make lib)")
+
 
 class Context:
     """Owns a gh_ctx.  `stream` (int hipStream_t) lets kernels run on the caller's torch stream."""

@@ -175,7 +175,8 @@ class EstimatorHIP : public GSLAM::Estimator {
     if (forced == "NOSAMPLE") return GH_SAMPLE_NONE;
     if (forced == "RANSAC") return GH_SAMPLE_RANSAC;
     if ((method & GSLAM::NOSAMPLE) != 0) return GH_SAMPLE_NONE;
-    if (method == GSLAM::LMEDS && model != GH_MODEL_FUNDAMENTAL) return GH_SAMPLE_LMEDS;  // (== F8_Point: see the header)
+    // (GSLAM::LMEDS == F8_Point numerically: for the two-view models the value names the algorithm, not the sampling)
+    if (method == GSLAM::LMEDS && model != GH_MODEL_FUNDAMENTAL && model != GH_MODEL_ESSENTIAL) return GH_SAMPLE_LMEDS;
     return GH_SAMPLE_RANSAC;
   }
   bool estimate(int model, const double* a, const double* b, int n, double threshold, double confidence, double* m,

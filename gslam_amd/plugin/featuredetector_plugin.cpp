@@ -206,8 +206,10 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       if (d.rows > 0 && d.cols * d.elemSize() != 32) return false;
       cap = std::max(cap, d.rows);
     }
-    if (cap > 65535) return false;  // (frames, not maps: the batched entry keeps 16-bit train indices)
     cap = (cap + 15) & ~15;
+    if (cap > 65535) cap = 65535;   // (a frame of 65521 .. 65535 rows: match() takes it, so must the batch)
+    for (const GSLAM::GImage& d : descriptors)
+      if (d.rows > 65535) return false;  // (frames, not maps: the batched entry keeps 16-bit train indices)
     const bool cross = _config.matchCrossCheck;
     const int NP = cross ? 2 * P : P;
     std::vector<int32_t> counts((size_t)F), pq((size_t)NP), pt((size_t)NP);
@@ -313,9 +315,16 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
       std::vector<int8_t> pat;
       int v;
       char c;
+      bool in_range = true;
       while (in) {
-        if (in >> v) pat.push_back((int8_t)v);
-        else if (!in.eof()) { in.clear(); in >> c; }  // separators: commas, braces, comments' punctuation
+        if (in >> v) {
+          in_range = in_range && v >= -128 && v <= 127;  // (a number of a comment or an identifier pasted along with the table)
+          pat.push_back((int8_t)v);
+        } else if (!in.eof()) { in.clear(); in >> c; }  // separators: commas, braces, comments' punctuation
+      }
+      if (!in_range) {
+        LOG(ERROR) << "FeatureDetectorHIP: " << pf << " holds an integer outside [-128, 127]: not a test pattern (strip comments and identifiers)";
+        return false;
       }
       if (pat.size() != 1024) {
         LOG(ERROR) << "FeatureDetectorHIP: " << pf << " holds " << pat.size() << " integers, a test pattern has 1024";

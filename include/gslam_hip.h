@@ -48,7 +48,9 @@ typedef enum gh_status {
 } gh_status;
 
 /* ------------------------------------------------------------------ context ---------- */
-int gh_abi_version(void); /* bumps when a struct in this header changes layout */
+int gh_abi_version(void); /* bumps when a struct in this header changes layout or entry points change meaning; 2 since round 5
+                             (GH_ABI_VERSION below is what this header describes: a host compares the two at start-up) */
+#define GH_ABI_VERSION 2
 gh_status gh_ctx_create(int device, gh_ctx** out);
 void gh_ctx_destroy(gh_ctx* ctx);
 const char* gh_last_error(const gh_ctx* ctx);

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert hip.bind(strict=False) == []
     for n in names:
         assert getattr(hip.lib, n) is not None
-    assert hip.lib.gh_abi_version() == 1
+    assert hip.lib.gh_abi_version() == 2  # (bumped in round 5: gh_graph_problem grew two fields in round 4, new entry points)
 
 
 def test_record_layouts():
@@ -94,7 +94,7 @@ def test_library_override_for_ab_measurements(tmp_path):
     code = "from gslam_amd import hip; print(hip.LIB_PATH, hip.lib.gh_abi_version())"
     env = dict(os.environ, GSLAM_HIP_LIB=str(other), PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
-    assert r.returncode == 0 and r.stdout.split() == [str(other), "1"], r.stderr[-400:]
+    assert r.returncode == 0 and r.stdout.split() == [str(other), "2"], r.stderr[-400:]
     env["GSLAM_HIP_LIB"] = str(tmp_path / "missing.so")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
     assert r.returncode != 0 and "ImportError" in r.stderr
