@@ -160,6 +160,13 @@ struct gh_comm {
   ShmSegment* shm_dev = nullptr;   // the segment as the GPU sees it (hipHostRegister)
   bool shm_registered = false;
   uint32_t round = 0;              // number of the exchange in flight / last issued
+  // One stream per peer for the pushes (GSLAM_HIP_IPC_PEER_STREAMS=0: all on `stream`, one after the other): copies on ONE
+  // stream run one at a time, i.e. over one xGMI link at a time; the mesh has a link to every peer (7 x ~153 GB/s), so the
+  // slices to the 7 peers go out together -- the direct peer all-gather SURVEY 8(e) prefers over a ring.
+  bool peer_streams = true;
+  hipStream_t pstream[kMaxWorld] = {nullptr};
+  hipEvent_t pev[kMaxWorld] = {nullptr};
+  hipEvent_t ev_fork = nullptr;
 };
 
 namespace {
@@ -308,6 +315,14 @@ gh_status ipc_rendezvous(gh_ctx* ctx, gh_comm* c) {
 }
 
 void comm_common_free(gh_comm* c) {
+  for (int p = 0; p < kMaxWorld; ++p) {
+    if (c->pev[p]) hipEventDestroy(c->pev[p]);
+    if (c->pstream[p]) hipStreamDestroy(c->pstream[p]);
+    c->pev[p] = nullptr;
+    c->pstream[p] = nullptr;
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  c->ev_fork = nullptr;
   if (c->ev_ready) hipEventDestroy(c->ev_ready);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -331,11 +346,20 @@ gh_status gather_one(gh_comm* c, const void* send, void* gathered, size_t bytes,
   }
   IpcBuffer* b = find_ipc_buffer(c, gathered, stride);
   if (!b) return gh_set_error(ctx, GH_ERR_ARG, "IPC transport: the gathered buffer must come from gh_comm_buffer");
+  const bool fan = c->peer_streams && c->ev_fork != nullptr;
+  if (fan) GH_HIP(ctx, hipEventRecord(c->ev_fork, c->stream));  // behind the ready-poll of this exchange (and earlier gathers of it)
   for (int r = 0; r < c->world; ++r) {
     const int p = (c->rank + r) % c->world;  // stagger the targets so the ranks do not all hit the same peer first
     char* dst = (char*)b->peer[p] + (size_t)c->rank * stride;
     if (dst == (const char*)send) continue;  // in-place slice of my own buffer
-    GH_HIP(ctx, hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (fan && p != c->rank) {
+      GH_HIP(ctx, hipStreamWaitEvent(c->pstream[p], c->ev_fork, 0));
+      GH_HIP(ctx, hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, c->pstream[p]));
+      GH_HIP(ctx, hipEventRecord(c->pev[p], c->pstream[p]));
+      GH_HIP(ctx, hipStreamWaitEvent(c->stream, c->pev[p], 0));  // the done flag (end_collective) comes behind every push
+    } else {
+      GH_HIP(ctx, hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
   }
   return GH_OK;
 }
@@ -442,7 +466,17 @@ extern "C" gh_status gh_comm_create_ipc(gh_ctx* ctx, int rank, int world, const 
   c->shm_name = std::string(rendezvous_name[0] == '/' ? "" : "/") + rendezvous_name;
   if (const char* t = getenv("GSLAM_HIP_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
   if (const char* e = getenv("GSLAM_HIP_IPC_SYNC")) c->ipc_sync = atoi(e) != 0;
+  if (const char* e = getenv("GSLAM_HIP_IPC_PEER_STREAMS")) c->peer_streams = atoi(e) != 0;
   gh_status st = comm_common_init(ctx, c);
+  if (st == GH_OK && c->peer_streams) {
+    bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int p = 0; ok && p < world; ++p) {
+      if (p == rank) continue;
+      ok = hipStreamCreateWithFlags(&c->pstream[p], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&c->pev[p], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) st = gh_set_error(ctx, GH_ERR_HIP, "IPC transport: cannot create the per-peer streams");
+  }
   if (st == GH_OK) st = ipc_rendezvous(ctx, c);
   if (st == GH_OK && !c->ipc_sync) {
     // the GPU's view of the segment (pinned + mapped: device loads / stores go straight to host memory)
@@ -491,6 +525,11 @@ extern "C" void gh_comm_destroy(gh_comm* c) {
       if (left == 0 || c->rank == 0) shm_unlink(c->shm_name.c_str());
     }
   }
+  for (int p = 0; p < kMaxWorld; ++p) {
+    if (c->pev[p]) hipEventDestroy(c->pev[p]);
+    if (c->pstream[p]) hipStreamDestroy(c->pstream[p]);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   hipEventDestroy(c->ev_ready);
   hipEventDestroy(c->ev_done);
   hipStreamDestroy(c->stream);

@@ -57,6 +57,11 @@ def test_two_rank_bench_equals_single_rank(tmp_path):
     ap2, ap1 = two["extra"]["all_pairs_sharded"], one["extra"]["all_pairs_sharded"]
     assert ap2["frame_pairs"] == ap1["frame_pairs"] == 66 and ap2["pairs"] == ap1["pairs"] > 0
     assert "c3_stereo" in two["extra"] and "error" not in two["extra"]["c3_stereo"]  # the C3 leg ran on both ranks
+    # the N > 1 line carries BOTH scaling modes (the other one as a second leg) and what the exchange moved, by which path
+    ol = two["extra"]["other_scaling"]
+    assert "error" not in ol and ol["scaling"] == "strong" and ol["frames_per_gpu"] == 3 and ol["global_frames"] == 6 and ol["Mkeypoints_per_s"] > 0
+    xc = two["extra"]["exchange"]
+    assert xc["transport"] == "gh_comm (ipc)" and "push" in xc["path"] and xc["bytes_sent_per_rank_per_step"] == 6 * 600 * 32 + 6 * 4 + 6 * 600 * 4
 
 
 def test_strong_scaling_mode_splits_the_same_frames(tmp_path):
@@ -76,6 +81,7 @@ def test_strong_scaling_mode_splits_the_same_frames(tmp_path):
     assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
     one = _line(r1.stdout)
     assert two["scaling"] == one["scaling"] == "strong" and two["config"]["frames_per_gpu"] == 6 and one["config"]["frames_per_gpu"] == 12
+    assert two["extra"]["other_scaling"]["scaling"] == "weak" and two["extra"]["other_scaling"]["frames_per_gpu"] == 12
     v2, v1 = two["extra"]["verify"], one["extra"]["verify"]
     assert v2["global_frames"] == v1["global_frames"] == 12
     assert v2["features_sha256"] == v1["features_sha256"] and v2["matches_sha256"] == v1["matches_sha256"]
