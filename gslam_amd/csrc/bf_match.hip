@@ -454,6 +454,122 @@ extern "C" gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev,
   return gh_bf_match_pairs_popc_dev(ctx, desc_dev, counts_dev, cap, pair_q_dev, pair_t_dev, npairs, idx1_dev, d1_dev, d2_dev);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Descriptors of ANY width that is a multiple of 8 bytes: GSLAM/core/Vocabulary.h:493-513 (hamming64: 64-byte rows -- BRISK /
+// FREAK sized; hamming8x: bytes / 8 uint64_t words) with the same first-minimum rule (:1712-1725).  The reference picks the
+// distance by the descriptor's width (DistanceFactory::create, :565-567); so do these entries: 32 bytes run the kernels above.
+// One query row per lane (64 per wave), the train row wave-uniform through scalar loads as above; W = 16 dwords holds the
+// query in registers, other widths read it from an LDS copy of the wave's 64 rows.  Keys as above (distance <= 2048 fits).
+namespace {
+struct BytesArgs {
+  const uint32_t* q;   // single: query rows; pairs: the descriptor batch
+  const uint32_t* t;   // single: train rows
+  const int32_t *counts, *pair_q, *pair_t;  // pairs (null = single)
+  int nq, nt, cap, words;
+  int32_t* idx1;
+  uint16_t *d1, *d2;
+};
+
+template <int W>
+__global__ __launch_bounds__(64) void bf_match_bytes_kernel(BytesArgs a) {
+  extern __shared__ uint32_t qs[];  // W == 0: [words][64] query words of the wave
+  const int lane = threadIdx.x;
+  const int words = W ? W : a.words;
+  const uint32_t *qrows = a.q, *trows = a.t;
+  int nq = a.nq, nt = a.nt, out_rows = a.nq;
+  size_t out0 = 0;
+  if (a.counts != nullptr) {
+    const int p = blockIdx.y, fq = a.pair_q[p], ft = a.pair_t[p];
+    qrows = a.q + (size_t)fq * a.cap * words;
+    trows = a.q + (size_t)ft * a.cap * words;
+    nq = min(a.counts[fq], a.cap);
+    nt = min(a.counts[ft], a.cap);
+    out_rows = a.cap;
+    out0 = (size_t)p * a.cap;
+  }
+  nt = __builtin_amdgcn_readfirstlane(nt);
+  const int qi = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= out_rows) return;
+  const int qc = qi < nq ? qi : (nq > 0 ? nq - 1 : 0);
+  uint32_t qr[W ? W : 1];
+  if (nq > 0) {
+    if constexpr (W != 0) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) qr[k] = qrows[(size_t)qc * W + k];
+    } else {
+      for (int k = 0; k < words; ++k) qs[k * 64 + lane] = qrows[(size_t)qc * words + k];
+    }
+  }
+  uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+  if (nq > 0) {
+    for (int j = 0; j < nt; ++j) {
+      const uint32_t* tp = trows + (size_t)j * words;  // wave-uniform: scalar loads
+      uint32_t d = 0;
+      if constexpr (W != 0) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) d += (uint32_t)__popc(qr[k] ^ tp[k]);
+      } else {
+        for (int k = 0; k < words; ++k) d += (uint32_t)__popc(qs[k * 64 + lane] ^ tp[k]);
+      }
+      const uint32_t key = (d << 16) | (uint32_t)j;
+      second = umed3(key, best, second);
+      best = min(best, key);
+    }
+  }
+  if (qi < out_rows) {
+    const bool valid = qi < nq;
+    const uint32_t b = valid ? best : 0xFFFFFFFFu, sc = valid ? second : 0xFFFFFFFFu;
+    a.idx1[out0 + qi] = (b == 0xFFFFFFFFu) ? -1 : (int32_t)(b & 0xFFFFu);
+    a.d1[out0 + qi] = (uint16_t)(b >> 16);
+    a.d2[out0 + qi] = (uint16_t)(sc >> 16);
+  }
+}
+
+gh_status bf_bytes_launch(gh_ctx* ctx, const BytesArgs& a, int rows, int ny) {
+  const dim3 grid(gh_div_up(rows, 64), ny);
+  if (a.words == 16) {
+    GH_LAUNCH(ctx, "bf_match_bytes", bf_match_bytes_kernel<16>, grid, dim3(64), 0, a);
+  } else {
+    GH_LAUNCH(ctx, "bf_match_bytes", bf_match_bytes_kernel<0>, grid, dim3(64), (size_t)a.words * 64 * 4, a);
+  }
+  return GH_OK;
+}
+}  // namespace
+
+extern "C" gh_status gh_bf_match_bytes_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int desc_bytes,
+                                           int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  if (desc_bytes == 32) return gh_bf_match_dev(ctx, q_dev, nq, t_dev, nt, idx1_dev, d1_dev, d2_dev);
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && desc_bytes >= 8 && desc_bytes <= 256 && desc_bytes % 8 == 0);
+  if (nq == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, q_dev && idx1_dev && d1_dev && d2_dev && (nt == 0 || t_dev));
+  GH_CHECK_ARG(ctx, ((uintptr_t)q_dev & 3) == 0 && ((uintptr_t)t_dev & 3) == 0);
+  GH_CHECK_ARG(ctx, nt <= 65535);  // (16-bit train index in the key; the 32-byte entry chunks larger sets)
+  BytesArgs a{(const uint32_t*)q_dev, (const uint32_t*)t_dev, nullptr, nullptr, nullptr, nq, nt, 0, desc_bytes / 4, idx1_dev, d1_dev, d2_dev};
+  return bf_bytes_launch(ctx, a, nq, 1);
+}
+
+extern "C" gh_status gh_bf_match_pairs_bytes_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap, int desc_bytes,
+                                                 const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
+                                                 int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
+  if (!ctx) return GH_ERR_ARG;
+  if (desc_bytes == 32)
+    return gh_bf_match_pairs_dev(ctx, desc_dev, counts_dev, cap, pair_q_dev, pair_t_dev, npairs, idx1_dev, d1_dev, d2_dev);
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, cap >= 0 && cap <= 65535 && npairs >= 0 && desc_bytes >= 8 && desc_bytes <= 256 && desc_bytes % 8 == 0);
+  if (npairs == 0 || cap == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, desc_dev && counts_dev && pair_q_dev && pair_t_dev && idx1_dev && d1_dev && d2_dev && ((uintptr_t)desc_dev & 3) == 0);
+  for (int p0 = 0; p0 < npairs; p0 += 65535) {  // grid.y is limited to 65535
+    const int np = npairs - p0 < 65535 ? npairs - p0 : 65535;
+    const size_t o = (size_t)p0 * cap;
+    BytesArgs a{(const uint32_t*)desc_dev, nullptr, counts_dev, pair_q_dev + p0, pair_t_dev + p0, 0, 0, cap, desc_bytes / 4,
+                idx1_dev + o, d1_dev + o, d2_dev + o};
+    GH_TRY(bf_bytes_launch(ctx, a, cap, np));
+  }
+  return GH_OK;
+}
+
 extern "C" gh_status gh_bf_match_band_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const gh_keypoint* kps_dev,
                                                 const int32_t* counts_dev, int cap, const int32_t* pair_q_dev,
                                                 const int32_t* pair_t_dev, int npairs, float band_per_size,

@@ -160,7 +160,7 @@ struct gh_comm {
   ShmSegment* shm_dev = nullptr;   // the segment as the GPU sees it (hipHostRegister)
   bool shm_registered = false;
   uint32_t round = 0;              // number of the exchange in flight / last issued
-  // One stream per peer for the pushes (GSLAM_HIP_IPC_PEER_STREAMS=0: all on `stream`, one after the other): copies on ONE
+  // One stream per peer for the pushes when there is more than one peer (GSLAM_HIP_IPC_PEER_STREAMS=0 / 1 forces it): copies on ONE
   // stream run one at a time, i.e. over one xGMI link at a time; the mesh has a link to every peer (7 x ~153 GB/s), so the
   // slices to the 7 peers go out together -- the direct peer all-gather SURVEY 8(e) prefers over a ring.
   bool peer_streams = true;
@@ -466,7 +466,8 @@ extern "C" gh_status gh_comm_create_ipc(gh_ctx* ctx, int rank, int world, const 
   c->shm_name = std::string(rendezvous_name[0] == '/' ? "" : "/") + rendezvous_name;
   if (const char* t = getenv("GSLAM_HIP_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
   if (const char* e = getenv("GSLAM_HIP_IPC_SYNC")) c->ipc_sync = atoi(e) != 0;
-  if (const char* e = getenv("GSLAM_HIP_IPC_PEER_STREAMS")) c->peer_streams = atoi(e) != 0;
+  c->peer_streams = world > 2;  // (with one peer there is one link: the fork / join events would only cost host time)
+  if (const char* e = getenv("GSLAM_HIP_IPC_PEER_STREAMS")) c->peer_streams = atoi(e) != 0;  // 1 forces them on (2-rank tests)
   gh_status st = comm_common_init(ctx, c);
   if (st == GH_OK && c->peer_streams) {
     bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;

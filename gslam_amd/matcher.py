@@ -31,6 +31,28 @@ class BFMatcher:
         self.ctx.check(hip.lib.gh_bf_match_dev(self.ctx.h, _p(q), nq, _p(t), nt, _p(idx1), _p(d1), _p(d2)))
         return idx1, d1, d2
 
+    def match_bytes(self, q: torch.Tensor, t: torch.Tensor):
+        """Descriptors of any width that is a multiple of 8 bytes (q: nq x B u8, t: nt x B u8): gh_bf_match_bytes_dev --
+        hamming64 / hamming8x of the reference (GSLAM/core/Vocabulary.h:493-513), same outputs as match()."""
+        assert q.is_cuda and t.is_cuda and q.dtype == t.dtype == torch.uint8 and q.is_contiguous() and t.is_contiguous()
+        nq, nt, nb = q.shape[0], t.shape[0], q.shape[1]
+        assert t.shape[1] == nb or nt == 0
+        idx1 = torch.empty(nq, dtype=torch.int32, device=q.device)
+        d1 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        d2 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        self.ctx.check(hip.lib.gh_bf_match_bytes_dev(self.ctx.h, _p(q), nq, _p(t), nt, nb, _p(idx1), _p(d1), _p(d2)))
+        return idx1, d1, d2
+
+    def match_pairs_bytes(self, desc: torch.Tensor, counts: torch.Tensor, pair_q: torch.Tensor, pair_t: torch.Tensor):
+        """desc: F x cap x B u8 (B a multiple of 8): gh_bf_match_pairs_bytes_dev."""
+        cap, nb, P = desc.shape[1], desc.shape[2], pair_q.shape[0]
+        idx1 = torch.empty((P, cap), dtype=torch.int32, device=desc.device)
+        d1 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
+        d2 = torch.empty((P, cap), dtype=torch.int16, device=desc.device)
+        self.ctx.check(hip.lib.gh_bf_match_pairs_bytes_dev(self.ctx.h, _p(desc), _p(counts), cap, nb, _p(pair_q), _p(pair_t), P,
+                                                           _p(idx1), _p(d1), _p(d2)))
+        return idx1, d1, d2
+
     def match_pairs(self, desc: torch.Tensor, counts: torch.Tensor, pair_q: torch.Tensor, pair_t: torch.Tensor,
                     out=None, mfma=None):
         """desc: F x cap x 32 u8; counts: F int32; pair_q/pair_t: P int32 -> (P x cap) idx1, d1, d2.

@@ -57,6 +57,42 @@ void oracle_bf_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t
   }
 }
 
+/* Descriptors of any width that is a multiple of 8 bytes -- GSLAM/core/Vocabulary.h:493-513: DistanceFactory::hamming64 (eight
+ * uint64_t words) and hamming8x (bytes / 8 words: trailing bytes beyond a multiple of 8 are not compared) -- with the same
+ * first-minimum rule.  Pinned like hamming32: oracle/ref_shim.cpp compiles the reference's own two functions
+ * (tests/test_bf_oracle.py, tests/golden/bf_bytes_reference.npz). */
+int oracle_hamming8x(const uint8_t* a, const uint8_t* b, int bytes) {
+  int d = 0;
+  for (int w = 0; w < bytes / 8; ++w) {
+    uint64_t pa, pb;
+    memcpy(&pa, a + 8 * w, 8);
+    memcpy(&pb, b + 8 * w, 8);
+    d += popcount64(pa ^ pb);
+  }
+  return d;
+}
+
+void oracle_bf_match_bytes(const uint8_t* q, int nq, const uint8_t* t, int nt, int bytes, int32_t* idx1, uint16_t* d1,
+                           uint16_t* d2) {
+  for (int i = 0; i < nq; ++i) {
+    int best_d = 1 << 30, best_j = -1, second_d = 1 << 30;
+    const uint8_t* qi = q + (size_t)i * bytes;
+    for (int j = 0; j < nt; ++j) {
+      int d = oracle_hamming8x(qi, t + (size_t)j * bytes, bytes);
+      if (d < best_d) {
+        second_d = best_d;
+        best_d = d;
+        best_j = j;
+      } else if (d < second_d) {
+        second_d = d;
+      }
+    }
+    idx1[i] = best_j;
+    d1[i] = best_j >= 0 ? (uint16_t)best_d : 65535;
+    d2[i] = second_d < (1 << 30) ? (uint16_t)second_d : 65535;
+  }
+}
+
 /* Multi-threaded variant for the timed CPU baseline (parallel over query rows). */
 void oracle_bf_match_omp(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx1, uint16_t* d1,
                          uint16_t* d2, int threads) {

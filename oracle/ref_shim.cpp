@@ -36,6 +36,31 @@ void ref_bf_match(const unsigned char* q, int nq, const unsigned char* t, int nt
   }
 }
 
+// the reference's own wider Hamming distances (GSLAM/core/Vocabulary.h:493-513)
+float ref_hamming64(const unsigned char* a, const unsigned char* b) { return GSLAM::Vocabulary::DistanceFactory::hamming64(a, b); }
+float ref_hamming8x(const unsigned char* a, const unsigned char* b, int bytes) {
+  return GSLAM::Vocabulary::DistanceFactory::hamming8x(a, b, bytes);
+}
+// ... and the child-scan loop over rows of `bytes` bytes: hamming64 for 64, hamming8x otherwise (what
+// Vocabulary picks for a descriptor width, DistanceFactory::create, Vocabulary.h:565-567)
+void ref_bf_match_bytes(const unsigned char* q, int nq, const unsigned char* t, int nt, int bytes, int32_t* idx1, float* d1) {
+  for (int i = 0; i < nq; ++i) {
+    float best_d = std::numeric_limits<float>::max();
+    int best = -1;
+    for (int j = 0; j < nt; ++j) {
+      const unsigned char *a = q + (size_t)i * bytes, *b = t + (size_t)j * bytes;
+      const float d = bytes == 64 ? GSLAM::Vocabulary::DistanceFactory::hamming64(a, b)
+                                  : GSLAM::Vocabulary::DistanceFactory::hamming8x(a, b, bytes);
+      if (d < best_d) {
+        best_d = d;
+        best = j;
+      }
+    }
+    idx1[i] = best;
+    d1[i] = best_d;
+  }
+}
+
 // Lie-group helpers of the BA pose update (GSLAM/core/SE3.h, SO3.h).  Pose layout: tx ty tz qx qy qz qw.
 void ref_se3_exp(const double* xi6, double* pose7) {
   GSLAM::Vector<double, 6> l;

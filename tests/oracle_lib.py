@@ -40,6 +40,15 @@ class Oracle:
             self.lib.oracle_bf_match_omp(_ptr(q), nq, _ptr(t), nt, _ptr(idx1), _ptr(d1), _ptr(d2), int(threads))
         return idx1, d1, d2
 
+    def bf_match_bytes(self, q, t, nbytes):
+        """descriptors of `nbytes` bytes per row (a multiple of 8): hamming64 / hamming8x + first minimum"""
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, nbytes)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, nbytes)
+        nq, nt = q.shape[0], t.shape[0]
+        idx1, d1, d2 = np.empty(nq, np.int32), np.empty(nq, np.uint16), np.empty(nq, np.uint16)
+        self.lib.oracle_bf_match_bytes(_ptr(q), nq, _ptr(t), nt, int(nbytes), _ptr(idx1), _ptr(d1), _ptr(d2))
+        return idx1, d1, d2
+
     def bf_match_band(self, q, kq, t, kt, band_per_size):
         """kq / kt: structured KeyPoint arrays parallel to q / t."""
         q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
@@ -76,6 +85,14 @@ class Reference:
         idx1 = np.empty(q.shape[0], np.int32)
         d1 = np.empty(q.shape[0], np.float32)
         self.lib.ref_bf_match(_ptr(q), q.shape[0], _ptr(t), t.shape[0], _ptr(idx1), _ptr(d1), int(threads))
+        return idx1, d1
+
+    def bf_match_bytes(self, q, t, nbytes):
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, nbytes)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, nbytes)
+        idx1 = np.empty(q.shape[0], np.int32)
+        d1 = np.empty(q.shape[0], np.float32)
+        self.lib.ref_bf_match_bytes(_ptr(q), q.shape[0], _ptr(t), t.shape[0], int(nbytes), _ptr(idx1), _ptr(d1))
         return idx1, d1
 
     def _se3(self, name, *ins, out_n):

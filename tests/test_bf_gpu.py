@@ -284,3 +284,55 @@ def test_train_set_beyond_65535_rows(ctx, oracle):
     ctx.check(hip.lib.gh_bf_match_host(ctx.h, q.ctypes.data_as(C.c_void_p), nq, t.ctypes.data_as(C.c_void_p), nt,
                                        hi.ctypes.data_as(C.c_void_p), h1.ctypes.data_as(C.c_void_p), h2.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(hi, e[0]) and np.array_equal(h1, e[1]) and np.array_equal(h2, e[2])
+
+
+# ------------------------------------------------------------------ wider descriptors (hamming64 / hamming8x)
+@pytest.mark.parametrize("nb,nq,nt", [(64, 700, 900), (64, 1, 1), (16, 130, 257), (40, 333, 100), (128, 200, 300), (256, 65, 64),
+                                      (8, 64, 1000), (64, 5, 0)])
+def test_wide_descriptors_match_the_oracle(ctx, oracle, nb, nq, nt):
+    """gh_bf_match_bytes_dev (GSLAM/core/Vocabulary.h:493-513: hamming64 for 64-byte rows, hamming8x for other multiples of 8)
+    against the oracle, which is pinned to the reference's own functions: indices, best and second-best distances bit for bit,
+    duplicated train rows (first minimum) included."""
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    rng = np.random.default_rng(nb * 1000 + nq)
+    q = rng.integers(0, 256, size=(nq, nb), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, nb), dtype=np.uint8)
+    if nt > 40 and nq > 20:
+        t[:20] = q[:20] ^ (rng.random((20, nb)) < 0.05).astype(np.uint8)
+        t[33] = t[4]
+    m = BFMatcher(ctx)
+    idx1, d1, d2 = m.match_bytes(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    torch.cuda.synchronize()
+    e = oracle.bf_match_bytes(q, t, nb)
+    assert np.array_equal(idx1.cpu().numpy(), e[0])
+    assert np.array_equal(d1.cpu().numpy().view(np.uint16), e[1]) and np.array_equal(d2.cpu().numpy().view(np.uint16), e[2])
+
+
+def test_wide_descriptor_batched_pairs(ctx, oracle):
+    import torch
+    from gslam_amd.matcher import BFMatcher
+    rng = np.random.default_rng(9)
+    F, cap, nb = 5, 300, 64
+    desc = rng.integers(0, 256, size=(F, cap, nb), dtype=np.uint8)
+    counts = np.array([300, 120, 0, 299, 64], np.int32)
+    pq = np.array([0, 1, 3, 4, 2, 0], np.int32)
+    pt = np.array([1, 0, 4, 3, 0, 2], np.int32)
+    m = BFMatcher(ctx)
+    idx1, d1, d2 = m.match_pairs_bytes(torch.from_numpy(desc).cuda(), torch.from_numpy(counts).cuda(), torch.from_numpy(pq).cuda(),
+                                       torch.from_numpy(pt).cuda())
+    torch.cuda.synchronize()
+    for p in range(len(pq)):
+        nq_, nt_ = counts[pq[p]], counts[pt[p]]
+        e = oracle.bf_match_bytes(desc[pq[p], :nq_], desc[pt[p], :nt_], nb)
+        assert np.array_equal(idx1[p, :nq_].cpu().numpy(), e[0]) and bool((idx1[p, nq_:] == -1).all())
+        assert np.array_equal(d1[p, :nq_].cpu().numpy().view(np.uint16), e[1])
+        assert np.array_equal(d2[p, :nq_].cpu().numpy().view(np.uint16), e[2])
+    # 32-byte rows through the generic entries are the kernels of the default path
+    d32 = rng.integers(0, 256, size=(2, 200, 32), dtype=np.uint8)
+    c32 = np.array([200, 150], np.int32)
+    a = m.match_pairs_bytes(torch.from_numpy(d32).cuda(), torch.from_numpy(c32).cuda(), torch.tensor([0], dtype=torch.int32).cuda(),
+                            torch.tensor([1], dtype=torch.int32).cuda())
+    b = m.match_pairs(torch.from_numpy(d32).cuda(), torch.from_numpy(c32).cuda(), torch.tensor([0], dtype=torch.int32).cuda(),
+                      torch.tensor([1], dtype=torch.int32).cuda())
+    assert all(torch.equal(x, y) for x, y in zip(a, b))

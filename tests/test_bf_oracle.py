@@ -67,3 +67,35 @@ def test_mask_semantics(oracle):
     keep = oracle.match_mask(idx1, d1, d2, back, 3, 50, 7, 10, 1)
     # row0: 10<=50, 10*10<7*40, back[0]==0 -> keep; row1: d1>50; row2: ratio 300<217 false; row3: no match
     assert keep.tolist() == [1, 0, 0, 0]
+
+
+# ------------------------------------------------------------------ wider descriptors (hamming64 / hamming8x)
+GOLD_BYTES = os.path.join(os.path.dirname(__file__), "golden", "bf_bytes_reference.npz")
+
+
+def test_wide_descriptor_golden_vectors_from_reference(oracle):
+    """oracle_bf_match_bytes against vectors generated from the reference's own hamming64 / hamming8x (tools/gen_golden.py
+    bf_bytes; GSLAM/core/Vocabulary.h:493-513,565-567)."""
+    g = np.load(GOLD_BYTES)
+    for nb in (64, 40, 16, 128):
+        idx1, d1, d2 = oracle.bf_match_bytes(g["q%d" % nb], g["t%d" % nb], nb)
+        assert np.array_equal(idx1, g["idx%d" % nb]) and np.array_equal(d1.astype(np.float32), g["d%d" % nb])
+        assert (d2 >= d1).all()
+    # 32 bytes through the generic entry is hamming32
+    q, t = oracle_lib.random_descriptors(40, 3), oracle_lib.random_descriptors(50, 4)
+    for a, b in zip(oracle.bf_match_bytes(q, t, 32), oracle.bf_match(q, t)):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.skipif(not oracle_lib.have_reference(), reason="oracle/_ref not built (needs /root/reference)")
+def test_wide_descriptor_oracle_equals_reference_live(oracle):
+    ref = oracle_lib.load_reference()
+    rng = np.random.default_rng(5)
+    for nb in (64, 8, 24, 72, 256):
+        q = rng.integers(0, 256, size=(70, nb), dtype=np.uint8)
+        t = rng.integers(0, 256, size=(90, nb), dtype=np.uint8)
+        t[33] = t[2]
+        t[:20] = q[:20]
+        idx_r, d_r = ref.bf_match_bytes(q, t, nb)
+        idx_o, d1, d2 = oracle.bf_match_bytes(q, t, nb)
+        assert np.array_equal(idx_r, idx_o) and np.array_equal(d_r, d1.astype(np.float32))

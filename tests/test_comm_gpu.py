@@ -288,3 +288,20 @@ def test_ipc_synchronous_protocol_still_agrees(tmp_path):
         del os.environ["GSLAM_HIP_IPC_SYNC"]
     for k in ("g_desc", "g_counts", "g_kps", "g_idx", "g_d1", "g_d2"):
         assert r0[k].tobytes() == r1[k].tobytes(), k
+
+
+def test_ipc_per_peer_streams_gather_the_same_bytes(tmp_path):
+    """GSLAM_HIP_IPC_PEER_STREAMS=1: one push stream per peer with fork / join events -- what runs by itself from three ranks up
+    (all xGMI links at once) -- forced on for two ranks, against the default single-stream pushes: identical gathered buffers on
+    both ranks and between the two modes; also with the synchronous protocol."""
+    F, K, W, H = 2, 300, 640, 376
+    base = _spawn(2, F, K, W, H, "gslam_comm_ps0_%d" % os.getpid(), tmp_path)
+    for extra_env in ({"GSLAM_HIP_IPC_PEER_STREAMS": "1"}, {"GSLAM_HIP_IPC_PEER_STREAMS": "1", "GSLAM_HIP_IPC_SYNC": "1"}):
+        os.environ.update(extra_env)
+        try:
+            r0, r1 = _spawn(2, F, K, W, H, "gslam_comm_ps1_%d_%d" % (os.getpid(), len(extra_env)), tmp_path)
+        finally:
+            for k in extra_env:
+                del os.environ[k]
+        for k in ("g_desc", "g_counts", "g_kps", "g_idx", "g_d1", "g_d2"):
+            assert r0[k].tobytes() == r1[k].tobytes() == base[0][k].tobytes(), k

@@ -71,8 +71,26 @@ def camera_golden(ref, out):
     print("camera_reference.npz written")
 
 
+def bf_bytes_golden(ref, out):
+    """bf_bytes_reference.npz: the reference's hamming64 / hamming8x (Vocabulary.h:493-513) + its first-minimum scan on rows of
+    64, 40, 16 and 128 bytes (with duplicated train rows: the tie rule)"""
+    rng = np.random.default_rng(0xB17E5)
+    data = {}
+    for nb in (64, 40, 16, 128):
+        q = rng.integers(0, 256, size=(48, nb), dtype=np.uint8)
+        t = rng.integers(0, 256, size=(61, nb), dtype=np.uint8)
+        t[:40] = q[:40] ^ (rng.random((40, nb)) < 0.04).astype(np.uint8) * np.uint8(1 << 3)  # correlated rows
+        t[50] = t[9]
+        idx1, d1 = ref.bf_match_bytes(q, t, nb)
+        data.update({"q%d" % nb: q, "t%d" % nb: t, "idx%d" % nb: idx1, "d%d" % nb: d1})
+    np.savez_compressed(os.path.join(out, "bf_bytes_reference.npz"), **data)
+    print("bf_bytes_reference.npz written")
+
+
 def main():
     ref = oracle_lib.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "bf_bytes":
+        return bf_bytes_golden(ref, os.path.join(ROOT, "tests", "golden"))
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         return wide_bow(ref, os.path.join(ROOT, "tests", "golden"))
     if len(sys.argv) > 1 and sys.argv[1] == "camera":
