@@ -550,6 +550,37 @@ extern "C" gh_status gh_bf_match_bytes_dev(gh_ctx* ctx, const uint8_t* q_dev, in
   return bf_bytes_launch(ctx, a, nq, 1);
 }
 
+// host arrays in and out (what FeatureDetector::match of the plugin calls for descriptors that are not 32 bytes wide)
+extern "C" gh_status gh_bf_match_bytes_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes,
+                                            int32_t* idx1, uint16_t* d1, uint16_t* d2) {
+  if (!ctx) return GH_ERR_ARG;
+  if (desc_bytes == 32) return gh_bf_match_host(ctx, q, nq, t, nt, idx1, d1, d2);
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535 && desc_bytes >= 8 && desc_bytes <= 256 && desc_bytes % 8 == 0);
+  if (nq == 0) return GH_OK;
+  GH_CHECK_ARG(ctx, q && idx1 && d1 && d2 && (nt == 0 || t));
+  const size_t qb = (size_t)nq * desc_bytes, tb = (size_t)nt * desc_bytes;
+  const size_t off_t = (qb + 255) & ~(size_t)255, off_i = off_t + ((tb + 255) & ~(size_t)255);
+  const size_t off_d1 = off_i + (((size_t)nq * 4 + 255) & ~(size_t)255), off_d2 = off_d1 + (((size_t)nq * 2 + 255) & ~(size_t)255);
+  const size_t total = off_d2 + (size_t)nq * 2;
+  void *base = nullptr, *hbase = nullptr;
+  GH_TRY(gh_scratch(ctx, total, &base));
+  GH_TRY(gh_pinned(ctx, total, &hbase));
+  uint8_t *b = (uint8_t*)base, *hb = (uint8_t*)hbase;
+  memcpy(hb, q, qb);
+  if (tb) memcpy(hb + off_t, t, tb);
+  GH_HIP(ctx, hipMemcpyAsync(b, hb, off_t + tb, hipMemcpyHostToDevice, ctx->stream));
+  BytesArgs a{(const uint32_t*)b, (const uint32_t*)(b + off_t), nullptr, nullptr, nullptr, nq, nt, 0, desc_bytes / 4,
+              (int32_t*)(b + off_i), (uint16_t*)(b + off_d1), (uint16_t*)(b + off_d2)};
+  GH_TRY(bf_bytes_launch(ctx, a, nq, 1));
+  GH_HIP(ctx, hipMemcpyAsync(hb + off_i, b + off_i, total - off_i, hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(idx1, hb + off_i, (size_t)nq * 4);
+  memcpy(d1, hb + off_d1, (size_t)nq * 2);
+  memcpy(d2, hb + off_d2, (size_t)nq * 2);
+  return GH_OK;
+}
+
 extern "C" gh_status gh_bf_match_pairs_bytes_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap, int desc_bytes,
                                                  const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs,
                                                  int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {

@@ -114,6 +114,7 @@ SIGNATURES = {
     "gh_bf_match_host": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_pairs_dev": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_bytes_dev": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "gh_bf_match_bytes_host": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "gh_bf_match_pairs_bytes_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_pairs_popc_dev": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "gh_bf_match_pairs_mfma_dev": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -166,17 +166,21 @@ class FeatureDetectorHIP : public GSLAM::FeatureDetector {
     std::lock_guard<std::mutex> lock(mu_);
     matches.clear();
     if (mask) mask->clear();
-    if (q.cols * q.elemSize() != 32 || (t.rows > 0 && t.cols * t.elemSize() != 32) || !context()) return false;
+    // descriptor width as the reference's DistanceFactory::create picks the distance by it (GSLAM/core/Vocabulary.h:565-567):
+    // 32 bytes (ORB: hamming32), 64 (hamming64), other multiples of 8 up to 256 (hamming8x)
+    const int nb = (int)(q.cols * q.elemSize());
+    if (nb < 8 || nb > 256 || nb % 8 != 0 || (t.rows > 0 && (int)(t.cols * t.elemSize()) != nb) || !context()) return false;
     const int nq = q.rows, nt = t.rows;
     if (nq == 0) return true;
+    if (nb != 32 && (nt > 65535 || nq > 65535)) return false;
     std::vector<int32_t> idx1((size_t)nq), back;
     std::vector<uint16_t> d1((size_t)nq), d2((size_t)nq), bd1, bd2;
-    if (gh_bf_match_host(ctx_, q.data, nq, t.data, nt, idx1.data(), d1.data(), d2.data()) != GH_OK)
-      return fail("gh_bf_match_host");
+    if (gh_bf_match_bytes_host(ctx_, q.data, nq, t.data, nt, nb, idx1.data(), d1.data(), d2.data()) != GH_OK)
+      return fail("gh_bf_match_bytes_host");
     if (_config.matchCrossCheck && nt > 0) {
       back.resize((size_t)nt); bd1.resize((size_t)nt); bd2.resize((size_t)nt);
-      if (gh_bf_match_host(ctx_, t.data, nt, q.data, nq, back.data(), bd1.data(), bd2.data()) != GH_OK)
-        return fail("gh_bf_match_host(back)");
+      if (gh_bf_match_bytes_host(ctx_, t.data, nt, q.data, nq, nb, back.data(), bd1.data(), bd2.data()) != GH_OK)
+        return fail("gh_bf_match_bytes_host(back)");
     }
     std::vector<uchar> keep((size_t)nq, 0);
     for (int i = 0; i < nq; ++i) {  // same integer rules as gh_match_mask_dev (tiny, host side here)

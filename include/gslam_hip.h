@@ -130,6 +130,8 @@ gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int3
  * included).  Same outputs, same first-minimum rule; nt <= 65535 train rows per call for widths other than 32. */
 gh_status gh_bf_match_bytes_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int desc_bytes,
                                 int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
+gh_status gh_bf_match_bytes_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes, int32_t* idx1,
+                                 uint16_t* d1, uint16_t* d2); /* host arrays in and out, like gh_bf_match_host */
 gh_status gh_bf_match_pairs_bytes_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int32_t* counts_dev, int cap, int desc_bytes,
                                       const int32_t* pair_q_dev, const int32_t* pair_t_dev, int npairs, int32_t* idx1_dev,
                                       uint16_t* d1_dev, uint16_t* d2_dev);

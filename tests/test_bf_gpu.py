@@ -336,3 +336,19 @@ def test_wide_descriptor_batched_pairs(ctx, oracle):
     b = m.match_pairs(torch.from_numpy(d32).cuda(), torch.from_numpy(c32).cuda(), torch.tensor([0], dtype=torch.int32).cuda(),
                       torch.tensor([1], dtype=torch.int32).cuda())
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_wide_descriptors_host_entry(ctx, oracle):
+    """gh_bf_match_bytes_host: what FeatureDetector::match of the plugin calls for descriptors that are not 32 bytes wide."""
+    import ctypes as C
+    from gslam_amd import hip
+    rng = np.random.default_rng(77)
+    for nb in (64, 24):
+        q = rng.integers(0, 256, size=(300, nb), dtype=np.uint8)
+        t = rng.integers(0, 256, size=(411, nb), dtype=np.uint8)
+        t[100:150] = q[:50]
+        idx1, d1, d2 = np.empty(300, np.int32), np.empty(300, np.uint16), np.empty(300, np.uint16)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        ctx.check(hip.lib.gh_bf_match_bytes_host(ctx.h, p(q), 300, p(t), 411, nb, p(idx1), p(d1), p(d2)))
+        e = oracle.bf_match_bytes(q, t, nb)
+        assert np.array_equal(idx1, e[0]) and np.array_equal(d1, e[1]) and np.array_equal(d2, e[2])
