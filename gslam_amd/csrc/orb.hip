@@ -106,6 +106,11 @@ struct ResizeTabs {
   const uint32_t* xsel;  // perm selector per output column
   const uint32_t* xwgt;  // fx << 16 | (2048 - fx)
   const uint32_t* ytab;  // idx << 16 | frac per output row
+  // fused MFMA resize (resize_tile_mfma): per 8-column output group g the A operand of v_mfma_f32_16x16x32_f16 for the 16 output
+  // columns 8 g .. 8 g + 15 -- A[m][k] = the weight of source column mcw[g] + k for output column 8 g + m (2048 - fx at the left
+  // tap, fx at the right one, f16) -- as 64 lanes x 4 dwords, and the window start mcw[g] = sx(8 g) & ~7.  Null: not available.
+  const uint32_t* mtab = nullptr;
+  const uint32_t* mcw = nullptr;
 };
 
 // One work item: output columns x8 .. x8 + 7, output rows y0 .. y_end - 1 (at most kResizeRows of them) of one frame.
@@ -209,6 +214,97 @@ inline uint32_t magic_div(uint32_t d, uint32_t n_max) {
   const uint64_t inv = ((1ull << 32) + d - 1) / d;   // ceil(2^32 / d)
   const uint64_t excess = inv * d - (1ull << 32);    // < d
   return (inv < (1ull << 32) && (uint64_t)n_max * excess < (1ull << 32)) ? (uint32_t)inv : 0u;
+}
+
+// The next pyramid level of an INTERIOR tile from the image tile in LDS, horizontal taps on the matrix cores (VERDICT r4 item
+// 1a; the same idea as orb_describe's blur, desc_blur_mfma).  For 16 output rows x 16 output columns:
+//     D1[m][n] = sum_k A[m][k] B1[k][n],  A = the weights of ResizeTabs::mtab (rows = output columns), B1[k][n] = f16(1024 +
+//     P[sy(y_n)][cw + k]) -- a byte OR 0x6400 --, B2 the same with row sy + 1;  C = 0.
+// The bias adds 1024 * 2048: D = 2^21 + h with h = (2048 - fx) a + fx b < 2^19, a float in [2^21, 2^22) whose bits are
+// 0x4A000000 | (h << 2) -- the low 24 bits are the integer 4 h (exact: every partial sum is an integer below 2^24).  The lane
+// holds output row n = lane & 15, output columns 4 (lane >> 4) + j: the vertical lerp is two v_mad_u32_u24 per pixel straight on
+// the accumulator bits, top byte = (h0 (2048 - fy) + h1 fy + 2^21) >> 22 as resize_item computes it, four bytes = one dword
+// store.  16 VALU per 4 output pixels become ~7 (perms of the B operands shared by 4 columns) + two MFMAs.
+// Interior: the tile's owned outputs read source rows oy .. oy + 64 and columns ax .. ax + 87 -- all inside the 72 x 96 tile,
+// none clamped.  (row block, column block) pairs are dealt round-robin to the four waves; tile = the image tile in LDS.
+__device__ __forceinline__ void resize_tile_mfma(const uint8_t* tile, int tile_pitch, int ax, int oy, uint8_t* __restrict__ d,
+                                                 int dst_pitch, const ResizeTabs& tb, int g0, int ng, int r0, int r1,
+                                                 uint32_t* __restrict__ dbg) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, n16 = lane & 15, q4 = lane >> 4;
+  // wave w = row block w (an interior tile owns at most 64 output rows), all column blocks: ONE round of global loads up front
+  // (the row's table entry, the column blocks' operands and window starts), then only LDS reads, MFMAs and the stores
+  const int rb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (r0 + 16 * rb >= r1) return;
+  const int ncb = (ng + 1) >> 1;  // <= 4
+  const int yq = r0 + 16 * rb + n16, y = yq < r1 ? yq : r1 - 1;
+  const uint32_t ty = tb.ytab[y];
+  uint4 aw[4];
+  int cwv[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int g = g0 + 2 * (cb < ncb ? cb : 0);
+    aw[cb] = *reinterpret_cast<const uint4*>(tb.mtab + ((size_t)g * 64 + lane) * 4);
+    cwv[cb] = (int)tb.mcw[g] - ax;  // tile column of the K window (a multiple of 8)
+  }
+  const int R = (int)(ty >> 16) - oy;
+  const uint32_t fy = ty & 0xFFFFu;
+  const uint32_t wy0 = 2048u - fy, wy1 = fy, c23 = 1u << 23, k64 = 0x64646464u;
+  const uint8_t* row1 = tile + R * tile_pitch + 8 * q4;
+  const uint8_t* row2 = row1 + tile_pitch;
+  const uint32_t rowoff = __umul24((uint32_t)y, (uint32_t)dst_pitch);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (2 * half >= ncb) break;
+    uint32_t u[2][4], v[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int cb = 2 * half + e;
+      const uint2 b1 = *reinterpret_cast<const uint2*>(row1 + cwv[cb]);
+      const uint2 b2 = *reinterpret_cast<const uint2*>(row2 + cwv[cb]);
+      uint4 f1, f2;
+      f1.x = __builtin_amdgcn_perm(k64, b1.x, 0x04010400u);
+      f1.y = __builtin_amdgcn_perm(k64, b1.x, 0x04030402u);
+      f1.z = __builtin_amdgcn_perm(k64, b1.y, 0x04010400u);
+      f1.w = __builtin_amdgcn_perm(k64, b1.y, 0x04030402u);
+      f2.x = __builtin_amdgcn_perm(k64, b2.x, 0x04010400u);
+      f2.y = __builtin_amdgcn_perm(k64, b2.x, 0x04030402u);
+      f2.z = __builtin_amdgcn_perm(k64, b2.y, 0x04010400u);
+      f2.w = __builtin_amdgcn_perm(k64, b2.y, 0x04030402u);
+      const f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f};
+      const f16x8 af = __builtin_bit_cast(f16x8, aw[cb]);
+      const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, f1), c0, 0, 0, 0);
+      const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, f2), c0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u[e][j] = __float_as_uint(d1[j]);
+        v[e][j] = __float_as_uint(d2[j]);
+      }
+    }
+    uint32_t o[2][4];
+    // (one asm statement for both column blocks that opens with its own wait states: the hazard recogniser does not look inside
+    //  asm, and a VALU read of an MFMA result needs up to 18 of them -- see desc_blur_mfma)
+    asm volatile(
+        "s_nop 15\n\ts_nop 2\n\t"
+        "v_mad_u32_u24 %0, %12, %25, %26\n\tv_mad_u32_u24 %1, %13, %25, %26\n\tv_mad_u32_u24 %2, %14, %25, %26\n\tv_mad_u32_u24 %3, %15, %25, %26\n\t"
+        "v_mad_u32_u24 %4, %20, %25, %26\n\tv_mad_u32_u24 %5, %21, %25, %26\n\tv_mad_u32_u24 %6, %22, %25, %26\n\tv_mad_u32_u24 %7, %23, %25, %26\n\t"
+        "v_mad_u32_u24 %0, %8, %24, %0\n\tv_mad_u32_u24 %1, %9, %24, %1\n\tv_mad_u32_u24 %2, %10, %24, %2\n\tv_mad_u32_u24 %3, %11, %24, %3\n\t"
+        "v_mad_u32_u24 %4, %16, %24, %4\n\tv_mad_u32_u24 %5, %17, %24, %5\n\tv_mad_u32_u24 %6, %18, %24, %6\n\tv_mad_u32_u24 %7, %19, %24, %7"
+        : "=&v"(o[0][0]), "=&v"(o[0][1]), "=&v"(o[0][2]), "=&v"(o[0][3]), "=&v"(o[1][0]), "=&v"(o[1][1]), "=&v"(o[1][2]), "=&v"(o[1][3])
+        : "v"(u[0][0]), "v"(u[0][1]), "v"(u[0][2]), "v"(u[0][3]), "v"(v[0][0]), "v"(v[0][1]), "v"(v[0][2]), "v"(v[0][3]),
+          "v"(u[1][0]), "v"(u[1][1]), "v"(u[1][2]), "v"(u[1][3]), "v"(v[1][0]), "v"(v[1][1]), "v"(v[1][2]), "v"(v[1][3]),
+          "v"(wy0), "v"(wy1), "s"(c23));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int cb = 2 * half + e;
+      const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[e][3], o[e][2], 0x0c0c0703u),
+                                                    __builtin_amdgcn_perm(o[e][1], o[e][0], 0x0c0c0703u), 0x05040100u);
+      const int xo = 8 * (g0 + 2 * cb) + 4 * q4;
+      if (cb < ncb && yq < r1 && xo < 8 * (g0 + ng)) *reinterpret_cast<uint32_t*>(d + (rowoff + (uint32_t)xo)) = packed;
+    }
+    if (dbg != nullptr && lane == 0) atomicAdd(&dbg[kDbgResizePasses], 1u);
+  }
 }
 
 // Inclusive prefix sum of one int per lane over the wave: four DPP row shifts scan each 16-lane row, two row broadcasts
@@ -367,6 +463,20 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     }
   }
   __syncthreads();
+  // The next pyramid level of an INTERIOR tile, now, out of the image tile (which the NMS lists overwrite after pass 2): h-taps
+  // on MFMA.  Edge tiles (first / last tile row, last tile column: they also own what lies outside every tile) keep the VALU
+  // path at the end of the kernel, which reads global memory.
+  bool resized = false;
+  if constexpr (P1 != 0) {
+    if (nx.dst_base != nullptr && nx.tb.mtab != nullptr && by > 0 && by < nby - 1 && bx < nbx - 1) {
+      const int g0 = nx.gx0[bx], ng = nx.gx0[bx + 1] - g0;
+      if (ng <= 8) {
+        resize_tile_mfma(tile, kTileW, ax, oy, nx.dst_base + (size_t)frame * nx.dst_frame_stride, nx.dst_pitch, nx.tb, g0, ng,
+                         nx.gy0[by], nx.gy0[by + 1], dbg);
+        resized = true;
+      }
+    }
+  }
 
   // Scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 18, row sy + 3.
   // Pass 1: cheap necessary condition on the 4 compass pixels (any 9-arc holds two ADJACENT compass
@@ -575,7 +685,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   // pulled through its L1 / the XCD's L2 for the tile (edge tiles also take the image border).  The pipeline is VALU-issue
   // bound and a stand-alone resize pass is memory-instruction bound, so the bilinear arithmetic rides in this kernel's idle
   // memory slots and the level is read from HBM once instead of twice.  Same arithmetic as resize_kernel (resize_item).
-  if (nx.dst_base != nullptr) {
+  if (nx.dst_base != nullptr && !resized) {
     const int g0 = nx.gx0[bx], ng = nx.gx0[bx + 1] - g0;
     const int r0 = nx.gy0[by], r1 = nx.gy0[by + 1];
     const int nq = (r1 - r0 + kResizeRows - 1) / kResizeRows;
@@ -1620,6 +1730,9 @@ struct gh_orb_plan {
   uint32_t* ytab[kMaxL]{};
   uint32_t* xsel[kMaxL]{};  // per output column: perm selector / weight pair of the horizontal lerp (ResizeTabs)
   uint32_t* xwgt[kMaxL]{};
+  uint32_t* mtab[kMaxL]{};   // MFMA resize: A operands per 8-column group of level l / window starts (ResizeTabs); null = not available
+  uint32_t* mcw[kMaxL]{};
+  bool resize_mfma = true;   // GSLAM_HIP_ORB_RESIZE_MFMA=0: the fused resize of interior tiles on the VALU as well (rounds 2-4)
   uint32_t* cell_cnt = nullptr;
   uint32_t* cell_ent = nullptr;
   SelKp* sel = nullptr;
@@ -1861,6 +1974,7 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   if (const char* e = getenv("GSLAM_HIP_ORB_PKSCORE")) p->pk_score = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_LDSPAD")) p->lds_pad = atoi(e) < 0 ? 0 : atoi(e);
   if (const char* e = getenv("GSLAM_HIP_ORB_DESC_LDSPAD")) p->desc_lds_pad = atoi(e) < 0 ? 0 : atoi(e);
+  if (const char* e = getenv("GSLAM_HIP_ORB_RESIZE_MFMA")) p->resize_mfma = atoi(e) != 0;
   if (const char* e = getenv("GSLAM_HIP_ORB_DESC_MFMA")) p->desc_mfma = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
   if (const char* e = getenv("GSLAM_HIP_ORB_PASS1")) p->pass1 = atoi(e) != 0;
   const int L = p->L = prm.n_levels;
@@ -1909,6 +2023,11 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
   // every table starts 32-byte aligned; x tables are padded to a multiple of 8 entries (pads continue with the next
   // source column, fraction 0, so that the per-thread window bounds hold), y tables to a multiple of 4 (last replicated)
   for (int l = 1; l < L; ++l) tab_words += 3 * (((size_t)p->lw[l] + 7) & ~(size_t)7) + (((size_t)p->lh[l] + 7) & ~(size_t)7);
+  // + the MFMA resize's A operands (256 words per 8-column group) and window starts (one word per group, padded to 8)
+  for (int l = 1; l < L; ++l) {
+    const size_t ngr = ((size_t)p->lw[l] + 7) / 8;
+    tab_words += ngr * 256 + ((ngr + 7) & ~(size_t)7);
+  }
   // + per source level l < L - 1: ownership of level l + 1 by the tile columns / rows of fast_cells(l), padded to 8 words
   for (int l = 0; l + 1 < L; ++l)
     tab_words += (((size_t)(p->ncx[l] + 1) / 2 + 1 + 7) & ~(size_t)7) + (((size_t)(p->ncy[l] + 1) / 2 + 1 + 7) & ~(size_t)7);
@@ -1973,6 +2092,44 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
     if (st != GH_OK) {
       gh_set_error(ctx, st, "resize table violates the 8-column window contract (level size ratio is not ~1.2)");
       break;
+    }
+    // MFMA resize tables of level l (as a destination): see ResizeTabs / resize_tile_mfma
+    for (int l = 1; l < L; ++l) {
+      const uint32_t* xt = htab.data() + (p->xtab[l] - p->tabs);
+      const int wd = p->lw[l], ngr = (wd + 7) / 8, n_src = p->lw[l - 1];
+      auto f16_of = [](int v) -> uint32_t {  // 0 <= v <= 2048: exact
+        if (v == 0) return 0u;
+        int e = 0;
+        while ((v >> (e + 1)) != 0) ++e;
+        return (uint32_t)(((e + 15) << 10) | ((v << (10 - e)) & 0x3FF));
+      };
+      uint32_t* mt = htab.data() + tw;
+      uint32_t* mc = htab.data() + tw + (size_t)ngr * 256;
+      bool ok = p->resize_mfma;
+      for (int g = 0; g < ngr; ++g) {
+        const int cw = (int)(xt[8 * g] >> 16) & ~7;
+        mc[g] = (uint32_t)cw;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, x = 8 * g + m;
+          uint32_t wds[4] = {0, 0, 0, 0};
+          if (x < wd) {
+            const int sx = (int)(xt[x] >> 16), fx = (int)(xt[x] & 0xFFFFu);
+            const int k0 = sx - cw, k1 = (sx + 1 < n_src ? sx + 1 : n_src - 1) - cw;
+            if (k0 < 0 || k1 > 31) ok = false;  // the 32-column K window must hold both taps of all 16 columns
+            for (int e = 0; e < 8; ++e) {
+              const int k = 8 * (lane >> 4) + e;
+              int wgt = 0;
+              if (k == k0) wgt += 2048 - fx;
+              if (k == k1) wgt += fx;  // (k1 == k0 at the right border, where fx = 0)
+              wds[e >> 1] |= f16_of(wgt) << (16 * (e & 1));
+            }
+          }
+          for (int e = 0; e < 4; ++e) mt[((size_t)g * 64 + lane) * 4 + e] = wds[e];
+        }
+      }
+      p->mtab[l] = ok ? p->tabs + tw : nullptr;
+      p->mcw[l] = ok ? p->tabs + tw + (size_t)ngr * 256 : nullptr;
+      tw += (size_t)ngr * 256 + (((size_t)ngr + 7) & ~(size_t)7);
     }
     // ownership of level l + 1 inside fast_cells(l): tile column bx (level-l columns 64 bx .. 64 bx + 63 plus halo) owns
     // the output 8-groups whose first source column lies in [64 bx, 64 bx + 64); tile row by (rows from 64 by + 15) the
@@ -2290,7 +2447,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       NextLevel nx{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
       if (l + 1 < L && p->fuse_pyramid)
         nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1],
-                       ResizeTabs{p->xtab[l + 1], p->xsel[l + 1], p->xwgt[l + 1], p->ytab[l + 1]},
+                       ResizeTabs{p->xtab[l + 1], p->xsel[l + 1], p->xwgt[l + 1], p->ytab[l + 1], p->mtab[l + 1], p->mcw[l + 1]},
                        p->own_gx[l], p->own_gy[l], (l == 0 && aligned0) ? batch - 1 : -1};
       const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
       GH_CHECK_ARG(ctx, tiles < (1LL << 30));
