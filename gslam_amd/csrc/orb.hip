@@ -205,6 +205,11 @@ struct NextLevel {
   // tile id -> (frame, tile row, tile column) without integer divisions: q = __umulhi(n, inv) == n / d for every tile id of
   // the launch (checked on the host: magic_div); 0 = divide (the one-launch-for-all-levels path of small calls)
   uint32_t tiles_inv = 0, nbx_inv = 0;
+  // PLANE variant of the kernel (the quadtree mode's score plane, orb_quadtree.hip): S of this level, pixel (y, x) of a frame at
+  // plane[y * plane_pitch + x + 1]
+  uint8_t* plane = nullptr;
+  size_t plane_frame_stride = 0;
+  int plane_pitch = 0;
 };
 
 // inv with __umulhi(n, inv) == n / d for every n <= n_max, or 0 when no such 32-bit constant is guaranteed
@@ -398,7 +403,7 @@ constexpr int kScoreWPk = 72;  // row pitch (bytes) of the packed-16-bit pass 1;
 // P1: formulation of pass 1 (GSLAM_HIP_ORB_PASS1, decided per plan) -- 0 = packed 16-bit min / max (rounds 2-3),
 //     1 = SWAR on 16-bit fields (full-rate and / or / sub / v_bitop3), fields split in registers.  (A variant that read the
 //     fields pre-split from LDS planes lost 22 %: 38 KB of LDS leave 4 workgroups per CU; profiles/orb_pass1_ab_r04.txt.)
-template <bool PK, int P1>
+template <bool PK, int P1, bool PLANE = false>
 __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, int ncy, int min_th, int ini_th,
                                                 uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_ent,
                                                 int cells_per_frame, int cell_off, int n_frames, const NextLevel& nx,
@@ -704,6 +709,21 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     }
   }
 
+  if constexpr (PLANE) {
+    // the quadtree mode wants S itself: the tile's 64 x 64 scores (zero outside the valid region) to the level's score plane,
+    // 16 dwords per row (score byte 68 (r + 1) + 4 + c is dword aligned at c % 4 == 0, and so is plane column x0 + 1 + c)
+    static_assert(P1 != 0, "the plane variant is written for the flat 68-byte score rows");
+    uint8_t* pl = nx.plane + (size_t)frame * nx.plane_frame_stride;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(score);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 256 * k, r = idx >> 4, cd = idx & 15;
+      if (y0 + r < lv.h && x0 + 4 * cd + 4 < nx.plane_pitch)
+        *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)(y0 + r), (uint32_t)nx.plane_pitch) + (uint32_t)(x0 + 1 + 4 * cd))) =
+            s32[17 * (r + 1) + 1 + cd];
+    }
+    return;
+  }
   // one wave per 32x32 cell
   const int wv = tid >> 6, lane = tid & 63;
   const int cx = 2 * bx + (wv & 1), cy = 2 * by + (wv >> 1);
@@ -856,7 +876,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
 }
 
 // (SWAR variant: 8 waves per SIMD -- at most 64 VGPRs -- and 20.4 KB of LDS let 8 workgroups share a CU)
-template <bool PK, int P1>
+template <bool PK, int P1, bool PLANE = false>
 __global__ __launch_bounds__(256, P1 != 0 ? GH_FAST_WAVES : 1) void fast_cells_kernel(LevelView lv, int ncx, int ncy, int min_th, int ini_th,
                                                          uint32_t* __restrict__ cell_cnt,
                                                          uint32_t* __restrict__ cell_ent, int cells_per_frame,
@@ -865,7 +885,7 @@ __global__ __launch_bounds__(256, P1 != 0 ? GH_FAST_WAVES : 1) void fast_cells_k
   const int total = ((ncx + 1) >> 1) * ((ncy + 1) >> 1) * n_frames;
   const int tile_id = xcd_strip_tile(blockIdx.x, total);
   if (tile_id >= total) return;
-  fast_cells_tile<PK, P1>(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
+  fast_cells_tile<PK, P1, PLANE>(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
 }
 
 // Every level in ONE launch, over a pyramid that exists already (stand-alone resize launches): what a small call wants --
@@ -1754,6 +1774,9 @@ struct gh_orb_plan {
   bool base_pattern_fits_table = true;  // every 12-degree rotation stays within +-13 (the 30-bin table exists)
   int distribution = 0;              // gh_orb_plan_set_distribution: 0 = 32 x 32 cells + rank order, 1 = ORB-SLAM's cells + quadtree
   gh_qt_plan* qt = nullptr;          // buffers of mode 1 (orb_quadtree.hip)
+  uint8_t* score_plane = nullptr;    // mode 1: S of every level (fast_cells_kernel<.., PLANE>), allocated with qt; GSLAM_HIP_QT_PLANE=0: cells from the image
+  size_t plane_off[kMaxL] = {}, plane_slab = 0;
+  int plane_pitch[kMaxL] = {};
   int steer = 0;                     // gh_orb_plan_set_steering: 0 = 30 orientation bins, 1 = continuous (fastAtan2 + per-keypoint rotation)
   int32_t* d_dir = nullptr;
   uint32_t* tabs = nullptr;
@@ -1942,6 +1965,19 @@ extern "C" gh_status gh_orb_plan_set_distribution(gh_orb_plan* p, int mode) {
   if (mode == 1 && !p->qt) {
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GH_TRY(gh_qt_create(ctx, p->L, p->lw, p->lh, p->quota, p->max_batch, &p->qt, &p->bytes));
+    const char* e = getenv("GSLAM_HIP_QT_PLANE");
+    if (!(e && e[0] == '0') && p->pass1 != 0 && p->pk_score) {
+      size_t off = 0;
+      for (int l = 0; l < p->L; ++l) {
+        p->plane_pitch[l] = p->pitch[l] + 64;
+        p->plane_off[l] = off;
+        off += (size_t)p->plane_pitch[l] * p->lh[l];
+      }
+      p->plane_slab = (off + 255) & ~(size_t)255;
+      GH_TRY(plan_alloc(p, (size_t)p->max_batch * p->plane_slab, (void**)&p->score_plane));
+      GH_HIP(ctx, hipMemsetAsync(p->score_plane, 0, (size_t)p->max_batch * p->plane_slab, ctx->stream));
+      GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
   }
   p->distribution = mode;
   return GH_OK;
@@ -2351,11 +2387,16 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   bool overlap = overlap_env < 0 ? (long long)batch * p->w * p->h >= (16LL << 20) : overlap_env == 1;  // >= 8 frames of 1080p
+  // (quadtree mode from the score plane: the cells of level l run on the same side stream beside the tile kernel of level l + 1)
+  // -- measured: 2.30 ms per 100 x 1080p against 2.23 on one stream (the two kernels do not overlap on this part, the events
+  // cost); kept behind GSLAM_HIP_QT_SIDE=1
+  static const bool qt_side_env = [] { const char* e = getenv("GSLAM_HIP_QT_SIDE"); return e && e[0] == '1'; }();
+  bool qt_side = qt_side_env && p->distribution != 0 && p->score_plane != nullptr && !p->capturing && overlap;
   if (p->capturing || p->distribution != 0) overlap = false;  // (a captured call is a small one: one select launch)
-  if (overlap && !p->side) {
+  if ((overlap || qt_side) && !p->side) {
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
       p->side = nullptr;
-      overlap = false;
+      overlap = qt_side = false;
     } else {
       bool ok = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
       for (int l = 0; l < kMaxL && ok; ++l) ok = hipEventCreateWithFlags(&p->ev_level[l], hipEventDisableTiming) == hipSuccess;
@@ -2378,8 +2419,57 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
   if (quadtree) {
     // ORB-SLAM's distribution (oracle steps 4', 5'): the whole pyramid first, then cells + tree of orb_quadtree.hip leave sel /
     // level_cnt as orb_select would
-    for (int l = 1; l < L; ++l) GH_TRY(resize_standalone(l));
-    GH_TRY(gh_qt_enqueue(ctx, p->qt, lv, batch, p->prm.min_th_fast, p->prm.ini_th_fast, p->quota_off, K, p->sel, p->level_cnt));
+    LevelView planes[kMaxL];
+    for (int l = 0; l < kMaxL; ++l) planes[l] = LevelView{nullptr, 0, 0, 0, 0};
+    if (p->score_plane != nullptr) {
+      // S of every level by the default mode's tile kernel (plane variant: no cell stage), the next level fused as there; a
+      // level whose cells do not fit the wave-per-cell kernel keeps the image path of orb_quadtree.hip.  The cells of level l
+      // (latency bound: LDS round trips per cell) run on the side stream beside the tile kernel of level l + 1 (VALU bound).
+      const bool side_ok = qt_side && p->side != nullptr && !dbg;
+      GH_TRY(gh_qt_begin(ctx, p->qt, batch));
+      auto cells_of = [&](int l, const LevelView* plane) -> gh_status {
+        if (!side_ok) return gh_qt_cells(ctx, p->qt, l, lv[l], plane, batch, p->prm.min_th_fast, p->prm.ini_th_fast);
+        GH_HIP(ctx, hipEventRecord(p->ev_level[l], ctx->stream));  // level l's image / plane (and the cleared counters) exist
+        GH_HIP(ctx, hipStreamWaitEvent(p->side, p->ev_level[l], 0));
+        StreamSwap sw(ctx, p->side);
+        return gh_qt_cells(ctx, p->qt, l, lv[l], plane, batch, p->prm.min_th_fast, p->prm.ini_th_fast);
+      };
+      for (int l = 0; l < L; ++l) {
+        const bool plane = p->ncx[l] != 0 && gh_qt_plane_ok(p->qt, l);
+        if (!plane) {
+          GH_TRY(cells_of(l, nullptr));
+          if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
+          continue;
+        }
+        NextLevel nx{nullptr, 0, 0, 0, ResizeTabs{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};
+        if (l + 1 < L && p->fuse_pyramid)
+          nx = NextLevel{p->pyr + p->lvl_off[l + 1], p->slab, p->pitch[l + 1], p->lh[l + 1],
+                         ResizeTabs{p->xtab[l + 1], p->xsel[l + 1], p->xwgt[l + 1], p->ytab[l + 1], p->mtab[l + 1], p->mcw[l + 1]},
+                         p->own_gx[l], p->own_gy[l], (l == 0 && aligned0) ? batch - 1 : -1};
+        nx.plane = p->score_plane + p->plane_off[l];
+        nx.plane_frame_stride = p->plane_slab;
+        nx.plane_pitch = p->plane_pitch[l];
+        const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
+        GH_CHECK_ARG(ctx, tiles < (1LL << 30));
+        const uint32_t nbx = (uint32_t)gh_div_up(p->ncx[l], 2), tpf = nbx * (uint32_t)gh_div_up(p->ncy[l], 2);
+        nx.tiles_inv = magic_div(tpf, (uint32_t)tiles);
+        nx.nbx_inv = magic_div(nbx, tpf);
+        GH_LAUNCH(ctx, "orb_fast_plane", (fast_cells_kernel<true, 1, true>), dim3(8 * gh_div_up(tiles, 8)), dim3(256), p->lds_pad, lv[l],
+                  p->ncx[l], p->ncy[l], p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame,
+                  p->cell_off[l], batch, nx, dbg);
+        if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
+        planes[l] = LevelView{p->score_plane + p->plane_off[l], p->plane_slab, p->plane_pitch[l], p->lw[l], p->lh[l]};
+        GH_TRY(cells_of(l, &planes[l]));
+      }
+      if (side_ok) {
+        GH_HIP(ctx, hipEventRecord(p->ev_join, p->side));
+        GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->ev_join, 0));
+      }
+      GH_TRY(gh_qt_tree(ctx, p->qt, batch, p->quota_off, K, p->sel, p->level_cnt));
+    } else {
+      for (int l = 1; l < L; ++l) GH_TRY(resize_standalone(l));
+      GH_TRY(gh_qt_enqueue(ctx, p->qt, lv, batch, p->prm.min_th_fast, p->prm.ini_th_fast, p->quota_off, K, p->sel, p->level_cnt, planes));
+    }
     overlap = false;
   } else if (all_levels) {
     for (int l = 1; l < L; ++l) GH_TRY(resize_standalone(l));

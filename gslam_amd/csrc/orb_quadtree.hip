@@ -247,6 +247,181 @@ __global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, i
   }
 }
 
+// step 4' from a SCORE PLANE (round 5): orb.hip's 64 x 64 tile kernel -- the default mode's FAST passes: SWAR compass test,
+// packed arc scores, the next pyramid level fused -- writes S (oracle step 2 / 3: the score where it exceeds min_th, else 0)
+// for the whole level (fast_cells_kernel<.., PLANE>), and a wave per cell only does what the cell decides: 8-neighbour
+// suppression against a zero border, the 20 -> 7 fallback, the key list.  The oracle is written the same way
+// (oracle_orb_slam_candidates reads S).  Against slam_cells_wave_kernel the image is read once per level instead of 1.44
+// times (36 x 36 tiles for 30 x 30 cells), the compass test runs 4 pixels per instruction, and seven resize launches go.
+// Plane pixel (y, x) of a frame lives at plane[y * pitch + x + 1] (the + 1 makes the tile kernel's rows dword aligned).
+constexpr int kPSPitch = 48;  // LDS score rows: a zero dword, up to nine data dwords, slack
+constexpr int kPlaneCellsPerWave = 4;  // cells a wave takes one after the other (see the slot reservation below)
+constexpr int kPlaneOut = 128;         // kept keys a wave buffers before it must reserve slots by itself
+struct PlaneCellLds {
+  __attribute__((aligned(16))) uint32_t S[(kWcMax + 2) * (kPSPitch / 4)];  // rows -1 .. 32 of the cell, zero outside it: 1632 B
+  uint16_t queue[kWcMax * kWcMax];            // the cell's scored pixels, (y << 5) | x
+  uint32_t list[(kWcMax / 2) * (kWcMax / 2)];  // its suppressed maxima (pairwise non-adjacent: at most 16 x 16)
+  uint32_t obuf[kPlaneOut];                   // kept keys of the wave's cells until the workgroup reserves their slots
+};
+static_assert(sizeof(PlaneCellLds) * 4 <= 160 * 1024 / 7, "seven workgroups per CU");
+
+// SLOT RESERVATION.  Every cell of a (frame, level) appends to one key list through one counter; with a returning atomic per
+// cell -- 2108 cells of a 1080p level 0 on ONE address -- the atomics were two thirds of the kernel (1.54 ms of which 1.04 ms,
+// measured by replacing the reservation with fixed slots).  So a workgroup takes 16 cells (4 waves x 4 cells, one after the
+// other), every wave buffers what its cells keep, and ONE atomic per workgroup reserves the slots of all of them (the order of
+// the keys is irrelevant: every later step is a function of the key set).  A wave whose buffer fills up (> 128 kept keys in
+// four cells: dense noise) reserves for itself and goes on.
+__global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, int ncols, int ncells, int wc, int hc, int ini_th,
+                                                               uint32_t* __restrict__ keys, size_t keys_per_frame, uint32_t cap,
+                                                               uint32_t* __restrict__ key_cnt, int level,
+                                                               uint32_t* __restrict__ flags) {
+  __shared__ PlaneCellLds sh[4];
+  __shared__ uint32_t wave_tot[4], wg_base;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.y;
+  PlaneCellLds& L = sh[wv];
+  const uint8_t* plane = pl.base + (size_t)b * pl.frame_stride;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint32_t* out = keys + (size_t)b * keys_per_frame;
+  uint32_t* list = L.list;
+  int nout = 0;  // keys in L.obuf (wave-uniform)
+  auto put_out = [&](uint32_t base, int count) {  // obuf[0 .. count) -> out[base ..]
+    for (int e = lane; e < count; e += 64) {
+      const uint32_t slot = base + (uint32_t)e;
+      if (slot < cap) out[slot] = L.obuf[e];
+      else atomicOr(flags, 1u);  // reported by gh_qt_check: never a silent drop
+    }
+  };
+  for (int cc = 0; cc < kPlaneCellsPerWave; ++cc) {
+    const int cell = ((int)blockIdx.x * 4 + wv) * kPlaneCellsPerWave + cc;
+    if (cell >= ncells) break;  // (wave-uniform)
+    const int ci = cell / ncols, cj = cell - ci * ncols;
+    const int x0 = kEdge + cj * wc, y0 = kEdge + ci * hc;
+    const int x1 = min(x0 + wc, pl.w - kEdge), y1 = min(y0 + hc, pl.h - kEdge);
+    const int cw = x1 - x0, ch = y1 - y0;
+    if (cw <= 0 || ch <= 0) continue;
+    // rows y0 .. y1 - 1 as the aligned dwords that cover plane bytes x0 + 1 .. x1; bytes of neighbouring cells masked to zero.
+    // All (at most five) loads of a lane are asked for at once, the LDS plane is cleared under them.
+    const int xa = (x0 + 1) & ~3, al = (x0 + 1) & 3;
+    const int ndw = (al + cw + 3) >> 2;  // <= 9
+    uint32_t vv[5];
+    int slot[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int idx = lane + 64 * t;
+      const int r = (int)(__umul24((uint32_t)idx, 7282u) >> 16), d = idx - r * 9;  // idx / 9: exact for idx < 320 (7282 / 65536 - 1 / 9 = 1.7e-6)
+      const bool on = idx < ch * 9 && d < ndw;
+      const int rc = on ? r : 0, dc = on ? d : 0;  // (clamped: a load without a branch around it)
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(plane + (__umul24((uint32_t)(y0 + rc), (uint32_t)pl.pitch) + (uint32_t)(xa + 4 * dc)));
+      const int lo = al - 4 * dc, hi = al + cw - 4 * dc;  // keep bytes lo <= k < hi
+      uint32_t m = 0xFFFFFFFFu;
+      if (lo > 0) m &= lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
+      if (hi < 4) m &= hi <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - hi)));
+      vv[t] = v & m;
+      slot[t] = on ? (rc + 1) * (kPSPitch / 4) + 1 + dc : -1;
+    }
+    {
+      uint4* s4 = reinterpret_cast<uint4*>(L.S);
+      static_assert(sizeof(L.S) % 16 == 0, "cleared by 16-byte stores");
+      for (int idx = lane; idx < (int)(sizeof(L.S) / 16); idx += 64) s4[idx] = uint4{0u, 0u, 0u, 0u};
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+      if (slot[t] >= 0) L.S[slot[t]] = vv[t];
+    __builtin_amdgcn_wave_barrier();
+    uint8_t* S = reinterpret_cast<uint8_t*>(L.S) + kPSPitch + 4 + al;  // score of cell pixel (0, 0)
+    // the scored pixels: lane = (row, half), 16 bytes each; positions appended by a prefix sum over the lanes' counts
+    int nq = 0;
+    {
+      const int r = lane >> 1, c0 = 16 * (lane & 1);
+      uint32_t nzb = 0;
+      if (r < ch && c0 < cw) {
+        const uint32_t* q = L.S + (r + 1) * (kPSPitch / 4) + 1 + ((al + c0) >> 2);
+        const uint32_t shb = (uint32_t)(al & 3);  // (c0 is a multiple of 4: the byte offset inside the dword is al)
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        const uint32_t w4[4] = {__builtin_amdgcn_alignbyte(d1, d0, shb), __builtin_amdgcn_alignbyte(d2, d1, shb),
+                                __builtin_amdgcn_alignbyte(d3, d2, shb), __builtin_amdgcn_alignbyte(d4, d3, shb)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = w4[j];
+          const uint32_t f = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7) & 0x01010101u;  // byte k -> 1 if non-zero
+          nzb |= __builtin_amdgcn_udot4(f, 0x08040201u, 0u, false) << (4 * j);
+        }
+      }
+      const int cnt = __popc(nzb);
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      nq = __shfl(incl, 63);
+      int pos = incl - cnt;
+      const uint32_t rc0 = (uint32_t)((r << 5) | c0);
+      while (nzb) {
+        const int k = __ffs((int)nzb) - 1;
+        L.queue[pos++] = (uint16_t)(rc0 + (uint32_t)k);
+        nzb &= nzb - 1u;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 8-neighbour suppression inside the cell (the border of the score plane is zero: pixels outside the cell do not compete)
+    int n = 0;
+    bool strong = false;
+    for (int base = 0; base < nq; base += 64) {
+      const int i = base + lane;
+      bool ismax = false;
+      uint32_t key = 0;
+      int sc = 0;
+      if (i < nq) {
+        const int yx = L.queue[i], y = yx >> 5, x = yx & 31;
+        const uint8_t* sp = S + y * kPSPitch + x;
+        sc = sp[0];
+        const int n0 = sp[-kPSPitch - 1], n1 = sp[-kPSPitch], n2 = sp[-kPSPitch + 1], n3 = sp[-1], n4 = sp[1],
+                  n5 = sp[kPSPitch - 1], n6 = sp[kPSPitch], n7 = sp[kPSPitch + 1];
+        ismax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7))) < sc;
+        key = ((uint32_t)sc << 24) | ((uint32_t)(y0 + y) << 12) | (uint32_t)(x0 + x);
+      }
+      const uint64_t m = __ballot(ismax);
+      if (ismax) list[n + __popcll(m & lt_mask)] = key;
+      n += __popcll(m);
+      strong = strong || __ballot(ismax && sc > ini_th) != 0ull;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // a strong corner silences the weak ones of the cell; what is kept goes to the wave's buffer
+    for (int base = 0; base < n; base += 64) {
+      const int e = base + lane;
+      const uint32_t v = e < n ? list[e] : 0u;
+      const bool keep = e < n && (!strong || (int)(v >> 24) > ini_th);
+      const uint64_t m = __ballot(keep);
+      const int kc = __popcll(m);
+      if (nout + kc > kPlaneOut) {  // (wave-uniform) the buffer is full: this wave reserves the slots of what it holds
+        uint32_t base0 = 0;
+        if (lane == 0) base0 = atomicAdd(&key_cnt[b * kMaxL + level], (uint32_t)nout);
+        base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0);
+        __builtin_amdgcn_wave_barrier();
+        put_out(base0, nout);
+        __builtin_amdgcn_wave_barrier();
+        nout = 0;
+      }
+      if (keep) L.obuf[nout + __popcll(m & lt_mask)] = v;
+      nout += kc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // one reservation for the workgroup's (up to) 16 cells
+  if (lane == 0) wave_tot[wv] = (uint32_t)nout;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    wg_base = tot ? atomicAdd(&key_cnt[b * kMaxL + level], tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t base0 = wg_base;
+  for (int k = 0; k < wv; ++k) base0 += wave_tot[k];
+  put_out(base0, nout);
+}
+
 // step 4', any cell size: one workgroup per cell
 __global__ __launch_bounds__(256) void slam_cells_kernel(LevelView lv, int ncols, int wc, int hc, int min_th, int ini_th,
                                                          uint32_t* __restrict__ keys, size_t keys_per_frame,
@@ -695,32 +870,51 @@ gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, 
   return GH_OK;
 }
 
-gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int batch, int min_th, int ini_th,
-                        const int* quota_off, int K, SelKp* sel, int32_t* level_cnt) {
+// The three parts of gh_qt_enqueue, for a caller that wants the cells of level l on another stream than the kernel that
+// produces level l + 1 (orb.hip): begin (counters), cells of one level, tree.  All on ctx->stream at the time of the call.
+gh_status gh_qt_begin(gh_ctx* ctx, gh_qt_plan* q, int batch) {
   GH_CHECK_ARG(ctx, q && batch >= 1 && batch <= q->max_batch);
-  for (int l = 0; l < q->L; ++l) GH_CHECK_ARG(ctx, q->args.lv[l].quota == 0 || q->args.lv[l].quota_off == quota_off[l]);
   if (!q->attr_set) {
     GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(slam_quadtree_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(QtShared)));
     q->attr_set = true;
   }
   GH_HIP(ctx, hipMemsetAsync(q->key_cnt, 0, ((size_t)batch * kMaxL) * 4, ctx->stream));
-  uint32_t* flags = q->key_cnt + (size_t)q->max_batch * kMaxL;
-  for (int l = 0; l < q->L; ++l) {
-    const QtLevel& v = q->args.lv[l];
-    if (v.quota <= 0) continue;
-    static const bool wave_cells = getenv("GSLAM_HIP_QT_WAVE_CELLS") == nullptr || atoi(getenv("GSLAM_HIP_QT_WAVE_CELLS")) != 0;  // (A/B switch)
-    if (wave_cells && v.wc <= kWcMax && v.hc <= kWcMax && (lv[l].pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(lv[l].base) & 3) == 0 &&
-        (lv[l].frame_stride & 3) == 0)
-      GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_wave_kernel, dim3(gh_div_up(v.ncols * v.nrows, 4), batch), dim3(256), 0, lv[l], v.ncols,
-                v.ncols * v.nrows, v.wc, v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
-    else
-      GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_kernel, dim3(v.ncols * v.nrows, batch), dim3(256), 0, lv[l], v.ncols, v.wc,
-                v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
-  }
-  GH_LAUNCH(ctx, "orb_slam_quadtree", slam_quadtree_kernel, dim3(q->L, batch), dim3(kQtThreads), sizeof(QtShared), q->args,
-            q->keys, q->knode, q->keys_per_frame, q->key_cnt, K, sel, level_cnt);
   return GH_OK;
+}
+
+gh_status gh_qt_cells(gh_ctx* ctx, gh_qt_plan* q, int l, const LevelView& img, const LevelView* plane, int batch, int min_th, int ini_th) {
+  uint32_t* flags = q->key_cnt + (size_t)q->max_batch * kMaxL;
+  const QtLevel& v = q->args.lv[l];
+  if (v.quota <= 0) return GH_OK;
+  static const bool wave_cells = getenv("GSLAM_HIP_QT_WAVE_CELLS") == nullptr || atoi(getenv("GSLAM_HIP_QT_WAVE_CELLS")) != 0;  // (A/B switch)
+  if (plane != nullptr && plane->base != nullptr) {  // the level's score plane exists (gh_qt_plane_ok): cells from it
+    GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_plane_kernel, dim3(gh_div_up(v.ncols * v.nrows, 4 * kPlaneCellsPerWave), batch), dim3(256),
+              0, *plane, v.ncols, v.ncols * v.nrows, v.wc, v.hc, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l,
+              flags);
+  } else if (wave_cells && v.wc <= kWcMax && v.hc <= kWcMax && (img.pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(img.base) & 3) == 0 &&
+             (img.frame_stride & 3) == 0) {
+    GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_wave_kernel, dim3(gh_div_up(v.ncols * v.nrows, 4), batch), dim3(256), 0, img, v.ncols,
+              v.ncols * v.nrows, v.wc, v.hc, min_th, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
+  } else {
+    GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_kernel, dim3(v.ncols * v.nrows, batch), dim3(256), 0, img, v.ncols, v.wc, v.hc, min_th,
+              ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l, flags);
+  }
+  return GH_OK;
+}
+
+gh_status gh_qt_tree(gh_ctx* ctx, gh_qt_plan* q, int batch, const int* quota_off, int K, SelKp* sel, int32_t* level_cnt) {
+  for (int l = 0; l < q->L; ++l) GH_CHECK_ARG(ctx, q->args.lv[l].quota == 0 || q->args.lv[l].quota_off == quota_off[l]);
+  GH_LAUNCH(ctx, "orb_slam_quadtree", slam_quadtree_kernel, dim3(q->L, batch), dim3(kQtThreads), sizeof(QtShared), q->args, q->keys,
+            q->knode, q->keys_per_frame, q->key_cnt, K, sel, level_cnt);
+  return GH_OK;
+}
+
+gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int batch, int min_th, int ini_th,
+                        const int* quota_off, int K, SelKp* sel, int32_t* level_cnt, const LevelView* planes) {
+  GH_TRY(gh_qt_begin(ctx, q, batch));
+  for (int l = 0; l < q->L; ++l) GH_TRY(gh_qt_cells(ctx, q, l, lv[l], planes ? &planes[l] : nullptr, batch, min_th, ini_th));
+  return gh_qt_tree(ctx, q, batch, quota_off, K, sel, level_cnt);
 }
 
 gh_status gh_qt_check(gh_ctx* ctx, gh_qt_plan* q) {
@@ -734,4 +928,9 @@ gh_status gh_qt_check(gh_ctx* ctx, gh_qt_plan* q) {
                         "key budget holds for this batch size; use a smaller max_batch)");
   }
   return GH_OK;
+}
+
+// whether level l's cells can be taken from a score plane (cells of at most 32 x 32: every level but very narrow ones)
+bool gh_qt_plane_ok(const gh_qt_plan* q, int l) {
+  return q && l >= 0 && l < q->L && q->args.lv[l].quota > 0 && q->args.lv[l].wc <= kWcMax && q->args.lv[l].hc <= kWcMax;
 }
