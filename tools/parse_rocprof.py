@@ -20,7 +20,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "select_kernel": "orb_select",
-         "describe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "bf_match_pairs_mfma_kernel": "bf_match_pairs_mfma", "synth_kernel": "synth_frames",
+         "describe_kernel": "orb_describe", "describe_pipe_kernel": "orb_describe", "bf_match_pairs_kernel": "bf_match_pairs", "bf_match_pairs_mfma_kernel": "bf_match_pairs_mfma", "synth_kernel": "synth_frames",
          "syrk_mfma_kernel": "ba_syrk", "panel_step_kernel": "ba_panel_step", "potf2_inv_kernel": "ba_potf2", "trsm_inv_kernel": "ba_trsm",
          "schur_blocks_kernel": "ba_schur_blocks", "schur_reduce_kernel": "ba_schur_reduce",
          "lin_kernel": "ba_lin", "lin_cams_reduce_kernel": "ba_lin_cams_reduce",
@@ -28,7 +28,10 @@ NAMES = {"fast_cells_kernel": "orb_fast_cells", "resize_kernel": "orb_resize", "
          "potrf_flow_kernel": "ba_potrf_flow", "bwd_chain_kernel": "ba_trsv_bwd (single launch)",
          "cr_factor_kernel": "ba_cr_factor", "cr_panels_kernel": "ba_cr_panels (+ ba_cr_inverse)",
          "cr_update_kernel": "ba_cr_update (+ ba_cr_backprep)", "cr_back_kernel": "ba_cr_back",
-         "schur_blocks_init_kernel": "ba_schur_blocks (+ seed of S)"}
+         "schur_blocks_init_kernel": "ba_schur_blocks (+ seed of S)",
+         "cr_border_update_kernel": "ba_cr_border_update", "cr_border_syrk_kernel": "ba_cr_border_syrk",
+         "cr_border_syrk_reduce_kernel": "ba_cr_border_syrk_reduce", "cr_border_gather_kernel": "ba_cr_border_gather",
+         "cr_border_back_kernel": "ba_cr_border_back", "cr_border_yh_kernel": "ba_cr_border_yh"}
 
 
 def short(name):
