@@ -1895,7 +1895,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     if (cr_T) {
       GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n_band, cr_T)));
       GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n_band, cr_T)));
-      if (n_band < n) GH_TRY(db.alloc(&S.d_arrow_ws, gh_arrow_ws_doubles(ctx, n_band, cr_T, n - n_band)));
+      // (band-only systems too: the reduction's last levels go to the dense path -- chol_cr.hip, DENSE TOP)
+      GH_TRY(db.alloc(&S.d_arrow_ws, gh_arrow_ws_doubles(ctx, n_band, cr_T, n - n_band)));
     }
     if (opt.verbose)
       fprintf(stderr, "[gh_ba] band cameras of a point at most %d indices apart, %d border cameras: half-bandwidth %d of n = %d -> %s\n",
@@ -2090,18 +2091,16 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const double t_solve0 = now_ms();
     // (one single-launch factorisation at a time per process, until this iteration's synchronisation: see chol.hip)
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
-    if ((d_flow && !cr_T) || (cr_T && n_band < n)) flow_lock.lock();  // (arrowhead: its dense corner may run as the single-launch factorisation)
+    if (d_flow || cr_T) flow_lock.lock();  // (band / arrowhead: the dense top may run as the single-launch factorisation)
     // The whole candidate step is enqueued without waiting for the factorisation flags (the kernels have no
     // data-dependent control flow, so a failed factorisation only produces numbers that are then ignored): one host
     // synchronisation per iteration instead of three.
     // rhs -> row n of S: already there when schur_init_kernel + schur_reduce_kernel wrote it
     if (!(slim_init && opt.deterministic))
       GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
-    if (cr_T && n_band < n) {
+    if (cr_T) {  // (n_band == n: a band without a border)
       GH_TRY(gh_arrow_solve_dev_impl(ctx, d_S, n_band, n - n_band, lda, cr_T, d_cr_dinv, d_cr_W, S.d_arrow_ws, d_dc, d_info,
                                      solve_state_ready));
-    } else if (cr_T) {
-      GH_TRY(gh_cr_solve_dev_impl(ctx, d_S, n, lda, cr_T, d_cr_dinv, d_cr_W, d_dc, d_info, solve_state_ready));
     } else {
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place

@@ -37,6 +37,7 @@ gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, do
 size_t gh_potrf_flow_words(const gh_ctx* ctx, int n, int extra_rows);
 size_t gh_potrf_flow_flag_words(int n, int extra_rows);
 std::mutex& gh_potrf_flow_mutex(int device);
+int gh_cr_top(int nbr);
 
 namespace {
 
@@ -77,6 +78,9 @@ struct CrArgs {
   // Arrowhead systems (band + dense border, cr_arrow_solve_t below): `nbr` border rows a.n .. a.n + nbr - 1 lie under the band
   // and the right-hand side is row rr = a.n + nbr (band-only systems: nbr = 0, rr = n -- the layout of rounds 1-4)
   int rr = 0, nbr = 0;
+  // DENSE TOP (cr_solve_t): the reduction stops when at most gh_cr_top(nbr) superblocks survive -- 0, keep, 2 keep, ... -- and the
+  // block tridiagonal system they form (+ the border) goes to chol.hip's dense path; keep >= N: only superblock 0 survives
+  int keep = 1 << 30;
 };
 
 // compile-time loop: f(std::integral_constant<int, K>) for K = 0 .. N - 1 (a runtime loop around the potf2 code is not
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
   if (e >= a.count) return;
   // (a.s == 0: every eliminated superblock of every level, i = 1 .. N - 1 -- only the identity strips are run that way)
   const int i = a.s == 0 ? 1 + e : a.first + e * 2 * a.s, i0 = i * m_, n = a.n;
+  if (a.s == 0 && (i & (a.keep - 1)) == 0) return;  // a survivor of the dense top: never eliminated, no L_i
   const size_t lda = (size_t)a.lda;
   const double* const A = a.A;
   // forward launches: tasks 0 .. 4T-1 side u, 4T .. 8T-1 side d, 8T the right-hand side, from 8T + 1 side 4 = a 16-row strip of
@@ -544,6 +549,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
     const int c = 16 * (task - (ntask - NV)) + (tid & 15), tg = tid >> 4;
     const int j = grp * 2 * a.s;             // survivor
     const int i = elim_task ? 1 + grp : 0;   // eliminated (mode 1 runs over the superblocks of every level)
+    if (elim_task && (i & (a.keep - 1)) == 0) return;  // (a survivor of the dense top; uniform, before the barrier)
     double sum = 0.0;
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
   size_t ldo;
   if (elim_task) {
     const int i = 1 + grp, si = i & -i;  // eliminated at the level of stride si
+    if ((i & (a.keep - 1)) == 0) return;         // (a survivor of the dense top)
     const int side = tile / (T * T), f = tile - side * (T * T);
     const int nb = side == 0 ? i - si : i + si;
     if (nb < 0 || nb >= a.N) return;
@@ -847,8 +854,8 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
 // enough chunks that tiles x chunks fill the chip when the corner has few tiles (C4 + 20 loop closures: 21 tiles)
 struct BorderChunks { int kc, n; };
 inline BorderChunks border_chunks(int n_band, int m, int nbr) {
-  const int K = n_band > m ? n_band - m : 0;
-  if (K == 0) return BorderChunks{16, 0};
+  const int K = n_band > m ? n_band : 0;  // (the chunks run over every band column; the survivors' columns are skipped in the kernel)
+  if (K == 0 || nbr == 0) return BorderChunks{16, 0};
   const int ntr = (nbr + 1 + 63) / 64, ntiles = ntr * (ntr + 1) / 2;
   int want = (K + 16 * m - 1) / (16 * m);
   const int fill = (1024 + ntiles - 1) / ntiles;
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt
 }
 
 // The corner: partial[chunk][tile] = sum over the chunk's columns k of Yx[rows of the tile][k] Yx[cols of the tile][k], Yx = rows
-// n .. rr of A (the border rows and the right-hand side), k from m (superblock 0 stays) to n.  Tiles of 64 x 64 over the lower
+// n .. rr of A (the border rows and the right-hand side), k over the columns of every ELIMINATED superblock.  Tiles of 64 x 64 over the lower
 // triangle of the (nbr + 1) x nbr corner, four waves = 2 x 2 blocks of 32 x 32.
 template <int T>
 __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int kcols, int ntiles, double* __restrict__ part) {
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int kcols
   const int n = a.n, next = a.nbr + 1;
   const size_t lda = (size_t)a.lda;
   const double* const A = a.A;
-  const int k0 = m_ + chunk * kcols, k1 = k0 + kcols < n ? k0 + kcols : n;
+  const int k0 = chunk * kcols, k1 = k0 + kcols < n ? k0 + kcols : n;
   double4_t acc[2][2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -936,6 +943,7 @@ __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int kcols
     co[b] = n + (c < next ? c : next - 1);
   }
   for (int k = k0; k < k1; k += 16) {
+    if ((((k / m_)) & (a.keep - 1)) == 0) continue;  // (uniform) a survivor's columns hold E_j, not Y: they join the dense system
     double av[4][2], bv[4][2];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -991,13 +999,15 @@ __global__ __launch_bounds__(256) void cr_border_syrk_reduce_kernel(CrArgs a, in
   a.A[(size_t)(n + col) * lda + n + row] -= sum;
 }
 
-// The dense system that is left: superblock 0 (reduced, not factored) and the border, with the right-hand side as row qn.
+// The dense system that is left: the surviving superblocks 0, keep, 2 keep, ... (reduced, not factored; block tridiagonal among
+// themselves: D_j, B(j + keep, j), zeros elsewhere -- written, not read: A is only defined where the reduction put something),
+// then the border, with the right-hand side as row qn.  qb = band unknowns that survive (only the last survivor can be partial).
 // M is qn x qn column-major with pitch ldq; element (r, c), r >= c.
 template <int T>
-__global__ void cr_border_gather_kernel(CrArgs a, double* __restrict__ M, int ldq, unsigned* __restrict__ flow_flags, unsigned n_flow,
+__global__ void cr_border_gather_kernel(CrArgs a, int qb, double* __restrict__ M, int ldq, unsigned* __restrict__ flow_flags, unsigned n_flow,
                                         unsigned* __restrict__ xh_words, unsigned n_xh) {
   constexpr int m_ = NBI * T;
-  const int c = (int)blockIdx.x, qn = m_ + a.nbr, n = a.n;
+  const int c = (int)blockIdx.x, qn = qb + a.nbr, n = a.n;
   if (c >= qn) {  // the workgroups behind the columns clear what the single-launch solve kernels need (as ba.hip's schur_reduce does)
     const unsigned i0 = (unsigned)(c - qn) * blockDim.x + threadIdx.x, step = (gridDim.x - (unsigned)qn) * blockDim.x;
     for (unsigned i = i0; i < n_flow; i += step) flow_flags[i] = 0u;
@@ -1005,27 +1015,39 @@ __global__ void cr_border_gather_kernel(CrArgs a, double* __restrict__ M, int ld
     return;
   }
   const size_t lda = (size_t)a.lda;
-  const size_t src_col = c < m_ ? (size_t)c : (size_t)(n + c - m_);
+  const int keep = a.keep < a.N ? a.keep : a.N;  // (keep >= N: one survivor; the products below stay small)
+  const int jc = c < qb ? c / m_ : -1;            // survivor index of the column (-1: a border column)
+  const size_t src_col = c < qb ? (size_t)jc * keep * m_ + (size_t)(c - jc * m_) : (size_t)(n + c - qb);
   for (int r = c + (int)threadIdx.x; r <= qn; r += (int)blockDim.x) {
-    const size_t src_row = r < m_ ? (size_t)r : (r < qn ? (size_t)(n + r - m_) : (size_t)a.rr);
-    M[(size_t)c * ldq + r] = a.A[src_col * lda + src_row];
+    double v = 0.0;
+    if (r < qb) {
+      const int jr = r / m_;
+      if (jr - jc <= 1) v = a.A[src_col * lda + (size_t)jr * keep * m_ + (size_t)(r - jr * m_)];
+    } else {
+      v = a.A[src_col * lda + (r < qn ? (size_t)(n + r - qb) : (size_t)a.rr)];
+    }
+    M[(size_t)c * ldq + r] = v;
   }
 }
 
-// x_0 and x_c out of the dense solution; t[k] = sum_r x_c[r] Y[r][k] for the columns k >= m of the band (one wave per column)
+// The survivors' x and x_c out of the dense solution; t[k] = sum_r x_c[r] Y[r][k] for the columns k of the eliminated superblocks
+// (one wave per column)
 template <int T>
-__global__ __launch_bounds__(256) void cr_border_back_kernel(CrArgs a, const double* __restrict__ xq, double* __restrict__ tvec) {
+__global__ __launch_bounds__(256) void cr_border_back_kernel(CrArgs a, int qb, const double* __restrict__ xq, double* __restrict__ tvec) {
   constexpr int m_ = NBI * T;
   const int n = a.n, lane = threadIdx.x & 63;
   const int k = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // k < n: a column of the band; n <= k < n + nbr: a border unknown
   if (k >= n + a.nbr) return;
-  if (k < m_ || k >= n) {  // superblock 0 and the border: x is final
-    if (lane == 0) a.x[k] = xq[k < m_ ? k : m_ + k - n];
+  const int sb = k < n ? k / m_ : 0;
+  if (k >= n || (sb & (a.keep - 1)) == 0) {  // a survivor or the border: x is final
+    const int keep = a.keep < a.N ? a.keep : a.N;
+    if (lane == 0) a.x[k] = xq[k < n ? (sb / keep) * m_ + (k - sb * m_) : qb + k - n];
     return;
   }
+  if (a.nbr == 0) return;
   const double* col = a.A + (size_t)k * a.lda + n;
   double sum = 0.0;
-  for (int r = lane; r < a.nbr; r += 64) sum = __builtin_fma(xq[m_ + r], col[r], sum);
+  for (int r = lane; r < a.nbr; r += 64) sum = __builtin_fma(xq[qb + r], col[r], sum);
   sum = wave_sum63(sum);
   if (lane == 63) tvec[k] = sum;
 }
@@ -1035,6 +1057,7 @@ __global__ __launch_bounds__(256) void cr_border_yh_kernel(CrArgs a, const doubl
   constexpr int m_ = NBI * T;
   __shared__ double ts[m_];
   const int i = 1 + (int)blockIdx.x, n = a.n;
+  if ((i & (a.keep - 1)) == 0) return;  // (a survivor of the dense top)
   for (int c = threadIdx.x; c < m_; c += 256) ts[c] = i * m_ + c < n ? tvec[i * m_ + c] : 0.0;
   __syncthreads();
   const double* W3 = a.W3 + (size_t)i * ((size_t)m_ * m_);
@@ -1096,7 +1119,15 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     const int G = ngroups > 4 ? 8 : (ngroups > 2 ? 4 : (ngroups > 1 ? 2 : 1)), kx = 8 / G;
     return 8 * gh_div_up(ntask, kx) * gh_div_up(ngroups, G);
   };
-  for (int s = 1; s < N; s *= 2) {
+  // DENSE TOP: the reduction stops when at most `top` superblocks survive (0, S, 2 S, ...): the last levels eliminate one or
+  // two superblocks each behind a full-length pivot chain (58 us per level at T = 3), while the single-launch dense
+  // factorisation takes the block tridiagonal system of four survivors in about the time of ONE level
+  const int top = (bws != nullptr) ? gh_cr_top(nbr) : 1;
+  int S = 1;
+  while (gh_div_up(N, S) > top) S *= 2;
+  const int nsv = gh_div_up(N, S);  // survivors
+  a.keep = S;
+  for (int s = 1; s < S; s *= 2) {
     a.s = s;
     a.first = s;
     a.count = (N - s + 2 * s - 1) / (2 * s);
@@ -1104,7 +1135,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(a.count), dim3(512), factor_lds, a);
     // (the border strips of an arrowhead system ride in the same launch: they need nothing but L_i either)
     GH_LAUNCH(ctx, "ba_cr_panels", cr_panels_kernel<T>, dim3(g8 * (8 * T + 1 + nbs)), dim3(256), 0, a, 0, 8 * T + 1 + nbs);
-    if (2 * s >= N) {  // the last level: everything the side work reads is (or will be, in stream order) complete here
+    if (2 * s >= S) {  // the last level: everything the side work reads is (or will be, in stream order) complete here
       GH_HIP(ctx, hipEventRecord(ctx->cr_events[0], ctx->stream));
       GH_HIP(ctx, hipStreamWaitEvent(side, ctx->cr_events[0], 0));
       CrArgs b = a;
@@ -1120,15 +1151,14 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(update_grid(nsurv, NTS)), dim3(256), 0, a, 0, nsurv);
     if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_update", cr_border_update_kernel<T>, dim3(nsurv * nrt * T * 4), dim3(256), 0, a, nrt);
   }
-  // the last block: block 0 with no neighbours (stride >= N)
-  int s_top = 1;
-  while (s_top < N) s_top *= 2;
-  a.s = s_top;
+  // what is left: block 0 with no neighbours (stride >= N), or the dense top
+  a.s = S;
   a.first = 0;
   a.count = 1;
-  if (nbr > 0) {
-    // superblock 0 is not factored on its own: it joins the border in the dense system that is left
-    const int qn = m_ + nbr, ldq = (qn + 1 + 15) & ~15;
+  if (nbr > 0 || nsv > 1) {
+    // the survivors are not factored on their own: they join the border in the dense system that is left
+    const int qb = (nsv - 1) * m_ + (n - (nsv - 1) * S * m_ < m_ ? n - (nsv - 1) * S * m_ : m_);
+    const int qn = qb + nbr, ldq = (qn + 1 + 15) & ~15;
     const int ntr = gh_div_up(nbr + 1, 64), ntiles = ntr * (ntr + 1) / 2;
     const BorderChunks bc = border_chunks(n, m_, nbr);
     const int nchunks = bc.n;
@@ -1150,18 +1180,18 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
       GH_LAUNCH(ctx, "ba_cr_border_reduce", cr_border_syrk_reduce_kernel<T>, dim3(16 * ntiles), dim3(256), 0, a, ntiles, nchunks,
                 (const double*)part);
     }
-    GH_LAUNCH(ctx, "ba_cr_border_gather", cr_border_gather_kernel<T>, dim3(qn + 8), dim3(256), 0, a, Mq, ldq, flow_q, n_flow,
+    GH_LAUNCH(ctx, "ba_cr_border_gather", cr_border_gather_kernel<T>, dim3(qn + 8), dim3(256), 0, a, qb, Mq, ldq, flow_q, n_flow,
               reinterpret_cast<unsigned*>(xh_q), n_xh);
     GH_TRY(gh_potrf_dev_impl(ctx, Mq, qn, ldq, info_dev, 1, dinv_q, xwork_q, flow_q, false, true));
     GH_TRY(gh_potrs_bwd_dev_impl(ctx, Mq, qn, ldq, xq, work_q, dinv_q, Mq + qn, ldq, xh_q, info_dev, true));
-    if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
-    GH_LAUNCH(ctx, "ba_cr_border_back", cr_border_back_kernel<T>, dim3(gh_div_up(n + nbr, 4)), dim3(256), 0, a, (const double*)xq, tvec);
-    if (N > 1) GH_LAUNCH(ctx, "ba_cr_border_yh", cr_border_yh_kernel<T>, dim3(N - 1), dim3(256), 0, a, (const double*)tvec);
+    if (S > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
+    GH_LAUNCH(ctx, "ba_cr_border_back", cr_border_back_kernel<T>, dim3(gh_div_up(n + nbr, 4)), dim3(256), 0, a, qb, (const double*)xq, tvec);
+    if (S > 1 && nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_yh", cr_border_yh_kernel<T>, dim3(N - 1), dim3(256), 0, a, (const double*)tvec);
   } else {
   GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(1), dim3(512), factor_lds, a);  // (also solves: x_0 is final)
-  if (N > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
+  if (S > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
   }
-  for (int s = s_top / 2; s >= 1; s /= 2) {
+  for (int s = S / 2; s >= 1; s /= 2) {
     a.s = s;
     a.first = s;
     a.count = (N - s + 2 * s - 1) / (2 * s);
@@ -1172,10 +1202,24 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
 
 }  // namespace
 
+// Superblocks the dense top takes: GSLAM_HIP_CR_TOP = 1 .. 16 (1 = reduce down to superblock 0, the form before the dense top);
+// default 2 for a band and 4 with a border, whose dense corner is there anyway.  Measured at C4, LM iterations per second on the
+// resident graph by top = 1 / 2 / 4 / 8: band 1717 / 1803 / 1747 / 1449, + 20 loop closures 1234 / 1320 / 1335 / 1231
+// (profiles/ba_dense_top_r05.txt): the single-launch factorisation costs ~16 us per 64 columns, a level ~85 us.
+int gh_cr_top_env() {
+  static const int v = [] {
+    const char* e = getenv("GSLAM_HIP_CR_TOP");
+    const int t = e ? atoi(e) : 0;
+    return t < 1 ? 0 : (t > 16 ? 16 : t);
+  }();
+  return v;
+}
+int gh_cr_top(int nbr) { return gh_cr_top_env() ? gh_cr_top_env() : (nbr > 0 ? 4 : 2); }
+
 // border workspace of an arrowhead solve (doubles): the corner update's partial tiles, the dense system of superblock 0 + border
 // and what chol.hip's dense path needs for it, the backward pass's t vector
 size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr) {
-  const size_t m = (size_t)NBI * T, qn = m + (size_t)nbr, ldq = (qn + 1 + 15) & ~(size_t)15;
+  const size_t m = (size_t)NBI * T, qn = (size_t)gh_cr_top(nbr) * m + (size_t)nbr, ldq = (qn + 1 + 15) & ~(size_t)15;
   const size_t ntr = ((size_t)nbr + 1 + 63) / 64, ntiles = ntr * (ntr + 1) / 2;
   const size_t nchunks = (size_t)border_chunks(n_band, (int)m, nbr).n;
   const size_t qb = (qn + NBI - 1) / NBI;
@@ -1204,6 +1248,7 @@ size_t gh_cr_panel_doubles(int n, int T) {
 // *info_dev: 0 or the first column + 1 of a diagonal tile that is not positive definite.  Asynchronous on the ctx stream.
 gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, double* dinv, double* W, double* x_dev,
                                int* info_dev, bool info_ready) {
+  // (no border workspace: the reduction runs down to superblock 0 -- the form of rounds 4 / 5a, kept for A/B runs and tests)
   if (!info_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   switch (T) {
     case 1: return cr_solve_t<1>(ctx, A, n, lda, dinv, W, x_dev, info_dev);
@@ -1243,14 +1288,16 @@ extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int ld
     return gh_set_error(ctx, GH_ERR_ARG, "gh_band_solve_dev: half-bandwidth %d of n = %d does not fit (<= %d, >= 4 superblocks)",
                         half_bandwidth, n, 3 * NBI);
   void* scratch = nullptr;
-  const size_t nd = gh_cr_dinv_doubles(n, T), nw = gh_cr_panel_doubles(n, T);
-  GH_TRY(gh_scratch(ctx, 256 + (nd + nw + (size_t)n) * sizeof(double), &scratch));
+  const size_t nd = gh_cr_dinv_doubles(n, T), nw = gh_cr_panel_doubles(n, T), nbw = gh_arrow_ws_doubles(ctx, n, T, 0);
+  std::lock_guard<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device));  // (the dense top may run as the single-launch factorisation)
+  GH_TRY(gh_scratch(ctx, 256 + (nd + nw + nbw + (size_t)n) * sizeof(double), &scratch));
   int* info_dev = (int*)scratch;
   double* dinv = (double*)((char*)scratch + 256);
   double* W = dinv + nd;
-  double* x = W + nw;
+  double* bws = W + nw;
+  double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_cr_solve_dev_impl(ctx, A_dev, n, lda, T, dinv, W, x, info_dev, false));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));

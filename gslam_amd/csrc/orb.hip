@@ -206,7 +206,7 @@ struct NextLevel {
   // the launch (checked on the host: magic_div); 0 = divide (the one-launch-for-all-levels path of small calls)
   uint32_t tiles_inv = 0, nbx_inv = 0;
   // PLANE variant of the kernel (the quadtree mode's score plane, orb_quadtree.hip): S of this level, pixel (y, x) of a frame at
-  // plane[y * plane_pitch + x + 1]
+  // plane[y * plane_pitch + x + kQtPlaneX]
   uint8_t* plane = nullptr;
   size_t plane_frame_stride = 0;
   int plane_pitch = 0;
@@ -711,15 +711,17 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
 
   if constexpr (PLANE) {
     // the quadtree mode wants S itself: the tile's 64 x 64 scores (zero outside the valid region) to the level's score plane,
-    // 16 dwords per row (score byte 68 (r + 1) + 4 + c is dword aligned at c % 4 == 0, and so is plane column x0 + 1 + c)
+    // 16 dwords per row (score byte 68 (r + 1) + 4 + c is dword aligned at c % 4 == 0; plane column x0 + kQtPlaneX + c starts a 64-byte
+    // segment: a tile row is ONE aligned 64-byte write -- at x + 1 it straddled two, and the kernel was store bound)
     static_assert(P1 != 0, "the plane variant is written for the flat 68-byte score rows");
     uint8_t* pl = nx.plane + (size_t)frame * nx.plane_frame_stride;
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(score);
+    if (nx.plane_pitch == 0) return;  // (timing experiments only: GSLAM_HIP_QT_EXP=nostore)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = tid + 256 * k, r = idx >> 4, cd = idx & 15;
-      if (y0 + r < lv.h && x0 + 4 * cd + 4 < nx.plane_pitch)
-        *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)(y0 + r), (uint32_t)nx.plane_pitch) + (uint32_t)(x0 + 1 + 4 * cd))) =
+      if (y0 + r < lv.h && x0 + kQtPlaneX + 4 * cd + 3 < nx.plane_pitch)
+        *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)(y0 + r), (uint32_t)nx.plane_pitch) + (uint32_t)(x0 + kQtPlaneX + 4 * cd))) =
             s32[17 * (r + 1) + 1 + cd];
     }
     return;
@@ -1969,7 +1971,7 @@ extern "C" gh_status gh_orb_plan_set_distribution(gh_orb_plan* p, int mode) {
     if (!(e && e[0] == '0') && p->pass1 != 0 && p->pk_score) {
       size_t off = 0;
       for (int l = 0; l < p->L; ++l) {
-        p->plane_pitch[l] = p->pitch[l] + 64;
+        p->plane_pitch[l] = p->pitch[l] + 128;  // (a multiple of 64: rows start on a 64-byte boundary, like the tile rows)
         p->plane_off[l] = off;
         off += (size_t)p->plane_pitch[l] * p->lh[l];
       }
@@ -2449,6 +2451,7 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
         nx.plane = p->score_plane + p->plane_off[l];
         nx.plane_frame_stride = p->plane_slab;
         nx.plane_pitch = p->plane_pitch[l];
+        if (const char* e = getenv("GSLAM_HIP_QT_EXP")) if (strstr(e, "nostore")) nx.plane_pitch = 0;
         const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
         GH_CHECK_ARG(ctx, tiles < (1LL << 30));
         const uint32_t nbx = (uint32_t)gh_div_up(p->ncx[l], 2), tpf = nbx * (uint32_t)gh_div_up(p->ncy[l], 2);

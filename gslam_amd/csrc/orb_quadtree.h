@@ -2,6 +2,7 @@
 // gh_orb_plan_set_distribution(plan, 1); specification: oracle/orb_oracle.c steps 4' and 5').
 #pragma once
 #include "common.h"
+#include "gslam_orb_tables.h"
 
 struct LevelView {
   const uint8_t* base;   // frame 0
@@ -18,6 +19,11 @@ struct SelKp {
 
 struct gh_qt_plan;
 
+// Score planes (orb.hip's tile kernel -> slam_cells_plane_kernel): pixel (y, x) of a level lives at base[y * pitch + x + kQtPlaneX].
+// A 64 x 64 tile starts at x = GH_ORB_EDGE + 64 bx, so with 45 = 64 - 19 a tile row is one 64-byte aligned segment of the plane.
+constexpr int kQtPlaneX = 64 - GH_ORB_EDGE;
+static_assert(kQtPlaneX % 4 == 1, "the tile kernel's dword stores and the cell kernel's dword loads assume x + kQtPlaneX = x + 1 (mod 4)");
+
 // Buffers of the quadtree mode for `max_batch` frames of the given pyramid.  *bytes += device bytes allocated.
 gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, const int* quota, int max_batch,
                        gh_qt_plan** out, size_t* bytes);
@@ -25,7 +31,7 @@ void gh_qt_destroy(gh_qt_plan* q);
 // Steps 4' and 5' for levels 0 .. n_levels-1 of `batch` frames on ctx->stream: sel[b * K + quota_off[l] + i], level_cnt[b * 8 + l]
 // exactly as orb_select leaves them.
 // planes (may be null): per level the score plane orb.hip's tile kernel wrote (base = null: none for that level; pixel (y, x)
-// at base[y * pitch + x + 1], S of oracle step 2 / 3) -- the cells of such a level are taken from it instead of the image.
+// at base[y * pitch + x + kQtPlaneX], S of oracle step 2 / 3) -- the cells of such a level are taken from it instead of the image.
 gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int batch, int min_th, int ini_th,
                         const int* quota_off, int K, SelKp* sel, int32_t* level_cnt, const LevelView* planes = nullptr);
 bool gh_qt_plane_ok(const gh_qt_plan* q, int l);

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, i
 // suppression against a zero border, the 20 -> 7 fallback, the key list.  The oracle is written the same way
 // (oracle_orb_slam_candidates reads S).  Against slam_cells_wave_kernel the image is read once per level instead of 1.44
 // times (36 x 36 tiles for 30 x 30 cells), the compass test runs 4 pixels per instruction, and seven resize launches go.
-// Plane pixel (y, x) of a frame lives at plane[y * pitch + x + 1] (the + 1 makes the tile kernel's rows dword aligned).
+// Plane pixel (y, x) of a frame lives at plane[y * pitch + x + kQtPlaneX] (orb_quadtree.h).
 constexpr int kPSPitch = 48;  // LDS score rows: a zero dword, up to nine data dwords, slack
 constexpr int kPlaneCellsPerWave = 4;  // cells a wave takes one after the other (see the slot reservation below)
 constexpr int kPlaneOut = 128;         // kept keys a wave buffers before it must reserve slots by itself
@@ -299,9 +299,9 @@ __global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, 
     const int x1 = min(x0 + wc, pl.w - kEdge), y1 = min(y0 + hc, pl.h - kEdge);
     const int cw = x1 - x0, ch = y1 - y0;
     if (cw <= 0 || ch <= 0) continue;
-    // rows y0 .. y1 - 1 as the aligned dwords that cover plane bytes x0 + 1 .. x1; bytes of neighbouring cells masked to zero.
+    // rows y0 .. y1 - 1 as the aligned dwords that cover plane bytes of columns x0 .. x1 - 1; bytes of neighbouring cells masked to zero.
     // All (at most five) loads of a lane are asked for at once, the LDS plane is cleared under them.
-    const int xa = (x0 + 1) & ~3, al = (x0 + 1) & 3;
+    const int xa = (x0 + kQtPlaneX) & ~3, al = (x0 + kQtPlaneX) & 3;
     const int ndw = (al + cw + 3) >> 2;  // <= 9
     uint32_t vv[5];
     int slot[5];

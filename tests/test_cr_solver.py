@@ -100,11 +100,13 @@ def make_arrow(n_band, hb, nbr, seed=0, fill=1.0):
     return A
 
 
-def arrow_solve_restated(S, b, n_band, m):
+def arrow_solve_restated(S, b, n_band, m, top=1):
     """The schedule of chol_cr.hip's arrowhead mode: block cyclic reduction on the band with the border rows E and the
     right-hand side riding along as extra rows (Y_i = E_i L_i^-T, E_u -= Y_i W_u^T, E_d -= Y_i W_d^T), the corner update
     C -= sum_i Y_i Y_i^T over every eliminated superblock, the dense solve of superblock 0 + border, and the backward pass
-    with - x_c Y_i added to the right-hand side of superblock i."""
+    with - x_c Y_i added to the right-hand side of superblock i.
+    top > 1 (the DENSE TOP of cr_solve_t): the reduction stops as soon as at most `top` superblocks survive (0, st, 2 st, ...);
+    they -- block tridiagonal among themselves -- join the border in the dense system instead of superblock 0 alone."""
     n = S.shape[0]
     nbr = n - n_band
     N = -(-n_band // m)
@@ -113,8 +115,12 @@ def arrow_solve_restated(S, b, n_band, m):
     blk = lambda k: slice(k * m, min((k + 1) * m, n_band))
     bord = slice(n_band, n)
     W, L, Y, levels = {}, {}, {}, []
+    st = 1
+    while -(-N // st) > top:
+        st *= 2
+    surv = list(range(0, N, st))
     s = 1
-    while s < N:
+    while s < st:
         elim = list(range(s, N, 2 * s))
         levels.append((s, elim))
         for i in elim:
@@ -142,21 +148,28 @@ def arrow_solve_restated(S, b, n_band, m):
             if u >= 0 and d < N:
                 A[blk(d), blk(u)] -= W[(i, 1)] @ W[(i, 0)].T
         s *= 2
-    # corner: every eliminated superblock at once (columns m .. n_band of the border rows now hold the Y_i)
-    Yall = A[bord, m:n_band]
+    # corner: every eliminated superblock at once (their columns of the border rows now hold the Y_i)
+    ecols = np.concatenate([np.arange(n_band)[blk(i)] for i in range(N) if i not in surv]) if len(surv) < N else np.zeros(0, int)
+    Yall = A[bord][:, ecols]
     C = A[bord, bord] - np.tril(Yall @ Yall.T)
-    gc = rhs[bord] - Yall @ rhs[m:n_band]
-    # dense system of superblock 0 + border
-    q = m + nbr
+    gc = rhs[bord] - Yall @ rhs[ecols]
+    # dense system of the survivors (D_j, B(j + st, j), nothing else) + border
+    scols = np.concatenate([np.arange(n_band)[blk(j)] for j in surv])
+    qb = len(scols)
+    q = qb + nbr
     M = np.zeros((q, q))
-    M[:m, :m] = A[blk(0), blk(0)]
-    M[m:, :m] = A[bord, blk(0)]
-    M[m:, m:] = C
+    off = np.cumsum([0] + [len(np.arange(n_band)[blk(j)]) for j in surv])
+    for a_, j in enumerate(surv):
+        M[off[a_]:off[a_ + 1], off[a_]:off[a_ + 1]] = A[blk(j), blk(j)]
+        if a_ + 1 < len(surv):
+            M[off[a_ + 1]:off[a_ + 2], off[a_]:off[a_ + 1]] = A[blk(surv[a_ + 1]), blk(j)]
+        M[qb:, off[a_]:off[a_ + 1]] = A[bord, blk(j)]
+    M[qb:, qb:] = C
     M = np.tril(M) + np.tril(M, -1).T
-    xq = np.linalg.solve(M, np.concatenate([rhs[blk(0)], gc]))
+    xq = np.linalg.solve(M, np.concatenate([rhs[scols], gc]))
     x = np.zeros(n)
-    x[blk(0)] = xq[:m]
-    x[bord] = xq[m:]
+    x[scols] = xq[:qb]
+    x[bord] = xq[qb:]
     for s, elim in reversed(levels):
         for i in elim:
             t = rhs[blk(i)] - Y[i].T @ x[bord]
@@ -174,6 +187,18 @@ def test_arrow_schedule_restated_matches_dense(n_band, hb, m, nbr):
     S = make_arrow(n_band, hb, nbr, seed=n_band + nbr)
     b = np.random.default_rng(1).standard_normal(n_band + nbr)
     x = arrow_solve_restated(S, b, n_band, m)
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-13 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("n_band,hb,m,nbr,top", [(3000, 149, 192, 90, 4), (3000, 149, 192, 0, 4), (1000, 60, 64, 7, 4), (777, 100, 128, 130, 2),
+                                                 (520, 191, 192, 64, 4), (1345, 128, 128, 0, 8), (1345, 128, 128, 1, 3), (1000, 60, 64, 0, 16)])
+def test_dense_top_schedule_restated_matches_dense(n_band, hb, m, nbr, top):
+    """The reduction stopped at `top` survivors (chol_cr.hip: DENSE TOP, GSLAM_HIP_CR_TOP), with and without a border; a last
+    survivor that is a partial superblock and a `top` that is not a power of two included."""
+    S = make_arrow(n_band, hb, nbr, seed=n_band + nbr) if nbr else make_band(n_band, hb, seed=n_band)
+    b = np.random.default_rng(1).standard_normal(n_band + nbr)
+    x = arrow_solve_restated(S, b, n_band, m, top=top)
     xr = np.linalg.solve(S, b)
     assert np.abs(x - xr).max() <= 1e-13 * np.abs(xr).max()
 
