@@ -793,11 +793,13 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     }
     const uint64_t strong_mask = __ballot(ismax && sv > ini_th);
     const uint64_t cand = strong_mask != 0ull ? strong_mask : __ballot(ismax);  // a strong corner silences the weak ones
+    // rank = candidates that come first by (score desc, raster asc).  With the raster bits of e inverted that order is ONE unsigned
+    // comparison (lane order is raster order, rc is unique): v_readlane + v_cmp + v_addc per candidate instead of three compares
+    const uint32_t key = e ^ 0x3FFu;
     int rank = 0;
     for (uint64_t mm = cand; mm != 0ull; mm &= mm - 1ull) {
       const int j = __ffsll((unsigned long long)mm) - 1;
-      const int sj = __builtin_amdgcn_readlane(sv, j);
-      rank += (sj > sv || (sj == sv && j < lane)) ? 1 : 0;
+      rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) > key ? 1 : 0;
     }
     const bool keep = ((cand >> lane) & 1ull) != 0ull && rank < kCap;
     const uint64_t m = __ballot(keep);
@@ -829,7 +831,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
         ismax = max3i(max3i(n0, n1, n2), max3i(n3, n4, n5), max(n6, n7)) < sv;
       }
       const uint64_t bm = __ballot(ismax);
-      if (ismax) list[n + __popcll(bm & lt_mask)] = e;
+      if (ismax) list[n + __popcll(bm & lt_mask)] = e ^ 0x3FFu;  // (the list holds KEYS: raster bits inverted, see the rank loop)
       n += __popcll(bm);
       strong = strong || (__ballot(ismax && (int)(e >> 10) > ini_th) != 0ull);
     }
@@ -851,19 +853,16 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
       atomicAdd(&dbg[kDbgDenseCells], 1u);
       if (n > kCap) atomicAdd(&dbg[kDbgRankDropped], 1u);
     }
-    // rank within the cell by (score desc, raster asc); keep rank < cap, write in raster order
+    // rank within the cell by (score desc, raster asc) = by key, descending (list order is raster order and the raster position is
+    // unique, so the key order is total): one comparison per pair; keep rank < cap, write in raster order
     for (int base = 0; base < n; base += 64) {
       const int i = base + lane;
-      const uint32_t e = i < n ? list[i] : 0u;
-      const int s = (int)(e >> 10);
+      const uint32_t key = i < n ? list[i] : 0xFFFFFFFFu;
       int rank = 0;
-      for (int j = 0; j < n; ++j) {
-        const int sj = (int)(list[j] >> 10);
-        rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
-      }
+      for (int j = 0; j < n; ++j) rank += list[j] > key ? 1 : 0;
       const bool keep = i < n && rank < kCap;
       const uint64_t m = __ballot(keep);
-      if (keep) put_entry(kept + __popcll(m & lt_mask), ((uint32_t)rank << 18) | e);
+      if (keep) put_entry(kept + __popcll(m & lt_mask), ((uint32_t)rank << 18) | (key ^ 0x3FFu));
       kept += __popcll(m);
     }
   }

@@ -254,16 +254,24 @@ __global__ __launch_bounds__(256, 8) void slam_cells_wave_kernel(LevelView lv, i
 // (oracle_orb_slam_candidates reads S).  Against slam_cells_wave_kernel the image is read once per level instead of 1.44
 // times (36 x 36 tiles for 30 x 30 cells), the compass test runs 4 pixels per instruction, and seven resize launches go.
 // Plane pixel (y, x) of a frame lives at plane[y * pitch + x + kQtPlaneX] (orb_quadtree.h).
-constexpr int kPSPitch = 48;  // LDS score rows: a zero dword, up to nine data dwords, slack
+// Two size classes (template BIG): cells up to 32 x 32 -- every level of a large image -- and up to 40 x 40: ORB-SLAM's cell is
+// ceil(W / floor(W / 30)) pixels, i.e. 33 .. 36 where a side holds fewer than 15 cells (the upper levels of 1080p, most levels of
+// VGA); until round 5b those levels fell back to the image-based one-workgroup-per-cell kernel (0.11 of 2.2 ms at 1080p).
+constexpr int kPSPitch = 48;  // LDS score rows: a zero dword, up to nine (BIG: eleven) data dwords, slack
 constexpr int kPlaneCellsPerWave = 4;  // cells a wave takes one after the other (see the slot reservation below)
 constexpr int kPlaneOut = 128;         // kept keys a wave buffers before it must reserve slots by itself
+constexpr int kPcBig = 40;
+template <bool BIG>
 struct PlaneCellLds {
-  __attribute__((aligned(16))) uint32_t S[(kWcMax + 2) * (kPSPitch / 4)];  // rows -1 .. 32 of the cell, zero outside it: 1632 B
-  uint16_t queue[kWcMax * kWcMax];            // the cell's scored pixels, (y << 5) | x
-  uint32_t list[(kWcMax / 2) * (kWcMax / 2)];  // its suppressed maxima (pairwise non-adjacent: at most 16 x 16)
-  uint32_t obuf[kPlaneOut];                   // kept keys of the wave's cells until the workgroup reserves their slots
+  static constexpr int kPc = BIG ? kPcBig : kWcMax;
+  __attribute__((aligned(16))) uint32_t S[(kPc + 2) * (kPSPitch / 4)];  // rows -1 .. kPc of the cell, zero outside it: 1632 B
+  uint16_t queue[kPc * kPc];            // the cell's scored pixels, (y << 5) | x  (BIG: y << 6)
+  uint32_t list[(kPc / 2) * (kPc / 2)];  // its suppressed maxima (pairwise non-adjacent: at most 16 x 16 / 20 x 20)
+  uint32_t obuf[kPlaneOut];             // kept keys of the wave's cells until the workgroup reserves their slots
 };
-static_assert(sizeof(PlaneCellLds) * 4 <= 160 * 1024 / 7, "seven workgroups per CU");
+static_assert(sizeof(PlaneCellLds<false>) * 4 <= 160 * 1024 / 7, "seven workgroups per CU");
+static_assert(sizeof(PlaneCellLds<false>::S) % 16 == 0 && sizeof(PlaneCellLds<true>::S) % 16 == 0, "cleared by 16-byte stores");
+static_assert(4 + 3 + kPcBig + 1 <= kPSPitch, "zero dword + alignment + the widest cell fit a score row");
 
 // SLOT RESERVATION.  Every cell of a (frame, level) appends to one key list through one counter; with a returning atomic per
 // cell -- 2108 cells of a 1080p level 0 on ONE address -- the atomics were two thirds of the kernel (1.54 ms of which 1.04 ms,
@@ -271,14 +279,18 @@ static_assert(sizeof(PlaneCellLds) * 4 <= 160 * 1024 / 7, "seven workgroups per 
 // other), every wave buffers what its cells keep, and ONE atomic per workgroup reserves the slots of all of them (the order of
 // the keys is irrelevant: every later step is a function of the key set).  A wave whose buffer fills up (> 128 kept keys in
 // four cells: dense noise) reserves for itself and goes on.
-__global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, int ncols, int ncells, int wc, int hc, int ini_th,
+template <bool BIG>
+__global__ __launch_bounds__(256, BIG ? 5 : 7) void slam_cells_plane_kernel(LevelView pl, int ncols, int ncells, int wc, int hc, int ini_th,
                                                                uint32_t* __restrict__ keys, size_t keys_per_frame, uint32_t cap,
                                                                uint32_t* __restrict__ key_cnt, int level,
                                                                uint32_t* __restrict__ flags) {
-  __shared__ PlaneCellLds sh[4];
+  constexpr int kSlots = BIG ? 11 : 9;                              // data dwords per row
+  constexpr int kLoadTrips = BIG ? (kPcBig * 11 + 63) / 64 : 5;     // 64-lane trips over rows x kSlots
+  constexpr int kQShift = BIG ? 6 : 5;
+  __shared__ PlaneCellLds<BIG> sh[4];
   __shared__ uint32_t wave_tot[4], wg_base;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.y;
-  PlaneCellLds& L = sh[wv];
+  PlaneCellLds<BIG>& L = sh[wv];
   const uint8_t* plane = pl.base + (size_t)b * pl.frame_stride;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   uint32_t* out = keys + (size_t)b * keys_per_frame;
@@ -302,14 +314,15 @@ __global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, 
     // rows y0 .. y1 - 1 as the aligned dwords that cover plane bytes of columns x0 .. x1 - 1; bytes of neighbouring cells masked to zero.
     // All (at most five) loads of a lane are asked for at once, the LDS plane is cleared under them.
     const int xa = (x0 + kQtPlaneX) & ~3, al = (x0 + kQtPlaneX) & 3;
-    const int ndw = (al + cw + 3) >> 2;  // <= 9
-    uint32_t vv[5];
-    int slot[5];
+    const int ndw = (al + cw + 3) >> 2;  // <= kSlots
+    uint32_t vv[kLoadTrips];
+    int slot[kLoadTrips];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < kLoadTrips; ++t) {
       const int idx = lane + 64 * t;
-      const int r = (int)(__umul24((uint32_t)idx, 7282u) >> 16), d = idx - r * 9;  // idx / 9: exact for idx < 320 (7282 / 65536 - 1 / 9 = 1.7e-6)
-      const bool on = idx < ch * 9 && d < ndw;
+      // idx / 9: exact for idx < 320 (7282 / 65536 - 1 / 9 = 1.7e-6); idx / 11: exact for idx < 448 (5958 / 65536 - 1 / 11 = 2.8e-6)
+      const int r = (int)(__umul24((uint32_t)idx, BIG ? 5958u : 7282u) >> 16), d = idx - r * kSlots;
+      const bool on = idx < ch * kSlots && d < ndw;
       const int rc = on ? r : 0, dc = on ? d : 0;  // (clamped: a load without a branch around it)
       const uint32_t v = *reinterpret_cast<const uint32_t*>(plane + (__umul24((uint32_t)(y0 + rc), (uint32_t)pl.pitch) + (uint32_t)(xa + 4 * dc)));
       const int lo = al - 4 * dc, hi = al + cw - 4 * dc;  // keep bytes lo <= k < hi
@@ -321,19 +334,22 @@ __global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, 
     }
     {
       uint4* s4 = reinterpret_cast<uint4*>(L.S);
-      static_assert(sizeof(L.S) % 16 == 0, "cleared by 16-byte stores");
       for (int idx = lane; idx < (int)(sizeof(L.S) / 16); idx += 64) s4[idx] = uint4{0u, 0u, 0u, 0u};
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < kLoadTrips; ++t)
       if (slot[t] >= 0) L.S[slot[t]] = vv[t];
     __builtin_amdgcn_wave_barrier();
     uint8_t* S = reinterpret_cast<uint8_t*>(L.S) + kPSPitch + 4 + al;  // score of cell pixel (0, 0)
-    // the scored pixels: lane = (row, half), 16 bytes each; positions appended by a prefix sum over the lanes' counts
+    // the scored pixels: a unit = 16 bytes of a row (small cells: lane = (row, half); BIG: three parts per row, two trips of 64
+    // units); positions appended by a prefix sum over the units' counts (the order of the queue is irrelevant)
     int nq = 0;
-    {
-      const int r = lane >> 1, c0 = 16 * (lane & 1);
+#pragma unroll
+    for (int t = 0; t < (BIG ? 2 : 1); ++t) {
+      const int u = lane + 64 * t;
+      const int r = BIG ? (int)(__umul24((uint32_t)u, 43u) >> 7) : u >> 1;  // u / 3: exact for u < 128
+      const int c0 = 16 * (BIG ? u - 3 * r : u & 1);
       uint32_t nzb = 0;
       if (r < ch && c0 < cw) {
         const uint32_t* q = L.S + (r + 1) * (kPSPitch / 4) + 1 + ((al + c0) >> 2);
@@ -347,17 +363,19 @@ __global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, 
           const uint32_t f = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7) & 0x01010101u;  // byte k -> 1 if non-zero
           nzb |= __builtin_amdgcn_udot4(f, 0x08040201u, 0u, false) << (4 * j);
         }
+        // (BIG: the third part's dwords run past the row into the next one -- only columns < cw count)
+        if constexpr (BIG) nzb &= cw - c0 >= 16 ? 0xFFFFu : ((1u << (cw - c0)) - 1u);
       }
       const int cnt = __popc(nzb);
       int incl = cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+        const int tt = __shfl_up(incl, o);
+        if (lane >= o) incl += tt;
       }
-      nq = __shfl(incl, 63);
-      int pos = incl - cnt;
-      const uint32_t rc0 = (uint32_t)((r << 5) | c0);
+      int pos = nq + incl - cnt;
+      nq += __shfl(incl, 63);
+      const uint32_t rc0 = (uint32_t)((r << kQShift) | c0);
       while (nzb) {
         const int k = __ffs((int)nzb) - 1;
         L.queue[pos++] = (uint16_t)(rc0 + (uint32_t)k);
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(256, 7) void slam_cells_plane_kernel(LevelView pl, 
       uint32_t key = 0;
       int sc = 0;
       if (i < nq) {
-        const int yx = L.queue[i], y = yx >> 5, x = yx & 31;
+        const int yx = L.queue[i], y = yx >> kQShift, x = yx & ((1 << kQShift) - 1);
         const uint8_t* sp = S + y * kPSPitch + x;
         sc = sp[0];
         const int n0 = sp[-kPSPitch - 1], n1 = sp[-kPSPitch], n2 = sp[-kPSPitch + 1], n3 = sp[-1], n4 = sp[1],
@@ -889,9 +907,14 @@ gh_status gh_qt_cells(gh_ctx* ctx, gh_qt_plan* q, int l, const LevelView& img, c
   if (v.quota <= 0) return GH_OK;
   static const bool wave_cells = getenv("GSLAM_HIP_QT_WAVE_CELLS") == nullptr || atoi(getenv("GSLAM_HIP_QT_WAVE_CELLS")) != 0;  // (A/B switch)
   if (plane != nullptr && plane->base != nullptr) {  // the level's score plane exists (gh_qt_plane_ok): cells from it
-    GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_plane_kernel, dim3(gh_div_up(v.ncols * v.nrows, 4 * kPlaneCellsPerWave), batch), dim3(256),
-              0, *plane, v.ncols, v.ncols * v.nrows, v.wc, v.hc, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap, q->key_cnt, l,
-              flags);
+    if (v.wc <= kWcMax && v.hc <= kWcMax)
+      GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_plane_kernel<false>, dim3(gh_div_up(v.ncols * v.nrows, 4 * kPlaneCellsPerWave), batch),
+                dim3(256), 0, *plane, v.ncols, v.ncols * v.nrows, v.wc, v.hc, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap,
+                q->key_cnt, l, flags);
+    else
+      GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_plane_kernel<true>, dim3(gh_div_up(v.ncols * v.nrows, 4 * kPlaneCellsPerWave), batch),
+                dim3(256), 0, *plane, v.ncols, v.ncols * v.nrows, v.wc, v.hc, ini_th, q->keys + v.key_off, q->keys_per_frame, v.cap,
+                q->key_cnt, l, flags);
   } else if (wave_cells && v.wc <= kWcMax && v.hc <= kWcMax && (img.pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(img.base) & 3) == 0 &&
              (img.frame_stride & 3) == 0) {
     GH_LAUNCH(ctx, "orb_slam_cells", slam_cells_wave_kernel, dim3(gh_div_up(v.ncols * v.nrows, 4), batch), dim3(256), 0, img, v.ncols,
@@ -930,7 +953,7 @@ gh_status gh_qt_check(gh_ctx* ctx, gh_qt_plan* q) {
   return GH_OK;
 }
 
-// whether level l's cells can be taken from a score plane (cells of at most 32 x 32: every level but very narrow ones)
+// whether level l's cells can be taken from a score plane (cells of at most 40 x 40: a level whose side holds 3+ cells)
 bool gh_qt_plane_ok(const gh_qt_plan* q, int l) {
-  return q && l >= 0 && l < q->L && q->args.lv[l].quota > 0 && q->args.lv[l].wc <= kWcMax && q->args.lv[l].hc <= kWcMax;
+  return q && l >= 0 && l < q->L && q->args.lv[l].quota > 0 && q->args.lv[l].wc <= kPcBig && q->args.lv[l].hc <= kPcBig;
 }
