@@ -1341,6 +1341,62 @@ __device__ __forceinline__ void desc_blur_mfma(const uint8_t* patch, uint8_t* bl
   }
 }
 
+// The same for the 45 x 45 patch of the continuous-steering mode (describe_kernel<19, true, true>): rows of 12 dwords, patch column
+// 0 at byte 0, 49 rows allocated.  Three 16-column blocks (blur columns 0 .. 38 + scratch), each with its own K window (patch
+// columns 16 nb .. 16 nb + 31: past column 47 the window runs into the next row -- finite after the OR, under zero taps).  D row
+// m = 4 q + j of M-block mb is patch row 10 q + 4 mb + j: lane group q holds the 16 consecutive rows 10 q .. 10 q + 15 of its blur
+// column, enough for the TEN blur rows 10 q .. 10 q + 9 (4 x 10 = 40 >= 39).  Blurred patch: column-major, 48 bytes per column,
+// the ten rows of group q at byte 12 q (blur_offset_mfma19).
+__host__ __device__ constexpr int blur_offset_mfma19(int row, int col) { return col * 48 + 12 * (row / 10) + row % 10; }
+__device__ __forceinline__ void desc_blur_mfma19(const uint8_t* patch, uint8_t* bl, int lane, const uint4 bw) {
+  constexpr int kRowDw = 12;
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int n16 = lane & 15, q4 = lane >> 4;
+  const f16x8 bfrag = __builtin_bit_cast(f16x8, bw);
+  const uint32_t* arow = reinterpret_cast<const uint32_t*>(patch) + (10 * (n16 >> 2) + (lane & 3)) * kRowDw + 2 * q4;
+  const uint32_t k64 = 0x64646464u;
+  const uint32_t gw0 = 144u, gw1 = 268u, gw2 = 391u, gw3 = 442u, c23 = 1u << 23;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb) {
+    uint32_t hs[16];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const uint32_t d0 = arow[4 * mb * kRowDw + 4 * nb], d1 = arow[4 * mb * kRowDw + 4 * nb + 1];
+      uint4 af;
+      af.x = __builtin_amdgcn_perm(k64, d0, 0x04010400u);  // {1024 + p0, 1024 + p1}
+      af.y = __builtin_amdgcn_perm(k64, d0, 0x04030402u);
+      af.z = __builtin_amdgcn_perm(k64, d1, 0x04010400u);
+      af.w = __builtin_amdgcn_perm(k64, d1, 0x04030402u);
+      const f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f};
+      const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af), bfrag, c0, 0, 0, 0);
+      hs[4 * mb + 0] = __float_as_uint(dd[0]);
+      hs[4 * mb + 1] = __float_as_uint(dd[1]);
+      hs[4 * mb + 2] = __float_as_uint(dd[2]);
+      hs[4 * mb + 3] = __float_as_uint(dd[3]);
+    }
+    // two asm statements of 35 multiply-adds (an asm statement takes at most 30 operands): blur rows 0 .. 4 from h rows 0 .. 10,
+    // rows 5 .. 9 from h rows 5 .. 15; the first opens with the wait states a VALU read of an MFMA result needs (see desc_blur_mfma)
+    uint32_t o[12];
+    asm volatile("s_nop 15\n\ts_nop 2\n\tv_mad_u32_u24 %0, %5, %16, %20\n\tv_mad_u32_u24 %0, %6, %17, %0\n\tv_mad_u32_u24 %0, %7, %18, %0\n\tv_mad_u32_u24 %0, %8, %19, %0\n\tv_mad_u32_u24 %0, %9, %18, %0\n\tv_mad_u32_u24 %0, %10, %17, %0\n\tv_mad_u32_u24 %0, %11, %16, %0\n\tv_mad_u32_u24 %1, %6, %16, %20\n\tv_mad_u32_u24 %1, %7, %17, %1\n\tv_mad_u32_u24 %1, %8, %18, %1\n\tv_mad_u32_u24 %1, %9, %19, %1\n\tv_mad_u32_u24 %1, %10, %18, %1\n\tv_mad_u32_u24 %1, %11, %17, %1\n\tv_mad_u32_u24 %1, %12, %16, %1\n\tv_mad_u32_u24 %2, %7, %16, %20\n\tv_mad_u32_u24 %2, %8, %17, %2\n\tv_mad_u32_u24 %2, %9, %18, %2\n\tv_mad_u32_u24 %2, %10, %19, %2\n\tv_mad_u32_u24 %2, %11, %18, %2\n\tv_mad_u32_u24 %2, %12, %17, %2\n\tv_mad_u32_u24 %2, %13, %16, %2\n\tv_mad_u32_u24 %3, %8, %16, %20\n\tv_mad_u32_u24 %3, %9, %17, %3\n\tv_mad_u32_u24 %3, %10, %18, %3\n\tv_mad_u32_u24 %3, %11, %19, %3\n\tv_mad_u32_u24 %3, %12, %18, %3\n\tv_mad_u32_u24 %3, %13, %17, %3\n\tv_mad_u32_u24 %3, %14, %16, %3\n\tv_mad_u32_u24 %4, %9, %16, %20\n\tv_mad_u32_u24 %4, %10, %17, %4\n\tv_mad_u32_u24 %4, %11, %18, %4\n\tv_mad_u32_u24 %4, %12, %19, %4\n\tv_mad_u32_u24 %4, %13, %18, %4\n\tv_mad_u32_u24 %4, %14, %17, %4\n\tv_mad_u32_u24 %4, %15, %16, %4"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4])
+                 : "v"(hs[0]), "v"(hs[1]), "v"(hs[2]), "v"(hs[3]), "v"(hs[4]), "v"(hs[5]), "v"(hs[6]), "v"(hs[7]), "v"(hs[8]), "v"(hs[9]),
+                   "v"(hs[10]), "v"(gw0), "v"(gw1), "v"(gw2), "v"(gw3), "s"(c23));
+    asm volatile("v_mad_u32_u24 %0, %5, %16, %20\n\tv_mad_u32_u24 %0, %6, %17, %0\n\tv_mad_u32_u24 %0, %7, %18, %0\n\tv_mad_u32_u24 %0, %8, %19, %0\n\tv_mad_u32_u24 %0, %9, %18, %0\n\tv_mad_u32_u24 %0, %10, %17, %0\n\tv_mad_u32_u24 %0, %11, %16, %0\n\tv_mad_u32_u24 %1, %6, %16, %20\n\tv_mad_u32_u24 %1, %7, %17, %1\n\tv_mad_u32_u24 %1, %8, %18, %1\n\tv_mad_u32_u24 %1, %9, %19, %1\n\tv_mad_u32_u24 %1, %10, %18, %1\n\tv_mad_u32_u24 %1, %11, %17, %1\n\tv_mad_u32_u24 %1, %12, %16, %1\n\tv_mad_u32_u24 %2, %7, %16, %20\n\tv_mad_u32_u24 %2, %8, %17, %2\n\tv_mad_u32_u24 %2, %9, %18, %2\n\tv_mad_u32_u24 %2, %10, %19, %2\n\tv_mad_u32_u24 %2, %11, %18, %2\n\tv_mad_u32_u24 %2, %12, %17, %2\n\tv_mad_u32_u24 %2, %13, %16, %2\n\tv_mad_u32_u24 %3, %8, %16, %20\n\tv_mad_u32_u24 %3, %9, %17, %3\n\tv_mad_u32_u24 %3, %10, %18, %3\n\tv_mad_u32_u24 %3, %11, %19, %3\n\tv_mad_u32_u24 %3, %12, %18, %3\n\tv_mad_u32_u24 %3, %13, %17, %3\n\tv_mad_u32_u24 %3, %14, %16, %3\n\tv_mad_u32_u24 %4, %9, %16, %20\n\tv_mad_u32_u24 %4, %10, %17, %4\n\tv_mad_u32_u24 %4, %11, %18, %4\n\tv_mad_u32_u24 %4, %12, %19, %4\n\tv_mad_u32_u24 %4, %13, %18, %4\n\tv_mad_u32_u24 %4, %14, %17, %4\n\tv_mad_u32_u24 %4, %15, %16, %4"
+                 : "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9])
+                 : "v"(hs[5]), "v"(hs[6]), "v"(hs[7]), "v"(hs[8]), "v"(hs[9]), "v"(hs[10]), "v"(hs[11]), "v"(hs[12]), "v"(hs[13]),
+                   "v"(hs[14]), "v"(hs[15]), "v"(gw0), "v"(gw1), "v"(gw2), "v"(gw3), "s"(c23));
+    // the top bytes of the ten sums -> 10 bytes of the column: three dword stores (the group's 12-byte slot)
+    const uint32_t w0 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0c0c0703u), __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
+    const uint32_t w1 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[7], o[6], 0x0c0c0703u), __builtin_amdgcn_perm(o[5], o[4], 0x0c0c0703u), 0x05040100u);
+    const uint32_t w2 = __builtin_amdgcn_perm(o[9], o[8], 0x0c0c0703u);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(bl + (16 * nb + n16) * 48 + 12 * q4);
+    dst[0] = w0;
+    dst[1] = w1;
+    dst[2] = w2;
+  }
+}
+
 template <int BR, bool STEER, bool MF = false>
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
@@ -1352,15 +1408,15 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
   constexpr int kC = G::kC, kPatch = G::kPatch, kPatchPitch = G::kPatchPitch, kRowDw = G::kRowDw, kBlur = G::kBlur,
                 kBlurPitch = G::kBlurPitch, kGroups = G::kGroups;
   static_assert(kPatch <= 64 && kC >= 16, "one lane per patch row; the radius-15 centroid disc lies inside the patch");
-  static_assert(!MF || (BR == 13 && !STEER), "the MFMA blur is written for the 33 x 33 patch of the table mode");
+  static_assert(!MF || (BR == 13 && !STEER) || (BR == 19 && STEER), "the MFMA blur is written for the 33 x 33 patch of the table mode and the 45 x 45 one of the continuous mode");
   // MF: four more (uninitialised) rows below the patch -- the row map of the MFMA h-pass runs to row 36 with constant offsets
   constexpr int kPatchRows = MF ? kPatch + 4 : kPatch;
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatchRows * kPatchPitch + 28];  // + slack for the 16-B row reads
-  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][MF ? 256 : (kPatch + 1) * kBlurPitch];  // MF: the blurred patch (1 KB)
+  __shared__ __attribute__((aligned(16))) uint32_t s_h[4][MF ? (BR == 13 ? 256 : 48 * 48 / 4) : (kPatch + 1) * kBlurPitch];  // MF: the blurred patch (1 KB / 2.25 KB)
   // VALU variant: the blurred patch REPLACES the raw one (last read by the h-pass, a wave barrier before the v-pass writes): 20.2 KB of
   // LDS per workgroup in the table mode = 8 workgroups per CU instead of 6 (GSLAM_HIP_ORB_DESC_LDSPAD=3000 restores 6 for A/B runs)
   static_assert(sizeof(s_patch[0]) >= kBlur * kBlurPitch + 12, "the blurred patch fits where the raw patch was");
-  static_assert(BR != 13 || sizeof(s_patch) + sizeof(s_h) <= 20480, "8 workgroups per CU");
+  static_assert((BR != 13 && !MF) || sizeof(s_patch) + sizeof(s_h) <= 20480, "8 workgroups per CU");
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blocks_per_frame = (K + 3) >> 2;
   const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
@@ -1427,7 +1483,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
       const uint8_t* rp = img + (size_t)orb_reflect101(py0 + lane, lv.h) * lv.pitch;
       for (int c = 0; c < kRowDw; ++c) {
         uint32_t w = 0;
-        for (int e = 0; e < 4; ++e) w |= (uint32_t)rp[orb_reflect101(pa + 4 * c + e, lv.w)] << (8 * e);
+        for (int e = 0; e < 4; ++e) w |= (uint32_t)rp[orb_reflect101((MF ? px0 : pa) + 4 * c + e, lv.w)] << (8 * e);
         dst[c] = w;
       }
     }
@@ -1449,8 +1505,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
                               : reinterpret_cast<const uint32_t*>(tb.pattern) + (size_t)bin * 256;
   const uint32_t pws[4] = {pat[lane], pat[64 + lane], pat[128 + lane], pat[192 + lane]};
   uint8_t* bl = MF ? reinterpret_cast<uint8_t*>(s_h[wv]) : s_patch[wv];
-  if constexpr (MF) {
+  if constexpr (MF && BR == 13) {
     desc_blur_mfma(s_patch[wv], bl, lane, desc_blur_b(lane));
+  } else if constexpr (MF) {
+    desc_blur_mfma19(s_patch[wv], bl, lane, desc_blur_b(lane));
   } else {
     // separable 7x7 integer Gaussian: patch rows 0..kPatch-1 x blur cols -> s_h, then blur rows -> the blurred patch
     uint32_t* hb = s_h[wv];
@@ -1531,8 +1589,15 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables
       const float bx = (float)(int)(int8_t)((pw >> 16) & 0xFFu), by = (float)(int)(int8_t)(pw >> 24);
       const int rax = (int)rintf(ax * cs - ay * sn), ray = (int)rintf(ax * sn + ay * cs);
       const int rbx = (int)rintf(bx * cs - by * sn), rby = (int)rintf(bx * sn + by * cs);
-      va = bl[(BR + ray) * kBlurPitch + BR + rax];
-      vb = bl[(BR + rby) * kBlurPitch + BR + rbx];
+      if constexpr (MF) {
+        // blur_offset_mfma19: column-major, row r of a column at byte r + 2 (r / 10)  (r / 10 = 205 r >> 11 for r < 64)
+        const uint32_t ra = (uint32_t)(BR + ray), rb = (uint32_t)(BR + rby);
+        va = bl[__umul24((uint32_t)(BR + rax), 48u) + ra + 2u * (__umul24(ra, 205u) >> 11)];
+        vb = bl[__umul24((uint32_t)(BR + rbx), 48u) + rb + 2u * (__umul24(rb, 205u) >> 11)];
+      } else {
+        va = bl[(BR + ray) * kBlurPitch + BR + rax];
+        vb = bl[(BR + rby) * kBlurPitch + BR + rbx];
+      }
     } else {
       va = bl[pw & 0xFFFFu];  // byte offsets of the two sample points in the blurred patch
       vb = bl[pw >> 16];
@@ -2595,6 +2660,9 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
     else if (p->steer == 0)
       GH_LAUNCH(ctx, "orb_describe", (describe_kernel<13, false, false>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
                 p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
+    else if (p->desc_mfma)  // continuous steering: the 45 x 45 patch's blur on MFMA too (18.7 instead of 38 KB of LDS: 8 workgroups per CU)
+      GH_LAUNCH(ctx, "orb_describe", (describe_kernel<19, true, true>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
+                p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
     else
       GH_LAUNCH(ctx, "orb_describe", (describe_kernel<19, true, false>), dim3(8 * gh_div_up(blocks, 8)), dim3(256), 0, a, tb, K, p->sel,
                 p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
