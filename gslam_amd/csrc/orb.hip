@@ -1398,7 +1398,7 @@ __device__ __forceinline__ void desc_blur_mfma19(const uint8_t* patch, uint8_t* 
 }
 
 template <int BR, bool STEER, bool MF = false>
-__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a, DevTables tb, int K,
+__global__ __launch_bounds__(256, (MF && BR == 19) ? 8 : 1) void describe_kernel(DescribeArgs a, DevTables tb, int K,
                                                        const SelKp* __restrict__ sel,
                                                        const int32_t* __restrict__ level_cnt,
                                                        gh_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,

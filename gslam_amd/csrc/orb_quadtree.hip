@@ -510,8 +510,9 @@ __global__ __launch_bounds__(256) void slam_cells_kernel(LevelView lv, int ncols
 }
 
 // ---- step 5'
-// exclusive scan of one int per thread over the 1024-lane workgroup
-__device__ __forceinline__ int block_scan_1024(int v, int* wave_tot /* shared[16] */, int* total) {
+// exclusive scan of one int per thread over the workgroup of THREADS lanes
+template <int THREADS>
+__device__ __forceinline__ int block_scan_wg(int v, int* wave_tot /* shared[16] */, int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int incl = v;
 #pragma unroll
@@ -524,7 +525,7 @@ __device__ __forceinline__ int block_scan_1024(int v, int* wave_tot /* shared[16
   __syncthreads();
   int off = 0, tot = 0;
 #pragma unroll
-  for (int k = 0; k < kQtThreads / 64; ++k) {
+  for (int k = 0; k < THREADS / 64; ++k) {
     const int t = wave_tot[k];
     if (k < wv) off += t;
     tot += t;
@@ -533,13 +534,13 @@ __device__ __forceinline__ int block_scan_1024(int v, int* wave_tot /* shared[16
   return off + incl - v;
 }
 
-// ascending bitonic sort of kQtNodes values in LDS (every thread of the workgroup calls it)
-template <typename T>
+// ascending bitonic sort of NODES values in LDS (every thread of the NODES / 2 of the workgroup calls it)
+template <int NODES, typename T>
 __device__ __forceinline__ void bitonic_sort_nodes(T* a) {
-  for (int k = 2; k <= kQtNodes; k <<= 1)
+  for (int k = 2; k <= NODES; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
-      const int t = threadIdx.x;                     // pair index: kQtNodes / 2 pairs
+      const int t = threadIdx.x;                     // pair index: NODES / 2 pairs
       const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
       const int p = i | j;
       const bool up = (i & k) == 0;
@@ -552,19 +553,22 @@ __device__ __forceinline__ void bitonic_sort_nodes(T* a) {
   __syncthreads();
 }
 
+// (NODES = table capacity: quota + 3 and 4 * roots must fit; the workgroup has NODES / 2 threads, each owns two table rows)
+template <int NODES>
 struct QtShared {
-  uint32_t box_x[2][kQtNodes];   // x0 | x1 << 16 (region coordinates)
-  uint32_t box_y[2][kQtNodes];
-  uint32_t cnt[2][kQtNodes];     // keys of the node
-  uint8_t fresh[2][kQtNodes];    // created by the last pass
-  uint32_t ccnt[kQtNodes][4];    // keys of the four children of a node being split
-  uint16_t cbase[kQtNodes];      // id of the node (or of its first child) in the next table
-  uint8_t split[kQtNodes];
-  unsigned long long sortbuf[kQtNodes];
+  uint32_t box_x[2][NODES];   // x0 | x1 << 16 (region coordinates)
+  uint32_t box_y[2][NODES];
+  uint32_t cnt[2][NODES];     // keys of the node
+  uint8_t fresh[2][NODES];    // created by the last pass
+  uint32_t ccnt[NODES][4];    // keys of the four children of a node being split
+  uint16_t cbase[NODES];      // id of the node (or of its first child) in the next table
+  uint8_t split[NODES];
+  unsigned long long sortbuf[NODES];
   int wave_tot[16];
   int cut;
 };
-static_assert(sizeof(QtShared) <= 120 * 1024, "one workgroup per CU: 160 KB of LDS");
+static_assert(sizeof(QtShared<2048>) <= 120 * 1024 && sizeof(QtShared<1024>) <= 160 * 1024 / 3 && sizeof(QtShared<512>) <= 160 * 1024 / 5,
+              "workgroups per CU by LDS: 1 / 3 / 5 (by threads: 2 / 4 / 8)");
 
 __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, uint32_t key) {
   const int x0 = (int)(bx & 0xFFFFu), x1 = (int)(bx >> 16), y0 = (int)(by & 0xFFFFu), y1 = (int)(by >> 16);
@@ -573,12 +577,14 @@ __device__ __forceinline__ int qt_quadrant(uint32_t bx, uint32_t by, uint32_t ke
   return (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
 }
 
-__global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, const uint32_t* __restrict__ keys,
+template <int NODES>
+__global__ __launch_bounds__(NODES / 2) void slam_quadtree_kernel(QtArgs a, const uint32_t* __restrict__ keys,
                                                                    uint16_t* __restrict__ knode, size_t keys_per_frame,
                                                                    const uint32_t* __restrict__ key_cnt, int K,
                                                                    SelKp* __restrict__ sel, int32_t* __restrict__ level_cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t qt_lds[];
-  QtShared& sh = *reinterpret_cast<QtShared*>(qt_lds);
+  constexpr int kQtNodes = NODES, kQtThreads = NODES / 2;
+  QtShared<NODES>& sh = *reinterpret_cast<QtShared<NODES>*>(qt_lds);
   const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const QtLevel L = a.lv[l];
   const int N = L.quota;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, con
   {
     int mine = 0;
     for (int n = tid; n < n_tab; n += kQtThreads) mine += sh.cnt[0][n] > 0;
-    block_scan_1024(mine, sh.wave_tot, &n_nodes);
+    block_scan_wg<NODES / 2>(mine, sh.wave_tot, &n_nodes);
   }
   // one pass: the children of every node with split[] set have been counted into ccnt; builds the next table and moves the keys.
   // Returns the new node count; *made = children holding more than one key.
@@ -638,8 +644,8 @@ __global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, con
       }
     }
     int total, made_total;
-    const int base = block_scan_1024(c[0] + c[1], sh.wave_tot, &total);
-    block_scan_1024(e, sh.wave_tot, &made_total);
+    const int base = block_scan_wg<NODES / 2>(c[0] + c[1], sh.wave_tot, &total);
+    block_scan_wg<NODES / 2>(e, sh.wave_tot, &made_total);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int n = 2 * tid + u;
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, con
         if (tid == 0) sh.cut = kQtNodes;
         __syncthreads();
         count_children();
-        bitonic_sort_nodes(sh.sortbuf);
+        bitonic_sort_nodes<NODES>(sh.sortbuf);
         // gains in expansion order; the first position where the node count reaches N ends the pass
         int g[2] = {0, 0};
 #pragma unroll
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, con
           }
         }
         int tot;
-        const int excl = block_scan_1024(g[0] + g[1], sh.wave_tot, &tot);
+        const int excl = block_scan_wg<NODES / 2>(g[0] + g[1], sh.wave_tot, &tot);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           if (sh.sortbuf[2 * tid + u] != ~0ull && n_nodes + excl + g[0] + (u ? g[1] : 0) >= N) atomicMin(&sh.cut, 2 * tid + u);
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, con
   // the tree may hold up to 3 nodes more than N: keep the N best, then (y, x) order
   uint32_t* srt = reinterpret_cast<uint32_t*>(sh.sortbuf);
   for (int n = tid; n < kQtNodes; n += kQtThreads) srt[n] = ~best[n];  // ascending ~ = descending (S, ~yx); empty slots last
-  bitonic_sort_nodes(srt);
+  bitonic_sort_nodes<NODES>(srt);
   const int keep = min(n_tab, N);
   {
     uint32_t v[2];
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(kQtThreads) void slam_quadtree_kernel(QtArgs a, con
     srt[2 * tid] = v[0];
     srt[2 * tid + 1] = v[1];
   }
-  bitonic_sort_nodes(srt);
+  bitonic_sort_nodes<NODES>(srt);
   SelKp* out = sel + (size_t)b * K + L.quota_off;
   for (int i = tid; i < keep; i += kQtThreads) {
     const uint32_t v = srt[i];
@@ -801,6 +807,8 @@ struct gh_qt_plan {
   uint16_t* knode = nullptr;
   uint32_t* key_cnt = nullptr;  // [max_batch][8], then the overflow flag word
   bool attr_set = false;
+  int nodes = 2048;  // least table capacity of the tree kernel (512 / 1024 / 2048) that holds every level's quota + 3 and 4 roots
+  int nodes_forced = 0;  // GSLAM_HIP_QT_NODES
 };
 
 void gh_qt_destroy(gh_qt_plan* q) {
@@ -824,6 +832,7 @@ gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, 
   // key slots: the exact bound (suppressed maxima of a cell are pairwise non-adjacent) while it fits the budget, a share
   // of the budget otherwise -- an overflowing list is an error of the call (gh_qt_check), never a silent truncation
   size_t worst[kMaxL] = {}, worst_total = 0;
+  int need_nodes = 0;
   int qo = 0;
   for (int l = 0; l < kMaxL; ++l) {
     QtLevel& v = q->args.lv[l];
@@ -858,6 +867,15 @@ gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, 
     }
     worst[l] = (size_t)v.ncols * v.nrows * ((v.wc + 1) / 2) * ((v.hc + 1) / 2);
     worst_total += worst[l];
+    need_nodes = need_nodes > v.quota + 3 ? need_nodes : v.quota + 3;
+    need_nodes = need_nodes > 4 * v.n_ini ? need_nodes : 4 * v.n_ini;
+  }
+  // The tree kernel is one workgroup of nodes / 2 threads per (frame, level), bound by the latency of its passes: a smaller table
+  // means more workgroups per CU at once (LDS 106 / 53 / 27 KB: 1 / 3 / 5 per CU; GSLAM_HIP_QT_NODES forces a larger one for A/B runs)
+  q->nodes = need_nodes <= 512 ? 512 : (need_nodes <= 1024 ? 1024 : 2048);
+  if (const char* e = getenv("GSLAM_HIP_QT_NODES")) {
+    const int f = atoi(e);
+    if ((f == 512 || f == 1024 || f == 2048) && f >= q->nodes) q->nodes_forced = f;
   }
   const size_t budget = ((size_t)4 << 30) / 6 / (size_t)max_batch;  // 4 GB for keys (4 B) + node ids (2 B) of all frames
   size_t off = 0;
@@ -893,8 +911,8 @@ gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, 
 gh_status gh_qt_begin(gh_ctx* ctx, gh_qt_plan* q, int batch) {
   GH_CHECK_ARG(ctx, q && batch >= 1 && batch <= q->max_batch);
   if (!q->attr_set) {
-    GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(slam_quadtree_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(QtShared)));
+    GH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(slam_quadtree_kernel<2048>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(QtShared<2048>)));
     q->attr_set = true;
   }
   GH_HIP(ctx, hipMemsetAsync(q->key_cnt, 0, ((size_t)batch * kMaxL) * 4, ctx->stream));
@@ -928,8 +946,16 @@ gh_status gh_qt_cells(gh_ctx* ctx, gh_qt_plan* q, int l, const LevelView& img, c
 
 gh_status gh_qt_tree(gh_ctx* ctx, gh_qt_plan* q, int batch, const int* quota_off, int K, SelKp* sel, int32_t* level_cnt) {
   for (int l = 0; l < q->L; ++l) GH_CHECK_ARG(ctx, q->args.lv[l].quota == 0 || q->args.lv[l].quota_off == quota_off[l]);
-  GH_LAUNCH(ctx, "orb_slam_quadtree", slam_quadtree_kernel, dim3(q->L, batch), dim3(kQtThreads), sizeof(QtShared), q->args, q->keys,
-            q->knode, q->keys_per_frame, q->key_cnt, K, sel, level_cnt);
+#define GH_QT_TREE(NODES_)                                                                                                     \
+  GH_LAUNCH(ctx, "orb_slam_quadtree", slam_quadtree_kernel<NODES_>, dim3(q->L, batch), dim3(NODES_ / 2), sizeof(QtShared<NODES_>), \
+            q->args, q->keys, q->knode, q->keys_per_frame, q->key_cnt, K, sel, level_cnt)
+  // 256-thread workgroups win when there are many (VGA x 500 frames: 0.235 vs 0.39 ms), 512-thread ones when a launch is a few
+  // hundred long trees (1080p x 100 frames: 0.30 vs 0.33 ms) -- profiles/orb_slam_mode_r05.txt
+  const int nodes = q->nodes_forced ? q->nodes_forced : (q->nodes <= 512 && (long long)q->L * batch >= 2048 ? 512 : (q->nodes <= 1024 ? 1024 : 2048));
+  if (nodes == 512) GH_QT_TREE(512);
+  else if (nodes == 1024) GH_QT_TREE(1024);
+  else GH_QT_TREE(2048);
+#undef GH_QT_TREE
   return GH_OK;
 }
 
