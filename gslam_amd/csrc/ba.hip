@@ -38,7 +38,7 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
                                int* info_dev, bool info_ready);
 size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr);
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
-                                  double* x_dev, int* info_dev, bool info_ready);
+                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
@@ -2003,6 +2003,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;
   bool need_lin = true;
+  bool cr_flow_ok = true;  // band / arrowhead solver: the dense top may use the single-launch kernels (until one of their waits expires)
   int term = 0, it = 0;
   // Speculative linearisation: behind the candidate cost's read-back the stream goes on to linearise the CANDIDATE state
   // into the second buffer set while the host waits for that cost (an event, not the stream) and decides -- the ~30 us of
@@ -2100,7 +2101,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
     if (cr_T) {  // (n_band == n: a band without a border)
       GH_TRY(gh_arrow_solve_dev_impl(ctx, d_S, n_band, n - n_band, lda, cr_T, d_cr_dinv, d_cr_W, S.d_arrow_ws, d_dc, d_info,
-                                     solve_state_ready));
+                                     solve_state_ready, cr_flow_ok));
     } else {
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place
@@ -2169,13 +2170,14 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
         break;
       }
     }
-    if (rb->info > n && (d_flow || d_xh)) {
+    if (rb->info > n && (cr_T ? cr_flow_ok : (d_flow || d_xh))) {
       // A bounded wait inside one of the single-launch kernels expired (chol.hip: the launch could not get all its
       // workgroups resident, e.g. another process holds part of the GPU).  Nothing was decided yet: repeat this iteration
       // on the launch-per-step path and stay on it for the rest of the solve.
       if (opt.verbose) fprintf(stderr, "[gh_ba] it %3d: single-launch solve timed out (info %d), repeating on the launch path\n", it, rb->info);
       d_flow = nullptr;
       d_xh = nullptr;
+      cr_flow_ok = false;  // (band / arrowhead: the dense top stays off the single-launch kernels)
       if (fresh_lin) need_lin = true;  // (cheap, and keeps the gradient read-back of this iteration in place)
       if (spec_launched) {  // the speculation wrote the gradient maximum the repeated linearisation accumulates into
         GH_HIP(ctx, hipMemsetAsync(d_gmax, 0, sizeof(unsigned long long), ctx->stream));

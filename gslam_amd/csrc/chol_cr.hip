@@ -1005,11 +1005,12 @@ __global__ __launch_bounds__(256) void cr_border_syrk_reduce_kernel(CrArgs a, in
 // M is qn x qn column-major with pitch ldq; element (r, c), r >= c.
 template <int T>
 __global__ void cr_border_gather_kernel(CrArgs a, int qb, double* __restrict__ M, int ldq, unsigned* __restrict__ flow_flags, unsigned n_flow,
-                                        unsigned* __restrict__ xh_words, unsigned n_xh) {
+                                        unsigned* __restrict__ xh_words, unsigned n_xh, int* __restrict__ info_q) {
   constexpr int m_ = NBI * T;
   const int c = (int)blockIdx.x, qn = qb + a.nbr, n = a.n;
   if (c >= qn) {  // the workgroups behind the columns clear what the single-launch solve kernels need (as ba.hip's schur_reduce does)
     const unsigned i0 = (unsigned)(c - qn) * blockDim.x + threadIdx.x, step = (gridDim.x - (unsigned)qn) * blockDim.x;
+    if (i0 == 0) *info_q = 0;
     for (unsigned i = i0; i < n_flow; i += step) flow_flags[i] = 0u;
     for (unsigned i = i0; i < n_xh; i += step) xh_words[i] = 0xFFF8BEEFu;
     return;
@@ -1033,10 +1034,18 @@ __global__ void cr_border_gather_kernel(CrArgs a, int qb, double* __restrict__ M
 // The survivors' x and x_c out of the dense solution; t[k] = sum_r x_c[r] Y[r][k] for the columns k of the eliminated superblocks
 // (one wave per column)
 template <int T>
-__global__ __launch_bounds__(256) void cr_border_back_kernel(CrArgs a, int qb, const double* __restrict__ xq, double* __restrict__ tvec) {
+__global__ __launch_bounds__(256) void cr_border_back_kernel(CrArgs a, int qb, const double* __restrict__ xq, double* __restrict__ tvec,
+                                                             const int* __restrict__ info_q) {
   constexpr int m_ = NBI * T;
   const int n = a.n, lane = threadIdx.x & 63;
   const int k = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // k < n: a column of the band; n <= k < n + nbr: a border unknown
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // an expired hand-off wait of the dense top's single-launch kernels (info = its n + 1 + block) -> beyond THIS system's size,
+    // which is how the callers tell "repeat without the single-launch kernels" from "not positive definite"
+    // (a column of the dense system that is not positive definite: reported as a column of the first survivor / the border)
+    const int iq = *info_q, qn = qb + a.nbr;
+    if (iq != 0 && *a.info == 0) *a.info = iq > qn ? n + a.nbr + 1 + (iq - qn) : (iq <= qb ? iq : n + (iq - qb));
+  }
   if (k >= n + a.nbr) return;
   const int sb = k < n ? k / m_ : 0;
   if (k >= n || (sb & (a.keep - 1)) == 0) {  // a survivor or the border: x is final
@@ -1084,7 +1093,7 @@ __global__ __launch_bounds__(256) void cr_border_yh_kernel(CrArgs a, const doubl
 // nbr > 0: an arrowhead system (see above) -- A holds n + nbr unknowns, bws the border workspace (gh_arrow_ws_doubles).
 template <int T>
 gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, double* W, double* x, int* info_dev, int nbr = 0,
-                     double* bws = nullptr) {
+                     double* bws = nullptr, bool allow_flow = true) {
   constexpr int m_ = NBI * T;
   const int N = gh_div_up(n, m_);
   const size_t mm = (size_t)m_ * m_;
@@ -1171,8 +1180,10 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     double* xh_q = xq + (((size_t)qn + 15) & ~(size_t)15);
     double* tvec = xh_q + (size_t)gh_div_up(qn, NBI) * NBI;
     // the corner through the single-launch factorisation when its shape fits (the caller holds gh_potrf_flow_mutex)
-    const size_t flow_words = gh_potrf_flow_words(ctx, qn, 1);
-    unsigned* flow_q = flow_words ? reinterpret_cast<unsigned*>(tvec + (((size_t)n + 15) & ~(size_t)15)) : nullptr;
+    const size_t flow_words = allow_flow ? gh_potrf_flow_words(ctx, qn, 1) : 0;
+    // the dense top reports into a word of its own (the reduction's factor kernels use *info_dev with THEIR column numbers)
+    int* info_q = reinterpret_cast<int*>(tvec + (((size_t)n + 15) & ~(size_t)15));
+    unsigned* flow_q = flow_words ? reinterpret_cast<unsigned*>(tvec + (((size_t)n + 15) & ~(size_t)15) + 16) : nullptr;
     const unsigned n_flow = flow_words ? (unsigned)gh_potrf_flow_flag_words(qn, 1) : 0u;
     const unsigned n_xh = (unsigned)gh_div_up(qn, NBI) * NBI * 2u;
     if (nchunks > 0) {
@@ -1181,11 +1192,11 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
                 (const double*)part);
     }
     GH_LAUNCH(ctx, "ba_cr_border_gather", cr_border_gather_kernel<T>, dim3(qn + 8), dim3(256), 0, a, qb, Mq, ldq, flow_q, n_flow,
-              reinterpret_cast<unsigned*>(xh_q), n_xh);
-    GH_TRY(gh_potrf_dev_impl(ctx, Mq, qn, ldq, info_dev, 1, dinv_q, xwork_q, flow_q, false, true));
-    GH_TRY(gh_potrs_bwd_dev_impl(ctx, Mq, qn, ldq, xq, work_q, dinv_q, Mq + qn, ldq, xh_q, info_dev, true));
+              reinterpret_cast<unsigned*>(xh_q), n_xh, info_q);
+    GH_TRY(gh_potrf_dev_impl(ctx, Mq, qn, ldq, info_q, 1, dinv_q, xwork_q, flow_q, false, true));
+    GH_TRY(gh_potrs_bwd_dev_impl(ctx, Mq, qn, ldq, xq, work_q, dinv_q, Mq + qn, ldq, allow_flow ? xh_q : nullptr, info_q, true));
     if (S > 1) GH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->cr_events[1], 0));
-    GH_LAUNCH(ctx, "ba_cr_border_back", cr_border_back_kernel<T>, dim3(gh_div_up(n + nbr, 4)), dim3(256), 0, a, qb, (const double*)xq, tvec);
+    GH_LAUNCH(ctx, "ba_cr_border_back", cr_border_back_kernel<T>, dim3(gh_div_up(n + nbr, 4)), dim3(256), 0, a, qb, (const double*)xq, tvec, (const int*)info_q);
     if (S > 1 && nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_yh", cr_border_yh_kernel<T>, dim3(N - 1), dim3(256), 0, a, (const double*)tvec);
   } else {
   GH_LAUNCH(ctx, "ba_cr_factor", cr_factor_kernel<T>, dim3(1), dim3(512), factor_lds, a);  // (also solves: x_0 is final)
@@ -1260,13 +1271,15 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
 
 // Arrowhead solve: A holds n_band + nbr unknowns (band first, border last) and the right-hand side in row n_band + nbr; the
 // lower triangle of the band part must be zero outside the band, the border rows are dense.  x_dev: n_band + nbr doubles.
+// allow_flow = false: the dense top stays off chol.hip's single-launch kernels (the caller saw one of their bounded waits expire:
+// *info_dev > n_band + nbr).
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
-                                  double* x_dev, int* info_dev, bool info_ready) {
+                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow) {
   if (!info_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   switch (T) {
-    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws);
-    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws);
-    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws);
+    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow);
+    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow);
+    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow);
     default: return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve: %d tiles per superblock", T);
   }
 }
@@ -1297,7 +1310,7 @@ extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int ld
   double* bws = W + nw;
   double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false, true));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1325,7 +1338,7 @@ extern "C" gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   double* bws = W + nw;
   double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
