@@ -10,7 +10,7 @@ for line in open("gpurun_out/BENCH_r05_n1.json"):
         j = json.loads(line)
         e = j["extra"]
         print("value", j["value"], "ms/step", j["ms_per_step"], "frac", j["roofline"]["frac"], "attainable", j["roofline"].get("attainable"))
-        print("kernels", {k: round(v["total_ms"] / j["steps"], 3) for k, v in e["kernels"].items() if k.startswith("orb") or k.startswith("bf")})
+        print("kernels", e["kernels"]); print("slam", e.get("orb_slam_mode"))
         print("pipeline", e["roofline_pipeline"])
         print("ba", {k: e["ba"].get(k) for k in ("iters_per_s", "resolve_iters_per_s")}, "lc", {k: (e["ba"].get("loop_closure") or {}).get(k) for k in ("iters_per_s", "resolve_iters_per_s", "border_cams")})
         c5 = e.get("ba_c5") or {}
