@@ -430,6 +430,20 @@ def test_quadtree_distribution_parity(ctx, oracle, w, h, K, B, steer):
     assert (counts > 0).all()
 
 
+@pytest.mark.parametrize("nodes", ["512", "1024", "2048"])
+def test_quadtree_tree_kernel_table_capacities(ctx, oracle, monkeypatch, nodes):
+    """Round 5b: the tree kernel is compiled for node tables of 512 / 1024 / 2048 entries (256 / 512 / 1024 threads) and picks
+    by quota and launch size; here every capacity is forced (GSLAM_HIP_QT_NODES, read when the plan switches mode) on frames
+    whose levels take both cell kernels' size classes (VGA: cells of 31 .. 35 pixels), clean and noisy."""
+    from gslam_amd.orb import synth_frames
+    monkeypatch.setenv("GSLAM_HIP_QT_NODES", nodes)
+    host = synth_frames(ctx, 2, 640, 480, base_seed=0x5EED0777).cpu().numpy()[:, :, :640]
+    _quadtree_case(ctx, oracle, host, 1000, True)
+    rng = np.random.default_rng(int(nodes))
+    noise = rng.integers(0, 256, (1, 260, 380), dtype=np.uint8)
+    _quadtree_case(ctx, oracle, noise, 300, False)
+
+
 def test_quadtree_distribution_dense_candidates_and_small_quotas(ctx, oracle):
     """Noise frames: ~1 candidate per 12 pixels, deep trees, stage (B) of the tree repeated; K from 8 (quotas of 1-2 per
     level, the first pass already overshoots them) to 6000; other level counts and thresholds."""
