@@ -1745,8 +1745,10 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   auto t128_of = [&](int cb, int ce) { return (long long)gh_div_up(nr - cb, TM) * gh_div_up(ce - cb, TM); };
   // rank-kdim update of rows [cb, nr) x columns [cb, ce) + factorisation of the diagonal block at cb
   // The eight-wave tile is worth 4.5 % on the reduced camera system of C5 (1175 -> 1124 ms per LM iteration, same box) and
-  // nothing on a dense random matrix of the same size (1154 ms for either tile shape, and for every other variant tried):
-  // fully dense operands run into the board's power limit at ~62.5 TFLOP/s, the Schur complement's many zero blocks do not.
+  // nothing on a dense random matrix of the same size (1154 ms for either tile shape, and for every other variant tried).
+  // (Rounds 3-4 put that down to the board's power limit.  The round-5 counters say otherwise: SQ_VALU_MFMA_BUSY_CYCLES against
+  // GRBM_GUI_ACTIVE has the matrix pipe 85 % busy inside this kernel at 2.2-2.3 GHz effective -- most of the gap to the peak is
+  // waiting inside the kernel: profiles/c5_dense_solve_r05.txt.)
   // (Tried and dropped: look-ahead -- the bulk of a trailing update on a low-priority side stream while the next panel is
   // factored on this one.  Bit-identical, but the two streams' kernels do not overlap on this part: 1155 ms against
   // 1152 ms for the n = 60 000 factorisation, tools/c5_solve_probe.py.)
