@@ -649,7 +649,10 @@ gh_status gh_potrf_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, double*
  * overwritten, A[r][c] = 0 (stored zeros) for r - c > half_bandwidth; lda > n (row n is scratch for the right-hand side);
  * b_dev in, x out.  half_bandwidth <= 192 and n >= 4 superblocks of 64 * ceil(half_bandwidth / 64) columns, else
  * GH_ERR_ARG.  The result equals gh_potrf_solve_dev's up to rounding (a Cholesky factorisation of the odd-even permuted
- * matrix).  *info: 0 = ok, else first column + 1 of a diagonal tile that is not positive definite. */
+ * matrix).  The reduction stops when two superblocks survive (four with a border: gh_arrow_solve_dev) and hands the system they
+ * form to the dense path (GSLAM_HIP_CR_TOP = 1 .. 16 survivors; 1 = reduce down to the first superblock).
+ * *info: 0 = ok; 1 .. n = first column + 1 of a diagonal tile that is not positive definite; > n = a bounded wait inside the dense
+ * path's single-launch kernels expired (as gh_potrf_solve_dev reports it; A is overwritten either way). */
 gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half_bandwidth, double* b_dev, int* info);
 
 /* ... and for an ARROWHEAD matrix, a band with a dense border: the reduced camera system of a trajectory with a few loop
@@ -657,7 +660,7 @@ gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half
  * gh_ba_options.solver / the arrow ordering of gslam_amd/csrc/ba.hip; the graphs global BA exists for,
  * GSLAM/core/Optimizer.h:127-148,229).  The first n_band unknowns form the band (A[r][c] = 0 for r - c > half_bandwidth,
  * r < n_band), rows n_band .. n - 1 are dense.  Block cyclic reduction on the band with the border rows riding along as extra
- * rows of every eliminated superblock, then the dense system of the first superblock + the border through the dense
+ * rows of every eliminated superblock, then the dense system of the surviving superblocks + the border through the dense
  * factorisation.  Same limits on the band as gh_band_solve_dev; the result equals gh_potrf_solve_dev's up to rounding. */
 gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth, double* b_dev,
                              int* info);
