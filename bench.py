@@ -1199,7 +1199,7 @@ def main():
             torch.cuda.empty_cache()
         extra["orb_range"] = out
         # the ORB-SLAM compatible mode (gh_orb_plan_set_distribution + gh_orb_plan_set_steering): per-cell FAST, quadtree,
-        # continuous steering.  A compatibility path (each call waits for its kernels), reported beside the default mode.
+        # continuous steering.  The compatibility path, reported beside the default mode.
         slam = {}
         for (w, h, k, nfr) in ((640, 480, 1000, 500), (1920, 1080, 2000, 100)):
             exr = OrbExtractor(ctx, w, h, max_batch=nfr, n_features=k)

@@ -2309,9 +2309,11 @@ extern "C" gh_status gh_orb_extract_dev(gh_orb_plan* p, const uint8_t* gray_dev,
   }();
   const bool small = (long long)batch * p->w * p->h <= (4LL << 20);  // up to two 1080p frames: launch-bound
   if (p->distribution != 0) {
-    // quadtree mode: the candidate lists have a budget, and a list that overflowed is an error of THIS call -- it waits for
-    // its own kernels (the mode is the compatibility path, not the throughput path)
+    // quadtree mode: when the plan's key budget cut a candidate list below its worst case, a list that overflowed is an error of
+    // THIS call -- it waits for its own kernels.  Otherwise (every plan whose worst case fits 4 GB: 1080p up to ~400 frames per
+    // call) nothing can overflow and the call is asynchronous like the default mode's.
     GH_TRY(orb_enqueue(p, gray_dev, batch, frame_stride, row_stride, kps_dev, desc_dev, counts_dev));
+    if (!gh_qt_can_overflow(p->qt)) return GH_OK;
     GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return gh_qt_check(ctx, p->qt);
   }

@@ -34,6 +34,7 @@ void gh_qt_destroy(gh_qt_plan* q);
 // at base[y * pitch + x + kQtPlaneX], S of oracle step 2 / 3) -- the cells of such a level are taken from it instead of the image.
 gh_status gh_qt_enqueue(gh_ctx* ctx, gh_qt_plan* q, const LevelView* lv, int batch, int min_th, int ini_th,
                         const int* quota_off, int K, SelKp* sel, int32_t* level_cnt, const LevelView* planes = nullptr);
+bool gh_qt_can_overflow(const gh_qt_plan* q);
 bool gh_qt_plane_ok(const gh_qt_plan* q, int l);
 // gh_qt_enqueue in three parts (each on ctx->stream at the time of the call): counters, the cells of ONE level (plane may be
 // null / hold a null base), the tree -- for a caller that runs the cells of level l beside the kernel producing level l + 1

@@ -809,6 +809,7 @@ struct gh_qt_plan {
   bool attr_set = false;
   int nodes = 2048;  // least table capacity of the tree kernel (512 / 1024 / 2048) that holds every level's quota + 3 and 4 roots
   int nodes_forced = 0;  // GSLAM_HIP_QT_NODES
+  bool can_overflow = true;  // the key lists are smaller than the worst case (the plan's key budget cut them): calls must check the flag
 };
 
 void gh_qt_destroy(gh_qt_plan* q) {
@@ -833,6 +834,7 @@ gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, 
   // of the budget otherwise -- an overflowing list is an error of the call (gh_qt_check), never a silent truncation
   size_t worst[kMaxL] = {}, worst_total = 0;
   int need_nodes = 0;
+  bool any_cut = false;
   int qo = 0;
   for (int l = 0; l < kMaxL; ++l) {
     QtLevel& v = q->args.lv[l];
@@ -884,11 +886,13 @@ gh_status gh_qt_create(gh_ctx* ctx, int n_levels, const int* lw, const int* lh, 
     size_t cap = worst[l];
     if (worst_total > budget) cap = (size_t)((double)worst[l] * (double)budget / (double)worst_total);
     if (cap >= ((size_t)1 << 22)) cap = ((size_t)1 << 22) - 1;  // the sort key of stage (B) carries the count in 22 bits
+    if (cap < worst[l]) any_cut = true;
     v.cap = (uint32_t)cap;
     v.key_off = off;
     off += (cap + 63) & ~(size_t)63;
   }
   q->keys_per_frame = off ? off : 64;
+  q->can_overflow = any_cut;
   const size_t B = (size_t)max_batch;
   gh_status st;
   if ((st = gh_dev_alloc(ctx, B * q->keys_per_frame * 4, (void**)&q->keys)) != GH_OK ||
@@ -978,6 +982,10 @@ gh_status gh_qt_check(gh_ctx* ctx, gh_qt_plan* q) {
   }
   return GH_OK;
 }
+
+// Whether a call has to wait for its kernels and read the overflow flag (gh_qt_check): only when the plan's key budget cut a
+// level's list below its worst case -- ceil(wc / 2) ceil(hc / 2) strict maxima per cell, they are pairwise non-adjacent.
+bool gh_qt_can_overflow(const gh_qt_plan* q) { return !q || q->can_overflow; }
 
 // whether level l's cells can be taken from a score plane (cells of at most 40 x 40: a level whose side holds 3+ cells)
 bool gh_qt_plane_ok(const gh_qt_plan* q, int l) {

@@ -226,8 +226,10 @@ gh_status gh_orb_plan_set_steering(gh_orb_plan* plan, int mode);
  * (frame, level) the quadtree: nodes split into four until there are n_l of them (largest first in the last stage), the
  * strongest corner of each node kept.  Specification: oracle/orb_oracle.c steps 4' and 5' (bit-exact; ties that ORB-SLAM
  * leaves to heap addresses are fixed there).  Output rows per level are in (y, x) order.  Limits: levels up to 4096 x 4096,
- * per-level quota <= 2045.  A call in this mode waits for its kernels; a frame with more FAST maxima than the plan's
- * candidate budget (exact worst case while that fits 4 GB over max_batch frames) fails with GH_ERR_NOMEM, never silently.
+ * per-level quota <= 2045.  The candidate lists hold the exact worst case (one strict maximum per 2 x 2 pixels of a cell) while
+ * that fits 4 GB over max_batch frames (1080p: up to ~400 frames per call) and calls are asynchronous like the default mode's;
+ * a plan whose budget had to cut the lists makes every call wait for its kernels, and a frame with more FAST maxima than a
+ * list holds fails with GH_ERR_NOMEM, never silently.
  * Together with gh_orb_plan_set_steering(plan, 1) and the canonical pattern this is the ORB-SLAM extraction up to the image
  * arithmetic (integer pyramid and blur here, float resize there; KeyPoint.response = FAST score, OpenCV's is score - 1). */
 gh_status gh_orb_plan_set_distribution(gh_orb_plan* plan, int mode);
