@@ -716,7 +716,6 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     static_assert(P1 != 0, "the plane variant is written for the flat 68-byte score rows");
     uint8_t* pl = nx.plane + (size_t)frame * nx.plane_frame_stride;
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(score);
-    if (nx.plane_pitch == 0) return;  // (timing experiments only: GSLAM_HIP_QT_EXP=nostore)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = tid + 256 * k, r = idx >> 4, cd = idx & 15;
@@ -2517,7 +2516,6 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
         nx.plane = p->score_plane + p->plane_off[l];
         nx.plane_frame_stride = p->plane_slab;
         nx.plane_pitch = p->plane_pitch[l];
-        if (const char* e = getenv("GSLAM_HIP_QT_EXP")) if (strstr(e, "nostore")) nx.plane_pitch = 0;
         const long long tiles = (long long)gh_div_up(p->ncx[l], 2) * gh_div_up(p->ncy[l], 2) * batch;
         GH_CHECK_ARG(ctx, tiles < (1LL << 30));
         const uint32_t nbx = (uint32_t)gh_div_up(p->ncx[l], 2), tpf = nbx * (uint32_t)gh_div_up(p->ncy[l], 2);

@@ -1,5 +1,5 @@
-"""GPU box: wall time of the quadtree (ORB-SLAM) extraction mode at 1080p, K = 2000, 100 frames, by variant:
-   steering on / off, and whatever GSLAM_HIP_QT_EXP switches the caller sets.  Wall clock over 5 calls, no per-kernel events."""
+"""GPU box: wall time of the quadtree (ORB-SLAM) extraction mode at 1080p, K = 2000, 100 frames, steering on / off, under
+   whatever GSLAM_HIP_* switches the caller sets.  Best of three groups of 5 back-to-back calls, no per-kernel events."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,5 +26,5 @@ for steer in (1, 0):
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t) / 5)
     kp = int(o[2].sum().item())
-    print("EXP=%s steer=%d: %.3f ms per call, %.2f Mkeypoints/s" % (os.environ.get("GSLAM_HIP_QT_EXP", ""), steer, best * 1e3, kp / best / 1e6))
+    print("steer=%d: %.3f ms per call, %.2f Mkeypoints/s" % (steer, best * 1e3, kp / best / 1e6))
     ex.close()
