@@ -38,7 +38,9 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
                                int* info_dev, bool info_ready);
 size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr);
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
-                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow);
+                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz);
+size_t gh_cr_border_symbolic_bytes(int n_band, int T, int nbr);
+void gh_cr_border_symbolic(int n_band, int T, int nbr, const uint8_t* init, uint8_t* out);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
 gh_status gh_potrs_bwd_dev_impl(gh_ctx* ctx, const double* L, int n, int lda, double* b, double* work,
                                 const double* dinv, const double* yv, long long ystride, double* xh, int* info_dev,
@@ -1530,6 +1532,10 @@ struct BaSession {
   std::vector<int32_t> perm;
   int n_border = 0;  // cameras of the border
   double* d_arrow_ws = nullptr;
+  // structure of the border rows of the reduced camera system (arrowhead solver): border_cam_nz[strip * nc_band + c] != 0 iff a
+  // border camera with rows in the 16-row strip sees a point band camera c sees; d_border_nz = what gh_cr_border_symbolic made of it
+  std::vector<uint8_t> border_cam_nz;
+  uint8_t* d_border_nz = nullptr;
   bool ready = false;
   void* arena = nullptr;  // graph-owned arena (unused by one-shot solves)
   size_t arena_bytes = 0;
@@ -1598,6 +1604,40 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     for (int p = 0; p < np; ++p)
       if (cam_hi[p] >= 0 && cam_hi[p] - cam_lo[p] > span) span = cam_hi[p] - cam_lo[p];
     S.cam_span = span;
+    S.border_cam_nz.clear();
+    // (GSLAM_HIP_BA_ARROW_DENSE_BORDER = 1: never, 0: always; default: when the border block has 4 M entries or more -- at C4 + 20
+    //  closures, 0.8 M, the two passes below cost what the border kernels save over a dozen iterations; at C5 + 50, 51 M, one
+    //  iteration pays for them)
+    const char* dense_border_env = getenv("GSLAM_HIP_BA_ARROW_DENSE_BORDER");
+    const bool want_structure = dense_border_env ? dense_border_env[0] == '0' : 36LL * S.n_border * nc_band >= (4LL << 20);
+    if (S.n_border > 0 && want_structure) {
+      // which (border strip, band camera) blocks of the reduced system can be non-zero: a common point (two more passes)
+      const int nbs = (6 * S.n_border + 15) / 16;
+      std::vector<int32_t> first((size_t)np, -1), next_of;   // per point: chain of its border observers
+      std::vector<int32_t> cam_of;
+      std::vector<uint8_t> has((size_t)np / 8 + 1, 0);        // (a bit per point: the test of the second pass stays in cache)
+      for (int k = 0; k < no; ++k) {
+        const int32_t c = pr->obs_cam[k];
+        if (c < nc_band) continue;
+        const int32_t p = pr->obs_point[k];
+        cam_of.push_back(c - nc_band);
+        next_of.push_back(first[p]);
+        first[p] = (int32_t)cam_of.size() - 1;
+        has[(size_t)p >> 3] |= (uint8_t)(1u << (p & 7));
+      }
+      S.border_cam_nz.assign((size_t)nbs * nc_band, 0);
+      for (int k = 0; k < no; ++k) {
+        const int32_t p = pr->obs_point[k];
+        if (!((has[(size_t)p >> 3] >> (p & 7)) & 1)) continue;
+        const int32_t c = pr->obs_cam[k];
+        if (c >= nc_band) continue;
+        for (int32_t e = first[p]; e >= 0; e = next_of[e]) {
+          const int r0 = 6 * cam_of[e];
+          S.border_cam_nz[(size_t)(r0 / 16) * nc_band + c] = 1;
+          S.border_cam_nz[(size_t)((r0 + 5) / 16) * nc_band + c] = 1;
+        }
+      }
+    }
   }
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
@@ -1897,6 +1937,26 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n_band, cr_T)));
       // (band-only systems too: the reduction's last levels go to the dense path -- chol_cr.hip, DENSE TOP)
       GH_TRY(db.alloc(&S.d_arrow_ws, gh_arrow_ws_doubles(ctx, n_band, cr_T, n - n_band)));
+      S.d_border_nz = nullptr;
+      if (n_band < n && !S.border_cam_nz.empty()) {
+        // per (superblock, strip), through the levels of the reduction: the border kernels skip what stays zero
+        const int m = 64 * cr_T, N = gh_div_up(n_band, m), nbs = gh_div_up(n - n_band, 16), ncb = nc - S.n_border;
+        std::vector<uint8_t> init((size_t)N * nbs, 0), sym(gh_cr_border_symbolic_bytes(n_band, cr_T, n - n_band));
+        for (int t = 0; t < nbs; ++t)
+          for (int c = 0; c < ncb; ++c)
+            if (S.border_cam_nz[(size_t)t * ncb + c]) {
+              init[(size_t)((6 * c) / m) * nbs + t] = 1;
+              init[(size_t)((6 * c + 5) / m) * nbs + t] = 1;
+            }
+        gh_cr_border_symbolic(n_band, cr_T, n - n_band, init.data(), sym.data());
+        GH_TRY(db.alloc(&S.d_border_nz, sym.size()));
+        GH_HIP(ctx, hipMemcpy(S.d_border_nz, sym.data(), sym.size(), hipMemcpyHostToDevice));
+        if (opt.verbose) {
+          size_t nzc = 0;
+          for (size_t e = 0; e < (size_t)N * nbs; ++e) nzc += sym[e] != 0;
+          fprintf(stderr, "[gh_ba] border structure: %zu of %zu (superblock, 16-row strip) blocks can be non-zero when eliminated\n", nzc, (size_t)N * nbs);
+        }
+      }
     }
     if (opt.verbose)
       fprintf(stderr, "[gh_ba] band cameras of a point at most %d indices apart, %d border cameras: half-bandwidth %d of n = %d -> %s\n",
@@ -2101,7 +2161,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
     if (cr_T) {  // (n_band == n: a band without a border)
       GH_TRY(gh_arrow_solve_dev_impl(ctx, d_S, n_band, n - n_band, lda, cr_T, d_cr_dinv, d_cr_W, S.d_arrow_ws, d_dc, d_info,
-                                     solve_state_ready, cr_flow_ok));
+                                     solve_state_ready, cr_flow_ok, S.d_border_nz));
     } else {
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place

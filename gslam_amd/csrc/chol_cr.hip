@@ -81,6 +81,12 @@ struct CrArgs {
   // DENSE TOP (cr_solve_t): the reduction stops when at most gh_cr_top(nbr) superblocks survive -- 0, keep, 2 keep, ... -- and the
   // block tridiagonal system they form (+ the border) goes to chol.hip's dense path; keep >= N: only superblock 0 survives
   int keep = 1 << 30;
+  // STRUCTURE OF THE BORDER (gh_cr_border_symbolic; null = treat E as dense): nzY[i * nbs + strip] != 0 iff the 16-row strip of the
+  // border can be non-zero in the columns of superblock i at the moment i is eliminated; nzT[i * ntr + t] the same per 64-row
+  // tile of the corner (the tile that holds the right-hand-side row is always set)
+  const uint8_t* nzY = nullptr;
+  const uint8_t* nzT = nullptr;
+  int nbs = 0, ntr = 0;
 };
 
 // compile-time loop: f(std::integral_constant<int, K>) for K = 0 .. N - 1 (a runtime loop around the potf2 code is not
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
   const int strip = side == 4 ? task - 8 * T - 1 : (side == 3 ? task : task - 4 * T * (side == 1 ? 1 : (side == 2 ? 2 : 0)));
   const int nb = side == 0 ? i - a.s : i + a.s;
   if (side < 2 && (nb < 0 || nb >= a.N)) return;
+  if (side == 4 && a.nzY != nullptr && a.nzY[i * a.nbs + strip] == 0) return;  // E_i is zero in these rows: Y_i = 0 is already there
   const int nb0 = nb * m_ + 16 * strip;  // first row of the strip (side u / d)
   CR_STAMP(16);
   // ---- the strip of P: asked for first (it is needed first), into registers; LDS behind the operand requests below
@@ -886,10 +893,13 @@ __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt
   const int r = row_b + m;
   const size_t roff = (size_t)n + (size_t)(r < a.nbr ? r : a.nbr - 1);
   double4_t acc0 = (double4_t){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  bool any = false;
 #pragma unroll
   for (int sd = 0; sd < 2; ++sd) {
     const int src = sd == 0 ? j - a.s : j + a.s;
     if (src < 0 || src >= a.N) continue;
+    if (a.nzY != nullptr && a.nzY[src * a.nbs + (row_b >> 4)] == 0) continue;  // (wave-uniform) Y_src is zero in this wave's rows
+    any = true;
     const double* Wp = a.W + ((size_t)src * 2 + (sd == 0 ? 1 : 0)) * mm + col_b + m;  // j is the d-neighbour of j - s, the u-neighbour of j + s
     const int s0 = src * m_;
     double av[KS], bv[KS];
@@ -906,6 +916,7 @@ __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt
       acc1 = mma(av[ks + 1], bv[ks + 1], acc1);
     }
   }
+  if (!any) return;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int col = j * m_ + col_b + q + 4 * rr;
@@ -943,7 +954,9 @@ __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int kcols
     co[b] = n + (c < next ? c : next - 1);
   }
   for (int k = k0; k < k1; k += 16) {
-    if ((((k / m_)) & (a.keep - 1)) == 0) continue;  // (uniform) a survivor's columns hold E_j, not Y: they join the dense system
+    const int sbk = k / m_;
+    if ((sbk & (a.keep - 1)) == 0) continue;  // (uniform) a survivor's columns hold E_j, not Y: they join the dense system
+    if (a.nzT != nullptr && (a.nzT[sbk * a.ntr + ta] == 0 || a.nzT[sbk * a.ntr + tb] == 0)) continue;  // Y is zero in the rows of one operand
     double av[4][2], bv[4][2];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1093,7 +1106,7 @@ __global__ __launch_bounds__(256) void cr_border_yh_kernel(CrArgs a, const doubl
 // nbr > 0: an arrowhead system (see above) -- A holds n + nbr unknowns, bws the border workspace (gh_arrow_ws_doubles).
 template <int T>
 gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, double* W, double* x, int* info_dev, int nbr = 0,
-                     double* bws = nullptr, bool allow_flow = true) {
+                     double* bws = nullptr, bool allow_flow = true, const uint8_t* border_nz = nullptr) {
   constexpr int m_ = NBI * T;
   const int N = gh_div_up(n, m_);
   const size_t mm = (size_t)m_ * m_;
@@ -1122,6 +1135,12 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   CrArgs a{A, lda, n, N, 1, 0, 0, dinv, W, W + 2 * (size_t)N * mm, W + 4 * (size_t)N * mm, W + 5 * (size_t)N * mm, x, info_dev};
   a.nbr = nbr;
   a.rr = n + nbr;
+  if (border_nz != nullptr && nbr > 0) {
+    a.nbs = gh_div_up(nbr, 16);
+    a.ntr = gh_div_up(nbr + 1, 64);
+    a.nzY = border_nz;
+    a.nzT = border_nz + (size_t)N * a.nbs;
+  }
   const int nbs = gh_div_up(nbr, 16), nrt = gh_div_up(nbr, 64);  // 16-row strips / 64-row tiles of the border
   constexpr int NTS = 4 * (T * (T + 1) / 2 + T * T) + m_ / 16, NTE = 4 * (2 * T * T) + m_ / 16;
   auto update_grid = [](int ngroups, int ntask) {  // the mapping of cr_update_kernel
@@ -1238,6 +1257,52 @@ size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr) {
          (((size_t)n_band + 15) & ~(size_t)15) + gh_potrf_flow_words(ctx, (int)qn, 1) / 2 + 64;
 }
 
+// Structure of the border through the reduction (host, once per topology).  init[i * nbs + strip] != 0 iff the 16-row strip
+// of the border rows has a structural non-zero among the band columns of superblock i (a border camera and a band camera that
+// see a common point).  Eliminating i at level s fills the strips of i into i - s and i + s (E_u -= Y_i W_u^T); out receives
+// nzY [N][nbs] -- the strips of E_i when i is eliminated, all set for the survivors of the dense top -- then nzT [N][ntr]: per
+// 64-row tile of the corner, with the tile that holds the right-hand-side row (it rides along as row nbr) always set.
+// Conservative by construction: a block marked zero is never written by any kernel and was cleared by the assembly.
+size_t gh_cr_border_symbolic_bytes(int n_band, int T, int nbr) {
+  const size_t N = (size_t)gh_div_up(n_band, NBI * T);
+  return N * ((size_t)gh_div_up(nbr, 16) + (size_t)gh_div_up(nbr + 1, 64));
+}
+void gh_cr_border_symbolic(int n_band, int T, int nbr, const uint8_t* init, uint8_t* out) {
+  const int m = NBI * T, N = gh_div_up(n_band, m), nbs = gh_div_up(nbr, 16), ntr = gh_div_up(nbr + 1, 64);
+  std::vector<uint8_t> cur(init, init + (size_t)N * nbs);
+  uint8_t* nzY = out;
+  uint8_t* nzT = out + (size_t)N * nbs;
+  memset(nzY, 1, (size_t)N * nbs);
+  const int top = gh_cr_top(nbr);
+  int S = 1;
+  while (gh_div_up(N, S) > top) S *= 2;
+  for (int s = 1; s < S; s *= 2)
+    for (int i = s; i < N; i += 2 * s) {
+      memcpy(nzY + (size_t)i * nbs, &cur[(size_t)i * nbs], (size_t)nbs);
+      for (int side = -1; side <= 1; side += 2) {
+        const int j = i + side * s;
+        if (j < 0 || j >= N) continue;
+        for (int t = 0; t < nbs; ++t) cur[(size_t)j * nbs + t] |= cur[(size_t)i * nbs + t];
+      }
+    }
+  for (int i = 0; i < N; ++i)
+    for (int t = 0; t < ntr; ++t) {
+      uint8_t v = (t == nbr / 64) ? 1 : 0;
+      for (int w = 0; w < 4; ++w)
+        if (4 * t + w < nbs) v |= nzY[(size_t)i * nbs + 4 * t + w];
+      nzT[(size_t)i * ntr + t] = v;
+    }
+}
+
+// C-ABI face of the two functions above for tests and tools (host only, no GPU): returns the bytes `out` needs (N * (nbs + ntr))
+// and fills it when out != NULL and out_bytes suffices; 0 = bad arguments.
+extern "C" size_t gh_cr_border_structure(int n_band, int tiles, int nbr, const uint8_t* init, uint8_t* out, size_t out_bytes) {
+  if (n_band < 1 || tiles < 1 || tiles > 3 || nbr < 1) return 0;
+  const size_t need = gh_cr_border_symbolic_bytes(n_band, tiles, nbr);
+  if (out != nullptr && init != nullptr && out_bytes >= need) gh_cr_border_symbolic(n_band, tiles, nbr, init, out);
+  return need;
+}
+
 // Tiles per superblock for a half-bandwidth of `hbw` scalars (A[r][c] = 0 for r - c > hbw), 0 = the band is too wide for
 // this solver (or the matrix too small to gain from it): the caller stays on the dense factorisation.
 int gh_cr_tiles(int n, int hbw) {
@@ -1271,15 +1336,16 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
 
 // Arrowhead solve: A holds n_band + nbr unknowns (band first, border last) and the right-hand side in row n_band + nbr; the
 // lower triangle of the band part must be zero outside the band, the border rows are dense.  x_dev: n_band + nbr doubles.
+// border_nz (device, may be null = E dense): the structure gh_cr_border_symbolic computed for this system, N * (nbs + ntr) bytes.
 // allow_flow = false: the dense top stays off chol.hip's single-launch kernels (the caller saw one of their bounded waits expire:
 // *info_dev > n_band + nbr).
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
-                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow) {
+                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz) {
   if (!info_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   switch (T) {
-    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow);
-    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow);
-    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow);
+    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz);
+    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz);
+    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz);
     default: return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve: %d tiles per superblock", T);
   }
 }
@@ -1310,7 +1376,7 @@ extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int ld
   double* bws = W + nw;
   double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false, true));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1338,7 +1404,7 @@ extern "C" gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   double* bws = W + nw;
   double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -667,6 +667,18 @@ gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half
 gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth, double* b_dev,
                              int* info);
 
+/* Structure of the border through the reduction (host only, no GPU; what gh_ba_solve computes once per topology when the
+ * border block has 4 M entries or more, so that the border kernels of the arrowhead solver skip what stays zero).
+ * tiles = 64-column tiles per superblock (1 .. 3, as the solver picks them for the half-bandwidth); with m = 64 tiles,
+ * N = ceil(n_band / m), nbs = ceil(nbr / 16), ntr = ceil((nbr + 1) / 64):
+ *   init[i * nbs + t] != 0  iff  the 16-row strip t of the border rows has a structural non-zero among the band columns of
+ *                                superblock i (a border camera and a band camera that see a common point);
+ *   out: N * nbs bytes -- the strips that can be non-zero in superblock i at the moment the reduction eliminates it (all set
+ *        for the superblocks that survive into the dense system) -- then N * ntr bytes, the same per 64-row tile of the
+ *        corner (the tile that holds the right-hand-side row always set).
+ * Returns the bytes `out` needs (0 = bad arguments); fills `out` when it is non-NULL and out_bytes suffices. */
+size_t gh_cr_border_structure(int n_band, int tiles, int nbr, const uint8_t* init, uint8_t* out, size_t out_bytes);
+
 /* Block-sparse Cholesky with a dense root: the linear solver gh_pg_solve uses for LARGE pose graphs
  * (GSLAM/core/Optimizer.h:127-148,162-167 -- se3Graph / sim3Graph / gpsGraph over thousands of keyframes; the system has
  * one 7 x 7 block per keyframe and one per edge).  Exposed for tests and tools:

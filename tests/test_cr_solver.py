@@ -100,7 +100,7 @@ def make_arrow(n_band, hb, nbr, seed=0, fill=1.0):
     return A
 
 
-def arrow_solve_restated(S, b, n_band, m, top=1):
+def arrow_solve_restated(S, b, n_band, m, top=1, on_eliminate=None):
     """The schedule of chol_cr.hip's arrowhead mode: block cyclic reduction on the band with the border rows E and the
     right-hand side riding along as extra rows (Y_i = E_i L_i^-T, E_u -= Y_i W_u^T, E_d -= Y_i W_d^T), the corner update
     C -= sum_i Y_i Y_i^T over every eliminated superblock, the dense solve of superblock 0 + border, and the backward pass
@@ -132,6 +132,8 @@ def arrow_solve_restated(S, b, n_band, m, top=1):
             if d < N:
                 W[(i, 1)] = np.linalg.solve(L[i], A[blk(d), blk(i)].T).T
             rhs[blk(i)] = np.linalg.solve(L[i], rhs[blk(i)])
+            if on_eliminate is not None:
+                on_eliminate(i, A[bord, blk(i)])
             Y[i] = np.linalg.solve(L[i], A[bord, blk(i)].T).T            # E_i L_i^-T  (nbr x m)
             A[bord, blk(i)] = Y[i]
         for i in elim:
@@ -201,6 +203,58 @@ def test_dense_top_schedule_restated_matches_dense(n_band, hb, m, nbr, top):
     x = arrow_solve_restated(S, b, n_band, m, top=top)
     xr = np.linalg.solve(S, b)
     assert np.abs(x - xr).max() <= 1e-13 * np.abs(xr).max()
+
+
+def _load_lib_cpu():
+    """the C-ABI library without a GPU context (host-only entry points)"""
+    from gslam_amd import hip
+    return hip.lib
+
+
+@pytest.mark.parametrize("n_band,hb,m,nbr,top", [(3000, 149, 192, 90, 4), (2000, 60, 64, 130, 4), (1345, 128, 128, 40, 4), (3000, 149, 192, 300, 4)])
+def test_border_structure_is_conservative(n_band, hb, m, nbr, top):
+    """gh_cr_border_structure (what lets the border kernels of the arrowhead solver skip blocks): on a border that couples every
+    16-row strip to a few random places of the band, every (superblock, strip) block that is non-zero in the numpy restatement
+    at the moment the superblock is eliminated is marked -- and the marking is not trivial (most blocks stay unmarked)."""
+    import ctypes as C
+    lib = _load_lib_cpu()
+    rng = np.random.default_rng(n_band + nbr)
+    S = make_arrow(n_band, hb, nbr, seed=n_band + nbr)
+    N, nbs = -(-n_band // m), -(-nbr // 16)
+    E = np.zeros((nbr, n_band))
+    init = np.zeros((N, nbs), np.uint8)
+    for t in range(nbs):
+        for c0 in rng.integers(0, n_band - 12, 3):  # three "cameras" of 6 columns per strip, two strips may share one
+            r0, r1 = 16 * t, min(nbr, 16 * t + 16)
+            E[r0:r1, c0:c0 + 6] = rng.standard_normal((r1 - r0, 6)) * 0.05
+            init[c0 // m, t] = 1
+            init[(c0 + 5) // m, t] = 1
+    S[n_band:, :n_band] = E
+    S[:n_band, n_band:] = E.T
+    S[n_band:, n_band:] += np.eye(nbr) * 2.0
+    need = lib.gh_cr_border_structure(n_band, m // 64, nbr, None, None, 0)
+    ntr = -(-(nbr + 1) // 64)
+    assert need == N * (nbs + ntr)
+    out = np.zeros(need, np.uint8)
+    assert lib.gh_cr_border_structure(n_band, m // 64, nbr, init.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), need) == need
+    nzY, nzT = out[:N * nbs].reshape(N, nbs), out[N * nbs:].reshape(N, ntr)
+    seen = {}
+
+    def on_eliminate(i, Ei):
+        seen[i] = np.array([np.any(Ei[16 * t:16 * t + 16] != 0.0) for t in range(nbs)])
+
+    b = rng.standard_normal(n_band + nbr)
+    x = arrow_solve_restated(S, b, n_band, m, top=top, on_eliminate=on_eliminate)
+    assert np.abs(x - np.linalg.solve(S, b)).max() <= 1e-12 * np.abs(x).max()
+    assert len(seen) >= N - top
+    for i, nz in seen.items():
+        assert not np.any(nz & (nzY[i] == 0)), "superblock %d: a non-zero strip is marked zero" % i
+        for t in range(ntr):
+            assert nzT[i, t] == (1 if (t == nbr // 64 or nzY[i, 4 * t:4 * t + 4].any()) else 0)
+    elim = sorted(seen)
+    assert nzY[elim].mean() < 0.6  # (sparse input: most blocks are skipped)
+    surv = [i for i in range(N) if i not in seen]
+    assert nzY[surv].all()
 
 
 # ---------------------------------------------------------------------------------------------------------------- GPU
@@ -381,11 +435,15 @@ def test_ba_one_loop_closure_takes_the_arrow_solver(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cams,points,closures,span", [(160, 8000, 5, 80), (300, 20000, 12, None), (500, 50000, 20, None)])
-def test_ba_arrow_and_dense_solvers_agree(ctx, cams, points, closures, span):
+@pytest.mark.parametrize("structure", ["0", "1"])
+def test_ba_arrow_and_dense_solvers_agree(ctx, monkeypatch, cams, points, closures, span, structure):
     """Trajectories with loop-closure points (ba_synth.make_graph(loop_closures=...)) through the dense factorisation and through
     the arrowhead solver (band + border, arrow ordering of the cameras inside gh_ba_solve): identical LM decisions, costs to
     1e-10, states to 1e-9 in the CALLER's camera order (C4 + 20 closures at full size included)."""
     from gslam_amd.ba_synth import make_graph
+    # GSLAM_HIP_BA_ARROW_DENSE_BORDER = 0: the border kernels skip the blocks gh_cr_border_structure marks zero (by default only
+    # from 4 M entries of border block on: C5-sized systems); 1: every block is processed
+    monkeypatch.setenv("GSLAM_HIP_BA_ARROW_DENSE_BORDER", structure)
     g = make_graph(cams, points, n_obs_per_point=6, seed=2, loop_closures=closures, closure_span=span)
     pd, xd, sd, used_d = _solve_with(ctx, g, "dense")
     pa, xa, sa, used_a = _solve_with(ctx, g, "auto")
@@ -398,11 +456,13 @@ def test_ba_arrow_and_dense_solvers_agree(ctx, cams, points, closures, span):
 
 
 @pytest.mark.gpu
-def test_ba_arrow_graph_session_round_trip(ctx):
+@pytest.mark.parametrize("structure", ["0", "1"])
+def test_ba_arrow_graph_session_round_trip(ctx, monkeypatch, structure):
     """The device-resident graph API keeps its cameras in arrow order inside: create / update / solve / read give the one-shot
-    solve's result in the caller's camera order."""
+    solve's result in the caller's camera order (with and without the border's block structure: it is kept with the session)."""
     from gslam_amd import ba
     from gslam_amd.ba_synth import make_graph
+    monkeypatch.setenv("GSLAM_HIP_BA_ARROW_DENSE_BORDER", structure)
     g = make_graph(200, 10000, n_obs_per_point=6, seed=4, loop_closures=6)
     p1, x1, s1, _ = ba.solve(ctx, g, ba.default_options(max_iterations=15))
     assert ctx.last_ba_solver()[0] == "arrow"
