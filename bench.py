@@ -889,7 +889,7 @@ def main():
         ctx.prof_enable(False)
         s = s or sp
         resolve = None
-        if separate_timed_run and cams < 10000:
+        if separate_timed_run and (cams < 10000 or iters >= 40):  # (C5: only with the runs to convergence)
             # the same graph kept on the device (gh_ba_graph_*): what a back end that re-optimises its window pays per solve
             G = ba.Graph(ctx, g, ba.default_options(max_iterations=iters))
             G.solve(ba.default_options(max_iterations=iters))
@@ -1027,7 +1027,7 @@ def main():
             # 5 iterations are mostly set-up (index lists + 200 MB of upload) at this solver's speed: the rate of a run to convergence
             bl = ba_leg(10000, 1000000, 40, True, prof_iters=2, solver="auto", graph=g5)
             extra["ba_c5"]["band_solver"]["to_convergence"] = {k: bl[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
-                                                                                    "initial_cost", "final_cost")}
+                                                                                    "initial_cost", "final_cost", "resolve_iters_per_s")}
             del g5
             torch.cuda.empty_cache()
             # C5 + 50 loop-closure points 5000 cameras apart: rounds 1-4 solved this dense (0.89 LM it/s), now band + border
@@ -1042,7 +1042,7 @@ def main():
             extra["ba_c5"]["loop_closure"] = {"closure_points": 50, "closure_span_cams": 5000, "border_cams": int(ctx_border_cams(g5c)),
                                               **{k: lc5[k] for k in keys5}, "kernels": lc5["kernels"],
                                               "to_convergence": {k: ll5[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
-                                                                                     "initial_cost", "final_cost")},
+                                                                                     "initial_cost", "final_cost", "resolve_iters_per_s")},
                                               "dense_solver_2_iterations": {k: ld5[k] for k in ("iters_per_s", "ms_per_iteration", "iterations", "final_cost")},
                                               "what": "make_graph(loop_closures=50, closure_span=5000); arrowhead solver (band + border); the "
                                                       "dense solver on the same graph for 2 iterations as the parity check and the rate rounds "
