@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["--steps", "2", "--warmup", "1", "--width", "640", "--height", "480", "--kpts", "600", "--no-cpu-baseline", "--no-ba",
-         "--no-bow", "--no-c5", "--no-host-fed", "--no-all-pairs-full", "--no-range"]
+         "--no-bow", "--no-c5", "--no-host-fed", "--no-all-pairs-full", "--no-range", "--full-line"]
 
 
 def _free_port():
