@@ -993,7 +993,10 @@ def main():
                 "dense_solve": ({"bound": "mfma", "n": n,
                                  "achieved_TFLOPs": round(solve_flops / (chol_ms * 1e-3) / 1e12, 3),
                                  "peak_TFLOPs": FP64_MFMA_PEAK / 1e12,
-                                 "frac": round(solve_flops / (chol_ms * 1e-3) / FP64_MFMA_PEAK, 4)} if chol_ms else None),
+                                 "frac": round(solve_flops / (chol_ms * 1e-3) / FP64_MFMA_PEAK, 4)}
+                                # (only when the dense factorisation RAN: the band / arrowhead solvers put their dense top through the same
+                                #  kernels, and n^3 / 3 flops over that time is not a rate of anything -- VERDICT r5 W9 (i))
+                                if chol_ms and used == "dense" else None),
                 "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in bprof.items()}}
 
     def ctx_border_cams(g):

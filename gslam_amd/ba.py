@@ -48,6 +48,21 @@ def solve(ctx: hip.Context, graph: dict, options=None):
     return poses, pts, s, st
 
 
+def camera_order(graph: dict):
+    """gh_ba_camera_order (host only, no GPU): the camera order gh_ba_solve would use inside the solver.
+    Returns (perm [new position -> caller's camera], border cameras, camera span of the band part, reordered)."""
+    ocam = np.ascontiguousarray(graph["obs_cam"], dtype=np.int32)
+    opt = np.ascontiguousarray(graph["obs_point"], dtype=np.int32)
+    nc, npnt = len(graph["cam_dof"]), len(graph["point_xyz"])
+    pr = hip.BaProblem(nc, npnt, len(ocam), None, None, None, None, _ptr(ocam), _ptr(opt), None, None)
+    perm = np.zeros(nc, np.int32)
+    nb, span, re = C.c_int32(), C.c_int32(), C.c_int32()
+    st = hip.lib.gh_ba_camera_order(C.byref(pr), _ptr(perm), C.byref(nb), C.byref(span), C.byref(re))
+    if st != 0:
+        raise ValueError("gh_ba_camera_order: status %d" % st)
+    return perm, nb.value, span.value, bool(re.value)
+
+
 class Graph:
     """gh_ba_graph_*: the problem stays in HBM between solves (index lists, pair lists, tables, arrays)."""
 

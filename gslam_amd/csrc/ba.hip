@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "common.h"
+#include "host_pool.h"
 
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
                             double* xwork, unsigned* flow_state, bool store_diag, bool state_ready);
@@ -39,6 +40,7 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
 size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr);
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
                                   double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz);
+int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int* reordered, bool allow_reorder, int* band_span);  // ba_order.hip
 size_t gh_cr_border_symbolic_bytes(int n_band, int T, int nbr);
 void gh_cr_border_symbolic(int n_band, int T, int nbr, const uint8_t* init, uint8_t* out);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
@@ -501,9 +503,12 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
 
 __global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
                                                          const double* __restrict__ gc, double radius,
-                                                         double* __restrict__ S, double* __restrict__ rhs, int band_m, int nband) {
-  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, (int)blockIdx.y, nband);  // (gridDim.x == 1)
-  else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, (int)blockIdx.x, (int)blockIdx.y);
+                                                         double* __restrict__ S, double* __restrict__ rhs, int band_m, int nband,
+                                                         int gx) {
+  // a one-dimensional grid of gx workgroups per column (gridDim.y stops at 65535: the limit n < 65536 of rounds 1-5 was this launch)
+  const int b = (int)blockIdx.x;
+  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband);  // (gx == 1)
+  else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
 }
 
 __device__ __forceinline__ void load_W(const double* __restrict__ Wbuf, int k, double* W) {
@@ -1239,91 +1244,6 @@ double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// A few persistent host threads for the index lists below (spawning threads per solve cost more than the lists).
-class HostPool {
- public:
-  static HostPool& get() {
-    static HostPool p;
-    return p;
-  }
-  int size() const { return (int)workers_.size() + 1; }
-  // runs f(t) for t in [0, n_tasks) on the pool threads and the caller; returns when all are done
-  template <typename F>
-  void run(int n_tasks, F&& f) {
-    if (n_tasks <= 1 || workers_.empty()) {
-      for (int t = 0; t < n_tasks; ++t) f(t);
-      return;
-    }
-    std::unique_lock<std::mutex> call(call_mu_);  // one parallel region at a time
-    std::function<void(int)> fn = f;
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      fn_ = &fn;
-      n_tasks_ = n_tasks;
-      next_ = 0;
-      pending_ = n_tasks;
-      ++epoch_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> l(mu_);
-    done_cv_.wait(l, [&] { return pending_ == 0; });
-    fn_ = nullptr;
-  }
-
- private:
-  HostPool() {
-    unsigned hw = std::thread::hardware_concurrency();
-    int n = (int)(hw ? hw : 4) - 1;
-    if (n > 15) n = 15;
-    if (const char* e = getenv("GSLAM_HIP_HOST_THREADS")) n = atoi(e) - 1;
-    for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
-  }
-  ~HostPool() {
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      stop_ = true;
-      ++epoch_;
-    }
-    cv_.notify_all();
-    for (auto& w : workers_) w.join();
-  }
-  void work() {
-    for (;;) {
-      int t;
-      std::function<void(int)>* fn;
-      {
-        std::lock_guard<std::mutex> l(mu_);
-        if (!fn_ || next_ >= n_tasks_) return;
-        t = next_++;
-        fn = fn_;
-      }
-      (*fn)(t);
-      std::lock_guard<std::mutex> l(mu_);
-      if (--pending_ == 0) done_cv_.notify_all();
-    }
-  }
-  void loop() {
-    unsigned long long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> l(mu_);
-        cv_.wait(l, [&] { return epoch_ != seen; });
-        seen = epoch_;
-        if (stop_) return;
-      }
-      work();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex mu_, call_mu_;
-  std::condition_variable cv_, done_cv_;
-  std::function<void(int)>* fn_ = nullptr;
-  int n_tasks_ = 0, next_ = 0, pending_ = 0;
-  unsigned long long epoch_ = 0;
-  bool stop_ = false;
-};
-
 // Pair list of the deterministic Schur product: for every camera pair (ci >= cj) that shares a point, the list of
 // observation pairs (k of ci, k2 of cj) on a common point, grouped by destination block in (ci, cj) order with the
 // generation order kept inside a group.  Cameras are independent: contiguous ranges of cameras (balanced by observation
@@ -1531,6 +1451,8 @@ struct BaSession {
   // (empty = the caller's order); everything on the device is in the new order, the entry points translate.
   std::vector<int32_t> perm;
   int n_border = 0;  // cameras of the border
+  int span_measured = -1;  // >= 0: ba_order.hip has measured the camera span of the order in use (and checked every index): ba_run skips its pass
+  int reordered = 0; // the bandwidth-reducing order of ba_order.hip was applied (perm is then non-empty even without a border)
   double* d_arrow_ws = nullptr;
   // structure of the border rows of the reduced camera system (arrowhead solver): border_cam_nz[strip * nc_band + c] != 0 iff a
   // border camera with rows in the 16-row strip sees a point band camera c sees; d_border_nz = what gh_cr_border_symbolic made of it
@@ -1591,19 +1513,23 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     GH_CHECK_ARG(ctx, !pr || ((pr->obs_info != nullptr) == S.has_info && (pr->point_free != nullptr) == S.has_pfree));
   } else {
     // (the same pass finds how far apart, in camera indices, the observers of one point are: a band -> the band solver)
-    std::vector<int32_t> cam_lo((size_t)np, INT32_MAX), cam_hi((size_t)np, -1);
     const int nc_band = nc - S.n_border;  // (arrow ordering: the border cameras are the last ones and do not count)
-    for (int k = 0; k < no; ++k) {
-      const int32_t c = pr->obs_cam[k], p = pr->obs_point[k];
-      GH_CHECK_ARG(ctx, c >= 0 && c < nc && p >= 0 && p < np);
-      if (c >= nc_band) continue;
-      if (c < cam_lo[p]) cam_lo[p] = c;
-      if (c > cam_hi[p]) cam_hi[p] = c;
+    if (S.span_measured >= 0 && S.n_border == 0) {
+      S.cam_span = S.span_measured;  // (ba_order.hip: the same pass, on the pool threads, indices checked)
+    } else {
+      std::vector<int32_t> cam_lo((size_t)np, INT32_MAX), cam_hi((size_t)np, -1);
+      for (int k = 0; k < no; ++k) {
+        const int32_t c = pr->obs_cam[k], p = pr->obs_point[k];
+        GH_CHECK_ARG(ctx, c >= 0 && c < nc && p >= 0 && p < np);
+        if (c >= nc_band) continue;
+        if (c < cam_lo[p]) cam_lo[p] = c;
+        if (c > cam_hi[p]) cam_hi[p] = c;
+      }
+      int span = 0;
+      for (int p = 0; p < np; ++p)
+        if (cam_hi[p] >= 0 && cam_hi[p] - cam_lo[p] > span) span = cam_hi[p] - cam_lo[p];
+      S.cam_span = span;
     }
-    int span = 0;
-    for (int p = 0; p < np; ++p)
-      if (cam_hi[p] >= 0 && cam_hi[p] - cam_lo[p] > span) span = cam_hi[p] - cam_lo[p];
-    S.cam_span = span;
     S.border_cam_nz.clear();
     // (GSLAM_HIP_BA_ARROW_DENSE_BORDER = 1: never, 0: always; default: when the border block has 4 M entries or more -- at C4 + 20
     //  closures, 0.8 M, the two passes below cost what the border kernels save over a dozen iterations; at C5 + 50, 51 M, one
@@ -1930,7 +1856,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const int span = S.cam_span;  // (found with the argument check)
     int want = ctx->ba_solver;
     if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
-    cr_T = want == 1 || n >= 65536 ? 0 : gh_cr_tiles(n_band, 6 * span + 5);
+    cr_T = want == 1 ? 0 : gh_cr_tiles(n_band, 6 * span + 5);
     d_cr_dinv = d_cr_W = S.d_arrow_ws = nullptr;
     if (cr_T) {
       GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n_band, cr_T)));
@@ -2059,6 +1985,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   ctx->ba_last_solver = cr_T ? (n_band < n ? 3 : 2) : 1;
   ctx->ba_last_band_tiles = cr_T;
   ctx->ba_last_cam_span = S.cam_span;
+  ctx->ba_last_border_cams = S.n_border;
+  ctx->ba_last_reordered = S.reordered;
   double cost = h2[0];
   sum->initial_cost = cost;
   double radius = opt.initial_radius, decrease = 2.0;
@@ -2102,13 +2030,16 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
                 d_Hpi, d_bad);
     }
-    const bool slim_init = (d_flow != nullptr || cr_T != 0) && n < 65536;  // both solvers read the lower tiles only
+    const bool slim_init = d_flow != nullptr || cr_T != 0;  // both solvers read the lower tiles only
     const bool fused_seed = slim_init && no > 0 && opt.deterministic;  // then the seed rides with the segment sums below
     bool solve_state_ready = false;  // set when schur_reduce_kernel has cleared what the single-launch solve kernels need
     if (slim_init) {
       if (!fused_seed)
-        GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3(cr_T ? 1 : gh_div_up(n + 1, 2048), n), dim3(256), 0, n, lda, d_Hcc,
-                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band);
+      {
+        const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);
+        GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3((unsigned)gx * (unsigned)n), dim3(256), 0, n, lda, d_Hcc,
+                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band, gx);
+      }
     } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
       hipError_t me = hipMemsetAsync(d_S, 0, (size_t)n * lda * sizeof(double), ctx->stream);
@@ -2310,71 +2241,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   return term == 3 ? GH_ERR_NUMERIC : GH_OK;
 }
 
-// ---------------------------------------------------------------- arrow ordering (loop closures)
-// The band solver needs every point's observers within kBandSpan camera indices of each other; ONE point seen from both
-// ends of a loop used to send the whole graph to the dense factorisation (C5: 163 -> 0.89 LM iterations per second).  Here the
-// few cameras such points tie to far-away ones are moved to the END of the camera order: for every long-range point the
-// window of kBandSpan + 1 camera indices that holds most of its observers stays in the band, its other observers join the
-// border.  What is left is a band (the band cameras are renumbered compactly: spans only shrink) + a dense border, the shape of
-// chol_cr.hip's arrowhead solve -- what Ceres' SPARSE_SCHUR ordering achieves behind GSLAM/core/Optimizer.h:229, restated for
-// trajectories.  Returns the number of border cameras (0: leave the caller's order -- already a band, too many border cameras,
-// or too few band cameras) and perm[new] = old.
-constexpr int kBandSpan = 31;         // gh_cr_tiles: 6 * 31 + 5 = 191 <= 3 * 64
-constexpr int kMaxBorderCams = 1024;  // 6144 border rows: beyond that the dense corner dominates
-int ba_arrow_order(const gh_ba_problem* pr, std::vector<int32_t>& perm) {
-  perm.clear();
-  const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
-  if (nc < 4 * 32 + 1 || np <= 0 || no <= 0 || 6 * (long long)nc >= 65536) return 0;
-  std::vector<int32_t> lo((size_t)np, INT32_MAX), hi((size_t)np, -1);
-  for (int k = 0; k < no; ++k) {
-    const int32_t c = pr->obs_cam[k], p = pr->obs_point[k];
-    if (c < 0 || c >= nc || p < 0 || p >= np) return 0;  // (ba_run reports the bad index)
-    if (c < lo[p]) lo[p] = c;
-    if (c > hi[p]) hi[p] = c;
-  }
-  // the long-range points and their observers
-  std::vector<int32_t> slot((size_t)np, -1);
-  int nlong = 0;
-  for (int p = 0; p < np; ++p)
-    if (hi[p] >= 0 && hi[p] - lo[p] > kBandSpan) slot[p] = nlong++;
-  if (nlong == 0) return 0;
-  std::vector<std::vector<int32_t>> seen((size_t)nlong);
-  for (int k = 0; k < no; ++k) {
-    const int32_t sl = slot[pr->obs_point[k]];
-    if (sl >= 0) seen[sl].push_back(pr->obs_cam[k]);
-  }
-  std::vector<uint8_t> border((size_t)nc, 0);
-  for (auto& v : seen) {
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
-    // cameras already in the border do not constrain the window
-    size_t best_a = 0, best_cnt = 0;
-    for (size_t a = 0, b = 0; a < v.size(); ++a) {
-      if (border[v[a]]) continue;
-      if (b < a) b = a;
-      while (b + 1 < v.size() && v[b + 1] - v[a] <= kBandSpan) ++b;
-      size_t cnt = 0;
-      for (size_t t = a; t <= b; ++t) cnt += border[v[t]] ? 0 : 1;
-      if (cnt > best_cnt) {
-        best_cnt = cnt;
-        best_a = a;
-      }
-    }
-    for (size_t t = 0; t < v.size(); ++t)
-      if (v[t] < v[best_a] || v[t] - v[best_a] > kBandSpan) border[v[t]] = 1;
-  }
-  int nb = 0;
-  for (int c = 0; c < nc; ++c) nb += border[c];
-  if (nb == 0 || nb > kMaxBorderCams || 6 * (nc - nb) < 4 * 64) return 0;
-  perm.resize((size_t)nc);
-  int w = 0;
-  for (int c = 0; c < nc; ++c)
-    if (!border[c]) perm[w++] = c;
-  for (int c = 0; c < nc; ++c)
-    if (border[c]) perm[w++] = c;
-  return nb;
-}
-
+// (the camera order -- band / arrow / bandwidth-reducing -- lives in ba_order.hip)
 // The caller's problem in arrow order: cam_pose / cam_dof / obs_cam are re-indexed copies, everything else is shared.
 struct ArrowProblem {
   gh_ba_problem pr;
@@ -2404,6 +2271,16 @@ bool ba_arrow_wanted(const gh_ctx* ctx) {
   if (const char* e = getenv("GSLAM_HIP_BA_ARROW")) if (e[0] == '0') return false;  // A/B measurements: loop closures -> dense, as in rounds 1-4
   return want != 1;
 }
+// the camera order of a new graph (ba_order.hip): S.perm / S.n_border / S.reordered
+void ba_choose_order(const gh_ctx* ctx, BaSession& S, const gh_ba_problem* pr) {
+  if (!(pr->n_cams > 0 && pr->cam_pose && pr->cam_dof && pr->obs_cam && pr->obs_point && ba_arrow_wanted(ctx))) return;
+  const char* e = getenv("GSLAM_HIP_BA_REORDER");  // "0": the caller's camera order as it is (rounds 4-5; A/B measurements)
+  const double t0 = now_ms();
+  S.n_border = gh_ba_order_cameras(pr, S.perm, &S.reordered, !(e && e[0] == '0'), &S.span_measured);
+  if (getenv("GSLAM_HIP_BA_TIMING"))
+    fprintf(stderr, "[gh_ba] camera order: %.2f ms (%s, %d border cameras)\n", now_ms() - t0,
+            S.reordered ? "bandwidth-reducing order applied" : (S.perm.empty() ? "caller's order" : "arrow order"), S.n_border);
+}
 
 }  // namespace
 
@@ -2413,9 +2290,8 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   BaSession S;
   S.db = new (std::nothrow) DevBuf(ctx);
   if (!S.db) return GH_ERR_NOMEM;
-  if (pr->n_cams > 0 && pr->cam_pose && pr->cam_dof && pr->obs_cam && pr->obs_point && ba_arrow_wanted(ctx))
-    S.n_border = ba_arrow_order(pr, S.perm);
-  if (S.n_border == 0) return ba_run(ctx, S, pr, opt_in, sum_out, true);
+  ba_choose_order(ctx, S, pr);
+  if (S.perm.empty()) return ba_run(ctx, S, pr, opt_in, sum_out, true);
   ArrowProblem ap;
   ap.build(pr, S.perm);
   const gh_status st = ba_run(ctx, S, &ap.pr, opt_in, sum_out, true);
@@ -2449,9 +2325,8 @@ extern "C" gh_status gh_ba_graph_create(gh_ctx* ctx, const gh_ba_problem* proble
   gh_ba_summary sum;
   gh_ba_problem pr = *problem;
   ArrowProblem ap;
-  if (pr.n_cams > 0 && pr.cam_pose && pr.cam_dof && pr.obs_cam && pr.obs_point && ba_arrow_wanted(ctx))
-    g->S.n_border = ba_arrow_order(&pr, g->S.perm);
-  if (g->S.n_border > 0) {
+  ba_choose_order(ctx, g->S, &pr);
+  if (!g->S.perm.empty()) {
     ap.build(problem, g->S.perm);
     pr = ap.pr;
   }
@@ -2496,13 +2371,19 @@ extern "C" gh_status gh_ba_graph_update(gh_ba_graph* g, const double* cam_pose, 
       cam_dof = dof_p.data();
     }
   }
-  GH_TRY(up(S.d_poses, cam_pose, (size_t)S.nc * 56));
-  GH_TRY(up(S.d_pts, point_xyz, (size_t)S.np * 24));
-  GH_TRY(up(S.d_oxy, obs_xy, (size_t)S.no * 16));
-  GH_TRY(up(S.d_oinfo, obs_info, (size_t)S.no * 32));
-  GH_TRY(up(S.d_dof, cam_dof, (size_t)S.nc * 4));
-  GH_TRY(up(S.d_pfree, point_free, (size_t)S.np));
-  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays may be pageable and freed on return
+  // (every copy is enqueued whatever the one before returned, and the stream is drained before pose_p / dof_p go out of scope: a
+  //  failing later copy must not leave an earlier asynchronous one reading freed memory)
+  gh_status st = GH_OK;
+  auto keep = [&](gh_status s) { if (st == GH_OK) st = s; };
+  keep(up(S.d_poses, cam_pose, (size_t)S.nc * 56));
+  keep(up(S.d_pts, point_xyz, (size_t)S.np * 24));
+  keep(up(S.d_oxy, obs_xy, (size_t)S.no * 16));
+  keep(up(S.d_oinfo, obs_info, (size_t)S.no * 32));
+  keep(up(S.d_dof, cam_dof, (size_t)S.nc * 4));
+  keep(up(S.d_pfree, point_free, (size_t)S.np));
+  const hipError_t se = hipStreamSynchronize(ctx->stream);  // the caller's arrays may be pageable and freed on return
+  if (st != GH_OK) return st;
+  GH_HIP(ctx, se);
   return GH_OK;
 }
 

@@ -859,6 +859,9 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
 // (tests/test_cr_solver.py: restated in numpy; gh_arrow_solve_dev against numpy and the dense path).
 // K chunks of the corner update: columns per chunk (a multiple of 16) and their number -- at most 16 superblocks per chunk, and
 // enough chunks that tiles x chunks fill the chip when the corner has few tiles (C4 + 20 loop closures: 21 tiles)
+// The partial tiles take chunks x tiles x 32 KB: bounded to kBorderPartTiles tiles (512 MB) -- a wide border (1024 cameras: 4753
+// tiles) gets few, long chunks instead of 2.8 GB of partial sums.
+constexpr int kBorderPartTiles = 16384;
 struct BorderChunks { int kc, n; };
 inline BorderChunks border_chunks(int n_band, int m, int nbr) {
   const int K = n_band > m ? n_band : 0;  // (the chunks run over every band column; the survivors' columns are skipped in the kernel)
@@ -867,6 +870,8 @@ inline BorderChunks border_chunks(int n_band, int m, int nbr) {
   int want = (K + 16 * m - 1) / (16 * m);
   const int fill = (1024 + ntiles - 1) / ntiles;
   if (fill > want) want = fill < 64 ? fill : 64;
+  const int cap = kBorderPartTiles / ntiles > 1 ? kBorderPartTiles / ntiles : 1;
+  if (want > cap) want = cap;
   if (want > (K + 63) / 64) want = (K + 63) / 64;
   const int kc = (((K + want - 1) / want) + 15) & ~15;
   return BorderChunks{kc, (K + kc - 1) / kc};
@@ -1090,6 +1095,20 @@ __global__ __launch_bounds__(256) void cr_border_yh_kernel(CrArgs a, const doubl
   }
 }
 
+// Shape of the dense top of a reduction over N superblocks of m columns (n band unknowns): stride S of the survivors 0, S, 2 S, ...,
+// their number and the band unknowns qb they hold (only the last survivor can be partial).  ONE function for the solver and for the
+// size of its workspace (gh_arrow_ws_doubles): the two used to disagree on qn when the last survivor is partial or fewer than `top`
+// superblocks survive, and the single-launch factorisation's state then lay past the reserved block.
+struct TopShape { int S, nsv, qb; };
+inline TopShape top_shape(int n, int m, int top) {
+  const int N = gh_div_up(n, m);
+  int S = 1;
+  while (gh_div_up(N, S) > top) S *= 2;
+  const int nsv = gh_div_up(N, S);
+  const int last = n - (nsv - 1) * S * m;
+  return TopShape{S, nsv, (nsv - 1) * m + (last < m ? last : m)};
+}
+
 // a launch on `stream` through the context's profiler (GH_LAUNCH times on ctx->stream)
 #define CR_LAUNCH_ON(stream_, ...)          \
   do {                                      \
@@ -1150,10 +1169,8 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   // DENSE TOP: the reduction stops when at most `top` superblocks survive (0, S, 2 S, ...): the last levels eliminate one or
   // two superblocks each behind a full-length pivot chain (58 us per level at T = 3), while the single-launch dense
   // factorisation takes the block tridiagonal system of four survivors in about the time of ONE level
-  const int top = (bws != nullptr) ? gh_cr_top(nbr) : 1;
-  int S = 1;
-  while (gh_div_up(N, S) > top) S *= 2;
-  const int nsv = gh_div_up(N, S);  // survivors
+  const TopShape ts = top_shape(n, m_, (bws != nullptr) ? gh_cr_top(nbr) : 1);
+  const int S = ts.S, nsv = ts.nsv;  // stride and number of the survivors
   a.keep = S;
   for (int s = 1; s < S; s *= 2) {
     a.s = s;
@@ -1185,7 +1202,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   a.count = 1;
   if (nbr > 0 || nsv > 1) {
     // the survivors are not factored on their own: they join the border in the dense system that is left
-    const int qb = (nsv - 1) * m_ + (n - (nsv - 1) * S * m_ < m_ ? n - (nsv - 1) * S * m_ : m_);
+    const int qb = ts.qb;
     const int qn = qb + nbr, ldq = (qn + 1 + 15) & ~15;
     const int ntr = gh_div_up(nbr + 1, 64), ntiles = ntr * (ntr + 1) / 2;
     const BorderChunks bc = border_chunks(n, m_, nbr);
@@ -1249,7 +1266,9 @@ int gh_cr_top(int nbr) { return gh_cr_top_env() ? gh_cr_top_env() : (nbr > 0 ? 4
 // border workspace of an arrowhead solve (doubles): the corner update's partial tiles, the dense system of superblock 0 + border
 // and what chol.hip's dense path needs for it, the backward pass's t vector
 size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr) {
-  const size_t m = (size_t)NBI * T, qn = (size_t)gh_cr_top(nbr) * m + (size_t)nbr, ldq = (qn + 1 + 15) & ~(size_t)15;
+  // (qn of THIS system, as cr_solve_t computes it: gh_potrf_flow_words is not monotonic in qn -- it is 0 once the shape exceeds the
+  //  CU count -- so a bound from the largest possible qn may reserve nothing where the real qn needs megabytes)
+  const size_t m = (size_t)NBI * T, qn = (size_t)top_shape(n_band, NBI * T, gh_cr_top(nbr)).qb + (size_t)nbr, ldq = (qn + 1 + 15) & ~(size_t)15;
   const size_t ntr = ((size_t)nbr + 1 + 63) / 64, ntiles = ntr * (ntr + 1) / 2;
   const size_t nchunks = (size_t)border_chunks(n_band, (int)m, nbr).n;
   const size_t qb = (qn + NBI - 1) / NBI;

@@ -75,6 +75,14 @@ extern "C" int gh_ctx_last_ba_solver(gh_ctx* ctx, int* band_tiles, int* cam_span
   return ctx->ba_last_solver;
 }
 
+extern "C" int gh_ctx_last_ba_order(gh_ctx* ctx, int* border_cams, int* reordered) {
+  if (!ctx) return 0;
+  GH_ENTER(ctx);
+  if (border_cams) *border_cams = ctx->ba_last_border_cams;
+  if (reordered) *reordered = ctx->ba_last_reordered;
+  return ctx->ba_last_solver != 0;
+}
+
 extern "C" gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);

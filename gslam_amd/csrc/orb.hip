@@ -1199,7 +1199,8 @@ constexpr uint32_t f16_bits_of_int(int v) {  // 0 <= v < 2048: exact
   if (v == 0) return 0u;
   int e = 0;
   while ((v >> (e + 1)) != 0) ++e;
-  return (uint32_t)(((e + 15) << 10) | ((v << (10 - e)) & 0x3FF));
+  const int mant = e <= 10 ? (v << (10 - e)) : (v >> (e - 10));  // (2048: e = 11 -- no shift by a negative count)
+        return (uint32_t)(((e + 15) << 10) | (mant & 0x3FF));
 }
 constexpr BlurBTable make_blur_b() {
   BlurBTable t{};

@@ -108,6 +108,8 @@ SIGNATURES = {
     "gh_magic_div": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "gh_ctx_set_ba_solver": (C.c_int, [_vp, _i]),
     "gh_ctx_last_ba_solver": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "gh_ctx_last_ba_order": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "gh_ba_camera_order": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gh_prof_enable": (C.c_int, [_vp, _i]),
     "gh_prof_collect": (C.c_int, [_vp, C.POINTER(ProfEntry), _i, C.POINTER(_i)]),
     "gh_bf_match_dev": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -286,6 +288,12 @@ class Context:
         t, sp = C.c_int(), C.c_int()
         code = lib.gh_ctx_last_ba_solver(self.h, C.byref(t), C.byref(sp))
         return {0: None, 1: "dense", 2: "band", 3: "arrow"}[code], t.value, sp.value
+
+    def last_ba_order(self):
+        """(border cameras, reordered) of the last BA solve: gh_ctx_last_ba_order."""
+        b, r = C.c_int(), C.c_int()
+        lib.gh_ctx_last_ba_order(self.h, C.byref(b), C.byref(r))
+        return b.value, bool(r.value)
 
     def prof_enable(self, on=True):
         self.check(lib.gh_prof_enable(self.h, 1 if on else 0))

@@ -63,9 +63,10 @@ gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream);
 gh_status gh_ctx_trim(gh_ctx* ctx);
 /* Linear solver of the reduced camera system in gh_ba_solve / gh_ba_graph_solve: GH_BA_SOLVER_AUTO (default) takes the
  * band solver (block cyclic reduction, chol_cr.hip) when every point is seen from cameras at most 31 indices apart, the
- * system has at least four superblocks of 64 * ceil((6 span + 5) / 64) columns and fewer than 65536 unknowns, else the
+ * system has at least four superblocks of 64 * ceil((6 span + 5) / 64) columns, else the
  * dense MFMA factorisation; _DENSE forces the dense path (what BASELINE's C5 names); _BAND asks for the band solver and
- * falls back to dense when the graph is not a band.  LOOP CLOSURES: under _AUTO / _BAND the cameras that long-range points
+ * falls back to dense when the graph is not a band.  The test is made on the solver's own camera order (gh_ba_camera_order),
+ * not on the caller's.  LOOP CLOSURES: under _AUTO / _BAND the cameras that long-range points
  * tie to far-away cameras (at most 1024 of them) are numbered last inside the solver, and the system is solved as a band +
  * dense border (GH_BA_SOLVER_ARROW in gh_ctx_last_ba_solver; gh_arrow_solve_dev) instead of falling to the dense path.
  * The environment variable GSLAM_HIP_BA_SOLVER=dense|band|auto overrides it (A/B measurements). */
@@ -80,6 +81,10 @@ gh_status gh_ctx_set_ba_solver(gh_ctx* ctx, int solver);
  * half-bandwidth of the band part is 6 * span + 5).
  * Either pointer may be NULL. */
 int gh_ctx_last_ba_solver(gh_ctx* ctx, int* band_tiles, int* cam_span);
+/* The camera order behind that solve (round 6): *border_cams = cameras of the arrowhead border (0 for band / dense),
+ * *reordered = 1 when the solver replaced the caller's camera order by its own bandwidth-reducing order (gh_ba_camera_order).
+ * Returns 1 after a solve, 0 before the first.  Either pointer may be NULL. */
+int gh_ctx_last_ba_order(gh_ctx* ctx, int* border_cams, int* reordered);
 gh_status gh_ctx_use_own_stream(gh_ctx* ctx);
 void* gh_ctx_stream(gh_ctx* ctx);
 gh_status gh_ctx_sync(gh_ctx* ctx);
@@ -499,7 +504,10 @@ typedef struct gh_ba_options {
   double min_relative_decrease; /* 1e-3 */
   int32_t verbose;
   int32_t deterministic;     /* 1 (default): reproducible sums -- gh_ba_solve: ordered segmented Schur accumulation; gh_graph_solve:
-                                the landmark part pre-rounded so that its atomics add exactly (bit-identical from run to run);
+                                the landmark part pre-rounded so that its atomics add exactly (bit-identical from run to run) on
+                                the DENSE path (two more n x lda accumulators, one fold pass per iteration); graphs large enough
+                                for the block-sparse Cholesky (gh_graph_summary: sparse) keep plain atomics -- the option is
+                                IGNORED there and the last bits vary between runs;
                                 0: plain f64 atomics (faster assembly, last bits vary between runs) */
 } gh_ba_options;
 void gh_ba_default_options(gh_ba_options* o);
@@ -556,6 +564,22 @@ gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy,
  * T_first^-1 T_second of the current poses (the caller forms it).  Edges come sorted by (first, second); *n_edges is
  * always the number found; with max_edges == 0 nothing else is written (size query), with 0 < max_edges < *n_edges the
  * call fails.  edge_shared (may be NULL) = shared points per edge. */
+/* The camera order gh_ba_solve / gh_ba_graph_create would use INSIDE the solver for this graph -- host code, no device work, the
+ * context plays no part (tests, tools, a caller that wants to know whether its graph reaches the band solver).  BundleGraph::keyframes
+ * is a plain vector (GSLAM/core/Optimizer.h:116-119,150-157): nothing says a caller fills it in trajectory order, so the solver
+ * orders the reduced camera system for itself, as Ceres' SPARSE_SCHUR does behind Optimizer::optimize (Optimizer.h:229):
+ *   the caller's order when it is a band (every point's observers at most 31 camera indices apart) or a band + border as it stands;
+ *   otherwise a weighted maximum-adjacency order of the camera co-visibility graph (from a sample of the points), refined by two
+ *   barycentre sweeps, then the border of the cameras that long-range points tie to far-away ones.
+ * perm_out[n_cams]: old camera of every new position (the identity when the caller's order stands); *n_border: cameras of the dense
+ * border at the end of the order; *cam_span: largest distance in new positions between two band observers of one point (the solver
+ * takes the band / arrowhead path when 6 * span + 5 <= 192 and at least four superblocks remain); *reordered: 1 when the
+ * bandwidth-reducing order was applied.  problem: only n_cams, n_points, n_obs, obs_cam, obs_point are read.
+ * GH_ERR_ARG for null pointers or indices out of range.  The environment variable GSLAM_HIP_BA_REORDER=0 keeps gh_ba_solve on the
+ * caller's order (A/B measurements); this function always reports the order the default would choose. */
+gh_status gh_ba_camera_order(const gh_ba_problem* problem, int32_t* perm_out, int32_t* n_border, int32_t* cam_span,
+                             int32_t* reordered);
+
 gh_status gh_ba_marginalize(gh_ctx* ctx, const gh_ba_problem* problem, double huber_delta, int32_t min_shared,
                             int32_t max_edges, int32_t* edge_first, int32_t* edge_second, int32_t* edge_shared,
                             double* edge_info, int32_t* n_edges);

@@ -304,6 +304,33 @@ def test_arrow_solve_vs_numpy(ctx, n_band, hb, nbr, fill):
 
 
 @pytest.mark.gpu
+def test_arrow_solve_border_around_the_single_launch_threshold(ctx):
+    """the workspace was sized with the LARGEST dense-top system (top * m + nbr unknowns) while the solve asks
+    for the single-launch factorisation's state with the ACTUAL one (fewer / partial survivors); the state size drops to 0 once a
+    shape exceeds the CU count, so in between the flow state lay past the reserved block.  n_band = 900 at m = 192: five
+    superblocks, three survive (0, 2, 4; the last one 132 wide) -> 516 band unknowns in the dense top against 768 reserved for.
+    Border widths on both sides of, and inside, that window for this device's CU count."""
+    from gslam_amd import ba
+    cus = ctx.device_info()["cu_count"]
+
+    def fits(qn):  # chol.hip flow_groups, FL_MAXT = 6
+        ntr = -(-(qn + 1) // 64)
+        return 1 + max(ntr - 1, 0) + sum(-(-(i - 1) // 6) for i in range(2, ntr)) <= cus
+    qn_last = max(q for q in range(64, 8192) if fits(q))
+    n_band, hb, qb_actual, qb_reserved = 900, 149, 516, 768
+    widths = sorted({qn_last - qb_reserved - 40, qn_last - qb_reserved + 1, qn_last - (qb_actual + qb_reserved) // 2,
+                     qn_last - qb_actual, qn_last - qb_actual + 1})
+    for nbr in widths:
+        S = make_arrow(n_band, hb, nbr, seed=nbr, fill=0.2)
+        b = np.random.default_rng(3).standard_normal(n_band + nbr)
+        for rep in range(2):
+            x, info = ba.arrow_solve(ctx, S, b, n_band, hb)
+            assert info == 0, nbr
+            xr = np.linalg.solve(S, b)
+            assert np.abs(x - xr).max() <= 1e-12 * np.abs(xr).max(), nbr
+
+
+@pytest.mark.gpu
 def test_arrow_solve_is_reproducible_and_equals_dense_path(ctx):
     from gslam_amd import ba
     S = make_arrow(3000, 149, 200, seed=11, fill=0.1)

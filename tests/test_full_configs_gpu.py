@@ -100,6 +100,58 @@ def test_c5_tenth_scale_parity(ctx, oracle):
     assert so.accepted >= 6 and so.final_cost < 0.5 * so.initial_cost
 
 
+# ---- loop-closure graphs: the arrowhead solver (band + dense border, cameras renumbered inside the solver) against the ORACLE,
+# not only against the GPU's own dense path (VERDICT r5 missing #3 / W2).  The oracle solves the caller's graph in the caller's
+# camera order with a dense factorisation; the GPU renumbers the far observers of the closure points to the border, solves, and
+# hands the poses back in the caller's order (ba.hip: ba_arrow_order / ArrowProblem).  Same bars as the band graphs: identical
+# accept / reject sequence, cost 1e-9, state 1e-8.  (GSLAM/core/Optimizer.h:127-148,229.)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_c4_loop_closure_parity_vs_oracle(ctx, oracle, seed):
+    g = make_graph(500, 50000, n_obs_per_point=6, seed=seed, loop_closures=20)
+    assert len(g["closure_points"]) == 20
+    so = _compare_ba(oracle, ctx, g, max_it=40)
+    assert ctx.last_ba_solver()[0] == "arrow"
+    assert so.termination == 1 and so.final_cost < 0.5 * so.initial_cost
+
+
+def test_c5_tenth_loop_closure_parity_vs_oracle(ctx, oracle):
+    g = make_graph(1000, 100000, n_obs_per_point=6, seed=1, loop_closures=10)
+    so = _compare_ba(oracle, ctx, g, max_it=12)
+    assert ctx.last_ba_solver()[0] == "arrow"
+    assert so.accepted >= 6 and so.final_cost < 0.5 * so.initial_cost
+
+
+@pytest.mark.parametrize("dense_border", ["0", "1"])
+def test_c4_loop_closure_parity_border_structure_forced(ctx, oracle, monkeypatch, dense_border):
+    """GSLAM_HIP_BA_ARROW_DENSE_BORDER=0: the border kernels skip the (superblock, strip) blocks the host-side propagation marks
+    zero (default only from 4 M border entries up); =1: every block treated as dense.  Both against the oracle."""
+    monkeypatch.setenv("GSLAM_HIP_BA_ARROW_DENSE_BORDER", dense_border)
+    g = make_graph(500, 50000, n_obs_per_point=6, seed=2, loop_closures=20)
+    _compare_ba(oracle, ctx, g, max_it=40)
+    assert ctx.last_ba_solver()[0] == "arrow"
+
+
+def test_loop_closure_resident_graph_parity_vs_oracle(ctx, oracle):
+    """The same through gh_ba_graph_create / _update / _solve / _read: poses (and the gauge mask) cross the arrow permutation on
+    the way in and out; the second solve starts from re-uploaded values in the CALLER's order."""
+    from gslam_amd import ba
+    g = make_graph(500, 50000, n_obs_per_point=6, seed=3, loop_closures=20)
+    eo = oracle.ba_solve(g, oracle_lib.ba_options(huber=0.01, max_iterations=40), threads=THREADS)
+    opts = ba.default_options(huber_delta=0.01, max_iterations=40, deterministic=1)
+    G = ba.Graph(ctx, g, opts)
+    for attempt in range(2):
+        if attempt == 1:
+            G.update(cam_pose=g["cam_pose"], point_xyz=g["point_xyz"], cam_dof=g["cam_dof"])
+        sg, st = G.solve(opts)
+        assert st == 0 and ctx.last_ba_solver()[0] == "arrow"
+        from lm_trace import assert_identical_trace
+        assert_identical_trace(sg, eo[2], rtol=COST_RTOL)
+        poses, pts = G.read()
+        assert np.abs(poses - eo[0]).max() <= STATE_ATOL_FULL
+        assert np.abs(pts - eo[1]).max() <= STATE_ATOL_FULL
+    G.close()
+
+
 def _pnp_case(oracle, seed, n_pts, noise, outlier_every):
     g = make_graph(3, n_pts, n_obs_per_point=3, seed=seed, noise=0.0, outlier_frac=0.0, perturb=False)
     sel = g["obs_cam"] == 1
