@@ -51,10 +51,22 @@ double now_ms() {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-// pool threads the passes over the observation list use (GSLAM_HIP_BA_ORDER_THREADS; 1 = serial)
+// pool threads of the sampling pass and of the adjacency lists (GSLAM_HIP_BA_ORDER_THREADS; 1 = serial).  Measured on the GPU
+// box's host (EPYC 9575F, C5 shuffled, 1 / 4 / 8 threads): sample lists 12.4 / 17.0 / 6.7 ms, adjacency 22.5 / 10.2 / 5.4 ms.
 int order_threads() {
   static const int v = [] {
     const char* e = getenv("GSLAM_HIP_BA_ORDER_THREADS");
+    const int t = e ? atoi(e) : 8;
+    return t < 1 ? 1 : (t > 16 ? 16 : t);
+  }();
+  return v;
+}
+// ... and of the per-point camera range (GSLAM_HIP_BA_ORDER_RANGE_THREADS, default 1: with the observations in random order the
+// pass is bound by the cache misses of lo / hi and by the scan's unpredictable range test -- 36 / 45 / 37 ms at 1 / 4 / 8
+// threads on the same box; with the observations grouped by point it takes 5 ms serial)
+int range_threads() {
+  static const int v = [] {
+    const char* e = getenv("GSLAM_HIP_BA_ORDER_RANGE_THREADS");
     const int t = e ? atoi(e) : 1;
     return t < 1 ? 1 : (t > 16 ? 16 : t);
   }();
@@ -65,13 +77,13 @@ int order_threads() {
 // lo[p] / hi[p] = smallest / largest POSITION (pos[camera], or the camera index itself when pos is null) among the observers of
 // point p (INT32_MAX / -1 for an unobserved point).  Every pool thread owns a contiguous RANGE OF POINTS and scans the whole
 // observation list for them: the scan is sequential, the thread's part of lo / hi (8 MB / threads at C5) stays in its cache, no
-// atomics, nothing to merge.  (Slices of the observation list with full-size arrays per thread were SLOWER than one thread:
-// eight 8 MB working sets fall out of the last-level cache -- 199 ms against 95 ms for C5's 6 M shuffled observations.)
+// atomics, nothing to merge.  (Slices of the observation list with full-size arrays per thread were slower than one thread in
+// the build container: eight 8 MB working sets fall out of the last-level cache.)  Serial by default: see range_threads.
 // false: an index out of range (ba_run reports it).
 bool point_ranges(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32_t>& lo, std::vector<int32_t>& hi) {
   const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
   HostPool& pool = HostPool::get();
-  const int T = no >= (1 << 18) ? std::min(pool.size(), order_threads()) : 1;
+  const int T = no >= (1 << 18) ? std::min(pool.size(), range_threads()) : 1;
   lo.resize((size_t)np);
   hi.resize((size_t)np);
   std::vector<uint8_t> bad((size_t)T, 0);
@@ -240,7 +252,7 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
   constexpr int kMaxObsPerPoint = 64;
   std::vector<int32_t> astart((size_t)nc + 1, 0), adj, wgt;
   {
-    const int TA = ns >= (1 << 15) ? std::min(pool.size(), 2 * order_threads()) : 1;
+    const int TA = ns >= (1 << 15) ? std::min(pool.size(), order_threads()) : 1;
     std::vector<std::vector<int32_t>> tadj((size_t)TA), twgt((size_t)TA);
     std::vector<int32_t> deg((size_t)nc, 0);
     pool.run(TA, [&](int t) {
