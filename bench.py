@@ -961,6 +961,7 @@ def main():
         arrow_ms = sum(v["total_ms"] for k, v in bprof.items() if k in ARROW)
         launches = sum(v["launches"] for v in bprof.values())
         used, tiles, span = ctx.last_ba_solver()
+        border_cams, reordered = ctx.last_ba_order()
         band_flops = None
         if used == "band" and cr_ms:
             # executed flops of the block cyclic reduction, per solve: per eliminated superblock (two neighbours) m^3 / 3 (potrf)
@@ -969,7 +970,7 @@ def main():
             m_sb = 64 * tiles
             band_flops = (-(-n // m_sb) - 1) * (1.0 / 3 + 6 + 2.4) * m_sb ** 3
         return {"workload": f"{name}: {cams} cams, {points} pts, {len(g['obs_cam'])} obs, Huber LM",
-                "graph_census": census,
+                "graph_census": census, "border_cams": border_cams, "cameras_reordered_by_the_solver": reordered,
                 "linear_solver": {"used": used, "camera_span": span, "half_bandwidth": 6 * span + 5,
                                   "superblock_columns": 64 * tiles if tiles else None,
                                   "solver_kernel_ms_per_iteration": round((cr_ms if used == "band" else (arrow_ms if used == "arrow" else chol_ms)) / max(1, sp.iterations), 4),
@@ -999,16 +1000,19 @@ def main():
                                 if chol_ms and used == "dense" else None),
                 "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in bprof.items()}}
 
-    def ctx_border_cams(g):
-        """how many cameras the arrow ordering of gh_ba_solve moves to the border (restated: per long-range point the observers
-        outside the 32-camera window that holds most of them)"""
-        border = set()
-        oc, op = np.asarray(g["obs_cam"]), np.asarray(g["obs_point"])
-        for p in g.get("closure_points", []):
-            v = np.unique(oc[op == p])
-            best = max(range(len(v)), key=lambda a: (sum(1 for t in v[a:] if t - v[a] <= 31 and t not in border), -a))
-            border.update(int(t) for t in v if t < v[best] or t - v[best] > 31)
-        return len(border)
+    def shuffle_cameras(g, seed):
+        """the same graph with the cameras renumbered by a random permutation: BundleGraph::keyframes is a plain vector
+        (GSLAM/core/Optimizer.h:116-119), a back end fills it in co-visibility order, not in trajectory order"""
+        rng = np.random.default_rng(seed)
+        nc = len(g["cam_dof"])
+        new_of_old = rng.permutation(nc).astype(np.int32)
+        old_of_new = np.argsort(new_of_old)
+        h = dict(g)
+        h["cam_pose"] = np.ascontiguousarray(g["cam_pose"][old_of_new])
+        h["cam_dof"] = np.ascontiguousarray(g["cam_dof"][old_of_new])
+        h["obs_cam"] = new_of_old[g["obs_cam"]].astype(np.int32)
+        h.pop("cam_pose_gt", None)
+        return h
 
     def dense_solve_check(n):
         """gh_potrf_solve_dev on a well conditioned SPD system of the C5 size: TFLOP/s and ||A x - b|| / ||b|| <= 1e-10."""
@@ -1054,13 +1058,28 @@ def main():
                     "loop closures: the arrowhead and the dense solver led the LM loop to different results"
                 keys = ("iters_per_s", "ms_per_iteration", "resolve_iters_per_s", "launches_per_iteration", "linear_solver", "iterations", "final_cost")
                 extra["ba"]["loop_closure"] = {"closure_points": nlc, "closure_span_cams": a.ba_cams // 2,
-                                               "border_cams": int(ctx_border_cams(g4c)),
+                                               "border_cams": lc["border_cams"],
                                                **{k: lc[k] for k in keys}, "kernels": lc["kernels"],
                                                "dense_solver": {k: ld[k] for k in keys},
                                                "what": "make_graph(loop_closures=20): 20 points seen from two ends of the trajectory; "
                                                        "gh_ba_solve orders their far observers last (arrow ordering) and solves band + "
                                                        "border; dense_solver = the same graph through the dense factorisation (what rounds "
                                                        "1-4 fell back to); same LM run asserted"}
+            # the same graphs with the cameras in a random order (VERDICT r5 missing #2): the solver orders them for itself (ba_order.hip)
+            g4s = shuffle_cameras(g4, 1)
+            sh = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True, graph=g4s)
+            assert sh["iterations"] == extra["ba"]["iterations"] and abs(sh["final_cost"] - extra["ba"]["final_cost"]) <= 1e-9 * abs(sh["final_cost"]), \
+                "shuffled cameras: a different LM run"
+            skeys = ("iters_per_s", "ms_per_iteration", "resolve_iters_per_s", "iterations", "final_cost", "border_cams", "cameras_reordered_by_the_solver")
+            extra["ba"]["shuffled"] = {**{k: sh[k] for k in skeys}, "linear_solver": sh["linear_solver"]["used"], "camera_span": sh["linear_solver"]["camera_span"],
+                                       "what": "the C4 graph with the cameras renumbered by a random permutation (observations in their order): one-shot rate "
+                                               "incl. the ordering, resident rate without it; same LM run asserted"}
+            if a.ba_cams >= 200:
+                g4cs = shuffle_cameras(g4c, 2)
+                shc = ba_leg(a.ba_cams, a.ba_points, a.ba_iters, True, graph=g4cs)
+                assert shc["iterations"] == lc["iterations"] and abs(shc["final_cost"] - lc["final_cost"]) <= 1e-9 * abs(lc["final_cost"]), \
+                    "shuffled cameras + loop closures: a different LM run"
+                extra["ba"]["loop_closure"]["shuffled"] = {**{k: shc[k] for k in skeys}, "linear_solver": shc["linear_solver"]["used"]}
     except Exception as exc:  # an optional leg must never cost the headline line
         extra.setdefault("errors", {})["ba"] = repr(exc)
         log("ba leg failed: %r" % (exc,))
@@ -1081,7 +1100,17 @@ def main():
             bl = ba_leg(10000, 1000000, 40, True, prof_iters=2, solver="auto", graph=g5)
             extra["ba_c5"]["band_solver"]["to_convergence"] = {k: bl[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
                                                                                     "initial_cost", "final_cost", "resolve_iters_per_s")}
-            del g5
+            g5s = shuffle_cameras(g5, 1)
+            sh5 = ba_leg(10000, 1000000, 40, True, prof_iters=2, solver="auto", graph=g5s)
+            assert sh5["iterations"] == bl["iterations"] and abs(sh5["final_cost"] - bl["final_cost"]) <= 1e-9 * abs(bl["final_cost"]), \
+                "C5 shuffled cameras: a different LM run"
+            extra["ba_c5"]["shuffled"] = {**{k: sh5[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms", "final_cost",
+                                                                 "resolve_iters_per_s", "border_cams", "cameras_reordered_by_the_solver")},
+                                          "linear_solver": sh5["linear_solver"]["used"], "camera_span": sh5["linear_solver"]["camera_span"],
+                                          "of_in_order_rate": round(sh5["iters_per_s"] / bl["iters_per_s"], 3),
+                                          "what": "C5 with the cameras renumbered by a random permutation, run to convergence: the one-shot rate includes "
+                                                  "the solver's own camera ordering (ba_order.hip); compare band_solver.to_convergence"}
+            del g5, g5s
             torch.cuda.empty_cache()
             # C5 + 50 loop-closure points 5000 cameras apart: rounds 1-4 solved this dense (0.89 LM it/s), now band + border
             g5c = _mk(10000, 1000000, n_obs_per_point=6, seed=1, loop_closures=50, closure_span=5000)
@@ -1092,7 +1121,7 @@ def main():
                 "C5 + loop closures: the arrowhead and the dense solver disagree"
             ll5 = ba_leg(10000, 1000000, 40, True, prof_iters=2, solver="auto", graph=g5c)
             keys5 = ("iters_per_s", "ms_per_iteration", "launches_per_iteration", "linear_solver", "iterations", "final_cost")
-            extra["ba_c5"]["loop_closure"] = {"closure_points": 50, "closure_span_cams": 5000, "border_cams": int(ctx_border_cams(g5c)),
+            extra["ba_c5"]["loop_closure"] = {"closure_points": 50, "closure_span_cams": 5000, "border_cams": lc5["border_cams"],
                                               **{k: lc5[k] for k in keys5}, "kernels": lc5["kernels"],
                                               "to_convergence": {k: ll5[k] for k in ("iterations", "iters_per_s", "ms_per_iteration", "total_ms",
                                                                                      "initial_cost", "final_cost", "resolve_iters_per_s")},
@@ -1619,6 +1648,9 @@ def main():
         "ba_c4_resident_graph_lm_iters_per_s": (extra.get("ba") or {}).get("resolve_iters_per_s"),
         "ba_c4_loop_closure_lm_iters_per_s": ((extra.get("ba") or {}).get("loop_closure") or {}).get("iters_per_s"),
         "ba_c5_loop_closure_lm_iters_per_s": ((extra.get("ba_c5") or {}).get("loop_closure") or {}).get("iters_per_s"),
+        "ba_c4_shuffled_cameras_lm_iters_per_s": ((extra.get("ba") or {}).get("shuffled") or {}).get("iters_per_s"),
+        "ba_c5_to_convergence_lm_iters_per_s": (((extra.get("ba_c5") or {}).get("band_solver") or {}).get("to_convergence") or {}).get("iters_per_s"),
+        "ba_c5_shuffled_cameras_lm_iters_per_s": ((extra.get("ba_c5") or {}).get("shuffled") or {}).get("iters_per_s"),
         "host_fed_Mkeypoints_per_s": (extra.get("host_fed") or {}).get("Mkeypoints_per_s"),
         "extra": extra,
     }

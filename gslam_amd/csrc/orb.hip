@@ -888,6 +888,205 @@ __global__ __launch_bounds__(256, P1 != 0 ? GH_FAST_WAVES : 1) void fast_cells_k
   fast_cells_tile<PK, P1, PLANE>(lv, ncx, ncy, min_th, ini_th, cell_cnt, cell_ent, cells_per_frame, cell_off, n_frames, nx, dbg, tile_id);
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT, round 6: the score plane by WAVE-AUTONOMOUS SLIDING WINDOWS -- no block-wide barrier, no shared tile.
+// fast_cells_tile stages a 64 x 64 tile for 256 threads and crosses three __syncthreads; its tile stages reach ~60 % of the issue
+// rate between them (docs/notes_r05.md).  Here a WAVE owns a strip of 256 pixel columns (one dword per lane; 248 of them are its
+// own, the rest is the +-3 px halo) and marches down kSwRows rows of one frame:
+//   * the image rows it needs live in a wave-private LDS ring of 16 rows x 256 B, fed from registers that were loaded two row
+//     groups (8 rows) ahead -- the HBM latency is covered by the wave's own work, not by occupancy;
+//   * pass 1 (the SWAR compass test of fast_cells_tile, same arithmetic) runs on 4 rows at a time, its survivors are appended to a
+//     wave-private queue with ONE wave scan per group;
+//   * pass 2 (exact arc score) pops 64 survivors at a time, so every lane is busy whatever the candidate density, reads its 17
+//     pixels from the ring and drops the score byte into a wave-private score ring (8 rows);
+//   * a row of the score ring leaves as 62 aligned dwords (one 248-byte run of the plane) once the survivors of its group are
+//     done -- at most one group later -- and is cleared for the row eight below.
+// Only wave-level ordering is needed (LDS operations of a wave execute in order; the fences below are compiler fences).
+// Output = the plane fast_cells_kernel<.., PLANE> writes (S of oracle step 2 / 3; pixel (y, x) at plane[y * pitch + x + kQtPlaneX]),
+// rows kEdge .. h - 1, bit for bit.  GSLAM_HIP_ORB_PLANE_SW=1 selects it for the quadtree mode (the pyramid then comes from the
+// stand-alone resize launches).  Result of the experiment: profiles/orb_sliding_window_r06.txt, DESIGN.md 6a.
+constexpr int kSwOwn = 248;    // pixels a strip owns: columns xs + 3 .. xs + 250 of its 256 (plane dwords are aligned at x = 3 mod 4)
+constexpr int kSwRows = 128;   // rows per wave
+constexpr int kSwGroup = 4;    // rows per pass-1 group (their candidate flags share one register: bits 15 - 2 t, 14 - 2 t, 31 - 2 t, 30 - 2 t)
+constexpr int kSwRing = 16;    // image ring: rows y - 3 .. y + 6 of the current group + the 4 rows of the group before it (their leftover survivors)
+constexpr int kSwSRing = 8;    // score ring: two groups
+constexpr int kSwQueue = 4 * kSwOwn + 64 + 32;  // a whole group of candidates + the leftover of the one before
+struct SwLds {
+  uint32_t img[kSwRing * 64];
+  uint32_t sc[kSwSRing * 64];
+  uint16_t q[kSwQueue];
+};
+__device__ __forceinline__ void sw_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int min_th, int nstrips, int nchunks, int n_frames,
+                                                            uint8_t* __restrict__ plane, size_t plane_frame_stride, int plane_pitch) {
+  __shared__ __attribute__((aligned(16))) SwLds lds_all[4];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  SwLds& L = lds_all[wv];
+  const int total = nstrips * nchunks * n_frames;
+  const int wid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);
+  if (wid >= total) return;
+  const int frame = wid / (nstrips * nchunks), rem = wid - frame * (nstrips * nchunks);
+  const int chunk = rem / nstrips, strip = rem - chunk * nstrips;
+  const int xs = kSwOwn * strip;                                        // first image column of the strip (a multiple of 4)
+  const int y_begin = kEdge + kSwRows * chunk;
+  const int y_out_end = min(y_begin + kSwRows, lv.h);                   // rows written (zeros below the valid region)
+  const int y_valid_end = min(y_out_end, lv.h - kEdge);                 // rows scored
+  const int ngroups = (y_out_end - y_begin + kSwGroup - 1) / kSwGroup;
+  const uint8_t* img = lv.base + (size_t)frame * lv.frame_stride;
+  uint8_t* pl = plane + (size_t)frame * plane_frame_stride;
+  const uint32_t gx = (uint32_t)min(xs + 4 * lane, lv.pitch - 4);
+  auto load_row = [&](int y) -> uint32_t {
+    const int yc = y < 0 ? 0 : (y > lv.h - 1 ? lv.h - 1 : y);
+    return *reinterpret_cast<const uint32_t*>(img + (__umul24((uint32_t)yc, (uint32_t)lv.pitch) + gx));
+  };
+  auto ring_row = [&](int y) { return (uint32_t)(y - y_begin + 3) & (kSwRing - 1); };
+  // rows y_begin - 3 .. y_begin + 2 now, the new rows of groups 0 and 1 in flight
+  {
+    uint32_t v[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[r] = load_row(y_begin - 3 + r);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) L.img[r * 64 + lane] = v[r];
+  }
+  uint32_t pfA[kSwGroup], pfB[kSwGroup];
+#pragma unroll
+  for (int r = 0; r < kSwGroup; ++r) {
+    pfA[r] = load_row(y_begin + 3 + r);
+    pfB[r] = load_row(y_begin + 3 + kSwGroup + r);
+  }
+#pragma unroll
+  for (int r = 0; r < kSwSRing; ++r) L.sc[r * 64 + lane] = 0u;
+  // which of its four pixels a lane owns: lane 0 only pixel 3, lane 62 pixels 0 .. 2, lane 63 none
+  const uint32_t own = lane == 0 ? 0x55000000u : (lane == 62 ? 0xAA00FF00u : (lane == 63 ? 0u : 0xFF00FF00u));
+  constexpr uint32_t kF = 0x00FF00FFu;
+  const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(min_th, 0), 255));
+  const uint32_t kAe = (0x8000u + t) * 0x10001u, kDe = (0x8000u - t - 1u) * 0x10001u;
+  const uint32_t kAo = (0x4000u + t) * 0x10001u, kDo = (0x4000u - t - 1u) * 0x10001u;
+  const int lm = lane > 0 ? lane - 1 : 0, lp = lane < 63 ? lane + 1 : 63;
+  int q_n = 0, q_old = 0;  // entries in the queue; how many of them are left over from the group before (wave-uniform)
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  (void)lt_mask;
+
+  // pass 2 on the queue entries [head, head + cnt), cnt <= 64
+  auto pass2 = [&](int head, int cnt) {
+    if (lane < cnt) {
+      const uint32_t e = L.q[head + lane];
+      const uint32_t rr = e >> 8, col = e & 255u;
+      const uint8_t* ib = reinterpret_cast<const uint8_t*>(L.img);
+      auto px = [&](int dy, int dx) -> int { return ib[((rr + (uint32_t)(dy + kSwRing)) & (kSwRing - 1)) * 256u + col + dx]; };
+      const int c = px(0, 0);
+      int r[16];
+      r[0] = px(-3, 0);  r[1] = px(-3, 1);  r[2] = px(-2, 2);   r[3] = px(-1, 3);
+      r[4] = px(0, 3);   r[5] = px(1, 3);   r[6] = px(2, 2);    r[7] = px(3, 1);
+      r[8] = px(3, 0);   r[9] = px(3, -1);  r[10] = px(2, -2);  r[11] = px(1, -3);
+      r[12] = px(0, -3); r[13] = px(-1, -3); r[14] = px(-2, -2); r[15] = px(-3, -1);
+      const int s = fast_score16_pk(r, c);
+      const int x = xs + (int)col;
+      if (s > min_th && x >= kEdge && x < lv.w - kEdge)
+        reinterpret_cast<uint8_t*>(L.sc)[((rr - 3u) & (kSwSRing - 1)) * 256u + col - 3u] = (uint8_t)s;
+    }
+  };
+  // rows [y0, y0 + 4) of the score ring to the plane, then cleared
+  auto flush = [&](int y0) {
+#pragma unroll
+    for (int r = 0; r < kSwGroup; ++r) {
+      const int y = y0 + r;
+      const uint32_t idx = ((uint32_t)(y - y_begin) & (kSwSRing - 1)) * 64u + (uint32_t)lane;
+      const uint32_t v = L.sc[idx];
+      L.sc[idx] = 0u;
+      const int pc = xs + 3 + kQtPlaneX + 4 * lane;  // plane column of the lane's first owned pixel (a multiple of 4)
+      if (lane < 62 && y < y_out_end && xs + 3 + 4 * lane < lv.w && pc + 3 < plane_pitch)
+        *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)y, (uint32_t)plane_pitch) + (uint32_t)pc)) = v;
+    }
+  };
+  auto group = [&](int g, uint32_t (&pf)[kSwGroup]) {
+    const int y = y_begin + kSwGroup * g;
+    // the group's new rows y + 3 .. y + 6 into the ring; their registers go back out for the rows two groups on
+#pragma unroll
+    for (int r = 0; r < kSwGroup; ++r) L.img[ring_row(y + 3 + r) * 64u + (uint32_t)lane] = pf[r];
+#pragma unroll
+    for (int r = 0; r < kSwGroup; ++r) pf[r] = load_row(y + 3 + 2 * kSwGroup + r);
+    sw_fence();
+    // ---- pass 1: SWAR compass test (fast_cells_tile, P1 = 1) on the rows y .. y + 3
+    uint32_t allbits = 0;
+#pragma unroll
+    for (int tr = 0; tr < kSwGroup; ++tr) {
+      const uint32_t rc = ring_row(y + tr) * 64u, ru = ring_row(y + tr - 3) * 64u, rd = ring_row(y + tr + 3) * 64u;
+      const uint32_t wc = L.img[rc + lane], wl = L.img[rc + lm], wr = L.img[rc + lp], wu = L.img[ru + lane], wd = L.img[rd + lane];
+      constexpr uint32_t kOdd = 0x0c030c01u;
+      const uint2 C{wc & kF, __builtin_amdgcn_perm(0u, wc, kOdd)}, U{wu & kF, __builtin_amdgcn_perm(0u, wu, kOdd)},
+          D{wd & kF, __builtin_amdgcn_perm(0u, wd, kOdd)};
+      const uint32_t le = __builtin_amdgcn_perm(0u, wl, kOdd), re = __builtin_amdgcn_perm(wr, wc, 0x0c050c03u);
+      const uint32_t lo = __builtin_amdgcn_perm(wc, wl, 0x0c040c02u), ro = wr & kF;
+      auto half = [](uint32_t A, uint32_t Dk, uint32_t u, uint32_t d, uint32_t l, uint32_t r) {
+        const uint32_t not_bright_lr = (A - l) & (A - r);
+        const uint32_t bright = __builtin_amdgcn_bitop3_b32(A - u, A - d, not_bright_lr, 0x15);  // ~(a & b) & ~c
+        const uint32_t dark_lr = (Dk - l) | (Dk - r);
+        const uint32_t dark = __builtin_amdgcn_bitop3_b32(Dk - u, Dk - d, dark_lr, 0xA8);  // (a | b) & c
+        return bright | dark;
+      };
+      const uint32_t ye = half(C.x + kAe, C.x + kDe, U.x, D.x, le, re);
+      const uint32_t yo = half(C.y + kAo, C.y + kDo, U.y, D.y, lo, ro);
+      const uint32_t w = __builtin_amdgcn_bitop3_b32(ye, yo, 0x80008000u, 0xE4);  // (a & c) | (b & ~c)
+      const uint32_t rowmask = y + tr < y_valid_end ? 0xC000C000u >> (2 * tr) : 0u;
+      allbits = __builtin_amdgcn_bitop3_b32(allbits, w >> (2 * tr), rowmask, 0xF8);  // a | (b & c)
+    }
+    allbits &= own;
+    // ---- the survivors join the queue: one wave scan per group
+    {
+      const int cnt = __popc(allbits);
+      const int incl = wave_incl_scan_i32(cnt);
+      const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+      int base = q_n + incl - cnt;
+      const uint32_t rr0 = ring_row(y);
+      while (allbits) {
+        const int b = __ffs((int)allbits) - 1;
+        const uint32_t bb = 15u - ((uint32_t)b & 15u), tr = bb >> 1, k = 2u * ((uint32_t)b >> 4) + (bb & 1u);
+        L.q[base++] = (uint16_t)((((rr0 + tr) & (kSwRing - 1)) << 8) | (4u * (uint32_t)lane + k));
+        allbits &= allbits - 1u;
+      }
+      q_n += wave_total;
+    }
+    sw_fence();
+    // ---- pass 2: full chunks, then whatever is still left of the group before (its rows leave the ring next group)
+    int head = 0;
+    while (q_n - head >= 64) {
+      pass2(head, 64);
+      head += 64;
+    }
+    if (head < q_old) {
+      const int cnt = min(64, q_n - head);
+      pass2(head, cnt);
+      head += cnt;
+    }
+    sw_fence();
+    // the leftover (< 64 entries, all of this group) to the front
+    const int left = q_n - head;
+    if (head > 0 && left > 0) {
+      const uint16_t e = lane < left ? L.q[head + lane] : (uint16_t)0;
+      sw_fence();
+      if (lane < left) L.q[lane] = e;
+    }
+    q_n = q_old = left;
+    sw_fence();
+    if (g > 0) flush(y - kSwGroup);
+  };
+  for (int g = 0; g < ngroups; g += 2) {
+    group(g, pfA);
+    if (g + 1 < ngroups) group(g + 1, pfB);
+  }
+  // the last group's leftover, then its rows
+  sw_fence();
+  if (q_n > 0) pass2(0, q_n);
+  sw_fence();
+  flush(y_begin + kSwGroup * (ngroups - 1));
+}
+
 // Every level in ONE launch, over a pyramid that exists already (stand-alone resize launches): what a small call wants --
 // with the next level fused into fast_cells(l) the eight levels are eight DEPENDENT launches of ~14 us of latency each,
 // whatever the image size; here the dependent chain is seven small resize launches and one FAST launch.
@@ -2522,10 +2721,22 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
         const uint32_t nbx = (uint32_t)gh_div_up(p->ncx[l], 2), tpf = nbx * (uint32_t)gh_div_up(p->ncy[l], 2);
         nx.tiles_inv = magic_div(tpf, (uint32_t)tiles);
         nx.nbx_inv = magic_div(nbx, tpf);
+        // GSLAM_HIP_ORB_PLANE_SW=1: the plane by the barrier-free sliding-window kernel (round-6 experiment), the next level by the
+        // stand-alone resize launch
+        static const bool plane_sw = [] { const char* e = getenv("GSLAM_HIP_ORB_PLANE_SW"); return e && e[0] == '1'; }();
+        if (plane_sw) {
+          const int nstrips = gh_div_up(p->lw[l] - 3, kSwOwn), nchunks = gh_div_up(p->lh[l] - kEdge, kSwRows);
+          const long long waves = (long long)nstrips * nchunks * batch;
+          GH_CHECK_ARG(ctx, waves < (1LL << 30));
+          GH_LAUNCH(ctx, "orb_fast_plane_sw", fast_plane_sw_kernel, dim3((unsigned)gh_div_up(waves, 4)), dim3(256), 0, lv[l],
+                    p->prm.min_th_fast, nstrips, nchunks, batch, nx.plane, nx.plane_frame_stride, nx.plane_pitch);
+          if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
+        } else {
         GH_LAUNCH(ctx, "orb_fast_plane", (fast_cells_kernel<true, 1, true>), dim3(8 * gh_div_up(tiles, 8)), dim3(256), p->lds_pad, lv[l],
                   p->ncx[l], p->ncy[l], p->prm.min_th_fast, p->prm.ini_th_fast, p->cell_cnt, p->cell_ent, p->cells_per_frame,
                   p->cell_off[l], batch, nx, dbg);
         if (l + 1 < L && !p->fuse_pyramid) GH_TRY(resize_standalone(l + 1));
+        }
         planes[l] = LevelView{p->score_plane + p->plane_off[l], p->plane_slab, p->plane_pitch[l], p->lw[l], p->lh[l]};
         GH_TRY(cells_of(l, &planes[l]));
       }
