@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256, P1 != 0 ? GH_FAST_WAVES : 1) void fast_cells_k
 // rows kEdge .. h - 1, bit for bit.  GSLAM_HIP_ORB_PLANE_SW=1 selects it for the quadtree mode (the pyramid then comes from the
 // stand-alone resize launches).  Result of the experiment: profiles/orb_sliding_window_r06.txt, DESIGN.md 6a.
 constexpr int kSwOwn = 248;    // pixels a strip owns: columns xs + 3 .. xs + 250 of its 256 (plane dwords are aligned at x = 3 mod 4)
-constexpr int kSwRows = 128;   // rows per wave
+constexpr int kSwRows = 64;    // rows per wave (128: 1.49 ms per 100 x 1080p against 1.38 -- fewer, longer waves fill the chip worse)
 constexpr int kSwGroup = 4;    // rows per pass-1 group (their candidate flags share one register: bits 15 - 2 t, 14 - 2 t, 31 - 2 t, 30 - 2 t)
 constexpr int kSwRing = 16;    // image ring: rows y - 3 .. y + 6 of the current group + the 4 rows of the group before it (their leftover survivors)
 constexpr int kSwSRing = 8;    // score ring: two groups
@@ -923,7 +923,8 @@ __device__ __forceinline__ void sw_fence() {
 }
 
 __global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int min_th, int nstrips, int nchunks, int n_frames,
-                                                            uint8_t* __restrict__ plane, size_t plane_frame_stride, int plane_pitch) {
+                                                            uint8_t* __restrict__ plane, size_t plane_frame_stride, int plane_pitch,
+                                                            int variant) {
   __shared__ __attribute__((aligned(16))) SwLds lds_all[4];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   SwLds& L = lds_all[wv];
@@ -944,6 +945,17 @@ __global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int mi
     const int yc = y < 0 ? 0 : (y > lv.h - 1 ? lv.h - 1 : y);
     return *reinterpret_cast<const uint32_t*>(img + (__umul24((uint32_t)yc, (uint32_t)lv.pitch) + gx));
   };
+  // The PREFETCHED rows are loaded by inline asm and waited for by hand.  The compiler's s_waitcnt insertion treats a counter with
+  // loads AND stores pending as out of order and drains it (vmcnt(0)) at the top of every other group -- the plane stores of the
+  // flush are always pending -- which cut the prefetch distance from two groups to none.  Loads return in order among themselves,
+  // so "at most 4 operations outstanding" implies that everything older than the 4 youngest loads has landed, whatever the stores
+  // do (a pending store can only make the wait longer).  The registers must not be copied between the two asm statements (the
+  // compiler believes they are valid at once): 48 of 128 registers are in use, and tests/test_build_isa.py looks at the code.
+  auto load_row_async = [&](int y, uint32_t& dst) {
+    const int yc = y < 0 ? 0 : (y > lv.h - 1 ? lv.h - 1 : y);
+    const uint32_t off = __umul24((uint32_t)yc, (uint32_t)lv.pitch) + gx;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(img) : "memory");
+  };
   auto ring_row = [&](int y) { return (uint32_t)(y - y_begin + 3) & (kSwRing - 1); };
   // rows y_begin - 3 .. y_begin + 2 now, the new rows of groups 0 and 1 in flight
   {
@@ -955,10 +967,9 @@ __global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int mi
   }
   uint32_t pfA[kSwGroup], pfB[kSwGroup];
 #pragma unroll
-  for (int r = 0; r < kSwGroup; ++r) {
-    pfA[r] = load_row(y_begin + 3 + r);
-    pfB[r] = load_row(y_begin + 3 + kSwGroup + r);
-  }
+  for (int r = 0; r < kSwGroup; ++r) load_row_async(y_begin + 3 + r, pfA[r]);
+#pragma unroll
+  for (int r = 0; r < kSwGroup; ++r) load_row_async(y_begin + 3 + kSwGroup + r, pfB[r]);
 #pragma unroll
   for (int r = 0; r < kSwSRing; ++r) L.sc[r * 64 + lane] = 0u;
   // which of its four pixels a lane owns: lane 0 only pixel 3, lane 62 pixels 0 .. 2, lane 63 none
@@ -999,18 +1010,34 @@ __global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int mi
       const uint32_t idx = ((uint32_t)(y - y_begin) & (kSwSRing - 1)) * 64u + (uint32_t)lane;
       const uint32_t v = L.sc[idx];
       L.sc[idx] = 0u;
+      // UNCONDITIONAL store: a lane without a dword of its own writes to the row's left margin (plane columns 0 .. 3: pixel x sits
+      // at column x + kQtPlaneX, nobody reads the margin).  A branch around the store costs the compiler its count of the memory
+      // operations in flight: it then drains the prefetched rows (s_waitcnt vmcnt(0)) at the top of every other group.
       const int pc = xs + 3 + kQtPlaneX + 4 * lane;  // plane column of the lane's first owned pixel (a multiple of 4)
-      if (lane < 62 && y < y_out_end && xs + 3 + 4 * lane < lv.w && pc + 3 < plane_pitch)
-        *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)y, (uint32_t)plane_pitch) + (uint32_t)pc)) = v;
+      const bool mine = lane < 62 && y < y_out_end && xs + 3 + 4 * lane < lv.w && pc + 3 < plane_pitch;
+      const int yy = y < lv.h ? y : lv.h - 1;
+      if (variant & 2) {  // (A/B: the conditional store of the first version)
+        if (mine) *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)yy, (uint32_t)plane_pitch) + (uint32_t)pc)) = v;
+      } else {
+        *reinterpret_cast<uint32_t*>(pl + (__umul24((uint32_t)yy, (uint32_t)plane_pitch) + (uint32_t)(mine ? pc : 0))) = v;
+      }
     }
   };
   auto group = [&](int g, uint32_t (&pf)[kSwGroup]) {
     const int y = y_begin + kSwGroup * g;
-    // the group's new rows y + 3 .. y + 6 into the ring; their registers go back out for the rows two groups on
+    // the group's new rows y + 3 .. y + 6 (asked for two groups ago; the 4 loads of the group in between may still be in
+    // flight) into the ring; their registers go back out for the rows two groups on
+    static_assert(kSwGroup == 4, "the wait below names four registers and leaves four loads in flight");
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3])::"memory");
 #pragma unroll
     for (int r = 0; r < kSwGroup; ++r) L.img[ring_row(y + 3 + r) * 64u + (uint32_t)lane] = pf[r];
+    if (variant & 8) {  // (A/B: compiler-tracked loads)
 #pragma unroll
-    for (int r = 0; r < kSwGroup; ++r) pf[r] = load_row(y + 3 + 2 * kSwGroup + r);
+      for (int r = 0; r < kSwGroup; ++r) pf[r] = load_row(y + 3 + 2 * kSwGroup + r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < kSwGroup; ++r) load_row_async(y + 3 + 2 * kSwGroup + r, pf[r]);
+    }
     sw_fence();
     // ---- pass 1: SWAR compass test (fast_cells_tile, P1 = 1) on the rows y .. y + 3
     uint32_t allbits = 0;
@@ -1054,15 +1081,19 @@ __global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int mi
     }
     sw_fence();
     // ---- pass 2: full chunks, then whatever is still left of the group before (its rows leave the ring next group)
+    // (the leftover of the group before first, then ITS rows go out -- half a group ahead of the next wait for prefetched rows,
+    //  which would otherwise sit behind plane stores issued a moment ago -- then the rest of the full chunks)
     int head = 0;
-    while (q_n - head >= 64) {
-      pass2(head, 64);
-      head += 64;
-    }
-    if (head < q_old) {
+    while (head < q_old) {
       const int cnt = min(64, q_n - head);
       pass2(head, cnt);
       head += cnt;
+    }
+    sw_fence();
+    if (g > 0 && !(variant & 4)) flush(y - kSwGroup);
+    while (q_n - head >= 64) {
+      pass2(head, 64);
+      head += 64;
     }
     sw_fence();
     // the leftover (< 64 entries, all of this group) to the front
@@ -1074,7 +1105,7 @@ __global__ __launch_bounds__(256) void fast_plane_sw_kernel(LevelView lv, int mi
     }
     q_n = q_old = left;
     sw_fence();
-    if (g > 0) flush(y - kSwGroup);
+    if (g > 0 && (variant & 4)) flush(y - kSwGroup);  // (A/B: the first version's place)
   };
   for (int g = 0; g < ngroups; g += 2) {
     group(g, pfA);
@@ -2723,13 +2754,14 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
         nx.nbx_inv = magic_div(nbx, tpf);
         // GSLAM_HIP_ORB_PLANE_SW=1: the plane by the barrier-free sliding-window kernel (round-6 experiment), the next level by the
         // stand-alone resize launch
-        static const bool plane_sw = [] { const char* e = getenv("GSLAM_HIP_ORB_PLANE_SW"); return e && e[0] == '1'; }();
-        if (plane_sw) {
+        const char* sw_env = getenv("GSLAM_HIP_ORB_PLANE_SW");  // (read per call: the experiment's A/B runs switch inside one process)
+        const int plane_sw = sw_env ? atoi(sw_env) : 0;  // bit 0: on; bits 1-3: A/B variants of the kernel
+        if (plane_sw & 1) {
           const int nstrips = gh_div_up(p->lw[l] - 3, kSwOwn), nchunks = gh_div_up(p->lh[l] - kEdge, kSwRows);
           const long long waves = (long long)nstrips * nchunks * batch;
           GH_CHECK_ARG(ctx, waves < (1LL << 30));
           GH_LAUNCH(ctx, "orb_fast_plane_sw", fast_plane_sw_kernel, dim3((unsigned)gh_div_up(waves, 4)), dim3(256), 0, lv[l],
-                    p->prm.min_th_fast, nstrips, nchunks, batch, nx.plane, nx.plane_frame_stride, nx.plane_pitch);
+                    p->prm.min_th_fast, nstrips, nchunks, batch, nx.plane, nx.plane_frame_stride, nx.plane_pitch, plane_sw);
           if (l + 1 < L) GH_TRY(resize_standalone(l + 1));
         } else {
         GH_LAUNCH(ctx, "orb_fast_plane", (fast_cells_kernel<true, 1, true>), dim3(8 * gh_div_up(tiles, 8)), dim3(256), p->lds_pad, lv[l],

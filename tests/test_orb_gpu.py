@@ -478,3 +478,18 @@ def test_quadtree_distribution_limits_and_host_entry(ctx, oracle):
         oracle.orb_set_distribution(0)
     assert kps.tobytes() == ek.tobytes() and np.array_equal(desc, ed)
     ex.close()
+
+def test_quadtree_plane_by_sliding_window_kernel(ctx, oracle, monkeypatch):
+    """Round-6 experiment (profiles/orb_sliding_window_r06.txt): the score plane by the barrier-free sliding-window kernel
+    (GSLAM_HIP_ORB_PLANE_SW, read per call; variant bits 2 / 4 / 8 = the A/B forms) -- same keypoints and descriptors as the oracle,
+    i.e. as the tile kernel's plane, on images whose width / height leave partial strips and partial row groups."""
+    for var, (w, h, B) in (("1", (640, 480, 3)), ("15", (752, 480, 2)), ("1", (1241, 376, 2)), ("7", (333, 259, 2))):
+        from gslam_amd.orb import synth_frames
+        monkeypatch.setenv("GSLAM_HIP_ORB_PLANE_SW", var)
+        host = synth_frames(ctx, B, w, h, base_seed=0x5EED0900 + w).cpu().numpy()[:, :, :w]
+        counts = _quadtree_case(ctx, oracle, host, 1000, False)
+        assert (counts > 0).all()
+    # candidate density at its worst (every queue chunk full, the group's leftover carried): noise
+    monkeypatch.setenv("GSLAM_HIP_ORB_PLANE_SW", "1")
+    rng = np.random.default_rng(5)
+    _quadtree_case(ctx, oracle, rng.integers(0, 256, (2, 300, 520), dtype=np.uint8), 500, False)
