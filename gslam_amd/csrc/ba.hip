@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "common.h"
+#include "cr_map.h"
 #include "host_pool.h"
 
 gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_dev, int extra_rows, double* dinv,
@@ -38,8 +39,9 @@ size_t gh_cr_panel_doubles(int n, int T);
 gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, double* dinv, double* W, double* x_dev,
                                int* info_dev, bool info_ready);
 size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr);
+int gh_cr_compact_lda(int n_band, int T, int nbr, int* brow);
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
-                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz);
+                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz, bool compact);
 int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int* reordered, bool allow_reorder, int* band_span);  // ba_order.hip
 size_t gh_cr_border_symbolic_bytes(int n_band, int T, int nbr);
 void gh_cr_border_symbolic(int n_band, int T, int nbr, const uint8_t* init, uint8_t* out);
@@ -453,11 +455,13 @@ __device__ __forceinline__ void schur_init_block(int n, int lda, const double* _
 // also clears its border rows nband .. n - 1, a border column its whole lower part.
 __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, const double* __restrict__ Hcc,
                                                       const double* __restrict__ gc, double radius, double* __restrict__ S,
-                                                      double* __restrict__ rhs, int c, int nband) {
+                                                      double* __restrict__ rhs, int c, int nband, CrMap map) {
+  // (map: cr_map.h -- dense columns of n + 1 rows, or compact columns that hold exactly the rows cleared here)
   const int cam = c / 6, b = c - 6 * cam;
-  double* col = S + (size_t)c * lda;
-  if (c >= nband) {  // a border column: dense from its 64-row tile down
-    for (int r = ((c >> 6) << 6) + (int)threadIdx.x; r < n; r += 256) {
+  double* const colB = S + (size_t)c * lda + map.bshift();  // border rows and the right-hand-side row of this column
+  if (c >= nband) {  // a border column: dense from its 64-row tile down (compact: its border rows)
+    const int r_first = map.m ? nband : ((c >> 6) << 6);
+    for (int r = r_first + (int)threadIdx.x; r < n; r += 256) {
       double v = 0.0;
       if (r / 6 == cam) {
         const int a = r - 6 * cam;
@@ -465,19 +469,20 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
         if (a == b) h += clampd(h, 1e-6, 1e32) / radius;
         v = h;
       }
-      col[r] = v;
+      (r >= nband ? colB : S + (size_t)c * lda)[r] = v;
     }
     if (threadIdx.x == 0) {
       const double v = -gc[c];
-      col[n] = v;
+      colB[n] = v;
       rhs[c] = v;
     }
     return;
   }
-  for (int r = nband + (int)threadIdx.x; r < n; r += 256) col[r] = 0.0;  // (nothing when there is no border)
+  for (int r = nband + (int)threadIdx.x; r < n; r += 256) colB[r] = 0.0;  // (nothing when there is no border)
   const int n_full = n;
   n = nband;
   const int J = c / m, N = (n + m - 1) / m;
+  double* const col = S + (size_t)c * lda + map.shift(J, J);  // rows of the superblocks J and J + 1 (the same shift)
   const int r0 = (c >> 6) << 6, r1 = min(n, (J + 2) * m);
   for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
     double v = 0.0;
@@ -492,11 +497,12 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
   for (int s = 1; J + 2 * s < N; s *= 2) {
     if (J % (2 * s) != 0) break;  // (J survives level s only if it survived every level before)
     const int f0 = (J + 2 * s) * m, f1 = min(n, f0 + m);
-    for (int r = f0 + (int)threadIdx.x; r < f1; r += 256) col[r] = 0.0;
+    double* const colF = S + (size_t)c * lda + map.shift(J + 2 * s, J);
+    for (int r = f0 + (int)threadIdx.x; r < f1; r += 256) colF[r] = 0.0;
   }
   if (threadIdx.x == 0) {
     const double v = -gc[c];
-    col[n_full] = v;
+    colB[n_full] = v;
     rhs[c] = v;
   }
 }
@@ -504,10 +510,10 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
 __global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
                                                          const double* __restrict__ gc, double radius,
                                                          double* __restrict__ S, double* __restrict__ rhs, int band_m, int nband,
-                                                         int gx) {
+                                                         int gx, CrMap map) {
   // a one-dimensional grid of gx workgroups per column (gridDim.y stops at 65535: the limit n < 65536 of rounds 1-5 was this launch)
   const int b = (int)blockIdx.x;
-  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband);  // (gx == 1)
+  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband, map);  // (gx == 1)
   else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
 }
 
@@ -521,11 +527,17 @@ __device__ __forceinline__ void load_W(const double* __restrict__ Wbuf, int k, d
   }
 }
 
+// element (r, c) of the reduced camera system, r >= c, as the assembly addresses it: a band row (at most one superblock below
+// the column's: the camera span guarantees it), a border row, or the right-hand-side row (cr_map.h)
+__device__ __forceinline__ double* s_elem(double* __restrict__ S, int lda, const CrMap& map, int r, int c) {
+  if (map.m == 0) return S + (size_t)c * lda + r;
+  return S + (size_t)c * lda + r + (r >= map.n_band ? map.bshift() : -(long long)(c / map.m) * map.m);
+}
 // Fast mode: one thread per observation i (in point-CSR order); all j of the same point; f64 atomics.
 __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const double* __restrict__ Hpi,
                                                            const double* __restrict__ gp, double* __restrict__ S,
                                                            int n, double* __restrict__ rhs,
-                                                           const double* __restrict__ Wbuf) {
+                                                           const double* __restrict__ Wbuf, CrMap map) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= P.no) return;
   const int k = P.plist[q];
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const doub
       for (int b = 0; b < 6; ++b) {
         if (ci == cj && a < b) continue;
         const double v = WH[3 * a] * Wj[3 * b] + WH[3 * a + 1] * Wj[3 * b + 1] + WH[3 * a + 2] * Wj[3 * b + 2];
-        atomicAdd(&S[(size_t)(6 * cj + b) * n + 6 * ci + a], -v);
+        atomicAdd(s_elem(S, n, map, 6 * ci + a, 6 * cj + b), -v);
       }
   }
 }
@@ -668,12 +680,12 @@ __global__ __launch_bounds__(256) void schur_blocks_init_kernel(Problem P, Schur
                                                                 const double* __restrict__ Hcc,
                                                                 const double* __restrict__ gc, double radius,
                                                                 double* __restrict__ S, double* __restrict__ rhs, int gx,
-                                                                int band_m, int nband) {
+                                                                int band_m, int nband, CrMap map) {
   if (blockIdx.x < nsb) {
     schur_blocks_block(P, B, Hpi, gp, Wbuf, partial, blockIdx.x, nsb);
   } else {
     const int b = (int)(blockIdx.x - nsb);
-    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband);  // (gx == 1)
+    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband, map);  // (gx == 1)
     else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
   }
 }
@@ -929,7 +941,7 @@ struct SolveState {
 };
 __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const double* __restrict__ partial,
                                                            double* __restrict__ S, int n, double* __restrict__ rhs,
-                                                           int rhs_row, int n_reduce_blocks, SolveState st) {
+                                                           int rhs_row, int n_reduce_blocks, SolveState st, CrMap map) {
   if ((int)blockIdx.x >= n_reduce_blocks) {
     const unsigned i = ((unsigned)blockIdx.x - (unsigned)n_reduce_blocks) * 256u + threadIdx.x;
     if (i < st.n_flow) st.flow_flags[i] = 0u;
@@ -945,19 +957,19 @@ __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const 
   if (t < 36) {
     const int a = t / 6, b = t - 6 * a;
     if (ci == cj && a < b) return;  // lower triangle only
-    double* dst = &S[(size_t)(6 * cj + b) * n + 6 * ci + a];
+    double* dst = s_elem(S, n, map, 6 * ci + a, 6 * cj + b);
     *dst = *dst - tot;
   } else if (ci == cj) {
     const double v = rhs[6 * ci + (t - 36)] + tot;
     rhs[6 * ci + (t - 36)] = v;
-    S[(size_t)(6 * ci + (t - 36)) * n + rhs_row] = v;
+    *s_elem(S, n, map, rhs_row, 6 * ci + (t - 36)) = v;
   }
 }
 
 // rhs -> row n of S (rides through the factorisation, becomes y = L^-1 rhs; the back-substitution reads it there)
-__global__ void rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ S, int lda, int n) {
+__global__ void rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ S, int lda, int n, CrMap map) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) S[(size_t)j * lda + n] = rhs[j];
+  if (j < n) S[(size_t)j * lda + n + map.bshift()] = rhs[j];
 }
 
 // back-substitution for the points and the candidate state in one launch: thread i handles point i and camera i; it also
@@ -1484,6 +1496,8 @@ struct BaSession {
   size_t n_pairs = 0;
   // band solver (chol_cr.hip): tiles per superblock (0 = the dense factorisation), its inverted diagonal tiles and panels
   int cr_T = 0, cam_span = 0;
+  int lda = 0;   // rows per column of d_S as allocated
+  CrMap map;     // layout of d_S: dense (map.m == 0) or the band solver's compact columns
   double *d_cr_dinv = nullptr, *d_cr_W = nullptr;
   ~BaSession() {
     delete db;
@@ -1570,7 +1584,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   const int n = 6 * nc;
   const int n_band = 6 * (nc - S.n_border);  // (== n unless the cameras are in arrow order)
   // one extra row carries the right-hand side through the factorisation; columns start on 128-byte lines
-  const int lda = (n + 1 + 15) & ~15;
+  // (dense: n + 1 rows per column; band / arrowhead solver: compact columns, decided with the solver below -- cr_map.h)
+  int lda = S.ready ? S.lda : (n + 1 + 15) & ~15;
 
   // Everything the host reads back during an iteration (gradient maximum, factorisation / damping flags, candidate cost
   // and model decrease) lands in ONE pinned block: copies into pageable memory are staged and block the host in the middle
@@ -1840,7 +1855,6 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   GH_TRY(db.alloc(&d_Hpp, (size_t)np * 9));
   GH_TRY(db.alloc(&d_gp, (size_t)np * 3));
   GH_TRY(db.alloc(&d_Hpi, (size_t)np * 9));
-  GH_TRY(db.alloc(&d_S, (size_t)n * lda));
   GH_TRY(db.alloc(&d_dc, (size_t)n));
   GH_TRY(db.alloc(&d_dp, (size_t)np * 3));
   GH_TRY(db.alloc(&d_work, (size_t)n));
@@ -1858,6 +1872,21 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
     cr_T = want == 1 ? 0 : gh_cr_tiles(n_band, 6 * span + 5);
     d_cr_dinv = d_cr_W = S.d_arrow_ws = nullptr;
+    S.map = CrMap{};
+    if (cr_T) {
+      // COMPACT columns: the band rows, one slot per reduction level for the fill, the border rows, the right-hand side --
+      // 0.93 GB at C5 where the dense lower triangle takes 28.8 GB (GSLAM_HIP_BA_DENSE_S=1: the dense layout of rounds 4-5, A/B)
+      const char* de = getenv("GSLAM_HIP_BA_DENSE_S");
+      if (!(de && de[0] == '1')) {
+        int brow = 0;
+        lda = gh_cr_compact_lda(n_band, cr_T, n - n_band, &brow);
+        S.map.m = 64 * cr_T;
+        S.map.n_band = n_band;
+        S.map.brow = brow;
+      }
+    }
+    S.lda = lda;
+    GH_TRY(db.alloc(&d_S, (size_t)n * lda));
     if (cr_T) {
       GH_TRY(db.alloc(&d_cr_dinv, gh_cr_dinv_doubles(n_band, cr_T)));
       GH_TRY(db.alloc(&d_cr_W, gh_cr_panel_doubles(n_band, cr_T)));
@@ -2038,7 +2067,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       {
         const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);
         GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3((unsigned)gx * (unsigned)n), dim3(256), 0, n, lda, d_Hcc,
-                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band, gx);
+                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band, gx, S.map);
       }
     } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
@@ -2054,7 +2083,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
           const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);  // (the band solver's seed: one workgroup per column)
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_init_kernel, dim3(nsb + (unsigned)gx * (unsigned)n), dim3(256), 0, P,
                     SB, d_Hpi, d_gp, (const double*)d_W, d_spart, nsb, n, lda, (const double*)d_Hcc, (const double*)d_gc,
-                    radius, d_S, d_dc, gx, 64 * cr_T, n_band);
+                    radius, d_S, d_dc, gx, 64 * cr_T, n_band, S.map);
         } else {
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(nsb), dim3(256), 0, P, SB, d_Hpi, d_gp,
                     (const double*)d_W, d_spart);
@@ -2072,12 +2101,12 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
           }
           const unsigned words = st.n_flow > st.n_xh ? st.n_flow : st.n_xh;
           GH_LAUNCH(ctx, "ba_schur_reduce", schur_reduce_kernel, dim3(nred + gh_div_up((int)(words ? words : 1u), 256)),
-                    dim3(256), 0, SB, (const double*)d_spart, d_S, lda, d_dc, n, nred, st);
+                    dim3(256), 0, SB, (const double*)d_spart, d_S, lda, d_dc, n, nred, st, S.map);
           solve_state_ready = true;
         }
       } else {
         GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
-                  d_S, lda, d_dc, (const double*)d_W);
+                  d_S, lda, d_dc, (const double*)d_W, S.map);
       }
     }
     const double t_solve0 = now_ms();
@@ -2089,10 +2118,10 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     // synchronisation per iteration instead of three.
     // rhs -> row n of S: already there when schur_init_kernel + schur_reduce_kernel wrote it
     if (!(slim_init && opt.deterministic))
-      GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n);
+      GH_LAUNCH(ctx, "ba_rhs_row", rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, d_dc, d_S, lda, n, S.map);
     if (cr_T) {  // (n_band == n: a band without a border)
       GH_TRY(gh_arrow_solve_dev_impl(ctx, d_S, n_band, n - n_band, lda, cr_T, d_cr_dinv, d_cr_W, S.d_arrow_ws, d_dc, d_info,
-                                     solve_state_ready, cr_flow_ok, S.d_border_nz));
+                                     solve_state_ready, cr_flow_ok, S.d_border_nz, S.map.m != 0));
     } else {
     GH_TRY(gh_potrf_dev_impl(ctx, d_S, n, lda, d_info, 1, d_dinv, d_xwork, d_flow, false, solve_state_ready));
     // y = L^-1 b is row n of the factored matrix; the back-substitution reads it in place

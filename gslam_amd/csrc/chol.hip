@@ -232,7 +232,7 @@ constexpr int TM = 128, KC = 16;
 // (tools/clock_probe.hip: 8 accumulators per wave reach 50 TFLOP/s with two waves per SIMD and 88 with four).
 template <bool INTERIOR, int TMT, int WAVES = 4>
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n, int r_begin, int c_end, int kc0,
-                                          int kdim, int i0, int j0, double* sP, double* sQ, int skip_end) {
+                                          int kdim, int i0, int j0, double* sP, double* sQ, int skip_end, int prio = 0) {
   constexpr int WC = WAVES / 2;                  // wave grid: 2 row halves x WC column parts
   constexpr int SUBI = TMT / 2, SUBJ = TMT / WC; // wave sub-tile: rows (i) x columns (j)
   constexpr int MTI = SUBI / 16, MTJ = SUBJ / 16;  // MFMA tiles per edge of the wave sub-tile
@@ -296,6 +296,10 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
     if (kc + KC < kdim) fetch(kc + KC);
     // (Fetching the fragments of step ks + 1 ahead of the MFMAs of step ks was measured slower with eight waves: 1164 ms
     // against 1154 ms for the n = 60 000 factorisation; four waves per SIMD hide the LDS latency by themselves.)
+    // (round-6 A/B, VERDICT r5 item 8: the waves inside their MFMA block at a raised issue priority, so that a wave that is
+    //  staging the next chunk does not take issue slots from one that feeds the matrix core: GSLAM_HIP_SYRK_PRIO)
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio >= 2) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
       double fa[MTJ], fb[MTI];
@@ -310,6 +314,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int lda, int n
         for (int it = 0; it < MTI; ++it)
           acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[jt], fb[it], acc[jt][it], 0, 0, 0);
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
   }
   // C -= acc^T : lane holds, for tile (jt, it): j = jbase + (lane>>4) + 4r, i = ibase + (lane&15)
 #pragma unroll
@@ -467,7 +472,7 @@ template <int TMT>
 __global__ __launch_bounds__(512, 4) void syrk_mfma8_kernel(double* __restrict__ A, int lda, int n, int r_begin,
                                                         int c_begin, int c_end, int kc0, int kdim, int tiles_i,
                                                         int tiles_j, int fuse_d, int fuse_kb, int* __restrict__ info,
-                                                        double* __restrict__ minv_next) {
+                                                        double* __restrict__ minv_next, int prio) {
   __shared__ __attribute__((aligned(16))) Potf2Lds sh;  // the tile path uses its first 2 * KC * (TMT + 16) doubles
   static_assert(2 * 2 * KC * (TM + 16) * sizeof(double) <= sizeof(Potf2Lds), "double-buffered operand staging must fit");
   int bid = blockIdx.x;
@@ -503,8 +508,8 @@ __global__ __launch_bounds__(512, 4) void syrk_mfma8_kernel(double* __restrict__
   }
   const int j0 = c_begin + tj * TMT, i0 = r_begin + ti * TMT;
   const bool interior = i0 + TMT <= n && j0 + TMT <= c_end && i0 >= j0 + TMT && (kdim % KC) == 0;
-  if (interior) syrk_tile<true, TMT, 8>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0);
-  else syrk_tile<false, TMT, 8>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end);
+  if (interior) syrk_tile<true, TMT, 8>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, 0, prio);
+  else syrk_tile<false, TMT, 8>(A, lda, n, r_begin, c_end, kc0, kdim, i0, j0, sP, sQ, skip_end, prio);
 }
 
 // One WHOLE panel step of the small-matrix regime in a single launch (the step used to be trsm + update: at
@@ -1753,6 +1758,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
   // factored on this one.  Bit-identical, but the two streams' kernels do not overlap on this part: 1155 ms against
   // 1152 ms for the n = 60 000 factorisation, tools/c5_solve_probe.py.)
   const int syrk8 = [] { const char* e = getenv("GSLAM_HIP_SYRK8"); return e ? atoi(e) : 1; }();
+  const int syrk_prio = [] { const char* e = getenv("GSLAM_HIP_SYRK_PRIO"); return e ? atoi(e) : 0; }();
   auto update = [&](const char* name, int cb, int ce, int kc0, int kdim, int kbn, double* minv_next) -> gh_status {
     // grid = the lower tiles (see the decode in the kernel), rounded up to the 8 XCD strips, + the potf2 workgroup
     if (t128_of(cb, ce) >= 1024) {  // enough 128-tiles for 256 CUs x 2 workgroups
@@ -1760,7 +1766,7 @@ gh_status gh_potrf_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int* info_de
       const dim3 grid(8 * gh_div_up(lower_tiles(tiles_i, tiles_j), 8) + 1);
       if (syrk8)  // eight waves per tile: four waves per SIMD keep the f64 matrix core busier (GSLAM_HIP_SYRK8=0: four)
         GH_LAUNCH(ctx, name, syrk_mfma8_kernel<TM>, grid, dim3(512), 0, A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb,
-                  kbn, info_dev, minv_next);
+                  kbn, info_dev, minv_next, syrk_prio);
       else
         GH_LAUNCH(ctx, name, syrk_mfma_kernel<TM>, grid, dim3(256), 0, A, lda, nr, cb, cb, ce, kc0, kdim, tiles_i, tiles_j, cb, kbn,
                   info_dev, minv_next);

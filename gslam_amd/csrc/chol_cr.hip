@@ -25,6 +25,7 @@
 // Storage: A is the dense column-major lower triangle chol.hip uses (n x n, lda > n, rhs in row n); L_i overwrites D_i, the
 // W panels go to a workspace (2 N m^2 doubles), the inverted diagonal tiles to `dinv` (N T tiles).
 #include "common.h"
+#include "cr_map.h"
 
 #include <type_traits>
 
@@ -87,6 +88,11 @@ struct CrArgs {
   const uint8_t* nzY = nullptr;
   const uint8_t* nzT = nullptr;
   int nbs = 0, ntr = 0;
+  // storage of A (cr_map.h): dense (map.m == 0, the C-ABI test entries) or compact (gh_ba_solve)
+  CrMap map;
+  // base pointers with the shift of the block they address folded in: element (r, c) at ptr[c * lda + r], r / c GLOBAL
+  __device__ __forceinline__ double* blk(int I, int J) const { return A + map.shift(I, J); }
+  __device__ __forceinline__ double* brd() const { return A + map.bshift(); }
 };
 
 // compile-time loop: f(std::integral_constant<int, K>) for K = 0 .. N - 1 (a runtime loop around the potf2 code is not
@@ -161,7 +167,8 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
   const int i = a.first + (int)blockIdx.x * 2 * a.s;
   const int i0 = i * m_, n = a.n;
   const size_t lda = (size_t)a.lda;
-  double* const A = a.A;
+  double* const A = a.blk(i, i);      // (every tile of this kernel lies in the superblock's own diagonal block)
+  double* const Ab = a.brd();         // the right-hand-side row
   CR_STAMP(0);
   // neg[tile (ii, jj)][cbi]: -(A - sum) of the lower tiles, ii >= jj.  Tile (0, 0) is asked for alone and goes to LDS as
   // soon as it is there; the other tiles are asked for behind that and land while the first potf2 runs (one wait for all 48
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512) void cr_factor_kernel(CrArgs a) {
   const bool last = a.first == 0;
   double* const tvec = reinterpret_cast<double*>(cr_lds + kShBytes + 16 * 17 * sizeof(double)) + (size_t)(T - 1) * (NBI * XP);
   double* const yv = tvec + m_;
-  if (last && tid < m_) tvec[tid] = ld_guard(A, lda, a.rr, i0 + tid, a.rr + 1, n);
+  if (last && tid < m_) tvec[tid] = ld_guard(Ab, lda, a.rr, i0 + tid, a.rr + 1, n);
   for (int e = tid; e < NBI * LP; e += 512) sh.Ms[e] = 0.0;  // the inversion only ever writes the lower blocks
 #pragma unroll
   for (int cbi = 0; cbi < 2; ++cbi) {
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
   const int i = a.s == 0 ? 1 + e : a.first + e * 2 * a.s, i0 = i * m_, n = a.n;
   if (a.s == 0 && (i & (a.keep - 1)) == 0) return;  // a survivor of the dense top: never eliminated, no L_i
   const size_t lda = (size_t)a.lda;
-  const double* const A = a.A;
+  const double* const A = a.blk(i, i);  // L_i and M of the eliminated superblock
   // forward launches: tasks 0 .. 4T-1 side u, 4T .. 8T-1 side d, 8T the right-hand side, from 8T + 1 side 4 = a 16-row strip of
   // the BORDER rows a.n .. a.n + nbr - 1 of an arrowhead system (Y_i = E_i L_i^-T in place); inverse launches: 4T strips of
   // the identity (side 3)
@@ -427,6 +434,8 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
   if (side < 2 && (nb < 0 || nb >= a.N)) return;
   if (side == 4 && a.nzY != nullptr && a.nzY[i * a.nbs + strip] == 0) return;  // E_i is zero in these rows: Y_i = 0 is already there
   const int nb0 = nb * m_ + 16 * strip;  // first row of the strip (side u / d)
+  // the strip's source: B(i, u) (rows of i in the columns of u), B(d, i), the right-hand side / a border strip, or nothing (identity)
+  const double* const Ap = side == 0 ? a.blk(i, nb) : (side == 1 ? a.blk(nb, i) : ((side == 2 || side == 4) ? a.brd() : a.blk(0, 0)));
   CR_STAMP(16);
   // ---- the strip of P: asked for first (it is needed first), into registers; LDS behind the operand requests below
   constexpr int kStripIt = 16 * m_ / 256;
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
     const int j = side == 0 ? idx / m_ : (idx & 15), t = side == 0 ? idx - (idx / m_) * m_ : (idx >> 4);
     const int row = side == 0 ? i0 + t : (side == 1 ? nb0 + j : (side == 2 ? a.rr : (side == 4 ? n + 16 * strip + j : 0)));
     const int col = side == 0 ? nb0 + j : (side == 3 ? 0 : i0 + t);
-    const double v = ld_guard(A, lda, row, col, side == 2 ? a.rr + 1 : (side == 4 ? n + a.nbr : n), n);
+    const double v = ld_guard(Ap, lda, row, col, side == 2 ? a.rr + 1 : (side == 4 ? n + a.nbr : n), n);
     pv[it] = keep_if(v, side < 2 || (side == 2 && j == 0) || side == 4) + ((side == 3 && t == 16 * strip + j) ? 1.0 : 0.0);
   }
   // ---- operands of every product of this wave
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
 #pragma unroll
     for (int it = 0; it < 16 * m_ / 256; ++it) {
       const int idx = tid + 256 * it, j = idx & 15, t = idx >> 4;
-      if (i0 + t < n && 16 * strip + j < a.nbr) a.A[(size_t)(i0 + t) * lda + n + 16 * strip + j] = Xl[t * PW + j];
+      if (i0 + t < n && 16 * strip + j < a.nbr) a.brd()[(size_t)(i0 + t) * lda + n + 16 * strip + j] = Xl[t * PW + j];
     }
   } else if (side != 2) {
     double* Wo = (side == 3 ? a.W3 + (size_t)i * ((size_t)m_ * m_) : a.W + ((size_t)i * 2 + side) * ((size_t)m_ * m_)) + 16 * strip;
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
     }
   } else {
     for (int t = tid; t < m_; t += 256)
-      if (i0 + t < n) a.A[(size_t)(i0 + t) * lda + a.rr] = Xl[t * PW];
+      if (i0 + t < n) a.brd()[(size_t)(i0 + t) * lda + a.rr] = Xl[t * PW];
   }
   CR_STAMP(19);
 }
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
 #pragma unroll
       for (int k = 0; k < m_ / 16; ++k) {
         const int t = tg + 16 * k;
-        yv[k] = ld_guard(a.A, lda, a.rr, s0 + t, a.rr + 1, n);
+        yv[k] = ld_guard(a.brd(), lda, a.rr, s0 + t, a.rr + 1, n);
         wv[k] = Wp[(size_t)t * m_ + c];
       }
 #pragma unroll
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
 #pragma unroll
       for (int g = 0; g < 16; ++g) tot += red[g][tid];
       if (elim_task) a.yh[(size_t)i * m_ + c] = tot;
-      else if (j * m_ + c < n) a.A[(size_t)(j * m_ + c) * lda + a.rr] -= tot;
+      else if (j * m_ + c < n) a.brd()[(size_t)(j * m_ + c) * lda + a.rr] -= tot;
     }
     return;
   }
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
     row0 = row_blk * m_ + NBI * ta;
     col0 = j * m_ + NBI * tb;
     if (row0 >= n || col0 >= n) return;
-    out = a.A + (size_t)col0 * lda + row0;
+    out = a.blk(row_blk, j) + (size_t)col0 * lda + row0;  // D_j, or the fill block B(j + 2 s, j)
     ldo = lda;
   }
   if (diag && cb > rb) return;  // strictly upper block of a diagonal tile
@@ -786,14 +795,14 @@ __global__ __launch_bounds__(1024) void cr_back_last_kernel(CrArgs a) {
 #pragma unroll
       for (int kp = k + 1; kp < T; ++kp) {
         const int row = i0 + NBI * kp + lane, col = i0 + NBI * k + c;
-        lreg[kp * (kp - 1) / 2 + k][cj] = ld_guard(a.A, lda, row, col, n, n);
+        lreg[kp * (kp - 1) / 2 + k][cj] = ld_guard(a.blk(i, i), lda, row, col, n, n);
       }
     }
   }
   if (tid < m_) {
     xu[tid] = (has_u && u * m_ + tid < n) ? a.x[u * m_ + tid] : 0.0;
     xd[tid] = (has_d && d * m_ + tid < n) ? a.x[d * m_ + tid] : 0.0;
-    tv[tid] = i0 + tid < n ? a.A[(size_t)(i0 + tid) * lda + a.rr] : 0.0;
+    tv[tid] = i0 + tid < n ? a.brd()[(size_t)(i0 + tid) * lda + a.rr] : 0.0;
   }
   __syncthreads();
   if (has_u || has_d) {
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt
   const int j = grp * 2 * a.s, n = a.n;
   if (j >= a.N) return;
   const size_t lda = (size_t)a.lda, mm = (size_t)m_ * m_;
-  const double* const A = a.A;
+  const double* const A = a.brd();     // (border rows only)
   const int row_b = 64 * rt + 16 * w;  // border row of this wave's block
   const int col_b = 16 * cq;           // column within superblock j
   if (row_b >= a.nbr) return;
@@ -925,7 +934,7 @@ __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int col = j * m_ + col_b + q + 4 * rr;
-    if (col < n && r < a.nbr) a.A[(size_t)col * lda + n + r] -= acc0[rr] + acc1[rr];
+    if (col < n && r < a.nbr) a.brd()[(size_t)col * lda + n + r] -= acc0[rr] + acc1[rr];
   }
 }
 
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(256) void cr_border_syrk_kernel(CrArgs a, int kcols
   const int tb = tile - ta * (ta + 1) / 2;
   const int n = a.n, next = a.nbr + 1;
   const size_t lda = (size_t)a.lda;
-  const double* const A = a.A;
+  const double* const A = a.brd();  // (border rows only)
   const int k0 = chunk * kcols, k1 = k0 + kcols < n ? k0 + kcols : n;
   double4_t acc[2][2];
 #pragma unroll
@@ -1014,7 +1023,7 @@ __global__ __launch_bounds__(256) void cr_border_syrk_reduce_kernel(CrArgs a, in
     for (int u = 0; u < 8; ++u) sum += v[u];
   }
   for (; ch < nchunks; ++ch) sum += p[(size_t)ch * stride];
-  a.A[(size_t)(n + col) * lda + n + row] -= sum;
+  a.brd()[(size_t)(n + col) * lda + n + row] -= sum;
 }
 
 // The dense system that is left: the surviving superblocks 0, keep, 2 keep, ... (reduced, not factored; block tridiagonal among
@@ -1040,10 +1049,10 @@ __global__ void cr_border_gather_kernel(CrArgs a, int qb, double* __restrict__ M
   for (int r = c + (int)threadIdx.x; r <= qn; r += (int)blockDim.x) {
     double v = 0.0;
     if (r < qb) {
-      const int jr = r / m_;
-      if (jr - jc <= 1) v = a.A[src_col * lda + (size_t)jr * keep * m_ + (size_t)(r - jr * m_)];
+      const int jr = r / m_;  // (c < qb here: r >= c)
+      if (jr - jc <= 1) v = a.blk(jr * keep, jc * keep)[src_col * lda + (size_t)jr * keep * m_ + (size_t)(r - jr * m_)];  // D_j / B(j + keep, j)
     } else {
-      v = a.A[src_col * lda + (r < qn ? (size_t)(n + r - qb) : (size_t)a.rr)];
+      v = a.brd()[src_col * lda + (r < qn ? (size_t)(n + r - qb) : (size_t)a.rr)];
     }
     M[(size_t)c * ldq + r] = v;
   }
@@ -1072,7 +1081,7 @@ __global__ __launch_bounds__(256) void cr_border_back_kernel(CrArgs a, int qb, c
     return;
   }
   if (a.nbr == 0) return;
-  const double* col = a.A + (size_t)k * a.lda + n;
+  const double* col = a.brd() + (size_t)k * a.lda + n;
   double sum = 0.0;
   for (int r = lane; r < a.nbr; r += 64) sum = __builtin_fma(xq[qb + r], col[r], sum);
   sum = wave_sum63(sum);
@@ -1125,7 +1134,7 @@ inline TopShape top_shape(int n, int m, int top) {
 // nbr > 0: an arrowhead system (see above) -- A holds n + nbr unknowns, bws the border workspace (gh_arrow_ws_doubles).
 template <int T>
 gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, double* W, double* x, int* info_dev, int nbr = 0,
-                     double* bws = nullptr, bool allow_flow = true, const uint8_t* border_nz = nullptr) {
+                     double* bws = nullptr, bool allow_flow = true, const uint8_t* border_nz = nullptr, bool compact = false) {
   constexpr int m_ = NBI * T;
   const int N = gh_div_up(n, m_);
   const size_t mm = (size_t)m_ * m_;
@@ -1172,6 +1181,14 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
   const TopShape ts = top_shape(n, m_, (bws != nullptr) ? gh_cr_top(nbr) : 1);
   const int S = ts.S, nsv = ts.nsv;  // stride and number of the survivors
   a.keep = S;
+  if (compact) {  // (cr_map.h; lda = gh_cr_compact_lda of the same system)
+    int levels = 0;
+    while ((1 << levels) < S) ++levels;
+    a.map.m = m_;
+    a.map.n_band = n;
+    a.map.brow = (2 + levels) * m_;
+    if (lda < cr_compact_lda(m_, levels, nbr)) return gh_set_error(ctx, GH_ERR_ARG, "band solver: compact columns of %d rows, %d needed", lda, cr_compact_lda(m_, levels, nbr));
+  }
   for (int s = 1; s < S; s *= 2) {
     a.s = s;
     a.first = s;
@@ -1262,6 +1279,17 @@ int gh_cr_top_env() {
   return v;
 }
 int gh_cr_top(int nbr) { return gh_cr_top_env() ? gh_cr_top_env() : (nbr > 0 ? 4 : 2); }
+
+// Rows of a column of the COMPACT layout (cr_map.h) for this system as cr_solve_t will reduce it; *brow = local row of the first
+// border row / of the right-hand side when there is no border.  Only systems solved WITH the border workspace (dense top).
+int gh_cr_compact_lda(int n_band, int T, int nbr, int* brow) {
+  const int m = NBI * T;
+  const TopShape ts = top_shape(n_band, m, gh_cr_top(nbr));
+  int levels = 0;
+  while ((1 << levels) < ts.S) ++levels;
+  if (brow) *brow = (2 + levels) * m;
+  return cr_compact_lda(m, levels, nbr);
+}
 
 // border workspace of an arrowhead solve (doubles): the corner update's partial tiles, the dense system of superblock 0 + border
 // and what chol.hip's dense path needs for it, the backward pass's t vector
@@ -1359,12 +1387,12 @@ gh_status gh_cr_solve_dev_impl(gh_ctx* ctx, double* A, int n, int lda, int T, do
 // allow_flow = false: the dense top stays off chol.hip's single-launch kernels (the caller saw one of their bounded waits expire:
 // *info_dev > n_band + nbr).
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
-                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz) {
+                                  double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz, bool compact) {
   if (!info_ready) GH_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int), ctx->stream));
   switch (T) {
-    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz);
-    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz);
-    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz);
+    case 1: return cr_solve_t<1>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz, compact);
+    case 2: return cr_solve_t<2>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz, compact);
+    case 3: return cr_solve_t<3>(ctx, A, n_band, lda, dinv, W, x_dev, info_dev, nbr, bws, allow_flow, border_nz, compact);
     default: return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve: %d tiles per superblock", T);
   }
 }
@@ -1395,7 +1423,7 @@ extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int ld
   double* bws = W + nw;
   double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr, false));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1423,7 +1451,7 @@ extern "C" gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   double* bws = W + nw;
   double* x = bws + nbw;
   GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
-  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr));
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr, false));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
