@@ -175,6 +175,46 @@ def arrow_solve(ctx: hip.Context, A, b, n_band, half_bandwidth):
     return db.cpu().numpy(), info.value
 
 
+def compact_layout(n_band, half_bandwidth, nbr):
+    """gh_cr_compact_layout: (lda, m, brow) of the compact columns, or None when the band does not fit the band solver."""
+    lda, m, brow = C.c_int(), C.c_int(), C.c_int()
+    if not hip.lib.gh_cr_compact_layout(int(n_band), int(half_bandwidth), int(nbr), C.byref(lda), C.byref(m), C.byref(brow)):
+        return None
+    return lda.value, m.value, brow.value
+
+
+def to_compact(A, n_band, lda, m, brow):
+    """The lower triangle of the symmetric n x n matrix A in the compact layout (include/gslam_hip.h: gh_cr_compact_layout):
+    row c of the result = column c of the device matrix.  Elements outside the band / border must be zero in A."""
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    buf = np.zeros((n, lda))
+    for c in range(n):
+        if c < n_band:
+            J = c // m
+            r1 = min(n_band, (J + 2) * m)
+            buf[c, c - J * m:r1 - J * m] = A[c:r1, c]
+            assert not A[r1:n_band, c].any(), "a band element more than one superblock below its column"
+            buf[c, brow:brow + n - n_band] = A[n_band:, c]
+        else:
+            buf[c, brow + c - n_band:brow + n - n_band] = A[c:, c]
+    return buf
+
+
+def arrow_solve_compact(ctx: hip.Context, A, b, n_band, half_bandwidth):
+    """gh_arrow_solve_compact_dev: arrow_solve on the compact layout (n_band == n: a band).  Returns (x, info)."""
+    import torch
+    n = A.shape[0]
+    lda, m, brow = compact_layout(n_band, half_bandwidth, n - n_band)
+    dA = torch.from_numpy(to_compact(A, n_band, lda, m, brow)).cuda()
+    db = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).cuda()
+    info = C.c_int()
+    ctx.check(hip.lib.gh_arrow_solve_compact_dev(ctx.h, C.c_void_p(dA.data_ptr()), n, lda, int(n_band), int(half_bandwidth),
+                                                 C.c_void_p(db.data_ptr()), C.byref(info)))
+    ctx.sync()
+    return db.cpu().numpy(), info.value
+
+
 def marginalize(ctx: hip.Context, graph: dict, huber=0.01, min_shared=1):
     """gh_ba_marginalize (Optimizer::magin): the SE3 edges of the pose graph a bundle graph marginalises to.
     Returns (first, second, shared, info n x 6 x 6)."""

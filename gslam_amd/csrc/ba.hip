@@ -494,7 +494,9 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
     }
     col[r] = v;
   }
-  for (int s = 1; J + 2 * s < N; s *= 2) {
+  // (compact columns have a slot for the levels the reduction RUNS -- the dense top takes over at stride 2^levels; a fill block of
+  //  a level beyond that would land in the border rows and the right-hand side)
+  for (int s = 1; J + 2 * s < N && (map.m == 0 || 2 * s <= (1 << map.levels)); s *= 2) {
     if (J % (2 * s) != 0) break;  // (J survives level s only if it survived every level before)
     const int f0 = (J + 2 * s) * m, f1 = min(n, f0 + m);
     double* const colF = S + (size_t)c * lda + map.shift(J + 2 * s, J);
@@ -1883,6 +1885,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
         S.map.m = 64 * cr_T;
         S.map.n_band = n_band;
         S.map.brow = brow;
+        S.map.levels = brow / (64 * cr_T) - 2;
       }
     }
     S.lda = lda;

@@ -1187,6 +1187,7 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
     a.map.m = m_;
     a.map.n_band = n;
     a.map.brow = (2 + levels) * m_;
+    a.map.levels = levels;
     if (lda < cr_compact_lda(m_, levels, nbr)) return gh_set_error(ctx, GH_ERR_ARG, "band solver: compact columns of %d rows, %d needed", lda, cr_compact_lda(m_, levels, nbr));
   }
   for (int s = 1; s < S; s *= 2) {
@@ -1398,9 +1399,9 @@ gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, i
 }
 
 namespace {
-__global__ void cr_rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ A, int lda, int n) {
+__global__ void cr_rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ A, int lda, int row, int n) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n) A[(size_t)j * lda + n] = rhs[j];
+  if (j < n) A[(size_t)j * lda + row] = rhs[j];
 }
 }  // namespace
 
@@ -1422,7 +1423,7 @@ extern "C" gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int ld
   double* W = dinv + nd;
   double* bws = W + nw;
   double* x = bws + nbw;
-  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
+  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n, n);
   GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n, 0, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr, false));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1450,8 +1451,58 @@ extern "C" gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int l
   double* W = dinv + nd;
   double* bws = W + nw;
   double* x = bws + nbw;
-  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n);
+  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, n, n);
   GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr, false));
+  GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}
+
+// ---------------------------------------------------------------- the compact layout through the C ABI (tests, tools)
+// Layout of the compact columns (cr_map.h) gh_ba_solve keeps its reduced camera system in, for a system of n_band band unknowns of
+// `half_bandwidth` + nbr border unknowns: *lda = rows per column, *m = superblock columns, *brow = local row of the first border row
+// (the right-hand side is local row brow + nbr).  Element (r, c), r >= c, lives at c * lda + local(r, c):
+//   r >= n_band                  brow + (r - n_band)
+//   I - J <= 1 (I = r / m, J = c / m)   r - J m
+//   I - J = 2^k, k >= 1          (1 + k) m + (r - I m)       (fill of the reduction: zero on entry)
+// Returns 0 when the band does not fit the solver (gh_band_solve_dev's rule).
+extern "C" int gh_cr_compact_layout(int n_band, int half_bandwidth, int nbr, int* lda, int* m, int* brow) {
+  const int T = gh_cr_tiles(n_band, half_bandwidth);
+  if (T == 0 || nbr < 0) return 0;
+  int br = 0;
+  const int l = gh_cr_compact_lda(n_band, T, nbr, &br);
+  if (lda) *lda = l;
+  if (m) *m = NBI * T;
+  if (brow) *brow = br;
+  return 1;
+}
+
+// gh_arrow_solve_dev / gh_band_solve_dev (n_band == n) on a matrix in the compact layout: A_dev holds n columns of `lda` doubles
+// (gh_cr_compact_layout), right-hand side b_dev (n doubles, overwritten by x).  Test / tool entry.
+extern "C" gh_status gh_arrow_solve_compact_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth,
+                                                double* b_dev, int* info) {
+  if (!ctx) return GH_ERR_ARG;
+  GH_ENTER(ctx);
+  GH_CHECK_ARG(ctx, A_dev && b_dev && info && n > 0 && half_bandwidth >= 0 && n_band > 0 && n_band <= n);
+  const int T = gh_cr_tiles(n_band, half_bandwidth), nbr = n - n_band;
+  if (T == 0)
+    return gh_set_error(ctx, GH_ERR_ARG, "gh_arrow_solve_compact_dev: half-bandwidth %d of n_band = %d does not fit (<= %d, >= 4 superblocks)",
+                        half_bandwidth, n_band, 3 * NBI);
+  int brow = 0;
+  GH_CHECK_ARG(ctx, lda >= gh_cr_compact_lda(n_band, T, nbr, &brow));
+  void* scratch = nullptr;
+  const size_t nd = gh_cr_dinv_doubles(n_band, T), nw = gh_cr_panel_doubles(n_band, T), nbw = gh_arrow_ws_doubles(ctx, n_band, T, nbr);
+  std::lock_guard<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device));
+  GH_TRY(gh_scratch(ctx, 256 + (nd + nw + nbw + (size_t)n) * sizeof(double), &scratch));
+  int* info_dev = (int*)scratch;
+  double* dinv = (double*)((char*)scratch + 256);
+  double* W = dinv + nd;
+  double* bws = W + nw;
+  double* x = bws + nbw;
+  // the right-hand side into its row: local row brow + nbr of every column
+  GH_LAUNCH(ctx, "ba_rhs_row", cr_rhs_to_row_kernel, dim3(gh_div_up(n, 256)), dim3(256), 0, (const double*)b_dev, A_dev, lda, brow + nbr, n);
+  GH_TRY(gh_arrow_solve_dev_impl(ctx, A_dev, n_band, nbr, lda, T, dinv, W, bws, x, info_dev, false, true, nullptr, true));
   GH_HIP(ctx, hipMemcpyAsync(b_dev, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   GH_HIP(ctx, hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));

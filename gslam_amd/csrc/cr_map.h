@@ -20,6 +20,7 @@ struct CrMap {
   int m = 0;       // superblock columns (64 T); 0 = dense layout
   int n_band = 0;  // band unknowns: the border rows / the right-hand-side row start at this global row
   int brow = 0;    // compact: local row of global row n_band
+  int levels = 0;  // compact: fill slots = reduction levels (log2 of the survivors' stride: the dense top takes the rest)
 #if defined(__HIPCC__) || defined(__CUDACC__)
   __host__ __device__
 #endif

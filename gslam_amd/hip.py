@@ -193,6 +193,8 @@ SIGNATURES = {
     "gh_potrf_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, C.POINTER(_i)]),
     "gh_band_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i)]),
     "gh_arrow_solve_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i)]),
+    "gh_cr_compact_layout": (C.c_int, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "gh_arrow_solve_compact_dev": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i)]),
     "gh_cr_border_structure": (C.c_size_t, [_i, _i, _i, _vp, _vp, C.c_size_t]),
     "gh_bs_symbolic": (C.c_int, [_i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "gh_bs_solve_host": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp, C.POINTER(_i)]),

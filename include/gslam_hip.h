@@ -690,6 +690,20 @@ gh_status gh_band_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int half
  * factorisation.  Same limits on the band as gh_band_solve_dev; the result equals gh_potrf_solve_dev's up to rounding. */
 gh_status gh_arrow_solve_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth, double* b_dev,
                              int* info);
+/* The COMPACT storage gh_ba_solve keeps its reduced camera system in when the band / arrowhead solver runs (round 6): a column
+ * holds the rows block cyclic reduction ever touches -- 0.93 GB instead of the 28.8 GB of the dense lower triangle at C5.
+ * gh_cr_compact_layout: for n_band band unknowns of `half_bandwidth` and nbr border unknowns, *lda = doubles per column, *m =
+ * superblock columns, *brow = local row of the first border row.  Element (r, c), r >= c (plus the strictly upper part of a
+ * column's own 64 x 64 diagonal tile, which is never read as data), at A[c * lda + local(r, c)]:
+ *     r >= n_band                          brow + (r - n_band)        border rows; the right-hand side is local row brow + nbr
+ *     I - J <= 1  (I = r / m, J = c / m)    r - J * m                  the band
+ *     I - J = 2^k, k >= 1                   (1 + k) * m + (r - I * m)  the fill of the reduction: ZERO on entry
+ * Returns 0 when the band does not fit the solver (more than 192 wide or fewer than four superblocks).
+ * gh_arrow_solve_compact_dev: gh_arrow_solve_dev on such a matrix (n_band == n: a band without a border); A_dev is overwritten,
+ * b_dev (n doubles) receives x.  Test / tool entries: gh_ba_solve builds the layout itself. */
+int gh_cr_compact_layout(int n_band, int half_bandwidth, int nbr, int* lda, int* m, int* brow);
+gh_status gh_arrow_solve_compact_dev(gh_ctx* ctx, double* A_dev, int n, int lda, int n_band, int half_bandwidth, double* b_dev,
+                                     int* info);
 
 /* Structure of the border through the reduction (host only, no GPU; what gh_ba_solve computes once per topology when the
  * border block has 4 M entries or more, so that the border kernels of the arrowhead solver skip what stays zero).

@@ -304,6 +304,25 @@ def test_arrow_solve_vs_numpy(ctx, n_band, hb, nbr, fill):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_band,hb,nbr,fill", [(3000, 149, 90, 1.0), (3000, 149, 0, 1.0), (876, 149, 84, 0.3), (954, 149, 6, 1.0), (768, 192, 64, 1.0),
+                                                (1024, 64, 7, 1.0), (1000, 40, 0, 1.0), (777, 100, 130, 0.3), (1345, 128, 65, 1.0), (260, 17, 300, 1.0),
+                                                (6000, 149, 128, 0.02), (1620, 149, 180, 0.5), (590, 191, 33, 1.0)])
+def test_arrow_solve_compact_layout_vs_numpy(ctx, n_band, hb, nbr, fill):
+    """The compact columns gh_ba_solve keeps its reduced camera system in (cr_map.h; gh_cr_compact_layout): the same systems as
+    test_arrow_solve_vs_numpy, laid out compactly on the host, against numpy and against the dense-layout entry -- every tile count,
+    1 .. 5 reduction levels (one fill slot each), partial last superblocks, with and without a border."""
+    from gslam_amd import ba
+    S = make_arrow(n_band, hb, nbr, seed=n_band + hb + nbr, fill=fill) if nbr else make_band(n_band, hb, seed=n_band + hb)
+    b = np.random.default_rng(2).standard_normal(n_band + nbr)
+    x, info = ba.arrow_solve_compact(ctx, S, b, n_band, hb)
+    assert info == 0
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-12 * np.abs(xr).max()
+    xd, info_d = (ba.arrow_solve(ctx, S, b, n_band, hb) if nbr else ba.band_solve(ctx, S, b, hb))
+    assert info_d == 0 and np.array_equal(x, xd), "the two layouts run the same arithmetic"
+
+
+@pytest.mark.gpu
 def test_arrow_solve_border_around_the_single_launch_threshold(ctx):
     """the workspace was sized with the LARGEST dense-top system (top * m + nbr unknowns) while the solve asks
     for the single-launch factorisation's state with the ACTUAL one (fewer / partial survivors); the state size drops to 0 once a
