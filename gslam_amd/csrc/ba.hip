@@ -2277,8 +2277,9 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
 // The caller's problem in arrow order: cam_pose / cam_dof / obs_cam are re-indexed copies, everything else is shared.
 struct ArrowProblem {
   gh_ba_problem pr;
-  std::vector<double> pose;
-  std::vector<int32_t> dof, ocam;
+  std::vector<double>& pose;     // (the context's buffers: see common.h)
+  std::vector<int32_t>&dof, &ocam;
+  explicit ArrowProblem(gh_ctx* ctx) : pose(ctx->ba_order_pose), dof(ctx->ba_order_dof), ocam(ctx->ba_order_ocam) {}
   void build(const gh_ba_problem* src, const std::vector<int32_t>& perm) {
     pr = *src;
     const int nc = src->n_cams, no = src->n_obs;
@@ -2291,7 +2292,12 @@ struct ArrowProblem {
       dof[c] = src->cam_dof[perm[c]];
     }
     ocam.resize((size_t)no);
-    for (int k = 0; k < no; ++k) ocam[k] = inv[src->obs_cam[k]];
+    HostPool& pool = HostPool::get();
+    const int T = no >= (1 << 20) ? std::min(pool.size(), 8) : 1;
+    pool.run(T, [&](int t) {
+      const int k0 = (int)((long long)no * t / T), k1 = (int)((long long)no * (t + 1) / T);
+      for (int k = k0; k < k1; ++k) ocam[k] = inv[src->obs_cam[k]];
+    });
     pr.cam_pose = pose.data();
     pr.cam_dof = dof.data();
     pr.obs_cam = ocam.data();
@@ -2322,12 +2328,25 @@ extern "C" gh_status gh_ba_solve(gh_ctx* ctx, gh_ba_problem* pr, const gh_ba_opt
   BaSession S;
   S.db = new (std::nothrow) DevBuf(ctx);
   if (!S.db) return GH_ERR_NOMEM;
+  // (summary.total_ms covers the whole call: the solver's own camera ordering and the renumbered copy of the problem included)
+  const double t_call = now_ms();
+  gh_ba_summary local_sum;
+  if (!sum_out) sum_out = &local_sum;
   ba_choose_order(ctx, S, pr);
-  if (S.perm.empty()) return ba_run(ctx, S, pr, opt_in, sum_out, true);
-  ArrowProblem ap;
+  if (S.perm.empty()) {
+    const double t_order = now_ms() - t_call;
+    const gh_status st = ba_run(ctx, S, pr, opt_in, sum_out, true);
+    sum_out->total_ms += t_order;
+    return st;
+  }
+  ArrowProblem ap(ctx);
   ap.build(pr, S.perm);
+  const double t_order = now_ms() - t_call;
   const gh_status st = ba_run(ctx, S, &ap.pr, opt_in, sum_out, true);
+  const double t_back = now_ms();
   for (int c = 0; c < pr->n_cams; ++c) memcpy(pr->cam_pose + (size_t)S.perm[c] * 7, &ap.pose[(size_t)c * 7], 7 * sizeof(double));
+  sum_out->total_ms += t_order + (now_ms() - t_back);
+  if (getenv("GSLAM_HIP_BA_TIMING")) fprintf(stderr, "[gh_ba] camera order + renumbered problem: %.2f ms of the call\n", t_order);
   return st;
 }
 
@@ -2356,7 +2375,7 @@ extern "C" gh_status gh_ba_graph_create(gh_ctx* ctx, const gh_ba_problem* proble
   o.max_iterations = 0;  // set-up only: lists, tables, uploads, the initial cost
   gh_ba_summary sum;
   gh_ba_problem pr = *problem;
-  ArrowProblem ap;
+  ArrowProblem ap(ctx);
   ba_choose_order(ctx, g->S, &pr);
   if (!g->S.perm.empty()) {
     ap.build(problem, g->S.perm);

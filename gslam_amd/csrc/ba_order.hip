@@ -98,6 +98,12 @@ bool point_ranges(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32
     const int32_t* const oc = pr->obs_cam;
     const int32_t* const op = pr->obs_point;
     uint8_t is_bad = 0;
+    // A RUN of observations of one point (the usual order of an observation list) is folded in registers and written once: with the
+    // list grouped by point the branch below is taken every k-th time (predictable) and lo / hi see one update per point; with the
+    // list in random order every observation is its own run and the updates are the unconditional minimum / maximum -- no
+    // compare-and-branch on the camera position, which mispredicts every other time when the cameras are in random order (23 ms
+    // against 5 for C5's 6 M observations) and costs nothing but is slower when they are not (9 ms with unconditional stores).
+    int32_t cur = -1, cl = INT32_MAX, ch = -1;
     for (int k = 0; k < no; ++k) {
       const int32_t p = op[k];
       if (p < p0 || p >= p1) {
@@ -110,8 +116,21 @@ bool point_ranges(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32
         continue;
       }
       const int32_t c = pos ? pos[c0] : c0;
-      if (c < l[p]) l[p] = c;
-      if (c > h[p]) h[p] = c;
+      if (p != cur) {
+        if (cur >= 0) {
+          l[cur] = std::min(l[cur], cl);
+          h[cur] = std::max(h[cur], ch);
+        }
+        cur = p;
+        cl = ch = c;
+      } else {
+        cl = std::min(cl, c);
+        ch = std::max(ch, c);
+      }
+    }
+    if (cur >= 0) {
+      l[cur] = std::min(l[cur], cl);
+      h[cur] = std::max(h[cur], ch);
     }
     bad[t] = is_bad;
   });
@@ -212,10 +231,10 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
   // the graph has fewer (a power of two: the test is a mask, not a division, in a pass over every observation)
   constexpr int kSamplePerCam = 48;
   int sh = 0;
-  while (sh < 20 && ((long long)no >> (sh + 1)) >= (long long)kSamplePerCam * nc && ((long long)no >> (sh + 1)) >= (1 << 16)) ++sh;
+  while (sh < 20 && ((long long)no >> (sh + 1)) >= (long long)kSamplePerCam * nc && ((long long)no >> (sh + 1)) >= (1 << 14)) ++sh;
   const int32_t mask = (1 << sh) - 1;
   const int nsp = ((np - 1) >> sh) + 1;  // sampled point s = p >> sh for p & mask == 0
-  const int T = no >= (1 << 17) ? std::min(pool.size(), order_threads()) : 1;
+  const int T = no >= (1 << 20) ? std::min(pool.size(), order_threads()) : 1;  // (waking the pool costs ~0.3 ms: C4's 300 k observations stay serial)
   std::vector<std::vector<int32_t>> tp((size_t)T), tc((size_t)T);
   pool.run(T, [&](int t) {
     const int k0 = (int)((long long)no * t / T), k1 = (int)((long long)no * (t + 1) / T);
@@ -252,7 +271,7 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
   constexpr int kMaxObsPerPoint = 64;
   std::vector<int32_t> astart((size_t)nc + 1, 0), adj, wgt;
   {
-    const int TA = ns >= (1 << 15) ? std::min(pool.size(), order_threads()) : 1;
+    const int TA = ns >= (1 << 18) ? std::min(pool.size(), 2 * order_threads()) : 1;
     std::vector<std::vector<int32_t>> tadj((size_t)TA), twgt((size_t)TA);
     std::vector<int32_t> deg((size_t)nc, 0);
     pool.run(TA, [&](int t) {
@@ -304,8 +323,8 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
   // The START matters: from the middle of a trajectory the numbered set grows both ways and neighbours end up two window
   // widths apart.  The LAST camera of any such order is an end of the trajectory (the side that is exhausted last), and unlike
   // the last level of a breadth-first sweep it is found by following the strong edges -- a few loop-closure points shortcut
-  // breadth-first levels, they do not outweigh a camera's shared points with its neighbours.  So: order from the seed, restart
-  // from the last camera, restart once more from the last camera of that.
+  // breadth-first levels, they do not outweigh a camera's shared points with its neighbours.  So: order from the seed, then
+  // again from the last camera of that order.
   std::vector<uint8_t> numbered((size_t)nc, 0);
   std::vector<int32_t> key((size_t)nc, 0), comp;
   std::vector<std::vector<int32_t>> bucket;
@@ -340,9 +359,9 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
   for (int seed = 0; seed < nc; ++seed) {
     if (numbered[seed] || astart[(size_t)seed + 1] == astart[seed]) continue;  // (unobserved in the sample: appended at the end)
     int root = seed;
-    for (int sweep = 0; sweep < 3; ++sweep) {
+    for (int sweep = 0; sweep < 2; ++sweep) {
       max_adjacency(root, pass);
-      if (sweep == 2) break;
+      if (sweep == 1) break;
       root = pass.back();
       for (int32_t v : pass) {  // (un-number the component for the next sweep)
         numbered[v] = 0;
@@ -354,39 +373,63 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
   for (int c = 0; c < nc; ++c)
     if (!numbered[c]) order.push_back(c);  // cameras without a sampled observation (or without any): behind everything else
   lap("maximum-adjacency order");
-  // ---- barycentre refinement on the sample
+  // ---- barycentre refinement on the sample (points and cameras in parallel on the pool: each writes only its own entry)
   std::vector<double> cpos((size_t)nc), ppos((size_t)nsp);
   std::vector<int32_t> rank((size_t)nc);
   constexpr int kMaxSweeps = 8;  // (C4 shuffled, span 24 in trajectory order: 0 / 1 / 2 / 4 / 8 sweeps leave spans of 45 / 36 / 32 / 28 / 27)
+  const int TS = ns >= (1 << 18) ? std::min(pool.size(), 2 * order_threads()) : 1;
   std::vector<int32_t> before;
   for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
     before = order;
     for (int i = 0; i < nc; ++i) rank[order[i]] = i;
-    for (int s = 0; s < nsp; ++s) {
-      const int32_t q0 = pstart[s], q1 = pstart[(size_t)s + 1];
-      if (q0 == q1) continue;
-      int32_t lo = INT32_MAX, hi = -1;
-      double sum = 0.0;
-      for (int32_t q = q0; q < q1; ++q) {
-        const int32_t r = rank[plist[q]];
-        lo = std::min(lo, r);
-        hi = std::max(hi, r);
-        sum += r;
-      }
-      ppos[s] = hi - lo > 4 * kBandSpan ? -1.0 : sum / (q1 - q0);  // (a long-range point does not vote)
-    }
-    for (int c = 0; c < nc; ++c) {
-      double sum = 0.0;
-      int cnt = 0;
-      for (int32_t e = cstart[c]; e < cstart[(size_t)c + 1]; ++e)
-        if (ppos[clist[e]] >= 0.0) {
-          sum += ppos[clist[e]];
-          ++cnt;
+    pool.run(TS, [&](int t) {
+      const int s0 = (int)((long long)nsp * t / TS), s1 = (int)((long long)nsp * (t + 1) / TS);
+      for (int s = s0; s < s1; ++s) {
+        const int32_t q0 = pstart[s], q1 = pstart[(size_t)s + 1];
+        if (q0 == q1) continue;
+        int32_t lo = INT32_MAX, hi = -1;
+        double sum = 0.0;
+        for (int32_t q = q0; q < q1; ++q) {
+          const int32_t r = rank[plist[q]];
+          lo = std::min(lo, r);
+          hi = std::max(hi, r);
+          sum += r;
         }
-      cpos[c] = cnt ? sum / cnt : (double)rank[c];
-    }
+        ppos[s] = hi - lo > 4 * kBandSpan ? -1.0 : sum / (q1 - q0);  // (a long-range point does not vote)
+      }
+    });
+    pool.run(TS, [&](int t) {
+      const int c0 = (int)((long long)nc * t / TS), c1 = (int)((long long)nc * (t + 1) / TS);
+      for (int c = c0; c < c1; ++c) {
+        double sum = 0.0;
+        int cnt = 0;
+        for (int32_t e = cstart[c]; e < cstart[(size_t)c + 1]; ++e)
+          if (ppos[clist[e]] >= 0.0) {
+            sum += ppos[clist[e]];
+            ++cnt;
+          }
+        cpos[c] = cnt ? sum / cnt : (double)rank[c];
+      }
+    });
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cpos[a] < cpos[b]; });
     if (order == before) break;
+  }
+  // ---- orientation: a trajectory can be walked from either end.  The caller's observation list usually names a point's cameras in
+  // the caller's camera order; keep that direction (the set-up kernels that sort per-camera lists like their input nearly sorted:
+  // with the order reversed the first cost of a shuffled C5 took 20 ms instead of 0.1).  Vote of the sampled points: position of
+  // the last listed camera against the first.
+  {
+    for (int i = 0; i < nc; ++i) rank[order[i]] = i;
+    long long up = 0, down = 0;
+    for (int s = 0; s < nsp; ++s) {
+      const int32_t q0 = pstart[s], q1 = pstart[(size_t)s + 1];
+      if (q1 - q0 < 2) continue;
+      const int32_t d = rank[plist[q1 - 1]] - rank[plist[q0]];
+      up += d > 0;
+      down += d < 0;
+    }
+    const char* fe = getenv("GSLAM_HIP_BA_ORDER_FLIP");  // (experiments: the other direction)
+    if ((down > up) != (fe && fe[0] == '1')) std::reverse(order.begin(), order.end());
   }
   lap("barycentre sweeps");
   return true;

@@ -51,6 +51,10 @@ struct gh_ctx {
   int ba_last_band_tiles = 0, ba_last_cam_span = 0;
   int ba_last_border_cams = 0, ba_last_reordered = 0;  // cameras in the arrowhead border; 1 = the solver re-ordered the cameras (ba_order.hip)
   // band solver (chol_cr.hip): side stream for the work off its critical path, and the events that order the two
+  // renumbered copy of a problem's camera-indexed arrays (ba.hip: ArrowProblem), kept between solves: a fresh 24 MB vector per
+  // solve cost the upload path ~20 ms at C5 (first use of never-seen pageable memory by the copy engine's staging)
+  std::vector<double> ba_order_pose;
+  std::vector<int32_t> ba_order_dof, ba_order_ocam;
   hipStream_t cr_side = nullptr;
   std::vector<hipEvent_t> cr_events;
   // gh_ba_solve: marks the candidate cost's read-back (the host waits for it, not for the stream: see ba.hip)

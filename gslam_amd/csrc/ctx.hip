@@ -225,6 +225,9 @@ extern "C" gh_status gh_ctx_trim(gh_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   ctx->pinned = nullptr;
   ctx->pinned_bytes = 0;
+  std::vector<double>().swap(ctx->ba_order_pose);
+  std::vector<int32_t>().swap(ctx->ba_order_dof);
+  std::vector<int32_t>().swap(ctx->ba_order_ocam);
   if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
   ctx->ba_arena = nullptr;
   ctx->ba_arena_bytes = 0;
