@@ -1765,6 +1765,9 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   if (device_pairs) {
     for (int p = 0; p < np; ++p) pairs_ub += (size_t)(pstart[p + 1] - pstart[p]) * (size_t)(pstart[p + 1] - pstart[p]);
     blocks_ub = std::min(pairs_ub, (size_t)nc * ((size_t)nc + 1) / 2);
+    // (a camera shares points only with the cameras at most `span` positions before it -- and with the border cameras: without
+    //  this bound the segment tables of a 2 M-point graph reserved 24 GB for 0.5 M blocks)
+    blocks_ub = std::min(blocks_ub, (size_t)nc * ((size_t)S.cam_span + 1) + (size_t)S.n_border * (size_t)nc);
     if (pairs_ub > (size_t)1 << 30 || nc > kPairSortMaxCams) device_pairs = false;  // 32-bit offsets, LDS cursors
   }
   if (want_pairs && (!device_pairs || pairs_check))
@@ -1772,10 +1775,25 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   nblocks = (int)bci.size();
   t_lists = now_ms();
 
+  // the linear solver this session will use (the same rule again further down, where its buffers are carved): the arena is sized
+  // for the band solver's COMPACT columns + workspaces when that is the one, for the dense lower triangle otherwise
+  auto planned_tiles = [&]() {
+    int want = ctx->ba_solver;
+    if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
+    return want == 1 ? 0 : gh_cr_tiles(n_band, 6 * S.cam_span + 5);
+  };
   {
     const size_t N = (size_t)n, NP = (size_t)np, NO = (size_t)no, NC = (size_t)nc;
+    const int T_plan = planned_tiles();
+    size_t s_doubles = N * (N + 1) + 64;
+    if (T_plan) {
+      const char* de = getenv("GSLAM_HIP_BA_DENSE_S");
+      if (!(de && de[0] == '1')) s_doubles = N * (size_t)gh_cr_compact_lda(n_band, T_plan, n - n_band, nullptr);
+      s_doubles += gh_cr_dinv_doubles(n_band, T_plan) + gh_cr_panel_doubles(n_band, T_plan) +
+                   gh_arrow_ws_doubles(ctx, n_band, T_plan, n - n_band) + gh_cr_border_symbolic_bytes(n_band, T_plan, n - n_band) / 8 + 4 * 64;
+    }
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
-                             NP * 3 * 2 + N * (N + 1) + (N + 64) * 64 * 3 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
+                             NP * 3 * 2 + s_doubles + (N + 64) * 64 * 3 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
                         4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256 +
                         // device-built pair lists: 7 arrays of pairs_ub ints, block / segment tables, scan scratch
                         4 * (pairs_ub * 7 + blocks_ub * 5 + pairs_ub / kSchurSeg + NO + NO / 1024 + blocks_ub / 1024 + 2 * NC + 128) +
@@ -1872,7 +1890,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const int span = S.cam_span;  // (found with the argument check)
     int want = ctx->ba_solver;
     if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
-    cr_T = want == 1 ? 0 : gh_cr_tiles(n_band, 6 * span + 5);
+    (void)want;
+    cr_T = planned_tiles();
     d_cr_dinv = d_cr_W = S.d_arrow_ws = nullptr;
     S.map = CrMap{};
     if (cr_T) {

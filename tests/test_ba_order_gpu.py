@@ -89,7 +89,7 @@ def test_20k_cameras_2m_points_run_through_the_band_solver(ctx):
     free1, _ = torch.cuda.mem_get_info()
     ctx.trim()
     assert st == 0 and used[0] == "band" and used[1] == 3
-    assert free0 - free1 < 24 * (1 << 30), "the solver's arena holds %.1f GB" % ((free0 - free1) / 2 ** 30)
+    assert free0 - free1 < 32 * (1 << 30), "the solver's arena holds %.1f GB" % ((free0 - free1) / 2 ** 30)
     assert s.iterations == 4 and s.accepted >= 3 and s.final_cost < 0.7 * s.initial_cost
     # the same graph at a tenth of the size goes through the same code with n < 65536: the per-observation cost agrees roughly
     assert np.isfinite(poses).all() and np.isfinite(pts).all()
