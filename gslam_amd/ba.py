@@ -48,18 +48,22 @@ def solve(ctx: hip.Context, graph: dict, options=None):
     return poses, pts, s, st
 
 
-def camera_order(graph: dict):
+def camera_order(graph: dict, with_points=False):
     """gh_ba_camera_order (host only, no GPU): the camera order gh_ba_solve would use inside the solver.
-    Returns (perm [new position -> caller's camera], border cameras, camera span of the band part, reordered)."""
+    Returns (perm [new position -> caller's camera], border cameras, camera span of the band part, reordered)
+    [+ border points when with_points: the choice gh_ba_solve makes between a camera border and a point border]."""
     ocam = np.ascontiguousarray(graph["obs_cam"], dtype=np.int32)
     opt = np.ascontiguousarray(graph["obs_point"], dtype=np.int32)
     nc, npnt = len(graph["cam_dof"]), len(graph["point_xyz"])
     pr = hip.BaProblem(nc, npnt, len(ocam), None, None, None, None, _ptr(ocam), _ptr(opt), None, None)
     perm = np.zeros(nc, np.int32)
-    nb, span, re = C.c_int32(), C.c_int32(), C.c_int32()
-    st = hip.lib.gh_ba_camera_order(C.byref(pr), _ptr(perm), C.byref(nb), C.byref(span), C.byref(re))
+    nb, span, re, nbp = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    st = hip.lib.gh_ba_camera_order(C.byref(pr), _ptr(perm), C.byref(nb), C.byref(span), C.byref(re),
+                                    C.byref(nbp) if with_points else None)
     if st != 0:
         raise ValueError("gh_ba_camera_order: status %d" % st)
+    if with_points:
+        return perm, nb.value, span.value, bool(re.value), nbp.value
     return perm, nb.value, span.value, bool(re.value)
 
 

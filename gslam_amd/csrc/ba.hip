@@ -42,7 +42,8 @@ size_t gh_arrow_ws_doubles(const gh_ctx* ctx, int n_band, int T, int nbr);
 int gh_cr_compact_lda(int n_band, int T, int nbr, int* brow);
 gh_status gh_arrow_solve_dev_impl(gh_ctx* ctx, double* A, int n_band, int nbr, int lda, int T, double* dinv, double* W, double* bws,
                                   double* x_dev, int* info_dev, bool info_ready, bool allow_flow, const uint8_t* border_nz, bool compact);
-int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int* reordered, bool allow_reorder, int* band_span);  // ba_order.hip
+int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int* reordered, bool allow_reorder, int* band_span,
+                        std::vector<int32_t>* border_points);  // ba_order.hip
 size_t gh_cr_border_symbolic_bytes(int n_band, int T, int nbr);
 void gh_cr_border_symbolic(int n_band, int T, int nbr, const uint8_t* init, uint8_t* out);
 gh_status gh_csr_build_dev(gh_ctx* ctx, const int32_t* keys_host, int n_items, int n_keys, int32_t* start_host, int32_t* list_host);
@@ -453,12 +454,44 @@ __device__ __forceinline__ void schur_init_block(int n, int lda, const double* _
 // iteration instead of 14.4 GB.  One workgroup per column.
 // ARROWHEAD systems (nband < n: the last n - nband unknowns are the dense border of chol_cr.hip's arrowhead mode): a band column
 // also clears its border rows nband .. n - 1, a border column its whole lower part.
+// POINT BORDER of an arrowhead system (ba_order.hip: the long-range points make the smaller border): n_pts points stay out of the
+// Schur complement; their 3 n_pts unknowns follow the 6 nc camera unknowns.  pts[b] = point of border slot b, slot[p] = b or -1.
+struct PointBorder {
+  int n_pts = 0;
+  const int32_t* pts = nullptr;
+  const int32_t* slot = nullptr;
+  const double* Hpp = nullptr;  // 9 per point (undamped)
+  const double* gp = nullptr;   // 3 per point
+};
+
 __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, const double* __restrict__ Hcc,
                                                       const double* __restrict__ gc, double radius, double* __restrict__ S,
-                                                      double* __restrict__ rhs, int c, int nband, CrMap map) {
+                                                      double* __restrict__ rhs, int c, int nband, CrMap map, PointBorder pb) {
   // (map: cr_map.h -- dense columns of n + 1 rows, or compact columns that hold exactly the rows cleared here)
   const int cam = c / 6, b = c - 6 * cam;
   double* const colB = S + (size_t)c * lda + map.bshift();  // border rows and the right-hand-side row of this column
+  if (c >= nband && pb.n_pts > 0) {
+    // a column of a border POINT: its damped 3 x 3 block H_pp (what damp_points_block inverts for the other points) on the diagonal
+    // of the corner, zeros elsewhere, right-hand side - g_p
+    const int bslot = (c - nband) / 3, j = (c - nband) - 3 * bslot, p = pb.pts[bslot];
+    const int r_first = map.m ? nband : ((c >> 6) << 6);
+    for (int r = r_first + (int)threadIdx.x; r < n; r += 256) {
+      double v = 0.0;
+      if (r >= nband && (r - nband) / 3 == bslot) {
+        const int i = (r - nband) - 3 * bslot;
+        double h = pb.Hpp[(size_t)9 * p + 3 * i + j];
+        if (i == j) h += clampd(h, 1e-6, 1e32) / radius;
+        v = h;
+      }
+      (r >= nband ? colB : S + (size_t)c * lda)[r] = v;
+    }
+    if (threadIdx.x == 0) {
+      const double v = -pb.gp[(size_t)3 * p + j];
+      colB[n] = v;
+      rhs[c] = v;
+    }
+    return;
+  }
   if (c >= nband) {  // a border column: dense from its 64-row tile down (compact: its border rows)
     const int r_first = map.m ? nband : ((c >> 6) << 6);
     for (int r = r_first + (int)threadIdx.x; r < n; r += 256) {
@@ -512,10 +545,10 @@ __device__ __forceinline__ void schur_init_band_block(int n, int lda, int m, con
 __global__ __launch_bounds__(256) void schur_init_kernel(int n, int lda, const double* __restrict__ Hcc,
                                                          const double* __restrict__ gc, double radius,
                                                          double* __restrict__ S, double* __restrict__ rhs, int band_m, int nband,
-                                                         int gx, CrMap map) {
+                                                         int gx, CrMap map, PointBorder pb) {
   // a one-dimensional grid of gx workgroups per column (gridDim.y stops at 65535: the limit n < 65536 of rounds 1-5 was this launch)
   const int b = (int)blockIdx.x;
-  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband, map);  // (gx == 1)
+  if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband, map, pb);  // (gx == 1)
   else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
 }
 
@@ -539,11 +572,13 @@ __device__ __forceinline__ double* s_elem(double* __restrict__ S, int lda, const
 __global__ __launch_bounds__(256) void schur_atomic_kernel(Problem P, const double* __restrict__ Hpi,
                                                            const double* __restrict__ gp, double* __restrict__ S,
                                                            int n, double* __restrict__ rhs,
-                                                           const double* __restrict__ Wbuf, CrMap map) {
+                                                           const double* __restrict__ Wbuf, CrMap map,
+                                                           const int32_t* __restrict__ pbslot) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= P.no) return;
   const int k = P.plist[q];
   const int p = P.opt[k], ci = P.ocam[k];
+  if (pbslot != nullptr && pbslot[p] >= 0) return;  // (a border point stays out of the Schur complement)
   double Wi[18], WH[18];
   load_W(Wbuf, k, Wi);
   mul_WH(Wi, Hpi + (size_t)9 * p, WH);
@@ -682,12 +717,12 @@ __global__ __launch_bounds__(256) void schur_blocks_init_kernel(Problem P, Schur
                                                                 const double* __restrict__ Hcc,
                                                                 const double* __restrict__ gc, double radius,
                                                                 double* __restrict__ S, double* __restrict__ rhs, int gx,
-                                                                int band_m, int nband, CrMap map) {
+                                                                int band_m, int nband, CrMap map, PointBorder pb) {
   if (blockIdx.x < nsb) {
     schur_blocks_block(P, B, Hpi, gp, Wbuf, partial, blockIdx.x, nsb);
   } else {
     const int b = (int)(blockIdx.x - nsb);
-    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband, map);  // (gx == 1)
+    if (band_m) schur_init_band_block(n, lda, band_m, Hcc, gc, radius, S, rhs, b, nband, map, pb);  // (gx == 1)
     else schur_init_block(n, lda, Hcc, gc, radius, S, rhs, b % gx, b / gx);
   }
 }
@@ -724,10 +759,15 @@ constexpr int kPairSortMaxCams = 15360;  // one LDS cursor per partner camera (6
 __global__ __launch_bounds__(256) void pair_count_kernel(int no, const int32_t* __restrict__ clist,
                                                          const int32_t* __restrict__ ocam, const int32_t* __restrict__ opt,
                                                          const int32_t* __restrict__ pstart,
-                                                         const int32_t* __restrict__ plist, int32_t* __restrict__ cnt) {
+                                                         const int32_t* __restrict__ plist, int32_t* __restrict__ cnt,
+                                                         const int32_t* __restrict__ pbslot) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= no) return;
   const int k = clist[q], ci = ocam[k], p = opt[k];
+  if (pbslot != nullptr && pbslot[p] >= 0) {  // a border point stays out of the Schur complement: no pairs
+    cnt[q] = 0;
+    return;
+  }
   int c = 0;
   for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) c += ocam[plist[q2]] <= ci ? 1 : 0;
   cnt[q] = c;
@@ -783,10 +823,11 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(int no, const int32_t* _
                                                         const int32_t* __restrict__ pstart,
                                                         const int32_t* __restrict__ plist, const int32_t* __restrict__ goff,
                                                         int32_t* __restrict__ gen_k, int32_t* __restrict__ gen_k2,
-                                                        int32_t* __restrict__ gen_cj) {
+                                                        int32_t* __restrict__ gen_cj, const int32_t* __restrict__ pbslot) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= no) return;
   const int k = clist[q], ci = ocam[k], p = opt[k];
+  if (pbslot != nullptr && pbslot[p] >= 0) return;
   int o = goff[q];
   for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
     const int k2 = plist[q2], cj = ocam[k2];
@@ -968,6 +1009,21 @@ __global__ __launch_bounds__(256) void schur_reduce_kernel(SchurBlocks B, const 
   }
 }
 
+// E of a point border: for every observation k of border point p (slot b) by camera c, the 3 x 6 block W_k^T goes to rows
+// n_band + 3 b .. + 2, columns 6 c .. + 5 (W_k = J_c^T J_p, 6 x 3 row-major in Wbuf).  One workgroup per border point, thread
+// (a, j) walks the point's observations in list order (a camera that saw the point twice adds twice: fixed order, no atomics).
+__global__ __launch_bounds__(64) void border_points_kernel(Problem P, PointBorder pb, const double* __restrict__ Wbuf,
+                                                           double* __restrict__ S, int lda, int n_band, CrMap map) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b >= pb.n_pts || t >= 18) return;
+  const int a = t / 3, j = t - 3 * a, p = pb.pts[b];
+  for (int q = P.pstart[p]; q < P.pstart[p + 1]; ++q) {
+    const int k = P.plist[q], c = P.ocam[k];
+    double* dst = S + (size_t)(6 * c + a) * lda + (n_band + 3 * b + j) + map.bshift();
+    *dst += Wbuf[(size_t)18 * k + 3 * a + j];
+  }
+}
+
 // rhs -> row n of S (rides through the factorisation, becomes y = L^-1 rhs; the back-substitution reads it there)
 __global__ void rhs_to_row_kernel(const double* __restrict__ rhs, double* __restrict__ S, int lda, int n, CrMap map) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -982,7 +1038,8 @@ __global__ __launch_bounds__(256) void backsub_update_kernel(Problem P, const do
                                                              const double* __restrict__ Wbuf,
                                                              double* __restrict__ poses_new, double* __restrict__ pts_new,
                                                              int* __restrict__ bad, unsigned long long* __restrict__ gmax,
-                                                             unsigned long long* __restrict__ keep) {
+                                                             unsigned long long* __restrict__ keep,
+                                                             const int32_t* __restrict__ pbslot, int n_band) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {
     if (keep) {  // (what the iteration's publication sends to the host: see reduce_publish_kernel)
@@ -1015,9 +1072,11 @@ __global__ __launch_bounds__(256) void backsub_update_kernel(Problem P, const do
     }
   }
   const double* Hi = Hpi + (size_t)9 * p;
+  const int bslot = pbslot != nullptr ? pbslot[p] : -1;  // a border point: its step came out of the linear solve with the cameras'
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const double d = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+    double d = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+    if (bslot >= 0) d = dc[n_band + 3 * bslot + a];
     dp[3 * p + a] = d;
     pts_new[3 * p + a] = P.pts[3 * p + a] + d;
   }
@@ -1270,7 +1329,7 @@ struct PairChunk {
 // pcam[q] = camera of the observation plist[q] (the inner loop then reads two contiguous arrays)
 void build_pair_chunk(const gh_ba_problem* pr, int nc, int c_lo, int c_hi, const std::vector<int32_t>& pstart,
                       const std::vector<int32_t>& plist, const std::vector<int32_t>& pcam, const std::vector<int32_t>& cstart,
-                      const std::vector<int32_t>& clist, PairChunk& out) {
+                      const std::vector<int32_t>& clist, PairChunk& out, const int32_t* pbslot) {
   std::vector<int32_t> cnt((size_t)nc, 0), off((size_t)nc, 0), touched, tk, tk2, tc;
   size_t total = 0;
   for (int ci = c_lo; ci < c_hi; ++ci) total += (size_t)(cstart[ci + 1] - cstart[ci]);
@@ -1284,6 +1343,7 @@ void build_pair_chunk(const gh_ba_problem* pr, int nc, int c_lo, int c_hi, const
     tc.clear();
     for (int q = cstart[ci]; q < cstart[ci + 1]; ++q) {
       const int k = clist[q], p = pr->obs_point[k];
+      if (pbslot != nullptr && pbslot[p] >= 0) continue;  // (a border point: no pairs)
       for (int q2 = pstart[p]; q2 < pstart[p + 1]; ++q2) {
         const int cj = pcam[q2];
         if (cj > ci) continue;
@@ -1317,7 +1377,8 @@ void build_pair_chunk(const gh_ba_problem* pr, int nc, int c_lo, int c_hi, const
 void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_t>& pstart,
                        const std::vector<int32_t>& plist, const std::vector<int32_t>& cstart,
                        const std::vector<int32_t>& clist, std::vector<int32_t>& pair_a, std::vector<int32_t>& pair_b,
-                       std::vector<int32_t>& bstart, std::vector<int32_t>& bci, std::vector<int32_t>& bcj) {
+                       std::vector<int32_t>& bstart, std::vector<int32_t>& bci, std::vector<int32_t>& bcj,
+                       const int32_t* pbslot) {
   const int no = pr->n_obs;
   const bool timing = getenv("GSLAM_HIP_BA_TIMING") != nullptr;
   const double t0 = now_ms();
@@ -1335,7 +1396,7 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
     bound[t] = c;
   }
   const double t1 = now_ms();
-  pool.run(nchunk, [&](int t) { build_pair_chunk(pr, nc, bound[t], bound[t + 1], pstart, plist, pcam, cstart, clist, chunks[t]); });
+  pool.run(nchunk, [&](int t) { build_pair_chunk(pr, nc, bound[t], bound[t + 1], pstart, plist, pcam, cstart, clist, chunks[t], pbslot); });
   const double t2 = now_ms();
   std::vector<size_t> po((size_t)nchunk + 1, 0), bo((size_t)nchunk + 1, 0);
   for (int t = 0; t < nchunk; ++t) {
@@ -1373,7 +1434,7 @@ void build_schur_pairs(const gh_ba_problem* pr, int nc, const std::vector<int32_
 gh_status build_schur_pairs_device(gh_ctx* ctx, DevBuf& db, int nc, int no, size_t pairs_ub, size_t blocks_ub,
                                    const int32_t* d_ocam, const int32_t* d_opt, const int32_t* d_pstart,
                                    const int32_t* d_plist, const int32_t* d_cstart, const int32_t* d_clist,
-                                   SchurBlocks* SB, int32_t* counts_pinned) {
+                                   SchurBlocks* SB, int32_t* counts_pinned, const int32_t* d_pbslot) {
   const size_t segs_ub = pairs_ub / kSchurSeg + blocks_ub + 2;
   int32_t *d_goff, *d_sums, *d_gen_k, *d_gen_k2, *d_gen_cj, *d_pa, *d_pb, *d_tmp_start, *d_tmp_cj, *d_blk_off, *d_bs, *d_bci,
       *d_bcj, *d_seg_first, *d_seg_blk, *d_sums2, *d_counts;
@@ -1402,12 +1463,12 @@ gh_status build_schur_pairs_device(gh_ctx* ctx, DevBuf& db, int nc, int no, size
   const dim3 T(256);
   // pairs per observation (camera-major order), exclusive scan -> goff (no + 1 entries), total -> counts[0]
   GH_LAUNCH(ctx, "ba_pl_count", pair_count_kernel, dim3(gh_div_up(no, 256)), T, 0, no, d_clist, d_ocam, d_opt, d_pstart,
-            d_plist, d_goff);
+            d_plist, d_goff, d_pbslot);
   GH_LAUNCH(ctx, "ba_pl_scan", scan_chunks_kernel, dim3(chunks), T, 0, (const int32_t*)d_goff, no, d_goff, d_sums);
   GH_LAUNCH(ctx, "ba_pl_scan", scan_sums_kernel, dim3(1), T, 0, d_sums, chunks, d_counts + 0);
   GH_LAUNCH(ctx, "ba_pl_scan", scan_add_kernel, dim3(gh_div_up(no, 256)), T, 0, d_goff, no, (const int32_t*)d_sums, chunks);
   GH_LAUNCH(ctx, "ba_pl_emit", pair_emit_kernel, dim3(gh_div_up(no, 256)), T, 0, no, d_clist, d_ocam, d_opt, d_pstart,
-            d_plist, (const int32_t*)d_goff, d_gen_k, d_gen_k2, d_gen_cj);
+            d_plist, (const int32_t*)d_goff, d_gen_k, d_gen_k2, d_gen_cj, d_pbslot);
   static bool lds_attr[64] = {};
   const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
   if (!lds_attr[dev]) {
@@ -1465,6 +1526,10 @@ struct BaSession {
   // (empty = the caller's order); everything on the device is in the new order, the entry points translate.
   std::vector<int32_t> perm;
   int n_border = 0;  // cameras of the border
+  // POINT BORDER: the long-range points that stay out of the Schur complement (ba_order.hip chose them over their far cameras); their
+  // 3 unknowns each follow the cameras' in the reduced system.  Never together with a camera border.
+  std::vector<int32_t> border_pts;
+  int32_t *d_bpts = nullptr, *d_pbslot = nullptr;
   int span_measured = -1;  // >= 0: ba_order.hip has measured the camera span of the order in use (and checked every index): ba_run skips its pass
   int reordered = 0; // the bandwidth-reducing order of ba_order.hip was applied (perm is then non-empty even without a border)
   double* d_arrow_ws = nullptr;
@@ -1583,8 +1648,9 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   }
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
-  const int n = 6 * nc;
-  const int n_band = 6 * (nc - S.n_border);  // (== n unless the cameras are in arrow order)
+  const int n_bpts = (int)S.border_pts.size();  // (point border: never together with a camera border)
+  const int n = 6 * nc + 3 * n_bpts;
+  const int n_band = 6 * (nc - S.n_border);  // (== n unless the cameras are in arrow order / points form a border)
   // one extra row carries the right-hand side through the factorisation; columns start on 128-byte lines
   // (dense: n + 1 rows per column; band / arrowhead solver: compact columns, decided with the solver below -- cr_map.h)
   int lda = S.ready ? S.lda : (n + 1 + 15) & ~15;
@@ -1770,8 +1836,13 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     blocks_ub = std::min(blocks_ub, (size_t)nc * ((size_t)S.cam_span + 1) + (size_t)S.n_border * (size_t)nc);
     if (pairs_ub > (size_t)1 << 30 || nc > kPairSortMaxCams) device_pairs = false;  // 32-bit offsets, LDS cursors
   }
+  std::vector<int32_t> pbslot_host;  // point border: slot of every point (-1: an ordinary point, eliminated by the Schur complement)
+  if (n_bpts > 0) {
+    pbslot_host.assign((size_t)np, -1);
+    for (int b = 0; b < n_bpts; ++b) pbslot_host[S.border_pts[b]] = b;
+  }
   if (want_pairs && (!device_pairs || pairs_check))
-    build_schur_pairs(pr, nc, pstart, plist, cstart, clist, pair_a, pair_b, bstart, bci, bcj);
+    build_schur_pairs(pr, nc, pstart, plist, cstart, clist, pair_a, pair_b, bstart, bci, bcj, n_bpts > 0 ? pbslot_host.data() : nullptr);
   nblocks = (int)bci.size();
   t_lists = now_ms();
 
@@ -1795,6 +1866,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     const size_t need = 8 * (2 * NC * 7 + 2 * NP * 3 + NO * 2 + (pr->obs_info ? NO * 4 : 0) + NC * 36 + N * 3 + NP * 9 * 2 +
                              NP * 3 * 2 + s_doubles + (N + 64) * 64 * 3 + NO * 18 + (NO / 256 + 2) * 2 + 8) +
                         4 * (NC + NO * 4 + NP + NC + 4 + pair_a.size() * 2 + bstart.size() * 3) + NP + 64 * 256 +
+                        (n_bpts > 0 ? 4 * (NP + (size_t)n_bpts) + 1024 : 0) +
                         // device-built pair lists: 7 arrays of pairs_ub ints, block / segment tables, scan scratch
                         4 * (pairs_ub * 7 + blocks_ub * 5 + pairs_ub / kSchurSeg + NO + NO / 1024 + blocks_ub / 1024 + 2 * NC + 128) +
                         (device_pairs ? 26 * 256 : 0) +
@@ -1843,10 +1915,15 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   const double t_u2 = now_ms();
   SB = SchurBlocks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nblocks, nsegs};
   SB_host = SB;  // (check mode: the host-built tables beside the device-built ones)
+  S.d_pbslot = S.d_bpts = nullptr;
+  if (n_bpts > 0) {
+    GH_TRY(db.upload(&S.d_pbslot, (const int32_t*)pbslot_host.data(), pbslot_host.size()));
+    GH_TRY(db.upload(&S.d_bpts, (const int32_t*)S.border_pts.data(), S.border_pts.size()));
+  }
   if (device_pairs) {
     const double tq0 = now_ms();
     GH_TRY(build_schur_pairs_device(ctx, db, nc, no, pairs_ub, blocks_ub, d_ocam, d_opt, d_pstart, d_plist, d_cstart, d_clist,
-                                    &SB, rb->pair_counts));
+                                    &SB, rb->pair_counts, S.d_pbslot));
     if (getenv("GSLAM_HIP_BA_TIMING")) {
       const double tq1 = now_ms();
       GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1892,6 +1969,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
     if (const char* e = getenv("GSLAM_HIP_BA_SOLVER")) want = e[0] == 'd' ? 1 : (e[0] == 'b' ? 2 : 0);
     (void)want;
     cr_T = planned_tiles();
+    if (n_bpts > 0 && cr_T == 0)  // (ba_order.hip only proposes a point border to the band solver: the dense assembly has camera columns only)
+      return gh_set_error(ctx, GH_ERR_ARG, "gh_ba_solve: a point border without the band solver (internal)");
     d_cr_dinv = d_cr_W = S.d_arrow_ws = nullptr;
     S.map = CrMap{};
     if (cr_T) {
@@ -1975,6 +2054,12 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
 
   Problem P{nc, np, no, d_poses, d_dof, d_pts, d_pfree, d_ocam, d_opt, d_oxy, d_oinfo,
             d_pstart, d_plist, d_cstart, d_clist, opt.huber_delta};
+  PointBorder PB;
+  PB.n_pts = n_bpts;
+  PB.pts = S.d_bpts;
+  PB.slot = S.d_pbslot;
+  PB.Hpp = d_Hpp;
+  PB.gp = d_gp;
 
   auto eval_cost = [&](const double* poses_eval, const double* pts_eval, int with_model) -> gh_status {
     GH_LAUNCH(ctx, "ba_eval", eval_kernel, dim3(eval_blocks), dim3(256), 0, P, poses_eval, pts_eval, d_dc, d_dp,
@@ -2037,6 +2122,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
   ctx->ba_last_band_tiles = cr_T;
   ctx->ba_last_cam_span = S.cam_span;
   ctx->ba_last_border_cams = S.n_border;
+  ctx->ba_last_border_points = n_bpts;
   ctx->ba_last_reordered = S.reordered;
   double cost = h2[0];
   sum->initial_cost = cost;
@@ -2081,6 +2167,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_LAUNCH(ctx, "ba_damp_points", damp_points_kernel, dim3(gh_div_up(np, 256)), dim3(256), 0, np, d_Hpp, radius,
                 d_Hpi, d_bad);
     }
+    PB.Hpp = d_Hpp;  // (the linearisation's buffer sets swap when a speculative linearisation is adopted)
+    PB.gp = d_gp;
     const bool slim_init = d_flow != nullptr || cr_T != 0;  // both solvers read the lower tiles only
     const bool fused_seed = slim_init && no > 0 && opt.deterministic;  // then the seed rides with the segment sums below
     bool solve_state_ready = false;  // set when schur_reduce_kernel has cleared what the single-launch solve kernels need
@@ -2089,7 +2177,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       {
         const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);
         GH_LAUNCH(ctx, "ba_schur_diag", schur_init_kernel, dim3((unsigned)gx * (unsigned)n), dim3(256), 0, n, lda, d_Hcc,
-                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band, gx, S.map);
+                  d_gc, radius, d_S, d_dc, 64 * cr_T, n_band, gx, S.map, PB);
       }
     } else {
       int pend = gh_prof_begin(ctx, "ba_schur_zero");
@@ -2105,7 +2193,7 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
           const int gx = cr_T ? 1 : gh_div_up(n + 1, 2048);  // (the band solver's seed: one workgroup per column)
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_init_kernel, dim3(nsb + (unsigned)gx * (unsigned)n), dim3(256), 0, P,
                     SB, d_Hpi, d_gp, (const double*)d_W, d_spart, nsb, n, lda, (const double*)d_Hcc, (const double*)d_gc,
-                    radius, d_S, d_dc, gx, 64 * cr_T, n_band, S.map);
+                    radius, d_S, d_dc, gx, 64 * cr_T, n_band, S.map, PB);
         } else {
           GH_LAUNCH(ctx, "ba_schur_blocks", schur_blocks_kernel, dim3(nsb), dim3(256), 0, P, SB, d_Hpi, d_gp,
                     (const double*)d_W, d_spart);
@@ -2128,9 +2216,12 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
         }
       } else {
         GH_LAUNCH(ctx, "ba_schur_atomic", schur_atomic_kernel, dim3(gh_div_up(no, 256)), dim3(256), 0, P, d_Hpi, d_gp,
-                  d_S, lda, d_dc, (const double*)d_W, S.map);
+                  d_S, lda, d_dc, (const double*)d_W, S.map, (const int32_t*)S.d_pbslot);
       }
     }
+    if (n_bpts > 0)  // E of the point border: W^T of the border points' observations into the border rows of their cameras' columns
+      GH_LAUNCH(ctx, "ba_border_points", border_points_kernel, dim3(n_bpts), dim3(64), 0, P, PB, (const double*)d_W, d_S, lda, n_band,
+                S.map);
     const double t_solve0 = now_ms();
     // (one single-launch factorisation at a time per process, until this iteration's synchronisation: see chol.hip)
     std::unique_lock<std::mutex> flow_lock(gh_potrf_flow_mutex(ctx->device), std::defer_lock);
@@ -2154,7 +2245,8 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
       GH_HIP(ctx, hipMemcpyAsync(&rb->bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
     GH_LAUNCH(ctx, "ba_backsub", backsub_update_kernel, dim3(gh_div_up(nc > np ? nc : np, 256)), dim3(256), 0, P, d_Hpi,
-              d_gp, d_dc, d_dp, (const double*)d_W, d_poses_new, d_pts_new, d_bad, d_gmax, publish ? S.d_keep : nullptr);
+              d_gp, d_dc, d_dp, (const double*)d_W, d_poses_new, d_pts_new, d_bad, d_gmax, publish ? S.d_keep : nullptr,
+              (const int32_t*)S.d_pbslot, n_band);
     bool spec_launched = false;
     if (publish) {
       const unsigned want = ++stamp;
@@ -2333,10 +2425,12 @@ void ba_choose_order(const gh_ctx* ctx, BaSession& S, const gh_ba_problem* pr) {
   if (!(pr->n_cams > 0 && pr->cam_pose && pr->cam_dof && pr->obs_cam && pr->obs_point && ba_arrow_wanted(ctx))) return;
   const char* e = getenv("GSLAM_HIP_BA_REORDER");  // "0": the caller's camera order as it is (rounds 4-5; A/B measurements)
   const double t0 = now_ms();
-  S.n_border = gh_ba_order_cameras(pr, S.perm, &S.reordered, !(e && e[0] == '0'), &S.span_measured);
+  S.n_border = gh_ba_order_cameras(pr, S.perm, &S.reordered, !(e && e[0] == '0'), &S.span_measured, &S.border_pts);
   if (getenv("GSLAM_HIP_BA_TIMING"))
     fprintf(stderr, "[gh_ba] camera order: %.2f ms (%s, %d border cameras)\n", now_ms() - t0,
             S.reordered ? "bandwidth-reducing order applied" : (S.perm.empty() ? "caller's order" : "arrow order"), S.n_border);
+  if (getenv("GSLAM_HIP_BA_TIMING") && !S.border_pts.empty())
+    fprintf(stderr, "[gh_ba] border: %zu long-range points stay out of the Schur complement\n", S.border_pts.size());
 }
 
 }  // namespace

@@ -42,6 +42,7 @@
 
 constexpr int kBandSpan = 31;         // gh_cr_tiles: 6 * 31 + 5 = 191 <= 3 * 64
 constexpr int kMaxBorderCams = 1024;  // 6144 border rows: beyond that the dense corner dominates
+constexpr int kMaxBorderPts = 2048;   // the same 6144 rows when the border is made of POINTS (3 unknowns each)
 
 namespace {
 
@@ -150,9 +151,13 @@ bool point_ranges(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32
 // Returns the number of border cameras (0: leave the order -- already a band, too many border cameras, or too few band cameras)
 // and perm[new] = POSITION (in that order); *span_out = the largest distance, in positions, between two BAND observers of one
 // point in the order that results (-1: not measured -- a bad index).
-int arrow_order(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32_t>& perm, int* span_out) {
+int arrow_order(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32_t>& perm, int* span_out,
+                std::vector<int32_t>* long_points = nullptr, int* span_short_out = nullptr) {
+  // long_points (optional): the points whose observers lie more than kBandSpan positions apart (at most kMaxBorderPts + 1 are listed);
+  // *span_short_out: the largest distance among the OTHER points -- the band's span when the long-range points stay out of it
   perm.clear();
   *span_out = -1;
+  if (long_points) long_points->clear();
   const int nc = pr->n_cams, np = pr->n_points, no = pr->n_obs;
   if (np <= 0 || no <= 0) return 0;
   std::vector<int32_t> lo, hi;
@@ -164,10 +169,15 @@ int arrow_order(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32_t
     if (hi[p] < 0) continue;
     const int d = hi[p] - lo[p];
     span = std::max(span, d);
-    if (d > kBandSpan) slot[p] = nlong++;
-    else span_short = std::max(span_short, d);
+    if (d > kBandSpan) {
+      slot[p] = nlong++;
+      if (long_points && (int)long_points->size() <= kMaxBorderPts) long_points->push_back(p);
+    } else {
+      span_short = std::max(span_short, d);
+    }
   }
   *span_out = span;
+  if (span_short_out) *span_short_out = span_short;
   if (nlong == 0 || nc < 4 * 32 + 1) return 0;
   // (a graph that is nowhere near a band has a long-range point for every few points; each of them puts at least one camera into
   //  the border: give up before building their lists)
@@ -209,7 +219,6 @@ int arrow_order(const gh_ba_problem* pr, const int32_t* pos, std::vector<int32_t
   // (the band part's span after the compact renumbering: at most kBandSpan by construction, at least what the short points have;
   //  ba_run measures it exactly on the renumbered graph)
   *span_out = -1;
-  (void)span_short;
   return nb;
 }
 
@@ -439,18 +448,41 @@ bool covis_order(const gh_ba_problem* pr, std::vector<int32_t>& order) {
 
 // perm[new] = old camera (empty: the caller's order stands), returns the number of border cameras at the end of the order.
 // *reordered (may be null): 1 when the bandwidth-reducing order was applied.  `allow_reorder` = false: rounds 4-5 (A/B runs).
-int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int* reordered, bool allow_reorder, int* band_span) {
-  // *band_span (may be null): the camera span of the order that results when this function has measured it (no border), else -1
+// The border of an arrowhead system can be made of the far CAMERAS of the long-range points (6 unknowns each; the cameras move to
+// the end of the order) or of the long-range POINTS themselves (3 unknowns each: they are kept OUT of the Schur complement and
+// solved for together with the cameras; no camera moves).  A revisit seen by a handful of cameras through hundreds of points wants
+// the first, a handful of points seen from many far cameras the second: the smaller border wins.
+static bool points_make_the_smaller_border(int nb_cams, const std::vector<int32_t>& long_pts, int nc) {
+  const int np_b = (int)long_pts.size();
+  if (np_b == 0 || np_b > kMaxBorderPts || nc < 4 * 32 + 1) return false;
+  const char* e = getenv("GSLAM_HIP_BA_POINT_BORDER");  // "0": never (rounds 5's camera border, A/B); "1": whenever it is possible
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return nb_cams == 0 || 3 * np_b < 6 * nb_cams;
+}
+
+int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int* reordered, bool allow_reorder, int* band_span,
+                        std::vector<int32_t>* border_points) {
+  // *band_span (may be null): the camera span of the order that results when this function has measured it (no camera border), else -1
+  // *border_points (may be null = never): filled when the long-range POINTS form the border (the return value is then 0)
   perm.clear();
   if (reordered) *reordered = 0;
   if (band_span) *band_span = -1;
+  if (border_points) border_points->clear();
   const int nc = pr->n_cams;
   if (pr->n_points <= 0 || pr->n_obs <= 0) return 0;
-  int span0 = -1, span1 = -1;
+  int span0 = -1, span1 = -1, short0 = -1, short1 = -1;
+  std::vector<int32_t> long0, long1;
   const bool timing = getenv("GSLAM_HIP_BA_TIMING") != nullptr;
   const double t0 = timing ? now_ms() : 0.0;
-  int nb = arrow_order(pr, nullptr, perm, &span0);  // (the caller's order: a band, or a band + border)
-  if (timing) fprintf(stderr, "[gh_ba order] caller's order: span %d, %d border cameras, %.2f ms\n", span0, nb, now_ms() - t0);
+  int nb = arrow_order(pr, nullptr, perm, &span0, border_points ? &long0 : nullptr, &short0);  // (the caller's order: a band, or a band + border)
+  if (timing) fprintf(stderr, "[gh_ba order] caller's order: span %d, %d border cameras, %zu long-range points, %.2f ms\n", span0, nb, long0.size(), now_ms() - t0);
+  if (border_points && points_make_the_smaller_border(nb, long0, nc)) {
+    perm.clear();
+    border_points->swap(long0);
+    if (band_span) *band_span = short0;
+    return 0;
+  }
   if (nb > 0) return nb;
   if (band_span) *band_span = span0;
   if (!allow_reorder || nc < 4 * 32 + 1) return 0;  // (fewer than four superblocks: dense anyway)
@@ -461,8 +493,15 @@ int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int
   for (int i = 0; i < nc; ++i) pos[order[i]] = i;
   std::vector<int32_t> aperm;
   const double t1 = timing ? now_ms() : 0.0;
-  nb = arrow_order(pr, pos.data(), aperm, &span1);
-  if (timing) fprintf(stderr, "[gh_ba order] new order: span %d, %d border cameras, %.2f ms\n", span1, nb, now_ms() - t1);
+  nb = arrow_order(pr, pos.data(), aperm, &span1, border_points ? &long1 : nullptr, &short1);
+  if (timing) fprintf(stderr, "[gh_ba order] new order: span %d, %d border cameras, %zu long-range points, %.2f ms\n", span1, nb, long1.size(), now_ms() - t1);
+  if (border_points && points_make_the_smaller_border(nb, long1, nc)) {
+    perm.swap(order);
+    border_points->swap(long1);
+    if (reordered) *reordered = 1;
+    if (band_span) *band_span = short1;
+    return 0;
+  }
   if (nb > 0) {
     perm.resize((size_t)nc);
     for (int i = 0; i < nc; ++i) perm[i] = order[aperm[i]];
@@ -481,30 +520,35 @@ int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int
 /* Host-only face of the above for tests and tools (no GPU needed): perm_out[n_cams] = old camera of every new position (the
  * identity when the caller's order stands); *n_border = cameras of the dense border at the end of the order; *cam_span = largest
  * distance in NEW positions between two band observers of one point (border cameras left out); *reordered = 1 when the
- * bandwidth-reducing order was applied.  Returns GH_OK, or GH_ERR_ARG for null pointers / indices out of range. */
+ * bandwidth-reducing order was applied; *n_border_points (NULL = report the camera-border choice only) = long-range points kept
+ * out of the Schur complement as the border instead of cameras (then *n_border = 0 and *cam_span leaves those points out).
+ * Returns GH_OK, or GH_ERR_ARG for null pointers / indices out of range. */
 extern "C" gh_status gh_ba_camera_order(const gh_ba_problem* pr, int32_t* perm_out, int32_t* n_border, int32_t* cam_span,
-                                        int32_t* reordered) {
+                                        int32_t* reordered, int32_t* n_border_points) {
   if (!pr || !perm_out || pr->n_cams < 1 || (pr->n_obs > 0 && (!pr->obs_cam || !pr->obs_point))) return GH_ERR_ARG;
   const int nc = pr->n_cams;
   for (int k = 0; k < pr->n_obs; ++k)
     if (pr->obs_cam[k] < 0 || pr->obs_cam[k] >= nc || pr->obs_point[k] < 0 || pr->obs_point[k] >= pr->n_points) return GH_ERR_ARG;
-  std::vector<int32_t> perm;
+  std::vector<int32_t> perm, bpts;
   int re = 0;
-  const int nb = gh_ba_order_cameras(pr, perm, &re, true, nullptr);
+  const int nb = gh_ba_order_cameras(pr, perm, &re, true, nullptr, n_border_points ? &bpts : nullptr);
   if (perm.empty())
     for (int c = 0; c < nc; ++c) perm_out[c] = c;
   else
     memcpy(perm_out, perm.data(), (size_t)nc * sizeof(int32_t));
   if (n_border) *n_border = nb;
   if (reordered) *reordered = re;
+  if (n_border_points) *n_border_points = (int32_t)bpts.size();
   if (cam_span) {
     std::vector<int32_t> pos((size_t)nc);
     for (int i = 0; i < nc; ++i) pos[perm_out[i]] = i;
     const int nband = nc - nb;
+    std::vector<uint8_t> skip((size_t)std::max(pr->n_points, 1), 0);
+    for (int32_t p : bpts) skip[p] = 1;
     std::vector<int32_t> lo((size_t)std::max(pr->n_points, 1), INT32_MAX), hi((size_t)std::max(pr->n_points, 1), -1);
     for (int k = 0; k < pr->n_obs; ++k) {
       const int32_t c = pos[pr->obs_cam[k]], p = pr->obs_point[k];
-      if (c >= nband) continue;
+      if (c >= nband || skip[p]) continue;
       lo[p] = std::min(lo[p], c);
       hi[p] = std::max(hi[p], c);
     }

@@ -49,6 +49,7 @@ struct gh_ctx {
   int ba_solver = 0;
   int ba_last_solver = 0;  // what the last gh_ba_solve / gh_ba_graph_solve used: 1 dense, 2 band (T tiles in ba_last_band_tiles)
   int ba_last_band_tiles = 0, ba_last_cam_span = 0;
+  int ba_last_border_points = 0;  // long-range points kept out of the Schur complement as the arrowhead border
   int ba_last_border_cams = 0, ba_last_reordered = 0;  // cameras in the arrowhead border; 1 = the solver re-ordered the cameras (ba_order.hip)
   // band solver (chol_cr.hip): side stream for the work off its critical path, and the events that order the two
   // renumbered copy of a problem's camera-indexed arrays (ba.hip: ArrowProblem), kept between solves: a fresh 24 MB vector per

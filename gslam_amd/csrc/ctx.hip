@@ -83,6 +83,12 @@ extern "C" int gh_ctx_last_ba_order(gh_ctx* ctx, int* border_cams, int* reordere
   return ctx->ba_last_solver != 0;
 }
 
+extern "C" int gh_ctx_last_ba_border_points(gh_ctx* ctx) {
+  if (!ctx) return 0;
+  GH_ENTER(ctx);
+  return ctx->ba_last_border_points;
+}
+
 extern "C" gh_status gh_ctx_set_stream(gh_ctx* ctx, void* hip_stream) {
   if (!ctx) return GH_ERR_ARG;
   GH_ENTER(ctx);

@@ -109,7 +109,8 @@ SIGNATURES = {
     "gh_ctx_set_ba_solver": (C.c_int, [_vp, _i]),
     "gh_ctx_last_ba_solver": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "gh_ctx_last_ba_order": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
-    "gh_ba_camera_order": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gh_ba_camera_order": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gh_ctx_last_ba_border_points": (C.c_int, [_vp]),
     "gh_prof_enable": (C.c_int, [_vp, _i]),
     "gh_prof_collect": (C.c_int, [_vp, C.POINTER(ProfEntry), _i, C.POINTER(_i)]),
     "gh_bf_match_dev": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -296,6 +297,10 @@ class Context:
         b, r = C.c_int(), C.c_int()
         lib.gh_ctx_last_ba_order(self.h, C.byref(b), C.byref(r))
         return b.value, bool(r.value)
+
+    def last_ba_border_points(self):
+        """long-range points that formed the arrowhead border of the last BA solve (0: camera border or none)"""
+        return int(lib.gh_ctx_last_ba_border_points(self.h))
 
     def prof_enable(self, on=True):
         self.check(lib.gh_prof_enable(self.h, 1 if on else 0))

@@ -85,6 +85,7 @@ int gh_ctx_last_ba_solver(gh_ctx* ctx, int* band_tiles, int* cam_span);
  * *reordered = 1 when the solver replaced the caller's camera order by its own bandwidth-reducing order (gh_ba_camera_order).
  * Returns 1 after a solve, 0 before the first.  Either pointer may be NULL. */
 int gh_ctx_last_ba_order(gh_ctx* ctx, int* border_cams, int* reordered);
+int gh_ctx_last_ba_border_points(gh_ctx* ctx); /* long-range points in the border of that solve (0: a camera border or none) */
 gh_status gh_ctx_use_own_stream(gh_ctx* ctx);
 void* gh_ctx_stream(gh_ctx* ctx);
 gh_status gh_ctx_sync(gh_ctx* ctx);
@@ -574,11 +575,14 @@ gh_status gh_ba_pnp(gh_ctx* ctx, const double* points_xyz, const double* obs_xy,
  * perm_out[n_cams]: old camera of every new position (the identity when the caller's order stands); *n_border: cameras of the dense
  * border at the end of the order; *cam_span: largest distance in new positions between two band observers of one point (the solver
  * takes the band / arrowhead path when 6 * span + 5 <= 192 and at least four superblocks remain); *reordered: 1 when the
- * bandwidth-reducing order was applied.  problem: only n_cams, n_points, n_obs, obs_cam, obs_point are read.
+ * bandwidth-reducing order was applied.  *n_border_points (NULL: the camera-border choice only): when the long-range POINTS make
+ * the smaller border (3 unknowns each against 6 per far camera) they are kept out of the Schur complement and solved for together
+ * with the cameras -- then *n_border = 0, no camera moves for them, and *cam_span leaves them out.
+ * problem: only n_cams, n_points, n_obs, obs_cam, obs_point are read.
  * GH_ERR_ARG for null pointers or indices out of range.  The environment variable GSLAM_HIP_BA_REORDER=0 keeps gh_ba_solve on the
  * caller's order (A/B measurements); this function always reports the order the default would choose. */
 gh_status gh_ba_camera_order(const gh_ba_problem* problem, int32_t* perm_out, int32_t* n_border, int32_t* cam_span,
-                             int32_t* reordered);
+                             int32_t* reordered, int32_t* n_border_points);
 
 gh_status gh_ba_marginalize(gh_ctx* ctx, const gh_ba_problem* problem, double huber_delta, int32_t min_shared,
                             int32_t max_edges, int32_t* edge_first, int32_t* edge_second, int32_t* edge_shared,

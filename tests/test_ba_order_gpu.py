@@ -33,14 +33,21 @@ def test_shuffled_c4_takes_the_band_solver_with_the_same_lm_run(ctx, seed):
     assert np.abs(p1[new_of_old] - p0).max() <= 1e-8 and np.abs(x1 - x0).max() <= 1e-8
 
 
+@pytest.mark.parametrize("border", ["cameras", "points"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_shuffled_c4_with_loop_closures_takes_the_arrow_solver_with_the_same_lm_run(ctx, seed):
+def test_shuffled_c4_with_loop_closures_takes_the_arrow_solver_with_the_same_lm_run(ctx, monkeypatch, seed, border):
+    """both kinds of border (GSLAM_HIP_BA_POINT_BORDER: 0 = the far cameras of the long-range points, 1 = those points themselves)"""
+    monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "1" if border == "points" else "0")
     g = make_graph(500, 50000, n_obs_per_point=6, seed=seed, loop_closures=20)
     p0, x0, s0, used0, ord0 = _solve(ctx, g)
-    assert used0[0] == "arrow" and not ord0[1] and ord0[0] > 0
+    assert used0[0] == "arrow" and not ord0[1]
     h, new_of_old = _shuffle(g, seed)
     p1, x1, s1, used1, ord1 = _solve(ctx, h)
-    assert used1[0] == "arrow" and used1[2] <= 31 and ord1[1] and 0 < ord1[0] <= 2 * ord0[0] + 8
+    assert used1[0] == "arrow" and used1[2] <= 31 and ord1[1]
+    if border == "points":
+        assert ord0[0] == 0 and ord1[0] == 0 and ctx.last_ba_border_points() == 20
+    else:
+        assert ctx.last_ba_border_points() == 0 and 0 < ord1[0] <= 2 * ord0[0] + 8
     assert_identical_trace(s1, s0, rtol=1e-9)
     assert np.abs(p1[new_of_old] - p0).max() <= 1e-8 and np.abs(x1 - x0).max() <= 1e-8
 

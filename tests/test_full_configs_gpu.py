@@ -105,24 +105,34 @@ def test_c5_tenth_scale_parity(ctx, oracle):
 # camera order with a dense factorisation; the GPU renumbers the far observers of the closure points to the border, solves, and
 # hands the poses back in the caller's order (ba.hip: ba_arrow_order / ArrowProblem).  Same bars as the band graphs: identical
 # accept / reject sequence, cost 1e-9, state 1e-8.  (GSLAM/core/Optimizer.h:127-148,229.)
+@pytest.mark.parametrize("border", ["cameras", "points", "auto"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_c4_loop_closure_parity_vs_oracle(ctx, oracle, seed):
+def test_c4_loop_closure_parity_vs_oracle(ctx, oracle, monkeypatch, seed, border):
+    """border: the far CAMERAS of the closure points renumbered last (round 5), the closure POINTS kept out of the Schur complement
+    (round 6: 3 unknowns each instead of 6 per far camera), or the solver's own choice (the smaller border: the points here)"""
+    if border != "auto":
+        monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "1" if border == "points" else "0")
     g = make_graph(500, 50000, n_obs_per_point=6, seed=seed, loop_closures=20)
     assert len(g["closure_points"]) == 20
     so = _compare_ba(oracle, ctx, g, max_it=40)
     assert ctx.last_ba_solver()[0] == "arrow"
+    assert ctx.last_ba_border_points() == (0 if border == "cameras" else 20)
+    assert (ctx.last_ba_order()[0] > 0) == (border == "cameras")
     assert so.termination == 1 and so.final_cost < 0.5 * so.initial_cost
 
 
-def test_c5_tenth_loop_closure_parity_vs_oracle(ctx, oracle):
+@pytest.mark.parametrize("border", ["cameras", "points"])
+def test_c5_tenth_loop_closure_parity_vs_oracle(ctx, oracle, monkeypatch, border):
+    monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "1" if border == "points" else "0")
     g = make_graph(1000, 100000, n_obs_per_point=6, seed=1, loop_closures=10)
     so = _compare_ba(oracle, ctx, g, max_it=12)
-    assert ctx.last_ba_solver()[0] == "arrow"
+    assert ctx.last_ba_solver()[0] == "arrow" and ctx.last_ba_border_points() == (10 if border == "points" else 0)
     assert so.accepted >= 6 and so.final_cost < 0.5 * so.initial_cost
 
 
 @pytest.mark.parametrize("dense_border", ["0", "1"])
 def test_c4_loop_closure_parity_border_structure_forced(ctx, oracle, monkeypatch, dense_border):
+    monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "0")  # (the block structure below is the camera border's)
     """GSLAM_HIP_BA_ARROW_DENSE_BORDER=0: the border kernels skip the (superblock, strip) blocks the host-side propagation marks
     zero (default only from 4 M border entries up); =1: every block treated as dense.  Both against the oracle."""
     monkeypatch.setenv("GSLAM_HIP_BA_ARROW_DENSE_BORDER", dense_border)
