@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void cr_panels_kernel(CrArgs a, int inverse, i
 //   yh_i = y_i L_i^-1.
 // A workgroup = one quadrant (32 x 32) of a tile, or the vector task of the group.
 template <int T>
-__global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int ngroups) {
+__device__ __forceinline__ void cr_update_body(const CrArgs& a, int mode, int ngroups, int bid) {
   constexpr int m_ = NBI * T, ND = T * (T + 1) / 2, NV = m_ / 16, NTS = 4 * (ND + T * T) + NV, NTE = 4 * (2 * T * T) + NV;
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
   // times: nothing at those sizes)
   const int G = ngroups >= 8 ? 8 : (ngroups > 4 ? 8 : (ngroups > 2 ? 4 : (ngroups > 1 ? 2 : 1))), kx = 8 / G;
   const int per = (ntask + kx - 1) / kx;  // slots per XCD and group
-  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int grp = xcd / kx + G * (slot / per), task = (slot % per) * kx + xcd % kx;
   if (grp >= ngroups || task >= ntask) return;
   // ---- the vector tasks: out[c] (+)= -+ sum_t y[t] W[c][t], 16 columns per workgroup (a whole panel through one CU takes
@@ -714,6 +714,11 @@ __global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int 
     if (row < rlim && col < clim && (!diag || col <= row)) out[(size_t)col * ldo + row] = elim_task ? v : -v;
   }
   CR_STAMP(27);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void cr_update_kernel(CrArgs a, int mode, int ngroups) {
+  cr_update_body<T>(a, mode, ngroups, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -891,12 +896,12 @@ inline BorderChunks border_chunks(int n_band, int m, int nbr) {
 // is a chain of L2 round trips: two per wave this way; 32 x 32 blocks with 16 k-steps in flight took 35 us per level at C4).
 // D'[out column][out row]: the lane holds out column q + 4 r, out row m -- 16 consecutive rows of A per register, a 128-byte run.
 template <int T>
-__global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt) {
+__device__ __forceinline__ void cr_border_update_body(const CrArgs& a, int nrt, int bid) {
   constexpr int m_ = NBI * T, KS = m_ / 4;
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per = nrt * T * 4;
-  const int grp = (int)blockIdx.x / per, rem = (int)blockIdx.x - grp * per, rt = rem / (T * 4), cq = rem - rt * (T * 4);
+  const int grp = bid / per, rem = bid - grp * per, rt = rem / (T * 4), cq = rem - rt * (T * 4);
   const int j = grp * 2 * a.s, n = a.n;
   if (j >= a.N) return;
   const size_t lda = (size_t)a.lda, mm = (size_t)m_ * m_;
@@ -936,6 +941,19 @@ __global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt
     const int col = j * m_ + col_b + q + 4 * rr;
     if (col < n && r < a.nbr) a.brd()[(size_t)col * lda + n + r] -= acc0[rr] + acc1[rr];
   }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void cr_border_update_kernel(CrArgs a, int nrt) {
+  cr_border_update_body<T>(a, nrt, (int)blockIdx.x);
+}
+// Both updates of a level in ONE launch: the survivors' tiles (cr_update_body, the first n_update workgroups) and the border rows
+// of the survivors (cr_border_update_body).  They write disjoint parts of A from the same panels; as two launches the second cost
+// a dependent-launch latency per level (~10 us: a third of what a 60-row border adds to a C4 iteration).
+template <int T>
+__global__ __launch_bounds__(256) void cr_update_both_kernel(CrArgs a, int ngroups, int n_update, int nrt) {
+  if ((int)blockIdx.x < n_update) cr_update_body<T>(a, 0, ngroups, (int)blockIdx.x);
+  else cr_border_update_body<T>(a, nrt, (int)blockIdx.x - n_update);
 }
 
 // The corner: partial[chunk][tile] = sum over the chunk's columns k of Yx[rows of the tile][k] Yx[cols of the tile][k], Yx = rows
@@ -1211,8 +1229,12 @@ gh_status cr_solve_t(gh_ctx* ctx, double* A, int n, int lda, double* dinv, doubl
       GH_HIP(ctx, hipEventRecord(ctx->cr_events[1], side));
     }
     const int nsurv = gh_div_up(N, 2 * s);
-    GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(update_grid(nsurv, NTS)), dim3(256), 0, a, 0, nsurv);
-    if (nbr > 0) GH_LAUNCH(ctx, "ba_cr_border_update", cr_border_update_kernel<T>, dim3(nsurv * nrt * T * 4), dim3(256), 0, a, nrt);
+    if (nbr > 0) {
+      const int nu = update_grid(nsurv, NTS);
+      GH_LAUNCH(ctx, "ba_cr_update", cr_update_both_kernel<T>, dim3(nu + nsurv * nrt * T * 4), dim3(256), 0, a, nsurv, nu, nrt);
+    } else {
+      GH_LAUNCH(ctx, "ba_cr_update", cr_update_kernel<T>, dim3(update_grid(nsurv, NTS)), dim3(256), 0, a, 0, nsurv);
+    }
   }
   // what is left: block 0 with no neighbours (stride >= N), or the dense top
   a.s = S;
