@@ -1,6 +1,8 @@
 """GPU parity of camera self-calibration in gh_graph_solve (BundleGraph::camera + cameraDOF, GSLAM/core/Optimizer.h:86-100,
 169-171) against oracle/graph_oracle.c through the C ABI: same LM trace, same intrinsics, same state.  The projection model
 itself is pinned to the reference's Camera::Project in tests/test_calib_oracle.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -38,6 +40,8 @@ def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-9):
     S1, x1, r1, c1, sg, st1 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, iters))
     assert st0 == 0 and st1 == 0
     assert_identical_trace(sg, so, rtol)
+    if os.environ.get("GSLAM_TEST_PRINT_DIFFS"):
+        print("DIFF calib: cam rel %.3e frames %.3e landmarks %.3e rho %.3e" % ((np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-3)).max(), np.abs(S1 - S0).max(), np.abs(x1 - x0).max() if x0.size else 0.0, np.abs(r1 - r0).max() if r0.size else 0.0))
     assert np.allclose(c1[:4], c0[:4], rtol=1e-7) and np.allclose(c1[4:], c0[4:], atol=1e-7), (c1 - c0)
     assert np.allclose(S1, S0, atol=1e-6) and np.allclose(x1, x0, atol=1e-5) and np.allclose(r1, r0, rtol=1e-5, atol=1e-8)
     S2, x2, r2, c2, sg2, st2 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, iters))

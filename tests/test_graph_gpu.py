@@ -2,6 +2,8 @@
 oracle/graph_oracle.c through the C ABI.  f64 on both sides; the GPU's sums are REPRODUCIBLE (pre-rounded accumulation,
 gh_ba_options.deterministic = 1, the default) but in another order than the oracle's: identical LM decisions, every cost of
 the trace to 1e-9 relative, bit-identical from one GPU run to the next."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,6 +30,8 @@ def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-9, state
     S1, x1, r1, sg, st1 = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, iters))
     assert st0 == 0 and st1 == 0
     assert_identical_trace(sg, so, rtol)
+    if os.environ.get("GSLAM_TEST_PRINT_DIFFS"):
+        print("DIFF graph: frames %.3e landmarks %.3e rho %.3e" % (np.abs(S1 - S0).max(), np.abs(x1 - x0).max() if x0.size else 0.0, np.abs(r1 - r0).max() if r0.size else 0.0))
     assert np.allclose(S1, S0, atol=state_atol) and np.allclose(x1, x0, atol=10 * state_atol) and np.allclose(r1, r0, rtol=1e-6, atol=1e-9)
     S2, x2, r2, sg2, st2 = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, iters))
     assert st2 == 0 and S2.tobytes() == S1.tobytes() and x2.tobytes() == x1.tobytes() and r2.tobytes() == r1.tobytes()
