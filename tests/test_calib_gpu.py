@@ -32,8 +32,12 @@ def _start_cam(free, rel=0.04):
     return c
 
 
-def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-9):
-    """whole LM trace: same decisions, costs to rtol; the GPU run twice is bit-identical (reproducible accumulation)"""
+def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-9, loose=False):
+    """whole LM trace: same decisions, costs to rtol; the GPU run twice is bit-identical (reproducible accumulation).
+    States at the bars of SURVEY.md 8(c) since round 6: intrinsics 1e-9 relative, frames 1e-8, landmarks 1e-7 (measured: <= 5e-15,
+    1.2e-10, 1.1e-10).  loose = the one ill-conditioned case (all nine intrinsics free, no robust kernel, 60 iterations into a
+    long focal / distortion valley): 4.4e-8 relative on the intrinsics, 1.2e-8 on the frames, 1.2e-7 on the landmarks measured,
+    bars a decade above (GSLAM_TEST_PRINT_DIFFS=1 prints the figures)."""
     from gslam_amd import posegraph
     oo = oracle_lib.ba_options(huber=huber, max_iterations=iters)
     S0, x0, r0, c0, so, st0 = oracle.graph_solve_cam(start, dof, prob, oo)
@@ -42,8 +46,9 @@ def _compare(ctx, oracle, start, dof, prob, huber, iters=60, rtol=1e-9):
     assert_identical_trace(sg, so, rtol)
     if os.environ.get("GSLAM_TEST_PRINT_DIFFS"):
         print("DIFF calib: cam rel %.3e frames %.3e landmarks %.3e rho %.3e" % ((np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-3)).max(), np.abs(S1 - S0).max(), np.abs(x1 - x0).max() if x0.size else 0.0, np.abs(r1 - r0).max() if r0.size else 0.0))
-    assert np.allclose(c1[:4], c0[:4], rtol=1e-7) and np.allclose(c1[4:], c0[4:], atol=1e-7), (c1 - c0)
-    assert np.allclose(S1, S0, atol=1e-6) and np.allclose(x1, x0, atol=1e-5) and np.allclose(r1, r0, rtol=1e-5, atol=1e-8)
+    k = 100.0 if loose else 1.0
+    assert np.allclose(c1[:4], c0[:4], rtol=1e-9 * k * 10) and np.allclose(c1[4:], c0[4:], atol=1e-9 * k * 10), (c1 - c0)
+    assert np.allclose(S1, S0, atol=1e-8 * k) and np.allclose(x1, x0, atol=1e-7 * k) and np.allclose(r1, r0, rtol=1e-7 * k, atol=1e-10 * k)
     S2, x2, r2, c2, sg2, st2 = posegraph.solve_graph(ctx, start, dof, prob, _opts(huber, iters))
     assert st2 == 0 and S2.tobytes() == S1.tobytes() and x2.tobytes() == x1.tobytes() and c2.tobytes() == c1.tobytes()
     assert list(sg2.trace_cost[:sg2.trace_len]) == list(sg.trace_cost[:sg.trace_len]), "self-calibration is not reproducible run to run"
@@ -64,7 +69,7 @@ def test_calibration_matches_the_oracle(ctx, oracle, free, n_xyz, n_idp, with_in
     # (all nine free: rejected steps far from the minimum amplify the summation-order differences to ~1e-6 relative)
     # (all nine free and no robust kernel: the cost of a REJECTED trial step far from the minimum, where the damped system is
     #  ill-conditioned, differs by 2e-6 relative between the two summation orders -- decisions and accepted costs do not)
-    so, sg, cam = _compare(ctx, oracle, start, dof, prob, huber, rtol=1e-4 if free == 0x1FF else 1e-9)
+    so, sg, cam = _compare(ctx, oracle, start, dof, prob, huber, rtol=1e-4 if free == 0x1FF else 1e-9, loose=free == 0x1FF)
     assert so.final_cost < 0.2 * so.initial_cost
     fixed = [k for k in range(9) if not (free >> k) & 1]
     assert np.array_equal(cam[fixed], prob["intrinsics"][0][fixed])

@@ -22,8 +22,10 @@ def _opts(huber, iters=40):
     return o
 
 
-def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-9, state_atol=1e-7):
-    """The whole LM trace: same length, same decisions, every cost to rtol; and the GPU run twice is bit-identical."""
+def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-9, state_atol=1e-8):
+    """The whole LM trace: same length, same decisions, every cost to rtol; and the GPU run twice is bit-identical.
+    States at the bars of SURVEY.md 8(c) since round 6 (frames 1e-8, landmarks 1e-7): the largest differences measured over
+    this file's cases are 1.8e-10 (frames), 1.1e-10 (landmarks), 1.5e-12 (inverse depths) -- GSLAM_TEST_PRINT_DIFFS=1 prints them."""
     from gslam_amd import posegraph
     oo = oracle_lib.ba_options(huber=huber, max_iterations=iters)
     S0, x0, r0, so, st0 = oracle.graph_solve(start, dof, problem, oo)
@@ -32,7 +34,7 @@ def _compare(ctx, oracle, start, dof, problem, huber, iters=40, rtol=1e-9, state
     assert_identical_trace(sg, so, rtol)
     if os.environ.get("GSLAM_TEST_PRINT_DIFFS"):
         print("DIFF graph: frames %.3e landmarks %.3e rho %.3e" % (np.abs(S1 - S0).max(), np.abs(x1 - x0).max() if x0.size else 0.0, np.abs(r1 - r0).max() if r0.size else 0.0))
-    assert np.allclose(S1, S0, atol=state_atol) and np.allclose(x1, x0, atol=10 * state_atol) and np.allclose(r1, r0, rtol=1e-6, atol=1e-9)
+    assert np.allclose(S1, S0, atol=state_atol) and np.allclose(x1, x0, atol=10 * state_atol) and np.allclose(r1, r0, rtol=1e-8, atol=1e-10)
     S2, x2, r2, sg2, st2 = posegraph.solve_graph(ctx, start, dof, problem, _opts(huber, iters))
     assert st2 == 0 and S2.tobytes() == S1.tobytes() and x2.tobytes() == x1.tobytes() and r2.tobytes() == r1.tobytes()
     assert list(sg2.trace_cost[:sg2.trace_len]) == list(sg.trace_cost[:sg.trace_len]), "gh_graph_solve is not reproducible run to run"
