@@ -65,3 +65,47 @@ def test_no_quarter_rate_integer_arithmetic_in_the_loops_of_the_orb_kernels():
     for frag, budget in BUDGET.items():
         assert frag in found, "kernel %s not found in the shipped code objects" % frag
         assert len(found[frag]) <= budget, (frag, found[frag])
+
+
+def test_sliding_window_prefetch_registers_are_not_copied_between_load_and_wait():
+    """fast_plane_sw_kernel (round-6 experiment) loads its prefetched rows by inline asm and waits for them by hand
+    (`s_waitcnt vmcnt(4)`): the compiler believes the destination registers are valid at once, so a register copy (or a spill)
+    between the load and the wait would read them before the data lands.  In the shipped code object every `global_load_dword vD, vD,
+    s[..]` (destination == address register: the inline-asm form) must be followed by no VALU / DS instruction that READS vD before
+    the next hand-placed `s_waitcnt vmcnt(4)`."""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    body = None
+    for i, co in enumerate(_code_objects(LIB)):
+        path = "/tmp/gslam_isa_sw_%d_%d.elf" % (os.getpid(), i)
+        with open(path, "wb") as f:
+            f.write(co)
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+        os.remove(path)
+        m = re.search(r"<(_Z\S*fast_plane_sw_kernel\S*)>:\n(.*?)\n\n", dis, re.S)
+        if m:
+            body = m.group(2)
+    assert body is not None, "fast_plane_sw_kernel not found in the shipped code objects"
+    lines = [l.split("//")[0].strip() for l in body.splitlines() if l.strip()]
+    pending = {}  # register -> line of the asm load that owns it
+    checked = 0
+    for n, l in enumerate(lines):
+        m = re.match(r"global_load_dword (v\d+), (v\d+), s\[", l)
+        if m and m.group(1) == m.group(2):
+            pending[m.group(1)] = n
+            continue
+        if l.startswith("s_waitcnt vmcnt(4)") or l.startswith("s_waitcnt vmcnt(0)"):
+            checked += len(pending)
+            pending.clear()
+            continue
+        if l.startswith("s_") or not pending:
+            continue
+        ops = l.split(None, 1)[1] if " " in l else ""
+        srcs = ops.split(",")[1:] if not l.startswith(("ds_write", "global_store", "v_cmp")) else ops.split(",")
+        for reg in pending:
+            for src in srcs:
+                assert not re.search(r"\b%s\b" % reg, src), "line %d reads %s before its load (line %d) was waited for: %s" % (n, reg, pending[reg], l)
+            m2 = re.search(r"v\[(\d+):(\d+)\]", ",".join(srcs))
+            if m2:
+                assert not (int(m2.group(1)) <= int(reg[1:]) <= int(m2.group(2))), (n, l)
+    assert checked >= 8, "expected the prologue's and the loop's prefetch sets (got %d registers)" % checked
