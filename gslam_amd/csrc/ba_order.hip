@@ -471,49 +471,78 @@ int gh_ba_order_cameras(const gh_ba_problem* pr, std::vector<int32_t>& perm, int
   if (border_points) border_points->clear();
   const int nc = pr->n_cams;
   if (pr->n_points <= 0 || pr->n_obs <= 0) return 0;
-  int span0 = -1, span1 = -1, short0 = -1, short1 = -1;
-  std::vector<int32_t> long0, long1;
   const bool timing = getenv("GSLAM_HIP_BA_TIMING") != nullptr;
-  const double t0 = timing ? now_ms() : 0.0;
-  int nb = arrow_order(pr, nullptr, perm, &span0, border_points ? &long0 : nullptr, &short0);  // (the caller's order: a band, or a band + border)
-  if (timing) fprintf(stderr, "[gh_ba order] caller's order: span %d, %d border cameras, %zu long-range points, %.2f ms\n", span0, nb, long0.size(), now_ms() - t0);
-  if (border_points && points_make_the_smaller_border(nb, long0, nc)) {
-    perm.clear();
-    border_points->swap(long0);
-    if (band_span) *band_span = short0;
-    return 0;
-  }
-  if (nb > 0) return nb;
-  if (band_span) *band_span = span0;
-  if (!allow_reorder || nc < 4 * 32 + 1) return 0;  // (fewer than four superblocks: dense anyway)
-  if (span0 <= kBandSpan) return 0;  // a band as it stands (or a bad index: ba_run reports it)
+  // a candidate: an order (empty = the caller's), its camera border / its long-range points, and what the border costs in unknowns
+  struct Candidate {
+    std::vector<int32_t> perm_arrow, long_pts;  // perm_arrow[new] = position (arrow ordering on top of the order), when nb > 0
+    int nb = 0, span = -1, span_short = -1;
+    bool points = false;
+    long long cost = 0;  // border unknowns; -1: neither a band nor a band + border
+  };
+  auto evaluate = [&](const int32_t* pos, Candidate& c, const char* what) {
+    const double t0 = timing ? now_ms() : 0.0;
+    c.nb = arrow_order(pr, pos, c.perm_arrow, &c.span, border_points ? &c.long_pts : nullptr, &c.span_short);
+    c.points = border_points != nullptr && points_make_the_smaller_border(c.nb, c.long_pts, nc);
+    if (c.points) c.cost = 3LL * (long long)c.long_pts.size();
+    else if (c.nb > 0) c.cost = 6LL * c.nb;
+    else c.cost = (c.span >= 0 && c.span <= kBandSpan) ? 0 : -1;
+    if (c.cost > 3LL * nc) {  // a border of more than half the system: the dense factorisation does the same work without the detour
+      c.cost = -1;
+      c.nb = 0;
+      c.points = false;
+    }
+    if (timing)
+      fprintf(stderr, "[gh_ba order] %s: span %d, %d border cameras, %zu long-range points -> %s, %.2f ms\n", what, c.span, c.nb, c.long_pts.size(),
+              c.cost < 0 ? "no band" : (c.cost == 0 ? "a band" : (c.points ? "band + point border" : "band + camera border")), now_ms() - t0);
+  };
+  Candidate A;
+  evaluate(nullptr, A, "caller's order");
+  // The caller's order stands when it is a band, or a band with a border that is small next to the system (a trajectory with
+  // loop closures handed over in order: no reason to pay for the ordering).  A LARGE border in the caller's order -- cameras in
+  // random order can come out as "47 band cameras + 489 border cameras" -- is a sign that the order is the problem.
+  const long long small = std::max<long long>(192, 6LL * nc / 16);
+  Candidate B;
   std::vector<int32_t> order;
-  if (!covis_order(pr, order)) return 0;
-  std::vector<int32_t> pos((size_t)nc);
-  for (int i = 0; i < nc; ++i) pos[order[i]] = i;
-  std::vector<int32_t> aperm;
-  const double t1 = timing ? now_ms() : 0.0;
-  nb = arrow_order(pr, pos.data(), aperm, &span1, border_points ? &long1 : nullptr, &short1);
-  if (timing) fprintf(stderr, "[gh_ba order] new order: span %d, %d border cameras, %zu long-range points, %.2f ms\n", span1, nb, long1.size(), now_ms() - t1);
-  if (border_points && points_make_the_smaller_border(nb, long1, nc)) {
+  bool have_b = false;
+  if (allow_reorder && nc >= 4 * 32 + 1 && A.span > kBandSpan && (A.cost < 0 || A.cost > small) && covis_order(pr, order)) {
+    std::vector<int32_t> pos((size_t)nc);
+    for (int i = 0; i < nc; ++i) pos[order[i]] = i;
+    evaluate(pos.data(), B, "new order");
+    have_b = true;
+  }
+  // the better candidate: a band or band + border beats none; then the smaller border; the caller's order on a tie
+  const bool use_b = have_b && B.cost >= 0 && (A.cost < 0 || B.cost < A.cost);
+  if (!use_b && have_b && A.cost < 0 && B.span >= 0 && A.span >= 0 && B.span < A.span) {
+    // (neither is a band: the narrower order still gives the dense solver a sparser system; never worse than what came in)
     perm.swap(order);
-    border_points->swap(long1);
     if (reordered) *reordered = 1;
-    if (band_span) *band_span = short1;
+    if (band_span) *band_span = B.span;
     return 0;
   }
-  if (nb > 0) {
-    perm.resize((size_t)nc);
-    for (int i = 0; i < nc; ++i) perm[i] = order[aperm[i]];
-    if (reordered) *reordered = 1;
+  Candidate& C = use_b ? B : A;
+  if (use_b && reordered) *reordered = 1;
+  if (C.cost < 0) {  // (the caller's order, no band: the dense solver; ba_run still wants the span it measured)
+    if (band_span) *band_span = C.span;
+    return 0;
+  }
+  if (C.points) {
+    if (use_b) perm.swap(order);
+    border_points->swap(C.long_pts);
+    if (band_span) *band_span = C.span_short;
+    return 0;
+  }
+  if (C.nb > 0) {
+    if (use_b) {
+      perm.resize((size_t)nc);
+      for (int i = 0; i < nc; ++i) perm[i] = order[C.perm_arrow[i]];
+    } else {
+      perm.swap(C.perm_arrow);
+    }
     if (band_span) *band_span = -1;
-    return nb;
+    return C.nb;
   }
-  if (span1 >= 0 && span1 < span0) {  // (a narrower band, or at least a sparser dense system; never worse than what came in)
-    perm.swap(order);
-    if (reordered) *reordered = 1;
-    if (band_span) *band_span = span1;
-  }
+  if (use_b) perm.swap(order);  // a band
+  if (band_span) *band_span = C.span;
   return 0;
 }
 
