@@ -591,3 +591,49 @@ def test_ba_band_solver_with_masked_dofs_fixed_points_and_information(ctx):
     assert np.abs(pd - pb).max() <= 1e-8 and np.abs(xd - xb).max() <= 1e-8
     assert np.array_equal(pb[50], np.asarray(g["cam_pose"])[50])            # the fixed camera did not move
     assert np.array_equal(xb[pf == 0], np.asarray(g["point_xyz"])[pf == 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("border", ["cameras", "points"])
+@pytest.mark.parametrize("deterministic", [1, 0])
+def test_ba_borders_with_masked_dofs_fixed_points_and_information(ctx, monkeypatch, border, deterministic):
+    """Both kinds of arrowhead border (round 6) on a graph that carries everything the assembly has to respect: a fixed and partly
+    fixed cameras (one of them an observer of a closure point), FIXED closure points and free ones, per-observation information
+    matrices -- against the dense solver; with the deterministic assembly and with the atomics one (whose pair skip is separate code)."""
+    from gslam_amd import ba
+    from gslam_amd.ba_synth import make_graph
+    monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "1" if border == "points" else "0")
+    g = make_graph(300, 20000, n_obs_per_point=6, seed=21, loop_closures=12)
+    rng = np.random.default_rng(21)
+    cp = np.asarray(g["closure_points"])
+    oc, op = np.asarray(g["obs_cam"]), np.asarray(g["obs_point"])
+    dof = np.array(g["cam_dof"], dtype=np.int32).copy()
+    far = int(oc[op == cp[0]].max())
+    dof[far] = 0                       # a fixed far observer of a closure point
+    dof[int(oc[op == cp[1]].min())] = 7
+    dof[150] = 56
+    g["cam_dof"] = dof
+    pf = np.ones(len(g["point_xyz"]), np.uint8)
+    pf[rng.choice(len(pf), 400, replace=False)] = 0
+    pf[cp[2]] = 0                      # a fixed closure point
+    pf[cp[3]] = 1
+    g["point_free"] = pf
+    M = rng.standard_normal((len(oc), 2, 2)) * 0.2
+    g["obs_info"] = np.ascontiguousarray((M @ M.transpose(0, 2, 1) + np.eye(2)).reshape(-1, 4))
+    opts = lambda: ba.default_options(max_iterations=25, deterministic=deterministic)
+    ctx.set_ba_solver("dense")
+    try:
+        pd, xd, sd, _ = ba.solve(ctx, g, opts())
+        assert ctx.last_ba_solver()[0] == "dense"
+    finally:
+        ctx.set_ba_solver("auto")
+    pa, xa, sa, _ = ba.solve(ctx, g, opts())
+    assert ctx.last_ba_solver()[0] == "arrow" and (ctx.last_ba_border_points() == 12) == (border == "points")
+    n = sd.trace_len
+    assert sd.iterations == sa.iterations and list(sd.trace_accepted[:n]) == list(sa.trace_accepted[:n])
+    cd, ca = np.array(sd.trace_cost[:n]), np.array(sa.trace_cost[:n])
+    tol = 1e-9 if deterministic else 1e-7
+    assert np.abs(cd - ca).max() <= tol * np.abs(cd).max()
+    assert np.abs(pd - pa).max() <= 10 * tol and np.abs(xd - xa).max() <= 10 * tol
+    assert np.array_equal(pa[far], np.asarray(g["cam_pose"])[far])
+    assert np.array_equal(xa[pf == 0], np.asarray(g["point_xyz"])[pf == 0])
