@@ -1645,6 +1645,22 @@ gh_status ba_run(gh_ctx* ctx, BaSession& S, gh_ba_problem* pr, const gh_ba_optio
         }
       }
     }
+    // the same for a POINT border: border point b (rows 3 b .. 3 b + 2) only touches the columns of the cameras that see it
+    const int nbp0 = (int)S.border_pts.size();
+    const bool want_pstructure = dense_border_env ? dense_border_env[0] == '0' : 18LL * nbp0 * nc >= (4LL << 20);
+    if (nbp0 > 0 && want_pstructure) {
+      const int nbs = (3 * nbp0 + 15) / 16;
+      std::vector<int32_t> slot_of((size_t)np, -1);
+      for (int b = 0; b < nbp0; ++b) slot_of[S.border_pts[b]] = b;
+      S.border_cam_nz.assign((size_t)nbs * nc, 0);
+      for (int k = 0; k < no; ++k) {
+        const int32_t b = slot_of[pr->obs_point[k]];
+        if (b < 0) continue;
+        const int32_t c = pr->obs_cam[k];
+        S.border_cam_nz[(size_t)((3 * b) / 16) * nc + c] = 1;
+        S.border_cam_nz[(size_t)((3 * b + 2) / 16) * nc + c] = 1;
+      }
+    }
   }
   GH_HIP(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();

@@ -130,9 +130,10 @@ def test_c5_tenth_loop_closure_parity_vs_oracle(ctx, oracle, monkeypatch, border
     assert so.accepted >= 6 and so.final_cost < 0.5 * so.initial_cost
 
 
+@pytest.mark.parametrize("border", ["cameras", "points"])
 @pytest.mark.parametrize("dense_border", ["0", "1"])
-def test_c4_loop_closure_parity_border_structure_forced(ctx, oracle, monkeypatch, dense_border):
-    monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "0")  # (the block structure below is the camera border's)
+def test_c4_loop_closure_parity_border_structure_forced(ctx, oracle, monkeypatch, dense_border, border):
+    monkeypatch.setenv("GSLAM_HIP_BA_POINT_BORDER", "1" if border == "points" else "0")  # (both kinds of border have their block structure)
     """GSLAM_HIP_BA_ARROW_DENSE_BORDER=0: the border kernels skip the (superblock, strip) blocks the host-side propagation marks
     zero (default only from 4 M border entries up); =1: every block treated as dense.  Both against the oracle."""
     monkeypatch.setenv("GSLAM_HIP_BA_ARROW_DENSE_BORDER", dense_border)
