@@ -536,6 +536,30 @@ gh_status bf_bytes_launch(gh_ctx* ctx, const BytesArgs& a, int rows, int ny) {
 }
 }  // namespace
 
+// Train sets beyond 65535 rows, any descriptor width: chunks of 65532 rows folded with bf_merge_chunk_kernel exactly as the 32-byte
+// path does (bf_match_any): the 16-bit train index of the search key holds one chunk, an equal distance in a later chunk never
+// displaces the earlier index.  tmp: bf_chunk_tmp_bytes(nq, nt) bytes of device memory (null up to 65535 rows).
+static gh_status bf_bytes_any(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int desc_bytes, int32_t* idx1_dev,
+                              uint16_t* d1_dev, uint16_t* d2_dev, void* tmp) {
+  constexpr int kChunk = 65532;
+  const size_t ib = (((size_t)nq * 4) + 255) & ~(size_t)255, db = (((size_t)nq * 2) + 255) & ~(size_t)255;
+  int32_t* cidx = (int32_t*)tmp;
+  uint16_t* cd1 = (uint16_t*)((uint8_t*)tmp + ib);
+  uint16_t* cd2 = (uint16_t*)((uint8_t*)tmp + ib + db);
+  for (int base = 0; base < (nt > 0 ? nt : 1); base += kChunk) {
+    const int n = nt <= 65535 ? nt : (nt - base < kChunk ? nt - base : kChunk);
+    const bool first = base == 0;
+    BytesArgs a{(const uint32_t*)q_dev, (const uint32_t*)(t_dev + (size_t)base * desc_bytes), nullptr, nullptr, nullptr, nq, n, 0, desc_bytes / 4,
+                first ? idx1_dev : cidx, first ? d1_dev : cd1, first ? d2_dev : cd2};
+    GH_TRY(bf_bytes_launch(ctx, a, nq, 1));
+    if (!first)
+      GH_LAUNCH(ctx, "bf_merge_chunk", bf_merge_chunk_kernel, dim3(gh_div_up(nq, 256)), dim3(256), 0, nq, idx1_dev, d1_dev, d2_dev,
+                (const int32_t*)cidx, (const uint16_t*)cd1, (const uint16_t*)cd2, base);
+    if (nt <= 65535) break;
+  }
+  return GH_OK;
+}
+
 extern "C" gh_status gh_bf_match_bytes_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int desc_bytes,
                                            int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev) {
   if (!ctx) return GH_ERR_ARG;
@@ -545,9 +569,9 @@ extern "C" gh_status gh_bf_match_bytes_dev(gh_ctx* ctx, const uint8_t* q_dev, in
   if (nq == 0) return GH_OK;
   GH_CHECK_ARG(ctx, q_dev && idx1_dev && d1_dev && d2_dev && (nt == 0 || t_dev));
   GH_CHECK_ARG(ctx, ((uintptr_t)q_dev & 3) == 0 && ((uintptr_t)t_dev & 3) == 0);
-  GH_CHECK_ARG(ctx, nt <= 65535);  // (16-bit train index in the key; the 32-byte entry chunks larger sets)
-  BytesArgs a{(const uint32_t*)q_dev, (const uint32_t*)t_dev, nullptr, nullptr, nullptr, nq, nt, 0, desc_bytes / 4, idx1_dev, d1_dev, d2_dev};
-  return bf_bytes_launch(ctx, a, nq, 1);
+  void* tmp = nullptr;
+  if (nt > 65535) GH_TRY(gh_scratch(ctx, bf_chunk_tmp_bytes(nq, nt), &tmp));
+  return bf_bytes_any(ctx, q_dev, nq, t_dev, nt, desc_bytes, idx1_dev, d1_dev, d2_dev, tmp);
 }
 
 // host arrays in and out (what FeatureDetector::match of the plugin calls for descriptors that are not 32 bytes wide)
@@ -556,23 +580,23 @@ extern "C" gh_status gh_bf_match_bytes_host(gh_ctx* ctx, const uint8_t* q, int n
   if (!ctx) return GH_ERR_ARG;
   if (desc_bytes == 32) return gh_bf_match_host(ctx, q, nq, t, nt, idx1, d1, d2);
   GH_ENTER(ctx);
-  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && nt <= 65535 && desc_bytes >= 8 && desc_bytes <= 256 && desc_bytes % 8 == 0);
+  GH_CHECK_ARG(ctx, nq >= 0 && nt >= 0 && desc_bytes >= 8 && desc_bytes <= 256 && desc_bytes % 8 == 0);
   if (nq == 0) return GH_OK;
   GH_CHECK_ARG(ctx, q && idx1 && d1 && d2 && (nt == 0 || t));
   const size_t qb = (size_t)nq * desc_bytes, tb = (size_t)nt * desc_bytes;
   const size_t off_t = (qb + 255) & ~(size_t)255, off_i = off_t + ((tb + 255) & ~(size_t)255);
   const size_t off_d1 = off_i + (((size_t)nq * 4 + 255) & ~(size_t)255), off_d2 = off_d1 + (((size_t)nq * 2 + 255) & ~(size_t)255);
   const size_t total = off_d2 + (size_t)nq * 2;
+  const size_t off_tmp = (total + 255) & ~(size_t)255;  // chunk results of a train set beyond 65535 rows (device side only)
   void *base = nullptr, *hbase = nullptr;
-  GH_TRY(gh_scratch(ctx, total, &base));
+  GH_TRY(gh_scratch(ctx, off_tmp + bf_chunk_tmp_bytes(nq, nt), &base));
   GH_TRY(gh_pinned(ctx, total, &hbase));
   uint8_t *b = (uint8_t*)base, *hb = (uint8_t*)hbase;
   memcpy(hb, q, qb);
   if (tb) memcpy(hb + off_t, t, tb);
   GH_HIP(ctx, hipMemcpyAsync(b, hb, off_t + tb, hipMemcpyHostToDevice, ctx->stream));
-  BytesArgs a{(const uint32_t*)b, (const uint32_t*)(b + off_t), nullptr, nullptr, nullptr, nq, nt, 0, desc_bytes / 4,
-              (int32_t*)(b + off_i), (uint16_t*)(b + off_d1), (uint16_t*)(b + off_d2)};
-  GH_TRY(bf_bytes_launch(ctx, a, nq, 1));
+  GH_TRY(bf_bytes_any(ctx, b, nq, b + off_t, nt, desc_bytes, (int32_t*)(b + off_i), (uint16_t*)(b + off_d1), (uint16_t*)(b + off_d2),
+                      nt > 65535 ? b + off_tmp : nullptr));
   GH_HIP(ctx, hipMemcpyAsync(hb + off_i, b + off_i, total - off_i, hipMemcpyDeviceToHost, ctx->stream));
   GH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(idx1, hb + off_i, (size_t)nq * 4);

@@ -133,7 +133,7 @@ gh_status gh_bf_match_pairs_dev(gh_ctx* ctx, const uint8_t* desc_dev, const int3
 /* The same matchers for descriptors of ANY width that is a multiple of 8 bytes (8 .. 256): the reference chooses its distance
  * by the descriptor's width -- GSLAM/core/Vocabulary.h:565-567: hamming32 for 32 bytes, hamming64 (:493-500) for 64,
  * hamming8x (:502-513) for other multiples of 8 -- and so do these entries (32 bytes run the kernels above, MFMA formulation
- * included).  Same outputs, same first-minimum rule; nt <= 65535 train rows per call for widths other than 32. */
+ * included).  Same outputs, same first-minimum rule; train sets beyond 65535 rows are swept in chunks for every width (round 6). */
 gh_status gh_bf_match_bytes_dev(gh_ctx* ctx, const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt, int desc_bytes,
                                 int32_t* idx1_dev, uint16_t* d1_dev, uint16_t* d2_dev);
 gh_status gh_bf_match_bytes_host(gh_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes, int32_t* idx1,

@@ -352,3 +352,33 @@ def test_wide_descriptors_host_entry(ctx, oracle):
         ctx.check(hip.lib.gh_bf_match_bytes_host(ctx.h, p(q), 300, p(t), 411, nb, p(idx1), p(d1), p(d2)))
         e = oracle.bf_match_bytes(q, t, nb)
         assert np.array_equal(idx1, e[0]) and np.array_equal(d1, e[1]) and np.array_equal(d2, e[2])
+
+
+@pytest.mark.parametrize("nb", [64, 24])
+def test_wide_descriptors_train_set_beyond_65535_rows(ctx, oracle, nb):
+    """Round 6: the wide path chunks large train sets like the 32-byte one (it refused nt > 65535 in round 5): duplicates of the
+    best row in later chunks do not displace the first one, a strictly better row in the last chunk wins, duplicates across
+    the chunk boundary keep the earlier index.  Device and host entries against the oracle (pinned to the reference's hamming64 /
+    hamming8x)."""
+    import ctypes as C
+    import torch
+    from gslam_amd import hip
+    from gslam_amd.matcher import BFMatcher
+    rng = np.random.default_rng(nb)
+    nq, nt = 200, 140000
+    q = rng.integers(0, 256, (nq, nb), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, nb), dtype=np.uint8)
+    t[1000] = q[0]; t[70000] = q[0]; t[135000] = q[0]
+    t[66000] = q[1]; t[66000, 0] ^= 1; t[139999] = q[1]
+    t[65531] = q[2]; t[65532] = q[2]
+    e = oracle.bf_match_bytes(q, t, nb)
+    assert e[0][0] == 1000 and e[2][0] == 0 and e[0][1] == 139999 and e[2][1] == 1 and e[0][2] == 65531
+    m = BFMatcher(ctx)
+    idx1, d1, d2 = m.match_bytes(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(idx1.cpu().numpy(), e[0])
+    assert np.array_equal(d1.cpu().numpy().view(np.uint16), e[1]) and np.array_equal(d2.cpu().numpy().view(np.uint16), e[2])
+    hi, h1, h2 = np.empty(nq, np.int32), np.empty(nq, np.uint16), np.empty(nq, np.uint16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(hip.lib.gh_bf_match_bytes_host(ctx.h, p(q), nq, p(t), nt, nb, p(hi), p(h1), p(h2)))
+    assert np.array_equal(hi, e[0]) and np.array_equal(h1, e[1]) and np.array_equal(h2, e[2])
