@@ -796,10 +796,12 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     // comparison (lane order is raster order, rc is unique): v_readlane + v_cmp + v_addc per candidate instead of three compares
     const uint32_t key = e ^ 0x3FFu;
     int rank = 0;
+#ifndef GH_ORB_WHATIF_NORANK  // (timing experiment only: what the in-cell ranking costs -- docs/notes_r06.md)
     for (uint64_t mm = cand; mm != 0ull; mm &= mm - 1ull) {
       const int j = __ffsll((unsigned long long)mm) - 1;
       rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) > key ? 1 : 0;
     }
+#endif
     const bool keep = ((cand >> lane) & 1ull) != 0ull && rank < kCap;
     const uint64_t m = __ballot(keep);
     if (keep) put_entry(__popcll(m & lt_mask), ((uint32_t)rank << 18) | e);
