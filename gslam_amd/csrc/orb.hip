@@ -232,8 +232,28 @@ inline uint32_t magic_div(uint32_t d, uint32_t n_max) {
 // store.  16 VALU per 4 output pixels become ~7 (perms of the B operands shared by 4 columns) + two MFMAs.
 // Interior: the tile's owned outputs read source rows oy .. oy + 64 and columns ax .. ax + 87 -- all inside the 72 x 96 tile,
 // none clamped.  (row block, column block) pairs are dealt round-robin to the four waves; tile = the image tile in LDS.
-__device__ __forceinline__ void resize_tile_mfma(const uint8_t* tile, int tile_pitch, int ax, int oy, uint8_t* __restrict__ d,
-                                                 int dst_pitch, const ResizeTabs& tb, int g0, int ng, int r0, int r1,
+struct ResizeOps {  // what resize_tile_mfma reads from global memory: one round trip, requested ahead of the tile stages
+  uint4 aw[4];     // A operands (weights) of up to four column-block pairs
+  int cwv[4];      // tile column of their K windows
+  uint32_t ty;     // source row << 16 | fy of this lane's output row
+};
+__device__ __forceinline__ ResizeOps resize_tile_mfma_load(int ax, const ResizeTabs& tb, int g0, int ng, int r0, int r1) {
+  const int lane = threadIdx.x & 63, n16 = lane & 15;
+  const int rb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ncb = (ng + 1) >> 1;  // <= 4
+  const int yq = r0 + 16 * rb + n16, y = yq < r1 ? yq : r1 - 1;
+  ResizeOps o;
+  o.ty = tb.ytab[y];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int g = g0 + 2 * (cb < ncb ? cb : 0);
+    o.aw[cb] = *reinterpret_cast<const uint4*>(tb.mtab + ((size_t)g * 64 + lane) * 4);
+    o.cwv[cb] = (int)tb.mcw[g] - ax;  // tile column of the K window (a multiple of 8)
+  }
+  return o;
+}
+__device__ __forceinline__ void resize_tile_mfma(const uint8_t* tile, int tile_pitch, int oy, uint8_t* __restrict__ d,
+                                                 int dst_pitch, const ResizeOps& ops, int g0, int ng, int r0, int r1,
                                                  uint32_t* __restrict__ dbg) {
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -244,15 +264,9 @@ __device__ __forceinline__ void resize_tile_mfma(const uint8_t* tile, int tile_p
   if (r0 + 16 * rb >= r1) return;
   const int ncb = (ng + 1) >> 1;  // <= 4
   const int yq = r0 + 16 * rb + n16, y = yq < r1 ? yq : r1 - 1;
-  const uint32_t ty = tb.ytab[y];
-  uint4 aw[4];
-  int cwv[4];
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    const int g = g0 + 2 * (cb < ncb ? cb : 0);
-    aw[cb] = *reinterpret_cast<const uint4*>(tb.mtab + ((size_t)g * 64 + lane) * 4);
-    cwv[cb] = (int)tb.mcw[g] - ax;  // tile column of the K window (a multiple of 8)
-  }
+  const uint32_t ty = ops.ty;
+  const uint4 (&aw)[4] = ops.aw;
+  const int (&cwv)[4] = ops.cwv;
   const int R = (int)(ty >> 16) - oy;
   const uint32_t fy = ty & 0xFFFFu;
   const uint32_t wy0 = 2048u - fy, wy1 = fy, c23 = 1u << 23, k64 = 0x64646464u;
@@ -392,6 +406,24 @@ __device__ __forceinline__ int fast_score16_pk(const int (&r)[16], int c) {
 #ifndef GH_FAST_WAVES
 #define GH_FAST_WAVES 8
 #endif
+// measuring builds only (-DGH_ORB_PHASES, tools/r6_phases.py): wall-clock time (100 MHz) thread 0 of every workgroup spends between the
+// barriers of a tile, summed over the launch -- [0] start -> tile in LDS, [1] -> pass 1 done, [2] -> pass 2 done, [3] -> cell of wave 0
+// done, [4] (tile loop) -> all waves done, [8] tiles
+#ifdef GH_ORB_PHASES
+__device__ unsigned int* g_orb_phase_buf;  // [slots][8] ticks per phase, one slot per tile (plain stores: no contended atomics)
+__shared__ unsigned long long ph_t;
+__shared__ unsigned int ph_slot;
+#define GH_PHASE_START() do { if (threadIdx.x == 0) ph_t = wall_clock64(); } while (0)
+#define GH_PHASE(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_orb_phase_buf[(size_t)ph_slot * 8 + (k)] = (unsigned int)(now_ - ph_t); ph_t = now_; } } while (0)
+#else
+#define GH_PHASE_START()
+#define GH_PHASE(k)
+#endif
+// timing experiments only (docs/notes_r06.md: what each stage of orb_fast_cells costs; wrong results): bit 0 no pass 2, bit 1 no pass 1,
+// bit 2 no cell stage, bit 3 no next pyramid level
+#ifndef GH_ORB_WHATIF
+#define GH_ORB_WHATIF 0
+#endif
 constexpr int kTileW = 96;   // bytes per LDS tile row (6 x 16 B: 16-byte aligned window that covers x0-4 .. x0+67), 72 rows
 constexpr int kTileH = 72;
 constexpr int kScoreH = 66;   // score window: 64x64 region + 1 px NMS halo
@@ -403,6 +435,33 @@ constexpr int kScoreWPk = 72;  // row pitch (bytes) of the packed-16-bit pass 1;
 // P1: formulation of pass 1 (GSLAM_HIP_ORB_PASS1, decided per plan) -- 0 = packed 16-bit min / max (rounds 2-3),
 //     1 = SWAR on 16-bit fields (full-rate and / or / sub / v_bitop3), fields split in registers.  (A variant that read the
 //     fields pre-split from LDS planes lost 22 %: 38 KB of LDS leave 4 workgroups per CU; profiles/orb_pass1_ab_r04.txt.)
+// tile id -> (frame, tile row, tile column)
+__device__ __forceinline__ void fast_tile_coords(const NextLevel& nx, int nbx, int nby, int tile_id, int& frame, int& bx, int& by) {
+  if (nx.tiles_inv != 0u && nx.nbx_inv != 0u) {  // (two integer divisions were ~40 VALU per wave: 4 % of the kernel)
+    frame = (int)__umulhi((uint32_t)tile_id, nx.tiles_inv);
+    const int trem = tile_id - frame * (nbx * nby);
+    by = (int)__umulhi((uint32_t)trem, nx.nbx_inv);
+    bx = trem - by * nbx;
+  } else {
+    frame = tile_id / (nbx * nby);
+    const int trem = tile_id - frame * (nbx * nby);
+    bx = trem % nbx;
+    by = trem / nbx;
+  }
+}
+// 16-byte item i (< kTileH * 6) of the image tile of (frame, bx, by): LDS byte offset 16 i, global source clamped to the level
+__device__ __forceinline__ const uint4* fast_tile_src(const LevelView& lv, int frame, int bx, int by, int i) {
+  // i / 6 on the full-rate 24-bit multiplier: exact for i < 420 since 10923 / 65536 - 1 / 6 = 5e-6 (a division by a
+  // constant costs a quarter-rate v_mul_hi)
+  const int row = (int)(__umul24((uint32_t)i, 10923u) >> 16), c = i - row * 6;
+  int gy = kEdge + 64 * by - 4 + row;
+  gy = gy < 0 ? 0 : (gy > lv.h - 1 ? lv.h - 1 : gy);
+  int gx = 64 * bx + 16 * c;
+  gx = gx > lv.pitch - 16 ? lv.pitch - 16 : gx;
+  // (rows and pitch are < 2^24, a level is < 4 GiB: 32-bit offset, full-rate multiply instead of a 64-bit v_mad_i64_i32)
+  return reinterpret_cast<const uint4*>(lv.base + (size_t)frame * lv.frame_stride + (__umul24((uint32_t)gy, (uint32_t)lv.pitch) + (uint32_t)gx));
+}
+
 template <bool PK, int P1, bool PLANE = false>
 __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, int ncy, int min_th, int ini_th,
                                                 uint32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_ent,
@@ -424,42 +483,46 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   __shared__ uint16_t queue[kQueueLen];
   __shared__ int q_count;
   __shared__ uint16_t bit_pos[32];  // P1 != 0: score-tile offset of candidate bit b of a thread, relative to 4 tid
+  GH_PHASE_START();
 
   const int tid = threadIdx.x;
   __builtin_assume(tid >= 0 && tid < 256);
   const int nbx = (ncx + 1) >> 1, nby = (ncy + 1) >> 1;
-  int frame, trem, bx, by;
-  if (nx.tiles_inv != 0u && nx.nbx_inv != 0u) {  // (two integer divisions were ~40 VALU per wave: 4 % of the kernel)
-    frame = (int)__umulhi((uint32_t)tile_id, nx.tiles_inv);
-    trem = tile_id - frame * (nbx * nby);
-    by = (int)__umulhi((uint32_t)trem, nx.nbx_inv);
-    bx = trem - by * nbx;
-  } else {
-    frame = tile_id / (nbx * nby);
-    trem = tile_id - frame * (nbx * nby);
-    bx = trem % nbx;
-    by = trem / nbx;
+  int frame, bx, by;
+  fast_tile_coords(nx, nbx, nby, tile_id, frame, bx, by);
+#ifdef GH_ORB_PHASES
+  if (threadIdx.x == 0) {
+    const unsigned int slot_ = (unsigned int)(frame * cells_per_frame + cell_off + by * nbx + bx);
+    ph_slot = slot_;
+    g_orb_phase_buf[(size_t)slot_ * 8 + 6] = 1u;
   }
+#endif
+  static_assert(kTileW / 16 == 6 && kTileH * (kTileW / 16) <= 512 && kTileH * (kTileW / 16) > 256, "two 16-byte items per thread");
   if (tid == 0) q_count = 0;
   const int x0 = kEdge + 64 * bx, y0 = kEdge + 64 * by;  // region origin
   const int oy = y0 - 4;                       // tile origin row
   const int ax = 64 * bx;                      // 16-byte aligned tile origin column: x0 - 4 == ax + 15
   const uint8_t* img = lv.base + (size_t)frame * lv.frame_stride;
 
-  // 16 B per lane: rows of the level are 16-byte aligned (pitch % 16 == 0, checked by the launcher)
-  for (int i = tid; i < kTileH * (kTileW / 16); i += 256) {
-    // i / 6 on the full-rate 24-bit multiplier: exact for i < 420 since 10923 / 65536 - 1 / 6 = 5e-6 (a division by a
-    // constant costs a quarter-rate v_mul_hi)
-    static_assert(kTileW / 16 == 6 && kTileH * (kTileW / 16) <= 4096, "the constant below divides by 6");
-    const int row = (int)(__umul24((uint32_t)i, 10923u) >> 16), c = i - row * (kTileW / 16);
-    int gy = oy + row;
-    gy = gy < 0 ? 0 : (gy > lv.h - 1 ? lv.h - 1 : gy);
-    int gx = ax + 16 * c;
-    gx = gx > lv.pitch - 16 ? lv.pitch - 16 : gx;
-    // (rows and pitch are < 2^24, a level is < 4 GiB: 32-bit offset, full-rate multiply instead of a 64-bit v_mad_i64_i32)
-    const uint4 v = *reinterpret_cast<const uint4*>(img + (__umul24((uint32_t)gy, (uint32_t)lv.pitch) + (uint32_t)gx));
-    *reinterpret_cast<uint4*>(&tile[row * kTileW + 16 * c]) = v;
+  // interior tile: the operands of the fused MFMA resize are requested FIRST, in front of the tile loads -- their round trip (L2)
+  // runs under the tile's (HBM) instead of behind the first barrier (round 6: -2 % on the kernel)
+  bool resized = false;
+  ResizeOps rops;
+  int rg0 = 0, rng = 0, rr0 = 0, rr1 = 0;
+  if constexpr (P1 != 0) {
+    if (!(GH_ORB_WHATIF & 8) && nx.dst_base != nullptr && nx.tb.mtab != nullptr && by > 0 && by < nby - 1 && bx < nbx - 1) {
+      rg0 = nx.gx0[bx];
+      rng = nx.gx0[bx + 1] - rg0;
+      if (rng <= 8) {
+        rr0 = nx.gy0[by];
+        rr1 = nx.gy0[by + 1];
+        rops = resize_tile_mfma_load(ax, nx.tb, rg0, rng, rr0, rr1);
+        resized = true;
+      }
+    }
   }
+  // 16 B per lane: rows of the level are 16-byte aligned (pitch % 16 == 0, checked by the launcher)
+  for (int i = tid; i < kTileH * (kTileW / 16); i += 256) *reinterpret_cast<uint4*>(&tile[16 * i]) = *fast_tile_src(lv, frame, bx, by, i);
   if constexpr (P1 != 0) {
     // candidate bit b of a thread (see pass 1): b ^ 15 = 16 (k >> 1) + 2 trip + (k & 1) -> score offset 1024 trip + 1 + k
     if (tid < 32) {
@@ -468,19 +531,12 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     }
   }
   __syncthreads();
+  GH_PHASE(0);
   // The next pyramid level of an INTERIOR tile, now, out of the image tile (which the NMS lists overwrite after pass 2): h-taps
   // on MFMA.  Edge tiles (first / last tile row, last tile column: they also own what lies outside every tile) keep the VALU
   // path at the end of the kernel, which reads global memory.
-  bool resized = false;
   if constexpr (P1 != 0) {
-    if (nx.dst_base != nullptr && nx.tb.mtab != nullptr && by > 0 && by < nby - 1 && bx < nbx - 1) {
-      const int g0 = nx.gx0[bx], ng = nx.gx0[bx + 1] - g0;
-      if (ng <= 8) {
-        resize_tile_mfma(tile, kTileW, ax, oy, nx.dst_base + (size_t)frame * nx.dst_frame_stride, nx.dst_pitch, nx.tb, g0, ng,
-                         nx.gy0[by], nx.gy0[by + 1], dbg);
-        resized = true;
-      }
-    }
+    if (resized) resize_tile_mfma(tile, kTileW, oy, nx.dst_base + (size_t)frame * nx.dst_frame_stride, nx.dst_pitch, rops, rg0, rng, rr0, rr1, dbg);
   }
 
   // Scores for the 66x66 window (region + 1 px NMS halo); tile col of window col sx is sx + 18, row sy + 3.
@@ -516,7 +572,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     const uint32_t tid3856 = (uint32_t)tid * 3856u;  // (item * 3856) >> 16 == item / 17 for item < 3855
     uint32_t allbits = 0;
 #pragma unroll
-    for (int trip = 0; trip < kTrips; ++trip) {
+    for (int trip = 0; trip < ((GH_ORB_WHATIF & 2) ? 0 : kTrips); ++trip) {
       const int item = 256 * trip + tid;
       if (item < kItems) {
         const uint32_t sy = (tid3856 + 3856u * 256u * (uint32_t)trip) >> 16;
@@ -642,7 +698,8 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     }
   }
   __syncthreads();
-  const int nq = q_count;
+  GH_PHASE(1);
+  const int nq = (GH_ORB_WHATIF & 1) ? 0 : q_count;
   for (int i = tid; i < nq; i += 256) {
     int pos = queue[i];
     if constexpr (P1 != 0) pos = 4 * (pos & 255) + bit_pos[pos >> 8];
@@ -684,13 +741,14 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     if (s > min_th) score[pos] = (uint8_t)s;
   }
   __syncthreads();
+  GH_PHASE(2);
 
   // (placed after the last block-wide barrier: a wave that is done here goes straight on to its cell, nobody waits)
   // The next pyramid level, fused: this workgroup resizes the part of level l + 1 whose source pixels it has just
   // pulled through its L1 / the XCD's L2 for the tile (edge tiles also take the image border).  The pipeline is VALU-issue
   // bound and a stand-alone resize pass is memory-instruction bound, so the bilinear arithmetic rides in this kernel's idle
   // memory slots and the level is read from HBM once instead of twice.  Same arithmetic as resize_kernel (resize_item).
-  if (nx.dst_base != nullptr && !resized) {
+  if (!(GH_ORB_WHATIF & 8) && nx.dst_base != nullptr && !resized) {
     const int g0 = nx.gx0[bx], ng = nx.gx0[bx + 1] - g0;
     const int r0 = nx.gy0[by], r1 = nx.gy0[by + 1];
     const int nq = (r1 - r0 + kResizeRows - 1) / kResizeRows;
@@ -769,6 +827,10 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   // 32-byte record per cell instead of a count plus a 128-byte slot); entries 7.. go to the cell's slot in cell_ent
   uint32_t* rec = cell_cnt + cell * kCellRec;
   uint32_t* ovf = cell_ent + cell * kCap;
+  if (GH_ORB_WHATIF & 4) {
+    if (lane == 0) rec[0] = 0u;
+    return;
+  }
   auto put_entry = [&](int idx, uint32_t v) {
     if (idx < kCellRec - 1) rec[1 + idx] = v;
     else ovf[idx] = v;
@@ -868,6 +930,7 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
     }
   }
   if (lane == 0) rec[0] = (uint32_t)kept;
+  GH_PHASE(3);
   if (dbg != nullptr && lane == 0) {
     atomicAdd(&dbg[kDbgCells], 1u);
     if (kept > kCellRec - 1) atomicAdd(&dbg[kDbgOverflowCells], 1u);
@@ -2435,7 +2498,8 @@ extern "C" gh_status gh_orb_plan_create(gh_ctx* ctx, int width, int height, int 
         if (v == 0) return 0u;
         int e = 0;
         while ((v >> (e + 1)) != 0) ++e;
-        return (uint32_t)(((e + 15) << 10) | ((v << (10 - e)) & 0x3FF));
+        const int mant = e <= 10 ? (v << (10 - e)) : (v >> (e - 10));  // (v = 2048 has e = 11: a shift by -1 is undefined)
+        return (uint32_t)(((e + 15) << 10) | (mant & 0x3FF));
       };
       uint32_t* mt = htab.data() + tw;
       uint32_t* mc = htab.data() + tw + (size_t)ngr * 256;
@@ -2915,6 +2979,12 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
   }
   return GH_OK;
 }
+
+#ifdef GH_ORB_PHASES
+extern "C" int gh_orb_debug_phases(unsigned int* buf_dev) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_orb_phase_buf), &buf_dev, sizeof(buf_dev)) != hipSuccess;
+}
+#endif
 
 extern "C" gh_status gh_orb_extract_host(gh_orb_plan* p, const uint8_t* gray, int row_stride, gh_keypoint* kps,
                                          uint8_t* desc, int32_t* count) {
