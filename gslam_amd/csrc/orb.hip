@@ -544,8 +544,12 @@ __device__ __forceinline__ void fast_cells_tile(const LevelView& lv, int ncx, in
   // pixels) for every pixel; survivors are appended to an LDS queue so that pass 2 (the ~100-op arc
   // score) runs with all lanes busy instead of paying full price in every partially-hit wave.
   // The queue order is irrelevant: results land in score[] by position.
-  // score tile cleared with dword stores
-  for (int i = tid; i < kScoreBytes / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0u;  // incl. pad cols
+  // score tile cleared (incl. pad cols): 16 bytes per store where the size allows (two trips instead of five)
+  if constexpr (kScoreBytes % 16 == 0) {
+    for (int i = tid; i < kScoreBytes / 16; i += 256) reinterpret_cast<uint4*>(score)[i] = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (int i = tid; i < kScoreBytes / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0u;
+  }
   // One work item = one aligned tile dword = 4 horizontally adjacent pixels (tile cols 4m .. 4m+3, m = 4..21,
   // i.e. window cols -2 .. 69), evaluated with packed 16-bit math: 5 LDS dword reads and ~56 VALU per 4 px.
   // bright test: some adjacent compass pair both > c + t; dark: both < c - t.
