@@ -1426,6 +1426,9 @@ struct DescribeArgs {
   int quota[kMaxL], quota_off[kMaxL];
   float scale[kMaxL];
   int nlevels;
+  // describe_pipe_kernel: workgroups are dealt PER LEVEL (blk_off[l] = first workgroup of level l within a frame, blk_off[nlevels] =
+  // workgroups per frame; a workgroup = 4 kDescPipe slots of ONE level's quota)
+  int blk_off[kMaxL + 1];
 };
 
 // Sum of one int per lane over the wave, returned in every lane: four DPP adds give each 16-lane row its row sum
@@ -1936,51 +1939,47 @@ __global__ __launch_bounds__(256) void describe_pipe_kernel(DescribeArgs a, DevT
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][(kPatch + 4) * kPatchPitch + 28];
   __shared__ __attribute__((aligned(16))) uint32_t s_blur[4][256];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int blocks_per_frame = (K + 4 * kDescPipe - 1) / (4 * kDescPipe);
+  // Round 6: a workgroup's slots lie in ONE level's quota (the host deals workgroups per level: DescribeArgs::blk_off), so the level,
+  // its view, its scale and the slot arithmetic are wave-uniform loop invariants.  The general form -- any slot of the frame, level
+  // and output row found by eight-way selects per slot, the level's view fetched from the argument segment per keypoint -- cost 230
+  // SALU instructions per keypoint and several scalar-cache round trips that an in-order wave of this latency-bound kernel (5 waves
+  // per SIMD) sits out.
+  const int blocks_per_frame = a.blk_off[a.nlevels];
   const int gid = xcd_strip_tile(blockIdx.x, blocks_per_frame * n_frames);
   if (gid >= blocks_per_frame * n_frames) return;
   const int b = __builtin_amdgcn_readfirstlane(gid / blocks_per_frame);
-  const int slot0 = __builtin_amdgcn_readfirstlane((gid - b * blocks_per_frame) * (4 * kDescPipe) + wv);
-  if (slot0 >= K) return;
-  // per-frame level counts, once per wave (scalar loads)
-  int cnt[kMaxL], total = 0;
+  const int g = __builtin_amdgcn_readfirstlane(gid - b * blocks_per_frame);
+  int lvl = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxL; ++k)
+    if (k < a.nlevels && g >= a.blk_off[k]) lvl = k;
+  // per-frame level counts, once per wave (scalar loads); what lies in front of this level's rows
+  int total = 0, before = 0, unused_before = 0, cnt_l = 0;
 #pragma unroll
   for (int k = 0; k < kMaxL; ++k) {
-    cnt[k] = k < a.nlevels ? level_cnt[b * kMaxL + k] : 0;
-    total += cnt[k];
+    const int ck = k < a.nlevels ? level_cnt[b * kMaxL + k] : 0;
+    total += ck;
+    if (k < lvl) {
+      before += ck;
+      unused_before += a.quota[k] - ck;
+    }
+    if (k == lvl) cnt_l = ck;
   }
-  if (slot0 == 0 && lane == 0) counts[b] = total;
+  const int qoff = a.quota_off[lvl], slot_end = qoff + a.quota[lvl];
+  const int slot0 = __builtin_amdgcn_readfirstlane(qoff + (g - a.blk_off[lvl]) * (4 * kDescPipe) + wv);
+  if (g == 0 && wv == 0 && lane == 0) counts[b] = total;
+  if (slot0 >= slot_end) return;
+  const LevelView lv_l = a.lv[lvl], lv_0 = a.lv[0];
+  const float scale_l = a.scale[lvl];
 
-  // what a slot is: 0 = beyond K, 1 = unused slot of its level (zero-fill output row pos), 2 = keypoint (output row pos)
-  struct SlotInfo { int kind, pos, l; };
+  // what a slot is: 0 = beyond the level's quota, 1 = unused slot (zero-fill output row pos), 2 = keypoint (output row pos)
+  struct SlotInfo { int kind, pos; };
   auto slot_info = [&](int slot) {
-    SlotInfo si{0, 0, 0};
-    if (slot >= K) return si;
-    int l = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxL; ++k)
-      if (k < a.nlevels && slot >= a.quota_off[k]) l = k;
-    int before = 0, unused_before = 0, cnt_l = 0, qoff = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxL; ++k) {
-      if (k < l) {
-        before += cnt[k];
-        unused_before += a.quota[k] - cnt[k];
-      }
-      if (k == l) {
-        cnt_l = cnt[k];
-        qoff = a.quota_off[k];
-      }
-    }
+    SlotInfo si{0, 0};
+    if (slot >= slot_end) return si;
     const int i = slot - qoff;
-    si.l = l;
-    if (i >= cnt_l) {
-      si.kind = 1;
-      si.pos = total + unused_before + (i - cnt_l);
-    } else {
-      si.kind = 2;
-      si.pos = before + i;
-    }
+    si.kind = i >= cnt_l ? 1 : 2;
+    si.pos = i >= cnt_l ? total + unused_before + (i - cnt_l) : before + i;
     return si;
   };
   // selection record of a slot as one 8-byte scalar load: x | y << 16, score | level << 8
@@ -2000,7 +1999,7 @@ __global__ __launch_bounds__(256) void describe_pipe_kernel(DescribeArgs a, DevT
   // insertion would merge the paths with and without them conservatively, and the waits for the test words behind them
   // (vmcnt counts in order) would then wait for the prefetched rows too
   auto issue_patch = [&](bool valid, const SlotInfo& si, uint2 raw, RowN& row) {
-    const LevelView lv = a.lv[valid ? si.l : 0];
+    const LevelView lv = valid ? lv_l : lv_0;
     const uint32_t xy = valid ? raw.x : (uint32_t)(kC | (kC << 16));
     const uint8_t* img = lv.base + (size_t)b * lv.frame_stride;
     const int px0 = (int)(xy & 0xFFFFu) - kC, py0 = (int)(xy >> 16) - kC;
@@ -2029,7 +2028,7 @@ __global__ __launch_bounds__(256) void describe_pipe_kernel(DescribeArgs a, DevT
     __builtin_amdgcn_wave_barrier();
     // keypoint j + 2: its selection record (a scalar load)
     const int slot2 = slot0 + 4 * (j + 2);
-    const SlotInfo si2 = j + 2 < kDescPipe ? slot_info(slot2) : SlotInfo{0, 0, 0};
+    const SlotInfo si2 = j + 2 < kDescPipe ? slot_info(slot2) : SlotInfo{0, 0};
     const uint2 raw2 = si2.kind == 2 ? load_sel(slot2) : uint2{0u, 0u};
 
     if (si0.kind == 1) {  // unused slot: zero-fill one tail row so the whole K-row output is deterministic
@@ -2062,14 +2061,14 @@ __global__ __launch_bounds__(256) void describe_pipe_kernel(DescribeArgs a, DevT
       if (lane == 0) {
         reinterpret_cast<uint4*>(drow)[0] = uint4{(uint32_t)bits[0], (uint32_t)(bits[0] >> 32), (uint32_t)bits[1], (uint32_t)(bits[1] >> 32)};
         reinterpret_cast<uint4*>(drow)[1] = uint4{(uint32_t)bits[2], (uint32_t)(bits[2] >> 32), (uint32_t)bits[3], (uint32_t)(bits[3] >> 32)};
-        const float sc = a.scale[si0.l];
+        const float sc = scale_l;
         gh_keypoint o;
         o.x = __fmul_rn((float)(raw0.x & 0xFFFFu), sc);
         o.y = __fmul_rn((float)(raw0.x >> 16), sc);
         o.size = __fmul_rn(31.0f, sc);
         o.angle = 12.0f * (float)bin;
         o.response = (float)(raw0.y & 0xFFu);
-        o.octave = si0.l;
+        o.octave = lvl;
         o.class_id = -1;
         kps[(size_t)b * K + si0.pos] = o;
       }
@@ -2961,11 +2960,13 @@ static gh_status orb_enqueue(gh_orb_plan* p, const uint8_t* gray_dev, int batch,
       a.scale[l] = l < L ? p->scale[l] : 1.0f;
     }
     a.nlevels = L;
+    a.blk_off[0] = 0;
+    for (int l = 0; l < kMaxL; ++l) a.blk_off[l + 1] = a.blk_off[l] + (l < L ? gh_div_up(a.quota[l], 4 * kDescPipe) : 0);
     DevTables tb{p->d_pattern, p->d_dir, p->d_base_pattern};
     const long long blocks = (long long)gh_div_up(K, 4) * batch;
     GH_CHECK_ARG(ctx, blocks < (1LL << 30));
     if (p->steer == 0 && p->desc_mfma == 2) {
-      const long long pblocks = (long long)gh_div_up(K, 4 * kDescPipe) * batch;
+      const long long pblocks = (long long)a.blk_off[L] * batch;
       GH_LAUNCH(ctx, "orb_describe", describe_pipe_kernel, dim3(8 * gh_div_up(pblocks, 8)), dim3(256), p->desc_lds_pad, a, tb, K,
                 p->sel, p->level_cnt, kps_dev, desc_dev, counts_dev, batch, dbg);
     } else if (p->steer == 0 && p->desc_mfma)
