@@ -22,8 +22,19 @@ ex.extract(fr, out); torch.cuda.synchronize()
 buf.zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ex.extract(fr, out); e1.record(); torch.cuda.synchronize()
-a = buf.cpu().numpy().astype(np.int64)
-a = a[a[:, 6] == 1]
+a_all = buf.cpu().numpy().astype(np.int64)
+d = a_all[a_all[:, 6] == 2]  # describe_pipe_kernel: one record per wave (up to 8 keypoints), ticks summed over its keypoints
+if len(d):
+    dn = ["patch rows -> LDS", "moments + bin", "pattern words / next patch requested / blur (MFMA)", "256 tests (LDS reads + ballots)", "stores / next slot"]
+    kp = float(out[2].sum())
+    print("orb_describe: %d waves, %d keypoints" % (len(d), int(kp)))
+    tot = 0.0
+    for k, n in enumerate(dn):
+        us = d[:, k].sum() * 0.01 / kp
+        tot += us
+        print("  %-52s %7.3f us per keypoint" % (n, us))
+    print("  %-52s %7.3f us per keypoint per wave" % ("sum", tot))
+a = a_all[a_all[:, 6] == 1]
 names = ["start -> tile in LDS", "-> resize + pass 1 done", "-> pass 2 done", "-> wave 0's cell done", "-> all waves done (tile loop)", "(after the cell: own stores acknowledged)"]
 print("persist=%s: %d tiles, extract %.3f ms" % (os.environ.get("GSLAM_HIP_ORB_PERSIST", "default"), len(a), e0.elapsed_time(e1)))
 tot = 0.0
