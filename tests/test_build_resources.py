@@ -17,6 +17,7 @@ BUDGET = {
     "describe_kernelILi13ELb0ELb1E": (56, 0),   # the 30-bin table mode (default), h-pass of the blur on MFMA: 9 waves per SIMD, 9.5 KB of LDS
     "describe_kernelILi13ELb0ELb0E": (48, 0),   # ... with the blur on the VALU (GSLAM_HIP_ORB_DESC_MFMA=0): 8 workgroups per CU with 20.1 KB of LDS
     "describe_kernelILi19ELb1ELb0E": (96, 0),   # continuous steering (optional mode: 45 x 45 patch, 38 KB of LDS per workgroup)
+    "describe_pipe_kernel": (96, 0),            # the shipped default (software pipeline over 8 keypoints per wave): 5 waves per SIMD, no scratch
     "select_kernel": (128, 0),
     "resize_kernel": (64, 0),
     "bf_match_pairs_kernel": (64, 0),    # 8 waves per SIMD
