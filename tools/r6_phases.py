@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a tile of orb_fast_cells spends its time (measuring build of the library: -DGH_ORB_PHASES, GSLAM_HIP_LIB=build/ab/libgslam_hip_ph.so).
 Thread 0 of every workgroup stamps the 100 MHz wall clock at the barriers of a tile and stores the differences in the tile's own
-record (no contended atomics); averages over one extraction of B x 1080p frames."""
+record (no contended atomics); averages over one extraction of B x 1080p frames.  (The per-keypoint stamps of orb_describe that the
+second table reads -- records marked 2 -- are part of docs/history/orb_describe_asm_waits_r06.patch, not of the tree.)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
